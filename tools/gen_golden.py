@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box).  It imports the reference's Python modules (with empty stubs for the two absent
+third-party imports `editdistance` and `soundfile`, which nothing on the hot path calls),
+instantiates them with tiny dimensions, and records inputs, weights, dropout masks,
+host-RNG coin flips and outputs as .npz data.  No reference source is copied anywhere.
+
+    python tools/gen_golden.py            # (re)writes tests/golden/*.npz
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+for _m in ('editdistance', 'soundfile'):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+from src.tts import Tacotron2 as RefTacotron2            # noqa: E402
+from src.embed import L2Embedding as RefL2, SeperateEmbedding as RefSep   # noqa: E402
+from src.module import Postnet as RefPostnet             # noqa: E402
+from src.vqvae import VQVAE as RefVQVAE                  # noqa: E402
+from src.util import freq_loss as ref_freq_loss          # noqa: E402
+
+torch.set_num_threads(1)
+
+
+class Recorder:
+    """Records dropout masks (scaled) and np.random.rand draws made by the reference."""
+
+    def __init__(self):
+        self.masks, self.coins = [], []
+
+    def __enter__(self):
+        self._drop, self._rand = F.dropout, np.random.rand
+
+        def dropout(input, p=0.5, training=True, inplace=False):
+            if (not training) or p == 0.0:
+                return input
+            m = torch.bernoulli(torch.full_like(input, 1.0 - p)) / (1.0 - p)
+            self.masks.append(m.detach().clone())
+            return input * m
+
+        def rand(*a):
+            v = self._rand(*a)
+            if not a:
+                self.coins.append(float(v))
+            return v
+
+        F.dropout = dropout
+        torch.nn.functional.dropout = dropout
+        np.random.rand = rand
+        return self
+
+    def __exit__(self, *a):
+        F.dropout = self._drop
+        torch.nn.functional.dropout = self._drop
+        np.random.rand = self._rand
+
+
+def randomize_buffers(mod, gen):
+    """make BN running stats / biases non-trivial so eval-mode parity means something"""
+    for name, buf in mod.named_buffers():
+        if name.endswith('running_mean'):
+            buf.copy_(torch.randn(buf.shape, generator=gen) * 0.2)
+        elif name.endswith('running_var'):
+            buf.copy_(torch.rand(buf.shape, generator=gen) + 0.5)
+    for name, p in mod.named_parameters():
+        if name.endswith('bias') and p.dim() == 1:
+            p.data.copy_(torch.randn(p.shape, generator=gen) * 0.1 + p.data)
+        if '.bn.weight' in name or (name.endswith('.1.weight') and p.dim() == 1):
+            p.data.copy_(torch.rand(p.shape, generator=gen) + 0.5)
+
+
+def save(name, weights, arrays, meta):
+    d = {}
+    for k, v in weights.items():
+        d['w/' + k] = v.detach().cpu().numpy()
+    for k, v in arrays.items():
+        if isinstance(v, (list, tuple)):
+            for i, m in enumerate(v):
+                d['%s/%03d' % (k, i)] = m.detach().cpu().numpy() if torch.is_tensor(m) else np.asarray(m)
+        else:
+            d[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    d['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **d)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+TINY = dict(
+    n_mels=8, linear_dim=20, in_embed_dim=12, spkr_embed_dim=8,
+    paras={
+        'encoder': dict(enc_n_conv=3, enc_kernel_size=5, enc_rnn_layer=1, enc_embed_dim=32, enc_dropout=0.0),
+        'decoder': dict(n_frames_per_step=3, prenet_dim=16, prenet_dropout=0.5, query_rnn_dim=48, dec_rnn_dim=40,
+                        query_dropout=0.1, dec_dropout=0.1, attn_dim=16, n_location_filters=4,
+                        location_kernel_size=5, loc_aware=True, use_summed_weights=True, drop_dec_in=0.0),
+    })
+
+
+def tiny_model(seed, **over):
+    torch.manual_seed(seed)
+    cfg = json.loads(json.dumps(TINY))
+    cfg['paras']['decoder'].update(over)
+    m = RefTacotron2(cfg['n_mels'], cfg['linear_dim'], cfg['in_embed_dim'], cfg['spkr_embed_dim'], cfg['paras'])
+    g = torch.Generator().manual_seed(seed + 100)
+    with torch.no_grad():
+        randomize_buffers(m, g)
+    hp = dict(cfg['paras']['decoder'])
+    hp['n_mels'] = cfg['n_mels']
+    hp['enc_dropout'] = cfg['paras']['encoder']['enc_dropout']
+    return m, cfg, hp
+
+
+def tts_case(name, seed, B, L, teacher, tf_rate, training, teacher_bs=None, unpair_max_frame=None, **over):
+    m, cfg, hp = tiny_model(seed, **over)
+    m.train(training)
+    g = torch.Generator().manual_seed(seed + 1)
+    txt = torch.randn(B, L, cfg['in_embed_dim'], generator=g)
+    spk = torch.randn(B, cfg['spkr_embed_dim'], generator=g)
+    if isinstance(teacher, int):
+        tch = teacher
+    else:
+        tch = torch.rand(teacher_bs or B, teacher[0], cfg['n_mels'], generator=g)
+    w0 = {k: v.clone() for k, v in m.state_dict().items()}
+    np.random.seed(seed)
+    torch.manual_seed(seed + 2)
+    with Recorder() as rec, torch.no_grad():
+        mel, lin, align, stop = m(txt, None, tch, spk, tf_rate=tf_rate, unpair_max_frame=unpair_max_frame)
+    arrays = dict(txt_embed=txt, spkr_embed=spk, mel=mel, linear=lin, align=align, stop=stop,
+                  mask=rec.masks, coins=np.asarray(rec.coins, np.float64))
+    if not isinstance(tch, int):
+        arrays['teacher'] = tch
+    if training:   # running stats after the training-mode forward
+        arrays['post'] = [v for k, v in m.state_dict().items() if 'running_' in k]
+        arrays['post_keys'] = np.frombuffer(json.dumps([k for k in m.state_dict() if 'running_' in k]).encode(), np.uint8)
+    meta = dict(hp=hp, cfg=cfg, tf_rate=tf_rate, training=training,
+                teacher=tch if isinstance(tch, int) else None, unpair_max_frame=unpair_max_frame)
+    save(name, w0, arrays, meta)
+
+
+def vq_cases():
+    os.chdir(REF)   # phn_attr_pth is relative in the configs
+    base = dict(softmax='normal', latent_dim=64, commit_weight=0, vq_weight=0, temp=1, skip_prob=0, stop_grad=True)
+    g = torch.Generator().manual_seed(7)
+    # native 43 x 64 table with projected phoneme attributes
+    torch.manual_seed(11)
+    cb = RefL2(43, False, phn_attr_pth='data/phn_attr.csv', proj_attr=16, **base).eval()
+    x = torch.randn(3, 17, 64, generator=g)
+    # a few exact-tie / near-tie rows: midpoints of two codes, and exact code vectors
+    tab = cb.embedding.weight.detach()
+    x[0, 0] = 0.5 * (tab[5] + tab[9])
+    x[0, 1] = tab[12]
+    x[0, 2] = 0.5 * (tab[3] + tab[4]) + 1e-7
+    txt = torch.randint(0, 43, (3, 11), generator=g)
+    with torch.no_grad():
+        p, out, _, _ = cb(x)
+        inf = cb.inference(txt)
+    save('vq_l2_native', dict(cb.state_dict()), dict(x=x, p_code=p, idx=p.argmax(-1), new_latent=out,
+                                                     txt=txt, inference=inf, table=tab), dict(V=43, D=64))
+    # synthetic 512 x 64 table, no attributes, duplicated rows -> first-index-wins ties
+    torch.manual_seed(12)
+    cb = RefL2(512, False, phn_attr_pth='', proj_attr=None, **base).eval()
+    with torch.no_grad():
+        cb.learnable_table[300] = cb.learnable_table[20]
+        cb.learnable_table[301] = cb.learnable_table[20]
+    x = torch.randn(2, 33, 64, generator=g)
+    x[1, 0] = cb.learnable_table[20].detach()
+    x[1, 1] = cb.learnable_table[20].detach() * 0.9
+    with torch.no_grad():
+        p, out, _, _ = cb(x)
+    save('vq_l2_512', dict(cb.state_dict()), dict(x=x, p_code=p, idx=p.argmax(-1), new_latent=out),
+         dict(V=512, D=64))
+    # temp = 0.25 (sharper/softer distribution changes the softmax, not the index)
+    torch.manual_seed(13)
+    b2 = dict(base)
+    b2['temp'] = 0.25
+    cb = RefL2(43, False, phn_attr_pth='data/phn_attr.csv', proj_attr=16, **b2).eval()
+    x = torch.randn(2, 9, 64, generator=g) * 2
+    with torch.no_grad():
+        p, out, _, _ = cb(x)
+    save('vq_l2_temp', dict(cb.state_dict()), dict(x=x, p_code=p, idx=p.argmax(-1), new_latent=out), dict(V=43, D=64))
+    # 'seperate' bone (config/supervised.yaml)
+    torch.manual_seed(14)
+    cb = RefSep(43, False, phn_attr_pth='data/phn_attr.csv', proj_attr=16, **base).eval()
+    x = torch.randn(3, 13, 64, generator=g)
+    txt = torch.randint(0, 43, (3, 11), generator=g)
+    with torch.no_grad():
+        p, out, _, _ = cb(x)
+        inf = cb.inference(txt)
+    save('vq_seperate', dict(cb.state_dict()), dict(x=x, p_code=p, idx=p.argmax(-1), new_latent=out,
+                                                    txt=txt, inference=inf), dict(V=43, D=64))
+    os.chdir(REPO)
+
+
+def mean_forward_case():
+    import yaml
+    os.chdir(REF)
+    cfg = yaml.safe_load(open('config/semi-single-spkr-paired-data.yaml'))['model']
+    torch.manual_seed(3)
+    m = RefVQVAE(80, 1025, 43, 109, **cfg)
+    os.chdir(REPO)
+    g = torch.Generator().manual_seed(21)
+    cases = {}
+    for ci, (B, T) in enumerate([(3, 23), (2, 9), (1, 1), (2, 14)]):
+        idx = torch.randint(0, 4, (B, T), generator=g)            # few symbols -> long runs, blanks (0)
+        if ci == 3:
+            idx[1] = 0                                            # an all-blank utterance -> None
+        p = F.one_hot(idx, 43).float()
+        lat = torch.randn(B, T, 64, generator=g)
+        out = m.mean_forward(p, lat)
+        cases['idx%d' % ci] = idx
+        cases['lat%d' % ci] = lat
+        if out is None:
+            cases['none%d' % ci] = np.array([1])
+        else:
+            cases['out%d' % ci] = out[0]
+            cases['len%d' % ci] = out[1]
+    save('vq_mean_forward', {}, cases, dict(max_frames_per_phn=cfg['max_frames_per_phn'], n_cases=4))
+
+
+def postnet_class_case():
+    torch.manual_seed(31)
+    m = RefPostnet(8, 16, 5, 5, 0.0).eval()
+    g = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        randomize_buffers(m, g)
+        x = torch.randn(2, 11, 8, generator=g)
+        y = m(x)
+    save('conv_postnet_tiny', dict(m.state_dict()), dict(x=x, y=y), {})
+
+
+def loss_case():
+    g = torch.Generator().manual_seed(41)
+    pm, lm = torch.rand(2, 12, 80, generator=g), torch.rand(2, 12, 80, generator=g)
+    pl, ll = torch.rand(2, 12, 1025, generator=g), torch.rand(2, 12, 1025, generator=g)
+    a = ref_freq_loss(pm, lm, 22050, 80, 'mse', True, True)
+    b = ref_freq_loss(pl, ll, 22050, 80, 'mse', True, True)
+    c = ref_freq_loss(pl, ll, 22050, 80, 'l1', True, True)
+    save('freq_loss', {}, dict(pm=pm, lm=lm, pl=pl, ll=ll, mel_mse=a, lin_mse=b, lin_l1=c), {})
+
+
+def full_size_case():
+    """Full-dimension C1 (B=4, T=66, L=12) inference through the real reference with the
+    build's own seeded synthetic weights (regenerated on the GPU box from the seed, so the
+    125 MB of weights are never committed); outputs committed in full for mel/align and as
+    a strided slice for linear."""
+    import yaml
+    from semi_tts_amd.synthetic import synthetic_state_dict
+    cfg = yaml.safe_load(open(os.path.join(REF, 'config/semi-single-spkr-paired-data.yaml')))['model']
+    dec = json.loads(json.dumps(cfg['decoder']))
+    dec['decoder']['prenet_dropout'] = 0.0
+    torch.manual_seed(0)
+    m = RefTacotron2(80, 1025, 64, 128, dec).eval()
+    sd = synthetic_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    g = torch.Generator().manual_seed(5)
+    B, L, T = 4, 12, 66
+    txt = torch.randn(B, L, 64, generator=g) * 0.5
+    spk = torch.randn(B, 128, generator=g) * 0.5
+    teacher = torch.rand(B, T, 80, generator=g)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        mel_i, lin_i, al_i, st_i = m(txt, None, T, spk, tf_rate=0.0)
+        m.decoder.query_dropout.p = 0.0   # eval mode anyway
+        mel_t, lin_t, al_t, st_t = m(txt, None, teacher, spk, tf_rate=1.0)
+    torch.set_num_threads(1)
+    save('tts_full_c1', {}, dict(txt_embed=txt, spkr_embed=spk, teacher=teacher,
+                                 mel_infer=mel_i, align_infer=al_i, stop_infer=st_i, linear_infer_s=lin_i[:, ::7, ::41],
+                                 mel_tf=mel_t, align_tf=al_t, stop_tf=st_t, linear_tf_s=lin_t[:, ::7, ::41]),
+         dict(seed=1234, B=B, L=L, T=T, shapes={k: list(v.shape) for k, v in m.state_dict().items()}))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full']
+    if 'tts' in which:
+        # eval-mode free-running inference, prenet dropout active (always-on), masks recorded
+        tts_case('tts_tiny_infer', 1, B=2, L=7, teacher=15, tf_rate=0.0, training=False)
+        # eval-mode, prenet dropout off: deterministic, no masks
+        tts_case('tts_tiny_infer_nodrop', 2, B=3, L=9, teacher=12, tf_rate=0.0, training=False, prenet_dropout=0.0)
+        # training-mode teacher forcing: BN batch stats, all three dropouts recorded
+        tts_case('tts_tiny_train_tf', 3, B=4, L=6, teacher=(12,), tf_rate=1.0, training=True)
+        # eval-mode teacher forcing (running-stat BN), tensor teacher
+        tts_case('tts_tiny_eval_tf', 4, B=2, L=5, teacher=(9,), tf_rate=1.0, training=False)
+        # scheduled sampling: coin flips recorded
+        tts_case('tts_tiny_sched', 5, B=2, L=6, teacher=(12,), tf_rate=0.5, training=True)
+        # partial teacher (unpaired text rows have no teacher), text-to-text cycle
+        tts_case('tts_tiny_partial', 6, B=3, L=6, teacher=(9,), tf_rate=1.0, training=True, teacher_bs=2,
+                 unpair_max_frame=12)
+        # tensor teacher with tf_rate 0: un-divided step-count quirk (module.py:168)
+        tts_case('tts_tiny_quirk', 7, B=2, L=5, teacher=(4,), tf_rate=0.0, training=False, prenet_dropout=0.0)
+    if 'vq' in which:
+        vq_cases()
+        mean_forward_case()
+    if 'misc' in which:
+        postnet_class_case()
+        loss_case()
+    if 'full' in which:
+        full_size_case()
+
+
+if __name__ == '__main__':
+    main()

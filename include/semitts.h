@@ -1,0 +1,256 @@
+/* semitts.h -- C ABI of libsemitts_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the Tacotron-style TTS decode hot path and the VQ codebook lookup of
+ * ttaoREtw/semi-tts.  The reference has NO native/FFI layer (it is pure PyTorch, SURVEY.md
+ * section 8b): each entry point below replaces the torch.nn / torch.nn.functional call(s)
+ * of the reference cited next to it (`ref:` = path:line under the reference tree).  The
+ * Python host (the .py files of semi_tts_amd/) binds these with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous row-major fp32 (or int64 where said);
+ *    the caller (PyTorch) owns every buffer; the library allocates nothing persistent
+ *    except graphs/streams explicitly created through st_graph_* / st_stream_*;
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and is
+ *    hipGraph-capturable (no host sync, no malloc, no blocking memcpy inside);
+ *  - return value 0 = success; negative = error, text via st_last_error() (thread-local);
+ *  - "ld*" arguments are row strides in elements.
+ */
+#ifndef SEMITTS_H
+#define SEMITTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_ABI_VERSION 1
+
+/* activation codes */
+#define ST_ACT_NONE 0
+#define ST_ACT_RELU 1
+#define ST_ACT_TANH 2
+#define ST_ACT_SIGMOID 3
+
+const char* st_last_error(void);
+int st_abi_version(void);
+/* number of compute units / device name of the current device (diagnostics for bench.py) */
+int st_device_info(int* n_cu, int* lds_bytes, char* name, int name_len);
+
+/* ------------------------------------------------------------------ streams and graphs */
+/* HIP stream + hipGraph plumbing so that a launch-bound sequence of st_* calls (the 86..355
+ * step decode loop) is recorded once and replayed as ONE graph launch. */
+int st_stream_create(void** stream_out);
+int st_stream_destroy(void* stream);
+int st_stream_sync(void* stream);
+int st_graph_begin(void* stream);                       /* hipStreamBeginCapture            */
+int st_graph_end(void* stream, void** graph_exec_out);  /* EndCapture + Instantiate         */
+int st_graph_launch(void* graph_exec, void* stream);
+int st_graph_destroy(void* graph_exec);
+/* HIP-event timing on a given stream (bench.py measures kernels on the stream they run on) */
+int st_event_create(void** ev_out);
+int st_event_record(void* ev, void* stream);
+int st_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* syncs on ev_stop */
+int st_event_destroy(void* ev);
+
+/* ------------------------------------------------------------------ skinny (small-batch) ops
+ * Weight-streaming kernels for M = batch <= a few dozen rows: the weight matrix is the MFMA
+ * A operand (16 rows per workgroup, K split over the waves of the workgroup), the batch is
+ * the MFMA N dimension, so every weight byte is read from HBM exactly once per call.
+ * The logical input is the concatenation of up to 3 segments x_s (B, k_s) with row stride
+ * ldx_s, multiplied by W_s (N, k_s) with row stride ldw_s (slices of torch weights).
+ */
+typedef struct st_seg {
+    const float* x; /* (B, k) activations                       */
+    const float* w; /* (N, k) weight slice, torch [out][in]     */
+    int ldx;
+    int ldw;
+    int k;
+} st_seg;
+
+/* One LSTMCell step, fused gate GEMM + pointwise (+ hidden-state dropout).
+ * ref: nn.LSTMCell src/module.py:127-128,133-134 called :228,:277; nn.Dropout :230,:279;
+ *      nn.LSTM time step src/module.py:458-460 (with `pre` = x W_ih^T + b_ih + b_hh).
+ * gates(b, g*H+u) = sum_s x_s W_s^T + b_ih + b_hh + pre ; order (i,f,g,o)
+ * c' = s(f) c + s(i) tanh(g);  h' = s(o) tanh(c');  h_out = h' * mask (mask already scaled by 1/(1-p))
+ * b_ih, b_hh, pre, mask, gates_out may be NULL.  gates_out (B,4,H) receives the ACTIVATED
+ * gates (i,f,g,o) for the backward pass.  c_prev/c_out and h_out are (B,H) with row strides
+ * ldc / ldh (so they can point into a (B,T,H) sequence tensor). */
+int st_lstm_cell_fwd(const st_seg* segs, int nseg, const float* b_ih, const float* b_hh,
+                     const float* pre, int ldpre, const float* c_prev, int ldc_prev,
+                     const float* mask, float* h_out, int ldh, float* c_out, int ldc,
+                     float* gates_out, int B, int H, void* stream);
+
+/* y(b, n) = act(sum_s x_s W_s^T + bias) * mask      (B small)
+ * ref: Linear wrapper src/module.py:500-522 (prenet :337-339, query_layer :380,
+ *      pseudo_latent_mean/std :268-269).
+ * If n_split > 0 the output columns n >= n_split go to y2 instead, each value repeated
+ * `rep` times: the proj (+) gate_layer pair of src/module.py:285-287 in one launch
+ * (y = mel (B, r*n_mels), y2 = stop (B, r)). */
+int st_skinny_linear_fwd(const st_seg* segs, int nseg, const float* bias, int act,
+                         const float* mask, int ldmask, float* y, int ldy,
+                         int n_split, float* y2, int ldy2, int rep,
+                         int B, int N, void* stream);
+
+/* ------------------------------------------------------------------ location-sensitive attention
+ * One decode step for the whole batch, one workgroup per utterance.
+ * ref: Attention.energy/.forward src/module.py:371-407 and the state update :262-264,
+ *      AdaIN :267-269 (std/mean hoisted out of the loop).
+ *   loc   = W_loclin . conv1d(stack[w_prev, w_cum]; 2->F, k=K, pad (K-1)/2)      (L,A)
+ *   e_l   = v . tanh(pq + loc_l + pm_l)
+ *   w     = softmax_L(e)  (no mask)             -> w_out ; w_cum_out = w + w_cum_prev
+ *   ctx   = sum_l w_l memory_l                  -> ctx (B,E)
+ *   if h_q != NULL: h_adapt = ada_std * (h_q - ada_mean)                          (B,Q)
+ * pq (B,A) = query_layer(h_q) is produced by st_skinny_linear_fwd. */
+int st_attn_step_fwd(const float* pq, const float* pm, const float* memory,
+                     const float* w_prev, int ld_wprev, const float* w_cum_prev,
+                     float* w_out, int ld_wout, float* w_cum_out,
+                     const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                     float* ctx, int ld_ctx,
+                     const float* h_q, int ld_hq, const float* ada_std, const float* ada_mean,
+                     float* h_adapt, int Q,
+                     int B, int L, int A, int E, int F, int K, void* stream);
+
+/* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
+ * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) + tap - pad, ci) * W(n, ci, tap) )
+ * channels-last activations: A is (Bn * Tin, Cin) with row stride lda, C is (Bn * Tout, N)
+ * with row stride ldc; rows of one utterance never read across its [0,Tin) range (zero pad).
+ * W is the torch Conv1d weight (N, Cin, KT) or, with KT == 1, the torch Linear weight (N, Cin).
+ * epilogue: v += bias[n]; v = act_pre(v); if bn_mean: v = (v - bn_mean[n]) / sqrt(bn_var[n] + eps)
+ *           * bn_w[n] + bn_b[n]; v = act_post(v); if highway_h: v = highway_h(m,n) * v +
+ *           res(m,n) * (1 - v) else if res: v += res(m,n); if mask: v *= mask(m,n)
+ * pool_prev != 0: A(row, ci) is replaced by max(A(row, ci), A(row - 1, ci)) (row-1 inside the
+ * utterance), i.e. MaxPool1d(2, stride 1, padding 1)[:T] fused into the load.
+ * ref: Conv1d+BatchNorm1d+ReLU src/module.py:421-431; BatchNormConv1d :527-538; CBHG bank /
+ *      maxpool / projections / pre_highway / Highway :597-611, :541-555; nn.Linear src/tts.py:34;
+ *      memory_layer src/module.py:306; prenet over the whole teacher :178-179. */
+typedef struct st_gemm_epilogue {
+    const float* bias;
+    int act_pre;
+    const float* bn_mean; const float* bn_var; const float* bn_w; const float* bn_b; float bn_eps;
+    int act_post;
+    const float* res; int ldres;
+    const float* highway_h; int ldhw;
+    const float* mask; int ldmask;
+} st_gemm_epilogue;
+
+int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
+                int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev,
+                const st_gemm_epilogue* ep, void* stream);
+
+/* per-column statistics over M rows (training-mode BatchNorm): mean, biased variance, and
+ * the running-stat update  run = (1-mom) run + mom * {mean, unbiased var}.
+ * ref: nn.BatchNorm1d in training mode, src/module.py:429,:531 */
+int st_bn_stats(const float* X, int ldx, int coff, int M, int N, float* mean_out, float* var_out,
+                float* run_mean, float* run_var, float momentum, void* stream);
+/* X(m, coff+n) = act((X - mean) / sqrt(var + eps) * w + b), in place */
+int st_bn_apply(float* X, int ldx, int coff, int M, int N, const float* mean, const float* var,
+                const float* w, const float* b, float eps, int act, void* stream);
+
+/* ------------------------------------------------------------------ recurrent sequence layers */
+/* One direction of nn.LSTM over a full sequence: xproj (B,T,4H) = x W_ih^T + b_ih
+ * (from st_gemm_fwd; b_hh is added in the cell), out(b, t, ocol : ocol+H) = h_t.  Workspace ws: 3*B*H floats.
+ * ref: nn.LSTM src/module.py:432-438,:458-460 (lengths ignored, zero initial state). */
+int st_lstm_seq_fwd(const float* xproj, const float* w_hh, const float* b_hh, float* out, int ldo, int ocol,
+                    float* ws, int B, int T, int H, int reverse, void* stream);
+/* nn.GRU, ndir directions in one launch (direction 1 runs time-reversed), one workgroup per
+ * (utterance, direction) keeps W_hh rows in registers and h in LDS for all T steps.
+ * gi[d] (B,T,3H) = x W_ih[d]^T + b_ih[d] (from st_gemm_fwd); out(b, t, d*H : (d+1)*H) = h_t.
+ * ref: nn.GRU src/module.py:585-586,:617 */
+int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const float* w_hh_fwd, const float* w_hh_bwd,
+                   const float* b_hh_fwd, const float* b_hh_bwd, float* out, int ldo,
+                   int B, int T, int H, int ndir, void* stream);
+
+/* ------------------------------------------------------------------ VQ codebook */
+/* table(v, :) = cat[learnable(v, 0:Dl), attr(v,:) W_attr^T + b_attr]      (V, Dl + Da)
+ * ref: L2Embedding.embedding / forward src/embed.py:87-94,109-112 */
+int st_vq_build_table(const float* learnable, int Dl, const float* attr, int n_attr,
+                      const float* attr_w, const float* attr_b, int Da, float* table, int V, void* stream);
+/* out(n, :) = table(idx(n), :)   ref: F.embedding src/embed.py:97-101,:134,:181-183 */
+int st_gather_rows(const float* table, const int64_t* idx, float* out, int n, int D, int V, void* stream);
+/* Nearest-code search.  x (n, D), table (V, D):
+ *   sim = relu(temp) * -(|x|^2 + |e|^2 - 2 x.e) ; p = softmax_V(sim) ; idx = argmax_V(p)
+ *   (first maximum wins) ; out = (x + table[idx]) - x   (straight-through forward value)
+ * ref: L2Embedding.forward src/embed.py:105-147, neg_batch_l2 :208-213 */
+int st_vq_l2_fwd(const float* x, const float* table, const float* temp, float* p_code,
+                 int64_t* idx, float* out, int n, int D, int V, void* stream);
+/* softmax + argmax over rows of logits (n, V) -> p (n, V), idx (n)
+ * ref: SeperateEmbedding.forward src/embed.py:190-193 */
+int st_softmax_argmax(const float* logits, float* p, int64_t* idx, int n, int V, void* stream);
+
+/* ------------------------------------------------------------------ the decode loop
+ * Decoder.forward's `for t in range(decode_steps)` (src/module.py:184-206) issued natively:
+ * per step  query LSTM -> query projection -> attention (+AdaIN) -> decoder LSTM -> proj/gate
+ * [-> prenet of the own output when the next input is not a teacher frame].
+ * All per-step state lives in caller-owned "tapes" indexed by step (slot 0 = initial zeros),
+ * which double as the saved tensors of the backward pass.
+ */
+typedef struct st_decoder_weights {
+    const float* prenet_w0;      /* decoder.prenet.layers.0.linear.weight (P, r*n_mels)   */
+    const float* prenet_w1;      /* decoder.prenet.layers.1.linear.weight (P, P)          */
+    const float* q_w_ih;         /* decoder.query_rnn.weight_ih (4Q, P+E)                  */
+    const float* q_w_hh;         /* decoder.query_rnn.weight_hh (4Q, Q)                    */
+    const float* q_b_ih; const float* q_b_hh;
+    const float* attn_query_w;   /* decoder.attn.query_layer.linear.weight (A, Q)          */
+    const float* attn_v;         /* decoder.attn.v.linear.weight (1, A)                    */
+    const float* attn_loc_conv_w;/* decoder.attn.loc_conv.conv.weight (F, 2, K)            */
+    const float* attn_loc_lin_w; /* decoder.attn.loc_linear.linear.weight (A, F)           */
+    const float* d_w_ih;         /* decoder.dec_rnn.weight_ih (4D, E+Q)                    */
+    const float* d_w_hh;         /* decoder.dec_rnn.weight_hh (4D, D)                      */
+    const float* d_b_ih; const float* d_b_hh;
+    const float* projgate_w;     /* cat[proj.linear.weight; gate_layer.linear.weight] (r*n_mels+1, D+E) */
+    const float* projgate_b;     /* cat[proj.linear.bias; gate_layer.linear.bias]                      */
+} st_decoder_weights;
+
+typedef struct st_decoder_dims {
+    int B, L, E, n_mels, r, P, Q, D, A, F, K;
+} st_decoder_dims;
+
+typedef struct st_decoder_io {
+    const float* memory;      /* (B, L, E)  encoder output                                  */
+    const float* pm;          /* (B, L, A)  memory_layer(memory)        src/module.py:306   */
+    const float* ada_std;     /* (B, Q) relu(pseudo_latent_std(spkr))   src/module.py:268   */
+    const float* ada_mean;    /* (B, Q) pseudo_latent_mean(spkr)        src/module.py:269   */
+    /* next-input policy, decided by the host exactly as src/module.py:190-206:
+     * step_src[t] (HOST array, `steps` entries) tells where dec_in of step t+1 comes from:
+     *   -1 = prenet(own output) for every row; -2 = teacher mean (rows < Bt) ; >= 0 = teacher
+     *   frame index `take_frame` (rows < Bt); rows >= Bt always use prenet(own output).   */
+    const int* step_src;
+    const float* teacher_pre; /* (Bt, Tt, P) prenet(teacher) or NULL     src/module.py:178-179 */
+    const float* teacher_mean;/* (Bt, P) teacher_pre.mean(1) or NULL     src/module.py:194   */
+    int Bt, Tt;
+    const float* prenet_mask; /* (steps, 2, B, P) scaled masks for prenet(own output) after step t, or NULL */
+    const float* q_mask;      /* (steps, B, Q) scaled hidden-state dropout masks or NULL   */
+    const float* d_mask;      /* (steps, B, D) */
+    int steps;
+    /* outputs */
+    float* mel_out;           /* (B, steps*r, n_mels) */
+    float* align_out;         /* (B, steps, L)        */
+    float* stop_out;          /* (B, steps*r)         */
+    /* tapes, all (steps+1, B, dim) with slot 0 pre-zeroed by the callee */
+    float* hq_tape; float* cq_tape; float* hd_tape; float* cd_tape;   /* Q,Q,D,D */
+    float* ctx_tape; float* wcum_tape;                               /* E, L    */
+    float* hadapt_tape;       /* (steps, B, Q)  */
+    float* decin_tape;        /* (steps+1, B, P): slot t = dec_in of step t (slot 0 zeros) */
+    float* pq_buf;            /* (B, A) scratch */
+    float* pre1_buf;          /* (B, P) scratch (prenet layer-1 output) */
+    float* zero_row;          /* (B, max(L,1)) zeros (w_prev of step 0) -- zeroed by the callee */
+    float* gates_q_tape;      /* (steps, B, 4, Q) or NULL (training) */
+    float* gates_d_tape;      /* (steps, B, 4, D) or NULL */
+} st_decoder_io;
+
+int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io,
+                       void* stream);
+
+/* ------------------------------------------------------------------ small utilities */
+int st_fill(float* p, float v, size_t n, void* stream);
+int st_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream);
+/* dst(b, :) = mean over t of src(b, t, :)    ref: teacher.mean(dim=1) src/module.py:194 */
+int st_mean_rows(const float* src, float* dst, int B, int T, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMITTS_H */

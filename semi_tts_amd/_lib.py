@@ -1,0 +1,116 @@
+"""ctypes binding of libsemitts_hip.so (the C ABI declared in include/semitts.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libsemitts_hip.so')
+
+c_float_p = C.c_void_p   # device pointers travel as integers
+c_void_p = C.c_void_p
+
+
+class StSeg(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('ldx', C.c_int), ('ldw', C.c_int), ('k', C.c_int)]
+
+
+class StGemmEpilogue(C.Structure):
+    _fields_ = [('bias', C.c_void_p), ('act_pre', C.c_int),
+                ('bn_mean', C.c_void_p), ('bn_var', C.c_void_p), ('bn_w', C.c_void_p), ('bn_b', C.c_void_p),
+                ('bn_eps', C.c_float), ('act_post', C.c_int),
+                ('res', C.c_void_p), ('ldres', C.c_int),
+                ('highway_h', C.c_void_p), ('ldhw', C.c_int),
+                ('mask', C.c_void_p), ('ldmask', C.c_int)]
+
+
+class StDecoderWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'prenet_w0', 'prenet_w1', 'q_w_ih', 'q_w_hh', 'q_b_ih', 'q_b_hh',
+        'attn_query_w', 'attn_v', 'attn_loc_conv_w', 'attn_loc_lin_w',
+        'd_w_ih', 'd_w_hh', 'd_b_ih', 'd_b_hh', 'projgate_w', 'projgate_b')]
+
+
+class StDecoderDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('B', 'L', 'E', 'n_mels', 'r', 'P', 'Q', 'D', 'A', 'F', 'K')]
+
+
+class StDecoderIO(C.Structure):
+    _fields_ = [('memory', C.c_void_p), ('pm', C.c_void_p), ('ada_std', C.c_void_p), ('ada_mean', C.c_void_p),
+                ('step_src', C.POINTER(C.c_int)), ('teacher_pre', C.c_void_p), ('teacher_mean', C.c_void_p),
+                ('Bt', C.c_int), ('Tt', C.c_int),
+                ('prenet_mask', C.c_void_p), ('q_mask', C.c_void_p), ('d_mask', C.c_void_p),
+                ('steps', C.c_int),
+                ('mel_out', C.c_void_p), ('align_out', C.c_void_p), ('stop_out', C.c_void_p),
+                ('hq_tape', C.c_void_p), ('cq_tape', C.c_void_p), ('hd_tape', C.c_void_p), ('cd_tape', C.c_void_p),
+                ('ctx_tape', C.c_void_p), ('wcum_tape', C.c_void_p), ('hadapt_tape', C.c_void_p),
+                ('decin_tape', C.c_void_p), ('pq_buf', C.c_void_p), ('pre1_buf', C.c_void_p), ('zero_row', C.c_void_p),
+                ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p)]
+
+
+P, I, F, Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/semitts.h
+SIGNATURES = {
+    'st_last_error': [],
+    'st_abi_version': [],
+    'st_device_info': [C.POINTER(I), C.POINTER(I), C.c_char_p, I],
+    'st_stream_create': [C.POINTER(P)],
+    'st_stream_destroy': [P],
+    'st_stream_sync': [P],
+    'st_graph_begin': [P],
+    'st_graph_end': [P, C.POINTER(P)],
+    'st_graph_launch': [P, P],
+    'st_graph_destroy': [P],
+    'st_event_create': [C.POINTER(P)],
+    'st_event_record': [P, P],
+    'st_event_elapsed_ms': [P, P, C.POINTER(F)],
+    'st_event_destroy': [P],
+    'st_lstm_cell_fwd': [C.POINTER(StSeg), I, P, P, P, I, P, I, P, P, I, P, I, P, I, I, P],
+    'st_skinny_linear_fwd': [C.POINTER(StSeg), I, P, I, P, I, P, I, I, P, I, I, I, I, P],
+    'st_attn_step_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, P, I, P, I, P, P, P, I, I, I, I, I, I, I, P],
+    'st_gemm_fwd': [P, I, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(StGemmEpilogue), P],
+    'st_bn_stats': [P, I, I, I, I, P, P, P, P, F, P],
+    'st_bn_apply': [P, I, I, I, I, P, P, P, P, F, I, P],
+    'st_lstm_seq_fwd': [P, P, P, P, I, I, P, I, I, I, I, P],
+    'st_gru_seq_fwd': [P, P, P, P, P, P, P, I, I, I, I, I, P],
+    'st_vq_build_table': [P, I, P, I, P, P, I, P, I, P],
+    'st_gather_rows': [P, P, P, I, I, I, P],
+    'st_vq_l2_fwd': [P, P, P, P, P, P, I, I, I, P],
+    'st_softmax_argmax': [P, P, P, I, I, P],
+    'st_decoder_forward': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderIO), P],
+    'st_fill': [P, F, Z, P],
+    'st_copy2d': [P, I, P, I, I, I, P],
+    'st_mean_rows': [P, P, I, I, I, P],
+}
+_RESTYPES = {'st_last_error': C.c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libsemitts_hip.so not found at %s -- build it with `python -m semi_tts_amd.build` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.st_abi_version() != 1:
+        raise RuntimeError('libsemitts_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().st_last_error()
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))

@@ -1,0 +1,247 @@
+// gemm.hip -- fp32 MFMA GEMM / implicit-GEMM conv1d with a fused epilogue, gfx950 (MI355X).
+//
+// Used for everything on the path that has many rows (once per utterance, not per step):
+// encoder Conv1d+BN+ReLU stack, LSTM/GRU input projections, memory_layer, the whole-teacher
+// prenet, the CBHG conv bank / projections / highways, and Linear(2*n_mels -> linear_dim).
+// Activations are channels-last (rows = (utterance, frame)), so a k-tap conv is a sum over
+// taps of row-shifted GEMMs and needs no im2col buffer; utterance boundaries are handled by
+// zero-filling rows outside [0, Tin).
+//   tile 64(M) x 64(N) x 16(K), 4 wavefronts as 2x2, each 32x32 = 2x2 v_mfma_f32_16x16x4_f32
+//   (exact fp32).  A lane reads its MFMA operands as one ds_read_b128 per 16x16 sub-tile (4
+//   consecutive k, fed to 4 successive MFMAs; A and B use the same k permutation); LDS rows
+//   are padded to 20 floats so the 16 rows of a lane group fall on distinct 16-byte slots.
+//   Global loads of tile t+1 are issued before the MFMAs of tile t.
+#include "st_common.h"
+
+namespace {
+
+constexpr int GM_BM = 64, GM_BN = 64, GM_BK = 16, GM_LD = 20, GM_THREADS = 256;
+
+struct GmArgs {
+    const float* A; int lda; const float* W; float* C; int ldc; int coff;
+    int Bn, Tin, Tout, Cin, N, KT, pad, pool_prev;
+    int M;      // Bn * Tout
+    int cpb;    // 16-float k-blocks per tap
+    st_gemm_epilogue ep;
+};
+
+template <bool VECA, bool VECW>
+__global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GM_BM * GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_BN * GM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * GM_BM, n0 = blockIdx.y * GM_BN;
+
+    // staging role of this thread: one 4-float piece of row `srow` of each tile
+    const int srow = tid >> 2, skq = tid & 3;
+    const int am = m0 + srow;
+    const bool a_row_ok = am < g.M;
+    int ab = 0, ato = 0;
+    if (a_row_ok) { ab = am / g.Tout; ato = am - ab * g.Tout; }
+    const int wn_row = n0 + srow;
+    const bool w_row_ok = wn_row < g.N;
+
+    auto load_a = [&](int kb) -> f32x4 {
+        const int tap = kb / g.cpb;
+        const int ci = (kb - tap * g.cpb) * GM_BK + skq * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int ti = ato + tap - g.pad;
+        if (!a_row_ok || ti < 0 || ti >= g.Tin || ci >= g.Cin) return v;
+        const float* p = g.A + ((size_t)ab * g.Tin + ti) * g.lda + ci;
+        if (VECA) v = st_ld4(p); else v = st_ld4_guard(p, g.Cin - ci);
+        if (g.pool_prev && ti > 0) {  // MaxPool1d(2, stride 1, padding 1)[:T] fused into the load
+            f32x4 q;
+            if (VECA) q = st_ld4(p - g.lda); else q = st_ld4_guard(p - g.lda, g.Cin - ci);
+            v[0] = fmaxf(v[0], q[0]); v[1] = fmaxf(v[1], q[1]); v[2] = fmaxf(v[2], q[2]); v[3] = fmaxf(v[3], q[3]);
+        }
+        return v;
+    };
+    auto load_w = [&](int kb) -> f32x4 {
+        const int tap = kb / g.cpb;
+        const int ci = (kb - tap * g.cpb) * GM_BK + skq * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!w_row_ok || ci >= g.Cin) return v;
+        if (VECW) {  // KT == 1: torch Linear weight rows are contiguous in ci
+            v = st_ld4(g.W + (size_t)wn_row * g.Cin + ci);
+        } else {     // torch Conv1d weight (N, Cin, KT): stride KT between consecutive ci
+            const float* p = g.W + ((size_t)wn_row * g.Cin + ci) * g.KT + tap;
+            const int rem = g.Cin - ci;
+            v[0] = p[0];
+            if (rem > 1) v[1] = p[g.KT];
+            if (rem > 2) v[2] = p[2 * g.KT];
+            if (rem > 3) v[3] = p[3 * g.KT];
+        }
+        return v;
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkb = g.KT * g.cpb;
+    f32x4 ra = load_a(0), rw = load_w(0);
+    const int fr = lane & 15, fk = (lane >> 4) * 4;
+    for (int kb = 0; kb < nkb; ++kb) {
+        *reinterpret_cast<f32x4*>(As + srow * GM_LD + skq * 4) = ra;
+        *reinterpret_cast<f32x4*>(Bs + srow * GM_LD + skq * 4) = rw;
+        __syncthreads();
+        if (kb + 1 < nkb) { ra = load_a(kb + 1); rw = load_w(kb + 1); }
+        f32x4 a4[2], b4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a4[t] = *reinterpret_cast<const f32x4*>(As + (wm * 32 + t * 16 + fr) * GM_LD + fk);
+            b4[t] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + t * 16 + fr) * GM_LD + fk);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = 4*(lane>>4) + r][col = lane&15]
+    const st_gemm_epilogue& ep = g.ep;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 32 + nt * 16 + (lane & 15);
+        if (n >= g.N) continue;
+        const float bias = ep.bias ? ep.bias[n] : 0.0f;
+        float bn_m = 0.f, bn_s = 1.f, bn_w = 1.f, bn_b = 0.f;
+        if (ep.bn_mean) {
+            bn_m = ep.bn_mean[n];
+            bn_s = 1.0f / sqrtf(ep.bn_var[n] + ep.bn_eps);
+            bn_w = ep.bn_w ? ep.bn_w[n] : 1.0f;
+            bn_b = ep.bn_b ? ep.bn_b[n] : 0.0f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + mt * 16 + 4 * (lane >> 4) + r;
+                if (m >= g.M) continue;
+                float v = acc[mt][nt][r] + bias;
+                v = st_act(v, ep.act_pre);
+                if (ep.bn_mean) v = (v - bn_m) * bn_s * bn_w + bn_b;
+                v = st_act(v, ep.act_post);
+                if (ep.highway_h) {
+                    // Highway: y = H * T + x * (1 - T), v = T                (module.py:551-554)
+                    const float hh = ep.highway_h[(size_t)m * ep.ldhw + n];
+                    const float xx = ep.res[(size_t)m * ep.ldres + n];
+                    v = hh * v + xx * (1.0f - v);
+                } else if (ep.res) {
+                    v += ep.res[(size_t)m * ep.ldres + n];
+                }
+                if (ep.mask) v *= ep.mask[(size_t)m * ep.ldmask + n];
+                g.C[(size_t)m * g.ldc + g.coff + n] = v;
+            }
+        }
+    }
+}
+
+// ---- training-mode BatchNorm helpers ---------------------------------------------------
+// column statistics: grid.x = column blocks of 64, block = 256 threads = 4 row lanes x 64 cols.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* X, int ldx, int coff, int M, int N,
+                                                       float* mean_out, float* var_out,
+                                                       float* run_mean, float* run_var, float momentum) {
+    __shared__ float red[4][64];
+    __shared__ float smean[64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const bool ok = n < N;
+    float s = 0.0f;
+    if (ok) for (int m = rl; m < M; m += 4) s += X[(size_t)m * ldx + coff + n];
+    red[rl][c] = s;
+    __syncthreads();
+    if (rl == 0) smean[c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)M;
+    __syncthreads();
+    const float mean = smean[c];
+    float q = 0.0f;
+    if (ok) for (int m = rl; m < M; m += 4) { const float d = X[(size_t)m * ldx + coff + n] - mean; q = fmaf(d, d, q); }
+    __syncthreads();
+    red[rl][c] = q;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        const float ss = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        const float var_b = ss / (float)M;
+        mean_out[n] = mean;
+        var_out[n] = var_b;
+        if (run_mean) {
+            const float var_u = M > 1 ? ss / (float)(M - 1) : var_b;
+            run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
+            run_var[n] = (1.0f - momentum) * run_var[n] + momentum * var_u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(float* X, int ldx, int coff, int M, int N,
+                                                       const float* mean, const float* var, const float* w,
+                                                       const float* b, float eps, int act) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+        float* p = X + (size_t)m * ldx + coff + n;
+        float v = (*p - mean[n]) / sqrtf(var[n] + eps);
+        v = v * (w ? w[n] : 1.0f) + (b ? b[n] : 0.0f);
+        *p = st_act(v, act);
+    }
+}
+
+}  // namespace
+
+extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
+                           int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev,
+                           const st_gemm_epilogue* ep, void* stream) {
+    ST_CHECK_ARG(A && W && C, "st_gemm_fwd: null pointer");
+    ST_CHECK_ARG(Bn > 0 && Tin > 0 && Tout > 0 && Cin > 0 && N > 0 && KT > 0 && pad >= 0, "st_gemm_fwd: bad dims");
+    ST_CHECK_ARG(lda >= Cin && ldc >= coff + N, "st_gemm_fwd: lda=%d < Cin=%d or ldc=%d < coff+N=%d", lda, Cin, ldc, coff + N);
+    ST_CHECK_ARG(Tout <= Tin + 2 * pad - KT + 1, "st_gemm_fwd: Tout=%d exceeds conv output length %d", Tout, Tin + 2 * pad - KT + 1);
+    GmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.W = W; g.C = C; g.ldc = ldc; g.coff = coff;
+    g.Bn = Bn; g.Tin = Tin; g.Tout = Tout; g.Cin = Cin; g.N = N; g.KT = KT; g.pad = pad; g.pool_prev = pool_prev;
+    g.M = Bn * Tout;
+    g.cpb = (Cin + GM_BK - 1) / GM_BK;
+    if (ep) {
+        g.ep = *ep;
+        ST_CHECK_ARG(!ep->highway_h || ep->res, "st_gemm_fwd: highway epilogue needs res (the layer input)");
+        ST_CHECK_ARG(!ep->bn_mean || ep->bn_var, "st_gemm_fwd: bn_mean without bn_var");
+    }
+    const bool veca = st_aligned16(A) && (lda % 4 == 0) && (Cin % 4 == 0);
+    const bool vecw = (KT == 1) && st_aligned16(W) && (Cin % 4 == 0);
+    dim3 grid((g.M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
+    hipStream_t st = (hipStream_t)stream;
+    if (veca && vecw) hipLaunchKernelGGL((gm_kernel<true, true>), grid, dim3(GM_THREADS), 0, st, g);
+    else if (veca) hipLaunchKernelGGL((gm_kernel<true, false>), grid, dim3(GM_THREADS), 0, st, g);
+    else if (vecw) hipLaunchKernelGGL((gm_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);
+    else hipLaunchKernelGGL((gm_kernel<false, false>), grid, dim3(GM_THREADS), 0, st, g);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, float* mean_out, float* var_out,
+                           float* run_mean, float* run_var, float momentum, void* stream) {
+    ST_CHECK_ARG(X && mean_out && var_out && M > 0 && N > 0, "st_bn_stats: bad arguments");
+    ST_CHECK_ARG((run_mean == nullptr) == (run_var == nullptr), "st_bn_stats: run_mean/run_var must both be given");
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       X, ldx, coff, M, N, mean_out, var_out, run_mean, run_var, momentum);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_apply(float* X, int ldx, int coff, int M, int N, const float* mean, const float* var,
+                           const float* w, const float* b, float eps, int act, void* stream) {
+    ST_CHECK_ARG(X && mean && var && M > 0 && N > 0, "st_bn_apply: bad arguments");
+    const size_t total = (size_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       X, ldx, coff, M, N, mean, var, w, b, eps, act);
+    ST_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,242 @@
+// skinny.hip -- small-batch, weight-streaming matrix kernels for gfx950 (MI355X).
+//
+// One decode step multiplies a (B<=64, K) activation block by LSTM/Linear weights whose
+// bytes dominate everything else (75.5 MB per step at the headline shape), so these
+// kernels are designed around ONE pass over the weights at HBM speed:
+//   * the weight matrix is the MFMA *A* operand: a workgroup owns 16 weight rows
+//     (for the LSTM: the i,f,g,o rows of 4 hidden units, so the cell update is local),
+//   * the batch is the MFMA *N* dimension (16 columns per v_mfma_f32_16x16x4_f32, NB tiles),
+//   * K is split over the KW waves of the workgroup in 32-float chunks (each lane loads two
+//     16-byte pieces so a wave touches whole 128-byte lines of 16 rows), partial tiles are
+//     reduced through LDS in a fixed order (deterministic),
+//   * v_mfma_f32_16x16x4_f32 is exact fp32 (one rounding per fma), so results differ from a
+//     CPU BLAS only by summation order.
+// Lane mapping of the 16x16x4 MFMA: A[i = lane&15][k = lane>>4], B[k = lane>>4][n = lane&15],
+// D[row = 4*(lane>>4) + r][col = lane&15].  A lane loads 4 consecutive k of its row as one
+// float4 and feeds component c to the c-th of 4 MFMAs; A and B use the same k permutation.
+#include "st_common.h"
+
+namespace {
+
+constexpr int SK_MAXSEG = 3;
+
+struct SkArgs {
+    st_seg seg[SK_MAXSEG];
+    int nseg;
+    int B, N, H;
+    // LSTM epilogue
+    const float* b_ih; const float* b_hh; const float* pre; int ldpre;
+    const float* c_prev; int ldc_prev; const float* mask;
+    float* h_out; int ldh; float* c_out; int ldc; float* gates_out;
+    // linear epilogue
+    const float* bias; int act; const float* lmask; int ldmask;
+    float* y; int ldy; int n_split; float* y2; int ldy2; int rep;
+};
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 sk_load(const float* p, int k0, int klim) {
+    // 4 floats at p[k0..k0+3]; elements at or beyond klim read as zero
+    if (VEC) {
+        if (k0 + 4 <= klim) return st_ld4(p + k0);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        return z;
+    } else {
+        return st_ld4_guard(p + k0, klim - k0);
+    }
+}
+
+// MODE 0: LSTM cell, MODE 1: linear
+template <int MODE, int NB, int KW, bool VEC>
+__global__ __launch_bounds__(KW * 64) void sk_kernel(const SkArgs a) {
+    __shared__ f32x4 red[KW * NB * 64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;   // weight row within the tile / batch column within a batch tile
+    const int kq = lane >> 4;  // which 4-float group of a 16-float block
+    const int tile = blockIdx.x;
+    const int bbase = blockIdx.y * (NB * 16);
+
+    int wrow;
+    if (MODE == 0) wrow = (i & 3) * a.H + tile * 4 + (i >> 2);
+    else { wrow = tile * 16 + i; if (wrow >= a.N) wrow = a.N - 1; }
+
+    int brow[NB];
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+        int b = bbase + bt * 16 + i;
+        brow[bt] = b < a.B ? b : a.B - 1;
+    }
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) acc[bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int cstart = wave;  // rotates so that waves stay balanced across segments
+    for (int s = 0; s < a.nseg; ++s) {
+        const float* __restrict__ wp = a.seg[s].w + (size_t)wrow * a.seg[s].ldw;
+        const float* xp[NB];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) xp[bt] = a.seg[s].x + (size_t)brow[bt] * a.seg[s].ldx;
+        const int K = a.seg[s].k;
+        const int nchunk = (K + 31) >> 5;
+        int c = cstart;
+        for (; c < nchunk; c += 2 * KW) {
+            // two 32-float chunks per trip: 4 weight + 4*NB activation 16-byte loads in flight
+            const int k0 = c * 32 + kq * 4;
+            const int k1 = (c + KW) * 32 + kq * 4;  // may lie beyond K: loads return zeros
+            f32x4 w00 = sk_load<VEC>(wp, k0, K), w01 = sk_load<VEC>(wp, k0 + 16, K);
+            f32x4 w10 = sk_load<VEC>(wp, k1, K), w11 = sk_load<VEC>(wp, k1 + 16, K);
+            f32x4 x00[NB], x01[NB], x10[NB], x11[NB];
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                x00[bt] = sk_load<VEC>(xp[bt], k0, K);
+                x01[bt] = sk_load<VEC>(xp[bt], k0 + 16, K);
+                x10[bt] = sk_load<VEC>(xp[bt], k1, K);
+                x11[bt] = sk_load<VEC>(xp[bt], k1 + 16, K);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w00[cc], x00[bt][cc], acc[bt], 0, 0, 0);
+                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w01[cc], x01[bt][cc], acc[bt], 0, 0, 0);
+                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w10[cc], x10[bt][cc], acc[bt], 0, 0, 0);
+                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w11[cc], x11[bt][cc], acc[bt], 0, 0, 0);
+                }
+            }
+        }
+        // next segment: the wave that would have taken chunk `nchunk` takes its chunk 0
+        cstart = (cstart + KW - (nchunk % KW)) % KW;
+    }
+
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) red[(wave * NB + bt) * 64 + lane] = acc[bt];
+    __syncthreads();
+    if (tid >= NB * 64) return;
+
+    const int bt = tid >> 6;
+    f32x4 s = red[bt * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) {
+        f32x4 t = red[(w * NB + bt) * 64 + lane];
+        s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    const int b = bbase + bt * 16 + (lane & 15);
+    if (b >= a.B) return;
+
+    if (MODE == 0) {
+        const int H = a.H;
+        const int u = tile * 4 + (lane >> 4);
+        float g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = s[r];
+            if (a.b_ih) v += a.b_ih[r * H + u];
+            if (a.b_hh) v += a.b_hh[r * H + u];
+            if (a.pre) v += a.pre[(size_t)b * a.ldpre + r * H + u];
+            g[r] = v;
+        }
+        const float gi = st_sigmoid(g[0]), gf = st_sigmoid(g[1]), gg = tanhf(g[2]), go = st_sigmoid(g[3]);
+        const float cp = a.c_prev ? a.c_prev[(size_t)b * a.ldc_prev + u] : 0.0f;
+        const float c2 = gf * cp + gi * gg;
+        float h2 = go * tanhf(c2);
+        if (a.mask) h2 *= a.mask[(size_t)b * H + u];
+        a.c_out[(size_t)b * a.ldc + u] = c2;
+        a.h_out[(size_t)b * a.ldh + u] = h2;
+        if (a.gates_out) {
+            float* gp = a.gates_out + (size_t)b * 4 * H + u;
+            gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = tile * 16 + 4 * (lane >> 4) + r;
+            if (n >= a.N) continue;
+            float v = s[r];
+            if (a.bias) v += a.bias[n];
+            v = st_act(v, a.act);
+            if (a.lmask) v *= a.lmask[(size_t)b * a.ldmask + n];
+            if (a.n_split > 0 && n >= a.n_split) {
+                float* p = a.y2 + (size_t)b * a.ldy2 + (size_t)(n - a.n_split) * a.rep;
+                for (int j = 0; j < a.rep; ++j) p[j] = v;
+            } else {
+                a.y[(size_t)b * a.ldy + n] = v;
+            }
+        }
+    }
+}
+
+template <int MODE, int NB, bool VEC>
+int sk_launch(const SkArgs& a, int tiles, hipStream_t st) {
+    constexpr int KW = 8;
+    dim3 grid(tiles, (a.B + NB * 16 - 1) / (NB * 16));
+    hipLaunchKernelGGL((sk_kernel<MODE, NB, KW, VEC>), grid, dim3(KW * 64), 0, st, a);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE>
+int sk_dispatch(const SkArgs& a, int tiles, hipStream_t st) {
+    bool vec = true;
+    for (int s = 0; s < a.nseg; ++s) {
+        const st_seg& g = a.seg[s];
+        vec = vec && st_aligned16(g.x) && st_aligned16(g.w) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) && (g.k % 4 == 0);
+    }
+    const int nb = a.B <= 16 ? 1 : (a.B <= 32 ? 2 : 4);
+    if (vec) {
+        if (nb == 1) return sk_launch<MODE, 1, true>(a, tiles, st);
+        if (nb == 2) return sk_launch<MODE, 2, true>(a, tiles, st);
+        return sk_launch<MODE, 4, true>(a, tiles, st);
+    }
+    if (nb == 1) return sk_launch<MODE, 1, false>(a, tiles, st);
+    if (nb == 2) return sk_launch<MODE, 2, false>(a, tiles, st);
+    return sk_launch<MODE, 4, false>(a, tiles, st);
+}
+
+int sk_fill_segs(SkArgs& a, const st_seg* segs, int nseg) {
+    ST_CHECK_ARG(nseg >= 1 && nseg <= SK_MAXSEG, "skinny op: nseg=%d not in [1,%d]", nseg, SK_MAXSEG);
+    a.nseg = nseg;
+    for (int s = 0; s < nseg; ++s) {
+        ST_CHECK_ARG(segs[s].x && segs[s].w && segs[s].k > 0, "skinny op: segment %d has null pointer or k<=0", s);
+        ST_CHECK_ARG(segs[s].ldx >= segs[s].k && segs[s].ldw >= segs[s].k, "skinny op: segment %d stride < k", s);
+        a.seg[s] = segs[s];
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int st_lstm_cell_fwd(const st_seg* segs, int nseg, const float* b_ih, const float* b_hh,
+                                const float* pre, int ldpre, const float* c_prev, int ldc_prev,
+                                const float* mask, float* h_out, int ldh, float* c_out, int ldc,
+                                float* gates_out, int B, int H, void* stream) {
+    ST_CHECK_ARG(B > 0 && H > 0, "st_lstm_cell_fwd: B=%d H=%d", B, H);
+    ST_CHECK_ARG(H % 4 == 0, "st_lstm_cell_fwd: H=%d must be a multiple of 4", H);
+    ST_CHECK_ARG(h_out && c_out, "st_lstm_cell_fwd: null output");
+    SkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = sk_fill_segs(a, segs, nseg);
+    if (rc) return rc;
+    a.B = B; a.N = 4 * H; a.H = H;
+    a.b_ih = b_ih; a.b_hh = b_hh; a.pre = pre; a.ldpre = ldpre;
+    a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
+    a.h_out = h_out; a.ldh = ldh; a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
+    return sk_dispatch<0>(a, H / 4, (hipStream_t)stream);
+}
+
+extern "C" int st_skinny_linear_fwd(const st_seg* segs, int nseg, const float* bias, int act,
+                                    const float* mask, int ldmask, float* y, int ldy,
+                                    int n_split, float* y2, int ldy2, int rep,
+                                    int B, int N, void* stream) {
+    ST_CHECK_ARG(B > 0 && N > 0 && y, "st_skinny_linear_fwd: B=%d N=%d y=%p", B, N, (void*)y);
+    ST_CHECK_ARG(n_split <= 0 || (y2 && rep >= 1), "st_skinny_linear_fwd: n_split without y2/rep");
+    SkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = sk_fill_segs(a, segs, nseg);
+    if (rc) return rc;
+    a.B = B; a.N = N; a.H = 0;
+    a.bias = bias; a.act = act; a.lmask = mask; a.ldmask = ldmask;
+    a.y = y; a.ldy = ldy; a.n_split = n_split; a.y2 = y2; a.ldy2 = ldy2; a.rep = rep;
+    return sk_dispatch<1>(a, (N + 15) / 16, (hipStream_t)stream);
+}

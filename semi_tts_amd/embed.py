@@ -1,0 +1,146 @@
+"""VQ codebook on the HIP path: mirror of the reference's src/embed.py (L2Embedding,
+SeperateEmbedding) with the same constructor arguments, attributes read by callers
+(`.out_dim`, `.embedding.weight`, `.create_msg()`), state_dict keys and return tuples.
+
+forward values only: distance -> softmax -> argmax -> lookup -> straight-through value is one
+fused kernel (st_vq_l2_fwd); nothing here falls back to torch arithmetic.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+PRESERVE_INDICES = 3     # <pad>, <space>, <eos>                        ref: src/util.py:15
+
+
+def read_phn_attr(path, neg_val=0):
+    """Tab-separated table, first column = phoneme symbol, header row = attribute names;
+    three all-zero rows are prepended for <pad>/<space>/<eos>.   ref: src/util.py:240-245"""
+    rows = []
+    with open(path) as f:
+        next(f)                                   # header
+        for line in f:
+            parts = line.rstrip('\n').split('\t')
+            if len(parts) > 1:
+                rows.append([float(v) for v in parts[1:]])
+    attr = np.asarray(rows, dtype=np.float64)
+    attr[attr == 0] = neg_val
+    return np.concatenate([np.zeros((PRESERVE_INDICES, attr.shape[1])), attr])
+
+
+class _TableView:
+    """what `codebook.embedding` returns: an object with `.weight` (the full (V, D) table)"""
+
+    def __init__(self, weight):
+        self.weight = weight
+
+
+class BaseEmbedding(nn.Module):
+    """ref: src/embed.py:9-55"""
+
+    def __init__(self, vocab_size, softmax, latent_dim, commit_weight, vq_weight, temp):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.softmax = softmax
+        self.latent_dim = latent_dim
+        self.out_dim = latent_dim
+        self.commit_weight = commit_weight
+        self.vq_weight = vq_weight
+        self.ema = False
+        self.phn_attr = None
+        self.proj_attr = None
+        self.use_phn_attr = False
+        self.onehot = nn.Embedding.from_pretrained(torch.eye(vocab_size), freeze=True)
+        if temp < 0:
+            self.temp = nn.Parameter(torch.FloatTensor([1]))
+        else:
+            self.register_buffer('temp', torch.FloatTensor([temp]))
+
+    def _setup_attr(self, phn_attr_pth, proj_attr, latent_dim):
+        self.use_phn_attr = phn_attr_pth is not None and phn_attr_pth != ''
+        if self.use_phn_attr:
+            assert latent_dim > proj_attr > 0, 'Currently, proj attr is necessary'
+            phn_attr = torch.FloatTensor(read_phn_attr(phn_attr_pth))
+            self.phn_attr = nn.Embedding.from_pretrained(phn_attr, freeze=True, padding_idx=0)
+            self.proj_attr = nn.Linear(phn_attr.shape[1], proj_attr)
+            return proj_attr
+        return 0
+
+    def _table(self, learnable):
+        """cat[learnable, proj_attr(phn_attr.weight)] built on device.   ref: src/embed.py:87-94,109-112"""
+        if self.use_phn_attr:
+            return ops.vq_build_table(learnable, self.phn_attr.weight, self.proj_attr.weight, self.proj_attr.bias)
+        return ops.vq_build_table(learnable)
+
+    def create_msg(self):
+        return '           | EMA update = {}\t | Temp. = {}\t| Phn. attributs = {} ( projected = {})'.format(
+            self.ema, 'learnable' if type(self.temp) is nn.Parameter else self.temp.data.item(),
+            self.use_phn_attr, self.proj_attr is not None)
+
+
+class L2Embedding(BaseEmbedding):
+    """ref: src/embed.py:57-147"""
+
+    def __init__(self, vocab_size, ema, softmax, latent_dim, commit_weight, vq_weight, temp,
+                 skip_prob, stop_grad, phn_attr_pth=None, proj_attr=None):
+        super().__init__(vocab_size, softmax, latent_dim, commit_weight, vq_weight, temp)
+        assert self.softmax == 'normal'
+        assert not ema
+        assert commit_weight == 0
+        assert vq_weight == 0
+        self.skip_prob = skip_prob
+        self.stop_grad = stop_grad
+        n_attr = self._setup_attr(phn_attr_pth, proj_attr, latent_dim)
+        self.learnable_table = nn.Parameter(torch.randn((vocab_size, latent_dim - n_attr)))
+
+    @property
+    def embedding(self):
+        return _TableView(self._table(self.learnable_table))
+
+    def inference(self, txt):
+        """token ids (B,L) -> vectors (B,L,latent_dim)                     ref: src/embed.py:96-103"""
+        return ops.gather_rows(self._table(self.learnable_table), txt)
+
+    def forward(self, enc_embs, first_n_real_mel=0):
+        """enc_embs (B,S,D) -> (p_code (B,S,V), new_latent (B,S,D), 0, 0).  ref: src/embed.py:105-147.
+        `first_n_real_mel` only detaches the table for part of the batch (forward values unchanged)."""
+        if not self.stop_grad:
+            raise NotImplementedError('ST-onehot variant (stop_grad=False): every shipped config uses stop_grad=True')
+        if self.training and self.skip_prob > 0 and np.random.rand() < self.skip_prob:
+            raise NotImplementedError('skip connection (skip_prob > 0): every shipped config uses 0')
+        table = self._table(self.learnable_table)
+        p_code, idx, new_latent = ops.vq_l2(enc_embs.contiguous(), table, self.temp)
+        self.last_idx = idx
+        return p_code, new_latent, 0, 0
+
+
+class SeperateEmbedding(BaseEmbedding):
+    """Separate ASR classifier / TTS embedding (the codebook of config/supervised.yaml).
+    ref: src/embed.py:150-205"""
+
+    def __init__(self, vocab_size, ema, softmax, latent_dim, commit_weight, vq_weight, temp,
+                 skip_prob, stop_grad, phn_attr_pth=None, proj_attr=None):
+        super().__init__(vocab_size, softmax, latent_dim, commit_weight, vq_weight, temp)
+        assert self.softmax == 'normal'
+        assert not ema
+        assert commit_weight == 0
+        assert vq_weight == 0
+        assert skip_prob == 0
+        self.stop_grad = stop_grad
+        self.asr_final_layer = nn.Linear(latent_dim, vocab_size)
+        n_attr = self._setup_attr(phn_attr_pth, proj_attr, latent_dim)
+        self.embedding = nn.Embedding(vocab_size, latent_dim - n_attr)
+
+    def inference(self, txt):
+        return ops.gather_rows(self._table(self.embedding.weight), txt)              # :180-185
+
+    def forward(self, enc_embs, first_n_real_mel=0):
+        if not self.stop_grad:
+            raise NotImplementedError('ST-onehot variant (stop_grad=False)')
+        x = enc_embs.contiguous()
+        logits = ops.gemm(x.view(-1, x.shape[-1]), self.asr_final_layer.weight, bias=self.asr_final_layer.bias)
+        p_code, idx = ops.softmax_argmax(logits.view(*x.shape[:-1], -1))             # :190-193
+        self.last_idx = idx
+        new_latent = ops.gather_rows(self._table(self.embedding.weight), idx)        # :195-197
+        return p_code, new_latent, 0, 0

@@ -1,0 +1,483 @@
+"""Host-side mirror of the reference's TTS building blocks (src/module.py:53-622) on the
+MI355X HIP path.
+
+Same class names, constructor arguments, forward signatures and state_dict keys as the
+reference, so `load_state_dict` of a reference checkpoint works and callers
+(`Tacotron2`, `VQVAE.text_to_speech`) do not change.  torch.nn modules appear here only as
+parameter containers (they give the reference's parameter names and initialisation); none
+of their `forward`s is ever called -- every forward below goes through libsemitts_hip.so
+via `ops` and raises on CPU tensors.
+
+Activations are kept channels-last (B, T, C) end to end (the reference transposes to
+(B, C, T) around every Conv1d; the HIP conv is an implicit GEMM over channels-last rows).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import _lib
+from ._lib import StDecoderWeights, StDecoderDims, StDecoderIO, check
+
+
+def _scaled_mask(shape, p, device):
+    """bernoulli(1-p)/(1-p) dropout mask (device RNG; the values the reference's F.dropout multiplies by)"""
+    return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
+# ----------------------------------------------------------------------------- thin parameter wrappers
+class Conv1d(nn.Module):
+    """ref: src/module.py:480-497 (xavier-uniform init with `w_init_gain`)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=None, dilation=1,
+                 bias=True, w_init_gain='linear'):
+        super().__init__()
+        if padding is None:
+            assert kernel_size % 2 == 1, 'kernel_size should be odd if no given padding.'
+            padding = (dilation * (kernel_size - 1)) // 2
+        assert stride == 1 and dilation == 1, 'the HIP conv1d supports stride 1, dilation 1 (all the path uses)'
+        self.padding = padding
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                              dilation=dilation, bias=bias)
+        nn.init.xavier_uniform_(self.conv.weight, gain=nn.init.calculate_gain(w_init_gain))
+
+    def forward(self, x_cl, **epilogue):
+        """x_cl (B,T,Cin) channels-last -> (B,T',Cout)"""
+        return ops.gemm(x_cl, self.conv.weight, pad=self.padding, bias=self.conv.bias, **epilogue)
+
+
+class Linear(nn.Module):
+    """ref: src/module.py:500-522"""
+
+    def __init__(self, in_dim, out_dim, bias=True, w_init_gain='linear', norm_type=None):
+        super().__init__()
+        self.linear = nn.Linear(in_dim, out_dim, bias=bias)
+        nn.init.xavier_uniform_(self.linear.weight, gain=nn.init.calculate_gain(w_init_gain))
+        self.apply_norm = norm_type is not None
+        if self.apply_norm:
+            raise NotImplementedError('norm_type=%r: no shipped config uses a normalised Linear' % norm_type)
+
+    def forward(self, x, act=None, mask=None):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        m2 = mask.reshape(-1, mask.shape[-1]) if mask is not None else None
+        if x2.shape[0] <= 64:
+            y = ops.linear_small(x2, self.linear.weight, self.linear.bias, act, m2)
+        else:
+            y = ops.gemm(x2, self.linear.weight, bias=self.linear.bias, act_pre=act, mask=m2)
+        return y.view(*lead, -1)
+
+
+# ----------------------------------------------------------------------------- batch norm helper
+def _conv_bn_act(x, weight, bias, bn, pad, eps, momentum, order, training, Tout=None, out=None, coff=0,
+                 pool_prev=False, stats_Tout=None):
+    """conv1d followed by {BN, act} in the order the reference applies them.
+    order 'bn_relu' (encoder, module.py:429-430), 'relu_bn' (BatchNormConv1d with activation,
+    :535-537), 'bn' (no activation), 'bn_tanh' (Postnet class).  Eval mode folds everything into
+    the GEMM epilogue; training mode needs the batch statistics of the pre-BN tensor first."""
+    pre = 'relu' if order == 'relu_bn' else None
+    post = {'bn_relu': 'relu', 'bn_tanh': 'tanh'}.get(order)
+    if not training:
+        return ops.gemm(x, weight, out, pad=pad, Tout=Tout, coff=coff, bias=bias, act_pre=pre,
+                        bn=(bn.running_mean, bn.running_var, bn.weight, bn.bias), bn_eps=eps, act_post=post,
+                        pool_prev=pool_prev)
+    N = weight.shape[0]
+    if stats_Tout is not None and stats_Tout != Tout:
+        # statistics over more output positions than are kept: one conv pass for the statistics,
+        # then the eval-style fused pass with the batch statistics
+        tmp = ops.gemm(x, weight, pad=pad, Tout=stats_Tout, bias=bias, act_pre=pre, pool_prev=pool_prev)
+        mean, var = ops.bn_stats(tmp.view(-1, N), 0, N, bn.running_mean, bn.running_var, momentum)
+        bn.num_batches_tracked += 1
+        return ops.gemm(x, weight, out, pad=pad, Tout=Tout, coff=coff, bias=bias, act_pre=pre,
+                        bn=(mean, var, bn.weight, bn.bias), bn_eps=eps, act_post=post, pool_prev=pool_prev)
+    y = ops.gemm(x, weight, out, pad=pad, Tout=Tout, coff=coff, bias=bias, act_pre=pre, pool_prev=pool_prev)
+    y2 = y.view(-1, y.shape[-1])
+    mean, var = ops.bn_stats(y2, coff, N, bn.running_mean, bn.running_var, momentum)
+    bn.num_batches_tracked += 1
+    ops.bn_apply(y2, coff, N, mean, var, bn.weight, bn.bias, eps, post)
+    return y
+
+
+# ----------------------------------------------------------------------------- encoder
+class Encoder(nn.Module):
+    """Tacotron2 text encoder: n x [Conv1d k5 + BN + ReLU + Dropout] -> BiLSTM, lengths ignored.
+    ref: src/module.py:410-462"""
+
+    def __init__(self, in_dim, enc_embed_dim, enc_n_conv, enc_rnn_layer, enc_kernel_size, enc_dropout=0.5):
+        super().__init__()
+        in_size = [in_dim] + [enc_embed_dim] * (enc_n_conv - 1)
+        self.enc_embed_dim = enc_embed_dim
+        self.enc_dropout = enc_dropout
+        self.convs = nn.ModuleList([
+            nn.Sequential(Conv1d(din, enc_embed_dim, kernel_size=enc_kernel_size, stride=1,
+                                 padding=(enc_kernel_size - 1) // 2, dilation=1, w_init_gain='relu'),
+                          nn.BatchNorm1d(enc_embed_dim), nn.ReLU(), nn.Dropout(enc_dropout))
+            for din in in_size])
+        assert enc_rnn_layer == 1, 'the HIP encoder implements the 1-layer BiLSTM of the shipped configs'
+        self.lstm = nn.LSTM(input_size=enc_embed_dim, hidden_size=enc_embed_dim // 2, num_layers=enc_rnn_layer,
+                            batch_first=True, bidirectional=True)
+
+    def forward(self, txt_embed, input_lengths=None):
+        x = txt_embed.contiguous()
+        for blk in self.convs:
+            conv, bn = blk[0], blk[1]
+            x = _conv_bn_act(x, conv.conv.weight, conv.conv.bias, bn, conv.padding, bn.eps, bn.momentum,
+                             'bn_relu', self.training)
+            if self.training and self.enc_dropout > 0:
+                raise NotImplementedError('enc_dropout > 0 in training (all shipped configs use 0.0)')
+        B, L, _ = x.shape
+        H = self.lstm.hidden_size
+        out = torch.empty(B, L, 2 * H, device=x.device, dtype=torch.float32)
+        ws = torch.empty(3 * B * H, device=x.device, dtype=torch.float32)
+        for rev, sfx in ((False, '_l0'), (True, '_l0_reverse')):
+            w_ih, w_hh = getattr(self.lstm, 'weight_ih' + sfx), getattr(self.lstm, 'weight_hh' + sfx)
+            b_ih, b_hh = getattr(self.lstm, 'bias_ih' + sfx), getattr(self.lstm, 'bias_hh' + sfx)
+            xproj = ops.gemm(x, w_ih, bias=b_ih)                      # (B, L, 4H), all time steps at once
+            ops.lstm_seq(xproj, w_hh, b_hh, out, H if rev else 0, rev, ws)
+        return out
+
+
+# ----------------------------------------------------------------------------- decoder pieces
+class Prenet(nn.Module):
+    """2 x [Linear(no bias) -> ReLU -> dropout(always on)].  ref: src/module.py:320-340"""
+
+    def __init__(self, in_dim, hidden_dim=(256, 256), apply_dropout=0.5, norm_type=None):
+        super().__init__()
+        hidden_dim = list(hidden_dim)
+        dims = [in_dim] + hidden_dim[:-1]
+        self.layers = nn.ModuleList([Linear(din, dout, bias=False, norm_type=norm_type)
+                                     for din, dout in zip(dims, hidden_dim)])
+        self.apply_dropout = apply_dropout
+
+    def forward(self, x, masks=None):
+        """masks: optional list of scaled masks, one per layer (drawn on device when None)"""
+        for i, layer in enumerate(self.layers):
+            if masks is not None:
+                m = masks[i]
+            elif self.apply_dropout > 0:
+                m = _scaled_mask(x.shape[:-1] + (layer.linear.out_features,), self.apply_dropout, x.device)
+            else:
+                m = None
+            x = layer(x, act='relu', mask=m)
+        return x
+
+
+class Attention(nn.Module):
+    """Location-sensitive attention parameters.  ref: src/module.py:343-407.
+    The per-step computation is the fused kernel st_attn_step_fwd (see Decoder)."""
+
+    def __init__(self, query_dim, memory_dim, hidden_dim, n_location_filters, location_kernel_size,
+                 loc_aware, use_summed_weights):
+        super().__init__()
+        self.query_layer = Linear(query_dim, hidden_dim, bias=False, w_init_gain='tanh')
+        self.memory_layer = Linear(memory_dim, hidden_dim, bias=False, w_init_gain='tanh')
+        self.v = Linear(hidden_dim, 1, bias=False)
+        self.loc_aware = loc_aware
+        self.use_summed_weights = use_summed_weights
+        if not (loc_aware and use_summed_weights):
+            raise NotImplementedError('the HIP attention implements loc_aware=True, use_summed_weights=True '
+                                      '(every shipped config)')
+        self.loc_conv = Conv1d(in_channels=2, out_channels=n_location_filters, kernel_size=location_kernel_size,
+                               bias=False, stride=1, dilation=1)
+        self.loc_linear = Linear(n_location_filters, hidden_dim, bias=False, w_init_gain='tanh')
+
+    def process_memory(self, memory):
+        return ops.gemm(memory, self.memory_layer.linear.weight)
+
+    def forward(self, query, memory, processed_memory, attn_history, mask=None):
+        """Single step with the reference's signature: attn_history (B,2,L) = stack[prev, cum]."""
+        assert mask is None, 'the reference never passes a mask (module.py:163)'
+        B, L, E = memory.shape
+        pq = ops.linear_small(query, self.query_layer.linear.weight)
+        hist = attn_history.contiguous()
+        w_prev, w_cum = hist[:, 0].contiguous(), hist[:, 1].contiguous()
+        w = torch.empty(B, L, device=memory.device, dtype=torch.float32)
+        w_cum_new = torch.empty_like(w)
+        ctx = torch.empty(B, E, device=memory.device, dtype=torch.float32)
+        ops.attn_step(pq, processed_memory, memory, w_prev, w_cum, w, w_cum_new, self.loc_conv.conv.weight,
+                      self.loc_linear.linear.weight, self.v.linear.weight, ctx)
+        return ctx, w
+
+
+def plan_decode(teacher_is_int, teacher_frames, teacher_bs, B, r, tf_rate, drop_dec_in, unpair_max_frame,
+                coin=None):
+    """Host-side step-count and next-input policy of Decoder.forward (src/module.py:156-206).
+
+    Returns (steps, step_src) with step_src[t] = source of the decoder input of step t+1:
+    -1 prenet(own output), -2 teacher mean, k >= 0 teacher frame k (rows >= teacher_bs always
+    feed back their own output).  `coin` is drawn exactly as the reference draws np.random.rand
+    (one or two draws per step, including after the last step)."""
+    coin = coin or np.random.rand          # looked up at call time, like the reference does
+    inference = tf_rate == 0.0
+    partial = (not teacher_is_int) and B != teacher_bs
+    if inference:
+        steps = teacher_frames // r if teacher_is_int else teacher_frames       # :168 (un-divided quirk)
+        t_groups = None
+    else:
+        assert not teacher_is_int, 'teacher forcing needs a teacher tensor'
+        t_groups = teacher_frames // r
+        if partial:
+            assert unpair_max_frame is not None
+            steps = max(t_groups, unpair_max_frame // r)                          # :172-173
+        else:
+            steps = t_groups                                                      # :177
+    src = []
+    for t in range(steps):
+        if inference or (coin() > tf_rate):                                       # :190
+            src.append(-1)
+        elif coin() < drop_dec_in:                                                # :193
+            src.append(-2)
+        else:
+            src.append(min(t, t_groups - 1))                                      # :201
+    return steps, src
+
+
+class Decoder(nn.Module):
+    """Tacotron2 decoder: prenet, query LSTM, location-sensitive attention, AdaIN speaker
+    adaptation, decoder LSTM, r-frame projection + stop gate.  ref: src/module.py:85-317"""
+
+    def __init__(self, n_mels, n_frames_per_step, enc_embed_dim, spkr_embed_dim, prenet_dim, prenet_dropout,
+                 query_rnn_dim, dec_rnn_dim, query_dropout, dec_dropout, attn_dim, n_location_filters,
+                 location_kernel_size, loc_aware, use_summed_weights, drop_dec_in, prenet_norm_type=None,
+                 pretrain=False, spkr_embed_mode='adaIN'):
+        super().__init__()
+        self.n_mels = n_mels
+        self.n_frames_per_step = n_frames_per_step
+        self.enc_embed_dim = enc_embed_dim
+        self.spkr_embed_dim = spkr_embed_dim
+        self.query_rnn_dim = query_rnn_dim
+        self.dec_rnn_dim = dec_rnn_dim
+        self.prenet_dropout = prenet_dropout
+        self.prenet_dim = prenet_dim
+        self.query_dropout = nn.Dropout(query_dropout)
+        self.dec_dropout = nn.Dropout(dec_dropout)
+        self.attn_dim = attn_dim
+        self.n_location_filters = n_location_filters
+        self.location_kernel_size = location_kernel_size
+        self.pretrain = pretrain
+        self.loc_aware = loc_aware
+        self.use_summed_weights = use_summed_weights
+        self.drop_dec_in = drop_dec_in
+        self.prenet_norm_type = prenet_norm_type
+        self.spkr_embed_mode = spkr_embed_mode.lower()
+        if self.spkr_embed_mode != 'adain' or pretrain:
+            raise NotImplementedError("the HIP decoder implements spkr_embed_mode='adaIN', pretrain=False "
+                                      "(the default every shipped config uses)")
+        self.pseudo_latent_mean = nn.Linear(spkr_embed_dim, query_rnn_dim)
+        self.pseudo_latent_std = nn.Sequential(nn.Linear(spkr_embed_dim, query_rnn_dim), nn.ReLU())
+        self.prenet = Prenet(n_mels * n_frames_per_step, [prenet_dim, prenet_dim], apply_dropout=prenet_dropout,
+                             norm_type=prenet_norm_type)
+        self.query_rnn = nn.LSTMCell(prenet_dim + enc_embed_dim, query_rnn_dim)
+        self.attn = Attention(query_rnn_dim, enc_embed_dim, attn_dim, n_location_filters, location_kernel_size,
+                              loc_aware, use_summed_weights)
+        self.dec_rnn = nn.LSTMCell(query_rnn_dim + enc_embed_dim, dec_rnn_dim)
+        self.proj = Linear(dec_rnn_dim + enc_embed_dim, n_mels * n_frames_per_step)
+        self.gate_layer = Linear(dec_rnn_dim + enc_embed_dim, 1, bias=True, w_init_gain='sigmoid')
+        self.last_tapes = None     # tapes of the most recent forward (saved tensors of the backward pass)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _weights_struct(self, keep):
+        w = StDecoderWeights()
+        pg_w = torch.cat([self.proj.linear.weight, self.gate_layer.linear.weight], dim=0).contiguous()
+        pg_b = torch.cat([self.proj.linear.bias, self.gate_layer.linear.bias], dim=0).contiguous()
+        keep += [pg_w, pg_b]
+        tensors = dict(
+            prenet_w0=self.prenet.layers[0].linear.weight, prenet_w1=self.prenet.layers[1].linear.weight,
+            q_w_ih=self.query_rnn.weight_ih, q_w_hh=self.query_rnn.weight_hh,
+            q_b_ih=self.query_rnn.bias_ih, q_b_hh=self.query_rnn.bias_hh,
+            attn_query_w=self.attn.query_layer.linear.weight, attn_v=self.attn.v.linear.weight,
+            attn_loc_conv_w=self.attn.loc_conv.conv.weight, attn_loc_lin_w=self.attn.loc_linear.linear.weight,
+            d_w_ih=self.dec_rnn.weight_ih, d_w_hh=self.dec_rnn.weight_hh,
+            d_b_ih=self.dec_rnn.bias_ih, d_b_hh=self.dec_rnn.bias_hh, projgate_w=pg_w, projgate_b=pg_b)
+        for k, t in tensors.items():
+            setattr(w, k, ops._p(t))
+        return w
+
+    def forward(self, memory, memory_lengths, teacher, spkr_embed, tf_rate=0.0, unpair_max_frame=None, _masks=None):
+        """Same contract as the reference (src/module.py:140-214):
+        memory (B,L,E); teacher int (max frames, inference) or (Bt,T,n_mels); spkr_embed (B,S).
+        Returns mel (B, steps*r, n_mels), alignments (B, steps, L), stops (B, steps*r).
+        `_masks` (tests only): dict with explicit scaled dropout masks 'teacher' [m1, m2],
+        'own' (steps,2,B,P), 'q' (steps,B,Q), 'd' (steps,B,D)."""
+        assert len(self.prenet.layers) == 2
+        dev = memory.device
+        memory = memory.contiguous()
+        spkr_embed = spkr_embed.contiguous()
+        B, L, E = memory.shape
+        r, n_mels, P = self.n_frames_per_step, self.n_mels, self.prenet_dim
+        Q, D, A = self.query_rnn_dim, self.dec_rnn_dim, self.attn_dim
+        _masks = _masks or {}
+        is_int = isinstance(teacher, int)
+        Bt = B if is_int else teacher.shape[0]
+        steps, step_src = plan_decode(is_int, teacher if is_int else teacher.shape[1], Bt, B, r, tf_rate,
+                                      self.drop_dec_in, unpair_max_frame)
+        keep = []
+        f32 = dict(device=dev, dtype=torch.float32)
+        # once per utterance: processed memory, AdaIN statistics (hoisted out of the loop)
+        pm = self.attn.process_memory(memory)
+        ada_std = ops.linear_small(spkr_embed, self.pseudo_latent_std[0].weight, self.pseudo_latent_std[0].bias, 'relu')
+        ada_mean = ops.linear_small(spkr_embed, self.pseudo_latent_mean.weight, self.pseudo_latent_mean.bias)
+        teacher_pre = teacher_mean = None
+        Tt = 0
+        if tf_rate != 0.0:
+            tch = teacher.contiguous().view(Bt, -1, n_mels * r)                                   # :178
+            Tt = tch.shape[1]
+            teacher_pre = self.prenet(tch, _masks.get('teacher'))                                 # :179
+            if any(s == -2 for s in step_src):
+                teacher_mean = ops.mean_rows(teacher_pre)
+        uses_own = any(s == -1 for s in step_src[:-1]) or Bt < B
+        own_mask = _masks.get('own')
+        if own_mask is None and uses_own and self.prenet_dropout > 0:
+            own_mask = _scaled_mask((steps, 2, B, P), self.prenet_dropout, dev)
+        q_mask, d_mask = _masks.get('q'), _masks.get('d')
+        if self.training:
+            if q_mask is None and self.query_dropout.p > 0:
+                q_mask = _scaled_mask((steps, B, Q), self.query_dropout.p, dev)
+            if d_mask is None and self.dec_dropout.p > 0:
+                d_mask = _scaled_mask((steps, B, D), self.dec_dropout.p, dev)
+
+        mel = torch.empty(B, steps * r, n_mels, **f32)
+        align = torch.empty(B, steps, L, **f32)
+        stop = torch.empty(B, steps * r, **f32)
+        tapes = dict(
+            hq=torch.empty(steps + 1, B, Q, **f32), cq=torch.empty(steps + 1, B, Q, **f32),
+            hd=torch.empty(steps + 1, B, D, **f32), cd=torch.empty(steps + 1, B, D, **f32),
+            ctx=torch.empty(steps + 1, B, E, **f32), wcum=torch.empty(steps + 1, B, L, **f32),
+            hadapt=torch.empty(steps, B, Q, **f32), decin=torch.empty(steps + 1, B, P, **f32),
+            pq=torch.empty(B, A, **f32), pre1=torch.empty(B, P, **f32), zero=torch.empty(B, L, **f32))
+        if self.training and torch.is_grad_enabled():
+            tapes['gates_q'] = torch.empty(steps, B, 4, Q, **f32)
+            tapes['gates_d'] = torch.empty(steps, B, 4, D, **f32)
+
+        w = self._weights_struct(keep)
+        dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A,
+                             F=self.n_location_filters, K=self.location_kernel_size)
+        io = StDecoderIO()
+        src_arr = (C.c_int * max(steps, 1))(*step_src)
+        io.memory, io.pm, io.ada_std, io.ada_mean = ops._p(memory), ops._p(pm), ops._p(ada_std), ops._p(ada_mean)
+        io.step_src = C.cast(src_arr, C.POINTER(C.c_int))
+        io.teacher_pre, io.teacher_mean = ops._p(teacher_pre), ops._p(teacher_mean)
+        io.Bt, io.Tt = Bt, Tt
+        io.prenet_mask, io.q_mask, io.d_mask = ops._p(own_mask), ops._p(q_mask), ops._p(d_mask)
+        io.steps = steps
+        io.mel_out, io.align_out, io.stop_out = ops._p(mel), ops._p(align), ops._p(stop)
+        io.hq_tape, io.cq_tape, io.hd_tape, io.cd_tape = (ops._p(tapes[k]) for k in ('hq', 'cq', 'hd', 'cd'))
+        io.ctx_tape, io.wcum_tape, io.hadapt_tape = ops._p(tapes['ctx']), ops._p(tapes['wcum']), ops._p(tapes['hadapt'])
+        io.decin_tape, io.pq_buf, io.pre1_buf, io.zero_row = (ops._p(tapes[k]) for k in ('decin', 'pq', 'pre1', 'zero'))
+        io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
+        check(_lib.load().st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
+              'st_decoder_forward')
+        tapes.update(pm=pm, ada_std=ada_std, ada_mean=ada_mean, teacher_pre=teacher_pre, masks=(own_mask, q_mask, d_mask),
+                     keep=keep, step_src=step_src)
+        self.last_tapes = tapes
+        return mel, align, stop
+
+
+# ----------------------------------------------------------------------------- CBHG
+class BatchNormConv1d(nn.Module):
+    """conv1d(no bias) -> activation -> BatchNorm1d(momentum .99, eps 1e-3).  ref: src/module.py:527-538"""
+
+    def __init__(self, in_size, out_size, kernel_size, stride, padding, activation=None):
+        super().__init__()
+        assert stride == 1
+        self.conv1d = nn.Conv1d(in_size, out_size, kernel_size=kernel_size, stride=stride, padding=padding, bias=False)
+        self.bn = nn.BatchNorm1d(out_size, momentum=0.99, eps=1e-3)
+        self.activation = activation
+        self.padding = padding
+
+    def forward(self, x_cl, training=None, Tout=None, out=None, coff=0, pool_prev=False, stats_Tout=None):
+        order = 'relu_bn' if self.activation is not None else 'bn'
+        return _conv_bn_act(x_cl, self.conv1d.weight, None, self.bn, self.padding, self.bn.eps, self.bn.momentum,
+                            order, self.training if training is None else training, Tout, out, coff, pool_prev,
+                            stats_Tout)
+
+
+class Highway(nn.Module):
+    """y = relu(H x) * sigmoid(T x) + x * (1 - sigmoid(T x)).  ref: src/module.py:541-555"""
+
+    def __init__(self, in_size, out_size):
+        super().__init__()
+        self.H = nn.Linear(in_size, out_size)
+        self.H.bias.data.zero_()
+        self.T = nn.Linear(in_size, out_size)
+        self.T.bias.data.fill_(-1)
+
+    def forward(self, x):
+        h = ops.gemm(x, self.H.weight, bias=self.H.bias, act_pre='relu')
+        return ops.gemm(x, self.T.weight, bias=self.T.bias, act_pre='sigmoid', highway_h=h, res=x)
+
+
+class CBHG(nn.Module):
+    """conv bank (k = 1..K) -> max-pool -> conv projections -> highways -> BiGRU.
+    ref: src/module.py:558-622"""
+
+    def __init__(self, in_dim, K=16, hidden_sizes=(128, 128)):
+        super().__init__()
+        hidden_sizes = list(hidden_sizes)
+        self.in_dim = in_dim
+        relu = nn.ReLU()
+        self.conv1d_banks = nn.ModuleList([BatchNormConv1d(in_dim, in_dim, kernel_size=k, stride=1, padding=k // 2,
+                                                           activation=relu) for k in range(1, K + 1)])
+        in_sizes = [K * in_dim] + hidden_sizes[:-1]
+        acts = [relu] * (len(hidden_sizes) - 1) + [None]
+        self.conv1d_projs = nn.ModuleList([BatchNormConv1d(i, o, kernel_size=3, stride=1, padding=1, activation=a)
+                                           for i, o, a in zip(in_sizes, hidden_sizes, acts)])
+        self.pre_highway_proj = nn.Linear(hidden_sizes[-1], in_dim, bias=False)
+        self.highways = nn.ModuleList([Highway(in_dim, in_dim) for _ in range(4)])
+        self.gru = nn.GRU(in_dim, in_dim, num_layers=1, batch_first=True, bidirectional=True)
+
+    def forward(self, inputs, input_lengths=None):
+        assert input_lengths is None, 'the reference never passes lengths to the postnet CBHG'
+        x = inputs.contiguous()
+        B, T, Cn = x.shape
+        assert Cn == self.in_dim
+        K = len(self.conv1d_banks)
+        bank = torch.empty(B, T, K * Cn, device=x.device, dtype=torch.float32)
+        for i, blk in enumerate(self.conv1d_banks):
+            k = i + 1
+            # even k yields T+1 positions and, in training mode, BatchNorm sees all of them before
+            # the trim to T (module.py:597-598): stats_Tout tells the helper to include the extra one
+            blk(x, Tout=T, out=bank, coff=i * Cn, stats_Tout=T + 1 if k % 2 == 0 else T)
+        y = self.conv1d_projs[0](bank, pool_prev=True)       # MaxPool1d(2,1,1)[:T] fused into the load
+        for blk in self.conv1d_projs[1:]:
+            y = blk(y)
+        y = ops.gemm(y, self.pre_highway_proj.weight, res=x)                                  # :607-609
+        for hw in self.highways:
+            y = hw(y)
+        H = self.gru.hidden_size
+        gi_f = ops.gemm(y, self.gru.weight_ih_l0, bias=self.gru.bias_ih_l0)
+        gi_b = ops.gemm(y, self.gru.weight_ih_l0_reverse, bias=self.gru.bias_ih_l0_reverse)
+        out = torch.empty(B, T, 2 * H, device=x.device, dtype=torch.float32)
+        ops.gru_seq(gi_f, gi_b, self.gru.weight_hh_l0, self.gru.weight_hh_l0_reverse,
+                    self.gru.bias_hh_l0, self.gru.bias_hh_l0_reverse, out)
+        return out
+
+
+class Postnet(nn.Module):
+    """The Tacotron-2 5-conv postnet class: defined and imported by the reference but never
+    constructed by any config.  ref: src/module.py:53-82"""
+
+    def __init__(self, n_mels, postnet_embed_dim, postnet_kernel_size, postnet_n_conv, postnet_dropout):
+        super().__init__()
+        in_size = [n_mels] + [postnet_embed_dim] * (postnet_n_conv - 1)
+        out_size = [postnet_embed_dim] * (postnet_n_conv - 1) + [n_mels]
+        act_fn = ['tanh'] * (postnet_n_conv - 1) + ['linear']
+        self.postnet_dropout = postnet_dropout
+        self.convs = nn.ModuleList([
+            nn.Sequential(Conv1d(din, dout, kernel_size=postnet_kernel_size, stride=1,
+                                 padding=(postnet_kernel_size - 1) // 2, dilation=1, w_init_gain=fn),
+                          nn.BatchNorm1d(dout), nn.Tanh() if fn == 'tanh' else nn.Identity(), nn.Dropout(postnet_dropout))
+            for din, dout, fn in zip(in_size, out_size, act_fn)])
+
+    def forward(self, x):
+        x = x.contiguous()
+        for blk in self.convs:
+            conv, bn = blk[0], blk[1]
+            order = 'bn_tanh' if isinstance(blk[2], nn.Tanh) else 'bn'
+            x = _conv_bn_act(x, conv.conv.weight, conv.conv.bias, bn, conv.padding, bn.eps, bn.momentum, order,
+                             self.training)
+            if self.training and self.postnet_dropout > 0:
+                raise NotImplementedError('Postnet dropout in training mode')
+        return x

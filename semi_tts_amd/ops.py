@@ -1,0 +1,291 @@
+"""Thin torch-tensor front end over the C ABI (include/semitts.h).
+
+PyTorch is used only for device memory and stream handles: every function here takes
+contiguous fp32 (or int64 index) CUDA/HIP tensors, passes raw device pointers to
+libsemitts_hip.so and returns.  There is no eager/CPU fallback -- a CPU tensor raises.
+"""
+import ctypes as C
+from contextlib import contextmanager
+
+import torch
+
+from . import _lib
+from ._lib import StSeg, StGemmEpilogue, check
+
+ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
+
+_stream_override = None
+
+
+def stream_handle():
+    """hipStream_t (as int) all st_* calls are issued on: torch's current stream unless overridden."""
+    if _stream_override is not None:
+        return _stream_override
+    return torch.cuda.current_stream().cuda_stream
+
+
+@contextmanager
+def use_stream(handle):
+    global _stream_override
+    prev, _stream_override = _stream_override, handle
+    try:
+        yield
+    finally:
+        _stream_override = prev
+
+
+def _p(t, dtype=torch.float32):
+    """device pointer of a tensor (None -> NULL) after checking it is usable by the kernels"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('semi_tts_amd: the HIP path needs device tensors (got a CPU tensor); there is no CPU fallback')
+    if t.dtype != dtype:
+        raise RuntimeError('semi_tts_amd: expected %s, got %s' % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _seg(x, w, k=None, ldx=None, ldw=None):
+    s = StSeg()
+    s.x, s.w = _p(x), _p(w)
+    s.k = int(k if k is not None else w.shape[-1])
+    s.ldx = int(ldx if ldx is not None else x.stride(-2) if x.dim() > 1 else s.k)
+    s.ldw = int(ldw if ldw is not None else w.stride(-2) if w.dim() > 1 else s.k)
+    return s
+
+
+def _segs(pairs):
+    arr = (StSeg * len(pairs))()
+    for i, s in enumerate(pairs):
+        arr[i] = s
+    return arr
+
+
+# ---------------------------------------------------------------------------------------------
+def lstm_cell(segs, b_ih, b_hh, c_prev, h_out, c_out, mask=None, pre=None, ldpre=0, gates_out=None,
+              ldh=None, ldc=None, ldc_prev=None):
+    """segs: list of StSeg (see seg()).  h_out/c_out (B,H) views; writes in place."""
+    lib = _lib.load()
+    B, H = h_out.shape[0], h_out.shape[-1]
+    arr = _segs(segs)
+    check(lib.st_lstm_cell_fwd(arr, len(segs), _p(b_ih), _p(b_hh), _p(pre), int(ldpre),
+                               _p(c_prev), int(ldc_prev if ldc_prev is not None else (c_prev.stride(0) if c_prev is not None else H)),
+                               _p(mask), _p(h_out), int(ldh if ldh is not None else h_out.stride(0)),
+                               _p(c_out), int(ldc if ldc is not None else c_out.stride(0)),
+                               _p(gates_out), B, H, stream_handle()), 'st_lstm_cell_fwd')
+
+
+seg = _seg
+
+
+def skinny_linear(segs, y, bias=None, act=None, mask=None, n_split=0, y2=None, rep=0, N=None):
+    lib = _lib.load()
+    B = y.shape[0]
+    N = int(N if N is not None else y.shape[-1])
+    arr = _segs(segs)
+    check(lib.st_skinny_linear_fwd(arr, len(segs), _p(bias), ACT[act], _p(mask), int(mask.stride(0)) if mask is not None else 0,
+                                   _p(y), int(y.stride(0)), int(n_split), _p(y2), int(y2.stride(0)) if y2 is not None else 0,
+                                   int(rep), B, N, stream_handle()), 'st_skinny_linear_fwd')
+    return y
+
+
+def linear_small(x, w, bias=None, act=None, mask=None, out=None):
+    """y = act(x W^T + b) * mask for a small number of rows (B <= a few dozen)."""
+    if out is None:
+        out = torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=torch.float32)
+    return skinny_linear([_seg(x, w)], out, bias, act, mask)
+
+
+def attn_step(pq, pm, memory, w_prev, w_cum_prev, w_out, w_cum_out, loc_conv_w, loc_lin_w, v, ctx,
+              h_q=None, ada_std=None, ada_mean=None, h_adapt=None):
+    lib = _lib.load()
+    B, L, E = memory.shape
+    A = pm.shape[-1]
+    F_, _, K = loc_conv_w.shape
+    Q = h_q.shape[-1] if h_q is not None else 0
+    check(lib.st_attn_step_fwd(_p(pq), _p(pm), _p(memory), _p(w_prev), int(w_prev.stride(0)), _p(w_cum_prev),
+                               _p(w_out), int(w_out.stride(0)), _p(w_cum_out), _p(loc_conv_w), _p(loc_lin_w), _p(v),
+                               _p(ctx), int(ctx.stride(0)), _p(h_q), int(h_q.stride(0)) if h_q is not None else 0,
+                               _p(ada_std), _p(ada_mean), _p(h_adapt), Q, B, L, A, E, F_, K, stream_handle()),
+          'st_attn_step_fwd')
+
+
+def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, coff=0, bias=None, act_pre=None,
+         bn=None, bn_eps=1e-5, act_post=None, res=None, highway_h=None, mask=None, pool_prev=False):
+    """C = epilogue(conv1d / linear).  a: (Bn, Tin, Cin) or (M, Cin) channels-last; w: torch Linear
+    (N, Cin) or Conv1d (N, Cin, KT) weight.  bn = (mean, var, weight, bias) tensors."""
+    lib = _lib.load()
+    if a.dim() == 3:
+        Bn_, Tin_, Cin = a.shape
+    else:
+        Bn_, Tin_, Cin = 1, a.shape[0], a.shape[1]
+    Bn = Bn or Bn_
+    Tin = Tin or Tin_
+    KT = w.shape[2] if w.dim() == 3 else 1
+    N = w.shape[0]
+    if Tout is None:
+        Tout = Tin + 2 * pad - KT + 1
+    lda = a.stride(-2)
+    if out is None:
+        shape = (Bn, Tout, N) if a.dim() == 3 else (Bn * Tout, N)
+        out = torch.empty(shape, device=a.device, dtype=torch.float32)
+    ldc = out.stride(-2)
+    ep = StGemmEpilogue()
+    ep.bias = _p(bias)
+    ep.act_pre = ACT[act_pre]
+    if bn is not None:
+        ep.bn_mean, ep.bn_var, ep.bn_w, ep.bn_b = _p(bn[0]), _p(bn[1]), _p(bn[2]), _p(bn[3])
+    ep.bn_eps = float(bn_eps)
+    ep.act_post = ACT[act_post]
+    ep.res = _p(res)
+    ep.ldres = int(res.stride(-2)) if res is not None else 0
+    ep.highway_h = _p(highway_h)
+    ep.ldhw = int(highway_h.stride(-2)) if highway_h is not None else 0
+    ep.mask = _p(mask)
+    ep.ldmask = int(mask.stride(-2)) if mask is not None else 0
+    check(lib.st_gemm_fwd(_p(a), int(lda), _p(w), _p(out), int(ldc), int(coff), int(Bn), int(Tin), int(Tout),
+                          int(Cin), int(N), int(KT), int(pad), 1 if pool_prev else 0, C.byref(ep), stream_handle()),
+          'st_gemm_fwd')
+    return out
+
+
+def bn_stats(x2d, coff, N, run_mean=None, run_var=None, momentum=0.1):
+    """per-column batch statistics of x2d[:, coff:coff+N] (+ running-stat update in place)"""
+    lib = _lib.load()
+    M = x2d.shape[0]
+    mean = torch.empty(N, device=x2d.device, dtype=torch.float32)
+    var = torch.empty(N, device=x2d.device, dtype=torch.float32)
+    check(lib.st_bn_stats(_p(x2d), int(x2d.stride(0)), int(coff), M, N, _p(mean), _p(var), _p(run_mean), _p(run_var),
+                          float(momentum), stream_handle()), 'st_bn_stats')
+    return mean, var
+
+
+def bn_apply(x2d, coff, N, mean, var, w, b, eps, act=None):
+    lib = _lib.load()
+    check(lib.st_bn_apply(_p(x2d), int(x2d.stride(0)), int(coff), x2d.shape[0], N, _p(mean), _p(var), _p(w), _p(b),
+                          float(eps), ACT[act], stream_handle()), 'st_bn_apply')
+
+
+def lstm_seq(xproj, w_hh, b_hh, out, ocol, reverse, ws=None):
+    lib = _lib.load()
+    B, T, H4 = xproj.shape
+    H = H4 // 4
+    if ws is None:
+        ws = torch.empty(3 * B * H, device=xproj.device, dtype=torch.float32)
+    check(lib.st_lstm_seq_fwd(_p(xproj), _p(w_hh), _p(b_hh), _p(out), int(out.stride(1)), int(ocol), _p(ws), B, T, H,
+                              1 if reverse else 0, stream_handle()), 'st_lstm_seq_fwd')
+
+
+def gru_seq(gi_f, gi_b, w_hh_f, w_hh_b, b_hh_f, b_hh_b, out):
+    lib = _lib.load()
+    B, T, H3 = gi_f.shape
+    ndir = 2 if gi_b is not None else 1
+    check(lib.st_gru_seq_fwd(_p(gi_f), _p(gi_b), _p(w_hh_f), _p(w_hh_b), _p(b_hh_f), _p(b_hh_b), _p(out),
+                             int(out.stride(1)), B, T, H3 // 3, ndir, stream_handle()), 'st_gru_seq_fwd')
+
+
+def vq_build_table(learnable, attr=None, attr_w=None, attr_b=None):
+    lib = _lib.load()
+    V, Dl = learnable.shape
+    Da = attr_w.shape[0] if attr_w is not None else 0
+    table = torch.empty(V, Dl + Da, device=learnable.device, dtype=torch.float32)
+    check(lib.st_vq_build_table(_p(learnable), Dl, _p(attr), attr.shape[1] if attr is not None else 0, _p(attr_w),
+                                _p(attr_b), Da, _p(table), V, stream_handle()), 'st_vq_build_table')
+    return table
+
+
+def gather_rows(table, idx):
+    lib = _lib.load()
+    V, D = table.shape
+    idx = idx.contiguous()
+    out = torch.empty(tuple(idx.shape) + (D,), device=table.device, dtype=torch.float32)
+    check(lib.st_gather_rows(_p(table), _p(idx, torch.int64), _p(out), idx.numel(), D, V, stream_handle()), 'st_gather_rows')
+    return out
+
+
+def vq_l2(x, table, temp):
+    lib = _lib.load()
+    lead, D = x.shape[:-1], x.shape[-1]
+    V = table.shape[0]
+    n = x.numel() // D
+    p = torch.empty(tuple(lead) + (V,), device=x.device, dtype=torch.float32)
+    idx = torch.empty(tuple(lead), device=x.device, dtype=torch.int64)
+    out = torch.empty_like(x)
+    check(lib.st_vq_l2_fwd(_p(x), _p(table), _p(temp), _p(p), _p(idx, torch.int64), _p(out), n, D, V, stream_handle()),
+          'st_vq_l2_fwd')
+    return p, idx, out
+
+
+def softmax_argmax(logits):
+    lib = _lib.load()
+    V = logits.shape[-1]
+    n = logits.numel() // V
+    p = torch.empty_like(logits)
+    idx = torch.empty(logits.shape[:-1], device=logits.device, dtype=torch.int64)
+    check(lib.st_softmax_argmax(_p(logits), _p(p), _p(idx, torch.int64), n, V, stream_handle()), 'st_softmax_argmax')
+    return p, idx
+
+
+def fill_(t, v):
+    check(_lib.load().st_fill(_p(t), float(v), t.numel(), stream_handle()), 'st_fill')
+    return t
+
+
+def copy2d(dst, src, rows, cols, ldd=None, lds=None):
+    check(_lib.load().st_copy2d(_p(dst), int(ldd if ldd is not None else dst.stride(0)), _p(src),
+                                int(lds if lds is not None else src.stride(0)), rows, cols, stream_handle()), 'st_copy2d')
+
+
+def mean_rows(src):
+    B, T, D = src.shape
+    dst = torch.empty(B, D, device=src.device, dtype=torch.float32)
+    check(_lib.load().st_mean_rows(_p(src), _p(dst), B, T, D, stream_handle()), 'st_mean_rows')
+    return dst
+
+
+# --------------------------------------------------------------------------------------------- graphs
+class Graph:
+    """Records every st_* call issued inside `with g.capture():` on a private HIP stream into a
+    hipGraph; `g.launch()` replays it on torch's current stream.  All tensors touched inside
+    the capture must be allocated beforehand and kept alive by the caller."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.exec = None
+        self._stream = C.c_void_p()
+        check(self.lib.st_stream_create(C.byref(self._stream)), 'st_stream_create')
+
+    @contextmanager
+    def capture(self):
+        torch.cuda.synchronize()
+        check(self.lib.st_graph_begin(self._stream), 'st_graph_begin')
+        ok = False
+        try:
+            with use_stream(self._stream.value):
+                yield
+            ok = True
+        finally:
+            ex = C.c_void_p()
+            rc = self.lib.st_graph_end(self._stream, C.byref(ex))
+            if ok:
+                check(rc, 'st_graph_end')
+                self.exec = ex
+
+    def launch(self):
+        check(self.lib.st_graph_launch(self.exec, stream_handle()), 'st_graph_launch')
+
+    def __del__(self):
+        try:
+            if self.exec is not None:
+                self.lib.st_graph_destroy(self.exec)
+            self.lib.st_stream_destroy(self._stream)
+        except Exception:
+            pass
+
+
+def device_info():
+    lib = _lib.load()
+    ncu, lds = C.c_int(), C.c_int()
+    name = C.create_string_buffer(128)
+    check(lib.st_device_info(C.byref(ncu), C.byref(lds), name, 128), 'st_device_info')
+    return {'n_cu': ncu.value, 'lds_bytes': lds.value, 'name': name.value.decode()}

@@ -1,0 +1,57 @@
+"""Deterministic synthetic weights and inputs (numpy RandomState, identical on every box).
+
+There is no network: checkpoints and corpora are unavailable, so benchmarks and the
+full-size parity fixture use random-init weights of the exact architecture.  The same
+generator feeds (a) the real reference in tools/gen_golden.py and (b) the HIP modules on
+the GPU box, so 125 MB of weights never have to be committed.
+"""
+import zlib
+
+import numpy as np
+
+
+def synthetic_state_dict(shapes, seed=1234):
+    """shapes: {state_dict key: shape}.  Returns {key: float32 ndarray} (int64 for
+    num_batches_tracked).  Each tensor has its own stream derived from (seed, key), so the
+    result does not depend on dict order.  Scales keep activations O(1): matrices ~
+    U(-a, a) with a = sqrt(3 / fan_in) * gain."""
+    out = {}
+    for key, shape in shapes.items():
+        shape = tuple(int(s) for s in shape)
+        rs = np.random.RandomState((seed * 1000003 + zlib.crc32(key.encode())) % (2 ** 31 - 1))
+        if key.endswith('num_batches_tracked'):
+            out[key] = np.zeros(shape, np.int64)
+        elif key.endswith('running_var'):
+            out[key] = rs.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif key.endswith('running_mean'):
+            out[key] = (rs.standard_normal(shape) * 0.1).astype(np.float32)
+        elif len(shape) == 1:
+            if key.endswith('.weight'):                       # BatchNorm scale
+                out[key] = rs.uniform(0.7, 1.3, shape).astype(np.float32)
+            else:                                             # biases
+                out[key] = (rs.standard_normal(shape) * 0.05).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            a = np.sqrt(3.0 / fan_in)
+            out[key] = rs.uniform(-a, a, shape).astype(np.float32)
+    return out
+
+
+def load_synthetic(module, seed=1234):
+    """fill a torch module's state_dict in place with synthetic_state_dict values"""
+    import torch
+    sd = module.state_dict()
+    syn = synthetic_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed)
+    with torch.no_grad():
+        for k, v in sd.items():
+            v.copy_(torch.from_numpy(syn[k]).to(v.device))
+    return module
+
+
+def synthetic_batch(B, L, T, in_dim=64, spkr_dim=128, n_mels=80, seed=5):
+    """inputs of Tacotron2.forward: txt_embed (B,L,in_dim), spkr_embed (B,spkr_dim), teacher (B,T,n_mels) in [0,1)"""
+    rs = np.random.RandomState(seed)
+    txt = (rs.standard_normal((B, L, in_dim)) * 0.5).astype(np.float32)
+    spk = (rs.standard_normal((B, spkr_dim)) * 0.5).astype(np.float32)
+    mel = rs.uniform(0, 1, (B, T, n_mels)).astype(np.float32)
+    return txt, spk, mel

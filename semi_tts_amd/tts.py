@@ -1,0 +1,53 @@
+"""Tacotron2 wrapper (encoder -> decoder -> CBHG mel->linear postnet) on the HIP path.
+Mirror of the reference's src/tts.py:9-51: same constructor, forward signature and
+state_dict keys (`encoder.*`, `decoder.*`, `postnet.0.*`, `postnet.1.*`)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .module import Encoder, Decoder, CBHG
+
+
+class _PostLinear(nn.Linear):
+    """nn.Linear(2*n_mels, linear_dim) of src/tts.py:34 executed by the HIP GEMM"""
+
+    def forward(self, x):
+        return ops.gemm(x, self.weight, bias=self.bias)
+
+
+class Tacotron2(nn.Module):
+    def __init__(self, n_mels, linear_dim, in_embed_dim, spkr_embed_dim, paras):
+        super().__init__()
+        self.n_mels = n_mels
+        self.linear_dim = linear_dim
+        self.separate_postnet = paras.get('separate_postnet', False)
+        self.encoder = Encoder(in_embed_dim, **paras['encoder'])
+        self.decoder = Decoder(n_mels, enc_embed_dim=self.encoder.enc_embed_dim, spkr_embed_dim=spkr_embed_dim,
+                               **paras['decoder'])
+        self.prenet_dim = self.decoder.prenet_dim
+        self.prenet_dropout = self.decoder.prenet_dropout
+        self.loc_aware = self.decoder.loc_aware
+        self.use_summed_weights = self.decoder.use_summed_weights
+        self.n_frames_per_step = self.decoder.n_frames_per_step
+        self.postnet = None
+        if linear_dim is not None:
+            # CBHG output size is 2 * input size                                    ref: src/tts.py:29-34
+            self.postnet = nn.Sequential(CBHG(n_mels, K=8), _PostLinear(n_mels * 2, linear_dim))
+
+    def forward(self, txt_embed, txt_lengths, teacher, spkr_embed, tf_rate=0.0, unpair_max_frame=None, _masks=None):
+        """txt_embed (B,L,in_embed_dim); teacher: int (max frames, inference) or (B',T,n_mels);
+        returns (mel_pred, linear_pred, alignment, stop)                          ref: src/tts.py:36-51"""
+        enc_output = self.encoder(txt_embed, txt_lengths)
+        mel_pred, alignment, stop = self.decoder(enc_output, txt_lengths, teacher, spkr_embed, tf_rate=tf_rate,
+                                                 unpair_max_frame=unpair_max_frame, _masks=_masks)
+        linear_pred = None
+        if self.postnet is not None:
+            # separate_postnet only cuts the gradient (mel_pred.detach()); forward values are identical
+            linear_pred = self.postnet(mel_pred.detach() if self.separate_postnet else mel_pred)
+        return mel_pred, linear_pred, alignment, stop
+
+    def create_msg(self):
+        return ['Model spec.| Model = `TACO-2`\t| Prenet dim = {}\t| Prenet dropout = {}\t'.format(
+                    self.prenet_dim, self.prenet_dropout),
+                '           | Loc. aware = {}\t| frames/step = {}\t| mel2linear = {}\t| sep_post = {}\t'.format(
+                    self.loc_aware, self.n_frames_per_step, self.postnet is not None, self.separate_postnet)]

@@ -41,17 +41,23 @@ def cpu_baseline(m, txt_mem, spk, passes=3):
     from oracle import tts_oracle as O
     from helpers import full_hp
     W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-    cores = os.cpu_count() or 1
+    # B=32 GEMMs stop scaling long before a 128-core host is full (the survey measured 8 threads);
+    # use min(cores, 16) threads and say so
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     hp = full_hp(0.5)
     mem, s = txt_mem.cpu(), spk.cpu()
     drop = O.DropoutSource('rng', generator=torch.Generator().manual_seed(0))
     times = []
+    budget = time.perf_counter() + 40.0          # bounded sample: stop after ~40 s whatever happens
     with torch.no_grad():
         for i in range(passes + 1):
             t0 = time.perf_counter()
             O.decoder_forward(W, mem, T, s, hp, tf_rate=0.0, training=False, drop=drop)
             times.append(time.perf_counter() - t0)
+            if time.perf_counter() > budget and len(times) >= 2:
+                break
+    passes = len(times) - 1
     t = float(np.median(times[1:]))
     return {'value': B * T / t, 'unit': 'mel-frames/s', 'cores': cores, 'kind': 'port',
             'sample': '%d full passes of Decoder.forward (B=%d, %d steps, L=%d) after 1 warm-up, median; '
@@ -88,29 +94,26 @@ def main():
     with torch.no_grad():
         memory = m.encoder(txt, None).contiguous()        # inputs of the timed region, resident in HBM
     dec = m.decoder
-    own_mask = torch.empty(STEPS, 2, B, dec.prenet_dim, device=dev)
-
-    def draw_masks():
-        own_mask.bernoulli_(0.5).mul_(2.0)               # fresh prenet dropout masks every pass
-
+    from semi_tts_amd.runtime import GraphedDecoder
+    gd = GraphedDecoder(dec, B, L, T, dev)
+    gd.memory.copy_(memory)
+    gd.spkr.copy_(spk)
     graph = None
-    with torch.no_grad():
-        draw_masks()
-        out = dec(memory, None, T, spk, _masks={'own': own_mask})
-        torch.cuda.synchronize()
-        if not args.no_graph:
-            graph = ops.Graph()
-            with graph.capture():
-                out = dec(memory, None, T, spk, _masks={'own': own_mask})
-    mel = out[0]
+    if not args.no_graph:
+        gd.capture()
+        graph = gd.graph
+    state = {}
 
     def one_pass():
-        draw_masks()
+        # fresh prenet dropout masks every pass (device RNG, inside the timed region), then the loop
         if graph is not None:
-            graph.launch()
+            state['out'] = gd(redraw=True)
         else:
-            with torch.no_grad():
-                dec(memory, None, T, spk, _masks={'own': own_mask})
+            gd.draw_masks()
+            state['out'] = gd._run()
+
+    one_pass()
+    mel = state['out'][0]
 
     def barrier():
         torch.cuda.synchronize()

@@ -94,6 +94,45 @@ int st_skinny_linear_fwd(const st_seg* segs, int nseg, const float* bias, int ac
                          int n_split, float* y2, int ldy2, int rep,
                          int B, int N, void* stream);
 
+/* ------------------------------------------------------------------ pre-packed operands (decode loop)
+ * A global load whose lanes touch 16 different cache lines per quarter-wave (the natural MFMA
+ * operand pattern over row-major data) sustains ~18 B/clk per CU on MI355X; 1 KiB-contiguous
+ * wave loads sustain ~90-140 B/clk (tools/mb).  The decode loop therefore keeps its operands
+ * in MFMA lane order in HBM:
+ *   P16 (weights):      [row tile of 16][k block of 16][lane 0..63][4 floats]
+ *   T16 (activations):  [batch tile of 16][k block of 16][lane 0..63][4 floats]
+ *   element (r, k) of a block lives at lane 16*((k>>2)&3) + (r&15), component k&3.
+ * Rows/columns beyond the logical shape are zero.  T16 destinations must be zero-filled by the
+ * caller once (kernels only write logical elements). */
+typedef struct st_pseg {
+    const float* x_t16; /* (B, k) activations in T16 layout */
+    int k;              /* logical k of this segment (padded to 16 inside the layout) */
+} st_pseg;
+
+size_t st_packed_weight_floats(const int* k, int nseg, int N, int lstm_H); /* size of a P16 buffer */
+size_t st_t16_floats(int B, int K);                                        /* size of a T16 buffer */
+/* Pack up to 3 K-segments w[s] (N, k[s]) (row stride ldw[s], torch [out][in]) into one P16 buffer
+ * whose K axis is the concatenation of the segments.  lstm_H > 0: N == 4*lstm_H and the 16 rows of
+ * tile t are the (i,f,g,o) rows of hidden units 4t..4t+3 (so the cell update is workgroup-local). */
+int st_pack_weight(const float* const* w, const int* ldw, const int* k, int nseg, int N, int lstm_H,
+                   float* packed, void* stream);
+int st_tile_rows(const float* src, int ld, float* dst_t16, int B, int K, void* stream);   /* natural -> T16 */
+int st_untile_rows(const float* src_t16, float* dst, int ld, int B, int K, void* stream); /* T16 -> natural */
+/* st_lstm_cell_fwd on packed operands; h goes out in T16; optionally also the AdaIN-adapted
+ * hidden state  hadapt = ada_std * (h_out - ada_mean)  (ada_* natural (B,H)).
+ * ref: as st_lstm_cell_fwd, AdaIN src/module.py:268-269 */
+int st_lstm_cell_packed_fwd(const float* packed_w, const st_pseg* segs, int nseg,
+                            const float* b_ih, const float* b_hh, const float* pre, int ldpre,
+                            const float* c_prev, int ldc_prev, const float* mask,
+                            float* h_out_t16, float* c_out, int ldc, float* gates_out,
+                            const float* ada_std, const float* ada_mean, float* hadapt_t16,
+                            int B, int H, void* stream);
+/* st_skinny_linear_fwd on packed operands; output natural (y) and/or T16 (y_t16) */
+int st_skinny_linear_packed_fwd(const float* packed_w, const st_pseg* segs, int nseg,
+                                const float* bias, int act, const float* mask, int ldmask,
+                                float* y, int ldy, float* y_t16, int n_split, float* y2, int ldy2, int rep,
+                                int B, int N, void* stream);
+
 /* ------------------------------------------------------------------ location-sensitive attention
  * One decode step for the whole batch, one workgroup per utterance.
  * ref: Attention.energy/.forward src/module.py:371-407 and the state update :262-264,
@@ -112,6 +151,14 @@ int st_attn_step_fwd(const float* pq, const float* pm, const float* memory,
                      const float* h_q, int ld_hq, const float* ada_std, const float* ada_mean,
                      float* h_adapt, int Q,
                      int B, int L, int A, int E, int F, int K, void* stream);
+/* same step with the context written in T16 (ctx_t16) and/or natural (ctx) layout; no AdaIN
+ * (the decode loop fuses it into the query LSTM epilogue) */
+int st_attn_step_t16_fwd(const float* pq, const float* pm, const float* memory,
+                         const float* w_prev, int ld_wprev, const float* w_cum_prev,
+                         float* w_out, int ld_wout, float* w_cum_out,
+                         const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                         float* ctx_t16, float* ctx, int ld_ctx,
+                         int B, int L, int A, int E, int F, int K, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
  * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) + tap - pad, ci) * W(n, ci, tap) )
@@ -229,18 +276,26 @@ typedef struct st_decoder_io {
     float* mel_out;           /* (B, steps*r, n_mels) */
     float* align_out;         /* (B, steps, L)        */
     float* stop_out;          /* (B, steps*r)         */
-    /* tapes, all (steps+1, B, dim) with slot 0 pre-zeroed by the callee */
+    /* packed weights: st_decoder_packed_floats() floats, filled by st_decoder_pack() */
+    const float* packed;
+    /* tapes.  hq/hd/ctx/decin/hadapt are T16-tiled, (steps+1) [hadapt: steps] slots of
+     * st_t16_floats(B, dim) floats each, handed in ZERO-FILLED; cq/cd/wcum are natural
+     * (steps+1, B, dim).  Slot 0 = initial zero state, slot t+1 = state after step t. */
     float* hq_tape; float* cq_tape; float* hd_tape; float* cd_tape;   /* Q,Q,D,D */
     float* ctx_tape; float* wcum_tape;                               /* E, L    */
-    float* hadapt_tape;       /* (steps, B, Q)  */
-    float* decin_tape;        /* (steps+1, B, P): slot t = dec_in of step t (slot 0 zeros) */
-    float* pq_buf;            /* (B, A) scratch */
-    float* pre1_buf;          /* (B, P) scratch (prenet layer-1 output) */
+    float* hadapt_tape;       /* steps slots, T16 (B,Q) */
+    float* decin_tape;        /* steps+1 slots, T16 (B,P): slot t = dec_in of step t (slot 0 zeros) */
+    float* pq_buf;            /* (B, A) scratch, natural */
+    float* pre1_t16;          /* T16 (B,P) scratch (prenet layer-1 output), zero-filled */
+    float* mel_t16;           /* T16 (B, r*n_mels) scratch (own output as the prenet input), zero-filled */
     float* zero_row;          /* (B, max(L,1)) zeros (w_prev of step 0) -- zeroed by the callee */
     float* gates_q_tape;      /* (steps, B, 4, Q) or NULL (training) */
     float* gates_d_tape;      /* (steps, B, 4, D) or NULL */
 } st_decoder_io;
 
+size_t st_decoder_packed_floats(const st_decoder_dims* d);
+/* pack the six matrices the loop streams every step (once per forward / per weight update) */
+int st_decoder_pack(const st_decoder_weights* w, const st_decoder_dims* d, float* packed, void* stream);
 int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io,
                        void* stream);
 

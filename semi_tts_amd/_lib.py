@@ -17,6 +17,10 @@ class StSeg(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('ldx', C.c_int), ('ldw', C.c_int), ('k', C.c_int)]
 
 
+class StPSeg(C.Structure):
+    _fields_ = [('x_t16', C.c_void_p), ('k', C.c_int)]
+
+
 class StGemmEpilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('act_pre', C.c_int),
                 ('bn_mean', C.c_void_p), ('bn_var', C.c_void_p), ('bn_w', C.c_void_p), ('bn_b', C.c_void_p),
@@ -44,9 +48,11 @@ class StDecoderIO(C.Structure):
                 ('prenet_mask', C.c_void_p), ('q_mask', C.c_void_p), ('d_mask', C.c_void_p),
                 ('steps', C.c_int),
                 ('mel_out', C.c_void_p), ('align_out', C.c_void_p), ('stop_out', C.c_void_p),
+                ('packed', C.c_void_p),
                 ('hq_tape', C.c_void_p), ('cq_tape', C.c_void_p), ('hd_tape', C.c_void_p), ('cd_tape', C.c_void_p),
                 ('ctx_tape', C.c_void_p), ('wcum_tape', C.c_void_p), ('hadapt_tape', C.c_void_p),
-                ('decin_tape', C.c_void_p), ('pq_buf', C.c_void_p), ('pre1_buf', C.c_void_p), ('zero_row', C.c_void_p),
+                ('decin_tape', C.c_void_p), ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
+                ('zero_row', C.c_void_p),
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p)]
 
 
@@ -80,12 +86,23 @@ SIGNATURES = {
     'st_gather_rows': [P, P, P, I, I, I, P],
     'st_vq_l2_fwd': [P, P, P, P, P, P, I, I, I, P],
     'st_softmax_argmax': [P, P, P, I, I, P],
+    'st_packed_weight_floats': [C.POINTER(I), I, I, I],
+    'st_t16_floats': [I, I],
+    'st_pack_weight': [C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, I, P, P],
+    'st_tile_rows': [P, I, P, I, I, P],
+    'st_untile_rows': [P, P, I, I, I, P],
+    'st_lstm_cell_packed_fwd': [P, C.POINTER(StPSeg), I, P, P, P, I, P, I, P, P, P, I, P, P, P, P, I, I, P],
+    'st_skinny_linear_packed_fwd': [P, C.POINTER(StPSeg), I, P, I, P, I, P, I, P, I, P, I, I, I, I, P],
+    'st_attn_step_t16_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
+    'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],
     'st_decoder_forward': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderIO), P],
     'st_fill': [P, F, Z, P],
     'st_copy2d': [P, I, P, I, I, I, P],
     'st_mean_rows': [P, P, I, I, I, P],
 }
-_RESTYPES = {'st_last_error': C.c_char_p}
+_RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
+             'st_decoder_packed_floats': C.c_size_t}
 
 _lib = None
 
@@ -95,6 +112,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64 (NEEDED as "libamdhip64.so"); ours is linked against
+    # "libamdhip64.so.7".  Importing torch first makes the loader resolve both to ONE HIP
+    # runtime -- loading ours first would put two runtimes in the process (hipErrorNoDevice).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             'libsemitts_hip.so not found at %s -- build it with `python -m semi_tts_amd.build` '

@@ -1,51 +1,62 @@
 // attention.hip -- fused location-sensitive attention step for gfx950 (MI355X).
 //
 // One workgroup (8 wavefronts) per utterance does the whole of Attention.forward for one
-// decode step (ref: src/module.py:371-407 + state update :262-264 + AdaIN :267-269):
-//   P0  stage loc_linear^T (F x A), loc_conv (F x 2 x K) and the zero-padded attention
-//       history (w_prev, w_cum) in LDS; issue the coalesced 16-byte loads of the encoder
-//       memory rows this thread will need for the context (they land while P1-P3 run)
-//   P1  location conv  cf[l][f]   (2 -> F channels, K taps)            -- LDS only
-//   P2  energies       e[l] = v . tanh(pq + W_l cf[l] + pm[l])         -- one wave per l,
-//       each lane owns 4 consecutive attention dims, processed-memory row read as one
-//       coalesced 1 KiB wave load, wave shuffle reduction over the attention dim
+// decode step (ref: src/module.py:371-407 + state update :262-264 [+ AdaIN :267-269]):
+//   P0  issue the coalesced 16-byte loads of the encoder-memory rows this thread needs for
+//       the context (they land while P1-P3 run); stage loc_linear (transposed to [f][a]),
+//       loc_conv and the zero-padded attention history in LDS
+//   P1  location conv  cf[f][l]  (2 -> F channels, K taps): one thread = one filter x 4
+//       consecutive positions (sliding register window, 4 independent accumulators)
+//   P2  energies  e[l] = v . tanh((pq + W_l cf[l]) + pm[l]): one wave = 8 consecutive
+//       positions, each lane owns 4 attention dims; per filter one ds_read_b128 of W_l^T and two
+//       broadcast ds_read_b128 of cf feed 32 FMAs; the processed-memory rows are 1 KiB
+//       coalesced wave loads issued before the filter loop; wave shuffle reduction over dims
 //   P3  softmax over L by wave 0 (shuffle max / sum), alignment + cumulative weights out
-//   P4  context = sum_l w[l] * memory[l][:]   (4 row-groups, LDS cross-group reduction)
-// HBM/L2 traffic per step and utterance: pm (L*A*4) + memory (L*E*4) bytes, read exactly once.
+//   P4  context = sum_l w[l] * memory[l][:]   (row groups, LDS cross-group reduction)
+// Everything between the loads and the stores stays in LDS/registers; per step and utterance
+// the kernel reads pm (L*A*4 B) + memory (L*E*4 B) exactly once.
 #include "st_common.h"
 
 namespace {
 
 constexpr int AT_THREADS = 512;
-constexpr int AT_PF = 12;  // encoder-memory rows prefetched into registers per thread
+constexpr int AT_WAVES = AT_THREADS / 64;
+constexpr int AT_PF = 12;   // encoder-memory rows prefetched into registers per thread
+constexpr int AT_LB = 8;    // positions per wave in the energy phase
+constexpr int AT_CB = 4;    // positions per thread in the conv phase
 
 struct AtArgs {
     const float* pq; const float* pm; const float* memory;
     const float* w_prev; int ld_wprev; const float* w_cum_prev;
     float* w_out; int ld_wout; float* w_cum_out;
     const float* loc_conv_w; const float* loc_lin_w; const float* v;
-    float* ctx; int ld_ctx;
+    float* ctx; int ld_ctx; float* ctx_t16;
     const float* h_q; int ld_hq; const float* ada_std; const float* ada_mean; float* h_adapt; int Q;
     int B, L, A, E, F, K;
 };
 
 struct AtLds {  // offsets in floats into dynamic LDS
-    int wt, wc, hs, cf, e, part, total;
+    int wt, wt_ld, wc, hs, hl, cf, cf_ld, e, part, total;
 };
 
 __host__ __device__ inline AtLds at_layout(int L, int A, int E, int F, int K) {
     AtLds o;
     int p = 0;
-    const int A4 = (A + 3) & ~3;
-    o.wt = p; p += F * A4;                 // loc_linear transposed: [f][a]
-    o.wc = p; p += ((F * 2 * K + 3) & ~3);  // loc_conv [f][c][k]
-    const int hl = L + K - 1;
-    o.hs = p; p += ((2 * hl + 3) & ~3);     // padded history [c][l + k]
-    o.cf = p; p += ((L * F + 3) & ~3);      // conv features [l][f]
-    o.e = p; p += ((L + 3) & ~3);           // energies, then softmax weights
-    o.part = p; p += 4 * AT_THREADS;        // context partials [group][E]
+    o.wt_ld = ((A + 3) & ~3) + 4;               // row stride of W_l^T: +4 spreads the transposing stores
+    o.wt = p; p += F * o.wt_ld;
+    o.wc = p; p += ((F * 2 * K + 3) & ~3);      // loc_conv [f][c][k]
+    o.hl = ((L + AT_CB + K - 1) + 3) & ~3;      // padded history length per channel
+    o.hs = p; p += 2 * o.hl;
+    o.cf_ld = ((L + AT_LB - 1) / AT_LB) * AT_LB; // conv features [f][l], l padded to the wave block
+    o.cf = p; p += F * o.cf_ld;
+    o.e = p; p += ((L + 3) & ~3);               // energies, then softmax weights
+    o.part = p; p += 4 * AT_THREADS;            // context partials [group][E]
     o.total = p;
     return o;
+}
+
+__device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
+    return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
 }
 
 __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
@@ -53,7 +64,6 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
-    const int A4 = (A + 3) & ~3;
     const AtLds o = at_layout(L, A, E, F, K);
     float* Wt = lds + o.wt;
     float* Wc = lds + o.wc;
@@ -62,9 +72,8 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
     float* es = lds + o.e;
     float* part = lds + o.part;
     const int pad = (K - 1) / 2;
-    const int hl = L + K - 1;
 
-    // ---- P0: context prefetch (memory rows l = g, g+ng, ...), then LDS staging
+    // ---- P0a: context prefetch (memory rows l = g, g+ng, ...)
     const int ne4 = E >> 2;                    // E % 4 == 0 checked on the host
     const int ng = AT_THREADS / ne4;           // row groups (>= 1 checked on the host)
     const int e4 = tid % ne4, g = tid / ne4;
@@ -77,13 +86,24 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
         mpf[j] = (ctx_active && l < L) ? st_ld4(memb + (size_t)l * E + e4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int idx = tid; idx < A * F; idx += AT_THREADS) {  // global [a][f] -> LDS [f][a]
-        const int aa = idx / F, f = idx - aa * F;
-        Wt[f * A4 + aa] = a.loc_lin_w[idx];
+    // ---- P0b: staging.  W_l (A,F) is read coalesced along f and stored transposed [f][a]
+    if ((F & 3) == 0 && st_aligned16(a.loc_lin_w)) {
+        const int f4n = F >> 2;
+        for (int idx = tid; idx < A * f4n; idx += AT_THREADS) {
+            const int aa = idx / f4n, f0 = (idx - aa * f4n) * 4;
+            const f32x4 w4 = st_ld4(a.loc_lin_w + (size_t)aa * F + f0);
+            Wt[(f0 + 0) * o.wt_ld + aa] = w4[0]; Wt[(f0 + 1) * o.wt_ld + aa] = w4[1];
+            Wt[(f0 + 2) * o.wt_ld + aa] = w4[2]; Wt[(f0 + 3) * o.wt_ld + aa] = w4[3];
+        }
+    } else {
+        for (int idx = tid; idx < A * F; idx += AT_THREADS) {
+            const int aa = idx / F, f = idx - aa * F;
+            Wt[f * o.wt_ld + aa] = a.loc_lin_w[idx];
+        }
     }
     for (int idx = tid; idx < F * 2 * K; idx += AT_THREADS) Wc[idx] = a.loc_conv_w[idx];
-    for (int idx = tid; idx < 2 * hl; idx += AT_THREADS) {
-        const int c = idx / hl, p = idx - c * hl;
+    for (int idx = tid; idx < 2 * o.hl; idx += AT_THREADS) {
+        const int c = idx / o.hl, p = idx - c * o.hl;
         const int l = p - pad;
         float v = 0.0f;
         if (l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
@@ -97,54 +117,82 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
     }
     __syncthreads();
 
-    // ---- P1: location conv, cf[l][f] = sum_c sum_k Wc[f][c][k] * hist[c][l + k - pad]
-    for (int idx = tid; idx < L * F; idx += AT_THREADS) {
-        const int l = idx / F, f = idx - l * F;
-        const float* w0 = Wc + f * 2 * K;
-        float acc = 0.0f;
-        for (int c = 0; c < 2; ++c) {
-            const float* h = hs + c * hl + l;
-            const float* w = w0 + c * K;
-            for (int k = 0; k < K; ++k) acc = fmaf(w[k], h[k], acc);
+    // ---- P1: location conv, cf[f][l] = sum_c sum_k Wc[f][c][k] * hist[c][l + k - pad]
+    {
+        const int nlb = (L + AT_CB - 1) / AT_CB;
+        for (int idx = tid; idx < F * nlb; idx += AT_THREADS) {
+            const int f = idx / nlb, l0 = (idx - f * nlb) * AT_CB;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+            for (int c = 0; c < 2; ++c) {
+                const float* h = hs + c * o.hl + l0;
+                const float* w = Wc + (f * 2 + c) * K;
+                float h0 = h[0], h1 = h[1], h2 = h[2];
+#pragma unroll 8
+                for (int k = 0; k < K; ++k) {
+                    const float h3 = h[k + 3];
+                    const float wk = w[k];
+                    acc0 = fmaf(wk, h0, acc0); acc1 = fmaf(wk, h1, acc1);
+                    acc2 = fmaf(wk, h2, acc2); acc3 = fmaf(wk, h3, acc3);
+                    h0 = h1; h1 = h2; h2 = h3;
+                }
+            }
+            float* dst = cf + f * o.cf_ld + l0;   // cf_ld is padded, stores beyond L are harmless
+            dst[0] = acc0;
+            if (l0 + 1 < o.cf_ld) dst[1] = acc1;
+            if (l0 + 2 < o.cf_ld) dst[2] = acc2;
+            if (l0 + 3 < o.cf_ld) dst[3] = acc3;
         }
-        cf[idx] = acc;
     }
     __syncthreads();
 
-    // ---- P2: energies, one wave per l, lane owns attention dims a0..a0+3 of each 256-chunk
+    // ---- P2: energies; a wave owns AT_LB consecutive positions, a lane 4 consecutive dims
     const float* pmb = a.pm + (size_t)b * L * A;
     const float* pqb = a.pq + (size_t)b * A;
-    for (int l = wave; l < L; l += AT_THREADS / 64) {
-        float esum = 0.0f;
+    const bool vecA = (A & 3) == 0;
+    for (int l0 = wave * AT_LB; l0 < L; l0 += AT_WAVES * AT_LB) {
+        float esum[AT_LB];
+#pragma unroll
+        for (int j = 0; j < AT_LB; ++j) esum[j] = 0.0f;
         for (int a0 = lane * 4; a0 < A; a0 += 256) {
             const int rem = A - a0;
-            f32x4 pm4, pq4, v4;
-            if (rem >= 4 && (A & 3) == 0) {
-                pm4 = st_ld4(pmb + (size_t)l * A + a0);
-                pq4 = st_ld4(pqb + a0);
-                v4 = st_ld4(a.v + a0);
-            } else {
-                pm4 = st_ld4_guard(pmb + (size_t)l * A + a0, rem);
-                pq4 = st_ld4_guard(pqb + a0, rem);
-                v4 = st_ld4_guard(a.v + a0, rem);
+            f32x4 pm4[AT_LB];
+#pragma unroll
+            for (int j = 0; j < AT_LB; ++j) {
+                const int l = l0 + j < L ? l0 + j : L - 1;
+                pm4[j] = (vecA && rem >= 4) ? st_ld4(pmb + (size_t)l * A + a0) : st_ld4_guard(pmb + (size_t)l * A + a0, rem);
             }
-            f32x4 loc = {0.f, 0.f, 0.f, 0.f};
-            const float* cfl = cf + l * F;
+            const f32x4 pq4 = (vecA && rem >= 4) ? st_ld4(pqb + a0) : st_ld4_guard(pqb + a0, rem);
+            const f32x4 v4 = (vecA && rem >= 4) ? st_ld4(a.v + a0) : st_ld4_guard(a.v + a0, rem);
+            f32x4 loc[AT_LB];
+#pragma unroll
+            for (int j = 0; j < AT_LB; ++j) loc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
             for (int f = 0; f < F; ++f) {
-                const float cv = cfl[f];
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wt + f * A4 + a0);
-                loc[0] = fmaf(w4[0], cv, loc[0]); loc[1] = fmaf(w4[1], cv, loc[1]);
-                loc[2] = fmaf(w4[2], cv, loc[2]); loc[3] = fmaf(w4[3], cv, loc[3]);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wt + f * o.wt_ld + a0);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf + f * o.cf_ld + l0);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + f * o.cf_ld + l0 + 4);
+#pragma unroll
+                for (int j = 0; j < AT_LB; ++j) {
+                    const float cv = j < 4 ? c0[j & 3] : c1[j & 3];
+                    loc[j][0] = fmaf(w4[0], cv, loc[j][0]); loc[j][1] = fmaf(w4[1], cv, loc[j][1]);
+                    loc[j][2] = fmaf(w4[2], cv, loc[j][2]); loc[j][3] = fmaf(w4[3], cv, loc[j][3]);
+                }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // (processed_query + processed_loc_feat) + processed_memory, module.py:389-390
-                const float t = tanhf((pq4[j] + loc[j]) + pm4[j]);
-                esum = fmaf(v4[j], j < rem ? t : 0.0f, esum);
+            for (int j = 0; j < AT_LB; ++j) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // (processed_query + processed_loc_feat) + processed_memory, module.py:389-390
+                    const float t = tanhf((pq4[c] + loc[j][c]) + pm4[j][c]);
+                    esum[j] = fmaf(v4[c], c < rem ? t : 0.0f, esum[j]);
+                }
             }
         }
-        esum = st_wave_sum(esum);
-        if (lane == 0) es[l] = esum;
+#pragma unroll
+        for (int j = 0; j < AT_LB; ++j) {
+            const float s = st_wave_sum(esum[j]);
+            if (lane == 0 && l0 + j < L) es[l0 + j] = s;
+        }
     }
     __syncthreads();
 
@@ -164,7 +212,7 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
             const float w = es[l] / s;
             es[l] = w;
             a.w_out[(size_t)b * a.ld_wout + l] = w;
-            a.w_cum_out[(size_t)b * L + l] = w + hs[hl + pad + l];   // weights + attn_weights_sum, :264
+            a.w_cum_out[(size_t)b * L + l] = w + hs[o.hl + pad + l];   // weights + attn_weights_sum, :264
         }
     }
     __syncthreads();
@@ -190,11 +238,36 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
         *reinterpret_cast<f32x4*>(part + (size_t)(g * ne4 + e4) * 4) = acc;
     }
     __syncthreads();
+    const int EKB = (E + 15) >> 4;
     for (int e = tid; e < E; e += AT_THREADS) {
         float s = 0.0f;
         for (int gg = 0; gg < ng; ++gg) s += part[gg * E + e];
-        a.ctx[(size_t)b * a.ld_ctx + e] = s;
+        if (a.ctx) a.ctx[(size_t)b * a.ld_ctx + e] = s;
+        if (a.ctx_t16) a.ctx_t16[at_t16_off(b, e, EKB)] = s;
     }
+}
+
+int at_launch(const AtArgs& a, hipStream_t stream) {
+    ST_CHECK_ARG(a.B > 0 && a.L > 0 && a.A > 0 && a.E > 0 && a.F > 0 && a.K > 0, "attention step: bad dims");
+    ST_CHECK_ARG(a.K % 2 == 1, "attention step: location kernel size %d must be odd", a.K);
+    ST_CHECK_ARG(a.E % 4 == 0 && a.E / 4 <= AT_THREADS, "attention step: E=%d must be a multiple of 4 and <= %d", a.E, 4 * AT_THREADS);
+    ST_CHECK_ARG(st_aligned16(a.memory), "attention step: memory must be 16-byte aligned");
+    ST_CHECK_ARG((a.A % 4 != 0) || (st_aligned16(a.pm) && st_aligned16(a.pq) && st_aligned16(a.v)),
+                 "attention step: pm/pq/v must be 16-byte aligned");
+    ST_CHECK_ARG(a.ctx || a.ctx_t16, "attention step: no context output");
+    ST_CHECK_ARG(!a.h_q || (a.ada_std && a.ada_mean && a.h_adapt), "attention step: AdaIN pointers");
+    const AtLds o = at_layout(a.L, a.A, a.E, a.F, a.K);
+    const size_t lds_bytes = (size_t)o.total * sizeof(float);
+    ST_CHECK_ARG(lds_bytes <= 160 * 1024, "attention step: L=%d needs %zu B of LDS (> 160 KiB)", a.L, lds_bytes);
+    static bool configured = false;
+    if (!configured) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    hipLaunchKernelGGL(at_kernel, dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
+    ST_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -207,29 +280,30 @@ extern "C" int st_attn_step_fwd(const float* pq, const float* pm, const float* m
                                 const float* h_q, int ld_hq, const float* ada_std, const float* ada_mean,
                                 float* h_adapt, int Q,
                                 int B, int L, int A, int E, int F, int K, void* stream) {
-    ST_CHECK_ARG(B > 0 && L > 0 && A > 0 && E > 0 && F > 0 && K > 0, "st_attn_step_fwd: bad dims");
-    ST_CHECK_ARG(K % 2 == 1, "st_attn_step_fwd: location kernel size %d must be odd", K);
-    ST_CHECK_ARG(E % 4 == 0 && E / 4 <= AT_THREADS, "st_attn_step_fwd: E=%d must be a multiple of 4 and <= %d", E, 4 * AT_THREADS);
-    ST_CHECK_ARG(st_aligned16(memory), "st_attn_step_fwd: memory must be 16-byte aligned");
-    ST_CHECK_ARG((A % 4 != 0) || (st_aligned16(pm) && st_aligned16(pq) && st_aligned16(v)),
-                 "st_attn_step_fwd: pm/pq/v must be 16-byte aligned");
-    ST_CHECK_ARG(!h_q || (ada_std && ada_mean && h_adapt), "st_attn_step_fwd: AdaIN pointers");
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     AtArgs a;
+    memset(&a, 0, sizeof(a));
     a.pq = pq; a.pm = pm; a.memory = memory; a.w_prev = w_prev; a.ld_wprev = ld_wprev; a.w_cum_prev = w_cum_prev;
     a.w_out = w_out; a.ld_wout = ld_wout; a.w_cum_out = w_cum_out;
     a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx;
     a.h_q = h_q; a.ld_hq = ld_hq; a.ada_std = ada_std; a.ada_mean = ada_mean; a.h_adapt = h_adapt; a.Q = Q;
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
-    const AtLds o = at_layout(L, A, E, F, K);
-    const size_t lds_bytes = (size_t)o.total * sizeof(float);
-    ST_CHECK_ARG(lds_bytes <= 160 * 1024, "st_attn_step_fwd: L=%d needs %zu B of LDS (> 160 KiB)", L, lds_bytes);
-    static size_t configured = 0;
-    if (lds_bytes > configured) {
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = 160 * 1024;
-    }
-    hipLaunchKernelGGL(at_kernel, dim3(B), dim3(AT_THREADS), lds_bytes, (hipStream_t)stream, a);
-    ST_LAUNCH_CHECK();
-    return 0;
+    return at_launch(a, (hipStream_t)stream);
+}
+
+// decode-loop variant: context written in the tiled T16 layout (and optionally natural)
+extern "C" int st_attn_step_t16_fwd(const float* pq, const float* pm, const float* memory,
+                                    const float* w_prev, int ld_wprev, const float* w_cum_prev,
+                                    float* w_out, int ld_wout, float* w_cum_out,
+                                    const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                                    float* ctx_t16, float* ctx, int ld_ctx,
+                                    int B, int L, int A, int E, int F, int K, void* stream) {
+    (void)hipGetLastError();
+    AtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pq = pq; a.pm = pm; a.memory = memory; a.w_prev = w_prev; a.ld_wprev = ld_wprev; a.w_cum_prev = w_cum_prev;
+    a.w_out = w_out; a.ld_wout = ld_wout; a.w_cum_out = w_cum_out;
+    a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx; a.ctx_t16 = ctx_t16;
+    a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
+    return at_launch(a, (hipStream_t)stream);
 }

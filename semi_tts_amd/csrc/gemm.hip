@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* X, int ldx, int co
 extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
                            int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev,
                            const st_gemm_epilogue* ep, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(A && W && C, "st_gemm_fwd: null pointer");
     ST_CHECK_ARG(Bn > 0 && Tin > 0 && Tout > 0 && Cin > 0 && N > 0 && KT > 0 && pad >= 0, "st_gemm_fwd: bad dims");
     ST_CHECK_ARG(lda >= Cin && ldc >= coff + N, "st_gemm_fwd: lda=%d < Cin=%d or ldc=%d < coff+N=%d", lda, Cin, ldc, coff + N);
@@ -226,6 +227,7 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
 
 extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, float* mean_out, float* var_out,
                            float* run_mean, float* run_var, float momentum, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(X && mean_out && var_out && M > 0 && N > 0, "st_bn_stats: bad arguments");
     ST_CHECK_ARG((run_mean == nullptr) == (run_var == nullptr), "st_bn_stats: run_mean/run_var must both be given");
     hipLaunchKernelGGL(bn_stats_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream,
@@ -236,6 +238,7 @@ extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, floa
 
 extern "C" int st_bn_apply(float* X, int ldx, int coff, int M, int N, const float* mean, const float* var,
                            const float* w, const float* b, float eps, int act, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(X && mean && var && M > 0 && N > 0, "st_bn_apply: bad arguments");
     const size_t total = (size_t)M * N;
     int blocks = (int)((total + 255) / 256);

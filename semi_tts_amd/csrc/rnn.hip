@@ -90,6 +90,7 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_kernel(const GruArgs
 extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const float* w_hh_fwd, const float* w_hh_bwd,
                               const float* b_hh_fwd, const float* b_hh_bwd, float* out, int ldo,
                               int B, int T, int H, int ndir, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(ndir == 1 || ndir == 2, "st_gru_seq_fwd: ndir=%d", ndir);
     ST_CHECK_ARG(gi_fwd && w_hh_fwd && b_hh_fwd && out && B > 0 && T > 0 && H > 0, "st_gru_seq_fwd: bad arguments");
     ST_CHECK_ARG(ndir == 1 || (gi_bwd && w_hh_bwd && b_hh_bwd), "st_gru_seq_fwd: missing reverse-direction pointers");
@@ -109,6 +110,7 @@ extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const fl
 
 extern "C" int st_lstm_seq_fwd(const float* xproj, const float* w_hh, const float* b_hh, float* out, int ldo, int ocol,
                                float* ws, int B, int T, int H, int reverse, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(xproj && w_hh && out && ws && B > 0 && T > 0 && H > 0, "st_lstm_seq_fwd: bad arguments");
     ST_CHECK_ARG(ldo >= ocol + H, "st_lstm_seq_fwd: ldo=%d < ocol+H", ldo);
     hipStream_t st = (hipStream_t)stream;

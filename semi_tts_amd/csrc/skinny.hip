@@ -211,6 +211,7 @@ extern "C" int st_lstm_cell_fwd(const st_seg* segs, int nseg, const float* b_ih,
                                 const float* pre, int ldpre, const float* c_prev, int ldc_prev,
                                 const float* mask, float* h_out, int ldh, float* c_out, int ldc,
                                 float* gates_out, int B, int H, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(B > 0 && H > 0, "st_lstm_cell_fwd: B=%d H=%d", B, H);
     ST_CHECK_ARG(H % 4 == 0, "st_lstm_cell_fwd: H=%d must be a multiple of 4", H);
     ST_CHECK_ARG(h_out && c_out, "st_lstm_cell_fwd: null output");
@@ -229,6 +230,7 @@ extern "C" int st_skinny_linear_fwd(const st_seg* segs, int nseg, const float* b
                                     const float* mask, int ldmask, float* y, int ldy,
                                     int n_split, float* y2, int ldy2, int rep,
                                     int B, int N, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(B > 0 && N > 0 && y, "st_skinny_linear_fwd: B=%d N=%d y=%p", B, N, (void*)y);
     ST_CHECK_ARG(n_split <= 0 || (y2 && rep >= 1), "st_skinny_linear_fwd: n_split without y2/rep");
     SkArgs a;

@@ -1,0 +1,367 @@
+// skinny_packed.hip -- the weight-streaming kernels of the decode loop on PRE-PACKED operands.
+//
+// Measured on MI355X (tools/mb): a global load whose 16-lane quarter touches 16 different
+// cache lines (the natural MFMA operand pattern: lane l holds row l&15) moves only ~18 B/clk
+// per CU, while 1 KiB-contiguous wave loads move ~90-140 B/clk.  So the decode loop keeps its
+// operands in HBM already in MFMA lane order:
+//   * weights are packed ONCE per forward ("P16"): [row tile][k block][lane][4 floats], one
+//     1 KiB block per (16 rows x 16 k); a workgroup's whole weight stream is one contiguous
+//     run of 16*K*4 bytes, every wave instruction reads 1 KiB of it;
+//   * activations live in the tiled layout "T16": [batch tile][k block][lane][4 floats]; the
+//     kernels that PRODUCE activations (LSTM cell, attention, prenet) write them tiled, so the
+//     consumers pay nothing.
+// block layout (both): lane = 16*((k>>2)&3) + (r&15), component = k&3, i.e. exactly the
+// v_mfma_f32_16x16x4_f32 operand registers A[i=lane&15][k=lane>>4] / B[k=lane>>4][n=lane&15]
+// when a lane feeds component c of its float4 to the c-th of 4 successive MFMAs.
+// The K loop is software pipelined (loads of group g+1 are in flight during the MFMAs of g).
+#include "st_common.h"
+
+namespace {
+
+constexpr int PK_MAXSEG = 3;
+
+__host__ __device__ inline int pk_kb(int k) { return (k + 15) >> 4; }
+
+// ------------------------------------------------------------------------------ layout kernels
+struct PackArgs {
+    const float* w[PK_MAXSEG]; int ldw[PK_MAXSEG]; int k[PK_MAXSEG]; int kb0[PK_MAXSEG];
+    int nseg; int N; int H; int KB; int tiles; float* out;
+};
+
+// one thread per (tile, kb, lane): gathers 4 floats of one weight row
+__global__ __launch_bounds__(256) void pack_weight_kernel(const PackArgs a) {
+    const size_t total = (size_t)a.tiles * a.KB * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t blk = idx >> 6;
+        const int kb = (int)(blk % a.KB), tile = (int)(blk / a.KB);
+        const int i = lane & 15, kq = lane >> 4;
+        int row;
+        if (a.H > 0) row = (i & 3) * a.H + tile * 4 + (i >> 2);    // LSTM: (gate, unit) interleave
+        else row = tile * 16 + i;
+        int s = 0;
+        while (s + 1 < a.nseg && kb >= a.kb0[s + 1]) ++s;
+        const int k = (kb - a.kb0[s]) * 16 + kq * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < a.N) {
+            const float* p = a.w[s] + (size_t)row * a.ldw[s] + k;
+            const int rem = a.k[s] - k;
+            if (rem > 0) v[0] = p[0];
+            if (rem > 1) v[1] = p[1];
+            if (rem > 2) v[2] = p[2];
+            if (rem > 3) v[3] = p[3];
+        }
+        reinterpret_cast<f32x4*>(a.out)[idx] = v;
+    }
+}
+
+// natural (B, K) rows with stride ld  ->  tiled T16 (pads written as zero)
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float* src, int ld, float* dst, int B, int K) {
+    const int KB = pk_kb(K), BT = (B + 15) >> 4;
+    const size_t total = (size_t)BT * KB * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t blk = idx >> 6;
+        const int kb = (int)(blk % KB), bt = (int)(blk / KB);
+        const int b = bt * 16 + (lane & 15), k = kb * 16 + (lane >> 4) * 4;
+        if (b >= B) continue;       // rows beyond B are left untouched (the destination is pre-zeroed)
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* p = src + (size_t)b * ld + k;
+        const int rem = K - k;
+        if (rem > 0) v[0] = p[0];
+        if (rem > 1) v[1] = p[1];
+        if (rem > 2) v[2] = p[2];
+        if (rem > 3) v[3] = p[3];
+        reinterpret_cast<f32x4*>(dst)[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void untile_rows_kernel(const float* src, float* dst, int ld, int B, int K) {
+    const int KB = pk_kb(K);
+    const size_t total = (size_t)B * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / K), k = (int)(idx - (size_t)b * K);
+        const size_t off = (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
+        dst[(size_t)b * ld + k] = src[off];
+    }
+}
+
+// element offset (in floats) of (b, k) in a T16 buffer with KB k-blocks
+__device__ __forceinline__ size_t t16_off(int b, int k, int KB) {
+    return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
+}
+
+// ------------------------------------------------------------------------------ the kernel
+struct PkArgs {
+    const f32x4* w;                      // packed weights [tile][KB][64]
+    const f32x4* x[PK_MAXSEG]; int kb[PK_MAXSEG]; int nseg; int KB;   // tiled activations per segment
+    int B, N, H;
+    // LSTM epilogue
+    const float* b_ih; const float* b_hh; const float* pre; int ldpre;
+    const float* c_prev; int ldc_prev; const float* mask;
+    float* h_t16; int h_kb; float* c_out; int ldc; float* gates_out;
+    const float* ada_std; const float* ada_mean; float* hadapt_t16;       // optional AdaIN of the new h
+    // linear epilogue
+    const float* bias; int act; const float* lmask; int ldmask;
+    float* y; int ldy; float* y_t16; int y_kb; int n_split; float* y2; int ldy2; int rep;
+};
+
+template <int NB, int TRIP>
+struct PkRegs { f32x4 w[TRIP]; f32x4 x[TRIP][NB]; };
+
+template <int NB, int KW, int TRIP>
+__device__ __forceinline__ void pk_load(PkRegs<NB, TRIP>& r, const f32x4* wp, const f32x4* xp, int xKB, int kb, int nkb,
+                                        int bt0) {
+#pragma unroll
+    for (int t = 0; t < TRIP; ++t) {
+        const int k = kb + t * KW;
+        if (k < nkb) {
+            r.w[t] = wp[(size_t)k * 64];
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = xp[((size_t)(bt0 + bt) * xKB + k) * 64];
+        } else {   // beyond this segment: contributes nothing
+            r.w[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+template <int NB, int TRIP>
+__device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[NB]) {
+#pragma unroll
+    for (int t = 0; t < TRIP; ++t)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.w[t][cc], r.x[t][bt][cc], acc[bt], 0, 0, 0);
+}
+
+// MODE 0: LSTM cell, MODE 1: linear
+template <int MODE, int NB, int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
+    __shared__ f32x4 red[KW * NB * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int bt0 = blockIdx.y * NB;
+    const int BT = (a.B + 15) >> 4;
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) acc[bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // batch tiles beyond BT alias the last valid one (their results are discarded)
+    const int bt_base = bt0 + NB <= BT ? bt0 : (BT >= NB ? BT - NB : 0);
+    const f32x4* wseg = a.w + (size_t)tile * a.KB * 64 + lane;
+    constexpr int STEP = KW * TRIP;
+    for (int s = 0; s < a.nseg; ++s) {
+        const int nkb = a.kb[s];
+        const f32x4* xp = a.x[s] + lane;
+        PkRegs<NB, TRIP> ra, rb;
+        int kb = wave;
+        if (kb < nkb) pk_load<NB, KW, TRIP>(ra, wseg, xp, nkb, kb, nkb, bt_base);
+        while (kb < nkb) {
+            int kn = kb + STEP;
+            if (kn < nkb) pk_load<NB, KW, TRIP>(rb, wseg, xp, nkb, kn, nkb, bt_base);
+            pk_mma<NB, TRIP>(ra, acc);
+            kb = kn;
+            if (kb >= nkb) break;
+            kn = kb + STEP;
+            if (kn < nkb) pk_load<NB, KW, TRIP>(ra, wseg, xp, nkb, kn, nkb, bt_base);
+            pk_mma<NB, TRIP>(rb, acc);
+            kb = kn;
+        }
+        wseg += (size_t)nkb * 64;
+    }
+
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) red[(wave * NB + bt) * 64 + lane] = acc[bt];
+    __syncthreads();
+    if (tid >= NB * 64) return;
+    const int btl = tid >> 6;
+    f32x4 s = red[btl * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) {
+        const f32x4 t = red[(w * NB + btl) * 64 + lane];
+        s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    const int b = (bt_base + btl) * 16 + (lane & 15);
+    if (b >= a.B || bt_base + btl < bt0) return;    // aliased tiles: somebody else owns these rows
+
+    if (MODE == 0) {
+        const int H = a.H;
+        const int u = tile * 4 + (lane >> 4);
+        float g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = s[r];
+            if (a.b_ih) v += a.b_ih[r * H + u];
+            if (a.b_hh) v += a.b_hh[r * H + u];
+            if (a.pre) v += a.pre[(size_t)b * a.ldpre + r * H + u];
+            g[r] = v;
+        }
+        const float gi = st_sigmoid(g[0]), gf = st_sigmoid(g[1]), gg = tanhf(g[2]), go = st_sigmoid(g[3]);
+        const float cp = a.c_prev ? a.c_prev[(size_t)b * a.ldc_prev + u] : 0.0f;
+        const float c2 = gf * cp + gi * gg;
+        float h2 = go * tanhf(c2);
+        if (a.mask) h2 *= a.mask[(size_t)b * H + u];
+        a.c_out[(size_t)b * a.ldc + u] = c2;
+        a.h_t16[t16_off(b, u, a.h_kb)] = h2;
+        if (a.hadapt_t16) {   // AdaIN: relu(W_s s + b) * (h - (W_m s + b))        ref: src/module.py:268-269
+            const size_t q = (size_t)b * H + u;
+            a.hadapt_t16[t16_off(b, u, a.h_kb)] = a.ada_std[q] * (h2 - a.ada_mean[q]);
+        }
+        if (a.gates_out) {
+            float* gp = a.gates_out + (size_t)b * 4 * H + u;
+            gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = tile * 16 + 4 * (lane >> 4) + r;
+            if (n >= a.N) continue;
+            float v = s[r];
+            if (a.bias) v += a.bias[n];
+            v = st_act(v, a.act);
+            if (a.lmask) v *= a.lmask[(size_t)b * a.ldmask + n];
+            if (a.n_split > 0 && n >= a.n_split) {
+                float* p = a.y2 + (size_t)b * a.ldy2 + (size_t)(n - a.n_split) * a.rep;
+                for (int j = 0; j < a.rep; ++j) p[j] = v;
+            } else {
+                if (a.y) a.y[(size_t)b * a.ldy + n] = v;
+                if (a.y_t16) a.y_t16[t16_off(b, n, a.y_kb)] = v;
+            }
+        }
+    }
+}
+
+template <int MODE, int NB>
+int pk_launch(const PkArgs& a, int tiles, hipStream_t st) {
+    constexpr int KW = 8, TRIP = 2;
+    const int BT = (a.B + 15) >> 4;
+    dim3 grid(tiles, (BT + NB - 1) / NB);
+    hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE>
+int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st) {
+    const int BT = (a.B + 15) >> 4;
+    if (BT == 1) return pk_launch<MODE, 1>(a, tiles, st);
+    if (BT == 2) return pk_launch<MODE, 2>(a, tiles, st);
+    if (BT == 3) return pk_launch<MODE, 3>(a, tiles, st);
+    return pk_launch<MODE, 4>(a, tiles, st);
+}
+
+int pk_fill(PkArgs& a, const float* packed_w, const st_pseg* segs, int nseg, const char* who) {
+    ST_CHECK_ARG(packed_w && segs && nseg >= 1 && nseg <= PK_MAXSEG, "%s: bad packed operands (nseg=%d)", who, nseg);
+    ST_CHECK_ARG(st_aligned16(packed_w), "%s: packed weights must be 16-byte aligned", who);
+    a.w = reinterpret_cast<const f32x4*>(packed_w);
+    a.nseg = nseg;
+    a.KB = 0;
+    for (int s = 0; s < nseg; ++s) {
+        ST_CHECK_ARG(segs[s].x_t16 && segs[s].k > 0 && st_aligned16(segs[s].x_t16), "%s: segment %d invalid", who, s);
+        a.x[s] = reinterpret_cast<const f32x4*>(segs[s].x_t16);
+        a.kb[s] = pk_kb(segs[s].k);
+        a.KB += a.kb[s];
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t st_packed_weight_floats(const int* k, int nseg, int N, int lstm_H) {
+    size_t KB = 0;
+    for (int s = 0; s < nseg; ++s) KB += (size_t)pk_kb(k[s]);
+    const size_t tiles = lstm_H > 0 ? (size_t)lstm_H / 4 : ((size_t)N + 15) / 16;
+    return tiles * KB * 256;
+}
+
+extern "C" size_t st_t16_floats(int B, int K) { return (size_t)((B + 15) >> 4) * pk_kb(K) * 256; }
+
+extern "C" int st_pack_weight(const float* const* w, const int* ldw, const int* k, int nseg, int N, int lstm_H,
+                              float* packed, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(w && ldw && k && packed && nseg >= 1 && nseg <= PK_MAXSEG && N > 0, "st_pack_weight: bad arguments");
+    ST_CHECK_ARG(lstm_H == 0 || (lstm_H % 4 == 0 && N == 4 * lstm_H), "st_pack_weight: lstm_H=%d N=%d", lstm_H, N);
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    int kb = 0;
+    for (int s = 0; s < nseg; ++s) {
+        ST_CHECK_ARG(w[s] && k[s] > 0 && ldw[s] >= k[s], "st_pack_weight: segment %d invalid", s);
+        a.w[s] = w[s]; a.ldw[s] = ldw[s]; a.k[s] = k[s]; a.kb0[s] = kb;
+        kb += pk_kb(k[s]);
+    }
+    a.nseg = nseg; a.N = N; a.H = lstm_H; a.KB = kb;
+    a.tiles = lstm_H > 0 ? lstm_H / 4 : (N + 15) / 16;
+    a.out = packed;
+    const size_t total = (size_t)a.tiles * a.KB * 64;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_tile_rows(const float* src, int ld, float* dst_t16, int B, int K, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(src && dst_t16 && B > 0 && K > 0 && ld >= K, "st_tile_rows: bad arguments");
+    const size_t total = (size_t)((B + 15) >> 4) * pk_kb(K) * 64;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, dst_t16, B, K);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_untile_rows(const float* src_t16, float* dst, int ld, int B, int K, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(src_t16 && dst && B > 0 && K > 0 && ld >= K, "st_untile_rows: bad arguments");
+    const size_t total = (size_t)B * K;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(untile_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src_t16, dst, ld, B, K);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_pseg* segs, int nseg,
+                                       const float* b_ih, const float* b_hh, const float* pre, int ldpre,
+                                       const float* c_prev, int ldc_prev, const float* mask,
+                                       float* h_out_t16, float* c_out, int ldc, float* gates_out,
+                                       const float* ada_std, const float* ada_mean, float* hadapt_t16,
+                                       int B, int H, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && h_out_t16 && c_out, "st_lstm_cell_packed_fwd: bad arguments");
+    ST_CHECK_ARG(!hadapt_t16 || (ada_std && ada_mean), "st_lstm_cell_packed_fwd: AdaIN pointers");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, segs, nseg, "st_lstm_cell_packed_fwd");
+    if (rc) return rc;
+    a.B = B; a.N = 4 * H; a.H = H;
+    a.b_ih = b_ih; a.b_hh = b_hh; a.pre = pre; a.ldpre = ldpre;
+    a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
+    a.h_t16 = h_out_t16; a.h_kb = pk_kb(H); a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
+    a.ada_std = ada_std; a.ada_mean = ada_mean; a.hadapt_t16 = hadapt_t16;
+    return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
+}
+
+extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_pseg* segs, int nseg,
+                                           const float* bias, int act, const float* mask, int ldmask,
+                                           float* y, int ldy, float* y_t16, int n_split, float* y2, int ldy2, int rep,
+                                           int B, int N, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(B > 0 && N > 0 && (y || y_t16), "st_skinny_linear_packed_fwd: bad arguments");
+    ST_CHECK_ARG(n_split <= 0 || (y2 && rep >= 1), "st_skinny_linear_packed_fwd: n_split without y2/rep");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, segs, nseg, "st_skinny_linear_packed_fwd");
+    if (rc) return rc;
+    a.B = B; a.N = N; a.H = 0;
+    a.bias = bias; a.act = act; a.lmask = mask; a.ldmask = ldmask;
+    a.y = y; a.ldy = ldy; a.y_t16 = y_t16; a.y_kb = pk_kb(n_split > 0 ? n_split : N);
+    a.n_split = n_split; a.y2 = y2; a.ldy2 = ldy2; a.rep = rep;
+    return pk_dispatch<1>(a, (N + 15) / 16, (hipStream_t)stream);
+}

@@ -35,7 +35,7 @@ void st_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
-static inline bool st_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static __host__ __device__ inline bool st_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---------------------------------------------------------------- device helpers (wave = 64)
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(VQ_WAVES * 64) void softmax_argmax_kernel(const flo
 
 extern "C" int st_vq_build_table(const float* learnable, int Dl, const float* attr, int n_attr,
                                  const float* attr_w, const float* attr_b, int Da, float* table, int V, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(learnable && table && V > 0 && Dl > 0 && Da >= 0, "st_vq_build_table: bad arguments");
     ST_CHECK_ARG(Da == 0 || (attr && attr_w && attr_b && n_attr > 0), "st_vq_build_table: attribute pointers missing");
     const int total = V * (Dl + Da);
@@ -149,6 +150,7 @@ extern "C" int st_vq_build_table(const float* learnable, int Dl, const float* at
 }
 
 extern "C" int st_gather_rows(const float* table, const int64_t* idx, float* out, int n, int D, int V, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(table && idx && out && n > 0 && D > 0 && V > 0, "st_gather_rows: bad arguments");
     size_t total = (size_t)n * D;
     int blocks = (int)((total + 255) / 256);
@@ -160,6 +162,7 @@ extern "C" int st_gather_rows(const float* table, const int64_t* idx, float* out
 
 extern "C" int st_vq_l2_fwd(const float* x, const float* table, const float* temp, float* p_code,
                             int64_t* idx, float* out, int n, int D, int V, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(x && table && temp && p_code && idx && out && n > 0 && D > 0 && V > 0, "st_vq_l2_fwd: bad arguments");
     const size_t lds = ((size_t)D * (V + 1) + V + (size_t)VQ_WAVES * D + (size_t)VQ_WAVES * V) * sizeof(float);
     ST_CHECK_ARG(lds <= 160 * 1024, "st_vq_l2_fwd: V=%d x D=%d table needs %zu B of LDS (> 160 KiB)", V, D, lds);
@@ -179,6 +182,7 @@ extern "C" int st_vq_l2_fwd(const float* x, const float* table, const float* tem
 }
 
 extern "C" int st_softmax_argmax(const float* logits, float* p, int64_t* idx, int n, int V, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(logits && p && idx && n > 0 && V > 0, "st_softmax_argmax: bad arguments");
     const size_t lds = (size_t)VQ_WAVES * V * sizeof(float);
     ST_CHECK_ARG(lds <= 64 * 1024, "st_softmax_argmax: V=%d too large", V);

@@ -341,12 +341,20 @@ class Decoder(nn.Module):
         mel = torch.empty(B, steps * r, n_mels, **f32)
         align = torch.empty(B, steps, L, **f32)
         stop = torch.empty(B, steps * r, **f32)
-        tapes = dict(
-            hq=torch.empty(steps + 1, B, Q, **f32), cq=torch.empty(steps + 1, B, Q, **f32),
-            hd=torch.empty(steps + 1, B, D, **f32), cd=torch.empty(steps + 1, B, D, **f32),
-            ctx=torch.empty(steps + 1, B, E, **f32), wcum=torch.empty(steps + 1, B, L, **f32),
-            hadapt=torch.empty(steps, B, Q, **f32), decin=torch.empty(steps + 1, B, P, **f32),
-            pq=torch.empty(B, A, **f32), pre1=torch.empty(B, P, **f32), zero=torch.empty(B, L, **f32))
+        lib = _lib.load()
+        t16 = lambda k: int(lib.st_t16_floats(B, k))           # floats of one T16-tiled (B, k) slot
+        in_dim = r * n_mels
+        # T16-tiled tapes are handed in zero-filled (pad lanes/rows must be zero); ONE memset covers them all
+        sizes = dict(hq=(steps + 1) * t16(Q), hd=(steps + 1) * t16(D), ctx=(steps + 1) * t16(E),
+                     hadapt=steps * t16(Q), decin=(steps + 1) * t16(P), pre1=t16(P), melt=t16(in_dim))
+        tiled = torch.zeros(sum(sizes.values()), **f32)
+        tapes, off = {}, 0
+        for k, n in sizes.items():
+            tapes[k] = tiled[off:off + n]
+            off += n
+        tapes.update(cq=torch.empty(steps + 1, B, Q, **f32), cd=torch.empty(steps + 1, B, D, **f32),
+                     wcum=torch.empty(steps + 1, B, L, **f32), pq=torch.empty(B, A, **f32),
+                     zero=torch.empty(B, L, **f32), tiled=tiled)
         if self.training and torch.is_grad_enabled():
             tapes['gates_q'] = torch.empty(steps, B, 4, Q, **f32)
             tapes['gates_d'] = torch.empty(steps, B, 4, D, **f32)
@@ -354,6 +362,9 @@ class Decoder(nn.Module):
         w = self._weights_struct(keep)
         dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A,
                              F=self.n_location_filters, K=self.location_kernel_size)
+        # the six matrices the loop streams every step, packed into MFMA lane order once per forward
+        packed = torch.empty(int(lib.st_decoder_packed_floats(C.byref(dims))), **f32)
+        check(lib.st_decoder_pack(C.byref(w), C.byref(dims), ops._p(packed), ops.stream_handle()), 'st_decoder_pack')
         io = StDecoderIO()
         src_arr = (C.c_int * max(steps, 1))(*step_src)
         io.memory, io.pm, io.ada_std, io.ada_mean = ops._p(memory), ops._p(pm), ops._p(ada_std), ops._p(ada_mean)
@@ -363,12 +374,15 @@ class Decoder(nn.Module):
         io.prenet_mask, io.q_mask, io.d_mask = ops._p(own_mask), ops._p(q_mask), ops._p(d_mask)
         io.steps = steps
         io.mel_out, io.align_out, io.stop_out = ops._p(mel), ops._p(align), ops._p(stop)
+        io.packed = ops._p(packed)
         io.hq_tape, io.cq_tape, io.hd_tape, io.cd_tape = (ops._p(tapes[k]) for k in ('hq', 'cq', 'hd', 'cd'))
         io.ctx_tape, io.wcum_tape, io.hadapt_tape = ops._p(tapes['ctx']), ops._p(tapes['wcum']), ops._p(tapes['hadapt'])
-        io.decin_tape, io.pq_buf, io.pre1_buf, io.zero_row = (ops._p(tapes[k]) for k in ('decin', 'pq', 'pre1', 'zero'))
+        io.decin_tape, io.pq_buf, io.pre1_t16, io.mel_t16 = (ops._p(tapes[k]) for k in ('decin', 'pq', 'pre1', 'melt'))
+        io.zero_row = ops._p(tapes['zero'])
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
-        check(_lib.load().st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
+        check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
+        tapes['packed'] = packed
         tapes.update(pm=pm, ada_std=ada_std, ada_mean=ada_mean, teacher_pre=teacher_pre, masks=(own_mask, q_mask, d_mask),
                      keep=keep, step_src=step_src)
         self.last_tapes = tapes

@@ -243,6 +243,64 @@ def mean_rows(src):
     return dst
 
 
+# --------------------------------------------------------------------------------------------- packed operands
+def t16_floats(B, K):
+    return int(_lib.load().st_t16_floats(int(B), int(K)))
+
+
+def pack_weight(ws, ks, N, lstm_H=0, ldws=None):
+    """ws: list of (N, k_s) weight slices (views of torch weights); returns the P16 buffer"""
+    lib = _lib.load()
+    n = len(ws)
+    karr = (C.c_int * n)(*[int(k) for k in ks])
+    ldarr = (C.c_int * n)(*[int(ld) for ld in (ldws or [w.stride(0) for w in ws])])
+    warr = (C.c_void_p * n)(*[_p(w) for w in ws])
+    size = int(lib.st_packed_weight_floats(karr, n, int(N), int(lstm_H)))
+    out = torch.empty(size, device=ws[0].device, dtype=torch.float32)
+    check(lib.st_pack_weight(warr, ldarr, karr, n, int(N), int(lstm_H), _p(out), stream_handle()), 'st_pack_weight')
+    return out
+
+
+def tile_rows(x, out=None):
+    """natural (B, K) -> T16"""
+    B, K = x.shape
+    if out is None:
+        out = torch.zeros(t16_floats(B, K), device=x.device, dtype=torch.float32)
+    check(_lib.load().st_tile_rows(_p(x), int(x.stride(0)), _p(out), B, K, stream_handle()), 'st_tile_rows')
+    return out
+
+
+def untile_rows(x_t16, B, K):
+    out = torch.empty(B, K, device=x_t16.device, dtype=torch.float32)
+    check(_lib.load().st_untile_rows(_p(x_t16), _p(out), K, B, K, stream_handle()), 'st_untile_rows')
+    return out
+
+
+def _psegs(pairs):
+    arr = (_lib.StPSeg * len(pairs))()
+    for i, (x, k) in enumerate(pairs):
+        arr[i].x_t16, arr[i].k = _p(x), int(k)
+    return arr
+
+
+def lstm_cell_packed(packed_w, segs, b_ih, b_hh, c_prev, h_out_t16, c_out, B, H, mask=None, gates_out=None,
+                     ada_std=None, ada_mean=None, hadapt_t16=None):
+    """segs: list of (x_t16, k)"""
+    check(_lib.load().st_lstm_cell_packed_fwd(_p(packed_w), _psegs(segs), len(segs), _p(b_ih), _p(b_hh), None, 0,
+                                              _p(c_prev), H, _p(mask), _p(h_out_t16), _p(c_out), H, _p(gates_out),
+                                              _p(ada_std), _p(ada_mean), _p(hadapt_t16), int(B), int(H),
+                                              stream_handle()), 'st_lstm_cell_packed_fwd')
+
+
+def skinny_linear_packed(packed_w, segs, B, N, y=None, y_t16=None, bias=None, act=None, mask=None,
+                         n_split=0, y2=None, rep=0):
+    check(_lib.load().st_skinny_linear_packed_fwd(
+        _p(packed_w), _psegs(segs), len(segs), _p(bias), ACT[act], _p(mask),
+        int(mask.stride(0)) if mask is not None else 0, _p(y), int(y.stride(0)) if y is not None else 0, _p(y_t16),
+        int(n_split), _p(y2), int(y2.stride(0)) if y2 is not None else 0, int(rep), int(B), int(N), stream_handle()),
+        'st_skinny_linear_packed_fwd')
+
+
 # --------------------------------------------------------------------------------------------- graphs
 class Graph:
     """Records every st_* call issued inside `with g.capture():` on a private HIP stream into a

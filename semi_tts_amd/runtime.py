@@ -1,0 +1,65 @@
+"""hipGraph-captured decode for fixed shapes (batched inference, BASELINE config 5; also used
+by bench.py): the whole autoregressive loop of Decoder.forward -- processed memory, AdaIN
+statistics and `steps` x (query LSTM, query projection, attention, decoder LSTM, proj/gate,
+prenet) -- is recorded once on a private HIP stream and replayed with ONE graph launch, so the
+loop runs at device pace instead of host-launch pace.
+
+Static-buffer discipline (same as any stream capture): inputs are copied into buffers owned by
+this object, dropout masks are redrawn in place before each replay, outputs are views of
+buffers that the next call overwrites.
+"""
+import torch
+
+from . import ops
+
+
+class GraphedDecoder:
+    def __init__(self, decoder, B, L, frames, device, prenet_dropout=None):
+        """decoder: semi_tts_amd.module.Decoder (eval mode); frames: int teacher (max frames)"""
+        self.decoder = decoder
+        self.frames = int(frames)
+        self.steps = self.frames // decoder.n_frames_per_step
+        E, S = decoder.enc_embed_dim, decoder.spkr_embed_dim
+        f32 = dict(device=device, dtype=torch.float32)
+        self.memory = torch.zeros(B, L, E, **f32)
+        self.spkr = torch.zeros(B, S, **f32)
+        p = decoder.prenet_dropout if prenet_dropout is None else prenet_dropout
+        self.p = p
+        self.own_mask = torch.ones(self.steps, 2, B, decoder.prenet_dim, **f32) if p > 0 else None
+        self.graph = None
+        self.outputs = None
+        self._keep = None
+
+    def _run(self):
+        masks = {'own': self.own_mask} if self.own_mask is not None else None
+        with torch.no_grad():
+            return self.decoder(self.memory, None, self.frames, self.spkr, tf_rate=0.0, _masks=masks)
+
+    def capture(self):
+        assert not self.decoder.training, 'graph replay is for eval-mode inference'
+        # 1. eager pass: warms the caching allocator with blocks of exactly the sizes the loop needs
+        self._run()
+        torch.cuda.synchronize()
+        self.decoder.last_tapes = None            # release them back to the allocator's cache
+        # 2. capture: every torch.empty below is served from the cache (no hipMalloc while capturing)
+        self.graph = ops.Graph()
+        with self.graph.capture():
+            self.outputs = self._run()
+        self._keep = self.decoder.last_tapes      # buffers the graph reads/writes must stay alive
+        return self
+
+    def draw_masks(self):
+        if self.own_mask is not None:
+            self.own_mask.bernoulli_(1.0 - self.p).div_(1.0 - self.p)
+
+    def __call__(self, memory=None, spkr_embed=None, redraw=True):
+        if self.graph is None:
+            self.capture()
+        if memory is not None:
+            self.memory.copy_(memory)
+        if spkr_embed is not None:
+            self.spkr.copy_(spkr_embed)
+        if redraw:
+            self.draw_masks()
+        self.graph.launch()
+        return self.outputs

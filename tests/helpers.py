@@ -9,12 +9,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = os.path.join(REPO, 'gpurun_out', 'parity_report.jsonl')
 
 
-def report(name, **vals):
+def report(test, **vals):
     """append one line of measured errors to gpurun_out/parity_report.jsonl (best effort)"""
     try:
         os.makedirs(os.path.dirname(REPORT), exist_ok=True)
         with open(REPORT, 'a') as f:
-            f.write(json.dumps(dict(test=name, **{k: (float(v) if not isinstance(v, (str, int)) else v)
+            f.write(json.dumps(dict(test=test, **{k: (float(v) if not isinstance(v, (str, int)) else v)
                                                    for k, v in vals.items()})) + '\n')
     except OSError:
         pass

@@ -87,6 +87,82 @@ def test_lstm_cell(dev, B, H, K1, K2):
     assert maxdiff(gates[:, 0], torch.sigmoid(g_ref[:, :H])) < 1e-5
 
 
+@pytest.mark.parametrize('B,K', [(1, 4), (5, 24), (16, 16), (17, 33), (32, 240), (70, 100)])
+def test_tile_untile_roundtrip(dev, B, K):
+    from semi_tts_amd import ops
+    x = rnd(B, K, seed=3).to(dev)
+    t = ops.tile_rows(x)
+    assert t.numel() == ((B + 15) // 16) * ((K + 15) // 16) * 256
+    assert torch.equal(ops.untile_rows(t, B, K), x)
+    # pads are zero and the logical elements are a permutation of x
+    assert abs(float(t.abs().sum()) - float(x.abs().sum())) < 1e-3 * (1 + float(x.abs().sum()))
+
+
+@pytest.mark.parametrize('B,H,Ks', [(2, 8, (12, 20, 8)), (4, 48, (16, 32, 48)), (32, 1024, (256, 512, 1024)),
+                                    (64, 256, (64, 256)), (19, 40, (30, 40)), (70, 16, (24,)), (33, 64, (48, 64))])
+def test_lstm_cell_packed(dev, B, H, Ks):
+    """the decode loop's LSTM cell on pre-packed (P16) weights and tiled (T16) activations"""
+    from semi_tts_amd import ops
+    K = sum(Ks)
+    xs = [rnd(B, k, seed=10 + i) for i, k in enumerate(Ks)]
+    c = rnd(B, H, seed=3)
+    w = rnd(4 * H, K, scale=K ** -0.5, seed=4)
+    b_ih, b_hh = rnd(4 * H, scale=0.1, seed=6), rnd(4 * H, scale=0.1, seed=7)
+    mask = (torch.rand(B, H) > 0.1).float() / 0.9
+    std, mean = torch.relu(rnd(B, H, seed=8)), rnd(B, H, seed=9)
+    gates = torch.cat(xs, 1) @ w.t() + b_ih + b_hh
+    i, f, g, o = [gates[:, j * H:(j + 1) * H] for j in range(4)]
+    c_ref = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref) * mask
+    wd = w.to(dev)
+    offs = np.cumsum([0] + list(Ks))
+    packed = ops.pack_weight([wd[:, offs[j]:] for j in range(len(Ks))], Ks, 4 * H, lstm_H=H, ldws=[K] * len(Ks))
+    segs = [(ops.tile_rows(x.to(dev)), k) for x, k in zip(xs, Ks)]
+    h_t16 = torch.zeros(ops.t16_floats(B, H), device=dev)
+    ha_t16 = torch.zeros(ops.t16_floats(B, H), device=dev)
+    c_out = torch.empty(B, H, device=dev)
+    gts = torch.empty(B, 4, H, device=dev)
+    ops.lstm_cell_packed(packed, segs, b_ih.to(dev), b_hh.to(dev), c.to(dev), h_t16, c_out, B, H, mask=mask.to(dev),
+                         gates_out=gts, ada_std=std.to(dev), ada_mean=mean.to(dev), hadapt_t16=ha_t16)
+    h = ops.untile_rows(h_t16, B, H)
+    e_h, e_c = maxdiff(h, h_ref), maxdiff(c_out, c_ref)
+    report('lstm_cell_packed', B=B, H=H, K=K, err_h=e_h, err_c=e_c)
+    assert e_h < 1e-5 and e_c < 1e-5
+    assert maxdiff(ops.untile_rows(ha_t16, B, H), std * (h_ref - mean)) < 1e-5
+    assert maxdiff(gts[:, 3], torch.sigmoid(o)) < 1e-5
+
+
+@pytest.mark.parametrize('B,N,Ks', [(1, 16, (32,)), (4, 40, (24,)), (32, 241, (1024, 512)), (32, 256, (240,)),
+                                    (33, 48, (100, 28)), (64, 80, (62,)), (70, 33, (31,))])
+def test_skinny_linear_packed(dev, B, N, Ks):
+    from semi_tts_amd import ops
+    K = sum(Ks)
+    xs = [rnd(B, k, seed=20 + i) for i, k in enumerate(Ks)]
+    w, b = rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+    mask = (torch.rand(B, N) > 0.5).float() * 2
+    ref = torch.relu(torch.cat(xs, 1).double() @ w.double().t() + b.double()) * mask.double()
+    wd = w.to(dev)
+    offs = np.cumsum([0] + list(Ks))
+    packed = ops.pack_weight([wd[:, offs[j]:] for j in range(len(Ks))], Ks, N, ldws=[K] * len(Ks))
+    segs = [(ops.tile_rows(x.to(dev)), k) for x, k in zip(xs, Ks)]
+    y = torch.zeros(B, N, device=dev)
+    y_t16 = torch.zeros(ops.t16_floats(B, N), device=dev)
+    ops.skinny_linear_packed(packed, segs, B, N, y=y, y_t16=y_t16, bias=b.to(dev), act='relu', mask=mask.to(dev))
+    err = maxdiff(y, ref)
+    report('skinny_linear_packed', B=B, N=N, K=K, err=err)
+    assert err < 2e-5
+    assert torch.equal(ops.untile_rows(y_t16, B, N), y)
+    # split output (proj + gate): the last column goes to y2, repeated
+    if N > 16:
+        y1 = torch.zeros(B, N - 1, device=dev)
+        y2 = torch.zeros(B, 3, device=dev)
+        t1 = torch.zeros(ops.t16_floats(B, N - 1), device=dev)
+        ops.skinny_linear_packed(packed, segs, B, N, y=y1, y_t16=t1, bias=b.to(dev), n_split=N - 1, y2=y2, rep=3)
+        lin = torch.cat(xs, 1).double() @ w.double().t() + b.double()
+        assert maxdiff(y1, lin[:, :N - 1]) < 2e-5 and maxdiff(y2, lin[:, N - 1:].repeat(1, 3)) < 2e-5
+        assert torch.equal(ops.untile_rows(t1, B, N - 1), y1)
+
+
 @pytest.mark.parametrize('B,L,A,E,F,K,Q', [(2, 7, 16, 32, 4, 5, 48), (4, 12, 256, 512, 32, 31, 1024),
                                          (32, 43, 256, 512, 32, 31, 1024), (3, 171, 256, 512, 32, 31, 1024),
                                          (2, 70, 20, 24, 3, 3, 10)])
@@ -254,7 +330,9 @@ def test_vq_l2_against_reference(dev, name):
     n_bad = int((idx != A['idx']).sum())
     report('vq_l2', name=name, mismatches=n_bad, err_p=maxdiff(p, A['p_code']))
     assert torch.equal(idx, A['idx']), 'VQ code indices must be bit-exact (%d differ)' % n_bad
-    assert maxdiff(p, A['p_code']) < 2e-6
+    # sims are O(100) (squared distances of 64-dim vectors), so one fp32 ulp of a sim (7.6e-6)
+    # moves a softmax entry by ~1e-5 relative: 5e-5 absolute on p in [0,1]
+    assert maxdiff(p, A['p_code']) < 5e-5
     assert maxdiff(out, A['new_latent']) < 1e-6
     if 'inference' in A:
         assert maxdiff(cb.inference(A['txt'].to(dev)), A['inference']) < 1e-6
@@ -273,7 +351,7 @@ def test_vq_seperate_against_reference(dev):
     cb = cb.to(dev).eval()
     p, out, _, _ = cb(A['x'].to(dev))
     assert torch.equal(cb.last_idx.cpu(), A['idx'])
-    assert maxdiff(p, A['p_code']) < 2e-6 and maxdiff(out, A['new_latent']) < 1e-6
+    assert maxdiff(p, A['p_code']) < 5e-6 and maxdiff(out, A['new_latent']) < 1e-6
     assert maxdiff(cb.inference(A['txt'].to(dev)), A['inference']) < 1e-6
 
 
@@ -292,7 +370,7 @@ def test_vq_full_size_properties(dev, V):
     n_bad = int((idx.cpu() != idx_ref).sum())
     report('vq_full', V=V, mismatches=n_bad)
     assert n_bad == 0
-    assert maxdiff(p, p_ref) < 2e-6 and maxdiff(out, out_ref) < 1e-6
+    assert maxdiff(p, p_ref) < 5e-5 and maxdiff(out, out_ref) < 1e-6
     k = min(V, 129)
     assert torch.equal(idx[0, :k].cpu(), torch.arange(k))
     _, idx2, _ = ops.vq_l2(ops.gather_rows(table.to(dev), idx), table.to(dev), temp.to(dev))
@@ -405,17 +483,15 @@ def test_decode_is_deterministic_and_graph_replay_matches(dev):
         a = m.decoder(mem, None, T, spk)[0].clone()
         b = m.decoder(mem, None, T, spk)[0].clone()
     assert torch.equal(a, b)
-    graph = ops.Graph()
-    torch.cuda.synchronize()
-    with torch.no_grad():
-        m.decoder(mem, None, T, spk)                     # warm the allocator
-        torch.cuda.synchronize()
-        with graph.capture():
-            out = m.decoder(mem, None, T, spk)[0]
-    out.zero_()
-    graph.launch()
+    from semi_tts_amd.runtime import GraphedDecoder
+    gd = GraphedDecoder(m.decoder, B, L, T, dev).capture()
+    out = gd(mem, spk)[0]
     torch.cuda.synchronize()
     assert torch.equal(out, a)
+    out.zero_()
+    out2 = gd(mem, spk)[0]                               # replay overwrites the same static buffers
+    torch.cuda.synchronize()
+    assert out2.data_ptr() == out.data_ptr() and torch.equal(out2, a)
 
 
 def test_cpu_tensor_is_refused():

@@ -104,33 +104,52 @@ int st_skinny_linear_fwd(const st_seg* segs, int nseg, const float* bias, int ac
  *   element (r, k) of a block lives at lane 16*((k>>2)&3) + (r&15), component k&3.
  * Rows/columns beyond the logical shape are zero.  T16 destinations must be zero-filled by the
  * caller once (kernels only write logical elements). */
-typedef struct st_pseg {
-    const float* x_t16; /* (B, k) activations in T16 layout */
-    int k;              /* logical k of this segment (padded to 16 inside the layout) */
-} st_pseg;
+typedef struct st_t16_view {   /* a k-block range [kb0, kb0 + ceil(k/16)) of a T16 buffer */
+    float* base;      /* start of the T16 buffer                                     */
+    int kb_stride;    /* k-blocks per batch tile of the WHOLE buffer                 */
+    int kb0;          /* first k-block of this view                                  */
+} st_t16_view;
+/* Several logical activations that one consumer multiplies with ONE packed weight matrix share one
+ * T16 buffer (e.g. [dec_in | ctx | h_q] for the query LSTM): each producer writes its k-block range
+ * of every consumer's buffer, so a consumer streams exactly one contiguous activation run. */
 
 size_t st_packed_weight_floats(const int* k, int nseg, int N, int lstm_H); /* size of a P16 buffer */
 size_t st_t16_floats(int B, int K);                                        /* size of a T16 buffer */
 /* Pack up to 3 K-segments w[s] (N, k[s]) (row stride ldw[s], torch [out][in]) into one P16 buffer
- * whose K axis is the concatenation of the segments.  lstm_H > 0: N == 4*lstm_H and the 16 rows of
- * tile t are the (i,f,g,o) rows of hidden units 4t..4t+3 (so the cell update is workgroup-local). */
+ * whose K axis is the concatenation of the segments (each padded to a multiple of 16).
+ * lstm_H > 0: N == 4*lstm_H and the 16 rows of tile t are the (i,f,g,o) rows of hidden units
+ * 4t..4t+3 (so the cell update is workgroup-local). */
 int st_pack_weight(const float* const* w, const int* ldw, const int* k, int nseg, int N, int lstm_H,
                    float* packed, void* stream);
-int st_tile_rows(const float* src, int ld, float* dst_t16, int B, int K, void* stream);   /* natural -> T16 */
-int st_untile_rows(const float* src_t16, float* dst, int ld, int B, int K, void* stream); /* T16 -> natural */
-/* st_lstm_cell_fwd on packed operands; h goes out in T16; optionally also the AdaIN-adapted
- * hidden state  hadapt = ada_std * (h_out - ada_mean)  (ada_* natural (B,H)).
+int st_tile_rows(const float* src, int ld, const st_t16_view* dst, int B, int K, void* stream);   /* natural -> T16 */
+int st_untile_rows(const st_t16_view* src, float* dst, int ld, int B, int K, void* stream);       /* T16 -> natural */
+/* st_lstm_cell_fwd on packed operands: x = K logical columns starting at view x.  The new hidden
+ * state goes to up to two T16 destinations; optionally also the AdaIN-adapted hidden state
+ * hadapt = ada_std * (h_out - ada_mean)  (ada_* natural (B,H)).
  * ref: as st_lstm_cell_fwd, AdaIN src/module.py:268-269 */
-int st_lstm_cell_packed_fwd(const float* packed_w, const st_pseg* segs, int nseg,
+int st_lstm_cell_packed_fwd(const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K,
                             const float* b_ih, const float* b_hh, const float* pre, int ldpre,
                             const float* c_prev, int ldc_prev, const float* mask,
-                            float* h_out_t16, float* c_out, int ldc, float* gates_out,
-                            const float* ada_std, const float* ada_mean, float* hadapt_t16,
+                            const st_t16_view* h_dst0, const st_t16_view* h_dst1,
+                            float* c_out, int ldc, float* gates_out,
+                            const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
                             int B, int H, void* stream);
-/* st_skinny_linear_fwd on packed operands; output natural (y) and/or T16 (y_t16) */
-int st_skinny_linear_packed_fwd(const float* packed_w, const st_pseg* segs, int nseg,
+/* (w_kb_stride, w_kb0): reduce only over the k-blocks [w_kb0, w_kb0 + ceil(K/16)) of a packed matrix
+ * that has w_kb_stride k-blocks per row tile (0, 0 = the whole matrix).  Together with
+ * st_lstm_gates_partial_packed_fwd this splits an LSTM cell into an early part (inputs that are
+ * already known: recurrent state, previous context) and a late part (the input still being computed),
+ * so the early part streams its weights on a second HIP stream off the critical path. */
+int st_lstm_gates_partial_packed_fwd(const float* packed_w, int w_kb_stride, int w_kb0,
+                                     const st_t16_view* x, int K, float* pre_out, int ldpre,
+                                     int B, int H, void* stream);
+/* st_skinny_linear_fwd on packed operands; output natural (y) and/or T16 (y_dst).
+ * Optional third row range [n_split2, N): v = act2(v) * mask2(b, n - n_split2) -> y3_dst column
+ * n - n_split2 (used to emit prenet layer 1 of the next step from the same launch as proj/gate). */
+int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
                                 const float* bias, int act, const float* mask, int ldmask,
-                                float* y, int ldy, float* y_t16, int n_split, float* y2, int ldy2, int rep,
+                                float* y, int ldy, const st_t16_view* y_dst,
+                                int n_split, float* y2, int ldy2, int rep,
+                                int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                 int B, int N, void* stream);
 
 /* ------------------------------------------------------------------ location-sensitive attention
@@ -151,13 +170,13 @@ int st_attn_step_fwd(const float* pq, const float* pm, const float* memory,
                      const float* h_q, int ld_hq, const float* ada_std, const float* ada_mean,
                      float* h_adapt, int Q,
                      int B, int L, int A, int E, int F, int K, void* stream);
-/* same step with the context written in T16 (ctx_t16) and/or natural (ctx) layout; no AdaIN
- * (the decode loop fuses it into the query LSTM epilogue) */
+/* same step with the context written to up to 3 T16 destinations (and optionally natural); no
+ * AdaIN (the decode loop fuses it into the query LSTM epilogue) */
 int st_attn_step_t16_fwd(const float* pq, const float* pm, const float* memory,
                          const float* w_prev, int ld_wprev, const float* w_cum_prev,
                          float* w_out, int ld_wout, float* w_cum_out,
                          const float* loc_conv_w, const float* loc_lin_w, const float* v,
-                         float* ctx_t16, float* ctx, int ld_ctx,
+                         const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
                          int B, int L, int A, int E, int F, int K, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
@@ -253,6 +272,10 @@ typedef struct st_decoder_weights {
 
 typedef struct st_decoder_dims {
     int B, L, E, n_mels, r, P, Q, D, A, F, K;
+    /* fuse_pre0 != 0 (free-running inference only: every next input is prenet(own output)):
+     * projgate_w/_b carry P extra rows  W_pre0 . W_proj  /  W_pre0 . b_proj, so the proj/gate launch
+     * also emits relu(prenet layer 1) of the next step (same function, re-associated in fp32). */
+    int fuse_pre0;
 } st_decoder_dims;
 
 typedef struct st_decoder_io {
@@ -278,22 +301,28 @@ typedef struct st_decoder_io {
     float* stop_out;          /* (B, steps*r)         */
     /* packed weights: st_decoder_packed_floats() floats, filled by st_decoder_pack() */
     const float* packed;
-    /* tapes.  hq/hd/ctx/decin/hadapt are T16-tiled, (steps+1) [hadapt: steps] slots of
-     * st_t16_floats(B, dim) floats each, handed in ZERO-FILLED; cq/cd/wcum are natural
-     * (steps+1, B, dim).  Slot 0 = initial zero state, slot t+1 = state after step t. */
-    float* hq_tape; float* cq_tape; float* hd_tape; float* cd_tape;   /* Q,Q,D,D */
-    float* ctx_tape; float* wcum_tape;                               /* E, L    */
-    float* hadapt_tape;       /* steps slots, T16 (B,Q) */
-    float* decin_tape;        /* steps+1 slots, T16 (B,P): slot t = dec_in of step t (slot 0 zeros) */
+    /* tapes.  The step inputs live in three T16 buffers per step, handed in ZERO-FILLED:
+     *   xq_tape: steps+1 slots of T16 (B, P+E+Q)  slot t = [dec_in_t | ctx_{t-1} | h_q_{t-1}]
+     *   xd_tape: steps+1 slots of T16 (B, E+Q+D)  slot t = [ctx_t | adapted h_q_t | h_d_{t-1}]
+     *   xo_tape: steps   slots of T16 (B, D+E)    slot t = [h_d_t | ctx_t]
+     * (each logical piece padded to a multiple of 16 columns; slot size = st_t16_floats(B, padded sum)).
+     * cq/cd/wcum are natural (steps+1, B, dim); slot 0 = initial zero state. */
+    float* xq_tape; float* xd_tape; float* xo_tape;
+    float* cq_tape; float* cd_tape; float* wcum_tape;
     float* pq_buf;            /* (B, A) scratch, natural */
     float* pre1_t16;          /* T16 (B,P) scratch (prenet layer-1 output), zero-filled */
     float* mel_t16;           /* T16 (B, r*n_mels) scratch (own output as the prenet input), zero-filled */
     float* zero_row;          /* (B, max(L,1)) zeros (w_prev of step 0) -- zeroed by the callee */
+    /* two-stream overlap: (B, 4Q) and (B, 4D) scratch for the early partial gate sums; overlap != 0
+     * runs the early part of both LSTM cells on the library's auxiliary stream */
+    float* preq_buf; float* pred_buf; int overlap;
     float* gates_q_tape;      /* (steps, B, 4, Q) or NULL (training) */
     float* gates_d_tape;      /* (steps, B, 4, D) or NULL */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);
+/* floats of ONE slot of xq_tape (which = 0), xd_tape (1), xo_tape (2) */
+size_t st_decoder_tape_floats(const st_decoder_dims* d, int which);
 /* pack the six matrices the loop streams every step (once per forward / per weight update) */
 int st_decoder_pack(const st_decoder_weights* w, const st_decoder_dims* d, float* packed, void* stream);
 int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io,

@@ -17,8 +17,8 @@ class StSeg(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('ldx', C.c_int), ('ldw', C.c_int), ('k', C.c_int)]
 
 
-class StPSeg(C.Structure):
-    _fields_ = [('x_t16', C.c_void_p), ('k', C.c_int)]
+class StT16View(C.Structure):
+    _fields_ = [('base', C.c_void_p), ('kb_stride', C.c_int), ('kb0', C.c_int)]
 
 
 class StGemmEpilogue(C.Structure):
@@ -38,7 +38,7 @@ class StDecoderWeights(C.Structure):
 
 
 class StDecoderDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('B', 'L', 'E', 'n_mels', 'r', 'P', 'Q', 'D', 'A', 'F', 'K')]
+    _fields_ = [(n, C.c_int) for n in ('B', 'L', 'E', 'n_mels', 'r', 'P', 'Q', 'D', 'A', 'F', 'K', 'fuse_pre0')]
 
 
 class StDecoderIO(C.Structure):
@@ -49,10 +49,10 @@ class StDecoderIO(C.Structure):
                 ('steps', C.c_int),
                 ('mel_out', C.c_void_p), ('align_out', C.c_void_p), ('stop_out', C.c_void_p),
                 ('packed', C.c_void_p),
-                ('hq_tape', C.c_void_p), ('cq_tape', C.c_void_p), ('hd_tape', C.c_void_p), ('cd_tape', C.c_void_p),
-                ('ctx_tape', C.c_void_p), ('wcum_tape', C.c_void_p), ('hadapt_tape', C.c_void_p),
-                ('decin_tape', C.c_void_p), ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
-                ('zero_row', C.c_void_p),
+                ('xq_tape', C.c_void_p), ('xd_tape', C.c_void_p), ('xo_tape', C.c_void_p),
+                ('cq_tape', C.c_void_p), ('cd_tape', C.c_void_p), ('wcum_tape', C.c_void_p),
+                ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
+                ('zero_row', C.c_void_p), ('preq_buf', C.c_void_p), ('pred_buf', C.c_void_p), ('overlap', C.c_int),
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p)]
 
 
@@ -89,12 +89,16 @@ SIGNATURES = {
     'st_packed_weight_floats': [C.POINTER(I), I, I, I],
     'st_t16_floats': [I, I],
     'st_pack_weight': [C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, I, P, P],
-    'st_tile_rows': [P, I, P, I, I, P],
-    'st_untile_rows': [P, P, I, I, I, P],
-    'st_lstm_cell_packed_fwd': [P, C.POINTER(StPSeg), I, P, P, P, I, P, I, P, P, P, I, P, P, P, P, I, I, P],
-    'st_skinny_linear_packed_fwd': [P, C.POINTER(StPSeg), I, P, I, P, I, P, I, P, I, P, I, I, I, I, P],
-    'st_attn_step_t16_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    'st_tile_rows': [P, I, C.POINTER(StT16View), I, I, P],
+    'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
+    'st_lstm_gates_partial_packed_fwd': [P, I, I, C.POINTER(StT16View), I, P, I, I, I, P],
+    'st_lstm_cell_packed_fwd': [P, I, I, C.POINTER(StT16View), I, P, P, P, I, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
+                                P, I, P, P, P, C.POINTER(StT16View), I, I, P],
+    'st_skinny_linear_packed_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
+                                    I, I, P, I, C.POINTER(StT16View), I, I, P],
+    'st_attn_step_t16_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
+    'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],
     'st_decoder_forward': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderIO), P],
     'st_fill': [P, F, Z, P],
@@ -102,7 +106,7 @@ SIGNATURES = {
     'st_mean_rows': [P, P, I, I, I, P],
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
-             'st_decoder_packed_floats': C.c_size_t}
+             'st_decoder_packed_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t}
 
 _lib = None
 

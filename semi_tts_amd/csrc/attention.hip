@@ -17,6 +17,10 @@
 // the kernel reads pm (L*A*4 B) + memory (L*E*4 B) exactly once.
 #include "st_common.h"
 
+#ifndef AT_PROF
+#define AT_PROF(n)   // phase timestamps, only defined by tools/mb/mb_attn.hip
+#endif
+
 namespace {
 
 constexpr int AT_THREADS = 512;
@@ -24,19 +28,20 @@ constexpr int AT_WAVES = AT_THREADS / 64;
 constexpr int AT_PF = 12;   // encoder-memory rows prefetched into registers per thread
 constexpr int AT_LB = 8;    // positions per wave in the energy phase
 constexpr int AT_CB = 4;    // positions per thread in the conv phase
+constexpr int AT_WLPF = 4;  // float4 pieces of W_l each thread parks in registers during the conv
 
 struct AtArgs {
     const float* pq; const float* pm; const float* memory;
     const float* w_prev; int ld_wprev; const float* w_cum_prev;
     float* w_out; int ld_wout; float* w_cum_out;
     const float* loc_conv_w; const float* loc_lin_w; const float* v;
-    float* ctx; int ld_ctx; float* ctx_t16;
+    float* ctx; int ld_ctx; st_t16_view ctx_dst[3];
     const float* h_q; int ld_hq; const float* ada_std; const float* ada_mean; float* h_adapt; int Q;
     int B, L, A, E, F, K;
 };
 
 struct AtLds {  // offsets in floats into dynamic LDS
-    int wt, wt_ld, wc, hs, hl, cf, cf_ld, e, part, total;
+    int wt, wt_ld, wc, kp, hs, hl, cf, cf_ld, e, part, total;
 };
 
 __host__ __device__ inline AtLds at_layout(int L, int A, int E, int F, int K) {
@@ -44,8 +49,9 @@ __host__ __device__ inline AtLds at_layout(int L, int A, int E, int F, int K) {
     int p = 0;
     o.wt_ld = ((A + 3) & ~3) + 4;               // row stride of W_l^T: +4 spreads the transposing stores
     o.wt = p; p += F * o.wt_ld;
-    o.wc = p; p += ((F * 2 * K + 3) & ~3);      // loc_conv [f][c][k]
-    o.hl = ((L + AT_CB + K - 1) + 3) & ~3;      // padded history length per channel
+    o.kp = K <= 32 ? 32 : ((K + 3) & ~3);       // filter rows padded so they can be read as float4
+    o.wc = p; p += F * 2 * o.kp;                // loc_conv [f][c][kp]
+    o.hl = ((L + AT_CB + o.kp + 3) + 3) & ~3;   // padded history length per channel (window of kp + 4)
     o.hs = p; p += 2 * o.hl;
     o.cf_ld = ((L + AT_LB - 1) / AT_LB) * AT_LB; // conv features [f][l], l padded to the wave block
     o.cf = p; p += F * o.cf_ld;
@@ -55,10 +61,18 @@ __host__ __device__ inline AtLds at_layout(int L, int A, int E, int F, int K) {
     return o;
 }
 
+// tanh from one v_exp_f32 and one fast reciprocal: |error| <= ~2e-7 absolute (the energies feed a
+// softmax whose outputs are compared at 1e-5; the accurate tanhf costs ~10x more and was 50% of the kernel)
+__device__ __forceinline__ float at_tanh(float x) {
+    const float t = __expf(-2.0f * fabsf(x));
+    return copysignf(__fdividef(1.0f - t, 1.0f + t), x);
+}
+
 __device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
     return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,6 +87,7 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
     float* part = lds + o.part;
     const int pad = (K - 1) / 2;
 
+    AT_PROF(0);
     // ---- P0a: context prefetch (memory rows l = g, g+ng, ...)
     const int ne4 = E >> 2;                    // E % 4 == 0 checked on the host
     const int ng = AT_THREADS / ne4;           // row groups (>= 1 checked on the host)
@@ -86,22 +101,25 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
         mpf[j] = (ctx_active && l < L) ? st_ld4(memb + (size_t)l * E + e4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- P0b: staging.  W_l (A,F) is read coalesced along f and stored transposed [f][a]
-    if ((F & 3) == 0 && st_aligned16(a.loc_lin_w)) {
-        const int f4n = F >> 2;
-        for (int idx = tid; idx < A * f4n; idx += AT_THREADS) {
-            const int aa = idx / f4n, f0 = (idx - aa * f4n) * 4;
-            const f32x4 w4 = st_ld4(a.loc_lin_w + (size_t)aa * F + f0);
-            Wt[(f0 + 0) * o.wt_ld + aa] = w4[0]; Wt[(f0 + 1) * o.wt_ld + aa] = w4[1];
-            Wt[(f0 + 2) * o.wt_ld + aa] = w4[2]; Wt[(f0 + 3) * o.wt_ld + aa] = w4[3];
-        }
-    } else {
-        for (int idx = tid; idx < A * F; idx += AT_THREADS) {
-            const int aa = idx / F, f = idx - aa * F;
-            Wt[f * o.wt_ld + aa] = a.loc_lin_w[idx];
+    AT_PROF(1);
+    // ---- P0b: W_l (A,F) is fetched now (coalesced along f) and parked in registers; it is only
+    // needed by P2, so its transposing LDS stores happen after the conv
+    const bool wl_vec = VEC || ((F & 3) == 0 && st_aligned16(a.loc_lin_w));
+    const int f4n = F >> 2;
+    f32x4 wl4[AT_WLPF];
+    if (wl_vec) {
+#pragma unroll
+        for (int j = 0; j < AT_WLPF; ++j) {
+            const int idx = tid + j * AT_THREADS;
+            wl4[j] = idx < A * f4n ? st_ld4(a.loc_lin_w + (size_t)idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    for (int idx = tid; idx < F * 2 * K; idx += AT_THREADS) Wc[idx] = a.loc_conv_w[idx];
+    // conv filters [f][c][KP] (rows padded to KP so they can be read as float4) and padded history
+    const int KP = o.kp;
+    for (int idx = tid; idx < F * 2 * KP; idx += AT_THREADS) {
+        const int row = idx / KP, k = idx - row * KP;
+        Wc[idx] = k < K ? a.loc_conv_w[row * K + k] : 0.0f;
+    }
     for (int idx = tid; idx < 2 * o.hl; idx += AT_THREADS) {
         const int c = idx / o.hl, p = idx - c * o.hl;
         const int l = p - pad;
@@ -115,7 +133,9 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
             a.h_adapt[q] = a.ada_std[q] * (a.h_q[(size_t)b * a.ld_hq + j] - a.ada_mean[q]);
         }
     }
+    AT_PROF(2);
     __syncthreads();
+    AT_PROF(3);
 
     // ---- P1: location conv, cf[f][l] = sum_c sum_k Wc[f][c][k] * hist[c][l + k - pad]
     {
@@ -123,17 +143,37 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
         for (int idx = tid; idx < F * nlb; idx += AT_THREADS) {
             const int f = idx / nlb, l0 = (idx - f * nlb) * AT_CB;
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            for (int c = 0; c < 2; ++c) {
-                const float* h = hs + c * o.hl + l0;
-                const float* w = Wc + (f * 2 + c) * K;
-                float h0 = h[0], h1 = h[1], h2 = h[2];
+            if (KP == 32) {
+                // K <= 32: filters and history window are pulled with ds_read_b128 (8 + 9 per channel)
+                // up front, then 32 x 4 FMAs run out of registers
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x4* hq = reinterpret_cast<const f32x4*>(hs + c * o.hl + l0);
+                    const f32x4* wq = reinterpret_cast<const f32x4*>(Wc + (f * 2 + c) * 32);
+                    float h[36], w[32];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) { const f32x4 t = hq[j]; h[4 * j] = t[0]; h[4 * j + 1] = t[1]; h[4 * j + 2] = t[2]; h[4 * j + 3] = t[3]; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const f32x4 t = wq[j]; w[4 * j] = t[0]; w[4 * j + 1] = t[1]; w[4 * j + 2] = t[2]; w[4 * j + 3] = t[3]; }
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) {
+                        acc0 = fmaf(w[k], h[k], acc0); acc1 = fmaf(w[k], h[k + 1], acc1);
+                        acc2 = fmaf(w[k], h[k + 2], acc2); acc3 = fmaf(w[k], h[k + 3], acc3);
+                    }
+                }
+            } else {
+                for (int c = 0; c < 2; ++c) {
+                    const float* h = hs + c * o.hl + l0;
+                    const float* w = Wc + (f * 2 + c) * KP;
+                    float h0 = h[0], h1 = h[1], h2 = h[2];
 #pragma unroll 8
-                for (int k = 0; k < K; ++k) {
-                    const float h3 = h[k + 3];
-                    const float wk = w[k];
-                    acc0 = fmaf(wk, h0, acc0); acc1 = fmaf(wk, h1, acc1);
-                    acc2 = fmaf(wk, h2, acc2); acc3 = fmaf(wk, h3, acc3);
-                    h0 = h1; h1 = h2; h2 = h3;
+                    for (int k = 0; k < K; ++k) {
+                        const float h3 = h[k + 3];
+                        const float wk = w[k];
+                        acc0 = fmaf(wk, h0, acc0); acc1 = fmaf(wk, h1, acc1);
+                        acc2 = fmaf(wk, h2, acc2); acc3 = fmaf(wk, h3, acc3);
+                        h0 = h1; h1 = h2; h2 = h3;
+                    }
                 }
             }
             float* dst = cf + f * o.cf_ld + l0;   // cf_ld is padded, stores beyond L are harmless
@@ -143,26 +183,60 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
             if (l0 + 3 < o.cf_ld) dst[3] = acc3;
         }
     }
+    // W_l^T into LDS: Wt[f][a] (row stride wt_ld = A4 + 4 spreads the transposing stores over banks)
+    if (wl_vec) {
+#pragma unroll
+        for (int j = 0; j < AT_WLPF; ++j) {
+            const int idx = tid + j * AT_THREADS;
+            if (idx < A * f4n) {
+                const int aa = idx / f4n, f0 = (idx - aa * f4n) * 4;
+                Wt[(f0 + 0) * o.wt_ld + aa] = wl4[j][0]; Wt[(f0 + 1) * o.wt_ld + aa] = wl4[j][1];
+                Wt[(f0 + 2) * o.wt_ld + aa] = wl4[j][2]; Wt[(f0 + 3) * o.wt_ld + aa] = wl4[j][3];
+            }
+        }
+        for (int idx = tid + AT_WLPF * AT_THREADS; idx < A * f4n; idx += AT_THREADS) {
+            const int aa = idx / f4n, f0 = (idx - aa * f4n) * 4;
+            const f32x4 w4 = st_ld4(a.loc_lin_w + (size_t)idx * 4);
+            Wt[(f0 + 0) * o.wt_ld + aa] = w4[0]; Wt[(f0 + 1) * o.wt_ld + aa] = w4[1];
+            Wt[(f0 + 2) * o.wt_ld + aa] = w4[2]; Wt[(f0 + 3) * o.wt_ld + aa] = w4[3];
+        }
+    } else {
+        for (int idx = tid; idx < A * F; idx += AT_THREADS) {
+            const int aa = idx / F, f = idx - aa * F;
+            Wt[f * o.wt_ld + aa] = a.loc_lin_w[idx];
+        }
+    }
+    AT_PROF(4);
     __syncthreads();
+    AT_PROF(5);
 
     // ---- P2: energies; a wave owns AT_LB consecutive positions, a lane 4 consecutive dims
     const float* pmb = a.pm + (size_t)b * L * A;
     const float* pqb = a.pq + (size_t)b * A;
-    const bool vecA = (A & 3) == 0;
     for (int l0 = wave * AT_LB; l0 < L; l0 += AT_WAVES * AT_LB) {
         float esum[AT_LB];
 #pragma unroll
         for (int j = 0; j < AT_LB; ++j) esum[j] = 0.0f;
         for (int a0 = lane * 4; a0 < A; a0 += 256) {
             const int rem = A - a0;
-            f32x4 pm4[AT_LB];
+            f32x4 pm4[AT_LB], pq4, v4;
+            if (VEC) {          // A % 4 == 0 and aligned operands: plain 16-byte loads, no per-lane branches
 #pragma unroll
-            for (int j = 0; j < AT_LB; ++j) {
-                const int l = l0 + j < L ? l0 + j : L - 1;
-                pm4[j] = (vecA && rem >= 4) ? st_ld4(pmb + (size_t)l * A + a0) : st_ld4_guard(pmb + (size_t)l * A + a0, rem);
+                for (int j = 0; j < AT_LB; ++j) {
+                    const int l = l0 + j < L ? l0 + j : L - 1;
+                    pm4[j] = st_ld4(pmb + (size_t)l * A + a0);
+                }
+                pq4 = st_ld4(pqb + a0);
+                v4 = st_ld4(a.v + a0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < AT_LB; ++j) {
+                    const int l = l0 + j < L ? l0 + j : L - 1;
+                    pm4[j] = st_ld4_guard(pmb + (size_t)l * A + a0, rem);
+                }
+                pq4 = st_ld4_guard(pqb + a0, rem);
+                v4 = st_ld4_guard(a.v + a0, rem);   // zero beyond A: those dims add nothing below
             }
-            const f32x4 pq4 = (vecA && rem >= 4) ? st_ld4(pqb + a0) : st_ld4_guard(pqb + a0, rem);
-            const f32x4 v4 = (vecA && rem >= 4) ? st_ld4(a.v + a0) : st_ld4_guard(a.v + a0, rem);
             f32x4 loc[AT_LB];
 #pragma unroll
             for (int j = 0; j < AT_LB; ++j) loc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -183,18 +257,41 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     // (processed_query + processed_loc_feat) + processed_memory, module.py:389-390
-                    const float t = tanhf((pq4[c] + loc[j][c]) + pm4[j][c]);
-                    esum[j] = fmaf(v4[c], c < rem ? t : 0.0f, esum[j]);
+                    float t = at_tanh((pq4[c] + loc[j][c]) + pm4[j][c]);
+                    if (!VEC) t = c < rem ? t : 0.0f;   // W_l^T pad columns hold garbage
+                    esum[j] = fmaf(v4[c], t, esum[j]);
                 }
             }
         }
+        // 8 sums over 64 lanes with 10 shuffles: each butterfly step also halves the number of
+        // values a lane carries (instead of 8 independent 6-step reductions)
+        static_assert(AT_LB == 8, "the folded reduction below is written for 8 positions per wave");
+        {
+            const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0, hi8 = (lane & 8) != 0;
+            float r4[4], r2[2];
 #pragma unroll
-        for (int j = 0; j < AT_LB; ++j) {
-            const float s = st_wave_sum(esum[j]);
-            if (lane == 0 && l0 + j < L) es[l0 + j] = s;
+            for (int j = 0; j < 4; ++j) {
+                const float send = hi32 ? esum[j] : esum[j + 4];
+                const float keep = hi32 ? esum[j + 4] : esum[j];
+                r4[j] = keep + __shfl_xor(send, 32, 64);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float send = hi16 ? r4[j] : r4[j + 2];
+                const float keep = hi16 ? r4[j + 2] : r4[j];
+                r2[j] = keep + __shfl_xor(send, 16, 64);
+            }
+            float r = (hi8 ? r2[1] : r2[0]) + __shfl_xor(hi8 ? r2[0] : r2[1], 8, 64);
+            r += __shfl_xor(r, 4, 64);
+            r += __shfl_xor(r, 2, 64);
+            r += __shfl_xor(r, 1, 64);
+            const int l = l0 + (lane >> 3);      // bits 5,4,3 of the lane select the position
+            if ((lane & 7) == 0 && l < L) es[l] = r;
         }
     }
+    AT_PROF(6);
     __syncthreads();
+    AT_PROF(7);
 
     // ---- P3: softmax over L (wave 0), write alignment and cumulative weights
     if (wave == 0) {
@@ -215,7 +312,9 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
             a.w_cum_out[(size_t)b * L + l] = w + hs[o.hl + pad + l];   // weights + attn_weights_sum, :264
         }
     }
+    AT_PROF(8);
     __syncthreads();
+    AT_PROF(9);
 
     // ---- P4: context
     if (ctx_active) {
@@ -237,14 +336,18 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
         }
         *reinterpret_cast<f32x4*>(part + (size_t)(g * ne4 + e4) * 4) = acc;
     }
+    AT_PROF(10);
     __syncthreads();
-    const int EKB = (E + 15) >> 4;
+    AT_PROF(11);
     for (int e = tid; e < E; e += AT_THREADS) {
         float s = 0.0f;
         for (int gg = 0; gg < ng; ++gg) s += part[gg * E + e];
         if (a.ctx) a.ctx[(size_t)b * a.ld_ctx + e] = s;
-        if (a.ctx_t16) a.ctx_t16[at_t16_off(b, e, EKB)] = s;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (a.ctx_dst[d].base) a.ctx_dst[d].base[at_t16_off(b, a.ctx_dst[d].kb0 * 16 + e, a.ctx_dst[d].kb_stride)] = s;
     }
+    AT_PROF(12);
 }
 
 int at_launch(const AtArgs& a, hipStream_t stream) {
@@ -254,18 +357,23 @@ int at_launch(const AtArgs& a, hipStream_t stream) {
     ST_CHECK_ARG(st_aligned16(a.memory), "attention step: memory must be 16-byte aligned");
     ST_CHECK_ARG((a.A % 4 != 0) || (st_aligned16(a.pm) && st_aligned16(a.pq) && st_aligned16(a.v)),
                  "attention step: pm/pq/v must be 16-byte aligned");
-    ST_CHECK_ARG(a.ctx || a.ctx_t16, "attention step: no context output");
+    ST_CHECK_ARG(a.ctx || a.ctx_dst[0].base, "attention step: no context output");
     ST_CHECK_ARG(!a.h_q || (a.ada_std && a.ada_mean && a.h_adapt), "attention step: AdaIN pointers");
     const AtLds o = at_layout(a.L, a.A, a.E, a.F, a.K);
     const size_t lds_bytes = (size_t)o.total * sizeof(float);
     ST_CHECK_ARG(lds_bytes <= 160 * 1024, "attention step: L=%d needs %zu B of LDS (> 160 KiB)", a.L, lds_bytes);
+    const bool vec = (a.A % 4 == 0) && (a.F % 4 == 0) && st_aligned16(a.pm) && st_aligned16(a.pq) && st_aligned16(a.v) &&
+                     st_aligned16(a.loc_lin_w);
     static bool configured = false;
     if (!configured) {
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel),
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    hipLaunchKernelGGL(at_kernel, dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
+    if (vec) hipLaunchKernelGGL(at_kernel<true>, dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
+    else hipLaunchKernelGGL(at_kernel<false>, dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -291,19 +399,21 @@ extern "C" int st_attn_step_fwd(const float* pq, const float* pm, const float* m
     return at_launch(a, (hipStream_t)stream);
 }
 
-// decode-loop variant: context written in the tiled T16 layout (and optionally natural)
+// decode-loop variant: context written to up to 3 T16 destinations (and optionally natural)
 extern "C" int st_attn_step_t16_fwd(const float* pq, const float* pm, const float* memory,
                                     const float* w_prev, int ld_wprev, const float* w_cum_prev,
                                     float* w_out, int ld_wout, float* w_cum_out,
                                     const float* loc_conv_w, const float* loc_lin_w, const float* v,
-                                    float* ctx_t16, float* ctx, int ld_ctx,
+                                    const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
                                     int B, int L, int A, int E, int F, int K, void* stream) {
     (void)hipGetLastError();
+    ST_CHECK_ARG(n_ctx_dst >= 0 && n_ctx_dst <= 3 && (n_ctx_dst == 0 || ctx_dst), "st_attn_step_t16_fwd: n_ctx_dst=%d", n_ctx_dst);
     AtArgs a;
     memset(&a, 0, sizeof(a));
     a.pq = pq; a.pm = pm; a.memory = memory; a.w_prev = w_prev; a.ld_wprev = ld_wprev; a.w_cum_prev = w_cum_prev;
     a.w_out = w_out; a.ld_wout = ld_wout; a.w_cum_out = w_cum_out;
-    a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx; a.ctx_t16 = ctx_t16;
+    a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx;
+    for (int d = 0; d < n_ctx_dst; ++d) a.ctx_dst[d] = ctx_dst[d];
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
     return at_launch(a, (hipStream_t)stream);
 }

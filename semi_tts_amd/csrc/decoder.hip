@@ -4,7 +4,7 @@
 // Once per forward the six weight matrices the loop streams every step are packed into MFMA
 // lane order (skinny_packed.hip, "P16"); all per-step activations live in the tiled "T16"
 // layout, written that way by their producers.  Per step the loop enqueues, in dependency order:
-//   1. query LSTM cell      x = [dec_in | ctx_{t-1} | h_q], fused AdaIN of the new h_q
+//   1. query LSTM cell      x = [dec_in | ctx_{t-1} | h_q] (ONE tiled buffer per step), fused AdaIN of the new h_q
 //   2. query projection     pq = W_q h_q
 //   3. attention step       energies, softmax, context, cumulative weights   (attention.hip)
 //   4. decoder LSTM cell    x = [ctx_t | adapted h_q | h_d]
@@ -32,29 +32,66 @@ PackedLayout packed_layout(const st_decoder_dims* d) {
     { int k[3] = {d->P, d->E, d->Q}; o.q = p; p += st_packed_weight_floats(k, 3, 4 * d->Q, d->Q); }
     { int k[1] = {d->Q}; o.pq = p; p += st_packed_weight_floats(k, 1, d->A, 0); }
     { int k[3] = {d->E, d->Q, d->D}; o.d = p; p += st_packed_weight_floats(k, 3, 4 * d->D, d->D); }
-    { int k[2] = {d->D, d->E}; o.pg = p; p += st_packed_weight_floats(k, 2, in_dim + 1, 0); }
+    { int k[2] = {d->D, d->E}; o.pg = p; p += st_packed_weight_floats(k, 2, in_dim + 1 + (d->fuse_pre0 ? d->P : 0), 0); }
     { int k[1] = {in_dim}; o.p0 = p; p += st_packed_weight_floats(k, 1, d->P, 0); }
     { int k[1] = {d->P}; o.p1 = p; p += st_packed_weight_floats(k, 1, d->P, 0); }
     o.total = p;
     return o;
 }
 
-int prenet_own(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io, const PackedLayout& pl,
-               int t, void* stream) {
+inline int kb16(int k) { return (k + 15) >> 4; }
+
+// second HIP stream + fork/join events of the decode loop (created once, lazily).  The early parts of
+// the two LSTM cells (everything but the input that is still being computed) stream their weights
+// there while the critical path runs the small kernels; under stream capture the event waits become
+// graph dependencies, so a hipGraph replay keeps the same overlap.
+struct Aux { hipStream_t s; hipEvent_t fork, e1, e2, f1, f2; bool ok; };
+Aux* aux_get() {
+    static Aux a = {};
+    if (!a.ok) {
+        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        hipEvent_t* ev[5] = {&a.fork, &a.e1, &a.e2, &a.f1, &a.f2};
+        for (auto e : ev)
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        a.ok = true;
+    }
+    return &a;
+}
+
+struct StepViews {   // k-block geometry of the three step-input buffers
+    int q_kbs, q_ctx, q_h;        // xq = [dec_in | ctx | h_q]
+    int d_kbs, d_ha, d_h;         // xd = [ctx | hadapt | h_d]
+    int o_kbs, o_ctx;             // xo = [h_d | ctx]
+    size_t q_floats, d_floats, o_floats;
+};
+
+StepViews step_views(const st_decoder_dims* d) {
+    StepViews v;
+    const int bt = (d->B + 15) >> 4;
+    v.q_ctx = kb16(d->P); v.q_h = v.q_ctx + kb16(d->E); v.q_kbs = v.q_h + kb16(d->Q);
+    v.d_ha = kb16(d->E); v.d_h = v.d_ha + kb16(d->Q); v.d_kbs = v.d_h + kb16(d->D);
+    v.o_ctx = kb16(d->D); v.o_kbs = v.o_ctx + kb16(d->E);
+    v.q_floats = (size_t)bt * v.q_kbs * 256; v.d_floats = (size_t)bt * v.d_kbs * 256; v.o_floats = (size_t)bt * v.o_kbs * 256;
+    return v;
+}
+
+int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLayout& pl, const StepViews& sv,
+               int t, bool layer1_done, void* stream) {
     // dec_in_{t+1} = prenet(mel_t) for every row                ref: src/module.py:192,:197-198,:205-206
     const int in_dim = d->r * d->n_mels;
     const size_t BP = (size_t)d->B * d->P;
-    const size_t tP = st_t16_floats(d->B, d->P);
     const float* m1 = io->prenet_mask ? io->prenet_mask + ((size_t)t * 2 + 0) * BP : nullptr;
     const float* m2 = io->prenet_mask ? io->prenet_mask + ((size_t)t * 2 + 1) * BP : nullptr;
-    st_pseg s1 = {io->mel_t16, in_dim};
-    int rc = st_skinny_linear_packed_fwd(io->packed + pl.p0, &s1, 1, nullptr, ST_ACT_RELU, m1, d->P,
-                                         nullptr, 0, io->pre1_t16, 0, nullptr, 0, 0, d->B, d->P, stream);
+    st_t16_view mel = {io->mel_t16, kb16(in_dim), 0};
+    st_t16_view pre1 = {io->pre1_t16, kb16(d->P), 0};
+    int rc = 0;
+    if (!layer1_done)
+        rc = st_skinny_linear_packed_fwd(io->packed + pl.p0, &mel, 16 * kb16(in_dim), nullptr, ST_ACT_RELU, m1, d->P,
+                                         nullptr, 0, &pre1, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
     if (rc) return rc;
-    st_pseg s2 = {io->pre1_t16, d->P};
-    return st_skinny_linear_packed_fwd(io->packed + pl.p1, &s2, 1, nullptr, ST_ACT_RELU, m2, d->P,
-                                       nullptr, 0, io->decin_tape + (size_t)(t + 1) * tP, 0, nullptr, 0, 0,
-                                       d->B, d->P, stream);
+    st_t16_view next = {io->xq_tape + (size_t)(t + 1) * sv.q_floats, sv.q_kbs, 0};
+    return st_skinny_linear_packed_fwd(io->packed + pl.p1, &pre1, 16 * kb16(d->P), nullptr, ST_ACT_RELU, m2, d->P,
+                                       nullptr, 0, &next, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
 }
 
 }  // namespace
@@ -82,13 +119,19 @@ extern "C" int st_decoder_pack(const st_decoder_weights* w, const st_decoder_dim
     {   // proj (+) gate: K = [h_d (D) | ctx (E)]                             ref: src/module.py:282-287
         const float* ws[2] = {w->projgate_w, w->projgate_w + d->D};
         int ld[2] = {d->D + d->E, d->D + d->E}, k[2] = {d->D, d->E};
-        if ((rc = st_pack_weight(ws, ld, k, 2, in_dim + 1, 0, packed + pl.pg, stream))) return rc;
+        if ((rc = st_pack_weight(ws, ld, k, 2, in_dim + 1 + (d->fuse_pre0 ? d->P : 0), 0, packed + pl.pg, stream))) return rc;
     }
     {   const float* ws[1] = {w->prenet_w0}; int ld[1] = {in_dim}, k[1] = {in_dim};
         if ((rc = st_pack_weight(ws, ld, k, 1, d->P, 0, packed + pl.p0, stream))) return rc; }
     {   const float* ws[1] = {w->prenet_w1}; int ld[1] = {d->P}, k[1] = {d->P};
         if ((rc = st_pack_weight(ws, ld, k, 1, d->P, 0, packed + pl.p1, stream))) return rc; }
     return 0;
+}
+
+extern "C" size_t st_decoder_tape_floats(const st_decoder_dims* d, int which) {
+    if (!d) return 0;
+    const StepViews sv = step_views(d);
+    return which == 0 ? sv.q_floats : (which == 1 ? sv.d_floats : sv.o_floats);
 }
 
 extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io,
@@ -102,96 +145,140 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     ST_CHECK_ARG(io->memory && io->pm && io->ada_std && io->ada_mean && io->step_src && io->packed,
                  "st_decoder_forward: null input");
     ST_CHECK_ARG(io->mel_out && io->align_out && io->stop_out, "st_decoder_forward: null output");
-    ST_CHECK_ARG(io->hq_tape && io->cq_tape && io->hd_tape && io->cd_tape && io->ctx_tape && io->wcum_tape &&
-                 io->hadapt_tape && io->decin_tape && io->pq_buf && io->pre1_t16 && io->mel_t16 && io->zero_row,
-                 "st_decoder_forward: null tape/scratch");
+    ST_CHECK_ARG(io->xq_tape && io->xd_tape && io->xo_tape && io->cq_tape && io->cd_tape && io->wcum_tape &&
+                 io->pq_buf && io->pre1_t16 && io->mel_t16 && io->zero_row, "st_decoder_forward: null tape/scratch");
     for (int t = 0; t + 1 < steps; ++t) {
         const int src = io->step_src[t];
+        ST_CHECK_ARG(!d->fuse_pre0 || src == -1, "st_decoder_forward: fuse_pre0 needs every next input to be the own output");
         ST_CHECK_ARG(src >= -2 && (src < 0 || (io->teacher_pre && src < io->Tt)), "st_decoder_forward: step_src[%d]=%d invalid", t, src);
         ST_CHECK_ARG(src != -2 || io->teacher_mean, "st_decoder_forward: step_src[%d]=-2 without teacher_mean", t);
         ST_CHECK_ARG(src == -1 || (io->Bt > 0 && io->Bt <= B), "st_decoder_forward: Bt=%d invalid", io->Bt);
     }
     hipStream_t st = (hipStream_t)stream;
     const PackedLayout pl = packed_layout(d);
+    const StepViews sv = step_views(d);
     const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
-    const size_t tQ = st_t16_floats(B, Q), tD = st_t16_floats(B, D), tE = st_t16_floats(B, E), tP = st_t16_floats(B, P);
-    // Tiled tapes must be zero wherever a pad lane/row lives: the CALLER hands them in zero-filled
-    // (torch.zeros); slot 0 (= initial zero state, src/module.py:290-303) is therefore already set.
+    // The tiled tapes are handed in zero-filled (torch.zeros): slot 0 of xq / the h_d part of xd slot 0
+    // are the initial zero state (src/module.py:290-303) and dec_in_0 = prenet(go frame) = 0 (:161,:183).
     ST_HIP(hipMemsetAsync(io->cq_tape, 0, BQ * sizeof(float), st));
     ST_HIP(hipMemsetAsync(io->cd_tape, 0, BD * sizeof(float), st));
     ST_HIP(hipMemsetAsync(io->wcum_tape, 0, BL * sizeof(float), st));
     ST_HIP(hipMemsetAsync(io->zero_row, 0, BL * sizeof(float), st));
-    ST_HIP(hipMemsetAsync(io->hq_tape, 0, tQ * sizeof(float), st));
-    ST_HIP(hipMemsetAsync(io->hd_tape, 0, tD * sizeof(float), st));
-    ST_HIP(hipMemsetAsync(io->ctx_tape, 0, tE * sizeof(float), st));
-    // dec_in of step 0 = prenet(go frame of zeros) = relu(0) * mask = 0     ref: :161,:183
-    ST_HIP(hipMemsetAsync(io->decin_tape, 0, tP * sizeof(float), st));
+    ST_HIP(hipMemsetAsync(io->xq_tape, 0, sv.q_floats * sizeof(float), st));
+    ST_HIP(hipMemsetAsync(io->xd_tape, 0, sv.d_floats * sizeof(float), st));
 
     const size_t ldmel = (size_t)steps * in_dim;
     const int ldal = steps * L;
+    const int Kq = 16 * sv.q_kbs, Kd = 16 * sv.d_kbs, Ko = 16 * sv.o_kbs;
+    const int kbP = sv.q_ctx, kbE = sv.d_ha;          // k-blocks of the late inputs (dec_in, ctx)
     int rc;
+    // overlap: split both LSTM cells into an early partial-gate launch on the aux stream and a late
+    // launch (late input + `pre` + cell update) on the caller's stream
+    Aux* ax = io->overlap && io->preq_buf && io->pred_buf ? aux_get() : nullptr;
+    const bool ov = ax != nullptr;
+    hipStream_t sb = ov ? ax->s : st;
+    if (ov) {
+        ST_HIP(hipMemsetAsync(io->preq_buf, 0, 4 * BQ * sizeof(float), st));   // step 0: ctx_{-1} = h_q_{-1} = 0
+        ST_HIP(hipEventRecord(ax->fork, st));
+        ST_HIP(hipStreamWaitEvent(sb, ax->fork, 0));
+    }
     for (int t = 0; t < steps; ++t) {
-        const float* decin = io->decin_tape + (size_t)t * tP;
-        const float* ctx_prev = io->ctx_tape + (size_t)t * tE;
-        float* ctx_new = io->ctx_tape + (size_t)(t + 1) * tE;
-        const float* hq_prev = io->hq_tape + (size_t)t * tQ;
-        float* hq_new = io->hq_tape + (size_t)(t + 1) * tQ;
-        const float* hd_prev = io->hd_tape + (size_t)t * tD;
-        float* hd_new = io->hd_tape + (size_t)(t + 1) * tD;
-        float* hadapt = io->hadapt_tape + (size_t)t * tQ;
+        float* xq = io->xq_tape + (size_t)t * sv.q_floats;
+        float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
+        float* xd = io->xd_tape + (size_t)t * sv.d_floats;
+        float* xd_next = io->xd_tape + (size_t)(t + 1) * sv.d_floats;
+        float* xo = io->xo_tape + (size_t)t * sv.o_floats;
 
         // 1. query LSTM (+ AdaIN of the new hidden state)                ref: :227-231, :267-269
-        st_pseg sq[3] = {{decin, P}, {ctx_prev, E}, {hq_prev, Q}};
-        rc = st_lstm_cell_packed_fwd(io->packed + pl.q, sq, 3, w->q_b_ih, w->q_b_hh, nullptr, 0,
+        //    h_q_t -> xq_{t+1}[h part] (next step's recurrent input, also the query projection's input)
+        //    adapted h_q_t -> xd_t[hadapt part]
+        st_t16_view xq_v = {xq, sv.q_kbs, 0};
+        st_t16_view hq_dst = {xq_next, sv.q_kbs, sv.q_h};
+        st_t16_view ha_dst = {xd, sv.d_kbs, sv.d_ha};
+        if (ov && t > 0) ST_HIP(hipStreamWaitEvent(st, ax->f2, 0));            // early part of this step is ready
+        rc = st_lstm_cell_packed_fwd(io->packed + pl.q, ov ? sv.q_kbs : 0, 0, &xq_v, ov ? 16 * kbP : Kq,
+                                     w->q_b_ih, w->q_b_hh, ov ? io->preq_buf : nullptr, 4 * Q,
                                      io->cq_tape + (size_t)t * BQ, Q, io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
-                                     hq_new, io->cq_tape + (size_t)(t + 1) * BQ, Q,
+                                     &hq_dst, nullptr, io->cq_tape + (size_t)(t + 1) * BQ, Q,
                                      io->gates_q_tape ? io->gates_q_tape + (size_t)t * 4 * BQ : nullptr,
-                                     io->ada_std, io->ada_mean, hadapt, B, Q, stream);
+                                     io->ada_std, io->ada_mean, &ha_dst, B, Q, stream);
         if (rc) return rc;
+        if (ov) {   // aux stream: early part of the decoder LSTM, x = [adapted h_q_t | h_d_{t-1}]
+            ST_HIP(hipEventRecord(ax->e1, st));
+            ST_HIP(hipStreamWaitEvent(sb, ax->e1, 0));
+            st_t16_view xd_early = {xd, sv.d_kbs, kbE};
+            rc = st_lstm_gates_partial_packed_fwd(io->packed + pl.d, sv.d_kbs, kbE, &xd_early, 16 * (sv.d_kbs - kbE),
+                                                  io->pred_buf, 4 * D, B, D, (void*)sb);
+            if (rc) return rc;
+            ST_HIP(hipEventRecord(ax->f1, sb));
+        }
 
         // 2. processed query                                             ref: :380
-        st_pseg sp = {hq_new, Q};
-        rc = st_skinny_linear_packed_fwd(io->packed + pl.pq, &sp, 1, nullptr, ST_ACT_NONE, nullptr, 0,
-                                         io->pq_buf, A, nullptr, 0, nullptr, 0, 0, B, A, stream);
+        rc = st_skinny_linear_packed_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
+                                         io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A, stream);
         if (rc) return rc;
 
         // 3. attention + state update                                    ref: :256-264, :371-407
+        //    ctx_t -> xq_{t+1}[ctx part], xd_t[ctx part], xo_t[ctx part]
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
+        st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
         rc = st_attn_step_t16_fwd(io->pq_buf, io->pm, io->memory, w_prev, t == 0 ? L : ldal,
                                   io->wcum_tape + (size_t)t * BL, io->align_out + (size_t)t * L, ldal,
                                   io->wcum_tape + (size_t)(t + 1) * BL,
-                                  w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v, ctx_new, nullptr, 0,
+                                  w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v, ctx_dst, 3, nullptr, 0,
                                   B, L, A, E, d->F, d->K, stream);
         if (rc) return rc;
 
-        // 4. decoder LSTM                                                ref: :275-280
-        st_pseg sd[3] = {{ctx_new, E}, {hadapt, Q}, {hd_prev, D}};
-        rc = st_lstm_cell_packed_fwd(io->packed + pl.d, sd, 3, w->d_b_ih, w->d_b_hh, nullptr, 0,
+        if (ov && t + 1 < steps) {   // aux stream: early part of the NEXT query LSTM, x = [ctx_t | h_q_t]
+            ST_HIP(hipEventRecord(ax->e2, st));
+            ST_HIP(hipStreamWaitEvent(sb, ax->e2, 0));
+            st_t16_view xq_early = {xq_next, sv.q_kbs, kbP};
+            rc = st_lstm_gates_partial_packed_fwd(io->packed + pl.q, sv.q_kbs, kbP, &xq_early, 16 * (sv.q_kbs - kbP),
+                                                  io->preq_buf, 4 * Q, B, Q, (void*)sb);
+            if (rc) return rc;
+            ST_HIP(hipEventRecord(ax->f2, sb));
+        }
+
+        // 4. decoder LSTM: h_d_t -> xd_{t+1}[h part], xo_t[h part]        ref: :275-280
+        st_t16_view xd_v = {xd, sv.d_kbs, 0};
+        st_t16_view hd_dst0 = {xd_next, sv.d_kbs, sv.d_h};
+        st_t16_view hd_dst1 = {xo, sv.o_kbs, 0};
+        if (ov) ST_HIP(hipStreamWaitEvent(st, ax->f1, 0));
+        rc = st_lstm_cell_packed_fwd(io->packed + pl.d, ov ? sv.d_kbs : 0, 0, &xd_v, ov ? 16 * kbE : Kd,
+                                     w->d_b_ih, w->d_b_hh, ov ? io->pred_buf : nullptr, 4 * D,
                                      io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
-                                     hd_new, io->cd_tape + (size_t)(t + 1) * BD, D,
+                                     &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                      io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
                                      nullptr, nullptr, nullptr, B, D, stream);
         if (rc) return rc;
 
-        // 5. mel frames + stop logit                                     ref: :282-287
-        st_pseg so[2] = {{hd_new, D}, {ctx_new, E}};
-        rc = st_skinny_linear_packed_fwd(io->packed + pl.pg, so, 2, w->projgate_b, ST_ACT_NONE, nullptr, 0,
-                                         io->mel_out + (size_t)t * in_dim, (int)ldmel, io->mel_t16, in_dim,
-                                         io->stop_out + (size_t)t * d->r, steps * d->r, d->r, B, in_dim + 1, stream);
+        // 5. mel frames + stop logit (+ prenet layer 1 of the next input when fused)   ref: :282-287
+        st_t16_view xo_v = {xo, sv.o_kbs, 0};
+        st_t16_view mel_dst = {io->mel_t16, kb16(in_dim), 0};
+        st_t16_view pre1_dst = {io->pre1_t16, kb16(P), 0};
+        const bool fuse = d->fuse_pre0 != 0;
+        rc = st_skinny_linear_packed_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
+                                         io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
+                                         io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
+                                         fuse ? in_dim + 1 : 0, ST_ACT_RELU,
+                                         io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
+                                         fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0), stream);
         if (rc) return rc;
 
-        // 6. next decoder input                                          ref: :190-206
+        // 6. next decoder input -> xq_{t+1}[dec_in part]                 ref: :190-206
         if (t + 1 < steps) {
             const int src = io->step_src[t];
-            float* next = io->decin_tape + (size_t)(t + 1) * tP;
+            st_t16_view next = {xq_next, sv.q_kbs, 0};
             if (src == -1 || io->Bt < B) {   // rows without a teacher feed their own output back
-                rc = prenet_own(w, d, io, pl, t, stream);
+                rc = prenet_own(d, io, pl, sv, t, fuse, stream);
                 if (rc) return rc;
             }
-            if (src >= 0) rc = st_tile_rows(io->teacher_pre + (size_t)src * P, io->Tt * P, next, io->Bt, P, stream);
-            else if (src == -2) rc = st_tile_rows(io->teacher_mean, P, next, io->Bt, P, stream);
+            if (src >= 0) rc = st_tile_rows(io->teacher_pre + (size_t)src * P, io->Tt * P, &next, io->Bt, P, stream);
+            else if (src == -2) rc = st_tile_rows(io->teacher_mean, P, &next, io->Bt, P, stream);
             if (rc) return rc;
         }
     }
+    // the aux stream has nothing pending that the caller's stream has not already waited for: its last
+    // launch (the early decoder-LSTM part of the last step) was joined by the f1 wait above
     return 0;
 }

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const PackArgs a) {
 }
 
 // natural (B, K) rows with stride ld  ->  tiled T16 (pads written as zero)
-__global__ __launch_bounds__(256) void tile_rows_kernel(const float* src, int ld, float* dst, int B, int K) {
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float* src, int ld, float* dst, int kbs, int kb0, int B, int K) {
     const int KB = pk_kb(K), BT = (B + 15) >> 4;
     const size_t total = (size_t)BT * KB * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -72,16 +72,15 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float* src, int ld
         if (rem > 1) v[1] = p[1];
         if (rem > 2) v[2] = p[2];
         if (rem > 3) v[3] = p[3];
-        reinterpret_cast<f32x4*>(dst)[idx] = v;
+        reinterpret_cast<f32x4*>(dst)[((size_t)bt * kbs + kb0 + kb) * 64 + lane] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void untile_rows_kernel(const float* src, float* dst, int ld, int B, int K) {
-    const int KB = pk_kb(K);
+__global__ __launch_bounds__(256) void untile_rows_kernel(const float* src, int kbs, int kb0, float* dst, int ld, int B, int K) {
     const size_t total = (size_t)B * K;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(idx / K), k = (int)(idx - (size_t)b * K);
-        const size_t off = (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
+        const size_t off = (((size_t)(b >> 4) * kbs + kb0 + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
         dst[(size_t)b * ld + k] = src[off];
     }
 }
@@ -92,38 +91,45 @@ __device__ __forceinline__ size_t t16_off(int b, int k, int KB) {
 }
 
 // ------------------------------------------------------------------------------ the kernel
+// One contiguous weight run (P16) times one contiguous activation run (a k-block range of a T16
+// buffer): the K loop is two pointer increments and TRIP*(1+NB) 1-KiB wave loads per group.
+struct PkOut { float* base; int kb_stride; int kb0; };   // a k-block range of a T16 buffer
+
 struct PkArgs {
-    const f32x4* w;                      // packed weights [tile][KB][64]
-    const f32x4* x[PK_MAXSEG]; int kb[PK_MAXSEG]; int nseg; int KB;   // tiled activations per segment
+    const f32x4* w; int w_kbs;           // packed weights [tile][w_kbs][64], pre-offset to the first k-block used
+    const f32x4* x; int x_kbs;           // activations: T16 buffer pre-offset to the first k-block; its k-block stride
+    int KB;                              // k-blocks to reduce over
     int B, N, H;
     // LSTM epilogue
     const float* b_ih; const float* b_hh; const float* pre; int ldpre;
     const float* c_prev; int ldc_prev; const float* mask;
-    float* h_t16; int h_kb; float* c_out; int ldc; float* gates_out;
-    const float* ada_std; const float* ada_mean; float* hadapt_t16;       // optional AdaIN of the new h
+    float* c_out; int ldc; float* gates_out;
+    PkOut h_dst[2];                                                        // tiled destinations of the new h
+    const float* ada_std; const float* ada_mean; PkOut ha_dst;             // optional AdaIN of the new h
     // linear epilogue
     const float* bias; int act; const float* lmask; int ldmask;
-    float* y; int ldy; float* y_t16; int y_kb; int n_split; float* y2; int ldy2; int rep;
+    float* y; int ldy; PkOut y_dst; int n_split; float* y2; int ldy2; int rep;
+    // optional third row range [n_split2, N): act2/mask2 applied, written to y3_dst (column n - n_split2)
+    int n_split2; int act2; const float* mask2; int ldmask2; PkOut y3_dst;
 };
+
+__device__ __forceinline__ void pk_store(const PkOut& d, int b, int k, float v) {
+    if (d.base) d.base[t16_off(b, d.kb0 * 16 + k, d.kb_stride)] = v;
+}
 
 template <int NB, int TRIP>
 struct PkRegs { f32x4 w[TRIP]; f32x4 x[TRIP][NB]; };
 
 template <int NB, int KW, int TRIP>
-__device__ __forceinline__ void pk_load(PkRegs<NB, TRIP>& r, const f32x4* wp, const f32x4* xp, int xKB, int kb, int nkb,
-                                        int bt0) {
+__device__ __forceinline__ void pk_load(PkRegs<NB, TRIP>& r, const f32x4* wp, const f32x4* xp, int x_kbs, int kb, int KB) {
 #pragma unroll
     for (int t = 0; t < TRIP; ++t) {
-        const int k = kb + t * KW;
-        if (k < nkb) {
-            r.w[t] = wp[(size_t)k * 64];
+        int k = kb + t * KW;
+        k = k < KB ? k : KB - 1;        // clamped duplicate; its weight is zeroed below
+        r.w[t] = wp[(size_t)k * 64];
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = xp[((size_t)(bt0 + bt) * xKB + k) * 64];
-        } else {   // beyond this segment: contributes nothing
-            r.w[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = xp[((size_t)bt * x_kbs + k) * 64];
+        if (kb + t * KW >= KB) r.w[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -138,7 +144,7 @@ __device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[N
                 acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.w[t][cc], r.x[t][bt][cc], acc[bt], 0, 0, 0);
 }
 
-// MODE 0: LSTM cell, MODE 1: linear
+// MODE 0: LSTM cell, MODE 1: linear, MODE 2: partial LSTM gate sums (no bias, no cell update)
 template <int MODE, int NB, int KW, int TRIP>
 __global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
     __shared__ f32x4 red[KW * NB * 64];
@@ -151,28 +157,50 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) acc[bt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // batch tiles beyond BT alias the last valid one (their results are discarded)
+    // batch tiles beyond BT alias the last valid ones (their results are discarded)
     const int bt_base = bt0 + NB <= BT ? bt0 : (BT >= NB ? BT - NB : 0);
-    const f32x4* wseg = a.w + (size_t)tile * a.KB * 64 + lane;
+    const int KB = a.KB;
+    const f32x4* wp = a.w + (size_t)tile * a.w_kbs * 64 + lane;
+    const f32x4* xp = a.x + (size_t)bt_base * a.x_kbs * 64 + lane;
     constexpr int STEP = KW * TRIP;
-    for (int s = 0; s < a.nseg; ++s) {
-        const int nkb = a.kb[s];
-        const f32x4* xp = a.x[s] + lane;
+    // epilogue operands of the threads that will run the epilogue: requested now, consumed after the
+    // K loop, so their latency is hidden behind the weight stream
+    const int eb = (bt_base + (tid >> 6)) * 16 + (lane & 15);
+    const bool e_on = tid < NB * 64 && eb < a.B && bt_base + (tid >> 6) >= bt0;
+    float e_b[4] = {0.f, 0.f, 0.f, 0.f}, e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
+    if (MODE == 0 && e_on) {
+        const int u = tile * 4 + (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (a.b_ih) e_b[r] += a.b_ih[r * a.H + u];
+            if (a.b_hh) e_b[r] += a.b_hh[r * a.H + u];
+            if (a.pre) e_b[r] += a.pre[(size_t)eb * a.ldpre + r * a.H + u];
+        }
+        if (a.c_prev) e_c = a.c_prev[(size_t)eb * a.ldc_prev + u];
+        if (a.mask) e_m = a.mask[(size_t)eb * a.H + u];
+        if (a.ha_dst.base) { e_s = a.ada_std[(size_t)eb * a.H + u]; e_mu = a.ada_mean[(size_t)eb * a.H + u]; }
+    }
+    if (MODE != 1) {   // bandwidth bound: double-buffered groups of TRIP k-blocks
         PkRegs<NB, TRIP> ra, rb;
         int kb = wave;
-        if (kb < nkb) pk_load<NB, KW, TRIP>(ra, wseg, xp, nkb, kb, nkb, bt_base);
-        while (kb < nkb) {
+        if (kb < KB) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb, KB);
+        while (kb < KB) {
             int kn = kb + STEP;
-            if (kn < nkb) pk_load<NB, KW, TRIP>(rb, wseg, xp, nkb, kn, nkb, bt_base);
+            if (kn < KB) pk_load<NB, KW, TRIP>(rb, wp, xp, a.x_kbs, kn, KB);
             pk_mma<NB, TRIP>(ra, acc);
             kb = kn;
-            if (kb >= nkb) break;
+            if (kb >= KB) break;
             kn = kb + STEP;
-            if (kn < nkb) pk_load<NB, KW, TRIP>(ra, wseg, xp, nkb, kn, nkb, bt_base);
+            if (kn < KB) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kn, KB);
             pk_mma<NB, TRIP>(rb, acc);
             kb = kn;
         }
-        wseg += (size_t)nkb * 64;
+    } else {           // latency bound (a handful of workgroups): the whole K of a wave in flight at once
+        for (int kb = wave; kb < KB; kb += STEP) {
+            PkRegs<NB, TRIP> ra;
+            pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb, KB);
+            pk_mma<NB, TRIP>(ra, acc);
+        }
     }
 
 #pragma unroll
@@ -189,29 +217,22 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
     const int b = (bt_base + btl) * 16 + (lane & 15);
     if (b >= a.B || bt_base + btl < bt0) return;    // aliased tiles: somebody else owns these rows
 
-    if (MODE == 0) {
+    if (MODE == 2) {
+        const int u = tile * 4 + (lane >> 4);
+        float* gp = a.gates_out + (size_t)b * a.ldpre + u;      // (B, 4H) pre-activation partials
+        gp[0] = s[0]; gp[a.H] = s[1]; gp[2 * a.H] = s[2]; gp[3 * a.H] = s[3];
+    } else if (MODE == 0) {
         const int H = a.H;
         const int u = tile * 4 + (lane >> 4);
-        float g[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = s[r];
-            if (a.b_ih) v += a.b_ih[r * H + u];
-            if (a.b_hh) v += a.b_hh[r * H + u];
-            if (a.pre) v += a.pre[(size_t)b * a.ldpre + r * H + u];
-            g[r] = v;
-        }
-        const float gi = st_sigmoid(g[0]), gf = st_sigmoid(g[1]), gg = tanhf(g[2]), go = st_sigmoid(g[3]);
-        const float cp = a.c_prev ? a.c_prev[(size_t)b * a.ldc_prev + u] : 0.0f;
-        const float c2 = gf * cp + gi * gg;
-        float h2 = go * tanhf(c2);
-        if (a.mask) h2 *= a.mask[(size_t)b * H + u];
+        const float gi = st_sigmoid(s[0] + e_b[0]), gf = st_sigmoid(s[1] + e_b[1]);
+        const float gg = tanhf(s[2] + e_b[2]), go = st_sigmoid(s[3] + e_b[3]);
+        const float c2 = gf * e_c + gi * gg;
+        const float h2 = go * tanhf(c2) * e_m;
         a.c_out[(size_t)b * a.ldc + u] = c2;
-        a.h_t16[t16_off(b, u, a.h_kb)] = h2;
-        if (a.hadapt_t16) {   // AdaIN: relu(W_s s + b) * (h - (W_m s + b))        ref: src/module.py:268-269
-            const size_t q = (size_t)b * H + u;
-            a.hadapt_t16[t16_off(b, u, a.h_kb)] = a.ada_std[q] * (h2 - a.ada_mean[q]);
-        }
+        pk_store(a.h_dst[0], b, u, h2);
+        pk_store(a.h_dst[1], b, u, h2);
+        // AdaIN: relu(W_s s + b) * (h - (W_m s + b))                        ref: src/module.py:268-269
+        if (a.ha_dst.base) pk_store(a.ha_dst, b, u, e_s * (h2 - e_mu));
         if (a.gates_out) {
             float* gp = a.gates_out + (size_t)b * 4 * H + u;
             gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
@@ -225,12 +246,16 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
             if (a.bias) v += a.bias[n];
             v = st_act(v, a.act);
             if (a.lmask) v *= a.lmask[(size_t)b * a.ldmask + n];
-            if (a.n_split > 0 && n >= a.n_split) {
+            if (a.n_split2 > 0 && n >= a.n_split2) {
+                v = st_act(v, a.act2);
+                if (a.mask2) v *= a.mask2[(size_t)b * a.ldmask2 + (n - a.n_split2)];
+                pk_store(a.y3_dst, b, n - a.n_split2, v);
+            } else if (a.n_split > 0 && n >= a.n_split) {
                 float* p = a.y2 + (size_t)b * a.ldy2 + (size_t)(n - a.n_split) * a.rep;
                 for (int j = 0; j < a.rep; ++j) p[j] = v;
             } else {
                 if (a.y) a.y[(size_t)b * a.ldy + n] = v;
-                if (a.y_t16) a.y_t16[t16_off(b, n, a.y_kb)] = v;
+                pk_store(a.y_dst, b, n, v);
             }
         }
     }
@@ -238,7 +263,10 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
 
 template <int MODE, int NB>
 int pk_launch(const PkArgs& a, int tiles, hipStream_t st) {
-    constexpr int KW = 8, TRIP = 2;
+    // LSTM: 256 workgroups stream 29-42 MB: 8 waves x 2 k-blocks, double buffered.
+    // linear: 16-32 workgroups, 0.25-3 MB: 8 waves x up to 6 k-blocks each, all in flight at once
+    // (1024-thread workgroups measured slower to start than they gain).
+    constexpr int KW = 8, TRIP = MODE != 1 ? 2 : (NB <= 2 ? 6 : 3);
     const int BT = (a.B + 15) >> 4;
     dim3 grid(tiles, (BT + NB - 1) / NB);
     hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a);
@@ -255,22 +283,28 @@ int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st) {
     return pk_launch<MODE, 4>(a, tiles, st);
 }
 
-int pk_fill(PkArgs& a, const float* packed_w, const st_pseg* segs, int nseg, const char* who) {
-    ST_CHECK_ARG(packed_w && segs && nseg >= 1 && nseg <= PK_MAXSEG, "%s: bad packed operands (nseg=%d)", who, nseg);
-    ST_CHECK_ARG(st_aligned16(packed_w), "%s: packed weights must be 16-byte aligned", who);
-    a.w = reinterpret_cast<const f32x4*>(packed_w);
-    a.nseg = nseg;
-    a.KB = 0;
-    for (int s = 0; s < nseg; ++s) {
-        ST_CHECK_ARG(segs[s].x_t16 && segs[s].k > 0 && st_aligned16(segs[s].x_t16), "%s: segment %d invalid", who, s);
-        a.x[s] = reinterpret_cast<const f32x4*>(segs[s].x_t16);
-        a.kb[s] = pk_kb(segs[s].k);
-        a.KB += a.kb[s];
-    }
+PkOut pk_out(const st_t16_view* v) {
+    PkOut o = {nullptr, 0, 0};
+    if (v && v->base) { o.base = v->base; o.kb_stride = v->kb_stride; o.kb0 = v->kb0; }
+    return o;
+}
+
+int pk_fill(PkArgs& a, const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K, const char* who) {
+    ST_CHECK_ARG(packed_w && x && x->base && K > 0, "%s: bad packed operands", who);
+    ST_CHECK_ARG(st_aligned16(packed_w) && st_aligned16(x->base), "%s: operands must be 16-byte aligned", who);
+    ST_CHECK_ARG(x->kb0 >= 0 && x->kb0 + pk_kb(K) <= x->kb_stride, "%s: k-block range [%d,%d) outside the T16 buffer (%d)",
+                 who, x->kb0, x->kb0 + pk_kb(K), x->kb_stride);
+    ST_CHECK_ARG(w_kb_stride == 0 || (w_kb0 >= 0 && w_kb0 + pk_kb(K) <= w_kb_stride), "%s: weight k-block range", who);
+    a.w = reinterpret_cast<const f32x4*>(packed_w) + (size_t)(w_kb_stride ? w_kb0 : 0) * 64;
+    a.w_kbs = w_kb_stride ? w_kb_stride : pk_kb(K);
+    a.x = reinterpret_cast<const f32x4*>(x->base) + (size_t)x->kb0 * 64;
+    a.x_kbs = x->kb_stride;
+    a.KB = pk_kb(K);
     return 0;
 }
 
 }  // namespace
+
 
 extern "C" size_t st_packed_weight_floats(const int* k, int nseg, int N, int lstm_H) {
     size_t KB = 0;
@@ -305,63 +339,90 @@ extern "C" int st_pack_weight(const float* const* w, const int* ldw, const int* 
     return 0;
 }
 
-extern "C" int st_tile_rows(const float* src, int ld, float* dst_t16, int B, int K, void* stream) {
+extern "C" int st_tile_rows(const float* src, int ld, const st_t16_view* dst, int B, int K, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(src && dst_t16 && B > 0 && K > 0 && ld >= K, "st_tile_rows: bad arguments");
+    ST_CHECK_ARG(src && dst && dst->base && B > 0 && K > 0 && ld >= K, "st_tile_rows: bad arguments");
+    ST_CHECK_ARG(dst->kb0 >= 0 && dst->kb0 + pk_kb(K) <= dst->kb_stride, "st_tile_rows: k-block range outside the buffer");
     const size_t total = (size_t)((B + 15) >> 4) * pk_kb(K) * 64;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(tile_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, dst_t16, B, K);
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, dst->base, dst->kb_stride,
+                       dst->kb0, B, K);
     ST_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int st_untile_rows(const float* src_t16, float* dst, int ld, int B, int K, void* stream) {
+extern "C" int st_untile_rows(const st_t16_view* src, float* dst, int ld, int B, int K, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(src_t16 && dst && B > 0 && K > 0 && ld >= K, "st_untile_rows: bad arguments");
+    ST_CHECK_ARG(src && src->base && dst && B > 0 && K > 0 && ld >= K, "st_untile_rows: bad arguments");
     const size_t total = (size_t)B * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(untile_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src_t16, dst, ld, B, K);
+    hipLaunchKernelGGL(untile_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src->base, src->kb_stride,
+                       src->kb0, dst, ld, B, K);
     ST_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_pseg* segs, int nseg,
+extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K,
                                        const float* b_ih, const float* b_hh, const float* pre, int ldpre,
                                        const float* c_prev, int ldc_prev, const float* mask,
-                                       float* h_out_t16, float* c_out, int ldc, float* gates_out,
-                                       const float* ada_std, const float* ada_mean, float* hadapt_t16,
+                                       const st_t16_view* h_dst0, const st_t16_view* h_dst1,
+                                       float* c_out, int ldc, float* gates_out,
+                                       const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
                                        int B, int H, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && h_out_t16 && c_out, "st_lstm_cell_packed_fwd: bad arguments");
-    ST_CHECK_ARG(!hadapt_t16 || (ada_std && ada_mean), "st_lstm_cell_packed_fwd: AdaIN pointers");
+    ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && c_out && h_dst0 && h_dst0->base, "st_lstm_cell_packed_fwd: bad arguments");
+    ST_CHECK_ARG(!(hadapt_dst && hadapt_dst->base) || (ada_std && ada_mean), "st_lstm_cell_packed_fwd: AdaIN pointers");
     PkArgs a;
     memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, segs, nseg, "st_lstm_cell_packed_fwd");
+    int rc = pk_fill(a, packed_w, w_kb_stride, w_kb0, x, K, "st_lstm_cell_packed_fwd");
     if (rc) return rc;
     a.B = B; a.N = 4 * H; a.H = H;
     a.b_ih = b_ih; a.b_hh = b_hh; a.pre = pre; a.ldpre = ldpre;
     a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
-    a.h_t16 = h_out_t16; a.h_kb = pk_kb(H); a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
-    a.ada_std = ada_std; a.ada_mean = ada_mean; a.hadapt_t16 = hadapt_t16;
+    a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
+    a.h_dst[0] = pk_out(h_dst0); a.h_dst[1] = pk_out(h_dst1);
+    a.ada_std = ada_std; a.ada_mean = ada_mean; a.ha_dst = pk_out(hadapt_dst);
     return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
 }
 
-extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_pseg* segs, int nseg,
+extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
                                            const float* bias, int act, const float* mask, int ldmask,
-                                           float* y, int ldy, float* y_t16, int n_split, float* y2, int ldy2, int rep,
+                                           float* y, int ldy, const st_t16_view* y_dst,
+                                           int n_split, float* y2, int ldy2, int rep,
+                                           int n_split2, int act2, const float* mask2, int ldmask2,
+                                           const st_t16_view* y3_dst,
                                            int B, int N, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(B > 0 && N > 0 && (y || y_t16), "st_skinny_linear_packed_fwd: bad arguments");
+    ST_CHECK_ARG(n_split2 <= 0 || (y3_dst && y3_dst->base && n_split2 >= n_split), "st_skinny_linear_packed_fwd: third range");
+    ST_CHECK_ARG(B > 0 && N > 0 && (y || (y_dst && y_dst->base)), "st_skinny_linear_packed_fwd: bad arguments");
     ST_CHECK_ARG(n_split <= 0 || (y2 && rep >= 1), "st_skinny_linear_packed_fwd: n_split without y2/rep");
     PkArgs a;
     memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, segs, nseg, "st_skinny_linear_packed_fwd");
+    int rc = pk_fill(a, packed_w, 0, 0, x, K, "st_skinny_linear_packed_fwd");
     if (rc) return rc;
     a.B = B; a.N = N; a.H = 0;
     a.bias = bias; a.act = act; a.lmask = mask; a.ldmask = ldmask;
-    a.y = y; a.ldy = ldy; a.y_t16 = y_t16; a.y_kb = pk_kb(n_split > 0 ? n_split : N);
+    a.y = y; a.ldy = ldy; a.y_dst = pk_out(y_dst);
     a.n_split = n_split; a.y2 = y2; a.ldy2 = ldy2; a.rep = rep;
+    a.n_split2 = n_split2; a.act2 = act2; a.mask2 = mask2; a.ldmask2 = ldmask2; a.y3_dst = pk_out(y3_dst);
     return pk_dispatch<1>(a, (N + 15) / 16, (hipStream_t)stream);
+}
+
+// Partial LSTM gate pre-activations over a k-block range of the packed weights:
+// pre_out(b, g*H + u) = sum_{k in range} W x     (no bias, no activation).  A later
+// st_lstm_cell_packed_fwd over the remaining k-blocks takes it as its `pre` addend.
+extern "C" int st_lstm_gates_partial_packed_fwd(const float* packed_w, int w_kb_stride, int w_kb0,
+                                                const st_t16_view* x, int K, float* pre_out, int ldpre,
+                                                int B, int H, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && pre_out && ldpre >= 4 * H, "st_lstm_gates_partial_packed_fwd: bad arguments");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, w_kb_stride, w_kb0, x, K, "st_lstm_gates_partial_packed_fwd");
+    if (rc) return rc;
+    a.B = B; a.N = 4 * H; a.H = H;
+    a.gates_out = pre_out; a.ldpre = ldpre;
+    return pk_dispatch<2>(a, H / 4, (hipStream_t)stream);
 }

@@ -276,12 +276,34 @@ class Decoder(nn.Module):
         self.proj = Linear(dec_rnn_dim + enc_embed_dim, n_mels * n_frames_per_step)
         self.gate_layer = Linear(dec_rnn_dim + enc_embed_dim, 1, bias=True, w_init_gain='sigmoid')
         self.last_tapes = None     # tapes of the most recent forward (saved tensors of the backward pass)
+        import os
+        # early parts of the LSTM cells on a second HIP stream: measured SLOWER on MI355X/ROCm 7.2 (cross-stream
+        # event dependencies cost more than the ~15 us of overlap they buy: 86.7 vs 68.1 us/step), so off by default
+        self.overlap = os.environ.get('ST_OVERLAP', '0') != '0'
+        self.fuse_prenet = True    # inference: emit prenet layer 1 from the proj/gate launch (fp32 re-association)
 
     # -- helpers ---------------------------------------------------------------------------------
-    def _weights_struct(self, keep):
+    def _weights_struct(self, keep, fuse_pre0=False):
         w = StDecoderWeights()
-        pg_w = torch.cat([self.proj.linear.weight, self.gate_layer.linear.weight], dim=0).contiguous()
-        pg_b = torch.cat([self.proj.linear.bias, self.gate_layer.linear.bias], dim=0).contiguous()
+        # [proj ; gate (; W_pre0 . W_proj)] assembled with library kernels only, so that a hipGraph capture
+        # of this forward re-creates it on replay (torch ops issued during a capture are NOT captured)
+        pw, gw = self.proj.linear.weight, self.gate_layer.linear.weight
+        in_dim, KO = pw.shape
+        n_rows = in_dim + 1 + (self.prenet_dim if fuse_pre0 else 0)
+        pg_w = torch.empty(n_rows, KO, device=pw.device, dtype=torch.float32)
+        pg_b = torch.empty(n_rows, device=pw.device, dtype=torch.float32)
+        ops.copy2d(pg_w, pw, in_dim, KO)
+        ops.copy2d(pg_w[in_dim:], gw, 1, KO)
+        ops.copy2d(pg_b.view(1, -1), self.proj.linear.bias.view(1, -1), 1, in_dim)
+        ops.copy2d(pg_b.view(1, -1)[:, in_dim:], self.gate_layer.linear.bias.view(1, -1), 1, 1)
+        if fuse_pre0:
+            # prenet layer 1 of the own output, folded into the projection: relu(W0 (Wp y + bp)) =
+            # relu((W0 Wp) y + W0 bp); the two products are formed once per forward on device
+            w0 = self.prenet.layers[0].linear.weight
+            pwT = pw.detach().t().contiguous()            # parameter layout change only (no captured input)
+            ops.gemm(w0, pwT, out=pg_w[in_dim + 1:])
+            ops.gemm(w0, self.proj.linear.bias.view(1, -1), out=pg_b[in_dim + 1:].view(-1, 1))
+            keep.append(pwT)
         keep += [pg_w, pg_b]
         tensors = dict(
             prenet_w0=self.prenet.layers[0].linear.weight, prenet_w1=self.prenet.layers[1].linear.weight,
@@ -342,11 +364,16 @@ class Decoder(nn.Module):
         align = torch.empty(B, steps, L, **f32)
         stop = torch.empty(B, steps * r, **f32)
         lib = _lib.load()
-        t16 = lambda k: int(lib.st_t16_floats(B, k))           # floats of one T16-tiled (B, k) slot
+        # free-running inference: fold prenet layer 1 into the proj/gate launch (one kernel less per step)
+        fuse_pre0 = (not self.training) and self.fuse_prenet and Bt == B and all(s_ == -1 for s_ in step_src)
+        dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A,
+                             F=self.n_location_filters, K=self.location_kernel_size, fuse_pre0=1 if fuse_pre0 else 0)
+        t16 = lambda k: int(lib.st_t16_floats(B, k))           # floats of one T16-tiled (B, k) buffer
+        slot = [int(lib.st_decoder_tape_floats(C.byref(dims), i)) for i in range(3)]
         in_dim = r * n_mels
-        # T16-tiled tapes are handed in zero-filled (pad lanes/rows must be zero); ONE memset covers them all
-        sizes = dict(hq=(steps + 1) * t16(Q), hd=(steps + 1) * t16(D), ctx=(steps + 1) * t16(E),
-                     hadapt=steps * t16(Q), decin=(steps + 1) * t16(P), pre1=t16(P), melt=t16(in_dim))
+        # T16-tiled step-input tapes (xq = [dec_in|ctx|h_q], xd = [ctx|adapted h_q|h_d], xo = [h_d|ctx]) are
+        # handed in zero-filled (pad lanes/rows must be zero); ONE memset covers them all
+        sizes = dict(xq=(steps + 1) * slot[0], xd=(steps + 1) * slot[1], xo=steps * slot[2], pre1=t16(P), melt=t16(in_dim))
         tiled = torch.zeros(sum(sizes.values()), **f32)
         tapes, off = {}, 0
         for k, n in sizes.items():
@@ -354,14 +381,13 @@ class Decoder(nn.Module):
             off += n
         tapes.update(cq=torch.empty(steps + 1, B, Q, **f32), cd=torch.empty(steps + 1, B, D, **f32),
                      wcum=torch.empty(steps + 1, B, L, **f32), pq=torch.empty(B, A, **f32),
-                     zero=torch.empty(B, L, **f32), tiled=tiled)
+                     zero=torch.empty(B, L, **f32), tiled=tiled, preq=torch.empty(B, 4 * Q, **f32),
+                     pred=torch.empty(B, 4 * D, **f32))
         if self.training and torch.is_grad_enabled():
             tapes['gates_q'] = torch.empty(steps, B, 4, Q, **f32)
             tapes['gates_d'] = torch.empty(steps, B, 4, D, **f32)
 
-        w = self._weights_struct(keep)
-        dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A,
-                             F=self.n_location_filters, K=self.location_kernel_size)
+        w = self._weights_struct(keep, fuse_pre0)
         # the six matrices the loop streams every step, packed into MFMA lane order once per forward
         packed = torch.empty(int(lib.st_decoder_packed_floats(C.byref(dims))), **f32)
         check(lib.st_decoder_pack(C.byref(w), C.byref(dims), ops._p(packed), ops.stream_handle()), 'st_decoder_pack')
@@ -375,10 +401,11 @@ class Decoder(nn.Module):
         io.steps = steps
         io.mel_out, io.align_out, io.stop_out = ops._p(mel), ops._p(align), ops._p(stop)
         io.packed = ops._p(packed)
-        io.hq_tape, io.cq_tape, io.hd_tape, io.cd_tape = (ops._p(tapes[k]) for k in ('hq', 'cq', 'hd', 'cd'))
-        io.ctx_tape, io.wcum_tape, io.hadapt_tape = ops._p(tapes['ctx']), ops._p(tapes['wcum']), ops._p(tapes['hadapt'])
-        io.decin_tape, io.pq_buf, io.pre1_t16, io.mel_t16 = (ops._p(tapes[k]) for k in ('decin', 'pq', 'pre1', 'melt'))
+        io.xq_tape, io.xd_tape, io.xo_tape = (ops._p(tapes[k]) for k in ('xq', 'xd', 'xo'))
+        io.cq_tape, io.cd_tape, io.wcum_tape = (ops._p(tapes[k]) for k in ('cq', 'cd', 'wcum'))
+        io.pq_buf, io.pre1_t16, io.mel_t16 = (ops._p(tapes[k]) for k in ('pq', 'pre1', 'melt'))
         io.zero_row = ops._p(tapes['zero'])
+        io.preq_buf, io.pred_buf, io.overlap = ops._p(tapes['preq']), ops._p(tapes['pred']), 1 if self.overlap else 0
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')

@@ -261,44 +261,64 @@ def pack_weight(ws, ks, N, lstm_H=0, ldws=None):
     return out
 
 
-def tile_rows(x, out=None):
-    """natural (B, K) -> T16"""
+def kb16(k):
+    return (int(k) + 15) // 16
+
+
+def t16_view(buf, kb_stride=None, kb0=0, K=None):
+    """StT16View over a T16 buffer (kb_stride defaults to the k-blocks of a (B, K) buffer)"""
+    v = _lib.StT16View()
+    v.base = _p(buf)
+    v.kb_stride = int(kb_stride if kb_stride is not None else kb16(K))
+    v.kb0 = int(kb0)
+    return v
+
+
+def tile_rows(x, out=None, kb_stride=None, kb0=0):
+    """natural (B, K) -> T16 (optionally into the k-block range kb0.. of a wider buffer)"""
     B, K = x.shape
     if out is None:
         out = torch.zeros(t16_floats(B, K), device=x.device, dtype=torch.float32)
-    check(_lib.load().st_tile_rows(_p(x), int(x.stride(0)), _p(out), B, K, stream_handle()), 'st_tile_rows')
+    v = t16_view(out, kb_stride if kb_stride is not None else kb16(K), kb0)
+    check(_lib.load().st_tile_rows(_p(x), int(x.stride(0)), C.byref(v), B, K, stream_handle()), 'st_tile_rows')
     return out
 
 
-def untile_rows(x_t16, B, K):
+def untile_rows(x_t16, B, K, kb_stride=None, kb0=0):
     out = torch.empty(B, K, device=x_t16.device, dtype=torch.float32)
-    check(_lib.load().st_untile_rows(_p(x_t16), _p(out), K, B, K, stream_handle()), 'st_untile_rows')
+    v = t16_view(x_t16, kb_stride if kb_stride is not None else kb16(K), kb0)
+    check(_lib.load().st_untile_rows(C.byref(v), _p(out), K, B, K, stream_handle()), 'st_untile_rows')
     return out
 
 
-def _psegs(pairs):
-    arr = (_lib.StPSeg * len(pairs))()
-    for i, (x, k) in enumerate(pairs):
-        arr[i].x_t16, arr[i].k = _p(x), int(k)
-    return arr
+def _vp(v):
+    return C.byref(v) if v is not None else None
 
 
-def lstm_cell_packed(packed_w, segs, b_ih, b_hh, c_prev, h_out_t16, c_out, B, H, mask=None, gates_out=None,
-                     ada_std=None, ada_mean=None, hadapt_t16=None):
-    """segs: list of (x_t16, k)"""
-    check(_lib.load().st_lstm_cell_packed_fwd(_p(packed_w), _psegs(segs), len(segs), _p(b_ih), _p(b_hh), None, 0,
-                                              _p(c_prev), H, _p(mask), _p(h_out_t16), _p(c_out), H, _p(gates_out),
-                                              _p(ada_std), _p(ada_mean), _p(hadapt_t16), int(B), int(H),
+def lstm_cell_packed(packed_w, x_view, Kpad, b_ih, b_hh, c_prev, h_dst0, c_out, B, H, h_dst1=None, mask=None,
+                     gates_out=None, ada_std=None, ada_mean=None, hadapt_dst=None, pre=None, w_kb_stride=0, w_kb0=0):
+    """x_view / *_dst: StT16View (see t16_view); Kpad = 16 * (k-blocks to reduce over)"""
+    check(_lib.load().st_lstm_cell_packed_fwd(_p(packed_w), int(w_kb_stride), int(w_kb0), C.byref(x_view), int(Kpad),
+                                              _p(b_ih), _p(b_hh), _p(pre), int(pre.stride(0)) if pre is not None else 0,
+                                              _p(c_prev), H, _p(mask), C.byref(h_dst0), _vp(h_dst1), _p(c_out), H,
+                                              _p(gates_out), _p(ada_std), _p(ada_mean), _vp(hadapt_dst), int(B), int(H),
                                               stream_handle()), 'st_lstm_cell_packed_fwd')
 
 
-def skinny_linear_packed(packed_w, segs, B, N, y=None, y_t16=None, bias=None, act=None, mask=None,
-                         n_split=0, y2=None, rep=0):
+def lstm_gates_partial_packed(packed_w, w_kb_stride, w_kb0, x_view, Kpad, pre_out, B, H):
+    check(_lib.load().st_lstm_gates_partial_packed_fwd(_p(packed_w), int(w_kb_stride), int(w_kb0), C.byref(x_view), int(Kpad),
+                                                       _p(pre_out), int(pre_out.stride(0)), int(B), int(H), stream_handle()),
+          'st_lstm_gates_partial_packed_fwd')
+
+
+def skinny_linear_packed(packed_w, x_view, Kpad, B, N, y=None, y_dst=None, bias=None, act=None, mask=None,
+                         n_split=0, y2=None, rep=0, n_split2=0, act2=None, mask2=None, y3_dst=None):
     check(_lib.load().st_skinny_linear_packed_fwd(
-        _p(packed_w), _psegs(segs), len(segs), _p(bias), ACT[act], _p(mask),
-        int(mask.stride(0)) if mask is not None else 0, _p(y), int(y.stride(0)) if y is not None else 0, _p(y_t16),
-        int(n_split), _p(y2), int(y2.stride(0)) if y2 is not None else 0, int(rep), int(B), int(N), stream_handle()),
-        'st_skinny_linear_packed_fwd')
+        _p(packed_w), C.byref(x_view), int(Kpad), _p(bias), ACT[act], _p(mask),
+        int(mask.stride(0)) if mask is not None else 0, _p(y), int(y.stride(0)) if y is not None else 0, _vp(y_dst),
+        int(n_split), _p(y2), int(y2.stride(0)) if y2 is not None else 0, int(rep),
+        int(n_split2), ACT[act2], _p(mask2), int(mask2.stride(0)) if mask2 is not None else 0, _vp(y3_dst),
+        int(B), int(N), stream_handle()), 'st_skinny_linear_packed_fwd')
 
 
 # --------------------------------------------------------------------------------------------- graphs

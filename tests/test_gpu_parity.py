@@ -98,10 +98,23 @@ def test_tile_untile_roundtrip(dev, B, K):
     assert abs(float(t.abs().sum()) - float(x.abs().sum())) < 1e-3 * (1 + float(x.abs().sum()))
 
 
+def _combined_t16(ops, xs, Ks, dev):
+    """tile several (B, k_s) activations into ONE T16 buffer, each at its own k-block range"""
+    B = xs[0].shape[0]
+    kbs = [ops.kb16(k) for k in Ks]
+    stride = sum(kbs)
+    buf = torch.zeros(((B + 15) // 16) * stride * 256, device=dev)
+    kb0 = 0
+    for x, k, n in zip(xs, Ks, kbs):
+        ops.tile_rows(x.to(dev), out=buf, kb_stride=stride, kb0=kb0)
+        kb0 += n
+    return buf, stride
+
+
 @pytest.mark.parametrize('B,H,Ks', [(2, 8, (12, 20, 8)), (4, 48, (16, 32, 48)), (32, 1024, (256, 512, 1024)),
                                     (64, 256, (64, 256)), (19, 40, (30, 40)), (70, 16, (24,)), (33, 64, (48, 64))])
 def test_lstm_cell_packed(dev, B, H, Ks):
-    """the decode loop's LSTM cell on pre-packed (P16) weights and tiled (T16) activations"""
+    """the decode loop's LSTM cell on pre-packed (P16) weights and ONE tiled (T16) activation run"""
     from semi_tts_amd import ops
     K = sum(Ks)
     xs = [rnd(B, k, seed=10 + i) for i, k in enumerate(Ks)]
@@ -117,17 +130,22 @@ def test_lstm_cell_packed(dev, B, H, Ks):
     wd = w.to(dev)
     offs = np.cumsum([0] + list(Ks))
     packed = ops.pack_weight([wd[:, offs[j]:] for j in range(len(Ks))], Ks, 4 * H, lstm_H=H, ldws=[K] * len(Ks))
-    segs = [(ops.tile_rows(x.to(dev)), k) for x, k in zip(xs, Ks)]
+    xbuf, stride = _combined_t16(ops, xs, Ks, dev)
+    # the new h goes to two destinations: its own buffer and a slice of a wider one
     h_t16 = torch.zeros(ops.t16_floats(B, H), device=dev)
+    wide_kbs = ops.kb16(H) + 3
+    wide = torch.zeros(((B + 15) // 16) * wide_kbs * 256, device=dev)
     ha_t16 = torch.zeros(ops.t16_floats(B, H), device=dev)
     c_out = torch.empty(B, H, device=dev)
     gts = torch.empty(B, 4, H, device=dev)
-    ops.lstm_cell_packed(packed, segs, b_ih.to(dev), b_hh.to(dev), c.to(dev), h_t16, c_out, B, H, mask=mask.to(dev),
-                         gates_out=gts, ada_std=std.to(dev), ada_mean=mean.to(dev), hadapt_t16=ha_t16)
+    ops.lstm_cell_packed(packed, ops.t16_view(xbuf, stride), 16 * stride, b_ih.to(dev), b_hh.to(dev), c.to(dev),
+                         ops.t16_view(h_t16, K=H), c_out, B, H, h_dst1=ops.t16_view(wide, wide_kbs, 2), mask=mask.to(dev),
+                         gates_out=gts, ada_std=std.to(dev), ada_mean=mean.to(dev), hadapt_dst=ops.t16_view(ha_t16, K=H))
     h = ops.untile_rows(h_t16, B, H)
     e_h, e_c = maxdiff(h, h_ref), maxdiff(c_out, c_ref)
     report('lstm_cell_packed', B=B, H=H, K=K, err_h=e_h, err_c=e_c)
     assert e_h < 1e-5 and e_c < 1e-5
+    assert torch.equal(ops.untile_rows(wide, B, H, kb_stride=wide_kbs, kb0=2), h)
     assert maxdiff(ops.untile_rows(ha_t16, B, H), std * (h_ref - mean)) < 1e-5
     assert maxdiff(gts[:, 3], torch.sigmoid(o)) < 1e-5
 
@@ -144,10 +162,12 @@ def test_skinny_linear_packed(dev, B, N, Ks):
     wd = w.to(dev)
     offs = np.cumsum([0] + list(Ks))
     packed = ops.pack_weight([wd[:, offs[j]:] for j in range(len(Ks))], Ks, N, ldws=[K] * len(Ks))
-    segs = [(ops.tile_rows(x.to(dev)), k) for x, k in zip(xs, Ks)]
+    xbuf, stride = _combined_t16(ops, xs, Ks, dev)
+    xv = ops.t16_view(xbuf, stride)
     y = torch.zeros(B, N, device=dev)
     y_t16 = torch.zeros(ops.t16_floats(B, N), device=dev)
-    ops.skinny_linear_packed(packed, segs, B, N, y=y, y_t16=y_t16, bias=b.to(dev), act='relu', mask=mask.to(dev))
+    ops.skinny_linear_packed(packed, xv, 16 * stride, B, N, y=y, y_dst=ops.t16_view(y_t16, K=N), bias=b.to(dev),
+                             act='relu', mask=mask.to(dev))
     err = maxdiff(y, ref)
     report('skinny_linear_packed', B=B, N=N, K=K, err=err)
     assert err < 2e-5
@@ -157,7 +177,8 @@ def test_skinny_linear_packed(dev, B, N, Ks):
         y1 = torch.zeros(B, N - 1, device=dev)
         y2 = torch.zeros(B, 3, device=dev)
         t1 = torch.zeros(ops.t16_floats(B, N - 1), device=dev)
-        ops.skinny_linear_packed(packed, segs, B, N, y=y1, y_t16=t1, bias=b.to(dev), n_split=N - 1, y2=y2, rep=3)
+        ops.skinny_linear_packed(packed, xv, 16 * stride, B, N, y=y1, y_dst=ops.t16_view(t1, K=N - 1), bias=b.to(dev),
+                                 n_split=N - 1, y2=y2, rep=3)
         lin = torch.cat(xs, 1).double() @ w.double().t() + b.double()
         assert maxdiff(y1, lin[:, :N - 1]) < 2e-5 and maxdiff(y2, lin[:, N - 1:].repeat(1, 3)) < 2e-5
         assert torch.equal(ops.untile_rows(t1, B, N - 1), y1)

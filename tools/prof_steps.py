@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-call-site kernel durations inside one decode step, from a rocprofv3 rocpd database."""
+import collections
+import sqlite3
+import statistics as st
+import sys
+
+con = sqlite3.connect(sys.argv[1])
+rows = con.execute("select name, start, end from kernels order by start").fetchall()
+def code(n):
+    if 'pk_kernel<0' in n: return 'L'
+    if 'pk_kernel<1' in n: return 'l'
+    if 'at_kernel' in n: return 'A'
+    return 'x'
+seq = [(code(n), s, e) for n, s, e in rows]
+text = ''.join(c for c, _, _ in seq)
+for pat, names in (('LlALll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj+pre0', 'pre1']),
+                   ('LlALlll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj', 'pre0', 'pre1'])):
+    dur = collections.defaultdict(list)
+    i = 0
+    n = len(pat)
+    while i + n <= len(seq):
+        if text[i:i + n] == pat and (i + n >= len(seq) or text[i + n] != 'l'):
+            for j in range(n):
+                dur[j].append(seq[i + j][2] - seq[i + j][1])
+            i += n
+        else:
+            i += 1
+    if dur and len(dur[0]) > 50:
+        tot = 0
+        for j in range(n):
+            m = st.median(dur[j]) / 1e3
+            tot += m
+            print('%-10s n=%5d median %6.2f us' % (names[j], len(dur[j]), m))
+        print('sum of medians %.2f us' % tot)
+        break

@@ -189,9 +189,15 @@ def main():
         avg_us = ms.value * 1e3 / (2 * reps)
         alg = 0.5 * (lstm_algorithmic_bytes(B, Q, P + E + Q) + lstm_algorithmic_bytes(B, D, E + Q + D))
         achieved = alg / (avg_us * 1e-6) / 1e9
+        traffic = None       # HBM bytes per launch from the PMC pass of the same command (tools/gpu_pmc.sh)
+        try:
+            with open(os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')) as f:
+                traffic = json.load(f)['hbm_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {'bound': 'hbm', 'kernel': 'pk_kernel<0,2,8,2> (fused LSTM cell on packed operands: gate GEMM + pointwise)',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(avg_us, 3),
                 'launches_per_step': 2 * STEPS}
 

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
         if (a.mask) e_m = a.mask[(size_t)eb * a.H + u];
         if (a.ha_dst.base) { e_s = a.ada_std[(size_t)eb * a.H + u]; e_mu = a.ada_mean[(size_t)eb * a.H + u]; }
     }
-    if (MODE != 1) {   // bandwidth bound: double-buffered groups of TRIP k-blocks
+    if (true) {        // double-buffered groups of TRIP k-blocks (measured faster than one big group for every shape)
         PkRegs<NB, TRIP> ra, rb;
         int kb = wave;
         if (kb < KB) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb, KB);
@@ -263,10 +263,10 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
 
 template <int MODE, int NB>
 int pk_launch(const PkArgs& a, int tiles, hipStream_t st) {
-    // LSTM: 256 workgroups stream 29-42 MB: 8 waves x 2 k-blocks, double buffered.
-    // linear: 16-32 workgroups, 0.25-3 MB: 8 waves x up to 6 k-blocks each, all in flight at once
-    // (1024-thread workgroups measured slower to start than they gain).
-    constexpr int KW = 8, TRIP = MODE != 1 ? 2 : (NB <= 2 ? 6 : 3);
+    // 8 waves x 2 k-blocks in flight, double buffered.  Measured alternatives on MI355X (us per launch in
+    // the decode graph, pq / proj / prenet): 16 waves x 6 single-buffered 7.2 / 8.8 / 7.3; 8 waves x 6
+    // single-buffered 8.6 / 10.6 / 5.7; this configuration 6.1 / 8.8 / 4.8.
+    constexpr int KW = 8, TRIP = 2;
     const int BT = (a.B + 15) >> 4;
     dim3 grid(tiles, (BT + NB - 1) / NB);
     hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a);

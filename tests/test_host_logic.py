@@ -1,0 +1,182 @@
+"""CPU-side tests: host logic of the drop-in modules, the C-ABI library's exported symbols, the
+oracle at full size against the reference fixture, and the multi-process helpers (gloo).
+No GPU needed; nothing here launches a kernel."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO, load_golden
+from helpers import FULL_CFG, coin_source, full_hp
+
+
+def test_library_exports_every_declared_symbol():
+    """libsemitts_hip.so loads on a CPU-only box and exports every function include/semitts.h declares"""
+    from semi_tts_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build()
+    hdr = open(os.path.join(REPO, 'include', 'semitts.h')).read()
+    declared = sorted(set(re.findall(r'\b(st_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 40
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, 'declared in semitts.h but not exported: %s' % missing
+    # and the ctypes table binds exactly the declared set
+    assert sorted(_lib.SIGNATURES) == declared
+    lib2 = _lib.load()
+    assert lib2.st_abi_version() == 1
+    assert lib2.st_t16_floats(32, 240) == 2 * 15 * 256
+    k = (ctypes.c_int * 3)(256, 512, 1024)
+    assert lib2.st_packed_weight_floats(k, 3, 4096, 1024) == 256 * 112 * 256
+
+
+def test_product_path_refuses_cpu_tensors():
+    from semi_tts_amd import ops
+    from semi_tts_amd.tts import Tacotron2
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.linear_small(torch.zeros(2, 8), torch.zeros(4, 8))
+    m = Tacotron2(80, 1025, 64, 128, json.loads(json.dumps(FULL_CFG))).eval()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 5, 64), None, 6, torch.zeros(1, 128))
+
+
+def test_state_dict_keys_match_reference():
+    """same parameter/buffer names and shapes as the reference modules, so its checkpoints load"""
+    from semi_tts_amd.embed import L2Embedding, SeperateEmbedding
+    from semi_tts_amd.tts import Tacotron2
+    ref = json.load(open(os.path.join(GOLDEN, 'state_dict_keys.json')))
+    m = Tacotron2(80, 1025, 64, 128, json.loads(json.dumps(FULL_CFG)))
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref['tts']
+    W, _, _ = load_golden('vq_l2_native')
+    attr = os.path.join(REPO, 'tests', 'golden', '_attr_tmp.csv')
+    try:
+        a = W['phn_attr.weight'].numpy()[3:]
+        with open(attr, 'w') as f:
+            f.write('\t' + '\t'.join('a%d' % i for i in range(a.shape[1])) + '\n')
+            for i, row in enumerate(a):
+                f.write('p%d\t' % i + '\t'.join(str(int(v)) for v in row) + '\n')
+        kw = dict(softmax='normal', latent_dim=64, commit_weight=0, vq_weight=0, temp=1, skip_prob=0, stop_grad=True,
+                  phn_attr_pth=attr, proj_attr=16)
+        l2 = L2Embedding(43, False, **kw)
+        sep = SeperateEmbedding(43, False, **kw)
+    finally:
+        os.remove(attr)
+    assert {k: list(v.shape) for k, v in l2.state_dict().items()} == ref['l2']
+    assert {k: list(v.shape) for k, v in sep.state_dict().items()} == ref['seperate']
+    # the attribute table read from the tab-separated file equals the reference's (3 zero rows prepended)
+    assert torch.equal(l2.phn_attr.weight, W['phn_attr.weight'])
+    assert l2.out_dim == 64 and 'Temp.' in l2.create_msg()
+
+
+@pytest.mark.parametrize('name', ['tts_tiny_infer', 'tts_tiny_train_tf', 'tts_tiny_sched', 'tts_tiny_partial', 'tts_tiny_quirk'])
+def test_plan_decode_matches_reference_step_policy(name):
+    """step count and next-input source sequence reproduce what the reference did (alignment length,
+    number of host-RNG draws consumed)"""
+    from semi_tts_amd.module import plan_decode
+    _, A, meta = load_golden(name)
+    hp = meta['hp']
+    is_int = meta['teacher'] is not None
+    B = A['txt_embed'].shape[0]
+    Bt = B if is_int else A['teacher'].shape[0]
+    draws = []
+    src_coins = coin_source(A['coins'])
+
+    def coin():
+        draws.append(1)
+        return src_coins()
+    steps, src = plan_decode(is_int, meta['teacher'] if is_int else A['teacher'].shape[1], Bt, B,
+                             hp['n_frames_per_step'], meta['tf_rate'], hp['drop_dec_in'], meta['unpair_max_frame'], coin)
+    assert steps == A['align'].shape[1] and len(src) == steps
+    assert len(draws) == len(A['coins'])
+    if meta['tf_rate'] == 0.0:
+        assert set(src) == {-1}
+    if name == 'tts_tiny_train_tf':
+        assert src == list(range(steps))
+    if name == 'tts_tiny_sched':
+        assert -1 in src and any(s >= 0 for s in src)
+
+
+def test_synthetic_weights_are_deterministic_and_order_independent():
+    from semi_tts_amd.synthetic import synthetic_batch, synthetic_state_dict
+    shapes = {'a.weight': (8, 4), 'b.bias': (8,), 'c.running_var': (8,), 'd.num_batches_tracked': ()}
+    s1 = synthetic_state_dict(shapes, 7)
+    s2 = synthetic_state_dict(dict(reversed(list(shapes.items()))), 7)
+    for k in shapes:
+        assert np.array_equal(s1[k], s2[k])
+    assert not np.array_equal(s1['a.weight'], synthetic_state_dict(shapes, 8)['a.weight'])
+    assert (s1['c.running_var'] > 0).all() and s1['d.num_batches_tracked'].dtype == np.int64
+    t1, t2 = synthetic_batch(2, 3, 6), synthetic_batch(2, 3, 6)
+    assert all(np.array_equal(a, b) for a, b in zip(t1, t2))
+
+
+def test_oracle_full_size_against_reference_fixture():
+    """the oracle at FULL dimensions (B=4, T=66, L=12) with the seeded synthetic weights reproduces the
+    real reference's output recorded in tests/golden/tts_full_c1.npz"""
+    from oracle import tts_oracle as O
+    from semi_tts_amd.synthetic import synthetic_state_dict
+    _, A, meta = load_golden('tts_full_c1')
+    W = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(meta['shapes'], meta['seed']).items()}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        mel, lin, align, stop = O.tacotron2_forward(W, A['txt_embed'], meta['T'], A['spkr_embed'], full_hp(0.0))
+    assert (mel - A['mel_infer']).abs().max() < 5e-5
+    assert (align - A['align_infer']).abs().max() < 1e-5
+    assert (lin[:, ::7, ::41] - A['linear_infer_s']).abs().max() < 2e-4
+
+
+def test_shard_range_covers_everything_once():
+    from semi_tts_amd.parallel import shard_range
+    for n in (0, 1, 7, 32, 33, 64):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from semi_tts_amd.parallel import allreduce_gradients, broadcast_parameters, max_over_ranks, shard_range
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+torch.manual_seed(rank)                       # replicas start different ...
+net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+broadcast_parameters(net)                     # ... and are made identical
+x = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10.0
+lo, hi = shard_range(8, world, rank)          # utterance-level sharding of one global batch
+loss = net(x[lo:hi]).pow(2).sum() / 8.0
+loss.backward()
+n = allreduce_gradients(net.parameters(), bucket_bytes=64, average=False)
+ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+ref.load_state_dict(net.state_dict())
+(ref(x).pow(2).sum() / 8.0).backward()       # the single-process result on the whole batch
+err = max((a.grad - b.grad).abs().max().item() for a, b in zip(net.parameters(), ref.parameters()))
+t = max_over_ranks(1.0 + rank)
+if rank == 0:
+    print('RESULT', err, n, t)
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_gradient_allreduce_matches_single_process(tmp_path):
+    """world_size 2 over gloo: shard a batch by utterance, all-reduce bucketed gradients, compare with
+    the single-process gradient of the whole batch (the N>1 training path of BASELINE config 4)"""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script), REPO], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0].splitlines() if l.startswith('RESULT')][0].split()
+    assert float(line[1]) < 1e-5          # gradients equal the single-process ones
+    assert int(line[2]) >= 2              # more than one bucket was exercised
+    assert float(line[3]) == 2.0          # max over ranks of (1, 2)

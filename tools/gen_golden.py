@@ -315,3 +315,27 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def state_dict_keys_case():
+    """key -> shape of the reference's Tacotron2 / codebooks with the shipped configuration (data only)"""
+    import yaml
+    os.chdir(REF)
+    cfg = yaml.safe_load(open('config/semi-single-spkr-paired-data.yaml'))['model']
+    torch.manual_seed(0)
+    tts = RefTacotron2(80, 1025, 64, 128, json.loads(json.dumps(cfg['decoder'])))
+    cb = dict(cfg['codebook'])
+    cb.pop('bone')
+    l2 = RefL2(43, False, **cb)
+    sep = RefSep(43, False, **cb)
+    os.chdir(REPO)
+    out = {'tts': {k: list(v.shape) for k, v in tts.state_dict().items()},
+           'l2': {k: list(v.shape) for k, v in l2.state_dict().items()},
+           'seperate': {k: list(v.shape) for k, v in sep.state_dict().items()}}
+    with open(os.path.join(OUT, 'state_dict_keys.json'), 'w') as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print('state_dict_keys.json', sum(len(v) for v in out.values()), 'keys')
+
+
+if __name__ == '__main__' and 'keys' in sys.argv[1:]:
+    state_dict_keys_case()

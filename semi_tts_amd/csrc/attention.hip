@@ -240,6 +240,7 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
             f32x4 loc[AT_LB];
 #pragma unroll
             for (int j = 0; j < AT_LB; ++j) loc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef AT_ABLATE_FLOOP   // (tools/mb ablation switches; never defined in the product build)
 #pragma unroll 4
             for (int f = 0; f < F; ++f) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wt + f * o.wt_ld + a0);
@@ -252,12 +253,17 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
                     loc[j][2] = fmaf(w4[2], cv, loc[j][2]); loc[j][3] = fmaf(w4[3], cv, loc[j][3]);
                 }
             }
+#endif
 #pragma unroll
             for (int j = 0; j < AT_LB; ++j) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     // (processed_query + processed_loc_feat) + processed_memory, module.py:389-390
+#ifdef AT_ABLATE_TANH
+                    float t = (pq4[c] + loc[j][c]) + pm4[j][c];
+#else
                     float t = at_tanh((pq4[c] + loc[j][c]) + pm4[j][c]);
+#endif
                     if (!VEC) t = c < rem ? t : 0.0f;   // W_l^T pad columns hold garbage
                     esum[j] = fmaf(v4[c], t, esum[j]);
                 }

@@ -1,0 +1,105 @@
+"""VQVAE orchestration on the HIP path: the caller of the hot path (H1/H2 rows of SURVEY.md 8a).
+
+Mirrors the parts of the reference's src/vqvae.py that sit on the TTS side: constructor arguments
+and config splatting (:26-68), `text_to_speech` with its paired / unpaired batch concatenation and
+output slicing (:143-207), `padded_concat` (:259-271).  The speech side (`speech_to_text`) needs the
+CTC speech encoder src/asr.py, which is outside the hot path: here the codebook is
+applied to latents the caller already has (`quantize`), and `speech_to_text` says so.
+State-dict prefixes are the reference's (`codebook.*`, `spkr_embed.weight`, `tts.*`).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .embed import L2Embedding, SeperateEmbedding
+from .tts import Tacotron2
+
+FRAME_PHN_RATIO = 6.0          # ref: src/vqvae.py:18
+
+
+class VQVAE(nn.Module):
+    def __init__(self, n_mels, linear_dim, vocab_size, n_spkr, encoder, codebook, decoder, spkr_latent_dim,
+                 max_frames_per_phn, stop_threshold, asr_postnet_weight=0.0, txt_update_codebook=False,
+                 pretrained_asr=None, pretrained_emb=None, pretrained_tts=None):
+        super().__init__()
+        self.in_dim = n_mels
+        self.vocab_size = vocab_size
+        self.n_spkr = n_spkr
+        self.n_mels = n_mels
+        self.linear_dim = linear_dim
+        self.spkr_latent_dim = spkr_latent_dim
+        self.stop_threshold = stop_threshold
+        self.max_frames_per_phn = max_frames_per_phn
+        self.txt_update_codebook = txt_update_codebook
+        codebook = dict(codebook)
+        self.code_bone = codebook.pop('bone')                          # :41
+        self.latent_dim = codebook['latent_dim']
+        self.n_frames_per_step = decoder['decoder']['n_frames_per_step']
+        self.encoder_config = encoder      # the CTC speech encoder is not built (out of the hot path)
+        if self.code_bone == 'l2':                                     # :56-61
+            self.codebook = L2Embedding(vocab_size, False, **codebook)
+        elif self.code_bone == 'seperate':
+            self.codebook = SeperateEmbedding(vocab_size, False, **codebook)
+        else:
+            raise NotImplementedError
+        self.spkr_embed = nn.Embedding(self.n_spkr, spkr_latent_dim)   # :64
+        self.tts = Tacotron2(n_mels, self.linear_dim, self.codebook.out_dim, self.spkr_latent_dim, decoder)   # :68
+        for name, val in (('pretrained_asr', pretrained_asr), ('pretrained_emb', pretrained_emb),
+                          ('pretrained_tts', pretrained_tts)):
+            if val:
+                raise NotImplementedError('%s: load the checkpoint with load_state_dict instead' % name)
+
+    def padded_concat(self, pair, unpair):
+        """zero-pad the shorter of two (B, T, D) batches in time and stack them on the batch axis.  ref: :259-271"""
+        pair_bs, pair_ts, unpair_ts = pair.shape[0], pair.shape[1], unpair.shape[1]
+        T = max(pair_ts, unpair_ts)
+        out = torch.zeros(pair_bs + unpair.shape[0], T, pair.shape[2], device=pair.device, dtype=pair.dtype)
+        out[:pair_bs, :pair_ts] = pair
+        out[pair_bs:, :unpair_ts] = unpair
+        return pair_bs, out
+
+    def embed_speakers(self, sid):
+        return ops.gather_rows(self.spkr_embed.weight, sid)
+
+    def quantize(self, enc_latent, first_n_real_mel=0):
+        """codebook lookup of speech-encoder latents: (p_code, quantized_latent)   ref: :119"""
+        p_code, quantized, _, _ = self.codebook(enc_latent, first_n_real_mel)
+        return p_code, quantized
+
+    def speech_to_text(self, paired_mel, unpaired_mel, using_fake_mel=False):
+        raise NotImplementedError('speech_to_text needs the CTC speech encoder (src/asr.py), which is outside the '
+                                  'decode hot path; use quantize(enc_latent) on latents you already have')
+
+    def text_to_speech(self, paired_text, paired_sid, unpaired_sid, unpaired_latent, unpaired_text, unpaired_latent_len,
+                       paired_teacher, unpaired_teacher, tf_rate):
+        """same contract and return tuple as the reference (:143-207)"""
+        paired_latent = self.codebook.inference(paired_text)                                   # :147
+        unpair_max_frame = None
+        if unpaired_text is not None:                       # text-to-text cycle              :150-163
+            assert unpaired_latent is None
+            use_unpaired = True
+            unpaired_latent = self.codebook.inference(unpaired_text)
+            paired_latent_bs, all_latent = self.padded_concat(paired_latent, unpaired_latent)
+            paired_ts = paired_teacher.shape[1]
+            unpaired_ts = int(FRAME_PHN_RATIO * unpaired_text.shape[1])
+            unpaired_ts += unpaired_ts % self.n_frames_per_step
+            unpair_max_frame = unpaired_ts
+            all_teacher = paired_teacher
+            all_spkr = torch.cat([self.embed_speakers(paired_sid), self.embed_speakers(unpaired_sid)], dim=0)
+        elif unpaired_latent is not None:                   # speech-to-speech cycle          :164-173
+            use_unpaired = True
+            paired_latent_bs, all_latent = self.padded_concat(paired_latent, unpaired_latent)
+            paired_ts, unpaired_ts = paired_teacher.shape[1], unpaired_teacher.shape[1]
+            _, all_teacher = self.padded_concat(paired_teacher, unpaired_teacher)
+            all_spkr = torch.cat([self.embed_speakers(paired_sid), self.embed_speakers(unpaired_sid)], dim=0)
+        else:                                                                                   # :174-180
+            use_unpaired = False
+            all_latent, all_teacher = paired_latent, paired_teacher
+            all_spkr = self.embed_speakers(paired_sid)
+        mel, linear, align, stop = self.tts(all_latent, None, all_teacher, all_spkr, tf_rate=tf_rate,
+                                            unpair_max_frame=unpair_max_frame)                  # :183-184
+        if use_unpaired:                                                                        # :187-195
+            b = paired_latent_bs
+            return (mel[:b, :paired_ts], linear[:b, :paired_ts], align[:b, :paired_ts], stop[:b],
+                    mel[b:, :unpaired_ts], linear[b:, :unpaired_ts], align[b:, :unpaired_ts], stop[b:])
+        return mel, linear, align, stop, None, None, None, None

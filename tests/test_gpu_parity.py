@@ -520,3 +520,89 @@ def test_cpu_tensor_is_refused():
     from semi_tts_amd import ops
     with pytest.raises(RuntimeError):
         ops.linear_small(torch.zeros(2, 8), torch.zeros(4, 8))
+
+
+# ------------------------------------------------------------------------------------ callers (H2) and long form (C5)
+def _full_vqvae(dev, bone='l2', seed=77):
+    import yaml
+    from semi_tts_amd.synthetic import load_synthetic
+    from semi_tts_amd.vqvae import VQVAE
+    import os
+    from conftest import REPO
+    cfg = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-single-spkr-paired-data.yaml')))['model']
+    cfg['codebook'].update(bone=bone, phn_attr_pth='', proj_attr=None)   # the attribute csv lives in the reference tree
+    cfg['decoder']['decoder']['prenet_dropout'] = 0.0
+    m = VQVAE(80, 1025, 43, 109, **cfg)
+    load_synthetic(m, seed)
+    return m.to(dev).eval()
+
+
+def test_vqvae_text_to_speech_against_oracle(dev):
+    """VQVAE.text_to_speech (codebook.inference -> speaker embedding -> Tacotron2) with the reference's
+    argument list and 8-tuple, paired-only and text-to-text (unpaired text) batches"""
+    m = _full_vqvae(dev)
+    W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    Wt = {k[4:]: v for k, v in W.items() if k.startswith('tts.')}
+    Wc = {k[9:]: v for k, v in W.items() if k.startswith('codebook.')}
+    g = torch.Generator().manual_seed(3)
+    text = torch.randint(3, 43, (3, 9), generator=g)
+    sid = torch.randint(0, 109, (3,), generator=g)
+    frames = 30
+    with torch.no_grad():
+        out = m.text_to_speech(text.to(dev), sid.to(dev), None, None, None, None, frames, None, tf_rate=0.0)
+    assert len(out) == 8 and all(o is None for o in out[4:])
+    lat = VQ.l2_inference(Wc, text)
+    spk = W['spkr_embed.weight'][sid]
+    mel_r, lin_r, al_r, st_r = O.tacotron2_forward(Wt, lat, frames, spk, full_hp(0.0))
+    errs = dict(mel=maxdiff(out[0], mel_r), lin=maxdiff(out[1], lin_r), align=maxdiff(out[2], al_r))
+    report('vqvae_tts', **errs)
+    assert errs['mel'] < 5e-5 and errs['lin'] < 2e-4 and errs['align'] < 1e-5
+
+
+def test_specgram_generator_writes_reference_style_files(dev, tmp_path):
+    """H2: the gen_specgram counterpart decodes mel_len + 40 frames and writes -mel/-spec/-align .npy"""
+    import types
+    import yaml
+    import os
+    from conftest import REPO
+    from semi_tts_amd.solver import SpecgramGenerator, INFERENCE_MARGIN_FRAMES
+    config = yaml.safe_load(open(os.path.join(REPO, 'config', 'supervised.yaml')))
+    paras = types.SimpleNamespace(name='t', logdir=str(tmp_path), load=None, seed=1, cpu=False, verbose=False,
+                                  batch_size=2, frames=24, n_batches=1)
+    s = SpecgramGenerator(config, paras, 'test')
+    s.load_data()
+    s.set_model()
+    n = s.exec()
+    assert n == 2
+    out = os.path.join(str(tmp_path), 't_0k')
+    mel = np.load(os.path.join(out, 'utt00000-mel.npy'))
+    spec = np.load(os.path.join(out, 'utt00000-spec.npy'))
+    ali = np.load(os.path.join(out, 'utt00001-align.npy'))
+    T = 24 + 3 + INFERENCE_MARGIN_FRAMES             # 24 is a multiple of r=3: a full extra group is padded
+    T -= T % 3
+    assert mel.shape == (T, 80) and spec.shape == (T, 1025) and mel.dtype == np.float32
+    assert ali.shape == (int(3 * 6.0) // 3, 3)        # text length 4 with the last token 0 -> 3 real tokens
+    assert np.isfinite(mel).all() and np.isfinite(spec).all()
+
+
+def test_long_form_c5_shape(dev):
+    """BASELINE config 5 shape: B=64, L=171, 1026+40 frames -> 355 decode steps.  The decode is causal,
+    so its first 8 steps must equal an 8-step decode by the oracle; plus size-independent properties."""
+    from semi_tts_amd.synthetic import synthetic_batch
+    m = full_tacotron(dev, seed=5)
+    B, L, T = 64, 171, 1066
+    txt, spk, _ = synthetic_batch(B, L, 3, seed=9)
+    txt, spk = torch.from_numpy(txt), torch.from_numpy(spk)
+    with torch.no_grad():
+        mem = m.encoder(txt.to(dev), None)
+        mel, align, stop = m.decoder(mem, None, T, spk.to(dev), tf_rate=0.0)
+    assert mel.shape == (B, 1065, 80) and align.shape == (B, 355, L)
+    assert bool(torch.isfinite(mel).all())
+    assert float((align.sum(-1) - 1).abs().max()) < 1e-5
+    W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        mel_r, al_r, _ = O.decoder_forward(W, mem.cpu(), 24, spk, full_hp(0.0))
+    errs = dict(mel=maxdiff(mel[:, :24], mel_r), align=maxdiff(align[:, :8], al_r))
+    report('c5_prefix', **errs)
+    assert errs['mel'] < 5e-5 and errs['align'] < 1e-5

@@ -19,7 +19,8 @@ int main() {
     float* wout = dalloc((size_t)B * L, 0), *wcum2 = dalloc((size_t)B * L, 0);
     float* wc = dalloc((size_t)F * 2 * K, 0.1f), *wl = dalloc((size_t)A * F, 0.1f), *v = dalloc(A, 0.1f);
     float* ctx = dalloc((size_t)B * E, 0), *ctxt = dalloc((size_t)2 * 32 * 256, 0);
-    auto run = [&] { int rc = st_attn_step_t16_fwd(pq, pm, mem, wprev, L, wcum, wout, L, wcum2, wc, wl, v, ctxt, ctx, E, B, L, A, E, F, K, nullptr);
+    st_t16_view cv = {ctxt, 32, 0};
+    auto run = [&] { int rc = st_attn_step_t16_fwd(pq, pm, mem, wprev, L, wcum, wout, L, wcum2, wc, wl, v, &cv, 1, ctx, E, B, L, A, E, F, K, nullptr);
         if (rc) { printf("rc=%d %s\n", rc, st_last_error()); exit(1); } };
     for (int i = 0; i < 5; ++i) run();
     CK(hipDeviceSynchronize());

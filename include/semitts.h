@@ -215,6 +215,46 @@ int st_bn_stats(const float* X, int ldx, int coff, int M, int N, float* mean_out
 int st_bn_apply(float* X, int ldx, int coff, int M, int N, const float* mean, const float* var,
                 const float* w, const float* b, float eps, int act, void* stream);
 
+/* out-of-place variant of st_bn_apply (training keeps the pre-normalisation tensor for the backward) */
+int st_bn_norm_fwd(const float* X, int ldx, int xoff, float* Y, int ldy, int yoff, int M, int N,
+                   const float* mean, const float* var, const float* w, const float* b, float eps, int act,
+                   void* stream);
+
+/* ------------------------------------------------------------------ backward building blocks (training, H1)
+ * Input gradient of st_gemm_fwd = st_gemm_fwd itself on dC with the weight transposed and tap-flipped
+ * (W'(ci, n, t) = W(n, ci, KT-1-t), pad' = KT-1-pad, Tin/Tout swapped).
+ * ref: what torch autograd derives for nn.Conv1d / nn.Linear / nn.BatchNorm1d / activations used at
+ * src/module.py:421-431,:527-538,:541-555,:597-611 and src/tts.py:34. */
+/* dW(n, ci, tap) (+)= sum_rows dC(row, dcoff+n) * A(row + tap - pad, ci)   [torch weight layout (N, Cin, KT)]
+ * ws: st_gemm_wgrad_workspace_floats() floats of scratch (row-split partial slabs, added in fixed order) */
+size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int N, int KT);
+int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* ws,
+                  int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate, void* stream);
+/* out(n) (+)= sum_m X(m, xoff+n) [* Y(m, yoff+n)]      (bias gradients, AdaIN statistics gradients) */
+int st_colsum(const float* X, int ldx, int xoff, const float* Y, int ldy, int yoff, int M, int N,
+              float* out, int accumulate, void* stream);
+/* dpre = dout * mask * act'(out)   (out = the activated forward value; mask may be NULL) */
+int st_act_bwd(const float* dout, int ldd, const float* out, int ldo, int act, const float* mask, int ldm,
+               float* dpre, int ldp, int M, int N, void* stream);
+/* BatchNorm backward with batch statistics, y = act((x - mean)/sqrt(var+eps)*w + b):
+ * dx = w/sigma * (dyb - mean(dyb) - xhat * mean(dyb*xhat)), dw (+)= sum dyb*xhat, db (+)= sum dyb,
+ * dyb = dy * act'(y).  ws: 2*N floats. */
+int st_bn_bwd(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+              const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+              int M, int N, float* dx, int lddx, int dxoff, float* dw, float* db, int accumulate, float* ws, void* stream);
+/* Highway combine y = H*T + x*(1-T) and its backward dH = dy*T, dT = dy*(H-x), dx_direct = dy*(1-T)
+ * ref: src/module.py:551-554 */
+int st_highway_fwd(const float* H, const float* Tgate, const float* x, float* y, size_t total, void* stream);
+int st_highway_bwd(const float* dy, const float* H, const float* x, const float* Tgate,
+                   float* dH, float* dT, float* dx_direct, size_t total, void* stream);
+/* backward of the fused MaxPool1d(2,1,1)[:T]: dx(b,t,c) from the gradient w.r.t. the pooled tensor */
+int st_pool_prev_bwd(const float* dy_pooled, const float* x, float* dx, int Bn, int T, int C, void* stream);
+/* dst(b,t,:) (+)= src(b,t,:) with arbitrary (b,t) strides (elements) */
+int st_copy3d(float* dst, long dst_sb, long dst_st, const float* src, long src_sb, long src_st,
+              int Bn, int T, int C, int accumulate, void* stream);
+/* dtable(idx(r), :) += dout(r, :)    ref: backward of F.embedding src/embed.py:97-101 */
+int st_scatter_add_rows(const float* dout, const int64_t* idx, float* dtable, int n, int D, int V, void* stream);
+
 /* ------------------------------------------------------------------ recurrent sequence layers */
 /* One direction of nn.LSTM over a full sequence: xproj (B,T,4H) = x W_ih^T + b_ih
  * (from st_gemm_fwd; b_hh is added in the cell), out(b, t, ocol : ocol+H) = h_t.  Workspace ws: 3*B*H floats.

@@ -101,12 +101,24 @@ SIGNATURES = {
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],
     'st_decoder_forward': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderIO), P],
+    'st_bn_norm_fwd': [P, I, I, P, I, I, I, I, P, P, P, P, F, I, P],
+    'st_gemm_wgrad_workspace_floats': [I, I, I, I, I],
+    'st_gemm_wgrad': [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, I, P],
+    'st_colsum': [P, I, I, P, I, I, I, I, P, I, P],
+    'st_act_bwd': [P, I, P, I, I, P, I, P, I, I, I, P],
+    'st_bn_bwd': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, I, I, P, P, I, P, P],
+    'st_highway_fwd': [P, P, P, P, Z, P],
+    'st_highway_bwd': [P, P, P, P, P, P, P, Z, P],
+    'st_pool_prev_bwd': [P, P, P, I, I, I, P],
+    'st_copy3d': [P, C.c_long, C.c_long, P, C.c_long, C.c_long, I, I, I, I, P],
+    'st_scatter_add_rows': [P, P, P, I, I, I, P],
     'st_fill': [P, F, Z, P],
     'st_copy2d': [P, I, P, I, I, I, P],
     'st_mean_rows': [P, P, I, I, I, P],
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
-             'st_decoder_packed_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t}
+             'st_decoder_packed_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
+             'st_gemm_wgrad_workspace_floats': C.c_size_t}
 
 _lib = None
 

@@ -1,0 +1,435 @@
+// grad.hip -- backward-pass building blocks for gfx950 (MI355X), training path.
+//
+//  * weight gradient of a conv1d / linear:  dW[n][ci][tap] = sum_rows dC[row][n] * A[row + tap - pad][ci]
+//    ("TN" GEMM: the reduction runs over the (utterance, frame) rows).  Same 64x64x16 fp32-MFMA tile
+//    engine as gemm.hip; both operands are transposed into LDS while staging so the MFMA fragments
+//    are again one ds_read_b128 each.  Rows are split over blockIdx.z into partial slabs that a
+//    second kernel adds in a fixed order (deterministic, no atomics).
+//  * the input gradient of a conv/linear is the FORWARD kernel (st_gemm_fwd) on dC with the
+//    weight transposed and tap-flipped by the caller, so nothing is needed here for it.
+//  * column sums (bias gradients), BatchNorm backward (training statistics), activation / dropout
+//    backward, Highway backward, the fused max-pool backward, strided copies and row scatter-add.
+#include "st_common.h"
+
+namespace {
+
+constexpr int TN_T = 64, TN_BK = 16, TN_LD = 20, TN_THREADS = 256;
+
+struct TnArgs {
+    const float* dC; int lddc; int dcoff;       // (Bn*Tout, >= dcoff+N)
+    const float* A; int lda;                    // (Bn*Tin, Cin)
+    float* part;                                // [Z][N][Cin][KT]
+    int Bn, Tin, Tout, Cin, N, KT, pad, pool_prev;
+    int M, rows_per_z;
+};
+
+__global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
+    __shared__ __attribute__((aligned(16))) float Xs[TN_T * TN_LD];   // [n][m]
+    __shared__ __attribute__((aligned(16))) float Ys[TN_T * TN_LD];   // [ci][m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * TN_T;
+    const int cblocks = (g.Cin + TN_T - 1) / TN_T;
+    const int tap = blockIdx.y / cblocks, c0 = (blockIdx.y - tap * cblocks) * TN_T;
+    const int z = blockIdx.z;
+    const int mbeg = z * g.rows_per_z, mend = min(g.M, mbeg + g.rows_per_z);
+
+    // staging role: row m_local = tid/16 of the 16-row chunk, 4 consecutive columns
+    const int sm = tid >> 4, sc = (tid & 15) * 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_x = [&](int m) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m >= mend) return v;
+        const float* p = g.dC + (size_t)m * g.lddc + g.dcoff + n0 + sc;
+        const int rem = g.N - (n0 + sc);
+        if (rem > 0) v[0] = p[0];
+        if (rem > 1) v[1] = p[1];
+        if (rem > 2) v[2] = p[2];
+        if (rem > 3) v[3] = p[3];
+        return v;
+    };
+    auto load_y = [&](int m) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m >= mend) return v;
+        const int b = m / g.Tout, to = m - b * g.Tout;
+        const int ti = to + tap - g.pad;
+        const int ci = c0 + sc;
+        if (ti < 0 || ti >= g.Tin || ci >= g.Cin) return v;
+        const float* p = g.A + ((size_t)b * g.Tin + ti) * g.lda + ci;
+        const int rem = g.Cin - ci;
+        v[0] = p[0];
+        if (rem > 1) v[1] = p[1];
+        if (rem > 2) v[2] = p[2];
+        if (rem > 3) v[3] = p[3];
+        if (g.pool_prev && ti > 0) {
+            const float* q = p - g.lda;
+            v[0] = fmaxf(v[0], q[0]);
+            if (rem > 1) v[1] = fmaxf(v[1], q[1]);
+            if (rem > 2) v[2] = fmaxf(v[2], q[2]);
+            if (rem > 3) v[3] = fmaxf(v[3], q[3]);
+        }
+        return v;
+    };
+
+    const int fr = lane & 15, fk = (lane >> 4) * 4;
+    f32x4 rx = load_x(mbeg + sm), ry = load_y(mbeg + sm);
+    for (int m = mbeg; m < mend; m += TN_BK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Xs[(sc + j) * TN_LD + sm] = rx[j]; Ys[(sc + j) * TN_LD + sm] = ry[j]; }
+        __syncthreads();
+        if (m + TN_BK < mend) { rx = load_x(m + TN_BK + sm); ry = load_y(m + TN_BK + sm); }
+        f32x4 a4[2], b4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a4[t] = *reinterpret_cast<const f32x4*>(Xs + (wm * 32 + t * 16 + fr) * TN_LD + fk);
+            b4[t] = *reinterpret_cast<const f32x4*>(Ys + (wn * 32 + t * 16 + fr) * TN_LD + fk);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
+        __syncthreads();
+    }
+    float* out = g.part + (size_t)z * g.N * g.Cin * g.KT;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int ci = c0 + wn * 32 + nt * 16 + (lane & 15);
+        if (ci >= g.Cin) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * 32 + mt * 16 + 4 * (lane >> 4) + r;
+                if (n < g.N) out[((size_t)n * g.Cin + ci) * g.KT + tap] = acc[mt][nt][r];
+            }
+    }
+}
+
+// out[i] (+)= sum_z part[z][i]   (fixed order)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, float* out, size_t n, int Z, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = accumulate ? out[i] : 0.0f;
+        for (int z = 0; z < Z; ++z) s += part[(size_t)z * n + i];
+        out[i] = s;
+    }
+}
+
+// column sums over M rows, optionally of X * Y:  out[n] (+)= sum_m X[m][n] (* Y[m][n])
+__global__ __launch_bounds__(256) void colsum_kernel(const float* X, int ldx, int xoff, const float* Y, int ldy, int yoff,
+                                                     int M, int N, float* out, int accumulate) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float s = 0.0f;
+    if (n < N)
+        for (int m = rl; m < M; m += 4) {
+            float v = X[(size_t)m * ldx + xoff + n];
+            if (Y) v *= Y[(size_t)m * ldy + yoff + n];
+            s += v;
+        }
+    red[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+
+__device__ __forceinline__ float act_grad(float out, int act) {
+    switch (act) {
+        case ST_ACT_RELU: return out > 0.0f ? 1.0f : 0.0f;
+        case ST_ACT_TANH: return 1.0f - out * out;
+        case ST_ACT_SIGMOID: return out * (1.0f - out);
+        default: return 1.0f;
+    }
+}
+
+// dpre = dout * mask * act'(out)      (2-D strided views, M x N)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, int ldd, const float* out, int ldo, int act,
+                                                      const float* mask, int ldm, float* dpre, int ldp, int M, int N) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / N;
+        const int n = (int)(i - m * N);
+        float g = dout[m * ldd + n];
+        if (mask) g *= mask[m * ldm + n];
+        if (act != ST_ACT_NONE) g *= act_grad(out[m * ldo + n], act);
+        dpre[m * ldp + n] = g;
+    }
+}
+
+// BatchNorm (batch statistics) backward.  y = act((x - mean) / sqrt(var + eps) * w + b).
+//   pass 1 (bn_bwd_reduce): s1[n] = sum dyb, s2[n] = sum dyb * xhat     with dyb = dy * act'(y)
+//   pass 2 (bn_bwd_apply):  dx = w / sigma * (dyb - s1/M - xhat * s2/M)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff,
+                                                            int act, const float* x, int ldx, int xoff, const float* mean,
+                                                            const float* var, float eps, int M, int N, float* s1, float* s2) {
+    __shared__ float r1[4][64], r2[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float a = 0.0f, b = 0.0f;
+    if (n < N) {
+        const float mu = mean[n], inv = 1.0f / sqrtf(var[n] + eps);
+        for (int m = rl; m < M; m += 4) {
+            float g = dy[(size_t)m * ldd + doff + n];
+            if (act != ST_ACT_NONE) g *= act_grad(y[(size_t)m * ldy + yoff + n], act);
+            a += g;
+            b = fmaf(g, (x[(size_t)m * ldx + xoff + n] - mu) * inv, b);
+        }
+    }
+    r1[rl][c] = a; r2[rl][c] = b;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        s1[n] = r1[0][c] + r1[1][c] + r1[2][c] + r1[3][c];
+        s2[n] = r2[0][c] + r2[1][c] + r2[2][c] + r2[3][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff,
+                                                           int act, const float* x, int ldx, int xoff, const float* mean,
+                                                           const float* var, const float* w, float eps, int M, int N,
+                                                           const float* s1, const float* s2, float* dx, int lddx, int dxoff) {
+    const size_t total = (size_t)M * N;
+    const float invM = 1.0f / (float)M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / N;
+        const int n = (int)(i - m * N);
+        float g = dy[m * ldd + doff + n];
+        if (act != ST_ACT_NONE) g *= act_grad(y[m * ldy + yoff + n], act);
+        const float inv = 1.0f / sqrtf(var[n] + eps);
+        const float xh = (x[m * ldx + xoff + n] - mean[n]) * inv;
+        dx[m * lddx + dxoff + n] = (w ? w[n] : 1.0f) * inv * (g - s1[n] * invM - xh * s2[n] * invM);
+    }
+}
+
+// Highway y = H*T + x*(1-T):  dH = dy*T, dT = dy*(H - x), dx_direct = dy*(1-T)      ref: src/module.py:551-554
+// (the activation derivatives of H = relu(.) and T = sigmoid(.) are applied by the producers' backward)
+__global__ __launch_bounds__(256) void highway_bwd_kernel(const float* dy, const float* H, const float* x, const float* T,
+                                                          float* dH, float* dT, float* dxd, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = dy[i], t = T[i];
+        dH[i] = g * t;
+        dT[i] = g * (H[i] - x[i]);
+        dxd[i] = g * (1.0f - t);
+    }
+}
+
+// backward of x'[t] = max(x[t-1], x[t]) within an utterance (t = 0 keeps x[0]).  torch's MaxPool1d scans the
+// window left to right and keeps the FIRST maximum, so on a tie x[t-1] receives the gradient of output t.
+__global__ __launch_bounds__(256) void pool_prev_bwd_kernel(const float* dyp, const float* x, float* dx, int Bn, int T, int C) {
+    const size_t total = (size_t)Bn * T * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t row = i / C;
+        const int t = (int)(row % T);
+        const float xv = x[i];
+        float g = 0.0f;
+        // contribution of output t: x[t] is selected when t == 0 or x[t] > x[t-1]
+        if (t == 0 || xv > x[i - C]) g += dyp[i];
+        // contribution of output t+1: x[t] is selected when x[t] >= x[t+1]
+        if (t + 1 < T && xv >= x[i + C]) g += dyp[i + C];
+        dx[i] = g;
+        (void)c;
+    }
+}
+
+// dst(b, t, c) (+)= src(b, t, c) over arbitrary (b, t) strides, contiguous c
+__global__ __launch_bounds__(256) void copy3d_kernel(float* dst, long dsb, long dst_, const float* src, long ssb, long sst,
+                                                     int Bn, int T, int C, int accumulate) {
+    const size_t total = (size_t)Bn * T * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t row = i / C;
+        const int t = (int)(row % T);
+        const size_t b = row / T;
+        const float v = src[b * ssb + (size_t)t * sst + c];
+        float* p = dst + b * dsb + (size_t)t * dst_ + c;
+        *p = accumulate ? *p + v : v;
+    }
+}
+
+// dtable(idx(r), :) += dout(r, :)   (embedding backward; fp32 atomics: the order of additions into one row
+// is not fixed, rows have at most a few dozen contributions)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* dout, const int64_t* idx, float* dtable,
+                                                               int n, int D, int V) {
+    const size_t total = (size_t)n * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / D;
+        const int d = (int)(i - r * D);
+        const int64_t v = idx[r];
+        if (v >= 0 && v < V) atomicAdd(dtable + (size_t)v * D + d, dout[i]);
+    }
+}
+
+// out-of-place BatchNorm normalisation: Y = act((X - mean) / sqrt(var + eps) * w + b); X is kept for the backward
+__global__ __launch_bounds__(256) void bn_norm_fwd_kernel(const float* X, int ldx, int xoff, float* Y, int ldy, int yoff,
+                                                          int M, int N, const float* mean, const float* var, const float* w,
+                                                          const float* b, float eps, int act) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / N;
+        const int n = (int)(i - m * N);
+        float v = (X[m * ldx + xoff + n] - mean[n]) / sqrtf(var[n] + eps);
+        v = v * (w ? w[n] : 1.0f) + (b ? b[n] : 0.0f);
+        Y[m * ldy + yoff + n] = st_act(v, act);
+    }
+}
+
+// Highway combine (training forward keeps H and T): y = H * T + x * (1 - T)      ref: src/module.py:554
+__global__ __launch_bounds__(256) void highway_fwd_kernel(const float* H, const float* T, const float* x, float* y, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = T[i];
+        y[i] = H[i] * t + x[i] * (1.0f - t);
+    }
+}
+
+inline int blocks_for(size_t n, int cap = 4096) {
+    size_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b > (size_t)cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int N, int KT) {
+    const int M = Bn * Tout;
+    const int tiles = ((N + TN_T - 1) / TN_T) * ((Cin + TN_T - 1) / TN_T) * KT;
+    int Z = (512 + tiles - 1) / tiles;
+    const int maxz = (M + 255) / 256;
+    if (Z > maxz) Z = maxz;
+    if (Z < 1) Z = 1;
+    return (size_t)Z * N * Cin * KT;
+}
+
+extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* ws,
+                             int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate,
+                             void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dC && A && dW && ws && Bn > 0 && Tin > 0 && Tout > 0 && Cin > 0 && N > 0 && KT > 0, "st_gemm_wgrad: bad arguments");
+    TnArgs g;
+    memset(&g, 0, sizeof(g));
+    g.dC = dC; g.lddc = lddc; g.dcoff = dcoff; g.A = A; g.lda = lda; g.part = ws;
+    g.Bn = Bn; g.Tin = Tin; g.Tout = Tout; g.Cin = Cin; g.N = N; g.KT = KT; g.pad = pad; g.pool_prev = pool_prev;
+    g.M = Bn * Tout;
+    const size_t per = (size_t)N * Cin * KT;
+    const int Z = (int)(st_gemm_wgrad_workspace_floats(Bn, Tout, Cin, N, KT) / per);
+    g.rows_per_z = (((g.M + Z - 1) / Z) + TN_BK - 1) / TN_BK * TN_BK;
+    dim3 grid((N + TN_T - 1) / TN_T, ((Cin + TN_T - 1) / TN_T) * KT, Z);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tn_kernel, grid, dim3(TN_THREADS), 0, st, g);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(per)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_colsum(const float* X, int ldx, int xoff, const float* Y, int ldy, int yoff, int M, int N,
+                         float* out, int accumulate, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(X && out && M > 0 && N > 0, "st_colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, ldx, xoff, Y, ldy, yoff,
+                       M, N, out, accumulate);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_act_bwd(const float* dout, int ldd, const float* out, int ldo, int act, const float* mask, int ldm,
+                          float* dpre, int ldp, int M, int N, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dout && dpre && M > 0 && N > 0 && (act == ST_ACT_NONE || out), "st_act_bwd: bad arguments");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, (hipStream_t)stream,
+                       dout, ldd, out, ldo, act, mask, ldm, dpre, ldp, M, N);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_bwd(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                         const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+                         int M, int N, float* dx, int lddx, int dxoff, float* dw, float* db, int accumulate, float* ws,
+                         void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dy && x && mean && var && dx && ws && M > 0 && N > 0 && (act == ST_ACT_NONE || y), "st_bn_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* s1 = ws;
+    float* s2 = ws + N;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 63) / 64), dim3(256), 0, st, dy, ldd, doff, y, ldy, yoff, act,
+                       x, ldx, xoff, mean, var, eps, M, N, s1, s2);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, st, dy, ldd, doff, y, ldy, yoff,
+                       act, x, ldx, xoff, mean, var, w, eps, M, N, s1, s2, dx, lddx, dxoff);
+    ST_LAUNCH_CHECK();
+    if (db) {   // d beta = s1, d gamma = s2
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, st, s1, db, (size_t)N, 1, accumulate);
+        ST_LAUNCH_CHECK();
+    }
+    if (dw) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, st, s2, dw, (size_t)N, 1, accumulate);
+        ST_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int st_highway_bwd(const float* dy, const float* H, const float* x, const float* Tgate,
+                              float* dH, float* dT, float* dx_direct, size_t total, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dy && H && x && Tgate && dH && dT && dx_direct && total > 0, "st_highway_bwd: bad arguments");
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       dy, H, x, Tgate, dH, dT, dx_direct, total);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_pool_prev_bwd(const float* dy_pooled, const float* x, float* dx, int Bn, int T, int C, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dy_pooled && x && dx && Bn > 0 && T > 0 && C > 0, "st_pool_prev_bwd: bad arguments");
+    hipLaunchKernelGGL(pool_prev_bwd_kernel, dim3(blocks_for((size_t)Bn * T * C)), dim3(256), 0, (hipStream_t)stream,
+                       dy_pooled, x, dx, Bn, T, C);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_copy3d(float* dst, long dst_sb, long dst_st, const float* src, long src_sb, long src_st,
+                         int Bn, int T, int C, int accumulate, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dst && src && Bn > 0 && T > 0 && C > 0, "st_copy3d: bad arguments");
+    hipLaunchKernelGGL(copy3d_kernel, dim3(blocks_for((size_t)Bn * T * C)), dim3(256), 0, (hipStream_t)stream,
+                       dst, dst_sb, dst_st, src, src_sb, src_st, Bn, T, C, accumulate);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_scatter_add_rows(const float* dout, const int64_t* idx, float* dtable, int n, int D, int V, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dout && idx && dtable && n > 0 && D > 0 && V > 0, "st_scatter_add_rows: bad arguments");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks_for((size_t)n * D)), dim3(256), 0, (hipStream_t)stream,
+                       dout, idx, dtable, n, D, V);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_norm_fwd(const float* X, int ldx, int xoff, float* Y, int ldy, int yoff, int M, int N,
+                              const float* mean, const float* var, const float* w, const float* b, float eps, int act,
+                              void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(X && Y && mean && var && M > 0 && N > 0, "st_bn_norm_fwd: bad arguments");
+    hipLaunchKernelGGL(bn_norm_fwd_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, (hipStream_t)stream,
+                       X, ldx, xoff, Y, ldy, yoff, M, N, mean, var, w, b, eps, act);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_highway_fwd(const float* H, const float* Tgate, const float* x, float* y, size_t total, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(H && Tgate && x && y && total > 0, "st_highway_fwd: bad arguments");
+    hipLaunchKernelGGL(highway_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, H, Tgate, x, y, total);
+    ST_LAUNCH_CHECK();
+    return 0;
+}

@@ -243,6 +243,111 @@ def mean_rows(src):
     return dst
 
 
+# --------------------------------------------------------------------------------------------- backward blocks
+def bn_norm(x2d, xoff, N, mean, var, w, b, eps, act=None, out=None, yoff=0):
+    """out-of-place BatchNorm normalisation (training forward keeps x2d for the backward)"""
+    M = x2d.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    check(_lib.load().st_bn_norm_fwd(_p(x2d), int(x2d.stride(0)), int(xoff), _p(out), int(out.stride(0)), int(yoff), M, N,
+                                     _p(mean), _p(var), _p(w), _p(b), float(eps), ACT[act], stream_handle()), 'st_bn_norm_fwd')
+    return out
+
+
+def gemm_wgrad(dc, a, KT=1, pad=0, *, Bn=None, Tin=None, Tout=None, dcoff=0, N=None, pool_prev=False, out=None,
+               accumulate=False):
+    """dW (N, Cin[, KT]) of C = conv1d/linear(a, W): dc (Bn, Tout, >=dcoff+N) or (M, .), a (Bn, Tin, Cin) or (M, Cin)"""
+    lib = _lib.load()
+    if a.dim() == 3:
+        Bn_, Tin_, Cin = a.shape
+    else:
+        Bn_, Tin_, Cin = 1, a.shape[0], a.shape[1]
+    Bn = Bn or Bn_
+    Tin = Tin or Tin_
+    if Tout is None:
+        Tout = dc.shape[1] if dc.dim() == 3 else dc.shape[0] // Bn
+    N = N if N is not None else dc.shape[-1] - dcoff
+    if out is None:
+        out = torch.empty((N, Cin, KT) if KT > 1 else (N, Cin), device=a.device, dtype=torch.float32)
+    nws = int(lib.st_gemm_wgrad_workspace_floats(int(Bn), int(Tout), int(Cin), int(N), int(KT)))
+    ws = torch.empty(nws, device=a.device, dtype=torch.float32)
+    check(lib.st_gemm_wgrad(_p(dc), int(dc.stride(-2)), int(dcoff), _p(a), int(a.stride(-2)), _p(out), _p(ws), int(Bn),
+                            int(Tin), int(Tout), int(Cin), int(N), int(KT), int(pad), 1 if pool_prev else 0,
+                            1 if accumulate else 0, stream_handle()), 'st_gemm_wgrad')
+    return out
+
+
+def colsum(x2d, N=None, xoff=0, y2d=None, yoff=0, out=None, accumulate=False):
+    M = x2d.shape[0]
+    N = N if N is not None else x2d.shape[1] - xoff
+    if out is None:
+        out = torch.empty(N, device=x2d.device, dtype=torch.float32)
+    check(_lib.load().st_colsum(_p(x2d), int(x2d.stride(0)), int(xoff), _p(y2d), int(y2d.stride(0)) if y2d is not None else 0,
+                                int(yoff), M, N, _p(out), 1 if accumulate else 0, stream_handle()), 'st_colsum')
+    return out
+
+
+def act_bwd(dout2d, out2d, act, mask2d=None, dpre=None):
+    M, N = dout2d.shape
+    if dpre is None:
+        dpre = torch.empty(M, N, device=dout2d.device, dtype=torch.float32)
+    check(_lib.load().st_act_bwd(_p(dout2d), int(dout2d.stride(0)), _p(out2d), int(out2d.stride(0)) if out2d is not None else 0,
+                                 ACT[act], _p(mask2d), int(mask2d.stride(0)) if mask2d is not None else 0, _p(dpre),
+                                 int(dpre.stride(0)), M, N, stream_handle()), 'st_act_bwd')
+    return dpre
+
+
+def bn_bwd(dy2d, y2d, act, x2d, mean, var, w, eps, need_wb=True):
+    """returns dx, dw, db for y = act(BN_train(x))"""
+    M, N = x2d.shape
+    dx = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    dw = torch.empty(N, device=x2d.device, dtype=torch.float32) if need_wb else None
+    db = torch.empty(N, device=x2d.device, dtype=torch.float32) if need_wb else None
+    ws = torch.empty(2 * N, device=x2d.device, dtype=torch.float32)
+    check(_lib.load().st_bn_bwd(_p(dy2d), int(dy2d.stride(0)), 0, _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, 0,
+                                ACT[act], _p(x2d), int(x2d.stride(0)), 0, _p(mean), _p(var), _p(w), float(eps), M, N,
+                                _p(dx), N, 0, _p(dw), _p(db), 0, _p(ws), stream_handle()), 'st_bn_bwd')
+    return dx, dw, db
+
+
+def highway_fwd(H, Tg, x):
+    y = torch.empty_like(x)
+    check(_lib.load().st_highway_fwd(_p(H), _p(Tg), _p(x), _p(y), x.numel(), stream_handle()), 'st_highway_fwd')
+    return y
+
+
+def highway_bwd(dy, H, x, Tg):
+    dH, dT, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    check(_lib.load().st_highway_bwd(_p(dy), _p(H), _p(x), _p(Tg), _p(dH), _p(dT), _p(dx), x.numel(), stream_handle()),
+          'st_highway_bwd')
+    return dH, dT, dx
+
+
+def pool_prev_bwd(dy_pooled, x):
+    Bn, T, Cc = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().st_pool_prev_bwd(_p(dy_pooled), _p(x), _p(dx), Bn, T, Cc, stream_handle()), 'st_pool_prev_bwd')
+    return dx
+
+
+def copy3d(dst, src, Bn, T, Cc, accumulate=False):
+    """dst[b, t, :Cc] (+)= src[b, t, :Cc]; both (Bn, T, >=Cc) views with unit channel stride"""
+    assert dst.stride(-1) == 1 and src.stride(-1) == 1
+    check(_lib.load().st_copy3d(_p(dst), int(dst.stride(0)), int(dst.stride(1)), _p(src), int(src.stride(0)),
+                                int(src.stride(1)), Bn, T, Cc, 1 if accumulate else 0, stream_handle()), 'st_copy3d')
+    return dst
+
+
+def scatter_add_rows(dout, idx, V):
+    D = dout.shape[-1]
+    idx = idx.contiguous()
+    dtable = torch.empty(V, D, device=dout.device, dtype=torch.float32)
+    fill_(dtable, 0.0)
+    check(_lib.load().st_scatter_add_rows(_p(dout), _p(idx, torch.int64), _p(dtable), idx.numel(), D, V, stream_handle()),
+          'st_scatter_add_rows')
+    return dtable
+
+
 # --------------------------------------------------------------------------------------------- packed operands
 def t16_floats(B, K):
     return int(_lib.load().st_t16_floats(int(B), int(K)))

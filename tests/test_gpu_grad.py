@@ -1,0 +1,164 @@
+"""Gradient parity of the HIP backward path (through the C ABI) against CPU autograd through the
+oracle / the torch ops the reference's modules are made of.  Needs a real MI355X: pytest -m gpu
+
+Tolerances are written next to each check; gradients are sums of O(rows) fp32 products, compared
+with a float64 CPU evaluation and normalised by the gradient's own scale.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import maxdiff, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'the gpu-marked tests need a GPU'
+    from semi_tts_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def relerr(a, b):
+    b = b.detach().cpu().double()
+    return float((a.detach().cpu().double() - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def conv_cl_ref(x, w, b, pad, Tout, act, pool_prev=False, res=None, mask=None):
+    """float64 torch restatement of the conv the reference builds from nn.Conv1d (+MaxPool1d(2,1,1)[:T])"""
+    xt = x.transpose(1, 2)
+    if pool_prev:
+        xt = F.max_pool1d(xt, 2, 1, 1)[:, :, :x.shape[1]]
+    y = F.conv1d(xt, w, b, padding=pad)[:, :, :Tout].transpose(1, 2)
+    if act == 'relu':
+        y = torch.relu(y)
+    elif act == 'tanh':
+        y = torch.tanh(y)
+    elif act == 'sigmoid':
+        y = torch.sigmoid(y)
+    if res is not None:
+        y = y + res
+    if mask is not None:
+        y = y * mask
+    return y
+
+
+@pytest.mark.parametrize('B,T,Cin,N,KT,pad,act,pool', [
+    (3, 37, 24, 40, 5, 2, None, False),        # encoder conv
+    (2, 50, 80, 80, 4, 2, 'relu', False),      # even-k bank conv (Tout = T+1 and T below)
+    (2, 33, 70, 65, 3, 1, 'relu', True),       # first projection conv with the fused max-pool
+    (4, 20, 16, 130, 1, 0, 'sigmoid', False),  # k=1
+    (2, 29, 48, 33, 16, 8, 'tanh', False),     # widest bank conv
+])
+def test_conv_backward(dev, B, T, Cin, N, KT, pad, act, pool):
+    from semi_tts_amd import autograd as AG
+    x, w, b = rnd(B, T, Cin, seed=1), rnd(N, Cin, KT, scale=(Cin * KT) ** -0.5, seed=2), rnd(N, seed=3)
+    for Tout in sorted({T + 2 * pad - KT + 1, T}):
+        if Tout > T + 2 * pad - KT + 1:
+            continue
+        dy = rnd(B, Tout, N, seed=4)
+        xd, wd, bd = (t.to(dev).requires_grad_() for t in (x, w, b))
+        y = AG.conv(xd, wd, bd, pad=pad, Tout=Tout, act=act, pool_prev=pool)
+        y.backward(dy.to(dev))
+        xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+        yr = conv_cl_ref(xr, wr, br, pad, Tout, act, pool)
+        yr.backward(dy.double())
+        errs = dict(y=maxdiff(y, yr), dx=relerr(xd.grad, xr.grad), dw=relerr(wd.grad, wr.grad), db=relerr(bd.grad, br.grad))
+        report('conv_backward', B=B, T=T, Cin=Cin, N=N, KT=KT, Tout=Tout, **errs)
+        assert errs['y'] < 2e-5
+        assert max(errs['dx'], errs['dw'], errs['db']) < 2e-5      # fp32 sums of <= B*T*KT*N terms vs float64
+
+
+def test_linear_backward_with_mask_and_residual(dev):
+    from semi_tts_amd import autograd as AG
+    M, K, N = 300, 70, 50
+    x, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
+    mask = (torch.rand(M, N) > 0.5).float() * 2
+    dy = rnd(M, N, seed=3)
+    xd, wd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+    y = AG.linear(xd, wd, None, 'relu', mask.to(dev))
+    y.backward(dy.to(dev))
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = torch.relu(xr @ wr.t()) * mask.double()
+    yr.backward(dy.double())
+    assert maxdiff(y, yr) < 1e-5
+    assert relerr(xd.grad, xr.grad) < 1e-5 and relerr(wd.grad, wr.grad) < 1e-5
+    # residual after a linear map (pre_highway_proj + inputs, src/module.py:607-609)
+    res = rnd(2, 150, N, seed=5)
+    xd, wd, rd = x.view(2, 150, K).to(dev).requires_grad_(), w.to(dev).requires_grad_(), res.to(dev).requires_grad_()
+    y = AG.conv(xd, wd, None, res=rd)
+    y.backward(dy.view(2, 150, N).to(dev))
+    xr, wr, rr = x.view(2, 150, K).double().requires_grad_(), w.double().requires_grad_(), res.double().requires_grad_()
+    (xr @ wr.t() + rr).backward(dy.view(2, 150, N).double())
+    assert relerr(xd.grad, xr.grad) < 1e-5 and relerr(wd.grad, wr.grad) < 1e-5 and relerr(rd.grad, rr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
+def test_batchnorm_train_backward(dev, act):
+    from semi_tts_amd import autograd as AG
+    B, T, N = 3, 41, 70
+    x = rnd(B, T, N, seed=1) * 2 + 0.5
+    bn = torch.nn.BatchNorm1d(N, momentum=0.99, eps=1e-3)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(N, seed=2) * 0.3 + 1)
+        bn.bias.copy_(rnd(N, seed=3) * 0.3)
+    import copy
+    bnd = copy.deepcopy(bn).to(dev)
+    dy = rnd(B, T, N, seed=4)
+    xd = x.to(dev).requires_grad_()
+    y = AG.batch_norm_train(xd, bnd, act)
+    y.backward(dy.to(dev))
+    bn = bn.double()
+    xr = x.double().requires_grad_()
+    yr = bn(xr.transpose(1, 2)).transpose(1, 2)
+    yr = {'relu': torch.relu, 'tanh': torch.tanh, None: lambda v: v}[act](yr)
+    yr.backward(dy.double())
+    errs = dict(y=maxdiff(y, yr), dx=relerr(xd.grad, xr.grad), dw=relerr(bnd.weight.grad, bn.weight.grad),
+                db=relerr(bnd.bias.grad, bn.bias.grad), rm=maxdiff(bnd.running_mean, bn.running_mean),
+                rv=maxdiff(bnd.running_var, bn.running_var))
+    report('bn_train_backward', act=str(act), **errs)
+    assert errs['y'] < 1e-5 and errs['rm'] < 1e-5 and errs['rv'] < 1e-5
+    assert max(errs['dx'], errs['dw'], errs['db']) < 2e-5
+    assert int(bnd.num_batches_tracked) == 1
+
+
+def test_highway_and_gather_backward(dev):
+    from semi_tts_amd import autograd as AG
+    H, Tg, x, dy = (rnd(4, 30, 48, seed=s) for s in (1, 2, 3, 4))
+    Tg = torch.sigmoid(Tg)
+    d = [t.to(dev).requires_grad_() for t in (H, Tg, x)]
+    y = AG.highway_combine(*d)
+    y.backward(dy.to(dev))
+    r = [t.double().requires_grad_() for t in (H, Tg, x)]
+    yr = r[0] * r[1] + r[2] * (1 - r[1])
+    yr.backward(dy.double())
+    assert maxdiff(y, yr) < 1e-6
+    for a, b in zip(d, r):
+        assert relerr(a.grad, b.grad) < 1e-6
+    table, idx = rnd(40, 24, seed=5), torch.randint(0, 40, (6, 17))
+    td = table.to(dev).requires_grad_()
+    out = AG.gather(td, idx.to(dev))
+    g = rnd(6, 17, 24, seed=6)
+    out.backward(g.to(dev))
+    tr = table.double().requires_grad_()
+    F.embedding(idx, tr).backward(g.double())
+    assert maxdiff(out, F.embedding(idx, table)) == 0.0
+    assert relerr(td.grad, tr.grad) < 1e-6      # fp32 atomics: order of <= ~10 additions per row is free
+
+
+def test_pool_prev_backward_ties(dev):
+    # MaxPool1d(2,1,1)[:T] keeps the FIRST maximum of a window: ties send the gradient to x[t-1]
+    from semi_tts_amd import ops
+    x = torch.tensor([[[1.0], [1.0], [0.5], [2.0], [2.0], [2.0]]])
+    dyp = torch.tensor([[[1.0], [10.0], [100.0], [1000.0], [1e4], [1e5]]])
+    dx = ops.pool_prev_bwd(dyp.to(dev), x.to(dev))
+    xr = x.double().requires_grad_()
+    F.max_pool1d(xr.transpose(1, 2), 2, 1, 1)[:, :, :6].backward(dyp.double().transpose(1, 2))
+    assert maxdiff(dx, xr.grad) == 0.0

@@ -258,16 +258,38 @@ int st_scatter_add_rows(const float* dout, const int64_t* idx, float* dtable, in
 /* ------------------------------------------------------------------ recurrent sequence layers */
 /* One direction of nn.LSTM over a full sequence: xproj (B,T,4H) = x W_ih^T + b_ih
  * (from st_gemm_fwd; b_hh is added in the cell), out(b, t, ocol : ocol+H) = h_t.  Workspace ws: 3*B*H floats.
+ * Training: gates_tape (T,B,4,H) receives the activated gates and c_tape (T,B,H) every cell state (both
+ * indexed by time step); NULL in inference.
  * ref: nn.LSTM src/module.py:432-438,:458-460 (lengths ignored, zero initial state). */
 int st_lstm_seq_fwd(const float* xproj, const float* w_hh, const float* b_hh, float* out, int ldo, int ocol,
-                    float* ws, int B, int T, int H, int reverse, void* stream);
+                    float* ws, float* gates_tape, float* c_tape, int B, int T, int H, int reverse, void* stream);
+/* Pointwise half of one LSTM cell backward step (shared by the encoder BiLSTM and the decoder's two cells):
+ * dh = (dh0 + dh1 + dh2 * scale2) * mask;  from dh and the carried dc (B,H, updated in place to dL/dc_{t-1})
+ * to dgates (B,4H) w.r.t. the pre-activation gates in torch order (i,f,g,o).  dh1, dh2, scale2, mask, c_prev
+ * may be NULL.  ref: backward of nn.LSTMCell src/module.py:228,:277 */
+int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float* dh1, int ld1, const float* dh2, int ld2,
+                               const float* scale2, const float* mask, const float* gates, const float* c, int ldc,
+                               const float* c_prev, int ldcp, float* dc, float* dgates, int ldg, int B, int H,
+                               void* stream);
+/* Backward through time of st_lstm_seq_fwd: dout(b, t, dcol : dcol+H) -> dxproj (B,T,4H) (= gradient of the
+ * input projection incl. both biases).  w_hh_t = W_hh^T (H, 4H).  ws: 2*B*H floats.  The caller finishes with
+ * dW_hh = st_gemm_wgrad(dxproj, out shifted by one step) and db = st_colsum(dxproj). */
+int st_lstm_seq_bwd(const float* dout, int ldd, int dcol, const float* gates_tape, const float* c_tape,
+                    const float* w_hh_t, float* dxproj, float* ws, int B, int T, int H, int reverse, void* stream);
 /* nn.GRU, ndir directions in one launch (direction 1 runs time-reversed), one workgroup per
  * (utterance, direction) keeps W_hh rows in registers and h in LDS for all T steps.
  * gi[d] (B,T,3H) = x W_ih[d]^T + b_ih[d] (from st_gemm_fwd); out(b, t, d*H : (d+1)*H) = h_t.
+ * Training: tape (ndir,B,T,4,H) receives (r, z, n, W_hn h + b_hn) per step; NULL in inference.
  * ref: nn.GRU src/module.py:585-586,:617 */
 int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const float* w_hh_fwd, const float* w_hh_bwd,
-                   const float* b_hh_fwd, const float* b_hh_bwd, float* out, int ldo,
+                   const float* b_hh_fwd, const float* b_hh_bwd, float* out, int ldo, float* tape,
                    int B, int T, int H, int ndir, void* stream);
+/* Backward through time of st_gru_seq_fwd, again one workgroup per (utterance, direction) with W_hh^T columns
+ * in registers: dout (B,T,>=ndir*H) -> dgi[d] (B,T,3H) (gradient of gi) and dgh[d] (B,T,3H) (gradient of
+ * W_hh h + b_hh).  The caller finishes with dW_hh = st_gemm_wgrad(dgh, out shifted by one step), db_hh = colsum. */
+int st_gru_seq_bwd(const float* dout, int ldd, const float* out, int ldo, const float* tape,
+                   const float* w_hh_fwd, const float* w_hh_bwd, float* dgi_fwd, float* dgi_bwd,
+                   float* dgh_fwd, float* dgh_bwd, int B, int T, int H, int ndir, void* stream);
 
 /* ------------------------------------------------------------------ VQ codebook */
 /* table(v, :) = cat[learnable(v, 0:Dl), attr(v,:) W_attr^T + b_attr]      (V, Dl + Da)

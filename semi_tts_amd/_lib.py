@@ -80,8 +80,11 @@ SIGNATURES = {
     'st_gemm_fwd': [P, I, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(StGemmEpilogue), P],
     'st_bn_stats': [P, I, I, I, I, P, P, P, P, F, P],
     'st_bn_apply': [P, I, I, I, I, P, P, P, P, F, I, P],
-    'st_lstm_seq_fwd': [P, P, P, P, I, I, P, I, I, I, I, P],
-    'st_gru_seq_fwd': [P, P, P, P, P, P, P, I, I, I, I, I, P],
+    'st_lstm_seq_fwd': [P, P, P, P, I, I, P, P, P, I, I, I, I, P],
+    'st_lstm_cell_bwd_pointwise': [P, I, P, I, P, I, P, P, P, P, I, P, I, P, P, I, I, I, P],
+    'st_lstm_seq_bwd': [P, I, I, P, P, P, P, P, I, I, I, I, P],
+    'st_gru_seq_fwd': [P, P, P, P, P, P, P, I, P, I, I, I, I, P],
+    'st_gru_seq_bwd': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, P],
     'st_vq_build_table': [P, I, P, I, P, P, I, P, I, P],
     'st_gather_rows': [P, P, P, I, I, I, P],
     'st_vq_l2_fwd': [P, P, P, P, P, P, I, I, I, P],

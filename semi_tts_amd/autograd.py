@@ -141,3 +141,69 @@ class _GatherFn(Function):
 
 def gather(table, idx):
     return _GatherFn.apply(table, idx)
+
+
+class _BiLstmFn(Function):
+    """Bidirectional nn.LSTM layer over precomputed input projections (lengths ignored, zero initial state).
+    ref: src/module.py:432-438,:458-460"""
+
+    @staticmethod
+    def forward(ctx, xp_f, xp_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
+        B, T, H4 = xp_f.shape
+        H = H4 // 4
+        dev = xp_f.device
+        out = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
+        ws = torch.empty(3 * B * H, device=dev, dtype=torch.float32)
+        tapes = []
+        for d, (xp, w, b) in enumerate(((xp_f, w_hh_f, b_hh_f), (xp_b, w_hh_b, b_hh_b))):
+            g = torch.empty(T, B, 4, H, device=dev, dtype=torch.float32)
+            c = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+            ops.lstm_seq(xp.contiguous(), w, b, out, d * H, d == 1, ws, g, c)
+            tapes += [g, c]
+        ctx.save_for_backward(out, w_hh_f, w_hh_b, *tapes)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, w_hh_f, w_hh_b, g_f, c_f, g_b, c_b = ctx.saved_tensors
+        dout = dout.contiguous()
+        H = w_hh_f.shape[1]
+        res = []
+        for d, (w, g, c) in enumerate(((w_hh_f, g_f, c_f), (w_hh_b, g_b, c_b))):
+            dxp = ops.lstm_seq_bwd(dout, d * H, g, c, w.detach().t().contiguous(), d == 1)
+            # h_{t-1} of the forward direction is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1 / -1
+            dw = ops.gemm_wgrad(dxp, out[:, :, d * H:(d + 1) * H], 1, 1 if d == 0 else -1)
+            db = ops.colsum(_rows(dxp))
+            res.append((dxp, dw, db))
+        return res[0][0], res[1][0], res[0][1], res[0][2], res[1][1], res[1][2]
+
+
+def bilstm(xp_f, xp_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
+    return _BiLstmFn.apply(xp_f, xp_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b)
+
+
+class _BiGruFn(Function):
+    """Bidirectional nn.GRU layer over precomputed input projections.  ref: src/module.py:585-586,:617"""
+
+    @staticmethod
+    def forward(ctx, gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
+        B, T, H3 = gi_f.shape
+        H = H3 // 3
+        out = torch.empty(B, T, 2 * H, device=gi_f.device, dtype=torch.float32)
+        tape = torch.empty(2, B, T, 4, H, device=gi_f.device, dtype=torch.float32)
+        ops.gru_seq(gi_f.contiguous(), gi_b.contiguous(), w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, tape)
+        ctx.save_for_backward(out, tape, w_hh_f, w_hh_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, tape, w_hh_f, w_hh_b = ctx.saved_tensors
+        H = w_hh_f.shape[1]
+        dgi_f, dgi_b, dgh_f, dgh_b = ops.gru_seq_bwd(dout.contiguous(), out, tape, w_hh_f, w_hh_b)
+        dw_f = ops.gemm_wgrad(dgh_f, out[:, :, :H], 1, 1)
+        dw_b = ops.gemm_wgrad(dgh_b, out[:, :, H:], 1, -1)
+        return dgi_f, dgi_b, dw_f, ops.colsum(_rows(dgh_f)), dw_b, ops.colsum(_rows(dgh_b))
+
+
+def bigru(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
+    return _BiGruFn.apply(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b)

@@ -17,6 +17,7 @@ constexpr int GRU_HMAX = 128;
 struct GruArgs {
     const float* gi[2]; const float* w_hh[2]; const float* b_hh[2];
     float* out; int ldo; int B, T, H;
+    float* tape;     // training: [dir][b][t][4][H] = (r, z, n, W_hn h + b_hn); NULL in inference
 };
 
 template <bool REG>
@@ -78,6 +79,10 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_kernel(const GruArgs
             const float hn = (1.0f - z) * n + z * hbuf[j];
             hbuf[j] = hn;
             a.out[((size_t)b * T + t) * a.ldo + d * H + j] = hn;
+            if (a.tape) {
+                float* tp = a.tape + ((((size_t)d * a.B + b) * T + t) * 4) * H + j;
+                tp[0] = r; tp[H] = z; tp[2 * H] = n; tp[3 * H] = ghs[2 * H + j];
+            }
             gr = nr; gz = nz; gn = nn;
         }
         __syncthreads();
@@ -85,11 +90,138 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_kernel(const GruArgs
     }
 }
 
+// ---- GRU backward through time: one workgroup per (utterance, direction), thread (g, k) keeps column k of
+// gate block g of W_hh in registers (the transposed mat-vec dh += W_hh^T dgh), dh carried in LDS.
+struct GruBwdArgs {
+    const float* dout; int ldd;       // (B, T, >= ndir*H) gradient w.r.t. out
+    const float* out; int ldo;        // forward output (h_t)
+    const float* tape;                // [dir][b][t][4][H]
+    const float* w_hh[2];
+    float* dgi[2];                    // (B, T, 3H) gradient w.r.t. gi (input projection incl. b_ih)
+    float* dgh[2];                    // (B, T, 3H) gradient w.r.t. W_hh h + b_hh
+    int B, T, H;
+};
+
+template <bool REG>
+__global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const GruBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = a.H, H3 = 3 * H, T = a.T;
+    const int H4 = (H + 3) & ~3;
+    float* dghs = lds;                 // [3][H4]  (pad entries stay zero)
+    float* part = lds + 3 * H4;        // [3H]
+    float* dhc = part + H3;            // [H]
+    const int b = blockIdx.x, d = blockIdx.y;
+    const int j = threadIdx.x;
+    const bool row_ok = j < H3;
+    const int g = row_ok ? j / H : 0, k = row_ok ? j - g * H : 0;
+    const float* __restrict__ whh = a.w_hh[d];
+    float wreg[REG ? GRU_HMAX : 4];
+    if (REG && row_ok) {
+#pragma unroll
+        for (int jj = 0; jj < GRU_HMAX; ++jj) wreg[jj] = jj < H ? whh[(size_t)(g * H + jj) * H + k] : 0.0f;
+    }
+    for (int i = j; i < 3 * H4; i += blockDim.x) dghs[i] = 0.0f;
+    if (j < H) dhc[j] = 0.0f;
+    __syncthreads();
+    const bool upd = j < H;
+    const float* tape = a.tape + (((size_t)d * a.B + b) * T) * 4 * H;
+    const float* outb = a.out + (size_t)b * T * a.ldo + d * H;
+    const float* doutb = a.dout + (size_t)b * T * a.ldd + d * H;
+    float* dgi = a.dgi[d] + (size_t)b * T * H3;
+    float* dgh = a.dgh[d] + (size_t)b * T * H3;
+    // processing order of the forward was t = 0..T-1 (d = 0) or T-1..0 (d = 1); walk it backwards
+    int t = d ? 0 : T - 1;
+    float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hp = 0.f, go = 0.f;
+    auto fetch = [&](int tt) {
+        const float* tp = tape + (size_t)tt * 4 * H + j;
+        r = tp[0]; z = tp[H]; n = tp[2 * H]; ghn = tp[3 * H];
+        const int tprev = d ? tt + 1 : tt - 1;
+        hp = (tprev >= 0 && tprev < T) ? outb[(size_t)tprev * a.ldo + j] : 0.0f;
+        go = doutb[(size_t)tt * a.ldd + j];
+    };
+    if (upd) fetch(t);
+    for (int s = 0; s < T; ++s) {
+        float dhp_direct = 0.0f;
+        if (upd) {
+            const float dh = dhc[j] + go;
+            const float dn = dh * (1.0f - z), dz = dh * (hp - n);
+            dhp_direct = dh * z;
+            const float dnp = dn * (1.0f - n * n);
+            const float dzp = dz * z * (1.0f - z);
+            const float drp = dnp * ghn * r * (1.0f - r);
+            float* gi_ = dgi + (size_t)t * H3 + j;
+            float* gh_ = dgh + (size_t)t * H3 + j;
+            gi_[0] = drp; gi_[H] = dzp; gi_[2 * H] = dnp;
+            gh_[0] = drp; gh_[H] = dzp; gh_[2 * H] = dnp * r;
+            dghs[j] = drp; dghs[H4 + j] = dzp; dghs[2 * H4 + j] = dnp * r;
+        }
+        __syncthreads();
+        const int tn = d ? t + 1 : t - 1;
+        if (upd && s + 1 < T) fetch(tn);        // next step's operands fly while the mat-vec runs
+        if (row_ok) {
+            float acc = 0.0f;
+            const float* dg = dghs + g * H4;
+            if (REG) {
+#pragma unroll
+                for (int jj = 0; jj < GRU_HMAX; jj += 4) {
+                    if (jj < H) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(dg + jj);
+                        acc = fmaf(wreg[jj], v[0], acc); acc = fmaf(wreg[jj + 1], v[1], acc);
+                        acc = fmaf(wreg[jj + 2], v[2], acc); acc = fmaf(wreg[jj + 3], v[3], acc);
+                    }
+                }
+            } else {
+                for (int jj = 0; jj < H; ++jj) acc = fmaf(whh[(size_t)(g * H + jj) * H + k], dg[jj], acc);
+            }
+            part[j] = acc;
+        }
+        __syncthreads();
+        if (upd) dhc[j] = dhp_direct + part[j] + part[H + j] + part[2 * H + j];
+        __syncthreads();
+        t = tn;
+    }
+}
+
+// ---- LSTM cell backward, pointwise part: from dh_t (sum of up to three addends, the third optionally scaled
+// element-wise, then the dropout mask) and the carried dc_t to the pre-activation gate gradients and dc_{t-1}.
+struct LstmPwArgs {
+    const float* dh0; int ld0; const float* dh1; int ld1; const float* dh2; int ld2; const float* scale2;
+    const float* mask;                 // (B, H) contiguous, may be NULL
+    const float* gates;                // (B, 4, H) activated (i, f, g, o)
+    const float* c; int ldc;           // c_t
+    const float* c_prev; int ldcp;     // c_{t-1}, NULL = zeros
+    float* dc;                         // (B, H) in: dL/dc_t carried from step t+1, out: dL/dc_{t-1}
+    float* dgates; int ldg;            // (B, 4H) torch gate order
+    int B, H;
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_pw_kernel(const LstmPwArgs a) {
+    const int total = a.B * a.H, H = a.H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / H, u = i - b * H;
+        float dh = a.dh0[(size_t)b * a.ld0 + u];
+        if (a.dh1) dh += a.dh1[(size_t)b * a.ld1 + u];
+        if (a.dh2) dh += a.dh2[(size_t)b * a.ld2 + u] * (a.scale2 ? a.scale2[i] : 1.0f);
+        if (a.mask) dh *= a.mask[i];
+        const float* gp = a.gates + (size_t)b * 4 * H + u;
+        const float gi = gp[0], gf = gp[H], gg = gp[2 * H], go = gp[3 * H];
+        const float tc = tanhf(a.c[(size_t)b * a.ldc + u]);
+        const float cp = a.c_prev ? a.c_prev[(size_t)b * a.ldcp + u] : 0.0f;
+        const float dc = a.dc[i] + dh * go * (1.0f - tc * tc);
+        float* dg = a.dgates + (size_t)b * a.ldg + u;
+        dg[0] = dc * gg * gi * (1.0f - gi);
+        dg[H] = dc * cp * gf * (1.0f - gf);
+        dg[2 * H] = dc * gi * (1.0f - gg * gg);
+        dg[3 * H] = dh * tc * go * (1.0f - go);
+        a.dc[i] = dc * gf;
+    }
+}
+
 }  // namespace
 
 extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const float* w_hh_fwd, const float* w_hh_bwd,
                               const float* b_hh_fwd, const float* b_hh_bwd, float* out, int ldo,
-                              int B, int T, int H, int ndir, void* stream) {
+                              float* tape, int B, int T, int H, int ndir, void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(ndir == 1 || ndir == 2, "st_gru_seq_fwd: ndir=%d", ndir);
     ST_CHECK_ARG(gi_fwd && w_hh_fwd && b_hh_fwd && out && B > 0 && T > 0 && H > 0, "st_gru_seq_fwd: bad arguments");
@@ -98,7 +230,7 @@ extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const fl
     ST_CHECK_ARG(ldo >= ndir * H, "st_gru_seq_fwd: ldo=%d < ndir*H", ldo);
     GruArgs a;
     a.gi[0] = gi_fwd; a.gi[1] = gi_bwd; a.w_hh[0] = w_hh_fwd; a.w_hh[1] = w_hh_bwd;
-    a.b_hh[0] = b_hh_fwd; a.b_hh[1] = b_hh_bwd; a.out = out; a.ldo = ldo; a.B = B; a.T = T; a.H = H;
+    a.b_hh[0] = b_hh_fwd; a.b_hh[1] = b_hh_bwd; a.out = out; a.ldo = ldo; a.B = B; a.T = T; a.H = H; a.tape = tape;
     const int threads = ((3 * H + 63) / 64) * 64;
     const size_t lds = (size_t)(((H + 3) & ~3) + 3 * H) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
@@ -109,7 +241,7 @@ extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const fl
 }
 
 extern "C" int st_lstm_seq_fwd(const float* xproj, const float* w_hh, const float* b_hh, float* out, int ldo, int ocol,
-                               float* ws, int B, int T, int H, int reverse, void* stream) {
+                               float* ws, float* gates_tape, float* c_tape, int B, int T, int H, int reverse, void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(xproj && w_hh && out && ws && B > 0 && T > 0 && H > 0, "st_lstm_seq_fwd: bad arguments");
     ST_CHECK_ARG(ldo >= ocol + H, "st_lstm_seq_fwd: ldo=%d < ocol+H", ldo);
@@ -125,11 +257,76 @@ extern "C" int st_lstm_seq_fwd(const float* xproj, const float* w_hh, const floa
         seg.w = w_hh; seg.ldw = H; seg.k = H;
         if (s == 0) { seg.x = zero; seg.ldx = H; }
         else { seg.x = out + (size_t)tp * ldo + ocol; seg.ldx = T * ldo; }
-        const float* cprev = s == 0 ? zero : cbuf[(s - 1) & 1];
+        // training keeps every c_t and the activated gates (tapes indexed by t, not by processing order)
+        const float* cprev = s == 0 ? zero : (c_tape ? c_tape + (size_t)tp * bh : cbuf[(s - 1) & 1]);
+        float* cnew = c_tape ? c_tape + (size_t)t * bh : cbuf[s & 1];
         int rc = st_lstm_cell_fwd(&seg, 1, nullptr, b_hh, xproj + (size_t)t * 4 * H, T * 4 * H,
                                   cprev, H, nullptr, out + (size_t)t * ldo + ocol, T * ldo,
-                                  cbuf[s & 1], H, nullptr, B, H, stream);
+                                  cnew, H, gates_tape ? gates_tape + (size_t)t * 4 * bh : nullptr, B, H, stream);
         if (rc) return rc;
     }
+    return 0;
+}
+
+extern "C" int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float* dh1, int ld1, const float* dh2, int ld2,
+                                          const float* scale2, const float* mask, const float* gates, const float* c, int ldc,
+                                          const float* c_prev, int ldcp, float* dc, float* dgates, int ldg, int B, int H,
+                                          void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dh0 && gates && c && dc && dgates && B > 0 && H > 0, "st_lstm_cell_bwd_pointwise: bad arguments");
+    LstmPwArgs a;
+    a.dh0 = dh0; a.ld0 = ld0; a.dh1 = dh1; a.ld1 = ld1; a.dh2 = dh2; a.ld2 = ld2; a.scale2 = scale2; a.mask = mask;
+    a.gates = gates; a.c = c; a.ldc = ldc; a.c_prev = c_prev; a.ldcp = ldcp; a.dc = dc; a.dgates = dgates; a.ldg = ldg;
+    a.B = B; a.H = H;
+    const int blocks = (B * H + 255) / 256;
+    hipLaunchKernelGGL(lstm_bwd_pw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_lstm_seq_bwd(const float* dout, int ldd, int dcol, const float* gates_tape, const float* c_tape,
+                               const float* w_hh_t, float* dxproj, float* ws, int B, int T, int H, int reverse, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dout && gates_tape && c_tape && w_hh_t && dxproj && ws && B > 0 && T > 0 && H > 0, "st_lstm_seq_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bh = (size_t)B * H;
+    float* dc = ws;            // carried dL/dc
+    float* dhrec = ws + bh;    // dL/dh_{t-1} through W_hh
+    ST_HIP(hipMemsetAsync(ws, 0, 2 * bh * sizeof(float), st));
+    for (int s = T - 1; s >= 0; --s) {                  // s = processing index of the forward
+        const int t = reverse ? T - 1 - s : s;
+        const int tp = reverse ? t + 1 : t - 1;
+        float* dg = dxproj + (size_t)t * 4 * H;          // row stride T*4H
+        int rc = st_lstm_cell_bwd_pointwise(dout + (size_t)t * ldd + dcol, T * ldd, dhrec, H, nullptr, 0, nullptr, nullptr,
+                                            gates_tape + (size_t)t * 4 * bh, c_tape + (size_t)t * bh, H,
+                                            s == 0 ? nullptr : c_tape + (size_t)tp * bh, H, dc, dg, T * 4 * H, B, H, stream);
+        if (rc) return rc;
+        if (s == 0) break;
+        st_seg seg;
+        seg.x = dg; seg.ldx = T * 4 * H; seg.w = w_hh_t; seg.ldw = 4 * H; seg.k = 4 * H;
+        rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, dhrec, H, 0, nullptr, 0, 0, B, H, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int st_gru_seq_bwd(const float* dout, int ldd, const float* out, int ldo, const float* tape,
+                              const float* w_hh_fwd, const float* w_hh_bwd, float* dgi_fwd, float* dgi_bwd,
+                              float* dgh_fwd, float* dgh_bwd, int B, int T, int H, int ndir, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(ndir == 1 || ndir == 2, "st_gru_seq_bwd: ndir=%d", ndir);
+    ST_CHECK_ARG(dout && out && tape && w_hh_fwd && dgi_fwd && dgh_fwd && B > 0 && T > 0 && H > 0, "st_gru_seq_bwd: bad arguments");
+    ST_CHECK_ARG(ndir == 1 || (w_hh_bwd && dgi_bwd && dgh_bwd), "st_gru_seq_bwd: missing reverse-direction pointers");
+    ST_CHECK_ARG(3 * H <= 1024, "st_gru_seq_bwd: H=%d too large (3H must be <= 1024)", H);
+    GruBwdArgs a;
+    a.dout = dout; a.ldd = ldd; a.out = out; a.ldo = ldo; a.tape = tape;
+    a.w_hh[0] = w_hh_fwd; a.w_hh[1] = w_hh_bwd; a.dgi[0] = dgi_fwd; a.dgi[1] = dgi_bwd; a.dgh[0] = dgh_fwd; a.dgh[1] = dgh_bwd;
+    a.B = B; a.T = T; a.H = H;
+    const int threads = ((3 * H + 63) / 64) * 64;
+    const size_t lds = (size_t)(3 * ((H + 3) & ~3) + 3 * H + H) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (H <= GRU_HMAX) hipLaunchKernelGGL((gru_seq_bwd_kernel<true>), dim3(B, ndir), dim3(threads), lds, st, a);
+    else hipLaunchKernelGGL((gru_seq_bwd_kernel<false>), dim3(B, ndir), dim3(threads), lds, st, a);
+    ST_LAUNCH_CHECK();
     return 0;
 }

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import ops
 from . import _lib
+from . import autograd as AG
 from ._lib import StDecoderWeights, StDecoderDims, StDecoderIO, check
 
 
@@ -60,6 +61,8 @@ class Linear(nn.Module):
             raise NotImplementedError('norm_type=%r: no shipped config uses a normalised Linear' % norm_type)
 
     def forward(self, x, act=None, mask=None):
+        if self.training:            # differentiable path (same kernels + saved tensors)
+            return AG.linear(x, self.linear.weight, self.linear.bias, act, mask)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         m2 = mask.reshape(-1, mask.shape[-1]) if mask is not None else None
@@ -83,20 +86,14 @@ def _conv_bn_act(x, weight, bias, bn, pad, eps, momentum, order, training, Tout=
         return ops.gemm(x, weight, out, pad=pad, Tout=Tout, coff=coff, bias=bias, act_pre=pre,
                         bn=(bn.running_mean, bn.running_var, bn.weight, bn.bias), bn_eps=eps, act_post=post,
                         pool_prev=pool_prev)
-    N = weight.shape[0]
-    if stats_Tout is not None and stats_Tout != Tout:
-        # statistics over more output positions than are kept: one conv pass for the statistics,
-        # then the eval-style fused pass with the batch statistics
-        tmp = ops.gemm(x, weight, pad=pad, Tout=stats_Tout, bias=bias, act_pre=pre, pool_prev=pool_prev)
-        mean, var = ops.bn_stats(tmp.view(-1, N), 0, N, bn.running_mean, bn.running_var, momentum)
-        bn.num_batches_tracked += 1
-        return ops.gemm(x, weight, out, pad=pad, Tout=Tout, coff=coff, bias=bias, act_pre=pre,
-                        bn=(mean, var, bn.weight, bn.bias), bn_eps=eps, act_post=post, pool_prev=pool_prev)
-    y = ops.gemm(x, weight, out, pad=pad, Tout=Tout, coff=coff, bias=bias, act_pre=pre, pool_prev=pool_prev)
-    y2 = y.view(-1, y.shape[-1])
-    mean, var = ops.bn_stats(y2, coff, N, bn.running_mean, bn.running_var, momentum)
-    bn.num_batches_tracked += 1
-    ops.bn_apply(y2, coff, N, mean, var, bn.weight, bn.bias, eps, post)
+    # training: differentiable conv -> BatchNorm with batch statistics.  For the even-k bank convs the
+    # statistics run over stats_Tout = T+1 positions and the extra one is trimmed afterwards (module.py:597-598)
+    assert out is None, 'the training path returns new tensors (autograd owns them)'
+    To = stats_Tout if stats_Tout is not None else Tout
+    y = AG.conv(x, weight, bias, pad=pad, Tout=To, act=pre, pool_prev=pool_prev)
+    y = AG.batch_norm_train(y, bn, post)
+    if Tout is not None and To != Tout:
+        y = y[:, :Tout]
     return y
 
 
@@ -129,6 +126,11 @@ class Encoder(nn.Module):
                 raise NotImplementedError('enc_dropout > 0 in training (all shipped configs use 0.0)')
         B, L, _ = x.shape
         H = self.lstm.hidden_size
+        if self.training:
+            ls = self.lstm
+            xp_f = AG.conv(x, ls.weight_ih_l0, ls.bias_ih_l0)
+            xp_b = AG.conv(x, ls.weight_ih_l0_reverse, ls.bias_ih_l0_reverse)
+            return AG.bilstm(xp_f, xp_b, ls.weight_hh_l0, ls.bias_hh_l0, ls.weight_hh_l0_reverse, ls.bias_hh_l0_reverse)
         out = torch.empty(B, L, 2 * H, device=x.device, dtype=torch.float32)
         ws = torch.empty(3 * B * H, device=x.device, dtype=torch.float32)
         for rev, sfx in ((False, '_l0'), (True, '_l0_reverse')):
@@ -446,6 +448,10 @@ class Highway(nn.Module):
         self.T.bias.data.fill_(-1)
 
     def forward(self, x):
+        if self.training:
+            h = AG.conv(x, self.H.weight, self.H.bias, act='relu')
+            t = AG.conv(x, self.T.weight, self.T.bias, act='sigmoid')
+            return AG.highway_combine(h, t, x)
         h = ops.gemm(x, self.H.weight, bias=self.H.bias, act_pre='relu')
         return ops.gemm(x, self.T.weight, bias=self.T.bias, act_pre='sigmoid', highway_h=h, res=x)
 
@@ -475,6 +481,8 @@ class CBHG(nn.Module):
         B, T, Cn = x.shape
         assert Cn == self.in_dim
         K = len(self.conv1d_banks)
+        if self.training:
+            return self._forward_train(x)
         bank = torch.empty(B, T, K * Cn, device=x.device, dtype=torch.float32)
         for i, blk in enumerate(self.conv1d_banks):
             k = i + 1
@@ -494,6 +502,27 @@ class CBHG(nn.Module):
         ops.gru_seq(gi_f, gi_b, self.gru.weight_hh_l0, self.gru.weight_hh_l0_reverse,
                     self.gru.bias_hh_l0, self.gru.bias_hh_l0_reverse, out)
         return out
+
+
+def _cbhg_forward_train(self, x):
+    """differentiable CBHG (same kernels; every stage keeps what its backward needs)"""
+    B, T, Cn = x.shape
+    # even k yields T+1 positions and BatchNorm sees all of them before the trim to T (module.py:597-598)
+    bank = torch.cat([blk(x, Tout=T, stats_Tout=T + 1 if (i + 1) % 2 == 0 else T)
+                      for i, blk in enumerate(self.conv1d_banks)], dim=-1)
+    y = self.conv1d_projs[0](bank, pool_prev=True)
+    for blk in self.conv1d_projs[1:]:
+        y = blk(y)
+    y = AG.conv(y, self.pre_highway_proj.weight, res=x)                                       # :607-609
+    for hw in self.highways:
+        y = hw(y)
+    g = self.gru
+    gi_f = AG.conv(y, g.weight_ih_l0, g.bias_ih_l0)
+    gi_b = AG.conv(y, g.weight_ih_l0_reverse, g.bias_ih_l0_reverse)
+    return AG.bigru(gi_f, gi_b, g.weight_hh_l0, g.bias_hh_l0, g.weight_hh_l0_reverse, g.bias_hh_l0_reverse)
+
+
+CBHG._forward_train = _cbhg_forward_train
 
 
 class Postnet(nn.Module):

@@ -166,22 +166,44 @@ def bn_apply(x2d, coff, N, mean, var, w, b, eps, act=None):
                           float(eps), ACT[act], stream_handle()), 'st_bn_apply')
 
 
-def lstm_seq(xproj, w_hh, b_hh, out, ocol, reverse, ws=None):
+def lstm_seq(xproj, w_hh, b_hh, out, ocol, reverse, ws=None, gates_tape=None, c_tape=None):
     lib = _lib.load()
     B, T, H4 = xproj.shape
     H = H4 // 4
     if ws is None:
         ws = torch.empty(3 * B * H, device=xproj.device, dtype=torch.float32)
-    check(lib.st_lstm_seq_fwd(_p(xproj), _p(w_hh), _p(b_hh), _p(out), int(out.stride(1)), int(ocol), _p(ws), B, T, H,
-                              1 if reverse else 0, stream_handle()), 'st_lstm_seq_fwd')
+    check(lib.st_lstm_seq_fwd(_p(xproj), _p(w_hh), _p(b_hh), _p(out), int(out.stride(1)), int(ocol), _p(ws),
+                              _p(gates_tape), _p(c_tape), B, T, H, 1 if reverse else 0, stream_handle()), 'st_lstm_seq_fwd')
 
 
-def gru_seq(gi_f, gi_b, w_hh_f, w_hh_b, b_hh_f, b_hh_b, out):
+def lstm_seq_bwd(dout, dcol, gates_tape, c_tape, w_hh_t, reverse):
+    """dout (B,T,>=dcol+H) -> dxproj (B,T,4H)"""
+    T, B, _, H = gates_tape.shape
+    dxproj = torch.empty(B, T, 4 * H, device=dout.device, dtype=torch.float32)
+    ws = torch.empty(2 * B * H, device=dout.device, dtype=torch.float32)
+    check(_lib.load().st_lstm_seq_bwd(_p(dout), int(dout.stride(1)), int(dcol), _p(gates_tape), _p(c_tape), _p(w_hh_t),
+                                      _p(dxproj), _p(ws), B, T, H, 1 if reverse else 0, stream_handle()), 'st_lstm_seq_bwd')
+    return dxproj
+
+
+def gru_seq(gi_f, gi_b, w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, tape=None):
     lib = _lib.load()
     B, T, H3 = gi_f.shape
     ndir = 2 if gi_b is not None else 1
     check(lib.st_gru_seq_fwd(_p(gi_f), _p(gi_b), _p(w_hh_f), _p(w_hh_b), _p(b_hh_f), _p(b_hh_b), _p(out),
-                             int(out.stride(1)), B, T, H3 // 3, ndir, stream_handle()), 'st_gru_seq_fwd')
+                             int(out.stride(1)), _p(tape), B, T, H3 // 3, ndir, stream_handle()), 'st_gru_seq_fwd')
+
+
+def gru_seq_bwd(dout, out, tape, w_hh_f, w_hh_b):
+    """returns (dgi_f, dgi_b, dgh_f, dgh_b), each (B,T,3H)"""
+    ndir, B, T, _, H = tape.shape
+    mk = lambda: torch.empty(B, T, 3 * H, device=dout.device, dtype=torch.float32)
+    dgi_f, dgh_f = mk(), mk()
+    dgi_b, dgh_b = (mk(), mk()) if ndir == 2 else (None, None)
+    check(_lib.load().st_gru_seq_bwd(_p(dout), int(dout.stride(1)), _p(out), int(out.stride(1)), _p(tape), _p(w_hh_f),
+                                     _p(w_hh_b), _p(dgi_f), _p(dgi_b), _p(dgh_f), _p(dgh_b), B, T, H, ndir,
+                                     stream_handle()), 'st_gru_seq_bwd')
+    return dgi_f, dgi_b, dgh_f, dgh_b
 
 
 def vq_build_table(learnable, attr=None, attr_w=None, attr_b=None):

@@ -12,6 +12,9 @@ class _PostLinear(nn.Linear):
     """nn.Linear(2*n_mels, linear_dim) of src/tts.py:34 executed by the HIP GEMM"""
 
     def forward(self, x):
+        if self.training:
+            from . import autograd as AG
+            return AG.conv(x, self.weight, self.bias)
         return ops.gemm(x, self.weight, bias=self.bias)
 
 

@@ -162,3 +162,124 @@ def test_pool_prev_backward_ties(dev):
     xr = x.double().requires_grad_()
     F.max_pool1d(xr.transpose(1, 2), 2, 1, 1)[:, :, :6].backward(dyp.double().transpose(1, 2))
     assert maxdiff(dx, xr.grad) == 0.0
+
+
+# ------------------------------------------------------------------------------------ sequence layers
+def test_bilstm_backward(dev):
+    from semi_tts_amd import autograd as AG
+    B, T, I, H = 5, 13, 24, 32
+    lstm = torch.nn.LSTM(I, H, batch_first=True, bidirectional=True).double()
+    x = rnd(B, T, I, seed=1)
+    dy = rnd(B, T, 2 * H, seed=2)
+    p = {k: v.detach().float().to(dev).requires_grad_() for k, v in lstm.named_parameters()}
+    xd = x.to(dev).requires_grad_()
+    xp_f = AG.conv(xd, p['weight_ih_l0'], p['bias_ih_l0'])
+    xp_b = AG.conv(xd, p['weight_ih_l0_reverse'], p['bias_ih_l0_reverse'])
+    y = AG.bilstm(xp_f, xp_b, p['weight_hh_l0'], p['bias_hh_l0'], p['weight_hh_l0_reverse'], p['bias_hh_l0_reverse'])
+    y.backward(dy.to(dev))
+    xr = x.double().requires_grad_()
+    yr, _ = lstm(xr)
+    yr.backward(dy.double())
+    errs = {'y': maxdiff(y, yr), 'dx': relerr(xd.grad, xr.grad)}
+    for k, v in lstm.named_parameters():
+        errs[k] = relerr(p[k].grad, v.grad)
+    report('bilstm_backward', **errs)
+    assert errs.pop('y') < 1e-5
+    assert max(errs.values()) < 2e-5, errs
+
+
+@pytest.mark.parametrize('B,T,H', [(3, 17, 20), (4, 33, 80)])
+def test_bigru_backward(dev, B, T, H):
+    from semi_tts_amd import autograd as AG
+    gru = torch.nn.GRU(H, H, batch_first=True, bidirectional=True).double()
+    x = rnd(B, T, H, seed=1)
+    dy = rnd(B, T, 2 * H, seed=2)
+    p = {k: v.detach().float().to(dev).requires_grad_() for k, v in gru.named_parameters()}
+    xd = x.to(dev).requires_grad_()
+    gi_f = AG.conv(xd, p['weight_ih_l0'], p['bias_ih_l0'])
+    gi_b = AG.conv(xd, p['weight_ih_l0_reverse'], p['bias_ih_l0_reverse'])
+    y = AG.bigru(gi_f, gi_b, p['weight_hh_l0'], p['bias_hh_l0'], p['weight_hh_l0_reverse'], p['bias_hh_l0_reverse'])
+    y.backward(dy.to(dev))
+    xr = x.double().requires_grad_()
+    yr, _ = gru(xr)
+    yr.backward(dy.double())
+    errs = {'y': maxdiff(y, yr), 'dx': relerr(xd.grad, xr.grad)}
+    for k, v in gru.named_parameters():
+        errs[k] = relerr(p[k].grad, v.grad)
+    report('bigru_backward', B=B, T=T, H=H, **errs)
+    assert errs.pop('y') < 1e-5
+    assert max(errs.values()) < 2e-5, errs
+
+
+# ------------------------------------------------------------------------------------ module level vs the oracle
+def oracle_grads(fn, weights, inputs, douts):
+    """run an oracle function in float64 on leaf copies of weights/inputs; returns (outputs, weight grads, input grads)"""
+    W = {k: (v.double().requires_grad_() if v.is_floating_point() else v) for k, v in weights.items()}
+    ins = [t.double().requires_grad_() for t in inputs]
+    torch.set_default_dtype(torch.float64)       # the oracle creates its zero states in the default dtype
+    try:
+        outs = fn(W, *ins)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    outs = outs if isinstance(outs, (tuple, list)) else (outs,)
+    pairs = [(o, d) for o, d in zip(outs, douts) if d is not None]
+    torch.autograd.backward([o for o, _ in pairs], [d.double() for _, d in pairs])
+    return outs, {k: v.grad for k, v in W.items() if v.is_floating_point() and v.grad is not None}, [t.grad for t in ins]
+
+
+def check_param_grads(module, prefix, wg, tol, name):
+    worst = 0.0
+    n = 0
+    for k, p in module.named_parameters():
+        ref = wg.get(prefix + k)
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, 'unexpected gradient for ' + k
+            continue
+        assert p.grad is not None, 'missing gradient for ' + k
+        if float(ref.abs().max()) < 1e-9:
+            # analytically zero (a bias in front of a BatchNorm): float64 leaves ~1e-16, fp32 ~1e-6 of round-off
+            assert float(p.grad.abs().max()) < 1e-4, (k, float(p.grad.abs().max()))
+            continue
+        e = relerr(p.grad, ref)
+        report(name, param=k, err=e)
+        worst = max(worst, e)
+        n += 1
+        assert e < tol, (k, e)
+    assert n > 0
+    return worst
+
+
+def test_encoder_backward_vs_oracle(dev):
+    from conftest import load_golden
+    from helpers import tiny_tacotron
+    from oracle import tts_oracle as O
+    W, A, meta = load_golden('tts_tiny_train_tf')
+    m = tiny_tacotron(meta, W, dev).train()
+    x = A['txt_embed'].float()
+    xd = x.to(dev).requires_grad_()
+    out = m.encoder(xd)
+    dy = rnd(*out.shape, seed=5)
+    out.backward(dy.to(dev))
+    outs, wg, ig = oracle_grads(lambda Wd, xx: O.encoder_forward(Wd, xx, 'encoder.', training=True), W, [x], [dy])
+    assert maxdiff(out, outs[0]) < 1e-5
+    assert relerr(xd.grad, ig[0]) < 5e-5
+    check_param_grads(m.encoder, 'encoder.', wg, 5e-5, 'encoder_backward')
+
+
+def test_postnet_backward_vs_oracle(dev):
+    from conftest import load_golden
+    from helpers import tiny_tacotron
+    from oracle import tts_oracle as O
+    W, A, meta = load_golden('tts_tiny_train_tf')
+    m = tiny_tacotron(meta, W, dev).train()
+    n_mels = meta['cfg']['n_mels']
+    mel = torch.rand(3, 21, n_mels, generator=torch.Generator().manual_seed(7))
+    md = mel.to(dev).requires_grad_()
+    m.zero_grad()
+    lin = m.postnet(md)
+    dy = rnd(*lin.shape, seed=9)
+    lin.backward(dy.to(dev))
+    outs, wg, ig = oracle_grads(lambda Wd, xx: O.postnet_forward(Wd, xx, training=True), W, [mel], [dy])
+    assert maxdiff(lin, outs[0]) < 2e-5
+    assert relerr(md.grad, ig[0]) < 1e-4
+    check_param_grads(m.postnet, 'postnet.', wg, 1e-4, 'postnet_backward')      # BN-heavy chain: fp32 vs float64

@@ -390,6 +390,61 @@ int st_decoder_pack(const st_decoder_weights* w, const st_decoder_dims* d, float
 int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io,
                        void* stream);
 
+/* ------------------------------------------------------------------ decoder backward (training, teacher forcing)
+ * ref: what torch autograd derives for Decoder.forward / decode_one_step, src/module.py:184-288 */
+/* Backward of one attention step (recomputes the location features and tanh from the saved weights).
+ * dctx / dw_direct: up to three addends each (row strides ld_*); dcum (B,L) carries dL/dcum_t across steps
+ * (+ dcum_add).  Outputs dpq (B,A) and dhist (B,2,L) = gradient w.r.t. [w_{t-1}; cum_{t-1}] through the
+ * location conv; dpm (B,L,A), dmem (B,L,E) and the per-utterance slabs dv_part (B,A), dwl_part (B,A,F),
+ * dwc_part (B,F,2,K) are ACCUMULATED (zero them before the first step; sum the slabs over B afterwards). */
+int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,
+                     const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                     const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                     const float* const* dctx, const int* ld_dctx, int n_dctx,
+                     const float* const* dw_direct, const int* ld_dw, int n_dw,
+                     float* dcum, const float* dcum_add, int ld_dcum_add,
+                     float* dpq, float* dhist, float* dpm, float* dmem,
+                     float* dv_part, float* dwl_part, float* dwc_part,
+                     int B, int L, int A, int E, int F, int K, void* stream);
+
+typedef struct st_decoder_bwd_weights {   /* transposed copies prepared by the caller (layout only) */
+    const float* q_w_cat_t;        /* [W_ih_q | W_hh_q]^T   (P+E+Q, 4Q) */
+    const float* d_w_cat_t;        /* [W_ih_d | W_hh_d]^T   (E+Q+D, 4D) */
+    const float* attn_query_w_t;   /* W_q^T                 (Q, A)      */
+    const float* attn_v; const float* attn_loc_conv_w; const float* attn_loc_lin_w;
+} st_decoder_bwd_weights;
+
+/* All step-indexed tensors are natural row-major with Bp >= B rows per step slot (Bp = B rounded up to 16,
+ * the row count of the un-tiled forward tapes; rows >= B are zero). */
+typedef struct st_decoder_bwd_io {
+    const float* memory; const float* pm; const float* ada_std;   /* (B,L,E) (B,L,A) (B,Q) */
+    const float* align;            /* (B, steps, L) forward output            */
+    const float* wcum_tape;        /* (steps+1, B, L)                         */
+    const float* cq_tape; const float* cd_tape;             /* (steps+1, B, Q / D) */
+    const float* gates_q_tape; const float* gates_d_tape;   /* (steps, B, 4, Q / D) activated gates */
+    const float* q_mask; const float* d_mask;               /* (steps, B, Q / D) or NULL */
+    const float* pq_all;           /* (steps, Bp, A)  = W_q h_q_t, recomputed by the caller */
+    int steps; int Bp;
+    const float* dxo;              /* (steps, Bp, D+E) = [dmel_t | dstop_t] [W_proj ; W_gate] */
+    const float* dalign;           /* (B, steps, L) or NULL */
+    float* dgq; float* dgd;        /* (steps, Bp, 4Q / 4D) out: pre-activation gate gradients */
+    float* dxq; float* dxd;        /* (steps+1, Bp, P+E+Q / E+Q+D) out; slot `steps` must be zero */
+    float* dpq;                    /* (steps, Bp, A) out */
+    float* dpm; float* dmem; float* dv_part; float* dwl_part; float* dwc_part;   /* accumulated, see st_attn_step_bwd */
+    float* dcq; float* dcd;        /* (B,Q) (B,D) scratch, zero on entry */
+    float* dhist[2];               /* (B,2,L) x 2 scratch, zero on entry */
+    float* dcum;                   /* (B,L) scratch, zero on entry */
+    float* dhq_attn;               /* (B,Q) scratch */
+} st_decoder_bwd_io;
+int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
+/* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp, r*n_mels+1); NULL = zeros */
+int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int B, int Bp, int steps, int r, int n_mels,
+                         void* stream);
+/* AdaIN statistics gradients (ref: src/module.py:267-269): adapted_t = std * (h_q_t - mean)
+ * dstd = sum_t dadapt_t * (h_q_t - mean), dmean = -std * sum_t dadapt_t; *_step_stride / *_ld in elements */
+int st_adain_bwd(const float* dadapt, long da_step_stride, int da_ld, const float* hq, long hq_step_stride, int hq_ld,
+                 const float* ada_std, const float* ada_mean, float* dstd, float* dmean, int B, int Q, int steps, void* stream);
+
 /* ------------------------------------------------------------------ small utilities */
 int st_fill(float* p, float v, size_t n, void* stream);
 int st_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream);

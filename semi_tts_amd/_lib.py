@@ -56,6 +56,20 @@ class StDecoderIO(C.Structure):
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p)]
 
 
+class StDecoderBwdWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('q_w_cat_t', 'd_w_cat_t', 'attn_query_w_t', 'attn_v', 'attn_loc_conv_w',
+                                          'attn_loc_lin_w')]
+
+
+class StDecoderBwdIO(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ('memory', 'pm', 'ada_std', 'align', 'wcum_tape', 'cq_tape', 'cd_tape',
+                                           'gates_q_tape', 'gates_d_tape', 'q_mask', 'd_mask', 'pq_all')] +
+                [('steps', C.c_int), ('Bp', C.c_int)] +
+                [(n, C.c_void_p) for n in ('dxo', 'dalign', 'dgq', 'dgd', 'dxq', 'dxd', 'dpq', 'dpm', 'dmem', 'dv_part',
+                                           'dwl_part', 'dwc_part', 'dcq', 'dcd')] +
+                [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p)])
+
+
 P, I, F, Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/semitts.h
@@ -104,6 +118,11 @@ SIGNATURES = {
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],
     'st_decoder_forward': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderIO), P],
+    'st_attn_step_bwd': [P, P, P, P, I, P, P, I, P, P, P, C.POINTER(P), C.POINTER(I), I, C.POINTER(P), C.POINTER(I), I,
+                         P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],
+    'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, P],
+    'st_adain_bwd': [P, C.c_long, I, P, C.c_long, I, P, P, P, P, I, I, I, P],
     'st_bn_norm_fwd': [P, I, I, P, I, I, I, I, P, P, P, P, F, I, P],
     'st_gemm_wgrad_workspace_floats': [I, I, I, I, I],
     'st_gemm_wgrad': [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, I, P],

@@ -207,3 +207,148 @@ class _BiGruFn(Function):
 
 def bigru(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
     return _BiGruFn.apply(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b)
+
+
+# --------------------------------------------------------------------------------------------- decoder loop
+def _untile_tape(flat, slots, Bp, kb_stride, segs):
+    """T16 step tape (slots x [Bp/16][kb_stride][64][4]) -> natural (slots, Bp, sum(k)); segs = [(kb0, k), ...].
+    Consecutive slots are consecutive batch tiles, so one launch per segment un-tiles every step."""
+    import ctypes as C
+    from . import _lib
+    width = sum(k for _, k in segs)
+    out = torch.empty(slots, Bp, width, device=flat.device, dtype=torch.float32)
+    col = 0
+    for kb0, k in segs:
+        v = ops.t16_view(flat, kb_stride, kb0)
+        _lib.check(_lib.load().st_untile_rows(C.byref(v), ops._p(out) + 4 * col, width, slots * Bp, k, ops.stream_handle()),
+                   'st_untile_rows')
+        col += k
+    return out
+
+
+class _DecoderFn(Function):
+    """The whole teacher-forced decode loop as one autograd node: forward = st_decoder_forward (the inference
+    kernels, plus the gate tapes), backward = st_decoder_backward + batched TN GEMMs over the tapes.
+    ref: src/module.py:184-288"""
+
+    @staticmethod
+    def forward(ctx, dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, *params):
+        mel, align, stop, tapes = dec._run_loop(plan, memory, pm, ada_std, ada_mean, teacher_pre, keep_tapes=True)
+        ctx.dec, ctx.plan, ctx.tapes = dec, plan, tapes
+        ctx.save_for_backward(memory, pm, ada_std, ada_mean, teacher_pre, align, *params)
+        return mel, align, stop
+
+    @staticmethod
+    def backward(ctx, dmel, dalign, dstop):
+        import ctypes as C
+        from . import _lib
+        from ._lib import StDecoderBwdWeights, StDecoderBwdIO, StDecoderDims
+        dec, plan, tapes = ctx.dec, ctx.plan, ctx.tapes
+        memory, pm, ada_std, ada_mean, teacher_pre, align = ctx.saved_tensors[:6]
+        (pre_w0, pre_w1, q_w_ih, q_w_hh, q_b_ih, q_b_hh, wq, v, wc, wl, d_w_ih, d_w_hh, d_b_ih, d_b_hh,
+         proj_w, proj_b, gate_w, gate_b) = ctx.saved_tensors[6:]
+        steps, src, Bt = plan['steps'], plan['step_src'], plan['Bt']
+        B, L, E = memory.shape
+        r, n_mels, P = dec.n_frames_per_step, dec.n_mels, dec.prenet_dim
+        Q, D, A, F, K = dec.query_rnn_dim, dec.dec_rnn_dim, dec.attn_dim, dec.n_location_filters, dec.location_kernel_size
+        if Bt != B or any(s < 0 for s in src[:steps - 1]):
+            raise NotImplementedError('decoder backward implements teacher forcing (tf_rate=1, drop_dec_in=0, paired '
+                                      'batches: every shipped training config); scheduled sampling / unpaired rows '
+                                      'feed the own output back and are forward-only for now')
+        dev = memory.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        lib = _lib.load()
+        kb = ops.kb16
+        Bp = ((B + 15) // 16) * 16
+        in_dim = r * n_mels
+        XQw, XDw, XOw = P + E + Q, E + Q + D, D + E
+        _, q_mask, d_mask = plan['masks']
+        # forward tapes, un-tiled once: xq = [dec_in | ctx_{t-1} | h_q_{t-1}], xd = [ctx_t | adapted h_q_t | h_d_{t-1}], xo = [h_d_t | ctx_t]
+        q_kbs, d_kbs, o_kbs = kb(P) + kb(E) + kb(Q), kb(E) + kb(Q) + kb(D), kb(D) + kb(E)
+        XQ = _untile_tape(tapes['xq'], steps + 1, Bp, q_kbs, [(0, P), (kb(P), E), (kb(P) + kb(E), Q)])
+        XD = _untile_tape(tapes['xd'], steps, Bp, d_kbs, [(0, E), (kb(E), Q), (kb(E) + kb(Q), D)])
+        XO = _untile_tape(tapes['xo'], steps, Bp, o_kbs, [(0, D), (kb(D), E)])
+        hq_all = XQ[1:steps + 1].reshape(-1, XQw)[:, P + E:]               # h_q_t (dropped-out), rows (t, b)
+        pq_all = ops.gemm(hq_all, wq)                                       # (steps*Bp, A)
+        # output gradients through proj (+) gate for all steps at once
+        dY = torch.zeros(steps, Bp, in_dim + 1, **f32)
+        _lib.check(lib.st_decoder_pack_dout(ops._p(dmel.contiguous()) if dmel is not None else None,
+                                            ops._p(dstop.contiguous()) if dstop is not None else None,
+                                            ops._p(dY), B, Bp, steps, r, n_mels, ops.stream_handle()), 'st_decoder_pack_dout')
+        wpg = torch.cat([proj_w.detach(), gate_w.detach()], 0)             # (in_dim+1, D+E)   parameter layout only
+        dY2 = dY.view(-1, in_dim + 1)
+        dxo = ops.gemm(dY2, wpg.t().contiguous())                           # (steps*Bp, D+E)
+
+        z = lambda *shape: torch.zeros(*shape, **f32)
+        dgq, dgd = z(steps, Bp, 4 * Q), z(steps, Bp, 4 * D)
+        dxq, dxd, dpq = z(steps + 1, Bp, XQw), z(steps + 1, Bp, XDw), z(steps, Bp, A)
+        dpm, dmem = z(B, L, A), z(B, L, E)
+        dv_part, dwl_part, dwc_part = z(B, A), z(B, A * F), z(B, F * 2 * K)
+        dcq, dcd, dh0, dh1, dcum, dhq_attn = z(B, Q), z(B, D), z(B, 2, L), z(B, 2, L), z(B, L), z(B, Q)
+        wt = dict(q=torch.cat([q_w_ih.detach(), q_w_hh.detach()], 1).t().contiguous(),      # (P+E+Q, 4Q)
+                  d=torch.cat([d_w_ih.detach(), d_w_hh.detach()], 1).t().contiguous(),      # (E+Q+D, 4D)
+                  pq=wq.detach().t().contiguous())                                         # (Q, A)
+        bw = StDecoderBwdWeights()
+        bw.q_w_cat_t, bw.d_w_cat_t, bw.attn_query_w_t = ops._p(wt['q']), ops._p(wt['d']), ops._p(wt['pq'])
+        bw.attn_v, bw.attn_loc_conv_w, bw.attn_loc_lin_w = ops._p(v), ops._p(wc), ops._p(wl)
+        dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A, F=F, K=K, fuse_pre0=0)
+        io = StDecoderBwdIO()
+        io.memory, io.pm, io.ada_std, io.align = ops._p(memory), ops._p(pm), ops._p(ada_std), ops._p(align)
+        io.wcum_tape, io.cq_tape, io.cd_tape = ops._p(tapes['wcum']), ops._p(tapes['cq']), ops._p(tapes['cd'])
+        io.gates_q_tape, io.gates_d_tape = ops._p(tapes['gates_q']), ops._p(tapes['gates_d'])
+        io.q_mask, io.d_mask, io.pq_all = ops._p(q_mask), ops._p(d_mask), ops._p(pq_all)
+        io.steps, io.Bp = steps, Bp
+        io.dxo = ops._p(dxo)
+        io.dalign = ops._p(dalign.contiguous()) if dalign is not None else None
+        io.dgq, io.dgd, io.dxq, io.dxd, io.dpq = ops._p(dgq), ops._p(dgd), ops._p(dxq), ops._p(dxd), ops._p(dpq)
+        io.dpm, io.dmem, io.dv_part, io.dwl_part, io.dwc_part = (ops._p(t) for t in (dpm, dmem, dv_part, dwl_part, dwc_part))
+        io.dcq, io.dcd, io.dcum, io.dhq_attn = ops._p(dcq), ops._p(dcd), ops._p(dcum), ops._p(dhq_attn)
+        io.dhist[0], io.dhist[1] = ops._p(dh0), ops._p(dh1)
+        _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
+
+        # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)
+        dgq2, dgd2 = dgq.view(-1, 4 * Q), dgd.view(-1, 4 * D)
+        dwq_cat = ops.gemm_wgrad(dgq2, XQ[:steps].reshape(-1, XQw))
+        dwd_cat = ops.gemm_wgrad(dgd2, XD.view(-1, XDw))
+        dbq, dbd = ops.colsum(dgq2), ops.colsum(dgd2)
+        dwpg = ops.gemm_wgrad(dY2, XO.view(-1, XOw))
+        dbpg = ops.colsum(dY2)
+        dwq_attn = ops.gemm_wgrad(dpq.view(-1, A), hq_all)
+        dv = ops.colsum(dv_part).view(v.shape)
+        dwl = ops.colsum(dwl_part).view(wl.shape)
+        dwc = ops.colsum(dwc_part).view(wc.shape)
+        dstd, dmean = torch.empty(B, Q, **f32), torch.empty(B, Q, **f32)
+        _lib.check(lib.st_adain_bwd(ops._p(dxd) + 4 * E, Bp * XDw, XDw, ops._p(XQ) + 4 * (Bp * XQw + P + E), Bp * XQw, XQw,
+                                    ops._p(ada_std), ops._p(ada_mean), ops._p(dstd), ops._p(dmean), B, Q, steps,
+                                    ops.stream_handle()), 'st_adain_bwd')
+        # d prenet(teacher): step t+1 read teacher frame src[t]
+        dteacher = None
+        if teacher_pre is not None:
+            Tt = teacher_pre.shape[1]
+            dteacher = z(Bt, Tt, P)
+            if steps > 1:
+                if list(src[:steps - 1]) == list(range(steps - 1)):
+                    ops.copy3d(dteacher.view(Bt, Tt, P)[:, :steps - 1], dxq[1:steps].permute(1, 0, 2)[:Bt, :, :P], Bt, steps - 1, P)
+                else:
+                    for t in range(steps - 1):
+                        ops.copy3d(dteacher[:, src[t]:src[t] + 1], dxq[t + 1:t + 2].permute(1, 0, 2)[:Bt, :, :P], Bt, 1, P,
+                                   accumulate=True)
+        c = lambda t: t.contiguous()
+        grads = (None, None, dmem, dpm, dstd, dmean, dteacher,
+                 None, None,                                                      # prenet weights: only via own-output feedback
+                 c(dwq_cat[:, :P + E]), c(dwq_cat[:, P + E:]), dbq, dbq.clone(),
+                 dwq_attn, dv, dwc, dwl,
+                 c(dwd_cat[:, :E + Q]), c(dwd_cat[:, E + Q:]), dbd, dbd.clone(),
+                 c(dwpg[:in_dim]), c(dbpg[:in_dim]), c(dwpg[in_dim:]), c(dbpg[in_dim:]))
+        ctx.tapes = None
+        return grads
+
+
+def decoder_loop(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre):
+    params = (dec.prenet.layers[0].linear.weight, dec.prenet.layers[1].linear.weight,
+              dec.query_rnn.weight_ih, dec.query_rnn.weight_hh, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh,
+              dec.attn.query_layer.linear.weight, dec.attn.v.linear.weight, dec.attn.loc_conv.conv.weight,
+              dec.attn.loc_linear.linear.weight,
+              dec.dec_rnn.weight_ih, dec.dec_rnn.weight_hh, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh,
+              dec.proj.linear.weight, dec.proj.linear.bias, dec.gate_layer.linear.weight, dec.gate_layer.linear.bias)
+    return _DecoderFn.apply(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, *params)

@@ -1,0 +1,166 @@
+// decoder_bwd.hip -- backward through time of the teacher-forced decode loop (training).
+//
+// ref: what torch autograd derives for Decoder.forward / decode_one_step, src/module.py:184-288.
+// The caller (semi_tts_amd/autograd.py) has already
+//   * un-tiled the forward tapes and recomputed pq_t = W_q h_q_t for all steps in one GEMM,
+//   * pushed the output gradients through proj/gate for all steps in one GEMM (dxo), which is possible
+//     because with teacher forcing no step's input depends on an earlier step's output.
+// Per step, from the last to the first, this file enqueues (no host sync, graph-capturable):
+//   a. decoder LSTM, pointwise part        dh_d = dxo_t[:, :D] + (W_hh_d^T dgates_d)_{t+1}
+//   b. dxd_t = dgates_d_t [W_ih_d | W_hh_d]     -> dctx, d(adapted h_q), dh_d carried to t-1
+//   c. attention backward (attention_bwd.hip)  -> dpq_t, d[w_{t-1}; cum_{t-1}], accumulates dpm, dmem, dv, dW_l, dW_c
+//   d. dh_q += W_q^T dpq_t
+//   e. query LSTM, pointwise part          dh_q = d + (W_hh_q^T dgates_q)_{t+1} + std * d(adapted h_q)
+//   f. dxq_t = dgates_q_t [W_ih_q | W_hh_q]     -> d(dec_in_t), dctx_{t-1}, dh_q carried to t-1
+// Weight gradients are the caller's TN GEMMs over the tapes written here (dgates_q/d, dpq) afterwards.
+#include "st_common.h"
+
+extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,
+                                const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                                const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                                const float* const* dctx, const int* ld_dctx, int n_dctx,
+                                const float* const* dw_direct, const int* ld_dw, int n_dw,
+                                float* dcum, const float* dcum_add, int ld_dcum_add,
+                                float* dpq, float* dhist, float* dpm, float* dmem,
+                                float* dv_part, float* dwl_part, float* dwc_part,
+                                int B, int L, int A, int E, int F, int K, void* stream);
+
+extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io,
+                                   void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(w && d && io, "st_decoder_backward: null struct pointer");
+    const int B = d->B, L = d->L, E = d->E, P = d->P, Q = d->Q, D = d->D, A = d->A;
+    const int steps = io->steps, Bp = io->Bp;
+    ST_CHECK_ARG(B > 0 && steps > 0 && Bp >= B, "st_decoder_backward: B=%d steps=%d Bp=%d", B, steps, Bp);
+    ST_CHECK_ARG(w->q_w_cat_t && w->d_w_cat_t && w->attn_query_w_t && w->attn_v && w->attn_loc_conv_w && w->attn_loc_lin_w,
+                 "st_decoder_backward: null weight");
+    ST_CHECK_ARG(io->memory && io->pm && io->ada_std && io->align && io->wcum_tape && io->cq_tape && io->cd_tape &&
+                 io->gates_q_tape && io->gates_d_tape && io->pq_all && io->dxo, "st_decoder_backward: null saved tensor");
+    ST_CHECK_ARG(io->dgq && io->dgd && io->dxq && io->dxd && io->dpq && io->dpm && io->dmem && io->dv_part && io->dwl_part &&
+                 io->dwc_part && io->dcq && io->dcd && io->dhist[0] && io->dhist[1] && io->dcum && io->dhq_attn,
+                 "st_decoder_backward: null output/scratch");
+    const int XQ = P + E + Q, XD = E + Q + D, XO = D + E;
+    const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
+    const int ldal = steps * L;
+    int rc;
+    for (int t = steps - 1; t >= 0; --t) {
+        const float* dxo = io->dxo + (size_t)t * Bp * XO;
+        float* dxd = io->dxd + (size_t)t * Bp * XD;
+        const float* dxd_next = io->dxd + (size_t)(t + 1) * Bp * XD;
+        float* dxq = io->dxq + (size_t)t * Bp * XQ;
+        const float* dxq_next = io->dxq + (size_t)(t + 1) * Bp * XQ;
+        float* dgd = io->dgd + (size_t)t * Bp * 4 * D;
+        float* dgq = io->dgq + (size_t)t * Bp * 4 * Q;
+        float* dpq = io->dpq + (size_t)t * Bp * A;
+        float* dhist_cur = io->dhist[t & 1];
+        const float* dhist_next = io->dhist[(t + 1) & 1];
+
+        // a. decoder LSTM pointwise
+        rc = st_lstm_cell_bwd_pointwise(dxo, XO, dxd_next + E + Q, XD, nullptr, 0, nullptr,
+                                        io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
+                                        io->gates_d_tape + (size_t)t * 4 * BD, io->cd_tape + (size_t)(t + 1) * BD, D,
+                                        io->cd_tape + (size_t)t * BD, D, io->dcd, dgd, 4 * D, B, D, stream);
+        if (rc) return rc;
+        // b. gradient w.r.t. [ctx_t | adapted h_q_t | h_d_{t-1}]
+        st_seg seg;
+        seg.x = dgd; seg.ldx = 4 * D; seg.w = w->d_w_cat_t; seg.ldw = 4 * D; seg.k = 4 * D;
+        rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, dxd, XD, 0, nullptr, 0, 0, B, XD, stream);
+        if (rc) return rc;
+        // c. attention
+        const float* dctx[3] = {dxo + D, dxd, dxq_next + P};
+        const int ld_dctx[3] = {XO, XD, XQ};
+        const float* dwd[2] = {dhist_next, io->dalign ? io->dalign + (size_t)t * L : nullptr};
+        const int ld_dw[2] = {2 * L, ldal};
+        rc = st_attn_step_bwd(io->pq_all + (size_t)t * Bp * A, io->pm, io->memory,
+                              t > 0 ? io->align + (size_t)(t - 1) * L : nullptr, ldal, io->wcum_tape + (size_t)t * BL,
+                              io->align + (size_t)t * L, ldal, w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v,
+                              dctx, ld_dctx, 3, dwd, ld_dw, io->dalign ? 2 : 1,
+                              io->dcum, dhist_next + L, 2 * L,
+                              dpq, dhist_cur, io->dpm, io->dmem, io->dv_part, io->dwl_part, io->dwc_part,
+                              B, L, A, E, d->F, d->K, stream);
+        if (rc) return rc;
+        // d. through the query projection
+        seg.x = dpq; seg.ldx = A; seg.w = w->attn_query_w_t; seg.ldw = A; seg.k = A;
+        rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, io->dhq_attn, Q, 0, nullptr, 0, 0, B, Q, stream);
+        if (rc) return rc;
+        // e. query LSTM pointwise (AdaIN: adapted = std * (h_q - mean) -> dh_q += std * d adapted)
+        rc = st_lstm_cell_bwd_pointwise(io->dhq_attn, Q, dxq_next + P + E, XQ, dxd + E, XD, io->ada_std,
+                                        io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
+                                        io->gates_q_tape + (size_t)t * 4 * BQ, io->cq_tape + (size_t)(t + 1) * BQ, Q,
+                                        io->cq_tape + (size_t)t * BQ, Q, io->dcq, dgq, 4 * Q, B, Q, stream);
+        if (rc) return rc;
+        // f. gradient w.r.t. [dec_in_t | ctx_{t-1} | h_q_{t-1}]  (step 0: go frame and zero initial state, nothing to do)
+        if (t > 0) {
+            seg.x = dgq; seg.ldx = 4 * Q; seg.w = w->q_w_cat_t; seg.ldw = 4 * Q; seg.k = 4 * Q;
+            rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, dxq, XQ, 0, nullptr, 0, 0, B, XQ, stream);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+namespace {
+
+// dY[t][b][:] = [dmel[b][t*r .. t*r+r][:] | sum_j dstop[b][t*r + j]]     rows b >= B of a slot are left untouched (zero)
+__global__ __launch_bounds__(256) void pack_dout_kernel(const float* dmel, const float* dstop, float* dY,
+                                                        int B, int Bp, int steps, int r, int n_mels) {
+    const int in_dim = r * n_mels, W = in_dim + 1;
+    const size_t total = (size_t)steps * B * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % W);
+        const size_t row = i / W;
+        const int b = (int)(row % B), t = (int)(row / B);
+        float v;
+        if (c < in_dim) v = dmel ? dmel[((size_t)b * steps + t) * in_dim + c] : 0.0f;
+        else {
+            v = 0.0f;
+            if (dstop) for (int j = 0; j < r; ++j) v += dstop[(size_t)b * steps * r + (size_t)t * r + j];
+        }
+        dY[((size_t)t * Bp + b) * W + c] = v;
+    }
+}
+
+// AdaIN parameter gradients: adapted_t = std * (h_q_t - mean)
+//   dstd[b][q] = sum_t da[t][b][q] * (h_q_t[b][q] - mean[b][q]);   dmean[b][q] = -std[b][q] * sum_t da[t][b][q]
+__global__ __launch_bounds__(256) void adain_bwd_kernel(const float* da, long da_st, int da_ld, const float* hq, long hq_st, int hq_ld,
+                                                        const float* std_, const float* mean, float* dstd, float* dmean,
+                                                        int B, int Q, int steps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Q) return;
+    const int b = i / Q, q = i - b * Q;
+    const float mu = mean[i];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int t = 0; t < steps; ++t) {
+        const float g = da[(size_t)t * da_st + (size_t)b * da_ld + q];
+        s1 += g;
+        s2 = fmaf(g, hq[(size_t)t * hq_st + (size_t)b * hq_ld + q] - mu, s2);
+    }
+    dstd[i] = s2;
+    dmean[i] = -std_[i] * s1;
+}
+
+}  // namespace
+
+extern "C" int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int B, int Bp, int steps, int r,
+                                    int n_mels, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dY && B > 0 && Bp >= B && steps > 0 && r > 0 && n_mels > 0, "st_decoder_pack_dout: bad arguments");
+    const size_t total = (size_t)steps * B * (r * n_mels + 1);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_dout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dmel, dstop, dY, B, Bp,
+                       steps, r, n_mels);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_adain_bwd(const float* dadapt, long da_step_stride, int da_ld, const float* hq, long hq_step_stride, int hq_ld,
+                            const float* ada_std, const float* ada_mean, float* dstd, float* dmean, int B, int Q, int steps,
+                            void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dadapt && hq && ada_std && ada_mean && dstd && dmean && B > 0 && Q > 0 && steps > 0, "st_adain_bwd: bad arguments");
+    hipLaunchKernelGGL(adain_bwd_kernel, dim3((B * Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, dadapt, da_step_stride,
+                       da_ld, hq, hq_step_stride, hq_ld, ada_std, ada_mean, dstd, dmean, B, Q, steps);
+    ST_LAUNCH_CHECK();
+    return 0;
+}

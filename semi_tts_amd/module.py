@@ -339,10 +339,16 @@ class Decoder(nn.Module):
                                       self.drop_dec_in, unpair_max_frame)
         keep = []
         f32 = dict(device=dev, dtype=torch.float32)
+        differentiable = self.training and torch.is_grad_enabled()
         # once per utterance: processed memory, AdaIN statistics (hoisted out of the loop)
-        pm = self.attn.process_memory(memory)
-        ada_std = ops.linear_small(spkr_embed, self.pseudo_latent_std[0].weight, self.pseudo_latent_std[0].bias, 'relu')
-        ada_mean = ops.linear_small(spkr_embed, self.pseudo_latent_mean.weight, self.pseudo_latent_mean.bias)
+        if differentiable:
+            pm = AG.conv(memory, self.attn.memory_layer.linear.weight)
+            ada_std = AG.linear(spkr_embed, self.pseudo_latent_std[0].weight, self.pseudo_latent_std[0].bias, 'relu')
+            ada_mean = AG.linear(spkr_embed, self.pseudo_latent_mean.weight, self.pseudo_latent_mean.bias)
+        else:
+            pm = self.attn.process_memory(memory)
+            ada_std = ops.linear_small(spkr_embed, self.pseudo_latent_std[0].weight, self.pseudo_latent_std[0].bias, 'relu')
+            ada_mean = ops.linear_small(spkr_embed, self.pseudo_latent_mean.weight, self.pseudo_latent_mean.bias)
         teacher_pre = teacher_mean = None
         Tt = 0
         if tf_rate != 0.0:
@@ -350,7 +356,7 @@ class Decoder(nn.Module):
             Tt = tch.shape[1]
             teacher_pre = self.prenet(tch, _masks.get('teacher'))                                 # :179
             if any(s == -2 for s in step_src):
-                teacher_mean = ops.mean_rows(teacher_pre)
+                teacher_mean = ops.mean_rows(teacher_pre.detach())
         uses_own = any(s == -1 for s in step_src[:-1]) or Bt < B
         own_mask = _masks.get('own')
         if own_mask is None and uses_own and self.prenet_dropout > 0:
@@ -361,7 +367,26 @@ class Decoder(nn.Module):
                 q_mask = _scaled_mask((steps, B, Q), self.query_dropout.p, dev)
             if d_mask is None and self.dec_dropout.p > 0:
                 d_mask = _scaled_mask((steps, B, D), self.dec_dropout.p, dev)
+        plan = dict(steps=steps, step_src=step_src, Bt=Bt, Tt=Tt, masks=(own_mask, q_mask, d_mask),
+                    teacher_mean=teacher_mean)
+        if differentiable:
+            return AG.decoder_loop(self, plan, memory, pm, ada_std, ada_mean, teacher_pre)
+        mel, align, stop, tapes = self._run_loop(plan, memory, pm, ada_std, ada_mean, teacher_pre, keep_tapes=False)
+        self.last_tapes = tapes
+        return mel, align, stop
 
+    def _run_loop(self, plan, memory, pm, ada_std, ada_mean, teacher_pre, keep_tapes):
+        """the decode loop itself (st_decoder_forward) on plain tensors; `keep_tapes` also records what the
+        backward needs (activated LSTM gates)"""
+        dev = memory.device
+        B, L, E = memory.shape
+        r, n_mels, P = self.n_frames_per_step, self.n_mels, self.prenet_dim
+        Q, D, A = self.query_rnn_dim, self.dec_rnn_dim, self.attn_dim
+        steps, step_src, Bt, Tt = plan['steps'], plan['step_src'], plan['Bt'], plan['Tt']
+        own_mask, q_mask, d_mask = plan['masks']
+        teacher_mean = plan['teacher_mean']
+        keep = []
+        f32 = dict(device=dev, dtype=torch.float32)
         mel = torch.empty(B, steps * r, n_mels, **f32)
         align = torch.empty(B, steps, L, **f32)
         stop = torch.empty(B, steps * r, **f32)
@@ -385,7 +410,7 @@ class Decoder(nn.Module):
                      wcum=torch.empty(steps + 1, B, L, **f32), pq=torch.empty(B, A, **f32),
                      zero=torch.empty(B, L, **f32), tiled=tiled, preq=torch.empty(B, 4 * Q, **f32),
                      pred=torch.empty(B, 4 * D, **f32))
-        if self.training and torch.is_grad_enabled():
+        if keep_tapes:
             tapes['gates_q'] = torch.empty(steps, B, 4, Q, **f32)
             tapes['gates_d'] = torch.empty(steps, B, 4, D, **f32)
 
@@ -413,9 +438,8 @@ class Decoder(nn.Module):
               'st_decoder_forward')
         tapes['packed'] = packed
         tapes.update(pm=pm, ada_std=ada_std, ada_mean=ada_mean, teacher_pre=teacher_pre, masks=(own_mask, q_mask, d_mask),
-                     keep=keep, step_src=step_src)
-        self.last_tapes = tapes
-        return mel, align, stop
+                     keep=keep, step_src=step_src, slot=slot)
+        return mel, align, stop, tapes
 
 
 # ----------------------------------------------------------------------------- CBHG

@@ -283,3 +283,97 @@ def test_postnet_backward_vs_oracle(dev):
     assert maxdiff(lin, outs[0]) < 2e-5
     assert relerr(md.grad, ig[0]) < 1e-4
     check_param_grads(m.postnet, 'postnet.', wg, 1e-4, 'postnet_backward')      # BN-heavy chain: fp32 vs float64
+
+
+# ------------------------------------------------------------------------------------ decoder BPTT / whole model
+def _double_masks(masks):
+    return [m.double() for m in masks]
+
+
+def test_tacotron2_backward_against_oracle_tiny_golden(dev):
+    """Whole Tacotron2 in training mode (teacher forcing, the reference's recorded dropout masks):
+    every parameter gradient and the input gradients vs float64 autograd through the oracle."""
+    from conftest import load_golden
+    from helpers import coin_source, masks_to, split_masks, tiny_tacotron
+    from oracle import tts_oracle as O
+    from semi_tts_amd.module import plan_decode
+    W, A, meta = load_golden('tts_tiny_train_tf')
+    hp = meta['hp']
+    m = tiny_tacotron(meta, W, dev).train()
+    txt, spk, teacher = A['txt_embed'], A['spkr_embed'], A['teacher']
+    B = txt.shape[0]
+    steps, src = plan_decode(False, teacher.shape[1], teacher.shape[0], B, hp['n_frames_per_step'], meta['tf_rate'],
+                             hp['drop_dec_in'], meta['unpair_max_frame'], coin_source(A['coins']))
+    masks = masks_to(split_masks(A.get('mask', []), hp, True, meta['tf_rate'], B, teacher.shape[0], steps, src,
+                                 hp['prenet_dim']), dev)
+    import numpy as np
+    saved = np.random.rand
+    np.random.rand = coin_source(A['coins'])
+    try:
+        txt_d, spk_d = txt.to(dev).requires_grad_(), spk.to(dev).requires_grad_()
+        mel, lin, align, stop = m(txt_d, None, teacher.to(dev), spk_d, tf_rate=meta['tf_rate'], _masks=masks)
+    finally:
+        np.random.rand = saved
+    douts = [rnd(*mel.shape, seed=1), rnd(*lin.shape, seed=2), rnd(*align.shape, seed=3), rnd(*stop.shape, seed=4)]
+    torch.autograd.backward([mel, lin, align, stop], [d.to(dev) for d in douts])
+
+    def fn(Wd, t, s):
+        drop = O.DropoutSource('list', _double_masks(A.get('mask', [])))
+        return O.tacotron2_forward(Wd, t, teacher.double(), s, hp, meta['tf_rate'], None, True, drop, coin_source(A['coins']))
+    outs, wg, ig = oracle_grads(fn, W, [txt, spk], douts)
+    assert maxdiff(mel, outs[0]) < 1e-4 and maxdiff(lin, outs[1]) < 2e-4
+    errs = dict(dtxt=relerr(txt_d.grad, ig[0]), dspk=relerr(spk_d.grad, ig[1]))
+    report('tacotron2_backward_tiny', **errs)
+    assert errs['dtxt'] < 2e-4 and errs['dspk'] < 2e-4
+    check_param_grads(m, '', wg, 2e-4, 'tacotron2_backward_tiny')     # fp32 BPTT over 4 steps + BN chains vs float64
+
+
+@pytest.mark.parametrize('B,L,steps', [(20, 11, 7), (3, 5, 3)])
+def test_decoder_backward_against_oracle(dev, B, L, steps):
+    """Decoder only, dimensions that are not multiples of the tile sizes, dropout masks drawn by the oracle and
+    replayed through the HIP path; B=20 exercises the padded rows of the step tapes (Bp=32)."""
+    from helpers import masks_to, split_masks
+    from oracle import tts_oracle as O
+    from semi_tts_amd.module import Decoder
+    hp = dict(n_frames_per_step=2, prenet_dim=24, prenet_dropout=0.5, query_rnn_dim=40, dec_rnn_dim=36, query_dropout=0.1,
+              dec_dropout=0.1, attn_dim=32, n_location_filters=8, location_kernel_size=7, loc_aware=True,
+              use_summed_weights=True, drop_dec_in=0.0)
+    n_mels, E, S = 10, 28, 12
+    torch.manual_seed(5)
+    dec = Decoder(n_mels, enc_embed_dim=E, spkr_embed_dim=S, **hp).to(dev).train()
+    W = {'decoder.' + k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    memory, spk = rnd(B, L, E, seed=1), rnd(B, S, seed=2)
+    teacher = torch.rand(B, steps * 2, n_mels, generator=torch.Generator().manual_seed(3))
+    hpo = dict(hp, n_mels=n_mels)
+    drop = O.DropoutSource('rng', generator=torch.Generator().manual_seed(11))
+    torch.set_default_dtype(torch.float64)
+    try:
+        Wd = {k: v.double().requires_grad_() for k, v in W.items()}
+        mem_r, spk_r = memory.double().requires_grad_(), spk.double().requires_grad_()
+
+        class Drop64(O.DropoutSource):
+            def __call__(self, x, p, training):
+                if (not training) or p == 0.0:
+                    return x
+                keep = torch.full(x.shape, 1.0 - p, dtype=torch.float32)
+                mk = torch.bernoulli(keep, generator=self.gen) / (1.0 - p)
+                self.used.append(mk)
+                return x * mk.double()
+        drop = Drop64('rng', generator=torch.Generator().manual_seed(11))
+        outs = O.decoder_forward(Wd, mem_r, teacher.double(), spk_r, hpo, 1.0, None, True, drop, lambda: 0.0)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    douts = [rnd(*outs[0].shape, seed=1), rnd(*outs[1].shape, seed=2), rnd(*outs[2].shape, seed=3)]
+    torch.autograd.backward(list(outs), [d.double() for d in douts])
+    src = list(range(steps))
+    masks = masks_to(split_masks(drop.used, hpo, True, 1.0, B, B, steps, src, hp['prenet_dim']), dev)
+    mem_d, spk_d = memory.to(dev).requires_grad_(), spk.to(dev).requires_grad_()
+    mel, align, stop = dec(mem_d, None, teacher.to(dev), spk_d, tf_rate=1.0, _masks=masks)
+    torch.autograd.backward([mel, align, stop], [d.to(dev) for d in douts])
+    errs = dict(mel=maxdiff(mel, outs[0]), align=maxdiff(align, outs[1]), dmem=relerr(mem_d.grad, mem_r.grad),
+                dspk=relerr(spk_d.grad, spk_r.grad))
+    report('decoder_backward', B=B, L=L, steps=steps, **errs)
+    assert errs['mel'] < 1e-4 and errs['align'] < 1e-5
+    assert errs['dmem'] < 1e-4 and errs['dspk'] < 1e-4
+    wg = {k: v.grad for k, v in Wd.items() if v.grad is not None}
+    check_param_grads(dec, 'decoder.', wg, 1e-4, 'decoder_backward')

@@ -445,6 +445,15 @@ int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int B
 int st_adain_bwd(const float* dadapt, long da_step_stride, int da_ld, const float* hq, long hq_step_stride, int hq_ld,
                  const float* ada_std, const float* ada_mean, float* dstd, float* dmean, int B, int Q, int steps, void* stream);
 
+/* ------------------------------------------------------------------ trainer loss
+ * loss = w_all*crit(pred,label) + w_low*crit(low n_low bins) + w_diff*crit(first differences along T), crit = MSE or
+ * (l1 != 0) mean absolute error; writes the scalar to *loss and d loss / d pred to dpred (B,T,D).  ws: 256 floats.
+ * ref: freq_loss src/util.py:80-126 (mel: w = 1, 0, 0.5; linear with low-band emphasis: w = 0.5, 0.5, 0) */
+int st_freq_loss(const float* pred, const float* label, float* loss, float* dpred, float* ws,
+                 int B, int T, int D, int n_low, float w_all, float w_low, float w_diff, int l1, void* stream);
+/* y = x * (*scalar)   (scalar on the device: the incoming gradient of a scalar loss) */
+int st_scale_by(const float* x, const float* scalar, float* y, size_t n, void* stream);
+
 /* ------------------------------------------------------------------ small utilities */
 int st_fill(float* p, float v, size_t n, void* stream);
 int st_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream);

@@ -1,9 +1,11 @@
 #!/usr/bin/env python
 """Entry point with the reference's flags (ref: main.py:14-68): YAML config + Solver dispatch.
-Only the solvers on the TTS decode path exist here: `--gen-specgram` runs batched
-free-running synthesis on the MI355X path with synthetic inputs (the corpus is not available).
+Only the solvers on the TTS path exist here: `--gen-specgram` runs batched free-running
+synthesis, the default mode runs the paired TTS training step (forward, loss, backward on the HIP
+kernels; clip + Adam from torch), both on synthetic inputs (the corpus is not available).
 
     python main.py --config config/supervised.yaml --gen-specgram [--load ckpt.pth] [--frames 256 --batch-size 32]
+    python main.py --config config/supervised.yaml --max-step 20 [--frames 256 --batch-size 32]
 """
 import argparse
 import random
@@ -27,6 +29,7 @@ parser.add_argument('--no-msg', action='store_true', help='Hide all messages.')
 parser.add_argument('--frames', default=256, type=int, help='mel frames per synthetic utterance')
 parser.add_argument('--batch-size', default=None, type=int)
 parser.add_argument('--n-batches', default=1, type=int)
+parser.add_argument('--max-step', default=None, type=int, help='training steps (default: hparas.max_step)')
 
 
 def main():
@@ -45,8 +48,8 @@ def main():
         from semi_tts_amd.solver import SpecgramGenerator as Solver
         mode = 'test'
     else:
-        raise SystemExit('training through the HIP path needs the backward kernels (DESIGN.md section 6); '
-                         'run with --gen-specgram')
+        from semi_tts_amd.solver import TtsTrainer as Solver
+        mode = 'train'
     solver = Solver(config, paras, mode)
     solver.load_data()
     solver.set_model()

@@ -123,6 +123,8 @@ SIGNATURES = {
     'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],
     'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, P],
     'st_adain_bwd': [P, C.c_long, I, P, C.c_long, I, P, P, P, P, I, I, I, P],
+    'st_freq_loss': [P, P, P, P, P, I, I, I, I, F, F, F, I, P],
+    'st_scale_by': [P, P, P, Z, P],
     'st_bn_norm_fwd': [P, I, I, P, I, I, I, I, P, P, P, P, F, I, P],
     'st_gemm_wgrad_workspace_floats': [I, I, I, I, I],
     'st_gemm_wgrad': [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, I, P],

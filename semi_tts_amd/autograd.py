@@ -352,3 +352,43 @@ def decoder_loop(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre):
               dec.dec_rnn.weight_ih, dec.dec_rnn.weight_hh, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh,
               dec.proj.linear.weight, dec.proj.linear.bias, dec.gate_layer.linear.weight, dec.gate_layer.linear.bias)
     return _DecoderFn.apply(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, *params)
+
+
+# --------------------------------------------------------------------------------------------- trainer loss
+class _FreqLossFn(Function):
+    @staticmethod
+    def forward(ctx, pred, label, n_low, w_all, w_low, w_diff, l1):
+        from . import _lib
+        pred, label = pred.contiguous(), label.contiguous()
+        B, T, D = pred.shape
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        dpred = torch.empty_like(pred)
+        ws = torch.empty(256, device=pred.device, dtype=torch.float32)
+        _lib.check(_lib.load().st_freq_loss(ops._p(pred), ops._p(label), ops._p(loss), ops._p(dpred), ops._p(ws), B, T, D,
+                                            int(n_low), float(w_all), float(w_low), float(w_diff), 1 if l1 else 0,
+                                            ops.stream_handle()), 'st_freq_loss')
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        from . import _lib
+        dpred, = ctx.saved_tensors
+        out = torch.empty_like(dpred)
+        _lib.check(_lib.load().st_scale_by(ops._p(dpred), ops._p(dloss.contiguous()), ops._p(out), dpred.numel(),
+                                           ops.stream_handle()), 'st_scale_by')
+        return out, None, None, None, None, None, None
+
+
+def freq_loss(pred, label, sample_rate, n_mels, loss='mse', differential_loss=True, emphasize_linear_low=True):
+    """the trainer's spectrogram loss (same signature as the reference, src/util.py:80-126) on the HIP path"""
+    if loss not in ('l1', 'mse'):
+        raise NotImplementedError(loss)
+    dim = pred.shape[-1]
+    w_all, w_low, w_diff, n_low = 1.0, 0.0, 0.0, 0
+    if dim != n_mels and emphasize_linear_low:
+        n_low = int(dim * (3000 / (sample_rate / 2)))
+        w_all, w_low = 0.5, 0.5
+    if dim == n_mels and differential_loss:
+        w_diff = 0.5
+    return _FreqLossFn.apply(pred, label, n_low, w_all, w_low, w_diff, loss == 'l1')

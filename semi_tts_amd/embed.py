@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import autograd as AG
 
 PRESERVE_INDICES = 3     # <pad>, <space>, <eos>                        ref: src/util.py:15
 
@@ -69,9 +70,20 @@ class BaseEmbedding(nn.Module):
 
     def _table(self, learnable):
         """cat[learnable, proj_attr(phn_attr.weight)] built on device.   ref: src/embed.py:87-94,109-112"""
+        if self.training and torch.is_grad_enabled():
+            # differentiable: the attribute projection is an ordinary linear layer over the V table rows
+            if not self.use_phn_attr:
+                return learnable
+            attr = AG.linear(self.phn_attr.weight, self.proj_attr.weight, self.proj_attr.bias)
+            return torch.cat([learnable, attr], dim=1)
         if self.use_phn_attr:
             return ops.vq_build_table(learnable, self.phn_attr.weight, self.proj_attr.weight, self.proj_attr.bias)
         return ops.vq_build_table(learnable)
+
+    def _lookup(self, table, idx):
+        if self.training and torch.is_grad_enabled():
+            return AG.gather(table, idx)
+        return ops.gather_rows(table, idx)
 
     def create_msg(self):
         return '           | EMA update = {}\t | Temp. = {}\t| Phn. attributs = {} ( projected = {})'.format(
@@ -100,7 +112,7 @@ class L2Embedding(BaseEmbedding):
 
     def inference(self, txt):
         """token ids (B,L) -> vectors (B,L,latent_dim)                     ref: src/embed.py:96-103"""
-        return ops.gather_rows(self._table(self.learnable_table), txt)
+        return self._lookup(self._table(self.learnable_table), txt)
 
     def forward(self, enc_embs, first_n_real_mel=0):
         """enc_embs (B,S,D) -> (p_code (B,S,V), new_latent (B,S,D), 0, 0).  ref: src/embed.py:105-147.
@@ -133,7 +145,7 @@ class SeperateEmbedding(BaseEmbedding):
         self.embedding = nn.Embedding(vocab_size, latent_dim - n_attr)
 
     def inference(self, txt):
-        return ops.gather_rows(self._table(self.embedding.weight), txt)              # :180-185
+        return self._lookup(self._table(self.embedding.weight), txt)                 # :180-185
 
     def forward(self, enc_embs, first_n_real_mel=0):
         if not self.stop_grad:

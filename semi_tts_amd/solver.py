@@ -101,3 +101,98 @@ class SpecgramGenerator(BaseSolver):
         dt = time.perf_counter() - t0
         self.verbose('Save %d spectrograms (%d frames) in %s, %.2f s' % (cnt, frames_out, output_dir, dt))
         return cnt
+
+
+class TtsTrainer(BaseSolver):
+    """Synthetic-batch counterpart of the paired TTS branch of VqvaeTrainer.exec (bin/train_vqvae.py:132-270)
+    with BaseSolver.backward (src/solver.py:138-151): per step
+
+        tf_rate = optimizer.pre_step(step)                       (lr schedule, zero_grad)
+        mel, linear = model.text_to_speech(text, sid, ..., paired_teacher=mel, tf_rate)
+        loss = tts_weight * (freq_loss(mel) + freq_loss(linear))
+        loss.backward(); [all-reduce over ranks]; clip_grad_norm_(5.0); optimizer.step()
+
+    Forward, loss and backward run on the HIP kernels (semi_tts_amd/autograd.py); clip + Adam are torch's
+    (reused).  The ASR/CTC half of the reference's step is outside the hot path."""
+    GRAD_CLIP = 5.0
+
+    def __init__(self, config, paras, mode='train'):
+        super().__init__(config, paras, mode)
+        hp = config['hparas']
+        self.hp = hp
+        self.max_step = int(getattr(paras, 'max_step', None) or hp.get('max_step', 1))
+        self.tts_weight = float(hp.get('tts_weight', 1.0))
+        self.sample_rate = config['data']['audio']['sample_rate']
+        self.log = []
+
+    def load_data(self):
+        from .synthetic import synthetic_train_batch
+        B = int(getattr(self.paras, 'batch_size', None) or self.config['data']['corpus'].get('batch_size', 8))
+        frames = int(getattr(self.paras, 'frames', 256))
+        n = int(getattr(self.paras, 'n_batches', 1))
+        self.r = self.config['model']['decoder']['decoder']['n_frames_per_step']
+        rank = int(os.environ.get('RANK', 0))
+        self.batches = [synthetic_train_batch(B, frames, self.r, self.vocab_size, self.n_spkr, self.n_mels, self.linear_dim,
+                                              seed=1000 * rank + i + getattr(self.paras, 'seed', 0))
+                        for i in range(n)]
+        return self
+
+    def set_model(self):
+        from .optim import Optimizer
+        from .synthetic import load_synthetic
+        self.model = self._build_model().train()
+        if getattr(self.paras, 'load', None):
+            ckpt = torch.load(self.paras.load, map_location=self.device)
+            self.model.load_state_dict(ckpt['model'], strict=False)
+            self.step = ckpt.get('global_step', 0)
+        else:
+            load_synthetic(self.model, seed=getattr(self.paras, 'seed', 0) + 1234)
+        hp = self.hp
+        self.optimizer = Optimizer(self.model.parameters(), hp['optimizer'], hp['lr'], hp['lr_scheduler'],
+                                   **{k: hp[k] for k in ('tf_start', 'tf_end', 'tf_step') if k in hp})
+        from . import parallel
+        parallel.broadcast_parameters(self.model)
+        return self
+
+    def freq_loss(self, pred, label):
+        from . import autograd as AG
+        hp = self.hp
+        return AG.freq_loss(pred, label, self.sample_rate, self.n_mels, hp.get('freq_loss_type', 'mse'),
+                            hp.get('differential_loss', True), hp.get('emphasize_linear_low', True))
+
+    def train_step(self, text, sid, mel, linear, _masks=None):
+        from . import parallel
+        tf_rate = self.optimizer.pre_step(self.step)
+        mel_pred, linear_pred, align, _, _, _, _, _ = self.model.text_to_speech(
+            text, sid, None, None, None, None, mel, None, tf_rate, _masks=_masks)
+        mel_loss = self.freq_loss(mel_pred, mel)
+        linear_loss = self.freq_loss(linear_pred, linear)
+        total = self.tts_weight * (mel_loss + linear_loss)
+        total.backward()
+        parallel.allreduce_gradients(self.model.parameters())
+        grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
+        gn = float(grad_norm)
+        if gn != gn:
+            self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
+        else:
+            self.optimizer.step()
+        self.step += 1
+        return dict(loss=float(total), mel_loss=float(mel_loss), linear_loss=float(linear_loss), grad_norm=gn,
+                    tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
+
+    def exec(self):
+        t0 = time.perf_counter()
+        frames = 0
+        while self.step < self.max_step:
+            text, sid, mel, linear = (t.to(self.device) for t in self.batches[self.step % len(self.batches)])
+            st = self.train_step(text, sid, mel, linear)
+            frames += mel.shape[0] * mel.shape[1]
+            self.log.append(st)
+            if self.step == 1 or self.step % 10 == 0:
+                self.verbose('Tr stat | step %d | Loss - %.4f | Grad. Norm - %.3f | lr %.2e' %
+                             (self.step, st['loss'], st['grad_norm'], st['lr']))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        self.verbose('%d steps, %d frames in %.2f s (%.0f frames/s incl. first-step set-up)' %
+                     (len(self.log), frames, dt, frames / max(dt, 1e-9)))
+        return self.log

@@ -55,3 +55,19 @@ def synthetic_batch(B, L, T, in_dim=64, spkr_dim=128, n_mels=80, seed=5):
     spk = (rs.standard_normal((B, spkr_dim)) * 0.5).astype(np.float32)
     mel = rs.uniform(0, 1, (B, T, n_mels)).astype(np.float32)
     return txt, spk, mel
+
+
+def synthetic_train_batch(B, frames, r, vocab_size=43, n_spkr=109, n_mels=80, linear_dim=1025, seed=5):
+    """one paired training batch with the shapes the reference's loader delivers:
+    text ids ~ U{3..V-1} with the trailing 0 PhoneTextEncoder appends, speaker ids, mel / linear in [0,1)
+    padded to a multiple of r frames the way bin/train_vqvae.py:43-46 pads (r - T % r, at least one)."""
+    import torch
+    rs = np.random.RandomState(seed)
+    T = frames + (r - frames % r)
+    L = int(np.ceil(frames / 6.0))
+    text = rs.randint(3, vocab_size, (B, L)).astype(np.int64)
+    text[:, -1] = 0
+    sid = rs.randint(0, n_spkr, (B,)).astype(np.int64)
+    mel = rs.uniform(0, 1, (B, T, n_mels)).astype(np.float32)
+    linear = rs.uniform(0, 1, (B, T, linear_dim)).astype(np.float32)
+    return torch.from_numpy(text), torch.from_numpy(sid), torch.from_numpy(mel), torch.from_numpy(linear)

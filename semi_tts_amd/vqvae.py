@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import autograd as AG
 from .embed import L2Embedding, SeperateEmbedding
 from .tts import Tacotron2
 
@@ -59,6 +60,8 @@ class VQVAE(nn.Module):
         return pair_bs, out
 
     def embed_speakers(self, sid):
+        if self.training and torch.is_grad_enabled():
+            return AG.gather(self.spkr_embed.weight, sid)
         return ops.gather_rows(self.spkr_embed.weight, sid)
 
     def quantize(self, enc_latent, first_n_real_mel=0):
@@ -71,8 +74,8 @@ class VQVAE(nn.Module):
                                   'decode hot path; use quantize(enc_latent) on latents you already have')
 
     def text_to_speech(self, paired_text, paired_sid, unpaired_sid, unpaired_latent, unpaired_text, unpaired_latent_len,
-                       paired_teacher, unpaired_teacher, tf_rate):
-        """same contract and return tuple as the reference (:143-207)"""
+                       paired_teacher, unpaired_teacher, tf_rate, _masks=None):
+        """same contract and return tuple as the reference (:143-207); `_masks` (tests only) = explicit dropout masks"""
         paired_latent = self.codebook.inference(paired_text)                                   # :147
         unpair_max_frame = None
         if unpaired_text is not None:                       # text-to-text cycle              :150-163
@@ -97,7 +100,7 @@ class VQVAE(nn.Module):
             all_latent, all_teacher = paired_latent, paired_teacher
             all_spkr = self.embed_speakers(paired_sid)
         mel, linear, align, stop = self.tts(all_latent, None, all_teacher, all_spkr, tf_rate=tf_rate,
-                                            unpair_max_frame=unpair_max_frame)                  # :183-184
+                                            unpair_max_frame=unpair_max_frame, _masks=_masks)   # :183-184
         if use_unpaired:                                                                        # :187-195
             b = paired_latent_bs
             return (mel[:b, :paired_ts], linear[:b, :paired_ts], align[:b, :paired_ts], stop[:b],

@@ -107,3 +107,22 @@ def full_hp(prenet_dropout=0.0):
     hp['n_mels'] = 80
     hp['enc_dropout'] = 0.0
     return hp
+
+
+def tiny_vqvae(meta, weights, device):
+    """HIP VQVAE for the H1 fixture: the phoneme-attribute table comes from the fixture (data), not from a file"""
+    from semi_tts_amd.vqvae import VQVAE
+    cfg = json.loads(json.dumps(meta['model']))
+    proj = cfg['codebook'].get('proj_attr')
+    cfg['codebook']['proj_attr'] = None
+    m = VQVAE(meta['audio']['num_mels'], meta['audio']['num_freq'], meta['vocab_size'], meta['n_spkr'], **cfg)
+    if 'codebook.phn_attr.weight' in weights:
+        cb = m.codebook
+        attr = weights['codebook.phn_attr.weight']
+        cb.use_phn_attr = True
+        cb.phn_attr = torch.nn.Embedding.from_pretrained(attr.clone(), freeze=True, padding_idx=0)
+        cb.proj_attr = torch.nn.Linear(attr.shape[1], proj)
+        cb.learnable_table = torch.nn.Parameter(torch.zeros(meta['vocab_size'], cfg['codebook']['latent_dim'] - proj))
+    missing = m.load_state_dict(weights, strict=False)
+    assert not missing.missing_keys, missing.missing_keys
+    return m.to(device)

@@ -377,3 +377,91 @@ def test_decoder_backward_against_oracle(dev, B, L, steps):
     assert errs['dmem'] < 1e-4 and errs['dspk'] < 1e-4
     wg = {k: v.grad for k, v in Wd.items() if v.grad is not None}
     check_param_grads(dec, 'decoder.', wg, 1e-4, 'decoder_backward')
+
+
+# ------------------------------------------------------------------------------------ H1: the training step
+def test_freq_loss_against_reference_golden(dev):
+    from conftest import load_golden
+    from semi_tts_amd import autograd as AG
+    _, A, _ = load_golden('freq_loss')
+    for pred, lab, ref, kind in ((A['pm'], A['lm'], A['mel_mse'], 'mse'), (A['pl'], A['ll'], A['lin_mse'], 'mse'),
+                                 (A['pl'], A['ll'], A['lin_l1'], 'l1')):
+        pd = pred.to(dev).requires_grad_()
+        loss = AG.freq_loss(pd, lab.to(dev), 22050, 80, kind, True, True)
+        (loss * 3.0).backward()
+        from oracle import tts_oracle as O
+        pr = pred.double().requires_grad_()
+        (O.freq_loss(pr, lab.double(), 22050, 80, kind, True, True) * 3.0).backward()
+        assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+        assert relerr(pd.grad, pr.grad) < 1e-5
+
+
+def test_training_step_against_reference_golden(dev):
+    """Two optimisation steps of the paired TTS branch (VQVAE.text_to_speech -> freq_loss -> backward -> clip ->
+    Adam with the 'decay' schedule) against what the real reference produced for the same weights, batch and
+    dropout masks: losses, grad norm, every parameter gradient of step 1, selected parameters after step 2."""
+    import json
+    from argparse import Namespace
+    from conftest import load_golden
+    from helpers import masks_to, split_masks, tiny_vqvae
+    from semi_tts_amd.solver import TtsTrainer
+    W, A, meta = load_golden('train_step_tiny')
+    hp = meta['hp']
+    config = dict(data=dict(audio=meta['audio'], corpus=dict(batch_size=4)), hparas=meta['hparas'], model=meta['model'])
+    tr = TtsTrainer(config, Namespace(vocab_size=meta['vocab_size'], n_spkr=meta['n_spkr'], verbose=False, max_step=2), 'train')
+    tr.model = tiny_vqvae(meta, W, dev).train()
+    from semi_tts_amd.optim import Optimizer
+    h = meta['hparas']
+    tr.optimizer = Optimizer(tr.model.parameters(), h['optimizer'], h['lr'], h['lr_scheduler'], tf_start=h['tf_start'],
+                             tf_end=h['tf_end'], tf_step=h['tf_step'])
+    text, sid, mel, linear = (A[k].to(dev) for k in ('text', 'sid', 'mel', 'linear'))
+    B, steps = text.shape[0], mel.shape[1] // hp['n_frames_per_step']
+    pos = 0
+    for step, (n, ref) in enumerate(zip(meta['n_masks'], meta['stats'])):
+        rec = A['mask'][pos:pos + n]
+        pos += n
+        masks = masks_to(split_masks(rec, hp, True, 1.0, B, B, steps, list(range(steps)), hp['prenet_dim']), dev)
+        if step == 0:
+            # gradients of the first backward, before clipping
+            grads = {}
+            hooks = []
+            st = None
+            orig = torch.nn.utils.clip_grad_norm_
+
+            def spy(params, max_norm, *a, **k):
+                params = list(params)
+                for (kname, p) in tr.model.named_parameters():
+                    if p.grad is not None:
+                        grads[kname] = p.grad.detach().clone()
+                return orig(params, max_norm, *a, **k)
+            torch.nn.utils.clip_grad_norm_ = spy
+            try:
+                st = tr.train_step(text, sid, mel, linear, _masks=masks)
+            finally:
+                torch.nn.utils.clip_grad_norm_ = orig
+            keys = json.loads(bytes(A['grad_keys']).decode())
+            worst = 0.0
+            for k, gref in zip(keys, A['grad']):
+                assert k in grads, 'missing gradient for ' + k
+                if float(gref.abs().max()) < 1e-9:
+                    assert float(grads[k].abs().max()) < 1e-5
+                    continue
+                e = relerr(grads[k], gref)
+                worst = max(worst, e)
+                assert e < 5e-4, (k, e)          # fp32 HIP vs fp32 reference (different summation orders on both sides)
+            report('train_step_grads', worst=worst, n=len(keys))
+        else:
+            st = tr.train_step(text, sid, mel, linear, _masks=masks)
+        report('train_step', step=step, loss=st['loss'], ref_loss=ref['loss'], gn=st['grad_norm'], ref_gn=ref['grad_norm'])
+        assert abs(st['loss'] - ref['loss']) < 2e-5 and abs(st['mel_loss'] - ref['mel_loss']) < 2e-5
+        assert abs(st['grad_norm'] - ref['grad_norm']) < 1e-4 * ref['grad_norm']
+        assert abs(st['lr'] - ref['lr']) < 1e-12 and st['tf_rate'] == ref['tf_rate']
+    sd = tr.model.state_dict()
+    for k, v in zip(json.loads(bytes(A['post_keys']).decode()), A['post']):
+        # Adam's first steps move every weight by ~lr (1e-6, 2e-6) whatever the gradient scale: the bound checks
+        # the update direction element-wise wherever the gradient is not round-off
+        assert maxdiff(sd[k], v) < 2e-5, k
+        if 'running_' not in k and 'num_batches' not in k:
+            upd_ref = (v.double() - W[k].double())
+            upd = (sd[k].detach().cpu().double() - W[k].double())
+            assert float((upd - upd_ref).abs().mean()) < 0.05 * float(upd_ref.abs().mean()), k

@@ -284,9 +284,84 @@ def full_size_case():
          dict(seed=1234, B=B, L=L, T=T, shapes={k: list(v.shape) for k, v in m.state_dict().items()}))
 
 
+def train_step_case():
+    """H1: two optimisation steps of the paired TTS branch through the REAL reference classes -- VQVAE
+    (codebook + speaker table + Tacotron2), util.freq_loss, optim.Optimizer, clip 5.0 -- at tiny dimensions.
+    Records inputs, initial weights, dropout masks, and per step: losses, grad norm (before clipping), and after
+    the first backward every parameter gradient; after the second step every parameter and buffer."""
+    import yaml
+    from functools import partial
+    from src.optim import Optimizer as RefOptimizer
+    os.chdir(REF)
+    full = yaml.safe_load(open('config/semi-single-spkr-paired-data.yaml'))
+    cfg = full['model']
+    cfg['decoder'] = json.loads(json.dumps(TINY['paras']))
+    cfg['decoder']['separate_postnet'] = True
+    cfg['spkr_latent_dim'] = TINY['spkr_embed_dim']
+    cfg['encoder'].update(dim=16, rnn_dim=8)               # the CTC speech encoder is built but never called here
+    torch.manual_seed(11)
+    m = RefVQVAE(TINY['n_mels'], TINY['linear_dim'], 43, 5, **json.loads(json.dumps(cfg)))
+    os.chdir(REPO)
+    g = torch.Generator().manual_seed(111)
+    with torch.no_grad():
+        randomize_buffers(m.tts, g)
+    m.train()
+    keep = lambda k: k.split('.')[0] in ('codebook', 'spkr_embed', 'tts')
+    w0 = {k: v.clone() for k, v in m.state_dict().items() if keep(k)}
+    B, L, T = 4, 6, 12
+    text = torch.randint(3, 43, (B, L), generator=g)
+    text[:, -1] = 0
+    sid = torch.randint(0, 5, (B,), generator=g)
+    mel = torch.rand(B, T, TINY['n_mels'], generator=g)
+    linear = torch.rand(B, T, TINY['linear_dim'], generator=g)
+    hp = full['hparas']
+    floss = partial(ref_freq_loss, sample_rate=full['data']['audio']['sample_rate'], n_mels=TINY['n_mels'],
+                    loss=hp['freq_loss_type'], differential_loss=hp['differential_loss'],
+                    emphasize_linear_low=hp['emphasize_linear_low'])
+    opt = RefOptimizer(m.parameters(), hp['optimizer'], hp['lr'], hp['lr_scheduler'],
+                       tf_start=hp['tf_start'], tf_end=hp['tf_end'], tf_step=hp['tf_step'])
+    arrays = dict(text=text, sid=sid, mel=mel, linear=linear)
+    stats, n_masks = [], []
+    np.random.seed(11)
+    torch.manual_seed(12)
+    for step in range(2):
+        tf_rate = opt.pre_step(step)
+        with Recorder() as rec:
+            mp, lp, al, _, _, _, _, _ = m.text_to_speech(text, sid, None, None, None, None, mel, None, tf_rate)
+            mel_loss, lin_loss = floss(mp, mel), floss(lp, linear)
+            total = hp['tts_weight'] * (mel_loss + lin_loss)
+            total.backward()
+        if step == 0:
+            gkeys = [k for k, p in m.named_parameters() if keep(k) and p.grad is not None]
+            arrays['grad'] = [dict(m.named_parameters())[k].grad.clone() for k in gkeys]
+            arrays['grad_keys'] = np.frombuffer(json.dumps(gkeys).encode(), np.uint8)
+            arrays['mel_pred0'], arrays['linear_pred0'] = mp.detach().clone(), lp.detach().clone()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+        opt.step()
+        arrays.setdefault('mask', []).extend(rec.masks)
+        n_masks.append(len(rec.masks))
+        stats.append(dict(loss=float(total), mel_loss=float(mel_loss), linear_loss=float(lin_loss), grad_norm=float(gn),
+                          tf_rate=float(tf_rate), lr=float(opt.opt.param_groups[0]['lr'])))
+    sel = ('running_', 'codebook.learnable_table', 'spkr_embed.weight', 'tts.decoder.query_rnn.weight_hh',
+           'tts.decoder.attn.v.linear.weight', 'tts.decoder.attn.loc_conv.conv.weight', 'tts.encoder.lstm.weight_hh_l0_reverse',
+           'tts.postnet.0.gru.weight_hh_l0', 'tts.postnet.1.bias', 'tts.decoder.prenet.layers.0.linear.weight')
+    post = {k: v for k, v in m.state_dict().items() if keep(k) and any(t in k for t in sel)}
+    arrays['post'] = list(post.values())
+    arrays['post_keys'] = np.frombuffer(json.dumps(list(post)).encode(), np.uint8)
+    mcfg = json.loads(json.dumps(cfg))
+    mcfg['codebook']['phn_attr_pth'] = ''                   # the table itself travels as w/codebook.phn_attr.weight
+    save('train_step_tiny', w0, arrays, dict(stats=stats, n_masks=n_masks, model=mcfg, hparas=hp,
+                                             audio=dict(sample_rate=full['data']['audio']['sample_rate'],
+                                                        num_mels=TINY['n_mels'], num_freq=TINY['linear_dim']),
+                                             vocab_size=43, n_spkr=5, hp=dict(TINY['paras']['decoder'], n_mels=TINY['n_mels'])))
+    print(stats)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full']
+    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train']
+    if 'train' in which:
+        train_step_case()
     if 'tts' in which:
         # eval-mode free-running inference, prenet dropout active (always-on), masks recorded
         tts_case('tts_tiny_infer', 1, B=2, L=7, teacher=15, tf_rate=0.0, training=False)

@@ -210,7 +210,7 @@ int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int 
  * the running-stat update  run = (1-mom) run + mom * {mean, unbiased var}.
  * ref: nn.BatchNorm1d in training mode, src/module.py:429,:531 */
 int st_bn_stats(const float* X, int ldx, int coff, int M, int N, float* mean_out, float* var_out,
-                float* run_mean, float* run_var, float momentum, void* stream);
+                float* run_mean, float* run_var, float momentum, float* ws, void* stream);
 /* X(m, coff+n) = act((X - mean) / sqrt(var + eps) * w + b), in place */
 int st_bn_apply(float* X, int ldx, int coff, int M, int N, const float* mean, const float* var,
                 const float* w, const float* b, float eps, int act, void* stream);
@@ -232,13 +232,15 @@ int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* A, int lda,
                   int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate, void* stream);
 /* out(n) (+)= sum_m X(m, xoff+n) [* Y(m, yoff+n)]      (bias gradients, AdaIN statistics gradients) */
 int st_colsum(const float* X, int ldx, int xoff, const float* Y, int ldy, int yoff, int M, int N,
-              float* out, int accumulate, void* stream);
+              float* out, int accumulate, float* ws, void* stream);
+/* scratch of the row-split column reductions st_bn_stats / st_colsum / st_bn_bwd (M rows, N columns) */
+size_t st_colreduce_workspace_floats(int M, int N);
 /* dpre = dout * mask * act'(out)   (out = the activated forward value; mask may be NULL) */
 int st_act_bwd(const float* dout, int ldd, const float* out, int ldo, int act, const float* mask, int ldm,
                float* dpre, int ldp, int M, int N, void* stream);
 /* BatchNorm backward with batch statistics, y = act((x - mean)/sqrt(var+eps)*w + b):
  * dx = w/sigma * (dyb - mean(dyb) - xhat * mean(dyb*xhat)), dw (+)= sum dyb*xhat, db (+)= sum dyb,
- * dyb = dy * act'(y).  ws: 2*N floats. */
+ * dyb = dy * act'(y).  ws: st_colreduce_workspace_floats(M, N) floats. */
 int st_bn_bwd(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
               const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
               int M, int N, float* dx, int lddx, int dxoff, float* dw, float* db, int accumulate, float* ws, void* stream);
@@ -394,18 +396,23 @@ int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, co
  * ref: what torch autograd derives for Decoder.forward / decode_one_step, src/module.py:184-288 */
 /* Backward of one attention step (recomputes the location features and tanh from the saved weights).
  * dctx / dw_direct: up to three addends each (row strides ld_*); dcum (B,L) carries dL/dcum_t across steps
- * (+ dcum_add).  Outputs dpq (B,A) and dhist (B,2,L) = gradient w.r.t. [w_{t-1}; cum_{t-1}] through the
- * location conv; dpm (B,L,A), dmem (B,L,E) and the per-utterance slabs dv_part (B,A), dwl_part (B,A,F),
- * dwc_part (B,F,2,K) are ACCUMULATED (zero them before the first step; sum the slabs over B afterwards). */
+ * (+ dcum_add).  Outputs needed by the recurrence: dpq (B,A) and dhist (B,2,L) = gradient w.r.t.
+ * [w_{t-1}; cum_{t-1}] through the location conv.  Everything that is a sum over steps is left to the caller:
+ * the kernel writes this step's slices ds_t (B,L,A), loc_t / dloc_t (B,L,F), hist_t (B,L,2) channels-last,
+ * dctx_t (B,E), dv_t (B,A), from which dpm = sum_t ds, dW_l = ds^T loc, dW_c = conv weight gradient of
+ * (dloc, hist), dmem[b] = w^T dctx, dv = sum dv_t. */
 int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,
                      const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
                      const float* loc_conv_w, const float* loc_lin_w, const float* v,
                      const float* const* dctx, const int* ld_dctx, int n_dctx,
                      const float* const* dw_direct, const int* ld_dw, int n_dw,
                      float* dcum, const float* dcum_add, int ld_dcum_add,
-                     float* dpq, float* dhist, float* dpm, float* dmem,
-                     float* dv_part, float* dwl_part, float* dwc_part,
+                     float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                     float* dctx_t, float* dv_t,
                      int B, int L, int A, int E, int F, int K, void* stream);
+
+/* dmem(b,l,:) = sum_t align(b,t,l) * dctx_tape(t,b,:)   (gradient of the encoder memory through the contexts) */
+int st_attn_dmem(const float* align, const float* dctx_tape, float* dmem, int B, int steps, int L, int E, void* stream);
 
 typedef struct st_decoder_bwd_weights {   /* transposed copies prepared by the caller (layout only) */
     const float* q_w_cat_t;        /* [W_ih_q | W_hh_q]^T   (P+E+Q, 4Q) */
@@ -430,7 +437,8 @@ typedef struct st_decoder_bwd_io {
     float* dgq; float* dgd;        /* (steps, Bp, 4Q / 4D) out: pre-activation gate gradients */
     float* dxq; float* dxd;        /* (steps+1, Bp, P+E+Q / E+Q+D) out; slot `steps` must be zero */
     float* dpq;                    /* (steps, Bp, A) out */
-    float* dpm; float* dmem; float* dv_part; float* dwl_part; float* dwc_part;   /* accumulated, see st_attn_step_bwd */
+    float* ds_tape; float* loc_tape; float* dloc_tape;   /* (steps, B, L, A / F / F) out, see st_attn_step_bwd */
+    float* hist_tape; float* dctx_tape; float* dv_tape;  /* (steps, B, L, 2), (steps, B, E), (steps, B, A) out */
     float* dcq; float* dcd;        /* (B,Q) (B,D) scratch, zero on entry */
     float* dhist[2];               /* (B,2,L) x 2 scratch, zero on entry */
     float* dcum;                   /* (B,L) scratch, zero on entry */

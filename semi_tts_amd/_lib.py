@@ -65,8 +65,8 @@ class StDecoderBwdIO(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ('memory', 'pm', 'ada_std', 'align', 'wcum_tape', 'cq_tape', 'cd_tape',
                                            'gates_q_tape', 'gates_d_tape', 'q_mask', 'd_mask', 'pq_all')] +
                 [('steps', C.c_int), ('Bp', C.c_int)] +
-                [(n, C.c_void_p) for n in ('dxo', 'dalign', 'dgq', 'dgd', 'dxq', 'dxd', 'dpq', 'dpm', 'dmem', 'dv_part',
-                                           'dwl_part', 'dwc_part', 'dcq', 'dcd')] +
+                [(n, C.c_void_p) for n in ('dxo', 'dalign', 'dgq', 'dgd', 'dxq', 'dxd', 'dpq', 'ds_tape', 'loc_tape', 'dloc_tape',
+                                           'hist_tape', 'dctx_tape', 'dv_tape', 'dcq', 'dcd')] +
                 [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p)])
 
 
@@ -92,7 +92,8 @@ SIGNATURES = {
     'st_skinny_linear_fwd': [C.POINTER(StSeg), I, P, I, P, I, P, I, I, P, I, I, I, I, P],
     'st_attn_step_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, P, I, P, I, P, P, P, I, I, I, I, I, I, I, P],
     'st_gemm_fwd': [P, I, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(StGemmEpilogue), P],
-    'st_bn_stats': [P, I, I, I, I, P, P, P, P, F, P],
+    'st_bn_stats': [P, I, I, I, I, P, P, P, P, F, P, P],
+    'st_colreduce_workspace_floats': [I, I],
     'st_bn_apply': [P, I, I, I, I, P, P, P, P, F, I, P],
     'st_lstm_seq_fwd': [P, P, P, P, I, I, P, P, P, I, I, I, I, P],
     'st_lstm_cell_bwd_pointwise': [P, I, P, I, P, I, P, P, P, P, I, P, I, P, P, I, I, I, P],
@@ -119,7 +120,8 @@ SIGNATURES = {
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],
     'st_decoder_forward': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderIO), P],
     'st_attn_step_bwd': [P, P, P, P, I, P, P, I, P, P, P, C.POINTER(P), C.POINTER(I), I, C.POINTER(P), C.POINTER(I), I,
-                         P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+                         P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    'st_attn_dmem': [P, P, P, I, I, I, I, P],
     'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],
     'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, P],
     'st_adain_bwd': [P, C.c_long, I, P, C.c_long, I, P, P, P, P, I, I, I, P],
@@ -128,7 +130,7 @@ SIGNATURES = {
     'st_bn_norm_fwd': [P, I, I, P, I, I, I, I, P, P, P, P, F, I, P],
     'st_gemm_wgrad_workspace_floats': [I, I, I, I, I],
     'st_gemm_wgrad': [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, I, P],
-    'st_colsum': [P, I, I, P, I, I, I, I, P, I, P],
+    'st_colsum': [P, I, I, P, I, I, I, I, P, I, P, P],
     'st_act_bwd': [P, I, P, I, I, P, I, P, I, I, I, P],
     'st_bn_bwd': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, I, I, P, P, I, P, P],
     'st_highway_fwd': [P, P, P, P, Z, P],
@@ -142,7 +144,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
              'st_decoder_packed_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
-             'st_gemm_wgrad_workspace_floats': C.c_size_t}
+             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t}
 
 _lib = None
 

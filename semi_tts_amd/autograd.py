@@ -282,8 +282,9 @@ class _DecoderFn(Function):
         z = lambda *shape: torch.zeros(*shape, **f32)
         dgq, dgd = z(steps, Bp, 4 * Q), z(steps, Bp, 4 * D)
         dxq, dxd, dpq = z(steps + 1, Bp, XQw), z(steps + 1, Bp, XDw), z(steps, Bp, A)
-        dpm, dmem = z(B, L, A), z(B, L, E)
-        dv_part, dwl_part, dwc_part = z(B, A), z(B, A * F), z(B, F * 2 * K)
+        e_ = lambda *shape: torch.empty(*shape, **f32)
+        ds_tape, loc_tape, dloc_tape = e_(steps, B, L, A), e_(steps, B, L, F), e_(steps, B, L, F)
+        hist_tape, dctx_tape, dv_tape = e_(steps, B, L, 2), e_(steps, B, E), e_(steps, B, A)
         dcq, dcd, dh0, dh1, dcum, dhq_attn = z(B, Q), z(B, D), z(B, 2, L), z(B, 2, L), z(B, L), z(B, Q)
         wt = dict(q=torch.cat([q_w_ih.detach(), q_w_hh.detach()], 1).t().contiguous(),      # (P+E+Q, 4Q)
                   d=torch.cat([d_w_ih.detach(), d_w_hh.detach()], 1).t().contiguous(),      # (E+Q+D, 4D)
@@ -301,7 +302,8 @@ class _DecoderFn(Function):
         io.dxo = ops._p(dxo)
         io.dalign = ops._p(dalign.contiguous()) if dalign is not None else None
         io.dgq, io.dgd, io.dxq, io.dxd, io.dpq = ops._p(dgq), ops._p(dgd), ops._p(dxq), ops._p(dxd), ops._p(dpq)
-        io.dpm, io.dmem, io.dv_part, io.dwl_part, io.dwc_part = (ops._p(t) for t in (dpm, dmem, dv_part, dwl_part, dwc_part))
+        io.ds_tape, io.loc_tape, io.dloc_tape = ops._p(ds_tape), ops._p(loc_tape), ops._p(dloc_tape)
+        io.hist_tape, io.dctx_tape, io.dv_tape = ops._p(hist_tape), ops._p(dctx_tape), ops._p(dv_tape)
         io.dcq, io.dcd, io.dcum, io.dhq_attn = ops._p(dcq), ops._p(dcd), ops._p(dcum), ops._p(dhq_attn)
         io.dhist[0], io.dhist[1] = ops._p(dh0), ops._p(dh1)
         _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
@@ -314,9 +316,14 @@ class _DecoderFn(Function):
         dwpg = ops.gemm_wgrad(dY2, XO.view(-1, XOw))
         dbpg = ops.colsum(dY2)
         dwq_attn = ops.gemm_wgrad(dpq.view(-1, A), hq_all)
-        dv = ops.colsum(dv_part).view(v.shape)
-        dwl = ops.colsum(dwl_part).view(wl.shape)
-        dwc = ops.colsum(dwc_part).view(wc.shape)
+        # attention parameters / inputs: sums over the steps of the per-step tape slices
+        dv = ops.colsum(dv_tape.view(-1, A)).view(v.shape)
+        dwl = ops.gemm_wgrad(ds_tape.view(-1, A), loc_tape.view(-1, F))                     # (A, F)
+        dwc = ops.gemm_wgrad(dloc_tape.view(steps * B, L, F), hist_tape.view(steps * B, L, 2), K, (K - 1) // 2)   # (F, 2, K)
+        dpm = ops.colsum(ds_tape.view(steps, -1)).view(B, L, A)
+        dmem = torch.empty(B, L, E, **f32)
+        _lib.check(lib.st_attn_dmem(ops._p(align), ops._p(dctx_tape), ops._p(dmem), B, steps, L, E, ops.stream_handle()),
+                   'st_attn_dmem')
         dstd, dmean = torch.empty(B, Q, **f32), torch.empty(B, Q, **f32)
         _lib.check(lib.st_adain_bwd(ops._p(dxd) + 4 * E, Bp * XDw, XDw, ops._p(XQ) + 4 * (Bp * XQw + P + E), Bp * XQw, XQw,
                                     ops._p(ada_std), ops._p(ada_mean), ops._p(dstd), ops._p(dmean), B, Q, steps,

@@ -5,12 +5,18 @@
 //   s[l][a]    = pq[a] + pm[l][a] + sum_f Wl[a][f] * loc[l][f]
 //   e[l]       = sum_a v[a] * tanh(s[l][a]);   w = softmax_l(e);   ctx = sum_l w[l] * mem[l][:]
 //   cum_t      = cum_{t-1} + w
-// One workgroup (512 threads) per utterance recomputes loc and tanh(s) from the saved attention
-// weights (nothing of size L x A is kept from the forward) and produces
-//   dpq (A), dhist (2, L) for step t-1, and accumulates over the steps, in slabs it owns (no atomics):
-//   dpm[b] (L,A), dmem[b] (L,E), dv_part[b] (A), dWl_part[b] (A,F), dWc_part[b] (F,2,K).
-// The per-utterance weight-gradient slabs are summed over b once after the loop (st_colsum).
+// One workgroup (512 threads) per utterance recomputes loc and tanh(s) from the saved attention weights
+// (nothing of size L x A is kept from the forward) and produces dpq (A) and dhist (2, L) for step t-1, which the
+// recurrence needs immediately.  Everything that is a SUM OVER STEPS (dpm, dmem, dv, dW_l, dW_c) is not
+// accumulated here (read-modify-write chains on global memory serialise on latency: 178 us/step measured):
+// the kernel writes per-step tape slices -- ds (L,A), loc / dloc (L,F), the channels-last history (L,2), the
+// total dctx (E), dv_t (A) -- and the caller reduces them after the loop with a handful of large launches
+// (column sums and TN GEMMs).
 #include "st_common.h"
+
+#ifndef AB_PROF
+#define AB_PROF(n)   // phase timestamps, only defined by tools/mb/mb_attn_bwd.hip
+#endif
 
 namespace {
 
@@ -29,8 +35,13 @@ struct AbArgs {
     float* dcum; const float* dcum_add; int ld_dcum_add;   // dL/dcum_t = dcum (B,L, in/out) + dcum_add; also an addend of dw
     float* dpq;                            // (B, A) out
     float* dhist;                          // (B, 2, L) out: gradient w.r.t. [w_{t-1} ; cum_{t-1}] through the conv
-    float* dpm; float* dmem;               // (B, L, A), (B, L, E) accumulated in place
-    float* dv_part; float* dwl_part; float* dwc_part;   // (B, A), (B, A, F), (B, F, 2, K) accumulated in place
+    // tape slices of this step (all written, never read back here)
+    float* ds_t;      // (B, L, A)  d loss / d s[l][a]              -> dpm = sum_t, dW_l = ds^T loc
+    float* loc_t;     // (B, L, F)  location features               -> dW_l
+    float* dloc_t;    // (B, L, F)  gradient of the location features -> dW_c (conv weight gradient)
+    float* hist_t;    // (B, L, 2)  [w_{t-1}, cum_{t-1}] channels-last  -> dW_c
+    float* dctx_t;    // (B, E)     total gradient w.r.t. ctx_t      -> dmem[b] = w^T dctx
+    float* dv_t;      // (B, A)     sum_l de[l] * tanh(s[l][a])      -> dv = sum over (t, b)
     int B, L, A, E, F, K;
 };
 
@@ -49,7 +60,7 @@ __host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K) {
     o.w = p; p += L;
     o.dw = p; p += L;
     o.dctx = p; p += E;
-    o.dsb = p; p += AB_LBLK * A;
+    o.dsb = p; p += (AB_LBLK * A > 2 * AB_THREADS ? AB_LBLK * A : 2 * AB_THREADS);   // also the fold buffer of P4
     o.red = p; p += 16;
     o.total = p;
     return o;
@@ -66,6 +77,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     float* dsb = lds + o.dsb; float* red = lds + o.red;
     const int pad = (K - 1) / 2, HL = o.hl, WLD = o.wl_ld;
 
+    AB_PROF(0);
     // ---- P0: stage operands
     for (int i = tid; i < 2 * HL; i += AB_THREADS) {
         const int c = i / HL, j = i - c * HL, l = j - pad;
@@ -73,6 +85,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         if (l >= 0 && l < L) {
             if (c == 0) v = a.w_prev ? a.w_prev[(size_t)b * a.ld_wprev + l] : 0.0f;
             else v = a.w_cum_prev[(size_t)b * L + l];
+            a.hist_t[((size_t)b * L + l) * 2 + c] = v;
         }
         hist[i] = v;
     }
@@ -96,9 +109,11 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) if (a.dctx[j]) g += a.dctx[j][(size_t)b * a.ld_dctx[j] + e];
         dctx[e] = g;
+        a.dctx_t[(size_t)b * E + e] = g;
     }
     __syncthreads();
 
+    AB_PROF(1);
     // ---- P1: location features  loc[l][f]
     for (int i = tid; i < L * F; i += AB_THREADS) {
         const int l = i / F, f = i - l * F;
@@ -109,22 +124,19 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
             for (int k = 0; k < K; ++k) acc = fmaf(wr[k], hr[k], acc);
         }
         loc[i] = acc;
+        a.loc_t[(size_t)b * L * F + i] = acc;
     }
-    // ---- P2: dw[l] += dctx . mem[l];  dmem[l] += w[l] * dctx     (one wave per position, lanes over E)
-    const float* memb = a.memory + (size_t)b * L * E;
-    float* dmemb = a.dmem + (size_t)b * L * E;
+    AB_PROF(2);
+    // ---- P2: dw[l] += dctx . mem[l]     (one wave per position, lanes over E; independent coalesced loads)
+    const float* __restrict__ memb = a.memory + (size_t)b * L * E;
     for (int l = wave; l < L; l += AB_THREADS / 64) {
-        const float wl_ = ws[l];
         float acc = 0.0f;
-        for (int e = lane; e < E; e += 64) {
-            const float dc = dctx[e];
-            acc = fmaf(dc, memb[(size_t)l * E + e], acc);
-            dmemb[(size_t)l * E + e] += wl_ * dc;
-        }
+        for (int e = lane; e < E; e += 64) acc = fmaf(dctx[e], memb[(size_t)l * E + e], acc);
         acc = st_wave_sum(acc);
         if (lane == 0) dws[l] += acc;
     }
     __syncthreads();
+    AB_PROF(3);
     // softmax backward: de[l] = w[l] * (dw[l] - sum_j w[j] dw[j])
     if (wave == 0) {
         float acc = 0.0f;
@@ -138,15 +150,14 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     for (int l = tid; l < L; l += AB_THREADS) dws[l] = ws[l] * (dws[l] - dot);     // dws now holds de
     __syncthreads();
 
+    AB_PROF(4);
     // ---- P3: energy gradient, blocks of AB_LBLK positions; thread = fixed attention dim a0, positions l0 + grp, ...
     const int a0 = tid % A, grp = tid / A, ngrp = AB_THREADS / A;    // host guarantees A <= 512 and 512 % A == 0
     const float pq_a = a.pq[(size_t)b * A + a0], v_a = a.v[a0];
-    const float* pmb = a.pm + (size_t)b * L * A;
-    float* dpmb = a.dpm + (size_t)b * L * A;
+    const float* __restrict__ pmb = a.pm + (size_t)b * L * A;
+    float* __restrict__ dsg = a.ds_t + (size_t)b * L * A;
+    float* __restrict__ dlocg = a.dloc_t + (size_t)b * L * F;
     float dv_acc = 0.0f, dpq_acc = 0.0f;
-    float dwl_acc[AB_FMAX];
-#pragma unroll
-    for (int f = 0; f < AB_FMAX; ++f) dwl_acc[f] = 0.0f;
     float wl_r[AB_FMAX];
 #pragma unroll
     for (int f = 0; f < AB_FMAX; ++f) wl_r[f] = f < F ? Wl[a0 * WLD + f] : 0.0f;
@@ -163,10 +174,8 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
             dv_acc = fmaf(g, th, dv_acc);
             const float ds = g * v_a * (1.0f - th * th);
             dpq_acc += ds;
-            dpmb[(size_t)l * A + a0] += ds;
+            dsg[(size_t)l * A + a0] = ds;
             dsb[(l - l0) * A + a0] = ds;
-#pragma unroll
-            for (int f = 0; f < AB_FMAX; ++f) if (f < F) dwl_acc[f] = fmaf(ds, lr[f], dwl_acc[f]);
         }
         __syncthreads();
         // dloc[l][f] = sum_a Wl[a][f] * ds[l][a]
@@ -176,32 +185,23 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
             float acc = 0.0f;
             for (int aa = 0; aa < A; ++aa) acc = fmaf(Wl[aa * WLD + f], dr[aa], acc);
             dloc[(l0 + ll) * F + f] = acc;
+            dlocg[(l0 + ll) * F + f] = acc;
         }
         __syncthreads();
     }
-    // ---- P4: fold the per-thread accumulators of the ngrp threads sharing an attention dim, group by group
-    // (fixed order: deterministic), into the slabs this workgroup owns
-    float* dvp = a.dv_part + (size_t)b * A;
-    float* dwlp = a.dwl_part + ((size_t)b * A + a0) * F;
-    float* dpqo = a.dpq + (size_t)b * A;
-    for (int gturn = 0; gturn < ngrp; ++gturn) {
-        if (grp == gturn) {
-            dvp[a0] += dv_acc;
-            dpqo[a0] = gturn == 0 ? dpq_acc : dpqo[a0] + dpq_acc;
-#pragma unroll
-            for (int f = 0; f < AB_FMAX; ++f) if (f < F) dwlp[f] += dwl_acc[f];
-        }
-        __syncthreads();
+    AB_PROF(5);
+    // ---- P4: fold the per-thread sums of the ngrp threads sharing an attention dim (LDS, fixed order)
+    float* fold = dsb;                       // reuse: [2][AB_THREADS]   sized in ab_layout
+    fold[tid] = dv_acc; fold[AB_THREADS + tid] = dpq_acc;
+    __syncthreads();
+    if (grp == 0) {
+        float sv = 0.0f, sp = 0.0f;
+        for (int gq = 0; gq < ngrp; ++gq) { sv += fold[gq * A + a0]; sp += fold[AB_THREADS + gq * A + a0]; }
+        a.dv_t[(size_t)b * A + a0] = sv;
+        a.dpq[(size_t)b * A + a0] = sp;
     }
-    // ---- P5: conv backward
-    float* dwcp = a.dwc_part + (size_t)b * F * 2 * K;
-    for (int i = tid; i < F * 2 * K; i += AB_THREADS) {
-        const int f = i / (2 * K), r = i - f * 2 * K, c = r / K, k = r - c * K;
-        const float* hr = hist + c * HL + k;
-        float acc = 0.0f;
-        for (int l = 0; l < L; ++l) acc = fmaf(dloc[l * F + f], hr[l], acc);
-        dwcp[i] += acc;
-    }
+    AB_PROF(6);
+    // ---- P5: gradient w.r.t. the attention history through the location conv
     // dhist[c][j] = sum_{f,k} dloc[j - k + pad][f] * Wc[f][c][k]; 4 adjacent lanes split the filters
     float* dh = a.dhist + (size_t)b * 2 * L;
     for (int base = 0; base < 2 * L; base += AB_THREADS / 4) {
@@ -221,9 +221,35 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         acc += __shfl_xor(acc, 2);
         if (cj < 2 * L && q == 0) dh[cj] = acc;
     }
+    AB_PROF(7);
+}
+
+// dmem[b][l][e] = sum_t w_t[b][l] * dctx_t[b][e]      (the context is ctx_t = sum_l w_t[l] mem[l])
+__global__ __launch_bounds__(256) void attn_dmem_kernel(const float* align, const float* dctx, float* dmem, int B, int steps, int L, int E) {
+    const size_t total = (size_t)B * L * E;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const size_t bl = i / E;
+        const int l = (int)(bl % L), b = (int)(bl / L);
+        const float* wp = align + (size_t)b * steps * L + l;
+        const float* dp = dctx + (size_t)b * E + e;
+        float acc = 0.0f;
+        for (int t = 0; t < steps; ++t) acc = fmaf(wp[(size_t)t * L], dp[(size_t)t * B * E], acc);
+        dmem[i] = acc;
+    }
 }
 
 }  // namespace
+
+extern "C" int st_attn_dmem(const float* align, const float* dctx_tape, float* dmem, int B, int steps, int L, int E, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(align && dctx_tape && dmem && B > 0 && steps > 0 && L > 0 && E > 0, "st_attn_dmem: bad arguments");
+    size_t blocks = ((size_t)B * L * E + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(attn_dmem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, align, dctx_tape, dmem, B, steps, L, E);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,
                                 const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
@@ -231,12 +257,12 @@ extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* m
                                 const float* const* dctx, const int* ld_dctx, int n_dctx,
                                 const float* const* dw_direct, const int* ld_dw, int n_dw,
                                 float* dcum, const float* dcum_add, int ld_dcum_add,
-                                float* dpq, float* dhist, float* dpm, float* dmem,
-                                float* dv_part, float* dwl_part, float* dwc_part,
+                                float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                                float* dctx_t, float* dv_t,
                                 int B, int L, int A, int E, int F, int K, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(pq && pm && memory && w_cum_prev && w && loc_conv_w && loc_lin_w && v, "st_attn_step_bwd: null input");
-    ST_CHECK_ARG(dpq && dhist && dpm && dmem && dv_part && dwl_part && dwc_part, "st_attn_step_bwd: null output");
+    ST_CHECK_ARG(dpq && dhist && ds_t && loc_t && dloc_t && hist_t && dctx_t && dv_t, "st_attn_step_bwd: null output");
     ST_CHECK_ARG(B > 0 && L > 0 && A > 0 && E > 0 && F > 0 && K > 0 && (K & 1), "st_attn_step_bwd: bad dims (K must be odd)");
     ST_CHECK_ARG(A <= AB_THREADS && AB_THREADS % A == 0, "st_attn_step_bwd: attn_dim=%d must divide %d", A, AB_THREADS);
     ST_CHECK_ARG(F <= AB_FMAX, "st_attn_step_bwd: n_location_filters=%d > %d", F, AB_FMAX);
@@ -248,7 +274,7 @@ extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* m
     for (int j = 0; j < n_dctx; ++j) { a.dctx[j] = dctx[j]; a.ld_dctx[j] = ld_dctx[j]; }
     for (int j = 0; j < n_dw; ++j) { a.dw_direct[j] = dw_direct[j]; a.ld_dw[j] = ld_dw[j]; }
     a.dcum = dcum; a.dcum_add = dcum_add; a.ld_dcum_add = ld_dcum_add;
-    a.dpq = dpq; a.dhist = dhist; a.dpm = dpm; a.dmem = dmem; a.dv_part = dv_part; a.dwl_part = dwl_part; a.dwc_part = dwc_part;
+    a.dpq = dpq; a.dhist = dhist; a.ds_t = ds_t; a.loc_t = loc_t; a.dloc_t = dloc_t; a.hist_t = hist_t; a.dctx_t = dctx_t; a.dv_t = dv_t;
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
     const size_t lds = (size_t)ab_layout(L, A, E, F, K).total * sizeof(float);
     ST_CHECK_ARG(lds <= 160 * 1024, "st_attn_step_bwd: L=%d needs %zu bytes of LDS (> 160 KiB)", L, lds);

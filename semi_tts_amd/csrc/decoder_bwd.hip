@@ -8,7 +8,7 @@
 // Per step, from the last to the first, this file enqueues (no host sync, graph-capturable):
 //   a. decoder LSTM, pointwise part        dh_d = dxo_t[:, :D] + (W_hh_d^T dgates_d)_{t+1}
 //   b. dxd_t = dgates_d_t [W_ih_d | W_hh_d]     -> dctx, d(adapted h_q), dh_d carried to t-1
-//   c. attention backward (attention_bwd.hip)  -> dpq_t, d[w_{t-1}; cum_{t-1}], accumulates dpm, dmem, dv, dW_l, dW_c
+//   c. attention backward (attention_bwd.hip)  -> dpq_t, d[w_{t-1}; cum_{t-1}], per-step tape slices for dpm, dmem, dv, dW_l, dW_c
 //   d. dh_q += W_q^T dpq_t
 //   e. query LSTM, pointwise part          dh_q = d + (W_hh_q^T dgates_q)_{t+1} + std * d(adapted h_q)
 //   f. dxq_t = dgates_q_t [W_ih_q | W_hh_q]     -> d(dec_in_t), dctx_{t-1}, dh_q carried to t-1
@@ -21,8 +21,8 @@ extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* m
                                 const float* const* dctx, const int* ld_dctx, int n_dctx,
                                 const float* const* dw_direct, const int* ld_dw, int n_dw,
                                 float* dcum, const float* dcum_add, int ld_dcum_add,
-                                float* dpq, float* dhist, float* dpm, float* dmem,
-                                float* dv_part, float* dwl_part, float* dwc_part,
+                                float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                                float* dctx_t, float* dv_t,
                                 int B, int L, int A, int E, int F, int K, void* stream);
 
 extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io,
@@ -36,8 +36,9 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                  "st_decoder_backward: null weight");
     ST_CHECK_ARG(io->memory && io->pm && io->ada_std && io->align && io->wcum_tape && io->cq_tape && io->cd_tape &&
                  io->gates_q_tape && io->gates_d_tape && io->pq_all && io->dxo, "st_decoder_backward: null saved tensor");
-    ST_CHECK_ARG(io->dgq && io->dgd && io->dxq && io->dxd && io->dpq && io->dpm && io->dmem && io->dv_part && io->dwl_part &&
-                 io->dwc_part && io->dcq && io->dcd && io->dhist[0] && io->dhist[1] && io->dcum && io->dhq_attn,
+    ST_CHECK_ARG(io->dgq && io->dgd && io->dxq && io->dxd && io->dpq && io->ds_tape && io->loc_tape && io->dloc_tape &&
+                 io->hist_tape && io->dctx_tape && io->dv_tape && io->dcq && io->dcd && io->dhist[0] && io->dhist[1] && io->dcum &&
+                 io->dhq_attn,
                  "st_decoder_backward: null output/scratch");
     const int XQ = P + E + Q, XD = E + Q + D, XO = D + E;
     const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
@@ -76,7 +77,9 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                               io->align + (size_t)t * L, ldal, w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v,
                               dctx, ld_dctx, 3, dwd, ld_dw, io->dalign ? 2 : 1,
                               io->dcum, dhist_next + L, 2 * L,
-                              dpq, dhist_cur, io->dpm, io->dmem, io->dv_part, io->dwl_part, io->dwc_part,
+                              dpq, dhist_cur, io->ds_tape + (size_t)t * BL * A, io->loc_tape + (size_t)t * BL * d->F,
+                              io->dloc_tape + (size_t)t * BL * d->F, io->hist_tape + (size_t)t * BL * 2,
+                              io->dctx_tape + (size_t)t * B * E, io->dv_tape + (size_t)t * B * A,
                               B, L, A, E, d->F, d->K, stream);
         if (rc) return rc;
         // d. through the query projection

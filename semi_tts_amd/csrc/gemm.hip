@@ -145,37 +145,57 @@ __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
 }
 
 // ---- training-mode BatchNorm helpers ---------------------------------------------------
-// column statistics: grid.x = column blocks of 64, block = 256 threads = 4 row lanes x 64 cols.
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* X, int ldx, int coff, int M, int N,
-                                                       float* mean_out, float* var_out,
-                                                       float* run_mean, float* run_var, float momentum) {
+// column statistics, two launches: (1) grid = (column blocks of 64, row chunks): every block reduces its chunk of
+// rows to (mean_c, M2_c) with a chunk-local two-pass (the second pass re-reads <= 64 KB from cache);
+// (2) one thread per column merges the chunks in a fixed order (Chan et al.: exact pairwise update of mean / M2).
+__global__ __launch_bounds__(256) void bn_stats_chunk_kernel(const float* X, int ldx, int coff, int M, int N, int rows_per_chunk,
+                                                             float* part) {   // part[chunk][2][N]
     __shared__ float red[4][64];
     __shared__ float smean[64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
     const bool ok = n < N;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
     float s = 0.0f;
-    if (ok) for (int m = rl; m < M; m += 4) s += X[(size_t)m * ldx + coff + n];
+    if (ok) for (int m = m0 + rl; m < m1; m += 4) s += X[(size_t)m * ldx + coff + n];
     red[rl][c] = s;
     __syncthreads();
-    if (rl == 0) smean[c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)M;
+    if (rl == 0) smean[c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)max(m1 - m0, 1);
     __syncthreads();
     const float mean = smean[c];
     float q = 0.0f;
-    if (ok) for (int m = rl; m < M; m += 4) { const float d = X[(size_t)m * ldx + coff + n] - mean; q = fmaf(d, d, q); }
+    if (ok) for (int m = m0 + rl; m < m1; m += 4) { const float d = X[(size_t)m * ldx + coff + n] - mean; q = fmaf(d, d, q); }
     __syncthreads();
     red[rl][c] = q;
     __syncthreads();
     if (rl == 0 && ok) {
-        const float ss = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-        const float var_b = ss / (float)M;
-        mean_out[n] = mean;
-        var_out[n] = var_b;
-        if (run_mean) {
-            const float var_u = M > 1 ? ss / (float)(M - 1) : var_b;
-            run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
-            run_var[n] = (1.0f - momentum) * run_var[n] + momentum * var_u;
-        }
+        part[((size_t)blockIdx.y * 2 + 0) * N + n] = mean;
+        part[((size_t)blockIdx.y * 2 + 1) * N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, int chunks, int rows_per_chunk, int M, int N,
+                                                             float* mean_out, float* var_out, float* run_mean, float* run_var,
+                                                             float momentum) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const float nb = (float)(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk);
+        if (nb <= 0.0f) break;
+        const float mb = part[((size_t)ch * 2 + 0) * N + n], qb = part[((size_t)ch * 2 + 1) * N + n];
+        const float tot = cnt + nb, delta = mb - mean;
+        mean += delta * (nb / tot);
+        m2 += qb + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+    }
+    const float var_b = m2 / (float)M;
+    mean_out[n] = mean;
+    var_out[n] = var_b;
+    if (run_mean) {
+        const float var_u = M > 1 ? m2 / (float)(M - 1) : var_b;
+        run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
+        run_var[n] = (1.0f - momentum) * run_var[n] + momentum * var_u;
     }
 }
 
@@ -227,12 +247,18 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
 }
 
 extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, float* mean_out, float* var_out,
-                           float* run_mean, float* run_var, float momentum, void* stream) {
+                           float* run_mean, float* run_var, float momentum, float* ws, void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(X && mean_out && var_out && M > 0 && N > 0, "st_bn_stats: bad arguments");
     ST_CHECK_ARG((run_mean == nullptr) == (run_var == nullptr), "st_bn_stats: run_mean/run_var must both be given");
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       X, ldx, coff, M, N, mean_out, var_out, run_mean, run_var, momentum);
+    ST_CHECK_ARG(ws, "st_bn_stats: null workspace (st_colreduce_workspace_floats)");
+    const int chunks = st_colreduce_chunks(M);
+    const int rpc = (M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(bn_stats_chunk_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream,
+                       X, ldx, coff, M, N, rpc, ws);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       ws, chunks, rpc, M, N, mean_out, var_out, run_mean, run_var, momentum);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -122,25 +122,24 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, fl
     }
 }
 
-// column sums over M rows, optionally of X * Y:  out[n] (+)= sum_m X[m][n] (* Y[m][n])
+// column sums over M rows, optionally of X * Y:  out[n] (+)= sum_m X[m][n] (* Y[m][n]).  Rows are split into chunks
+// over blockIdx.y (partials [chunk][N]); colsum_final adds the chunks in a fixed order.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* X, int ldx, int xoff, const float* Y, int ldy, int yoff,
-                                                     int M, int N, float* out, int accumulate) {
+                                                     int M, int N, int rows_per_chunk, float* part) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
     float s = 0.0f;
     if (n < N)
-        for (int m = rl; m < M; m += 4) {
+        for (int m = m0 + rl; m < m1; m += 4) {
             float v = X[(size_t)m * ldx + xoff + n];
             if (Y) v *= Y[(size_t)m * ldy + yoff + n];
             s += v;
         }
     red[rl][c] = s;
     __syncthreads();
-    if (rl == 0 && n < N) {
-        const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-        out[n] = accumulate ? out[n] + t : t;
-    }
+    if (rl == 0 && n < N) part[(size_t)blockIdx.y * N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
 __device__ __forceinline__ float act_grad(float out, int act) {
@@ -171,14 +170,16 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, int ldd
 //   pass 2 (bn_bwd_apply):  dx = w / sigma * (dyb - s1/M - xhat * s2/M)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff,
                                                             int act, const float* x, int ldx, int xoff, const float* mean,
-                                                            const float* var, float eps, int M, int N, float* s1, float* s2) {
+                                                            const float* var, float eps, int M, int N, int rows_per_chunk,
+                                                            float* part) {   // part[chunk][2][N]
     __shared__ float r1[4][64], r2[4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
     float a = 0.0f, b = 0.0f;
     if (n < N) {
         const float mu = mean[n], inv = 1.0f / sqrtf(var[n] + eps);
-        for (int m = rl; m < M; m += 4) {
+        for (int m = m0 + rl; m < m1; m += 4) {
             float g = dy[(size_t)m * ldd + doff + n];
             if (act != ST_ACT_NONE) g *= act_grad(y[(size_t)m * ldy + yoff + n], act);
             a += g;
@@ -188,9 +189,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, int
     r1[rl][c] = a; r2[rl][c] = b;
     __syncthreads();
     if (rl == 0 && n < N) {
-        s1[n] = r1[0][c] + r1[1][c] + r1[2][c] + r1[3][c];
-        s2[n] = r2[0][c] + r2[1][c] + r2[2][c] + r2[3][c];
+        part[((size_t)blockIdx.y * 2 + 0) * N + n] = r1[0][c] + r1[1][c] + r1[2][c] + r1[3][c];
+        part[((size_t)blockIdx.y * 2 + 1) * N + n] = r2[0][c] + r2[1][c] + r2[2][c] + r2[3][c];
     }
+}
+
+// out[q][n] (+)= sum_chunks part[chunk][q][n], q < Q   (fixed order)
+__global__ __launch_bounds__(256) void chunk_final_kernel(const float* part, int chunks, int Q, int N, float* out0, float* out1,
+                                                          int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q * N) return;
+    const int q = i / N, n = i - q * N;
+    float* out = q == 0 ? out0 : out1;
+    float s = accumulate ? out[n] : 0.0f;
+    for (int ch = 0; ch < chunks; ++ch) s += part[((size_t)ch * Q + q) * N + n];
+    out[n] = s;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff,
@@ -331,12 +344,18 @@ extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* 
     return 0;
 }
 
+extern "C" size_t st_colreduce_workspace_floats(int M, int N) { return (size_t)2 * st_colreduce_chunks(M) * N + 2 * (size_t)N; }
+
 extern "C" int st_colsum(const float* X, int ldx, int xoff, const float* Y, int ldy, int yoff, int M, int N,
-                         float* out, int accumulate, void* stream) {
+                         float* out, int accumulate, float* ws, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(X && out && M > 0 && N > 0, "st_colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, ldx, xoff, Y, ldy, yoff,
-                       M, N, out, accumulate);
+    ST_CHECK_ARG(X && out && ws && M > 0 && N > 0, "st_colsum: bad arguments");
+    const int chunks = st_colreduce_chunks(M);
+    const int rpc = (M + chunks - 1) / chunks;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, X, ldx, xoff, Y, ldy, yoff, M, N, rpc, ws);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, chunks, 1, N, out, out, accumulate);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -360,8 +379,13 @@ extern "C" int st_bn_bwd(const float* dy, int ldd, int doff, const float* y, int
     hipStream_t st = (hipStream_t)stream;
     float* s1 = ws;
     float* s2 = ws + N;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 63) / 64), dim3(256), 0, st, dy, ldd, doff, y, ldy, yoff, act,
-                       x, ldx, xoff, mean, var, eps, M, N, s1, s2);
+    float* part = ws + 2 * (size_t)N;
+    const int chunks = st_colreduce_chunks(M);
+    const int rpc = (M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, dy, ldd, doff, y, ldy, yoff, act,
+                       x, ldx, xoff, mean, var, eps, M, N, rpc, part);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_final_kernel, dim3((2 * N + 255) / 256), dim3(256), 0, st, part, chunks, 2, N, s1, s2, 0);
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, st, dy, ldd, doff, y, ldy, yoff,
                        act, x, ldx, xoff, mean, var, w, eps, M, N, s1, s2, dx, lddx, dxoff);

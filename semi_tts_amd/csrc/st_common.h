@@ -40,6 +40,10 @@ static __host__ __device__ inline bool st_aligned16(const void* p) { return (rei
 // ---------------------------------------------------------------- device helpers (wave = 64)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// row chunks of the split column reductions (st_bn_stats, st_colsum, st_bn_bwd): enough blocks to fill 256 CUs
+// even for 80-column tensors, chunks of >= 64 rows
+static inline int st_colreduce_chunks(int M) { int c = M / 64; if (c < 1) c = 1; if (c > 128) c = 128; return c; }
+
 #define ST_WAVE 64
 
 __device__ __forceinline__ float st_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

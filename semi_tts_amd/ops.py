@@ -149,6 +149,11 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, coff=0, bias=No
     return out
 
 
+def _colreduce_ws(M, N, device):
+    n = int(_lib.load().st_colreduce_workspace_floats(int(M), int(N)))
+    return torch.empty(n, device=device, dtype=torch.float32)
+
+
 def bn_stats(x2d, coff, N, run_mean=None, run_var=None, momentum=0.1):
     """per-column batch statistics of x2d[:, coff:coff+N] (+ running-stat update in place)"""
     lib = _lib.load()
@@ -156,7 +161,7 @@ def bn_stats(x2d, coff, N, run_mean=None, run_var=None, momentum=0.1):
     mean = torch.empty(N, device=x2d.device, dtype=torch.float32)
     var = torch.empty(N, device=x2d.device, dtype=torch.float32)
     check(lib.st_bn_stats(_p(x2d), int(x2d.stride(0)), int(coff), M, N, _p(mean), _p(var), _p(run_mean), _p(run_var),
-                          float(momentum), stream_handle()), 'st_bn_stats')
+                          float(momentum), _p(_colreduce_ws(M, N, x2d.device)), stream_handle()), 'st_bn_stats')
     return mean, var
 
 
@@ -305,7 +310,8 @@ def colsum(x2d, N=None, xoff=0, y2d=None, yoff=0, out=None, accumulate=False):
     if out is None:
         out = torch.empty(N, device=x2d.device, dtype=torch.float32)
     check(_lib.load().st_colsum(_p(x2d), int(x2d.stride(0)), int(xoff), _p(y2d), int(y2d.stride(0)) if y2d is not None else 0,
-                                int(yoff), M, N, _p(out), 1 if accumulate else 0, stream_handle()), 'st_colsum')
+                                int(yoff), M, N, _p(out), 1 if accumulate else 0, _p(_colreduce_ws(M, N, x2d.device)),
+                                stream_handle()), 'st_colsum')
     return out
 
 
@@ -325,7 +331,7 @@ def bn_bwd(dy2d, y2d, act, x2d, mean, var, w, eps, need_wb=True):
     dx = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
     dw = torch.empty(N, device=x2d.device, dtype=torch.float32) if need_wb else None
     db = torch.empty(N, device=x2d.device, dtype=torch.float32) if need_wb else None
-    ws = torch.empty(2 * N, device=x2d.device, dtype=torch.float32)
+    ws = _colreduce_ws(M, N, x2d.device)
     check(_lib.load().st_bn_bwd(_p(dy2d), int(dy2d.stride(0)), 0, _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, 0,
                                 ACT[act], _p(x2d), int(x2d.stride(0)), 0, _p(mean), _p(var), _p(w), float(eps), M, N,
                                 _p(dx), N, 0, _p(dw), _p(db), 0, _p(ws), stream_handle()), 'st_bn_bwd')

@@ -23,6 +23,7 @@ namespace {
 constexpr int AB_THREADS = 512;
 constexpr int AB_LBLK = 16;     // positions per block of the energy-gradient phase
 constexpr int AB_FMAX = 32;     // location filters held in registers per thread
+constexpr int AB_LPT = AB_LBLK / 2;   // positions per thread and block (at least two threads share an attention dim)
 
 struct AbArgs {
     const float* pq; const float* pm; const float* memory;
@@ -45,22 +46,31 @@ struct AbArgs {
     int B, L, A, E, F, K;
 };
 
-struct AbLds { int hist, hl, wc, wl, wl_ld, loc, dloc, w, dw, dctx, dsb, red, total; };
+// tanh from one v_exp_f32 and one fast reciprocal (same as the forward kernel): |error| <= ~2e-7 absolute
+__device__ __forceinline__ float ab_tanh(float x) {
+    const float t = __expf(-2.0f * fabsf(x));
+    return copysignf(__fdividef(1.0f - t, 1.0f + t), x);
+}
+
+struct AbLds { int hist, hl, wct, f4, wl, wlt, ld, loc, dloc, w, dw, dctx, dsb, part, red, total; };
 
 __host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K) {
     AbLds o;
     int p = 0;
-    o.hl = L + K;                         // pad zeros both sides
+    o.f4 = (F + 3) & ~3;                  // rows of loc / dloc / W_l / transposed W_c padded to float4
+    o.hl = (L + K + 4 + 3) & ~3;          // zero-padded history per channel
     o.hist = p; p += 2 * o.hl;
-    o.wc = p; p += F * 2 * K;
-    o.wl_ld = F | 1;                      // odd row stride: lanes with different a hit different banks
-    o.wl = p; p += A * o.wl_ld;
-    o.loc = p; p += L * F;
-    o.dloc = p; p += L * F;
-    o.w = p; p += L;
-    o.dw = p; p += L;
-    o.dctx = p; p += E;
-    o.dsb = p; p += (AB_LBLK * A > 2 * AB_THREADS ? AB_LBLK * A : 2 * AB_THREADS);   // also the fold buffer of P4
+    o.wct = p; p += 2 * K * o.f4;         // W_c transposed to [c][k][f]
+    o.wl = p; p += A * o.f4;              // W_l [a][f]
+    o.ld = ((A + 63) & ~63) + 4;          // row stride of the two MFMA operands: a padded to 64, +4 floats against bank conflicts
+    o.wlt = p; p += 32 * o.ld;            // W_l^T [f][a] (rows f >= F and columns a >= A are zero)
+    o.loc = p; p += L * AB_FMAX;          // rows padded to AB_FMAX zeros: the energy phase reads them unconditionally
+    o.dloc = p; p += L * o.f4;
+    o.w = p; p += (L + 3) & ~3;
+    o.dw = p; p += (L + 3) & ~3;
+    o.dctx = p; p += (E + 3) & ~3;
+    o.dsb = p; p += (AB_LBLK * o.ld > 2 * AB_THREADS ? AB_LBLK * o.ld : 2 * AB_THREADS);   // ds block [l][a]; also the fold buffer of P4
+    o.part = p; p += 4 * AB_LBLK * 32;    // partial dloc sums [a quarter][l][f lane]
     o.red = p; p += 16;
     o.total = p;
     return o;
@@ -72,13 +82,43 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     const int b = blockIdx.x;
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
     const AbLds o = ab_layout(L, A, E, F, K);
-    float* hist = lds + o.hist; float* Wc = lds + o.wc; float* Wl = lds + o.wl; float* loc = lds + o.loc;
+    float* hist = lds + o.hist; float* WcT = lds + o.wct; float* Wl = lds + o.wl; float* WlT = lds + o.wlt; float* loc = lds + o.loc;
     float* dloc = lds + o.dloc; float* ws = lds + o.w; float* dws = lds + o.dw; float* dctx = lds + o.dctx;
-    float* dsb = lds + o.dsb; float* red = lds + o.red;
-    const int pad = (K - 1) / 2, HL = o.hl, WLD = o.wl_ld;
+    float* dsb = lds + o.dsb; float* part = lds + o.part; float* red = lds + o.red;
+    const int pad = (K - 1) / 2, HL = o.hl, F4 = o.f4, LD = o.ld;
 
     AB_PROF(0);
-    // ---- P0: stage operands
+    // energy-gradient role of this thread: fixed attention dim a0, positions l0 + grp, l0 + grp + ngrp, ...
+    const int a0 = tid % A, grp = tid / A, ngrp = AB_THREADS / A;    // host: A <= 256 and 512 % A == 0, so ngrp >= 2
+    const float* __restrict__ pmb = a.pm + (size_t)b * L * A;
+    // processed-memory values of the first block: issued before anything else, consumed in P3
+    float pmr[AB_LPT];
+#pragma unroll
+    for (int i = 0; i < AB_LPT; ++i) {
+        const int l = grp + i * ngrp;
+        pmr[i] = (i * ngrp + grp < AB_LBLK && l < L) ? pmb[(size_t)l * A + a0] : 0.0f;
+    }
+    // encoder-memory rows of the first round of P2 (wave w: positions w, w+8, w+16, w+24), issued now, consumed after P1
+    constexpr int NW = AB_THREADS / 64;
+    const float* __restrict__ memb = a.memory + (size_t)b * L * E;
+    const bool mem_pf = E <= 512;
+    f32x4 mpf[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int l = wave + j * NW, e = lane * 4 + h * 256;
+            mpf[j][h] = (mem_pf && l < L && e < E) ? st_ld4(memb + (size_t)l * E + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    // ---- P0: stage operands.  The first round of the weight loads goes to registers before any LDS traffic so
+    // that all global latencies of this phase overlap (each separate load -> store loop costs one round trip).
+    const int nWc = F * 2 * K, nWl = A * F;
+    float wc_v[4], wl_v[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = tid + j * AB_THREADS; wc_v[j] = i < nWc ? a.loc_conv_w[i] : 0.0f; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int i = tid + j * AB_THREADS; wl_v[j] = i < nWl ? a.loc_lin_w[i] : 0.0f; }
+    AB_PROF(8);
     for (int i = tid; i < 2 * HL; i += AB_THREADS) {
         const int c = i / HL, j = i - c * HL, l = j - pad;
         float v = 0.0f;
@@ -89,8 +129,45 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         }
         hist[i] = v;
     }
-    for (int i = tid; i < F * 2 * K; i += AB_THREADS) Wc[i] = a.loc_conv_w[i];
-    for (int i = tid; i < A * F; i += AB_THREADS) { const int aa = i / F, f = i - aa * F; Wl[aa * WLD + f] = a.loc_lin_w[i]; }
+    AB_PROF(9);
+    // zero padding of the LDS operands: pad columns a >= A of the two MFMA operands always; everything else only
+    // when F is not the full 32 filters (then whole arrays are cleared before the scattering stores)
+    const bool ragged = F != AB_FMAX;
+    if (ragged) {
+        for (int i = tid; i < 2 * K * F4; i += AB_THREADS) WcT[i] = 0.0f;
+        for (int i = tid; i < A * F4; i += AB_THREADS) Wl[i] = 0.0f;
+        for (int i = tid; i < 32 * LD; i += AB_THREADS) WlT[i] = 0.0f;
+        for (int i = tid; i < AB_LBLK * LD; i += AB_THREADS) dsb[i] = 0.0f;
+        for (int i = tid; i < L * AB_FMAX; i += AB_THREADS) loc[i] = 0.0f;
+        __syncthreads();
+    } else {
+        const int padw = LD - A;
+        for (int i = tid; i < (32 + AB_LBLK) * padw; i += AB_THREADS) {
+            const int r = i / padw, c = A + (i - r * padw);
+            if (r < 32) WlT[r * LD + c] = 0.0f; else dsb[(r - 32) * LD + c] = 0.0f;
+        }
+    }
+    AB_PROF(10);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                               // [c][k][f] <- [f][c][k]
+        const int i = tid + j * AB_THREADS;
+        if (i < nWc) { const int f = i / (2 * K), ck = i - f * 2 * K; WcT[ck * F4 + f] = wc_v[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = tid + j * AB_THREADS;
+        if (i < nWl) { const int aa = i / F, f = i - aa * F; Wl[aa * F4 + f] = wl_v[j]; WlT[f * LD + aa] = wl_v[j]; }
+    }
+    for (int i = tid + 4 * AB_THREADS; i < nWc; i += AB_THREADS) {      // sizes beyond the register rounds
+        const int f = i / (2 * K), ck = i - f * 2 * K;
+        WcT[ck * F4 + f] = a.loc_conv_w[i];
+    }
+    for (int i = tid + 16 * AB_THREADS; i < nWl; i += AB_THREADS) {
+        const int aa = i / F, f = i - aa * F;
+        const float wv = a.loc_lin_w[i];
+        Wl[aa * F4 + f] = wv; WlT[f * LD + aa] = wv;
+    }
+    AB_PROF(11);
     for (int l = tid; l < L; l += AB_THREADS) {
         ws[l] = a.w[(size_t)b * a.ld_w + l];
         float g = 0.0f;
@@ -104,6 +181,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         }
         dws[l] = g;
     }
+    AB_PROF(12);
     for (int e = tid; e < E; e += AB_THREADS) {
         float g = 0.0f;
 #pragma unroll
@@ -112,28 +190,87 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         a.dctx_t[(size_t)b * E + e] = g;
     }
     __syncthreads();
+    // W_l row of this thread in registers (for s = pq + pm + W_l loc)
+    float wl_r[AB_FMAX];
+#pragma unroll
+    for (int f = 0; f < AB_FMAX; ++f) wl_r[f] = 0.0f;
+    if (F4 == AB_FMAX) {
+#pragma unroll
+        for (int f = 0; f < AB_FMAX; f += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wl + a0 * F4 + f);
+            wl_r[f] = w4[0]; wl_r[f + 1] = w4[1]; wl_r[f + 2] = w4[2]; wl_r[f + 3] = w4[3];
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < AB_FMAX; ++f) if (f < F) wl_r[f] = Wl[a0 * F4 + f];
+    }
 
     AB_PROF(1);
-    // ---- P1: location features  loc[l][f]
-    for (int i = tid; i < L * F; i += AB_THREADS) {
-        const int l = i / F, f = i - l * F;
-        float acc = 0.0f;
-        for (int c = 0; c < 2; ++c) {
-            const float* wr = Wc + (f * 2 + c) * K;
-            const float* hr = hist + c * HL + l;
-            for (int k = 0; k < K; ++k) acc = fmaf(wr[k], hr[k], acc);
+    // ---- P1: location features loc[l][f]: one thread = one filter x 4 consecutive positions, sliding window
+    {
+        const int nlb = (L + 3) >> 2;
+        for (int i = tid; i < nlb * F4; i += AB_THREADS) {
+            const int f = i % F4, l0 = (i / F4) * 4;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+            if (f < F) {
+                for (int c = 0; c < 2; ++c) {
+                    const float* hr = hist + c * HL + l0;
+                    const float* wr = WcT + (size_t)c * K * F4 + f;
+                    float h0 = hr[0], h1 = hr[1], h2 = hr[2];
+#pragma unroll 4
+                    for (int k = 0; k < K; ++k) {
+                        const float h3 = hr[k + 3], wv = wr[k * F4];
+                        acc0 = fmaf(wv, h0, acc0); acc1 = fmaf(wv, h1, acc1); acc2 = fmaf(wv, h2, acc2); acc3 = fmaf(wv, h3, acc3);
+                        h0 = h1; h1 = h2; h2 = h3;
+                    }
+                }
+            }
+            const float r[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (l0 + j < L) {
+                    loc[(l0 + j) * AB_FMAX + f] = r[j];
+                    if (f < F) a.loc_t[((size_t)b * L + l0 + j) * F + f] = r[j];
+                }
         }
-        loc[i] = acc;
-        a.loc_t[(size_t)b * L * F + i] = acc;
     }
     AB_PROF(2);
-    // ---- P2: dw[l] += dctx . mem[l]     (one wave per position, lanes over E; independent coalesced loads)
-    const float* __restrict__ memb = a.memory + (size_t)b * L * E;
-    for (int l = wave; l < L; l += AB_THREADS / 64) {
-        float acc = 0.0f;
-        for (int e = lane; e < E; e += 64) acc = fmaf(dctx[e], memb[(size_t)l * E + e], acc);
-        acc = st_wave_sum(acc);
-        if (lane == 0) dws[l] += acc;
+    // ---- P2: dw[l] += dctx . mem[l]     (one wave per position, lanes over E)
+    {
+        int lstart = wave;
+        if (mem_pf) {
+            f32x4 d4[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const int e = lane * 4 + h * 256; d4[h] = e < E ? *reinterpret_cast<const f32x4*>(dctx + e) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int l = wave + j * NW;
+                float acc = 0.0f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    acc = fmaf(d4[h][0], mpf[j][h][0], acc); acc = fmaf(d4[h][1], mpf[j][h][1], acc);
+                    acc = fmaf(d4[h][2], mpf[j][h][2], acc); acc = fmaf(d4[h][3], mpf[j][h][3], acc);
+                }
+                acc = st_wave_sum(acc);
+                if (lane == 0 && l < L) dws[l] += acc;
+            }
+            lstart = wave + 4 * NW;
+        }
+        for (int l = lstart; l < L; l += 2 * NW) {          // remaining positions: two rows' loads in flight per wave
+            const int l2 = l + NW;
+            float acc = 0.0f, acc2 = 0.0f;
+            for (int e = lane * 4; e < E; e += 256) {      // E % 4 == 0 checked on the host
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dctx + e);
+                const f32x4 m4 = st_ld4(memb + (size_t)l * E + e);
+                f32x4 n4 = {0.f, 0.f, 0.f, 0.f};
+                if (l2 < L) n4 = st_ld4(memb + (size_t)l2 * E + e);
+                acc = fmaf(d4[0], m4[0], acc); acc = fmaf(d4[1], m4[1], acc); acc = fmaf(d4[2], m4[2], acc); acc = fmaf(d4[3], m4[3], acc);
+                acc2 = fmaf(d4[0], n4[0], acc2); acc2 = fmaf(d4[1], n4[1], acc2); acc2 = fmaf(d4[2], n4[2], acc2); acc2 = fmaf(d4[3], n4[3], acc2);
+            }
+            acc = st_wave_sum(acc);
+            acc2 = st_wave_sum(acc2);
+            if (lane == 0) { dws[l] += acc; if (l2 < L) dws[l2] += acc2; }
+        }
     }
     __syncthreads();
     AB_PROF(3);
@@ -151,47 +288,91 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     __syncthreads();
 
     AB_PROF(4);
-    // ---- P3: energy gradient, blocks of AB_LBLK positions; thread = fixed attention dim a0, positions l0 + grp, ...
-    const int a0 = tid % A, grp = tid / A, ngrp = AB_THREADS / A;    // host guarantees A <= 512 and 512 % A == 0
+    // ---- P3: energy gradient in blocks of AB_LBLK positions
     const float pq_a = a.pq[(size_t)b * A + a0], v_a = a.v[a0];
-    const float* __restrict__ pmb = a.pm + (size_t)b * L * A;
     float* __restrict__ dsg = a.ds_t + (size_t)b * L * A;
     float* __restrict__ dlocg = a.dloc_t + (size_t)b * L * F;
     float dv_acc = 0.0f, dpq_acc = 0.0f;
-    float wl_r[AB_FMAX];
-#pragma unroll
-    for (int f = 0; f < AB_FMAX; ++f) wl_r[f] = f < F ? Wl[a0 * WLD + f] : 0.0f;
+    const int fl = tid & 31;
 
     for (int l0 = 0; l0 < L; l0 += AB_LBLK) {
         const int lend = min(L, l0 + AB_LBLK);
-        for (int l = l0 + grp; l < lend; l += ngrp) {
-            const float* lr = loc + l * F;
-            float s = pq_a + pmb[(size_t)l * A + a0];
+        // prefetch the next block's processed-memory values while this block computes
+        float pmn[AB_LPT];
 #pragma unroll
-            for (int f = 0; f < AB_FMAX; ++f) if (f < F) s = fmaf(wl_r[f], lr[f], s);
-            const float th = tanhf(s);
-            const float g = dws[l];
-            dv_acc = fmaf(g, th, dv_acc);
-            const float ds = g * v_a * (1.0f - th * th);
-            dpq_acc += ds;
-            dsg[(size_t)l * A + a0] = ds;
-            dsb[(l - l0) * A + a0] = ds;
+        for (int i = 0; i < AB_LPT; ++i) {
+            const int l = l0 + AB_LBLK + grp + i * ngrp;
+            pmn[i] = (i * ngrp + grp < AB_LBLK && l < L) ? pmb[(size_t)l * A + a0] : 0.0f;
+        }
+        // branch-free: rows past the block / past L are computed on a clamped position with de = 0; two positions
+        // per pass (16 independent 16-byte LDS reads in flight; more would spill registers)
+#pragma unroll
+        for (int i0 = 0; i0 < AB_LPT; i0 += 2) {
+            float sarr[2];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int l = min(l0 + grp + (i0 + ii) * ngrp, L - 1);
+                const float* lr = loc + l * AB_FMAX;
+                float s = pq_a + pmr[i0 + ii], s2 = 0.0f;
+#pragma unroll
+                for (int f = 0; f < AB_FMAX; f += 4) {          // pad columns are zero on both sides
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lr + f);
+                    s = fmaf(wl_r[f], l4[0], s); s2 = fmaf(wl_r[f + 1], l4[1], s2);
+                    s = fmaf(wl_r[f + 2], l4[2], s); s2 = fmaf(wl_r[f + 3], l4[3], s2);
+                }
+                sarr[ii] = s + s2;
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int row = (i0 + ii) * ngrp + grp, l = l0 + row;
+                const bool in_blk = row < AB_LBLK, valid = in_blk && l < lend;
+                const float th = ab_tanh(sarr[ii]);
+                const float g = valid ? dws[min(l, L - 1)] : 0.0f;
+                dv_acc = fmaf(g, th, dv_acc);
+                const float ds = g * v_a * (1.0f - th * th);
+                dpq_acc += ds;
+                if (valid) dsg[(size_t)l * A + a0] = ds;
+                if (in_blk) dsb[row * LD + a0] = ds;            // zero for rows past L
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AB_LPT; ++i) pmr[i] = pmn[i];
+        __syncthreads();
+        // dloc[l][f] = sum_a ds[l][a] * W_l[a][f] on the matrix cores: wave = (filter tile nt of 16, quarter kq of the
+        // padded a range); exact-fp32 16x16x4 MFMAs, each lane's float4 along a feeds four of them (same k order
+        // for both operands), 16 x 16 partial tiles to LDS, summed below
+        {
+            const int nt = wave & 1, kq = wave >> 1;
+            const int APq = (LD - 4) >> 2;                      // a range of one quarter (multiple of 16)
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (nt * 16 < F4) {
+                const float* ap = dsb + (lane & 15) * LD + kq * APq + 4 * (lane >> 4);
+                const float* bp = WlT + (nt * 16 + (lane & 15)) * LD + kq * APq + 4 * (lane >> 4);
+                for (int kc = 0; kc < APq; kc += 16) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + kc);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + kc);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], b4[c], acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(kq * AB_LBLK + 4 * (lane >> 4) + r) * 32 + nt * 16 + (lane & 15)] = acc[r];
         }
         __syncthreads();
-        // dloc[l][f] = sum_a Wl[a][f] * ds[l][a]
-        for (int i = tid; i < (lend - l0) * F; i += AB_THREADS) {
-            const int ll = i / F, f = i - ll * F;
-            const float* dr = dsb + ll * A;
-            float acc = 0.0f;
-            for (int aa = 0; aa < A; ++aa) acc = fmaf(Wl[aa * WLD + f], dr[aa], acc);
-            dloc[(l0 + ll) * F + f] = acc;
-            dlocg[(l0 + ll) * F + f] = acc;
+        {
+            const int ll = tid >> 5;                      // 16 positions x 32 filter lanes = 512 threads
+            const float sum = part[(0 * AB_LBLK + ll) * 32 + fl] + part[(1 * AB_LBLK + ll) * 32 + fl] +
+                              part[(2 * AB_LBLK + ll) * 32 + fl] + part[(3 * AB_LBLK + ll) * 32 + fl];
+            if (l0 + ll < L && fl < F4) {
+                dloc[(l0 + ll) * F4 + fl] = sum;
+                if (fl < F) dlocg[(size_t)(l0 + ll) * F + fl] = sum;
+            }
         }
         __syncthreads();
     }
     AB_PROF(5);
     // ---- P4: fold the per-thread sums of the ngrp threads sharing an attention dim (LDS, fixed order)
-    float* fold = dsb;                       // reuse: [2][AB_THREADS]   sized in ab_layout
+    float* fold = dsb;
     fold[tid] = dv_acc; fold[AB_THREADS + tid] = dpq_acc;
     __syncthreads();
     if (grp == 0) {
@@ -202,23 +383,28 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     }
     AB_PROF(6);
     // ---- P5: gradient w.r.t. the attention history through the location conv
-    // dhist[c][j] = sum_{f,k} dloc[j - k + pad][f] * Wc[f][c][k]; 4 adjacent lanes split the filters
+    // dhist[c][j] = sum_{f,k} dloc[j - k + pad][f] * Wc[f][c][k]; 8 adjacent lanes split the filters in float4 groups
     float* dh = a.dhist + (size_t)b * 2 * L;
-    for (int base = 0; base < 2 * L; base += AB_THREADS / 4) {
-        const int cj = base + (tid >> 2), q = tid & 3;
+    for (int base = 0; base < 2 * L; base += AB_THREADS / 8) {
+        const int cj = base + (tid >> 3), q = tid & 7;
         float acc = 0.0f;
         if (cj < 2 * L) {
             const int c = cj / L, j = cj - c * L;
-            for (int f = q; f < F; f += 4) {
-                const float* wr = Wc + (f * 2 + c) * K;
-                for (int k = 0; k < K; ++k) {
-                    const int l = j - k + pad;
-                    if (l >= 0 && l < L) acc = fmaf(dloc[l * F + f], wr[k], acc);
+            const int klo = max(0, j + pad - (L - 1)), khi = min(K - 1, j + pad);     // 0 <= j - k + pad < L
+            for (int f = q * 4; f < F4; f += 32) {
+                const float* wr = WcT + (size_t)c * K * F4 + f;
+#pragma unroll 4
+                for (int k = klo; k <= khi; ++k) {
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dloc + (j - k + pad) * F4 + f);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + k * F4);
+                    acc = fmaf(d4[0], w4[0], acc); acc = fmaf(d4[1], w4[1], acc);
+                    acc = fmaf(d4[2], w4[2], acc); acc = fmaf(d4[3], w4[3], acc);
                 }
             }
         }
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
         if (cj < 2 * L && q == 0) dh[cj] = acc;
     }
     AB_PROF(7);
@@ -264,7 +450,8 @@ extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* m
     ST_CHECK_ARG(pq && pm && memory && w_cum_prev && w && loc_conv_w && loc_lin_w && v, "st_attn_step_bwd: null input");
     ST_CHECK_ARG(dpq && dhist && ds_t && loc_t && dloc_t && hist_t && dctx_t && dv_t, "st_attn_step_bwd: null output");
     ST_CHECK_ARG(B > 0 && L > 0 && A > 0 && E > 0 && F > 0 && K > 0 && (K & 1), "st_attn_step_bwd: bad dims (K must be odd)");
-    ST_CHECK_ARG(A <= AB_THREADS && AB_THREADS % A == 0, "st_attn_step_bwd: attn_dim=%d must divide %d", A, AB_THREADS);
+    ST_CHECK_ARG(A <= AB_THREADS / 2 && AB_THREADS % A == 0, "st_attn_step_bwd: attn_dim=%d must divide %d", A, AB_THREADS / 2);
+    ST_CHECK_ARG((E & 3) == 0 && st_aligned16(memory), "st_attn_step_bwd: E=%d must be a multiple of 4 (16-byte aligned rows)", E);
     ST_CHECK_ARG(F <= AB_FMAX, "st_attn_step_bwd: n_location_filters=%d > %d", F, AB_FMAX);
     ST_CHECK_ARG(n_dctx >= 0 && n_dctx <= 3 && n_dw >= 0 && n_dw <= 3, "st_attn_step_bwd: at most 3 addends");
     AbArgs a;

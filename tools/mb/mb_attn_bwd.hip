@@ -40,6 +40,12 @@ int main() {
     for (int blk : {0, 17}) {
         printf("block %d (cycles since wave 0 start):\n", blk);
         unsigned long long t0 = h[(blk * 8 + 0) * 16 + 0];
+        const char* sub[5] = {"  p0: loads issued", "  p0: hist done", "  p0: pads done", "  p0: scatter done", "  p0: per-l done"};
+        for (int n = 8; n < 13; ++n) {
+            printf("  %-22s", sub[n - 8]);
+            for (int wv = 0; wv < 8; ++wv) printf(" %8lld", (long long)(h[(blk * 8 + wv) * 16 + n] - t0));
+            printf("\n");
+        }
         for (int n = 0; n < 8; ++n) {
             printf("  %-22s", names[n]);
             for (int wv = 0; wv < 8; ++wv) printf(" %8lld", (long long)(h[(blk * 8 + wv) * 16 + n] - t0));

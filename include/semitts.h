@@ -151,6 +151,20 @@ int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_view* x, int
                                 int n_split, float* y2, int ldy2, int rep,
                                 int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                 int B, int N, void* stream);
+/* Heterogeneous launch: the same linear plus, on the compute units it leaves idle, a partial LSTM gate sum
+ * (st_lstm_gates_partial_packed_fwd) whose inputs are already known -- the "early" part of the NEXT LSTM cell of
+ * the decode step streams its weights inside the launch of a small latency-bound linear (no second stream). */
+typedef struct st_side_partial {
+    const float* packed_w; int w_kb_stride; int w_kb0;   /* k-block range of the packed LSTM matrix        */
+    const st_t16_view* x; int K;                         /* activations of that range (K = 16 * k-blocks)  */
+    float* pre_out; int ldpre; int H;                    /* (B, 4H) partial pre-activations out            */
+} st_side_partial;
+int st_skinny_linear_packed_side_fwd(const float* packed_w, const st_t16_view* x, int K,
+                                const float* bias, int act, const float* mask, int ldmask,
+                                float* y, int ldy, const st_t16_view* y_dst,
+                                int n_split, float* y2, int ldy2, int rep,
+                                int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
+                                int B, int N, const st_side_partial* side, void* stream);
 
 /* ------------------------------------------------------------------ location-sensitive attention
  * One decode step for the whole batch, one workgroup per utterance.

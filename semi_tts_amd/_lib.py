@@ -70,6 +70,11 @@ class StDecoderBwdIO(C.Structure):
                 [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p)])
 
 
+class StSidePartial(C.Structure):
+    _fields_ = [('packed_w', C.c_void_p), ('w_kb_stride', C.c_int), ('w_kb0', C.c_int), ('x', C.POINTER(StT16View)),
+                ('K', C.c_int), ('pre_out', C.c_void_p), ('ldpre', C.c_int), ('H', C.c_int)]
+
+
 P, I, F, Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/semitts.h
@@ -114,6 +119,8 @@ SIGNATURES = {
                                 P, I, P, P, P, C.POINTER(StT16View), I, I, P],
     'st_skinny_linear_packed_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                     I, I, P, I, C.POINTER(StT16View), I, I, P],
+    'st_skinny_linear_packed_side_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
+                                         I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StSidePartial), P],
     'st_attn_step_t16_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],

@@ -174,11 +174,15 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     int rc;
     // overlap: split both LSTM cells into an early partial-gate launch on the aux stream and a late
     // launch (late input + `pre` + cell update) on the caller's stream
-    Aux* ax = io->overlap && io->preq_buf && io->pred_buf ? aux_get() : nullptr;
-    const bool ov = ax != nullptr;
-    hipStream_t sb = ov ? ax->s : st;
-    if (ov) {
-        ST_HIP(hipMemsetAsync(io->preq_buf, 0, 4 * BQ * sizeof(float), st));   // step 0: ctx_{-1} = h_q_{-1} = 0
+    // overlap == 1: early parts on a second stream (kept for reference: slower); overlap == 2: early parts as
+    // SIDE JOBS of the small launches of the same stream (st_skinny_linear_packed_side_fwd)
+    const bool side = io->overlap == 2 && io->preq_buf && io->pred_buf;
+    Aux* ax = io->overlap == 1 && io->preq_buf && io->pred_buf ? aux_get() : nullptr;
+    const bool aux = ax != nullptr;
+    const bool ov = aux || side;            // both split the LSTM cells into an early partial and a late launch
+    hipStream_t sb = aux ? ax->s : st;
+    if (ov) ST_HIP(hipMemsetAsync(io->preq_buf, 0, 4 * BQ * sizeof(float), st));   // step 0: ctx_{-1} = h_q_{-1} = 0
+    if (aux) {
         ST_HIP(hipEventRecord(ax->fork, st));
         ST_HIP(hipStreamWaitEvent(sb, ax->fork, 0));
     }
@@ -195,7 +199,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view xq_v = {xq, sv.q_kbs, 0};
         st_t16_view hq_dst = {xq_next, sv.q_kbs, sv.q_h};
         st_t16_view ha_dst = {xd, sv.d_kbs, sv.d_ha};
-        if (ov && t > 0) ST_HIP(hipStreamWaitEvent(st, ax->f2, 0));            // early part of this step is ready
+        if (aux && t > 0) ST_HIP(hipStreamWaitEvent(st, ax->f2, 0));           // early part of this step is ready
         rc = st_lstm_cell_packed_fwd(io->packed + pl.q, ov ? sv.q_kbs : 0, 0, &xq_v, ov ? 16 * kbP : Kq,
                                      w->q_b_ih, w->q_b_hh, ov ? io->preq_buf : nullptr, 4 * Q,
                                      io->cq_tape + (size_t)t * BQ, Q, io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
@@ -203,7 +207,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                      io->gates_q_tape ? io->gates_q_tape + (size_t)t * 4 * BQ : nullptr,
                                      io->ada_std, io->ada_mean, &ha_dst, B, Q, stream);
         if (rc) return rc;
-        if (ov) {   // aux stream: early part of the decoder LSTM, x = [adapted h_q_t | h_d_{t-1}]
+        if (aux) {  // aux stream: early part of the decoder LSTM, x = [adapted h_q_t | h_d_{t-1}]
             ST_HIP(hipEventRecord(ax->e1, st));
             ST_HIP(hipStreamWaitEvent(sb, ax->e1, 0));
             st_t16_view xd_early = {xd, sv.d_kbs, kbE};
@@ -214,8 +218,12 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         }
 
         // 2. processed query                                             ref: :380
-        rc = st_skinny_linear_packed_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
-                                         io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A, stream);
+        //    side job: early part of the decoder LSTM, x = [adapted h_q_t | h_d_{t-1}] (both known now)
+        st_t16_view xd_early_v = {xd, sv.d_kbs, kbE};
+        st_side_partial sd = {io->packed + pl.d, sv.d_kbs, kbE, &xd_early_v, 16 * (sv.d_kbs - kbE), io->pred_buf, 4 * D, D};
+        rc = st_skinny_linear_packed_side_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
+                                              io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
+                                              side ? &sd : nullptr, stream);
         if (rc) return rc;
 
         // 3. attention + state update                                    ref: :256-264, :371-407
@@ -229,7 +237,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                   B, L, A, E, d->F, d->K, stream);
         if (rc) return rc;
 
-        if (ov && t + 1 < steps) {   // aux stream: early part of the NEXT query LSTM, x = [ctx_t | h_q_t]
+        if (aux && t + 1 < steps) {  // aux stream: early part of the NEXT query LSTM, x = [ctx_t | h_q_t]
             ST_HIP(hipEventRecord(ax->e2, st));
             ST_HIP(hipStreamWaitEvent(sb, ax->e2, 0));
             st_t16_view xq_early = {xq_next, sv.q_kbs, kbP};
@@ -243,7 +251,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view xd_v = {xd, sv.d_kbs, 0};
         st_t16_view hd_dst0 = {xd_next, sv.d_kbs, sv.d_h};
         st_t16_view hd_dst1 = {xo, sv.o_kbs, 0};
-        if (ov) ST_HIP(hipStreamWaitEvent(st, ax->f1, 0));
+        if (aux) ST_HIP(hipStreamWaitEvent(st, ax->f1, 0));
         rc = st_lstm_cell_packed_fwd(io->packed + pl.d, ov ? sv.d_kbs : 0, 0, &xd_v, ov ? 16 * kbE : Kd,
                                      w->d_b_ih, w->d_b_hh, ov ? io->pred_buf : nullptr, 4 * D,
                                      io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
@@ -257,12 +265,16 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view mel_dst = {io->mel_t16, kb16(in_dim), 0};
         st_t16_view pre1_dst = {io->pre1_t16, kb16(P), 0};
         const bool fuse = d->fuse_pre0 != 0;
-        rc = st_skinny_linear_packed_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
-                                         io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
-                                         io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
-                                         fuse ? in_dim + 1 : 0, ST_ACT_RELU,
-                                         io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
-                                         fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0), stream);
+        //    side job: early part of the NEXT query LSTM, x = [ctx_t | h_q_t] (both known now)
+        st_t16_view xq_early_v = {xq_next, sv.q_kbs, kbP};
+        st_side_partial sq = {io->packed + pl.q, sv.q_kbs, kbP, &xq_early_v, 16 * (sv.q_kbs - kbP), io->preq_buf, 4 * Q, Q};
+        rc = st_skinny_linear_packed_side_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
+                                              io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
+                                              io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
+                                              fuse ? in_dim + 1 : 0, ST_ACT_RELU,
+                                              io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
+                                              fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0),
+                                              side && t + 1 < steps ? &sq : nullptr, stream);
         if (rc) return rc;
 
         // 6. next decoder input -> xq_{t+1}[dec_in part]                 ref: :190-206

@@ -146,11 +146,9 @@ __device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[N
 
 // MODE 0: LSTM cell, MODE 1: linear, MODE 2: partial LSTM gate sums (no bias, no cell update)
 template <int MODE, int NB, int KW, int TRIP>
-__global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
-    __shared__ f32x4 red[KW * NB * 64];
+__device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const int by, f32x4* red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
-    const int bt0 = blockIdx.y * NB;
+    const int bt0 = by * NB;
     const int BT = (a.B + 15) >> 4;
 
     f32x4 acc[NB];
@@ -261,26 +259,48 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
     }
 }
 
+template <int MODE, int NB, int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
+    __shared__ f32x4 red[KW * NB * 64];
+    pk_body<MODE, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red);
+}
+
+// Heterogeneous launch: the first `tiles_a` workgroup columns run the main job `a` (a small, latency-bound linear
+// on the critical path of the decode step), the remaining ones a partial LSTM gate sum `s` whose inputs are
+// already known (MODE 2).  The side job streams its weights on the compute units the main job leaves idle,
+// inside the same launch: no second stream, no cross-stream event (measured to cost more than it saves).
+template <int MODE, int NB, int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_pair_kernel(const PkArgs a, const PkArgs s, const int tiles_a) {
+    __shared__ f32x4 red[KW * NB * 64];
+    if ((int)blockIdx.x < tiles_a) pk_body<MODE, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red);
+    else pk_body<2, NB, KW, TRIP>(s, (int)blockIdx.x - tiles_a, blockIdx.y, red);
+}
+
 template <int MODE, int NB>
-int pk_launch(const PkArgs& a, int tiles, hipStream_t st) {
+int pk_launch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = nullptr, int side_tiles = 0) {
     // 8 waves x 2 k-blocks in flight, double buffered.  Measured alternatives on MI355X (us per launch in
     // the decode graph, pq / proj / prenet): 16 waves x 6 single-buffered 7.2 / 8.8 / 7.3; 8 waves x 6
     // single-buffered 8.6 / 10.6 / 5.7; this configuration 6.1 / 8.8 / 4.8.
     constexpr int KW = 8, TRIP = 2;
     const int BT = (a.B + 15) >> 4;
-    dim3 grid(tiles, (BT + NB - 1) / NB);
-    hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a);
+    if (side) {
+        dim3 grid(tiles + side_tiles, (BT + NB - 1) / NB);
+        hipLaunchKernelGGL((pk_pair_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a, *side, tiles);
+    } else {
+        dim3 grid(tiles, (BT + NB - 1) / NB);
+        hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a);
+    }
     ST_LAUNCH_CHECK();
     return 0;
 }
 
 template <int MODE>
-int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st) {
+int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = nullptr, int side_tiles = 0) {
     const int BT = (a.B + 15) >> 4;
-    if (BT == 1) return pk_launch<MODE, 1>(a, tiles, st);
-    if (BT == 2) return pk_launch<MODE, 2>(a, tiles, st);
-    if (BT == 3) return pk_launch<MODE, 3>(a, tiles, st);
-    return pk_launch<MODE, 4>(a, tiles, st);
+    if (BT == 1) return pk_launch<MODE, 1>(a, tiles, st, side, side_tiles);
+    if (BT == 2) return pk_launch<MODE, 2>(a, tiles, st, side, side_tiles);
+    if (BT == 3) return pk_launch<MODE, 3>(a, tiles, st, side, side_tiles);
+    return pk_launch<MODE, 4>(a, tiles, st, side, side_tiles);
 }
 
 PkOut pk_out(const st_t16_view* v) {
@@ -394,6 +414,17 @@ extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_v
                                            int n_split2, int act2, const float* mask2, int ldmask2,
                                            const st_t16_view* y3_dst,
                                            int B, int N, void* stream) {
+    return st_skinny_linear_packed_side_fwd(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
+                                            n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, stream);
+}
+
+extern "C" int st_skinny_linear_packed_side_fwd(const float* packed_w, const st_t16_view* x, int K,
+                                                const float* bias, int act, const float* mask, int ldmask,
+                                                float* y, int ldy, const st_t16_view* y_dst,
+                                                int n_split, float* y2, int ldy2, int rep,
+                                                int n_split2, int act2, const float* mask2, int ldmask2,
+                                                const st_t16_view* y3_dst,
+                                                int B, int N, const st_side_partial* side, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(n_split2 <= 0 || (y3_dst && y3_dst->base && n_split2 >= n_split), "st_skinny_linear_packed_fwd: third range");
     ST_CHECK_ARG(B > 0 && N > 0 && (y || (y_dst && y_dst->base)), "st_skinny_linear_packed_fwd: bad arguments");
@@ -407,6 +438,17 @@ extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_v
     a.y = y; a.ldy = ldy; a.y_dst = pk_out(y_dst);
     a.n_split = n_split; a.y2 = y2; a.ldy2 = ldy2; a.rep = rep;
     a.n_split2 = n_split2; a.act2 = act2; a.mask2 = mask2; a.ldmask2 = ldmask2; a.y3_dst = pk_out(y3_dst);
+    if (side && side->packed_w) {
+        ST_CHECK_ARG(side->H > 0 && side->H % 4 == 0 && side->pre_out && side->ldpre >= 4 * side->H && side->x,
+                     "st_skinny_linear_packed_side_fwd: bad side job");
+        PkArgs sj;
+        memset(&sj, 0, sizeof(sj));
+        rc = pk_fill(sj, side->packed_w, side->w_kb_stride, side->w_kb0, side->x, side->K, "st_skinny_linear_packed_side_fwd(side)");
+        if (rc) return rc;
+        sj.B = B; sj.N = 4 * side->H; sj.H = side->H;
+        sj.gates_out = side->pre_out; sj.ldpre = side->ldpre;
+        return pk_dispatch<1>(a, (N + 15) / 16, (hipStream_t)stream, &sj, side->H / 4);
+    }
     return pk_dispatch<1>(a, (N + 15) / 16, (hipStream_t)stream);
 }
 

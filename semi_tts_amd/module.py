@@ -281,7 +281,7 @@ class Decoder(nn.Module):
         import os
         # early parts of the LSTM cells on a second HIP stream: measured SLOWER on MI355X/ROCm 7.2 (cross-stream
         # event dependencies cost more than the ~15 us of overlap they buy: 86.7 vs 68.1 us/step), so off by default
-        self.overlap = os.environ.get('ST_OVERLAP', '0') != '0'
+        self.overlap = int(os.environ.get('ST_OVERLAP', '0'))
         self.fuse_prenet = True    # inference: emit prenet layer 1 from the proj/gate launch (fp32 re-association)
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -432,7 +432,7 @@ class Decoder(nn.Module):
         io.cq_tape, io.cd_tape, io.wcum_tape = (ops._p(tapes[k]) for k in ('cq', 'cd', 'wcum'))
         io.pq_buf, io.pre1_t16, io.mel_t16 = (ops._p(tapes[k]) for k in ('pq', 'pre1', 'melt'))
         io.zero_row = ops._p(tapes['zero'])
-        io.preq_buf, io.pred_buf, io.overlap = ops._p(tapes['preq']), ops._p(tapes['pred']), 1 if self.overlap else 0
+        io.preq_buf, io.pred_buf, io.overlap = ops._p(tapes['preq']), ops._p(tapes['pred']), int(self.overlap)
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')

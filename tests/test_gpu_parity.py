@@ -478,6 +478,14 @@ def test_headline_shape_c2_against_oracle(dev):
     txt, spk = torch.from_numpy(txt), torch.from_numpy(spk)
     with torch.no_grad():
         mel, lin, align, stop = m(txt.to(dev), None, 258, spk.to(dev), tf_rate=0.0)
+        # the split-LSTM variants of the loop (early parts on a second stream / as side jobs of the small launches)
+        # must give the same values up to the re-association of the gate sums
+        for mode in (1, 2):
+            m.decoder.overlap = mode
+            mel_o, _, align_o, _ = m(txt.to(dev), None, 258, spk.to(dev), tf_rate=0.0)
+            report('tts_c2_overlap', mode=mode, mel=maxdiff(mel_o, mel), align=maxdiff(align_o, align))
+            assert maxdiff(mel_o, mel) < 2e-5 and maxdiff(align_o, align) < 1e-5
+        m.decoder.overlap = 0
     torch.set_num_threads(8)
     with torch.no_grad():
         mel_r, lin_r, align_r, stop_r = O.tacotron2_forward(_oracle_weights(m), txt, 258, spk, full_hp(0.0))

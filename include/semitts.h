@@ -282,11 +282,12 @@ int st_lstm_seq_fwd(const float* xproj, const float* w_hh, const float* b_hh, fl
 /* Pointwise half of one LSTM cell backward step (shared by the encoder BiLSTM and the decoder's two cells):
  * dh = (dh0 + dh1 + dh2 * scale2) * mask;  from dh and the carried dc (B,H, updated in place to dL/dc_{t-1})
  * to dgates (B,4H) w.r.t. the pre-activation gates in torch order (i,f,g,o).  dh1, dh2, scale2, mask, c_prev
- * may be NULL.  ref: backward of nn.LSTMCell src/module.py:228,:277 */
+ * may be NULL; dgates_t16 (optional): a second copy of dgates in the T16 tile layout (K = 4H), the operand of
+ * st_skinny_linear_packed_fwd over the packed W^T.  ref: backward of nn.LSTMCell src/module.py:228,:277 */
 int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float* dh1, int ld1, const float* dh2, int ld2,
                                const float* scale2, const float* mask, const float* gates, const float* c, int ldc,
-                               const float* c_prev, int ldcp, float* dc, float* dgates, int ldg, int B, int H,
-                               void* stream);
+                               const float* c_prev, int ldcp, float* dc, float* dgates, int ldg,
+                               const st_t16_view* dgates_t16, int B, int H, void* stream);
 /* Backward through time of st_lstm_seq_fwd: dout(b, t, dcol : dcol+H) -> dxproj (B,T,4H) (= gradient of the
  * input projection incl. both biases).  w_hh_t = W_hh^T (H, 4H).  ws: 2*B*H floats.  The caller finishes with
  * dW_hh = st_gemm_wgrad(dxproj, out shifted by one step) and db = st_colsum(dxproj). */
@@ -320,6 +321,17 @@ int st_gather_rows(const float* table, const int64_t* idx, float* out, int n, in
  * ref: L2Embedding.forward src/embed.py:105-147, neg_batch_l2 :208-213 */
 int st_vq_l2_fwd(const float* x, const float* table, const float* temp, float* p_code,
                  int64_t* idx, float* out, int n, int D, int V, void* stream);
+/* Run-length merge of VQ codes with blank filtering (ref: VQVAE.mean_forward src/vqvae.py:218-257): per utterance,
+ * consecutive frames with the same argmax code (runs capped at max_frames_per_phn+1 frames) are replaced by the
+ * mean of their latents, runs of code 0 are dropped.  out (B, T, D) must be ZERO on entry (rows >= lens(b) stay
+ * zero = the reference's pad_sequence); lens (B) int32 = kept segments per utterance (0 = all-blank utterance:
+ * the reference returns None for the batch); frame_seg (B,T) int32 / frame_w (B,T) = segment of every frame
+ * (-1 = dropped) and 1/len, the saved tensors of st_vq_mean_bwd. */
+int st_vq_mean_fwd(const float* p_code, const float* latent, float* out, int* lens, int* frame_seg, float* frame_w,
+                   int B, int T, int D, int V, int max_frames_per_phn, void* stream);
+/* dlatent(b,t,:) = dout(b, seg(t), :) / len(seg(t)); dout is (B, n_seg_rows, D) */
+int st_vq_mean_bwd(const float* dout, int n_seg_rows, const int* frame_seg, const float* frame_w, float* dlatent,
+                   int B, int T, int D, void* stream);
 /* softmax + argmax over rows of logits (n, V) -> p (n, V), idx (n)
  * ref: SeperateEmbedding.forward src/embed.py:190-193 */
 int st_softmax_argmax(const float* logits, float* p, int64_t* idx, int n, int V, void* stream);
@@ -432,6 +444,8 @@ typedef struct st_decoder_bwd_weights {   /* transposed copies prepared by the c
     const float* q_w_cat_t;        /* [W_ih_q | W_hh_q]^T   (P+E+Q, 4Q) */
     const float* d_w_cat_t;        /* [W_ih_d | W_hh_d]^T   (E+Q+D, 4D) */
     const float* attn_query_w_t;   /* W_q^T                 (Q, A)      */
+    const float* q_w_cat_t_p16;    /* optional: q_w_cat_t packed by st_pack_weight (N = P+E+Q, K = 4Q); NULL = natural kernels */
+    const float* d_w_cat_t_p16;    /* optional: d_w_cat_t packed (N = E+Q+D, K = 4D) */
     const float* attn_v; const float* attn_loc_conv_w; const float* attn_loc_lin_w;
 } st_decoder_bwd_weights;
 
@@ -457,6 +471,7 @@ typedef struct st_decoder_bwd_io {
     float* dhist[2];               /* (B,2,L) x 2 scratch, zero on entry */
     float* dcum;                   /* (B,L) scratch, zero on entry */
     float* dhq_attn;               /* (B,Q) scratch */
+    float* dgq_t16; float* dgd_t16;   /* st_t16_floats(B, 4Q / 4D) scratch, ZERO on entry; needed with the packed weights */
 } st_decoder_bwd_io;
 int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
 /* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp, r*n_mels+1); NULL = zeros */

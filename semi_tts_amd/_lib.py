@@ -57,8 +57,8 @@ class StDecoderIO(C.Structure):
 
 
 class StDecoderBwdWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('q_w_cat_t', 'd_w_cat_t', 'attn_query_w_t', 'attn_v', 'attn_loc_conv_w',
-                                          'attn_loc_lin_w')]
+    _fields_ = [(n, C.c_void_p) for n in ('q_w_cat_t', 'd_w_cat_t', 'attn_query_w_t', 'q_w_cat_t_p16', 'd_w_cat_t_p16',
+                                          'attn_v', 'attn_loc_conv_w', 'attn_loc_lin_w')]
 
 
 class StDecoderBwdIO(C.Structure):
@@ -67,7 +67,8 @@ class StDecoderBwdIO(C.Structure):
                 [('steps', C.c_int), ('Bp', C.c_int)] +
                 [(n, C.c_void_p) for n in ('dxo', 'dalign', 'dgq', 'dgd', 'dxq', 'dxd', 'dpq', 'ds_tape', 'loc_tape', 'dloc_tape',
                                            'hist_tape', 'dctx_tape', 'dv_tape', 'dcq', 'dcd')] +
-                [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p)])
+                [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p), ('dgq_t16', C.c_void_p),
+                 ('dgd_t16', C.c_void_p)])
 
 
 class StSidePartial(C.Structure):
@@ -101,13 +102,15 @@ SIGNATURES = {
     'st_colreduce_workspace_floats': [I, I],
     'st_bn_apply': [P, I, I, I, I, P, P, P, P, F, I, P],
     'st_lstm_seq_fwd': [P, P, P, P, I, I, P, P, P, I, I, I, I, P],
-    'st_lstm_cell_bwd_pointwise': [P, I, P, I, P, I, P, P, P, P, I, P, I, P, P, I, I, I, P],
+    'st_lstm_cell_bwd_pointwise': [P, I, P, I, P, I, P, P, P, P, I, P, I, P, P, I, C.POINTER(StT16View), I, I, P],
     'st_lstm_seq_bwd': [P, I, I, P, P, P, P, P, I, I, I, I, P],
     'st_gru_seq_fwd': [P, P, P, P, P, P, P, I, P, I, I, I, I, P],
     'st_gru_seq_bwd': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, P],
     'st_vq_build_table': [P, I, P, I, P, P, I, P, I, P],
     'st_gather_rows': [P, P, P, I, I, I, P],
     'st_vq_l2_fwd': [P, P, P, P, P, P, I, I, I, P],
+    'st_vq_mean_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],
+    'st_vq_mean_bwd': [P, I, P, P, P, I, I, I, P],
     'st_softmax_argmax': [P, P, P, I, I, P],
     'st_packed_weight_floats': [C.POINTER(I), I, I, I],
     'st_t16_floats': [I, I],

@@ -292,6 +292,11 @@ class _DecoderFn(Function):
         bw = StDecoderBwdWeights()
         bw.q_w_cat_t, bw.d_w_cat_t, bw.attn_query_w_t = ops._p(wt['q']), ops._p(wt['d']), ops._p(wt['pq'])
         bw.attn_v, bw.attn_loc_conv_w, bw.attn_loc_lin_w = ops._p(v), ops._p(wc), ops._p(wl)
+        # the two big per-step products dgates . W stream W^T in MFMA lane order (packed once per backward)
+        wt['q_p16'] = ops.pack_weight([wt['q']], [4 * Q], XQw)
+        wt['d_p16'] = ops.pack_weight([wt['d']], [4 * D], XDw)
+        bw.q_w_cat_t_p16, bw.d_w_cat_t_p16 = ops._p(wt['q_p16']), ops._p(wt['d_p16'])
+        dgq_t16, dgd_t16 = z(ops.t16_floats(B, 4 * Q)), z(ops.t16_floats(B, 4 * D))
         dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A, F=F, K=K, fuse_pre0=0)
         io = StDecoderBwdIO()
         io.memory, io.pm, io.ada_std, io.align = ops._p(memory), ops._p(pm), ops._p(ada_std), ops._p(align)
@@ -306,6 +311,7 @@ class _DecoderFn(Function):
         io.hist_tape, io.dctx_tape, io.dv_tape = ops._p(hist_tape), ops._p(dctx_tape), ops._p(dv_tape)
         io.dcq, io.dcd, io.dcum, io.dhq_attn = ops._p(dcq), ops._p(dcd), ops._p(dcum), ops._p(dhq_attn)
         io.dhist[0], io.dhist[1] = ops._p(dh0), ops._p(dh1)
+        io.dgq_t16, io.dgd_t16 = ops._p(dgq_t16), ops._p(dgd_t16)
         _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
 
         # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)
@@ -399,3 +405,48 @@ def freq_loss(pred, label, sample_rate, n_mels, loss='mse', differential_loss=Tr
     if dim == n_mels and differential_loss:
         w_diff = 0.5
     return _FreqLossFn.apply(pred, label, n_low, w_all, w_low, w_diff, loss == 'l1')
+
+
+# --------------------------------------------------------------------------------------------- VQ run-length merge
+class _MeanForwardFn(Function):
+    """VQVAE.mean_forward (src/vqvae.py:218-257) on device; returns the worst-case padded (B, T, D) tensor + lens"""
+
+    @staticmethod
+    def forward(ctx, p_code, latent, max_frames):
+        from . import _lib
+        p_code, latent = p_code.contiguous(), latent.contiguous()
+        B, T, D = latent.shape
+        V = p_code.shape[-1]
+        dev = latent.device
+        out = torch.zeros(B, T, D, device=dev, dtype=torch.float32)
+        lens = torch.empty(B, device=dev, dtype=torch.int32)
+        seg = torch.empty(B, T, device=dev, dtype=torch.int32)
+        w = torch.empty(B, T, device=dev, dtype=torch.float32)
+        _lib.check(_lib.load().st_vq_mean_fwd(ops._p(p_code), ops._p(latent), ops._p(out), ops._p(lens, torch.int32),
+                                              ops._p(seg, torch.int32), ops._p(w), B, T, D, V, int(max_frames),
+                                              ops.stream_handle()), 'st_vq_mean_fwd')
+        ctx.save_for_backward(seg, w)
+        ctx.mark_non_differentiable(lens)
+        return out, lens
+
+    @staticmethod
+    def backward(ctx, dout, _dlens):
+        from . import _lib
+        seg, w = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, T = seg.shape
+        D = dout.shape[-1]
+        dlat = torch.empty(B, T, D, device=dout.device, dtype=torch.float32)
+        _lib.check(_lib.load().st_vq_mean_bwd(ops._p(dout), dout.shape[1], ops._p(seg, torch.int32), ops._p(w), ops._p(dlat),
+                                              B, T, D, ops.stream_handle()), 'st_vq_mean_bwd')
+        return None, dlat, None
+
+
+def mean_forward(p_code, latent, max_frames_per_phn):
+    """-> (batch_latent (B, Nmax, D), lengths (B,) int64) or None when an utterance is all blank; ONE device->host copy
+    (the lengths, which fix the output shape) instead of the reference's per-utterance `.cpu().tolist()` + host loop"""
+    out, lens = _MeanForwardFn.apply(p_code, latent, max_frames_per_phn)
+    lens_h = lens.cpu()
+    if int(lens_h.min()) == 0:
+        return None
+    return out[:, :int(lens_h.max())], lens.long()

@@ -41,6 +41,8 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                  io->dhq_attn,
                  "st_decoder_backward: null output/scratch");
     const int XQ = P + E + Q, XD = E + Q + D, XO = D + E;
+    const bool packed = w->q_w_cat_t_p16 && w->d_w_cat_t_p16 && io->dgq_t16 && io->dgd_t16;
+    st_t16_view dgq_v = {io->dgq_t16, (4 * Q + 15) >> 4, 0}, dgd_v = {io->dgd_t16, (4 * D + 15) >> 4, 0};
     const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
     const int ldal = steps * L;
     int rc;
@@ -60,12 +62,17 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
         rc = st_lstm_cell_bwd_pointwise(dxo, XO, dxd_next + E + Q, XD, nullptr, 0, nullptr,
                                         io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                         io->gates_d_tape + (size_t)t * 4 * BD, io->cd_tape + (size_t)(t + 1) * BD, D,
-                                        io->cd_tape + (size_t)t * BD, D, io->dcd, dgd, 4 * D, B, D, stream);
+                                        io->cd_tape + (size_t)t * BD, D, io->dcd, dgd, 4 * D, packed ? &dgd_v : nullptr, B, D, stream);
         if (rc) return rc;
         // b. gradient w.r.t. [ctx_t | adapted h_q_t | h_d_{t-1}]
         st_seg seg;
-        seg.x = dgd; seg.ldx = 4 * D; seg.w = w->d_w_cat_t; seg.ldw = 4 * D; seg.k = 4 * D;
-        rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, dxd, XD, 0, nullptr, 0, 0, B, XD, stream);
+        if (packed) {   // W^T streamed in MFMA lane order (P16), dgates in T16
+            rc = st_skinny_linear_packed_fwd(w->d_w_cat_t_p16, &dgd_v, 4 * D, nullptr, ST_ACT_NONE, nullptr, 0, dxd, XD, nullptr,
+                                             0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XD, stream);
+        } else {
+            seg.x = dgd; seg.ldx = 4 * D; seg.w = w->d_w_cat_t; seg.ldw = 4 * D; seg.k = 4 * D;
+            rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, dxd, XD, 0, nullptr, 0, 0, B, XD, stream);
+        }
         if (rc) return rc;
         // c. attention
         const float* dctx[3] = {dxo + D, dxd, dxq_next + P};
@@ -90,12 +97,17 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
         rc = st_lstm_cell_bwd_pointwise(io->dhq_attn, Q, dxq_next + P + E, XQ, dxd + E, XD, io->ada_std,
                                         io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
                                         io->gates_q_tape + (size_t)t * 4 * BQ, io->cq_tape + (size_t)(t + 1) * BQ, Q,
-                                        io->cq_tape + (size_t)t * BQ, Q, io->dcq, dgq, 4 * Q, B, Q, stream);
+                                        io->cq_tape + (size_t)t * BQ, Q, io->dcq, dgq, 4 * Q, packed ? &dgq_v : nullptr, B, Q, stream);
         if (rc) return rc;
         // f. gradient w.r.t. [dec_in_t | ctx_{t-1} | h_q_{t-1}]  (step 0: go frame and zero initial state, nothing to do)
         if (t > 0) {
-            seg.x = dgq; seg.ldx = 4 * Q; seg.w = w->q_w_cat_t; seg.ldw = 4 * Q; seg.k = 4 * Q;
-            rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, dxq, XQ, 0, nullptr, 0, 0, B, XQ, stream);
+            if (packed) {
+                rc = st_skinny_linear_packed_fwd(w->q_w_cat_t_p16, &dgq_v, 4 * Q, nullptr, ST_ACT_NONE, nullptr, 0, dxq, XQ, nullptr,
+                                                 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XQ, stream);
+            } else {
+                seg.x = dgq; seg.ldx = 4 * Q; seg.w = w->q_w_cat_t; seg.ldw = 4 * Q; seg.k = 4 * Q;
+                rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, dxq, XQ, 0, nullptr, 0, 0, B, XQ, stream);
+            }
             if (rc) return rc;
         }
     }

@@ -179,16 +179,36 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, 
                                                              float momentum) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
-    for (int ch = 0; ch < chunks; ++ch) {
-        const float nb = (float)(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk);
-        if (nb <= 0.0f) break;
-        const float mb = part[((size_t)ch * 2 + 0) * N + n], qb = part[((size_t)ch * 2 + 1) * N + n];
-        const float tot = cnt + nb, delta = mb - mean;
-        mean += delta * (nb / tot);
-        m2 += qb + delta * delta * (cnt * nb / tot);
-        cnt = tot;
+    // two sweeps over the chunk records with independent loads (no serial dependence between chunks):
+    //   mean = sum_c n_c mean_c / M;   M2 = sum_c [M2_c + n_c (mean_c - mean)^2]      (exact decomposition)
+    const float* pm = part + n;
+    const size_t cs = (size_t)2 * N;
+    float a0 = 0.f, a1 = 0.f;
+    int ch = 0;
+    for (; ch + 2 <= chunks; ch += 2) {
+        const float n0 = (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0);
+        const float n1 = (float)max(min(M, (ch + 2) * rows_per_chunk) - (ch + 1) * rows_per_chunk, 0);
+        a0 = fmaf(n0, pm[(size_t)ch * cs], a0); a1 = fmaf(n1, pm[(size_t)(ch + 1) * cs], a1);
     }
+    for (; ch < chunks; ++ch) {
+        const float n0 = (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0);
+        a0 = fmaf(n0, pm[(size_t)ch * cs], a0);
+    }
+    const float mean = (a0 + a1) / (float)M;
+    float q0 = 0.f, q1 = 0.f;
+    for (ch = 0; ch + 2 <= chunks; ch += 2) {
+        const float n0 = (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0);
+        const float n1 = (float)max(min(M, (ch + 2) * rows_per_chunk) - (ch + 1) * rows_per_chunk, 0);
+        const float d0 = pm[(size_t)ch * cs] - mean, d1 = pm[(size_t)(ch + 1) * cs] - mean;
+        const float m0 = pm[(size_t)ch * cs + N], m1 = pm[(size_t)(ch + 1) * cs + N];
+        q0 += m0 + n0 * d0 * d0; q1 += m1 + n1 * d1 * d1;
+    }
+    for (; ch < chunks; ++ch) {
+        const float nb = (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0);
+        const float d = pm[(size_t)ch * cs] - mean;
+        q0 += pm[(size_t)ch * cs + N] + nb * d * d;
+    }
+    const float m2 = q0 + q1;
     const float var_b = m2 / (float)M;
     mean_out[n] = mean;
     var_out[n] = var_b;

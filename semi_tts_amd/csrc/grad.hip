@@ -194,16 +194,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, int
     }
 }
 
-// out[q][n] (+)= sum_chunks part[chunk][q][n], q < Q   (fixed order)
+// out[q][n] (+)= sum_chunks part[chunk][q][n], q < Q.  Fixed order (four interleaved running sums, then a fixed
+// combination), loads of four chunks in flight per thread.
 __global__ __launch_bounds__(256) void chunk_final_kernel(const float* part, int chunks, int Q, int N, float* out0, float* out1,
                                                           int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Q * N) return;
     const int q = i / N, n = i - q * N;
     float* out = q == 0 ? out0 : out1;
-    float s = accumulate ? out[n] : 0.0f;
-    for (int ch = 0; ch < chunks; ++ch) s += part[((size_t)ch * Q + q) * N + n];
-    out[n] = s;
+    const float* p = part + (size_t)q * N + n;
+    const size_t cs = (size_t)Q * N;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int ch = 0;
+    for (; ch + 4 <= chunks; ch += 4) {
+        s0 += p[(size_t)ch * cs]; s1 += p[(size_t)(ch + 1) * cs]; s2 += p[(size_t)(ch + 2) * cs]; s3 += p[(size_t)(ch + 3) * cs];
+    }
+    for (; ch < chunks; ++ch) s0 += p[(size_t)ch * cs];
+    const float s = (s0 + s1) + (s2 + s3);
+    out[n] = accumulate ? out[n] + s : s;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff,

@@ -192,8 +192,13 @@ struct LstmPwArgs {
     const float* c_prev; int ldcp;     // c_{t-1}, NULL = zeros
     float* dc;                         // (B, H) in: dL/dc_t carried from step t+1, out: dL/dc_{t-1}
     float* dgates; int ldg;            // (B, 4H) torch gate order
+    float* dg_t16; int t16_kbs; int t16_kb0;   // optional second copy in the T16 tile layout (operand of the packed GEMM)
     int B, H;
 };
+
+__device__ __forceinline__ size_t lstm_t16_off(int b, int k, int KB) {
+    return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
+}
 
 __global__ __launch_bounds__(256) void lstm_bwd_pw_kernel(const LstmPwArgs a) {
     const int total = a.B * a.H, H = a.H;
@@ -209,10 +214,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_pw_kernel(const LstmPwArgs a) {
         const float cp = a.c_prev ? a.c_prev[(size_t)b * a.ldcp + u] : 0.0f;
         const float dc = a.dc[i] + dh * go * (1.0f - tc * tc);
         float* dg = a.dgates + (size_t)b * a.ldg + u;
-        dg[0] = dc * gg * gi * (1.0f - gi);
-        dg[H] = dc * cp * gf * (1.0f - gf);
-        dg[2 * H] = dc * gi * (1.0f - gg * gg);
-        dg[3 * H] = dh * tc * go * (1.0f - go);
+        const float d0 = dc * gg * gi * (1.0f - gi), d1 = dc * cp * gf * (1.0f - gf);
+        const float d2 = dc * gi * (1.0f - gg * gg), d3 = dh * tc * go * (1.0f - go);
+        dg[0] = d0; dg[H] = d1; dg[2 * H] = d2; dg[3 * H] = d3;
+        if (a.dg_t16) {
+            const int k0 = a.t16_kb0 * 16 + u;
+            a.dg_t16[lstm_t16_off(b, k0, a.t16_kbs)] = d0;
+            a.dg_t16[lstm_t16_off(b, k0 + H, a.t16_kbs)] = d1;
+            a.dg_t16[lstm_t16_off(b, k0 + 2 * H, a.t16_kbs)] = d2;
+            a.dg_t16[lstm_t16_off(b, k0 + 3 * H, a.t16_kbs)] = d3;
+        }
         a.dc[i] = dc * gf;
     }
 }
@@ -270,13 +281,15 @@ extern "C" int st_lstm_seq_fwd(const float* xproj, const float* w_hh, const floa
 
 extern "C" int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float* dh1, int ld1, const float* dh2, int ld2,
                                           const float* scale2, const float* mask, const float* gates, const float* c, int ldc,
-                                          const float* c_prev, int ldcp, float* dc, float* dgates, int ldg, int B, int H,
-                                          void* stream) {
+                                          const float* c_prev, int ldcp, float* dc, float* dgates, int ldg,
+                                          const st_t16_view* dgates_t16, int B, int H, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dh0 && gates && c && dc && dgates && B > 0 && H > 0, "st_lstm_cell_bwd_pointwise: bad arguments");
     LstmPwArgs a;
     a.dh0 = dh0; a.ld0 = ld0; a.dh1 = dh1; a.ld1 = ld1; a.dh2 = dh2; a.ld2 = ld2; a.scale2 = scale2; a.mask = mask;
     a.gates = gates; a.c = c; a.ldc = ldc; a.c_prev = c_prev; a.ldcp = ldcp; a.dc = dc; a.dgates = dgates; a.ldg = ldg;
+    a.dg_t16 = dgates_t16 ? dgates_t16->base : nullptr;
+    a.t16_kbs = dgates_t16 ? dgates_t16->kb_stride : 0; a.t16_kb0 = dgates_t16 ? dgates_t16->kb0 : 0;
     a.B = B; a.H = H;
     const int blocks = (B * H + 255) / 256;
     hipLaunchKernelGGL(lstm_bwd_pw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -299,7 +312,7 @@ extern "C" int st_lstm_seq_bwd(const float* dout, int ldd, int dcol, const float
         float* dg = dxproj + (size_t)t * 4 * H;          // row stride T*4H
         int rc = st_lstm_cell_bwd_pointwise(dout + (size_t)t * ldd + dcol, T * ldd, dhrec, H, nullptr, 0, nullptr, nullptr,
                                             gates_tape + (size_t)t * 4 * bh, c_tape + (size_t)t * bh, H,
-                                            s == 0 ? nullptr : c_tape + (size_t)tp * bh, H, dc, dg, T * 4 * H, B, H, stream);
+                                            s == 0 ? nullptr : c_tape + (size_t)tp * bh, H, dc, dg, T * 4 * H, nullptr, B, H, stream);
         if (rc) return rc;
         if (s == 0) break;
         st_seg seg;

@@ -135,6 +135,69 @@ __global__ __launch_bounds__(VQ_WAVES * 64) void softmax_argmax_kernel(const flo
     }
 }
 
+// ---- run-length merge of the VQ codes (ref: VQVAE.mean_forward, src/vqvae.py:218-257) --------------------------
+// One workgroup per utterance.  Phase 1: argmax of p_code per frame (first maximum wins).  Phase 2: thread 0 walks
+// the frame indices exactly like the reference's Python loop (a new segment starts when the code changes or the
+// current one already holds max_frames+1 frames; blank (0) segments are dropped) -- T integer steps in LDS instead
+// of a D2H copy plus a host loop per utterance.  Phase 3: all threads average the frames of the kept segments.
+__global__ __launch_bounds__(256) void vq_mean_fwd_kernel(const float* p_code, const float* latent, float* out, int* lens,
+                                                          int* frame_seg, float* frame_w, int B, int T, int D, int V,
+                                                          int max_frames) {
+    extern __shared__ __attribute__((aligned(16))) int ilds[];
+    int* idx = ilds;              // [T]
+    int* seg_start = ilds + T;    // [T] first frame of kept segment n
+    int* seg_len = ilds + 2 * T;  // [T]
+    __shared__ int nseg_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < T; t += blockDim.x) {
+        const float* p = p_code + ((size_t)b * T + t) * V;
+        float best = p[0];
+        int bi = 0;
+        for (int v = 1; v < V; ++v) { const float x = p[v]; if (x > best) { best = x; bi = v; } }
+        idx[t] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0, last_idx = idx[0], last_pos = 0;
+        for (int t = 0; t < T; ++t) {
+            const int i = idx[t];
+            if (last_idx != i || (t - last_pos) > max_frames) {                     // :231
+                if (last_idx != 0) { seg_start[n] = last_pos; seg_len[n] = t - last_pos; ++n; }
+                last_idx = i; last_pos = t;
+            }
+        }
+        if (last_idx != 0) { seg_start[n] = last_pos; seg_len[n] = T - last_pos; ++n; }   // :239-245
+        nseg_s = n;
+        lens[b] = n;
+    }
+    __syncthreads();
+    const int nseg = nseg_s;
+    for (int t = tid; t < T; t += blockDim.x) { frame_seg[(size_t)b * T + t] = -1; frame_w[(size_t)b * T + t] = 0.0f; }
+    __syncthreads();
+    for (int i = tid; i < nseg * D; i += blockDim.x) {
+        const int n = i / D, d = i - n * D;
+        const int s0 = seg_start[n], len = seg_len[n];
+        const float* lp = latent + ((size_t)b * T + s0) * D + d;
+        float acc = 0.0f;
+        for (int j = 0; j < len; ++j) acc += lp[(size_t)j * D];
+        out[((size_t)b * T + n) * D + d] = len == 1 ? acc : acc / (float)len;
+        if (d == 0) for (int j = 0; j < len; ++j) { frame_seg[(size_t)b * T + s0 + j] = n; frame_w[(size_t)b * T + s0 + j] = 1.0f / (float)len; }
+    }
+}
+
+// dlatent(b, t, :) = dout(b, seg(t), :) / len(seg(t))   (zero for dropped frames)
+__global__ __launch_bounds__(256) void vq_mean_bwd_kernel(const float* dout, int ld_seg, const int* frame_seg, const float* frame_w,
+                                                          float* dlat, int B, int T, int D) {
+    const size_t total = (size_t)B * T * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const size_t bt = i / D;
+        const int b = (int)(bt / T);
+        const int n = frame_seg[bt];
+        dlat[i] = (n >= 0 && n < ld_seg) ? dout[((size_t)b * ld_seg + n) * D + d] * frame_w[bt] : 0.0f;
+    }
+}
+
 }  // namespace
 
 extern "C" int st_vq_build_table(const float* learnable, int Dl, const float* attr, int n_attr,
@@ -190,6 +253,31 @@ extern "C" int st_softmax_argmax(const float* logits, float* p, int64_t* idx, in
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(softmax_argmax_kernel, dim3(blocks), dim3(VQ_WAVES * 64), lds, (hipStream_t)stream,
                        logits, p, idx, n, V);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_vq_mean_fwd(const float* p_code, const float* latent, float* out, int* lens, int* frame_seg, float* frame_w,
+                              int B, int T, int D, int V, int max_frames_per_phn, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(p_code && latent && out && lens && frame_seg && frame_w && B > 0 && T > 0 && D > 0 && V > 0 && max_frames_per_phn >= 0,
+                 "st_vq_mean_fwd: bad arguments");
+    const size_t lds = (size_t)3 * T * sizeof(int);
+    ST_CHECK_ARG(lds <= 64 * 1024, "st_vq_mean_fwd: T=%d too long (3*T ints of LDS)", T);
+    hipLaunchKernelGGL(vq_mean_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, p_code, latent, out, lens, frame_seg,
+                       frame_w, B, T, D, V, max_frames_per_phn);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_vq_mean_bwd(const float* dout, int n_seg_rows, const int* frame_seg, const float* frame_w, float* dlatent,
+                              int B, int T, int D, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dout && frame_seg && frame_w && dlatent && n_seg_rows > 0 && B > 0 && T > 0 && D > 0, "st_vq_mean_bwd: bad arguments");
+    size_t blocks = ((size_t)B * T * D + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vq_mean_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, n_seg_rows, frame_seg,
+                       frame_w, dlatent, B, T, D);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -69,6 +69,10 @@ class VQVAE(nn.Module):
         p_code, quantized, _, _ = self.codebook(enc_latent, first_n_real_mel)
         return p_code, quantized
 
+    def mean_forward(self, p_code, latent):
+        """run-length merge + blank filter of the quantised latents on device.      ref: :218-257"""
+        return AG.mean_forward(p_code, latent, self.max_frames_per_phn)
+
     def speech_to_text(self, paired_mel, unpaired_mel, using_fake_mel=False):
         raise NotImplementedError('speech_to_text needs the CTC speech encoder (src/asr.py), which is outside the '
                                   'decode hot path; use quantize(enc_latent) on latents you already have')

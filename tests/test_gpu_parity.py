@@ -614,3 +614,61 @@ def test_long_form_c5_shape(dev):
     errs = dict(mel=maxdiff(mel[:, :24], mel_r), align=maxdiff(align[:, :8], al_r))
     report('c5_prefix', **errs)
     assert errs['mel'] < 5e-5 and errs['align'] < 1e-5
+
+
+# ------------------------------------------------------------------------------------ next row (8f-1): mean_forward
+def test_vq_mean_forward_against_reference_golden(dev):
+    """Run-length merge + blank filter of VQ codes on device vs the reference's recorded outputs (incl. the
+    all-blank utterance -> None case and runs longer than max_frames_per_phn)."""
+    from semi_tts_amd import autograd as AG
+    _, A, meta = load_golden('vq_mean_forward')
+    for ci in range(meta['n_cases']):
+        idx, lat = A['idx%d' % ci], A['lat%d' % ci]
+        p = torch.nn.functional.one_hot(idx, 43).float()
+        out = AG.mean_forward(p.to(dev), lat.to(dev), meta['max_frames_per_phn'])
+        if ('none%d' % ci) in A:
+            assert out is None
+            continue
+        got, ln = out
+        assert torch.equal(ln.cpu(), A['len%d' % ci])
+        assert got.shape == A['out%d' % ci].shape
+        assert maxdiff(got, A['out%d' % ci]) < 1e-6
+
+
+def test_vq_mean_forward_c3_size_and_gradient(dev):
+    # C3 shape: B=32 utterances of 129 ASR frames, V=43, D=64; few distinct codes so that runs, caps and blanks all occur
+    from semi_tts_amd import autograd as AG
+    g = torch.Generator().manual_seed(3)
+    B, T, D, V, maxf = 32, 129, 64, 43, 3
+    idx = torch.randint(0, 5, (B, T), generator=g)
+    idx = torch.where(torch.rand(B, T, generator=g) < 0.6, idx.roll(1, 1), idx)      # longer runs
+    idx[:, 0] = torch.randint(1, 5, (B,), generator=g)                                # no all-blank utterance
+    p = torch.rand(B, T, V, generator=g) * 0.1
+    p.scatter_(2, idx.unsqueeze(-1), 1.0)
+    lat = torch.randn(B, T, D, generator=g)
+    ref = VQ.mean_forward(idx.numpy(), lat.numpy(), maxf)
+    lat_d = lat.to(dev).requires_grad_()
+    got, ln = AG.mean_forward(p.to(dev), lat_d, maxf)
+    assert np.array_equal(ln.cpu().numpy(), ref[1])
+    assert maxdiff(got, torch.from_numpy(ref[0])) < 1e-6
+    # properties: every kept segment has 1..maxf+1 frames, lengths <= T, padding rows are exactly zero
+    for b in range(B):
+        assert float(got[b, int(ln[b]):].abs().max()) == 0.0 if int(ln[b]) < got.shape[1] else True
+    # gradient: d/dlatent of sum(out * w) = w[seg(t)] / len(seg(t))
+    w = torch.randn(*got.shape, generator=g)
+    (got * w.to(dev)).sum().backward()
+    lat_r = lat.double().requires_grad_()
+    tot = 0
+    for b in range(B):       # float64 restatement of the segmentation for the gradient reference
+        row = idx[b].tolist()
+        last_idx, last_pos, n = row[0], 0, 0
+        for t, i in enumerate(row):
+            if last_idx != i or (t - last_pos) > maxf:
+                if last_idx != 0:
+                    tot = tot + (lat_r[b, last_pos:t].mean(0) * w[b, n].double()).sum()
+                    n += 1
+                last_idx, last_pos = i, t
+        if last_idx != 0:
+            tot = tot + (lat_r[b, last_pos:].mean(0) * w[b, n].double()).sum()
+    tot.backward()
+    assert maxdiff(lat_d.grad, lat_r.grad) < 1e-6

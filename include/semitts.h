@@ -194,7 +194,7 @@ int st_attn_step_t16_fwd(const float* pq, const float* pm, const float* memory,
                          int B, int L, int A, int E, int F, int K, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
- * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) + tap - pad, ci) * W(n, ci, tap) )
+ * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) * stride + tap - pad, ci) * W(n, ci, tap) )
  * channels-last activations: A is (Bn * Tin, Cin) with row stride lda, C is (Bn * Tout, N)
  * with row stride ldc; rows of one utterance never read across its [0,Tin) range (zero pad).
  * W is the torch Conv1d weight (N, Cin, KT) or, with KT == 1, the torch Linear weight (N, Cin).
@@ -205,7 +205,8 @@ int st_attn_step_t16_fwd(const float* pq, const float* pm, const float* memory,
  * utterance), i.e. MaxPool1d(2, stride 1, padding 1)[:T] fused into the load.
  * ref: Conv1d+BatchNorm1d+ReLU src/module.py:421-431; BatchNormConv1d :527-538; CBHG bank /
  *      maxpool / projections / pre_highway / Highway :597-611, :541-555; nn.Linear src/tts.py:34;
- *      memory_layer src/module.py:306; prenet over the whole teacher :178-179. */
+ *      memory_layer src/module.py:306; prenet over the whole teacher :178-179; the strided / residual
+ *      ConvLayer of the speech encoder src/module.py:627-648. */
 typedef struct st_gemm_epilogue {
     const float* bias;
     int act_pre;
@@ -217,7 +218,7 @@ typedef struct st_gemm_epilogue {
 } st_gemm_epilogue;
 
 int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
-                int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev,
+                int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int stride, int pool_prev,
                 const st_gemm_epilogue* ep, void* stream);
 
 /* per-column statistics over M rows (training-mode BatchNorm): mean, biased variance, and

@@ -97,7 +97,7 @@ SIGNATURES = {
     'st_lstm_cell_fwd': [C.POINTER(StSeg), I, P, P, P, I, P, I, P, P, I, P, I, P, I, I, P],
     'st_skinny_linear_fwd': [C.POINTER(StSeg), I, P, I, P, I, P, I, I, P, I, I, I, I, P],
     'st_attn_step_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, P, I, P, I, P, P, P, I, I, I, I, I, I, I, P],
-    'st_gemm_fwd': [P, I, P, P, I, I, I, I, I, I, I, I, I, I, C.POINTER(StGemmEpilogue), P],
+    'st_gemm_fwd': [P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, C.POINTER(StGemmEpilogue), P],
     'st_bn_stats': [P, I, I, I, I, P, P, P, P, F, P, P],
     'st_colreduce_workspace_floats': [I, I],
     'st_bn_apply': [P, I, I, I, I, P, P, P, P, F, I, P],

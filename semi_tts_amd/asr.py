@@ -1,0 +1,95 @@
+"""CTC speech encoder on the HIP path: mirror of the reference's src/asr.py:5-64 and
+`ConvLayer` (src/module.py:627-648) -- same constructor arguments, attributes (`time_reduce_factor`, `out_dim`)
+and state_dict keys (`layer{l}.conv.*`, `layer{l}.bn.*`, `rnn.*`, `postnet.*`).
+
+Every ConvLayer is ONE launch of the implicit-GEMM conv (stride in the row mapping) with bias -> BatchNorm ->
+activation -> residual add -> dropout mask fused in its epilogue; the BiLSTM layers reuse the encoder's
+sequence kernels.  Forward only: the speech encoder is trained by the CTC half of the reference's step, which is
+outside the hot path (a strided conv input-gradient kernel does not exist here), so a differentiable call raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_ACT = {'tanh': 'tanh', 'relu': 'relu', 'sigmoid': 'sigmoid'}
+
+
+class ConvLayer(nn.Module):
+    def __init__(self, in_dim, out_dim, kernel_size, stride, residual, batch_norm, activation, dropout):
+        super().__init__()
+        self.residual, self.batch_norm, self.stride = bool(residual), batch_norm, stride
+        self.activation = _ACT[activation.lower()]
+        self.padding = 1 if kernel_size != 1 else 0
+        self.conv = nn.Conv1d(in_dim, out_dim, kernel_size, stride, padding=self.padding)
+        if batch_norm:
+            self.bn = nn.BatchNorm1d(out_dim)
+        self.drop = nn.Dropout(dropout)
+
+    def forward(self, x, mask=None):
+        """x (B,T,C) channels-last (the reference keeps (B,C,T))"""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('the speech encoder is forward-only on the HIP path (run it under torch.no_grad())')
+        w, b = self.conv.weight, self.conv.bias
+        p = self.drop.p
+        if self.training and p > 0 and mask is None:
+            B, T, _ = x.shape
+            To = (T + 2 * self.padding - w.shape[2]) // self.stride + 1
+            mask = torch.empty(B, To, w.shape[0], device=x.device, dtype=torch.float32).bernoulli_(1 - p).div_(1 - p)
+        res = x if self.residual else None
+        if not self.batch_norm:
+            return ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b, act_post=self.activation, res=res, mask=mask)
+        bn = self.bn
+        if not self.training:
+            return ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b,
+                            bn=(bn.running_mean, bn.running_var, bn.weight, bn.bias), bn_eps=bn.eps,
+                            act_post=self.activation, res=res, mask=mask)
+        # training: batch statistics of the biased conv output first, then the same fused pass with them
+        y = ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b)
+        mean, var = ops.bn_stats(y.view(-1, y.shape[-1]), 0, y.shape[-1], bn.running_mean, bn.running_var, bn.momentum)
+        bn.num_batches_tracked += 1
+        return ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b, bn=(mean, var, bn.weight, bn.bias),
+                        bn_eps=bn.eps, act_post=self.activation, res=res, mask=mask)
+
+
+class CTC(nn.Module):
+    def __init__(self, in_dim, out_dim, dim, dropout, kernel, stride, residual, batch_norm, activation,
+                 rnn_layers, rnn_dim, rnn_bid, layer_norm):
+        super().__init__()
+        self.kernel, self.stride, self.residual = kernel, stride, residual
+        self.layers = len(kernel)
+        self.dim = [in_dim] + ([dim] * self.layers if isinstance(dim, int) else list(dim))
+        self.rnn_dim, self.batch_norm, self.layer_norm = rnn_dim, batch_norm, layer_norm
+        self.out_dim, self.dropout = out_dim, dropout
+        self.time_reduce_factor = 2 ** sum(1 for s in stride if s != 1)                      # :22
+        for l in range(self.layers):
+            setattr(self, 'layer' + str(l), ConvLayer(self.dim[l], self.dim[l + 1], kernel[l], stride[l], residual[l],
+                                                      batch_norm, activation, dropout))
+        assert rnn_dim > 0
+        if not rnn_bid or layer_norm:
+            raise NotImplementedError('the HIP speech encoder implements the bidirectional LSTM without LayerNorm '
+                                      '(every shipped config)')
+        self.rnn = nn.LSTM(self.dim[-1], rnn_dim, num_layers=rnn_layers, dropout=dropout, bidirectional=True, batch_first=True)
+        self.rnn_layers = rnn_layers
+        self.drop = nn.Dropout(dropout)
+        self.postnet = nn.Linear(2 * rnn_dim, out_dim)
+
+    def forward(self, x):
+        """x (B,T,n_mels) -> (B, T / time_reduce_factor, out_dim)                            ref: src/asr.py:46-64"""
+        x = x.contiguous()
+        for l in range(self.layers):
+            x = getattr(self, 'layer' + str(l))(x)
+        B, T, _ = x.shape
+        H = self.rnn_dim
+        p = self.dropout if self.training else 0.0
+        ws = torch.empty(3 * B * H, device=x.device, dtype=torch.float32)
+        for layer in range(self.rnn_layers):
+            out = torch.empty(B, T, 2 * H, device=x.device, dtype=torch.float32)
+            for rev, sfx in ((False, '_l%d' % layer), (True, '_l%d_reverse' % layer)):
+                g = lambda n: getattr(self.rnn, n + sfx)
+                xproj = ops.gemm(x, g('weight_ih'), bias=g('bias_ih'))
+                ops.lstm_seq(xproj, g('weight_hh'), g('bias_hh'), out, H if rev else 0, rev, ws)
+            x = out
+            if p > 0:   # inter-layer dropout of nn.LSTM and the dropout in front of the projection (:62)
+                x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)
+        return ops.gemm(x, self.postnet.weight, bias=self.postnet.bias)

@@ -19,7 +19,7 @@ constexpr int GM_BM = 64, GM_BN = 64, GM_BK = 16, GM_LD = 20, GM_THREADS = 256;
 
 struct GmArgs {
     const float* A; int lda; const float* W; float* C; int ldc; int coff;
-    int Bn, Tin, Tout, Cin, N, KT, pad, pool_prev;
+    int Bn, Tin, Tout, Cin, N, KT, pad, pool_prev, stride;
     int M;      // Bn * Tout
     int cpb;    // 16-float k-blocks per tap
     st_gemm_epilogue ep;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
         const int tap = kb / g.cpb;
         const int ci = (kb - tap * g.cpb) * GM_BK + skq * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int ti = ato + tap - g.pad;
+        const int ti = ato * g.stride + tap - g.pad;
         if (!a_row_ok || ti < 0 || ti >= g.Tin || ci >= g.Cin) return v;
         const float* p = g.A + ((size_t)ab * g.Tin + ti) * g.lda + ci;
         if (VECA) v = st_ld4(p); else v = st_ld4_guard(p, g.Cin - ci);
@@ -235,18 +235,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* X, int ldx, int co
 }  // namespace
 
 extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
-                           int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev,
+                           int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int stride, int pool_prev,
                            const st_gemm_epilogue* ep, void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(A && W && C, "st_gemm_fwd: null pointer");
-    ST_CHECK_ARG(Bn > 0 && Tin > 0 && Tout > 0 && Cin > 0 && N > 0 && KT > 0 && pad >= 0, "st_gemm_fwd: bad dims");
+    ST_CHECK_ARG(Bn > 0 && Tin > 0 && Tout > 0 && Cin > 0 && N > 0 && KT > 0 && pad >= 0 && stride >= 1, "st_gemm_fwd: bad dims");
     ST_CHECK_ARG(lda >= Cin && ldc >= coff + N, "st_gemm_fwd: lda=%d < Cin=%d or ldc=%d < coff+N=%d", lda, Cin, ldc, coff + N);
     // rows of A outside [0, Tin) read as zero, so Tout may exceed the natural conv length (used by the
     // input-gradient pass, where the forward output was trimmed)
     GmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.W = W; g.C = C; g.ldc = ldc; g.coff = coff;
-    g.Bn = Bn; g.Tin = Tin; g.Tout = Tout; g.Cin = Cin; g.N = N; g.KT = KT; g.pad = pad; g.pool_prev = pool_prev;
+    g.Bn = Bn; g.Tin = Tin; g.Tout = Tout; g.Cin = Cin; g.N = N; g.KT = KT; g.pad = pad; g.pool_prev = pool_prev; g.stride = stride;
     g.M = Bn * Tout;
     g.cpb = (Cin + GM_BK - 1) / GM_BK;
     if (ep) {

@@ -110,7 +110,7 @@ def attn_step(pq, pm, memory, w_prev, w_cum_prev, w_out, w_cum_out, loc_conv_w, 
           'st_attn_step_fwd')
 
 
-def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, coff=0, bias=None, act_pre=None,
+def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=0, bias=None, act_pre=None,
          bn=None, bn_eps=1e-5, act_post=None, res=None, highway_h=None, mask=None, pool_prev=False):
     """C = epilogue(conv1d / linear).  a: (Bn, Tin, Cin) or (M, Cin) channels-last; w: torch Linear
     (N, Cin) or Conv1d (N, Cin, KT) weight.  bn = (mean, var, weight, bias) tensors."""
@@ -124,7 +124,7 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, coff=0, bias=No
     KT = w.shape[2] if w.dim() == 3 else 1
     N = w.shape[0]
     if Tout is None:
-        Tout = Tin + 2 * pad - KT + 1
+        Tout = (Tin + 2 * pad - KT) // stride + 1
     lda = a.stride(-2)
     if out is None:
         shape = (Bn, Tout, N) if a.dim() == 3 else (Bn * Tout, N)
@@ -144,7 +144,7 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, coff=0, bias=No
     ep.mask = _p(mask)
     ep.ldmask = int(mask.stride(-2)) if mask is not None else 0
     check(lib.st_gemm_fwd(_p(a), int(lda), _p(w), _p(out), int(ldc), int(coff), int(Bn), int(Tin), int(Tout),
-                          int(Cin), int(N), int(KT), int(pad), 1 if pool_prev else 0, C.byref(ep), stream_handle()),
+                          int(Cin), int(N), int(KT), int(pad), int(stride), 1 if pool_prev else 0, C.byref(ep), stream_handle()),
           'st_gemm_fwd')
     return out
 

@@ -1,17 +1,17 @@
 """VQVAE orchestration on the HIP path: the caller of the hot path (H1/H2 rows of SURVEY.md 8a).
 
-Mirrors the parts of the reference's src/vqvae.py that sit on the TTS side: constructor arguments
-and config splatting (:26-68), `text_to_speech` with its paired / unpaired batch concatenation and
-output slicing (:143-207), `padded_concat` (:259-271).  The speech side (`speech_to_text`) needs the
-CTC speech encoder src/asr.py, which is outside the hot path: here the codebook is
-applied to latents the caller already has (`quantize`), and `speech_to_text` says so.
-State-dict prefixes are the reference's (`codebook.*`, `spkr_embed.weight`, `tts.*`).
+Mirrors the reference's src/vqvae.py: constructor arguments and config splatting (:26-68),
+`speech_to_text` (:106-141: CTC speech encoder -> codebook -> run-length merge of the unpaired part),
+`text_to_speech` with its paired / unpaired batch concatenation and output slicing (:143-207),
+`mean_forward` (:218-257), `padded_concat` (:259-271).
+State-dict prefixes are the reference's (`asr.*`, `codebook.*`, `spkr_embed.weight`, `tts.*`).
 """
 import torch
 import torch.nn as nn
 
 from . import ops
 from . import autograd as AG
+from .asr import CTC
 from .embed import L2Embedding, SeperateEmbedding
 from .tts import Tacotron2
 
@@ -36,7 +36,11 @@ class VQVAE(nn.Module):
         self.code_bone = codebook.pop('bone')                          # :41
         self.latent_dim = codebook['latent_dim']
         self.n_frames_per_step = decoder['decoder']['n_frames_per_step']
-        self.encoder_config = encoder      # the CTC speech encoder is not built (out of the hot path)
+        self.asr = CTC(n_mels, self.latent_dim, **encoder)                                    # :46
+        self.time_reduce_factor = self.asr.time_reduce_factor
+        self.use_asr_postnet = asr_postnet_weight > 0
+        if self.use_asr_postnet:
+            raise NotImplementedError('ASRPostnet (asr_postnet_weight > 0): no shipped config enables it')
         if self.code_bone == 'l2':                                     # :56-61
             self.codebook = L2Embedding(vocab_size, False, **codebook)
         elif self.code_bone == 'seperate':
@@ -74,8 +78,24 @@ class VQVAE(nn.Module):
         return AG.mean_forward(p_code, latent, self.max_frames_per_phn)
 
     def speech_to_text(self, paired_mel, unpaired_mel, using_fake_mel=False):
-        raise NotImplementedError('speech_to_text needs the CTC speech encoder (src/asr.py), which is outside the '
-                                  'decode hot path; use quantize(enc_latent) on latents you already have')
+        """same contract and return tuple as the reference (:106-141)"""
+        use_unpaired = unpaired_mel is not None
+        if use_unpaired:
+            paired_mel_bs, all_mel = self.padded_concat(paired_mel, unpaired_mel)
+        else:
+            all_mel, paired_mel_bs = paired_mel, len(paired_mel)
+        enc_latent = self.asr(all_mel)                                                          # :116
+        first_n_real_mel = len(paired_mel) if using_fake_mel else 0
+        p_code, quantized_latent, _, rest = self.codebook(enc_latent, first_n_real_mel)         # :119
+        if use_unpaired:                                                                        # :122-133
+            pair_prob, pair_latent = p_code[:paired_mel_bs], quantized_latent[:paired_mel_bs]
+            unpair_prob, unpair_latent = p_code[paired_mel_bs:], quantized_latent[paired_mel_bs:]
+            trim_out = self.mean_forward(unpair_prob, unpair_latent)
+            unpair_latent, unpair_latent_len = trim_out if trim_out is not None else (None, None)
+        else:
+            pair_prob, pair_latent = p_code, quantized_latent
+            unpair_prob = unpair_latent = unpair_latent_len = None
+        return pair_prob, pair_latent, unpair_prob, unpair_latent, unpair_latent_len, None, rest
 
     def text_to_speech(self, paired_text, paired_sid, unpaired_sid, unpaired_latent, unpaired_text, unpaired_latent_len,
                        paired_teacher, unpaired_teacher, tf_rate, _masks=None):

@@ -672,3 +672,65 @@ def test_vq_mean_forward_c3_size_and_gradient(dev):
             tot = tot + (lat_r[b, last_pos:].mean(0) * w[b, n].double()).sum()
     tot.backward()
     assert maxdiff(lat_d.grad, lat_r.grad) < 1e-6
+
+
+# ------------------------------------------------------------------------------------ next row (8f-2): speech encoder
+@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train'])
+def test_ctc_encoder_against_reference_golden(dev, name):
+    import json
+    from semi_tts_amd.asr import CTC
+    W, A, meta = load_golden(name)
+    m = CTC(meta['in_dim'], meta['out_dim'], **meta['cfg'])
+    m.load_state_dict(W)
+    m = m.to(dev).train(meta['training'])
+    with torch.no_grad():
+        y = m(A['x'].to(dev))
+    err = maxdiff(y, A['y'])
+    report('asr_golden', name=name, err=err)
+    assert y.shape == A['y'].shape and err < 2e-5
+    if meta['training']:
+        sd = m.state_dict()
+        for k, v in zip(json.loads(bytes(A['post_keys']).decode()), A['post']):
+            assert maxdiff(sd[k], v) < 1e-5, k
+
+
+def test_speech_to_text_c3_shape_against_oracle(dev):
+    """Full-size CTC encoder (6 conv layers of 512 incl. the stride-2 one, 2-layer BiLSTM(256), Linear -> 64), the L2
+    codebook and the run-length merge, B=8 utterances of 258 frames, vs the oracle composition on CPU."""
+    import yaml, os
+    from oracle import asr_oracle as AO
+    from semi_tts_amd.synthetic import load_synthetic
+    from semi_tts_amd.vqvae import VQVAE
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, 'config', 'semi-single-spkr-paired-data.yaml')))['model']
+    cfg['codebook'].update(phn_attr_pth='', proj_attr=None)
+    m = VQVAE(80, 1025, 43, 109, **cfg)
+    load_synthetic(m, 77)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    mel, umel = torch.rand(5, 258, 80, generator=g), torch.rand(3, 200, 80, generator=g)
+    with torch.no_grad():
+        pp, pl, up, ul, ulen, _, _ = m.speech_to_text(mel.to(dev), umel.to(dev))
+    Wd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    allmel = torch.zeros(8, 258, 80)
+    allmel[:5], allmel[5:, :200] = mel, umel
+    enc = AO.ctc_forward({k[4:]: v for k, v in Wd.items() if k.startswith('asr.')}, allmel, cfg['encoder'])
+    cbW = {k[9:]: v for k, v in Wd.items() if k.startswith('codebook.')}
+    p_ref, idx_ref, out_ref, table = VQ.l2_forward(cbW, enc)
+    assert pp.shape == (5, 129, 43) and pl.shape == (5, 129, 64)
+    # the codes are an argmax over distances computed from a ~1e-5-accurate encoder output: compare where decisive
+    p_all = torch.cat([pp, up], 0).cpu()
+    idx_hip = p_all.argmax(-1)
+    top2 = p_ref.topk(2, -1).values
+    decisive = (top2[..., 0] - top2[..., 1]) > 2e-5          # p is near-uniform with synthetic weights (entries ~1/43)
+    assert float(decisive.float().mean()) > 0.8
+    assert bool((idx_hip[decisive] == idx_ref[decisive]).all())
+    errs = dict(p=maxdiff(p_all[decisive], p_ref[decisive]))
+    report('speech_to_text_c3', decisive=float(decisive.float().mean()), **errs)
+    assert errs['p'] < 1e-5
+    # run-length merge of the unpaired part: oracle segmentation on the HIP codes and HIP latents
+    mf = VQ.mean_forward(idx_hip[5:].numpy(), table[idx_hip[5:]].numpy(), cfg['max_frames_per_phn'])
+    if mf is None:
+        assert ul is None
+    else:
+        assert np.array_equal(ulen.cpu().numpy(), mf[1]) and maxdiff(ul, torch.from_numpy(mf[0])) < 1e-5

@@ -108,3 +108,17 @@ def test_vq_mean_forward():
         lat, ln = out
         assert np.array_equal(ln, A['len%d' % ci].numpy())
         assert np.abs(lat - A['out%d' % ci].numpy()).max() < 1e-6
+
+
+@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train'])
+def test_asr_oracle_against_reference(name):
+    from oracle import asr_oracle as AO
+    W, A, meta = load_golden(name)
+    stats = {}
+    y = AO.ctc_forward(W, A['x'], meta['cfg'], training=meta['training'], stats_out=stats)
+    assert y.shape == A['y'].shape
+    assert (y - A['y']).abs().max() < 2e-6
+    if meta['training']:
+        import json
+        for k, v in zip(json.loads(bytes(A['post_keys']).decode()), A['post']):
+            assert (stats[k] - v).abs().max() < 1e-6, k

@@ -357,9 +357,41 @@ def train_step_case():
     print(stats)
 
 
+def asr_cases():
+    """CTC speech encoder (src/asr.py) at tiny dimensions: eval mode, and training mode with dropout 0 (BatchNorm batch
+    statistics; the inter-layer dropout of nn.LSTM cannot be recorded, so no dropout case)."""
+    from src.asr import CTC as RefCTC
+    base = dict(dim=24, kernel=[3, 4, 3, 3, 3, 1], stride=[1, 2, 1, 1, 1, 1], residual=[0, 0, 1, 1, 1, 1], activation='Tanh',
+                batch_norm=True, rnn_bid=True, rnn_layers=2, rnn_dim=12, layer_norm=False)
+    for name, training, dropout, seed in (('asr_tiny_eval', False, 0.5, 51), ('asr_tiny_train', True, 0.0, 52)):
+        torch.manual_seed(seed)
+        cfg = dict(base, dropout=dropout)
+        m = RefCTC(8, 10, **cfg)
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for n_, buf in m.named_buffers():
+                if n_.endswith('running_mean'):
+                    buf.copy_(torch.randn(buf.shape, generator=g) * 0.2)
+                elif n_.endswith('running_var'):
+                    buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+        m.train(training)
+        w0 = {k: v.clone() for k, v in m.state_dict().items()}
+        x = torch.rand(3, 14, 8, generator=g)
+        with torch.no_grad():
+            y = m(x)
+        arrays = dict(x=x, y=y)
+        if training:
+            post = {k: v for k, v in m.state_dict().items() if 'running_' in k}
+            arrays['post'] = list(post.values())
+            arrays['post_keys'] = np.frombuffer(json.dumps(list(post)).encode(), np.uint8)
+        save(name, w0, arrays, dict(cfg=cfg, in_dim=8, out_dim=10, training=training))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train']
+    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr']
+    if 'asr' in which:
+        asr_cases()
     if 'train' in which:
         train_step_case()
     if 'tts' in which:

@@ -492,6 +492,20 @@ int st_freq_loss(const float* pred, const float* label, float* loss, float* dpre
 /* y = x * (*scalar)   (scalar on the device: the incoming gradient of a scalar loss) */
 int st_scale_by(const float* x, const float* scalar, float* y, size_t n, void* stream);
 
+/* ------------------------------------------------------------------ optimiser step (multi-tensor)
+ * ref: BaseSolver.backward src/solver.py:138-151 (clip_grad_norm_ 5.0, optimizer.step()), torch.optim.Adam as built by
+ * src/optim.py.  The pointer arrays are HOST arrays of device pointers (nt tensors, n[t] elements each); the
+ * kernels take them through their arguments, a few launches for ~100 tensors. */
+size_t st_mt_blocks(const long* n, int nt);                   /* floats of `partials` st_mt_grad_norm needs */
+/* *norm_out (device) = sqrt(sum_t sum_i g_t[i]^2), fixed summation order */
+int st_mt_grad_norm(float* const* g, const long* n, int nt, float* partials, float* norm_out, void* stream);
+/* g *= max_norm / (norm + 1e-6) when that is < 1 (torch.nn.utils.clip_grad_norm_); norm is a device scalar */
+int st_mt_clip_scale(float* const* g, const long* n, int nt, const float* norm, float max_norm, void* stream);
+/* torch.optim.Adam (no weight decay, no amsgrad): m = m + (g-m)(1-b1); v = b2 v + (1-b2) g^2;
+ * p -= step_size * m / (sqrt(v)/bias_correction2_sqrt + eps), step_size = lr / (1 - b1^t) */
+int st_mt_adam(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,
+               float beta1, float beta2, float eps, float step_size, float bias_correction2_sqrt, void* stream);
+
 /* ------------------------------------------------------------------ small utilities */
 int st_fill(float* p, float v, size_t n, void* stream);
 int st_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream);

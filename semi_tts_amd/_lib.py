@@ -135,6 +135,10 @@ SIGNATURES = {
     'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],
     'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, P],
     'st_adain_bwd': [P, C.c_long, I, P, C.c_long, I, P, P, P, P, I, I, I, P],
+    'st_mt_blocks': [P, I],
+    'st_mt_grad_norm': [P, P, I, P, P, P],
+    'st_mt_clip_scale': [P, P, I, P, F, P],
+    'st_mt_adam': [P, P, P, P, P, I, F, F, F, F, F, P],
     'st_freq_loss': [P, P, P, P, P, I, I, I, I, F, F, F, I, P],
     'st_scale_by': [P, P, P, Z, P],
     'st_bn_norm_fwd': [P, I, I, P, I, I, I, I, P, P, P, P, F, I, P],
@@ -154,7 +158,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
              'st_decoder_packed_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
-             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t}
+             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
 
 _lib = None
 

@@ -1,0 +1,135 @@
+// optim.hip -- the optimiser half of the training step as multi-tensor kernels.
+// ref: BaseSolver.backward src/solver.py:138-151 (clip_grad_norm_(5.0) then optimizer.step()), src/optim.py
+// (torch.optim.Adam with its defaults).  ~100 parameter tensors are processed by a handful of launches: tensor
+// pointers and the block -> (tensor, chunk) map travel in the kernel arguments, up to MT_T tensors / MT_NB
+// blocks per launch (no device-side tables, nothing to upload).
+#include "st_common.h"
+
+namespace {
+
+constexpr int MT_T = 24, MT_NB = 320, MT_CHUNK = 65536, MT_THREADS = 512;
+
+struct MtArgs {
+    float* p[MT_T]; float* g[MT_T]; float* m[MT_T]; float* v[MT_T];
+    long n[MT_T];
+    unsigned char blk_tensor[MT_NB];
+    int blk_chunk[MT_NB];
+    // op parameters
+    float* partial; int partial_base;            // sumsq
+    const float* norm; float max_norm;           // scale
+    float b1, b2, eps, step_size, bc2_sqrt;      // adam
+};
+
+// OP 0: partial[block] = sum g^2;  OP 1: g *= min(1, max_norm / (norm + 1e-6));  OP 2: Adam update
+template <int OP>
+__global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
+    __shared__ float red[MT_THREADS / 64];
+    const int t = a.blk_tensor[blockIdx.x];
+    const long beg = (long)a.blk_chunk[blockIdx.x] * MT_CHUNK;
+    const long n = a.n[t];
+    const long end = beg + MT_CHUNK < n ? beg + MT_CHUNK : n;
+    float* __restrict__ g = a.g[t];
+    if (OP == 0) {
+        float acc = 0.0f;
+        for (long i = beg + threadIdx.x; i < end; i += MT_THREADS) { const float x = g[i]; acc = fmaf(x, x, acc); }
+        acc = st_wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.0f;
+            for (int w = 0; w < MT_THREADS / 64; ++w) s += red[w];
+            a.partial[a.partial_base + blockIdx.x] = s;
+        }
+    } else if (OP == 1) {
+        const float coef = a.max_norm / (*a.norm + 1e-6f);         // torch.nn.utils.clip_grad_norm_
+        if (coef < 1.0f) for (long i = beg + threadIdx.x; i < end; i += MT_THREADS) g[i] *= coef;
+    } else {
+        float* __restrict__ p = a.p[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
+        for (long i = beg + threadIdx.x; i < end; i += MT_THREADS) {
+            const float gr = g[i];
+            const float mi = m[i] + (gr - m[i]) * (1.0f - a.b1);          // exp_avg.lerp_(grad, 1 - beta1)
+            const float vi = v[i] * a.b2 + (1.0f - a.b2) * gr * gr;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+            const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+            m[i] = mi; v[i] = vi;
+            p[i] = p[i] - a.step_size * (mi / denom);
+        }
+    }
+}
+
+__global__ void mt_norm_final_kernel(const float* partial, int n, float* out) {
+    // fixed-order sum of the per-block partials (a few hundred), then the square root
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *out = sqrtf(s);
+}
+
+template <int OP>
+int mt_run(MtArgs& a, float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt, hipStream_t st,
+           int* blocks_total) {
+    int ti = 0, bl = 0, base = 0;
+    auto flush = [&]() -> int {
+        if (bl == 0) { ti = 0; return 0; }
+        a.partial_base = base;
+        hipLaunchKernelGGL((mt_kernel<OP>), dim3(bl), dim3(MT_THREADS), 0, st, a);
+        ST_LAUNCH_CHECK();
+        base += bl; ti = 0; bl = 0;
+        return 0;
+    };
+    for (int t = 0; t < nt; ++t) {
+        if (n[t] <= 0) continue;
+        const int chunks = (int)((n[t] + MT_CHUNK - 1) / MT_CHUNK);
+        int c = 0;
+        while (c < chunks) {
+            if (ti == MT_T || bl == MT_NB) { int rc = flush(); if (rc) return rc; }
+            // (re)register this tensor in the current launch
+            a.p[ti] = p ? p[t] : nullptr; a.g[ti] = g[t]; a.m[ti] = m ? m[t] : nullptr; a.v[ti] = v ? v[t] : nullptr; a.n[ti] = n[t];
+            while (c < chunks && bl < MT_NB) { a.blk_tensor[bl] = (unsigned char)ti; a.blk_chunk[bl] = c; ++bl; ++c; }
+            ++ti;
+        }
+    }
+    int rc = flush();
+    if (rc) return rc;
+    if (blocks_total) *blocks_total = base;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t st_mt_blocks(const long* n, int nt) {
+    size_t b = 0;
+    for (int t = 0; t < nt; ++t) if (n[t] > 0) b += (size_t)((n[t] + MT_CHUNK - 1) / MT_CHUNK);
+    return b;
+}
+
+extern "C" int st_mt_grad_norm(float* const* g, const long* n, int nt, float* partials, float* norm_out, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(g && n && nt > 0 && partials && norm_out, "st_mt_grad_norm: bad arguments");
+    MtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.partial = partials;
+    int total = 0;
+    int rc = mt_run<0>(a, nullptr, g, nullptr, nullptr, n, nt, (hipStream_t)stream, &total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mt_norm_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partials, total, norm_out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_mt_clip_scale(float* const* g, const long* n, int nt, const float* norm, float max_norm, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(g && n && nt > 0 && norm && max_norm > 0.0f, "st_mt_clip_scale: bad arguments");
+    MtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.norm = norm; a.max_norm = max_norm;
+    return mt_run<1>(a, nullptr, g, nullptr, nullptr, n, nt, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int st_mt_adam(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,
+                          float beta1, float beta2, float eps, float step_size, float bias_correction2_sqrt, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(p && g && m && v && n && nt > 0 && bias_correction2_sqrt > 0.0f, "st_mt_adam: bad arguments");
+    MtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.step_size = step_size; a.bc2_sqrt = bias_correction2_sqrt;
+    return mt_run<2>(a, p, g, m, v, n, nt, (hipStream_t)stream, nullptr);
+}

@@ -1,7 +1,8 @@
 """Optimizer wrapper with the reference's interface (src/optim.py:4-54): a torch.optim optimiser whose
 learning rate is set before every step from a Noam-style schedule ('warmup' 4000 / 'decay' 1000 steps,
-'fixed' otherwise), plus the linear teacher-forcing schedule `pre_step` returns.  The optimiser
-itself is torch's (ROCm) -- SURVEY.md lists it as reused, not rebuilt."""
+'fixed' otherwise), plus the linear teacher-forcing schedule `pre_step` returns.  'Adam' on device
+tensors runs on the multi-tensor HIP kernels (FusedAdam below); any other torch.optim
+name is torch's own optimiser."""
 import torch
 
 _SCHEDULE_STEPS = {'warmup': 4000.0, 'decay': 1000.0}
@@ -16,7 +17,10 @@ class Optimizer:
         self.opt_type, self.sch_type, self.init_lr = optimizer, lr_scheduler, lr
         self.knee = _SCHEDULE_STEPS.get(lr_scheduler)
         # with a schedule the optimiser is built with lr 1.0 and the rate is overwritten every step
-        self.opt = getattr(torch.optim, optimizer)(parameters, lr=1.0 if self.knee else lr)
+        parameters = list(parameters)
+        on_device = bool(parameters) and all(p.is_cuda for p in parameters)
+        cls = FusedAdam if (optimizer == 'Adam' and on_device) else getattr(torch.optim, optimizer)
+        self.opt = cls(parameters, lr=1.0 if self.knee else lr)
 
     def tf_rate(self, step):
         return max(self.tf_end, self.tf_start - (self.tf_start - self.tf_end) * step / self.tf_step)
@@ -45,3 +49,101 @@ class Optimizer:
     def create_msg(self):
         return ['Optim.spec.| Algo. = {}\t| Lr/sampling/rec.loss scheduler = {}/{}/{}'.format(
             self.opt_type, self.sch_type, self.tf_type, self.recon_sch)]
+
+
+# --------------------------------------------------------------------------------------------- multi-tensor HIP path
+def _tables(tensors):
+    import ctypes as C
+    n = len(tensors)
+    return (C.c_void_p * n)(*[t.data_ptr() for t in tensors]), (C.c_long * n)(*[t.numel() for t in tensors])
+
+
+def clip_grad_norm_(parameters, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (L2) on the multi-tensor HIP kernels: returns the total norm as a 0-dim device
+    tensor and scales every .grad in place by max_norm / (norm + 1e-6) when that is below 1.
+    ref: BaseSolver.backward src/solver.py:145"""
+    from . import _lib, ops
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    for g in grads:
+        if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
+            raise RuntimeError('clip_grad_norm_: gradients must be contiguous fp32 device tensors (no CPU fallback)')
+    lib = _lib.load()
+    ptrs, sizes = _tables(grads)
+    dev = grads[0].device
+    partials = torch.empty(int(lib.st_mt_blocks(sizes, len(grads))), device=dev, dtype=torch.float32)
+    norm = torch.empty((), device=dev, dtype=torch.float32)
+    _lib.check(lib.st_mt_grad_norm(ptrs, sizes, len(grads), ops._p(partials), ops._p(norm), ops.stream_handle()), 'st_mt_grad_norm')
+    _lib.check(lib.st_mt_clip_scale(ptrs, sizes, len(grads), ops._p(norm), float(max_norm), ops.stream_handle()), 'st_mt_clip_scale')
+    return norm
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) with the update of all
+    parameter tensors in a handful of multi-tensor launches (st_mt_adam).  State keys (`step`, `exp_avg`,
+    `exp_avg_sq`) and param_group keys are torch's, so optimizer state_dicts are interchangeable with the reference's
+    checkpoints (src/solver.py:211-216)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError('FusedAdam implements the configuration the reference uses (no weight decay / amsgrad)')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None))
+
+    def state_dict(self):
+        # the per-parameter `step` tensors torch's Adam keeps are materialised only here (102 tiny host-tensor
+        # updates per step would cost more than the update kernels)
+        for group in self.param_groups:
+            for p in group['params']:
+                if p in self.state and '_step' in self.state[p]:
+                    self.state[p]['step'] = torch.tensor(float(self.state[p]['_step']))
+        sd = super().state_dict()
+        for st in sd['state'].values():
+            st.pop('_step', None)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if 'step' in st:
+                st['_step'] = int(float(st['step']))
+        self._cache = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib, ops
+        lib = _lib.load()
+        cache = self.__dict__.setdefault('_cache', {})
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            b1, b2 = group['betas']
+            buckets = {}
+            for p in ps:
+                st = self.state[p]
+                if 'exp_avg' not in st:
+                    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                        raise RuntimeError('FusedAdam: parameters must be contiguous fp32 device tensors')
+                    st['_step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['_step'] = st.get('_step', 0) + 1
+                buckets.setdefault(st['_step'], []).append(p)
+            for step, plist in buckets.items():        # parameters share one step count unless some were frozen for a while
+                key = (gi, tuple(id(p) for p in plist))
+                if key not in cache:                   # pointer tables of parameters and moments are stable across steps
+                    pp, sizes = _tables(plist)
+                    mp, _ = _tables([self.state[p]['exp_avg'] for p in plist])
+                    vp, _ = _tables([self.state[p]['exp_avg_sq'] for p in plist])
+                    cache[key] = (pp, mp, vp, sizes)
+                pp, mp, vp, sizes = cache[key]
+                grads = [p.grad for p in plist]
+                if not all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
+                    raise RuntimeError('FusedAdam: gradients must be contiguous fp32 tensors')
+                gp, _ = _tables(grads)
+                bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+                _lib.check(lib.st_mt_adam(pp, gp, mp, vp, sizes, len(plist), float(b1), float(b2), float(group['eps']),
+                                          float(group['lr'] / bc1), float(bc2 ** 0.5), ops.stream_handle()), 'st_mt_adam')
+        return None

@@ -112,9 +112,14 @@ class TtsTrainer(BaseSolver):
         loss = tts_weight * (freq_loss(mel) + freq_loss(linear))
         loss.backward(); [all-reduce over ranks]; clip_grad_norm_(5.0); optimizer.step()
 
-    Forward, loss and backward run on the HIP kernels (semi_tts_amd/autograd.py); clip + Adam are torch's
-    (reused).  The ASR/CTC half of the reference's step is outside the hot path."""
+    Forward, loss, backward, gradient clipping and Adam all run on the HIP kernels (semi_tts_amd/autograd.py,
+    semi_tts_amd/optim.py).  The ASR/CTC half of the reference's step is outside the hot path."""
     GRAD_CLIP = 5.0
+
+    @staticmethod
+    def clip_grad_norm_(params, max_norm):
+        from .optim import clip_grad_norm_
+        return clip_grad_norm_(list(params), max_norm)
 
     def __init__(self, config, paras, mode='train'):
         super().__init__(config, paras, mode)
@@ -170,7 +175,7 @@ class TtsTrainer(BaseSolver):
         total = self.tts_weight * (mel_loss + linear_loss)
         total.backward()
         parallel.allreduce_gradients(self.model.parameters())
-        grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
+        grad_norm = self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
         gn = float(grad_norm)
         if gn != gn:
             self.verbose('Error : grad norm is NaN @ step ' + str(self.step))

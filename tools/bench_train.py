@@ -44,7 +44,7 @@ def main():
         sync(); t1 = time.perf_counter()
         total.backward()
         sync(); t2 = time.perf_counter()
-        gn = torch.nn.utils.clip_grad_norm_(tr.model.parameters(), tr.GRAD_CLIP)
+        gn = tr.clip_grad_norm_(tr.model.parameters(), tr.GRAD_CLIP)
         tr.optimizer.step()
         tr.step += 1
         sync(); t3 = time.perf_counter()

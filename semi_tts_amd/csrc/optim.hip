@@ -7,13 +7,13 @@
 
 namespace {
 
-constexpr int MT_T = 24, MT_NB = 320, MT_CHUNK = 65536, MT_THREADS = 512;
+constexpr int MT_T = 24, MT_NB = 640, MT_CHUNK = 32768, MT_THREADS = 256;
 
 struct MtArgs {
     float* p[MT_T]; float* g[MT_T]; float* m[MT_T]; float* v[MT_T];
     long n[MT_T];
     unsigned char blk_tensor[MT_NB];
-    int blk_chunk[MT_NB];
+    unsigned short blk_chunk[MT_NB];         // chunk index inside the tensor (tensors up to 2^31 elements)
     // op parameters
     float* partial; int partial_base;            // sumsq
     const float* norm; float max_norm;           // scale
@@ -29,10 +29,21 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
     const long n = a.n[t];
     const long end = beg + MT_CHUNK < n ? beg + MT_CHUNK : n;
     float* __restrict__ g = a.g[t];
+    // 16-byte accesses when the chunk is aligned (torch allocations are; chunk starts are multiples of 32768 floats)
+    const bool vec = (((uintptr_t)g | (uintptr_t)a.p[t] | (uintptr_t)a.m[t] | (uintptr_t)a.v[t]) & 15u) == 0;
+    const long nvec = vec ? ((end - beg) >> 2) : 0;
     if (OP == 0) {
-        float acc = 0.0f;
-        for (long i = beg + threadIdx.x; i < end; i += MT_THREADS) { const float x = g[i]; acc = fmaf(x, x, acc); }
-        acc = st_wave_sum(acc);
+        float acc = 0.0f, acc2 = 0.0f;
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(g + beg);
+        long i = threadIdx.x;
+        for (; i + MT_THREADS < nvec; i += 2 * MT_THREADS) {
+            const f32x4 x = g4[i], y = g4[i + MT_THREADS];
+            acc = fmaf(x[0], x[0], acc); acc = fmaf(x[1], x[1], acc); acc = fmaf(x[2], x[2], acc); acc = fmaf(x[3], x[3], acc);
+            acc2 = fmaf(y[0], y[0], acc2); acc2 = fmaf(y[1], y[1], acc2); acc2 = fmaf(y[2], y[2], acc2); acc2 = fmaf(y[3], y[3], acc2);
+        }
+        for (; i < nvec; i += MT_THREADS) { const f32x4 x = g4[i]; acc = fmaf(x[0], x[0], acc); acc = fmaf(x[1], x[1], acc); acc = fmaf(x[2], x[2], acc); acc = fmaf(x[3], x[3], acc); }
+        for (long j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) { const float x = g[j]; acc = fmaf(x, x, acc); }
+        acc = st_wave_sum(acc + acc2);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -42,17 +53,30 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
         }
     } else if (OP == 1) {
         const float coef = a.max_norm / (*a.norm + 1e-6f);         // torch.nn.utils.clip_grad_norm_
-        if (coef < 1.0f) for (long i = beg + threadIdx.x; i < end; i += MT_THREADS) g[i] *= coef;
+        if (coef < 1.0f) {
+            f32x4* g4 = reinterpret_cast<f32x4*>(g + beg);
+            for (long i = threadIdx.x; i < nvec; i += MT_THREADS) { f32x4 x = g4[i]; x[0] *= coef; x[1] *= coef; x[2] *= coef; x[3] *= coef; g4[i] = x; }
+            for (long j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) g[j] *= coef;
+        }
     } else {
         float* __restrict__ p = a.p[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
-        for (long i = beg + threadIdx.x; i < end; i += MT_THREADS) {
-            const float gr = g[i];
-            const float mi = m[i] + (gr - m[i]) * (1.0f - a.b1);          // exp_avg.lerp_(grad, 1 - beta1)
-            const float vi = v[i] * a.b2 + (1.0f - a.b2) * gr * gr;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
+        auto upd = [&](float gr, float& pi, float& mi, float& vi) {
+            mi = mi + (gr - mi) * omb1;                           // exp_avg.lerp_(grad, 1 - beta1)
+            vi = vi * a.b2 + omb2 * gr * gr;                      // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
             const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-            m[i] = mi; v[i] = vi;
-            p[i] = p[i] - a.step_size * (mi / denom);
+            pi = pi - a.step_size * (mi / denom);
+        };
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(g + beg);
+        f32x4* p4 = reinterpret_cast<f32x4*>(p + beg); f32x4* m4 = reinterpret_cast<f32x4*>(m + beg); f32x4* v4 = reinterpret_cast<f32x4*>(v + beg);
+        for (long i = threadIdx.x; i < nvec; i += MT_THREADS) {
+            const f32x4 gg = g4[i];
+            f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { float pi = pp[c], mi = mm[c], vi = vv[c]; upd(gg[c], pi, mi, vi); pp[c] = pi; mm[c] = mi; vv[c] = vi; }
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
         }
+        for (long j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) upd(g[j], p[j], m[j], v[j]);
     }
 }
 
@@ -78,12 +102,13 @@ int mt_run(MtArgs& a, float* const* p, float* const* g, float* const* m, float* 
     for (int t = 0; t < nt; ++t) {
         if (n[t] <= 0) continue;
         const int chunks = (int)((n[t] + MT_CHUNK - 1) / MT_CHUNK);
+        ST_CHECK_ARG(chunks <= 65535, "multi-tensor op: tensor %d has %ld elements (> 2^31)", t, n[t]);
         int c = 0;
         while (c < chunks) {
             if (ti == MT_T || bl == MT_NB) { int rc = flush(); if (rc) return rc; }
             // (re)register this tensor in the current launch
             a.p[ti] = p ? p[t] : nullptr; a.g[ti] = g[t]; a.m[ti] = m ? m[t] : nullptr; a.v[ti] = v ? v[t] : nullptr; a.n[ti] = n[t];
-            while (c < chunks && bl < MT_NB) { a.blk_tensor[bl] = (unsigned char)ti; a.blk_chunk[bl] = c; ++bl; ++c; }
+            while (c < chunks && bl < MT_NB) { a.blk_tensor[bl] = (unsigned char)ti; a.blk_chunk[bl] = (unsigned short)c; ++bl; ++c; }
             ++ti;
         }
     }

@@ -30,6 +30,7 @@ parser.add_argument('--frames', default=256, type=int, help='mel frames per synt
 parser.add_argument('--batch-size', default=None, type=int)
 parser.add_argument('--n-batches', default=1, type=int)
 parser.add_argument('--max-step', default=None, type=int, help='training steps (default: hparas.max_step)')
+parser.add_argument('--save', action='store_true', help='write ckpt/<name>/latest.pth ({model, optimizer, global_step}) after training')
 
 
 def main():

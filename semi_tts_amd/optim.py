@@ -99,8 +99,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if p in self.state and '_step' in self.state[p]:
                     self.state[p]['step'] = torch.tensor(float(self.state[p]['_step']))
         sd = super().state_dict()
-        for st in sd['state'].values():
-            st.pop('_step', None)
+        # the packed state maps to the live per-parameter dicts: return copies without the private counter
+        sd['state'] = {k: {n: v for n, v in st.items() if n != '_step'} for k, st in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):

@@ -37,6 +37,35 @@ class BaseSolver:
         if getattr(self.paras, 'verbose', True):
             print('[INFO]', msg)
 
+    # -- checkpoints: the reference's on-disk format {"model", "optimizer", "global_step"} (src/solver.py:118-135, :203-216)
+    def save_checkpoint(self, f_name, score=0.0):
+        ckpdir = os.path.join(getattr(self.paras, 'ckpdir', 'ckpt/'), self.exp_name)
+        os.makedirs(ckpdir, exist_ok=True)
+        path = os.path.join(ckpdir, f_name)
+        full = {'model': self.model.state_dict(), 'global_step': self.step}
+        if getattr(self, 'optimizer', None) is not None:
+            full['optimizer'] = self.optimizer.get_opt_state_dict()
+        torch.save(full, path)
+        self.verbose('Saved checkpoint (step = %d, score = %.2f) and status @ %s' % (self.step, score, path))
+        return path
+
+    def load_ckpt(self):
+        """load `paras.load` into self.model (and, in training mode, the optimizer state and step counter)"""
+        path = getattr(self.paras, 'load', None)
+        if not path:
+            return False
+        ckpt = torch.load(path, map_location=self.device)
+        missing = self.model.load_state_dict(ckpt['model'], strict=False)
+        if self.mode == 'train':
+            self.step = ckpt.get('global_step', 0)
+            if getattr(self, 'optimizer', None) is not None and 'optimizer' in ckpt:
+                self.optimizer.load_opt_state_dict(ckpt['optimizer'])
+            self.verbose('Load ckpt from %s, restarting at step %d' % (path, self.step))
+        else:
+            self.step = ckpt.get('global_step', 0)
+            self.verbose('Evaluation target = %s (step %d)' % (path, self.step))
+        return missing
+
     def _build_model(self):
         cfg = json.loads(json.dumps(self.config['model']))
         attr = cfg['codebook'].get('phn_attr_pth')
@@ -66,11 +95,7 @@ class SpecgramGenerator(BaseSolver):
     def set_model(self):
         self.model = self._build_model().eval()
         self.n_frames_per_step = self.model.n_frames_per_step
-        if getattr(self.paras, 'load', None):
-            ckpt = torch.load(self.paras.load, map_location=self.device)
-            self.model.load_state_dict(ckpt['model'], strict=False)
-            self.step = ckpt.get('global_step', 0)
-        else:
+        if not self.load_ckpt():
             from .synthetic import load_synthetic
             load_synthetic(self.model, seed=getattr(self.paras, 'seed', 0) + 1234)
         return self
@@ -146,15 +171,11 @@ class TtsTrainer(BaseSolver):
         from .optim import Optimizer
         from .synthetic import load_synthetic
         self.model = self._build_model().train()
-        if getattr(self.paras, 'load', None):
-            ckpt = torch.load(self.paras.load, map_location=self.device)
-            self.model.load_state_dict(ckpt['model'], strict=False)
-            self.step = ckpt.get('global_step', 0)
-        else:
-            load_synthetic(self.model, seed=getattr(self.paras, 'seed', 0) + 1234)
         hp = self.hp
         self.optimizer = Optimizer(self.model.parameters(), hp['optimizer'], hp['lr'], hp['lr_scheduler'],
                                    **{k: hp[k] for k in ('tf_start', 'tf_end', 'tf_step') if k in hp})
+        if not self.load_ckpt():
+            load_synthetic(self.model, seed=getattr(self.paras, 'seed', 0) + 1234)
         from . import parallel
         parallel.broadcast_parameters(self.model)
         return self
@@ -198,6 +219,8 @@ class TtsTrainer(BaseSolver):
                              (self.step, st['loss'], st['grad_norm'], st['lr']))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if getattr(self.paras, 'save', False):
+            self.save_checkpoint('latest.pth', self.log[-1]['loss'] if self.log else 0.0)
         self.verbose('%d steps, %d frames in %.2f s (%.0f frames/s incl. first-step set-up)' %
                      (len(self.log), frames, dt, frames / max(dt, 1e-9)))
         return self.log

@@ -499,3 +499,50 @@ def test_multi_tensor_clip_and_adam_against_torch(dev):
     o2 = FusedAdam(hip, lr=1e-3)
     o2.load_state_dict(sd)
     assert o2.state[hip[0]]['_step'] == 3
+
+
+def test_checkpoint_round_trip_resumes_training(dev, tmp_path):
+    """{"model", "optimizer", "global_step"} (the reference's checkpoint layout, src/solver.py:203-216): train 2 steps,
+    save, reload into a fresh trainer, and the third step must be bit-identical to continuing in place."""
+    from argparse import Namespace
+    from conftest import load_golden
+    from helpers import tiny_vqvae
+    from semi_tts_amd.optim import Optimizer
+    from semi_tts_amd.solver import TtsTrainer
+    W, A, meta = load_golden('train_step_tiny')
+    config = dict(data=dict(audio=meta['audio'], corpus=dict(batch_size=4)), hparas=dict(meta['hparas'], lr_scheduler='fixed'),
+                  model=meta['model'])
+    h = config['hparas']
+    batch = [A[k].to(dev) for k in ('text', 'sid', 'mel', 'linear')]
+
+    def make(load=None):
+        tr = TtsTrainer(config, Namespace(vocab_size=meta['vocab_size'], n_spkr=meta['n_spkr'], verbose=False, max_step=3,
+                                          ckpdir=str(tmp_path), name='rt', load=load), 'train')
+        tr.model = tiny_vqvae(meta, W, dev).train()
+        for mod in tr.model.modules():                 # no dropout: the two runs must see identical arithmetic
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        tr.model.tts.decoder.prenet_dropout = 0.0
+        tr.model.tts.decoder.prenet.apply_dropout = 0.0
+        tr.optimizer = Optimizer(tr.model.parameters(), h['optimizer'], h['lr'], h['lr_scheduler'])
+        if load:
+            tr.load_ckpt()
+        return tr
+    a = make()
+    for _ in range(2):
+        a.train_step(*batch)
+    path = a.save_checkpoint('two.pth', 0.0)
+    ck = torch.load(path, map_location='cpu')
+    assert set(ck) == {'model', 'optimizer', 'global_step'} and ck['global_step'] == 2
+    assert set(ck['optimizer']) == {'state', 'param_groups'}
+    st_a = a.train_step(*batch)
+    b = make(load=path)
+    assert b.step == 2
+    st_b = b.train_step(*batch)
+    assert st_a['loss'] == st_b['loss'] and st_a['grad_norm'] == st_b['grad_norm']
+    sa, sb = a.model.state_dict(), b.model.state_dict()
+    diff = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    # the embedding-table gradients are accumulated with fp32 atomics (order not fixed): last-bit differences only there
+    assert all(k in ('codebook.learnable_table', 'spkr_embed.weight') for k in diff), diff
+    assert all(maxdiff(sa[k], sb[k]) < 1e-6 for k in diff)
+    assert a.optimizer.opt.state[next(iter(a.model.tts.parameters()))]['_step'] == 3

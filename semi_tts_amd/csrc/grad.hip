@@ -21,6 +21,7 @@ struct TnArgs {
     float* part;                                // [Z][N][Cin][KT]
     int Bn, Tin, Tout, Cin, N, KT, pad, pool_prev;
     int M, rows_per_z;
+    int fold;      // few input channels: the taps are folded into the column axis (column = ci*KT + tap)
 };
 
 __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
@@ -30,7 +31,9 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * TN_T;
     const int cblocks = (g.Cin + TN_T - 1) / TN_T;
-    const int tap = blockIdx.y / cblocks, c0 = (blockIdx.y - tap * cblocks) * TN_T;
+    const int tap = g.fold ? 0 : blockIdx.y / cblocks;
+    const int c0 = g.fold ? blockIdx.y * TN_T : (blockIdx.y - tap * cblocks) * TN_T;
+    const int ncols = g.fold ? g.Cin * g.KT : g.Cin;
     const int z = blockIdx.z;
     const int mbeg = z * g.rows_per_z, mend = min(g.M, mbeg + g.rows_per_z);
 
@@ -57,6 +60,17 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m >= mend) return v;
         const int b = m / g.Tout, to = m - b * g.Tout;
+        if (g.fold) {          // four consecutive (ci, tap) columns, each its own row shift
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = c0 + sc + j;
+                if (cc >= ncols) continue;
+                const int ci = cc / g.KT, tp = cc - ci * g.KT;
+                const int ti = to + tp - g.pad;
+                if (ti >= 0 && ti < g.Tin) v[j] = g.A[((size_t)b * g.Tin + ti) * g.lda + ci];
+            }
+            return v;
+        }
         const int ti = to + tap - g.pad;
         const int ci = c0 + sc;
         if (ti < 0 || ti >= g.Tin || ci >= g.Cin) return v;
@@ -102,13 +116,15 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int ci = c0 + wn * 32 + nt * 16 + (lane & 15);
-        if (ci >= g.Cin) continue;
+        if (ci >= ncols) continue;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wm * 32 + mt * 16 + 4 * (lane >> 4) + r;
-                if (n < g.N) out[((size_t)n * g.Cin + ci) * g.KT + tap] = acc[mt][nt][r];
+                if (n >= g.N) continue;
+                if (g.fold) out[(size_t)n * ncols + ci] = acc[mt][nt][r];
+                else out[((size_t)n * g.Cin + ci) * g.KT + tap] = acc[mt][nt][r];
             }
     }
 }
@@ -116,9 +132,16 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
 // out[i] (+)= sum_z part[z][i]   (fixed order)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, float* out, size_t n, int Z, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = accumulate ? out[i] : 0.0f;
-        for (int z = 0; z < Z; ++z) s += part[(size_t)z * n + i];
-        out[i] = s;
+        // fixed order: four interleaved running sums (loads of four slabs in flight), then a fixed combination
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 4 <= Z; z += 4) {
+            s0 += part[(size_t)z * n + i]; s1 += part[(size_t)(z + 1) * n + i];
+            s2 += part[(size_t)(z + 2) * n + i]; s3 += part[(size_t)(z + 3) * n + i];
+        }
+        for (; z < Z; ++z) s0 += part[(size_t)z * n + i];
+        const float s = (s0 + s1) + (s2 + s3);
+        out[i] = accumulate ? out[i] + s : s;
     }
 }
 
@@ -320,12 +343,16 @@ inline int blocks_for(size_t n, int cap = 4096) {
 
 }  // namespace
 
+static inline bool tn_fold(int Cin, int KT, int pool_prev) { return Cin < 16 && KT > 1 && !pool_prev; }
+
 extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int N, int KT) {
     const int M = Bn * Tout;
-    const int tiles = ((N + TN_T - 1) / TN_T) * ((Cin + TN_T - 1) / TN_T) * KT;
+    const int colblocks = tn_fold(Cin, KT, 0) ? (Cin * KT + TN_T - 1) / TN_T : ((Cin + TN_T - 1) / TN_T) * KT;
+    const int tiles = ((N + TN_T - 1) / TN_T) * colblocks;
     int Z = (512 + tiles - 1) / tiles;
     const int maxz = (M + 255) / 256;
     if (Z > maxz) Z = maxz;
+    if (Z > 96) Z = 96;          // the slabs are added by one thread per output element
     if (Z < 1) Z = 1;
     return (size_t)Z * N * Cin * KT;
 }
@@ -343,7 +370,9 @@ extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* 
     const size_t per = (size_t)N * Cin * KT;
     const int Z = (int)(st_gemm_wgrad_workspace_floats(Bn, Tout, Cin, N, KT) / per);
     g.rows_per_z = (((g.M + Z - 1) / Z) + TN_BK - 1) / TN_BK * TN_BK;
-    dim3 grid((N + TN_T - 1) / TN_T, ((Cin + TN_T - 1) / TN_T) * KT, Z);
+    // the workspace (hence Z) is sized for the folded layout whenever Cin < 16; a pooled input falls back to the per-tap grid
+    g.fold = tn_fold(Cin, KT, pool_prev) ? 1 : 0;
+    dim3 grid((N + TN_T - 1) / TN_T, g.fold ? (Cin * KT + TN_T - 1) / TN_T : ((Cin + TN_T - 1) / TN_T) * KT, Z);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(tn_kernel, grid, dim3(TN_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();

@@ -56,6 +56,8 @@ def conv_cl_ref(x, w, b, pad, Tout, act, pool_prev=False, res=None, mask=None):
     (2, 33, 70, 65, 3, 1, 'relu', True),       # first projection conv with the fused max-pool
     (4, 20, 16, 130, 1, 0, 'sigmoid', False),  # k=1
     (2, 29, 48, 33, 16, 8, 'tanh', False),     # widest bank conv
+    (6, 43, 2, 32, 31, 15, None, False),       # location conv of the attention: 2 channels, taps folded into columns
+    (3, 20, 5, 70, 3, 1, 'relu', False),       # few channels, ragged
 ])
 def test_conv_backward(dev, B, T, Cin, N, KT, pad, act, pool):
     from semi_tts_amd import autograd as AG

@@ -409,6 +409,8 @@ typedef struct st_decoder_io {
     float* preq_buf; float* pred_buf; int overlap;
     float* gates_q_tape;      /* (steps, B, 4, Q) or NULL (training) */
     float* gates_d_tape;      /* (steps, B, 4, D) or NULL */
+    int pre1_step_floats;     /* > 0: pre1_t16 is a tape of `steps` slots of that many floats (training keeps the prenet
+                               * layer-1 output of every own-output feedback for the backward); 0: one scratch slot */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);
@@ -473,6 +475,19 @@ typedef struct st_decoder_bwd_io {
     float* dcum;                   /* (B,L) scratch, zero on entry */
     float* dhq_attn;               /* (B,Q) scratch */
     float* dgq_t16; float* dgd_t16;   /* st_t16_floats(B, 4Q / 4D) scratch, ZERO on entry; needed with the packed weights */
+    /* own-output feedback (scheduled sampling: step_src[t] == -1 for all rows; unpaired rows: rows >= Bt always):
+     * dec_in_{t+1} = prenet(mel_t) for those rows, so the gradient w.r.t. dec_in_{t+1} flows back into mel_t and the
+     * projection gradient of step t can only be formed inside the loop.  All NULL / 0 for pure teacher forcing. */
+    const int* step_src; int Bt;      /* host array (steps entries) as given to st_decoder_forward */
+    float* dY;                        /* (steps, Bp, r*n_mels+1) [dmel_t | dstop_t]; gets the feedback gradient ADDED */
+    float* dxo_rw;                    /* = dxo, written per step in this mode */
+    const float* wpg_t;               /* [W_proj ; W_gate]^T   (D+E, r*n_mels+1) */
+    const float* pre_w1_t; const float* pre_w0_t;   /* prenet W1^T (P,P), W0^T (r*n_mels, P) */
+    const float* own_mask;            /* (steps, 2, B, P) or NULL */
+    const float* xq_nat;              /* (steps+1, Bp, P+E+Q) un-tiled forward tape (dec_in = first P columns) */
+    const float* pre1_nat;            /* (steps, Bp, P) un-tiled prenet layer-1 outputs */
+    float* d2_tape; float* dp1_tape;  /* (steps, Bp, P) out, zero on entry: gradients at the two prenet layers (-> dW1, dW0) */
+    float* tmp_p; float* tmp_in;      /* (B, P), (B, r*n_mels) scratch */
 } st_decoder_bwd_io;
 int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
 /* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp, r*n_mels+1); NULL = zeros */

@@ -53,7 +53,7 @@ class StDecoderIO(C.Structure):
                 ('cq_tape', C.c_void_p), ('cd_tape', C.c_void_p), ('wcum_tape', C.c_void_p),
                 ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
                 ('zero_row', C.c_void_p), ('preq_buf', C.c_void_p), ('pred_buf', C.c_void_p), ('overlap', C.c_int),
-                ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p)]
+                ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('pre1_step_floats', C.c_int)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -68,7 +68,9 @@ class StDecoderBwdIO(C.Structure):
                 [(n, C.c_void_p) for n in ('dxo', 'dalign', 'dgq', 'dgd', 'dxq', 'dxd', 'dpq', 'ds_tape', 'loc_tape', 'dloc_tape',
                                            'hist_tape', 'dctx_tape', 'dv_tape', 'dcq', 'dcd')] +
                 [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p), ('dgq_t16', C.c_void_p),
-                 ('dgd_t16', C.c_void_p)])
+                 ('dgd_t16', C.c_void_p), ('step_src', C.POINTER(C.c_int)), ('Bt', C.c_int)] +
+                [(n, C.c_void_p) for n in ('dY', 'dxo_rw', 'wpg_t', 'pre_w1_t', 'pre_w0_t', 'own_mask', 'xq_nat', 'pre1_nat',
+                                           'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in')])
 
 
 class StSidePartial(C.Structure):

@@ -235,7 +235,7 @@ class _DecoderFn(Function):
     def forward(ctx, dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, *params):
         mel, align, stop, tapes = dec._run_loop(plan, memory, pm, ada_std, ada_mean, teacher_pre, keep_tapes=True)
         ctx.dec, ctx.plan, ctx.tapes = dec, plan, tapes
-        ctx.save_for_backward(memory, pm, ada_std, ada_mean, teacher_pre, align, *params)
+        ctx.save_for_backward(memory, pm, ada_std, ada_mean, teacher_pre, align, mel, *params)
         return mel, align, stop
 
     @staticmethod
@@ -244,17 +244,17 @@ class _DecoderFn(Function):
         from . import _lib
         from ._lib import StDecoderBwdWeights, StDecoderBwdIO, StDecoderDims
         dec, plan, tapes = ctx.dec, ctx.plan, ctx.tapes
-        memory, pm, ada_std, ada_mean, teacher_pre, align = ctx.saved_tensors[:6]
+        memory, pm, ada_std, ada_mean, teacher_pre, align, mel_fwd = ctx.saved_tensors[:7]
         (pre_w0, pre_w1, q_w_ih, q_w_hh, q_b_ih, q_b_hh, wq, v, wc, wl, d_w_ih, d_w_hh, d_b_ih, d_b_hh,
-         proj_w, proj_b, gate_w, gate_b) = ctx.saved_tensors[6:]
+         proj_w, proj_b, gate_w, gate_b) = ctx.saved_tensors[7:]
         steps, src, Bt = plan['steps'], plan['step_src'], plan['Bt']
         B, L, E = memory.shape
         r, n_mels, P = dec.n_frames_per_step, dec.n_mels, dec.prenet_dim
         Q, D, A, F, K = dec.query_rnn_dim, dec.dec_rnn_dim, dec.attn_dim, dec.n_location_filters, dec.location_kernel_size
-        if Bt != B or any(s < 0 for s in src[:steps - 1]):
-            raise NotImplementedError('decoder backward implements teacher forcing (tf_rate=1, drop_dec_in=0, paired '
-                                      'batches: every shipped training config); scheduled sampling / unpaired rows '
-                                      'feed the own output back and are forward-only for now')
+        if any(s == -2 for s in src[:steps - 1]):
+            raise NotImplementedError('teacher-mean decoder inputs (drop_dec_in > 0) have no backward (no shipped config uses them)')
+        # own-output feedback (scheduled sampling steps / rows without a teacher): the gradient of dec_in_{t+1} flows into mel_t
+        own = Bt != B or any(s == -1 for s in src[:steps - 1])
         dev = memory.device
         f32 = dict(device=dev, dtype=torch.float32)
         lib = _lib.load()
@@ -277,7 +277,10 @@ class _DecoderFn(Function):
                                             ops._p(dY), B, Bp, steps, r, n_mels, ops.stream_handle()), 'st_decoder_pack_dout')
         wpg = torch.cat([proj_w.detach(), gate_w.detach()], 0)             # (in_dim+1, D+E)   parameter layout only
         dY2 = dY.view(-1, in_dim + 1)
-        dxo = ops.gemm(dY2, wpg.t().contiguous())                           # (steps*Bp, D+E)
+        wpg_t = wpg.t().contiguous()
+        # teacher forcing: no step's input depends on an earlier output, so all steps go through proj (+) gate at once;
+        # with own-output feedback the loop forms dxo_t after adding the feedback gradient to dmel_t
+        dxo = torch.zeros(steps * Bp, XOw, **f32) if own else ops.gemm(dY2, wpg_t)          # (steps*Bp, D+E)
 
         z = lambda *shape: torch.zeros(*shape, **f32)
         dgq, dgd = z(steps, Bp, 4 * Q), z(steps, Bp, 4 * D)
@@ -312,6 +315,18 @@ class _DecoderFn(Function):
         io.dcq, io.dcd, io.dcum, io.dhq_attn = ops._p(dcq), ops._p(dcd), ops._p(dcum), ops._p(dhq_attn)
         io.dhist[0], io.dhist[1] = ops._p(dh0), ops._p(dh1)
         io.dgq_t16, io.dgd_t16 = ops._p(dgq_t16), ops._p(dgd_t16)
+        src_arr = (C.c_int * max(steps, 1))(*src)
+        io.step_src, io.Bt = C.cast(src_arr, C.POINTER(C.c_int)), Bt
+        if own:
+            own_mask = plan['masks'][0]
+            pre1_nat = _untile_tape(tapes['pre1'], steps, Bp, kb(P), [(0, P)])
+            d2_tape, dp1_tape = z(steps, Bp, P), z(steps, Bp, P)
+            wt.update(w1=pre_w1.detach().t().contiguous(), w0=pre_w0.detach().t().contiguous())
+            tmp_p, tmp_in = z(B, P), z(B, in_dim)
+            io.dY, io.dxo_rw, io.wpg_t = ops._p(dY), ops._p(dxo), ops._p(wpg_t)
+            io.pre_w1_t, io.pre_w0_t, io.own_mask = ops._p(wt['w1']), ops._p(wt['w0']), ops._p(own_mask)
+            io.xq_nat, io.pre1_nat = ops._p(XQ), ops._p(pre1_nat)
+            io.d2_tape, io.dp1_tape, io.tmp_p, io.tmp_in = ops._p(d2_tape), ops._p(dp1_tape), ops._p(tmp_p), ops._p(tmp_in)
         _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
 
         # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)
@@ -334,6 +349,13 @@ class _DecoderFn(Function):
         _lib.check(lib.st_adain_bwd(ops._p(dxd) + 4 * E, Bp * XDw, XDw, ops._p(XQ) + 4 * (Bp * XQw + P + E), Bp * XQw, XQw,
                                     ops._p(ada_std), ops._p(ada_mean), ops._p(dstd), ops._p(dmean), B, Q, steps,
                                     ops.stream_handle()), 'st_adain_bwd')
+        # prenet weights on the own-output path: dW1 = d2^T pre1, dW0 = dp1^T mel over the steps / rows that fed back
+        dpre_w0 = dpre_w1 = None
+        if own:
+            mel_tb = z(steps, Bp, in_dim)                       # mel_t in (step, utterance) row order
+            ops.copy3d(mel_tb.permute(1, 0, 2)[:B], mel_fwd.view(B, steps, in_dim), B, steps, in_dim)
+            dpre_w1 = ops.gemm_wgrad(d2_tape.view(-1, P), pre1_nat.view(-1, P))
+            dpre_w0 = ops.gemm_wgrad(dp1_tape.view(-1, P), mel_tb.view(-1, in_dim))
         # d prenet(teacher): step t+1 read teacher frame src[t]
         dteacher = None
         if teacher_pre is not None:
@@ -344,11 +366,12 @@ class _DecoderFn(Function):
                     ops.copy3d(dteacher.view(Bt, Tt, P)[:, :steps - 1], dxq[1:steps].permute(1, 0, 2)[:Bt, :, :P], Bt, steps - 1, P)
                 else:
                     for t in range(steps - 1):
-                        ops.copy3d(dteacher[:, src[t]:src[t] + 1], dxq[t + 1:t + 2].permute(1, 0, 2)[:Bt, :, :P], Bt, 1, P,
-                                   accumulate=True)
+                        if src[t] >= 0:
+                            ops.copy3d(dteacher[:, src[t]:src[t] + 1], dxq[t + 1:t + 2].permute(1, 0, 2)[:Bt, :, :P], Bt, 1, P,
+                                       accumulate=True)
         c = lambda t: t.contiguous()
         grads = (None, None, dmem, dpm, dstd, dmean, dteacher,
-                 None, None,                                                      # prenet weights: only via own-output feedback
+                 dpre_w0, dpre_w1,                                                # prenet weights: only via own-output feedback
                  c(dwq_cat[:, :P + E]), c(dwq_cat[:, P + E:]), dbq, dbq.clone(),
                  dwq_attn, dv, dwc, dwl,
                  c(dwd_cat[:, :E + Q]), c(dwd_cat[:, E + Q:]), dbd, dbd.clone(),

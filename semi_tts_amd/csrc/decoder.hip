@@ -83,7 +83,7 @@ int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLa
     const float* m1 = io->prenet_mask ? io->prenet_mask + ((size_t)t * 2 + 0) * BP : nullptr;
     const float* m2 = io->prenet_mask ? io->prenet_mask + ((size_t)t * 2 + 1) * BP : nullptr;
     st_t16_view mel = {io->mel_t16, kb16(in_dim), 0};
-    st_t16_view pre1 = {io->pre1_t16, kb16(d->P), 0};
+    st_t16_view pre1 = {io->pre1_t16 + (size_t)t * io->pre1_step_floats, kb16(d->P), 0};
     int rc = 0;
     if (!layer1_done)
         rc = st_skinny_linear_packed_fwd(io->packed + pl.p0, &mel, 16 * kb16(in_dim), nullptr, ST_ACT_RELU, m1, d->P,
@@ -263,7 +263,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         // 5. mel frames + stop logit (+ prenet layer 1 of the next input when fused)   ref: :282-287
         st_t16_view xo_v = {xo, sv.o_kbs, 0};
         st_t16_view mel_dst = {io->mel_t16, kb16(in_dim), 0};
-        st_t16_view pre1_dst = {io->pre1_t16, kb16(P), 0};
+        st_t16_view pre1_dst = {io->pre1_t16 + (size_t)t * io->pre1_step_floats, kb16(P), 0};
         const bool fuse = d->fuse_pre0 != 0;
         //    side job: early part of the NEXT query LSTM, x = [ctx_t | h_q_t] (both known now)
         st_t16_view xq_early_v = {xq_next, sv.q_kbs, kbP};

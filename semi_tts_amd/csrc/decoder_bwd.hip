@@ -41,6 +41,17 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                  io->dhq_attn,
                  "st_decoder_backward: null output/scratch");
     const int XQ = P + E + Q, XD = E + Q + D, XO = D + E;
+    const int in_dim = d->r * d->n_mels, YW = in_dim + 1;
+    // own-output feedback anywhere in the plan?
+    bool own = false;
+    if (io->step_src)
+        for (int t = 0; t + 1 < steps; ++t) {
+            ST_CHECK_ARG(io->step_src[t] != -2, "st_decoder_backward: teacher-mean inputs (drop_dec_in > 0) have no backward");
+            own = own || io->step_src[t] == -1 || io->Bt < B;
+        }
+    ST_CHECK_ARG(!own || (io->dY && io->dxo_rw && io->wpg_t && io->pre_w1_t && io->pre_w0_t && io->xq_nat && io->pre1_nat &&
+                          io->d2_tape && io->dp1_tape && io->tmp_p && io->tmp_in && io->Bt > 0 && io->Bt <= B),
+                 "st_decoder_backward: own-output feedback needs the prenet tapes / scratch");
     const bool packed = w->q_w_cat_t_p16 && w->d_w_cat_t_p16 && io->dgq_t16 && io->dgd_t16;
     st_t16_view dgq_v = {io->dgq_t16, (4 * Q + 15) >> 4, 0}, dgd_v = {io->dgd_t16, (4 * D + 15) >> 4, 0};
     const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
@@ -58,6 +69,39 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
         float* dhist_cur = io->dhist[t & 1];
         const float* dhist_next = io->dhist[(t + 1) & 1];
 
+        if (own) {
+            // 0. own-output feedback: dec_in_{t+1}[rows] = prenet(mel_t[rows]) -> add its gradient to dmel_t, then
+            //    push [dmel_t | dstop_t] through proj (+) gate (done for all steps at once by the caller otherwise)
+            float* dY = io->dY + (size_t)t * Bp * YW;
+            const int r0 = (t + 1 < steps) ? (io->step_src[t] == -1 ? 0 : io->Bt) : B;      // first own row (B = none)
+            const int nr = B - r0;
+            if (nr > 0) {
+                const size_t BP = (size_t)B * P;
+                const float* m1 = io->own_mask ? io->own_mask + ((size_t)t * 2 + 0) * BP + (size_t)r0 * P : nullptr;
+                const float* m2 = io->own_mask ? io->own_mask + ((size_t)t * 2 + 1) * BP + (size_t)r0 * P : nullptr;
+                float* d2 = io->d2_tape + ((size_t)t * Bp + r0) * P;
+                float* dp1 = io->dp1_tape + ((size_t)t * Bp + r0) * P;
+                rc = st_act_bwd(dxq_next + (size_t)r0 * XQ, XQ, io->xq_nat + ((size_t)(t + 1) * Bp + r0) * XQ, XQ, ST_ACT_RELU,
+                                m2, P, d2, P, nr, P, stream);
+                if (rc) return rc;
+                st_seg sg;
+                sg.x = d2; sg.ldx = P; sg.w = io->pre_w1_t; sg.ldw = P; sg.k = P;
+                rc = st_skinny_linear_fwd(&sg, 1, nullptr, ST_ACT_NONE, nullptr, 0, io->tmp_p, P, 0, nullptr, 0, 0, nr, P, stream);
+                if (rc) return rc;
+                rc = st_act_bwd(io->tmp_p, P, io->pre1_nat + ((size_t)t * Bp + r0) * P, P, ST_ACT_RELU, m1, P, dp1, P, nr, P, stream);
+                if (rc) return rc;
+                sg.x = dp1; sg.ldx = P; sg.w = io->pre_w0_t; sg.ldw = P; sg.k = P;
+                rc = st_skinny_linear_fwd(&sg, 1, nullptr, ST_ACT_NONE, nullptr, 0, io->tmp_in, in_dim, 0, nullptr, 0, 0, nr, in_dim, stream);
+                if (rc) return rc;
+                rc = st_copy3d(dY + (size_t)r0 * YW, YW, YW, io->tmp_in, in_dim, in_dim, nr, 1, in_dim, 1, stream);
+                if (rc) return rc;
+            }
+            st_seg so;
+            so.x = dY; so.ldx = YW; so.w = io->wpg_t; so.ldw = YW; so.k = YW;
+            rc = st_skinny_linear_fwd(&so, 1, nullptr, ST_ACT_NONE, nullptr, 0, io->dxo_rw + (size_t)t * Bp * XO, XO, 0, nullptr, 0, 0,
+                                      B, XO, stream);
+            if (rc) return rc;
+        }
         // a. decoder LSTM pointwise
         rc = st_lstm_cell_bwd_pointwise(dxo, XO, dxd_next + E + Q, XD, nullptr, 0, nullptr,
                                         io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,

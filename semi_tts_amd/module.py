@@ -400,7 +400,9 @@ class Decoder(nn.Module):
         in_dim = r * n_mels
         # T16-tiled step-input tapes (xq = [dec_in|ctx|h_q], xd = [ctx|adapted h_q|h_d], xo = [h_d|ctx]) are
         # handed in zero-filled (pad lanes/rows must be zero); ONE memset covers them all
-        sizes = dict(xq=(steps + 1) * slot[0], xd=(steps + 1) * slot[1], xo=steps * slot[2], pre1=t16(P), melt=t16(in_dim))
+        # training keeps the prenet layer-1 output of every step (own-output feedback needs it in the backward)
+        n_pre1 = steps if keep_tapes else 1
+        sizes = dict(xq=(steps + 1) * slot[0], xd=(steps + 1) * slot[1], xo=steps * slot[2], pre1=n_pre1 * t16(P), melt=t16(in_dim))
         tiled = torch.zeros(sum(sizes.values()), **f32)
         tapes, off = {}, 0
         for k, n in sizes.items():
@@ -434,6 +436,7 @@ class Decoder(nn.Module):
         io.zero_row = ops._p(tapes['zero'])
         io.preq_buf, io.pred_buf, io.overlap = ops._p(tapes['preq']), ops._p(tapes['pred']), int(self.overlap)
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
+        io.pre1_step_floats = t16(P) if keep_tapes else 0
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
         tapes['packed'] = packed

@@ -292,14 +292,16 @@ def _double_masks(masks):
     return [m.double() for m in masks]
 
 
-def test_tacotron2_backward_against_oracle_tiny_golden(dev):
-    """Whole Tacotron2 in training mode (teacher forcing, the reference's recorded dropout masks):
-    every parameter gradient and the input gradients vs float64 autograd through the oracle."""
+@pytest.mark.parametrize('name', ['tts_tiny_train_tf', 'tts_tiny_sched', 'tts_tiny_partial'])
+def test_tacotron2_backward_against_oracle_tiny_golden(dev, name):
+    """Whole Tacotron2 in training mode with the reference's recorded dropout masks and coin flips -- teacher forcing,
+    scheduled sampling (own output fed back on some steps) and a partial-teacher batch (unpaired rows always feed their
+    own output back): every parameter gradient and the input gradients vs float64 autograd through the oracle."""
     from conftest import load_golden
     from helpers import coin_source, masks_to, split_masks, tiny_tacotron
     from oracle import tts_oracle as O
     from semi_tts_amd.module import plan_decode
-    W, A, meta = load_golden('tts_tiny_train_tf')
+    W, A, meta = load_golden(name)
     hp = meta['hp']
     m = tiny_tacotron(meta, W, dev).train()
     txt, spk, teacher = A['txt_embed'], A['spkr_embed'], A['teacher']
@@ -313,7 +315,8 @@ def test_tacotron2_backward_against_oracle_tiny_golden(dev):
     np.random.rand = coin_source(A['coins'])
     try:
         txt_d, spk_d = txt.to(dev).requires_grad_(), spk.to(dev).requires_grad_()
-        mel, lin, align, stop = m(txt_d, None, teacher.to(dev), spk_d, tf_rate=meta['tf_rate'], _masks=masks)
+        mel, lin, align, stop = m(txt_d, None, teacher.to(dev), spk_d, tf_rate=meta['tf_rate'],
+                                  unpair_max_frame=meta['unpair_max_frame'], _masks=masks)
     finally:
         np.random.rand = saved
     douts = [rnd(*mel.shape, seed=1), rnd(*lin.shape, seed=2), rnd(*align.shape, seed=3), rnd(*stop.shape, seed=4)]
@@ -321,11 +324,12 @@ def test_tacotron2_backward_against_oracle_tiny_golden(dev):
 
     def fn(Wd, t, s):
         drop = O.DropoutSource('list', _double_masks(A.get('mask', [])))
-        return O.tacotron2_forward(Wd, t, teacher.double(), s, hp, meta['tf_rate'], None, True, drop, coin_source(A['coins']))
+        return O.tacotron2_forward(Wd, t, teacher.double(), s, hp, meta['tf_rate'], meta['unpair_max_frame'], True, drop,
+                                   coin_source(A['coins']))
     outs, wg, ig = oracle_grads(fn, W, [txt, spk], douts)
     assert maxdiff(mel, outs[0]) < 1e-4 and maxdiff(lin, outs[1]) < 2e-4
     errs = dict(dtxt=relerr(txt_d.grad, ig[0]), dspk=relerr(spk_d.grad, ig[1]))
-    report('tacotron2_backward_tiny', **errs)
+    report('tacotron2_backward_tiny', name=name, **errs)
     assert errs['dtxt'] < 2e-4 and errs['dspk'] < 2e-4
     check_param_grads(m, '', wg, 2e-4, 'tacotron2_backward_tiny')     # fp32 BPTT over 4 steps + BN chains vs float64
 

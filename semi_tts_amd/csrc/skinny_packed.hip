@@ -16,6 +16,10 @@
 // The K loop is software pipelined (loads of group g+1 are in flight during the MFMAs of g).
 #include "st_common.h"
 
+#ifndef PK_PROF
+#define PK_PROF(n)   // phase timestamps, only defined by tools/mb/mb_pk.hip
+#endif
+
 namespace {
 
 constexpr int PK_MAXSEG = 3;
@@ -151,6 +155,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     const int bt0 = by * NB;
     const int BT = (a.B + 15) >> 4;
 
+    PK_PROF(0);
     f32x4 acc[NB];
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) acc[bt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -178,32 +183,39 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
         if (a.mask) e_m = a.mask[(size_t)eb * a.H + u];
         if (a.ha_dst.base) { e_s = a.ada_std[(size_t)eb * a.H + u]; e_mu = a.ada_mean[(size_t)eb * a.H + u]; }
     }
-    if (true) {        // double-buffered groups of TRIP k-blocks (measured faster than one big group for every shape)
+    {   // double-buffered groups of TRIP k-blocks per wave (measured faster than one big group for every shape).
+        // Every workgroup walks the K axis from a different starting group (rotated by its tile index): at any moment
+        // the 256 workgroups then read different lines of the shared activation operand and different HBM channels,
+        // instead of all requesting the same first k-blocks at kernel start.
+        const int G = (KB + STEP - 1) / STEP;                  // groups per wave
+#ifdef PK_NO_ROTATE
+        const int rot = 0;
+#else
+        const int rot = G > 0 ? (int)((unsigned)tile % (unsigned)G) : 0;
+#endif
+        auto kb_of = [&](int g) { int q = g + rot; if (q >= G) q -= G; return q * STEP + wave; };
         PkRegs<NB, TRIP> ra, rb;
-        int kb = wave;
-        if (kb < KB) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb, KB);
-        while (kb < KB) {
-            int kn = kb + STEP;
-            if (kn < KB) pk_load<NB, KW, TRIP>(rb, wp, xp, a.x_kbs, kn, KB);
+        int g = 0;
+        if (g < G) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb_of(0), KB);
+        PK_PROF(1);
+        bool first = true;
+        while (g < G) {
+            if (g + 1 < G) pk_load<NB, KW, TRIP>(rb, wp, xp, a.x_kbs, kb_of(g + 1), KB);
             pk_mma<NB, TRIP>(ra, acc);
-            kb = kn;
-            if (kb >= KB) break;
-            kn = kb + STEP;
-            if (kn < KB) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kn, KB);
+            if (first) { PK_PROF(2); first = false; }
+            ++g;
+            if (g >= G) break;
+            if (g + 1 < G) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb_of(g + 1), KB);
             pk_mma<NB, TRIP>(rb, acc);
-            kb = kn;
-        }
-    } else {           // latency bound (a handful of workgroups): the whole K of a wave in flight at once
-        for (int kb = wave; kb < KB; kb += STEP) {
-            PkRegs<NB, TRIP> ra;
-            pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb, KB);
-            pk_mma<NB, TRIP>(ra, acc);
+            ++g;
         }
     }
 
+    PK_PROF(3);
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) red[(wave * NB + bt) * 64 + lane] = acc[bt];
     __syncthreads();
+    PK_PROF(4);
     if (tid >= NB * 64) return;
     const int btl = tid >> 6;
     f32x4 s = red[btl * 64 + lane];
@@ -235,6 +247,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
             float* gp = a.gates_out + (size_t)b * 4 * H + u;
             gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
         }
+        PK_PROF(5);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

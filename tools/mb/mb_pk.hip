@@ -1,0 +1,46 @@
+// Micro-benchmark (development tool): phase timing of the packed LSTM-cell kernel (pk_kernel<0>) at the decode shapes.
+// hipcc --offload-arch=gfx950 -O3 -o mb_pk mb_pk.hip ../../semi_tts_amd/csrc/runtime.hip
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_prof[256 * 8 * 8];
+#define PK_PROF(n) do { if ((threadIdx.x & 63) == 0) g_prof[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (n)] = __builtin_readcyclecounter(); } while (0)
+#include "../../semi_tts_amd/csrc/skinny_packed.hip"
+#include <cstdio>
+#include <vector>
+#include <cstdlib>
+#include <algorithm>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+int main() {
+    const int B = 32, H = 1024;
+    for (int K : {256, 1792, 2560}) {
+        int ks[1] = {K};
+        size_t wf = st_packed_weight_floats(ks, 1, 4 * H, H), xf = st_t16_floats(B, K), hf = st_t16_floats(B, H);
+        float *w, *x, *h0, *h1, *ha, *c0, *c1, *bi, *bh, *as, *am;
+        CK(hipMalloc(&w, wf * 4)); CK(hipMalloc(&x, xf * 4)); CK(hipMalloc(&h0, hf * 4)); CK(hipMalloc(&h1, hf * 4)); CK(hipMalloc(&ha, hf * 4));
+        CK(hipMalloc(&c0, B * H * 4)); CK(hipMalloc(&c1, B * H * 4)); CK(hipMalloc(&bi, 4 * H * 4)); CK(hipMalloc(&bh, 4 * H * 4));
+        CK(hipMalloc(&as, B * H * 4)); CK(hipMalloc(&am, B * H * 4));
+        CK(hipMemset(w, 0, wf * 4)); CK(hipMemset(x, 0, xf * 4)); CK(hipMemset(c0, 0, B * H * 4)); CK(hipMemset(bi, 0, 16 * H)); CK(hipMemset(bh, 0, 16 * H));
+        CK(hipMemset(as, 0, B * H * 4)); CK(hipMemset(am, 0, B * H * 4)); CK(hipMemset(h0, 0, hf * 4)); CK(hipMemset(h1, 0, hf * 4)); CK(hipMemset(ha, 0, hf * 4));
+        st_t16_view xv = {x, (K + 15) / 16, 0}, d0 = {h0, H / 16, 0}, d1 = {h1, H / 16, 0}, da = {ha, H / 16, 0};
+        auto run = [&] { int rc = st_lstm_cell_packed_fwd(w, 0, 0, &xv, K, bi, bh, nullptr, 0, c0, H, nullptr, &d0, &d1, c1, H, nullptr, as, am, &da, B, H, nullptr);
+            if (rc) { printf("rc=%d %s\n", rc, st_last_error()); exit(1); } };
+        for (int i = 0; i < 5; ++i) run();
+        CK(hipDeviceSynchronize());
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 200; ++i) run();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> hp(256 * 8 * 8);
+        CK(hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_prof), hp.size() * 8));
+        printf("K=%4d: %.2f us/launch (back-to-back, independent).  cycles since the workgroup's own wave-0 start (clocks of different XCDs are not comparable), over 256 workgroups:\n", K, ms * 1e3 / 200);
+        const char* names[6] = {"wave start", "first loads issued", "first group multiplied", "K loop done", "LDS reduce synced", "epilogue done"};
+        for (int n = 1; n < 6; ++n) {
+            std::vector<long long> v;
+            for (int b = 0; b < 256; ++b) v.push_back((long long)(hp[(b * 8 + 0) * 8 + n] - hp[(b * 8 + 0) * 8 + 0]));
+            std::sort(v.begin(), v.end());
+            printf("  %-24s min %7lld  median %7lld  max %7lld\n", names[n], v[0], v[128], v[255]);
+        }
+    }
+    return 0;
+}

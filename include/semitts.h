@@ -409,6 +409,8 @@ typedef struct st_decoder_io {
     float* preq_buf; float* pred_buf; int overlap;
     float* gates_q_tape;      /* (steps, B, 4, Q) or NULL (training) */
     float* gates_d_tape;      /* (steps, B, 4, D) or NULL */
+    int defer_proj;           /* pure teacher forcing only: skip the per-step proj (+) gate launch; the caller computes mel /
+                               * stop for all steps with one GEMM over xo_tape afterwards (mel_out / stop_out untouched) */
     int pre1_step_floats;     /* > 0: pre1_t16 is a tape of `steps` slots of that many floats (training keeps the prenet
                                * layer-1 output of every own-output feedback for the backward); 0: one scratch slot */
 } st_decoder_io;

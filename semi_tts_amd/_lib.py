@@ -53,7 +53,8 @@ class StDecoderIO(C.Structure):
                 ('cq_tape', C.c_void_p), ('cd_tape', C.c_void_p), ('wcum_tape', C.c_void_p),
                 ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
                 ('zero_row', C.c_void_p), ('preq_buf', C.c_void_p), ('pred_buf', C.c_void_p), ('overlap', C.c_int),
-                ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('pre1_step_floats', C.c_int)]
+                ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('defer_proj', C.c_int),
+                ('pre1_step_floats', C.c_int)]
 
 
 class StDecoderBwdWeights(C.Structure):

@@ -210,20 +210,7 @@ def bigru(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
 
 
 # --------------------------------------------------------------------------------------------- decoder loop
-def _untile_tape(flat, slots, Bp, kb_stride, segs):
-    """T16 step tape (slots x [Bp/16][kb_stride][64][4]) -> natural (slots, Bp, sum(k)); segs = [(kb0, k), ...].
-    Consecutive slots are consecutive batch tiles, so one launch per segment un-tiles every step."""
-    import ctypes as C
-    from . import _lib
-    width = sum(k for _, k in segs)
-    out = torch.empty(slots, Bp, width, device=flat.device, dtype=torch.float32)
-    col = 0
-    for kb0, k in segs:
-        v = ops.t16_view(flat, kb_stride, kb0)
-        _lib.check(_lib.load().st_untile_rows(C.byref(v), ops._p(out) + 4 * col, width, slots * Bp, k, ops.stream_handle()),
-                   'st_untile_rows')
-        col += k
-    return out
+_untile_tape = ops.untile_tape
 
 
 class _DecoderFn(Function):
@@ -267,7 +254,9 @@ class _DecoderFn(Function):
         q_kbs, d_kbs, o_kbs = kb(P) + kb(E) + kb(Q), kb(E) + kb(Q) + kb(D), kb(D) + kb(E)
         XQ = _untile_tape(tapes['xq'], steps + 1, Bp, q_kbs, [(0, P), (kb(P), E), (kb(P) + kb(E), Q)])
         XD = _untile_tape(tapes['xd'], steps, Bp, d_kbs, [(0, E), (kb(E), Q), (kb(E) + kb(Q), D)])
-        XO = _untile_tape(tapes['xo'], steps, Bp, o_kbs, [(0, D), (kb(D), E)])
+        XO = tapes.get('xo_nat')
+        if XO is None:
+            XO = _untile_tape(tapes['xo'], steps, Bp, o_kbs, [(0, D), (kb(D), E)])
         hq_all = XQ[1:steps + 1].reshape(-1, XQw)[:, P + E:]               # h_q_t (dropped-out), rows (t, b)
         pq_all = ops.gemm(hq_all, wq)                                       # (steps*Bp, A)
         # output gradients through proj (+) gate for all steps at once

@@ -75,6 +75,21 @@ StepViews step_views(const st_decoder_dims* d) {
     return v;
 }
 
+// dec_in_{s} = teacher frame min(s-1, Tt-1) for every step s = 1..steps-1 and row b < Bt, written straight into the
+// dec_in k-blocks of the xq tape (slot s) in T16 order: one launch instead of one st_tile_rows per step
+__global__ __launch_bounds__(256) void tile_teacher_kernel(const float* teacher_pre, int Tt, float* xq_tape, size_t slot_floats,
+                                                           int q_kbs, int steps, int Bt, int P) {
+    const size_t total = (size_t)(steps - 1) * Bt * P;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % P);
+        const size_t sb = i / P;
+        const int b = (int)(sb % Bt), s = (int)(sb / Bt) + 1;
+        const int frame = s - 1 < Tt ? s - 1 : Tt - 1;
+        const float v = teacher_pre[((size_t)b * Tt + frame) * P + k];
+        xq_tape[(size_t)s * slot_floats + (((size_t)(b >> 4) * q_kbs + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3)] = v;
+    }
+}
+
 int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLayout& pl, const StepViews& sv,
                int t, bool layer1_done, void* stream) {
     // dec_in_{t+1} = prenet(mel_t) for every row                ref: src/module.py:192,:197-198,:205-206
@@ -154,6 +169,14 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         ST_CHECK_ARG(src != -2 || io->teacher_mean, "st_decoder_forward: step_src[%d]=-2 without teacher_mean", t);
         ST_CHECK_ARG(src == -1 || (io->Bt > 0 && io->Bt <= B), "st_decoder_forward: Bt=%d invalid", io->Bt);
     }
+    // pure teacher forcing (every next input is teacher frame min(t, Tt-1), all rows have a teacher): the inputs of all
+    // steps are tiled into the tape up front, and with io->defer_proj the projection is left to the caller (one GEMM
+    // over all steps instead of one launch per step -- no step's input depends on an earlier output)
+    bool pure_tf = io->teacher_pre && io->Bt == B && io->Tt > 0;
+    for (int t = 0; t + 1 < steps && pure_tf; ++t) pure_tf = io->step_src[t] == (t < io->Tt ? t : io->Tt - 1);
+    const bool defer = io->defer_proj != 0;
+    ST_CHECK_ARG(!defer || (pure_tf && !d->fuse_pre0 && io->overlap != 2),
+                 "st_decoder_forward: defer_proj needs pure teacher forcing (and no side jobs)");
     hipStream_t st = (hipStream_t)stream;
     const PackedLayout pl = packed_layout(d);
     const StepViews sv = step_views(d);
@@ -167,6 +190,14 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     ST_HIP(hipMemsetAsync(io->xq_tape, 0, sv.q_floats * sizeof(float), st));
     ST_HIP(hipMemsetAsync(io->xd_tape, 0, sv.d_floats * sizeof(float), st));
 
+    if (pure_tf && steps > 1) {
+        const size_t total = (size_t)(steps - 1) * B * P;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(tile_teacher_kernel, dim3((unsigned)blocks), dim3(256), 0, st, io->teacher_pre, io->Tt, io->xq_tape,
+                           sv.q_floats, sv.q_kbs, steps, B, P);
+        ST_LAUNCH_CHECK();
+    }
     const size_t ldmel = (size_t)steps * in_dim;
     const int ldal = steps * L;
     const int Kq = 16 * sv.q_kbs, Kd = 16 * sv.d_kbs, Ko = 16 * sv.o_kbs;
@@ -265,6 +296,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view mel_dst = {io->mel_t16, kb16(in_dim), 0};
         st_t16_view pre1_dst = {io->pre1_t16 + (size_t)t * io->pre1_step_floats, kb16(P), 0};
         const bool fuse = d->fuse_pre0 != 0;
+        if (defer) continue;         // mel / stop of all steps come from one GEMM over the xo tape (caller)
         //    side job: early part of the NEXT query LSTM, x = [ctx_t | h_q_t] (both known now)
         st_t16_view xq_early_v = {xq_next, sv.q_kbs, kbP};
         st_side_partial sq = {io->packed + pl.q, sv.q_kbs, kbP, &xq_early_v, 16 * (sv.q_kbs - kbP), io->preq_buf, 4 * Q, Q};
@@ -285,7 +317,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                 rc = prenet_own(d, io, pl, sv, t, fuse, stream);
                 if (rc) return rc;
             }
-            if (src >= 0) rc = st_tile_rows(io->teacher_pre + (size_t)src * P, io->Tt * P, &next, io->Bt, P, stream);
+            if (pure_tf) rc = 0;             // tiled for all steps before the loop
+            else if (src >= 0) rc = st_tile_rows(io->teacher_pre + (size_t)src * P, io->Tt * P, &next, io->Bt, P, stream);
             else if (src == -2) rc = st_tile_rows(io->teacher_mean, P, &next, io->Bt, P, stream);
             if (rc) return rc;
         }

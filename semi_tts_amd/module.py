@@ -437,8 +437,23 @@ class Decoder(nn.Module):
         io.preq_buf, io.pred_buf, io.overlap = ops._p(tapes['preq']), ops._p(tapes['pred']), int(self.overlap)
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
         io.pre1_step_floats = t16(P) if keep_tapes else 0
+        # training with pure teacher forcing: no step's input depends on an earlier output, so mel / stop of all steps
+        # come from ONE GEMM over the xo tape after the loop instead of one launch per step
+        pure_tf = teacher_pre is not None and Bt == B and all(step_src[t] == min(t, Tt - 1) for t in range(steps - 1))
+        defer = bool(keep_tapes and pure_tf and self.overlap != 2)
+        io.defer_proj = 1 if defer else 0
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
+        if defer:
+            kb = ops.kb16
+            Bp = ((B + 15) // 16) * 16
+            xo_nat = ops.untile_tape(tapes['xo'], steps, Bp, kb(D) + kb(E), [(0, D), (kb(D), E)])       # [h_d_t | ctx_t]
+            y = ops.gemm(xo_nat.view(-1, D + E), keep[-2], bias=keep[-1]).view(steps, Bp, in_dim + 1)   # proj (+) gate rows
+            yb = y.permute(1, 0, 2)[:B]
+            ops.copy3d(mel.view(B, steps, in_dim), yb[:, :, :in_dim], B, steps, in_dim)
+            for j in range(r):                                                                       # stop.repeat(1, r) :287
+                ops.copy3d(stop.view(B, steps, r)[:, :, j:j + 1], yb[:, :, in_dim:], B, steps, 1)
+            tapes['xo_nat'] = xo_nat
         tapes['packed'] = packed
         tapes.update(pm=pm, ada_std=ada_std, ada_mean=ada_mean, teacher_pre=teacher_pre, masks=(own_mask, q_mask, d_mask),
                      keep=keep, step_src=step_src, slot=slot)

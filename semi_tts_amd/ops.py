@@ -424,6 +424,19 @@ def untile_rows(x_t16, B, K, kb_stride=None, kb0=0):
     return out
 
 
+def untile_tape(flat, slots, Bp, kb_stride, segs):
+    """T16 step tape (slots x [Bp/16][kb_stride][64][4]) -> natural (slots, Bp, sum(k)); segs = [(kb0, k), ...].
+    Consecutive slots are consecutive batch tiles, so one launch per segment un-tiles every step."""
+    width = sum(k for _, k in segs)
+    out = torch.empty(slots, Bp, width, device=flat.device, dtype=torch.float32)
+    col = 0
+    for kb0, k in segs:
+        v = t16_view(flat, kb_stride, kb0)
+        check(_lib.load().st_untile_rows(C.byref(v), _p(out) + 4 * col, width, slots * Bp, k, stream_handle()), 'st_untile_rows')
+        col += k
+    return out
+
+
 def _vp(v):
     return C.byref(v) if v is not None else None
 

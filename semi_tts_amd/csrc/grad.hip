@@ -22,48 +22,55 @@ struct TnArgs {
     int Bn, Tin, Tout, Cin, N, KT, pad, pool_prev;
     int M, rows_per_z;
     int fold;      // few input channels: the taps are folded into the column axis (column = ci*KT + tap)
+    int vecx, vecy;   // rows of dC / A are 16-byte aligned: one 16-byte load per thread instead of four scalar ones
 };
 
+// TM = tile edge (64 or 128): 4 waves as 2x2, each (TM/2) x (TM/2) = (TM/32)^2 MFMA 16x16 tiles.  The 128 tile halves the
+// LDS reads per MFMA (8 ds_read_b128 feed 64 MFMAs instead of 4 feeding 16) and is used when both N and the column
+// count reach 128.
+template <int TM>
 __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
-    __shared__ __attribute__((aligned(16))) float Xs[TN_T * TN_LD];   // [n][m]
-    __shared__ __attribute__((aligned(16))) float Ys[TN_T * TN_LD];   // [ci][m]
+    constexpr int FR = TM / 32;                                            // MFMA tiles per wave and dimension
+    __shared__ __attribute__((aligned(16))) float Xs[TM * TN_LD];   // [n][m]
+    __shared__ __attribute__((aligned(16))) float Ys[TM * TN_LD];   // [ci][m]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * TN_T;
-    const int cblocks = (g.Cin + TN_T - 1) / TN_T;
+    const int n0 = blockIdx.x * TM;
+    const int cblocks = (g.Cin + TM - 1) / TM;
     const int tap = g.fold ? 0 : blockIdx.y / cblocks;
-    const int c0 = g.fold ? blockIdx.y * TN_T : (blockIdx.y - tap * cblocks) * TN_T;
+    const int c0 = g.fold ? blockIdx.y * TM : (blockIdx.y - tap * cblocks) * TM;
     const int ncols = g.fold ? g.Cin * g.KT : g.Cin;
     const int z = blockIdx.z;
     const int mbeg = z * g.rows_per_z, mend = min(g.M, mbeg + g.rows_per_z);
 
-    // staging role: row m_local = tid/16 of the 16-row chunk, 4 consecutive columns
+    // staging role: row m_local = tid/16 of the 16-row chunk, 4 consecutive columns (+64 for the second half of a 128 tile)
     const int sm = tid >> 4, sc = (tid & 15) * 4;
-    f32x4 acc[2][2];
+    f32x4 acc[FR][FR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FR; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto load_x = [&](int m) -> f32x4 {
+    auto load_x = [&](int m, int cofs) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m >= mend) return v;
-        const float* p = g.dC + (size_t)m * g.lddc + g.dcoff + n0 + sc;
-        const int rem = g.N - (n0 + sc);
+        const float* p = g.dC + (size_t)m * g.lddc + g.dcoff + n0 + sc + cofs;
+        const int rem = g.N - (n0 + sc + cofs);
+        if (g.vecx && rem >= 4) return st_ld4(p);
         if (rem > 0) v[0] = p[0];
         if (rem > 1) v[1] = p[1];
         if (rem > 2) v[2] = p[2];
         if (rem > 3) v[3] = p[3];
         return v;
     };
-    auto load_y = [&](int m) -> f32x4 {
+    auto load_y = [&](int m, int cofs) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m >= mend) return v;
         const int b = m / g.Tout, to = m - b * g.Tout;
         if (g.fold) {          // four consecutive (ci, tap) columns, each its own row shift
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int cc = c0 + sc + j;
+                const int cc = c0 + sc + cofs + j;
                 if (cc >= ncols) continue;
                 const int ci = cc / g.KT, tp = cc - ci * g.KT;
                 const int ti = to + tp - g.pad;
@@ -72,10 +79,11 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
             return v;
         }
         const int ti = to + tap - g.pad;
-        const int ci = c0 + sc;
+        const int ci = c0 + sc + cofs;
         if (ti < 0 || ti >= g.Tin || ci >= g.Cin) return v;
         const float* p = g.A + ((size_t)b * g.Tin + ti) * g.lda + ci;
         const int rem = g.Cin - ci;
+        if (g.vecy && rem >= 4 && !g.pool_prev) return st_ld4(p);
         v[0] = p[0];
         if (rem > 1) v[1] = p[1];
         if (rem > 2) v[2] = p[2];
@@ -90,38 +98,49 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
         return v;
     };
 
+    constexpr int NH = TM / 64;                                            // column halves staged per thread
     const int fr = lane & 15, fk = (lane >> 4) * 4;
-    f32x4 rx = load_x(mbeg + sm), ry = load_y(mbeg + sm);
+    f32x4 rx[NH], ry[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { rx[h] = load_x(mbeg + sm, h * 64); ry[h] = load_y(mbeg + sm, h * 64); }
     for (int m = mbeg; m < mend; m += TN_BK) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { Xs[(sc + j) * TN_LD + sm] = rx[j]; Ys[(sc + j) * TN_LD + sm] = ry[j]; }
-        __syncthreads();
-        if (m + TN_BK < mend) { rx = load_x(m + TN_BK + sm); ry = load_y(m + TN_BK + sm); }
-        f32x4 a4[2], b4[2];
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            a4[t] = *reinterpret_cast<const f32x4*>(Xs + (wm * 32 + t * 16 + fr) * TN_LD + fk);
-            b4[t] = *reinterpret_cast<const f32x4*>(Ys + (wn * 32 + t * 16 + fr) * TN_LD + fk);
+            for (int j = 0; j < 4; ++j) {
+                Xs[(h * 64 + sc + j) * TN_LD + sm] = rx[h][j];
+                Ys[(h * 64 + sc + j) * TN_LD + sm] = ry[h][j];
+            }
+        __syncthreads();
+        if (m + TN_BK < mend) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) { rx[h] = load_x(m + TN_BK + sm, h * 64); ry[h] = load_y(m + TN_BK + sm, h * 64); }
+        }
+        f32x4 a4[FR], b4[FR];
+#pragma unroll
+        for (int t = 0; t < FR; ++t) {
+            a4[t] = *reinterpret_cast<const f32x4*>(Xs + (wm * (TM / 2) + t * 16 + fr) * TN_LD + fk);
+            b4[t] = *reinterpret_cast<const f32x4*>(Ys + (wn * (TM / 2) + t * 16 + fr) * TN_LD + fk);
         }
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < FR; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < FR; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
         __syncthreads();
     }
     float* out = g.part + (size_t)z * g.N * g.Cin * g.KT;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int ci = c0 + wn * 32 + nt * 16 + (lane & 15);
+    for (int nt = 0; nt < FR; ++nt) {
+        const int ci = c0 + wn * (TM / 2) + nt * 16 + (lane & 15);
         if (ci >= ncols) continue;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < FR; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wm * 32 + mt * 16 + 4 * (lane >> 4) + r;
+                const int n = n0 + wm * (TM / 2) + mt * 16 + 4 * (lane >> 4) + r;
                 if (n >= g.N) continue;
                 if (g.fold) out[(size_t)n * ncols + ci] = acc[mt][nt][r];
                 else out[((size_t)n * g.Cin + ci) * g.KT + tap] = acc[mt][nt][r];
@@ -345,10 +364,13 @@ inline int blocks_for(size_t n, int cap = 4096) {
 
 static inline bool tn_fold(int Cin, int KT, int pool_prev) { return Cin < 16 && KT > 1 && !pool_prev; }
 
+static inline int tn_tile(int Cin, int N, int KT) { return (N >= 128 && Cin >= 128 && !tn_fold(Cin, KT, 0)) ? 128 : TN_T; }
+
 extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int N, int KT) {
     const int M = Bn * Tout;
-    const int colblocks = tn_fold(Cin, KT, 0) ? (Cin * KT + TN_T - 1) / TN_T : ((Cin + TN_T - 1) / TN_T) * KT;
-    const int tiles = ((N + TN_T - 1) / TN_T) * colblocks;
+    const int TM = tn_tile(Cin, N, KT);
+    const int colblocks = tn_fold(Cin, KT, 0) ? (Cin * KT + TM - 1) / TM : ((Cin + TM - 1) / TM) * KT;
+    const int tiles = ((N + TM - 1) / TM) * colblocks;
     int Z = (512 + tiles - 1) / tiles;
     const int maxz = (M + 255) / 256;
     if (Z > maxz) Z = maxz;
@@ -372,9 +394,13 @@ extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* 
     g.rows_per_z = (((g.M + Z - 1) / Z) + TN_BK - 1) / TN_BK * TN_BK;
     // the workspace (hence Z) is sized for the folded layout whenever Cin < 16; a pooled input falls back to the per-tap grid
     g.fold = tn_fold(Cin, KT, pool_prev) ? 1 : 0;
-    dim3 grid((N + TN_T - 1) / TN_T, g.fold ? (Cin * KT + TN_T - 1) / TN_T : ((Cin + TN_T - 1) / TN_T) * KT, Z);
+    g.vecx = st_aligned16(dC) && (lddc % 4 == 0) && (dcoff % 4 == 0);
+    g.vecy = st_aligned16(A) && (lda % 4 == 0);
+    const int TM = tn_tile(Cin, N, KT);
+    dim3 grid((N + TM - 1) / TM, g.fold ? (Cin * KT + TM - 1) / TM : ((Cin + TM - 1) / TM) * KT, Z);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(tn_kernel, grid, dim3(TN_THREADS), 0, st, g);
+    if (TM == 128) hipLaunchKernelGGL((tn_kernel<128>), grid, dim3(TN_THREADS), 0, st, g);
+    else hipLaunchKernelGGL((tn_kernel<64>), grid, dim3(TN_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(per)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
     ST_LAUNCH_CHECK();

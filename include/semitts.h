@@ -259,6 +259,15 @@ int st_act_bwd(const float* dout, int ldd, const float* out, int ldo, int act, c
 int st_bn_bwd(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
               const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
               int M, int N, float* dx, int lddx, int dxoff, float* dw, float* db, int accumulate, float* ws, void* stream);
+/* The two halves of st_bn_bwd, for data-parallel training with synchronised statistics: the caller all-reduces
+ * s (2N floats: sum dyb, sum dyb*xhat over the local rows) across ranks between the calls and passes the global row
+ * count as Mstat (mean / var must then be the global batch statistics too).  ws as for st_bn_bwd. */
+int st_bn_bwd_reduce(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                     const float* x, int ldx, int xoff, const float* mean, const float* var, float eps,
+                     int M, int N, float* s, float* ws, void* stream);
+int st_bn_bwd_apply(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                    const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+                    int M, int N, const float* s, int Mstat, float* dx, int lddx, int dxoff, void* stream);
 /* Highway combine y = H*T + x*(1-T) and its backward dH = dy*T, dT = dy*(H-x), dx_direct = dy*(1-T)
  * ref: src/module.py:551-554 */
 int st_highway_fwd(const float* H, const float* Tgate, const float* x, float* y, size_t total, void* stream);

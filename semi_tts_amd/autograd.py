@@ -76,25 +76,48 @@ def linear(x, w, b=None, act=None, mask=None):
 
 class _BnTrainFn(Function):
     """y = act(BatchNorm1d(x)) with batch statistics over all leading dims (training mode);
-    updates running_mean / running_var in place like nn.BatchNorm1d (unbiased running var)."""
+    updates running_mean / running_var in place like nn.BatchNorm1d (unbiased running var).
+    With parallel.sync_batchnorm() under torch.distributed the statistics are those of the global batch."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, run_mean, run_var, eps, momentum, act):
+        from . import parallel
         x = x.contiguous()
         N = x.shape[-1]
         x2 = _rows(x)
-        mean, var = ops.bn_stats(x2, 0, N, run_mean, run_var, momentum)
+        M = x2.shape[0]
+        sync = parallel.sync_bn_active()
+        mean, var = ops.bn_stats(x2, 0, N, None if sync else run_mean, None if sync else run_var, momentum)
+        Mstat = M
+        if sync:
+            # merge the per-rank (count, mean, M2) exactly (Chan et al.); N-vectors only, two small all-reduces
+            buf = torch.cat([mean * M, mean.new_tensor([float(M)])])
+            parallel.all_reduce_sum_(buf)
+            Mstat = int(round(float(buf[-1])))
+            gmean = buf[:-1] / Mstat
+            m2 = var * M + (mean - gmean) ** 2 * M
+            parallel.all_reduce_sum_(m2)
+            mean, var = gmean, m2 / Mstat
+            if run_mean is not None:
+                run_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                run_var.mul_(1 - momentum).add_(m2 / max(Mstat - 1, 1), alpha=momentum)
         y = ops.bn_norm(x2, 0, N, mean, var, weight, bias, eps, act).view(x.shape)
         ctx.save_for_backward(x, y if act is not None else None, mean, var, weight)
-        ctx.cfg = (eps, act)
+        ctx.cfg = (eps, act, Mstat, sync)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        from . import parallel
         x, y, mean, var, weight = ctx.saved_tensors
-        eps, act = ctx.cfg
-        dx, dw, db = ops.bn_bwd(_rows(dy.contiguous()), _rows(y) if y is not None else None, act, _rows(x), mean, var,
-                                weight, eps)
+        eps, act, Mstat, sync = ctx.cfg
+        dy2, y2, x2 = _rows(dy.contiguous()), _rows(y) if y is not None else None, _rows(x)
+        N = x2.shape[1]
+        s = ops.bn_bwd_reduce(dy2, y2, act, x2, mean, var, eps)
+        db, dw = s[:N].clone(), s[N:].clone()           # parameter gradients: local sums (averaged over ranks later)
+        if sync:
+            parallel.all_reduce_sum_(s)
+        dx = ops.bn_bwd_apply(dy2, y2, act, x2, mean, var, weight, eps, s, Mstat)
         return dx.view(x.shape), dw, db, None, None, None, None, None
 
 

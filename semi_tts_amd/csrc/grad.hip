@@ -259,9 +259,10 @@ __global__ __launch_bounds__(256) void chunk_final_kernel(const float* part, int
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff,
                                                            int act, const float* x, int ldx, int xoff, const float* mean,
                                                            const float* var, const float* w, float eps, int M, int N,
-                                                           const float* s1, const float* s2, float* dx, int lddx, int dxoff) {
+                                                           const float* s1, const float* s2, float* dx, int lddx, int dxoff,
+                                                           int Mstat) {
     const size_t total = (size_t)M * N;
-    const float invM = 1.0f / (float)M;
+    const float invM = 1.0f / (float)Mstat;     // rows the statistics (and s1, s2) were taken over: > M under SyncBN
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t m = i / N;
         const int n = (int)(i - m * N);
@@ -433,32 +434,53 @@ extern "C" int st_act_bwd(const float* dout, int ldd, const float* out, int ldo,
     return 0;
 }
 
-extern "C" int st_bn_bwd(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
-                         const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
-                         int M, int N, float* dx, int lddx, int dxoff, float* dw, float* db, int accumulate, float* ws,
-                         void* stream) {
+// BatchNorm backward in two halves so that a data-parallel caller can all-reduce the two sums in between (SyncBN):
+//   reduce: s[0:N] = sum_rows dyb, s[N:2N] = sum_rows dyb * xhat      (local rows)
+//   apply:  dx = w/sigma * (dyb - s1/Mstat - xhat * s2/Mstat)          (Mstat = rows behind mean / var / s)
+extern "C" int st_bn_bwd_reduce(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                                const float* x, int ldx, int xoff, const float* mean, const float* var, float eps,
+                                int M, int N, float* s, float* ws, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(dy && x && mean && var && dx && ws && M > 0 && N > 0 && (act == ST_ACT_NONE || y), "st_bn_bwd: bad arguments");
+    ST_CHECK_ARG(dy && x && mean && var && s && ws && M > 0 && N > 0 && (act == ST_ACT_NONE || y), "st_bn_bwd_reduce: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    float* s1 = ws;
-    float* s2 = ws + N;
     float* part = ws + 2 * (size_t)N;
     const int chunks = st_colreduce_chunks(M);
     const int rpc = (M + chunks - 1) / chunks;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, dy, ldd, doff, y, ldy, yoff, act,
                        x, ldx, xoff, mean, var, eps, M, N, rpc, part);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chunk_final_kernel, dim3((2 * N + 255) / 256), dim3(256), 0, st, part, chunks, 2, N, s1, s2, 0);
+    hipLaunchKernelGGL(chunk_final_kernel, dim3((2 * N + 255) / 256), dim3(256), 0, st, part, chunks, 2, N, s, s + N, 0);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, st, dy, ldd, doff, y, ldy, yoff,
-                       act, x, ldx, xoff, mean, var, w, eps, M, N, s1, s2, dx, lddx, dxoff);
+    return 0;
+}
+
+extern "C" int st_bn_bwd_apply(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                               const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+                               int M, int N, const float* s, int Mstat, float* dx, int lddx, int dxoff, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dy && x && mean && var && s && dx && M > 0 && N > 0 && Mstat >= M && (act == ST_ACT_NONE || y), "st_bn_bwd_apply: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, (hipStream_t)stream, dy, ldd, doff, y, ldy, yoff,
+                       act, x, ldx, xoff, mean, var, w, eps, M, N, s, s + N, dx, lddx, dxoff, Mstat);
     ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_bwd(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                         const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+                         int M, int N, float* dx, int lddx, int dxoff, float* dw, float* db, int accumulate, float* ws,
+                         void* stream) {
+    ST_CHECK_ARG(ws, "st_bn_bwd: null workspace");
+    int rc = st_bn_bwd_reduce(dy, ldd, doff, y, ldy, yoff, act, x, ldx, xoff, mean, var, eps, M, N, ws, ws, stream);
+    if (rc) return rc;
+    rc = st_bn_bwd_apply(dy, ldd, doff, y, ldy, yoff, act, x, ldx, xoff, mean, var, w, eps, M, N, ws, M, dx, lddx, dxoff, stream);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
     if (db) {   // d beta = s1, d gamma = s2
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, st, s1, db, (size_t)N, 1, accumulate);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, st, ws, db, (size_t)N, 1, accumulate);
         ST_LAUNCH_CHECK();
     }
     if (dw) {
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, st, s2, dw, (size_t)N, 1, accumulate);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, st, ws + N, dw, (size_t)N, 1, accumulate);
         ST_LAUNCH_CHECK();
     }
     return 0;

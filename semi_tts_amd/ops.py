@@ -338,6 +338,26 @@ def bn_bwd(dy2d, y2d, act, x2d, mean, var, w, eps, need_wb=True):
     return dx, dw, db
 
 
+def bn_bwd_reduce(dy2d, y2d, act, x2d, mean, var, eps):
+    """-> s (2N): [sum dyb, sum dyb * xhat] over the local rows"""
+    M, N = x2d.shape
+    s = torch.empty(2 * N, device=x2d.device, dtype=torch.float32)
+    ws = _colreduce_ws(M, N, x2d.device)
+    check(_lib.load().st_bn_bwd_reduce(_p(dy2d), int(dy2d.stride(0)), 0, _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, 0,
+                                       ACT[act], _p(x2d), int(x2d.stride(0)), 0, _p(mean), _p(var), float(eps), M, N, _p(s), _p(ws),
+                                       stream_handle()), 'st_bn_bwd_reduce')
+    return s
+
+
+def bn_bwd_apply(dy2d, y2d, act, x2d, mean, var, w, eps, s, Mstat):
+    M, N = x2d.shape
+    dx = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    check(_lib.load().st_bn_bwd_apply(_p(dy2d), int(dy2d.stride(0)), 0, _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, 0,
+                                      ACT[act], _p(x2d), int(x2d.stride(0)), 0, _p(mean), _p(var), _p(w), float(eps), M, N, _p(s),
+                                      int(Mstat), _p(dx), N, 0, stream_handle()), 'st_bn_bwd_apply')
+    return dx
+
+
 def highway_fwd(H, Tg, x):
     y = torch.empty_like(x)
     check(_lib.load().st_highway_fwd(_p(H), _p(Tg), _p(x), _p(y), x.numel(), stream_handle()), 'st_highway_fwd')

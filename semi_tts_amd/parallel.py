@@ -45,7 +45,7 @@ def allreduce_gradients(params, bucket_bytes=32 << 20, average=True):
         if not bucket:
             return
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        all_reduce_sum_(flat)
         if average:
             flat /= world
         off = 0
@@ -75,3 +75,30 @@ def broadcast_parameters(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+
+
+# --------------------------------------------------------------------------------------------- synchronised BatchNorm
+_SYNC_BN = False
+
+
+def sync_batchnorm(enabled=True):
+    """Make training-mode BatchNorm use the statistics of the GLOBAL batch (all ranks), like the reference's
+    single-process full batch.  Per layer and step: two small all-reduces in forward (count + weighted
+    means, then the centred second moments) and one in backward (the two sums of the dx formula)."""
+    global _SYNC_BN
+    _SYNC_BN = bool(enabled)
+
+
+def sync_bn_active():
+    return _SYNC_BN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def all_reduce_sum_(t):
+    """in-place SUM all-reduce of a small tensor; device tensors are staged through the host for the gloo backend"""
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t

@@ -1,0 +1,77 @@
+"""Data-parallel training on the HIP path: two processes (one GPU shared, gloo for the tiny collectives so that the test
+runs on a 1-GPU box) each take half of a batch; with synchronised BatchNorm statistics and the bucketed gradient
+all-reduce the averaged gradients must equal the single-process full-batch gradients.  Needs a real MI355X."""
+import os
+
+import pytest
+import torch
+
+from helpers import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dev):
+    from conftest import load_golden
+    from helpers import tiny_tacotron
+    W, A, meta = load_golden('tts_tiny_train_tf')
+    m = tiny_tacotron(meta, W, dev).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.decoder.prenet_dropout = 0.0
+    m.decoder.prenet.apply_dropout = 0.0
+    return m, A, meta
+
+
+def _step(m, A, rows, dev):
+    from semi_tts_amd import autograd as AG
+    txt, spk, teacher = (A[k][rows].to(dev) for k in ('txt_embed', 'spkr_embed', 'teacher'))
+    lin_t = torch.rand(4, teacher.shape[1], 20, generator=torch.Generator().manual_seed(3))[rows].to(dev)
+    mel, lin, _, _ = m(txt, None, teacher, spk, tf_rate=1.0)
+    loss = AG.freq_loss(mel, teacher, 22050, 8) + AG.freq_loss(lin, lin_t, 22050, 8)
+    loss.backward()
+    return float(loss)
+
+
+def _worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from semi_tts_amd import parallel
+    dev = torch.device('cuda:0')
+    m, A, _ = _build(dev)
+    parallel.sync_batchnorm(True)
+    parallel.broadcast_parameters(m)
+    rows = slice(rank * 2, rank * 2 + 2)
+    loss = _step(m, A, rows, dev)
+    n_coll = parallel.allreduce_gradients(m.parameters(), bucket_bytes=64 << 10)     # small buckets: several collectives
+    assert n_coll > 1
+    if rank == 0:
+        torch.save({'loss': loss, 'grads': {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None},
+                    'stats': {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}}, out_path)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_bn_training_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    dev = torch.device('cuda:0')
+    m, A, _ = _build(dev)
+    _step(m, A, slice(0, 4), dev)
+    ref = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
+    ref_stats = {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}
+    out = str(tmp_path / 'dp.pt')
+    mp.spawn(_worker, args=(2, 29517 + os.getpid() % 500, out), nprocs=2, join=True)
+    got = torch.load(out)
+    worst = 0.0
+    for k, g in ref.items():
+        scale = float(g.abs().max())
+        if scale < 1e-9:
+            continue
+        e = maxdiff(got['grads'][k], g) / scale
+        worst = max(worst, e)
+        assert e < 5e-5, (k, e)          # same arithmetic split differently over two ranks (fp32 summation order)
+    for k, v in ref_stats.items():
+        assert maxdiff(got['stats'][k], v) < 1e-5, k
+    print('worst relative gradient difference DP vs single process: %.2e' % worst)

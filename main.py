@@ -45,6 +45,12 @@ def main():
     torch.manual_seed(paras.seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(paras.seed)
+    import os
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:      # one process per GPU (torch.distributed.run), RCCL over xGMI
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     if paras.gen_specgram:
         from semi_tts_amd.solver import SpecgramGenerator as Solver
         mode = 'test'

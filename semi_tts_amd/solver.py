@@ -24,7 +24,7 @@ class BaseSolver:
         self.config, self.paras, self.mode = config, paras, mode
         if not torch.cuda.is_available() or getattr(paras, 'cpu', False):
             raise RuntimeError('the MI355X path needs a GPU (there is no CPU fallback)')
-        self.device = torch.device('cuda')
+        self.device = torch.device('cuda', torch.cuda.current_device())
         self.exp_name = getattr(paras, 'name', None) or 'synthetic'
         self.logdir = os.path.join(getattr(paras, 'logdir', 'log/'), self.exp_name)
         self.step = 0
@@ -177,6 +177,7 @@ class TtsTrainer(BaseSolver):
         if not self.load_ckpt():
             load_synthetic(self.model, seed=getattr(self.paras, 'seed', 0) + 1234)
         from . import parallel
+        parallel.sync_batchnorm(True)        # no-op for a single process; global-batch statistics under torch.distributed
         parallel.broadcast_parameters(self.model)
         return self
 

@@ -204,7 +204,7 @@ class TtsTrainer(BaseSolver):
         else:
             self.optimizer.step()
         self.step += 1
-        return dict(loss=float(total), mel_loss=float(mel_loss), linear_loss=float(linear_loss), grad_norm=gn,
+        return dict(loss=float(total.detach()), mel_loss=float(mel_loss.detach()), linear_loss=float(linear_loss.detach()), grad_norm=gn,
                     tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
 
     def exec(self):

@@ -398,7 +398,7 @@ def test_freq_loss_against_reference_golden(dev):
         from oracle import tts_oracle as O
         pr = pred.double().requires_grad_()
         (O.freq_loss(pr, lab.double(), 22050, 80, kind, True, True) * 3.0).backward()
-        assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+        assert abs(float(loss.detach()) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
         assert relerr(pd.grad, pr.grad) < 1e-5
 
 

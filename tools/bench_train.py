@@ -50,7 +50,7 @@ def main():
         sync(); t3 = time.perf_counter()
         if timed:
             phases['fwd'] += t1 - t0; phases['bwd'] += t2 - t1; phases['opt'] += t3 - t2
-        stats = dict(loss=float(total), grad_norm=float(gn))
+        stats = dict(loss=float(total.detach()), grad_norm=float(gn))
     tot = sum(phases.values())
     frames = mel.shape[0] * mel.shape[1] * a.steps
     print(json.dumps(dict(metric='train_mel_frames_per_sec', value=frames / tot, unit='frames/s', n_gpus=1, steps=a.steps,

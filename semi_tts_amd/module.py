@@ -283,6 +283,7 @@ class Decoder(nn.Module):
         # event dependencies cost more than the ~15 us of overlap they buy: 86.7 vs 68.1 us/step), so off by default
         self.overlap = int(os.environ.get('ST_OVERLAP', '0'))
         self.fuse_prenet = True    # inference: emit prenet layer 1 from the proj/gate launch (fp32 re-association)
+        self.cache_packed = False  # frozen-weight inference: keep the packed weights across forwards
 
     # -- helpers ---------------------------------------------------------------------------------
     def _weights_struct(self, keep, fuse_pre0=False):
@@ -416,10 +417,20 @@ class Decoder(nn.Module):
             tapes['gates_q'] = torch.empty(steps, B, 4, Q, **f32)
             tapes['gates_d'] = torch.empty(steps, B, 4, D, **f32)
 
-        w = self._weights_struct(keep, fuse_pre0)
-        # the six matrices the loop streams every step, packed into MFMA lane order once per forward
-        packed = torch.empty(int(lib.st_decoder_packed_floats(C.byref(dims))), **f32)
-        check(lib.st_decoder_pack(C.byref(w), C.byref(dims), ops._p(packed), ops.stream_handle()), 'st_decoder_pack')
+        # the six matrices the loop streams every step, packed into MFMA lane order: once per forward while the weights
+        # can change (training), once per weight version for frozen-weight inference (`cache_packed`, see
+        # runtime.GraphedDecoder.refresh_weights)
+        cache = self.__dict__.setdefault('_packed_cache', {}) if (self.cache_packed and not self.training) else None
+        ckey = (bool(fuse_pre0), str(dev))
+        if cache is not None and ckey in cache:
+            w, keep_w, packed = cache[ckey]
+            keep.append(keep_w)
+        else:
+            w = self._weights_struct(keep, fuse_pre0)
+            packed = torch.empty(int(lib.st_decoder_packed_floats(C.byref(dims))), **f32)
+            check(lib.st_decoder_pack(C.byref(w), C.byref(dims), ops._p(packed), ops.stream_handle()), 'st_decoder_pack')
+            if cache is not None:
+                cache[ckey] = (w, list(keep), packed)
         io = StDecoderIO()
         src_arr = (C.c_int * max(steps, 1))(*step_src)
         io.memory, io.pm, io.ada_std, io.ada_mean = ops._p(memory), ops._p(pm), ops._p(ada_std), ops._p(ada_mean)

@@ -35,8 +35,18 @@ class GraphedDecoder:
         with torch.no_grad():
             return self.decoder(self.memory, None, self.frames, self.spkr, tf_rate=0.0, _masks=masks)
 
+    def refresh_weights(self):
+        """call after the decoder's parameters changed (load_state_dict, an optimiser step): drops the cached packed
+        weights and re-captures"""
+        self.decoder.__dict__.pop('_packed_cache', None)
+        self.graph = None
+        return self.capture()
+
     def capture(self):
         assert not self.decoder.training, 'graph replay is for eval-mode inference'
+        # weights are frozen while a captured graph is replayed: their MFMA-order copy (75 MB read + write per packing) is
+        # made once, outside the graph, instead of on every replay
+        self.decoder.cache_packed = True
         # 1. eager pass: warms the caching allocator with blocks of exactly the sizes the loop needs
         self._run()
         torch.cuda.synchronize()

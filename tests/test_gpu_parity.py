@@ -521,6 +521,16 @@ def test_decode_is_deterministic_and_graph_replay_matches(dev):
     out2 = gd(mem, spk)[0]                               # replay overwrites the same static buffers
     torch.cuda.synchronize()
     assert out2.data_ptr() == out.data_ptr() and torch.equal(out2, a)
+    # the graph replays with the weights packed at capture time; after a weight change refresh_weights() re-packs
+    with torch.no_grad():
+        m.decoder.proj.linear.bias.add_(0.25)
+    gd.refresh_weights()
+    out3 = gd(mem, spk)[0].clone()
+    torch.cuda.synchronize()
+    m.decoder.cache_packed = False
+    with torch.no_grad():
+        c = m.decoder(mem, None, T, spk)[0]
+    assert torch.equal(out3, c) and not torch.equal(out3, a)
 
 
 def test_cpu_tensor_is_refused():

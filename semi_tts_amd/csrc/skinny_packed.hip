@@ -166,23 +166,49 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     const f32x4* wp = a.w + (size_t)tile * a.w_kbs * 64 + lane;
     const f32x4* xp = a.x + (size_t)bt_base * a.x_kbs * 64 + lane;
     constexpr int STEP = KW * TRIP;
+    PK_PROF(6);
     // epilogue operands of the threads that will run the epilogue: requested now, consumed after the
     // K loop, so their latency is hidden behind the weight stream
     const int eb = (bt_base + (tid >> 6)) * 16 + (lane & 15);
     const bool e_on = tid < NB * 64 && eb < a.B && bt_base + (tid >> 6) >= bt0;
-    float e_b[4] = {0.f, 0.f, 0.f, 0.f}, e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
+    // IMPORTANT: every load lands in its own register and nothing is combined before the K loop.  An accumulation
+    // like `e += p[i]` inside `if (p)` forces the wave to WAIT for that load right there (the add sits in the branch),
+    // which serialised ~12 memory round trips (2-4 us) in front of the weight stream of waves 0..NB-1.
+    float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f}, e_pr[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
+    float l_bias[4] = {0.f, 0.f, 0.f, 0.f}, l_m1[4] = {1.f, 1.f, 1.f, 1.f}, l_m2[4] = {1.f, 1.f, 1.f, 1.f};
+    // Branch-free: absent operands are read from a valid dummy address (the weight buffer) and replaced by their neutral
+    // value when they are consumed, so the block is a straight line of independent loads.
+    const float* dummy = reinterpret_cast<const float*>(a.w);
     if (MODE == 0 && e_on) {
         const int u = tile * 4 + (lane >> 4);
+        const float* pbi = a.b_ih ? a.b_ih + u : dummy;
+        const float* pbh = a.b_hh ? a.b_hh + u : dummy;
+        const float* ppr = a.pre ? a.pre + (size_t)eb * a.ldpre + u : dummy;
+        const int sH = a.H;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (a.b_ih) e_b[r] += a.b_ih[r * a.H + u];
-            if (a.b_hh) e_b[r] += a.b_hh[r * a.H + u];
-            if (a.pre) e_b[r] += a.pre[(size_t)eb * a.ldpre + r * a.H + u];
+            e_bi[r] = pbi[a.b_ih ? r * sH : 0];
+            e_bh[r] = pbh[a.b_hh ? r * sH : 0];
+            e_pr[r] = ppr[a.pre ? r * sH : 0];
         }
-        if (a.c_prev) e_c = a.c_prev[(size_t)eb * a.ldc_prev + u];
-        if (a.mask) e_m = a.mask[(size_t)eb * a.H + u];
-        if (a.ha_dst.base) { e_s = a.ada_std[(size_t)eb * a.H + u]; e_mu = a.ada_mean[(size_t)eb * a.H + u]; }
+        e_c = (a.c_prev ? a.c_prev + (size_t)eb * a.ldc_prev + u : dummy)[0];
+        e_m = (a.mask ? a.mask + (size_t)eb * a.H + u : dummy)[0];
+        e_s = (a.ha_dst.base ? a.ada_std + (size_t)eb * a.H + u : dummy)[0];
+        e_mu = (a.ha_dst.base ? a.ada_mean + (size_t)eb * a.H + u : dummy)[0];
     }
+    if (MODE == 1 && e_on) {      // linear epilogue operands (bias, dropout masks) requested up front as well
+        const int nb = tile * 16 + 4 * (lane >> 4);
+        const bool has_m2 = a.mask2 && a.n_split2 > 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nb + r < a.N ? nb + r : a.N - 1;                      // clamped: rows past N are never stored
+            l_bias[r] = (a.bias ? a.bias + n : dummy)[0];
+            l_m1[r] = (a.lmask ? a.lmask + (size_t)eb * a.ldmask + n : dummy)[0];
+            l_m2[r] = (has_m2 && n >= a.n_split2 ? a.mask2 + (size_t)eb * a.ldmask2 + (n - a.n_split2) : dummy)[0];
+        }
+    }
+    PK_PROF(7);
     {   // double-buffered groups of TRIP k-blocks per wave (measured faster than one big group for every shape).
         // Every workgroup walks the K axis from a different starting group (rotated by its tile index): at any moment
         // the 256 workgroups then read different lines of the shared activation operand and different HBM channels,
@@ -234,6 +260,11 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     } else if (MODE == 0) {
         const int H = a.H;
         const int u = tile * 4 + (lane >> 4);
+        float e_b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e_b[r] = ((a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f)) + (a.pre ? e_pr[r] : 0.0f);
+        e_c = a.c_prev ? e_c : 0.0f;
+        e_m = a.mask ? e_m : 1.0f;
         const float gi = st_sigmoid(s[0] + e_b[0]), gf = st_sigmoid(s[1] + e_b[1]);
         const float gg = tanhf(s[2] + e_b[2]), go = st_sigmoid(s[3] + e_b[3]);
         const float c2 = gf * e_c + gi * gg;
@@ -253,13 +284,12 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
         for (int r = 0; r < 4; ++r) {
             const int n = tile * 16 + 4 * (lane >> 4) + r;
             if (n >= a.N) continue;
-            float v = s[r];
-            if (a.bias) v += a.bias[n];
+            float v = s[r] + (a.bias ? l_bias[r] : 0.0f);
             v = st_act(v, a.act);
-            if (a.lmask) v *= a.lmask[(size_t)b * a.ldmask + n];
+            if (a.lmask) v *= l_m1[r];
             if (a.n_split2 > 0 && n >= a.n_split2) {
                 v = st_act(v, a.act2);
-                if (a.mask2) v *= a.mask2[(size_t)b * a.ldmask2 + (n - a.n_split2)];
+                if (a.mask2) v *= l_m2[r];
                 pk_store(a.y3_dst, b, n - a.n_split2, v);
             } else if (a.n_split > 0 && n >= a.n_split) {
                 float* p = a.y2 + (size_t)b * a.ldy2 + (size_t)(n - a.n_split) * a.rep;

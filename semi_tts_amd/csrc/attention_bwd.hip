@@ -168,24 +168,35 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         Wl[aa * F4 + f] = wv; WlT[f * LD + aa] = wv;
     }
     AB_PROF(11);
+    // absent addends are read from a valid dummy address and dropped by a select afterwards: a chain of
+    // `if (p) g += p[i]` makes the wave wait for every load in turn (one memory round trip per addend)
     for (int l = tid; l < L; l += AB_THREADS) {
-        ws[l] = a.w[(size_t)b * a.ld_w + l];
+        const float* dummy = a.w + (size_t)b * a.ld_w + l;
+        const float wv = dummy[0];
+        float dl[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dl[j] = (a.dw_direct[j] ? a.dw_direct[j] + (size_t)b * a.ld_dw[j] + l : dummy)[0];
+        const float gc0 = (a.dcum ? a.dcum + (size_t)b * L + l : dummy)[0];
+        const float gc1 = (a.dcum && a.dcum_add ? a.dcum_add + (size_t)b * a.ld_dcum_add + l : dummy)[0];
+        ws[l] = wv;
         float g = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) if (a.dw_direct[j]) g += a.dw_direct[j][(size_t)b * a.ld_dw[j] + l];
+        for (int j = 0; j < 3; ++j) g += a.dw_direct[j] ? dl[j] : 0.0f;
         if (a.dcum) {   // cum_t = cum_{t-1} + w_t: the total gradient w.r.t. cum_t reaches w_t and is carried to cum_{t-1}
-            float gc = a.dcum[(size_t)b * L + l];
-            if (a.dcum_add) gc += a.dcum_add[(size_t)b * a.ld_dcum_add + l];
+            const float gc = gc0 + (a.dcum_add ? gc1 : 0.0f);
             a.dcum[(size_t)b * L + l] = gc;
             g += gc;
         }
         dws[l] = g;
     }
-    AB_PROF(12);
     for (int e = tid; e < E; e += AB_THREADS) {
+        const float* dummy = a.memory + (size_t)b * L * E + e;
+        float dl[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dl[j] = (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + e : dummy)[0];
         float g = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) if (a.dctx[j]) g += a.dctx[j][(size_t)b * a.ld_dctx[j] + e];
+        for (int j = 0; j < 3; ++j) g += a.dctx[j] ? dl[j] : 0.0f;
         dctx[e] = g;
         a.dctx_t[(size_t)b * E + e] = g;
     }

@@ -204,15 +204,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_pw_kernel(const LstmPwArgs a) {
     const int total = a.B * a.H, H = a.H;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int b = i / H, u = i - b * H;
-        float dh = a.dh0[(size_t)b * a.ld0 + u];
-        if (a.dh1) dh += a.dh1[(size_t)b * a.ld1 + u];
-        if (a.dh2) dh += a.dh2[(size_t)b * a.ld2 + u] * (a.scale2 ? a.scale2[i] : 1.0f);
-        if (a.mask) dh *= a.mask[i];
+        // all operands are requested before any of them is consumed (absent ones read a valid dummy address and are
+        // replaced by their neutral value): a chain of `if (p) dh += p[i]` would wait for every load in turn
+        const float* dummy = a.dh0 + (size_t)b * a.ld0 + u;
+        const float l0 = dummy[0];
+        const float l1 = (a.dh1 ? a.dh1 + (size_t)b * a.ld1 + u : dummy)[0];
+        const float l2 = (a.dh2 ? a.dh2 + (size_t)b * a.ld2 + u : dummy)[0];
+        const float ls = (a.scale2 ? a.scale2 + i : dummy)[0];
+        const float lm = (a.mask ? a.mask + i : dummy)[0];
         const float* gp = a.gates + (size_t)b * 4 * H + u;
         const float gi = gp[0], gf = gp[H], gg = gp[2 * H], go = gp[3 * H];
-        const float tc = tanhf(a.c[(size_t)b * a.ldc + u]);
-        const float cp = a.c_prev ? a.c_prev[(size_t)b * a.ldcp + u] : 0.0f;
-        const float dc = a.dc[i] + dh * go * (1.0f - tc * tc);
+        const float craw = a.c[(size_t)b * a.ldc + u];
+        const float cp_l = (a.c_prev ? a.c_prev + (size_t)b * a.ldcp + u : dummy)[0];
+        const float dc_in = a.dc[i];
+        float dh = l0;
+        if (a.dh1) dh += l1;
+        if (a.dh2) dh += l2 * (a.scale2 ? ls : 1.0f);
+        if (a.mask) dh *= lm;
+        const float tc = tanhf(craw);
+        const float cp = a.c_prev ? cp_l : 0.0f;
+        const float dc = dc_in + dh * go * (1.0f - tc * tc);
         float* dg = a.dgates + (size_t)b * a.ldg + u;
         const float d0 = dc * gg * gi * (1.0f - gi), d1 = dc * cp * gf * (1.0f - gf);
         const float d2 = dc * gi * (1.0f - gg * gg), d3 = dh * tc * go * (1.0f - go);

@@ -72,6 +72,38 @@ __global__ __launch_bounds__(KW * 64) void sk_kernel(const SkArgs a) {
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) acc[bt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // epilogue operands of the threads that run the epilogue: requested now (independent, branch-free loads; absent
+    // operands read a valid dummy address and are dropped by a select when consumed), consumed after the K loop
+    const int eb_ = bbase + (tid >> 6) * 16 + (lane & 15);
+    const bool e_on = tid < NB * 64 && eb_ < a.B;
+    float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f}, e_pr[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_c = 0.f, e_m = 1.f, l_bias[4] = {0.f, 0.f, 0.f, 0.f}, l_m1[4] = {1.f, 1.f, 1.f, 1.f};
+    if (e_on) {
+        const float* dummy = a.seg[0].w;
+        if (MODE == 0) {
+            const int u = tile * 4 + (lane >> 4);
+            const float* pbi = a.b_ih ? a.b_ih + u : dummy;
+            const float* pbh = a.b_hh ? a.b_hh + u : dummy;
+            const float* ppr = a.pre ? a.pre + (size_t)eb_ * a.ldpre + u : dummy;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e_bi[r] = pbi[a.b_ih ? r * a.H : 0];
+                e_bh[r] = pbh[a.b_hh ? r * a.H : 0];
+                e_pr[r] = ppr[a.pre ? r * a.H : 0];
+            }
+            e_c = (a.c_prev ? a.c_prev + (size_t)eb_ * a.ldc_prev + u : dummy)[0];
+            e_m = (a.mask ? a.mask + (size_t)eb_ * a.H + u : dummy)[0];
+        } else {
+            const int nb = tile * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + r < a.N ? nb + r : a.N - 1;
+                l_bias[r] = (a.bias ? a.bias + n : dummy)[0];
+                l_m1[r] = (a.lmask ? a.lmask + (size_t)eb_ * a.ldmask + n : dummy)[0];
+            }
+        }
+    }
+
     int cstart = wave;  // rotates so that waves stay balanced across segments
     for (int s = 0; s < a.nseg; ++s) {
         const float* __restrict__ wp = a.seg[s].w + (size_t)wrow * a.seg[s].ldw;
@@ -131,17 +163,13 @@ __global__ __launch_bounds__(KW * 64) void sk_kernel(const SkArgs a) {
         float g[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = s[r];
-            if (a.b_ih) v += a.b_ih[r * H + u];
-            if (a.b_hh) v += a.b_hh[r * H + u];
-            if (a.pre) v += a.pre[(size_t)b * a.ldpre + r * H + u];
-            g[r] = v;
+            g[r] = s[r] + (((a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f)) + (a.pre ? e_pr[r] : 0.0f));
         }
         const float gi = st_sigmoid(g[0]), gf = st_sigmoid(g[1]), gg = tanhf(g[2]), go = st_sigmoid(g[3]);
-        const float cp = a.c_prev ? a.c_prev[(size_t)b * a.ldc_prev + u] : 0.0f;
+        const float cp = a.c_prev ? e_c : 0.0f;
         const float c2 = gf * cp + gi * gg;
         float h2 = go * tanhf(c2);
-        if (a.mask) h2 *= a.mask[(size_t)b * H + u];
+        if (a.mask) h2 *= e_m;
         a.c_out[(size_t)b * a.ldc + u] = c2;
         a.h_out[(size_t)b * a.ldh + u] = h2;
         if (a.gates_out) {
@@ -153,10 +181,9 @@ __global__ __launch_bounds__(KW * 64) void sk_kernel(const SkArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int n = tile * 16 + 4 * (lane >> 4) + r;
             if (n >= a.N) continue;
-            float v = s[r];
-            if (a.bias) v += a.bias[n];
+            float v = s[r] + (a.bias ? l_bias[r] : 0.0f);
             v = st_act(v, a.act);
-            if (a.lmask) v *= a.lmask[(size_t)b * a.ldmask + n];
+            if (a.lmask) v *= l_m1[r];
             if (a.n_split > 0 && n >= a.n_split) {
                 float* p = a.y2 + (size_t)b * a.ldy2 + (size_t)(n - a.n_split) * a.rep;
                 for (int j = 0; j < a.rep; ++j) p[j] = v;

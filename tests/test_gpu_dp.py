@@ -62,12 +62,20 @@ def test_two_rank_sync_bn_training_equals_single_process(tmp_path):
     ref = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
     ref_stats = {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}
     out = str(tmp_path / 'dp.pt')
-    mp.spawn(_worker, args=(2, 29517 + os.getpid() % 500, out), nprocs=2, join=True)
+    ctx = mp.start_processes(_worker, args=(2, 29517 + os.getpid() % 500, out), nprocs=2, join=False, start_method='spawn')
+    import time
+    deadline = time.time() + 90                 # never hang the suite: a stuck rank is killed and the test fails
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail('data-parallel workers did not finish within 90 s')
     got = torch.load(out)
     worst = 0.0
     for k, g in ref.items():
         scale = float(g.abs().max())
-        if scale < 1e-9:
+        if scale < 1e-6:           # analytically zero (a bias in front of a BatchNorm): fp32 round-off on both sides
+            assert maxdiff(got['grads'][k], g) < 1e-6, k
             continue
         e = maxdiff(got['grads'][k], g) / scale
         worst = max(worst, e)

@@ -26,7 +26,9 @@ namespace {
 constexpr int AT_THREADS = 512;
 constexpr int AT_WAVES = AT_THREADS / 64;
 constexpr int AT_PF = 12;   // encoder-memory rows prefetched into registers per thread
-constexpr int AT_LB = 8;    // positions per wave in the energy phase
+constexpr int AT_LB = 8;    // slots of the folded energy reduction (values a wave reduces at once)
+constexpr int AT_LP = 6;    // positions per wave and round in the energy phase: ceil(43 / 6) = 8 blocks = one per wave, so all
+                            // four SIMDs carry two busy waves (with 8 positions per wave L = 43 gives 6 blocks: two SIMDs idle half the time)
 constexpr int AT_CB = 4;    // positions per thread in the conv phase
 constexpr int AT_WLPF = 4;  // float4 pieces of W_l each thread parks in registers during the conv
 
@@ -53,7 +55,7 @@ __host__ __device__ inline AtLds at_layout(int L, int A, int E, int F, int K) {
     o.wc = p; p += F * 2 * o.kp;                // loc_conv [f][c][kp]
     o.hl = ((L + AT_CB + o.kp + 3) + 3) & ~3;   // padded history length per channel (window of kp + 4)
     o.hs = p; p += 2 * o.hl;
-    o.cf_ld = ((L + AT_LB - 1) / AT_LB) * AT_LB; // conv features [f][l], l padded to the wave block
+    o.cf_ld = ((((L + AT_LP - 1) / AT_LP) * AT_LP + AT_CB + 3) & ~3); // conv features [f][l], l padded to the wave block and the conv's 4-wide stores
     o.cf = p; p += F * o.cf_ld;
     o.e = p; p += ((L + 3) & ~3);               // energies, then softmax weights
     o.part = p; p += 4 * AT_THREADS;            // context partials [group][E]
@@ -116,16 +118,39 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
     }
     // conv filters [f][c][KP] (rows padded to KP so they can be read as float4) and padded history
     const int KP = o.kp;
-    for (int idx = tid; idx < F * 2 * KP; idx += AT_THREADS) {
-        const int row = idx / KP, k = idx - row * KP;
-        Wc[idx] = k < K ? a.loc_conv_w[row * K + k] : 0.0f;
-    }
-    for (int idx = tid; idx < 2 * o.hl; idx += AT_THREADS) {
-        const int c = idx / o.hl, p = idx - c * o.hl;
-        const int l = p - pad;
-        float v = 0.0f;
-        if (l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
-        hs[idx] = v;
+    // (all global loads of this phase are issued before the first LDS store: a load -> store loop costs one memory round
+    // trip per iteration)
+    {
+        const int nwc = F * 2 * KP, nhs = 2 * o.hl;
+        float wcv[4], hv[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + j * AT_THREADS;
+            const int row = idx / KP, k = idx - row * KP;
+            wcv[j] = (idx < nwc && k < K) ? a.loc_conv_w[row * K + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + j * AT_THREADS;
+            const int c = idx / o.hl, p = idx - c * o.hl, l = p - pad;
+            float v = 0.0f;
+            if (idx < nhs && l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
+            hv[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int idx = tid + j * AT_THREADS; if (idx < nwc) Wc[idx] = wcv[j]; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int idx = tid + j * AT_THREADS; if (idx < nhs) hs[idx] = hv[j]; }
+        for (int idx = tid + 4 * AT_THREADS; idx < nwc; idx += AT_THREADS) {      // sizes beyond the register rounds
+            const int row = idx / KP, k = idx - row * KP;
+            Wc[idx] = k < K ? a.loc_conv_w[row * K + k] : 0.0f;
+        }
+        for (int idx = tid + 2 * AT_THREADS; idx < nhs; idx += AT_THREADS) {
+            const int c = idx / o.hl, p = idx - c * o.hl, l = p - pad;
+            float v = 0.0f;
+            if (l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
+            hs[idx] = v;
+        }
     }
     if (a.h_q) {  // AdaIN: relu(W_s s + b) * (h_q - (W_m s + b)), the two Linears are hoisted
         for (int j = tid; j < a.Q; j += AT_THREADS) {
@@ -213,16 +238,16 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
     // ---- P2: energies; a wave owns AT_LB consecutive positions, a lane 4 consecutive dims
     const float* pmb = a.pm + (size_t)b * L * A;
     const float* pqb = a.pq + (size_t)b * A;
-    for (int l0 = wave * AT_LB; l0 < L; l0 += AT_WAVES * AT_LB) {
+    for (int l0 = wave * AT_LP; l0 < L; l0 += AT_WAVES * AT_LP) {
         float esum[AT_LB];
 #pragma unroll
-        for (int j = 0; j < AT_LB; ++j) esum[j] = 0.0f;
+        for (int j = 0; j < AT_LB; ++j) esum[j] = 0.0f;        // slots AT_LP.. stay zero
         for (int a0 = lane * 4; a0 < A; a0 += 256) {
             const int rem = A - a0;
-            f32x4 pm4[AT_LB], pq4, v4;
+            f32x4 pm4[AT_LP], pq4, v4;
             if (VEC) {          // A % 4 == 0 and aligned operands: plain 16-byte loads, no per-lane branches
 #pragma unroll
-                for (int j = 0; j < AT_LB; ++j) {
+                for (int j = 0; j < AT_LP; ++j) {
                     const int l = l0 + j < L ? l0 + j : L - 1;
                     pm4[j] = st_ld4(pmb + (size_t)l * A + a0);
                 }
@@ -230,32 +255,36 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
                 v4 = st_ld4(a.v + a0);
             } else {
 #pragma unroll
-                for (int j = 0; j < AT_LB; ++j) {
+                for (int j = 0; j < AT_LP; ++j) {
                     const int l = l0 + j < L ? l0 + j : L - 1;
                     pm4[j] = st_ld4_guard(pmb + (size_t)l * A + a0, rem);
                 }
                 pq4 = st_ld4_guard(pqb + a0, rem);
                 v4 = st_ld4_guard(a.v + a0, rem);   // zero beyond A: those dims add nothing below
             }
-            f32x4 loc[AT_LB];
+            f32x4 loc[AT_LP];
 #pragma unroll
-            for (int j = 0; j < AT_LB; ++j) loc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < AT_LP; ++j) loc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef AT_ABLATE_FLOOP   // (tools/mb ablation switches; never defined in the product build)
 #pragma unroll 4
             for (int f = 0; f < F; ++f) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wt + f * o.wt_ld + a0);
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cf + f * o.cf_ld + l0);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + f * o.cf_ld + l0 + 4);
+                // l0 is a multiple of 6: 8-byte aligned, three ds_read_b64 cover the six positions
+                typedef __attribute__((ext_vector_type(2))) float f32x2;
+                const f32x2 c01 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0);
+                const f32x2 c23 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0 + 2);
+                const f32x2 c45 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0 + 4);
+                const float cvs[AT_LP] = {c01[0], c01[1], c23[0], c23[1], c45[0], c45[1]};
 #pragma unroll
-                for (int j = 0; j < AT_LB; ++j) {
-                    const float cv = j < 4 ? c0[j & 3] : c1[j & 3];
+                for (int j = 0; j < AT_LP; ++j) {
+                    const float cv = cvs[j];
                     loc[j][0] = fmaf(w4[0], cv, loc[j][0]); loc[j][1] = fmaf(w4[1], cv, loc[j][1]);
                     loc[j][2] = fmaf(w4[2], cv, loc[j][2]); loc[j][3] = fmaf(w4[3], cv, loc[j][3]);
                 }
             }
 #endif
 #pragma unroll
-            for (int j = 0; j < AT_LB; ++j) {
+            for (int j = 0; j < AT_LP; ++j) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     // (processed_query + processed_loc_feat) + processed_memory, module.py:389-390
@@ -271,7 +300,7 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
         }
         // 8 sums over 64 lanes with 10 shuffles: each butterfly step also halves the number of
         // values a lane carries (instead of 8 independent 6-step reductions)
-        static_assert(AT_LB == 8, "the folded reduction below is written for 8 positions per wave");
+        static_assert(AT_LB == 8 && AT_LP <= AT_LB && AT_LP % 2 == 0, "the folded reduction below reduces 8 slots per wave");
         {
             const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0, hi8 = (lane & 8) != 0;
             float r4[4], r2[2];
@@ -292,7 +321,7 @@ __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
             r += __shfl_xor(r, 2, 64);
             r += __shfl_xor(r, 1, 64);
             const int l = l0 + (lane >> 3);      // bits 5,4,3 of the lane select the position
-            if ((lane & 7) == 0 && l < L) es[l] = r;
+            if ((lane & 7) == 0 && (lane >> 3) < AT_LP && l < L) es[l] = r;
         }
     }
     AT_PROF(6);

@@ -122,30 +122,32 @@ __device__ __forceinline__ void pk_store(const PkOut& d, int b, int k, float v) 
 }
 
 template <int NB, int TRIP>
-struct PkRegs { f32x4 w[TRIP]; f32x4 x[TRIP][NB]; };
+struct PkRegs { f32x4 w[TRIP]; f32x4 x[TRIP][NB]; bool ok[TRIP]; };
 
 template <int NB, int KW, int TRIP>
 __device__ __forceinline__ void pk_load(PkRegs<NB, TRIP>& r, const f32x4* wp, const f32x4* xp, int x_kbs, int kb, int KB) {
 #pragma unroll
     for (int t = 0; t < TRIP; ++t) {
         int k = kb + t * KW;
-        k = k < KB ? k : KB - 1;        // clamped duplicate; its weight is zeroed below
-        r.w[t] = wp[(size_t)k * 64];
+        k = k < KB ? k : KB - 1;        // clamped duplicate; its weight is zeroed when it is consumed (pk_mma): touching
+        r.w[t] = wp[(size_t)k * 64];    // the loaded value here would make the wave wait for the load right away
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = xp[((size_t)bt * x_kbs + k) * 64];
-        if (kb + t * KW >= KB) r.w[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r.ok[t] = kb + t * KW < KB;
     }
 }
 
 template <int NB, int TRIP>
 __device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[NB]) {
 #pragma unroll
-    for (int t = 0; t < TRIP; ++t)
+    for (int t = 0; t < TRIP; ++t) {
+        const f32x4 w = r.ok[t] ? r.w[t] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt)
-                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.w[t][cc], r.x[t][bt][cc], acc[bt], 0, 0, 0);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cc], r.x[t][bt][cc], acc[bt], 0, 0, 0);
+    }
 }
 
 // MODE 0: LSTM cell, MODE 1: linear, MODE 2: partial LSTM gate sums (no bias, no cell update)
@@ -167,6 +169,20 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     const f32x4* xp = a.x + (size_t)bt_base * a.x_kbs * 64 + lane;
     constexpr int STEP = KW * TRIP;
     PK_PROF(6);
+    // Double-buffered groups of TRIP k-blocks per wave (measured faster than one big group for every shape).  Every
+    // workgroup walks the K axis from a different starting group (rotated by its tile index): at any moment the 256
+    // workgroups then read different lines of the shared activation operand and different HBM channels, instead of all
+    // requesting the same first k-blocks at kernel start.  The first two groups are requested before anything else.
+    const int G = (KB + STEP - 1) / STEP;                  // groups per wave
+#ifdef PK_NO_ROTATE
+    const int rot = 0;
+#else
+    const int rot = G > 0 ? (int)((unsigned)tile % (unsigned)G) : 0;
+#endif
+    auto kb_of = [&](int gq) { int q = gq + rot; if (q >= G) q -= G; return q * STEP + wave; };
+    PkRegs<NB, TRIP> ra, rb;
+    if (G > 0) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb_of(0), KB);
+    if (G > 1) pk_load<NB, KW, TRIP>(rb, wp, xp, a.x_kbs, kb_of(1), KB);
     // epilogue operands of the threads that will run the epilogue: requested now, consumed after the
     // K loop, so their latency is hidden behind the weight stream
     const int eb = (bt_base + (tid >> 6)) * 16 + (lane & 15);
@@ -209,30 +225,18 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
         }
     }
     PK_PROF(7);
-    {   // double-buffered groups of TRIP k-blocks per wave (measured faster than one big group for every shape).
-        // Every workgroup walks the K axis from a different starting group (rotated by its tile index): at any moment
-        // the 256 workgroups then read different lines of the shared activation operand and different HBM channels,
-        // instead of all requesting the same first k-blocks at kernel start.
-        const int G = (KB + STEP - 1) / STEP;                  // groups per wave
-#ifdef PK_NO_ROTATE
-        const int rot = 0;
-#else
-        const int rot = G > 0 ? (int)((unsigned)tile % (unsigned)G) : 0;
-#endif
-        auto kb_of = [&](int g) { int q = g + rot; if (q >= G) q -= G; return q * STEP + wave; };
-        PkRegs<NB, TRIP> ra, rb;
+    {
         int g = 0;
-        if (g < G) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb_of(0), KB);
         PK_PROF(1);
         bool first = true;
-        while (g < G) {
-            if (g + 1 < G) pk_load<NB, KW, TRIP>(rb, wp, xp, a.x_kbs, kb_of(g + 1), KB);
+        while (g < G) {                                   // ra holds group g, rb group g+1
             pk_mma<NB, TRIP>(ra, acc);
             if (first) { PK_PROF(2); first = false; }
+            if (g + 2 < G) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb_of(g + 2), KB);
             ++g;
             if (g >= G) break;
-            if (g + 1 < G) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb_of(g + 1), KB);
             pk_mma<NB, TRIP>(rb, acc);
+            if (g + 2 < G) pk_load<NB, KW, TRIP>(rb, wp, xp, a.x_kbs, kb_of(g + 2), KB);
             ++g;
         }
     }

@@ -158,6 +158,18 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     const int BT = (a.B + 15) >> 4;
 
     PK_PROF(0);
+    // All kernel arguments the prologue needs are pulled into scalar registers NOW, with one wait: left to itself the
+    // compiler fetches the argument block piecemeal, one scalar-cache round trip (300-500 cycles) in front of each use.
+#define PK_TOUCH(x) asm volatile("" :: "s"(x))
+    PK_TOUCH(a.w); PK_TOUCH(a.x); PK_TOUCH(a.w_kbs); PK_TOUCH(a.x_kbs); PK_TOUCH(a.KB); PK_TOUCH(a.B); PK_TOUCH(a.N); PK_TOUCH(a.H);
+    if (MODE == 0) {
+        PK_TOUCH(a.b_ih); PK_TOUCH(a.b_hh); PK_TOUCH(a.pre); PK_TOUCH(a.ldpre); PK_TOUCH(a.c_prev); PK_TOUCH(a.ldc_prev);
+        PK_TOUCH(a.mask); PK_TOUCH(a.ada_std); PK_TOUCH(a.ada_mean); PK_TOUCH(a.ha_dst.base);
+    }
+    if (MODE == 1) {
+        PK_TOUCH(a.bias); PK_TOUCH(a.lmask); PK_TOUCH(a.ldmask); PK_TOUCH(a.mask2); PK_TOUCH(a.ldmask2); PK_TOUCH(a.n_split2);
+    }
+#undef PK_TOUCH
     f32x4 acc[NB];
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) acc[bt] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -77,6 +77,11 @@ __device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
 template <bool VEC>
 __global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // kernel arguments of the first phases: fetched now, one wait (otherwise one scalar-cache round trip per first use)
+#define AT_TOUCH(x) asm volatile("" :: "s"(x))
+    AT_TOUCH(a.pq); AT_TOUCH(a.pm); AT_TOUCH(a.memory); AT_TOUCH(a.w_prev); AT_TOUCH(a.ld_wprev); AT_TOUCH(a.w_cum_prev);
+    AT_TOUCH(a.loc_conv_w); AT_TOUCH(a.loc_lin_w); AT_TOUCH(a.v); AT_TOUCH(a.L); AT_TOUCH(a.A); AT_TOUCH(a.E); AT_TOUCH(a.F); AT_TOUCH(a.K);
+#undef AT_TOUCH
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;

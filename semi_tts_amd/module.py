@@ -421,7 +421,11 @@ class Decoder(nn.Module):
         # can change (training), once per weight version for frozen-weight inference (`cache_packed`, see
         # runtime.GraphedDecoder.refresh_weights)
         cache = self.__dict__.setdefault('_packed_cache', {}) if (self.cache_packed and not self.training) else None
-        ckey = (bool(fuse_pre0), str(dev))
+        # keyed by the in-place version counters of the decoder's parameters: load_state_dict / an optimiser step bump them,
+        # so a stale packing is never reused by an eager forward (a captured graph still needs refresh_weights())
+        ckey = (bool(fuse_pre0), str(dev), tuple(p._version for p in self.parameters()))
+        if cache is not None and ckey not in cache:
+            cache.clear()
         if cache is not None and ckey in cache:
             w, keep_w, packed = cache[ckey]
             keep.append(keep_w)

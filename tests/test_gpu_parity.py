@@ -527,10 +527,12 @@ def test_decode_is_deterministic_and_graph_replay_matches(dev):
     gd.refresh_weights()
     out3 = gd(mem, spk)[0].clone()
     torch.cuda.synchronize()
-    m.decoder.cache_packed = False
     with torch.no_grad():
-        c = m.decoder(mem, None, T, spk)[0]
-    assert torch.equal(out3, c) and not torch.equal(out3, a)
+        c = m.decoder(mem, None, T, spk)[0].clone()           # eager, served from the packed-weight cache
+        assert torch.equal(out3, c) and not torch.equal(out3, a)
+        m.decoder.proj.linear.bias.sub_(0.25)                 # an in-place weight change invalidates the cache by itself
+        d = m.decoder(mem, None, T, spk)[0]
+    assert torch.equal(d, a)
 
 
 def test_cpu_tensor_is_refused():

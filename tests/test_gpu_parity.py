@@ -522,6 +522,7 @@ def test_decode_is_deterministic_and_graph_replay_matches(dev):
     torch.cuda.synchronize()
     assert out2.data_ptr() == out.data_ptr() and torch.equal(out2, a)
     # the graph replays with the weights packed at capture time; after a weight change refresh_weights() re-packs
+    bias0 = m.decoder.proj.linear.bias.detach().clone()
     with torch.no_grad():
         m.decoder.proj.linear.bias.add_(0.25)
     gd.refresh_weights()
@@ -530,7 +531,7 @@ def test_decode_is_deterministic_and_graph_replay_matches(dev):
     with torch.no_grad():
         c = m.decoder(mem, None, T, spk)[0].clone()           # eager, served from the packed-weight cache
         assert torch.equal(out3, c) and not torch.equal(out3, a)
-        m.decoder.proj.linear.bias.sub_(0.25)                 # an in-place weight change invalidates the cache by itself
+        m.decoder.proj.linear.bias.copy_(bias0)               # an in-place weight change invalidates the cache by itself
         d = m.decoder(mem, None, T, spk)[0]
     assert torch.equal(d, a)
 

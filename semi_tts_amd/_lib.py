@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libsemitts_hip.so')
+LIB_PATH = os.environ.get('ST_LIB_PATH') or os.path.join(HERE, 'lib', 'libsemitts_hip.so')   # ST_LIB_PATH: kernel experiments
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 c_void_p = C.c_void_p

@@ -359,7 +359,7 @@ int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side =
 #ifndef PK_NO_BATCH_SPLIT
     // a small linear (few row tiles) is bound by what ONE compute unit can pull in (its weight tile + the whole activation
     // operand): one batch tile per workgroup halves the activation bytes per workgroup and doubles the workgroups
-    if (MODE == 1 && !side && tiles <= 64 && BT > 1) return pk_launch<MODE, 1>(a, tiles, st, side, side_tiles);
+    if (MODE == 1 && !side && tiles <= 128 && BT > 1) return pk_launch<MODE, 1>(a, tiles, st, side, side_tiles);
 #endif
     if (BT == 1) return pk_launch<MODE, 1>(a, tiles, st, side, side_tiles);
     if (BT == 2) return pk_launch<MODE, 2>(a, tiles, st, side, side_tiles);

@@ -124,15 +124,27 @@ __device__ __forceinline__ void pk_store(const PkOut& d, int b, int k, float v) 
 template <int NB, int TRIP>
 struct PkRegs { f32x4 w[TRIP]; f32x4 x[TRIP][NB]; bool ok[TRIP]; };
 
+typedef __attribute__((ext_vector_type(4))) unsigned int pk_u32x4;
+
+// Loads go through buffer descriptors (SRSRC): base in four scalar registers, the wave-uniform k-block offset in a scalar
+// register, only the lane offset (lane * 16 B) in a vector register -- no 64-bit vector address arithmetic per load.
+struct PkSrc {
+    __amdgpu_buffer_rsrc_t w, x;   // descriptors of the weight tile base / the activation base of this workgroup
+    unsigned voff;                 // lane * 16
+    int x_kbs;
+};
+
 template <int NB, int KW, int TRIP>
-__device__ __forceinline__ void pk_load(PkRegs<NB, TRIP>& r, const f32x4* wp, const f32x4* xp, int x_kbs, int kb, int KB) {
+__device__ __forceinline__ void pk_load(PkRegs<NB, TRIP>& r, const PkSrc& src, int kb, int KB) {
 #pragma unroll
     for (int t = 0; t < TRIP; ++t) {
         int k = kb + t * KW;
         k = k < KB ? k : KB - 1;        // clamped duplicate; its weight is zeroed when it is consumed (pk_mma): touching
-        r.w[t] = wp[(size_t)k * 64];    // the loaded value here would make the wave wait for the load right away
+                                        // the loaded value here would make the wave wait for the load right away
+        r.w[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src.w, src.voff, k * 1024, 0));
 #pragma unroll
-        for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = xp[((size_t)bt * x_kbs + k) * 64];
+        for (int bt = 0; bt < NB; ++bt)
+            r.x[t][bt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src.x, src.voff, (bt * src.x_kbs + k) * 1024, 0));
         r.ok[t] = kb + t * KW < KB;
     }
 }
@@ -153,7 +165,9 @@ __device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[N
 // MODE 0: LSTM cell, MODE 1: linear, MODE 2: partial LSTM gate sums (no bias, no cell update)
 template <int MODE, int NB, int KW, int TRIP>
 __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const int by, f32x4* red) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is wave-uniform: telling the compiler (readfirstlane) keeps every k-block address in scalar registers,
+    // so a load is `global_load v, lane_offset, s[base]` instead of a 64-bit vector address computation per load
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bt0 = by * NB;
     const int BT = (a.B + 15) >> 4;
 
@@ -177,8 +191,11 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     // batch tiles beyond BT alias the last valid ones (their results are discarded)
     const int bt_base = bt0 + NB <= BT ? bt0 : (BT >= NB ? BT - NB : 0);
     const int KB = a.KB;
-    const f32x4* wp = a.w + (size_t)tile * a.w_kbs * 64 + lane;
-    const f32x4* xp = a.x + (size_t)bt_base * a.x_kbs * 64 + lane;
+    PkSrc src;
+    src.w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)tile * a.w_kbs * 64), 0, 0x7fffffff, 0x00020000);
+    src.x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)bt_base * a.x_kbs * 64), 0, 0x7fffffff, 0x00020000);
+    src.voff = (unsigned)lane * 16u;
+    src.x_kbs = a.x_kbs;
     constexpr int STEP = KW * TRIP;
     PK_PROF(6);
     // Double-buffered groups of TRIP k-blocks per wave (measured faster than one big group for every shape).  Every
@@ -193,8 +210,8 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
 #endif
     auto kb_of = [&](int gq) { int q = gq + rot; if (q >= G) q -= G; return q * STEP + wave; };
     PkRegs<NB, TRIP> ra, rb;
-    if (G > 0) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb_of(0), KB);
-    if (G > 1) pk_load<NB, KW, TRIP>(rb, wp, xp, a.x_kbs, kb_of(1), KB);
+    if (G > 0) pk_load<NB, KW, TRIP>(ra, src, kb_of(0), KB);
+    if (G > 1) pk_load<NB, KW, TRIP>(rb, src, kb_of(1), KB);
     // epilogue operands of the threads that will run the epilogue: requested now, consumed after the
     // K loop, so their latency is hidden behind the weight stream
     const int eb = (bt_base + (tid >> 6)) * 16 + (lane & 15);
@@ -244,11 +261,11 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
         while (g < G) {                                   // ra holds group g, rb group g+1
             pk_mma<NB, TRIP>(ra, acc);
             if (first) { PK_PROF(2); first = false; }
-            if (g + 2 < G) pk_load<NB, KW, TRIP>(ra, wp, xp, a.x_kbs, kb_of(g + 2), KB);
+            if (g + 2 < G) pk_load<NB, KW, TRIP>(ra, src, kb_of(g + 2), KB);
             ++g;
             if (g >= G) break;
             pk_mma<NB, TRIP>(rb, acc);
-            if (g + 2 < G) pk_load<NB, KW, TRIP>(rb, wp, xp, a.x_kbs, kb_of(g + 2), KB);
+            if (g + 2 < G) pk_load<NB, KW, TRIP>(rb, src, kb_of(g + 2), KB);
             ++g;
         }
     }

@@ -192,6 +192,18 @@ int st_attn_step_t16_fwd(const float* pq, const float* pm, const float* memory,
                          const float* loc_conv_w, const float* loc_lin_w, const float* v,
                          const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
                          int B, int L, int A, int E, int F, int K, void* stream);
+/* The same step in two launches.  `pre` only needs the PREVIOUS step's attention weights: location conv and
+ * S(b,l,:) = pm(b,l,:) + W_l conv([w_prev; w_cum_prev])(l) -> s_buf (B,L,A); it can run while the rest of the decode step
+ * does (st_skinny_linear_packed_attnpre_fwd runs it as extra workgroups of the proj launch).  `fin` = energies
+ * v . tanh(pq + S), softmax, cumulative weights, context.  (pq + W_l cf) + pm becomes pq + (pm + W_l cf): fp32
+ * re-association only. */
+int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wprev, const float* w_cum_prev,
+                    const float* loc_conv_w, const float* loc_lin_w, float* s_buf,
+                    int B, int L, int A, int F, int K, void* stream);
+int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
+                        float* w_out, int ld_wout, float* w_cum_out, const float* v,
+                        const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
+                        int B, int L, int A, int E, int F, int K, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
  * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) * stride + tap - pad, ci) * W(n, ci, tap) )

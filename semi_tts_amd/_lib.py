@@ -128,6 +128,10 @@ SIGNATURES = {
     'st_skinny_linear_packed_side_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                          I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StSidePartial), P],
     'st_attn_step_t16_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
+    'st_attn_pre_fwd': [P, P, I, P, P, P, P, I, I, I, I, I, P],
+    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
+    'st_attn_pre_fwd': [P, P, I, P, P, P, P, I, I, I, I, I, P],
+    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],

@@ -1,419 +1,34 @@
-// attention.hip -- fused location-sensitive attention step for gfx950 (MI355X).
-//
-// One workgroup (8 wavefronts) per utterance does the whole of Attention.forward for one
-// decode step (ref: src/module.py:371-407 + state update :262-264 [+ AdaIN :267-269]):
-//   P0  issue the coalesced 16-byte loads of the encoder-memory rows this thread needs for
-//       the context (they land while P1-P3 run); stage loc_linear (transposed to [f][a]),
-//       loc_conv and the zero-padded attention history in LDS
-//   P1  location conv  cf[f][l]  (2 -> F channels, K taps): one thread = one filter x 4
-//       consecutive positions (sliding register window, 4 independent accumulators)
-//   P2  energies  e[l] = v . tanh((pq + W_l cf[l]) + pm[l]): one wave = 8 consecutive
-//       positions, each lane owns 4 attention dims; per filter one ds_read_b128 of W_l^T and two
-//       broadcast ds_read_b128 of cf feed 32 FMAs; the processed-memory rows are 1 KiB
-//       coalesced wave loads issued before the filter loop; wave shuffle reduction over dims
-//   P3  softmax over L by wave 0 (shuffle max / sum), alignment + cumulative weights out
-//   P4  context = sum_l w[l] * memory[l][:]   (row groups, LDS cross-group reduction)
-// Everything between the loads and the stores stays in LDS/registers; per step and utterance
-// the kernel reads pm (L*A*4 B) + memory (L*E*4 B) exactly once.
-#include "st_common.h"
-
-#ifndef AT_PROF
-#define AT_PROF(n)   // phase timestamps, only defined by tools/mb/mb_attn.hip
-#endif
+// attention.hip -- launches and C ABI of the fused attention step (device code: attention_body.h)
+#include "attention_body.h"
 
 namespace {
 
-constexpr int AT_THREADS = 512;
-constexpr int AT_WAVES = AT_THREADS / 64;
-constexpr int AT_PF = 12;   // encoder-memory rows prefetched into registers per thread
-constexpr int AT_LB = 8;    // slots of the folded energy reduction (values a wave reduces at once)
-constexpr int AT_LP = 6;    // positions per wave and round in the energy phase: ceil(43 / 6) = 8 blocks = one per wave, so all
-                            // four SIMDs carry two busy waves (with 8 positions per wave L = 43 gives 6 blocks: two SIMDs idle half the time)
-constexpr int AT_CB = 4;    // positions per thread in the conv phase
-constexpr int AT_WLPF = 4;  // float4 pieces of W_l each thread parks in registers during the conv
-
-struct AtArgs {
-    const float* pq; const float* pm; const float* memory;
-    const float* w_prev; int ld_wprev; const float* w_cum_prev;
-    float* w_out; int ld_wout; float* w_cum_out;
-    const float* loc_conv_w; const float* loc_lin_w; const float* v;
-    float* ctx; int ld_ctx; st_t16_view ctx_dst[3];
-    const float* h_q; int ld_hq; const float* ada_std; const float* ada_mean; float* h_adapt; int Q;
-    int B, L, A, E, F, K;
-};
-
-struct AtLds {  // offsets in floats into dynamic LDS
-    int wt, wt_ld, wc, kp, hs, hl, cf, cf_ld, e, part, total;
-};
-
-__host__ __device__ inline AtLds at_layout(int L, int A, int E, int F, int K) {
-    AtLds o;
-    int p = 0;
-    o.wt_ld = ((A + 3) & ~3) + 4;               // row stride of W_l^T: +4 spreads the transposing stores
-    o.wt = p; p += F * o.wt_ld;
-    o.kp = K <= 32 ? 32 : ((K + 3) & ~3);       // filter rows padded so they can be read as float4
-    o.wc = p; p += F * 2 * o.kp;                // loc_conv [f][c][kp]
-    o.hl = ((L + AT_CB + o.kp + 3) + 3) & ~3;   // padded history length per channel (window of kp + 4)
-    o.hs = p; p += 2 * o.hl;
-    o.cf_ld = ((((L + AT_LP - 1) / AT_LP) * AT_LP + AT_CB + 3) & ~3); // conv features [f][l], l padded to the wave block and the conv's 4-wide stores
-    o.cf = p; p += F * o.cf_ld;
-    o.e = p; p += ((L + 3) & ~3);               // energies, then softmax weights
-    o.part = p; p += 4 * AT_THREADS;            // context partials [group][E]
-    o.total = p;
-    return o;
-}
-
-// tanh from one v_exp_f32 and one fast reciprocal: |error| <= ~2e-7 absolute (the energies feed a
-// softmax whose outputs are compared at 1e-5; the accurate tanhf costs ~10x more and was 50% of the kernel)
-__device__ __forceinline__ float at_tanh(float x) {
-    const float t = __expf(-2.0f * fabsf(x));
-    return copysignf(__fdividef(1.0f - t, 1.0f + t), x);
-}
-
-__device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
-    return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
-}
-
-template <bool VEC>
-__global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // kernel arguments of the first phases: fetched now, one wait (otherwise one scalar-cache round trip per first use)
-#define AT_TOUCH(x) asm volatile("" :: "s"(x))
-    AT_TOUCH(a.pq); AT_TOUCH(a.pm); AT_TOUCH(a.memory); AT_TOUCH(a.w_prev); AT_TOUCH(a.ld_wprev); AT_TOUCH(a.w_cum_prev);
-    AT_TOUCH(a.loc_conv_w); AT_TOUCH(a.loc_lin_w); AT_TOUCH(a.v); AT_TOUCH(a.L); AT_TOUCH(a.A); AT_TOUCH(a.E); AT_TOUCH(a.F); AT_TOUCH(a.K);
-#undef AT_TOUCH
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
-    const AtLds o = at_layout(L, A, E, F, K);
-    float* Wt = lds + o.wt;
-    float* Wc = lds + o.wc;
-    float* hs = lds + o.hs;
-    float* cf = lds + o.cf;
-    float* es = lds + o.e;
-    float* part = lds + o.part;
-    const int pad = (K - 1) / 2;
-
-    AT_PROF(0);
-    // ---- P0a: context prefetch (memory rows l = g, g+ng, ...)
-    const int ne4 = E >> 2;                    // E % 4 == 0 checked on the host
-    const int ng = AT_THREADS / ne4;           // row groups (>= 1 checked on the host)
-    const int e4 = tid % ne4, g = tid / ne4;
-    const bool ctx_active = g < ng;
-    const float* memb = a.memory + (size_t)b * L * E;
-    f32x4 mpf[AT_PF];
-#pragma unroll
-    for (int j = 0; j < AT_PF; ++j) {
-        const int l = g + j * ng;
-        mpf[j] = (ctx_active && l < L) ? st_ld4(memb + (size_t)l * E + e4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    AT_PROF(1);
-    // ---- P0b: W_l (A,F) is fetched now (coalesced along f) and parked in registers; it is only
-    // needed by P2, so its transposing LDS stores happen after the conv
-    const bool wl_vec = VEC || ((F & 3) == 0 && st_aligned16(a.loc_lin_w));
-    const int f4n = F >> 2;
-    f32x4 wl4[AT_WLPF];
-    if (wl_vec) {
-#pragma unroll
-        for (int j = 0; j < AT_WLPF; ++j) {
-            const int idx = tid + j * AT_THREADS;
-            wl4[j] = idx < A * f4n ? st_ld4(a.loc_lin_w + (size_t)idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    // conv filters [f][c][KP] (rows padded to KP so they can be read as float4) and padded history
-    const int KP = o.kp;
-    // (all global loads of this phase are issued before the first LDS store: a load -> store loop costs one memory round
-    // trip per iteration)
-    {
-        const int nwc = F * 2 * KP, nhs = 2 * o.hl;
-        float wcv[4], hv[2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = tid + j * AT_THREADS;
-            const int row = idx / KP, k = idx - row * KP;
-            wcv[j] = (idx < nwc && k < K) ? a.loc_conv_w[row * K + k] : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + j * AT_THREADS;
-            const int c = idx / o.hl, p = idx - c * o.hl, l = p - pad;
-            float v = 0.0f;
-            if (idx < nhs && l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
-            hv[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int idx = tid + j * AT_THREADS; if (idx < nwc) Wc[idx] = wcv[j]; }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const int idx = tid + j * AT_THREADS; if (idx < nhs) hs[idx] = hv[j]; }
-        for (int idx = tid + 4 * AT_THREADS; idx < nwc; idx += AT_THREADS) {      // sizes beyond the register rounds
-            const int row = idx / KP, k = idx - row * KP;
-            Wc[idx] = k < K ? a.loc_conv_w[row * K + k] : 0.0f;
-        }
-        for (int idx = tid + 2 * AT_THREADS; idx < nhs; idx += AT_THREADS) {
-            const int c = idx / o.hl, p = idx - c * o.hl, l = p - pad;
-            float v = 0.0f;
-            if (l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
-            hs[idx] = v;
-        }
-    }
-    if (a.h_q) {  // AdaIN: relu(W_s s + b) * (h_q - (W_m s + b)), the two Linears are hoisted
-        for (int j = tid; j < a.Q; j += AT_THREADS) {
-            const size_t q = (size_t)b * a.Q + j;
-            a.h_adapt[q] = a.ada_std[q] * (a.h_q[(size_t)b * a.ld_hq + j] - a.ada_mean[q]);
-        }
-    }
-    AT_PROF(2);
-    __syncthreads();
-    AT_PROF(3);
-
-    // ---- P1: location conv, cf[f][l] = sum_c sum_k Wc[f][c][k] * hist[c][l + k - pad]
-    {
-        const int nlb = (L + AT_CB - 1) / AT_CB;
-        for (int idx = tid; idx < F * nlb; idx += AT_THREADS) {
-            const int f = idx / nlb, l0 = (idx - f * nlb) * AT_CB;
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            if (KP == 32) {
-                // K <= 32: filters and history window are pulled with ds_read_b128 (8 + 9 per channel)
-                // up front, then 32 x 4 FMAs run out of registers
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const f32x4* hq = reinterpret_cast<const f32x4*>(hs + c * o.hl + l0);
-                    const f32x4* wq = reinterpret_cast<const f32x4*>(Wc + (f * 2 + c) * 32);
-                    float h[36], w[32];
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) { const f32x4 t = hq[j]; h[4 * j] = t[0]; h[4 * j + 1] = t[1]; h[4 * j + 2] = t[2]; h[4 * j + 3] = t[3]; }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { const f32x4 t = wq[j]; w[4 * j] = t[0]; w[4 * j + 1] = t[1]; w[4 * j + 2] = t[2]; w[4 * j + 3] = t[3]; }
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) {
-                        acc0 = fmaf(w[k], h[k], acc0); acc1 = fmaf(w[k], h[k + 1], acc1);
-                        acc2 = fmaf(w[k], h[k + 2], acc2); acc3 = fmaf(w[k], h[k + 3], acc3);
-                    }
-                }
-            } else {
-                for (int c = 0; c < 2; ++c) {
-                    const float* h = hs + c * o.hl + l0;
-                    const float* w = Wc + (f * 2 + c) * KP;
-                    float h0 = h[0], h1 = h[1], h2 = h[2];
-#pragma unroll 8
-                    for (int k = 0; k < K; ++k) {
-                        const float h3 = h[k + 3];
-                        const float wk = w[k];
-                        acc0 = fmaf(wk, h0, acc0); acc1 = fmaf(wk, h1, acc1);
-                        acc2 = fmaf(wk, h2, acc2); acc3 = fmaf(wk, h3, acc3);
-                        h0 = h1; h1 = h2; h2 = h3;
-                    }
-                }
-            }
-            float* dst = cf + f * o.cf_ld + l0;   // cf_ld is padded, stores beyond L are harmless
-            dst[0] = acc0;
-            if (l0 + 1 < o.cf_ld) dst[1] = acc1;
-            if (l0 + 2 < o.cf_ld) dst[2] = acc2;
-            if (l0 + 3 < o.cf_ld) dst[3] = acc3;
-        }
-    }
-    // W_l^T into LDS: Wt[f][a] (row stride wt_ld = A4 + 4 spreads the transposing stores over banks)
-    if (wl_vec) {
-#pragma unroll
-        for (int j = 0; j < AT_WLPF; ++j) {
-            const int idx = tid + j * AT_THREADS;
-            if (idx < A * f4n) {
-                const int aa = idx / f4n, f0 = (idx - aa * f4n) * 4;
-                Wt[(f0 + 0) * o.wt_ld + aa] = wl4[j][0]; Wt[(f0 + 1) * o.wt_ld + aa] = wl4[j][1];
-                Wt[(f0 + 2) * o.wt_ld + aa] = wl4[j][2]; Wt[(f0 + 3) * o.wt_ld + aa] = wl4[j][3];
-            }
-        }
-        for (int idx = tid + AT_WLPF * AT_THREADS; idx < A * f4n; idx += AT_THREADS) {
-            const int aa = idx / f4n, f0 = (idx - aa * f4n) * 4;
-            const f32x4 w4 = st_ld4(a.loc_lin_w + (size_t)idx * 4);
-            Wt[(f0 + 0) * o.wt_ld + aa] = w4[0]; Wt[(f0 + 1) * o.wt_ld + aa] = w4[1];
-            Wt[(f0 + 2) * o.wt_ld + aa] = w4[2]; Wt[(f0 + 3) * o.wt_ld + aa] = w4[3];
-        }
-    } else {
-        for (int idx = tid; idx < A * F; idx += AT_THREADS) {
-            const int aa = idx / F, f = idx - aa * F;
-            Wt[f * o.wt_ld + aa] = a.loc_lin_w[idx];
-        }
-    }
-    AT_PROF(4);
-    __syncthreads();
-    AT_PROF(5);
-
-    // ---- P2: energies; a wave owns AT_LB consecutive positions, a lane 4 consecutive dims
-    const float* pmb = a.pm + (size_t)b * L * A;
-    const float* pqb = a.pq + (size_t)b * A;
-    for (int l0 = wave * AT_LP; l0 < L; l0 += AT_WAVES * AT_LP) {
-        float esum[AT_LB];
-#pragma unroll
-        for (int j = 0; j < AT_LB; ++j) esum[j] = 0.0f;        // slots AT_LP.. stay zero
-        for (int a0 = lane * 4; a0 < A; a0 += 256) {
-            const int rem = A - a0;
-            f32x4 pm4[AT_LP], pq4, v4;
-            if (VEC) {          // A % 4 == 0 and aligned operands: plain 16-byte loads, no per-lane branches
-#pragma unroll
-                for (int j = 0; j < AT_LP; ++j) {
-                    const int l = l0 + j < L ? l0 + j : L - 1;
-                    pm4[j] = st_ld4(pmb + (size_t)l * A + a0);
-                }
-                pq4 = st_ld4(pqb + a0);
-                v4 = st_ld4(a.v + a0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < AT_LP; ++j) {
-                    const int l = l0 + j < L ? l0 + j : L - 1;
-                    pm4[j] = st_ld4_guard(pmb + (size_t)l * A + a0, rem);
-                }
-                pq4 = st_ld4_guard(pqb + a0, rem);
-                v4 = st_ld4_guard(a.v + a0, rem);   // zero beyond A: those dims add nothing below
-            }
-            f32x4 loc[AT_LP];
-#pragma unroll
-            for (int j = 0; j < AT_LP; ++j) loc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifndef AT_ABLATE_FLOOP   // (tools/mb ablation switches; never defined in the product build)
-#pragma unroll 4
-            for (int f = 0; f < F; ++f) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wt + f * o.wt_ld + a0);
-                // l0 is a multiple of 6: 8-byte aligned, three ds_read_b64 cover the six positions
-                typedef __attribute__((ext_vector_type(2))) float f32x2;
-                const f32x2 c01 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0);
-                const f32x2 c23 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0 + 2);
-                const f32x2 c45 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0 + 4);
-                const float cvs[AT_LP] = {c01[0], c01[1], c23[0], c23[1], c45[0], c45[1]};
-#pragma unroll
-                for (int j = 0; j < AT_LP; ++j) {
-                    const float cv = cvs[j];
-                    loc[j][0] = fmaf(w4[0], cv, loc[j][0]); loc[j][1] = fmaf(w4[1], cv, loc[j][1]);
-                    loc[j][2] = fmaf(w4[2], cv, loc[j][2]); loc[j][3] = fmaf(w4[3], cv, loc[j][3]);
-                }
-            }
-#endif
-#pragma unroll
-            for (int j = 0; j < AT_LP; ++j) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    // (processed_query + processed_loc_feat) + processed_memory, module.py:389-390
-#ifdef AT_ABLATE_TANH
-                    float t = (pq4[c] + loc[j][c]) + pm4[j][c];
-#else
-                    float t = at_tanh((pq4[c] + loc[j][c]) + pm4[j][c]);
-#endif
-                    if (!VEC) t = c < rem ? t : 0.0f;   // W_l^T pad columns hold garbage
-                    esum[j] = fmaf(v4[c], t, esum[j]);
-                }
-            }
-        }
-        // 8 sums over 64 lanes with 10 shuffles: each butterfly step also halves the number of
-        // values a lane carries (instead of 8 independent 6-step reductions)
-        static_assert(AT_LB == 8 && AT_LP <= AT_LB && AT_LP % 2 == 0, "the folded reduction below reduces 8 slots per wave");
-        {
-            const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0, hi8 = (lane & 8) != 0;
-            float r4[4], r2[2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float send = hi32 ? esum[j] : esum[j + 4];
-                const float keep = hi32 ? esum[j + 4] : esum[j];
-                r4[j] = keep + __shfl_xor(send, 32, 64);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float send = hi16 ? r4[j] : r4[j + 2];
-                const float keep = hi16 ? r4[j + 2] : r4[j];
-                r2[j] = keep + __shfl_xor(send, 16, 64);
-            }
-            float r = (hi8 ? r2[1] : r2[0]) + __shfl_xor(hi8 ? r2[0] : r2[1], 8, 64);
-            r += __shfl_xor(r, 4, 64);
-            r += __shfl_xor(r, 2, 64);
-            r += __shfl_xor(r, 1, 64);
-            const int l = l0 + (lane >> 3);      // bits 5,4,3 of the lane select the position
-            if ((lane & 7) == 0 && (lane >> 3) < AT_LP && l < L) es[l] = r;
-        }
-    }
-    AT_PROF(6);
-    __syncthreads();
-    AT_PROF(7);
-
-    // ---- P3: softmax over L (wave 0), write alignment and cumulative weights
-    if (wave == 0) {
-        float m = -INFINITY;
-        for (int l = lane; l < L; l += 64) m = fmaxf(m, es[l]);
-        m = st_wave_max(m);
-        float s = 0.0f;
-        for (int l = lane; l < L; l += 64) {
-            const float ex = expf(es[l] - m);
-            es[l] = ex;
-            s += ex;
-        }
-        s = st_wave_sum(s);
-        for (int l = lane; l < L; l += 64) {
-            const float w = es[l] / s;
-            es[l] = w;
-            a.w_out[(size_t)b * a.ld_wout + l] = w;
-            a.w_cum_out[(size_t)b * L + l] = w + hs[o.hl + pad + l];   // weights + attn_weights_sum, :264
-        }
-    }
-    AT_PROF(8);
-    __syncthreads();
-    AT_PROF(9);
-
-    // ---- P4: context
-    if (ctx_active) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < AT_PF; ++j) {
-            const int l = g + j * ng;
-            if (l < L) {
-                const float w = es[l];
-                acc[0] = fmaf(w, mpf[j][0], acc[0]); acc[1] = fmaf(w, mpf[j][1], acc[1]);
-                acc[2] = fmaf(w, mpf[j][2], acc[2]); acc[3] = fmaf(w, mpf[j][3], acc[3]);
-            }
-        }
-        for (int l = g + AT_PF * ng; l < L; l += ng) {
-            const f32x4 m4 = st_ld4(memb + (size_t)l * E + e4 * 4);
-            const float w = es[l];
-            acc[0] = fmaf(w, m4[0], acc[0]); acc[1] = fmaf(w, m4[1], acc[1]);
-            acc[2] = fmaf(w, m4[2], acc[2]); acc[3] = fmaf(w, m4[3], acc[3]);
-        }
-        *reinterpret_cast<f32x4*>(part + (size_t)(g * ne4 + e4) * 4) = acc;
-    }
-    AT_PROF(10);
-    __syncthreads();
-    AT_PROF(11);
-    for (int e = tid; e < E; e += AT_THREADS) {
-        float s = 0.0f;
-        for (int gg = 0; gg < ng; ++gg) s += part[gg * E + e];
-        if (a.ctx) a.ctx[(size_t)b * a.ld_ctx + e] = s;
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-            if (a.ctx_dst[d].base) a.ctx_dst[d].base[at_t16_off(b, a.ctx_dst[d].kb0 * 16 + e, a.ctx_dst[d].kb_stride)] = s;
-    }
-    AT_PROF(12);
-}
-
+template <int PART>
 int at_launch(const AtArgs& a, hipStream_t stream) {
     ST_CHECK_ARG(a.B > 0 && a.L > 0 && a.A > 0 && a.E > 0 && a.F > 0 && a.K > 0, "attention step: bad dims");
     ST_CHECK_ARG(a.K % 2 == 1, "attention step: location kernel size %d must be odd", a.K);
     ST_CHECK_ARG(a.E % 4 == 0 && a.E / 4 <= AT_THREADS, "attention step: E=%d must be a multiple of 4 and <= %d", a.E, 4 * AT_THREADS);
-    ST_CHECK_ARG(st_aligned16(a.memory), "attention step: memory must be 16-byte aligned");
+    ST_CHECK_ARG(PART == 1 || st_aligned16(a.memory), "attention step: memory must be 16-byte aligned");
     ST_CHECK_ARG((a.A % 4 != 0) || (st_aligned16(a.pm) && st_aligned16(a.pq) && st_aligned16(a.v)),
                  "attention step: pm/pq/v must be 16-byte aligned");
-    ST_CHECK_ARG(a.ctx || a.ctx_dst[0].base, "attention step: no context output");
+    ST_CHECK_ARG(PART == 1 || a.ctx || a.ctx_dst[0].base, "attention step: no context output");
+    ST_CHECK_ARG(PART == 0 || (a.s_buf && ((a.A % 4 != 0) || st_aligned16(a.s_buf))), "attention step: S buffer missing / unaligned");
     ST_CHECK_ARG(!a.h_q || (a.ada_std && a.ada_mean && a.h_adapt), "attention step: AdaIN pointers");
     const AtLds o = at_layout(a.L, a.A, a.E, a.F, a.K);
     const size_t lds_bytes = (size_t)o.total * sizeof(float);
     ST_CHECK_ARG(lds_bytes <= 160 * 1024, "attention step: L=%d needs %zu B of LDS (> 160 KiB)", a.L, lds_bytes);
-    const bool vec = (a.A % 4 == 0) && (a.F % 4 == 0) && st_aligned16(a.pm) && st_aligned16(a.pq) && st_aligned16(a.v) &&
+    const bool vec = (a.A % 4 == 0) && (a.F % 4 == 0) && st_aligned16(a.pm) && (PART == 1 || (st_aligned16(a.pq) && st_aligned16(a.v))) &&
                      st_aligned16(a.loc_lin_w);
     static bool configured = false;
     if (!configured) {
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel<true>),
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel<true, PART>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel<false>),
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel<false, PART>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    if (vec) hipLaunchKernelGGL(at_kernel<true>, dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
-    else hipLaunchKernelGGL(at_kernel<false>, dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
+    if (vec) hipLaunchKernelGGL((at_kernel<true, PART>), dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((at_kernel<false, PART>), dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -436,7 +51,7 @@ extern "C" int st_attn_step_fwd(const float* pq, const float* pm, const float* m
     a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx;
     a.h_q = h_q; a.ld_hq = ld_hq; a.ada_std = ada_std; a.ada_mean = ada_mean; a.h_adapt = h_adapt; a.Q = Q;
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
-    return at_launch(a, (hipStream_t)stream);
+    return at_launch<0>(a, (hipStream_t)stream);
 }
 
 // decode-loop variant: context written to up to 3 T16 destinations (and optionally natural)
@@ -455,5 +70,35 @@ extern "C" int st_attn_step_t16_fwd(const float* pq, const float* pm, const floa
     a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx;
     for (int d = 0; d < n_ctx_dst; ++d) a.ctx_dst[d] = ctx_dst[d];
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
-    return at_launch(a, (hipStream_t)stream);
+    return at_launch<0>(a, (hipStream_t)stream);
+}
+
+// The step in two parts (see attention_body.h): `pre` needs only the previous step's weights (w_prev, w_cum_prev) and writes
+// S = pm + W_l conv(hist); `fin` needs the processed query and S.  pre(t+1) can run any time after fin(t).
+extern "C" int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wprev, const float* w_cum_prev,
+                               const float* loc_conv_w, const float* loc_lin_w, float* s_buf,
+                               int B, int L, int A, int F, int K, void* stream) {
+    (void)hipGetLastError();
+    AtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pm = pm; a.w_prev = w_prev; a.ld_wprev = ld_wprev; a.w_cum_prev = w_cum_prev;
+    a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.s_buf = s_buf;
+    a.B = B; a.L = L; a.A = A; a.E = 4; a.F = F; a.K = K;
+    return at_launch<1>(a, (hipStream_t)stream);
+}
+
+extern "C" int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
+                                   float* w_out, int ld_wout, float* w_cum_out, const float* v,
+                                   const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
+                                   int B, int L, int A, int E, int F, int K, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(n_ctx_dst >= 0 && n_ctx_dst <= 3 && (n_ctx_dst == 0 || ctx_dst), "st_attn_fin_t16_fwd: n_ctx_dst=%d", n_ctx_dst);
+    AtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pq = pq; a.pm = s_buf; a.s_buf = const_cast<float*>(s_buf); a.memory = memory; a.w_cum_prev = w_cum_prev;
+    a.w_out = w_out; a.ld_wout = ld_wout; a.w_cum_out = w_cum_out; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx;
+    a.loc_lin_w = s_buf;     // (unused by this part; only its alignment is looked at)
+    for (int d = 0; d < n_ctx_dst; ++d) a.ctx_dst[d] = ctx_dst[d];
+    a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
+    return at_launch<2>(a, (hipStream_t)stream);
 }

@@ -110,6 +110,25 @@ def attn_step(pq, pm, memory, w_prev, w_cum_prev, w_out, w_cum_out, loc_conv_w, 
           'st_attn_step_fwd')
 
 
+def attn_pre(pm, w_prev, w_cum_prev, loc_conv_w, loc_lin_w, s_buf=None):
+    """S = pm + W_l conv([w_prev; w_cum_prev]): the part of the attention step that only needs the previous weights"""
+    B, L, A = pm.shape
+    F_, _, K = loc_conv_w.shape
+    if s_buf is None:
+        s_buf = torch.empty(B, L, A, device=pm.device, dtype=torch.float32)
+    check(_lib.load().st_attn_pre_fwd(_p(pm), _p(w_prev), int(w_prev.stride(0)), _p(w_cum_prev), _p(loc_conv_w), _p(loc_lin_w),
+                                      _p(s_buf), B, L, A, F_, K, stream_handle()), 'st_attn_pre_fwd')
+    return s_buf
+
+
+def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K):
+    B, L, E = memory.shape
+    A = s_buf.shape[-1]
+    check(_lib.load().st_attn_fin_t16_fwd(_p(pq), _p(s_buf), _p(memory), _p(w_cum_prev), _p(w_out), int(w_out.stride(0)),
+                                          _p(w_cum_out), _p(v), None, 0, _p(ctx), int(ctx.stride(0)), B, L, A, E, int(F_), int(K),
+                                          stream_handle()), 'st_attn_fin_t16_fwd')
+
+
 def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=0, bias=None, act_pre=None,
          bn=None, bn_eps=1e-5, act_post=None, res=None, highway_h=None, mask=None, pool_prev=False):
     """C = epilogue(conv1d / linear).  a: (Bn, Tin, Cin) or (M, Cin) channels-last; w: torch Linear

@@ -213,6 +213,25 @@ def test_attention_step(dev, B, L, A, E, F, K, Q):
     assert abs(float(w_out.sum(-1).mean()) - 1.0) < 1e-5
 
 
+@pytest.mark.parametrize('B,L,A,E,F,K', [(2, 7, 16, 32, 4, 5), (32, 43, 256, 512, 32, 31), (3, 171, 256, 512, 32, 31), (5, 13, 24, 40, 6, 7)])
+def test_attention_step_in_two_parts(dev, B, L, A, E, F, K):
+    # pre (conv + W_l, from the previous weights only) then fin (energies, softmax, context) == the one-launch step
+    from semi_tts_amd import ops
+    pq, pm, mem = rnd(B, A, seed=1), rnd(B, L, A, seed=2), rnd(B, L, E, seed=3)
+    w_prev = torch.softmax(rnd(B, L, seed=4), -1)
+    w_cum = w_prev * 2.5
+    wc, wl, v = rnd(F, 2, K, scale=0.3, seed=5), rnd(A, F, scale=0.3, seed=6), rnd(1, A, seed=7)
+    d = [t.to(dev) for t in (pq, pm, mem, w_prev, w_cum, wc, wl, v)]
+    w1, c1, x1 = (torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, E, device=dev))
+    ops.attn_step(d[0], d[1], d[2], d[3], d[4], w1, c1, d[5], d[6], d[7], x1)
+    s_buf = ops.attn_pre(d[1], d[3], d[4], d[5], d[6])
+    w2, c2, x2 = torch.empty_like(w1), torch.empty_like(c1), torch.empty_like(x1)
+    ops.attn_fin(d[0], s_buf, d[2], d[4], d[7], w2, c2, x2, F, K)
+    errs = dict(w=maxdiff(w2, w1), cum=maxdiff(c2, c1), ctx=maxdiff(x2, x1))
+    report('attention_two_parts', B=B, L=L, A=A, **errs)
+    assert errs['w'] < 2e-6 and errs['cum'] < 2e-6 and errs['ctx'] < 2e-5      # (pq + ploc) + pm vs pq + (pm + ploc)
+
+
 CONV_CASES = [  # B, T, Cin, N, KT, pad, Tout(None = natural)
     (2, 9, 12, 32, 5, 2, None), (3, 13, 80, 80, 4, 2, 13), (3, 13, 80, 80, 4, 2, 14), (2, 20, 640, 128, 3, 1, None),
     (4, 12, 64, 512, 5, 2, None), (2, 7, 8, 8, 8, 4, 7), (1, 130, 160, 1025, 1, 0, None), (2, 5, 30, 70, 1, 0, None),

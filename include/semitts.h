@@ -204,6 +204,20 @@ int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory
                         float* w_out, int ld_wout, float* w_cum_out, const float* v,
                         const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
                         int B, int L, int A, int E, int F, int K, void* stream);
+/* st_skinny_linear_packed_fwd plus, as extra workgroups of the same launch (one per utterance), st_attn_pre_fwd for the NEXT
+ * decode step: the proj (+) gate launch of step t leaves most compute units idle and the attention weights of step t are
+ * already known, so S of step t+1 is ready when its attention launch starts. */
+typedef struct st_attn_pre_job {
+    const float* pm; const float* w_prev; int ld_wprev; const float* w_cum_prev;
+    const float* loc_conv_w; const float* loc_lin_w; float* s_buf;
+    int L, A, F, K;
+} st_attn_pre_job;
+int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,
+                                        const float* bias, int act, const float* mask, int ldmask,
+                                        float* y, int ldy, const st_t16_view* y_dst,
+                                        int n_split, float* y2, int ldy2, int rep,
+                                        int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
+                                        int B, int N, const st_attn_pre_job* pre, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
  * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) * stride + tap - pad, ci) * W(n, ci, tap) )
@@ -430,6 +444,9 @@ typedef struct st_decoder_io {
     float* preq_buf; float* pred_buf; int overlap;
     float* gates_q_tape;      /* (steps, B, 4, Q) or NULL (training) */
     float* gates_d_tape;      /* (steps, B, 4, D) or NULL */
+    float* attn_s_buf;        /* (B,L,A) or NULL: split the attention step -- its location conv + W_l part for step t+1 runs inside
+                               * the proj (+) gate launch of step t (st_skinny_linear_packed_attnpre_fwd), the attention launch
+                               * itself starts from S (free-running fused-prenet inference) */
     int defer_proj;           /* pure teacher forcing only: skip the per-step proj (+) gate launch; the caller computes mel /
                                * stop for all steps with one GEMM over xo_tape afterwards (mel_out / stop_out untouched) */
     int pre1_step_floats;     /* > 0: pre1_t16 is a tape of `steps` slots of that many floats (training keeps the prenet

@@ -211,6 +211,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     Aux* ax = io->overlap == 1 && io->preq_buf && io->pred_buf ? aux_get() : nullptr;
     const bool aux = ax != nullptr;
     const bool ov = aux || side;            // both split the LSTM cells into an early partial and a late launch
+    // attention split (free-running inference): the location part of step t+1 rides in the proj launch of step t
+    const bool split_attn = io->attn_s_buf && !ov && !io->defer_proj;
     hipStream_t sb = aux ? ax->s : st;
     if (ov) ST_HIP(hipMemsetAsync(io->preq_buf, 0, 4 * BQ * sizeof(float), st));   // step 0: ctx_{-1} = h_q_{-1} = 0
     if (aux) {
@@ -261,11 +263,16 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    ctx_t -> xq_{t+1}[ctx part], xd_t[ctx part], xo_t[ctx part]
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
-        rc = st_attn_step_t16_fwd(io->pq_buf, io->pm, io->memory, w_prev, t == 0 ? L : ldal,
-                                  io->wcum_tape + (size_t)t * BL, io->align_out + (size_t)t * L, ldal,
-                                  io->wcum_tape + (size_t)(t + 1) * BL,
-                                  w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v, ctx_dst, 3, nullptr, 0,
-                                  B, L, A, E, d->F, d->K, stream);
+        if (split_attn)     // S of this step was written inside the previous proj launch (step 0: no history yet, S = pm)
+            rc = st_attn_fin_t16_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf, io->memory, io->wcum_tape + (size_t)t * BL,
+                                     io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL, w->attn_v,
+                                     ctx_dst, 3, nullptr, 0, B, L, A, E, d->F, d->K, stream);
+        else
+            rc = st_attn_step_t16_fwd(io->pq_buf, io->pm, io->memory, w_prev, t == 0 ? L : ldal,
+                                      io->wcum_tape + (size_t)t * BL, io->align_out + (size_t)t * L, ldal,
+                                      io->wcum_tape + (size_t)(t + 1) * BL,
+                                      w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v, ctx_dst, 3, nullptr, 0,
+                                      B, L, A, E, d->F, d->K, stream);
         if (rc) return rc;
 
         if (aux && t + 1 < steps) {  // aux stream: early part of the NEXT query LSTM, x = [ctx_t | h_q_t]
@@ -300,6 +307,16 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    side job: early part of the NEXT query LSTM, x = [ctx_t | h_q_t] (both known now)
         st_t16_view xq_early_v = {xq_next, sv.q_kbs, kbP};
         st_side_partial sq = {io->packed + pl.q, sv.q_kbs, kbP, &xq_early_v, 16 * (sv.q_kbs - kbP), io->preq_buf, 4 * Q, Q};
+        if (split_attn && t + 1 < steps) {
+            st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
+                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K};
+            rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
+                                                     io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
+                                                     io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
+                                                     fuse ? in_dim + 1 : 0, ST_ACT_RELU,
+                                                     io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
+                                                     fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0), &job, stream);
+        } else
         rc = st_skinny_linear_packed_side_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
                                               io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
                                               io->stop_out + (size_t)t * d->r, steps * d->r, d->r,

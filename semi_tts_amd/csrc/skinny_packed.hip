@@ -15,6 +15,7 @@
 // when a lane feeds component c of its float4 to the c-th of 4 successive MFMAs.
 // The K loop is software pipelined (loads of group g+1 are in flight during the MFMAs of g).
 #include "st_common.h"
+#include "attention_body.h"   // the "pre" part of the attention step runs as extra workgroups of a small linear
 
 #ifndef PK_PROF
 #define PK_PROF(n)   // phase timestamps, only defined by tools/mb/mb_pk.hip
@@ -352,6 +353,38 @@ __global__ __launch_bounds__(KW * 64) void pk_pair_kernel(const PkArgs a, const 
     else pk_body<2, NB, KW, TRIP>(s, (int)blockIdx.x - tiles_a, blockIdx.y, red);
 }
 
+// The proj (+) gate launch of decode step t with, on the compute units it leaves idle, the part of the attention of step t+1
+// that only needs the attention weights of step t (location conv + W_l + processed memory -> S): one workgroup per
+// utterance after the linear's workgroups.  The attention launch of step t+1 then starts from S.
+template <int NB, int KW, int TRIP, bool VEC>
+__global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const PkArgs a, const AtArgs t, const int tiles_a, const int n_lin) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * NB * 64];
+    static_assert(KW * 64 == AT_THREADS, "both parts use 512-thread workgroups");
+    const int i = blockIdx.x;
+    if (i < n_lin) pk_body<1, NB, KW, TRIP>(a, i % tiles_a, i / tiles_a, red);
+    else at_body<VEC, 1>(t, i - n_lin, pk_dyn_lds);
+}
+
+template <int NB>
+int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st) {
+    constexpr int KW = 8, TRIP = 2;
+    const int BT = (a.B + 15) >> 4, gy = (BT + NB - 1) / NB;
+    const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K);
+    const size_t lds = (size_t)o.total * sizeof(float);
+    ST_CHECK_ARG(lds + sizeof(f32x4) * KW * NB * 64 <= 160 * 1024, "linear + attention-pre launch: L=%d needs too much LDS", t.L);
+    const bool vec = (t.A % 4 == 0) && (t.F % 4 == 0) && st_aligned16(t.pm) && st_aligned16(t.loc_lin_w) && st_aligned16(t.s_buf);
+    auto kern = vec ? pk_attnpre_kernel<NB, KW, TRIP, true> : pk_attnpre_kernel<NB, KW, TRIP, false>;
+    static size_t configured[2] = {0, 0};
+    if (lds > 48 * 1024 && lds > configured[vec ? 1 : 0]) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[vec ? 1 : 0] = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * gy + t.B), dim3(KW * 64), lds, st, a, t, tiles, tiles * gy);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int MODE, int NB>
 int pk_launch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = nullptr, int side_tiles = 0) {
     // 8 waves x 2 k-blocks in flight, double buffered.  Measured alternatives on MI355X (us per launch in
@@ -488,6 +521,55 @@ extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, int w_kb_stride, i
     return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
 }
 
+static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
+                          const float* bias, int act, const float* mask, int ldmask,
+                          float* y, int ldy, const st_t16_view* y_dst,
+                          int n_split, float* y2, int ldy2, int rep,
+                          int n_split2, int act2, const float* mask2, int ldmask2,
+                          const st_t16_view* y3_dst,
+                          int B, int N, const st_side_partial* side, const st_attn_pre_job* pre, void* stream) {
+    ST_CHECK_ARG(n_split2 <= 0 || (y3_dst && y3_dst->base && n_split2 >= n_split), "st_skinny_linear_packed_fwd: third range");
+    ST_CHECK_ARG(B > 0 && N > 0 && (y || (y_dst && y_dst->base)), "st_skinny_linear_packed_fwd: bad arguments");
+    ST_CHECK_ARG(n_split <= 0 || (y2 && rep >= 1), "st_skinny_linear_packed_fwd: n_split without y2/rep");
+    ST_CHECK_ARG(!(side && side->packed_w && pre && pre->s_buf), "st_skinny_linear_packed_*: one kind of side work per launch");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, 0, 0, x, K, "st_skinny_linear_packed_fwd");
+    if (rc) return rc;
+    a.B = B; a.N = N; a.H = 0;
+    a.bias = bias; a.act = act; a.lmask = mask; a.ldmask = ldmask;
+    a.y = y; a.ldy = ldy; a.y_dst = pk_out(y_dst);
+    a.n_split = n_split; a.y2 = y2; a.ldy2 = ldy2; a.rep = rep;
+    a.n_split2 = n_split2; a.act2 = act2; a.mask2 = mask2; a.ldmask2 = ldmask2; a.y3_dst = pk_out(y3_dst);
+    const int tiles = (N + 15) / 16;
+    if (side && side->packed_w) {
+        ST_CHECK_ARG(side->H > 0 && side->H % 4 == 0 && side->pre_out && side->ldpre >= 4 * side->H && side->x,
+                     "st_skinny_linear_packed_side_fwd: bad side job");
+        PkArgs sj;
+        memset(&sj, 0, sizeof(sj));
+        rc = pk_fill(sj, side->packed_w, side->w_kb_stride, side->w_kb0, side->x, side->K, "st_skinny_linear_packed_side_fwd(side)");
+        if (rc) return rc;
+        sj.B = B; sj.N = 4 * side->H; sj.H = side->H;
+        sj.gates_out = side->pre_out; sj.ldpre = side->ldpre;
+        return pk_dispatch<1>(a, tiles, (hipStream_t)stream, &sj, side->H / 4);
+    }
+    if (pre && pre->s_buf) {
+        ST_CHECK_ARG(pre->pm && pre->w_prev && pre->w_cum_prev && pre->loc_conv_w && pre->loc_lin_w && pre->L > 0 && pre->A > 0 &&
+                     pre->F > 0 && pre->K > 0 && (pre->K & 1), "st_skinny_linear_packed_attnpre_fwd: bad attention job");
+        AtArgs t;
+        memset(&t, 0, sizeof(t));
+        t.pm = pre->pm; t.w_prev = pre->w_prev; t.ld_wprev = pre->ld_wprev; t.w_cum_prev = pre->w_cum_prev;
+        t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf;
+        t.B = B; t.L = pre->L; t.A = pre->A; t.E = 4; t.F = pre->F; t.K = pre->K;
+        const int BT = (B + 15) >> 4;
+        if (BT == 1 || tiles <= 128) return pk_launch_attnpre<1>(a, tiles, t, (hipStream_t)stream);
+        if (BT == 2) return pk_launch_attnpre<2>(a, tiles, t, (hipStream_t)stream);
+        if (BT == 3) return pk_launch_attnpre<3>(a, tiles, t, (hipStream_t)stream);
+        return pk_launch_attnpre<4>(a, tiles, t, (hipStream_t)stream);
+    }
+    return pk_dispatch<1>(a, tiles, (hipStream_t)stream);
+}
+
 extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
                                            const float* bias, int act, const float* mask, int ldmask,
                                            float* y, int ldy, const st_t16_view* y_dst,
@@ -495,8 +577,9 @@ extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_v
                                            int n_split2, int act2, const float* mask2, int ldmask2,
                                            const st_t16_view* y3_dst,
                                            int B, int N, void* stream) {
-    return st_skinny_linear_packed_side_fwd(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
-                                            n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, stream);
+    (void)hipGetLastError();
+    return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
+                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, nullptr, stream);
 }
 
 extern "C" int st_skinny_linear_packed_side_fwd(const float* packed_w, const st_t16_view* x, int K,
@@ -507,30 +590,20 @@ extern "C" int st_skinny_linear_packed_side_fwd(const float* packed_w, const st_
                                                 const st_t16_view* y3_dst,
                                                 int B, int N, const st_side_partial* side, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(n_split2 <= 0 || (y3_dst && y3_dst->base && n_split2 >= n_split), "st_skinny_linear_packed_fwd: third range");
-    ST_CHECK_ARG(B > 0 && N > 0 && (y || (y_dst && y_dst->base)), "st_skinny_linear_packed_fwd: bad arguments");
-    ST_CHECK_ARG(n_split <= 0 || (y2 && rep >= 1), "st_skinny_linear_packed_fwd: n_split without y2/rep");
-    PkArgs a;
-    memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, 0, 0, x, K, "st_skinny_linear_packed_fwd");
-    if (rc) return rc;
-    a.B = B; a.N = N; a.H = 0;
-    a.bias = bias; a.act = act; a.lmask = mask; a.ldmask = ldmask;
-    a.y = y; a.ldy = ldy; a.y_dst = pk_out(y_dst);
-    a.n_split = n_split; a.y2 = y2; a.ldy2 = ldy2; a.rep = rep;
-    a.n_split2 = n_split2; a.act2 = act2; a.mask2 = mask2; a.ldmask2 = ldmask2; a.y3_dst = pk_out(y3_dst);
-    if (side && side->packed_w) {
-        ST_CHECK_ARG(side->H > 0 && side->H % 4 == 0 && side->pre_out && side->ldpre >= 4 * side->H && side->x,
-                     "st_skinny_linear_packed_side_fwd: bad side job");
-        PkArgs sj;
-        memset(&sj, 0, sizeof(sj));
-        rc = pk_fill(sj, side->packed_w, side->w_kb_stride, side->w_kb0, side->x, side->K, "st_skinny_linear_packed_side_fwd(side)");
-        if (rc) return rc;
-        sj.B = B; sj.N = 4 * side->H; sj.H = side->H;
-        sj.gates_out = side->pre_out; sj.ldpre = side->ldpre;
-        return pk_dispatch<1>(a, (N + 15) / 16, (hipStream_t)stream, &sj, side->H / 4);
-    }
-    return pk_dispatch<1>(a, (N + 15) / 16, (hipStream_t)stream);
+    return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
+                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, side, nullptr, stream);
+}
+
+extern "C" int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,
+                                                   const float* bias, int act, const float* mask, int ldmask,
+                                                   float* y, int ldy, const st_t16_view* y_dst,
+                                                   int n_split, float* y2, int ldy2, int rep,
+                                                   int n_split2, int act2, const float* mask2, int ldmask2,
+                                                   const st_t16_view* y3_dst,
+                                                   int B, int N, const st_attn_pre_job* pre, void* stream) {
+    (void)hipGetLastError();
+    return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
+                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, pre, stream);
 }
 
 // Partial LSTM gate pre-activations over a k-block range of the packed weights:

@@ -284,6 +284,8 @@ class Decoder(nn.Module):
         self.overlap = int(os.environ.get('ST_OVERLAP', '0'))
         self.fuse_prenet = True    # inference: emit prenet layer 1 from the proj/gate launch (fp32 re-association)
         self.cache_packed = False  # frozen-weight inference: keep the packed weights across forwards
+        # inference: the location conv + W_l part of the attention of step t+1 runs inside the proj launch of step t
+        self.attn_split = os.environ.get('ST_ATTN_SPLIT', '1') != '0'
 
     # -- helpers ---------------------------------------------------------------------------------
     def _weights_struct(self, keep, fuse_pre0=False):
@@ -452,6 +454,9 @@ class Decoder(nn.Module):
         io.preq_buf, io.pred_buf, io.overlap = ops._p(tapes['preq']), ops._p(tapes['pred']), int(self.overlap)
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
         io.pre1_step_floats = t16(P) if keep_tapes else 0
+        if self.attn_split and not self.training and self.overlap == 0:
+            tapes['attn_s'] = torch.empty(B, L, A, **f32)
+            io.attn_s_buf = ops._p(tapes['attn_s'])
         # training with pure teacher forcing: no step's input depends on an earlier output, so mel / stop of all steps
         # come from ONE GEMM over the xo tape after the loop instead of one launch per step
         pure_tf = teacher_pre is not None and Bt == B and all(step_src[t] == min(t, Tt - 1) for t in range(steps - 1))

@@ -10,17 +10,19 @@ rows = con.execute("select name, start, end from kernels order by start").fetcha
 def code(n):
     if 'pk_kernel<0' in n: return 'L'
     if 'pk_kernel<1' in n: return 'l'
+    if 'pk_attnpre_kernel' in n: return 'P'
     if 'at_kernel' in n: return 'A'
     return 'x'
 seq = [(code(n), s, e) for n, s, e in rows]
 text = ''.join(c for c, _, _ in seq)
-for pat, names in (('LlALll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj+pre0', 'pre1']),
+for pat, names in (('LlALPl', ['LSTM_q', 'pq', 'attn (fin part)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
+                   ('LlALll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj+pre0', 'pre1']),
                    ('LlALlll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj', 'pre0', 'pre1'])):
     dur = collections.defaultdict(list)
     i = 0
     n = len(pat)
     while i + n <= len(seq):
-        if text[i:i + n] == pat and (i + n >= len(seq) or text[i + n] != 'l'):
+        if text[i:i + n] == pat and (i + n >= len(seq) or text[i + n] not in 'l'):
             for j in range(n):
                 dur[j].append(seq[i + j][2] - seq[i + j][1])
             i += n
@@ -31,6 +33,6 @@ for pat, names in (('LlALll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj+pre0', 'p
         for j in range(n):
             m = st.median(dur[j]) / 1e3
             tot += m
-            print('%-10s n=%5d median %6.2f us' % (names[j], len(dur[j]), m))
+            print('%-36s n=%5d median %6.2f us' % (names[j], len(dur[j]), m))
         print('sum of medians %.2f us' % tot)
         break

@@ -340,8 +340,6 @@ class Decoder(nn.Module):
         Bt = B if is_int else teacher.shape[0]
         steps, step_src = plan_decode(is_int, teacher if is_int else teacher.shape[1], Bt, B, r, tf_rate,
                                       self.drop_dec_in, unpair_max_frame)
-        keep = []
-        f32 = dict(device=dev, dtype=torch.float32)
         differentiable = self.training and torch.is_grad_enabled()
         # once per utterance: processed memory, AdaIN statistics (hoisted out of the loop)
         if differentiable:

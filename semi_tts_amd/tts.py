@@ -1,7 +1,6 @@
 """Tacotron2 wrapper (encoder -> decoder -> CBHG mel->linear postnet) on the HIP path.
 Mirror of the reference's src/tts.py:9-51: same constructor, forward signature and
 state_dict keys (`encoder.*`, `decoder.*`, `postnet.0.*`, `postnet.1.*`)."""
-import torch
 import torch.nn as nn
 
 from . import ops

@@ -212,7 +212,10 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     const bool aux = ax != nullptr;
     const bool ov = aux || side;            // both split the LSTM cells into an early partial and a late launch
     // attention split (free-running inference): the location part of step t+1 rides in the proj launch of step t
-    const bool split_attn = io->attn_s_buf && !ov && !io->defer_proj;
+    // Host launch of the pre part: the proj launch of the previous step when the loop has one, otherwise (deferred
+    // projection = teacher-forced training) the query-projection launch of the same step.
+    const bool split_attn = io->attn_s_buf && !ov;
+    const bool pre_in_pq = split_attn && io->defer_proj;
     hipStream_t sb = aux ? ax->s : st;
     if (ov) ST_HIP(hipMemsetAsync(io->preq_buf, 0, 4 * BQ * sizeof(float), st));   // step 0: ctx_{-1} = h_q_{-1} = 0
     if (aux) {
@@ -254,6 +257,13 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    side job: early part of the decoder LSTM, x = [adapted h_q_t | h_d_{t-1}] (both known now)
         st_t16_view xd_early_v = {xd, sv.d_kbs, kbE};
         st_side_partial sd = {io->packed + pl.d, sv.d_kbs, kbE, &xd_early_v, 16 * (sv.d_kbs - kbE), io->pred_buf, 4 * D, D};
+        if (pre_in_pq && t > 0) {   // attention pre part of THIS step rides along (needs only the weights of step t-1)
+            st_attn_pre_job job = {io->pm, io->align_out + (size_t)(t - 1) * L, ldal, io->wcum_tape + (size_t)t * BL,
+                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K};
+            rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
+                                                     io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
+                                                     &job, stream);
+        } else
         rc = st_skinny_linear_packed_side_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                               io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
                                               side ? &sd : nullptr, stream);
@@ -307,7 +317,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    side job: early part of the NEXT query LSTM, x = [ctx_t | h_q_t] (both known now)
         st_t16_view xq_early_v = {xq_next, sv.q_kbs, kbP};
         st_side_partial sq = {io->packed + pl.q, sv.q_kbs, kbP, &xq_early_v, 16 * (sv.q_kbs - kbP), io->preq_buf, 4 * Q, Q};
-        if (split_attn && t + 1 < steps) {
+        if (split_attn && !pre_in_pq && t + 1 < steps) {
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
                                    w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K};
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,

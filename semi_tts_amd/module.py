@@ -452,14 +452,14 @@ class Decoder(nn.Module):
         io.preq_buf, io.pred_buf, io.overlap = ops._p(tapes['preq']), ops._p(tapes['pred']), int(self.overlap)
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
         io.pre1_step_floats = t16(P) if keep_tapes else 0
-        if self.attn_split and not self.training and self.overlap == 0:
-            tapes['attn_s'] = torch.empty(B, L, A, **f32)
-            io.attn_s_buf = ops._p(tapes['attn_s'])
         # training with pure teacher forcing: no step's input depends on an earlier output, so mel / stop of all steps
         # come from ONE GEMM over the xo tape after the loop instead of one launch per step
         pure_tf = teacher_pre is not None and Bt == B and all(step_src[t] == min(t, Tt - 1) for t in range(steps - 1))
         defer = bool(keep_tapes and pure_tf and self.overlap != 2)
         io.defer_proj = 1 if defer else 0
+        if self.attn_split and self.overlap == 0 and (not self.training or defer):
+            tapes['attn_s'] = torch.empty(B, L, A, **f32)
+            io.attn_s_buf = ops._p(tapes['attn_s'])
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
         if defer:

@@ -31,7 +31,7 @@ def _step(m, A, rows, dev):
     mel, lin, _, _ = m(txt, None, teacher, spk, tf_rate=1.0)
     loss = AG.freq_loss(mel, teacher, 22050, 8) + AG.freq_loss(lin, lin_t, 22050, 8)
     loss.backward()
-    return float(loss)
+    return float(loss.detach())
 
 
 def _worker(rank, world, port, out_path):

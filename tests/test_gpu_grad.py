@@ -545,7 +545,9 @@ def test_checkpoint_round_trip_resumes_training(dev, tmp_path):
     b = make(load=path)
     assert b.step == 2
     st_b = b.train_step(*batch)
-    assert st_a['loss'] == st_b['loss'] and st_a['grad_norm'] == st_b['grad_norm']
+    # the loss is bit-identical; the grad norm includes the embedding-table gradients, which are accumulated with fp32
+    # atomics (order not fixed), so it may differ in the last bits
+    assert st_a['loss'] == st_b['loss'] and abs(st_a['grad_norm'] - st_b['grad_norm']) <= 1e-6 * st_a['grad_norm']
     sa, sb = a.model.state_dict(), b.model.state_dict()
     diff = [k for k in sa if not torch.equal(sa[k], sb[k])]
     # the embedding-table gradients are accumulated with fp32 atomics (order not fixed): last-bit differences only there

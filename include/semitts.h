@@ -304,7 +304,8 @@ int st_pool_prev_bwd(const float* dy_pooled, const float* x, float* dx, int Bn, 
 /* dst(b,t,:) (+)= src(b,t,:) with arbitrary (b,t) strides (elements) */
 int st_copy3d(float* dst, long dst_sb, long dst_st, const float* src, long src_sb, long src_st,
               int Bn, int T, int C, int accumulate, void* stream);
-/* dtable(idx(r), :) += dout(r, :)    ref: backward of F.embedding src/embed.py:97-101 */
+/* dtable(v, :) += sum of dout(r, :) over the rows with idx(r) == v, in row order (deterministic, no atomics)
+ * ref: backward of F.embedding src/embed.py:97-101 */
 int st_scatter_add_rows(const float* dout, const int64_t* idx, float* dtable, int n, int D, int V, void* stream);
 
 /* ------------------------------------------------------------------ recurrent sequence layers */

@@ -320,17 +320,17 @@ __global__ __launch_bounds__(256) void copy3d_kernel(float* dst, long dsb, long 
     }
 }
 
-// dtable(idx(r), :) += dout(r, :)   (embedding backward; fp32 atomics: the order of additions into one row
-// is not fixed, rows have at most a few dozen contributions)
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* dout, const int64_t* idx, float* dtable,
-                                                               int n, int D, int V) {
-    const size_t total = (size_t)n * D;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i / D;
-        const int d = (int)(i - r * D);
-        const int64_t v = idx[r];
-        if (v >= 0 && v < V) atomicAdd(dtable + (size_t)v * D + d, dout[i]);
-    }
+// dtable(v, :) = sum over the rows r with idx(r) == v of dout(r, :), added in row order: one workgroup column per table row
+// scans the index vector (a few thousand entries, read through the scalar cache) -- deterministic, no atomics
+__global__ __launch_bounds__(64) void scatter_add_rows_kernel(const float* dout, const int64_t* idx, float* dtable,
+                                                              int n, int D, int V) {
+    const int v = blockIdx.x;
+    const int d = blockIdx.y * 64 + threadIdx.x;
+    if (d >= D) return;
+    float acc = 0.0f;
+    for (int r = 0; r < n; ++r)
+        if (idx[r] == (int64_t)v) acc += dout[(size_t)r * D + d];
+    dtable[(size_t)v * D + d] += acc;
 }
 
 // out-of-place BatchNorm normalisation: Y = act((X - mean) / sqrt(var + eps) * w + b); X is kept for the backward
@@ -518,7 +518,7 @@ extern "C" int st_copy3d(float* dst, long dst_sb, long dst_st, const float* src,
 extern "C" int st_scatter_add_rows(const float* dout, const int64_t* idx, float* dtable, int n, int D, int V, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dout && idx && dtable && n > 0 && D > 0 && V > 0, "st_scatter_add_rows: bad arguments");
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks_for((size_t)n * D)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(V, (D + 63) / 64), dim3(64), 0, (hipStream_t)stream,
                        dout, idx, dtable, n, D, V);
     ST_LAUNCH_CHECK();
     return 0;

@@ -198,8 +198,8 @@ int st_attn_step_t16_fwd(const float* pq, const float* pm, const float* memory,
  * v . tanh(pq + S), softmax, cumulative weights, context.  (pq + W_l cf) + pm becomes pq + (pm + W_l cf): fp32
  * re-association only. */
 int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wprev, const float* w_cum_prev,
-                    const float* loc_conv_w, const float* loc_lin_w, float* s_buf,
-                    int B, int L, int A, int F, int K, void* stream);
+                    const float* loc_conv_w, const float* loc_lin_w, float* s_buf, int parts,
+                    int B, int L, int A, int F, int K, void* stream);   /* parts = workgroups per utterance: 1, 2 or 4 */
 int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
                         float* w_out, int ld_wout, float* w_cum_out, const float* v,
                         const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
@@ -211,6 +211,7 @@ typedef struct st_attn_pre_job {
     const float* pm; const float* w_prev; int ld_wprev; const float* w_cum_prev;
     const float* loc_conv_w; const float* loc_lin_w; float* s_buf;
     int L, A, F, K;
+    int parts;      /* workgroups per utterance (ranges of positions): 1, 2 or 4 */
 } st_attn_pre_job;
 int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,
                                         const float* bias, int act, const float* mask, int ldmask,
@@ -448,6 +449,7 @@ typedef struct st_decoder_io {
     float* attn_s_buf;        /* (B,L,A) or NULL: split the attention step -- its location conv + W_l part for step t+1 runs inside
                                * the proj (+) gate launch of step t (st_skinny_linear_packed_attnpre_fwd), the attention launch
                                * itself starts from S (free-running fused-prenet inference) */
+    int attn_pre_parts;       /* workgroups per utterance of the pre part (1, 2, 4) */
     int defer_proj;           /* pure teacher forcing only: skip the per-step proj (+) gate launch; the caller computes mel /
                                * stop for all steps with one GEMM over xo_tape afterwards (mel_out / stop_out untouched) */
     int pre1_step_floats;     /* > 0: pre1_t16 is a tape of `steps` slots of that many floats (training keeps the prenet

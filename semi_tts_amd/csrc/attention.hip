@@ -27,8 +27,9 @@ int at_launch(const AtArgs& a, hipStream_t stream) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    if (vec) hipLaunchKernelGGL((at_kernel<true, PART>), dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((at_kernel<false, PART>), dim3(a.B), dim3(AT_THREADS), lds_bytes, stream, a);
+    const int nwg = a.B * (PART == 1 && a.pre_parts > 1 ? a.pre_parts : 1);
+    if (vec) hipLaunchKernelGGL((at_kernel<true, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((at_kernel<false, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -76,13 +77,14 @@ extern "C" int st_attn_step_t16_fwd(const float* pq, const float* pm, const floa
 // The step in two parts (see attention_body.h): `pre` needs only the previous step's weights (w_prev, w_cum_prev) and writes
 // S = pm + W_l conv(hist); `fin` needs the processed query and S.  pre(t+1) can run any time after fin(t).
 extern "C" int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wprev, const float* w_cum_prev,
-                               const float* loc_conv_w, const float* loc_lin_w, float* s_buf,
+                               const float* loc_conv_w, const float* loc_lin_w, float* s_buf, int parts,
                                int B, int L, int A, int F, int K, void* stream) {
     (void)hipGetLastError();
     AtArgs a;
     memset(&a, 0, sizeof(a));
     a.pm = pm; a.w_prev = w_prev; a.ld_wprev = ld_wprev; a.w_cum_prev = w_cum_prev;
     a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.s_buf = s_buf;
+    a.pre_parts = parts == 2 || parts == 4 ? parts : 1;
     a.B = B; a.L = L; a.A = A; a.E = 4; a.F = F; a.K = K;
     return at_launch<1>(a, (hipStream_t)stream);
 }

@@ -42,6 +42,7 @@ struct AtArgs {
     float* ctx; int ld_ctx; st_t16_view ctx_dst[3];
     const float* h_q; int ld_hq; const float* ada_std; const float* ada_mean; float* h_adapt; int Q;
     float* s_buf;      // (B, L, A): S = pm + W_l cf, written by the pre part, read by the fin part
+    int pre_parts;     // pre part only: workgroups per utterance, each a contiguous range of positions (1, 2 or 4)
     int B, L, A, E, F, K;
 };
 
@@ -81,7 +82,11 @@ __device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
 // S[l][a] = pm[l][a] + sum_f W_l[a][f] cf[f][l] -- written to a.s_buf; it can run while the rest of the decode step does
 // (as extra workgroups of the proj launch, skinny_packed.hip).  PART 2 ("fin"): energies from S, softmax, context.
 template <bool VEC, int PART>
-__device__ __forceinline__ void at_body(const AtArgs& a, const int b, float* lds) {
+__device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* lds) {
+    // the pre part may spread an utterance over several workgroups (ranges of positions): only the conv and the W_l product
+    // scale with the range, the staging is repeated
+    const int nparts = (PART == 1 && a.pre_parts > 1) ? a.pre_parts : 1;
+    const int b = wg / nparts, ipart = wg - b * nparts;
     // kernel arguments of the first phases: fetched now, one wait (otherwise one scalar-cache round trip per first use)
 #define AT_TOUCH(x) asm volatile("" :: "s"(x))
     AT_TOUCH(a.pq); AT_TOUCH(a.pm); AT_TOUCH(a.memory); AT_TOUCH(a.w_prev); AT_TOUCH(a.ld_wprev); AT_TOUCH(a.w_cum_prev);
@@ -90,6 +95,9 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int b, float* lds
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
     const AtLds o = at_layout(L, A, E, F, K);
+    // position range of this workgroup (multiples of 12 = lcm of the conv's 4-blocks and the energy phase's 6-blocks)
+    const int pos_per = nparts > 1 ? (((L + nparts - 1) / nparts + 11) / 12) * 12 : L;
+    const int pos_lo = min(L, ipart * pos_per), pos_hi = min(L, pos_lo + pos_per);
     float* Wt = lds + o.wt;
     float* Wc = lds + o.wc;
     float* hs = lds + o.hs;
@@ -176,9 +184,9 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int b, float* lds
     if (PART != 2) {
     // ---- P1: location conv, cf[f][l] = sum_c sum_k Wc[f][c][k] * hist[c][l + k - pad]
     {
-        const int nlb = (L + AT_CB - 1) / AT_CB;
+        const int nlb = (pos_hi - pos_lo + AT_CB - 1) / AT_CB;
         for (int idx = tid; idx < F * nlb; idx += AT_THREADS) {
-            const int f = idx / nlb, l0 = (idx - f * nlb) * AT_CB;
+            const int f = idx / nlb, l0 = pos_lo + (idx - f * nlb) * AT_CB;
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
             if (KP == 32) {
                 // K <= 32: filters and history window are pulled with ds_read_b128 (8 + 9 per channel)
@@ -252,7 +260,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int b, float* lds
     // PART 2 reads S (= pm + W_l cf, written by the pre part) where the full kernel reads pm
     const float* pmb = (PART == 2 ? a.s_buf : a.pm) + (size_t)b * L * A;
     const float* pqb = a.pq + (size_t)b * A;
-    for (int l0 = wave * AT_LP; l0 < L; l0 += AT_WAVES * AT_LP) {
+    for (int l0 = pos_lo + wave * AT_LP; l0 < pos_hi; l0 += AT_WAVES * AT_LP) {
         float esum[AT_LB];
 #pragma unroll
         for (int j = 0; j < AT_LB; ++j) esum[j] = 0.0f;        // slots AT_LP.. stay zero

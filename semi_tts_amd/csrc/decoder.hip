@@ -259,7 +259,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_side_partial sd = {io->packed + pl.d, sv.d_kbs, kbE, &xd_early_v, 16 * (sv.d_kbs - kbE), io->pred_buf, 4 * D, D};
         if (pre_in_pq && t > 0) {   // attention pre part of THIS step rides along (needs only the weights of step t-1)
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)(t - 1) * L, ldal, io->wcum_tape + (size_t)t * BL,
-                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K};
+                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K, io->attn_pre_parts};
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                                      io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
                                                      &job, stream);
@@ -319,7 +319,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_side_partial sq = {io->packed + pl.q, sv.q_kbs, kbP, &xq_early_v, 16 * (sv.q_kbs - kbP), io->preq_buf, 4 * Q, Q};
         if (split_attn && !pre_in_pq && t + 1 < steps) {
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
-                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K};
+                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K, io->attn_pre_parts};
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
                                                      io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
                                                      io->stop_out + (size_t)t * d->r, steps * d->r, d->r,

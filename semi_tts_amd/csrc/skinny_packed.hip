@@ -380,7 +380,7 @@ int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t s
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured[vec ? 1 : 0] = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles * gy + t.B), dim3(KW * 64), lds, st, a, t, tiles, tiles * gy);
+    hipLaunchKernelGGL(kern, dim3(tiles * gy + t.B * (t.pre_parts > 1 ? t.pre_parts : 1)), dim3(KW * 64), lds, st, a, t, tiles, tiles * gy);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -561,6 +561,7 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
         t.pm = pre->pm; t.w_prev = pre->w_prev; t.ld_wprev = pre->ld_wprev; t.w_cum_prev = pre->w_cum_prev;
         t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf;
         t.B = B; t.L = pre->L; t.A = pre->A; t.E = 4; t.F = pre->F; t.K = pre->K;
+        t.pre_parts = pre->parts == 2 || pre->parts == 4 ? pre->parts : 1;
         const int BT = (B + 15) >> 4;
         if (BT == 1 || tiles <= 128) return pk_launch_attnpre<1>(a, tiles, t, (hipStream_t)stream);
         if (BT == 2) return pk_launch_attnpre<2>(a, tiles, t, (hipStream_t)stream);

@@ -12,6 +12,7 @@ Activations are kept channels-last (B, T, C) end to end (the reference transpose
 (B, C, T) around every Conv1d; the HIP conv is an implicit GEMM over channels-last rows).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -460,6 +461,7 @@ class Decoder(nn.Module):
         if self.attn_split and self.overlap == 0 and (not self.training or defer):
             tapes['attn_s'] = torch.empty(B, L, A, **f32)
             io.attn_s_buf = ops._p(tapes['attn_s'])
+            io.attn_pre_parts = int(os.environ.get('ST_ATTN_PRE_PARTS', '2'))
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
         if defer:

@@ -110,14 +110,14 @@ def attn_step(pq, pm, memory, w_prev, w_cum_prev, w_out, w_cum_out, loc_conv_w, 
           'st_attn_step_fwd')
 
 
-def attn_pre(pm, w_prev, w_cum_prev, loc_conv_w, loc_lin_w, s_buf=None):
+def attn_pre(pm, w_prev, w_cum_prev, loc_conv_w, loc_lin_w, s_buf=None, parts=1):
     """S = pm + W_l conv([w_prev; w_cum_prev]): the part of the attention step that only needs the previous weights"""
     B, L, A = pm.shape
     F_, _, K = loc_conv_w.shape
     if s_buf is None:
         s_buf = torch.empty(B, L, A, device=pm.device, dtype=torch.float32)
     check(_lib.load().st_attn_pre_fwd(_p(pm), _p(w_prev), int(w_prev.stride(0)), _p(w_cum_prev), _p(loc_conv_w), _p(loc_lin_w),
-                                      _p(s_buf), B, L, A, F_, K, stream_handle()), 'st_attn_pre_fwd')
+                                      _p(s_buf), int(parts), B, L, A, F_, K, stream_handle()), 'st_attn_pre_fwd')
     return s_buf
 
 

@@ -225,6 +225,8 @@ def test_attention_step_in_two_parts(dev, B, L, A, E, F, K):
     w1, c1, x1 = (torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, E, device=dev))
     ops.attn_step(d[0], d[1], d[2], d[3], d[4], w1, c1, d[5], d[6], d[7], x1)
     s_buf = ops.attn_pre(d[1], d[3], d[4], d[5], d[6])
+    for parts in (2, 4):       # the pre part spread over several workgroups per utterance gives the same S bit for bit
+        assert torch.equal(ops.attn_pre(d[1], d[3], d[4], d[5], d[6], parts=parts), s_buf)
     w2, c2, x2 = torch.empty_like(w1), torch.empty_like(c1), torch.empty_like(x1)
     ops.attn_fin(d[0], s_buf, d[2], d[4], d[7], w2, c2, x2, F, K)
     errs = dict(w=maxdiff(w2, w1), cum=maxdiff(c2, c1), ctx=maxdiff(x2, x1))

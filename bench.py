@@ -28,6 +28,7 @@ import torch
 B, T_RAW, R, L, N_MELS = 32, 256, 3, 43, 80
 T = T_RAW + (R - T_RAW % R)          # 258: the reference pads r - T % r frames (bin/train_vqvae.py:43-46)
 STEPS = T // R                        # 86
+MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix peak (256 CUs x 256 FLOP/cycle x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -71,7 +72,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='issue the decode loop eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['c2', 'c5'], default='c2',
+                    help="c2 = the headline configuration; c5 = BASELINE config 5 (bin/gen_specgram.py long-form: B=64, L=171, "
+                         "(1026+40)//3 = 355 decode steps) as a secondary line for DESIGN.md")
     args = ap.parse_args()
+    global B, L, T, STEPS
+    if args.workload == 'c5':
+        B, L, STEPS = 64, 171, (1026 + 40) // R
+        T = STEPS * R
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -189,17 +197,23 @@ def main():
         avg_us = ms.value * 1e3 / (2 * reps)
         alg = 0.5 * (lstm_algorithmic_bytes(B, Q, P + E + Q) + lstm_algorithmic_bytes(B, D, E + Q + D))
         achieved = alg / (avg_us * 1e-6) / 1e9
+        flops = 0.5 * (2.0 * B * 4 * Q * Kq + 2.0 * B * 4 * D * Kd)
         traffic = None       # HBM bytes per launch from the PMC pass of the same command (tools/gpu_pmc.sh)
         try:
-            with open(os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')) as f:
-                traffic = json.load(f)['hbm_bytes_per_launch']
+            if args.workload == 'c2':
+                with open(os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')) as f:
+                    traffic = json.load(f)['hbm_bytes_per_launch']
         except (OSError, KeyError, ValueError):
             pass
         roof = {'bound': 'hbm', 'kernel': 'pk_kernel<0,2,8,2> (fused LSTM cell on packed operands: gate GEMM + pointwise)',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(avg_us, 3),
-                'launches_per_step': 2 * STEPS}
+                'launches_per_step': 2 * STEPS,
+                # the same launch against the fp32 matrix-core peak (at B=32 the cell sits just left of the ridge:
+                # 15.7 FLOP/B against 19.7; PMC evidence: profiles/r01_pmc_mfma.*)
+                'mfma': {'achieved': round(flops / (avg_us * 1e-6) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(flops / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}}
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -208,9 +222,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'C2: Decoder.forward free-running inference (decode+attn), B=%d per GPU, '
-                                   '256->%d frames = %d decode steps (r=3), L=%d, n_mels=%d, prenet dropout 0.5, '
-                                   'config/supervised.yaml decoder section' % (B, T, STEPS, L, N_MELS),
+            'config': {'workload': '%s: Decoder.forward free-running inference (decode+attn), B=%d per GPU, '
+                                   '%s->%d frames = %d decode steps (r=3), L=%d, n_mels=%d, prenet dropout 0.5, '
+                                   'config/supervised.yaml decoder section'
+                                   % (args.workload.upper(), B, '256' if args.workload == 'c2' else '1026+40', T, STEPS, L, N_MELS),
                        'batch_per_gpu': B, 'frames': T, 'decode_steps': STEPS, 'text_len': L,
                        'parallelism': 'replicas x%d (utterance-sharded, no collective)' % world,
                        'launch': 'eager' if graph is None else 'hipGraph replay of the whole decode loop'},

@@ -19,8 +19,48 @@ def stats(tag, counter):
                        (counter,)).fetchall()
 
 
+def mfma(tag):
+    """matrix-core pass -> profiles/<tag>_pmc_mfma.{txt,json}: issued F32 MFMA FLOP (MOPS x 512, counter_defs.yaml) per
+    launch against the algorithmic 2*B*K*4H, FLOP/s against the 157.3 TFLOP/s fp32-matrix peak, busy cycles as counted"""
+    db = os.path.join(REPO, 'gpurun_out', 'pmc_%s_MFMA' % tag, 'pmc_results.db')
+    if not os.path.exists(db):
+        return
+    con = sqlite3.connect(db)
+    # the SQ counters come as one row per shader engine (32) and GRBM as one per XCD (8): sum (max for the active-cycle
+    # count) over the rows of a dispatch first, then average over the dispatches of a kernel
+    rows = con.execute("select name, counter_name, count(*), avg(v), avg(duration) from (select name, counter_name, dispatch_id, "
+                       "duration, case when counter_name = 'GRBM_GUI_ACTIVE' then max(counter_value) else sum(counter_value) end as v "
+                       "from pmc_events group by name, counter_name, dispatch_id) group by name, counter_name order by name").fetchall()
+    per = {}
+    for name, cn, n, avg, dur in rows:
+        per.setdefault(name, dict(n=n, dur_ns=dur))[cn] = avg
+    lines, out = [], {}
+    for name, d in sorted(per.items(), key=lambda kv: -kv[1].get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) * kv[1]['n']):
+        flop = d.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0.0) * 512
+        tfs = flop / max(d['dur_ns'], 1) / 1e3
+        lines.append('%-70s n=%5d dur_ns=%9.0f mfma_flop=%14.0f TFLOP/s=%7.2f frac_of_157.3=%.3f busy_cycles=%.0f cu_busy=%.0f gui_active=%.0f'
+                     % (name[:70], d['n'], d['dur_ns'], flop, tfs, tfs / 157.3, d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0),
+                        d.get('SQ_BUSY_CU_CYCLES', 0), d.get('GRBM_GUI_ACTIVE', 0)))
+        if 'pk_kernel<0' in name and 'kernel' not in out:
+            out = dict(kernel=name[:60], launches=d['n'], avg_duration_ns=round(d['dur_ns']), mfma_flop_per_launch=flop,
+                       mfma_tflops=round(tfs, 2), frac_of_fp32_matrix_peak=round(tfs / 157.3, 4),
+                       SQ_VALU_MFMA_BUSY_CYCLES=d.get('SQ_VALU_MFMA_BUSY_CYCLES'), GRBM_GUI_ACTIVE=d.get('GRBM_GUI_ACTIVE'),
+                       SQ_BUSY_CU_CYCLES=d.get('SQ_BUSY_CU_CYCLES'),
+                       mfma_util_pct_derived_formula=round(100 * d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) /
+                                                           max(d.get('GRBM_GUI_ACTIVE', 1) * 1024, 1), 1),
+                       note='MOPS x 512 = FLOP (counter_defs.yaml), equal to the algorithmic 2*B*K*4H; busy cycles = 32 per '
+                            '16x16x4 f32 MFMA per SIMD; util = sum(busy) / (max GRBM_GUI_ACTIVE x 1024 SIMDs), the gfx94x '
+                            'MfmaUtil formula; durations under PMC collection are ~7 % longer than in the plain kernel trace')
+    open(os.path.join(REPO, 'profiles', '%s_pmc_mfma.txt' % tag), 'w').write('\n'.join(lines[:12]) + '\n')
+    json.dump(out, open(os.path.join(REPO, 'profiles', '%s_pmc_mfma.json' % tag), 'w'), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+    mfma(tag)
+    if not os.path.exists(os.path.join(REPO, 'gpurun_out', 'pmc_%s_FETCH_SIZE' % tag, 'pmc_results.db')):
+        return
     lines, vals = [], {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         for name, n, avg, mn, mx, dur in stats(tag, c):

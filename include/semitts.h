@@ -202,8 +202,10 @@ int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wprev, const fl
                     int B, int L, int A, int F, int K, void* stream);   /* parts = workgroups per utterance: 1, 2 or 4 */
 int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
                         float* w_out, int ld_wout, float* w_cum_out, const float* v,
-                        const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
+                        const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx, int parts,
                         int B, int L, int A, int E, int F, int K, void* stream);
+/* (parts = workgroups per utterance of the fin part: each takes E/parts context dims and repeats the energies + softmax;
+ *  1, 2, 4 or 8 with E % (4*parts) == 0) */
 /* st_skinny_linear_packed_fwd plus, as extra workgroups of the same launch (one per utterance), st_attn_pre_fwd for the NEXT
  * decode step: the proj (+) gate launch of step t leaves most compute units idle and the attention weights of step t are
  * already known, so S of step t+1 is ready when its attention launch starts. */
@@ -450,6 +452,7 @@ typedef struct st_decoder_io {
                                * the proj (+) gate launch of step t (st_skinny_linear_packed_attnpre_fwd), the attention launch
                                * itself starts from S (free-running fused-prenet inference) */
     int attn_pre_parts;       /* workgroups per utterance of the pre part (1, 2, 4) */
+    int attn_fin_parts;       /* workgroups per utterance of the fin part (0/1, 2, 4, 8; E % (4*parts) == 0) */
     int defer_proj;           /* pure teacher forcing only: skip the per-step proj (+) gate launch; the caller computes mel /
                                * stop for all steps with one GEMM over xo_tape afterwards (mel_out / stop_out untouched) */
     int pre1_step_floats;     /* > 0: pre1_t16 is a tape of `steps` slots of that many floats (training keeps the prenet

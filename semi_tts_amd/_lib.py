@@ -53,7 +53,7 @@ class StDecoderIO(C.Structure):
                 ('cq_tape', C.c_void_p), ('cd_tape', C.c_void_p), ('wcum_tape', C.c_void_p),
                 ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
                 ('zero_row', C.c_void_p), ('preq_buf', C.c_void_p), ('pred_buf', C.c_void_p), ('overlap', C.c_int),
-                ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('defer_proj', C.c_int),
+                ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('attn_fin_parts', C.c_int), ('defer_proj', C.c_int),
                 ('pre1_step_floats', C.c_int)]
 
 
@@ -137,11 +137,7 @@ SIGNATURES = {
     'st_skinny_linear_packed_attnpre_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                             I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StAttnPreJob), P],
     'st_attn_pre_fwd': [P, P, I, P, P, P, P, I, I, I, I, I, I, P],
-    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
-    'st_skinny_linear_packed_attnpre_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
-                                            I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StAttnPreJob), P],
-    'st_attn_pre_fwd': [P, P, I, P, P, P, P, I, I, I, I, I, I, P],
-    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
+    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],

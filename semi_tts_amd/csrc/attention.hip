@@ -27,7 +27,7 @@ int at_launch(const AtArgs& a, hipStream_t stream) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    const int nwg = a.B * (PART == 1 && a.pre_parts > 1 ? a.pre_parts : 1);
+    const int nwg = a.B * (PART == 1 && a.pre_parts > 1 ? a.pre_parts : PART == 2 && a.fin_parts > 1 ? a.fin_parts : 1);
     if (vec) hipLaunchKernelGGL((at_kernel<true, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a);
     else hipLaunchKernelGGL((at_kernel<false, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a);
     ST_LAUNCH_CHECK();
@@ -91,15 +91,18 @@ extern "C" int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wpre
 
 extern "C" int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
                                    float* w_out, int ld_wout, float* w_cum_out, const float* v,
-                                   const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx,
+                                   const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx, int parts,
                                    int B, int L, int A, int E, int F, int K, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(n_ctx_dst >= 0 && n_ctx_dst <= 3 && (n_ctx_dst == 0 || ctx_dst), "st_attn_fin_t16_fwd: n_ctx_dst=%d", n_ctx_dst);
+    ST_CHECK_ARG(parts == 1 || ((parts == 2 || parts == 4 || parts == 8) && E % (4 * parts) == 0),
+                 "st_attn_fin_t16_fwd: parts=%d must be 1, 2, 4 or 8 with E=%d a multiple of 4*parts", parts, E);
     AtArgs a;
     memset(&a, 0, sizeof(a));
     a.pq = pq; a.pm = s_buf; a.s_buf = const_cast<float*>(s_buf); a.memory = memory; a.w_cum_prev = w_cum_prev;
     a.w_out = w_out; a.ld_wout = ld_wout; a.w_cum_out = w_cum_out; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx;
     a.loc_lin_w = s_buf;     // (unused by this part; only its alignment is looked at)
+    a.fin_parts = parts;
     for (int d = 0; d < n_ctx_dst; ++d) a.ctx_dst[d] = ctx_dst[d];
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
     return at_launch<2>(a, (hipStream_t)stream);

@@ -43,6 +43,8 @@ struct AtArgs {
     const float* h_q; int ld_hq; const float* ada_std; const float* ada_mean; float* h_adapt; int Q;
     float* s_buf;      // (B, L, A): S = pm + W_l cf, written by the pre part, read by the fin part
     int pre_parts;     // pre part only: workgroups per utterance, each a contiguous range of positions (1, 2 or 4)
+    int fin_parts;     // fin part only: workgroups per utterance, each a slice of the context dims E (1, 2, 4 or 8); every one
+                       // repeats the energies + softmax (cheap), so the memory rows -- the bulk of the bytes -- are spread over more CUs
     int B, L, A, E, F, K;
 };
 
@@ -85,19 +87,20 @@ template <bool VEC, int PART>
 __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* lds) {
     // the pre part may spread an utterance over several workgroups (ranges of positions): only the conv and the W_l product
     // scale with the range, the staging is repeated
-    const int nparts = (PART == 1 && a.pre_parts > 1) ? a.pre_parts : 1;
+    const int nparts = (PART == 1 && a.pre_parts > 1) ? a.pre_parts : (PART == 2 && a.fin_parts > 1) ? a.fin_parts : 1;
     const int b = wg / nparts, ipart = wg - b * nparts;
     // kernel arguments of the first phases: fetched now, one wait (otherwise one scalar-cache round trip per first use)
 #define AT_TOUCH(x) asm volatile("" :: "s"(x))
     AT_TOUCH(a.pq); AT_TOUCH(a.pm); AT_TOUCH(a.memory); AT_TOUCH(a.w_prev); AT_TOUCH(a.ld_wprev); AT_TOUCH(a.w_cum_prev);
+    AT_TOUCH(a.s_buf); AT_TOUCH(a.w_out); AT_TOUCH(a.w_cum_out); AT_TOUCH(a.ld_wout);
     AT_TOUCH(a.loc_conv_w); AT_TOUCH(a.loc_lin_w); AT_TOUCH(a.v); AT_TOUCH(a.L); AT_TOUCH(a.A); AT_TOUCH(a.E); AT_TOUCH(a.F); AT_TOUCH(a.K);
 #undef AT_TOUCH
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
     const AtLds o = at_layout(L, A, E, F, K);
     // position range of this workgroup (multiples of 12 = lcm of the conv's 4-blocks and the energy phase's 6-blocks)
-    const int pos_per = nparts > 1 ? (((L + nparts - 1) / nparts + 11) / 12) * 12 : L;
-    const int pos_lo = min(L, ipart * pos_per), pos_hi = min(L, pos_lo + pos_per);
+    const int pos_per = (PART == 1 && nparts > 1) ? (((L + nparts - 1) / nparts + 11) / 12) * 12 : L;
+    const int pos_lo = PART == 1 ? min(L, ipart * pos_per) : 0, pos_hi = min(L, pos_lo + pos_per);
     float* Wt = lds + o.wt;
     float* Wc = lds + o.wc;
     float* hs = lds + o.hs;
@@ -107,17 +110,41 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     const int pad = (K - 1) / 2;
 
     AT_PROF(0);
+    // ---- fin part: the operands of the energy phase are requested first (nothing is staged in LDS for this part, so the
+    // wave's first block of S rows, pq and v can be in flight from the first instruction on), then cum_prev for the softmax
+    const float* pmb = (PART == 2 ? a.s_buf : a.pm) + (size_t)b * L * A;
+    const float* pqb = a.pq + (size_t)b * A;
+    f32x4 pf_pm4[AT_LP], pf_pq4 = {0.f, 0.f, 0.f, 0.f}, pf_v4 = {0.f, 0.f, 0.f, 0.f};
+    float pf_cum = 0.0f;
+    const bool pf_ok = PART == 2 && VEC && wave * AT_LP < L && lane * 4 < A;
+    if (PART == 2 && VEC) {
+#pragma unroll
+        for (int j = 0; j < AT_LP; ++j) {
+            const int l = min(wave * AT_LP + j, L - 1);
+            pf_pm4[j] = st_ld4(pmb + (size_t)l * A + min(lane * 4, A - 4));
+        }
+        pf_pq4 = st_ld4(pqb + min(lane * 4, A - 4));
+        pf_v4 = st_ld4(a.v + min(lane * 4, A - 4));
+        if (wave == 0) pf_cum = a.w_cum_prev[(size_t)b * L + min(lane, L - 1)];
+    }
     // ---- P0a: context prefetch (memory rows l = g, g+ng, ...)
-    const int ne4 = E >> 2;                    // E % 4 == 0 checked on the host
+    const int Es = PART == 2 ? E / nparts : E; // context dims of this workgroup (E % (4 * parts) == 0 checked on the host)
+    const int e_lo = PART == 2 ? ipart * Es : 0;
+    const int ne4 = Es >> 2;
     const int ng = AT_THREADS / ne4;           // row groups (>= 1 checked on the host)
     const int e4 = tid % ne4, g = tid / ne4;
     const bool ctx_active = g < ng;
     const float* memb = a.memory + (size_t)b * L * E;
     f32x4 mpf[AT_PF];
+    if (PART != 1) {
+        // buffer loads: one descriptor per utterance whose size ends at row L, so rows past L (and idle threads, sent past
+        // the end) read zeros without a branch or a 64-bit address per row
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)memb, 0, L * E * 4, 0x00020000);
+        const int v0 = ctx_active ? (g * E + e_lo + e4 * 4) * 4 : 0x7ffffff0;
+        const int vstep = ng * E * 4;
 #pragma unroll
-    for (int j = 0; j < AT_PF; ++j) {
-        const int l = g + j * ng;
-        mpf[j] = (PART != 1 && ctx_active && l < L) ? st_ld4(memb + (size_t)l * E + e4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < AT_PF; ++j)
+            mpf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, ctx_active ? v0 + j * vstep : v0, 0, 0));
     }
 
     AT_PROF(1);
@@ -171,14 +198,14 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         }
     }
     }
-    if (a.h_q) {  // AdaIN: relu(W_s s + b) * (h_q - (W_m s + b)), the two Linears are hoisted
+    if (a.h_q && ipart == 0) {  // AdaIN: relu(W_s s + b) * (h_q - (W_m s + b)), the two Linears are hoisted
         for (int j = tid; j < a.Q; j += AT_THREADS) {
             const size_t q = (size_t)b * a.Q + j;
             a.h_adapt[q] = a.ada_std[q] * (a.h_q[(size_t)b * a.ld_hq + j] - a.ada_mean[q]);
         }
     }
     AT_PROF(2);
-    __syncthreads();
+    if (PART != 2) __syncthreads();
     AT_PROF(3);
 
     if (PART != 2) {
@@ -253,13 +280,11 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     }
     }
     AT_PROF(4);
-    __syncthreads();
+    if (PART != 2) __syncthreads();
     AT_PROF(5);
 
     // ---- P2: energies; a wave owns AT_LB consecutive positions, a lane 4 consecutive dims
     // PART 2 reads S (= pm + W_l cf, written by the pre part) where the full kernel reads pm
-    const float* pmb = (PART == 2 ? a.s_buf : a.pm) + (size_t)b * L * A;
-    const float* pqb = a.pq + (size_t)b * A;
     for (int l0 = pos_lo + wave * AT_LP; l0 < pos_hi; l0 += AT_WAVES * AT_LP) {
         float esum[AT_LB];
 #pragma unroll
@@ -267,7 +292,12 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         for (int a0 = lane * 4; a0 < A; a0 += 256) {
             const int rem = A - a0;
             f32x4 pm4[AT_LP], pq4, v4;
-            if (VEC) {          // A % 4 == 0 and aligned operands: plain 16-byte loads, no per-lane branches
+            if (pf_ok && l0 == wave * AT_LP && a0 == lane * 4) {      // requested at the top of the kernel
+#pragma unroll
+                for (int j = 0; j < AT_LP; ++j) pm4[j] = pf_pm4[j];
+                pq4 = pf_pq4;
+                v4 = pf_v4;
+            } else if (VEC) {   // A % 4 == 0 and aligned operands: plain 16-byte loads, no per-lane branches
 #pragma unroll
                 for (int j = 0; j < AT_LP; ++j) {
                     const int l = l0 + j < L ? l0 + j : L - 1;
@@ -316,19 +346,22 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                 }
                 continue;
             }
+            // v . tanh(x) with tanh(x) = 1 - 2 / (1 + exp(2x)):  sum_c v_c - 2 sum_c v_c / (1 + exp(2 x_c)) -- per element one
+            // v_exp_f32, one v_rcp_f32 and three plain VALU ops (this phase is VALU-issue bound: 43 x 256 tanh per utterance on
+            // one CU); exp -> inf gives 1, exp -> 0 gives -1, |error| ~1e-7 absolute like at_tanh
+            const float vsum = (v4[0] + v4[1]) + (v4[2] + v4[3]);
 #pragma unroll
             for (int j = 0; j < AT_LP; ++j) {
+                float acc = 0.0f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    // (processed_query + processed_loc_feat) + processed_memory, module.py:389-390
-#ifdef AT_ABLATE_TANH
-                    float t = (pq4[c] + loc[j][c]) + pm4[j][c];
-#else
-                    float t = at_tanh((pq4[c] + loc[j][c]) + pm4[j][c]);
-#endif
-                    if (!VEC) t = c < rem ? t : 0.0f;   // W_l^T pad columns hold garbage
-                    esum[j] = fmaf(v4[c], t, esum[j]);
+                    // (processed_query + processed_loc_feat) + processed_memory, module.py:389-390 (fin part: loc is inside S)
+                    const float x = PART == 2 ? pq4[c] + pm4[j][c] : (pq4[c] + loc[j][c]) + pm4[j][c];
+                    float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
+                    if (!VEC) r = c < rem ? r : 0.0f;   // W_l^T pad columns hold garbage (v4 is zero there)
+                    acc = fmaf(v4[c], r, acc);
                 }
+                esum[j] += fmaf(-2.0f, acc, vsum);
             }
         }
         if (PART == 1) continue;
@@ -378,8 +411,9 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         for (int l = lane; l < L; l += 64) {
             const float w = es[l] / s;
             es[l] = w;
+            if (PART == 2 && ipart != 0) continue;      // the other context slices repeat the softmax, one of them writes it
             a.w_out[(size_t)b * a.ld_wout + l] = w;
-            const float cum_prev = PART == 2 ? a.w_cum_prev[(size_t)b * L + l] : hs[o.hl + pad + l];
+            const float cum_prev = PART == 2 ? (VEC && l < 64 ? pf_cum : a.w_cum_prev[(size_t)b * L + l]) : hs[o.hl + pad + l];
             a.w_cum_out[(size_t)b * L + l] = w + cum_prev;              // weights + attn_weights_sum, :264
         }
     }
@@ -391,16 +425,15 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     if (ctx_active) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < AT_PF; ++j) {
+        for (int j = 0; j < AT_PF; ++j) {        // rows past L were read as zeros: clamp the weight index, no branch
             const int l = g + j * ng;
-            if (l < L) {
-                const float w = es[l];
-                acc[0] = fmaf(w, mpf[j][0], acc[0]); acc[1] = fmaf(w, mpf[j][1], acc[1]);
-                acc[2] = fmaf(w, mpf[j][2], acc[2]); acc[3] = fmaf(w, mpf[j][3], acc[3]);
-            }
+            const float wv = es[min(l, L - 1)];
+            const float w = l < L ? wv : 0.0f;
+            acc[0] = fmaf(w, mpf[j][0], acc[0]); acc[1] = fmaf(w, mpf[j][1], acc[1]);
+            acc[2] = fmaf(w, mpf[j][2], acc[2]); acc[3] = fmaf(w, mpf[j][3], acc[3]);
         }
         for (int l = g + AT_PF * ng; l < L; l += ng) {
-            const f32x4 m4 = st_ld4(memb + (size_t)l * E + e4 * 4);
+            const f32x4 m4 = st_ld4(memb + (size_t)l * E + e_lo + e4 * 4);
             const float w = es[l];
             acc[0] = fmaf(w, m4[0], acc[0]); acc[1] = fmaf(w, m4[1], acc[1]);
             acc[2] = fmaf(w, m4[2], acc[2]); acc[3] = fmaf(w, m4[3], acc[3]);
@@ -410,13 +443,13 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     AT_PROF(10);
     __syncthreads();
     AT_PROF(11);
-    for (int e = tid; e < E; e += AT_THREADS) {
+    for (int e = tid; e < Es; e += AT_THREADS) {
         float s = 0.0f;
-        for (int gg = 0; gg < ng; ++gg) s += part[gg * E + e];
-        if (a.ctx) a.ctx[(size_t)b * a.ld_ctx + e] = s;
+        for (int gg = 0; gg < ng; ++gg) s += part[gg * Es + e];
+        if (a.ctx) a.ctx[(size_t)b * a.ld_ctx + e_lo + e] = s;
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-            if (a.ctx_dst[d].base) a.ctx_dst[d].base[at_t16_off(b, a.ctx_dst[d].kb0 * 16 + e, a.ctx_dst[d].kb_stride)] = s;
+            if (a.ctx_dst[d].base) a.ctx_dst[d].base[at_t16_off(b, a.ctx_dst[d].kb0 * 16 + e_lo + e, a.ctx_dst[d].kb_stride)] = s;
     }
     AT_PROF(12);
 }

@@ -216,6 +216,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     // projection = teacher-forced training) the query-projection launch of the same step.
     const bool split_attn = io->attn_s_buf && !ov;
     const bool pre_in_pq = split_attn && io->defer_proj;
+    const int fp_req = io->attn_fin_parts;
+    const int fin_parts = (fp_req == 2 || fp_req == 4 || fp_req == 8) && E % (4 * fp_req) == 0 ? fp_req : 1;
     hipStream_t sb = aux ? ax->s : st;
     if (ov) ST_HIP(hipMemsetAsync(io->preq_buf, 0, 4 * BQ * sizeof(float), st));   // step 0: ctx_{-1} = h_q_{-1} = 0
     if (aux) {
@@ -276,7 +278,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         if (split_attn)     // S of this step was written inside the previous proj launch (step 0: no history yet, S = pm)
             rc = st_attn_fin_t16_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf, io->memory, io->wcum_tape + (size_t)t * BL,
                                      io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL, w->attn_v,
-                                     ctx_dst, 3, nullptr, 0, B, L, A, E, d->F, d->K, stream);
+                                     ctx_dst, 3, nullptr, 0, fin_parts, B, L, A, E, d->F, d->K, stream);
         else
             rc = st_attn_step_t16_fwd(io->pq_buf, io->pm, io->memory, w_prev, t == 0 ? L : ldal,
                                       io->wcum_tape + (size_t)t * BL, io->align_out + (size_t)t * L, ldal,

@@ -121,11 +121,11 @@ def attn_pre(pm, w_prev, w_cum_prev, loc_conv_w, loc_lin_w, s_buf=None, parts=1)
     return s_buf
 
 
-def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K):
+def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K, parts=1):
     B, L, E = memory.shape
     A = s_buf.shape[-1]
     check(_lib.load().st_attn_fin_t16_fwd(_p(pq), _p(s_buf), _p(memory), _p(w_cum_prev), _p(w_out), int(w_out.stride(0)),
-                                          _p(w_cum_out), _p(v), None, 0, _p(ctx), int(ctx.stride(0)), B, L, A, E, int(F_), int(K),
+                                          _p(w_cum_out), _p(v), None, 0, _p(ctx), int(ctx.stride(0)), int(parts), B, L, A, E, int(F_), int(K),
                                           stream_handle()), 'st_attn_fin_t16_fwd')
 
 

@@ -229,6 +229,15 @@ def test_attention_step_in_two_parts(dev, B, L, A, E, F, K):
         assert torch.equal(ops.attn_pre(d[1], d[3], d[4], d[5], d[6], parts=parts), s_buf)
     w2, c2, x2 = torch.empty_like(w1), torch.empty_like(c1), torch.empty_like(x1)
     ops.attn_fin(d[0], s_buf, d[2], d[4], d[7], w2, c2, x2, F, K)
+    for parts in (2, 4, 8):    # the fin part over several workgroups per utterance (slices of the context dims)
+        w3, c3, x3 = torch.empty_like(w1), torch.empty_like(c1), torch.empty_like(x1)
+        if E % (4 * parts):    # a slice must be whole float4 columns: refused, not mis-computed
+            with pytest.raises(RuntimeError):
+                ops.attn_fin(d[0], s_buf, d[2], d[4], d[7], w3, c3, x3, F, K, parts=parts)
+            continue
+        ops.attn_fin(d[0], s_buf, d[2], d[4], d[7], w3, c3, x3, F, K, parts=parts)
+        assert torch.equal(w3, w2) and torch.equal(c3, c2)
+        assert float((x3 - x2).abs().max()) < 1e-6
     errs = dict(w=maxdiff(w2, w1), cum=maxdiff(c2, c1), ctx=maxdiff(x2, x1))
     report('attention_two_parts', B=B, L=L, A=A, **errs)
     assert errs['w'] < 2e-6 and errs['cum'] < 2e-6 and errs['ctx'] < 2e-5      # (pq + ploc) + pm vs pq + (pm + ploc)

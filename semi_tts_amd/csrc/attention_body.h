@@ -83,8 +83,12 @@ __device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
 // PART 0: the whole step.  PART 1 ("pre"): only what depends on the PREVIOUS step's attention weights -- location conv and
 // S[l][a] = pm[l][a] + sum_f W_l[a][f] cf[f][l] -- written to a.s_buf; it can run while the rest of the decode step does
 // (as extra workgroups of the proj launch, skinny_packed.hip).  PART 2 ("fin"): energies from S, softmax, context.
-template <bool VEC, int PART>
+// NT = threads per workgroup (512 in every launch; a 256-thread fin part measured slower, see attention.hip)
+template <bool VEC, int PART, int NT = AT_THREADS>
 __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* lds) {
+    constexpr int NWV = NT / 64;                      // waves
+    constexpr int PFR = AT_PF * (AT_THREADS / NT);    // memory rows parked in registers per thread
+    constexpr int NPB = PART == 2 ? AT_THREADS / NT : 0;   // energy blocks per wave whose operands are requested at kernel entry
     // the pre part may spread an utterance over several workgroups (ranges of positions): only the conv and the W_l product
     // scale with the range, the staging is repeated
     const int nparts = (PART == 1 && a.pre_parts > 1) ? a.pre_parts : (PART == 2 && a.fin_parts > 1) ? a.fin_parts : 1;
@@ -114,14 +118,17 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     // wave's first block of S rows, pq and v can be in flight from the first instruction on), then cum_prev for the softmax
     const float* pmb = (PART == 2 ? a.s_buf : a.pm) + (size_t)b * L * A;
     const float* pqb = a.pq + (size_t)b * A;
-    f32x4 pf_pm4[AT_LP], pf_pq4 = {0.f, 0.f, 0.f, 0.f}, pf_v4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pf_pm4[NPB > 0 ? NPB : 1][AT_LP], pf_pq4 = {0.f, 0.f, 0.f, 0.f}, pf_v4 = {0.f, 0.f, 0.f, 0.f};
     float pf_cum = 0.0f;
-    const bool pf_ok = PART == 2 && VEC && wave * AT_LP < L && lane * 4 < A;
+    const bool pf_ok = PART == 2 && VEC && lane * 4 < A;
     if (PART == 2 && VEC) {
 #pragma unroll
-        for (int j = 0; j < AT_LP; ++j) {
-            const int l = min(wave * AT_LP + j, L - 1);
-            pf_pm4[j] = st_ld4(pmb + (size_t)l * A + min(lane * 4, A - 4));
+        for (int i = 0; i < NPB; ++i) {
+#pragma unroll
+            for (int j = 0; j < AT_LP; ++j) {
+                const int l = min((wave + i * NWV) * AT_LP + j, L - 1);
+                pf_pm4[i][j] = st_ld4(pmb + (size_t)l * A + min(lane * 4, A - 4));
+            }
         }
         pf_pq4 = st_ld4(pqb + min(lane * 4, A - 4));
         pf_v4 = st_ld4(a.v + min(lane * 4, A - 4));
@@ -131,11 +138,11 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     const int Es = PART == 2 ? E / nparts : E; // context dims of this workgroup (E % (4 * parts) == 0 checked on the host)
     const int e_lo = PART == 2 ? ipart * Es : 0;
     const int ne4 = Es >> 2;
-    const int ng = AT_THREADS / ne4;           // row groups (>= 1 checked on the host)
+    const int ng = NT / ne4;           // row groups (>= 1 checked on the host)
     const int e4 = tid % ne4, g = tid / ne4;
     const bool ctx_active = g < ng;
     const float* memb = a.memory + (size_t)b * L * E;
-    f32x4 mpf[AT_PF];
+    f32x4 mpf[PFR];
     if (PART != 1) {
         // buffer loads: one descriptor per utterance whose size ends at row L, so rows past L (and idle threads, sent past
         // the end) read zeros without a branch or a 64-bit address per row
@@ -143,7 +150,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         const int v0 = ctx_active ? (g * E + e_lo + e4 * 4) * 4 : 0x7ffffff0;
         const int vstep = ng * E * 4;
 #pragma unroll
-        for (int j = 0; j < AT_PF; ++j)
+        for (int j = 0; j < PFR; ++j)
             mpf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, ctx_active ? v0 + j * vstep : v0, 0, 0));
     }
 
@@ -158,7 +165,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     if (wl_vec) {
 #pragma unroll
         for (int j = 0; j < AT_WLPF; ++j) {
-            const int idx = tid + j * AT_THREADS;
+            const int idx = tid + j * NT;
             wl4[j] = idx < A * f4n ? st_ld4(a.loc_lin_w + (size_t)idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -170,27 +177,27 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         float wcv[4], hv[2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int idx = tid + j * AT_THREADS;
+            const int idx = tid + j * NT;
             const int row = idx / KP, k = idx - row * KP;
             wcv[j] = (idx < nwc && k < K) ? a.loc_conv_w[row * K + k] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int idx = tid + j * AT_THREADS;
+            const int idx = tid + j * NT;
             const int c = idx / o.hl, p = idx - c * o.hl, l = p - pad;
             float v = 0.0f;
             if (idx < nhs && l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
             hv[j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int idx = tid + j * AT_THREADS; if (idx < nwc) Wc[idx] = wcv[j]; }
+        for (int j = 0; j < 4; ++j) { const int idx = tid + j * NT; if (idx < nwc) Wc[idx] = wcv[j]; }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const int idx = tid + j * AT_THREADS; if (idx < nhs) hs[idx] = hv[j]; }
-        for (int idx = tid + 4 * AT_THREADS; idx < nwc; idx += AT_THREADS) {      // sizes beyond the register rounds
+        for (int j = 0; j < 2; ++j) { const int idx = tid + j * NT; if (idx < nhs) hs[idx] = hv[j]; }
+        for (int idx = tid + 4 * NT; idx < nwc; idx += NT) {      // sizes beyond the register rounds
             const int row = idx / KP, k = idx - row * KP;
             Wc[idx] = k < K ? a.loc_conv_w[row * K + k] : 0.0f;
         }
-        for (int idx = tid + 2 * AT_THREADS; idx < nhs; idx += AT_THREADS) {
+        for (int idx = tid + 2 * NT; idx < nhs; idx += NT) {
             const int c = idx / o.hl, p = idx - c * o.hl, l = p - pad;
             float v = 0.0f;
             if (l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
@@ -199,7 +206,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     }
     }
     if (a.h_q && ipart == 0) {  // AdaIN: relu(W_s s + b) * (h_q - (W_m s + b)), the two Linears are hoisted
-        for (int j = tid; j < a.Q; j += AT_THREADS) {
+        for (int j = tid; j < a.Q; j += NT) {
             const size_t q = (size_t)b * a.Q + j;
             a.h_adapt[q] = a.ada_std[q] * (a.h_q[(size_t)b * a.ld_hq + j] - a.ada_mean[q]);
         }
@@ -212,7 +219,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     // ---- P1: location conv, cf[f][l] = sum_c sum_k Wc[f][c][k] * hist[c][l + k - pad]
     {
         const int nlb = (pos_hi - pos_lo + AT_CB - 1) / AT_CB;
-        for (int idx = tid; idx < F * nlb; idx += AT_THREADS) {
+        for (int idx = tid; idx < F * nlb; idx += NT) {
             const int f = idx / nlb, l0 = pos_lo + (idx - f * nlb) * AT_CB;
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
             if (KP == 32) {
@@ -259,21 +266,21 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     if (wl_vec) {
 #pragma unroll
         for (int j = 0; j < AT_WLPF; ++j) {
-            const int idx = tid + j * AT_THREADS;
+            const int idx = tid + j * NT;
             if (idx < A * f4n) {
                 const int aa = idx / f4n, f0 = (idx - aa * f4n) * 4;
                 Wt[(f0 + 0) * o.wt_ld + aa] = wl4[j][0]; Wt[(f0 + 1) * o.wt_ld + aa] = wl4[j][1];
                 Wt[(f0 + 2) * o.wt_ld + aa] = wl4[j][2]; Wt[(f0 + 3) * o.wt_ld + aa] = wl4[j][3];
             }
         }
-        for (int idx = tid + AT_WLPF * AT_THREADS; idx < A * f4n; idx += AT_THREADS) {
+        for (int idx = tid + AT_WLPF * NT; idx < A * f4n; idx += NT) {
             const int aa = idx / f4n, f0 = (idx - aa * f4n) * 4;
             const f32x4 w4 = st_ld4(a.loc_lin_w + (size_t)idx * 4);
             Wt[(f0 + 0) * o.wt_ld + aa] = w4[0]; Wt[(f0 + 1) * o.wt_ld + aa] = w4[1];
             Wt[(f0 + 2) * o.wt_ld + aa] = w4[2]; Wt[(f0 + 3) * o.wt_ld + aa] = w4[3];
         }
     } else {
-        for (int idx = tid; idx < A * F; idx += AT_THREADS) {
+        for (int idx = tid; idx < A * F; idx += NT) {
             const int aa = idx / F, f = idx - aa * F;
             Wt[f * o.wt_ld + aa] = a.loc_lin_w[idx];
         }
@@ -285,16 +292,16 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
 
     // ---- P2: energies; a wave owns AT_LB consecutive positions, a lane 4 consecutive dims
     // PART 2 reads S (= pm + W_l cf, written by the pre part) where the full kernel reads pm
-    for (int l0 = pos_lo + wave * AT_LP; l0 < pos_hi; l0 += AT_WAVES * AT_LP) {
+    auto energy_block = [&](const int l0, const f32x4* pf) __attribute__((always_inline)) {
         float esum[AT_LB];
 #pragma unroll
         for (int j = 0; j < AT_LB; ++j) esum[j] = 0.0f;        // slots AT_LP.. stay zero
         for (int a0 = lane * 4; a0 < A; a0 += 256) {
             const int rem = A - a0;
             f32x4 pm4[AT_LP], pq4, v4;
-            if (pf_ok && l0 == wave * AT_LP && a0 == lane * 4) {      // requested at the top of the kernel
+            if (pf && pf_ok && a0 == lane * 4) {      // requested at the top of the kernel
 #pragma unroll
-                for (int j = 0; j < AT_LP; ++j) pm4[j] = pf_pm4[j];
+                for (int j = 0; j < AT_LP; ++j) pm4[j] = pf[j];
                 pq4 = pf_pq4;
                 v4 = pf_v4;
             } else if (VEC) {   // A % 4 == 0 and aligned operands: plain 16-byte loads, no per-lane branches
@@ -364,7 +371,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                 esum[j] += fmaf(-2.0f, acc, vsum);
             }
         }
-        if (PART == 1) continue;
+        if (PART == 1) return;
         // 8 sums over 64 lanes with 10 shuffles: each butterfly step also halves the number of
         // values a lane carries (instead of 8 independent 6-step reductions)
         static_assert(AT_LB == 8 && AT_LP <= AT_LB && AT_LP % 2 == 0, "the folded reduction below reduces 8 slots per wave");
@@ -383,14 +390,19 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                 const float keep = hi16 ? r4[j + 2] : r4[j];
                 r2[j] = keep + __shfl_xor(send, 16, 64);
             }
-            float r = (hi8 ? r2[1] : r2[0]) + __shfl_xor(hi8 ? r2[0] : r2[1], 8, 64);
-            r += __shfl_xor(r, 4, 64);
-            r += __shfl_xor(r, 2, 64);
-            r += __shfl_xor(r, 1, 64);
+            // the last four steps stay inside a row of 16 lanes: DPP permutations instead of LDS-crossbar shuffles
+            float r = (hi8 ? r2[1] : r2[0]) + st_dpp<ST_DPP_ROW_ROR8>(hi8 ? r2[0] : r2[1]);
+            r = st_oct_sum_dpp(r);
             const int l = l0 + (lane >> 3);      // bits 5,4,3 of the lane select the position
             if ((lane & 7) == 0 && (lane >> 3) < AT_LP && l < L) es[l] = r;
         }
+    };
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {      // (fin part: pos_lo = 0, pos_hi = L)
+        const int l0 = (wave + i * NWV) * AT_LP;
+        if (l0 < pos_hi) energy_block(l0, pf_pm4[i]);
     }
+    for (int l0 = pos_lo + (wave + NPB * NWV) * AT_LP; l0 < pos_hi; l0 += NWV * AT_LP) energy_block(l0, nullptr);
     if (PART == 1) return;
     AT_PROF(6);
     __syncthreads();
@@ -400,14 +412,14 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     if (wave == 0) {
         float m = -INFINITY;
         for (int l = lane; l < L; l += 64) m = fmaxf(m, es[l]);
-        m = st_wave_max(m);
+        m = st_wave_max_dpp(m);
         float s = 0.0f;
         for (int l = lane; l < L; l += 64) {
             const float ex = expf(es[l] - m);
             es[l] = ex;
             s += ex;
         }
-        s = st_wave_sum(s);
+        s = st_wave_sum_dpp(s);
         for (int l = lane; l < L; l += 64) {
             const float w = es[l] / s;
             es[l] = w;
@@ -425,14 +437,14 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     if (ctx_active) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < AT_PF; ++j) {        // rows past L were read as zeros: clamp the weight index, no branch
+        for (int j = 0; j < PFR; ++j) {        // rows past L were read as zeros: clamp the weight index, no branch
             const int l = g + j * ng;
             const float wv = es[min(l, L - 1)];
             const float w = l < L ? wv : 0.0f;
             acc[0] = fmaf(w, mpf[j][0], acc[0]); acc[1] = fmaf(w, mpf[j][1], acc[1]);
             acc[2] = fmaf(w, mpf[j][2], acc[2]); acc[3] = fmaf(w, mpf[j][3], acc[3]);
         }
-        for (int l = g + AT_PF * ng; l < L; l += ng) {
+        for (int l = g + PFR * ng; l < L; l += ng) {
             const f32x4 m4 = st_ld4(memb + (size_t)l * E + e_lo + e4 * 4);
             const float w = es[l];
             acc[0] = fmaf(w, m4[0], acc[0]); acc[1] = fmaf(w, m4[1], acc[1]);
@@ -443,7 +455,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     AT_PROF(10);
     __syncthreads();
     AT_PROF(11);
-    for (int e = tid; e < Es; e += AT_THREADS) {
+    for (int e = tid; e < Es; e += NT) {
         float s = 0.0f;
         for (int gg = 0; gg < ng; ++gg) s += part[gg * Es + e];
         if (a.ctx) a.ctx[(size_t)b * a.ld_ctx + e_lo + e] = s;
@@ -455,10 +467,10 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
 }
 
 
-template <bool VEC, int PART>
-__global__ __launch_bounds__(AT_THREADS) void at_kernel(const AtArgs a) {
+template <bool VEC, int PART, int NT = AT_THREADS>
+__global__ __launch_bounds__(NT) void at_kernel(const AtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float at_lds[];
-    at_body<VEC, PART>(a, blockIdx.x, at_lds);
+    at_body<VEC, PART, NT>(a, blockIdx.x, at_lds);
 }
 
 }  // namespace

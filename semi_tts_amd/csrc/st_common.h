@@ -68,6 +68,40 @@ __device__ __forceinline__ float st_wave_max(float v) {
     return v;
 }
 
+// DPP forms of the wave reductions (all 64 lanes must be active): the permutations ride on the VALU instruction itself, where
+// __shfl_xor is a ds_bpermute_b32 through the LDS crossbar (~100 cycles of latency per step in a dependent chain)
+constexpr int ST_DPP_QUAD_XOR1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int ST_DPP_QUAD_XOR2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int ST_DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int ST_DPP_ROW_MIRROR = 0x140;
+constexpr int ST_DPP_ROW_ROR8 = 0x128;       // lane i of a row of 16 reads lane (i + 8) % 16 = i ^ 8
+template <int CTRL>
+__device__ __forceinline__ float st_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float st_lane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// sum over the 8 lanes sharing lane >> 3 (every one of them gets it)
+__device__ __forceinline__ float st_oct_sum_dpp(float v) {
+    v += st_dpp<ST_DPP_QUAD_XOR1>(v);
+    v += st_dpp<ST_DPP_QUAD_XOR2>(v);
+    v += st_dpp<ST_DPP_ROW_HALF_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float st_wave_sum_dpp(float v) {
+    v = st_oct_sum_dpp(v);
+    v += st_dpp<ST_DPP_ROW_MIRROR>(v);
+    return (st_lane(v, 0) + st_lane(v, 16)) + (st_lane(v, 32) + st_lane(v, 48));
+}
+__device__ __forceinline__ float st_wave_max_dpp(float v) {
+    v = fmaxf(v, st_dpp<ST_DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, st_dpp<ST_DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, st_dpp<ST_DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, st_dpp<ST_DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(st_lane(v, 0), st_lane(v, 16)), fmaxf(st_lane(v, 32), st_lane(v, 48)));
+}
+
 // 16-byte global load of 4 consecutive floats (caller guarantees alignment)
 __device__ __forceinline__ f32x4 st_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
                     acc = fmaf(d4[h][0], mpf[j][h][0], acc); acc = fmaf(d4[h][1], mpf[j][h][1], acc);
                     acc = fmaf(d4[h][2], mpf[j][h][2], acc); acc = fmaf(d4[h][3], mpf[j][h][3], acc);
                 }
-                acc = st_wave_sum(acc);
+                acc = st_wave_sum_dpp(acc);
                 if (lane == 0 && l < L) dws[l] += acc;
             }
             lstart = wave + 4 * NW;
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
                 acc = fmaf(d4[0], m4[0], acc); acc = fmaf(d4[1], m4[1], acc); acc = fmaf(d4[2], m4[2], acc); acc = fmaf(d4[3], m4[3], acc);
                 acc2 = fmaf(d4[0], n4[0], acc2); acc2 = fmaf(d4[1], n4[1], acc2); acc2 = fmaf(d4[2], n4[2], acc2); acc2 = fmaf(d4[3], n4[3], acc2);
             }
-            acc = st_wave_sum(acc);
-            acc2 = st_wave_sum(acc2);
+            acc = st_wave_sum_dpp(acc);
+            acc2 = st_wave_sum_dpp(acc2);
             if (lane == 0) { dws[l] += acc; if (l2 < L) dws[l2] += acc2; }
         }
     }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     if (wave == 0) {
         float acc = 0.0f;
         for (int l = lane; l < L; l += 64) acc = fmaf(ws[l], dws[l], acc);
-        acc = st_wave_sum(acc);
+        acc = st_wave_sum_dpp(acc);
         if (lane == 0) red[0] = acc;
     }
     __syncthreads();
@@ -413,9 +413,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
                 }
             }
         }
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        acc += __shfl_xor(acc, 4);
+        acc = st_oct_sum_dpp(acc);      // (uniform loop: all lanes active)
         if (cj < 2 * L && q == 0) dh[cj] = acc;
     }
     AB_PROF(7);

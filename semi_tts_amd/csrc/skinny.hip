@@ -165,10 +165,10 @@ __global__ __launch_bounds__(KW * 64) void sk_kernel(const SkArgs a) {
         for (int r = 0; r < 4; ++r) {
             g[r] = s[r] + (((a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f)) + (a.pre ? e_pr[r] : 0.0f));
         }
-        const float gi = st_sigmoid(g[0]), gf = st_sigmoid(g[1]), gg = tanhf(g[2]), go = st_sigmoid(g[3]);
+        const float gi = st_sigmoid_fast(g[0]), gf = st_sigmoid_fast(g[1]), gg = st_tanh_fast(g[2]), go = st_sigmoid_fast(g[3]);
         const float cp = a.c_prev ? e_c : 0.0f;
         const float c2 = gf * cp + gi * gg;
-        float h2 = go * tanhf(c2);
+        float h2 = go * st_tanh_fast(c2);
         if (a.mask) h2 *= e_m;
         a.c_out[(size_t)b * a.ldc + u] = c2;
         a.h_out[(size_t)b * a.ldh + u] = h2;

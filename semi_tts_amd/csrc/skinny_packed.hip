@@ -123,30 +123,33 @@ __device__ __forceinline__ void pk_store(const PkOut& d, int b, int k, float v) 
 }
 
 template <int NB, int TRIP>
-struct PkRegs { f32x4 w[TRIP]; f32x4 x[TRIP][NB]; bool ok[TRIP]; };
+struct PkRegs { f32x4 w[TRIP]; f32x4 x[TRIP][NB]; };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int pk_u32x4;
 
 // Loads go through buffer descriptors (SRSRC): base in four scalar registers, the wave-uniform k-block offset in a scalar
 // register, only the lane offset (lane * 16 B) in a vector register -- no 64-bit vector address arithmetic per load.
+#ifndef PK_W_AUX
+#define PK_W_AUX 0      // cache policy of the weight stream; 2 (nt) measured 12 % slower: the default policy keeps the 75 MB of weights in the 256 MB MALL across steps
+#endif
 struct PkSrc {
     __amdgpu_buffer_rsrc_t w, x;   // descriptors of the weight tile base / the activation base of this workgroup
     unsigned voff;                 // lane * 16
     int x_kbs;
 };
 
+// The weight descriptor ends at k-block KB (num_records = KB KiB past the tile base): a k-block past KB reads zeros by
+// itself, so there is no clamp, no validity flag and no select in front of the MFMAs.
 template <int NB, int KW, int TRIP>
 __device__ __forceinline__ void pk_load(PkRegs<NB, TRIP>& r, const PkSrc& src, int kb, int KB) {
+    (void)KB;
 #pragma unroll
     for (int t = 0; t < TRIP; ++t) {
-        int k = kb + t * KW;
-        k = k < KB ? k : KB - 1;        // clamped duplicate; its weight is zeroed when it is consumed (pk_mma): touching
-                                        // the loaded value here would make the wave wait for the load right away
-        r.w[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src.w, src.voff, k * 1024, 0));
+        const unsigned vo = src.voff + (unsigned)(kb + t * KW) * 1024u;
+        r.w[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src.w, vo, 0, PK_W_AUX));
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt)
-            r.x[t][bt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src.x, src.voff, (bt * src.x_kbs + k) * 1024, 0));
-        r.ok[t] = kb + t * KW < KB;
+            r.x[t][bt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src.x, vo, bt * src.x_kbs * 1024, 0));
     }
 }
 
@@ -154,7 +157,7 @@ template <int NB, int TRIP>
 __device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[NB]) {
 #pragma unroll
     for (int t = 0; t < TRIP; ++t) {
-        const f32x4 w = r.ok[t] ? r.w[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 w = r.w[t];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
@@ -193,8 +196,10 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     const int bt_base = bt0 + NB <= BT ? bt0 : (BT >= NB ? BT - NB : 0);
     const int KB = a.KB;
     PkSrc src;
-    src.w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)tile * a.w_kbs * 64), 0, 0x7fffffff, 0x00020000);
-    src.x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)bt_base * a.x_kbs * 64), 0, 0x7fffffff, 0x00020000);
+    src.w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)tile * a.w_kbs * 64), 0, KB * 1024, 0x00020000);
+    // (measured on gfx950: the scalar offset IS part of the range check, so the activation descriptor spans all NB batch
+    // tiles; a k-block past KB of an earlier tile then reads finite data of the same buffer against a zero weight block)
+    src.x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)bt_base * a.x_kbs * 64), 0, ((NB - 1) * a.x_kbs + KB) * 1024, 0x00020000);
     src.voff = (unsigned)lane * 16u;
     src.x_kbs = a.x_kbs;
     constexpr int STEP = KW * TRIP;
@@ -207,7 +212,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
 #ifdef PK_NO_ROTATE
     const int rot = 0;
 #else
-    const int rot = G > 0 ? (int)((unsigned)tile % (unsigned)G) : 0;
+    const int rot = (int)((((unsigned)tile & 255u) * (unsigned)G) >> 8);      // in [0, G), spread over the tiles, no division
 #endif
     auto kb_of = [&](int gq) { int q = gq + rot; if (q >= G) q -= G; return q * STEP + wave; };
     PkRegs<NB, TRIP> ra, rb;
@@ -226,6 +231,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     // Branch-free: absent operands are read from a valid dummy address (the weight buffer) and replaced by their neutral
     // value when they are consumed, so the block is a straight line of independent loads.
     const float* dummy = reinterpret_cast<const float*>(a.w);
+    auto epi_prefetch = [&]() __attribute__((always_inline)) {
     if (MODE == 0 && e_on) {
         const int u = tile * 4 + (lane >> 4);
         const float* pbi = a.b_ih ? a.b_ih + u : dummy;
@@ -254,6 +260,11 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
             l_m2[r] = (has_m2 && n >= a.n_split2 ? a.mask2 + (size_t)eb * a.ldmask2 + (n - a.n_split2) : dummy)[0];
         }
     }
+    };
+    // long K loops: the address arithmetic of this request (~100 instructions on the two waves that run the epilogue) goes
+    // behind the first group's MFMAs instead of in front of them -- those two waves set the pace of the K loop's barrier
+    const bool epi_late = G >= 3;
+    if (!epi_late) epi_prefetch();
     PK_PROF(7);
     {
         int g = 0;
@@ -263,6 +274,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
             pk_mma<NB, TRIP>(ra, acc);
             if (first) { PK_PROF(2); first = false; }
             if (g + 2 < G) pk_load<NB, KW, TRIP>(ra, src, kb_of(g + 2), KB);
+            if (g == 0 && epi_late) epi_prefetch();
             ++g;
             if (g >= G) break;
             pk_mma<NB, TRIP>(rb, acc);
@@ -299,10 +311,10 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
         for (int r = 0; r < 4; ++r) e_b[r] = ((a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f)) + (a.pre ? e_pr[r] : 0.0f);
         e_c = a.c_prev ? e_c : 0.0f;
         e_m = a.mask ? e_m : 1.0f;
-        const float gi = st_sigmoid(s[0] + e_b[0]), gf = st_sigmoid(s[1] + e_b[1]);
-        const float gg = tanhf(s[2] + e_b[2]), go = st_sigmoid(s[3] + e_b[3]);
+        const float gi = st_sigmoid_fast(s[0] + e_b[0]), gf = st_sigmoid_fast(s[1] + e_b[1]);
+        const float gg = st_tanh_fast(s[2] + e_b[2]), go = st_sigmoid_fast(s[3] + e_b[3]);
         const float c2 = gf * e_c + gi * gg;
-        const float h2 = go * tanhf(c2) * e_m;
+        const float h2 = go * st_tanh_fast(c2) * e_m;
         a.c_out[(size_t)b * a.ldc + u] = c2;
         pk_store(a.h_dst[0], b, u, h2);
         pk_store(a.h_dst[1], b, u, h2);

@@ -47,6 +47,15 @@ static inline int st_colreduce_chunks(int M) { int c = M / 64; if (c < 1) c = 1;
 #define ST_WAVE 64
 
 __device__ __forceinline__ float st_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Hardware-transcendental forms for the per-step LSTM epilogues (one v_exp_f32 + one v_rcp_f32 each, ~1e-7 absolute error;
+// the libm forms cost 5-10x the instructions on a path where every instruction is latency)
+__device__ __forceinline__ float st_sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ float st_tanh_fast(float x) {
+    const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.885390081777927f);      // exp(-2|x|): (1 - t) is exact-ish near 0
+    return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+}
 
 __device__ __forceinline__ float st_act(float v, int act) {
     switch (act) {

@@ -326,9 +326,29 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
         }
         PK_PROF(5);
     } else {
+        // a thread holds 4 consecutive outputs n0..n0+3 of one batch row: when they all belong to the plain range they leave as
+        // ONE 16-byte store per destination (natural y and / or the T16 tile, where 4 consecutive k of a row are adjacent)
+        const int n0 = tile * 16 + 4 * (lane >> 4);
+        const int lim = a.n_split > 0 ? a.n_split : (a.n_split2 > 0 ? a.n_split2 : a.N);
+        if (n0 + 3 < min(lim, a.N)) {
+            f32x4 v4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = st_act(s[r] + (a.bias ? l_bias[r] : 0.0f), a.act);
+                v4[r] = a.lmask ? v * l_m1[r] : v;
+            }
+            if (a.y) {
+                float* py = a.y + (size_t)b * a.ldy + n0;
+                if ((a.ldy & 3) == 0 && st_aligned16(a.y)) *reinterpret_cast<f32x4*>(py) = v4;
+                else { py[0] = v4[0]; py[1] = v4[1]; py[2] = v4[2]; py[3] = v4[3]; }
+            }
+            if (a.y_dst.base) *reinterpret_cast<f32x4*>(a.y_dst.base + t16_off(b, a.y_dst.kb0 * 16 + n0, a.y_dst.kb_stride)) = v4;
+            PK_PROF(5);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = tile * 16 + 4 * (lane >> 4) + r;
+            const int n = n0 + r;
             if (n >= a.N) continue;
             float v = s[r] + (a.bias ? l_bias[r] : 0.0f);
             v = st_act(v, a.act);
@@ -345,6 +365,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
                 pk_store(a.y_dst, b, n, v);
             }
         }
+        PK_PROF(5);
     }
 }
 
@@ -378,9 +399,12 @@ __global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const PkArgs a, con
     else at_body<VEC, 1>(t, i - n_lin, pk_dyn_lds);
 }
 
+#ifndef PK_TRIP_SMALL
+#define PK_TRIP_SMALL 2     // k-blocks per wave and group of the one-batch-tile linears (double buffered)
+#endif
 template <int NB>
 int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st) {
-    constexpr int KW = 8, TRIP = 2;
+    constexpr int KW = 8, TRIP = NB == 1 ? PK_TRIP_SMALL : 2;
     const int BT = (a.B + 15) >> 4, gy = (BT + NB - 1) / NB;
     const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K);
     const size_t lds = (size_t)o.total * sizeof(float);
@@ -402,7 +426,7 @@ int pk_launch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = n
     // 8 waves x 2 k-blocks in flight, double buffered.  Measured alternatives on MI355X (us per launch in
     // the decode graph, pq / proj / prenet): 16 waves x 6 single-buffered 7.2 / 8.8 / 7.3; 8 waves x 6
     // single-buffered 8.6 / 10.6 / 5.7; this configuration 6.1 / 8.8 / 4.8.
-    constexpr int KW = 8, TRIP = 2;
+    constexpr int KW = 8, TRIP = (MODE == 1 && NB == 1) ? PK_TRIP_SMALL : 2;
     const int BT = (a.B + 15) >> 4;
     if (side) {
         dim3 grid(tiles + side_tiles, (BT + NB - 1) / NB);

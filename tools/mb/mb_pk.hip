@@ -72,5 +72,43 @@ int main() {
             printf("  %-28s min %7lld  median %7lld  max %7lld\n", nm[n], v[0], v[128], v[255]);
         }
     }
+    // ---- the small linears of the decode step (MODE 1, one batch tile per workgroup): pq (K=1024 -> 256), prenet-2 (256 -> 256),
+    // proj (+) gate (+) prenet-1 (1536 -> 497)
+    for (int which = 0; which < 3; ++which) {
+        const int K = which == 0 ? 1024 : which == 1 ? 256 : 1536, N = which == 2 ? 497 : 256;
+        int ks[1] = {K};
+        size_t wf = st_packed_weight_floats(ks, 1, N, 0), xf = st_t16_floats(B, K);
+        float *w, *x, *y, *bias;
+        CK(hipMalloc(&w, wf * 4)); CK(hipMalloc(&x, xf * 4)); CK(hipMalloc(&y, B * N * 4)); CK(hipMalloc(&bias, N * 4));
+        CK(hipMemset(w, 0, wf * 4)); CK(hipMemset(x, 0, xf * 4)); CK(hipMemset(bias, 0, N * 4));
+        st_t16_view xv = {x, (K + 15) / 16, 0};
+        auto run = [&] { int rc = st_skinny_linear_packed_fwd(w, &xv, K, bias, which == 1 ? ST_ACT_RELU : ST_ACT_NONE, nullptr, 0, y, N, nullptr,
+                                                              0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, N, nullptr);
+            if (rc) { printf("rc=%d %s\n", rc, st_last_error()); exit(1); } };
+        float* junk; CK(hipMalloc(&junk, 64 << 20));
+        for (int i = 0; i < 3; ++i) run();
+        CK(hipDeviceSynchronize());
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float tot = 0;
+        for (int it = 0; it < 50; ++it) {
+            CK(hipMemsetAsync(junk, it, 64 << 20, nullptr));
+            CK(hipEventRecord(e0)); run(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
+        }
+        const int tiles = (N + 15) / 16;
+        std::vector<unsigned long long> hp(256 * 8 * 8);
+        CK(hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_prof), hp.size() * 8));
+        printf("linear K=%d N=%d: %.2f us/launch (event to event, cold L2); cycles since wave-0 start over %d tiles:\n", K, N, tot * 1e3 / 50, tiles);
+        const int order[7] = {6, 7, 1, 2, 3, 4, 5};
+        const char* nm[8] = {"wave start", "first group data in", "first group multiplied", "K loop done", "LDS reduce synced", "epilogue done",
+                             "kernargs in, pointers set", "loads + epilogue operands requested"};
+        for (int oi = 0; oi < 7; ++oi) {
+            const int n = order[oi];
+            std::vector<long long> v;
+            for (int b = 0; b < tiles; ++b) v.push_back((long long)(hp[(b * 8 + 0) * 8 + n] - hp[(b * 8 + 0) * 8 + 0]));
+            std::sort(v.begin(), v.end());
+            printf("  %-36s min %7lld  median %7lld  max %7lld\n", nm[n], v[0], v[tiles / 2], v[tiles - 1]);
+        }
+    }
     return 0;
 }

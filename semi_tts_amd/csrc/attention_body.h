@@ -159,10 +159,21 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     const int f4n = F >> 2;
     const int KP = o.kp;
     f32x4 wl4[AT_WLPF];
+    // pre part with F == 32, A % 16 == 0: S = pm + cf^T W_l^T runs on the matrix cores (exact-fp32 16x16x4 MFMA): a wave owns
+    // 16-dim tiles of A (mt = wave, wave + 8, ...), a tile of 16 positions is one MFMA column block, the 32 filters are 8
+    // k-steps (lane group g = lane >> 4 takes filters 8g..8g+7, so its A fragment is 32 contiguous bytes of a W_l row).  The
+    // first two dim tiles' fragments and their processed-memory rows (three position tiles) are requested here, before the conv.
+    constexpr int SM_MT = 2, SM_NT = 3;
+    const bool s_mfma = PART == 1 && VEC && F == 32 && (A & 15) == 0;
+    const int sm_g = lane >> 4, sm_n = lane & 15;
+    const int sm_ntile = (pos_hi - pos_lo + 15) >> 4;
+    float sm_aw[SM_MT][8];
+    f32x4 sm_pm[SM_MT][SM_NT];
+    const float* sm_pmb = a.pm + (size_t)b * L * A;
     if (PART != 2) {
     // ---- P0b: W_l (A,F) is fetched now (coalesced along f) and parked in registers; it is only
     // needed by P2, so its transposing LDS stores happen after the conv
-    if (wl_vec) {
+    if (wl_vec && !s_mfma) {
 #pragma unroll
         for (int j = 0; j < AT_WLPF; ++j) {
             const int idx = tid + j * NT;
@@ -212,9 +223,30 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         }
     }
     AT_PROF(2);
-    if (PART != 2) __syncthreads();
+    if (PART != 2) st_lds_barrier();
     AT_PROF(3);
 
+    // Requested after the staging barrier (80 KB per workgroup in front of the other waves' staging loads delayed that
+    // barrier by ~2000 cycles; the conv below covers their latency) and WITHOUT a run-time branch around them (a branch
+    // makes the compiler wait for every outstanding load at the join): shapes that do not take the MFMA form read clamped,
+    // valid addresses and ignore the values.
+    if (PART == 1 && VEC) {
+        const int wmax = A * F - 8, pmax = L * A - 4;
+#pragma unroll
+        for (int i = 0; i < SM_MT; ++i) {
+            const int a0 = max(min(wave + i * NWV, (A >> 4) - 1), 0) * 16;        // a tile past A is loaded, not used
+            const int wi = max(min((a0 + sm_n) * F + sm_g * 8, wmax), 0) & ~3;
+            const f32x4 w0 = st_ld4(a.loc_lin_w + wi);
+            const f32x4 w1 = st_ld4(a.loc_lin_w + wi + 4);
+            sm_aw[i][0] = w0[0]; sm_aw[i][1] = w0[1]; sm_aw[i][2] = w0[2]; sm_aw[i][3] = w0[3];
+            sm_aw[i][4] = w1[0]; sm_aw[i][5] = w1[1]; sm_aw[i][6] = w1[2]; sm_aw[i][7] = w1[3];
+#pragma unroll
+            for (int j = 0; j < SM_NT; ++j) {
+                const int l = min(pos_lo + j * 16 + sm_n, L - 1);
+                sm_pm[i][j] = st_ld4(sm_pmb + (min(l * A + a0 + 4 * sm_g, pmax) & ~3));
+            }
+        }
+    }
     if (PART != 2) {
     // ---- P1: location conv, cf[f][l] = sum_c sum_k Wc[f][c][k] * hist[c][l + k - pad]
     {
@@ -263,7 +295,8 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         }
     }
     // W_l^T into LDS: Wt[f][a] (row stride wt_ld = A4 + 4 spreads the transposing stores over banks)
-    if (wl_vec) {
+    if (s_mfma) {
+    } else if (wl_vec) {
 #pragma unroll
         for (int j = 0; j < AT_WLPF; ++j) {
             const int idx = tid + j * NT;
@@ -287,8 +320,46 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     }
     }
     AT_PROF(4);
-    if (PART != 2) __syncthreads();
+    if (PART != 2) st_lds_barrier();
     AT_PROF(5);
+
+    if (PART == 1 && s_mfma) {
+        // D[row = 4g + r][col = n] of a (dim tile, position tile): lane (g, n) ends up with S[l0 + n][a0 + 4g .. 4g + 3]
+        auto sm_tile = [&](const int a0, const int nt, const float (&aw)[8], const f32x4 pm4) __attribute__((always_inline)) {
+            const int l0 = pos_lo + nt * 16, l = l0 + sm_n;
+            const float* cfp = cf + (sm_g * 8) * o.cf_ld + l0 + sm_n;      // columns past the range read neighbours: discarded
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[k], cfp[k * o.cf_ld], acc, 0, 0, 0);
+            if (l < pos_hi) {
+                const f32x4 sv = {acc[0] + pm4[0], acc[1] + pm4[1], acc[2] + pm4[2], acc[3] + pm4[3]};
+                *reinterpret_cast<f32x4*>(a.s_buf + ((size_t)b * L + l) * A + a0 + 4 * sm_g) = sv;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < SM_MT; ++i) {
+            const int mt = wave + i * NWV;
+            if (mt >= (A >> 4)) break;
+#pragma unroll
+            for (int j = 0; j < SM_NT; ++j)
+                if (j < sm_ntile) sm_tile(mt * 16, j, sm_aw[i], sm_pm[i][j]);
+            for (int j = SM_NT; j < sm_ntile; ++j) {        // longer position ranges: rows fetched in place
+                const int l = min(pos_lo + j * 16 + sm_n, L - 1);
+                sm_tile(mt * 16, j, sm_aw[i], st_ld4(sm_pmb + (size_t)l * A + mt * 16 + 4 * sm_g));
+            }
+        }
+        for (int mt = wave + SM_MT * NWV; mt < (A >> 4); mt += NWV) {      // A > 256: fragments fetched in place
+            const int a0 = mt * 16;
+            const f32x4 w0 = st_ld4(a.loc_lin_w + (size_t)(a0 + sm_n) * 32 + sm_g * 8);
+            const f32x4 w1 = st_ld4(a.loc_lin_w + (size_t)(a0 + sm_n) * 32 + sm_g * 8 + 4);
+            const float aw[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+            for (int j = 0; j < sm_ntile; ++j) {
+                const int l = min(pos_lo + j * 16 + sm_n, L - 1);
+                sm_tile(a0, j, aw, st_ld4(sm_pmb + (size_t)l * A + a0 + 4 * sm_g));
+            }
+        }
+        return;
+    }
 
     // ---- P2: energies; a wave owns AT_LB consecutive positions, a lane 4 consecutive dims
     // PART 2 reads S (= pm + W_l cf, written by the pre part) where the full kernel reads pm
@@ -405,7 +476,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     for (int l0 = pos_lo + (wave + NPB * NWV) * AT_LP; l0 < pos_hi; l0 += NWV * AT_LP) energy_block(l0, nullptr);
     if (PART == 1) return;
     AT_PROF(6);
-    __syncthreads();
+    st_lds_barrier();
     AT_PROF(7);
 
     // ---- P3: softmax over L (wave 0), write alignment and cumulative weights
@@ -430,7 +501,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         }
     }
     AT_PROF(8);
-    __syncthreads();
+    st_lds_barrier();
     AT_PROF(9);
 
     // ---- P4: context
@@ -453,7 +524,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         *reinterpret_cast<f32x4*>(part + (size_t)(g * ne4 + e4) * 4) = acc;
     }
     AT_PROF(10);
-    __syncthreads();
+    st_lds_barrier();
     AT_PROF(11);
     for (int e = tid; e < Es; e += NT) {
         float s = 0.0f;

@@ -77,6 +77,13 @@ __device__ __forceinline__ float st_wave_max(float v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it also waits
+// for every global load still in flight, i.e. it exposes the full latency of anything prefetched into registers before it.
+// Use this one where the threads only exchange data through LDS (never to publish global-memory writes to other threads).
+__device__ __forceinline__ void st_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // DPP forms of the wave reductions (all 64 lanes must be active): the permutations ride on the VALU instruction itself, where
 // __shfl_xor is a ds_bpermute_b32 through the LDS crossbar (~100 cycles of latency per step in a dependent chain)
 constexpr int ST_DPP_QUAD_XOR1 = 0xB1;       // quad_perm:[1,0,3,2]

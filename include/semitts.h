@@ -158,6 +158,8 @@ typedef struct st_side_partial {
     const float* packed_w; int w_kb_stride; int w_kb0;   /* k-block range of the packed LSTM matrix        */
     const st_t16_view* x; int K;                         /* activations of that range (K = 16 * k-blocks)  */
     float* pre_out; int ldpre; int H;                    /* (B, 4H) partial pre-activations out            */
+    const float* pre_in;                                 /* optional running sum (B, ldpre) added to the partial: a cell's
+                                                          * early inputs can be reduced over several launches (may alias pre_out) */
 } st_side_partial;
 int st_skinny_linear_packed_side_fwd(const float* packed_w, const st_t16_view* x, int K,
                                 const float* bias, int act, const float* mask, int ldmask,
@@ -221,6 +223,23 @@ int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view
                                         int n_split, float* y2, int ldy2, int rep,
                                         int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                         int B, int N, const st_attn_pre_job* pre, void* stream);
+/* "Distributed side jobs" of the decode step (B = 17..32): the same linear with a partial LSTM gate sum (`side`, may be NULL)
+ * AND / OR the attention pre part (`pre`, may be NULL) as extra workgroups of one launch, and the LSTM cell launch with such a
+ * side job.  Each LSTM cell's early inputs (known before the cell's turn) are reduced in the shadow of the small latency-bound
+ * launches, chained through side->pre_in; the cell launch itself only reduces its late input and adds the running sum (`pre`). */
+int st_skinny_linear_packed_multi_fwd(const float* packed_w, const st_t16_view* x, int K,
+                                      const float* bias, int act, const float* mask, int ldmask,
+                                      float* y, int ldy, const st_t16_view* y_dst,
+                                      int n_split, float* y2, int ldy2, int rep,
+                                      int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
+                                      int B, int N, const st_side_partial* side, const st_attn_pre_job* pre, void* stream);
+int st_lstm_cell_packed_side_fwd(const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K,
+                                 const float* b_ih, const float* b_hh, const float* pre, int ldpre,
+                                 const float* c_prev, int ldc_prev, const float* mask,
+                                 const st_t16_view* h_dst0, const st_t16_view* h_dst1,
+                                 float* c_out, int ldc, float* gates_out,
+                                 const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
+                                 int B, int H, const st_side_partial* side, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
  * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) * stride + tap - pad, ci) * W(n, ci, tap) )

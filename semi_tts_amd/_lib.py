@@ -76,7 +76,7 @@ class StDecoderBwdIO(C.Structure):
 
 class StSidePartial(C.Structure):
     _fields_ = [('packed_w', C.c_void_p), ('w_kb_stride', C.c_int), ('w_kb0', C.c_int), ('x', C.POINTER(StT16View)),
-                ('K', C.c_int), ('pre_out', C.c_void_p), ('ldpre', C.c_int), ('H', C.c_int)]
+                ('K', C.c_int), ('pre_out', C.c_void_p), ('ldpre', C.c_int), ('H', C.c_int), ('pre_in', C.c_void_p)]
 
 
 class StAttnPreJob(C.Structure):
@@ -137,6 +137,10 @@ SIGNATURES = {
     'st_skinny_linear_packed_attnpre_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                             I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StAttnPreJob), P],
     'st_attn_pre_fwd': [P, P, I, P, P, P, P, I, I, I, I, I, I, P],
+    'st_skinny_linear_packed_multi_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
+                                          I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StSidePartial), C.POINTER(StAttnPreJob), P],
+    'st_lstm_cell_packed_side_fwd': [P, I, I, C.POINTER(StT16View), I, P, P, P, I, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
+                                     P, I, P, P, P, C.POINTER(StT16View), I, I, C.POINTER(StSidePartial), P],
     'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],

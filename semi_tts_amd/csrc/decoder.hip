@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void tile_teacher_kernel(const float* teacher_
 }
 
 int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLayout& pl, const StepViews& sv,
-               int t, bool layer1_done, void* stream) {
+               int t, bool layer1_done, void* stream, const st_side_partial* side = nullptr) {
     // dec_in_{t+1} = prenet(mel_t) for every row                ref: src/module.py:192,:197-198,:205-206
     const int in_dim = d->r * d->n_mels;
     const size_t BP = (size_t)d->B * d->P;
@@ -105,8 +105,8 @@ int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLa
                                          nullptr, 0, &pre1, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
     if (rc) return rc;
     st_t16_view next = {io->xq_tape + (size_t)(t + 1) * sv.q_floats, sv.q_kbs, 0};
-    return st_skinny_linear_packed_fwd(io->packed + pl.p1, &pre1, 16 * kb16(d->P), nullptr, ST_ACT_RELU, m2, d->P,
-                                       nullptr, 0, &next, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
+    return st_skinny_linear_packed_multi_fwd(io->packed + pl.p1, &pre1, 16 * kb16(d->P), nullptr, ST_ACT_RELU, m2, d->P,
+                                             nullptr, 0, &next, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, side, nullptr, stream);
 }
 
 }  // namespace
@@ -210,16 +210,25 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     const bool side = io->overlap == 2 && io->preq_buf && io->pred_buf;
     Aux* ax = io->overlap == 1 && io->preq_buf && io->pred_buf ? aux_get() : nullptr;
     const bool aux = ax != nullptr;
-    const bool ov = aux || side;            // both split the LSTM cells into an early partial and a late launch
+    // overlap == 3, "distributed side jobs" (free-running fused-prenet inference, B = 17..32): the early inputs of both cells are
+    // reduced as side jobs spread over FOUR launches of the step (k-block ranges chained through the running sums preq / pred):
+    //   pq launch      (+) decoder cell, adapted-h_q_t columns          proj launch   (+) decoder cell of t+1, h_d_t columns
+    //   decoder cell   (+) query cell of t+1, h_q_t columns             prenet launch (+) query cell of t+1, ctx_t columns
+    // and the attention stays split (its pre part rides in the proj launch as well).
+    bool dist = io->overlap == 3 && io->preq_buf && io->pred_buf && io->attn_s_buf && !io->defer_proj && d->fuse_pre0 && B > 16 &&
+                B <= 32;
+    for (int t = 0; dist && t + 1 < steps; ++t) dist = io->step_src[t] == -1;
+    const bool ov = aux || side || dist;    // all split the LSTM cells into early partial sums and a late launch
     // attention split (free-running inference): the location part of step t+1 rides in the proj launch of step t
     // Host launch of the pre part: the proj launch of the previous step when the loop has one, otherwise (deferred
     // projection = teacher-forced training) the query-projection launch of the same step.
-    const bool split_attn = io->attn_s_buf && !ov;
+    const bool split_attn = io->attn_s_buf && (!ov || dist);
     const bool pre_in_pq = split_attn && io->defer_proj;
     const int fp_req = io->attn_fin_parts;
     const int fin_parts = (fp_req == 2 || fp_req == 4 || fp_req == 8) && E % (4 * fp_req) == 0 ? fp_req : 1;
     hipStream_t sb = aux ? ax->s : st;
     if (ov) ST_HIP(hipMemsetAsync(io->preq_buf, 0, 4 * BQ * sizeof(float), st));   // step 0: ctx_{-1} = h_q_{-1} = 0
+    if (dist) ST_HIP(hipMemsetAsync(io->pred_buf, 0, 4 * BD * sizeof(float), st));  // step 0: h_d_{-1} = 0, the pq launch adds to it
     if (aux) {
         ST_HIP(hipEventRecord(ax->fork, st));
         ST_HIP(hipStreamWaitEvent(sb, ax->fork, 0));
@@ -265,6 +274,12 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                                      io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
                                                      &job, stream);
+        } else if (dist) {     // side job: decoder cell, adapted-h_q_t columns, added to the running sum (h_d_{t-1} columns)
+            st_t16_view xd_ha_v = {xd, sv.d_kbs, sv.d_ha};
+            st_side_partial sj = {io->packed + pl.d, sv.d_kbs, sv.d_ha, &xd_ha_v, 16 * kb16(Q), io->pred_buf, 4 * D, D, io->pred_buf};
+            rc = st_skinny_linear_packed_multi_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
+                                                   io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
+                                                   &sj, nullptr, stream);
         } else
         rc = st_skinny_linear_packed_side_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                               io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
@@ -302,12 +317,15 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view hd_dst0 = {xd_next, sv.d_kbs, sv.d_h};
         st_t16_view hd_dst1 = {xo, sv.o_kbs, 0};
         if (aux) ST_HIP(hipStreamWaitEvent(st, ax->f1, 0));
-        rc = st_lstm_cell_packed_fwd(io->packed + pl.d, ov ? sv.d_kbs : 0, 0, &xd_v, ov ? 16 * kbE : Kd,
-                                     w->d_b_ih, w->d_b_hh, ov ? io->pred_buf : nullptr, 4 * D,
-                                     io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
-                                     &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
-                                     io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
-                                     nullptr, nullptr, nullptr, B, D, stream);
+        //    (distributed side jobs: + query cell of t+1, h_q_t columns -> preq)
+        st_t16_view xq_h_v = {xq_next, sv.q_kbs, sv.q_h};
+        st_side_partial sj_qh = {io->packed + pl.q, sv.q_kbs, sv.q_h, &xq_h_v, 16 * kb16(Q), io->preq_buf, 4 * Q, Q, nullptr};
+        rc = st_lstm_cell_packed_side_fwd(io->packed + pl.d, ov ? sv.d_kbs : 0, 0, &xd_v, ov ? 16 * kbE : Kd,
+                                          w->d_b_ih, w->d_b_hh, ov ? io->pred_buf : nullptr, 4 * D,
+                                          io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
+                                          &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
+                                          io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
+                                          nullptr, nullptr, nullptr, B, D, dist && t + 1 < steps ? &sj_qh : nullptr, stream);
         if (rc) return rc;
 
         // 5. mel frames + stop logit (+ prenet layer 1 of the next input when fused)   ref: :282-287
@@ -319,7 +337,18 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    side job: early part of the NEXT query LSTM, x = [ctx_t | h_q_t] (both known now)
         st_t16_view xq_early_v = {xq_next, sv.q_kbs, kbP};
         st_side_partial sq = {io->packed + pl.q, sv.q_kbs, kbP, &xq_early_v, 16 * (sv.q_kbs - kbP), io->preq_buf, 4 * Q, Q};
-        if (split_attn && !pre_in_pq && t + 1 < steps) {
+        if (dist && t + 1 < steps) {   // + attention pre part of t+1 + decoder cell of t+1, h_d_t columns -> pred
+            st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
+                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K, io->attn_pre_parts};
+            st_t16_view xd_h_v = {xd_next, sv.d_kbs, sv.d_h};
+            st_side_partial sj = {io->packed + pl.d, sv.d_kbs, sv.d_h, &xd_h_v, 16 * kb16(D), io->pred_buf, 4 * D, D, nullptr};
+            rc = st_skinny_linear_packed_multi_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
+                                                   io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
+                                                   io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
+                                                   fuse ? in_dim + 1 : 0, ST_ACT_RELU,
+                                                   io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
+                                                   fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0), &sj, &job, stream);
+        } else if (split_attn && !pre_in_pq && t + 1 < steps) {
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
                                    w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K, io->attn_pre_parts};
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
@@ -343,7 +372,10 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             const int src = io->step_src[t];
             st_t16_view next = {xq_next, sv.q_kbs, 0};
             if (src == -1 || io->Bt < B) {   // rows without a teacher feed their own output back
-                rc = prenet_own(d, io, pl, sv, t, fuse, stream);
+                //    (distributed side jobs: + query cell of t+1, ctx_t columns added to preq)
+                st_t16_view xq_ctx_v = {xq_next, sv.q_kbs, sv.q_ctx};
+                st_side_partial sj = {io->packed + pl.q, sv.q_kbs, sv.q_ctx, &xq_ctx_v, 16 * kb16(E), io->preq_buf, 4 * Q, Q, io->preq_buf};
+                rc = prenet_own(d, io, pl, sv, t, fuse, stream, dist ? &sj : nullptr);
                 if (rc) return rc;
             }
             if (pure_tf) rc = 0;             // tiled for all steps before the loop

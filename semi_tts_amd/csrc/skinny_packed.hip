@@ -232,6 +232,12 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     // value when they are consumed, so the block is a straight line of independent loads.
     const float* dummy = reinterpret_cast<const float*>(a.w);
     auto epi_prefetch = [&]() __attribute__((always_inline)) {
+    if (MODE == 2 && e_on) {       // partial sums chained over several launches: the running sum comes in through a.pre
+        const int u = tile * 4 + (lane >> 4);
+        const float* ppr = a.pre ? a.pre + (size_t)eb * a.ldpre + u : dummy;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e_pr[r] = ppr[a.pre ? r * a.H : 0];
+    }
     if (MODE == 0 && e_on) {
         const int u = tile * 4 + (lane >> 4);
         const float* pbi = a.b_ih ? a.b_ih + u : dummy;
@@ -302,6 +308,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     if (MODE == 2) {
         const int u = tile * 4 + (lane >> 4);
         float* gp = a.gates_out + (size_t)b * a.ldpre + u;      // (B, 4H) pre-activation partials
+        if (a.pre) { s[0] += e_pr[0]; s[1] += e_pr[1]; s[2] += e_pr[2]; s[3] += e_pr[3]; }
         gp[0] = s[0]; gp[a.H] = s[1]; gp[2 * a.H] = s[2]; gp[3 * a.H] = s[3];
     } else if (MODE == 0) {
         const int H = a.H;
@@ -402,6 +409,65 @@ __global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const PkArgs a, con
 #ifndef PK_TRIP_SMALL
 #define PK_TRIP_SMALL 2     // k-blocks per wave and group of the one-batch-tile linears (double buffered)
 #endif
+// General heterogeneous launch of the decode step ("distributed side jobs"): workgroups [0, n_main) run the main job (a small
+// linear, MODE 1, or the late part of an LSTM cell, MODE 0), [n_main, n_main + n_side) a partial LSTM gate sum over a k-block
+// range whose inputs are already known (MODE 2, all NBS batch tiles per workgroup), the rest the attention pre part of the next
+// step.  The 75 MB of LSTM weights then stream in the shadow of the latency-bound launches instead of in two launches of
+// their own; what stays on the critical path of an LSTM cell is its late input (256 / 512 of 1792 / 2560 columns).
+template <int MAINMODE, int NBM, int NBS, int KW, int TRIP, bool VEC, bool HAS_AT>
+__global__ __launch_bounds__(KW * 64) void pk_multi_kernel(const PkArgs a, const PkArgs s, const AtArgs t, const int tiles_a,
+                                                           const int n_main, const int n_side) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * (NBM > NBS ? NBM : NBS) * 64];
+    const int i = blockIdx.x;
+    if (i < n_main) pk_body<MAINMODE, NBM, KW, TRIP>(a, i % tiles_a, i / tiles_a, red);
+    else if (i < n_main + n_side) pk_body<2, NBS, KW, TRIP>(s, i - n_main, 0, red);
+    else if (HAS_AT) at_body<VEC, 1>(t, i - n_main - n_side, pk_dyn_lds);
+}
+
+// main job + side job (+ attention pre part); B must be 17..32 (two batch tiles: the side job takes both per workgroup)
+template <int MAINMODE, int NBM>
+int pk_launch_multi(const PkArgs& a, int tiles, const PkArgs& sj, int side_tiles, const AtArgs* t, hipStream_t st) {
+    constexpr int KW = 8, TRIP = 2;
+    const int BT = (a.B + 15) >> 4, gy = (BT + NBM - 1) / NBM;
+    const int n_main = tiles * gy;
+    AtArgs none;
+    memset(&none, 0, sizeof(none));
+    if (!t) {
+        hipLaunchKernelGGL((pk_multi_kernel<MAINMODE, NBM, 2, KW, TRIP, true, false>), dim3(n_main + side_tiles), dim3(KW * 64), 0, st,
+                           a, sj, none, tiles, n_main, side_tiles);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
+    const AtLds o = at_layout(t->L, t->A, t->E, t->F, t->K);
+    const size_t lds = (size_t)o.total * sizeof(float);
+    ST_CHECK_ARG(lds + sizeof(f32x4) * KW * 2 * 64 <= 160 * 1024, "linear + side + attention-pre launch: L=%d needs too much LDS", t->L);
+    const bool vec = (t->A % 4 == 0) && (t->F % 4 == 0) && st_aligned16(t->pm) && st_aligned16(t->loc_lin_w) && st_aligned16(t->s_buf);
+    auto kern = vec ? pk_multi_kernel<MAINMODE, NBM, 2, KW, TRIP, true, true> : pk_multi_kernel<MAINMODE, NBM, 2, KW, TRIP, false, true>;
+    static size_t configured[2] = {0, 0};
+    if (lds > 48 * 1024 && lds > configured[vec ? 1 : 0]) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[vec ? 1 : 0] = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_main + side_tiles + t->B * (t->pre_parts > 1 ? t->pre_parts : 1)), dim3(KW * 64), lds, st,
+                       a, sj, *t, tiles, n_main, side_tiles);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+int pk_fill(PkArgs& a, const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K, const char* who);
+
+// PkArgs of a side job (partial LSTM gate sums, optionally continuing a running sum)
+int pk_side_args(PkArgs& sj, const st_side_partial* side, int B, const char* who) {
+    ST_CHECK_ARG(side->H > 0 && side->H % 4 == 0 && side->pre_out && side->ldpre >= 4 * side->H && side->x, "%s: bad side job", who);
+    memset(&sj, 0, sizeof(sj));
+    int rc = pk_fill(sj, side->packed_w, side->w_kb_stride, side->w_kb0, side->x, side->K, who);
+    if (rc) return rc;
+    sj.B = B; sj.N = 4 * side->H; sj.H = side->H;
+    sj.gates_out = side->pre_out; sj.ldpre = side->ldpre; sj.pre = side->pre_in;
+    return 0;
+}
+
 template <int NB>
 int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st) {
     constexpr int KW = 8, TRIP = NB == 1 ? PK_TRIP_SMALL : 2;
@@ -557,17 +623,46 @@ extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, int w_kb_stride, i
     return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
 }
 
+// The LSTM cell launch with a side job: partial gate sums of ANOTHER cell (or of the same cell's next step) over a k-block range
+// whose inputs are already known, as extra workgroups (distributed side jobs, see pk_multi_kernel).  B must be 17..32.
+extern "C" int st_lstm_cell_packed_side_fwd(const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K,
+                                            const float* b_ih, const float* b_hh, const float* pre, int ldpre,
+                                            const float* c_prev, int ldc_prev, const float* mask,
+                                            const st_t16_view* h_dst0, const st_t16_view* h_dst1,
+                                            float* c_out, int ldc, float* gates_out,
+                                            const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
+                                            int B, int H, const st_side_partial* side, void* stream) {
+    if (!side || !side->packed_w)
+        return st_lstm_cell_packed_fwd(packed_w, w_kb_stride, w_kb0, x, K, b_ih, b_hh, pre, ldpre, c_prev, ldc_prev, mask, h_dst0, h_dst1,
+                                       c_out, ldc, gates_out, ada_std, ada_mean, hadapt_dst, B, H, stream);
+    (void)hipGetLastError();
+    ST_CHECK_ARG(B > 16 && B <= 32, "st_lstm_cell_packed_side_fwd: side jobs need 17..32 batch rows (B=%d)", B);
+    ST_CHECK_ARG(H > 0 && H % 4 == 0 && c_out && h_dst0 && h_dst0->base, "st_lstm_cell_packed_side_fwd: bad arguments");
+    ST_CHECK_ARG(!(hadapt_dst && hadapt_dst->base) || (ada_std && ada_mean), "st_lstm_cell_packed_side_fwd: AdaIN pointers");
+    PkArgs a, sj;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, w_kb_stride, w_kb0, x, K, "st_lstm_cell_packed_side_fwd");
+    if (rc) return rc;
+    a.B = B; a.N = 4 * H; a.H = H;
+    a.b_ih = b_ih; a.b_hh = b_hh; a.pre = pre; a.ldpre = ldpre;
+    a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
+    a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
+    a.h_dst[0] = pk_out(h_dst0); a.h_dst[1] = pk_out(h_dst1);
+    a.ada_std = ada_std; a.ada_mean = ada_mean; a.ha_dst = pk_out(hadapt_dst);
+    if ((rc = pk_side_args(sj, side, B, "st_lstm_cell_packed_side_fwd(side)"))) return rc;
+    return pk_launch_multi<0, 2>(a, H / 4, sj, side->H / 4, nullptr, (hipStream_t)stream);
+}
+
 static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
                           const float* bias, int act, const float* mask, int ldmask,
                           float* y, int ldy, const st_t16_view* y_dst,
                           int n_split, float* y2, int ldy2, int rep,
                           int n_split2, int act2, const float* mask2, int ldmask2,
                           const st_t16_view* y3_dst,
-                          int B, int N, const st_side_partial* side, const st_attn_pre_job* pre, void* stream) {
+                          int B, int N, const st_side_partial* side, const st_attn_pre_job* pre, void* stream, bool multi = false) {
     ST_CHECK_ARG(n_split2 <= 0 || (y3_dst && y3_dst->base && n_split2 >= n_split), "st_skinny_linear_packed_fwd: third range");
     ST_CHECK_ARG(B > 0 && N > 0 && (y || (y_dst && y_dst->base)), "st_skinny_linear_packed_fwd: bad arguments");
     ST_CHECK_ARG(n_split <= 0 || (y2 && rep >= 1), "st_skinny_linear_packed_fwd: n_split without y2/rep");
-    ST_CHECK_ARG(!(side && side->packed_w && pre && pre->s_buf), "st_skinny_linear_packed_*: one kind of side work per launch");
     PkArgs a;
     memset(&a, 0, sizeof(a));
     int rc = pk_fill(a, packed_w, 0, 0, x, K, "st_skinny_linear_packed_fwd");
@@ -578,6 +673,24 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
     a.n_split = n_split; a.y2 = y2; a.ldy2 = ldy2; a.rep = rep;
     a.n_split2 = n_split2; a.act2 = act2; a.mask2 = mask2; a.ldmask2 = ldmask2; a.y3_dst = pk_out(y3_dst);
     const int tiles = (N + 15) / 16;
+    if (side && side->packed_w && (multi || (pre && pre->s_buf))) {      // distributed side jobs (pk_multi_kernel)
+        ST_CHECK_ARG(B > 16 && B <= 32, "st_skinny_linear_packed_multi_fwd: side jobs need 17..32 batch rows (B=%d)", B);
+        PkArgs sj;
+        if ((rc = pk_side_args(sj, side, B, "st_skinny_linear_packed_multi_fwd(side)"))) return rc;
+        AtArgs t;
+        const bool has_at = pre && pre->s_buf;
+        if (has_at) {
+            ST_CHECK_ARG(pre->pm && pre->w_prev && pre->w_cum_prev && pre->loc_conv_w && pre->loc_lin_w && pre->L > 0 && pre->A > 0 &&
+                         pre->F > 0 && pre->K > 0 && (pre->K & 1), "st_skinny_linear_packed_multi_fwd: bad attention job");
+            memset(&t, 0, sizeof(t));
+            t.pm = pre->pm; t.w_prev = pre->w_prev; t.ld_wprev = pre->ld_wprev; t.w_cum_prev = pre->w_cum_prev;
+            t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf;
+            t.B = B; t.L = pre->L; t.A = pre->A; t.E = 4; t.F = pre->F; t.K = pre->K;
+            t.pre_parts = pre->parts == 2 || pre->parts == 4 ? pre->parts : 1;
+        }
+        if (tiles <= 128) return pk_launch_multi<1, 1>(a, tiles, sj, side->H / 4, has_at ? &t : nullptr, (hipStream_t)stream);
+        return pk_launch_multi<1, 2>(a, tiles, sj, side->H / 4, has_at ? &t : nullptr, (hipStream_t)stream);
+    }
     if (side && side->packed_w) {
         ST_CHECK_ARG(side->H > 0 && side->H % 4 == 0 && side->pre_out && side->ldpre >= 4 * side->H && side->x,
                      "st_skinny_linear_packed_side_fwd: bad side job");
@@ -629,6 +742,18 @@ extern "C" int st_skinny_linear_packed_side_fwd(const float* packed_w, const st_
     (void)hipGetLastError();
     return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
                           n_split2, act2, mask2, ldmask2, y3_dst, B, N, side, nullptr, stream);
+}
+
+extern "C" int st_skinny_linear_packed_multi_fwd(const float* packed_w, const st_t16_view* x, int K,
+                                                 const float* bias, int act, const float* mask, int ldmask,
+                                                 float* y, int ldy, const st_t16_view* y_dst,
+                                                 int n_split, float* y2, int ldy2, int rep,
+                                                 int n_split2, int act2, const float* mask2, int ldmask2,
+                                                 const st_t16_view* y3_dst,
+                                                 int B, int N, const st_side_partial* side, const st_attn_pre_job* pre, void* stream) {
+    (void)hipGetLastError();
+    return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
+                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, side, pre, stream, true);
 }
 
 extern "C" int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,

@@ -456,9 +456,9 @@ class Decoder(nn.Module):
         # training with pure teacher forcing: no step's input depends on an earlier output, so mel / stop of all steps
         # come from ONE GEMM over the xo tape after the loop instead of one launch per step
         pure_tf = teacher_pre is not None and Bt == B and all(step_src[t] == min(t, Tt - 1) for t in range(steps - 1))
-        defer = bool(keep_tapes and pure_tf and self.overlap != 2)
+        defer = bool(keep_tapes and pure_tf and self.overlap not in (2, 3))
         io.defer_proj = 1 if defer else 0
-        if self.attn_split and self.overlap == 0 and (not self.training or defer):
+        if self.attn_split and self.overlap in (0, 3) and (not self.training or defer):
             tapes['attn_s'] = torch.empty(B, L, A, **f32)
             io.attn_s_buf = ops._p(tapes['attn_s'])
             io.attn_pre_parts = int(os.environ.get('ST_ATTN_PRE_PARTS', '2'))

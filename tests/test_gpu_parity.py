@@ -510,7 +510,7 @@ def test_headline_shape_c2_against_oracle(dev):
         mel, lin, align, stop = m(txt.to(dev), None, 258, spk.to(dev), tf_rate=0.0)
         # the split-LSTM variants of the loop (early parts on a second stream / as side jobs of the small launches)
         # must give the same values up to the re-association of the gate sums
-        for mode in (1, 2):
+        for mode in (1, 2, 3):     # 3 = distributed side jobs (early inputs reduced in four launches of the step)
             m.decoder.overlap = mode
             mel_o, _, align_o, _ = m(txt.to(dev), None, 258, spk.to(dev), tf_rate=0.0)
             report('tts_c2_overlap', mode=mode, mel=maxdiff(mel_o, mel), align=maxdiff(align_o, align))

@@ -499,6 +499,28 @@ def _oracle_weights(m):
     return {k: v.detach().cpu() for k, v in m.state_dict().items()}
 
 
+@pytest.mark.parametrize('B,L,T', [(1, 1, 3), (2, 2, 9), (3, 200, 12), (17, 43, 30), (33, 7, 6), (5, 400, 6)])
+def test_edge_shapes_against_oracle(dev, B, L, T):
+    """smallest, ragged and long inputs through the whole HIP Tacotron2.forward (full dims): one position, one utterance,
+    batches straddling the 16-row tiles, text far longer than the headline shape"""
+    m = full_tacotron(dev, seed=5)
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    txt, spk = torch.randn(B, L, 64, generator=g), torch.randn(B, 128, generator=g)
+    with torch.no_grad():
+        mel, lin, align, stop = m(txt.to(dev), None, T, spk.to(dev), tf_rate=0.0)
+        mel_r, lin_r, align_r, _ = O.tacotron2_forward(_oracle_weights(m), txt, T, spk, full_hp(0.0))
+    errs = dict(mel=maxdiff(mel, mel_r), lin=maxdiff(lin, lin_r), align=maxdiff(align, align_r))
+    report('tts_edge', B=B, L=L, T=T, **errs)
+    assert errs['mel'] < 2e-5 and errs['lin'] < 2e-5 and errs['align'] < 1e-5
+
+
+def test_too_long_text_is_refused(dev):
+    # the attention step keeps its staging in LDS: a text that does not fit is an error from the C ABI, not a wrong answer
+    m = full_tacotron(dev, seed=5)
+    with torch.no_grad(), pytest.raises(RuntimeError, match='LDS'):
+        m(torch.randn(2, 900, 64).to(dev), None, 6, torch.randn(2, 128).to(dev), tf_rate=0.0)
+
+
 def test_headline_shape_c2_against_oracle(dev):
     """BASELINE config 2 shape (B=32, T=258 -> 86 steps, L=43): whole Tacotron2.forward,
     inference, against the CPU oracle on the same inputs; mel within 1e-3 (north star)."""

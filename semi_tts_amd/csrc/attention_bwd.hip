@@ -139,7 +139,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         for (int i = tid; i < 32 * LD; i += AB_THREADS) WlT[i] = 0.0f;
         for (int i = tid; i < AB_LBLK * LD; i += AB_THREADS) dsb[i] = 0.0f;
         for (int i = tid; i < L * AB_FMAX; i += AB_THREADS) loc[i] = 0.0f;
-        __syncthreads();
+        st_lds_barrier();
     } else {
         const int padw = LD - A;
         for (int i = tid; i < (32 + AB_LBLK) * padw; i += AB_THREADS) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         dctx[e] = g;
         a.dctx_t[(size_t)b * E + e] = g;
     }
-    __syncthreads();
+    st_lds_barrier();
     // W_l row of this thread in registers (for s = pq + pm + W_l loc)
     float wl_r[AB_FMAX];
 #pragma unroll
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
             if (lane == 0) { dws[l] += acc; if (l2 < L) dws[l2] += acc2; }
         }
     }
-    __syncthreads();
+    st_lds_barrier();
     AB_PROF(3);
     // softmax backward: de[l] = w[l] * (dw[l] - sum_j w[j] dw[j])
     if (wave == 0) {
@@ -292,11 +292,11 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         acc = st_wave_sum_dpp(acc);
         if (lane == 0) red[0] = acc;
     }
-    __syncthreads();
+    st_lds_barrier();
     const float dot = red[0];
-    __syncthreads();
+    st_lds_barrier();
     for (int l = tid; l < L; l += AB_THREADS) dws[l] = ws[l] * (dws[l] - dot);     // dws now holds de
-    __syncthreads();
+    st_lds_barrier();
 
     AB_PROF(4);
     // ---- P3: energy gradient in blocks of AB_LBLK positions
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < AB_LPT; ++i) pmr[i] = pmn[i];
-        __syncthreads();
+        st_lds_barrier();
         // dloc[l][f] = sum_a ds[l][a] * W_l[a][f] on the matrix cores: wave = (filter tile nt of 16, quarter kq of the
         // padded a range); exact-fp32 16x16x4 MFMAs, each lane's float4 along a feeds four of them (same k order
         // for both operands), 16 x 16 partial tiles to LDS, summed below
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[(kq * AB_LBLK + 4 * (lane >> 4) + r) * 32 + nt * 16 + (lane & 15)] = acc[r];
         }
-        __syncthreads();
+        st_lds_barrier();
         {
             const int ll = tid >> 5;                      // 16 positions x 32 filter lanes = 512 threads
             const float sum = part[(0 * AB_LBLK + ll) * 32 + fl] + part[(1 * AB_LBLK + ll) * 32 + fl] +
@@ -379,13 +379,13 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
                 if (fl < F) dlocg[(size_t)(l0 + ll) * F + fl] = sum;
             }
         }
-        __syncthreads();
+        st_lds_barrier();
     }
     AB_PROF(5);
     // ---- P4: fold the per-thread sums of the ngrp threads sharing an attention dim (LDS, fixed order)
     float* fold = dsb;
     fold[tid] = dv_acc; fold[AB_THREADS + tid] = dpq_acc;
-    __syncthreads();
+    st_lds_barrier();
     if (grp == 0) {
         float sv = 0.0f, sp = 0.0f;
         for (int gq = 0; gq < ngrp; ++gq) { sv += fold[gq * A + a0]; sp += fold[AB_THREADS + gq * A + a0]; }

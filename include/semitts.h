@@ -216,6 +216,7 @@ typedef struct st_attn_pre_job {
     const float* loc_conv_w; const float* loc_lin_w; float* s_buf;
     int L, A, F, K;
     int parts;      /* workgroups per utterance (ranges of positions): 1, 2 or 4 */
+    float* cf_out;  /* optional (B, L, F): the location features of the step, kept for the backward pass */
 } st_attn_pre_job;
 int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,
                                         const float* bias, int act, const float* mask, int ldmask,
@@ -476,6 +477,8 @@ typedef struct st_decoder_io {
                                * stop for all steps with one GEMM over xo_tape afterwards (mel_out / stop_out untouched) */
     int pre1_step_floats;     /* > 0: pre1_t16 is a tape of `steps` slots of that many floats (training keeps the prenet
                                * layer-1 output of every own-output feedback for the backward); 0: one scratch slot */
+    int attn_s_step_floats;   /* > 0: attn_s_buf is a tape, slot t = S of step t (B*L*A floats apart), kept for the backward */
+    float* attn_loc_tape;     /* optional (steps, B, L, F): location features of every step (slot 0 is never written: zero it) */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);
@@ -553,7 +556,20 @@ typedef struct st_decoder_bwd_io {
     const float* pre1_nat;            /* (steps, Bp, P) un-tiled prenet layer-1 outputs */
     float* d2_tape; float* dp1_tape;  /* (steps, Bp, P) out, zero on entry: gradients at the two prenet layers (-> dW1, dW0) */
     float* tmp_p; float* tmp_in;      /* (B, P), (B, r*n_mels) scratch */
+    const float* attn_s_tape;         /* optional (steps, B, L, A): S_t = pm + W_l loc_t saved by the forward (slot 0 unused: S_0 =
+                                       * pm).  Then loc_tape is an INPUT (the forward's attn_loc_tape) and the attention backward
+                                       * neither recomputes the location conv nor the W_l product. */
 } st_decoder_bwd_io;
+/* st_attn_step_bwd with S = pm + W_l loc of the step given (s_in, (B,L,A)): loc_t is not written (may be NULL) */
+int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
+                       const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                       const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                       const float* const* dctx, const int* ld_dctx, int n_dctx,
+                       const float* const* dw_direct, const int* ld_dw, int n_dw,
+                       float* dcum, const float* dcum_add, int ld_dcum_add,
+                       float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                       float* dctx_t, float* dv_t, const float* s_in,
+                       int B, int L, int A, int E, int F, int K, void* stream);
 int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
 /* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp, r*n_mels+1); NULL = zeros */
 int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int B, int Bp, int steps, int r, int n_mels,

@@ -54,7 +54,7 @@ class StDecoderIO(C.Structure):
                 ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
                 ('zero_row', C.c_void_p), ('preq_buf', C.c_void_p), ('pred_buf', C.c_void_p), ('overlap', C.c_int),
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('attn_fin_parts', C.c_int), ('defer_proj', C.c_int),
-                ('pre1_step_floats', C.c_int)]
+                ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -71,7 +71,7 @@ class StDecoderBwdIO(C.Structure):
                 [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p), ('dgq_t16', C.c_void_p),
                  ('dgd_t16', C.c_void_p), ('step_src', C.POINTER(C.c_int)), ('Bt', C.c_int)] +
                 [(n, C.c_void_p) for n in ('dY', 'dxo_rw', 'wpg_t', 'pre_w1_t', 'pre_w0_t', 'own_mask', 'xq_nat', 'pre1_nat',
-                                           'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in')])
+                                           'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in', 'attn_s_tape')])
 
 
 class StSidePartial(C.Structure):
@@ -82,7 +82,7 @@ class StSidePartial(C.Structure):
 class StAttnPreJob(C.Structure):
     _fields_ = [('pm', C.c_void_p), ('w_prev', C.c_void_p), ('ld_wprev', C.c_int), ('w_cum_prev', C.c_void_p),
                 ('loc_conv_w', C.c_void_p), ('loc_lin_w', C.c_void_p), ('s_buf', C.c_void_p),
-                ('L', C.c_int), ('A', C.c_int), ('F', C.c_int), ('K', C.c_int), ('parts', C.c_int)]
+                ('L', C.c_int), ('A', C.c_int), ('F', C.c_int), ('K', C.c_int), ('parts', C.c_int), ('cf_out', C.c_void_p)]
 
 
 P, I, F, Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -148,6 +148,8 @@ SIGNATURES = {
     'st_decoder_forward': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderIO), P],
     'st_attn_step_bwd': [P, P, P, P, I, P, P, I, P, P, P, C.POINTER(P), C.POINTER(I), I, C.POINTER(P), C.POINTER(I), I,
                          P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    'st_attn_step_bwd_s': [P, P, P, P, I, P, P, I, P, P, P, C.POINTER(P), C.POINTER(I), I, C.POINTER(P), C.POINTER(I), I,
+                           P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     'st_attn_dmem': [P, P, P, I, I, I, I, P],
     'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],
     'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, P],

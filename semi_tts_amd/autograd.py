@@ -322,6 +322,10 @@ class _DecoderFn(Function):
         io.dxo = ops._p(dxo)
         io.dalign = ops._p(dalign.contiguous()) if dalign is not None else None
         io.dgq, io.dgd, io.dxq, io.dxd, io.dpq = ops._p(dgq), ops._p(dgd), ops._p(dxq), ops._p(dxd), ops._p(dpq)
+        if tapes.get('attn_loc') is not None and tapes.get('attn_s') is not None and tapes['attn_s'].dim() == 4:
+            # the forward kept S_t = pm + W_l loc_t and loc_t of every step: the attention backward starts from them
+            loc_tape = tapes['attn_loc']
+            io.attn_s_tape = ops._p(tapes['attn_s'])
         io.ds_tape, io.loc_tape, io.dloc_tape = ops._p(ds_tape), ops._p(loc_tape), ops._p(dloc_tape)
         io.hist_tape, io.dctx_tape, io.dv_tape = ops._p(hist_tape), ops._p(dctx_tape), ops._p(dv_tape)
         io.dcq, io.dcd, io.dcum, io.dhq_attn = ops._p(dcq), ops._p(dcd), ops._p(dcum), ops._p(dhq_attn)

@@ -42,6 +42,7 @@ struct AtArgs {
     float* ctx; int ld_ctx; st_t16_view ctx_dst[3];
     const float* h_q; int ld_hq; const float* ada_std; const float* ada_mean; float* h_adapt; int Q;
     float* s_buf;      // (B, L, A): S = pm + W_l cf, written by the pre part, read by the fin part
+    float* cf_out;     // pre part only, optional: location features (B, L, F) of this step, saved for the backward pass
     int pre_parts;     // pre part only: workgroups per utterance, each a contiguous range of positions (1, 2 or 4)
     int fin_parts;     // fin part only: workgroups per utterance, each a slice of the context dims E (1, 2, 4 or 8); every one
                        // repeats the energies + softmax (cheap), so the memory rows -- the bulk of the bytes -- are spread over more CUs
@@ -292,6 +293,13 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
             if (l0 + 1 < o.cf_ld) dst[1] = acc1;
             if (l0 + 2 < o.cf_ld) dst[2] = acc2;
             if (l0 + 3 < o.cf_ld) dst[3] = acc3;
+            if (PART == 1 && a.cf_out) {             // training: the backward pass reuses them (dW_l = ds^T loc) instead of recomputing
+                float* cg = a.cf_out + ((size_t)b * L + l0) * F + f;
+                if (l0 < pos_hi) cg[0] = acc0;
+                if (l0 + 1 < pos_hi) cg[F] = acc1;
+                if (l0 + 2 < pos_hi) cg[2 * F] = acc2;
+                if (l0 + 3 < pos_hi) cg[3 * F] = acc3;
+            }
         }
     }
     // W_l^T into LDS: Wt[f][a] (row stride wt_ld = A4 + 4 spreads the transposing stores over banks)

@@ -43,6 +43,7 @@ struct AbArgs {
     float* hist_t;    // (B, L, 2)  [w_{t-1}, cum_{t-1}] channels-last  -> dW_c
     float* dctx_t;    // (B, E)     total gradient w.r.t. ctx_t      -> dmem[b] = w^T dctx
     float* dv_t;      // (B, A)     sum_l de[l] * tanh(s[l][a])      -> dv = sum over (t, b)
+    const float* s_in; // optional (B, L, A): pm + W_l loc of this step from the forward (then loc is neither recomputed nor written)
     int B, L, A, E, F, K;
 };
 
@@ -76,6 +77,9 @@ __host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K) {
     return o;
 }
 
+// HAS_S: S = pm + W_l loc of the step comes from the forward pass (training keeps it: 1.4 MB per step against 288 GB) -- no
+// location conv (P1) and no 32-filter product per (position, dim) in the energy gradient (P3)
+template <bool HAS_S>
 __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     AB_PROF(0);
     // energy-gradient role of this thread: fixed attention dim a0, positions l0 + grp, l0 + grp + ngrp, ...
     const int a0 = tid % A, grp = tid / A, ngrp = AB_THREADS / A;    // host: A <= 256 and 512 % A == 0, so ngrp >= 2
-    const float* __restrict__ pmb = a.pm + (size_t)b * L * A;
+    const float* __restrict__ pmb = (HAS_S ? a.s_in : a.pm) + (size_t)b * L * A;
     // processed-memory values of the first block: issued before anything else, consumed in P3
     float pmr[AB_LPT];
 #pragma unroll
@@ -205,7 +209,8 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     float wl_r[AB_FMAX];
 #pragma unroll
     for (int f = 0; f < AB_FMAX; ++f) wl_r[f] = 0.0f;
-    if (F4 == AB_FMAX) {
+    if (HAS_S) {
+    } else if (F4 == AB_FMAX) {
 #pragma unroll
         for (int f = 0; f < AB_FMAX; f += 4) {
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wl + a0 * F4 + f);
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
 
     AB_PROF(1);
     // ---- P1: location features loc[l][f]: one thread = one filter x 4 consecutive positions, sliding window
-    {
+    if (!HAS_S) {
         const int nlb = (L + 3) >> 2;
         for (int i = tid; i < nlb * F4; i += AB_THREADS) {
             const int f = i % F4, l0 = (i / F4) * 4;
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
                 const float* lr = loc + l * AB_FMAX;
                 float s = pq_a + pmr[i0 + ii], s2 = 0.0f;
 #pragma unroll
-                for (int f = 0; f < AB_FMAX; f += 4) {          // pad columns are zero on both sides
+                for (int f = 0; f < (HAS_S ? 0 : AB_FMAX); f += 4) {          // pad columns are zero on both sides
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(lr + f);
                     s = fmaf(wl_r[f], l4[0], s); s2 = fmaf(wl_r[f + 1], l4[1], s2);
                     s = fmaf(wl_r[f + 2], l4[2], s); s2 = fmaf(wl_r[f + 3], l4[3], s2);
@@ -446,18 +451,18 @@ extern "C" int st_attn_dmem(const float* align, const float* dctx_tape, float* d
     return 0;
 }
 
-extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,
+extern "C" int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
                                 const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
                                 const float* loc_conv_w, const float* loc_lin_w, const float* v,
                                 const float* const* dctx, const int* ld_dctx, int n_dctx,
                                 const float* const* dw_direct, const int* ld_dw, int n_dw,
                                 float* dcum, const float* dcum_add, int ld_dcum_add,
                                 float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
-                                float* dctx_t, float* dv_t,
+                                float* dctx_t, float* dv_t, const float* s_in,
                                 int B, int L, int A, int E, int F, int K, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(pq && pm && memory && w_cum_prev && w && loc_conv_w && loc_lin_w && v, "st_attn_step_bwd: null input");
-    ST_CHECK_ARG(dpq && dhist && ds_t && loc_t && dloc_t && hist_t && dctx_t && dv_t, "st_attn_step_bwd: null output");
+    ST_CHECK_ARG(dpq && dhist && ds_t && (loc_t || s_in) && dloc_t && hist_t && dctx_t && dv_t, "st_attn_step_bwd: null output");
     ST_CHECK_ARG(B > 0 && L > 0 && A > 0 && E > 0 && F > 0 && K > 0 && (K & 1), "st_attn_step_bwd: bad dims (K must be odd)");
     ST_CHECK_ARG(A <= AB_THREADS / 2 && AB_THREADS % A == 0, "st_attn_step_bwd: attn_dim=%d must divide %d", A, AB_THREADS / 2);
     ST_CHECK_ARG((E & 3) == 0 && st_aligned16(memory), "st_attn_step_bwd: E=%d must be a multiple of 4 (16-byte aligned rows)", E);
@@ -471,15 +476,32 @@ extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* m
     for (int j = 0; j < n_dw; ++j) { a.dw_direct[j] = dw_direct[j]; a.ld_dw[j] = ld_dw[j]; }
     a.dcum = dcum; a.dcum_add = dcum_add; a.ld_dcum_add = ld_dcum_add;
     a.dpq = dpq; a.dhist = dhist; a.ds_t = ds_t; a.loc_t = loc_t; a.dloc_t = dloc_t; a.hist_t = hist_t; a.dctx_t = dctx_t; a.dv_t = dv_t;
+    a.s_in = s_in;
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
     const size_t lds = (size_t)ab_layout(L, A, E, F, K).total * sizeof(float);
     ST_CHECK_ARG(lds <= 160 * 1024, "st_attn_step_bwd: L=%d needs %zu bytes of LDS (> 160 KiB)", L, lds);
     static size_t lds_enabled = 0;
     if (lds > 64 * 1024 && lds > lds_enabled) {
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ab_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ab_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ab_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_enabled = lds;
     }
-    hipLaunchKernelGGL(ab_kernel, dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
+    if (s_in) hipLaunchKernelGGL(ab_kernel<true>, dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ab_kernel<false>, dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
     ST_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,
+                                const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                                const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                                const float* const* dctx, const int* ld_dctx, int n_dctx,
+                                const float* const* dw_direct, const int* ld_dw, int n_dw,
+                                float* dcum, const float* dcum_add, int ld_dcum_add,
+                                float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                                float* dctx_t, float* dv_t,
+                                int B, int L, int A, int E, int F, int K, void* stream) {
+    return st_attn_step_bwd_s(pq, pm, memory, w_prev, ld_wprev, w_cum_prev, w, ld_w, loc_conv_w, loc_lin_w, v, dctx, ld_dctx, n_dctx,
+                              dw_direct, ld_dw, n_dw, dcum, dcum_add, ld_dcum_add, dpq, dhist, ds_t, loc_t, dloc_t, hist_t, dctx_t, dv_t,
+                              nullptr, B, L, A, E, F, K, stream);
 }

@@ -270,7 +270,9 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_side_partial sd = {io->packed + pl.d, sv.d_kbs, kbE, &xd_early_v, 16 * (sv.d_kbs - kbE), io->pred_buf, 4 * D, D};
         if (pre_in_pq && t > 0) {   // attention pre part of THIS step rides along (needs only the weights of step t-1)
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)(t - 1) * L, ldal, io->wcum_tape + (size_t)t * BL,
-                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K, io->attn_pre_parts};
+                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)t * io->attn_s_step_floats, L, A, d->F,
+                                   d->K, io->attn_pre_parts,
+                                   io->attn_loc_tape ? io->attn_loc_tape + (size_t)t * BL * d->F : nullptr};
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                                      io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
                                                      &job, stream);
@@ -291,7 +293,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
         if (split_attn)     // S of this step was written inside the previous proj launch (step 0: no history yet, S = pm)
-            rc = st_attn_fin_t16_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf, io->memory, io->wcum_tape + (size_t)t * BL,
+            rc = st_attn_fin_t16_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats, io->memory,
+                                     io->wcum_tape + (size_t)t * BL,
                                      io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL, w->attn_v,
                                      ctx_dst, 3, nullptr, 0, fin_parts, B, L, A, E, d->F, d->K, stream);
         else
@@ -339,7 +342,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_side_partial sq = {io->packed + pl.q, sv.q_kbs, kbP, &xq_early_v, 16 * (sv.q_kbs - kbP), io->preq_buf, 4 * Q, Q};
         if (dist && t + 1 < steps) {   // + attention pre part of t+1 + decoder cell of t+1, h_d_t columns -> pred
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
-                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K, io->attn_pre_parts};
+                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)(t + 1) * io->attn_s_step_floats, L, A, d->F, d->K,
+                                   io->attn_pre_parts, io->attn_loc_tape ? io->attn_loc_tape + (size_t)(t + 1) * BL * d->F : nullptr};
             st_t16_view xd_h_v = {xd_next, sv.d_kbs, sv.d_h};
             st_side_partial sj = {io->packed + pl.d, sv.d_kbs, sv.d_h, &xd_h_v, 16 * kb16(D), io->pred_buf, 4 * D, D, nullptr};
             rc = st_skinny_linear_packed_multi_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
@@ -350,7 +354,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                                    fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0), &sj, &job, stream);
         } else if (split_attn && !pre_in_pq && t + 1 < steps) {
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
-                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf, L, A, d->F, d->K, io->attn_pre_parts};
+                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)(t + 1) * io->attn_s_step_floats, L, A, d->F, d->K,
+                                   io->attn_pre_parts, io->attn_loc_tape ? io->attn_loc_tape + (size_t)(t + 1) * BL * d->F : nullptr};
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
                                                      io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
                                                      io->stop_out + (size_t)t * d->r, steps * d->r, d->r,

@@ -24,6 +24,15 @@ extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* m
                                 float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
                                 float* dctx_t, float* dv_t,
                                 int B, int L, int A, int E, int F, int K, void* stream);
+extern "C" int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
+                                  const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                                  const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                                  const float* const* dctx, const int* ld_dctx, int n_dctx,
+                                  const float* const* dw_direct, const int* ld_dw, int n_dw,
+                                  float* dcum, const float* dcum_add, int ld_dcum_add,
+                                  float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                                  float* dctx_t, float* dv_t, const float* s_in,
+                                  int B, int L, int A, int E, int F, int K, void* stream);
 
 extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io,
                                    void* stream) {
@@ -123,14 +132,16 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
         const int ld_dctx[3] = {XO, XD, XQ};
         const float* dwd[2] = {dhist_next, io->dalign ? io->dalign + (size_t)t * L : nullptr};
         const int ld_dw[2] = {2 * L, ldal};
-        rc = st_attn_step_bwd(io->pq_all + (size_t)t * Bp * A, io->pm, io->memory,
+        // S_t from the forward when it kept it (S_0 = pm: no history before the first step); loc_tape is then an input
+        const float* s_in = io->attn_s_tape ? (t == 0 ? io->pm : io->attn_s_tape + (size_t)t * BL * A) : nullptr;
+        rc = st_attn_step_bwd_s(io->pq_all + (size_t)t * Bp * A, io->pm, io->memory,
                               t > 0 ? io->align + (size_t)(t - 1) * L : nullptr, ldal, io->wcum_tape + (size_t)t * BL,
                               io->align + (size_t)t * L, ldal, w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v,
                               dctx, ld_dctx, 3, dwd, ld_dw, io->dalign ? 2 : 1,
                               io->dcum, dhist_next + L, 2 * L,
                               dpq, dhist_cur, io->ds_tape + (size_t)t * BL * A, io->loc_tape + (size_t)t * BL * d->F,
                               io->dloc_tape + (size_t)t * BL * d->F, io->hist_tape + (size_t)t * BL * 2,
-                              io->dctx_tape + (size_t)t * B * E, io->dv_tape + (size_t)t * B * A,
+                              io->dctx_tape + (size_t)t * B * E, io->dv_tape + (size_t)t * B * A, s_in,
                               B, L, A, E, d->F, d->K, stream);
         if (rc) return rc;
         // d. through the query projection

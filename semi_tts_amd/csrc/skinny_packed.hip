@@ -684,7 +684,7 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
                          pre->F > 0 && pre->K > 0 && (pre->K & 1), "st_skinny_linear_packed_multi_fwd: bad attention job");
             memset(&t, 0, sizeof(t));
             t.pm = pre->pm; t.w_prev = pre->w_prev; t.ld_wprev = pre->ld_wprev; t.w_cum_prev = pre->w_cum_prev;
-            t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf;
+            t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf; t.cf_out = pre->cf_out;
             t.B = B; t.L = pre->L; t.A = pre->A; t.E = 4; t.F = pre->F; t.K = pre->K;
             t.pre_parts = pre->parts == 2 || pre->parts == 4 ? pre->parts : 1;
         }
@@ -708,7 +708,7 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
         AtArgs t;
         memset(&t, 0, sizeof(t));
         t.pm = pre->pm; t.w_prev = pre->w_prev; t.ld_wprev = pre->ld_wprev; t.w_cum_prev = pre->w_cum_prev;
-        t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf;
+        t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf; t.cf_out = pre->cf_out;
         t.B = B; t.L = pre->L; t.A = pre->A; t.E = 4; t.F = pre->F; t.K = pre->K;
         t.pre_parts = pre->parts == 2 || pre->parts == 4 ? pre->parts : 1;
         const int BT = (B + 15) >> 4;

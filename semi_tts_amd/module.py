@@ -459,7 +459,13 @@ class Decoder(nn.Module):
         defer = bool(keep_tapes and pure_tf and self.overlap not in (2, 3))
         io.defer_proj = 1 if defer else 0
         if self.attn_split and self.overlap in (0, 3) and (not self.training or defer):
-            tapes['attn_s'] = torch.empty(B, L, A, **f32)
+            if keep_tapes:      # training: S and the location features of every step stay for the backward pass
+                tapes['attn_s'] = torch.empty(steps, B, L, A, **f32)
+                tapes['attn_loc'] = torch.zeros(steps, B, L, self.n_location_filters, **f32)     # slot 0: no history yet
+                io.attn_s_step_floats = B * L * A
+                io.attn_loc_tape = ops._p(tapes['attn_loc'])
+            else:
+                tapes['attn_s'] = torch.empty(B, L, A, **f32)
             io.attn_s_buf = ops._p(tapes['attn_s'])
             io.attn_pre_parts = int(os.environ.get('ST_ATTN_PRE_PARTS', '2'))
             io.attn_fin_parts = int(os.environ.get('ST_ATTN_FIN_PARTS', '2'))

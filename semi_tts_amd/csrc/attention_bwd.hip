@@ -96,32 +96,60 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     const int a0 = tid % A, grp = tid / A, ngrp = AB_THREADS / A;    // host: A <= 256 and 512 % A == 0, so ngrp >= 2
     const float* __restrict__ pmb = (HAS_S ? a.s_in : a.pm) + (size_t)b * L * A;
     // processed-memory values of the first block: issued before anything else, consumed in P3
+    // (buffer loads: the descriptor ends at row L, rows past it and slots past the block read zeros without a branch)
+    const __amdgpu_buffer_rsrc_t pm_rs = __builtin_amdgcn_make_buffer_rsrc((void*)pmb, 0, L * A * 4, 0x00020000);
     float pmr[AB_LPT];
 #pragma unroll
     for (int i = 0; i < AB_LPT; ++i) {
         const int l = grp + i * ngrp;
-        pmr[i] = (i * ngrp + grp < AB_LBLK && l < L) ? pmb[(size_t)l * A + a0] : 0.0f;
+        pmr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pm_rs, i * ngrp + grp < AB_LBLK ? (l * A + a0) * 4 : 0x7ffffff0, 0, 0));
     }
     // encoder-memory rows of the first round of P2 (wave w: positions w, w+8, w+16, w+24), issued now, consumed after P1
     constexpr int NW = AB_THREADS / 64;
     const float* __restrict__ memb = a.memory + (size_t)b * L * E;
     const bool mem_pf = E <= 512;
+    const __amdgpu_buffer_rsrc_t mem_rs = __builtin_amdgcn_make_buffer_rsrc((void*)memb, 0, L * E * 4, 0x00020000);
     f32x4 mpf[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int l = wave + j * NW, e = lane * 4 + h * 256;
-            mpf[j][h] = (mem_pf && l < L && e < E) ? st_ld4(memb + (size_t)l * E + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+            mpf[j][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mem_rs, (mem_pf && e < E) ? (l * E + e) * 4 : 0x7ffffff0, 0, 0));
         }
+    // addends of dw[l] / dctx[e], first round (l = tid, e = tid): requested with the other operands, consumed after the staging
+    // (absent addends read a valid dummy address and are dropped by a select when consumed)
+    const int pl_l = min(tid, L - 1), pl_e = min(tid, E - 1);
+    const float* pl_dummy = a.w + (size_t)b * a.ld_w + pl_l;
+    const float* pe_dummy = a.memory + (size_t)b * L * E + pl_e;
+    const float pl_w = pl_dummy[0];
+    float pl_dl[3], pe_dl[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pl_dl[j] = (a.dw_direct[j] ? a.dw_direct[j] + (size_t)b * a.ld_dw[j] + pl_l : pl_dummy)[0];
+    const float pl_gc0 = (a.dcum ? a.dcum + (size_t)b * L + pl_l : pl_dummy)[0];
+    const float pl_gc1 = (a.dcum && a.dcum_add ? a.dcum_add + (size_t)b * a.ld_dcum_add + pl_l : pl_dummy)[0];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pe_dl[j] = (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + pl_e : pe_dummy)[0];
     // ---- P0: stage operands.  The first round of the weight loads goes to registers before any LDS traffic so
     // that all global latencies of this phase overlap (each separate load -> store loop costs one round trip).
     const int nWc = F * 2 * K, nWl = A * F;
     float wc_v[4], wl_v[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int i = tid + j * AB_THREADS; wc_v[j] = i < nWc ? a.loc_conv_w[i] : 0.0f; }
+    // the usual shape (32 filters, 16-byte aligned W_l): four 16-byte loads per thread and shift / mask indexing below instead of
+    // sixteen scalar loads and a division by F per element (this prologue is instruction-issue bound)
+    const bool wl_fast = F == AB_FMAX && nWl <= 16 * AB_THREADS && st_aligned16(a.loc_lin_w);
+    if (wl_fast) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const int i = tid + j * AB_THREADS; wl_v[j] = i < nWl ? a.loc_lin_w[i] : 0.0f; }
+        for (int j = 0; j < 4; ++j) {
+            const int i4 = tid + j * AB_THREADS;
+            const f32x4 t = st_ld4(a.loc_lin_w + (size_t)min(i4, (nWl >> 2) - 1) * 4);
+            wl_v[4 * j] = t[0]; wl_v[4 * j + 1] = t[1]; wl_v[4 * j + 2] = t[2]; wl_v[4 * j + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int i = tid + j * AB_THREADS; wl_v[j] = i < nWl ? a.loc_lin_w[i] : 0.0f; }
+    }
     AB_PROF(8);
     for (int i = tid; i < 2 * HL; i += AB_THREADS) {
         const int c = i / HL, j = i - c * HL, l = j - pad;
@@ -157,10 +185,23 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         const int i = tid + j * AB_THREADS;
         if (i < nWc) { const int f = i / (2 * K), ck = i - f * 2 * K; WcT[ck * F4 + f] = wc_v[j]; }
     }
+    if (wl_fast) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int i = tid + j * AB_THREADS;
-        if (i < nWl) { const int aa = i / F, f = i - aa * F; Wl[aa * F4 + f] = wl_v[j]; WlT[f * LD + aa] = wl_v[j]; }
+        for (int j = 0; j < 4; ++j) {
+            const int i4 = tid + j * AB_THREADS;
+            if (i4 < (nWl >> 2)) {
+                const int aa = i4 >> 3, f0 = (i4 & 7) * 4;         // F == 32: eight float4 per W_l row
+                if (!HAS_S) *reinterpret_cast<f32x4*>(Wl + aa * F4 + f0) = f32x4{wl_v[4 * j], wl_v[4 * j + 1], wl_v[4 * j + 2], wl_v[4 * j + 3]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) WlT[(f0 + c) * LD + aa] = wl_v[4 * j + c];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = tid + j * AB_THREADS;
+            if (i < nWl) { const int aa = i / F, f = i - aa * F; Wl[aa * F4 + f] = wl_v[j]; WlT[f * LD + aa] = wl_v[j]; }
+        }
     }
     for (int i = tid + 4 * AB_THREADS; i < nWc; i += AB_THREADS) {      // sizes beyond the register rounds
         const int f = i / (2 * K), ck = i - f * 2 * K;
@@ -175,13 +216,14 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     // absent addends are read from a valid dummy address and dropped by a select afterwards: a chain of
     // `if (p) g += p[i]` makes the wave wait for every load in turn (one memory round trip per addend)
     for (int l = tid; l < L; l += AB_THREADS) {
+        const bool first = l == tid;           // requested at the top of the kernel
         const float* dummy = a.w + (size_t)b * a.ld_w + l;
-        const float wv = dummy[0];
+        const float wv = first ? pl_w : dummy[0];
         float dl[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dl[j] = (a.dw_direct[j] ? a.dw_direct[j] + (size_t)b * a.ld_dw[j] + l : dummy)[0];
-        const float gc0 = (a.dcum ? a.dcum + (size_t)b * L + l : dummy)[0];
-        const float gc1 = (a.dcum && a.dcum_add ? a.dcum_add + (size_t)b * a.ld_dcum_add + l : dummy)[0];
+        for (int j = 0; j < 3; ++j) dl[j] = first ? pl_dl[j] : (a.dw_direct[j] ? a.dw_direct[j] + (size_t)b * a.ld_dw[j] + l : dummy)[0];
+        const float gc0 = first ? pl_gc0 : (a.dcum ? a.dcum + (size_t)b * L + l : dummy)[0];
+        const float gc1 = first ? pl_gc1 : (a.dcum && a.dcum_add ? a.dcum_add + (size_t)b * a.ld_dcum_add + l : dummy)[0];
         ws[l] = wv;
         float g = 0.0f;
 #pragma unroll
@@ -194,10 +236,11 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         dws[l] = g;
     }
     for (int e = tid; e < E; e += AB_THREADS) {
+        const bool first = e == tid;
         const float* dummy = a.memory + (size_t)b * L * E + e;
         float dl[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dl[j] = (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + e : dummy)[0];
+        for (int j = 0; j < 3; ++j) dl[j] = first ? pe_dl[j] : (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + e : dummy)[0];
         float g = 0.0f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) g += a.dctx[j] ? dl[j] : 0.0f;

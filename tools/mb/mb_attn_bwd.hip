@@ -23,8 +23,9 @@ int main() {
     float* hist = dalloc((size_t)B * L * 2, 0), *dctx = dalloc((size_t)B * E, 0), *dv = dalloc((size_t)B * A, 0);
     const float* dctxs[3] = {d0, d1, d2}; const int ldc[3] = {E, E, E};
     const float* dws[1] = {dwa}; const int ldw[1] = {2 * L};
-    auto run = [&] { int rc = st_attn_step_bwd(pq, pm, mem, wprev, L, wcum, w, L, wc, wl, v, dctxs, ldc, 3, dws, ldw, 1, dcum, dwa + L, 2 * L,
-                                              dpq, dhist, ds, loc, dloc, hist, dctx, dv, B, L, A, E, F, K, nullptr);
+    const bool has_s = getenv("MB_S") != nullptr;      // S of the step given (training keeps it): no conv / W_l recompute
+    auto run = [&] { int rc = st_attn_step_bwd_s(pq, pm, mem, wprev, L, wcum, w, L, wc, wl, v, dctxs, ldc, 3, dws, ldw, 1, dcum, dwa + L, 2 * L,
+                                                dpq, dhist, ds, loc, dloc, hist, dctx, dv, has_s ? pm : nullptr, B, L, A, E, F, K, nullptr);
         if (rc) { printf("rc=%d %s\n", rc, st_last_error()); exit(1); } };
     for (int i = 0; i < 5; ++i) run();
     CK(hipDeviceSynchronize());

@@ -93,7 +93,9 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     // the pre part may spread an utterance over several workgroups (ranges of positions): only the conv and the W_l product
     // scale with the range, the staging is repeated
     const int nparts = (PART == 1 && a.pre_parts > 1) ? a.pre_parts : (PART == 2 && a.fin_parts > 1) ? a.fin_parts : 1;
-    const int b = wg / nparts, ipart = wg - b * nparts;
+    // (parts are powers of two -- checked on the host: shifts instead of integer divisions; this prologue is issue bound)
+    const int pshift = 31 - __builtin_clz((unsigned)nparts);
+    const int b = wg >> pshift, ipart = wg & (nparts - 1);
     // kernel arguments of the first phases: fetched now, one wait (otherwise one scalar-cache round trip per first use)
 #define AT_TOUCH(x) asm volatile("" :: "s"(x))
     AT_TOUCH(a.pq); AT_TOUCH(a.pm); AT_TOUCH(a.memory); AT_TOUCH(a.w_prev); AT_TOUCH(a.ld_wprev); AT_TOUCH(a.w_cum_prev);
@@ -104,7 +106,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
     const AtLds o = at_layout(L, A, E, F, K);
     // position range of this workgroup (multiples of 12 = lcm of the conv's 4-blocks and the energy phase's 6-blocks)
-    const int pos_per = (PART == 1 && nparts > 1) ? (((L + nparts - 1) / nparts + 11) / 12) * 12 : L;
+    const int pos_per = (PART == 1 && nparts > 1) ? ((((L + nparts - 1) >> pshift) + 11) / 12) * 12 : L;
     const int pos_lo = PART == 1 ? min(L, ipart * pos_per) : 0, pos_hi = min(L, pos_lo + pos_per);
     float* Wt = lds + o.wt;
     float* Wc = lds + o.wc;
@@ -136,11 +138,16 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         if (wave == 0) pf_cum = a.w_cum_prev[(size_t)b * L + min(lane, L - 1)];
     }
     // ---- P0a: context prefetch (memory rows l = g, g+ng, ...)
-    const int Es = PART == 2 ? E / nparts : E; // context dims of this workgroup (E % (4 * parts) == 0 checked on the host)
+    const int Es = PART == 2 ? E >> pshift : E; // context dims of this workgroup (E % (4 * parts) == 0 checked on the host)
     const int e_lo = PART == 2 ? ipart * Es : 0;
     const int ne4 = Es >> 2;
-    const int ng = NT / ne4;           // row groups (>= 1 checked on the host)
-    const int e4 = tid % ne4, g = tid / ne4;
+    int ng, e4, g;                     // row groups (>= 1 checked on the host), this thread's float4 column and group
+    if ((ne4 & (ne4 - 1)) == 0) {      // power of two (the usual E = 512): no integer divisions
+        const int sh = 31 - __builtin_clz((unsigned)ne4);
+        ng = NT >> sh; e4 = tid & (ne4 - 1); g = tid >> sh;
+    } else {
+        ng = NT / ne4; e4 = tid % ne4; g = tid / ne4;
+    }
     const bool ctx_active = g < ng;
     const float* memb = a.memory + (size_t)b * L * E;
     f32x4 mpf[PFR];

@@ -402,7 +402,11 @@ __global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const PkArgs a, con
     __shared__ f32x4 red[KW * NB * 64];
     static_assert(KW * 64 == AT_THREADS, "both parts use 512-thread workgroups");
     const int i = blockIdx.x;
-    if (i < n_lin) pk_body<1, NB, KW, TRIP>(a, i % tiles_a, i / tiles_a, red);
+    if (i < n_lin) {
+        // (tile, batch tile group) of this workgroup without an integer division when there are at most two groups
+        const int by = n_lin <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
+        pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
+    }
     else at_body<VEC, 1>(t, i - n_lin, pk_dyn_lds);
 }
 
@@ -420,7 +424,10 @@ __global__ __launch_bounds__(KW * 64) void pk_multi_kernel(const PkArgs a, const
     extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
     __shared__ f32x4 red[KW * (NBM > NBS ? NBM : NBS) * 64];
     const int i = blockIdx.x;
-    if (i < n_main) pk_body<MAINMODE, NBM, KW, TRIP>(a, i % tiles_a, i / tiles_a, red);
+    if (i < n_main) {
+        const int by = n_main <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
+        pk_body<MAINMODE, NBM, KW, TRIP>(a, i - by * tiles_a, by, red);
+    }
     else if (i < n_main + n_side) pk_body<2, NBS, KW, TRIP>(s, i - n_main, 0, red);
     else if (HAS_AT) at_body<VEC, 1>(t, i - n_main - n_side, pk_dyn_lds);
 }

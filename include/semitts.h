@@ -348,6 +348,15 @@ int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float* dh1, int 
                                const float* scale2, const float* mask, const float* gates, const float* c, int ldc,
                                const float* c_prev, int ldcp, float* dc, float* dgates, int ldg,
                                const st_t16_view* dgates_t16, int B, int H, void* stream);
+/* Both directions of nn.LSTM(bidirectional=True) in one pass: per time step ONE launch advances direction 0 at t = s and direction
+ * 1 at t = T-1-s (st_lstm_cell_pair_fwd: two cells of the same shape, blockIdx.z picks the job).  Arguments as st_lstm_seq_fwd in
+ * arrays of two; ws: 6*B*H floats.  ref: nn.LSTM src/module.py:432-438,458-460 */
+int st_lstm_cell_pair_fwd(const st_seg* segs2, const float* const* b_hh2, const float* const* pre2, int ldpre,
+                          const float* const* c_prev2, int ldc_prev, float* const* h_out2, int ldh,
+                          float* const* c_out2, int ldc, float* const* gates_out2, int B, int H, void* stream);
+int st_lstm_seq2_fwd(const float* const* xproj2, const float* const* w_hh2, const float* const* b_hh2, float* out, int ldo,
+                     const int* ocol2, float* ws, float* const* gates_tape2, float* const* c_tape2,
+                     int B, int T, int H, void* stream);
 /* Backward through time of st_lstm_seq_fwd: dout(b, t, dcol : dcol+H) -> dxproj (B,T,4H) (= gradient of the
  * input projection incl. both biases).  w_hh_t = W_hh^T (H, 4H).  ws: 2*B*H floats.  The caller finishes with
  * dW_hh = st_gemm_wgrad(dxproj, out shifted by one step) and db = st_colsum(dxproj). */

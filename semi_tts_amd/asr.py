@@ -82,13 +82,11 @@ class CTC(nn.Module):
         B, T, _ = x.shape
         H = self.rnn_dim
         p = self.dropout if self.training else 0.0
-        ws = torch.empty(3 * B * H, device=x.device, dtype=torch.float32)
         for layer in range(self.rnn_layers):
             out = torch.empty(B, T, 2 * H, device=x.device, dtype=torch.float32)
-            for rev, sfx in ((False, '_l%d' % layer), (True, '_l%d_reverse' % layer)):
-                g = lambda n: getattr(self.rnn, n + sfx)
-                xproj = ops.gemm(x, g('weight_ih'), bias=g('bias_ih'))
-                ops.lstm_seq(xproj, g('weight_hh'), g('bias_hh'), out, H if rev else 0, rev, ws)
+            g = lambda n, rev: getattr(self.rnn, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))
+            xp = [ops.gemm(x, g('weight_ih', rev), bias=g('bias_ih', rev)) for rev in (False, True)]
+            ops.lstm_seq2(xp[0], xp[1], g('weight_hh', False), g('weight_hh', True), g('bias_hh', False), g('bias_hh', True), out)
             x = out
             if p > 0:   # inter-layer dropout of nn.LSTM and the dropout in front of the projection (:62)
                 x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)

@@ -176,14 +176,10 @@ class _BiLstmFn(Function):
         H = H4 // 4
         dev = xp_f.device
         out = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
-        ws = torch.empty(3 * B * H, device=dev, dtype=torch.float32)
-        tapes = []
-        for d, (xp, w, b) in enumerate(((xp_f, w_hh_f, b_hh_f), (xp_b, w_hh_b, b_hh_b))):
-            g = torch.empty(T, B, 4, H, device=dev, dtype=torch.float32)
-            c = torch.empty(T, B, H, device=dev, dtype=torch.float32)
-            ops.lstm_seq(xp.contiguous(), w, b, out, d * H, d == 1, ws, g, c)
-            tapes += [g, c]
-        ctx.save_for_backward(out, w_hh_f, w_hh_b, *tapes)
+        gs = [torch.empty(T, B, 4, H, device=dev, dtype=torch.float32) for _ in range(2)]
+        cs = [torch.empty(T, B, H, device=dev, dtype=torch.float32) for _ in range(2)]
+        ops.lstm_seq2(xp_f.contiguous(), xp_b.contiguous(), w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, gs, cs)
+        ctx.save_for_backward(out, w_hh_f, w_hh_b, gs[0], cs[0], gs[1], cs[1])
         return out
 
     @staticmethod

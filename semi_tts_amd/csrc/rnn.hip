@@ -290,6 +290,48 @@ extern "C" int st_lstm_seq_fwd(const float* xproj, const float* w_hh, const floa
     return 0;
 }
 
+extern "C" int st_lstm_cell_pair_fwd(const st_seg* segs2, const float* const* b_hh2, const float* const* pre2, int ldpre,
+                                     const float* const* c_prev2, int ldc_prev, float* const* h_out2, int ldh,
+                                     float* const* c_out2, int ldc, float* const* gates_out2, int B, int H, void* stream);
+
+// Both directions of a bidirectional LSTM layer, one launch per time step for the two of them (direction 0 walks t = s,
+// direction 1 walks t = T-1-s).  Arguments as st_lstm_seq_fwd, in arrays of two; ws: 6*B*H floats.
+extern "C" int st_lstm_seq2_fwd(const float* const* xproj2, const float* const* w_hh2, const float* const* b_hh2, float* out, int ldo,
+                                const int* ocol2, float* ws, float* const* gates_tape2, float* const* c_tape2,
+                                int B, int T, int H, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(xproj2 && w_hh2 && out && ws && ocol2 && xproj2[0] && xproj2[1] && w_hh2[0] && w_hh2[1] && B > 0 && T > 0 && H > 0,
+                 "st_lstm_seq2_fwd: bad arguments");
+    ST_CHECK_ARG(ldo >= ocol2[0] + H && ldo >= ocol2[1] + H, "st_lstm_seq2_fwd: ldo=%d too small", ldo);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bh = (size_t)B * H;
+    float* zero = ws + 4 * bh;
+    ST_HIP(hipMemsetAsync(zero, 0, bh * sizeof(float), st));
+    for (int s = 0; s < T; ++s) {
+        st_seg seg[2];
+        const float *bh2[2], *pre[2], *cprev[2];
+        float *hout[2], *cnew[2], *gout[2];
+        for (int d = 0; d < 2; ++d) {
+            const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
+            float* cbuf[2] = {ws + (size_t)(2 * d) * bh, ws + (size_t)(2 * d + 1) * bh};
+            float* ct = c_tape2 ? c_tape2[d] : nullptr;
+            float* gt = gates_tape2 ? gates_tape2[d] : nullptr;
+            seg[d].w = w_hh2[d]; seg[d].ldw = H; seg[d].k = H;
+            if (s == 0) { seg[d].x = zero; seg[d].ldx = H; }
+            else { seg[d].x = out + (size_t)tp * ldo + ocol2[d]; seg[d].ldx = T * ldo; }
+            bh2[d] = b_hh2 ? b_hh2[d] : nullptr;
+            pre[d] = xproj2[d] + (size_t)t * 4 * H;
+            cprev[d] = s == 0 ? zero : (ct ? ct + (size_t)tp * bh : cbuf[(s - 1) & 1]);
+            cnew[d] = ct ? ct + (size_t)t * bh : cbuf[s & 1];
+            hout[d] = out + (size_t)t * ldo + ocol2[d];
+            gout[d] = gt ? gt + (size_t)t * 4 * bh : nullptr;
+        }
+        int rc = st_lstm_cell_pair_fwd(seg, bh2, pre, T * 4 * H, cprev, H, hout, T * ldo, cnew, H, gout, B, H, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float* dh1, int ld1, const float* dh2, int ld2,
                                           const float* scale2, const float* mask, const float* gates, const float* c, int ldc,
                                           const float* c_prev, int ldcp, float* dc, float* dgates, int ldg,

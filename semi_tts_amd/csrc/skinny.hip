@@ -47,8 +47,7 @@ __device__ __forceinline__ f32x4 sk_load(const float* p, int k0, int klim) {
 
 // MODE 0: LSTM cell, MODE 1: linear
 template <int MODE, int NB, int KW, bool VEC>
-__global__ __launch_bounds__(KW * 64) void sk_kernel(const SkArgs a) {
-    __shared__ f32x4 red[KW * NB * 64];
+__device__ __forceinline__ void sk_body(const SkArgs& a, f32x4* red) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -194,6 +193,30 @@ __global__ __launch_bounds__(KW * 64) void sk_kernel(const SkArgs a) {
     }
 }
 
+template <int MODE, int NB, int KW, bool VEC>
+__global__ __launch_bounds__(KW * 64) void sk_kernel(const SkArgs a) {
+    __shared__ f32x4 red[KW * NB * 64];
+    sk_body<MODE, NB, KW, VEC>(a, red);
+}
+
+// two independent jobs of the same shape in one launch (blockIdx.z picks the job): the two directions of a bidirectional LSTM
+// advance one step each per launch instead of one launch per direction and step
+template <int MODE, int NB, int KW, bool VEC>
+__global__ __launch_bounds__(KW * 64) void sk_pair_kernel(const SkArgs a0, const SkArgs a1) {
+    __shared__ f32x4 red[KW * NB * 64];
+    if (blockIdx.z == 0) sk_body<MODE, NB, KW, VEC>(a0, red);
+    else sk_body<MODE, NB, KW, VEC>(a1, red);
+}
+
+template <int NB, bool VEC>
+int sk_launch_pair(const SkArgs& a0, const SkArgs& a1, int tiles, hipStream_t st) {
+    constexpr int KW = 8;
+    dim3 grid(tiles, (a0.B + NB * 16 - 1) / (NB * 16), 2);
+    hipLaunchKernelGGL((sk_pair_kernel<0, NB, KW, VEC>), grid, dim3(KW * 64), 0, st, a0, a1);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int MODE, int NB, bool VEC>
 int sk_launch(const SkArgs& a, int tiles, hipStream_t st) {
     constexpr int KW = 8;
@@ -251,6 +274,40 @@ extern "C" int st_lstm_cell_fwd(const st_seg* segs, int nseg, const float* b_ih,
     a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
     a.h_out = h_out; a.ldh = ldh; a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
     return sk_dispatch<0>(a, H / 4, (hipStream_t)stream);
+}
+
+// Two LSTM cells of the same shape (e.g. the two directions of nn.LSTM(bidirectional=True) at their own time steps) in ONE launch.
+// Arrays of two: segs2[j] (one segment each), b_hh2, pre2, c_prev2, h_out2, c_out2, gates_out2 (entries may be NULL where optional).
+extern "C" int st_lstm_cell_pair_fwd(const st_seg* segs2, const float* const* b_hh2, const float* const* pre2, int ldpre,
+                                     const float* const* c_prev2, int ldc_prev, float* const* h_out2, int ldh,
+                                     float* const* c_out2, int ldc, float* const* gates_out2, int B, int H, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && segs2 && h_out2 && c_out2, "st_lstm_cell_pair_fwd: bad arguments");
+    SkArgs a[2];
+    bool vec = true;
+    for (int j = 0; j < 2; ++j) {
+        memset(&a[j], 0, sizeof(SkArgs));
+        int rc = sk_fill_segs(a[j], segs2 + j, 1);
+        if (rc) return rc;
+        ST_CHECK_ARG(h_out2[j] && c_out2[j], "st_lstm_cell_pair_fwd: null output");
+        a[j].B = B; a[j].N = 4 * H; a[j].H = H;
+        a[j].b_hh = b_hh2 ? b_hh2[j] : nullptr; a[j].pre = pre2 ? pre2[j] : nullptr; a[j].ldpre = ldpre;
+        a[j].c_prev = c_prev2 ? c_prev2[j] : nullptr; a[j].ldc_prev = ldc_prev;
+        a[j].h_out = h_out2[j]; a[j].ldh = ldh; a[j].c_out = c_out2[j]; a[j].ldc = ldc;
+        a[j].gates_out = gates_out2 ? gates_out2[j] : nullptr;
+        const st_seg& g = a[j].seg[0];
+        vec = vec && st_aligned16(g.x) && st_aligned16(g.w) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) && (g.k % 4 == 0);
+    }
+    const int nb = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) {
+        if (nb == 1) return sk_launch_pair<1, true>(a[0], a[1], H / 4, st);
+        if (nb == 2) return sk_launch_pair<2, true>(a[0], a[1], H / 4, st);
+        return sk_launch_pair<4, true>(a[0], a[1], H / 4, st);
+    }
+    if (nb == 1) return sk_launch_pair<1, false>(a[0], a[1], H / 4, st);
+    if (nb == 2) return sk_launch_pair<2, false>(a[0], a[1], H / 4, st);
+    return sk_launch_pair<4, false>(a[0], a[1], H / 4, st);
 }
 
 extern "C" int st_skinny_linear_fwd(const st_seg* segs, int nseg, const float* bias, int act,

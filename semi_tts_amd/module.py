@@ -133,12 +133,11 @@ class Encoder(nn.Module):
             xp_b = AG.conv(x, ls.weight_ih_l0_reverse, ls.bias_ih_l0_reverse)
             return AG.bilstm(xp_f, xp_b, ls.weight_hh_l0, ls.bias_hh_l0, ls.weight_hh_l0_reverse, ls.bias_hh_l0_reverse)
         out = torch.empty(B, L, 2 * H, device=x.device, dtype=torch.float32)
-        ws = torch.empty(3 * B * H, device=x.device, dtype=torch.float32)
-        for rev, sfx in ((False, '_l0'), (True, '_l0_reverse')):
-            w_ih, w_hh = getattr(self.lstm, 'weight_ih' + sfx), getattr(self.lstm, 'weight_hh' + sfx)
-            b_ih, b_hh = getattr(self.lstm, 'bias_ih' + sfx), getattr(self.lstm, 'bias_hh' + sfx)
-            xproj = ops.gemm(x, w_ih, bias=b_ih)                      # (B, L, 4H), all time steps at once
-            ops.lstm_seq(xproj, w_hh, b_hh, out, H if rev else 0, rev, ws)
+        g = lambda n: getattr(self.lstm, n)
+        xp_f = ops.gemm(x, g('weight_ih_l0'), bias=g('bias_ih_l0'))                      # (B, L, 4H), all time steps at once
+        xp_b = ops.gemm(x, g('weight_ih_l0_reverse'), bias=g('bias_ih_l0_reverse'))
+        # the two directions advance together: one launch per time step for both
+        ops.lstm_seq2(xp_f, xp_b, g('weight_hh_l0'), g('weight_hh_l0_reverse'), g('bias_hh_l0'), g('bias_hh_l0_reverse'), out)
         return out
 
 

@@ -200,6 +200,21 @@ def lstm_seq(xproj, w_hh, b_hh, out, ocol, reverse, ws=None, gates_tape=None, c_
                               _p(gates_tape), _p(c_tape), B, T, H, 1 if reverse else 0, stream_handle()), 'st_lstm_seq_fwd')
 
 
+def lstm_seq2(xproj_f, xproj_b, w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, gates_tapes=None, c_tapes=None):
+    """both directions of a bidirectional LSTM layer, one launch per time step for the two of them; out (B,T,2H):
+    forward direction in columns [0,H), reverse in [H,2H)"""
+    lib = _lib.load()
+    B, T, H4 = xproj_f.shape
+    H = H4 // 4
+    ws = torch.empty(6 * B * H, device=xproj_f.device, dtype=torch.float32)
+    P2 = C.c_void_p * 2
+    arr = lambda a, b_: P2(_p(a), _p(b_))
+    g2 = arr(*gates_tapes) if gates_tapes is not None else None
+    c2 = arr(*c_tapes) if c_tapes is not None else None
+    check(lib.st_lstm_seq2_fwd(arr(xproj_f, xproj_b), arr(w_hh_f, w_hh_b), arr(b_hh_f, b_hh_b), _p(out), int(out.stride(1)),
+                               (C.c_int * 2)(0, H), _p(ws), g2, c2, B, T, H, stream_handle()), 'st_lstm_seq2_fwd')
+
+
 def lstm_seq_bwd(dout, dcol, gates_tape, c_tape, w_hh_t, reverse):
     """dout (B,T,>=dcol+H) -> dxproj (B,T,4H)"""
     T, B, _, H = gates_tape.shape

@@ -12,6 +12,7 @@
 //   are padded to 20 floats so the 16 rows of a lane group fall on distinct 16-byte slots.
 //   Global loads of tile t+1 are issued before the MFMAs of tile t.
 #include "st_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -24,6 +25,46 @@ struct GmArgs {
     int cpb;    // 16-float k-blocks per tap
     st_gemm_epilogue ep;
 };
+
+// epilogue of both GEMM kernels: D[row = 4*(lane>>4) + r][col = lane&15] of the wave's 2 x 2 sub-tiles
+__device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane) {
+    const st_gemm_epilogue& ep = g.ep;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 32 + nt * 16 + (lane & 15);
+        if (n >= g.N) continue;
+        const float bias = ep.bias ? ep.bias[n] : 0.0f;
+        float bn_m = 0.f, bn_s = 1.f, bn_w = 1.f, bn_b = 0.f;
+        if (ep.bn_mean) {
+            bn_m = ep.bn_mean[n];
+            bn_s = 1.0f / sqrtf(ep.bn_var[n] + ep.bn_eps);
+            bn_w = ep.bn_w ? ep.bn_w[n] : 1.0f;
+            bn_b = ep.bn_b ? ep.bn_b[n] : 0.0f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + mt * 16 + 4 * (lane >> 4) + r;
+                if (m >= g.M) continue;
+                float v = acc[mt][nt][r] + bias;
+                v = st_act(v, ep.act_pre);
+                if (ep.bn_mean) v = (v - bn_m) * bn_s * bn_w + bn_b;
+                v = st_act(v, ep.act_post);
+                if (ep.highway_h) {
+                    // Highway: y = H * T + x * (1 - T), v = T                (module.py:551-554)
+                    const float hh = ep.highway_h[(size_t)m * ep.ldhw + n];
+                    const float xx = ep.res[(size_t)m * ep.ldres + n];
+                    v = hh * v + xx * (1.0f - v);
+                } else if (ep.res) {
+                    v += ep.res[(size_t)m * ep.ldres + n];
+                }
+                if (ep.mask) v *= ep.mask[(size_t)m * ep.ldmask + n];
+                g.C[(size_t)m * g.ldc + g.coff + n] = v;
+            }
+        }
+    }
+}
 
 template <bool VECA, bool VECW>
 __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
@@ -105,43 +146,99 @@ __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row = 4*(lane>>4) + r][col = lane&15]
-    const st_gemm_epilogue& ep = g.ep;
+    gm_epilogue(g, acc, m0, n0, wm, wn, lane);
+}
+
+// Pipelined form for 16-byte addressable A (the usual case): two k-blocks of operands in flight in registers, requested with
+// clamped (always valid) addresses and a validity flag applied when they are written to LDS -- no branch around a load, no
+// integer division per block -- and barriers that only order the LDS traffic (__syncthreads would drain the prefetch).
+// The one-block form below spent ~2100 cycles per k-block against 512 cycles of MFMAs.
+template <bool VECW, bool POOL>
+__global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GM_BM * GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_BN * GM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * GM_BM, n0 = blockIdx.y * GM_BN;
+    const int srow = tid >> 2, skq = tid & 3;
+    const int am = m0 + srow;
+    const bool a_row_ok = am < g.M;
+    int ab = 0, ato = 0;
+    if (a_row_ok) { ab = am / g.Tout; ato = am - ab * g.Tout; }
+    const int wn_row = n0 + srow;
+    const bool w_row_ok = wn_row < g.N;
+    const float* __restrict__ abase = g.A + (size_t)ab * g.Tin * g.lda;
+    const float* __restrict__ wbase = g.W + (size_t)min(wn_row, g.N - 1) * g.Cin * g.KT;
+    const int t_base = ato * g.stride - g.pad;
+
+    struct Blk { f32x4 a, q, w; bool va, vw; };
+    int tap_n = 0, cb_n = 0;                       // (tap, 16-float block within the tap) of the next block to request
+    auto issue = [&](Blk& r) __attribute__((always_inline)) {
+        const int ci = cb_n * GM_BK + skq * 4;
+        const bool in_k = tap_n < g.KT && ci < g.Cin;
+        const int tap = min(tap_n, g.KT - 1), cic = min(ci, g.Cin - 4);
+        const int ti = t_base + tap;
+        const int tic = min(max(ti, 0), g.Tin - 1);
+        const float* pa = abase + (size_t)tic * g.lda + cic;
+        r.a = st_ld4(pa);
+        if (POOL) r.q = st_ld4(tic > 0 ? pa - g.lda : pa);       // MaxPool1d(2, stride 1, padding 1)[:T] fused into the load
+        r.va = in_k && a_row_ok && ti >= 0 && ti < g.Tin;
+        if (VECW) {
+            r.w = st_ld4(wbase + cic);
+        } else {     // torch Conv1d weight (N, Cin, KT): stride KT between consecutive ci
+            const float* pw = wbase + (size_t)cic * g.KT + tap;
+            r.w = f32x4{pw[0], pw[g.KT], pw[2 * g.KT], pw[3 * g.KT]};
+        }
+        r.vw = in_k && w_row_ok;
+        if (++cb_n == g.cpb) { cb_n = 0; ++tap_n; }
+    };
+    auto commit = [&](const Blk& r) __attribute__((always_inline)) {
+        f32x4 va = r.a;
+        if (POOL) { va[0] = fmaxf(va[0], r.q[0]); va[1] = fmaxf(va[1], r.q[1]); va[2] = fmaxf(va[2], r.q[2]); va[3] = fmaxf(va[3], r.q[3]); }
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(As + srow * GM_LD + skq * 4) = r.va ? va : z;
+        *reinterpret_cast<f32x4*>(Bs + srow * GM_LD + skq * 4) = r.vw ? r.w : z;
+    };
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wn * 32 + nt * 16 + (lane & 15);
-        if (n >= g.N) continue;
-        const float bias = ep.bias ? ep.bias[n] : 0.0f;
-        float bn_m = 0.f, bn_s = 1.f, bn_w = 1.f, bn_b = 0.f;
-        if (ep.bn_mean) {
-            bn_m = ep.bn_mean[n];
-            bn_s = 1.0f / sqrtf(ep.bn_var[n] + ep.bn_eps);
-            bn_w = ep.bn_w ? ep.bn_w[n] : 1.0f;
-            bn_b = ep.bn_b ? ep.bn_b[n] : 0.0f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = (lane >> 4) * 4;
+    auto compute = [&]() __attribute__((always_inline)) {
+        f32x4 a4[2], b4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a4[t] = *reinterpret_cast<const f32x4*>(As + (wm * 32 + t * 16 + fr) * GM_LD + fk);
+            b4[t] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + t * 16 + fr) * GM_LD + fk);
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + mt * 16 + 4 * (lane >> 4) + r;
-                if (m >= g.M) continue;
-                float v = acc[mt][nt][r] + bias;
-                v = st_act(v, ep.act_pre);
-                if (ep.bn_mean) v = (v - bn_m) * bn_s * bn_w + bn_b;
-                v = st_act(v, ep.act_post);
-                if (ep.highway_h) {
-                    // Highway: y = H * T + x * (1 - T), v = T                (module.py:551-554)
-                    const float hh = ep.highway_h[(size_t)m * ep.ldhw + n];
-                    const float xx = ep.res[(size_t)m * ep.ldres + n];
-                    v = hh * v + xx * (1.0f - v);
-                } else if (ep.res) {
-                    v += ep.res[(size_t)m * ep.ldres + n];
-                }
-                if (ep.mask) v *= ep.mask[(size_t)m * ep.ldmask + n];
-                g.C[(size_t)m * g.ldc + g.coff + n] = v;
-            }
-        }
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
+    };
+
+    const int nkb = g.KT * g.cpb;
+    Blk r0, r1;
+    issue(r0);
+    issue(r1);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        commit(r0);
+        st_lds_barrier();
+        issue(r0);                 // block kb + 2 (past the end: clamped addresses, flags false)
+        compute();
+        st_lds_barrier();
+        if (kb + 1 >= nkb) break;
+        commit(r1);
+        st_lds_barrier();
+        issue(r1);
+        compute();
+        st_lds_barrier();
     }
+    gm_epilogue(g, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- training-mode BatchNorm helpers ---------------------------------------------------
@@ -258,7 +355,13 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
     const bool vecw = (KT == 1) && st_aligned16(W) && (Cin % 4 == 0);
     dim3 grid((g.M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     hipStream_t st = (hipStream_t)stream;
-    if (veca && vecw) hipLaunchKernelGGL((gm_kernel<true, true>), grid, dim3(GM_THREADS), 0, st, g);
+    static const bool pipe = !(getenv("ST_GEMM_PIPE") && atoi(getenv("ST_GEMM_PIPE")) == 0);
+    if (veca && pipe && Cin >= 4) {
+        if (vecw && pool_prev) hipLaunchKernelGGL((gm_pipe_kernel<true, true>), grid, dim3(GM_THREADS), 0, st, g);
+        else if (vecw) hipLaunchKernelGGL((gm_pipe_kernel<true, false>), grid, dim3(GM_THREADS), 0, st, g);
+        else if (pool_prev) hipLaunchKernelGGL((gm_pipe_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);
+        else hipLaunchKernelGGL((gm_pipe_kernel<false, false>), grid, dim3(GM_THREADS), 0, st, g);
+    } else if (veca && vecw) hipLaunchKernelGGL((gm_kernel<true, true>), grid, dim3(GM_THREADS), 0, st, g);
     else if (veca) hipLaunchKernelGGL((gm_kernel<true, false>), grid, dim3(GM_THREADS), 0, st, g);
     else if (vecw) hipLaunchKernelGGL((gm_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);
     else hipLaunchKernelGGL((gm_kernel<false, false>), grid, dim3(GM_THREADS), 0, st, g);

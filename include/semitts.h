@@ -264,6 +264,8 @@ typedef struct st_gemm_epilogue {
     const float* res; int ldres;
     const float* highway_h; int ldhw;
     const float* mask; int ldmask;
+    int w_tap_major;   /* KT > 1 only: W is given as (N, KT, Cin) -- taps outermost, so a k-block of weights is contiguous (16-byte
+                        * loads) -- instead of the torch Conv1d layout (N, Cin, KT) */
 } st_gemm_epilogue;
 
 int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,

@@ -27,7 +27,7 @@ class StGemmEpilogue(C.Structure):
                 ('bn_eps', C.c_float), ('act_post', C.c_int),
                 ('res', C.c_void_p), ('ldres', C.c_int),
                 ('highway_h', C.c_void_p), ('ldhw', C.c_int),
-                ('mask', C.c_void_p), ('ldmask', C.c_int)]
+                ('mask', C.c_void_p), ('ldmask', C.c_int), ('w_tap_major', C.c_int)]
 
 
 class StDecoderWeights(C.Structure):

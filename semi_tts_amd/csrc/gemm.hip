@@ -103,8 +103,8 @@ __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
         const int ci = (kb - tap * g.cpb) * GM_BK + skq * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!w_row_ok || ci >= g.Cin) return v;
-        if (VECW) {  // KT == 1: torch Linear weight rows are contiguous in ci
-            v = st_ld4(g.W + (size_t)wn_row * g.Cin + ci);
+        if (VECW) {  // KT == 1 (torch Linear weight) or tap-major conv weight (N, KT, Cin): contiguous in ci
+            v = st_ld4(g.W + ((size_t)wn_row * g.KT + tap) * g.Cin + ci);
         } else {     // torch Conv1d weight (N, Cin, KT): stride KT between consecutive ci
             const float* p = g.W + ((size_t)wn_row * g.Cin + ci) * g.KT + tap;
             const int rem = g.Cin - ci;
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
         r.a = st_ld4(pa);
         if (POOL) r.q = st_ld4(tic > 0 ? pa - g.lda : pa);       // MaxPool1d(2, stride 1, padding 1)[:T] fused into the load
         r.va = in_k && a_row_ok && ti >= 0 && ti < g.Tin;
-        if (VECW) {
-            r.w = st_ld4(wbase + cic);
+        if (VECW) {  // Linear weight (KT == 1) or tap-major conv weight (N, KT, Cin): a k-block is contiguous
+            r.w = st_ld4(wbase + (size_t)tap * g.Cin + cic);
         } else {     // torch Conv1d weight (N, Cin, KT): stride KT between consecutive ci
             const float* pw = wbase + (size_t)cic * g.KT + tap;
             r.w = f32x4{pw[0], pw[g.KT], pw[2 * g.KT], pw[3 * g.KT]};
@@ -352,7 +352,9 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
         ST_CHECK_ARG(!ep->bn_mean || ep->bn_var, "st_gemm_fwd: bn_mean without bn_var");
     }
     const bool veca = st_aligned16(A) && (lda % 4 == 0) && (Cin % 4 == 0);
-    const bool vecw = (KT == 1) && st_aligned16(W) && (Cin % 4 == 0);
+    const bool tap_major = ep && ep->w_tap_major && KT > 1;
+    ST_CHECK_ARG(!tap_major || (st_aligned16(W) && Cin % 4 == 0), "st_gemm_fwd: tap-major weights need Cin %% 4 == 0 and 16-byte alignment");
+    const bool vecw = (KT == 1 || tap_major) && st_aligned16(W) && (Cin % 4 == 0);
     dim3 grid((g.M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     hipStream_t st = (hipStream_t)stream;
     static const bool pipe = !(getenv("ST_GEMM_PIPE") && atoi(getenv("ST_GEMM_PIPE")) == 0);

@@ -129,6 +129,27 @@ def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K, par
                                           stream_handle()), 'st_attn_fin_t16_fwd')
 
 
+_TAP_MAJOR = {}     # id(weight) -> (weakref to it, version, converted copy)
+
+
+def _tap_major(w):
+    """Conv1d weight (N, Cin, KT) -> (N, KT, Cin) contiguous (layout change of a PARAMETER; a k-block of the implicit GEMM is then
+    16-byte loadable).  Cached per tensor object and version: inference converts a weight once, training once per step."""
+    import weakref
+    ent = _TAP_MAJOR.get(id(w))
+    if ent is not None and ent[0]() is w and ent[1] == w._version:
+        return ent[2]
+    wt = w.detach().permute(0, 2, 1).contiguous()
+    if len(_TAP_MAJOR) > 256:
+        for k in [k for k, e in _TAP_MAJOR.items() if e[0]() is None]:
+            del _TAP_MAJOR[k]
+    try:
+        _TAP_MAJOR[id(w)] = (weakref.ref(w), w._version, wt)
+    except TypeError:
+        pass
+    return wt
+
+
 def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=0, bias=None, act_pre=None,
          bn=None, bn_eps=1e-5, act_post=None, res=None, highway_h=None, mask=None, pool_prev=False):
     """C = epilogue(conv1d / linear).  a: (Bn, Tin, Cin) or (M, Cin) channels-last; w: torch Linear
@@ -162,6 +183,9 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=
     ep.ldhw = int(highway_h.stride(-2)) if highway_h is not None else 0
     ep.mask = _p(mask)
     ep.ldmask = int(mask.stride(-2)) if mask is not None else 0
+    if KT > 1 and Cin % 4 == 0 and Cin >= 16:
+        w = _tap_major(w)
+        ep.w_tap_major = 1
     check(lib.st_gemm_fwd(_p(a), int(lda), _p(w), _p(out), int(ldc), int(coff), int(Bn), int(Tin), int(Tout),
                           int(Cin), int(N), int(KT), int(pad), int(stride), 1 if pool_prev else 0, C.byref(ep), stream_handle()),
           'st_gemm_fwd')

@@ -146,4 +146,8 @@ class FusedAdam(torch.optim.Optimizer):
                 bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
                 _lib.check(lib.st_mt_adam(pp, gp, mp, vp, sizes, len(plist), float(b1), float(b2), float(group['eps']),
                                           float(group['lr'] / bc1), float(bc2 ** 0.5), ops.stream_handle()), 'st_mt_adam')
+                # the kernel wrote the parameters behind torch's back: bump their version counters so that everything keyed on
+                # them (tap-major / packed weight copies, autograd's saved-tensor checks) sees the in-place update
+                for p in plist:
+                    torch.autograd.graph.increment_version(p)
         return None

@@ -71,11 +71,11 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_kernel(const GruArgs
             }
             ghs[j] = acc;
         }
-        __syncthreads();
+        st_lds_barrier();      // (LDS-only: __syncthreads would also wait for the next step's input projection just requested)
         if (upd) {
-            const float r = st_sigmoid(gr + ghs[j]);
-            const float z = st_sigmoid(gz + ghs[H + j]);
-            const float n = tanhf(gn + r * ghs[2 * H + j]);
+            const float r = st_sigmoid_fast(gr + ghs[j]);
+            const float z = st_sigmoid_fast(gz + ghs[H + j]);
+            const float n = st_tanh_fast(gn + r * ghs[2 * H + j]);
             const float hn = (1.0f - z) * n + z * hbuf[j];
             hbuf[j] = hn;
             a.out[((size_t)b * T + t) * a.ldo + d * H + j] = hn;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_kernel(const GruArgs
             }
             gr = nr; gz = nz; gn = nn;
         }
-        __syncthreads();
+        st_lds_barrier();
         t = tn;
     }
 }

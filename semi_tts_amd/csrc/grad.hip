@@ -111,7 +111,7 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
                 Xs[(h * 64 + sc + j) * TN_LD + sm] = rx[h][j];
                 Ys[(h * 64 + sc + j) * TN_LD + sm] = ry[h][j];
             }
-        __syncthreads();
+        st_lds_barrier();      // LDS-only: the next chunk's global loads stay in flight across it
         if (m + TN_BK < mend) {
 #pragma unroll
             for (int h = 0; h < NH; ++h) { rx[h] = load_x(m + TN_BK + sm, h * 64); ry[h] = load_y(m + TN_BK + sm, h * 64); }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
 #pragma unroll
                 for (int nt = 0; nt < FR; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
-        __syncthreads();
+        st_lds_barrier();      // LDS-only: the next chunk's global loads stay in flight across it
     }
     float* out = g.part + (size_t)z * g.N * g.Cin * g.KT;
 #pragma unroll

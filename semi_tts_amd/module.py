@@ -466,7 +466,7 @@ class Decoder(nn.Module):
             else:
                 tapes['attn_s'] = torch.empty(B, L, A, **f32)
             io.attn_s_buf = ops._p(tapes['attn_s'])
-            io.attn_pre_parts = int(os.environ.get('ST_ATTN_PRE_PARTS', '2'))
+            io.attn_pre_parts = int(os.environ.get('ST_ATTN_PRE_PARTS', '4' if L > 96 else '2'))   # long texts: 2 % at L = 171
             io.attn_fin_parts = int(os.environ.get('ST_ATTN_FIN_PARTS', '2'))
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')

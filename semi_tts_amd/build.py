@@ -34,7 +34,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-mllvm', '-amdgpu-kernarg-preload-count=16', '-c', os.path.join(CSRC, src), '-o', obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     for src, p in procs:

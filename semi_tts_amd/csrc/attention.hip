@@ -30,8 +30,10 @@ int at_launch(const AtArgs& a, hipStream_t stream) {
     const int nwg = a.B * (PART == 1 && a.pre_parts > 1 ? a.pre_parts : PART == 2 && a.fin_parts > 1 ? a.fin_parts : 1);
     // (a 256-thread form of the fin part -- one wave per SIMD -- measured SLOWER: 11968 vs 10376 cycles; the serial stretches
     // are bound by dependent-issue latency, not by two waves sharing a SIMD)
-    if (vec) hipLaunchKernelGGL((at_kernel<true, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((at_kernel<false, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a);
+    if (vec) hipLaunchKernelGGL((at_kernel<true, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a.pq, a.pm, a.v, a.w_cum_prev, a.memory,
+                                a.s_buf, a.L, a.A, a.E, a.fin_parts, a);
+    else hipLaunchKernelGGL((at_kernel<false, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a.pq, a.pm, a.v, a.w_cum_prev, a.memory,
+                            a.s_buf, a.L, a.A, a.E, a.fin_parts, a);
     ST_LAUNCH_CHECK();
     return 0;
 }

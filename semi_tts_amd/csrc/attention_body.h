@@ -553,9 +553,14 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
 }
 
 
+// (leading scalar arguments: handed over in user SGPRs at wave launch with -mllvm -amdgpu-kernarg-preload-count=16, so the
+// operand requests at kernel entry do not wait for a scalar-cache round trip on the argument block)
 template <bool VEC, int PART, int NT = AT_THREADS>
-__global__ __launch_bounds__(NT) void at_kernel(const AtArgs a) {
+__global__ __launch_bounds__(NT) void at_kernel(const float* pq, const float* pm, const float* v, const float* w_cum_prev, const float* memory,
+                                                float* s_buf, const int L, const int A, const int E, const int fin_parts, const AtArgs rest) {
     extern __shared__ __attribute__((aligned(16))) float at_lds[];
+    AtArgs a = rest;
+    a.pq = pq; a.pm = pm; a.v = v; a.w_cum_prev = w_cum_prev; a.memory = memory; a.s_buf = s_buf; a.L = L; a.A = A; a.E = E; a.fin_parts = fin_parts;
     at_body<VEC, PART, NT>(a, blockIdx.x, at_lds);
 }
 

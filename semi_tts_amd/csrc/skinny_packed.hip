@@ -376,9 +376,15 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     }
 }
 
+// The arguments the prologue needs come first and as plain scalars: with -mllvm -amdgpu-kernarg-preload-count=16 (build.py) the
+// command processor hands them over in user SGPRs at wave launch, so the first loads do not wait for a scalar-cache round
+// trip on the argument block (a struct passed by value is never preloaded).
 template <int MODE, int NB, int KW, int TRIP>
-__global__ __launch_bounds__(KW * 64) void pk_kernel(const PkArgs a) {
+__global__ __launch_bounds__(KW * 64) void pk_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                     const int B, const int N, const int H, const PkArgs rest) {
     __shared__ f32x4 red[KW * NB * 64];
+    PkArgs a = rest;
+    a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N; a.H = H;
     pk_body<MODE, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red);
 }
 
@@ -397,9 +403,17 @@ __global__ __launch_bounds__(KW * 64) void pk_pair_kernel(const PkArgs a, const 
 // that only needs the attention weights of step t (location conv + W_l + processed memory -> S): one workgroup per
 // utterance after the linear's workgroups.  The attention launch of step t+1 then starts from S.
 template <int NB, int KW, int TRIP, bool VEC>
-__global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const PkArgs a, const AtArgs t, const int tiles_a, const int n_lin) {
+__global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                             const int B, const int N, const int tiles_a, const int n_lin,
+                                                             const float* at_pm, const float* at_wprev, const int at_L,
+                                                             const PkArgs a_rest, const AtArgs t_rest) {
     extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
     __shared__ f32x4 red[KW * NB * 64];
+    // (leading scalar arguments: preloaded into SGPRs at wave launch, see pk_kernel)
+    PkArgs a = a_rest;
+    a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N;
+    AtArgs t = t_rest;
+    t.pm = at_pm; t.w_prev = at_wprev; t.L = at_L;
     static_assert(KW * 64 == AT_THREADS, "both parts use 512-thread workgroups");
     const int i = blockIdx.x;
     if (i < n_lin) {
@@ -489,7 +503,8 @@ int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t s
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured[vec ? 1 : 0] = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles * gy + t.B * (t.pre_parts > 1 ? t.pre_parts : 1)), dim3(KW * 64), lds, st, a, t, tiles, tiles * gy);
+    hipLaunchKernelGGL(kern, dim3(tiles * gy + t.B * (t.pre_parts > 1 ? t.pre_parts : 1)), dim3(KW * 64), lds, st, a.w, a.x, a.w_kbs, a.x_kbs,
+                       a.KB, a.B, a.N, tiles, tiles * gy, t.pm, t.w_prev, t.L, a, t);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -506,7 +521,7 @@ int pk_launch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = n
         hipLaunchKernelGGL((pk_pair_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a, *side, tiles);
     } else {
         dim3 grid(tiles, (BT + NB - 1) / NB);
-        hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a);
+        hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, a.H, a);
     }
     ST_LAUNCH_CHECK();
     return 0;

@@ -155,8 +155,9 @@ __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
 // The one-block form below spent ~2100 cycles per k-block against 512 cycles of MFMAs.
 template <bool VECW, bool POOL>
 __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GM_BM * GM_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[GM_BN * GM_LD];
+    // two LDS buffers: block kb+1 is written while block kb is multiplied -- one barrier per k-block
+    __shared__ __attribute__((aligned(16))) float As[2][GM_BM * GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GM_BN * GM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * GM_BM, n0 = blockIdx.y * GM_BN;
@@ -192,12 +193,12 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
         r.vw = in_k && w_row_ok;
         if (++cb_n == g.cpb) { cb_n = 0; ++tap_n; }
     };
-    auto commit = [&](const Blk& r) __attribute__((always_inline)) {
+    auto commit = [&](const Blk& r, const int buf) __attribute__((always_inline)) {
         f32x4 va = r.a;
         if (POOL) { va[0] = fmaxf(va[0], r.q[0]); va[1] = fmaxf(va[1], r.q[1]); va[2] = fmaxf(va[2], r.q[2]); va[3] = fmaxf(va[3], r.q[3]); }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(As + srow * GM_LD + skq * 4) = r.va ? va : z;
-        *reinterpret_cast<f32x4*>(Bs + srow * GM_LD + skq * 4) = r.vw ? r.w : z;
+        *reinterpret_cast<f32x4*>(As[buf] + srow * GM_LD + skq * 4) = r.va ? va : z;
+        *reinterpret_cast<f32x4*>(Bs[buf] + srow * GM_LD + skq * 4) = r.vw ? r.w : z;
     };
     f32x4 acc[2][2];
 #pragma unroll
@@ -205,12 +206,12 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = (lane >> 4) * 4;
-    auto compute = [&]() __attribute__((always_inline)) {
+    auto compute = [&](const int buf) __attribute__((always_inline)) {
         f32x4 a4[2], b4[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            a4[t] = *reinterpret_cast<const f32x4*>(As + (wm * 32 + t * 16 + fr) * GM_LD + fk);
-            b4[t] = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + t * 16 + fr) * GM_LD + fk);
+            a4[t] = *reinterpret_cast<const f32x4*>(As[buf] + (wm * 32 + t * 16 + fr) * GM_LD + fk);
+            b4[t] = *reinterpret_cast<const f32x4*>(Bs[buf] + (wn * 32 + t * 16 + fr) * GM_LD + fk);
         }
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
@@ -225,17 +226,19 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
     Blk r0, r1;
     issue(r0);
     issue(r1);
+    commit(r0, 0);
+    issue(r0);                     // block 2 (past the end: clamped addresses, flags false)
+    st_lds_barrier();
     for (int kb = 0; kb < nkb; kb += 2) {
-        commit(r0);
-        st_lds_barrier();
-        issue(r0);                 // block kb + 2 (past the end: clamped addresses, flags false)
-        compute();
-        st_lds_barrier();
+        // buffer 0 holds block kb; r1 = block kb+1, r0 = block kb+2
+        commit(r1, 1);             // (nobody reads buffer 1 now: its last readers passed the barrier below / above)
+        issue(r1);                 // block kb + 3
+        compute(0);
+        st_lds_barrier();          // buffer 1 complete, buffer 0 free
         if (kb + 1 >= nkb) break;
-        commit(r1);
-        st_lds_barrier();
-        issue(r1);
-        compute();
+        commit(r0, 0);
+        issue(r0);                 // block kb + 4
+        compute(1);
         st_lds_barrier();
     }
     gm_epilogue(g, acc, m0, n0, wm, wn, lane);

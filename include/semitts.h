@@ -359,6 +359,11 @@ int st_lstm_cell_pair_fwd(const st_seg* segs2, const float* const* b_hh2, const 
 int st_lstm_seq2_fwd(const float* const* xproj2, const float* const* w_hh2, const float* const* b_hh2, float* out, int ldo,
                      const int* ocol2, float* ws, float* const* gates_tape2, float* const* c_tape2,
                      int B, int T, int H, void* stream);
+/* backward of both directions at once (see st_lstm_seq_bwd; arrays of two, ws: 4*B*H floats): one pointwise launch and one
+ * W_hh^T launch per time step for the two directions */
+int st_lstm_seq2_bwd(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,
+                     const float* const* w_hh_t2, float* const* dxproj2, float* ws, int B, int T, int H, void* stream);
+int st_skinny_linear_pair_fwd(const st_seg* segs2, float* const* y2, int ldy, int B, int N, void* stream);
 /* Backward through time of st_lstm_seq_fwd: dout(b, t, dcol : dcol+H) -> dxproj (B,T,4H) (= gradient of the
  * input projection incl. both biases).  w_hh_t = W_hh^T (H, 4H).  ws: 2*B*H floats.  The caller finishes with
  * dW_hh = st_gemm_wgrad(dxproj, out shifted by one step) and db = st_colsum(dxproj). */

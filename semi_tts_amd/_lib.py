@@ -151,6 +151,8 @@ SIGNATURES = {
     'st_attn_step_bwd_s': [P, P, P, P, I, P, P, I, P, P, P, C.POINTER(P), C.POINTER(I), I, C.POINTER(P), C.POINTER(I), I,
                            P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     'st_lstm_seq2_fwd': [C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, C.POINTER(I), P, C.POINTER(P), C.POINTER(P), I, I, I, P],
+    'st_lstm_seq2_bwd': [P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, I, I, P],
+    'st_skinny_linear_pair_fwd': [P, C.POINTER(P), I, I, I, P],
     'st_lstm_cell_pair_fwd': [P, C.POINTER(P), C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, I, P],
     'st_attn_dmem': [P, P, P, I, I, I, I, P],
     'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],

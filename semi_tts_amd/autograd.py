@@ -188,8 +188,9 @@ class _BiLstmFn(Function):
         dout = dout.contiguous()
         H = w_hh_f.shape[1]
         res = []
-        for d, (w, g, c) in enumerate(((w_hh_f, g_f, c_f), (w_hh_b, g_b, c_b))):
-            dxp = ops.lstm_seq_bwd(dout, d * H, g, c, w.detach().t().contiguous(), d == 1)
+        dxps = ops.lstm_seq2_bwd(dout, (g_f, g_b), (c_f, c_b), (w_hh_f.detach().t().contiguous(), w_hh_b.detach().t().contiguous()))
+        for d in range(2):
+            dxp = dxps[d]
             # h_{t-1} of the forward direction is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1 / -1
             dw = ops.gemm_wgrad(dxp, out[:, :, d * H:(d + 1) * H], 1, 1 if d == 0 else -1)
             db = ops.colsum(_rows(dxp))

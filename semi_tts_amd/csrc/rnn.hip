@@ -200,7 +200,7 @@ __device__ __forceinline__ size_t lstm_t16_off(int b, int k, int KB) {
     return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
 }
 
-__global__ __launch_bounds__(256) void lstm_bwd_pw_kernel(const LstmPwArgs a) {
+__device__ __forceinline__ void lstm_bwd_pw_body(const LstmPwArgs& a) {
     const int total = a.B * a.H, H = a.H;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int b = i / H, u = i - b * H;
@@ -237,6 +237,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_pw_kernel(const LstmPwArgs a) {
         }
         a.dc[i] = dc * gf;
     }
+}
+
+__global__ __launch_bounds__(256) void lstm_bwd_pw_kernel(const LstmPwArgs a) { lstm_bwd_pw_body(a); }
+// two cells of the same shape in one launch (blockIdx.y picks the job): both directions of a bidirectional layer
+__global__ __launch_bounds__(256) void lstm_bwd_pw_pair_kernel(const LstmPwArgs a0, const LstmPwArgs a1) {
+    if (blockIdx.y == 0) lstm_bwd_pw_body(a0); else lstm_bwd_pw_body(a1);
 }
 
 }  // namespace
@@ -371,6 +377,44 @@ extern "C" int st_lstm_seq_bwd(const float* dout, int ldd, int dcol, const float
         st_seg seg;
         seg.x = dg; seg.ldx = T * 4 * H; seg.w = w_hh_t; seg.ldw = 4 * H; seg.k = 4 * H;
         rc = st_skinny_linear_fwd(&seg, 1, nullptr, ST_ACT_NONE, nullptr, 0, dhrec, H, 0, nullptr, 0, 0, B, H, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int st_skinny_linear_pair_fwd(const st_seg* segs2, float* const* y2, int ldy, int B, int N, void* stream);
+
+// Backward through time of both directions of a bidirectional LSTM layer: per time step ONE pointwise launch and ONE W_hh^T
+// launch serve the two directions (st_lstm_seq_bwd: two launches per step and direction).  ws: 4*B*H floats.
+extern "C" int st_lstm_seq2_bwd(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,
+                                const float* const* w_hh_t2, float* const* dxproj2, float* ws, int B, int T, int H, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dout && dcol2 && gates_tape2 && c_tape2 && w_hh_t2 && dxproj2 && ws && B > 0 && T > 0 && H > 0, "st_lstm_seq2_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bh = (size_t)B * H;
+    ST_HIP(hipMemsetAsync(ws, 0, 4 * bh * sizeof(float), st));
+    const int blocks = (B * H + 255) / 256;
+    for (int s = T - 1; s >= 0; --s) {                  // s = processing index of the forward
+        LstmPwArgs a[2];
+        st_seg seg[2];
+        float* dh2[2];
+        for (int d = 0; d < 2; ++d) {
+            const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
+            float* dc = ws + (size_t)(2 * d) * bh;
+            float* dhrec = ws + (size_t)(2 * d + 1) * bh;
+            float* dg = dxproj2[d] + (size_t)t * 4 * H;          // row stride T*4H
+            memset(&a[d], 0, sizeof(LstmPwArgs));
+            a[d].dh0 = dout + (size_t)t * ldd + dcol2[d]; a[d].ld0 = T * ldd; a[d].dh1 = dhrec; a[d].ld1 = H;
+            a[d].gates = gates_tape2[d] + (size_t)t * 4 * bh; a[d].c = c_tape2[d] + (size_t)t * bh; a[d].ldc = H;
+            a[d].c_prev = s == 0 ? nullptr : c_tape2[d] + (size_t)tp * bh; a[d].ldcp = H;
+            a[d].dc = dc; a[d].dgates = dg; a[d].ldg = T * 4 * H; a[d].B = B; a[d].H = H;
+            seg[d].x = dg; seg[d].ldx = T * 4 * H; seg[d].w = w_hh_t2[d]; seg[d].ldw = 4 * H; seg[d].k = 4 * H;
+            dh2[d] = dhrec;
+        }
+        hipLaunchKernelGGL(lstm_bwd_pw_pair_kernel, dim3(blocks, 2), dim3(256), 0, st, a[0], a[1]);
+        ST_LAUNCH_CHECK();
+        if (s == 0) break;
+        int rc = st_skinny_linear_pair_fwd(seg, dh2, H, B, H, stream);
         if (rc) return rc;
     }
     return 0;

@@ -208,13 +208,31 @@ __global__ __launch_bounds__(KW * 64) void sk_pair_kernel(const SkArgs a0, const
     else sk_body<MODE, NB, KW, VEC>(a1, red);
 }
 
-template <int NB, bool VEC>
+template <int MODE, int NB, bool VEC>
 int sk_launch_pair(const SkArgs& a0, const SkArgs& a1, int tiles, hipStream_t st) {
     constexpr int KW = 8;
     dim3 grid(tiles, (a0.B + NB * 16 - 1) / (NB * 16), 2);
-    hipLaunchKernelGGL((sk_pair_kernel<0, NB, KW, VEC>), grid, dim3(KW * 64), 0, st, a0, a1);
+    hipLaunchKernelGGL((sk_pair_kernel<MODE, NB, KW, VEC>), grid, dim3(KW * 64), 0, st, a0, a1);
     ST_LAUNCH_CHECK();
     return 0;
+}
+
+template <int MODE>
+int sk_dispatch_pair(const SkArgs (&a)[2], int tiles, hipStream_t st) {
+    bool vec = true;
+    for (int j = 0; j < 2; ++j) {
+        const st_seg& g = a[j].seg[0];
+        vec = vec && st_aligned16(g.x) && st_aligned16(g.w) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) && (g.k % 4 == 0);
+    }
+    const int nb = a[0].B <= 16 ? 1 : (a[0].B <= 32 ? 2 : 4);
+    if (vec) {
+        if (nb == 1) return sk_launch_pair<MODE, 1, true>(a[0], a[1], tiles, st);
+        if (nb == 2) return sk_launch_pair<MODE, 2, true>(a[0], a[1], tiles, st);
+        return sk_launch_pair<MODE, 4, true>(a[0], a[1], tiles, st);
+    }
+    if (nb == 1) return sk_launch_pair<MODE, 1, false>(a[0], a[1], tiles, st);
+    if (nb == 2) return sk_launch_pair<MODE, 2, false>(a[0], a[1], tiles, st);
+    return sk_launch_pair<MODE, 4, false>(a[0], a[1], tiles, st);
 }
 
 template <int MODE, int NB, bool VEC>
@@ -298,16 +316,22 @@ extern "C" int st_lstm_cell_pair_fwd(const st_seg* segs2, const float* const* b_
         const st_seg& g = a[j].seg[0];
         vec = vec && st_aligned16(g.x) && st_aligned16(g.w) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) && (g.k % 4 == 0);
     }
-    const int nb = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-    hipStream_t st = (hipStream_t)stream;
-    if (vec) {
-        if (nb == 1) return sk_launch_pair<1, true>(a[0], a[1], H / 4, st);
-        if (nb == 2) return sk_launch_pair<2, true>(a[0], a[1], H / 4, st);
-        return sk_launch_pair<4, true>(a[0], a[1], H / 4, st);
+    (void)vec;
+    return sk_dispatch_pair<0>(a, H / 4, (hipStream_t)stream);
+}
+
+// Two plain linears y_j = x_j W_j^T of the same shape (one segment each, no bias / activation) in one launch.
+extern "C" int st_skinny_linear_pair_fwd(const st_seg* segs2, float* const* y2, int ldy, int B, int N, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(B > 0 && N > 0 && segs2 && y2 && y2[0] && y2[1], "st_skinny_linear_pair_fwd: bad arguments");
+    SkArgs a[2];
+    for (int j = 0; j < 2; ++j) {
+        memset(&a[j], 0, sizeof(SkArgs));
+        int rc = sk_fill_segs(a[j], segs2 + j, 1);
+        if (rc) return rc;
+        a[j].B = B; a[j].N = N; a[j].H = 0; a[j].act = ST_ACT_NONE; a[j].y = y2[j]; a[j].ldy = ldy;
     }
-    if (nb == 1) return sk_launch_pair<1, false>(a[0], a[1], H / 4, st);
-    if (nb == 2) return sk_launch_pair<2, false>(a[0], a[1], H / 4, st);
-    return sk_launch_pair<4, false>(a[0], a[1], H / 4, st);
+    return sk_dispatch_pair<1>(a, (N + 15) / 16, (hipStream_t)stream);
 }
 
 extern "C" int st_skinny_linear_fwd(const st_seg* segs, int nseg, const float* bias, int act,

@@ -249,6 +249,18 @@ def lstm_seq_bwd(dout, dcol, gates_tape, c_tape, w_hh_t, reverse):
     return dxproj
 
 
+def lstm_seq2_bwd(dout, gates_tapes, c_tapes, w_hh_ts):
+    """both directions at once: dout (B,T,2H) -> (dxproj_f, dxproj_b), each (B,T,4H)"""
+    T, B, _, H = gates_tapes[0].shape
+    dx = [torch.empty(B, T, 4 * H, device=dout.device, dtype=torch.float32) for _ in range(2)]
+    ws = torch.empty(4 * B * H, device=dout.device, dtype=torch.float32)
+    P2 = C.c_void_p * 2
+    arr = lambda a, b_: P2(_p(a), _p(b_))
+    check(_lib.load().st_lstm_seq2_bwd(_p(dout), int(dout.stride(1)), (C.c_int * 2)(0, H), arr(*gates_tapes), arr(*c_tapes),
+                                       arr(*w_hh_ts), arr(*dx), _p(ws), B, T, H, stream_handle()), 'st_lstm_seq2_bwd')
+    return dx
+
+
 def gru_seq(gi_f, gi_b, w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, tape=None):
     lib = _lib.load()
     B, T, H3 = gi_f.shape

@@ -87,10 +87,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)     # RCCL on ROCm
+        # RCCL ('nccl' on ROCm).  ST_BENCH_BACKEND=gloo only exists to exercise this multi-rank path on a box with fewer GPUs
+        # than ranks (the ranks then share devices; the max-over-ranks reduction goes through a CPU tensor).
+        backend = os.environ.get('ST_BENCH_BACKEND', 'nccl')
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
 
     from helpers import full_tacotron
     from semi_tts_amd import ops
@@ -140,7 +144,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert bool(torch.isfinite(mel).all()), 'non-finite mel output'

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const Gru
             gh_[0] = drp; gh_[H] = dzp; gh_[2 * H] = dnp * r;
             dghs[j] = drp; dghs[H4 + j] = dzp; dghs[2 * H4 + j] = dnp * r;
         }
-        __syncthreads();
+        st_lds_barrier();      // LDS-only (the next step's operand loads stay in flight)
         const int tn = d ? t + 1 : t - 1;
         if (upd && s + 1 < T) fetch(tn);        // next step's operands fly while the mat-vec runs
         if (row_ok) {
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const Gru
             }
             part[j] = acc;
         }
-        __syncthreads();
+        st_lds_barrier();      // LDS-only (the next step's operand loads stay in flight)
         if (upd) dhc[j] = dhp_direct + part[j] + part[H + j] + part[2 * H + j];
-        __syncthreads();
+        st_lds_barrier();      // LDS-only (the next step's operand loads stay in flight)
         t = tn;
     }
 }

@@ -44,7 +44,11 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     const int mbeg = z * g.rows_per_z, mend = min(g.M, mbeg + g.rows_per_z);
 
     // staging role: row m_local = tid/16 of the 16-row chunk, 4 consecutive columns (+64 for the second half of a 128 tile)
-    const int sm = tid >> 4, sc = (tid & 15) * 4;
+    // 16 adjacent lanes take the 16 rows of the chunk (same 4 columns): their transposing LDS stores Xs[(col)*LD + row] then fall
+    // on 16 consecutive banks, and the next 16 lanes (4 columns further = 4*LD floats = 16 banks on) on the other 16 -- the
+    // former mapping (adjacent lanes = adjacent column groups) put a wave's 64 stores on 8 banks (8-way conflict), which made the
+    // staging cost as much LDS time as the chunk's MFMAs.  A row's 16 floats (64 B) are still one contiguous global segment.
+    const int sm = tid & 15, sc = (tid >> 4) * 4;
     f32x4 acc[FR][FR];
 #pragma unroll
     for (int i = 0; i < FR; ++i)

@@ -15,7 +15,8 @@
 // when a lane feeds component c of its float4 to the c-th of 4 successive MFMAs.
 // The K loop is software pipelined (loads of group g+1 are in flight during the MFMAs of g).
 #include "st_common.h"
-#include "attention_body.h"   // the "pre" part of the attention step runs as extra workgroups of a small linear
+#include "attention_body.h"
+#include <cstdlib>   // the "pre" part of the attention step runs as extra workgroups of a small linear
 
 #ifndef PK_PROF
 #define PK_PROF(n)   // phase timestamps, only defined by tools/mb/mb_pk.hip
@@ -376,6 +377,129 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     }
 }
 
+// LSTM cell for FOUR batch tiles (B = 49..64), 2-D tiling: a workgroup takes TWO adjacent row tiles (32 gate rows = 8 hidden units)
+// and TWO batch tiles (grid.y picks the batch half), instead of one row tile and all four batch tiles.  Per MFMA the activation
+// traffic halves (every workgroup of the one-row-tile form re-reads ALL of x: 655 KB at K = 2560, B = 64, and the cell is
+// matrix-core bound there); each weight tile is read by the two batch halves, whose workgroups are 128 apart in launch order
+// (= the same XCD under round-robin placement), so the second read is an L2 hit.
+template <int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, const f32x4* xp, const int w_kbs, const int x_kbs, const int KB,
+                                                          const int B, const int H, const PkArgs rest) {
+    constexpr int RT = 2, NB = 2;
+    __shared__ f32x4 red[KW * RT * NB * 64];
+    const PkArgs& a = rest;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile0 = blockIdx.x * RT, bt_base = blockIdx.y * NB;          // host: B in 49..64, so both batch tiles of a half exist
+    __amdgpu_buffer_rsrc_t rw[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+        rw[rt] = __builtin_amdgcn_make_buffer_rsrc((void*)(wp + (size_t)(tile0 + rt) * w_kbs * 64), 0, KB * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xp + (size_t)bt_base * x_kbs * 64), 0, ((NB - 1) * x_kbs + KB) * 1024, 0x00020000);
+    const unsigned voff = (unsigned)lane * 16u;
+    constexpr int STEP = KW * TRIP;
+    const int G = (KB + STEP - 1) / STEP;
+    const int rot = (int)((((unsigned)blockIdx.x & 255u) * (unsigned)G) >> 8);
+    auto kb_of = [&](int gq) { int q = gq + rot; if (q >= G) q -= G; return q * STEP + wave; };
+    struct Regs { f32x4 w[TRIP][RT]; f32x4 x[TRIP][NB]; };
+    auto load = [&](Regs& r, int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < TRIP; ++t) {
+            const unsigned vo = voff + (unsigned)(kb + t * KW) * 1024u;         // past KB: zeros from the range check
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) r.w[t][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw[rt], vo, 0, 0));
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, bt * x_kbs * 1024, 0));
+        }
+    };
+    f32x4 acc[RT][NB];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) acc[rt][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const Regs& r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < TRIP; ++t)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt)
+                        acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.w[t][rt][cc], r.x[t][bt][cc], acc[rt][bt], 0, 0, 0);
+    };
+    Regs ra, rb;
+    if (G > 0) load(ra, kb_of(0));
+    if (G > 1) load(rb, kb_of(1));
+    // epilogue operands of the 4 waves that run the epilogue (wave = rt * NB + bt)
+    const int e_rt = (tid >> 6) / NB, e_bt = (tid >> 6) % NB;
+    const int eb = (bt_base + e_bt) * 16 + (lane & 15);
+    const int u = (tile0 + e_rt) * 4 + (lane >> 4);
+    const bool e_on = tid < RT * NB * 64 && eb < B;
+    float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f}, e_pr[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
+    const float* dummy = reinterpret_cast<const float*>(wp);
+    auto epi_prefetch = [&]() __attribute__((always_inline)) {
+        if (e_on) {
+            const float* pbi = a.b_ih ? a.b_ih + u : dummy;
+            const float* pbh = a.b_hh ? a.b_hh + u : dummy;
+            const float* ppr = a.pre ? a.pre + (size_t)eb * a.ldpre + u : dummy;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e_bi[r] = pbi[a.b_ih ? r * H : 0];
+                e_bh[r] = pbh[a.b_hh ? r * H : 0];
+                e_pr[r] = ppr[a.pre ? r * H : 0];
+            }
+            e_c = (a.c_prev ? a.c_prev + (size_t)eb * a.ldc_prev + u : dummy)[0];
+            e_m = (a.mask ? a.mask + (size_t)eb * H + u : dummy)[0];
+            e_s = (a.ha_dst.base ? a.ada_std + (size_t)eb * H + u : dummy)[0];
+            e_mu = (a.ha_dst.base ? a.ada_mean + (size_t)eb * H + u : dummy)[0];
+        }
+    };
+    {
+        int g = 0;
+        while (g < G) {
+            mma(ra);
+            if (g + 2 < G) load(ra, kb_of(g + 2));
+            if (g == 0) epi_prefetch();
+            ++g;
+            if (g >= G) break;
+            mma(rb);
+            if (g + 2 < G) load(rb, kb_of(g + 2));
+            ++g;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) red[((wave * RT + rt) * NB + bt) * 64 + lane] = acc[rt][bt];
+    __syncthreads();
+    if (tid >= RT * NB * 64) return;
+    f32x4 s = red[(e_rt * NB + e_bt) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) {
+        const f32x4 t = red[((w * RT + e_rt) * NB + e_bt) * 64 + lane];
+        s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    if (eb >= B) return;
+    float e_b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e_b[r] = ((a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f)) + (a.pre ? e_pr[r] : 0.0f);
+    e_c = a.c_prev ? e_c : 0.0f;
+    e_m = a.mask ? e_m : 1.0f;
+    const float gi = st_sigmoid_fast(s[0] + e_b[0]), gf = st_sigmoid_fast(s[1] + e_b[1]);
+    const float gg = st_tanh_fast(s[2] + e_b[2]), go = st_sigmoid_fast(s[3] + e_b[3]);
+    const float c2 = gf * e_c + gi * gg;
+    const float h2 = go * st_tanh_fast(c2) * e_m;
+    a.c_out[(size_t)eb * a.ldc + u] = c2;
+    pk_store(a.h_dst[0], eb, u, h2);
+    pk_store(a.h_dst[1], eb, u, h2);
+    if (a.ha_dst.base) pk_store(a.ha_dst, eb, u, e_s * (h2 - e_mu));
+    if (a.gates_out) {
+        float* gp = a.gates_out + (size_t)eb * 4 * H + u;
+        gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+    }
+}
+
 // The arguments the prologue needs come first and as plain scalars: with -mllvm -amdgpu-kernarg-preload-count=16 (build.py) the
 // command processor hands them over in user SGPRs at wave launch, so the first loads do not wait for a scalar-cache round
 // trip on the argument block (a struct passed by value is never preloaded).
@@ -530,6 +654,14 @@ int pk_launch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = n
 template <int MODE>
 int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = nullptr, int side_tiles = 0) {
     const int BT = (a.B + 15) >> 4;
+    if (MODE == 0 && !side && BT == 4 && (tiles & 1) == 0 && a.B > 48) {        // 2-D tiling for four batch tiles
+        static const bool rt2 = !(getenv("ST_PK_RT2") && atoi(getenv("ST_PK_RT2")) == 0);
+        if (rt2) {
+            hipLaunchKernelGGL((pk_lstm_rt2_kernel<8, 2>), dim3(tiles / 2, 2), dim3(8 * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+            ST_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #ifndef PK_NO_BATCH_SPLIT
     // a small linear (few row tiles) is bound by what ONE compute unit can pull in (its weight tile + the whole activation
     // operand): one batch tile per workgroup halves the activation bytes per workgroup and doubles the workgroups

@@ -209,7 +209,7 @@ def main():
                     traffic = json.load(f)['hbm_bytes_per_launch']
         except (OSError, KeyError, ValueError):
             pass
-        roof = {'bound': 'hbm', 'kernel': 'pk_kernel<0,2,8,2> (fused LSTM cell on packed operands: gate GEMM + pointwise)',
+        roof = {'bound': 'hbm', 'kernel': 'pk_lstm_rt2_kernel<8,2,1> (fused LSTM cell on packed operands: gate GEMM + pointwise; 2 row tiles x 1 batch tile per workgroup)',
                 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(avg_us, 3),

@@ -377,15 +377,15 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     }
 }
 
-// LSTM cell for FOUR batch tiles (B = 49..64), 2-D tiling: a workgroup takes TWO adjacent row tiles (32 gate rows = 8 hidden units)
-// and TWO batch tiles (grid.y picks the batch half), instead of one row tile and all four batch tiles.  Per MFMA the activation
-// traffic halves (every workgroup of the one-row-tile form re-reads ALL of x: 655 KB at K = 2560, B = 64, and the cell is
-// matrix-core bound there); each weight tile is read by the two batch halves, whose workgroups are 128 apart in launch order
-// (= the same XCD under round-robin placement), so the second read is an L2 hit.
-template <int KW, int TRIP>
+// LSTM cell with 2-D tiling for an even number of batch tiles: a workgroup takes TWO adjacent row tiles (32 gate rows = 8 hidden
+// units) and HALF of the batch tiles (grid.y picks the half), instead of one row tile and all batch tiles.  Per MFMA the
+// activation traffic halves (every workgroup of the one-row-tile form re-reads ALL of x: 229 KB at K = 1792, B = 32; 655 KB at
+// K = 2560, B = 64); each weight tile is read by the two batch halves, whose workgroups are gridDim.x (a multiple of 8) apart in
+// launch order (= the same XCD under round-robin placement), so the second read is an L2 hit.
+template <int KW, int TRIP, int NB>
 __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, const f32x4* xp, const int w_kbs, const int x_kbs, const int KB,
                                                           const int B, const int H, const PkArgs rest) {
-    constexpr int RT = 2, NB = 2;
+    constexpr int RT = 2;
     __shared__ f32x4 red[KW * RT * NB * 64];
     const PkArgs& a = rest;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -654,13 +654,16 @@ int pk_launch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = n
 template <int MODE>
 int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = nullptr, int side_tiles = 0) {
     const int BT = (a.B + 15) >> 4;
-    if (MODE == 0 && !side && BT == 4 && (tiles & 1) == 0 && a.B > 48) {        // 2-D tiling for four batch tiles
-        static const bool rt2 = !(getenv("ST_PK_RT2") && atoi(getenv("ST_PK_RT2")) == 0);
-        if (rt2) {
-            hipLaunchKernelGGL((pk_lstm_rt2_kernel<8, 2>), dim3(tiles / 2, 2), dim3(8 * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
-            ST_LAUNCH_CHECK();
-            return 0;
-        }
+    // LSTM cell with an even number of batch tiles (B = 17..32 or 49..64): 2-D tiling, two row tiles x half the batch tiles per
+    // workgroup (pk_lstm_rt2_kernel).  Measured: B = 32 9.54 -> 9.05 us per cell (3.16 -> 3.09 ms per C2 pass), B = 64 15.0 -> 13.7 us.
+    static const bool rt2 = !(getenv("ST_PK_RT2") && atoi(getenv("ST_PK_RT2")) == 0);
+    if (MODE == 0 && !side && rt2 && (tiles & 1) == 0 && (BT == 2 || BT == 4) && a.B > 16 * (BT - 1)) {
+        if (BT == 2)
+            hipLaunchKernelGGL((pk_lstm_rt2_kernel<8, 2, 1>), dim3(tiles / 2, 2), dim3(8 * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+        else
+            hipLaunchKernelGGL((pk_lstm_rt2_kernel<8, 2, 2>), dim3(tiles / 2, 2), dim3(8 * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+        ST_LAUNCH_CHECK();
+        return 0;
     }
 #ifndef PK_NO_BATCH_SPLIT
     // a small linear (few row tiles) is bound by what ONE compute unit can pull in (its weight tile + the whole activation

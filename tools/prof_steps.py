@@ -8,7 +8,7 @@ import sys
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
 def code(n):
-    if 'pk_kernel<0' in n: return 'L'
+    if 'pk_kernel<0' in n or 'pk_lstm_rt2_kernel' in n: return 'L'
     if 'pk_kernel<1' in n: return 'l'
     if 'pk_attnpre_kernel' in n: return 'P'
     if 'at_kernel' in n: return 'A'

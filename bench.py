@@ -5,16 +5,26 @@ attention), free-running inference, on BASELINE.json config 2:
 B = 32 utterances per GPU, 256 -> 258 frames (86 decode steps, r = 3), L = 43, n_mels = 80, fp32,
 prenet dropout 0.5 active (it never turns off in the reference), synthetic weights and inputs.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c5|c3|train]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch.  Weak scaling: every rank decodes its
-own batch of 32 utterances (utterances are independent; there is no data-path collective in
-inference).  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one batch.  Weak scaling: every rank works on its own batch
+(utterances are independent; inference has no data-path collective, training all-reduces gradients).
+With --gpus N > 1 and no WORLD_SIZE in the environment this process starts N ranks itself
+(python -m torch.distributed.run, one per GPU, RCCL) BEFORE touching the GPU, and exits with their code.
+Prints ONE JSON line on rank 0.
+
+Secondary workloads (not the headline):
+  c5     BASELINE config 5 (bin/gen_specgram.py long form: B=64, L=171, 355 decode steps)
+  c3     the VQ nearest-code search (L2Embedding.forward) at 32x129 / 256x129 vectors, V=43 / 512
+  train  BASELINE config 4: the paired TTS training step, B=32 per GPU, 109 speakers, SyncBN over the
+         global batch, RCCL all-reduce of the gradients (ms_allreduce / ms_syncbn reported)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,14 +32,32 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests'))
 
-import numpy as np
-import torch
-
 B, T_RAW, R, L, N_MELS = 32, 256, 3, 43, 80
 T = T_RAW + (R - T_RAW % R)          # 258: the reference pads r - T % r frames (bin/train_vqvae.py:43-46)
 STEPS = T // R                        # 86
 MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix peak (256 CUs x 256 FLOP/cycle x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+# PMC pass of the dominant kernel (tools/gpu_pmc.sh -> tools/pmc_summary.py): HBM bytes per launch.  bench.py does not
+# measure this itself (PMC counters need their own rocprofv3 passes); the value is quoted WITH its source file.
+TRAFFIC_FILES = ('profiles/r02_pmc_hbm_traffic.json', 'profiles/r01_pmc_hbm_traffic.json')
+
+
+def decode_step_algorithmic_bytes(Bsz, Lt, dec):
+    """bytes one decode step must move if every operand is read once: all per-step weights, the memory and
+    processed-memory tiles of every utterance, and the recurrent state (read + write)."""
+    P, Q, D, E, A = dec.prenet_dim, dec.query_rnn_dim, dec.dec_rnn_dim, dec.enc_embed_dim, dec.attn_dim
+    in_dim = dec.n_mels * dec.n_frames_per_step
+    F_, K = dec.n_location_filters, dec.location_kernel_size
+    w = (in_dim * P + P * P                       # prenet
+         + 4 * Q * (P + E + Q) + 8 * Q            # query LSTM
+         + A * Q + F_ * 2 * K + A * F_ + A        # attention: query layer, location conv, location linear, v
+         + 4 * D * (E + Q + D) + 8 * D            # decoder LSTM
+         + (in_dim + 1) * (D + E) + in_dim + 1    # proj + gate
+         + 2 * (dec.spkr_embed_dim * Q + Q))      # AdaIN linears: counted per step as SURVEY 8d does (18,876,337 weights =
+    #                                               75.5 MB), although this implementation hoists them out of the loop
+    mem = Bsz * Lt * (E + A)
+    state = Bsz * (2 * (2 * Q + 2 * D) + 2 * E + 4 * Lt + 2 * in_dim)
+    return 4.0 * (w + mem + state)
 
 
 def lstm_algorithmic_bytes(Bsz, H, K):
@@ -37,76 +65,224 @@ def lstm_algorithmic_bytes(Bsz, H, K):
     return 4 * (4 * H * K + 8 * H + Bsz * K + 3 * Bsz * H)
 
 
-def cpu_baseline(m, txt_mem, spk, passes=3):
-    """the oracle's Decoder.forward on the host cores, same workload, full 86 steps"""
-    from oracle import tts_oracle as O
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(m, txt_mem, spk):
+    """The CPU reference of the same workload on this box's host cores.  Two bounded legs:
+    'reference-style' = the decode path assembled from the torch.nn modules the reference itself is made of
+    (nn.LSTMCell, nn.Linear, nn.Conv1d: oracle/nn_baseline.py, the same ATen kernels the reference would hit) and
+    'port' = the functional oracle.  The faster of the thread settings tried is reported as `value`."""
+    import numpy as np
+    import torch
+    from oracle import nn_baseline as NB
     from helpers import full_hp
     W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-    # B=32 GEMMs stop scaling long before a 128-core host is full (the survey measured 8 threads);
-    # use min(cores, 16) threads and say so
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
     hp = full_hp(0.5)
     mem, s = txt_mem.cpu(), spk.cpu()
-    drop = O.DropoutSource('rng', generator=torch.Generator().manual_seed(0))
-    times = []
-    budget = time.perf_counter() + 40.0          # bounded sample: stop after ~40 s whatever happens
-    with torch.no_grad():
-        for i in range(passes + 1):
-            t0 = time.perf_counter()
-            O.decoder_forward(W, mem, T, s, hp, tf_rate=0.0, training=False, drop=drop)
-            times.append(time.perf_counter() - t0)
-            if time.perf_counter() > budget and len(times) >= 2:
-                break
-    passes = len(times) - 1
-    t = float(np.median(times[1:]))
-    return {'value': B * T / t, 'unit': 'mel-frames/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d full passes of Decoder.forward (B=%d, %d steps, L=%d) after 1 warm-up, median; '
-                      'torch CPU fp32, %d threads' % (passes, B, STEPS, L, cores), 'seconds_per_pass': t}
+    cores = host_cores()
+    runs = []
+    deadline = time.perf_counter() + 45.0           # bounded sample: ~10-30 s of CPU work in total
+    for threads in sorted({min(cores, 16), min(cores, 64), cores}):
+        if time.perf_counter() > deadline:
+            break
+        torch.set_num_threads(threads)
+        ref = NB.NNDecoder(W, hp)
+        times = []
+        with torch.no_grad():
+            for i in range(3):
+                t0 = time.perf_counter()
+                ref(mem, T, s, seed=i)
+                times.append(time.perf_counter() - t0)
+                if time.perf_counter() > deadline and len(times) >= 2:
+                    break
+        runs.append({'threads': threads, 'seconds_per_pass': float(np.min(times[1:] or times)), 'passes': len(times)})
+    best = min(runs, key=lambda r: r['seconds_per_pass'])
+    return {'value': B * T / best['seconds_per_pass'], 'unit': 'mel-frames/s', 'cores': best['threads'], 'kind': 'port',
+            'host_cores': cores, 'runs': runs,
+            'sample': 'full passes of Decoder.forward (B=%d, %d steps, L=%d, prenet dropout 0.5) assembled from the torch.nn '
+                      'modules the reference is made of (nn.LSTMCell / nn.Linear / nn.Conv1d, oracle/nn_baseline.py), torch CPU '
+                      'fp32, 1 warm-up + best of the following passes at each thread count in `runs`; the fastest is `value`'
+                      % (B, STEPS, L)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--no-graph', action='store_true', help='issue the decode loop eagerly instead of replaying a hipGraph')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['c2', 'c5'], default='c2',
-                    help="c2 = the headline configuration; c5 = BASELINE config 5 (bin/gen_specgram.py long-form: B=64, L=171, "
-                         "(1026+40)//3 = 355 decode steps) as a secondary line for DESIGN.md")
-    args = ap.parse_args()
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start N fresh ranks (one per GPU) before this process touches the GPU."""
+    import torch
+    n_dev = torch.cuda.device_count()                  # counting devices does not initialise the GPU
+    if args.gpus > n_dev and os.environ.get('ST_BENCH_BACKEND', 'nccl') == 'nccl':
+        sys.stderr.write('bench.py: --gpus %d but this node exposes %d GPU(s): refusing to run fewer ranks than asked '
+                         '(set ST_BENCH_BACKEND=gloo to share devices in a functional test)\n' % (args.gpus, n_dev))
+        return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Ranks:
+    """rank bookkeeping + the barrier / max-over-ranks timing contract"""
+
+    def __init__(self, args):
+        import torch
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        if self.world != args.gpus:
+            raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, self.world))
+        assert torch.cuda.is_available(), 'bench.py needs a GPU'
+        # RCCL ('nccl' on ROCm).  ST_BENCH_BACKEND=gloo only exists to exercise the multi-rank path on a box with fewer GPUs
+        # than ranks (the ranks then share devices; reductions go through CPU tensors).
+        self.backend = os.environ.get('ST_BENCH_BACKEND', 'nccl')
+        n_dev = torch.cuda.device_count()
+        if self.backend == 'nccl' and self.world > n_dev:
+            raise SystemExit('bench.py: %d ranks but %d GPU(s)' % (self.world, n_dev))
+        self.local_dev = self.local_rank % n_dev
+        torch.cuda.set_device(self.local_dev)
+        self.dev = torch.device('cuda', self.local_dev)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            kw = {'device_id': self.dev} if self.backend == 'nccl' else {}
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_seconds(self, seconds):
+        import torch
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], device=self.dev if self.backend == 'nccl' else 'cpu', dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, steps, warmup):
+        """W untimed + exactly K timed calls of fn, bracketed by barrier + synchronize; max over ranks"""
+        for _ in range(warmup):
+            fn()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return self.max_seconds(time.perf_counter() - t0)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def event_timer(lib):
+    """HIP events on the stream the st_* kernels are launched on (torch.cuda.Event would also do for torch's current stream;
+    this goes through the library's own plumbing so it is right under ops.use_stream as well)"""
+    import ctypes as C
+    from semi_tts_amd import ops
+
+    class Timer:
+        def __enter__(self):
+            self.e0, self.e1 = C.c_void_p(), C.c_void_p()
+            lib.st_event_create(C.byref(self.e0)); lib.st_event_create(C.byref(self.e1))
+            lib.st_event_record(self.e0, ops.stream_handle())
+            return self
+
+        def __exit__(self, *a):
+            lib.st_event_record(self.e1, ops.stream_handle())
+            ms = C.c_float()
+            lib.st_event_elapsed_ms(self.e0, self.e1, C.byref(ms))     # synchronises on e1
+            self.ms = ms.value
+            lib.st_event_destroy(self.e0); lib.st_event_destroy(self.e1)
+    return Timer
+
+
+# ===================================================================================== decode (c2 / c5)
+def lstm_probe(dec, dev, Bsz):
+    """Roofline probe of the dominant kernel (the weight-streaming LSTM cell), measured with HIP events on the stream the
+    kernel runs on: the two launches of a decode step (query LSTM K=1792, decoder LSTM K=2560) alternate exactly as in the
+    loop, so the 75.5 MB of weights cycle through the caches as they do there.  Replayed from a hipGraph (as in the decode
+    loop) so the measurement sees device time, not the Python/ctypes issue rate."""
+    import torch
+    from semi_tts_amd import _lib, ops
+    lib = _lib.load()
+    Q, D, E, P = dec.query_rnn_dim, dec.dec_rnn_dim, dec.enc_embed_dim, dec.prenet_dim
+    f32 = dict(device=dev, dtype=torch.float32)
+    wq_ih, wd_ih = dec.query_rnn.weight_ih, dec.dec_rnn.weight_ih
+    pk_q = ops.pack_weight([wq_ih, wq_ih[:, P:], dec.query_rnn.weight_hh], [P, E, Q], 4 * Q, lstm_H=Q, ldws=[P + E, P + E, Q])
+    pk_d = ops.pack_weight([wd_ih, wd_ih[:, E:], dec.dec_rnn.weight_hh], [E, Q, D], 4 * D, lstm_H=D, ldws=[E + Q, E + Q, D])
+    Kq, Kd = P + E + Q, E + Q + D                       # all multiples of 16 at the headline shape
+    xq = ops.tile_rows(torch.randn(Bsz, Kq, **f32))
+    xd = ops.tile_rows(torch.randn(Bsz, Kd, **f32))
+    c_q, c_d = torch.randn(Bsz, Q, **f32), torch.randn(Bsz, D, **f32)
+    ho, co = torch.zeros(ops.t16_floats(Bsz, Q), **f32), torch.empty(Bsz, Q, **f32)
+    xq_v, xd_v, ho_v = ops.t16_view(xq, K=Kq), ops.t16_view(xd, K=Kd), ops.t16_view(ho, K=Q)
+
+    def pair():
+        ops.lstm_cell_packed(pk_q, xq_v, Kq, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh, c_q, ho_v, co, Bsz, Q)
+        ops.lstm_cell_packed(pk_d, xd_v, Kd, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
+
+    inner, outer = 50, 10
+    g2 = ops.Graph()
+    pair()
+    with g2.capture():
+        for _ in range(inner):
+            pair()
+    for _ in range(3):
+        g2.launch()
+    torch.cuda.synchronize()
+    with event_timer(lib)() as tm:
+        for _ in range(outer):
+            g2.launch()
+    avg_us = tm.ms * 1e3 / (2 * inner * outer)
+    alg = 0.5 * (lstm_algorithmic_bytes(Bsz, Q, Kq) + lstm_algorithmic_bytes(Bsz, D, Kd))
+    flops = 0.5 * (2.0 * Bsz * 4 * Q * Kq + 2.0 * Bsz * 4 * D * Kd)
+    return avg_us, alg, flops
+
+
+def kernel_name_of_lstm(Bsz):
+    bt = (Bsz + 15) // 16
+    if bt in (2, 4):
+        return 'pk_lstm_rt2_kernel<8,2,%d> (fused LSTM cell on packed operands: gate GEMM + pointwise; 2 row tiles x %d batch tile(s) per workgroup)' % (bt // 2, bt // 2)
+    return 'pk_kernel<0,%d,8,2> (fused LSTM cell on packed operands)' % bt
+
+
+def bench_decode(args, rk):
+    import torch
     global B, L, T, STEPS
     if args.workload == 'c5':
         B, L, STEPS = 64, 171, (1026 + 40) // R
         T = STEPS * R
-
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # RCCL ('nccl' on ROCm).  ST_BENCH_BACKEND=gloo only exists to exercise this multi-rank path on a box with fewer GPUs
-        # than ranks (the ranks then share devices; the max-over-ranks reduction goes through a CPU tensor).
-        backend = os.environ.get('ST_BENCH_BACKEND', 'nccl')
-        dist.init_process_group(backend, rank=rank, world_size=world)
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    local_dev = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_dev)
-    dev = torch.device('cuda', local_dev)
-
+    dev = rk.dev
     from helpers import full_tacotron
     from semi_tts_amd import ops
+    from semi_tts_amd.runtime import GraphedDecoder
     from semi_tts_amd.synthetic import synthetic_batch
 
     m = full_tacotron(dev, seed=1234, prenet_dropout=0.5)
-    txt, spk, _ = synthetic_batch(B, L, T, seed=100 + rank)
+    txt, spk, _ = synthetic_batch(B, L, T, seed=100 + rk.rank)
     txt, spk = torch.from_numpy(txt).to(dev), torch.from_numpy(spk).to(dev)
     with torch.no_grad():
         memory = m.encoder(txt, None).contiguous()        # inputs of the timed region, resident in HBM
     dec = m.decoder
-    from semi_tts_amd.runtime import GraphedDecoder
     gd = GraphedDecoder(dec, B, L, T, dev)
     gd.memory.copy_(memory)
     gd.spkr.copy_(spk)
@@ -125,128 +301,197 @@ def main():
             state['out'] = gd._run()
 
     one_pass()
+    elapsed = rk.timed(one_pass, args.steps, args.warmup)
     mel = state['out'][0]
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_pass()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_pass()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     assert bool(torch.isfinite(mel).all()), 'non-finite mel output'
+    if rk.rank != 0:
+        return None
 
-    # ---- roofline of the dominant kernel (the weight-streaming LSTM cell), measured with HIP events
-    # on the stream the kernel runs on: the two launches of a decode step (query LSTM K=1792, decoder
-    # LSTM K=2560) alternate exactly as in the loop, so the 75.5 MB of weights cycle through the caches.
-    roof = None
-    if rank == 0:
-        import ctypes as C
-        from semi_tts_amd import _lib
-        lib = _lib.load()
-        Q, D, E, P = dec.query_rnn_dim, dec.dec_rnn_dim, dec.enc_embed_dim, dec.prenet_dim
-        f32 = dict(device=dev, dtype=torch.float32)
-        wq_ih, wd_ih = dec.query_rnn.weight_ih, dec.dec_rnn.weight_ih
-        pk_q = ops.pack_weight([wq_ih, wq_ih[:, P:], dec.query_rnn.weight_hh], [P, E, Q], 4 * Q, lstm_H=Q,
-                               ldws=[P + E, P + E, Q])
-        pk_d = ops.pack_weight([wd_ih, wd_ih[:, E:], dec.dec_rnn.weight_hh], [E, Q, D], 4 * D, lstm_H=D,
-                               ldws=[E + Q, E + Q, D])
-        Kq, Kd = P + E + Q, E + Q + D                       # all multiples of 16 at the headline shape
-        xq = ops.tile_rows(torch.randn(B, Kq, **f32))
-        xd = ops.tile_rows(torch.randn(B, Kd, **f32))
-        c_q, c_d = torch.randn(B, Q, **f32), torch.randn(B, D, **f32)
-        ho, co = torch.zeros(ops.t16_floats(B, Q), **f32), torch.empty(B, Q, **f32)
-        xq_v, xd_v, ho_v = ops.t16_view(xq, K=Kq), ops.t16_view(xd, K=Kd), ops.t16_view(ho, K=Q)
+    us_step = elapsed / args.steps / STEPS * 1e6
+    avg_us, alg, flops = lstm_probe(dec, dev, B)
+    achieved = alg / (avg_us * 1e-6) / 1e9
+    traffic, traffic_src = None, None
+    if args.workload == 'c2':
+        for rel in ([args.traffic_json] if args.traffic_json else []) + list(TRAFFIC_FILES):
+            try:
+                with open(rel if os.path.isabs(rel) else os.path.join(REPO, rel)) as f:
+                    tj = json.load(f)
+                traffic = tj['hbm_bytes_per_launch']
+                traffic_src = {'file': rel, 'kernel': tj.get('kernel'), 'commit': tj.get('commit'),
+                               'note': 'separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, tools/gpu_pmc.sh), not measured by this run'}
+                break
+            except (OSError, KeyError, ValueError):
+                continue
+    step_bytes = decode_step_algorithmic_bytes(B, L, dec)
+    roof = {'bound': 'hbm', 'kernel': kernel_name_of_lstm(B),
+            'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+            'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(avg_us, 3),
+            'launches_per_step': 2 * STEPS,
+            # the same launch against the fp32 matrix-core peak (at B=32 the cell sits just left of the ridge:
+            # 15.7 FLOP/B against 19.7)
+            'mfma': {'achieved': round(flops / (avg_us * 1e-6) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(flops / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)},
+            # the WHOLE decode step (all launches of one step; they are dependent, so the step is their sum) against the
+            # same HBM peak: this, not the dominant kernel's fraction, is how far the path is from its roofline
+            'step': {'algorithmic_bytes': step_bytes, 'us': round(us_step, 2),
+                     'achieved': round(step_bytes / (us_step * 1e-6) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(step_bytes / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+    frames = rk.world * B * T * args.steps
+    res = {
+        'metric': 'mel-frames/sec (decode+attn)', 'value': round(frames / elapsed, 1), 'unit': 'mel-frames/s',
+        'n_gpus': rk.world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: Decoder.forward free-running inference (decode+attn), B=%d per GPU, '
+                               '%s->%d frames = %d decode steps (r=3), L=%d, n_mels=%d, prenet dropout 0.5, '
+                               'config/supervised.yaml decoder section'
+                               % (args.workload.upper(), B, '256' if args.workload == 'c2' else '1026+40', T, STEPS, L, N_MELS),
+                   'batch_per_gpu': B, 'frames': T, 'decode_steps': STEPS, 'text_len': L,
+                   'parallelism': 'replicas x%d (utterance-sharded, no collective)' % rk.world,
+                   'launch': 'eager' if graph is None else 'hipGraph replay of the whole decode loop'},
+        'rccl_ranks': rk.world if (rk.world > 1 and rk.backend == 'nccl') else 0,
+        'us_per_decode_step': round(us_step, 2),
+        'roofline': roof,
+    }
+    if not args.no_cpu_baseline and args.workload == 'c2':
+        res['cpu_baseline'] = cpu_baseline(m, memory, spk)
+    try:
+        res['device'] = ops.device_info()
+    except Exception:
+        pass
+    return res
 
-        def pair():
-            ops.lstm_cell_packed(pk_q, xq_v, Kq, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh, c_q, ho_v, co, B, Q)
-            ops.lstm_cell_packed(pk_d, xd_v, Kd, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, B, D)
 
-        # the launches are replayed from a hipGraph (as in the decode loop) so the measurement sees
-        # device time, not the Python/ctypes issue rate
-        inner = 50
-        g2 = ops.Graph()
-        pair()
-        with g2.capture():
+# ===================================================================================== VQ (c3)
+def bench_vq(args, rk):
+    """L2Embedding.forward's nearest-code search (src/embed.py:105-147,208-213) on (B,129,64) encoder latents:
+    BASELINE config 3 (V=512 synthetic table) and the native V=43 table, at 32 and 256 utterances.
+    Algorithmic bytes per vector: 256 in + 256 out + 8 idx + 4V p_code; the table is read once."""
+    import torch
+    from semi_tts_amd import _lib, ops
+    lib = _lib.load()
+    dev = rk.dev
+    g = torch.Generator().manual_seed(7 + rk.rank)
+    rows = []
+    head = None
+    for Bn, V in ((32, 512), (256, 512), (32, 43), (256, 43)):
+        n, D = Bn * 129, 64
+        x = torch.randn(Bn, 129, D, generator=g).to(dev)
+        table = torch.randn(V, D, generator=g).to(dev)
+        temp = torch.ones(1, device=dev)
+        p, idx, out = ops.vq_l2(x, table, temp)
+        p_buf, idx_buf, out_buf = torch.empty_like(p), torch.empty_like(idx), torch.empty_like(out)
+
+        def launch():
+            lib.st_vq_l2_fwd(ops._p(x), ops._p(table), ops._p(temp), ops._p(p_buf), ops._p(idx_buf, torch.int64),
+                             ops._p(out_buf), n, D, V, ops.stream_handle())
+        inner = 20
+        gph = ops.Graph()
+        launch()
+        with gph.capture():
             for _ in range(inner):
-                pair()
-        for _ in range(3):
-            g2.launch()
+                launch()
+        gph.launch()
         torch.cuda.synchronize()
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        lib.st_event_create(C.byref(e0)); lib.st_event_create(C.byref(e1))
-        outer = 10
-        reps = inner * outer
-        s = ops.stream_handle()
-        lib.st_event_record(e0, s)
-        for _ in range(outer):
-            g2.launch()
-        lib.st_event_record(e1, s)
-        ms = C.c_float()
-        lib.st_event_elapsed_ms(e0, e1, C.byref(ms))
-        lib.st_event_destroy(e0); lib.st_event_destroy(e1)
-        avg_us = ms.value * 1e3 / (2 * reps)
-        alg = 0.5 * (lstm_algorithmic_bytes(B, Q, P + E + Q) + lstm_algorithmic_bytes(B, D, E + Q + D))
-        achieved = alg / (avg_us * 1e-6) / 1e9
-        flops = 0.5 * (2.0 * B * 4 * Q * Kq + 2.0 * B * 4 * D * Kd)
-        traffic = None       # HBM bytes per launch from the PMC pass of the same command (tools/gpu_pmc.sh)
-        try:
-            if args.workload == 'c2':
-                with open(os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.json')) as f:
-                    traffic = json.load(f)['hbm_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
-        roof = {'bound': 'hbm', 'kernel': 'pk_lstm_rt2_kernel<8,2,1> (fused LSTM cell on packed operands: gate GEMM + pointwise; 2 row tiles x 1 batch tile per workgroup)',
-                'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(avg_us, 3),
-                'launches_per_step': 2 * STEPS,
-                # the same launch against the fp32 matrix-core peak (at B=32 the cell sits just left of the ridge:
-                # 15.7 FLOP/B against 19.7; PMC evidence: profiles/r01_pmc_mfma.*)
-                'mfma': {'achieved': round(flops / (avg_us * 1e-6) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(flops / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}}
+        reps = max(args.steps, 5)
+        with event_timer(lib)() as tm:
+            for _ in range(reps):
+                gph.launch()
+        us = tm.ms * 1e3 / (reps * inner)
+        assert torch.equal(idx_buf, idx)
+        alg = n * (520 + 4 * V) + V * D * 4
+        row = {'utterances': Bn, 'vectors': n, 'V': V, 'us_per_launch': round(us, 3), 'algorithmic_bytes': alg,
+               'GBps': round(alg / (us * 1e-6) / 1e9, 1), 'frac_of_hbm_peak': round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+               'vectors_per_s': round(n / (us * 1e-6), 1), 'GFLOPs': round(2.0 * n * V * D / (us * 1e-6) / 1e9, 1)}
+        rows.append(row)
+        if (Bn, V) == (32, 512):
+            head = row
+    if rk.rank != 0:
+        return None
+    return {'metric': 'VQ vectors/sec (L2Embedding.forward nearest-code search)', 'value': head['vectors_per_s'] * rk.world,
+            'unit': 'vectors/s', 'n_gpus': rk.world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': head['us_per_launch'] * 1e-3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C3: L2Embedding.forward on (32,129,64) latents, V=512 synthetic table (config 3); other shapes in `cases`'},
+            'roofline': {'bound': 'hbm', 'kernel': 'vq_l2_kernel', 'achieved': head['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': head['frac_of_hbm_peak'], 'traffic': None,
+                         'algorithmic_bytes_per_launch': head['algorithmic_bytes'], 'avg_launch_us': head['us_per_launch']},
+            'cases': rows}
 
-    if rank == 0:
-        frames = world * B * T * args.steps
-        res = {
-            'metric': 'mel-frames/sec (decode+attn)', 'value': round(frames / elapsed, 1), 'unit': 'mel-frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+
+# ===================================================================================== training (C4)
+def bench_train(args, rk):
+    """BASELINE config 4: config/semi-multi-spkr-paired-data.yaml, utterance-level data parallelism -- every rank runs the
+    paired TTS training step on its own B=32 synthetic batch (109 speakers), BatchNorm statistics over the global batch
+    (SyncBN), gradients summed by RCCL all-reduce, identical clip + Adam on every rank.
+    ms_allreduce / ms_syncbn = step time with the collective minus step time without it (exposed cost)."""
+    import torch
+    import yaml
+    from argparse import Namespace
+    from semi_tts_amd import parallel
+    from semi_tts_amd.solver import TtsTrainer
+    config = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-multi-spkr-paired-data.yaml')))
+    paras = Namespace(batch_size=B, frames=T_RAW, n_batches=1, seed=0, verbose=False, max_step=10 ** 9, load=None, n_spkr=109)
+    tr = TtsTrainer(config, paras, 'train').load_data().set_model()
+    batch = [t.to(rk.dev) for t in tr.batches[0]]
+    last = {}
+
+    def step():
+        last.update(tr.train_step(*batch))
+
+    step()
+    variants = {}
+    elapsed = rk.timed(step, args.steps, args.warmup)
+    variants['full'] = elapsed
+    if rk.world > 1:
+        parallel.set_gradient_allreduce(False)
+        variants['no_allreduce'] = rk.timed(step, args.steps, 1)
+        parallel.set_gradient_allreduce(True)
+        parallel.sync_batchnorm(False)
+        variants['no_syncbn'] = rk.timed(step, args.steps, 1)
+        parallel.sync_batchnorm(True)
+    if rk.rank != 0:
+        return None
+    ms = {k: v / args.steps * 1e3 for k, v in variants.items()}
+    frames = rk.world * batch[2].shape[0] * batch[2].shape[1] * args.steps
+    n_par = sum(p.numel() for p in tr.model.parameters() if p.requires_grad)
+    return {'metric': 'training mel-frames/sec (paired TTS step: fwd + loss + bwd + all-reduce + clip + Adam)',
+            'value': round(frames / elapsed, 1), 'unit': 'mel-frames/s', 'n_gpus': rk.world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms['full'], 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s: Decoder.forward free-running inference (decode+attn), B=%d per GPU, '
-                                   '%s->%d frames = %d decode steps (r=3), L=%d, n_mels=%d, prenet dropout 0.5, '
-                                   'config/supervised.yaml decoder section'
-                                   % (args.workload.upper(), B, '256' if args.workload == 'c2' else '1026+40', T, STEPS, L, N_MELS),
-                       'batch_per_gpu': B, 'frames': T, 'decode_steps': STEPS, 'text_len': L,
-                       'parallelism': 'replicas x%d (utterance-sharded, no collective)' % world,
-                       'launch': 'eager' if graph is None else 'hipGraph replay of the whole decode loop'},
-            'us_per_decode_step': round(elapsed / args.steps / STEPS * 1e6, 2),
-            'roofline': roof,
-        }
-        if not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(m, memory, spk)
-        try:
-            res['device'] = ops.device_info()
-        except Exception:
-            pass
+            'config': {'workload': 'C4: TtsTrainer.train_step, B=%d per GPU, %d->%d frames, L=%d, 109 speakers, tf_rate=1, '
+                                   'config/semi-multi-spkr-paired-data.yaml' % (B, T_RAW, batch[2].shape[1], batch[0].shape[1]),
+                       'parallelism': 'dp%d (utterance-sharded, SyncBN, gradient all-reduce of %.1f MB)' % (rk.world, n_par * 4 / 1e6)},
+            'rccl_ranks': rk.world if (rk.world > 1 and rk.backend == 'nccl') else 0,
+            'ms_allreduce': round(ms['full'] - ms['no_allreduce'], 3) if 'no_allreduce' in ms else 0.0,
+            'ms_syncbn': round(ms['full'] - ms['no_syncbn'], 3) if 'no_syncbn' in ms else 0.0,
+            'ms_variants': {k: round(v, 3) for k, v in ms.items()},
+            'collectives_per_step': parallel.collective_counts(),
+            'last': {k: last[k] for k in ('loss', 'grad_norm')}, 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-graph', action='store_true', help='issue the decode loop eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--traffic-json', default=None, help='PMC summary (tools/pmc_summary.py) to quote as roofline.traffic')
+    ap.add_argument('--workload', choices=['c2', 'c5', 'c3', 'train'], default='c2',
+                    help="c2 = the headline configuration; c5 / c3 / train = secondary lines (see the module docstring)")
+    args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))            # nothing above this line has touched the GPU
+
+    rk = Ranks(args)
+    fn = {'c2': bench_decode, 'c5': bench_decode, 'c3': bench_vq, 'train': bench_train}[args.workload]
+    res = fn(args, rk)
+    if rk.rank == 0:
         print(json.dumps(res))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    rk.close()
 
 
 if __name__ == '__main__':

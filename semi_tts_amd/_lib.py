@@ -216,3 +216,17 @@ def check(rc, what):
     if rc != 0:
         msg = load().st_last_error()
         raise RuntimeError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def check_header_symbols():
+    """every function include/semitts.h declares is exported by the library and bound by SIGNATURES (and nothing else is)"""
+    import re
+    hdr = open(os.path.join(os.path.dirname(HERE), 'include', 'semitts.h')).read()
+    declared = sorted(set(re.findall(r'\b(st_[a-z0-9_]+)\s*\(', hdr)))
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    if missing:
+        raise RuntimeError('declared in include/semitts.h but not exported by %s: %s' % (LIB_PATH, missing))
+    if sorted(SIGNATURES) != declared:
+        raise RuntimeError('ctypes table and include/semitts.h disagree: %s' % sorted(set(SIGNATURES) ^ set(declared)))
+    return declared

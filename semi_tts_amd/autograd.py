@@ -92,6 +92,7 @@ class _BnTrainFn(Function):
         if sync:
             # merge the per-rank (count, mean, M2) exactly (Chan et al.); N-vectors only, two small all-reduces
             buf = torch.cat([mean * M, mean.new_tensor([float(M)])])
+            parallel._COUNTS['syncbn_fwd'] += 2
             parallel.all_reduce_sum_(buf)
             Mstat = int(round(float(buf[-1])))
             gmean = buf[:-1] / Mstat
@@ -116,6 +117,7 @@ class _BnTrainFn(Function):
         s = ops.bn_bwd_reduce(dy2, y2, act, x2, mean, var, eps)
         db, dw = s[:N].clone(), s[N:].clone()           # parameter gradients: local sums (averaged over ranks later)
         if sync:
+            parallel._COUNTS['syncbn_bwd'] += 1
             parallel.all_reduce_sum_(s)
         dx = ops.bn_bwd_apply(dy2, y2, act, x2, mean, var, weight, eps, s, Mstat)
         return dx.view(x.shape), dw, db, None, None, None, None, None

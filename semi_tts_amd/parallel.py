@@ -21,6 +21,13 @@ def shard_range(n_items, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rank_world():
+    """(rank, world_size) of this process; (0, 1) outside torch.distributed"""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def max_over_ranks(seconds, device=None):
     """the slowest rank's wall time (what bench.py reports)"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -30,11 +37,30 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+_GRAD_ALLREDUCE = True
+_COUNTS = {'grad_buckets': 0, 'syncbn_fwd': 0, 'syncbn_bwd': 0}
+
+
+def set_gradient_allreduce(enabled=True):
+    """measurement hook (bench.py --workload train): switch the gradient all-reduce off to time the step without it"""
+    global _GRAD_ALLREDUCE
+    _GRAD_ALLREDUCE = bool(enabled)
+
+
+def collective_counts(reset=False):
+    """collectives issued by the LAST training step, by kind (gradient buckets, SyncBN forward / backward)"""
+    out = dict(_COUNTS)
+    if reset:
+        for k in _COUNTS:
+            _COUNTS[k] = 0
+    return out
+
+
 def allreduce_gradients(params, bucket_bytes=32 << 20, average=True):
     """Sum (or average) .grad of `params` across ranks with flat buckets; returns the number of
     collectives issued.  Parameters without a gradient contribute zeros so every rank issues the same
     sequence of collectives."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not _GRAD_ALLREDUCE:
         return 0
     world = dist.get_world_size()
     params = [p for p in params if p.requires_grad]
@@ -58,6 +84,7 @@ def allreduce_gradients(params, bucket_bytes=32 << 20, average=True):
                 p.grad.copy_(g)
             off += n
         n_coll += 1
+        _COUNTS['grad_buckets'] += 1
         bucket, size = [], 0
 
     for p in params:

@@ -55,7 +55,9 @@ class BaseSolver:
         if not path:
             return False
         ckpt = torch.load(path, map_location=self.device)
-        missing = self.model.load_state_dict(ckpt['model'], strict=False)
+        # strict, like the reference (bin/gen_specgram.py:80, bin/train_vqvae.py:106): a checkpoint of another architecture
+        # must not leave the constructor's random weights in place silently
+        self.model.load_state_dict(ckpt['model'], strict=True)
         if self.mode == 'train':
             self.step = ckpt.get('global_step', 0)
             if getattr(self, 'optimizer', None) is not None and 'optimizer' in ckpt:
@@ -64,7 +66,7 @@ class BaseSolver:
         else:
             self.step = ckpt.get('global_step', 0)
             self.verbose('Evaluation target = %s (step %d)' % (path, self.step))
-        return missing
+        return True
 
     def _build_model(self):
         cfg = json.loads(json.dumps(self.config['model']))
@@ -90,6 +92,10 @@ class SpecgramGenerator(BaseSolver):
             sid = rs.randint(0, self.n_spkr, (B,)).astype(np.int64)
             self.test_set.append((frames, torch.from_numpy(text), torch.from_numpy(sid)))
         self.filelist = ['utt%05d' % i for i in range(B * len(self.test_set))]
+        # utterance-sharded replicas: under torch.distributed every rank decodes and writes only its own
+        # contiguous range of each batch (no collective, no two ranks writing the same file)
+        from . import parallel
+        self.rank, self.world = parallel.rank_world()
         return self
 
     def set_model(self):
@@ -107,8 +113,16 @@ class SpecgramGenerator(BaseSolver):
         os.makedirs(output_dir, exist_ok=True)
         r = self.n_frames_per_step
         cnt, frames_out, t0 = 0, 0, time.perf_counter()
+        rank, world = getattr(self, 'rank', 0), getattr(self, 'world', 1)
+        from .parallel import shard_range
+        next_first = 0
         for frames, text, sid in self.test_set:
-            text, sid = text.to(self.device), sid.to(self.device)
+            batch_first, next_first = next_first, next_first + text.shape[0]
+            lo, hi = shard_range(text.shape[0], world, rank)
+            if hi <= lo:
+                continue
+            names = self.filelist[batch_first + lo:batch_first + hi]
+            text, sid = text[lo:hi].to(self.device), sid[lo:hi].to(self.device)
             pad = r - frames % r                                                      # gen_specgram.py:36-37
             with torch.no_grad():
                 mel, lin, align, _, _, _, _, _ = self.model.text_to_speech(
@@ -117,14 +131,16 @@ class SpecgramGenerator(BaseSolver):
             enc_step = (text != 0).sum(dim=-1).cpu().tolist()
             dec_step = [int(n * FRAME_PHN_RATIO) // r for n in enc_step]
             for i, (msp, sp, ali) in enumerate(zip(mel, lin, align)):
-                name = os.path.join(output_dir, self.filelist[cnt])
+                name = os.path.join(output_dir, names[i])
                 np.save(name + '-mel.npy', msp.cpu().numpy().astype(np.float32), allow_pickle=False)
                 np.save(name + '-spec.npy', sp.cpu().numpy().astype(np.float32), allow_pickle=False)
                 np.save(name + '-align.npy', ali[:dec_step[i], :enc_step[i]].cpu().numpy())
                 cnt += 1
                 frames_out += msp.shape[0]
         dt = time.perf_counter() - t0
-        self.verbose('Save %d spectrograms (%d frames) in %s, %.2f s' % (cnt, frames_out, output_dir, dt))
+        if rank == 0 or world == 1:
+            self.verbose('Save %d spectrograms%s (%d frames) in %s, %.2f s' %
+                         (cnt, ' on rank 0 of %d' % world if world > 1 else '', frames_out, output_dir, dt))
         return cnt
 
 
@@ -189,6 +205,7 @@ class TtsTrainer(BaseSolver):
 
     def train_step(self, text, sid, mel, linear, _masks=None):
         from . import parallel
+        parallel.collective_counts(reset=True)
         tf_rate = self.optimizer.pre_step(self.step)
         mel_pred, linear_pred, align, _, _, _, _, _ = self.model.text_to_speech(
             text, sid, None, None, None, None, mel, None, tf_rate, _masks=_masks)

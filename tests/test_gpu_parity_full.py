@@ -1,0 +1,245 @@
+"""Full-size parity of the HIP path in the configurations that are actually benchmarked and shipped
+(round-2 additions; needs a real MI355X: pytest -m gpu):
+
+  * the `Postnet` class on device against the reference-recorded fixture;
+  * BASELINE config 5: the whole 355-step free-running trajectory (B=64, L=171) against the oracle,
+    with the per-step error curve written to gpurun_out/parity_report.jsonl;
+  * BASELINE config 2 exactly as bench.py times it: hipGraph replay of the decode loop, prenet dropout 0.5
+    with the ORACLE's masks replayed through GraphedDecoder.own_mask, prenet layer 1 fused into the
+    projection launch;
+  * one C2-size training step (B=32, 258 frames, L=43): loss, global gradient norm and every parameter
+    gradient against CPU autograd through the oracle;
+  * C2 with the recurrent weights scaled x2.5 (non-contractive dynamics: fp32-vs-fp64 CPU error grows to
+    1e-5 over 86 steps) to see real error accumulation instead of summation-order noise.
+
+Tolerances: north star = 1e-3 max-abs on mel; the measured values are reported and much smaller.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, REPO
+from helpers import full_hp, full_tacotron, masks_to, maxdiff, report, split_masks
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tts_oracle as O   # noqa: E402
+from oracle import vq_oracle as VQ   # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'the gpu-marked tests need a GPU'
+    from semi_tts_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def _weights(m):
+    return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+def _step_curve(a, b, steps):
+    """max-abs difference per decode step of two (B, steps*r, n_mels) tensors"""
+    d = (a.detach().cpu().double() - b.detach().cpu().double()).abs()
+    return d.view(d.shape[0], steps, -1).amax(dim=(0, 2))
+
+
+# ------------------------------------------------------------------------------------ a14
+def test_postnet_class_against_reference_golden(dev):
+    """The 5-conv `Postnet` class (src/module.py:53-82; constructed by no config) on the HIP path against what
+    the real reference produced for the same weights and input (eval mode: BatchNorm folded into the conv)."""
+    from semi_tts_amd.module import Postnet
+    W, A, _ = load_golden('conv_postnet_tiny')
+    m = Postnet(8, 16, 5, 5, 0.0)
+    m.load_state_dict(W)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        y = m(A['x'].to(dev))
+    err = maxdiff(y, A['y'])
+    report('postnet_class', err=err)
+    assert y.shape == A['y'].shape and err < 1e-5
+    # ragged shape against the oracle: T not a multiple of the tile, B = 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 37, 8, generator=g)
+    with torch.no_grad():
+        y2 = m(x.to(dev))
+    assert maxdiff(y2, O.conv_postnet_forward(W, x)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ C5, whole trajectory
+def test_long_form_c5_full_trajectory_against_oracle(dev):
+    """BASELINE config 5 (B=64, L=171, (1026+40)//3 = 355 decode steps), free running, prenet dropout 0:
+    the whole trajectory against the oracle -- the case where a per-step error could accumulate."""
+    from semi_tts_amd.synthetic import synthetic_batch
+    m = full_tacotron(dev, seed=5)
+    B, L, T = 64, 171, 1066
+    steps = T // 3
+    txt, spk, _ = synthetic_batch(B, L, 3, seed=9)
+    txt, spk = torch.from_numpy(txt), torch.from_numpy(spk)
+    with torch.no_grad():
+        mem = m.encoder(txt.to(dev), None)
+        mel, align, stop = m.decoder(mem, None, T, spk.to(dev), tf_rate=0.0)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    with torch.no_grad():
+        mel_r, al_r, st_r = O.decoder_forward(_weights(m), mem.cpu(), T, spk, full_hp(0.0))
+    curve = _step_curve(mel, mel_r, steps)
+    errs = dict(mel=maxdiff(mel, mel_r), align=maxdiff(align, al_r), stop=maxdiff(stop, st_r))
+    report('c5_full_trajectory', steps=steps, mel_first=float(curve[0]), mel_mid=float(curve[steps // 2]),
+           mel_last=float(curve[-1]), curve_every_25=json.dumps([float('%.2e' % v) for v in curve[::25]]), **errs)
+    assert mel.shape == (B, 1065, 80) and align.shape == (B, 355, L)
+    assert errs['mel'] < 1e-3 and errs['align'] < 1e-4 and errs['stop'] < 1e-3          # north star
+    assert errs['mel'] < 5e-5                                                            # measured: ~1e-6
+
+
+# ------------------------------------------------------------------------------------ C2 exactly as benchmarked
+def test_c2_bench_configuration_graph_replay_with_oracle_masks(dev):
+    """What bench.py times: GraphedDecoder replay (hipGraph of the 86-step loop, packed weights cached, prenet layer 1
+    fused into the proj launch) with prenet dropout 0.5.  The oracle draws the masks (the reference's draw order),
+    they are replayed through GraphedDecoder.own_mask, and the outputs must agree."""
+    from semi_tts_amd.module import plan_decode
+    from semi_tts_amd.runtime import GraphedDecoder
+    from semi_tts_amd.synthetic import synthetic_batch
+    B, L, T = 32, 43, 258
+    m = full_tacotron(dev, seed=1234, prenet_dropout=0.5)
+    txt, spk, _ = synthetic_batch(B, L, T, seed=100)
+    txt, spk = torch.from_numpy(txt), torch.from_numpy(spk)
+    with torch.no_grad():
+        mem = m.encoder(txt.to(dev), None).contiguous()
+    hp = full_hp(0.5)
+    drop = O.DropoutSource('rng', generator=torch.Generator().manual_seed(3))
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    with torch.no_grad():
+        mel_r, al_r, st_r = O.decoder_forward(_weights(m), mem.cpu(), T, spk, hp, tf_rate=0.0, training=False, drop=drop)
+    steps, src = plan_decode(True, T, B, B, 3, 0.0, 0.0, None)
+    masks = split_masks(drop.used, hp, False, 0.0, B, B, steps, src, hp['prenet_dim'])
+    gd = GraphedDecoder(m.decoder, B, L, T, dev)
+    gd.capture()
+    assert m.decoder.fuse_prenet and gd.own_mask is not None
+    gd.own_mask.copy_(masks['own'].to(dev))
+    mel, align, stop = gd(mem, spk.to(dev), redraw=False)
+    torch.cuda.synchronize()
+    curve = _step_curve(mel, mel_r, steps)
+    errs = dict(mel=maxdiff(mel, mel_r), align=maxdiff(align, al_r), stop=maxdiff(stop, st_r))
+    report('c2_bench_config', mel_last_step=float(curve[-1]), **errs)
+    assert errs['mel'] < 1e-3 and errs['align'] < 1e-4 and errs['stop'] < 1e-3          # north star
+    assert errs['mel'] < 5e-5
+    # a second replay with the same masks is bit-identical; eager with the same masks too
+    mel_a = mel.clone()
+    mel_b = gd(redraw=False)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(mel_a, mel_b)
+    with torch.no_grad():
+        mel_e = m.decoder(mem, None, T, spk.to(dev), tf_rate=0.0, _masks={'own': gd.own_mask})[0]
+    assert torch.equal(mel_e, mel_a)
+
+
+# ------------------------------------------------------------------------------------ C2 with expanding dynamics
+def test_c2_with_scaled_recurrent_weights(dev):
+    """LSTM weights x2.5: the synthetic U(+-sqrt(3/fan_in)) weights are contractive, so every other full-size test sees
+    only summation-order noise (1e-7).  With gain 2.5 the fp32 CPU oracle itself drifts 1e-5 from its float64 self over
+    86 steps; the HIP path must stay within the same order of the fp32 oracle (bound: the north star's 1e-3)."""
+    from semi_tts_amd.synthetic import synthetic_batch
+    B, L, T = 32, 43, 258
+    m = full_tacotron(dev, seed=99)
+    with torch.no_grad():
+        for cell in (m.decoder.query_rnn, m.decoder.dec_rnn):
+            cell.weight_ih.mul_(2.5)
+            cell.weight_hh.mul_(2.5)
+    txt, spk, _ = synthetic_batch(B, L, T)
+    txt, spk = torch.from_numpy(txt), torch.from_numpy(spk)
+    with torch.no_grad():
+        mem = m.encoder(txt.to(dev), None)
+        mel, align, stop = m.decoder(mem, None, T, spk.to(dev), tf_rate=0.0)
+    W = _weights(m)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    with torch.no_grad():
+        mel_r, al_r, _ = O.decoder_forward(W, mem.cpu(), T, spk, full_hp(0.0))
+        torch.set_default_dtype(torch.float64)
+        try:
+            mel_d, _, _ = O.decoder_forward({k: v.double() for k, v in W.items()}, mem.cpu().double(), T, spk.double(),
+                                            full_hp(0.0))
+        finally:
+            torch.set_default_dtype(torch.float32)
+    c_hip, c_cpu = _step_curve(mel, mel_d, 86), _step_curve(mel_r, mel_d, 86)
+    errs = dict(mel_vs_fp32_oracle=maxdiff(mel, mel_r), hip_vs_fp64=float(c_hip.max()), cpu_fp32_vs_fp64=float(c_cpu.max()),
+                align=maxdiff(align, al_r))
+    report('c2_gain2p5', hip_curve=json.dumps([float('%.1e' % v) for v in c_hip[::10]]),
+           cpu_curve=json.dumps([float('%.1e' % v) for v in c_cpu[::10]]), **errs)
+    assert errs['mel_vs_fp32_oracle'] < 1e-3 and errs['hip_vs_fp64'] < 1e-3
+    # the HIP path accumulates error no faster than the CPU fp32 path does (x8 head-room for run-to-run variation)
+    assert errs['hip_vs_fp64'] < 8 * max(errs['cpu_fp32_vs_fp64'], 1e-6)
+
+
+# ------------------------------------------------------------------------------------ C2-size training step
+def test_c2_training_step_against_oracle_autograd(dev):
+    """One paired training step at BASELINE config 2 size through the trainer's own path (VQVAE.text_to_speech ->
+    freq_loss(mel) + freq_loss(linear) -> backward -> global grad norm), tf_rate 1, all dropouts and batch-statistics
+    BatchNorm active, against CPU fp32 autograd through the oracle replaying the same masks.
+    ref: bin/train_vqvae.py:219-223,270; src/solver.py:138-151; src/util.py:80-126."""
+    import yaml
+    from semi_tts_amd import autograd as AG
+    from semi_tts_amd.optim import clip_grad_norm_
+    from semi_tts_amd.synthetic import load_synthetic, synthetic_train_batch
+    from semi_tts_amd.vqvae import VQVAE
+    cfg = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-single-spkr-paired-data.yaml')))
+    mcfg = cfg['model']
+    mcfg['codebook'].update(phn_attr_pth='', proj_attr=None)          # the attribute csv lives in the reference tree
+    sr, n_mels = cfg['data']['audio']['sample_rate'], cfg['data']['audio']['num_mels']
+    m = VQVAE(80, 1025, 43, 109, **mcfg)
+    load_synthetic(m, 321)
+    m = m.to(dev).train()
+    text, sid, mel, linear = synthetic_train_batch(32, 256, 3, seed=17)
+    B, T = mel.shape[0], mel.shape[1]
+    steps = T // 3
+    hp = dict(mcfg['decoder']['decoder'], n_mels=80, enc_dropout=mcfg['decoder']['encoder']['enc_dropout'])
+
+    # ---- oracle: fp32 CPU autograd
+    W = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    Wt = {k[4:]: v.requires_grad_(v.is_floating_point() and 'running_' not in k) for k, v in W.items() if k.startswith('tts.')}
+    table = W['codebook.learnable_table'].requires_grad_()
+    spk_table = W['spkr_embed.weight'].requires_grad_()
+    drop = O.DropoutSource('rng', generator=torch.Generator().manual_seed(23))
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    lat = VQ.l2_inference({'learnable_table': table}, text)
+    # Tacotron2.forward with separate_postnet = true (every shipped config): the postnet sees mel.detach()  (src/tts.py:47-50)
+    enc_r = O.encoder_forward(Wt, lat, 'encoder.', True, hp['enc_dropout'], drop, None)
+    mel_r, al_r, _ = O.decoder_forward(Wt, enc_r, mel, spk_table[sid], hp, 1.0, None, True, drop, lambda: 0.0)
+    lin_r = O.postnet_forward(Wt, mel_r.detach(), True, None)
+    loss_r = O.freq_loss(mel_r, mel, sr, n_mels) + O.freq_loss(lin_r, linear, sr, n_mels)
+    loss_r.backward()
+    ref_g = {'tts.' + k: v.grad for k, v in Wt.items() if v.requires_grad and v.grad is not None}
+    ref_g['codebook.learnable_table'] = table.grad
+    ref_g['spkr_embed.weight'] = spk_table.grad
+    gn_ref = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref_g.values())))
+
+    # ---- HIP: same masks
+    masks = masks_to(split_masks(drop.used, hp, True, 1.0, B, B, steps, list(range(steps)), hp['prenet_dim']), dev)
+    mel_p, lin_p, align, *_ = m.text_to_speech(text.to(dev), sid.to(dev), None, None, None, None, mel.to(dev), None, 1.0,
+                                               _masks=masks)
+    f = lambda p, l: AG.freq_loss(p, l, sr, n_mels, 'mse', True, True)
+    loss = f(mel_p, mel.to(dev)) + f(lin_p, linear.to(dev))
+    loss.backward()
+    gn = float(clip_grad_norm_([p for p in m.parameters() if p.grad is not None], 1e9))
+    named = dict(m.named_parameters())
+    worst, worst_k, n = 0.0, '', 0
+    for k, g in ref_g.items():
+        assert named[k].grad is not None, 'missing gradient for ' + k
+        scale = float(g.abs().max())
+        if scale < 1e-9:
+            continue
+        e = float((named[k].grad.detach().cpu().double() - g.double()).abs().max()) / scale
+        n += 1
+        if e > worst:
+            worst, worst_k = e, k
+    errs = dict(mel=maxdiff(mel_p, mel_r), lin=maxdiff(lin_p, lin_r), align=maxdiff(align, al_r),
+                loss=abs(float(loss.detach()) - float(loss_r.detach())), loss_ref=float(loss_r.detach()),
+                grad_norm=gn, grad_norm_ref=gn_ref, worst_grad_relerr=worst, n_grads=n)
+    report('c2_train_step', worst_grad=worst_k, **errs)
+    assert errs['mel'] < 1e-3 and errs['lin'] < 1e-3 and errs['align'] < 1e-4
+    assert errs['loss'] < 1e-5 * max(1.0, abs(errs['loss_ref']))
+    assert abs(gn - gn_ref) < 1e-3 * gn_ref
+    assert n >= 95 and worst < 2e-3, (worst_k, worst)      # fp32 BPTT over 86 steps on both sides, different summation orders

@@ -122,3 +122,17 @@ def test_asr_oracle_against_reference(name):
         import json
         for k, v in zip(json.loads(bytes(A['post_keys']).decode()), A['post']):
             assert (stats[k] - v).abs().max() < 1e-6, k
+
+
+def test_nn_module_baseline_matches_reference_recording():
+    """oracle/nn_baseline.py (the cpu_baseline of bench.py: the decode loop assembled from stock nn.LSTMCell / nn.Linear /
+    nn.Conv1d) reproduces what the real reference produced (free-running inference, no dropout)"""
+    from oracle import nn_baseline as NB
+    W, A, meta = load_golden('tts_tiny_infer_nodrop')
+    hp = meta['hp']
+    with torch.no_grad():
+        enc = O.encoder_forward(W, A['txt_embed'])
+        mel, align, stop = NB.NNDecoder(W, hp)(enc, meta['teacher'], A['spkr_embed'])
+    assert (mel - A['mel']).abs().max() < 2e-5
+    assert (align - A['align']).abs().max() < 1e-5
+    assert (stop - A['stop']).abs().max() < 2e-5

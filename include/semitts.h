@@ -127,21 +127,24 @@ int st_untile_rows(const st_t16_view* src, float* dst, int ld, int B, int K, voi
  * state goes to up to two T16 destinations; optionally also the AdaIN-adapted hidden state
  * hadapt = ada_std * (h_out - ada_mean)  (ada_* natural (B,H)).
  * ref: as st_lstm_cell_fwd, AdaIN src/module.py:268-269 */
-int st_lstm_cell_packed_fwd(const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K,
-                            const float* b_ih, const float* b_hh, const float* pre, int ldpre,
+int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
+                            const float* b_ih, const float* b_hh,
                             const float* c_prev, int ldc_prev, const float* mask,
                             const st_t16_view* h_dst0, const st_t16_view* h_dst1,
                             float* c_out, int ldc, float* gates_out,
                             const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
+                            const float* pq_w_fold, float* pq_slab, int pq_A,
                             int B, int H, void* stream);
-/* (w_kb_stride, w_kb0): reduce only over the k-blocks [w_kb0, w_kb0 + ceil(K/16)) of a packed matrix
- * that has w_kb_stride k-blocks per row tile (0, 0 = the whole matrix).  Together with
- * st_lstm_gates_partial_packed_fwd this splits an LSTM cell into an early part (inputs that are
- * already known: recurrent state, previous context) and a late part (the input still being computed),
- * so the early part streams its weights on a second HIP stream off the critical path. */
-int st_lstm_gates_partial_packed_fwd(const float* packed_w, int w_kb_stride, int w_kb0,
-                                     const st_t16_view* x, int K, float* pre_out, int ldpre,
-                                     int B, int H, void* stream);
+/* Optional (pq_slab != NULL): the attention's query projection (`self.query_layer(query)`, src/module.py:380) folded into this
+ * launch.  Every workgroup of the 2-D tiled cell holds 8 hidden units of the new h for its batch rows and emits the rank-8
+ * partial product W_q[:, units] h[units] (exact-fp32 MFMA) into slab g = units / 8 of pq_slab, laid out
+ * (H/8 slabs, ceil(B/16)*16 rows, pq_A) floats; st_attn_fin_t16_fwd adds the slabs in a fixed order.  pq_w_fold = W_q (pq_A, H)
+ * in the fold layout (st_pack_fold_weight).  Shapes: st_lstm_pq_fold_supported (B in 17..32 or 49..64, H % 8 == 0,
+ * pq_A % 16 == 0, pq_A <= 256). */
+int st_lstm_pq_fold_supported(int B, int H, int A);
+size_t st_fold_weight_floats(int K);                       /* floats of the fold layout of an (N <= 256, K) weight   */
+size_t st_pq_slab_floats(int B, int H, int A);             /* floats of pq_slab                                      */
+int st_pack_fold_weight(const float* w, int ldw, int N, int K, float* out, void* stream);
 /* st_skinny_linear_fwd on packed operands; output natural (y) and/or T16 (y_dst).
  * Optional third row range [n_split2, N): v = act2(v) * mask2(b, n - n_split2) -> y3_dst column
  * n - n_split2 (used to emit prenet layer 1 of the next step from the same launch as proj/gate). */
@@ -151,22 +154,6 @@ int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_view* x, int
                                 int n_split, float* y2, int ldy2, int rep,
                                 int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                 int B, int N, void* stream);
-/* Heterogeneous launch: the same linear plus, on the compute units it leaves idle, a partial LSTM gate sum
- * (st_lstm_gates_partial_packed_fwd) whose inputs are already known -- the "early" part of the NEXT LSTM cell of
- * the decode step streams its weights inside the launch of a small latency-bound linear (no second stream). */
-typedef struct st_side_partial {
-    const float* packed_w; int w_kb_stride; int w_kb0;   /* k-block range of the packed LSTM matrix        */
-    const st_t16_view* x; int K;                         /* activations of that range (K = 16 * k-blocks)  */
-    float* pre_out; int ldpre; int H;                    /* (B, 4H) partial pre-activations out            */
-    const float* pre_in;                                 /* optional running sum (B, ldpre) added to the partial: a cell's
-                                                          * early inputs can be reduced over several launches (may alias pre_out) */
-} st_side_partial;
-int st_skinny_linear_packed_side_fwd(const float* packed_w, const st_t16_view* x, int K,
-                                const float* bias, int act, const float* mask, int ldmask,
-                                float* y, int ldy, const st_t16_view* y_dst,
-                                int n_split, float* y2, int ldy2, int rep,
-                                int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
-                                int B, int N, const st_side_partial* side, void* stream);
 
 /* ------------------------------------------------------------------ location-sensitive attention
  * One decode step for the whole batch, one workgroup per utterance.
@@ -205,7 +192,10 @@ int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wprev, const fl
 int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
                         float* w_out, int ld_wout, float* w_cum_out, const float* v,
                         const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx, int parts,
+                        const float* pq_slab, int pq_nslab, int pq_rows,
                         int B, int L, int A, int E, int F, int K, void* stream);
+/* (pq_slab != NULL: the processed query is the sum of pq_nslab slabs of (pq_rows, A) floats written by
+ *  st_lstm_cell_packed_fwd; pq may then be NULL) */
 /* (parts = workgroups per utterance of the fin part: each takes E/parts context dims and repeats the energies + softmax;
  *  1, 2, 4 or 8 with E % (4*parts) == 0) */
 /* st_skinny_linear_packed_fwd plus, as extra workgroups of the same launch (one per utterance), st_attn_pre_fwd for the NEXT
@@ -224,23 +214,6 @@ int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view
                                         int n_split, float* y2, int ldy2, int rep,
                                         int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                         int B, int N, const st_attn_pre_job* pre, void* stream);
-/* "Distributed side jobs" of the decode step (B = 17..32): the same linear with a partial LSTM gate sum (`side`, may be NULL)
- * AND / OR the attention pre part (`pre`, may be NULL) as extra workgroups of one launch, and the LSTM cell launch with such a
- * side job.  Each LSTM cell's early inputs (known before the cell's turn) are reduced in the shadow of the small latency-bound
- * launches, chained through side->pre_in; the cell launch itself only reduces its late input and adds the running sum (`pre`). */
-int st_skinny_linear_packed_multi_fwd(const float* packed_w, const st_t16_view* x, int K,
-                                      const float* bias, int act, const float* mask, int ldmask,
-                                      float* y, int ldy, const st_t16_view* y_dst,
-                                      int n_split, float* y2, int ldy2, int rep,
-                                      int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
-                                      int B, int N, const st_side_partial* side, const st_attn_pre_job* pre, void* stream);
-int st_lstm_cell_packed_side_fwd(const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K,
-                                 const float* b_ih, const float* b_hh, const float* pre, int ldpre,
-                                 const float* c_prev, int ldc_prev, const float* mask,
-                                 const st_t16_view* h_dst0, const st_t16_view* h_dst1,
-                                 float* c_out, int ldc, float* gates_out,
-                                 const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
-                                 int B, int H, const st_side_partial* side, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
  * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) * stride + tap - pad, ci) * W(n, ci, tap) )
@@ -479,9 +452,8 @@ typedef struct st_decoder_io {
     float* pre1_t16;          /* T16 (B,P) scratch (prenet layer-1 output), zero-filled */
     float* mel_t16;           /* T16 (B, r*n_mels) scratch (own output as the prenet input), zero-filled */
     float* zero_row;          /* (B, max(L,1)) zeros (w_prev of step 0) -- zeroed by the callee */
-    /* two-stream overlap: (B, 4Q) and (B, 4D) scratch for the early partial gate sums; overlap != 0
-     * runs the early part of both LSTM cells on the library's auxiliary stream */
-    float* preq_buf; float* pred_buf; int overlap;
+    float* pq_slab;           /* st_pq_slab_floats(B, Q, A) floats or NULL: fold the query projection into the query LSTM launch
+                               * (used when st_lstm_pq_fold_supported(B, Q, A), the attention is split and defer_proj == 0) */
     float* gates_q_tape;      /* (steps, B, 4, Q) or NULL (training) */
     float* gates_d_tape;      /* (steps, B, 4, D) or NULL */
     float* attn_s_buf;        /* (B,L,A) or NULL: split the attention step -- its location conv + W_l part for step t+1 runs inside

@@ -52,7 +52,7 @@ class StDecoderIO(C.Structure):
                 ('xq_tape', C.c_void_p), ('xd_tape', C.c_void_p), ('xo_tape', C.c_void_p),
                 ('cq_tape', C.c_void_p), ('cd_tape', C.c_void_p), ('wcum_tape', C.c_void_p),
                 ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
-                ('zero_row', C.c_void_p), ('preq_buf', C.c_void_p), ('pred_buf', C.c_void_p), ('overlap', C.c_int),
+                ('zero_row', C.c_void_p), ('pq_slab', C.c_void_p),
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('attn_fin_parts', C.c_int), ('defer_proj', C.c_int),
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p)]
 
@@ -73,10 +73,6 @@ class StDecoderBwdIO(C.Structure):
                 [(n, C.c_void_p) for n in ('dY', 'dxo_rw', 'wpg_t', 'pre_w1_t', 'pre_w0_t', 'own_mask', 'xq_nat', 'pre1_nat',
                                            'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in', 'attn_s_tape')])
 
-
-class StSidePartial(C.Structure):
-    _fields_ = [('packed_w', C.c_void_p), ('w_kb_stride', C.c_int), ('w_kb0', C.c_int), ('x', C.POINTER(StT16View)),
-                ('K', C.c_int), ('pre_out', C.c_void_p), ('ldpre', C.c_int), ('H', C.c_int), ('pre_in', C.c_void_p)]
 
 
 class StAttnPreJob(C.Structure):
@@ -126,22 +122,19 @@ SIGNATURES = {
     'st_pack_weight': [C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, I, P, P],
     'st_tile_rows': [P, I, C.POINTER(StT16View), I, I, P],
     'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
-    'st_lstm_gates_partial_packed_fwd': [P, I, I, C.POINTER(StT16View), I, P, I, I, I, P],
-    'st_lstm_cell_packed_fwd': [P, I, I, C.POINTER(StT16View), I, P, P, P, I, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
-                                P, I, P, P, P, C.POINTER(StT16View), I, I, P],
+    'st_lstm_cell_packed_fwd': [P, C.POINTER(StT16View), I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
+                                P, I, P, P, P, C.POINTER(StT16View), P, P, I, I, I, P],
+    'st_lstm_pq_fold_supported': [I, I, I],
+    'st_fold_weight_floats': [I],
+    'st_pq_slab_floats': [I, I, I],
+    'st_pack_fold_weight': [P, I, I, I, P, P],
     'st_skinny_linear_packed_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                     I, I, P, I, C.POINTER(StT16View), I, I, P],
-    'st_skinny_linear_packed_side_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
-                                         I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StSidePartial), P],
     'st_attn_step_t16_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
     'st_skinny_linear_packed_attnpre_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                             I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StAttnPreJob), P],
     'st_attn_pre_fwd': [P, P, I, P, P, P, P, I, I, I, I, I, I, P],
-    'st_skinny_linear_packed_multi_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
-                                          I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StSidePartial), C.POINTER(StAttnPreJob), P],
-    'st_lstm_cell_packed_side_fwd': [P, I, I, C.POINTER(StT16View), I, P, P, P, I, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
-                                     P, I, P, P, P, C.POINTER(StT16View), I, I, C.POINTER(StSidePartial), P],
-    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, I, P],
+    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, P, I, I, I, I, I, I, I, I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],
@@ -182,7 +175,7 @@ SIGNATURES = {
     'st_mean_rows': [P, P, I, I, I, P],
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
-             'st_decoder_packed_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
+             'st_decoder_packed_floats': C.c_size_t, 'st_fold_weight_floats': C.c_size_t, 'st_pq_slab_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
              'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
 
 _lib = None

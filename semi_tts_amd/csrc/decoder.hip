@@ -18,11 +18,12 @@
 
 extern "C" size_t st_packed_weight_floats(const int* k, int nseg, int N, int lstm_H);
 extern "C" size_t st_t16_floats(int B, int K);
+extern "C" size_t st_fold_weight_floats(int K);
 
 namespace {
 
 struct PackedLayout {   // offsets (floats) of the six packed matrices inside the packed buffer
-    size_t q, pq, d, pg, p0, p1, total;
+    size_t q, pq, d, pg, p0, p1, pqf, total;
 };
 
 PackedLayout packed_layout(const st_decoder_dims* d) {
@@ -35,28 +36,12 @@ PackedLayout packed_layout(const st_decoder_dims* d) {
     { int k[2] = {d->D, d->E}; o.pg = p; p += st_packed_weight_floats(k, 2, in_dim + 1 + (d->fuse_pre0 ? d->P : 0), 0); }
     { int k[1] = {in_dim}; o.p0 = p; p += st_packed_weight_floats(k, 1, d->P, 0); }
     { int k[1] = {d->P}; o.p1 = p; p += st_packed_weight_floats(k, 1, d->P, 0); }
+    o.pqf = p; p += st_fold_weight_floats(d->Q);     // W_q in the fold layout (query projection inside the query LSTM's epilogue)
     o.total = p;
     return o;
 }
 
 inline int kb16(int k) { return (k + 15) >> 4; }
-
-// second HIP stream + fork/join events of the decode loop (created once, lazily).  The early parts of
-// the two LSTM cells (everything but the input that is still being computed) stream their weights
-// there while the critical path runs the small kernels; under stream capture the event waits become
-// graph dependencies, so a hipGraph replay keeps the same overlap.
-struct Aux { hipStream_t s; hipEvent_t fork, e1, e2, f1, f2; bool ok; };
-Aux* aux_get() {
-    static Aux a = {};
-    if (!a.ok) {
-        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        hipEvent_t* ev[5] = {&a.fork, &a.e1, &a.e2, &a.f1, &a.f2};
-        for (auto e : ev)
-            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        a.ok = true;
-    }
-    return &a;
-}
 
 struct StepViews {   // k-block geometry of the three step-input buffers
     int q_kbs, q_ctx, q_h;        // xq = [dec_in | ctx | h_q]
@@ -91,7 +76,7 @@ __global__ __launch_bounds__(256) void tile_teacher_kernel(const float* teacher_
 }
 
 int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLayout& pl, const StepViews& sv,
-               int t, bool layer1_done, void* stream, const st_side_partial* side = nullptr) {
+               int t, bool layer1_done, void* stream) {
     // dec_in_{t+1} = prenet(mel_t) for every row                ref: src/module.py:192,:197-198,:205-206
     const int in_dim = d->r * d->n_mels;
     const size_t BP = (size_t)d->B * d->P;
@@ -105,8 +90,8 @@ int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLa
                                          nullptr, 0, &pre1, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
     if (rc) return rc;
     st_t16_view next = {io->xq_tape + (size_t)(t + 1) * sv.q_floats, sv.q_kbs, 0};
-    return st_skinny_linear_packed_multi_fwd(io->packed + pl.p1, &pre1, 16 * kb16(d->P), nullptr, ST_ACT_RELU, m2, d->P,
-                                             nullptr, 0, &next, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, side, nullptr, stream);
+    return st_skinny_linear_packed_fwd(io->packed + pl.p1, &pre1, 16 * kb16(d->P), nullptr, ST_ACT_RELU, m2, d->P,
+                                       nullptr, 0, &next, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
 }
 
 }  // namespace
@@ -140,6 +125,7 @@ extern "C" int st_decoder_pack(const st_decoder_weights* w, const st_decoder_dim
         if ((rc = st_pack_weight(ws, ld, k, 1, d->P, 0, packed + pl.p0, stream))) return rc; }
     {   const float* ws[1] = {w->prenet_w1}; int ld[1] = {d->P}, k[1] = {d->P};
         if ((rc = st_pack_weight(ws, ld, k, 1, d->P, 0, packed + pl.p1, stream))) return rc; }
+    if (d->A <= 256 && d->Q % 8 == 0 && (rc = st_pack_fold_weight(w->attn_query_w, d->Q, d->A, d->Q, packed + pl.pqf, stream))) return rc;
     return 0;
 }
 
@@ -175,8 +161,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     bool pure_tf = io->teacher_pre && io->Bt == B && io->Tt > 0;
     for (int t = 0; t + 1 < steps && pure_tf; ++t) pure_tf = io->step_src[t] == (t < io->Tt ? t : io->Tt - 1);
     const bool defer = io->defer_proj != 0;
-    ST_CHECK_ARG(!defer || (pure_tf && !d->fuse_pre0 && io->overlap != 2),
-                 "st_decoder_forward: defer_proj needs pure teacher forcing (and no side jobs)");
+    ST_CHECK_ARG(!defer || (pure_tf && !d->fuse_pre0), "st_decoder_forward: defer_proj needs pure teacher forcing");
     hipStream_t st = (hipStream_t)stream;
     const PackedLayout pl = packed_layout(d);
     const StepViews sv = step_views(d);
@@ -201,38 +186,21 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     const size_t ldmel = (size_t)steps * in_dim;
     const int ldal = steps * L;
     const int Kq = 16 * sv.q_kbs, Kd = 16 * sv.d_kbs, Ko = 16 * sv.o_kbs;
-    const int kbP = sv.q_ctx, kbE = sv.d_ha;          // k-blocks of the late inputs (dec_in, ctx)
     int rc;
-    // overlap: split both LSTM cells into an early partial-gate launch on the aux stream and a late
-    // launch (late input + `pre` + cell update) on the caller's stream
-    // overlap == 1: early parts on a second stream (kept for reference: slower); overlap == 2: early parts as
-    // SIDE JOBS of the small launches of the same stream (st_skinny_linear_packed_side_fwd)
-    const bool side = io->overlap == 2 && io->preq_buf && io->pred_buf;
-    Aux* ax = io->overlap == 1 && io->preq_buf && io->pred_buf ? aux_get() : nullptr;
-    const bool aux = ax != nullptr;
-    // overlap == 3, "distributed side jobs" (free-running fused-prenet inference, B = 17..32): the early inputs of both cells are
-    // reduced as side jobs spread over FOUR launches of the step (k-block ranges chained through the running sums preq / pred):
-    //   pq launch      (+) decoder cell, adapted-h_q_t columns          proj launch   (+) decoder cell of t+1, h_d_t columns
-    //   decoder cell   (+) query cell of t+1, h_q_t columns             prenet launch (+) query cell of t+1, ctx_t columns
-    // and the attention stays split (its pre part rides in the proj launch as well).
-    bool dist = io->overlap == 3 && io->preq_buf && io->pred_buf && io->attn_s_buf && !io->defer_proj && d->fuse_pre0 && B > 16 &&
-                B <= 32;
-    for (int t = 0; dist && t + 1 < steps; ++t) dist = io->step_src[t] == -1;
-    const bool ov = aux || side || dist;    // all split the LSTM cells into early partial sums and a late launch
-    // attention split (free-running inference): the location part of step t+1 rides in the proj launch of step t
-    // Host launch of the pre part: the proj launch of the previous step when the loop has one, otherwise (deferred
-    // projection = teacher-forced training) the query-projection launch of the same step.
-    const bool split_attn = io->attn_s_buf && (!ov || dist);
-    const bool pre_in_pq = split_attn && io->defer_proj;
+    // Attention in two parts (io->attn_s_buf set by the host): the location part of step t+1 ("pre": conv + W_l + processed
+    // memory -> S) only needs the attention weights of step t, so it rides as extra workgroups of a small launch that runs
+    // anyway -- the proj launch of step t when the loop has one, otherwise (deferred projection = teacher-forced training) the
+    // query-projection launch of step t+1 itself.  The attention launch then starts from S ("fin").
+    // Measured and removed: early LSTM inputs on a second stream, as side jobs of the small launches, and as
+    // distributed side jobs over four launches of the step -- all slower than the plain chain of dependent launches.
+    const bool split_attn = io->attn_s_buf != nullptr;
+    const bool pre_in_pq = split_attn && defer;
+    // query projection folded into the query LSTM (io->pq_slab set by the host): its workgroups emit rank-8 partial products of
+    // W_q h_q from their epilogues and the attention's fin part adds the slabs -- the pq launch (1 MB, ~5 us of latency) is gone
+    const bool fold_pq = io->pq_slab && split_attn && !defer && st_lstm_pq_fold_supported(B, Q, A);
+    const int pq_rows = ((B + 15) >> 4) * 16;
     const int fp_req = io->attn_fin_parts;
     const int fin_parts = (fp_req == 2 || fp_req == 4 || fp_req == 8) && E % (4 * fp_req) == 0 ? fp_req : 1;
-    hipStream_t sb = aux ? ax->s : st;
-    if (ov) ST_HIP(hipMemsetAsync(io->preq_buf, 0, 4 * BQ * sizeof(float), st));   // step 0: ctx_{-1} = h_q_{-1} = 0
-    if (dist) ST_HIP(hipMemsetAsync(io->pred_buf, 0, 4 * BD * sizeof(float), st));  // step 0: h_d_{-1} = 0, the pq launch adds to it
-    if (aux) {
-        ST_HIP(hipEventRecord(ax->fork, st));
-        ST_HIP(hipStreamWaitEvent(sb, ax->fork, 0));
-    }
     for (int t = 0; t < steps; ++t) {
         float* xq = io->xq_tape + (size_t)t * sv.q_floats;
         float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
@@ -246,28 +214,15 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view xq_v = {xq, sv.q_kbs, 0};
         st_t16_view hq_dst = {xq_next, sv.q_kbs, sv.q_h};
         st_t16_view ha_dst = {xd, sv.d_kbs, sv.d_ha};
-        if (aux && t > 0) ST_HIP(hipStreamWaitEvent(st, ax->f2, 0));           // early part of this step is ready
-        rc = st_lstm_cell_packed_fwd(io->packed + pl.q, ov ? sv.q_kbs : 0, 0, &xq_v, ov ? 16 * kbP : Kq,
-                                     w->q_b_ih, w->q_b_hh, ov ? io->preq_buf : nullptr, 4 * Q,
+        rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, Kq, w->q_b_ih, w->q_b_hh,
                                      io->cq_tape + (size_t)t * BQ, Q, io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
                                      &hq_dst, nullptr, io->cq_tape + (size_t)(t + 1) * BQ, Q,
                                      io->gates_q_tape ? io->gates_q_tape + (size_t)t * 4 * BQ : nullptr,
-                                     io->ada_std, io->ada_mean, &ha_dst, B, Q, stream);
+                                     io->ada_std, io->ada_mean, &ha_dst,
+                                     fold_pq ? io->packed + pl.pqf : nullptr, fold_pq ? io->pq_slab : nullptr, A, B, Q, stream);
         if (rc) return rc;
-        if (aux) {  // aux stream: early part of the decoder LSTM, x = [adapted h_q_t | h_d_{t-1}]
-            ST_HIP(hipEventRecord(ax->e1, st));
-            ST_HIP(hipStreamWaitEvent(sb, ax->e1, 0));
-            st_t16_view xd_early = {xd, sv.d_kbs, kbE};
-            rc = st_lstm_gates_partial_packed_fwd(io->packed + pl.d, sv.d_kbs, kbE, &xd_early, 16 * (sv.d_kbs - kbE),
-                                                  io->pred_buf, 4 * D, B, D, (void*)sb);
-            if (rc) return rc;
-            ST_HIP(hipEventRecord(ax->f1, sb));
-        }
 
         // 2. processed query                                             ref: :380
-        //    side job: early part of the decoder LSTM, x = [adapted h_q_t | h_d_{t-1}] (both known now)
-        st_t16_view xd_early_v = {xd, sv.d_kbs, kbE};
-        st_side_partial sd = {io->packed + pl.d, sv.d_kbs, kbE, &xd_early_v, 16 * (sv.d_kbs - kbE), io->pred_buf, 4 * D, D};
         if (pre_in_pq && t > 0) {   // attention pre part of THIS step rides along (needs only the weights of step t-1)
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)(t - 1) * L, ldal, io->wcum_tape + (size_t)t * BL,
                                    w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)t * io->attn_s_step_floats, L, A, d->F,
@@ -276,27 +231,21 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                                      io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
                                                      &job, stream);
-        } else if (dist) {     // side job: decoder cell, adapted-h_q_t columns, added to the running sum (h_d_{t-1} columns)
-            st_t16_view xd_ha_v = {xd, sv.d_kbs, sv.d_ha};
-            st_side_partial sj = {io->packed + pl.d, sv.d_kbs, sv.d_ha, &xd_ha_v, 16 * kb16(Q), io->pred_buf, 4 * D, D, io->pred_buf};
-            rc = st_skinny_linear_packed_multi_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
-                                                   io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
-                                                   &sj, nullptr, stream);
-        } else
-        rc = st_skinny_linear_packed_side_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
-                                              io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
-                                              side ? &sd : nullptr, stream);
+        } else if (!fold_pq)
+            rc = st_skinny_linear_packed_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
+                                             io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A, stream);
         if (rc) return rc;
 
         // 3. attention + state update                                    ref: :256-264, :371-407
         //    ctx_t -> xq_{t+1}[ctx part], xd_t[ctx part], xo_t[ctx part]
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
-        if (split_attn)     // S of this step was written inside the previous proj launch (step 0: no history yet, S = pm)
-            rc = st_attn_fin_t16_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats, io->memory,
-                                     io->wcum_tape + (size_t)t * BL,
+        if (split_attn)     // S of this step was written by the pre part (step 0: no history yet, S = pm)
+            rc = st_attn_fin_t16_fwd(fold_pq ? nullptr : io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats,
+                                     io->memory, io->wcum_tape + (size_t)t * BL,
                                      io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL, w->attn_v,
-                                     ctx_dst, 3, nullptr, 0, fin_parts, B, L, A, E, d->F, d->K, stream);
+                                     ctx_dst, 3, nullptr, 0, fin_parts, fold_pq ? io->pq_slab : nullptr, Q / 8, pq_rows,
+                                     B, L, A, E, d->F, d->K, stream);
         else
             rc = st_attn_step_t16_fwd(io->pq_buf, io->pm, io->memory, w_prev, t == 0 ? L : ldal,
                                       io->wcum_tape + (size_t)t * BL, io->align_out + (size_t)t * L, ldal,
@@ -305,30 +254,15 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                       B, L, A, E, d->F, d->K, stream);
         if (rc) return rc;
 
-        if (aux && t + 1 < steps) {  // aux stream: early part of the NEXT query LSTM, x = [ctx_t | h_q_t]
-            ST_HIP(hipEventRecord(ax->e2, st));
-            ST_HIP(hipStreamWaitEvent(sb, ax->e2, 0));
-            st_t16_view xq_early = {xq_next, sv.q_kbs, kbP};
-            rc = st_lstm_gates_partial_packed_fwd(io->packed + pl.q, sv.q_kbs, kbP, &xq_early, 16 * (sv.q_kbs - kbP),
-                                                  io->preq_buf, 4 * Q, B, Q, (void*)sb);
-            if (rc) return rc;
-            ST_HIP(hipEventRecord(ax->f2, sb));
-        }
-
         // 4. decoder LSTM: h_d_t -> xd_{t+1}[h part], xo_t[h part]        ref: :275-280
         st_t16_view xd_v = {xd, sv.d_kbs, 0};
         st_t16_view hd_dst0 = {xd_next, sv.d_kbs, sv.d_h};
         st_t16_view hd_dst1 = {xo, sv.o_kbs, 0};
-        if (aux) ST_HIP(hipStreamWaitEvent(st, ax->f1, 0));
-        //    (distributed side jobs: + query cell of t+1, h_q_t columns -> preq)
-        st_t16_view xq_h_v = {xq_next, sv.q_kbs, sv.q_h};
-        st_side_partial sj_qh = {io->packed + pl.q, sv.q_kbs, sv.q_h, &xq_h_v, 16 * kb16(Q), io->preq_buf, 4 * Q, Q, nullptr};
-        rc = st_lstm_cell_packed_side_fwd(io->packed + pl.d, ov ? sv.d_kbs : 0, 0, &xd_v, ov ? 16 * kbE : Kd,
-                                          w->d_b_ih, w->d_b_hh, ov ? io->pred_buf : nullptr, 4 * D,
-                                          io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
-                                          &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
-                                          io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
-                                          nullptr, nullptr, nullptr, B, D, dist && t + 1 < steps ? &sj_qh : nullptr, stream);
+        rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, Kd, w->d_b_ih, w->d_b_hh,
+                                     io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
+                                     &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
+                                     io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, D, stream);
         if (rc) return rc;
 
         // 5. mel frames + stop logit (+ prenet layer 1 of the next input when fused)   ref: :282-287
@@ -337,39 +271,17 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view pre1_dst = {io->pre1_t16 + (size_t)t * io->pre1_step_floats, kb16(P), 0};
         const bool fuse = d->fuse_pre0 != 0;
         if (defer) continue;         // mel / stop of all steps come from one GEMM over the xo tape (caller)
-        //    side job: early part of the NEXT query LSTM, x = [ctx_t | h_q_t] (both known now)
-        st_t16_view xq_early_v = {xq_next, sv.q_kbs, kbP};
-        st_side_partial sq = {io->packed + pl.q, sv.q_kbs, kbP, &xq_early_v, 16 * (sv.q_kbs - kbP), io->preq_buf, 4 * Q, Q};
-        if (dist && t + 1 < steps) {   // + attention pre part of t+1 + decoder cell of t+1, h_d_t columns -> pred
-            st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
-                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)(t + 1) * io->attn_s_step_floats, L, A, d->F, d->K,
-                                   io->attn_pre_parts, io->attn_loc_tape ? io->attn_loc_tape + (size_t)(t + 1) * BL * d->F : nullptr};
-            st_t16_view xd_h_v = {xd_next, sv.d_kbs, sv.d_h};
-            st_side_partial sj = {io->packed + pl.d, sv.d_kbs, sv.d_h, &xd_h_v, 16 * kb16(D), io->pred_buf, 4 * D, D, nullptr};
-            rc = st_skinny_linear_packed_multi_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
-                                                   io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
-                                                   io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
-                                                   fuse ? in_dim + 1 : 0, ST_ACT_RELU,
-                                                   io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
-                                                   fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0), &sj, &job, stream);
-        } else if (split_attn && !pre_in_pq && t + 1 < steps) {
-            st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
-                                   w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)(t + 1) * io->attn_s_step_floats, L, A, d->F, d->K,
-                                   io->attn_pre_parts, io->attn_loc_tape ? io->attn_loc_tape + (size_t)(t + 1) * BL * d->F : nullptr};
-            rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
-                                                     io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
-                                                     io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
-                                                     fuse ? in_dim + 1 : 0, ST_ACT_RELU,
-                                                     io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
-                                                     fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0), &job, stream);
-        } else
-        rc = st_skinny_linear_packed_side_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
-                                              io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
-                                              io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
-                                              fuse ? in_dim + 1 : 0, ST_ACT_RELU,
-                                              io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
-                                              fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0),
-                                              side && t + 1 < steps ? &sq : nullptr, stream);
+        st_attn_pre_job job = {io->pm, io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL,
+                               w->attn_loc_conv_w, w->attn_loc_lin_w,
+                               split_attn ? io->attn_s_buf + (size_t)(t + 1) * io->attn_s_step_floats : nullptr, L, A, d->F, d->K,
+                               io->attn_pre_parts, io->attn_loc_tape ? io->attn_loc_tape + (size_t)(t + 1) * BL * d->F : nullptr};
+        rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
+                                                 io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
+                                                 io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
+                                                 fuse ? in_dim + 1 : 0, ST_ACT_RELU,
+                                                 io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
+                                                 fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0),
+                                                 split_attn && t + 1 < steps ? &job : nullptr, stream);
         if (rc) return rc;
 
         // 6. next decoder input -> xq_{t+1}[dec_in part]                 ref: :190-206
@@ -377,10 +289,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             const int src = io->step_src[t];
             st_t16_view next = {xq_next, sv.q_kbs, 0};
             if (src == -1 || io->Bt < B) {   // rows without a teacher feed their own output back
-                //    (distributed side jobs: + query cell of t+1, ctx_t columns added to preq)
-                st_t16_view xq_ctx_v = {xq_next, sv.q_kbs, sv.q_ctx};
-                st_side_partial sj = {io->packed + pl.q, sv.q_kbs, sv.q_ctx, &xq_ctx_v, 16 * kb16(E), io->preq_buf, 4 * Q, Q, io->preq_buf};
-                rc = prenet_own(d, io, pl, sv, t, fuse, stream, dist ? &sj : nullptr);
+                rc = prenet_own(d, io, pl, sv, t, fuse, stream);
                 if (rc) return rc;
             }
             if (pure_tf) rc = 0;             // tiled for all steps before the loop
@@ -389,7 +298,5 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             if (rc) return rc;
         }
     }
-    // the aux stream has nothing pending that the caller's stream has not already waited for: its last
-    // launch (the early decoder-LSTM part of the last step) was joined by the f1 wait above
     return 0;
 }

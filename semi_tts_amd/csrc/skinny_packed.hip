@@ -91,6 +91,20 @@ __global__ __launch_bounds__(256) void untile_rows_kernel(const float* src, int 
     }
 }
 
+// Fold layout of a small linear's weight w (N <= 256, K) for the partial product in the LSTM epilogue (pk_lstm_rt2_kernel):
+// [K/8 groups of 8 input columns][8 waves][64 lanes][4 floats], float c of lane l of wave w = w[a][u] with
+// a = 16 * (w + 8 * (c >> 1)) + (l & 15), u = 8 * group + 4 * (c & 1) + (l >> 4)  -- the MFMA A fragments (16 outputs x 4 inputs)
+// of output tiles w and w + 8 for the two k-steps of the group; each wave reads ONE 16-byte value per lane.
+__global__ __launch_bounds__(256) void pack_fold_kernel(const float* w, int ldw, int N, int K, float* out) {
+    const size_t total = (size_t)(K >> 3) * 2048;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx & 3), lane = (int)((idx >> 2) & 63), wave = (int)((idx >> 8) & 7);
+        const int gp = (int)(idx >> 11);
+        const int a = 16 * (wave + 8 * (c >> 1)) + (lane & 15), u = 8 * gp + 4 * (c & 1) + (lane >> 4);
+        out[idx] = (a < N && u < K) ? w[(size_t)a * ldw + u] : 0.0f;
+    }
+}
+
 // element offset (in floats) of (b, k) in a T16 buffer with KB k-blocks
 __device__ __forceinline__ size_t t16_off(int b, int k, int KB) {
     return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
@@ -107,11 +121,14 @@ struct PkArgs {
     int KB;                              // k-blocks to reduce over
     int B, N, H;
     // LSTM epilogue
-    const float* b_ih; const float* b_hh; const float* pre; int ldpre;
+    const float* b_ih; const float* b_hh;
     const float* c_prev; int ldc_prev; const float* mask;
     float* c_out; int ldc; float* gates_out;
     PkOut h_dst[2];                                                        // tiled destinations of the new h
     const float* ada_std; const float* ada_mean; PkOut ha_dst;             // optional AdaIN of the new h
+    // optional rank-(4*RT) partial of a linear on the NEW h (the attention's query projection folded into the query LSTM):
+    // pq_w = that linear's weight in the fold layout (st_pack_fold_weight), pq_slab (tile pairs, padded rows, pq_A) out
+    const float* pq_w; float* pq_slab; int pq_A; int pq_rows;
     // linear epilogue
     const float* bias; int act; const float* lmask; int ldmask;
     float* y; int ldy; PkOut y_dst; int n_split; float* y2; int ldy2; int rep;
@@ -167,7 +184,7 @@ __device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[N
     }
 }
 
-// MODE 0: LSTM cell, MODE 1: linear, MODE 2: partial LSTM gate sums (no bias, no cell update)
+// MODE 0: LSTM cell, MODE 1: linear
 template <int MODE, int NB, int KW, int TRIP>
 __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const int by, f32x4* red) {
     // the wave index is wave-uniform: telling the compiler (readfirstlane) keeps every k-block address in scalar registers,
@@ -182,7 +199,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
 #define PK_TOUCH(x) asm volatile("" :: "s"(x))
     PK_TOUCH(a.w); PK_TOUCH(a.x); PK_TOUCH(a.w_kbs); PK_TOUCH(a.x_kbs); PK_TOUCH(a.KB); PK_TOUCH(a.B); PK_TOUCH(a.N); PK_TOUCH(a.H);
     if (MODE == 0) {
-        PK_TOUCH(a.b_ih); PK_TOUCH(a.b_hh); PK_TOUCH(a.pre); PK_TOUCH(a.ldpre); PK_TOUCH(a.c_prev); PK_TOUCH(a.ldc_prev);
+        PK_TOUCH(a.b_ih); PK_TOUCH(a.b_hh); PK_TOUCH(a.c_prev); PK_TOUCH(a.ldc_prev);
         PK_TOUCH(a.mask); PK_TOUCH(a.ada_std); PK_TOUCH(a.ada_mean); PK_TOUCH(a.ha_dst.base);
     }
     if (MODE == 1) {
@@ -226,30 +243,22 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     // IMPORTANT: every load lands in its own register and nothing is combined before the K loop.  An accumulation
     // like `e += p[i]` inside `if (p)` forces the wave to WAIT for that load right there (the add sits in the branch),
     // which serialised ~12 memory round trips (2-4 us) in front of the weight stream of waves 0..NB-1.
-    float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f}, e_pr[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f};
     float e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
     float l_bias[4] = {0.f, 0.f, 0.f, 0.f}, l_m1[4] = {1.f, 1.f, 1.f, 1.f}, l_m2[4] = {1.f, 1.f, 1.f, 1.f};
     // Branch-free: absent operands are read from a valid dummy address (the weight buffer) and replaced by their neutral
     // value when they are consumed, so the block is a straight line of independent loads.
     const float* dummy = reinterpret_cast<const float*>(a.w);
     auto epi_prefetch = [&]() __attribute__((always_inline)) {
-    if (MODE == 2 && e_on) {       // partial sums chained over several launches: the running sum comes in through a.pre
-        const int u = tile * 4 + (lane >> 4);
-        const float* ppr = a.pre ? a.pre + (size_t)eb * a.ldpre + u : dummy;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e_pr[r] = ppr[a.pre ? r * a.H : 0];
-    }
     if (MODE == 0 && e_on) {
         const int u = tile * 4 + (lane >> 4);
         const float* pbi = a.b_ih ? a.b_ih + u : dummy;
         const float* pbh = a.b_hh ? a.b_hh + u : dummy;
-        const float* ppr = a.pre ? a.pre + (size_t)eb * a.ldpre + u : dummy;
         const int sH = a.H;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             e_bi[r] = pbi[a.b_ih ? r * sH : 0];
             e_bh[r] = pbh[a.b_hh ? r * sH : 0];
-            e_pr[r] = ppr[a.pre ? r * sH : 0];
         }
         e_c = (a.c_prev ? a.c_prev + (size_t)eb * a.ldc_prev + u : dummy)[0];
         e_m = (a.mask ? a.mask + (size_t)eb * a.H + u : dummy)[0];
@@ -306,17 +315,12 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
     const int b = (bt_base + btl) * 16 + (lane & 15);
     if (b >= a.B || bt_base + btl < bt0) return;    // aliased tiles: somebody else owns these rows
 
-    if (MODE == 2) {
-        const int u = tile * 4 + (lane >> 4);
-        float* gp = a.gates_out + (size_t)b * a.ldpre + u;      // (B, 4H) pre-activation partials
-        if (a.pre) { s[0] += e_pr[0]; s[1] += e_pr[1]; s[2] += e_pr[2]; s[3] += e_pr[3]; }
-        gp[0] = s[0]; gp[a.H] = s[1]; gp[2 * a.H] = s[2]; gp[3 * a.H] = s[3];
-    } else if (MODE == 0) {
+    if (MODE == 0) {
         const int H = a.H;
         const int u = tile * 4 + (lane >> 4);
         float e_b[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e_b[r] = ((a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f)) + (a.pre ? e_pr[r] : 0.0f);
+        for (int r = 0; r < 4; ++r) e_b[r] = (a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f);
         e_c = a.c_prev ? e_c : 0.0f;
         e_m = a.mask ? e_m : 1.0f;
         const float gi = st_sigmoid_fast(s[0] + e_b[0]), gf = st_sigmoid_fast(s[1] + e_b[1]);
@@ -386,7 +390,7 @@ template <int KW, int TRIP, int NB>
 __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, const f32x4* xp, const int w_kbs, const int x_kbs, const int KB,
                                                           const int B, const int H, const PkArgs rest) {
     constexpr int RT = 2;
-    __shared__ f32x4 red[KW * RT * NB * 64];
+    __shared__ f32x4 red[KW * RT * NB * 64 + RT * NB * 16];     // partial sums of the KW waves + the new-h tile of the query-projection fold
     const PkArgs& a = rest;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile0 = blockIdx.x * RT, bt_base = blockIdx.y * NB;          // host: B in 49..64, so both batch tiles of a half exist
@@ -435,19 +439,19 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
     const int eb = (bt_base + e_bt) * 16 + (lane & 15);
     const int u = (tile0 + e_rt) * 4 + (lane >> 4);
     const bool e_on = tid < RT * NB * 64 && eb < B;
-    float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f}, e_pr[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f};
     float e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
     const float* dummy = reinterpret_cast<const float*>(wp);
+    f32x4 pq_w4 = {0.f, 0.f, 0.f, 0.f};     // fold layout: [tile pair][wave][lane][(tile w, k-step 0), (w, 1), (w + 8, 0), (w + 8, 1)]
     auto epi_prefetch = [&]() __attribute__((always_inline)) {
+        pq_w4 = *reinterpret_cast<const f32x4*>((a.pq_w ? a.pq_w + ((size_t)blockIdx.x * KW + wave) * 256 : dummy) + lane * 4);
         if (e_on) {
             const float* pbi = a.b_ih ? a.b_ih + u : dummy;
             const float* pbh = a.b_hh ? a.b_hh + u : dummy;
-            const float* ppr = a.pre ? a.pre + (size_t)eb * a.ldpre + u : dummy;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 e_bi[r] = pbi[a.b_ih ? r * H : 0];
                 e_bh[r] = pbh[a.b_hh ? r * H : 0];
-                e_pr[r] = ppr[a.pre ? r * H : 0];
             }
             e_c = (a.c_prev ? a.c_prev + (size_t)eb * a.ldc_prev + u : dummy)[0];
             e_m = (a.mask ? a.mask + (size_t)eb * H + u : dummy)[0];
@@ -473,30 +477,68 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) red[((wave * RT + rt) * NB + bt) * 64 + lane] = acc[rt][bt];
     __syncthreads();
-    if (tid >= RT * NB * 64) return;
-    f32x4 s = red[(e_rt * NB + e_bt) * 64 + lane];
+    const bool fold = a.pq_slab != nullptr;              // (wave-uniform; set by the host for the query LSTM of the decode loop)
+    float* hs = reinterpret_cast<float*>(red);           // [RT * 4 units][NB * 16 rows] new h, rows past B zero (reuses wave 0's slab slot:
+    //                                                      read by the epilogue waves before the barrier below, written after their reads)
+    if (tid < RT * NB * 64) {
+        f32x4 s = red[(e_rt * NB + e_bt) * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < KW; ++w) {
-        const f32x4 t = red[((w * RT + e_rt) * NB + e_bt) * 64 + lane];
-        s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        for (int w = 1; w < KW; ++w) {
+            const f32x4 t = red[((w * RT + e_rt) * NB + e_bt) * 64 + lane];
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        float h2 = 0.0f;
+        if (eb < B) {
+            float e_b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e_b[r] = (a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f);
+            e_c = a.c_prev ? e_c : 0.0f;
+            e_m = a.mask ? e_m : 1.0f;
+            const float gi = st_sigmoid_fast(s[0] + e_b[0]), gf = st_sigmoid_fast(s[1] + e_b[1]);
+            const float gg = st_tanh_fast(s[2] + e_b[2]), go = st_sigmoid_fast(s[3] + e_b[3]);
+            const float c2 = gf * e_c + gi * gg;
+            h2 = go * st_tanh_fast(c2) * e_m;
+            a.c_out[(size_t)eb * a.ldc + u] = c2;
+            pk_store(a.h_dst[0], eb, u, h2);
+            pk_store(a.h_dst[1], eb, u, h2);
+            if (a.ha_dst.base) pk_store(a.ha_dst, eb, u, e_s * (h2 - e_mu));
+            if (a.gates_out) {
+                float* gp = a.gates_out + (size_t)eb * 4 * H + u;
+                gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+            }
+        }
+        if (fold) {
+            // every epilogue wave has read all it needs from `red` only when ALL of them are past the reads above: the h tile
+            // therefore lives behind the partial sums (red holds KW * RT * NB * 64 float4; the tile is RT * 4 * NB * 16 floats)
+            hs = reinterpret_cast<float*>(red + KW * RT * NB * 64);
+            hs[(e_rt * 4 + (lane >> 4)) * (NB * 16) + e_bt * 16 + (lane & 15)] = h2;
+        }
     }
-    if (eb >= B) return;
-    float e_b[4];
+    if (!fold) return;
+    // ---- partial query projection of this workgroup's RT*4 hidden units (ref: Attention.forward `self.query_layer(query)`,
+    // src/module.py:380): P[a][row] = sum_j Wq[a][u0 + j] h[row][u0 + j] on the matrix cores, one 16-dim tile of `a` at a time
+    // (wave w takes tiles w and w + 8), K = RT*4 = 8 units = two 16x16x4 steps.  The attention launch adds the slabs of all
+    // workgroups in a fixed order, so the launch that used to compute W_q h_q (1 MB of weights, ~5 us of latency) is gone.
+    hs = reinterpret_cast<float*>(red + KW * RT * NB * 64);
+    st_lds_barrier();
+    {
+        const int A = a.pq_A, n_at = A >> 4;
+        const int g = lane >> 4, n = lane & 15;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) e_b[r] = ((a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f)) + (a.pre ? e_pr[r] : 0.0f);
-    e_c = a.c_prev ? e_c : 0.0f;
-    e_m = a.mask ? e_m : 1.0f;
-    const float gi = st_sigmoid_fast(s[0] + e_b[0]), gf = st_sigmoid_fast(s[1] + e_b[1]);
-    const float gg = st_tanh_fast(s[2] + e_b[2]), go = st_sigmoid_fast(s[3] + e_b[3]);
-    const float c2 = gf * e_c + gi * gg;
-    const float h2 = go * st_tanh_fast(c2) * e_m;
-    a.c_out[(size_t)eb * a.ldc + u] = c2;
-    pk_store(a.h_dst[0], eb, u, h2);
-    pk_store(a.h_dst[1], eb, u, h2);
-    if (a.ha_dst.base) pk_store(a.ha_dst, eb, u, e_s * (h2 - e_mu));
-    if (a.gates_out) {
-        float* gp = a.gates_out + (size_t)eb * 4 * H + u;
-        gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+        for (int j = 0; j < 2; ++j) {
+            const int at = wave + j * KW;
+            if (at >= n_at) break;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                f32x4 p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < RT; ++kk)
+                    p = __builtin_amdgcn_mfma_f32_16x16x4f32(pq_w4[j * 2 + kk], hs[(kk * 4 + g) * (NB * 16) + bt * 16 + n], p, 0, 0, 0);
+                // lane (g, n) holds P[a = at*16 + 4g .. 4g+3][row = n]: one 16-byte store
+                float* dst = a.pq_slab + ((size_t)blockIdx.x * a.pq_rows + (bt_base + bt) * 16 + n) * A + at * 16 + 4 * g;
+                *reinterpret_cast<f32x4*>(dst) = p;
+            }
+        }
     }
 }
 
@@ -510,17 +552,6 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const f32x4* w, const f32x4
     PkArgs a = rest;
     a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N; a.H = H;
     pk_body<MODE, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red);
-}
-
-// Heterogeneous launch: the first `tiles_a` workgroup columns run the main job `a` (a small, latency-bound linear
-// on the critical path of the decode step), the remaining ones a partial LSTM gate sum `s` whose inputs are
-// already known (MODE 2).  The side job streams its weights on the compute units the main job leaves idle,
-// inside the same launch: no second stream, no cross-stream event (measured to cost more than it saves).
-template <int MODE, int NB, int KW, int TRIP>
-__global__ __launch_bounds__(KW * 64) void pk_pair_kernel(const PkArgs a, const PkArgs s, const int tiles_a) {
-    __shared__ f32x4 red[KW * NB * 64];
-    if ((int)blockIdx.x < tiles_a) pk_body<MODE, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red);
-    else pk_body<2, NB, KW, TRIP>(s, (int)blockIdx.x - tiles_a, blockIdx.y, red);
 }
 
 // The proj (+) gate launch of decode step t with, on the compute units it leaves idle, the part of the attention of step t+1
@@ -551,67 +582,7 @@ __global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const f32x4* w, con
 #ifndef PK_TRIP_SMALL
 #define PK_TRIP_SMALL 2     // k-blocks per wave and group of the one-batch-tile linears (double buffered)
 #endif
-// General heterogeneous launch of the decode step ("distributed side jobs"): workgroups [0, n_main) run the main job (a small
-// linear, MODE 1, or the late part of an LSTM cell, MODE 0), [n_main, n_main + n_side) a partial LSTM gate sum over a k-block
-// range whose inputs are already known (MODE 2, all NBS batch tiles per workgroup), the rest the attention pre part of the next
-// step.  The 75 MB of LSTM weights then stream in the shadow of the latency-bound launches instead of in two launches of
-// their own; what stays on the critical path of an LSTM cell is its late input (256 / 512 of 1792 / 2560 columns).
-template <int MAINMODE, int NBM, int NBS, int KW, int TRIP, bool VEC, bool HAS_AT>
-__global__ __launch_bounds__(KW * 64) void pk_multi_kernel(const PkArgs a, const PkArgs s, const AtArgs t, const int tiles_a,
-                                                           const int n_main, const int n_side) {
-    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
-    __shared__ f32x4 red[KW * (NBM > NBS ? NBM : NBS) * 64];
-    const int i = blockIdx.x;
-    if (i < n_main) {
-        const int by = n_main <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
-        pk_body<MAINMODE, NBM, KW, TRIP>(a, i - by * tiles_a, by, red);
-    }
-    else if (i < n_main + n_side) pk_body<2, NBS, KW, TRIP>(s, i - n_main, 0, red);
-    else if (HAS_AT) at_body<VEC, 1>(t, i - n_main - n_side, pk_dyn_lds);
-}
-
-// main job + side job (+ attention pre part); B must be 17..32 (two batch tiles: the side job takes both per workgroup)
-template <int MAINMODE, int NBM>
-int pk_launch_multi(const PkArgs& a, int tiles, const PkArgs& sj, int side_tiles, const AtArgs* t, hipStream_t st) {
-    constexpr int KW = 8, TRIP = 2;
-    const int BT = (a.B + 15) >> 4, gy = (BT + NBM - 1) / NBM;
-    const int n_main = tiles * gy;
-    AtArgs none;
-    memset(&none, 0, sizeof(none));
-    if (!t) {
-        hipLaunchKernelGGL((pk_multi_kernel<MAINMODE, NBM, 2, KW, TRIP, true, false>), dim3(n_main + side_tiles), dim3(KW * 64), 0, st,
-                           a, sj, none, tiles, n_main, side_tiles);
-        ST_LAUNCH_CHECK();
-        return 0;
-    }
-    const AtLds o = at_layout(t->L, t->A, t->E, t->F, t->K);
-    const size_t lds = (size_t)o.total * sizeof(float);
-    ST_CHECK_ARG(lds + sizeof(f32x4) * KW * 2 * 64 <= 160 * 1024, "linear + side + attention-pre launch: L=%d needs too much LDS", t->L);
-    const bool vec = (t->A % 4 == 0) && (t->F % 4 == 0) && st_aligned16(t->pm) && st_aligned16(t->loc_lin_w) && st_aligned16(t->s_buf);
-    auto kern = vec ? pk_multi_kernel<MAINMODE, NBM, 2, KW, TRIP, true, true> : pk_multi_kernel<MAINMODE, NBM, 2, KW, TRIP, false, true>;
-    static size_t configured[2] = {0, 0};
-    if (lds > 48 * 1024 && lds > configured[vec ? 1 : 0]) {
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured[vec ? 1 : 0] = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3(n_main + side_tiles + t->B * (t->pre_parts > 1 ? t->pre_parts : 1)), dim3(KW * 64), lds, st,
-                       a, sj, *t, tiles, n_main, side_tiles);
-    ST_LAUNCH_CHECK();
-    return 0;
-}
-
-int pk_fill(PkArgs& a, const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K, const char* who);
-
-// PkArgs of a side job (partial LSTM gate sums, optionally continuing a running sum)
-int pk_side_args(PkArgs& sj, const st_side_partial* side, int B, const char* who) {
-    ST_CHECK_ARG(side->H > 0 && side->H % 4 == 0 && side->pre_out && side->ldpre >= 4 * side->H && side->x, "%s: bad side job", who);
-    memset(&sj, 0, sizeof(sj));
-    int rc = pk_fill(sj, side->packed_w, side->w_kb_stride, side->w_kb0, side->x, side->K, who);
-    if (rc) return rc;
-    sj.B = B; sj.N = 4 * side->H; sj.H = side->H;
-    sj.gates_out = side->pre_out; sj.ldpre = side->ldpre; sj.pre = side->pre_in;
-    return 0;
-}
+int pk_fill(PkArgs& a, const float* packed_w, const st_t16_view* x, int K, const char* who);
 
 template <int NB>
 int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st) {
@@ -634,30 +605,30 @@ int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t s
 }
 
 template <int MODE, int NB>
-int pk_launch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = nullptr, int side_tiles = 0) {
+int pk_launch(const PkArgs& a, int tiles, hipStream_t st) {
     // 8 waves x 2 k-blocks in flight, double buffered.  Measured alternatives on MI355X (us per launch in
     // the decode graph, pq / proj / prenet): 16 waves x 6 single-buffered 7.2 / 8.8 / 7.3; 8 waves x 6
     // single-buffered 8.6 / 10.6 / 5.7; this configuration 6.1 / 8.8 / 4.8.
     constexpr int KW = 8, TRIP = (MODE == 1 && NB == 1) ? PK_TRIP_SMALL : 2;
     const int BT = (a.B + 15) >> 4;
-    if (side) {
-        dim3 grid(tiles + side_tiles, (BT + NB - 1) / NB);
-        hipLaunchKernelGGL((pk_pair_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a, *side, tiles);
-    } else {
-        dim3 grid(tiles, (BT + NB - 1) / NB);
-        hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, a.H, a);
-    }
+    dim3 grid(tiles, (BT + NB - 1) / NB);
+    hipLaunchKernelGGL((pk_kernel<MODE, NB, KW, TRIP>), grid, dim3(KW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, a.H, a);
     ST_LAUNCH_CHECK();
     return 0;
 }
 
+// shapes the 2-D tiled LSTM cell takes (two row tiles x half the batch tiles per workgroup)
+inline bool pk_rt2_shape(int B, int tiles) {
+    const int BT = (B + 15) >> 4;
+    return (tiles & 1) == 0 && (BT == 2 || BT == 4) && B > 16 * (BT - 1);
+}
+
 template <int MODE>
-int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side = nullptr, int side_tiles = 0) {
+int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st) {
     const int BT = (a.B + 15) >> 4;
     // LSTM cell with an even number of batch tiles (B = 17..32 or 49..64): 2-D tiling, two row tiles x half the batch tiles per
     // workgroup (pk_lstm_rt2_kernel).  Measured: B = 32 9.54 -> 9.05 us per cell (3.16 -> 3.09 ms per C2 pass), B = 64 15.0 -> 13.7 us.
-    static const bool rt2 = !(getenv("ST_PK_RT2") && atoi(getenv("ST_PK_RT2")) == 0);
-    if (MODE == 0 && !side && rt2 && (tiles & 1) == 0 && (BT == 2 || BT == 4) && a.B > 16 * (BT - 1)) {
+    if (MODE == 0 && pk_rt2_shape(a.B, tiles)) {
         if (BT == 2)
             hipLaunchKernelGGL((pk_lstm_rt2_kernel<8, 2, 1>), dim3(tiles / 2, 2), dim3(8 * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
         else
@@ -665,15 +636,14 @@ int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st, const PkArgs* side =
         ST_LAUNCH_CHECK();
         return 0;
     }
-#ifndef PK_NO_BATCH_SPLIT
+    ST_CHECK_ARG(!(MODE == 0 && a.pq_slab), "st_lstm_cell_packed_fwd: the query-projection fold needs the 2-D tiled shape (see st_lstm_pq_fold_supported)");
     // a small linear (few row tiles) is bound by what ONE compute unit can pull in (its weight tile + the whole activation
     // operand): one batch tile per workgroup halves the activation bytes per workgroup and doubles the workgroups
-    if (MODE == 1 && !side && tiles <= 128 && BT > 1) return pk_launch<MODE, 1>(a, tiles, st, side, side_tiles);
-#endif
-    if (BT == 1) return pk_launch<MODE, 1>(a, tiles, st, side, side_tiles);
-    if (BT == 2) return pk_launch<MODE, 2>(a, tiles, st, side, side_tiles);
-    if (BT == 3) return pk_launch<MODE, 3>(a, tiles, st, side, side_tiles);
-    return pk_launch<MODE, 4>(a, tiles, st, side, side_tiles);
+    if (MODE == 1 && tiles <= 128 && BT > 1) return pk_launch<MODE, 1>(a, tiles, st);
+    if (BT == 1) return pk_launch<MODE, 1>(a, tiles, st);
+    if (BT == 2) return pk_launch<MODE, 2>(a, tiles, st);
+    if (BT == 3) return pk_launch<MODE, 3>(a, tiles, st);
+    return pk_launch<MODE, 4>(a, tiles, st);
 }
 
 PkOut pk_out(const st_t16_view* v) {
@@ -682,14 +652,13 @@ PkOut pk_out(const st_t16_view* v) {
     return o;
 }
 
-int pk_fill(PkArgs& a, const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K, const char* who) {
+int pk_fill(PkArgs& a, const float* packed_w, const st_t16_view* x, int K, const char* who) {
     ST_CHECK_ARG(packed_w && x && x->base && K > 0, "%s: bad packed operands", who);
     ST_CHECK_ARG(st_aligned16(packed_w) && st_aligned16(x->base), "%s: operands must be 16-byte aligned", who);
     ST_CHECK_ARG(x->kb0 >= 0 && x->kb0 + pk_kb(K) <= x->kb_stride, "%s: k-block range [%d,%d) outside the T16 buffer (%d)",
                  who, x->kb0, x->kb0 + pk_kb(K), x->kb_stride);
-    ST_CHECK_ARG(w_kb_stride == 0 || (w_kb0 >= 0 && w_kb0 + pk_kb(K) <= w_kb_stride), "%s: weight k-block range", who);
-    a.w = reinterpret_cast<const f32x4*>(packed_w) + (size_t)(w_kb_stride ? w_kb0 : 0) * 64;
-    a.w_kbs = w_kb_stride ? w_kb_stride : pk_kb(K);
+    a.w = reinterpret_cast<const f32x4*>(packed_w);
+    a.w_kbs = pk_kb(K);
     a.x = reinterpret_cast<const f32x4*>(x->base) + (size_t)x->kb0 * 64;
     a.x_kbs = x->kb_stride;
     a.KB = pk_kb(K);
@@ -757,57 +726,48 @@ extern "C" int st_untile_rows(const st_t16_view* src, float* dst, int ld, int B,
     return 0;
 }
 
-extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K,
-                                       const float* b_ih, const float* b_hh, const float* pre, int ldpre,
+extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
+                                       const float* b_ih, const float* b_hh,
                                        const float* c_prev, int ldc_prev, const float* mask,
                                        const st_t16_view* h_dst0, const st_t16_view* h_dst1,
                                        float* c_out, int ldc, float* gates_out,
                                        const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
+                                       const float* pq_w_fold, float* pq_slab, int pq_A,
                                        int B, int H, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && c_out && h_dst0 && h_dst0->base, "st_lstm_cell_packed_fwd: bad arguments");
+    ST_CHECK_ARG(!pq_slab || (pq_w_fold && st_lstm_pq_fold_supported(B, H, pq_A) && st_aligned16(pq_w_fold) && st_aligned16(pq_slab)),
+                 "st_lstm_cell_packed_fwd: query-projection fold not available for B=%d H=%d A=%d", B, H, pq_A);
     ST_CHECK_ARG(!(hadapt_dst && hadapt_dst->base) || (ada_std && ada_mean), "st_lstm_cell_packed_fwd: AdaIN pointers");
     PkArgs a;
     memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, w_kb_stride, w_kb0, x, K, "st_lstm_cell_packed_fwd");
+    int rc = pk_fill(a, packed_w, x, K, "st_lstm_cell_packed_fwd");
     if (rc) return rc;
     a.B = B; a.N = 4 * H; a.H = H;
-    a.b_ih = b_ih; a.b_hh = b_hh; a.pre = pre; a.ldpre = ldpre;
+    a.b_ih = b_ih; a.b_hh = b_hh;
     a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
     a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
     a.h_dst[0] = pk_out(h_dst0); a.h_dst[1] = pk_out(h_dst1);
     a.ada_std = ada_std; a.ada_mean = ada_mean; a.ha_dst = pk_out(hadapt_dst);
+    if (pq_slab) { a.pq_w = pq_w_fold; a.pq_slab = pq_slab; a.pq_A = pq_A; a.pq_rows = ((B + 15) >> 4) * 16; }
     return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
 }
 
-// The LSTM cell launch with a side job: partial gate sums of ANOTHER cell (or of the same cell's next step) over a k-block range
-// whose inputs are already known, as extra workgroups (distributed side jobs, see pk_multi_kernel).  B must be 17..32.
-extern "C" int st_lstm_cell_packed_side_fwd(const float* packed_w, int w_kb_stride, int w_kb0, const st_t16_view* x, int K,
-                                            const float* b_ih, const float* b_hh, const float* pre, int ldpre,
-                                            const float* c_prev, int ldc_prev, const float* mask,
-                                            const st_t16_view* h_dst0, const st_t16_view* h_dst1,
-                                            float* c_out, int ldc, float* gates_out,
-                                            const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
-                                            int B, int H, const st_side_partial* side, void* stream) {
-    if (!side || !side->packed_w)
-        return st_lstm_cell_packed_fwd(packed_w, w_kb_stride, w_kb0, x, K, b_ih, b_hh, pre, ldpre, c_prev, ldc_prev, mask, h_dst0, h_dst1,
-                                       c_out, ldc, gates_out, ada_std, ada_mean, hadapt_dst, B, H, stream);
+// ---- the attention's query projection folded into the query LSTM (see pk_lstm_rt2_kernel)
+extern "C" int st_lstm_pq_fold_supported(int B, int H, int A) {
+    return H > 0 && H % 8 == 0 && pk_rt2_shape(B, H / 4) && A > 0 && A % 16 == 0 && A <= 256;
+}
+extern "C" size_t st_fold_weight_floats(int K) { return (size_t)(K >> 3) * 2048; }
+extern "C" size_t st_pq_slab_floats(int B, int H, int A) { return (size_t)(H / 8) * (((B + 15) >> 4) * 16) * A; }
+extern "C" int st_pack_fold_weight(const float* w, int ldw, int N, int K, float* out, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(B > 16 && B <= 32, "st_lstm_cell_packed_side_fwd: side jobs need 17..32 batch rows (B=%d)", B);
-    ST_CHECK_ARG(H > 0 && H % 4 == 0 && c_out && h_dst0 && h_dst0->base, "st_lstm_cell_packed_side_fwd: bad arguments");
-    ST_CHECK_ARG(!(hadapt_dst && hadapt_dst->base) || (ada_std && ada_mean), "st_lstm_cell_packed_side_fwd: AdaIN pointers");
-    PkArgs a, sj;
-    memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, w_kb_stride, w_kb0, x, K, "st_lstm_cell_packed_side_fwd");
-    if (rc) return rc;
-    a.B = B; a.N = 4 * H; a.H = H;
-    a.b_ih = b_ih; a.b_hh = b_hh; a.pre = pre; a.ldpre = ldpre;
-    a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
-    a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
-    a.h_dst[0] = pk_out(h_dst0); a.h_dst[1] = pk_out(h_dst1);
-    a.ada_std = ada_std; a.ada_mean = ada_mean; a.ha_dst = pk_out(hadapt_dst);
-    if ((rc = pk_side_args(sj, side, B, "st_lstm_cell_packed_side_fwd(side)"))) return rc;
-    return pk_launch_multi<0, 2>(a, H / 4, sj, side->H / 4, nullptr, (hipStream_t)stream);
+    ST_CHECK_ARG(w && out && N > 0 && N <= 256 && K > 0 && K % 8 == 0 && ldw >= K, "st_pack_fold_weight: N=%d (<= 256) K=%d (multiple of 8)", N, K);
+    const size_t total = (size_t)(K >> 3) * 2048;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, out);
+    ST_LAUNCH_CHECK();
+    return 0;
 }
 
 static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
@@ -816,13 +776,13 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
                           int n_split, float* y2, int ldy2, int rep,
                           int n_split2, int act2, const float* mask2, int ldmask2,
                           const st_t16_view* y3_dst,
-                          int B, int N, const st_side_partial* side, const st_attn_pre_job* pre, void* stream, bool multi = false) {
+                          int B, int N, const st_attn_pre_job* pre, void* stream) {
     ST_CHECK_ARG(n_split2 <= 0 || (y3_dst && y3_dst->base && n_split2 >= n_split), "st_skinny_linear_packed_fwd: third range");
     ST_CHECK_ARG(B > 0 && N > 0 && (y || (y_dst && y_dst->base)), "st_skinny_linear_packed_fwd: bad arguments");
     ST_CHECK_ARG(n_split <= 0 || (y2 && rep >= 1), "st_skinny_linear_packed_fwd: n_split without y2/rep");
     PkArgs a;
     memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, 0, 0, x, K, "st_skinny_linear_packed_fwd");
+    int rc = pk_fill(a, packed_w, x, K, "st_skinny_linear_packed_fwd");
     if (rc) return rc;
     a.B = B; a.N = N; a.H = 0;
     a.bias = bias; a.act = act; a.lmask = mask; a.ldmask = ldmask;
@@ -830,35 +790,6 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
     a.n_split = n_split; a.y2 = y2; a.ldy2 = ldy2; a.rep = rep;
     a.n_split2 = n_split2; a.act2 = act2; a.mask2 = mask2; a.ldmask2 = ldmask2; a.y3_dst = pk_out(y3_dst);
     const int tiles = (N + 15) / 16;
-    if (side && side->packed_w && (multi || (pre && pre->s_buf))) {      // distributed side jobs (pk_multi_kernel)
-        ST_CHECK_ARG(B > 16 && B <= 32, "st_skinny_linear_packed_multi_fwd: side jobs need 17..32 batch rows (B=%d)", B);
-        PkArgs sj;
-        if ((rc = pk_side_args(sj, side, B, "st_skinny_linear_packed_multi_fwd(side)"))) return rc;
-        AtArgs t;
-        const bool has_at = pre && pre->s_buf;
-        if (has_at) {
-            ST_CHECK_ARG(pre->pm && pre->w_prev && pre->w_cum_prev && pre->loc_conv_w && pre->loc_lin_w && pre->L > 0 && pre->A > 0 &&
-                         pre->F > 0 && pre->K > 0 && (pre->K & 1), "st_skinny_linear_packed_multi_fwd: bad attention job");
-            memset(&t, 0, sizeof(t));
-            t.pm = pre->pm; t.w_prev = pre->w_prev; t.ld_wprev = pre->ld_wprev; t.w_cum_prev = pre->w_cum_prev;
-            t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf; t.cf_out = pre->cf_out;
-            t.B = B; t.L = pre->L; t.A = pre->A; t.E = 4; t.F = pre->F; t.K = pre->K;
-            t.pre_parts = pre->parts == 2 || pre->parts == 4 ? pre->parts : 1;
-        }
-        if (tiles <= 128) return pk_launch_multi<1, 1>(a, tiles, sj, side->H / 4, has_at ? &t : nullptr, (hipStream_t)stream);
-        return pk_launch_multi<1, 2>(a, tiles, sj, side->H / 4, has_at ? &t : nullptr, (hipStream_t)stream);
-    }
-    if (side && side->packed_w) {
-        ST_CHECK_ARG(side->H > 0 && side->H % 4 == 0 && side->pre_out && side->ldpre >= 4 * side->H && side->x,
-                     "st_skinny_linear_packed_side_fwd: bad side job");
-        PkArgs sj;
-        memset(&sj, 0, sizeof(sj));
-        rc = pk_fill(sj, side->packed_w, side->w_kb_stride, side->w_kb0, side->x, side->K, "st_skinny_linear_packed_side_fwd(side)");
-        if (rc) return rc;
-        sj.B = B; sj.N = 4 * side->H; sj.H = side->H;
-        sj.gates_out = side->pre_out; sj.ldpre = side->ldpre;
-        return pk_dispatch<1>(a, tiles, (hipStream_t)stream, &sj, side->H / 4);
-    }
     if (pre && pre->s_buf) {
         ST_CHECK_ARG(pre->pm && pre->w_prev && pre->w_cum_prev && pre->loc_conv_w && pre->loc_lin_w && pre->L > 0 && pre->A > 0 &&
                      pre->F > 0 && pre->K > 0 && (pre->K & 1), "st_skinny_linear_packed_attnpre_fwd: bad attention job");
@@ -886,31 +817,7 @@ extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_v
                                            int B, int N, void* stream) {
     (void)hipGetLastError();
     return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
-                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, nullptr, stream);
-}
-
-extern "C" int st_skinny_linear_packed_side_fwd(const float* packed_w, const st_t16_view* x, int K,
-                                                const float* bias, int act, const float* mask, int ldmask,
-                                                float* y, int ldy, const st_t16_view* y_dst,
-                                                int n_split, float* y2, int ldy2, int rep,
-                                                int n_split2, int act2, const float* mask2, int ldmask2,
-                                                const st_t16_view* y3_dst,
-                                                int B, int N, const st_side_partial* side, void* stream) {
-    (void)hipGetLastError();
-    return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
-                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, side, nullptr, stream);
-}
-
-extern "C" int st_skinny_linear_packed_multi_fwd(const float* packed_w, const st_t16_view* x, int K,
-                                                 const float* bias, int act, const float* mask, int ldmask,
-                                                 float* y, int ldy, const st_t16_view* y_dst,
-                                                 int n_split, float* y2, int ldy2, int rep,
-                                                 int n_split2, int act2, const float* mask2, int ldmask2,
-                                                 const st_t16_view* y3_dst,
-                                                 int B, int N, const st_side_partial* side, const st_attn_pre_job* pre, void* stream) {
-    (void)hipGetLastError();
-    return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
-                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, side, pre, stream, true);
+                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, stream);
 }
 
 extern "C" int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,
@@ -922,22 +829,5 @@ extern "C" int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const 
                                                    int B, int N, const st_attn_pre_job* pre, void* stream) {
     (void)hipGetLastError();
     return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
-                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, pre, stream);
-}
-
-// Partial LSTM gate pre-activations over a k-block range of the packed weights:
-// pre_out(b, g*H + u) = sum_{k in range} W x     (no bias, no activation).  A later
-// st_lstm_cell_packed_fwd over the remaining k-blocks takes it as its `pre` addend.
-extern "C" int st_lstm_gates_partial_packed_fwd(const float* packed_w, int w_kb_stride, int w_kb0,
-                                                const st_t16_view* x, int K, float* pre_out, int ldpre,
-                                                int B, int H, void* stream) {
-    (void)hipGetLastError();
-    ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && pre_out && ldpre >= 4 * H, "st_lstm_gates_partial_packed_fwd: bad arguments");
-    PkArgs a;
-    memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, w_kb_stride, w_kb0, x, K, "st_lstm_gates_partial_packed_fwd");
-    if (rc) return rc;
-    a.B = B; a.N = 4 * H; a.H = H;
-    a.gates_out = pre_out; a.ldpre = ldpre;
-    return pk_dispatch<2>(a, H / 4, (hipStream_t)stream);
+                          n_split2, act2, mask2, ldmask2, y3_dst, B, N, pre, stream);
 }

@@ -12,7 +12,6 @@ Activations are kept channels-last (B, T, C) end to end (the reference transpose
 (B, C, T) around every Conv1d; the HIP conv is an implicit GEMM over channels-last rows).
 """
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -278,14 +277,14 @@ class Decoder(nn.Module):
         self.proj = Linear(dec_rnn_dim + enc_embed_dim, n_mels * n_frames_per_step)
         self.gate_layer = Linear(dec_rnn_dim + enc_embed_dim, 1, bias=True, w_init_gain='sigmoid')
         self.last_tapes = None     # tapes of the most recent forward (saved tensors of the backward pass)
-        import os
-        # early parts of the LSTM cells on a second HIP stream: measured SLOWER on MI355X/ROCm 7.2 (cross-stream
-        # event dependencies cost more than the ~15 us of overlap they buy: 86.7 vs 68.1 us/step), so off by default
-        self.overlap = int(os.environ.get('ST_OVERLAP', '0'))
         self.fuse_prenet = True    # inference: emit prenet layer 1 from the proj/gate launch (fp32 re-association)
         self.cache_packed = False  # frozen-weight inference: keep the packed weights across forwards
-        # inference: the location conv + W_l part of the attention of step t+1 runs inside the proj launch of step t
-        self.attn_split = os.environ.get('ST_ATTN_SPLIT', '1') != '0'
+        # the location conv + W_l part of the attention of step t+1 runs inside the proj launch of step t (st_decoder_io fields)
+        self.attn_split = True
+        self.attn_pre_parts = None   # workgroups per utterance of the pre part: None = 2, or 4 for long texts (L > 96: 2 % at L = 171)
+        self.attn_fin_parts = 2      # workgroups per utterance of the fin part (slices of the context dims)
+        # the attention's query projection folded into the query LSTM launch (st_lstm_cell_packed_fwd pq_slab): one launch less per step
+        self.fold_query_proj = True
 
     # -- helpers ---------------------------------------------------------------------------------
     def _weights_struct(self, keep, fuse_pre0=False):
@@ -411,8 +410,7 @@ class Decoder(nn.Module):
             off += n
         tapes.update(cq=torch.empty(steps + 1, B, Q, **f32), cd=torch.empty(steps + 1, B, D, **f32),
                      wcum=torch.empty(steps + 1, B, L, **f32), pq=torch.empty(B, A, **f32),
-                     zero=torch.empty(B, L, **f32), tiled=tiled, preq=torch.empty(B, 4 * Q, **f32),
-                     pred=torch.empty(B, 4 * D, **f32))
+                     zero=torch.empty(B, L, **f32), tiled=tiled)
         if keep_tapes:
             tapes['gates_q'] = torch.empty(steps, B, 4, Q, **f32)
             tapes['gates_d'] = torch.empty(steps, B, 4, D, **f32)
@@ -449,15 +447,14 @@ class Decoder(nn.Module):
         io.cq_tape, io.cd_tape, io.wcum_tape = (ops._p(tapes[k]) for k in ('cq', 'cd', 'wcum'))
         io.pq_buf, io.pre1_t16, io.mel_t16 = (ops._p(tapes[k]) for k in ('pq', 'pre1', 'melt'))
         io.zero_row = ops._p(tapes['zero'])
-        io.preq_buf, io.pred_buf, io.overlap = ops._p(tapes['preq']), ops._p(tapes['pred']), int(self.overlap)
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
         io.pre1_step_floats = t16(P) if keep_tapes else 0
         # training with pure teacher forcing: no step's input depends on an earlier output, so mel / stop of all steps
         # come from ONE GEMM over the xo tape after the loop instead of one launch per step
         pure_tf = teacher_pre is not None and Bt == B and all(step_src[t] == min(t, Tt - 1) for t in range(steps - 1))
-        defer = bool(keep_tapes and pure_tf and self.overlap not in (2, 3))
+        defer = bool(keep_tapes and pure_tf)
         io.defer_proj = 1 if defer else 0
-        if self.attn_split and self.overlap in (0, 3) and (not self.training or defer):
+        if self.attn_split and (not self.training or defer):
             if keep_tapes:      # training: S and the location features of every step stay for the backward pass
                 tapes['attn_s'] = torch.empty(steps, B, L, A, **f32)
                 tapes['attn_loc'] = torch.zeros(steps, B, L, self.n_location_filters, **f32)     # slot 0: no history yet
@@ -466,8 +463,11 @@ class Decoder(nn.Module):
             else:
                 tapes['attn_s'] = torch.empty(B, L, A, **f32)
             io.attn_s_buf = ops._p(tapes['attn_s'])
-            io.attn_pre_parts = int(os.environ.get('ST_ATTN_PRE_PARTS', '4' if L > 96 else '2'))   # long texts: 2 % at L = 171
-            io.attn_fin_parts = int(os.environ.get('ST_ATTN_FIN_PARTS', '2'))
+            io.attn_pre_parts = int(self.attn_pre_parts or (4 if L > 96 else 2))
+            io.attn_fin_parts = int(self.attn_fin_parts)
+            if self.fold_query_proj and not defer and lib.st_lstm_pq_fold_supported(B, Q, A):
+                tapes['pq_slab'] = torch.empty(int(lib.st_pq_slab_floats(B, Q, A)), **f32)
+                io.pq_slab = ops._p(tapes['pq_slab'])
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
         if defer:

@@ -121,11 +121,14 @@ def attn_pre(pm, w_prev, w_cum_prev, loc_conv_w, loc_lin_w, s_buf=None, parts=1)
     return s_buf
 
 
-def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K, parts=1):
+def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K, parts=1, pq_slab=None):
+    """pq_slab (n_slab, rows, A): the processed query as partial-sum slabs (lstm_cell_packed(pq_slab=...)) instead of pq"""
     B, L, E = memory.shape
     A = s_buf.shape[-1]
+    n_slab, rows = (pq_slab.shape[0], pq_slab.shape[1]) if pq_slab is not None else (0, 0)
     check(_lib.load().st_attn_fin_t16_fwd(_p(pq), _p(s_buf), _p(memory), _p(w_cum_prev), _p(w_out), int(w_out.stride(0)),
-                                          _p(w_cum_out), _p(v), None, 0, _p(ctx), int(ctx.stride(0)), int(parts), B, L, A, E, int(F_), int(K),
+                                          _p(w_cum_out), _p(v), None, 0, _p(ctx), int(ctx.stride(0)), int(parts),
+                                          _p(pq_slab), int(n_slab), int(rows), B, L, A, E, int(F_), int(K),
                                           stream_handle()), 'st_attn_fin_t16_fwd')
 
 
@@ -532,19 +535,22 @@ def _vp(v):
 
 
 def lstm_cell_packed(packed_w, x_view, Kpad, b_ih, b_hh, c_prev, h_dst0, c_out, B, H, h_dst1=None, mask=None,
-                     gates_out=None, ada_std=None, ada_mean=None, hadapt_dst=None, pre=None, w_kb_stride=0, w_kb0=0):
+                     gates_out=None, ada_std=None, ada_mean=None, hadapt_dst=None, pq_w_fold=None, pq_slab=None, pq_A=0):
     """x_view / *_dst: StT16View (see t16_view); Kpad = 16 * (k-blocks to reduce over)"""
-    check(_lib.load().st_lstm_cell_packed_fwd(_p(packed_w), int(w_kb_stride), int(w_kb0), C.byref(x_view), int(Kpad),
-                                              _p(b_ih), _p(b_hh), _p(pre), int(pre.stride(0)) if pre is not None else 0,
+    check(_lib.load().st_lstm_cell_packed_fwd(_p(packed_w), C.byref(x_view), int(Kpad), _p(b_ih), _p(b_hh),
                                               _p(c_prev), H, _p(mask), C.byref(h_dst0), _vp(h_dst1), _p(c_out), H,
-                                              _p(gates_out), _p(ada_std), _p(ada_mean), _vp(hadapt_dst), int(B), int(H),
+                                              _p(gates_out), _p(ada_std), _p(ada_mean), _vp(hadapt_dst),
+                                              _p(pq_w_fold), _p(pq_slab), int(pq_A), int(B), int(H),
                                               stream_handle()), 'st_lstm_cell_packed_fwd')
 
 
-def lstm_gates_partial_packed(packed_w, w_kb_stride, w_kb0, x_view, Kpad, pre_out, B, H):
-    check(_lib.load().st_lstm_gates_partial_packed_fwd(_p(packed_w), int(w_kb_stride), int(w_kb0), C.byref(x_view), int(Kpad),
-                                                       _p(pre_out), int(pre_out.stride(0)), int(B), int(H), stream_handle()),
-          'st_lstm_gates_partial_packed_fwd')
+def pack_fold_weight(w):
+    """(N <= 256, K % 8 == 0) linear weight -> the fold layout read by lstm_cell_packed(pq_w_fold=...)"""
+    lib = _lib.load()
+    N, K = w.shape
+    out = torch.empty(int(lib.st_fold_weight_floats(K)), device=w.device, dtype=torch.float32)
+    check(lib.st_pack_fold_weight(_p(w), int(w.stride(0)), int(N), int(K), _p(out), stream_handle()), 'st_pack_fold_weight')
+    return out
 
 
 def skinny_linear_packed(packed_w, x_view, Kpad, B, N, y=None, y_dst=None, bias=None, act=None, mask=None,

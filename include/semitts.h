@@ -369,7 +369,11 @@ int st_gather_rows(const float* table, const int64_t* idx, float* out, int n, in
  *   (first maximum wins) ; out = (x + table[idx]) - x   (straight-through forward value)
  * ref: L2Embedding.forward src/embed.py:105-147, neg_batch_l2 :208-213 */
 int st_vq_l2_fwd(const float* x, const float* table, const float* temp, float* p_code,
-                 int64_t* idx, float* out, int n, int D, int V, void* stream);
+                 int64_t* idx, float* out, float* workspace, int n, int D, int V, void* stream);
+/* workspace: st_vq_l2_workspace_floats(D, V) floats (the table re-packed into MFMA operand order + |e|^2 per code) selects the
+ * matrix-core kernel (D <= 64, D % 4 == 0, V <= 1024; exact-fp32 MFMA keeps the dimension-ascending dot product, so the indices
+ * are those of the scalar kernel); NULL or another shape runs the scalar kernel (table staged in LDS). */
+size_t st_vq_l2_workspace_floats(int D, int V);
 /* Run-length merge of VQ codes with blank filtering (ref: VQVAE.mean_forward src/vqvae.py:218-257): per utterance,
  * consecutive frames with the same argmax code (runs capped at max_frames_per_phn+1 frames) are replaced by the
  * mean of their latents, runs of code 0 are dropped.  out (B, T, D) must be ZERO on entry (rows >= lens(b) stay

@@ -113,7 +113,8 @@ SIGNATURES = {
     'st_gru_seq_bwd': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, P],
     'st_vq_build_table': [P, I, P, I, P, P, I, P, I, P],
     'st_gather_rows': [P, P, P, I, I, I, P],
-    'st_vq_l2_fwd': [P, P, P, P, P, P, I, I, I, P],
+    'st_vq_l2_fwd': [P, P, P, P, P, P, P, I, I, I, P],
+    'st_vq_l2_workspace_floats': [I, I],
     'st_vq_mean_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],
     'st_vq_mean_bwd': [P, I, P, P, P, I, I, I, P],
     'st_softmax_argmax': [P, P, P, I, I, P],
@@ -175,7 +176,7 @@ SIGNATURES = {
     'st_mean_rows': [P, P, I, I, I, P],
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
-             'st_decoder_packed_floats': C.c_size_t, 'st_fold_weight_floats': C.c_size_t, 'st_pq_slab_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
+             'st_decoder_packed_floats': C.c_size_t, 'st_fold_weight_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_pq_slab_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
              'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
 
 _lib = None

@@ -15,6 +15,7 @@
 // State lives in caller-owned tapes indexed by step; nothing is overwritten, so the same
 // buffers are the saved tensors of the backward pass.
 #include "st_common.h"
+#include <cstdlib>
 
 extern "C" size_t st_packed_weight_floats(const int* k, int nseg, int N, int lstm_H);
 extern "C" size_t st_t16_floats(int B, int K);
@@ -186,7 +187,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     const size_t ldmel = (size_t)steps * in_dim;
     const int ldal = steps * L;
     const int Kq = 16 * sv.q_kbs, Kd = 16 * sv.d_kbs, Ko = 16 * sv.o_kbs;
-    int rc;
+    int rc = 0;
     // Attention in two parts (io->attn_s_buf set by the host): the location part of step t+1 ("pre": conv + W_l + processed
     // memory -> S) only needs the attention weights of step t, so it rides as extra workgroups of a small launch that runs
     // anyway -- the proj launch of step t when the loop has one, otherwise (deferred projection = teacher-forced training) the
@@ -201,6 +202,12 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     const int pq_rows = ((B + 15) >> 4) * 16;
     const int fp_req = io->attn_fin_parts;
     const int fin_parts = (fp_req == 2 || fp_req == 4 || fp_req == 8) && E % (4 * fp_req) == 0 ? fp_req : 1;
+#ifdef ST_ABLATE   // timing experiments only (tools/gpu_ablate.sh builds a SEPARATE library with this macro): skip launches by bit mask
+    const int skip = getenv("ST_SKIP") ? atoi(getenv("ST_SKIP")) : 0;
+#define ST_SKIPPED(bit) (skip & (1 << (bit)))
+#else
+#define ST_SKIPPED(bit) 0
+#endif
     for (int t = 0; t < steps; ++t) {
         float* xq = io->xq_tape + (size_t)t * sv.q_floats;
         float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
@@ -214,7 +221,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view xq_v = {xq, sv.q_kbs, 0};
         st_t16_view hq_dst = {xq_next, sv.q_kbs, sv.q_h};
         st_t16_view ha_dst = {xd, sv.d_kbs, sv.d_ha};
-        rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, Kq, w->q_b_ih, w->q_b_hh,
+        if (!ST_SKIPPED(0)) rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, Kq, w->q_b_ih, w->q_b_hh,
                                      io->cq_tape + (size_t)t * BQ, Q, io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
                                      &hq_dst, nullptr, io->cq_tape + (size_t)(t + 1) * BQ, Q,
                                      io->gates_q_tape ? io->gates_q_tape + (size_t)t * 4 * BQ : nullptr,
@@ -231,7 +238,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                                      io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
                                                      &job, stream);
-        } else if (!fold_pq)
+        } else if (!fold_pq && !ST_SKIPPED(1))
             rc = st_skinny_linear_packed_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                              io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A, stream);
         if (rc) return rc;
@@ -240,7 +247,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    ctx_t -> xq_{t+1}[ctx part], xd_t[ctx part], xo_t[ctx part]
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
-        if (split_attn)     // S of this step was written by the pre part (step 0: no history yet, S = pm)
+        if (ST_SKIPPED(2)) rc = 0;
+        else if (split_attn)     // S of this step was written by the pre part (step 0: no history yet, S = pm)
             rc = st_attn_fin_t16_fwd(fold_pq ? nullptr : io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats,
                                      io->memory, io->wcum_tape + (size_t)t * BL,
                                      io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL, w->attn_v,
@@ -258,7 +266,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view xd_v = {xd, sv.d_kbs, 0};
         st_t16_view hd_dst0 = {xd_next, sv.d_kbs, sv.d_h};
         st_t16_view hd_dst1 = {xo, sv.o_kbs, 0};
-        rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, Kd, w->d_b_ih, w->d_b_hh,
+        if (!ST_SKIPPED(3)) rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, Kd, w->d_b_ih, w->d_b_hh,
                                      io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                      &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                      io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
@@ -275,7 +283,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                w->attn_loc_conv_w, w->attn_loc_lin_w,
                                split_attn ? io->attn_s_buf + (size_t)(t + 1) * io->attn_s_step_floats : nullptr, L, A, d->F, d->K,
                                io->attn_pre_parts, io->attn_loc_tape ? io->attn_loc_tape + (size_t)(t + 1) * BL * d->F : nullptr};
-        rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
+        if (!ST_SKIPPED(4)) rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
                                                  io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
                                                  io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
                                                  fuse ? in_dim + 1 : 0, ST_ACT_RELU,
@@ -288,7 +296,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         if (t + 1 < steps) {
             const int src = io->step_src[t];
             st_t16_view next = {xq_next, sv.q_kbs, 0};
-            if (src == -1 || io->Bt < B) {   // rows without a teacher feed their own output back
+            if ((src == -1 || io->Bt < B) && !ST_SKIPPED(5)) {   // rows without a teacher feed their own output back
                 rc = prenet_own(d, io, pl, sv, t, fuse, stream);
                 if (rc) return rc;
             }

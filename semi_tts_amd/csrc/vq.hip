@@ -123,6 +123,196 @@ __global__ __launch_bounds__(VQ_WAVES * 64) void vq_l2_kernel(const float* x, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Nearest-code search on the matrix cores (D <= 64, D % 4 == 0, V <= 1024): sims = X E^T is a GEMM with K = D, and the
+// exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: an fmaf chain over k, bitwise) reproduces the dimension-ascending dot product of
+// the scalar kernel above, so the indices stay what the reference's golden vectors pin.
+//   * the table is re-packed once per call into MFMA B-operand order (vq_pack_table_kernel, 4*V*D bytes, L2 resident):
+//     [code tile of 16][group of 4 k-steps][lane][4 floats], plus |e|^2 per code -- a wave fetches a tile's operands with
+//     four 16-byte loads per lane;
+//   * a workgroup (4 waves) owns 16 input vectors; wave w scores the code tiles w, w+4, ...: the softmax max / sum and the
+//     argmax are DPP reductions over the 16 lanes that hold one vector's codes, then over the 4 waves through LDS;
+//   * |x|^2 uses the same summation tree as the scalar kernel's wave butterfly (dims d, d^32 first ... d^1 last).
+// Algorithmic bytes per vector: 4D in + 4D out + 8 idx + 4V p_code; the packed table is read from L2 by every workgroup.
+constexpr int VQM_THREADS = 256, VQM_XLD = 68;
+
+__global__ __launch_bounds__(256) void vq_pack_table_kernel(const float* table, int V, int D, float* ws, int n_ct, int ks4n) {
+    const size_t total = (size_t)n_ct * ks4n * 256;
+    float* e2 = ws + total;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + (size_t)n_ct * 16; idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx < total) {
+            const int c = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+            const int blk = (int)(idx >> 8), ks4 = blk % ks4n, ct = blk / ks4n;
+            const int code = ct * 16 + (lane & 15), d = (ks4 * 4 + c) * 4 + (lane >> 4);
+            ws[idx] = (code < V && d < D) ? table[(size_t)code * D + d] : 0.0f;
+        } else {                                        // sum(y.pow(2), -1): dimension-ascending fma chain (as the scalar kernel)
+            const int code = (int)(idx - total);
+            float acc = 0.0f;
+            if (code < V) {
+                f32x4 row[16];          // the whole row is requested up front (D <= 64, D % 4 == 0: checked on the host)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) row[q] = 4 * q < D ? *reinterpret_cast<const f32x4*>(table + (size_t)code * D + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc = fmaf(row[q][c], row[q][c], acc);      // zeros past D leave the chain unchanged
+            }
+            e2[code] = acc;
+        }
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ int vq_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+// all-reduce over the 16 lanes of a DPP row
+__device__ __forceinline__ float vq_row_max(float v) {
+    v = fmaxf(v, st_dpp<ST_DPP_QUAD_XOR1>(v)); v = fmaxf(v, st_dpp<ST_DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, st_dpp<ST_DPP_ROW_HALF_MIRROR>(v)); v = fmaxf(v, st_dpp<ST_DPP_ROW_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ float vq_row_sum(float v) {
+    v += st_dpp<ST_DPP_QUAD_XOR1>(v); v += st_dpp<ST_DPP_QUAD_XOR2>(v);
+    v += st_dpp<ST_DPP_ROW_HALF_MIRROR>(v); v += st_dpp<ST_DPP_ROW_MIRROR>(v);
+    return v;
+}
+// larger value wins, equal values: smaller index (torch.argmax: the first maximum)
+__device__ __forceinline__ void vq_best(float& v, int& i, float ov, int oi) { if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } }
+template <int CTRL>
+__device__ __forceinline__ void vq_row_argmax_step(float& v, int& i) { const float ov = st_dpp<CTRL>(v); const int oi = vq_dpp_i<CTRL>(i); vq_best(v, i, ov, oi); }
+
+template <int TPW>     // code tiles per wave: V <= 64 * TPW
+__global__ __launch_bounds__(VQM_THREADS) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
+                                                                 float* p_code, int64_t* idx_out, float* out, int n, int D, int V,
+                                                                 int n_ct, int ks4n) {
+    __shared__ __attribute__((aligned(16))) float xt[16 * VQM_XLD];
+    __shared__ float xxs[4][16];
+    __shared__ float red[4][16];
+    __shared__ int redi[4][16];
+    __shared__ int fidx[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, nn = lane & 15;
+    const int v0 = blockIdx.x * 16;
+    // operands of the first code tile of this wave are requested before anything else
+    const f32x4* wsp = reinterpret_cast<const f32x4*>(ws);
+    const float* e2 = ws + (size_t)n_ct * ks4n * 256;
+    {   // stage the 16 input vectors (zeros past D and past n)
+        const int vec = tid >> 4, d4 = (tid & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (v0 + vec < n && d4 < D) v = *reinterpret_cast<const f32x4*>(x + (size_t)(v0 + vec) * D + d4);
+        *reinterpret_cast<f32x4*>(xt + vec * VQM_XLD + d4) = v;
+    }
+    __syncthreads();
+    {   // |x|^2 with the butterfly tree of the scalar kernel: lane (vec = lane >> 2, j = lane & 3) owns dims j, j + 4, ...
+        const int vec = lane >> 2, j = lane & 3;
+        float a[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { const float t = xt[vec * VQM_XLD + j + 4 * m]; a[m] = t * t; }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a[m] += a[m + 8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] += a[m + 4];
+        a[0] += a[2]; a[1] += a[3];
+        float f = a[0] + a[1];
+        f += st_dpp<ST_DPP_QUAD_XOR2>(f);
+        f += st_dpp<ST_DPP_QUAD_XOR1>(f);
+        if (j == 0) xxs[wave][vec] = f;
+    }
+    float ax[16];                                   // A fragments: x[vec nn][4 ks + g]
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) ax[ks] = xt[nn * VQM_XLD + ks * 4 + g];
+    f32x4 acc[TPW];
+    float e2v[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ct = min(wave + 4 * t, n_ct - 1);         // tiles past the table repeat the last one (discarded below)
+        e2v[t] = e2[ct * 16 + nn];
+        f32x4 b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = q < ks4n ? wsp[((size_t)ct * ks4n + q) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q * 4 + c], b4[q][c], acc[t], 0, 0, 0);
+    }
+    // lane (g, nn) now holds dot(x[vec 4g + r], e[code (wave + 4t) * 16 + nn]) in acc[t][r]
+    const float tscale = fmaxf(temp[0], 0.0f);          // F.relu(self.temp)
+    float xxr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xxr[r] = xxs[wave][4 * g + r];
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const bool on = (wave + 4 * t) * 16 + nn < V;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dist = (xxr[r] + e2v[t]) - 2.0f * acc[t][r];     // embed.py:210-212 association order
+            const float sim = on ? tscale * (-dist) : -INFINITY;
+            acc[t][r] = sim;
+            mx[r] = fmaxf(mx[r], sim);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mx[r] = vq_row_max(mx[r]); if (nn == 0) red[wave][4 * g + r] = mx[r]; }
+    __syncthreads();
+    float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(fmaxf(red[0][4 * g + r], red[1][4 * g + r]), fmaxf(red[2][4 * g + r], red[3][4 * g + r]));
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = expf(acc[t][r] - mx[r]); acc[t][r] = e; sm[r] += e; }
+    __syncthreads();                                     // everybody has read the maxima: the slots are reused for the sums
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sm[r] = vq_row_sum(sm[r]); if (nn == 0) red[wave][4 * g + r] = sm[r]; }
+    __syncthreads();
+    float bv[4] = {-1.f, -1.f, -1.f, -1.f};
+    int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sm[r] = ((red[0][4 * g + r] + red[1][4 * g + r]) + red[2][4 * g + r]) + red[3][4 * g + r];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int code = (wave + 4 * t) * 16 + nn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = acc[t][r] / sm[r];
+            const int vec = v0 + 4 * g + r;
+            if (code < V && vec < n) p_code[(size_t)vec * V + code] = p;
+            if (code < V && p > bv[r]) { bv[r] = p; bi[r] = code; }      // ascending codes per lane: strict > keeps the first
+        }
+    }
+    __syncthreads();                                     // sums consumed: slots reused for the per-wave best
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        vq_row_argmax_step<ST_DPP_QUAD_XOR1>(bv[r], bi[r]); vq_row_argmax_step<ST_DPP_QUAD_XOR2>(bv[r], bi[r]);
+        vq_row_argmax_step<ST_DPP_ROW_HALF_MIRROR>(bv[r], bi[r]); vq_row_argmax_step<ST_DPP_ROW_MIRROR>(bv[r], bi[r]);
+        if (nn == 0) { red[wave][4 * g + r] = bv[r]; redi[wave][4 * g + r] = bi[r]; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float v = red[0][tid];
+        int i = redi[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) vq_best(v, i, red[w][tid], redi[w][tid]);
+        fidx[tid] = i;
+        if (v0 + tid < n) idx_out[v0 + tid] = i;
+    }
+    __syncthreads();
+    {   // out = (x + code) - x.detach(): the straight-through forward value (embed.py:145)
+        const int vec = tid >> 4, d4 = (tid & 15) * 4;
+        if (v0 + vec < n && d4 < D) {
+            const f32x4 e = *reinterpret_cast<const f32x4*>(table + (size_t)fidx[vec] * D + d4);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + vec * VQM_XLD + d4);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (xv[c] + e[c]) - xv[c];
+            *reinterpret_cast<f32x4*>(out + (size_t)(v0 + vec) * D + d4) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(VQ_WAVES * 64) void softmax_argmax_kernel(const float* logits, float* p, int64_t* idx_out,
                                                                        int n, int V) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -223,10 +413,36 @@ extern "C" int st_gather_rows(const float* table, const int64_t* idx, float* out
     return 0;
 }
 
+extern "C" size_t st_vq_l2_workspace_floats(int D, int V) {
+    if (D <= 0 || V <= 0) return 0;
+    const size_t n_ct = ((size_t)V + 15) / 16, ks4n = ((size_t)D + 15) / 16;
+    return n_ct * ks4n * 256 + n_ct * 16;
+}
+
 extern "C" int st_vq_l2_fwd(const float* x, const float* table, const float* temp, float* p_code,
-                            int64_t* idx, float* out, int n, int D, int V, void* stream) {
+                            int64_t* idx, float* out, float* workspace, int n, int D, int V, void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(x && table && temp && p_code && idx && out && n > 0 && D > 0 && V > 0, "st_vq_l2_fwd: bad arguments");
+    // matrix-core form: D <= 64 in 16-byte pieces, at most 16 code tiles per wave, a caller-provided workspace for the packed table
+    if (workspace && D <= 64 && D % 4 == 0 && V <= 1024 && st_aligned16(x) && st_aligned16(table) && st_aligned16(out) &&
+        st_aligned16(workspace)) {
+        const int n_ct = (V + 15) / 16, ks4n = (D + 15) / 16;
+        const size_t total = (size_t)n_ct * ks4n * 256 + (size_t)n_ct * 16;
+        hipLaunchKernelGGL(vq_pack_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, V, D,
+                           workspace, n_ct, ks4n);
+        ST_LAUNCH_CHECK();
+        const dim3 grid((n + 15) / 16), block(VQM_THREADS);
+        const int tpw = (n_ct + 3) / 4;
+#define VQ_LAUNCH(T) hipLaunchKernelGGL((vq_l2_mfma_kernel<T>), grid, block, 0, (hipStream_t)stream, x, table, workspace, temp, p_code, idx, out, n, D, V, n_ct, ks4n)
+        if (tpw <= 1) VQ_LAUNCH(1);
+        else if (tpw <= 2) VQ_LAUNCH(2);
+        else if (tpw <= 4) VQ_LAUNCH(4);
+        else if (tpw <= 8) VQ_LAUNCH(8);
+        else VQ_LAUNCH(16);
+#undef VQ_LAUNCH
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = ((size_t)D * (V + 1) + V + (size_t)VQ_WAVES * D + (size_t)VQ_WAVES * V) * sizeof(float);
     ST_CHECK_ARG(lds <= 160 * 1024, "st_vq_l2_fwd: V=%d x D=%d table needs %zu B of LDS (> 160 KiB)", V, D, lds);
     static bool configured = false;

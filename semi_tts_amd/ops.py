@@ -303,7 +303,8 @@ def gather_rows(table, idx):
     return out
 
 
-def vq_l2(x, table, temp):
+def vq_l2(x, table, temp, scalar_kernel=False):
+    """scalar_kernel=True (tests): the LDS-table kernel instead of the matrix-core one"""
     lib = _lib.load()
     lead, D = x.shape[:-1], x.shape[-1]
     V = table.shape[0]
@@ -311,7 +312,8 @@ def vq_l2(x, table, temp):
     p = torch.empty(tuple(lead) + (V,), device=x.device, dtype=torch.float32)
     idx = torch.empty(tuple(lead), device=x.device, dtype=torch.int64)
     out = torch.empty_like(x)
-    check(lib.st_vq_l2_fwd(_p(x), _p(table), _p(temp), _p(p), _p(idx, torch.int64), _p(out), n, D, V, stream_handle()),
+    ws = None if scalar_kernel else torch.empty(int(lib.st_vq_l2_workspace_floats(D, V)), device=x.device, dtype=torch.float32)
+    check(lib.st_vq_l2_fwd(_p(x), _p(table), _p(temp), _p(p), _p(idx, torch.int64), _p(out), _p(ws), n, D, V, stream_handle()),
           'st_vq_l2_fwd')
     return p, idx, out
 

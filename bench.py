@@ -296,8 +296,6 @@ def bench_decode(args, rk):
     with torch.no_grad():
         memory = m.encoder(txt, None).contiguous()        # inputs of the timed region, resident in HBM
     dec = m.decoder
-    if args.no_fold:
-        dec.fold_query_proj = False
     gd = GraphedDecoder(dec, B, L, T, dev)
     gd.memory.copy_(memory)
     gd.spkr.copy_(spk)
@@ -496,7 +494,6 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='issue the decode loop eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-finite-check', action='store_true', help=argparse.SUPPRESS)    # timing experiments (tools/gpu_ablate.sh)
-    ap.add_argument('--no-fold', action='store_true', help='A/B: keep the query projection as its own launch (decode workloads)')
     ap.add_argument('--traffic-json', default=None, help='PMC summary (tools/pmc_summary.py) to quote as roofline.traffic')
     ap.add_argument('--workload', choices=['c2', 'c5', 'c3', 'train'], default='c2',
                     help="c2 = the headline configuration; c5 / c3 / train = secondary lines (see the module docstring)")

@@ -133,18 +133,7 @@ int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
                             const st_t16_view* h_dst0, const st_t16_view* h_dst1,
                             float* c_out, int ldc, float* gates_out,
                             const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
-                            const float* pq_w_fold, float* pq_slab, int pq_A,
                             int B, int H, void* stream);
-/* Optional (pq_slab != NULL): the attention's query projection (`self.query_layer(query)`, src/module.py:380) folded into this
- * launch.  Every workgroup of the 2-D tiled cell holds 8 hidden units of the new h for its batch rows and emits the rank-8
- * partial product W_q[:, units] h[units] (exact-fp32 MFMA) into slab g = units / 8 of pq_slab, laid out
- * (H/8 slabs, ceil(B/16)*16 rows, pq_A) floats; st_attn_fin_t16_fwd adds the slabs in a fixed order.  pq_w_fold = W_q (pq_A, H)
- * in the fold layout (st_pack_fold_weight).  Shapes: st_lstm_pq_fold_supported (B in 17..32 or 49..64, H % 8 == 0,
- * pq_A % 16 == 0, pq_A <= 256). */
-int st_lstm_pq_fold_supported(int B, int H, int A);
-size_t st_fold_weight_floats(int K);                       /* floats of the fold layout of an (N <= 256, K) weight   */
-size_t st_pq_slab_floats(int B, int H, int A);             /* floats of pq_slab                                      */
-int st_pack_fold_weight(const float* w, int ldw, int N, int K, float* out, void* stream);
 /* st_skinny_linear_fwd on packed operands; output natural (y) and/or T16 (y_dst).
  * Optional third row range [n_split2, N): v = act2(v) * mask2(b, n - n_split2) -> y3_dst column
  * n - n_split2 (used to emit prenet layer 1 of the next step from the same launch as proj/gate). */
@@ -192,10 +181,7 @@ int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wprev, const fl
 int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
                         float* w_out, int ld_wout, float* w_cum_out, const float* v,
                         const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx, int parts,
-                        const float* pq_slab, int pq_nslab, int pq_rows,
                         int B, int L, int A, int E, int F, int K, void* stream);
-/* (pq_slab != NULL: the processed query is the sum of pq_nslab slabs of (pq_rows, A) floats written by
- *  st_lstm_cell_packed_fwd; pq may then be NULL) */
 /* (parts = workgroups per utterance of the fin part: each takes E/parts context dims and repeats the energies + softmax;
  *  1, 2, 4 or 8 with E % (4*parts) == 0) */
 /* st_skinny_linear_packed_fwd plus, as extra workgroups of the same launch (one per utterance), st_attn_pre_fwd for the NEXT
@@ -374,6 +360,16 @@ int st_vq_l2_fwd(const float* x, const float* table, const float* temp, float* p
  * matrix-core kernel (D <= 64, D % 4 == 0, V <= 1024; exact-fp32 MFMA keeps the dimension-ascending dot product, so the indices
  * are those of the scalar kernel); NULL or another shape runs the scalar kernel (table staged in LDS). */
 size_t st_vq_l2_workspace_floats(int D, int V);
+/* Backward pieces of the codebook lookup (what autograd derives for src/embed.py:105-147 and :187-205):
+ *   st_softmax_bwd:       dz(n, v) = s * p(n, v) * (dp(n, v) - sum_v' dp(n, v') p(n, v')),  s = scale * (relu_scale ? max(relu_scale[0], 0) : 1);
+ *                         rowsum (optional) = sum_v dz(n, v)
+ *   st_rowscale_combine:  out(m, d) = alpha * a(m, d) + beta * r(m) * x(m, d) + c(m, d)   (x/r and c optional) -- with a = dz E or
+ *                         dz^T X from the GEMM entry points this forms dX = 2 (dz E) - 2 X rowsum + dnew_latent and
+ *                         dE = 2 (dz^T X) - 2 E colsum + scatter_add(dnew_latent) of sim = -relu(temp) (|x|^2 + |e|^2 - 2 x.e). */
+int st_softmax_bwd(const float* p, const float* dp, const float* relu_scale, float scale, float* dz, float* rowsum,
+                   int n, int V, void* stream);
+int st_rowscale_combine(const float* a, float alpha, const float* x, const float* r, float beta, const float* c,
+                        float* out, int M, int D, void* stream);
 /* Run-length merge of VQ codes with blank filtering (ref: VQVAE.mean_forward src/vqvae.py:218-257): per utterance,
  * consecutive frames with the same argmax code (runs capped at max_frames_per_phn+1 frames) are replaced by the
  * mean of their latents, runs of code 0 are dropped.  out (B, T, D) must be ZERO on entry (rows >= lens(b) stay
@@ -456,8 +452,6 @@ typedef struct st_decoder_io {
     float* pre1_t16;          /* T16 (B,P) scratch (prenet layer-1 output), zero-filled */
     float* mel_t16;           /* T16 (B, r*n_mels) scratch (own output as the prenet input), zero-filled */
     float* zero_row;          /* (B, max(L,1)) zeros (w_prev of step 0) -- zeroed by the callee */
-    float* pq_slab;           /* st_pq_slab_floats(B, Q, A) floats or NULL: fold the query projection into the query LSTM launch
-                               * (used when st_lstm_pq_fold_supported(B, Q, A), the attention is split and defer_proj == 0) */
     float* gates_q_tape;      /* (steps, B, 4, Q) or NULL (training) */
     float* gates_d_tape;      /* (steps, B, 4, D) or NULL */
     float* attn_s_buf;        /* (B,L,A) or NULL: split the attention step -- its location conv + W_l part for step t+1 runs inside

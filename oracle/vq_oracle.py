@@ -37,18 +37,25 @@ def neg_batch_l2(x: Tensor, y: Tensor) -> Tensor:
     return -d
 
 
-def l2_forward(W: Weights, x: Tensor):
+def l2_forward(W: Weights, x: Tensor, first_n_real_mel: int = 0):
     """L2Embedding.forward (stop_grad=True, skip_prob=0: every shipped config).
     ref: src/embed.py:105-147.
     Returns p_code (B,S,V), idx (B,S) int64, new_latent (B,S,D) with the straight-through
-    value fl(fl(x + code) - x) (embed.py:145), and the table."""
+    value fl(fl(x + code) - x) (embed.py:145), and the table.  first_n_real_mel > 0: the similarities of the remaining
+    utterances see a detached table (:115-122; same values, different gradient)."""
     B, S, D = x.shape
     table = full_table(W)
-    sim = torch.relu(W['temp']) * neg_batch_l2(x, table).view(B, S, -1)               # :124
+    ts = torch.relu(W['temp'])
+    if first_n_real_mel > 0:
+        n = first_n_real_mel
+        sim = torch.cat([ts * neg_batch_l2(x[:n], table).view(n, S, -1),
+                         ts * neg_batch_l2(x[n:], table.detach()).view(B - n, S, -1)], dim=0)
+    else:
+        sim = ts * neg_batch_l2(x, table).view(B, S, -1)                              # :124
     p = sim.softmax(dim=-1)                                                           # :127
     idx = p.argmax(dim=-1)                                                            # :130 (argmax of p, not sim)
     code = table[idx]                                                                 # :134
-    new_latent = x + code - x                                                         # :145
+    new_latent = x + code - x.detach()                                                # :145 (straight-through estimator)
     return p, idx, new_latent, table
 
 

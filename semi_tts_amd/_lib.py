@@ -52,7 +52,7 @@ class StDecoderIO(C.Structure):
                 ('xq_tape', C.c_void_p), ('xd_tape', C.c_void_p), ('xo_tape', C.c_void_p),
                 ('cq_tape', C.c_void_p), ('cd_tape', C.c_void_p), ('wcum_tape', C.c_void_p),
                 ('pq_buf', C.c_void_p), ('pre1_t16', C.c_void_p), ('mel_t16', C.c_void_p),
-                ('zero_row', C.c_void_p), ('pq_slab', C.c_void_p),
+                ('zero_row', C.c_void_p),
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('attn_fin_parts', C.c_int), ('defer_proj', C.c_int),
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p)]
 
@@ -115,6 +115,8 @@ SIGNATURES = {
     'st_gather_rows': [P, P, P, I, I, I, P],
     'st_vq_l2_fwd': [P, P, P, P, P, P, P, I, I, I, P],
     'st_vq_l2_workspace_floats': [I, I],
+    'st_softmax_bwd': [P, P, P, C.c_float, P, P, I, I, P],
+    'st_rowscale_combine': [P, C.c_float, P, P, C.c_float, P, P, I, I, P],
     'st_vq_mean_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],
     'st_vq_mean_bwd': [P, I, P, P, P, I, I, I, P],
     'st_softmax_argmax': [P, P, P, I, I, P],
@@ -124,18 +126,14 @@ SIGNATURES = {
     'st_tile_rows': [P, I, C.POINTER(StT16View), I, I, P],
     'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
     'st_lstm_cell_packed_fwd': [P, C.POINTER(StT16View), I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
-                                P, I, P, P, P, C.POINTER(StT16View), P, P, I, I, I, P],
-    'st_lstm_pq_fold_supported': [I, I, I],
-    'st_fold_weight_floats': [I],
-    'st_pq_slab_floats': [I, I, I],
-    'st_pack_fold_weight': [P, I, I, I, P, P],
+                                P, I, P, P, P, C.POINTER(StT16View), I, I, P],
     'st_skinny_linear_packed_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                     I, I, P, I, C.POINTER(StT16View), I, I, P],
     'st_attn_step_t16_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],
     'st_skinny_linear_packed_attnpre_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                             I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StAttnPreJob), P],
     'st_attn_pre_fwd': [P, P, I, P, P, P, P, I, I, I, I, I, I, P],
-    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, P, I, I, I, I, I, I, I, I, P],
+    'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],
@@ -176,7 +174,7 @@ SIGNATURES = {
     'st_mean_rows': [P, P, I, I, I, P],
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
-             'st_decoder_packed_floats': C.c_size_t, 'st_fold_weight_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_pq_slab_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
+             'st_decoder_packed_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
              'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
 
 _lib = None

@@ -4,13 +4,15 @@ and state_dict keys (`layer{l}.conv.*`, `layer{l}.bn.*`, `rnn.*`, `postnet.*`).
 
 Every ConvLayer is ONE launch of the implicit-GEMM conv (stride in the row mapping) with bias -> BatchNorm ->
 activation -> residual add -> dropout mask fused in its epilogue; the BiLSTM layers reuse the encoder's
-sequence kernels.  Forward only: the speech encoder is trained by the CTC half of the reference's step, which is
-outside the hot path (a strided conv input-gradient kernel does not exist here), so a differentiable call raises.
+sequence kernels.  In training mode with gradients enabled the same kernels run as differentiable pieces
+(semi_tts_amd/autograd.py: conv incl. the stride-2 layer, batch-statistics BatchNorm, BiLSTM), so the CTC half of
+the reference's training step (bin/train_vqvae.py:208-217,270) reaches the speech encoder.
 """
 import torch
 import torch.nn as nn
 
 from . import ops
+from . import autograd as AG
 
 _ACT = {'tanh': 'tanh', 'relu': 'relu', 'sigmoid': 'sigmoid'}
 
@@ -28,10 +30,19 @@ class ConvLayer(nn.Module):
 
     def forward(self, x, mask=None):
         """x (B,T,C) channels-last (the reference keeps (B,C,T))"""
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError('the speech encoder is forward-only on the HIP path (run it under torch.no_grad())')
         w, b = self.conv.weight, self.conv.bias
         p = self.drop.p
+        if self.training and torch.is_grad_enabled():
+            # differentiable: conv (+ bias) -> BatchNorm over the batch -> activation -> + x -> dropout     (src/module.py:638-648)
+            if self.batch_norm:
+                y = AG.batch_norm_train(AG.conv(x, w, b, pad=self.padding, stride=self.stride), self.bn, self.activation)
+            else:
+                y = AG.conv(x, w, b, pad=self.padding, stride=self.stride, act=self.activation)
+            if self.residual:
+                y = y + x
+            if p > 0:
+                y = y * (mask if mask is not None else torch.empty_like(y).bernoulli_(1 - p).div_(1 - p))
+            return y
         if self.training and p > 0 and mask is None:
             B, T, _ = x.shape
             To = (T + 2 * self.padding - w.shape[2]) // self.stride + 1
@@ -82,6 +93,15 @@ class CTC(nn.Module):
         B, T, _ = x.shape
         H = self.rnn_dim
         p = self.dropout if self.training else 0.0
+        if self.training and torch.is_grad_enabled():
+            for layer in range(self.rnn_layers):
+                g = lambda n, rev: getattr(self.rnn, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))
+                xp_f = AG.conv(x, g('weight_ih', False), g('bias_ih', False))
+                xp_b = AG.conv(x, g('weight_ih', True), g('bias_ih', True))
+                x = AG.bilstm(xp_f, xp_b, g('weight_hh', False), g('bias_hh', False), g('weight_hh', True), g('bias_hh', True))
+                if p > 0:   # inter-layer dropout of nn.LSTM, and (after the last layer) the dropout in front of the projection
+                    x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)
+            return AG.conv(x, self.postnet.weight, self.postnet.bias)
         for layer in range(self.rnn_layers):
             out = torch.empty(B, T, 2 * H, device=x.device, dtype=torch.float32)
             g = lambda n, rev: getattr(self.rnn, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))

@@ -21,19 +21,20 @@ class _ConvFn(Function):
     """y = [act(conv1d/linear(pool?(x)) + b) (+ res)] (* mask), channels-last"""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, mask, pad, Tout, act, pool_prev):
+    def forward(ctx, x, w, b, res, mask, pad, Tout, act, pool_prev, stride=1):
         assert not (res is not None and (act is not None or mask is not None)), 'residual only after a linear map'
         assert mask is None or act in (None, 'relu'), 'dropout mask is fused only after relu / identity'
+        assert stride == 1 or (not pool_prev and Tout is None), 'strided conv: plain form only'
         x = x.contiguous()
-        y = ops.gemm(x, w, pad=pad, Tout=Tout, bias=b, act_pre=act, res=res, mask=mask, pool_prev=pool_prev)
+        y = ops.gemm(x, w, pad=pad, stride=stride, Tout=Tout, bias=b, act_pre=act, res=res, mask=mask, pool_prev=pool_prev)
         ctx.save_for_backward(x, w, y if act is not None else None, mask)
-        ctx.cfg = (pad, act, pool_prev, b is not None, res is not None)
+        ctx.cfg = (pad, act, pool_prev, b is not None, res is not None, stride)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y, mask = ctx.saved_tensors
-        pad, act, pool_prev, has_b, has_res = ctx.cfg
+        pad, act, pool_prev, has_b, has_res, stride = ctx.cfg
         dy = dy.contiguous()
         N = w.shape[0]
         KT = w.shape[2] if w.dim() == 3 else 1
@@ -49,6 +50,16 @@ class _ConvFn(Function):
         else:
             Bn, Tin, Cin = 1, x.shape[0], x.shape[1]
             To = dy.shape[0]
+        if has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(_rows(dpre))
+        if stride > 1:
+            # a stride-s conv is the stride-1 conv sampled every s positions: its gradients are those of the stride-1 conv for
+            # an output gradient with zeros in between (zero-stuffing; only the speech encoder's second layer takes this path)
+            To1 = Tin + 2 * pad - KT + 1
+            up = torch.empty(Bn, To1, N, device=dpre.device, dtype=torch.float32)
+            ops.fill_(up, 0.0)
+            ops.copy3d(up[:, 0:(To - 1) * stride + 1:stride], dpre.view(Bn, To, N), Bn, To, N)
+            dpre, To = up, To1
         if ctx.needs_input_grad[0]:
             wt = (w.detach().permute(1, 0, 2).flip(2) if w.dim() == 3 else w.detach().t()).contiguous()
             dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pad)
@@ -56,15 +67,13 @@ class _ConvFn(Function):
                 dx = ops.pool_prev_bwd(dx, x)
         if ctx.needs_input_grad[1]:
             dw = ops.gemm_wgrad(dpre, x, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_prev).view(w.shape)
-        if has_b and ctx.needs_input_grad[2]:
-            db = ops.colsum(_rows(dpre))
         dres = dy if has_res and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
-def conv(x, w, b=None, *, pad=0, Tout=None, act=None, res=None, mask=None, pool_prev=False):
+def conv(x, w, b=None, *, pad=0, Tout=None, act=None, res=None, mask=None, pool_prev=False, stride=1):
     """differentiable ops.gemm (conv1d over channels-last rows, or linear when w is 2-D)"""
-    return _ConvFn.apply(x, w, b, res, mask, pad, Tout, act, pool_prev)
+    return _ConvFn.apply(x, w, b, res, mask, pad, Tout, act, pool_prev, stride)
 
 
 def linear(x, w, b=None, act=None, mask=None):
@@ -168,6 +177,69 @@ def gather(table, idx):
     return _GatherFn.apply(table, idx)
 
 
+class _SoftmaxArgmaxFn(Function):
+    """p = softmax(logits, -1) with the argmax as a by-product (SeperateEmbedding.forward, src/embed.py:190-193)"""
+
+    @staticmethod
+    def forward(ctx, logits):
+        p, idx = ops.softmax_argmax(logits.contiguous())
+        ctx.save_for_backward(p)
+        ctx.mark_non_differentiable(idx)
+        return p, idx
+
+    @staticmethod
+    def backward(ctx, dp, _didx):
+        p, = ctx.saved_tensors
+        return ops.softmax_bwd(p, dp.contiguous())
+
+
+def softmax_argmax(logits):
+    return _SoftmaxArgmaxFn.apply(logits)
+
+
+class _VqL2Fn(Function):
+    """L2Embedding.forward with stop_grad=True (src/embed.py:105-147): p_code = softmax(relu(temp) * neg_batch_l2(x, table)),
+    idx = argmax, new_latent = x + table[idx] - x.detach() (straight-through).  Backward (what autograd derives there):
+        g      = relu(temp) * softmax'(dp_code)                       (n, V)
+        dx     = dnew_latent + 2 (g E) - 2 x rowsum(g)
+        dtable = scatter_add(dnew_latent by idx) + [rows < n_real:] 2 (g^T x) - 2 E colsum(g)
+    `n_real` rows (first_n_real_mel * S, or all) let the p_code objectives reach the table (:115-122)."""
+
+    @staticmethod
+    def forward(ctx, x, table, temp, n_real):
+        x = x.contiguous()
+        p, idx, out = ops.vq_l2(x, table, temp)
+        ctx.save_for_backward(x, table, temp, p, idx)
+        ctx.n_real = n_real
+        ctx.mark_non_differentiable(idx)
+        return p, out, idx
+
+    @staticmethod
+    def backward(ctx, dp, dlat, _didx):
+        x, table, temp, p, idx = ctx.saved_tensors
+        V, D = table.shape
+        x2, dl2 = _rows(x), _rows(dlat.contiguous())
+        n = x2.shape[0]
+        n_real = n if ctx.n_real is None else ctx.n_real
+        g, rs = ops.softmax_bwd(_rows(p), _rows(dp.contiguous()), 1.0, temp, want_rowsum=True)
+        dx = dtab = None
+        if ctx.needs_input_grad[0]:
+            ge = ops.gemm(g, table.detach().t().contiguous())                      # (n, D) = g E
+            dx = ops.rowscale_combine(ge, 2.0, x2, rs.reshape(-1), -2.0, dl2).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dtab = ops.scatter_add_rows(dl2, idx.reshape(-1), V)
+            if n_real > 0:
+                gx = ops.gemm_wgrad(g[:n_real], x2[:n_real])                       # (V, D) = g^T x over the real rows
+                cs = ops.colsum(g[:n_real])
+                dtab = ops.rowscale_combine(gx, 2.0, table.detach().contiguous(), cs, -2.0, dtab)
+        return dx, dtab, None, None
+
+
+def vq_l2(x, table, temp, n_real=None):
+    """-> (p_code, new_latent, idx)"""
+    return _VqL2Fn.apply(x, table, temp, n_real)
+
+
 class _BiLstmFn(Function):
     """Bidirectional nn.LSTM layer over precomputed input projections (lengths ignored, zero initial state).
     ref: src/module.py:432-438,:458-460"""
@@ -229,6 +301,18 @@ class _BiGruFn(Function):
 
 def bigru(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
     return _BiGruFn.apply(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b)
+
+
+def ctc_loss(prob, text, eps=1e-10):
+    """torch.nn.CTCLoss()(log(prob + eps).transpose(0, 1), nonzero tokens of text, all frames, tokens per row): the paired ASR
+    loss of bin/train_vqvae.py:430-444.  prob (B, T, V) posteriors over the codebook (index 0 = blank), text (B, L) int64."""
+    import torch.nn.functional as F
+    B, T, _ = prob.shape
+    lp = (prob + eps).transpose(0, 1).log()
+    tgt_len = (text != 0).sum(dim=-1)
+    targets = text[text != 0]
+    in_len = torch.full((B,), T, dtype=torch.long, device=prob.device)
+    return F.ctc_loss(lp, targets, in_len, tgt_len, blank=0, reduction='mean')
 
 
 # --------------------------------------------------------------------------------------------- decoder loop

@@ -11,7 +11,6 @@ int at_launch(const AtArgs& a, hipStream_t stream) {
     ST_CHECK_ARG(PART == 1 || st_aligned16(a.memory), "attention step: memory must be 16-byte aligned");
     ST_CHECK_ARG((a.A % 4 != 0) || (st_aligned16(a.pm) && st_aligned16(a.pq) && st_aligned16(a.v)),
                  "attention step: pm/pq/v must be 16-byte aligned");
-    ST_CHECK_ARG(PART == 1 || a.pq || (PART == 2 && a.pq_slab), "attention step: no processed query");
     ST_CHECK_ARG(PART == 1 || a.ctx || a.ctx_dst[0].base, "attention step: no context output");
     ST_CHECK_ARG(PART == 0 || (a.s_buf && ((a.A % 4 != 0) || st_aligned16(a.s_buf))), "attention step: S buffer missing / unaligned");
     ST_CHECK_ARG(!a.h_q || (a.ada_std && a.ada_mean && a.h_adapt), "attention step: AdaIN pointers");
@@ -31,21 +30,6 @@ int at_launch(const AtArgs& a, hipStream_t stream) {
     const int nwg = a.B * (PART == 1 && a.pre_parts > 1 ? a.pre_parts : PART == 2 && a.fin_parts > 1 ? a.fin_parts : 1);
     // (a 256-thread form of the fin part -- one wave per SIMD -- measured SLOWER: 11968 vs 10376 cycles; the serial stretches
     // are bound by dependent-issue latency, not by two waves sharing a SIMD)
-    if (PART == 2 && a.pq_slab) {
-        // the processed query arrives as partial-sum slabs (query projection folded into the query LSTM's epilogue)
-        ST_CHECK_ARG(vec && a.A <= 256 && a.pq_nslab > 0 && a.pq_rows >= a.B && st_aligned16(a.pq_slab),
-                     "attention fin part: the folded query projection needs A %% 4 == 0, A <= 256, aligned operands (A=%d)", a.A);
-        static bool conf2 = false;
-        if (!conf2) {
-            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel<true, 2, AT_THREADS, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            conf2 = true;
-        }
-        hipLaunchKernelGGL((at_kernel<true, 2, AT_THREADS, true>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a.pq, a.pm, a.v, a.w_cum_prev,
-                           a.memory, a.s_buf, a.L, a.A, a.E, a.fin_parts, a);
-        ST_LAUNCH_CHECK();
-        return 0;
-    }
     if (vec) hipLaunchKernelGGL((at_kernel<true, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a.pq, a.pm, a.v, a.w_cum_prev, a.memory,
                                 a.s_buf, a.L, a.A, a.E, a.fin_parts, a);
     else hipLaunchKernelGGL((at_kernel<false, PART>), dim3(nwg), dim3(AT_THREADS), lds_bytes, stream, a.pq, a.pm, a.v, a.w_cum_prev, a.memory,
@@ -112,7 +96,6 @@ extern "C" int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wpre
 extern "C" int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
                                    float* w_out, int ld_wout, float* w_cum_out, const float* v,
                                    const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx, int parts,
-                                   const float* pq_slab, int pq_nslab, int pq_rows,
                                    int B, int L, int A, int E, int F, int K, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(n_ctx_dst >= 0 && n_ctx_dst <= 3 && (n_ctx_dst == 0 || ctx_dst), "st_attn_fin_t16_fwd: n_ctx_dst=%d", n_ctx_dst);
@@ -124,8 +107,6 @@ extern "C" int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const fl
     a.w_out = w_out; a.ld_wout = ld_wout; a.w_cum_out = w_cum_out; a.v = v; a.ctx = ctx; a.ld_ctx = ld_ctx;
     a.loc_lin_w = s_buf;     // (unused by this part; only its alignment is looked at)
     a.fin_parts = parts;
-    a.pq_slab = pq_slab; a.pq_nslab = pq_nslab; a.pq_rows = pq_rows;
-    if (pq_slab && !pq) a.pq = pq_slab;      // (only its alignment is looked at)
     for (int d = 0; d < n_ctx_dst; ++d) a.ctx_dst[d] = ctx_dst[d];
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
     return at_launch<2>(a, (hipStream_t)stream);

@@ -46,9 +46,6 @@ struct AtArgs {
     int pre_parts;     // pre part only: workgroups per utterance, each a contiguous range of positions (1, 2 or 4)
     int fin_parts;     // fin part only: workgroups per utterance, each a slice of the context dims E (1, 2, 4 or 8); every one
                        // repeats the energies + softmax (cheap), so the memory rows -- the bulk of the bytes -- are spread over more CUs
-    // fin part, optional: the processed query arrives as partial sums (one slab per pair of LSTM row tiles, written by the query
-    // LSTM's epilogue: st_lstm_cell_packed_fwd pq_slab) instead of pq; slab g holds (pq_rows, A) floats
-    const float* pq_slab; int pq_nslab; int pq_rows;
     int B, L, A, E, F, K;
 };
 
@@ -88,7 +85,7 @@ __device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
 // S[l][a] = pm[l][a] + sum_f W_l[a][f] cf[f][l] -- written to a.s_buf; it can run while the rest of the decode step does
 // (as extra workgroups of the proj launch, skinny_packed.hip).  PART 2 ("fin"): energies from S, softmax, context.
 // NT = threads per workgroup (512 in every launch; a 256-thread fin part measured slower, see attention.hip)
-template <bool VEC, int PART, int NT = AT_THREADS, bool FOLD = false>
+template <bool VEC, int PART, int NT = AT_THREADS>
 __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* lds) {
     constexpr int NWV = NT / 64;                      // waves
     constexpr int PFR = AT_PF * (AT_THREADS / NT);    // memory rows parked in registers per thread
@@ -120,19 +117,6 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
     const int pad = (K - 1) / 2;
 
     AT_PROF(0);
-    // ---- fin part with the folded query projection: pq(b, :) = sum over the slabs, in a fixed order.  Wave w requests slabs
-    // w, w + 8, ... (one 16-byte value per lane and slab: a whole (A <= 256)-float row per wave load) before anything else;
-    // they are added up after the other operand requests below have been issued.
-    constexpr int SLB = 16;
-    f32x4 slab4[FOLD ? SLB : 1];
-    const float* slab_b = nullptr;
-    size_t slab_gs = 0;
-    if (FOLD) {
-        slab_b = a.pq_slab + (size_t)b * A + min(lane * 4, A - 4);
-        slab_gs = (size_t)a.pq_rows * A;
-#pragma unroll
-        for (int i = 0; i < SLB; ++i) slab4[i] = st_ld4(slab_b + (size_t)min(wave + i * NWV, a.pq_nslab - 1) * slab_gs);
-    }
     // ---- fin part: the operands of the energy phase are requested first (nothing is staged in LDS for this part, so the
     // wave's first block of S rows, pq and v can be in flight from the first instruction on), then cum_prev for the softmax
     const float* pmb = (PART == 2 ? a.s_buf : a.pm) + (size_t)b * L * A;
@@ -149,7 +133,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                 pf_pm4[i][j] = st_ld4(pmb + (size_t)l * A + min(lane * 4, A - 4));
             }
         }
-        if (!FOLD) pf_pq4 = st_ld4(pqb + min(lane * 4, A - 4));
+        pf_pq4 = st_ld4(pqb + min(lane * 4, A - 4));
         pf_v4 = st_ld4(a.v + min(lane * 4, A - 4));
         if (wave == 0) pf_cum = a.w_cum_prev[(size_t)b * L + min(lane, L - 1)];
     }
@@ -178,29 +162,6 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
             mpf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, ctx_active ? v0 + j * vstep : v0, 0, 0));
     }
 
-    if (FOLD) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < SLB; ++i) {
-            const bool on = wave + i * NWV < a.pq_nslab;
-            acc[0] += on ? slab4[i][0] : 0.0f; acc[1] += on ? slab4[i][1] : 0.0f;
-            acc[2] += on ? slab4[i][2] : 0.0f; acc[3] += on ? slab4[i][3] : 0.0f;
-        }
-        for (int g2 = wave + SLB * NWV; g2 < a.pq_nslab; g2 += NWV) {      // more than 128 slabs (Q > 1024)
-            const f32x4 t = st_ld4(slab_b + (size_t)g2 * slab_gs);
-            acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3];
-        }
-        // the 8 waves' partial rows meet in LDS (the region of the context partials, free until P4) and every wave adds them
-        // in wave order
-        *reinterpret_cast<f32x4*>(part + wave * 256 + lane * 4) = acc;
-        st_lds_barrier();
-        pf_pq4 = *reinterpret_cast<const f32x4*>(part + lane * 4);
-#pragma unroll
-        for (int w = 1; w < NWV; ++w) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(part + w * 256 + lane * 4);
-            pf_pq4[0] += t[0]; pf_pq4[1] += t[1]; pf_pq4[2] += t[2]; pf_pq4[3] += t[3];
-        }
-    }
     AT_PROF(1);
     const bool wl_vec = VEC || ((F & 3) == 0 && st_aligned16(a.loc_lin_w));
     const int f4n = F >> 2;
@@ -435,7 +396,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                     const int l = l0 + j < L ? l0 + j : L - 1;
                     pm4[j] = st_ld4(pmb + (size_t)l * A + a0);
                 }
-                pq4 = FOLD ? pf_pq4 : st_ld4(pqb + a0);      // (fold: A <= 256, so a0 == lane * 4)
+                pq4 = st_ld4(pqb + a0);
                 v4 = st_ld4(a.v + a0);
             } else {
 #pragma unroll
@@ -594,13 +555,13 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
 
 // (leading scalar arguments: handed over in user SGPRs at wave launch with -mllvm -amdgpu-kernarg-preload-count=16, so the
 // operand requests at kernel entry do not wait for a scalar-cache round trip on the argument block)
-template <bool VEC, int PART, int NT = AT_THREADS, bool FOLD = false>
+template <bool VEC, int PART, int NT = AT_THREADS>
 __global__ __launch_bounds__(NT) void at_kernel(const float* pq, const float* pm, const float* v, const float* w_cum_prev, const float* memory,
                                                 float* s_buf, const int L, const int A, const int E, const int fin_parts, const AtArgs rest) {
     extern __shared__ __attribute__((aligned(16))) float at_lds[];
     AtArgs a = rest;
     a.pq = pq; a.pm = pm; a.v = v; a.w_cum_prev = w_cum_prev; a.memory = memory; a.s_buf = s_buf; a.L = L; a.A = A; a.E = E; a.fin_parts = fin_parts;
-    at_body<VEC, PART, NT, FOLD>(a, blockIdx.x, at_lds);
+    at_body<VEC, PART, NT>(a, blockIdx.x, at_lds);
 }
 
 }  // namespace

@@ -19,12 +19,11 @@
 
 extern "C" size_t st_packed_weight_floats(const int* k, int nseg, int N, int lstm_H);
 extern "C" size_t st_t16_floats(int B, int K);
-extern "C" size_t st_fold_weight_floats(int K);
 
 namespace {
 
 struct PackedLayout {   // offsets (floats) of the six packed matrices inside the packed buffer
-    size_t q, pq, d, pg, p0, p1, pqf, total;
+    size_t q, pq, d, pg, p0, p1, total;
 };
 
 PackedLayout packed_layout(const st_decoder_dims* d) {
@@ -37,7 +36,6 @@ PackedLayout packed_layout(const st_decoder_dims* d) {
     { int k[2] = {d->D, d->E}; o.pg = p; p += st_packed_weight_floats(k, 2, in_dim + 1 + (d->fuse_pre0 ? d->P : 0), 0); }
     { int k[1] = {in_dim}; o.p0 = p; p += st_packed_weight_floats(k, 1, d->P, 0); }
     { int k[1] = {d->P}; o.p1 = p; p += st_packed_weight_floats(k, 1, d->P, 0); }
-    o.pqf = p; p += st_fold_weight_floats(d->Q);     // W_q in the fold layout (query projection inside the query LSTM's epilogue)
     o.total = p;
     return o;
 }
@@ -126,7 +124,6 @@ extern "C" int st_decoder_pack(const st_decoder_weights* w, const st_decoder_dim
         if ((rc = st_pack_weight(ws, ld, k, 1, d->P, 0, packed + pl.p0, stream))) return rc; }
     {   const float* ws[1] = {w->prenet_w1}; int ld[1] = {d->P}, k[1] = {d->P};
         if ((rc = st_pack_weight(ws, ld, k, 1, d->P, 0, packed + pl.p1, stream))) return rc; }
-    if (d->A <= 256 && d->Q % 8 == 0 && (rc = st_pack_fold_weight(w->attn_query_w, d->Q, d->A, d->Q, packed + pl.pqf, stream))) return rc;
     return 0;
 }
 
@@ -196,10 +193,6 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     // distributed side jobs over four launches of the step -- all slower than the plain chain of dependent launches.
     const bool split_attn = io->attn_s_buf != nullptr;
     const bool pre_in_pq = split_attn && defer;
-    // query projection folded into the query LSTM (io->pq_slab set by the host): its workgroups emit rank-8 partial products of
-    // W_q h_q from their epilogues and the attention's fin part adds the slabs -- the pq launch (1 MB, ~5 us of latency) is gone
-    const bool fold_pq = io->pq_slab && split_attn && !defer && st_lstm_pq_fold_supported(B, Q, A);
-    const int pq_rows = ((B + 15) >> 4) * 16;
     const int fp_req = io->attn_fin_parts;
     const int fin_parts = (fp_req == 2 || fp_req == 4 || fp_req == 8) && E % (4 * fp_req) == 0 ? fp_req : 1;
 #ifdef ST_ABLATE   // timing experiments only (tools/gpu_ablate.sh builds a SEPARATE library with this macro): skip launches by bit mask
@@ -225,8 +218,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                      io->cq_tape + (size_t)t * BQ, Q, io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
                                      &hq_dst, nullptr, io->cq_tape + (size_t)(t + 1) * BQ, Q,
                                      io->gates_q_tape ? io->gates_q_tape + (size_t)t * 4 * BQ : nullptr,
-                                     io->ada_std, io->ada_mean, &ha_dst,
-                                     fold_pq ? io->packed + pl.pqf : nullptr, fold_pq ? io->pq_slab : nullptr, A, B, Q, stream);
+                                     io->ada_std, io->ada_mean, &ha_dst, B, Q, stream);
         if (rc) return rc;
 
         // 2. processed query                                             ref: :380
@@ -238,7 +230,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                                      io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
                                                      &job, stream);
-        } else if (!fold_pq && !ST_SKIPPED(1))
+        } else if (!ST_SKIPPED(1))
             rc = st_skinny_linear_packed_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                              io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A, stream);
         if (rc) return rc;
@@ -249,11 +241,10 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
         if (ST_SKIPPED(2)) rc = 0;
         else if (split_attn)     // S of this step was written by the pre part (step 0: no history yet, S = pm)
-            rc = st_attn_fin_t16_fwd(fold_pq ? nullptr : io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats,
-                                     io->memory, io->wcum_tape + (size_t)t * BL,
+            rc = st_attn_fin_t16_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats, io->memory,
+                                     io->wcum_tape + (size_t)t * BL,
                                      io->align_out + (size_t)t * L, ldal, io->wcum_tape + (size_t)(t + 1) * BL, w->attn_v,
-                                     ctx_dst, 3, nullptr, 0, fin_parts, fold_pq ? io->pq_slab : nullptr, Q / 8, pq_rows,
-                                     B, L, A, E, d->F, d->K, stream);
+                                     ctx_dst, 3, nullptr, 0, fin_parts, B, L, A, E, d->F, d->K, stream);
         else
             rc = st_attn_step_t16_fwd(io->pq_buf, io->pm, io->memory, w_prev, t == 0 ? L : ldal,
                                       io->wcum_tape + (size_t)t * BL, io->align_out + (size_t)t * L, ldal,
@@ -270,7 +261,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                      io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                      &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                      io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
-                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, D, stream);
+                                     nullptr, nullptr, nullptr, B, D, stream);
         if (rc) return rc;
 
         // 5. mel frames + stop logit (+ prenet layer 1 of the next input when fused)   ref: :282-287
@@ -283,13 +274,13 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                w->attn_loc_conv_w, w->attn_loc_lin_w,
                                split_attn ? io->attn_s_buf + (size_t)(t + 1) * io->attn_s_step_floats : nullptr, L, A, d->F, d->K,
                                io->attn_pre_parts, io->attn_loc_tape ? io->attn_loc_tape + (size_t)(t + 1) * BL * d->F : nullptr};
-        if (!ST_SKIPPED(4)) rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
+        if (!ST_SKIPPED(4)) rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, ST_SKIPPED(7) ? Ko / 4 : Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
                                                  io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
                                                  io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
                                                  fuse ? in_dim + 1 : 0, ST_ACT_RELU,
                                                  io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
                                                  fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0),
-                                                 split_attn && t + 1 < steps ? &job : nullptr, stream);
+                                                 split_attn && t + 1 < steps && !ST_SKIPPED(6) ? &job : nullptr, stream);
         if (rc) return rc;
 
         // 6. next decoder input -> xq_{t+1}[dec_in part]                 ref: :190-206

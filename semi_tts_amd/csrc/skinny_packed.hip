@@ -91,20 +91,6 @@ __global__ __launch_bounds__(256) void untile_rows_kernel(const float* src, int 
     }
 }
 
-// Fold layout of a small linear's weight w (N <= 256, K) for the partial product in the LSTM epilogue (pk_lstm_rt2_kernel):
-// [K/8 groups of 8 input columns][8 waves][64 lanes][4 floats], float c of lane l of wave w = w[a][u] with
-// a = 16 * (w + 8 * (c >> 1)) + (l & 15), u = 8 * group + 4 * (c & 1) + (l >> 4)  -- the MFMA A fragments (16 outputs x 4 inputs)
-// of output tiles w and w + 8 for the two k-steps of the group; each wave reads ONE 16-byte value per lane.
-__global__ __launch_bounds__(256) void pack_fold_kernel(const float* w, int ldw, int N, int K, float* out) {
-    const size_t total = (size_t)(K >> 3) * 2048;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx & 3), lane = (int)((idx >> 2) & 63), wave = (int)((idx >> 8) & 7);
-        const int gp = (int)(idx >> 11);
-        const int a = 16 * (wave + 8 * (c >> 1)) + (lane & 15), u = 8 * gp + 4 * (c & 1) + (lane >> 4);
-        out[idx] = (a < N && u < K) ? w[(size_t)a * ldw + u] : 0.0f;
-    }
-}
-
 // element offset (in floats) of (b, k) in a T16 buffer with KB k-blocks
 __device__ __forceinline__ size_t t16_off(int b, int k, int KB) {
     return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
@@ -126,9 +112,6 @@ struct PkArgs {
     float* c_out; int ldc; float* gates_out;
     PkOut h_dst[2];                                                        // tiled destinations of the new h
     const float* ada_std; const float* ada_mean; PkOut ha_dst;             // optional AdaIN of the new h
-    // optional rank-(4*RT) partial of a linear on the NEW h (the attention's query projection folded into the query LSTM):
-    // pq_w = that linear's weight in the fold layout (st_pack_fold_weight), pq_slab (tile pairs, padded rows, pq_A) out
-    const float* pq_w; float* pq_slab; int pq_A; int pq_rows;
     // linear epilogue
     const float* bias; int act; const float* lmask; int ldmask;
     float* y; int ldy; PkOut y_dst; int n_split; float* y2; int ldy2; int rep;
@@ -390,7 +373,7 @@ template <int KW, int TRIP, int NB>
 __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, const f32x4* xp, const int w_kbs, const int x_kbs, const int KB,
                                                           const int B, const int H, const PkArgs rest) {
     constexpr int RT = 2;
-    __shared__ f32x4 red[KW * RT * NB * 64 + RT * NB * 16];     // partial sums of the KW waves + the new-h tile of the query-projection fold
+    __shared__ f32x4 red[KW * RT * NB * 64];
     const PkArgs& a = rest;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile0 = blockIdx.x * RT, bt_base = blockIdx.y * NB;          // host: B in 49..64, so both batch tiles of a half exist
@@ -442,9 +425,7 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
     float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f};
     float e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
     const float* dummy = reinterpret_cast<const float*>(wp);
-    f32x4 pq_w4 = {0.f, 0.f, 0.f, 0.f};     // fold layout: [tile pair][wave][lane][(tile w, k-step 0), (w, 1), (w + 8, 0), (w + 8, 1)]
     auto epi_prefetch = [&]() __attribute__((always_inline)) {
-        pq_w4 = *reinterpret_cast<const f32x4*>((a.pq_w ? a.pq_w + ((size_t)blockIdx.x * KW + wave) * 256 : dummy) + lane * 4);
         if (e_on) {
             const float* pbi = a.b_ih ? a.b_ih + u : dummy;
             const float* pbh = a.b_hh ? a.b_hh + u : dummy;
@@ -477,68 +458,30 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) red[((wave * RT + rt) * NB + bt) * 64 + lane] = acc[rt][bt];
     __syncthreads();
-    const bool fold = a.pq_slab != nullptr;              // (wave-uniform; set by the host for the query LSTM of the decode loop)
-    float* hs = reinterpret_cast<float*>(red);           // [RT * 4 units][NB * 16 rows] new h, rows past B zero (reuses wave 0's slab slot:
-    //                                                      read by the epilogue waves before the barrier below, written after their reads)
-    if (tid < RT * NB * 64) {
-        f32x4 s = red[(e_rt * NB + e_bt) * 64 + lane];
+    if (tid >= RT * NB * 64) return;
+    f32x4 s = red[(e_rt * NB + e_bt) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < KW; ++w) {
-            const f32x4 t = red[((w * RT + e_rt) * NB + e_bt) * 64 + lane];
-            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
-        }
-        float h2 = 0.0f;
-        if (eb < B) {
-            float e_b[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e_b[r] = (a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f);
-            e_c = a.c_prev ? e_c : 0.0f;
-            e_m = a.mask ? e_m : 1.0f;
-            const float gi = st_sigmoid_fast(s[0] + e_b[0]), gf = st_sigmoid_fast(s[1] + e_b[1]);
-            const float gg = st_tanh_fast(s[2] + e_b[2]), go = st_sigmoid_fast(s[3] + e_b[3]);
-            const float c2 = gf * e_c + gi * gg;
-            h2 = go * st_tanh_fast(c2) * e_m;
-            a.c_out[(size_t)eb * a.ldc + u] = c2;
-            pk_store(a.h_dst[0], eb, u, h2);
-            pk_store(a.h_dst[1], eb, u, h2);
-            if (a.ha_dst.base) pk_store(a.ha_dst, eb, u, e_s * (h2 - e_mu));
-            if (a.gates_out) {
-                float* gp = a.gates_out + (size_t)eb * 4 * H + u;
-                gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
-            }
-        }
-        if (fold) {
-            // every epilogue wave has read all it needs from `red` only when ALL of them are past the reads above: the h tile
-            // therefore lives behind the partial sums (red holds KW * RT * NB * 64 float4; the tile is RT * 4 * NB * 16 floats)
-            hs = reinterpret_cast<float*>(red + KW * RT * NB * 64);
-            hs[(e_rt * 4 + (lane >> 4)) * (NB * 16) + e_bt * 16 + (lane & 15)] = h2;
-        }
+    for (int w = 1; w < KW; ++w) {
+        const f32x4 t = red[((w * RT + e_rt) * NB + e_bt) * 64 + lane];
+        s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
     }
-    if (!fold) return;
-    // ---- partial query projection of this workgroup's RT*4 hidden units (ref: Attention.forward `self.query_layer(query)`,
-    // src/module.py:380): P[a][row] = sum_j Wq[a][u0 + j] h[row][u0 + j] on the matrix cores, one 16-dim tile of `a` at a time
-    // (wave w takes tiles w and w + 8), K = RT*4 = 8 units = two 16x16x4 steps.  The attention launch adds the slabs of all
-    // workgroups in a fixed order, so the launch that used to compute W_q h_q (1 MB of weights, ~5 us of latency) is gone.
-    hs = reinterpret_cast<float*>(red + KW * RT * NB * 64);
-    st_lds_barrier();
-    {
-        const int A = a.pq_A, n_at = A >> 4;
-        const int g = lane >> 4, n = lane & 15;
+    if (eb >= B) return;
+    float e_b[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int at = wave + j * KW;
-            if (at >= n_at) break;
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                f32x4 p = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < RT; ++kk)
-                    p = __builtin_amdgcn_mfma_f32_16x16x4f32(pq_w4[j * 2 + kk], hs[(kk * 4 + g) * (NB * 16) + bt * 16 + n], p, 0, 0, 0);
-                // lane (g, n) holds P[a = at*16 + 4g .. 4g+3][row = n]: one 16-byte store
-                float* dst = a.pq_slab + ((size_t)blockIdx.x * a.pq_rows + (bt_base + bt) * 16 + n) * A + at * 16 + 4 * g;
-                *reinterpret_cast<f32x4*>(dst) = p;
-            }
-        }
+    for (int r = 0; r < 4; ++r) e_b[r] = (a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f);
+    e_c = a.c_prev ? e_c : 0.0f;
+    e_m = a.mask ? e_m : 1.0f;
+    const float gi = st_sigmoid_fast(s[0] + e_b[0]), gf = st_sigmoid_fast(s[1] + e_b[1]);
+    const float gg = st_tanh_fast(s[2] + e_b[2]), go = st_sigmoid_fast(s[3] + e_b[3]);
+    const float c2 = gf * e_c + gi * gg;
+    const float h2 = go * st_tanh_fast(c2) * e_m;
+    a.c_out[(size_t)eb * a.ldc + u] = c2;
+    pk_store(a.h_dst[0], eb, u, h2);
+    pk_store(a.h_dst[1], eb, u, h2);
+    if (a.ha_dst.base) pk_store(a.ha_dst, eb, u, e_s * (h2 - e_mu));
+    if (a.gates_out) {
+        float* gp = a.gates_out + (size_t)eb * 4 * H + u;
+        gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
     }
 }
 
@@ -636,7 +579,6 @@ int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st) {
         ST_LAUNCH_CHECK();
         return 0;
     }
-    ST_CHECK_ARG(!(MODE == 0 && a.pq_slab), "st_lstm_cell_packed_fwd: the query-projection fold needs the 2-D tiled shape (see st_lstm_pq_fold_supported)");
     // a small linear (few row tiles) is bound by what ONE compute unit can pull in (its weight tile + the whole activation
     // operand): one batch tile per workgroup halves the activation bytes per workgroup and doubles the workgroups
     if (MODE == 1 && tiles <= 128 && BT > 1) return pk_launch<MODE, 1>(a, tiles, st);
@@ -732,13 +674,9 @@ extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view*
                                        const st_t16_view* h_dst0, const st_t16_view* h_dst1,
                                        float* c_out, int ldc, float* gates_out,
                                        const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
-                                       const float* pq_w_fold, float* pq_slab, int pq_A,
                                        int B, int H, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && c_out && h_dst0 && h_dst0->base, "st_lstm_cell_packed_fwd: bad arguments");
-    ST_CHECK_ARG(!pq_slab || (pq_w_fold && st_lstm_pq_fold_supported(B, H, pq_A) && st_aligned16(pq_w_fold) && st_aligned16(pq_slab)),
-                 "st_lstm_cell_packed_fwd: query-projection fold not available for B=%d H=%d A=%d", B, H, pq_A);
-    ST_CHECK_ARG(!(hadapt_dst && hadapt_dst->base) || (ada_std && ada_mean), "st_lstm_cell_packed_fwd: AdaIN pointers");
     PkArgs a;
     memset(&a, 0, sizeof(a));
     int rc = pk_fill(a, packed_w, x, K, "st_lstm_cell_packed_fwd");
@@ -749,25 +687,7 @@ extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view*
     a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
     a.h_dst[0] = pk_out(h_dst0); a.h_dst[1] = pk_out(h_dst1);
     a.ada_std = ada_std; a.ada_mean = ada_mean; a.ha_dst = pk_out(hadapt_dst);
-    if (pq_slab) { a.pq_w = pq_w_fold; a.pq_slab = pq_slab; a.pq_A = pq_A; a.pq_rows = ((B + 15) >> 4) * 16; }
     return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
-}
-
-// ---- the attention's query projection folded into the query LSTM (see pk_lstm_rt2_kernel)
-extern "C" int st_lstm_pq_fold_supported(int B, int H, int A) {
-    return H > 0 && H % 8 == 0 && pk_rt2_shape(B, H / 4) && A > 0 && A % 16 == 0 && A <= 256;
-}
-extern "C" size_t st_fold_weight_floats(int K) { return (size_t)(K >> 3) * 2048; }
-extern "C" size_t st_pq_slab_floats(int B, int H, int A) { return (size_t)(H / 8) * (((B + 15) >> 4) * 16) * A; }
-extern "C" int st_pack_fold_weight(const float* w, int ldw, int N, int K, float* out, void* stream) {
-    (void)hipGetLastError();
-    ST_CHECK_ARG(w && out && N > 0 && N <= 256 && K > 0 && K % 8 == 0 && ldw >= K, "st_pack_fold_weight: N=%d (<= 256) K=%d (multiple of 8)", N, K);
-    const size_t total = (size_t)(K >> 3) * 2048;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ldw, N, K, out);
-    ST_LAUNCH_CHECK();
-    return 0;
 }
 
 static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,

@@ -325,6 +325,42 @@ __global__ __launch_bounds__(VQ_WAVES * 64) void softmax_argmax_kernel(const flo
     }
 }
 
+// ---- backward pieces of the codebook lookup (ref: what autograd derives for src/embed.py:105-147 / :187-205) -------------------
+// softmax backward of one row per wave: dz = scale * p * (dp - sum_v dp p); optionally the row sums of dz (they multiply the
+// |x|^2 term of the L2 similarity: zero up to rounding, kept for fidelity)
+__global__ __launch_bounds__(VQ_WAVES * 64) void softmax_bwd_kernel(const float* p, const float* dp, const float* scale_ptr, float scale,
+                                                                    float* dz, float* rowsum, int n, int V) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float sc = scale_ptr ? fmaxf(scale_ptr[0], 0.0f) * scale : scale;       // relu(temp) of the L2 codebook
+    for (int r = blockIdx.x * VQ_WAVES + wave; r < n; r += gridDim.x * VQ_WAVES) {
+        const float* pr = p + (size_t)r * V;
+        const float* dr = dp + (size_t)r * V;
+        float dot = 0.0f;
+        for (int v = lane; v < V; v += 64) dot = fmaf(dr[v], pr[v], dot);
+        dot = st_wave_sum_dpp(dot);
+        float rs = 0.0f;
+        for (int v = lane; v < V; v += 64) {
+            const float g = sc * pr[v] * (dr[v] - dot);
+            dz[(size_t)r * V + v] = g;
+            rs += g;
+        }
+        if (rowsum) { rs = st_wave_sum_dpp(rs); if (lane == 0) rowsum[r] = rs; }
+    }
+}
+
+// out[m][d] = alpha * a[m][d] + beta * x[m][d] * r[m] (+ c[m][d])     (the |x|^2 / |e|^2 terms and the straight-through addend)
+__global__ __launch_bounds__(256) void rowscale_combine_kernel(const float* a, float alpha, const float* x, const float* r, float beta,
+                                                               const float* c, float* out, int M, int D) {
+    const size_t total = (size_t)M * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / D;
+        float v = alpha * a[i];
+        if (x) v = fmaf(beta * r[m], x[i], v);
+        if (c) v += c[i];
+        out[i] = v;
+    }
+}
+
 // ---- run-length merge of the VQ codes (ref: VQVAE.mean_forward, src/vqvae.py:218-257) --------------------------
 // One workgroup per utterance.  Phase 1: argmax of p_code per frame (first maximum wins).  Phase 2: thread 0 walks
 // the frame indices exactly like the reference's Python loop (a new segment starts when the code changes or the
@@ -456,6 +492,28 @@ extern "C" int st_vq_l2_fwd(const float* x, const float* table, const float* tem
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(vq_l2_kernel, dim3(blocks), dim3(VQ_WAVES * 64), lds, (hipStream_t)stream,
                        x, table, temp, p_code, idx, out, n, D, V);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_softmax_bwd(const float* p, const float* dp, const float* relu_scale, float scale, float* dz, float* rowsum,
+                              int n, int V, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(p && dp && dz && n > 0 && V > 0, "st_softmax_bwd: bad arguments");
+    int blocks = (n + VQ_WAVES - 1) / VQ_WAVES;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(blocks), dim3(VQ_WAVES * 64), 0, (hipStream_t)stream, p, dp, relu_scale, scale, dz, rowsum, n, V);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_rowscale_combine(const float* a, float alpha, const float* x, const float* r, float beta, const float* c,
+                                   float* out, int M, int D, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(a && out && M > 0 && D > 0 && ((x == nullptr) == (r == nullptr)), "st_rowscale_combine: bad arguments");
+    size_t blocks = ((size_t)M * D + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rowscale_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, alpha, x, r, beta, c, out, M, D);
     ST_LAUNCH_CHECK();
     return 0;
 }

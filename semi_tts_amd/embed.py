@@ -122,7 +122,15 @@ class L2Embedding(BaseEmbedding):
         if self.training and self.skip_prob > 0 and np.random.rand() < self.skip_prob:
             raise NotImplementedError('skip connection (skip_prob > 0): every shipped config uses 0')
         table = self._table(self.learnable_table)
-        p_code, idx, new_latent = ops.vq_l2(enc_embs.contiguous(), table, self.temp)
+        if self.training and torch.is_grad_enabled():
+            # differentiable: straight-through gradient to enc_embs, p_code -> CTC gradient to enc_embs and (for the first
+            # `first_n_real_mel` utterances, or all of them) to the table, scatter-add of the picked rows      :115-145
+            if isinstance(self.temp, nn.Parameter) and self.temp.requires_grad:
+                raise NotImplementedError("learnable temperature (temp='learnable'): no shipped config")
+            S = enc_embs.shape[1]
+            p_code, new_latent, idx = AG.vq_l2(enc_embs, table, self.temp, first_n_real_mel * S if first_n_real_mel > 0 else None)
+        else:
+            p_code, idx, new_latent = ops.vq_l2(enc_embs.contiguous(), table, self.temp)
         self.last_idx = idx
         return p_code, new_latent, 0, 0
 
@@ -151,6 +159,11 @@ class SeperateEmbedding(BaseEmbedding):
         if not self.stop_grad:
             raise NotImplementedError('ST-onehot variant (stop_grad=False)')
         x = enc_embs.contiguous()
+        if self.training and torch.is_grad_enabled():
+            logits = AG.linear(x, self.asr_final_layer.weight, self.asr_final_layer.bias)
+            p_code, idx = AG.softmax_argmax(logits)                                  # :190-193
+            self.last_idx = idx
+            return p_code, self._lookup(self._table(self.embedding.weight), idx), 0, 0      # :195-197
         logits = ops.gemm(x.view(-1, x.shape[-1]), self.asr_final_layer.weight, bias=self.asr_final_layer.bias)
         p_code, idx = ops.softmax_argmax(logits.view(*x.shape[:-1], -1))             # :190-193
         self.last_idx = idx

@@ -283,8 +283,6 @@ class Decoder(nn.Module):
         self.attn_split = True
         self.attn_pre_parts = None   # workgroups per utterance of the pre part: None = 2, or 4 for long texts (L > 96: 2 % at L = 171)
         self.attn_fin_parts = 2      # workgroups per utterance of the fin part (slices of the context dims)
-        # the attention's query projection folded into the query LSTM launch (st_lstm_cell_packed_fwd pq_slab): one launch less per step
-        self.fold_query_proj = True
 
     # -- helpers ---------------------------------------------------------------------------------
     def _weights_struct(self, keep, fuse_pre0=False):
@@ -465,9 +463,6 @@ class Decoder(nn.Module):
             io.attn_s_buf = ops._p(tapes['attn_s'])
             io.attn_pre_parts = int(self.attn_pre_parts or (4 if L > 96 else 2))
             io.attn_fin_parts = int(self.attn_fin_parts)
-            if self.fold_query_proj and not defer and lib.st_lstm_pq_fold_supported(B, Q, A):
-                tapes['pq_slab'] = torch.empty(int(lib.st_pq_slab_floats(B, Q, A)), **f32)
-                io.pq_slab = ops._p(tapes['pq_slab'])
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
         if defer:

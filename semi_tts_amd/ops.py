@@ -121,14 +121,11 @@ def attn_pre(pm, w_prev, w_cum_prev, loc_conv_w, loc_lin_w, s_buf=None, parts=1)
     return s_buf
 
 
-def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K, parts=1, pq_slab=None):
-    """pq_slab (n_slab, rows, A): the processed query as partial-sum slabs (lstm_cell_packed(pq_slab=...)) instead of pq"""
+def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K, parts=1):
     B, L, E = memory.shape
     A = s_buf.shape[-1]
-    n_slab, rows = (pq_slab.shape[0], pq_slab.shape[1]) if pq_slab is not None else (0, 0)
     check(_lib.load().st_attn_fin_t16_fwd(_p(pq), _p(s_buf), _p(memory), _p(w_cum_prev), _p(w_out), int(w_out.stride(0)),
-                                          _p(w_cum_out), _p(v), None, 0, _p(ctx), int(ctx.stride(0)), int(parts),
-                                          _p(pq_slab), int(n_slab), int(rows), B, L, A, E, int(F_), int(K),
+                                          _p(w_cum_out), _p(v), None, 0, _p(ctx), int(ctx.stride(0)), int(parts), B, L, A, E, int(F_), int(K),
                                           stream_handle()), 'st_attn_fin_t16_fwd')
 
 
@@ -316,6 +313,25 @@ def vq_l2(x, table, temp, scalar_kernel=False):
     check(lib.st_vq_l2_fwd(_p(x), _p(table), _p(temp), _p(p), _p(idx, torch.int64), _p(out), _p(ws), n, D, V, stream_handle()),
           'st_vq_l2_fwd')
     return p, idx, out
+
+
+def softmax_bwd(p, dp, scale=1.0, relu_scale=None, want_rowsum=False):
+    """dz = s * p * (dp - sum(dp * p, -1)) with s = scale * relu(relu_scale[0]); optionally also dz.sum(-1)"""
+    V = p.shape[-1]
+    n = p.numel() // V
+    dz = torch.empty_like(p)
+    rs = torch.empty(p.shape[:-1], device=p.device, dtype=torch.float32) if want_rowsum else None
+    check(_lib.load().st_softmax_bwd(_p(p), _p(dp), _p(relu_scale), float(scale), _p(dz), _p(rs), n, V, stream_handle()), 'st_softmax_bwd')
+    return (dz, rs) if want_rowsum else dz
+
+
+def rowscale_combine(a, alpha, x=None, r=None, beta=0.0, c=None):
+    """alpha * a + beta * r[:, None] * x (+ c), all (M, D) row-major"""
+    M, D = a.shape
+    out = torch.empty_like(a)
+    check(_lib.load().st_rowscale_combine(_p(a), float(alpha), _p(x), _p(r), float(beta), _p(c), _p(out), M, D, stream_handle()),
+          'st_rowscale_combine')
+    return out
 
 
 def softmax_argmax(logits):
@@ -537,22 +553,12 @@ def _vp(v):
 
 
 def lstm_cell_packed(packed_w, x_view, Kpad, b_ih, b_hh, c_prev, h_dst0, c_out, B, H, h_dst1=None, mask=None,
-                     gates_out=None, ada_std=None, ada_mean=None, hadapt_dst=None, pq_w_fold=None, pq_slab=None, pq_A=0):
+                     gates_out=None, ada_std=None, ada_mean=None, hadapt_dst=None):
     """x_view / *_dst: StT16View (see t16_view); Kpad = 16 * (k-blocks to reduce over)"""
     check(_lib.load().st_lstm_cell_packed_fwd(_p(packed_w), C.byref(x_view), int(Kpad), _p(b_ih), _p(b_hh),
                                               _p(c_prev), H, _p(mask), C.byref(h_dst0), _vp(h_dst1), _p(c_out), H,
-                                              _p(gates_out), _p(ada_std), _p(ada_mean), _vp(hadapt_dst),
-                                              _p(pq_w_fold), _p(pq_slab), int(pq_A), int(B), int(H),
+                                              _p(gates_out), _p(ada_std), _p(ada_mean), _vp(hadapt_dst), int(B), int(H),
                                               stream_handle()), 'st_lstm_cell_packed_fwd')
-
-
-def pack_fold_weight(w):
-    """(N <= 256, K % 8 == 0) linear weight -> the fold layout read by lstm_cell_packed(pq_w_fold=...)"""
-    lib = _lib.load()
-    N, K = w.shape
-    out = torch.empty(int(lib.st_fold_weight_floats(K)), device=w.device, dtype=torch.float32)
-    check(lib.st_pack_fold_weight(_p(w), int(w.stride(0)), int(N), int(K), _p(out), stream_handle()), 'st_pack_fold_weight')
-    return out
 
 
 def skinny_linear_packed(packed_w, x_view, Kpad, B, N, y=None, y_dst=None, bias=None, act=None, mask=None,

@@ -242,3 +242,55 @@ class TtsTrainer(BaseSolver):
         self.verbose('%d steps, %d frames in %.2f s (%.0f frames/s incl. first-step set-up)' %
                      (len(self.log), frames, dt, frames / max(dt, 1e-9)))
         return self.log
+
+
+EPS = 1e-10                      # ref: bin/train_vqvae.py:18
+
+
+class VqvaeTrainer(TtsTrainer):
+    """The speech -> text -> speech cycle of VqvaeTrainer.exec (bin/train_vqvae.py:139-176,208-270) on synthetic batches:
+
+        pair_prob, _, unpair_prob, unpair_latent, unpair_len = model.speech_to_text(aug_mel, unpair_aug_mel)
+        mel, linear, ..., unpair_mel, unpair_linear, ...     = model.text_to_speech(text, sid, unpair_sid, unpair_latent, ...)
+        loss = asr_weight * CTC(log(pair_prob + EPS), text) + tts_weight * (freq_loss(mel) + freq_loss(linear))
+               [+ unpair_speech_weight * (freq_loss(unpair_mel) + freq_loss(unpair_linear))]
+        loss.backward(); all-reduce; clip_grad_norm_(5.0); optimizer.step()
+
+    Everything between the inputs and the gradients runs on the HIP kernels: the CTC speech encoder and its backward
+    (asr.py), the codebook lookup with the straight-through estimator (autograd.vq_l2), the run-length merge (autograd.mean_forward),
+    the TTS branch, the CTC loss (autograd.ctc_loss)."""
+
+    def ctc_loss(self, prob, text):
+        """compute_ctcloss with paras.actual_len = False (bin/train_vqvae.py:430-444): every frame counts, the targets are the
+        non-zero tokens; torch.nn.CTCLoss() defaults (blank 0, mean over the batch of nll / target length)"""
+        from . import autograd as AG
+        return AG.ctc_loss(prob, text, EPS)
+
+    def speech_first_step(self, mel, aug_mel, linear, text, sid, unpair_mel=None, unpair_aug_mel=None, unpair_linear=None,
+                          unpair_sid=None, _masks=None):
+        from . import parallel
+        hp = self.hp
+        parallel.collective_counts(reset=True)
+        tf_rate = self.optimizer.pre_step(self.step)
+        pair_prob, _, unpair_prob, unpair_latent, unpair_latent_len, _, _ = self.model.speech_to_text(
+            paired_mel=aug_mel, unpaired_mel=unpair_aug_mel)
+        ignore_speech_cycle = unpair_latent is None                                               # :163-172
+        out = self.model.text_to_speech(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
+                                        unpair_latent_len, mel, None if ignore_speech_cycle else unpair_mel, tf_rate, _masks=_masks)
+        pm, pl, _, _, upm, upl, _, _ = out
+        asr_loss = self.ctc_loss(pair_prob, text)                                                 # :209
+        tts_loss = self.freq_loss(pm, mel) + self.freq_loss(pl, linear)                           # :221-224
+        total = float(hp.get('asr_weight', 1.0)) * asr_loss + self.tts_weight * tts_loss
+        stats = dict(asr_loss=float(asr_loss.detach()), tts_loss=float(tts_loss.detach()))
+        if not ignore_speech_cycle:                                                               # :227-233
+            un = self.freq_loss(upm, unpair_mel) + self.freq_loss(upl, unpair_linear)
+            total = total + float(hp.get('unpair_speech_weight', 10.0)) * un
+            stats['unpair_speech_loss'] = float(un.detach())
+        total.backward()
+        parallel.allreduce_gradients(self.model.parameters())
+        gn = float(self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP))
+        if gn == gn:
+            self.optimizer.step()
+        self.step += 1
+        stats.update(loss=float(total.detach()), grad_norm=gn, tf_rate=tf_rate)
+        return stats

@@ -109,7 +109,7 @@ def full_hp(prenet_dropout=0.0):
     return hp
 
 
-def tiny_vqvae(meta, weights, device):
+def tiny_vqvae(meta, weights, device, strict=False):
     """HIP VQVAE for the H1 fixture: the phoneme-attribute table comes from the fixture (data), not from a file"""
     from semi_tts_amd.vqvae import VQVAE
     cfg = json.loads(json.dumps(meta['model']))
@@ -124,5 +124,6 @@ def tiny_vqvae(meta, weights, device):
         cb.proj_attr = torch.nn.Linear(attr.shape[1], proj)
         cb.learnable_table = torch.nn.Parameter(torch.zeros(meta['vocab_size'], cfg['codebook']['latent_dim'] - proj))
     missing = m.load_state_dict(weights, strict=False)
-    assert not [k for k in missing.missing_keys if not k.startswith('asr.')], missing.missing_keys
+    assert not [k for k in missing.missing_keys if not (k.startswith('asr.') and not strict)], missing.missing_keys
+    assert not (strict and missing.unexpected_keys), missing.unexpected_keys
     return m.to(device)

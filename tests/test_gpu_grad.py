@@ -549,3 +549,150 @@ def test_checkpoint_round_trip_resumes_training(dev, tmp_path):
     sa, sb = a.model.state_dict(), b.model.state_dict()
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
     assert a.optimizer.opt.state[next(iter(a.model.tts.parameters()))]['_step'] == 3
+
+
+# ------------------------------------------------------------------------------------ codebook lookup / speech encoder backward
+@pytest.mark.parametrize('B,S,D,V,attr,n_real', [(3, 7, 64, 43, True, 0), (4, 9, 64, 512, False, 0), (5, 6, 64, 43, False, 2),
+                                                  (2, 5, 24, 10, False, 0)])
+def test_vq_l2_backward_vs_oracle(dev, B, S, D, V, attr, n_real):
+    """L2Embedding.forward in training mode: straight-through gradient to the latents, p_code gradient to latents and table
+    (only the first `first_n_real_mel` utterances reach the table when set), scatter-add of the picked rows -- against
+    float64 autograd through the oracle (src/embed.py:105-147)."""
+    from oracle import vq_oracle as VQ
+    from semi_tts_amd.embed import L2Embedding
+    torch.manual_seed(B * 100 + V)
+    cb = L2Embedding(V, False, 'normal', D, 0, 0, 1, 0, True)
+    W = {'learnable_table': rnd(V, D - (16 if attr else 0), scale=0.5, seed=1), 'temp': torch.tensor([0.7])}
+    if attr:
+        cb.use_phn_attr = True
+        cb.phn_attr = torch.nn.Embedding.from_pretrained((torch.rand(V, 31) > 0.5).float(), freeze=True, padding_idx=0)
+        cb.proj_attr = torch.nn.Linear(31, 16)
+        W.update({'phn_attr.weight': cb.phn_attr.weight.detach().clone(), 'proj_attr.weight': cb.proj_attr.weight.detach().clone(),
+                  'proj_attr.bias': cb.proj_attr.bias.detach().clone()})
+    cb.learnable_table = torch.nn.Parameter(W['learnable_table'].clone())
+    cb.temp.copy_(W['temp'])
+    cb = cb.to(dev).train()
+    x = rnd(B, S, D, scale=0.6, seed=2)
+    dp, dl = rnd(B, S, V, seed=3), rnd(B, S, D, seed=4)
+    xd = x.to(dev).requires_grad_()
+    p, lat, _, _ = cb(xd, n_real)
+    torch.autograd.backward([p, lat], [dp.to(dev), dl.to(dev)])
+
+    def fn(Wd, xx):
+        pp, idx, nl, _ = VQ.l2_forward(Wd, xx, n_real)
+        return pp, nl
+    outs, wg, ig = oracle_grads(fn, W, [x], [dp, dl])
+    assert torch.equal(cb.last_idx.cpu(), outs[0].argmax(-1))
+    errs = dict(p=maxdiff(p, outs[0]), lat=maxdiff(lat, outs[1]), dx=relerr(xd.grad, ig[0]),
+                dtable=relerr(cb.learnable_table.grad, wg['learnable_table']))
+    if attr:
+        errs['dproj_w'] = relerr(cb.proj_attr.weight.grad, wg['proj_attr.weight'])
+        errs['dproj_b'] = relerr(cb.proj_attr.bias.grad, wg['proj_attr.bias'])
+    report('vq_l2_backward', B=B, V=V, **errs)
+    assert errs['p'] < 5e-5 and errs['lat'] < 1e-5
+    assert all(v < 2e-5 for k, v in errs.items() if k.startswith('d')), errs
+
+
+def test_seperate_embedding_backward_vs_oracle(dev):
+    """SeperateEmbedding.forward in training mode (the codebook of config/supervised.yaml): softmax(Linear) posterior +
+    embedding of the argmax (no straight-through path).  ref: src/embed.py:187-205"""
+    from oracle import vq_oracle as VQ
+    from semi_tts_amd.embed import SeperateEmbedding
+    torch.manual_seed(3)
+    V, D = 43, 64
+    cb = SeperateEmbedding(V, False, 'normal', D, 0, 0, 1, 0, True).to(dev).train()
+    W = {k: v.detach().cpu().clone() for k, v in cb.state_dict().items()}
+    x = rnd(3, 8, D, seed=5)
+    dp, dl = rnd(3, 8, V, seed=6), rnd(3, 8, D, seed=7)
+    xd = x.to(dev).requires_grad_()
+    p, lat, _, _ = cb(xd)
+    torch.autograd.backward([p, lat], [dp.to(dev), dl.to(dev)])
+    outs, wg, ig = oracle_grads(lambda Wd, xx: (lambda r: (r[0], r[2]))(VQ.seperate_forward(Wd, xx)), W, [x], [dp, dl])
+    assert maxdiff(p, outs[0]) < 1e-5 and maxdiff(lat, outs[1]) < 1e-6
+    assert relerr(xd.grad, ig[0]) < 2e-5
+    assert relerr(cb.asr_final_layer.weight.grad, wg['asr_final_layer.weight']) < 2e-5
+    assert relerr(cb.asr_final_layer.bias.grad, wg['asr_final_layer.bias']) < 2e-5
+    assert relerr(cb.embedding.weight.grad, wg['embedding.weight']) < 2e-5
+
+
+def test_ctc_encoder_backward_vs_oracle(dev):
+    """The CTC speech encoder in training mode (stride-2 conv layer, batch-statistics BatchNorm + tanh + residual, 2-layer
+    BiLSTM, projection) against float64 autograd through the oracle.  ref: src/asr.py:46-64, src/module.py:627-648"""
+    from conftest import load_golden
+    from oracle import asr_oracle as AO
+    from semi_tts_amd.asr import CTC
+    W, A, meta = load_golden('asr_tiny_train')
+    cfg = meta['cfg']
+    m = CTC(meta['in_dim'], meta['out_dim'], **cfg)
+    m.load_state_dict(W)
+    m = m.to(dev).train()
+    x = A['x']
+    xd = x.to(dev).requires_grad_()
+    y = m(xd)
+    assert maxdiff(y, A['y']) < 2e-5                     # the differentiable path gives the reference's training-mode output
+    dy = rnd(*y.shape, seed=9)
+    y.backward(dy.to(dev))
+    outs, wg, ig = oracle_grads(lambda Wd, xx: AO.ctc_forward(Wd, xx, cfg, training=True), W, [x], [dy])
+    e = relerr(xd.grad, ig[0])
+    report('ctc_encoder_backward', dx=e)
+    assert e < 2e-4
+    check_param_grads(m, '', wg, 2e-4, 'ctc_encoder_backward')
+
+
+@pytest.mark.parametrize('name', ['speech_first_paired', 'speech_first_unpaired'])
+def test_speech_first_step_against_reference_golden(dev, name):
+    """The speech -> text -> speech training step (bin/train_vqvae.py:159-176,208-270) against what the REAL reference
+    produced for the same weights, batch and dropout masks: CTC loss on the paired posteriors, freq_loss on the paired
+    (and unpaired) reconstructions, the grad norm and EVERY parameter gradient -- speech encoder, codebook (straight-through
+    estimator + p_code path), speaker table and TTS branch."""
+    import json
+    from argparse import Namespace
+    from conftest import load_golden
+    from helpers import masks_to, split_masks, tiny_vqvae
+    from semi_tts_amd.optim import Optimizer
+    from semi_tts_amd.solver import VqvaeTrainer
+    W, A, meta = load_golden(name)
+    hp, h = meta['hp'], meta['hparas']
+    config = dict(data=dict(audio=meta['audio'], corpus=dict(batch_size=3)), hparas=h, model=meta['model'])
+    tr = VqvaeTrainer(config, Namespace(vocab_size=meta['vocab_size'], n_spkr=meta['n_spkr'], verbose=False, max_step=1), 'train')
+    tr.model = tiny_vqvae(meta, W, dev, strict=True).train()
+    tr.optimizer = Optimizer(tr.model.parameters(), h['optimizer'], h['lr'], h['lr_scheduler'], tf_start=h['tf_start'],
+                             tf_end=h['tf_end'], tf_step=h['tf_step'])
+    text, sid, mel, linear = (A[k].to(dev) for k in ('text', 'sid', 'mel', 'linear'))
+    un = {}
+    if meta['with_unpaired']:
+        un = dict(unpair_mel=A['unpair_mel'].to(dev), unpair_aug_mel=A['unpair_mel'].to(dev), unpair_linear=A['unpair_linear'].to(dev),
+                  unpair_sid=A['unpair_sid'].to(dev))
+    Bt = text.shape[0]
+    B = Bt + (A['unpair_mel'].shape[0] if meta['with_unpaired'] else 0)
+    r = hp['n_frames_per_step']
+    steps = max(mel.shape[1], A['unpair_mel'].shape[1] if meta['with_unpaired'] else 0) // r
+    masks = masks_to(split_masks(A['mask'], hp, True, 1.0, B, B, steps, list(range(steps)), hp['prenet_dim']), dev)
+    grads = {}
+    orig = tr.clip_grad_norm_
+
+    def spy(params, max_norm):
+        for kname, p in tr.model.named_parameters():
+            if p.grad is not None:
+                grads[kname] = p.grad.detach().clone()
+        return orig(list(params), max_norm)
+    tr.clip_grad_norm_ = spy
+    st = tr.speech_first_step(mel, mel, linear, text, sid, _masks=masks, **un)
+    ref = meta['stats']
+    assert torch.equal(tr.model.codebook.last_idx.cpu(), A['idx'])                      # VQ indices: bit-exact
+    report('speech_first', name=name, **{k: st[k] for k in ref}, **{'ref_' + k: v for k, v in ref.items()})
+    for k in ('asr_loss', 'tts_loss', 'loss') + (('unpair_speech_loss',) if meta['with_unpaired'] else ()):
+        assert abs(st[k] - ref[k]) < 2e-5 * max(1.0, abs(ref[k])), (k, st[k], ref[k])
+    assert abs(st['grad_norm'] - ref['grad_norm']) < 2e-4 * ref['grad_norm']
+    keys = json.loads(bytes(A['grad_keys']).decode())
+    worst, worst_k = 0.0, ''
+    for k, gref in zip(keys, A['grad']):
+        assert k in grads, 'missing gradient for ' + k
+        if float(gref.abs().max()) < 1e-9:
+            assert float(grads[k].abs().max()) < 1e-4, k
+            continue
+        e = relerr(grads[k], gref)
+        if e > worst:
+            worst, worst_k = e, k
+        assert e < 1e-3, (k, e)              # fp32 HIP vs fp32 reference, different summation orders on both sides
+    report('speech_first_grads', name=name, worst=worst, worst_k=worst_k, n=len(keys))

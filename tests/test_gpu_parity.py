@@ -150,53 +150,6 @@ def test_lstm_cell_packed(dev, B, H, Ks):
     assert maxdiff(gts[:, 3], torch.sigmoid(o)) < 1e-5
 
 
-@pytest.mark.parametrize('B,H,K,A', [(32, 1024, 1792, 256), (20, 64, 48, 48), (64, 256, 320, 256), (50, 40, 32, 16), (17, 8, 16, 64)])
-def test_lstm_cell_packed_with_folded_query_projection(dev, B, H, K, A):
-    """The query LSTM launch also emits rank-8 partial products of the attention's query projection W_q h (one slab per pair
-    of row tiles, exact-fp32 MFMA); the slabs must add up to h @ W_q^T and the attention's fin part must accept them in
-    place of pq (src/module.py:380)."""
-    from semi_tts_amd import _lib, ops
-    lib = _lib.load()
-    assert lib.st_lstm_pq_fold_supported(B, H, A) == 1
-    assert lib.st_lstm_pq_fold_supported(16, H, A) == 0 and lib.st_lstm_pq_fold_supported(B, H, 300) == 0
-    x, c = rnd(B, K, seed=1), rnd(B, H, seed=3)
-    w = rnd(4 * H, K, scale=K ** -0.5, seed=4)
-    b_ih, b_hh = rnd(4 * H, scale=0.1, seed=6), rnd(4 * H, scale=0.1, seed=7)
-    wq = rnd(A, H, scale=H ** -0.5, seed=8)
-    mask = (torch.rand(B, H) > 0.1).float() / 0.9
-    gates = x @ w.t() + b_ih + b_hh
-    i, f, g, o = [gates[:, j * H:(j + 1) * H] for j in range(4)]
-    c_ref = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-    h_ref = torch.sigmoid(o) * torch.tanh(c_ref) * mask
-    packed = ops.pack_weight([w.to(dev)], [K], 4 * H, lstm_H=H, ldws=[K])
-    xbuf, stride = _combined_t16(ops, [x], [K], dev)
-    h_t16 = torch.zeros(ops.t16_floats(B, H), device=dev)
-    c_out = torch.empty(B, H, device=dev)
-    rows = ((B + 15) // 16) * 16
-    slab = torch.full((H // 8, rows, A), float('nan'), device=dev)
-    assert slab.numel() == lib.st_pq_slab_floats(B, H, A)
-    ops.lstm_cell_packed(packed, ops.t16_view(xbuf, stride), 16 * stride, b_ih.to(dev), b_hh.to(dev), c.to(dev),
-                         ops.t16_view(h_t16, K=H), c_out, B, H, mask=mask.to(dev),
-                         pq_w_fold=ops.pack_fold_weight(wq.to(dev)), pq_slab=slab, pq_A=A)
-    h = ops.untile_rows(h_t16, B, H)
-    assert maxdiff(h, h_ref) < 1e-5 and maxdiff(c_out, c_ref) < 1e-5
-    assert bool(torch.isfinite(slab).all()), 'every slab element (padding rows included) must be written'
-    pq = slab.sum(0)[:B]
-    err = maxdiff(pq, h.cpu().double() @ wq.double().t())
-    report('lstm_cell_packed_fold', B=B, H=H, A=A, err=err)
-    assert err < 1e-5
-    assert float(slab[:, B:].abs().max()) == 0.0 if rows > B else True
-    # the fin part of the attention takes the slabs in place of pq: same outputs up to the re-association of the sum
-    L, E, F_, Kc = 13, 64, 8, 7
-    s_buf, mem, wcum, v = rnd(B, L, A, seed=11).to(dev), rnd(B, L, E, seed=12).to(dev), torch.rand(B, L).to(dev), rnd(A, seed=13).to(dev)
-    outs = []
-    for kw in (dict(pq=pq.contiguous()), dict(pq=None, pq_slab=slab)):
-        w_out, wc_out, ctx = torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, E, device=dev)
-        ops.attn_fin(kw['pq'], s_buf, mem, wcum, v, w_out, wc_out, ctx, F_, Kc, parts=2, pq_slab=kw.get('pq_slab'))
-        outs.append((w_out, wc_out, ctx))
-    assert maxdiff(outs[0][0], outs[1][0]) < 1e-6 and maxdiff(outs[0][2], outs[1][2]) < 1e-5 and maxdiff(outs[0][1], outs[1][1]) < 1e-6
-
-
 @pytest.mark.parametrize('B,N,Ks', [(1, 16, (32,)), (4, 40, (24,)), (32, 241, (1024, 512)), (32, 256, (240,)),
                                     (33, 48, (100, 28)), (64, 80, (62,)), (70, 33, (31,))])
 def test_skinny_linear_packed(dev, B, N, Ks):
@@ -578,12 +531,12 @@ def test_headline_shape_c2_against_oracle(dev):
     with torch.no_grad():
         mel, lin, align, stop = m(txt.to(dev), None, 258, spk.to(dev), tf_rate=0.0)
         # the unsplit attention launch and other part counts must give the same values up to re-association
-        for split, fin, fold in ((False, 2, True), (True, 1, True), (True, 4, True), (True, 2, False)):
-            m.decoder.attn_split, m.decoder.attn_fin_parts, m.decoder.fold_query_proj = split, fin, fold
+        for split, fin in ((False, 2), (True, 1), (True, 4)):
+            m.decoder.attn_split, m.decoder.attn_fin_parts = split, fin
             mel_o, _, align_o, _ = m(txt.to(dev), None, 258, spk.to(dev), tf_rate=0.0)
             report('tts_c2_attn_variants', split=int(split), fin=fin, mel=maxdiff(mel_o, mel), align=maxdiff(align_o, align))
             assert maxdiff(mel_o, mel) < 2e-5 and maxdiff(align_o, align) < 1e-5
-        m.decoder.attn_split, m.decoder.attn_fin_parts, m.decoder.fold_query_proj = True, 2, True
+        m.decoder.attn_split, m.decoder.attn_fin_parts = True, 2
     torch.set_num_threads(8)
     with torch.no_grad():
         mel_r, lin_r, align_r, stop_r = O.tacotron2_forward(_oracle_weights(m), txt, 258, spk, full_hp(0.0))

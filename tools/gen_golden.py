@@ -357,6 +357,97 @@ def train_step_case():
     print(stats)
 
 
+def speech_first_case():
+    """The speech -> text -> speech training step of bin/train_vqvae.py:159-217,270 through the REAL reference classes at tiny
+    dimensions: VQVAE.speech_to_text on [paired | unpaired] mel (CTC speech encoder -> L2 codebook with the straight-through
+    estimator -> run-length merge of the unpaired part), VQVAE.text_to_speech with the unpaired latents as extra rows,
+    CTC loss on the paired posteriors + freq_loss on the paired and the unpaired reconstructions, backward, clip.
+    Records inputs, initial weights, dropout masks (the speech encoder's dropout is 0: nn.LSTM's inter-layer dropout cannot be
+    recorded), the losses, the grad norm and EVERY parameter gradient.  Two cases: paired only, and with unpaired speech."""
+    import yaml
+    from functools import partial
+    os.chdir(REF)
+    full = yaml.safe_load(open('config/semi-single-spkr-paired-data.yaml'))
+    cfg = full['model']
+    cfg['decoder'] = json.loads(json.dumps(TINY['paras']))
+    cfg['decoder']['separate_postnet'] = True
+    cfg['spkr_latent_dim'] = TINY['spkr_embed_dim']
+    cfg['encoder'].update(dim=16, rnn_dim=8, dropout=0.0)
+    hp = full['hparas']
+    floss = partial(ref_freq_loss, sample_rate=full['data']['audio']['sample_rate'], n_mels=TINY['n_mels'],
+                    loss=hp['freq_loss_type'], differential_loss=hp['differential_loss'],
+                    emphasize_linear_low=hp['emphasize_linear_low'])
+    ctc = torch.nn.CTCLoss()
+    EPS = 1e-10                                                  # bin/train_vqvae.py:18
+    for name, with_unpaired, seed in (('speech_first_paired', False, 21), ('speech_first_unpaired', True, 22)):
+        torch.manual_seed(seed)
+        m = RefVQVAE(TINY['n_mels'], TINY['linear_dim'], 43, 5, **json.loads(json.dumps(cfg)))
+        g = torch.Generator().manual_seed(seed + 100)
+        with torch.no_grad():
+            randomize_buffers(m.tts, g)
+            randomize_buffers(m.asr, g)
+            # keep the code usage varied at these tiny dimensions: latents comparable in size to the table rows
+            m.codebook.learnable_table.mul_(0.25)
+            m.asr.postnet.weight.mul_(12.0)
+        m.train()
+        w0 = {k: v.clone() for k, v in m.state_dict().items()}
+        B, L, T = 3, 5, 24
+        text = torch.randint(3, 43, (B, L), generator=g)
+        text[:, -1] = 0
+        text[1, -2:] = 0                                          # one shorter transcript
+        sid = torch.randint(0, 5, (B,), generator=g)
+        mel = torch.rand(B, T, TINY['n_mels'], generator=g)
+        linear = torch.rand(B, T, TINY['linear_dim'], generator=g)
+        arrays = dict(text=text, sid=sid, mel=mel, linear=linear)
+        um = ul = usid = None
+        if with_unpaired:
+            Bu, Tu = B, 18                                        # (the reference padded_concat needs equal batch sizes)
+            um = torch.rand(Bu, Tu, TINY['n_mels'], generator=g)
+            ul = torch.rand(Bu, Tu, TINY['linear_dim'], generator=g)
+            usid = torch.randint(0, 5, (Bu,), generator=g)
+            arrays.update(unpair_mel=um, unpair_linear=ul, unpair_sid=usid)
+        np.random.seed(seed)
+        torch.manual_seed(seed + 1)
+        with Recorder() as rec:
+            pair_prob, _, unpair_prob, unpair_latent, unpair_latent_len, _, _ = m.speech_to_text(paired_mel=mel, unpaired_mel=um)
+            assert (not with_unpaired) or unpair_latent is not None, 'an all-blank utterance: pick another seed'
+            out = m.text_to_speech(paired_text=text, paired_sid=sid, unpaired_sid=usid, unpaired_latent=unpair_latent,
+                                   unpaired_text=None, unpaired_latent_len=unpair_latent_len, paired_teacher=mel,
+                                   unpaired_teacher=um, tf_rate=1.0)
+            pm, pl, pa, _, upm, upl, upa, _ = out
+            ctc_in = (pair_prob + EPS).transpose(0, 1).log()                                        # :432
+            ctc_len = torch.LongTensor([pair_prob.shape[1]] * pair_prob.shape[0])                   # :442
+            asr_loss = ctc(ctc_in, text.to_sparse().values(), ctc_len, torch.sum(text != 0, dim=-1))   # :441-444
+            tts_loss = floss(pm, mel) + floss(pl, linear)
+            total = hp['asr_weight'] * asr_loss + hp['tts_weight'] * tts_loss
+            stats = dict(asr_loss=float(asr_loss), tts_loss=float(tts_loss))
+            if with_unpaired:
+                un_loss = floss(upm, um) + floss(upl, ul)                                           # :228-229
+                total = total + hp['unpair_speech_weight'] * un_loss
+                stats['unpair_speech_loss'] = float(un_loss)
+            total.backward()
+        gkeys = [k for k, p in m.named_parameters() if p.grad is not None]
+        arrays['grad'] = [dict(m.named_parameters())[k].grad.clone() for k in gkeys]
+        arrays['grad_keys'] = np.frombuffer(json.dumps(gkeys).encode(), np.uint8)
+        arrays['pair_prob'], arrays['mel_pred'], arrays['linear_pred'] = pair_prob.detach(), pm.detach(), pl.detach()
+        arrays['idx'] = pair_prob.detach().argmax(-1) if not with_unpaired else torch.cat([pair_prob, unpair_prob]).detach().argmax(-1)
+        if with_unpaired:
+            arrays['unpair_latent'], arrays['unpair_latent_len'] = unpair_latent.detach(), unpair_latent_len
+            arrays['unpair_mel_pred'] = upm.detach()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+        stats.update(loss=float(total), grad_norm=float(gn))
+        arrays['mask'] = rec.masks
+        mcfg = json.loads(json.dumps(cfg))
+        mcfg['codebook']['phn_attr_pth'] = ''
+        save(name, w0, arrays, dict(stats=stats, model=mcfg, hparas=hp,
+                                    audio=dict(sample_rate=full['data']['audio']['sample_rate'], num_mels=TINY['n_mels'],
+                                               num_freq=TINY['linear_dim']),
+                                    vocab_size=43, n_spkr=5, hp=dict(TINY['paras']['decoder'], n_mels=TINY['n_mels']),
+                                    with_unpaired=with_unpaired, n_grads=len(gkeys)))
+        print(name, stats, 'grads', len(gkeys), 'masks', len(rec.masks))
+    os.chdir(REPO)
+
+
 def asr_cases():
     """CTC speech encoder (src/asr.py) at tiny dimensions: eval mode, and training mode with dropout 0 (BatchNorm batch
     statistics; the inter-layer dropout of nn.LSTM cannot be recorded, so no dropout case)."""
@@ -389,7 +480,9 @@ def asr_cases():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr']
+    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr', 'speech']
+    if 'speech' in which:
+        speech_first_case()
     if 'asr' in which:
         asr_cases()
     if 'train' in which:

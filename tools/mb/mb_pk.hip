@@ -31,7 +31,7 @@ int main() {
         CK(hipMemset(w, 0, wf * 4)); CK(hipMemset(x, 0, xf * 4)); CK(hipMemset(c0, 0, B * H * 4)); CK(hipMemset(bi, 0, 16 * H)); CK(hipMemset(bh, 0, 16 * H));
         CK(hipMemset(as, 0, B * H * 4)); CK(hipMemset(am, 0, B * H * 4)); CK(hipMemset(h0, 0, hf * 4)); CK(hipMemset(h1, 0, hf * 4)); CK(hipMemset(ha, 0, hf * 4));
         st_t16_view xv = {x, (K + 15) / 16, 0}, d0 = {h0, H / 16, 0}, d1 = {h1, H / 16, 0}, da = {ha, H / 16, 0};
-        auto run = [&] { int rc = st_lstm_cell_packed_fwd(w, &xv, K, bi, bh, c0, H, nullptr, &d0, &d1, c1, H, nullptr, as, am, &da, nullptr, nullptr, 0, B, H, nullptr);
+        auto run = [&] { int rc = st_lstm_cell_packed_fwd(w, &xv, K, bi, bh, c0, H, nullptr, &d0, &d1, c1, H, nullptr, as, am, &da, B, H, nullptr);
             if (rc) { printf("rc=%d %s\n", rc, st_last_error()); exit(1); } };
         float* sink; CK(hipMalloc(&sink, 64));
         float* junk; CK(hipMalloc(&junk, 64 << 20));

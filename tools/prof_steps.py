@@ -15,8 +15,7 @@ def code(n):
     return 'x'
 seq = [(code(n), s, e) for n, s, e in rows]
 text = ''.join(c for c, _, _ in seq)
-for pat, names in (('LALPl', ['LSTM_q (+ query-projection partials)', 'attn (fin part, adds the slabs)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
-                   ('LlALPl', ['LSTM_q', 'pq', 'attn (fin part)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
+for pat, names in (('LlALPl', ['LSTM_q', 'pq', 'attn (fin part)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
                    ('LlALll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj+pre0', 'pre1']),
                    ('LlALlll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj', 'pre0', 'pre1'])):
     dur = collections.defaultdict(list)

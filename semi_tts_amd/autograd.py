@@ -99,14 +99,14 @@ class _BnTrainFn(Function):
         mean, var = ops.bn_stats(x2, 0, N, None if sync else run_mean, None if sync else run_var, momentum)
         Mstat = M
         if sync:
-            # merge the per-rank (count, mean, M2) exactly (Chan et al.); N-vectors only, two small all-reduces
-            buf = torch.cat([mean * M, mean.new_tensor([float(M)])])
-            parallel._COUNTS['syncbn_fwd'] += 2
-            parallel.all_reduce_sum_(buf)
-            Mstat = int(round(float(buf[-1])))
-            gmean = buf[:-1] / Mstat
-            m2 = var * M + (mean - gmean) ** 2 * M
-            parallel.all_reduce_sum_(m2)
+            # ONE collective: every rank's (mean, M2, count), merged exactly and identically on every rank in rank order
+            # (Chan et al.); no host round trip -- the global row count follows from the shard sizes (parallel.global_rows)
+            parallel._COUNTS['syncbn_fwd'] += 1
+            rec = parallel.all_gather_(torch.cat([mean, var * M, mean.new_tensor([float(M)])]))      # (world, 2N + 1)
+            cnt = rec[:, 2 * N:]
+            Mstat = parallel.global_rows(M)
+            gmean = (rec[:, :N] * cnt).sum(0) / Mstat
+            m2 = (rec[:, N:2 * N] + cnt * (rec[:, :N] - gmean) ** 2).sum(0)
             mean, var = gmean, m2 / Mstat
             if run_mean is not None:
                 run_mean.mul_(1 - momentum).add_(mean, alpha=momentum)

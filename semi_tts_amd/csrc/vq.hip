@@ -130,11 +130,11 @@ __global__ __launch_bounds__(VQ_WAVES * 64) void vq_l2_kernel(const float* x, co
 //   * the table is re-packed once per call into MFMA B-operand order (vq_pack_table_kernel, 4*V*D bytes, L2 resident):
 //     [code tile of 16][group of 4 k-steps][lane][4 floats], plus |e|^2 per code -- a wave fetches a tile's operands with
 //     four 16-byte loads per lane;
-//   * a workgroup (4 waves) owns 16 input vectors; wave w scores the code tiles w, w+4, ...: the softmax max / sum and the
-//     argmax are DPP reductions over the 16 lanes that hold one vector's codes, then over the 4 waves through LDS;
+//   * a workgroup (4..16 waves) owns 16 input vectors; wave w scores the code tiles w, w+NW, ...: the softmax max / sum and the
+//     argmax are DPP reductions over the 16 lanes that hold one vector's codes, then over the waves through LDS;
 //   * |x|^2 uses the same summation tree as the scalar kernel's wave butterfly (dims d, d^32 first ... d^1 last).
 // Algorithmic bytes per vector: 4D in + 4D out + 8 idx + 4V p_code; the packed table is read from L2 by every workgroup.
-constexpr int VQM_THREADS = 256, VQM_XLD = 68;
+constexpr int VQM_XLD = 68;
 
 __global__ __launch_bounds__(256) void vq_pack_table_kernel(const float* table, int V, int D, float* ws, int n_ct, int ks4n) {
     const size_t total = (size_t)n_ct * ks4n * 256;
@@ -181,14 +181,16 @@ __device__ __forceinline__ void vq_best(float& v, int& i, float ov, int oi) { if
 template <int CTRL>
 __device__ __forceinline__ void vq_row_argmax_step(float& v, int& i) { const float ov = st_dpp<CTRL>(v); const int oi = vq_dpp_i<CTRL>(i); vq_best(v, i, ov, oi); }
 
-template <int TPW>     // code tiles per wave: V <= 64 * TPW
-__global__ __launch_bounds__(VQM_THREADS) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
+// NW waves per workgroup split the code tiles (tile = wave + NW * t, t < TPW): the softmax phases are chains of dependent VALU
+// instructions (expf, IEEE division), so several waves per SIMD hide each other's latency -- V = 512 runs 16 waves x 2 tiles
+template <int NW, int TPW>     // V <= 16 * NW * TPW
+__global__ __launch_bounds__(NW * 64) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
                                                                  float* p_code, int64_t* idx_out, float* out, int n, int D, int V,
                                                                  int n_ct, int ks4n) {
     __shared__ __attribute__((aligned(16))) float xt[16 * VQM_XLD];
-    __shared__ float xxs[4][16];
-    __shared__ float red[4][16];
-    __shared__ int redi[4][16];
+    __shared__ float xxs[NW][16];
+    __shared__ float red[NW][16];
+    __shared__ int redi[NW][16];
     __shared__ int fidx[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nn = lane & 15;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(VQM_THREADS) void vq_l2_mfma_kernel(const float* x,
     // operands of the first code tile of this wave are requested before anything else
     const f32x4* wsp = reinterpret_cast<const f32x4*>(ws);
     const float* e2 = ws + (size_t)n_ct * ks4n * 256;
-    {   // stage the 16 input vectors (zeros past D and past n)
+    if (tid < 256) {   // stage the 16 input vectors (zeros past D and past n)
         const int vec = tid >> 4, d4 = (tid & 15) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (v0 + vec < n && d4 < D) v = *reinterpret_cast<const f32x4*>(x + (size_t)(v0 + vec) * D + d4);
@@ -221,23 +223,27 @@ __global__ __launch_bounds__(VQM_THREADS) void vq_l2_mfma_kernel(const float* x,
     float ax[16];                                   // A fragments: x[vec nn][4 ks + g]
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) ax[ks] = xt[nn * VQM_XLD + ks * 4 + g];
-    f32x4 acc[TPW];
+    // every operand of this wave's code tiles is requested up front (one wave per SIMD: the register file holds all TPW tiles), so
+    // the table costs ONE round trip to L2; the MFMAs then run k-step by k-step ACROSS the tiles -- consecutive MFMAs write
+    // different accumulators (no dependent-issue stalls), and every accumulator still sums its dimensions in ascending order
+    f32x4 acc[TPW], bq[TPW][4];
     float e2v[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ct = min(wave + 4 * t, n_ct - 1);         // tiles past the table repeat the last one (discarded below)
+        const int ct = min(wave + NW * t, n_ct - 1);        // tiles past the table repeat the last one (discarded below)
         e2v[t] = e2[ct * 16 + nn];
-        f32x4 b4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = q < ks4n ? wsp[((size_t)ct * ks4n + q) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q * 4 + c], b4[q][c], acc[t], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) bq[t][q] = q < ks4n ? wsp[((size_t)ct * ks4n + q) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // lane (g, nn) now holds dot(x[vec 4g + r], e[code (wave + 4t) * 16 + nn]) in acc[t][r]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q * 4 + c], bq[t][q][c], acc[t], 0, 0, 0);
+    // lane (g, nn) now holds dot(x[vec 4g + r], e[code (wave + NW t) * 16 + nn]) in acc[t][r]
     const float tscale = fmaxf(temp[0], 0.0f);          // F.relu(self.temp)
     float xxr[4];
 #pragma unroll
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(VQM_THREADS) void vq_l2_mfma_kernel(const float* x,
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const bool on = (wave + 4 * t) * 16 + nn < V;
+        const bool on = (wave + NW * t) * 16 + nn < V;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float dist = (xxr[r] + e2v[t]) - 2.0f * acc[t][r];     // embed.py:210-212 association order
@@ -259,7 +265,12 @@ __global__ __launch_bounds__(VQM_THREADS) void vq_l2_mfma_kernel(const float* x,
     __syncthreads();
     float sm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(fmaxf(red[0][4 * g + r], red[1][4 * g + r]), fmaxf(red[2][4 * g + r], red[3][4 * g + r]));
+    for (int r = 0; r < 4; ++r) {
+        float m = red[0][4 * g + r];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w][4 * g + r]);
+        mx[r] = m;
+    }
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -271,10 +282,15 @@ __global__ __launch_bounds__(VQM_THREADS) void vq_l2_mfma_kernel(const float* x,
     float bv[4] = {-1.f, -1.f, -1.f, -1.f};
     int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sm[r] = ((red[0][4 * g + r] + red[1][4 * g + r]) + red[2][4 * g + r]) + red[3][4 * g + r];
+    for (int r = 0; r < 4; ++r) {          // fixed order: wave 0, 1, ...
+        float sacc = red[0][4 * g + r];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sacc += red[w][4 * g + r];
+        sm[r] = sacc;
+    }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int code = (wave + 4 * t) * 16 + nn;
+        const int code = (wave + NW * t) * 16 + nn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float p = acc[t][r] / sm[r];
@@ -295,14 +311,14 @@ __global__ __launch_bounds__(VQM_THREADS) void vq_l2_mfma_kernel(const float* x,
         float v = red[0][tid];
         int i = redi[0][tid];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) vq_best(v, i, red[w][tid], redi[w][tid]);
+        for (int w = 1; w < NW; ++w) vq_best(v, i, red[w][tid], redi[w][tid]);
         fidx[tid] = i;
         if (v0 + tid < n) idx_out[v0 + tid] = i;
     }
     __syncthreads();
     {   // out = (x + code) - x.detach(): the straight-through forward value (embed.py:145)
-        const int vec = tid >> 4, d4 = (tid & 15) * 4;
-        if (v0 + vec < n && d4 < D) {
+        const int vec = (tid >> 4) & 15, d4 = (tid & 15) * 4;
+        if (tid < 256 && v0 + vec < n && d4 < D) {
             const f32x4 e = *reinterpret_cast<const f32x4*>(table + (size_t)fidx[vec] * D + d4);
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + vec * VQM_XLD + d4);
             f32x4 o;
@@ -467,14 +483,13 @@ extern "C" int st_vq_l2_fwd(const float* x, const float* table, const float* tem
         hipLaunchKernelGGL(vq_pack_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, V, D,
                            workspace, n_ct, ks4n);
         ST_LAUNCH_CHECK();
-        const dim3 grid((n + 15) / 16), block(VQM_THREADS);
-        const int tpw = (n_ct + 3) / 4;
-#define VQ_LAUNCH(T) hipLaunchKernelGGL((vq_l2_mfma_kernel<T>), grid, block, 0, (hipStream_t)stream, x, table, workspace, temp, p_code, idx, out, n, D, V, n_ct, ks4n)
-        if (tpw <= 1) VQ_LAUNCH(1);
-        else if (tpw <= 2) VQ_LAUNCH(2);
-        else if (tpw <= 4) VQ_LAUNCH(4);
-        else if (tpw <= 8) VQ_LAUNCH(8);
-        else VQ_LAUNCH(16);
+        const dim3 grid((n + 15) / 16);
+#define VQ_LAUNCH(NW, T) hipLaunchKernelGGL((vq_l2_mfma_kernel<NW, T>), grid, dim3(NW * 64), 0, (hipStream_t)stream, x, table, workspace, temp, p_code, idx, out, n, D, V, n_ct, ks4n)
+        if (n_ct <= 4) VQ_LAUNCH(4, 1);
+        else if (n_ct <= 8) VQ_LAUNCH(8, 1);
+        else if (n_ct <= 16) VQ_LAUNCH(16, 1);
+        else if (n_ct <= 32) VQ_LAUNCH(16, 2);
+        else VQ_LAUNCH(16, 4);
 #undef VQ_LAUNCH
         ST_LAUNCH_CHECK();
         return 0;

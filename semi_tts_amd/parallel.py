@@ -96,6 +96,136 @@ def allreduce_gradients(params, bucket_bytes=32 << 20, average=True):
     return n_coll
 
 
+class GradReducer:
+    """Gradient all-reduce overlapped with the backward pass, without copies.
+
+    The parameters (in REVERSE registration order, which is roughly the order their gradients become ready: postnet first,
+    then the decoder's BPTT, then the encoder) are laid out in persistent flat fp32 buckets and every `p.grad` is a VIEW into
+    its bucket, so autograd accumulates straight into the communication buffer.  A post-accumulate hook counts the gradients
+    of a bucket; when the last one has arrived the bucket's all-reduce is issued asynchronously (RCCL runs it on its own
+    stream while the rest of the backward pass keeps the compute stream busy); `finish()` issues what is left, waits, and
+    averages.  ~32 MiB buckets: 4 collectives for the 125 MB model -- few, large messages are what the per-link-bound xGMI
+    ring wants (ref: the step this replaces is BaseSolver.backward, src/solver.py:138-151, which needs the GLOBAL norm)."""
+
+    def __init__(self, params, bucket_bytes=32 << 20, average=True):
+        self.params = [p for p in list(params)[::-1] if p.requires_grad]
+        self.average = average
+        self.buckets, self.flats, self.slot = [], [], {}
+        cur, size = [], 0
+        for p in self.params:
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        for bi, bucket in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in bucket), device=bucket[0].device, dtype=torch.float32)
+            self.flats.append(flat)
+            off = 0
+            for p in bucket:
+                self.slot[p] = (bi, off)
+                off += p.numel()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.prepare()
+
+    def _view(self, p):
+        bi, off = self.slot[p]
+        return self.flats[bi][off:off + p.numel()].view_as(p)
+
+    def prepare(self):
+        """before every backward pass (after optimizer.zero_grad): zero the buckets and (re-)attach the gradient views"""
+        for flat in self.flats:
+            flat.zero_()
+        for p in self.params:
+            p.grad = self._view(p)
+        self.count = [0] * len(self.buckets)
+        self.fired = set()
+        self.works = [None] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
+
+    def _on_grad(self, p):
+        if p not in self.slot or p in self.fired:
+            return
+        if p.grad is None or p.grad.data_ptr() != self._view(p).data_ptr():      # somebody replaced the view: copy back in
+            self._view(p).copy_(p.grad)
+            p.grad = self._view(p)
+        self.fired.add(p)
+        bi = self.slot[p][0]
+        self.count[bi] += 1
+        if self.count[bi] == len(self.buckets[bi]):
+            self._launch(bi)
+
+    def _launch(self, bi):
+        self.launched[bi] = True
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not _GRAD_ALLREDUCE:
+            return
+        flat = self.flats[bi]
+        _COUNTS['grad_buckets'] += 1
+        if flat.is_cuda and dist.get_backend() == 'gloo':      # functional tests on a box with fewer GPUs than ranks
+            all_reduce_sum_(flat)
+        else:
+            self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """after backward: reduce the buckets that never filled up (parameters without a gradient this step contribute zeros
+        on every rank alike), wait, average; parameters that received no gradient on this rank get `.grad = None` back, as
+        autograd would have left them (the optimiser then skips them like the reference's does)"""
+        for bi in range(len(self.buckets)):
+            if not self.launched[bi]:
+                self._launch(bi)
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        for bi, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+        if world > 1 and self.average and _GRAD_ALLREDUCE:
+            for flat in self.flats:
+                flat.mul_(1.0 / world)
+        for p in self.params:
+            if p not in self.fired:
+                p.grad = None
+        return sum(1 for l in self.launched if l)
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+_SHARD_ROWS = None
+
+
+def set_shard_rows(mine=None, total=None):
+    """utterances of this rank / of the global batch, when the ranks hold different numbers of them (default: equal shards).
+    SyncBN needs the global row count on the host without a device round trip."""
+    global _SHARD_ROWS
+    _SHARD_ROWS = (int(mine), int(total)) if mine else None
+
+
+def global_rows(local_rows):
+    """rows of the global batch a BatchNorm layer sees, from this rank's rows"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_rows
+    if _SHARD_ROWS is None:
+        return local_rows * dist.get_world_size()
+    mine, total = _SHARD_ROWS
+    return local_rows * total // mine
+
+
+def all_gather_(t):
+    """(world, *t.shape) tensor of every rank's `t`; device tensors are staged through the host for the gloo backend"""
+    world = dist.get_world_size()
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.detach().cpu()
+        outs = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(outs, h)
+        return torch.stack(outs).to(t.device)
+    out = torch.empty((world,) + tuple(t.shape), device=t.device, dtype=t.dtype)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
 def broadcast_parameters(module, src=0):
     """make every replica start from rank `src`'s weights and buffers"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -110,8 +240,8 @@ _SYNC_BN = False
 
 def sync_batchnorm(enabled=True):
     """Make training-mode BatchNorm use the statistics of the GLOBAL batch (all ranks), like the reference's
-    single-process full batch.  Per layer and step: two small all-reduces in forward (count + weighted
-    means, then the centred second moments) and one in backward (the two sums of the dx formula)."""
+    single-process full batch.  Per layer and step: ONE all-gather of (mean, M2, count) in forward, merged
+    exactly on every rank in rank order (Chan et al.), and one all-reduce in backward (the two sums of the dx formula)."""
     global _SYNC_BN
     _SYNC_BN = bool(enabled)
 

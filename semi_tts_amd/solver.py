@@ -195,7 +195,22 @@ class TtsTrainer(BaseSolver):
         from . import parallel
         parallel.sync_batchnorm(True)        # no-op for a single process; global-batch statistics under torch.distributed
         parallel.broadcast_parameters(self.model)
+        self._attach_reducer()
         return self
+
+    def _attach_reducer(self):
+        """under torch.distributed: gradients live in flat buckets that are all-reduced while the backward pass still runs"""
+        from . import parallel
+        self.reducer = None
+        if parallel.rank_world()[1] > 1:
+            self.reducer = parallel.GradReducer(self.model.parameters())
+        return self.reducer
+
+    def _reduce_gradients(self):
+        from . import parallel
+        if getattr(self, 'reducer', None) is not None:
+            return self.reducer.finish()
+        return parallel.allreduce_gradients(self.model.parameters())
 
     def freq_loss(self, pred, label):
         from . import autograd as AG
@@ -207,13 +222,15 @@ class TtsTrainer(BaseSolver):
         from . import parallel
         parallel.collective_counts(reset=True)
         tf_rate = self.optimizer.pre_step(self.step)
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.prepare()
         mel_pred, linear_pred, align, _, _, _, _, _ = self.model.text_to_speech(
             text, sid, None, None, None, None, mel, None, tf_rate, _masks=_masks)
         mel_loss = self.freq_loss(mel_pred, mel)
         linear_loss = self.freq_loss(linear_pred, linear)
         total = self.tts_weight * (mel_loss + linear_loss)
         total.backward()
-        parallel.allreduce_gradients(self.model.parameters())
+        self._reduce_gradients()
         grad_norm = self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
         gn = float(grad_norm)
         if gn != gn:
@@ -272,6 +289,8 @@ class VqvaeTrainer(TtsTrainer):
         hp = self.hp
         parallel.collective_counts(reset=True)
         tf_rate = self.optimizer.pre_step(self.step)
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.prepare()
         pair_prob, _, unpair_prob, unpair_latent, unpair_latent_len, _, _ = self.model.speech_to_text(
             paired_mel=aug_mel, unpaired_mel=unpair_aug_mel)
         ignore_speech_cycle = unpair_latent is None                                               # :163-172
@@ -287,7 +306,7 @@ class VqvaeTrainer(TtsTrainer):
             total = total + float(hp.get('unpair_speech_weight', 10.0)) * un
             stats['unpair_speech_loss'] = float(un.detach())
         total.backward()
-        parallel.allreduce_gradients(self.model.parameters())
+        self._reduce_gradients()
         gn = float(self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP))
         if gn == gn:
             self.optimizer.step()

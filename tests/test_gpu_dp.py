@@ -44,9 +44,11 @@ def _worker(rank, world, port, out_path):
     parallel.sync_batchnorm(True)
     parallel.broadcast_parameters(m)
     rows = slice(rank * 2, rank * 2 + 2)
-    loss = _step(m, A, rows, dev)
-    n_coll = parallel.allreduce_gradients(m.parameters(), bucket_bytes=64 << 10)     # small buckets: several collectives
+    red = parallel.GradReducer(m.parameters(), bucket_bytes=64 << 10)               # small buckets: several collectives,
+    loss = _step(m, A, rows, dev)                                                   # issued from autograd hooks during backward
+    n_coll = red.finish()
     assert n_coll > 1
+    assert parallel.collective_counts()['syncbn_fwd'] == 13 and parallel.collective_counts()['syncbn_bwd'] == 13   # one each per BN layer
     if rank == 0:
         torch.save({'loss': loss, 'grads': {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None},
                     'stats': {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}}, out_path)

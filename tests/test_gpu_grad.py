@@ -686,10 +686,12 @@ def test_speech_first_step_against_reference_golden(dev, name):
     assert abs(st['grad_norm'] - ref['grad_norm']) < 2e-4 * ref['grad_norm']
     keys = json.loads(bytes(A['grad_keys']).decode())
     worst, worst_k = 0.0, ''
+    gmax = max(float(g.abs().max()) for g in A['grad'])
     for k, gref in zip(keys, A['grad']):
         assert k in grads, 'missing gradient for ' + k
-        if float(gref.abs().max()) < 1e-9:
-            assert float(grads[k].abs().max()) < 1e-4, k
+        if float(gref.abs().max()) < 1e-6 * gmax:
+            # analytically zero (a conv bias in front of a batch-statistics BatchNorm): round-off on both sides
+            assert float(grads[k].abs().max()) < 1e-5 * gmax, k
             continue
         e = relerr(grads[k], gref)
         if e > worst:

@@ -160,8 +160,21 @@ ref.load_state_dict(net.state_dict())
 (ref(x).pow(2).sum() / 8.0).backward()       # the single-process result on the whole batch
 err = max((a.grad - b.grad).abs().max().item() for a, b in zip(net.parameters(), ref.parameters()))
 t = max_over_ranks(1.0 + rank)
+# the overlapped form: gradients accumulate straight into flat buckets, every bucket is all-reduced from an autograd hook as
+# soon as its last gradient has arrived; a parameter that gets no gradient keeps .grad = None
+from semi_tts_amd.parallel import GradReducer
+net2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+net2.load_state_dict({**net.state_dict(), '2.weight': torch.zeros(2, 3), '2.bias': torch.zeros(2)})
+red = GradReducer(net2.parameters(), bucket_bytes=64, average=False)
+for it in range(2):                                    # twice: the buckets are persistent and re-armed by prepare()
+    red.prepare()
+    (net2[1](net2[0](x[lo:hi])).pow(2).sum() / 8.0).backward()
+    n2 = red.finish()
+err2 = max((a.grad - b.grad).abs().max().item() for a, b in zip(list(net2.parameters())[:4], ref.parameters()))
+unused_none = all(p.grad is None for p in net2[2].parameters())
+views = all(p.grad.data_ptr() == red._view(p).data_ptr() for p in list(net2.parameters())[:4])
 if rank == 0:
-    print('RESULT', err, n, t)
+    print('RESULT', err, n, t, err2, n2, int(unused_none), int(views))
 dist.destroy_process_group()
 '''
 
@@ -180,3 +193,5 @@ def test_two_process_gradient_allreduce_matches_single_process(tmp_path):
     assert float(line[1]) < 1e-5          # gradients equal the single-process ones
     assert int(line[2]) >= 2              # more than one bucket was exercised
     assert float(line[3]) == 2.0          # max over ranks of (1, 2)
+    assert float(line[4]) < 1e-5 and int(line[5]) >= 2       # hook-driven buckets give the same gradients
+    assert line[6] == '1' and line[7] == '1'                # unused parameters stay None, gradients are views of the buckets

@@ -181,8 +181,7 @@ __device__ __forceinline__ void vq_best(float& v, int& i, float ov, int oi) { if
 template <int CTRL>
 __device__ __forceinline__ void vq_row_argmax_step(float& v, int& i) { const float ov = st_dpp<CTRL>(v); const int oi = vq_dpp_i<CTRL>(i); vq_best(v, i, ov, oi); }
 
-// NW waves per workgroup split the code tiles (tile = wave + NW * t, t < TPW): the softmax phases are chains of dependent VALU
-// instructions (expf, IEEE division), so several waves per SIMD hide each other's latency -- V = 512 runs 16 waves x 2 tiles
+// NW waves per workgroup split the code tiles (tile = wave + NW * t, t < TPW)
 template <int NW, int TPW>     // V <= 16 * NW * TPW
 __global__ __launch_bounds__(NW * 64) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
                                                                  float* p_code, int64_t* idx_out, float* out, int n, int D, int V,
@@ -485,11 +484,15 @@ extern "C" int st_vq_l2_fwd(const float* x, const float* table, const float* tem
         ST_LAUNCH_CHECK();
         const dim3 grid((n + 15) / 16);
 #define VQ_LAUNCH(NW, T) hipLaunchKernelGGL((vq_l2_mfma_kernel<NW, T>), grid, dim3(NW * 64), 0, (hipStream_t)stream, x, table, workspace, temp, p_code, idx, out, n, D, V, n_ct, ks4n)
+        // 4 waves (one per SIMD) with all of a wave's code tiles in registers.  Measured at V = 512 (us per call incl. the pack
+        // launch, 32 x 129 / 256 x 129 vectors): 4 waves x 8 tiles 19.2 / 65.8; 16 waves x 2 tiles 25.4 / 95.2; 4 vector tiles per
+        // workgroup with the table operands held in registers (237 VGPRs, one workgroup per CU) 25.5 / 112.8; the scalar
+        // LDS-table kernel 130 / 779.
         if (n_ct <= 4) VQ_LAUNCH(4, 1);
-        else if (n_ct <= 8) VQ_LAUNCH(8, 1);
-        else if (n_ct <= 16) VQ_LAUNCH(16, 1);
-        else if (n_ct <= 32) VQ_LAUNCH(16, 2);
-        else VQ_LAUNCH(16, 4);
+        else if (n_ct <= 8) VQ_LAUNCH(4, 2);
+        else if (n_ct <= 16) VQ_LAUNCH(4, 4);
+        else if (n_ct <= 32) VQ_LAUNCH(4, 8);
+        else VQ_LAUNCH(4, 16);
 #undef VQ_LAUNCH
         ST_LAUNCH_CHECK();
         return 0;

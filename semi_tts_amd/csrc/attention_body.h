@@ -263,21 +263,25 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
             const int f = idx / nlb, l0 = pos_lo + (idx - f * nlb) * AT_CB;
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
             if (KP == 32) {
-                // K <= 32: filters and history window are pulled with ds_read_b128 (8 + 9 per channel)
-                // up front, then 32 x 4 FMAs run out of registers
+                // K <= 32: filters and history window are pulled with ds_read_b128, 8 taps at a time (2 + 3 reads feed 8 x 4 FMAs
+                // out of 20 registers; the whole 32-tap window at once took 68 and set the register count of every kernel this
+                // body is compiled into), taps in ascending order
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const f32x4* hq = reinterpret_cast<const f32x4*>(hs + c * o.hl + l0);
                     const f32x4* wq = reinterpret_cast<const f32x4*>(Wc + (f * 2 + c) * 32);
-                    float h[36], w[32];
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) { const f32x4 t = hq[j]; h[4 * j] = t[0]; h[4 * j + 1] = t[1]; h[4 * j + 2] = t[2]; h[4 * j + 3] = t[3]; }
+                    for (int kc = 0; kc < 4; ++kc) {
+                        float h[12], w[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const f32x4 t = wq[j]; w[4 * j] = t[0]; w[4 * j + 1] = t[1]; w[4 * j + 2] = t[2]; w[4 * j + 3] = t[3]; }
+                        for (int j = 0; j < 3; ++j) { const f32x4 t = hq[2 * kc + j]; h[4 * j] = t[0]; h[4 * j + 1] = t[1]; h[4 * j + 2] = t[2]; h[4 * j + 3] = t[3]; }
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) {
-                        acc0 = fmaf(w[k], h[k], acc0); acc1 = fmaf(w[k], h[k + 1], acc1);
-                        acc2 = fmaf(w[k], h[k + 2], acc2); acc3 = fmaf(w[k], h[k + 3], acc3);
+                        for (int j = 0; j < 2; ++j) { const f32x4 t = wq[2 * kc + j]; w[4 * j] = t[0]; w[4 * j + 1] = t[1]; w[4 * j + 2] = t[2]; w[4 * j + 3] = t[3]; }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            acc0 = fmaf(w[k], h[k], acc0); acc1 = fmaf(w[k], h[k + 1], acc1);
+                            acc2 = fmaf(w[k], h[k + 2], acc2); acc3 = fmaf(w[k], h[k + 3], acc3);
+                        }
                     }
                 }
             } else {

@@ -20,6 +20,91 @@ struct GruArgs {
     float* tape;     // training: [dir][b][t][4][H] = (r, z, n, W_hn h + b_hn); NULL in inference
 };
 
+// H <= 128: the three gate rows of hidden unit j live in three ADJACENT lanes (thread 4j + g, g = 0..2 = r, z, n; lane 3 of the
+// quad idles), each with its W_hh row in registers.  A step is: 80-term dot per lane as four independent fma chains over the
+// LDS-resident h (ds_read_b128 broadcasts), the two other gates fetched from the neighbour lanes with DPP quad permutes (no LDS
+// exchange), the pointwise update on lane g = 0, h written to the OTHER of two LDS buffers -- ONE LDS-only barrier per step
+// (the first form of this kernel: thread j = row j, gates exchanged through LDS, two barriers, one 80-deep fma chain: 1.42 us per
+// step of the 258-step CBHG GRU = 43 % of the postnet).
+// KQ = compile-time number of 4-float pieces of h (H <= 4 KQ): the dot product is a branch-free run of KQ ds_read_b128 + 4 KQ FMAs
+// (with a run-time `k < H` test inside the unrolled loop the compiler emitted a branch, a wait and SGPR-spill traffic per piece:
+// 1.4-1.6 us per step whatever the arithmetic; weights past H are zero and the padded h entries are zero).
+template <int KQ>
+__global__ __launch_bounds__(512) void gru_seq_quad_kernel(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = a.H, H3 = 3 * H, T = a.T;
+    constexpr int HP = 4 * KQ;
+    float* hb[2] = {lds, lds + HP};
+    const int b = blockIdx.x, d = blockIdx.y;
+    const int tid = threadIdx.x, j = tid >> 2, g = tid & 3;
+    const float* __restrict__ gi = a.gi[d] + (size_t)b * T * H3;
+    const bool row_ok = j < H && g < 3;
+    float wreg[HP];
+    float bh;
+    {   // branch-free: idle lanes and columns past H read a valid address and are zeroed by a select
+        const float* wr = a.w_hh[d] + (size_t)(row_ok ? g * H + j : 0) * H;
+        const float bv = a.b_hh[d][row_ok ? g * H + j : 0];
+        bh = row_ok ? bv : 0.0f;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) { const float w = wr[k < H ? k : H - 1]; wreg[k] = (row_ok && k < H) ? w : 0.0f; }
+    }
+    for (int k = tid; k < 2 * HP; k += blockDim.x) lds[k] = 0.0f;
+    __syncthreads();
+    const bool upd = j < H && g == 0;
+    float hprev = 0.f;
+    // The input projections are read GRU_PB steps ahead: a step takes ~0.3 us, a load from HBM / L2 1-2 us, so a one-step
+    // prefetch (the first form of this kernel) left every step waiting for memory.  Blocks of GRU_PB steps: the next block's
+    // three gate inputs per step are requested before the current block is computed out of registers.
+    constexpr int GRU_PB = 8;
+    float cur[GRU_PB][3], nxt[GRU_PB][3];
+    auto load_block = [&](float (&dst)[GRU_PB][3], int s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < GRU_PB; ++i) {
+            const int s = s0 + i;
+            const int tt = min(d ? T - 1 - s : s, T - 1);
+            const bool on = upd && s < T;
+            const float* p = gi + (size_t)(on ? max(tt, 0) : 0) * H3 + (on ? j : 0);
+            dst[i][0] = p[0]; dst[i][1] = p[on ? H : 0]; dst[i][2] = p[on ? 2 * H : 0];       // (idle lanes re-read one valid address)
+        }
+    };
+    load_block(cur, 0);
+    for (int s0 = 0; s0 < T; s0 += GRU_PB) {
+        load_block(nxt, s0 + GRU_PB);
+#pragma unroll
+        for (int i = 0; i < GRU_PB; ++i) {
+            const int s = s0 + i;
+            if (s >= T) break;                                        // (uniform)
+            const int t = d ? T - 1 - s : s;
+            const float* hcur = hb[s & 1];
+            float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < HP; k += 4) {          // padded h entries are zero, weights past H are zero
+                const f32x4 h4 = *reinterpret_cast<const f32x4*>(hcur + k);
+                a0 = fmaf(wreg[k], h4[0], a0); a1 = fmaf(wreg[k + 1], h4[1], a1);
+                a2 = fmaf(wreg[k + 2], h4[2], a2); a3 = fmaf(wreg[k + 3], h4[3], a3);
+            }
+            const float gh = (a0 + a1) + (a2 + a3);                   // W_hh[g*H + j] . h + b_hh
+            const float ghz = st_dpp<0x55>(gh), ghn = st_dpp<0xAA>(gh);      // quad_perm [1,1,1,1] / [2,2,2,2]: lanes g = 1, 2 of the quad
+            if (upd) {
+                const float r = st_sigmoid_fast(cur[i][0] + gh);
+                const float z = st_sigmoid_fast(cur[i][1] + ghz);
+                const float n = st_tanh_fast(cur[i][2] + r * ghn);
+                const float hn = (1.0f - z) * n + z * hprev;
+                hprev = hn;
+                hb[(s + 1) & 1][j] = hn;
+                a.out[((size_t)b * T + t) * a.ldo + d * H + j] = hn;
+                if (a.tape) {
+                    float* tp = a.tape + ((((size_t)d * a.B + b) * T + t) * 4) * H + j;
+                    tp[0] = r; tp[H] = z; tp[2 * H] = n; tp[3 * H] = ghn;
+                }
+            }
+            st_lds_barrier();      // (LDS-only: __syncthreads would also wait for the block of input projections just requested)
+        }
+#pragma unroll
+        for (int i = 0; i < GRU_PB; ++i) { cur[i][0] = nxt[i][0]; cur[i][1] = nxt[i][1]; cur[i][2] = nxt[i][2]; }
+    }
+}
+
 template <bool REG>
 __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_kernel(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -102,11 +187,11 @@ struct GruBwdArgs {
     int B, T, H;
 };
 
-template <bool REG>
+template <bool REG, int KQ = 32>      // REG: H <= 4 KQ, the mat-vec is a branch-free run over 4 KQ zero-padded entries (see gru_seq_quad_kernel)
 __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const GruBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int H = a.H, H3 = 3 * H, T = a.T;
-    const int H4 = (H + 3) & ~3;
+    const int H4 = REG ? 4 * KQ : ((H + 3) & ~3);
     float* dghs = lds;                 // [3][H4]  (pad entries stay zero)
     float* part = lds + 3 * H4;        // [3H]
     float* dhc = part + H3;            // [H]
@@ -115,10 +200,13 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const Gru
     const bool row_ok = j < H3;
     const int g = row_ok ? j / H : 0, k = row_ok ? j - g * H : 0;
     const float* __restrict__ whh = a.w_hh[d];
-    float wreg[REG ? GRU_HMAX : 4];
-    if (REG && row_ok) {
+    float wreg[REG ? 4 * KQ : 4];
+    if (REG) {
 #pragma unroll
-        for (int jj = 0; jj < GRU_HMAX; ++jj) wreg[jj] = jj < H ? whh[(size_t)(g * H + jj) * H + k] : 0.0f;
+        for (int jj = 0; jj < 4 * KQ; ++jj) {        // branch-free: clamped address, zeroed by a select
+            const float w = whh[(size_t)(g * H + (jj < H ? jj : H - 1)) * H + k];
+            wreg[jj] = (row_ok && jj < H) ? w : 0.0f;
+        }
     }
     for (int i = j; i < 3 * H4; i += blockDim.x) dghs[i] = 0.0f;
     if (j < H) dhc[j] = 0.0f;
@@ -162,14 +250,14 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const Gru
             float acc = 0.0f;
             const float* dg = dghs + g * H4;
             if (REG) {
+                float a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-                for (int jj = 0; jj < GRU_HMAX; jj += 4) {
-                    if (jj < H) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(dg + jj);
-                        acc = fmaf(wreg[jj], v[0], acc); acc = fmaf(wreg[jj + 1], v[1], acc);
-                        acc = fmaf(wreg[jj + 2], v[2], acc); acc = fmaf(wreg[jj + 3], v[3], acc);
-                    }
+                for (int jj = 0; jj < 4 * KQ; jj += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(dg + jj);
+                    acc = fmaf(wreg[jj], v[0], acc); a1 = fmaf(wreg[jj + 1], v[1], a1);
+                    a2 = fmaf(wreg[jj + 2], v[2], a2); a3 = fmaf(wreg[jj + 3], v[3], a3);
                 }
+                acc = (acc + a1) + (a2 + a3);
             } else {
                 for (int jj = 0; jj < H; ++jj) acc = fmaf(whh[(size_t)(g * H + jj) * H + k], dg[jj], acc);
             }
@@ -262,8 +350,11 @@ extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const fl
     const int threads = ((3 * H + 63) / 64) * 64;
     const size_t lds = (size_t)(((H + 3) & ~3) + 3 * H) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (H <= GRU_HMAX) hipLaunchKernelGGL((gru_seq_kernel<true>), dim3(B, ndir), dim3(threads), lds, st, a);
-    else hipLaunchKernelGGL((gru_seq_kernel<false>), dim3(B, ndir), dim3(threads), lds, st, a);
+    if (H <= GRU_HMAX) {
+        const int qthreads = ((4 * H + 63) / 64) * 64;             // <= 512
+        if (H <= 80) hipLaunchKernelGGL(gru_seq_quad_kernel<20>, dim3(B, ndir), dim3(qthreads), (size_t)2 * 80 * sizeof(float), st, a);
+        else hipLaunchKernelGGL(gru_seq_quad_kernel<32>, dim3(B, ndir), dim3(qthreads), (size_t)2 * 128 * sizeof(float), st, a);
+    } else hipLaunchKernelGGL((gru_seq_kernel<false>), dim3(B, ndir), dim3(threads), lds, st, a);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -433,9 +524,11 @@ extern "C" int st_gru_seq_bwd(const float* dout, int ldd, const float* out, int 
     a.w_hh[0] = w_hh_fwd; a.w_hh[1] = w_hh_bwd; a.dgi[0] = dgi_fwd; a.dgi[1] = dgi_bwd; a.dgh[0] = dgh_fwd; a.dgh[1] = dgh_bwd;
     a.B = B; a.T = T; a.H = H;
     const int threads = ((3 * H + 63) / 64) * 64;
-    const size_t lds = (size_t)(3 * ((H + 3) & ~3) + 3 * H + H) * sizeof(float);
+    const int hpad = H <= 80 ? 80 : (H <= GRU_HMAX ? GRU_HMAX : ((H + 3) & ~3));      // the REG forms pad the dgh rows to 4 KQ entries
+    const size_t lds = (size_t)(3 * hpad + 3 * H + H) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (H <= GRU_HMAX) hipLaunchKernelGGL((gru_seq_bwd_kernel<true>), dim3(B, ndir), dim3(threads), lds, st, a);
+    if (H <= 80) hipLaunchKernelGGL((gru_seq_bwd_kernel<true, 20>), dim3(B, ndir), dim3(threads), lds, st, a);
+    else if (H <= GRU_HMAX) hipLaunchKernelGGL((gru_seq_bwd_kernel<true, 32>), dim3(B, ndir), dim3(threads), lds, st, a);
     else hipLaunchKernelGGL((gru_seq_bwd_kernel<false>), dim3(B, ndir), dim3(threads), lds, st, a);
     ST_LAUNCH_CHECK();
     return 0;

@@ -73,3 +73,56 @@ class GraphedDecoder:
             self.draw_masks()
         self.graph.launch()
         return self.outputs
+
+
+class GraphedTacotron2:
+    """The whole Tacotron2.forward of free-running inference (text encoder -> decode loop -> CBHG postnet -> linear projection,
+    src/tts.py:36-51) captured into ONE hipGraph for fixed shapes: ~700 launches (3 encoder convs, 43 BiLSTM steps, 86 x 6 decode
+    launches, ~30 postnet launches) replayed with a single graph launch.  Same static-buffer discipline as GraphedDecoder."""
+
+    def __init__(self, model, B, L, frames, device):
+        self.model = model
+        dec = model.decoder
+        self.frames = int(frames)
+        self.steps = self.frames // dec.n_frames_per_step
+        f32 = dict(device=device, dtype=torch.float32)
+        self.txt = torch.zeros(B, L, model.encoder.convs[0][0].conv.in_channels, **f32)
+        self.spkr = torch.zeros(B, dec.spkr_embed_dim, **f32)
+        self.p = dec.prenet_dropout
+        self.own_mask = torch.ones(self.steps, 2, B, dec.prenet_dim, **f32) if self.p > 0 else None
+        self.graph = None
+        self.outputs = None
+        self._keep = None
+
+    def _run(self):
+        masks = {'own': self.own_mask} if self.own_mask is not None else None
+        with torch.no_grad():
+            return self.model(self.txt, None, self.frames, self.spkr, tf_rate=0.0, _masks=masks)
+
+    def capture(self):
+        assert not self.model.training, 'graph replay is for eval-mode inference'
+        self.model.decoder.cache_packed = True
+        self._run()                                   # warms the allocator cache, the packed weights, the tap-major conv weights
+        torch.cuda.synchronize()
+        self.model.decoder.last_tapes = None
+        self.graph = ops.Graph()
+        with self.graph.capture():
+            self.outputs = self._run()
+        self._keep = self.model.decoder.last_tapes
+        return self
+
+    def draw_masks(self):
+        if self.own_mask is not None:
+            self.own_mask.bernoulli_(1.0 - self.p).div_(1.0 - self.p)
+
+    def __call__(self, txt_embed=None, spkr_embed=None, redraw=True):
+        if self.graph is None:
+            self.capture()
+        if txt_embed is not None:
+            self.txt.copy_(txt_embed)
+        if spkr_embed is not None:
+            self.spkr.copy_(spkr_embed)
+        if redraw:
+            self.draw_masks()
+        self.graph.launch()
+        return self.outputs

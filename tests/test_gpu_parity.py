@@ -587,6 +587,26 @@ def test_decode_is_deterministic_and_graph_replay_matches(dev):
     assert torch.equal(d, a)
 
 
+def test_whole_forward_graph_replay_matches_eager(dev):
+    """GraphedTacotron2: encoder + decode loop + CBHG postnet + linear captured into one hipGraph; replay is bit-identical to
+    the eager forward with the same masks."""
+    from semi_tts_amd.runtime import GraphedTacotron2
+    m = full_tacotron(dev, seed=7, prenet_dropout=0.5)
+    g = torch.Generator().manual_seed(2)
+    B, L, T = 5, 11, 24
+    txt, spk = torch.randn(B, L, 64, generator=g).to(dev), torch.randn(B, 128, generator=g).to(dev)
+    gt = GraphedTacotron2(m, B, L, T, dev).capture()
+    mel, lin, align, stop = gt(txt, spk, redraw=True)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        mel_e, lin_e, align_e, stop_e = m(txt, None, T, spk, tf_rate=0.0, _masks={'own': gt.own_mask})
+    assert torch.equal(mel, mel_e) and torch.equal(lin, lin_e) and torch.equal(align, align_e) and torch.equal(stop, stop_e)
+    a = lin.clone()
+    lin2 = gt(redraw=False)[1]
+    torch.cuda.synchronize()
+    assert torch.equal(a, lin2)
+
+
 def test_cpu_tensor_is_refused():
     """the product path has no CPU fallback: CPU tensors raise"""
     from semi_tts_amd import ops

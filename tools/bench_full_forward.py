@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Secondary measurement: whole Tacotron2.forward (encoder + decoder + CBHG postnet + linear) at C2, free-running
-inference, eager launches (no graph): mel-frames/s and a split by part."""
+inference: mel-frames/s of one hipGraph replay of the whole forward, of eager launches, and a split by part."""
 import json
 import os
 import sys
@@ -35,6 +35,12 @@ with torch.no_grad():
     t_enc, mem = timed(lambda: m.encoder(txt, None))
     t_dec, dout = timed(lambda: m.decoder(mem, None, T, spk, tf_rate=0.0))
     t_post, _ = timed(lambda: m.postnet(dout[0]))
-print(json.dumps(dict(metric='mel-frames/sec (whole Tacotron2.forward, eager)', value=B * T / t_all, ms_total=1e3 * t_all,
+from semi_tts_amd.runtime import GraphedTacotron2
+gt = GraphedTacotron2(m, B, L, T, dev)
+gt.txt.copy_(txt); gt.spkr.copy_(spk)
+gt.capture()
+t_graph, gout = timed(lambda: gt(redraw=True))
+print(json.dumps(dict(metric='mel-frames/sec (whole Tacotron2.forward, one hipGraph replay)', value=B * T / t_graph, ms_total_graph=1e3 * t_graph,
+                      value_eager=B * T / t_all, ms_total=1e3 * t_all,
                       ms_encoder=1e3 * t_enc, ms_decoder_eager=1e3 * t_dec, ms_postnet=1e3 * t_post,
                       config='C2: B=32, 258 frames, L=43, fp32, prenet dropout 0.5')))

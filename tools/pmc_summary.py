@@ -67,7 +67,7 @@ def main():
             lines.append('%-12s %-70s n=%5d avg=%12.1f min=%10.1f max=%12.1f avg_dur_ns=%s' % (c, name[:70], n, avg, mn, mx, dur))
             if ('pk_lstm_rt2_kernel' in name or 'pk_kernel<0' in name) and c not in vals:
                 vals[c] = avg
-    out = dict(kernel='pk_lstm_rt2_kernel<8,2,1>', FETCH_SIZE_avg_KB=round(vals['FETCH_SIZE'], 1), WRITE_SIZE_avg_KB=round(vals['WRITE_SIZE'], 1),
+    out = dict(kernel='pk_lstm_rt2_kernel<8,2,1>', commit=os.environ.get('ST_COMMIT'), FETCH_SIZE_avg_KB=round(vals['FETCH_SIZE'], 1), WRITE_SIZE_avg_KB=round(vals['WRITE_SIZE'], 1),
                correction='MI355X_MICROARCH.md: FETCH_SIZE reads exactly 1/2 of wide coalesced reads on gfx950 -> x2; '
                           'WRITE_SIZE uncalibrated, taken as is',
                hbm_bytes_per_launch=int(round((2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)),

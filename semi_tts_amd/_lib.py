@@ -115,6 +115,8 @@ SIGNATURES = {
     'st_gather_rows': [P, P, P, I, I, I, P],
     'st_vq_l2_fwd': [P, P, P, P, P, P, P, I, I, I, P],
     'st_vq_l2_workspace_floats': [I, I],
+    'st_ctc_workspace_floats': [I, I],
+    'st_ctc_loss': [P, P, C.c_float, P, P, P, I, I, I, I, P],
     'st_softmax_bwd': [P, P, P, C.c_float, P, P, I, I, P],
     'st_rowscale_combine': [P, C.c_float, P, P, C.c_float, P, P, I, I, P],
     'st_vq_mean_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],
@@ -174,7 +176,7 @@ SIGNATURES = {
     'st_mean_rows': [P, P, I, I, I, P],
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
-             'st_decoder_packed_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
+             'st_decoder_packed_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_ctc_workspace_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
              'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
 
 _lib = None

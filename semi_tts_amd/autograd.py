@@ -303,16 +303,30 @@ def bigru(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
     return _BiGruFn.apply(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b)
 
 
+class _CtcLossFn(Function):
+    """torch.nn.CTCLoss()(log(prob + eps).transpose(0, 1), non-zero tokens of text, all frames, tokens per row): the paired ASR loss
+    of bin/train_vqvae.py:430-444.  Value and gradient come from ONE kernel launch (st_ctc_loss); backward scales the stored
+    gradient by the incoming scalar (like freq_loss)."""
+
+    @staticmethod
+    def forward(ctx, prob, text, eps):
+        loss, dprob = ops.ctc_loss(prob.contiguous(), text.contiguous(), eps, want_grad=True)
+        ctx.save_for_backward(dprob)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dprob, = ctx.saved_tensors
+        from . import _lib
+        out = torch.empty_like(dprob)
+        _lib.check(_lib.load().st_scale_by(ops._p(dprob), ops._p(dloss.contiguous()), ops._p(out), dprob.numel(), ops.stream_handle()),
+                   'st_scale_by')
+        return out, None, None
+
+
 def ctc_loss(prob, text, eps=1e-10):
-    """torch.nn.CTCLoss()(log(prob + eps).transpose(0, 1), nonzero tokens of text, all frames, tokens per row): the paired ASR
-    loss of bin/train_vqvae.py:430-444.  prob (B, T, V) posteriors over the codebook (index 0 = blank), text (B, L) int64."""
-    import torch.nn.functional as F
-    B, T, _ = prob.shape
-    lp = (prob + eps).transpose(0, 1).log()
-    tgt_len = (text != 0).sum(dim=-1)
-    targets = text[text != 0]
-    in_len = torch.full((B,), T, dtype=torch.long, device=prob.device)
-    return F.ctc_loss(lp, targets, in_len, tgt_len, blank=0, reduction='mean')
+    """prob (B, T, V) posteriors over the codebook (index 0 = blank), text (B, L) int64 (zeros = padding)"""
+    return _CtcLossFn.apply(prob, text, eps)
 
 
 # --------------------------------------------------------------------------------------------- decoder loop

@@ -56,7 +56,162 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float* x, const flo
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i] * f;
 }
 
+// ---- CTC loss (ref: torch.nn.CTCLoss() as called by compute_ctcloss, bin/train_vqvae.py:430-444) ----------------------------
+//   lp(t, c) = log(prob(b, t, c) + eps);  targets = the non-zero tokens of text(b, :) in order;  every frame counts;  blank = 0
+//   loss = mean_b [ nll_b / max(S_b, 1) ],  nll_b = -log sum over alignments  (the alpha recursion in log space)
+// One workgroup per utterance walks alpha forward over the T frames (stored to a workspace), then beta backward, and emits
+// d loss / d prob with the formula ATen's CPU kernel uses (grad wrt lp = exp(lp) - exp(log sum_{s in c}(alpha beta) + nll - lp),
+// chained through the log): one thread per state of the blank-extended target (2 S + 1 <= 256), lp values gathered per chunk of
+// CTC_TC frames into LDS, ONE LDS barrier per frame (double-buffered state), every reduction in a fixed order.
+constexpr int CTC_NT = 256, CTC_TC = 16;
+
+__device__ __forceinline__ float ctc_lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+__global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, const int64_t* text, float eps, float* nll_out,
+                                                          float* dprob, float* log_alpha, int B, int T, int V, int L) {
+    extern __shared__ int ctc_dyn[];                 // cls_first[V]
+    __shared__ int lab[CTC_NT], nxt[CTC_NT];
+    __shared__ float st_a[2][CTC_NT], gam[2][CTC_NT];
+    __shared__ float lpS[CTC_TC][CTC_NT];
+    __shared__ int S_s;
+    __shared__ float nll_s;
+    int* cls_first = ctc_dyn;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* pb = prob + (size_t)b * T * V;
+    for (int c = tid; c < V; c += CTC_NT) cls_first[c] = -1;
+    __syncthreads();
+    if (tid == 0) {                                   // blank-extended target and, per label, the chain of the states that carry it
+        int S = 0;
+        for (int i = 0; i < L; ++i) { const int64_t tk = text[(size_t)b * L + i]; if (tk != 0) { lab[2 * S + 1] = (int)tk; ++S; } }
+        for (int s2 = 0; s2 <= 2 * S; s2 += 2) lab[s2] = 0;
+        for (int s2 = 0; s2 <= 2 * S; ++s2) nxt[s2] = -1;
+        for (int s2 = 2 * S - 1; s2 >= 1; s2 -= 2) {   // odd states, descending: cls_first ends up as the FIRST occurrence
+            const int c = lab[s2];
+            nxt[s2] = cls_first[c];
+            cls_first[c] = s2;
+        }
+        S_s = S;
+    }
+    __syncthreads();
+    const int S = S_s, SP = 2 * S + 1;
+    const bool on = tid < SP;
+    const int my = on ? lab[tid] : 0;
+    const bool skip_f = on && tid >= 2 && my != 0 && my != lab[tid - 2];            // alpha may come from s - 2
+    const bool skip_b = on && tid + 2 < SP && lab[tid + 2] != 0 && lab[tid + 2] != my;   // beta may come from s + 2
+    float* la = log_alpha + (size_t)b * T * CTC_NT;
+    auto gather = [&](int t0, int nt, int dir) {      // lpS[i][s] = lp(t0 + dir * i, lab[s]) for i < nt
+        for (int i = 0; i < nt; ++i) lpS[i][tid] = on ? logf(pb[(size_t)(t0 + dir * i) * V + my] + eps) : -INFINITY;
+    };
+    // ---- alpha
+    int cur = 0;
+    for (int t0 = 0; t0 < T; t0 += CTC_TC) {
+        const int nt = min(CTC_TC, T - t0);
+        __syncthreads();
+        gather(t0, nt, 1);
+        __syncthreads();
+        for (int i = 0; i < nt; ++i) {
+            const int t = t0 + i;
+            float a;
+            if (t == 0) a = (tid < 2 && on) ? lpS[0][tid] : -INFINITY;
+            else {
+                const float* pa = st_a[cur ^ 1];
+                const float a0 = on ? pa[tid] : -INFINITY, a1 = (on && tid >= 1) ? pa[tid - 1] : -INFINITY;
+                const float a2 = skip_f ? pa[tid - 2] : -INFINITY;
+                a = ctc_lse3(a0, a1, a2) + lpS[i][tid];
+                if (!on) a = -INFINITY;
+            }
+            st_a[cur][tid] = a;
+            la[(size_t)t * CTC_NT + tid] = a;
+            st_lds_barrier();
+            cur ^= 1;
+        }
+    }
+    if (tid == 0) {
+        const float* pa = st_a[cur ^ 1];
+        const float l1 = pa[SP - 1], l2 = SP >= 2 ? pa[SP - 2] : -INFINITY;
+        const float m = fmaxf(l1, l2);
+        const float v = m == -INFINITY ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
+        nll_s = v;
+        nll_out[b] = v;
+    }
+    __syncthreads();
+    const float nll = nll_s;
+    if (!dprob) return;
+    const float gr = 1.0f / ((float)max(S, 1) * (float)B);
+    // ---- beta, occupancies and the gradient
+    cur = 0;
+    for (int t1 = T - 1; t1 >= 0; t1 -= CTC_TC) {
+        const int nt = min(CTC_TC, t1 + 1);
+        __syncthreads();
+        gather(t1, nt, -1);
+        __syncthreads();
+        for (int i = 0; i < nt; ++i) {
+            const int t = t1 - i;
+            const float lps = lpS[i][tid];
+            float bt;
+            if (t == T - 1) bt = (on && tid >= SP - 2) ? lps : -INFINITY;
+            else {
+                const float* pbt = st_a[cur ^ 1];
+                const float b0 = on ? pbt[tid] : -INFINITY, b1 = (on && tid + 1 < SP) ? pbt[tid + 1] : -INFINITY;
+                const float b2 = skip_b ? pbt[tid + 2] : -INFINITY;
+                bt = ctc_lse3(b0, b1, b2) + lps;
+                if (!on) bt = -INFINITY;
+            }
+            st_a[cur][tid] = bt;
+            const float ab = on ? la[(size_t)t * CTC_NT + tid] + bt : -INFINITY;
+            gam[cur][tid] = ab == -INFINITY ? 0.0f : expf(ab - lps + nll);     // posterior occupancy of state s at frame t
+            st_lds_barrier();
+            const float* gq = gam[cur];
+            float blank = 0.0f;
+            if (tid < 64) {                          // blank = the even states: fixed-order wave reduction
+                for (int s2 = 2 * lane; s2 < SP; s2 += 128) blank += gq[s2];
+                blank = st_wave_sum_dpp(blank);
+            }
+            for (int c = tid; c < V; c += CTC_NT) {
+                float occ = 0.0f;
+                if (c == 0) occ = blank;
+                else for (int s2 = cls_first[c]; s2 >= 0; s2 = nxt[s2]) occ += gq[s2];
+                const float p = pb[(size_t)t * V + c] + eps;
+                // d loss / d lp = gr * (exp(lp) - occ);  lp = log(p + eps)  ->  d / d prob = that / (p + eps)
+                dprob[((size_t)b * T + t) * V + c] = gr * (p - occ) / p;
+            }
+            cur ^= 1;
+        }
+    }
+}
+
+__global__ void ctc_loss_final_kernel(const float* nll, const int64_t* text, int B, int L, float* loss) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        int S = 0;
+        for (int i = 0; i < L; ++i) S += text[(size_t)b * L + i] != 0;
+        s += nll[b] / (float)max(S, 1);
+    }
+    *loss = s / (float)B;
+}
+
 }  // namespace
+
+extern "C" size_t st_ctc_workspace_floats(int B, int T) { return (size_t)B * T * CTC_NT + (size_t)B; }
+
+extern "C" int st_ctc_loss(const float* prob, const int64_t* text, float eps, float* loss, float* dprob, float* ws,
+                           int B, int T, int V, int L, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(prob && text && loss && ws && B > 0 && T > 0 && V > 1 && L > 0, "st_ctc_loss: bad arguments");
+    ST_CHECK_ARG(2 * L + 1 <= CTC_NT, "st_ctc_loss: transcripts of up to %d tokens (L=%d)", (CTC_NT - 1) / 2, L);
+    ST_CHECK_ARG((size_t)V * sizeof(int) <= 64 * 1024, "st_ctc_loss: V=%d too large", V);
+    hipStream_t st = (hipStream_t)stream;
+    float* nll = ws + (size_t)B * T * CTC_NT;
+    hipLaunchKernelGGL(ctc_loss_kernel, dim3(B), dim3(CTC_NT), (size_t)V * sizeof(int), st, prob, text, eps, nll, dprob, ws, B, T, V, L);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ctc_loss_final_kernel, dim3(1), dim3(1), 0, st, nll, text, B, L, loss);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int st_freq_loss(const float* pred, const float* label, float* loss, float* dpred, float* ws,
                             int B, int T, int D, int n_low, float w_all, float w_low, float w_diff, int l1, void* stream) {

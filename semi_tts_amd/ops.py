@@ -334,6 +334,19 @@ def rowscale_combine(a, alpha, x=None, r=None, beta=0.0, c=None):
     return out
 
 
+def ctc_loss(prob, text, eps, want_grad=True):
+    """-> (loss scalar tensor, d loss / d prob or None); see st_ctc_loss"""
+    lib = _lib.load()
+    B, T, V = prob.shape
+    L = text.shape[1]
+    loss = torch.empty((), device=prob.device, dtype=torch.float32)
+    dprob = torch.empty_like(prob) if want_grad else None
+    ws = torch.empty(int(lib.st_ctc_workspace_floats(B, T)), device=prob.device, dtype=torch.float32)
+    check(lib.st_ctc_loss(_p(prob), _p(text, torch.int64), float(eps), _p(loss), _p(dprob), _p(ws), B, T, V, L, stream_handle()),
+          'st_ctc_loss')
+    return loss, dprob
+
+
 def softmax_argmax(logits):
     lib = _lib.load()
     V = logits.shape[-1]

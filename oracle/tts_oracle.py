@@ -139,10 +139,10 @@ def lstm_cell(x: Tensor, h: Tensor, c: Tensor, w_ih: Tensor, w_hh: Tensor,
     return h2, c2
 
 
-def lstm_layer(x: Tensor, W: Weights, prefix: str, reverse: bool) -> Tensor:
-    """One direction of nn.LSTM(batch_first) over a full-length (unpacked) sequence,
+def lstm_layer(x: Tensor, W: Weights, prefix: str, reverse: bool, layer: int = 0) -> Tensor:
+    """One direction of one layer of nn.LSTM(batch_first) over a full-length (unpacked) sequence,
     zero initial state.  ref: src/module.py:432-438,458-460 (lengths are ignored)."""
-    sfx = '_l0_reverse' if reverse else '_l0'
+    sfx = '_l%d%s' % (layer, '_reverse' if reverse else '')
     w_ih, w_hh = W[prefix + '.weight_ih' + sfx], W[prefix + '.weight_hh' + sfx]
     b_ih, b_hh = W[prefix + '.bias_ih' + sfx], W[prefix + '.bias_hh' + sfx]
     B, L, _ = x.shape
@@ -198,9 +198,13 @@ def encoder_forward(W: Weights, txt_embed: Tensor, prefix: str = 'encoder.',
         x = torch.relu(x)                                                      # :430
         x = drop(x, enc_dropout, training)                                      # :431
         i += 1
-    fw = lstm_layer(x, W, prefix + 'lstm', reverse=False)                       # :458-460
-    bw = lstm_layer(x, W, prefix + 'lstm', reverse=True)
-    return torch.cat([fw, bw], dim=-1)
+    layer = 0
+    while (prefix + 'lstm.weight_ih_l%d' % layer) in W:                         # enc_rnn_layer stacked BiLSTM layers (1 in the configs)
+        fw = lstm_layer(x, W, prefix + 'lstm', False, layer)                    # :458-460
+        bw = lstm_layer(x, W, prefix + 'lstm', True, layer)
+        x = torch.cat([fw, bw], dim=-1)
+        layer += 1
+    return x
 
 
 # --------------------------------------------------------------------------- decoder
@@ -256,23 +260,39 @@ class DecoderState:
 
 def decode_one_step(W: Weights, st: DecoderState, dec_in: Tensor, spkr_embed: Tensor, r: int,
                     n_mels: int, q_drop: float, d_drop: float, training: bool,
-                    drop: DropoutSource, prefix: str = 'decoder.') -> Tuple[Tensor, Tensor, Tensor]:
-    """ref: Decoder.decode_one_step, src/module.py:216-288 (spkr_embed_mode 'adaIN',
-    loc_aware=True, use_summed_weights=True, pretrain=False: the shipped configuration)."""
+                    drop: DropoutSource, prefix: str = 'decoder.', mode: str = 'adain',
+                    pretrain: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+    """ref: Decoder.decode_one_step, src/module.py:216-288 (loc_aware=True, use_summed_weights=True; spkr_embed_mode
+    'adaIN' is the shipped configuration, 'concat' / 'add' condition the memory the context is read from, :241-250;
+    pretrain skips the attention, :238-240)."""
     B = dec_in.shape[0]
     xq = torch.cat([dec_in, st.ctx], dim=-1)                                          # :227
     h, c = lstm_cell(xq, st.h_q, st.c_q, W[prefix + 'query_rnn.weight_ih'], W[prefix + 'query_rnn.weight_hh'],
                      W[prefix + 'query_rnn.bias_ih'], W[prefix + 'query_rnn.bias_hh'])   # :228
     st.h_q = drop(h, q_drop, training)                                                # :230 (dropped h is the state)
     st.c_q = c                                                                        # :231
-    ctx, w = attention_step(W, st.h_q, st.memory, st.pm, st.w, st.w_cum, prefix + 'attn.')  # :256-261
+    if pretrain:                                                                      # :238-240
+        ctx, w = torch.zeros_like(st.ctx), torch.zeros_like(st.w)
+    else:
+        mem = st.memory
+        if mode == 'concat':                                                          # :243-245
+            L = mem.shape[1]
+            mem = linear(torch.cat([mem, spkr_embed.unsqueeze(1).repeat(1, L, 1)], dim=-1),
+                         W[prefix + 'spkr_mem_proj.weight'], W[prefix + 'spkr_mem_proj.bias'])
+        elif mode == 'add':                                                           # :246-247
+            sp = linear(spkr_embed.unsqueeze(1), W[prefix + 'spkr_proj.weight'], W[prefix + 'spkr_proj.bias'])
+            mem = linear(mem + sp, W[prefix + 'spkr_mem_proj.weight'], W[prefix + 'spkr_mem_proj.bias'])
+        ctx, w = attention_step(W, st.h_q, mem, st.pm, st.w, st.w_cum, prefix + 'attn.')   # :256-261
     st.ctx = ctx                                                                      # :262
     st.w = w                                                                          # :263
     st.w_cum = w + st.w_cum                                                           # :264
-    # AdaIN speaker adaptation                                                         :267-269
-    std = torch.relu(linear(spkr_embed, W[prefix + 'pseudo_latent_std.0.weight'], W[prefix + 'pseudo_latent_std.0.bias']))
-    mean = linear(spkr_embed, W[prefix + 'pseudo_latent_mean.weight'], W[prefix + 'pseudo_latent_mean.bias'])
-    adapted = std * (st.h_q - mean)
+    if mode == 'adain':
+        # AdaIN speaker adaptation                                                     :267-269
+        std = torch.relu(linear(spkr_embed, W[prefix + 'pseudo_latent_std.0.weight'], W[prefix + 'pseudo_latent_std.0.bias']))
+        mean = linear(spkr_embed, W[prefix + 'pseudo_latent_mean.weight'], W[prefix + 'pseudo_latent_mean.bias'])
+        adapted = std * (st.h_q - mean)
+    else:
+        adapted = st.h_q                                                              # :271-272
     xd = torch.cat([st.ctx, adapted], dim=-1)                                         # :275-276
     h, c = lstm_cell(xd, st.h_d, st.c_d, W[prefix + 'dec_rnn.weight_ih'], W[prefix + 'dec_rnn.weight_hh'],
                      W[prefix + 'dec_rnn.bias_ih'], W[prefix + 'dec_rnn.bias_hh'])       # :277
@@ -321,7 +341,8 @@ def decoder_forward(W: Weights, memory: Tensor, teacher: Union[int, Tensor], spk
     mels, aligns, stops = [], [], []
     dec_in = prenet_forward(W, torch.zeros(B, r * n_mels), p_pre, drop, prefix + 'prenet.')   # :161,:183
     for t in range(steps):
-        mel, al, stop = decode_one_step(W, st, dec_in, spkr_embed, r, n_mels, p_q, p_d, training, drop, prefix)
+        mel, al, stop = decode_one_step(W, st, dec_in, spkr_embed, r, n_mels, p_q, p_d, training, drop, prefix,
+                                        hp.get('spkr_embed_mode', 'adaIN').lower(), bool(hp.get('pretrain', False)))
         mels.append(mel)
         aligns.append(al)
         stops.append(stop)

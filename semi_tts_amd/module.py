@@ -112,7 +112,7 @@ class Encoder(nn.Module):
                                  padding=(enc_kernel_size - 1) // 2, dilation=1, w_init_gain='relu'),
                           nn.BatchNorm1d(enc_embed_dim), nn.ReLU(), nn.Dropout(enc_dropout))
             for din in in_size])
-        assert enc_rnn_layer == 1, 'the HIP encoder implements the 1-layer BiLSTM of the shipped configs'
+        self.enc_rnn_layer = enc_rnn_layer
         self.lstm = nn.LSTM(input_size=enc_embed_dim, hidden_size=enc_embed_dim // 2, num_layers=enc_rnn_layer,
                             batch_first=True, bidirectional=True)
 
@@ -126,18 +126,20 @@ class Encoder(nn.Module):
                 raise NotImplementedError('enc_dropout > 0 in training (all shipped configs use 0.0)')
         B, L, _ = x.shape
         H = self.lstm.hidden_size
-        if self.training:
-            ls = self.lstm
-            xp_f = AG.conv(x, ls.weight_ih_l0, ls.bias_ih_l0)
-            xp_b = AG.conv(x, ls.weight_ih_l0_reverse, ls.bias_ih_l0_reverse)
-            return AG.bilstm(xp_f, xp_b, ls.weight_hh_l0, ls.bias_hh_l0, ls.weight_hh_l0_reverse, ls.bias_hh_l0_reverse)
-        out = torch.empty(B, L, 2 * H, device=x.device, dtype=torch.float32)
-        g = lambda n: getattr(self.lstm, n)
-        xp_f = ops.gemm(x, g('weight_ih_l0'), bias=g('bias_ih_l0'))                      # (B, L, 4H), all time steps at once
-        xp_b = ops.gemm(x, g('weight_ih_l0_reverse'), bias=g('bias_ih_l0_reverse'))
-        # the two directions advance together: one launch per time step for both
-        ops.lstm_seq2(xp_f, xp_b, g('weight_hh_l0'), g('weight_hh_l0_reverse'), g('bias_hh_l0'), g('bias_hh_l0_reverse'), out)
-        return out
+        for layer in range(self.enc_rnn_layer):            # (nn.LSTM stacks the layers; no inter-layer dropout: module.py:432-438)
+            g = lambda n, rev=False: getattr(self.lstm, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))
+            if self.training:
+                xp_f = AG.conv(x, g('weight_ih'), g('bias_ih'))
+                xp_b = AG.conv(x, g('weight_ih', True), g('bias_ih', True))
+                x = AG.bilstm(xp_f, xp_b, g('weight_hh'), g('bias_hh'), g('weight_hh', True), g('bias_hh', True))
+                continue
+            out = torch.empty(B, L, 2 * H, device=x.device, dtype=torch.float32)
+            xp_f = ops.gemm(x, g('weight_ih'), bias=g('bias_ih'))                        # (B, L, 4H), all time steps at once
+            xp_b = ops.gemm(x, g('weight_ih', True), bias=g('bias_ih', True))
+            # the two directions advance together: one launch per time step for both
+            ops.lstm_seq2(xp_f, xp_b, g('weight_hh'), g('weight_hh', True), g('bias_hh'), g('bias_hh', True), out)
+            x = out
+        return x
 
 
 # ----------------------------------------------------------------------------- decoder pieces
@@ -263,11 +265,16 @@ class Decoder(nn.Module):
         self.drop_dec_in = drop_dec_in
         self.prenet_norm_type = prenet_norm_type
         self.spkr_embed_mode = spkr_embed_mode.lower()
-        if self.spkr_embed_mode != 'adain' or pretrain:
-            raise NotImplementedError("the HIP decoder implements spkr_embed_mode='adaIN', pretrain=False "
-                                      "(the default every shipped config uses)")
-        self.pseudo_latent_mean = nn.Linear(spkr_embed_dim, query_rnn_dim)
-        self.pseudo_latent_std = nn.Sequential(nn.Linear(spkr_embed_dim, query_rnn_dim), nn.ReLU())
+        if self.spkr_embed_mode == 'adain':                                               # ref: src/module.py:111-122
+            self.pseudo_latent_mean = nn.Linear(spkr_embed_dim, query_rnn_dim)
+            self.pseudo_latent_std = nn.Sequential(nn.Linear(spkr_embed_dim, query_rnn_dim), nn.ReLU())
+        elif self.spkr_embed_mode == 'concat':
+            self.spkr_mem_proj = nn.Linear(spkr_embed_dim + enc_embed_dim, enc_embed_dim)
+        elif self.spkr_embed_mode == 'add':
+            self.spkr_proj = nn.Linear(spkr_embed_dim, enc_embed_dim)
+            self.spkr_mem_proj = nn.Linear(enc_embed_dim, enc_embed_dim)
+        else:
+            raise NotImplementedError
         self.prenet = Prenet(n_mels * n_frames_per_step, [prenet_dim, prenet_dim], apply_dropout=prenet_dropout,
                              norm_type=prenet_norm_type)
         self.query_rnn = nn.LSTMCell(prenet_dim + enc_embed_dim, query_rnn_dim)
@@ -338,15 +345,36 @@ class Decoder(nn.Module):
         steps, step_src = plan_decode(is_int, teacher if is_int else teacher.shape[1], Bt, B, r, tf_rate,
                                       self.drop_dec_in, unpair_max_frame)
         differentiable = self.training and torch.is_grad_enabled()
-        # once per utterance: processed memory, AdaIN statistics (hoisted out of the loop)
-        if differentiable:
-            pm = AG.conv(memory, self.attn.memory_layer.linear.weight)
-            ada_std = AG.linear(spkr_embed, self.pseudo_latent_std[0].weight, self.pseudo_latent_std[0].bias, 'relu')
-            ada_mean = AG.linear(spkr_embed, self.pseudo_latent_mean.weight, self.pseudo_latent_mean.bias)
+        lin = (lambda x, m, act=None: AG.linear(x, m.weight, m.bias, act)) if differentiable else \
+              (lambda x, m, act=None: (ops.linear_small(x, m.weight, m.bias, act) if x.dim() == 2 and x.shape[0] <= 64
+                                       else ops.gemm(x, m.weight, bias=m.bias, act_pre=act)))
+        # once per utterance (everything the reference recomputes per step from step-invariant inputs is hoisted out of the loop):
+        # processed memory; AdaIN statistics, or -- spkr_embed_mode 'concat' / 'add' -- the speaker-conditioned memory the context
+        # is read from (src/module.py:243-250; the processed memory still comes from the plain memory, :306), with the AdaIN of the
+        # query state reduced to the identity (std 1, mean 0, :271-272)
+        pm = AG.conv(memory, self.attn.memory_layer.linear.weight) if differentiable else self.attn.process_memory(memory)
+        ctx_memory = memory
+        if self.spkr_embed_mode == 'adain':
+            ada_std = lin(spkr_embed, self.pseudo_latent_std[0], 'relu')
+            ada_mean = lin(spkr_embed, self.pseudo_latent_mean)
         else:
-            pm = self.attn.process_memory(memory)
-            ada_std = ops.linear_small(spkr_embed, self.pseudo_latent_std[0].weight, self.pseudo_latent_std[0].bias, 'relu')
-            ada_mean = ops.linear_small(spkr_embed, self.pseudo_latent_mean.weight, self.pseudo_latent_mean.bias)
+            ada_std = torch.ones(B, Q, device=dev, dtype=torch.float32)
+            ada_mean = torch.zeros(B, Q, device=dev, dtype=torch.float32)
+            if self.spkr_embed_mode == 'concat':
+                # Linear(cat[mem, spkr]) = W[:, :E] mem + (W[:, E:] spkr + b): the speaker part once per utterance, added per position
+                w = self.spkr_mem_proj.weight
+                sp = (AG.linear(spkr_embed, w[:, E:].contiguous(), self.spkr_mem_proj.bias) if differentiable
+                      else ops.linear_small(spkr_embed, w[:, E:].contiguous(), self.spkr_mem_proj.bias))
+                res = sp.unsqueeze(1).expand(B, L, E).contiguous()
+                ctx_memory = (AG.conv(memory, w[:, :E].contiguous(), res=res) if differentiable
+                              else ops.gemm(memory, w[:, :E].contiguous(), res=res))
+            else:                                                                          # 'add'
+                sp = lin(spkr_embed, self.spkr_proj)
+                ctx_memory = lin(memory + sp.unsqueeze(1), self.spkr_mem_proj)
+        if self.pretrain:
+            # decoder pre-training without attention (:238-240): context and alignments are zero.  A zero memory gives the zero
+            # context through the same kernels; the alignments handed back are zeroed below
+            ctx_memory = torch.zeros_like(memory)
         teacher_pre = teacher_mean = None
         Tt = 0
         if tf_rate != 0.0:
@@ -368,9 +396,12 @@ class Decoder(nn.Module):
         plan = dict(steps=steps, step_src=step_src, Bt=Bt, Tt=Tt, masks=(own_mask, q_mask, d_mask),
                     teacher_mean=teacher_mean)
         if differentiable:
-            return AG.decoder_loop(self, plan, memory, pm, ada_std, ada_mean, teacher_pre)
-        mel, align, stop, tapes = self._run_loop(plan, memory, pm, ada_std, ada_mean, teacher_pre, keep_tapes=False)
+            mel, align, stop = AG.decoder_loop(self, plan, ctx_memory.contiguous(), pm, ada_std, ada_mean, teacher_pre)
+            return mel, (align * 0.0 if self.pretrain else align), stop
+        mel, align, stop, tapes = self._run_loop(plan, ctx_memory.contiguous(), pm, ada_std, ada_mean, teacher_pre, keep_tapes=False)
         self.last_tapes = tapes
+        if self.pretrain:
+            ops.fill_(align, 0.0)
         return mel, align, stop
 
     def _run_loop(self, plan, memory, pm, ada_std, ada_mean, teacher_pre, keep_tapes):

@@ -114,6 +114,8 @@ TINY = dict(
 def tiny_model(seed, **over):
     torch.manual_seed(seed)
     cfg = json.loads(json.dumps(TINY))
+    if '_enc_rnn_layer' in over:
+        cfg['paras']['encoder']['enc_rnn_layer'] = over.pop('_enc_rnn_layer')
     cfg['paras']['decoder'].update(over)
     m = RefTacotron2(cfg['n_mels'], cfg['linear_dim'], cfg['in_embed_dim'], cfg['spkr_embed_dim'], cfg['paras'])
     g = torch.Generator().manual_seed(seed + 100)
@@ -480,13 +482,20 @@ def asr_cases():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr', 'speech']
+    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr', 'speech', 'variants']
     if 'speech' in which:
         speech_first_case()
     if 'asr' in which:
         asr_cases()
     if 'train' in which:
         train_step_case()
+    if 'variants' in which:
+        # decoder variants no shipped YAML reaches (src/module.py:116-120,238-250): speaker-conditioned memory, pre-training;
+        # a 2-layer text-encoder LSTM
+        tts_case('tts_tiny_concat', 31, B=3, L=6, teacher=(9,), tf_rate=1.0, training=False, spkr_embed_mode='concat')
+        tts_case('tts_tiny_add', 32, B=2, L=7, teacher=12, tf_rate=0.0, training=False, prenet_dropout=0.0, spkr_embed_mode='add')
+        tts_case('tts_tiny_pretrain', 33, B=2, L=5, teacher=(9,), tf_rate=1.0, training=True, pretrain=True)
+        tts_case('tts_tiny_enc2', 34, B=2, L=8, teacher=9, tf_rate=0.0, training=False, prenet_dropout=0.0, _enc_rnn_layer=2)
     if 'tts' in which:
         # eval-mode free-running inference, prenet dropout active (always-on), masks recorded
         tts_case('tts_tiny_infer', 1, B=2, L=7, teacher=15, tf_rate=0.0, training=False)

@@ -14,11 +14,13 @@ int at_launch(const AtArgs& a, hipStream_t stream) {
     ST_CHECK_ARG(PART == 1 || a.ctx || a.ctx_dst[0].base, "attention step: no context output");
     ST_CHECK_ARG(PART == 0 || (a.s_buf && ((a.A % 4 != 0) || st_aligned16(a.s_buf))), "attention step: S buffer missing / unaligned");
     ST_CHECK_ARG(!a.h_q || (a.ada_std && a.ada_mean && a.h_adapt), "attention step: AdaIN pointers");
-    const AtLds o = at_layout(a.L, a.A, a.E, a.F, a.K);
-    const size_t lds_bytes = (size_t)o.total * sizeof(float);
-    ST_CHECK_ARG(lds_bytes <= 160 * 1024, "attention step: L=%d needs %zu B of LDS (> 160 KiB)", a.L, lds_bytes);
     const bool vec = (a.A % 4 == 0) && (a.F % 4 == 0) && st_aligned16(a.pm) && (PART == 1 || (st_aligned16(a.pq) && st_aligned16(a.v))) &&
                      st_aligned16(a.loc_lin_w);
+    const int pre_parts = PART == 1 && a.pre_parts > 1 ? a.pre_parts : 1;
+    const AtLds o = at_layout(a.L, a.A, a.E, a.F, a.K, PART, at_pos_per(a.L, pre_parts), PART == 1 && vec && a.F == 32 && a.A % 16 == 0);
+    const size_t lds_bytes = (size_t)o.total * sizeof(float);
+    ST_CHECK_ARG(lds_bytes <= 160 * 1024, "attention step: L=%d needs %zu B of LDS (> 160 KiB)%s", a.L, lds_bytes,
+                 PART == 0 ? "; the split form (st_attn_pre_fwd with more parts + st_attn_fin_t16_fwd) takes longer texts" : "");
     static bool configured = false;
     if (!configured) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(at_kernel<true, PART>),
@@ -88,7 +90,7 @@ extern "C" int st_attn_pre_fwd(const float* pm, const float* w_prev, int ld_wpre
     memset(&a, 0, sizeof(a));
     a.pm = pm; a.w_prev = w_prev; a.ld_wprev = ld_wprev; a.w_cum_prev = w_cum_prev;
     a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.s_buf = s_buf;
-    a.pre_parts = parts == 2 || parts == 4 ? parts : 1;
+    a.pre_parts = (parts >= 2 && parts <= 64 && (parts & (parts - 1)) == 0) ? parts : 1;
     a.B = B; a.L = L; a.A = A; a.E = 4; a.F = F; a.K = K;
     return at_launch<1>(a, (hipStream_t)stream);
 }

@@ -53,17 +53,27 @@ struct AtLds {  // offsets in floats into dynamic LDS
     int wt, wt_ld, wc, kp, hs, hl, cf, cf_ld, e, part, total;
 };
 
-__host__ __device__ inline AtLds at_layout(int L, int A, int E, int F, int K) {
+// positions per workgroup of the pre part (multiples of 12 = lcm of the conv's 4-blocks and the energy phase's 6-blocks)
+__host__ __device__ inline int at_pos_per(int L, int nparts) {
+    return nparts > 1 ? (((L + nparts - 1) / nparts + 11) / 12) * 12 : L;
+}
+
+// part: 0 = the whole step, 1 = pre (history and conv features are held for the workgroup's OWN range of `Lr` positions only,
+// and W_l^T is not staged when S runs on the matrix cores), 2 = fin (energies + context partials only) -- so the split step has
+// no practical limit on the text length (the whole step keeps an utterance's conv features in LDS: L up to ~400)
+__host__ __device__ inline AtLds at_layout(int L, int A, int E, int F, int K, int part = 0, int Lr = 0, bool pre_mfma = false) {
     AtLds o;
     int p = 0;
+    const int Lh = part == 1 ? Lr : L;
     o.wt_ld = ((A + 3) & ~3) + 4;               // row stride of W_l^T: +4 spreads the transposing stores
-    o.wt = p; p += F * o.wt_ld;
+    o.wt = p; if (part == 0 || (part == 1 && !pre_mfma)) p += F * o.wt_ld;
     o.kp = K <= 32 ? 32 : ((K + 3) & ~3);       // filter rows padded so they can be read as float4
-    o.wc = p; p += F * 2 * o.kp;                // loc_conv [f][c][kp]
-    o.hl = ((L + AT_CB + o.kp + 3) + 3) & ~3;   // padded history length per channel (window of kp + 4)
-    o.hs = p; p += 2 * o.hl;
-    o.cf_ld = ((((L + AT_LP - 1) / AT_LP) * AT_LP + AT_CB + 3) & ~3); // conv features [f][l], l padded to the wave block and the conv's 4-wide stores
-    o.cf = p; p += F * o.cf_ld;
+    o.wc = p; if (part != 2) p += F * 2 * o.kp; // loc_conv [f][c][kp]
+    o.hl = ((Lh + AT_CB + o.kp + 3) + 3) & ~3;  // padded history length per channel (window of kp + 4)
+    o.hs = p; if (part != 2) p += 2 * o.hl;
+    // conv features [f][l], l padded to the wave block, the conv's 4-wide stores and the 16-position MFMA tiles
+    o.cf_ld = ((((Lh + AT_LP - 1) / AT_LP) * AT_LP + AT_CB + 3) & ~3) + (part == 1 ? 16 : 0);
+    o.cf = p; if (part != 2) p += F * o.cf_ld;
     o.e = p; p += ((L + 3) & ~3);               // energies, then softmax weights
     o.part = p; p += 4 * AT_THREADS;            // context partials [group][E]
     o.total = p;
@@ -104,10 +114,11 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
 #undef AT_TOUCH
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
-    const AtLds o = at_layout(L, A, E, F, K);
-    // position range of this workgroup (multiples of 12 = lcm of the conv's 4-blocks and the energy phase's 6-blocks)
-    const int pos_per = (PART == 1 && nparts > 1) ? ((((L + nparts - 1) >> pshift) + 11) / 12) * 12 : L;
+    // position range of this workgroup
+    const int pos_per = PART == 1 ? at_pos_per(L, nparts) : L;
     const int pos_lo = PART == 1 ? min(L, ipart * pos_per) : 0, pos_hi = min(L, pos_lo + pos_per);
+    const AtLds o = at_layout(L, A, E, F, K, PART, pos_per, PART == 1 && VEC && F == 32 && (A & 15) == 0);
+    const int lb = PART == 1 ? pos_lo : 0;       // first position held in the LDS history / conv-feature arrays
     float* Wt = lds + o.wt;
     float* Wc = lds + o.wc;
     float* hs = lds + o.hs;
@@ -203,7 +214,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + j * NT;
-            const int c = idx / o.hl, p = idx - c * o.hl, l = p - pad;
+            const int c = idx / o.hl, p = idx - c * o.hl, l = lb + p - pad;
             float v = 0.0f;
             if (idx < nhs && l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
             hv[j] = v;
@@ -217,7 +228,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
             Wc[idx] = k < K ? a.loc_conv_w[row * K + k] : 0.0f;
         }
         for (int idx = tid + 2 * NT; idx < nhs; idx += NT) {
-            const int c = idx / o.hl, p = idx - c * o.hl, l = p - pad;
+            const int c = idx / o.hl, p = idx - c * o.hl, l = lb + p - pad;
             float v = 0.0f;
             if (l >= 0 && l < L) v = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
             hs[idx] = v;
@@ -268,7 +279,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                 // body is compiled into), taps in ascending order
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const f32x4* hq = reinterpret_cast<const f32x4*>(hs + c * o.hl + l0);
+                    const f32x4* hq = reinterpret_cast<const f32x4*>(hs + c * o.hl + (l0 - lb));
                     const f32x4* wq = reinterpret_cast<const f32x4*>(Wc + (f * 2 + c) * 32);
 #pragma unroll
                     for (int kc = 0; kc < 4; ++kc) {
@@ -286,7 +297,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                 }
             } else {
                 for (int c = 0; c < 2; ++c) {
-                    const float* h = hs + c * o.hl + l0;
+                    const float* h = hs + c * o.hl + (l0 - lb);
                     const float* w = Wc + (f * 2 + c) * KP;
                     float h0 = h[0], h1 = h[1], h2 = h[2];
 #pragma unroll 8
@@ -299,11 +310,11 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                     }
                 }
             }
-            float* dst = cf + f * o.cf_ld + l0;   // cf_ld is padded, stores beyond L are harmless
+            float* dst = cf + f * o.cf_ld + (l0 - lb);   // cf_ld is padded, stores beyond the range are harmless
             dst[0] = acc0;
-            if (l0 + 1 < o.cf_ld) dst[1] = acc1;
-            if (l0 + 2 < o.cf_ld) dst[2] = acc2;
-            if (l0 + 3 < o.cf_ld) dst[3] = acc3;
+            if (l0 - lb + 1 < o.cf_ld) dst[1] = acc1;
+            if (l0 - lb + 2 < o.cf_ld) dst[2] = acc2;
+            if (l0 - lb + 3 < o.cf_ld) dst[3] = acc3;
             if (PART == 1 && a.cf_out) {             // training: the backward pass reuses them (dW_l = ds^T loc) instead of recomputing
                 float* cg = a.cf_out + ((size_t)b * L + l0) * F + f;
                 if (l0 < pos_hi) cg[0] = acc0;
@@ -346,7 +357,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         // D[row = 4g + r][col = n] of a (dim tile, position tile): lane (g, n) ends up with S[l0 + n][a0 + 4g .. 4g + 3]
         auto sm_tile = [&](const int a0, const int nt, const float (&aw)[8], const f32x4 pm4) __attribute__((always_inline)) {
             const int l0 = pos_lo + nt * 16, l = l0 + sm_n;
-            const float* cfp = cf + (sm_g * 8) * o.cf_ld + l0 + sm_n;      // columns past the range read neighbours: discarded
+            const float* cfp = cf + (sm_g * 8) * o.cf_ld + (l0 - lb) + sm_n;      // columns past the range read the row's padding: discarded
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[k], cfp[k * o.cf_ld], acc, 0, 0, 0);
@@ -420,9 +431,9 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wt + f * o.wt_ld + a0);
                 // l0 is a multiple of 6: 8-byte aligned, three ds_read_b64 cover the six positions
                 typedef __attribute__((ext_vector_type(2))) float f32x2;
-                const f32x2 c01 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0);
-                const f32x2 c23 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0 + 2);
-                const f32x2 c45 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + l0 + 4);
+                const f32x2 c01 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + (l0 - lb));
+                const f32x2 c23 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + (l0 - lb) + 2);
+                const f32x2 c45 = *reinterpret_cast<const f32x2*>(cf + f * o.cf_ld + (l0 - lb) + 4);
                 const float cvs[AT_LP] = {c01[0], c01[1], c23[0], c23[1], c45[0], c45[1]};
 #pragma unroll
                 for (int j = 0; j < AT_LP; ++j) {

@@ -531,10 +531,10 @@ template <int NB>
 int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st) {
     constexpr int KW = 8, TRIP = NB == 1 ? PK_TRIP_SMALL : 2;
     const int BT = (a.B + 15) >> 4, gy = (BT + NB - 1) / NB;
-    const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K);
-    const size_t lds = (size_t)o.total * sizeof(float);
-    ST_CHECK_ARG(lds + sizeof(f32x4) * KW * NB * 64 <= 160 * 1024, "linear + attention-pre launch: L=%d needs too much LDS", t.L);
     const bool vec = (t.A % 4 == 0) && (t.F % 4 == 0) && st_aligned16(t.pm) && st_aligned16(t.loc_lin_w) && st_aligned16(t.s_buf);
+    const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K, 1, at_pos_per(t.L, t.pre_parts > 1 ? t.pre_parts : 1), vec && t.F == 32 && t.A % 16 == 0);
+    const size_t lds = (size_t)o.total * sizeof(float);
+    ST_CHECK_ARG(lds + sizeof(f32x4) * KW * NB * 64 <= 160 * 1024, "linear + attention-pre launch: L=%d needs too much LDS (use more parts)", t.L);
     auto kern = vec ? pk_attnpre_kernel<NB, KW, TRIP, true> : pk_attnpre_kernel<NB, KW, TRIP, false>;
     static size_t configured[2] = {0, 0};
     if (lds > 48 * 1024 && lds > configured[vec ? 1 : 0]) {
@@ -718,7 +718,7 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
         t.pm = pre->pm; t.w_prev = pre->w_prev; t.ld_wprev = pre->ld_wprev; t.w_cum_prev = pre->w_cum_prev;
         t.loc_conv_w = pre->loc_conv_w; t.loc_lin_w = pre->loc_lin_w; t.s_buf = pre->s_buf; t.cf_out = pre->cf_out;
         t.B = B; t.L = pre->L; t.A = pre->A; t.E = 4; t.F = pre->F; t.K = pre->K;
-        t.pre_parts = pre->parts == 2 || pre->parts == 4 ? pre->parts : 1;
+        t.pre_parts = (pre->parts >= 2 && pre->parts <= 64 && (pre->parts & (pre->parts - 1)) == 0) ? pre->parts : 1;
         const int BT = (B + 15) >> 4;
         if (BT == 1 || tiles <= 128) return pk_launch_attnpre<1>(a, tiles, t, (hipStream_t)stream);
         if (BT == 2) return pk_launch_attnpre<2>(a, tiles, t, (hipStream_t)stream);

@@ -492,7 +492,10 @@ class Decoder(nn.Module):
             else:
                 tapes['attn_s'] = torch.empty(B, L, A, **f32)
             io.attn_s_buf = ops._p(tapes['attn_s'])
-            io.attn_pre_parts = int(self.attn_pre_parts)
+            parts = int(self.attn_pre_parts)
+            while parts < 64 and (L + parts - 1) // parts > 512:      # long texts: a workgroup holds the conv features of its
+                parts *= 2                                            # position range in LDS (32 filters x <= ~512 positions)
+            io.attn_pre_parts = parts
             io.attn_fin_parts = int(self.attn_fin_parts)
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')

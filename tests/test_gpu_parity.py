@@ -213,7 +213,8 @@ def test_attention_step(dev, B, L, A, E, F, K, Q):
     assert abs(float(w_out.sum(-1).mean()) - 1.0) < 1e-5
 
 
-@pytest.mark.parametrize('B,L,A,E,F,K', [(2, 7, 16, 32, 4, 5), (32, 43, 256, 512, 32, 31), (3, 171, 256, 512, 32, 31), (5, 13, 24, 40, 6, 7)])
+@pytest.mark.parametrize('B,L,A,E,F,K', [(2, 7, 16, 32, 4, 5), (32, 43, 256, 512, 32, 31), (3, 171, 256, 512, 32, 31), (5, 13, 24, 40, 6, 7),
+                                         (2, 300, 256, 512, 32, 31), (1, 350, 24, 40, 6, 7)])
 def test_attention_step_in_two_parts(dev, B, L, A, E, F, K):
     # pre (conv + W_l, from the previous weights only) then fin (energies, softmax, context) == the one-launch step
     from semi_tts_amd import ops
@@ -225,7 +226,7 @@ def test_attention_step_in_two_parts(dev, B, L, A, E, F, K):
     w1, c1, x1 = (torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, E, device=dev))
     ops.attn_step(d[0], d[1], d[2], d[3], d[4], w1, c1, d[5], d[6], d[7], x1)
     s_buf = ops.attn_pre(d[1], d[3], d[4], d[5], d[6])
-    for parts in (2, 4):       # the pre part spread over several workgroups per utterance gives the same S bit for bit
+    for parts in (2, 4, 8, 16):       # the pre part spread over several workgroups per utterance gives the same S bit for bit
         assert torch.equal(ops.attn_pre(d[1], d[3], d[4], d[5], d[6], parts=parts), s_buf)
     w2, c2, x2 = torch.empty_like(w1), torch.empty_like(c1), torch.empty_like(x1)
     ops.attn_fin(d[0], s_buf, d[2], d[4], d[7], w2, c2, x2, F, K)
@@ -516,11 +517,24 @@ def test_edge_shapes_against_oracle(dev, B, L, T):
     assert errs['mel'] < 2e-5 and errs['lin'] < 2e-5 and errs['align'] < 1e-5
 
 
-def test_too_long_text_is_refused(dev):
-    # the attention step keeps its staging in LDS: a text that does not fit is an error from the C ABI, not a wrong answer
+def test_long_text_runs_split_and_the_unsplit_step_refuses_it(dev):
+    """Text far beyond the headline length (L = 900): the decode loop's split attention holds only a position range (pre part)
+    or the energies (fin part) in LDS, so it runs and matches the oracle; the one-launch step keeps an utterance's conv features
+    in LDS and refuses the same text with an error from the C ABI -- not a wrong answer."""
+    from semi_tts_amd import ops
     m = full_tacotron(dev, seed=5)
-    with torch.no_grad(), pytest.raises(RuntimeError, match='LDS'):
-        m(torch.randn(2, 900, 64).to(dev), None, 6, torch.randn(2, 128).to(dev), tf_rate=0.0)
+    g = torch.Generator().manual_seed(900)
+    txt, spk = torch.randn(2, 900, 64, generator=g), torch.randn(2, 128, generator=g)
+    with torch.no_grad():
+        mel, lin, align, _ = m(txt.to(dev), None, 6, spk.to(dev), tf_rate=0.0)
+        mel_r, lin_r, align_r, _ = O.tacotron2_forward(_oracle_weights(m), txt, 6, spk, full_hp(0.0))
+    errs = dict(mel=maxdiff(mel, mel_r), lin=maxdiff(lin, lin_r), align=maxdiff(align, align_r))
+    report('tts_long_text', L=900, **errs)
+    assert errs['mel'] < 2e-5 and errs['lin'] < 2e-5 and errs['align'] < 1e-5
+    B, L, A, E = 2, 900, 256, 512
+    z = lambda *sh: torch.zeros(*sh, device=dev)
+    with pytest.raises(RuntimeError, match='LDS'):
+        ops.attn_step(z(B, A), z(B, L, A), z(B, L, E), z(B, L), z(B, L), z(B, L), z(B, L), z(32, 2, 31), z(A, 32), z(A), z(B, E))
 
 
 def test_headline_shape_c2_against_oracle(dev):

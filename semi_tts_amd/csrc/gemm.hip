@@ -16,7 +16,10 @@
 
 namespace {
 
-constexpr int GM_BM = 64, GM_BN = 64, GM_BK = 16, GM_LD = 20, GM_THREADS = 256;
+// LDS row stride 24 floats: the 16 lanes of each ds_read_b128 service group (rows 0-3 & 12-15 at one k offset, rows 4-11 at the next: see the
+// microarch guide) then hit 16 distinct 16-byte slots of the 64 banks (slot = (6 row + k piece) mod 16); with 20 floats three pairs
+// of a group collided (PMC bank-conflict ratio 0.33-0.55 in round 1)
+constexpr int GM_BM = 64, GM_BN = 64, GM_BK = 16, GM_LD = 24, GM_THREADS = 256;
 
 struct GmArgs {
     const float* A; int lda; const float* W; float* C; int ldc; int coff;
@@ -27,7 +30,8 @@ struct GmArgs {
 };
 
 // epilogue of both GEMM kernels: D[row = 4*(lane>>4) + r][col = lane&15] of the wave's 2 x 2 sub-tiles
-__device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane) {
+template <int MT = 2>
+__device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[MT][2], int m0, int n0, int wm, int wn, int lane) {
     const st_gemm_epilogue& ep = g.ep;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -42,10 +46,10 @@ __device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[
             bn_b = ep.bn_b ? ep.bn_b[n] : 0.0f;
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + mt * 16 + 4 * (lane >> 4) + r;
+                const int m = m0 + wm * (16 * MT) + mt * 16 + 4 * (lane >> 4) + r;
                 if (m >= g.M) continue;
                 float v = acc[mt][nt][r] + bias;
                 v = st_act(v, ep.act_pre);
@@ -153,16 +157,25 @@ __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
 // clamped (always valid) addresses and a validity flag applied when they are written to LDS -- no branch around a load, no
 // integer division per block -- and barriers that only order the LDS traffic (__syncthreads would drain the prefetch).
 // The one-block form below spent ~2100 cycles per k-block against 512 cycles of MFMAs.
-template <bool VECW, bool POOL>
+// MT = 16-row MFMA tiles per wave along M: the workgroup tile is (32 MT) x 64.  MT = 1 halves the tile for grids that would not
+// give every compute unit two workgroups with 64-row tiles: one wave per SIMD cannot overlap its own address arithmetic, LDS
+// traffic and barrier with its MFMAs, a second workgroup on the SIMD can (measured: 258 workgroups of 64 x 64 ran at 0.29 of the
+// fp32 matrix peak however the barriers were arranged).
+template <bool VECW, bool POOL, int MT = 2>
 __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
-    // two LDS buffers: block kb+1 is written while block kb is multiplied -- one barrier per k-block
-    __shared__ __attribute__((aligned(16))) float As[2][GM_BM * GM_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GM_BN * GM_LD];
+    constexpr int BM = 32 * MT;
+    // two LDS buffers of TWO 16-float k-blocks each: pair kp+1 is written while pair kp is multiplied -- one barrier per 32
+    // MFMAs per wave.  (r02: with one k-block per barrier an iteration took ~1350 cycles for 512 cycles of MFMAs -- one wave per
+    // SIMD cannot hide the LDS-write -> barrier -> LDS-read chain; the pair halves the barriers per MFMA.  A k-block stays the
+    // addressing unit, so a pair may straddle two conv taps.)
+    __shared__ __attribute__((aligned(16))) float As[2][2][BM * GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][2][GM_BN * GM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * GM_BM, n0 = blockIdx.y * GM_BN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * GM_BN;
     const int srow = tid >> 2, skq = tid & 3;
-    const int am = m0 + srow;
+    const int am = m0 + min(srow, BM - 1);          // (MT = 1: threads past the 32 A rows repeat the last row's loads, never stored)
+    const bool a_stage = srow < BM;
     const bool a_row_ok = am < g.M;
     int ab = 0, ato = 0;
     if (a_row_ok) { ab = am / g.Tout; ato = am - ab * g.Tout; }
@@ -193,55 +206,59 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
         r.vw = in_k && w_row_ok;
         if (++cb_n == g.cpb) { cb_n = 0; ++tap_n; }
     };
-    auto commit = [&](const Blk& r, const int buf) __attribute__((always_inline)) {
+    auto commit = [&](const Blk& r, const int buf, const int half) __attribute__((always_inline)) {
         f32x4 va = r.a;
         if (POOL) { va[0] = fmaxf(va[0], r.q[0]); va[1] = fmaxf(va[1], r.q[1]); va[2] = fmaxf(va[2], r.q[2]); va[3] = fmaxf(va[3], r.q[3]); }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(As[buf] + srow * GM_LD + skq * 4) = r.va ? va : z;
-        *reinterpret_cast<f32x4*>(Bs[buf] + srow * GM_LD + skq * 4) = r.vw ? r.w : z;
+        if (a_stage) *reinterpret_cast<f32x4*>(As[buf][half] + srow * GM_LD + skq * 4) = r.va ? va : z;
+        *reinterpret_cast<f32x4*>(Bs[buf][half] + srow * GM_LD + skq * 4) = r.vw ? r.w : z;
     };
-    f32x4 acc[2][2];
+    f32x4 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = (lane >> 4) * 4;
     auto compute = [&](const int buf) __attribute__((always_inline)) {
-        f32x4 a4[2], b4[2];
+        f32x4 a4[2][MT], b4[2][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            a4[t] = *reinterpret_cast<const f32x4*>(As[buf] + (wm * 32 + t * 16 + fr) * GM_LD + fk);
-            b4[t] = *reinterpret_cast<const f32x4*>(Bs[buf] + (wn * 32 + t * 16 + fr) * GM_LD + fk);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a4[h][t] = *reinterpret_cast<const f32x4*>(As[buf][h] + (wm * (16 * MT) + t * 16 + fr) * GM_LD + fk);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b4[h][t] = *reinterpret_cast<const f32x4*>(Bs[buf][h] + (wn * 32 + t * 16 + fr) * GM_LD + fk);
         }
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[h][mt][cc], b4[h][nt][cc], acc[mt][nt], 0, 0, 0);
     };
 
-    const int nkb = g.KT * g.cpb;
-    Blk r0, r1;
-    issue(r0);
-    issue(r1);
-    commit(r0, 0);
-    issue(r0);                     // block 2 (past the end: clamped addresses, flags false)
+    const int npairs = (g.KT * g.cpb + 1) >> 1;
+    Blk r0[2], r1[2];
+    issue(r0[0]); issue(r0[1]);
+    issue(r1[0]); issue(r1[1]);
+    commit(r0[0], 0, 0); commit(r0[1], 0, 1);
+    issue(r0[0]); issue(r0[1]);     // pair 2 (past the end: clamped addresses, flags false)
     st_lds_barrier();
-    for (int kb = 0; kb < nkb; kb += 2) {
-        // buffer 0 holds block kb; r1 = block kb+1, r0 = block kb+2
-        commit(r1, 1);             // (nobody reads buffer 1 now: its last readers passed the barrier below / above)
-        issue(r1);                 // block kb + 3
+    for (int kp = 0; kp < npairs; kp += 2) {
+        // buffer 0 holds pair kp; r1 = pair kp+1, r0 = pair kp+2
+        commit(r1[0], 1, 0); commit(r1[1], 1, 1);   // (nobody reads buffer 1 now: its last readers passed the barrier below / above)
+        issue(r1[0]); issue(r1[1]);                 // pair kp + 3
         compute(0);
-        st_lds_barrier();          // buffer 1 complete, buffer 0 free
-        if (kb + 1 >= nkb) break;
-        commit(r0, 0);
-        issue(r0);                 // block kb + 4
+        st_lds_barrier();                           // buffer 1 complete, buffer 0 free
+        if (kp + 1 >= npairs) break;
+        commit(r0[0], 0, 0); commit(r0[1], 0, 1);
+        issue(r0[0]); issue(r0[1]);                 // pair kp + 4
         compute(1);
         st_lds_barrier();
     }
-    gm_epilogue(g, acc, m0, n0, wm, wn, lane);
+    gm_epilogue<MT>(g, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- training-mode BatchNorm helpers ---------------------------------------------------
@@ -362,10 +379,16 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
     hipStream_t st = (hipStream_t)stream;
     static const bool pipe = !(getenv("ST_GEMM_PIPE") && atoi(getenv("ST_GEMM_PIPE")) == 0);
     if (veca && pipe && Cin >= 4) {
-        if (vecw && pool_prev) hipLaunchKernelGGL((gm_pipe_kernel<true, true>), grid, dim3(GM_THREADS), 0, st, g);
-        else if (vecw) hipLaunchKernelGGL((gm_pipe_kernel<true, false>), grid, dim3(GM_THREADS), 0, st, g);
-        else if (pool_prev) hipLaunchKernelGGL((gm_pipe_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);
-        else hipLaunchKernelGGL((gm_pipe_kernel<false, false>), grid, dim3(GM_THREADS), 0, st, g);
+        // 32-row tiles when 64-row tiles would leave compute units with fewer than two workgroups (st_device_info: 256 CUs)
+        const bool small = (size_t)grid.x * grid.y < 512;
+        const dim3 grid32((g.M + 31) / 32, grid.y);
+#define GM_LAUNCH(VW, PL) do { if (small) hipLaunchKernelGGL((gm_pipe_kernel<VW, PL, 1>), grid32, dim3(GM_THREADS), 0, st, g); \
+                               else hipLaunchKernelGGL((gm_pipe_kernel<VW, PL, 2>), grid, dim3(GM_THREADS), 0, st, g); } while (0)
+        if (vecw && pool_prev) GM_LAUNCH(true, true);
+        else if (vecw) GM_LAUNCH(true, false);
+        else if (pool_prev) GM_LAUNCH(false, true);
+        else GM_LAUNCH(false, false);
+#undef GM_LAUNCH
     } else if (veca && vecw) hipLaunchKernelGGL((gm_kernel<true, true>), grid, dim3(GM_THREADS), 0, st, g);
     else if (veca) hipLaunchKernelGGL((gm_kernel<true, false>), grid, dim3(GM_THREADS), 0, st, g);
     else if (vecw) hipLaunchKernelGGL((gm_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);

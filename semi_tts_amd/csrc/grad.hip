@@ -1,10 +1,9 @@
 // grad.hip -- backward-pass building blocks for gfx950 (MI355X), training path.
 //
 //  * weight gradient of a conv1d / linear:  dW[n][ci][tap] = sum_rows dC[row][n] * A[row + tap - pad][ci]
-//    ("TN" GEMM: the reduction runs over the (utterance, frame) rows).  Same 64x64x16 fp32-MFMA tile
-//    engine as gemm.hip; both operands are transposed into LDS while staging so the MFMA fragments
-//    are again one ds_read_b128 each.  Rows are split over blockIdx.z into partial slabs that a
-//    second kernel adds in a fixed order (deterministic, no atomics).
+//    ("TN" GEMM: the reduction runs over the (utterance, frame) rows).  fp32-MFMA tiles whose columns are
+//    interleaved so that neither operand is ever transposed (see tn_kernel).  Rows are split over blockIdx.z
+//    into partial slabs that a second kernel adds in a fixed order (deterministic, no atomics).
 //  * the input gradient of a conv/linear is the FORWARD kernel (st_gemm_fwd) on dC with the
 //    weight transposed and tap-flipped by the caller, so nothing is needed here for it.
 //  * column sums (bias gradients), BatchNorm backward (training statistics), activation / dropout
@@ -13,7 +12,7 @@
 
 namespace {
 
-constexpr int TN_T = 64, TN_BK = 16, TN_LD = 20, TN_THREADS = 256;
+constexpr int TN_T = 64, TN_BK = 16, TN_THREADS = 256;
 
 struct TnArgs {
     const float* dC; int lddc; int dcoff;       // (Bn*Tout, >= dcoff+N)
@@ -25,14 +24,23 @@ struct TnArgs {
     int vecx, vecy;   // rows of dC / A are 16-byte aligned: one 16-byte load per thread instead of four scalar ones
 };
 
-// TM = tile edge (64 or 128): 4 waves as 2x2, each (TM/2) x (TM/2) = (TM/32)^2 MFMA 16x16 tiles.  The 128 tile halves the
-// LDS reads per MFMA (8 ds_read_b128 feed 64 MFMAs instead of 4 feeding 16) and is used when both N and the column
-// count reach 128.
+// TM = tile edge (64 or 128): 4 waves as 2x2, each (TM/2) x (TM/2) = FR x FR MFMA 16x16 tiles, FR = TM/32.  The 128 tile
+// halves the LDS reads per MFMA and is used when both N and the column count reach 128.
+//
+// No transposition anywhere: a 16-row chunk of dC / A is staged into LDS AS IT LIES IN MEMORY ([row][column], 16-byte
+// loads and stores, 16 adjacent lanes = 256 contiguous bytes of one row), and the MFMA tiles take INTERLEAVED columns:
+// tile t of a wave owns columns {FR r + t : r = 0..15} of the wave's 16 FR columns.  Lane (r, q) then reads, for k-step c,
+// ONE FR-vector at [row 4q + c][FR r ..] that carries its operand of all FR tiles (the reduction index of MFMA slot
+// (q, c) is row 4q + c for both operands), and in the result lane (r, q) holds, per output row, FR CONSECUTIVE columns
+// (one from each tile) -- a 16-byte store.  (r01/r02 form: both operands transposed while staging with 16 scalar LDS
+// stores per thread and chunk; the LSTM weight gradients ran at 52 TFLOP/s.)
 template <int TM>
 __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     constexpr int FR = TM / 32;                                            // MFMA tiles per wave and dimension
-    __shared__ __attribute__((aligned(16))) float Xs[TM * TN_LD];   // [n][m]
-    __shared__ __attribute__((aligned(16))) float Ys[TM * TN_LD];   // [ci][m]
+    constexpr int LD = TM + (TM == 64 ? 8 : 0);                            // 64: rows 4 apart must not share banks (8-byte reads)
+    typedef float frag_t __attribute__((ext_vector_type(FR)));
+    __shared__ __attribute__((aligned(16))) float Xs[2][TN_BK * LD];   // [m][n]
+    __shared__ __attribute__((aligned(16))) float Ys[2][TN_BK * LD];   // [m][ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * TM;
@@ -43,12 +51,8 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     const int z = blockIdx.z;
     const int mbeg = z * g.rows_per_z, mend = min(g.M, mbeg + g.rows_per_z);
 
-    // staging role: row m_local = tid/16 of the 16-row chunk, 4 consecutive columns (+64 for the second half of a 128 tile)
-    // 16 adjacent lanes take the 16 rows of the chunk (same 4 columns): their transposing LDS stores Xs[(col)*LD + row] then fall
-    // on 16 consecutive banks, and the next 16 lanes (4 columns further = 4*LD floats = 16 banks on) on the other 16 -- the
-    // former mapping (adjacent lanes = adjacent column groups) put a wave's 64 stores on 8 banks (8-way conflict), which made the
-    // staging cost as much LDS time as the chunk's MFMAs.  A row's 16 floats (64 B) are still one contiguous global segment.
-    const int sm = tid & 15, sc = (tid >> 4) * 4;
+    // staging role: row tid/16 of the 16-row chunk, 4 consecutive columns (+64 for the second half of a 128 tile)
+    const int sm = tid >> 4, sc = (tid & 15) * 4;
     f32x4 acc[FR][FR];
 #pragma unroll
     for (int i = 0; i < FR; ++i)
@@ -103,53 +107,69 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     };
 
     constexpr int NH = TM / 64;                                            // column halves staged per thread
-    const int fr = lane & 15, fk = (lane >> 4) * 4;
+    const int fr = lane & 15, fq = lane >> 4;
     f32x4 rx[NH], ry[NH];
+    auto request = [&](int m) __attribute__((always_inline)) {
 #pragma unroll
-    for (int h = 0; h < NH; ++h) { rx[h] = load_x(mbeg + sm, h * 64); ry[h] = load_y(mbeg + sm, h * 64); }
-    for (int m = mbeg; m < mend; m += TN_BK) {
+        for (int h = 0; h < NH; ++h) { rx[h] = load_x(m + sm, h * 64); ry[h] = load_y(m + sm, h * 64); }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                Xs[(h * 64 + sc + j) * TN_LD + sm] = rx[h][j];
-                Ys[(h * 64 + sc + j) * TN_LD + sm] = ry[h][j];
-            }
-        st_lds_barrier();      // LDS-only: the next chunk's global loads stay in flight across it
-        if (m + TN_BK < mend) {
-#pragma unroll
-            for (int h = 0; h < NH; ++h) { rx[h] = load_x(m + TN_BK + sm, h * 64); ry[h] = load_y(m + TN_BK + sm, h * 64); }
+        for (int h = 0; h < NH; ++h) {
+            *reinterpret_cast<f32x4*>(Xs[buf] + sm * LD + h * 64 + sc) = rx[h];
+            *reinterpret_cast<f32x4*>(Ys[buf] + sm * LD + h * 64 + sc) = ry[h];
         }
-        f32x4 a4[FR], b4[FR];
+    };
+    // two LDS buffers: chunk k+1 is written while chunk k is multiplied, one (LDS-only) barrier per chunk; the global loads of
+    // chunk k+2 are in flight across it
+    request(mbeg);
+    commit(0);
+    request(mbeg + TN_BK);
+    st_lds_barrier();
+    int buf = 0;
+    for (int m = mbeg; m < mend; m += TN_BK, buf ^= 1) {
+        commit(buf ^ 1);
+        request(m + 2 * TN_BK);
+        frag_t a4[4], b4[4];
 #pragma unroll
-        for (int t = 0; t < FR; ++t) {
-            a4[t] = *reinterpret_cast<const f32x4*>(Xs + (wm * (TM / 2) + t * 16 + fr) * TN_LD + fk);
-            b4[t] = *reinterpret_cast<const f32x4*>(Ys + (wn * (TM / 2) + t * 16 + fr) * TN_LD + fk);
+        for (int c = 0; c < 4; ++c) {
+            a4[c] = *reinterpret_cast<const frag_t*>(Xs[buf] + (4 * fq + c) * LD + wm * (TM / 2) + FR * fr);
+            b4[c] = *reinterpret_cast<const frag_t*>(Ys[buf] + (4 * fq + c) * LD + wn * (TM / 2) + FR * fr);
         }
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int mt = 0; mt < FR; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < FR; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
-        st_lds_barrier();      // LDS-only: the next chunk's global loads stay in flight across it
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][mt], b4[c][nt], acc[mt][nt], 0, 0, 0);
+        st_lds_barrier();
     }
+    // result: lane (r, q) holds D[i = 4q + e][j = r] of tile (mt, nt): row n = .. + FR i + mt, columns .. + FR r + nt
     float* out = g.part + (size_t)z * g.N * g.Cin * g.KT;
+    const int cib = c0 + wn * (TM / 2) + FR * fr;
+    const bool vec_out = FR == 4 && (g.fold || g.KT == 1) && (ncols % 4 == 0) && cib + 3 < ncols && st_aligned16(out);
 #pragma unroll
-    for (int nt = 0; nt < FR; ++nt) {
-        const int ci = c0 + wn * (TM / 2) + nt * 16 + (lane & 15);
-        if (ci >= ncols) continue;
+    for (int mt = 0; mt < FR; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < FR; ++mt)
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wm * (TM / 2) + FR * (4 * fq + e) + mt;
+            if (n >= g.N) continue;
+            if (vec_out) {
+                f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wm * (TM / 2) + mt * 16 + 4 * (lane >> 4) + r;
-                if (n >= g.N) continue;
-                if (g.fold) out[(size_t)n * ncols + ci] = acc[mt][nt][r];
-                else out[((size_t)n * g.Cin + ci) * g.KT + tap] = acc[mt][nt][r];
+                for (int nt = 0; nt < FR; ++nt) v[nt] = acc[mt][nt][e];
+                *reinterpret_cast<f32x4*>(out + (size_t)n * ncols + cib) = v;
+                continue;
             }
-    }
+#pragma unroll
+            for (int nt = 0; nt < FR; ++nt) {
+                const int ci = cib + nt;
+                if (ci >= ncols) continue;
+                if (g.fold) out[(size_t)n * ncols + ci] = acc[mt][nt][e];
+                else out[((size_t)n * g.Cin + ci) * g.KT + tap] = acc[mt][nt][e];
+            }
+        }
 }
 
 // out[i] (+)= sum_z part[z][i]   (fixed order)

@@ -201,6 +201,23 @@ int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view
                                         int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                         int B, int N, const st_attn_pre_job* pre, void* stream);
 
+/* Query projection + attention fin part in ONE launch: pq = W_q h_q (ref: src/module.py:380) is computed by the first workgroups
+ * and handed to the fin workgroups of the same launch (st_attn_fin_t16_fwd's work: :389-406, :262-264) as 8-byte
+ * {value, tag} words in `granules` ((B, A) 64-bit words, device memory, ZEROED by the caller before the first step of a
+ * forward); `epoch` = decode step + 1 (never 0) is the tag this launch writes and waits for.  The fin workgroups request S, v
+ * and the memory rows while pq is being computed: one kernel boundary and one exposed load round trip less per decode step.
+ * Needs A % 16 == 0, A <= 256 and (A / 16) * ceil(B / 16) + B * parts workgroups resident at once (<= compute units); when that
+ * does not hold the call fails and the caller uses st_skinny_linear_packed_fwd + st_attn_fin_t16_fwd. */
+typedef struct st_attn_fin_job {
+    const float* s_buf; const float* memory; const float* w_cum_prev;
+    float* w_out; int ld_wout; float* w_cum_out; const float* v;
+    st_t16_view ctx_dst[3]; int n_ctx_dst;
+    int parts;          /* workgroups per utterance (slices of the context dims): 1, 2, 4, 8 */
+    int L, A, E, F, K;
+} st_attn_fin_job;
+int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
+                          const st_attn_fin_job* job, int B, void* stream);
+
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
  * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) * stride + tap - pad, ci) * W(n, ci, tap) )
  * channels-last activations: A is (Bn * Tin, Cin) with row stride lda, C is (Bn * Tout, N)
@@ -465,6 +482,8 @@ typedef struct st_decoder_io {
                                * layer-1 output of every own-output feedback for the backward); 0: one scratch slot */
     int attn_s_step_floats;   /* > 0: attn_s_buf is a tape, slot t = S of step t (B*L*A floats apart), kept for the backward */
     float* attn_loc_tape;     /* optional (steps, B, L, F): location features of every step (slot 0 is never written: zero it) */
+    unsigned long long* pq_granules;   /* optional (B, A) 64-bit words: with attn_s_buf, the query projection and the attention fin
+                                        * part of a step run as ONE launch (st_query_attn_fin_fwd); zeroed by the callee per forward */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);

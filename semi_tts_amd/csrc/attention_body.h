@@ -47,6 +47,9 @@ struct AtArgs {
     int fin_parts;     // fin part only: workgroups per utterance, each a slice of the context dims E (1, 2, 4 or 8); every one
                        // repeats the energies + softmax (cheap), so the memory rows -- the bulk of the bytes -- are spread over more CUs
     int B, L, A, E, F, K;
+    // fin part inside the query-projection launch (pk_attnfin_kernel): the processed query arrives as 8-byte {value, tag} granules
+    // written by the linear's workgroups of the SAME launch; tag = epoch (decode step + 1)
+    const unsigned long long* pq_gran; unsigned epoch;
 };
 
 struct AtLds {  // offsets in floats into dynamic LDS
@@ -95,8 +98,9 @@ __device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
 // S[l][a] = pm[l][a] + sum_f W_l[a][f] cf[f][l] -- written to a.s_buf; it can run while the rest of the decode step does
 // (as extra workgroups of the proj launch, skinny_packed.hip).  PART 2 ("fin"): energies from S, softmax, context.
 // NT = threads per workgroup (512 in every launch; a 256-thread fin part measured slower, see attention.hip)
-template <bool VEC, int PART, int NT = AT_THREADS>
+template <bool VEC, int PART, int NT = AT_THREADS, bool GRAN = false>
 __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* lds) {
+    static_assert(!GRAN || (PART == 2 && VEC), "granule hand-off: fin part, vector form only");
     constexpr int NWV = NT / 64;                      // waves
     constexpr int PFR = AT_PF * (AT_THREADS / NT);    // memory rows parked in registers per thread
     constexpr int NPB = PART == 2 ? AT_THREADS / NT : 0;   // energy blocks per wave whose operands are requested at kernel entry
@@ -144,7 +148,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                 pf_pm4[i][j] = st_ld4(pmb + (size_t)l * A + min(lane * 4, A - 4));
             }
         }
-        pf_pq4 = st_ld4(pqb + min(lane * 4, A - 4));
+        if (!GRAN) pf_pq4 = st_ld4(pqb + min(lane * 4, A - 4));
         pf_v4 = st_ld4(a.v + min(lane * 4, A - 4));
         if (wave == 0) pf_cum = a.w_cum_prev[(size_t)b * L + min(lane, L - 1)];
     }
@@ -173,6 +177,39 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
             mpf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, ctx_active ? v0 + j * vstep : v0, 0, 0));
     }
 
+    if (GRAN) {
+        // The processed query of THIS step is produced by the linear's workgroups of the same launch (pk_attnfin_kernel) and
+        // handed over as 8-byte {value, tag} granules (one relaxed agent-scope store each, write-through; the data is the flag:
+        // no fence on either side -- MI355X guide, hand-off recipe R2).  Everything else this workgroup needs (S rows, v, the
+        // memory rows) was requested above and is in flight while the wave re-reads its four granules until every tag is
+        // this step's epoch.  The spin is bounded: on a time-out the query is poisoned with NaN (the caller's finite check trips).
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        gu64* gp = (gu64*)(a.pq_gran + (size_t)b * A + min(lane * 4, A - 4));
+        unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+        bool ok = false;
+        // ONE wave per workgroup polls (eight polling waves per workgroup measured 0.35 us per step slower: the polls compete with
+        // the producers' own loads); the others take the query from LDS -- the context-partial area is free at this point
+        if (wave == 0) {
+            for (int spins = 0; spins < (1 << 18); ++spins) {
+                g0 = __hip_atomic_load(gp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g2 = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g3 = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool mine = (unsigned)(g0 >> 32) == a.epoch && (unsigned)(g1 >> 32) == a.epoch &&
+                                  (unsigned)(g2 >> 32) == a.epoch && (unsigned)(g3 >> 32) == a.epoch;
+                ok = __all(mine);
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const float nanv = __builtin_nanf("");
+            const f32x4 q4 = ok ? f32x4{__uint_as_float((unsigned)g0), __uint_as_float((unsigned)g1), __uint_as_float((unsigned)g2),
+                                        __uint_as_float((unsigned)g3)}
+                                : f32x4{nanv, nanv, nanv, nanv};
+            if (lane * 4 < A) *reinterpret_cast<f32x4*>(part + lane * 4) = q4;
+        }
+        __syncthreads();
+        pf_pq4 = *reinterpret_cast<const f32x4*>(part + min(lane * 4, A - 4));
+    }
     AT_PROF(1);
     const bool wl_vec = VEC || ((F & 3) == 0 && st_aligned16(a.loc_lin_w));
     const int f4n = F >> 2;
@@ -411,7 +448,7 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
                     const int l = l0 + j < L ? l0 + j : L - 1;
                     pm4[j] = st_ld4(pmb + (size_t)l * A + a0);
                 }
-                pq4 = st_ld4(pqb + a0);
+                pq4 = GRAN ? pf_pq4 : st_ld4(pqb + a0);      // (granule form: A <= 256, so a0 == lane * 4)
                 v4 = st_ld4(a.v + a0);
             } else {
 #pragma unroll

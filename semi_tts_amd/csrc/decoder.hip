@@ -201,6 +201,12 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
 #else
 #define ST_SKIPPED(bit) 0
 #endif
+    // query projection + attention fin part as one launch with an in-launch hand-off of pq (st_query_attn_fin_fwd): needs the split
+    // attention step, every workgroup of the launch resident at once, and the granule words zeroed before the first step (a memset
+    // node when the loop is captured: a replay must not see the tags of the previous one)
+    const bool fuse_pq_fin = split_attn && !pre_in_pq && io->pq_granules && A % 16 == 0 && A <= 256 && E % 4 == 0 &&
+                             (A / 16) * ((B + 15) / 16) + B * fin_parts <= st_device_cus();
+    if (fuse_pq_fin) ST_HIP(hipMemsetAsync(io->pq_granules, 0, (size_t)B * A * sizeof(unsigned long long), (hipStream_t)stream));
     for (int t = 0; t < steps; ++t) {
         float* xq = io->xq_tape + (size_t)t * sv.q_floats;
         float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
@@ -222,7 +228,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         if (rc) return rc;
 
         // 2. processed query                                             ref: :380
-        if (pre_in_pq && t > 0) {   // attention pre part of THIS step rides along (needs only the weights of step t-1)
+        if (fuse_pq_fin) rc = 0;    // (rides with step 3)
+        else if (pre_in_pq && t > 0) {   // attention pre part of THIS step rides along (needs only the weights of step t-1)
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)(t - 1) * L, ldal, io->wcum_tape + (size_t)t * BL,
                                    w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)t * io->attn_s_step_floats, L, A, d->F,
                                    d->K, io->attn_pre_parts,
@@ -239,7 +246,17 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    ctx_t -> xq_{t+1}[ctx part], xd_t[ctx part], xo_t[ctx part]
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
-        if (ST_SKIPPED(2)) rc = 0;
+        if (fuse_pq_fin) {   // 2 + 3 as one launch: the fin workgroups wait for pq inside the launch (granule hand-off)
+            st_attn_fin_job fj;
+            memset(&fj, 0, sizeof(fj));
+            fj.s_buf = t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats;
+            fj.memory = io->memory; fj.w_cum_prev = io->wcum_tape + (size_t)t * BL;
+            fj.w_out = io->align_out + (size_t)t * L; fj.ld_wout = ldal; fj.w_cum_out = io->wcum_tape + (size_t)(t + 1) * BL; fj.v = w->attn_v;
+            for (int c = 0; c < 3; ++c) fj.ctx_dst[c] = ctx_dst[c];
+            fj.n_ctx_dst = 3; fj.parts = fin_parts; fj.L = L; fj.A = A; fj.E = E; fj.F = d->F; fj.K = d->K;
+            rc = st_query_attn_fin_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, stream);
+        }
+        else if (ST_SKIPPED(2)) rc = 0;
         else if (split_attn)     // S of this step was written by the pre part (step 0: no history yet, S = pm)
             rc = st_attn_fin_t16_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats, io->memory,
                                      io->wcum_tape + (size_t)t * BL,

@@ -117,6 +117,8 @@ struct PkArgs {
     float* y; int ldy; PkOut y_dst; int n_split; float* y2; int ldy2; int rep;
     // optional third row range [n_split2, N): act2/mask2 applied, written to y3_dst (column n - n_split2)
     int n_split2; int act2; const float* mask2; int ldmask2; PkOut y3_dst;
+    // optional: the plain range leaves as 8-byte {value, tag = epoch} granules (B, N) for consumer workgroups of the SAME launch
+    unsigned long long* gran; unsigned epoch;
 };
 
 __device__ __forceinline__ void pk_store(const PkOut& d, int b, int k, float v) {
@@ -332,6 +334,14 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
                 float v = st_act(s[r] + (a.bias ? l_bias[r] : 0.0f), a.act);
                 v4[r] = a.lmask ? v * l_m1[r] : v;
             }
+            if (a.gran) {   // one relaxed agent-scope (write-through) 8-byte store per value: the tag travels with the data
+                typedef __attribute__((address_space(1))) unsigned long long gu64;
+                gu64* gp = (gu64*)(a.gran + (size_t)b * a.N + n0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(gp + r, ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(v4[r]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (a.y) {
                 float* py = a.y + (size_t)b * a.ldy + n0;
                 if ((a.ldy & 3) == 0 && st_aligned16(a.y)) *reinterpret_cast<f32x4*>(py) = v4;
@@ -520,6 +530,28 @@ __global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const f32x4* w, con
         pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
     }
     else at_body<VEC, 1>(t, i - n_lin, pk_dyn_lds);
+}
+
+// A small linear whose CONSUMER rides in the same launch: the query projection pq = W_q h_q (first n_lin workgroups) and the fin
+// part of the attention step (energies, softmax, context; the workgroups after them).  The fin workgroups request everything
+// that does not depend on pq at once and then wait for pq as {value, tag} granules (at_body<.., GRAN = true>): one kernel
+// boundary and the fin part's exposed first-load latency less per decode step.  All workgroups must be co-resident (the
+// launcher checks n_lin + B * parts against the compute units).
+template <int NB, int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_attnfin_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                             const int B, const int N, const int tiles_a, const int n_lin,
+                                                             const PkArgs a_rest, const AtArgs t) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * NB * 64];
+    static_assert(KW * 64 == AT_THREADS, "both parts use 512-thread workgroups");
+    const int i = blockIdx.x;
+    if (i < n_lin) {
+        PkArgs a = a_rest;
+        a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N;
+        const int by = n_lin <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
+        pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
+    }
+    else at_body<true, 2, AT_THREADS, true>(t, i - n_lin, pk_dyn_lds);
 }
 
 #ifndef PK_TRIP_SMALL
@@ -726,6 +758,52 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
         return pk_launch_attnpre<4>(a, tiles, t, (hipStream_t)stream);
     }
     return pk_dispatch<1>(a, tiles, (hipStream_t)stream);
+}
+
+extern "C" int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
+                                     const st_attn_fin_job* job, int B, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(packed_wq && h_q && h_q->base && granules && epoch != 0 && job && B > 0, "st_query_attn_fin_fwd: bad arguments");
+    const int L = job->L, A = job->A, E = job->E, parts = job->parts;
+    ST_CHECK_ARG(L > 0 && E > 0 && A > 0 && A % 16 == 0 && A <= 256, "st_query_attn_fin_fwd: attention dim %d must be a multiple of 16, at most 256", A);
+    ST_CHECK_ARG(parts == 1 || ((parts == 2 || parts == 4 || parts == 8) && E % (4 * parts) == 0), "st_query_attn_fin_fwd: parts=%d, E=%d", parts, E);
+    ST_CHECK_ARG(job->s_buf && job->memory && job->w_cum_prev && job->w_out && job->w_cum_out && job->v, "st_query_attn_fin_fwd: null attention operand");
+    ST_CHECK_ARG(job->n_ctx_dst >= 0 && job->n_ctx_dst <= 3, "st_query_attn_fin_fwd: n_ctx_dst=%d", job->n_ctx_dst);
+    ST_CHECK_ARG(st_aligned16(job->s_buf) && st_aligned16(job->memory) && st_aligned16(job->v) && (reinterpret_cast<uintptr_t>(granules) & 7) == 0 &&
+                 E % 4 == 0 && E / 4 <= AT_THREADS, "st_query_attn_fin_fwd: operands must be 16-byte aligned, E a multiple of 4");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_wq, h_q, Q, "st_query_attn_fin_fwd");
+    if (rc) return rc;
+    a.B = B; a.N = A; a.H = 0; a.act = ST_ACT_NONE;
+    a.gran = granules; a.epoch = epoch;
+    AtArgs t;
+    memset(&t, 0, sizeof(t));
+    t.pm = job->s_buf; t.s_buf = const_cast<float*>(job->s_buf); t.memory = job->memory; t.w_cum_prev = job->w_cum_prev;
+    t.w_out = job->w_out; t.ld_wout = job->ld_wout; t.w_cum_out = job->w_cum_out; t.v = job->v; t.loc_lin_w = job->s_buf;
+    t.fin_parts = parts;
+    for (int d = 0; d < job->n_ctx_dst; ++d) t.ctx_dst[d] = job->ctx_dst[d];
+    t.B = B; t.L = L; t.A = A; t.E = E; t.F = job->F; t.K = job->K;
+    t.pq_gran = granules; t.epoch = epoch;
+    const int tiles = A / 16, BT = (B + 15) >> 4;
+    const int n_lin = tiles * BT, n_fin = B * parts;
+    // the waiting workgroups hold their compute units: everything must be resident at once
+    ST_CHECK_ARG(n_lin + n_fin <= st_device_cus(), "st_query_attn_fin_fwd: %d + %d workgroups do not fit the device at once (use the two launches)",
+                 n_lin, n_fin);
+    const AtLds o = at_layout(L, A, E, job->F, job->K, 2, L, false);
+    const size_t lds = (size_t)o.total * sizeof(float);
+    constexpr int KW = 8;
+    ST_CHECK_ARG(lds + sizeof(f32x4) * KW * 64 <= 160 * 1024, "st_query_attn_fin_fwd: L=%d needs too much LDS", L);
+    auto kern = pk_attnfin_kernel<1, KW, PK_TRIP_SMALL>;
+    static size_t configured = 0;
+    if (lds > 48 * 1024 && lds > configured) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_lin + n_fin), dim3(KW * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N,
+                       tiles, n_lin, a, t);
+    ST_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_view* x, int K,

@@ -35,6 +35,17 @@ void st_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+// compute units of the current device (cached; 256 on MI355X)
+static inline int st_device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 1;
+    }
+    return n;
+}
+
 static __host__ __device__ inline bool st_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---------------------------------------------------------------- device helpers (wave = 64)

@@ -290,6 +290,7 @@ class Decoder(nn.Module):
         self.attn_split = True
         self.attn_pre_parts = 4      # workgroups per utterance of the pre part (measured at L = 43: 1 / 2 / 4 parts 37.1 / 35.9 / 35.4 us per step)
         self.attn_fin_parts = 2      # workgroups per utterance of the fin part (slices of the context dims)
+        self.attn_pq_in_fin = True   # inference: query projection and fin part share one launch (in-launch hand-off of pq)
 
     # -- helpers ---------------------------------------------------------------------------------
     def _weights_struct(self, keep, fuse_pre0=False):
@@ -497,6 +498,11 @@ class Decoder(nn.Module):
                 parts *= 2                                            # position range in LDS (32 filters x <= ~512 positions)
             io.attn_pre_parts = parts
             io.attn_fin_parts = int(self.attn_fin_parts)
+            if self.attn_pq_in_fin and not keep_tapes:
+                # query projection + attention fin part as ONE launch per step (st_query_attn_fin_fwd): pq is handed over inside
+                # the launch as 8-byte {value, tag} words; the library falls back to two launches when the shapes do not fit
+                tapes['pq_gran'] = torch.empty(B, 2 * A, **f32)            # (B, A) 64-bit words
+                io.pq_granules = ops._p(tapes['pq_gran'])
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
         if defer:

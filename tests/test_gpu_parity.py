@@ -553,6 +553,13 @@ def test_headline_shape_c2_against_oracle(dev):
             report('tts_c2_attn_variants', split=int(split), fin=fin, mel=maxdiff(mel_o, mel), align=maxdiff(align_o, align))
             assert maxdiff(mel_o, mel) < 2e-5 and maxdiff(align_o, align) < 1e-5
         m.decoder.attn_split, m.decoder.attn_fin_parts = True, 2
+        # the query projection handed to the attention fin part INSIDE one launch (8-byte {value, tag} granules) is the same
+        # arithmetic as the two launches: bit-identical outputs, and again on a second pass (the tags of the first must not leak)
+        m.decoder.attn_pq_in_fin = False
+        mel_2, _, align_2, _ = m(txt.to(dev), None, 258, spk.to(dev), tf_rate=0.0)
+        m.decoder.attn_pq_in_fin = True
+        mel_1, _, align_1, _ = m(txt.to(dev), None, 258, spk.to(dev), tf_rate=0.0)
+        assert torch.equal(mel_2, mel) and torch.equal(align_2, align) and torch.equal(mel_1, mel) and torch.equal(align_1, align)
     torch.set_num_threads(8)
     with torch.no_grad():
         mel_r, lin_r, align_r, stop_r = O.tacotron2_forward(_oracle_weights(m), txt, 258, spk, full_hp(0.0))

@@ -231,11 +231,15 @@ def attention_step(W: Weights, query: Tensor, memory: Tensor, processed_memory: 
       ctx  = w @ memory                                       :405-406
     """
     pq = linear(query, W[prefix + 'query_layer.linear.weight']).unsqueeze(1)        # (B,1,A)
-    hist = torch.stack([w_prev, w_cum], dim=-1)                                      # (B,L,2) channels-last
-    wc = W[prefix + 'loc_conv.conv.weight']                                          # (F,2,k)
-    k = wc.shape[2]
-    loc = conv1d_cl(hist, wc, None, (k - 1) // 2)                                    # (B,L,F)
-    loc = linear(loc, W[prefix + 'loc_linear.linear.weight'])                        # (B,L,A)
+    if (prefix + 'loc_conv.conv.weight') in W:                                       # loc_aware (:382-385)
+        wc = W[prefix + 'loc_conv.conv.weight']                                      # (F,2,k), or (F,1,k) without use_summed_weights
+        # attn_history: stack[w_prev, w_cum] or w_prev alone (:235-239)               (B,L,C) channels-last
+        hist = torch.stack([w_prev, w_cum], dim=-1) if wc.shape[1] == 2 else w_prev.unsqueeze(-1)
+        k = wc.shape[2]
+        loc = conv1d_cl(hist, wc, None, (k - 1) // 2)                                # (B,L,F)
+        loc = linear(loc, W[prefix + 'loc_linear.linear.weight'])                    # (B,L,A)
+    else:
+        loc = 0                                                                      # :386-387
     e = linear(torch.tanh(pq + loc + processed_memory), W[prefix + 'v.linear.weight']).squeeze(-1)
     w = torch.softmax(e, dim=1)
     ctx = torch.bmm(w.unsqueeze(1), memory).squeeze(1)

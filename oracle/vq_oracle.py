@@ -37,8 +37,9 @@ def neg_batch_l2(x: Tensor, y: Tensor) -> Tensor:
     return -d
 
 
-def l2_forward(W: Weights, x: Tensor, first_n_real_mel: int = 0):
-    """L2Embedding.forward (stop_grad=True, skip_prob=0: every shipped config).
+def l2_forward(W: Weights, x: Tensor, first_n_real_mel: int = 0, stop_grad: bool = True, skip: bool = False):
+    """L2Embedding.forward (stop_grad=True, skip_prob=0 in every shipped config; stop_grad=False = ST-onehot code :137-138,
+    skip=True = the skip connection drawn at :140-142).
     ref: src/embed.py:105-147.
     Returns p_code (B,S,V), idx (B,S) int64, new_latent (B,S,D) with the straight-through
     value fl(fl(x + code) - x) (embed.py:145), and the table.  first_n_real_mel > 0: the similarities of the remaining
@@ -54,8 +55,13 @@ def l2_forward(W: Weights, x: Tensor, first_n_real_mel: int = 0):
         sim = ts * neg_batch_l2(x, table).view(B, S, -1)                              # :124
     p = sim.softmax(dim=-1)                                                           # :127
     idx = p.argmax(dim=-1)                                                            # :130 (argmax of p, not sim)
-    code = table[idx]                                                                 # :134
-    new_latent = x + code - x.detach()                                                # :145 (straight-through estimator)
+    if stop_grad:
+        code = table[idx]                                                             # :134
+    else:
+        onehot = torch.nn.functional.one_hot(idx, table.shape[0]).to(p.dtype)
+        p_hard = p + (onehot - p).detach()                                            # :137
+        code = p_hard.matmul(table)                                                   # :138  F.linear(p_hard, table.T)
+    new_latent = x if skip else x + code - x.detach()                                 # :142 / :145 (straight-through estimator)
     return p, idx, new_latent, table
 
 
@@ -69,15 +75,24 @@ def l2_inference(W: Weights, txt: Tensor) -> Tensor:
     return e
 
 
-def seperate_forward(W: Weights, x: Tensor):
-    """SeperateEmbedding.forward (stop_grad=True).  ref: src/embed.py:187-205."""
+def seperate_forward(W: Weights, x: Tensor, stop_grad: bool = True):
+    """SeperateEmbedding.forward (stop_grad=True in config/supervised.yaml; False = the ST-onehot code, :198-203).
+    ref: src/embed.py:187-205."""
     logits = x.matmul(W['asr_final_layer.weight'].t()) + W['asr_final_layer.bias']
     p = torch.softmax(logits, dim=-1)                                                 # :190
     idx = p.argmax(dim=-1)                                                            # :193
-    out = W['embedding.weight'][idx]                                                  # :195
-    if 'proj_attr.weight' in W:                                                       # :196-197
-        a = W['phn_attr.weight'][idx].matmul(W['proj_attr.weight'].t()) + W['proj_attr.bias']
-        out = torch.cat([out, a], dim=-1)
+    if stop_grad:
+        out = W['embedding.weight'][idx]                                              # :195
+        if 'proj_attr.weight' in W:                                                   # :196-197
+            a = W['phn_attr.weight'][idx].matmul(W['proj_attr.weight'].t()) + W['proj_attr.bias']
+            out = torch.cat([out, a], dim=-1)
+    else:
+        onehot = torch.nn.functional.one_hot(idx, p.shape[-1]).to(p.dtype)
+        p_hard = p + (onehot - p).detach()                                            # :199
+        out = p_hard.matmul(W['embedding.weight'])                                    # :200  F.linear(p_hard, weight.T)
+        if 'proj_attr.weight' in W:                                                   # :201-203
+            a = p_hard.matmul(W['phn_attr.weight']).matmul(W['proj_attr.weight'].t()) + W['proj_attr.bias']
+            out = torch.cat([out, a], dim=-1)
     return p, idx, out
 
 

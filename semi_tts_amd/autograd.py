@@ -198,19 +198,22 @@ def softmax_argmax(logits):
 
 
 class _VqL2Fn(Function):
-    """L2Embedding.forward with stop_grad=True (src/embed.py:105-147): p_code = softmax(relu(temp) * neg_batch_l2(x, table)),
-    idx = argmax, new_latent = x + table[idx] - x.detach() (straight-through).  Backward (what autograd derives there):
-        g      = relu(temp) * softmax'(dp_code)                       (n, V)
+    """L2Embedding.forward (src/embed.py:105-147): p_code = softmax(relu(temp) * neg_batch_l2(x, table)), idx = argmax,
+    new_latent = x + picked - x.detach() (straight-through).  Backward (what autograd derives there):
+        g      = relu(temp) * softmax'(dp_code [+ dnew_latent E^T with the ST-onehot code])              (n, V)
         dx     = dnew_latent + 2 (g E) - 2 x rowsum(g)
         dtable = scatter_add(dnew_latent by idx) + [rows < n_real:] 2 (g^T x) - 2 E colsum(g)
-    `n_real` rows (first_n_real_mel * S, or all) let the p_code objectives reach the table (:115-122)."""
+        dtemp  = [temp > 0] sum(g * meas) / relu(temp)           (a learnable temperature, embed.py:34)
+    `n_real` rows (first_n_real_mel * S, or all) let the p_code objectives reach the table (:115-122).
+    stop_grad=True picks table[idx] (:134); False is the ST-onehot code p_hard @ table with p_hard = p + (onehot - p).detach()
+    (:137-138): the same value up to one rounding of p + (1 - p), and its gradient also reaches p_code."""
 
     @staticmethod
-    def forward(ctx, x, table, temp, n_real):
+    def forward(ctx, x, table, temp, n_real, st_onehot):
         x = x.contiguous()
         p, idx, out = ops.vq_l2(x, table, temp)
         ctx.save_for_backward(x, table, temp, p, idx)
-        ctx.n_real = n_real
+        ctx.n_real, ctx.st_onehot = n_real, bool(st_onehot)
         ctx.mark_non_differentiable(idx)
         return p, out, idx
 
@@ -221,23 +224,56 @@ class _VqL2Fn(Function):
         x2, dl2 = _rows(x), _rows(dlat.contiguous())
         n = x2.shape[0]
         n_real = n if ctx.n_real is None else ctx.n_real
-        g, rs = ops.softmax_bwd(_rows(p), _rows(dp.contiguous()), 1.0, temp, want_rowsum=True)
-        dx = dtab = None
+        tab = table.detach().contiguous()
+        dp2 = _rows(dp.contiguous())
+        if ctx.st_onehot:
+            dp2 = dp2 + ops.gemm(dl2, tab)                                           # d p_hard = dnew_latent E^T   (n, V)
+        g, rs = ops.softmax_bwd(_rows(p), dp2, 1.0, temp, want_rowsum=True)
+        dx = dtab = dtemp = None
         if ctx.needs_input_grad[0]:
-            ge = ops.gemm(g, table.detach().t().contiguous())                      # (n, D) = g E
+            ge = ops.gemm(g, tab.t().contiguous())                                   # (n, D) = g E
             dx = ops.rowscale_combine(ge, 2.0, x2, rs.reshape(-1), -2.0, dl2).view(x.shape)
         if ctx.needs_input_grad[1]:
             dtab = ops.scatter_add_rows(dl2, idx.reshape(-1), V)
             if n_real > 0:
                 gx = ops.gemm_wgrad(g[:n_real], x2[:n_real])                       # (V, D) = g^T x over the real rows
                 cs = ops.colsum(g[:n_real])
-                dtab = ops.rowscale_combine(gx, 2.0, table.detach().contiguous(), cs, -2.0, dtab)
-        return dx, dtab, None, None
+                dtab = ops.rowscale_combine(gx, 2.0, tab, cs, -2.0, dtab)
+        if ctx.needs_input_grad[2]:
+            # sim = relu(temp) * meas, meas = -(|x|^2 + |e|^2 - 2 x.e): d temp = sum(g / relu(temp) * meas) for temp > 0
+            meas = 2.0 * ops.gemm(x2, tab) - x2.pow(2).sum(1, keepdim=True) - tab.pow(2).sum(1)
+            t = temp.detach().clamp_min(0.0)
+            dtemp = torch.where(t > 0, (g * meas).sum() / t.clamp_min(1e-30), torch.zeros_like(t)).view(temp.shape)
+        return dx, dtab, dtemp, None, None
 
 
-def vq_l2(x, table, temp, n_real=None):
+def vq_l2(x, table, temp, n_real=None, st_onehot=False):
     """-> (p_code, new_latent, idx)"""
-    return _VqL2Fn.apply(x, table, temp, n_real)
+    return _VqL2Fn.apply(x, table, temp, n_real, st_onehot)
+
+
+class _StOnehotCodeFn(Function):
+    """ST-onehot code of SeperateEmbedding (src/embed.py:198-203): p_hard @ table with p_hard = p + (onehot(idx) - p).detach() --
+    the value of table[idx] (up to one rounding of p + (1 - p)); the gradient reaches p (d p = d code @ table^T) and the table rows
+    (scatter-add, as p_hard is the one-hot matrix in value)."""
+
+    @staticmethod
+    def forward(ctx, p, table, idx):
+        ctx.save_for_backward(table, idx)
+        ctx.p_shape = p.shape
+        return ops.gather_rows(table.detach().contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        table, idx = ctx.saved_tensors
+        d2 = _rows(dout.contiguous())
+        dp = ops.gemm(d2, table.detach().contiguous()).view(ctx.p_shape) if ctx.needs_input_grad[0] else None
+        dtab = ops.scatter_add_rows(d2, idx.reshape(-1), table.shape[0]) if ctx.needs_input_grad[1] else None
+        return dp, dtab, None
+
+
+def st_onehot_code(p, table, idx):
+    return _StOnehotCodeFn.apply(p, table, idx)
 
 
 class _BiLstmFn(Function):
@@ -358,8 +394,6 @@ class _DecoderFn(Function):
         B, L, E = memory.shape
         r, n_mels, P = dec.n_frames_per_step, dec.n_mels, dec.prenet_dim
         Q, D, A, F, K = dec.query_rnn_dim, dec.dec_rnn_dim, dec.attn_dim, dec.n_location_filters, dec.location_kernel_size
-        if any(s == -2 for s in src[:steps - 1]):
-            raise NotImplementedError('teacher-mean decoder inputs (drop_dec_in > 0) have no backward (no shipped config uses them)')
         # own-output feedback (scheduled sampling steps / rows without a teacher): the gradient of dec_in_{t+1} flows into mel_t
         own = Bt != B or any(s == -1 for s in src[:steps - 1])
         dev = memory.device
@@ -482,6 +516,11 @@ class _DecoderFn(Function):
                         if src[t] >= 0:
                             ops.copy3d(dteacher[:, src[t]:src[t] + 1], dxq[t + 1:t + 2].permute(1, 0, 2)[:Bt, :, :P], Bt, 1, P,
                                        accumulate=True)
+                    # steps fed with teacher.mean(dim=1) (drop_dec_in, src/module.py:193-194): d mean / d frame = 1 / Tt for every frame
+                    mean_steps = [t + 1 for t in range(steps - 1) if src[t] == -2]
+                    if mean_steps:
+                        dmean_in = dxq[mean_steps][:, :Bt, :P].sum(0) / Tt                 # (Bt, P)
+                        dteacher += dmean_in.unsqueeze(1)
         c = lambda t: t.contiguous()
         grads = (None, None, dmem, dpm, dstd, dmean, dteacher,
                  dpre_w0, dpre_w1,                                                # prenet weights: only via own-output feedback
@@ -496,8 +535,7 @@ class _DecoderFn(Function):
 def decoder_loop(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre):
     params = (dec.prenet.layers[0].linear.weight, dec.prenet.layers[1].linear.weight,
               dec.query_rnn.weight_ih, dec.query_rnn.weight_hh, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh,
-              dec.attn.query_layer.linear.weight, dec.attn.v.linear.weight, dec.attn.loc_conv.conv.weight,
-              dec.attn.loc_linear.linear.weight,
+              dec.attn.query_layer.linear.weight, dec.attn.v.linear.weight, *dec.attn.location_weights(),
               dec.dec_rnn.weight_ih, dec.dec_rnn.weight_hh, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh,
               dec.proj.linear.weight, dec.proj.linear.bias, dec.gate_layer.linear.weight, dec.gate_layer.linear.bias)
     return _DecoderFn.apply(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, *params)

@@ -54,10 +54,8 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
     // own-output feedback anywhere in the plan?
     bool own = false;
     if (io->step_src)
-        for (int t = 0; t + 1 < steps; ++t) {
-            ST_CHECK_ARG(io->step_src[t] != -2, "st_decoder_backward: teacher-mean inputs (drop_dec_in > 0) have no backward");
-            own = own || io->step_src[t] == -1 || io->Bt < B;
-        }
+        for (int t = 0; t + 1 < steps; ++t)     // (-2 = teacher mean: like a teacher frame, no feedback for rows < Bt; the caller spreads
+            own = own || io->step_src[t] == -1 || io->Bt < B;     //  the input gradient of such a step over the teacher's frames)
     ST_CHECK_ARG(!own || (io->dY && io->dxo_rw && io->wpg_t && io->pre_w1_t && io->pre_w0_t && io->xq_nat && io->pre1_nat &&
                           io->d2_tape && io->dp1_tape && io->tmp_p && io->tmp_in && io->Bt > 0 && io->Bt <= B),
                  "st_decoder_backward: own-output feedback needs the prenet tapes / scratch");

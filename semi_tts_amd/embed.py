@@ -117,22 +117,19 @@ class L2Embedding(BaseEmbedding):
     def forward(self, enc_embs, first_n_real_mel=0):
         """enc_embs (B,S,D) -> (p_code (B,S,V), new_latent (B,S,D), 0, 0).  ref: src/embed.py:105-147.
         `first_n_real_mel` only detaches the table for part of the batch (forward values unchanged)."""
-        if not self.stop_grad:
-            raise NotImplementedError('ST-onehot variant (stop_grad=False): every shipped config uses stop_grad=True')
-        if self.training and self.skip_prob > 0 and np.random.rand() < self.skip_prob:
-            raise NotImplementedError('skip connection (skip_prob > 0): every shipped config uses 0')
         table = self._table(self.learnable_table)
         if self.training and torch.is_grad_enabled():
             # differentiable: straight-through gradient to enc_embs, p_code -> CTC gradient to enc_embs and (for the first
             # `first_n_real_mel` utterances, or all of them) to the table, scatter-add of the picked rows      :115-145
-            if isinstance(self.temp, nn.Parameter) and self.temp.requires_grad:
-                raise NotImplementedError("learnable temperature (temp='learnable'): no shipped config")
             S = enc_embs.shape[1]
-            p_code, new_latent, idx = AG.vq_l2(enc_embs, table, self.temp, first_n_real_mel * S if first_n_real_mel > 0 else None)
+            p_code, new_latent, idx = AG.vq_l2(enc_embs, table, self.temp, first_n_real_mel * S if first_n_real_mel > 0 else None,
+                                               st_onehot=not self.stop_grad)                                    # :132-138
         else:
             p_code, idx, new_latent = ops.vq_l2(enc_embs.contiguous(), table, self.temp)
         self.last_idx = idx
-        return p_code, new_latent, 0, 0
+        if self.training and self.skip_prob > 0 and np.random.rand() < self.skip_prob:
+            new_latent = enc_embs                        # skip connection, only when training (:140-142; the draw comes after the
+        return p_code, new_latent, 0, 0                  # code is picked, as in the reference)
 
 
 class SeperateEmbedding(BaseEmbedding):
@@ -156,14 +153,15 @@ class SeperateEmbedding(BaseEmbedding):
         return self._lookup(self._table(self.embedding.weight), txt)                 # :180-185
 
     def forward(self, enc_embs, first_n_real_mel=0):
-        if not self.stop_grad:
-            raise NotImplementedError('ST-onehot variant (stop_grad=False)')
         x = enc_embs.contiguous()
         if self.training and torch.is_grad_enabled():
             logits = AG.linear(x, self.asr_final_layer.weight, self.asr_final_layer.bias)
             p_code, idx = AG.softmax_argmax(logits)                                  # :190-193
             self.last_idx = idx
-            return p_code, self._lookup(self._table(self.embedding.weight), idx), 0, 0      # :195-197
+            table = self._table(self.embedding.weight)
+            if not self.stop_grad:                                                   # ST-onehot code :198-203
+                return p_code, AG.st_onehot_code(p_code, table, idx), 0, 0
+            return p_code, self._lookup(table, idx), 0, 0                            # :195-197
         logits = ops.gemm(x.view(-1, x.shape[-1]), self.asr_final_layer.weight, bias=self.asr_final_layer.bias)
         p_code, idx = ops.softmax_argmax(logits.view(*x.shape[:-1], -1))             # :190-193
         self.last_idx = idx

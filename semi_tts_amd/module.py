@@ -179,12 +179,24 @@ class Attention(nn.Module):
         self.v = Linear(hidden_dim, 1, bias=False)
         self.loc_aware = loc_aware
         self.use_summed_weights = use_summed_weights
-        if not (loc_aware and use_summed_weights):
-            raise NotImplementedError('the HIP attention implements loc_aware=True, use_summed_weights=True '
-                                      '(every shipped config)')
-        self.loc_conv = Conv1d(in_channels=2, out_channels=n_location_filters, kernel_size=location_kernel_size,
-                               bias=False, stride=1, dilation=1)
-        self.loc_linear = Linear(n_location_filters, hidden_dim, bias=False, w_init_gain='tanh')
+        self._dims = (hidden_dim, n_location_filters, location_kernel_size)
+        if loc_aware:                                                                    # ref: src/module.py:358-366
+            self.loc_conv = Conv1d(in_channels=2 if use_summed_weights else 1, out_channels=n_location_filters,
+                                   kernel_size=location_kernel_size, bias=False, stride=1, dilation=1)
+            self.loc_linear = Linear(n_location_filters, hidden_dim, bias=False, w_init_gain='tanh')
+
+    def location_weights(self):
+        """(W_c (F, 2, K), W_l (A, F)) as the kernels take them.  The kernels always convolve [w_prev ; w_cum]: without
+        use_summed_weights the cumulative channel gets zero taps (the conv over w_prev alone, src/module.py:239), without
+        loc_aware both are zero (processed_loc_feat = 0, :386-387).  Differentiable in the real parameters (torch.cat)."""
+        A, F_, K = self._dims
+        if not self.loc_aware:
+            dev = self.v.linear.weight.device
+            return torch.zeros(F_, 2, K, device=dev), torch.zeros(A, F_, device=dev)
+        wc = self.loc_conv.conv.weight
+        if not self.use_summed_weights:
+            wc = torch.cat([wc, torch.zeros_like(wc)], dim=1)
+        return wc, self.loc_linear.linear.weight
 
     def process_memory(self, memory):
         return ops.gemm(memory, self.memory_layer.linear.weight)
@@ -195,12 +207,14 @@ class Attention(nn.Module):
         B, L, E = memory.shape
         pq = ops.linear_small(query, self.query_layer.linear.weight)
         hist = attn_history.contiguous()
-        w_prev, w_cum = hist[:, 0].contiguous(), hist[:, 1].contiguous()
+        w_prev = hist[:, 0].contiguous()
+        w_cum = hist[:, 1].contiguous() if hist.shape[1] > 1 else torch.zeros_like(w_prev)      # (B,1,L) without use_summed_weights
         w = torch.empty(B, L, device=memory.device, dtype=torch.float32)
         w_cum_new = torch.empty_like(w)
         ctx = torch.empty(B, E, device=memory.device, dtype=torch.float32)
-        ops.attn_step(pq, processed_memory, memory, w_prev, w_cum, w, w_cum_new, self.loc_conv.conv.weight,
-                      self.loc_linear.linear.weight, self.v.linear.weight, ctx)
+        wc, wl = self.location_weights()
+        ops.attn_step(pq, processed_memory, memory, w_prev, w_cum, w, w_cum_new, wc.detach().contiguous(), wl.detach().contiguous(),
+                      self.v.linear.weight, ctx)
         return ctx, w
 
 
@@ -314,13 +328,15 @@ class Decoder(nn.Module):
             ops.gemm(w0, pwT, out=pg_w[in_dim + 1:])
             ops.gemm(w0, self.proj.linear.bias.view(1, -1), out=pg_b[in_dim + 1:].view(-1, 1))
             keep.append(pwT)
-        keep += [pg_w, pg_b]
+        loc_wc, loc_wl = (t.detach().contiguous() for t in self.attn.location_weights())
+        keep += [loc_wc, loc_wl]
+        keep += [pg_w, pg_b]           # (the last two entries: the deferred projection of _run_loop reads them)
         tensors = dict(
             prenet_w0=self.prenet.layers[0].linear.weight, prenet_w1=self.prenet.layers[1].linear.weight,
             q_w_ih=self.query_rnn.weight_ih, q_w_hh=self.query_rnn.weight_hh,
             q_b_ih=self.query_rnn.bias_ih, q_b_hh=self.query_rnn.bias_hh,
             attn_query_w=self.attn.query_layer.linear.weight, attn_v=self.attn.v.linear.weight,
-            attn_loc_conv_w=self.attn.loc_conv.conv.weight, attn_loc_lin_w=self.attn.loc_linear.linear.weight,
+            attn_loc_conv_w=loc_wc, attn_loc_lin_w=loc_wl,
             d_w_ih=self.dec_rnn.weight_ih, d_w_hh=self.dec_rnn.weight_hh,
             d_b_ih=self.dec_rnn.bias_ih, d_b_hh=self.dec_rnn.bias_hh, projgate_w=pg_w, projgate_b=pg_b)
         for k, t in tensors.items():

@@ -292,7 +292,8 @@ def _double_masks(masks):
     return [m.double() for m in masks]
 
 
-@pytest.mark.parametrize('name', ['tts_tiny_train_tf', 'tts_tiny_sched', 'tts_tiny_partial', 'tts_tiny_pretrain'])
+@pytest.mark.parametrize('name', ['tts_tiny_train_tf', 'tts_tiny_sched', 'tts_tiny_partial', 'tts_tiny_pretrain', 'tts_tiny_dropin',
+                                  'tts_tiny_noloc', 'tts_tiny_nosum'])
 def test_tacotron2_backward_against_oracle_tiny_golden(dev, name):
     """Whole Tacotron2 in training mode with the reference's recorded dropout masks and coin flips -- teacher forcing,
     scheduled sampling (own output fed back on some steps) and a partial-teacher batch (unpaired rows always feed their
@@ -601,21 +602,61 @@ def test_vq_l2_backward_vs_oracle(dev, B, S, D, V, attr, n_real):
     assert all(v < 2e-5 for k, v in errs.items() if k.startswith('d')), errs
 
 
-def test_seperate_embedding_backward_vs_oracle(dev):
+@pytest.mark.parametrize('variant', ['st_onehot', 'learn_temp', 'skip', 'st_onehot_real2'])
+def test_vq_l2_variants_backward_vs_oracle(dev, variant):
+    """The L2Embedding options no shipped config turns on: the ST-onehot code (stop_grad=False, src/embed.py:137-138: the latent
+    gradient also reaches p_code), a learnable temperature (temp < 0 in the constructor, :33-34), the skip connection
+    (skip_prob, :140-142) -- forward values and every gradient against float64 autograd through the oracle."""
+    import numpy as np
+    from oracle import vq_oracle as VQ
+    from semi_tts_amd.embed import L2Embedding
+    B, S, D, V = 4, 6, 32, 21
+    n_real = 2 if variant.endswith('real2') else 0
+    stop = not variant.startswith('st_onehot')
+    cb = L2Embedding(V, False, 'normal', D, 0, 0, -1 if variant == 'learn_temp' else 1, 1.0 if variant == 'skip' else 0, stop)
+    W = {'learnable_table': rnd(V, D, scale=0.5, seed=1), 'temp': torch.tensor([0.7])}
+    cb.learnable_table = torch.nn.Parameter(W['learnable_table'].clone())
+    with torch.no_grad():
+        cb.temp.copy_(W['temp'])
+    cb = cb.to(dev).train()
+    x = rnd(B, S, D, scale=0.6, seed=2)
+    dp, dl = rnd(B, S, V, seed=3), rnd(B, S, D, seed=4)
+    xd = x.to(dev).requires_grad_()
+    p, lat, _, _ = cb(xd, n_real)
+    torch.autograd.backward([p, lat], [dp.to(dev), dl.to(dev)])
+
+    def fn(Wd, xx):
+        pp, idx, nl, _ = VQ.l2_forward(Wd, xx, n_real, stop_grad=stop, skip=variant == 'skip')
+        return pp, nl
+    outs, wg, ig = oracle_grads(fn, W, [x], [dp, dl])
+    assert torch.equal(cb.last_idx.cpu(), outs[0].argmax(-1))
+    errs = dict(p=maxdiff(p, outs[0]), lat=maxdiff(lat, outs[1]), dx=relerr(xd.grad, ig[0]),
+                dtable=relerr(cb.learnable_table.grad, wg['learnable_table']))
+    if variant == 'learn_temp':
+        assert isinstance(cb.temp, torch.nn.Parameter)
+        errs['dtemp'] = abs(float(cb.temp.grad) - float(wg['temp'])) / max(1.0, abs(float(wg['temp'])))
+    report('vq_l2_variants', variant=variant, **errs)
+    assert errs['p'] < 5e-5 and errs['lat'] < 1e-5
+    assert all(v < 3e-5 for k, v in errs.items() if k.startswith('d')), errs
+
+
+@pytest.mark.parametrize('stop_grad', [True, False])
+def test_seperate_embedding_backward_vs_oracle(dev, stop_grad):
     """SeperateEmbedding.forward in training mode (the codebook of config/supervised.yaml): softmax(Linear) posterior +
-    embedding of the argmax (no straight-through path).  ref: src/embed.py:187-205"""
+    embedding of the argmax (no straight-through path); stop_grad=False = the ST-onehot code whose gradient also reaches the
+    posterior.  ref: src/embed.py:187-205"""
     from oracle import vq_oracle as VQ
     from semi_tts_amd.embed import SeperateEmbedding
     torch.manual_seed(3)
     V, D = 43, 64
-    cb = SeperateEmbedding(V, False, 'normal', D, 0, 0, 1, 0, True).to(dev).train()
+    cb = SeperateEmbedding(V, False, 'normal', D, 0, 0, 1, 0, stop_grad).to(dev).train()
     W = {k: v.detach().cpu().clone() for k, v in cb.state_dict().items()}
     x = rnd(3, 8, D, seed=5)
     dp, dl = rnd(3, 8, V, seed=6), rnd(3, 8, D, seed=7)
     xd = x.to(dev).requires_grad_()
     p, lat, _, _ = cb(xd)
     torch.autograd.backward([p, lat], [dp.to(dev), dl.to(dev)])
-    outs, wg, ig = oracle_grads(lambda Wd, xx: (lambda r: (r[0], r[2]))(VQ.seperate_forward(Wd, xx)), W, [x], [dp, dl])
+    outs, wg, ig = oracle_grads(lambda Wd, xx: (lambda r: (r[0], r[2]))(VQ.seperate_forward(Wd, xx, stop_grad)), W, [x], [dp, dl])
     assert maxdiff(p, outs[0]) < 1e-5 and maxdiff(lat, outs[1]) < 1e-6
     assert relerr(xd.grad, ig[0]) < 2e-5
     assert relerr(cb.asr_final_layer.weight.grad, wg['asr_final_layer.weight']) < 2e-5

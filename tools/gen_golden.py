@@ -496,6 +496,10 @@ def main():
         tts_case('tts_tiny_add', 32, B=2, L=7, teacher=12, tf_rate=0.0, training=False, prenet_dropout=0.0, spkr_embed_mode='add')
         tts_case('tts_tiny_pretrain', 33, B=2, L=5, teacher=(9,), tf_rate=1.0, training=True, pretrain=True)
         tts_case('tts_tiny_enc2', 34, B=2, L=8, teacher=9, tf_rate=0.0, training=False, prenet_dropout=0.0, _enc_rnn_layer=2)
+        # teacher-mean inputs (drop_dec_in), attention without location features / without the cumulative-weights channel
+        tts_case('tts_tiny_dropin', 35, B=3, L=6, teacher=(18,), tf_rate=0.8, training=True, drop_dec_in=0.5)
+        tts_case('tts_tiny_noloc', 36, B=2, L=7, teacher=(9,), tf_rate=1.0, training=True, loc_aware=False)
+        tts_case('tts_tiny_nosum', 37, B=2, L=6, teacher=(9,), tf_rate=1.0, training=True, use_summed_weights=False)
     if 'tts' in which:
         # eval-mode free-running inference, prenet dropout active (always-on), masks recorded
         tts_case('tts_tiny_infer', 1, B=2, L=7, teacher=15, tf_rate=0.0, training=False)

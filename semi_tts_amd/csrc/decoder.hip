@@ -246,7 +246,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    ctx_t -> xq_{t+1}[ctx part], xd_t[ctx part], xo_t[ctx part]
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
-        if (fuse_pq_fin) {   // 2 + 3 as one launch: the fin workgroups wait for pq inside the launch (granule hand-off)
+        if (fuse_pq_fin && (ST_SKIPPED(1) || ST_SKIPPED(2))) rc = 0;
+        else if (fuse_pq_fin) {   // 2 + 3 as one launch: the fin workgroups wait for pq inside the launch (granule hand-off)
             st_attn_fin_job fj;
             memset(&fj, 0, sizeof(fj));
             fj.s_buf = t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats;

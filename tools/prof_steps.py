@@ -11,11 +11,13 @@ def code(n):
     if 'pk_kernel<0' in n or 'pk_lstm_rt2_kernel' in n: return 'L'
     if 'pk_kernel<1' in n: return 'l'
     if 'pk_attnpre_kernel' in n: return 'P'
+    if 'pk_attnfin_kernel' in n: return 'F'
     if 'at_kernel' in n: return 'A'
     return 'x'
 seq = [(code(n), s, e) for n, s, e in rows]
 text = ''.join(c for c, _, _ in seq)
-for pat, names in (('LlALPl', ['LSTM_q', 'pq', 'attn (fin part)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
+for pat, names in (('LFLPl', ['LSTM_q', 'pq + attn fin part (one launch)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
+                   ('LlALPl', ['LSTM_q', 'pq', 'attn (fin part)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
                    ('LlALll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj+pre0', 'pre1']),
                    ('LlALlll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj', 'pre0', 'pre1'])):
     dur = collections.defaultdict(list)

@@ -5,6 +5,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/art_$TAG
 mkdir -p $OUT
 cd $ROOT
+echo "== PMC passes (HBM traffic, MFMA)"; bash tools/gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log
+python tools/pmc_summary.py $TAG > $OUT/pmc_summary.log 2>&1; cp profiles/${TAG}_pmc_* $OUT/ 2>/dev/null; rm -rf $ROOT/gpurun_out/pmc_${TAG}_*
 echo "== headline bench"; timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?"; cut -c1-300 $OUT/bench.json
 echo "== kernel trace of the same command"
 (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/prof.err)
@@ -12,8 +14,6 @@ DB=$(find $OUT/prof -name "*.db" | head -1)
 python tools/prof_stats.py $DB --csv $OUT/bench_kernel_stats.csv | head -8
 python tools/prof_steps.py $DB | tee $OUT/decode_step_breakdown.txt
 rm -rf $OUT/prof
-echo "== PMC passes (HBM traffic, MFMA)"; bash tools/gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log
-python tools/pmc_summary.py $TAG > $OUT/pmc_summary.log 2>&1; cp profiles/${TAG}_pmc_* $OUT/ 2>/dev/null; rm -rf $ROOT/gpurun_out/pmc_${TAG}_*
 echo "== secondary benches"
 timeout 300 python bench.py --workload c5 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_c5.json 2>/dev/null; cut -c1-200 $OUT/bench_c5.json
 timeout 300 python bench.py --workload c3 --steps 10 > $OUT/bench_c3.json 2>/dev/null; cut -c1-200 $OUT/bench_c3.json

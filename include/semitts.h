@@ -242,7 +242,12 @@ typedef struct st_gemm_epilogue {
     const float* mask; int ldmask;
     int w_tap_major;   /* KT > 1 only: W is given as (N, KT, Cin) -- taps outermost, so a k-block of weights is contiguous (16-byte
                         * loads) -- instead of the torch Conv1d layout (N, Cin, KT) */
+    float* splitk_ws;  /* optional workspace of splitk_slabs * (Bn * Tout) * N floats: the reduction is split over splitk_slabs =
+                        * st_gemm_splitk_slabs(...) (> 1) groups of workgroups whose partial products a finish pass adds in a
+                        * fixed order before the epilogue (small grids with long reductions: the encoder convs) */
+    int splitk_slabs;
 } st_gemm_epilogue;
+int st_gemm_splitk_slabs(int Bn, int Tout, int Cin, int N, int KT);   /* 1 = no split */
 
 int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
                 int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int stride, int pool_prev,

@@ -27,7 +27,8 @@ class StGemmEpilogue(C.Structure):
                 ('bn_eps', C.c_float), ('act_post', C.c_int),
                 ('res', C.c_void_p), ('ldres', C.c_int),
                 ('highway_h', C.c_void_p), ('ldhw', C.c_int),
-                ('mask', C.c_void_p), ('ldmask', C.c_int), ('w_tap_major', C.c_int)]
+                ('mask', C.c_void_p), ('ldmask', C.c_int), ('w_tap_major', C.c_int),
+                ('splitk_ws', C.c_void_p), ('splitk_slabs', C.c_int)]
 
 
 class StDecoderWeights(C.Structure):
@@ -111,6 +112,7 @@ SIGNATURES = {
     'st_skinny_linear_fwd': [C.POINTER(StSeg), I, P, I, P, I, P, I, I, P, I, I, I, I, P],
     'st_attn_step_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, P, I, P, I, P, P, P, I, I, I, I, I, I, I, P],
     'st_gemm_fwd': [P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, C.POINTER(StGemmEpilogue), P],
+    'st_gemm_splitk_slabs': [I, I, I, I, I],
     'st_bn_stats': [P, I, I, I, I, P, P, P, P, F, P, P],
     'st_colreduce_workspace_floats': [I, I],
     'st_bn_apply': [P, I, I, I, I, P, P, P, P, F, I, P],

@@ -26,13 +26,35 @@ struct GmArgs {
     int Bn, Tin, Tout, Cin, N, KT, pad, pool_prev, stride;
     int M;      // Bn * Tout
     int cpb;    // 16-float k-blocks per tap
+    int kb_per_split;   // > 0: blockIdx.z takes k-blocks [z * kb_per_split, (z + 1) * kb_per_split) and writes its raw partial
+    float* split_ws;    //      product to split_ws[z][m][n] (row stride N); gm_splitk_finish_kernel adds the slabs + epilogue
     st_gemm_epilogue ep;
 };
+
+// epilogue of one output element (shared by the tile epilogue and the split-K finish)
+__device__ __forceinline__ float gm_epilogue_one(const st_gemm_epilogue& ep, float v, int m, int n, float bias, float bn_m, float bn_s, float bn_w,
+                                                 float bn_b) {
+    v += bias;
+    v = st_act(v, ep.act_pre);
+    if (ep.bn_mean) v = (v - bn_m) * bn_s * bn_w + bn_b;
+    v = st_act(v, ep.act_post);
+    if (ep.highway_h) {
+        // Highway: y = H * T + x * (1 - T), v = T                (module.py:551-554)
+        const float hh = ep.highway_h[(size_t)m * ep.ldhw + n];
+        const float xx = ep.res[(size_t)m * ep.ldres + n];
+        v = hh * v + xx * (1.0f - v);
+    } else if (ep.res) {
+        v += ep.res[(size_t)m * ep.ldres + n];
+    }
+    if (ep.mask) v *= ep.mask[(size_t)m * ep.ldmask + n];
+    return v;
+}
 
 // epilogue of both GEMM kernels: D[row = 4*(lane>>4) + r][col = lane&15] of the wave's 2 x 2 sub-tiles
 template <int MT = 2>
 __device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[MT][2], int m0, int n0, int wm, int wn, int lane) {
     const st_gemm_epilogue& ep = g.ep;
+    float* ws = g.kb_per_split > 0 ? g.split_ws + (size_t)blockIdx.z * g.M * g.N : nullptr;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int n = n0 + wn * 32 + nt * 16 + (lane & 15);
@@ -51,21 +73,57 @@ __device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * (16 * MT) + mt * 16 + 4 * (lane >> 4) + r;
                 if (m >= g.M) continue;
-                float v = acc[mt][nt][r] + bias;
-                v = st_act(v, ep.act_pre);
-                if (ep.bn_mean) v = (v - bn_m) * bn_s * bn_w + bn_b;
-                v = st_act(v, ep.act_post);
-                if (ep.highway_h) {
-                    // Highway: y = H * T + x * (1 - T), v = T                (module.py:551-554)
-                    const float hh = ep.highway_h[(size_t)m * ep.ldhw + n];
-                    const float xx = ep.res[(size_t)m * ep.ldres + n];
-                    v = hh * v + xx * (1.0f - v);
-                } else if (ep.res) {
-                    v += ep.res[(size_t)m * ep.ldres + n];
-                }
-                if (ep.mask) v *= ep.mask[(size_t)m * ep.ldmask + n];
-                g.C[(size_t)m * g.ldc + g.coff + n] = v;
+                if (ws) { ws[(size_t)m * g.N + n] = acc[mt][nt][r]; continue; }        // split-K: the raw partial product
+                g.C[(size_t)m * g.ldc + g.coff + n] = gm_epilogue_one(ep, acc[mt][nt][r], m, n, bias, bn_m, bn_s, bn_w, bn_b);
             }
+        }
+    }
+}
+
+// split-K finish: C = epilogue(sum_z slab_z), slabs added in a fixed order (deterministic); one thread per output element,
+// consecutive threads = consecutive columns
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gm_splitk_finish_kernel(const GmArgs g, int S) {
+    constexpr int W = VEC4 ? 4 : 1;                       // columns per thread (VEC4: N % 4 == 0, 16-byte slab loads)
+    const size_t total = (size_t)g.M * g.N, items = total / W;
+    const st_gemm_epilogue& ep = g.ep;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = it * W;
+        const int m = (int)(i / g.N), n0 = (int)(i - (size_t)m * g.N);
+        float v[W];
+        if (VEC4) {
+            f32x4 s0 = st_ld4(g.split_ws + i), s1 = {0.f, 0.f, 0.f, 0.f};
+            int z = 1;
+            for (; z + 2 <= S; z += 2) {      // two slab loads in flight; the slabs are still added in the order 0, 1, 2, ...
+                const f32x4 a = st_ld4(g.split_ws + (size_t)z * total + i), b = st_ld4(g.split_ws + (size_t)(z + 1) * total + i);
+                s0 = (s0 + a) + b;
+            }
+            if (z < S) s1 = st_ld4(g.split_ws + (size_t)z * total + i);
+            s0 = s0 + s1;
+#pragma unroll
+            for (int c = 0; c < W; ++c) v[c] = s0[c];
+        } else {
+            float s0 = g.split_ws[i];
+            for (int z = 1; z < S; ++z) s0 += g.split_ws[(size_t)z * total + i];
+            v[0] = s0;
+        }
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const int n = n0 + c;
+            float bn_m = 0.f, bn_s = 1.f, bn_w = 1.f, bn_b = 0.f;
+            if (ep.bn_mean) {
+                bn_m = ep.bn_mean[n];
+                bn_s = 1.0f / sqrtf(ep.bn_var[n] + ep.bn_eps);
+                bn_w = ep.bn_w ? ep.bn_w[n] : 1.0f;
+                bn_b = ep.bn_b ? ep.bn_b[n] : 0.0f;
+            }
+            v[c] = gm_epilogue_one(ep, v[c], m, n, ep.bias ? ep.bias[n] : 0.0f, bn_m, bn_s, bn_w, bn_b);
+        }
+        float* cp = g.C + (size_t)m * g.ldc + g.coff + n0;
+        if (VEC4 && st_aligned16(cp)) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[VEC4 ? 1 : 0], v[VEC4 ? 2 : 0], v[VEC4 ? 3 : 0]};
+        else {
+#pragma unroll
+            for (int c = 0; c < W; ++c) cp[c] = v[c];
         }
     }
 }
@@ -186,10 +244,16 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
     const int t_base = ato * g.stride - g.pad;
 
     struct Blk { f32x4 a, q, w; bool va, vw; };
-    int tap_n = 0, cb_n = 0;                       // (tap, 16-float block within the tap) of the next block to request
+    // split-K: this workgroup's k-blocks are [kb_lo, kb_hi) of the KT * cpb blocks (the whole range without a split)
+    const int nkb = g.KT * g.cpb;
+    const int kb_lo = g.kb_per_split > 0 ? (int)blockIdx.z * g.kb_per_split : 0;
+    const int kb_hi = g.kb_per_split > 0 ? min(nkb, kb_lo + g.kb_per_split) : nkb;
+    int tap_n = kb_lo / g.cpb, cb_n = kb_lo - tap_n * g.cpb;      // (tap, 16-float block within the tap) of the next block to request
+    int left_n = kb_hi - kb_lo;                                   // blocks of the range not requested yet
     auto issue = [&](Blk& r) __attribute__((always_inline)) {
         const int ci = cb_n * GM_BK + skq * 4;
-        const bool in_k = tap_n < g.KT && ci < g.Cin;
+        const bool in_k = left_n > 0 && tap_n < g.KT && ci < g.Cin;
+        --left_n;
         const int tap = min(tap_n, g.KT - 1), cic = min(ci, g.Cin - 4);
         const int ti = t_base + tap;
         const int tic = min(max(ti, 0), g.Tin - 1);
@@ -239,7 +303,7 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[h][mt][cc], b4[h][nt][cc], acc[mt][nt], 0, 0, 0);
     };
 
-    const int npairs = (g.KT * g.cpb + 1) >> 1;
+    const int npairs = (kb_hi - kb_lo + 1) >> 1;
     Blk r0[2], r1[2];
     issue(r0[0]); issue(r0[1]);
     issue(r1[0]); issue(r1[1]);
@@ -351,6 +415,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* X, int ldx, int co
 
 }  // namespace
 
+// Split-K pays where the 64 x 64 grid is small AND the reduction is long: the encoder convs (1376 x 512 x 2560: 176 workgroups
+// walking 160 k-blocks each, 83 -> 45 us with 4 slabs incl. the finish pass, tools/gemm_lab.hip), the 640 -> 128 projection conv
+// (76 -> 52).  Short reductions (K <= 640) lose or gain nothing.  Slabs: enough for ~900 workgroups, at least 24 k-blocks each.
+extern "C" int st_gemm_splitk_slabs(int Bn, int Tout, int Cin, int N, int KT) {
+    if (Bn <= 0 || Tout <= 0 || Cin < 4 || Cin % 4 != 0 || N <= 0 || KT <= 0) return 1;
+    const long M = (long)Bn * Tout;
+    const long wgs = ((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
+    const int nkb = KT * ((Cin + GM_BK - 1) / GM_BK);
+    if (wgs >= 512) return 1;
+    int S = (int)((900 + wgs / 2) / wgs);
+    if (S > nkb / 24) S = nkb / 24;
+    if (S > 8) S = 8;
+    return S < 2 ? 1 : S;
+}
+
 extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
                            int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int stride, int pool_prev,
                            const st_gemm_epilogue* ep, void* stream) {
@@ -378,9 +457,17 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
     dim3 grid((g.M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     hipStream_t st = (hipStream_t)stream;
     static const bool pipe = !(getenv("ST_GEMM_PIPE") && atoi(getenv("ST_GEMM_PIPE")) == 0);
+    // split-K: the caller passes slabs = st_gemm_splitk_slabs(...) and a workspace of slabs * M * N floats in the epilogue struct
+    const int S = (ep && ep->splitk_ws && veca && pipe) ? ep->splitk_slabs : 1;
+    if (S > 1) {
+        ST_CHECK_ARG(S == st_gemm_splitk_slabs(Bn, Tout, Cin, N, KT) && st_aligned16(ep->splitk_ws), "st_gemm_fwd: splitk_slabs=%d does not match st_gemm_splitk_slabs()", S);
+        g.kb_per_split = (KT * g.cpb + S - 1) / S;
+        g.split_ws = ep->splitk_ws;
+        grid.z = S;
+    }
     if (veca && pipe && Cin >= 4) {
         // 32-row tiles when 64-row tiles would leave compute units with fewer than two workgroups (st_device_info: 256 CUs)
-        const bool small = (size_t)grid.x * grid.y < 512;
+        const bool small = S == 1 && (size_t)grid.x * grid.y < 512;
         const dim3 grid32((g.M + 31) / 32, grid.y);
 #define GM_LAUNCH(VW, PL) do { if (small) hipLaunchKernelGGL((gm_pipe_kernel<VW, PL, 1>), grid32, dim3(GM_THREADS), 0, st, g); \
                                else hipLaunchKernelGGL((gm_pipe_kernel<VW, PL, 2>), grid, dim3(GM_THREADS), 0, st, g); } while (0)
@@ -394,6 +481,15 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
     else if (vecw) hipLaunchKernelGGL((gm_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);
     else hipLaunchKernelGGL((gm_kernel<false, false>), grid, dim3(GM_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();
+    if (S > 1) {
+        const bool vec4 = N % 4 == 0;
+        const size_t items = (size_t)g.M * N / (vec4 ? 4 : 1);
+        size_t blocks = (items + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (vec4) hipLaunchKernelGGL((gm_splitk_finish_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, g, S);
+        else hipLaunchKernelGGL((gm_splitk_finish_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, g, S);
+        ST_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -186,6 +186,10 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=
     if KT > 1 and Cin % 4 == 0 and Cin >= 16:
         w = _tap_major(w)
         ep.w_tap_major = 1
+    slabs = int(lib.st_gemm_splitk_slabs(int(Bn), int(Tout), int(Cin), int(N), int(KT)))
+    if slabs > 1:         # small grid, long reduction: partial products per k range + a finish pass (st_gemm_epilogue.splitk_ws)
+        ws = torch.empty(slabs * Bn * Tout * N, device=a.device, dtype=torch.float32)
+        ep.splitk_ws, ep.splitk_slabs = _p(ws), slabs
     check(lib.st_gemm_fwd(_p(a), int(lda), _p(w), _p(out), int(ldc), int(coff), int(Bn), int(Tin), int(Tout),
                           int(Cin), int(N), int(KT), int(pad), int(stride), 1 if pool_prev else 0, C.byref(ep), stream_handle()),
           'st_gemm_fwd')

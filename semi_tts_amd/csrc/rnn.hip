@@ -105,6 +105,89 @@ __global__ __launch_bounds__(512) void gru_seq_quad_kernel(const GruArgs a) {
     }
 }
 
+// H <= 84 (the CBHG GRU: 80): FOUR waves, one per SIMD.  The quad form above needs 4 H = 320 lanes = five waves, so one SIMD
+// carries two of them (233 -> 221 us for the 258 steps: the imbalance is not what bounds a step either).  Here a wave owns 21 hidden units, three ADJACENT lanes each (lane 3u + g,
+// g = r, z, n; lane 63 idles): 80-term dot per lane as in the quad form, the two other gates arrive with whole-wave DPP shifts
+// (wave_shl:1, once and twice), lane g = 0 does the pointwise update.  One LDS-only barrier per step.
+template <int KQ>
+__global__ __launch_bounds__(256) void gru_seq_tri_kernel(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = a.H, H3 = 3 * H, T = a.T;
+    constexpr int HP = 4 * KQ;
+    float* hb[2] = {lds, lds + HP};
+    const int b = blockIdx.x, d = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = lane / 3, g = lane - 3 * u, j = wave * 21 + u;
+    const float* __restrict__ gi = a.gi[d] + (size_t)b * T * H3;
+    const bool row_ok = lane < 63 && j < H;
+    float wreg[HP];
+    float bh;
+    {   // branch-free: idle lanes and columns past H read a valid address and are zeroed by a select
+        const float* wr = a.w_hh[d] + (size_t)(row_ok ? g * H + j : 0) * H;
+        const float bv = a.b_hh[d][row_ok ? g * H + j : 0];
+        bh = row_ok ? bv : 0.0f;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) { const float w = wr[k < H ? k : H - 1]; wreg[k] = (row_ok && k < H) ? w : 0.0f; }
+    }
+    for (int k = tid; k < 2 * HP; k += blockDim.x) lds[k] = 0.0f;
+    __syncthreads();
+    const bool upd = row_ok && g == 0;
+    float hprev = 0.f;
+    constexpr int GRU_PB = 8;      // input projections read GRU_PB steps ahead (see gru_seq_quad_kernel)
+    float cur[GRU_PB][3], nxt[GRU_PB][3];
+    auto load_block = [&](float (&dst)[GRU_PB][3], int s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < GRU_PB; ++i) {
+            const int s = s0 + i;
+            const int tt = min(d ? T - 1 - s : s, T - 1);
+            const bool on = upd && s < T;
+            const float* p = gi + (size_t)(on ? max(tt, 0) : 0) * H3 + (on ? j : 0);
+            dst[i][0] = p[0]; dst[i][1] = p[on ? H : 0]; dst[i][2] = p[on ? 2 * H : 0];
+        }
+    };
+    load_block(cur, 0);
+    for (int s0 = 0; s0 < T; s0 += GRU_PB) {
+        load_block(nxt, s0 + GRU_PB);
+#pragma unroll
+        for (int i = 0; i < GRU_PB; ++i) {
+            const int s = s0 + i;
+            if (s >= T) break;                                        // (uniform)
+            const int t = d ? T - 1 - s : s;
+            const float* hcur = hb[s & 1];
+            float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            // all KQ LDS reads of h go out back to back (left alone the compiler keeps only two in flight: ds_read, wait, 4 FMAs,
+            // ds_read ...); measured 221 -> 212 us for the 258-step H = 80 GRU -- the step is NOT bound by these round trips
+            f32x4 hreg[KQ];
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) hreg[k] = *reinterpret_cast<const f32x4*>(hcur + 4 * k);
+            asm volatile("" ::: "memory");             // (keeps the reads above the multiply-adds)
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) {             // padded h entries are zero, weights past H are zero
+                a0 = fmaf(wreg[4 * k], hreg[k][0], a0); a1 = fmaf(wreg[4 * k + 1], hreg[k][1], a1);
+                a2 = fmaf(wreg[4 * k + 2], hreg[k][2], a2); a3 = fmaf(wreg[4 * k + 3], hreg[k][3], a3);
+            }
+            const float gh = (a0 + a1) + (a2 + a3);                   // W_hh[g*H + j] . h + b_hh
+            const float ghz = st_dpp<0x130>(gh), ghn = st_dpp<0x130>(ghz);      // wave_shl:1: the value of lane + 1, of lane + 2
+            if (upd) {
+                const float r = st_sigmoid_fast(cur[i][0] + gh);
+                const float z = st_sigmoid_fast(cur[i][1] + ghz);
+                const float n = st_tanh_fast(cur[i][2] + r * ghn);
+                const float hn = (1.0f - z) * n + z * hprev;
+                hprev = hn;
+                hb[(s + 1) & 1][j] = hn;
+                a.out[((size_t)b * T + t) * a.ldo + d * H + j] = hn;
+                if (a.tape) {
+                    float* tp = a.tape + ((((size_t)d * a.B + b) * T + t) * 4) * H + j;
+                    tp[0] = r; tp[H] = z; tp[2 * H] = n; tp[3 * H] = ghn;
+                }
+            }
+            st_lds_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < GRU_PB; ++i) { cur[i][0] = nxt[i][0]; cur[i][1] = nxt[i][1]; cur[i][2] = nxt[i][2]; }
+    }
+}
+
 template <bool REG>
 __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_kernel(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -352,7 +435,7 @@ extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const fl
     hipStream_t st = (hipStream_t)stream;
     if (H <= GRU_HMAX) {
         const int qthreads = ((4 * H + 63) / 64) * 64;             // <= 512
-        if (H <= 80) hipLaunchKernelGGL(gru_seq_quad_kernel<20>, dim3(B, ndir), dim3(qthreads), (size_t)2 * 80 * sizeof(float), st, a);
+        if (H <= 80) hipLaunchKernelGGL(gru_seq_tri_kernel<20>, dim3(B, ndir), dim3(256), (size_t)2 * 80 * sizeof(float), st, a);
         else hipLaunchKernelGGL(gru_seq_quad_kernel<32>, dim3(B, ndir), dim3(qthreads), (size_t)2 * 128 * sizeof(float), st, a);
     } else hipLaunchKernelGGL((gru_seq_kernel<false>), dim3(B, ndir), dim3(threads), lds, st, a);
     ST_LAUNCH_CHECK();

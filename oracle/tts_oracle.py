@@ -196,7 +196,8 @@ def encoder_forward(W: Weights, txt_embed: Tensor, prefix: str = 'encoder.',
         x = conv1d_cl(x, w, b, (k - 1) // 2)                                   # :421-428
         x = batchnorm_cl(x, W, prefix + 'convs.%d.1' % i, 1e-5, 0.1, training, stats_out)  # :429
         x = torch.relu(x)                                                      # :430
-        x = drop(x, enc_dropout, training)                                      # :431
+        # :431 -- the reference drops on its (B, C, L) layout: a recorded mask is replayed through the same layout
+        x = drop(x.transpose(1, 2), enc_dropout, training).transpose(1, 2)
         i += 1
     layer = 0
     while (prefix + 'lstm.weight_ih_l%d' % layer) in W:                         # enc_rnn_layer stacked BiLSTM layers (1 in the configs)

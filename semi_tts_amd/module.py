@@ -116,14 +116,15 @@ class Encoder(nn.Module):
         self.lstm = nn.LSTM(input_size=enc_embed_dim, hidden_size=enc_embed_dim // 2, num_layers=enc_rnn_layer,
                             batch_first=True, bidirectional=True)
 
-    def forward(self, txt_embed, input_lengths=None):
+    def forward(self, txt_embed, input_lengths=None, _masks=None):
+        """_masks: optional list of scaled dropout masks (B, L, C), one per conv block (tests replay the reference's draws)"""
         x = txt_embed.contiguous()
-        for blk in self.convs:
+        for i, blk in enumerate(self.convs):
             conv, bn = blk[0], blk[1]
             x = _conv_bn_act(x, conv.conv.weight, conv.conv.bias, bn, conv.padding, bn.eps, bn.momentum,
                              'bn_relu', self.training)
-            if self.training and self.enc_dropout > 0:
-                raise NotImplementedError('enc_dropout > 0 in training (all shipped configs use 0.0)')
+            if self.training and self.enc_dropout > 0:                                   # nn.Dropout of the block, :431
+                x = x * (_masks[i] if _masks is not None else _scaled_mask(x.shape, self.enc_dropout, x.device))
         B, L, _ = x.shape
         H = self.lstm.hidden_size
         for layer in range(self.enc_rnn_layer):            # (nn.LSTM stacks the layers; no inter-layer dropout: module.py:432-438)

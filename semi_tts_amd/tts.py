@@ -39,7 +39,7 @@ class Tacotron2(nn.Module):
     def forward(self, txt_embed, txt_lengths, teacher, spkr_embed, tf_rate=0.0, unpair_max_frame=None, _masks=None):
         """txt_embed (B,L,in_embed_dim); teacher: int (max frames, inference) or (B',T,n_mels);
         returns (mel_pred, linear_pred, alignment, stop)                          ref: src/tts.py:36-51"""
-        enc_output = self.encoder(txt_embed, txt_lengths)
+        enc_output = self.encoder(txt_embed, txt_lengths, _masks=_masks.get('enc') if _masks else None)
         mel_pred, alignment, stop = self.decoder(enc_output, txt_lengths, teacher, spkr_embed, tf_rate=tf_rate,
                                                  unpair_max_frame=unpair_max_frame, _masks=_masks)
         linear_pred = None

@@ -36,6 +36,8 @@ def split_masks(masks, hp, training, tf_rate, B, Bt, steps, step_src, P):
     prenet of the own output (2; all rows, or only the rows without a teacher)."""
     it = iter(masks)
     out = {}
+    if training and hp.get('enc_dropout', 0.0) > 0:      # the encoder's conv blocks come first, (B, C, L) in the reference
+        out['enc'] = [next(it).transpose(1, 2).contiguous() for _ in range(hp.get('enc_n_conv', 3))]
     pd = hp['prenet_dropout'] > 0
     if tf_rate != 0.0 and pd:
         out['teacher'] = [next(it), next(it)]

@@ -435,7 +435,7 @@ TTS_CASES = ['tts_tiny_infer', 'tts_tiny_infer_nodrop', 'tts_tiny_train_tf', 'tt
              'tts_tiny_sched', 'tts_tiny_partial', 'tts_tiny_quirk',
              # decoder / encoder variants no shipped YAML reaches: speaker-conditioned memory, pre-training, 2-layer encoder LSTM
              'tts_tiny_concat', 'tts_tiny_add', 'tts_tiny_pretrain', 'tts_tiny_enc2', 'tts_tiny_dropin', 'tts_tiny_noloc',
-             'tts_tiny_nosum']
+             'tts_tiny_nosum', 'tts_tiny_encdrop']
 
 
 @pytest.mark.parametrize('name', TTS_CASES)

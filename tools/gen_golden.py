@@ -116,6 +116,8 @@ def tiny_model(seed, **over):
     cfg = json.loads(json.dumps(TINY))
     if '_enc_rnn_layer' in over:
         cfg['paras']['encoder']['enc_rnn_layer'] = over.pop('_enc_rnn_layer')
+    if '_enc_dropout' in over:
+        cfg['paras']['encoder']['enc_dropout'] = over.pop('_enc_dropout')
     cfg['paras']['decoder'].update(over)
     m = RefTacotron2(cfg['n_mels'], cfg['linear_dim'], cfg['in_embed_dim'], cfg['spkr_embed_dim'], cfg['paras'])
     g = torch.Generator().manual_seed(seed + 100)
@@ -500,6 +502,7 @@ def main():
         tts_case('tts_tiny_dropin', 35, B=3, L=6, teacher=(18,), tf_rate=0.8, training=True, drop_dec_in=0.5)
         tts_case('tts_tiny_noloc', 36, B=2, L=7, teacher=(9,), tf_rate=1.0, training=True, loc_aware=False)
         tts_case('tts_tiny_nosum', 37, B=2, L=6, teacher=(9,), tf_rate=1.0, training=True, use_summed_weights=False)
+        tts_case('tts_tiny_encdrop', 38, B=2, L=6, teacher=(9,), tf_rate=1.0, training=True, _enc_dropout=0.3)
     if 'tts' in which:
         # eval-mode free-running inference, prenet dropout active (always-on), masks recorded
         tts_case('tts_tiny_infer', 1, B=2, L=7, teacher=15, tf_rate=0.0, training=False)

@@ -456,16 +456,15 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
     const bool vecw = (KT == 1 || tap_major) && st_aligned16(W) && (Cin % 4 == 0);
     dim3 grid((g.M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     hipStream_t st = (hipStream_t)stream;
-    static const bool pipe = !(getenv("ST_GEMM_PIPE") && atoi(getenv("ST_GEMM_PIPE")) == 0);
     // split-K: the caller passes slabs = st_gemm_splitk_slabs(...) and a workspace of slabs * M * N floats in the epilogue struct
-    const int S = (ep && ep->splitk_ws && veca && pipe) ? ep->splitk_slabs : 1;
+    const int S = (ep && ep->splitk_ws && veca) ? ep->splitk_slabs : 1;
     if (S > 1) {
         ST_CHECK_ARG(S == st_gemm_splitk_slabs(Bn, Tout, Cin, N, KT) && st_aligned16(ep->splitk_ws), "st_gemm_fwd: splitk_slabs=%d does not match st_gemm_splitk_slabs()", S);
         g.kb_per_split = (KT * g.cpb + S - 1) / S;
         g.split_ws = ep->splitk_ws;
         grid.z = S;
     }
-    if (veca && pipe && Cin >= 4) {
+    if (veca) {      // (16-byte addressable A: Cin % 4 == 0, so Cin >= 4) the pipelined kernel; otherwise the generic one-block form
         // 32-row tiles when 64-row tiles would leave compute units with fewer than two workgroups (st_device_info: 256 CUs)
         const bool small = S == 1 && (size_t)grid.x * grid.y < 512;
         const dim3 grid32((g.M + 31) / 32, grid.y);
@@ -476,9 +475,7 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
         else if (pool_prev) GM_LAUNCH(false, true);
         else GM_LAUNCH(false, false);
 #undef GM_LAUNCH
-    } else if (veca && vecw) hipLaunchKernelGGL((gm_kernel<true, true>), grid, dim3(GM_THREADS), 0, st, g);
-    else if (veca) hipLaunchKernelGGL((gm_kernel<true, false>), grid, dim3(GM_THREADS), 0, st, g);
-    else if (vecw) hipLaunchKernelGGL((gm_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);
+    } else if (vecw) hipLaunchKernelGGL((gm_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);
     else hipLaunchKernelGGL((gm_kernel<false, false>), grid, dim3(GM_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();
     if (S > 1) {

@@ -613,7 +613,17 @@ int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st) {
     }
     // a small linear (few row tiles) is bound by what ONE compute unit can pull in (its weight tile + the whole activation
     // operand): one batch tile per workgroup halves the activation bytes per workgroup and doubles the workgroups
-    if (MODE == 1 && tiles <= 128 && BT > 1) return pk_launch<MODE, 1>(a, tiles, st);
+    // ... and a linear with MANY row tiles still wants every compute unit pulling (one CU takes in ~30 GB/s): the fewest batch
+    // tiles per workgroup that keep the grid within 512 workgroups (the 2560-row dgates . W^T of the decoder-LSTM backward: 160
+    // workgroups of two batch tiles -> 320 of one; the second reader of a weight tile is gridDim.x workgroups on: same XCD, an L2 hit)
+    if (MODE == 1 && BT > 1) {
+        int nb = 1;
+        while (nb < 4 && tiles * ((BT + nb - 1) / nb) > 512) ++nb;
+        if (nb == 1) return pk_launch<MODE, 1>(a, tiles, st);
+        if (nb == 2) return pk_launch<MODE, 2>(a, tiles, st);
+        if (nb == 3) return pk_launch<MODE, 3>(a, tiles, st);
+        return pk_launch<MODE, 4>(a, tiles, st);
+    }
     if (BT == 1) return pk_launch<MODE, 1>(a, tiles, st);
     if (BT == 2) return pk_launch<MODE, 2>(a, tiles, st);
     if (BT == 3) return pk_launch<MODE, 3>(a, tiles, st);

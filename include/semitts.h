@@ -201,6 +201,16 @@ int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view
                                         int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                         int B, int N, const st_attn_pre_job* pre, void* stream);
 
+/* The fin part for LONG texts: every utterance split over `parts` (2..64) ranges of positions -- local softmax statistics and an
+ * un-normalised partial context per range (flash-decoding style), then a combine launch.  S and the memory rows are read once in
+ * total; st_attn_fin_t16_fwd re-reads S in each of its context slices and one compute unit has to pull ~2 L A 4 bytes (12 us at
+ * L = 171).  Same arithmetic as softmax(e) @ memory up to fp32 rounding (~1e-7).  workspace: B * parts * (4 + E) floats. */
+size_t st_attn_fin_split_workspace_floats(int B, int E, int parts);
+int st_attn_fin_split_fwd(const float* pq, const float* s_buf, const float* memory, const float* w_cum_prev,
+                          float* w_out, int ld_wout, float* w_cum_out, const float* v,
+                          const st_t16_view* ctx_dst, int n_ctx_dst, float* ctx, int ld_ctx, float* workspace, int parts,
+                          int B, int L, int A, int E, void* stream);
+
 /* Query projection + attention fin part in ONE launch: pq = W_q h_q (ref: src/module.py:380) is computed by the first workgroups
  * and handed to the fin workgroups of the same launch (st_attn_fin_t16_fwd's work: :389-406, :262-264) as 8-byte
  * {value, tag} words in `granules` ((B, A) 64-bit words, device memory, ZEROED by the caller before the first step of a
@@ -487,6 +497,9 @@ typedef struct st_decoder_io {
                                * layer-1 output of every own-output feedback for the backward); 0: one scratch slot */
     int attn_s_step_floats;   /* > 0: attn_s_buf is a tape, slot t = S of step t (B*L*A floats apart), kept for the backward */
     float* attn_loc_tape;     /* optional (steps, B, L, F): location features of every step (slot 0 is never written: zero it) */
+    float* attn_split_ws;     /* optional, st_attn_fin_split_workspace_floats(B, E, attn_split_parts) floats: long texts run the fin part
+                               * split over attn_split_parts position ranges + a combine launch (st_attn_fin_split_fwd) */
+    int attn_split_parts;
     unsigned long long* pq_granules;   /* optional (B, A) 64-bit words: with attn_s_buf, the query projection and the attention fin
                                         * part of a step run as ONE launch (st_query_attn_fin_fwd); zeroed by the callee per forward */
 } st_decoder_io;

@@ -56,7 +56,7 @@ class StDecoderIO(C.Structure):
                 ('zero_row', C.c_void_p),
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('attn_fin_parts', C.c_int), ('defer_proj', C.c_int),
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p),
-                ('pq_granules', C.c_void_p)]
+                ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -146,6 +146,8 @@ SIGNATURES = {
                                             I, I, P, I, C.POINTER(StT16View), I, I, C.POINTER(StAttnPreJob), P],
     'st_attn_pre_fwd': [P, P, I, P, P, P, P, I, I, I, I, I, I, P],
     'st_attn_fin_t16_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, I, P],
+    'st_attn_fin_split_workspace_floats': [I, I, I],
+    'st_attn_fin_split_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, P, I, I, I, I, I, P],
     'st_query_attn_fin_fwd': [P, C.POINTER(StT16View), I, P, C.c_uint, C.POINTER(StAttnFinJob), I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
@@ -188,7 +190,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
              'st_decoder_packed_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_ctc_workspace_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
-             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
+             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
 
 _lib = None
 

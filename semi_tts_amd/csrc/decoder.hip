@@ -204,7 +204,11 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     // query projection + attention fin part as one launch with an in-launch hand-off of pq (st_query_attn_fin_fwd): needs the split
     // attention step, every workgroup of the launch resident at once, and the granule words zeroed before the first step (a memset
     // node when the loop is captured: a replay must not see the tags of the previous one)
-    const bool fuse_pq_fin = split_attn && !pre_in_pq && io->pq_granules && A % 16 == 0 && A <= 256 && E % 4 == 0 &&
+    // long texts: the fin part split over position ranges + a combine launch (see at_split_kernel)
+    const int sp_parts = io->attn_split_parts;
+    const bool fin_split = split_attn && io->attn_split_ws && sp_parts >= 2 && sp_parts <= 64 && A % 4 == 0 && A <= 256 && E % 4 == 0 &&
+                           E / 4 <= 512 && 512 % (E / 4) == 0 && (L + sp_parts - 1) / sp_parts <= 512;
+    const bool fuse_pq_fin = !fin_split && split_attn && !pre_in_pq && io->pq_granules && A % 16 == 0 && A <= 256 && E % 4 == 0 &&
                              (A / 16) * ((B + 15) / 16) + B * fin_parts <= st_device_cus();
     if (fuse_pq_fin) ST_HIP(hipMemsetAsync(io->pq_granules, 0, (size_t)B * A * sizeof(unsigned long long), (hipStream_t)stream));
     for (int t = 0; t < steps; ++t) {
@@ -246,7 +250,13 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    ctx_t -> xq_{t+1}[ctx part], xd_t[ctx part], xo_t[ctx part]
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
-        if (fuse_pq_fin && (ST_SKIPPED(1) || ST_SKIPPED(2))) rc = 0;
+        if (fin_split && !ST_SKIPPED(2))
+            rc = st_attn_fin_split_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats, io->memory,
+                                       io->wcum_tape + (size_t)t * BL, io->align_out + (size_t)t * L, ldal,
+                                       io->wcum_tape + (size_t)(t + 1) * BL, w->attn_v, ctx_dst, 3, nullptr, 0, io->attn_split_ws, sp_parts,
+                                       B, L, A, E, stream);
+        else if (fin_split) rc = 0;
+        else if (fuse_pq_fin && (ST_SKIPPED(1) || ST_SKIPPED(2))) rc = 0;
         else if (fuse_pq_fin) {   // 2 + 3 as one launch: the fin workgroups wait for pq inside the launch (granule hand-off)
             st_attn_fin_job fj;
             memset(&fj, 0, sizeof(fj));

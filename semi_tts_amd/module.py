@@ -306,6 +306,8 @@ class Decoder(nn.Module):
         self.attn_pre_parts = 4      # workgroups per utterance of the pre part (measured at L = 43: 1 / 2 / 4 parts 37.1 / 35.9 / 35.4 us per step)
         self.attn_fin_parts = 2      # workgroups per utterance of the fin part (slices of the context dims)
         self.attn_pq_in_fin = True   # inference: query projection and fin part share one launch (in-launch hand-off of pq)
+        self.attn_split_min_len = 128     # texts at least this long: fin part over position ranges (~attn_split_positions each) + combine
+        self.attn_split_positions = 43
 
     # -- helpers ---------------------------------------------------------------------------------
     def _weights_struct(self, keep, fuse_pre0=False):
@@ -515,6 +517,11 @@ class Decoder(nn.Module):
                 parts *= 2                                            # position range in LDS (32 filters x <= ~512 positions)
             io.attn_pre_parts = parts
             io.attn_fin_parts = int(self.attn_fin_parts)
+            if L >= self.attn_split_min_len and not keep_tapes:
+                # long texts: fin part split over position ranges + a combine launch (one CU cannot pull 2 L A 4 bytes fast enough)
+                sp = max(2, min(64, (L + self.attn_split_positions - 1) // self.attn_split_positions))
+                tapes['attn_split_ws'] = torch.empty(int(lib.st_attn_fin_split_workspace_floats(B, E, sp)), **f32)
+                io.attn_split_ws, io.attn_split_parts = ops._p(tapes['attn_split_ws']), sp
             if self.attn_pq_in_fin and not keep_tapes:
                 # query projection + attention fin part as ONE launch per step (st_query_attn_fin_fwd): pq is handed over inside
                 # the launch as 8-byte {value, tag} words; the library falls back to two launches when the shapes do not fit

@@ -591,14 +591,24 @@ def skinny_linear_packed(packed_w, x_view, Kpad, B, N, y=None, y_dst=None, bias=
 # --------------------------------------------------------------------------------------------- graphs
 class Graph:
     """Records every st_* call issued inside `with g.capture():` on a private HIP stream into a
-    hipGraph; `g.launch()` replays it on torch's current stream.  All tensors touched inside
-    the capture must be allocated beforehand and kept alive by the caller."""
+    hipGraph; `g.launch()` replays it on torch's current stream.  Every tensor touched inside the
+    capture must stay alive as long as the graph is replayed: either allocated beforehand and kept
+    by the caller, or allocated inside `with g.memory():` -- a private torch memory pool owned by
+    this object, so that a buffer freed after the capture is never handed to anybody else (run the
+    same code once inside `g.memory()` BEFORE the capture: the pool then serves the capture's
+    allocations from its cache; a hipMalloc is not allowed while capturing)."""
 
     def __init__(self):
         self.lib = _lib.load()
         self.exec = None
         self._stream = C.c_void_p()
         check(self.lib.st_stream_create(C.byref(self._stream)), 'st_stream_create')
+        self.pool = torch.cuda.MemPool()
+
+    @contextmanager
+    def memory(self):
+        with torch.cuda.use_mem_pool(self.pool):
+            yield
 
     @contextmanager
     def capture(self):

@@ -47,15 +47,18 @@ class GraphedDecoder:
         # weights are frozen while a captured graph is replayed: their MFMA-order copy (75 MB read + write per packing) is
         # made once, outside the graph, instead of on every replay
         self.decoder.cache_packed = True
-        # 1. eager pass: warms the caching allocator with blocks of exactly the sizes the loop needs
-        self._run()
-        torch.cuda.synchronize()
-        self.decoder.last_tapes = None            # release them back to the allocator's cache
-        # 2. capture: every torch.empty below is served from the cache (no hipMalloc while capturing)
+        # 1. eager pass inside the graph's PRIVATE memory pool: the pool now owns blocks of exactly the sizes the loop needs
         self.graph = ops.Graph()
-        with self.graph.capture():
+        with self.graph.memory():
+            for _ in range(2):                        # (the second pass allocates in the capture's order: weights already packed)
+                self._run()
+                torch.cuda.synchronize()
+                self.decoder.last_tapes = None        # release them back to the pool's cache
+        # 2. capture: every torch.empty below is served from that cache (no hipMalloc while capturing), and whatever is freed
+        #    afterwards goes back to the pool, not to other tensors of the process -- the graph keeps writing to these addresses
+        with self.graph.capture(), self.graph.memory():
             self.outputs = self._run()
-        self._keep = self.decoder.last_tapes      # buffers the graph reads/writes must stay alive
+        self._keep = self.decoder.last_tapes      # (the tapes stay referenced as well)
         return self
 
     def draw_masks(self):
@@ -102,11 +105,15 @@ class GraphedTacotron2:
     def capture(self):
         assert not self.model.training, 'graph replay is for eval-mode inference'
         self.model.decoder.cache_packed = True
-        self._run()                                   # warms the allocator cache, the packed weights, the tap-major conv weights
-        torch.cuda.synchronize()
-        self.model.decoder.last_tapes = None
+        # (as GraphedDecoder.capture: warm-up and capture inside the graph's private memory pool -- the encoder / postnet
+        # intermediates and GEMM workspaces allocated by the forward are freed after the capture, and the replay still uses them)
         self.graph = ops.Graph()
-        with self.graph.capture():
+        with self.graph.memory():
+            for _ in range(2):                        # warms the pool, the packed weights, the tap-major conv weights; the second
+                self._run()                           # pass allocates in the capture's order
+                torch.cuda.synchronize()
+                self.model.decoder.last_tapes = None
+        with self.graph.capture(), self.graph.memory():
             self.outputs = self._run()
         self._keep = self.model.decoder.last_tapes
         return self

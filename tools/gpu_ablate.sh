@@ -13,7 +13,7 @@ done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/gpurun_out/ablate/libsemitts_ablate.so $OBJS || exit 1
 export ST_LIB_PATH=$ROOT/gpurun_out/ablate/libsemitts_ablate.so
-for EXTRA in ""; do
+for EXTRA in "${ABL_ARGS:-}"; do
 for SKIP in ${SKIPS:-0 1 6 8 16 32 64 128 192 63}; do      # (2 | 4 = the merged query-projection + attention-fin launch)
   ST_SKIP=$SKIP timeout 300 python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-finite-check $EXTRA 2> /dev/null | python -c "
 import json,sys

@@ -626,9 +626,14 @@ def test_whole_forward_graph_replay_matches_eager(dev):
         mel_e, lin_e, align_e, stop_e = m(txt, None, T, spk, tf_rate=0.0, _masks={'own': gt.own_mask})
     assert torch.equal(mel, mel_e) and torch.equal(lin, lin_e) and torch.equal(align, align_e) and torch.equal(stop, stop_e)
     a = lin.clone()
+    # the intermediates the forward allocated during the capture (encoder / postnet activations, GEMM workspaces) were freed
+    # when it returned, and the graph still writes to them: they live in the graph's private memory pool, so other tensors of
+    # the process never land on them -- allocate and poison plenty of memory, replay, and look at both sides
+    junk = [torch.full((n,), float('nan'), device=dev) for n in (1 << 12, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 3 << 20, 5 << 18) * 3]
     lin2 = gt(redraw=False)[1]
     torch.cuda.synchronize()
     assert torch.equal(a, lin2)
+    assert all(bool(torch.isnan(j).all()) for j in junk)
 
 
 def test_cpu_tensor_is_refused():

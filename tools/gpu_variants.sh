@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing experiment (MI355X box): builds the library once per set of -D switches given in VARIANTS (';'-separated, e.g.
-# "-DAT_GRAN_MODE=0;-DAT_GRAN_MODE=1") into gpurun_out/variants/ and prints bench.py's decode-step time for each.
+# "-DPK_TRIP_SMALL=2;-DPK_TRIP_SMALL=3") into gpurun_out/variants/ and prints bench.py's decode-step time for each.
 # The product library is never built with such switches.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out/variants

@@ -129,6 +129,35 @@ def attn_fin(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, F_, K, par
                                           stream_handle()), 'st_attn_fin_t16_fwd')
 
 
+def attn_fin_split(pq, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx, parts):
+    """the fin part over `parts` position ranges + a combine launch (long texts): st_attn_fin_split_fwd"""
+    lib = _lib.load()
+    B, L, E = memory.shape
+    A = s_buf.shape[-1]
+    ws = torch.empty(int(lib.st_attn_fin_split_workspace_floats(B, E, int(parts))), device=memory.device, dtype=torch.float32)
+    check(lib.st_attn_fin_split_fwd(_p(pq), _p(s_buf), _p(memory), _p(w_cum_prev), _p(w_out), int(w_out.stride(0)), _p(w_cum_out), _p(v),
+                                    None, 0, _p(ctx), int(ctx.stride(0)), _p(ws), int(parts), B, L, A, E, stream_handle()),
+          'st_attn_fin_split_fwd')
+
+
+def query_attn_fin(packed_wq, h_q_t16, Q, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx_t16, F_, K, parts=2, epoch=1, granules=None):
+    """query projection + attention fin part in ONE launch (pq handed over inside the launch): st_query_attn_fin_fwd.
+    h_q_t16 / ctx_t16: T16 buffers of (B, Q) / (B, E); `granules` (B, 2 A floats) must be zero before the first epoch."""
+    B, L, E = memory.shape
+    A = s_buf.shape[-1]
+    if granules is None:
+        granules = torch.zeros(B, 2 * A, device=memory.device, dtype=torch.float32)
+    job = _lib.StAttnFinJob()
+    job.s_buf, job.memory, job.w_cum_prev = _p(s_buf), _p(memory), _p(w_cum_prev)
+    job.w_out, job.ld_wout, job.w_cum_out, job.v = _p(w_out), int(w_out.stride(0)), _p(w_cum_out), _p(v)
+    job.ctx_dst[0] = t16_view(ctx_t16, K=E)
+    job.n_ctx_dst, job.parts, job.L, job.A, job.E, job.F, job.K = 1, int(parts), L, A, E, int(F_), int(K)
+    hv = t16_view(h_q_t16, K=Q)
+    check(_lib.load().st_query_attn_fin_fwd(_p(packed_wq), C.byref(hv), 16 * kb16(Q), _p(granules), int(epoch), C.byref(job), B,
+                                            stream_handle()), 'st_query_attn_fin_fwd')
+    return granules
+
+
 _TAP_MAJOR = {}     # id(weight) -> (weakref to it, version, converted copy)
 
 

@@ -244,6 +244,62 @@ def test_attention_step_in_two_parts(dev, B, L, A, E, F, K):
     assert errs['w'] < 2e-6 and errs['cum'] < 2e-6 and errs['ctx'] < 2e-5      # (pq + ploc) + pm vs pq + (pm + ploc)
 
 
+@pytest.mark.parametrize('B,L,A,E,parts', [(3, 171, 256, 512, 4), (2, 300, 256, 512, 7), (5, 40, 24, 64, 2), (1, 900, 256, 512, 21),
+                                           (4, 130, 64, 128, 64)])
+def test_attention_fin_part_over_position_ranges(dev, B, L, A, E, parts):
+    """st_attn_fin_split_fwd (long texts): local softmax statistics and partial contexts per position range + a combine launch
+    == the one-workgroup fin part (same softmax, rounded differently) and == softmax(v . tanh(pq + S)) @ memory in float64."""
+    from semi_tts_amd import ops
+    pq, S, mem = rnd(B, A, seed=1), rnd(B, L, A, seed=2), rnd(B, L, E, seed=3)
+    w_cum, v = torch.rand(B, L, generator=torch.Generator().manual_seed(4)), rnd(1, A, seed=7)
+    d = [t.to(dev) for t in (pq, S, mem, w_cum, v)]
+    w1, c1, x1 = (torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, E, device=dev))
+    ops.attn_fin(d[0], d[1], d[2], d[3], d[4], w1, c1, x1, 32, 31)
+    w2, c2, x2 = torch.empty_like(w1), torch.empty_like(c1), torch.empty_like(x1)
+    ops.attn_fin_split(d[0], d[1], d[2], d[3], d[4], w2, c2, x2, parts)
+    e = torch.tanh(pq.double().unsqueeze(1) + S.double()).matmul(v.double().view(-1))
+    w_r = torch.softmax(e, -1)
+    x_r = torch.bmm(w_r.unsqueeze(1), mem.double()).squeeze(1)
+    errs = dict(w_vs_fin=maxdiff(w2, w1), ctx_vs_fin=maxdiff(x2, x1), w=maxdiff(w2, w_r), ctx=maxdiff(x2, x_r), cum=maxdiff(c2, w_r + w_cum.double()))
+    report('attention_fin_split', B=B, L=L, parts=parts, **errs)
+    assert errs['w_vs_fin'] < 1e-6 and errs['ctx_vs_fin'] < 1e-5
+    assert errs['w'] < 2e-6 and errs['ctx'] < 2e-5 and errs['cum'] < 2e-6
+    assert abs(float(w2.sum(-1).mean()) - 1.0) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.attn_fin_split(d[0], d[1], d[2], d[3], d[4], w2, c2, x2, 1)          # parts must be 2..64
+
+
+@pytest.mark.parametrize('B,L,Q,A,E,parts', [(32, 43, 1024, 256, 512, 2), (5, 9, 48, 16, 32, 1), (17, 30, 64, 32, 64, 2)])
+def test_query_projection_and_fin_part_in_one_launch(dev, B, L, Q, A, E, parts):
+    """st_query_attn_fin_fwd: pq = W_q h_q handed to the fin workgroups INSIDE the launch as {value, tag} words == the packed
+    linear followed by the fin part, bit for bit, for consecutive epochs on the same granule buffer; a launch that would not fit the
+    device at once is refused."""
+    from semi_tts_amd import ops
+    wq, hq = rnd(A, Q, scale=Q ** -0.5, seed=1), rnd(B, Q, seed=2)
+    S, mem = rnd(B, L, A, seed=3), rnd(B, L, E, seed=4)
+    w_cum, v = torch.rand(B, L, generator=torch.Generator().manual_seed(5)), rnd(1, A, seed=6)
+    d = [t.to(dev) for t in (wq, hq, S, mem, w_cum, v)]
+    packed = ops.pack_weight([d[0]], [Q], A)
+    h_t = ops.tile_rows(d[1])
+    pq = torch.empty(B, A, device=dev)                          # the two-launch form: packed linear, then the fin part
+    ops.skinny_linear_packed(packed, ops.t16_view(h_t, K=Q), 16 * ops.kb16(Q), B, A, y=pq)
+    assert maxdiff(pq, hq.double() @ wq.double().t()) < 1e-5
+    w1, c1, x1 = (torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, E, device=dev))
+    ops.attn_fin(pq, d[2], d[3], d[4], d[5], w1, c1, x1, 32, 31, parts=parts)
+    gran = None
+    for epoch in (1, 2, 3):
+        w2, c2 = torch.empty_like(w1), torch.empty_like(c1)
+        x_t = torch.zeros(ops.t16_floats(B, E), device=dev)
+        gran = ops.query_attn_fin(packed, h_t, Q, d[2], d[3], d[4], d[5], w2, c2, x_t, 32, 31, parts=parts, epoch=epoch, granules=gran)
+        x2 = ops.untile_rows(x_t, B, E)
+        errs = dict(w=maxdiff(w2, w1), cum=maxdiff(c2, c1), ctx=maxdiff(x2, x1))
+        report('query_attn_fin', B=B, L=L, epoch=epoch, **errs)
+        assert errs['w'] == 0.0 and errs['cum'] == 0.0 and errs['ctx'] == 0.0     # the same arithmetic as the two launches
+        assert bool(torch.isfinite(x2).all())
+    with pytest.raises(RuntimeError):       # epoch 0 is the "never written" tag
+        ops.query_attn_fin(packed, h_t, Q, d[2], d[3], d[4], d[5], w2, c2, x_t, 32, 31, parts=parts, epoch=0, granules=gran)
+
+
 CONV_CASES = [  # B, T, Cin, N, KT, pad, Tout(None = natural)
     (2, 9, 12, 32, 5, 2, None), (3, 13, 80, 80, 4, 2, 13), (3, 13, 80, 80, 4, 2, 14), (2, 20, 640, 128, 3, 1, None),
     (4, 12, 64, 512, 5, 2, None), (2, 7, 8, 8, 8, 4, 7), (1, 130, 160, 1025, 1, 0, None), (2, 5, 30, 70, 1, 0, None),

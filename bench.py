@@ -140,6 +140,9 @@ def spawn_ranks(args):
                          '(set ST_BENCH_BACKEND=gloo to share devices in a functional test)\n' % (args.gpus, n_dev))
         return 2
     env = dict(os.environ)
+    # This pool's host driver only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's peer-memory setup fails
+    # with `hipIpcGetMemHandle: invalid argument` (environment notes of the build image, which exports it already; kept as a
+    # default so that a launcher with a scrubbed environment still works).
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -167,12 +170,21 @@ class Ranks:
         torch.cuda.set_device(self.local_dev)
         self.dev = torch.device('cuda', self.local_dev)
         self.dist = None
-        if self.world > 1:
+        # --dist (or ST_BENCH_FORCE_DIST=1): initialise the process group even for ONE rank and force every collective to be
+        # issued (parallel.force_collectives), so a 1-GPU box executes the RCCL branch end to end -- world-size-1 sums are the
+        # identity, the numbers must equal the plain run's.  This process has not touched the GPU yet.
+        self.forced = self.world == 1 and (getattr(args, 'dist', False) or os.environ.get('ST_BENCH_FORCE_DIST') == '1')
+        if self.world > 1 or self.forced:
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if self.forced:
+                os.environ.setdefault('MASTER_PORT', str(free_port()))
             kw = {'device_id': self.dev} if self.backend == 'nccl' else {}
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
+            if self.forced:
+                from semi_tts_amd import parallel
+                parallel.force_collectives(True)
 
     def barrier(self):
         import torch
@@ -363,7 +375,7 @@ def bench_decode(args, rk):
                    'batch_per_gpu': B, 'frames': T, 'decode_steps': STEPS, 'text_len': L,
                    'parallelism': 'replicas x%d (utterance-sharded, no collective)' % rk.world,
                    'launch': 'eager' if graph is None else 'hipGraph replay of the whole decode loop'},
-        'rccl_ranks': rk.world if (rk.world > 1 and rk.backend == 'nccl') else 0,
+        'rccl_ranks': rk.world if (rk.dist is not None and rk.backend == 'nccl') else 0,
         'us_per_decode_step': round(us_step, 2),
         'roofline': roof,
     }
@@ -459,7 +471,8 @@ def bench_train(args, rk):
     elapsed = rk.timed(step, args.steps, args.warmup)
     variants['full'] = elapsed
     counts = parallel.collective_counts()
-    if rk.world > 1:
+    counts['async_grad_buckets'] = parallel.async_bucket_count()
+    if rk.world > 1 or rk.forced:
         parallel.set_gradient_allreduce(False)
         variants['no_allreduce'] = rk.timed(step, args.steps, 1)
         parallel.set_gradient_allreduce(True)
@@ -478,7 +491,7 @@ def bench_train(args, rk):
             'config': {'workload': 'C4: TtsTrainer.train_step, B=%d per GPU, %d->%d frames, L=%d, 109 speakers, tf_rate=1, '
                                    'config/semi-multi-spkr-paired-data.yaml' % (B, T_RAW, batch[2].shape[1], batch[0].shape[1]),
                        'parallelism': 'dp%d (utterance-sharded, SyncBN, gradient all-reduce of %.1f MB)' % (rk.world, n_par * 4 / 1e6)},
-            'rccl_ranks': rk.world if (rk.world > 1 and rk.backend == 'nccl') else 0,
+            'rccl_ranks': rk.world if (rk.dist is not None and rk.backend == 'nccl') else 0,
             'ms_allreduce': round(ms['full'] - ms['no_allreduce'], 3) if 'no_allreduce' in ms else 0.0,
             'ms_syncbn': round(ms['full'] - ms['no_syncbn'], 3) if 'no_syncbn' in ms else 0.0,
             'ms_variants': {k: round(v, 3) for k, v in ms.items()},
@@ -493,6 +506,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='issue the decode loop eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dist', action='store_true',
+                    help='with --gpus 1: initialise a world-size-1 process group (RCCL) and issue every collective anyway')
     ap.add_argument('--no-finite-check', action='store_true', help=argparse.SUPPRESS)    # timing experiments (tools/gpu_ablate.sh)
     ap.add_argument('--traffic-json', default=None, help='PMC summary (tools/pmc_summary.py) to quote as roofline.traffic')
     ap.add_argument('--workload', choices=['c2', 'c5', 'c3', 'train'], default='c2',

@@ -97,30 +97,32 @@ class _BnTrainFn(Function):
         M = x2.shape[0]
         sync = parallel.sync_bn_active()
         mean, var = ops.bn_stats(x2, 0, N, None if sync else run_mean, None if sync else run_var, momentum)
-        Mstat = M
+        scale = None
         if sync:
             # ONE collective: every rank's (mean, M2, count), merged exactly and identically on every rank in rank order
-            # (Chan et al.); no host round trip -- the global row count follows from the shard sizes (parallel.global_rows)
+            # (Chan et al.).  The counts stay on the device -- no host round trip, and shards of different sizes (a ragged
+            # last batch, B % world != 0, different T per rank in the speech encoder) are weighted by their true row counts.
             parallel._COUNTS['syncbn_fwd'] += 1
             rec = parallel.all_gather_(torch.cat([mean, var * M, mean.new_tensor([float(M)])]))      # (world, 2N + 1)
             cnt = rec[:, 2 * N:]
-            Mstat = parallel.global_rows(M)
-            gmean = (rec[:, :N] * cnt).sum(0) / Mstat
+            total = cnt.sum()
+            gmean = (rec[:, :N] * cnt).sum(0) / total
             m2 = (rec[:, N:2 * N] + cnt * (rec[:, :N] - gmean) ** 2).sum(0)
-            mean, var = gmean, m2 / Mstat
+            mean, var = gmean, m2 / total
+            scale = float(M) / total              # the dx formula divides its two sums by the GLOBAL row count
             if run_mean is not None:
                 run_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                run_var.mul_(1 - momentum).add_(m2 / max(Mstat - 1, 1), alpha=momentum)
+                run_var.mul_(1 - momentum).add_(m2 / (total - 1).clamp(min=1.0), alpha=momentum)
         y = ops.bn_norm(x2, 0, N, mean, var, weight, bias, eps, act).view(x.shape)
-        ctx.save_for_backward(x, y if act is not None else None, mean, var, weight)
-        ctx.cfg = (eps, act, Mstat, sync)
+        ctx.save_for_backward(x, y if act is not None else None, mean, var, weight, scale)
+        ctx.cfg = (eps, act, M, sync)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import parallel
-        x, y, mean, var, weight = ctx.saved_tensors
-        eps, act, Mstat, sync = ctx.cfg
+        x, y, mean, var, weight, scale = ctx.saved_tensors
+        eps, act, M, sync = ctx.cfg
         dy2, y2, x2 = _rows(dy.contiguous()), _rows(y) if y is not None else None, _rows(x)
         N = x2.shape[1]
         s = ops.bn_bwd_reduce(dy2, y2, act, x2, mean, var, eps)
@@ -128,7 +130,8 @@ class _BnTrainFn(Function):
         if sync:
             parallel._COUNTS['syncbn_bwd'] += 1
             parallel.all_reduce_sum_(s)
-        dx = ops.bn_bwd_apply(dy2, y2, act, x2, mean, var, weight, eps, s, Mstat)
+            s = s * scale                         # s / M_local below == (sum over ranks) / M_global
+        dx = ops.bn_bwd_apply(dy2, y2, act, x2, mean, var, weight, eps, s, M)
         return dx.view(x.shape), dw, db, None, None, None, None, None
 
 

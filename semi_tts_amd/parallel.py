@@ -14,6 +14,22 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE = False
+
+
+def force_collectives(enabled=True):
+    """Issue every collective even in a world of ONE rank (bench.py --dist, tests/test_gpu_rccl.py): a single-GPU box can then
+    execute the RCCL branch of the reducer, of SyncBN and of the timing helpers end to end -- the sums over one rank are the
+    identity, so the step must reproduce the non-distributed one."""
+    global _FORCE
+    _FORCE = bool(enabled)
+
+
+def dist_on():
+    """torch.distributed is initialised and there is something to reduce over (or collectives are forced)"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
 def shard_range(n_items, world_size, rank):
     """contiguous, balanced [lo, hi) of `n_items` utterances for `rank` (first ranks get the remainder)"""
     base, rem = divmod(n_items, world_size)
@@ -30,7 +46,7 @@ def rank_world():
 
 def max_over_ranks(seconds, device=None):
     """the slowest rank's wall time (what bench.py reports)"""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not dist_on():
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -39,6 +55,7 @@ def max_over_ranks(seconds, device=None):
 
 _GRAD_ALLREDUCE = True
 _COUNTS = {'grad_buckets': 0, 'syncbn_fwd': 0, 'syncbn_bwd': 0}
+_HANDOFF = {'async_buckets': 0}      # buckets issued with async_op=True (the RCCL branch), since the last collective_counts(reset=True)
 
 
 def set_gradient_allreduce(enabled=True):
@@ -53,14 +70,20 @@ def collective_counts(reset=False):
     if reset:
         for k in _COUNTS:
             _COUNTS[k] = 0
+        _HANDOFF['async_buckets'] = 0
     return out
+
+
+def async_bucket_count():
+    """gradient buckets of the last step that went out as asynchronous collectives on the backend's own stream (RCCL)"""
+    return _HANDOFF['async_buckets']
 
 
 def allreduce_gradients(params, bucket_bytes=32 << 20, average=True):
     """Sum (or average) .grad of `params` across ranks with flat buckets; returns the number of
     collectives issued.  Parameters without a gradient contribute zeros so every rank issues the same
     sequence of collectives."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not _GRAD_ALLREDUCE:
+    if not dist_on() or not _GRAD_ALLREDUCE:
         return 0
     world = dist.get_world_size()
     params = [p for p in params if p.requires_grad]
@@ -102,10 +125,18 @@ class GradReducer:
     The parameters (in REVERSE registration order, which is roughly the order their gradients become ready: postnet first,
     then the decoder's BPTT, then the encoder) are laid out in persistent flat fp32 buckets and every `p.grad` is a VIEW into
     its bucket, so autograd accumulates straight into the communication buffer.  A post-accumulate hook counts the gradients
-    of a bucket; when the last one has arrived the bucket's all-reduce is issued asynchronously (RCCL runs it on its own
-    stream while the rest of the backward pass keeps the compute stream busy); `finish()` issues what is left, waits, and
-    averages.  ~32 MiB buckets: 4 collectives for the 125 MB model -- few, large messages are what the per-link-bound xGMI
-    ring wants (ref: the step this replaces is BaseSolver.backward, src/solver.py:138-151, which needs the GLOBAL norm)."""
+    of a bucket; when the last one has arrived the bucket is READY, and ready buckets are issued strictly in index order
+    (bucket i only after buckets 0..i-1, as DDP does): ranks whose autograd graphs differ (a data-dependent
+    `ignore_speech_cycle`, per-rank `skip_prob` draws) still issue the same collectives in the same order.  The all-reduce is
+    asynchronous (RCCL runs it on its own stream while the rest of the backward pass keeps the compute stream busy);
+    `finish()` issues what is left, waits, and averages.  ~32 MiB buckets: 4 collectives for the 125 MB model -- few, large
+    messages are what the per-link-bound xGMI ring wants (ref: the step this replaces is BaseSolver.backward,
+    src/solver.py:138-151, which needs the GLOBAL norm).
+
+    Which parameters received a gradient on ANY rank travels with the last bucket (one flag per parameter behind its
+    gradients, no extra collective): a parameter keeps its averaged gradient on every rank when at least one rank produced
+    one, and gets `.grad = None` on every rank when none did -- the optimiser then skips it everywhere or nowhere, and the
+    global clip norm is the same on all ranks."""
 
     def __init__(self, params, bucket_bytes=32 << 20, average=True):
         self.params = [p for p in list(params)[::-1] if p.requires_grad]
@@ -120,13 +151,18 @@ class GradReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
+        self.index = {p: i for i, p in enumerate(self.params)}
         for bi, bucket in enumerate(self.buckets):
-            flat = torch.zeros(sum(p.numel() for p in bucket), device=bucket[0].device, dtype=torch.float32)
+            n = sum(p.numel() for p in bucket)
+            if bi == len(self.buckets) - 1:
+                n += len(self.params)                  # the "fired on some rank" flags ride behind the last bucket's gradients
+            flat = torch.zeros(n, device=bucket[0].device, dtype=torch.float32)
             self.flats.append(flat)
             off = 0
             for p in bucket:
                 self.slot[p] = (bi, off)
                 off += p.numel()
+        self.flags = self.flats[-1][self.flats[-1].numel() - len(self.params):] if self.flats else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.prepare()
 
@@ -143,7 +179,10 @@ class GradReducer:
         self.count = [0] * len(self.buckets)
         self.fired = set()
         self.works = [None] * len(self.buckets)
+        self.ready = [False] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
+        self.next = 0                                  # the next bucket to issue (in-order launches)
+        self.order = []                                # launch order of this step (tests)
 
     def _on_grad(self, p):
         if p not in self.slot or p in self.fired:
@@ -155,62 +194,59 @@ class GradReducer:
         bi = self.slot[p][0]
         self.count[bi] += 1
         if self.count[bi] == len(self.buckets[bi]):
-            self._launch(bi)
+            self.ready[bi] = True
+            self._launch_ready()
+
+    def _launch_ready(self, everything=False):
+        while self.next < len(self.buckets) and (everything or self.ready[self.next]):
+            self._launch(self.next)
+            self.next += 1
 
     def _launch(self, bi):
         self.launched[bi] = True
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not _GRAD_ALLREDUCE:
+        self.order.append(bi)
+        if not dist_on() or not _GRAD_ALLREDUCE:
             return
         flat = self.flats[bi]
+        if bi == len(self.buckets) - 1:                # flags of this rank; final here: every earlier bucket is out already
+            if len(self.fired) == len(self.params):
+                self.flags.fill_(1.0)
+            else:
+                self.flags.copy_(torch.tensor([1.0 if p in self.fired else 0.0 for p in self.params]), non_blocking=True)
         _COUNTS['grad_buckets'] += 1
         if flat.is_cuda and dist.get_backend() == 'gloo':      # functional tests on a box with fewer GPUs than ranks
             all_reduce_sum_(flat)
         else:
             self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            _HANDOFF['async_buckets'] += 1
 
     def finish(self):
-        """after backward: reduce the buckets that never filled up (parameters without a gradient this step contribute zeros
-        on every rank alike), wait, average; parameters that received no gradient on this rank get `.grad = None` back, as
-        autograd would have left them (the optimiser then skips them like the reference's does)"""
-        for bi in range(len(self.buckets)):
-            if not self.launched[bi]:
-                self._launch(bi)
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        for bi, w in enumerate(self.works):
+        """after backward: issue the buckets that never filled up (parameters without a gradient this step contribute zeros),
+        wait, average.  A parameter that received no gradient on ANY rank gets `.grad = None` back, as autograd would have
+        left it (the optimiser skips it like the reference's does); one that fired on some other rank keeps the averaged
+        gradient here too."""
+        self._launch_ready(everything=True)
+        reduced = dist_on() and _GRAD_ALLREDUCE
+        world = dist.get_world_size() if reduced else 1
+        for w in self.works:
             if w is not None:
                 w.wait()
-        if world > 1 and self.average and _GRAD_ALLREDUCE:
-            for flat in self.flats:
-                flat.mul_(1.0 / world)
-        for p in self.params:
-            if p not in self.fired:
-                p.grad = None
+        if len(self.fired) < len(self.params):
+            # only now, and only in the irregular case, the flags are read back (one small device -> host copy)
+            anywhere = self.flags.detach().cpu().tolist() if reduced else None
+            for i, p in enumerate(self.params):
+                if p not in self.fired and (anywhere is None or anywhere[i] == 0.0):
+                    p.grad = None
+        if world > 1 and self.average:
+            n_flags = len(self.params)
+            for bi, flat in enumerate(self.flats):
+                (flat[:flat.numel() - n_flags] if bi == len(self.flats) - 1 else flat).mul_(1.0 / world)
         return sum(1 for l in self.launched if l)
 
     def close(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
-
-
-_SHARD_ROWS = None
-
-
-def set_shard_rows(mine=None, total=None):
-    """utterances of this rank / of the global batch, when the ranks hold different numbers of them (default: equal shards).
-    SyncBN needs the global row count on the host without a device round trip."""
-    global _SHARD_ROWS
-    _SHARD_ROWS = (int(mine), int(total)) if mine else None
-
-
-def global_rows(local_rows):
-    """rows of the global batch a BatchNorm layer sees, from this rank's rows"""
-    if not (dist.is_available() and dist.is_initialized()):
-        return local_rows
-    if _SHARD_ROWS is None:
-        return local_rows * dist.get_world_size()
-    mine, total = _SHARD_ROWS
-    return local_rows * total // mine
 
 
 def all_gather_(t):
@@ -228,7 +264,7 @@ def all_gather_(t):
 
 def broadcast_parameters(module, src=0):
     """make every replica start from rank `src`'s weights and buffers"""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not dist_on():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
@@ -247,7 +283,7 @@ def sync_batchnorm(enabled=True):
 
 
 def sync_bn_active():
-    return _SYNC_BN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return _SYNC_BN and dist_on()
 
 
 def all_reduce_sum_(t):

@@ -202,7 +202,7 @@ class TtsTrainer(BaseSolver):
         """under torch.distributed: gradients live in flat buckets that are all-reduced while the backward pass still runs"""
         from . import parallel
         self.reducer = None
-        if parallel.rank_world()[1] > 1:
+        if parallel.dist_on():               # more than one rank, or collectives forced in a world of one (bench.py --dist)
             self.reducer = parallel.GradReducer(self.model.parameters())
         return self.reducer
 

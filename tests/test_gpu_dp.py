@@ -24,17 +24,17 @@ def _build(dev):
     return m, A, meta
 
 
-def _step(m, A, rows, dev):
+def _step(m, A, rows, dev, weight=1.0):
     from semi_tts_amd import autograd as AG
     txt, spk, teacher = (A[k][rows].to(dev) for k in ('txt_embed', 'spkr_embed', 'teacher'))
     lin_t = torch.rand(4, teacher.shape[1], 20, generator=torch.Generator().manual_seed(3))[rows].to(dev)
     mel, lin, _, _ = m(txt, None, teacher, spk, tf_rate=1.0)
-    loss = AG.freq_loss(mel, teacher, 22050, 8) + AG.freq_loss(lin, lin_t, 22050, 8)
+    loss = (AG.freq_loss(mel, teacher, 22050, 8) + AG.freq_loss(lin, lin_t, 22050, 8)) * weight
     loss.backward()
     return float(loss.detach())
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, cut=2):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -43,9 +43,12 @@ def _worker(rank, world, port, out_path):
     m, A, _ = _build(dev)
     parallel.sync_batchnorm(True)
     parallel.broadcast_parameters(m)
-    rows = slice(rank * 2, rank * 2 + 2)
+    # rank 0 takes utterances [0, cut), rank 1 [cut, 4); each local mean loss is weighted by its share of the global batch
+    # (n_r * world / N) so that the AVERAGE over ranks is the global mean loss also for unequal shards
+    rows = slice(0, cut) if rank == 0 else slice(cut, 4)
+    n_r = cut if rank == 0 else 4 - cut
     red = parallel.GradReducer(m.parameters(), bucket_bytes=64 << 10)               # small buckets: several collectives,
-    loss = _step(m, A, rows, dev)                                                   # issued from autograd hooks during backward
+    loss = _step(m, A, rows, dev, weight=n_r * world / 4.0)                         # issued from autograd hooks during backward
     n_coll = red.finish()
     assert n_coll > 1
     assert parallel.collective_counts()['syncbn_fwd'] == 13 and parallel.collective_counts()['syncbn_bwd'] == 13   # one each per BN layer
@@ -55,7 +58,8 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_sync_bn_training_equals_single_process(tmp_path):
+@pytest.mark.parametrize('cut', [2, 3])        # equal shards (2 + 2 utterances) and unequal ones (3 + 1)
+def test_two_rank_sync_bn_training_equals_single_process(tmp_path, cut):
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
     dev = torch.device('cuda:0')
@@ -64,7 +68,7 @@ def test_two_rank_sync_bn_training_equals_single_process(tmp_path):
     ref = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
     ref_stats = {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}
     out = str(tmp_path / 'dp.pt')
-    ctx = mp.start_processes(_worker, args=(2, 29517 + os.getpid() % 500, out), nprocs=2, join=False, start_method='spawn')
+    ctx = mp.start_processes(_worker, args=(2, 29517 + os.getpid() % 500 + 7 * cut, out, cut), nprocs=2, join=False, start_method='spawn')
     import time
     deadline = time.time() + 90                 # never hang the suite: a stuck rank is killed and the test fails
     while not ctx.join(timeout=5):

@@ -173,8 +173,22 @@ for it in range(2):                                    # twice: the buckets are 
 err2 = max((a.grad - b.grad).abs().max().item() for a, b in zip(list(net2.parameters())[:4], ref.parameters()))
 unused_none = all(p.grad is None for p in net2[2].parameters())
 views = all(p.grad.data_ptr() == red._view(p).data_ptr() for p in list(net2.parameters())[:4])
+# ranks whose autograd graphs DIFFER (only rank 0 uses the third layer): the buckets still go out in index order on both ranks,
+# and the parameter that fired on one rank only keeps the same summed gradient on BOTH (none of them drops it)
+net3 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+broadcast_parameters(net3)
+red3 = GradReducer(net3.parameters(), bucket_bytes=64, average=False)
+red3.prepare()
+h = net3[1](net3[0](x[lo:hi]))
+(((net3[2](h) if rank == 0 else h).pow(2).sum()) / 8.0).backward()
+red3.finish()
+in_order = red3.order == sorted(red3.order) and len(red3.order) == len(red3.buckets)
+g2 = torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.full((p.numel(),), float('nan')) for p in net3[2].parameters()])
+both = [torch.empty_like(g2) for _ in range(world)]
+dist.all_gather(both, g2)
+shared = bool(torch.equal(both[0], both[1]) and torch.isfinite(both[0]).all() and both[0].abs().max() > 0)
 if rank == 0:
-    print('RESULT', err, n, t, err2, n2, int(unused_none), int(views))
+    print('RESULT', err, n, t, err2, n2, int(unused_none), int(views), int(in_order), int(shared))
 dist.destroy_process_group()
 '''
 
@@ -195,3 +209,5 @@ def test_two_process_gradient_allreduce_matches_single_process(tmp_path):
     assert float(line[3]) == 2.0          # max over ranks of (1, 2)
     assert float(line[4]) < 1e-5 and int(line[5]) >= 2       # hook-driven buckets give the same gradients
     assert line[6] == '1' and line[7] == '1'                # unused parameters stay None, gradients are views of the buckets
+    assert line[8] == '1'                                   # buckets issued in index order although the ranks' graphs differ
+    assert line[9] == '1'                                   # a parameter that fired on one rank only: same gradient on both

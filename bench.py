@@ -329,6 +329,8 @@ def bench_decode(args, rk):
     elapsed = rk.timed(one_pass, args.steps, args.warmup)
     mel = state['out'][0]
     assert args.no_finite_check or bool(torch.isfinite(mel).all()), 'non-finite mel output'
+    if not args.no_finite_check:
+        gd.check()                                      # no in-launch hand-off of the timed replays timed out
     if rk.rank != 0:
         return None
 

@@ -224,9 +224,16 @@ typedef struct st_attn_fin_job {
     st_t16_view ctx_dst[3]; int n_ctx_dst;
     int parts;          /* workgroups per utterance (slices of the context dims): 1, 2, 4, 8 */
     int L, A, E, F, K;
+    unsigned* status;   /* optional device word: bit 0 is set when a fin workgroup gave up waiting for its granules (the query is
+                         * then poisoned with NaN as well); never cleared by the library -- the caller zeroes and reads it */
 } st_attn_fin_job;
 int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
                           const st_attn_fin_job* job, int B, void* stream);
+/* Diagnostics: one wave runs the consumer side of that hand-off on `granules` (A 64-bit {value, tag} words) as they are and writes
+ * the A values to `out` -- or NaN, with bit 0 of *status set, after `max_spins` polls without every tag == epoch (the failure
+ * path of a starved launch, which the scheduler never produces on an idle device). */
+int st_handoff_wait_selftest(const unsigned long long* granules, unsigned epoch, int A, unsigned* status, float* out,
+                             int max_spins, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM / conv1d (many rows)
  * C(m, coff + n) = epilogue( sum_tap sum_ci A(row(m) * stride + tap - pad, ci) * W(n, ci, tap) )
@@ -502,6 +509,9 @@ typedef struct st_decoder_io {
     int attn_split_parts;
     unsigned long long* pq_granules;   /* optional (B, A) 64-bit words: with attn_s_buf, the query projection and the attention fin
                                         * part of a step run as ONE launch (st_query_attn_fin_fwd); zeroed by the callee per forward */
+    unsigned* handoff_status;          /* optional device word for pq_granules: bit 0 = an in-launch hand-off timed out (a starved launch:
+                                        * the waiting workgroups were not co-resident with their producers).  Sticky; owned, zeroed and
+                                        * read by the caller after the forward -- a time-out is an ERROR, not a NaN to find later */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);

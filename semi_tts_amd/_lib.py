@@ -56,7 +56,8 @@ class StDecoderIO(C.Structure):
                 ('zero_row', C.c_void_p),
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('attn_fin_parts', C.c_int), ('defer_proj', C.c_int),
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p),
-                ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p)]
+                ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p),
+                ('handoff_status', C.c_void_p)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -87,7 +88,7 @@ class StAttnFinJob(C.Structure):
     _fields_ = [('s_buf', C.c_void_p), ('memory', C.c_void_p), ('w_cum_prev', C.c_void_p),
                 ('w_out', C.c_void_p), ('ld_wout', C.c_int), ('w_cum_out', C.c_void_p), ('v', C.c_void_p),
                 ('ctx_dst', StT16View * 3), ('n_ctx_dst', C.c_int), ('parts', C.c_int),
-                ('L', C.c_int), ('A', C.c_int), ('E', C.c_int), ('F', C.c_int), ('K', C.c_int)]
+                ('L', C.c_int), ('A', C.c_int), ('E', C.c_int), ('F', C.c_int), ('K', C.c_int), ('status', C.c_void_p)]
 
 
 P, I, F, Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -149,6 +150,7 @@ SIGNATURES = {
     'st_attn_fin_split_workspace_floats': [I, I, I],
     'st_attn_fin_split_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, P, I, I, I, I, I, P],
     'st_query_attn_fin_fwd': [P, C.POINTER(StT16View), I, P, C.c_uint, C.POINTER(StAttnFinJob), I, P],
+    'st_handoff_wait_selftest': [P, C.c_uint, I, P, P, I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],

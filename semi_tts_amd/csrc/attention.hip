@@ -307,3 +307,25 @@ extern "C" int st_attn_fin_split_fwd(const float* pq, const float* s_buf, const 
     ST_LAUNCH_CHECK();
     return 0;
 }
+
+
+// One wave runs the consumer side of the granule hand-off (at_wait_granules, the routine the fin workgroups of st_query_attn_fin_fwd
+// wait in) on `granules` as they are: the A values, or NaN + status bit 0 after `max_spins` polls without every tag == epoch.
+namespace {
+__global__ __launch_bounds__(64) void handoff_wait_kernel(const unsigned long long* granules, unsigned epoch, int A, unsigned* status,
+                                                          float* out, int max_spins) {
+    const int lane = threadIdx.x;
+    const f32x4 q4 = at_wait_granules(granules, epoch, lane, A, status, max_spins);
+    if (lane * 4 < A) *reinterpret_cast<f32x4*>(out + lane * 4) = q4;
+}
+}  // namespace
+
+extern "C" int st_handoff_wait_selftest(const unsigned long long* granules, unsigned epoch, int A, unsigned* status, float* out,
+                                        int max_spins, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(granules && out && A > 0 && A % 4 == 0 && A <= 256 && max_spins > 0 && st_aligned16(out),
+                 "st_handoff_wait_selftest: bad arguments");
+    hipLaunchKernelGGL(handoff_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, granules, epoch, A, status, out, max_spins);
+    ST_LAUNCH_CHECK();
+    return 0;
+}

@@ -50,7 +50,36 @@ struct AtArgs {
     // fin part inside the query-projection launch (pk_attnfin_kernel): the processed query arrives as 8-byte {value, tag} granules
     // written by the linear's workgroups of the SAME launch; tag = epoch (decode step + 1)
     const unsigned long long* pq_gran; unsigned epoch;
+    unsigned* status;  // optional: bit 0 set when the wait for the granules timed out
 };
+
+// Wait of one wave for the A {value, tag} granules of one utterance (lane l takes granules 4l .. 4l+3): re-read until every tag is
+// `epoch`, at most `max_spins` times.  On a time-out the values are NaN AND bit 0 of *status is set (when status is given): the
+// caller of the forward checks that word, so a starved launch is an error and not a NaN to be found in a .npy file later.
+constexpr int AT_GRAN_SPINS = 1 << 18;
+__device__ __forceinline__ f32x4 at_wait_granules(const unsigned long long* base, unsigned epoch, int lane, int A, unsigned* status,
+                                                  int max_spins) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    gu64* gp = (gu64*)(base + min(lane * 4, A - 4));
+    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+    bool ok = false;
+    for (int spins = 0; spins < max_spins; ++spins) {
+        g0 = __hip_atomic_load(gp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g2 = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g3 = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool mine = (unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch &&
+                          (unsigned)(g2 >> 32) == epoch && (unsigned)(g3 >> 32) == epoch;
+        ok = __all(mine);
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok && lane == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float nanv = __builtin_nanf("");
+    return ok ? f32x4{__uint_as_float((unsigned)g0), __uint_as_float((unsigned)g1), __uint_as_float((unsigned)g2),
+                      __uint_as_float((unsigned)g3)}
+              : f32x4{nanv, nanv, nanv, nanv};
+}
 
 struct AtLds {  // offsets in floats into dynamic LDS
     int wt, wt_ld, wc, kp, hs, hl, cf, cf_ld, e, part, total;
@@ -182,29 +211,11 @@ __device__ __forceinline__ void at_body(const AtArgs& a, const int wg, float* ld
         // handed over as 8-byte {value, tag} granules (one relaxed agent-scope store each, write-through; the data is the flag:
         // no fence on either side -- MI355X guide, hand-off recipe R2).  Everything else this workgroup needs (S rows, v, the
         // memory rows) was requested above and is in flight while the wave re-reads its four granules until every tag is
-        // this step's epoch.  The spin is bounded: on a time-out the query is poisoned with NaN (the caller's finite check trips).
-        typedef __attribute__((address_space(1))) unsigned long long gu64;
-        gu64* gp = (gu64*)(a.pq_gran + (size_t)b * A + min(lane * 4, A - 4));
-        unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-        bool ok = false;
+        // this step's epoch.  The spin is bounded: on a time-out the query is poisoned with NaN and bit 0 of the status word is set.
         // ONE wave per workgroup polls (eight polling waves per workgroup measured 0.35 us per step slower: the polls compete with
         // the producers' own loads); the others take the query from LDS -- the context-partial area is free at this point
         if (wave == 0) {
-            for (int spins = 0; spins < (1 << 18); ++spins) {
-                g0 = __hip_atomic_load(gp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g2 = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g3 = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool mine = (unsigned)(g0 >> 32) == a.epoch && (unsigned)(g1 >> 32) == a.epoch &&
-                                  (unsigned)(g2 >> 32) == a.epoch && (unsigned)(g3 >> 32) == a.epoch;
-                ok = __all(mine);
-                if (ok) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            const float nanv = __builtin_nanf("");
-            const f32x4 q4 = ok ? f32x4{__uint_as_float((unsigned)g0), __uint_as_float((unsigned)g1), __uint_as_float((unsigned)g2),
-                                        __uint_as_float((unsigned)g3)}
-                                : f32x4{nanv, nanv, nanv, nanv};
+            const f32x4 q4 = at_wait_granules(a.pq_gran + (size_t)b * A, a.epoch, lane, A, a.status, AT_GRAN_SPINS);
             if (lane * 4 < A) *reinterpret_cast<f32x4*>(part + lane * 4) = q4;
         }
         __syncthreads();

@@ -264,6 +264,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             fj.memory = io->memory; fj.w_cum_prev = io->wcum_tape + (size_t)t * BL;
             fj.w_out = io->align_out + (size_t)t * L; fj.ld_wout = ldal; fj.w_cum_out = io->wcum_tape + (size_t)(t + 1) * BL; fj.v = w->attn_v;
             for (int c = 0; c < 3; ++c) fj.ctx_dst[c] = ctx_dst[c];
+            fj.status = io->handoff_status;
             fj.n_ctx_dst = 3; fj.parts = fin_parts; fj.L = L; fj.A = A; fj.E = E; fj.F = d->F; fj.K = d->K;
             rc = st_query_attn_fin_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, stream);
         }

@@ -794,7 +794,7 @@ extern "C" int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* 
     t.fin_parts = parts;
     for (int d = 0; d < job->n_ctx_dst; ++d) t.ctx_dst[d] = job->ctx_dst[d];
     t.B = B; t.L = L; t.A = A; t.E = E; t.F = job->F; t.K = job->K;
-    t.pq_gran = granules; t.epoch = epoch;
+    t.pq_gran = granules; t.epoch = epoch; t.status = job->status;
     const int tiles = A / 16, BT = (B + 15) >> 4;
     const int n_lin = tiles * BT, n_fin = B * parts;
     // the waiting workgroups hold their compute units: everything must be resident at once

@@ -306,6 +306,10 @@ class Decoder(nn.Module):
         self.attn_pre_parts = 4      # workgroups per utterance of the pre part (measured at L = 43: 1 / 2 / 4 parts 37.1 / 35.9 / 35.4 us per step)
         self.attn_fin_parts = 2      # workgroups per utterance of the fin part (slices of the context dims)
         self.attn_pq_in_fin = True   # inference: query projection and fin part share one launch (in-launch hand-off of pq)
+        # the hand-off's failure word (st_decoder_io.handoff_status): an eager forward reads it back right away (one small
+        # device -> host copy); under stream capture nobody can, so GraphedDecoder / bench.py / gen_specgram check it after replays
+        self.check_handoff = True
+        self.handoff_status = None
         self.attn_split_min_len = 128     # texts at least this long: fin part over position ranges (~attn_split_positions each) + combine
         self.attn_split_positions = 43
 
@@ -527,8 +531,13 @@ class Decoder(nn.Module):
                 # the launch as 8-byte {value, tag} words; the library falls back to two launches when the shapes do not fit
                 tapes['pq_gran'] = torch.empty(B, 2 * A, **f32)            # (B, A) 64-bit words
                 io.pq_granules = ops._p(tapes['pq_gran'])
+                if self.handoff_status is None or self.handoff_status.device != dev:
+                    self.handoff_status = torch.zeros(1, device=dev, dtype=torch.int32)
+                io.handoff_status = ops._p(self.handoff_status, torch.int32)
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
+        if io.handoff_status and self.check_handoff and not ops.capturing():
+            ops.check_handoff(self.handoff_status)
         if defer:
             kb = ops.kb16
             Bp = ((B + 15) // 16) * 16

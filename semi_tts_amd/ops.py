@@ -24,6 +24,25 @@ def stream_handle():
     return torch.cuda.current_stream().cuda_stream
 
 
+def capturing():
+    """st_* calls are being issued on an overridden stream (a hipGraph capture): nothing may read results back now"""
+    return _stream_override is not None
+
+
+def check_handoff(status):
+    """Raise if an in-launch hand-off of the decode loop timed out since the word was last cleared (st_decoder_io.handoff_status):
+    the waiting workgroups were not co-resident with their producers -- the outputs of that forward are poisoned with NaN.
+    Reads one device word (synchronises) and clears it."""
+    if status is None:
+        return
+    v = int(status.item())
+    if v != 0:
+        status.zero_()
+        raise RuntimeError('decode loop: an in-launch hand-off of the processed query timed out (status word 0x%x): the launch was '
+                           'starved of compute units; the outputs of this forward are invalid.  Set decoder.attn_pq_in_fin = False '
+                           'to run the query projection and the attention as two launches.' % v)
+
+
 @contextmanager
 def use_stream(handle):
     global _stream_override

@@ -29,6 +29,12 @@ class GraphedDecoder:
         self.graph = None
         self.outputs = None
         self._keep = None
+        import os
+        self.debug = os.environ.get('ST_CHECK_HANDOFF') == '1'    # read the hand-off status word back after every replay
+
+    def check(self):
+        """raise if any replay since the last check had a starved in-launch hand-off (one device word, synchronises)"""
+        ops.check_handoff(self.decoder.handoff_status)
 
     def _run(self):
         masks = {'own': self.own_mask} if self.own_mask is not None else None
@@ -75,6 +81,8 @@ class GraphedDecoder:
         if redraw:
             self.draw_masks()
         self.graph.launch()
+        if self.debug:
+            self.check()
         return self.outputs
 
 

@@ -128,6 +128,9 @@ class SpecgramGenerator(BaseSolver):
                 mel, lin, align, _, _, _, _, _ = self.model.text_to_speech(
                     text, sid, None, None, None, None, frames + pad + INFERENCE_MARGIN_FRAMES, None, tf_rate=0.0)
             torch.cuda.synchronize()
+            # (the eager forward has already checked the decode loop's hand-off status word: ops.check_handoff)
+            if not (bool(torch.isfinite(mel).all()) and bool(torch.isfinite(lin).all())):
+                raise RuntimeError('gen_specgram: non-finite spectrogram for batch starting at %s -- nothing written' % names[0])
             enc_step = (text != 0).sum(dim=-1).cpu().tolist()
             dec_step = [int(n * FRAME_PHN_RATIO) // r for n in enc_step]
             for i, (msp, sp, ali) in enumerate(zip(mel, lin, align)):

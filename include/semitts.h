@@ -395,6 +395,12 @@ int st_gather_rows(const float* table, const int64_t* idx, float* out, int n, in
  * ref: L2Embedding.forward src/embed.py:105-147, neg_batch_l2 :208-213 */
 int st_vq_l2_fwd(const float* x, const float* table, const float* temp, float* p_code,
                  int64_t* idx, float* out, float* workspace, int n, int D, int V, void* stream);
+/* The same search with the table's MFMA-order copy made ONCE per table version instead of on every call (the table only changes
+ * with the weights): st_vq_pack_table fills `packed` (st_vq_l2_workspace_floats(D, V) floats; D <= 64, D % 4 == 0, V <= 1024),
+ * st_vq_l2_packed_fwd searches with it.  Same results as st_vq_l2_fwd bit for bit. */
+int st_vq_pack_table(const float* table, float* packed, int D, int V, void* stream);
+int st_vq_l2_packed_fwd(const float* x, const float* table, const float* packed, const float* temp, float* p_code,
+                        int64_t* idx, float* out, int n, int D, int V, void* stream);
 /* workspace: st_vq_l2_workspace_floats(D, V) floats (the table re-packed into MFMA operand order + |e|^2 per code) selects the
  * matrix-core kernel (D <= 64, D % 4 == 0, V <= 1024; exact-fp32 MFMA keeps the dimension-ascending dot product, so the indices
  * are those of the scalar kernel); NULL or another shape runs the scalar kernel (table staged in LDS). */

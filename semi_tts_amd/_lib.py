@@ -125,6 +125,8 @@ SIGNATURES = {
     'st_vq_build_table': [P, I, P, I, P, P, I, P, I, P],
     'st_gather_rows': [P, P, P, I, I, I, P],
     'st_vq_l2_fwd': [P, P, P, P, P, P, P, I, I, I, P],
+    'st_vq_pack_table': [P, P, I, I, P],
+    'st_vq_l2_packed_fwd': [P, P, P, P, P, P, P, I, I, I, P],
     'st_vq_l2_workspace_floats': [I, I],
     'st_ctc_workspace_floats': [I, I],
     'st_ctc_loss': [P, P, C.c_float, P, P, P, I, I, I, I, P],

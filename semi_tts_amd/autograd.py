@@ -595,7 +595,8 @@ class _MeanForwardFn(Function):
         B, T, D = latent.shape
         V = p_code.shape[-1]
         dev = latent.device
-        out = torch.zeros(B, T, D, device=dev, dtype=torch.float32)
+        out = torch.empty(B, T, D, device=dev, dtype=torch.float32)
+        ops.fill_(out, 0.0)            # (a library launch, not torch.zeros: it is then part of a captured graph as well)
         lens = torch.empty(B, device=dev, dtype=torch.int32)
         seg = torch.empty(B, T, device=dev, dtype=torch.int32)
         w = torch.empty(B, T, device=dev, dtype=torch.float32)

@@ -379,7 +379,8 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
 // activation traffic halves (every workgroup of the one-row-tile form re-reads ALL of x: 229 KB at K = 1792, B = 32; 655 KB at
 // K = 2560, B = 64); each weight tile is read by the two batch halves, whose workgroups are gridDim.x (a multiple of 8) apart in
 // launch order (= the same XCD under round-robin placement), so the second read is an L2 hit.
-template <int KW, int TRIP, int NB>
+// AUX0 / AUX1: cache policy of the weight loads of the workgroup's first / second row tile (0 default, 2 = nt)
+template <int KW, int TRIP, int NB, int AUX0 = 0, int AUX1 = 0>
 __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, const f32x4* xp, const int w_kbs, const int x_kbs, const int KB,
                                                           const int B, const int H, const PkArgs rest) {
     constexpr int RT = 2;
@@ -403,7 +404,9 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
         for (int t = 0; t < TRIP; ++t) {
             const unsigned vo = voff + (unsigned)(kb + t * KW) * 1024u;         // past KB: zeros from the range check
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) r.w[t][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw[rt], vo, 0, 0));
+            for (int rt = 0; rt < RT; ++rt)
+                r.w[t][rt] = rt == 0 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw[0], vo, 0, AUX0))
+                                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw[rt], vo, 0, AUX1));
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, bt * x_kbs * 1024, 0));
         }
@@ -592,6 +595,13 @@ int pk_launch(const PkArgs& a, int tiles, hipStream_t st) {
     return 0;
 }
 
+// waves per workgroup x k-blocks per wave and group of the 2-D tiled LSTM cell (tools/gpu_variants.sh sweeps them)
+#ifndef PK_LSTM_KW
+#define PK_LSTM_KW 8
+#endif
+#ifndef PK_LSTM_TRIP
+#define PK_LSTM_TRIP 2
+#endif
 // shapes the 2-D tiled LSTM cell takes (two row tiles x half the batch tiles per workgroup)
 inline bool pk_rt2_shape(int B, int tiles) {
     const int BT = (B + 15) >> 4;
@@ -604,10 +614,18 @@ int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st) {
     // LSTM cell with an even number of batch tiles (B = 17..32 or 49..64): 2-D tiling, two row tiles x half the batch tiles per
     // workgroup (pk_lstm_rt2_kernel).  Measured: B = 32 9.54 -> 9.05 us per cell (3.16 -> 3.09 ms per C2 pass), B = 64 15.0 -> 13.7 us.
     if (MODE == 0 && pk_rt2_shape(a.B, tiles)) {
-        if (BT == 2)
-            hipLaunchKernelGGL((pk_lstm_rt2_kernel<8, 2, 1>), dim3(tiles / 2, 2), dim3(8 * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+        constexpr int LKW = PK_LSTM_KW, LTR = PK_LSTM_TRIP;
+#if defined(PK_AUX_Q0) || defined(PK_AUX_D0)      // cache-policy experiment (tools/gpu_lstm_variants.sh): long reductions (the decoder cell) vs short ones
+        if (BT == 2 && a.KB > 128)
+            hipLaunchKernelGGL((pk_lstm_rt2_kernel<LKW, LTR, 1, PK_AUX_D0, PK_AUX_D1>), dim3(tiles / 2, 2), dim3(LKW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+        else if (BT == 2)
+            hipLaunchKernelGGL((pk_lstm_rt2_kernel<LKW, LTR, 1, PK_AUX_Q0, PK_AUX_Q1>), dim3(tiles / 2, 2), dim3(LKW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
         else
-            hipLaunchKernelGGL((pk_lstm_rt2_kernel<8, 2, 2>), dim3(tiles / 2, 2), dim3(8 * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+#endif
+        if (BT == 2)
+            hipLaunchKernelGGL((pk_lstm_rt2_kernel<LKW, LTR, 1>), dim3(tiles / 2, 2), dim3(LKW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+        else
+            hipLaunchKernelGGL((pk_lstm_rt2_kernel<LKW, LTR, 2>), dim3(tiles / 2, 2), dim3(LKW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
         ST_LAUNCH_CHECK();
         return 0;
     }

@@ -470,18 +470,50 @@ extern "C" size_t st_vq_l2_workspace_floats(int D, int V) {
     return n_ct * ks4n * 256 + n_ct * 16;
 }
 
+// shapes the matrix-core search takes: D <= 64 in 16-byte pieces, at most 16 code tiles per wave
+static inline bool vq_mfma_shape(int D, int V) { return D <= 64 && D % 4 == 0 && V <= 1024; }
+
+extern "C" int st_vq_pack_table(const float* table, float* packed, int D, int V, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(table && packed && vq_mfma_shape(D, V) && D > 0 && V > 0 && st_aligned16(table) && st_aligned16(packed),
+                 "st_vq_pack_table: D=%d V=%d not a matrix-core shape, or unaligned operands", D, V);
+    const int n_ct = (V + 15) / 16, ks4n = (D + 15) / 16;
+    const size_t total = (size_t)n_ct * ks4n * 256 + (size_t)n_ct * 16;
+    hipLaunchKernelGGL(vq_pack_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, V, D,
+                       packed, n_ct, ks4n);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+static int vq_l2_impl(const float* x, const float* table, const float* temp, float* p_code,
+                      int64_t* idx, float* out, float* workspace, bool pack, int n, int D, int V, void* stream);
+
+extern "C" int st_vq_l2_packed_fwd(const float* x, const float* table, const float* packed, const float* temp, float* p_code,
+                                   int64_t* idx, float* out, int n, int D, int V, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(x && table && packed && temp && p_code && idx && out && n > 0 && D > 0 && V > 0, "st_vq_l2_packed_fwd: bad arguments");
+    ST_CHECK_ARG(vq_mfma_shape(D, V) && st_aligned16(x) && st_aligned16(table) && st_aligned16(out) && st_aligned16(packed),
+                 "st_vq_l2_packed_fwd: D=%d V=%d not a matrix-core shape, or unaligned operands", D, V);
+    return vq_l2_impl(x, table, temp, p_code, idx, out, const_cast<float*>(packed), false, n, D, V, stream);
+}
+
 extern "C" int st_vq_l2_fwd(const float* x, const float* table, const float* temp, float* p_code,
                             int64_t* idx, float* out, float* workspace, int n, int D, int V, void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(x && table && temp && p_code && idx && out && n > 0 && D > 0 && V > 0, "st_vq_l2_fwd: bad arguments");
-    // matrix-core form: D <= 64 in 16-byte pieces, at most 16 code tiles per wave, a caller-provided workspace for the packed table
-    if (workspace && D <= 64 && D % 4 == 0 && V <= 1024 && st_aligned16(x) && st_aligned16(table) && st_aligned16(out) &&
+    return vq_l2_impl(x, table, temp, p_code, idx, out, workspace, true, n, D, V, stream);
+}
+
+static int vq_l2_impl(const float* x, const float* table, const float* temp, float* p_code,
+                      int64_t* idx, float* out, float* workspace, bool pack, int n, int D, int V, void* stream) {
+    // matrix-core form: a caller-provided workspace for the packed table (packed here, or once per table version by st_vq_pack_table)
+    if (workspace && vq_mfma_shape(D, V) && st_aligned16(x) && st_aligned16(table) && st_aligned16(out) &&
         st_aligned16(workspace)) {
         const int n_ct = (V + 15) / 16, ks4n = (D + 15) / 16;
-        const size_t total = (size_t)n_ct * ks4n * 256 + (size_t)n_ct * 16;
-        hipLaunchKernelGGL(vq_pack_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, V, D,
-                           workspace, n_ct, ks4n);
-        ST_LAUNCH_CHECK();
+        if (pack) {
+            int rc = st_vq_pack_table(table, workspace, D, V, stream);
+            if (rc) return rc;
+        }
         const dim3 grid((n + 15) / 16);
 #define VQ_LAUNCH(NW, T) hipLaunchKernelGGL((vq_l2_mfma_kernel<NW, T>), grid, dim3(NW * 64), 0, (hipStream_t)stream, x, table, workspace, temp, p_code, idx, out, n, D, V, n_ct, ks4n)
         // 4 waves (one per SIMD) with all of a wave's code tiles in registers.  Measured at V = 512 (us per call incl. the pack

@@ -68,6 +68,19 @@ class BaseEmbedding(nn.Module):
             return proj_attr
         return 0
 
+    def _table_cached(self, learnable):
+        """(table, its MFMA-order copy or None) of frozen-weight inference: built once per VERSION of the tensors the table is
+        made of (in-place updates -- an optimiser step, load_state_dict -- bump the version counters), not on every lookup."""
+        srcs = [learnable] + ([self.phn_attr.weight, self.proj_attr.weight, self.proj_attr.bias] if self.use_phn_attr else [])
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in srcs)
+        ent = self.__dict__.get('_table_cache')
+        if ent is None or ent[0] != key:
+            table = self._table(learnable)
+            packed = ops.vq_pack_table(table) if ops.vq_mfma_shape(table.shape[1], table.shape[0]) else None
+            ent = (key, table, packed)
+            self.__dict__['_table_cache'] = ent
+        return ent[1], ent[2]
+
     def _table(self, learnable):
         """cat[learnable, proj_attr(phn_attr.weight)] built on device.   ref: src/embed.py:87-94,109-112"""
         if self.training and torch.is_grad_enabled():
@@ -112,12 +125,18 @@ class L2Embedding(BaseEmbedding):
 
     def inference(self, txt):
         """token ids (B,L) -> vectors (B,L,latent_dim)                     ref: src/embed.py:96-103"""
-        return self._lookup(self._table(self.learnable_table), txt)
+        if self.training and torch.is_grad_enabled():
+            return self._lookup(self._table(self.learnable_table), txt)
+        return self._lookup(self._table_cached(self.learnable_table)[0], txt)
 
     def forward(self, enc_embs, first_n_real_mel=0):
         """enc_embs (B,S,D) -> (p_code (B,S,V), new_latent (B,S,D), 0, 0).  ref: src/embed.py:105-147.
         `first_n_real_mel` only detaches the table for part of the batch (forward values unchanged)."""
-        table = self._table(self.learnable_table)
+        packed = None
+        if self.training and torch.is_grad_enabled():
+            table = self._table(self.learnable_table)
+        else:
+            table, packed = self._table_cached(self.learnable_table)
         if self.training and torch.is_grad_enabled():
             # differentiable: straight-through gradient to enc_embs, p_code -> CTC gradient to enc_embs and (for the first
             # `first_n_real_mel` utterances, or all of them) to the table, scatter-add of the picked rows      :115-145
@@ -125,7 +144,7 @@ class L2Embedding(BaseEmbedding):
             p_code, new_latent, idx = AG.vq_l2(enc_embs, table, self.temp, first_n_real_mel * S if first_n_real_mel > 0 else None,
                                                st_onehot=not self.stop_grad)                                    # :132-138
         else:
-            p_code, idx, new_latent = ops.vq_l2(enc_embs.contiguous(), table, self.temp)
+            p_code, idx, new_latent = ops.vq_l2(enc_embs.contiguous(), table, self.temp, packed=packed)
         self.last_idx = idx
         if self.training and self.skip_prob > 0 and np.random.rand() < self.skip_prob:
             new_latent = enc_embs                        # skip connection, only when training (:140-142; the draw comes after the

@@ -352,8 +352,22 @@ def gather_rows(table, idx):
     return out
 
 
-def vq_l2(x, table, temp, scalar_kernel=False):
-    """scalar_kernel=True (tests): the LDS-table kernel instead of the matrix-core one"""
+def vq_mfma_shape(D, V):
+    """shapes the matrix-core nearest-code search takes (st_vq_pack_table / st_vq_l2_packed_fwd)"""
+    return D <= 64 and D % 4 == 0 and V <= 1024
+
+
+def vq_pack_table(table):
+    """MFMA-order copy of a (V, D) code table: made once per table version (embed.L2Embedding caches it), not per lookup"""
+    lib = _lib.load()
+    V, D = table.shape
+    packed = torch.empty(int(lib.st_vq_l2_workspace_floats(D, V)), device=table.device, dtype=torch.float32)
+    check(lib.st_vq_pack_table(_p(table), _p(packed), D, V, stream_handle()), 'st_vq_pack_table')
+    return packed
+
+
+def vq_l2(x, table, temp, scalar_kernel=False, packed=None):
+    """scalar_kernel=True (tests): the LDS-table kernel instead of the matrix-core one; packed: vq_pack_table(table)"""
     lib = _lib.load()
     lead, D = x.shape[:-1], x.shape[-1]
     V = table.shape[0]
@@ -361,6 +375,10 @@ def vq_l2(x, table, temp, scalar_kernel=False):
     p = torch.empty(tuple(lead) + (V,), device=x.device, dtype=torch.float32)
     idx = torch.empty(tuple(lead), device=x.device, dtype=torch.int64)
     out = torch.empty_like(x)
+    if packed is not None and not scalar_kernel:
+        check(lib.st_vq_l2_packed_fwd(_p(x), _p(table), _p(packed), _p(temp), _p(p), _p(idx, torch.int64), _p(out), n, D, V,
+                                      stream_handle()), 'st_vq_l2_packed_fwd')
+        return p, idx, out
     ws = None if scalar_kernel else torch.empty(int(lib.st_vq_l2_workspace_floats(D, V)), device=x.device, dtype=torch.float32)
     check(lib.st_vq_l2_fwd(_p(x), _p(table), _p(temp), _p(p), _p(idx, torch.int64), _p(out), _p(ws), n, D, V, stream_handle()),
           'st_vq_l2_fwd')

@@ -141,3 +141,60 @@ class GraphedTacotron2:
             self.draw_masks()
         self.graph.launch()
         return self.outputs
+
+
+class GraphedSpeechToText:
+    """VQVAE.speech_to_text of evaluation (src/vqvae.py:106-141: CTC speech encoder -> codebook lookup -> run-length merge of the
+    unpaired part) captured into ONE hipGraph for fixed shapes: the ~25 launches of the speech encoder (6 conv layers, 2 BiLSTM
+    layers step by step), the nearest-code search on the cached MFMA-order table and the segmented-mean kernel replay with a
+    single graph launch.  The only host work left is the reference's own data-dependent decision (an all-blank utterance drops
+    the unpaired part; the longest merged sequence fixes the output length): one small device -> host copy of the lengths AFTER
+    the replay.  Same static-buffer discipline as GraphedDecoder."""
+
+    def __init__(self, model, B_pair, T, device, B_unpair=0):
+        self.model = model
+        self.Bp, self.Bu = int(B_pair), int(B_unpair)
+        self.mel = torch.zeros(self.Bp + self.Bu, int(T), model.n_mels, device=device, dtype=torch.float32)
+        self.graph = None
+        self.outputs = None
+
+    def _run(self):
+        from . import autograd as AG
+        m = self.model
+        with torch.no_grad():
+            enc = m.asr(self.mel)
+            p_code, quantized, _, _ = m.codebook(enc, 0)
+            merged = None
+            if self.Bu > 0:
+                merged = AG._MeanForwardFn.apply(p_code[self.Bp:].contiguous(), quantized[self.Bp:].contiguous(), m.max_frames_per_phn)
+        return p_code, quantized, merged
+
+    def capture(self):
+        assert not self.model.training, 'graph replay is for eval-mode inference'
+        self.graph = ops.Graph()
+        with self.graph.memory():
+            for _ in range(2):
+                self._run()
+                torch.cuda.synchronize()
+        with self.graph.capture(), self.graph.memory():
+            self.outputs = self._run()
+        return self
+
+    def __call__(self, paired_mel=None, unpaired_mel=None):
+        """-> the tuple VQVAE.speech_to_text returns (views of buffers the next call overwrites)"""
+        if self.graph is None:
+            self.capture()
+        if paired_mel is not None:
+            self.mel[:self.Bp, :paired_mel.shape[1]].copy_(paired_mel)
+        if unpaired_mel is not None:
+            self.mel[self.Bp:].zero_()
+            self.mel[self.Bp:, :unpaired_mel.shape[1]].copy_(unpaired_mel)
+        self.graph.launch()
+        p_code, quantized, merged = self.outputs
+        if self.Bu == 0:
+            return p_code, quantized, None, None, None, None, 0
+        out, lens = merged
+        lens_h = lens.cpu()
+        if int(lens_h.min()) == 0:                      # an all-blank utterance: the unpaired speech is ignored (:129-133)
+            return p_code[:self.Bp], quantized[:self.Bp], p_code[self.Bp:], None, None, None, 0
+        return (p_code[:self.Bp], quantized[:self.Bp], p_code[self.Bp:], out[:, :int(lens_h.max())], lens.long(), None, 0)

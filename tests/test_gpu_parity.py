@@ -903,3 +903,59 @@ def test_speech_to_text_c3_shape_against_oracle(dev):
         assert ul is None
     else:
         assert np.array_equal(ulen.cpu().numpy(), mf[1]) and maxdiff(ul, torch.from_numpy(mf[0])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ round 3: packed-table cache, graphed speech_to_text
+@pytest.mark.parametrize('V', [43, 512])
+def test_vq_packed_table_search_is_bit_identical_and_cache_follows_the_weights(dev, V):
+    """st_vq_pack_table + st_vq_l2_packed_fwd (table packed once per version) == st_vq_l2_fwd (packed per call) bit for bit;
+    L2Embedding's cache is rebuilt when the table's parameter changes in place (an optimiser step, load_state_dict)."""
+    from semi_tts_amd import ops
+    from semi_tts_amd.embed import L2Embedding
+    g = torch.Generator().manual_seed(11)
+    table = torch.randn(V, 64, generator=g).to(dev)
+    x = torch.randn(7, 129, 64, generator=g).to(dev)
+    temp = torch.tensor([1.0], device=dev)
+    p0, i0, o0 = ops.vq_l2(x, table, temp)
+    p1, i1, o1 = ops.vq_l2(x, table, temp, packed=ops.vq_pack_table(table))
+    assert torch.equal(i0, i1) and torch.equal(p0, p1) and torch.equal(o0, o1)
+    cb = L2Embedding(V, False, 'normal', 64, 0, 0, 1.0, 0, True).to(dev).eval()
+    with torch.no_grad():
+        cb.learnable_table.copy_(table)
+        pa, oa, _, _ = cb(x)
+        ia = cb.last_idx.clone()
+        ent = cb.__dict__['_table_cache']
+        cb(x)
+        assert cb.__dict__['_table_cache'] is ent                       # same weights: the packed table is reused
+        assert torch.equal(ia, i0) and torch.equal(pa, p0)
+        cb.learnable_table.mul_(-1.0)                                   # in-place update -> new version -> new table
+        pb, ob, _, _ = cb(x)
+        assert cb.__dict__['_table_cache'] is not ent
+        p2, i2, o2 = ops.vq_l2(x, -table, temp)
+        assert torch.equal(cb.last_idx, i2) and torch.equal(pb, p2) and torch.equal(ob, o2)
+
+
+def test_graphed_speech_to_text_equals_eager(dev):
+    """runtime.GraphedSpeechToText (speech encoder -> codebook -> run-length merge as ONE hipGraph) returns what
+    VQVAE.speech_to_text returns, bit for bit, also on a replay with new inputs"""
+    import yaml, os
+    from semi_tts_amd.runtime import GraphedSpeechToText
+    from semi_tts_amd.synthetic import load_synthetic
+    from semi_tts_amd.vqvae import VQVAE
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, 'config', 'semi-single-spkr-paired-data.yaml')))['model']
+    cfg['codebook'].update(phn_attr_pth='', proj_attr=None)
+    m = VQVAE(80, 1025, 43, 109, **cfg)
+    load_synthetic(m, 77)
+    m = m.to(dev).eval()
+    gs = GraphedSpeechToText(m, 5, 258, dev, B_unpair=3).capture()
+    for seed in (5, 6):
+        g = torch.Generator().manual_seed(seed)
+        mel, umel = torch.rand(5, 258, 80, generator=g).to(dev), torch.rand(3, 200, 80, generator=g).to(dev)
+        with torch.no_grad():
+            ref = m.speech_to_text(mel, umel)
+        got = gs(mel, umel)
+        for name, a, b in zip(('pair_prob', 'pair_latent', 'unpair_prob', 'unpair_latent', 'unpair_len'), got, ref):
+            assert (a is None) == (b is None), name
+            if a is not None:
+                assert torch.equal(a, b), name

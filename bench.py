@@ -72,55 +72,62 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(m, txt_mem, spk):
-    """The CPU reference of the same workload on this box's host cores: the decode path assembled from the torch.nn modules
-    the reference itself is made of (nn.LSTMCell, nn.Linear, nn.Conv1d: oracle/nn_baseline.py, the same ATen kernels the
-    reference would hit).  B=32 GEMMs stop scaling long before a 128-core host is full (and oversubscribed thread pools get
-    pathologically slow), so a 3-step probe picks the thread count first; the full passes run at the fastest setting only."""
+def cpu_timed(short_fn, full_fn, units_per_pass, unit, kind, sample, max_passes=3, budget=(25.0, 45.0)):
+    """CPU baseline protocol shared by every workload: B=32 GEMMs stop scaling long before a 128-core host is full (and
+    oversubscribed thread pools get pathologically slow), so `short_fn()` (a few per cent of a pass) is timed at 8 ... all cores
+    first; `full_fn(i)` (one full pass of the workload) then runs 1 warm-up + up to `max_passes` timed passes at the two fastest
+    settings, and the better median is the baseline.  Bounded: the probe stops after 20 s, the passes after `budget` seconds."""
     import numpy as np
     import torch
-    from oracle import nn_baseline as NB
-    from helpers import full_hp
-    W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-    hp = full_hp(0.5)
-    mem, s = txt_mem.cpu(), spk.cpu()
     cores = host_cores()
-    ref = NB.NNDecoder(W, hp)
     probe = []
     t_start = time.perf_counter()
-    with torch.no_grad():
+    with torch.no_grad() if kind != 'nn_modules_autograd' else torch.enable_grad():
         for threads in sorted({t for t in (8, 16, 32, 64, cores) if t <= cores}):
             torch.set_num_threads(threads)
-            ref(mem, 2 * R, s)                                     # warm-up of the thread pool at this size
+            short_fn()                                             # warm-up of the thread pool at this size
             t0 = time.perf_counter()
-            ref(mem, 3 * R, s)
-            probe.append({'threads': threads, 'ms_per_decode_step': round((time.perf_counter() - t0) / 3 * 1e3, 3)})
+            short_fn()
+            probe.append({'threads': threads, 'probe_ms': round((time.perf_counter() - t0) * 1e3, 3)})
             if time.perf_counter() - t_start > 20.0:
                 break
-        # full passes at the two fastest settings of the probe (a 3-step probe is noisy on a multi-socket host); the better
-        # median is the baseline
-        cand = [r['threads'] for r in sorted(probe, key=lambda r: r['ms_per_decode_step'])[:2]]
+        cand = [r['threads'] for r in sorted(probe, key=lambda r: r['probe_ms'])[:2]]
         full = {}
         for th in cand:
             torch.set_num_threads(th)
             times = []
-            for i in range(4):                                      # 1 warm-up + up to 3 timed passes per setting
+            for i in range(1 + max_passes):
                 t0 = time.perf_counter()
-                ref(mem, T, s, seed=i)
+                full_fn(i)
                 times.append(time.perf_counter() - t0)
-                if time.perf_counter() - t_start > (25.0 if th == cand[0] else 45.0) and len(times) >= 2:
+                if time.perf_counter() - t_start > (budget[0] if th == cand[0] else budget[1]) and len(times) >= 2:
                     break
             full[th] = times
         best = min(full, key=lambda th: float(np.median(full[th][1:])))
         times = full[best]
     t = float(np.median(times[1:]))
-    return {'value': B * T / t, 'unit': 'mel-frames/s', 'cores': best, 'kind': 'port', 'host_cores': cores,
+    return {'value': units_per_pass / t, 'unit': unit, 'cores': best, 'kind': kind.replace('_autograd', ''), 'host_cores': cores,
             'seconds_per_pass': t, 'thread_probe': probe,
             'full_pass_seconds': {str(k): [round(x, 4) for x in v] for k, v in full.items()},
-            'sample': '%d full passes of Decoder.forward (B=%d, %d steps, L=%d, prenet dropout 0.5) after 1 warm-up, median; '
-                      'the decode loop assembled from the torch.nn modules the reference is made of (nn.LSTMCell / nn.Linear / '
-                      'nn.Conv1d, oracle/nn_baseline.py), torch CPU fp32, %d threads = the better of the two fastest settings of the 3-step '
-                      'probe in `thread_probe` (host has %d cores)' % (len(times) - 1, B, STEPS, L, best, cores)}
+            'sample': sample + '; %d timed pass(es) after 1 warm-up, median; torch CPU fp32, %d threads = the better of the two fastest '
+                               'settings of the probe in `thread_probe` (host has %d cores)' % (len(times) - 1, best, cores)}
+
+
+def cpu_baseline(m, txt_mem, spk, frames=None):
+    """The CPU reference of the decode workload on this box's host cores: the decode path assembled from the torch.nn modules
+    the reference itself is made of (nn.LSTMCell, nn.Linear, nn.Conv1d: oracle/nn_baseline.py, the same ATen kernels the
+    reference would hit)."""
+    from oracle import nn_baseline as NB
+    from helpers import full_hp
+    W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    mem, s = txt_mem.cpu(), spk.cpu()
+    ref = NB.NNDecoder(W, full_hp(0.5))
+    frames = frames or T
+    Bn, Ln = mem.shape[0], mem.shape[1]
+    return cpu_timed(lambda: ref(mem, 3 * R, s), lambda i: ref(mem, frames, s, seed=i), Bn * frames, 'mel-frames/s', 'nn_modules',
+                     'full passes of Decoder.forward (B=%d, %d steps, L=%d, prenet dropout 0.5); the decode loop assembled from the '
+                     'torch.nn modules the reference is made of (nn.LSTMCell / nn.Linear / nn.Conv1d, oracle/nn_baseline.py); probe = 3 '
+                     'decode steps' % (Bn, frames // R, Ln), max_passes=3 if Bn * frames <= 32 * 300 else 2)
 
 
 def free_port():
@@ -381,8 +388,8 @@ def bench_decode(args, rk):
         'us_per_decode_step': round(us_step, 2),
         'roofline': roof,
     }
-    if not args.no_cpu_baseline and args.workload == 'c2':
-        res['cpu_baseline'] = cpu_baseline(m, memory, spk)
+    if not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(m, memory, spk, frames=T)
     try:
         res['device'] = ops.device_info()
     except Exception:
@@ -437,7 +444,18 @@ def bench_vq(args, rk):
             head = row
     if rk.rank != 0:
         return None
-    return {'metric': 'VQ vectors/sec (L2Embedding.forward nearest-code search)', 'value': head['vectors_per_s'] * rk.world,
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the reference's own formulation on the host: neg_batch_l2 (expanded squares) -> softmax -> argmax -> embedding lookup
+        # (src/embed.py:105-147,208-213; the codebook has no nn module beyond the table, so this is the functional restatement)
+        from oracle import vq_oracle as VQ
+        gc = torch.Generator().manual_seed(7)
+        xc, tc = torch.randn(32, 129, 64, generator=gc), torch.randn(512, 64, generator=gc)
+        Wc = {'learnable_table': tc, 'temp': torch.ones(1)}
+        cpu = cpu_timed(lambda: VQ.l2_forward(Wc, xc[:4]), lambda i: [VQ.l2_forward(Wc, xc) for _ in range(20)], 20 * 32 * 129,
+                        'vectors/s', 'port', '20 calls of L2Embedding.forward on (32,129,64) latents, V=512 (oracle/vq_oracle.py: the '
+                        'reference\'s torch formulation); probe = 4 utterances', max_passes=3)
+    res = {'metric': 'VQ vectors/sec (L2Embedding.forward nearest-code search)', 'value': head['vectors_per_s'] * rk.world,
             'unit': 'vectors/s', 'n_gpus': rk.world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': head['us_per_launch'] * 1e-3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
@@ -446,6 +464,9 @@ def bench_vq(args, rk):
                          'frac': head['frac_of_hbm_peak'], 'traffic': None,
                          'algorithmic_bytes_per_launch': head['algorithmic_bytes'], 'avg_launch_us': head['us_per_launch']},
             'cases': rows}
+    if cpu is not None:
+        res['cpu_baseline'] = cpu
+    return res
 
 
 # ===================================================================================== training (C4)
@@ -483,6 +504,9 @@ def bench_train(args, rk):
         parallel.sync_batchnorm(True)
     if rk.rank != 0:
         return None
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline_train(tr, batch, config)
     ms = {k: v / args.steps * 1e3 for k, v in variants.items()}
     frames = rk.world * batch[2].shape[0] * batch[2].shape[1] * args.steps
     n_par = sum(p.numel() for p in tr.model.parameters() if p.requires_grad)
@@ -498,7 +522,39 @@ def bench_train(args, rk):
             'ms_syncbn': round(ms['full'] - ms['no_syncbn'], 3) if 'no_syncbn' in ms else 0.0,
             'ms_variants': {k: round(v, 3) for k, v in ms.items()},
             'collectives_per_step': counts,
-            'last': {k: last[k] for k in ('loss', 'grad_norm')}, 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+            # whole-step roofline: forward 132 GFLOP per C2 batch, training ~3x that, against the fp32 matrix peak
+            'roofline': {'bound': 'mfma', 'kernel': 'whole training step (1.6k launches; the largest share is the weight-gradient GEMM tn_kernel)',
+                         'achieved': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None},
+            'last': {k: last[k] for k in ('loss', 'grad_norm')}, 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            **({'cpu_baseline': cpu} if cpu is not None else {})}
+
+
+def cpu_baseline_train(tr, batch, config):
+    """the paired TTS training step on the host: forward (teacher forcing) + freq_loss + backward + clip + Adam through the
+    torch.nn assembly of Tacotron2 (oracle/nn_baseline.py) and torch autograd -- what the reference's step executes on CPU"""
+    import torch
+    from oracle import nn_baseline as NB
+    from oracle import tts_oracle as O
+    text, sid, mel, linear = batch
+    with torch.no_grad():
+        txt_embed = tr.model.codebook.inference(text).cpu()
+        spk = tr.model.embed_speakers(sid).cpu()
+    W = {k[4:]: v.detach().cpu() for k, v in tr.model.state_dict().items() if k.startswith('tts.')}
+    hp = dict(config['model']['decoder']['decoder'])
+    hp['n_mels'] = tr.n_mels
+    net = NB.NNTacotron2(W, hp).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    mel_c, lin_c = mel.cpu(), linear.cpu()
+    sr = config['data']['audio']['sample_rate']
+    fl = lambda p, l: O.freq_loss(p, l, sr, tr.n_mels)
+    short = lambda: NB.train_step(net, opt, txt_embed[:4], spk[:4], mel_c[:4, :24], lin_c[:4, :24], fl)
+    full = lambda i: NB.train_step(net, opt, txt_embed, spk, mel_c, lin_c, fl)
+    Bn, Tn = mel_c.shape[0], mel_c.shape[1]
+    return cpu_timed(short, full, Bn * Tn, 'mel-frames/s', 'nn_modules_autograd',
+                     'full training steps (B=%d, %d frames: teacher-forced forward + freq_loss + backward + clip 5.0 + Adam) of the torch.nn '
+                     'assembly of Tacotron2 (oracle/nn_baseline.py) under torch autograd; probe = one step at B=4, 24 frames' % (Bn, Tn),
+                     max_passes=2, budget=(30.0, 50.0))
 
 
 def main():

@@ -622,10 +622,13 @@ int st_adain_bwd(const float* dadapt, long da_step_stride, int da_ld, const floa
  * paras.actual_len = False): lp = log(prob + eps), targets = the non-zero tokens of text (B, L) in order, every one of the T
  * frames counts, blank = 0, loss = mean_b(nll_b / max(S_b, 1)).  prob (B, T, V) posteriors over the codebook.  One call gives the
  * loss (device scalar) and, when dprob != NULL, d loss / d prob (the backward scales it by the incoming scalar: st_scale_by).
- * ws: st_ctc_workspace_floats(B, T) floats.  Transcripts of up to 127 tokens. */
+ * ws: st_ctc_workspace_floats(B, T) floats.  Transcripts of up to 127 tokens, at most 10240 classes.
+ * log_input != 0: `prob` already holds log-probabilities (ASRPostnet's log_softmax, src/asr.py:80; compute_ctcloss(..., apply_log=False),
+ * bin/train_vqvae.py:212) and the gradient is with respect to them; eps is ignored.
+ * A token outside [0, V) makes that utterance's loss and gradient NaN (torch raises; the device cannot). */
 size_t st_ctc_workspace_floats(int B, int T);
 int st_ctc_loss(const float* prob, const int64_t* text, float eps, float* loss, float* dprob, float* ws,
-                int B, int T, int V, int L, void* stream);
+                int B, int T, int V, int L, int log_input, void* stream);
 /* ------------------------------------------------------------------ trainer loss
  * loss = w_all*crit(pred,label) + w_low*crit(low n_low bins) + w_diff*crit(first differences along T), crit = MSE or
  * (l1 != 0) mean absolute error; writes the scalar to *loss and d loss / d pred to dpred (B,T,D).  ws: 256 floats.

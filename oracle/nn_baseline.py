@@ -98,3 +98,140 @@ class NNDecoder(nn.Module):
             stops.append(self.gate(y).repeat(1, self.r))                                      # :287
             dec_in = self.prenet(mel)                                                         # :192
         return torch.cat(mels, dim=1), torch.stack(aligns, dim=1), torch.cat(stops, dim=1)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Whole Tacotron2.forward and the paired TTS training step from stock torch.nn modules (round 3: CPU baselines of the secondary
+# bench lines -- BASELINE.md section 3, regions b-d).  Same rule as above: the ATen kernels the reference would hit.
+def _copy(dst: nn.Module, W: Dict[str, Tensor], prefix: str) -> nn.Module:
+    sd = dst.state_dict()
+    for k in sd:
+        if k.endswith('num_batches_tracked'):
+            continue
+        sd[k].copy_(W[prefix + k])
+    return dst
+
+
+class NNTacotron2(nn.Module):
+    """src/tts.py:12-51 with spkr_embed_mode 'adaIN': Encoder (3 x [Conv1d k5 -> BatchNorm1d -> ReLU] -> BiLSTM, src/module.py:410-462),
+    the decoder above (free running) or its teacher-forced form (src/module.py:140-214 with tf_rate = 1), CBHG(K = 8) + Linear
+    (src/module.py:558-622, src/tts.py:29-34)."""
+
+    def __init__(self, W: Dict[str, Tensor], hp: dict):
+        super().__init__()
+        self.hp = hp
+        self.enc_convs, self.enc_bns = nn.ModuleList(), nn.ModuleList()
+        i = 0
+        while ('encoder.convs.%d.0.conv.weight' % i) in W:
+            w = W['encoder.convs.%d.0.conv.weight' % i]
+            self.enc_convs.append(_copy(nn.Conv1d(w.shape[1], w.shape[0], w.shape[2], padding=(w.shape[2] - 1) // 2), W,
+                                        'encoder.convs.%d.0.conv.' % i))
+            self.enc_bns.append(_copy(nn.BatchNorm1d(w.shape[0]), W, 'encoder.convs.%d.1.' % i))
+            i += 1
+        n_layers = 1
+        while ('encoder.lstm.weight_ih_l%d' % n_layers) in W:
+            n_layers += 1
+        w_ih = W['encoder.lstm.weight_ih_l0']
+        self.enc_lstm = _copy(nn.LSTM(w_ih.shape[1], w_ih.shape[0] // 4, n_layers, batch_first=True, bidirectional=True), W, 'encoder.lstm.')
+        self.decoder = NNDecoder(W, hp)
+        self.q_drop, self.d_drop = hp.get('query_dropout', 0.0), hp.get('dec_dropout', 0.0)
+        p = 'postnet.0.'
+        self.banks, self.bank_bns = nn.ModuleList(), nn.ModuleList()
+        k = 0
+        while (p + 'conv1d_banks.%d.conv1d.weight' % k) in W:
+            w = W[p + 'conv1d_banks.%d.conv1d.weight' % k]
+            self.banks.append(_copy(nn.Conv1d(w.shape[1], w.shape[0], w.shape[2], padding=w.shape[2] // 2, bias=False), W,
+                                    p + 'conv1d_banks.%d.conv1d.' % k))
+            self.bank_bns.append(_copy(nn.BatchNorm1d(w.shape[0], momentum=0.99, eps=1e-3), W, p + 'conv1d_banks.%d.bn.' % k))
+            k += 1
+        self.pool = nn.MaxPool1d(kernel_size=2, stride=1, padding=1)
+        self.projs, self.proj_bns = nn.ModuleList(), nn.ModuleList()
+        for j in range(2):
+            w = W[p + 'conv1d_projs.%d.conv1d.weight' % j]
+            self.projs.append(_copy(nn.Conv1d(w.shape[1], w.shape[0], 3, padding=1, bias=False), W, p + 'conv1d_projs.%d.conv1d.' % j))
+            self.proj_bns.append(_copy(nn.BatchNorm1d(w.shape[0], momentum=0.99, eps=1e-3), W, p + 'conv1d_projs.%d.bn.' % j))
+        self.pre_highway = _linear(W[p + 'pre_highway_proj.weight'])
+        self.hw_H, self.hw_T = nn.ModuleList(), nn.ModuleList()
+        j = 0
+        while (p + 'highways.%d.H.weight' % j) in W:
+            self.hw_H.append(_linear(W[p + 'highways.%d.H.weight' % j], W[p + 'highways.%d.H.bias' % j]))
+            self.hw_T.append(_linear(W[p + 'highways.%d.T.weight' % j], W[p + 'highways.%d.T.bias' % j]))
+            j += 1
+        g_ih = W[p + 'gru.weight_ih_l0']
+        self.gru = _copy(nn.GRU(g_ih.shape[1], g_ih.shape[0] // 3, 1, batch_first=True, bidirectional=True), W, p + 'gru.')
+        self.last = _linear(W['postnet.1.weight'], W['postnet.1.bias'])
+
+    def encode(self, txt_embed: Tensor) -> Tensor:
+        x = txt_embed.transpose(1, 2)                                           # :446
+        for conv, bn in zip(self.enc_convs, self.enc_bns):
+            x = F.relu(bn(conv(x)))                                             # :448-452 (dropout p = 0 in every shipped config)
+        y, _ = self.enc_lstm(x.transpose(1, 2))                                 # :458-460
+        return y
+
+    def postnet(self, mel: Tensor) -> Tensor:
+        T = mel.shape[1]
+        x = mel.transpose(1, 2)                                                 # :594
+        x = torch.cat([bn(F.relu(conv(x)))[:, :, :T] for conv, bn in zip(self.banks, self.bank_bns)], dim=1)    # :597-598
+        x = self.pool(x)[:, :, :T]                                              # :600
+        x = self.proj_bns[0](F.relu(self.projs[0](x)))                          # :602-603 (conv -> ReLU -> BN; the last one without ReLU)
+        x = self.proj_bns[1](self.projs[1](x))
+        x = self.pre_highway(x.transpose(1, 2)) + mel                           # :607-609
+        for H, Tg in zip(self.hw_H, self.hw_T):                                 # :551-554
+            t = torch.sigmoid(Tg(x))
+            x = F.relu(H(x)) * t + x * (1.0 - t)
+        y, _ = self.gru(x)                                                      # :617
+        return self.last(y)                                                     # src/tts.py:34
+
+    def forward(self, txt_embed: Tensor, frames: int, spkr_embed: Tensor, seed: int = 0):
+        """free-running inference: (mel, linear, align, stop)                  src/tts.py:36-51"""
+        mel, align, stop = self.decoder(self.encode(txt_embed), frames, spkr_embed, seed=seed)
+        return mel, self.postnet(mel), align, stop
+
+    def forward_teacher(self, txt_embed: Tensor, teacher: Tensor, spkr_embed: Tensor):
+        """tf_rate = 1 (every shipped config): the prenet over the whole teacher at once, every step fed the previous teacher
+        group; hidden-state dropouts active in training mode                    src/module.py:166-206"""
+        d = self.decoder
+        memory = self.encode(txt_embed)
+        B, L, E = memory.shape
+        r, n_mels = d.r, d.n_mels
+        steps = teacher.shape[1] // r
+        Q, D = d.query_rnn.hidden_size, d.dec_rnn.hidden_size
+        z = lambda *s: memory.new_zeros(*s)
+        h_q, c_q, h_d, c_d = z(B, Q), z(B, Q), z(B, D), z(B, D)
+        w, w_cum, ctx = z(B, L), z(B, L), z(B, E)
+        pm = d.memory_layer(memory)
+        tpre = d.prenet(teacher.reshape(B, steps, r * n_mels))                  # :178-179
+        dec_in = d.prenet(z(B, r * n_mels))
+        ada_s, ada_m = F.relu(d.ada_std(spkr_embed)), d.ada_mean(spkr_embed)
+        mels, aligns, stops = [], [], []
+        for t in range(steps):
+            h_q, c_q = d.query_rnn(torch.cat([dec_in, ctx], dim=-1), (h_q, c_q))
+            h_q = F.dropout(h_q, self.q_drop, self.training)                    # :230
+            pq = d.query_layer(h_q).unsqueeze(1)
+            loc = d.loc_linear(d.loc_conv(torch.stack([w, w_cum], dim=1)).transpose(1, 2))
+            e = d.v(torch.tanh(pq + loc + pm)).squeeze(-1)
+            w = F.softmax(e, dim=1)
+            ctx = torch.bmm(w.unsqueeze(1), memory).squeeze(1)
+            w_cum = w_cum + w
+            h_d, c_d = d.dec_rnn(torch.cat([ctx, ada_s * (h_q - ada_m)], dim=-1), (h_d, c_d))
+            h_d = F.dropout(h_d, self.d_drop, self.training)                    # :279
+            y = torch.cat([h_d, ctx], dim=-1)
+            mels.append(d.proj(y).view(B, r, n_mels))
+            aligns.append(w)
+            stops.append(d.gate(y).repeat(1, r))
+            dec_in = tpre[:, t]                                                 # :200-203 (teacher frame group t feeds step t + 1)
+        mel = torch.cat(mels, dim=1)
+        return mel, self.postnet(mel), torch.stack(aligns, dim=1), torch.cat(stops, dim=1)
+
+
+def train_step(model: 'NNTacotron2', opt: torch.optim.Optimizer, txt_embed: Tensor, spkr_embed: Tensor, mel: Tensor, linear: Tensor,
+               freq_loss, clip: float = 5.0):
+    """forward + freq_loss(mel) + freq_loss(linear) + backward + clip_grad_norm_(5.0) + optimizer step
+    (bin/train_vqvae.py:219-223,270; src/solver.py:138-151), the codebook lookup and speaker table left out (negligible)"""
+    opt.zero_grad()
+    mel_p, lin_p, _, _ = model.forward_teacher(txt_embed, mel, spkr_embed)
+    loss = freq_loss(mel_p, mel) + freq_loss(lin_p, linear)
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+    opt.step()
+    return float(loss.detach()), float(gn)

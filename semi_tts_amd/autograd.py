@@ -348,8 +348,8 @@ class _CtcLossFn(Function):
     gradient by the incoming scalar (like freq_loss)."""
 
     @staticmethod
-    def forward(ctx, prob, text, eps):
-        loss, dprob = ops.ctc_loss(prob.contiguous(), text.contiguous(), eps, want_grad=True)
+    def forward(ctx, prob, text, eps, log_input=False):
+        loss, dprob = ops.ctc_loss(prob.contiguous(), text.contiguous(), eps, want_grad=True, log_input=log_input)
         ctx.save_for_backward(dprob)
         return loss
 
@@ -360,12 +360,13 @@ class _CtcLossFn(Function):
         out = torch.empty_like(dprob)
         _lib.check(_lib.load().st_scale_by(ops._p(dprob), ops._p(dloss.contiguous()), ops._p(out), dprob.numel(), ops.stream_handle()),
                    'st_scale_by')
-        return out, None, None
+        return out, None, None, None
 
 
-def ctc_loss(prob, text, eps=1e-10):
-    """prob (B, T, V) posteriors over the codebook (index 0 = blank), text (B, L) int64 (zeros = padding)"""
-    return _CtcLossFn.apply(prob, text, eps)
+def ctc_loss(prob, text, eps=1e-10, apply_log=True):
+    """prob (B, T, V) posteriors over the codebook (index 0 = blank), text (B, L) int64 (zeros = padding);
+    apply_log=False: prob holds log-probabilities already (compute_ctcloss(..., apply_log=False), bin/train_vqvae.py:430-434)"""
+    return _CtcLossFn.apply(prob, text, eps, not apply_log)
 
 
 # --------------------------------------------------------------------------------------------- decoder loop

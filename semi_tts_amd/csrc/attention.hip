@@ -290,6 +290,10 @@ extern "C" int st_attn_fin_split_fwd(const float* pq, const float* s_buf, const 
     ST_CHECK_ARG(parts >= 2 && parts <= 64, "st_attn_fin_split_fwd: parts=%d (2..64)", parts);
     const int Lp = (L + parts - 1) / parts;
     ST_CHECK_ARG(Lp <= 512, "st_attn_fin_split_fwd: %d positions per part (> 512): use more parts", Lp);
+    // ceil(L / parts) positions per part can leave trailing parts EMPTY (L = 9, parts = 4: 3 + 3 + 3 + 0); an empty part would
+    // prefetch row L of its utterance -- the next utterance's, or one row past the end of s_buf for the last one.  Only the parts
+    // that hold positions are launched and combined (the workspace is sized for the requested count, which is never smaller).
+    parts = (L + Lp - 1) / Lp;
     ST_CHECK_ARG(st_aligned16(pq) && st_aligned16(s_buf) && st_aligned16(memory) && st_aligned16(v) && st_aligned16(workspace),
                  "st_attn_fin_split_fwd: operands must be 16-byte aligned");
     AsArgs s;

@@ -71,13 +71,15 @@ __device__ __forceinline__ float ctc_lse3(float a, float b, float c) {
     return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
 
+// log_input != 0: `prob` already holds log-probabilities (ASRPostnet's log_softmax, compute_ctcloss(apply_log=False)); the gradient is
+// then taken with respect to them.  A token outside [0, V) poisons the utterance's loss and gradient with NaN (torch raises).
 __global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, const int64_t* text, float eps, float* nll_out,
-                                                          float* dprob, float* log_alpha, int B, int T, int V, int L) {
+                                                          float* dprob, float* log_alpha, int B, int T, int V, int L, int log_input) {
     extern __shared__ int ctc_dyn[];                 // cls_first[V]
     __shared__ int lab[CTC_NT], nxt[CTC_NT];
     __shared__ float st_a[2][CTC_NT], gam[2][CTC_NT];
     __shared__ float lpS[CTC_TC][CTC_NT];
-    __shared__ int S_s;
+    __shared__ int S_s, bad_s;
     __shared__ float nll_s;
     int* cls_first = ctc_dyn;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -85,8 +87,13 @@ __global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, con
     for (int c = tid; c < V; c += CTC_NT) cls_first[c] = -1;
     __syncthreads();
     if (tid == 0) {                                   // blank-extended target and, per label, the chain of the states that carry it
-        int S = 0;
-        for (int i = 0; i < L; ++i) { const int64_t tk = text[(size_t)b * L + i]; if (tk != 0) { lab[2 * S + 1] = (int)tk; ++S; } }
+        int S = 0, bad = 0;
+        for (int i = 0; i < L; ++i) {
+            int64_t tk = text[(size_t)b * L + i];
+            if (tk < 0 || tk >= V) { bad = 1; tk = 0; }            // never index cls_first / prob out of range
+            if (tk != 0) { lab[2 * S + 1] = (int)tk; ++S; }
+        }
+        bad_s = bad;
         for (int s2 = 0; s2 <= 2 * S; s2 += 2) lab[s2] = 0;
         for (int s2 = 0; s2 <= 2 * S; ++s2) nxt[s2] = -1;
         for (int s2 = 2 * S - 1; s2 >= 1; s2 -= 2) {   // odd states, descending: cls_first ends up as the FIRST occurrence
@@ -104,7 +111,10 @@ __global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, con
     const bool skip_b = on && tid + 2 < SP && lab[tid + 2] != 0 && lab[tid + 2] != my;   // beta may come from s + 2
     float* la = log_alpha + (size_t)b * T * CTC_NT;
     auto gather = [&](int t0, int nt, int dir) {      // lpS[i][s] = lp(t0 + dir * i, lab[s]) for i < nt
-        for (int i = 0; i < nt; ++i) lpS[i][tid] = on ? logf(pb[(size_t)(t0 + dir * i) * V + my] + eps) : -INFINITY;
+        for (int i = 0; i < nt; ++i) {
+            const float pv = on ? pb[(size_t)(t0 + dir * i) * V + my] : 0.0f;
+            lpS[i][tid] = on ? (log_input ? pv : logf(pv + eps)) : -INFINITY;
+        }
     };
     // ---- alpha
     int cur = 0;
@@ -134,14 +144,15 @@ __global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, con
         const float* pa = st_a[cur ^ 1];
         const float l1 = pa[SP - 1], l2 = SP >= 2 ? pa[SP - 2] : -INFINITY;
         const float m = fmaxf(l1, l2);
-        const float v = m == -INFINITY ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
+        float v = m == -INFINITY ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
+        if (bad_s) v = __builtin_nanf("");
         nll_s = v;
         nll_out[b] = v;
     }
     __syncthreads();
     const float nll = nll_s;
     if (!dprob) return;
-    const float gr = 1.0f / ((float)max(S, 1) * (float)B);
+    const float gr = bad_s ? __builtin_nanf("") : 1.0f / ((float)max(S, 1) * (float)B);
     // ---- beta, occupancies and the gradient
     cur = 0;
     for (int t1 = T - 1; t1 >= 0; t1 -= CTC_TC) {
@@ -175,9 +186,10 @@ __global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, con
                 float occ = 0.0f;
                 if (c == 0) occ = blank;
                 else for (int s2 = cls_first[c]; s2 >= 0; s2 = nxt[s2]) occ += gq[s2];
-                const float p = pb[(size_t)t * V + c] + eps;
                 // d loss / d lp = gr * (exp(lp) - occ);  lp = log(p + eps)  ->  d / d prob = that / (p + eps)
-                dprob[((size_t)b * T + t) * V + c] = gr * (p - occ) / p;
+                const float pin = pb[(size_t)t * V + c];
+                const float p = log_input ? expf(pin) : pin + eps;
+                dprob[((size_t)b * T + t) * V + c] = log_input ? gr * (p - occ) : gr * (p - occ) / p;
             }
             cur ^= 1;
         }
@@ -199,14 +211,16 @@ __global__ void ctc_loss_final_kernel(const float* nll, const int64_t* text, int
 extern "C" size_t st_ctc_workspace_floats(int B, int T) { return (size_t)B * T * CTC_NT + (size_t)B; }
 
 extern "C" int st_ctc_loss(const float* prob, const int64_t* text, float eps, float* loss, float* dprob, float* ws,
-                           int B, int T, int V, int L, void* stream) {
+                           int B, int T, int V, int L, int log_input, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(prob && text && loss && ws && B > 0 && T > 0 && V > 1 && L > 0, "st_ctc_loss: bad arguments");
     ST_CHECK_ARG(2 * L + 1 <= CTC_NT, "st_ctc_loss: transcripts of up to %d tokens (L=%d)", (CTC_NT - 1) / 2, L);
-    ST_CHECK_ARG((size_t)V * sizeof(int) <= 64 * 1024, "st_ctc_loss: V=%d too large", V);
+    // dynamic LDS (one int per class) on top of ~23 KiB of static LDS, within the 64 KiB a launch gets without raising
+    // hipFuncAttributeMaxDynamicSharedMemorySize: the argument check, not the launch, is what fails for a huge codebook
+    ST_CHECK_ARG((size_t)V * sizeof(int) <= 40 * 1024, "st_ctc_loss: V=%d too large (at most %d classes)", V, 40 * 1024 / 4);
     hipStream_t st = (hipStream_t)stream;
     float* nll = ws + (size_t)B * T * CTC_NT;
-    hipLaunchKernelGGL(ctc_loss_kernel, dim3(B), dim3(CTC_NT), (size_t)V * sizeof(int), st, prob, text, eps, nll, dprob, ws, B, T, V, L);
+    hipLaunchKernelGGL(ctc_loss_kernel, dim3(B), dim3(CTC_NT), (size_t)V * sizeof(int), st, prob, text, eps, nll, dprob, ws, B, T, V, L, log_input);
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(ctc_loss_final_kernel, dim3(1), dim3(1), 0, st, nll, text, B, L, loss);
     ST_LAUNCH_CHECK();

@@ -540,6 +540,7 @@ __global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const f32x4* w, con
 // that does not depend on pq at once and then wait for pq as {value, tag} granules (at_body<.., GRAN = true>): one kernel
 // boundary and the fin part's exposed first-load latency less per decode step.  All workgroups must be co-resident (the
 // launcher checks n_lin + B * parts against the compute units).
+
 template <int NB, int KW, int TRIP>
 __global__ __launch_bounds__(KW * 64) void pk_attnfin_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
                                                              const int B, const int N, const int tiles_a, const int n_lin,

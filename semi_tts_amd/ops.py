@@ -404,16 +404,16 @@ def rowscale_combine(a, alpha, x=None, r=None, beta=0.0, c=None):
     return out
 
 
-def ctc_loss(prob, text, eps, want_grad=True):
-    """-> (loss scalar tensor, d loss / d prob or None); see st_ctc_loss"""
+def ctc_loss(prob, text, eps, want_grad=True, log_input=False):
+    """-> (loss scalar tensor, d loss / d prob or None); see st_ctc_loss (log_input: prob holds log-probabilities)"""
     lib = _lib.load()
     B, T, V = prob.shape
     L = text.shape[1]
     loss = torch.empty((), device=prob.device, dtype=torch.float32)
     dprob = torch.empty_like(prob) if want_grad else None
     ws = torch.empty(int(lib.st_ctc_workspace_floats(B, T)), device=prob.device, dtype=torch.float32)
-    check(lib.st_ctc_loss(_p(prob), _p(text, torch.int64), float(eps), _p(loss), _p(dprob), _p(ws), B, T, V, L, stream_handle()),
-          'st_ctc_loss')
+    check(lib.st_ctc_loss(_p(prob), _p(text, torch.int64), float(eps), _p(loss), _p(dprob), _p(ws), B, T, V, L, 1 if log_input else 0,
+                          stream_handle()), 'st_ctc_loss')
     return loss, dprob
 
 

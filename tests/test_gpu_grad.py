@@ -778,3 +778,29 @@ def test_ctc_loss_against_torch(dev, B, T, V, L):
     # torch's own fp32 CPU kernel is 2.3e-4 from its float64 self at (4, 129, 43, 43): log-space recursions over 129 frames,
     # and d/dprob = (p - occupancy) / p amplifies at small p
     assert e_loss < 2e-6 and e_grad < (2e-5 if T < 20 else 1e-3)
+
+
+def test_ctc_loss_on_log_probabilities_and_invalid_tokens(dev):
+    """compute_ctcloss(..., apply_log=False) (bin/train_vqvae.py:430-434: ASRPostnet's log_softmax goes into CTCLoss as it is):
+    value and gradient w.r.t. the log-probabilities against torch float64; a token outside [0, V) gives NaN, not a wild read"""
+    import torch.nn.functional as F
+    from semi_tts_amd import autograd as AG
+    B, T, V, L = 3, 40, 43, 9
+    g = torch.Generator().manual_seed(21)
+    lp0 = torch.log_softmax(torch.randn(B, T, V, generator=g) * 2.0, dim=-1)
+    text = torch.randint(1, 6, (B, L), generator=g)
+    text[1, 3:] = 0
+    pd = lp0.to(dev).requires_grad_()
+    loss = AG.ctc_loss(pd, text.to(dev), 1e-10, apply_log=False)
+    (loss * 0.7).backward()
+    pr = lp0.double().requires_grad_()
+    ref = F.ctc_loss(pr.transpose(0, 1), text[text != 0], torch.full((B,), T, dtype=torch.long), (text != 0).sum(-1), blank=0,
+                     reduction='mean')
+    (ref * 0.7).backward()
+    e_loss, e_grad = abs(float(loss.detach()) - float(ref)) / max(1.0, abs(float(ref))), relerr(pd.grad, pr.grad)
+    report('ctc_loss_log_input', err_loss=e_loss, err_grad=e_grad)
+    assert e_loss < 2e-6 and e_grad < 2e-4
+    bad = text.clone()
+    bad[0, 1] = V + 5
+    l2 = AG.ctc_loss(lp0.to(dev), bad.to(dev), 1e-10, apply_log=False)
+    assert bool(torch.isnan(l2))

@@ -139,3 +139,28 @@ def test_nn_module_baseline_matches_reference_recording():
     assert (mel - A['mel']).abs().max() < 2e-5
     assert (align - A['align']).abs().max() < 1e-5
     assert (stop - A['stop']).abs().max() < 2e-5
+
+
+def test_nn_module_tacotron2_assembly_against_reference_and_oracle():
+    """oracle/nn_baseline.NNTacotron2 (the CPU baseline of the whole-forward and training bench lines): free-running inference
+    reproduces the outputs recorded from the real reference; the teacher-forced form equals the oracle"""
+    from oracle import nn_baseline as NB, tts_oracle as O
+    W, A, meta = load_golden('tts_tiny_infer_nodrop')
+    m = NB.NNTacotron2(W, dict(meta['hp'])).eval()
+    with torch.no_grad():
+        mel, lin, align, stop = m(A['txt_embed'], meta['teacher'], A['spkr_embed'])
+    assert (mel - A['mel']).abs().max() < 1e-6 and (lin - A['linear']).abs().max() < 1e-5 and (align - A['align']).abs().max() < 1e-6
+    W2, A2, meta2 = load_golden('tts_tiny_eval_tf')
+    hp2 = dict(meta2['hp'], prenet_dropout=0.0)
+    m2 = NB.NNTacotron2(W2, hp2).eval()
+    with torch.no_grad():
+        out = m2.forward_teacher(A2['txt_embed'], A2['teacher'], A2['spkr_embed'])
+        ref = O.tacotron2_forward(W2, A2['txt_embed'], A2['teacher'], A2['spkr_embed'], hp2, tf_rate=1.0)
+    assert all((a - b).abs().max() < 1e-5 for a, b in zip(out, ref))
+    # one optimisation step runs and moves the weights (the bench's cpu_baseline leg of --workload train)
+    m2.train()
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    lin_t = torch.rand_like(out[1])
+    loss, gn = NB.train_step(m2, opt, A2['txt_embed'], A2['spkr_embed'], A2['teacher'], lin_t,
+                             lambda p, l: O.freq_loss(p, l, 22050, hp2['n_mels']))
+    assert loss == loss and gn > 0

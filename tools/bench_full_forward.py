@@ -40,7 +40,28 @@ gt = GraphedTacotron2(m, B, L, T, dev)
 gt.txt.copy_(txt); gt.spkr.copy_(spk)
 gt.capture()
 t_graph, gout = timed(lambda: gt(redraw=True))
-print(json.dumps(dict(metric='mel-frames/sec (whole Tacotron2.forward, one hipGraph replay)', value=B * T / t_graph, ms_total_graph=1e3 * t_graph,
-                      value_eager=B * T / t_all, ms_total=1e3 * t_all,
-                      ms_encoder=1e3 * t_enc, ms_decoder_eager=1e3 * t_dec, ms_postnet=1e3 * t_post,
-                      config='C2: B=32, 258 frames, L=43, fp32, prenet dropout 0.5')))
+assert bool(torch.isfinite(gout[0]).all()) and bool(torch.isfinite(gout[1]).all())
+# roofline of the whole forward: SURVEY 8d counts 132 GFLOP per C2 batch (encoder 12.4 + decoder 106.3 + postnet 13.7, dense
+# contractions on the fp32 matrix cores) and, per decode step, 81.0 MB of operands that must stream (weights re-read every step)
+import bench
+flops = 12.4e9 + 106.3e9 + 13.7e9
+hbm_bytes = 86 * 81.0e6 + 33.9e6
+res = dict(metric='mel-frames/sec (whole Tacotron2.forward, one hipGraph replay)', value=B * T / t_graph, unit='mel-frames/s',
+           ms_total_graph=1e3 * t_graph, value_eager=B * T / t_all, ms_total=1e3 * t_all,
+           ms_encoder=1e3 * t_enc, ms_decoder_eager=1e3 * t_dec, ms_postnet=1e3 * t_post, dtype='f32', data='synthetic',
+           config={'workload': 'C2 whole forward: encoder + decode loop + CBHG postnet + Linear(160, 1025), B=32, 258 frames, L=43, prenet dropout 0.5'},
+           roofline={'bound': 'hbm', 'kernel': 'whole forward (the decode loop streams its weights every step)',
+                     'achieved': round(hbm_bytes / t_graph / 1e9, 1), 'peak': bench.HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(hbm_bytes / t_graph / 1e9 / bench.HBM_PEAK_GBS, 4), 'traffic': None,
+                     'mfma': {'achieved': round(flops / t_graph / 1e12, 2), 'peak': bench.MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(flops / t_graph / 1e12 / bench.MFMA_F32_PEAK_TFLOPS, 4)}})
+if '--no-cpu-baseline' not in sys.argv:
+    from oracle import nn_baseline as NB
+    from helpers import full_hp
+    W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    net = NB.NNTacotron2(W, full_hp(0.5)).eval()
+    txt_c, spk_c = txt.cpu(), spk.cpu()
+    res['cpu_baseline'] = bench.cpu_timed(lambda: net(txt_c[:4], 12, spk_c[:4]), lambda i: net(txt_c, T, spk_c, seed=i), B * T, 'mel-frames/s',
+                                          'nn_modules', 'full passes of Tacotron2.forward (B=%d, %d frames, L=%d, free running, prenet dropout 0.5) '
+                                          'assembled from torch.nn modules (oracle/nn_baseline.py); probe = 4 utterances x 4 decode steps' % (B, T, L))
+print(json.dumps(res))

@@ -8,7 +8,7 @@ for V in "${VARS[@]}"; do
   D=$ROOT/gpurun_out/variants/v$i; mkdir -p $D; OBJS=""
   for f in $ROOT/semi_tts_amd/csrc/*.hip; do
     o=$D/$(basename $f .hip).o
-    if [ $(basename $f) = skinny_packed.hip ]; then
+    if [ $(basename $f) = skinny_packed.hip ] || [ $(basename $f) = decoder.hip ]; then
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=16 $V -c $f -o $o || exit 1
     else
       o=$ROOT/semi_tts_amd/lib/$(basename $f .hip).o

@@ -12,10 +12,12 @@ __device__ unsigned long long g_prof[256 * 8 * 8];
 
 // touches the first `kbs` k-blocks of every tile's packed weights (and nothing else): does a warm L2 / TLB shorten the start of
 // the next kernel?  WG t of this kernel and WG t of the LSTM kernel land on the same XCD (round-robin dispatch).
+// (round 3: the 2-D tiled cell gives workgroup x the row tiles 2x and 2x+1, so prefetch workgroup x touches exactly those two)
 __global__ __launch_bounds__(512) void prefetch_kernel(const f32x4* w, int w_kbs, int kbs, float* sink) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k = wave; k < kbs; k += 8) { const f32x4 v = w[((size_t)blockIdx.x * w_kbs + k) * 64 + lane]; acc[0] += v[0]; acc[1] += v[1]; }
+    for (int rt = 0; rt < 2; ++rt)
+        for (int k = wave; k < kbs; k += 8) { const f32x4 v = w[((size_t)(2 * blockIdx.x + rt) * w_kbs + k) * 64 + lane]; acc[0] += v[0]; acc[1] += v[1]; }
     if (acc[0] == 12345.678f) sink[0] = acc[1];
 }
 
@@ -41,8 +43,8 @@ int main() {
             float tot = 0;
             for (int it = 0; it < 20; ++it) {
                 CK(hipMemsetAsync(junk, it, 64 << 20, nullptr));                 // evict L2 / MALL-ish
-                if (variant == 1) hipLaunchKernelGGL(prefetch_kernel, dim3(H / 4), dim3(512), 0, nullptr, (const f32x4*)w, (K + 15) / 16, ((K + 15) / 16 < 32 ? (K + 15) / 16 : 32), sink);
-                if (variant == 2) hipLaunchKernelGGL(prefetch_kernel, dim3(H / 4), dim3(512), 0, nullptr, (const f32x4*)w, (K + 15) / 16, (K + 15) / 16, sink);
+                if (variant == 1) hipLaunchKernelGGL(prefetch_kernel, dim3(H / 8), dim3(512), 0, nullptr, (const f32x4*)w, (K + 15) / 16, ((K + 15) / 16 < 32 ? (K + 15) / 16 : 32), sink);
+                if (variant == 2) hipLaunchKernelGGL(prefetch_kernel, dim3(H / 8), dim3(512), 0, nullptr, (const f32x4*)w, (K + 15) / 16, (K + 15) / 16, sink);
                 CK(hipEventRecord(a0)); run(); CK(hipEventRecord(a1)); CK(hipEventSynchronize(a1));
                 float ms; CK(hipEventElapsedTime(&ms, a0, a1)); tot += ms;
             }

@@ -229,6 +229,17 @@ typedef struct st_attn_fin_job {
 } st_attn_fin_job;
 int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
                           const st_attn_fin_job* job, int B, void* stream);
+/* Long texts (the fin part is bound by what ONE compute unit pulls in: S and the memory rows of an utterance): the same launch with the
+ * fin part over `job->parts` (2..8) POSITION ranges per utterance -- local softmax statistics and an un-normalised partial context per
+ * range, as st_attn_fin_split_fwd -- and the combine INSIDE the launch: the ranges of an utterance exchange (max, sum, partial context)
+ * as 8-byte {value, tag} granules through `xchg` (st_attn_rng_xchg_words(B, E, parts) 64-bit words, zero before the first epoch of a
+ * forward) and each finishes E / parts context dims and the weights of its own positions.  One launch instead of three.
+ * Needs E % (4 * parts) == 0, E / parts <= 256 and every workgroup resident at once: st_query_attn_rng_fits(B, A, parts) != 0
+ * (occupancy query of the kernel x compute units); otherwise use the two / three launch forms. */
+int st_query_attn_rng_fits(int B, int A, int parts);
+size_t st_attn_rng_xchg_words(int B, int E, int parts);
+int st_query_attn_rng_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules,
+                          unsigned long long* xchg, unsigned epoch, const st_attn_fin_job* job, int B, void* stream);
 /* Diagnostics: one wave runs the consumer side of that hand-off on `granules` (A 64-bit {value, tag} words) as they are and writes
  * the A values to `out` -- or NaN, with bit 0 of *status set, after `max_spins` polls without every tag == epoch (the failure
  * path of a starved launch, which the scheduler never produces on an idle device). */
@@ -515,6 +526,10 @@ typedef struct st_decoder_io {
     int attn_split_parts;
     unsigned long long* pq_granules;   /* optional (B, A) 64-bit words: with attn_s_buf, the query projection and the attention fin
                                         * part of a step run as ONE launch (st_query_attn_fin_fwd); zeroed by the callee per forward */
+    unsigned long long* attn_xchg;     /* optional, st_attn_rng_xchg_words(B, E, attn_split_parts) 64-bit words: with pq_granules and
+                                        * attn_split_parts in 2..8, long texts run query projection + fin part over position ranges +
+                                        * combine as ONE launch per step (st_query_attn_rng_fwd) when it fits the device; zeroed by the
+                                        * callee per forward */
     unsigned* handoff_status;          /* optional device word for pq_granules: bit 0 = an in-launch hand-off timed out (a starved launch:
                                         * the waiting workgroups were not co-resident with their producers).  Sticky; owned, zeroed and
                                         * read by the caller after the forward -- a time-out is an ERROR, not a NaN to find later */

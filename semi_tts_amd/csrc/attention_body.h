@@ -123,6 +123,163 @@ __device__ __forceinline__ size_t at_t16_off(int b, int k, int KB) {
     return (((size_t)(b >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3);
 }
 
+__device__ __forceinline__ void at_put_granule(unsigned long long* p, float v, unsigned epoch) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    __hip_atomic_store((gu64*)p, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- fin part over POSITION ranges with the combine INSIDE the launch (long texts; ref: Attention.forward src/module.py:371-407 +
+// state update :262-264).  Workgroup (b, p) takes the positions [p Lp, (p+1) Lp) of utterance b exactly like at_split_kernel
+// (attention.hip): energies from its S rows, a LOCAL softmax (m_p, w~_l = exp(e_l - m_p), s_p) and the un-normalised partial context
+// c_p -- S and the memory rows are read once in total, 1/P of them per compute unit.  Instead of a second launch, the P workgroups
+// of an utterance exchange (m_p, s_p, c_p) as 8-byte {value, tag = epoch} granules (the hand-off the processed query already uses)
+// and every one of them finishes ITS share: the context dims [p E/P, (p+1) E/P) and the weights of its own positions, scaled by
+// exp(m_p - M) / D.  All workgroups of the launch must be resident at once (the launcher asks the occupancy API).
+struct ArArgs {
+    const float* s_buf; const float* memory; const float* v; const float* w_cum_prev;
+    float* w_out; int ld_wout; float* w_cum_out;
+    st_t16_view ctx_dst[3];
+    const unsigned long long* pq_gran;     // (B, A) granules of the processed query, written by the linear's workgroups of this launch
+    unsigned long long* xchg;              // (B, P, E + 4) granules: c_p (E), m_p, s_p, two pads
+    unsigned epoch; unsigned* status;
+    int B, L, A, E, P, Lp;
+};
+
+template <int NT>
+__device__ __forceinline__ void at_range_body(const ArArgs& a, const int wg) {
+    __shared__ float es[512];                           // energies, then w~ of this range (Lp <= 512)
+    __shared__ __attribute__((aligned(16))) float part[4 * NT];
+    __shared__ __attribute__((aligned(16))) float pqs[256];
+    __shared__ __attribute__((aligned(16))) float cb[8 * 256];   // the other parts' partial contexts, this workgroup's dims only
+    __shared__ float stat[2], gst[16];
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P, b = wg / P, p = wg - b * P;
+    const int L = a.L, A = a.A, E = a.E;
+    const int l0 = p * a.Lp, l1 = min(L, l0 + a.Lp), n = l1 - l0;
+    const float* sb = a.s_buf + ((size_t)b * L + l0) * A;
+    const float* memb = a.memory + ((size_t)b * L + l0) * E;
+    const int ne4 = E >> 2;
+    const int ng = NT / ne4, e4 = tid % ne4, g = tid / ne4;
+    constexpr int PFR = 11;                 // (44 rows with E = 512: a whole range of <= 44 positions is in flight from the start)
+    f32x4 mpf[PFR];
+#pragma unroll
+    for (int j = 0; j < PFR; ++j) {
+        const int l = g + j * ng;
+        mpf[j] = (g < ng && l < n) ? st_ld4(memb + (size_t)l * E + e4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int a0 = min(lane * 4, A - 4);
+    const bool a_on = lane * 4 < A;
+    const f32x4 v4 = st_ld4(a.v + a0);
+    const float vsum = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+    constexpr int NPW = 8;
+    f32x4 spf[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) spf[i] = st_ld4(sb + (size_t)min(wave + i * NW, max(n - 1, 0)) * A + a0);
+    // the processed query of this step: one wave polls the granules, the others take it from LDS
+    if (wave == 0) {
+        const f32x4 q4 = at_wait_granules(a.pq_gran + (size_t)b * A, a.epoch, lane, A, a.status, AT_GRAN_SPINS);
+        if (lane * 4 < A) *reinterpret_cast<f32x4*>(pqs + lane * 4) = q4;
+    }
+    __syncthreads();
+    const f32x4 pq4 = *reinterpret_cast<const f32x4*>(pqs + a0);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int l = wave + i * NW;
+        if (l >= n) break;
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {      // v . tanh(x), tanh(x) = 1 - 2 / (1 + exp(2x)) as in at_body
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((pq4[c] + spf[i][c]) * 2.885390081777927f));
+            acc = fmaf(v4[c], r, acc);
+        }
+        float e = a_on ? fmaf(-2.0f, acc, vsum) : 0.0f;
+        e = st_wave_sum_dpp(e);
+        if (lane == 0) es[l] = e;
+    }
+    for (int l = wave + NPW * NW; l < n; l += NW) {
+        const f32x4 s4 = st_ld4(sb + (size_t)l * A + a0);
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((pq4[c] + s4[c]) * 2.885390081777927f));
+            acc = fmaf(v4[c], r, acc);
+        }
+        float e = a_on ? fmaf(-2.0f, acc, vsum) : 0.0f;
+        e = st_wave_sum_dpp(e);
+        if (lane == 0) es[l] = e;
+    }
+    __syncthreads();
+    unsigned long long* xme = a.xchg + ((size_t)b * P + p) * (E + 4);
+    if (wave == 0) {      // local softmax statistics, published at once
+        float m = -INFINITY;
+        for (int l = lane; l < n; l += 64) m = fmaxf(m, es[l]);
+        m = st_wave_max_dpp(m);
+        float ssum = 0.0f;
+        for (int l = lane; l < n; l += 64) {
+            const float w = __expf(es[l] - m);
+            es[l] = w;
+            ssum += w;
+        }
+        ssum = st_wave_sum_dpp(ssum);
+        if (lane < 4) at_put_granule(xme + E + lane, lane == 0 ? m : (lane == 1 ? ssum : 0.0f), a.epoch);
+        if (lane == 0) { stat[0] = m; stat[1] = ssum; }
+    }
+    __syncthreads();
+    if (g < ng) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < PFR; ++j) {
+            const int l = g + j * ng;
+            const float w = l < n ? es[min(l, n - 1)] : 0.0f;
+            acc[0] = fmaf(w, mpf[j][0], acc[0]); acc[1] = fmaf(w, mpf[j][1], acc[1]);
+            acc[2] = fmaf(w, mpf[j][2], acc[2]); acc[3] = fmaf(w, mpf[j][3], acc[3]);
+        }
+        for (int l = g + PFR * ng; l < n; l += ng) {
+            const f32x4 m4 = st_ld4(memb + (size_t)l * E + e4 * 4);
+            const float w = es[l];
+            acc[0] = fmaf(w, m4[0], acc[0]); acc[1] = fmaf(w, m4[1], acc[1]);
+            acc[2] = fmaf(w, m4[2], acc[2]); acc[3] = fmaf(w, m4[3], acc[3]);
+        }
+        *reinterpret_cast<f32x4*>(part + (size_t)(g * ne4 + e4) * 4) = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += NT) {       // partial context of this range: one granule per context dim
+        float s = 0.0f;
+        for (int gg = 0; gg < ng; ++gg) s += part[gg * E + e];
+        at_put_granule(xme + e, s, a.epoch);
+    }
+    // ---- combine: wave q collects part q's statistics and the slice of its partial context this workgroup finishes
+    const int Es = E / P;
+    if (wave < P) {
+        const unsigned long long* xq = a.xchg + ((size_t)b * P + wave) * (E + 4);
+        const f32x4 st4 = at_wait_granules(xq + E, a.epoch, lane, 4, a.status, AT_GRAN_SPINS);
+        const f32x4 c4 = at_wait_granules(xq + (size_t)p * Es, a.epoch, lane, Es, a.status, AT_GRAN_SPINS);
+        if (lane * 4 < Es) *reinterpret_cast<f32x4*>(cb + wave * 256 + lane * 4) = c4;
+        if (lane == 0) { gst[2 * wave] = st4[0]; gst[2 * wave + 1] = st4[1]; }
+    }
+    __syncthreads();
+    float M = -INFINITY;
+    for (int q = 0; q < P; ++q) M = fmaxf(M, gst[2 * q]);
+    float D = 0.0f;
+    for (int q = 0; q < P; ++q) D += gst[2 * q + 1] * __expf(gst[2 * q] - M);
+    if (tid < Es) {
+        float s = 0.0f;
+        for (int q = 0; q < P; ++q) s = fmaf(__expf(gst[2 * q] - M) / D, cb[q * 256 + tid], s);
+        const int e = p * Es + tid;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (a.ctx_dst[d].base) a.ctx_dst[d].base[at_t16_off(b, a.ctx_dst[d].kb0 * 16 + e, a.ctx_dst[d].kb_stride)] = s;
+    }
+    const float scp = __expf(stat[0] - M) / D;
+    for (int l = tid; l < n; l += NT) {
+        const float w = es[l] * scp;
+        a.w_out[(size_t)b * a.ld_wout + l0 + l] = w;
+        a.w_cum_out[(size_t)b * L + l0 + l] = w + a.w_cum_prev[(size_t)b * L + l0 + l];      // weights + attn_weights_sum, :264
+    }
+}
+
 // PART 0: the whole step.  PART 1 ("pre"): only what depends on the PREVIOUS step's attention weights -- location conv and
 // S[l][a] = pm[l][a] + sum_f W_l[a][f] cf[f][l] -- written to a.s_buf; it can run while the rest of the decode step does
 // (as extra workgroups of the proj launch, skinny_packed.hip).  PART 2 ("fin"): energies from S, softmax, context.

@@ -208,6 +208,13 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     const int sp_parts = io->attn_split_parts;
     const bool fin_split = split_attn && io->attn_split_ws && sp_parts >= 2 && sp_parts <= 64 && A % 4 == 0 && A <= 256 && E % 4 == 0 &&
                            E / 4 <= 512 && 512 % (E / 4) == 0 && (L + sp_parts - 1) / sp_parts <= 512;
+    // ... or, when the device holds all its workgroups at once, query projection + fin part over position ranges + combine as ONE launch
+    const bool fin_rng = fin_split && !pre_in_pq && io->pq_granules && io->attn_xchg && sp_parts <= 8 && A % 16 == 0 && E % (4 * sp_parts) == 0 &&
+                         E / sp_parts <= 256 && (sp_parts - 1) * ((L + sp_parts - 1) / sp_parts) < L && st_query_attn_rng_fits(B, A, sp_parts);
+    if (fin_rng) {
+        ST_HIP(hipMemsetAsync(io->pq_granules, 0, (size_t)B * A * sizeof(unsigned long long), (hipStream_t)stream));
+        ST_HIP(hipMemsetAsync(io->attn_xchg, 0, st_attn_rng_xchg_words(B, E, sp_parts) * sizeof(unsigned long long), (hipStream_t)stream));
+    }
     const bool fuse_pq_fin = !fin_split && split_attn && !pre_in_pq && io->pq_granules && A % 16 == 0 && A <= 256 && E % 4 == 0 &&
                              (A / 16) * ((B + 15) / 16) + B * fin_parts <= st_device_cus();
     if (fuse_pq_fin) ST_HIP(hipMemsetAsync(io->pq_granules, 0, (size_t)B * A * sizeof(unsigned long long), (hipStream_t)stream));
@@ -232,7 +239,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         if (rc) return rc;
 
         // 2. processed query                                             ref: :380
-        if (fuse_pq_fin) rc = 0;    // (rides with step 3)
+        if (fuse_pq_fin || fin_rng) rc = 0;    // (rides with step 3)
         else if (pre_in_pq && t > 0) {   // attention pre part of THIS step rides along (needs only the weights of step t-1)
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)(t - 1) * L, ldal, io->wcum_tape + (size_t)t * BL,
                                    w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)t * io->attn_s_step_floats, L, A, d->F,
@@ -250,7 +257,19 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         //    ctx_t -> xq_{t+1}[ctx part], xd_t[ctx part], xo_t[ctx part]
         const float* w_prev = t == 0 ? io->zero_row : io->align_out + (size_t)(t - 1) * L;
         st_t16_view ctx_dst[3] = {{xq_next, sv.q_kbs, sv.q_ctx}, {xd, sv.d_kbs, 0}, {xo, sv.o_kbs, sv.o_ctx}};
-        if (fin_split && !ST_SKIPPED(2))
+        if (fin_rng && !(ST_SKIPPED(1) || ST_SKIPPED(2))) {   // 2 + 3 + combine as one launch (long texts)
+            st_attn_fin_job fj;
+            memset(&fj, 0, sizeof(fj));
+            fj.s_buf = t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats;
+            fj.memory = io->memory; fj.w_cum_prev = io->wcum_tape + (size_t)t * BL;
+            fj.w_out = io->align_out + (size_t)t * L; fj.ld_wout = ldal; fj.w_cum_out = io->wcum_tape + (size_t)(t + 1) * BL; fj.v = w->attn_v;
+            for (int c = 0; c < 3; ++c) fj.ctx_dst[c] = ctx_dst[c];
+            fj.status = io->handoff_status;
+            fj.n_ctx_dst = 3; fj.parts = sp_parts; fj.L = L; fj.A = A; fj.E = E; fj.F = d->F; fj.K = d->K;
+            rc = st_query_attn_rng_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, io->attn_xchg, (unsigned)(t + 1), &fj, B, stream);
+        }
+        else if (fin_rng) rc = 0;
+        else if (fin_split && !ST_SKIPPED(2))
             rc = st_attn_fin_split_fwd(io->pq_buf, t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats, io->memory,
                                        io->wcum_tape + (size_t)t * BL, io->align_out + (size_t)t * L, ldal,
                                        io->wcum_tape + (size_t)(t + 1) * BL, w->attn_v, ctx_dst, 3, nullptr, 0, io->attn_split_ws, sp_parts,

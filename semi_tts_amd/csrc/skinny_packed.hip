@@ -558,6 +558,25 @@ __global__ __launch_bounds__(KW * 64) void pk_attnfin_kernel(const f32x4* w, con
     else at_body<true, 2, AT_THREADS, true>(t, i - n_lin, pk_dyn_lds);
 }
 
+// Long texts: the query projection and the fin part over POSITION ranges (at_range_body) with the combine inside the launch: the
+// linear's workgroups, then B * P range workgroups that exchange their partial results as granules.  At most 128 VGPRs
+// (__launch_bounds__(512, 4)) so that two workgroups fit a compute unit: 64 + 64 * 4 = 320 workgroups at C5 must be resident at once.
+template <int NB, int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64, 4) void pk_attnrng_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                                const int B, const int N, const int tiles_a, const int n_lin,
+                                                                const PkArgs a_rest, const ArArgs t) {
+    __shared__ f32x4 red[KW * NB * 64];
+    static_assert(KW * 64 == AT_THREADS, "both parts use 512-thread workgroups");
+    const int i = blockIdx.x;
+    if (i < n_lin) {
+        PkArgs a = a_rest;
+        a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N;
+        const int by = n_lin <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
+        pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
+    }
+    else at_range_body<AT_THREADS>(t, i - n_lin);
+}
+
 #ifndef PK_TRIP_SMALL
 #define PK_TRIP_SMALL 2     // k-blocks per wave and group of the one-batch-tile linears (double buffered)
 #endif
@@ -831,6 +850,65 @@ extern "C" int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* 
     }
     hipLaunchKernelGGL(kern, dim3(n_lin + n_fin), dim3(KW * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N,
                        tiles, n_lin, a, t);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// workgroups of pk_attnrng_kernel the device holds at once (occupancy API x compute units; 0 on error)
+static int pk_attnrng_capacity() {
+    static int cap = -1;
+    if (cap < 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pk_attnrng_kernel<1, 8, PK_TRIP_SMALL>), 8 * 64, 0) != hipSuccess)
+            per_cu = 0;
+        (void)hipGetLastError();
+        cap = per_cu * st_device_cus();
+    }
+    return cap;
+}
+
+extern "C" int st_query_attn_rng_fits(int B, int A, int parts) {
+    if (B <= 0 || A <= 0 || A % 16 != 0 || parts < 2 || parts > 8) return 0;
+    return (A / 16) * ((B + 15) / 16) + B * parts <= pk_attnrng_capacity() ? 1 : 0;
+}
+
+extern "C" size_t st_attn_rng_xchg_words(int B, int E, int parts) { return (size_t)B * parts * (E + 4); }
+
+extern "C" int st_query_attn_rng_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules,
+                                     unsigned long long* xchg, unsigned epoch, const st_attn_fin_job* job, int B, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(packed_wq && h_q && h_q->base && granules && xchg && epoch != 0 && job && B > 0, "st_query_attn_rng_fwd: bad arguments");
+    const int L = job->L, A = job->A, E = job->E, parts = job->parts;
+    ST_CHECK_ARG(L > 0 && A > 0 && A % 16 == 0 && A <= 256, "st_query_attn_rng_fwd: attention dim %d must be a multiple of 16, at most 256", A);
+    ST_CHECK_ARG(parts >= 2 && parts <= 8 && E % (4 * parts) == 0 && E / parts <= 256 && E / 4 <= AT_THREADS && AT_THREADS % (E / 4) == 0,
+                 "st_query_attn_rng_fwd: parts=%d (2..8), E=%d", parts, E);
+    const int Lp = (L + parts - 1) / parts;
+    ST_CHECK_ARG(Lp <= 512 && (parts - 1) * Lp < L, "st_query_attn_rng_fwd: L=%d over %d parts leaves an empty or oversized range", L, parts);
+    ST_CHECK_ARG(job->s_buf && job->memory && job->w_cum_prev && job->w_out && job->w_cum_out && job->v, "st_query_attn_rng_fwd: null attention operand");
+    ST_CHECK_ARG(job->n_ctx_dst >= 1 && job->n_ctx_dst <= 3, "st_query_attn_rng_fwd: n_ctx_dst=%d", job->n_ctx_dst);
+    ST_CHECK_ARG(st_aligned16(job->s_buf) && st_aligned16(job->memory) && st_aligned16(job->v) && (reinterpret_cast<uintptr_t>(granules) & 7) == 0 &&
+                 (reinterpret_cast<uintptr_t>(xchg) & 7) == 0, "st_query_attn_rng_fwd: operands must be 16-byte aligned");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_wq, h_q, Q, "st_query_attn_rng_fwd");
+    if (rc) return rc;
+    a.B = B; a.N = A; a.H = 0; a.act = ST_ACT_NONE;
+    a.gran = granules; a.epoch = epoch;
+    ArArgs t;
+    memset(&t, 0, sizeof(t));
+    t.s_buf = job->s_buf; t.memory = job->memory; t.v = job->v; t.w_cum_prev = job->w_cum_prev;
+    t.w_out = job->w_out; t.ld_wout = job->ld_wout; t.w_cum_out = job->w_cum_out;
+    for (int d = 0; d < job->n_ctx_dst; ++d) t.ctx_dst[d] = job->ctx_dst[d];
+    t.pq_gran = granules; t.xchg = xchg; t.epoch = epoch; t.status = job->status;
+    t.B = B; t.L = L; t.A = A; t.E = E; t.P = parts; t.Lp = Lp;
+    const int tiles = A / 16, BT = (B + 15) >> 4;
+    const int n_lin = tiles * BT, n_rng = B * parts;
+    // the waiting workgroups hold their compute units: everything must be resident at once
+    ST_CHECK_ARG(n_lin + n_rng <= pk_attnrng_capacity(), "st_query_attn_rng_fwd: %d + %d workgroups do not fit the device at once (%d)",
+                 n_lin, n_rng, pk_attnrng_capacity());
+    constexpr int KW = 8;
+    hipLaunchKernelGGL((pk_attnrng_kernel<1, KW, PK_TRIP_SMALL>), dim3(n_lin + n_rng), dim3(KW * 64), 0, (hipStream_t)stream, a.w, a.x, a.w_kbs,
+                       a.x_kbs, a.KB, a.B, a.N, tiles, n_lin, a, t);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -312,6 +312,7 @@ class Decoder(nn.Module):
         self.handoff_status = None
         self.attn_split_min_len = 128     # texts at least this long: fin part over position ranges (~attn_split_positions each) + combine
         self.attn_split_positions = 43
+        self.attn_rng_one_launch = True   # long texts: query projection + fin part over position ranges + combine in one launch
 
     # -- helpers ---------------------------------------------------------------------------------
     def _weights_struct(self, keep, fuse_pre0=False):
@@ -526,6 +527,11 @@ class Decoder(nn.Module):
                 sp = max(2, min(64, (L + self.attn_split_positions - 1) // self.attn_split_positions))
                 tapes['attn_split_ws'] = torch.empty(int(lib.st_attn_fin_split_workspace_floats(B, E, sp)), **f32)
                 io.attn_split_ws, io.attn_split_parts = ops._p(tapes['attn_split_ws']), sp
+                if self.attn_pq_in_fin and sp <= 8 and self.attn_rng_one_launch:
+                    # ... and, when the device holds every workgroup at once, as ONE launch with the combine inside (the library
+                    # decides: st_query_attn_rng_fits; the three-launch form stays the fall-back)
+                    tapes['attn_xchg'] = torch.empty(2 * int(lib.st_attn_rng_xchg_words(B, E, sp)), **f32)
+                    io.attn_xchg = ops._p(tapes['attn_xchg'])
             if self.attn_pq_in_fin and not keep_tapes:
                 # query projection + attention fin part as ONE launch per step (st_query_attn_fin_fwd): pq is handed over inside
                 # the launch as 8-byte {value, tag} words; the library falls back to two launches when the shapes do not fit

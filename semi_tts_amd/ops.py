@@ -177,6 +177,29 @@ def query_attn_fin(packed_wq, h_q_t16, Q, s_buf, memory, w_cum_prev, v, w_out, w
     return granules
 
 
+def query_attn_rng(packed_wq, h_q_t16, Q, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx_t16, parts, epoch=1, granules=None,
+                   xchg=None, status=None):
+    """query projection + attention fin part over `parts` position ranges + combine in ONE launch: st_query_attn_rng_fwd.
+    `granules` (B, 2 A floats) and `xchg` must be zero before the first epoch; returns them."""
+    lib = _lib.load()
+    B, L, E = memory.shape
+    A = s_buf.shape[-1]
+    if granules is None:
+        granules = torch.zeros(B, 2 * A, device=memory.device, dtype=torch.float32)
+    if xchg is None:
+        xchg = torch.zeros(2 * int(lib.st_attn_rng_xchg_words(B, E, int(parts))), device=memory.device, dtype=torch.float32)
+    job = _lib.StAttnFinJob()
+    job.s_buf, job.memory, job.w_cum_prev = _p(s_buf), _p(memory), _p(w_cum_prev)
+    job.w_out, job.ld_wout, job.w_cum_out, job.v = _p(w_out), int(w_out.stride(0)), _p(w_cum_out), _p(v)
+    job.ctx_dst[0] = t16_view(ctx_t16, K=E)
+    job.n_ctx_dst, job.parts, job.L, job.A, job.E, job.F, job.K = 1, int(parts), L, A, E, 0, 0
+    job.status = _p(status, torch.int32)
+    hv = t16_view(h_q_t16, K=Q)
+    check(lib.st_query_attn_rng_fwd(_p(packed_wq), C.byref(hv), 16 * kb16(Q), _p(granules), _p(xchg), int(epoch), C.byref(job), B,
+                                    stream_handle()), 'st_query_attn_rng_fwd')
+    return granules, xchg
+
+
 _TAP_MAJOR = {}     # id(weight) -> (weakref to it, version, converted copy)
 
 

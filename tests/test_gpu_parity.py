@@ -959,3 +959,66 @@ def test_graphed_speech_to_text_equals_eager(dev):
             assert (a is None) == (b is None), name
             if a is not None:
                 assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize('B,L,Q,A,E,parts', [(64, 171, 1024, 256, 512, 4), (3, 171, 1024, 256, 512, 4), (5, 130, 64, 32, 64, 2),
+                                             (2, 300, 128, 64, 128, 8), (7, 17, 48, 16, 128, 4)])
+def test_query_projection_and_fin_part_over_position_ranges_in_one_launch(dev, B, L, Q, A, E, parts):
+    """st_query_attn_rng_fwd (long texts, BASELINE config 5): query projection + fin part over position ranges + combine in ONE launch
+    -- pq and the ranges' (max, sum, partial context) travel as {value, tag} granules inside the launch -- against the packed
+    linear + st_attn_fin_split_fwd (same split, combine as a second launch) and against float64; consecutive epochs on the same
+    granule buffers; the status word stays clear."""
+    from semi_tts_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.st_query_attn_rng_fits(B, A, parts) == 1
+    wq, hq = rnd(A, Q, scale=Q ** -0.5, seed=1), rnd(B, Q, seed=2)
+    S, mem = rnd(B, L, A, seed=3), rnd(B, L, E, seed=4)
+    w_cum, v = torch.rand(B, L, generator=torch.Generator().manual_seed(5)), rnd(1, A, seed=6)
+    d = [t.to(dev) for t in (wq, hq, S, mem, w_cum, v)]
+    packed = ops.pack_weight([d[0]], [Q], A)
+    h_t = ops.tile_rows(d[1])
+    pq = torch.empty(B, A, device=dev)
+    ops.skinny_linear_packed(packed, ops.t16_view(h_t, K=Q), 16 * ops.kb16(Q), B, A, y=pq)
+    w1, c1, x1 = (torch.empty(B, L, device=dev), torch.empty(B, L, device=dev), torch.empty(B, E, device=dev))
+    ops.attn_fin_split(pq, d[2], d[3], d[4], d[5], w1, c1, x1, parts)
+    e = torch.tanh((hq.double() @ wq.double().t()).unsqueeze(1) + S.double()).matmul(v.double().view(-1))
+    w_r = torch.softmax(e, -1)
+    x_r = torch.bmm(w_r.unsqueeze(1), mem.double()).squeeze(1)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    gran = xchg = None
+    for epoch in (1, 2, 3):
+        w2, c2 = torch.full_like(w1, float('nan')), torch.full_like(c1, float('nan'))
+        x_t = torch.zeros(ops.t16_floats(B, E), device=dev)
+        gran, xchg = ops.query_attn_rng(packed, h_t, Q, d[2], d[3], d[4], d[5], w2, c2, x_t, parts, epoch=epoch, granules=gran, xchg=xchg,
+                                        status=status)
+        x2 = ops.untile_rows(x_t, B, E)
+        errs = dict(w_vs_split=maxdiff(w2, w1), ctx_vs_split=maxdiff(x2, x1), w=maxdiff(w2, w_r), ctx=maxdiff(x2, x_r),
+                    cum=maxdiff(c2, w_r + w_cum.double()))
+        report('query_attn_rng', B=B, L=L, parts=parts, epoch=epoch, **errs)
+        assert errs['w_vs_split'] < 1e-6 and errs['ctx_vs_split'] < 1e-5
+        assert errs['w'] < 2e-6 and errs['ctx'] < 2e-5 and errs['cum'] < 2e-6
+        assert int(status.item()) == 0
+    with pytest.raises(RuntimeError):       # E / parts must be whole float4 columns; 9 parts are not offered
+        ops.query_attn_rng(packed, h_t, Q, d[2], d[3], d[4], d[5], w2, c2, x_t, 9, epoch=4, granules=gran)
+
+
+def test_long_text_decode_uses_the_one_launch_form_and_matches_the_three_launch_form(dev):
+    """Decoder.forward at L = 171 (free running): the loop with query projection + range fin part + combine as one launch per step
+    == the loop with the split + combine launches (same split of the softmax; ~1e-7), both finite"""
+    from helpers import full_tacotron
+    from semi_tts_amd.synthetic import synthetic_batch
+    B, L, T = 8, 171, 36
+    m = full_tacotron(dev, seed=21, prenet_dropout=0.0)
+    txt, spk, _ = synthetic_batch(B, L, T, seed=9)
+    txt, spk = torch.from_numpy(txt).to(dev), torch.from_numpy(spk).to(dev)
+    with torch.no_grad():
+        mem = m.encoder(txt, None).contiguous()
+        m.decoder.attn_rng_one_launch = True
+        mel1, al1, _ = m.decoder(mem, None, T, spk, tf_rate=0.0)
+        assert 'attn_xchg' in m.decoder.last_tapes
+        m.decoder.attn_rng_one_launch = False
+        mel2, al2, _ = m.decoder(mem, None, T, spk, tf_rate=0.0)
+        assert 'attn_xchg' not in m.decoder.last_tapes
+    errs = dict(mel=maxdiff(mel1, mel2), align=maxdiff(al1, al2))
+    report('decode_long_text_one_launch', **errs)
+    assert errs['mel'] < 5e-6 and errs['align'] < 1e-6 and bool(torch.isfinite(mel1).all())

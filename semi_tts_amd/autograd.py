@@ -103,7 +103,7 @@ class _BnTrainFn(Function):
             # (Chan et al.).  The counts stay on the device -- no host round trip, and shards of different sizes (a ragged
             # last batch, B % world != 0, different T per rank in the speech encoder) are weighted by their true row counts.
             parallel._COUNTS['syncbn_fwd'] += 1
-            rec = parallel.all_gather_(torch.cat([mean, var * M, mean.new_tensor([float(M)])]))      # (world, 2N + 1)
+            rec = parallel.all_gather_(torch.cat([mean, var * M, parallel.count_tensor(M, mean.device)]))      # (world, 2N + 1)
             cnt = rec[:, 2 * N:]
             total = cnt.sum()
             gmean = (rec[:, :N] * cnt).sum(0) / total

@@ -57,8 +57,8 @@ class ConvLayer(nn.Module):
                             act_post=self.activation, res=res, mask=mask)
         # training: batch statistics of the biased conv output first, then the same fused pass with them
         y = ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b)
-        mean, var = ops.bn_stats(y.view(-1, y.shape[-1]), 0, y.shape[-1], bn.running_mean, bn.running_var, bn.momentum)
-        bn.num_batches_tracked += 1
+        mean, var = ops.bn_stats(y.view(-1, y.shape[-1]), 0, y.shape[-1], bn.running_mean, bn.running_var, bn.momentum,
+                                 bn.num_batches_tracked)
         return ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b, bn=(mean, var, bn.weight, bn.bias),
                         bn_eps=bn.eps, act_post=self.activation, res=res, mask=mask)
 

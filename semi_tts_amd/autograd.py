@@ -89,14 +89,14 @@ class _BnTrainFn(Function):
     With parallel.sync_batchnorm() under torch.distributed the statistics are those of the global batch."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, run_mean, run_var, eps, momentum, act):
+    def forward(ctx, x, weight, bias, run_mean, run_var, eps, momentum, act, batches_tracked=None):
         from . import parallel
         x = x.contiguous()
         N = x.shape[-1]
         x2 = _rows(x)
         M = x2.shape[0]
         sync = parallel.sync_bn_active()
-        mean, var = ops.bn_stats(x2, 0, N, None if sync else run_mean, None if sync else run_var, momentum)
+        mean, var = ops.bn_stats(x2, 0, N, None if sync else run_mean, None if sync else run_var, momentum, batches_tracked)
         scale = None
         if sync:
             # ONE collective: every rank's (mean, M2, count), merged exactly and identically on every rank in rank order
@@ -126,19 +126,19 @@ class _BnTrainFn(Function):
         dy2, y2, x2 = _rows(dy.contiguous()), _rows(y) if y is not None else None, _rows(x)
         N = x2.shape[1]
         s = ops.bn_bwd_reduce(dy2, y2, act, x2, mean, var, eps)
-        db, dw = s[:N].clone(), s[N:].clone()           # parameter gradients: local sums (averaged over ranks later)
+        db, dw = s[:N], s[N:]                           # parameter gradients: local sums (averaged over ranks later)
         if sync:
+            db, dw = db.clone(), dw.clone()             # (s is all-reduced in place below; otherwise the views are handed out as they are)
             parallel._COUNTS['syncbn_bwd'] += 1
             parallel.all_reduce_sum_(s)
             s = s * scale                         # s / M_local below == (sum over ranks) / M_global
         dx = ops.bn_bwd_apply(dy2, y2, act, x2, mean, var, weight, eps, s, M)
-        return dx.view(x.shape), dw, db, None, None, None, None, None
+        return dx.view(x.shape), dw, db, None, None, None, None, None, None
 
 
 def batch_norm_train(x, bn, act=None):
-    y = _BnTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act)
-    bn.num_batches_tracked += 1
-    return y
+    """(num_batches_tracked is incremented by the statistics launch itself)"""
+    return _BnTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, bn.num_batches_tracked)
 
 
 class _HighwayFn(Function):
@@ -429,13 +429,22 @@ class _DecoderFn(Function):
         # with own-output feedback the loop forms dxo_t after adding the feedback gradient to dmel_t
         dxo = torch.zeros(steps * Bp, XOw, **f32) if own else ops.gemm(dY2, wpg_t)          # (steps*Bp, D+E)
 
+        # every zero-initialised buffer of this backward comes out of ONE allocation and ONE fill launch
+        zshapes = dict(dgq=(steps, Bp, 4 * Q), dgd=(steps, Bp, 4 * D), dxq=(steps + 1, Bp, XQw), dxd=(steps + 1, Bp, XDw),
+                       dpq=(steps, Bp, A), dcq=(B, Q), dcd=(B, D), dh0=(B, 2, L), dh1=(B, 2, L), dcum=(B, L), dhq_attn=(B, Q),
+                       dgq_t16=(ops.t16_floats(B, 4 * Q),), dgd_t16=(ops.t16_floats(B, 4 * D),))
+        numel = lambda shp: int(torch.Size(shp).numel())
+        pool = torch.zeros(sum((numel(s) + 3) // 4 * 4 for s in zshapes.values()), **f32)      # (16-byte aligned pieces)
+        zb, off = {}, 0
+        for k, shp in zshapes.items():
+            zb[k] = pool[off:off + numel(shp)].view(*shp)
+            off += (numel(shp) + 3) // 4 * 4
         z = lambda *shape: torch.zeros(*shape, **f32)
-        dgq, dgd = z(steps, Bp, 4 * Q), z(steps, Bp, 4 * D)
-        dxq, dxd, dpq = z(steps + 1, Bp, XQw), z(steps + 1, Bp, XDw), z(steps, Bp, A)
+        dgq, dgd, dxq, dxd, dpq = zb['dgq'], zb['dgd'], zb['dxq'], zb['dxd'], zb['dpq']
         e_ = lambda *shape: torch.empty(*shape, **f32)
         ds_tape, loc_tape, dloc_tape = e_(steps, B, L, A), e_(steps, B, L, F), e_(steps, B, L, F)
         hist_tape, dctx_tape, dv_tape = e_(steps, B, L, 2), e_(steps, B, E), e_(steps, B, A)
-        dcq, dcd, dh0, dh1, dcum, dhq_attn = z(B, Q), z(B, D), z(B, 2, L), z(B, 2, L), z(B, L), z(B, Q)
+        dcq, dcd, dh0, dh1, dcum, dhq_attn = (zb[k] for k in ('dcq', 'dcd', 'dh0', 'dh1', 'dcum', 'dhq_attn'))
         wt = dict(q=torch.cat([q_w_ih.detach(), q_w_hh.detach()], 1).t().contiguous(),      # (P+E+Q, 4Q)
                   d=torch.cat([d_w_ih.detach(), d_w_hh.detach()], 1).t().contiguous(),      # (E+Q+D, 4D)
                   pq=wq.detach().t().contiguous())                                         # (Q, A)
@@ -444,9 +453,17 @@ class _DecoderFn(Function):
         bw.attn_v, bw.attn_loc_conv_w, bw.attn_loc_lin_w = ops._p(v), ops._p(wc), ops._p(wl)
         # the two big per-step products dgates . W stream W^T in MFMA lane order (packed once per backward)
         wt['q_p16'] = ops.pack_weight([wt['q']], [4 * Q], XQw)
-        wt['d_p16'] = ops.pack_weight([wt['d']], [4 * D], XDw)
-        bw.q_w_cat_t_p16, bw.d_w_cat_t_p16 = ops._p(wt['q_p16']), ops._p(wt['d_p16'])
-        dgq_t16, dgd_t16 = z(ops.t16_floats(B, 4 * Q)), z(ops.t16_floats(B, 4 * D))
+        # pure teacher forcing: the decoder cell's recurrence runs first on its own (phase 1: only W_hh_d^T is streamed per step),
+        # its input-side gradient for ALL steps is one GEMM, then the attention / query chain (phase 2)
+        split_loop = (not own) and dec.bwd_split_loop
+        if split_loop:
+            wt['d_hh_p16'] = ops.pack_weight([wt['d'][E + Q:]], [4 * D], D)
+            bw.d_w_hh_t_p16 = ops._p(wt['d_hh_p16'])
+        else:
+            wt['d_p16'] = ops.pack_weight([wt['d']], [4 * D], XDw)
+            bw.d_w_cat_t_p16 = ops._p(wt['d_p16'])
+        bw.q_w_cat_t_p16 = ops._p(wt['q_p16'])
+        dgq_t16, dgd_t16 = zb['dgq_t16'], zb['dgd_t16']
         dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A, F=F, K=K, fuse_pre0=0)
         io = StDecoderBwdIO()
         io.memory, io.pm, io.ada_std, io.align = ops._p(memory), ops._p(pm), ops._p(ada_std), ops._p(align)
@@ -478,6 +495,14 @@ class _DecoderFn(Function):
             io.pre_w1_t, io.pre_w0_t, io.own_mask = ops._p(wt['w1']), ops._p(wt['w0']), ops._p(own_mask)
             io.xq_nat, io.pre1_nat = ops._p(XQ), ops._p(pre1_nat)
             io.d2_tape, io.dp1_tape, io.tmp_p, io.tmp_in = ops._p(d2_tape), ops._p(dp1_tape), ops._p(tmp_p), ops._p(tmp_in)
+        if split_loop:
+            n_sl = int(dec.bwd_d_slices)
+            dh_slabs = e_(n_sl, Bp, D)
+            io.phase, io.d_slices, io.dh_slabs = 1, n_sl, ops._p(dh_slabs)
+            _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
+            # d[ctx_t | adapted h_q_t] = dgates_d_t . W_ih_d for every step at once, written into the first E+Q columns of the dxd tape
+            ops.gemm(dgd.view(-1, 4 * D), wt['d'][:E + Q], out=dxd.view(-1, XDw)[:steps * Bp])
+            io.phase = 2
         _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
 
         # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)

@@ -357,8 +357,9 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_kernel(const float* X, int
 
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, int chunks, int rows_per_chunk, int M, int N,
                                                              float* mean_out, float* var_out, float* run_mean, float* run_var,
-                                                             float momentum) {
+                                                             float momentum, long long* batches_tracked) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0 && batches_tracked) batches_tracked[0] += 1;      // nn.BatchNorm1d.num_batches_tracked, without a launch of its own
     if (n >= N) return;
     // two sweeps over the chunk records with independent loads (no serial dependence between chunks):
     //   mean = sum_c n_c mean_c / M;   M2 = sum_c [M2_c + n_c (mean_c - mean)^2]      (exact decomposition)
@@ -491,7 +492,7 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
 }
 
 extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, float* mean_out, float* var_out,
-                           float* run_mean, float* run_var, float momentum, float* ws, void* stream) {
+                           float* run_mean, float* run_var, float momentum, long long* batches_tracked, float* ws, void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
     ST_CHECK_ARG(X && mean_out && var_out && M > 0 && N > 0, "st_bn_stats: bad arguments");
     ST_CHECK_ARG((run_mean == nullptr) == (run_var == nullptr), "st_bn_stats: run_mean/run_var must both be given");
@@ -502,7 +503,7 @@ extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, floa
                        X, ldx, coff, M, N, rpc, ws);
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       ws, chunks, rpc, M, N, mean_out, var_out, run_mean, run_var, momentum);
+                       ws, chunks, rpc, M, N, mean_out, var_out, run_mean, run_var, momentum, batches_tracked);
     ST_LAUNCH_CHECK();
     return 0;
 }

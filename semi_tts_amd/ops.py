@@ -272,14 +272,15 @@ def _colreduce_ws(M, N, device):
     return torch.empty(n, device=device, dtype=torch.float32)
 
 
-def bn_stats(x2d, coff, N, run_mean=None, run_var=None, momentum=0.1):
-    """per-column batch statistics of x2d[:, coff:coff+N] (+ running-stat update in place)"""
+def bn_stats(x2d, coff, N, run_mean=None, run_var=None, momentum=0.1, batches_tracked=None):
+    """per-column batch statistics of x2d[:, coff:coff+N] (+ running-stat update in place, + `num_batches_tracked` += 1)"""
     lib = _lib.load()
     M = x2d.shape[0]
     mean = torch.empty(N, device=x2d.device, dtype=torch.float32)
     var = torch.empty(N, device=x2d.device, dtype=torch.float32)
     check(lib.st_bn_stats(_p(x2d), int(x2d.stride(0)), int(coff), M, N, _p(mean), _p(var), _p(run_mean), _p(run_var),
-                          float(momentum), _p(_colreduce_ws(M, N, x2d.device)), stream_handle()), 'st_bn_stats')
+                          float(momentum), _p(batches_tracked, torch.int64), _p(_colreduce_ws(M, N, x2d.device)), stream_handle()),
+          'st_bn_stats')
     return mean, var
 
 

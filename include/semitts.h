@@ -200,12 +200,6 @@ int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view
                                         int n_split, float* y2, int ldy2, int rep,
                                         int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                         int B, int N, const st_attn_pre_job* pre, void* stream);
-/* K-sliced form of st_skinny_linear_packed_fwd (no bias / activation): slice z of `slices` (1..8) reduces over its share of the
- * k-blocks and writes the partial product to y_slabs + z * slab_stride (row stride ldy); the consumer adds the slabs in index order
- * (st_lstm_cell_bwd_pointwise_slabs).  For skinny products whose (row tile, batch tile) grid does not fill the device:
- * dh_{t-1} = dgates_t . W_hh of the decoder cell's backward recurrence (N = 1024, K = 4096, B = 32: 128 workgroups -> 512). */
-int st_skinny_linear_packed_sliced_fwd(const float* packed_w, const st_t16_view* x, int K, int slices,
-                                       float* y_slabs, int ldy, long slab_stride, int B, int N, void* stream);
 
 /* The fin part for LONG texts: every utterance split over `parts` (2..64) ranges of positions -- local softmax statistics and an
  * un-normalised partial context per range (flash-decoding style), then a combine launch.  S and the memory rows are read once in
@@ -366,12 +360,6 @@ int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float* dh1, int 
                                const float* scale2, const float* mask, const float* gates, const float* c, int ldc,
                                const float* c_prev, int ldcp, float* dc, float* dgates, int ldg,
                                const st_t16_view* dgates_t16, int B, int H, void* stream);
-/* The same with dh = (dh0 + sum of n_slabs slabs of dh1, slab_stride floats apart, added in index order) * mask: the partial
- * products of st_skinny_linear_packed_sliced_fwd are consumed without a reduction launch of their own.  n_slabs 0..8. */
-int st_lstm_cell_bwd_pointwise_slabs(const float* dh0, int ld0, const float* dh1_slabs, int ld1, int n_slabs, long slab_stride,
-                                     const float* mask, const float* gates, const float* c, int ldc,
-                                     const float* c_prev, int ldcp, float* dc, float* dgates, int ldg,
-                                     const st_t16_view* dgates_t16, int B, int H, void* stream);
 /* Both directions of nn.LSTM(bidirectional=True) in one pass: per time step ONE launch advances direction 0 at t = s and direction
  * 1 at t = T-1-s (st_lstm_cell_pair_fwd: two cells of the same shape, blockIdx.z picks the job).  Arguments as st_lstm_seq_fwd in
  * arrays of two; ws: 6*B*H floats.  ref: nn.LSTM src/module.py:432-438,458-460 */
@@ -584,7 +572,6 @@ typedef struct st_decoder_bwd_weights {   /* transposed copies prepared by the c
     const float* attn_query_w_t;   /* W_q^T                 (Q, A)      */
     const float* q_w_cat_t_p16;    /* optional: q_w_cat_t packed by st_pack_weight (N = P+E+Q, K = 4Q); NULL = natural kernels */
     const float* d_w_cat_t_p16;    /* optional: d_w_cat_t packed (N = E+Q+D, K = 4D) */
-    const float* d_w_hh_t_p16;     /* phase 1 only: W_hh_d^T packed (N = D, K = 4D) */
     const float* attn_v; const float* attn_loc_conv_w; const float* attn_loc_lin_w;
 } st_decoder_bwd_weights;
 
@@ -624,14 +611,6 @@ typedef struct st_decoder_bwd_io {
     const float* pre1_nat;            /* (steps, Bp, P) un-tiled prenet layer-1 outputs */
     float* d2_tape; float* dp1_tape;  /* (steps, Bp, P) out, zero on entry: gradients at the two prenet layers (-> dW1, dW0) */
     float* tmp_p; float* tmp_in;      /* (B, P), (B, r*n_mels) scratch */
-    /* Pure teacher forcing splits the loop (the decoder cell's recurrence does not depend on the attention / query chain):
-     *   phase 1  for t = steps-1 .. 0: dgates_d_t from dxo_t and dgates_d_{t+1} . W_hh_d -- a K-sliced product over `d_slices` slices
-     *            into dh_slabs + a pointwise launch that adds the slabs; writes dgd (all steps), nothing else
-     *   (caller) dxd[:, :, :E+Q] = dgd . W_ih_d for ALL steps as one GEMM
-     *   phase 2  the attention / query-cell chain per step (attention backward, W_q^T dpq, query cell pointwise, dgates_q . W)
-     * phase 0 = the single loop (needed with own-output feedback). */
-    int phase; int d_slices;
-    float* dh_slabs;                  /* phase 1: d_slices x (Bp, D) scratch */
     const float* attn_s_tape;         /* optional (steps, B, L, A): S_t = pm + W_l loc_t saved by the forward (slot 0 unused: S_0 =
                                        * pm).  Then loc_tape is an INPUT (the forward's attn_loc_tape) and the attention backward
                                        * neither recomputes the location conv nor the W_l product. */

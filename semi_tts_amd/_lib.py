@@ -61,7 +61,7 @@ class StDecoderIO(C.Structure):
 
 
 class StDecoderBwdWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('q_w_cat_t', 'd_w_cat_t', 'attn_query_w_t', 'q_w_cat_t_p16', 'd_w_cat_t_p16', 'd_w_hh_t_p16',
+    _fields_ = [(n, C.c_void_p) for n in ('q_w_cat_t', 'd_w_cat_t', 'attn_query_w_t', 'q_w_cat_t_p16', 'd_w_cat_t_p16',
                                           'attn_v', 'attn_loc_conv_w', 'attn_loc_lin_w')]
 
 
@@ -74,8 +74,7 @@ class StDecoderBwdIO(C.Structure):
                 [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p), ('dgq_t16', C.c_void_p),
                  ('dgd_t16', C.c_void_p), ('step_src', C.POINTER(C.c_int)), ('Bt', C.c_int)] +
                 [(n, C.c_void_p) for n in ('dY', 'dxo_rw', 'wpg_t', 'pre_w1_t', 'pre_w0_t', 'own_mask', 'xq_nat', 'pre1_nat',
-                                           'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in')] +
-                [('phase', C.c_int), ('d_slices', C.c_int), ('dh_slabs', C.c_void_p), ('attn_s_tape', C.c_void_p)])
+                                           'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in', 'attn_s_tape')])
 
 
 
@@ -120,8 +119,6 @@ SIGNATURES = {
     'st_bn_apply': [P, I, I, I, I, P, P, P, P, F, I, P],
     'st_lstm_seq_fwd': [P, P, P, P, I, I, P, P, P, I, I, I, I, P],
     'st_lstm_cell_bwd_pointwise': [P, I, P, I, P, I, P, P, P, P, I, P, I, P, P, I, C.POINTER(StT16View), I, I, P],
-    'st_lstm_cell_bwd_pointwise_slabs': [P, I, P, I, I, C.c_long, P, P, P, I, P, I, P, P, I, C.POINTER(StT16View), I, I, P],
-    'st_skinny_linear_packed_sliced_fwd': [P, C.POINTER(StT16View), I, I, P, I, C.c_long, I, I, P],
     'st_lstm_seq_bwd': [P, I, I, P, P, P, P, P, I, I, I, I, P],
     'st_gru_seq_fwd': [P, P, P, P, P, P, P, I, P, I, I, I, I, P],
     'st_gru_seq_bwd': [P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, P],

@@ -453,16 +453,8 @@ class _DecoderFn(Function):
         bw.attn_v, bw.attn_loc_conv_w, bw.attn_loc_lin_w = ops._p(v), ops._p(wc), ops._p(wl)
         # the two big per-step products dgates . W stream W^T in MFMA lane order (packed once per backward)
         wt['q_p16'] = ops.pack_weight([wt['q']], [4 * Q], XQw)
-        # pure teacher forcing: the decoder cell's recurrence runs first on its own (phase 1: only W_hh_d^T is streamed per step),
-        # its input-side gradient for ALL steps is one GEMM, then the attention / query chain (phase 2)
-        split_loop = (not own) and dec.bwd_split_loop
-        if split_loop:
-            wt['d_hh_p16'] = ops.pack_weight([wt['d'][E + Q:]], [4 * D], D)
-            bw.d_w_hh_t_p16 = ops._p(wt['d_hh_p16'])
-        else:
-            wt['d_p16'] = ops.pack_weight([wt['d']], [4 * D], XDw)
-            bw.d_w_cat_t_p16 = ops._p(wt['d_p16'])
-        bw.q_w_cat_t_p16 = ops._p(wt['q_p16'])
+        wt['d_p16'] = ops.pack_weight([wt['d']], [4 * D], XDw)
+        bw.q_w_cat_t_p16, bw.d_w_cat_t_p16 = ops._p(wt['q_p16']), ops._p(wt['d_p16'])
         dgq_t16, dgd_t16 = zb['dgq_t16'], zb['dgd_t16']
         dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A, F=F, K=K, fuse_pre0=0)
         io = StDecoderBwdIO()
@@ -495,14 +487,6 @@ class _DecoderFn(Function):
             io.pre_w1_t, io.pre_w0_t, io.own_mask = ops._p(wt['w1']), ops._p(wt['w0']), ops._p(own_mask)
             io.xq_nat, io.pre1_nat = ops._p(XQ), ops._p(pre1_nat)
             io.d2_tape, io.dp1_tape, io.tmp_p, io.tmp_in = ops._p(d2_tape), ops._p(dp1_tape), ops._p(tmp_p), ops._p(tmp_in)
-        if split_loop:
-            n_sl = int(dec.bwd_d_slices)
-            dh_slabs = e_(n_sl, Bp, D)
-            io.phase, io.d_slices, io.dh_slabs = 1, n_sl, ops._p(dh_slabs)
-            _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
-            # d[ctx_t | adapted h_q_t] = dgates_d_t . W_ih_d for every step at once, written into the first E+Q columns of the dxd tape
-            ops.gemm(dgd.view(-1, 4 * D), wt['d'][:E + Q], out=dxd.view(-1, XDw)[:steps * Bp])
-            io.phase = 2
         _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
 
         # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)

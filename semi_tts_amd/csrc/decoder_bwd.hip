@@ -59,35 +59,11 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
     ST_CHECK_ARG(!own || (io->dY && io->dxo_rw && io->wpg_t && io->pre_w1_t && io->pre_w0_t && io->xq_nat && io->pre1_nat &&
                           io->d2_tape && io->dp1_tape && io->tmp_p && io->tmp_in && io->Bt > 0 && io->Bt <= B),
                  "st_decoder_backward: own-output feedback needs the prenet tapes / scratch");
-    const bool packed = w->q_w_cat_t_p16 && (w->d_w_cat_t_p16 || io->phase != 0) && io->dgq_t16 && io->dgd_t16;
-    const int phase = io->phase;
-    ST_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 0 || !own), "st_decoder_backward: phase=%d (the split loop needs pure teacher forcing)", phase);
-    ST_CHECK_ARG(phase != 1 || (w->d_w_hh_t_p16 && io->dh_slabs && io->dgd_t16 && io->d_slices >= 1 && io->d_slices <= 8),
-                 "st_decoder_backward: phase 1 needs the packed W_hh_d^T, the slab scratch and 1..8 slices");
+    const bool packed = w->q_w_cat_t_p16 && w->d_w_cat_t_p16 && io->dgq_t16 && io->dgd_t16;
     st_t16_view dgq_v = {io->dgq_t16, (4 * Q + 15) >> 4, 0}, dgd_v = {io->dgd_t16, (4 * D + 15) >> 4, 0};
     const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
     const int ldal = steps * L;
     int rc;
-    if (phase == 1) {
-        // The decoder cell's backward recurrence on its own: dh_d_t = dxo_t[:, :D] + dgates_d_{t+1} . W_hh_d needs nothing from the
-        // attention / query chain, and under teacher forcing nothing of step t+1's chain needs dxd_{t+1} before the whole d-chain is
-        // done.  Per step: a pointwise launch (adds the slabs of the previous product) and a K-sliced product over W_hh_d^T only
-        // (16.8 MB instead of the 42.9 MB of [W_ih_d | W_hh_d]^T); dxd[:, :E+Q] = dgd . W_ih_d follows as ONE GEMM over all steps.
-        st_t16_view dgd_t = {io->dgd_t16, (4 * D + 15) >> 4, 0};
-        const long slab = (long)Bp * D;
-        for (int t = steps - 1; t >= 0; --t) {
-            rc = st_lstm_cell_bwd_pointwise_slabs(io->dxo + (size_t)t * Bp * XO, XO, io->dh_slabs, D, t + 1 < steps ? io->d_slices : 0, slab,
-                                                  io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
-                                                  io->gates_d_tape + (size_t)t * 4 * BD, io->cd_tape + (size_t)(t + 1) * BD, D,
-                                                  io->cd_tape + (size_t)t * BD, D, io->dcd, io->dgd + (size_t)t * Bp * 4 * D, 4 * D, &dgd_t,
-                                                  B, D, stream);
-            if (rc) return rc;
-            if (t == 0) break;
-            rc = st_skinny_linear_packed_sliced_fwd(w->d_w_hh_t_p16, &dgd_t, 4 * D, io->d_slices, io->dh_slabs, D, slab, B, D, stream);
-            if (rc) return rc;
-        }
-        return 0;
-    }
     for (int t = steps - 1; t >= 0; --t) {
         const float* dxo = io->dxo + (size_t)t * Bp * XO;
         float* dxd = io->dxd + (size_t)t * Bp * XD;
@@ -133,16 +109,15 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                                       B, XO, stream);
             if (rc) return rc;
         }
-        // a. decoder LSTM pointwise  (phase 2: a + b ran for all steps already, dxd holds dgates_d . W_ih_d)
-        if (phase == 0) rc = st_lstm_cell_bwd_pointwise(dxo, XO, dxd_next + E + Q, XD, nullptr, 0, nullptr,
+        // a. decoder LSTM pointwise
+        rc = st_lstm_cell_bwd_pointwise(dxo, XO, dxd_next + E + Q, XD, nullptr, 0, nullptr,
                                         io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                         io->gates_d_tape + (size_t)t * 4 * BD, io->cd_tape + (size_t)(t + 1) * BD, D,
                                         io->cd_tape + (size_t)t * BD, D, io->dcd, dgd, 4 * D, packed ? &dgd_v : nullptr, B, D, stream);
         if (rc) return rc;
         // b. gradient w.r.t. [ctx_t | adapted h_q_t | h_d_{t-1}]
         st_seg seg;
-        if (phase == 2) rc = 0;
-        else if (packed) {   // W^T streamed in MFMA lane order (P16), dgates in T16
+        if (packed) {   // W^T streamed in MFMA lane order (P16), dgates in T16
             rc = st_skinny_linear_packed_fwd(w->d_w_cat_t_p16, &dgd_v, 4 * D, nullptr, ST_ACT_NONE, nullptr, 0, dxd, XD, nullptr,
                                              0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XD, stream);
         } else {

@@ -357,7 +357,6 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const Gru
 // element-wise, then the dropout mask) and the carried dc_t to the pre-activation gate gradients and dc_{t-1}.
 struct LstmPwArgs {
     const float* dh0; int ld0; const float* dh1; int ld1; const float* dh2; int ld2; const float* scale2;
-    int n1; long st1;                  // dh1 is the sum of n1 (1..8) slabs, st1 floats apart (partial products of a K-sliced linear)
     const float* mask;                 // (B, H) contiguous, may be NULL
     const float* gates;                // (B, 4, H) activated (i, f, g, o)
     const float* c; int ldc;           // c_t
@@ -380,14 +379,7 @@ __device__ __forceinline__ void lstm_bwd_pw_body(const LstmPwArgs& a) {
         // replaced by their neutral value): a chain of `if (p) dh += p[i]` would wait for every load in turn
         const float* dummy = a.dh0 + (size_t)b * a.ld0 + u;
         const float l0 = dummy[0];
-        float l1 = (a.dh1 ? a.dh1 + (size_t)b * a.ld1 + u : dummy)[0];
-        if (a.n1 > 1) {                // slabs added in index order (all requested before the first add)
-            float ls1[7];
-#pragma unroll
-            for (int s = 1; s < 8; ++s) ls1[s - 1] = (s < a.n1 ? a.dh1 + (size_t)s * a.st1 + (size_t)b * a.ld1 + u : dummy)[0];
-#pragma unroll
-            for (int s = 1; s < 8; ++s) if (s < a.n1) l1 += ls1[s - 1];
-        }
+        const float l1 = (a.dh1 ? a.dh1 + (size_t)b * a.ld1 + u : dummy)[0];
         const float l2 = (a.dh2 ? a.dh2 + (size_t)b * a.ld2 + u : dummy)[0];
         const float ls = (a.scale2 ? a.scale2 + i : dummy)[0];
         const float lm = (a.mask ? a.mask + i : dummy)[0];
@@ -528,26 +520,6 @@ extern "C" int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float
     ST_CHECK_ARG(dh0 && gates && c && dc && dgates && B > 0 && H > 0, "st_lstm_cell_bwd_pointwise: bad arguments");
     LstmPwArgs a;
     a.dh0 = dh0; a.ld0 = ld0; a.dh1 = dh1; a.ld1 = ld1; a.dh2 = dh2; a.ld2 = ld2; a.scale2 = scale2; a.mask = mask;
-    a.gates = gates; a.c = c; a.ldc = ldc; a.c_prev = c_prev; a.ldcp = ldcp; a.dc = dc; a.dgates = dgates; a.ldg = ldg;
-    a.dg_t16 = dgates_t16 ? dgates_t16->base : nullptr;
-    a.t16_kbs = dgates_t16 ? dgates_t16->kb_stride : 0; a.t16_kb0 = dgates_t16 ? dgates_t16->kb0 : 0;
-    a.B = B; a.H = H; a.n1 = 1; a.st1 = 0;
-    const int blocks = (B * H + 255) / 256;
-    hipLaunchKernelGGL(lstm_bwd_pw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    ST_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int st_lstm_cell_bwd_pointwise_slabs(const float* dh0, int ld0, const float* dh1_slabs, int ld1, int n_slabs, long slab_stride,
-                                                const float* mask, const float* gates, const float* c, int ldc,
-                                                const float* c_prev, int ldcp, float* dc, float* dgates, int ldg,
-                                                const st_t16_view* dgates_t16, int B, int H, void* stream) {
-    (void)hipGetLastError();
-    ST_CHECK_ARG(dh0 && gates && c && dc && dgates && B > 0 && H > 0, "st_lstm_cell_bwd_pointwise_slabs: bad arguments");
-    ST_CHECK_ARG(n_slabs >= 0 && n_slabs <= 8 && (n_slabs == 0 || dh1_slabs), "st_lstm_cell_bwd_pointwise_slabs: %d slabs (0..8)", n_slabs);
-    LstmPwArgs a;
-    a.dh0 = dh0; a.ld0 = ld0; a.dh1 = n_slabs > 0 ? dh1_slabs : nullptr; a.ld1 = ld1; a.dh2 = nullptr; a.ld2 = 0; a.scale2 = nullptr;
-    a.mask = mask; a.n1 = n_slabs; a.st1 = slab_stride;
     a.gates = gates; a.c = c; a.ldc = ldc; a.c_prev = c_prev; a.ldcp = ldcp; a.dc = dc; a.dgates = dgates; a.ldg = ldg;
     a.dg_t16 = dgates_t16 ? dgates_t16->base : nullptr;
     a.t16_kbs = dgates_t16 ? dgates_t16->kb_stride : 0; a.t16_kb0 = dgates_t16 ? dgates_t16->kb0 : 0;

@@ -510,22 +510,6 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const f32x4* w, const f32x4
     pk_body<MODE, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red);
 }
 
-// K-sliced linear: blockIdx.z picks a range of k-blocks, every slice writes its partial product to its own slab of y (the consumer
-// adds the slabs in index order).  A skinny product whose row tiles x batch tiles do not fill the chip (N = 1024, B = 32: 128
-// workgroups, each bound by what ONE compute unit pulls in -- its 16 rows x K weights) runs on 2-4x the compute units this way.
-template <int NB, int KW, int TRIP>
-__global__ __launch_bounds__(KW * 64) void pk_sliced_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
-                                                            const int B, const int N, const int kb_per_slice, const long slab_stride,
-                                                            const PkArgs rest) {
-    __shared__ f32x4 red[KW * NB * 64];
-    PkArgs a = rest;
-    const int z = blockIdx.z, kb0 = z * kb_per_slice;
-    a.w = w + (size_t)kb0 * 64; a.x = x + (size_t)kb0 * 64; a.w_kbs = w_kbs; a.x_kbs = x_kbs;
-    a.KB = min(kb_per_slice, KB - kb0); a.B = B; a.N = N; a.H = 0;
-    a.y = rest.y + (size_t)z * slab_stride;
-    pk_body<1, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red);
-}
-
 // The proj (+) gate launch of decode step t with, on the compute units it leaves idle, the part of the attention of step t+1
 // that only needs the attention weights of step t (location conv + W_l + processed memory -> S): one workgroup per
 // utterance after the linear's workgroups.  The attention launch of step t+1 then starts from S.
@@ -939,26 +923,6 @@ extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_v
     (void)hipGetLastError();
     return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
                           n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, stream);
-}
-
-extern "C" int st_skinny_linear_packed_sliced_fwd(const float* packed_w, const st_t16_view* x, int K, int slices,
-                                                  float* y_slabs, int ldy, long slab_stride, int B, int N, void* stream) {
-    (void)hipGetLastError();
-    ST_CHECK_ARG(y_slabs && B > 0 && N > 0 && ldy >= N && slices >= 1 && slices <= 8 && slab_stride >= (long)B * ldy,
-                 "st_skinny_linear_packed_sliced_fwd: bad arguments (slices 1..8)");
-    PkArgs a;
-    memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, x, K, "st_skinny_linear_packed_sliced_fwd");
-    if (rc) return rc;
-    a.B = B; a.N = N; a.H = 0; a.act = ST_ACT_NONE;
-    a.y = y_slabs; a.ldy = ldy;
-    const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
-    const int per = (a.KB + slices - 1) / slices;
-    ST_CHECK_ARG((slices - 1) * per < a.KB, "st_skinny_linear_packed_sliced_fwd: %d slices of %d k-blocks leave an empty slice", slices, a.KB);
-    hipLaunchKernelGGL((pk_sliced_kernel<1, 8, 2>), dim3(tiles, BT, slices), dim3(8 * 64), 0, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs,
-                       a.KB, a.B, a.N, per, slab_stride, a);
-    ST_LAUNCH_CHECK();
-    return 0;
 }
 
 extern "C" int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,

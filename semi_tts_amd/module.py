@@ -312,8 +312,6 @@ class Decoder(nn.Module):
         self.handoff_status = None
         self.attn_split_min_len = 128     # texts at least this long: fin part over position ranges (~attn_split_positions each) + combine
         self.attn_split_positions = 43
-        self.bwd_split_loop = True   # training, pure teacher forcing: decoder-cell recurrence of the backward pass as its own loop
-        self.bwd_d_slices = 4        # K slices of its per-step product dgates . W_hh^T (128 -> 512 workgroups)
         self.attn_rng_one_launch = True   # long texts: query projection + fin part over position ranges + combine in one launch
 
     # -- helpers ---------------------------------------------------------------------------------

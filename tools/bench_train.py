@@ -24,8 +24,6 @@ def main():
     ap.add_argument('--batch-size', type=int, default=32)
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--config', default='config/semi-single-spkr-paired-data.yaml')
-    ap.add_argument('--d-slices', type=int, default=None, help='K slices of the decoder-cell recurrence product of the backward pass')
-    ap.add_argument('--no-split-loop', action='store_true', help='single backward loop (the round-2 organisation)')
     a = ap.parse_args()
     from semi_tts_amd.solver import TtsTrainer
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,10 +32,6 @@ def main():
                       max_step=a.steps + a.warmup, load=None)
     tr = TtsTrainer(config, paras, 'train').load_data().set_model()
     text, sid, mel, linear = (t.to(tr.device) for t in tr.batches[0])
-    if a.d_slices:
-        tr.model.tts.decoder.bwd_d_slices = a.d_slices
-    if a.no_split_loop:
-        tr.model.tts.decoder.bwd_split_loop = False
     phases = dict(fwd=0.0, bwd=0.0, opt=0.0)
     sync = torch.cuda.synchronize
     stats = None

@@ -287,6 +287,25 @@ int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int 
  * ref: nn.BatchNorm1d in training mode, src/module.py:429,:531 */
 int st_bn_stats(const float* X, int ldx, int coff, int M, int N, float* mean_out, float* var_out,
                 float* run_mean, float* run_var, float momentum, long long* batches_tracked, float* ws, void* stream);
+/* nn.LayerNorm over the last dimension of (M, N) rows: y = (x - mean) / sqrt(var + eps) * gamma + beta (biased variance, two passes
+ * as ATen); mean_out / rstd_out (M) optional, kept for the backward.  ref: the speech encoder's `layer_norm` src/asr.py:38-39,58; the
+ * normalised prenet Linear src/module.py:508-521 */
+int st_layer_norm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float* y, int ldy,
+                      float* mean_out, float* rstd_out, int M, int N, void* stream);
+/* dx of the above; dyxhat (optional, (M, N) contiguous) = dy * xhat, whose column sum is d gamma (d beta = column sum of dy) */
+int st_layer_norm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
+                      const float* rstd, float* dx, int lddx, float* dyxhat, int M, int N, void* stream);
+/* log_softmax over the last dimension of (M, N) contiguous rows and its backward dx = dy - exp(y) * sum_n dy.
+ * ref: ASRPostnet.forward src/asr.py:80 */
+int st_log_softmax_fwd(const float* x, float* y, int M, int N, void* stream);
+int st_log_softmax_bwd(const float* dy, const float* y, float* dx, int M, int N, void* stream);
+/* One normalised prenet layer of a decode step after its Linear (the reference's Linear wrapper with norm_type, applied to the
+ * (B, P) rows of ONE step: src/module.py:192,:508-521,:337-339): dst (T16) = relu(norm(y)) * mask.
+ * mode 1: LayerNorm over the P columns; mode 2: BatchNorm1d with running statistics (eval); mode 3: BatchNorm1d with the
+ * statistics of the step's B rows, running statistics updated in place (momentum, unbiased variance), batches_tracked += 1. */
+int st_prenet_norm_fwd(const float* y, int ldy, int mode, const float* gamma, const float* beta, float* run_mean,
+                       float* run_var, long long* batches_tracked, float eps, float momentum, const float* mask, int ldmask,
+                       const st_t16_view* dst, int B, int P, void* stream);
 /* X(m, coff+n) = act((X - mean) / sqrt(var + eps) * w + b), in place */
 int st_bn_apply(float* X, int ldx, int coff, int M, int N, const float* mean, const float* var,
                 const float* w, const float* b, float eps, int act, void* stream);
@@ -464,6 +483,11 @@ typedef struct st_decoder_weights {
     const float* d_b_ih; const float* d_b_hh;
     const float* projgate_w;     /* cat[proj.linear.weight; gate_layer.linear.weight] (r*n_mels+1, D+E) */
     const float* projgate_b;     /* cat[proj.linear.bias; gate_layer.linear.bias]                      */
+    /* normalised prenet (st_decoder_dims.prenet_norm != 0; the reference's Linear wrapper with norm_type, src/module.py:508-521):
+     * per layer the norm's weight / bias and, for BatchNorm1d, its running statistics and batch counter */
+    const float* pre_norm_w[2]; const float* pre_norm_b[2];
+    float* pre_norm_rm[2]; float* pre_norm_rv[2]; long long* pre_norm_nbt[2];
+    float pre_norm_eps, pre_norm_momentum;
 } st_decoder_weights;
 
 typedef struct st_decoder_dims {
@@ -472,6 +496,10 @@ typedef struct st_decoder_dims {
      * projgate_w/_b carry P extra rows  W_pre0 . W_proj  /  W_pre0 . b_proj, so the proj/gate launch
      * also emits relu(prenet layer 1) of the next step (same function, re-associated in fp32). */
     int fuse_pre0;
+    /* 0: plain prenet.  1 LayerNorm / 2 BatchNorm1d (eval) / 3 BatchNorm1d (training: statistics of a step's B rows) between
+     * each prenet Linear and its ReLU (st_prenet_norm_fwd): the own-output prenet of the loop then runs as Linear, norm launch,
+     * Linear, norm launch; fuse_pre0 must be 0 and st_decoder_io.pre_nat given */
+    int prenet_norm;
 } st_decoder_dims;
 
 typedef struct st_decoder_io {
@@ -527,6 +555,9 @@ typedef struct st_decoder_io {
     int attn_split_parts;
     unsigned long long* pq_granules;   /* optional (B, A) 64-bit words: with attn_s_buf, the query projection and the attention fin
                                         * part of a step run as ONE launch (st_query_attn_fin_fwd); zeroed by the callee per forward */
+    const float* dec_in0;              /* optional (B, P) natural: the input of step 0 = prenet(go frame).  NULL = zeros, which is what a
+                                        * plain prenet makes of the all-zero go frame (src/module.py:161,183); a normalised prenet does not */
+    float* pre_nat;                    /* (B, P) scratch, natural layout: the Linear output of a normalised prenet layer (prenet_norm != 0) */
     unsigned long long* attn_xchg;     /* optional, st_attn_rng_xchg_words(B, E, attn_split_parts) 64-bit words: with pq_granules and
                                         * attn_split_parts in 2..8, long texts run query projection + fin part over position ranges +
                                         * combine as ONE launch per step (st_query_attn_rng_fwd) when it fits the device; zeroed by the
@@ -611,6 +642,8 @@ typedef struct st_decoder_bwd_io {
     const float* pre1_nat;            /* (steps, Bp, P) un-tiled prenet layer-1 outputs */
     float* d2_tape; float* dp1_tape;  /* (steps, Bp, P) out, zero on entry: gradients at the two prenet layers (-> dW1, dW0) */
     float* tmp_p; float* tmp_in;      /* (B, P), (B, r*n_mels) scratch */
+    int need_dxq0;                    /* != 0: also form dxq of step 0 (the gradient of dec_in_0 = prenet(go frame), which only a
+                                       * normalised prenet makes non-constant) */
     const float* attn_s_tape;         /* optional (steps, B, L, A): S_t = pm + W_l loc_t saved by the forward (slot 0 unused: S_0 =
                                        * pm).  Then loc_tape is an INPUT (the forward's attn_loc_tape) and the attention backward
                                        * neither recomputes the location conv nor the W_l product. */

@@ -66,10 +66,23 @@ def ctc_forward(W: Dict[str, Tensor], x: Tensor, cfg: dict, training: bool = Fal
     for l, (s, r) in enumerate(zip(cfg['stride'], cfg['residual'])):                                       # :51-52
         x = conv_layer(W, x, prefix + 'layer%d' % l, s, bool(r), cfg['batch_norm'], cfg['activation'], training,
                        cfg['dropout'], drop, stats_out)
-    assert cfg['rnn_bid'] and not cfg['layer_norm']
+    assert cfg['rnn_bid']
     for layer in range(cfg['rnn_layers']):                                                                 # :56
         x = torch.cat([lstm_layer_n(x, W, prefix + 'rnn', layer, False), lstm_layer_n(x, W, prefix + 'rnn', layer, True)], -1)
         if layer + 1 < cfg['rnn_layers']:
             x = drop(x, cfg['dropout'], training)       # nn.LSTM inter-layer dropout (identity in the parity cases)
+    if cfg['layer_norm']:                                                                                  # :57-58
+        x = torch.nn.functional.layer_norm(x, (x.shape[-1],), W[prefix + 'norm_layer.weight'], W[prefix + 'norm_layer.bias'], 1e-5)
     x = drop(x, cfg['dropout'], training)                                                                  # :62
     return x.matmul(W[prefix + 'postnet.weight'].t()) + W[prefix + 'postnet.bias']
+
+
+def asr_postnet_forward(W: Dict[str, Tensor], x: Tensor, training: bool = False, drop: Optional[DropoutSource] = None,
+                        prefix: str = '') -> Tensor:
+    """ASRPostnet: 2-layer BiLSTM (inter-layer dropout 0.5) -> dropout 0.5 -> Linear -> log_softmax.   ref: src/asr.py:67-80"""
+    drop = drop or DropoutSource('off')
+    for layer in range(2):
+        x = torch.cat([lstm_layer_n(x, W, prefix + 'rnn', layer, False), lstm_layer_n(x, W, prefix + 'rnn', layer, True)], -1)
+        x = drop(x, 0.5, training)          # after layer 0: nn.LSTM(dropout=0.5); after layer 1: self.dropout         :78-79
+    x = x.matmul(W[prefix + 'linear.weight'].t()) + W[prefix + 'linear.bias']
+    return torch.log_softmax(x, dim=-1)                                                                    # :80

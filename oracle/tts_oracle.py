@@ -210,12 +210,26 @@ def encoder_forward(W: Weights, txt_embed: Tensor, prefix: str = 'encoder.',
 
 # --------------------------------------------------------------------------- decoder
 def prenet_forward(W: Weights, x: Tensor, p: float, drop: DropoutSource,
-                   prefix: str = 'decoder.prenet.') -> Tensor:
+                   prefix: str = 'decoder.prenet.', norm_type: Optional[str] = None, training: bool = False,
+                   stats_out: Optional[dict] = None) -> Tensor:
     """Prenet: per layer relu(Linear_nobias(x)) then dropout with training=True ALWAYS.
-    ref: src/module.py:320-340 (:339 'The dropout does NOT turn off')."""
+    ref: src/module.py:320-340 (:339 'The dropout does NOT turn off').
+    norm_type 'LayerNorm' / 'BatchNorm1d': the Linear wrapper normalises its output before the ReLU (src/module.py:508-521;
+    BatchNorm1d sees a (B, T, C) input transposed and a (B, C) input as it is: statistics over every leading row in both cases;
+    in training mode the running statistics move on -- `stats_out`, fed back through W by the caller for per-step use)."""
     i = 0
     while (prefix + 'layers.%d.linear.weight' % i) in W:
-        x = torch.relu(linear(x, W[prefix + 'layers.%d.linear.weight' % i]))
+        x = linear(x, W[prefix + 'layers.%d.linear.weight' % i])
+        pn = prefix + 'layers.%d.norm' % i
+        if norm_type == 'LayerNorm':
+            x = F.layer_norm(x, (x.shape[-1],), W[pn + '.weight'], W[pn + '.bias'], 1e-5)
+        elif norm_type == 'BatchNorm1d':
+            lead = x.shape[:-1]
+            so = {} if (training and stats_out is None) else stats_out
+            x = batchnorm_cl(x.reshape(1, -1, x.shape[-1]), W, pn, 1e-5, 0.1, training, so).reshape(*lead, -1)
+            if training and so is not None:         # the next call of this layer (the next decode step) sees the updated statistics
+                W[pn + '.running_mean'], W[pn + '.running_var'] = so[pn + '.running_mean'], so[pn + '.running_var']
+        x = torch.relu(x)
         x = drop(x, p, True)
         i += 1
     return x
@@ -312,7 +326,7 @@ def decode_one_step(W: Weights, st: DecoderState, dec_in: Tensor, spkr_embed: Te
 def decoder_forward(W: Weights, memory: Tensor, teacher: Union[int, Tensor], spkr_embed: Tensor,
                     hp: dict, tf_rate: float = 0.0, unpair_max_frame: Optional[int] = None,
                     training: bool = False, drop: Optional[DropoutSource] = None,
-                    coin: Callable[[], float] = np.random.rand, prefix: str = 'decoder.'):
+                    coin: Callable[[], float] = np.random.rand, prefix: str = 'decoder.', stats_out: Optional[dict] = None):
     """ref: Decoder.forward, src/module.py:140-214.
 
     hp: the `model.decoder.decoder` section of the YAML (n_frames_per_step, prenet_dropout,
@@ -323,6 +337,9 @@ def decoder_forward(W: Weights, memory: Tensor, teacher: Union[int, Tensor], spk
     drop = drop or DropoutSource('off')
     r, n_mels = hp['n_frames_per_step'], hp['n_mels']
     p_pre, p_q, p_d = hp['prenet_dropout'], hp['query_dropout'], hp['dec_dropout']
+    pn_type = hp.get('prenet_norm_type')
+    if pn_type == 'BatchNorm1d' and training:
+        W = dict(W)                # the running statistics of the prenet's BatchNorm move with every call
     B = memory.shape[0]
     Q = W[prefix + 'query_rnn.weight_hh'].shape[1]
     D = W[prefix + 'dec_rnn.weight_hh'].shape[1]
@@ -342,9 +359,9 @@ def decoder_forward(W: Weights, memory: Tensor, teacher: Union[int, Tensor], spk
         else:
             steps = teacher.shape[1] // r                                             # :177
         teacher = teacher.reshape(teacher.shape[0], -1, n_mels * r)                   # :178
-        teacher = prenet_forward(W, teacher, p_pre, drop, prefix + 'prenet.')         # :179
+        teacher = prenet_forward(W, teacher, p_pre, drop, prefix + 'prenet.', pn_type, training, stats_out)         # :179
     mels, aligns, stops = [], [], []
-    dec_in = prenet_forward(W, torch.zeros(B, r * n_mels), p_pre, drop, prefix + 'prenet.')   # :161,:183
+    dec_in = prenet_forward(W, torch.zeros(B, r * n_mels), p_pre, drop, prefix + 'prenet.', pn_type, training, stats_out)   # :161,:183
     for t in range(steps):
         mel, al, stop = decode_one_step(W, st, dec_in, spkr_embed, r, n_mels, p_q, p_d, training, drop, prefix,
                                         hp.get('spkr_embed_mode', 'adaIN').lower(), bool(hp.get('pretrain', False)))
@@ -352,18 +369,18 @@ def decoder_forward(W: Weights, memory: Tensor, teacher: Union[int, Tensor], spk
         aligns.append(al)
         stops.append(stop)
         if inference or (coin() > tf_rate):                                           # :190
-            dec_in = prenet_forward(W, mel.reshape(B, r * n_mels), p_pre, drop, prefix + 'prenet.')   # :192
+            dec_in = prenet_forward(W, mel.reshape(B, r * n_mels), p_pre, drop, prefix + 'prenet.', pn_type, training, stats_out)   # :192
         elif coin() < hp.get('drop_dec_in', 0.0):                                     # :193
             dec_in = teacher.mean(dim=1)                                              # :194
             if partial_no_teacher:
                 own = mel[teacher_bs:].reshape(-1, r * n_mels)
-                dec_in = torch.cat([dec_in, prenet_forward(W, own, p_pre, drop, prefix + 'prenet.')], dim=0)
+                dec_in = torch.cat([dec_in, prenet_forward(W, own, p_pre, drop, prefix + 'prenet.', pn_type, training, stats_out)], dim=0)
         else:
             take = min(t, teacher.shape[1] - 1)                                       # :201
             dec_in = teacher[:, take, :]                                              # :202
             if partial_no_teacher:                                                    # :204-206
                 own = mel[teacher_bs:].reshape(-1, r * n_mels)
-                dec_in = torch.cat([dec_in, prenet_forward(W, own, p_pre, drop, prefix + 'prenet.')], dim=0)
+                dec_in = torch.cat([dec_in, prenet_forward(W, own, p_pre, drop, prefix + 'prenet.', pn_type, training, stats_out)], dim=0)
     mel_out = torch.cat(mels, dim=1)                                                  # :209
     align = torch.stack(aligns).transpose(0, 1)                                       # :211
     stop_out = torch.cat(stops, dim=1)                                                # :213
@@ -453,7 +470,7 @@ def tacotron2_forward(W: Weights, txt_embed: Tensor, teacher: Union[int, Tensor]
     drop = drop or DropoutSource('off')
     enc = encoder_forward(W, txt_embed, 'encoder.', training, hp.get('enc_dropout', 0.0), drop, stats_out)   # :44
     mel, align, stop = decoder_forward(W, enc, teacher, spkr_embed, hp, tf_rate, unpair_max_frame,
-                                       training, drop, coin, 'decoder.')                                   # :45-46
+                                       training, drop, coin, 'decoder.', stats_out)                        # :45-46
     lin = postnet_forward(W, mel, training, stats_out) if 'postnet.1.weight' in W else None                 # :47-50
     return mel, lin, align, stop
 

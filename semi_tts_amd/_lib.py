@@ -35,11 +35,13 @@ class StDecoderWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'prenet_w0', 'prenet_w1', 'q_w_ih', 'q_w_hh', 'q_b_ih', 'q_b_hh',
         'attn_query_w', 'attn_v', 'attn_loc_conv_w', 'attn_loc_lin_w',
-        'd_w_ih', 'd_w_hh', 'd_b_ih', 'd_b_hh', 'projgate_w', 'projgate_b')]
+        'd_w_ih', 'd_w_hh', 'd_b_ih', 'd_b_hh', 'projgate_w', 'projgate_b')] + [
+        ('pre_norm_w', C.c_void_p * 2), ('pre_norm_b', C.c_void_p * 2), ('pre_norm_rm', C.c_void_p * 2), ('pre_norm_rv', C.c_void_p * 2),
+        ('pre_norm_nbt', C.c_void_p * 2), ('pre_norm_eps', C.c_float), ('pre_norm_momentum', C.c_float)]
 
 
 class StDecoderDims(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ('B', 'L', 'E', 'n_mels', 'r', 'P', 'Q', 'D', 'A', 'F', 'K', 'fuse_pre0')]
+    _fields_ = [(n, C.c_int) for n in ('B', 'L', 'E', 'n_mels', 'r', 'P', 'Q', 'D', 'A', 'F', 'K', 'fuse_pre0', 'prenet_norm')]
 
 
 class StDecoderIO(C.Structure):
@@ -57,7 +59,7 @@ class StDecoderIO(C.Structure):
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('attn_fin_parts', C.c_int), ('defer_proj', C.c_int),
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p),
                 ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p),
-                ('attn_xchg', C.c_void_p), ('handoff_status', C.c_void_p)]
+                ('dec_in0', C.c_void_p), ('pre_nat', C.c_void_p), ('attn_xchg', C.c_void_p), ('handoff_status', C.c_void_p)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -74,7 +76,8 @@ class StDecoderBwdIO(C.Structure):
                 [('dhist', C.c_void_p * 2), ('dcum', C.c_void_p), ('dhq_attn', C.c_void_p), ('dgq_t16', C.c_void_p),
                  ('dgd_t16', C.c_void_p), ('step_src', C.POINTER(C.c_int)), ('Bt', C.c_int)] +
                 [(n, C.c_void_p) for n in ('dY', 'dxo_rw', 'wpg_t', 'pre_w1_t', 'pre_w0_t', 'own_mask', 'xq_nat', 'pre1_nat',
-                                           'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in', 'attn_s_tape')])
+                                           'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in')] +
+                [('need_dxq0', C.c_int), ('attn_s_tape', C.c_void_p)])
 
 
 
@@ -152,6 +155,11 @@ SIGNATURES = {
     'st_attn_fin_split_workspace_floats': [I, I, I],
     'st_attn_fin_split_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, P, I, I, I, I, I, P],
     'st_query_attn_fin_fwd': [P, C.POINTER(StT16View), I, P, C.c_uint, C.POINTER(StAttnFinJob), I, P],
+    'st_layer_norm_fwd': [P, I, P, P, F, P, I, P, P, I, I, P],
+    'st_layer_norm_bwd': [P, I, P, I, P, P, P, P, I, P, I, I, P],
+    'st_log_softmax_fwd': [P, P, I, I, P],
+    'st_log_softmax_bwd': [P, P, P, I, I, P],
+    'st_prenet_norm_fwd': [P, I, I, P, P, P, P, P, F, F, P, I, C.POINTER(StT16View), I, I, P],
     'st_handoff_wait_selftest': [P, C.c_uint, I, P, P, I, P],
     'st_query_attn_rng_fits': [I, I, I],
     'st_attn_rng_xchg_words': [I, I, I],

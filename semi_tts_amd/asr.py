@@ -77,11 +77,12 @@ class CTC(nn.Module):
             setattr(self, 'layer' + str(l), ConvLayer(self.dim[l], self.dim[l + 1], kernel[l], stride[l], residual[l],
                                                       batch_norm, activation, dropout))
         assert rnn_dim > 0
-        if not rnn_bid or layer_norm:
-            raise NotImplementedError('the HIP speech encoder implements the bidirectional LSTM without LayerNorm '
-                                      '(every shipped config)')
+        if not rnn_bid:
+            raise NotImplementedError('the HIP speech encoder implements the bidirectional LSTM (every shipped config)')
         self.rnn = nn.LSTM(self.dim[-1], rnn_dim, num_layers=rnn_layers, dropout=dropout, bidirectional=True, batch_first=True)
         self.rnn_layers = rnn_layers
+        if self.layer_norm:
+            self.norm_layer = nn.LayerNorm(2 * rnn_dim)                                        # :38-39
         self.drop = nn.Dropout(dropout)
         self.postnet = nn.Linear(2 * rnn_dim, out_dim)
 
@@ -99,6 +100,9 @@ class CTC(nn.Module):
                 xp_f = AG.conv(x, g('weight_ih', False), g('bias_ih', False))
                 xp_b = AG.conv(x, g('weight_ih', True), g('bias_ih', True))
                 x = AG.bilstm(xp_f, xp_b, g('weight_hh', False), g('bias_hh', False), g('weight_hh', True), g('bias_hh', True))
+                last = layer == self.rnn_layers - 1
+                if last and self.layer_norm:
+                    x = AG.layer_norm(x, self.norm_layer)                                    # :57-58 (before self.drop)
                 if p > 0:   # inter-layer dropout of nn.LSTM, and (after the last layer) the dropout in front of the projection
                     x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)
             return AG.conv(x, self.postnet.weight, self.postnet.bias)
@@ -108,6 +112,44 @@ class CTC(nn.Module):
             xp = [ops.gemm(x, g('weight_ih', rev), bias=g('bias_ih', rev)) for rev in (False, True)]
             ops.lstm_seq2(xp[0], xp[1], g('weight_hh', False), g('weight_hh', True), g('bias_hh', False), g('bias_hh', True), out)
             x = out
+            if layer == self.rnn_layers - 1 and self.layer_norm:
+                ln = self.norm_layer
+                x = ops.layer_norm(x.view(-1, 2 * H), ln.weight, ln.bias, ln.eps).view(B, T, 2 * H)
             if p > 0:   # inter-layer dropout of nn.LSTM and the dropout in front of the projection (:62)
                 x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)
         return ops.gemm(x, self.postnet.weight, bias=self.postnet.bias)
+
+
+class ASRPostnet(nn.Module):
+    """2-layer BiLSTM(latent -> latent, inter-layer dropout 0.5) -> dropout 0.5 -> Linear(2 latent -> vocab) -> log_softmax.
+    ref: src/asr.py:67-80 (state_dict keys `rnn.*`, `linear.*`).  Runs on the encoder's sequence kernels; differentiable whenever
+    gradients are enabled (the two dropouts only in training mode; `_masks` = explicit scaled masks for tests)."""
+
+    def __init__(self, latent_dim, vocab_size):
+        super().__init__()
+        self.rnn = nn.LSTM(latent_dim, latent_dim, num_layers=2, dropout=0.5, bidirectional=True, batch_first=True)
+        self.dropout = nn.Dropout(0.5)
+        self.linear = nn.Linear(latent_dim * 2, vocab_size)
+
+    def forward(self, x, _masks=None):
+        x = x.contiguous()
+        B, T, _ = x.shape
+        H = self.rnn.hidden_size
+        p = 0.5 if self.training else 0.0
+        grad = torch.is_grad_enabled()
+        for layer in range(2):
+            g = lambda n, rev: getattr(self.rnn, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))
+            if grad:
+                xp_f = AG.conv(x, g('weight_ih', False), g('bias_ih', False))
+                xp_b = AG.conv(x, g('weight_ih', True), g('bias_ih', True))
+                x = AG.bilstm(xp_f, xp_b, g('weight_hh', False), g('bias_hh', False), g('weight_hh', True), g('bias_hh', True))
+            else:
+                out = torch.empty(B, T, 2 * H, device=x.device, dtype=torch.float32)
+                xp = [ops.gemm(x, g('weight_ih', rev), bias=g('bias_ih', rev)) for rev in (False, True)]
+                ops.lstm_seq2(xp[0], xp[1], g('weight_hh', False), g('weight_hh', True), g('bias_hh', False), g('bias_hh', True), out)
+                x = out
+            if p > 0 or _masks is not None:   # nn.LSTM's inter-layer dropout after layer 0, self.dropout after layer 1
+                x = x * (_masks[layer] if _masks is not None else torch.empty_like(x).bernoulli_(1 - p).div_(1 - p))
+        if grad:
+            return AG.log_softmax(AG.conv(x, self.linear.weight, self.linear.bias))
+        return ops.log_softmax(ops.gemm(x, self.linear.weight, bias=self.linear.bias))

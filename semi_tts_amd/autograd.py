@@ -141,6 +141,48 @@ def batch_norm_train(x, bn, act=None):
     return _BnTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, bn.num_batches_tracked)
 
 
+class _LayerNormFn(Function):
+    """nn.LayerNorm over the last dimension (the speech encoder's layer_norm, src/asr.py:38-39,58; the normalised prenet Linear,
+    src/module.py:508-521)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        x2 = _rows(x)
+        y, mean, rstd = ops.layer_norm(x2, gamma, beta, eps, want_stats=True)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = _rows(dy.contiguous())
+        dx, dyxhat = ops.layer_norm_bwd(dy2, _rows(x), gamma, mean, rstd)
+        return dx.view(x.shape), ops.colsum(dyxhat), ops.colsum(dy2), None
+
+
+def layer_norm(x, ln):
+    """ln: nn.LayerNorm over the last dimension"""
+    return _LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+class _LogSoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.log_softmax(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        return ops.log_softmax_bwd(dy, y)
+
+
+def log_softmax(x):
+    return _LogSoftmaxFn.apply(x)
+
+
 class _HighwayFn(Function):
     """y = H*T + x*(1-T)      ref: src/module.py:551-554"""
 
@@ -379,9 +421,10 @@ class _DecoderFn(Function):
     ref: src/module.py:184-288"""
 
     @staticmethod
-    def forward(ctx, dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, *params):
+    def forward(ctx, dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, dec_in0, *params):
         mel, align, stop, tapes = dec._run_loop(plan, memory, pm, ada_std, ada_mean, teacher_pre, keep_tapes=True)
         ctx.dec, ctx.plan, ctx.tapes = dec, plan, tapes
+        ctx.has_in0 = dec_in0 is not None
         ctx.save_for_backward(memory, pm, ada_std, ada_mean, teacher_pre, align, mel, *params)
         return mel, align, stop
 
@@ -477,6 +520,7 @@ class _DecoderFn(Function):
         io.dgq_t16, io.dgd_t16 = ops._p(dgq_t16), ops._p(dgd_t16)
         src_arr = (C.c_int * max(steps, 1))(*src)
         io.step_src, io.Bt = C.cast(src_arr, C.POINTER(C.c_int)), Bt
+        io.need_dxq0 = 1 if ctx.has_in0 else 0
         if own:
             own_mask = plan['masks'][0]
             pre1_nat = _untile_tape(tapes['pre1'], steps, Bp, kb(P), [(0, P)])
@@ -535,7 +579,8 @@ class _DecoderFn(Function):
                         dmean_in = dxq[mean_steps][:, :Bt, :P].sum(0) / Tt                 # (Bt, P)
                         dteacher += dmean_in.unsqueeze(1)
         c = lambda t: t.contiguous()
-        grads = (None, None, dmem, dpm, dstd, dmean, dteacher,
+        ddec_in0 = dxq[0, :B, :P].contiguous() if ctx.has_in0 else None     # gradient of dec_in_0 = prenet(go frame)
+        grads = (None, None, dmem, dpm, dstd, dmean, dteacher, ddec_in0,
                  dpre_w0, dpre_w1,                                                # prenet weights: only via own-output feedback
                  c(dwq_cat[:, :P + E]), c(dwq_cat[:, P + E:]), dbq, dbq.clone(),
                  dwq_attn, dv, dwc, dwl,
@@ -545,13 +590,13 @@ class _DecoderFn(Function):
         return grads
 
 
-def decoder_loop(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre):
+def decoder_loop(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, dec_in0=None):
     params = (dec.prenet.layers[0].linear.weight, dec.prenet.layers[1].linear.weight,
               dec.query_rnn.weight_ih, dec.query_rnn.weight_hh, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh,
               dec.attn.query_layer.linear.weight, dec.attn.v.linear.weight, *dec.attn.location_weights(),
               dec.dec_rnn.weight_ih, dec.dec_rnn.weight_hh, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh,
               dec.proj.linear.weight, dec.proj.linear.bias, dec.gate_layer.linear.weight, dec.gate_layer.linear.bias)
-    return _DecoderFn.apply(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, *params)
+    return _DecoderFn.apply(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, dec_in0, *params)
 
 
 # --------------------------------------------------------------------------------------------- trainer loss

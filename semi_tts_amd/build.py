@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libsemitts_hip.so')
-SOURCES = ['skinny.hip', 'skinny_packed.hip', 'attention.hip', 'gemm.hip', 'rnn.hip', 'vq.hip', 'runtime.hip', 'decoder.hip', 'grad.hip', 'attention_bwd.hip', 'decoder_bwd.hip', 'loss.hip', 'optim.hip']
+SOURCES = ['skinny.hip', 'skinny_packed.hip', 'attention.hip', 'gemm.hip', 'rnn.hip', 'vq.hip', 'runtime.hip', 'decoder.hip', 'grad.hip', 'attention_bwd.hip', 'decoder_bwd.hip', 'loss.hip', 'optim.hip', 'norm.hip']
 
 
 def _hipcc():

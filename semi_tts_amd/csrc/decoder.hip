@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void tile_teacher_kernel(const float* teacher_
     }
 }
 
-int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLayout& pl, const StepViews& sv,
+int prenet_own(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io, const PackedLayout& pl, const StepViews& sv,
                int t, bool layer1_done, void* stream) {
     // dec_in_{t+1} = prenet(mel_t) for every row                ref: src/module.py:192,:197-198,:205-206
     const int in_dim = d->r * d->n_mels;
@@ -84,6 +84,25 @@ int prenet_own(const st_decoder_dims* d, const st_decoder_io* io, const PackedLa
     st_t16_view mel = {io->mel_t16, kb16(in_dim), 0};
     st_t16_view pre1 = {io->pre1_t16 + (size_t)t * io->pre1_step_floats, kb16(d->P), 0};
     int rc = 0;
+    if (d->prenet_norm) {
+        // normalised prenet (Linear -> LayerNorm / BatchNorm1d -> ReLU -> dropout, src/module.py:337-339,508-521): the Linear's
+        // output stays in natural layout, the norm launch applies norm + ReLU + mask and writes the T16 operand of the next product
+        st_t16_view next_n = {io->xq_tape + (size_t)(t + 1) * sv.q_floats, sv.q_kbs, 0};
+        const st_t16_view* dsts[2] = {&pre1, &next_n};
+        const st_t16_view* srcs[2] = {&mel, &pre1};
+        const float* pw[2] = {io->packed + pl.p0, io->packed + pl.p1};
+        const int Ks[2] = {16 * kb16(in_dim), 16 * kb16(d->P)};
+        const float* ms[2] = {m1, m2};
+        for (int l = 0; l < 2; ++l) {
+            rc = st_skinny_linear_packed_fwd(pw[l], srcs[l], Ks[l], nullptr, ST_ACT_NONE, nullptr, 0, io->pre_nat, d->P, nullptr, 0,
+                                             nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
+            if (rc) return rc;
+            rc = st_prenet_norm_fwd(io->pre_nat, d->P, d->prenet_norm, w->pre_norm_w[l], w->pre_norm_b[l], w->pre_norm_rm[l], w->pre_norm_rv[l],
+                                    w->pre_norm_nbt[l], w->pre_norm_eps, w->pre_norm_momentum, ms[l], d->P, dsts[l], d->B, d->P, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if (!layer1_done)
         rc = st_skinny_linear_packed_fwd(io->packed + pl.p0, &mel, 16 * kb16(in_dim), nullptr, ST_ACT_RELU, m1, d->P,
                                          nullptr, 0, &pre1, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
@@ -146,6 +165,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     ST_CHECK_ARG(io->mel_out && io->align_out && io->stop_out, "st_decoder_forward: null output");
     ST_CHECK_ARG(io->xq_tape && io->xd_tape && io->xo_tape && io->cq_tape && io->cd_tape && io->wcum_tape &&
                  io->pq_buf && io->pre1_t16 && io->mel_t16 && io->zero_row, "st_decoder_forward: null tape/scratch");
+    ST_CHECK_ARG(d->prenet_norm >= 0 && d->prenet_norm <= 3 && (!d->prenet_norm || (!d->fuse_pre0 && io->pre_nat && w->pre_norm_w[0] &&
+                 w->pre_norm_w[1] && w->pre_norm_b[0] && w->pre_norm_b[1])), "st_decoder_forward: normalised prenet needs pre_nat, the norm weights and fuse_pre0 = 0");
     for (int t = 0; t + 1 < steps; ++t) {
         const int src = io->step_src[t];
         ST_CHECK_ARG(!d->fuse_pre0 || src == -1, "st_decoder_forward: fuse_pre0 needs every next input to be the own output");
@@ -173,6 +194,11 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     ST_HIP(hipMemsetAsync(io->xq_tape, 0, sv.q_floats * sizeof(float), st));
     ST_HIP(hipMemsetAsync(io->xd_tape, 0, sv.d_floats * sizeof(float), st));
 
+    if (io->dec_in0) {      // dec_in_0 = prenet(go frame) of a normalised prenet (a plain one gives the zeros the tape holds already)
+        st_t16_view xq0 = {io->xq_tape, sv.q_kbs, 0};
+        int rc0 = st_tile_rows(io->dec_in0, P, &xq0, B, P, stream);
+        if (rc0) return rc0;
+    }
     if (pure_tf && steps > 1) {
         const size_t total = (size_t)(steps - 1) * B * P;
         size_t blocks = (total + 255) / 256;
@@ -336,7 +362,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             const int src = io->step_src[t];
             st_t16_view next = {xq_next, sv.q_kbs, 0};
             if ((src == -1 || io->Bt < B) && !ST_SKIPPED(5)) {   // rows without a teacher feed their own output back
-                rc = prenet_own(d, io, pl, sv, t, fuse, stream);
+                rc = prenet_own(w, d, io, pl, sv, t, fuse, stream);
                 if (rc) return rc;
             }
             if (pure_tf) rc = 0;             // tiled for all steps before the loop

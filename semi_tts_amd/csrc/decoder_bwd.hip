@@ -153,7 +153,7 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                                         io->cq_tape + (size_t)t * BQ, Q, io->dcq, dgq, 4 * Q, packed ? &dgq_v : nullptr, B, Q, stream);
         if (rc) return rc;
         // f. gradient w.r.t. [dec_in_t | ctx_{t-1} | h_q_{t-1}]  (step 0: go frame and zero initial state, nothing to do)
-        if (t > 0) {
+        if (t > 0 || io->need_dxq0) {
             if (packed) {
                 rc = st_skinny_linear_packed_fwd(w->q_w_cat_t_p16, &dgq_v, 4 * Q, nullptr, ST_ACT_NONE, nullptr, 0, dxq, XQ, nullptr,
                                                  0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XQ, stream);

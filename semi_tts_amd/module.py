@@ -57,10 +57,48 @@ class Linear(nn.Module):
         self.linear = nn.Linear(in_dim, out_dim, bias=bias)
         nn.init.xavier_uniform_(self.linear.weight, gain=nn.init.calculate_gain(w_init_gain))
         self.apply_norm = norm_type is not None
-        if self.apply_norm:
-            raise NotImplementedError('norm_type=%r: no shipped config uses a normalised Linear' % norm_type)
+        if self.apply_norm:                                                              # ref: src/module.py:508-513
+            assert norm_type in ['LayerNorm', 'BatchNorm1d']
+            self.norm_type = norm_type
+            self.norm = getattr(nn, norm_type)(out_dim)
+
+    def _forward_norm(self, x, act, mask):
+        """Linear -> LayerNorm / BatchNorm1d -> act -> mask (src/module.py:515-521; the caller's ReLU + dropout, :337-339).
+        BatchNorm1d sees the channels of a (B, T, C) input after a transpose and of a (B, C) input directly: in both cases the
+        statistics run over every leading row, which is how the rows-flattened kernels take it."""
+        lead = x.shape[:-1]
+        grad = self.training and torch.is_grad_enabled()
+        if grad:
+            y = AG.linear(x, self.linear.weight, self.linear.bias)
+        else:
+            x2 = x.reshape(-1, x.shape[-1])
+            y = (ops.linear_small(x2, self.linear.weight, self.linear.bias, None, None) if x2.shape[0] <= 64
+                 else ops.gemm(x2, self.linear.weight, bias=self.linear.bias))
+        y2 = y.reshape(-1, y.shape[-1])
+        nm = self.norm
+        if self.norm_type == 'LayerNorm':
+            y2 = AG.layer_norm(y2, nm) if grad else ops.layer_norm(y2, nm.weight, nm.bias, nm.eps)
+            if act == 'relu':
+                y2 = torch.relu(y2)
+            elif act is not None:
+                raise NotImplementedError(act)
+        elif grad:
+            y2 = AG.batch_norm_train(y2, nm, act)
+        else:
+            N = y2.shape[1]
+            if self.training:       # batch statistics (+ running-stat update) without autograd
+                mean, var = ops.bn_stats(y2, 0, N, nm.running_mean, nm.running_var, nm.momentum, nm.num_batches_tracked)
+            else:
+                mean, var = nm.running_mean, nm.running_var
+            y2 = y2.contiguous()
+            ops.bn_apply(y2, 0, N, mean, var, nm.weight, nm.bias, nm.eps, act)
+        if mask is not None:
+            y2 = y2 * mask.reshape(-1, mask.shape[-1])
+        return y2.view(*lead, -1)
 
     def forward(self, x, act=None, mask=None):
+        if self.apply_norm:
+            return self._forward_norm(x, act, mask)
         if self.training:            # differentiable path (same kernels + saved tensors)
             return AG.linear(x, self.linear.weight, self.linear.bias, act, mask)
         lead = x.shape[:-1]
@@ -349,6 +387,15 @@ class Decoder(nn.Module):
             d_b_ih=self.dec_rnn.bias_ih, d_b_hh=self.dec_rnn.bias_hh, projgate_w=pg_w, projgate_b=pg_b)
         for k, t in tensors.items():
             setattr(w, k, ops._p(t))
+        if self.prenet_norm_type is not None:
+            for l, layer in enumerate(self.prenet.layers):
+                nm = layer.norm
+                w.pre_norm_w[l], w.pre_norm_b[l] = ops._p(nm.weight), ops._p(nm.bias)
+                if self.prenet_norm_type == 'BatchNorm1d':
+                    w.pre_norm_rm[l], w.pre_norm_rv[l] = ops._p(nm.running_mean), ops._p(nm.running_var)
+                    w.pre_norm_nbt[l] = ops._p(nm.num_batches_tracked, torch.int64)
+                    w.pre_norm_momentum = float(nm.momentum)
+                w.pre_norm_eps = float(nm.eps)
         return w
 
     def forward(self, memory, memory_lengths, teacher, spkr_embed, tf_rate=0.0, unpair_max_frame=None, _masks=None):
@@ -408,6 +455,11 @@ class Decoder(nn.Module):
             teacher_pre = self.prenet(tch, _masks.get('teacher'))                                 # :179
             if any(s == -2 for s in step_src):
                 teacher_mean = ops.mean_rows(teacher_pre.detach())
+        # the go frame: prenet(0) is 0 for a plain prenet (bias-free Linear + ReLU), so the loop starts from a zero input; a
+        # normalised prenet maps the zero frame to relu(beta) (LayerNorm) / relu((0 - mean) / sigma * gamma + beta) (BatchNorm1d)  :161,:183
+        dec_in0 = None
+        if self.prenet_norm_type is not None:
+            dec_in0 = self.prenet(torch.zeros(B, n_mels * r, device=dev, dtype=torch.float32), _masks.get('go')).contiguous()
         uses_own = any(s == -1 for s in step_src[:-1]) or Bt < B
         own_mask = _masks.get('own')
         if own_mask is None and uses_own and self.prenet_dropout > 0:
@@ -419,9 +471,13 @@ class Decoder(nn.Module):
             if d_mask is None and self.dec_dropout.p > 0:
                 d_mask = _scaled_mask((steps, B, D), self.dec_dropout.p, dev)
         plan = dict(steps=steps, step_src=step_src, Bt=Bt, Tt=Tt, masks=(own_mask, q_mask, d_mask),
-                    teacher_mean=teacher_mean)
+                    teacher_mean=teacher_mean, dec_in0=dec_in0.detach() if dec_in0 is not None else None)
         if differentiable:
-            mel, align, stop = AG.decoder_loop(self, plan, ctx_memory.contiguous(), pm, ada_std, ada_mean, teacher_pre)
+            if uses_own and self.prenet_norm_type is not None:
+                # the loop's backward (decoder_bwd.hip) pushes the feedback gradient through relu(W x) * mask only
+                raise NotImplementedError('backward through own-output feedback (scheduled sampling / unpaired rows) with a '
+                                          'normalised prenet; teacher forcing (every shipped config) and the forward pass are built')
+            mel, align, stop = AG.decoder_loop(self, plan, ctx_memory.contiguous(), pm, ada_std, ada_mean, teacher_pre, dec_in0)
             return mel, (align * 0.0 if self.pretrain else align), stop
         mel, align, stop, tapes = self._run_loop(plan, ctx_memory.contiguous(), pm, ada_std, ada_mean, teacher_pre, keep_tapes=False)
         self.last_tapes = tapes
@@ -446,9 +502,13 @@ class Decoder(nn.Module):
         stop = torch.empty(B, steps * r, **f32)
         lib = _lib.load()
         # free-running inference: fold prenet layer 1 into the proj/gate launch (one kernel less per step)
-        fuse_pre0 = (not self.training) and self.fuse_prenet and Bt == B and all(s_ == -1 for s_ in step_src)
+        fuse_pre0 = ((not self.training) and self.fuse_prenet and Bt == B and all(s_ == -1 for s_ in step_src)
+                     and self.prenet_norm_type is None)
+        # normalised prenet: 1 LayerNorm, 2 BatchNorm1d with running statistics (eval), 3 BatchNorm1d with a step's batch statistics
+        pn_mode = {None: 0, 'LayerNorm': 1, 'BatchNorm1d': 3 if self.training else 2}[self.prenet_norm_type]
         dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A,
-                             F=self.n_location_filters, K=self.location_kernel_size, fuse_pre0=1 if fuse_pre0 else 0)
+                             F=self.n_location_filters, K=self.location_kernel_size, fuse_pre0=1 if fuse_pre0 else 0,
+                             prenet_norm=pn_mode)
         t16 = lambda k: int(lib.st_t16_floats(B, k))           # floats of one T16-tiled (B, k) buffer
         slot = [int(lib.st_decoder_tape_floats(C.byref(dims), i)) for i in range(3)]
         in_dim = r * n_mels
@@ -501,6 +561,11 @@ class Decoder(nn.Module):
         io.cq_tape, io.cd_tape, io.wcum_tape = (ops._p(tapes[k]) for k in ('cq', 'cd', 'wcum'))
         io.pq_buf, io.pre1_t16, io.mel_t16 = (ops._p(tapes[k]) for k in ('pq', 'pre1', 'melt'))
         io.zero_row = ops._p(tapes['zero'])
+        if pn_mode:
+            tapes['pre_nat'] = torch.empty(B, P, **f32)
+            io.pre_nat = ops._p(tapes['pre_nat'])
+        if plan.get('dec_in0') is not None:
+            io.dec_in0 = ops._p(plan['dec_in0'])
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))
         io.pre1_step_floats = t16(P) if keep_tapes else 0
         # training with pure teacher forcing: no step's input depends on an earlier output, so mel / stop of all steps

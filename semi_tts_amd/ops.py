@@ -284,6 +284,42 @@ def bn_stats(x2d, coff, N, run_mean=None, run_var=None, momentum=0.1, batches_tr
     return mean, var
 
 
+def layer_norm(x2d, gamma, beta, eps, want_stats=False):
+    """nn.LayerNorm over the last dimension of (M, N) rows -> y [, mean (M), rstd (M)]"""
+    M, N = x2d.shape
+    y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    mean = torch.empty(M, device=x2d.device, dtype=torch.float32) if want_stats else None
+    rstd = torch.empty(M, device=x2d.device, dtype=torch.float32) if want_stats else None
+    check(_lib.load().st_layer_norm_fwd(_p(x2d), int(x2d.stride(0)), _p(gamma), _p(beta), float(eps), _p(y), N, _p(mean), _p(rstd), M, N,
+                                        stream_handle()), 'st_layer_norm_fwd')
+    return (y, mean, rstd) if want_stats else y
+
+
+def layer_norm_bwd(dy2d, x2d, gamma, mean, rstd):
+    """-> (dx, dy * xhat): d gamma = colsum(dy * xhat), d beta = colsum(dy)"""
+    M, N = x2d.shape
+    dx = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    dyxhat = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    check(_lib.load().st_layer_norm_bwd(_p(dy2d), int(dy2d.stride(0)), _p(x2d), int(x2d.stride(0)), _p(gamma), _p(mean), _p(rstd),
+                                        _p(dx), N, _p(dyxhat), M, N, stream_handle()), 'st_layer_norm_bwd')
+    return dx, dyxhat
+
+
+def log_softmax(x):
+    N = x.shape[-1]
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.load().st_log_softmax_fwd(_p(x), _p(y), x.numel() // N, N, stream_handle()), 'st_log_softmax_fwd')
+    return y
+
+
+def log_softmax_bwd(dy, y):
+    N = y.shape[-1]
+    dx = torch.empty_like(y)
+    check(_lib.load().st_log_softmax_bwd(_p(dy.contiguous()), _p(y), _p(dx), y.numel() // N, N, stream_handle()), 'st_log_softmax_bwd')
+    return dx
+
+
 def bn_apply(x2d, coff, N, mean, var, w, b, eps, act=None):
     lib = _lib.load()
     check(lib.st_bn_apply(_p(x2d), int(x2d.stride(0)), int(coff), x2d.shape[0], N, _p(mean), _p(var), _p(w), _p(b),

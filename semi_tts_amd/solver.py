@@ -294,19 +294,33 @@ class VqvaeTrainer(TtsTrainer):
         tf_rate = self.optimizer.pre_step(self.step)
         if getattr(self, 'reducer', None) is not None:
             self.reducer.prepare()
-        pair_prob, _, unpair_prob, unpair_latent, unpair_latent_len, _, _ = self.model.speech_to_text(
+        pair_prob, _, unpair_prob, unpair_latent, unpair_latent_len, pair_post_prob, _ = self.model.speech_to_text(
             paired_mel=aug_mel, unpaired_mel=unpair_aug_mel)
         ignore_speech_cycle = unpair_latent is None                                               # :163-172
         out = self.model.text_to_speech(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
                                         unpair_latent_len, mel, None if ignore_speech_cycle else unpair_mel, tf_rate, _masks=_masks)
         pm, pl, _, _, upm, upl, _, _ = out
         asr_loss = self.ctc_loss(pair_prob, text)                                                 # :209
+        asr_w = float(hp.get('asr_weight', 1.0))
+        stats = {}
+        if self.model.use_asr_postnet:                                                            # :210-213
+            from . import autograd as AG
+            pw = float(self.model.asr_postnet_weight)
+            asr_post_loss = AG.ctc_loss(pair_post_prob, text, EPS, apply_log=False)               # compute_ctcloss(..., apply_log=False)
+            total = asr_w * (1.0 - pw) * asr_loss + asr_w * pw * asr_post_loss
+            stats['asr_post_loss'] = float(asr_post_loss.detach())
+        else:
+            total = asr_w * asr_loss                                                              # :215
+        al = float(asr_loss.detach())
+        if al != al or al in (float('inf'), float('-inf')):                                       # :216-218: counted, and (as in the
+            self.ctc_nan = getattr(self, 'ctc_nan', 0) + 1                                        # reference) already inside total
         tts_loss = self.freq_loss(pm, mel) + self.freq_loss(pl, linear)                           # :221-224
-        total = float(hp.get('asr_weight', 1.0)) * asr_loss + self.tts_weight * tts_loss
-        stats = dict(asr_loss=float(asr_loss.detach()), tts_loss=float(tts_loss.detach()))
+        total = total + self.tts_weight * tts_loss
+        stats.update(asr_loss=al, tts_loss=float(tts_loss.detach()))
         if not ignore_speech_cycle:                                                               # :227-233
             un = self.freq_loss(upm, unpair_mel) + self.freq_loss(upl, unpair_linear)
-            total = total + float(hp.get('unpair_speech_weight', 10.0)) * un
+            if self.step > int(hp.get('unpair_speech_start_step', 0)):                            # :232: only after the warm-up steps
+                total = total + float(hp.get('unpair_speech_weight', 10.0)) * un
             stats['unpair_speech_loss'] = float(un.detach())
         total.backward()
         self._reduce_gradients()

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import ops
 from . import autograd as AG
-from .asr import CTC
+from .asr import CTC, ASRPostnet
 from .embed import L2Embedding, SeperateEmbedding
 from .tts import Tacotron2
 
@@ -39,8 +39,9 @@ class VQVAE(nn.Module):
         self.asr = CTC(n_mels, self.latent_dim, **encoder)                                    # :46
         self.time_reduce_factor = self.asr.time_reduce_factor
         self.use_asr_postnet = asr_postnet_weight > 0
-        if self.use_asr_postnet:
-            raise NotImplementedError('ASRPostnet (asr_postnet_weight > 0): no shipped config enables it')
+        if self.use_asr_postnet:                                       # :50-52 (the reference passes latent_dim as the class count)
+            self.asr_postnet_weight = asr_postnet_weight
+            self.asr_postnet = ASRPostnet(self.latent_dim, self.latent_dim)
         if self.code_bone == 'l2':                                     # :56-61
             self.codebook = L2Embedding(vocab_size, False, **codebook)
         elif self.code_bone == 'seperate':
@@ -85,6 +86,7 @@ class VQVAE(nn.Module):
         else:
             all_mel, paired_mel_bs = paired_mel, len(paired_mel)
         enc_latent = self.asr(all_mel)                                                          # :116
+        paired_post_prob = self.asr_postnet(enc_latent[:paired_mel_bs]) if self.use_asr_postnet else None   # :117
         first_n_real_mel = len(paired_mel) if using_fake_mel else 0
         p_code, quantized_latent, _, rest = self.codebook(enc_latent, first_n_real_mel)         # :119
         if use_unpaired:                                                                        # :122-133
@@ -95,7 +97,7 @@ class VQVAE(nn.Module):
         else:
             pair_prob, pair_latent = p_code, quantized_latent
             unpair_prob = unpair_latent = unpair_latent_len = None
-        return pair_prob, pair_latent, unpair_prob, unpair_latent, unpair_latent_len, None, rest
+        return pair_prob, pair_latent, unpair_prob, unpair_latent, unpair_latent_len, paired_post_prob, rest
 
     def text_to_speech(self, paired_text, paired_sid, unpaired_sid, unpaired_latent, unpaired_text, unpaired_latent_len,
                        paired_teacher, unpaired_teacher, tf_rate, _masks=None):

@@ -41,7 +41,9 @@ def split_masks(masks, hp, training, tf_rate, B, Bt, steps, step_src, P):
     pd = hp['prenet_dropout'] > 0
     if tf_rate != 0.0 and pd:
         out['teacher'] = [next(it), next(it)]
-    if pd:
+    if pd and hp.get('prenet_norm_type'):
+        out['go'] = [next(it), next(it)]         # a normalised prenet maps the zero go frame to relu(beta ...): the masks matter
+    elif pd:
         next(it), next(it)                       # go frame: prenet(0) == 0 whatever the mask
     own = torch.ones(steps, 2, B, P)
     q, d = [], []

@@ -293,7 +293,7 @@ def _double_masks(masks):
 
 
 @pytest.mark.parametrize('name', ['tts_tiny_train_tf', 'tts_tiny_sched', 'tts_tiny_partial', 'tts_tiny_pretrain', 'tts_tiny_dropin',
-                                  'tts_tiny_noloc', 'tts_tiny_nosum', 'tts_tiny_encdrop'])
+                                  'tts_tiny_noloc', 'tts_tiny_nosum', 'tts_tiny_encdrop', 'tts_tiny_preln_train', 'tts_tiny_prebn_train'])
 def test_tacotron2_backward_against_oracle_tiny_golden(dev, name):
     """Whole Tacotron2 in training mode with the reference's recorded dropout masks and coin flips -- teacher forcing,
     scheduled sampling (own output fed back on some steps) and a partial-teacher batch (unpaired rows always feed their
@@ -664,13 +664,14 @@ def test_seperate_embedding_backward_vs_oracle(dev, stop_grad):
     assert relerr(cb.embedding.weight.grad, wg['embedding.weight']) < 2e-5
 
 
-def test_ctc_encoder_backward_vs_oracle(dev):
+@pytest.mark.parametrize('gname', ['asr_tiny_train', 'asr_tiny_ln_train'])
+def test_ctc_encoder_backward_vs_oracle(dev, gname):
     """The CTC speech encoder in training mode (stride-2 conv layer, batch-statistics BatchNorm + tanh + residual, 2-layer
     BiLSTM, projection) against float64 autograd through the oracle.  ref: src/asr.py:46-64, src/module.py:627-648"""
     from conftest import load_golden
     from oracle import asr_oracle as AO
     from semi_tts_amd.asr import CTC
-    W, A, meta = load_golden('asr_tiny_train')
+    W, A, meta = load_golden(gname)
     cfg = meta['cfg']
     m = CTC(meta['in_dim'], meta['out_dim'], **cfg)
     m.load_state_dict(W)
@@ -726,6 +727,7 @@ def test_speech_first_step_against_reference_golden(dev, name):
                 grads[kname] = p.grad.detach().clone()
         return orig(list(params), max_norm)
     tr.clip_grad_norm_ = spy
+    tr.step = 1          # the unpaired term only counts once step > unpair_speech_start_step (0 in the shipped configs; train_vqvae.py:232)
     st = tr.speech_first_step(mel, mel, linear, text, sid, _masks=masks, **un)
     ref = meta['stats']
     assert torch.equal(tr.model.codebook.last_idx.cpu(), A['idx'])                      # VQ indices: bit-exact
@@ -804,3 +806,40 @@ def test_ctc_loss_on_log_probabilities_and_invalid_tokens(dev):
     bad[0, 1] = V + 5
     l2 = AG.ctc_loss(lp0.to(dev), bad.to(dev), 1e-10, apply_log=False)
     assert bool(torch.isnan(l2))
+
+
+def test_asr_postnet_backward_vs_oracle(dev):
+    """ASRPostnet with gradients (eval mode: its two dropouts of 0.5 off) against float64 autograd through the oracle, and with
+    explicit dropout masks in training mode; the CTC loss on its log-probabilities closes the chain the trainer uses
+    (bin/train_vqvae.py:210-213)."""
+    from conftest import load_golden
+    from oracle import asr_oracle as AO
+    from oracle import tts_oracle as O
+    from semi_tts_amd.asr import ASRPostnet
+    W, A, meta = load_golden('asr_postnet_tiny')
+    m = ASRPostnet(meta['latent_dim'], meta['vocab_size'])
+    m.load_state_dict(W)
+    m = m.to(dev).eval()
+    x = A['x']
+    xd = x.to(dev).requires_grad_()
+    y = m(xd)
+    assert maxdiff(y, A['y']) < 2e-5
+    dy = rnd(*y.shape, seed=9)
+    y.backward(dy.to(dev))
+    outs, wg, ig = oracle_grads(lambda Wd, xx: AO.asr_postnet_forward(Wd, xx), W, [x], [dy])
+    e = relerr(xd.grad, ig[0])
+    report('asr_postnet_backward', dx=e)
+    assert e < 2e-4
+    check_param_grads(m, '', wg, 2e-4, 'asr_postnet_backward')
+    # training mode with explicit (scaled) masks
+    m.zero_grad()
+    m.train()
+    g = torch.Generator().manual_seed(4)
+    masks = [torch.bernoulli(torch.full((3, 9, 20), 0.5), generator=g) * 2.0 for _ in range(2)]
+    xd2 = x.to(dev).requires_grad_()
+    y2 = m(xd2, _masks=[mk.to(dev) for mk in masks])
+    y2.backward(dy.to(dev))
+    drop = lambda: O.DropoutSource('list', [mk.double() for mk in masks])
+    outs2, wg2, ig2 = oracle_grads(lambda Wd, xx: AO.asr_postnet_forward(Wd, xx, training=True, drop=drop()), W, [x], [dy])
+    assert maxdiff(y2, outs2[0]) < 2e-5 and relerr(xd2.grad, ig2[0]) < 2e-4
+    check_param_grads(m, '', wg2, 2e-4, 'asr_postnet_backward_train')

@@ -491,7 +491,9 @@ TTS_CASES = ['tts_tiny_infer', 'tts_tiny_infer_nodrop', 'tts_tiny_train_tf', 'tt
              'tts_tiny_sched', 'tts_tiny_partial', 'tts_tiny_quirk',
              # decoder / encoder variants no shipped YAML reaches: speaker-conditioned memory, pre-training, 2-layer encoder LSTM
              'tts_tiny_concat', 'tts_tiny_add', 'tts_tiny_pretrain', 'tts_tiny_enc2', 'tts_tiny_dropin', 'tts_tiny_noloc',
-             'tts_tiny_nosum', 'tts_tiny_encdrop']
+             'tts_tiny_nosum', 'tts_tiny_encdrop',
+             # normalised prenet (prenet_norm_type LayerNorm / BatchNorm1d): eval, teacher-forced training, scheduled sampling
+             'tts_tiny_preln_infer', 'tts_tiny_preln_train', 'tts_tiny_prebn_infer', 'tts_tiny_prebn_train', 'tts_tiny_prebn_sched']
 
 
 @pytest.mark.parametrize('name', TTS_CASES)
@@ -844,7 +846,7 @@ def test_vq_mean_forward_c3_size_and_gradient(dev):
 
 
 # ------------------------------------------------------------------------------------ next row (8f-2): speech encoder
-@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train'])
+@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train', 'asr_tiny_ln_eval', 'asr_tiny_ln_train'])
 def test_ctc_encoder_against_reference_golden(dev, name):
     import json
     from semi_tts_amd.asr import CTC
@@ -1022,3 +1024,18 @@ def test_long_text_decode_uses_the_one_launch_form_and_matches_the_three_launch_
     errs = dict(mel=maxdiff(mel1, mel2), align=maxdiff(al1, al2))
     report('decode_long_text_one_launch', **errs)
     assert errs['mel'] < 5e-6 and errs['align'] < 1e-6 and bool(torch.isfinite(mel1).all())
+
+
+def test_asr_postnet_against_reference_golden(dev):
+    """ASRPostnet (2-layer BiLSTM -> Linear -> log_softmax, src/asr.py:67-80) in eval mode vs the output recorded from the reference"""
+    from semi_tts_amd.asr import ASRPostnet
+    W, A, meta = load_golden('asr_postnet_tiny')
+    m = ASRPostnet(meta['latent_dim'], meta['vocab_size'])
+    m.load_state_dict(W)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        y = m(A['x'].to(dev))
+    err = maxdiff(y, A['y'])
+    report('asr_postnet_golden', err=err)
+    assert y.shape == A['y'].shape and err < 2e-5
+    assert float((y.exp().sum(-1) - 1).abs().max()) < 1e-5

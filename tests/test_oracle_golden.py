@@ -12,7 +12,9 @@ TTS_CASES = ['tts_tiny_infer', 'tts_tiny_infer_nodrop', 'tts_tiny_train_tf', 'tt
              'tts_tiny_sched', 'tts_tiny_partial', 'tts_tiny_quirk',
              # decoder / encoder variants no shipped YAML reaches: speaker-conditioned memory, pre-training, 2-layer encoder LSTM
              'tts_tiny_concat', 'tts_tiny_add', 'tts_tiny_pretrain', 'tts_tiny_enc2', 'tts_tiny_dropin', 'tts_tiny_noloc',
-             'tts_tiny_nosum', 'tts_tiny_encdrop']
+             'tts_tiny_nosum', 'tts_tiny_encdrop',
+             # normalised prenet (prenet_norm_type LayerNorm / BatchNorm1d: eval, teacher-forced training, scheduled sampling)
+             'tts_tiny_preln_infer', 'tts_tiny_preln_train', 'tts_tiny_prebn_infer', 'tts_tiny_prebn_train', 'tts_tiny_prebn_sched']
 
 
 def _coin_source(coins):
@@ -113,7 +115,7 @@ def test_vq_mean_forward():
         assert np.abs(lat - A['out%d' % ci].numpy()).max() < 1e-6
 
 
-@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train'])
+@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train', 'asr_tiny_ln_eval', 'asr_tiny_ln_train'])
 def test_asr_oracle_against_reference(name):
     from oracle import asr_oracle as AO
     W, A, meta = load_golden(name)
@@ -164,3 +166,10 @@ def test_nn_module_tacotron2_assembly_against_reference_and_oracle():
     loss, gn = NB.train_step(m2, opt, A2['txt_embed'], A2['spkr_embed'], A2['teacher'], lin_t,
                              lambda p, l: O.freq_loss(p, l, 22050, hp2['n_mels']))
     assert loss == loss and gn > 0
+
+
+def test_asr_postnet_oracle_against_reference():
+    from oracle import asr_oracle as AO
+    W, A, meta = load_golden('asr_postnet_tiny')
+    y = AO.asr_postnet_forward(W, A['x'])
+    assert y.shape == A['y'].shape and (y - A['y']).abs().max() < 2e-6

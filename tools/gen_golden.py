@@ -81,7 +81,7 @@ def randomize_buffers(mod, gen):
     for name, p in mod.named_parameters():
         if name.endswith('bias') and p.dim() == 1:
             p.data.copy_(torch.randn(p.shape, generator=gen) * 0.1 + p.data)
-        if '.bn.weight' in name or (name.endswith('.1.weight') and p.dim() == 1):
+        if '.bn.weight' in name or '.norm.weight' in name or 'norm_layer.weight' in name or (name.endswith('.1.weight') and p.dim() == 1):
             p.data.copy_(torch.rand(p.shape, generator=gen) + 0.5)
 
 
@@ -480,6 +480,34 @@ def asr_cases():
             arrays['post'] = list(post.values())
             arrays['post_keys'] = np.frombuffer(json.dumps(list(post)).encode(), np.uint8)
         save(name, w0, arrays, dict(cfg=cfg, in_dim=8, out_dim=10, training=training))
+    # LayerNorm after the BiLSTM (layer_norm=True, src/asr.py:38-39,58): eval, and training mode with dropout 0
+    for name, training, dropout, seed in (('asr_tiny_ln_eval', False, 0.5, 53), ('asr_tiny_ln_train', True, 0.0, 54)):
+        torch.manual_seed(seed)
+        cfg = dict(base, dropout=dropout, layer_norm=True)
+        m = RefCTC(8, 10, **cfg)
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            randomize_buffers(m, g)
+        m.train(training)
+        w0 = {k: v.clone() for k, v in m.state_dict().items()}
+        x = torch.rand(3, 14, 8, generator=g)
+        with torch.no_grad():
+            y = m(x)
+        arrays = dict(x=x, y=y)
+        if training:
+            post = {k: v for k, v in m.state_dict().items() if 'running_' in k}
+            arrays['post'] = list(post.values())
+            arrays['post_keys'] = np.frombuffer(json.dumps(list(post)).encode(), np.uint8)
+        save(name, w0, arrays, dict(cfg=cfg, in_dim=8, out_dim=10, training=training))
+    # ASRPostnet (src/asr.py:67-80): eval mode (its two dropouts of 0.5 are drawn inside torch in training mode)
+    from src.asr import ASRPostnet as RefPost
+    torch.manual_seed(55)
+    m = RefPost(10, 10).eval()
+    g = torch.Generator().manual_seed(56)
+    x = torch.randn(3, 9, 10, generator=g)
+    with torch.no_grad():
+        y = m(x)
+    save('asr_postnet_tiny', {k: v.clone() for k, v in m.state_dict().items()}, dict(x=x, y=y), dict(latent_dim=10, vocab_size=10))
 
 
 def main():
@@ -503,6 +531,12 @@ def main():
         tts_case('tts_tiny_noloc', 36, B=2, L=7, teacher=(9,), tf_rate=1.0, training=True, loc_aware=False)
         tts_case('tts_tiny_nosum', 37, B=2, L=6, teacher=(9,), tf_rate=1.0, training=True, use_summed_weights=False)
         tts_case('tts_tiny_encdrop', 38, B=2, L=6, teacher=(9,), tf_rate=1.0, training=True, _enc_dropout=0.3)
+        # normalised prenet (prenet_norm_type: the Linear wrapper's LayerNorm / BatchNorm1d, src/module.py:508-521)
+        tts_case('tts_tiny_preln_infer', 41, B=3, L=7, teacher=12, tf_rate=0.0, training=False, prenet_norm_type='LayerNorm')
+        tts_case('tts_tiny_preln_train', 42, B=3, L=6, teacher=(12,), tf_rate=1.0, training=True, prenet_norm_type='LayerNorm')
+        tts_case('tts_tiny_prebn_infer', 43, B=3, L=7, teacher=12, tf_rate=0.0, training=False, prenet_norm_type='BatchNorm1d')
+        tts_case('tts_tiny_prebn_train', 44, B=4, L=6, teacher=(12,), tf_rate=1.0, training=True, prenet_norm_type='BatchNorm1d')
+        tts_case('tts_tiny_prebn_sched', 45, B=4, L=6, teacher=(12,), tf_rate=0.5, training=True, prenet_norm_type='BatchNorm1d')
     if 'tts' in which:
         # eval-mode free-running inference, prenet dropout active (always-on), masks recorded
         tts_case('tts_tiny_infer', 1, B=2, L=7, teacher=15, tf_rate=0.0, training=False)

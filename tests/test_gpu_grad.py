@@ -835,7 +835,7 @@ def test_asr_postnet_backward_vs_oracle(dev):
     m.zero_grad()
     m.train()
     g = torch.Generator().manual_seed(4)
-    masks = [torch.bernoulli(torch.full((3, 9, 20), 0.5), generator=g) * 2.0 for _ in range(2)]
+    masks = [torch.bernoulli(torch.full((3, 9, 24), 0.5), generator=g) * 2.0 for _ in range(2)]
     xd2 = x.to(dev).requires_grad_()
     y2 = m(xd2, _masks=[mk.to(dev) for mk in masks])
     y2.backward(dy.to(dev))

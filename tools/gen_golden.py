@@ -502,12 +502,12 @@ def asr_cases():
     # ASRPostnet (src/asr.py:67-80): eval mode (its two dropouts of 0.5 are drawn inside torch in training mode)
     from src.asr import ASRPostnet as RefPost
     torch.manual_seed(55)
-    m = RefPost(10, 10).eval()
+    m = RefPost(12, 12).eval()
     g = torch.Generator().manual_seed(56)
-    x = torch.randn(3, 9, 10, generator=g)
+    x = torch.randn(3, 9, 12, generator=g)
     with torch.no_grad():
         y = m(x)
-    save('asr_postnet_tiny', {k: v.clone() for k, v in m.state_dict().items()}, dict(x=x, y=y), dict(latent_dim=10, vocab_size=10))
+    save('asr_postnet_tiny', {k: v.clone() for k, v in m.state_dict().items()}, dict(x=x, y=y), dict(latent_dim=12, vocab_size=12))
 
 
 def main():

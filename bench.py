@@ -39,7 +39,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix peak (256 CUs x 256 F
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 # PMC pass of the dominant kernel (tools/gpu_pmc.sh -> tools/pmc_summary.py): HBM bytes per launch.  bench.py does not
 # measure this itself (PMC counters need their own rocprofv3 passes); the value is quoted WITH its source file.
-TRAFFIC_FILES = ('profiles/r02_pmc_hbm_traffic.json', 'profiles/r01_pmc_hbm_traffic.json')
+TRAFFIC_FILES = ('profiles/r03_pmc_hbm_traffic%s.json', 'profiles/r02_pmc_hbm_traffic%s.json', 'profiles/r01_pmc_hbm_traffic%s.json')
 
 
 def decode_step_algorithmic_bytes(Bsz, Lt, dec):
@@ -63,6 +63,21 @@ def decode_step_algorithmic_bytes(Bsz, Lt, dec):
 def lstm_algorithmic_bytes(Bsz, H, K):
     """bytes one LSTM-cell launch must move: weights (4H x K) + biases + x/h in + c in/out + h out"""
     return 4 * (4 * H * K + 8 * H + Bsz * K + 3 * Bsz * H)
+
+
+def _quoted_traffic(sfx):
+    """roofline.traffic from the committed PMC summary of this workload (tools/gpu_pmc.sh + tools/pmc_summary.py), with its source"""
+    for f in TRAFFIC_FILES:
+        rel = f % sfx
+        try:
+            with open(os.path.join(REPO, rel)) as fh:
+                tj = json.load(fh)
+            return {'traffic': tj['hbm_bytes_per_launch'],
+                    'traffic_source': {'file': rel, 'kernel': tj.get('kernel'), 'commit': tj.get('commit'),
+                                       'note': 'separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE), not measured by this run'}}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {'traffic': None}
 
 
 def host_cores():
@@ -345,8 +360,9 @@ def bench_decode(args, rk):
     avg_us, alg, flops = lstm_probe(dec, dev, B)
     achieved = alg / (avg_us * 1e-6) / 1e9
     traffic, traffic_src = None, None
-    if args.workload == 'c2':
-        for rel in ([args.traffic_json] if args.traffic_json else []) + list(TRAFFIC_FILES):
+    if True:
+        sfx = '' if args.workload == 'c2' else '_' + args.workload
+        for rel in ([args.traffic_json] if args.traffic_json else []) + [f % sfx for f in TRAFFIC_FILES]:
             try:
                 with open(rel if os.path.isabs(rel) else os.path.join(REPO, rel)) as f:
                     tj = json.load(f)
@@ -461,7 +477,9 @@ def bench_vq(args, rk):
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'C3: L2Embedding.forward on (32,129,64) latents, V=512 synthetic table (config 3); other shapes in `cases`'},
             'roofline': {'bound': 'hbm', 'kernel': 'vq_l2_mfma_kernel (+ vq_pack_table_kernel)', 'achieved': head['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': head['frac_of_hbm_peak'], 'traffic': None,
+                         'frac': head['frac_of_hbm_peak'], **_quoted_traffic('_c3'),
+                         'mfma': {'achieved': round(head['GFLOPs'] / 1e3, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': round(head['GFLOPs'] / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
                          'algorithmic_bytes_per_launch': head['algorithmic_bytes'], 'avg_launch_us': head['us_per_launch']},
             'cases': rows}
     if cpu is not None:

@@ -775,7 +775,7 @@ def test_ctc_loss_against_torch(dev, B, T, V, L):
     lp = (pr + 1e-10).transpose(0, 1).log()
     ref = F.ctc_loss(lp, text[text != 0], torch.full((B,), T, dtype=torch.long), (text != 0).sum(-1), blank=0, reduction='mean')
     (ref * 1.7).backward()
-    e_loss, e_grad = abs(float(loss.detach()) - float(ref)) / max(1.0, abs(float(ref))), relerr(pd.grad, pr.grad)
+    e_loss, e_grad = abs(float(loss.detach()) - float(ref.detach())) / max(1.0, abs(float(ref.detach()))), relerr(pd.grad, pr.grad)
     report('ctc_loss', B=B, T=T, V=V, L=L, loss=float(ref), err_loss=e_loss, err_grad=e_grad)
     # torch's own fp32 CPU kernel is 2.3e-4 from its float64 self at (4, 129, 43, 43): log-space recursions over 129 frames,
     # and d/dprob = (p - occupancy) / p amplifies at small p
@@ -799,7 +799,7 @@ def test_ctc_loss_on_log_probabilities_and_invalid_tokens(dev):
     ref = F.ctc_loss(pr.transpose(0, 1), text[text != 0], torch.full((B,), T, dtype=torch.long), (text != 0).sum(-1), blank=0,
                      reduction='mean')
     (ref * 0.7).backward()
-    e_loss, e_grad = abs(float(loss.detach()) - float(ref)) / max(1.0, abs(float(ref))), relerr(pd.grad, pr.grad)
+    e_loss, e_grad = abs(float(loss.detach()) - float(ref.detach())) / max(1.0, abs(float(ref.detach()))), relerr(pd.grad, pr.grad)
     report('ctc_loss_log_input', err_loss=e_loss, err_grad=e_grad)
     assert e_loss < 2e-6 and e_grad < 2e-4
     bad = text.clone()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise the HBM-traffic PMC passes (tools/gpu_pmc.sh) into profiles/<tag>_pmc_hbm_traffic.{txt,json}.
-usage: tools/pmc_summary.py <tag>   (reads gpurun_out/pmc_<tag>_{FETCH,WRITE}_SIZE/pmc_results.db)
+"""Summarise the HBM-traffic PMC passes (tools/gpu_pmc.sh) into profiles/<tag>_pmc_hbm_traffic<sfx>.{txt,json}.
+usage: tools/pmc_summary.py <tag> [<sfx> <kernel name fragment> <algorithmic bytes per launch>]
+       (reads gpurun_out/pmc_<tag><sfx>_{FETCH,WRITE}_SIZE/pmc_results.db; defaults: the C2 LSTM cell)
 FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md (wide coalesced reads are counted at half their size); WRITE_SIZE as is."""
 import json
 import os
@@ -11,8 +12,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALGO_BYTES = 36356096          # mean algorithmic bytes of one LSTM-cell launch at C2 (bench.py: lstm_algorithmic_bytes)
 
 
+SFX = ''
+KERNELS = ('pk_lstm_rt2_kernel', 'pk_kernel<0')
+
+
 def stats(tag, counter):
-    db = os.path.join(REPO, 'gpurun_out', 'pmc_%s_%s' % (tag, counter), 'pmc_results.db')
+    db = os.path.join(REPO, 'gpurun_out', 'pmc_%s%s_%s' % (tag, SFX, counter), 'pmc_results.db')
     con = sqlite3.connect(db)
     return con.execute("select name, count(*), avg(counter_value), min(counter_value), max(counter_value), avg(duration) "
                        "from pmc_events where counter_name = ? group by name order by sum(counter_value) desc limit 6",
@@ -22,7 +27,7 @@ def stats(tag, counter):
 def mfma(tag):
     """matrix-core pass -> profiles/<tag>_pmc_mfma.{txt,json}: issued F32 MFMA FLOP (MOPS x 512, counter_defs.yaml) per
     launch against the algorithmic 2*B*K*4H, FLOP/s against the 157.3 TFLOP/s fp32-matrix peak, busy cycles as counted"""
-    db = os.path.join(REPO, 'gpurun_out', 'pmc_%s_MFMA' % tag, 'pmc_results.db')
+    db = os.path.join(REPO, 'gpurun_out', 'pmc_%s%s_MFMA' % (tag, SFX), 'pmc_results.db')
     if not os.path.exists(db):
         return
     con = sqlite3.connect(db)
@@ -41,7 +46,7 @@ def mfma(tag):
         lines.append('%-70s n=%5d dur_ns=%9.0f mfma_flop=%14.0f TFLOP/s=%7.2f frac_of_157.3=%.3f busy_cycles=%.0f cu_busy=%.0f gui_active=%.0f'
                      % (name[:70], d['n'], d['dur_ns'], flop, tfs, tfs / 157.3, d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0),
                         d.get('SQ_BUSY_CU_CYCLES', 0), d.get('GRBM_GUI_ACTIVE', 0)))
-        if ('pk_lstm_rt2_kernel' in name or 'pk_kernel<0' in name) and 'kernel' not in out:
+        if any(k in name for k in KERNELS) and 'kernel' not in out:
             out = dict(kernel=name[:60], launches=d['n'], avg_duration_ns=round(d['dur_ns']), mfma_flop_per_launch=flop,
                        mfma_tflops=round(tfs, 2), frac_of_fp32_matrix_peak=round(tfs / 157.3, 4),
                        SQ_VALU_MFMA_BUSY_CYCLES=d.get('SQ_VALU_MFMA_BUSY_CYCLES'), GRBM_GUI_ACTIVE=d.get('GRBM_GUI_ACTIVE'),
@@ -51,31 +56,35 @@ def mfma(tag):
                        note='MOPS x 512 = FLOP (counter_defs.yaml), equal to the algorithmic 2*B*K*4H; busy cycles = 32 per '
                             '16x16x4 f32 MFMA per SIMD; util = sum(busy) / (max GRBM_GUI_ACTIVE x 1024 SIMDs), the gfx94x '
                             'MfmaUtil formula; durations under PMC collection are ~7 % longer than in the plain kernel trace')
-    open(os.path.join(REPO, 'profiles', '%s_pmc_mfma.txt' % tag), 'w').write('\n'.join(lines[:12]) + '\n')
-    json.dump(out, open(os.path.join(REPO, 'profiles', '%s_pmc_mfma.json' % tag), 'w'), indent=1)
+    open(os.path.join(REPO, 'profiles', '%s_pmc_mfma%s.txt' % (tag, SFX)), 'w').write('\n'.join(lines[:12]) + '\n')
+    json.dump(out, open(os.path.join(REPO, 'profiles', '%s_pmc_mfma%s.json' % (tag, SFX)), 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
 
 def main():
+    global SFX, KERNELS, ALGO_BYTES
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+    if len(sys.argv) > 4:
+        SFX, KERNELS, ALGO_BYTES = sys.argv[2], (sys.argv[3],), int(float(sys.argv[4]))
     mfma(tag)
-    if not os.path.exists(os.path.join(REPO, 'gpurun_out', 'pmc_%s_FETCH_SIZE' % tag, 'pmc_results.db')):
+    if not os.path.exists(os.path.join(REPO, 'gpurun_out', 'pmc_%s%s_FETCH_SIZE' % (tag, SFX), 'pmc_results.db')):
         return
     lines, vals = [], {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         for name, n, avg, mn, mx, dur in stats(tag, c):
             lines.append('%-12s %-70s n=%5d avg=%12.1f min=%10.1f max=%12.1f avg_dur_ns=%s' % (c, name[:70], n, avg, mn, mx, dur))
-            if ('pk_lstm_rt2_kernel' in name or 'pk_kernel<0' in name) and c not in vals:
+            if any(k in name for k in KERNELS) and c not in vals:
                 vals[c] = avg
-    out = dict(kernel='pk_lstm_rt2_kernel<8,2,1>', commit=os.environ.get('ST_COMMIT'), FETCH_SIZE_avg_KB=round(vals['FETCH_SIZE'], 1), WRITE_SIZE_avg_KB=round(vals['WRITE_SIZE'], 1),
+                kname = name[:60]
+    out = dict(kernel=kname, commit=os.environ.get('ST_COMMIT'), FETCH_SIZE_avg_KB=round(vals['FETCH_SIZE'], 1), WRITE_SIZE_avg_KB=round(vals['WRITE_SIZE'], 1),
                correction='MI355X_MICROARCH.md: FETCH_SIZE reads exactly 1/2 of wide coalesced reads on gfx950 -> x2; '
                           'WRITE_SIZE uncalibrated, taken as is',
                hbm_bytes_per_launch=int(round((2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)),
                algorithmic_bytes_per_launch=ALGO_BYTES,
                source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 2 --warmup 1 '
-                      '--no-cpu-baseline`, see %s_pmc_hbm_traffic.txt' % tag)
-    open(os.path.join(REPO, 'profiles', '%s_pmc_hbm_traffic.txt' % tag), 'w').write('\n'.join(lines) + '\n')
-    json.dump(out, open(os.path.join(REPO, 'profiles', '%s_pmc_hbm_traffic.json' % tag), 'w'), indent=1)
+                      '--no-cpu-baseline%s`, see %s_pmc_hbm_traffic%s.txt' % (' ' + os.environ.get('PMC_ARGS', '') if SFX else '', tag, SFX))
+    open(os.path.join(REPO, 'profiles', '%s_pmc_hbm_traffic%s.txt' % (tag, SFX)), 'w').write('\n'.join(lines) + '\n')
+    json.dump(out, open(os.path.join(REPO, 'profiles', '%s_pmc_hbm_traffic%s.json' % (tag, SFX)), 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -10,8 +10,8 @@ bash tools/gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log
 python tools/pmc_summary.py $TAG > $OUT/pmc_summary.log 2>&1
 PMC_ARGS="--workload c5" PMC_SFX=_c5 bash tools/gpu_pmc.sh $TAG > $OUT/pmc_c5.log 2>&1
 PMC_ARGS="--workload c5" python tools/pmc_summary.py $TAG _c5 pk_lstm_rt2_kernel 49946624 >> $OUT/pmc_summary.log 2>&1    # mean of 4(4H K + 8H + B K + 3 B H), B = 64
-PMC_ARGS="--workload c3" PMC_SFX=_c3 bash tools/gpu_pmc.sh $TAG > $OUT/pmc_c3.log 2>&1
-PMC_ARGS="--workload c3" python tools/pmc_summary.py $TAG _c3 vq_l2_mfma_kernel 10731776 >> $OUT/pmc_summary.log 2>&1     # 4128 (520 + 4 x 512) + 512 x 64 x 4
+PMC_ARGS="--workload c3 --vq-head-only" PMC_SFX=_c3 bash tools/gpu_pmc.sh $TAG > $OUT/pmc_c3.log 2>&1
+PMC_ARGS="--workload c3 --vq-head-only" python tools/pmc_summary.py $TAG _c3 vq_l2_mfma_kernel 10731776 >> $OUT/pmc_summary.log 2>&1     # 4128 (520 + 4 x 512) + 512 x 64 x 4
 cp profiles/${TAG}_pmc_* $OUT/ 2>/dev/null; rm -rf $ROOT/gpurun_out/pmc_${TAG}*
 tail -5 $OUT/pmc_summary.log
 echo "== headline bench"; timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?"; cut -c1-300 $OUT/bench.json
@@ -26,7 +26,7 @@ timeout 600 python bench.py --workload c5 --steps 5 --warmup 2 > $OUT/bench_c5.j
 timeout 300 python bench.py --workload c3 --steps 10 > $OUT/bench_c3.json 2>/dev/null; cut -c1-200 $OUT/bench_c3.json
 timeout 900 python bench.py --workload train --steps 5 --warmup 2 > $OUT/bench_train.json 2>/dev/null; cut -c1-300 $OUT/bench_train.json
 timeout 900 python bench.py --workload train --dist --steps 5 --warmup 2 --no-cpu-baseline > $OUT/train_step_rccl_ws1.json 2>/dev/null; cut -c1-200 $OUT/train_step_rccl_ws1.json
-timeout 600 python tools/rccl_ws1_check.py 2>/dev/null | tail -1 > $OUT/rccl_ws1_check.json; cut -c1-200 $OUT/rccl_ws1_check.json
+timeout 600 python tools/rccl_ws1_check.py 2>/dev/null | grep '^{' | tail -1 > $OUT/rccl_ws1_check.json; cut -c1-200 $OUT/rccl_ws1_check.json
 ST_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --workload train --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $OUT/train_step_2ranks_gloo_shared_gpu.json; cut -c1-200 $OUT/train_step_2ranks_gloo_shared_gpu.json
 timeout 600 python tools/bench_full_forward.py 2>/dev/null | tail -1 > $OUT/bench_full_forward.json; cut -c1-300 $OUT/bench_full_forward.json
 echo "== profiles of the secondary benches"

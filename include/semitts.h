@@ -226,10 +226,6 @@ typedef struct st_attn_fin_job {
     int L, A, E, F, K;
     unsigned* status;   /* optional device word: bit 0 is set when a fin workgroup gave up waiting for its granules (the query is
                          * then poisoned with NaN as well); never cleared by the library -- the caller zeroes and reads it */
-    /* st_query_attn_rng_fwd only, optional: with pm != NULL the range workgroups compute S = pm + W_l conv([w_prev ; w_cum_prev]) of their
-     * positions THEMSELVES while the query projection runs (s_buf is then unused and no "pre" job has to write S in the previous launch):
-     * pm (B, L, A), w_prev (B rows, stride ld_wprev), loc_conv_w (F, 2, K), loc_lin_w (A, F); needs st_query_attn_rng_mode(...) == 2 */
-    const float* pm; const float* w_prev; int ld_wprev; const float* loc_conv_w; const float* loc_lin_w;
 } st_attn_fin_job;
 int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
                           const st_attn_fin_job* job, int B, void* stream);
@@ -241,9 +237,6 @@ int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q,
  * Needs E % (4 * parts) == 0, E / parts <= 256 and every workgroup resident at once: st_query_attn_rng_fits(B, A, parts) != 0
  * (occupancy query of the kernel x compute units); otherwise use the two / three launch forms. */
 int st_query_attn_rng_fits(int B, int A, int parts);
-/* 0: does not fit; 1: fits with S given (s_buf); 2: also fits in the form that computes S inside the launch (st_attn_fin_job.pm):
- * at most 64 positions per range, F <= 32 and a multiple of 4, K odd */
-int st_query_attn_rng_mode(int B, int L, int A, int parts, int F, int K);
 size_t st_attn_rng_xchg_words(int B, int E, int parts);
 int st_query_attn_rng_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules,
                           unsigned long long* xchg, unsigned epoch, const st_attn_fin_job* job, int B, void* stream);

@@ -91,8 +91,7 @@ class StAttnFinJob(C.Structure):
     _fields_ = [('s_buf', C.c_void_p), ('memory', C.c_void_p), ('w_cum_prev', C.c_void_p),
                 ('w_out', C.c_void_p), ('ld_wout', C.c_int), ('w_cum_out', C.c_void_p), ('v', C.c_void_p),
                 ('ctx_dst', StT16View * 3), ('n_ctx_dst', C.c_int), ('parts', C.c_int),
-                ('L', C.c_int), ('A', C.c_int), ('E', C.c_int), ('F', C.c_int), ('K', C.c_int), ('status', C.c_void_p),
-                ('pm', C.c_void_p), ('w_prev', C.c_void_p), ('ld_wprev', C.c_int), ('loc_conv_w', C.c_void_p), ('loc_lin_w', C.c_void_p)]
+                ('L', C.c_int), ('A', C.c_int), ('E', C.c_int), ('F', C.c_int), ('K', C.c_int), ('status', C.c_void_p)]
 
 
 P, I, F, Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -163,7 +162,6 @@ SIGNATURES = {
     'st_prenet_norm_fwd': [P, I, I, P, P, P, P, P, F, F, P, I, C.POINTER(StT16View), I, I, P],
     'st_handoff_wait_selftest': [P, C.c_uint, I, P, P, I, P],
     'st_query_attn_rng_fits': [I, I, I],
-    'st_query_attn_rng_mode': [I, I, I, I, I, I],
     'st_attn_rng_xchg_words': [I, I, I],
     'st_query_attn_rng_fwd': [P, C.POINTER(StT16View), I, P, P, C.c_uint, C.POINTER(StAttnFinJob), I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],

@@ -144,23 +144,15 @@ struct ArArgs {
     unsigned long long* xchg;              // (B, P, E + 4) granules: c_p (E), m_p, s_p, two pads
     unsigned epoch; unsigned* status;
     int B, L, A, E, P, Lp;
-    // PRE form: S = pm + W_l conv([w_prev ; cum_prev]) of the range is computed HERE, while the workgroup would otherwise wait for the
-    // processed query, instead of being written by a "pre" job of the previous launch and read back (s_buf unused)
-    const float* pm; const float* w_prev; int ld_wprev; const float* loc_conv_w; const float* loc_lin_w; int F, K;
 };
 
-constexpr int AR_WLD = 260;       // row stride of the transposed W_l in LDS (16-byte aligned rows, 4 banks apart: the transposing stores spread)
-constexpr int AR_PRE_LP = 64;     // PRE form: positions per range (8 waves x 8 register slots), filters <= 32, 2 K F <= 2048
-
-template <int NT, bool PRE>
+template <int NT>
 __device__ __forceinline__ void at_range_body(const ArArgs& a, const int wg) {
     __shared__ float es[512];                           // energies, then w~ of this range (Lp <= 512)
     __shared__ __attribute__((aligned(16))) float part[4 * NT];
     __shared__ __attribute__((aligned(16))) float pqs[256];
     __shared__ __attribute__((aligned(16))) float cb[8 * 256];   // the other parts' partial contexts, this workgroup's dims only
     __shared__ float stat[2], gst[16];
-    __shared__ __attribute__((aligned(16))) float wlt[PRE ? 32 * AR_WLD : 4];     // PRE: W_l^T [f][a], rows AR_WLD apart
-    __shared__ float hist[PRE ? 2 * (AR_PRE_LP + 64) : 2];                        // PRE: zero-padded [w_prev ; cum_prev] of the range + halo
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P, b = wg / P, p = wg - b * P;
@@ -183,64 +175,8 @@ __device__ __forceinline__ void at_range_body(const ArArgs& a, const int wg) {
     const float vsum = (v4[0] + v4[1]) + (v4[2] + v4[3]);
     constexpr int NPW = 8;
     f32x4 spf[NPW];
-    if (!PRE) {
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) spf[i] = st_ld4(sb + (size_t)min(wave + i * NW, max(n - 1, 0)) * A + a0);
-    } else {
-        // ---- S of this range, computed in the shadow of the query projection (ref: src/module.py:384-385 + the pm addend of :389)
-        const int F = a.F, K = a.K, pad = (K - 1) / 2, HL = n + K - 1;        // history positions l0 - pad .. l1 + pad
-        const float* pmb = a.pm + ((size_t)b * L + l0) * A;
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) spf[i] = st_ld4(pmb + (size_t)min(wave + i * NW, max(n - 1, 0)) * A + a0);
-        // operands of the conv and of W_l: all requested before the first LDS store
-        f32x4 wl4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {          // W_l (A, F) row-major: thread -> 4 consecutive floats of a row
-            const int idx = tid + j * NT;
-            wl4[j] = idx * 4 < A * F ? st_ld4(a.loc_lin_w + (size_t)idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        float wcv[4], hv = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int idx = tid + j * NT; wcv[j] = idx < F * 2 * K ? a.loc_conv_w[idx] : 0.0f; }
-        if (tid < 2 * HL) {
-            const int c = tid / HL, p = tid - c * HL, l = l0 + p - pad;
-            if (l >= 0 && l < L) hv = c == 0 ? a.w_prev[(size_t)b * a.ld_wprev + l] : a.w_cum_prev[(size_t)b * L + l];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {          // transposed to [f][a] (A <= 256): the S loop reads 4 dims of one filter as 16 bytes
-            const int idx = (tid + j * NT) * 4;
-            if (idx < A * F) {
-                const int ar = idx / F, f0 = idx - ar * F;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) wlt[(f0 + c) * AR_WLD + ar] = wl4[j][c];
-            }
-        }
-        float* wcs = part;                     // conv filters [f][c][k] (the context-partial area is free until the context phase)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int idx = tid + j * NT; if (idx < F * 2 * K) wcs[idx] = wcv[j]; }
-        if (tid < 2 * HL) hist[tid] = hv;
-        st_lds_barrier();
-        float* cfs = cb;                       // conv features [f][AR_PRE_LP] (the exchange staging area is free until the combine)
-        for (int idx = tid; idx < F * n; idx += NT) {
-            const int f = idx % F, l = idx / F;
-            const float* wf = wcs + f * 2 * K;
-            float acc = 0.0f;
-            for (int c = 0; c < 2; ++c)
-                for (int k = 0; k < K; ++k) acc = fmaf(wf[c * K + k], hist[c * HL + l + k], acc);
-            cfs[f * AR_PRE_LP + l] = acc;
-        }
-        st_lds_barrier();
-        for (int f = 0; f < F; ++f) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlt + f * AR_WLD + a0);
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) {
-                const float c = cfs[f * AR_PRE_LP + min(wave + i * NW, AR_PRE_LP - 1)];
-                spf[i][0] = fmaf(c, w4[0], spf[i][0]); spf[i][1] = fmaf(c, w4[1], spf[i][1]);
-                spf[i][2] = fmaf(c, w4[2], spf[i][2]); spf[i][3] = fmaf(c, w4[3], spf[i][3]);
-            }
-        }
-        st_lds_barrier();                      // part / cb are reused below
-    }
+    for (int i = 0; i < NPW; ++i) spf[i] = st_ld4(sb + (size_t)min(wave + i * NW, max(n - 1, 0)) * A + a0);
     // the processed query of this step: one wave polls the granules, the others take it from LDS
     if (wave == 0) {
         const f32x4 q4 = at_wait_granules(a.pq_gran + (size_t)b * A, a.epoch, lane, A, a.status, AT_GRAN_SPINS);
@@ -262,7 +198,7 @@ __device__ __forceinline__ void at_range_body(const ArArgs& a, const int wg) {
         e = st_wave_sum_dpp(e);
         if (lane == 0) es[l] = e;
     }
-    for (int l = wave + NPW * NW; !PRE && l < n; l += NW) {      // (the PRE form holds at most NPW * NW = 64 positions)
+    for (int l = wave + NPW * NW; l < n; l += NW) {
         const f32x4 s4 = st_ld4(sb + (size_t)l * A + a0);
         float acc = 0.0f;
 #pragma unroll

@@ -237,9 +237,6 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     // ... or, when the device holds all its workgroups at once, query projection + fin part over position ranges + combine as ONE launch
     const bool fin_rng = fin_split && !pre_in_pq && io->pq_granules && io->attn_xchg && sp_parts <= 8 && A % 16 == 0 && E % (4 * sp_parts) == 0 &&
                          E / sp_parts <= 256 && (sp_parts - 1) * ((L + sp_parts - 1) / sp_parts) < L && st_query_attn_rng_fits(B, A, sp_parts);
-    // ... and, when the ranges are short enough, with the location part (conv + W_l + processed memory -> S) computed by the range
-    // workgroups themselves in the shadow of the query projection: S is never written or read back and the proj launch carries no pre job
-    const bool rng_pre = fin_rng && st_query_attn_rng_mode(B, L, A, sp_parts, d->F, d->K) == 2 && st_aligned16(io->pm) && st_aligned16(w->attn_loc_lin_w);
     if (fin_rng) {
         ST_HIP(hipMemsetAsync(io->pq_granules, 0, (size_t)B * A * sizeof(unsigned long long), (hipStream_t)stream));
         ST_HIP(hipMemsetAsync(io->attn_xchg, 0, st_attn_rng_xchg_words(B, E, sp_parts) * sizeof(unsigned long long), (hipStream_t)stream));
@@ -290,10 +287,6 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             st_attn_fin_job fj;
             memset(&fj, 0, sizeof(fj));
             fj.s_buf = t == 0 ? io->pm : io->attn_s_buf + (size_t)t * io->attn_s_step_floats;
-            if (rng_pre) {
-                fj.s_buf = nullptr; fj.pm = io->pm; fj.w_prev = w_prev; fj.ld_wprev = t == 0 ? L : ldal;
-                fj.loc_conv_w = w->attn_loc_conv_w; fj.loc_lin_w = w->attn_loc_lin_w;
-            }
             fj.memory = io->memory; fj.w_cum_prev = io->wcum_tape + (size_t)t * BL;
             fj.w_out = io->align_out + (size_t)t * L; fj.ld_wout = ldal; fj.w_cum_out = io->wcum_tape + (size_t)(t + 1) * BL; fj.v = w->attn_v;
             for (int c = 0; c < 3; ++c) fj.ctx_dst[c] = ctx_dst[c];
@@ -361,7 +354,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                                  fuse ? in_dim + 1 : 0, ST_ACT_RELU,
                                                  io->prenet_mask ? io->prenet_mask + (size_t)t * 2 * B * P : nullptr, P,
                                                  fuse ? &pre1_dst : nullptr, B, in_dim + 1 + (fuse ? P : 0),
-                                                 split_attn && !rng_pre && t + 1 < steps && !ST_SKIPPED(6) ? &job : nullptr, stream);
+                                                 split_attn && t + 1 < steps && !ST_SKIPPED(6) ? &job : nullptr, stream);
         if (rc) return rc;
 
         // 6. next decoder input -> xq_{t+1}[dec_in part]                 ref: :190-206

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(KW * 64) void pk_attnfin_kernel(const f32x4* w, con
 // Long texts: the query projection and the fin part over POSITION ranges (at_range_body) with the combine inside the launch: the
 // linear's workgroups, then B * P range workgroups that exchange their partial results as granules.  At most 128 VGPRs
 // (__launch_bounds__(512, 4)) so that two workgroups fit a compute unit: 64 + 64 * 4 = 320 workgroups at C5 must be resident at once.
-template <int NB, int KW, int TRIP, bool PRE>
+template <int NB, int KW, int TRIP>
 __global__ __launch_bounds__(KW * 64, 4) void pk_attnrng_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
                                                                 const int B, const int N, const int tiles_a, const int n_lin,
                                                                 const PkArgs a_rest, const ArArgs t) {
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(KW * 64, 4) void pk_attnrng_kernel(const f32x4* w, 
         const int by = n_lin <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
         pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
     }
-    else at_range_body<AT_THREADS, PRE>(t, i - n_lin);
+    else at_range_body<AT_THREADS>(t, i - n_lin);
 }
 
 #ifndef PK_TRIP_SMALL
@@ -855,32 +855,21 @@ extern "C" int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* 
 }
 
 // workgroups of pk_attnrng_kernel the device holds at once (occupancy API x compute units; 0 on error)
-static int pk_attnrng_capacity(bool pre = false) {
-    static int cap[2] = {-1, -1};
-    int& c = cap[pre ? 1 : 0];
-    if (c < 0) {
+static int pk_attnrng_capacity() {
+    static int cap = -1;
+    if (cap < 0) {
         int per_cu = 0;
-        const void* k = pre ? reinterpret_cast<const void*>(pk_attnrng_kernel<1, 8, PK_TRIP_SMALL, true>)
-                            : reinterpret_cast<const void*>(pk_attnrng_kernel<1, 8, PK_TRIP_SMALL, false>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 8 * 64, 0) != hipSuccess) per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pk_attnrng_kernel<1, 8, PK_TRIP_SMALL>), 8 * 64, 0) != hipSuccess)
+            per_cu = 0;
         (void)hipGetLastError();
-        c = per_cu * st_device_cus();
+        cap = per_cu * st_device_cus();
     }
-    return c;
+    return cap;
 }
 
 extern "C" int st_query_attn_rng_fits(int B, int A, int parts) {
     if (B <= 0 || A <= 0 || A % 16 != 0 || parts < 2 || parts > 8) return 0;
     return (A / 16) * ((B + 15) / 16) + B * parts <= pk_attnrng_capacity() ? 1 : 0;
-}
-
-// 2: the form that also computes S = pm + W_l conv(history) inside the launch fits (and its shape limits hold), 1: only the plain one
-extern "C" int st_query_attn_rng_mode(int B, int L, int A, int parts, int F, int K) {
-    if (!st_query_attn_rng_fits(B, A, parts)) return 0;
-    const int Lp = (L + parts - 1) / parts;
-    const bool pre_ok = Lp <= AR_PRE_LP && F > 0 && F <= 32 && F % 4 == 0 && K > 0 && (K & 1) && K <= 63 && 2 * K * F <= 4 * AT_THREADS &&
-                        A * F <= 16 * AT_THREADS && (A / 16) * ((B + 15) / 16) + B * parts <= pk_attnrng_capacity(true);
-    return pre_ok ? 2 : 1;
 }
 
 extern "C" size_t st_attn_rng_xchg_words(int B, int E, int parts) { return (size_t)B * parts * (E + 4); }
@@ -895,14 +884,9 @@ extern "C" int st_query_attn_rng_fwd(const float* packed_wq, const st_t16_view* 
                  "st_query_attn_rng_fwd: parts=%d (2..8), E=%d", parts, E);
     const int Lp = (L + parts - 1) / parts;
     ST_CHECK_ARG(Lp <= 512 && (parts - 1) * Lp < L, "st_query_attn_rng_fwd: L=%d over %d parts leaves an empty or oversized range", L, parts);
-    const bool pre = job->pm != nullptr;
-    ST_CHECK_ARG((job->s_buf || pre) && job->memory && job->w_cum_prev && job->w_out && job->w_cum_out && job->v, "st_query_attn_rng_fwd: null attention operand");
-    ST_CHECK_ARG(!pre || (job->w_prev && job->loc_conv_w && job->loc_lin_w && st_aligned16(job->pm) && st_aligned16(job->loc_lin_w) &&
-                          st_query_attn_rng_mode(B, L, A, parts, job->F, job->K) == 2),
-                 "st_query_attn_rng_fwd: the form with the location part inside needs w_prev / the location weights, at most %d positions per range, "
-                 "F <= 32 (multiple of 4), an odd K", AR_PRE_LP);
+    ST_CHECK_ARG(job->s_buf && job->memory && job->w_cum_prev && job->w_out && job->w_cum_out && job->v, "st_query_attn_rng_fwd: null attention operand");
     ST_CHECK_ARG(job->n_ctx_dst >= 1 && job->n_ctx_dst <= 3, "st_query_attn_rng_fwd: n_ctx_dst=%d", job->n_ctx_dst);
-    ST_CHECK_ARG((pre || st_aligned16(job->s_buf)) && st_aligned16(job->memory) && st_aligned16(job->v) && (reinterpret_cast<uintptr_t>(granules) & 7) == 0 &&
+    ST_CHECK_ARG(st_aligned16(job->s_buf) && st_aligned16(job->memory) && st_aligned16(job->v) && (reinterpret_cast<uintptr_t>(granules) & 7) == 0 &&
                  (reinterpret_cast<uintptr_t>(xchg) & 7) == 0, "st_query_attn_rng_fwd: operands must be 16-byte aligned");
     PkArgs a;
     memset(&a, 0, sizeof(a));
@@ -917,20 +901,14 @@ extern "C" int st_query_attn_rng_fwd(const float* packed_wq, const st_t16_view* 
     for (int d = 0; d < job->n_ctx_dst; ++d) t.ctx_dst[d] = job->ctx_dst[d];
     t.pq_gran = granules; t.xchg = xchg; t.epoch = epoch; t.status = job->status;
     t.B = B; t.L = L; t.A = A; t.E = E; t.P = parts; t.Lp = Lp;
-    t.pm = job->pm; t.w_prev = job->w_prev; t.ld_wprev = job->ld_wprev; t.loc_conv_w = job->loc_conv_w; t.loc_lin_w = job->loc_lin_w;
-    t.F = job->F; t.K = job->K;
     const int tiles = A / 16, BT = (B + 15) >> 4;
     const int n_lin = tiles * BT, n_rng = B * parts;
     // the waiting workgroups hold their compute units: everything must be resident at once
-    ST_CHECK_ARG(n_lin + n_rng <= pk_attnrng_capacity(pre), "st_query_attn_rng_fwd: %d + %d workgroups do not fit the device at once (%d)",
-                 n_lin, n_rng, pk_attnrng_capacity(pre));
+    ST_CHECK_ARG(n_lin + n_rng <= pk_attnrng_capacity(), "st_query_attn_rng_fwd: %d + %d workgroups do not fit the device at once (%d)",
+                 n_lin, n_rng, pk_attnrng_capacity());
     constexpr int KW = 8;
-    if (pre)
-        hipLaunchKernelGGL((pk_attnrng_kernel<1, KW, PK_TRIP_SMALL, true>), dim3(n_lin + n_rng), dim3(KW * 64), 0, (hipStream_t)stream, a.w, a.x,
-                           a.w_kbs, a.x_kbs, a.KB, a.B, a.N, tiles, n_lin, a, t);
-    else
-        hipLaunchKernelGGL((pk_attnrng_kernel<1, KW, PK_TRIP_SMALL, false>), dim3(n_lin + n_rng), dim3(KW * 64), 0, (hipStream_t)stream, a.w, a.x,
-                           a.w_kbs, a.x_kbs, a.KB, a.B, a.N, tiles, n_lin, a, t);
+    hipLaunchKernelGGL((pk_attnrng_kernel<1, KW, PK_TRIP_SMALL>), dim3(n_lin + n_rng), dim3(KW * 64), 0, (hipStream_t)stream, a.w, a.x, a.w_kbs,
+                       a.x_kbs, a.KB, a.B, a.N, tiles, n_lin, a, t);
     ST_LAUNCH_CHECK();
     return 0;
 }

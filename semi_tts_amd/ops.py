@@ -178,13 +178,12 @@ def query_attn_fin(packed_wq, h_q_t16, Q, s_buf, memory, w_cum_prev, v, w_out, w
 
 
 def query_attn_rng(packed_wq, h_q_t16, Q, s_buf, memory, w_cum_prev, v, w_out, w_cum_out, ctx_t16, parts, epoch=1, granules=None,
-                   xchg=None, status=None, pre=None):
+                   xchg=None, status=None):
     """query projection + attention fin part over `parts` position ranges + combine in ONE launch: st_query_attn_rng_fwd.
-    `granules` (B, 2 A floats) and `xchg` must be zero before the first epoch; returns them.
-    pre = (pm, w_prev, loc_conv_w, loc_lin_w): S is computed inside the launch from these instead of being read from s_buf (None)"""
+    `granules` (B, 2 A floats) and `xchg` must be zero before the first epoch; returns them."""
     lib = _lib.load()
     B, L, E = memory.shape
-    A = (s_buf if s_buf is not None else pre[0]).shape[-1]
+    A = s_buf.shape[-1]
     if granules is None:
         granules = torch.zeros(B, 2 * A, device=memory.device, dtype=torch.float32)
     if xchg is None:
@@ -195,10 +194,6 @@ def query_attn_rng(packed_wq, h_q_t16, Q, s_buf, memory, w_cum_prev, v, w_out, w
     job.ctx_dst[0] = t16_view(ctx_t16, K=E)
     job.n_ctx_dst, job.parts, job.L, job.A, job.E, job.F, job.K = 1, int(parts), L, A, E, 0, 0
     job.status = _p(status, torch.int32)
-    if pre is not None:
-        pm, w_prev, wc, wl = pre
-        job.pm, job.w_prev, job.ld_wprev, job.loc_conv_w, job.loc_lin_w = _p(pm), _p(w_prev), int(w_prev.stride(0)), _p(wc), _p(wl)
-        job.F, job.K = int(wc.shape[0]), int(wc.shape[2])
     hv = t16_view(h_q_t16, K=Q)
     check(lib.st_query_attn_rng_fwd(_p(packed_wq), C.byref(hv), 16 * kb16(Q), _p(granules), _p(xchg), int(epoch), C.byref(job), B,
                                     stream_handle()), 'st_query_attn_rng_fwd')

@@ -1039,34 +1039,3 @@ def test_asr_postnet_against_reference_golden(dev):
     report('asr_postnet_golden', err=err)
     assert y.shape == A['y'].shape and err < 2e-5
     assert float((y.exp().sum(-1) - 1).abs().max()) < 1e-5
-
-
-@pytest.mark.parametrize('B,L,Q,A,E,parts', [(64, 171, 1024, 256, 512, 4), (5, 130, 64, 32, 64, 4), (2, 300, 128, 64, 128, 8)])
-def test_range_fin_with_the_location_part_inside_the_launch(dev, B, L, Q, A, E, parts):
-    """st_query_attn_rng_fwd with st_attn_fin_job.pm set: the range workgroups compute S = pm + W_l conv([w_prev ; cum_prev]) of their
-    positions themselves (in the shadow of the query projection) == the same launch reading the S a pre job wrote
-    (ref: src/module.py:384-391), to fp32 rounding; first step (no history) and a later one."""
-    from semi_tts_amd import _lib, ops
-    lib = _lib.load()
-    F_, K = 32, 31
-    assert lib.st_query_attn_rng_mode(B, L, A, parts, F_, K) == 2
-    wq, hq = rnd(A, Q, scale=Q ** -0.5, seed=1), rnd(B, Q, seed=2)
-    pm, mem = rnd(B, L, A, seed=3), rnd(B, L, E, seed=4)
-    g = torch.Generator().manual_seed(5)
-    w_prev = torch.softmax(torch.randn(B, L, generator=g) * 3, -1)
-    w_cum = w_prev + torch.softmax(torch.randn(B, L, generator=g), -1)
-    v, wc, wl = rnd(1, A, seed=6), rnd(F_, 2, K, scale=0.3, seed=7), rnd(A, F_, scale=0.3, seed=8)
-    for hist in (False, True):
-        wp = w_prev if hist else torch.zeros(B, L)
-        wcm = w_cum if hist else torch.zeros(B, L)
-        d = [t.to(dev) for t in (wq, hq, pm, mem, wp, wcm, v, wc, wl)]
-        packed = ops.pack_weight([d[0]], [Q], A)
-        h_t = ops.tile_rows(d[1])
-        S = ops.attn_pre(d[2], d[4], d[5], d[7], d[8])
-        w1, c1, w2, c2 = (torch.full((B, L), float('nan'), device=dev) for _ in range(4))
-        x1, x2 = torch.zeros(ops.t16_floats(B, E), device=dev), torch.zeros(ops.t16_floats(B, E), device=dev)
-        ops.query_attn_rng(packed, h_t, Q, S, d[3], d[5], d[6], w1, c1, x1, parts)
-        ops.query_attn_rng(packed, h_t, Q, None, d[3], d[5], d[6], w2, c2, x2, parts, pre=(d[2], d[4], d[7], d[8]))
-        errs = dict(w=maxdiff(w2, w1), cum=maxdiff(c2, c1), ctx=maxdiff(ops.untile_rows(x2, B, E), ops.untile_rows(x1, B, E)))
-        report('query_attn_rng_pre', B=B, L=L, parts=parts, hist=hist, **errs)
-        assert errs['w'] < 2e-6 and errs['cum'] < 2e-6 and errs['ctx'] < 2e-5

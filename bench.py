@@ -404,7 +404,7 @@ def bench_decode(args, rk):
         'us_per_decode_step': round(us_step, 2),
         'roofline': roof,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and rk.world == 1:      # (rank 0 at N = 1 only: the other ranks of a multi-GPU run would idle in the barrier)
         res['cpu_baseline'] = cpu_baseline(m, memory, spk, frames=T)
     try:
         res['device'] = ops.device_info()
@@ -470,7 +470,7 @@ def bench_vq(args, rk):
     if rk.rank != 0:
         return None
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and rk.world == 1:
         # the reference's own formulation on the host: neg_batch_l2 (expanded squares) -> softmax -> argmax -> embedding lookup
         # (src/embed.py:105-147,208-213; the codebook has no nn module beyond the table, so this is the functional restatement)
         from oracle import vq_oracle as VQ
@@ -532,7 +532,7 @@ def bench_train(args, rk):
     if rk.rank != 0:
         return None
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and rk.world == 1:
         cpu = cpu_baseline_train(tr, batch, config)
     ms = {k: v / args.steps * 1e3 for k, v in variants.items()}
     frames = rk.world * batch[2].shape[0] * batch[2].shape[1] * args.steps

@@ -201,6 +201,25 @@ int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view
                                         int n_split2, int act2, const float* mask2, int ldmask2, const st_t16_view* y3_dst,
                                         int B, int N, const st_attn_pre_job* pre, void* stream);
 
+/* st_skinny_linear_packed_fwd (no bias / activation, natural y) whose output columns [n0, n0 + H) are dh of an LSTM cell: the pointwise
+ * half of that cell's backward step (st_lstm_cell_bwd_pointwise with dh0 = those columns of y) runs in the EPILOGUE of the product
+ * instead of as a launch of its own.  The BPTT of the decode loop uses it twice per step: dgates_d(t) . [W_ih_d | W_hh_d] makes
+ * dh_d(t-1) in its last D columns, and W_q^T dpq(t) makes the attention's share of dh_q(t).  Every row stride a multiple of 4, every
+ * base 16-byte aligned, n0 a multiple of 16.  ref: backward of nn.LSTMCell src/module.py:228,:277 */
+typedef struct st_lstm_pw_job {
+    int n0, H;
+    const float* dh1; int ld1;                        /* optional addend (B rows) */
+    const float* dh2; int ld2; const float* scale2;   /* optional addend * scale2 (B, H) */
+    const float* mask;                                /* optional (B, H) */
+    const float* gates;                               /* (B, 4, H) activated (i, f, g, o) */
+    const float* c; int ldc; const float* c_prev; int ldcp;
+    float* dc;                                        /* (B, H) in: dL/dc_t, out: dL/dc_{t-1} */
+    float* dgates; int ldg;                           /* (B, 4H) out */
+    st_t16_view dgates_t16;                           /* optional second copy in T16 (K = 4H) */
+} st_lstm_pw_job;
+int st_skinny_linear_packed_lstm_bwd_fwd(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                         const st_lstm_pw_job* job, void* stream);
+
 /* The fin part for LONG texts: every utterance split over `parts` (2..64) ranges of positions -- local softmax statistics and an
  * un-normalised partial context per range (flash-decoding style), then a combine launch.  S and the memory rows are read once in
  * total; st_attn_fin_t16_fwd re-reads S in each of its context slices and one compute unit has to pull ~2 L A 4 bytes (12 us at
@@ -603,6 +622,8 @@ typedef struct st_decoder_bwd_weights {   /* transposed copies prepared by the c
     const float* attn_query_w_t;   /* W_q^T                 (Q, A)      */
     const float* q_w_cat_t_p16;    /* optional: q_w_cat_t packed by st_pack_weight (N = P+E+Q, K = 4Q); NULL = natural kernels */
     const float* d_w_cat_t_p16;    /* optional: d_w_cat_t packed (N = E+Q+D, K = 4D) */
+    const float* attn_query_w_t_p16;   /* optional: W_q^T packed (N = Q, K = A): with the two above and st_decoder_bwd_io.fuse_pw the loop runs
+                                        * the cells' pointwise backward in the epilogues of its products (4 launches per step instead of 6) */
     const float* attn_v; const float* attn_loc_conv_w; const float* attn_loc_lin_w;
 } st_decoder_bwd_weights;
 
@@ -642,6 +663,10 @@ typedef struct st_decoder_bwd_io {
     const float* pre1_nat;            /* (steps, Bp, P) un-tiled prenet layer-1 outputs */
     float* d2_tape; float* dp1_tape;  /* (steps, Bp, P) out, zero on entry: gradients at the two prenet layers (-> dW1, dW0) */
     float* tmp_p; float* tmp_in;      /* (B, P), (B, r*n_mels) scratch */
+    int fuse_pw;                      /* != 0 (pure teacher forcing, packed weights incl. attn_query_w_t_p16): pointwise LSTM backward in the
+                                       * epilogues of dgates_d . W (for step t-1) and of W_q^T dpq (for step t); needs dgd_t16_b and dpq_t16 */
+    float* dgd_t16_b;                 /* second st_t16_floats(B, 4D) buffer, zero on entry (the epilogue writes step t-1 while step t is read) */
+    float* dpq_t16;                   /* st_t16_floats(B, A) scratch, zero on entry */
     int need_dxq0;                    /* != 0: also form dxq of step 0 (the gradient of dec_in_0 = prenet(go frame), which only a
                                        * normalised prenet makes non-constant) */
     const float* attn_s_tape;         /* optional (steps, B, L, A): S_t = pm + W_l loc_t saved by the forward (slot 0 unused: S_0 =
@@ -658,6 +683,16 @@ int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
                        float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
                        float* dctx_t, float* dv_t, const float* s_in,
                        int B, int L, int A, int E, int F, int K, void* stream);
+/* st_attn_step_bwd_s with a second copy of dpq in the T16 tile layout (K = A): the operand of the packed W_q^T product that follows */
+int st_attn_step_bwd_t16(const float* pq, const float* pm, const float* memory,
+                         const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                         const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                         const float* const* dctx, const int* ld_dctx, int n_dctx,
+                         const float* const* dw_direct, const int* ld_dw, int n_dw,
+                         float* dcum, const float* dcum_add, int ld_dcum_add,
+                         float* dpq, const st_t16_view* dpq_t16, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                         float* dctx_t, float* dv_t, const float* s_in,
+                         int B, int L, int A, int E, int F, int K, void* stream);
 int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
 /* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp, r*n_mels+1); NULL = zeros */
 int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int B, int Bp, int steps, int r, int n_mels,

@@ -63,7 +63,7 @@ class StDecoderIO(C.Structure):
 
 
 class StDecoderBwdWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('q_w_cat_t', 'd_w_cat_t', 'attn_query_w_t', 'q_w_cat_t_p16', 'd_w_cat_t_p16',
+    _fields_ = [(n, C.c_void_p) for n in ('q_w_cat_t', 'd_w_cat_t', 'attn_query_w_t', 'q_w_cat_t_p16', 'd_w_cat_t_p16', 'attn_query_w_t_p16',
                                           'attn_v', 'attn_loc_conv_w', 'attn_loc_lin_w')]
 
 
@@ -77,8 +77,15 @@ class StDecoderBwdIO(C.Structure):
                  ('dgd_t16', C.c_void_p), ('step_src', C.POINTER(C.c_int)), ('Bt', C.c_int)] +
                 [(n, C.c_void_p) for n in ('dY', 'dxo_rw', 'wpg_t', 'pre_w1_t', 'pre_w0_t', 'own_mask', 'xq_nat', 'pre1_nat',
                                            'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in')] +
-                [('need_dxq0', C.c_int), ('attn_s_tape', C.c_void_p)])
+                [('fuse_pw', C.c_int), ('dgd_t16_b', C.c_void_p), ('dpq_t16', C.c_void_p), ('need_dxq0', C.c_int), ('attn_s_tape', C.c_void_p)])
 
+
+
+class StLstmPwJob(C.Structure):
+    _fields_ = [('n0', C.c_int), ('H', C.c_int), ('dh1', C.c_void_p), ('ld1', C.c_int), ('dh2', C.c_void_p), ('ld2', C.c_int),
+                ('scale2', C.c_void_p), ('mask', C.c_void_p), ('gates', C.c_void_p), ('c', C.c_void_p), ('ldc', C.c_int),
+                ('c_prev', C.c_void_p), ('ldcp', C.c_int), ('dc', C.c_void_p), ('dgates', C.c_void_p), ('ldg', C.c_int),
+                ('dgates_t16', StT16View)]
 
 
 class StAttnPreJob(C.Structure):
@@ -172,6 +179,9 @@ SIGNATURES = {
                          P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     'st_attn_step_bwd_s': [P, P, P, P, I, P, P, I, P, P, P, C.POINTER(P), C.POINTER(I), I, C.POINTER(P), C.POINTER(I), I,
                            P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    'st_attn_step_bwd_t16': [P, P, P, P, I, P, P, I, P, P, P, C.POINTER(P), C.POINTER(I), I, C.POINTER(P), C.POINTER(I), I,
+                             P, P, I, P, C.POINTER(StT16View), P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    'st_skinny_linear_packed_lstm_bwd_fwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), P],
     'st_lstm_seq2_fwd': [C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, C.POINTER(I), P, C.POINTER(P), C.POINTER(P), I, I, I, P],
     'st_lstm_seq2_bwd': [P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, I, I, P],
     'st_skinny_linear_pair_fwd': [P, C.POINTER(P), I, I, I, P],

@@ -473,9 +473,12 @@ class _DecoderFn(Function):
         dxo = torch.zeros(steps * Bp, XOw, **f32) if own else ops.gemm(dY2, wpg_t)          # (steps*Bp, D+E)
 
         # every zero-initialised buffer of this backward comes out of ONE allocation and ONE fill launch
+        fuse_pw = (not own) and dec.bwd_fuse_pointwise
         zshapes = dict(dgq=(steps, Bp, 4 * Q), dgd=(steps, Bp, 4 * D), dxq=(steps + 1, Bp, XQw), dxd=(steps + 1, Bp, XDw),
                        dpq=(steps, Bp, A), dcq=(B, Q), dcd=(B, D), dh0=(B, 2, L), dh1=(B, 2, L), dcum=(B, L), dhq_attn=(B, Q),
                        dgq_t16=(ops.t16_floats(B, 4 * Q),), dgd_t16=(ops.t16_floats(B, 4 * D),))
+        if fuse_pw:
+            zshapes.update(dgd_t16_b=(ops.t16_floats(B, 4 * D),), dpq_t16=(ops.t16_floats(B, A),))
         numel = lambda shp: int(torch.Size(shp).numel())
         pool = torch.zeros(sum((numel(s) + 3) // 4 * 4 for s in zshapes.values()), **f32)      # (16-byte aligned pieces)
         zb, off = {}, 0
@@ -518,6 +521,10 @@ class _DecoderFn(Function):
         io.dcq, io.dcd, io.dcum, io.dhq_attn = ops._p(dcq), ops._p(dcd), ops._p(dcum), ops._p(dhq_attn)
         io.dhist[0], io.dhist[1] = ops._p(dh0), ops._p(dh1)
         io.dgq_t16, io.dgd_t16 = ops._p(dgq_t16), ops._p(dgd_t16)
+        if fuse_pw:      # pointwise LSTM backward in the epilogues of the loop's products (4 launches per step instead of 6)
+            wt['pq_p16'] = ops.pack_weight([wt['pq']], [A], Q)
+            bw.attn_query_w_t_p16 = ops._p(wt['pq_p16'])
+            io.fuse_pw, io.dgd_t16_b, io.dpq_t16 = 1, ops._p(zb['dgd_t16_b']), ops._p(zb['dpq_t16'])
         src_arr = (C.c_int * max(steps, 1))(*src)
         io.step_src, io.Bt = C.cast(src_arr, C.POINTER(C.c_int)), Bt
         io.need_dxq0 = 1 if ctx.has_in0 else 0

@@ -35,6 +35,7 @@ struct AbArgs {
     const float* dw_direct[3]; int ld_dw[3];   // gradient w.r.t. w_t: up to three addends (B rows each)
     float* dcum; const float* dcum_add; int ld_dcum_add;   // dL/dcum_t = dcum (B,L, in/out) + dcum_add; also an addend of dw
     float* dpq;                            // (B, A) out
+    float* dpq_t16; int dpq_kbs, dpq_kb0;  // optional second copy in the T16 tile layout (operand of the packed W_q^T product)
     float* dhist;                          // (B, 2, L) out: gradient w.r.t. [w_{t-1} ; cum_{t-1}] through the conv
     // tape slices of this step (all written, never read back here)
     float* ds_t;      // (B, L, A)  d loss / d s[l][a]              -> dpm = sum_t, dW_l = ds^T loc
@@ -439,6 +440,10 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
         for (int gq = 0; gq < ngrp; ++gq) { sv += fold[gq * A + a0]; sp += fold[AB_THREADS + gq * A + a0]; }
         a.dv_t[(size_t)b * A + a0] = sv;
         a.dpq[(size_t)b * A + a0] = sp;
+        if (a.dpq_t16) {
+            const int k = a.dpq_kb0 * 16 + a0;
+            a.dpq_t16[(((size_t)(b >> 4) * a.dpq_kbs + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3)] = sp;
+        }
     }
     AB_PROF(6);
     // ---- P5: gradient w.r.t. the attention history through the location conv
@@ -494,7 +499,7 @@ extern "C" int st_attn_dmem(const float* align, const float* dctx_tape, float* d
     return 0;
 }
 
-extern "C" int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
+static int ab_step_impl(const st_t16_view* dpq_t16, const float* pq, const float* pm, const float* memory,
                                 const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
                                 const float* loc_conv_w, const float* loc_lin_w, const float* v,
                                 const float* const* dctx, const int* ld_dctx, int n_dctx,
@@ -520,6 +525,7 @@ extern "C" int st_attn_step_bwd_s(const float* pq, const float* pm, const float*
     a.dcum = dcum; a.dcum_add = dcum_add; a.ld_dcum_add = ld_dcum_add;
     a.dpq = dpq; a.dhist = dhist; a.ds_t = ds_t; a.loc_t = loc_t; a.dloc_t = dloc_t; a.hist_t = hist_t; a.dctx_t = dctx_t; a.dv_t = dv_t;
     a.s_in = s_in;
+    if (dpq_t16 && dpq_t16->base) { a.dpq_t16 = dpq_t16->base; a.dpq_kbs = dpq_t16->kb_stride; a.dpq_kb0 = dpq_t16->kb0; }
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
     const size_t lds = (size_t)ab_layout(L, A, E, F, K).total * sizeof(float);
     ST_CHECK_ARG(lds <= 160 * 1024, "st_attn_step_bwd: L=%d needs %zu bytes of LDS (> 160 KiB)", L, lds);
@@ -533,6 +539,35 @@ extern "C" int st_attn_step_bwd_s(const float* pq, const float* pm, const float*
     else hipLaunchKernelGGL(ab_kernel<false>, dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
     ST_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
+                                  const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                                  const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                                  const float* const* dctx, const int* ld_dctx, int n_dctx,
+                                  const float* const* dw_direct, const int* ld_dw, int n_dw,
+                                  float* dcum, const float* dcum_add, int ld_dcum_add,
+                                  float* dpq, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                                  float* dctx_t, float* dv_t, const float* s_in,
+                                  int B, int L, int A, int E, int F, int K, void* stream) {
+    return ab_step_impl(nullptr, pq, pm, memory, w_prev, ld_wprev, w_cum_prev, w, ld_w, loc_conv_w, loc_lin_w, v, dctx, ld_dctx, n_dctx,
+                        dw_direct, ld_dw, n_dw, dcum, dcum_add, ld_dcum_add, dpq, dhist, ds_t, loc_t, dloc_t, hist_t, dctx_t, dv_t, s_in,
+                        B, L, A, E, F, K, stream);
+}
+
+// the same with a second copy of dpq in the T16 tile layout (the x operand of the packed W_q^T product that follows in the BPTT loop)
+extern "C" int st_attn_step_bwd_t16(const float* pq, const float* pm, const float* memory,
+                                    const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                                    const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                                    const float* const* dctx, const int* ld_dctx, int n_dctx,
+                                    const float* const* dw_direct, const int* ld_dw, int n_dw,
+                                    float* dcum, const float* dcum_add, int ld_dcum_add,
+                                    float* dpq, const st_t16_view* dpq_t16, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                                    float* dctx_t, float* dv_t, const float* s_in,
+                                    int B, int L, int A, int E, int F, int K, void* stream) {
+    return ab_step_impl(dpq_t16, pq, pm, memory, w_prev, ld_wprev, w_cum_prev, w, ld_w, loc_conv_w, loc_lin_w, v, dctx, ld_dctx, n_dctx,
+                        dw_direct, ld_dw, n_dw, dcum, dcum_add, ld_dcum_add, dpq, dhist, ds_t, loc_t, dloc_t, hist_t, dctx_t, dv_t, s_in,
+                        B, L, A, E, F, K, stream);
 }
 
 extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,

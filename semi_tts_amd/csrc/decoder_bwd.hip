@@ -34,6 +34,16 @@ extern "C" int st_attn_step_bwd_s(const float* pq, const float* pm, const float*
                                   float* dctx_t, float* dv_t, const float* s_in,
                                   int B, int L, int A, int E, int F, int K, void* stream);
 
+extern "C" int st_attn_step_bwd_t16(const float* pq, const float* pm, const float* memory,
+                                    const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
+                                    const float* loc_conv_w, const float* loc_lin_w, const float* v,
+                                    const float* const* dctx, const int* ld_dctx, int n_dctx,
+                                    const float* const* dw_direct, const int* ld_dw, int n_dw,
+                                    float* dcum, const float* dcum_add, int ld_dcum_add,
+                                    float* dpq, const st_t16_view* dpq_t16, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
+                                    float* dctx_t, float* dv_t, const float* s_in,
+                                    int B, int L, int A, int E, int F, int K, void* stream);
+
 extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io,
                                    void* stream) {
     (void)hipGetLastError();
@@ -64,6 +74,91 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
     const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
     const int ldal = steps * L;
     int rc;
+    const bool fuse_pw = io->fuse_pw && !own && packed && w->attn_query_w_t_p16 && io->dgd_t16_b && io->dpq_t16 && Q % 16 == 0 && D % 16 == 0 &&
+                         (E + Q) % 16 == 0 && A % 4 == 0 && XD % 4 == 0 && XQ % 4 == 0 && XO % 4 == 0 &&
+                         (io->q_mask == nullptr || st_aligned16(io->q_mask)) && st_aligned16(io->dxo) && st_aligned16(io->dxd) && st_aligned16(io->dxq);
+    if (fuse_pw) {
+        // Four launches per step instead of six: the pointwise half of each cell's backward step runs in the epilogue of the product
+        // that makes its dh -- dgates_d(t) . [W_ih_d | W_hh_d] makes dh_d(t-1) in its last D columns (so the decoder cell's pointwise
+        // step of t-1 rides there; the T16 copy of dgates_d ping-pongs between two buffers because step t's is still being read), and
+        // W_q^T dpq(t), now a packed product over the T16 copy of dpq the attention backward writes, makes the attention's share of dh_q(t).
+        float* dgd_buf[2] = {io->dgd_t16, io->dgd_t16_b};
+        const int kbd = (4 * D + 15) >> 4;
+        st_t16_view dpq_v = {io->dpq_t16, (A + 15) >> 4, 0};
+        {   // the last step's decoder-cell pointwise part has no product in front of it
+            const int t = steps - 1;
+            st_t16_view v0 = {dgd_buf[t & 1], kbd, 0};
+            rc = st_lstm_cell_bwd_pointwise(io->dxo + (size_t)t * Bp * XO, XO, nullptr, 0, nullptr, 0, nullptr,
+                                            io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
+                                            io->gates_d_tape + (size_t)t * 4 * BD, io->cd_tape + (size_t)(t + 1) * BD, D,
+                                            io->cd_tape + (size_t)t * BD, D, io->dcd, io->dgd + (size_t)t * Bp * 4 * D, 4 * D, &v0, B, D, stream);
+            if (rc) return rc;
+        }
+        for (int t = steps - 1; t >= 0; --t) {
+            const float* dxo = io->dxo + (size_t)t * Bp * XO;
+            float* dxd = io->dxd + (size_t)t * Bp * XD;
+            float* dxq = io->dxq + (size_t)t * Bp * XQ;
+            const float* dxq_next = io->dxq + (size_t)(t + 1) * Bp * XQ;
+            float* dpq = io->dpq + (size_t)t * Bp * A;
+            float* dhist_cur = io->dhist[t & 1];
+            const float* dhist_next = io->dhist[(t + 1) & 1];
+            // b (+ a of step t-1). dxd_t = dgates_d_t [W_ih_d | W_hh_d]; its columns [E+Q, E+Q+D) + dxo_{t-1}[:, :D] = dh_d(t-1)
+            st_t16_view x_v = {dgd_buf[t & 1], kbd, 0};
+            if (t > 0) {
+                st_lstm_pw_job j;
+                memset(&j, 0, sizeof(j));
+                j.n0 = E + Q; j.H = D;
+                j.dh1 = io->dxo + (size_t)(t - 1) * Bp * XO; j.ld1 = XO;
+                j.mask = io->d_mask ? io->d_mask + (size_t)(t - 1) * BD : nullptr;
+                j.gates = io->gates_d_tape + (size_t)(t - 1) * 4 * BD;
+                j.c = io->cd_tape + (size_t)t * BD; j.ldc = D; j.c_prev = io->cd_tape + (size_t)(t - 1) * BD; j.ldcp = D;
+                j.dc = io->dcd; j.dgates = io->dgd + (size_t)(t - 1) * Bp * 4 * D; j.ldg = 4 * D;
+                j.dgates_t16.base = dgd_buf[(t - 1) & 1]; j.dgates_t16.kb_stride = kbd; j.dgates_t16.kb0 = 0;
+                rc = st_skinny_linear_packed_lstm_bwd_fwd(w->d_w_cat_t_p16, &x_v, 4 * D, dxd, XD, B, XD, &j, stream);
+            } else
+                rc = st_skinny_linear_packed_fwd(w->d_w_cat_t_p16, &x_v, 4 * D, nullptr, ST_ACT_NONE, nullptr, 0, dxd, XD, nullptr,
+                                                 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XD, stream);
+            if (rc) return rc;
+            // c. attention (dpq also in T16)
+            const float* dctx[3] = {dxo + D, dxd, dxq_next + P};
+            const int ld_dctx[3] = {XO, XD, XQ};
+            const float* dwd[2] = {dhist_next, io->dalign ? io->dalign + (size_t)t * L : nullptr};
+            const int ld_dw[2] = {2 * L, ldal};
+            const float* s_in = io->attn_s_tape ? (t == 0 ? io->pm : io->attn_s_tape + (size_t)t * BL * A) : nullptr;
+            rc = st_attn_step_bwd_t16(io->pq_all + (size_t)t * Bp * A, io->pm, io->memory,
+                                      t > 0 ? io->align + (size_t)(t - 1) * L : nullptr, ldal, io->wcum_tape + (size_t)t * BL,
+                                      io->align + (size_t)t * L, ldal, w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v,
+                                      dctx, ld_dctx, 3, dwd, ld_dw, io->dalign ? 2 : 1,
+                                      io->dcum, dhist_next + L, 2 * L,
+                                      dpq, &dpq_v, dhist_cur, io->ds_tape + (size_t)t * BL * A, io->loc_tape + (size_t)t * BL * d->F,
+                                      io->dloc_tape + (size_t)t * BL * d->F, io->hist_tape + (size_t)t * BL * 2,
+                                      io->dctx_tape + (size_t)t * B * E, io->dv_tape + (size_t)t * B * A, s_in,
+                                      B, L, A, E, d->F, d->K, stream);
+            if (rc) return rc;
+            // d + e. dh_q = W_q^T dpq + (W_hh_q^T dgates_q)_{t+1} + std * d(adapted h_q): the query cell's pointwise part in the epilogue
+            {
+                st_lstm_pw_job j;
+                memset(&j, 0, sizeof(j));
+                j.n0 = 0; j.H = Q;
+                j.dh1 = dxq_next + P + E; j.ld1 = XQ;
+                j.dh2 = dxd + E; j.ld2 = XD; j.scale2 = io->ada_std;
+                j.mask = io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr;
+                j.gates = io->gates_q_tape + (size_t)t * 4 * BQ;
+                j.c = io->cq_tape + (size_t)(t + 1) * BQ; j.ldc = Q; j.c_prev = io->cq_tape + (size_t)t * BQ; j.ldcp = Q;
+                j.dc = io->dcq; j.dgates = io->dgq + (size_t)t * Bp * 4 * Q; j.ldg = 4 * Q;
+                j.dgates_t16 = dgq_v;
+                rc = st_skinny_linear_packed_lstm_bwd_fwd(w->attn_query_w_t_p16, &dpq_v, A, io->dhq_attn, Q, B, Q, &j, stream);
+                if (rc) return rc;
+            }
+            // f. gradient w.r.t. [dec_in_t | ctx_{t-1} | h_q_{t-1}]
+            if (t > 0 || io->need_dxq0) {
+                rc = st_skinny_linear_packed_fwd(w->q_w_cat_t_p16, &dgq_v, 4 * Q, nullptr, ST_ACT_NONE, nullptr, 0, dxq, XQ, nullptr,
+                                                 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XQ, stream);
+                if (rc) return rc;
+            }
+        }
+        return 0;
+    }
     for (int t = steps - 1; t >= 0; --t) {
         const float* dxo = io->dxo + (size_t)t * Bp * XO;
         float* dxd = io->dxd + (size_t)t * Bp * XD;

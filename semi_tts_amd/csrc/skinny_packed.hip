@@ -121,6 +121,21 @@ struct PkArgs {
     unsigned long long* gran; unsigned epoch;
 };
 
+// MODE 2: a linear whose output columns [n0, n0 + H) are dh of an LSTM cell -- the pointwise half of the cell's backward step
+// (st_lstm_cell_bwd_pointwise) runs in the epilogue of the product that makes dh, instead of as a launch of its own:
+//   dh = (y + dh1 [+ dh2 * scale2]) * mask;  dc = dc_in + dh * o * (1 - tanh(c)^2);  dgates (i, f, g, o);  dc_out = dc * f
+struct PkPw {
+    int n0, H;
+    const float* dh1; int ld1;                       // addend, (B rows, stride ld1), column u
+    const float* dh2; int ld2; const float* scale2;  // optional addend times scale2 (B, H)
+    const float* mask;                               // optional (B, H)
+    const float* gates;                              // (B, 4, H) activated gates of the step
+    const float* c; int ldc; const float* c_prev; int ldcp;   // c_t, c_{t-1} (NULL = zeros)
+    float* dc;                                       // (B, H) in / out
+    float* dgates; int ldg;                          // (B, 4H) out, torch gate order
+    PkOut dg_t16;                                    // out: the same in T16 (operand of the next packed product)
+};
+
 __device__ __forceinline__ void pk_store(const PkOut& d, int b, int k, float v) {
     if (d.base) d.base[t16_off(b, d.kb0 * 16 + k, d.kb_stride)] = v;
 }
@@ -171,7 +186,7 @@ __device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[N
 
 // MODE 0: LSTM cell, MODE 1: linear
 template <int MODE, int NB, int KW, int TRIP>
-__device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const int by, f32x4* red) {
+__device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const int by, f32x4* red, const PkPw* pw = nullptr) {
     // the wave index is wave-uniform: telling the compiler (readfirstlane) keeps every k-block address in scalar registers,
     // so a load is `global_load v, lane_offset, s[base]` instead of a 64-bit vector address computation per load
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,7 +202,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
         PK_TOUCH(a.b_ih); PK_TOUCH(a.b_hh); PK_TOUCH(a.c_prev); PK_TOUCH(a.ldc_prev);
         PK_TOUCH(a.mask); PK_TOUCH(a.ada_std); PK_TOUCH(a.ada_mean); PK_TOUCH(a.ha_dst.base);
     }
-    if (MODE == 1) {
+    if (MODE >= 1) {
         PK_TOUCH(a.bias); PK_TOUCH(a.lmask); PK_TOUCH(a.ldmask); PK_TOUCH(a.mask2); PK_TOUCH(a.ldmask2); PK_TOUCH(a.n_split2);
     }
 #undef PK_TOUCH
@@ -250,7 +265,7 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
         e_s = (a.ha_dst.base ? a.ada_std + (size_t)eb * a.H + u : dummy)[0];
         e_mu = (a.ha_dst.base ? a.ada_mean + (size_t)eb * a.H + u : dummy)[0];
     }
-    if (MODE == 1 && e_on) {      // linear epilogue operands (bias, dropout masks) requested up front as well
+    if (MODE >= 1 && e_on) {      // linear epilogue operands (bias, dropout masks) requested up front as well
         const int nb = tile * 16 + 4 * (lane >> 4);
         const bool has_m2 = a.mask2 && a.n_split2 > 0;
 #pragma unroll
@@ -348,6 +363,48 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
                 else { py[0] = v4[0]; py[1] = v4[1]; py[2] = v4[2]; py[3] = v4[3]; }
             }
             if (a.y_dst.base) *reinterpret_cast<f32x4*>(a.y_dst.base + t16_off(b, a.y_dst.kb0 * 16 + n0, a.y_dst.kb_stride)) = v4;
+            if (MODE == 2 && n0 >= pw->n0 && n0 + 3 < pw->n0 + pw->H) {
+                // pointwise LSTM backward of the 4 hidden units u .. u+3 of batch row b (host: H, n0, every row stride multiples of 4,
+                // 16-byte aligned bases); every operand is requested before the first one is used
+                const PkPw& q = *pw;
+                const int H = q.H, u = n0 - q.n0;
+                const size_t bu = (size_t)b * H + u;
+                const float* gp = q.gates + (size_t)b * 4 * H + u;
+                const f32x4 gi = st_ld4(gp), gf = st_ld4(gp + H), gg = st_ld4(gp + 2 * H), go = st_ld4(gp + 3 * H);
+                const f32x4 cr = st_ld4(q.c + (size_t)b * q.ldc + u);
+                const f32x4 dci = st_ld4(q.dc + bu);
+                const float* dummy = q.gates;
+                const f32x4 l1 = st_ld4(q.dh1 ? q.dh1 + (size_t)b * q.ld1 + u : dummy);
+                const f32x4 l2 = st_ld4(q.dh2 ? q.dh2 + (size_t)b * q.ld2 + u : dummy);
+                const f32x4 sc = st_ld4(q.scale2 ? q.scale2 + bu : dummy);
+                const f32x4 mk = st_ld4(q.mask ? q.mask + bu : dummy);
+                const f32x4 cp = st_ld4(q.c_prev ? q.c_prev + (size_t)b * q.ldcp + u : dummy);
+                f32x4 d0, d1, d2, d3, dco;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float dh = v4[r];
+                    if (q.dh1) dh += l1[r];
+                    if (q.dh2) dh += l2[r] * (q.scale2 ? sc[r] : 1.0f);
+                    if (q.mask) dh *= mk[r];
+                    const float tc = tanhf(cr[r]);
+                    const float cpv = q.c_prev ? cp[r] : 0.0f;
+                    const float dc = dci[r] + dh * go[r] * (1.0f - tc * tc);
+                    d0[r] = dc * gg[r] * gi[r] * (1.0f - gi[r]); d1[r] = dc * cpv * gf[r] * (1.0f - gf[r]);
+                    d2[r] = dc * gi[r] * (1.0f - gg[r] * gg[r]); d3[r] = dh * tc * go[r] * (1.0f - go[r]);
+                    dco[r] = dc * gf[r];
+                }
+                float* dg = q.dgates + (size_t)b * q.ldg + u;
+                *reinterpret_cast<f32x4*>(dg) = d0; *reinterpret_cast<f32x4*>(dg + H) = d1;
+                *reinterpret_cast<f32x4*>(dg + 2 * H) = d2; *reinterpret_cast<f32x4*>(dg + 3 * H) = d3;
+                if (q.dg_t16.base) {
+                    const int k0 = q.dg_t16.kb0 * 16 + u;
+                    *reinterpret_cast<f32x4*>(q.dg_t16.base + t16_off(b, k0, q.dg_t16.kb_stride)) = d0;
+                    *reinterpret_cast<f32x4*>(q.dg_t16.base + t16_off(b, k0 + H, q.dg_t16.kb_stride)) = d1;
+                    *reinterpret_cast<f32x4*>(q.dg_t16.base + t16_off(b, k0 + 2 * H, q.dg_t16.kb_stride)) = d2;
+                    *reinterpret_cast<f32x4*>(q.dg_t16.base + t16_off(b, k0 + 3 * H, q.dg_t16.kb_stride)) = d3;
+                }
+                *reinterpret_cast<f32x4*>(q.dc + bu) = dco;
+            }
             PK_PROF(5);
             return;
         }
@@ -508,6 +565,16 @@ __global__ __launch_bounds__(KW * 64) void pk_kernel(const f32x4* w, const f32x4
     PkArgs a = rest;
     a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N; a.H = H;
     pk_body<MODE, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red);
+}
+
+// linear + pointwise LSTM backward in the epilogue of the columns that are a cell's dh (pk_body MODE 2)
+template <int NB, int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_pw_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                        const int B, const int N, const PkArgs rest, const PkPw pw) {
+    __shared__ f32x4 red[KW * NB * 64];
+    PkArgs a = rest;
+    a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N; a.H = 0;
+    pk_body<2, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red, &pw);
 }
 
 // The proj (+) gate launch of decode step t with, on the compute units it leaves idle, the part of the attention of step t+1
@@ -923,6 +990,39 @@ extern "C" int st_skinny_linear_packed_fwd(const float* packed_w, const st_t16_v
     (void)hipGetLastError();
     return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
                           n_split2, act2, mask2, ldmask2, y3_dst, B, N, nullptr, stream);
+}
+
+extern "C" int st_skinny_linear_packed_lstm_bwd_fwd(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                                    const st_lstm_pw_job* job, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(y && job && B > 0 && N > 0 && ldy >= N, "st_skinny_linear_packed_lstm_bwd_fwd: bad arguments");
+    const int H = job->H;
+    ST_CHECK_ARG(H > 0 && H % 4 == 0 && job->n0 >= 0 && job->n0 % 16 == 0 && job->n0 + H <= N && (N % 16 == 0 || job->n0 + H <= (N & ~15)),
+                 "st_skinny_linear_packed_lstm_bwd_fwd: the cell's columns [%d, %d) must be whole tiles of the %d outputs", job->n0, job->n0 + H, N);
+    ST_CHECK_ARG(job->gates && job->c && job->dc && job->dgates && job->ldg >= 4 * H && job->ldg % 4 == 0 && job->ldc % 4 == 0 &&
+                 (!job->c_prev || job->ldcp % 4 == 0) && (!job->dh1 || job->ld1 % 4 == 0) && (!job->dh2 || job->ld2 % 4 == 0) && ldy % 4 == 0,
+                 "st_skinny_linear_packed_lstm_bwd_fwd: null operand or a row stride that is not a multiple of 4");
+    ST_CHECK_ARG(st_aligned16(job->gates) && st_aligned16(job->c) && st_aligned16(job->dc) && st_aligned16(job->dgates) && st_aligned16(y) &&
+                 (!job->c_prev || st_aligned16(job->c_prev)) && (!job->dh1 || st_aligned16(job->dh1)) && (!job->dh2 || st_aligned16(job->dh2)) &&
+                 (!job->scale2 || st_aligned16(job->scale2)) && (!job->mask || st_aligned16(job->mask)) &&
+                 (!job->dgates_t16.base || st_aligned16(job->dgates_t16.base)), "st_skinny_linear_packed_lstm_bwd_fwd: operands must be 16-byte aligned");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, x, K, "st_skinny_linear_packed_lstm_bwd_fwd");
+    if (rc) return rc;
+    a.B = B; a.N = N; a.H = 0; a.act = ST_ACT_NONE;
+    a.y = y; a.ldy = ldy;
+    PkPw q;
+    memset(&q, 0, sizeof(q));
+    q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
+    q.gates = job->gates; q.c = job->c; q.ldc = job->ldc; q.c_prev = job->c_prev; q.ldcp = job->ldcp; q.dc = job->dc;
+    q.dgates = job->dgates; q.ldg = job->ldg; q.dg_t16 = pk_out(&job->dgates_t16);
+    const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
+    // one batch tile per workgroup, as the plain linear of these shapes runs (pk_dispatch<1>)
+    hipLaunchKernelGGL((pk_pw_kernel<1, 8, 2>), dim3(tiles, BT), dim3(8 * 64), 0, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B,
+                       a.N, a, q);
+    ST_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,

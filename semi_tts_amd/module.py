@@ -350,6 +350,7 @@ class Decoder(nn.Module):
         self.handoff_status = None
         self.attn_split_min_len = 128     # texts at least this long: fin part over position ranges (~attn_split_positions each) + combine
         self.attn_split_positions = 43
+        self.bwd_fuse_pointwise = True   # training (teacher forcing): the cells' pointwise backward in the epilogues of the loop's products
         self.attn_rng_one_launch = True   # long texts: query projection + fin part over position ranges + combine in one launch
 
     # -- helpers ---------------------------------------------------------------------------------

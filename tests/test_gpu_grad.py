@@ -343,10 +343,11 @@ def test_tacotron2_backward_against_oracle_tiny_golden(dev, name):
     check_param_grads(m, '', wg, 2e-4, 'tacotron2_backward_tiny')     # fp32 BPTT over 4 steps + BN chains vs float64
 
 
-@pytest.mark.parametrize('B,L,steps', [(20, 11, 7), (3, 5, 3)])
-def test_decoder_backward_against_oracle(dev, B, L, steps):
-    """Decoder only, dimensions that are not multiples of the tile sizes, dropout masks drawn by the oracle and
-    replayed through the HIP path; B=20 exercises the padded rows of the step tapes (Bp=32)."""
+@pytest.mark.parametrize('B,L,steps,tiled', [(20, 11, 7, False), (3, 5, 3, False), (20, 11, 7, True), (33, 6, 4, True)])
+def test_decoder_backward_against_oracle(dev, B, L, steps, tiled):
+    """Decoder only, dropout masks drawn by the oracle and replayed through the HIP path; B=20 exercises the padded rows of the step
+    tapes (Bp=32).  tiled=False: dimensions that are not multiples of the tile sizes (six launches per backward step);
+    tiled=True: dimensions the fused form takes -- the cells' pointwise backward in the epilogues of the loop's products."""
     from helpers import masks_to, split_masks
     from oracle import tts_oracle as O
     from semi_tts_amd.module import Decoder
@@ -354,6 +355,9 @@ def test_decoder_backward_against_oracle(dev, B, L, steps):
               dec_dropout=0.1, attn_dim=32, n_location_filters=8, location_kernel_size=7, loc_aware=True,
               use_summed_weights=True, drop_dec_in=0.0)
     n_mels, E, S = 10, 28, 12
+    if tiled:
+        hp.update(prenet_dim=32, query_rnn_dim=48, dec_rnn_dim=64)
+        E = 32
     torch.manual_seed(5)
     dec = Decoder(n_mels, enc_embed_dim=E, spkr_embed_dim=S, **hp).to(dev).train()
     W = {'decoder.' + k: v.detach().cpu() for k, v in dec.state_dict().items()}

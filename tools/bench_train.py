@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--batch-size', type=int, default=32)
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--config', default='config/semi-single-spkr-paired-data.yaml')
+    ap.add_argument('--no-fuse-pw', action='store_true', help='six launches per backward step (pointwise LSTM backward as launches of its own)')
     a = ap.parse_args()
     from semi_tts_amd.solver import TtsTrainer
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,6 +33,8 @@ def main():
                       max_step=a.steps + a.warmup, load=None)
     tr = TtsTrainer(config, paras, 'train').load_data().set_model()
     text, sid, mel, linear = (t.to(tr.device) for t in tr.batches[0])
+    if a.no_fuse_pw:
+        tr.model.tts.decoder.bwd_fuse_pointwise = False
     phases = dict(fwd=0.0, bwd=0.0, opt=0.0)
     sync = torch.cuda.synchronize
     stats = None

@@ -330,6 +330,8 @@ def bench_decode(args, rk):
     with torch.no_grad():
         memory = m.encoder(txt, None).contiguous()        # inputs of the timed region, resident in HBM
     dec = m.decoder
+    if args.pre_parts:
+        dec.attn_pre_parts = args.pre_parts
     gd = GraphedDecoder(dec, B, L, T, dev)
     gd.memory.copy_(memory)
     gd.spkr.copy_(spk)
@@ -591,6 +593,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='issue the decode loop eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pre-parts', type=int, default=0, help=argparse.SUPPRESS)      # experiment: workgroups per utterance of the attention pre part
     ap.add_argument('--vq-head-only', action='store_true', help='c3: only the headline case (32 x 129 vectors, V = 512): PMC passes')
     ap.add_argument('--dist', action='store_true',
                     help='with --gpus 1: initialise a world-size-1 process group (RCCL) and issue every collective anyway')

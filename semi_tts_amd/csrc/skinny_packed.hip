@@ -21,6 +21,9 @@
 #ifndef PK_PROF
 #define PK_PROF(n)   // phase timestamps, only defined by tools/mb/mb_pk.hip
 #endif
+#ifndef RT2_PROF
+#define RT2_PROF(n)  // phase timestamps of the 2-D tiled LSTM cell, only defined by tools/mb/mb_rt2.hip
+#endif
 
 namespace {
 
@@ -442,6 +445,7 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
                                                           const int B, const int H, const PkArgs rest) {
     constexpr int RT = 2;
     __shared__ f32x4 red[KW * RT * NB * 64];
+    RT2_PROF(0);
     const PkArgs& a = rest;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile0 = blockIdx.x * RT, bt_base = blockIdx.y * NB;          // host: B in 49..64, so both batch tiles of a half exist
@@ -487,6 +491,7 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
     Regs ra, rb;
     if (G > 0) load(ra, kb_of(0));
     if (G > 1) load(rb, kb_of(1));
+    RT2_PROF(1);
     // epilogue operands of the 4 waves that run the epilogue (wave = rt * NB + bt)
     const int e_rt = (tid >> 6) / NB, e_bt = (tid >> 6) % NB;
     const int eb = (bt_base + e_bt) * 16 + (lane & 15);
@@ -514,6 +519,7 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
         int g = 0;
         while (g < G) {
             mma(ra);
+            if (g == 0) RT2_PROF(2);
             if (g + 2 < G) load(ra, kb_of(g + 2));
             if (g == 0) epi_prefetch();
             ++g;
@@ -523,11 +529,13 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
             ++g;
         }
     }
+    RT2_PROF(3);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) red[((wave * RT + rt) * NB + bt) * 64 + lane] = acc[rt][bt];
     __syncthreads();
+    RT2_PROF(4);
     if (tid >= RT * NB * 64) return;
     f32x4 s = red[(e_rt * NB + e_bt) * 64 + lane];
 #pragma unroll
@@ -553,6 +561,7 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
         float* gp = a.gates_out + (size_t)eb * 4 * H + u;
         gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
     }
+    RT2_PROF(5);
 }
 
 // The arguments the prologue needs come first and as plain scalars: with -mllvm -amdgpu-kernarg-preload-count=16 (build.py) the

@@ -286,23 +286,12 @@ class VqvaeTrainer(TtsTrainer):
         from . import autograd as AG
         return AG.ctc_loss(prob, text, EPS)
 
-    def speech_first_step(self, mel, aug_mel, linear, text, sid, unpair_mel=None, unpair_aug_mel=None, unpair_linear=None,
-                          unpair_sid=None, _masks=None):
-        from . import parallel
+    def _paired_losses(self, pair_prob, pair_post_prob, pm, pl, mel, linear, text, stats):
+        """the terms both cycles share (bin/train_vqvae.py:208-224): CTC on the paired posteriors (+ the ASRPostnet term) and
+        freq_loss on the paired reconstruction; returns the weighted sum"""
         hp = self.hp
-        parallel.collective_counts(reset=True)
-        tf_rate = self.optimizer.pre_step(self.step)
-        if getattr(self, 'reducer', None) is not None:
-            self.reducer.prepare()
-        pair_prob, _, unpair_prob, unpair_latent, unpair_latent_len, pair_post_prob, _ = self.model.speech_to_text(
-            paired_mel=aug_mel, unpaired_mel=unpair_aug_mel)
-        ignore_speech_cycle = unpair_latent is None                                               # :163-172
-        out = self.model.text_to_speech(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
-                                        unpair_latent_len, mel, None if ignore_speech_cycle else unpair_mel, tf_rate, _masks=_masks)
-        pm, pl, _, _, upm, upl, _, _ = out
         asr_loss = self.ctc_loss(pair_prob, text)                                                 # :209
         asr_w = float(hp.get('asr_weight', 1.0))
-        stats = {}
         if self.model.use_asr_postnet:                                                            # :210-213
             from . import autograd as AG
             pw = float(self.model.asr_postnet_weight)
@@ -315,13 +304,10 @@ class VqvaeTrainer(TtsTrainer):
         if al != al or al in (float('inf'), float('-inf')):                                       # :216-218: counted, and (as in the
             self.ctc_nan = getattr(self, 'ctc_nan', 0) + 1                                        # reference) already inside total
         tts_loss = self.freq_loss(pm, mel) + self.freq_loss(pl, linear)                           # :221-224
-        total = total + self.tts_weight * tts_loss
         stats.update(asr_loss=al, tts_loss=float(tts_loss.detach()))
-        if not ignore_speech_cycle:                                                               # :227-233
-            un = self.freq_loss(upm, unpair_mel) + self.freq_loss(upl, unpair_linear)
-            if self.step > int(hp.get('unpair_speech_start_step', 0)):                            # :232: only after the warm-up steps
-                total = total + float(hp.get('unpair_speech_weight', 10.0)) * un
-            stats['unpair_speech_loss'] = float(un.detach())
+        return total + self.tts_weight * tts_loss
+
+    def _finish_step(self, total, stats, tf_rate):
         total.backward()
         self._reduce_gradients()
         gn = float(self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP))
@@ -330,3 +316,78 @@ class VqvaeTrainer(TtsTrainer):
         self.step += 1
         stats.update(loss=float(total.detach()), grad_norm=gn, tf_rate=tf_rate)
         return stats
+
+    def speech_first_step(self, mel, aug_mel, linear, text, sid, unpair_mel=None, unpair_aug_mel=None, unpair_linear=None,
+                          unpair_sid=None, _masks=None):
+        """The speech -> text -> speech cycle of VqvaeTrainer.exec (bin/train_vqvae.py:159-176,208-233)."""
+        from . import parallel
+        hp = self.hp
+        parallel.collective_counts(reset=True)
+        tf_rate = self.optimizer.pre_step(self.step)
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.prepare()
+        pair_prob, _, unpair_prob, unpair_latent, unpair_latent_len, pair_post_prob, _ = self.model.speech_to_text(
+            paired_mel=aug_mel, unpaired_mel=unpair_aug_mel)
+        ignore_speech_cycle = unpair_latent is None                                               # :163-172
+        out = self.model.text_to_speech(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
+                                        unpair_latent_len, mel, None if ignore_speech_cycle else unpair_mel, tf_rate, _masks=_masks)
+        pm, pl, _, _, upm, upl, _, _ = out
+        stats = {}
+        total = self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, stats)
+        if not ignore_speech_cycle:                                                               # :227-233
+            un = self.freq_loss(upm, unpair_mel) + self.freq_loss(upl, unpair_linear)
+            if self.step > int(hp.get('unpair_speech_start_step', 0)):                            # :232: only after the warm-up steps
+                total = total + float(hp.get('unpair_speech_weight', 10.0)) * un
+            stats['unpair_speech_loss'] = float(un.detach())
+        return self._finish_step(total, stats, tf_rate)
+
+    def text_first_step(self, mel, aug_mel, linear, text, sid, unpair_text=None, unpair_sid=None, _masks=None):
+        """The text -> speech -> text cycle of VqvaeTrainer.exec (bin/train_vqvae.py:186-205,208-224,234-250): text_to_speech on the
+        paired text (teacher forced) and, when given, the unpaired text (rows without a teacher feed their own output back); the
+        unpaired prediction is DETACHED and goes through speech_to_text next to the paired mel with `using_fake_mel` (the codebook
+        table is detached for the fake part); losses: the paired terms, plus CTC of the unpaired posteriors against the unpaired text
+        (paras.actual_len = False: every frame counts).  A NaN / inf unpaired term is counted and dropped, as the reference does."""
+        from . import parallel
+        hp = self.hp
+        parallel.collective_counts(reset=True)
+        tf_rate = self.optimizer.pre_step(self.step)
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.prepare()
+        use_unpair_text = unpair_text is not None                                                 # the caller gates it (:128,:149-152)
+        out = self.model.text_to_speech(text, sid, unpair_sid if use_unpair_text else None, None, unpair_text, None, mel, None,
+                                        tf_rate, _masks=_masks)                                   # :190-199
+        pm, pl, _, _, upm, _, _, _ = out
+        if use_unpair_text:
+            upm = upm.detach()                                                                    # :201-202
+        pair_prob, _, unpair_prob, _, _, pair_post_prob, _ = self.model.speech_to_text(
+            paired_mel=aug_mel, unpaired_mel=upm if use_unpair_text else None, using_fake_mel=use_unpair_text)   # :203-205
+        stats = {}
+        total = self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, stats)
+        if use_unpair_text:                                                                       # :234-250
+            ut = self.ctc_loss(unpair_prob, unpair_text)
+            v = float(ut.detach())
+            if v != v or v in (float('inf'), float('-inf')):                                      # :246-248
+                self.ctc_nan = getattr(self, 'ctc_nan', 0) + 1
+            else:
+                total = total + float(hp.get('unpair_text_weight', 0.0)) * ut
+            stats['unpair_text_loss'] = v
+        return self._finish_step(total, stats, tf_rate)
+
+    def cycle_step(self, pair, unpair=None, _masks=None):
+        """One iteration of VqvaeTrainer.exec's loop body (bin/train_vqvae.py:124-150): even steps run the speech-first cycle, odd
+        steps the text-first cycle; the unpaired batch joins only when its weight is positive and the step is past its start step.
+        `pair` = (mel, aug_mel, linear, text, sid); `unpair` = the same five for the unpaired batch, or None."""
+        hp = self.hp
+        mel, aug_mel, linear, text, sid = pair
+        use_text = float(hp.get('unpair_text_weight', 0.0)) > 0 and self.step > int(hp.get('unpair_text_start_step', 0))      # :128
+        use_speech = float(hp.get('unpair_speech_weight', 10.0)) > 0 and self.step > int(hp.get('unpair_speech_start_step', 0))  # :129
+        if self.step % 2 == 0:                                                                    # :137
+            if use_speech and unpair is not None:
+                umel, uaug, ulin, _, usid = unpair
+                return self.speech_first_step(mel, aug_mel, linear, text, sid, unpair_mel=umel, unpair_aug_mel=uaug,
+                                              unpair_linear=ulin, unpair_sid=usid, _masks=_masks)
+            return self.speech_first_step(mel, aug_mel, linear, text, sid, _masks=_masks)
+        if use_text and unpair is not None:
+            _, _, _, utext, usid = unpair
+            return self.text_first_step(mel, aug_mel, linear, text, sid, unpair_text=utext, unpair_sid=usid, _masks=_masks)
+        return self.text_first_step(mel, aug_mel, linear, text, sid, _masks=_masks)

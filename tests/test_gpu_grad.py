@@ -847,3 +847,66 @@ def test_asr_postnet_backward_vs_oracle(dev):
     outs2, wg2, ig2 = oracle_grads(lambda Wd, xx: AO.asr_postnet_forward(Wd, xx, training=True, drop=drop()), W, [x], [dy])
     assert maxdiff(y2, outs2[0]) < 2e-5 and relerr(xd2.grad, ig2[0]) < 2e-4
     check_param_grads(m, '', wg2, 2e-4, 'asr_postnet_backward_train')
+
+
+def test_text_first_step_against_reference_golden(dev):
+    """The text -> speech -> text training step (bin/train_vqvae.py:186-205,208-224,234-250) against what the REAL reference produced
+    for the same weights, batch and dropout masks: paired text teacher-forced, unpaired text decoded from its own outputs (partial
+    teacher), the unpaired prediction detached and quantised next to the paired mel with the table detached for the fake part; CTC on
+    both posteriors, freq_loss on the paired reconstruction, the grad norm and EVERY parameter gradient."""
+    import json
+    from argparse import Namespace
+    from conftest import load_golden
+    from helpers import coin_source, masks_to, split_masks, tiny_vqvae
+    from semi_tts_amd.module import plan_decode
+    from semi_tts_amd.optim import Optimizer
+    from semi_tts_amd.solver import VqvaeTrainer
+    import numpy as np
+    W, A, meta = load_golden('text_first_unpaired')
+    hp, h = meta['hp'], meta['hparas']
+    config = dict(data=dict(audio=meta['audio'], corpus=dict(batch_size=3)), hparas=h, model=meta['model'])
+    tr = VqvaeTrainer(config, Namespace(vocab_size=meta['vocab_size'], n_spkr=meta['n_spkr'], verbose=False, max_step=1), 'train')
+    tr.model = tiny_vqvae(meta, W, dev, strict=True).train()
+    tr.optimizer = Optimizer(tr.model.parameters(), h['optimizer'], h['lr'], h['lr_scheduler'], tf_start=h['tf_start'],
+                             tf_end=h['tf_end'], tf_step=h['tf_step'])
+    text, sid, mel, linear, utext, usid = (A[k].to(dev) for k in ('text', 'sid', 'mel', 'linear', 'unpair_text', 'unpair_sid'))
+    Bt, B = text.shape[0], text.shape[0] + utext.shape[0]
+    r = hp['n_frames_per_step']
+    umax = int(6.0 * utext.shape[1])
+    umax += umax % r                                          # VQVAE.text_to_speech :158-160
+    steps, src = plan_decode(False, mel.shape[1], Bt, B, r, 1.0, hp['drop_dec_in'], umax, coin_source(A['coins']))
+    masks = masks_to(split_masks(A['mask'], hp, True, 1.0, B, Bt, steps, src, hp['prenet_dim']), dev)
+    grads = {}
+    orig = tr.clip_grad_norm_
+
+    def spy(params, max_norm):
+        for kname, p in tr.model.named_parameters():
+            if p.grad is not None:
+                grads[kname] = p.grad.detach().clone()
+        return orig(list(params), max_norm)
+    tr.clip_grad_norm_ = spy
+    saved = np.random.rand
+    np.random.rand = coin_source(A['coins'])
+    try:
+        st = tr.text_first_step(mel, mel, linear, text, sid, unpair_text=utext, unpair_sid=usid, _masks=masks)
+    finally:
+        np.random.rand = saved
+    ref = meta['stats']
+    report('text_first', **{k: st[k] for k in ref}, **{'ref_' + k: v for k, v in ref.items()})
+    assert torch.equal(tr.model.codebook.last_idx.cpu(), A['idx'])                      # VQ indices: bit-exact
+    for k in ('asr_loss', 'tts_loss', 'unpair_text_loss', 'loss'):
+        assert abs(st[k] - ref[k]) < 2e-5 * max(1.0, abs(ref[k])), (k, st[k], ref[k])
+    assert abs(st['grad_norm'] - ref['grad_norm']) < 2e-4 * ref['grad_norm']
+    keys = json.loads(bytes(A['grad_keys']).decode())
+    worst, worst_k = 0.0, ''
+    gmax = max(float(g.abs().max()) for g in A['grad'])
+    for k, gref in zip(keys, A['grad']):
+        assert k in grads, 'missing gradient for ' + k
+        if float(gref.abs().max()) < 1e-6 * gmax:
+            assert float(grads[k].abs().max()) < 1e-5 * gmax, k
+            continue
+        e = relerr(grads[k], gref)
+        if e > worst:
+            worst, worst_k = e, k
+        assert e < 1e-3, (k, e)
+    report('text_first_grads', worst=worst, worst_k=worst_k, n=len(keys))

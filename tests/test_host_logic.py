@@ -211,3 +211,37 @@ def test_two_process_gradient_allreduce_matches_single_process(tmp_path):
     assert line[6] == '1' and line[7] == '1'                # unused parameters stay None, gradients are views of the buckets
     assert line[8] == '1'                                   # buckets issued in index order although the ranks' graphs differ
     assert line[9] == '1'                                   # a parameter that fired on one rank only: same gradient on both
+
+
+def test_cycle_step_alternates_and_gates_like_the_reference_loop():
+    """VqvaeTrainer.cycle_step mirrors the loop body of bin/train_vqvae.py:124-150: even steps speech-first, odd steps text-first;
+    the unpaired batch joins only when its weight is > 0 AND step > its start step."""
+    from semi_tts_amd.solver import VqvaeTrainer
+    tr = VqvaeTrainer.__new__(VqvaeTrainer)
+    calls = []
+
+    def sf(mel, aug, lin, text, sid, unpair_mel=None, unpair_aug_mel=None, unpair_linear=None, unpair_sid=None, _masks=None):
+        calls.append(('speech', unpair_mel))
+        tr.step += 1
+
+    def tf(mel, aug, lin, text, sid, unpair_text=None, unpair_sid=None, _masks=None):
+        calls.append(('text', unpair_text))
+        tr.step += 1
+    tr.speech_first_step, tr.text_first_step = sf, tf
+    pair, unpair = ('m', 'a', 'l', 't', 's'), ('um', 'ua', 'ul', 'ut', 'us')
+    tr.step = 0
+    tr.hp = dict(unpair_text_weight=0.5, unpair_text_start_step=2, unpair_speech_weight=10.0, unpair_speech_start_step=1)
+    for _ in range(6):
+        tr.cycle_step(pair, unpair)
+    #        step 0: speech, not past start; 1: text, not past 2; 2: speech + unpaired; 3: text + unpaired; ...
+    assert calls == [('speech', None), ('text', None), ('speech', 'um'), ('text', 'ut'), ('speech', 'um'), ('text', 'ut')]
+    calls.clear()
+    tr.step = 4
+    tr.hp = dict(unpair_text_weight=0.0, unpair_text_start_step=0, unpair_speech_weight=0.0, unpair_speech_start_step=0)
+    tr.cycle_step(pair, unpair), tr.cycle_step(pair, unpair)
+    assert calls == [('speech', None), ('text', None)]                   # zero weights (the shipped paired-only YAML): never joins
+    calls.clear()
+    tr.hp = dict(unpair_text_weight=1.0, unpair_speech_weight=1.0)
+    tr.step = 5
+    tr.cycle_step(pair, None)
+    assert calls == [('text', None)]                                      # no unpaired batch handed in

@@ -452,6 +452,89 @@ def speech_first_case():
     os.chdir(REPO)
 
 
+def text_first_case():
+    """The text -> speech -> text training step of bin/train_vqvae.py:186-205,208-224,234-250 through the REAL reference classes at tiny
+    dimensions: VQVAE.text_to_speech on paired text (teacher forced) + unpaired text (rows without a teacher feed their own output
+    back), the unpaired prediction detached, VQVAE.speech_to_text on [paired mel | predicted mel of the unpaired text] with
+    using_fake_mel (the codebook table is detached for the fake part), CTC on the paired posteriors, freq_loss on the paired
+    reconstruction, CTC on the unpaired posteriors against the unpaired text; backward, clip.  Records what speech_first_case records."""
+    import yaml
+    from functools import partial
+    os.chdir(REF)
+    full = yaml.safe_load(open('config/semi-single-spkr-paired-data.yaml'))
+    cfg = full['model']
+    cfg['decoder'] = json.loads(json.dumps(TINY['paras']))
+    cfg['decoder']['separate_postnet'] = True
+    cfg['spkr_latent_dim'] = TINY['spkr_embed_dim']
+    cfg['encoder'].update(dim=16, rnn_dim=8, dropout=0.0)
+    hp = dict(full['hparas'], unpair_text_weight=0.5)        # (0.0 in the shipped YAMLs: the term would not reach the gradients)
+    floss = partial(ref_freq_loss, sample_rate=full['data']['audio']['sample_rate'], n_mels=TINY['n_mels'],
+                    loss=hp['freq_loss_type'], differential_loss=hp['differential_loss'],
+                    emphasize_linear_low=hp['emphasize_linear_low'])
+    ctc = torch.nn.CTCLoss()
+    EPS = 1e-10
+    seed = 23
+    torch.manual_seed(seed)
+    m = RefVQVAE(TINY['n_mels'], TINY['linear_dim'], 43, 5, **json.loads(json.dumps(cfg)))
+    g = torch.Generator().manual_seed(seed + 100)
+    with torch.no_grad():
+        randomize_buffers(m.tts, g)
+        randomize_buffers(m.asr, g)
+        m.codebook.learnable_table.mul_(0.25)
+        m.asr.postnet.weight.mul_(12.0)
+    m.train()
+    w0 = {k: v.clone() for k, v in m.state_dict().items()}
+    B, L, T = 3, 5, 24
+    text = torch.randint(3, 43, (B, L), generator=g)
+    text[:, -1] = 0
+    text[1, -2:] = 0
+    sid = torch.randint(0, 5, (B,), generator=g)
+    mel = torch.rand(B, T, TINY['n_mels'], generator=g)
+    linear = torch.rand(B, T, TINY['linear_dim'], generator=g)
+    Bu, Lu = 3, 4                                             # FRAME_PHN_RATIO * 4 = 24 frames of predicted speech, 12 CTC frames
+    utext = torch.randint(3, 43, (Bu, Lu), generator=g)
+    utext[:, -1] = 0
+    usid = torch.randint(0, 5, (Bu,), generator=g)
+    arrays = dict(text=text, sid=sid, mel=mel, linear=linear, unpair_text=utext, unpair_sid=usid)
+    np.random.seed(seed)
+    torch.manual_seed(seed + 1)
+    with Recorder() as rec:
+        pm, pl, pa, _, upm, upl, upa, _ = m.text_to_speech(paired_text=text, paired_sid=sid, unpaired_sid=usid, unpaired_latent=None,
+                                                           unpaired_text=utext, unpaired_latent_len=None, paired_teacher=mel,
+                                                           unpaired_teacher=None, tf_rate=1.0)
+        upm = upm.detach()                                                                          # :201-202
+        pair_prob, _, unpair_prob, _, _, _, _ = m.speech_to_text(paired_mel=mel, unpaired_mel=upm, using_fake_mel=True)
+        ctc_in = (pair_prob + EPS).transpose(0, 1).log()
+        ctc_len = torch.LongTensor([pair_prob.shape[1]] * pair_prob.shape[0])
+        asr_loss = ctc(ctc_in, text.to_sparse().values(), ctc_len, torch.sum(text != 0, dim=-1))
+        tts_loss = floss(pm, mel) + floss(pl, linear)
+        uin = (unpair_prob + EPS).transpose(0, 1).log()                                             # :236
+        ulen = torch.LongTensor([unpair_prob.shape[1]] * unpair_prob.shape[0])                      # :242
+        unpair_text_loss = ctc(uin, utext.to_sparse().values(), ulen, torch.sum(utext != 0, dim=-1))   # :243-244
+        total = hp['asr_weight'] * asr_loss + hp['tts_weight'] * tts_loss + hp['unpair_text_weight'] * unpair_text_loss
+        stats = dict(asr_loss=float(asr_loss), tts_loss=float(tts_loss), unpair_text_loss=float(unpair_text_loss))
+        total.backward()
+    gkeys = [k for k, p in m.named_parameters() if p.grad is not None]
+    arrays['grad'] = [dict(m.named_parameters())[k].grad.clone() for k in gkeys]
+    arrays['grad_keys'] = np.frombuffer(json.dumps(gkeys).encode(), np.uint8)
+    arrays['pair_prob'], arrays['unpair_prob'] = pair_prob.detach(), unpair_prob.detach()
+    arrays['mel_pred'], arrays['unpair_mel_pred'] = pm.detach(), upm
+    arrays['idx'] = torch.cat([pair_prob, unpair_prob]).detach().argmax(-1)
+    gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+    stats.update(loss=float(total), grad_norm=float(gn))
+    arrays['mask'] = rec.masks
+    arrays['coins'] = np.asarray(rec.coins, np.float64)
+    mcfg = json.loads(json.dumps(cfg))
+    mcfg['codebook']['phn_attr_pth'] = ''
+    save('text_first_unpaired', w0, arrays, dict(stats=stats, model=mcfg, hparas=hp,
+                                                 audio=dict(sample_rate=full['data']['audio']['sample_rate'], num_mels=TINY['n_mels'],
+                                                            num_freq=TINY['linear_dim']),
+                                                 vocab_size=43, n_spkr=5, hp=dict(TINY['paras']['decoder'], n_mels=TINY['n_mels']),
+                                                 n_grads=len(gkeys)))
+    print('text_first_unpaired', stats, 'grads', len(gkeys), 'masks', len(rec.masks), 'unpair_prob', tuple(unpair_prob.shape))
+    os.chdir(REPO)
+
+
 def asr_cases():
     """CTC speech encoder (src/asr.py) at tiny dimensions: eval mode, and training mode with dropout 0 (BatchNorm batch
     statistics; the inter-layer dropout of nn.LSTM cannot be recorded, so no dropout case)."""
@@ -512,9 +595,11 @@ def asr_cases():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr', 'speech', 'variants']
+    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr', 'speech', 'text', 'variants']
     if 'speech' in which:
         speech_first_case()
+    if 'text' in which:
+        text_first_case()
     if 'asr' in which:
         asr_cases()
     if 'train' in which:

@@ -121,6 +121,10 @@ size_t st_t16_floats(int B, int K);                                        /* si
  * 4t..4t+3 (so the cell update is workgroup-local). */
 int st_pack_weight(const float* const* w, const int* ldw, const int* k, int nseg, int N, int lstm_H,
                    float* packed, void* stream);
+/* P16 image of the TRANSPOSE of the column concatenation [w[0] | w[1] | ...] (each (K, cols[s]), row stride ldw[s]): N = sum cols,
+ * one segment of K columns -- what st_pack_weight would make of torch.cat(w, 1).t().contiguous(), without those two copies
+ * (the BPTT loop's W^T operands: backward of nn.LSTMCell / Linear, src/module.py:247-283). */
+int st_pack_weight_t(const float* const* w, const int* ldw, const int* cols, int nseg, int K, float* packed, void* stream);
 int st_tile_rows(const float* src, int ld, const st_t16_view* dst, int B, int K, void* stream);   /* natural -> T16 */
 int st_untile_rows(const st_t16_view* src, float* dst, int ld, int B, int K, void* stream);       /* T16 -> natural */
 /* st_lstm_cell_fwd on packed operands: x = K logical columns starting at view x.  The new hidden
@@ -617,9 +621,9 @@ int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,
 int st_attn_dmem(const float* align, const float* dctx_tape, float* dmem, int B, int steps, int L, int E, void* stream);
 
 typedef struct st_decoder_bwd_weights {   /* transposed copies prepared by the caller (layout only) */
-    const float* q_w_cat_t;        /* [W_ih_q | W_hh_q]^T   (P+E+Q, 4Q) */
-    const float* d_w_cat_t;        /* [W_ih_d | W_hh_d]^T   (E+Q+D, 4D) */
-    const float* attn_query_w_t;   /* W_q^T                 (Q, A)      */
+    const float* q_w_cat_t;        /* [W_ih_q | W_hh_q]^T   (P+E+Q, 4Q)   (may be NULL when the packed form below is given) */
+    const float* d_w_cat_t;        /* [W_ih_d | W_hh_d]^T   (E+Q+D, 4D)   (likewise) */
+    const float* attn_query_w_t;   /* W_q^T                 (Q, A)        (may be NULL when the loop runs with fuse_pw) */
     const float* q_w_cat_t_p16;    /* optional: q_w_cat_t packed by st_pack_weight (N = P+E+Q, K = 4Q); NULL = natural kernels */
     const float* d_w_cat_t_p16;    /* optional: d_w_cat_t packed (N = E+Q+D, K = 4D) */
     const float* attn_query_w_t_p16;   /* optional: W_q^T packed (N = Q, K = A): with the two above and st_decoder_bwd_io.fuse_pw the loop runs

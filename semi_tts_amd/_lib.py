@@ -148,6 +148,7 @@ SIGNATURES = {
     'st_packed_weight_floats': [C.POINTER(I), I, I, I],
     'st_t16_floats': [I, I],
     'st_pack_weight': [C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, I, P, P],
+    'st_pack_weight_t': [C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, P, P],
     'st_tile_rows': [P, I, C.POINTER(StT16View), I, I, P],
     'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
     'st_lstm_cell_packed_fwd': [P, C.POINTER(StT16View), I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),

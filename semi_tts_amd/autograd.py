@@ -491,15 +491,14 @@ class _DecoderFn(Function):
         ds_tape, loc_tape, dloc_tape = e_(steps, B, L, A), e_(steps, B, L, F), e_(steps, B, L, F)
         hist_tape, dctx_tape, dv_tape = e_(steps, B, L, 2), e_(steps, B, E), e_(steps, B, A)
         dcq, dcd, dh0, dh1, dcum, dhq_attn = (zb[k] for k in ('dcq', 'dcd', 'dh0', 'dh1', 'dcum', 'dhq_attn'))
-        wt = dict(q=torch.cat([q_w_ih.detach(), q_w_hh.detach()], 1).t().contiguous(),      # (P+E+Q, 4Q)
-                  d=torch.cat([d_w_ih.detach(), d_w_hh.detach()], 1).t().contiguous(),      # (E+Q+D, 4D)
-                  pq=wq.detach().t().contiguous())                                         # (Q, A)
+        wt = dict(pq=wq.detach().t().contiguous())                                         # (Q, A)
         bw = StDecoderBwdWeights()
-        bw.q_w_cat_t, bw.d_w_cat_t, bw.attn_query_w_t = ops._p(wt['q']), ops._p(wt['d']), ops._p(wt['pq'])
+        bw.attn_query_w_t = ops._p(wt['pq'])
         bw.attn_v, bw.attn_loc_conv_w, bw.attn_loc_lin_w = ops._p(v), ops._p(wc), ops._p(wl)
-        # the two big per-step products dgates . W stream W^T in MFMA lane order (packed once per backward)
-        wt['q_p16'] = ops.pack_weight([wt['q']], [4 * Q], XQw)
-        wt['d_p16'] = ops.pack_weight([wt['d']], [4 * D], XDw)
+        # the two big per-step products dgates . W stream W^T = [W_ih | W_hh]^T in MFMA lane order: packed once per backward, straight
+        # from the two parameters (no cat / transpose copies; the natural transposed forms are not needed next to the packed ones)
+        wt['q_p16'] = ops.pack_weight_t([q_w_ih.detach(), q_w_hh.detach()])                 # N = P+E+Q, K = 4Q
+        wt['d_p16'] = ops.pack_weight_t([d_w_ih.detach(), d_w_hh.detach()])                 # N = E+Q+D, K = 4D
         bw.q_w_cat_t_p16, bw.d_w_cat_t_p16 = ops._p(wt['q_p16']), ops._p(wt['d_p16'])
         dgq_t16, dgd_t16 = zb['dgq_t16'], zb['dgd_t16']
         dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A, F=F, K=K, fuse_pre0=0)

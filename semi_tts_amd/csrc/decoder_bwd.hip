@@ -51,8 +51,7 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
     const int B = d->B, L = d->L, E = d->E, P = d->P, Q = d->Q, D = d->D, A = d->A;
     const int steps = io->steps, Bp = io->Bp;
     ST_CHECK_ARG(B > 0 && steps > 0 && Bp >= B, "st_decoder_backward: B=%d steps=%d Bp=%d", B, steps, Bp);
-    ST_CHECK_ARG(w->q_w_cat_t && w->d_w_cat_t && w->attn_query_w_t && w->attn_v && w->attn_loc_conv_w && w->attn_loc_lin_w,
-                 "st_decoder_backward: null weight");
+    ST_CHECK_ARG(w->attn_v && w->attn_loc_conv_w && w->attn_loc_lin_w, "st_decoder_backward: null weight");
     ST_CHECK_ARG(io->memory && io->pm && io->ada_std && io->align && io->wcum_tape && io->cq_tape && io->cd_tape &&
                  io->gates_q_tape && io->gates_d_tape && io->pq_all && io->dxo, "st_decoder_backward: null saved tensor");
     ST_CHECK_ARG(io->dgq && io->dgd && io->dxq && io->dxd && io->dpq && io->ds_tape && io->loc_tape && io->dloc_tape &&
@@ -77,6 +76,8 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
     const bool fuse_pw = io->fuse_pw && !own && packed && w->attn_query_w_t_p16 && io->dgd_t16_b && io->dpq_t16 && Q % 16 == 0 && D % 16 == 0 &&
                          (E + Q) % 16 == 0 && A % 4 == 0 && XD % 4 == 0 && XQ % 4 == 0 && XO % 4 == 0 &&
                          (io->q_mask == nullptr || st_aligned16(io->q_mask)) && st_aligned16(io->dxo) && st_aligned16(io->dxd) && st_aligned16(io->dxq);
+    ST_CHECK_ARG(packed || (w->q_w_cat_t && w->d_w_cat_t), "st_decoder_backward: neither packed nor natural [W_ih | W_hh]^T");
+    ST_CHECK_ARG(fuse_pw || w->attn_query_w_t, "st_decoder_backward: natural W_q^T missing (needed without fuse_pw)");
     if (fuse_pw) {
         // Four launches per step instead of six: the pointwise half of each cell's backward step runs in the epilogue of the product
         // that makes its dh -- dgates_d(t) . [W_ih_d | W_hh_d] makes dh_d(t-1) in its last D columns (so the decoder cell's pointwise

@@ -337,17 +337,30 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_kernel(const float* X, int
     const int n = blockIdx.x * 64 + c;
     const bool ok = n < N;
     const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
-    float s = 0.0f;
-    if (ok) for (int m = m0 + rl; m < m1; m += 4) s += X[(size_t)m * ldx + coff + n];
-    red[rl][c] = s;
+    const float* __restrict__ xp = X + coff + min(n, N - 1);
+    // rows m0 + rl, + 4, ...: four independent running sums (rows 16 apart) keep four loads in flight per thread -- with one sum the
+    // loop is a chain of dependent round trips (12.9 us per 4 MB layer in round 2's form)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int m = m0 + rl;
+    for (; m + 12 < m1; m += 16) {
+        s0 += xp[(size_t)m * ldx]; s1 += xp[(size_t)(m + 4) * ldx]; s2 += xp[(size_t)(m + 8) * ldx]; s3 += xp[(size_t)(m + 12) * ldx];
+    }
+    for (; m < m1; m += 4) s0 += xp[(size_t)m * ldx];
+    red[rl][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl == 0) smean[c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)max(m1 - m0, 1);
     __syncthreads();
     const float mean = smean[c];
-    float q = 0.0f;
-    if (ok) for (int m = m0 + rl; m < m1; m += 4) { const float d = X[(size_t)m * ldx + coff + n] - mean; q = fmaf(d, d, q); }
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    m = m0 + rl;
+    for (; m + 12 < m1; m += 16) {      // (second pass: the chunk's rows come from cache)
+        const float d0 = xp[(size_t)m * ldx] - mean, d1 = xp[(size_t)(m + 4) * ldx] - mean;
+        const float d2 = xp[(size_t)(m + 8) * ldx] - mean, d3 = xp[(size_t)(m + 12) * ldx] - mean;
+        q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
+    }
+    for (; m < m1; m += 4) { const float d = xp[(size_t)m * ldx] - mean; q0 = fmaf(d, d, q0); }
     __syncthreads();
-    red[rl][c] = q;
+    red[rl][c] = (q0 + q1) + (q2 + q3);
     __syncthreads();
     if (rl == 0 && ok) {
         part[((size_t)blockIdx.y * 2 + 0) * N + n] = mean;
@@ -355,47 +368,61 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_kernel(const float* X, int
     }
 }
 
+// merge of the chunk records: 16 columns x 16 chunk lanes per workgroup; lane j holds chunks j, j + 16, ... (at most 8: chunks <= 128)
+// in REGISTERS -- all its loads are issued at once, one memory round trip for both sweeps -- and the 16 lanes' sums are combined
+// through LDS in a fixed order.
+//   mean = sum_c n_c mean_c / M;   M2 = sum_c [M2_c + n_c (mean_c - mean)^2]      (exact decomposition, Chan et al.)
+// (one thread per column walking all the chunks took 16 us per layer: 2 x 64 dependent-latency iterations)
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, int chunks, int rows_per_chunk, int M, int N,
                                                              float* mean_out, float* var_out, float* run_mean, float* run_var,
                                                              float momentum, long long* batches_tracked) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n == 0 && batches_tracked) batches_tracked[0] += 1;      // nn.BatchNorm1d.num_batches_tracked, without a launch of its own
-    if (n >= N) return;
-    // two sweeps over the chunk records with independent loads (no serial dependence between chunks):
-    //   mean = sum_c n_c mean_c / M;   M2 = sum_c [M2_c + n_c (mean_c - mean)^2]      (exact decomposition)
-    const float* pm = part + n;
+    constexpr int CL = 16, PER = 8;
+    __shared__ float red[CL][16];
+    __shared__ float smean[16];
+    const int c = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && batches_tracked) batches_tracked[0] += 1;      // nn.BatchNorm1d.num_batches_tracked, without a launch of its own
+    const bool ok = n < N;
+    const float* pm = part + min(n, N - 1);
     const size_t cs = (size_t)2 * N;
-    float a0 = 0.f, a1 = 0.f;
-    int ch = 0;
-    for (; ch + 2 <= chunks; ch += 2) {
-        const float n0 = (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0);
-        const float n1 = (float)max(min(M, (ch + 2) * rows_per_chunk) - (ch + 1) * rows_per_chunk, 0);
-        a0 = fmaf(n0, pm[(size_t)ch * cs], a0); a1 = fmaf(n1, pm[(size_t)(ch + 1) * cs], a1);
+    float mu[PER], m2[PER], cnt[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int ch = cl + j * CL;
+        const bool in = ch < chunks;
+        const int chc = in ? ch : 0;
+        mu[j] = pm[(size_t)chc * cs]; m2[j] = pm[(size_t)chc * cs + N];
+        cnt[j] = in ? (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0) : 0.0f;
+        if (!in) m2[j] = 0.0f;
     }
-    for (; ch < chunks; ++ch) {
-        const float n0 = (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0);
-        a0 = fmaf(n0, pm[(size_t)ch * cs], a0);
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) a = fmaf(cnt[j], mu[j], a);
+    red[cl][c] = a;
+    __syncthreads();
+    if (cl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CL; ++k) t += red[k][c];
+        smean[c] = t / (float)M;
     }
-    const float mean = (a0 + a1) / (float)M;
-    float q0 = 0.f, q1 = 0.f;
-    for (ch = 0; ch + 2 <= chunks; ch += 2) {
-        const float n0 = (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0);
-        const float n1 = (float)max(min(M, (ch + 2) * rows_per_chunk) - (ch + 1) * rows_per_chunk, 0);
-        const float d0 = pm[(size_t)ch * cs] - mean, d1 = pm[(size_t)(ch + 1) * cs] - mean;
-        const float m0 = pm[(size_t)ch * cs + N], m1 = pm[(size_t)(ch + 1) * cs + N];
-        q0 += m0 + n0 * d0 * d0; q1 += m1 + n1 * d1 * d1;
-    }
-    for (; ch < chunks; ++ch) {
-        const float nb = (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0);
-        const float d = pm[(size_t)ch * cs] - mean;
-        q0 += pm[(size_t)ch * cs + N] + nb * d * d;
-    }
-    const float m2 = q0 + q1;
-    const float var_b = m2 / (float)M;
+    __syncthreads();
+    const float mean = smean[c];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const float d = mu[j] - mean; q += m2[j] + cnt[j] * d * d; }
+    __syncthreads();
+    red[cl][c] = q;
+    __syncthreads();
+    if (cl != 0 || !ok) return;
+    float m2t = 0.f;
+#pragma unroll
+    for (int k = 0; k < CL; ++k) m2t += red[k][c];
+    const float var_b = m2t / (float)M;
     mean_out[n] = mean;
     var_out[n] = var_b;
     if (run_mean) {
-        const float var_u = M > 1 ? m2 / (float)(M - 1) : var_b;
+        const float var_u = M > 1 ? m2t / (float)(M - 1) : var_b;
         run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
         run_var[n] = (1.0f - momentum) * run_var[n] + momentum * var_u;
     }
@@ -502,7 +529,8 @@ extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, floa
     hipLaunchKernelGGL(bn_stats_chunk_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream,
                        X, ldx, coff, M, N, rpc, ws);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    ST_CHECK_ARG(chunks <= 128, "st_bn_stats: %d chunks (the merge kernel holds at most 128)", chunks);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                        ws, chunks, rpc, M, N, mean_out, var_out, run_mean, run_var, momentum, batches_tracked);
     ST_LAUNCH_CHECK();
     return 0;

@@ -196,14 +196,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* X, int ldx, in
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
     const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
-    float s = 0.0f;
-    if (n < N)
-        for (int m = m0 + rl; m < m1; m += 4) {
-            float v = X[(size_t)m * ldx + xoff + n];
-            if (Y) v *= Y[(size_t)m * ldy + yoff + n];
-            s += v;
+    const float* __restrict__ xp = X + xoff + min(n, N - 1);
+    const float* __restrict__ yp = Y ? Y + yoff + min(n, N - 1) : nullptr;
+    // four independent running sums (rows 16 apart): four (eight with Y) loads in flight per thread
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int m = m0 + rl;
+    if (yp) {
+        for (; m + 12 < m1; m += 16) {
+            const float x0 = xp[(size_t)m * ldx], x1 = xp[(size_t)(m + 4) * ldx], x2 = xp[(size_t)(m + 8) * ldx], x3 = xp[(size_t)(m + 12) * ldx];
+            const float y0 = yp[(size_t)m * ldy], y1 = yp[(size_t)(m + 4) * ldy], y2 = yp[(size_t)(m + 8) * ldy], y3 = yp[(size_t)(m + 12) * ldy];
+            s0 = fmaf(x0, y0, s0); s1 = fmaf(x1, y1, s1); s2 = fmaf(x2, y2, s2); s3 = fmaf(x3, y3, s3);
         }
-    red[rl][c] = s;
+        for (; m < m1; m += 4) s0 = fmaf(xp[(size_t)m * ldx], yp[(size_t)m * ldy], s0);
+    } else {
+        for (; m + 12 < m1; m += 16) {
+            s0 += xp[(size_t)m * ldx]; s1 += xp[(size_t)(m + 4) * ldx]; s2 += xp[(size_t)(m + 8) * ldx]; s3 += xp[(size_t)(m + 12) * ldx];
+        }
+        for (; m < m1; m += 4) s0 += xp[(size_t)m * ldx];
+    }
+    red[rl][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl == 0 && n < N) part[(size_t)blockIdx.y * N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
@@ -241,18 +252,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, int
     __shared__ float r1[4][64], r2[4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    const int nc = min(n, N - 1);
     const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
-    float a = 0.0f, b = 0.0f;
-    if (n < N) {
-        const float mu = mean[n], inv = 1.0f / sqrtf(var[n] + eps);
-        for (int m = m0 + rl; m < m1; m += 4) {
-            float g = dy[(size_t)m * ldd + doff + n];
-            if (act != ST_ACT_NONE) g *= act_grad(y[(size_t)m * ldy + yoff + n], act);
-            a += g;
-            b = fmaf(g, (x[(size_t)m * ldx + xoff + n] - mu) * inv, b);
-        }
+    const float mu = mean[nc], inv = 1.0f / sqrtf(var[nc] + eps);
+    const float* __restrict__ dp = dy + doff + nc;
+    const float* __restrict__ xp = x + xoff + nc;
+    const float* __restrict__ yp = act != ST_ACT_NONE ? y + yoff + nc : nullptr;
+    // two rows per pass with independent sums: (up to) six loads in flight per thread instead of a chain of dependent round trips
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    int m = m0 + rl;
+    for (; m + 4 < m1; m += 8) {
+        float g0 = dp[(size_t)m * ldd], g1 = dp[(size_t)(m + 4) * ldd];
+        const float x0 = xp[(size_t)m * ldx], x1 = xp[(size_t)(m + 4) * ldx];
+        if (yp) { g0 *= act_grad(yp[(size_t)m * ldy], act); g1 *= act_grad(yp[(size_t)(m + 4) * ldy], act); }
+        a0 += g0; a1 += g1;
+        b0 = fmaf(g0, (x0 - mu) * inv, b0); b1 = fmaf(g1, (x1 - mu) * inv, b1);
     }
-    r1[rl][c] = a; r2[rl][c] = b;
+    for (; m < m1; m += 4) {
+        float g = dp[(size_t)m * ldd];
+        if (yp) g *= act_grad(yp[(size_t)m * ldy], act);
+        a0 += g;
+        b0 = fmaf(g, (xp[(size_t)m * ldx] - mu) * inv, b0);
+    }
+    r1[rl][c] = a0 + a1; r2[rl][c] = b0 + b1;
     __syncthreads();
     if (rl == 0 && n < N) {
         part[((size_t)blockIdx.y * 2 + 0) * N + n] = r1[0][c] + r1[1][c] + r1[2][c] + r1[3][c];
@@ -260,24 +282,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, int
     }
 }
 
-// out[q][n] (+)= sum_chunks part[chunk][q][n], q < Q.  Fixed order (four interleaved running sums, then a fixed
-// combination), loads of four chunks in flight per thread.
+// out[q][n] (+)= sum_chunks part[chunk][q][n], q < Q.  16 (q, n) pairs x 16 chunk lanes per workgroup: lane j adds chunks j, j + 16, ...
+// (at most 8, all loads issued at once), the lanes' sums are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void chunk_final_kernel(const float* part, int chunks, int Q, int N, float* out0, float* out1,
                                                           int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Q * N) return;
-    const int q = i / N, n = i - q * N;
-    float* out = q == 0 ? out0 : out1;
+    constexpr int CL = 16, PER = 8;
+    __shared__ float red[CL][16];
+    const int c = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
+    const bool ok = i < Q * N;
+    const int ic = min(i, Q * N - 1);
+    const int q = ic / N, n = ic - q * N;
     const float* p = part + (size_t)q * N + n;
     const size_t cs = (size_t)Q * N;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int ch = 0;
-    for (; ch + 4 <= chunks; ch += 4) {
-        s0 += p[(size_t)ch * cs]; s1 += p[(size_t)(ch + 1) * cs]; s2 += p[(size_t)(ch + 2) * cs]; s3 += p[(size_t)(ch + 3) * cs];
-    }
-    for (; ch < chunks; ++ch) s0 += p[(size_t)ch * cs];
-    const float s = (s0 + s1) + (s2 + s3);
-    out[n] = accumulate ? out[n] + s : s;
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const int ch = cl + j * CL; v[j] = p[(size_t)(ch < chunks ? ch : 0) * cs]; if (ch >= chunks) v[j] = 0.0f; }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) s += v[j];
+    red[cl][c] = s;
+    __syncthreads();
+    if (cl != 0 || !ok) return;
+    float* out = q == 0 ? out0 : out1;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < CL; ++k) t += red[k][c];
+    out[n] = accumulate ? out[n] + t : t;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff,
@@ -443,7 +474,7 @@ extern "C" int st_colsum(const float* X, int ldx, int xoff, const float* Y, int 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, X, ldx, xoff, Y, ldy, yoff, M, N, rpc, ws);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chunk_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, chunks, 1, N, out, out, accumulate);
+    hipLaunchKernelGGL(chunk_final_kernel, dim3((N + 15) / 16), dim3(256), 0, st, ws, chunks, 1, N, out, out, accumulate);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -473,7 +504,7 @@ extern "C" int st_bn_bwd_reduce(const float* dy, int ldd, int doff, const float*
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, dy, ldd, doff, y, ldy, yoff, act,
                        x, ldx, xoff, mean, var, eps, M, N, rpc, part);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chunk_final_kernel, dim3((2 * N + 255) / 256), dim3(256), 0, st, part, chunks, 2, N, s, s + N, 0);
+    hipLaunchKernelGGL(chunk_final_kernel, dim3((2 * N + 15) / 16), dim3(256), 0, st, part, chunks, 2, N, s, s + N, 0);
     ST_LAUNCH_CHECK();
     return 0;
 }

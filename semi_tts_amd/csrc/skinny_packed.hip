@@ -64,6 +64,51 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const PackArgs a) {
     }
 }
 
+// P16 image of the TRANSPOSE of a column concatenation: packed row r (segment s holds rows [r0_s, r0_s + k_s)) = column r - r0_s of
+// w[s], packed k = source row.  One thread per 4 (rows) x 4 (k) micro-tile: four 16-byte loads along the source rows, a register
+// transposition, four 16-byte stores to four adjacent lanes' slots -- the backward's W^T operands without a cat / transpose copy first.
+struct PackTArgs {
+    const float* w[PK_MAXSEG]; int ldw[PK_MAXSEG]; int r0[PK_MAXSEG + 1];
+    int nseg; int N; int K; int KB; int tiles; int vec; float* out;
+};
+
+__global__ __launch_bounds__(256) void pack_weight_t_kernel(const PackTArgs a) {
+    const size_t total = (size_t)a.tiles * a.KB * 16;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ig = (int)(idx & 3), kq = (int)((idx >> 2) & 3);
+        const size_t blk = idx >> 4;
+        const int kb = (int)(blk % a.KB), tile = (int)(blk / a.KB);
+        const int row = tile * 16 + ig * 4, k = kb * 16 + kq * 4;
+        f32x4 in[4];       // in[j] = source row k + j, columns row .. row + 3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < a.N) {
+            int s = 0;
+            while (s + 1 < a.nseg && row >= a.r0[s + 1]) ++s;
+            const bool whole = a.vec && row + 4 <= a.r0[s + 1];      // the four rows lie in one segment, 16-byte addressable
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k + j >= a.K) continue;
+                if (whole) {
+                    in[j] = st_ld4(a.w[s] + (size_t)(k + j) * a.ldw[s] + (row - a.r0[s]));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int r = row + c;
+                        if (r >= a.N) continue;
+                        int sc = s;
+                        while (sc + 1 < a.nseg && r >= a.r0[sc + 1]) ++sc;
+                        in[j][c] = a.w[sc][(size_t)(k + j) * a.ldw[sc] + (r - a.r0[sc])];
+                    }
+                }
+            }
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(a.out) + blk * 64 + kq * 16 + ig * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = f32x4{in[0][c], in[1][c], in[2][c], in[3][c]};
+    }
+}
+
 // natural (B, K) rows with stride ld  ->  tiled T16 (pads written as zero)
 __global__ __launch_bounds__(256) void tile_rows_kernel(const float* src, int ld, float* dst, int kbs, int kb0, int B, int K) {
     const int KB = pk_kb(K), BT = (B + 15) >> 4;
@@ -795,6 +840,28 @@ extern "C" int st_pack_weight(const float* const* w, const int* ldw, const int* 
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_pack_weight_t(const float* const* w, const int* ldw, const int* cols, int nseg, int K, float* packed, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(w && ldw && cols && packed && nseg >= 1 && nseg <= PK_MAXSEG && K > 0, "st_pack_weight_t: bad arguments");
+    PackTArgs a;
+    memset(&a, 0, sizeof(a));
+    int r = 0, vec = 1;
+    for (int s = 0; s < nseg; ++s) {
+        ST_CHECK_ARG(w[s] && cols[s] > 0 && ldw[s] >= cols[s], "st_pack_weight_t: segment %d invalid", s);
+        a.w[s] = w[s]; a.ldw[s] = ldw[s]; a.r0[s] = r;
+        vec = vec && st_aligned16(w[s]) && ldw[s] % 4 == 0 && r % 4 == 0;
+        r += cols[s];
+    }
+    a.r0[nseg] = r;
+    a.nseg = nseg; a.N = r; a.K = K; a.KB = pk_kb(K); a.tiles = (r + 15) / 16; a.vec = vec; a.out = packed;
+    const size_t total = (size_t)a.tiles * a.KB * 16;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_weight_t_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -53,7 +53,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // row chunks of the split column reductions (st_bn_stats, st_colsum, st_bn_bwd): enough blocks to fill 256 CUs
 // even for 80-column tensors, chunks of >= 64 rows
-static inline int st_colreduce_chunks(int M) { int c = M / 64; if (c < 1) c = 1; if (c > 64) c = 64; return c; }
+// row chunks of the column reductions (BatchNorm statistics / backward sums, bias gradients): ~32 rows per chunk, at most 128 chunks
+// (two column blocks x 128 chunks = one workgroup per compute unit for the 128-channel layers of the CBHG)
+static inline int st_colreduce_chunks(int M) { int c = M / 32; if (c < 1) c = 1; if (c > 128) c = 128; return c; }
 
 #define ST_WAVE 64
 

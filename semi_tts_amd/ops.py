@@ -648,6 +648,23 @@ def pack_weight(ws, ks, N, lstm_H=0, ldws=None):
     return out
 
 
+def pack_weight_t(ws):
+    """P16 buffer of torch.cat(ws, 1).t() -- ws: list of (K, cols_s) matrices (row stride >= cols_s); no cat / transpose copy"""
+    lib = _lib.load()
+    n = len(ws)
+    K = int(ws[0].shape[0])
+    assert all(int(w.shape[0]) == K and w.stride(1) == 1 for w in ws)
+    cols = [int(w.shape[1]) for w in ws]
+    carr = (C.c_int * n)(*cols)
+    ldarr = (C.c_int * n)(*[int(w.stride(0)) for w in ws])
+    warr = (C.c_void_p * n)(*[_p(w) for w in ws])
+    karr = (C.c_int * 1)(K)
+    size = int(lib.st_packed_weight_floats(karr, 1, sum(cols), 0))
+    out = torch.empty(size, device=ws[0].device, dtype=torch.float32)
+    check(lib.st_pack_weight_t(warr, ldarr, carr, n, K, _p(out), stream_handle()), 'st_pack_weight_t')
+    return out
+
+
 def kb16(k):
     return (int(k) + 15) // 16
 

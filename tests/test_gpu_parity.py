@@ -150,6 +150,21 @@ def test_lstm_cell_packed(dev, B, H, Ks):
     assert maxdiff(gts[:, 3], torch.sigmoid(o)) < 1e-5
 
 
+@pytest.mark.parametrize('K,cols', [(64, (32,)), (4096, (256, 512, 1024)), (100, (24, 40)), (37, (5, 18, 9)), (128, (1024,)), (48, (30, 34))])
+def test_pack_weight_transposed_concat(dev, K, cols):
+    """st_pack_weight_t: the P16 image of cat(ws, 1).t() straight from the parameters == st_pack_weight of the materialised
+    transpose, bit for bit (aligned and ragged segment boundaries, K and N that are not multiples of 16, strided sources)."""
+    from semi_tts_amd import ops
+    big = rnd(K, sum(cols) + 3, seed=5).to(dev)
+    ws, off = [], 0
+    for i, c in enumerate(cols):
+        ws.append(big[:, off:off + c] if i % 2 == 0 else big[:, off:off + c].contiguous())      # views with a row stride > cols too
+        off += c
+    ref = ops.pack_weight([torch.cat(ws, 1).t().contiguous()], [K], sum(cols))
+    got = ops.pack_weight_t(ws)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+
+
 @pytest.mark.parametrize('B,N,Ks', [(1, 16, (32,)), (4, 40, (24,)), (32, 241, (1024, 512)), (32, 256, (240,)),
                                     (33, 48, (100, 28)), (64, 80, (62,)), (70, 33, (31,))])
 def test_skinny_linear_packed(dev, B, N, Ks):

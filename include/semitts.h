@@ -742,6 +742,19 @@ int st_mt_adam(float* const* p, float* const* g, float* const* m, float* const* 
 
 /* ------------------------------------------------------------------ small utilities */
 int st_fill(float* p, float v, size_t n, void* stream);
+
+/* Re-layouts of many PARAMETERS in one launch: what `w.permute(0, 2, 1).contiguous()` (mode 0: Conv1d weight (N, Cin, KT) -> tap-major
+ * (N, KT, Cin), the forward implicit-GEMM operand) and `w.permute(1, 0, 2).flip(2)` in tap-major form (mode 1: -> (Cin, KT, N) with the
+ * taps reversed, the weight of the input-gradient conv; KT = 1: the transpose of a Linear weight) do one torch copy at a time.
+ * `table_dev` is a DEVICE array of n descriptors ordered by blk0; descriptor d owns workgroups [blk0, blk0 + st_relayout_blocks(N, Cin, KT)).
+ * Replaces the per-weight layout copies in front of torch's conv / linear backward (src/module.py: every Conv1d / Linear). */
+typedef struct st_relayout_desc {
+    const float* src; float* dst;
+    int N, Cin, KT, mode;
+    int blk0, pad_;
+} st_relayout_desc;
+int st_relayout_blocks(int N, int Cin, int KT);
+int st_relayout_batch(const st_relayout_desc* table_dev, int n, int total_blocks, void* stream);
 int st_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream);
 /* dst(b, :) = mean over t of src(b, t, :)    ref: teacher.mean(dim=1) src/module.py:194 */
 int st_mean_rows(const float* src, float* dst, int B, int T, int D, void* stream);

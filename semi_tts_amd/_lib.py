@@ -31,6 +31,11 @@ class StGemmEpilogue(C.Structure):
                 ('splitk_ws', C.c_void_p), ('splitk_slabs', C.c_int)]
 
 
+class StRelayoutDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('N', C.c_int), ('Cin', C.c_int), ('KT', C.c_int), ('mode', C.c_int),
+                ('blk0', C.c_int), ('pad_', C.c_int)]
+
+
 class StDecoderWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'prenet_w0', 'prenet_w1', 'q_w_ih', 'q_w_hh', 'q_b_ih', 'q_b_hh',
@@ -149,6 +154,8 @@ SIGNATURES = {
     'st_t16_floats': [I, I],
     'st_pack_weight': [C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, I, P, P],
     'st_pack_weight_t': [C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, P, P],
+    'st_relayout_blocks': [I, I, I],
+    'st_relayout_batch': [P, I, I, P],
     'st_tile_rows': [P, I, C.POINTER(StT16View), I, I, P],
     'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
     'st_lstm_cell_packed_fwd': [P, C.POINTER(StT16View), I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),

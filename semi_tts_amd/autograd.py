@@ -61,8 +61,8 @@ class _ConvFn(Function):
             ops.copy3d(up[:, 0:(To - 1) * stride + 1:stride], dpre.view(Bn, To, N), Bn, To, N)
             dpre, To = up, To1
         if ctx.needs_input_grad[0]:
-            wt = (w.detach().permute(1, 0, 2).flip(2) if w.dim() == 3 else w.detach().t()).contiguous()
-            dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pad)
+            wt, tap_major = ops.dx_weight(w.detach())        # (cached per weight version: all weights re-laid out by one launch per step)
+            dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pad, w_tap_major=tap_major)
             if pool_prev:
                 dx = ops.pool_prev_bwd(dx, x)
         if ctx.needs_input_grad[1]:
@@ -343,7 +343,7 @@ class _BiLstmFn(Function):
         dout = dout.contiguous()
         H = w_hh_f.shape[1]
         res = []
-        dxps = ops.lstm_seq2_bwd(dout, (g_f, g_b), (c_f, c_b), (w_hh_f.detach().t().contiguous(), w_hh_b.detach().t().contiguous()))
+        dxps = ops.lstm_seq2_bwd(dout, (g_f, g_b), (c_f, c_b), (ops.dx_weight(w_hh_f.detach())[0], ops.dx_weight(w_hh_b.detach())[0]))
         for d in range(2):
             dxp = dxps[d]
             # h_{t-1} of the forward direction is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1 / -1

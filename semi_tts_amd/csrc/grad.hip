@@ -410,6 +410,44 @@ __global__ __launch_bounds__(256) void highway_fwd_kernel(const float* H, const 
     }
 }
 
+// Re-layouts of MANY parameters in one launch (training re-lays every conv / linear weight out once per step: one launch instead of
+// one torch copy per weight and layout).  Workgroup b serves the descriptor d with blk0[d] <= b < blk0[d] + nblk[d]; a thread
+// writes four consecutive destination floats (one 16-byte store when aligned) gathered from the source.
+//   mode 0: (N, Cin, KT) -> (N, KT, Cin)                      tap-major conv weight (forward GEMM operand)
+//   mode 1: (N, Cin, KT) -> (Cin, KT, N), taps reversed        weight of the input-gradient conv, tap-major (KT = 1: plain transpose)
+__global__ __launch_bounds__(256) void relayout_batch_kernel(const st_relayout_desc* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                      // last descriptor whose first workgroup is <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const st_relayout_desc d = table[lo];
+    const size_t total = (size_t)d.N * d.Cin * d.KT;
+    const size_t i0 = ((size_t)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x) * 4;
+    if (i0 >= total) return;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const size_t i = i0 + c;
+        v[c] = 0.0f;
+        if (i >= total) continue;
+        if (d.mode == 0) {
+            const int ci = (int)(i % d.Cin);
+            const size_t r = i / d.Cin;
+            const int kt = (int)(r % d.KT), nn = (int)(r / d.KT);
+            v[c] = d.src[((size_t)nn * d.Cin + ci) * d.KT + kt];
+        } else {
+            const int nn = (int)(i % d.N);
+            const size_t r = i / d.N;
+            const int kt = (int)(r % d.KT), ci = (int)(r / d.KT);
+            v[c] = d.src[((size_t)nn * d.Cin + ci) * d.KT + (d.KT - 1 - kt)];
+        }
+    }
+    if (i0 + 4 <= total && st_aligned16(d.dst + i0)) *reinterpret_cast<f32x4*>(d.dst + i0) = f32x4{v[0], v[1], v[2], v[3]};
+    else
+        for (int c = 0; c < 4 && i0 + c < total; ++c) d.dst[i0 + c] = v[c];
+}
+
 inline int blocks_for(size_t n, int cap = 4096) {
     size_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -566,6 +604,16 @@ extern "C" int st_copy3d(float* dst, long dst_sb, long dst_st, const float* src,
     ST_CHECK_ARG(dst && src && Bn > 0 && T > 0 && C > 0, "st_copy3d: bad arguments");
     hipLaunchKernelGGL(copy3d_kernel, dim3(blocks_for((size_t)Bn * T * C)), dim3(256), 0, (hipStream_t)stream,
                        dst, dst_sb, dst_st, src, src_sb, src_st, Bn, T, C, accumulate);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_relayout_blocks(int N, int Cin, int KT) { return (int)(((size_t)N * Cin * KT + 1023) / 1024); }
+
+extern "C" int st_relayout_batch(const st_relayout_desc* table_dev, int n, int total_blocks, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(table_dev && n > 0 && total_blocks > 0, "st_relayout_batch: bad arguments");
+    hipLaunchKernelGGL(relayout_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -200,31 +200,100 @@ def query_attn_rng(packed_wq, h_q_t16, Q, s_buf, memory, w_cum_prev, v, w_out, w
     return granules, xchg
 
 
-_TAP_MAJOR = {}     # id(weight) -> (weakref to it, version, converted copy)
+class _ParamLayouts:
+    """Cached re-layouts of PARAMETERS (a layout change only: mode 0 = Conv1d weight (N, Cin, KT) -> tap-major (N, KT, Cin), the forward
+    implicit-GEMM operand; mode 1 = (N, Cin, KT) -> (Cin, KT, N) with the taps reversed, the weight of the input-gradient conv, for
+    KT = 1 the transpose of a Linear weight).  Keyed on (storage address, shape, mode); an entry holds a detached alias of the
+    parameter (same storage and version counter) and is valid while the version counter has not moved.  When ANY entry is found
+    stale (the optimiser has stepped), ALL entries are refreshed by ONE launch (st_relayout_batch): training re-lays out ~40 weights
+    per step, one torch copy each in round 2.  Entries nobody asked for during the last 8 epochs (steps) are dropped."""
+    MAX_ENTRIES = 1024
+
+    def __init__(self):
+        self.entries = {}       # key -> [alias, dst, version, (N, Cin, KT), epoch of the last use]
+        self.table = None       # device descriptor table of the entries
+        self.count = 0
+        self.total_blocks = 0
+        self.dirty = True
+        self.refreshes = 0      # launches
+        self.epoch = 0          # stale-triggered refreshes (~ optimisation steps)
+
+    def get(self, w, mode):
+        key = (w.data_ptr(), tuple(w.shape), mode)
+        e = self.entries.get(key)
+        if e is not None:
+            e[4] = self.epoch
+            if e[2] != e[0]._version:
+                self.epoch += 1              # (a weight has moved: a new optimisation step -- entries age by these, not by launches)
+                e[4] = self.epoch
+                self.refresh()
+            return e[1]
+        N, Cin = int(w.shape[0]), int(w.shape[1])
+        KT = int(w.shape[2]) if w.dim() == 3 else 1
+        assert w.is_contiguous() and w.dtype == torch.float32
+        if len(self.entries) >= self.MAX_ENTRIES:          # (inference-only processes never refresh: bound the table by age)
+            for k in sorted(self.entries, key=lambda k: self.entries[k][4])[:self.MAX_ENTRIES // 2]:
+                del self.entries[k]
+        dst = torch.empty((N, KT, Cin) if mode == 0 else (Cin, KT, N), device=w.device, dtype=torch.float32)
+        self.entries[key] = [w.detach(), dst, -1, (N, Cin, KT), self.epoch]
+        self.dirty = True
+        self.refresh()
+        return dst
+
+    def refresh(self):
+        lib = _lib.load()
+        self.refreshes += 1
+        drop = [k for k, e in self.entries.items() if self.epoch - e[4] > 8]
+        for k in drop:
+            del self.entries[k]
+            self.dirty = True
+        if not self.entries:
+            return
+        if self.dirty:
+            dev = next(iter(self.entries.values()))[1].device
+            assert all(e[1].device == dev for e in self.entries.values()), 'parameter layouts of several devices in one process'
+            arr = (_lib.StRelayoutDesc * len(self.entries))()
+            blk = 0
+            for d, (key, e) in zip(arr, self.entries.items()):
+                N, Cin, KT = e[3]
+                d.src, d.dst, d.N, d.Cin, d.KT, d.mode, d.blk0 = e[0].data_ptr(), e[1].data_ptr(), N, Cin, KT, key[2], blk
+                blk += int(lib.st_relayout_blocks(N, Cin, KT))
+            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.count, self.total_blocks, self.dirty = len(self.entries), blk, False
+        check(lib.st_relayout_batch(_p(self.table, torch.uint8), self.count, self.total_blocks, stream_handle()), 'st_relayout_batch')
+        for e in self.entries.values():
+            e[2] = e[0]._version
+
+
+_LAYOUTS = _ParamLayouts()
 
 
 def _tap_major(w):
     """Conv1d weight (N, Cin, KT) -> (N, KT, Cin) contiguous (layout change of a PARAMETER; a k-block of the implicit GEMM is then
-    16-byte loadable).  Cached per tensor object and version: inference converts a weight once, training once per step."""
-    import weakref
-    ent = _TAP_MAJOR.get(id(w))
-    if ent is not None and ent[0]() is w and ent[1] == w._version:
-        return ent[2]
-    wt = w.detach().permute(0, 2, 1).contiguous()
-    if len(_TAP_MAJOR) > 256:
-        for k in [k for k, e in _TAP_MAJOR.items() if e[0]() is None]:
-            del _TAP_MAJOR[k]
-    try:
-        _TAP_MAJOR[id(w)] = (weakref.ref(w), w._version, wt)
-    except TypeError:
-        pass
-    return wt
+    16-byte loadable).  Cached per tensor object and version: inference converts a weight once, training once per step -- and then
+    all weights in one launch (_ParamLayouts)."""
+    if w.is_contiguous() and w.is_cuda and w.dtype == torch.float32:
+        return _LAYOUTS.get(w, 0)
+    return w.detach().permute(0, 2, 1).contiguous()
+
+
+def dx_weight(w):
+    """the weight operand of the input-gradient product of a conv / linear layer with parameter w ((N, Cin, KT) or (N, Cin)):
+    returns (weight, tap_major) for ops.gemm -- the cached (Cin, KT, N) tap-reversed form when the tap-major kernel can take it,
+    otherwise torch's permute / flip copy in the Conv1d layout"""
+    KT = w.shape[2] if w.dim() == 3 else 1
+    N = w.shape[0]
+    if w.is_contiguous() and w.is_cuda and w.dtype == torch.float32 and (KT == 1 or (N % 4 == 0 and N >= 16)):
+        wt = _LAYOUTS.get(w, 1)
+        return (wt.view(wt.shape[0], N), False) if KT == 1 else (wt, True)
+    return (w.permute(1, 0, 2).flip(2) if w.dim() == 3 else w.t()).contiguous(), False
 
 
 def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=0, bias=None, act_pre=None,
-         bn=None, bn_eps=1e-5, act_post=None, res=None, highway_h=None, mask=None, pool_prev=False):
+         bn=None, bn_eps=1e-5, act_post=None, res=None, highway_h=None, mask=None, pool_prev=False, w_tap_major=False):
     """C = epilogue(conv1d / linear).  a: (Bn, Tin, Cin) or (M, Cin) channels-last; w: torch Linear
-    (N, Cin) or Conv1d (N, Cin, KT) weight.  bn = (mean, var, weight, bias) tensors."""
+    (N, Cin) or Conv1d (N, Cin, KT) weight -- or, with w_tap_major, a conv weight already in the tap-major (N, KT, Cin) layout
+    (ops.dx_weight).  bn = (mean, var, weight, bias) tensors."""
     lib = _lib.load()
     if a.dim() == 3:
         Bn_, Tin_, Cin = a.shape
@@ -232,8 +301,10 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=
         Bn_, Tin_, Cin = 1, a.shape[0], a.shape[1]
     Bn = Bn or Bn_
     Tin = Tin or Tin_
-    KT = w.shape[2] if w.dim() == 3 else 1
+    KT = (w.shape[1] if w_tap_major else w.shape[2]) if w.dim() == 3 else 1
     N = w.shape[0]
+    if w_tap_major:
+        assert w.dim() == 3 and w.shape[2] == Cin and w.is_contiguous() and KT > 1 and Cin % 4 == 0
     if Tout is None:
         Tout = (Tin + 2 * pad - KT) // stride + 1
     lda = a.stride(-2)
@@ -254,7 +325,9 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=
     ep.ldhw = int(highway_h.stride(-2)) if highway_h is not None else 0
     ep.mask = _p(mask)
     ep.ldmask = int(mask.stride(-2)) if mask is not None else 0
-    if KT > 1 and Cin % 4 == 0 and Cin >= 16:
+    if w_tap_major:
+        ep.w_tap_major = 1
+    elif KT > 1 and Cin % 4 == 0 and Cin >= 16:
         w = _tap_major(w)
         ep.w_tap_major = 1
     slabs = int(lib.st_gemm_splitk_slabs(int(Bn), int(Tout), int(Cin), int(N), int(KT)))

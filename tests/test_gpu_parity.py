@@ -1054,3 +1054,34 @@ def test_asr_postnet_against_reference_golden(dev):
     report('asr_postnet_golden', err=err)
     assert y.shape == A['y'].shape and err < 2e-5
     assert float((y.exp().sum(-1) - 1).abs().max()) < 1e-5
+
+
+def test_parameter_layouts_refresh_in_one_launch(dev):
+    """ops._ParamLayouts: tap-major (forward) and tap-reversed transposed (input-gradient) forms of conv / linear weights are cached
+    per weight version and equal torch's permute / flip copies; a version bump of ANY registered weight refreshes all of them."""
+    from semi_tts_amd import ops
+    ws = [rnd(24, 16, 5, seed=1).to(dev), rnd(128, 80, 3, seed=2).to(dev), rnd(40, 36, seed=3).to(dev), rnd(16, 20, 7, seed=4).to(dev)]
+    def check():
+        for w in ws:
+            if w.dim() == 3:
+                assert torch.equal(ops._tap_major(w), w.permute(0, 2, 1).contiguous())
+            wt, tm = ops.dx_weight(w)
+            if w.dim() == 2:
+                assert not tm and torch.equal(wt, w.t().contiguous())
+            elif tm:
+                assert torch.equal(wt, w.permute(1, 0, 2).flip(2).permute(0, 2, 1).contiguous())
+            else:
+                assert torch.equal(wt, w.permute(1, 0, 2).flip(2).contiguous())
+    check()
+    n0 = ops._LAYOUTS.refreshes
+    check()
+    assert ops._LAYOUTS.refreshes == n0                       # nothing stale: no launch
+    for w in ws:
+        w.mul_(1.5)                                           # (in-place update = what the optimiser does)
+    check()
+    assert ops._LAYOUTS.refreshes == n0 + 1                   # one refresh served every entry
+    # the conv through the cached layouts == torch's conv, forward and input gradient
+    x = rnd(3, 11, 80, seed=9).to(dev)
+    y = ops.gemm(x, ws[1], pad=1)
+    ref = torch.nn.functional.conv1d(x.cpu().double().transpose(1, 2), ws[1].cpu().double(), padding=1).transpose(1, 2)
+    assert maxdiff(y, ref) < 1e-4

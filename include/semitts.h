@@ -304,6 +304,17 @@ int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int 
                 int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int stride, int pool_prev,
                 const st_gemm_epilogue* ep, void* stream);
 
+/* Several independent st_gemm_fwd jobs in one launch: the K convolutions of the CBHG conv bank read the same input
+ * (`[conv1d(x)[:, :, :T] for conv1d in self.conv1d_banks]`, src/module.py:590-598).  Each job holds the arguments of st_gemm_fwd
+ * (the epilogue by value).  Jobs the pipelined kernel takes without pooling or split-K share launches (8 jobs each, longest
+ * reduction first); otherwise the jobs run one after the other -- the results are those of n st_gemm_fwd calls either way. */
+typedef struct st_gemm_job {
+    const float* A; int lda; const float* W; float* C; int ldc; int coff;
+    int Bn, Tin, Tout, Cin, N, KT, pad, stride, pool_prev;
+    st_gemm_epilogue ep;
+} st_gemm_job;
+int st_gemm_fwd_batch(const st_gemm_job* jobs, int n, void* stream);
+
 /* per-column statistics over M rows (training-mode BatchNorm): mean, biased variance, and
  * the running-stat update  run = (1-mom) run + mom * {mean, unbiased var}; batches_tracked (optional, one int64 on the device:
  * nn.BatchNorm1d.num_batches_tracked) is incremented by the same launch.

@@ -31,6 +31,12 @@ class StGemmEpilogue(C.Structure):
                 ('splitk_ws', C.c_void_p), ('splitk_slabs', C.c_int)]
 
 
+class StGemmJob(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_int), ('W', C.c_void_p), ('C', C.c_void_p), ('ldc', C.c_int), ('coff', C.c_int),
+                ('Bn', C.c_int), ('Tin', C.c_int), ('Tout', C.c_int), ('Cin', C.c_int), ('N', C.c_int), ('KT', C.c_int),
+                ('pad', C.c_int), ('stride', C.c_int), ('pool_prev', C.c_int), ('ep', StGemmEpilogue)]
+
+
 class StRelayoutDesc(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('N', C.c_int), ('Cin', C.c_int), ('KT', C.c_int), ('mode', C.c_int),
                 ('blk0', C.c_int), ('pad_', C.c_int)]
@@ -128,6 +134,7 @@ SIGNATURES = {
     'st_skinny_linear_fwd': [C.POINTER(StSeg), I, P, I, P, I, P, I, I, P, I, I, I, I, P],
     'st_attn_step_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, P, I, P, I, P, P, P, I, I, I, I, I, I, I, P],
     'st_gemm_fwd': [P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, C.POINTER(StGemmEpilogue), P],
+    'st_gemm_fwd_batch': [C.POINTER(StGemmJob), I, P],
     'st_gemm_splitk_slabs': [I, I, I, I, I],
     'st_bn_stats': [P, I, I, I, I, P, P, P, P, F, P, P, P],
     'st_colreduce_workspace_floats': [I, I],

@@ -21,9 +21,11 @@
 namespace {
 
 constexpr int AB_THREADS = 512;
-constexpr int AB_LBLK = 16;     // positions per block of the energy-gradient phase
+// positions per block of the energy-gradient phase: 48 (three MFMA row tiles per pass: the usual utterance of <= 48 positions is ONE
+// block -- three barriers instead of nine, 24 independent positions per thread in the tanh phase) when the forward kept S and the
+// block fits the LDS, else 16
+constexpr int AB_LBLK_MAX = 48;
 constexpr int AB_FMAX = 32;     // location filters held in registers per thread
-constexpr int AB_LPT = AB_LBLK / 2;   // positions per thread and block (at least two threads share an attention dim)
 
 struct AbArgs {
     const float* pq; const float* pm; const float* memory;
@@ -56,14 +58,14 @@ __device__ __forceinline__ float ab_tanh(float x) {
 
 struct AbLds { int hist, hl, wct, f4, wl, wlt, ld, loc, dloc, w, dw, dctx, dsb, part, red, total; };
 
-__host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K) {
+__host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K, int lblk, bool has_s) {
     AbLds o;
     int p = 0;
     o.f4 = (F + 3) & ~3;                  // rows of loc / dloc / W_l / transposed W_c padded to float4
     o.hl = (L + K + 4 + 3) & ~3;          // zero-padded history per channel
     o.hist = p; p += 2 * o.hl;
     o.wct = p; p += 2 * K * o.f4;         // W_c transposed to [c][k][f]
-    o.wl = p; p += A * o.f4;              // W_l [a][f]
+    o.wl = p; p += has_s ? 0 : A * o.f4;  // W_l [a][f] (only to recompute S)
     o.ld = ((A + 63) & ~63) + 4;          // row stride of the two MFMA operands: a padded to 64, +4 floats against bank conflicts
     o.wlt = p; p += 32 * o.ld;            // W_l^T [f][a] (rows f >= F and columns a >= A are zero)
     o.loc = p; p += L * AB_FMAX;          // rows padded to AB_FMAX zeros: the energy phase reads them unconditionally
@@ -71,8 +73,8 @@ __host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K) {
     o.w = p; p += (L + 3) & ~3;
     o.dw = p; p += (L + 3) & ~3;
     o.dctx = p; p += (E + 3) & ~3;
-    o.dsb = p; p += (AB_LBLK * o.ld > 2 * AB_THREADS ? AB_LBLK * o.ld : 2 * AB_THREADS);   // ds block [l][a]; also the fold buffer of P4
-    o.part = p; p += 4 * AB_LBLK * 32;    // partial dloc sums [a quarter][l][f lane]
+    o.dsb = p; p += (lblk * o.ld > 2 * AB_THREADS ? lblk * o.ld : 2 * AB_THREADS);   // ds block [l][a]; also the fold buffer of P4
+    o.part = p; p += 4 * lblk * 32;       // partial dloc sums [a quarter][l][f lane]
     o.red = p; p += 16;
     o.total = p;
     return o;
@@ -80,13 +82,15 @@ __host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K) {
 
 // HAS_S: S = pm + W_l loc of the step comes from the forward pass (training keeps it: 1.4 MB per step against 288 GB) -- no
 // location conv (P1) and no 32-filter product per (position, dim) in the energy gradient (P3)
-template <bool HAS_S>
+template <bool HAS_S, int LBLK>
 __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
+    constexpr int AB_LBLK = LBLK, AB_LPT = LBLK / 2;   // positions per thread and block (at least two threads share an attention dim)
+    constexpr int MTL = LBLK / 16;                      // MFMA row tiles per block
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
-    const AbLds o = ab_layout(L, A, E, F, K);
+    const AbLds o = ab_layout(L, A, E, F, K, LBLK, HAS_S);
     float* hist = lds + o.hist; float* WcT = lds + o.wct; float* Wl = lds + o.wl; float* WlT = lds + o.wlt; float* loc = lds + o.loc;
     float* dloc = lds + o.dloc; float* ws = lds + o.w; float* dws = lds + o.dw; float* dctx = lds + o.dctx;
     float* dsb = lds + o.dsb; float* part = lds + o.part; float* red = lds + o.red;
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     const float* pl_dummy = a.w + (size_t)b * a.ld_w + pl_l;
     const float* pe_dummy = a.memory + (size_t)b * L * E + pl_e;
     const float pl_w = pl_dummy[0];
+    const float pq_a = a.pq[(size_t)b * A + a0], v_a = a.v[a0];      // (consumed in P3: requested here, not behind the softmax)
     float pl_dl[3], pe_dl[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) pl_dl[j] = (a.dw_direct[j] ? a.dw_direct[j] + (size_t)b * a.ld_dw[j] + pl_l : pl_dummy)[0];
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     const bool ragged = F != AB_FMAX;
     if (ragged) {
         for (int i = tid; i < 2 * K * F4; i += AB_THREADS) WcT[i] = 0.0f;
-        for (int i = tid; i < A * F4; i += AB_THREADS) Wl[i] = 0.0f;
+        if (!HAS_S) for (int i = tid; i < A * F4; i += AB_THREADS) Wl[i] = 0.0f;      // (with S given W_l [a][f] has no LDS copy)
         for (int i = tid; i < 32 * LD; i += AB_THREADS) WlT[i] = 0.0f;
         for (int i = tid; i < AB_LBLK * LD; i += AB_THREADS) dsb[i] = 0.0f;
         for (int i = tid; i < L * AB_FMAX; i += AB_THREADS) loc[i] = 0.0f;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = tid + j * AB_THREADS;
-            if (i < nWl) { const int aa = i / F, f = i - aa * F; Wl[aa * F4 + f] = wl_v[j]; WlT[f * LD + aa] = wl_v[j]; }
+            if (i < nWl) { const int aa = i / F, f = i - aa * F; if (!HAS_S) Wl[aa * F4 + f] = wl_v[j]; WlT[f * LD + aa] = wl_v[j]; }
         }
     }
     for (int i = tid + 4 * AB_THREADS; i < nWc; i += AB_THREADS) {      // sizes beyond the register rounds
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     for (int i = tid + 16 * AB_THREADS; i < nWl; i += AB_THREADS) {
         const int aa = i / F, f = i - aa * F;
         const float wv = a.loc_lin_w[i];
-        Wl[aa * F4 + f] = wv; WlT[f * LD + aa] = wv;
+        if (!HAS_S) Wl[aa * F4 + f] = wv;
+        WlT[f * LD + aa] = wv;
     }
     AB_PROF(11);
     // absent addends are read from a valid dummy address and dropped by a select afterwards: a chain of
@@ -349,10 +355,10 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
 
     AB_PROF(4);
     // ---- P3: energy gradient in blocks of AB_LBLK positions
-    const float pq_a = a.pq[(size_t)b * A + a0], v_a = a.v[a0];
     float* __restrict__ dsg = a.ds_t + (size_t)b * L * A;
     float* __restrict__ dlocg = a.dloc_t + (size_t)b * L * F;
-    float dv_acc = 0.0f, dpq_acc = 0.0f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 dv2 = {0.f, 0.f}, dpq2 = {0.f, 0.f};          // sums over this thread's even / odd positions
     const int fl = tid & 31;
 
     for (int l0 = 0; l0 < L; l0 += AB_LBLK) {
@@ -364,63 +370,91 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
             const int l = l0 + AB_LBLK + grp + i * ngrp;
             pmn[i] = (i * ngrp + grp < AB_LBLK && l < L) ? pmb[(size_t)l * A + a0] : 0.0f;
         }
-        // branch-free: rows past the block / past L are computed on a clamped position with de = 0; two positions
-        // per pass (16 independent 16-byte LDS reads in flight; more would spill registers)
+        // branch-free: rows past the block / past L are computed on a clamped position with de = 0.  Three passes over the thread's
+        // positions so that nothing serialises them: (1) all the energy gradients de[l] come out of LDS back to back (inside the loop each
+        // read sat behind the previous position's LDS store -- the compiler cannot tell the two arrays apart -- and its latency, the
+        // exp and the reciprocal formed one dependent chain per position: 350 cycles each); (2) all s = pq + S; (3) tanh and the outputs
+        float gv[AB_LPT], sv[AB_LPT];
 #pragma unroll
-        for (int i0 = 0; i0 < AB_LPT; i0 += 2) {
-            float sarr[2];
+        for (int i = 0; i < AB_LPT; ++i) {
+            const int row = i * ngrp + grp, l = l0 + row;
+            gv[i] = dws[min(l, L - 1)];
+            if (!(row < AB_LBLK && l < lend)) gv[i] = 0.0f;
+        }
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int l = min(l0 + grp + (i0 + ii) * ngrp, L - 1);
-                const float* lr = loc + l * AB_FMAX;
-                float s = pq_a + pmr[i0 + ii], s2 = 0.0f;
+        for (int i = 0; i < AB_LPT; ++i) {
+            const int l = min(l0 + grp + i * ngrp, L - 1);
+            const float* lr = loc + l * AB_FMAX;
+            float sa = pq_a + pmr[i], sb = 0.0f;
 #pragma unroll
-                for (int f = 0; f < (HAS_S ? 0 : AB_FMAX); f += 4) {          // pad columns are zero on both sides
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lr + f);
-                    s = fmaf(wl_r[f], l4[0], s); s2 = fmaf(wl_r[f + 1], l4[1], s2);
-                    s = fmaf(wl_r[f + 2], l4[2], s); s2 = fmaf(wl_r[f + 3], l4[3], s2);
-                }
-                sarr[ii] = s + s2;
+            for (int f = 0; f < (HAS_S ? 0 : AB_FMAX); f += 4) {          // pad columns are zero on both sides
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lr + f);
+                sa = fmaf(wl_r[f], l4[0], sa); sb = fmaf(wl_r[f + 1], l4[1], sb);
+                sa = fmaf(wl_r[f + 2], l4[2], sa); sb = fmaf(wl_r[f + 3], l4[3], sb);
             }
+            sv[i] = sa + sb;
+        }
+        // two positions per instruction where the arithmetic allows (packed fp32: v_pk_mul / v_pk_add / v_pk_fma); the exponential and
+        // the reciprocal stay one lane-value each.  This phase is bound by instruction issue on ONE compute unit (L x A elements).
+        static_assert(AB_LPT % 2 == 0, "positions per thread come in pairs");
+#pragma unroll
+        for (int i = 0; i < AB_LPT; i += 2) {
+            const f32x2 s2 = {sv[i], sv[i + 1]}, g2 = {gv[i], gv[i + 1]};
+            const f32x2 e2 = f32x2{fabsf(s2[0]), fabsf(s2[1])} * -2.885390081777927f;          // exp(-2|x|) = exp2(-2 log2(e) |x|)
+            const f32x2 t2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+            const f32x2 num = 1.0f - t2, den = 1.0f + t2;
+            f32x2 th2 = num * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+            th2 = f32x2{copysignf(th2[0], s2[0]), copysignf(th2[1], s2[1])};
+            dv2 = dv2 + g2 * th2;
+            const f32x2 ds2 = (g2 * v_a) * (1.0f - th2 * th2);
+            dpq2 = dpq2 + ds2;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
-                const int row = (i0 + ii) * ngrp + grp, l = l0 + row;
+                const int row = (i + ii) * ngrp + grp, l = l0 + row;
                 const bool in_blk = row < AB_LBLK, valid = in_blk && l < lend;
-                const float th = ab_tanh(sarr[ii]);
-                const float g = valid ? dws[min(l, L - 1)] : 0.0f;
-                dv_acc = fmaf(g, th, dv_acc);
-                const float ds = g * v_a * (1.0f - th * th);
-                dpq_acc += ds;
-                if (valid) dsg[(size_t)l * A + a0] = ds;
-                if (in_blk) dsb[row * LD + a0] = ds;            // zero for rows past L
+#ifndef AB_ABLATE_DSG      // (tools/mb only: phase timing without the tape stores)
+                if (valid) dsg[(size_t)l * A + a0] = ds2[ii];
+#endif
+                if (in_blk) dsb[row * LD + a0] = ds2[ii];            // zero for rows past L
             }
         }
 #pragma unroll
         for (int i = 0; i < AB_LPT; ++i) pmr[i] = pmn[i];
+        AB_PROF(12);
         st_lds_barrier();
+        AB_PROF(13);
         // dloc[l][f] = sum_a ds[l][a] * W_l[a][f] on the matrix cores: wave = (filter tile nt of 16, quarter kq of the
         // padded a range); exact-fp32 16x16x4 MFMAs, each lane's float4 along a feeds four of them (same k order
         // for both operands), 16 x 16 partial tiles to LDS, summed below
         {
             const int nt = wave & 1, kq = wave >> 1;
             const int APq = (LD - 4) >> 2;                      // a range of one quarter (multiple of 16)
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[MTL];
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (nt * 16 < F4) {
                 const float* ap = dsb + (lane & 15) * LD + kq * APq + 4 * (lane >> 4);
                 const float* bp = WlT + (nt * 16 + (lane & 15)) * LD + kq * APq + 4 * (lane >> 4);
                 for (int kc = 0; kc < APq; kc += 16) {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + kc);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + kc);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + kc);       // one W_l fragment feeds every row tile
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], b4[c], acc, 0, 0, 0);
+                    for (int mt = 0; mt < MTL; ++mt) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + mt * 16 * LD + kc);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], b4[c], acc[mt], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[(kq * AB_LBLK + 4 * (lane >> 4) + r) * 32 + nt * 16 + (lane & 15)] = acc[r];
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[(kq * AB_LBLK + mt * 16 + 4 * (lane >> 4) + r) * 32 + nt * 16 + (lane & 15)] = acc[mt][r];
         }
+        AB_PROF(14);
         st_lds_barrier();
-        {
-            const int ll = tid >> 5;                      // 16 positions x 32 filter lanes = 512 threads
+#pragma unroll
+        for (int rr = 0; rr < MTL; ++rr) {
+            const int ll = rr * 16 + (tid >> 5);          // 16 positions x 32 filter lanes = 512 threads per pass
             const float sum = part[(0 * AB_LBLK + ll) * 32 + fl] + part[(1 * AB_LBLK + ll) * 32 + fl] +
                               part[(2 * AB_LBLK + ll) * 32 + fl] + part[(3 * AB_LBLK + ll) * 32 + fl];
             if (l0 + ll < L && fl < F4) {
@@ -433,7 +467,7 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
     AB_PROF(5);
     // ---- P4: fold the per-thread sums of the ngrp threads sharing an attention dim (LDS, fixed order)
     float* fold = dsb;
-    fold[tid] = dv_acc; fold[AB_THREADS + tid] = dpq_acc;
+    fold[tid] = dv2[0] + dv2[1]; fold[AB_THREADS + tid] = dpq2[0] + dpq2[1];
     st_lds_barrier();
     if (grp == 0) {
         float sv = 0.0f, sp = 0.0f;
@@ -527,16 +561,20 @@ static int ab_step_impl(const st_t16_view* dpq_t16, const float* pq, const float
     a.s_in = s_in;
     if (dpq_t16 && dpq_t16->base) { a.dpq_t16 = dpq_t16->base; a.dpq_kbs = dpq_t16->kb_stride; a.dpq_kb0 = dpq_t16->kb0; }
     a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
-    const size_t lds = (size_t)ab_layout(L, A, E, F, K).total * sizeof(float);
+    // the wide block when the forward kept S and its LDS image fits; two workgroups of it never share a compute unit anyway (B workgroups)
+    const bool wide = s_in && (size_t)ab_layout(L, A, E, F, K, AB_LBLK_MAX, true).total * sizeof(float) <= 160 * 1024;
+    const size_t lds = (size_t)ab_layout(L, A, E, F, K, wide ? AB_LBLK_MAX : 16, s_in != nullptr).total * sizeof(float);
     ST_CHECK_ARG(lds <= 160 * 1024, "st_attn_step_bwd: L=%d needs %zu bytes of LDS (> 160 KiB)", L, lds);
     static size_t lds_enabled = 0;
     if (lds > 64 * 1024 && lds > lds_enabled) {
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ab_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ab_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ab_kernel<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ab_kernel<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ab_kernel<true, AB_LBLK_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_enabled = lds;
     }
-    if (s_in) hipLaunchKernelGGL(ab_kernel<true>, dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(ab_kernel<false>, dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
+    if (wide) hipLaunchKernelGGL((ab_kernel<true, AB_LBLK_MAX>), dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
+    else if (s_in) hipLaunchKernelGGL((ab_kernel<true, 16>), dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((ab_kernel<false, 16>), dim3(B), dim3(AB_THREADS), lds, (hipStream_t)stream, a);
     ST_LAUNCH_CHECK();
     return 0;
 }

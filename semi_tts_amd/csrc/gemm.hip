@@ -50,14 +50,14 @@ __device__ __forceinline__ float gm_epilogue_one(const st_gemm_epilogue& ep, flo
     return v;
 }
 
-// epilogue of both GEMM kernels: D[row = 4*(lane>>4) + r][col = lane&15] of the wave's 2 x 2 sub-tiles
-template <int MT = 2>
-__device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[MT][2], int m0, int n0, int wm, int wn, int lane) {
+// epilogue of the GEMM kernels: D[row = 4*(lane>>4) + r][col = lane&15] of the wave's MT x NT sub-tiles whose first element is (mb, nb)
+template <int MT, int NT>
+__device__ __forceinline__ void gm_epilogue_tiles(const GmArgs& g, const f32x4 (&acc)[MT][NT], int mb, int nb, int lane) {
     const st_gemm_epilogue& ep = g.ep;
     float* ws = g.kb_per_split > 0 ? g.split_ws + (size_t)blockIdx.z * g.M * g.N : nullptr;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wn * 32 + nt * 16 + (lane & 15);
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nb + nt * 16 + (lane & 15);
         if (n >= g.N) continue;
         const float bias = ep.bias ? ep.bias[n] : 0.0f;
         float bn_m = 0.f, bn_s = 1.f, bn_w = 1.f, bn_b = 0.f;
@@ -71,13 +71,18 @@ __device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * (16 * MT) + mt * 16 + 4 * (lane >> 4) + r;
+                const int m = mb + mt * 16 + 4 * (lane >> 4) + r;
                 if (m >= g.M) continue;
                 if (ws) { ws[(size_t)m * g.N + n] = acc[mt][nt][r]; continue; }        // split-K: the raw partial product
                 g.C[(size_t)m * g.ldc + g.coff + n] = gm_epilogue_one(ep, acc[mt][nt][r], m, n, bias, bn_m, bn_s, bn_w, bn_b);
             }
         }
     }
+}
+
+template <int MT = 2>
+__device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[MT][2], int m0, int n0, int wm, int wn, int lane) {
+    gm_epilogue_tiles<MT, 2>(g, acc, m0 + wm * (16 * MT), n0 + wn * 32, lane);
 }
 
 // split-K finish: C = epilogue(sum_z slab_z), slabs added in a fixed order (deterministic); one thread per output element,
@@ -219,15 +224,15 @@ __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
 // give every compute unit two workgroups with 64-row tiles: one wave per SIMD cannot overlap its own address arithmetic, LDS
 // traffic and barrier with its MFMAs, a second workgroup on the SIMD can (measured: 258 workgroups of 64 x 64 ran at 0.29 of the
 // fp32 matrix peak however the barriers were arranged).
-template <bool VECW, bool POOL, int MT = 2>
-__global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
+template <bool VECW, bool POOL, int MT>
+__device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict__ As_, float* __restrict__ Bs_) {
     constexpr int BM = 32 * MT;
     // two LDS buffers of TWO 16-float k-blocks each: pair kp+1 is written while pair kp is multiplied -- one barrier per 32
     // MFMAs per wave.  (r02: with one k-block per barrier an iteration took ~1350 cycles for 512 cycles of MFMAs -- one wave per
     // SIMD cannot hide the LDS-write -> barrier -> LDS-read chain; the pair halves the barriers per MFMA.  A k-block stays the
     // addressing unit, so a pair may straddle two conv taps.)
-    __shared__ __attribute__((aligned(16))) float As[2][2][BM * GM_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][2][GM_BN * GM_LD];
+    float (*As)[2][BM * GM_LD] = reinterpret_cast<float (*)[2][BM * GM_LD]>(As_);
+    float (*Bs)[2][GM_BN * GM_LD] = reinterpret_cast<float (*)[2][GM_BN * GM_LD]>(Bs_);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * GM_BN;
@@ -323,6 +328,28 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
         st_lds_barrier();
     }
     gm_epilogue<MT>(g, acc, m0, n0, wm, wn, lane);
+}
+
+template <bool VECW, bool POOL, int MT = 2>
+__global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[4 * (32 * MT) * GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[4 * GM_BN * GM_LD];
+    gm_pipe_body<VECW, POOL, MT>(g, As, Bs);
+}
+
+// several jobs in one launch (blockIdx.z = job, longest reductions first): the conv bank's K convs over the same input.  A launch
+// of its own gives each of them ~one workgroup per compute unit -- one wave per SIMD, nothing to overlap its LDS traffic and barriers
+// with; together the K convs keep several workgroups resident per compute unit.
+constexpr int GM_MAX_BATCH = 8;      // (kernel arguments: 8 jobs stay well under the 4 KB limit)
+struct GmBatch { GmArgs g[GM_MAX_BATCH]; };
+
+template <bool VECW, int MT>
+__global__ __launch_bounds__(GM_THREADS) void gm_pipe_batch_kernel(const GmBatch b) {
+    __shared__ __attribute__((aligned(16))) float As[4 * (32 * MT) * GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[4 * GM_BN * GM_LD];
+    const GmArgs& g = b.g[blockIdx.z];
+    if ((int)blockIdx.x * (32 * MT) >= g.M || (int)blockIdx.y * GM_BN >= g.N) return;      // (uniform: the whole workgroup leaves)
+    gm_pipe_body<VECW, false, MT>(g, As, Bs);
 }
 
 // ---- training-mode BatchNorm helpers ---------------------------------------------------
@@ -458,16 +485,15 @@ extern "C" int st_gemm_splitk_slabs(int Bn, int Tout, int Cin, int N, int KT) {
     return S < 2 ? 1 : S;
 }
 
-extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
-                           int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int stride, int pool_prev,
-                           const st_gemm_epilogue* ep, void* stream) {
-    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
+// argument checks of one GEMM job and its kernel arguments; veca / vecw = 16-byte addressable activations / weights
+static int gm_prepare(const float* A, int lda, const float* W, float* C, int ldc, int coff,
+                      int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int stride, int pool_prev,
+                      const st_gemm_epilogue* ep, GmArgs& g, bool& veca, bool& vecw) {
     ST_CHECK_ARG(A && W && C, "st_gemm_fwd: null pointer");
     ST_CHECK_ARG(Bn > 0 && Tin > 0 && Tout > 0 && Cin > 0 && N > 0 && KT > 0 && pad >= 0 && stride >= 1, "st_gemm_fwd: bad dims");
     ST_CHECK_ARG(lda >= Cin && ldc >= coff + N, "st_gemm_fwd: lda=%d < Cin=%d or ldc=%d < coff+N=%d", lda, Cin, ldc, coff + N);
     // rows of A outside [0, Tin) read as zero, so Tout may exceed the natural conv length (used by the
     // input-gradient pass, where the forward output was trimmed)
-    GmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.W = W; g.C = C; g.ldc = ldc; g.coff = coff;
     g.Bn = Bn; g.Tin = Tin; g.Tout = Tout; g.Cin = Cin; g.N = N; g.KT = KT; g.pad = pad; g.pool_prev = pool_prev; g.stride = stride;
@@ -478,10 +504,67 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
         ST_CHECK_ARG(!ep->highway_h || ep->res, "st_gemm_fwd: highway epilogue needs res (the layer input)");
         ST_CHECK_ARG(!ep->bn_mean || ep->bn_var, "st_gemm_fwd: bn_mean without bn_var");
     }
-    const bool veca = st_aligned16(A) && (lda % 4 == 0) && (Cin % 4 == 0);
+    veca = st_aligned16(A) && (lda % 4 == 0) && (Cin % 4 == 0);
     const bool tap_major = ep && ep->w_tap_major && KT > 1;
     ST_CHECK_ARG(!tap_major || (st_aligned16(W) && Cin % 4 == 0), "st_gemm_fwd: tap-major weights need Cin %% 4 == 0 and 16-byte alignment");
-    const bool vecw = (KT == 1 || tap_major) && st_aligned16(W) && (Cin % 4 == 0);
+    vecw = (KT == 1 || tap_major) && st_aligned16(W) && (Cin % 4 == 0);
+    return 0;
+}
+
+// Several independent GEMM / conv jobs in ONE launch (the CBHG conv bank: K convolutions of the same input, src/module.py:590-598).
+// Jobs the pipelined kernel can take without pooling or split-K go out in launches of up to GM_MAX_BATCH jobs, longest reduction
+// first; a batch with any other job runs as separate st_gemm_fwd launches.
+extern "C" int st_gemm_fwd_batch(const st_gemm_job* jobs, int n, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(jobs && n > 0 && n <= 64, "st_gemm_fwd_batch: bad arguments");
+    GmArgs g[64];
+    bool all_ok = true;
+    for (int j = 0; j < n; ++j) {
+        const st_gemm_job& q = jobs[j];
+        bool veca, vecw;
+        const int rc = gm_prepare(q.A, q.lda, q.W, q.C, q.ldc, q.coff, q.Bn, q.Tin, q.Tout, q.Cin, q.N, q.KT, q.pad, q.stride, q.pool_prev,
+                                  &q.ep, g[j], veca, vecw);
+        if (rc) return rc;
+        all_ok = all_ok && veca && vecw && !q.pool_prev && !(q.ep.splitk_ws && q.ep.splitk_slabs > 1);
+    }
+    if (!all_ok || n == 1) {
+        for (int j = 0; j < n; ++j) {
+            const st_gemm_job& q = jobs[j];
+            const int rc = st_gemm_fwd(q.A, q.lda, q.W, q.C, q.ldc, q.coff, q.Bn, q.Tin, q.Tout, q.Cin, q.N, q.KT, q.pad, q.stride, q.pool_prev,
+                                       &q.ep, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    int order[64];
+    for (int j = 0; j < n; ++j) order[j] = j;
+    for (int i = 1; i < n; ++i)        // longest reductions first (insertion sort, stable)
+        for (int j = i; j > 0 && g[order[j]].KT * g[order[j]].cpb > g[order[j - 1]].KT * g[order[j - 1]].cpb; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    for (int c0 = 0; c0 < n; c0 += GM_MAX_BATCH) {
+        const int cnt = n - c0 < GM_MAX_BATCH ? n - c0 : GM_MAX_BATCH;
+        GmBatch b;
+        memset(&b, 0, sizeof(b));
+        int maxM = 0, maxN = 0;
+        for (int j = 0; j < cnt; ++j) {
+            b.g[j] = g[order[c0 + j]];
+            maxM = b.g[j].M > maxM ? b.g[j].M : maxM;
+            maxN = b.g[j].N > maxN ? b.g[j].N : maxN;
+        }
+        const int nby = (maxN + GM_BN - 1) / GM_BN;
+        // 64-row tiles: a batch has workgroups to spare
+        hipLaunchKernelGGL((gm_pipe_batch_kernel<true, 2>), dim3((maxM + 63) / 64, nby, cnt), dim3(GM_THREADS), 0, (hipStream_t)stream, b);
+        ST_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, int ldc, int coff,
+                           int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int stride, int pool_prev,
+                           const st_gemm_epilogue* ep, void* stream) {
+    (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
+    GmArgs g;
+    bool veca, vecw;
+    { const int rc = gm_prepare(A, lda, W, C, ldc, coff, Bn, Tin, Tout, Cin, N, KT, pad, stride, pool_prev, ep, g, veca, vecw); if (rc) return rc; }
     dim3 grid((g.M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN);
     hipStream_t st = (hipStream_t)stream;
     // split-K: the caller passes slabs = st_gemm_splitk_slabs(...) and a workspace of slabs * M * N floats in the epilogue struct

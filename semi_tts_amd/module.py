@@ -113,7 +113,7 @@ class Linear(nn.Module):
 
 # ----------------------------------------------------------------------------- batch norm helper
 def _conv_bn_act(x, weight, bias, bn, pad, eps, momentum, order, training, Tout=None, out=None, coff=0,
-                 pool_prev=False, stats_Tout=None):
+                 pool_prev=False, stats_Tout=None, collect=None):
     """conv1d followed by {BN, act} in the order the reference applies them.
     order 'bn_relu' (encoder, module.py:429-430), 'relu_bn' (BatchNormConv1d with activation,
     :535-537), 'bn' (no activation), 'bn_tanh' (Postnet class).  Eval mode folds everything into
@@ -123,7 +123,8 @@ def _conv_bn_act(x, weight, bias, bn, pad, eps, momentum, order, training, Tout=
     if not training:
         return ops.gemm(x, weight, out, pad=pad, Tout=Tout, coff=coff, bias=bias, act_pre=pre,
                         bn=(bn.running_mean, bn.running_var, bn.weight, bn.bias), bn_eps=eps, act_post=post,
-                        pool_prev=pool_prev)
+                        pool_prev=pool_prev, collect=collect)
+    assert collect is None, 'batched launches: inference only'
     # training: differentiable conv -> BatchNorm with batch statistics.  For the even-k bank convs the
     # statistics run over stats_Tout = T+1 positions and the extra one is trimmed afterwards (module.py:597-598)
     assert out is None, 'the training path returns new tensors (autograd owns them)'
@@ -173,8 +174,10 @@ class Encoder(nn.Module):
                 x = AG.bilstm(xp_f, xp_b, g('weight_hh'), g('bias_hh'), g('weight_hh', True), g('bias_hh', True))
                 continue
             out = torch.empty(B, L, 2 * H, device=x.device, dtype=torch.float32)
-            xp_f = ops.gemm(x, g('weight_ih'), bias=g('bias_ih'))                        # (B, L, 4H), all time steps at once
-            xp_b = ops.gemm(x, g('weight_ih', True), bias=g('bias_ih', True))
+            jobs = []
+            xp_f = ops.gemm(x, g('weight_ih'), bias=g('bias_ih'), collect=jobs)          # (B, L, 4H), all time steps at once;
+            xp_b = ops.gemm(x, g('weight_ih', True), bias=g('bias_ih', True), collect=jobs)      # both directions in one launch
+            ops.gemm_flush(jobs)
             # the two directions advance together: one launch per time step for both
             ops.lstm_seq2(xp_f, xp_b, g('weight_hh'), g('weight_hh', True), g('bias_hh'), g('bias_hh', True), out)
             x = out
@@ -638,11 +641,11 @@ class BatchNormConv1d(nn.Module):
         self.activation = activation
         self.padding = padding
 
-    def forward(self, x_cl, training=None, Tout=None, out=None, coff=0, pool_prev=False, stats_Tout=None):
+    def forward(self, x_cl, training=None, Tout=None, out=None, coff=0, pool_prev=False, stats_Tout=None, collect=None):
         order = 'relu_bn' if self.activation is not None else 'bn'
         return _conv_bn_act(x_cl, self.conv1d.weight, None, self.bn, self.padding, self.bn.eps, self.bn.momentum,
                             order, self.training if training is None else training, Tout, out, coff, pool_prev,
-                            stats_Tout)
+                            stats_Tout, collect)
 
 
 class Highway(nn.Module):
@@ -692,11 +695,13 @@ class CBHG(nn.Module):
         if self.training:
             return self._forward_train(x)
         bank = torch.empty(B, T, K * Cn, device=x.device, dtype=torch.float32)
+        jobs = []        # the K convs read the same input: one launch for all of them where the kernels allow (ops.gemm_flush)
         for i, blk in enumerate(self.conv1d_banks):
             k = i + 1
             # even k yields T+1 positions and, in training mode, BatchNorm sees all of them before
             # the trim to T (module.py:597-598): stats_Tout tells the helper to include the extra one
-            blk(x, Tout=T, out=bank, coff=i * Cn, stats_Tout=T + 1 if k % 2 == 0 else T)
+            blk(x, Tout=T, out=bank, coff=i * Cn, stats_Tout=T + 1 if k % 2 == 0 else T, collect=jobs)
+        ops.gemm_flush(jobs)
         y = self.conv1d_projs[0](bank, pool_prev=True)       # MaxPool1d(2,1,1)[:T] fused into the load
         for blk in self.conv1d_projs[1:]:
             y = blk(y)
@@ -704,8 +709,10 @@ class CBHG(nn.Module):
         for hw in self.highways:
             y = hw(y)
         H = self.gru.hidden_size
-        gi_f = ops.gemm(y, self.gru.weight_ih_l0, bias=self.gru.bias_ih_l0)
-        gi_b = ops.gemm(y, self.gru.weight_ih_l0_reverse, bias=self.gru.bias_ih_l0_reverse)
+        jobs = []        # the two directions' input projections: one launch
+        gi_f = ops.gemm(y, self.gru.weight_ih_l0, bias=self.gru.bias_ih_l0, collect=jobs)
+        gi_b = ops.gemm(y, self.gru.weight_ih_l0_reverse, bias=self.gru.bias_ih_l0_reverse, collect=jobs)
+        ops.gemm_flush(jobs)
         out = torch.empty(B, T, 2 * H, device=x.device, dtype=torch.float32)
         ops.gru_seq(gi_f, gi_b, self.gru.weight_hh_l0, self.gru.weight_hh_l0_reverse,
                     self.gru.bias_hh_l0, self.gru.bias_hh_l0_reverse, out)

@@ -290,10 +290,12 @@ def dx_weight(w):
 
 
 def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=0, bias=None, act_pre=None,
-         bn=None, bn_eps=1e-5, act_post=None, res=None, highway_h=None, mask=None, pool_prev=False, w_tap_major=False):
+         bn=None, bn_eps=1e-5, act_post=None, res=None, highway_h=None, mask=None, pool_prev=False, w_tap_major=False,
+         collect=None):
     """C = epilogue(conv1d / linear).  a: (Bn, Tin, Cin) or (M, Cin) channels-last; w: torch Linear
     (N, Cin) or Conv1d (N, Cin, KT) weight -- or, with w_tap_major, a conv weight already in the tap-major (N, KT, Cin) layout
-    (ops.dx_weight).  bn = (mean, var, weight, bias) tensors."""
+    (ops.dx_weight).  bn = (mean, var, weight, bias) tensors.  collect: a list -- the job is appended to it instead of being
+    launched (ops.gemm_flush(list) then runs all collected jobs, sharing launches where the kernels allow)."""
     lib = _lib.load()
     if a.dim() == 3:
         Bn_, Tin_, Cin = a.shape
@@ -331,13 +333,31 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=
         w = _tap_major(w)
         ep.w_tap_major = 1
     slabs = int(lib.st_gemm_splitk_slabs(int(Bn), int(Tout), int(Cin), int(N), int(KT)))
+    ws = None
     if slabs > 1:         # small grid, long reduction: partial products per k range + a finish pass (st_gemm_epilogue.splitk_ws)
         ws = torch.empty(slabs * Bn * Tout * N, device=a.device, dtype=torch.float32)
         ep.splitk_ws, ep.splitk_slabs = _p(ws), slabs
+    if collect is not None:
+        job = _lib.StGemmJob()
+        job.A, job.lda, job.W, job.C, job.ldc, job.coff = _p(a), int(lda), _p(w), _p(out), int(ldc), int(coff)
+        job.Bn, job.Tin, job.Tout, job.Cin, job.N, job.KT = int(Bn), int(Tin), int(Tout), int(Cin), int(N), int(KT)
+        job.pad, job.stride, job.pool_prev, job.ep = int(pad), int(stride), 1 if pool_prev else 0, ep
+        collect.append((job, (a, w, out, ws, bias, bn, res, highway_h, mask)))       # (the tensors stay alive until the flush)
+        return out
     check(lib.st_gemm_fwd(_p(a), int(lda), _p(w), _p(out), int(ldc), int(coff), int(Bn), int(Tin), int(Tout),
                           int(Cin), int(N), int(KT), int(pad), int(stride), 1 if pool_prev else 0, C.byref(ep), stream_handle()),
           'st_gemm_fwd')
     return out
+
+
+def gemm_flush(collected):
+    """run the jobs gathered by ops.gemm(..., collect=list) -- st_gemm_fwd_batch: one launch for up to eight jobs of the pipelined
+    kernel (the conv bank), separate launches otherwise"""
+    if not collected:
+        return
+    arr = (_lib.StGemmJob * len(collected))(*[j for j, _ in collected])
+    check(_lib.load().st_gemm_fwd_batch(arr, len(collected), stream_handle()), 'st_gemm_fwd_batch')
+    del collected[:]
 
 
 def _colreduce_ws(M, N, device):

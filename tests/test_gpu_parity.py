@@ -1085,3 +1085,34 @@ def test_parameter_layouts_refresh_in_one_launch(dev):
     y = ops.gemm(x, ws[1], pad=1)
     ref = torch.nn.functional.conv1d(x.cpu().double().transpose(1, 2), ws[1].cpu().double(), padding=1).transpose(1, 2)
     assert maxdiff(y, ref) < 1e-4
+
+
+def test_gemm_batch_equals_separate_launches(dev):
+    """ops.gemm(collect=...) + ops.gemm_flush: several conv / linear jobs of different tap counts and widths in one launch
+    (st_gemm_fwd_batch; the CBHG conv bank) write exactly what one st_gemm_fwd launch per job writes -- same k order per output
+    element -- including an odd number of jobs beyond one launch (9 > 8) and a batch that falls back to separate launches."""
+    from semi_tts_amd import ops
+    x = rnd(5, 37, 80, seed=1).to(dev)
+    ws = [rnd(80, 80, k, scale=(80 * k) ** -0.5, seed=10 + k).to(dev) for k in range(1, 10)]
+    bs = [rnd(80, seed=30 + k).to(dev) for k in range(1, 10)]
+    T = x.shape[1]
+    ref = torch.zeros(5, T, 80 * 9, device=dev)
+    got = torch.zeros_like(ref)
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        ops.gemm(x, w, ref, pad=(i + 1) // 2, Tout=T, coff=80 * i, bias=b, act_pre='relu')
+    jobs = []
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        ops.gemm(x, w, got, pad=(i + 1) // 2, Tout=T, coff=80 * i, bias=b, act_pre='relu', collect=jobs)
+    assert len(jobs) == 9 and float(got.abs().max()) == 0.0            # nothing ran yet
+    ops.gemm_flush(jobs)
+    assert jobs == [] and torch.equal(got, ref)
+    cpu = torch.relu(torch.nn.functional.conv1d(x.cpu().double().transpose(1, 2), ws[2].cpu().double(), bs[2].cpu().double(), padding=1))
+    assert maxdiff(got[:, :, 160:240], cpu.transpose(1, 2)) < 1e-4
+    # a job the batched kernel cannot take (Cin not a multiple of 4 -> generic kernel): the flush runs the jobs one by one
+    x2 = rnd(3, 20, 6, seed=2).to(dev)
+    w2a, w2b = rnd(8, 6, seed=3).to(dev), rnd(12, 6, seed=4).to(dev)
+    jobs = []
+    ya = ops.gemm(x2, w2a, collect=jobs)
+    yb = ops.gemm(x2, w2b, collect=jobs)
+    ops.gemm_flush(jobs)
+    assert torch.equal(ya, ops.gemm(x2, w2a)) and torch.equal(yb, ops.gemm(x2, w2b))

@@ -41,8 +41,8 @@ int main() {
     for (int blk : {0, 17}) {
         printf("block %d (cycles since wave 0 start):\n", blk);
         unsigned long long t0 = h[(blk * 8 + 0) * 16 + 0];
-        const char* sub[5] = {"  p0: loads issued", "  p0: hist done", "  p0: pads done", "  p0: scatter done", "  p0: per-l done"};
-        for (int n = 8; n < 13; ++n) {
+        const char* sub[7] = {"  p0: loads issued", "  p0: hist done", "  p0: pads done", "  p0: scatter done", "  p3: ds computed", "  p3: past barrier", "  p3: dloc MFMAs done"};
+        for (int n = 8; n < 15; ++n) {
             printf("  %-22s", sub[n - 8]);
             for (int wv = 0; wv < 8; ++wv) printf(" %8lld", (long long)(h[(blk * 8 + wv) * 16 + n] - t0));
             printf("\n");

@@ -466,6 +466,12 @@ extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int 
     const int colblocks = tn_fold(Cin, KT, 0) ? (Cin * KT + TM - 1) / TM : ((Cin + TM - 1) / TM) * KT;
     const int tiles = ((N + TM - 1) / TM) * colblocks;
     int Z = (512 + tiles - 1) / tiles;
+    // more tiles than compute units and a badly filled last round (640 tiles = 2.5 rounds of 256: the decoder LSTM's 4096 x 2560
+    // gradient): two slabs when they fill the rounds exactly -- the half-length products win more than the extra slab costs
+    if (Z == 1 && tiles > 256) {
+        const int r1 = (tiles + 255) / 256, r2 = (2 * tiles + 255) / 256;
+        if (tiles * 100 < r1 * 256 * 85 && 2 * tiles * 100 >= r2 * 256 * 98) Z = 2;
+    }
     const int maxz = (M + 255) / 256;
     if (Z > maxz) Z = maxz;
     if (Z > 96) Z = 96;          // the slabs are added by one thread per output element
@@ -493,9 +499,14 @@ extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* 
     const int TM = tn_tile(Cin, N, KT);
     dim3 grid((N + TM - 1) / TM, g.fold ? (Cin * KT + TM - 1) / TM : ((Cin + TM - 1) / TM) * KT, Z);
     hipStream_t st = (hipStream_t)stream;
+    // one slab and nothing to add to: the product goes straight to dW (the decoder LSTMs' weight gradients are 29 and 42 MB --
+    // the "sum" of one slab was a 17 us copy)
+    const bool direct = Z == 1 && !accumulate;
+    if (direct) g.part = dW;
     if (TM == 128) hipLaunchKernelGGL((tn_kernel<128>), grid, dim3(TN_THREADS), 0, st, g);
     else hipLaunchKernelGGL((tn_kernel<64>), grid, dim3(TN_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();
+    if (direct) return 0;
     hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(per)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
     ST_LAUNCH_CHECK();
     return 0;

@@ -40,3 +40,7 @@ done
 DB=$(find $OUT/prof_full -name "*.db" | head -1); python tools/prof_stats.py $DB --csv $OUT/full_forward_kernel_stats.csv | head -10; rm -rf $OUT/prof_full
 echo "== in-situ cost of each launch of the decode step (ablation build)"; bash tools/gpu_ablate.sh 2>&1 | grep "skip=" | tee $OUT/decode_step_ablation.txt
 ABL_ARGS="--workload c5" SKIPS="0 1 6 8 16 32 64" bash tools/gpu_ablate.sh 2>&1 | grep "skip=" | tee $OUT/decode_step_ablation_c5.txt
+echo "== one steady-state training step (launches and kernel time per step), GEMM shapes of the forward"
+bash tools/gpu_train_prof.sh $TAG > /dev/null 2>&1; cp gpurun_out/trainprof_$TAG/train_one_step_kernel_stats.csv $OUT/train_one_step_kernel_stats.csv; head -1 gpurun_out/trainprof_$TAG/train_one_step.txt | tee $OUT/train_one_step_summary.txt
+timeout 300 python tools/bench_gemm_shapes.py 2>/dev/null | tail -1 > $OUT/gemm_shapes.json; cut -c1-200 $OUT/gemm_shapes.json
+MB_S=1 timeout 60 tools/mb/mb_attn_bwd 2>&1 | head -18 > $OUT/attn_bwd_phase_stamps.txt; head -1 $OUT/attn_bwd_phase_stamps.txt

@@ -552,7 +552,7 @@ def bench_train(args, rk):
             'ms_variants': {k: round(v, 3) for k, v in ms.items()},
             'collectives_per_step': counts,
             # whole-step roofline: forward 132 GFLOP per C2 batch, training ~3x that, against the fp32 matrix peak
-            'roofline': {'bound': 'mfma', 'kernel': 'whole training step (1.6k launches; the largest share is the weight-gradient GEMM tn_kernel)',
+            'roofline': {'bound': 'mfma', 'kernel': 'whole training step (~1.25k launches; the largest shares are the weight-gradient GEMM tn_kernel and the per-step products of the BPTT loop)',
                          'achieved': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None},
             'last': {k: last[k] for k in ('loss', 'grad_norm')}, 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

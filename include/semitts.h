@@ -687,6 +687,9 @@ typedef struct st_decoder_bwd_io {
     const float* attn_s_tape;         /* optional (steps, B, L, A): S_t = pm + W_l loc_t saved by the forward (slot 0 unused: S_0 =
                                        * pm).  Then loc_tape is an INPUT (the forward's attn_loc_tape) and the attention backward
                                        * neither recomputes the location conv nor the W_l product. */
+    int overlap_attn;                 /* != 0 (with fuse_pw and attn_s_tape): the decoder cell's product of step t-1 and the attention backward
+                                       * of step t share one launch -- the decoder cell's recurrence runs one step ahead of the attention /
+                                       * query chain (3 launches per step on the critical path instead of 4) */
 } st_decoder_bwd_io;
 /* st_attn_step_bwd with S = pm + W_l loc of the step given (s_in, (B,L,A)): loc_t is not written (may be NULL) */
 int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
@@ -708,6 +711,23 @@ int st_attn_step_bwd_t16(const float* pq, const float* pm, const float* memory,
                          float* dpq, const st_t16_view* dpq_t16, float* dhist, float* ds_t, float* loc_t, float* dloc_t, float* hist_t,
                          float* dctx_t, float* dv_t, const float* s_in,
                          int B, int L, int A, int E, int F, int K, void* stream);
+/* The arguments of st_attn_step_bwd_t16 as a struct, for the launch that hosts the attention backward of BPTT step t beside the
+ * decoder cell's backward product of step t-1 (the decoder cell's recurrence does not depend on the attention / query chain of the
+ * same step; backward of src/module.py:247-283): st_skinny_linear_packed_lstm_bwd_fwd + st_attn_step_bwd_t16 in ONE launch. */
+typedef struct st_attn_bwd_job {
+    const float* pq; const float* pm; const float* memory;
+    const float* w_prev; int ld_wprev; const float* w_cum_prev; const float* w; int ld_w;
+    const float* loc_conv_w; const float* loc_lin_w; const float* v;
+    const float* dctx[3]; int ld_dctx[3]; int n_dctx;
+    const float* dw_direct[3]; int ld_dw[3]; int n_dw;
+    float* dcum; const float* dcum_add; int ld_dcum_add;
+    float* dpq; st_t16_view dpq_t16; float* dhist; float* ds_t; float* loc_t; float* dloc_t; float* hist_t;
+    float* dctx_t; float* dv_t; const float* s_in;
+    int B, L, A, E, F, K;
+} st_attn_bwd_job;
+/* job may be NULL (the plain product); ab->s_in must be given (the forward kept S) */
+int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                              const st_lstm_pw_job* job, const st_attn_bwd_job* ab, void* stream);
 int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
 /* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp, r*n_mels+1); NULL = zeros */
 int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int B, int Bp, int steps, int r, int n_mels,

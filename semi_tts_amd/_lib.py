@@ -88,7 +88,8 @@ class StDecoderBwdIO(C.Structure):
                  ('dgd_t16', C.c_void_p), ('step_src', C.POINTER(C.c_int)), ('Bt', C.c_int)] +
                 [(n, C.c_void_p) for n in ('dY', 'dxo_rw', 'wpg_t', 'pre_w1_t', 'pre_w0_t', 'own_mask', 'xq_nat', 'pre1_nat',
                                            'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in')] +
-                [('fuse_pw', C.c_int), ('dgd_t16_b', C.c_void_p), ('dpq_t16', C.c_void_p), ('need_dxq0', C.c_int), ('attn_s_tape', C.c_void_p)])
+                [('fuse_pw', C.c_int), ('dgd_t16_b', C.c_void_p), ('dpq_t16', C.c_void_p), ('need_dxq0', C.c_int), ('attn_s_tape', C.c_void_p),
+                 ('overlap_attn', C.c_int)])
 
 
 
@@ -97,6 +98,18 @@ class StLstmPwJob(C.Structure):
                 ('scale2', C.c_void_p), ('mask', C.c_void_p), ('gates', C.c_void_p), ('c', C.c_void_p), ('ldc', C.c_int),
                 ('c_prev', C.c_void_p), ('ldcp', C.c_int), ('dc', C.c_void_p), ('dgates', C.c_void_p), ('ldg', C.c_int),
                 ('dgates_t16', StT16View)]
+
+
+class StAttnBwdJob(C.Structure):
+    _fields_ = [('pq', C.c_void_p), ('pm', C.c_void_p), ('memory', C.c_void_p),
+                ('w_prev', C.c_void_p), ('ld_wprev', C.c_int), ('w_cum_prev', C.c_void_p), ('w', C.c_void_p), ('ld_w', C.c_int),
+                ('loc_conv_w', C.c_void_p), ('loc_lin_w', C.c_void_p), ('v', C.c_void_p),
+                ('dctx', C.c_void_p * 3), ('ld_dctx', C.c_int * 3), ('n_dctx', C.c_int),
+                ('dw_direct', C.c_void_p * 3), ('ld_dw', C.c_int * 3), ('n_dw', C.c_int),
+                ('dcum', C.c_void_p), ('dcum_add', C.c_void_p), ('ld_dcum_add', C.c_int),
+                ('dpq', C.c_void_p), ('dpq_t16', StT16View), ('dhist', C.c_void_p), ('ds_t', C.c_void_p), ('loc_t', C.c_void_p),
+                ('dloc_t', C.c_void_p), ('hist_t', C.c_void_p), ('dctx_t', C.c_void_p), ('dv_t', C.c_void_p), ('s_in', C.c_void_p),
+                ('B', C.c_int), ('L', C.c_int), ('A', C.c_int), ('E', C.c_int), ('F', C.c_int), ('K', C.c_int)]
 
 
 class StAttnPreJob(C.Structure):
@@ -197,6 +210,7 @@ SIGNATURES = {
     'st_attn_step_bwd_t16': [P, P, P, P, I, P, P, I, P, P, P, C.POINTER(P), C.POINTER(I), I, C.POINTER(P), C.POINTER(I), I,
                              P, P, I, P, C.POINTER(StT16View), P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     'st_skinny_linear_packed_lstm_bwd_fwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), P],
+    'st_skinny_linear_packed_lstm_bwd_attn_bwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), C.POINTER(StAttnBwdJob), P],
     'st_lstm_seq2_fwd': [C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, C.POINTER(I), P, C.POINTER(P), C.POINTER(P), I, I, I, P],
     'st_lstm_seq2_bwd': [P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, I, I, P],
     'st_skinny_linear_pair_fwd': [P, C.POINTER(P), I, I, I, P],

@@ -524,6 +524,7 @@ class _DecoderFn(Function):
             wt['pq_p16'] = ops.pack_weight([wt['pq']], [A], Q)
             bw.attn_query_w_t_p16 = ops._p(wt['pq_p16'])
             io.fuse_pw, io.dgd_t16_b, io.dpq_t16 = 1, ops._p(zb['dgd_t16_b']), ops._p(zb['dpq_t16'])
+            io.overlap_attn = 1 if dec.bwd_overlap_attn else 0
         src_arr = (C.c_int * max(steps, 1))(*src)
         io.step_src, io.Bt = C.cast(src_arr, C.POINTER(C.c_int)), Bt
         io.need_dxq0 = 1 if ctx.has_in0 else 0

@@ -13,497 +13,14 @@
 // total dctx (E), dv_t (A) -- and the caller reduces them after the loop with a handful of large launches
 // (column sums and TN GEMMs).
 #include "st_common.h"
-
-#ifndef AB_PROF
-#define AB_PROF(n)   // phase timestamps, only defined by tools/mb/mb_attn_bwd.hip
-#endif
+#include "attention_bwd_body.h"
 
 namespace {
 
-constexpr int AB_THREADS = 512;
-// positions per block of the energy-gradient phase: 48 (three MFMA row tiles per pass: the usual utterance of <= 48 positions is ONE
-// block -- three barriers instead of nine, 24 independent positions per thread in the tanh phase) when the forward kept S and the
-// block fits the LDS, else 16
-constexpr int AB_LBLK_MAX = 48;
-constexpr int AB_FMAX = 32;     // location filters held in registers per thread
-
-struct AbArgs {
-    const float* pq; const float* pm; const float* memory;
-    const float* w_prev; int ld_wprev;     // w_{t-1} (B rows, stride ld_wprev); NULL = zeros (t = 0)
-    const float* w_cum_prev;               // cum_{t-1} (B, L)
-    const float* w; int ld_w;              // w_t
-    const float* loc_conv_w; const float* loc_lin_w; const float* v;
-    const float* dctx[3]; int ld_dctx[3];  // gradient w.r.t. ctx_t = sum of up to three addends (NULL = absent)
-    const float* dw_direct[3]; int ld_dw[3];   // gradient w.r.t. w_t: up to three addends (B rows each)
-    float* dcum; const float* dcum_add; int ld_dcum_add;   // dL/dcum_t = dcum (B,L, in/out) + dcum_add; also an addend of dw
-    float* dpq;                            // (B, A) out
-    float* dpq_t16; int dpq_kbs, dpq_kb0;  // optional second copy in the T16 tile layout (operand of the packed W_q^T product)
-    float* dhist;                          // (B, 2, L) out: gradient w.r.t. [w_{t-1} ; cum_{t-1}] through the conv
-    // tape slices of this step (all written, never read back here)
-    float* ds_t;      // (B, L, A)  d loss / d s[l][a]              -> dpm = sum_t, dW_l = ds^T loc
-    float* loc_t;     // (B, L, F)  location features               -> dW_l
-    float* dloc_t;    // (B, L, F)  gradient of the location features -> dW_c (conv weight gradient)
-    float* hist_t;    // (B, L, 2)  [w_{t-1}, cum_{t-1}] channels-last  -> dW_c
-    float* dctx_t;    // (B, E)     total gradient w.r.t. ctx_t      -> dmem[b] = w^T dctx
-    float* dv_t;      // (B, A)     sum_l de[l] * tanh(s[l][a])      -> dv = sum over (t, b)
-    const float* s_in; // optional (B, L, A): pm + W_l loc of this step from the forward (then loc is neither recomputed nor written)
-    int B, L, A, E, F, K;
-};
-
-// tanh from one v_exp_f32 and one fast reciprocal (same as the forward kernel): |error| <= ~2e-7 absolute
-__device__ __forceinline__ float ab_tanh(float x) {
-    const float t = __expf(-2.0f * fabsf(x));
-    return copysignf(__fdividef(1.0f - t, 1.0f + t), x);
-}
-
-struct AbLds { int hist, hl, wct, f4, wl, wlt, ld, loc, dloc, w, dw, dctx, dsb, part, red, total; };
-
-__host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K, int lblk, bool has_s) {
-    AbLds o;
-    int p = 0;
-    o.f4 = (F + 3) & ~3;                  // rows of loc / dloc / W_l / transposed W_c padded to float4
-    o.hl = (L + K + 4 + 3) & ~3;          // zero-padded history per channel
-    o.hist = p; p += 2 * o.hl;
-    o.wct = p; p += 2 * K * o.f4;         // W_c transposed to [c][k][f]
-    o.wl = p; p += has_s ? 0 : A * o.f4;  // W_l [a][f] (only to recompute S)
-    o.ld = ((A + 63) & ~63) + 4;          // row stride of the two MFMA operands: a padded to 64, +4 floats against bank conflicts
-    o.wlt = p; p += 32 * o.ld;            // W_l^T [f][a] (rows f >= F and columns a >= A are zero)
-    o.loc = p; p += L * AB_FMAX;          // rows padded to AB_FMAX zeros: the energy phase reads them unconditionally
-    o.dloc = p; p += L * o.f4;
-    o.w = p; p += (L + 3) & ~3;
-    o.dw = p; p += (L + 3) & ~3;
-    o.dctx = p; p += (E + 3) & ~3;
-    o.dsb = p; p += (lblk * o.ld > 2 * AB_THREADS ? lblk * o.ld : 2 * AB_THREADS);   // ds block [l][a]; also the fold buffer of P4
-    o.part = p; p += 4 * lblk * 32;       // partial dloc sums [a quarter][l][f lane]
-    o.red = p; p += 16;
-    o.total = p;
-    return o;
-}
-
-// HAS_S: S = pm + W_l loc of the step comes from the forward pass (training keeps it: 1.4 MB per step against 288 GB) -- no
-// location conv (P1) and no 32-filter product per (position, dim) in the energy gradient (P3)
 template <bool HAS_S, int LBLK>
 __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
-    constexpr int AB_LBLK = LBLK, AB_LPT = LBLK / 2;   // positions per thread and block (at least two threads share an attention dim)
-    constexpr int MTL = LBLK / 16;                      // MFMA row tiles per block
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
-    const AbLds o = ab_layout(L, A, E, F, K, LBLK, HAS_S);
-    float* hist = lds + o.hist; float* WcT = lds + o.wct; float* Wl = lds + o.wl; float* WlT = lds + o.wlt; float* loc = lds + o.loc;
-    float* dloc = lds + o.dloc; float* ws = lds + o.w; float* dws = lds + o.dw; float* dctx = lds + o.dctx;
-    float* dsb = lds + o.dsb; float* part = lds + o.part; float* red = lds + o.red;
-    const int pad = (K - 1) / 2, HL = o.hl, F4 = o.f4, LD = o.ld;
-
-    AB_PROF(0);
-    // energy-gradient role of this thread: fixed attention dim a0, positions l0 + grp, l0 + grp + ngrp, ...
-    const int a0 = tid % A, grp = tid / A, ngrp = AB_THREADS / A;    // host: A <= 256 and 512 % A == 0, so ngrp >= 2
-    const float* __restrict__ pmb = (HAS_S ? a.s_in : a.pm) + (size_t)b * L * A;
-    // processed-memory values of the first block: issued before anything else, consumed in P3
-    // (buffer loads: the descriptor ends at row L, rows past it and slots past the block read zeros without a branch)
-    const __amdgpu_buffer_rsrc_t pm_rs = __builtin_amdgcn_make_buffer_rsrc((void*)pmb, 0, L * A * 4, 0x00020000);
-    float pmr[AB_LPT];
-#pragma unroll
-    for (int i = 0; i < AB_LPT; ++i) {
-        const int l = grp + i * ngrp;
-        pmr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pm_rs, i * ngrp + grp < AB_LBLK ? (l * A + a0) * 4 : 0x7ffffff0, 0, 0));
-    }
-    // encoder-memory rows of the first round of P2 (wave w: positions w, w+8, w+16, w+24), issued now, consumed after P1
-    constexpr int NW = AB_THREADS / 64;
-    const float* __restrict__ memb = a.memory + (size_t)b * L * E;
-    const bool mem_pf = E <= 512;
-    const __amdgpu_buffer_rsrc_t mem_rs = __builtin_amdgcn_make_buffer_rsrc((void*)memb, 0, L * E * 4, 0x00020000);
-    f32x4 mpf[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int l = wave + j * NW, e = lane * 4 + h * 256;
-            mpf[j][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mem_rs, (mem_pf && e < E) ? (l * E + e) * 4 : 0x7ffffff0, 0, 0));
-        }
-    // addends of dw[l] / dctx[e], first round (l = tid, e = tid): requested with the other operands, consumed after the staging
-    // (absent addends read a valid dummy address and are dropped by a select when consumed)
-    const int pl_l = min(tid, L - 1), pl_e = min(tid, E - 1);
-    const float* pl_dummy = a.w + (size_t)b * a.ld_w + pl_l;
-    const float* pe_dummy = a.memory + (size_t)b * L * E + pl_e;
-    const float pl_w = pl_dummy[0];
-    const float pq_a = a.pq[(size_t)b * A + a0], v_a = a.v[a0];      // (consumed in P3: requested here, not behind the softmax)
-    float pl_dl[3], pe_dl[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) pl_dl[j] = (a.dw_direct[j] ? a.dw_direct[j] + (size_t)b * a.ld_dw[j] + pl_l : pl_dummy)[0];
-    const float pl_gc0 = (a.dcum ? a.dcum + (size_t)b * L + pl_l : pl_dummy)[0];
-    const float pl_gc1 = (a.dcum && a.dcum_add ? a.dcum_add + (size_t)b * a.ld_dcum_add + pl_l : pl_dummy)[0];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) pe_dl[j] = (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + pl_e : pe_dummy)[0];
-    // ---- P0: stage operands.  The first round of the weight loads goes to registers before any LDS traffic so
-    // that all global latencies of this phase overlap (each separate load -> store loop costs one round trip).
-    const int nWc = F * 2 * K, nWl = A * F;
-    float wc_v[4], wl_v[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int i = tid + j * AB_THREADS; wc_v[j] = i < nWc ? a.loc_conv_w[i] : 0.0f; }
-    // the usual shape (32 filters, 16-byte aligned W_l): four 16-byte loads per thread and shift / mask indexing below instead of
-    // sixteen scalar loads and a division by F per element (this prologue is instruction-issue bound)
-    const bool wl_fast = F == AB_FMAX && nWl <= 16 * AB_THREADS && st_aligned16(a.loc_lin_w);
-    if (wl_fast) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i4 = tid + j * AB_THREADS;
-            const f32x4 t = st_ld4(a.loc_lin_w + (size_t)min(i4, (nWl >> 2) - 1) * 4);
-            wl_v[4 * j] = t[0]; wl_v[4 * j + 1] = t[1]; wl_v[4 * j + 2] = t[2]; wl_v[4 * j + 3] = t[3];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const int i = tid + j * AB_THREADS; wl_v[j] = i < nWl ? a.loc_lin_w[i] : 0.0f; }
-    }
-    AB_PROF(8);
-    for (int i = tid; i < 2 * HL; i += AB_THREADS) {
-        const int c = i / HL, j = i - c * HL, l = j - pad;
-        float v = 0.0f;
-        if (l >= 0 && l < L) {
-            if (c == 0) v = a.w_prev ? a.w_prev[(size_t)b * a.ld_wprev + l] : 0.0f;
-            else v = a.w_cum_prev[(size_t)b * L + l];
-            a.hist_t[((size_t)b * L + l) * 2 + c] = v;
-        }
-        hist[i] = v;
-    }
-    AB_PROF(9);
-    // zero padding of the LDS operands: pad columns a >= A of the two MFMA operands always; everything else only
-    // when F is not the full 32 filters (then whole arrays are cleared before the scattering stores)
-    const bool ragged = F != AB_FMAX;
-    if (ragged) {
-        for (int i = tid; i < 2 * K * F4; i += AB_THREADS) WcT[i] = 0.0f;
-        if (!HAS_S) for (int i = tid; i < A * F4; i += AB_THREADS) Wl[i] = 0.0f;      // (with S given W_l [a][f] has no LDS copy)
-        for (int i = tid; i < 32 * LD; i += AB_THREADS) WlT[i] = 0.0f;
-        for (int i = tid; i < AB_LBLK * LD; i += AB_THREADS) dsb[i] = 0.0f;
-        for (int i = tid; i < L * AB_FMAX; i += AB_THREADS) loc[i] = 0.0f;
-        st_lds_barrier();
-    } else {
-        const int padw = LD - A;
-        for (int i = tid; i < (32 + AB_LBLK) * padw; i += AB_THREADS) {
-            const int r = i / padw, c = A + (i - r * padw);
-            if (r < 32) WlT[r * LD + c] = 0.0f; else dsb[(r - 32) * LD + c] = 0.0f;
-        }
-    }
-    AB_PROF(10);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                               // [c][k][f] <- [f][c][k]
-        const int i = tid + j * AB_THREADS;
-        if (i < nWc) { const int f = i / (2 * K), ck = i - f * 2 * K; WcT[ck * F4 + f] = wc_v[j]; }
-    }
-    if (wl_fast) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i4 = tid + j * AB_THREADS;
-            if (i4 < (nWl >> 2)) {
-                const int aa = i4 >> 3, f0 = (i4 & 7) * 4;         // F == 32: eight float4 per W_l row
-                if (!HAS_S) *reinterpret_cast<f32x4*>(Wl + aa * F4 + f0) = f32x4{wl_v[4 * j], wl_v[4 * j + 1], wl_v[4 * j + 2], wl_v[4 * j + 3]};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) WlT[(f0 + c) * LD + aa] = wl_v[4 * j + c];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int i = tid + j * AB_THREADS;
-            if (i < nWl) { const int aa = i / F, f = i - aa * F; if (!HAS_S) Wl[aa * F4 + f] = wl_v[j]; WlT[f * LD + aa] = wl_v[j]; }
-        }
-    }
-    for (int i = tid + 4 * AB_THREADS; i < nWc; i += AB_THREADS) {      // sizes beyond the register rounds
-        const int f = i / (2 * K), ck = i - f * 2 * K;
-        WcT[ck * F4 + f] = a.loc_conv_w[i];
-    }
-    for (int i = tid + 16 * AB_THREADS; i < nWl; i += AB_THREADS) {
-        const int aa = i / F, f = i - aa * F;
-        const float wv = a.loc_lin_w[i];
-        if (!HAS_S) Wl[aa * F4 + f] = wv;
-        WlT[f * LD + aa] = wv;
-    }
-    AB_PROF(11);
-    // absent addends are read from a valid dummy address and dropped by a select afterwards: a chain of
-    // `if (p) g += p[i]` makes the wave wait for every load in turn (one memory round trip per addend)
-    for (int l = tid; l < L; l += AB_THREADS) {
-        const bool first = l == tid;           // requested at the top of the kernel
-        const float* dummy = a.w + (size_t)b * a.ld_w + l;
-        const float wv = first ? pl_w : dummy[0];
-        float dl[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dl[j] = first ? pl_dl[j] : (a.dw_direct[j] ? a.dw_direct[j] + (size_t)b * a.ld_dw[j] + l : dummy)[0];
-        const float gc0 = first ? pl_gc0 : (a.dcum ? a.dcum + (size_t)b * L + l : dummy)[0];
-        const float gc1 = first ? pl_gc1 : (a.dcum && a.dcum_add ? a.dcum_add + (size_t)b * a.ld_dcum_add + l : dummy)[0];
-        ws[l] = wv;
-        float g = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) g += a.dw_direct[j] ? dl[j] : 0.0f;
-        if (a.dcum) {   // cum_t = cum_{t-1} + w_t: the total gradient w.r.t. cum_t reaches w_t and is carried to cum_{t-1}
-            const float gc = gc0 + (a.dcum_add ? gc1 : 0.0f);
-            a.dcum[(size_t)b * L + l] = gc;
-            g += gc;
-        }
-        dws[l] = g;
-    }
-    for (int e = tid; e < E; e += AB_THREADS) {
-        const bool first = e == tid;
-        const float* dummy = a.memory + (size_t)b * L * E + e;
-        float dl[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) dl[j] = first ? pe_dl[j] : (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + e : dummy)[0];
-        float g = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) g += a.dctx[j] ? dl[j] : 0.0f;
-        dctx[e] = g;
-        a.dctx_t[(size_t)b * E + e] = g;
-    }
-    st_lds_barrier();
-    // W_l row of this thread in registers (for s = pq + pm + W_l loc)
-    float wl_r[AB_FMAX];
-#pragma unroll
-    for (int f = 0; f < AB_FMAX; ++f) wl_r[f] = 0.0f;
-    if (HAS_S) {
-    } else if (F4 == AB_FMAX) {
-#pragma unroll
-        for (int f = 0; f < AB_FMAX; f += 4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wl + a0 * F4 + f);
-            wl_r[f] = w4[0]; wl_r[f + 1] = w4[1]; wl_r[f + 2] = w4[2]; wl_r[f + 3] = w4[3];
-        }
-    } else {
-#pragma unroll
-        for (int f = 0; f < AB_FMAX; ++f) if (f < F) wl_r[f] = Wl[a0 * F4 + f];
-    }
-
-    AB_PROF(1);
-    // ---- P1: location features loc[l][f]: one thread = one filter x 4 consecutive positions, sliding window
-    if (!HAS_S) {
-        const int nlb = (L + 3) >> 2;
-        for (int i = tid; i < nlb * F4; i += AB_THREADS) {
-            const int f = i % F4, l0 = (i / F4) * 4;
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            if (f < F) {
-                for (int c = 0; c < 2; ++c) {
-                    const float* hr = hist + c * HL + l0;
-                    const float* wr = WcT + (size_t)c * K * F4 + f;
-                    float h0 = hr[0], h1 = hr[1], h2 = hr[2];
-#pragma unroll 4
-                    for (int k = 0; k < K; ++k) {
-                        const float h3 = hr[k + 3], wv = wr[k * F4];
-                        acc0 = fmaf(wv, h0, acc0); acc1 = fmaf(wv, h1, acc1); acc2 = fmaf(wv, h2, acc2); acc3 = fmaf(wv, h3, acc3);
-                        h0 = h1; h1 = h2; h2 = h3;
-                    }
-                }
-            }
-            const float r[4] = {acc0, acc1, acc2, acc3};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (l0 + j < L) {
-                    loc[(l0 + j) * AB_FMAX + f] = r[j];
-                    if (f < F) a.loc_t[((size_t)b * L + l0 + j) * F + f] = r[j];
-                }
-        }
-    }
-    AB_PROF(2);
-    // ---- P2: dw[l] += dctx . mem[l]     (one wave per position, lanes over E)
-    {
-        int lstart = wave;
-        if (mem_pf) {
-            f32x4 d4[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { const int e = lane * 4 + h * 256; d4[h] = e < E ? *reinterpret_cast<const f32x4*>(dctx + e) : f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int l = wave + j * NW;
-                float acc = 0.0f;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    acc = fmaf(d4[h][0], mpf[j][h][0], acc); acc = fmaf(d4[h][1], mpf[j][h][1], acc);
-                    acc = fmaf(d4[h][2], mpf[j][h][2], acc); acc = fmaf(d4[h][3], mpf[j][h][3], acc);
-                }
-                acc = st_wave_sum_dpp(acc);
-                if (lane == 0 && l < L) dws[l] += acc;
-            }
-            lstart = wave + 4 * NW;
-        }
-        for (int l = lstart; l < L; l += 2 * NW) {          // remaining positions: two rows' loads in flight per wave
-            const int l2 = l + NW;
-            float acc = 0.0f, acc2 = 0.0f;
-            for (int e = lane * 4; e < E; e += 256) {      // E % 4 == 0 checked on the host
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dctx + e);
-                const f32x4 m4 = st_ld4(memb + (size_t)l * E + e);
-                f32x4 n4 = {0.f, 0.f, 0.f, 0.f};
-                if (l2 < L) n4 = st_ld4(memb + (size_t)l2 * E + e);
-                acc = fmaf(d4[0], m4[0], acc); acc = fmaf(d4[1], m4[1], acc); acc = fmaf(d4[2], m4[2], acc); acc = fmaf(d4[3], m4[3], acc);
-                acc2 = fmaf(d4[0], n4[0], acc2); acc2 = fmaf(d4[1], n4[1], acc2); acc2 = fmaf(d4[2], n4[2], acc2); acc2 = fmaf(d4[3], n4[3], acc2);
-            }
-            acc = st_wave_sum_dpp(acc);
-            acc2 = st_wave_sum_dpp(acc2);
-            if (lane == 0) { dws[l] += acc; if (l2 < L) dws[l2] += acc2; }
-        }
-    }
-    st_lds_barrier();
-    AB_PROF(3);
-    // softmax backward: de[l] = w[l] * (dw[l] - sum_j w[j] dw[j])
-    if (wave == 0) {
-        float acc = 0.0f;
-        for (int l = lane; l < L; l += 64) acc = fmaf(ws[l], dws[l], acc);
-        acc = st_wave_sum_dpp(acc);
-        if (lane == 0) red[0] = acc;
-    }
-    st_lds_barrier();
-    const float dot = red[0];
-    st_lds_barrier();
-    for (int l = tid; l < L; l += AB_THREADS) dws[l] = ws[l] * (dws[l] - dot);     // dws now holds de
-    st_lds_barrier();
-
-    AB_PROF(4);
-    // ---- P3: energy gradient in blocks of AB_LBLK positions
-    float* __restrict__ dsg = a.ds_t + (size_t)b * L * A;
-    float* __restrict__ dlocg = a.dloc_t + (size_t)b * L * F;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 dv2 = {0.f, 0.f}, dpq2 = {0.f, 0.f};          // sums over this thread's even / odd positions
-    const int fl = tid & 31;
-
-    for (int l0 = 0; l0 < L; l0 += AB_LBLK) {
-        const int lend = min(L, l0 + AB_LBLK);
-        // prefetch the next block's processed-memory values while this block computes
-        float pmn[AB_LPT];
-#pragma unroll
-        for (int i = 0; i < AB_LPT; ++i) {
-            const int l = l0 + AB_LBLK + grp + i * ngrp;
-            pmn[i] = (i * ngrp + grp < AB_LBLK && l < L) ? pmb[(size_t)l * A + a0] : 0.0f;
-        }
-        // branch-free: rows past the block / past L are computed on a clamped position with de = 0.  Three passes over the thread's
-        // positions so that nothing serialises them: (1) all the energy gradients de[l] come out of LDS back to back (inside the loop each
-        // read sat behind the previous position's LDS store -- the compiler cannot tell the two arrays apart -- and its latency, the
-        // exp and the reciprocal formed one dependent chain per position: 350 cycles each); (2) all s = pq + S; (3) tanh and the outputs
-        float gv[AB_LPT], sv[AB_LPT];
-#pragma unroll
-        for (int i = 0; i < AB_LPT; ++i) {
-            const int row = i * ngrp + grp, l = l0 + row;
-            gv[i] = dws[min(l, L - 1)];
-            if (!(row < AB_LBLK && l < lend)) gv[i] = 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < AB_LPT; ++i) {
-            const int l = min(l0 + grp + i * ngrp, L - 1);
-            const float* lr = loc + l * AB_FMAX;
-            float sa = pq_a + pmr[i], sb = 0.0f;
-#pragma unroll
-            for (int f = 0; f < (HAS_S ? 0 : AB_FMAX); f += 4) {          // pad columns are zero on both sides
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lr + f);
-                sa = fmaf(wl_r[f], l4[0], sa); sb = fmaf(wl_r[f + 1], l4[1], sb);
-                sa = fmaf(wl_r[f + 2], l4[2], sa); sb = fmaf(wl_r[f + 3], l4[3], sb);
-            }
-            sv[i] = sa + sb;
-        }
-        // two positions per instruction where the arithmetic allows (packed fp32: v_pk_mul / v_pk_add / v_pk_fma); the exponential and
-        // the reciprocal stay one lane-value each.  This phase is bound by instruction issue on ONE compute unit (L x A elements).
-        static_assert(AB_LPT % 2 == 0, "positions per thread come in pairs");
-#pragma unroll
-        for (int i = 0; i < AB_LPT; i += 2) {
-            const f32x2 s2 = {sv[i], sv[i + 1]}, g2 = {gv[i], gv[i + 1]};
-            const f32x2 e2 = f32x2{fabsf(s2[0]), fabsf(s2[1])} * -2.885390081777927f;          // exp(-2|x|) = exp2(-2 log2(e) |x|)
-            const f32x2 t2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
-            const f32x2 num = 1.0f - t2, den = 1.0f + t2;
-            f32x2 th2 = num * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-            th2 = f32x2{copysignf(th2[0], s2[0]), copysignf(th2[1], s2[1])};
-            dv2 = dv2 + g2 * th2;
-            const f32x2 ds2 = (g2 * v_a) * (1.0f - th2 * th2);
-            dpq2 = dpq2 + ds2;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int row = (i + ii) * ngrp + grp, l = l0 + row;
-                const bool in_blk = row < AB_LBLK, valid = in_blk && l < lend;
-#ifndef AB_ABLATE_DSG      // (tools/mb only: phase timing without the tape stores)
-                if (valid) dsg[(size_t)l * A + a0] = ds2[ii];
-#endif
-                if (in_blk) dsb[row * LD + a0] = ds2[ii];            // zero for rows past L
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < AB_LPT; ++i) pmr[i] = pmn[i];
-        AB_PROF(12);
-        st_lds_barrier();
-        AB_PROF(13);
-        // dloc[l][f] = sum_a ds[l][a] * W_l[a][f] on the matrix cores: wave = (filter tile nt of 16, quarter kq of the
-        // padded a range); exact-fp32 16x16x4 MFMAs, each lane's float4 along a feeds four of them (same k order
-        // for both operands), 16 x 16 partial tiles to LDS, summed below
-        {
-            const int nt = wave & 1, kq = wave >> 1;
-            const int APq = (LD - 4) >> 2;                      // a range of one quarter (multiple of 16)
-            f32x4 acc[MTL];
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (nt * 16 < F4) {
-                const float* ap = dsb + (lane & 15) * LD + kq * APq + 4 * (lane >> 4);
-                const float* bp = WlT + (nt * 16 + (lane & 15)) * LD + kq * APq + 4 * (lane >> 4);
-                for (int kc = 0; kc < APq; kc += 16) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + kc);       // one W_l fragment feeds every row tile
-#pragma unroll
-                    for (int mt = 0; mt < MTL; ++mt) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + mt * 16 * LD + kc);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], b4[c], acc[mt], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) part[(kq * AB_LBLK + mt * 16 + 4 * (lane >> 4) + r) * 32 + nt * 16 + (lane & 15)] = acc[mt][r];
-        }
-        AB_PROF(14);
-        st_lds_barrier();
-#pragma unroll
-        for (int rr = 0; rr < MTL; ++rr) {
-            const int ll = rr * 16 + (tid >> 5);          // 16 positions x 32 filter lanes = 512 threads per pass
-            const float sum = part[(0 * AB_LBLK + ll) * 32 + fl] + part[(1 * AB_LBLK + ll) * 32 + fl] +
-                              part[(2 * AB_LBLK + ll) * 32 + fl] + part[(3 * AB_LBLK + ll) * 32 + fl];
-            if (l0 + ll < L && fl < F4) {
-                dloc[(l0 + ll) * F4 + fl] = sum;
-                if (fl < F) dlocg[(size_t)(l0 + ll) * F + fl] = sum;
-            }
-        }
-        st_lds_barrier();
-    }
-    AB_PROF(5);
-    // ---- P4: fold the per-thread sums of the ngrp threads sharing an attention dim (LDS, fixed order)
-    float* fold = dsb;
-    fold[tid] = dv2[0] + dv2[1]; fold[AB_THREADS + tid] = dpq2[0] + dpq2[1];
-    st_lds_barrier();
-    if (grp == 0) {
-        float sv = 0.0f, sp = 0.0f;
-        for (int gq = 0; gq < ngrp; ++gq) { sv += fold[gq * A + a0]; sp += fold[AB_THREADS + gq * A + a0]; }
-        a.dv_t[(size_t)b * A + a0] = sv;
-        a.dpq[(size_t)b * A + a0] = sp;
-        if (a.dpq_t16) {
-            const int k = a.dpq_kb0 * 16 + a0;
-            a.dpq_t16[(((size_t)(b >> 4) * a.dpq_kbs + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (b & 15)) * 4 + (k & 3)] = sp;
-        }
-    }
-    AB_PROF(6);
-    // ---- P5: gradient w.r.t. the attention history through the location conv
-    // dhist[c][j] = sum_{f,k} dloc[j - k + pad][f] * Wc[f][c][k]; 8 adjacent lanes split the filters in float4 groups
-    float* dh = a.dhist + (size_t)b * 2 * L;
-    for (int base = 0; base < 2 * L; base += AB_THREADS / 8) {
-        const int cj = base + (tid >> 3), q = tid & 7;
-        float acc = 0.0f;
-        if (cj < 2 * L) {
-            const int c = cj / L, j = cj - c * L;
-            const int klo = max(0, j + pad - (L - 1)), khi = min(K - 1, j + pad);     // 0 <= j - k + pad < L
-            for (int f = q * 4; f < F4; f += 32) {
-                const float* wr = WcT + (size_t)c * K * F4 + f;
-#pragma unroll 4
-                for (int k = klo; k <= khi; ++k) {
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dloc + (j - k + pad) * F4 + f);
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + k * F4);
-                    acc = fmaf(d4[0], w4[0], acc); acc = fmaf(d4[1], w4[1], acc);
-                    acc = fmaf(d4[2], w4[2], acc); acc = fmaf(d4[3], w4[3], acc);
-                }
-            }
-        }
-        acc = st_oct_sum_dpp(acc);      // (uniform loop: all lanes active)
-        if (cj < 2 * L && q == 0) dh[cj] = acc;
-    }
-    AB_PROF(7);
+    extern __shared__ __attribute__((aligned(16))) float ab_dyn_lds[];
+    ab_body<HAS_S, LBLK>(a, blockIdx.x, ab_dyn_lds);
 }
 
 // dmem[b][l][e] = sum_t w_t[b][l] * dctx_t[b][e]      (the context is ctx_t = sum_l w_t[l] mem[l])
@@ -543,27 +60,13 @@ static int ab_step_impl(const st_t16_view* dpq_t16, const float* pq, const float
                                 float* dctx_t, float* dv_t, const float* s_in,
                                 int B, int L, int A, int E, int F, int K, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(pq && pm && memory && w_cum_prev && w && loc_conv_w && loc_lin_w && v, "st_attn_step_bwd: null input");
-    ST_CHECK_ARG(dpq && dhist && ds_t && (loc_t || s_in) && dloc_t && hist_t && dctx_t && dv_t, "st_attn_step_bwd: null output");
-    ST_CHECK_ARG(B > 0 && L > 0 && A > 0 && E > 0 && F > 0 && K > 0 && (K & 1), "st_attn_step_bwd: bad dims (K must be odd)");
-    ST_CHECK_ARG(A <= AB_THREADS / 2 && AB_THREADS % A == 0, "st_attn_step_bwd: attn_dim=%d must divide %d", A, AB_THREADS / 2);
-    ST_CHECK_ARG((E & 3) == 0 && st_aligned16(memory), "st_attn_step_bwd: E=%d must be a multiple of 4 (16-byte aligned rows)", E);
-    ST_CHECK_ARG(F <= AB_FMAX, "st_attn_step_bwd: n_location_filters=%d > %d", F, AB_FMAX);
-    ST_CHECK_ARG(n_dctx >= 0 && n_dctx <= 3 && n_dw >= 0 && n_dw <= 3, "st_attn_step_bwd: at most 3 addends");
     AbArgs a;
-    memset(&a, 0, sizeof(a));
-    a.pq = pq; a.pm = pm; a.memory = memory; a.w_prev = w_prev; a.ld_wprev = ld_wprev; a.w_cum_prev = w_cum_prev;
-    a.w = w; a.ld_w = ld_w; a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.v = v;
-    for (int j = 0; j < n_dctx; ++j) { a.dctx[j] = dctx[j]; a.ld_dctx[j] = ld_dctx[j]; }
-    for (int j = 0; j < n_dw; ++j) { a.dw_direct[j] = dw_direct[j]; a.ld_dw[j] = ld_dw[j]; }
-    a.dcum = dcum; a.dcum_add = dcum_add; a.ld_dcum_add = ld_dcum_add;
-    a.dpq = dpq; a.dhist = dhist; a.ds_t = ds_t; a.loc_t = loc_t; a.dloc_t = dloc_t; a.hist_t = hist_t; a.dctx_t = dctx_t; a.dv_t = dv_t;
-    a.s_in = s_in;
-    if (dpq_t16 && dpq_t16->base) { a.dpq_t16 = dpq_t16->base; a.dpq_kbs = dpq_t16->kb_stride; a.dpq_kb0 = dpq_t16->kb0; }
-    a.B = B; a.L = L; a.A = A; a.E = E; a.F = F; a.K = K;
+    if (ab_fill(a, dpq_t16, pq, pm, memory, w_prev, ld_wprev, w_cum_prev, w, ld_w, loc_conv_w, loc_lin_w, v, dctx, ld_dctx, n_dctx,
+                dw_direct, ld_dw, n_dw, dcum, dcum_add, ld_dcum_add, dpq, dhist, ds_t, loc_t, dloc_t, hist_t, dctx_t, dv_t, s_in,
+                B, L, A, E, F, K)) return -1;
     // the wide block when the forward kept S and its LDS image fits; two workgroups of it never share a compute unit anyway (B workgroups)
-    const bool wide = s_in && (size_t)ab_layout(L, A, E, F, K, AB_LBLK_MAX, true).total * sizeof(float) <= 160 * 1024;
-    const size_t lds = (size_t)ab_layout(L, A, E, F, K, wide ? AB_LBLK_MAX : 16, s_in != nullptr).total * sizeof(float);
+    const bool wide = ab_wide(a);
+    const size_t lds = ab_lds_bytes(a, wide);
     ST_CHECK_ARG(lds <= 160 * 1024, "st_attn_step_bwd: L=%d needs %zu bytes of LDS (> 160 KiB)", L, lds);
     static size_t lds_enabled = 0;
     if (lds > 64 * 1024 && lds > lds_enabled) {

@@ -95,6 +95,31 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                                             io->cd_tape + (size_t)t * BD, D, io->dcd, io->dgd + (size_t)t * Bp * 4 * D, 4 * D, &v0, B, D, stream);
             if (rc) return rc;
         }
+        // launch "b" of step t: dxd_t = dgates_d_t [W_ih_d | W_hh_d] (+ the decoder cell's pointwise step of t-1 in its epilogue: columns
+        // [E+Q, E+Q+D) + dxo_{t-1}[:, :D] = dh_d(t-1)), optionally with the attention backward `ab` of the step AFTER it beside it
+        auto product_d = [&](int t, const st_attn_bwd_job* ab) -> int {
+            float* dxd = io->dxd + (size_t)t * Bp * XD;
+            st_t16_view x_v = {dgd_buf[t & 1], kbd, 0};
+            st_lstm_pw_job j;
+            memset(&j, 0, sizeof(j));
+            if (t > 0) {
+                j.n0 = E + Q; j.H = D;
+                j.dh1 = io->dxo + (size_t)(t - 1) * Bp * XO; j.ld1 = XO;
+                j.mask = io->d_mask ? io->d_mask + (size_t)(t - 1) * BD : nullptr;
+                j.gates = io->gates_d_tape + (size_t)(t - 1) * 4 * BD;
+                j.c = io->cd_tape + (size_t)t * BD; j.ldc = D; j.c_prev = io->cd_tape + (size_t)(t - 1) * BD; j.ldcp = D;
+                j.dc = io->dcd; j.dgates = io->dgd + (size_t)(t - 1) * Bp * 4 * D; j.ldg = 4 * D;
+                j.dgates_t16.base = dgd_buf[(t - 1) & 1]; j.dgates_t16.kb_stride = kbd; j.dgates_t16.kb0 = 0;
+            }
+            if (ab) return st_skinny_linear_packed_lstm_bwd_attn_bwd(w->d_w_cat_t_p16, &x_v, 4 * D, dxd, XD, B, XD, t > 0 ? &j : nullptr, ab, stream);
+            if (t > 0) return st_skinny_linear_packed_lstm_bwd_fwd(w->d_w_cat_t_p16, &x_v, 4 * D, dxd, XD, B, XD, &j, stream);
+            return st_skinny_linear_packed_fwd(w->d_w_cat_t_p16, &x_v, 4 * D, nullptr, ST_ACT_NONE, nullptr, 0, dxd, XD, nullptr,
+                                               0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XD, stream);
+        };
+        // the decoder cell's recurrence (dgates_d(t-1) from dgates_d(t) . W_hh_d and the output gradients) does not touch the attention /
+        // query chain of step t: with overlap_attn its product runs ONE STEP AHEAD, beside the attention backward of step t
+        const bool overlap = io->overlap_attn && io->attn_s_tape;
+        if (overlap) { rc = product_d(steps - 1, nullptr); if (rc) return rc; }
         for (int t = steps - 1; t >= 0; --t) {
             const float* dxo = io->dxo + (size_t)t * Bp * XO;
             float* dxd = io->dxd + (size_t)t * Bp * XD;
@@ -103,38 +128,28 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
             float* dpq = io->dpq + (size_t)t * Bp * A;
             float* dhist_cur = io->dhist[t & 1];
             const float* dhist_next = io->dhist[(t + 1) & 1];
-            // b (+ a of step t-1). dxd_t = dgates_d_t [W_ih_d | W_hh_d]; its columns [E+Q, E+Q+D) + dxo_{t-1}[:, :D] = dh_d(t-1)
-            st_t16_view x_v = {dgd_buf[t & 1], kbd, 0};
-            if (t > 0) {
-                st_lstm_pw_job j;
-                memset(&j, 0, sizeof(j));
-                j.n0 = E + Q; j.H = D;
-                j.dh1 = io->dxo + (size_t)(t - 1) * Bp * XO; j.ld1 = XO;
-                j.mask = io->d_mask ? io->d_mask + (size_t)(t - 1) * BD : nullptr;
-                j.gates = io->gates_d_tape + (size_t)(t - 1) * 4 * BD;
-                j.c = io->cd_tape + (size_t)t * BD; j.ldc = D; j.c_prev = io->cd_tape + (size_t)(t - 1) * BD; j.ldcp = D;
-                j.dc = io->dcd; j.dgates = io->dgd + (size_t)(t - 1) * Bp * 4 * D; j.ldg = 4 * D;
-                j.dgates_t16.base = dgd_buf[(t - 1) & 1]; j.dgates_t16.kb_stride = kbd; j.dgates_t16.kb0 = 0;
-                rc = st_skinny_linear_packed_lstm_bwd_fwd(w->d_w_cat_t_p16, &x_v, 4 * D, dxd, XD, B, XD, &j, stream);
-            } else
-                rc = st_skinny_linear_packed_fwd(w->d_w_cat_t_p16, &x_v, 4 * D, nullptr, ST_ACT_NONE, nullptr, 0, dxd, XD, nullptr,
-                                                 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XD, stream);
-            if (rc) return rc;
+            if (!overlap) { rc = product_d(t, nullptr); if (rc) return rc; }
             // c. attention (dpq also in T16)
-            const float* dctx[3] = {dxo + D, dxd, dxq_next + P};
-            const int ld_dctx[3] = {XO, XD, XQ};
-            const float* dwd[2] = {dhist_next, io->dalign ? io->dalign + (size_t)t * L : nullptr};
-            const int ld_dw[2] = {2 * L, ldal};
-            const float* s_in = io->attn_s_tape ? (t == 0 ? io->pm : io->attn_s_tape + (size_t)t * BL * A) : nullptr;
-            rc = st_attn_step_bwd_t16(io->pq_all + (size_t)t * Bp * A, io->pm, io->memory,
-                                      t > 0 ? io->align + (size_t)(t - 1) * L : nullptr, ldal, io->wcum_tape + (size_t)t * BL,
-                                      io->align + (size_t)t * L, ldal, w->attn_loc_conv_w, w->attn_loc_lin_w, w->attn_v,
-                                      dctx, ld_dctx, 3, dwd, ld_dw, io->dalign ? 2 : 1,
-                                      io->dcum, dhist_next + L, 2 * L,
-                                      dpq, &dpq_v, dhist_cur, io->ds_tape + (size_t)t * BL * A, io->loc_tape + (size_t)t * BL * d->F,
-                                      io->dloc_tape + (size_t)t * BL * d->F, io->hist_tape + (size_t)t * BL * 2,
-                                      io->dctx_tape + (size_t)t * B * E, io->dv_tape + (size_t)t * B * A, s_in,
-                                      B, L, A, E, d->F, d->K, stream);
+            st_attn_bwd_job ab;
+            memset(&ab, 0, sizeof(ab));
+            ab.pq = io->pq_all + (size_t)t * Bp * A; ab.pm = io->pm; ab.memory = io->memory;
+            ab.w_prev = t > 0 ? io->align + (size_t)(t - 1) * L : nullptr; ab.ld_wprev = ldal; ab.w_cum_prev = io->wcum_tape + (size_t)t * BL;
+            ab.w = io->align + (size_t)t * L; ab.ld_w = ldal;
+            ab.loc_conv_w = w->attn_loc_conv_w; ab.loc_lin_w = w->attn_loc_lin_w; ab.v = w->attn_v;
+            ab.dctx[0] = dxo + D; ab.dctx[1] = dxd; ab.dctx[2] = dxq_next + P; ab.ld_dctx[0] = XO; ab.ld_dctx[1] = XD; ab.ld_dctx[2] = XQ; ab.n_dctx = 3;
+            ab.dw_direct[0] = dhist_next; ab.dw_direct[1] = io->dalign ? io->dalign + (size_t)t * L : nullptr; ab.ld_dw[0] = 2 * L; ab.ld_dw[1] = ldal;
+            ab.n_dw = io->dalign ? 2 : 1;
+            ab.dcum = io->dcum; ab.dcum_add = dhist_next + L; ab.ld_dcum_add = 2 * L;
+            ab.dpq = dpq; ab.dpq_t16 = dpq_v; ab.dhist = dhist_cur; ab.ds_t = io->ds_tape + (size_t)t * BL * A;
+            ab.loc_t = io->loc_tape + (size_t)t * BL * d->F; ab.dloc_t = io->dloc_tape + (size_t)t * BL * d->F;
+            ab.hist_t = io->hist_tape + (size_t)t * BL * 2; ab.dctx_t = io->dctx_tape + (size_t)t * B * E; ab.dv_t = io->dv_tape + (size_t)t * B * A;
+            ab.s_in = io->attn_s_tape ? (t == 0 ? io->pm : io->attn_s_tape + (size_t)t * BL * A) : nullptr;
+            ab.B = B; ab.L = L; ab.A = A; ab.E = E; ab.F = d->F; ab.K = d->K;
+            if (overlap && t > 0) rc = product_d(t - 1, &ab);        // [attention backward of t | decoder cell product of t-1]: one launch
+            else rc = st_attn_step_bwd_t16(ab.pq, ab.pm, ab.memory, ab.w_prev, ab.ld_wprev, ab.w_cum_prev, ab.w, ab.ld_w, ab.loc_conv_w, ab.loc_lin_w,
+                                           ab.v, ab.dctx, ab.ld_dctx, ab.n_dctx, ab.dw_direct, ab.ld_dw, ab.n_dw, ab.dcum, ab.dcum_add, ab.ld_dcum_add,
+                                           ab.dpq, &ab.dpq_t16, ab.dhist, ab.ds_t, ab.loc_t, ab.dloc_t, ab.hist_t, ab.dctx_t, ab.dv_t, ab.s_in,
+                                           B, L, A, E, d->F, d->K, stream);
             if (rc) return rc;
             // d + e. dh_q = W_q^T dpq + (W_hh_q^T dgates_q)_{t+1} + std * d(adapted h_q): the query cell's pointwise part in the epilogue
             {

@@ -16,6 +16,7 @@
 // The K loop is software pipelined (loads of group g+1 are in flight during the MFMAs of g).
 #include "st_common.h"
 #include "attention_body.h"
+#include "attention_bwd_body.h"
 #include <cstdlib>   // the "pre" part of the attention step runs as extra workgroups of a small linear
 
 #ifndef PK_PROF
@@ -631,6 +632,25 @@ __global__ __launch_bounds__(KW * 64) void pk_pw_kernel(const f32x4* w, const f3
     pk_body<2, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red, &pw);
 }
 
+// The decoder cell's backward product of step t-1 (pk_body MODE 2) with the attention-step backward of step t BESIDE it: in the BPTT
+// loop dgates_d(t-1) only needs the decoder cell's own recurrence, so the two do not depend on each other.  The attention
+// workgroups come FIRST (dispatched first: each holds a compute unit for ~17 us), the product's workgroups after them.
+template <int NB, int KW, int TRIP, int LBLK>
+__global__ __launch_bounds__(KW * 64) void pk_pw_ab_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                           const int B, const int N, const int tiles_a, const int n_ab,
+                                                           const PkArgs rest, const PkPw pw, const AbArgs ab) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * NB * 64];
+    static_assert(KW * 64 == AB_THREADS, "both parts use 512-thread workgroups");
+    const int i = blockIdx.x;
+    if (i < n_ab) { ab_body<true, LBLK>(ab, i, pk_dyn_lds); return; }
+    PkArgs a = rest;
+    a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N; a.H = 0;
+    const int j = i - n_ab;
+    const int by = j / tiles_a;
+    pk_body<2, NB, KW, TRIP>(a, j - by * tiles_a, by, red, &pw);
+}
+
 // The proj (+) gate launch of decode step t with, on the compute units it leaves idle, the part of the attention of step t+1
 // that only needs the attention weights of step t (location conv + W_l + processed memory -> S): one workgroup per
 // utterance after the linear's workgroups.  The attention launch of step t+1 then starts from S.
@@ -1097,6 +1117,58 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_fwd(const float* packed_w, const
     // one batch tile per workgroup, as the plain linear of these shapes runs (pk_dispatch<1>)
     hipLaunchKernelGGL((pk_pw_kernel<1, 8, 2>), dim3(tiles, BT), dim3(8 * 64), 0, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B,
                        a.N, a, q);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// st_skinny_linear_packed_lstm_bwd_fwd (job may be NULL: the plain product) with one attention-step backward (the arguments of
+// st_attn_step_bwd_t16 as a struct; the forward must have kept S: s_in != NULL) in the same launch
+extern "C" int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                                         const st_lstm_pw_job* job, const st_attn_bwd_job* ab, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(y && ab && B > 0 && N > 0 && ldy >= N, "st_skinny_linear_packed_lstm_bwd_attn_bwd: bad arguments");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, x, K, "st_skinny_linear_packed_lstm_bwd_attn_bwd");
+    if (rc) return rc;
+    a.B = B; a.N = N; a.H = 0; a.act = ST_ACT_NONE;
+    a.y = y; a.ldy = ldy;
+    PkPw q;
+    memset(&q, 0, sizeof(q));
+    if (job) {
+        const int H = job->H;
+        ST_CHECK_ARG(H > 0 && H % 4 == 0 && job->n0 >= 0 && job->n0 % 16 == 0 && job->n0 + H <= N && (N % 16 == 0 || job->n0 + H <= (N & ~15)),
+                     "st_skinny_linear_packed_lstm_bwd_attn_bwd: the cell's columns [%d, %d) must be whole tiles of the %d outputs", job->n0, job->n0 + H, N);
+        ST_CHECK_ARG(job->gates && job->c && job->dc && job->dgates && job->ldg >= 4 * H && job->ldg % 4 == 0 && job->ldc % 4 == 0 &&
+                     (!job->c_prev || job->ldcp % 4 == 0) && (!job->dh1 || job->ld1 % 4 == 0) && (!job->dh2 || job->ld2 % 4 == 0) && ldy % 4 == 0,
+                     "st_skinny_linear_packed_lstm_bwd_attn_bwd: null operand or a row stride that is not a multiple of 4");
+        ST_CHECK_ARG(st_aligned16(job->gates) && st_aligned16(job->c) && st_aligned16(job->dc) && st_aligned16(job->dgates) && st_aligned16(y) &&
+                     (!job->c_prev || st_aligned16(job->c_prev)) && (!job->dh1 || st_aligned16(job->dh1)) && (!job->dh2 || st_aligned16(job->dh2)) &&
+                     (!job->scale2 || st_aligned16(job->scale2)) && (!job->mask || st_aligned16(job->mask)) &&
+                     (!job->dgates_t16.base || st_aligned16(job->dgates_t16.base)), "st_skinny_linear_packed_lstm_bwd_attn_bwd: operands must be 16-byte aligned");
+        q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
+        q.gates = job->gates; q.c = job->c; q.ldc = job->ldc; q.c_prev = job->c_prev; q.ldcp = job->ldcp; q.dc = job->dc;
+        q.dgates = job->dgates; q.ldg = job->ldg; q.dg_t16 = pk_out(&job->dgates_t16);
+    }      // (no job: H = 0, no column belongs to a cell -- the plain product)
+    AbArgs t;
+    if (ab_fill(t, &ab->dpq_t16, ab->pq, ab->pm, ab->memory, ab->w_prev, ab->ld_wprev, ab->w_cum_prev, ab->w, ab->ld_w, ab->loc_conv_w,
+                ab->loc_lin_w, ab->v, ab->dctx, ab->ld_dctx, ab->n_dctx, ab->dw_direct, ab->ld_dw, ab->n_dw, ab->dcum, ab->dcum_add,
+                ab->ld_dcum_add, ab->dpq, ab->dhist, ab->ds_t, ab->loc_t, ab->dloc_t, ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in,
+                ab->B, ab->L, ab->A, ab->E, ab->F, ab->K)) return -1;
+    ST_CHECK_ARG(t.s_in, "st_skinny_linear_packed_lstm_bwd_attn_bwd: the hosted attention backward starts from the forward's S (s_in)");
+    const size_t red_bytes = (size_t)8 * 1 * 64 * sizeof(f32x4);          // the product's static LDS in the same workgroup
+    const bool wide = ab_wide(t, red_bytes);
+    const size_t lds = ab_lds_bytes(t, wide);
+    ST_CHECK_ARG(lds + red_bytes <= 160 * 1024, "st_skinny_linear_packed_lstm_bwd_attn_bwd: L=%d needs %zu bytes of LDS", t.L, lds + red_bytes);
+    const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
+    auto kern = wide ? pk_pw_ab_kernel<1, 8, 2, AB_LBLK_MAX> : pk_pw_ab_kernel<1, 8, 2, 16>;
+    static size_t lds_set[2] = {0, 0};
+    if (lds > 48 * 1024 && lds > lds_set[wide ? 1 : 0]) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[wide ? 1 : 0] = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(t.B + tiles * BT), dim3(8 * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, tiles,
+                       t.B, a, q, t);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -354,6 +354,7 @@ class Decoder(nn.Module):
         self.attn_split_min_len = 128     # texts at least this long: fin part over position ranges (~attn_split_positions each) + combine
         self.attn_split_positions = 43
         self.bwd_fuse_pointwise = True   # training (teacher forcing): the cells' pointwise backward in the epilogues of the loop's products
+        self.bwd_overlap_attn = True     # ... and the decoder cell's product of step t-1 beside the attention backward of step t (one launch)
         self.attn_rng_one_launch = True   # long texts: query projection + fin part over position ranges + combine in one launch
 
     # -- helpers ---------------------------------------------------------------------------------

@@ -910,3 +910,37 @@ def test_text_first_step_against_reference_golden(dev):
             worst, worst_k = e, k
         assert e < 1e-3, (k, e)
     report('text_first_grads', worst=worst, worst_k=worst_k, n=len(keys))
+
+
+def test_bptt_loop_with_hosted_attention_backward_is_bitwise_the_plain_loop(dev):
+    """The software-pipelined BPTT loop (decoder cell product of step t-1 in ONE launch with the attention backward of step t,
+    st_skinny_linear_packed_lstm_bwd_attn_bwd) only re-schedules the same kernels' work: every gradient of the full-size decoder
+    (B = 32, L = 43, 6 steps, dropout on) is bit-identical to the loop with separate launches, and to the six-launch form's within
+    round-off."""
+    from helpers import full_tacotron
+    m = full_tacotron(dev, seed=4321, prenet_dropout=0.5).train()
+    dec = m.decoder
+    B, L, steps = 32, 43, 6
+    r, n_mels = dec.n_frames_per_step, dec.n_mels
+    mem0, spk0 = rnd(B, L, 512, seed=1).to(dev), rnd(B, 128, seed=2).to(dev)
+    teacher = torch.rand(B, steps * r, n_mels, generator=torch.Generator().manual_seed(3)).to(dev)
+    douts = None
+    res = {}
+    for mode in ('overlap', 'plain', 'six'):
+        dec.bwd_overlap_attn = mode == 'overlap'
+        dec.bwd_fuse_pointwise = mode != 'six'
+        for p in dec.parameters():
+            p.grad = None
+        torch.manual_seed(77)                                   # the same dropout masks in every pass
+        mem, spk = mem0.clone().requires_grad_(), spk0.clone().requires_grad_()
+        mel, align, stop = dec(mem, None, teacher, spk, tf_rate=1.0)
+        if douts is None:
+            douts = [rnd(*mel.shape, seed=5).to(dev), rnd(*align.shape, seed=6).to(dev), rnd(*stop.shape, seed=7).to(dev)]
+        torch.autograd.backward([mel, align, stop], douts)
+        res[mode] = dict(mel=mel.detach().clone(), dmem=mem.grad.clone(), dspk=spk.grad.clone(),
+                         **{k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+    dec.bwd_overlap_attn = dec.bwd_fuse_pointwise = True
+    assert len(res['overlap']) > 20
+    for k, v in res['overlap'].items():
+        assert torch.equal(v, res['plain'][k]), k
+        assert relerr(v, res['six'][k]) < 1e-5, k

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--config', default='config/semi-single-spkr-paired-data.yaml')
     ap.add_argument('--no-fuse-pw', action='store_true', help='six launches per backward step (pointwise LSTM backward as launches of its own)')
+    ap.add_argument('--no-overlap-attn', action='store_true', help='attention backward and the decoder cell product as separate launches')
     a = ap.parse_args()
     from semi_tts_amd.solver import TtsTrainer
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,6 +36,8 @@ def main():
     text, sid, mel, linear = (t.to(tr.device) for t in tr.batches[0])
     if a.no_fuse_pw:
         tr.model.tts.decoder.bwd_fuse_pointwise = False
+    if a.no_overlap_attn:
+        tr.model.tts.decoder.bwd_overlap_attn = False
     phases = dict(fwd=0.0, bwd=0.0, opt=0.0)
     sync = torch.cuda.synchronize
     stats = None

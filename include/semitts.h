@@ -750,8 +750,9 @@ int st_ctc_loss(const float* prob, const int64_t* text, float eps, float* loss, 
                 int B, int T, int V, int L, int log_input, void* stream);
 /* ------------------------------------------------------------------ trainer loss
  * loss = w_all*crit(pred,label) + w_low*crit(low n_low bins) + w_diff*crit(first differences along T), crit = MSE or
- * (l1 != 0) mean absolute error; writes the scalar to *loss and d loss / d pred to dpred (B,T,D).  ws: 256 floats.
+ * (l1 != 0) mean absolute error; writes the scalar to *loss and d loss / d pred to dpred (B,T,D).  ws: st_freq_loss_workspace_floats() floats (one partial sum per workgroup).
  * ref: freq_loss src/util.py:80-126 (mel: w = 1, 0, 0.5; linear with low-band emphasis: w = 0.5, 0.5, 0) */
+size_t st_freq_loss_workspace_floats(void);
 int st_freq_loss(const float* pred, const float* label, float* loss, float* dpred, float* ws,
                  int B, int T, int D, int n_low, float w_all, float w_low, float w_diff, int l1, void* stream);
 /* y = x * (*scalar)   (scalar on the device: the incoming gradient of a scalar loss) */

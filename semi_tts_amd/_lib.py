@@ -224,6 +224,7 @@ SIGNATURES = {
     'st_mt_clip_scale': [P, P, I, P, F, P],
     'st_mt_adam': [P, P, P, P, P, I, F, F, F, F, F, P],
     'st_freq_loss': [P, P, P, P, P, I, I, I, I, F, F, F, I, P],
+    'st_freq_loss_workspace_floats': [],
     'st_scale_by': [P, P, P, Z, P],
     'st_bn_norm_fwd': [P, I, I, P, I, I, I, I, P, P, P, P, F, I, P],
     'st_gemm_wgrad_workspace_floats': [I, I, I, I, I],
@@ -244,7 +245,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
              'st_decoder_packed_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_ctc_workspace_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
-             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_attn_rng_xchg_words': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
+             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_freq_loss_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_attn_rng_xchg_words': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
 
 _lib = None
 

@@ -615,7 +615,7 @@ class _FreqLossFn(Function):
         B, T, D = pred.shape
         loss = torch.empty((), device=pred.device, dtype=torch.float32)
         dpred = torch.empty_like(pred)
-        ws = torch.empty(256, device=pred.device, dtype=torch.float32)
+        ws = torch.empty(int(_lib.load().st_freq_loss_workspace_floats()), device=pred.device, dtype=torch.float32)
         _lib.check(_lib.load().st_freq_loss(ops._p(pred), ops._p(label), ops._p(loss), ops._p(dpred), ops._p(ws), B, T, D,
                                             int(n_low), float(w_all), float(w_low), float(w_diff), 1 if l1 else 0,
                                             ops.stream_handle()), 'st_freq_loss')

@@ -377,15 +377,26 @@ __global__ __launch_bounds__(256) void copy3d_kernel(float* dst, long dsb, long 
 
 // dtable(v, :) = sum over the rows r with idx(r) == v of dout(r, :), added in row order: one workgroup column per table row
 // scans the index vector (a few thousand entries, read through the scalar cache) -- deterministic, no atomics
-__global__ __launch_bounds__(64) void scatter_add_rows_kernel(const float* dout, const int64_t* idx, float* dtable,
-                                                              int n, int D, int V) {
+// 64 columns x 8 row lanes per workgroup: lane q scans its contiguous eighth of the index vector in row order, the eight partial sums
+// are added in lane order -- a fixed order whatever the data (one thread per column scanning all n rows took 56 us)
+__global__ __launch_bounds__(512) void scatter_add_rows_kernel(const float* dout, const int64_t* idx, float* dtable,
+                                                               int n, int D, int V) {
+    __shared__ float red[8][64];
     const int v = blockIdx.x;
-    const int d = blockIdx.y * 64 + threadIdx.x;
-    if (d >= D) return;
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int d = blockIdx.y * 64 + c;
+    const int per = (n + 7) / 8, r0 = q * per, r1 = min(n, r0 + per);
     float acc = 0.0f;
-    for (int r = 0; r < n; ++r)
-        if (idx[r] == (int64_t)v) acc += dout[(size_t)r * D + d];
-    dtable[(size_t)v * D + d] += acc;
+    if (d < D)
+        for (int r = r0; r < r1; ++r)
+            if (idx[r] == (int64_t)v) acc += dout[(size_t)r * D + d];
+    red[q][c] = acc;
+    __syncthreads();
+    if (q != 0 || d >= D) return;
+    float s = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][c];
+    dtable[(size_t)v * D + d] += s;
 }
 
 // out-of-place BatchNorm normalisation: Y = act((X - mean) / sqrt(var + eps) * w + b); X is kept for the backward
@@ -632,7 +643,7 @@ extern "C" int st_relayout_batch(const st_relayout_desc* table_dev, int n, int t
 extern "C" int st_scatter_add_rows(const float* dout, const int64_t* idx, float* dtable, int n, int D, int V, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dout && idx && dtable && n > 0 && D > 0 && V > 0, "st_scatter_add_rows: bad arguments");
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(V, (D + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(V, (D + 63) / 64), dim3(512), 0, (hipStream_t)stream,
                        dout, idx, dtable, n, D, V);
     ST_LAUNCH_CHECK();
     return 0;

@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int FL_BLOCKS = 256;
+constexpr int FL_BLOCKS = 1024;
 
 __device__ __forceinline__ float fl_val(float e, int l1) { return l1 ? fabsf(e) : e * e; }
 __device__ __forceinline__ float fl_grad(float e, int l1) { return l1 ? (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f)) : 2.0f * e; }
@@ -17,15 +17,20 @@ __global__ __launch_bounds__(256) void freq_loss_kernel(const float* pred, const
     __shared__ float red[4];
     const size_t total = (size_t)B * T * D;
     float acc = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % D);
-        const int t = (int)((i / D) % T);
+    // (row, channel) of the first element and of the stride once, then carried along: no 64-bit division per element
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    const unsigned rows_step = (unsigned)(step / D), c_step = (unsigned)(step % D);
+    size_t row = i0 / D;
+    unsigned c = (unsigned)(i0 - row * D);
+    unsigned t = (unsigned)(row % T);
+    const unsigned t_step = rows_step % (unsigned)T;
+    for (size_t i = i0; i < total; i += step) {
         const float e = pred[i] - label[i];
         float v = c_all * fl_val(e, l1), g = c_all * fl_grad(e, l1);
-        if (c < n_low) { v += c_low * fl_val(e, l1); g += c_low * fl_grad(e, l1); }
+        if ((int)c < n_low) { v += c_low * fl_val(e, l1); g += c_low * fl_grad(e, l1); }
         if (c_diff != 0.0f) {
             // delta[t] = e[t+1] - e[t] contributes for t = 0..T-2; e[t] appears in delta[t] (-) and delta[t-1] (+)
-            if (t + 1 < T) {
+            if ((int)t + 1 < T) {
                 const float dl = (pred[i + D] - label[i + D]) - e;
                 v += c_diff * fl_val(dl, l1);
                 g -= c_diff * fl_grad(dl, l1);
@@ -37,6 +42,10 @@ __global__ __launch_bounds__(256) void freq_loss_kernel(const float* pred, const
         }
         dpred[i] = g;
         acc += v;
+        c += c_step; t += t_step;
+        if (c >= (unsigned)D) { c -= D; t += 1; }
+        if (t >= (unsigned)T) t -= T;
+        if (t >= (unsigned)T) t -= T;
     }
     acc = st_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -44,10 +53,12 @@ __global__ __launch_bounds__(256) void freq_loss_kernel(const float* pred, const
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void freq_loss_final_kernel(const float* partial, int n, float* loss) {
+// fixed-order sum of the block partials by one wave: lane j adds partials j, j + 64, ..., then the lanes' sums in a fixed tree
+__global__ __launch_bounds__(64) void freq_loss_final_kernel(const float* partial, int n, float* loss) {
     float s = 0.0f;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    *loss = s;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = st_wave_sum(s);
+    if (threadIdx.x == 0) *loss = s;
 }
 
 // y[i] = x[i] * (*s)
@@ -227,6 +238,8 @@ extern "C" int st_ctc_loss(const float* prob, const int64_t* text, float eps, fl
     return 0;
 }
 
+extern "C" size_t st_freq_loss_workspace_floats(void) { return FL_BLOCKS; }
+
 extern "C" int st_freq_loss(const float* pred, const float* label, float* loss, float* dpred, float* ws,
                             int B, int T, int D, int n_low, float w_all, float w_low, float w_diff, int l1, void* stream) {
     (void)hipGetLastError();
@@ -240,7 +253,7 @@ extern "C" int st_freq_loss(const float* pred, const float* label, float* loss, 
     hipLaunchKernelGGL(freq_loss_kernel, dim3(FL_BLOCKS), dim3(256), 0, st, pred, label, dpred, ws, B, T, D,
                        c_low != 0.0f ? n_low : 0, c_all, c_low, c_diff, l1);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(freq_loss_final_kernel, dim3(1), dim3(1), 0, st, ws, FL_BLOCKS, loss);
+    hipLaunchKernelGGL(freq_loss_final_kernel, dim3(1), dim3(64), 0, st, ws, FL_BLOCKS, loss);
     ST_LAUNCH_CHECK();
     return 0;
 }

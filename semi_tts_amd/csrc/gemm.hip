@@ -224,8 +224,12 @@ __global__ __launch_bounds__(GM_THREADS) void gm_kernel(const GmArgs g) {
 // give every compute unit two workgroups with 64-row tiles: one wave per SIMD cannot overlap its own address arithmetic, LDS
 // traffic and barrier with its MFMAs, a second workgroup on the SIMD can (measured: 258 workgroups of 64 x 64 ran at 0.29 of the
 // fp32 matrix peak however the barriers were arranged).
-template <bool VECW, bool POOL, int MT>
+// VECA = false: rows of A (and of W) that are not 16-byte addressable (Cin % 4 != 0: the input gradient of Linear(160, 1025) contracts
+// over 1025 columns) -- the same pipeline with four scalar loads per piece, every column clamped and masked on its own (the
+// one-block-per-barrier gm_kernel took 91 us for that product).
+template <bool VECW, bool POOL, int MT, bool VECA = true>
 __device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict__ As_, float* __restrict__ Bs_) {
+    static_assert(VECA || !POOL, "the element-wise form has no fused max-pool");
     constexpr int BM = 32 * MT;
     // two LDS buffers of TWO 16-float k-blocks each: pair kp+1 is written while pair kp is multiplied -- one barrier per 32
     // MFMAs per wave.  (r02: with one k-block per barrier an iteration took ~1350 cycles for 512 cycles of MFMAs -- one wave per
@@ -248,7 +252,7 @@ __device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict_
     const float* __restrict__ wbase = g.W + (size_t)min(wn_row, g.N - 1) * g.Cin * g.KT;
     const int t_base = ato * g.stride - g.pad;
 
-    struct Blk { f32x4 a, q, w; bool va, vw; };
+    struct Blk { f32x4 a, q, w; bool va, vw; unsigned mk; };     // mk: per-column validity of the piece (element-wise form)
     // split-K: this workgroup's k-blocks are [kb_lo, kb_hi) of the KT * cpb blocks (the whole range without a split)
     const int nkb = g.KT * g.cpb;
     const int kb_lo = g.kb_per_split > 0 ? (int)blockIdx.z * g.kb_per_split : 0;
@@ -262,6 +266,23 @@ __device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict_
         const int tap = min(tap_n, g.KT - 1), cic = min(ci, g.Cin - 4);
         const int ti = t_base + tap;
         const int tic = min(max(ti, 0), g.Tin - 1);
+        if (!VECA) {
+            const int c0 = min(ci, g.Cin - 1), c1 = min(ci + 1, g.Cin - 1), c2 = min(ci + 2, g.Cin - 1), c3 = min(ci + 3, g.Cin - 1);
+            const float* pa = abase + (size_t)tic * g.lda;
+            r.a = f32x4{pa[c0], pa[c1], pa[c2], pa[c3]};
+            r.mk = (ci < g.Cin ? 1u : 0u) | (ci + 1 < g.Cin ? 2u : 0u) | (ci + 2 < g.Cin ? 4u : 0u) | (ci + 3 < g.Cin ? 8u : 0u);
+            r.va = in_k && a_row_ok && ti >= 0 && ti < g.Tin;
+            if (VECW) {      // Linear weight (KT == 1) or tap-major conv weight: consecutive ci are adjacent
+                const float* pw = wbase + (size_t)tap * g.Cin;
+                r.w = f32x4{pw[c0], pw[c1], pw[c2], pw[c3]};
+            } else {         // torch Conv1d weight (N, Cin, KT)
+                const float* pw = wbase + tap;
+                r.w = f32x4{pw[(size_t)c0 * g.KT], pw[(size_t)c1 * g.KT], pw[(size_t)c2 * g.KT], pw[(size_t)c3 * g.KT]};
+            }
+            r.vw = in_k && w_row_ok;
+            if (++cb_n == g.cpb) { cb_n = 0; ++tap_n; }
+            return;
+        }
         const float* pa = abase + (size_t)tic * g.lda + cic;
         r.a = st_ld4(pa);
         if (POOL) r.q = st_ld4(tic > 0 ? pa - g.lda : pa);       // MaxPool1d(2, stride 1, padding 1)[:T] fused into the load
@@ -279,8 +300,13 @@ __device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict_
         f32x4 va = r.a;
         if (POOL) { va[0] = fmaxf(va[0], r.q[0]); va[1] = fmaxf(va[1], r.q[1]); va[2] = fmaxf(va[2], r.q[2]); va[3] = fmaxf(va[3], r.q[3]); }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 vw = r.w;
+        if (!VECA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (!(r.mk & (1u << j))) { va[j] = 0.0f; vw[j] = 0.0f; }
+        }
         if (a_stage) *reinterpret_cast<f32x4*>(As[buf][half] + srow * GM_LD + skq * 4) = r.va ? va : z;
-        *reinterpret_cast<f32x4*>(Bs[buf][half] + srow * GM_LD + skq * 4) = r.vw ? r.w : z;
+        *reinterpret_cast<f32x4*>(Bs[buf][half] + srow * GM_LD + skq * 4) = r.vw ? vw : z;
     };
     f32x4 acc[MT][2];
 #pragma unroll
@@ -330,11 +356,11 @@ __device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict_
     gm_epilogue<MT>(g, acc, m0, n0, wm, wn, lane);
 }
 
-template <bool VECW, bool POOL, int MT = 2>
+template <bool VECW, bool POOL, int MT = 2, bool VECA = true>
 __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[4 * (32 * MT) * GM_LD];
     __shared__ __attribute__((aligned(16))) float Bs[4 * GM_BN * GM_LD];
-    gm_pipe_body<VECW, POOL, MT>(g, As, Bs);
+    gm_pipe_body<VECW, POOL, MT, VECA>(g, As, Bs);
 }
 
 // several jobs in one launch (blockIdx.z = job, longest reductions first): the conv bank's K convs over the same input.  A launch
@@ -586,6 +612,13 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
         else if (pool_prev) GM_LAUNCH(false, true);
         else GM_LAUNCH(false, false);
 #undef GM_LAUNCH
+    } else if (!pool_prev && Cin >= 4 && S == 1) {
+        // rows that are not 16-byte addressable: the pipelined kernel in its element-wise form.  W counts as "adjacent in ci" when it is
+        // a Linear weight or tap-major, whatever its alignment
+        const bool adj = KT == 1 || (ep && ep->w_tap_major);
+        // (64-row tiles whatever the grid: with 32-row tiles half the threads sit out the scalar A loads -- 124 vs 68 us measured)
+        if (adj) hipLaunchKernelGGL((gm_pipe_kernel<true, false, 2, false>), grid, dim3(GM_THREADS), 0, st, g);
+        else hipLaunchKernelGGL((gm_pipe_kernel<false, false, 2, false>), grid, dim3(GM_THREADS), 0, st, g);
     } else if (vecw) hipLaunchKernelGGL((gm_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, g);
     else hipLaunchKernelGGL((gm_kernel<false, false>), grid, dim3(GM_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();

@@ -138,6 +138,19 @@ int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
                             float* c_out, int ldc, float* gates_out,
                             const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
                             int B, int H, void* stream);
+/* The arguments of st_lstm_cell_packed_fwd as a struct, and two independent cells in ONE launch: under teacher forcing the decoder
+ * cell of step t and the query cell of step t+1 both only wait for the attention of step t (src/module.py:216-288 with a teacher
+ * frame as the next input).  Falls back to one launch per cell for shapes the 2-D tiled kernel does not take. */
+typedef struct st_lstm_cell_packed_job {
+    const float* packed_w; st_t16_view x; int K;
+    const float* b_ih; const float* b_hh;
+    const float* c_prev; int ldc_prev; const float* mask;
+    st_t16_view h_dst0; st_t16_view h_dst1;      /* h_dst1.base may be NULL */
+    float* c_out; int ldc; float* gates_out;
+    const float* ada_std; const float* ada_mean; st_t16_view hadapt_dst;   /* hadapt_dst.base may be NULL */
+    int B, H;
+} st_lstm_cell_packed_job;
+int st_lstm_cell_packed_pair_fwd(const st_lstm_cell_packed_job* j0, const st_lstm_cell_packed_job* j1, void* stream);
 /* st_skinny_linear_fwd on packed operands; output natural (y) and/or T16 (y_dst).
  * Optional third row range [n_split2, N): v = act2(v) * mask2(b, n - n_split2) -> y3_dst column
  * n - n_split2 (used to emit prenet layer 1 of the next step from the same launch as proj/gate). */
@@ -599,6 +612,8 @@ typedef struct st_decoder_io {
     unsigned* handoff_status;          /* optional device word for pq_granules: bit 0 = an in-launch hand-off timed out (a starved launch:
                                         * the waiting workgroups were not co-resident with their producers).  Sticky; owned, zeroed and
                                         * read by the caller after the forward -- a time-out is an ERROR, not a NaN to find later */
+    int pair_cells;                    /* != 0 (with defer_proj, i.e. pure teacher forcing): the decoder cell of step t and the query cell of
+                                        * step t+1 share one launch (st_lstm_cell_packed_pair_fwd) -- neither needs the other's output */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);

@@ -70,7 +70,8 @@ class StDecoderIO(C.Structure):
                 ('gates_q_tape', C.c_void_p), ('gates_d_tape', C.c_void_p), ('attn_s_buf', C.c_void_p), ('attn_pre_parts', C.c_int), ('attn_fin_parts', C.c_int), ('defer_proj', C.c_int),
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p),
                 ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p),
-                ('dec_in0', C.c_void_p), ('pre_nat', C.c_void_p), ('attn_xchg', C.c_void_p), ('handoff_status', C.c_void_p)]
+                ('dec_in0', C.c_void_p), ('pre_nat', C.c_void_p), ('attn_xchg', C.c_void_p), ('handoff_status', C.c_void_p),
+                ('pair_cells', C.c_int)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -98,6 +99,13 @@ class StLstmPwJob(C.Structure):
                 ('scale2', C.c_void_p), ('mask', C.c_void_p), ('gates', C.c_void_p), ('c', C.c_void_p), ('ldc', C.c_int),
                 ('c_prev', C.c_void_p), ('ldcp', C.c_int), ('dc', C.c_void_p), ('dgates', C.c_void_p), ('ldg', C.c_int),
                 ('dgates_t16', StT16View)]
+
+
+class StLstmCellPackedJob(C.Structure):
+    _fields_ = [('packed_w', C.c_void_p), ('x', StT16View), ('K', C.c_int), ('b_ih', C.c_void_p), ('b_hh', C.c_void_p),
+                ('c_prev', C.c_void_p), ('ldc_prev', C.c_int), ('mask', C.c_void_p), ('h_dst0', StT16View), ('h_dst1', StT16View),
+                ('c_out', C.c_void_p), ('ldc', C.c_int), ('gates_out', C.c_void_p), ('ada_std', C.c_void_p), ('ada_mean', C.c_void_p),
+                ('hadapt_dst', StT16View), ('B', C.c_int), ('H', C.c_int)]
 
 
 class StAttnBwdJob(C.Structure):
@@ -180,6 +188,7 @@ SIGNATURES = {
     'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
     'st_lstm_cell_packed_fwd': [P, C.POINTER(StT16View), I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
                                 P, I, P, P, P, C.POINTER(StT16View), I, I, P],
+    'st_lstm_cell_packed_pair_fwd': [C.POINTER(StLstmCellPackedJob), C.POINTER(StLstmCellPackedJob), P],
     'st_skinny_linear_packed_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                     I, I, P, I, C.POINTER(StT16View), I, I, P],
     'st_attn_step_t16_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, C.POINTER(StT16View), I, P, I, I, I, I, I, I, I, P],

@@ -268,6 +268,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                            sv.q_floats, sv.q_kbs, steps, B, P);
         ST_LAUNCH_CHECK();
     }
+    // teacher-forced training (deferred projection): [decoder cell of t | query cell of t+1] as one launch
+    const bool pair_cells = defer && pure_tf && io->pair_cells;
     for (int t = 0; t < steps; ++t) {
         float* xq = io->xq_tape + (size_t)t * sv.q_floats;
         float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
@@ -281,7 +283,9 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view xq_v = {xq, sv.q_kbs, 0};
         st_t16_view hq_dst = {xq_next, sv.q_kbs, sv.q_h};
         st_t16_view ha_dst = {xd, sv.d_kbs, sv.d_ha};
-        if (!ST_SKIPPED(0)) rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, Kq, w->q_b_ih, w->q_b_hh,
+        // (pair_cells: the query cell of step t > 0 ran beside the decoder cell of step t-1, see step 4)
+        if (!ST_SKIPPED(0) && !(pair_cells && t > 0))
+                            rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, Kq, w->q_b_ih, w->q_b_hh,
                                      io->cq_tape + (size_t)t * BQ, Q, io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
                                      &hq_dst, nullptr, io->cq_tape + (size_t)(t + 1) * BQ, Q,
                                      io->gates_q_tape ? io->gates_q_tape + (size_t)t * 4 * BQ : nullptr,
@@ -355,6 +359,24 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view xd_v = {xd, sv.d_kbs, 0};
         st_t16_view hd_dst0 = {xd_next, sv.d_kbs, sv.d_h};
         st_t16_view hd_dst1 = {xo, sv.o_kbs, 0};
+        if (pair_cells && t + 1 < steps) {
+            // teacher forcing: the query cell of step t+1 needs ctx_t, h_q_t and a teacher frame -- not h_d_t.  Both cells in one launch.
+            st_lstm_cell_packed_job jd, jq;
+            memset(&jd, 0, sizeof(jd)); memset(&jq, 0, sizeof(jq));
+            jd.packed_w = io->packed + pl.d; jd.x = xd_v; jd.K = Kd; jd.b_ih = w->d_b_ih; jd.b_hh = w->d_b_hh;
+            jd.c_prev = io->cd_tape + (size_t)t * BD; jd.ldc_prev = D; jd.mask = io->d_mask ? io->d_mask + (size_t)t * BD : nullptr;
+            jd.h_dst0 = hd_dst0; jd.h_dst1 = hd_dst1; jd.c_out = io->cd_tape + (size_t)(t + 1) * BD; jd.ldc = D;
+            jd.gates_out = io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr;
+            jd.B = B; jd.H = D;
+            float* xq_next2 = io->xq_tape + (size_t)(t + 2) * sv.q_floats;
+            jq.packed_w = io->packed + pl.q; jq.x = st_t16_view{xq_next, sv.q_kbs, 0}; jq.K = Kq; jq.b_ih = w->q_b_ih; jq.b_hh = w->q_b_hh;
+            jq.c_prev = io->cq_tape + (size_t)(t + 1) * BQ; jq.ldc_prev = Q; jq.mask = io->q_mask ? io->q_mask + (size_t)(t + 1) * BQ : nullptr;
+            jq.h_dst0 = st_t16_view{xq_next2, sv.q_kbs, sv.q_h}; jq.c_out = io->cq_tape + (size_t)(t + 2) * BQ; jq.ldc = Q;
+            jq.gates_out = io->gates_q_tape ? io->gates_q_tape + (size_t)(t + 1) * 4 * BQ : nullptr;
+            jq.ada_std = io->ada_std; jq.ada_mean = io->ada_mean; jq.hadapt_dst = st_t16_view{xd_next, sv.d_kbs, sv.d_ha};
+            jq.B = B; jq.H = Q;
+            rc = st_lstm_cell_packed_pair_fwd(&jd, &jq, stream);
+        } else
         if (!ST_SKIPPED(3)) rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, Kd, w->d_b_ih, w->d_b_hh,
                                      io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                      &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,

@@ -487,14 +487,12 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
 // launch order (= the same XCD under round-robin placement), so the second read is an L2 hit.
 // AUX0 / AUX1: cache policy of the weight loads of the workgroup's first / second row tile (0 default, 2 = nt)
 template <int KW, int TRIP, int NB, int AUX0 = 0, int AUX1 = 0>
-__global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, const f32x4* xp, const int w_kbs, const int x_kbs, const int KB,
-                                                          const int B, const int H, const PkArgs rest) {
+__device__ __forceinline__ void pk_lstm_rt2_body(const f32x4* wp, const f32x4* xp, const int w_kbs, const int x_kbs, const int KB,
+                                                 const int B, const int H, const PkArgs& a, const int bx, const int by, f32x4* red) {
     constexpr int RT = 2;
-    __shared__ f32x4 red[KW * RT * NB * 64];
     RT2_PROF(0);
-    const PkArgs& a = rest;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile0 = blockIdx.x * RT, bt_base = blockIdx.y * NB;          // host: B in 49..64, so both batch tiles of a half exist
+    const int tile0 = bx * RT, bt_base = by * NB;          // host: B in 49..64, so both batch tiles of a half exist
     __amdgpu_buffer_rsrc_t rw[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -503,7 +501,7 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
     const unsigned voff = (unsigned)lane * 16u;
     constexpr int STEP = KW * TRIP;
     const int G = (KB + STEP - 1) / STEP;
-    const int rot = (int)((((unsigned)blockIdx.x & 255u) * (unsigned)G) >> 8);
+    const int rot = (int)((((unsigned)bx & 255u) * (unsigned)G) >> 8);
     auto kb_of = [&](int gq) { int q = gq + rot; if (q >= G) q -= G; return q * STEP + wave; };
     struct Regs { f32x4 w[TRIP][RT]; f32x4 x[TRIP][NB]; };
     auto load = [&](Regs& r, int kb) __attribute__((always_inline)) {
@@ -608,6 +606,27 @@ __global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, c
         gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
     }
     RT2_PROF(5);
+}
+
+template <int KW, int TRIP, int NB, int AUX0 = 0, int AUX1 = 0>
+__global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_kernel(const f32x4* wp, const f32x4* xp, const int w_kbs, const int x_kbs, const int KB,
+                                                          const int B, const int H, const PkArgs rest) {
+    __shared__ f32x4 red[KW * 2 * NB * 64];
+    pk_lstm_rt2_body<KW, TRIP, NB, AUX0, AUX1>(wp, xp, w_kbs, x_kbs, KB, B, H, rest, blockIdx.x, blockIdx.y, red);
+}
+
+// Two independent cells in one launch (teacher-forced training: the decoder cell of step t and the query cell of step t+1 both
+// only wait for the attention of step t): the first n0 workgroups run cell 0, the others cell 1; within a cell the two batch halves
+// of a row-tile pair are half a cell apart in launch order, as in the single launch (same XCD: the second weight read is an L2 hit).
+template <int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_lstm_rt2_pair_kernel(const int n0, const PkArgs a0, const PkArgs a1) {
+    __shared__ f32x4 red[KW * 2 * 1 * 64];
+    const bool second = (int)blockIdx.x >= n0;
+    const PkArgs& a = second ? a1 : a0;
+    const int i = second ? (int)blockIdx.x - n0 : (int)blockIdx.x;
+    const int half = a.H >> 3;                  // row-tile pairs of the cell (H / 4 tiles, two per workgroup)
+    const int by = i >= half ? 1 : 0;
+    pk_lstm_rt2_body<KW, TRIP, 1>(a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a, i - by * half, by, red);
 }
 
 // The arguments the prologue needs come first and as plain scalars: with -mllvm -amdgpu-kernarg-preload-count=16 (build.py) the
@@ -931,6 +950,42 @@ extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view*
     a.h_dst[0] = pk_out(h_dst0); a.h_dst[1] = pk_out(h_dst1);
     a.ada_std = ada_std; a.ada_mean = ada_mean; a.ha_dst = pk_out(hadapt_dst);
     return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
+}
+
+static int pk_lstm_fill(PkArgs& a, const st_lstm_cell_packed_job* j, const char* who) {
+    ST_CHECK_ARG(j && j->B > 0 && j->H > 0 && j->H % 4 == 0 && j->c_out && j->h_dst0.base, "%s: bad arguments", who);
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, j->packed_w, &j->x, j->K, who);
+    if (rc) return rc;
+    a.B = j->B; a.N = 4 * j->H; a.H = j->H;
+    a.b_ih = j->b_ih; a.b_hh = j->b_hh;
+    a.c_prev = j->c_prev; a.ldc_prev = j->ldc_prev; a.mask = j->mask;
+    a.c_out = j->c_out; a.ldc = j->ldc; a.gates_out = j->gates_out;
+    a.h_dst[0] = pk_out(&j->h_dst0); a.h_dst[1] = pk_out(&j->h_dst1);
+    a.ada_std = j->ada_std; a.ada_mean = j->ada_mean; a.ha_dst = pk_out(&j->hadapt_dst);
+    return 0;
+}
+
+// two independent LSTM cells (the arguments of st_lstm_cell_packed_fwd as structs): one launch when both take the 2-D tiled kernel
+// with one batch tile per workgroup (B = 17..32), otherwise one launch each
+extern "C" int st_lstm_cell_packed_pair_fwd(const st_lstm_cell_packed_job* j0, const st_lstm_cell_packed_job* j1, void* stream) {
+    (void)hipGetLastError();
+    PkArgs a0, a1;
+    int rc = pk_lstm_fill(a0, j0, "st_lstm_cell_packed_pair_fwd");
+    if (rc) return rc;
+    rc = pk_lstm_fill(a1, j1, "st_lstm_cell_packed_pair_fwd");
+    if (rc) return rc;
+    const int t0 = a0.H / 4, t1 = a1.H / 4;
+    const bool pair = pk_rt2_shape(a0.B, t0) && pk_rt2_shape(a1.B, t1) && ((a0.B + 15) >> 4) == 2 && ((a1.B + 15) >> 4) == 2 &&
+                      a0.H % 8 == 0 && a1.H % 8 == 0;
+    if (!pair) {
+        rc = pk_dispatch<0>(a0, t0, (hipStream_t)stream);
+        if (rc) return rc;
+        return pk_dispatch<0>(a1, t1, (hipStream_t)stream);
+    }
+    hipLaunchKernelGGL((pk_lstm_rt2_pair_kernel<PK_LSTM_KW, PK_LSTM_TRIP>), dim3(t0 + t1), dim3(PK_LSTM_KW * 64), 0, (hipStream_t)stream, t0, a0, a1);
+    ST_LAUNCH_CHECK();
+    return 0;
 }
 
 static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,

@@ -355,6 +355,7 @@ class Decoder(nn.Module):
         self.attn_split_positions = 43
         self.bwd_fuse_pointwise = True   # training (teacher forcing): the cells' pointwise backward in the epilogues of the loop's products
         self.bwd_overlap_attn = True     # ... and the decoder cell's product of step t-1 beside the attention backward of step t (one launch)
+        self.fwd_pair_cells = True       # teacher-forced forward: the decoder cell of step t and the query cell of step t+1 in one launch
         self.attn_rng_one_launch = True   # long texts: query projection + fin part over position ranges + combine in one launch
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -578,6 +579,7 @@ class Decoder(nn.Module):
         pure_tf = teacher_pre is not None and Bt == B and all(step_src[t] == min(t, Tt - 1) for t in range(steps - 1))
         defer = bool(keep_tapes and pure_tf)
         io.defer_proj = 1 if defer else 0
+        io.pair_cells = 1 if (defer and self.fwd_pair_cells) else 0
         if self.attn_split and (not self.training or defer):
             if keep_tapes:      # training: S and the location features of every step stay for the backward pass
                 tapes['attn_s'] = torch.empty(steps, B, L, A, **f32)

@@ -929,6 +929,7 @@ def test_bptt_loop_with_hosted_attention_backward_is_bitwise_the_plain_loop(dev)
     for mode in ('overlap', 'plain', 'six'):
         dec.bwd_overlap_attn = mode == 'overlap'
         dec.bwd_fuse_pointwise = mode != 'six'
+        dec.fwd_pair_cells = mode == 'overlap'          # (the forward's paired LSTM cells too: same work, one launch for two cells)
         for p in dec.parameters():
             p.grad = None
         torch.manual_seed(77)                                   # the same dropout masks in every pass
@@ -939,7 +940,7 @@ def test_bptt_loop_with_hosted_attention_backward_is_bitwise_the_plain_loop(dev)
         torch.autograd.backward([mel, align, stop], douts)
         res[mode] = dict(mel=mel.detach().clone(), dmem=mem.grad.clone(), dspk=spk.grad.clone(),
                          **{k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
-    dec.bwd_overlap_attn = dec.bwd_fuse_pointwise = True
+    dec.bwd_overlap_attn = dec.bwd_fuse_pointwise = dec.fwd_pair_cells = True
     assert len(res['overlap']) > 20
     for k, v in res['overlap'].items():
         assert torch.equal(v, res['plain'][k]), k

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--config', default='config/semi-single-spkr-paired-data.yaml')
     ap.add_argument('--no-fuse-pw', action='store_true', help='six launches per backward step (pointwise LSTM backward as launches of its own)')
     ap.add_argument('--no-overlap-attn', action='store_true', help='attention backward and the decoder cell product as separate launches')
+    ap.add_argument('--no-pair-cells', action='store_true', help='the two LSTM cells of a teacher-forced forward step as separate launches')
     a = ap.parse_args()
     from semi_tts_amd.solver import TtsTrainer
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,6 +39,8 @@ def main():
         tr.model.tts.decoder.bwd_fuse_pointwise = False
     if a.no_overlap_attn:
         tr.model.tts.decoder.bwd_overlap_attn = False
+    if a.no_pair_cells:
+        tr.model.tts.decoder.fwd_pair_cells = False
     phases = dict(fwd=0.0, bwd=0.0, opt=0.0)
     sync = torch.cuda.synchronize
     stats = None

@@ -206,11 +206,13 @@ class _ParamLayouts:
     KT = 1 the transpose of a Linear weight).  Keyed on (storage address, shape, mode); an entry holds a detached alias of the
     parameter (same storage and version counter) and is valid while the version counter has not moved.  When ANY entry is found
     stale (the optimiser has stepped), ALL entries are refreshed by ONE launch (st_relayout_batch): training re-lays out ~40 weights
-    per step, one torch copy each in round 2.  Entries nobody asked for during the last 8 epochs (steps) are dropped."""
+    per step, one torch copy each in round 2.  Entries nobody asked for during the last 8 epochs (steps) are dropped -- except those a
+    hipGraph capture has seen (the graph holds the buffer's address; a refresh rewrites it in place, so a replay after a weight
+    update reads the new layout)."""
     MAX_ENTRIES = 1024
 
     def __init__(self):
-        self.entries = {}       # key -> [alias, dst, version, (N, Cin, KT), epoch of the last use]
+        self.entries = {}       # key -> [alias, dst, version, (N, Cin, KT), epoch of the last use, pinned]
         self.table = None       # device descriptor table of the entries
         self.count = 0
         self.total_blocks = 0
@@ -223,6 +225,8 @@ class _ParamLayouts:
         e = self.entries.get(key)
         if e is not None:
             e[4] = self.epoch
+            if capturing():
+                e[5] = True                  # a hipGraph now holds this buffer's address: the entry is never dropped (and refreshed in place)
             if e[2] != e[0]._version:
                 self.epoch += 1              # (a weight has moved: a new optimisation step -- entries age by these, not by launches)
                 e[4] = self.epoch
@@ -232,10 +236,10 @@ class _ParamLayouts:
         KT = int(w.shape[2]) if w.dim() == 3 else 1
         assert w.is_contiguous() and w.dtype == torch.float32
         if len(self.entries) >= self.MAX_ENTRIES:          # (inference-only processes never refresh: bound the table by age)
-            for k in sorted(self.entries, key=lambda k: self.entries[k][4])[:self.MAX_ENTRIES // 2]:
+            for k in [k for k in sorted(self.entries, key=lambda k: self.entries[k][4]) if not self.entries[k][5]][:self.MAX_ENTRIES // 2]:
                 del self.entries[k]
         dst = torch.empty((N, KT, Cin) if mode == 0 else (Cin, KT, N), device=w.device, dtype=torch.float32)
-        self.entries[key] = [w.detach(), dst, -1, (N, Cin, KT), self.epoch]
+        self.entries[key] = [w.detach(), dst, -1, (N, Cin, KT), self.epoch, capturing()]
         self.dirty = True
         self.refresh()
         return dst
@@ -243,7 +247,7 @@ class _ParamLayouts:
     def refresh(self):
         lib = _lib.load()
         self.refreshes += 1
-        drop = [k for k, e in self.entries.items() if self.epoch - e[4] > 8]
+        drop = [k for k, e in self.entries.items() if self.epoch - e[4] > 8 and not e[5]]
         for k in drop:
             del self.entries[k]
             self.dirty = True

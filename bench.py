@@ -514,9 +514,12 @@ def bench_train(args, rk):
     tr = TtsTrainer(config, paras, 'train').load_data().set_model()
     batch = [t.to(rk.dev) for t in tr.batches[0]]
     last = {}
+    # no host round trip inside a step (statistics read after the timed region, NaN steps skipped on the device): the host issues
+    # step k+1 while the GPU finishes step k.  --sync-stats restores the reference's per-step loss.item() / isnan(grad_norm) reads
+    tr.async_stats = not args.sync_stats
 
     def step():
-        last.update(tr.train_step(*batch))
+        last['st'] = tr.train_step(*batch)
 
     step()
     variants = {}
@@ -555,7 +558,7 @@ def bench_train(args, rk):
             'roofline': {'bound': 'mfma', 'kernel': 'whole training step (~1.25k launches; the largest shares are the weight-gradient GEMM tn_kernel and the per-step products of the BPTT loop)',
                          'achieved': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None},
-            'last': {k: last[k] for k in ('loss', 'grad_norm')}, 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'last': {k: float(last['st'][k]) for k in ('loss', 'grad_norm')}, 'stats_read': 'per step' if args.sync_stats else 'after the timed steps', 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             **({'cpu_baseline': cpu} if cpu is not None else {})}
 
 
@@ -593,6 +596,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-graph', action='store_true', help='issue the decode loop eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sync-stats', action='store_true', help='--workload train: read loss / grad norm on the host every step (as the reference does)')
     ap.add_argument('--pre-parts', type=int, default=0, help=argparse.SUPPRESS)      # experiment: workgroups per utterance of the attention pre part
     ap.add_argument('--vq-head-only', action='store_true', help='c3: only the headline case (32 x 129 vectors, V = 512): PMC passes')
     ap.add_argument('--dist', action='store_true',

@@ -786,6 +786,12 @@ int st_mt_clip_scale(float* const* g, const long* n, int nt, const float* norm, 
  * p -= step_size * m / (sqrt(v)/bias_correction2_sqrt + eps), step_size = lr / (1 - b1^t) */
 int st_mt_adam(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,
                float beta1, float beta2, float eps, float step_size, float bias_correction2_sqrt, void* stream);
+/* st_mt_adam that leaves parameters and moments untouched when *guard_norm (a device scalar: the gradient norm st_mt_grad_norm wrote)
+ * is NaN or inf -- BaseSolver.backward's `if math.isnan(grad_norm): ... else: self.optimizer.step()` (src/solver.py:147-150) decided
+ * on the device, so a training loop need not wait for the norm on the host every step.  guard_norm NULL = st_mt_adam. */
+int st_mt_adam_guarded(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,
+                       float beta1, float beta2, float eps, float step_size, float bias_correction2_sqrt,
+                       const float* guard_norm, void* stream);
 
 /* ------------------------------------------------------------------ small utilities */
 int st_fill(float* p, float v, size_t n, void* stream);

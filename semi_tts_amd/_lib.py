@@ -232,6 +232,7 @@ SIGNATURES = {
     'st_mt_grad_norm': [P, P, I, P, P, P],
     'st_mt_clip_scale': [P, P, I, P, F, P],
     'st_mt_adam': [P, P, P, P, P, I, F, F, F, F, F, P],
+    'st_mt_adam_guarded': [P, P, P, P, P, I, F, F, F, F, F, P, P],
     'st_freq_loss': [P, P, P, P, P, I, I, I, I, F, F, F, I, P],
     'st_freq_loss_workspace_floats': [],
     'st_scale_by': [P, P, P, Z, P],

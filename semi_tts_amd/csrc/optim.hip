@@ -59,6 +59,9 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
             for (long j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) g[j] *= coef;
         }
     } else {
+        // guarded form (st_mt_adam_guarded): no update at all when the gradient norm of this step is NaN / inf -- the decision the
+        // reference takes on the host (`if math.isnan(grad_norm)`: skip optimizer.step(), src/solver.py:147-150) without a host round trip
+        if (a.norm && !(fabsf(*a.norm) <= 3.0e38f)) return;
         float* __restrict__ p = a.p[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
         const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
         auto upd = [&](float gr, float& pi, float& mi, float& vi) {
@@ -151,12 +154,19 @@ extern "C" int st_mt_clip_scale(float* const* g, const long* n, int nt, const fl
     return mt_run<1>(a, nullptr, g, nullptr, nullptr, n, nt, (hipStream_t)stream, nullptr);
 }
 
-extern "C" int st_mt_adam(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,
-                          float beta1, float beta2, float eps, float step_size, float bias_correction2_sqrt, void* stream) {
+extern "C" int st_mt_adam_guarded(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,
+                                  float beta1, float beta2, float eps, float step_size, float bias_correction2_sqrt,
+                                  const float* guard_norm, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(p && g && m && v && n && nt > 0 && bias_correction2_sqrt > 0.0f, "st_mt_adam: bad arguments");
     MtArgs a;
     memset(&a, 0, sizeof(a));
     a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.step_size = step_size; a.bc2_sqrt = bias_correction2_sqrt;
+    a.norm = guard_norm;
     return mt_run<2>(a, p, g, m, v, n, nt, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int st_mt_adam(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,
+                          float beta1, float beta2, float eps, float step_size, float bias_correction2_sqrt, void* stream) {
+    return st_mt_adam_guarded(p, g, m, v, n, nt, beta1, beta2, eps, step_size, bias_correction2_sqrt, nullptr, stream);
 }

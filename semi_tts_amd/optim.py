@@ -43,8 +43,11 @@ class Optimizer:
         self.opt.zero_grad()
         return self.tf_rate(step)
 
-    def step(self):
-        self.opt.step()
+    def step(self, guard_norm=None):
+        if guard_norm is not None and isinstance(self.opt, FusedAdam):
+            self.opt.step(guard_norm=guard_norm)
+        else:
+            self.opt.step()
 
     def create_msg(self):
         return ['Optim.spec.| Algo. = {}\t| Lr/sampling/rec.loss scheduler = {}/{}/{}'.format(
@@ -111,7 +114,10 @@ class FusedAdam(torch.optim.Optimizer):
         self._cache = {}
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, guard_norm=None):
+        """guard_norm: optional 0-dim device tensor (the gradient norm of this step): a NaN / inf value makes the update a no-op ON THE
+        DEVICE (the reference's host-side `if math.isnan(grad_norm)` skip without waiting for the norm).  The host-side step counts
+        advance either way (bias corrections one step ahead after such an event)."""
         from . import _lib, ops
         lib = _lib.load()
         cache = self.__dict__.setdefault('_cache', {})
@@ -144,8 +150,10 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError('FusedAdam: gradients must be contiguous fp32 tensors')
                 gp, _ = _tables(grads)
                 bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
-                _lib.check(lib.st_mt_adam(pp, gp, mp, vp, sizes, len(plist), float(b1), float(b2), float(group['eps']),
-                                          float(group['lr'] / bc1), float(bc2 ** 0.5), ops.stream_handle()), 'st_mt_adam')
+                _lib.check(lib.st_mt_adam_guarded(pp, gp, mp, vp, sizes, len(plist), float(b1), float(b2), float(group['eps']),
+                                                  float(group['lr'] / bc1), float(bc2 ** 0.5),
+                                                  ops._p(guard_norm) if guard_norm is not None else None, ops.stream_handle()),
+                           'st_mt_adam')
                 # the kernel wrote the parameters behind torch's back: bump their version counters so that everything keyed on
                 # them (tap-major / packed weight copies, autograd's saved-tensor checks) sees the in-place update
                 for p in plist:

@@ -147,6 +147,27 @@ class SpecgramGenerator(BaseSolver):
         return cnt
 
 
+class LazyStats(dict):
+    """step statistics whose device scalars become Python floats when they are READ (st['loss'], st.items(), ...): a training loop
+    that only logs every n-th step never waits for the GPU in between (TtsTrainer.async_stats)"""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if torch.is_tensor(v):
+            v = float(v)
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+
 class TtsTrainer(BaseSolver):
     """Synthetic-batch counterpart of the paired TTS branch of VqvaeTrainer.exec (bin/train_vqvae.py:132-270)
     with BaseSolver.backward (src/solver.py:138-151): per step
@@ -159,6 +180,7 @@ class TtsTrainer(BaseSolver):
     Forward, loss, backward, gradient clipping and Adam all run on the HIP kernels (semi_tts_amd/autograd.py,
     semi_tts_amd/optim.py).  The ASR/CTC half of the reference's step is outside the hot path."""
     GRAD_CLIP = 5.0
+    async_stats = False      # True: train_step never waits for the GPU -- LazyStats, NaN steps skipped on the device (optim.FusedAdam guard)
 
     @staticmethod
     def clip_grad_norm_(params, max_norm):
@@ -235,6 +257,13 @@ class TtsTrainer(BaseSolver):
         total.backward()
         self._reduce_gradients()
         grad_norm = self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
+        if self.async_stats and torch.is_tensor(grad_norm) and grad_norm.is_cuda:
+            # no host round trip inside the step: the NaN check of BaseSolver.backward (src/solver.py:147-150) runs on the device (a
+            # non-finite norm makes the Adam launch a no-op) and the statistics stay device scalars until somebody reads them
+            self.optimizer.step(guard_norm=grad_norm)
+            self.step += 1
+            return LazyStats(loss=total.detach(), mel_loss=mel_loss.detach(), linear_loss=linear_loss.detach(), grad_norm=grad_norm,
+                             tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
         gn = float(grad_norm)
         if gn != gn:
             self.verbose('Error : grad norm is NaN @ step ' + str(self.step))

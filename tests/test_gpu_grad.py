@@ -945,3 +945,53 @@ def test_bptt_loop_with_hosted_attention_backward_is_bitwise_the_plain_loop(dev)
     for k, v in res['overlap'].items():
         assert torch.equal(v, res['plain'][k]), k
         assert relerr(v, res['six'][k]) < 1e-5, k
+
+
+def test_async_training_step_equals_the_synchronous_one_and_skips_nan_steps_on_device(dev):
+    """TtsTrainer.async_stats: no host read inside the step (LazyStats; Adam guarded by the device-side gradient norm).  Two steps give
+    bit-identical weights and statistics to the synchronous trainer; a step whose gradient norm is NaN leaves weights and Adam moments
+    untouched, as BaseSolver.backward's `if math.isnan(grad_norm)` does (src/solver.py:147-150)."""
+    from argparse import Namespace
+    from conftest import load_golden
+    from helpers import masks_to, split_masks, tiny_vqvae
+    from semi_tts_amd.optim import Optimizer
+    from semi_tts_amd.solver import LazyStats, TtsTrainer
+    W, A, meta = load_golden('train_step_tiny')
+    hp, h = meta['hp'], meta['hparas']
+    config = dict(data=dict(audio=meta['audio'], corpus=dict(batch_size=3)), hparas=h, model=meta['model'])
+    text, sid, mel, linear = (A[k].to(dev) for k in ('text', 'sid', 'mel', 'linear'))
+    B, steps = text.shape[0], mel.shape[1] // hp['n_frames_per_step']
+
+    def run(async_stats, poison=False):
+        tr = TtsTrainer(config, Namespace(vocab_size=meta['vocab_size'], n_spkr=meta['n_spkr'], verbose=False, max_step=2), 'train')
+        tr.model = tiny_vqvae(meta, W, dev).train()
+        tr.optimizer = Optimizer(tr.model.parameters(), h['optimizer'], h['lr'], h['lr_scheduler'], tf_start=h['tf_start'],
+                                 tf_end=h['tf_end'], tf_step=h['tf_step'])
+        tr.async_stats = async_stats
+        out, pos = [], 0
+        for n in meta['n_masks']:
+            masks = masks_to(split_masks(A['mask'][pos:pos + n], hp, True, 1.0, B, B, steps, list(range(steps)), hp['prenet_dim']), dev)
+            pos += n
+            m = mel.clone()
+            if poison:
+                m[0, 0, 0] = float('nan')
+            out.append(tr.train_step(text, sid, m, linear, _masks=masks))
+        return tr, out
+    tr_s, st_s = run(False)
+    tr_a, st_a = run(True)
+    assert isinstance(st_a[0], LazyStats) and torch.is_tensor(dict.__getitem__(st_a[0], 'loss'))      # nothing was read inside the step
+    for a, s in zip(st_a, st_s):
+        assert a['loss'] == s['loss'] and a['grad_norm'] == s['grad_norm'] and a['lr'] == s['lr']
+    trained = [k for k, p in tr_s.model.named_parameters() if p.grad is not None]     # (the ASR branch is not part of this step and is
+    assert len(trained) > 50                                                           #  initialised randomly per construction)
+    sd_a, sd_s = dict(tr_a.model.named_parameters()), dict(tr_s.model.named_parameters())
+    for k in trained:
+        assert torch.equal(sd_a[k].detach(), sd_s[k].detach()), k
+    tr_n, st_n = run(True, poison=True)
+    assert st_n[0]['grad_norm'] != st_n[0]['grad_norm']                       # NaN gradient norm ...
+    w0 = {k: v.to(dev) for k, v in tiny_vqvae(meta, W, dev).state_dict().items()}
+    for k, p in tr_n.model.named_parameters():                                # ... and no parameter moved
+        if k in W:
+            assert torch.equal(p.detach(), w0[k]), k
+    for st in tr_n.optimizer.opt.state.values():
+        assert float(st['exp_avg'].abs().max()) == 0.0 and float(st['exp_avg_sq'].abs().max()) == 0.0

@@ -31,6 +31,8 @@ parser.add_argument('--batch-size', default=None, type=int)
 parser.add_argument('--n-batches', default=1, type=int)
 parser.add_argument('--max-step', default=None, type=int, help='training steps (default: hparas.max_step)')
 parser.add_argument('--save', action='store_true', help='write ckpt/<name>/latest.pth ({model, optimizer, global_step}) after training')
+parser.add_argument('--async-stats', action='store_true', help='training: no host read of loss / gradient norm inside a step (read when logged; '
+                    'a NaN gradient norm skips the update on the device)')
 
 
 def main():

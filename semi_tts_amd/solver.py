@@ -195,6 +195,8 @@ class TtsTrainer(BaseSolver):
         self.tts_weight = float(hp.get('tts_weight', 1.0))
         self.sample_rate = config['data']['audio']['sample_rate']
         self.log = []
+        if getattr(paras, 'async_stats', False):
+            self.async_stats = True
 
     def load_data(self):
         from .synthetic import synthetic_train_batch

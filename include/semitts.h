@@ -328,6 +328,14 @@ typedef struct st_gemm_job {
 } st_gemm_job;
 int st_gemm_fwd_batch(const st_gemm_job* jobs, int n, void* stream);
 
+/* The highway stack of the CBHG in one launch (eval mode): n_layers times y = relu(W_H x + b_H) * T + x * (1 - T), T = sigmoid(W_T x + b_T),
+ * x (M, C) rows; w_h / w_t: n_layers pointers to torch Linear weights (C, C), b_h / b_t: their biases (NULL entries = no bias).
+ * Bit-identical to 2 n_layers st_gemm_fwd launches with the highway epilogue.  st_highway_stack_supported: C % 16 == 0, C <= 80, <= 8 layers.
+ * ref: Highway.forward src/module.py:541-555, CBHG.forward :609-611. */
+int st_highway_stack_supported(int C, int n_layers);
+int st_highway_stack_fwd(const float* x, int ldx, const float* const* w_h, const float* const* b_h, const float* const* w_t,
+                         const float* const* b_t, int n_layers, float* y, int ldy, int M, int C, void* stream);
+
 /* per-column statistics over M rows (training-mode BatchNorm): mean, biased variance, and
  * the running-stat update  run = (1-mom) run + mom * {mean, unbiased var}; batches_tracked (optional, one int64 on the device:
  * nn.BatchNorm1d.num_batches_tracked) is incremented by the same launch.

@@ -156,6 +156,8 @@ SIGNATURES = {
     'st_attn_step_fwd': [P, P, P, P, I, P, P, I, P, P, P, P, P, I, P, I, P, P, P, I, I, I, I, I, I, I, P],
     'st_gemm_fwd': [P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, C.POINTER(StGemmEpilogue), P],
     'st_gemm_fwd_batch': [C.POINTER(StGemmJob), I, P],
+    'st_highway_stack_supported': [I, I],
+    'st_highway_stack_fwd': [P, I, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), I, P, I, I, I, P],
     'st_gemm_splitk_slabs': [I, I, I, I, I],
     'st_bn_stats': [P, I, I, I, I, P, P, P, P, F, P, P, P],
     'st_colreduce_workspace_floats': [I, I],

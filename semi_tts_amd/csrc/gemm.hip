@@ -42,7 +42,7 @@ __device__ __forceinline__ float gm_epilogue_one(const st_gemm_epilogue& ep, flo
         // Highway: y = H * T + x * (1 - T), v = T                (module.py:551-554)
         const float hh = ep.highway_h[(size_t)m * ep.ldhw + n];
         const float xx = ep.res[(size_t)m * ep.ldres + n];
-        v = hh * v + xx * (1.0f - v);
+        v = st_highway(hh, v, xx);
     } else if (ep.res) {
         v += ep.res[(size_t)m * ep.ldres + n];
     }
@@ -378,6 +378,99 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_batch_kernel(const GmBatch
     gm_pipe_body<VECW, false, MT>(g, As, Bs);
 }
 
+// ---- the highway stack as ONE kernel (inference) ------------------------------------------------------------------------
+// y = H(x) * T(x) + x * (1 - T(x)), H = relu(W_H x + b_H), T = sigmoid(W_T x + b_T), n_layers times      (src/module.py:541-555, :609-611)
+// The layers are row-wise independent: a workgroup keeps its 32 rows in LDS through all the layers; the two weight matrices of a
+// layer (2C x C) are staged in LDS while the previous layer is multiplied.  Per layer a wave takes 2-3 of the 10 (row tile, column
+// tile) units and forms the H and the T tile of a unit side by side (same A fragment), so the combine happens in registers.  The k
+// order per output element is that of gm_pipe_kernel (k-blocks of 16 ascending, the lane's four k's in order): bit-identical to the
+// two-GEMMs-per-layer form it replaces (8 launches of ~10 us for 0.27 GFLOP each at the CBHG's 80 channels).
+constexpr int HW_ROWS = 32, HW_MAXC = 80, HW_MAXL = 8;
+struct HwArgs {
+    const float* x; int ldx; float* y; int ldy; int M, C, NL;
+    const float* wh[HW_MAXL]; const float* bh[HW_MAXL]; const float* wt[HW_MAXL]; const float* bt[HW_MAXL];
+};
+
+__global__ __launch_bounds__(256) void highway_stack_kernel(const HwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float hw_lds[];
+    const int C = a.C, LD = C + 4, C4 = C >> 2;          // LD: rows 16 apart in the b128 reads fall on distinct 16-byte slots (C % 16 == 0)
+    float* xs[2] = {hw_lds, hw_lds + HW_ROWS * LD};
+    float* ws[2] = {hw_lds + 2 * HW_ROWS * LD, hw_lds + 2 * HW_ROWS * LD + 2 * C * LD};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * HW_ROWS;
+    const int nw4 = 2 * C * C4;                          // float4 pieces of one layer's [W_H ; W_T]
+    constexpr int WPT = (2 * HW_MAXC * (HW_MAXC / 4) + 255) / 256;     // pieces per thread (13 at C = 80)
+    f32x4 wreg[WPT];
+    auto request_w = [&](int l) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int i = tid + j * 256;
+            const int ic = i < nw4 ? i : 0;
+            const int row = ic / C4, c4 = ic - row * C4;
+            const float* src = row < C ? a.wh[l] + (size_t)row * C : a.wt[l] + (size_t)(row - C) * C;
+            wreg[j] = st_ld4(src + 4 * c4);
+        }
+    };
+    auto commit_w = [&](float* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int i = tid + j * 256;
+            if (i < nw4) { const int row = i / C4, c4 = i - row * C4; *reinterpret_cast<f32x4*>(dst + row * LD + 4 * c4) = wreg[j]; }
+        }
+    };
+    request_w(0);
+    for (int i = tid; i < HW_ROWS * C4; i += 256) {      // the rows of this workgroup (rows past M: zeros, never stored)
+        const int r = i / C4, c4 = i - r * C4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < a.M) v = st_ld4(a.x + (size_t)(m0 + r) * a.ldx + 4 * c4);
+        *reinterpret_cast<f32x4*>(xs[0] + r * LD + 4 * c4) = v;
+    }
+    commit_w(ws[0]);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ntile = C >> 4, nunits = 2 * ntile;
+    for (int l = 0; l < a.NL; ++l) {
+        const float* xc = xs[l & 1];
+        float* xn = xs[(l + 1) & 1];
+        const float* wc = ws[l & 1];
+        if (l + 1 < a.NL) request_w(l + 1);              // in flight while this layer is multiplied
+        for (int u = wave; u < nunits; u += 4) {
+            const int rt = u / ntile, j = u - rt * ntile;
+            f32x4 acch = {0.f, 0.f, 0.f, 0.f}, acct = {0.f, 0.f, 0.f, 0.f};
+            const float* ap = xc + (rt * 16 + fr) * LD + 4 * fq;
+            const float* hp = wc + (j * 16 + fr) * LD + 4 * fq;
+            const float* tp = wc + (C + j * 16 + fr) * LD + 4 * fq;
+            for (int k0 = 0; k0 < C; k0 += 16) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + k0);
+                const f32x4 h4 = *reinterpret_cast<const f32x4*>(hp + k0);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(tp + k0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acch = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], h4[c], acch, 0, 0, 0);
+                    acct = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], t4[c], acct, 0, 0, 0);
+                }
+            }
+            const int n = j * 16 + fr;
+            const float bhv = a.bh[l] ? a.bh[l][n] : 0.0f, btv = a.bt[l] ? a.bt[l][n] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = rt * 16 + 4 * fq + e;
+                const float hh = st_act(acch[e] + bhv, ST_ACT_RELU);
+                const float tt = st_act(acct[e] + btv, ST_ACT_SIGMOID);
+                const float xx = xc[m * LD + n];
+                xn[m * LD + n] = st_highway(hh, tt, xx);
+            }
+        }
+        if (l + 1 < a.NL) commit_w(ws[(l + 1) & 1]);      // (nobody reads that buffer: its readers passed the barrier of layer l - 1)
+        __syncthreads();
+    }
+    const float* xf = xs[a.NL & 1];
+    for (int i = tid; i < HW_ROWS * C4; i += 256) {
+        const int r = i / C4, c4 = i - r * C4;
+        if (m0 + r < a.M) *reinterpret_cast<f32x4*>(a.y + (size_t)(m0 + r) * a.ldy + 4 * c4) = *reinterpret_cast<const f32x4*>(xf + r * LD + 4 * c4);
+    }
+}
+
 // ---- training-mode BatchNorm helpers ---------------------------------------------------
 // column statistics, two launches: (1) grid = (column blocks of 64, row chunks): every block reduces its chunk of
 // rows to (mean_c, M2_c) with a chunk-local two-pass (the second pass re-reads <= 64 KB from cache);
@@ -648,6 +741,33 @@ extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, floa
     ST_CHECK_ARG(chunks <= 128, "st_bn_stats: %d chunks (the merge kernel holds at most 128)", chunks);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                        ws, chunks, rpc, M, N, mean_out, var_out, run_mean, run_var, momentum, batches_tracked);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_highway_stack_supported(int C, int n_layers) { return C > 0 && C % 16 == 0 && C <= HW_MAXC && n_layers >= 1 && n_layers <= HW_MAXL; }
+
+extern "C" int st_highway_stack_fwd(const float* x, int ldx, const float* const* w_h, const float* const* b_h, const float* const* w_t,
+                                    const float* const* b_t, int n_layers, float* y, int ldy, int M, int C, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(x && y && w_h && w_t && M > 0 && ldx >= C && ldy >= C, "st_highway_stack_fwd: bad arguments");
+    ST_CHECK_ARG(st_highway_stack_supported(C, n_layers), "st_highway_stack_fwd: C=%d (a multiple of 16, <= %d), layers=%d (<= %d)", C, HW_MAXC, n_layers, HW_MAXL);
+    ST_CHECK_ARG(st_aligned16(x) && st_aligned16(y) && ldx % 4 == 0 && ldy % 4 == 0, "st_highway_stack_fwd: rows must be 16-byte aligned");
+    HwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.y = y; a.ldy = ldy; a.M = M; a.C = C; a.NL = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        ST_CHECK_ARG(w_h[l] && w_t[l] && st_aligned16(w_h[l]) && st_aligned16(w_t[l]), "st_highway_stack_fwd: layer %d weights", l);
+        a.wh[l] = w_h[l]; a.wt[l] = w_t[l]; a.bh[l] = b_h ? b_h[l] : nullptr; a.bt[l] = b_t ? b_t[l] : nullptr;
+    }
+    const int LD = C + 4;
+    const size_t lds = (size_t)(2 * HW_ROWS * LD + 2 * 2 * C * LD) * sizeof(float);
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(highway_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(highway_stack_kernel, dim3((M + HW_ROWS - 1) / HW_ROWS), dim3(256), lds, (hipStream_t)stream, a);
     ST_LAUNCH_CHECK();
     return 0;
 }

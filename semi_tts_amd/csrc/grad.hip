@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void bn_norm_fwd_kernel(const float* X, int ld
 __global__ __launch_bounds__(256) void highway_fwd_kernel(const float* H, const float* T, const float* x, float* y, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const float t = T[i];
-        y[i] = H[i] * t + x[i] * (1.0f - t);
+        y[i] = st_highway(H[i], t, x[i]);
     }
 }
 

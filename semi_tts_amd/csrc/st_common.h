@@ -70,6 +70,10 @@ __device__ __forceinline__ float st_tanh_fast(float x) {
     return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
 }
 
+// Highway combine y = H * T + x * (1 - T) in ONE spelled-out operation order (the compiler is free to contract `a*b + c*d` either
+// way; every kernel that forms it -- GEMM epilogue, fused stack, training forward -- must round alike)
+__device__ __forceinline__ float st_highway(float h, float t, float x) { return fmaf(h, t, x * (1.0f - t)); }
+
 __device__ __forceinline__ float st_act(float v, int act) {
     switch (act) {
         case ST_ACT_RELU: return v > 0.0f ? v : 0.0f;

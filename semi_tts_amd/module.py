@@ -709,8 +709,12 @@ class CBHG(nn.Module):
         for blk in self.conv1d_projs[1:]:
             y = blk(y)
         y = ops.gemm(y, self.pre_highway_proj.weight, res=x)                                  # :607-609
-        for hw in self.highways:
-            y = hw(y)
+        ys = ops.highway_stack(y, [(hw.H.weight, hw.H.bias, hw.T.weight, hw.T.bias) for hw in self.highways])      # one launch
+        if ys is None:
+            for hw in self.highways:
+                y = hw(y)
+        else:
+            y = ys
         H = self.gru.hidden_size
         jobs = []        # the two directions' input projections: one launch
         gi_f = ops.gemm(y, self.gru.weight_ih_l0, bias=self.gru.bias_ih_l0, collect=jobs)

@@ -354,6 +354,23 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=
     return out
 
 
+def highway_stack(x, layers):
+    """eval-mode highway stack in one launch; layers: [(W_H, b_H, W_T, b_T), ...] torch Linear parameters.  None when the shape is
+    not one the kernel takes (the caller then runs the layers as GEMM pairs)."""
+    lib = _lib.load()
+    Cn = int(x.shape[-1])
+    if not (x.is_contiguous() and lib.st_highway_stack_supported(Cn, len(layers))) or any(
+            tuple(w.shape) != (Cn, Cn) or not w.is_contiguous() for l in layers for w in (l[0], l[2])):
+        return None
+    n = len(layers)
+    arr = lambda k: (C.c_void_p * n)(*[_p(l[k]) for l in layers])
+    y = torch.empty_like(x)
+    M = x.numel() // Cn
+    check(lib.st_highway_stack_fwd(_p(x), Cn, arr(0), arr(1), arr(2), arr(3), n, _p(y), Cn, int(M), Cn, stream_handle()),
+          'st_highway_stack_fwd')
+    return y
+
+
 def gemm_flush(collected):
     """run the jobs gathered by ops.gemm(..., collect=list) -- st_gemm_fwd_batch: one launch for up to eight jobs of the pipelined
     kernel (the conv bank), separate launches otherwise"""

@@ -1116,3 +1116,25 @@ def test_gemm_batch_equals_separate_launches(dev):
     yb = ops.gemm(x2, w2b, collect=jobs)
     ops.gemm_flush(jobs)
     assert torch.equal(ya, ops.gemm(x2, w2a)) and torch.equal(yb, ops.gemm(x2, w2b))
+
+
+@pytest.mark.parametrize('M,C,NL', [(8256, 80, 4), (70, 80, 4), (33, 16, 1), (100, 64, 8)])
+def test_highway_stack_in_one_launch_is_bitwise_the_layer_by_layer_form(dev, M, C, NL):
+    """st_highway_stack_fwd (all highway layers of the CBHG in one launch, the rows of a workgroup kept in LDS) against the
+    two-GEMMs-per-layer form (same k order per output element: bit-identical) and against torch in float64."""
+    from semi_tts_amd import ops
+    x = rnd(M, C, seed=1).to(dev)
+    layers = [(rnd(C, C, scale=C ** -0.5, seed=10 + 4 * l).to(dev), rnd(C, seed=11 + 4 * l).to(dev),
+               rnd(C, C, scale=C ** -0.5, seed=12 + 4 * l).to(dev), rnd(C, seed=13 + 4 * l).to(dev)) for l in range(NL)]
+    y = ops.highway_stack(x, layers)
+    assert y is not None
+    ref, r64 = x, x.cpu().double()
+    for wh, bh, wt, bt in layers:
+        h = ops.gemm(ref, wh, bias=bh, act_pre='relu')
+        ref = ops.gemm(ref, wt, bias=bt, act_pre='sigmoid', highway_h=h, res=ref)
+        H = torch.relu(r64 @ wh.cpu().double().t() + bh.cpu().double())
+        T = torch.sigmoid(r64 @ wt.cpu().double().t() + bt.cpu().double())
+        r64 = H * T + r64 * (1.0 - T)
+    assert torch.equal(y, ref)
+    assert maxdiff(y, r64) < 1e-4
+    assert ops.highway_stack(rnd(40, 96, seed=2).to(dev), [(rnd(96, 96, seed=3).to(dev), None, rnd(96, 96, seed=4).to(dev), None)]) is None

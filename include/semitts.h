@@ -448,6 +448,12 @@ int st_lstm_seq2_fwd(const float* const* xproj2, const float* const* w_hh2, cons
 int st_lstm_seq2_bwd(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,
                      const float* const* w_hh_t2, float* const* dxproj2, float* ws, int B, int T, int H, void* stream);
 int st_skinny_linear_pair_fwd(const st_seg* segs2, float* const* y2, int ldy, int B, int N, void* stream);
+/* st_lstm_seq2_bwd on packed operands: ONE launch per time step for the two directions -- dgates(s) . W_hh with the pointwise backward of
+ * step s-1 in its epilogue (st_skinny_linear_packed_lstm_bwd_pair_fwd).  w_hh_t_p16_2: st_pack_weight_t of each direction's W_hh (N = H,
+ * K = 4H); dg_t16_ws: 4 * st_t16_floats(B, 4H) floats (two ping-pong T16 copies of dgates per direction).  ws: 2*B*H floats (dc carries). */
+int st_lstm_seq2_bwd_packed(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,
+                            const float* const* w_hh_t_p16_2, float* const* dxproj2, float* ws, float* dg_t16_ws,
+                            int B, int T, int H, void* stream);
 /* Backward through time of st_lstm_seq_fwd: dout(b, t, dcol : dcol+H) -> dxproj (B,T,4H) (= gradient of the
  * input projection incl. both biases).  w_hh_t = W_hh^T (H, 4H).  ws: 2*B*H floats.  The caller finishes with
  * dW_hh = st_gemm_wgrad(dxproj, out shifted by one step) and db = st_colsum(dxproj). */
@@ -749,6 +755,9 @@ typedef struct st_attn_bwd_job {
     int B, L, A, E, F, K;
 } st_attn_bwd_job;
 /* job may be NULL (the plain product); ab->s_in must be given (the forward kept S) */
+/* two st_skinny_linear_packed_lstm_bwd_fwd of one shape in one launch (arrays of two; y2 or its entries may be NULL) */
+int st_skinny_linear_packed_lstm_bwd_pair_fwd(const float* const* packed_w2, const st_t16_view* x2, int K, float* const* y2, int ldy,
+                                              int B, int N, const st_lstm_pw_job* job2, void* stream);
 int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
                                               const st_lstm_pw_job* job, const st_attn_bwd_job* ab, void* stream);
 int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);

@@ -225,6 +225,8 @@ SIGNATURES = {
     'st_lstm_seq2_fwd': [C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, C.POINTER(I), P, C.POINTER(P), C.POINTER(P), I, I, I, P],
     'st_lstm_seq2_bwd': [P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, I, I, P],
     'st_skinny_linear_pair_fwd': [P, C.POINTER(P), I, I, I, P],
+    'st_lstm_seq2_bwd_packed': [P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), P, P, I, I, I, P],
+    'st_skinny_linear_packed_lstm_bwd_pair_fwd': [C.POINTER(P), C.POINTER(StT16View), I, C.POINTER(P), I, I, I, C.POINTER(StLstmPwJob), P],
     'st_lstm_cell_pair_fwd': [P, C.POINTER(P), C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, I, P],
     'st_attn_dmem': [P, P, P, I, I, I, I, P],
     'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],

@@ -343,7 +343,10 @@ class _BiLstmFn(Function):
         dout = dout.contiguous()
         H = w_hh_f.shape[1]
         res = []
-        dxps = ops.lstm_seq2_bwd(dout, (g_f, g_b), (c_f, c_b), (ops.dx_weight(w_hh_f.detach())[0], ops.dx_weight(w_hh_b.detach())[0]))
+        if H % 16 == 0:     # packed operands: one launch per step for both directions (product + pointwise backward in its epilogue)
+            dxps = ops.lstm_seq2_bwd(dout, (g_f, g_b), (c_f, c_b), None, (w_hh_f, w_hh_b))
+        else:
+            dxps = ops.lstm_seq2_bwd(dout, (g_f, g_b), (c_f, c_b), (ops.dx_weight(w_hh_f.detach())[0], ops.dx_weight(w_hh_b.detach())[0]))
         for d in range(2):
             dxp = dxps[d]
             # h_{t-1} of the forward direction is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1 / -1

@@ -594,6 +594,57 @@ extern "C" int st_lstm_seq2_bwd(const float* dout, int ldd, const int* dcol2, co
     return 0;
 }
 
+extern "C" int st_lstm_seq2_bwd_packed(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,
+                                       const float* const* w_hh_t_p16_2, float* const* dxproj2, float* ws, float* dg_t16_ws,
+                                       int B, int T, int H, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dout && dcol2 && gates_tape2 && c_tape2 && w_hh_t_p16_2 && dxproj2 && ws && dg_t16_ws && B > 0 && T > 0 && H > 0 && H % 16 == 0,
+                 "st_lstm_seq2_bwd_packed: bad arguments (H must be a multiple of 16)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bh = (size_t)B * H;
+    const size_t t16 = st_t16_floats(B, 4 * H);
+    const int kbs = (4 * H + 15) >> 4;
+    ST_HIP(hipMemsetAsync(ws, 0, 2 * bh * sizeof(float), st));
+    ST_HIP(hipMemsetAsync(dg_t16_ws, 0, 4 * t16 * sizeof(float), st));       // (rows past B of the tiles stay zero)
+    auto buf = [&](int d, int par) { return dg_t16_ws + (size_t)(2 * d + par) * t16; };
+    const int blocks = (B * H + 255) / 256;
+    {   // the last processed step: nothing recurrent arrives yet
+        const int s = T - 1;
+        LstmPwArgs a[2];
+        for (int d = 0; d < 2; ++d) {
+            const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
+            memset(&a[d], 0, sizeof(LstmPwArgs));
+            a[d].dh0 = dout + (size_t)t * ldd + dcol2[d]; a[d].ld0 = T * ldd;
+            a[d].gates = gates_tape2[d] + (size_t)t * 4 * bh; a[d].c = c_tape2[d] + (size_t)t * bh; a[d].ldc = H;
+            a[d].c_prev = s == 0 ? nullptr : c_tape2[d] + (size_t)tp * bh; a[d].ldcp = H;
+            a[d].dc = ws + (size_t)d * bh; a[d].dgates = dxproj2[d] + (size_t)t * 4 * H; a[d].ldg = T * 4 * H;
+            a[d].dg_t16 = buf(d, s & 1); a[d].t16_kbs = kbs; a[d].t16_kb0 = 0;
+            a[d].B = B; a[d].H = H;
+        }
+        hipLaunchKernelGGL(lstm_bwd_pw_pair_kernel, dim3(blocks, 2), dim3(256), 0, st, a[0], a[1]);
+        ST_LAUNCH_CHECK();
+    }
+    for (int s = T - 1; s >= 1; --s) {        // dh_rec(s-1) = dgates(s) . W_hh, and the pointwise backward of step s-1 in the epilogue
+        st_t16_view xv[2];
+        st_lstm_pw_job job[2];
+        for (int d = 0; d < 2; ++d) {
+            const int s1 = s - 1;
+            const int t = d ? T - 1 - s1 : s1, tp = d ? t + 1 : t - 1;
+            xv[d].base = buf(d, s & 1); xv[d].kb_stride = kbs; xv[d].kb0 = 0;
+            memset(&job[d], 0, sizeof(st_lstm_pw_job));
+            job[d].n0 = 0; job[d].H = H;
+            job[d].dh1 = dout + (size_t)t * ldd + dcol2[d]; job[d].ld1 = T * ldd;
+            job[d].gates = gates_tape2[d] + (size_t)t * 4 * bh; job[d].c = c_tape2[d] + (size_t)t * bh; job[d].ldc = H;
+            job[d].c_prev = s1 == 0 ? nullptr : c_tape2[d] + (size_t)tp * bh; job[d].ldcp = H;
+            job[d].dc = ws + (size_t)d * bh; job[d].dgates = dxproj2[d] + (size_t)t * 4 * H; job[d].ldg = T * 4 * H;
+            job[d].dgates_t16.base = buf(d, s1 & 1); job[d].dgates_t16.kb_stride = kbs; job[d].dgates_t16.kb0 = 0;
+        }
+        int rc = st_skinny_linear_packed_lstm_bwd_pair_fwd(w_hh_t_p16_2, xv, 4 * H, nullptr, H, B, H, job, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int st_gru_seq_bwd(const float* dout, int ldd, const float* out, int ldo, const float* tape,
                               const float* w_hh_fwd, const float* w_hh_bwd, float* dgi_fwd, float* dgi_bwd,
                               float* dgh_fwd, float* dgh_bwd, int B, int T, int H, int ndir, void* stream) {

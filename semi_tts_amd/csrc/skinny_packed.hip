@@ -651,6 +651,20 @@ __global__ __launch_bounds__(KW * 64) void pk_pw_kernel(const f32x4* w, const f3
     pk_body<2, NB, KW, TRIP>(a, blockIdx.x, blockIdx.y, red, &pw);
 }
 
+// two products with a pointwise LSTM backward in their epilogues in one launch: the two directions of a bidirectional layer's BPTT
+// step (blockIdx.x < n0: job 0)
+template <int NB, int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_pw_pair_kernel(const int n0, const int tiles, const PkArgs a0, const PkPw pw0, const PkArgs a1,
+                                                             const PkPw pw1) {
+    __shared__ f32x4 red[KW * NB * 64];
+    const bool second = (int)blockIdx.x >= n0;
+    const PkArgs& a = second ? a1 : a0;
+    const PkPw& pw = second ? pw1 : pw0;
+    const int i = second ? (int)blockIdx.x - n0 : (int)blockIdx.x;
+    const int by = i / tiles;
+    pk_body<2, NB, KW, TRIP>(a, i - by * tiles, by, red, &pw);
+}
+
 // The decoder cell's backward product of step t-1 (pk_body MODE 2) with the attention-step backward of step t BESIDE it: in the BPTT
 // loop dgates_d(t-1) only needs the decoder cell's own recurrence, so the two do not depend on each other.  The attention
 // workgroups come FIRST (dispatched first: each holds a compute unit for ~17 us), the product's workgroups after them.
@@ -1172,6 +1186,47 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_fwd(const float* packed_w, const
     // one batch tile per workgroup, as the plain linear of these shapes runs (pk_dispatch<1>)
     hipLaunchKernelGGL((pk_pw_kernel<1, 8, 2>), dim3(tiles, BT), dim3(8 * 64), 0, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B,
                        a.N, a, q);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+static int pk_pw_fill(PkPw& q, const st_lstm_pw_job* job, int N, int ldy, const float* y, const char* who) {
+    memset(&q, 0, sizeof(q));
+    const int H = job->H;
+    ST_CHECK_ARG(H > 0 && H % 4 == 0 && job->n0 >= 0 && job->n0 % 16 == 0 && job->n0 + H <= N && (N % 16 == 0 || job->n0 + H <= (N & ~15)),
+                 "%s: the cell's columns [%d, %d) must be whole tiles of the %d outputs", who, job->n0, job->n0 + H, N);
+    ST_CHECK_ARG(job->gates && job->c && job->dc && job->dgates && job->ldg >= 4 * H && job->ldg % 4 == 0 && job->ldc % 4 == 0 &&
+                 (!job->c_prev || job->ldcp % 4 == 0) && (!job->dh1 || job->ld1 % 4 == 0) && (!job->dh2 || job->ld2 % 4 == 0) && ldy % 4 == 0,
+                 "%s: null operand or a row stride that is not a multiple of 4", who);
+    ST_CHECK_ARG(st_aligned16(job->gates) && st_aligned16(job->c) && st_aligned16(job->dc) && st_aligned16(job->dgates) && (!y || st_aligned16(y)) &&
+                 (!job->c_prev || st_aligned16(job->c_prev)) && (!job->dh1 || st_aligned16(job->dh1)) && (!job->dh2 || st_aligned16(job->dh2)) &&
+                 (!job->scale2 || st_aligned16(job->scale2)) && (!job->mask || st_aligned16(job->mask)) &&
+                 (!job->dgates_t16.base || st_aligned16(job->dgates_t16.base)), "%s: operands must be 16-byte aligned", who);
+    q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
+    q.gates = job->gates; q.c = job->c; q.ldc = job->ldc; q.c_prev = job->c_prev; q.ldcp = job->ldcp; q.dc = job->dc;
+    q.dgates = job->dgates; q.ldg = job->ldg; q.dg_t16 = pk_out(&job->dgates_t16);
+    return 0;
+}
+
+// two st_skinny_linear_packed_lstm_bwd_fwd of the same shape in one launch (arrays of two; y2 entries may be NULL: the product is
+// only consumed by its epilogue): the two directions of a bidirectional LSTM layer's BPTT step
+extern "C" int st_skinny_linear_packed_lstm_bwd_pair_fwd(const float* const* packed_w2, const st_t16_view* x2, int K, float* const* y2, int ldy,
+                                                         int B, int N, const st_lstm_pw_job* job2, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(packed_w2 && x2 && job2 && B > 0 && N > 0 && ldy >= N, "st_skinny_linear_packed_lstm_bwd_pair_fwd: bad arguments");
+    PkArgs a[2];
+    PkPw q[2];
+    for (int d = 0; d < 2; ++d) {
+        memset(&a[d], 0, sizeof(PkArgs));
+        int rc = pk_fill(a[d], packed_w2[d], &x2[d], K, "st_skinny_linear_packed_lstm_bwd_pair_fwd");
+        if (rc) return rc;
+        a[d].B = B; a[d].N = N; a[d].H = 0; a[d].act = ST_ACT_NONE;
+        a[d].y = y2 ? y2[d] : nullptr; a[d].ldy = ldy;
+        rc = pk_pw_fill(q[d], &job2[d], N, ldy, a[d].y, "st_skinny_linear_packed_lstm_bwd_pair_fwd");
+        if (rc) return rc;
+    }
+    const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
+    hipLaunchKernelGGL((pk_pw_pair_kernel<1, 8, 2>), dim3(2 * tiles * BT), dim3(8 * 64), 0, (hipStream_t)stream, tiles * BT, tiles, a[0], q[0], a[1], q[1]);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -475,10 +475,21 @@ def lstm_seq_bwd(dout, dcol, gates_tape, c_tape, w_hh_t, reverse):
     return dxproj
 
 
-def lstm_seq2_bwd(dout, gates_tapes, c_tapes, w_hh_ts):
-    """both directions at once: dout (B,T,2H) -> (dxproj_f, dxproj_b), each (B,T,4H)"""
+def lstm_seq2_bwd(dout, gates_tapes, c_tapes, w_hh_ts, w_hhs=None):
+    """both directions at once: dout (B,T,2H) -> (dxproj_f, dxproj_b), each (B,T,4H).  w_hhs = the two W_hh parameters (4H, H): with
+    H % 16 == 0 the loop runs on packed operands, one launch per step (product + pointwise backward of the previous step)."""
     T, B, _, H = gates_tapes[0].shape
     dx = [torch.empty(B, T, 4 * H, device=dout.device, dtype=torch.float32) for _ in range(2)]
+    if w_hhs is not None and H % 16 == 0:
+        P2 = C.c_void_p * 2
+        arr = lambda a, b_: P2(_p(a), _p(b_))
+        packed = [pack_weight_t([w.detach()]) for w in w_hhs]                 # W_hh^T in MFMA order: N = H, K = 4H
+        ws = torch.empty(2 * B * H, device=dout.device, dtype=torch.float32)
+        t16 = torch.empty(4 * t16_floats(B, 4 * H), device=dout.device, dtype=torch.float32)
+        check(_lib.load().st_lstm_seq2_bwd_packed(_p(dout), int(dout.stride(1)), (C.c_int * 2)(0, H), arr(*gates_tapes), arr(*c_tapes),
+                                                  arr(*packed), arr(*dx), _p(ws), _p(t16), B, T, H, stream_handle()),
+              'st_lstm_seq2_bwd_packed')
+        return dx
     ws = torch.empty(4 * B * H, device=dout.device, dtype=torch.float32)
     P2 = C.c_void_p * 2
     arr = lambda a, b_: P2(_p(a), _p(b_))

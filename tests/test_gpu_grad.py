@@ -167,9 +167,11 @@ def test_pool_prev_backward_ties(dev):
 
 
 # ------------------------------------------------------------------------------------ sequence layers
-def test_bilstm_backward(dev):
+@pytest.mark.parametrize('B,T,I,H', [(5, 13, 24, 32), (33, 7, 16, 48), (4, 9, 12, 24)])
+def test_bilstm_backward(dev, B, T, I, H):
+    """H % 16 == 0: the packed loop (one launch per step for both directions: dgates . W_hh with the pointwise backward of the previous step
+    in its epilogue); otherwise the two-launch form on natural operands"""
     from semi_tts_amd import autograd as AG
-    B, T, I, H = 5, 13, 24, 32
     lstm = torch.nn.LSTM(I, H, batch_first=True, bidirectional=True).double()
     x = rnd(B, T, I, seed=1)
     dy = rnd(B, T, 2 * H, seed=2)

@@ -380,6 +380,10 @@ int st_bn_norm_fwd(const float* X, int ldx, int xoff, float* Y, int ldy, int yof
 size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int N, int KT);
 int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* ws,
                   int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate, void* stream);
+/* st_gemm_wgrad + the bias gradient db[n] = sum over all (Bn * Tout) rows of dC[:, dcoff + n] in the same launches (no st_colsum
+ * next to the product): backward of nn.Linear / nn.Conv1d with bias. */
+int st_gemm_wgrad_db(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* db, float* ws,
+                     int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate, void* stream);
 /* out(n) (+)= sum_m X(m, xoff+n) [* Y(m, yoff+n)]      (bias gradients, AdaIN statistics gradients) */
 int st_colsum(const float* X, int ldx, int xoff, const float* Y, int ldy, int yoff, int M, int N,
               float* out, int accumulate, float* ws, void* stream);

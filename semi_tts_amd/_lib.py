@@ -243,6 +243,7 @@ SIGNATURES = {
     'st_bn_norm_fwd': [P, I, I, P, I, I, I, I, P, P, P, P, F, I, P],
     'st_gemm_wgrad_workspace_floats': [I, I, I, I, I],
     'st_gemm_wgrad': [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, I, P],
+    'st_gemm_wgrad_db': [P, I, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P],
     'st_colsum': [P, I, I, P, I, I, I, I, P, I, P, P],
     'st_act_bwd': [P, I, P, I, I, P, I, P, I, I, I, P],
     'st_bn_bwd': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, I, I, P, P, I, P, P],

@@ -50,7 +50,9 @@ class _ConvFn(Function):
         else:
             Bn, Tin, Cin = 1, x.shape[0], x.shape[1]
             To = dy.shape[0]
-        if has_b and ctx.needs_input_grad[2]:
+        # (the bias gradient rides in the weight-gradient launches when both are wanted and the conv has stride 1)
+        db_in_wgrad = has_b and ctx.needs_input_grad[2] and ctx.needs_input_grad[1] and stride == 1
+        if has_b and ctx.needs_input_grad[2] and not db_in_wgrad:
             db = ops.colsum(_rows(dpre))
         if stride > 1:
             # a stride-s conv is the stride-1 conv sampled every s positions: its gradients are those of the stride-1 conv for
@@ -65,7 +67,10 @@ class _ConvFn(Function):
             dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pad, w_tap_major=tap_major)
             if pool_prev:
                 dx = ops.pool_prev_bwd(dx, x)
-        if ctx.needs_input_grad[1]:
+        if db_in_wgrad:
+            dw, db = ops.gemm_wgrad(dpre, x, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_prev, with_db=True)
+            dw = dw.view(w.shape)
+        elif ctx.needs_input_grad[1]:
             dw = ops.gemm_wgrad(dpre, x, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_prev).view(w.shape)
         dres = dy if has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None, None, None, None, None
@@ -545,11 +550,9 @@ class _DecoderFn(Function):
 
         # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)
         dgq2, dgd2 = dgq.view(-1, 4 * Q), dgd.view(-1, 4 * D)
-        dwq_cat = ops.gemm_wgrad(dgq2, XQ[:steps].reshape(-1, XQw))
-        dwd_cat = ops.gemm_wgrad(dgd2, XD.view(-1, XDw))
-        dbq, dbd = ops.colsum(dgq2), ops.colsum(dgd2)
-        dwpg = ops.gemm_wgrad(dY2, XO.view(-1, XOw))
-        dbpg = ops.colsum(dY2)
+        dwq_cat, dbq = ops.gemm_wgrad(dgq2, XQ[:steps].reshape(-1, XQw), with_db=True)      # (bias gradients inside the same launches)
+        dwd_cat, dbd = ops.gemm_wgrad(dgd2, XD.view(-1, XDw), with_db=True)
+        dwpg, dbpg = ops.gemm_wgrad(dY2, XO.view(-1, XOw), with_db=True)
         dwq_attn = ops.gemm_wgrad(dpq.view(-1, A), hq_all)
         # attention parameters / inputs: sums over the steps of the per-step tape slices
         dv = ops.colsum(dv_tape.view(-1, A)).view(v.shape)

@@ -22,6 +22,8 @@ struct TnArgs {
     int M, rows_per_z;
     int fold;      // few input channels: the taps are folded into the column axis (column = ci*KT + tap)
     int vecx, vecy;   // rows of dC / A are 16-byte aligned: one 16-byte load per thread instead of four scalar ones
+    float* db_part;   // optional [Z][N]: column sums of dC over this slab's rows (the bias gradient), formed by the workgroups of the FIRST
+                      // column block from the dC chunks they stage anyway -- no colsum launches next to the product
 };
 
 // TM = tile edge (64 or 128): 4 waves as 2x2, each (TM/2) x (TM/2) = FR x FR MFMA 16x16 tiles, FR = TM/32.  The 128 tile
@@ -113,11 +115,16 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) { rx[h] = load_x(m + sm, h * 64); ry[h] = load_y(m + sm, h * 64); }
     };
+    const bool do_db = g.db_part != nullptr && blockIdx.y == 0;
+    f32x4 dbacc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) dbacc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             *reinterpret_cast<f32x4*>(Xs[buf] + sm * LD + h * 64 + sc) = rx[h];
             *reinterpret_cast<f32x4*>(Ys[buf] + sm * LD + h * 64 + sc) = ry[h];
+            if (do_db) dbacc[h] = dbacc[h] + rx[h];          // (rows past the slab were loaded as zeros)
         }
     };
     // two LDS buffers: chunk k+1 is written while chunk k is multiplied, one (LDS-only) barrier per chunk; the global loads of
@@ -144,6 +151,17 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
                 for (int nt = 0; nt < FR; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][mt], b4[c][nt], acc[mt][nt], 0, 0, 0);
         st_lds_barrier();
+    }
+    if (do_db) {   // the 16 row groups' column sums meet in LDS (the staging buffer: the loop ended with a barrier), fixed order
+#pragma unroll
+        for (int h = 0; h < NH; ++h) *reinterpret_cast<f32x4*>(Xs[0] + sm * LD + h * 64 + sc) = dbacc[h];
+        st_lds_barrier();
+        if (tid < TM && n0 + tid < g.N) {
+            float s = 0.0f;
+#pragma unroll
+            for (int r = 0; r < TN_BK; ++r) s += Xs[0][r * LD + tid];
+            g.db_part[(size_t)z * g.N + n0 + tid] = s;
+        }
     }
     // result: lane (r, q) holds D[i = 4q + e][j = r] of tile (mt, nt): row n = .. + FR i + mt, columns .. + FR r + nt
     float* out = g.part + (size_t)z * g.N * g.Cin * g.KT;
@@ -185,6 +203,25 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, fl
         for (; z < Z; ++z) s0 += part[(size_t)z * n + i];
         const float s = (s0 + s1) + (s2 + s3);
         out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// the same for a product with its bias gradient: elements [0, n) go to out, [n, n + nb) to out_b (slabs part_b[z][nb]; never accumulated)
+__global__ __launch_bounds__(256) void sum_partials2_kernel(const float* part, float* out, size_t n, int Z, int accumulate,
+                                                            const float* part_b, float* out_b, size_t nb) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + nb; i += (size_t)gridDim.x * blockDim.x) {
+        const bool isb = i >= n;
+        const float* p = isb ? part_b + (i - n) : part + i;
+        const size_t stride = isb ? nb : n;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 4 <= Z; z += 4) {
+            s0 += p[(size_t)z * stride]; s1 += p[(size_t)(z + 1) * stride]; s2 += p[(size_t)(z + 2) * stride]; s3 += p[(size_t)(z + 3) * stride];
+        }
+        for (; z < Z; ++z) s0 += p[(size_t)z * stride];
+        const float s = (s0 + s1) + (s2 + s3);
+        if (isb) out_b[i - n] = s;
+        else out[i] = accumulate ? out[i] + s : s;
     }
 }
 
@@ -487,12 +524,12 @@ extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int 
     if (Z > maxz) Z = maxz;
     if (Z > 96) Z = 96;          // the slabs are added by one thread per output element
     if (Z < 1) Z = 1;
-    return (size_t)Z * N * Cin * KT;
+    return (size_t)Z * N * Cin * KT + (size_t)Z * N;      // (+ the bias-gradient slabs of st_gemm_wgrad_db)
 }
 
-extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* ws,
-                             int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate,
-                             void* stream) {
+static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* db, float* ws,
+                   int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate,
+                   void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dC && A && dW && ws && Bn > 0 && Tin > 0 && Tout > 0 && Cin > 0 && N > 0 && KT > 0, "st_gemm_wgrad: bad arguments");
     TnArgs g;
@@ -501,7 +538,7 @@ extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* 
     g.Bn = Bn; g.Tin = Tin; g.Tout = Tout; g.Cin = Cin; g.N = N; g.KT = KT; g.pad = pad; g.pool_prev = pool_prev;
     g.M = Bn * Tout;
     const size_t per = (size_t)N * Cin * KT;
-    const int Z = (int)(st_gemm_wgrad_workspace_floats(Bn, Tout, Cin, N, KT) / per);
+    const int Z = (int)(st_gemm_wgrad_workspace_floats(Bn, Tout, Cin, N, KT) / (per + N));
     g.rows_per_z = (((g.M + Z - 1) / Z) + TN_BK - 1) / TN_BK * TN_BK;
     // the workspace (hence Z) is sized for the folded layout whenever Cin < 16; a pooled input falls back to the per-tap grid
     g.fold = tn_fold(Cin, KT, pool_prev) ? 1 : 0;
@@ -514,13 +551,30 @@ extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* 
     // the "sum" of one slab was a 17 us copy)
     const bool direct = Z == 1 && !accumulate;
     if (direct) g.part = dW;
+    if (db) g.db_part = direct ? db : ws + (size_t)Z * per;
     if (TM == 128) hipLaunchKernelGGL((tn_kernel<128>), grid, dim3(TN_THREADS), 0, st, g);
     else hipLaunchKernelGGL((tn_kernel<64>), grid, dim3(TN_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();
     if (direct) return 0;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(per)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
+    if (db) hipLaunchKernelGGL(sum_partials2_kernel, dim3(blocks_for(per + N)), dim3(256), 0, st, ws, dW, per, Z, accumulate, g.db_part, db, (size_t)N);
+    else hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(per)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
     ST_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* ws,
+                             int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate,
+                             void* stream) {
+    return tn_impl(dC, lddc, dcoff, A, lda, dW, nullptr, ws, Bn, Tin, Tout, Cin, N, KT, pad, pool_prev, accumulate, stream);
+}
+
+// st_gemm_wgrad that also writes db[n] = sum over all rows of dC[:, dcoff + n] (the bias gradient) from the chunks of dC the product
+// stages anyway
+extern "C" int st_gemm_wgrad_db(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* db, float* ws,
+                                int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate,
+                                void* stream) {
+    ST_CHECK_ARG(db, "st_gemm_wgrad_db: null db");
+    return tn_impl(dC, lddc, dcoff, A, lda, dW, db, ws, Bn, Tin, Tout, Cin, N, KT, pad, pool_prev, accumulate, stream);
 }
 
 extern "C" size_t st_colreduce_workspace_floats(int M, int N) { return (size_t)2 * st_colreduce_chunks(M) * N + 2 * (size_t)N; }

@@ -641,8 +641,9 @@ def bn_norm(x2d, xoff, N, mean, var, w, b, eps, act=None, out=None, yoff=0):
 
 
 def gemm_wgrad(dc, a, KT=1, pad=0, *, Bn=None, Tin=None, Tout=None, dcoff=0, N=None, pool_prev=False, out=None,
-               accumulate=False):
-    """dW (N, Cin[, KT]) of C = conv1d/linear(a, W): dc (Bn, Tout, >=dcoff+N) or (M, .), a (Bn, Tin, Cin) or (M, Cin)"""
+               accumulate=False, with_db=False):
+    """dW (N, Cin[, KT]) of C = conv1d/linear(a, W): dc (Bn, Tout, >=dcoff+N) or (M, .), a (Bn, Tin, Cin) or (M, Cin).
+    with_db: returns (dW, db) with db = the column sums of dc (the bias gradient), formed inside the same launches."""
     lib = _lib.load()
     if a.dim() == 3:
         Bn_, Tin_, Cin = a.shape
@@ -657,6 +658,12 @@ def gemm_wgrad(dc, a, KT=1, pad=0, *, Bn=None, Tin=None, Tout=None, dcoff=0, N=N
         out = torch.empty((N, Cin, KT) if KT > 1 else (N, Cin), device=a.device, dtype=torch.float32)
     nws = int(lib.st_gemm_wgrad_workspace_floats(int(Bn), int(Tout), int(Cin), int(N), int(KT)))
     ws = torch.empty(nws, device=a.device, dtype=torch.float32)
+    if with_db:
+        db = torch.empty(N, device=a.device, dtype=torch.float32)
+        check(lib.st_gemm_wgrad_db(_p(dc), int(dc.stride(-2)), int(dcoff), _p(a), int(a.stride(-2)), _p(out), _p(db), _p(ws), int(Bn),
+                                   int(Tin), int(Tout), int(Cin), int(N), int(KT), int(pad), 1 if pool_prev else 0,
+                                   1 if accumulate else 0, stream_handle()), 'st_gemm_wgrad_db')
+        return out, db
     check(lib.st_gemm_wgrad(_p(dc), int(dc.stride(-2)), int(dcoff), _p(a), int(a.stride(-2)), _p(out), _p(ws), int(Bn),
                             int(Tin), int(Tout), int(Cin), int(N), int(KT), int(pad), 1 if pool_prev else 0,
                             1 if accumulate else 0, stream_handle()), 'st_gemm_wgrad')

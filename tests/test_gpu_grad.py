@@ -997,3 +997,20 @@ def test_async_training_step_equals_the_synchronous_one_and_skips_nan_steps_on_d
             assert torch.equal(p.detach(), w0[k]), k
     for st in tr_n.optimizer.opt.state.values():
         assert float(st['exp_avg'].abs().max()) == 0.0 and float(st['exp_avg_sq'].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('M,N,Cin,KT', [(2752, 4096, 160, 1), (300, 70, 33, 1), (8256, 128, 80, 3), (5000, 200, 8, 5), (64, 16, 16, 1)])
+def test_weight_gradient_with_bias_gradient_in_the_same_launches(dev, M, N, Cin, KT):
+    """st_gemm_wgrad_db: dW as st_gemm_wgrad gives it (bit for bit) and db = column sums of dC, for one and many row slabs, both tile
+    sizes, the folded few-channel form and widths that are not multiples of the tile."""
+    from semi_tts_amd import ops
+    Bn = 1 if KT == 1 else 4
+    T = M // Bn
+    a = rnd(Bn, T, Cin, seed=1).to(dev)
+    dc = rnd(Bn, T, N, seed=2).to(dev)
+    pad = KT // 2
+    dw_ref = ops.gemm_wgrad(dc, a, KT, pad)
+    dw, db = ops.gemm_wgrad(dc, a, KT, pad, with_db=True)
+    assert torch.equal(dw, dw_ref)
+    ref = dc.cpu().double().sum((0, 1))
+    assert relerr(db, ref) < 2e-6

@@ -506,7 +506,14 @@ inline int blocks_for(size_t n, int cap = 4096) {
 
 static inline bool tn_fold(int Cin, int KT, int pool_prev) { return Cin < 16 && KT > 1 && !pool_prev; }
 
-static inline int tn_tile(int Cin, int N, int KT) { return (N >= 128 && Cin >= 128 && !tn_fold(Cin, KT, 0)) ? 128 : TN_T; }
+// 128 x 128 tiles only where they still make many workgroups per compute unit (>= 512 tiles: the 4096 x 2560 decoder-LSTM gradient);
+// below that the 64 x 64 form wins through occupancy (measured per training step: the sixteen mid-size products 749 -> 583 us, the
+// 4096 x 1792 query-LSTM gradient 487 -> 469; the decoder one 575 with 128-tiles against 630)
+static inline int tn_tile(int Cin, int N, int KT) {
+    if (!(N >= 128 && Cin >= 128) || tn_fold(Cin, KT, 0)) return TN_T;
+    const long tiles128 = (long)((N + 127) / 128) * ((Cin + 127) / 128) * KT;
+    return tiles128 >= 512 ? 128 : TN_T;
+}
 
 extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int N, int KT) {
     const int M = Bn * Tout;

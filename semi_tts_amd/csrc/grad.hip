@@ -22,6 +22,7 @@ struct TnArgs {
     int M, rows_per_z;
     int fold;      // few input channels: the taps are folded into the column axis (column = ci*KT + tap)
     int vecx, vecy;   // rows of dC / A are 16-byte aligned: one 16-byte load per thread instead of four scalar ones
+    int lin;          // KT == 1, pad == 0, Tin == Tout, no pooling: row m of A pairs with row m of dC (no per-chunk integer division)
     float* db_part;   // optional [Z][N]: column sums of dC over this slab's rows (the bias gradient), formed by the workgroups of the FIRST
                       // column block from the dC chunks they stage anyway -- no colsum launches next to the product
 };
@@ -76,6 +77,18 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     auto load_y = [&](int m, int cofs) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m >= mend) return v;
+        if (g.lin) {           // a Linear layer: plain rows
+            const int ci = c0 + sc + cofs;
+            if (ci >= g.Cin) return v;
+            const float* p = g.A + (size_t)m * g.lda + ci;
+            const int rem = g.Cin - ci;
+            if (g.vecy && rem >= 4) return st_ld4(p);
+            v[0] = p[0];
+            if (rem > 1) v[1] = p[1];
+            if (rem > 2) v[2] = p[2];
+            if (rem > 3) v[3] = p[3];
+            return v;
+        }
         const int b = m / g.Tout, to = m - b * g.Tout;
         if (g.fold) {          // four consecutive (ci, tap) columns, each its own row shift
 #pragma unroll
@@ -111,7 +124,34 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     constexpr int NH = TM / 64;                                            // column halves staged per thread
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 rx[NH], ry[NH];
+    // Linear layers with 16-byte addressable rows whose column pieces are whole (or wholly outside): running row pointers, one compare
+    // and one 16-byte load per piece and chunk -- the general path's address arithmetic (a 64-bit multiply, the utterance / frame split of
+    // the row index, the remainder logic) costs as many issue cycles per chunk as the 16 MFMAs of a 64-tile wave
+    const float* px[NH]; const float* py[NH];
+    bool okx[NH], oky[NH];
+    bool fastp = g.lin && g.vecx && g.vecy;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int colx = n0 + sc + h * 64, ci = c0 + sc + h * 64;
+        okx[h] = colx + 4 <= g.N; oky[h] = ci + 4 <= g.Cin;
+        fastp = fastp && (okx[h] || colx >= g.N) && (oky[h] || ci >= g.Cin);
+        px[h] = g.dC + (size_t)(mbeg + sm) * g.lddc + g.dcoff + colx;
+        py[h] = g.A + (size_t)(mbeg + sm) * g.lda + ci;
+    }
+    int mreq = mbeg + sm;                      // (fast path: the row the next request takes; requests come in chunk order)
     auto request = [&](int m) __attribute__((always_inline)) {
+        if (fastp) {
+            const bool row = mreq < mend;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                rx[h] = (row && okx[h]) ? st_ld4(px[h]) : z4;
+                ry[h] = (row && oky[h]) ? st_ld4(py[h]) : z4;
+                px[h] += (size_t)TN_BK * g.lddc; py[h] += (size_t)TN_BK * g.lda;
+            }
+            mreq += TN_BK;
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) { rx[h] = load_x(m + sm, h * 64); ry[h] = load_y(m + sm, h * 64); }
     };
@@ -506,13 +546,13 @@ inline int blocks_for(size_t n, int cap = 4096) {
 
 static inline bool tn_fold(int Cin, int KT, int pool_prev) { return Cin < 16 && KT > 1 && !pool_prev; }
 
-// 128 x 128 tiles only where they still make many workgroups per compute unit (>= 512 tiles: the 4096 x 2560 decoder-LSTM gradient);
-// below that the 64 x 64 form wins through occupancy (measured per training step: the sixteen mid-size products 749 -> 583 us, the
-// 4096 x 1792 query-LSTM gradient 487 -> 469; the decoder one 575 with 128-tiles against 630)
+// 128 x 128 tiles only where they still give every compute unit a workgroup (>= 256 tiles: the two decoder-LSTM gradients, 4096 x 2560
+// and 4096 x 1792); below that the 64 x 64 form wins through occupancy.  Measured per training step (all weight-gradient products):
+// 128-tiles wherever both dimensions reach 128: 2270 us; from 64 tiles on 2153; from 256 on 2112; from 512 on 2148
 static inline int tn_tile(int Cin, int N, int KT) {
     if (!(N >= 128 && Cin >= 128) || tn_fold(Cin, KT, 0)) return TN_T;
     const long tiles128 = (long)((N + 127) / 128) * ((Cin + 127) / 128) * KT;
-    return tiles128 >= 512 ? 128 : TN_T;
+    return tiles128 >= 256 ? 128 : TN_T;
 }
 
 extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int N, int KT) {
@@ -549,6 +589,7 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     g.rows_per_z = (((g.M + Z - 1) / Z) + TN_BK - 1) / TN_BK * TN_BK;
     // the workspace (hence Z) is sized for the folded layout whenever Cin < 16; a pooled input falls back to the per-tap grid
     g.fold = tn_fold(Cin, KT, pool_prev) ? 1 : 0;
+    g.lin = (KT == 1 && pad == 0 && Tin == Tout && !pool_prev) ? 1 : 0;
     g.vecx = st_aligned16(dC) && (lddc % 4 == 0) && (dcoff % 4 == 0);
     g.vecy = st_aligned16(A) && (lda % 4 == 0);
     const int TM = tn_tile(Cin, N, KT);

@@ -129,17 +129,38 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     // the row index, the remainder logic) costs as many issue cycles per chunk as the 16 MFMAs of a 64-tile wave
     const float* px[NH]; const float* py[NH];
     bool okx[NH], oky[NH];
-    bool fastp = g.lin && g.vecx && g.vecy;
+    bool whole = g.vecx && g.vecy;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int colx = n0 + sc + h * 64, ci = c0 + sc + h * 64;
         okx[h] = colx + 4 <= g.N; oky[h] = ci + 4 <= g.Cin;
-        fastp = fastp && (okx[h] || colx >= g.N) && (oky[h] || ci >= g.Cin);
+        whole = whole && (okx[h] || colx >= g.N) && (oky[h] || ci >= g.Cin);
         px[h] = g.dC + (size_t)(mbeg + sm) * g.lddc + g.dcoff + colx;
         py[h] = g.A + (size_t)(mbeg + sm) * g.lda + ci;
     }
-    int mreq = mbeg + sm;                      // (fast path: the row the next request takes; requests come in chunk order)
+    const bool fastp = whole && g.lin;
+    // ... and convolutions (one tap per workgroup, no pooling): the (utterance, frame) of the thread's row is carried from chunk to chunk
+    const bool fastc = whole && !g.lin && !g.fold && !g.pool_prev;
+    int mreq = mbeg + sm;                      // (fast paths: the row the next request takes; requests come in chunk order)
+    int cb = 0, cto = 0;
+    if (fastc) { cb = mreq / g.Tout; cto = mreq - cb * g.Tout; }
     auto request = [&](int m) __attribute__((always_inline)) {
+        if (fastc) {
+            const bool row = mreq < mend;
+            const int ti = cto + tap - g.pad;
+            const bool yrow = row && ti >= 0 && ti < g.Tin;
+            const float* pa = g.A + ((size_t)cb * g.Tin + (yrow ? ti : 0)) * g.lda + c0 + sc;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                rx[h] = (row && okx[h]) ? st_ld4(px[h]) : z4;
+                ry[h] = (yrow && oky[h]) ? st_ld4(pa + h * 64) : z4;
+                px[h] += (size_t)TN_BK * g.lddc;
+            }
+            mreq += TN_BK; cto += TN_BK;
+            while (cto >= g.Tout) { cto -= g.Tout; ++cb; }
+            return;
+        }
         if (fastp) {
             const bool row = mreq < mend;
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};

@@ -1269,7 +1269,18 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, 
     const size_t red_bytes = (size_t)8 * 1 * 64 * sizeof(f32x4);          // the product's static LDS in the same workgroup
     const bool wide = ab_wide(t, red_bytes);
     const size_t lds = ab_lds_bytes(t, wide);
-    ST_CHECK_ARG(lds + red_bytes <= 160 * 1024, "st_skinny_linear_packed_lstm_bwd_attn_bwd: L=%d needs %zu bytes of LDS", t.L, lds + red_bytes);
+    if (lds + red_bytes > 160 * 1024) {
+        // a text so long that the attention backward needs (nearly) all the LDS of a compute unit for itself: the two launches one after
+        // the other (they are independent: any order)
+        if (job) rc = st_skinny_linear_packed_lstm_bwd_fwd(packed_w, x, K, y, ldy, B, N, job, stream);
+        else rc = st_skinny_linear_packed_fwd(packed_w, x, K, nullptr, ST_ACT_NONE, nullptr, 0, y, ldy, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0,
+                                              nullptr, B, N, stream);
+        if (rc) return rc;
+        return st_attn_step_bwd_t16(ab->pq, ab->pm, ab->memory, ab->w_prev, ab->ld_wprev, ab->w_cum_prev, ab->w, ab->ld_w, ab->loc_conv_w,
+                                    ab->loc_lin_w, ab->v, ab->dctx, ab->ld_dctx, ab->n_dctx, ab->dw_direct, ab->ld_dw, ab->n_dw, ab->dcum,
+                                    ab->dcum_add, ab->ld_dcum_add, ab->dpq, &ab->dpq_t16, ab->dhist, ab->ds_t, ab->loc_t, ab->dloc_t,
+                                    ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in, ab->B, ab->L, ab->A, ab->E, ab->F, ab->K, stream);
+    }
     const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
     auto kern = wide ? pk_pw_ab_kernel<1, 8, 2, AB_LBLK_MAX> : pk_pw_ab_kernel<1, 8, 2, 16>;
     static size_t lds_set[2] = {0, 0};

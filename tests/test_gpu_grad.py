@@ -1014,3 +1014,28 @@ def test_weight_gradient_with_bias_gradient_in_the_same_launches(dev, M, N, Cin,
     assert torch.equal(dw, dw_ref)
     ref = dc.cpu().double().sum((0, 1))
     assert relerr(db, ref) < 2e-6
+
+
+def test_hosted_attention_backward_falls_back_for_texts_that_fill_the_lds(dev):
+    """L = 330: the attention backward alone needs 158 KB of LDS, so it cannot share a workgroup's LDS budget with the product it is hosted
+    beside (st_skinny_linear_packed_lstm_bwd_attn_bwd then runs the two launches one after the other): same gradients as the plain loop."""
+    from helpers import full_tacotron
+    m = full_tacotron(dev, seed=99, prenet_dropout=0.5).train()
+    dec = m.decoder
+    B, L, steps = 3, 330, 3
+    r, n_mels = dec.n_frames_per_step, dec.n_mels
+    mem0, spk0 = rnd(B, L, 512, seed=1).to(dev), rnd(B, 128, seed=2).to(dev)
+    teacher = torch.rand(B, steps * r, n_mels, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = {}
+    for mode in (True, False):
+        dec.bwd_overlap_attn = mode
+        for p in dec.parameters():
+            p.grad = None
+        torch.manual_seed(5)
+        mem, spk = mem0.clone().requires_grad_(), spk0.clone().requires_grad_()
+        mel, align, stop = dec(mem, None, teacher, spk, tf_rate=1.0)
+        torch.autograd.backward([mel, align, stop], [torch.ones_like(mel), torch.ones_like(align), torch.ones_like(stop)])
+        res[mode] = dict(dmem=mem.grad.clone(), **{k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+    dec.bwd_overlap_attn = True
+    for k, v in res[True].items():
+        assert torch.isfinite(v).all() and torch.equal(v, res[False][k]), k

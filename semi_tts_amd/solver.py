@@ -259,7 +259,8 @@ class TtsTrainer(BaseSolver):
         total.backward()
         self._reduce_gradients()
         grad_norm = self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
-        if self.async_stats and torch.is_tensor(grad_norm) and grad_norm.is_cuda:
+        from .optim import FusedAdam
+        if self.async_stats and torch.is_tensor(grad_norm) and grad_norm.is_cuda and isinstance(getattr(self.optimizer, 'opt', None), FusedAdam):
             # no host round trip inside the step: the NaN check of BaseSolver.backward (src/solver.py:147-150) runs on the device (a
             # non-finite norm makes the Adam launch a no-op) and the statistics stay device scalars until somebody reads them
             self.optimizer.step(guard_norm=grad_norm)

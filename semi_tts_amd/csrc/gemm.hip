@@ -259,14 +259,29 @@ __device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict_
     const int kb_hi = g.kb_per_split > 0 ? min(nkb, kb_lo + g.kb_per_split) : nkb;
     int tap_n = kb_lo / g.cpb, cb_n = kb_lo - tap_n * g.cpb;      // (tap, 16-float block within the tap) of the next block to request
     int left_n = kb_hi - kb_lo;                                   // blocks of the range not requested yet
+    // per-tap state of the 16-byte form (see issue())
+    const float* pa_tap = abase; const float* pw_tap = wbase;
+    bool oka_tap = false, okw_tap = false, pool_tap = false;
+    auto set_tap = [&]() __attribute__((always_inline)) {
+        const int tap = min(tap_n, g.KT - 1);
+        const int ti = t_base + tap;
+        const int tic = min(max(ti, 0), g.Tin - 1);
+        pa_tap = abase + (size_t)tic * g.lda;
+        pw_tap = VECW ? wbase + (size_t)tap * g.Cin : wbase + tap;
+        oka_tap = tap_n < g.KT && a_row_ok && ti >= 0 && ti < g.Tin;
+        okw_tap = tap_n < g.KT && w_row_ok;
+        pool_tap = tic > 0;
+    };
+    if (VECA) set_tap();
     auto issue = [&](Blk& r) __attribute__((always_inline)) {
         const int ci = cb_n * GM_BK + skq * 4;
         const bool in_k = left_n > 0 && tap_n < g.KT && ci < g.Cin;
         --left_n;
-        const int tap = min(tap_n, g.KT - 1), cic = min(ci, g.Cin - 4);
-        const int ti = t_base + tap;
-        const int tic = min(max(ti, 0), g.Tin - 1);
+        const int cic = min(ci, g.Cin - 4);
         if (!VECA) {
+            const int tap = min(tap_n, g.KT - 1);
+            const int ti = t_base + tap;
+            const int tic = min(max(ti, 0), g.Tin - 1);
             const int c0 = min(ci, g.Cin - 1), c1 = min(ci + 1, g.Cin - 1), c2 = min(ci + 2, g.Cin - 1), c3 = min(ci + 3, g.Cin - 1);
             const float* pa = abase + (size_t)tic * g.lda;
             r.a = f32x4{pa[c0], pa[c1], pa[c2], pa[c3]};
@@ -283,18 +298,20 @@ __device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict_
             if (++cb_n == g.cpb) { cb_n = 0; ++tap_n; }
             return;
         }
-        const float* pa = abase + (size_t)tic * g.lda + cic;
-        r.a = st_ld4(pa);
-        if (POOL) r.q = st_ld4(tic > 0 ? pa - g.lda : pa);       // MaxPool1d(2, stride 1, padding 1)[:T] fused into the load
-        r.va = in_k && a_row_ok && ti >= 0 && ti < g.Tin;
+        // (16-byte form: everything that only changes with the TAP -- the clamped row pointer of A, the weight pointer, the row
+        //  validity -- is kept from block to block and refreshed by set_tap() when the tap advances: per block there is one clamp of the
+        //  column, two pointer adds and the loads.  The per-block 64-bit address arithmetic cost as much issue time as the block's MFMAs.)
+        r.a = st_ld4(pa_tap + cic);
+        if (POOL) r.q = st_ld4((pool_tap ? pa_tap - g.lda : pa_tap) + cic);       // MaxPool1d(2, stride 1, padding 1)[:T] fused into the load
+        r.va = in_k && oka_tap;
         if (VECW) {  // Linear weight (KT == 1) or tap-major conv weight (N, KT, Cin): a k-block is contiguous
-            r.w = st_ld4(wbase + (size_t)tap * g.Cin + cic);
+            r.w = st_ld4(pw_tap + cic);
         } else {     // torch Conv1d weight (N, Cin, KT): stride KT between consecutive ci
-            const float* pw = wbase + (size_t)cic * g.KT + tap;
+            const float* pw = pw_tap + (size_t)cic * g.KT;
             r.w = f32x4{pw[0], pw[g.KT], pw[2 * g.KT], pw[3 * g.KT]};
         }
-        r.vw = in_k && w_row_ok;
-        if (++cb_n == g.cpb) { cb_n = 0; ++tap_n; }
+        r.vw = in_k && okw_tap;
+        if (++cb_n == g.cpb) { cb_n = 0; ++tap_n; set_tap(); }
     };
     auto commit = [&](const Blk& r, const int buf, const int half) __attribute__((always_inline)) {
         f32x4 va = r.a;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     }
     const bool fastp = whole && g.lin;
     // ... and convolutions (one tap per workgroup, no pooling): the (utterance, frame) of the thread's row is carried from chunk to chunk
-    const bool fastc = whole && !g.lin && !g.fold && !g.pool_prev;
+    const bool fastc = whole && !g.lin && !g.fold;          // (a pooled input: two 16-byte loads and a max per piece)
     int mreq = mbeg + sm;                      // (fast paths: the row the next request takes; requests come in chunk order)
     int cb = 0, cto = 0;
     if (fastc) { cb = mreq / g.Tout; cto = mreq - cb * g.Tout; }
@@ -155,6 +155,10 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
             for (int h = 0; h < NH; ++h) {
                 rx[h] = (row && okx[h]) ? st_ld4(px[h]) : z4;
                 ry[h] = (yrow && oky[h]) ? st_ld4(pa + h * 64) : z4;
+                if (g.pool_prev && yrow && ti > 0 && oky[h]) {       // MaxPool1d(2, stride 1, padding 1)[:T] of the forward, fused into the load
+                    const f32x4 q = st_ld4(pa - g.lda + h * 64);
+                    ry[h] = f32x4{fmaxf(ry[h][0], q[0]), fmaxf(ry[h][1], q[1]), fmaxf(ry[h][2], q[2]), fmaxf(ry[h][3], q[3])};
+                }
                 px[h] += (size_t)TN_BK * g.lddc;
             }
             mreq += TN_BK; cto += TN_BK;

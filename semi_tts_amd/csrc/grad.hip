@@ -129,7 +129,7 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
     // the row index, the remainder logic) costs as many issue cycles per chunk as the 16 MFMAs of a 64-tile wave
     const float* px[NH]; const float* py[NH];
     bool okx[NH], oky[NH];
-    bool whole = g.vecx && g.vecy;
+    bool whole = true;          // (16-byte loads also from rows that are only 4-byte aligned: st_ld4_u)
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int colx = n0 + sc + h * 64, ci = c0 + sc + h * 64;
@@ -153,10 +153,10 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
-                rx[h] = (row && okx[h]) ? st_ld4(px[h]) : z4;
-                ry[h] = (yrow && oky[h]) ? st_ld4(pa + h * 64) : z4;
+                rx[h] = (row && okx[h]) ? st_ld4_u(px[h]) : z4;
+                ry[h] = (yrow && oky[h]) ? st_ld4_u(pa + h * 64) : z4;
                 if (g.pool_prev && yrow && ti > 0 && oky[h]) {       // MaxPool1d(2, stride 1, padding 1)[:T] of the forward, fused into the load
-                    const f32x4 q = st_ld4(pa - g.lda + h * 64);
+                    const f32x4 q = st_ld4_u(pa - g.lda + h * 64);
                     ry[h] = f32x4{fmaxf(ry[h][0], q[0]), fmaxf(ry[h][1], q[1]), fmaxf(ry[h][2], q[2]), fmaxf(ry[h][3], q[3])};
                 }
                 px[h] += (size_t)TN_BK * g.lddc;
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
-                rx[h] = (row && okx[h]) ? st_ld4(px[h]) : z4;
-                ry[h] = (row && oky[h]) ? st_ld4(py[h]) : z4;
+                rx[h] = (row && okx[h]) ? st_ld4_u(px[h]) : z4;
+                ry[h] = (row && oky[h]) ? st_ld4_u(py[h]) : z4;
                 px[h] += (size_t)TN_BK * g.lddc; py[h] += (size_t)TN_BK * g.lda;
             }
             mreq += TN_BK;
@@ -594,7 +594,10 @@ extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int 
     }
     const int maxz = (M + 255) / 256;
     if (Z > maxz) Z = maxz;
-    if (Z > 96) Z = 96;          // the slabs are added by one thread per output element
+    // the slabs are added by one thread per output element: at most 96 of them -- 256 for a small matrix reduced over very many rows (the
+    // location conv / W_l gradients: 118k rows of the attention tapes into 2k / 8k elements, where 96 workgroups walk 77 chunks each)
+    const int zcap = (size_t)N * Cin * KT <= 16384 ? 256 : 96;
+    if (Z > zcap) Z = zcap;
     if (Z < 1) Z = 1;
     return (size_t)Z * N * Cin * KT + (size_t)Z * N;      // (+ the bias-gradient slabs of st_gemm_wgrad_db)
 }

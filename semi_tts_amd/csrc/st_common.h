@@ -135,6 +135,9 @@ __device__ __forceinline__ float st_wave_max_dpp(float v) {
     return fmaxf(fmaxf(st_lane(v, 0), st_lane(v, 16)), fmaxf(st_lane(v, 32), st_lane(v, 48)));
 }
 
+// 16-byte load of 4 consecutive floats from an address that is only 4-byte aligned (rows of 1025 floats): gfx950 under HSA serves
+// dword-aligned global_load_dwordx4 (the compiler emits exactly that for this copy)
+__device__ __forceinline__ f32x4 st_ld4_u(const float* p) { f32x4 v; __builtin_memcpy(&v, p, 16); return v; }
 // 16-byte global load of 4 consecutive floats (caller guarantees alignment)
 __device__ __forceinline__ f32x4 st_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 

@@ -8,4 +8,5 @@ mkdir -p $OUT
 DB=$(find $OUT/prof -name "*.db" | head -1)
 python $ROOT/tools/prof_train_step.py $DB --csv $OUT/train_one_step_kernel_stats.csv $2 > $OUT/train_one_step.txt
 head -60 $OUT/train_one_step.txt
+python $ROOT/tools/prof_tn.py $DB > $OUT/tn_launches.txt 2>&1
 rm -rf $OUT/prof

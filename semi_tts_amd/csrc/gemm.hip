@@ -284,12 +284,13 @@ __device__ __forceinline__ void gm_pipe_body(const GmArgs& g, float* __restrict_
             const int tic = min(max(ti, 0), g.Tin - 1);
             const int c0 = min(ci, g.Cin - 1), c1 = min(ci + 1, g.Cin - 1), c2 = min(ci + 2, g.Cin - 1), c3 = min(ci + 3, g.Cin - 1);
             const float* pa = abase + (size_t)tic * g.lda;
-            r.a = f32x4{pa[c0], pa[c1], pa[c2], pa[c3]};
+            const bool piece = ci + 4 <= g.Cin;           // a whole piece: one 16-byte load from the (4-byte aligned) row; only the tail goes by element
+            if (piece) r.a = st_ld4_u(pa + ci); else r.a = f32x4{pa[c0], pa[c1], pa[c2], pa[c3]};
             r.mk = (ci < g.Cin ? 1u : 0u) | (ci + 1 < g.Cin ? 2u : 0u) | (ci + 2 < g.Cin ? 4u : 0u) | (ci + 3 < g.Cin ? 8u : 0u);
             r.va = in_k && a_row_ok && ti >= 0 && ti < g.Tin;
             if (VECW) {      // Linear weight (KT == 1) or tap-major conv weight: consecutive ci are adjacent
                 const float* pw = wbase + (size_t)tap * g.Cin;
-                r.w = f32x4{pw[c0], pw[c1], pw[c2], pw[c3]};
+                if (piece) r.w = st_ld4_u(pw + ci); else r.w = f32x4{pw[c0], pw[c1], pw[c2], pw[c3]};
             } else {         // torch Conv1d weight (N, Cin, KT)
                 const float* pw = wbase + tap;
                 r.w = f32x4{pw[(size_t)c0 * g.KT], pw[(size_t)c1 * g.KT], pw[(size_t)c2 * g.KT], pw[(size_t)c3 * g.KT]};

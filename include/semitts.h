@@ -407,6 +407,19 @@ int st_bn_bwd_reduce(const float* dy, int ldd, int doff, const float* y, int ldy
 int st_bn_bwd_apply(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
                     const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
                     int M, int N, const float* s, int Mstat, float* dx, int lddx, int dxoff, void* stream);
+/* SyncBN (the data-parallel form of the BatchNorm1d layers above; the reference trains on one device, ref: src/module.py:434-455,
+ * so this is the path's own multi-GPU extension) with the row counts kept on the device:
+ *   st_bn_stats_record   rec (2N + 1) = (mean[N], M2[N], row count) of this rank's rows -- what the ranks all-gather;
+ *   st_bn_sync_merge     the gathered records (world, 2N + 1) -> mean / biased variance of the global batch, merged in rank order
+ *                        (identical on every rank), running statistics updated with the unbiased variance over the global count,
+ *                        *inv_total_out = 1 / (global row count);
+ *   st_bn_bwd_apply_sync st_bn_bwd_apply with s summed over all ranks and divided by the global count read from *inv_total. */
+int st_bn_stats_record(const float* X, int ldx, int coff, int M, int N, float* rec, long long* batches_tracked, float* ws, void* stream);
+int st_bn_sync_merge(const float* rec, int world, int N, float* mean_out, float* var_out, float* run_mean, float* run_var,
+                     float momentum, float* inv_total_out, void* stream);
+int st_bn_bwd_apply_sync(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                         const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+                         int M, int N, const float* s, const float* inv_total, float* dx, int lddx, int dxoff, void* stream);
 /* Highway combine y = H*T + x*(1-T) and its backward dH = dy*T, dT = dy*(H-x), dx_direct = dy*(1-T)
  * ref: src/module.py:551-554 */
 int st_highway_fwd(const float* H, const float* Tgate, const float* x, float* y, size_t total, void* stream);

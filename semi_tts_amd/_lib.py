@@ -249,6 +249,9 @@ SIGNATURES = {
     'st_bn_bwd': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, I, I, P, P, I, P, P],
     'st_bn_bwd_reduce': [P, I, I, P, I, I, I, P, I, I, P, P, F, I, I, P, P, P],
     'st_bn_bwd_apply': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, I, P, I, I, P],
+    'st_bn_stats_record': [P, I, I, I, I, P, P, P, P],
+    'st_bn_sync_merge': [P, I, I, P, P, P, P, F, P, P],
+    'st_bn_bwd_apply_sync': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, P, P, I, I, P],
     'st_highway_fwd': [P, P, P, P, Z, P],
     'st_highway_bwd': [P, P, P, P, P, P, P, Z, P],
     'st_pool_prev_bwd': [P, P, P, I, I, I, P],

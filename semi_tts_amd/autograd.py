@@ -101,32 +101,26 @@ class _BnTrainFn(Function):
         x2 = _rows(x)
         M = x2.shape[0]
         sync = parallel.sync_bn_active()
-        mean, var = ops.bn_stats(x2, 0, N, None if sync else run_mean, None if sync else run_var, momentum, batches_tracked)
-        scale = None
+        inv_total = None
         if sync:
-            # ONE collective: every rank's (mean, M2, count), merged exactly and identically on every rank in rank order
-            # (Chan et al.).  The counts stay on the device -- no host round trip, and shards of different sizes (a ragged
-            # last batch, B % world != 0, different T per rank in the speech encoder) are weighted by their true row counts.
+            # ONE collective: every rank's (mean, M2, count) record, written by the statistics launch itself and merged exactly and
+            # identically on every rank in rank order (Chan et al.) by one more launch.  The counts stay on the device -- no host
+            # round trip, and shards of different sizes (a ragged last batch, B % world != 0, different T per rank in the speech
+            # encoder) are weighted by their true row counts.
             parallel._COUNTS['syncbn_fwd'] += 1
-            rec = parallel.all_gather_(torch.cat([mean, var * M, parallel.count_tensor(M, mean.device)]))      # (world, 2N + 1)
-            cnt = rec[:, 2 * N:]
-            total = cnt.sum()
-            gmean = (rec[:, :N] * cnt).sum(0) / total
-            m2 = (rec[:, N:2 * N] + cnt * (rec[:, :N] - gmean) ** 2).sum(0)
-            mean, var = gmean, m2 / total
-            scale = float(M) / total              # the dx formula divides its two sums by the GLOBAL row count
-            if run_mean is not None:
-                run_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                run_var.mul_(1 - momentum).add_(m2 / (total - 1).clamp(min=1.0), alpha=momentum)
+            rec = parallel.all_gather_(ops.bn_stats_record(x2, 0, N, batches_tracked))      # (world, 2N + 1)
+            mean, var, inv_total = ops.bn_sync_merge(rec, N, run_mean, run_var, momentum)   # inv_total: 1 / the GLOBAL row count
+        else:
+            mean, var = ops.bn_stats(x2, 0, N, run_mean, run_var, momentum, batches_tracked)
         y = ops.bn_norm(x2, 0, N, mean, var, weight, bias, eps, act).view(x.shape)
-        ctx.save_for_backward(x, y if act is not None else None, mean, var, weight, scale)
+        ctx.save_for_backward(x, y if act is not None else None, mean, var, weight, inv_total)
         ctx.cfg = (eps, act, M, sync)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import parallel
-        x, y, mean, var, weight, scale = ctx.saved_tensors
+        x, y, mean, var, weight, inv_total = ctx.saved_tensors
         eps, act, M, sync = ctx.cfg
         dy2, y2, x2 = _rows(dy.contiguous()), _rows(y) if y is not None else None, _rows(x)
         N = x2.shape[1]
@@ -136,8 +130,7 @@ class _BnTrainFn(Function):
             db, dw = db.clone(), dw.clone()             # (s is all-reduced in place below; otherwise the views are handed out as they are)
             parallel._COUNTS['syncbn_bwd'] += 1
             parallel.all_reduce_sum_(s)
-            s = s * scale                         # s / M_local below == (sum over ranks) / M_global
-        dx = ops.bn_bwd_apply(dy2, y2, act, x2, mean, var, weight, eps, s, M)
+        dx = ops.bn_bwd_apply(dy2, y2, act, x2, mean, var, weight, eps, s, M, inv_total)     # sync: the sums / the GLOBAL row count
         return dx.view(x.shape), dw, db, None, None, None, None, None, None
 
 

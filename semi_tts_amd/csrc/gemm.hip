@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_kernel(const float* X, int
 // (one thread per column walking all the chunks took 16 us per layer: 2 x 64 dependent-latency iterations)
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, int chunks, int rows_per_chunk, int M, int N,
                                                              float* mean_out, float* var_out, float* run_mean, float* run_var,
-                                                             float momentum, long long* batches_tracked) {
+                                                             float momentum, long long* batches_tracked, int as_record) {
     constexpr int CL = 16, PER = 8;
     __shared__ float red[CL][16];
     __shared__ float smean[16];
@@ -584,11 +584,33 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, 
     for (int k = 0; k < CL; ++k) m2t += red[k][c];
     const float var_b = m2t / (float)M;
     mean_out[n] = mean;
-    var_out[n] = var_b;
+    var_out[n] = as_record ? m2t : var_b;          // record form (SyncBN): (mean, M2, row count) of this rank's rows, one buffer
+    if (as_record && n == 0) var_out[N] = (float)M;
     if (run_mean) {
         const float var_u = M > 1 ? m2t / (float)(M - 1) : var_b;
         run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
         run_var[n] = (1.0f - momentum) * run_var[n] + momentum * var_u;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_sync_merge_kernel(const float* rec, int world, int N, float* mean_out, float* var_out,
+                                                            float* run_mean, float* run_var, float momentum, float* inv_total_out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rs = (size_t)2 * N + 1;
+    float total = 0.0f;
+    for (int r = 0; r < world; ++r) total += rec[r * rs + 2 * N];
+    if (n == 0) inv_total_out[0] = 1.0f / total;
+    if (n >= N) return;
+    float a = 0.0f;
+    for (int r = 0; r < world; ++r) a = fmaf(rec[r * rs + 2 * N], rec[r * rs + n], a);
+    const float mean = a / total;
+    float m2 = 0.0f;
+    for (int r = 0; r < world; ++r) { const float d = rec[r * rs + n] - mean; m2 += rec[r * rs + N + n] + rec[r * rs + 2 * N] * d * d; }
+    mean_out[n] = mean;
+    var_out[n] = m2 / total;
+    if (run_mean) {
+        run_mean[n] = (1.0f - momentum) * run_mean[n] + momentum * mean;
+        run_var[n] = (1.0f - momentum) * run_var[n] + momentum * (m2 / fmaxf(total - 1.0f, 1.0f));
     }
 }
 
@@ -758,7 +780,36 @@ extern "C" int st_bn_stats(const float* X, int ldx, int coff, int M, int N, floa
     ST_LAUNCH_CHECK();
     ST_CHECK_ARG(chunks <= 128, "st_bn_stats: %d chunks (the merge kernel holds at most 128)", chunks);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream,
-                       ws, chunks, rpc, M, N, mean_out, var_out, run_mean, run_var, momentum, batches_tracked);
+                       ws, chunks, rpc, M, N, mean_out, var_out, run_mean, run_var, momentum, batches_tracked, 0);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// SyncBN, local half: rec = (mean[N], M2[N], row count) of THIS rank's rows -- what the ranks exchange in one all-gather
+extern "C" int st_bn_stats_record(const float* X, int ldx, int coff, int M, int N, float* rec, long long* batches_tracked, float* ws,
+                                  void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(X && rec && ws && M > 0 && N > 0, "st_bn_stats_record: bad arguments");
+    const int chunks = st_colreduce_chunks(M);
+    const int rpc = (M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(bn_stats_chunk_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, X, ldx, coff, M, N, rpc, ws);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                       ws, chunks, rpc, M, N, rec, rec + N, nullptr, nullptr, 0.0f, batches_tracked, 1);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// SyncBN, merged half: the gathered records of all ranks (world, 2N + 1) -> the statistics of the global batch, merged exactly and in
+// rank order (Chan et al.), identically on every rank; running statistics updated as nn.BatchNorm1d does (unbiased variance over the
+// GLOBAL row count); inv_total_out = 1 / (global row count), the factor the backward's two sums are divided by
+extern "C" int st_bn_sync_merge(const float* rec, int world, int N, float* mean_out, float* var_out, float* run_mean, float* run_var,
+                                float momentum, float* inv_total_out, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(rec && mean_out && var_out && inv_total_out && world > 0 && N > 0, "st_bn_sync_merge: bad arguments");
+    ST_CHECK_ARG((run_mean == nullptr) == (run_var == nullptr), "st_bn_sync_merge: run_mean/run_var must both be given");
+    hipLaunchKernelGGL(bn_sync_merge_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rec, world, N, mean_out, var_out,
+                       run_mean, run_var, momentum, inv_total_out);
     ST_LAUNCH_CHECK();
     return 0;
 }

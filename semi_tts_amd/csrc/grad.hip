@@ -417,9 +417,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
                                                            int act, const float* x, int ldx, int xoff, const float* mean,
                                                            const float* var, const float* w, float eps, int M, int N,
                                                            const float* s1, const float* s2, float* dx, int lddx, int dxoff,
-                                                           int Mstat) {
+                                                           int Mstat, const float* inv_total) {
     const size_t total = (size_t)M * N;
-    const float invM = 1.0f / (float)Mstat;     // rows the statistics (and s1, s2) were taken over: > M under SyncBN
+    // rows the statistics (and s1, s2) were taken over: > M under SyncBN, where 1 / (global row count) comes as a device scalar
+    const float invM = inv_total ? inv_total[0] : 1.0f / (float)Mstat;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t m = i / N;
         const int n = (int)(i - m * N);
@@ -699,16 +700,32 @@ extern "C" int st_bn_bwd_reduce(const float* dy, int ldd, int doff, const float*
     return 0;
 }
 
-extern "C" int st_bn_bwd_apply(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
-                               const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
-                               int M, int N, const float* s, int Mstat, float* dx, int lddx, int dxoff, void* stream) {
+static int bn_bwd_apply_impl(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                             const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+                             int M, int N, const float* s, int Mstat, const float* inv_total, float* dx, int lddx, int dxoff, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dy && x && mean && var && s && dx && M > 0 && N > 0 && Mstat >= M && (act == ST_ACT_NONE || y), "st_bn_bwd_apply: bad arguments");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, (hipStream_t)stream, dy, ldd, doff, y, ldy, yoff,
-                       act, x, ldx, xoff, mean, var, w, eps, M, N, s, s + N, dx, lddx, dxoff, Mstat);
+                       act, x, ldx, xoff, mean, var, w, eps, M, N, s, s + N, dx, lddx, dxoff, Mstat, inv_total);
     ST_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int st_bn_bwd_apply(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                               const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+                               int M, int N, const float* s, int Mstat, float* dx, int lddx, int dxoff, void* stream) {
+    return bn_bwd_apply_impl(dy, ldd, doff, y, ldy, yoff, act, x, ldx, xoff, mean, var, w, eps, M, N, s, Mstat, nullptr, dx, lddx, dxoff, stream);
+}
+
+// st_bn_bwd_apply under SyncBN: s holds the sums over ALL ranks' rows and *inv_total (device scalar, st_bn_sync_merge) = 1 / their count
+extern "C" int st_bn_bwd_apply_sync(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
+                                    const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
+                                    int M, int N, const float* s, const float* inv_total, float* dx, int lddx, int dxoff, void* stream) {
+    ST_CHECK_ARG(inv_total, "st_bn_bwd_apply_sync: null inv_total");
+    return bn_bwd_apply_impl(dy, ldd, doff, y, ldy, yoff, act, x, ldx, xoff, mean, var, w, eps, M, N, s, M, inv_total, dx, lddx, dxoff, stream);
+}
+
+
 
 extern "C" int st_bn_bwd(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
                          const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,

@@ -398,6 +398,27 @@ def bn_stats(x2d, coff, N, run_mean=None, run_var=None, momentum=0.1, batches_tr
     return mean, var
 
 
+def bn_stats_record(x2d, coff, N, batches_tracked=None):
+    """SyncBN, local half: (mean[N], M2[N], row count) of this rank's rows of x2d[:, coff:coff+N], as one (2N + 1) record"""
+    M = x2d.shape[0]
+    rec = torch.empty(2 * N + 1, device=x2d.device, dtype=torch.float32)
+    check(_lib.load().st_bn_stats_record(_p(x2d), int(x2d.stride(0)), int(coff), M, N, _p(rec), _p(batches_tracked, torch.int64),
+                                         _p(_colreduce_ws(M, N, x2d.device)), stream_handle()), 'st_bn_stats_record')
+    return rec
+
+
+def bn_sync_merge(rec, N, run_mean=None, run_var=None, momentum=0.1):
+    """SyncBN, merged half: the gathered (world, 2N + 1) records -> (mean, var, 1 / global row count) of the global batch in one
+    launch (+ running-stat update in place)"""
+    world = rec.shape[0]
+    assert rec.is_contiguous() and rec.shape[1] == 2 * N + 1
+    out = torch.empty(2 * N + 1, device=rec.device, dtype=torch.float32)
+    mean, var, inv_total = out[:N], out[N:2 * N], out[2 * N:]
+    check(_lib.load().st_bn_sync_merge(_p(rec), world, N, _p(mean), _p(var), _p(run_mean), _p(run_var), float(momentum), _p(inv_total),
+                                       stream_handle()), 'st_bn_sync_merge')
+    return mean, var, inv_total
+
+
 def layer_norm(x2d, gamma, beta, eps, want_stats=False):
     """nn.LayerNorm over the last dimension of (M, N) rows -> y [, mean (M), rstd (M)]"""
     M, N = x2d.shape
@@ -715,9 +736,15 @@ def bn_bwd_reduce(dy2d, y2d, act, x2d, mean, var, eps):
     return s
 
 
-def bn_bwd_apply(dy2d, y2d, act, x2d, mean, var, w, eps, s, Mstat):
+def bn_bwd_apply(dy2d, y2d, act, x2d, mean, var, w, eps, s, Mstat, inv_total=None):
+    """inv_total (device scalar, bn_sync_merge): s holds sums over all ranks' rows, divide them by the global count"""
     M, N = x2d.shape
     dx = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    if inv_total is not None:
+        check(_lib.load().st_bn_bwd_apply_sync(_p(dy2d), int(dy2d.stride(0)), 0, _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, 0,
+                                               ACT[act], _p(x2d), int(x2d.stride(0)), 0, _p(mean), _p(var), _p(w), float(eps), M, N,
+                                               _p(s), _p(inv_total), _p(dx), N, 0, stream_handle()), 'st_bn_bwd_apply_sync')
+        return dx
     check(_lib.load().st_bn_bwd_apply(_p(dy2d), int(dy2d.stride(0)), 0, _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, 0,
                                       ACT[act], _p(x2d), int(x2d.stride(0)), 0, _p(mean), _p(var), _p(w), float(eps), M, N, _p(s),
                                       int(Mstat), _p(dx), N, 0, stream_handle()), 'st_bn_bwd_apply')

@@ -249,21 +249,6 @@ class GradReducer:
         self._hooks = []
 
 
-_COUNT_T = {}
-
-
-def count_tensor(n, device):
-    """one-element device tensor holding float(n), cached per (n, device): building it from a Python number is a blocking
-    host -> device copy, and SyncBN needs its row count on the device 13 times per step"""
-    key = (int(n), str(device))
-    t = _COUNT_T.get(key)
-    if t is None:
-        if len(_COUNT_T) > 64:
-            _COUNT_T.clear()
-        t = _COUNT_T[key] = torch.tensor([float(n)], device=device, dtype=torch.float32)
-    return t
-
-
 def all_gather_(t):
     """(world, *t.shape) tensor of every rank's `t`; device tensors are staged through the host for the gloo backend"""
     world = dist.get_world_size()

@@ -89,3 +89,37 @@ def test_two_rank_sync_bn_training_equals_single_process(tmp_path, cut):
     for k, v in ref_stats.items():
         assert maxdiff(got['stats'][k], v) < 1e-5, k
     print('worst relative gradient difference DP vs single process: %.2e' % worst)
+
+
+@pytest.mark.parametrize('N', [80, 128, 7])
+def test_sync_bn_record_merge_kernels_equal_the_statistics_of_the_concatenated_batch(N):
+    """the two launches of the SyncBN forward (local record; merge of the gathered records) on three ragged shards = batch
+    statistics of all rows together, nn.BatchNorm1d's running update with the unbiased variance over the GLOBAL count, and the
+    backward's division by that count read from the device"""
+    from semi_tts_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(N)
+    shards = [(torch.randn(m, N, generator=g) * 2 + 0.5).to(dev) for m in (37, 1, 300)]
+    allrows = torch.cat(shards)
+    tracked = torch.zeros(1, dtype=torch.int64, device=dev)
+    recs = torch.stack([ops.bn_stats_record(x, 0, N, tracked if i == 0 else None) for i, x in enumerate(shards)])
+    assert int(tracked) == 1
+    assert [float(r[2 * N]) for r in recs] == [37.0, 1.0, 300.0]
+    rm, rv = torch.full((N,), 0.25, device=dev), torch.full((N,), 2.0, device=dev)
+    mean, var, inv_total = ops.bn_sync_merge(recs, N, rm, rv, 0.1)
+    assert float(inv_total) == pytest.approx(1.0 / 338.0, rel=1e-7)
+    assert maxdiff(mean, allrows.mean(0)) < 2e-6
+    assert maxdiff(var, allrows.var(0, unbiased=False)) < 1e-5
+    assert maxdiff(rm, 0.9 * 0.25 + 0.1 * allrows.mean(0)) < 1e-6
+    assert maxdiff(rv, 0.9 * 2.0 + 0.1 * allrows.var(0, unbiased=True)) < 1e-5
+    # one rank's record merged alone is that rank's own statistics
+    m1, v1, it1 = ops.bn_sync_merge(recs[2:3].contiguous(), N)
+    m0, v0 = ops.bn_stats(shards[2], 0, N)
+    assert maxdiff(m1, m0) < 1e-6 and maxdiff(v1, v0) < 1e-6 and float(it1) == pytest.approx(1.0 / 300.0, rel=1e-7)
+    # backward: the device-side 1 / count form is the host-side Mstat form
+    x = shards[0]
+    dy, w = torch.randn(37, N, generator=g).to(dev), torch.rand(N, generator=g).to(dev) + 0.5
+    s = torch.randn(2 * N, generator=g).to(dev)
+    a = ops.bn_bwd_apply(dy, None, None, x, mean, var, w, 1e-5, s, 338)
+    b = ops.bn_bwd_apply(dy, None, None, x, mean, var, w, 1e-5, s, 37, inv_total)
+    assert maxdiff(a, b) < 1e-6

@@ -460,6 +460,15 @@ int st_lstm_cell_pair_fwd(const st_seg* segs2, const float* const* b_hh2, const 
 int st_lstm_seq2_fwd(const float* const* xproj2, const float* const* w_hh2, const float* const* b_hh2, float* out, int ldo,
                      const int* ocol2, float* ws, float* const* gates_tape2, float* const* c_tape2,
                      int B, int T, int H, void* stream);
+/* The same layer as ONE launch for all T steps (H % 64 == 0, H <= 512, B <= 64, 2 * H/4 workgroups resident at once): the recurrent
+ * weights and the cell states stay in registers, h_{t-1} is polled straight out of `out`, which the entry first fills with a sentinel
+ * (every h is written exactly once: the data is the flag).  *status (optional device word): bit 1 set when a wait timed out -- the launch
+ * was starved of compute units, the affected rows are NaN.  st_lstm_seq2_persist_supported tells whether a shape is taken.
+ * ref: nn.LSTM src/module.py:432-438,458-460 */
+int st_lstm_seq2_persist_supported(int B, int T, int H, int ldo, int ocol0, int ocol1);
+int st_lstm_seq2_persist_fwd(const float* const* xproj2, const float* const* w_hh2, const float* const* b_hh2, float* out, int ldo,
+                             const int* ocol2, float* const* gates_tape2, float* const* c_tape2,
+                             int B, int T, int H, unsigned* status, void* stream);
 /* backward of both directions at once (see st_lstm_seq_bwd; arrays of two, ws: 4*B*H floats): one pointwise launch and one
  * W_hh^T launch per time step for the two directions */
 int st_lstm_seq2_bwd(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,

@@ -410,6 +410,181 @@ __device__ __forceinline__ void lstm_bwd_pw_body(const LstmPwArgs& a) {
     }
 }
 
+// ---- both directions of a bidirectional LSTM layer, ALL time steps in ONE launch -------------------------------------------------------
+// The per-step form above is one launch of ~5.4 us per step for 1.05 MB of recurrent weights per direction (43 launches for the text
+// encoder): the launch, not the work, is the step.  Here the layer is one launch of 2 * H/4 workgroups (128 of the 256 compute units at
+// H = 256), all resident at once.  Workgroup (tile, d) owns four hidden units of direction d: its 16 rows of W_hh (gates i, f, g, o of
+// the four units) stay in REGISTERS for the whole sequence (H/16 floats per lane: wave w holds the k-blocks w NKB .. w NKB + NKB - 1),
+// its cell states stay in registers, and a step is
+//   1. poll h_{t-1} of ALL units of the direction straight out of the layer's OUTPUT tensor: the launcher fills it with a sentinel bit
+//      pattern (0xFFFFFFFF, a NaN no arithmetic here produces) and every h is written exactly once with a write-through agent-scope
+//      store, so "the data is the flag" -- no tags, no fences, no extra buffer (the {value, tag} granules of the decode step cost twice
+//      the bytes).  Each wave re-reads its own K quarter of the B x H block (agent-scope loads) until no word is the sentinel;
+//   2. RT x NKB x 4 fp32 MFMAs per wave (D[gate row][batch] += W[gate row][k] h[batch][k]), the four waves' partial sums through LDS,
+//      ONE LDS-only barrier per step (two LDS buffers: a wave can run at most one step ahead of the workgroup's slowest wave);
+//   3. waves 0 .. RT-1: gates + the precomputed input projection (requested before the wait), the pointwise update, h to the output.
+// A step is then one cross-workgroup round trip (~2.3 us) + ~0.7 us of work instead of a launch.  A wait that does not complete
+// (workgroups not co-resident: another tenant holds compute units) gives up after LP_SPINS polls: bit 1 of *status is set, the rows of
+// that workgroup come out NaN, and every later wait of the launch polls once -- a starved launch ends, poisoned, instead of hanging.
+constexpr unsigned LP_SENTINEL = 0xFFFFFFFFu;
+constexpr int LP_SPINS = 1 << 16;
+struct LpArgs {
+    const float* xproj[2]; const float* w_hh[2]; const float* b_hh[2];
+    float* out; int ldo; int ocol[2];
+    float* gates_tape[2]; float* c_tape[2];
+    int B, T, H; unsigned* status;
+};
+
+__global__ __launch_bounds__(256) void lp_fill_kernel(float* out, int ldo, int ocol0, int ocol1, int H, int rows) {
+    const int h4 = H >> 2, per = 2 * h4;
+    const size_t total = (size_t)rows * per;
+    const f32x4 s = {__uint_as_float(LP_SENTINEL), __uint_as_float(LP_SENTINEL), __uint_as_float(LP_SENTINEL), __uint_as_float(LP_SENTINEL)};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / per;
+        const int c = (int)(i - row * per);
+        const int col = c < h4 ? ocol0 + 4 * c : ocol1 + 4 * (c - h4);
+        *reinterpret_cast<f32x4*>(out + row * ldo + col) = s;
+    }
+}
+
+template <int RT, int NKB>
+__global__ __launch_bounds__(256) void lstm_seq2_persist_kernel(const LpArgs a) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    __shared__ f32x4 red[2][4 * RT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, d = blockIdx.y;
+    const int H = a.H, T = a.T, B = a.B;
+    const int ar = lane & 15, q = lane >> 4;
+    // MFMA A operand: lane supplies row `ar` of the 16 x 4 block = (unit tile*4 + ar/4, gate ar%4), k = 16 kb + 4 q + cc for the cc-th of
+    // the four MFMAs of a k-block (the B operand uses the same k assignment, so the product is the plain one)
+    f32x4 wreg[NKB];
+    {
+        const float* wr = a.w_hh[d] + (size_t)((ar & 3) * H + tile * 4 + (ar >> 2)) * H + 4 * q;
+#pragma unroll
+        for (int i = 0; i < NKB; ++i) wreg[i] = st_ld4(wr + 16 * (wave * NKB + i));
+    }
+    const float* hp[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) hp[rt] = a.out + (size_t)min(rt * 16 + ar, B - 1) * T * a.ldo + a.ocol[d] + 16 * (wave * NKB) + 4 * q;
+    // pointwise role (waves 0 .. RT-1): batch row pb, hidden unit pu; D[row = 4 (lane >> 4) + r][col = lane & 15] -> r = gate
+    const int pb = wave * 16 + (lane & 15), pu = tile * 4 + (lane >> 4);
+    const bool pw = wave < RT && pb < B;
+    const int pbc = min(pb, B - 1);
+    float bh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.b_hh[d]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bh[r] = a.b_hh[d][r * H + pu];
+    }
+    const float* xp = a.xproj[d] + (size_t)pbc * T * 4 * H + pu;
+    float* op = a.out + (size_t)pbc * T * a.ldo + a.ocol[d] + pu;
+    const size_t bhs = (size_t)B * H;
+    float creg = 0.0f;
+    bool dead = false;
+    for (int s = 0; s < T; ++s) {
+        const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
+        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wave < RT) {      // does not depend on the recurrence: in flight during the wait
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre[r] = xp[(size_t)t * 4 * H + r * H];
+        }
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            f32x4 x[RT][NKB];
+            bool ok = false;
+            const int spins = dead ? 1 : LP_SPINS;
+            // (a) one CANARY word per producer workgroup and row tile of this wave's K range (its row 16 rt, first unit): a poll round
+            //     of the launch is 128 KB instead of the whole B x H block per workgroup (4 MB: the rounds, not the latency, were the step)
+            constexpr int NCAN = 4 * NKB * RT;
+            for (int sp = 0; sp < spins; ++sp) {
+                bool mine = true;
+#pragma unroll
+                for (int c0 = 0; c0 < NCAN; c0 += 64) {
+                    const int c = min(c0 + lane, NCAN - 1);
+                    const int crt = c / (4 * NKB), cj = c - crt * (4 * NKB);
+                    gu32* cp = (gu32*)(a.out + ((size_t)(crt * 16) * T + tp) * a.ldo + a.ocol[d] + 16 * (wave * NKB) + 4 * cj);
+                    mine = mine && __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != LP_SENTINEL;
+                }
+                if (__all(mine)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // (b) the block itself with plain loads (shared through the L2 by the workgroups of an XCD).  A word that still holds the
+            //     sentinel (the canary overtook a sibling store, or a line was cached half-written) sends the wave to (c)
+            {
+                bool mine = true;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int i = 0; i < NKB; ++i) {
+                        x[rt][i] = st_ld4(hp[rt] + (size_t)tp * a.ldo + 16 * i);
+                        mine = mine && __float_as_uint(x[rt][i][0]) != LP_SENTINEL && __float_as_uint(x[rt][i][1]) != LP_SENTINEL &&
+                               __float_as_uint(x[rt][i][2]) != LP_SENTINEL && __float_as_uint(x[rt][i][3]) != LP_SENTINEL;
+                    }
+                }
+                ok = __all(mine);
+            }
+            // (c) agent-scope re-reads of the block until it is complete
+            for (int sp = 0; sp < spins && !ok; ++sp) {
+                bool mine = true;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int i = 0; i < NKB; ++i) {
+                        gu64* gp = (gu64*)(hp[rt] + (size_t)tp * a.ldo + 16 * i);
+                        const unsigned long long lo = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long hi = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned u0 = (unsigned)lo, u1 = (unsigned)(lo >> 32), u2 = (unsigned)hi, u3 = (unsigned)(hi >> 32);
+                        mine = mine && u0 != LP_SENTINEL && u1 != LP_SENTINEL && u2 != LP_SENTINEL && u3 != LP_SENTINEL;
+                        x[rt][i] = f32x4{__uint_as_float(u0), __uint_as_float(u1), __uint_as_float(u2), __uint_as_float(u3)};
+                    }
+                }
+                ok = __all(mine);
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && !dead) {
+                dead = true;       // (a word still holding the sentinel is a NaN: the rows of this workgroup are poisoned from here on)
+                if (lane == 0 && a.status) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < NKB; ++i) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i][cc], x[rt][i][cc], acc[rt], 0, 0, 0);
+                }
+            }
+        }
+        f32x4* rb = red[s & 1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) rb[(wave * RT + rt) * 64 + lane] = acc[rt];
+        st_lds_barrier();
+        if (wave < RT) {
+            f32x4 g4 = rb[wave * 64 + lane];                               // (wave 0's partial of row tile `wave`)
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const f32x4 p = rb[(w * RT + wave) * 64 + lane]; g4[0] += p[0]; g4[1] += p[1]; g4[2] += p[2]; g4[3] += p[3]; }
+            float g[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = g4[r] + (bh[r] + pre[r]);
+            const float gi = st_sigmoid_fast(g[0]), gf = st_sigmoid_fast(g[1]), gg = st_tanh_fast(g[2]), go = st_sigmoid_fast(g[3]);
+            const float c2 = gf * creg + gi * gg;
+            float h2 = go * st_tanh_fast(c2);
+            if (h2 != h2) h2 = __uint_as_float(0x7FC00000u);      // (a NaN must not look like the sentinel: the consumers would wait for it)
+            creg = c2;
+            if (pw) {
+                __hip_atomic_store((gu32*)(op + (size_t)t * a.ldo), __float_as_uint(h2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.c_tape[d]) a.c_tape[d][(size_t)t * bhs + (size_t)pb * H + pu] = c2;
+                if (a.gates_tape[d]) {
+                    float* gp = a.gates_tape[d] + (size_t)t * 4 * bhs + (size_t)pb * 4 * H + pu;
+                    gp[0] = gi; gp[H] = gf; gp[2 * H] = gg; gp[3 * H] = go;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lstm_bwd_pw_kernel(const LstmPwArgs a) { lstm_bwd_pw_body(a); }
 // two cells of the same shape in one launch (blockIdx.y picks the job): both directions of a bidirectional layer
 __global__ __launch_bounds__(256) void lstm_bwd_pw_pair_kernel(const LstmPwArgs a0, const LstmPwArgs a1) {
@@ -509,6 +684,50 @@ extern "C" int st_lstm_seq2_fwd(const float* const* xproj2, const float* const* 
         int rc = st_lstm_cell_pair_fwd(seg, bh2, pre, T * 4 * H, cprev, H, hout, T * ldo, cnew, H, gout, B, H, stream);
         if (rc) return rc;
     }
+    return 0;
+}
+
+// The whole bidirectional layer as ONE launch (lstm_seq2_persist_kernel): shapes it takes
+extern "C" int st_lstm_seq2_persist_supported(int B, int T, int H, int ldo, int ocol0, int ocol1) {
+    const int nkb = H / 64;
+    return B > 0 && B <= 64 && T > 0 && H > 0 && H % 64 == 0 && (nkb == 1 || nkb == 2 || nkb == 4 || nkb == 8) &&
+           ldo % 4 == 0 && ocol0 % 4 == 0 && ocol1 % 4 == 0 && ocol0 >= 0 && ocol1 >= 0 && ldo >= ocol0 + H && ldo >= ocol1 + H &&
+           (ocol0 + H <= ocol1 || ocol1 + H <= ocol0) && 2 * (H / 4) <= st_device_cus();
+}
+
+template <int RT>
+static void lp_launch(const LpArgs& a, hipStream_t st) {
+    const dim3 grid(a.H / 4, 2), block(256);
+    switch (a.H / 64) {
+        case 1: hipLaunchKernelGGL((lstm_seq2_persist_kernel<RT, 1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((lstm_seq2_persist_kernel<RT, 2>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((lstm_seq2_persist_kernel<RT, 4>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((lstm_seq2_persist_kernel<RT, 8>), grid, block, 0, st, a); break;
+    }
+}
+
+extern "C" int st_lstm_seq2_persist_fwd(const float* const* xproj2, const float* const* w_hh2, const float* const* b_hh2, float* out, int ldo,
+                                        const int* ocol2, float* const* gates_tape2, float* const* c_tape2,
+                                        int B, int T, int H, unsigned* status, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(xproj2 && w_hh2 && out && ocol2 && xproj2[0] && xproj2[1] && w_hh2[0] && w_hh2[1], "st_lstm_seq2_persist_fwd: bad arguments");
+    ST_CHECK_ARG(st_lstm_seq2_persist_supported(B, T, H, ldo, ocol2[0], ocol2[1]),
+                 "st_lstm_seq2_persist_fwd: unsupported shape B=%d T=%d H=%d ldo=%d (see st_lstm_seq2_persist_supported)", B, T, H, ldo);
+    ST_CHECK_ARG(st_aligned16(out) && st_aligned16(w_hh2[0]) && st_aligned16(w_hh2[1]), "st_lstm_seq2_persist_fwd: out / w_hh must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    LpArgs a;
+    for (int d = 0; d < 2; ++d) {
+        a.xproj[d] = xproj2[d]; a.w_hh[d] = w_hh2[d]; a.b_hh[d] = b_hh2 ? b_hh2[d] : nullptr; a.ocol[d] = ocol2[d];
+        a.gates_tape[d] = gates_tape2 ? gates_tape2[d] : nullptr; a.c_tape[d] = c_tape2 ? c_tape2[d] : nullptr;
+    }
+    a.out = out; a.ldo = ldo; a.B = B; a.T = T; a.H = H; a.status = status;
+    const size_t pieces = (size_t)B * T * (H / 2);
+    hipLaunchKernelGGL(lp_fill_kernel, dim3((unsigned)((pieces + 255) / 256 < 1024 ? (pieces + 255) / 256 : 1024)), dim3(256), 0, st,
+                       out, ldo, ocol2[0], ocol2[1], H, B * T);
+    ST_LAUNCH_CHECK();
+    const int rt = (B + 15) / 16;
+    if (rt == 1) lp_launch<1>(a, st); else if (rt == 2) lp_launch<2>(a, st); else if (rt == 3) lp_launch<3>(a, st); else lp_launch<4>(a, st);
+    ST_LAUNCH_CHECK();
     return 0;
 }
 

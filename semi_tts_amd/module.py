@@ -616,6 +616,7 @@ class Decoder(nn.Module):
               'st_decoder_forward')
         if io.handoff_status and self.check_handoff and not ops.capturing():
             ops.check_handoff(self.handoff_status)
+            ops.check_persist_status(dev)           # (the text encoder's one-launch BiLSTM ran before this loop)
         if defer:
             kb = ops.kb16
             Bp = ((B + 15) // 16) * 16

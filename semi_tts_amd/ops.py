@@ -471,17 +471,56 @@ def lstm_seq(xproj, w_hh, b_hh, out, ocol, reverse, ws=None, gates_tape=None, c_
                               _p(gates_tape), _p(c_tape), B, T, H, 1 if reverse else 0, stream_handle()), 'st_lstm_seq_fwd')
 
 
+LSTM_PERSIST = True      # bidirectional LSTM layers as one launch for all steps where the shape allows (st_lstm_seq2_persist_fwd)
+_PERSIST_STATUS = {}
+
+
+def _dev_index(device):
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def persist_status(device):
+    """the device word the one-launch recurrent layers report a starved launch in (bit 1); see check_persist_status"""
+    key = _dev_index(device)
+    t = _PERSIST_STATUS.get(key)
+    if t is None:
+        t = _PERSIST_STATUS[key] = torch.zeros(1, device=torch.device('cuda', key), dtype=torch.int32)
+    return t
+
+
+def check_persist_status(device=None):
+    """Raise if a one-launch recurrent layer gave up waiting for its neighbour workgroups since the last check (the launch was starved
+    of compute units; the rows it produced are NaN).  Reads one device word per device (synchronises) and clears it."""
+    for key, t in list(_PERSIST_STATUS.items()):
+        if device is not None and key != _dev_index(device):
+            continue
+        v = int(t.item())
+        if v:
+            t.zero_()
+            raise RuntimeError('one-launch LSTM layer: a wait for the hidden state timed out (status word 0x%x): the launch was starved '
+                               'of compute units and its outputs are NaN.  Set semi_tts_amd.ops.LSTM_PERSIST = False to run the layer '
+                               'as one launch per time step.' % v)
+
+
 def lstm_seq2(xproj_f, xproj_b, w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, gates_tapes=None, c_tapes=None):
-    """both directions of a bidirectional LSTM layer, one launch per time step for the two of them; out (B,T,2H):
-    forward direction in columns [0,H), reverse in [H,2H)"""
+    """both directions of a bidirectional LSTM layer; out (B,T,2H): forward direction in columns [0,H), reverse in [H,2H).
+    One launch for the whole layer where st_lstm_seq2_persist_supported takes the shape, else one launch per time step."""
     lib = _lib.load()
     B, T, H4 = xproj_f.shape
     H = H4 // 4
-    ws = torch.empty(6 * B * H, device=xproj_f.device, dtype=torch.float32)
     P2 = C.c_void_p * 2
     arr = lambda a, b_: P2(_p(a), _p(b_))
     g2 = arr(*gates_tapes) if gates_tapes is not None else None
     c2 = arr(*c_tapes) if c_tapes is not None else None
+    if LSTM_PERSIST and out.stride(2) == 1 and out.stride(0) == T * out.stride(1) and \
+            lib.st_lstm_seq2_persist_supported(B, T, H, int(out.stride(1)), 0, H):
+        # all T steps in one launch (recurrent weights in registers, h handed over through `out` itself)
+        check(lib.st_lstm_seq2_persist_fwd(arr(xproj_f, xproj_b), arr(w_hh_f, w_hh_b), arr(b_hh_f, b_hh_b), _p(out), int(out.stride(1)),
+                                           (C.c_int * 2)(0, H), g2, c2, B, T, H, _p(persist_status(out.device), torch.int32), stream_handle()),
+              'st_lstm_seq2_persist_fwd')
+        return
+    ws = torch.empty(6 * B * H, device=xproj_f.device, dtype=torch.float32)
     check(lib.st_lstm_seq2_fwd(arr(xproj_f, xproj_b), arr(w_hh_f, w_hh_b), arr(b_hh_f, b_hh_b), _p(out), int(out.stride(1)),
                                (C.c_int * 2)(0, H), _p(ws), g2, c2, B, T, H, stream_handle()), 'st_lstm_seq2_fwd')
 
@@ -906,6 +945,7 @@ class Graph:
         self._stream = C.c_void_p()
         check(self.lib.st_stream_create(C.byref(self._stream)), 'st_stream_create')
         self.pool = torch.cuda.MemPool()
+        persist_status(torch.device('cuda', torch.cuda.current_device()))      # (allocated OUTSIDE the private pool: it outlives this graph)
 
     @contextmanager
     def memory(self):

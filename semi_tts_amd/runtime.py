@@ -35,6 +35,7 @@ class GraphedDecoder:
     def check(self):
         """raise if any replay since the last check had a starved in-launch hand-off (one device word, synchronises)"""
         ops.check_handoff(self.decoder.handoff_status)
+        ops.check_persist_status()
 
     def _run(self):
         masks = {'own': self.own_mask} if self.own_mask is not None else None
@@ -130,6 +131,12 @@ class GraphedTacotron2:
         if self.own_mask is not None:
             self.own_mask.bernoulli_(1.0 - self.p).div_(1.0 - self.p)
 
+    def check(self):
+        """raise if any replay since the last check had a starved in-launch hand-off (decode loop) or a starved one-launch LSTM layer
+        (text encoder); reads device words (synchronises)"""
+        ops.check_handoff(self.model.decoder.handoff_status)
+        ops.check_persist_status()
+
     def __call__(self, txt_embed=None, spkr_embed=None, redraw=True):
         if self.graph is None:
             self.capture()
@@ -179,6 +186,10 @@ class GraphedSpeechToText:
         with self.graph.capture(), self.graph.memory():
             self.outputs = self._run()
         return self
+
+    def check(self):
+        """raise if a one-launch LSTM layer of any replay since the last check was starved of compute units (synchronises)"""
+        ops.check_persist_status()
 
     def __call__(self, paired_mel=None, unpaired_mel=None):
         """-> the tuple VQVAE.speech_to_text returns (views of buffers the next call overwrites)"""

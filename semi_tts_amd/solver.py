@@ -14,6 +14,7 @@ import time
 import numpy as np
 import torch
 
+from . import ops
 from .vqvae import VQVAE, FRAME_PHN_RATIO
 
 INFERENCE_MARGIN_FRAMES = 40        # ref: bin/gen_specgram.py:17
@@ -129,6 +130,7 @@ class SpecgramGenerator(BaseSolver):
                     text, sid, None, None, None, None, frames + pad + INFERENCE_MARGIN_FRAMES, None, tf_rate=0.0)
             torch.cuda.synchronize()
             # (the eager forward has already checked the decode loop's hand-off status word: ops.check_handoff)
+            ops.check_persist_status(self.device)
             if not (bool(torch.isfinite(mel).all()) and bool(torch.isfinite(lin).all())):
                 raise RuntimeError('gen_specgram: non-finite spectrogram for batch starting at %s -- nothing written' % names[0])
             enc_step = (text != 0).sum(dim=-1).cpu().tolist()
@@ -269,6 +271,7 @@ class TtsTrainer(BaseSolver):
                              tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
         gn = float(grad_norm)
         if gn != gn:
+            ops.check_persist_status(self.device)        # (a starved one-launch LSTM layer is an error, not a skipped step)
             self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
         else:
             self.optimizer.step()

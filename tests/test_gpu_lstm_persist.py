@@ -1,0 +1,94 @@
+"""The bidirectional LSTM layer as ONE launch for all time steps (st_lstm_seq2_persist_fwd: recurrent weights and cell states in
+registers, h handed from workgroup to workgroup through the output tensor) against the one-launch-per-step form and against
+torch.nn.LSTM on the CPU.  Needs a real MI355X."""
+import pytest
+import torch
+
+from helpers import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(B, T, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    xp = [torch.randn(B, T, 4 * H, generator=g) for _ in range(2)]
+    w = [torch.randn(4 * H, H, generator=g) / H ** 0.5 for _ in range(2)]
+    b = [torch.randn(4 * H, generator=g) * 0.1 for _ in range(2)]
+    return xp, w, b
+
+
+def _run(xp, w, b, dev, persist, tapes):
+    from semi_tts_amd import ops
+    B, T, H4 = xp[0].shape
+    H = H4 // 4
+    out = torch.zeros(B, T, 2 * H, device=dev)
+    gs = [torch.zeros(T, B, 4, H, device=dev) for _ in range(2)] if tapes else None
+    cs = [torch.zeros(T, B, H, device=dev) for _ in range(2)] if tapes else None
+    old = ops.LSTM_PERSIST
+    ops.LSTM_PERSIST = persist
+    try:
+        ops.lstm_seq2(xp[0].to(dev), xp[1].to(dev), w[0].to(dev), w[1].to(dev), b[0].to(dev), b[1].to(dev), out, gs, cs)
+    finally:
+        ops.LSTM_PERSIST = old
+    torch.cuda.synchronize()
+    ops.check_persist_status(dev)
+    return out, gs, cs
+
+
+@pytest.mark.parametrize('B,T,H', [(32, 43, 256), (5, 7, 64), (64, 20, 128), (33, 9, 256), (16, 129, 256), (17, 5, 512)])
+def test_one_launch_bilstm_equals_the_per_step_form(B, T, H):
+    from semi_tts_amd import _lib
+    dev = torch.device('cuda:0')
+    assert _lib.load().st_lstm_seq2_persist_supported(B, T, H, 2 * H, 0, H)
+    xp, w, b = _layer(B, T, H, seed=B + T + H)
+    out_p, gs_p, cs_p = _run(xp, w, b, dev, True, True)
+    out_s, gs_s, cs_s = _run(xp, w, b, dev, False, True)
+    assert torch.isfinite(out_p).all()
+    assert maxdiff(out_p, out_s) < 3e-6
+    for d in range(2):
+        assert maxdiff(gs_p[d], gs_s[d]) < 3e-6 and maxdiff(cs_p[d], cs_s[d]) < 1e-5
+    # and torch.nn.LSTM given the same input projections: x = identity trick -- feed xproj through W_ih = I
+    lstm = torch.nn.LSTM(4 * H, H, batch_first=True, bidirectional=True)
+    with torch.no_grad():
+        for d, sfx in enumerate(('', '_reverse')):
+            getattr(lstm, 'weight_ih_l0' + sfx).copy_(torch.eye(4 * H))
+            getattr(lstm, 'bias_ih_l0' + sfx).zero_()
+            getattr(lstm, 'weight_hh_l0' + sfx).copy_(w[d])
+            getattr(lstm, 'bias_hh_l0' + sfx).copy_(b[d])
+        # (one input per direction: run the module twice and take each direction's half)
+        ref_f = lstm(xp[0])[0][:, :, :H]
+        ref_b = lstm(xp[1])[0][:, :, H:]
+    assert maxdiff(out_p[:, :, :H], ref_f) < 2e-5 and maxdiff(out_p[:, :, H:], ref_b) < 2e-5
+
+
+def test_one_launch_bilstm_is_deterministic_and_replays_in_a_graph():
+    from semi_tts_amd import ops
+    dev = torch.device('cuda:0')
+    B, T, H = 32, 43, 256
+    xp, w, b = _layer(B, T, H, seed=1)
+    a, _, _ = _run(xp, w, b, dev, True, False)
+    args = [t.to(dev) for t in (xp[0], xp[1], w[0], w[1], b[0], b[1])]
+    out = torch.zeros(B, T, 2 * H, device=dev)
+    g = ops.Graph()
+    with g.capture():
+        ops.lstm_seq2(*args, out)
+    for _ in range(3):
+        out.zero_()
+        g.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(out, a)
+    ops.check_persist_status(dev)
+
+
+def test_unsupported_shapes_take_the_per_step_form():
+    from semi_tts_amd import _lib
+    lib = _lib.load()
+    assert not lib.st_lstm_seq2_persist_supported(32, 43, 96, 192, 0, 96)        # H % 64
+    assert not lib.st_lstm_seq2_persist_supported(65, 43, 256, 512, 0, 256)      # more than four row tiles
+    assert not lib.st_lstm_seq2_persist_supported(32, 43, 1024, 2048, 0, 1024)   # 512 workgroups cannot be resident at once
+    assert not lib.st_lstm_seq2_persist_supported(32, 43, 256, 512, 0, 128)      # overlapping output columns
+    dev = torch.device('cuda:0')
+    xp, w, b = _layer(3, 5, 24, seed=2)
+    out, _, _ = _run(xp, w, b, dev, True, False)
+    ref, _, _ = _run(xp, w, b, dev, False, False)
+    assert torch.equal(out, ref)

@@ -514,6 +514,7 @@ def lstm_seq2(xproj_f, xproj_b, w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, gates_tapes
     g2 = arr(*gates_tapes) if gates_tapes is not None else None
     c2 = arr(*c_tapes) if c_tapes is not None else None
     if LSTM_PERSIST and out.stride(2) == 1 and out.stride(0) == T * out.stride(1) and \
+            all(t.data_ptr() % 16 == 0 for t in (out, w_hh_f, w_hh_b)) and w_hh_f.is_contiguous() and w_hh_b.is_contiguous() and \
             lib.st_lstm_seq2_persist_supported(B, T, H, int(out.stride(1)), 0, H):
         # all T steps in one launch (recurrent weights in registers, h handed over through `out` itself)
         check(lib.st_lstm_seq2_persist_fwd(arr(xproj_f, xproj_b), arr(w_hh_f, w_hh_b), arr(b_hh_f, b_hh_b), _p(out), int(out.stride(1)),

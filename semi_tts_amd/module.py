@@ -178,7 +178,8 @@ class Encoder(nn.Module):
             xp_f = ops.gemm(x, g('weight_ih'), bias=g('bias_ih'), collect=jobs)          # (B, L, 4H), all time steps at once;
             xp_b = ops.gemm(x, g('weight_ih', True), bias=g('bias_ih', True), collect=jobs)      # both directions in one launch
             ops.gemm_flush(jobs)
-            # the two directions advance together: one launch per time step for both
+            # the two directions advance together: the whole layer as ONE launch where the shape allows (H % 64 == 0: every shipped
+            # config), else one launch per time step for both
             ops.lstm_seq2(xp_f, xp_b, g('weight_hh'), g('weight_hh', True), g('bias_hh'), g('bias_hh', True), out)
             x = out
         return x

@@ -89,7 +89,7 @@ class GraphedDecoder:
 
 class GraphedTacotron2:
     """The whole Tacotron2.forward of free-running inference (text encoder -> decode loop -> CBHG postnet -> linear projection,
-    src/tts.py:36-51) captured into ONE hipGraph for fixed shapes: ~700 launches (3 encoder convs, 43 BiLSTM steps, 86 x 6 decode
+    src/tts.py:36-51) captured into ONE hipGraph for fixed shapes: ~480 launches (3 encoder convs, the BiLSTM layer as one launch, 86 x 5 decode
     launches, ~30 postnet launches) replayed with a single graph launch.  Same static-buffer discipline as GraphedDecoder."""
 
     def __init__(self, model, B, L, frames, device):

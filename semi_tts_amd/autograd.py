@@ -17,6 +17,18 @@ def _rows(t):
     return t.reshape(-1, t.shape[-1])
 
 
+def _rows_strided(t):
+    """(rows, N) view of a (..., N) tensor whose rows are evenly spaced in memory -- a column slice of a wider row-major buffer, e.g.
+    the gradient of one block of a torch.cat over channels -- WITHOUT a copy (the kernels take a row stride); a copy otherwise"""
+    if t.is_contiguous():
+        return t.view(-1, t.shape[-1])
+    if t.dim() >= 2 and t.stride(-1) == 1:
+        ld = t.stride(-2)
+        if ld >= t.shape[-1] and all(t.stride(i) == t.shape[i + 1] * t.stride(i + 1) for i in range(t.dim() - 2)):
+            return t.as_strided((t.numel() // t.shape[-1], t.shape[-1]), (ld, 1), t.storage_offset())
+    return t.contiguous().view(-1, t.shape[-1])
+
+
 class _ConvFn(Function):
     """y = [act(conv1d/linear(pool?(x)) + b) (+ res)] (* mask), channels-last"""
 
@@ -122,7 +134,7 @@ class _BnTrainFn(Function):
         from . import parallel
         x, y, mean, var, weight, inv_total = ctx.saved_tensors
         eps, act, M, sync = ctx.cfg
-        dy2, y2, x2 = _rows(dy.contiguous()), _rows(y) if y is not None else None, _rows(x)
+        dy2, y2, x2 = _rows_strided(dy), _rows(y) if y is not None else None, _rows(x)      # (dy: often a column slice of a cat's gradient)
         N = x2.shape[1]
         s = ops.bn_bwd_reduce(dy2, y2, act, x2, mean, var, eps)
         db, dw = s[:N], s[N:]                           # parameter gradients: local sums (averaged over ranks later)

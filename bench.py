@@ -153,8 +153,15 @@ def free_port():
     return p
 
 
+def _has_result_line(text):
+    return any(l.startswith('{') and '"metric"' in l for l in text.splitlines())
+
+
 def spawn_ranks(args):
-    """--gpus N > 1 without a launcher: start N fresh ranks (one per GPU) before this process touches the GPU."""
+    """--gpus N > 1 without a launcher: start N fresh ranks (one per GPU) before this process touches the GPU.  Should the
+    rank set die without printing its JSON line (a launcher or rendezvous problem the ranks' own RCCL probe cannot see), a
+    SECOND set of fresh ranks runs on gloo: the replica workloads only need a barrier and a max, the training workload
+    stages its all-reduce through the host (slow, flagged in the line).  No rank is ever re-executed."""
     import torch
     n_dev = torch.cuda.device_count()                  # counting devices does not initialise the GPU
     if args.gpus > n_dev and os.environ.get('ST_BENCH_BACKEND', 'nccl') == 'nccl':
@@ -166,13 +173,61 @@ def spawn_ranks(args):
     # with `hipIpcGetMemHandle: invalid argument` (environment notes of the build image, which exports it already; kept as a
     # default so that a launcher with a scrubbed environment still works).
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+
+    def run_set(e):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, text=True)
+        sys.stdout.write(r.stdout)
+        sys.stdout.flush()
+        return r.returncode, r.stdout
+    rc, out = run_set(env)
+    if (rc != 0 or not _has_result_line(out)) and env.get('ST_BENCH_BACKEND', 'nccl') == 'nccl':
+        sys.stderr.write('bench.py: the rank set exited with %d and no result line; second set of fresh ranks on gloo\n' % rc)
+        env2 = dict(env, ST_BENCH_BACKEND='gloo', ST_BENCH_RCCL_NOTE='first rank set exited with code %d before printing a line' % rc)
+        rc, out = run_set(env2)
+    return rc
+
+
+def rccl_probe_main():
+    """`bench.py --rccl-probe` (a CHILD of every rank, started before the rank touches the GPU): initialise RCCL with the rank's
+    coordinates on a port of its own, run one all-reduce over a device tensor and check the sum.  Exit code 0 = RCCL works on
+    this node; anything else (exception, crash, the parent's time-out on a hang) = it does not, and the ranks go on with gloo."""
+    if os.environ.get('ST_BENCH_FAKE_RCCL_FAIL') == '1':        # tests: what a failing peer-memory set-up looks like from outside
+        sys.stderr.write('rccl probe: failure faked by ST_BENCH_FAKE_RCCL_FAIL\n')
+        sys.exit(3)
+    import datetime
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ.get('LOCAL_RANK', '0'))
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.stderr.write('rccl probe: no GPU visible\n')
+        sys.exit(4)
+    dev = torch.device('cuda', local % n_dev)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=90))
+    t = torch.full((1 << 16,), float(rank + 1), device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    want = world * (world + 1) / 2.0
+    if float(t[0].item()) != want or float(t[-1].item()) != want:
+        sys.stderr.write('rccl probe: all-reduce returned %r, expected %r\n' % (float(t[0].item()), want))
+        sys.exit(5)
+    dist.barrier()
+    dist.destroy_process_group()
+    print('RCCL_PROBE_OK')
 
 
 class Ranks:
-    """rank bookkeeping + the barrier / max-over-ranks timing contract"""
+    """rank bookkeeping + the barrier / max-over-ranks timing contract.
+
+    N > 1: the ranks first meet on a TCP store (no GPU, no RCCL).  Every rank then runs `bench.py --rccl-probe` as a CHILD process
+    (this process has not touched the GPU yet) and posts the outcome; only when EVERY rank's probe passed is the process group
+    created on RCCL ('nccl' on ROCm).  Otherwise -- peer-memory set-up failing, a hang (the child is killed after
+    ST_BENCH_PROBE_TIMEOUT seconds), a crash -- the group is created on gloo: the replica workloads' only collectives are the
+    barrier and the max of the timing contract, so their line is produced either way, with `rccl_ranks: 0` and the probe's error
+    in `collectives`; the training workload then stages its reductions through the host and says so."""
 
     def __init__(self, args):
         import torch
@@ -181,39 +236,89 @@ class Ranks:
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         if self.world != args.gpus:
             raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, self.world))
-        assert torch.cuda.is_available(), 'bench.py needs a GPU'
-        # RCCL ('nccl' on ROCm).  ST_BENCH_BACKEND=gloo only exists to exercise the multi-rank path on a box with fewer GPUs
-        # than ranks (the ranks then share devices; reductions go through CPU tensors).
+        self.cpu_only = os.environ.get('ST_BENCH_ALLOW_CPU') == '1' and torch.cuda.device_count() == 0      # tests of this class
+        # ST_BENCH_BACKEND=gloo: skip the probe (a box with fewer GPUs than ranks: the ranks share devices, reductions go through
+        # CPU tensors; also the second rank set of spawn_ranks)
         self.backend = os.environ.get('ST_BENCH_BACKEND', 'nccl')
+        self.probe = os.environ.get('ST_BENCH_RCCL_NOTE') or ('not run (ST_BENCH_BACKEND=gloo)' if self.backend == 'gloo' else None)
         n_dev = torch.cuda.device_count()
-        if self.backend == 'nccl' and self.world > n_dev:
+        if self.backend == 'nccl' and self.world > max(n_dev, 1) and not self.cpu_only:
             raise SystemExit('bench.py: %d ranks but %d GPU(s)' % (self.world, n_dev))
-        self.local_dev = self.local_rank % n_dev
-        torch.cuda.set_device(self.local_dev)
-        self.dev = torch.device('cuda', self.local_dev)
         self.dist = None
         # --dist (or ST_BENCH_FORCE_DIST=1): initialise the process group even for ONE rank and force every collective to be
         # issued (parallel.force_collectives), so a 1-GPU box executes the RCCL branch end to end -- world-size-1 sums are the
         # identity, the numbers must equal the plain run's.  This process has not touched the GPU yet.
         self.forced = self.world == 1 and (getattr(args, 'dist', False) or os.environ.get('ST_BENCH_FORCE_DIST') == '1')
+        store = None
         if self.world > 1 or self.forced:
+            import datetime
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             if self.forced:
                 os.environ.setdefault('MASTER_PORT', str(free_port()))
+            # env:// rendezvous: under torch.distributed.run the launcher's agent hosts the store and every rank is a client
+            # (TORCHELASTIC_USE_AGENT_STORE), otherwise rank 0 hosts it
+            store, _, _ = next(dist.rendezvous('env://', rank=self.rank, world_size=self.world))
+            store.set_timeout(datetime.timedelta(seconds=900))
+            if self.backend == 'nccl' and self.world > 1:
+                self.backend, self.probe = self._probe_rccl(store)
+        if not self.cpu_only:
+            assert torch.cuda.is_available(), 'bench.py needs a GPU'
+            self.local_dev = self.local_rank % n_dev
+            torch.cuda.set_device(self.local_dev)
+            self.dev = torch.device('cuda', self.local_dev)
+        else:
+            self.dev = torch.device('cpu')
+        if store is not None:
             kw = {'device_id': self.dev} if self.backend == 'nccl' else {}
-            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+            dist.init_process_group(self.backend, store=dist.PrefixStore('pg_' + self.backend, store), rank=self.rank,
+                                    world_size=self.world, **kw)
             self.dist = dist
             if self.forced:
                 from semi_tts_amd import parallel
                 parallel.force_collectives(True)
 
-    def barrier(self):
+    def _probe_rccl(self, store):
+        """-> (backend, note): 'nccl' when every rank's child proved RCCL, else 'gloo' + the first error"""
+        if self.rank == 0:
+            store.set('probe_port', str(free_port()))
+        port = store.get('probe_port').decode()
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(self.rank), WORLD_SIZE=str(self.world),
+                   LOCAL_RANK=str(self.local_rank))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        limit = float(os.environ.get('ST_BENCH_PROBE_TIMEOUT', '300'))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--rccl-probe'], env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=limit)
+            ok = r.returncode == 0 and 'RCCL_PROBE_OK' in r.stdout
+            msg = 'ok' if ok else 'rank %d: exit %d: %s' % (self.rank, r.returncode, (r.stderr.strip().splitlines() or ['?'])[-1][:300])
+        except subprocess.TimeoutExpired:
+            ok, msg = False, 'rank %d: no answer within %.0f s (killed)' % (self.rank, limit)
+        store.set('probe_%d' % self.rank, msg)
+        msgs = [store.get('probe_%d' % r).decode() for r in range(self.world)]      # (blocks until every rank has posted)
+        bad = [m for m in msgs if m != 'ok']
+        if bad:
+            if self.rank == 0:
+                sys.stderr.write('bench.py: RCCL probe failed (%s); continuing on gloo\n' % bad[0])
+            return 'gloo', 'failed: ' + bad[0]
+        return 'nccl', 'ok'
+
+    def collectives_flat(self):
+        """what the JSON line says about the process group: `rccl_ranks` (0 = no RCCL group) + `collectives`"""
+        n = self.world if (self.dist is not None and self.backend == 'nccl') else 0
+        return {'rccl_ranks': n, 'collectives': {'backend': self.backend if self.dist is not None else None,
+                                                 'rccl_probe': self.probe if self.world > 1 else None}}
+
+    def sync(self):
         import torch
-        torch.cuda.synchronize()
+        if not self.cpu_only:
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        self.sync()
         if self.dist is not None:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        self.sync()
 
     def max_seconds(self, seconds):
         import torch
@@ -402,7 +507,7 @@ def bench_decode(args, rk):
                    'batch_per_gpu': B, 'frames': T, 'decode_steps': STEPS, 'text_len': L,
                    'parallelism': 'replicas x%d (utterance-sharded, no collective)' % rk.world,
                    'launch': 'eager' if graph is None else 'hipGraph replay of the whole decode loop'},
-        'rccl_ranks': rk.world if (rk.dist is not None and rk.backend == 'nccl') else 0,
+        **rk.collectives_flat(),
         'us_per_decode_step': round(us_step, 2),
         'roofline': roof,
     }
@@ -492,7 +597,7 @@ def bench_vq(args, rk):
                          'mfma': {'achieved': round(head['GFLOPs'] / 1e3, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': round(head['GFLOPs'] / 1e3 / MFMA_F32_PEAK_TFLOPS, 4)},
                          'algorithmic_bytes_per_launch': head['algorithmic_bytes'], 'avg_launch_us': head['us_per_launch']},
-            'cases': rows}
+            **rk.collectives_flat(), 'cases': rows}
     if cpu is not None:
         res['cpu_baseline'] = cpu
     return res
@@ -534,6 +639,10 @@ def bench_train(args, rk):
         parallel.sync_batchnorm(False)
         variants['no_syncbn'] = rk.timed(step, args.steps, 1)
         parallel.sync_batchnorm(True)
+    # a starved in-launch hand-off poisons the forward with NaN and the guarded Adam then skips every update on the device: a step
+    # time measured over skipped steps is not a measurement
+    tr.check_device_status()
+    assert float(last['st']['grad_norm']) == float(last['st']['grad_norm']), 'non-finite gradient norm in the timed steps'
     if rk.rank != 0:
         return None
     cpu = None
@@ -549,7 +658,7 @@ def bench_train(args, rk):
             'config': {'workload': 'C4: TtsTrainer.train_step, B=%d per GPU, %d->%d frames, L=%d, 109 speakers, tf_rate=1, '
                                    'config/semi-multi-spkr-paired-data.yaml' % (B, T_RAW, batch[2].shape[1], batch[0].shape[1]),
                        'parallelism': 'dp%d (utterance-sharded, SyncBN, gradient all-reduce of %.1f MB)' % (rk.world, n_par * 4 / 1e6)},
-            'rccl_ranks': rk.world if (rk.dist is not None and rk.backend == 'nccl') else 0,
+            **rk.collectives_flat(),
             'ms_allreduce': round(ms['full'] - ms['no_allreduce'], 3) if 'no_allreduce' in ms else 0.0,
             'ms_syncbn': round(ms['full'] - ms['no_syncbn'], 3) if 'no_syncbn' in ms else 0.0,
             'ms_variants': {k: round(v, 3) for k, v in ms.items()},
@@ -605,7 +714,10 @@ def main():
     ap.add_argument('--traffic-json', default=None, help='PMC summary (tools/pmc_summary.py) to quote as roofline.traffic')
     ap.add_argument('--workload', choices=['c2', 'c5', 'c3', 'train'], default='c2',
                     help="c2 = the headline configuration; c5 / c3 / train = secondary lines (see the module docstring)")
+    ap.add_argument('--rccl-probe', action='store_true', help=argparse.SUPPRESS)        # child of a rank: see Ranks._probe_rccl
     args = ap.parse_args()
+    if args.rccl_probe:
+        return rccl_probe_main()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))            # nothing above this line has touched the GPU
 

@@ -127,26 +127,44 @@ __global__ __launch_bounds__(VQ_WAVES * 64) void vq_l2_kernel(const float* x, co
 // Nearest-code search on the matrix cores (D <= 64, D % 4 == 0, V <= 1024): sims = X E^T is a GEMM with K = D, and the
 // exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: an fmaf chain over k, bitwise) reproduces the dimension-ascending dot product of
 // the scalar kernel above, so the indices stay what the reference's golden vectors pin.
-//   * the table is re-packed once per call into MFMA B-operand order (vq_pack_table_kernel, 4*V*D bytes, L2 resident):
+//   * the table is re-packed once per table version into MFMA B-operand order (vq_pack_table_kernel, L2 resident):
 //     [code tile of 16][group of 4 k-steps][lane][4 floats], plus |e|^2 per code -- a wave fetches a tile's operands with
 //     four 16-byte loads per lane;
-//   * a workgroup (4..16 waves) owns 16 input vectors; wave w scores the code tiles w, w+NW, ...: the softmax max / sum and the
-//     argmax are DPP reductions over the 16 lanes that hold one vector's codes, then over the waves through LDS;
+//   * PERSISTENT tile loop: a workgroup (4 waves, one per SIMD; two workgroups per compute unit when the registers allow) fetches
+//     its waves' table operands ONCE, keeps them in registers and walks the 16-vector tiles blockIdx.x, + gridDim.x, ...; the next
+//     tile's vectors are requested while the current one is scored.  (One tile per workgroup re-requested the whole packed table
+//     -- 131 KB at V = 512 -- per 16 vectors: 3.2x the problem's bytes in L2 reads, each behind a launch-to-first-MFMA latency.)
+//   * wave w scores TPW code tiles; the softmax max / sum and the argmax are DPP reductions over the 16 lanes that hold one
+//     vector's codes, then over the waves through LDS;
+//   * code <-> MFMA column: with TPW % 4 == 0 wave w owns the CONTIGUOUS codes [16 TPW w, 16 TPW (w + 1)) and column nn of its tile t
+//     is code 16 TPW w + 64 (t >> 2) + 4 nn + (t & 3): a lane then holds four consecutive codes of a vector (tiles 4h .. 4h + 3)
+//     and p_code leaves as 16-byte stores, 256 contiguous bytes per 16 lanes (it is 4V of the 520 + 4V bytes per vector).
+//     Per lane the codes still ascend with t (first maximum wins); TPW < 4 keeps code = 16 (w + NW t) + nn and 4-byte stores;
 //   * |x|^2 uses the same summation tree as the scalar kernel's wave butterfly (dims d, d^32 first ... d^1 last).
-// Algorithmic bytes per vector: 4D in + 4D out + 8 idx + 4V p_code; the packed table is read from L2 by every workgroup.
+// Algorithmic bytes per vector: 4D in + 4D out + 8 idx + 4V p_code; the packed table is read once per workgroup.
 constexpr int VQM_XLD = 68;
+constexpr int VQM_NW = 4;
 
-__global__ __launch_bounds__(256) void vq_pack_table_kernel(const float* table, int V, int D, float* ws, int n_ct, int ks4n) {
-    const size_t total = (size_t)n_ct * ks4n * 256;
+// code tiles per wave for a table of n_ct code tiles (the kernel instantiations below)
+__host__ __device__ inline int vq_tpw(int n_ct) { return n_ct <= 4 ? 1 : n_ct <= 8 ? 2 : n_ct <= 16 ? 4 : n_ct <= 32 ? 8 : 16; }
+// code held by column nn of packed tile pt = wave + NW * t
+__host__ __device__ inline int vq_code_of(int tpw, int pt, int nn) {
+    const int wave = pt % VQM_NW, t = pt / VQM_NW;
+    return tpw % 4 == 0 ? wave * 16 * tpw + (t >> 2) * 64 + nn * 4 + (t & 3) : pt * 16 + nn;
+}
+
+__global__ __launch_bounds__(256) void vq_pack_table_kernel(const float* table, int V, int D, float* ws, int n_pt, int ks4n, int tpw) {
+    const size_t total = (size_t)n_pt * ks4n * 256;
     float* e2 = ws + total;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + (size_t)n_ct * 16; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + (size_t)n_pt * 16; idx += (size_t)gridDim.x * blockDim.x) {
         if (idx < total) {
             const int c = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
-            const int blk = (int)(idx >> 8), ks4 = blk % ks4n, ct = blk / ks4n;
-            const int code = ct * 16 + (lane & 15), d = (ks4 * 4 + c) * 4 + (lane >> 4);
+            const int blk = (int)(idx >> 8), ks4 = blk % ks4n, pt = blk / ks4n;
+            const int code = vq_code_of(tpw, pt, lane & 15), d = (ks4 * 4 + c) * 4 + (lane >> 4);
             ws[idx] = (code < V && d < D) ? table[(size_t)code * D + d] : 0.0f;
         } else {                                        // sum(y.pow(2), -1): dimension-ascending fma chain (as the scalar kernel)
-            const int code = (int)(idx - total);
+            const int slot = (int)(idx - total);
+            const int code = vq_code_of(tpw, slot >> 4, slot & 15);
             float acc = 0.0f;
             if (code < V) {
                 f32x4 row[16];          // the whole row is requested up front (D <= 64, D % 4 == 0: checked on the host)
@@ -157,7 +175,7 @@ __global__ __launch_bounds__(256) void vq_pack_table_kernel(const float* table, 
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc = fmaf(row[q][c], row[q][c], acc);      // zeros past D leave the chain unchanged
             }
-            e2[code] = acc;
+            e2[slot] = acc;
         }
     }
 }
@@ -181,11 +199,13 @@ __device__ __forceinline__ void vq_best(float& v, int& i, float ov, int oi) { if
 template <int CTRL>
 __device__ __forceinline__ void vq_row_argmax_step(float& v, int& i) { const float ov = st_dpp<CTRL>(v); const int oi = vq_dpp_i<CTRL>(i); vq_best(v, i, ov, oi); }
 
-// NW waves per workgroup split the code tiles (tile = wave + NW * t, t < TPW)
-template <int NW, int TPW>     // V <= 16 * NW * TPW
-__global__ __launch_bounds__(NW * 64) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
-                                                                 float* p_code, int64_t* idx_out, float* out, int n, int D, int V,
-                                                                 int n_ct, int ks4n) {
+// TPW code tiles per wave (V <= 64 TPW); WPS = workgroups the launcher places per compute unit (register budget 512 / WPS per lane)
+template <int TPW, int WPS>
+__global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
+                                                                         float* p_code, int64_t* idx_out, float* out, int n, int D, int V,
+                                                                         int ks4n, int n_tiles, int p_vec4) {
+    constexpr int NW = VQM_NW;
+    constexpr bool PERM = TPW % 4 == 0;
     __shared__ __attribute__((aligned(16))) float xt[16 * VQM_XLD];
     __shared__ float xxs[NW][16];
     __shared__ float red[NW][16];
@@ -193,138 +213,173 @@ __global__ __launch_bounds__(NW * 64) void vq_l2_mfma_kernel(const float* x, con
     __shared__ int fidx[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, nn = lane & 15;
-    const int v0 = blockIdx.x * 16;
-    // operands of the first code tile of this wave are requested before anything else
     const f32x4* wsp = reinterpret_cast<const f32x4*>(ws);
-    const float* e2 = ws + (size_t)n_ct * ks4n * 256;
-    if (tid < 256) {   // stage the 16 input vectors (zeros past D and past n)
-        const int vec = tid >> 4, d4 = (tid & 15) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (v0 + vec < n && d4 < D) v = *reinterpret_cast<const f32x4*>(x + (size_t)(v0 + vec) * D + d4);
-        *reinterpret_cast<f32x4*>(xt + vec * VQM_XLD + d4) = v;
-    }
-    __syncthreads();
-    {   // |x|^2 with the butterfly tree of the scalar kernel: lane (vec = lane >> 2, j = lane & 3) owns dims j, j + 4, ...
-        const int vec = lane >> 2, j = lane & 3;
-        float a[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) { const float t = xt[vec * VQM_XLD + j + 4 * m]; a[m] = t * t; }
-#pragma unroll
-        for (int m = 0; m < 8; ++m) a[m] += a[m + 8];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] += a[m + 4];
-        a[0] += a[2]; a[1] += a[3];
-        float f = a[0] + a[1];
-        f += st_dpp<ST_DPP_QUAD_XOR2>(f);
-        f += st_dpp<ST_DPP_QUAD_XOR1>(f);
-        if (j == 0) xxs[wave][vec] = f;
-    }
-    float ax[16];                                   // A fragments: x[vec nn][4 ks + g]
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) ax[ks] = xt[nn * VQM_XLD + ks * 4 + g];
-    // every operand of this wave's code tiles is requested up front (one wave per SIMD: the register file holds all TPW tiles), so
-    // the table costs ONE round trip to L2; the MFMAs then run k-step by k-step ACROSS the tiles -- consecutive MFMAs write
-    // different accumulators (no dependent-issue stalls), and every accumulator still sums its dimensions in ascending order
-    f32x4 acc[TPW], bq[TPW][4];
+    const float* e2 = ws + (size_t)NW * TPW * ks4n * 256;
+    // the first tile's vectors (staging role of this thread: 16 bytes of vector tid >> 4; rows past n repeat the last one and are
+    // zeroed when they are written to LDS -- no branch around the load)
+    const int svec = tid >> 4, sd4 = min((tid & 15) * 4, D - 4);
+    const bool sd_ok = (tid & 15) * 4 < D;
+    int tile = blockIdx.x;
+    f32x4 xr = *reinterpret_cast<const f32x4*>(x + (size_t)min(tile * 16 + svec, n - 1) * D + sd4);
+    // every table operand of this wave: requested once, kept in registers for all the tiles of the workgroup
+    f32x4 bq[TPW][4];
     float e2v[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ct = min(wave + NW * t, n_ct - 1);        // tiles past the table repeat the last one (discarded below)
-        e2v[t] = e2[ct * 16 + nn];
+        const int pt = wave + NW * t;
+        e2v[t] = e2[pt * 16 + nn];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[t][q] = q < ks4n ? wsp[((size_t)ct * ks4n + q) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) bq[t][q] = q < ks4n ? wsp[((size_t)pt * ks4n + q) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q * 4 + c], bq[t][q][c], acc[t], 0, 0, 0);
-    // lane (g, nn) now holds dot(x[vec 4g + r], e[code (wave + NW t) * 16 + nn]) in acc[t][r]
     const float tscale = fmaxf(temp[0], 0.0f);          // F.relu(self.temp)
-    float xxr[4];
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int v0 = tile * 16;
+        *reinterpret_cast<f32x4*>(xt + svec * VQM_XLD + (tid & 15) * 4) = (sd_ok && v0 + svec < n) ? xr : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        {   // the next tile's vectors travel while this one is scored
+            const int nt = tile + (int)gridDim.x;
+            xr = *reinterpret_cast<const f32x4*>(x + (size_t)min(min(nt, n_tiles - 1) * 16 + svec, n - 1) * D + sd4);
+        }
+        {   // |x|^2 with the butterfly tree of the scalar kernel: lane (vec = lane >> 2, j = lane & 3) owns dims j, j + 4, ...
+            const int vec = lane >> 2, j = lane & 3;
+            float a[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xxr[r] = xxs[wave][4 * g + r];
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int m = 0; m < 16; ++m) { const float t = xt[vec * VQM_XLD + j + 4 * m]; a[m] = t * t; }
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const bool on = (wave + NW * t) * 16 + nn < V;
+            for (int m = 0; m < 8; ++m) a[m] += a[m + 8];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] += a[m + 4];
+            a[0] += a[2]; a[1] += a[3];
+            float f = a[0] + a[1];
+            f += st_dpp<ST_DPP_QUAD_XOR2>(f);
+            f += st_dpp<ST_DPP_QUAD_XOR1>(f);
+            if (j == 0) xxs[wave][vec] = f;
+        }
+        float ax[16];                                   // A fragments: x[vec nn][4 ks + g]
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) ax[ks] = xt[nn * VQM_XLD + ks * 4 + g];
+        // the MFMAs run k-step by k-step ACROSS the tiles -- consecutive MFMAs write different accumulators (no dependent-issue
+        // stalls), and every accumulator still sums its dimensions in ascending order
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q * 4 + c], bq[t][q][c], acc[t], 0, 0, 0);
+        // lane (g, nn) now holds dot(x[vec 4g + r], e[code of (tile wave + NW t, column nn)]) in acc[t][r]
+        float xxr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xxr[r] = xxs[wave][4 * g + r];
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const bool on = vq_code_of(TPW, wave + NW * t, nn) < V;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dist = (xxr[r] + e2v[t]) - 2.0f * acc[t][r];     // embed.py:210-212 association order
+                const float sim = on ? tscale * (-dist) : -INFINITY;
+                acc[t][r] = sim;
+                mx[r] = fmaxf(mx[r], sim);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mx[r] = vq_row_max(mx[r]); if (nn == 0) red[wave][4 * g + r] = mx[r]; }
+        __syncthreads();
+        float sm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float dist = (xxr[r] + e2v[t]) - 2.0f * acc[t][r];     // embed.py:210-212 association order
-            const float sim = on ? tscale * (-dist) : -INFINITY;
-            acc[t][r] = sim;
-            mx[r] = fmaxf(mx[r], sim);
+            float m = red[0][4 * g + r];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w][4 * g + r]);
+            mx[r] = m;
         }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { mx[r] = vq_row_max(mx[r]); if (nn == 0) red[wave][4 * g + r] = mx[r]; }
-    __syncthreads();
-    float sm[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float m = red[0][4 * g + r];
+            for (int r = 0; r < 4; ++r) { const float e = expf(acc[t][r] - mx[r]); acc[t][r] = e; sm[r] += e; }
+        __syncthreads();                                     // everybody has read the maxima: the slots are reused for the sums
 #pragma unroll
-        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w][4 * g + r]);
-        mx[r] = m;
-    }
+        for (int r = 0; r < 4; ++r) { sm[r] = vq_row_sum(sm[r]); if (nn == 0) red[wave][4 * g + r] = sm[r]; }
+        __syncthreads();
+        float bv[4] = {-1.f, -1.f, -1.f, -1.f};
+        int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
+        for (int r = 0; r < 4; ++r) {          // fixed order: wave 0, 1, ...
+            float sacc = red[0][4 * g + r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float e = expf(acc[t][r] - mx[r]); acc[t][r] = e; sm[r] += e; }
-    __syncthreads();                                     // everybody has read the maxima: the slots are reused for the sums
+            for (int w = 1; w < NW; ++w) sacc += red[w][4 * g + r];
+            sm[r] = sacc;
+        }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { sm[r] = vq_row_sum(sm[r]); if (nn == 0) red[wave][4 * g + r] = sm[r]; }
-    __syncthreads();
-    float bv[4] = {-1.f, -1.f, -1.f, -1.f};
-    int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        for (int t = 0; t < TPW; ++t) {
+            const int code = vq_code_of(TPW, wave + NW * t, nn);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {          // fixed order: wave 0, 1, ...
-        float sacc = red[0][4 * g + r];
+            for (int r = 0; r < 4; ++r) {
+                const float p = acc[t][r] / sm[r];
+                acc[t][r] = p;
+                if (code < V && p > bv[r]) { bv[r] = p; bi[r] = code; }      // ascending codes per lane: strict > keeps the first
+            }
+        }
+        if (PERM) {      // four consecutive codes per lane and vector: 16-byte stores, 256 contiguous bytes per 16 lanes
 #pragma unroll
-        for (int w = 1; w < NW; ++w) sacc += red[w][4 * g + r];
-        sm[r] = sacc;
-    }
+            for (int h = 0; h < (PERM ? TPW / 4 : 0); ++h) {
+                const int c0 = vq_code_of(TPW, wave + NW * 4 * h, nn);
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int code = (wave + NW * t) * 16 + nn;
+                for (int r = 0; r < 4; ++r) {
+                    const int vec = v0 + 4 * g + r;
+                    if (vec >= n || c0 >= V) continue;
+                    float* pp = p_code + (size_t)vec * V + c0;
+                    if (p_vec4 && c0 + 3 < V) *reinterpret_cast<f32x4*>(pp) = f32x4{acc[4 * h][r], acc[4 * h + 1][r], acc[4 * h + 2][r], acc[4 * h + 3][r]};
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (c0 + j < V) pp[j] = acc[4 * h + j][r];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int code = vq_code_of(TPW, wave + NW * t, nn);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int vec = v0 + 4 * g + r;
+                    if (code < V && vec < n) p_code[(size_t)vec * V + code] = acc[t][r];
+                }
+            }
+        }
+        __syncthreads();                                     // sums consumed: slots reused for the per-wave best
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float p = acc[t][r] / sm[r];
-            const int vec = v0 + 4 * g + r;
-            if (code < V && vec < n) p_code[(size_t)vec * V + code] = p;
-            if (code < V && p > bv[r]) { bv[r] = p; bi[r] = code; }      // ascending codes per lane: strict > keeps the first
+            vq_row_argmax_step<ST_DPP_QUAD_XOR1>(bv[r], bi[r]); vq_row_argmax_step<ST_DPP_QUAD_XOR2>(bv[r], bi[r]);
+            vq_row_argmax_step<ST_DPP_ROW_HALF_MIRROR>(bv[r], bi[r]); vq_row_argmax_step<ST_DPP_ROW_MIRROR>(bv[r], bi[r]);
+            if (nn == 0) { red[wave][4 * g + r] = bv[r]; redi[wave][4 * g + r] = bi[r]; }
         }
-    }
-    __syncthreads();                                     // sums consumed: slots reused for the per-wave best
+        __syncthreads();
+        if (tid < 16) {
+            float v = red[0][tid];
+            int i = redi[0][tid];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        vq_row_argmax_step<ST_DPP_QUAD_XOR1>(bv[r], bi[r]); vq_row_argmax_step<ST_DPP_QUAD_XOR2>(bv[r], bi[r]);
-        vq_row_argmax_step<ST_DPP_ROW_HALF_MIRROR>(bv[r], bi[r]); vq_row_argmax_step<ST_DPP_ROW_MIRROR>(bv[r], bi[r]);
-        if (nn == 0) { red[wave][4 * g + r] = bv[r]; redi[wave][4 * g + r] = bi[r]; }
-    }
-    __syncthreads();
-    if (tid < 16) {
-        float v = red[0][tid];
-        int i = redi[0][tid];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) vq_best(v, i, red[w][tid], redi[w][tid]);
-        fidx[tid] = i;
-        if (v0 + tid < n) idx_out[v0 + tid] = i;
-    }
-    __syncthreads();
-    {   // out = (x + code) - x.detach(): the straight-through forward value (embed.py:145)
-        const int vec = (tid >> 4) & 15, d4 = (tid & 15) * 4;
-        if (tid < 256 && v0 + vec < n && d4 < D) {
-            const f32x4 e = *reinterpret_cast<const f32x4*>(table + (size_t)fidx[vec] * D + d4);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + vec * VQM_XLD + d4);
-            f32x4 o;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = (xv[c] + e[c]) - xv[c];
-            *reinterpret_cast<f32x4*>(out + (size_t)(v0 + vec) * D + d4) = o;
+            for (int w = 1; w < NW; ++w) vq_best(v, i, red[w][tid], redi[w][tid]);
+            fidx[tid] = i;
+            if (v0 + tid < n) idx_out[v0 + tid] = i;
         }
+        __syncthreads();
+        {   // out = (x + code) - x.detach(): the straight-through forward value (embed.py:145)
+            const int d4 = (tid & 15) * 4;
+            if (v0 + svec < n && d4 < D) {
+                const f32x4 e = *reinterpret_cast<const f32x4*>(table + (size_t)fidx[svec] * D + d4);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + svec * VQM_XLD + d4);
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = (xv[c] + e[c]) - xv[c];
+                *reinterpret_cast<f32x4*>(out + (size_t)(v0 + svec) * D + d4) = o;
+            }
+        }
+        __syncthreads();                                     // xt / fidx are rewritten by the next tile
     }
 }
 
@@ -466,8 +521,8 @@ extern "C" int st_gather_rows(const float* table, const int64_t* idx, float* out
 
 extern "C" size_t st_vq_l2_workspace_floats(int D, int V) {
     if (D <= 0 || V <= 0) return 0;
-    const size_t n_ct = ((size_t)V + 15) / 16, ks4n = ((size_t)D + 15) / 16;
-    return n_ct * ks4n * 256 + n_ct * 16;
+    const size_t n_pt = (size_t)VQM_NW * vq_tpw((V + 15) / 16), ks4n = ((size_t)D + 15) / 16;      // packed tiles incl. the padding ones
+    return n_pt * ks4n * 256 + n_pt * 16;
 }
 
 // shapes the matrix-core search takes: D <= 64 in 16-byte pieces, at most 16 code tiles per wave
@@ -477,10 +532,10 @@ extern "C" int st_vq_pack_table(const float* table, float* packed, int D, int V,
     (void)hipGetLastError();
     ST_CHECK_ARG(table && packed && vq_mfma_shape(D, V) && D > 0 && V > 0 && st_aligned16(table) && st_aligned16(packed),
                  "st_vq_pack_table: D=%d V=%d not a matrix-core shape, or unaligned operands", D, V);
-    const int n_ct = (V + 15) / 16, ks4n = (D + 15) / 16;
-    const size_t total = (size_t)n_ct * ks4n * 256 + (size_t)n_ct * 16;
+    const int tpw = vq_tpw((V + 15) / 16), n_pt = VQM_NW * tpw, ks4n = (D + 15) / 16;
+    const size_t total = (size_t)n_pt * ks4n * 256 + (size_t)n_pt * 16;
     hipLaunchKernelGGL(vq_pack_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, V, D,
-                       packed, n_ct, ks4n);
+                       packed, n_pt, ks4n, tpw);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -509,22 +564,23 @@ static int vq_l2_impl(const float* x, const float* table, const float* temp, flo
     // matrix-core form: a caller-provided workspace for the packed table (packed here, or once per table version by st_vq_pack_table)
     if (workspace && vq_mfma_shape(D, V) && st_aligned16(x) && st_aligned16(table) && st_aligned16(out) &&
         st_aligned16(workspace)) {
-        const int n_ct = (V + 15) / 16, ks4n = (D + 15) / 16;
+        const int tpw = vq_tpw((V + 15) / 16), ks4n = (D + 15) / 16;
         if (pack) {
             int rc = st_vq_pack_table(table, workspace, D, V, stream);
             if (rc) return rc;
         }
-        const dim3 grid((n + 15) / 16);
-#define VQ_LAUNCH(NW, T) hipLaunchKernelGGL((vq_l2_mfma_kernel<NW, T>), grid, dim3(NW * 64), 0, (hipStream_t)stream, x, table, workspace, temp, p_code, idx, out, n, D, V, n_ct, ks4n)
-        // 4 waves (one per SIMD) with all of a wave's code tiles in registers.  Measured at V = 512 (us per call incl. the pack
-        // launch, 32 x 129 / 256 x 129 vectors): 4 waves x 8 tiles 19.2 / 65.8; 16 waves x 2 tiles 25.4 / 95.2; 4 vector tiles per
-        // workgroup with the table operands held in registers (237 VGPRs, one workgroup per CU) 25.5 / 112.8; the scalar
-        // LDS-table kernel 130 / 779.
-        if (n_ct <= 4) VQ_LAUNCH(4, 1);
-        else if (n_ct <= 8) VQ_LAUNCH(4, 2);
-        else if (n_ct <= 16) VQ_LAUNCH(4, 4);
-        else if (n_ct <= 32) VQ_LAUNCH(4, 8);
-        else VQ_LAUNCH(4, 16);
+        // persistent tile loop: at most WPS workgroups per compute unit (what the registers hold: 8 code tiles per wave = 128 operand
+        // registers fit twice into a SIMD's file, 16 tiles once), each walking tiles blockIdx.x, + gridDim.x, ...
+        const int n_tiles = (n + 15) / 16;
+        const int p_vec4 = (V % 4 == 0 && st_aligned16(p_code)) ? 1 : 0;
+#define VQ_LAUNCH(T, WPS) do { const int gmax = WPS * st_device_cus(); \
+        hipLaunchKernelGGL((vq_l2_mfma_kernel<T, WPS>), dim3(n_tiles < gmax ? n_tiles : gmax), dim3(VQM_NW * 64), 0, (hipStream_t)stream, \
+                           x, table, workspace, temp, p_code, idx, out, n, D, V, ks4n, n_tiles, p_vec4); } while (0)
+        if (tpw == 1) VQ_LAUNCH(1, 2);
+        else if (tpw == 2) VQ_LAUNCH(2, 2);
+        else if (tpw == 4) VQ_LAUNCH(4, 2);
+        else if (tpw == 8) VQ_LAUNCH(8, 2);
+        else VQ_LAUNCH(16, 1);
 #undef VQ_LAUNCH
         ST_LAUNCH_CHECK();
         return 0;

@@ -58,6 +58,24 @@ class BaseEmbedding(nn.Module):
         else:
             self.register_buffer('temp', torch.FloatTensor([temp]))
 
+    def load_pretrained_embedding(self, old_emb):
+        """ref: src/embed.py:41-48 (VQVAE's `pretrained_emb`): replace the code embedding by the checkpoint's.  Only the 'seperate'
+        codebook has an `embedding` module; on the L2 codebook `embedding` is the read-only table property and the reference's
+        call fails with an AttributeError -- so does this one."""
+        if not isinstance(self.__dict__.get('_modules', {}).get('embedding'), nn.Embedding):
+            raise AttributeError("'%s' has no embedding module to load a pretrained embedding into (as in the reference, "
+                                 "src/embed.py:43: `embedding` is the table property)" % type(self).__name__)
+        if 'emb.embedding.weight' in old_emb.keys():
+            self.embedding = nn.Embedding.from_pretrained(old_emb['emb.embedding.weight'].data, freeze=False)
+            if 'emb.temp' in old_emb.keys():
+                self.temp.data = old_emb['emb.temp'].data
+            if 'emb.running_tok_freq' in old_emb.keys():
+                self.running_tok_freq = old_emb['emb.running_tok_freq']
+            if 'emb.running_ema' in old_emb.keys():
+                self.terunning_emamp = old_emb['emb.running_ema']       # (sic: the reference's attribute name, :46)
+        else:
+            self.embedding = nn.Embedding.from_pretrained(old_emb['emb.weight'], freeze=False)
+
     def _setup_attr(self, phn_attr_pth, proj_attr, latent_dim):
         self.use_phn_attr = phn_attr_pth is not None and phn_attr_pth != ''
         if self.use_phn_attr:

@@ -113,11 +113,19 @@ class FusedAdam(torch.optim.Optimizer):
                 st['_step'] = int(float(st['step']))
         self._cache = {}
 
+    def rollback_step(self):
+        """a guarded step turned out to have been skipped on the device (TtsTrainer._skipped_on_device): take it off the host-side
+        step counts, so that the bias corrections of later steps and the checkpointed `step` agree with torch's Adam again"""
+        for st in self.state.values():
+            if st.get('_step', 0) > 0:
+                st['_step'] -= 1
+
     @torch.no_grad()
     def step(self, closure=None, guard_norm=None):
         """guard_norm: optional 0-dim device tensor (the gradient norm of this step): a NaN / inf value makes the update a no-op ON THE
         DEVICE (the reference's host-side `if math.isnan(grad_norm)` skip without waiting for the norm).  The host-side step counts
-        advance either way (bias corrections one step ahead after such an event)."""
+        advance either way; the trainer calls rollback_step() when it reads the non-finite norm (at most STATS_WINDOW steps later;
+        the bias corrections of the steps in between ran one step ahead)."""
         from . import _lib, ops
         lib = _lib.load()
         cache = self.__dict__.setdefault('_cache', {})

@@ -268,6 +268,9 @@ def broadcast_parameters(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+        # the write went through .data, behind autograd's back: bump the version counter, which the cached weight layouts
+        # (ops._ParamLayouts, the packed VQ table of L2Embedding) are keyed on
+        torch.autograd.graph.increment_version(t)
 
 
 # --------------------------------------------------------------------------------------------- synchronised BatchNorm

@@ -159,6 +159,8 @@ class GraphedSpeechToText:
     the replay.  Same static-buffer discipline as GraphedDecoder."""
 
     def __init__(self, model, B_pair, T, device, B_unpair=0):
+        # (the ASRPostnet output of speech_to_text is not part of the captured graph: the tuple's pair_post_prob slot would be wrong)
+        assert not getattr(model, 'use_asr_postnet', False), 'GraphedSpeechToText: use_asr_postnet is not captured; call model.speech_to_text'
         self.model = model
         self.Bp, self.Bu = int(B_pair), int(B_unpair)
         self.mel = torch.zeros(self.Bp + self.Bu, int(T), model.n_mels, device=device, dtype=torch.float32)
@@ -196,6 +198,7 @@ class GraphedSpeechToText:
         if self.graph is None:
             self.capture()
         if paired_mel is not None:
+            self.mel[:self.Bp, paired_mel.shape[1]:].zero_()        # zero padding past a shorter input, as padded_concat / the eager path do
             self.mel[:self.Bp, :paired_mel.shape[1]].copy_(paired_mel)
         if unpaired_mel is not None:
             self.mel[self.Bp:].zero_()

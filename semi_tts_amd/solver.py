@@ -153,12 +153,23 @@ class LazyStats(dict):
     """step statistics whose device scalars become Python floats when they are READ (st['loss'], st.items(), ...): a training loop
     that only logs every n-th step never waits for the GPU in between (TtsTrainer.async_stats)"""
 
+    on_nonfinite = None      # callable(stats): runs once when a non-finite 'grad_norm' is read (the device skipped that update)
+
     def __getitem__(self, k):
         v = dict.__getitem__(self, k)
         if torch.is_tensor(v):
             v = float(v)
             dict.__setitem__(self, k, v)
+            if k == 'grad_norm' and v != v and self.on_nonfinite is not None:
+                cb, self.on_nonfinite = self.on_nonfinite, None
+                cb(self)
         return v
+
+    def materialise(self):
+        """read every device scalar (one wait for the GPU): the entry no longer holds device memory"""
+        for k in dict.keys(self):
+            self[k]
+        return self
 
     def get(self, k, default=None):
         return self[k] if k in self else default
@@ -197,6 +208,7 @@ class TtsTrainer(BaseSolver):
         self.tts_weight = float(hp.get('tts_weight', 1.0))
         self.sample_rate = config['data']['audio']['sample_rate']
         self.log = []
+        self._unread = []
         if getattr(paras, 'async_stats', False):
             self.async_stats = True
 
@@ -267,17 +279,43 @@ class TtsTrainer(BaseSolver):
             # non-finite norm makes the Adam launch a no-op) and the statistics stay device scalars until somebody reads them
             self.optimizer.step(guard_norm=grad_norm)
             self.step += 1
-            return LazyStats(loss=total.detach(), mel_loss=mel_loss.detach(), linear_loss=linear_loss.detach(), grad_norm=grad_norm,
-                             tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
+            st = LazyStats(loss=total.detach(), mel_loss=mel_loss.detach(), linear_loss=linear_loss.detach(), grad_norm=grad_norm,
+                           tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
+            st.on_nonfinite = self._skipped_on_device
+            self._unread.append(st)
+            if len(self._unread) >= self.STATS_WINDOW:          # bounded: at most STATS_WINDOW steps of device scalars are alive, and a
+                self.drain_stats()                              # poisoned forward is noticed within that many steps
+            return st
         gn = float(grad_norm)
         if gn != gn:
-            ops.check_persist_status(self.device)        # (a starved one-launch LSTM layer is an error, not a skipped step)
+            self.check_device_status()                   # (a starved one-launch LSTM layer is an error, not a skipped step)
             self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
         else:
             self.optimizer.step()
         self.step += 1
         return dict(loss=float(total.detach()), mel_loss=float(mel_loss.detach()), linear_loss=float(linear_loss.detach()), grad_norm=gn,
                     tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
+
+    STATS_WINDOW = 64        # async_stats: steps whose statistics may stay unread on the device
+
+    def check_device_status(self):
+        """raise if a kernel of the training step reported starvation since the last check (the one-launch BiLSTM's status word):
+        such a forward is NaN and the guarded Adam skips its update -- an error, not a run of silently skipped steps"""
+        ops.check_persist_status(self.device)
+
+    def _skipped_on_device(self, st):
+        """a step whose gradient norm turned out non-finite (read late, async_stats): the device skipped that update"""
+        self.check_device_status()
+        opt = getattr(self.optimizer, 'opt', None)
+        if hasattr(opt, 'rollback_step'):
+            opt.rollback_step()                          # the host-side Adam step counts ran one ahead since then (bias corrections)
+        self.verbose('Error : grad norm is NaN @ step %s (update skipped on the device)' % st.get('step', '?'))
+
+    def drain_stats(self):
+        """read the statistics of every step issued so far (waits for the GPU once)"""
+        pending, self._unread = self._unread, []
+        for st in pending:
+            st.materialise()
 
     def exec(self):
         t0 = time.perf_counter()
@@ -291,6 +329,8 @@ class TtsTrainer(BaseSolver):
                 self.verbose('Tr stat | step %d | Loss - %.4f | Grad. Norm - %.3f | lr %.2e' %
                              (self.step, st['loss'], st['grad_norm'], st['lr']))
         torch.cuda.synchronize()
+        self.drain_stats()
+        self.check_device_status()
         dt = time.perf_counter() - t0
         if getattr(self.paras, 'save', False):
             self.save_checkpoint('latest.pth', self.log[-1]['loss'] if self.log else 0.0)
@@ -348,6 +388,9 @@ class VqvaeTrainer(TtsTrainer):
         gn = float(self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP))
         if gn == gn:
             self.optimizer.step()
+        else:
+            ops.check_persist_status(self.device)        # a starved one-launch LSTM layer is an error, not a skipped step
+            self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
         self.step += 1
         stats.update(loss=float(total.detach()), grad_norm=gn, tf_rate=tf_rate)
         return stats

@@ -16,6 +16,9 @@ from .embed import L2Embedding, SeperateEmbedding
 from .tts import Tacotron2
 
 FRAME_PHN_RATIO = 6.0          # ref: src/vqvae.py:18
+PRETRAINED_ENCODER_PREFIX = 'encoder.'      # ref: src/vqvae.py:13-15
+PRETRAINED_DECODER_PREFIX = 'decoder.'
+PRETRAINED_POSTNET_PREFIX = 'postnet.'
 
 
 class VQVAE(nn.Module):
@@ -50,10 +53,34 @@ class VQVAE(nn.Module):
             raise NotImplementedError
         self.spkr_embed = nn.Embedding(self.n_spkr, spkr_latent_dim)   # :64
         self.tts = Tacotron2(n_mels, self.linear_dim, self.codebook.out_dim, self.spkr_latent_dim, decoder)   # :68
-        for name, val in (('pretrained_asr', pretrained_asr), ('pretrained_emb', pretrained_emb),
-                          ('pretrained_tts', pretrained_tts)):
-            if val:
-                raise NotImplementedError('%s: load the checkpoint with load_state_dict instead' % name)
+        self._load_pretrained(pretrained_asr, pretrained_emb, pretrained_tts)
+
+    def _load_pretrained(self, pretrained_asr, pretrained_emb, pretrained_tts):
+        """Partial initialisation from earlier checkpoints with the reference's key rewriting (src/vqvae.py:70-90; advertised by
+        config/*.yaml:94-97).  Every occurrence of the prefix is removed from every key (str.replace, as the reference does), the
+        load is non-strict and must leave no key of the target module missing."""
+        from collections import OrderedDict
+
+        def ckpt(path):
+            return torch.load(path, map_location='cpu')['model']
+
+        def load_into(module, state, what):
+            missing, _ = module.load_state_dict(state, strict=False)
+            assert missing == [], 'Missing pretrained para. {} ({})'.format(missing, what)
+
+        self.pretrain_asr = pretrained_asr is not None and pretrained_asr != ''
+        if self.pretrain_asr:                                          # :71-76
+            old = OrderedDict((k.replace(PRETRAINED_ENCODER_PREFIX, ''), v) for k, v in ckpt(pretrained_asr).items())
+            load_into(self.asr, old, 'pretrained_asr')
+        self.pretrained_emb = pretrained_emb is not None and pretrained_emb != ''
+        if self.pretrained_emb:                                        # :77-80 (the reference reads the ASR checkpoint's path here)
+            self.codebook.load_pretrained_embedding(ckpt(pretrained_asr))
+        self.pretrained_tts = pretrained_tts is not None and pretrained_tts != ''
+        if self.pretrained_tts:                                        # :81-90
+            old = OrderedDict((k.replace(PRETRAINED_DECODER_PREFIX, ''), v) for k, v in ckpt(pretrained_tts).items())
+            load_into(self.tts.decoder, old, 'pretrained_tts decoder')
+            post = OrderedDict((k.replace(PRETRAINED_POSTNET_PREFIX, ''), v) for k, v in old.items() if PRETRAINED_POSTNET_PREFIX in k)
+            load_into(self.tts.postnet, post, 'pretrained_tts postnet')
 
     def padded_concat(self, pair, unpair):
         """zero-pad the shorter of two (B, T, D) batches in time and stack them on the batch axis.  ref: :259-271"""

@@ -28,7 +28,10 @@ def load_golden(name):
             weights[k[2:]] = torch.from_numpy(v)
         elif '/' in k:
             g, i = k.rsplit('/', 1)
-            groups.setdefault(g, {})[int(i)] = torch.from_numpy(v)
+            if i.isdigit():
+                groups.setdefault(g, {})[int(i)] = torch.from_numpy(v)
+            else:                                  # a named group ('ckpt_asr/<state-dict key>'): dict of tensors
+                arrays.setdefault(g, {})[i] = torch.from_numpy(v)
         else:
             arrays[k] = torch.from_numpy(v) if v.dtype != np.uint8 else v
     for g, d in groups.items():

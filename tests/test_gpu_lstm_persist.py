@@ -92,3 +92,34 @@ def test_unsupported_shapes_take_the_per_step_form():
     out, _, _ = _run(xp, w, b, dev, True, False)
     ref, _, _ = _run(xp, w, b, dev, False, False)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('B,T,H,In', [(32, 43, 256, 512), (5, 7, 64, 32), (17, 5, 512, 48)])
+def test_one_launch_bilstm_against_oracle(B, T, H, In):
+    """the whole layer as the product path runs it -- input projections of both directions (ops.gemm), then the ONE-launch recurrence
+    -- against oracle.tts_oracle.lstm_layer (the restatement of nn.LSTM at src/module.py:432-438,458-460) on the same weights"""
+    from oracle import tts_oracle as O
+    from semi_tts_amd import ops, _lib
+    dev = torch.device('cuda:0')
+    assert _lib.load().st_lstm_seq2_persist_supported(B, T, H, 2 * H, 0, H)
+    g = torch.Generator().manual_seed(1000 + B + T + H)
+    x = torch.randn(B, T, In, generator=g)
+    W = {}
+    for sfx in ('_l0', '_l0_reverse'):
+        W['lstm.weight_ih' + sfx] = torch.randn(4 * H, In, generator=g) / In ** 0.5
+        W['lstm.weight_hh' + sfx] = torch.randn(4 * H, H, generator=g) / H ** 0.5
+        W['lstm.bias_ih' + sfx] = torch.randn(4 * H, generator=g) * 0.1
+        W['lstm.bias_hh' + sfx] = torch.randn(4 * H, generator=g) * 0.1
+    ref = torch.cat([O.lstm_layer(x, W, 'lstm', False), O.lstm_layer(x, W, 'lstm', True)], dim=-1)
+    xd = x.to(dev)
+    xp = [ops.gemm(xd, W['lstm.weight_ih' + sfx].to(dev), bias=W['lstm.bias_ih' + sfx].to(dev)) for sfx in ('_l0', '_l0_reverse')]
+    out = torch.zeros(B, T, 2 * H, device=dev)
+    assert ops.LSTM_PERSIST
+    ops.lstm_seq2(xp[0], xp[1], W['lstm.weight_hh_l0'].to(dev), W['lstm.weight_hh_l0_reverse'].to(dev),
+                  W['lstm.bias_hh_l0'].to(dev), W['lstm.bias_hh_l0_reverse'].to(dev), out)
+    torch.cuda.synchronize()
+    ops.check_persist_status(dev)
+    err = maxdiff(out, ref)
+    from helpers import report
+    report('bilstm_one_launch_vs_oracle', B=B, T=T, H=H, err=err)
+    assert err < 2e-5, err

@@ -245,3 +245,77 @@ def test_cycle_step_alternates_and_gates_like_the_reference_loop():
     tr.step = 5
     tr.cycle_step(pair, None)
     assert calls == [('text', None)]                                      # no unpaired batch handed in
+
+
+@pytest.mark.parametrize('name', ['pretrained_l2', 'pretrained_seperate'])
+def test_pretrained_partial_loads_match_reference(name, tmp_path):
+    """VQVAE(pretrained_asr / _emb / _tts) with the reference's key-prefix rewriting (src/vqvae.py:70-90): the checkpoints and the
+    state_dict of the model the REAL reference built from them are recorded in the golden (tools/gen_golden.py pretrained_case)"""
+    import torch
+    from conftest import load_golden
+    from semi_tts_amd.vqvae import VQVAE
+    W, A, meta = load_golden(name)
+    ck = {'ckpt_asr': A['ckpt_asr'], 'ckpt_tts': A['ckpt_tts']}
+    pa, pt = str(tmp_path / 'asr.pth'), str(tmp_path / 'tts.pth')
+    torch.save({'model': ck['ckpt_asr']}, pa)
+    torch.save({'model': ck['ckpt_tts']}, pt)
+    cfg = dict(meta['model'])
+    cfg['codebook'] = dict(cfg['codebook'])
+    if cfg['codebook'].get('phn_attr_pth'):    # the attribute table as the tab-separated file the constructor reads (3 zero rows are prepended)
+        a = W['codebook.phn_attr.weight'].numpy()[3:]
+        attr = tmp_path / 'phn_attr.csv'
+        attr.write_text('\t' + '\t'.join('a%d' % i for i in range(a.shape[1])) + '\n' +
+                        ''.join('p%d\t' % i + '\t'.join(str(int(v)) for v in row) + '\n' for i, row in enumerate(a)))
+        cfg['codebook']['phn_attr_pth'] = str(attr)
+    cfg.update(pretrained_asr=pa, pretrained_tts=pt, pretrained_emb=pa if meta['bone'] == 'seperate' else '')
+    torch.manual_seed(meta['seed'])
+    m = VQVAE(8, 20, 43, 5, **cfg)
+    assert [bool(m.pretrain_asr), bool(m.pretrained_emb), bool(m.pretrained_tts)] == meta['flags']
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(W.keys())
+    loaded = [k for k in W if k.startswith(('asr.', 'tts.decoder.', 'tts.postnet.')) or (meta['bone'] == 'seperate' and k == 'codebook.embedding.weight')]
+    assert len(loaded) > 60
+    for k in loaded:
+        assert torch.equal(sd[k], W[k]), k
+    # the text encoder is NOT part of the partial load (only decoder + postnet keys are taken from the TTS checkpoint)
+    assert not torch.equal(sd['tts.encoder.convs.0.0.conv.weight'], ck['ckpt_tts']['encoder.convs.0.0.conv.weight'])
+    if meta['bone'] == 'l2':                   # on the L2 codebook `embedding` is the table property: the reference's call fails, so does ours
+        with pytest.raises(AttributeError):
+            m.codebook.load_pretrained_embedding({'emb.weight': torch.zeros(43, 48)})
+
+
+_RANKS_WORKER = r'''
+import os, sys, json
+from argparse import Namespace
+sys.path.insert(0, sys.argv[1])
+import bench
+rk = bench.Ranks(Namespace(gpus=2, dist=False))
+rk.barrier()
+t = rk.max_seconds(1.0 + rk.rank)
+info = rk.collectives_flat()
+rk.close()
+if rk.rank == 0:
+    print('RESULT ' + json.dumps(dict(backend=rk.backend, t=t, **info)))
+'''
+
+
+@pytest.mark.parametrize('fake', [False, True])
+def test_bench_ranks_fall_back_to_gloo_when_the_rccl_probe_fails(tmp_path, fake):
+    """bench.py's rank set-up under `python -m torch.distributed.run` (how the driver starts N > 1): every rank probes RCCL in a
+    CHILD process first; when the probe fails -- here genuinely (no GPU in this container) or faked (ST_BENCH_FAKE_RCCL_FAIL, what
+    a failing peer-memory set-up looks like from outside) -- the process group comes up on gloo, the timing contract's barrier and
+    max still work, and the line says rccl_ranks 0 with the probe's error."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_RANKS_WORKER)
+    env = dict(os.environ, ST_BENCH_ALLOW_CPU='1', ST_BENCH_PROBE_TIMEOUT='120')
+    env.pop('ST_BENCH_BACKEND', None)
+    if fake:
+        env['ST_BENCH_FAKE_RCCL_FAIL'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29541' if fake else '29543', str(script), REPO], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('RESULT ')][0][7:])
+    assert res['backend'] == 'gloo' and res['rccl_ranks'] == 0 and res['t'] == 2.0
+    assert res['collectives']['backend'] == 'gloo' and res['collectives']['rccl_probe'].startswith('failed: rank')
+    assert ('faked' in res['collectives']['rccl_probe']) == fake

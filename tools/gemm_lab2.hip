@@ -1,0 +1,315 @@
+// gemm_lab2.hip -- round-4 experiment bench for the forward fp32 MFMA GEMM / implicit-GEMM conv core.
+// Not part of the library: it measures tile geometries, the full-line loader and split-K factors on the shapes of one C2 forward
+// before they go into csrc/gemm.hip.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_lab2.hip -o tools/gemm_lab2 && tools/gemm_lab2
+// What differs from csrc/gemm.hip's gm_pipe_kernel (r03):
+//   * k-chunk of 32 floats: 8 adjacent lanes load ONE 128-byte line of a row (r03: 4 lanes x 16 bytes = half a line, 16 rows per
+//     wave instruction);
+//   * tile geometries up to 128 x 128 with 4 or 8 waves (bytes per flop of the operand stream halve from 64 x 64 to 128 x 128);
+//   * the columns of a wave's MFMA tiles are INTERLEAVED (tile nt, column r <-> output column NT r + nt), W rows are permuted while
+//     they are written to LDS, so a lane ends up with NT consecutive output columns per row: 8- or 16-byte stores;
+//   * the reduction axis of a conv is the flat (tap, channel) index of tap-major weights; a 16-float half chunk never straddles taps
+//     (Cin % 16 == 0).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct G2Args {
+    const float* A; int lda; const float* W; float* C; int ldc;
+    int Bn, Tin, Tout, Cin, N, KT, pad;
+    int M, K;                 // Bn * Tout, KT * Cin
+    int chunks_per_split;     // > 0: blockIdx.z takes chunks [z cps, (z + 1) cps) and writes its raw partial to ws[z][m][n]
+    float* ws;
+    const float* bias;
+};
+
+constexpr int G2_LD = 40;     // LDS row stride (floats) of a 32-float chunk: the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots
+
+template <int BM, int BN, int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN) void g2_kernel(const G2Args g) {
+    constexpr int NTH = 64 * NWM * NWN;
+    constexpr int MT = BM / NWM / 16, NT = BN / NWN / 16;
+    constexpr int RPP = NTH / 8;                  // rows one pass of the workgroup's threads covers (8 lanes per row)
+    constexpr int LA = BM / RPP, LB = BN / RPP;   // 16-byte loads per thread and chunk
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && MT >= 1 && NT >= 1, "geometry");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As[2] = {lds, lds + BM * G2_LD};
+    float* Bs[2] = {lds + 2 * BM * G2_LD, lds + 2 * BM * G2_LD + BN * G2_LD};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int srow = tid >> 3, sp = tid & 7;
+
+    // staging rows of this thread
+    const float* arow[LA]; int atb[LA]; bool aok[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int m = m0 + srow + i * RPP;
+        aok[i] = m < g.M;
+        const int mc = min(m, g.M - 1);
+        const int b = mc / g.Tout, t = mc - b * g.Tout;
+        arow[i] = g.A + (size_t)b * g.Tin * g.lda;
+        atb[i] = t - g.pad;
+    }
+    const float* wrow[LB]; bool wok[LB]; int wlds[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int r = srow + i * RPP;             // row of the W tile = output column n0 + r
+        wok[i] = n0 + r < g.N;
+        wrow[i] = g.W + (size_t)min(n0 + r, g.N - 1) * g.K;
+        const int wb = r / (16 * NT), j = r % (16 * NT);
+        wlds[i] = (wb * 16 * NT + (j % NT) * 16 + j / NT) * G2_LD + sp * 4;      // interleaved columns: see the header
+    }
+    const int nch = (g.K + 31) / 32;
+    const int c_lo = g.chunks_per_split > 0 ? (int)blockIdx.z * g.chunks_per_split : 0;
+    const int c_hi = g.chunks_per_split > 0 ? min(nch, c_lo + g.chunks_per_split) : nch;
+    // flat k of this thread's piece in the next chunk to request, as (tap, channel)
+    int k_n = c_lo * 32 + sp * 4;
+    int tap_n = k_n / g.Cin, ci_n = k_n - tap_n * g.Cin;
+    int left = c_hi - c_lo;
+
+    struct Regs { f32x4 a[LA], w[LB]; unsigned va, vw; };
+    auto issue = [&](Regs& r) __attribute__((always_inline)) {
+        const bool in_k = left > 0 && k_n < g.K;
+        --left;
+        const int kc = min(k_n, g.K - 4);
+        const int tapc = min(tap_n, g.KT - 1);
+        const int cic = in_k ? ci_n : 0;
+        r.va = 0; r.vw = 0;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int ti = atb[i] + tapc;
+            const int tic = min(max(ti, 0), g.Tin - 1);
+            r.a[i] = *reinterpret_cast<const f32x4*>(arow[i] + (size_t)tic * g.lda + cic);
+            if (in_k && aok[i] && ti >= 0 && ti < g.Tin) r.va |= 1u << i;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            r.w[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kc);
+            if (in_k && wok[i]) r.vw |= 1u << i;
+        }
+        k_n += 32; ci_n += 32;
+        if (ci_n >= g.Cin) { ci_n -= g.Cin; ++tap_n; }
+        if (ci_n >= g.Cin) { ci_n -= g.Cin; ++tap_n; }      // (Cin = 16)
+    };
+    auto commit = [&](const Regs& r, int buf) __attribute__((always_inline)) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(As[buf] + (srow + i * RPP) * G2_LD + sp * 4) = (r.va >> i) & 1 ? r.a[i] : z;
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<f32x4*>(Bs[buf] + wlds[i]) = (r.vw >> i) & 1 ? r.w[i] : z;
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a4[MT], b4[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a4[t] = *reinterpret_cast<const f32x4*>(As[buf] + (wm * 16 * MT + t * 16 + fr) * G2_LD + h * 16 + fq * 4);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b4[t] = *reinterpret_cast<const f32x4*>(Bs[buf] + (wn * 16 * NT + t * 16 + fr) * G2_LD + h * 16 + fq * 4);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    const int n_my = c_hi - c_lo;
+    Regs r0, r1;
+    issue(r0); issue(r1);
+    commit(r0, 0);
+    issue(r0);
+    lds_barrier();
+    for (int c = 0; c < n_my; c += 2) {
+        commit(r1, 1);
+        issue(r1);
+        compute(0);
+        lds_barrier();
+        if (c + 1 >= n_my) break;
+        commit(r0, 0);
+        issue(r0);
+        compute(1);
+        lds_barrier();
+    }
+    // epilogue: lane (fr, fq) holds rows 4 fq + e of each row tile and the NT consecutive columns nb + NT fr + nt
+    float* out = g.chunks_per_split > 0 ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const int ldo = g.chunks_per_split > 0 ? g.N : g.ldc;
+    const int nb = n0 + wn * 16 * NT + NT * fr;
+    const bool vec_ok = (g.N % NT == 0) && (ldo % NT == 0);
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = (g.bias && g.chunks_per_split == 0 && nb + nt < g.N) ? g.bias[nb + nt] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 16 * MT + mt * 16 + 4 * fq + e;
+            if (m >= g.M) continue;
+            float* p = out + (size_t)m * ldo + nb;
+            if (vec_ok && nb + NT <= g.N) {
+                if (NT == 4) *reinterpret_cast<f32x4*>(p) = f32x4{acc[mt][0][e] + bv[0], acc[mt][1 % NT][e] + bv[1 % NT], acc[mt][2 % NT][e] + bv[2 % NT], acc[mt][3 % NT][e] + bv[3 % NT]};
+                else if (NT == 2) *reinterpret_cast<f32x2*>(p) = f32x2{acc[mt][0][e] + bv[0], acc[mt][1 % NT][e] + bv[1 % NT]};
+                else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) p[nt] = acc[mt][nt][e] + bv[nt];
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) if (nb + nt < g.N) p[nt] = acc[mt][nt][e] + bv[nt];
+            }
+        }
+}
+
+__global__ void finish_kernel(const float* __restrict__ part, float* __restrict__ out, const float* bias, int N, size_t n4, int S) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+    for (int z = 1; z < S; ++z) { const f32x4 v = reinterpret_cast<const f32x4*>(part)[i + (size_t)z * n4]; s += v; }
+    if (bias) { const int n = (int)((i * 4) % N); s[0] += bias[n]; s[1] += bias[n + 1]; s[2] += bias[n + 2]; s[3] += bias[n + 3]; }
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+// reference: the conv as written (channels-last, tap-major weights), one thread per output element
+__global__ void naive_kernel(const G2Args g) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= g.N) return;
+    const int b = m / g.Tout, t = m - b * g.Tout;
+    float s = 0.f;
+    for (int tap = 0; tap < g.KT; ++tap) {
+        const int ti = t + tap - g.pad;
+        if (ti < 0 || ti >= g.Tin) continue;
+        const float* a = g.A + ((size_t)b * g.Tin + ti) * g.lda;
+        const float* w = g.W + (size_t)n * g.K + (size_t)tap * g.Cin;
+        for (int c = 0; c < g.Cin; ++c) s = fmaf(a[c], w[c], s);
+    }
+    g.C[(size_t)m * g.ldc + n] = s + (g.bias ? g.bias[n] : 0.0f);
+}
+
+struct Shape { const char* name; int Bn, T, Cin, N, KT, pad; };
+
+template <typename F>
+static float time_us(F launch, int iters = 40) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGetLastError());
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return ms * 1000.f / iters;
+}
+
+static float *dA, *dW, *dC, *dR, *dP, *dBias;
+static std::vector<float> hC, hR;
+
+static double check(size_t n) {
+    CK(hipMemcpy(hC.data(), dC, n * 4, hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    for (size_t i = 0; i < n; i += 13) worst = fmax(worst, fabs((double)hC[i] - hR[i]) / (1.0 + fabs((double)hR[i])));
+    return worst;
+}
+
+struct Best { float us = 1e30f; char what[96] = ""; };
+
+template <int BM, int BN, int NWM, int NWN>
+static void run(const Shape& s, G2Args g, int S, Best& best, bool verbose) {
+    const int nch = (g.K + 31) / 32;
+    if (S > nch) return;
+    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, S);
+    if ((long)grid.x * grid.y * S > 6000) return;
+    const size_t lds = (size_t)2 * (BM + BN) * G2_LD * 4;
+    static bool set = false;
+    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(g2_kernel<BM, BN, NWM, NWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    g.chunks_per_split = S > 1 ? (nch + S - 1) / S : 0;
+    g.ws = dP;
+    CK(hipMemset(dC, 0, (size_t)g.M * g.N * 4));
+    const size_t n4 = (size_t)g.M * g.N / 4;
+    auto f = [&] {
+        hipLaunchKernelGGL((g2_kernel<BM, BN, NWM, NWN>), grid, dim3(64 * NWM * NWN), lds, 0, g);
+        if (S > 1) hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, dP, dC, g.bias, g.N, n4, S);
+    };
+    const float us = time_us(f);
+    const double tf = 2.0 * g.M * g.N * g.K / us / 1e6;
+    const double err = check((size_t)g.M * g.N);
+    char what[96];
+    snprintf(what, sizeof what, "%dx%d w%dx%d S=%d wgs=%d", BM, BN, NWM, NWN, S, (int)(grid.x * grid.y * S));
+    if (verbose || err > 1e-4) printf("    %-34s %8.2f us  %6.1f TF  frac %.3f  err %.1e\n", what, us, tf, tf / 157.3, err);
+    if (err <= 1e-4 && us < best.us) { best.us = us; snprintf(best.what, sizeof best.what, "%s", what); }
+}
+
+int main(int argc, char** argv) {
+    const bool verbose = argc > 1;
+    const Shape shapes[] = {  // the forward products of one C2 pass (tools/bench_gemm_shapes.py)
+        {"enc conv k5 512->512", 32, 43, 512, 512, 5, 2}, {"enc conv k5 64->512", 32, 43, 64, 512, 5, 2},
+        {"enc lstm in-proj 512->1024", 32, 43, 512, 1024, 1, 0}, {"memory layer 512->256", 32, 43, 512, 256, 1, 0},
+        {"bank conv k1 80->80", 32, 258, 80, 80, 1, 0}, {"bank conv k4 80->80", 32, 258, 80, 80, 4, 2}, {"bank conv k8 80->80", 32, 258, 80, 80, 8, 4},
+        {"proj conv k3 640->128", 32, 258, 640, 128, 3, 1}, {"proj conv k3 128->80", 32, 258, 128, 80, 3, 1},
+        {"highway 80->80", 32, 258, 80, 80, 1, 0}, {"gru in-proj 80->240", 32, 258, 80, 240, 1, 0}, {"linear 160->1024", 32, 258, 160, 1024, 1, 0},
+        {"teacher prenet 240->256", 32, 86, 240, 256, 1, 0},
+        {"dx enc conv (same shape)", 32, 43, 512, 512, 5, 2}, {"dx linear 1024->160", 32, 258, 1024, 160, 1, 0},
+        {"c5 enc conv k5 512->512", 64, 171, 512, 512, 5, 2}, {"c5 proj conv 640->128", 64, 1066, 640, 128, 3, 1}};
+    size_t maxA = 0, maxW = 0, maxC = 0;
+    for (const Shape& s : shapes) {
+        const int Tout = s.T + 2 * s.pad - s.KT + 1;
+        maxA = std::max(maxA, (size_t)s.Bn * s.T * s.Cin); maxW = std::max(maxW, (size_t)s.N * s.Cin * s.KT); maxC = std::max(maxC, (size_t)s.Bn * Tout * s.N);
+    }
+    CK(hipMalloc(&dA, maxA * 4)); CK(hipMalloc(&dW, maxW * 4)); CK(hipMalloc(&dC, maxC * 4)); CK(hipMalloc(&dR, maxC * 4));
+    CK(hipMalloc(&dP, maxC * 4 * 8)); CK(hipMalloc(&dBias, 4096 * 4));
+    std::vector<float> h(std::max(std::max(maxA, maxW), (size_t)4096));
+    srand(1);
+    for (float& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    CK(hipMemcpy(dA, h.data(), maxA * 4, hipMemcpyHostToDevice));
+    for (float& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    CK(hipMemcpy(dW, h.data(), maxW * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dBias, h.data(), 4096 * 4, hipMemcpyHostToDevice));
+    hC.resize(maxC); hR.resize(maxC);
+    for (const Shape& s : shapes) {
+        G2Args g;
+        memset((void*)&g, 0, sizeof g);
+        g.A = dA; g.lda = s.Cin; g.W = dW; g.C = dC; g.Bn = s.Bn; g.Tin = s.T; g.Tout = s.T + 2 * s.pad - s.KT + 1; g.Cin = s.Cin; g.N = s.N;
+        g.ldc = s.N; g.KT = s.KT; g.pad = s.pad; g.M = g.Bn * g.Tout; g.K = s.KT * s.Cin; g.bias = dBias;
+        printf("%s  M=%d N=%d K=%d  (%.2f GFLOP, floor %.1f us)\n", s.name, g.M, g.N, g.K, 2e-9 * g.M * g.N * g.K, 2.0 * g.M * g.N * g.K / 157.3e6);
+        G2Args gr = g; gr.C = dR;
+        hipLaunchKernelGGL(naive_kernel, dim3((g.N + 255) / 256, g.M), dim3(256), 0, 0, gr);
+        CK(hipMemcpy(hR.data(), dR, (size_t)g.M * g.N * 4, hipMemcpyDeviceToHost));
+        Best best;
+        for (int S : {1, 2, 3, 4, 6, 8}) {
+            const bool big = (size_t)g.M * g.N * S > maxC * 8;
+            if (big) continue;
+            run<64, 64, 2, 2>(s, g, S, best, verbose);
+            run<128, 64, 2, 2>(s, g, S, best, verbose);
+            run<128, 64, 4, 2>(s, g, S, best, verbose);
+            run<128, 128, 2, 2>(s, g, S, best, verbose);
+            run<128, 128, 4, 2>(s, g, S, best, verbose);
+            run<64, 128, 2, 2>(s, g, S, best, verbose);
+            run<32, 64, 2, 2>(s, g, S, best, verbose);
+            run<64, 32, 2, 2>(s, g, S, best, verbose);
+        }
+        const double tf = 2.0 * g.M * g.N * g.K / best.us / 1e6;
+        printf("  BEST %-34s %8.2f us  %6.1f TF  frac %.3f\n", best.what, best.us, tf, tf / 157.3);
+    }
+    return 0;
+}

@@ -593,9 +593,56 @@ def asr_cases():
     save('asr_postnet_tiny', {k: v.clone() for k, v in m.state_dict().items()}, dict(x=x, y=y), dict(latent_dim=12, vocab_size=12))
 
 
+
+def pretrained_case():
+    """VQVAE(pretrained_asr=..., pretrained_emb=..., pretrained_tts=...) of the REAL reference (src/vqvae.py:70-90) at tiny
+    dimensions: a donor model's weights are written as two checkpoints with the key prefixes the reference expects
+    ('encoder.' + speech-encoder keys [+ 'emb.weight'], the TTS model's own 'encoder.' / 'decoder.' / 'postnet.' keys), a second
+    model is constructed from them, and its state_dict is recorded together with the two checkpoints.  Data only."""
+    import tempfile
+    import yaml
+    os.chdir(REF)
+    full = yaml.safe_load(open('config/semi-single-spkr-paired-data.yaml'))
+    for name, bone, seed in (('pretrained_l2', 'l2', 61), ('pretrained_seperate', 'seperate', 62)):
+        cfg = json.loads(json.dumps(full['model']))
+        cfg['decoder'] = json.loads(json.dumps(TINY['paras']))
+        cfg['decoder']['separate_postnet'] = True
+        cfg['spkr_latent_dim'] = TINY['spkr_embed_dim']
+        cfg['encoder'].update(dim=16, rnn_dim=8, dropout=0.0)
+        cfg['codebook']['bone'] = bone
+        torch.manual_seed(seed)
+        donor = RefVQVAE(TINY['n_mels'], TINY['linear_dim'], 43, 5, **json.loads(json.dumps(cfg)))
+        g = torch.Generator().manual_seed(seed + 100)
+        with torch.no_grad():
+            randomize_buffers(donor.tts, g)
+            randomize_buffers(donor.asr, g)
+        ck_asr = {'encoder.' + k: v.clone() for k, v in donor.asr.state_dict().items()}
+        if bone == 'seperate':
+            ck_asr['emb.weight'] = torch.randn(43, donor.codebook.embedding.weight.shape[1], generator=g)
+        ck_tts = {k: v.clone() for k, v in donor.tts.state_dict().items()}
+        with tempfile.TemporaryDirectory() as td:
+            pa, pt = os.path.join(td, 'asr.pth'), os.path.join(td, 'tts.pth')
+            torch.save({'model': ck_asr}, pa)
+            torch.save({'model': ck_tts}, pt)
+            cfg2 = json.loads(json.dumps(cfg))
+            cfg2.update(pretrained_asr=pa, pretrained_tts=pt, pretrained_emb=pa if bone == 'seperate' else '')
+            torch.manual_seed(seed + 1)
+            m = RefVQVAE(TINY['n_mels'], TINY['linear_dim'], 43, 5, **cfg2)
+        meta = dict(bone=bone, model=cfg, seed=seed + 1, flags=[bool(m.pretrain_asr), bool(m.pretrained_emb), bool(m.pretrained_tts)])
+        arrays = {}
+        for k, v in ck_asr.items():
+            arrays['ckpt_asr/' + k] = v
+        for k, v in ck_tts.items():
+            arrays['ckpt_tts/' + k] = v
+        save(name, {k: v for k, v in m.state_dict().items()}, arrays, meta)
+    os.chdir(REPO)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr', 'speech', 'text', 'variants']
+    which = sys.argv[1:] or ['tts', 'vq', 'misc', 'full', 'train', 'asr', 'speech', 'text', 'variants', 'pretrained']
+    if 'pretrained' in which:
+        pretrained_case()
     if 'speech' in which:
         speech_first_case()
     if 'text' in which:

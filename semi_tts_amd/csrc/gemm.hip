@@ -28,6 +28,7 @@ struct GmArgs {
     int cpb;    // 16-float k-blocks per tap
     int kb_per_split;   // > 0: blockIdx.z takes k-blocks [z * kb_per_split, (z + 1) * kb_per_split) and writes its raw partial
     float* split_ws;    //      product to split_ws[z][m][n] (row stride N); gm_splitk_finish_kernel adds the slabs + epilogue
+                        //      (gd_kernel: the same in 32-float chunks)
     st_gemm_epilogue ep;
 };
 
@@ -381,6 +382,190 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_kernel(const GmArgs g) {
     gm_pipe_body<VECW, POOL, MT, VECA>(g, As, Bs);
 }
 
+
+// ---- gd_kernel: both operands by LDS-DMA (round 4) ------------------------------------------------------------------------
+// global_load_lds_dwordx4 moves 8 rows x 128 bytes (one whole line per row) per wave instruction straight into LDS: no staging
+// registers, no ds_write pass, no selects -- the register-staged pipeline above spent 30-40 % of its time on exactly those (lab
+// ablations, tools/gemm_lab2.hip: 363 us with, 257 us without its loads on a 33 GFLOP conv; this form 314 us), and its 64-byte row
+// pieces were half lines.
+//   * LDS image per operand and 32-float chunk: [row][8 slots of 16 bytes], lane-linear as the DMA writes it; slot s of row L holds
+//     the row's piece s ^ (L & 7) (the swizzle is applied to the SOURCE address), a fragment read of piece p goes to slot
+//     p ^ (L & 7): the 16 lanes of every ds_read_b128 service group hit 16 distinct 16-byte slots;
+//   * the reduction axis is the flat (tap, channel) index of tap-major weights: with channels-last activations of row stride Cin the
+//     taps of one output row are ONE contiguous run of KT * Cin floats, so a piece's address is run start + k and its validity two
+//     compares (frames outside the utterance, k past K, rows past M / N read 16 zero bytes from a constant instead);
+//   * three buffers, ONE barrier per chunk: the requests of chunk c + 2 go out right after the barrier of iteration c (every wave
+//     has left compute(c - 1), whose buffer they overwrite); the counted vmcnt in front of the barrier retires this wave's pieces
+//     of chunk c and leaves chunk c + 1 in flight.  ALL LDS of the kernel is one array (a second __shared__ object makes the
+//     compiler drain the DMA queue before every ds_read);
+//   * the columns of a wave's MFMA tiles are INTERLEAVED (tile nt, column r <-> output column NT r + nt; the W rows are permuted
+//     through the source address), so a lane holds NT consecutive output columns per row: 8-byte stores;
+//   * per output element the k order is that of gm_pipe_kernel / highway_stack_kernel (16-float blocks ascending, the lane's four
+//     k's in order): results are bit-identical to theirs.
+// Shapes it takes: 16-byte addressable rows of A and W, weights contiguous in the flat k (Linear, or tap-major conv weights), row
+// stride Cin for KT > 1, no fused max-pool.
+__device__ const f32x4 gd_zero4 = {0.f, 0.f, 0.f, 0.f};
+typedef const __attribute__((address_space(1))) void* gd_gptr_t;
+typedef __attribute__((address_space(3))) void* gd_lptr_t;
+
+template <int BM, int BN>
+__device__ __forceinline__ void gd_body(const GmArgs& g, float* __restrict__ lds) {
+    constexpr int NWM = 2, NWN = 2, NTH = 256;
+    constexpr int MT = BM / NWM / 16, NT = BN / NWN / 16;
+    constexpr int RPP = NTH / 8;                  // rows one pass of the workgroup covers (8 lanes per row)
+    constexpr int LA = BM / RPP, LB = BN / RPP;   // DMA instructions per thread and chunk
+    constexpr int BUF = (BM + BN) * 32;           // floats per buffer
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && MT >= 1 && NT >= 1, "geometry");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int lrow = lane >> 3, slot = lane & 7;
+    const float* zp = reinterpret_cast<const float*>(&gd_zero4);
+    const int K = g.KT * g.Cin;
+    // per DMA: the row's run start (flat k = 0), its valid k range, the piece this lane fetches
+    const float* abase[LA]; int aklo[LA], akhi[LA], apk[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int L = i * RPP + wave * 8 + lrow;              // LDS row = tile row
+        const int m = m0 + L;
+        const int mc = min(m, g.M - 1);
+        const int b = mc / g.Tout, t = (mc - b * g.Tout) * g.stride - g.pad;      // first frame of the row's run (may lie in front of the utterance)
+        abase[i] = g.A + ((ptrdiff_t)b * g.Tin + t) * g.lda;
+        aklo[i] = m < g.M ? max(0, -t) * g.Cin : 0x7fffffff;
+        akhi[i] = min(g.KT, g.Tin - t) * g.Cin;
+        apk[i] = (slot ^ (L & 7)) * 4;
+    }
+    const float* wbase[LB]; int wkhi[LB], wpk[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int L = i * RPP + wave * 8 + lrow;              // LDS row; the W-tile row it holds: interleaved columns
+        const int wb = L / (16 * NT), within = L % (16 * NT);
+        const int r = wb * 16 * NT + NT * (within % 16) + within / 16;
+        wbase[i] = g.W + (size_t)min(n0 + r, g.N - 1) * K;
+        wkhi[i] = n0 + r < g.N ? K : 0;
+        wpk[i] = (slot ^ (L & 7)) * 4;
+    }
+    const int nch = (K + 31) / 32;
+    const int c_lo = g.kb_per_split > 0 ? (int)blockIdx.z * g.kb_per_split : 0;
+    const int c_hi = g.kb_per_split > 0 ? min(nch, c_lo + g.kb_per_split) : nch;
+    const int n_my = c_hi - c_lo;
+    int kreq = c_lo * 32;                          // flat k of the next chunk to request
+    auto issue = [&](int bufi) __attribute__((always_inline)) {
+        float* ab = lds + bufi * BUF;
+        float* bb = ab + BM * 32;
+        const bool live = kreq < c_hi * 32;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int k = kreq + apk[i];
+            const float* src = (live && k >= aklo[i] && k < akhi[i]) ? abase[i] + k : zp;
+            __builtin_amdgcn_global_load_lds((gd_gptr_t)src, (gd_lptr_t)(ab + (i * RPP + wave * 8) * 32), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int k = kreq + wpk[i];
+            const float* src = (live && k < wkhi[i]) ? wbase[i] + k : zp;
+            __builtin_amdgcn_global_load_lds((gd_gptr_t)src, (gd_lptr_t)(bb + (i * RPP + wave * 8) * 32), 16, 0, 0);
+        }
+        kreq += 32;
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](int bufi) __attribute__((always_inline)) {
+        const float* ab = lds + bufi * BUF;
+        const float* bb = ab + BM * 32;
+        f32x4 a4[2][MT], b4[2][NT];      // the fragments of both 16-float halves first: one exposed LDS latency per chunk
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { const int L = wm * 16 * MT + t * 16 + fr; a4[h][t] = *reinterpret_cast<const f32x4*>(ab + L * 32 + (((h * 4 + fq) ^ (L & 7)) * 4)); }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { const int L = wn * 16 * NT + t * 16 + fr; b4[h][t] = *reinterpret_cast<const f32x4*>(bb + L * 32 + (((h * 4 + fq) ^ (L & 7)) * 4)); }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[h][mt][cc], b4[h][nt][cc], acc[mt][nt], 0, 0, 0);
+    };
+    issue(0);
+    issue(1);
+    int bi = 0, bn = 2;
+    for (int c = 0; c < n_my; ++c) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LA + LB) : "memory");      // chunk c has landed (this wave's pieces); chunk c + 1 may be in flight
+        st_lds_barrier();                                                     // ... and every other wave's
+        issue(bn);
+        compute(bi);
+        bi = bi == 2 ? 0 : bi + 1;
+        bn = bn == 2 ? 0 : bn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (the two requests past the end: zeros into buffers nobody reads)
+    // epilogue: lane (fr, fq) holds rows 4 fq + e of each row tile and the NT consecutive columns nb .. nb + NT - 1
+    const st_gemm_epilogue& ep = g.ep;
+    const int nb = n0 + wn * 16 * NT + NT * fr;
+    if (g.kb_per_split > 0) {                      // split-K: the raw partial product
+        float* ws = g.split_ws + (size_t)blockIdx.z * g.M * g.N;
+        const bool vec = NT == 2 && g.N % 2 == 0 && nb + 1 < g.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm * 16 * MT + mt * 16 + 4 * fq + e;
+                if (m >= g.M) continue;
+                float* p = ws + (size_t)m * g.N + nb;
+                if (vec) { typedef float f32x2 __attribute__((ext_vector_type(2))); *reinterpret_cast<f32x2*>(p) = f32x2{acc[mt][0][e], acc[mt][NT - 1][e]}; }
+                else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) if (nb + nt < g.N) p[nt] = acc[mt][nt][e];
+                }
+            }
+        return;
+    }
+    float bias[NT], bn_m[NT], bn_s[NT], bn_w[NT], bn_b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(nb + nt, g.N - 1);
+        bias[nt] = ep.bias ? ep.bias[n] : 0.0f;
+        bn_m[nt] = 0.f; bn_s[nt] = 1.f; bn_w[nt] = 1.f; bn_b[nt] = 0.f;
+        if (ep.bn_mean) {
+            bn_m[nt] = ep.bn_mean[n];
+            bn_s[nt] = 1.0f / sqrtf(ep.bn_var[n] + ep.bn_eps);
+            bn_w[nt] = ep.bn_w ? ep.bn_w[n] : 1.0f;
+            bn_b[nt] = ep.bn_b ? ep.bn_b[n] : 0.0f;
+        }
+    }
+    const bool vec = NT == 2 && nb + 1 < g.N && ((g.ldc | g.coff) & 1) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 7) == 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 16 * MT + mt * 16 + 4 * fq + e;
+            if (m >= g.M) continue;
+            float v[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) v[nt] = nb + nt < g.N ? gm_epilogue_one(ep, acc[mt][nt][e], m, nb + nt, bias[nt], bn_m[nt], bn_s[nt], bn_w[nt], bn_b[nt]) : 0.0f;
+            float* p = g.C + (size_t)m * g.ldc + g.coff + nb;
+            if (vec) { typedef float f32x2 __attribute__((ext_vector_type(2))); *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[NT - 1]}; }
+            else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) if (nb + nt < g.N) p[nt] = v[nt];
+            }
+        }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gd_kernel(const GmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * (BM + BN) * 32];
+    gd_body<BM, BN>(g, lds);
+}
+
 // several jobs in one launch (blockIdx.z = job, longest reductions first): the conv bank's K convs over the same input.  A launch
 // of its own gives each of them ~one workgroup per compute unit -- one wave per SIMD, nothing to overlap its LDS traffic and barriers
 // with; together the K convs keep several workgroups resident per compute unit.
@@ -394,6 +579,14 @@ __global__ __launch_bounds__(GM_THREADS) void gm_pipe_batch_kernel(const GmBatch
     const GmArgs& g = b.g[blockIdx.z];
     if ((int)blockIdx.x * (32 * MT) >= g.M || (int)blockIdx.y * GM_BN >= g.N) return;      // (uniform: the whole workgroup leaves)
     gm_pipe_body<VECW, false, MT>(g, As, Bs);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gd_batch_kernel(const GmBatch b) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * (BM + BN) * 32];
+    const GmArgs& g = b.g[blockIdx.z];
+    if ((int)blockIdx.x * BM >= g.M || (int)blockIdx.y * BN >= g.N) return;      // (uniform: the whole workgroup leaves)
+    gd_body<BM, BN>(g, lds);
 }
 
 // ---- the highway stack as ONE kernel (inference) ------------------------------------------------------------------------
@@ -629,17 +822,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* X, int ldx, int co
 
 }  // namespace
 
-// Split-K pays where the 64 x 64 grid is small AND the reduction is long: the encoder convs (1376 x 512 x 2560: 176 workgroups
-// walking 160 k-blocks each, 83 -> 45 us with 4 slabs incl. the finish pass, tools/gemm_lab.hip), the 640 -> 128 projection conv
-// (76 -> 52).  Short reductions (K <= 640) lose or gain nothing.  Slabs: enough for ~900 workgroups, at least 24 k-blocks each.
+// Tile of the LDS-DMA kernel for an (M, N) product (measured on the shapes of one C2 / C5 forward, tools/gemm_lab2.hip):
+//   0 = 64 x 64: grids of >= 1024 such tiles, and the split-K shapes;  1 = 32 x 64: smaller grids (twice the workgroups);
+//   2 = 64 x 32: narrow outputs whose last 64-column block would be at most half full (N = 80: 96 padded columns instead of 128)
+static int gd_tile(long M, int N, int S) {
+    const int rem = N % 64;
+    if (N <= 192 && rem > 0 && rem <= 32) return 2;
+    const long wgs64 = ((M + 63) / 64) * ((N + 63) / 64);
+    return (S > 1 || wgs64 >= 1024) ? 0 : 1;
+}
+
+// Split-K pays where the 64 x 64 grid is small AND the reduction is long: the encoder convs (1376 x 512 x 2560: 176 tiles walking 80
+// chunks of 32 floats each; 4 slabs incl. the finish pass: 76 -> 44 us), the 640 -> 128 projection conv.  Short reductions (K < 1536)
+// lose or gain nothing.  Slabs: enough for ~700 workgroups, at least 12 chunks each.
 extern "C" int st_gemm_splitk_slabs(int Bn, int Tout, int Cin, int N, int KT) {
     if (Bn <= 0 || Tout <= 0 || Cin < 4 || Cin % 4 != 0 || N <= 0 || KT <= 0) return 1;
     const long M = (long)Bn * Tout;
     const long wgs = ((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
-    const int nkb = KT * ((Cin + GM_BK - 1) / GM_BK);
-    if (wgs >= 512) return 1;
-    int S = (int)((900 + wgs / 2) / wgs);
-    if (S > nkb / 24) S = nkb / 24;
+    const int nch = (KT * Cin + 31) / 32;
+    if (wgs >= 512 || nch < 48 || gd_tile(M, N, 1) == 2) return 1;
+    int S = (int)((704 + wgs / 2) / wgs);
+    if (S > nch / 12) S = nch / 12;
     if (S > 8) S = 8;
     return S < 2 ? 1 : S;
 }
@@ -709,9 +912,15 @@ extern "C" int st_gemm_fwd_batch(const st_gemm_job* jobs, int n, void* stream) {
             maxM = b.g[j].M > maxM ? b.g[j].M : maxM;
             maxN = b.g[j].N > maxN ? b.g[j].N : maxN;
         }
-        const int nby = (maxN + GM_BN - 1) / GM_BN;
-        // 64-row tiles: a batch has workgroups to spare
-        hipLaunchKernelGGL((gm_pipe_batch_kernel<true, 2>), dim3((maxM + 63) / 64, nby, cnt), dim3(GM_THREADS), 0, (hipStream_t)stream, b);
+        // LDS-DMA kernel when every job can take it (see st_gemm_fwd); 64 x 32 tiles for the narrow outputs of the conv bank
+        bool dma = true, narrow = true;
+        for (int j = 0; j < cnt; ++j) {
+            dma = dma && (b.g[j].KT == 1 || b.g[j].lda == b.g[j].Cin);
+            narrow = narrow && gd_tile(b.g[j].M, b.g[j].N, 1) == 2;
+        }
+        if (dma && narrow) hipLaunchKernelGGL((gd_batch_kernel<64, 32>), dim3((maxM + 63) / 64, (maxN + 31) / 32, cnt), dim3(256), 0, (hipStream_t)stream, b);
+        else if (dma) hipLaunchKernelGGL((gd_batch_kernel<64, 64>), dim3((maxM + 63) / 64, (maxN + 63) / 64, cnt), dim3(256), 0, (hipStream_t)stream, b);
+        else hipLaunchKernelGGL((gm_pipe_batch_kernel<true, 2>), dim3((maxM + 63) / 64, (maxN + GM_BN - 1) / GM_BN, cnt), dim3(GM_THREADS), 0, (hipStream_t)stream, b);
         ST_LAUNCH_CHECK();
     }
     return 0;
@@ -734,7 +943,13 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
         g.split_ws = ep->splitk_ws;
         grid.z = S;
     }
-    if (veca) {      // (16-byte addressable A: Cin % 4 == 0, so Cin >= 4) the pipelined kernel; otherwise the generic one-block form
+    if (veca && vecw && !pool_prev && (KT == 1 || lda == Cin)) {      // the LDS-DMA kernel (gd_kernel)
+        if (S > 1) g.kb_per_split = ((KT * Cin + 31) / 32 + S - 1) / S;          // (in 32-float chunks)
+        const int tile = gd_tile(g.M, N, S);
+        if (tile == 0) hipLaunchKernelGGL((gd_kernel<64, 64>), dim3((g.M + 63) / 64, (N + 63) / 64, S), dim3(256), 0, st, g);
+        else if (tile == 1) hipLaunchKernelGGL((gd_kernel<32, 64>), dim3((g.M + 31) / 32, (N + 63) / 64, S), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gd_kernel<64, 32>), dim3((g.M + 63) / 64, (N + 31) / 32, S), dim3(256), 0, st, g);
+    } else if (veca) {      // (16-byte addressable A: Cin % 4 == 0, so Cin >= 4) the pipelined kernel; otherwise the generic one-block form
         // 32-row tiles when 64-row tiles would leave compute units with fewer than two workgroups (st_device_info: 256 CUs)
         const bool small = S == 1 && (size_t)grid.x * grid.y < 512;
         const dim3 grid32((g.M + 31) / 32, grid.y);

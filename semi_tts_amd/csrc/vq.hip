@@ -194,13 +194,31 @@ __device__ __forceinline__ float vq_row_sum(float v) {
     v += st_dpp<ST_DPP_ROW_HALF_MIRROR>(v); v += st_dpp<ST_DPP_ROW_MIRROR>(v);
     return v;
 }
-// larger value wins, equal values: smaller index (torch.argmax: the first maximum)
-__device__ __forceinline__ void vq_best(float& v, int& i, float ov, int oi) { if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } }
-template <int CTRL>
-__device__ __forceinline__ void vq_row_argmax_step(float& v, int& i) { const float ov = st_dpp<CTRL>(v); const int oi = vq_dpp_i<CTRL>(i); vq_best(v, i, ov, oi); }
+#ifdef VQ_STAMPS      // phase stamps of workgroup 0 / wave 0, second tile (experiment builds only: tools/exp_vq_stamps.py)
+__device__ unsigned long long vq_stamps[32];
+#define VQ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tile == (int)gridDim.x) vq_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VQ_STAMP(i) do { } while (0)
+#endif
 
-// TPW code tiles per wave (V <= 64 TPW); WPS = workgroups the launcher places per compute unit (register budget 512 / WPS per lane)
-template <int TPW, int WPS>
+// exp(x) for x <= 0 as the softmax needs it: one multiply + v_exp_f32 (libm's expf is 13 instructions, half of them quarter-rate:
+// phase stamps showed 7.0k of a tile's 21k cycles in the 32 exponentials per lane).  Accurate to ~1 ulp where the argmax is decided
+// (x ~ 0: exp2 of a correctly rounded product), relative error ~ |x| 2^-24 in the tail; weakly monotone like expf, and exp(0) = 1
+// exactly.  The reference's own p_code comes from ATen's vectorised exp, so no form is bitwise "the" reference; the golden vectors
+// (ties, near-ties, duplicates) pin the indices.
+__device__ __forceinline__ float vq_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+// e / s with ONE IEEE division per row (r = 1 / s) and two fused multiply-adds per element: q = e r, q' = q + r (e - q s) is the
+// correctly rounded quotient whenever r is the correctly rounded reciprocal (Markstein), i.e. the value `e / s` itself -- at 3
+// instructions instead of the 11 of the division sequence (32 of them per lane and tile)
+__device__ __forceinline__ float vq_div(float e, float s, float r) {
+    const float q = e * r;
+    return fmaf(fmaf(-q, s, e), r, q);
+}
+
+// TPW code tiles per wave (V <= 64 TPW); WPS = workgroups the launcher places per compute unit (register budget 512 / WPS per lane);
+// FULL: V == 64 TPW, every code of every tile exists (no masks in the loop)
+template <int TPW, int WPS, bool FULL>
 __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
                                                                          float* p_code, int64_t* idx_out, float* out, int n, int D, int V,
                                                                          int ks4n, int n_tiles, int p_vec4) {
@@ -224,18 +242,27 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
     // every table operand of this wave: requested once, kept in registers for all the tiles of the workgroup
     f32x4 bq[TPW][4];
     float e2v[TPW];
+    float off[FULL ? 1 : TPW];            // 0 for an existing code, -inf past the table: added to the similarity (x + 0 == x)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int pt = wave + NW * t;
         e2v[t] = e2[pt * 16 + nn];
+        if (!FULL) off[t] = vq_code_of(TPW, pt, nn) < V ? 0.0f : -INFINITY;
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[t][q] = q < ks4n ? wsp[((size_t)pt * ks4n + q) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float tscale = fmaxf(temp[0], 0.0f);          // F.relu(self.temp)
+    // every barrier of the loop orders LDS traffic only (st_lds_barrier): __syncthreads() also waits for the global stores of p_code
+    // and for the prefetched vectors of the next tile -- a memory round trip per barrier, seven per tile
+    f32x4 oe = {0.f, 0.f, 0.f, 0.f}, ox = oe;           // the previous tile's picked code row (in flight) and its own vector piece
+    int ov = -1;                                        // ... of vector ov
     for (; tile < n_tiles; tile += gridDim.x) {
         const int v0 = tile * 16;
-        *reinterpret_cast<f32x4*>(xt + svec * VQM_XLD + (tid & 15) * 4) = (sd_ok && v0 + svec < n) ? xr : f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
+        VQ_STAMP(0);
+        const f32x4 xcur = (sd_ok && v0 + svec < n) ? xr : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(xt + svec * VQM_XLD + (tid & 15) * 4) = xcur;
+        st_lds_barrier();
+        VQ_STAMP(1);
         {   // the next tile's vectors travel while this one is scored
             const int nt = tile + (int)gridDim.x;
             xr = *reinterpret_cast<const f32x4*>(x + (size_t)min(min(nt, n_tiles - 1) * 16 + svec, n - 1) * D + sd4);
@@ -258,6 +285,7 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
         float ax[16];                                   // A fragments: x[vec nn][4 ks + g]
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) ax[ks] = xt[nn * VQM_XLD + ks * 4 + g];
+        VQ_STAMP(2);
         // the MFMAs run k-step by k-step ACROSS the tiles -- consecutive MFMAs write different accumulators (no dependent-issue
         // stalls), and every accumulator still sums its dimensions in ascending order
         f32x4 acc[TPW];
@@ -270,6 +298,12 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
 #pragma unroll
                 for (int t = 0; t < TPW; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q * 4 + c], bq[t][q][c], acc[t], 0, 0, 0);
+        if (ov >= 0 && ov < n && sd_ok) {               // the previous tile's output rows (the code rows have landed by now)
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (ox[c] + oe[c]) - ox[c];
+            *reinterpret_cast<f32x4*>(out + (size_t)ov * D + (tid & 15) * 4) = o;
+        }
         // lane (g, nn) now holds dot(x[vec 4g + r], e[code of (tile wave + NW t, column nn)]) in acc[t][r]
         float xxr[4];
 #pragma unroll
@@ -277,18 +311,19 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
         float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const bool on = vq_code_of(TPW, wave + NW * t, nn) < V;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float dist = (xxr[r] + e2v[t]) - 2.0f * acc[t][r];     // embed.py:210-212 association order
-                const float sim = on ? tscale * (-dist) : -INFINITY;
+                float sim = tscale * (-dist);
+                if (!FULL) sim += off[t];
                 acc[t][r] = sim;
                 mx[r] = fmaxf(mx[r], sim);
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { mx[r] = vq_row_max(mx[r]); if (nn == 0) red[wave][4 * g + r] = mx[r]; }
-        __syncthreads();
+        st_lds_barrier();
+        VQ_STAMP(3);
         float sm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -300,31 +335,47 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = expf(acc[t][r] - mx[r]); acc[t][r] = e; sm[r] += e; }
-        __syncthreads();                                     // everybody has read the maxima: the slots are reused for the sums
+            for (int r = 0; r < 4; ++r) { const float e = vq_exp(acc[t][r] - mx[r]); acc[t][r] = e; sm[r] += e; }
+        st_lds_barrier();                                     // everybody has read the maxima: the slots are reused for the sums
+        VQ_STAMP(4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sm[r] = vq_row_sum(sm[r]); if (nn == 0) red[wave][4 * g + r] = sm[r]; }
-        __syncthreads();
-        float bv[4] = {-1.f, -1.f, -1.f, -1.f};
+        st_lds_barrier();
+        VQ_STAMP(5);
+        // argmax over p with "first maximum wins": the largest e of a row is exp(0) = 1 exactly, so the row maximum of p is the value
+        // p takes for e = 1 -- known without a reduction -- and the index is the SMALLEST code whose p equals it (an integer min:
+        // one DPP min per step instead of a compare + two selects on (value, index) pairs: 2.7k of a tile's 21k cycles)
         int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        float rs[4], pmax[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {          // fixed order: wave 0, 1, ...
             float sacc = red[0][4 * g + r];
 #pragma unroll
             for (int w = 1; w < NW; ++w) sacc += red[w][4 * g + r];
             sm[r] = sacc;
+            rs[r] = 1.0f / sacc;
+            pmax[r] = vq_div(1.0f, sacc, rs[r]);
         }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             const int code = vq_code_of(TPW, wave + NW * t, nn);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = acc[t][r] / sm[r];
+                const float p = vq_div(acc[t][r], sm[r], rs[r]);
                 acc[t][r] = p;
-                if (code < V && p > bv[r]) { bv[r] = p; bi[r] = code; }      // ascending codes per lane: strict > keeps the first
+                bi[r] = min(bi[r], p == pmax[r] ? code : 0x7fffffff);      // (codes past the table have p = 0 < pmax)
             }
         }
-        if (PERM) {      // four consecutive codes per lane and vector: 16-byte stores, 256 contiguous bytes per 16 lanes
+        const bool whole = FULL && v0 + 16 <= n && p_vec4;       // (uniform) every vector and every code of the tile exists
+        VQ_STAMP(6);
+        if (PERM && whole) {      // four consecutive codes per lane and vector: 16-byte stores, 256 contiguous bytes per 16 lanes
+            float* pp = p_code + (size_t)(v0 + 4 * g) * V + vq_code_of(TPW, wave, nn);
+#pragma unroll
+            for (int h = 0; h < (PERM ? TPW / 4 : 0); ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<f32x4*>(pp + (size_t)r * V + 64 * h) = f32x4{acc[4 * h][r], acc[4 * h + 1][r], acc[4 * h + 2][r], acc[4 * h + 3][r]};
+        } else if (PERM) {
 #pragma unroll
             for (int h = 0; h < (PERM ? TPW / 4 : 0); ++h) {
                 const int c0 = vq_code_of(TPW, wave + NW * 4 * h, nn);
@@ -351,35 +402,36 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
                 }
             }
         }
-        __syncthreads();                                     // sums consumed: slots reused for the per-wave best
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            vq_row_argmax_step<ST_DPP_QUAD_XOR1>(bv[r], bi[r]); vq_row_argmax_step<ST_DPP_QUAD_XOR2>(bv[r], bi[r]);
-            vq_row_argmax_step<ST_DPP_ROW_HALF_MIRROR>(bv[r], bi[r]); vq_row_argmax_step<ST_DPP_ROW_MIRROR>(bv[r], bi[r]);
-            if (nn == 0) { red[wave][4 * g + r] = bv[r]; redi[wave][4 * g + r] = bi[r]; }
+            bi[r] = min(bi[r], vq_dpp_i<ST_DPP_QUAD_XOR1>(bi[r])); bi[r] = min(bi[r], vq_dpp_i<ST_DPP_QUAD_XOR2>(bi[r]));
+            bi[r] = min(bi[r], vq_dpp_i<ST_DPP_ROW_HALF_MIRROR>(bi[r])); bi[r] = min(bi[r], vq_dpp_i<ST_DPP_ROW_MIRROR>(bi[r]));
+            if (nn == 0) redi[wave][4 * g + r] = bi[r];
         }
-        __syncthreads();
+        VQ_STAMP(7);
+        st_lds_barrier();
+        VQ_STAMP(8);
         if (tid < 16) {
-            float v = red[0][tid];
             int i = redi[0][tid];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) vq_best(v, i, red[w][tid], redi[w][tid]);
+            for (int w = 1; w < NW; ++w) i = min(i, redi[w][tid]);
             fidx[tid] = i;
             if (v0 + tid < n) idx_out[v0 + tid] = i;
         }
-        __syncthreads();
-        {   // out = (x + code) - x.detach(): the straight-through forward value (embed.py:145)
-            const int d4 = (tid & 15) * 4;
-            if (v0 + svec < n && d4 < D) {
-                const f32x4 e = *reinterpret_cast<const f32x4*>(table + (size_t)fidx[svec] * D + d4);
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xt + svec * VQM_XLD + d4);
-                f32x4 o;
+        st_lds_barrier();
+        VQ_STAMP(9);
+        // out = (x + code) - x.detach(), the straight-through forward value (embed.py:145): the picked code's row is REQUESTED here and
+        // consumed one tile later (the gather's round trip, 2.1k cycles, sat on every tile's critical path)
+        oe = *reinterpret_cast<const f32x4*>(table + (size_t)fidx[svec] * D + sd4);
+        ox = xcur;
+        ov = v0 + svec;
+        VQ_STAMP(10);
+    }
+    if (ov >= 0 && ov < n && sd_ok) {
+        f32x4 o;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = (xv[c] + e[c]) - xv[c];
-                *reinterpret_cast<f32x4*>(out + (size_t)(v0 + svec) * D + d4) = o;
-            }
-        }
-        __syncthreads();                                     // xt / fidx are rewritten by the next tile
+        for (int c = 0; c < 4; ++c) o[c] = (ox[c] + oe[c]) - ox[c];
+        *reinterpret_cast<f32x4*>(out + (size_t)ov * D + (tid & 15) * 4) = o;
     }
 }
 
@@ -496,6 +548,10 @@ __global__ __launch_bounds__(256) void vq_mean_bwd_kernel(const float* dout, int
 
 }  // namespace
 
+#ifdef VQ_STAMPS
+extern "C" int st_vq_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vq_stamps), sizeof(vq_stamps)); }
+#endif
+
 extern "C" int st_vq_build_table(const float* learnable, int Dl, const float* attr, int n_attr,
                                  const float* attr_w, const float* attr_b, int Da, float* table, int V, void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
@@ -573,15 +629,20 @@ static int vq_l2_impl(const float* x, const float* table, const float* temp, flo
         // registers fit twice into a SIMD's file, 16 tiles once), each walking tiles blockIdx.x, + gridDim.x, ...
         const int n_tiles = (n + 15) / 16;
         const int p_vec4 = (V % 4 == 0 && st_aligned16(p_code)) ? 1 : 0;
-#define VQ_LAUNCH(T, WPS) do { const int gmax = WPS * st_device_cus(); \
-        hipLaunchKernelGGL((vq_l2_mfma_kernel<T, WPS>), dim3(n_tiles < gmax ? n_tiles : gmax), dim3(VQM_NW * 64), 0, (hipStream_t)stream, \
+#define VQ_LAUNCH_ONE(T, WPS, FULL_) do { static int occ = 0; \
+        if (occ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vq_l2_mfma_kernel<T, WPS, FULL_>, VQM_NW * 64, 0) != hipSuccess || occ < 1)) occ = WPS; \
+        const int gmax = occ * st_device_cus(); \
+        hipLaunchKernelGGL((vq_l2_mfma_kernel<T, WPS, FULL_>), dim3(n_tiles < gmax ? n_tiles : gmax), dim3(VQM_NW * 64), 0, (hipStream_t)stream, \
                            x, table, workspace, temp, p_code, idx, out, n, D, V, ks4n, n_tiles, p_vec4); } while (0)
+        // (the grid: as many workgroups as the registers keep resident -- 6 per compute unit at one code tile per wave, 2 at eight)
+#define VQ_LAUNCH(T, WPS) do { if (V == 64 * T) VQ_LAUNCH_ONE(T, WPS, true); else VQ_LAUNCH_ONE(T, WPS, false); } while (0)
         if (tpw == 1) VQ_LAUNCH(1, 2);
         else if (tpw == 2) VQ_LAUNCH(2, 2);
         else if (tpw == 4) VQ_LAUNCH(4, 2);
         else if (tpw == 8) VQ_LAUNCH(8, 2);
         else VQ_LAUNCH(16, 1);
 #undef VQ_LAUNCH
+#undef VQ_LAUNCH_ONE
         ST_LAUNCH_CHECK();
         return 0;
     }

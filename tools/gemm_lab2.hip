@@ -36,7 +36,9 @@ struct G2Args {
 
 constexpr int G2_LD = 40;     // LDS row stride (floats) of a 32-float chunk: the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots
 
-template <int BM, int BN, int NWM, int NWN>
+// ABL (timing ablations, results garbage): 1 = no global loads, 2 = no LDS stores, 3 = no LDS reads, 4 = no MFMAs, 5 = linear addressing
+// (no tap / frame arithmetic: valid for KT = 1 only)
+template <int BM, int BN, int NWM, int NWN, int ABL = 0>
 __global__ __launch_bounds__(64 * NWM * NWN) void g2_kernel(const G2Args g) {
     constexpr int NTH = 64 * NWM * NWN;
     constexpr int MT = BM / NWM / 16, NT = BN / NWN / 16;
@@ -87,6 +89,15 @@ __global__ __launch_bounds__(64 * NWM * NWN) void g2_kernel(const G2Args g) {
         const int tapc = min(tap_n, g.KT - 1);
         const int cic = in_k ? ci_n : 0;
         r.va = 0; r.vw = 0;
+        if (ABL == 1) { r.va = r.vw = in_k ? ~0u : 0u; k_n += 32; return; }
+        if (ABL == 5) {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) { r.a[i] = *reinterpret_cast<const f32x4*>(arow[i] + (size_t)(atb[i] + g.pad) * g.lda + kc); if (in_k && aok[i]) r.va |= 1u << i; }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) { r.w[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kc); if (in_k && wok[i]) r.vw |= 1u << i; }
+            k_n += 32;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int ti = atb[i] + tapc;
@@ -104,6 +115,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void g2_kernel(const G2Args g) {
         if (ci_n >= g.Cin) { ci_n -= g.Cin; ++tap_n; }      // (Cin = 16)
     };
     auto commit = [&](const Regs& r, int buf) __attribute__((always_inline)) {
+        if (ABL == 2) { if (r.va == 0x12345 && r.a[0][0] == 1.5f && r.w[0][0] == 2.5f) As[buf][tid] = 0.f; return; }
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(As[buf] + (srow + i * RPP) * G2_LD + sp * 4) = (r.va >> i) & 1 ? r.a[i] : z;
@@ -120,10 +132,24 @@ __global__ __launch_bounds__(64 * NWM * NWN) void g2_kernel(const G2Args g) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f32x4 a4[MT], b4[NT];
+            if (ABL == 3) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a4[t] = f32x4{(float)buf, (float)h, (float)t, 1.f};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b4[t] = f32x4{(float)buf, (float)h, (float)t, 2.f};
+            } else {
 #pragma unroll
             for (int t = 0; t < MT; ++t) a4[t] = *reinterpret_cast<const f32x4*>(As[buf] + (wm * 16 * MT + t * 16 + fr) * G2_LD + h * 16 + fq * 4);
 #pragma unroll
             for (int t = 0; t < NT; ++t) b4[t] = *reinterpret_cast<const f32x4*>(Bs[buf] + (wn * 16 * NT + t * 16 + fr) * G2_LD + h * 16 + fq * 4);
+            }
+            if (ABL == 4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += a4[mt] * b4[nt];
+                continue;
+            }
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
@@ -178,6 +204,191 @@ __global__ __launch_bounds__(64 * NWM * NWN) void g2_kernel(const G2Args g) {
             }
         }
 }
+
+
+// ---- g3: both operands by LDS-DMA (global_load_lds_dwordx4), XOR-swizzled lane-linear LDS image, three buffers, one barrier per chunk ----
+// A wave instruction moves 8 rows x 128 bytes (one full line per row) straight into LDS: no staging registers, no ds_write pass, no
+// selects.  LDS row L (128 bytes, 8 slots of 16 bytes) holds in slot s the row's piece s ^ (L & 7) -- the source address is swizzled,
+// the destination is lane-linear -- and a fragment read of piece p goes to slot p ^ (L & 7): the 16 lanes of every ds_read_b128 group
+// fall on 16 distinct 16-byte slots.  Rows / pieces that do not exist (frames outside the utterance, k past K, rows past M or N) read
+// 16 zero bytes from a constant instead.  The reduction axis is the flat (tap, channel) index: with channels-last activations whose
+// row stride is Cin, the taps of one output row are ONE contiguous run of KT * Cin floats.
+__device__ const f32x4 g3_zero4 = {0.f, 0.f, 0.f, 0.f};
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// OPT bit 0: XCD-aware tile order (workgroup b runs on XCD b % 8: XCD x takes the x-th contiguous eighth of the tiles in column-block-
+// major order, so the W rows of a column block stay in ONE XCD's L2); bit 1: the fragments of both 16-float halves are read before the
+// chunk's MFMAs (one exposed LDS latency per chunk instead of two)
+template <int BM, int BN, int NWM, int NWN, int ABL = 0, int OPT = 0>
+__global__ __launch_bounds__(64 * NWM * NWN) void g3_kernel(const G2Args g) {
+    constexpr int NTH = 64 * NWM * NWN, NW = NWM * NWN;
+    constexpr int MT = BM / NWM / 16, NT = BN / NWN / 16;
+    constexpr int RPP = NTH / 8;
+    constexpr int LA = BM / RPP, LB = BN / RPP;
+    constexpr int BUF = (BM + BN) * 32;           // floats per buffer
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "geometry");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (OPT & 1) {
+        const int gx = gridDim.x, T = gx * gridDim.y;
+        const int b = bx + gx * by;
+        const int per = (T + 7) / 8;
+        const int tile = (b % 8) * per + b / 8;
+        if (tile >= T || b / 8 >= per) return;      // (uniform; grids are padded to 8 * per by the launcher)
+        by = tile / gx; bx = tile - by * gx;
+    }
+    const int m0 = bx * BM, n0 = by * BN;
+    const int lrow = lane >> 3, slot = lane & 7;
+    const float* zp = reinterpret_cast<const float*>(&g3_zero4);
+    // per load: the row's run start (flat k = 0), its valid k range, the piece this lane fetches
+    const float* abase[LA]; int aklo[LA], akhi[LA], apk[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int L = i * RPP + wave * 8 + lrow;              // LDS row = tile row
+        const int m = m0 + L;
+        const int mc = min(m, g.M - 1);
+        const int b = mc / g.Tout, t = mc - b * g.Tout;
+        abase[i] = g.A + ((size_t)b * g.Tin + (t - g.pad)) * g.lda;     // (may point in front of the utterance: only valid pieces are read)
+        const int tlo = max(0, g.pad - t), thi = min(g.KT, g.Tin + g.pad - t);
+        aklo[i] = m < g.M ? tlo * g.Cin : 0x7fffffff;
+        akhi[i] = thi * g.Cin;
+        apk[i] = (slot ^ (L & 7)) * 4;
+    }
+    const float* wbase[LB]; int wkhi[LB], wpk[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int L = i * RPP + wave * 8 + lrow;              // LDS row; the W-tile row it holds: interleaved columns
+        const int wb = L / (16 * NT), within = L % (16 * NT);
+        const int r = wb * 16 * NT + NT * (within % 16) + within / 16;
+        wbase[i] = g.W + (size_t)min(n0 + r, g.N - 1) * g.K;
+        wkhi[i] = n0 + r < g.N ? g.K : 0;
+        wpk[i] = (slot ^ (L & 7)) * 4;
+    }
+    const int nch = (g.K + 31) / 32;
+    const int c_lo = g.chunks_per_split > 0 ? (int)blockIdx.z * g.chunks_per_split : 0;
+    const int c_hi = g.chunks_per_split > 0 ? min(nch, c_lo + g.chunks_per_split) : nch;
+    const int n_my = c_hi - c_lo;
+    int kreq = c_lo * 32;                          // flat k of the next chunk to request
+    auto issue = [&](int bufi) __attribute__((always_inline)) {
+        if (ABL == 1) return;
+        float* ab = lds + bufi * BUF;
+        float* bb = ab + BM * 32;
+        const bool live = kreq < c_hi * 32;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int k = kreq + apk[i];
+            const bool ok = live && k >= aklo[i] && k < akhi[i];
+            const float* src = ok ? abase[i] + k : zp;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ab + (i * RPP + wave * 8) * 32), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int k = kreq + wpk[i];
+            const bool ok = live && k < wkhi[i];
+            const float* src = ok ? wbase[i] + k : zp;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bb + (i * RPP + wave * 8) * 32), 16, 0, 0);
+        }
+        kreq += 32;
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](int bufi) __attribute__((always_inline)) {
+        const float* ab = lds + bufi * BUF;
+        const float* bb = ab + BM * 32;
+        if ((OPT & 2) && ABL != 4) {
+            f32x4 a4[2][MT], b4[2][NT];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) { const int L = wm * 16 * MT + t * 16 + fr; a4[h][t] = *reinterpret_cast<const f32x4*>(ab + L * 32 + (((h * 4 + fq) ^ (L & 7)) * 4)); }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { const int L = wn * 16 * NT + t * 16 + fr; b4[h][t] = *reinterpret_cast<const f32x4*>(bb + L * 32 + (((h * 4 + fq) ^ (L & 7)) * 4)); }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[h][mt][cc], b4[h][nt][cc], acc[mt][nt], 0, 0, 0);
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a4[MT], b4[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { const int L = wm * 16 * MT + t * 16 + fr; a4[t] = *reinterpret_cast<const f32x4*>(ab + L * 32 + (((h * 4 + fq) ^ (L & 7)) * 4)); }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { const int L = wn * 16 * NT + t * 16 + fr; b4[t] = *reinterpret_cast<const f32x4*>(bb + L * 32 + (((h * 4 + fq) ^ (L & 7)) * 4)); }
+            if (ABL == 4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += a4[mt] * b4[nt];
+                continue;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    // chunk c lives in buffer c % 3; the requests of chunk c + 2 go out right after the barrier of iteration c (every wave has left
+    // compute(c - 1), whose buffer they overwrite); at the top of iteration c only chunk c + 1 may still be in flight
+    issue(0);
+    issue(1);
+    int bi = 0, bn = 2;
+    for (int c = 0; c < n_my; ++c) {
+        if (ABL != 1) {
+            if (c + 1 < n_my + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LA + LB) : "memory");      // (chunk c + 1 stays in flight)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue(bn);
+        compute(bi);
+        bi = bi == 2 ? 0 : bi + 1;
+        bn = bn == 2 ? 0 : bn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* out = g.chunks_per_split > 0 ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const int ldo = g.chunks_per_split > 0 ? g.N : g.ldc;
+    const int nb = n0 + wn * 16 * NT + NT * fr;
+    const bool vec_ok = (g.N % NT == 0) && (ldo % NT == 0);
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = (g.bias && g.chunks_per_split == 0 && nb + nt < g.N) ? g.bias[nb + nt] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 16 * MT + mt * 16 + 4 * fq + e;
+            if (m >= g.M) continue;
+            float* p = out + (size_t)m * ldo + nb;
+            if (vec_ok && nb + NT <= g.N) {
+                if (NT == 4) *reinterpret_cast<f32x4*>(p) = f32x4{acc[mt][0][e] + bv[0], acc[mt][1 % NT][e] + bv[1 % NT], acc[mt][2 % NT][e] + bv[2 % NT], acc[mt][3 % NT][e] + bv[3 % NT]};
+                else if (NT == 2) *reinterpret_cast<f32x2*>(p) = f32x2{acc[mt][0][e] + bv[0], acc[mt][1 % NT][e] + bv[1 % NT]};
+                else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) p[nt] = acc[mt][nt][e] + bv[nt];
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) if (nb + nt < g.N) p[nt] = acc[mt][nt][e] + bv[nt];
+            }
+        }
+}
+#define G3_EPILOGUE_END 1
 
 __global__ void finish_kernel(const float* __restrict__ part, float* __restrict__ out, const float* bias, int N, size_t n4, int S) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,7 +445,7 @@ static double check(size_t n) {
 
 struct Best { float us = 1e30f; char what[96] = ""; };
 
-template <int BM, int BN, int NWM, int NWN>
+template <int BM, int BN, int NWM, int NWN, int ABL = 0>
 static void run(const Shape& s, G2Args g, int S, Best& best, bool verbose) {
     const int nch = (g.K + 31) / 32;
     if (S > nch) return;
@@ -242,22 +453,55 @@ static void run(const Shape& s, G2Args g, int S, Best& best, bool verbose) {
     if ((long)grid.x * grid.y * S > 6000) return;
     const size_t lds = (size_t)2 * (BM + BN) * G2_LD * 4;
     static bool set = false;
-    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(g2_kernel<BM, BN, NWM, NWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(g2_kernel<BM, BN, NWM, NWN, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
     g.chunks_per_split = S > 1 ? (nch + S - 1) / S : 0;
     g.ws = dP;
     CK(hipMemset(dC, 0, (size_t)g.M * g.N * 4));
     const size_t n4 = (size_t)g.M * g.N / 4;
     auto f = [&] {
-        hipLaunchKernelGGL((g2_kernel<BM, BN, NWM, NWN>), grid, dim3(64 * NWM * NWN), lds, 0, g);
+        hipLaunchKernelGGL((g2_kernel<BM, BN, NWM, NWN, ABL>), grid, dim3(64 * NWM * NWN), lds, 0, g);
         if (S > 1) hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, dP, dC, g.bias, g.N, n4, S);
     };
     const float us = time_us(f);
     const double tf = 2.0 * g.M * g.N * g.K / us / 1e6;
     const double err = check((size_t)g.M * g.N);
     char what[96];
-    snprintf(what, sizeof what, "%dx%d w%dx%d S=%d wgs=%d", BM, BN, NWM, NWN, S, (int)(grid.x * grid.y * S));
-    if (verbose || err > 1e-4) printf("    %-34s %8.2f us  %6.1f TF  frac %.3f  err %.1e\n", what, us, tf, tf / 157.3, err);
-    if (err <= 1e-4 && us < best.us) { best.us = us; snprintf(best.what, sizeof best.what, "%s", what); }
+    snprintf(what, sizeof what, "%dx%d w%dx%d S=%d wgs=%d%s", BM, BN, NWM, NWN, S, (int)(grid.x * grid.y * S),
+             ABL == 1 ? " -loads" : ABL == 2 ? " -ldsW" : ABL == 3 ? " -ldsR" : ABL == 4 ? " -mfma" : ABL == 5 ? " lin" : "");
+    if (verbose || err > 1e-4 || ABL) printf("    %-34s %8.2f us  %6.1f TF  frac %.3f  err %.1e\n", what, us, tf, tf / 157.3, err);
+    if (ABL == 0 && err <= 1e-4 && us < best.us) { best.us = us; snprintf(best.what, sizeof best.what, "%s", what); }
+}
+
+
+template <int BM, int BN, int NWM, int NWN, int ABL = 0, int OPT = 0>
+static void run3(const Shape& s, G2Args g, int S, Best& best, bool verbose) {
+    const int nch = (g.K + 31) / 32;
+    if (S > nch || g.lda != g.Cin) return;
+    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, S);
+    if ((long)grid.x * grid.y * S > 6000) return;
+    if (OPT & 1) {      // pad the tile count to a multiple of 8 (as extra column blocks' worth of workgroups, dropped in the kernel)
+        const int T = grid.x * grid.y, per = (T + 7) / 8;
+        while ((int)(grid.x * grid.y) < 8 * per) ++grid.y;
+    }
+    const size_t lds = (size_t)3 * (BM + BN) * 32 * 4;
+    static bool set = false;
+    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(g3_kernel<BM, BN, NWM, NWN, ABL, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+    g.chunks_per_split = S > 1 ? (nch + S - 1) / S : 0;
+    g.ws = dP;
+    CK(hipMemset(dC, 0, (size_t)g.M * g.N * 4));
+    const size_t n4 = (size_t)g.M * g.N / 4;
+    auto f = [&] {
+        hipLaunchKernelGGL((g3_kernel<BM, BN, NWM, NWN, ABL, OPT>), grid, dim3(64 * NWM * NWN), lds, 0, g);
+        if (S > 1) hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, dP, dC, g.bias, g.N, n4, S);
+    };
+    const float us = time_us(f);
+    const double tf = 2.0 * g.M * g.N * g.K / us / 1e6;
+    const double err = check((size_t)g.M * g.N);
+    char what[96];
+    snprintf(what, sizeof what, "g3%s%s %dx%d w%dx%d S=%d wgs=%d%s", OPT & 1 ? "x" : "", OPT & 2 ? "f" : "", BM, BN, NWM, NWN, S, (int)(grid.x * grid.y * S),
+             ABL == 1 ? " -loads" : ABL == 4 ? " -mfma" : "");
+    if (verbose || err > 1e-4 || ABL) printf("    %-34s %8.2f us  %6.1f TF  frac %.3f  err %.1e\n", what, us, tf, tf / 157.3, err);
+    if (ABL == 0 && err <= 1e-4 && us < best.us) { best.us = us; snprintf(best.what, sizeof best.what, "%s", what); }
 }
 
 int main(int argc, char** argv) {
@@ -270,7 +514,8 @@ int main(int argc, char** argv) {
         {"highway 80->80", 32, 258, 80, 80, 1, 0}, {"gru in-proj 80->240", 32, 258, 80, 240, 1, 0}, {"linear 160->1024", 32, 258, 160, 1024, 1, 0},
         {"teacher prenet 240->256", 32, 86, 240, 256, 1, 0},
         {"dx enc conv (same shape)", 32, 43, 512, 512, 5, 2}, {"dx linear 1024->160", 32, 258, 1024, 160, 1, 0},
-        {"c5 enc conv k5 512->512", 64, 171, 512, 512, 5, 2}, {"c5 proj conv 640->128", 64, 1066, 640, 128, 3, 1}};
+        {"c5 enc conv k5 512->512", 64, 171, 512, 512, 5, 2}, {"c5 proj conv 640->128", 64, 1066, 640, 128, 3, 1},
+        {"big linear 1920->128", 64, 1066, 1920, 128, 1, 0}, {"big linear 2048->1024", 64, 1066, 2048, 1024, 1, 0}};
     size_t maxA = 0, maxW = 0, maxC = 0;
     for (const Shape& s : shapes) {
         const int Tout = s.T + 2 * s.pad - s.KT + 1;
@@ -296,6 +541,17 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(naive_kernel, dim3((g.N + 255) / 256, g.M), dim3(256), 0, 0, gr);
         CK(hipMemcpy(hR.data(), dR, (size_t)g.M * g.N * 4, hipMemcpyDeviceToHost));
         Best best;
+        if (argc > 1 && argv[1][0] == 'a') {      // ablations on the steady-state shapes
+            if (g.M < 60000) continue;
+            for (int S : {1}) {
+#define ABLS(BM, BN, A, B) run<BM, BN, A, B, 0>(s, g, S, best, true); run<BM, BN, A, B, 1>(s, g, S, best, true); run<BM, BN, A, B, 2>(s, g, S, best, true); \
+                           run<BM, BN, A, B, 3>(s, g, S, best, true); run<BM, BN, A, B, 4>(s, g, S, best, true);
+                ABLS(64, 64, 2, 2) ABLS(128, 128, 2, 2) ABLS(128, 128, 4, 2) ABLS(128, 64, 4, 2)
+#define ABL3(BM, BN, A, B) run3<BM, BN, A, B, 0>(s, g, S, best, true); run3<BM, BN, A, B, 1>(s, g, S, best, true); run3<BM, BN, A, B, 4>(s, g, S, best, true);
+                ABL3(64, 64, 2, 2) ABL3(128, 128, 2, 2) ABL3(128, 128, 4, 2) ABL3(128, 64, 4, 2) ABL3(128, 64, 2, 2)
+            }
+            continue;
+        }
         for (int S : {1, 2, 3, 4, 6, 8}) {
             const bool big = (size_t)g.M * g.N * S > maxC * 8;
             if (big) continue;
@@ -307,6 +563,16 @@ int main(int argc, char** argv) {
             run<64, 128, 2, 2>(s, g, S, best, verbose);
             run<32, 64, 2, 2>(s, g, S, best, verbose);
             run<64, 32, 2, 2>(s, g, S, best, verbose);
+#define R3O(BM, BN, A, B) run3<BM, BN, A, B, 0, 1>(s, g, S, best, verbose); run3<BM, BN, A, B, 0, 2>(s, g, S, best, verbose); run3<BM, BN, A, B, 0, 3>(s, g, S, best, verbose);
+            R3O(64, 64, 2, 2) R3O(128, 64, 4, 2) R3O(128, 128, 4, 2) R3O(32, 64, 2, 2) R3O(64, 32, 2, 2) R3O(128, 128, 2, 2)
+            run3<64, 64, 2, 2>(s, g, S, best, verbose);
+            run3<128, 64, 2, 2>(s, g, S, best, verbose);
+            run3<128, 64, 4, 2>(s, g, S, best, verbose);
+            run3<128, 128, 2, 2>(s, g, S, best, verbose);
+            run3<128, 128, 4, 2>(s, g, S, best, verbose);
+            run3<64, 128, 2, 2>(s, g, S, best, verbose);
+            run3<32, 64, 2, 2>(s, g, S, best, verbose);
+            run3<64, 32, 2, 2>(s, g, S, best, verbose);
         }
         const double tf = 2.0 * g.M * g.N * g.K / best.us / 1e6;
         printf("  BEST %-34s %8.2f us  %6.1f TF  frac %.3f\n", best.what, best.us, tf, tf / 157.3);

@@ -585,7 +585,7 @@ def bench_vq(args, rk):
         xc, tc = torch.randn(32, 129, 64, generator=gc), torch.randn(512, 64, generator=gc)
         Wc = {'learnable_table': tc, 'temp': torch.ones(1)}
         cpu = cpu_timed(lambda: VQ.l2_forward(Wc, xc[:4]), lambda i: [VQ.l2_forward(Wc, xc) for _ in range(20)], 20 * 32 * 129,
-                        'vectors/s', 'port', '20 calls of L2Embedding.forward on (32,129,64) latents, V=512 (oracle/vq_oracle.py: the '
+                        'vectors/s', 'oracle_port', '20 calls of L2Embedding.forward on (32,129,64) latents, V=512 (oracle/vq_oracle.py: the '
                         'reference\'s torch formulation); probe = 4 utterances', max_passes=3)
     res = {'metric': 'VQ vectors/sec (L2Embedding.forward nearest-code search)', 'value': head['vectors_per_s'] * rk.world,
             'unit': 'vectors/s', 'n_gpus': rk.world, 'steps': args.steps, 'warmup': args.warmup,

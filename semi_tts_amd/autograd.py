@@ -151,6 +151,80 @@ def batch_norm_train(x, bn, act=None):
     return _BnTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, act, bn.num_batches_tracked)
 
 
+class _BnTrainGroupFn(Function):
+    """_BnTrainFn for n INDEPENDENT layers of equal width at once (the K BatchNorms of the CBHG conv bank, src/module.py:590-598: they
+    read one input and none depends on another).  Without torch.distributed it is n times the single-layer function; under SyncBN the
+    n layers share their collectives -- ONE all-gather of the n (mean, M2, count) records in forward, ONE all-reduce of the n pairs of
+    sums in backward (8 + 8 collectives of ~43 us each -> 1 + 1 per step).  Arguments: n, act, then n x (x, weight, bias, run_mean,
+    run_var, batches_tracked), then n x (eps, momentum) as floats."""
+
+    @staticmethod
+    def forward(ctx, n, act, *args):
+        from . import parallel
+        tens, scal = args[:6 * n], args[6 * n:]
+        xs = [tens[6 * i].contiguous() for i in range(n)]
+        N = xs[0].shape[-1]
+        assert all(x.shape[-1] == N for x in xs), 'group BatchNorm: equal channel counts'
+        sync = parallel.sync_bn_active()
+        stats = []
+        if sync:
+            parallel._COUNTS['syncbn_fwd'] += 1
+            recs = torch.cat([ops.bn_stats_record(_rows(xs[i]), 0, N, tens[6 * i + 5]) for i in range(n)])       # (n (2N + 1),)
+            allr = parallel.all_gather_(recs)                                                                     # (world, n (2N + 1))
+            per = allr.view(allr.shape[0], n, 2 * N + 1).transpose(0, 1).contiguous()                             # (n, world, 2N + 1)
+            for i in range(n):
+                stats.append(ops.bn_sync_merge(per[i], N, tens[6 * i + 3], tens[6 * i + 4], scal[2 * i + 1]))
+        else:
+            for i in range(n):
+                stats.append(ops.bn_stats(_rows(xs[i]), 0, N, tens[6 * i + 3], tens[6 * i + 4], scal[2 * i + 1], tens[6 * i + 5]) + (None,))
+        ys, saved = [], []
+        for i in range(n):
+            mean, var, inv_total = stats[i]
+            y = ops.bn_norm(_rows(xs[i]), 0, N, mean, var, tens[6 * i + 1], tens[6 * i + 2], scal[2 * i], act).view(xs[i].shape)
+            ys.append(y)
+            saved += [xs[i], y if act is not None else None, mean, var, tens[6 * i + 1], inv_total]
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (n, act, sync, [float(scal[2 * i]) for i in range(n)], [_rows(x).shape[0] for x in xs])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        from . import parallel
+        n, act, sync, eps, Ms = ctx.cfg
+        sv = ctx.saved_tensors
+        N = sv[0].shape[-1]
+        sums = []
+        for i in range(n):
+            x, y, mean, var = sv[6 * i], sv[6 * i + 1], sv[6 * i + 2], sv[6 * i + 3]
+            sums.append(ops.bn_bwd_reduce(_rows_strided(dys[i]), _rows(y) if y is not None else None, act, _rows(x), mean, var, eps[i]))
+        if sync:
+            local = torch.cat(sums)                      # the parameter gradients keep the LOCAL sums (averaged over ranks later)
+            flat = local.clone()
+            parallel._COUNTS['syncbn_bwd'] += 1
+            parallel.all_reduce_sum_(flat)
+            glob = [flat[2 * N * i:2 * N * (i + 1)] for i in range(n)]
+            sums = [local[2 * N * i:2 * N * (i + 1)] for i in range(n)]
+        else:
+            glob = sums
+        grads = []
+        for i in range(n):
+            x, y, mean, var, weight, inv_total = sv[6 * i:6 * i + 6]
+            dx = ops.bn_bwd_apply(_rows_strided(dys[i]), _rows(y) if y is not None else None, act, _rows(x), mean, var, weight, eps[i], glob[i], Ms[i], inv_total)
+            grads += [dx.view(x.shape), sums[i][N:], sums[i][:N], None, None, None]
+        return (None, None) + tuple(grads) + (None,) * (2 * n)
+
+
+def batch_norm_train_group(xs, bns, act=None):
+    """act(BatchNorm1d_i(x_i)) of n independent layers of equal width with shared SyncBN collectives (_BnTrainGroupFn)"""
+    n = len(xs)
+    args = []
+    for x, bn in zip(xs, bns):
+        args += [x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    for bn in bns:
+        args += [float(bn.eps), float(bn.momentum)]
+    return list(_BnTrainGroupFn.apply(n, act, *args))
+
+
 class _LayerNormFn(Function):
     """nn.LayerNorm over the last dimension (the speech encoder's layer_norm, src/asr.py:38-39,58; the normalised prenet Linear,
     src/module.py:508-521)"""

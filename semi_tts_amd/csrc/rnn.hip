@@ -105,33 +105,44 @@ __global__ __launch_bounds__(512) void gru_seq_quad_kernel(const GruArgs a) {
     }
 }
 
-// H <= 84 (the CBHG GRU: 80): FOUR waves, one per SIMD.  The quad form above needs 4 H = 320 lanes = five waves, so one SIMD
-// carries two of them (233 -> 221 us for the 258 steps: the imbalance is not what bounds a step either).  Here a wave owns 21 hidden units, three ADJACENT lanes each (lane 3u + g,
-// g = r, z, n; lane 63 idles): 80-term dot per lane as in the quad form, the two other gates arrive with whole-wave DPP shifts
-// (wave_shl:1, once and twice), lane g = 0 does the pointwise update.  One LDS-only barrier per step.
-template <int KQ>
+// H <= 84 (the CBHG GRU: 80): FOUR waves, one per SIMD; a wave owns 21 hidden units, three ADJACENT lanes each (lane 3u + s; lane
+// 63 idles).  Round 4: the three lanes of a unit split the REDUCTION, not the gates -- lane s holds columns [28 s, 28 s + 28) of ALL
+// three gate rows of its unit (3 x 28 weights in registers) and reads only ITS 28 entries of h: seven ds_read_b128 per lane instead
+// of twenty.  Phase stamps of the gate-per-lane form (tools/exp_gru_stamps.py): 572 of a step's 1644 cycles were the 80 broadcast
+// reads of h queuing on the LDS pipe (4 waves x 20 b128 x 4 cycles), 520 the multiply-adds.  The three partial sums of a gate meet
+// on lane s = 0 with whole-wave DPP shifts (wave_shl:1, :2), which then does the pointwise update.  One LDS-only barrier per step.
+// The output / tape / input-projection addresses are running pointers (the 64-bit index arithmetic per step was ~25 scalar
+// instructions in front of the stores).
+#ifdef GRU_STAMPS     // phase stamps of workgroup (0, 0), wave 0, step 100 (experiment builds only: tools/exp_gru_stamps.py)
+__device__ unsigned long long gru_stamps[16];
+#define GRU_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && s == 100) gru_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GRU_STAMP(i) do { } while (0)
+#endif
+constexpr int GRU_SL = 28;            // columns per lane (3 x 28 = 84 >= H)
 __global__ __launch_bounds__(256) void gru_seq_tri_kernel(const GruArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ __attribute__((aligned(16))) float hbuf[2][3 * GRU_SL];
     const int H = a.H, H3 = 3 * H, T = a.T;
-    constexpr int HP = 4 * KQ;
-    float* hb[2] = {lds, lds + HP};
     const int b = blockIdx.x, d = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int u = lane / 3, g = lane - 3 * u, j = wave * 21 + u;
+    const int u = lane / 3, sl = lane - 3 * u, j = wave * 21 + u;
     const float* __restrict__ gi = a.gi[d] + (size_t)b * T * H3;
-    const bool row_ok = lane < 63 && j < H;
-    float wreg[HP];
-    float bh;
+    const bool unit_ok = lane < 63 && j < H;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 wreg[3][GRU_SL / 2];           // (pairs of adjacent columns: the multiply-adds are v_pk_fma_f32 -- a lone wave issues one VALU
+    float bh[3];                         //  instruction per ~5 cycles, so halving their count is what shortens the phase)
     {   // branch-free: idle lanes and columns past H read a valid address and are zeroed by a select
-        const float* wr = a.w_hh[d] + (size_t)(row_ok ? g * H + j : 0) * H;
-        const float bv = a.b_hh[d][row_ok ? g * H + j : 0];
-        bh = row_ok ? bv : 0.0f;
 #pragma unroll
-        for (int k = 0; k < HP; ++k) { const float w = wr[k < H ? k : H - 1]; wreg[k] = (row_ok && k < H) ? w : 0.0f; }
+        for (int g = 0; g < 3; ++g) {
+            const float* wr = a.w_hh[d] + (size_t)(unit_ok ? g * H + j : 0) * H;
+            bh[g] = unit_ok ? a.b_hh[d][unit_ok ? g * H + j : 0] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < GRU_SL; ++k) { const int col = GRU_SL * sl + k; const float w = wr[col < H ? col : H - 1]; wreg[g][k >> 1][k & 1] = (unit_ok && col < H) ? w : 0.0f; }
+        }
     }
-    for (int k = tid; k < 2 * HP; k += blockDim.x) lds[k] = 0.0f;
+    for (int k = tid; k < 2 * 3 * GRU_SL; k += blockDim.x) (&hbuf[0][0])[k] = 0.0f;
     __syncthreads();
-    const bool upd = row_ok && g == 0;
+    const bool upd = unit_ok && sl == 0;
     float hprev = 0.f;
     constexpr int GRU_PB = 8;      // input projections read GRU_PB steps ahead (see gru_seq_quad_kernel)
     float cur[GRU_PB][3], nxt[GRU_PB][3];
@@ -146,42 +157,61 @@ __global__ __launch_bounds__(256) void gru_seq_tri_kernel(const GruArgs a) {
         }
     };
     load_block(cur, 0);
+    // running pointers of this lane's output element and tape record (step s -> frame t = s or T - 1 - s)
+    const ptrdiff_t ostep = (ptrdiff_t)(d ? -1 : 1) * a.ldo, tstep = (ptrdiff_t)(d ? -1 : 1) * 4 * H;
+    float* op = a.out + ((size_t)b * T + (d ? T - 1 : 0)) * a.ldo + d * H + (upd ? j : 0);
+    float* tp = a.tape ? a.tape + ((((size_t)d * a.B + b) * T + (d ? T - 1 : 0)) * 4) * H + (upd ? j : 0) : nullptr;
     for (int s0 = 0; s0 < T; s0 += GRU_PB) {
         load_block(nxt, s0 + GRU_PB);
 #pragma unroll
         for (int i = 0; i < GRU_PB; ++i) {
             const int s = s0 + i;
             if (s >= T) break;                                        // (uniform)
-            const int t = d ? T - 1 - s : s;
-            const float* hcur = hb[s & 1];
-            float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            // all KQ LDS reads of h go out back to back (left alone the compiler keeps only two in flight: ds_read, wait, 4 FMAs,
-            // ds_read ...); measured 221 -> 212 us for the 258-step H = 80 GRU -- the step is NOT bound by these round trips
-            f32x4 hreg[KQ];
+            const float* hcur = hbuf[s & 1] + GRU_SL * sl;
+            GRU_STAMP(0);
+            f32x4 hreg[GRU_SL / 4];
 #pragma unroll
-            for (int k = 0; k < KQ; ++k) hreg[k] = *reinterpret_cast<const f32x4*>(hcur + 4 * k);
+            for (int k = 0; k < GRU_SL / 4; ++k) hreg[k] = *reinterpret_cast<const f32x4*>(hcur + 4 * k);
             asm volatile("" ::: "memory");             // (keeps the reads above the multiply-adds)
+#ifdef GRU_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            GRU_STAMP(1);
+            f32x2 acc[3];
 #pragma unroll
-            for (int k = 0; k < KQ; ++k) {             // padded h entries are zero, weights past H are zero
-                a0 = fmaf(wreg[4 * k], hreg[k][0], a0); a1 = fmaf(wreg[4 * k + 1], hreg[k][1], a1);
-                a2 = fmaf(wreg[4 * k + 2], hreg[k][2], a2); a3 = fmaf(wreg[4 * k + 3], hreg[k][3], a3);
+            for (int g = 0; g < 3; ++g) acc[g] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < GRU_SL / 4; ++k) {     // three independent chains of packed multiply-adds (x: even columns, y: odd columns)
+                const f32x2 h01 = {hreg[k][0], hreg[k][1]}, h23 = {hreg[k][2], hreg[k][3]};
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_elementwise_fma(wreg[g][2 * k], h01, acc[g]);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_elementwise_fma(wreg[g][2 * k + 1], h23, acc[g]);
             }
-            const float gh = (a0 + a1) + (a2 + a3);                   // W_hh[g*H + j] . h + b_hh
-            const float ghz = st_dpp<0x130>(gh), ghn = st_dpp<0x130>(ghz);      // wave_shl:1: the value of lane + 1, of lane + 2
+            float gh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {              // the unit's three column slices meet on lane s = 0 (wave_shl:1 = the value of lane + 1)
+                const float part = acc[g].x + acc[g].y;
+                const float p1 = st_dpp<0x130>(part), p2 = st_dpp<0x130>(p1);
+                gh[g] = ((part + p1) + p2) + bh[g];    // W_hh[g*H + j] . h + b_hh
+            }
+            GRU_STAMP(2);
             if (upd) {
-                const float r = st_sigmoid_fast(cur[i][0] + gh);
-                const float z = st_sigmoid_fast(cur[i][1] + ghz);
-                const float n = st_tanh_fast(cur[i][2] + r * ghn);
+                const float r = st_sigmoid_fast(cur[i][0] + gh[0]);
+                const float z = st_sigmoid_fast(cur[i][1] + gh[1]);
+                const float n = st_tanh_fast(cur[i][2] + r * gh[2]);
                 const float hn = (1.0f - z) * n + z * hprev;
                 hprev = hn;
-                hb[(s + 1) & 1][j] = hn;
-                a.out[((size_t)b * T + t) * a.ldo + d * H + j] = hn;
-                if (a.tape) {
-                    float* tp = a.tape + ((((size_t)d * a.B + b) * T + t) * 4) * H + j;
-                    tp[0] = r; tp[H] = z; tp[2 * H] = n; tp[3 * H] = ghn;
-                }
+                GRU_STAMP(3);
+                hbuf[(s + 1) & 1][j] = hn;
+                *op = hn;
+                if (tp) { tp[0] = r; tp[H] = z; tp[2 * H] = n; tp[3 * H] = gh[2]; }
             }
+            op += ostep;
+            if (tp) tp += tstep;
+            GRU_STAMP(4);
             st_lds_barrier();
+            GRU_STAMP(5);
         }
 #pragma unroll
         for (int i = 0; i < GRU_PB; ++i) { cur[i][0] = nxt[i][0]; cur[i][1] = nxt[i][1]; cur[i][2] = nxt[i][2]; }
@@ -593,6 +623,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_pw_pair_kernel(const LstmPwArgs 
 
 }  // namespace
 
+#ifdef GRU_STAMPS
+extern "C" int st_gru_debug_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gru_stamps), sizeof(gru_stamps)); }
+#endif
+
 extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const float* w_hh_fwd, const float* w_hh_bwd,
                               const float* b_hh_fwd, const float* b_hh_bwd, float* out, int ldo,
                               float* tape, int B, int T, int H, int ndir, void* stream) {
@@ -610,7 +644,7 @@ extern "C" int st_gru_seq_fwd(const float* gi_fwd, const float* gi_bwd, const fl
     hipStream_t st = (hipStream_t)stream;
     if (H <= GRU_HMAX) {
         const int qthreads = ((4 * H + 63) / 64) * 64;             // <= 512
-        if (H <= 80) hipLaunchKernelGGL(gru_seq_tri_kernel<20>, dim3(B, ndir), dim3(256), (size_t)2 * 80 * sizeof(float), st, a);
+        if (H <= 3 * GRU_SL && H <= 84) hipLaunchKernelGGL(gru_seq_tri_kernel, dim3(B, ndir), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(gru_seq_quad_kernel<32>, dim3(B, ndir), dim3(qthreads), (size_t)2 * 128 * sizeof(float), st, a);
     } else hipLaunchKernelGGL((gru_seq_kernel<false>), dim3(B, ndir), dim3(threads), lds, st, a);
     ST_LAUNCH_CHECK();

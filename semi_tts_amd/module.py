@@ -732,8 +732,10 @@ def _cbhg_forward_train(self, x):
     """differentiable CBHG (same kernels; every stage keeps what its backward needs)"""
     B, T, Cn = x.shape
     # even k yields T+1 positions and BatchNorm sees all of them before the trim to T (module.py:597-598)
-    bank = torch.cat([blk(x, Tout=T, stats_Tout=T + 1 if (i + 1) % 2 == 0 else T)
-                      for i, blk in enumerate(self.conv1d_banks)], dim=-1)
+    # (the K BatchNorms go through ONE autograd function: under SyncBN they share one all-gather and one all-reduce)
+    pre = [AG.conv(x, blk.conv1d.weight, None, pad=blk.padding, Tout=T + 1 if (i + 1) % 2 == 0 else T,
+                   act='relu' if blk.activation is not None else None) for i, blk in enumerate(self.conv1d_banks)]
+    bank = torch.cat([y[:, :T] for y in AG.batch_norm_train_group(pre, [blk.bn for blk in self.conv1d_banks])], dim=-1)
     y = self.conv1d_projs[0](bank, pool_prev=True)
     for blk in self.conv1d_projs[1:]:
         y = blk(y)

@@ -193,6 +193,7 @@ class TtsTrainer(BaseSolver):
     Forward, loss, backward, gradient clipping and Adam all run on the HIP kernels (semi_tts_amd/autograd.py,
     semi_tts_amd/optim.py).  The ASR/CTC half of the reference's step is outside the hot path."""
     GRAD_CLIP = 5.0
+    STATIC_GRAPH = True      # the paired TTS step produces the same gradients in the same order every step (GradReducer: one hook per bucket)
     async_stats = False      # True: train_step never waits for the GPU -- LazyStats, NaN steps skipped on the device (optim.FusedAdam guard)
 
     @staticmethod
@@ -244,7 +245,7 @@ class TtsTrainer(BaseSolver):
         from . import parallel
         self.reducer = None
         if parallel.dist_on():               # more than one rank, or collectives forced in a world of one (bench.py --dist)
-            self.reducer = parallel.GradReducer(self.model.parameters())
+            self.reducer = parallel.GradReducer(self.model.parameters(), static_graph=self.STATIC_GRAPH)
         return self.reducer
 
     def _reduce_gradients(self):
@@ -354,6 +355,7 @@ class VqvaeTrainer(TtsTrainer):
     Everything between the inputs and the gradients runs on the HIP kernels: the CTC speech encoder and its backward
     (asr.py), the codebook lookup with the straight-through estimator (autograd.vq_l2), the run-length merge (autograd.mean_forward),
     the TTS branch, the CTC loss (autograd.ctc_loss)."""
+    STATIC_GRAPH = False     # the cycles' autograd graphs depend on the data (ignore_speech_cycle, skip_prob draws, txt_update_codebook)
 
     def ctc_loss(self, prob, text):
         """compute_ctcloss with paras.actual_len = False (bin/train_vqvae.py:430-444): every frame counts, the targets are the

@@ -187,8 +187,18 @@ g2 = torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.full((p.nume
 both = [torch.empty_like(g2) for _ in range(world)]
 dist.all_gather(both, g2)
 shared = bool(torch.equal(both[0], both[1]) and torch.isfinite(both[0]).all() and both[0].abs().max() > 0)
+# static graph: after the first (recorded) pass only the hook of the parameter that completes each bucket is left
+net4 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+net4.load_state_dict(net.state_dict())
+red4 = GradReducer(net4.parameters(), bucket_bytes=64, average=False, static_graph=True)
+for it in range(3):
+    red4.prepare()
+    (net4(x[lo:hi]).pow(2).sum() / 8.0).backward()
+    n4 = red4.finish()
+err4 = max((a.grad - b.grad).abs().max().item() for a, b in zip(net4.parameters(), ref.parameters()))
+sparse = red4._sparse and len(red4._hooks) == len(red4.buckets) and n4 == len(red4.buckets)
 if rank == 0:
-    print('RESULT', err, n, t, err2, n2, int(unused_none), int(views), int(in_order), int(shared))
+    print('RESULT', err, n, t, err2, n2, int(unused_none), int(views), int(in_order), int(shared), err4, int(sparse))
 dist.destroy_process_group()
 '''
 
@@ -211,6 +221,7 @@ def test_two_process_gradient_allreduce_matches_single_process(tmp_path):
     assert line[6] == '1' and line[7] == '1'                # unused parameters stay None, gradients are views of the buckets
     assert line[8] == '1'                                   # buckets issued in index order although the ranks' graphs differ
     assert line[9] == '1'                                   # a parameter that fired on one rank only: same gradient on both
+    assert float(line[10]) < 1e-5 and line[11] == '1'       # static graph: one hook per bucket after the first pass, same gradients
 
 
 def test_cycle_step_alternates_and_gates_like_the_reference_loop():

@@ -721,12 +721,16 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))            # nothing above this line has touched the GPU
 
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner to stdout when the first
+    # communicator comes up): from here on file descriptor 1 is stderr, and the result line alone goes to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rk = Ranks(args)
     fn = {'c2': bench_decode, 'c5': bench_decode, 'c3': bench_vq, 'train': bench_train}[args.workload]
     res = fn(args, rk)
     if rk.rank == 0:
-        print(json.dumps(res))
-        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + '\n').encode())
     rk.close()
 
 

@@ -140,21 +140,33 @@ class GradReducer:
 
     def __init__(self, params, bucket_bytes=32 << 20, average=True, static_graph=False):
         """static_graph=True (a promise, as DistributedDataParallel's): every backward pass produces gradients for the same parameters
-        in the same order.  The first pass runs with one hook per parameter and records which parameter completes each bucket; from
-        the second pass on only those hooks stay registered -- one Python call per bucket and step instead of one per parameter
-        (144 calls, ~0.4 ms of host time per step for the paired TTS model).  Trainers whose graph depends on the data (the
-        speech / text cycles: `ignore_speech_cycle`, per-rank `skip_prob` draws) must leave it off."""
+        in the same order on every rank.  The first pass runs as usual (one hook per parameter, registration-order buckets) and
+        records the order in which the gradients arrive; the buckets are then REBUILT in that order over the parameters that
+        actually receive gradients -- a bucket becomes ready as early as its position in the backward pass allows (the decoder's
+        weight gradients go out while the encoder's backward still runs; parameters the step never touches, e.g. the speech
+        encoder in the paired TTS step, no longer hold the last bucket back until finish()) -- and only the hook of each bucket's
+        LAST parameter stays registered: one Python call per bucket and step instead of one per parameter (144 calls, ~0.4 ms of
+        host time per step for the paired TTS model).  Trainers whose graph depends on the data (the speech / text cycles:
+        `ignore_speech_cycle`, per-rank `skip_prob` draws) must leave it off."""
         self.params = [p for p in list(params)[::-1] if p.requires_grad]
         self.average = average
+        self.bucket_bytes = int(bucket_bytes)
         self.static_graph = bool(static_graph)
-        self._sparse = False                           # static_graph: True once only the bucket-completing hooks are left
-        self._closer = {}                              # bucket index -> the parameter whose gradient completed it in the recorded pass
+        self._sparse = False                           # static_graph: True once the buckets follow the recorded order
+        self._fire_order = []                          # the recorded pass: parameters in the order their gradients arrived
+        self._hooks = {}
+        self._layout()
+        self._hooks = {p: p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params}
+        self.prepare()
+
+    def _layout(self):
+        """flat buckets over self.params (in that order) + the gradient views' slots"""
         self.buckets, self.flats, self.slot = [], [], {}
         cur, size = [], 0
         for p in self.params:
             cur.append(p)
             size += p.numel() * 4
-            if size >= bucket_bytes:
+            if size >= self.bucket_bytes:
                 self.buckets.append(cur)
                 cur, size = [], 0
         if cur:
@@ -171,8 +183,25 @@ class GradReducer:
                 self.slot[p] = (bi, off)
                 off += p.numel()
         self.flags = self.flats[-1][self.flats[-1].numel() - len(self.params):] if self.flats else None
-        self._hooks = {p: p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params}
-        self.prepare()
+
+    def _rebuild_static(self):
+        """after the recorded pass (its gradients are reduced and averaged in the OLD buckets): new buckets in arrival order over
+        the parameters that fired, this step's gradients carried over, one hook per bucket"""
+        old_view = {p: self._view(p) for p in self._fire_order}
+        dropped = [p for p in self.params if p not in old_view]
+        for h in self._hooks.values():
+            h.remove()
+        self.params = list(self._fire_order)
+        self._layout()
+        for p in self.params:
+            v = self._view(p)
+            v.copy_(old_view[p])
+            p.grad = v
+        for p in dropped:
+            p.grad = None                              # never touched by this (static) step: the optimiser skips it on every rank
+        closers = [bucket[-1] for bucket in self.buckets]
+        self._hooks = {p: p.register_post_accumulate_grad_hook(self._on_grad) for p in closers}
+        self._sparse = True
 
     def _view(self, p):
         bi, off = self.slot[p]
@@ -186,6 +215,7 @@ class GradReducer:
             p.grad = self._view(p)
         self.count = [0] * len(self.buckets)
         self.fired = set()
+        self._fire_order = []
         self.works = [None] * len(self.buckets)
         self.ready = [False] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
@@ -205,11 +235,12 @@ class GradReducer:
             self._view(p).copy_(p.grad)
             p.grad = self._view(p)
         self.fired.add(p)
+        if self.static_graph:
+            self._fire_order.append(p)
         bi = self.slot[p][0]
         self.count[bi] += 1
         if self.count[bi] == len(self.buckets[bi]):
             self.ready[bi] = True
-            self._closer[bi] = p
             self._launch_ready()
 
     def _launch_ready(self, everything=False):
@@ -248,14 +279,6 @@ class GradReducer:
         for w in self.works:
             if w is not None:
                 w.wait()
-        if self.static_graph and not self._sparse and len(self.fired) == len(self.params) and len(self._closer) == len(self.buckets):
-            # the recorded pass was regular: keep one hook per bucket, on the parameter that completed it
-            keep = set(self._closer.values())
-            for p, h in list(self._hooks.items()):
-                if p not in keep:
-                    h.remove()
-                    del self._hooks[p]
-            self._sparse = True
         if not self._sparse and len(self.fired) < len(self.params):
             # only now, and only in the irregular case, the flags are read back (one small device -> host copy)
             anywhere = self.flags.detach().cpu().tolist() if reduced else None
@@ -266,7 +289,10 @@ class GradReducer:
             n_flags = len(self.params)
             for bi, flat in enumerate(self.flats):
                 (flat[:flat.numel() - n_flags] if bi == len(self.flats) - 1 else flat).mul_(1.0 / world)
-        return sum(1 for l in self.launched if l)
+        issued = sum(1 for l in self.launched if l)
+        if self.static_graph and not self._sparse and self._fire_order:
+            self._rebuild_static()
+        return issued
 
     def close(self):
         for h in self._hooks.values():

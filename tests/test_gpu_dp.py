@@ -51,7 +51,7 @@ def _worker(rank, world, port, out_path, cut=2):
     loss = _step(m, A, rows, dev, weight=n_r * world / 4.0)                         # issued from autograd hooks during backward
     n_coll = red.finish()
     assert n_coll > 1
-    assert parallel.collective_counts()['syncbn_fwd'] == 13 and parallel.collective_counts()['syncbn_bwd'] == 13   # one each per BN layer
+    assert parallel.collective_counts()['syncbn_fwd'] == 6 and parallel.collective_counts()['syncbn_bwd'] == 6   # one each per BN layer; the 8 layers of the conv bank share theirs
     if rank == 0:
         torch.save({'loss': loss, 'grads': {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None},
                     'stats': {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}}, out_path)

@@ -51,6 +51,7 @@ __device__ __forceinline__ void cell(const u64* __restrict__ xin, u64* __restric
             u64 g0, g1, g2, g3;
             int spins = 0;
             while (true) {
+                asm volatile("" ::: "memory");           // (a plain buffer load is loop-invariant to the compiler: without this the poll is hoisted)
                 const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 32, soff, 16));
                 const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 32 + 16, soff, 16));
                 g0 = ((u64)__float_as_uint(lo[1]) << 32) | __float_as_uint(lo[0]); g1 = ((u64)__float_as_uint(lo[3]) << 32) | __float_as_uint(lo[2]);

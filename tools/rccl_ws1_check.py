@@ -105,7 +105,7 @@ def main():
           and res['reducer_only']['updated_weights_bitwise_equal']
           and red['st']['loss'] == plain['st']['loss'] and red['st']['grad_norm'] == plain['st']['grad_norm']
           and res['reducer_only']['collectives_per_step']['grad_buckets'] == 4
-          and res['reducer_syncbn']['collectives_per_step'] == {'grad_buckets': 4, 'syncbn_fwd': 13, 'syncbn_bwd': 13,
+          and res['reducer_syncbn']['collectives_per_step'] == {'grad_buckets': 4, 'syncbn_fwd': 6, 'syncbn_bwd': 6,
                                                                 'async_grad_buckets': 4 if a.backend == 'nccl' else 0}
           and res['reducer_syncbn']['loss_abs_diff'] <= 1e-6 * max(1.0, abs(plain['st']['loss']))
           and res['reducer_syncbn']['running_stats_max_rel_diff'] <= 1e-6

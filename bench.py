@@ -459,7 +459,9 @@ def bench_decode(args, rk):
     mel = state['out'][0]
     assert args.no_finite_check or bool(torch.isfinite(mel).all()), 'non-finite mel output'
     if not args.no_finite_check:
-        gd.check()                                      # no in-launch hand-off of the timed replays timed out
+        # a starved in-launch hand-off makes a replay NaN (GraphedDecoder.check() would recover, but a timed region with such a replay
+        # in it is not a measurement)
+        assert not ops.handoff_starved(dec.handoff_status), 'a timed replay was starved of compute units (shared GPU?)' 
     if rk.rank != 0:
         return None
 

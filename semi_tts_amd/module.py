@@ -616,8 +616,16 @@ class Decoder(nn.Module):
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
         if io.handoff_status and self.check_handoff and not ops.capturing():
-            ops.check_handoff(self.handoff_status)
-            ops.check_persist_status(dev)           # (the text encoder's one-launch BiLSTM ran before this loop)
+            if ops.handoff_starved(self.handoff_status):
+                # the fin workgroups ran without their producers (a shared / CU-masked GPU): the pass is NaN.  Run it again as two
+                # launches per hand-off -- same tapes (every slot is rewritten, the initial slots are re-zeroed by the loop's first
+                # launch), same masks -- and keep that form for the rest of the process
+                ops.degrade('decode loop (query projection -> attention hand-off)', 'one launch each (attn_pq_in_fin = False)')
+                self.attn_pq_in_fin = False
+                io.pq_granules, io.handoff_status, io.attn_xchg = None, None, None
+                check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_forward')
+        if not keep_tapes and self.check_handoff and not ops.capturing():
+            ops.check_persist_status(dev)           # (the text encoder's one-launch BiLSTM ran before this loop: Tacotron2.forward falls back)
         if defer:
             kb = ops.kb16
             Bp = ((B + 15) // 16) * 16

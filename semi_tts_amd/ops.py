@@ -29,6 +29,34 @@ def capturing():
     return _stream_override is not None
 
 
+class Starved(RuntimeError):
+    """a launch whose workgroups hand data to each other was scheduled without all of them resident (a shared or CU-masked GPU):
+    its outputs are NaN.  Callers that can, fall back to the multi-launch form and run again (degrade())."""
+
+
+_DEGRADED = set()
+
+
+def degrade(what, detail):
+    """log -- once per kind -- that an in-launch hand-off was starved and its multi-launch form takes over for the rest of the process"""
+    if what not in _DEGRADED:
+        _DEGRADED.add(what)
+        import warnings
+        warnings.warn('semi_tts_amd: %s: the launch was starved of compute units (another tenant or a CU mask on this GPU); falling back '
+                      'to %s for the rest of this process' % (what, detail), RuntimeWarning, stacklevel=3)
+
+
+def handoff_starved(status):
+    """True (and the word cleared) if an in-launch hand-off of the decode loop timed out since the word was last cleared.  Reads one
+    device word (synchronises)."""
+    if status is None:
+        return False
+    v = int(status.item())
+    if v != 0:
+        status.zero_()
+    return v != 0
+
+
 def check_handoff(status):
     """Raise if an in-launch hand-off of the decode loop timed out since the word was last cleared (st_decoder_io.handoff_status):
     the waiting workgroups were not co-resident with their producers -- the outputs of that forward are poisoned with NaN.
@@ -38,7 +66,7 @@ def check_handoff(status):
     v = int(status.item())
     if v != 0:
         status.zero_()
-        raise RuntimeError('decode loop: an in-launch hand-off of the processed query timed out (status word 0x%x): the launch was '
+        raise Starved('decode loop: an in-launch hand-off of the processed query timed out (status word 0x%x): the launch was '
                            'starved of compute units; the outputs of this forward are invalid.  Set decoder.attn_pq_in_fin = False '
                            'to run the query projection and the attention as two launches.' % v)
 
@@ -489,6 +517,19 @@ def persist_status(device):
     return t
 
 
+def persist_starved(device=None):
+    """True (and the word cleared) if a one-launch recurrent layer gave up waiting for its neighbour workgroups since the last check.
+    Reads one device word per device (synchronises)."""
+    hit = False
+    for key, t in list(_PERSIST_STATUS.items()):
+        if device is not None and key != _dev_index(device):
+            continue
+        if int(t.item()):
+            t.zero_()
+            hit = True
+    return hit
+
+
 def check_persist_status(device=None):
     """Raise if a one-launch recurrent layer gave up waiting for its neighbour workgroups since the last check (the launch was starved
     of compute units; the rows it produced are NaN).  Reads one device word per device (synchronises) and clears it."""
@@ -498,7 +539,7 @@ def check_persist_status(device=None):
         v = int(t.item())
         if v:
             t.zero_()
-            raise RuntimeError('one-launch LSTM layer: a wait for the hidden state timed out (status word 0x%x): the launch was starved '
+            raise Starved('one-launch LSTM layer: a wait for the hidden state timed out (status word 0x%x): the launch was starved '
                                'of compute units and its outputs are NaN.  Set semi_tts_amd.ops.LSTM_PERSIST = False to run the layer '
                                'as one launch per time step.' % v)
 

@@ -33,9 +33,17 @@ class GraphedDecoder:
         self.debug = os.environ.get('ST_CHECK_HANDOFF') == '1'    # read the hand-off status word back after every replay
 
     def check(self):
-        """raise if any replay since the last check had a starved in-launch hand-off (one device word, synchronises)"""
-        ops.check_handoff(self.decoder.handoff_status)
-        ops.check_persist_status()
+        """Did any replay since the last check have a starved in-launch hand-off (one device word, synchronises)?  If so the outputs
+        of those replays are NaN: the loop is captured AGAIN in its two-launch form (kept for the rest of the process) and the
+        last call replayed from the static input buffers with the same masks.  Returns the (possibly new) output tensors -- use
+        them, not views taken before the check."""
+        if ops.handoff_starved(self.decoder.handoff_status):
+            ops.degrade('decode loop (query projection -> attention hand-off)', 'one launch each (attn_pq_in_fin = False)')
+            self.decoder.attn_pq_in_fin = False
+            self.capture()
+            self.graph.launch()
+            torch.cuda.synchronize()
+        return self.outputs
 
     def _run(self):
         masks = {'own': self.own_mask} if self.own_mask is not None else None
@@ -83,7 +91,7 @@ class GraphedDecoder:
             self.draw_masks()
         self.graph.launch()
         if self.debug:
-            self.check()
+            return self.check()
         return self.outputs
 
 
@@ -132,10 +140,21 @@ class GraphedTacotron2:
             self.own_mask.bernoulli_(1.0 - self.p).div_(1.0 - self.p)
 
     def check(self):
-        """raise if any replay since the last check had a starved in-launch hand-off (decode loop) or a starved one-launch LSTM layer
-        (text encoder); reads device words (synchronises)"""
-        ops.check_handoff(self.model.decoder.handoff_status)
-        ops.check_persist_status()
+        """as GraphedDecoder.check, for the decode loop's hand-off AND the text encoder's one-launch BiLSTM: a starved launch means
+        NaN outputs; the forward is captured again in the multi-launch form(s) and the last call replayed.  Returns the outputs."""
+        bad_h = ops.handoff_starved(self.model.decoder.handoff_status)
+        bad_p = ops.persist_starved()
+        if bad_h:
+            ops.degrade('decode loop (query projection -> attention hand-off)', 'one launch each (attn_pq_in_fin = False)')
+            self.model.decoder.attn_pq_in_fin = False
+        if bad_p:
+            ops.degrade('one-launch BiLSTM layer', 'one launch per time step (ops.LSTM_PERSIST = False)')
+            ops.LSTM_PERSIST = False
+        if bad_h or bad_p:
+            self.capture()
+            self.graph.launch()
+            torch.cuda.synchronize()
+        return self.outputs
 
     def __call__(self, txt_embed=None, spkr_embed=None, redraw=True):
         if self.graph is None:
@@ -190,8 +209,16 @@ class GraphedSpeechToText:
         return self
 
     def check(self):
-        """raise if a one-launch LSTM layer of any replay since the last check was starved of compute units (synchronises)"""
-        ops.check_persist_status()
+        """a one-launch LSTM layer of a replay since the last check starved of compute units (synchronises)?  Then the graph is
+        captured again with one launch per time step and replayed on the inputs still in the static buffer; returns True if so"""
+        if not ops.persist_starved():
+            return False
+        ops.degrade('one-launch BiLSTM layer', 'one launch per time step (ops.LSTM_PERSIST = False)')
+        ops.LSTM_PERSIST = False
+        self.capture()
+        self.graph.launch()
+        torch.cuda.synchronize()
+        return True
 
     def __call__(self, paired_mel=None, unpaired_mel=None):
         """-> the tuple VQVAE.speech_to_text returns (views of buffers the next call overwrites)"""

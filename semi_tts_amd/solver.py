@@ -300,9 +300,14 @@ class TtsTrainer(BaseSolver):
     STATS_WINDOW = 64        # async_stats: steps whose statistics may stay unread on the device
 
     def check_device_status(self):
-        """raise if a kernel of the training step reported starvation since the last check (the one-launch BiLSTM's status word):
-        such a forward is NaN and the guarded Adam skips its update -- an error, not a run of silently skipped steps"""
-        ops.check_persist_status(self.device)
+        """a kernel of the training step reported starvation since the last check (the one-launch BiLSTM's status word)?  Such a
+        forward is NaN and the guarded Adam skips its update: the layer runs as one launch per time step from now on -- one skipped
+        step, not a run of silently skipped ones.  Returns True if it fell back."""
+        if ops.persist_starved(self.device):
+            ops.degrade('one-launch BiLSTM layer', 'one launch per time step (ops.LSTM_PERSIST = False)')
+            ops.LSTM_PERSIST = False
+            return True
+        return False
 
     def _skipped_on_device(self, st):
         """a step whose gradient norm turned out non-finite (read late, async_stats): the device skipped that update"""
@@ -391,7 +396,7 @@ class VqvaeTrainer(TtsTrainer):
         if gn == gn:
             self.optimizer.step()
         else:
-            ops.check_persist_status(self.device)        # a starved one-launch LSTM layer is an error, not a skipped step
+            self.check_device_status()                   # (a starved one-launch LSTM layer: per-step form from the next step on)
             self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
         self.step += 1
         stats.update(loss=float(total.detach()), grad_norm=gn, tf_rate=tf_rate)

@@ -1,6 +1,7 @@
 """Tacotron2 wrapper (encoder -> decoder -> CBHG mel->linear postnet) on the HIP path.
 Mirror of the reference's src/tts.py:9-51: same constructor, forward signature and
 state_dict keys (`encoder.*`, `decoder.*`, `postnet.0.*`, `postnet.1.*`)."""
+import torch
 import torch.nn as nn
 
 from . import ops
@@ -39,9 +40,20 @@ class Tacotron2(nn.Module):
     def forward(self, txt_embed, txt_lengths, teacher, spkr_embed, tf_rate=0.0, unpair_max_frame=None, _masks=None):
         """txt_embed (B,L,in_embed_dim); teacher: int (max frames, inference) or (B',T,n_mels);
         returns (mel_pred, linear_pred, alignment, stop)                          ref: src/tts.py:36-51"""
-        enc_output = self.encoder(txt_embed, txt_lengths, _masks=_masks.get('enc') if _masks else None)
-        mel_pred, alignment, stop = self.decoder(enc_output, txt_lengths, teacher, spkr_embed, tf_rate=tf_rate,
-                                                 unpair_max_frame=unpair_max_frame, _masks=_masks)
+        from . import ops
+        for attempt in (0, 1):
+            enc_output = self.encoder(txt_embed, txt_lengths, _masks=_masks.get('enc') if _masks else None)
+            try:
+                mel_pred, alignment, stop = self.decoder(enc_output, txt_lengths, teacher, spkr_embed, tf_rate=tf_rate,
+                                                         unpair_max_frame=unpair_max_frame, _masks=_masks)
+                break
+            except ops.Starved:
+                # the text encoder's one-launch BiLSTM was starved of compute units (its status word is read after the decode loop of
+                # an eager inference pass): the encoder output is NaN.  One launch per time step from now on, and the pass again.
+                if attempt or not ops.LSTM_PERSIST or torch.is_grad_enabled():
+                    raise
+                ops.degrade('one-launch BiLSTM layer', 'one launch per time step (ops.LSTM_PERSIST = False)')
+                ops.LSTM_PERSIST = False
         linear_pred = None
         if self.postnet is not None:
             # separate_postnet only cuts the gradient (mel_pred.detach()); forward values are identical

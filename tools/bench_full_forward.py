@@ -40,7 +40,8 @@ gt = GraphedTacotron2(m, B, L, T, dev)
 gt.txt.copy_(txt); gt.spkr.copy_(spk)
 gt.capture()
 t_graph, gout = timed(lambda: gt(redraw=True))
-gt.check()                                         # no starved hand-off / one-launch layer in the timed replays
+from semi_tts_amd import ops as _ops               # no starved hand-off / one-launch layer in the timed replays
+assert not _ops.handoff_starved(m.decoder.handoff_status) and not _ops.persist_starved(), 'a timed replay was starved of compute units' 
 assert bool(torch.isfinite(gout[0]).all()) and bool(torch.isfinite(gout[1]).all())
 # roofline of the whole forward: SURVEY 8d counts 132 GFLOP per C2 batch (encoder 12.4 + decoder 106.3 + postnet 13.7, dense
 # contractions on the fp32 matrix cores) and, per decode step, 81.0 MB of operands that must stream (weights re-read every step)

@@ -425,6 +425,10 @@ int st_bn_bwd_apply_sync(const float* dy, int ldd, int doff, const float* y, int
 int st_highway_fwd(const float* H, const float* Tgate, const float* x, float* y, size_t total, void* stream);
 int st_highway_bwd(const float* dy, const float* H, const float* x, const float* Tgate,
                    float* dH, float* dT, float* dx_direct, size_t total, void* stream);
+/* y(b,t,:) = max(x(b,t-1,:), x(b,t,:)), y(b,0,:) = x(b,0,:): nn.MaxPool1d(2, stride=1, padding=1)(x)[:, :, :T] of the CBHG,
+ * src/module.py:600, on contiguous channels-last (Bn, T, C) tensors, C % 4 == 0 (the input of the LDS-DMA conv kernel; the
+ * register-staged kernel fuses the same maximum into its loads: pool_prev of st_gemm_fwd) */
+int st_pool_prev_fwd(const float* x, float* y, int Bn, int T, int C, void* stream);
 /* backward of the fused MaxPool1d(2,1,1)[:T]: dx(b,t,c) from the gradient w.r.t. the pooled tensor */
 int st_pool_prev_bwd(const float* dy_pooled, const float* x, float* dx, int Bn, int T, int C, void* stream);
 /* dst(b,t,:) (+)= src(b,t,:) with arbitrary (b,t) strides (elements) */

@@ -256,6 +256,7 @@ SIGNATURES = {
     'st_bn_bwd_apply_sync': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, P, P, I, I, P],
     'st_highway_fwd': [P, P, P, P, Z, P],
     'st_highway_bwd': [P, P, P, P, P, P, P, Z, P],
+    'st_pool_prev_fwd': [P, P, I, I, I, P],
     'st_pool_prev_bwd': [P, P, P, I, I, I, P],
     'st_copy3d': [P, C.c_long, C.c_long, P, C.c_long, C.c_long, I, I, I, I, P],
     'st_scatter_add_rows': [P, P, P, I, I, I, P],

@@ -86,26 +86,32 @@ __device__ __forceinline__ void gm_epilogue(const GmArgs& g, const f32x4 (&acc)[
     gm_epilogue_tiles<MT, 2>(g, acc, m0 + wm * (16 * MT), n0 + wn * 32, lane);
 }
 
-// split-K finish: C = epilogue(sum_z slab_z), slabs added in a fixed order (deterministic); one thread per output element,
-// consecutive threads = consecutive columns
-template <bool VEC4>
-__global__ __launch_bounds__(256) void gm_splitk_finish_kernel(const GmArgs g, int S) {
+// split-K finish: C = epilogue(sum_z slab_z), slabs added in a fixed order (deterministic); one thread per output element (VEC4: per
+// four), consecutive threads = consecutive columns.  SS = compile-time slab count (0: run-time): all slab loads of a thread are
+// requested before the first add (with a run-time loop the adds serialise the round trips: 8.0 us per call in the r04 forward trace
+// for 4 slabs of 2.8 MB)
+template <bool VEC4, int SS>
+__global__ __launch_bounds__(256) void gm_splitk_finish_kernel(const GmArgs g, int Srt) {
     constexpr int W = VEC4 ? 4 : 1;                       // columns per thread (VEC4: N % 4 == 0, 16-byte slab loads)
+    const int S = SS > 0 ? SS : Srt;
     const size_t total = (size_t)g.M * g.N, items = total / W;
     const st_gemm_epilogue& ep = g.ep;
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
         const size_t i = it * W;
         const int m = (int)(i / g.N), n0 = (int)(i - (size_t)m * g.N);
         float v[W];
-        if (VEC4) {
-            f32x4 s0 = st_ld4(g.split_ws + i), s1 = {0.f, 0.f, 0.f, 0.f};
-            int z = 1;
-            for (; z + 2 <= S; z += 2) {      // two slab loads in flight; the slabs are still added in the order 0, 1, 2, ...
-                const f32x4 a = st_ld4(g.split_ws + (size_t)z * total + i), b = st_ld4(g.split_ws + (size_t)(z + 1) * total + i);
-                s0 = (s0 + a) + b;
-            }
-            if (z < S) s1 = st_ld4(g.split_ws + (size_t)z * total + i);
-            s0 = s0 + s1;
+        if (VEC4 && SS > 0) {
+            f32x4 sl[SS > 0 ? SS : 1];
+#pragma unroll
+            for (int z = 0; z < SS; ++z) sl[z] = st_ld4(g.split_ws + (size_t)z * total + i);
+            f32x4 s0 = sl[0];
+#pragma unroll
+            for (int z = 1; z < SS; ++z) s0 = s0 + sl[z];          // slab order 0, 1, 2, ...
+#pragma unroll
+            for (int c = 0; c < W; ++c) v[c] = s0[c];
+        } else if (VEC4) {
+            f32x4 s0 = st_ld4(g.split_ws + i);
+            for (int z = 1; z < S; ++z) s0 = s0 + st_ld4(g.split_ws + (size_t)z * total + i);
 #pragma unroll
             for (int c = 0; c < W; ++c) v[c] = s0[c];
         } else {
@@ -606,7 +612,10 @@ __global__ __launch_bounds__(256) void highway_stack_kernel(const HwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float hw_lds[];
     const int C = a.C, LD = C + 4, C4 = C >> 2;          // LD: rows 16 apart in the b128 reads fall on distinct 16-byte slots (C % 16 == 0)
     float* xs[2] = {hw_lds, hw_lds + HW_ROWS * LD};
-    float* ws[2] = {hw_lds + 2 * HW_ROWS * LD, hw_lds + 2 * HW_ROWS * LD + 2 * C * LD};
+    // ONE weight buffer (round 4): with two, a workgroup took 129 KB of LDS -- one per compute unit, and the 258 workgroups of the C2
+    // postnet (8256 rows / 32) needed a second round for their last two: 50 us in the forward trace.  75 KB lets two reside; the
+    // next layer's weights wait in registers (requested before the layer's MFMAs) and are written after an extra barrier.
+    float* wsb = hw_lds + 2 * HW_ROWS * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * HW_ROWS;
     const int nw4 = 2 * C * C4;                          // float4 pieces of one layer's [W_H ; W_T]
@@ -636,14 +645,14 @@ __global__ __launch_bounds__(256) void highway_stack_kernel(const HwArgs a) {
         if (m0 + r < a.M) v = st_ld4(a.x + (size_t)(m0 + r) * a.ldx + 4 * c4);
         *reinterpret_cast<f32x4*>(xs[0] + r * LD + 4 * c4) = v;
     }
-    commit_w(ws[0]);
+    commit_w(wsb);
     __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
     const int ntile = C >> 4, nunits = 2 * ntile;
     for (int l = 0; l < a.NL; ++l) {
         const float* xc = xs[l & 1];
         float* xn = xs[(l + 1) & 1];
-        const float* wc = ws[l & 1];
+        const float* wc = wsb;
         if (l + 1 < a.NL) request_w(l + 1);              // in flight while this layer is multiplied
         for (int u = wave; u < nunits; u += 4) {
             const int rt = u / ntile, j = u - rt * ntile;
@@ -672,7 +681,10 @@ __global__ __launch_bounds__(256) void highway_stack_kernel(const HwArgs a) {
                 xn[m * LD + n] = st_highway(hh, tt, xx);
             }
         }
-        if (l + 1 < a.NL) commit_w(ws[(l + 1) & 1]);      // (nobody reads that buffer: its readers passed the barrier of layer l - 1)
+        if (l + 1 < a.NL) {
+            st_lds_barrier();                            // every wave has read this layer's weights
+            commit_w(wsb);
+        }
         __syncthreads();
     }
     const float* xf = xs[a.NL & 1];
@@ -975,8 +987,11 @@ extern "C" int st_gemm_fwd(const float* A, int lda, const float* W, float* C, in
         const size_t items = (size_t)g.M * N / (vec4 ? 4 : 1);
         size_t blocks = (items + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        if (vec4) hipLaunchKernelGGL((gm_splitk_finish_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, g, S);
-        else hipLaunchKernelGGL((gm_splitk_finish_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, g, S);
+#define GM_FIN(SS) hipLaunchKernelGGL((gm_splitk_finish_kernel<true, SS>), dim3((unsigned)blocks), dim3(256), 0, st, g, S)
+        if (vec4) switch (S) { case 2: GM_FIN(2); break; case 3: GM_FIN(3); break; case 4: GM_FIN(4); break; case 5: GM_FIN(5); break;
+                               case 6: GM_FIN(6); break; case 7: GM_FIN(7); break; case 8: GM_FIN(8); break; default: GM_FIN(0); }
+        else hipLaunchKernelGGL((gm_splitk_finish_kernel<false, 0>), dim3((unsigned)blocks), dim3(256), 0, st, g, S);
+#undef GM_FIN
         ST_LAUNCH_CHECK();
     }
     return 0;
@@ -1045,7 +1060,7 @@ extern "C" int st_highway_stack_fwd(const float* x, int ldx, const float* const*
         a.wh[l] = w_h[l]; a.wt[l] = w_t[l]; a.bh[l] = b_h ? b_h[l] : nullptr; a.bt[l] = b_t ? b_t[l] : nullptr;
     }
     const int LD = C + 4;
-    const size_t lds = (size_t)(2 * HW_ROWS * LD + 2 * 2 * C * LD) * sizeof(float);
+    const size_t lds = (size_t)(2 * HW_ROWS * LD + 2 * C * LD) * sizeof(float);
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(highway_stack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

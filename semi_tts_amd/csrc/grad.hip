@@ -444,6 +444,22 @@ __global__ __launch_bounds__(256) void highway_bwd_kernel(const float* dy, const
     }
 }
 
+// x'[b][t][:] = max(x[b][t-1][:], x[b][t][:]), t = 0 keeps x[b][0]: MaxPool1d(2, stride 1, padding 1)[:T] of the CBHG (src/module.py:600)
+// as a tensor of its own -- the input of the LDS-DMA conv kernel, which cannot take a maximum on the way into LDS (21 MB each way at
+// C2: ~10 us; the register-staged kernel with the pool fused into its loads took 84 us for the 640 -> 128 conv, the DMA kernel 52)
+__global__ __launch_bounds__(256) void pool_prev_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int T, int C4, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / C4;
+        const int t = (int)(row % T);
+        f32x4 v = st_ld4(x + 4 * i);
+        if (t > 0) {
+            const f32x4 q = st_ld4(x + 4 * (i - C4));
+            v = f32x4{fmaxf(v[0], q[0]), fmaxf(v[1], q[1]), fmaxf(v[2], q[2]), fmaxf(v[3], q[3])};
+        }
+        *reinterpret_cast<f32x4*>(y + 4 * i) = v;
+    }
+}
+
 // backward of x'[t] = max(x[t-1], x[t]) within an utterance (t = 0 keeps x[0]).  torch's MaxPool1d scans the
 // window left to right and keeps the FIRST maximum, so on a tie x[t-1] receives the gradient of output t.
 __global__ __launch_bounds__(256) void pool_prev_bwd_kernel(const float* dyp, const float* x, float* dx, int Bn, int T, int C) {
@@ -754,6 +770,17 @@ extern "C" int st_highway_bwd(const float* dy, const float* H, const float* x, c
     ST_CHECK_ARG(dy && H && x && Tgate && dH && dT && dx_direct && total > 0, "st_highway_bwd: bad arguments");
     hipLaunchKernelGGL(highway_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        dy, H, x, Tgate, dH, dT, dx_direct, total);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_pool_prev_fwd(const float* x, float* y, int Bn, int T, int C, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(x && y && Bn > 0 && T > 0 && C > 0 && C % 4 == 0 && st_aligned16(x) && st_aligned16(y), "st_pool_prev_fwd: bad arguments (C %% 4 == 0, 16-byte aligned)");
+    const size_t total4 = (size_t)Bn * T * C / 4;
+    size_t blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pool_prev_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, T, C / 4, total4);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -364,6 +364,13 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=
     elif KT > 1 and Cin % 4 == 0 and Cin >= 16:
         w = _tap_major(w)
         ep.w_tap_major = 1
+    if pool_prev and ep.w_tap_major and a.dim() == 3 and a.is_contiguous() and stride == 1 and a.data_ptr() % 16 == 0 and \
+            (Bn, Tin) == (a.shape[0], a.shape[1]):
+        # the LDS-DMA kernel cannot take a maximum on the way into LDS: the pooled input becomes a tensor of its own (one elementwise
+        # launch, ~10 us for the CBHG's (32, 258, 640) bank output) and the conv runs on the fast kernel (52 against 84 us)
+        pooled = torch.empty_like(a)
+        check(lib.st_pool_prev_fwd(_p(a), _p(pooled), int(a.shape[0]), int(a.shape[1]), int(Cin), stream_handle()), 'st_pool_prev_fwd')
+        a, pool_prev = pooled, False
     slabs = int(lib.st_gemm_splitk_slabs(int(Bn), int(Tout), int(Cin), int(N), int(KT)))
     ws = None
     if slabs > 1:         # small grid, long reduction: partial products per k range + a finish pass (st_gemm_epilogue.splitk_ws)

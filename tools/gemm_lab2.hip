@@ -227,6 +227,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void g3_kernel(const G2Args g) {
     constexpr int RPP = NTH / 8;
     constexpr int LA = BM / RPP, LB = BN / RPP;
     constexpr int BUF = (BM + BN) * 32;           // floats per buffer
+    constexpr int NBUF = (OPT & 4) ? 4 : 3;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "geometry");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -345,20 +346,40 @@ __global__ __launch_bounds__(64 * NWM * NWN) void g3_kernel(const G2Args g) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
         }
     };
-    // chunk c lives in buffer c % 3; the requests of chunk c + 2 go out right after the barrier of iteration c (every wave has left
-    // compute(c - 1), whose buffer they overwrite); at the top of iteration c only chunk c + 1 may still be in flight
-    issue(0);
-    issue(1);
-    int bi = 0, bn = 2;
+    auto compute_half = [&](int bufi, int h) __attribute__((always_inline)) {
+        const float* ab = lds + bufi * BUF;
+        const float* bb = ab + BM * 32;
+        f32x4 a4[MT], b4[NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) { const int L = wm * 16 * MT + t * 16 + fr; a4[t] = *reinterpret_cast<const f32x4*>(ab + L * 32 + (((h * 4 + fq) ^ (L & 7)) * 4)); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { const int L = wn * 16 * NT + t * 16 + fr; b4[t] = *reinterpret_cast<const f32x4*>(bb + L * 32 + (((h * 4 + fq) ^ (L & 7)) * 4)); }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][cc], b4[nt][cc], acc[mt][nt], 0, 0, 0);
+    };
+    // chunk c lives in buffer c % NBUF; the requests of chunk c + NBUF - 1 go out after the barrier of iteration c (every wave has left
+    // compute(c - 1), whose buffer they overwrite); at the top of iteration c chunks c + 1 .. c + NBUF - 2 may still be in flight
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) issue(i);
+    int bi = 0, bn = NBUF - 1;
     for (int c = 0; c < n_my; ++c) {
-        if (ABL != 1) {
-            if (c + 1 < n_my + 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LA + LB) : "memory");      // (chunk c + 1 stays in flight)
-        }
+        if (ABL != 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * (LA + LB)) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        issue(bn);
-        compute(bi);
-        bi = bi == 2 ? 0 : bi + 1;
-        bn = bn == 2 ? 0 : bn + 1;
+        if (OPT & 8) {            // requests between the chunk's two MFMA halves: their address arithmetic issues in the MFMAs' shadow
+            compute_half(bi, 0);
+            issue(bn);
+            compute_half(bi, 1);
+        } else {
+            issue(bn);
+            compute(bi);
+        }
+        bi = bi == NBUF - 1 ? 0 : bi + 1;
+        bn = bn == NBUF - 1 ? 0 : bn + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* out = g.chunks_per_split > 0 ? g.ws + (size_t)blockIdx.z * g.M * g.N : g.C;
@@ -483,7 +504,8 @@ static void run3(const Shape& s, G2Args g, int S, Best& best, bool verbose) {
         const int T = grid.x * grid.y, per = (T + 7) / 8;
         while ((int)(grid.x * grid.y) < 8 * per) ++grid.y;
     }
-    const size_t lds = (size_t)3 * (BM + BN) * 32 * 4;
+    const size_t lds = (size_t)((OPT & 4) ? 4 : 3) * (BM + BN) * 32 * 4;
+    if (lds > 160 * 1024) return;
     static bool set = false;
     if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(g3_kernel<BM, BN, NWM, NWN, ABL, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
     g.chunks_per_split = S > 1 ? (nch + S - 1) / S : 0;
@@ -498,7 +520,7 @@ static void run3(const Shape& s, G2Args g, int S, Best& best, bool verbose) {
     const double tf = 2.0 * g.M * g.N * g.K / us / 1e6;
     const double err = check((size_t)g.M * g.N);
     char what[96];
-    snprintf(what, sizeof what, "g3%s%s %dx%d w%dx%d S=%d wgs=%d%s", OPT & 1 ? "x" : "", OPT & 2 ? "f" : "", BM, BN, NWM, NWN, S, (int)(grid.x * grid.y * S),
+    snprintf(what, sizeof what, "g3%s%s%s%s %dx%d w%dx%d S=%d wgs=%d%s", OPT & 1 ? "x" : "", OPT & 2 ? "f" : "", OPT & 4 ? "4" : "", OPT & 8 ? "i" : "", BM, BN, NWM, NWN, S, (int)(grid.x * grid.y * S),
              ABL == 1 ? " -loads" : ABL == 4 ? " -mfma" : "");
     if (verbose || err > 1e-4 || ABL) printf("    %-34s %8.2f us  %6.1f TF  frac %.3f  err %.1e\n", what, us, tf, tf / 157.3, err);
     if (ABL == 0 && err <= 1e-4 && us < best.us) { best.us = us; snprintf(best.what, sizeof best.what, "%s", what); }
@@ -525,9 +547,17 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dP, maxC * 4 * 8)); CK(hipMalloc(&dBias, 4096 * 4));
     std::vector<float> h(std::max(std::max(maxA, maxW), (size_t)4096));
     srand(1);
-    for (float& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    // LAB_RANDN=1: unit normal data as the library's benchmarks use (more bit toggling than U(-0.5, 0.5): the clock the chip sustains
+    // under MFMA load depends on it)
+    const bool randn = getenv("LAB_RANDN") != nullptr;
+    auto draw = [&]() -> float {
+        if (!randn) return (float)rand() / RAND_MAX - 0.5f;
+        const float u1 = ((float)rand() + 1.0f) / ((float)RAND_MAX + 2.0f), u2 = (float)rand() / RAND_MAX;
+        return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+    };
+    for (float& v : h) v = draw();
     CK(hipMemcpy(dA, h.data(), maxA * 4, hipMemcpyHostToDevice));
-    for (float& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    for (float& v : h) v = draw();
     CK(hipMemcpy(dW, h.data(), maxW * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dBias, h.data(), 4096 * 4, hipMemcpyHostToDevice));
     hC.resize(maxC); hR.resize(maxC);
@@ -541,6 +571,24 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(naive_kernel, dim3((g.N + 255) / 256, g.M), dim3(256), 0, 0, gr);
         CK(hipMemcpy(hR.data(), dR, (size_t)g.M * g.N * 4, hipMemcpyDeviceToHost));
         Best best;
+        if (argc > 1 && argv[1][0] == 'q') {      // profiler run: the library's configuration of the first shape only
+            if (&s != &shapes[0]) continue;
+            run3<64, 64, 2, 2, 0, 2>(s, g, 4, best, true);
+            continue;
+        }
+        if (argc > 1 && argv[1][0] == 'b') {      // 128-wide tiles at one workgroup per compute unit: buffers, interleave, split factors
+            const bool want = (g.K >= 1536 && g.N >= 128) ;
+            if (!want) continue;
+            for (int S : {1, 2, 3, 4, 5, 6}) {
+                if ((long)g.M * g.N * S > (long)maxC * 8) continue;
+#define R4(BM, BN, A, B, O) run3<BM, BN, A, B, 0, O>(s, g, S, best, true);
+                R4(128, 128, 4, 2, 0) R4(128, 128, 4, 2, 4) R4(128, 128, 4, 2, 8) R4(128, 128, 4, 2, 12) R4(128, 128, 4, 2, 14)
+                R4(128, 128, 2, 2, 4) R4(128, 128, 2, 2, 12) R4(128, 64, 4, 2, 12) R4(128, 64, 4, 2, 4) R4(64, 64, 2, 2, 12) R4(64, 64, 2, 2, 2)
+            }
+            const double tfb = 2.0 * g.M * g.N * g.K / best.us / 1e6;
+            printf("  BEST %-34s %8.2f us  %6.1f TF  frac %.3f\n", best.what, best.us, tfb, tfb / 157.3);
+            continue;
+        }
         if (argc > 1 && argv[1][0] == 'a') {      // ablations on the steady-state shapes
             if (g.M < 60000) continue;
             for (int S : {1}) {

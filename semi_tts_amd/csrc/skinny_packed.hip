@@ -818,6 +818,10 @@ int pk_dispatch(const PkArgs& a, int tiles, hipStream_t st) {
 #endif
         if (BT == 2)
             hipLaunchKernelGGL((pk_lstm_rt2_kernel<LKW, LTR, 1>), dim3(tiles / 2, 2), dim3(LKW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+#ifdef PK_C5_NB4      // experiment (round 4, tools/gpu_c5_nb4.sh): two row tiles x ALL FOUR batch tiles per workgroup -- 0.75 operand loads per MFMA instead of 1.0, half the workgroups
+        else if (getenv("ST_C5_NB4"))
+            hipLaunchKernelGGL((pk_lstm_rt2_kernel<LKW, LTR, 4>), dim3(tiles / 2, 1), dim3(LKW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
+#endif
         else
             hipLaunchKernelGGL((pk_lstm_rt2_kernel<LKW, LTR, 2>), dim3(tiles / 2, 2), dim3(LKW * 64), 0, st, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.H, a);
         ST_LAUNCH_CHECK();

@@ -12,6 +12,7 @@
 // HBM traffic per vector: D*4 in, D*4 out, 8 idx, V*4 p_code; the table is read once per
 // workgroup (grid is capped so each workgroup handles many vectors).
 #include "st_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -143,28 +144,32 @@ __global__ __launch_bounds__(VQ_WAVES * 64) void vq_l2_kernel(const float* x, co
 //   * |x|^2 uses the same summation tree as the scalar kernel's wave butterfly (dims d, d^32 first ... d^1 last).
 // Algorithmic bytes per vector: 4D in + 4D out + 8 idx + 4V p_code; the packed table is read once per workgroup.
 constexpr int VQM_XLD = 68;
-constexpr int VQM_NW = 4;
-
+// waves per workgroup: 4 (one per SIMD) up to 32 code tiles (V <= 512), 8 beyond.  (Measured and rejected in round 4: 8 waves x 4
+// tiles at V = 512 so that two workgroups = four waves per SIMD stay resident -- the 128-register budget spills 42 registers and the
+// search takes 58 instead of 37.5 us.  The exact-fp32 MFMA runs on the vector ALUs: it does not overlap with another wave's VALU
+// work on the same SIMD -- phase stamps: the partner's 4096-cycle MFMA burst stretches a 1.2k-cycle softmax phase to 5.3k -- so more
+// resident waves can only hide latency, never add a second pipe.)
+__host__ __device__ inline int vq_nw(int n_ct) { return n_ct <= 32 ? 4 : 8; }
 // code tiles per wave for a table of n_ct code tiles (the kernel instantiations below)
-__host__ __device__ inline int vq_tpw(int n_ct) { return n_ct <= 4 ? 1 : n_ct <= 8 ? 2 : n_ct <= 16 ? 4 : n_ct <= 32 ? 8 : 16; }
+__host__ __device__ inline int vq_tpw(int n_ct) { return n_ct <= 4 ? 1 : n_ct <= 8 ? 2 : n_ct <= 16 ? 4 : 8; }
 // code held by column nn of packed tile pt = wave + NW * t
-__host__ __device__ inline int vq_code_of(int tpw, int pt, int nn) {
-    const int wave = pt % VQM_NW, t = pt / VQM_NW;
+__host__ __device__ inline int vq_code_of(int nw, int tpw, int pt, int nn) {
+    const int wave = pt % nw, t = pt / nw;
     return tpw % 4 == 0 ? wave * 16 * tpw + (t >> 2) * 64 + nn * 4 + (t & 3) : pt * 16 + nn;
 }
 
-__global__ __launch_bounds__(256) void vq_pack_table_kernel(const float* table, int V, int D, float* ws, int n_pt, int ks4n, int tpw) {
+__global__ __launch_bounds__(256) void vq_pack_table_kernel(const float* table, int V, int D, float* ws, int n_pt, int ks4n, int nw, int tpw) {
     const size_t total = (size_t)n_pt * ks4n * 256;
     float* e2 = ws + total;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + (size_t)n_pt * 16; idx += (size_t)gridDim.x * blockDim.x) {
         if (idx < total) {
             const int c = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
             const int blk = (int)(idx >> 8), ks4 = blk % ks4n, pt = blk / ks4n;
-            const int code = vq_code_of(tpw, pt, lane & 15), d = (ks4 * 4 + c) * 4 + (lane >> 4);
+            const int code = vq_code_of(nw, tpw, pt, lane & 15), d = (ks4 * 4 + c) * 4 + (lane >> 4);
             ws[idx] = (code < V && d < D) ? table[(size_t)code * D + d] : 0.0f;
         } else {                                        // sum(y.pow(2), -1): dimension-ascending fma chain (as the scalar kernel)
             const int slot = (int)(idx - total);
-            const int code = vq_code_of(tpw, slot >> 4, slot & 15);
+            const int code = vq_code_of(nw, tpw, slot >> 4, slot & 15);
             float acc = 0.0f;
             if (code < V) {
                 f32x4 row[16];          // the whole row is requested up front (D <= 64, D % 4 == 0: checked on the host)
@@ -218,14 +223,13 @@ __device__ __forceinline__ float vq_div(float e, float s, float r) {
 
 // TPW code tiles per wave (V <= 64 TPW); WPS = workgroups the launcher places per compute unit (register budget 512 / WPS per lane);
 // FULL: V == 64 TPW, every code of every tile exists (no masks in the loop)
-template <int TPW, int WPS, bool FULL>
-__global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
+template <int NW, int TPW, int WPS, bool FULL>
+__global__ __launch_bounds__(NW * 64, WPS * NW / 4) void vq_l2_mfma_kernel(const float* x, const float* table, const float* ws, const float* temp,
                                                                          float* p_code, int64_t* idx_out, float* out, int n, int D, int V,
                                                                          int ks4n, int n_tiles, int p_vec4) {
-    constexpr int NW = VQM_NW;
     constexpr bool PERM = TPW % 4 == 0;
-    __shared__ __attribute__((aligned(16))) float xt[16 * VQM_XLD];
-    __shared__ float xxs[NW][16];
+    __shared__ __attribute__((aligned(16))) float xts[2][16 * VQM_XLD];      // the tile's vectors, double-buffered: the output stage of
+    __shared__ float xxs[NW][16];                                           // tile i reads them during tile i + 1
     __shared__ float red[NW][16];
     __shared__ int redi[NW][16];
     __shared__ int fidx[16];
@@ -235,8 +239,8 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
     const float* e2 = ws + (size_t)NW * TPW * ks4n * 256;
     // the first tile's vectors (staging role of this thread: 16 bytes of vector tid >> 4; rows past n repeat the last one and are
     // zeroed when they are written to LDS -- no branch around the load)
-    const int svec = tid >> 4, sd4 = min((tid & 15) * 4, D - 4);
-    const bool sd_ok = (tid & 15) * 4 < D;
+    const int svec = (tid >> 4) & 15, sd4 = min((tid & 15) * 4, D - 4);
+    const bool sd_ok = (tid & 15) * 4 < D && tid < 256;      // (the first four waves stage the 16 vectors and write their output rows)
     int tile = blockIdx.x;
     f32x4 xr = *reinterpret_cast<const f32x4*>(x + (size_t)min(tile * 16 + svec, n - 1) * D + sd4);
     // every table operand of this wave: requested once, kept in registers for all the tiles of the workgroup
@@ -247,20 +251,21 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
     for (int t = 0; t < TPW; ++t) {
         const int pt = wave + NW * t;
         e2v[t] = e2[pt * 16 + nn];
-        if (!FULL) off[t] = vq_code_of(TPW, pt, nn) < V ? 0.0f : -INFINITY;
+        if (!FULL) off[t] = vq_code_of(NW, TPW, pt, nn) < V ? 0.0f : -INFINITY;
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[t][q] = q < ks4n ? wsp[((size_t)pt * ks4n + q) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float tscale = fmaxf(temp[0], 0.0f);          // F.relu(self.temp)
     // every barrier of the loop orders LDS traffic only (st_lds_barrier): __syncthreads() also waits for the global stores of p_code
     // and for the prefetched vectors of the next tile -- a memory round trip per barrier, seven per tile
-    f32x4 oe = {0.f, 0.f, 0.f, 0.f}, ox = oe;           // the previous tile's picked code row (in flight) and its own vector piece
+    f32x4 oe = {0.f, 0.f, 0.f, 0.f};                    // the previous tile's picked code row (in flight)
     int ov = -1;                                        // ... of vector ov
-    for (; tile < n_tiles; tile += gridDim.x) {
+    int tog = 0;
+    for (; tile < n_tiles; tile += gridDim.x, tog ^= 1) {
         const int v0 = tile * 16;
+        float* xt = xts[tog];
         VQ_STAMP(0);
-        const f32x4 xcur = (sd_ok && v0 + svec < n) ? xr : f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(xt + svec * VQM_XLD + (tid & 15) * 4) = xcur;
+        if (tid < 256) *reinterpret_cast<f32x4*>(xt + svec * VQM_XLD + (tid & 15) * 4) = (sd_ok && v0 + svec < n) ? xr : f32x4{0.f, 0.f, 0.f, 0.f};
         st_lds_barrier();
         VQ_STAMP(1);
         {   // the next tile's vectors travel while this one is scored
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
             f += st_dpp<ST_DPP_QUAD_XOR1>(f);
             if (j == 0) xxs[wave][vec] = f;
         }
+        asm volatile("" ::: "memory");                  // (the 16 squares above die before the fragments are read: register pressure)
         float ax[16];                                   // A fragments: x[vec nn][4 ks + g]
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) ax[ks] = xt[nn * VQM_XLD + ks * 4 + g];
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
                 for (int t = 0; t < TPW; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[q * 4 + c], bq[t][q][c], acc[t], 0, 0, 0);
         if (ov >= 0 && ov < n && sd_ok) {               // the previous tile's output rows (the code rows have landed by now)
+            const f32x4 ox = *reinterpret_cast<const f32x4*>(xts[tog ^ 1] + svec * VQM_XLD + (tid & 15) * 4);
             f32x4 o;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = (ox[c] + oe[c]) - ox[c];
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
         }
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int code = vq_code_of(TPW, wave + NW * t, nn);
+            const int code = vq_code_of(NW, TPW, wave + NW * t, nn);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = vq_div(acc[t][r], sm[r], rs[r]);
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
         const bool whole = FULL && v0 + 16 <= n && p_vec4;       // (uniform) every vector and every code of the tile exists
         VQ_STAMP(6);
         if (PERM && whole) {      // four consecutive codes per lane and vector: 16-byte stores, 256 contiguous bytes per 16 lanes
-            float* pp = p_code + (size_t)(v0 + 4 * g) * V + vq_code_of(TPW, wave, nn);
+            float* pp = p_code + (size_t)(v0 + 4 * g) * V + vq_code_of(NW, TPW, wave, nn);
 #pragma unroll
             for (int h = 0; h < (PERM ? TPW / 4 : 0); ++h)
 #pragma unroll
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
         } else if (PERM) {
 #pragma unroll
             for (int h = 0; h < (PERM ? TPW / 4 : 0); ++h) {
-                const int c0 = vq_code_of(TPW, wave + NW * 4 * h, nn);
+                const int c0 = vq_code_of(NW, TPW, wave + NW * 4 * h, nn);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int vec = v0 + 4 * g + r;
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
         } else {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const int code = vq_code_of(TPW, wave + NW * t, nn);
+                const int code = vq_code_of(NW, TPW, wave + NW * t, nn);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int vec = v0 + 4 * g + r;
@@ -423,11 +430,11 @@ __global__ __launch_bounds__(VQM_NW * 64, WPS) void vq_l2_mfma_kernel(const floa
         // out = (x + code) - x.detach(), the straight-through forward value (embed.py:145): the picked code's row is REQUESTED here and
         // consumed one tile later (the gather's round trip, 2.1k cycles, sat on every tile's critical path)
         oe = *reinterpret_cast<const f32x4*>(table + (size_t)fidx[svec] * D + sd4);
-        ox = xcur;
         ov = v0 + svec;
         VQ_STAMP(10);
     }
     if (ov >= 0 && ov < n && sd_ok) {
+        const f32x4 ox = *reinterpret_cast<const f32x4*>(xts[tog ^ 1] + svec * VQM_XLD + (tid & 15) * 4);
         f32x4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = (ox[c] + oe[c]) - ox[c];
@@ -577,7 +584,7 @@ extern "C" int st_gather_rows(const float* table, const int64_t* idx, float* out
 
 extern "C" size_t st_vq_l2_workspace_floats(int D, int V) {
     if (D <= 0 || V <= 0) return 0;
-    const size_t n_pt = (size_t)VQM_NW * vq_tpw((V + 15) / 16), ks4n = ((size_t)D + 15) / 16;      // packed tiles incl. the padding ones
+    const size_t n_pt = (size_t)vq_nw((V + 15) / 16) * vq_tpw((V + 15) / 16), ks4n = ((size_t)D + 15) / 16;      // packed tiles incl. the padding ones
     return n_pt * ks4n * 256 + n_pt * 16;
 }
 
@@ -588,10 +595,10 @@ extern "C" int st_vq_pack_table(const float* table, float* packed, int D, int V,
     (void)hipGetLastError();
     ST_CHECK_ARG(table && packed && vq_mfma_shape(D, V) && D > 0 && V > 0 && st_aligned16(table) && st_aligned16(packed),
                  "st_vq_pack_table: D=%d V=%d not a matrix-core shape, or unaligned operands", D, V);
-    const int tpw = vq_tpw((V + 15) / 16), n_pt = VQM_NW * tpw, ks4n = (D + 15) / 16;
+    const int nw = vq_nw((V + 15) / 16), tpw = vq_tpw((V + 15) / 16), n_pt = nw * tpw, ks4n = (D + 15) / 16;
     const size_t total = (size_t)n_pt * ks4n * 256 + (size_t)n_pt * 16;
     hipLaunchKernelGGL(vq_pack_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, V, D,
-                       packed, n_pt, ks4n, tpw);
+                       packed, n_pt, ks4n, nw, tpw);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -620,7 +627,7 @@ static int vq_l2_impl(const float* x, const float* table, const float* temp, flo
     // matrix-core form: a caller-provided workspace for the packed table (packed here, or once per table version by st_vq_pack_table)
     if (workspace && vq_mfma_shape(D, V) && st_aligned16(x) && st_aligned16(table) && st_aligned16(out) &&
         st_aligned16(workspace)) {
-        const int tpw = vq_tpw((V + 15) / 16), ks4n = (D + 15) / 16;
+        const int ks4n = (D + 15) / 16;
         if (pack) {
             int rc = st_vq_pack_table(table, workspace, D, V, stream);
             if (rc) return rc;
@@ -629,18 +636,19 @@ static int vq_l2_impl(const float* x, const float* table, const float* temp, flo
         // registers fit twice into a SIMD's file, 16 tiles once), each walking tiles blockIdx.x, + gridDim.x, ...
         const int n_tiles = (n + 15) / 16;
         const int p_vec4 = (V % 4 == 0 && st_aligned16(p_code)) ? 1 : 0;
-#define VQ_LAUNCH_ONE(T, WPS, FULL_) do { static int occ = 0; \
-        if (occ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vq_l2_mfma_kernel<T, WPS, FULL_>, VQM_NW * 64, 0) != hipSuccess || occ < 1)) occ = WPS; \
-        const int gmax = occ * st_device_cus(); \
-        hipLaunchKernelGGL((vq_l2_mfma_kernel<T, WPS, FULL_>), dim3(n_tiles < gmax ? n_tiles : gmax), dim3(VQM_NW * 64), 0, (hipStream_t)stream, \
+#define VQ_LAUNCH_ONE(NW_, T, WPS, FULL_) do { static int occ = 0; \
+        if (occ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vq_l2_mfma_kernel<NW_, T, WPS, FULL_>, NW_ * 64, 0) != hipSuccess || occ < 1)) occ = WPS; \
+        const int gmax = (getenv("ST_VQ_WPS") ? atoi(getenv("ST_VQ_WPS")) : occ) * st_device_cus();      /* (ST_VQ_WPS: experiments) */ \
+        hipLaunchKernelGGL((vq_l2_mfma_kernel<NW_, T, WPS, FULL_>), dim3(n_tiles < gmax ? n_tiles : gmax), dim3(NW_ * 64), 0, (hipStream_t)stream, \
                            x, table, workspace, temp, p_code, idx, out, n, D, V, ks4n, n_tiles, p_vec4); } while (0)
-        // (the grid: as many workgroups as the registers keep resident -- 6 per compute unit at one code tile per wave, 2 at eight)
-#define VQ_LAUNCH(T, WPS) do { if (V == 64 * T) VQ_LAUNCH_ONE(T, WPS, true); else VQ_LAUNCH_ONE(T, WPS, false); } while (0)
-        if (tpw == 1) VQ_LAUNCH(1, 2);
-        else if (tpw == 2) VQ_LAUNCH(2, 2);
-        else if (tpw == 4) VQ_LAUNCH(4, 2);
-        else if (tpw == 8) VQ_LAUNCH(8, 2);
-        else VQ_LAUNCH(16, 1);
+        // (the grid: as many workgroups as the registers keep resident -- 6 per compute unit at one code tile per wave)
+#define VQ_LAUNCH(NW_, T, WPS) do { if (V == 16 * NW_ * T) VQ_LAUNCH_ONE(NW_, T, WPS, true); else VQ_LAUNCH_ONE(NW_, T, WPS, false); } while (0)
+        const int n_ct = (V + 15) / 16;
+        if (n_ct <= 4) VQ_LAUNCH(4, 1, 2);
+        else if (n_ct <= 8) VQ_LAUNCH(4, 2, 2);
+        else if (n_ct <= 16) VQ_LAUNCH(4, 4, 2);
+        else if (n_ct <= 32) VQ_LAUNCH(4, 8, 2);
+        else VQ_LAUNCH(8, 8, 1);
 #undef VQ_LAUNCH
 #undef VQ_LAUNCH_ONE
         ST_LAUNCH_CHECK();

@@ -88,6 +88,73 @@ class _ConvFn(Function):
         return dx, dw, db, dres, None, None, None, None, None, None
 
 
+class _ConvGroupFn(Function):
+    """n convolutions / linear maps of the SAME input (the K convs of the CBHG bank, src/module.py:590-598; the two directions' input
+    projections of a bidirectional GRU / LSTM): y_k = act(conv1d_k(x) + b_k).  Forward: the n products go out as ONE launch where the
+    kernels allow (ops.gemm_flush, as in inference).  Backward: the input gradient is accumulated by the products themselves (product
+    k adds product k - 1's result in its epilogue) instead of n tensors that autograd then adds up with n - 1 elementwise launches.
+    Arguments: n, act, x, then n weights, n biases (None = no bias), n (pad, Tout) pairs."""
+
+    @staticmethod
+    def forward(ctx, n, act, x, *args):
+        ws, bs, cfg = args[:n], args[n:2 * n], args[2 * n:]
+        x = x.contiguous()
+        jobs, ys = [], []
+        for k in range(n):
+            ys.append(ops.gemm(x, ws[k], pad=int(cfg[2 * k]), Tout=cfg[2 * k + 1], bias=bs[k], act_pre=act, collect=jobs))
+        ops.gemm_flush(jobs)
+        ctx.save_for_backward(x, *ws, *(ys if act is not None else []))
+        ctx.cfg = (n, act, [int(cfg[2 * k]) for k in range(n)], [b is not None for b in bs])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, act, pads, has_b = ctx.cfg
+        sv = ctx.saved_tensors
+        x, ws, ys = sv[0], sv[1:1 + n], sv[1 + n:]
+        if x.dim() == 3:
+            Bn, Tin, Cin = x.shape
+        else:
+            Bn, Tin, Cin = 1, x.shape[0], x.shape[1]
+        dx, dws, dbs = None, [], []
+        for k in range(n):
+            w = ws[k]
+            N, KT = w.shape[0], (w.shape[2] if w.dim() == 3 else 1)
+            dy = dys[k].contiguous()
+            dpre = ops.act_bwd(_rows(dy), _rows(ys[k]), act, None).view(dy.shape) if act is not None else dy
+            To = dy.shape[1] if x.dim() == 3 else dy.shape[0]
+            if ctx.needs_input_grad[2]:
+                wt, tap_major = ops.dx_weight(w.detach())
+                if dx is None:
+                    dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pads[k], w_tap_major=tap_major)
+                else:                                    # (in place: every element is read and written by the same thread)
+                    ops.gemm(dpre, wt, dx, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pads[k], w_tap_major=tap_major, res=dx)
+            dw = db = None
+            want_w, want_b = ctx.needs_input_grad[3 + k], has_b[k] and ctx.needs_input_grad[3 + n + k]
+            if want_w and want_b:
+                dw, db = ops.gemm_wgrad(dpre, x, KT, pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N, with_db=True)
+                dw = dw.view(w.shape)
+            elif want_w:
+                dw = ops.gemm_wgrad(dpre, x, KT, pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N).view(w.shape)
+            elif want_b:
+                db = ops.colsum(_rows(dpre))
+            dws.append(dw)
+            dbs.append(db)
+        if dx is not None:
+            dx = dx.view(x.shape)
+        return (None, None, dx) + tuple(dws) + tuple(dbs) + (None,) * (2 * n)
+
+
+def conv_group(x, weights, pads, Touts, act=None, biases=None):
+    """[act(conv1d_k(x) + b_k)] for n convolutions / linear maps of one input (see _ConvGroupFn)"""
+    n = len(weights)
+    biases = list(biases) if biases is not None else [None] * n
+    cfg = []
+    for p_, t_ in zip(pads, Touts):
+        cfg += [int(p_), t_]
+    return list(_ConvGroupFn.apply(n, act, x, *weights, *biases, *cfg))
+
+
 def conv(x, w, b=None, *, pad=0, Tout=None, act=None, res=None, mask=None, pool_prev=False, stride=1):
     """differentiable ops.gemm (conv1d over channels-last rows, or linear when w is 2-D)"""
     return _ConvFn.apply(x, w, b, res, mask, pad, Tout, act, pool_prev, stride)

@@ -169,8 +169,8 @@ class Encoder(nn.Module):
         for layer in range(self.enc_rnn_layer):            # (nn.LSTM stacks the layers; no inter-layer dropout: module.py:432-438)
             g = lambda n, rev=False: getattr(self.lstm, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))
             if self.training:
-                xp_f = AG.conv(x, g('weight_ih'), g('bias_ih'))
-                xp_b = AG.conv(x, g('weight_ih', True), g('bias_ih', True))
+                xp_f, xp_b = AG.conv_group(x, [g('weight_ih'), g('weight_ih', True)], [0, 0], [None, None],
+                                           biases=[g('bias_ih'), g('bias_ih', True)])       # both directions: one launch
                 x = AG.bilstm(xp_f, xp_b, g('weight_hh'), g('bias_hh'), g('weight_hh', True), g('bias_hh', True))
                 continue
             out = torch.empty(B, L, 2 * H, device=x.device, dtype=torch.float32)
@@ -741,8 +741,11 @@ def _cbhg_forward_train(self, x):
     B, T, Cn = x.shape
     # even k yields T+1 positions and BatchNorm sees all of them before the trim to T (module.py:597-598)
     # (the K BatchNorms go through ONE autograd function: under SyncBN they share one all-gather and one all-reduce)
-    pre = [AG.conv(x, blk.conv1d.weight, None, pad=blk.padding, Tout=T + 1 if (i + 1) % 2 == 0 else T,
-                   act='relu' if blk.activation is not None else None) for i, blk in enumerate(self.conv1d_banks)]
+    # (... and the K convolutions through ONE autograd function: one forward launch, the input gradient accumulated by the products)
+    acts = set(blk.activation is not None for blk in self.conv1d_banks)
+    assert len(acts) == 1
+    pre = AG.conv_group(x, [blk.conv1d.weight for blk in self.conv1d_banks], [blk.padding for blk in self.conv1d_banks],
+                        [T + 1 if (i + 1) % 2 == 0 else T for i in range(len(self.conv1d_banks))], act='relu' if acts.pop() else None)
     bank = torch.cat([y[:, :T] for y in AG.batch_norm_train_group(pre, [blk.bn for blk in self.conv1d_banks])], dim=-1)
     y = self.conv1d_projs[0](bank, pool_prev=True)
     for blk in self.conv1d_projs[1:]:
@@ -751,8 +754,8 @@ def _cbhg_forward_train(self, x):
     for hw in self.highways:
         y = hw(y)
     g = self.gru
-    gi_f = AG.conv(y, g.weight_ih_l0, g.bias_ih_l0)
-    gi_b = AG.conv(y, g.weight_ih_l0_reverse, g.bias_ih_l0_reverse)
+    gi_f, gi_b = AG.conv_group(y, [g.weight_ih_l0, g.weight_ih_l0_reverse], [0, 0], [None, None],
+                               biases=[g.bias_ih_l0, g.bias_ih_l0_reverse])         # one launch; dy accumulated by the products
     return AG.bigru(gi_f, gi_b, g.weight_hh_l0, g.bias_hh_l0, g.weight_hh_l0_reverse, g.bias_hh_l0_reverse)
 
 

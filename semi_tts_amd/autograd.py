@@ -38,15 +38,23 @@ class _ConvFn(Function):
         assert mask is None or act in (None, 'relu'), 'dropout mask is fused only after relu / identity'
         assert stride == 1 or (not pool_prev and Tout is None), 'strided conv: plain form only'
         x = x.contiguous()
-        y = ops.gemm(x, w, pad=pad, stride=stride, Tout=Tout, bias=b, act_pre=act, res=res, mask=mask, pool_prev=pool_prev)
-        ctx.save_for_backward(x, w, y if act is not None else None, mask)
+        xp = None
+        if pool_prev and x.dim() == 3 and x.shape[-1] % 4 == 0 and x.data_ptr() % 16 == 0:
+            # the pooled input as a tensor of its own: forward AND weight-gradient products then run on the LDS-DMA kernels (which
+            # cannot take a maximum on the way into LDS); x itself stays for the pool's backward
+            xp = ops.pool_prev_fwd(x)
+            y = ops.gemm(xp, w, pad=pad, stride=stride, Tout=Tout, bias=b, act_pre=act, res=res, mask=mask)
+        else:
+            y = ops.gemm(x, w, pad=pad, stride=stride, Tout=Tout, bias=b, act_pre=act, res=res, mask=mask, pool_prev=pool_prev)
+        ctx.save_for_backward(x, w, y if act is not None else None, mask, xp)
         ctx.cfg = (pad, act, pool_prev, b is not None, res is not None, stride)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y, mask = ctx.saved_tensors
+        x, w, y, mask, xp = ctx.saved_tensors
         pad, act, pool_prev, has_b, has_res, stride = ctx.cfg
+        xw, pool_w = (xp, False) if xp is not None else (x, pool_prev)       # the weight gradient's activation operand
         dy = dy.contiguous()
         N = w.shape[0]
         KT = w.shape[2] if w.dim() == 3 else 1
@@ -80,10 +88,10 @@ class _ConvFn(Function):
             if pool_prev:
                 dx = ops.pool_prev_bwd(dx, x)
         if db_in_wgrad:
-            dw, db = ops.gemm_wgrad(dpre, x, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_prev, with_db=True)
+            dw, db = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, with_db=True)
             dw = dw.view(w.shape)
         elif ctx.needs_input_grad[1]:
-            dw = ops.gemm_wgrad(dpre, x, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_prev).view(w.shape)
+            dw = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w).view(w.shape)
         dres = dy if has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None, None, None, None, None
 

@@ -255,6 +255,152 @@ __global__ __launch_bounds__(TN_THREADS) void tn_kernel(const TnArgs g) {
         }
 }
 
+// ---- tn_dma_kernel: the same product with both operands moved by LDS-DMA (round 4) ---------------------------------------------
+// A chunk of RC = 32 rows of dC / A goes straight into LDS AS IT LIES IN MEMORY (global_load_lds_dwordx4: a wave instruction moves
+// 4 rows x 256 bytes at TM = 64, 2 rows x 512 bytes at TM = 128): no staging registers, no ds_write pass, and -- with the MFMA tiles'
+// interleaved columns -- no swizzle either (a lane's fragment of row 4q + c is at [row][FR r ..]: 16 lanes read 16 FR consecutive
+// floats of one row; rows 4 apart fall on the same banks at TM = 64, a 2-way conflict on 8 ds_read_b64 per 32 MFMAs).  Three buffers,
+// ONE barrier per 32 rows (the register-staged form: one per 16).  Pieces that do not exist (rows past the slab, frames outside
+// the utterance, columns past N / Cin) read 16 zero bytes from a constant.  Shapes: what tn_kernel's running-pointer forms take
+// (16-byte addressable rows, whole 4-column pieces, no fold, no fused max-pool); the k order per output element is tn_kernel's
+// (rows ascending), so the results are bit-identical.
+__device__ const f32x4 tn_zero4 = {0.f, 0.f, 0.f, 0.f};
+typedef const __attribute__((address_space(1))) void* tn_gptr_t;
+typedef __attribute__((address_space(3))) void* tn_lptr_t;
+
+template <int TM>
+__global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) {
+    constexpr int FR = TM / 32;
+    constexpr int RC = 32;                              // rows per chunk
+    constexpr int PPR = TM / 4;                         // 16-byte pieces per row
+    constexpr int RPI = TN_THREADS / PPR;               // rows one DMA pass of the workgroup covers (16 at TM = 64, 8 at 128)
+    constexpr int NI = RC / RPI;                        // DMA instructions per thread, operand and chunk
+    constexpr int BUF = 2 * RC * TM;                    // floats per buffer: X then Y
+    typedef float frag_t __attribute__((ext_vector_type(FR)));
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * TM;
+    const int cblocks = (g.Cin + TM - 1) / TM;
+    const int tap = blockIdx.y / cblocks;
+    const int c0 = (blockIdx.y - tap * cblocks) * TM;
+    const int z = blockIdx.z;
+    const int mbeg = z * g.rows_per_z, mend = min(g.M, mbeg + g.rows_per_z);
+    const int srow = tid / PPR, sc = (tid % PPR) * 4;   // staging role: piece sc of rows srow, srow + RPI, ...
+    const float* zp = reinterpret_cast<const float*>(&tn_zero4);
+    const bool okx = n0 + sc + 4 <= g.N, oky = c0 + sc + 4 <= g.Cin;
+    const float* px = g.dC + (size_t)(mbeg + srow) * g.lddc + g.dcoff + n0 + sc;
+    const float* py = g.A + (size_t)(mbeg + srow) * g.lda + c0 + sc;          // (Linear layers)
+    int mreq = mbeg + srow;                             // the row this thread's first piece of the next chunk belongs to
+    int cb[NI], cto[NI];                                // (convolutions: utterance / frame of each of the thread's rows)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int m = min(mreq + i * RPI, g.M - 1); cb[i] = m / g.Tout; cto[i] = m - cb[i] * g.Tout; }
+    auto issue = [&](int bufi) __attribute__((always_inline)) {
+        float* xs = tn_lds + bufi * BUF;
+        float* ys = xs + RC * TM;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bool row = mreq + i * RPI < mend;
+            const float* sx = (row && okx) ? px + (size_t)i * RPI * g.lddc : zp;
+            const float* sy;
+            if (g.lin) sy = (row && oky) ? py + (size_t)i * RPI * g.lda : zp;
+            else {
+                const int ti = cto[i] + tap - g.pad;
+                sy = (row && oky && ti >= 0 && ti < g.Tin) ? g.A + ((size_t)cb[i] * g.Tin + ti) * g.lda + c0 + sc : zp;
+                cto[i] += RC;
+                while (cto[i] >= g.Tout) { cto[i] -= g.Tout; ++cb[i]; }
+            }
+            // (a wave instruction covers 64 / PPR consecutive rows: wave w of pass i starts at row i * RPI + w * (64 / PPR))
+            __builtin_amdgcn_global_load_lds((tn_gptr_t)sx, (tn_lptr_t)(xs + (i * RPI + wave * (64 / PPR)) * TM), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((tn_gptr_t)sy, (tn_lptr_t)(ys + (i * RPI + wave * (64 / PPR)) * TM), 16, 0, 0);
+        }
+        px += (size_t)RC * g.lddc; py += (size_t)RC * g.lda; mreq += RC;
+    };
+    f32x4 acc[FR][FR];
+#pragma unroll
+    for (int i = 0; i < FR; ++i)
+#pragma unroll
+        for (int j = 0; j < FR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool do_db = g.db_part != nullptr && blockIdx.y == 0;
+    f32x4 dbacc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dbacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nchunks = (mend - mbeg + RC - 1) / RC;
+    issue(0);
+    issue(1);
+    int bi = 0, bn = 2;
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");        // chunk c has landed (this wave's pieces); c + 1 may be in flight
+        st_lds_barrier();
+        issue(bn);
+        const float* xs = tn_lds + bi * BUF;
+        const float* ys = xs + RC * TM;
+        if (do_db) {                                    // the bias gradient: column sums of the dC rows this thread's pieces cover
+#pragma unroll
+            for (int i = 0; i < NI; ++i) dbacc[i] = dbacc[i] + *reinterpret_cast<const f32x4*>(xs + (i * RPI + srow) * TM + sc);
+        }
+#pragma unroll
+        for (int h = 0; h < RC / 16; ++h) {
+            frag_t a4[4], b4[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                a4[cc] = *reinterpret_cast<const frag_t*>(xs + (h * 16 + 4 * fq + cc) * TM + wm * (TM / 2) + FR * fr);
+                b4[cc] = *reinterpret_cast<const frag_t*>(ys + (h * 16 + 4 * fq + cc) * TM + wn * (TM / 2) + FR * fr);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int mt = 0; mt < FR; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < FR; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[cc][mt], b4[cc][nt], acc[mt][nt], 0, 0, 0);
+        }
+        bi = bi == 2 ? 0 : bi + 1;
+        bn = bn == 2 ? 0 : bn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (do_db) {   // the row groups' column sums meet in LDS (buffer 0: everybody is past the loop after this barrier), fixed order
+        st_lds_barrier();
+        f32x4 t = dbacc[0];
+#pragma unroll
+        for (int i = 1; i < NI; ++i) t = t + dbacc[i];
+        *reinterpret_cast<f32x4*>(tn_lds + srow * TM + sc) = t;
+        st_lds_barrier();
+        if (tid < TM && n0 + tid < g.N) {
+            float s = 0.0f;
+#pragma unroll
+            for (int r = 0; r < RPI; ++r) s += tn_lds[r * TM + tid];
+            g.db_part[(size_t)z * g.N + n0 + tid] = s;
+        }
+    }
+    // result: lane (r, q) holds D[i = 4q + e][j = r] of tile (mt, nt): row n = .. + FR i + mt, columns .. + FR r + nt
+    const int ncols = g.Cin;
+    float* out = g.part + (size_t)z * g.N * g.Cin * g.KT;
+    const int cib = c0 + wn * (TM / 2) + FR * fr;
+    const bool vec_out = FR == 4 && g.KT == 1 && (ncols % 4 == 0) && cib + 3 < ncols && st_aligned16(out);
+#pragma unroll
+    for (int mt = 0; mt < FR; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wm * (TM / 2) + FR * (4 * fq + e) + mt;
+            if (n >= g.N) continue;
+            if (vec_out) {
+                f32x4 v;
+#pragma unroll
+                for (int nt = 0; nt < FR; ++nt) v[nt] = acc[mt][nt][e];
+                *reinterpret_cast<f32x4*>(out + (size_t)n * ncols + cib) = v;
+                continue;
+            }
+#pragma unroll
+            for (int nt = 0; nt < FR; ++nt) {
+                const int ci = cib + nt;
+                if (ci >= ncols) continue;
+                out[((size_t)n * g.Cin + ci) * g.KT + tap] = acc[mt][nt][e];
+            }
+        }
+}
+
 // out[i] (+)= sum_z part[z][i]   (fixed order)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, float* out, size_t n, int Z, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -631,7 +777,7 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     g.M = Bn * Tout;
     const size_t per = (size_t)N * Cin * KT;
     const int Z = (int)(st_gemm_wgrad_workspace_floats(Bn, Tout, Cin, N, KT) / (per + N));
-    g.rows_per_z = (((g.M + Z - 1) / Z) + TN_BK - 1) / TN_BK * TN_BK;
+    g.rows_per_z = (((g.M + Z - 1) / Z) + 31) / 32 * 32;          // (whole 32-row chunks: the DMA form's unit)
     // the workspace (hence Z) is sized for the folded layout whenever Cin < 16; a pooled input falls back to the per-tap grid
     g.fold = tn_fold(Cin, KT, pool_prev) ? 1 : 0;
     g.lin = (KT == 1 && pad == 0 && Tin == Tout && !pool_prev) ? 1 : 0;
@@ -645,7 +791,19 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     const bool direct = Z == 1 && !accumulate;
     if (direct) g.part = dW;
     if (db) g.db_part = direct ? db : ws + (size_t)Z * per;
-    if (TM == 128) hipLaunchKernelGGL((tn_kernel<128>), grid, dim3(TN_THREADS), 0, st, g);
+    // the LDS-DMA form where every piece is whole (or wholly outside) and 16-byte addressable, no fold, no fused max-pool
+    const bool whole = N % 4 == 0 && Cin % 4 == 0;
+    const bool dma = !g.fold && !pool_prev && g.vecx && g.vecy && whole && g.rows_per_z % 32 == 0;
+    if (dma) {
+        const size_t lds = (size_t)3 * 2 * 32 * TM * sizeof(float);       // 48 KB at TM = 64, 96 KB at 128
+        static bool set128 = false;
+        if (TM == 128 && !set128) {
+            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tn_dma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set128 = true;
+        }
+        if (TM == 128) hipLaunchKernelGGL((tn_dma_kernel<128>), grid, dim3(TN_THREADS), lds, st, g);
+        else hipLaunchKernelGGL((tn_dma_kernel<64>), grid, dim3(TN_THREADS), lds, st, g);
+    } else if (TM == 128) hipLaunchKernelGGL((tn_kernel<128>), grid, dim3(TN_THREADS), 0, st, g);
     else hipLaunchKernelGGL((tn_kernel<64>), grid, dim3(TN_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();
     if (direct) return 0;

@@ -368,9 +368,7 @@ def gemm(a, w, out=None, *, Bn=None, Tin=None, Tout=None, pad=0, stride=1, coff=
             (Bn, Tin) == (a.shape[0], a.shape[1]):
         # the LDS-DMA kernel cannot take a maximum on the way into LDS: the pooled input becomes a tensor of its own (one elementwise
         # launch, ~10 us for the CBHG's (32, 258, 640) bank output) and the conv runs on the fast kernel (52 against 84 us)
-        pooled = torch.empty_like(a)
-        check(lib.st_pool_prev_fwd(_p(a), _p(pooled), int(a.shape[0]), int(a.shape[1]), int(Cin), stream_handle()), 'st_pool_prev_fwd')
-        a, pool_prev = pooled, False
+        a, pool_prev = pool_prev_fwd(a), False
     slabs = int(lib.st_gemm_splitk_slabs(int(Bn), int(Tout), int(Cin), int(N), int(KT)))
     ws = None
     if slabs > 1:         # small grid, long reduction: partial products per k range + a finish pass (st_gemm_epilogue.splitk_ws)
@@ -850,6 +848,14 @@ def highway_bwd(dy, H, x, Tg):
     check(_lib.load().st_highway_bwd(_p(dy), _p(H), _p(x), _p(Tg), _p(dH), _p(dT), _p(dx), x.numel(), stream_handle()),
           'st_highway_bwd')
     return dH, dT, dx
+
+
+def pool_prev_fwd(x):
+    """MaxPool1d(2, stride 1, padding 1)(x)[:T] of a contiguous channels-last (B, T, C) tensor as a tensor of its own (C % 4 == 0)"""
+    Bn, T, Cc = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().st_pool_prev_fwd(_p(x), _p(y), int(Bn), int(T), int(Cc), stream_handle()), 'st_pool_prev_fwd')
+    return y
 
 
 def pool_prev_bwd(dy_pooled, x):

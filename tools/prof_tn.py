@@ -10,5 +10,5 @@ rows = con.execute("select name, start, end, %s from kernels order by start" % '
 marks = [i for i, r in enumerate(rows) if 'mt_kernel<2>' in r[0]]
 lo = marks[-6] if len(marks) >= 6 else 0
 for r in rows[lo:marks[-1]]:
-    if 'tn_kernel' in r[0]:
-        print('%8.2f us  grid %s  %s' % ((r[2] - r[1]) / 1e3, r[3:], r[0][28:50]))
+    if 'tn_kernel' in r[0] or 'tn_dma_kernel' in r[0]:
+        print('%8.2f us  grid %s  %s' % ((r[2] - r[1]) / 1e3, r[3:], r[0][28:54]))

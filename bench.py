@@ -39,7 +39,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix peak (256 CUs x 256 F
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 # PMC pass of the dominant kernel (tools/gpu_pmc.sh -> tools/pmc_summary.py): HBM bytes per launch.  bench.py does not
 # measure this itself (PMC counters need their own rocprofv3 passes); the value is quoted WITH its source file.
-TRAFFIC_FILES = ('profiles/r03_pmc_hbm_traffic%s.json', 'profiles/r02_pmc_hbm_traffic%s.json', 'profiles/r01_pmc_hbm_traffic%s.json')
+TRAFFIC_FILES = ('profiles/r04_pmc_hbm_traffic%s.json', 'profiles/r03_pmc_hbm_traffic%s.json', 'profiles/r02_pmc_hbm_traffic%s.json', 'profiles/r01_pmc_hbm_traffic%s.json')
 
 
 def decode_step_algorithmic_bytes(Bsz, Lt, dec):
@@ -666,7 +666,7 @@ def bench_train(args, rk):
             'ms_variants': {k: round(v, 3) for k, v in ms.items()},
             'collectives_per_step': counts,
             # whole-step roofline: forward 132 GFLOP per C2 batch, training ~3x that, against the fp32 matrix peak
-            'roofline': {'bound': 'mfma', 'kernel': 'whole training step (~1.25k launches; the largest shares are the weight-gradient GEMM tn_kernel and the per-step products of the BPTT loop)',
+            'roofline': {'bound': 'mfma', 'kernel': 'whole training step (~940 launches; the largest shares are the per-step products of the two loops and the weight-gradient GEMM tn_dma_kernel)',
                          'achieved': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None},
             'last': {k: float(last['st'][k]) for k in ('loss', 'grad_norm')}, 'stats_read': 'per step' if args.sync_stats else 'after the timed steps', 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

@@ -66,9 +66,11 @@ def ctc_forward(W: Dict[str, Tensor], x: Tensor, cfg: dict, training: bool = Fal
     for l, (s, r) in enumerate(zip(cfg['stride'], cfg['residual'])):                                       # :51-52
         x = conv_layer(W, x, prefix + 'layer%d' % l, s, bool(r), cfg['batch_norm'], cfg['activation'], training,
                        cfg['dropout'], drop, stats_out)
-    assert cfg['rnn_bid']
     for layer in range(cfg['rnn_layers']):                                                                 # :56
-        x = torch.cat([lstm_layer_n(x, W, prefix + 'rnn', layer, False), lstm_layer_n(x, W, prefix + 'rnn', layer, True)], -1)
+        if cfg['rnn_bid']:                                                                                 # :35-37
+            x = torch.cat([lstm_layer_n(x, W, prefix + 'rnn', layer, False), lstm_layer_n(x, W, prefix + 'rnn', layer, True)], -1)
+        else:
+            x = lstm_layer_n(x, W, prefix + 'rnn', layer, False)
         if layer + 1 < cfg['rnn_layers']:
             x = drop(x, cfg['dropout'], training)       # nn.LSTM inter-layer dropout (identity in the parity cases)
     if cfg['layer_norm']:                                                                                  # :57-58

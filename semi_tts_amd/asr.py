@@ -77,14 +77,14 @@ class CTC(nn.Module):
             setattr(self, 'layer' + str(l), ConvLayer(self.dim[l], self.dim[l + 1], kernel[l], stride[l], residual[l],
                                                       batch_norm, activation, dropout))
         assert rnn_dim > 0
-        if not rnn_bid:
-            raise NotImplementedError('the HIP speech encoder implements the bidirectional LSTM (every shipped config)')
-        self.rnn = nn.LSTM(self.dim[-1], rnn_dim, num_layers=rnn_layers, dropout=dropout, bidirectional=True, batch_first=True)
+        self.rnn_bid = bool(rnn_bid)
+        self.rnn = nn.LSTM(self.dim[-1], rnn_dim, num_layers=rnn_layers, dropout=dropout, bidirectional=self.rnn_bid, batch_first=True)
         self.rnn_layers = rnn_layers
+        cur = rnn_dim * 2 if self.rnn_bid else rnn_dim                                         # :37
         if self.layer_norm:
-            self.norm_layer = nn.LayerNorm(2 * rnn_dim)                                        # :38-39
+            self.norm_layer = nn.LayerNorm(cur)                                                # :38-39
         self.drop = nn.Dropout(dropout)
-        self.postnet = nn.Linear(2 * rnn_dim, out_dim)
+        self.postnet = nn.Linear(cur, out_dim)
 
     def forward(self, x):
         """x (B,T,n_mels) -> (B, T / time_reduce_factor, out_dim)                            ref: src/asr.py:46-64"""
@@ -97,24 +97,32 @@ class CTC(nn.Module):
         if self.training and torch.is_grad_enabled():
             for layer in range(self.rnn_layers):
                 g = lambda n, rev: getattr(self.rnn, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))
-                xp_f = AG.conv(x, g('weight_ih', False), g('bias_ih', False))
-                xp_b = AG.conv(x, g('weight_ih', True), g('bias_ih', True))
-                x = AG.bilstm(xp_f, xp_b, g('weight_hh', False), g('bias_hh', False), g('weight_hh', True), g('bias_hh', True))
+                if self.rnn_bid:
+                    xp_f, xp_b = AG.conv_group(x, [g('weight_ih', False), g('weight_ih', True)], [0, 0], [None, None],
+                                               biases=[g('bias_ih', False), g('bias_ih', True)])
+                    x = AG.bilstm(xp_f, xp_b, g('weight_hh', False), g('bias_hh', False), g('weight_hh', True), g('bias_hh', True))
+                else:                                                                        # rnn_bid: False (src/asr.py:35-37)
+                    x = AG.lstm(AG.conv(x, g('weight_ih', False), g('bias_ih', False)), g('weight_hh', False), g('bias_hh', False))
                 last = layer == self.rnn_layers - 1
                 if last and self.layer_norm:
                     x = AG.layer_norm(x, self.norm_layer)                                    # :57-58 (before self.drop)
                 if p > 0:   # inter-layer dropout of nn.LSTM, and (after the last layer) the dropout in front of the projection
                     x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)
             return AG.conv(x, self.postnet.weight, self.postnet.bias)
+        Do = (2 if self.rnn_bid else 1) * H
         for layer in range(self.rnn_layers):
-            out = torch.empty(B, T, 2 * H, device=x.device, dtype=torch.float32)
+            out = torch.empty(B, T, Do, device=x.device, dtype=torch.float32)
             g = lambda n, rev: getattr(self.rnn, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))
-            xp = [ops.gemm(x, g('weight_ih', rev), bias=g('bias_ih', rev)) for rev in (False, True)]
-            ops.lstm_seq2(xp[0], xp[1], g('weight_hh', False), g('weight_hh', True), g('bias_hh', False), g('bias_hh', True), out)
+            if self.rnn_bid:
+                xp = [ops.gemm(x, g('weight_ih', rev), bias=g('bias_ih', rev)) for rev in (False, True)]
+                ops.lstm_seq2(xp[0], xp[1], g('weight_hh', False), g('weight_hh', True), g('bias_hh', False), g('bias_hh', True), out)
+            else:
+                ops.lstm_seq(ops.gemm(x, g('weight_ih', False), bias=g('bias_ih', False)), g('weight_hh', False), g('bias_hh', False),
+                             out, 0, False)
             x = out
             if layer == self.rnn_layers - 1 and self.layer_norm:
                 ln = self.norm_layer
-                x = ops.layer_norm(x.view(-1, 2 * H), ln.weight, ln.bias, ln.eps).view(B, T, 2 * H)
+                x = ops.layer_norm(x.view(-1, Do), ln.weight, ln.bias, ln.eps).view(B, T, Do)
             if p > 0:   # inter-layer dropout of nn.LSTM and the dropout in front of the projection (:62)
                 x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)
         return ops.gemm(x, self.postnet.weight, bias=self.postnet.bias)

@@ -519,6 +519,34 @@ def bilstm(xp_f, xp_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
     return _BiLstmFn.apply(xp_f, xp_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b)
 
 
+class _LstmFn(Function):
+    """Unidirectional nn.LSTM layer (forward in time) over precomputed input projections, zero initial state: the speech encoder
+    with `rnn_bid: False` (src/asr.py:35-37).  One launch per time step (st_lstm_seq_fwd / st_lstm_seq_bwd)."""
+
+    @staticmethod
+    def forward(ctx, xp, w_hh, b_hh):
+        B, T, H4 = xp.shape
+        H = H4 // 4
+        dev = xp.device
+        out = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+        g = torch.empty(T, B, 4, H, device=dev, dtype=torch.float32)
+        c = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        ops.lstm_seq(xp.contiguous(), w_hh, b_hh, out, 0, False, gates_tape=g, c_tape=c)
+        ctx.save_for_backward(out, w_hh, g, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, w_hh, g, c = ctx.saved_tensors
+        dxp = ops.lstm_seq_bwd(dout.contiguous(), 0, g, c, ops.dx_weight(w_hh.detach())[0], False)
+        dw = ops.gemm_wgrad(dxp, out, 1, 1)              # h_{t-1} is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1
+        return dxp, dw, ops.colsum(_rows(dxp))
+
+
+def lstm(xp, w_hh, b_hh):
+    return _LstmFn.apply(xp, w_hh, b_hh)
+
+
 class _BiGruFn(Function):
     """Bidirectional nn.GRU layer over precomputed input projections.  ref: src/module.py:585-586,:617"""
 

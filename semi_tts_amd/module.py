@@ -778,13 +778,14 @@ class Postnet(nn.Module):
                           nn.BatchNorm1d(dout), nn.Tanh() if fn == 'tanh' else nn.Identity(), nn.Dropout(postnet_dropout))
             for din, dout, fn in zip(in_size, out_size, act_fn)])
 
-    def forward(self, x):
+    def forward(self, x, _masks=None):
+        """_masks (tests): one scaled dropout mask (B, T, C) per block, replayed instead of drawn"""
         x = x.contiguous()
-        for blk in self.convs:
+        for i, blk in enumerate(self.convs):
             conv, bn = blk[0], blk[1]
             order = 'bn_tanh' if isinstance(blk[2], nn.Tanh) else 'bn'
             x = _conv_bn_act(x, conv.conv.weight, conv.conv.bias, bn, conv.padding, bn.eps, bn.momentum, order,
                              self.training)
-            if self.training and self.postnet_dropout > 0:
-                raise NotImplementedError('Postnet dropout in training mode')
+            if self.training and self.postnet_dropout > 0:                                   # nn.Dropout of the block, :73
+                x = x * (_masks[i] if _masks is not None else _scaled_mask(x.shape, self.postnet_dropout, x.device))
         return x

@@ -695,6 +695,33 @@ def test_ctc_encoder_backward_vs_oracle(dev, gname):
     check_param_grads(m, '', wg, 2e-4, 'ctc_encoder_backward')
 
 
+def test_ctc_encoder_unidirectional_backward_against_reference_golden(dev):
+    """`rnn_bid: False` (src/asr.py:35-37): the 2-layer unidirectional LSTM + LayerNorm speech encoder in training mode; output,
+    input gradient and EVERY parameter gradient against what the real reference's autograd produced for the recorded dy."""
+    from conftest import load_golden
+    from semi_tts_amd.asr import CTC
+    W, A, meta = load_golden('asr_tiny_uni_train')
+    m = CTC(meta['in_dim'], meta['out_dim'], **meta['cfg'])
+    m.load_state_dict(W)
+    m = m.to(dev).train()
+    xd = A['x'].to(dev).requires_grad_()
+    y = m(xd)
+    assert maxdiff(y, A['y']) < 2e-5
+    y.backward(A['dy'].to(dev))
+    e = relerr(xd.grad, A['dx'])
+    report('ctc_uni_backward', dx=e)
+    assert e < 2e-4
+    grads = A['grad']
+    n = 0
+    for k, p in m.named_parameters():
+        if k.endswith('conv.bias') and meta['cfg']['batch_norm']:      # analytically zero (a bias in front of a BatchNorm): fp32 round-off
+            assert float(p.grad.abs().max()) < 1e-4 and float(grads[k].abs().max()) < 1e-4, k
+        else:
+            assert relerr(p.grad, grads[k]) < 2e-4, k
+        n += 1
+    assert n == len(grads)
+
+
 @pytest.mark.parametrize('name', ['speech_first_paired', 'speech_first_unpaired'])
 def test_speech_first_step_against_reference_golden(dev, name):
     """The speech -> text -> speech training step (bin/train_vqvae.py:159-176,208-270) against what the REAL reference

@@ -861,7 +861,8 @@ def test_vq_mean_forward_c3_size_and_gradient(dev):
 
 
 # ------------------------------------------------------------------------------------ next row (8f-2): speech encoder
-@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train', 'asr_tiny_ln_eval', 'asr_tiny_ln_train'])
+@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train', 'asr_tiny_ln_eval', 'asr_tiny_ln_train', 'asr_tiny_uni_eval',
+                                  'asr_tiny_uni_train'])
 def test_ctc_encoder_against_reference_golden(dev, name):
     import json
     from semi_tts_amd.asr import CTC

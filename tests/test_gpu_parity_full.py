@@ -254,3 +254,29 @@ def test_c2_training_step_against_oracle_autograd(dev):
     assert errs['loss'] < 1e-5 * max(1.0, abs(errs['loss_ref']))
     assert abs(gn - gn_ref) < 1e-3 * gn_ref
     assert n >= 95
+
+
+def test_postnet_class_training_mode_against_reference_golden(dev):
+    """The `Postnet` class in TRAINING mode (batch-statistics BatchNorm + nn.Dropout(0.5) after every block, src/module.py:53-82):
+    forward with the reference's recorded masks, the running statistics after the step, and the gradients of y.pow(2).sum()
+    against what the real reference produced (tools/gen_golden.py postnet_class_train_case)"""
+    from semi_tts_amd.module import Postnet
+    W, A, _ = load_golden('conv_postnet_train')
+    m = Postnet(8, 16, 5, 5, 0.5)
+    m.load_state_dict(W)
+    m = m.to(dev).train()
+    x = A['x'].to(dev).requires_grad_(True)
+    y = m(x, _masks=[t.to(dev) for t in A['masks']])
+    e_y = maxdiff(y, A['y'])
+    y.pow(2).sum().backward()
+    e_dx = maxdiff(x.grad, A['dx'])
+    sd = m.state_dict()
+    e_run = max(maxdiff(sd[k].float(), v.float()) for k, v in A['after'].items())
+    scale = max(float(v.abs().max()) for v in A['grad'].values())
+    e_g = max(maxdiff(p.grad, A['grad'][k]) for k, p in m.named_parameters())
+    report('postnet_class_train', err_y=e_y, err_dx=e_dx, err_running=e_run, err_grad=e_g, grad_scale=scale)
+    assert e_y < 2e-5 and e_run < 1e-5
+    assert e_dx < 2e-4 * max(1.0, float(A['dx'].abs().max())) and e_g < 2e-4 * max(1.0, scale)
+    # without explicit masks the module draws its own (device RNG): finite, and about half of the last block's outputs dropped
+    y2 = m(A['x'].to(dev))
+    assert bool(torch.isfinite(y2).all()) and 0.3 < float((y2 == 0).float().mean()) < 0.7

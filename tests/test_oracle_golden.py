@@ -115,7 +115,8 @@ def test_vq_mean_forward():
         assert np.abs(lat - A['out%d' % ci].numpy()).max() < 1e-6
 
 
-@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train', 'asr_tiny_ln_eval', 'asr_tiny_ln_train'])
+@pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train', 'asr_tiny_ln_eval', 'asr_tiny_ln_train', 'asr_tiny_uni_eval',
+                                  'asr_tiny_uni_train'])
 def test_asr_oracle_against_reference(name):
     from oracle import asr_oracle as AO
     W, A, meta = load_golden(name)

@@ -247,6 +247,29 @@ def postnet_class_case():
     save('conv_postnet_tiny', dict(m.state_dict()), dict(x=x, y=y), {})
 
 
+def postnet_class_train_case():
+    """the Postnet class in TRAINING mode (batch-statistics BatchNorm, nn.Dropout(0.5) after every block, src/module.py:73): masks
+    recorded in the reference's (B, C, T) layout, output, running statistics after the step, and the gradients of y.pow(2).sum()"""
+    torch.manual_seed(35)
+    m = RefPostnet(8, 16, 5, 5, 0.5).train()
+    g = torch.Generator().manual_seed(36)
+    with torch.no_grad():
+        randomize_buffers(m, g)
+    w0 = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(3, 13, 8, generator=g).requires_grad_(True)
+    with Recorder() as rec:
+        y = m(x)
+    y.pow(2).sum().backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    arrays = dict(x=x.detach(), y=y.detach(), dx=x.grad.clone(), masks=[t.transpose(1, 2).contiguous() for t in rec.masks])
+    for k, v in grads.items():
+        arrays['grad/' + k] = v
+    for k, v in m.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            arrays['after/' + k] = v.clone()
+    save('conv_postnet_train', w0, arrays, {})
+
+
 def loss_case():
     g = torch.Generator().manual_seed(41)
     pm, lm = torch.rand(2, 12, 80, generator=g), torch.rand(2, 12, 80, generator=g)
@@ -582,6 +605,30 @@ def asr_cases():
             arrays['post'] = list(post.values())
             arrays['post_keys'] = np.frombuffer(json.dumps(list(post)).encode(), np.uint8)
         save(name, w0, arrays, dict(cfg=cfg, in_dim=8, out_dim=10, training=training))
+    # unidirectional LSTM (rnn_bid: False, src/asr.py:35-37) with LayerNorm: eval, and training mode with dropout 0 plus the
+    # reference's own gradients for a recorded output gradient
+    for name, training, dropout, seed in (('asr_tiny_uni_eval', False, 0.5, 57), ('asr_tiny_uni_train', True, 0.0, 58)):
+        torch.manual_seed(seed)
+        cfg = dict(base, dropout=dropout, layer_norm=True, rnn_bid=False)
+        m = RefCTC(8, 10, **cfg)
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            randomize_buffers(m, g)
+        m.train(training)
+        w0 = {k: v.clone() for k, v in m.state_dict().items()}
+        x = torch.rand(3, 14, 8, generator=g).requires_grad_(training)
+        y = m(x)
+        arrays = dict(x=x.detach(), y=y.detach())
+        if training:
+            dy = torch.randn(y.shape, generator=g)
+            y.backward(dy)
+            arrays.update(dy=dy, dx=x.grad)
+            for k, p_ in m.named_parameters():
+                arrays['grad/' + k] = p_.grad
+            post = {k: v for k, v in m.state_dict().items() if 'running_' in k}
+            arrays['post'] = list(post.values())
+            arrays['post_keys'] = np.frombuffer(json.dumps(list(post)).encode(), np.uint8)
+        save(name, w0, arrays, dict(cfg=cfg, in_dim=8, out_dim=10, training=training))
     # ASRPostnet (src/asr.py:67-80): eval mode (its two dropouts of 0.5 are drawn inside torch in training mode)
     from src.asr import ASRPostnet as RefPost
     torch.manual_seed(55)
@@ -690,6 +737,7 @@ def main():
         mean_forward_case()
     if 'misc' in which:
         postnet_class_case()
+        postnet_class_train_case()
         loss_case()
     if 'full' in which:
         full_size_case()

@@ -357,10 +357,17 @@ int st_log_softmax_bwd(const float* dy, const float* y, float* dx, int M, int N,
 /* One normalised prenet layer of a decode step after its Linear (the reference's Linear wrapper with norm_type, applied to the
  * (B, P) rows of ONE step: src/module.py:192,:508-521,:337-339): dst (T16) = relu(norm(y)) * mask.
  * mode 1: LayerNorm over the P columns; mode 2: BatchNorm1d with running statistics (eval); mode 3: BatchNorm1d with the
- * statistics of the step's B rows, running statistics updated in place (momentum, unbiased variance), batches_tracked += 1. */
+ * statistics of the step's rows, running statistics updated in place (momentum, unbiased variance), batches_tracked += 1.
+ * Rows b0 .. B-1 are normalised and written (y, mask and dst are indexed by the absolute row): with a partial teacher the
+ * reference's prenet sees the rows WITHOUT a teacher only (src/module.py:197-198,205-206), which is the batch of its BatchNorm1d. */
 int st_prenet_norm_fwd(const float* y, int ldy, int mode, const float* gamma, const float* beta, float* run_mean,
                        float* run_var, long long* batches_tracked, float eps, float momentum, const float* mask, int ldmask,
-                       const st_t16_view* dst, int B, int P, void* stream);
+                       const st_t16_view* dst, int b0, int B, int P, void* stream);
+/* Backward of that layer, in place: dn (rows, P) = gradient at the norm's output (ReLU / mask backward applied) -> gradient at the
+ * Linear's output y (rows, P); this step's sums are ADDED to dgamma / dbeta (P).  Statistics are recomputed from y (mode 2: the
+ * running ones).  What torch autograd derives for nn.LayerNorm / nn.BatchNorm1d on a (rows, P) input. */
+int st_prenet_norm_bwd(float* dn, int ld, const float* y, int ldy, int mode, const float* gamma, const float* run_mean,
+                       const float* run_var, float eps, float* dgamma, float* dbeta, int rows, int P, void* stream);
 /* X(m, coff+n) = act((X - mean) / sqrt(var + eps) * w + b), in place */
 int st_bn_apply(float* X, int ldx, int coff, int M, int N, const float* mean, const float* var,
                 const float* w, const float* b, float eps, int act, void* stream);
@@ -658,6 +665,8 @@ typedef struct st_decoder_io {
                                         * read by the caller after the forward -- a time-out is an ERROR, not a NaN to find later */
     int pair_cells;                    /* != 0 (with defer_proj, i.e. pure teacher forcing): the decoder cell of step t and the query cell of
                                         * step t+1 share one launch (st_lstm_cell_packed_pair_fwd) -- neither needs the other's output */
+    float* pre_nat_tape;               /* optional (steps, 2, B, P): with prenet_norm, the Linear outputs of both prenet layers of every
+                                        * own-output feedback are kept here (instead of pre_nat) for the backward */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);
@@ -749,6 +758,14 @@ typedef struct st_decoder_bwd_io {
     int overlap_attn;                 /* != 0 (with fuse_pw and attn_s_tape): the decoder cell's product of step t-1 and the attention backward
                                        * of step t share one launch -- the decoder cell's recurrence runs one step ahead of the attention /
                                        * query chain (3 launches per step on the critical path instead of 4) */
+    /* own-output feedback through a NORMALISED prenet (st_decoder_dims.prenet_norm of the forward; 0 = plain): the forward's
+     * pre_nat_tape, the norm weights (and, mode 2, running statistics) of the two layers, and (P) accumulators for their gradients,
+     * zero on entry.  d2_tape / dp1_tape then hold the gradients at the two Linear outputs. */
+    int prenet_norm;
+    const float* pre_y_tape;          /* (steps, 2, B, P) */
+    const float* pre_norm_w[2]; const float* pre_norm_rm[2]; const float* pre_norm_rv[2];
+    float pre_norm_eps;
+    float* dpre_norm_w[2]; float* dpre_norm_b[2];
 } st_decoder_bwd_io;
 /* st_attn_step_bwd with S = pm + W_l loc of the step given (s_in, (B,L,A)): loc_t is not written (may be NULL) */
 int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,

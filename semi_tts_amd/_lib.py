@@ -71,7 +71,7 @@ class StDecoderIO(C.Structure):
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p),
                 ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p),
                 ('dec_in0', C.c_void_p), ('pre_nat', C.c_void_p), ('attn_xchg', C.c_void_p), ('handoff_status', C.c_void_p),
-                ('pair_cells', C.c_int)]
+                ('pair_cells', C.c_int), ('pre_nat_tape', C.c_void_p)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -90,7 +90,9 @@ class StDecoderBwdIO(C.Structure):
                 [(n, C.c_void_p) for n in ('dY', 'dxo_rw', 'wpg_t', 'pre_w1_t', 'pre_w0_t', 'own_mask', 'xq_nat', 'pre1_nat',
                                            'd2_tape', 'dp1_tape', 'tmp_p', 'tmp_in')] +
                 [('fuse_pw', C.c_int), ('dgd_t16_b', C.c_void_p), ('dpq_t16', C.c_void_p), ('need_dxq0', C.c_int), ('attn_s_tape', C.c_void_p),
-                 ('overlap_attn', C.c_int)])
+                 ('overlap_attn', C.c_int), ('prenet_norm', C.c_int), ('pre_y_tape', C.c_void_p), ('pre_norm_w', C.c_void_p * 2),
+                 ('pre_norm_rm', C.c_void_p * 2), ('pre_norm_rv', C.c_void_p * 2), ('pre_norm_eps', C.c_float),
+                 ('dpre_norm_w', C.c_void_p * 2), ('dpre_norm_b', C.c_void_p * 2)])
 
 
 
@@ -205,7 +207,8 @@ SIGNATURES = {
     'st_layer_norm_bwd': [P, I, P, I, P, P, P, P, I, P, I, I, P],
     'st_log_softmax_fwd': [P, P, I, I, P],
     'st_log_softmax_bwd': [P, P, P, I, I, P],
-    'st_prenet_norm_fwd': [P, I, I, P, P, P, P, P, F, F, P, I, C.POINTER(StT16View), I, I, P],
+    'st_prenet_norm_fwd': [P, I, I, P, P, P, P, P, F, F, P, I, C.POINTER(StT16View), I, I, I, P],
+    'st_prenet_norm_bwd': [P, I, P, I, I, P, P, P, F, P, P, I, I, P],
     'st_handoff_wait_selftest': [P, C.c_uint, I, P, P, I, P],
     'st_query_attn_rng_fits': [I, I, I],
     'st_attn_rng_xchg_words': [I, I, I],

@@ -626,7 +626,8 @@ class _DecoderFn(Function):
         dec, plan, tapes = ctx.dec, ctx.plan, ctx.tapes
         memory, pm, ada_std, ada_mean, teacher_pre, align, mel_fwd = ctx.saved_tensors[:7]
         (pre_w0, pre_w1, q_w_ih, q_w_hh, q_b_ih, q_b_hh, wq, v, wc, wl, d_w_ih, d_w_hh, d_b_ih, d_b_hh,
-         proj_w, proj_b, gate_w, gate_b) = ctx.saved_tensors[7:]
+         proj_w, proj_b, gate_w, gate_b) = ctx.saved_tensors[7:25]
+        pre_norm = ctx.saved_tensors[25:]          # normalised prenet: (weight, bias) of the two norms
         steps, src, Bt = plan['steps'], plan['step_src'], plan['Bt']
         B, L, E = memory.shape
         r, n_mels, P = dec.n_frames_per_step, dec.n_mels, dec.prenet_dim
@@ -728,6 +729,17 @@ class _DecoderFn(Function):
             io.pre_w1_t, io.pre_w0_t, io.own_mask = ops._p(wt['w1']), ops._p(wt['w0']), ops._p(own_mask)
             io.xq_nat, io.pre1_nat = ops._p(XQ), ops._p(pre1_nat)
             io.d2_tape, io.dp1_tape, io.tmp_p, io.tmp_in = ops._p(d2_tape), ops._p(dp1_tape), ops._p(tmp_p), ops._p(tmp_in)
+            if pre_norm:
+                # through LayerNorm / BatchNorm1d of the two prenet layers: d2_tape / dp1_tape end up holding the gradients at the Linear
+                # outputs (what dW1 / dW0 need); the norms' own gradients are summed over the steps by the loop
+                dnorm = z(4, P)                                         # d weight_0, d bias_0, d weight_1, d bias_1
+                io.prenet_norm, io.pre_y_tape = int(tapes['pn_mode']), ops._p(tapes['pre_y'])
+                for l, nm in enumerate(lyr.norm for lyr in dec.prenet.layers):
+                    io.pre_norm_w[l] = ops._p(pre_norm[2 * l])
+                    if tapes['pn_mode'] == 2:
+                        io.pre_norm_rm[l], io.pre_norm_rv[l] = ops._p(nm.running_mean), ops._p(nm.running_var)
+                    io.dpre_norm_w[l], io.dpre_norm_b[l] = ops._p(dnorm[2 * l]), ops._p(dnorm[2 * l + 1])
+                io.pre_norm_eps = float(dec.prenet.layers[0].norm.eps)
         _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
 
         # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)
@@ -781,6 +793,8 @@ class _DecoderFn(Function):
                  dwq_attn, dv, dwc, dwl,
                  c(dwd_cat[:, :E + Q]), c(dwd_cat[:, E + Q:]), dbd, dbd.clone(),
                  c(dwpg[:in_dim]), c(dbpg[:in_dim]), c(dwpg[in_dim:]), c(dbpg[in_dim:]))
+        if pre_norm:
+            grads += tuple(dnorm[i] for i in range(4)) if own else (None,) * 4
         ctx.tapes = None
         return grads
 
@@ -791,6 +805,9 @@ def decoder_loop(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, dec_in0=
               dec.attn.query_layer.linear.weight, dec.attn.v.linear.weight, *dec.attn.location_weights(),
               dec.dec_rnn.weight_ih, dec.dec_rnn.weight_hh, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh,
               dec.proj.linear.weight, dec.proj.linear.bias, dec.gate_layer.linear.weight, dec.gate_layer.linear.bias)
+    if dec.prenet_norm_type is not None:
+        for lyr in dec.prenet.layers:
+            params += (lyr.norm.weight, lyr.norm.bias)
     return _DecoderFn.apply(dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, dec_in0, *params)
 
 

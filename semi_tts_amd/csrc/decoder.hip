@@ -108,12 +108,16 @@ int prenet_own(const st_decoder_weights* w, const st_decoder_dims* d, const st_d
         const float* pw[2] = {io->packed + pl.p0, io->packed + pl.p1};
         const int Ks[2] = {16 * kb16(in_dim), 16 * kb16(d->P)};
         const float* ms[2] = {m1, m2};
+        // the rows that feed back: all of them on an own-output step, the ones without a teacher otherwise -- the batch of a
+        // BatchNorm1d step (the products run over every row; rows < b0 of the next input come from the teacher afterwards)
+        const int b0 = io->step_src[t] == -1 ? 0 : io->Bt;
         for (int l = 0; l < 2; ++l) {
-            rc = st_skinny_linear_packed_fwd(pw[l], srcs[l], Ks[l], nullptr, ST_ACT_NONE, nullptr, 0, io->pre_nat, d->P, nullptr, 0,
+            float* y = io->pre_nat_tape ? io->pre_nat_tape + ((size_t)t * 2 + l) * BP : io->pre_nat;
+            rc = st_skinny_linear_packed_fwd(pw[l], srcs[l], Ks[l], nullptr, ST_ACT_NONE, nullptr, 0, y, d->P, nullptr, 0,
                                              nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, d->B, d->P, stream);
             if (rc) return rc;
-            rc = st_prenet_norm_fwd(io->pre_nat, d->P, d->prenet_norm, w->pre_norm_w[l], w->pre_norm_b[l], w->pre_norm_rm[l], w->pre_norm_rv[l],
-                                    w->pre_norm_nbt[l], w->pre_norm_eps, w->pre_norm_momentum, ms[l], d->P, dsts[l], d->B, d->P, stream);
+            rc = st_prenet_norm_fwd(y, d->P, d->prenet_norm, w->pre_norm_w[l], w->pre_norm_b[l], w->pre_norm_rm[l], w->pre_norm_rv[l],
+                                    w->pre_norm_nbt[l], w->pre_norm_eps, w->pre_norm_momentum, ms[l], d->P, dsts[l], b0, d->B, d->P, stream);
             if (rc) return rc;
         }
         return 0;
@@ -414,6 +418,11 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             if (pure_tf) rc = 0;             // tiled for all steps before the loop
             else if (src >= 0) rc = st_tile_rows(io->teacher_pre + (size_t)src * P, io->Tt * P, &next, io->Bt, P, stream);
             else if (src == -2) rc = st_tile_rows(io->teacher_mean, P, &next, io->Bt, P, stream);
+            if (rc) return rc;
+        } else if (d->prenet_norm == 3 && (io->step_src[t] == -1 || io->Bt < B)) {
+            // the reference forms the next input after the LAST step too (:192,:197-198,:205-206).  Nothing reads it, but a training-mode
+            // BatchNorm1d moves its running statistics (and counts the batch) once more: same launches into slot `steps` of the tape
+            rc = prenet_own(w, d, io, pl, sv, t, false, stream);
             if (rc) return rc;
         }
     }

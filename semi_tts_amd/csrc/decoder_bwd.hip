@@ -68,6 +68,9 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
     ST_CHECK_ARG(!own || (io->dY && io->dxo_rw && io->wpg_t && io->pre_w1_t && io->pre_w0_t && io->xq_nat && io->pre1_nat &&
                           io->d2_tape && io->dp1_tape && io->tmp_p && io->tmp_in && io->Bt > 0 && io->Bt <= B),
                  "st_decoder_backward: own-output feedback needs the prenet tapes / scratch");
+    ST_CHECK_ARG(!own || !io->prenet_norm || (io->prenet_norm >= 1 && io->prenet_norm <= 3 && io->pre_y_tape && io->pre_norm_w[0] && io->pre_norm_w[1] &&
+                 io->dpre_norm_w[0] && io->dpre_norm_w[1] && io->dpre_norm_b[0] && io->dpre_norm_b[1]),
+                 "st_decoder_backward: own-output feedback through a normalised prenet needs pre_y_tape, the norm weights and the gradient accumulators");
     const bool packed = w->q_w_cat_t_p16 && w->d_w_cat_t_p16 && io->dgq_t16 && io->dgd_t16;
     st_t16_view dgq_v = {io->dgq_t16, (4 * Q + 15) >> 4, 0}, dgd_v = {io->dgd_t16, (4 * D + 15) >> 4, 0};
     const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
@@ -202,12 +205,24 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                 rc = st_act_bwd(dxq_next + (size_t)r0 * XQ, XQ, io->xq_nat + ((size_t)(t + 1) * Bp + r0) * XQ, XQ, ST_ACT_RELU,
                                 m2, P, d2, P, nr, P, stream);
                 if (rc) return rc;
+                if (io->prenet_norm) {     // through the norm of layer 2: d2 becomes the gradient at the Linear's output
+                    rc = st_prenet_norm_bwd(d2, P, io->pre_y_tape + (((size_t)t * 2 + 1) * B + r0) * P, P, io->prenet_norm, io->pre_norm_w[1],
+                                            io->pre_norm_rm[1], io->pre_norm_rv[1], io->pre_norm_eps, io->dpre_norm_w[1], io->dpre_norm_b[1],
+                                            nr, P, stream);
+                    if (rc) return rc;
+                }
                 st_seg sg;
                 sg.x = d2; sg.ldx = P; sg.w = io->pre_w1_t; sg.ldw = P; sg.k = P;
                 rc = st_skinny_linear_fwd(&sg, 1, nullptr, ST_ACT_NONE, nullptr, 0, io->tmp_p, P, 0, nullptr, 0, 0, nr, P, stream);
                 if (rc) return rc;
                 rc = st_act_bwd(io->tmp_p, P, io->pre1_nat + ((size_t)t * Bp + r0) * P, P, ST_ACT_RELU, m1, P, dp1, P, nr, P, stream);
                 if (rc) return rc;
+                if (io->prenet_norm) {
+                    rc = st_prenet_norm_bwd(dp1, P, io->pre_y_tape + (((size_t)t * 2 + 0) * B + r0) * P, P, io->prenet_norm, io->pre_norm_w[0],
+                                            io->pre_norm_rm[0], io->pre_norm_rv[0], io->pre_norm_eps, io->dpre_norm_w[0], io->dpre_norm_b[0],
+                                            nr, P, stream);
+                    if (rc) return rc;
+                }
                 sg.x = dp1; sg.ldx = P; sg.w = io->pre_w0_t; sg.ldw = P; sg.k = P;
                 rc = st_skinny_linear_fwd(&sg, 1, nullptr, ST_ACT_NONE, nullptr, 0, io->tmp_in, in_dim, 0, nullptr, 0, 0, nr, in_dim, stream);
                 if (rc) return rc;

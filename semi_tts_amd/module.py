@@ -480,10 +480,6 @@ class Decoder(nn.Module):
         plan = dict(steps=steps, step_src=step_src, Bt=Bt, Tt=Tt, masks=(own_mask, q_mask, d_mask),
                     teacher_mean=teacher_mean, dec_in0=dec_in0.detach() if dec_in0 is not None else None)
         if differentiable:
-            if uses_own and self.prenet_norm_type is not None:
-                # the loop's backward (decoder_bwd.hip) pushes the feedback gradient through relu(W x) * mask only
-                raise NotImplementedError('backward through own-output feedback (scheduled sampling / unpaired rows) with a '
-                                          'normalised prenet; teacher forcing (every shipped config) and the forward pass are built')
             mel, align, stop = AG.decoder_loop(self, plan, ctx_memory.contiguous(), pm, ada_std, ada_mean, teacher_pre, dec_in0)
             return mel, (align * 0.0 if self.pretrain else align), stop
         mel, align, stop, tapes = self._run_loop(plan, ctx_memory.contiguous(), pm, ada_std, ada_mean, teacher_pre, keep_tapes=False)
@@ -571,6 +567,10 @@ class Decoder(nn.Module):
         if pn_mode:
             tapes['pre_nat'] = torch.empty(B, P, **f32)
             io.pre_nat = ops._p(tapes['pre_nat'])
+            tapes['pn_mode'] = pn_mode
+            if keep_tapes:      # the Linear outputs of both layers of every own-output feedback: the norm backward starts from them
+                tapes['pre_y'] = torch.empty(steps, 2, B, P, **f32)
+                io.pre_nat_tape = ops._p(tapes['pre_y'])
         if plan.get('dec_in0') is not None:
             io.dec_in0 = ops._p(plan['dec_in0'])
         io.gates_q_tape, io.gates_d_tape = ops._p(tapes.get('gates_q')), ops._p(tapes.get('gates_d'))

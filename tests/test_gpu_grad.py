@@ -295,7 +295,9 @@ def _double_masks(masks):
 
 
 @pytest.mark.parametrize('name', ['tts_tiny_train_tf', 'tts_tiny_sched', 'tts_tiny_partial', 'tts_tiny_pretrain', 'tts_tiny_dropin',
-                                  'tts_tiny_noloc', 'tts_tiny_nosum', 'tts_tiny_encdrop', 'tts_tiny_preln_train', 'tts_tiny_prebn_train'])
+                                  'tts_tiny_noloc', 'tts_tiny_nosum', 'tts_tiny_encdrop', 'tts_tiny_preln_train', 'tts_tiny_prebn_train',
+                                  # own-output feedback through a normalised prenet (LayerNorm; BatchNorm1d over the fed-back rows of a step)
+                                  'tts_tiny_preln_sched', 'tts_tiny_prebn_sched', 'tts_tiny_prebn_partial'])
 def test_tacotron2_backward_against_oracle_tiny_golden(dev, name):
     """Whole Tacotron2 in training mode with the reference's recorded dropout masks and coin flips -- teacher forcing,
     scheduled sampling (own output fed back on some steps) and a partial-teacher batch (unpaired rows always feed their

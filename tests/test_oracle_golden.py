@@ -14,7 +14,8 @@ TTS_CASES = ['tts_tiny_infer', 'tts_tiny_infer_nodrop', 'tts_tiny_train_tf', 'tt
              'tts_tiny_concat', 'tts_tiny_add', 'tts_tiny_pretrain', 'tts_tiny_enc2', 'tts_tiny_dropin', 'tts_tiny_noloc',
              'tts_tiny_nosum', 'tts_tiny_encdrop',
              # normalised prenet (prenet_norm_type LayerNorm / BatchNorm1d: eval, teacher-forced training, scheduled sampling)
-             'tts_tiny_preln_infer', 'tts_tiny_preln_train', 'tts_tiny_prebn_infer', 'tts_tiny_prebn_train', 'tts_tiny_prebn_sched']
+             'tts_tiny_preln_infer', 'tts_tiny_preln_train', 'tts_tiny_prebn_infer', 'tts_tiny_prebn_train', 'tts_tiny_prebn_sched',
+             'tts_tiny_preln_sched', 'tts_tiny_prebn_partial']
 
 
 def _coin_source(coins):

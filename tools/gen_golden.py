@@ -716,6 +716,11 @@ def main():
         tts_case('tts_tiny_prebn_infer', 43, B=3, L=7, teacher=12, tf_rate=0.0, training=False, prenet_norm_type='BatchNorm1d')
         tts_case('tts_tiny_prebn_train', 44, B=4, L=6, teacher=(12,), tf_rate=1.0, training=True, prenet_norm_type='BatchNorm1d')
         tts_case('tts_tiny_prebn_sched', 45, B=4, L=6, teacher=(12,), tf_rate=0.5, training=True, prenet_norm_type='BatchNorm1d')
+        # own-output feedback through a normalised prenet: LayerNorm with scheduled sampling; BatchNorm1d whose batch of a step is
+        # the rows WITHOUT a teacher only (src/module.py:197-198,205-206: prenet(mel_out[teacher_bs:]))
+        tts_case('tts_tiny_preln_sched', 46, B=3, L=6, teacher=(12,), tf_rate=0.5, training=True, prenet_norm_type='LayerNorm')
+        tts_case('tts_tiny_prebn_partial', 47, B=5, L=6, teacher=(9,), tf_rate=1.0, training=True, teacher_bs=2,
+                 unpair_max_frame=12, prenet_norm_type='BatchNorm1d')
     if 'tts' in which:
         # eval-mode free-running inference, prenet dropout active (always-on), masks recorded
         tts_case('tts_tiny_infer', 1, B=2, L=7, teacher=15, tf_rate=0.0, training=False)

@@ -41,12 +41,13 @@ __global__ __launch_bounds__(512) void gru_seq_quad_kernel(const GruArgs a) {
     const bool row_ok = j < H && g < 3;
     float wreg[HP];
     float bh;
-    {   // branch-free: idle lanes and columns past H read a valid address and are zeroed by a select
+    {   // branch-free: idle lanes and columns past H read a valid address and are zeroed by a 0 / 1 factor (a select on a loaded value
+        // becomes a branch around the load with a full wait behind it)
+        const float rok = row_ok ? 1.0f : 0.0f;
         const float* wr = a.w_hh[d] + (size_t)(row_ok ? g * H + j : 0) * H;
-        const float bv = a.b_hh[d][row_ok ? g * H + j : 0];
-        bh = row_ok ? bv : 0.0f;
+        bh = a.b_hh[d][row_ok ? g * H + j : 0] * rok;
 #pragma unroll
-        for (int k = 0; k < HP; ++k) { const float w = wr[k < H ? k : H - 1]; wreg[k] = (row_ok && k < H) ? w : 0.0f; }
+        for (int k = 0; k < HP; ++k) wreg[k] = wr[k < H ? k : H - 1] * (k < H ? rok : 0.0f);
     }
     for (int k = tid; k < 2 * HP; k += blockDim.x) lds[k] = 0.0f;
     __syncthreads();
@@ -61,10 +62,11 @@ __global__ __launch_bounds__(512) void gru_seq_quad_kernel(const GruArgs a) {
 #pragma unroll
         for (int i = 0; i < GRU_PB; ++i) {
             const int s = s0 + i;
-            const int tt = min(d ? T - 1 - s : s, T - 1);
-            const bool on = upd && s < T;
-            const float* p = gi + (size_t)(on ? max(tt, 0) : 0) * H3 + (on ? j : 0);
-            dst[i][0] = p[0]; dst[i][1] = p[on ? H : 0]; dst[i][2] = p[on ? 2 * H : 0];       // (idle lanes re-read one valid address)
+            const int tt = max(min(d ? T - 1 - s : s, T - 1), 0);
+            // every lane reads three valid addresses (idle lanes and steps past T: values nobody uses).  No condition on the loads: a
+            // `cond ? p[H] : p[0]` becomes a branch with a full s_waitcnt per step, and the "prefetch" is eight serial round trips
+            const float* p = gi + (size_t)tt * H3 + (upd ? j : 0);
+            dst[i][0] = p[0]; dst[i][1] = p[H]; dst[i][2] = p[2 * H];
         }
     };
     load_block(cur, 0);
@@ -131,13 +133,18 @@ __global__ __launch_bounds__(256) void gru_seq_tri_kernel(const GruArgs a) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 wreg[3][GRU_SL / 2];           // (pairs of adjacent columns: the multiply-adds are v_pk_fma_f32 -- a lone wave issues one VALU
     float bh[3];                         //  instruction per ~5 cycles, so halving their count is what shortens the phase)
-    {   // branch-free: idle lanes and columns past H read a valid address and are zeroed by a select
+    {   // branch-free: idle lanes and columns past H read a valid address and are zeroed by a 0 / 1 FACTOR.  (Not by a select: the
+        // compiler turns `cond ? loaded : 0` into a branch around the load with a full s_waitcnt behind it -- 84 serialised round trips.)
+        const float uok = unit_ok ? 1.0f : 0.0f;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const float* wr = a.w_hh[d] + (size_t)(unit_ok ? g * H + j : 0) * H;
-            bh[g] = unit_ok ? a.b_hh[d][unit_ok ? g * H + j : 0] : 0.0f;
+            bh[g] = a.b_hh[d][unit_ok ? g * H + j : 0] * uok;
 #pragma unroll
-            for (int k = 0; k < GRU_SL; ++k) { const int col = GRU_SL * sl + k; const float w = wr[col < H ? col : H - 1]; wreg[g][k >> 1][k & 1] = (unit_ok && col < H) ? w : 0.0f; }
+            for (int k = 0; k < GRU_SL; ++k) {
+                const int col = GRU_SL * sl + k;
+                wreg[g][k >> 1][k & 1] = wr[col < H ? col : H - 1] * (col < H ? uok : 0.0f);
+            }
         }
     }
     for (int k = tid; k < 2 * 3 * GRU_SL; k += blockDim.x) (&hbuf[0][0])[k] = 0.0f;
@@ -150,10 +157,11 @@ __global__ __launch_bounds__(256) void gru_seq_tri_kernel(const GruArgs a) {
 #pragma unroll
         for (int i = 0; i < GRU_PB; ++i) {
             const int s = s0 + i;
-            const int tt = min(d ? T - 1 - s : s, T - 1);
-            const bool on = upd && s < T;
-            const float* p = gi + (size_t)(on ? max(tt, 0) : 0) * H3 + (on ? j : 0);
-            dst[i][0] = p[0]; dst[i][1] = p[on ? H : 0]; dst[i][2] = p[on ? 2 * H : 0];
+            const int tt = max(min(d ? T - 1 - s : s, T - 1), 0);
+            // every lane reads three valid addresses (idle lanes and steps past T: values nobody uses).  No condition on the loads: a
+            // `cond ? p[H] : p[0]` becomes a branch with a full s_waitcnt per step, and the "prefetch" is eight serial round trips
+            const float* p = gi + (size_t)tt * H3 + (upd ? j : 0);
+            dst[i][0] = p[0]; dst[i][1] = p[H]; dst[i][2] = p[2 * H];
         }
     };
     load_block(cur, 0);
@@ -513,11 +521,12 @@ __global__ __launch_bounds__(256) void lstm_seq2_persist_kernel(const LpArgs a) 
     bool dead = false;
     for (int s = 0; s < T; ++s) {
         const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1;
-        float pre[4] = {0.f, 0.f, 0.f, 0.f};
-        if (wave < RT) {      // does not depend on the recurrence: in flight during the wait
+        // the input projection of this step does not depend on the recurrence: in flight during the wait.  EVERY wave loads (waves past
+        // RT read a valid row and ignore it): with `pre = 0; if (wave < RT) load` the registers are zeroed first, and the compiler
+        // drains the memory counter in front of that -- the previous step's write-through h store had to be acknowledged before the poll
+        float pre[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pre[r] = xp[(size_t)t * 4 * H + r * H];
-        }
+        for (int r = 0; r < 4; ++r) pre[r] = xp[(size_t)t * 4 * H + r * H];
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -543,21 +552,28 @@ __global__ __launch_bounds__(256) void lstm_seq2_persist_kernel(const LpArgs a) 
             // (b) the block itself with plain loads (shared through the L2 by the workgroups of an XCD).  A word that still holds the
             //     sentinel (the canary overtook a sibling store, or a line was cached half-written) sends the wave to (c)
             {
-                bool mine = true;
+                // ALL the loads first, then the checks, and those without short-circuit operators: with `mine = mine && x != ...` after
+                // each load the compiler emitted load, s_waitcnt vmcnt(0), compare, branch -- RT * NKB serialised L2 round trips per step
+                // (2.2 of the 4.3 us of a step at RT = 2, NKB = 4)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int i = 0; i < NKB; ++i) x[rt][i] = st_ld4(hp[rt] + (size_t)tp * a.ldo + 16 * i);
+                }
+                unsigned bad = 0;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
                     for (int i = 0; i < NKB; ++i) {
-                        x[rt][i] = st_ld4(hp[rt] + (size_t)tp * a.ldo + 16 * i);
-                        mine = mine && __float_as_uint(x[rt][i][0]) != LP_SENTINEL && __float_as_uint(x[rt][i][1]) != LP_SENTINEL &&
-                               __float_as_uint(x[rt][i][2]) != LP_SENTINEL && __float_as_uint(x[rt][i][3]) != LP_SENTINEL;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) bad |= (unsigned)(__float_as_uint(x[rt][i][c]) == LP_SENTINEL);
                     }
                 }
-                ok = __all(mine);
+                ok = __all(bad == 0);
             }
             // (c) agent-scope re-reads of the block until it is complete
             for (int sp = 0; sp < spins && !ok; ++sp) {
-                bool mine = true;
+                unsigned bad = 0;
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -566,11 +582,11 @@ __global__ __launch_bounds__(256) void lstm_seq2_persist_kernel(const LpArgs a) 
                         const unsigned long long lo = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned long long hi = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned u0 = (unsigned)lo, u1 = (unsigned)(lo >> 32), u2 = (unsigned)hi, u3 = (unsigned)(hi >> 32);
-                        mine = mine && u0 != LP_SENTINEL && u1 != LP_SENTINEL && u2 != LP_SENTINEL && u3 != LP_SENTINEL;
+                        bad |= (unsigned)(u0 == LP_SENTINEL) | (unsigned)(u1 == LP_SENTINEL) | (unsigned)(u2 == LP_SENTINEL) | (unsigned)(u3 == LP_SENTINEL);
                         x[rt][i] = f32x4{__uint_as_float(u0), __uint_as_float(u1), __uint_as_float(u2), __uint_as_float(u3)};
                     }
                 }
-                ok = __all(mine);
+                ok = __all(bad == 0);
                 if (ok) break;
                 __builtin_amdgcn_s_sleep(1);
             }

@@ -32,23 +32,31 @@ struct GmArgs {
     st_gemm_epilogue ep;
 };
 
-// epilogue of one output element (shared by the tile epilogue and the split-K finish)
-__device__ __forceinline__ float gm_epilogue_one(const st_gemm_epilogue& ep, float v, int m, int n, float bias, float bn_m, float bn_s, float bn_w,
-                                                 float bn_b) {
+// epilogue of one output element (shared by the tile epilogue and the split-K finish), in two halves: the element's optional
+// operands (residual / highway H / dropout mask) are FETCHED first -- for all elements of a thread, before any is consumed -- and
+// the arithmetic follows.  (As one function per element every operand was a load with a full s_waitcnt behind it: 16 elements x up
+// to three serial round trips per thread at the end of a tile.)
+__device__ __forceinline__ void gm_epilogue_fetch(const st_gemm_epilogue& ep, int m, int n, float& xr, float& xh, float& xm) {
+    xr = ep.res ? ep.res[(size_t)m * ep.ldres + n] : 0.0f;
+    xh = ep.highway_h ? ep.highway_h[(size_t)m * ep.ldhw + n] : 0.0f;
+    xm = ep.mask ? ep.mask[(size_t)m * ep.ldmask + n] : 1.0f;
+}
+__device__ __forceinline__ float gm_epilogue_vals(const st_gemm_epilogue& ep, float v, float bias, float bn_m, float bn_s, float bn_w, float bn_b,
+                                                  float xr, float xh, float xm) {
     v += bias;
     v = st_act(v, ep.act_pre);
     if (ep.bn_mean) v = (v - bn_m) * bn_s * bn_w + bn_b;
     v = st_act(v, ep.act_post);
-    if (ep.highway_h) {
-        // Highway: y = H * T + x * (1 - T), v = T                (module.py:551-554)
-        const float hh = ep.highway_h[(size_t)m * ep.ldhw + n];
-        const float xx = ep.res[(size_t)m * ep.ldres + n];
-        v = st_highway(hh, v, xx);
-    } else if (ep.res) {
-        v += ep.res[(size_t)m * ep.ldres + n];
-    }
-    if (ep.mask) v *= ep.mask[(size_t)m * ep.ldmask + n];
+    if (ep.highway_h) v = st_highway(xh, v, xr);        // Highway: y = H * T + x * (1 - T), v = T                (module.py:551-554)
+    else if (ep.res) v += xr;
+    if (ep.mask) v *= xm;
     return v;
+}
+__device__ __forceinline__ float gm_epilogue_one(const st_gemm_epilogue& ep, float v, int m, int n, float bias, float bn_m, float bn_s, float bn_w,
+                                                 float bn_b) {
+    float xr, xh, xm;
+    gm_epilogue_fetch(ep, m, n, xr, xh, xm);
+    return gm_epilogue_vals(ep, v, bias, bn_m, bn_s, bn_w, bn_b, xr, xh, xm);
 }
 
 // epilogue of the GEMM kernels: D[row = 4*(lane>>4) + r][col = lane&15] of the wave's MT x NT sub-tiles whose first element is (mb, nb)
@@ -119,18 +127,21 @@ __global__ __launch_bounds__(256) void gm_splitk_finish_kernel(const GmArgs g, i
             for (int z = 1; z < S; ++z) s0 += g.split_ws[(size_t)z * total + i];
             v[0] = s0;
         }
+        // every operand of the W elements is requested before any is consumed (one exposed latency instead of ~4 per column)
+        float pb[W], pm[W], pv[W], pw[W], pbb[W], xr[W], xh[W], xm[W];
 #pragma unroll
         for (int c = 0; c < W; ++c) {
             const int n = n0 + c;
-            float bn_m = 0.f, bn_s = 1.f, bn_w = 1.f, bn_b = 0.f;
-            if (ep.bn_mean) {
-                bn_m = ep.bn_mean[n];
-                bn_s = 1.0f / sqrtf(ep.bn_var[n] + ep.bn_eps);
-                bn_w = ep.bn_w ? ep.bn_w[n] : 1.0f;
-                bn_b = ep.bn_b ? ep.bn_b[n] : 0.0f;
-            }
-            v[c] = gm_epilogue_one(ep, v[c], m, n, ep.bias ? ep.bias[n] : 0.0f, bn_m, bn_s, bn_w, bn_b);
+            pb[c] = ep.bias ? ep.bias[n] : 0.0f;
+            pm[c] = ep.bn_mean ? ep.bn_mean[n] : 0.0f;
+            pv[c] = ep.bn_mean ? ep.bn_var[n] : 1.0f;
+            pw[c] = (ep.bn_mean && ep.bn_w) ? ep.bn_w[n] : 1.0f;
+            pbb[c] = (ep.bn_mean && ep.bn_b) ? ep.bn_b[n] : 0.0f;
+            gm_epilogue_fetch(ep, m, n, xr[c], xh[c], xm[c]);
         }
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+            v[c] = gm_epilogue_vals(ep, v[c], pb[c], pm[c], ep.bn_mean ? 1.0f / sqrtf(pv[c] + ep.bn_eps) : 1.0f, pw[c], pbb[c], xr[c], xh[c], xm[c]);
         float* cp = g.C + (size_t)m * g.ldc + g.coff + n0;
         if (VEC4 && st_aligned16(cp)) *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[VEC4 ? 1 : 0], v[VEC4 ? 2 : 0], v[VEC4 ? 3 : 0]};
         else {
@@ -501,6 +512,21 @@ __device__ __forceinline__ void gd_body(const GmArgs& g, float* __restrict__ lds
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[h][mt][cc], b4[h][nt][cc], acc[mt][nt], 0, 0, 0);
     };
+    // the per-column epilogue parameters of this lane's NT columns are requested BEFORE the product (they are older than every DMA
+    // request, so the counted waits below still hold) and consumed after it: in the epilogue each was a load with a full wait
+    // behind it (bias, mean, var -> rsqrt, weight, bias: ~6 serial round trips per workgroup at the end of a one-tile launch)
+    const st_gemm_epilogue& ep = g.ep;
+    const int nb = n0 + wn * 16 * NT + NT * fr;
+    float bias[NT], bn_m[NT], bn_v[NT], bn_w[NT], bn_b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(nb + nt, g.N - 1);
+        bias[nt] = ep.bias ? ep.bias[n] : 0.0f;
+        bn_m[nt] = ep.bn_mean ? ep.bn_mean[n] : 0.0f;
+        bn_v[nt] = ep.bn_mean ? ep.bn_var[n] : 1.0f;
+        bn_w[nt] = (ep.bn_mean && ep.bn_w) ? ep.bn_w[n] : 1.0f;
+        bn_b[nt] = (ep.bn_mean && ep.bn_b) ? ep.bn_b[n] : 0.0f;
+    }
     issue(0);
     issue(1);
     int bi = 0, bn = 2;
@@ -514,8 +540,6 @@ __device__ __forceinline__ void gd_body(const GmArgs& g, float* __restrict__ lds
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (the two requests past the end: zeros into buffers nobody reads)
     // epilogue: lane (fr, fq) holds rows 4 fq + e of each row tile and the NT consecutive columns nb .. nb + NT - 1
-    const st_gemm_epilogue& ep = g.ep;
-    const int nb = n0 + wn * 16 * NT + NT * fr;
     if (g.kb_per_split > 0) {                      // split-K: the raw partial product
         float* ws = g.split_ws + (size_t)blockIdx.z * g.M * g.N;
         const bool vec = NT == 2 && g.N % 2 == 0 && nb + 1 < g.N;
@@ -534,20 +558,28 @@ __device__ __forceinline__ void gd_body(const GmArgs& g, float* __restrict__ lds
             }
         return;
     }
-    float bias[NT], bn_m[NT], bn_s[NT], bn_w[NT], bn_b[NT];
+    float bn_s[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = min(nb + nt, g.N - 1);
-        bias[nt] = ep.bias ? ep.bias[n] : 0.0f;
-        bn_m[nt] = 0.f; bn_s[nt] = 1.f; bn_w[nt] = 1.f; bn_b[nt] = 0.f;
-        if (ep.bn_mean) {
-            bn_m[nt] = ep.bn_mean[n];
-            bn_s[nt] = 1.0f / sqrtf(ep.bn_var[n] + ep.bn_eps);
-            bn_w[nt] = ep.bn_w ? ep.bn_w[n] : 1.0f;
-            bn_b[nt] = ep.bn_b ? ep.bn_b[n] : 0.0f;
-        }
-    }
+    for (int nt = 0; nt < NT; ++nt) bn_s[nt] = ep.bn_mean ? 1.0f / sqrtf(bn_v[nt] + ep.bn_eps) : 1.0f;
     const bool vec = NT == 2 && nb + 1 < g.N && ((g.ldc | g.coff) & 1) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 7) == 0;
+    // the optional per-element operands of ALL the lane's elements first (clamped addresses: rows / columns past the edge re-read a valid one)
+    float xr[MT][4][NT], xh[MT][4][NT], xm[MT][4][NT];
+    if (ep.res || ep.highway_h || ep.mask) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    gm_epilogue_fetch(ep, min(m0 + wm * 16 * MT + mt * 16 + 4 * fq + e, g.M - 1), min(nb + nt, g.N - 1), xr[mt][e][nt], xh[mt][e][nt], xm[mt][e][nt]);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { xr[mt][e][nt] = 0.0f; xh[mt][e][nt] = 0.0f; xm[mt][e][nt] = 1.0f; }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -556,7 +588,9 @@ __device__ __forceinline__ void gd_body(const GmArgs& g, float* __restrict__ lds
             if (m >= g.M) continue;
             float v[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) v[nt] = nb + nt < g.N ? gm_epilogue_one(ep, acc[mt][nt][e], m, nb + nt, bias[nt], bn_m[nt], bn_s[nt], bn_w[nt], bn_b[nt]) : 0.0f;
+            for (int nt = 0; nt < NT; ++nt)
+                v[nt] = nb + nt < g.N ? gm_epilogue_vals(ep, acc[mt][nt][e], bias[nt], bn_m[nt], bn_s[nt], bn_w[nt], bn_b[nt], xr[mt][e][nt], xh[mt][e][nt],
+                                                         xm[mt][e][nt]) : 0.0f;
             float* p = g.C + (size_t)m * g.ldc + g.coff + nb;
             if (vec) { typedef float f32x2 __attribute__((ext_vector_type(2))); *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[NT - 1]}; }
             else {
@@ -760,9 +794,9 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, 
         const int ch = cl + j * CL;
         const bool in = ch < chunks;
         const int chc = in ? ch : 0;
-        mu[j] = pm[(size_t)chc * cs]; m2[j] = pm[(size_t)chc * cs + N];
+        // (absent chunks re-read chunk 0 and are zeroed by a FACTOR: `if (!in) m2 = 0` makes the compiler branch around the load and wait)
+        mu[j] = pm[(size_t)chc * cs]; m2[j] = pm[(size_t)chc * cs + N] * (in ? 1.0f : 0.0f);
         cnt[j] = in ? (float)max(min(M, (ch + 1) * rows_per_chunk) - ch * rows_per_chunk, 0) : 0.0f;
-        if (!in) m2[j] = 0.0f;
     }
     float a = 0.f;
 #pragma unroll

@@ -323,11 +323,11 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const Gru
     const float* __restrict__ whh = a.w_hh[d];
     float wreg[REG ? 4 * KQ : 4];
     if (REG) {
+        // branch-free: clamped address, zeroed by a 0 / 1 factor (a select on the loaded value becomes a branch around the load with a
+        // full wait behind it: 4 KQ serialised round trips, a quarter of this kernel's time at T = 258)
+        const float rok = row_ok ? 1.0f : 0.0f;
 #pragma unroll
-        for (int jj = 0; jj < 4 * KQ; ++jj) {        // branch-free: clamped address, zeroed by a select
-            const float w = whh[(size_t)(g * H + (jj < H ? jj : H - 1)) * H + k];
-            wreg[jj] = (row_ok && jj < H) ? w : 0.0f;
-        }
+        for (int jj = 0; jj < 4 * KQ; ++jj) wreg[jj] = whh[(size_t)(g * H + (jj < H ? jj : H - 1)) * H + k] * (jj < H ? rok : 0.0f);
     }
     for (int i = j; i < 3 * H4; i += blockDim.x) dghs[i] = 0.0f;
     if (j < H) dhc[j] = 0.0f;
@@ -338,56 +338,74 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const Gru
     const float* doutb = a.dout + (size_t)b * T * a.ldd + d * H;
     float* dgi = a.dgi[d] + (size_t)b * T * H3;
     float* dgh = a.dgh[d] + (size_t)b * T * H3;
-    // processing order of the forward was t = 0..T-1 (d = 0) or T-1..0 (d = 1); walk it backwards
-    int t = d ? 0 : T - 1;
-    float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, hp = 0.f, go = 0.f;
-    auto fetch = [&](int tt) {
-        const float* tp = tape + (size_t)tt * 4 * H + j;
-        r = tp[0]; z = tp[H]; n = tp[2 * H]; ghn = tp[3 * H];
-        const int tprev = d ? tt + 1 : tt - 1;
-        hp = (tprev >= 0 && tprev < T) ? outb[(size_t)tprev * a.ldo + j] : 0.0f;
-        go = doutb[(size_t)tt * a.ldd + j];
-    };
-    if (upd) fetch(t);
-    for (int s = 0; s < T; ++s) {
-        float dhp_direct = 0.0f;
-        if (upd) {
-            const float dh = dhc[j] + go;
-            const float dn = dh * (1.0f - z), dz = dh * (hp - n);
-            dhp_direct = dh * z;
-            const float dnp = dn * (1.0f - n * n);
-            const float dzp = dz * z * (1.0f - z);
-            const float drp = dnp * ghn * r * (1.0f - r);
-            float* gi_ = dgi + (size_t)t * H3 + j;
-            float* gh_ = dgh + (size_t)t * H3 + j;
-            gi_[0] = drp; gi_[H] = dzp; gi_[2 * H] = dnp;
-            gh_[0] = drp; gh_[H] = dzp; gh_[2 * H] = dnp * r;
-            dghs[j] = drp; dghs[H4 + j] = dzp; dghs[2 * H4 + j] = dnp * r;
-        }
-        st_lds_barrier();      // LDS-only (the next step's operand loads stay in flight)
-        const int tn = d ? t + 1 : t - 1;
-        if (upd && s + 1 < T) fetch(tn);        // next step's operands fly while the mat-vec runs
-        if (row_ok) {
-            float acc = 0.0f;
-            const float* dg = dghs + g * H4;
-            if (REG) {
-                float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // processing order of the forward was t = 0..T-1 (d = 0) or T-1..0 (d = 1); walk it backwards: step s handles t = T-1-s / s.
+    // The six operands of a step (r, z, n, W_hn h + b_hn, h_{t-1}, dout_t) are read GB_PB steps ahead, a block at a time, with
+    // unconditional loads from clamped addresses (see gru_seq_tri_kernel): a step is ~0.5 us, a first-touch load 1-2 us.
+    constexpr int GB_PB = 4;
+    float cur[GB_PB][6], nxt[GB_PB][6];
+    const int jc = upd ? j : 0;
+    auto load_block = [&](float (&dst)[GB_PB][6], int s0) __attribute__((always_inline)) {
 #pragma unroll
-                for (int jj = 0; jj < 4 * KQ; jj += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(dg + jj);
-                    acc = fmaf(wreg[jj], v[0], acc); a1 = fmaf(wreg[jj + 1], v[1], a1);
-                    a2 = fmaf(wreg[jj + 2], v[2], a2); a3 = fmaf(wreg[jj + 3], v[3], a3);
-                }
-                acc = (acc + a1) + (a2 + a3);
-            } else {
-                for (int jj = 0; jj < H; ++jj) acc = fmaf(whh[(size_t)(g * H + jj) * H + k], dg[jj], acc);
-            }
-            part[j] = acc;
+        for (int i = 0; i < GB_PB; ++i) {
+            const int s = min(s0 + i, T - 1);
+            const int tt = d ? s : T - 1 - s;
+            const float* tp = tape + (size_t)tt * 4 * H + jc;
+            dst[i][0] = tp[0]; dst[i][1] = tp[H]; dst[i][2] = tp[2 * H]; dst[i][3] = tp[3 * H];
+            const int tprev = d ? tt + 1 : tt - 1;
+            const bool inr = tprev >= 0 && tprev < T;
+            dst[i][4] = outb[(size_t)(inr ? tprev : tt) * a.ldo + jc] * (inr ? 1.0f : 0.0f);        // h before the first step is zero
+            dst[i][5] = doutb[(size_t)tt * a.ldd + jc];
         }
-        st_lds_barrier();      // LDS-only (the next step's operand loads stay in flight)
-        if (upd) dhc[j] = dhp_direct + part[j] + part[H + j] + part[2 * H + j];
-        st_lds_barrier();      // LDS-only (the next step's operand loads stay in flight)
-        t = tn;
+    };
+    load_block(cur, 0);
+    for (int s0 = 0; s0 < T; s0 += GB_PB) {
+        load_block(nxt, s0 + GB_PB);
+#pragma unroll
+        for (int i = 0; i < GB_PB; ++i) {
+            const int s = s0 + i;
+            if (s >= T) break;                                        // (uniform)
+            const int t = d ? s : T - 1 - s;
+            float dhp_direct = 0.0f;
+            if (upd) {
+                const float r = cur[i][0], z = cur[i][1], n = cur[i][2], ghn = cur[i][3], hp = cur[i][4], go = cur[i][5];
+                const float dh = dhc[j] + go;
+                const float dn = dh * (1.0f - z), dz = dh * (hp - n);
+                dhp_direct = dh * z;
+                const float dnp = dn * (1.0f - n * n);
+                const float dzp = dz * z * (1.0f - z);
+                const float drp = dnp * ghn * r * (1.0f - r);
+                float* gi_ = dgi + (size_t)t * H3 + j;
+                float* gh_ = dgh + (size_t)t * H3 + j;
+                gi_[0] = drp; gi_[H] = dzp; gi_[2 * H] = dnp;
+                gh_[0] = drp; gh_[H] = dzp; gh_[2 * H] = dnp * r;
+                dghs[j] = drp; dghs[H4 + j] = dzp; dghs[2 * H4 + j] = dnp * r;
+            }
+            st_lds_barrier();      // LDS-only (the next block's operand loads stay in flight)
+            if (row_ok) {
+                float acc = 0.0f;
+                const float* dg = dghs + g * H4;
+                if (REG) {
+                    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < 4 * KQ; jj += 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(dg + jj);
+                        acc = fmaf(wreg[jj], v[0], acc); a1 = fmaf(wreg[jj + 1], v[1], a1);
+                        a2 = fmaf(wreg[jj + 2], v[2], a2); a3 = fmaf(wreg[jj + 3], v[3], a3);
+                    }
+                    acc = (acc + a1) + (a2 + a3);
+                } else {
+                    for (int jj = 0; jj < H; ++jj) acc = fmaf(whh[(size_t)(g * H + jj) * H + k], dg[jj], acc);
+                }
+                part[j] = acc;
+            }
+            st_lds_barrier();
+            if (upd) dhc[j] = dhp_direct + part[j] + part[H + j] + part[2 * H + j];
+            st_lds_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < GB_PB; ++i)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) cur[i][c] = nxt[i][c];
     }
 }
 

@@ -409,6 +409,99 @@ __global__ __launch_bounds__(REG ? 384 : 1024) void gru_seq_bwd_kernel(const Gru
     }
 }
 
+// ---- the same for H <= 84 with the transposed mat-vec sliced like gru_seq_tri_kernel: the three gate blocks of output column k live in
+// three ADJACENT lanes (lane = 3u + g, column k = 21 wave + u), each with its 84 zero-padded weights W[g H + j][k] as 42 register
+// pairs (v_pk_fma_f32), the three partial sums meet on lane g = 0 through two DPP shifts, and THAT lane runs the pointwise part of
+// the next step: dh never goes through LDS, the step's 3 x H gate gradients do (two buffers, by step parity) -- ONE LDS-only barrier
+// per step instead of three (0.77 -> see DESIGN.md us per step at H = 80).
+constexpr int GB_LD = 84;
+__global__ __launch_bounds__(256) void gru_seq_bwd_tri_kernel(const GruBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float dgb[2][3 * GB_LD];
+    const int H = a.H, H3 = 3 * H, T = a.T;
+    const int b = blockIdx.x, d = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = lane / 3, g = lane - 3 * u, k = wave * 21 + u;
+    const bool unit_ok = lane < 63 && k < H;
+    const int kc = unit_ok ? k : 0;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 wreg[GB_LD / 2];
+    {
+        const float uok = unit_ok ? 1.0f : 0.0f;
+        const float* wc = a.w_hh[d] + (size_t)g * H * H + kc;           // column k of gate block g: W[g H + j][k], j = 0 .. H-1
+#pragma unroll
+        for (int jj = 0; jj < GB_LD; ++jj) wreg[jj >> 1][jj & 1] = wc[(size_t)(jj < H ? jj : H - 1) * H] * (jj < H ? uok : 0.0f);
+    }
+    for (int i = tid; i < 2 * 3 * GB_LD; i += blockDim.x) (&dgb[0][0])[i] = 0.0f;
+    __syncthreads();
+    const bool upd = unit_ok && g == 0;
+    const float* tape = a.tape + (((size_t)d * a.B + b) * T) * 4 * H;
+    const float* outb = a.out + (size_t)b * T * a.ldo + d * H;
+    const float* doutb = a.dout + (size_t)b * T * a.ldd + d * H;
+    float* dgi = a.dgi[d] + (size_t)b * T * H3;
+    float* dgh = a.dgh[d] + (size_t)b * T * H3;
+    constexpr int GB_PB = 4;
+    float cur[GB_PB][6], nxt[GB_PB][6];
+    const int jc = upd ? k : 0;
+    auto load_block = [&](float (&dst)[GB_PB][6], int s0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < GB_PB; ++i) {
+            const int s = min(s0 + i, T - 1);
+            const int tt = d ? s : T - 1 - s;
+            const float* tp = tape + (size_t)tt * 4 * H + jc;
+            dst[i][0] = tp[0]; dst[i][1] = tp[H]; dst[i][2] = tp[2 * H]; dst[i][3] = tp[3 * H];
+            const int tprev = d ? tt + 1 : tt - 1;
+            const bool inr = tprev >= 0 && tprev < T;
+            dst[i][4] = outb[(size_t)(inr ? tprev : tt) * a.ldo + jc] * (inr ? 1.0f : 0.0f);
+            dst[i][5] = doutb[(size_t)tt * a.ldd + jc];
+        }
+    };
+    load_block(cur, 0);
+    float dhc = 0.0f;                                   // dL/dh flowing into the step from the later ones (lane g = 0)
+    for (int s0 = 0; s0 < T; s0 += GB_PB) {
+        load_block(nxt, s0 + GB_PB);
+#pragma unroll
+        for (int i = 0; i < GB_PB; ++i) {
+            const int s = s0 + i;
+            if (s >= T) break;                                        // (uniform)
+            const int t = d ? s : T - 1 - s;
+            float* buf = dgb[s & 1];
+            float dhp_direct = 0.0f;
+            if (upd) {
+                const float r = cur[i][0], z = cur[i][1], n = cur[i][2], ghn = cur[i][3], hp = cur[i][4], go = cur[i][5];
+                const float dh = dhc + go;
+                const float dn = dh * (1.0f - z), dz = dh * (hp - n);
+                dhp_direct = dh * z;
+                const float dnp = dn * (1.0f - n * n);
+                const float dzp = dz * z * (1.0f - z);
+                const float drp = dnp * ghn * r * (1.0f - r);
+                float* gi_ = dgi + (size_t)t * H3 + k;
+                float* gh_ = dgh + (size_t)t * H3 + k;
+                gi_[0] = drp; gi_[H] = dzp; gi_[2 * H] = dnp;
+                gh_[0] = drp; gh_[H] = dzp; gh_[2 * H] = dnp * r;
+                buf[k] = drp; buf[GB_LD + k] = dzp; buf[2 * GB_LD + k] = dnp * r;
+            }
+            st_lds_barrier();      // LDS-only (the next block's operand loads stay in flight)
+            const float* dg = buf + g * GB_LD;
+            f32x4 hreg[GB_LD / 4];
+#pragma unroll
+            for (int q = 0; q < GB_LD / 4; ++q) hreg[q] = *reinterpret_cast<const f32x4*>(dg + 4 * q);
+            f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < GB_LD / 4; ++q) {
+                acc0 = __builtin_elementwise_fma(wreg[2 * q], f32x2{hreg[q][0], hreg[q][1]}, acc0);
+                acc1 = __builtin_elementwise_fma(wreg[2 * q + 1], f32x2{hreg[q][2], hreg[q][3]}, acc1);
+            }
+            const float part = (acc0.x + acc0.y) + (acc1.x + acc1.y);
+            const float p1 = st_dpp<0x130>(part), p2 = st_dpp<0x130>(p1);     // wave_shl:1 = the value of lane + 1: gates z, n of this column
+            dhc = dhp_direct + ((part + p1) + p2);
+        }
+#pragma unroll
+        for (int i = 0; i < GB_PB; ++i)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) cur[i][c] = nxt[i][c];
+    }
+}
+
 // ---- LSTM cell backward, pointwise part: from dh_t (sum of up to three addends, the third optionally scaled
 // element-wise, then the dropout mask) and the carried dc_t to the pre-activation gate gradients and dc_{t-1}.
 struct LstmPwArgs {
@@ -948,7 +1041,8 @@ extern "C" int st_gru_seq_bwd(const float* dout, int ldd, const float* out, int 
     const int hpad = H <= 80 ? 80 : (H <= GRU_HMAX ? GRU_HMAX : ((H + 3) & ~3));      // the REG forms pad the dgh rows to 4 KQ entries
     const size_t lds = (size_t)(3 * hpad + 3 * H + H) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (H <= 80) hipLaunchKernelGGL((gru_seq_bwd_kernel<true, 20>), dim3(B, ndir), dim3(threads), lds, st, a);
+    if (H <= GB_LD) hipLaunchKernelGGL(gru_seq_bwd_tri_kernel, dim3(B, ndir), dim3(256), 0, st, a);
+    else if (H <= 80) hipLaunchKernelGGL((gru_seq_bwd_kernel<true, 20>), dim3(B, ndir), dim3(threads), lds, st, a);
     else if (H <= GRU_HMAX) hipLaunchKernelGGL((gru_seq_bwd_kernel<true, 32>), dim3(B, ndir), dim3(threads), lds, st, a);
     else hipLaunchKernelGGL((gru_seq_bwd_kernel<false>), dim3(B, ndir), dim3(threads), lds, st, a);
     ST_LAUNCH_CHECK();

@@ -430,6 +430,12 @@ int st_bn_bwd_apply_sync(const float* dy, int ldd, int doff, const float* y, int
 /* Highway combine y = H*T + x*(1-T) and its backward dH = dy*T, dT = dy*(H-x), dx_direct = dy*(1-T)
  * ref: src/module.py:551-554 */
 int st_highway_fwd(const float* H, const float* Tgate, const float* x, float* y, size_t total, void* stream);
+/* One Highway layer on the PRE-activations of its two Linear layers side by side, ht (M, 2C) = [W_H x + b_H | W_T x + b_T] (one
+ * N = 2C product instead of two): y = relu(h) * sigmoid(t) + x * (1 - sigmoid(t)) (src/module.py:551-554), and its backward:
+ * dht (M, 2C) = gradients at the two pre-activations (the operand of ONE input-gradient product and ONE weight-gradient product),
+ * dx_direct (M, C) = dy * (1 - T). */
+int st_highway_ht_fwd(const float* ht, const float* x, float* y, int M, int C, void* stream);
+int st_highway_ht_bwd(const float* dy, const float* ht, const float* x, float* dht, float* dx_direct, int M, int C, void* stream);
 int st_highway_bwd(const float* dy, const float* H, const float* x, const float* Tgate,
                    float* dH, float* dT, float* dx_direct, size_t total, void* stream);
 /* y(b,t,:) = max(x(b,t-1,:), x(b,t,:)), y(b,0,:) = x(b,0,:): nn.MaxPool1d(2, stride=1, padding=1)(x)[:, :, :T] of the CBHG,
@@ -868,7 +874,9 @@ int st_fill(float* p, float v, size_t n, void* stream);
 typedef struct st_relayout_desc {
     const float* src; float* dst;
     int N, Cin, KT, mode;
-    int blk0, pad_;
+    int blk0;
+    int ld_dst;     /* mode 1 only: row stride of dst in floats (0 = N): the layout lands in a column block of a wider matrix (the
+                     * transposes of several Linear weights side by side = the weight of ONE input-gradient product) */
 } st_relayout_desc;
 int st_relayout_blocks(int N, int Cin, int KT);
 int st_relayout_batch(const st_relayout_desc* table_dev, int n, int total_blocks, void* stream);

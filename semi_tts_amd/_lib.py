@@ -39,7 +39,7 @@ class StGemmJob(C.Structure):
 
 class StRelayoutDesc(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('N', C.c_int), ('Cin', C.c_int), ('KT', C.c_int), ('mode', C.c_int),
-                ('blk0', C.c_int), ('pad_', C.c_int)]
+                ('blk0', C.c_int), ('ld_dst', C.c_int)]
 
 
 class StDecoderWeights(C.Structure):
@@ -258,6 +258,8 @@ SIGNATURES = {
     'st_bn_sync_merge': [P, I, I, P, P, P, P, F, P, P],
     'st_bn_bwd_apply_sync': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, P, P, I, I, P],
     'st_highway_fwd': [P, P, P, P, Z, P],
+    'st_highway_ht_fwd': [P, P, P, I, I, P],
+    'st_highway_ht_bwd': [P, P, P, P, P, I, I, P],
     'st_highway_bwd': [P, P, P, P, P, P, P, Z, P],
     'st_pool_prev_fwd': [P, P, I, I, I, P],
     'st_pool_prev_bwd': [P, P, P, I, I, I, P],

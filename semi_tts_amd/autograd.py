@@ -361,6 +361,36 @@ def highway_combine(H, Tg, x):
     return _HighwayFn.apply(H, Tg, x)
 
 
+class _HighwayLayerFn(Function):
+    """One Highway layer (src/module.py:541-555) with its two Linear layers as ONE product: [h | t] = x [W_H ; W_T]^T + [b_H | b_T]
+    (N = 2C), y = relu(h) sigmoid(t) + x (1 - sigmoid(t)).  Forward 2 launches (3 as two convs + combine), backward 4 (11): the
+    gradients at the two pre-activations leave one kernel side by side and feed one input-gradient product (K = 2C, the direct
+    path dy (1 - T) added in its epilogue) and one weight-gradient product (the two bias gradients in its launches)."""
+
+    @staticmethod
+    def forward(ctx, x, Hw, Hb, Tw, Tb):
+        lead = x.shape[:-1]
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        ht = ops.gemm(x2, ops.cat_params([Hw, Tw]), bias=ops.cat_params([Hb, Tb]))
+        ctx.save_for_backward(x2, ht, Hw, Tw)
+        ctx.lead = lead
+        return ops.highway_ht_fwd(ht, x2).view(*lead, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, ht, Hw, Tw = ctx.saved_tensors
+        Cn = x2.shape[1]
+        dht, dxd = ops.highway_ht_bwd(dy.contiguous().view(-1, Cn), ht, x2)
+        # dx = dht [W_H ; W_T] + dy (1 - T): the weight of that product is the (C, 2C) "Linear weight" [W_H^T | W_T^T]
+        dx = ops.gemm(dht, ops.cat_params([Hw.detach(), Tw.detach()], transposed=True), res=dxd)
+        dw, db = ops.gemm_wgrad(dht, x2, with_db=True)
+        return dx.view(*ctx.lead, Cn), dw[:Cn], db[:Cn], dw[Cn:], db[Cn:]
+
+
+def highway_layer(x, Hw, Hb, Tw, Tb):
+    return _HighwayLayerFn.apply(x, Hw, Hb, Tw, Tb)
+
+
 class _GatherFn(Function):
     """rows of a table (F.embedding, src/embed.py:97-101) with scatter-add backward"""
 

@@ -686,6 +686,29 @@ __global__ __launch_bounds__(256) void highway_fwd_kernel(const float* H, const 
     }
 }
 
+// One Highway layer on the pre-activations of its two Linear layers side by side, ht (M, 2C) = [h | t]   (see st_highway_ht_fwd)
+__global__ __launch_bounds__(256) void highway_ht_fwd_kernel(const float* __restrict__ ht, const float* __restrict__ x, float* __restrict__ y,
+                                                             int C, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / C;
+        const int c = (int)(i - m * C);
+        const float h = st_act(ht[m * 2 * C + c], ST_ACT_RELU), t = st_act(ht[m * 2 * C + C + c], ST_ACT_SIGMOID);
+        y[i] = st_highway(h, t, x[i]);
+    }
+}
+__global__ __launch_bounds__(256) void highway_ht_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ht, const float* __restrict__ x,
+                                                             float* __restrict__ dht, float* __restrict__ dxd, int C, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / C;
+        const int c = (int)(i - m * C);
+        const float h = st_act(ht[m * 2 * C + c], ST_ACT_RELU), t = st_act(ht[m * 2 * C + C + c], ST_ACT_SIGMOID);
+        const float g = dy[i];
+        dht[m * 2 * C + c] = (g * t) * act_grad(h, ST_ACT_RELU);                      // dH = dy T, through relu
+        dht[m * 2 * C + C + c] = (g * (h - x[i])) * act_grad(t, ST_ACT_SIGMOID);      // dT = dy (H - x), through sigmoid
+        dxd[i] = g * (1.0f - t);
+    }
+}
+
 // Re-layouts of MANY parameters in one launch (training re-lays every conv / linear weight out once per step: one launch instead of
 // one torch copy per weight and layout).  Workgroup b serves the descriptor d with blk0[d] <= b < blk0[d] + nblk[d]; a thread
 // writes four consecutive destination floats (one 16-byte store when aligned) gathered from the source.
@@ -718,6 +741,10 @@ __global__ __launch_bounds__(256) void relayout_batch_kernel(const st_relayout_d
             const int kt = (int)(r % d.KT), ci = (int)(r / d.KT);
             v[c] = d.src[((size_t)nn * d.Cin + ci) * d.KT + (d.KT - 1 - kt)];
         }
+    }
+    if (d.mode == 1 && d.ld_dst > d.N) {      // a column block of a wider matrix: row r = i / N of the layout starts at dst + r * ld_dst
+        for (int c = 0; c < 4 && i0 + c < total; ++c) { const size_t i = i0 + c; d.dst[(i / d.N) * d.ld_dst + (i % d.N)] = v[c]; }
+        return;
     }
     if (i0 + 4 <= total && st_aligned16(d.dst + i0)) *reinterpret_cast<f32x4*>(d.dst + i0) = f32x4{v[0], v[1], v[2], v[3]};
     else
@@ -928,6 +955,24 @@ extern "C" int st_highway_bwd(const float* dy, const float* H, const float* x, c
     ST_CHECK_ARG(dy && H && x && Tgate && dH && dT && dx_direct && total > 0, "st_highway_bwd: bad arguments");
     hipLaunchKernelGGL(highway_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        dy, H, x, Tgate, dH, dT, dx_direct, total);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_highway_ht_fwd(const float* ht, const float* x, float* y, int M, int C, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(ht && x && y && M > 0 && C > 0, "st_highway_ht_fwd: bad arguments");
+    const size_t total = (size_t)M * C;
+    hipLaunchKernelGGL(highway_ht_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, ht, x, y, C, total);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_highway_ht_bwd(const float* dy, const float* ht, const float* x, float* dht, float* dx_direct, int M, int C, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dy && ht && x && dht && dx_direct && M > 0 && C > 0, "st_highway_ht_bwd: bad arguments");
+    const size_t total = (size_t)M * C;
+    hipLaunchKernelGGL(highway_ht_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, dy, ht, x, dht, dx_direct, C, total);
     ST_LAUNCH_CHECK();
     return 0;
 }

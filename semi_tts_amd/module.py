@@ -673,9 +673,7 @@ class Highway(nn.Module):
 
     def forward(self, x):
         if self.training:
-            h = AG.conv(x, self.H.weight, self.H.bias, act='relu')
-            t = AG.conv(x, self.T.weight, self.T.bias, act='sigmoid')
-            return AG.highway_combine(h, t, x)
+            return AG.highway_layer(x, self.H.weight, self.H.bias, self.T.weight, self.T.bias)
         h = ops.gemm(x, self.H.weight, bias=self.H.bias, act_pre='relu')
         return ops.gemm(x, self.T.weight, bias=self.T.bias, act_pre='sigmoid', highway_h=h, res=x)
 

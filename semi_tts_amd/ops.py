@@ -240,7 +240,8 @@ class _ParamLayouts:
     MAX_ENTRIES = 1024
 
     def __init__(self):
-        self.entries = {}       # key -> [alias, dst, version, (N, Cin, KT), epoch of the last use, pinned]
+        self.entries = {}       # key -> [alias, dst, version, (N, Cin, KT), epoch of the last use, pinned(, row stride of dst)]
+        self.cats = {}          # key -> (dst, keys of its parts in `entries`): see get_cat
         self.table = None       # device descriptor table of the entries
         self.count = 0
         self.total_blocks = 0
@@ -272,6 +273,44 @@ class _ParamLayouts:
         self.refresh()
         return dst
 
+    def get_cat(self, ws, mode):
+        """Several parameters of equal Cin laid out side by side as ONE operand: mode 0 -> (sum N, Cin), their rows one after the other
+        (the weight of one forward product in place of len(ws); 1-D parameters: their concatenation); mode 1 -> (Cin, sum N), their
+        transposes as column blocks (the weight of one input-gradient product).  Same caching and the same single refresh launch as get()."""
+        key = (tuple(w.data_ptr() for w in ws), tuple(tuple(w.shape) for w in ws), mode, 'cat')
+        c = self.cats.get(key)
+        if c is not None and all(k in self.entries for k in c[1]):
+            stale = False
+            for k in c[1]:
+                e = self.entries[k]
+                e[4] = self.epoch
+                if capturing():
+                    e[5] = True
+                stale = stale or e[2] != e[0]._version
+            if stale:
+                self.epoch += 1
+                for k in c[1]:
+                    self.entries[k][4] = self.epoch
+                self.refresh()
+            return c[0]
+        one_d = ws[0].dim() == 1
+        Ns = [int(w.shape[0]) for w in ws]
+        Cin = 1 if one_d else int(ws[0].shape[1])
+        assert all(w.is_contiguous() and w.dtype == torch.float32 and w.dim() == ws[0].dim() and (one_d or int(w.shape[1]) == Cin) for w in ws)
+        Nt = sum(Ns)
+        dst = torch.empty((Nt,) if one_d else ((Nt, Cin) if mode == 0 else (Cin, Nt)), device=ws[0].device, dtype=torch.float32)
+        keys, off = [], 0
+        for w, N in zip(ws, Ns):
+            part = dst[off:off + N] if (mode == 0 or one_d) else dst[:, off:off + N]
+            k = (w.data_ptr(), tuple(w.shape), mode, 'part', dst.data_ptr(), off)
+            self.entries[k] = [w.detach(), part, -1, (N, Cin, 1), self.epoch, capturing(), Nt if (mode == 1 and not one_d) else 0]
+            keys.append(k)
+            off += N
+        self.cats[key] = (dst, keys)
+        self.dirty = True
+        self.refresh()
+        return dst
+
     def refresh(self):
         lib = _lib.load()
         self.refreshes += 1
@@ -279,6 +318,8 @@ class _ParamLayouts:
         for k in drop:
             del self.entries[k]
             self.dirty = True
+        if drop:
+            self.cats = {k: c for k, c in self.cats.items() if all(pk in self.entries for pk in c[1])}
         if not self.entries:
             return
         if self.dirty:
@@ -289,6 +330,7 @@ class _ParamLayouts:
             for d, (key, e) in zip(arr, self.entries.items()):
                 N, Cin, KT = e[3]
                 d.src, d.dst, d.N, d.Cin, d.KT, d.mode, d.blk0 = e[0].data_ptr(), e[1].data_ptr(), N, Cin, KT, key[2], blk
+                d.ld_dst = e[6] if len(e) > 6 else 0
                 blk += int(lib.st_relayout_blocks(N, Cin, KT))
             self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             self.count, self.total_blocks, self.dirty = len(self.entries), blk, False
@@ -848,6 +890,25 @@ def highway_bwd(dy, H, x, Tg):
     check(_lib.load().st_highway_bwd(_p(dy), _p(H), _p(x), _p(Tg), _p(dH), _p(dT), _p(dx), x.numel(), stream_handle()),
           'st_highway_bwd')
     return dH, dT, dx
+
+
+def cat_params(ws, transposed=False):
+    """parameters side by side as one GEMM operand (cached per weight version, refreshed with the other layouts in one launch)"""
+    return _LAYOUTS.get_cat(list(ws), 1 if transposed else 0)
+
+
+def highway_ht_fwd(ht, x):
+    M, Cn = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().st_highway_ht_fwd(_p(ht), _p(x), _p(y), int(M), int(Cn), stream_handle()), 'st_highway_ht_fwd')
+    return y
+
+
+def highway_ht_bwd(dy, ht, x):
+    M, Cn = x.shape
+    dht, dxd = torch.empty_like(ht), torch.empty_like(x)
+    check(_lib.load().st_highway_ht_bwd(_p(dy), _p(ht), _p(x), _p(dht), _p(dxd), int(M), int(Cn), stream_handle()), 'st_highway_ht_bwd')
+    return dht, dxd
 
 
 def pool_prev_fwd(x):

@@ -434,6 +434,26 @@ int st_highway_fwd(const float* H, const float* Tgate, const float* x, float* y,
  * N = 2C product instead of two): y = relu(h) * sigmoid(t) + x * (1 - sigmoid(t)) (src/module.py:551-554), and its backward:
  * dht (M, 2C) = gradients at the two pre-activations (the operand of ONE input-gradient product and ONE weight-gradient product),
  * dx_direct (M, C) = dy * (1 - T). */
+/* The K BatchNorm1d layers of a conv bank (K independent layers of equal width N over K tensors of (Bn, T_k, N) rows, src/module.py:590-598)
+ * as one launch per phase.  Segment k: x (Bn * T_k rows, stride ldx), statistics over ALL its rows (the reference normalises the T + 1
+ * positions of an even-k conv before trimming to T); the normalised rows t < Tout go to columns [k N, (k + 1) N) of Y (Bn * Tout rows, stride
+ * ldy) -- the concatenated bank, no torch.cat.  Backward: dY (same geometry) -> dx_k over all rows of each segment (rows t >= Tout see
+ * dy = 0), optionally through the ReLU in FRONT of the norm (relu_in: x_k = relu(conv), so the factor is x > 0), and (s1, s2) = (d bias, d weight).
+ * ws: st_bn_bank_workspace_floats(nseg, max rows, N). */
+#define ST_BN_BANK_MAX 16
+typedef struct st_bn_bank_seg {
+    const float* x; int ldx; int T;                /* rows b * T + t, b < Bn */
+    const float* w; const float* b;                /* weight, bias (N) or NULL */
+    float* run_mean; float* run_var; long long* batches_tracked;   /* updated in place by st_bn_bank_fwd (NULL = none) */
+    float momentum, eps;
+    float* mean; float* var;                       /* (N) out of st_bn_bank_fwd, in of st_bn_bank_bwd */
+    float* dx; int lddx;                           /* st_bn_bank_bwd: out, Bn * T rows */
+    float* sums;                                   /* st_bn_bank_bwd: out (2, N) = (sum dy, sum dy xhat) = (d bias, d weight) */
+} st_bn_bank_seg;
+size_t st_bn_bank_workspace_floats(int nseg, int max_rows, int N);
+int st_bn_bank_fwd(const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* Y, int ldy, int Tout, float* ws, void* stream);
+int st_bn_bank_bwd(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, int relu_in, float* ws,
+                   void* stream);
 int st_highway_ht_fwd(const float* ht, const float* x, float* y, int M, int C, void* stream);
 int st_highway_ht_bwd(const float* dy, const float* ht, const float* x, float* dht, float* dx_direct, int M, int C, void* stream);
 int st_highway_bwd(const float* dy, const float* H, const float* x, const float* Tgate,

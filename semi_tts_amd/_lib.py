@@ -42,6 +42,12 @@ class StRelayoutDesc(C.Structure):
                 ('blk0', C.c_int), ('ld_dst', C.c_int)]
 
 
+class StBnBankSeg(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('ldx', C.c_int), ('T', C.c_int), ('w', C.c_void_p), ('b', C.c_void_p), ('run_mean', C.c_void_p),
+                ('run_var', C.c_void_p), ('batches_tracked', C.c_void_p), ('momentum', C.c_float), ('eps', C.c_float),
+                ('mean', C.c_void_p), ('var', C.c_void_p), ('dx', C.c_void_p), ('lddx', C.c_int), ('sums', C.c_void_p)]
+
+
 class StDecoderWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'prenet_w0', 'prenet_w1', 'q_w_ih', 'q_w_hh', 'q_b_ih', 'q_b_hh',
@@ -258,6 +264,9 @@ SIGNATURES = {
     'st_bn_sync_merge': [P, I, I, P, P, P, P, F, P, P],
     'st_bn_bwd_apply_sync': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, P, P, I, I, P],
     'st_highway_fwd': [P, P, P, P, Z, P],
+    'st_bn_bank_workspace_floats': [I, I, I],
+    'st_bn_bank_fwd': [C.POINTER(StBnBankSeg), I, I, I, P, I, I, P, P],
+    'st_bn_bank_bwd': [C.POINTER(StBnBankSeg), I, I, I, P, I, I, I, P, P],
     'st_highway_ht_fwd': [P, P, P, I, I, P],
     'st_highway_ht_bwd': [P, P, P, P, P, I, I, P],
     'st_highway_bwd': [P, P, P, P, P, P, P, Z, P],
@@ -271,7 +280,8 @@ SIGNATURES = {
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
              'st_decoder_packed_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_ctc_workspace_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
-             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_freq_loss_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_attn_rng_xchg_words': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t}
+             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_freq_loss_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_attn_rng_xchg_words': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t,
+             'st_bn_bank_workspace_floats': C.c_size_t}
 
 _lib = None
 

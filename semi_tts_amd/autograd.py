@@ -105,14 +105,18 @@ class _ConvGroupFn(Function):
 
     @staticmethod
     def forward(ctx, n, act, x, *args):
-        ws, bs, cfg = args[:n], args[n:2 * n], args[2 * n:]
+        ws, bs, cfg = args[:n], args[n:2 * n], args[2 * n:2 * n + 2 * n]
+        grad_done = bool(args[4 * n]) if len(args) > 4 * n else False     # the incoming gradients are already at the pre-activations
         x = x.contiguous()
         jobs, ys = [], []
         for k in range(n):
             ys.append(ops.gemm(x, ws[k], pad=int(cfg[2 * k]), Tout=cfg[2 * k + 1], bias=bs[k], act_pre=act, collect=jobs))
         ops.gemm_flush(jobs)
+        if grad_done:
+            act = None
         ctx.save_for_backward(x, *ws, *(ys if act is not None else []))
         ctx.cfg = (n, act, [int(cfg[2 * k]) for k in range(n)], [b is not None for b in bs])
+        ctx.extra = len(args) - 4 * n
         return tuple(ys)
 
     @staticmethod
@@ -150,17 +154,19 @@ class _ConvGroupFn(Function):
             dbs.append(db)
         if dx is not None:
             dx = dx.view(x.shape)
-        return (None, None, dx) + tuple(dws) + tuple(dbs) + (None,) * (2 * n)
+        return (None, None, dx) + tuple(dws) + tuple(dbs) + (None,) * (2 * n + ctx.extra)
 
 
-def conv_group(x, weights, pads, Touts, act=None, biases=None):
-    """[act(conv1d_k(x) + b_k)] for n convolutions / linear maps of one input (see _ConvGroupFn)"""
+def conv_group(x, weights, pads, Touts, act=None, biases=None, act_grad_done=False):
+    """[act(conv1d_k(x) + b_k)] for n convolutions / linear maps of one input (see _ConvGroupFn).  act_grad_done: whoever consumes the
+    outputs returns gradients that already went through act's derivative (batch_norm_bank with relu_in)."""
     n = len(weights)
     biases = list(biases) if biases is not None else [None] * n
     cfg = []
     for p_, t_ in zip(pads, Touts):
         cfg += [int(p_), t_]
-    return list(_ConvGroupFn.apply(n, act, x, *weights, *biases, *cfg))
+    extra = (True,) if act_grad_done else ()
+    return list(_ConvGroupFn.apply(n, act, x, *weights, *biases, *cfg, *extra))
 
 
 def conv(x, w, b=None, *, pad=0, Tout=None, act=None, res=None, mask=None, pool_prev=False, stride=1):
@@ -287,6 +293,38 @@ class _BnTrainGroupFn(Function):
             dx = ops.bn_bwd_apply(_rows_strided(dys[i]), _rows(y) if y is not None else None, act, _rows(x), mean, var, weight, eps[i], glob[i], Ms[i], inv_total)
             grads += [dx.view(x.shape), sums[i][N:], sums[i][:N], None, None, None]
         return (None, None) + tuple(grads) + (None,) * (2 * n)
+
+
+class _BnBankFn(Function):
+    """The K BatchNorm1d layers of the CBHG conv bank (src/module.py:590-598) WITHOUT SyncBN, straight into the concatenated bank: 3
+    launches forward (K x 3 + a torch.cat before), 3 backward (K x (reduce, merge, apply, ReLU backward) + the zero-padding of the four
+    trimmed positions before).  relu_in: the inputs are relu(conv) and the ReLU's backward rides in the apply launch -- the gradients
+    returned for xs are then the gradients at the convs' PRE-activations (conv_group(..., act_grad_done=True) takes them as such)."""
+
+    @staticmethod
+    def forward(ctx, holder, Tout, relu_in, *tens):
+        n = len(holder)
+        xs = [t.contiguous() for t in tens[:n]]
+        Y, stats = ops.bn_bank_fwd(xs, holder, Tout)
+        ctx.holder, ctx.relu_in = holder, relu_in
+        ctx.save_for_backward(stats, *xs)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        sv = ctx.saved_tensors
+        stats, xs = sv[0], list(sv[1:])
+        n = len(xs)
+        dxs, sums = ops.bn_bank_bwd(dY.contiguous(), xs, ctx.holder, stats, ctx.relu_in)
+        gw = [sums[k, 1] for k in range(n)]
+        gb = [sums[k, 0] for k in range(n)]
+        return (None, None, None) + tuple(dxs) + tuple(gw) + tuple(gb)
+
+
+def batch_norm_bank(xs, bns, Tout, relu_in):
+    """cat_k BatchNorm1d_k(x_k)[:, :Tout] (batch statistics; no SyncBN)"""
+    bns = list(bns)
+    return _BnBankFn.apply(bns, Tout, relu_in, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns])
 
 
 def batch_norm_train_group(xs, bns, act=None):

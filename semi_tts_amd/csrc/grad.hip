@@ -686,6 +686,213 @@ __global__ __launch_bounds__(256) void highway_fwd_kernel(const float* H, const 
     }
 }
 
+// ---- the K BatchNorm1d layers of a conv bank, one launch per phase (see st_bn_bank_fwd) ----------------------------------------------------
+// The per-layer kernels above with a segment index in the grid: same chunking of the rows per segment, same merge order, so a bank of one
+// segment gives what st_bn_stats / st_bn_norm_fwd / st_bn_bwd give.  part: [seg][chunk][2][N].
+struct BnBank { st_bn_bank_seg s[ST_BN_BANK_MAX]; int nseg, Bn, N; };
+
+__global__ __launch_bounds__(256) void bnb_stats_chunk_kernel(const BnBank a, float* part, int max_chunks) {
+    __shared__ float red[4][64];
+    __shared__ float smean[64];
+    const st_bn_bank_seg& sg = a.s[blockIdx.z];
+    const int N = a.N, M = a.Bn * sg.T;
+    const int chunks = st_colreduce_chunks(M), rpc = (M + chunks - 1) / chunks;
+    if ((int)blockIdx.y >= chunks) return;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const bool ok = n < N;
+    const int m0 = blockIdx.y * rpc, m1 = min(M, m0 + rpc);
+    const int ldx = sg.ldx;
+    const float* __restrict__ xp = sg.x + min(n, N - 1);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int m = m0 + rl;
+    for (; m + 12 < m1; m += 16) {
+        s0 += xp[(size_t)m * ldx]; s1 += xp[(size_t)(m + 4) * ldx]; s2 += xp[(size_t)(m + 8) * ldx]; s3 += xp[(size_t)(m + 12) * ldx];
+    }
+    for (; m < m1; m += 4) s0 += xp[(size_t)m * ldx];
+    red[rl][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0) smean[c] = (red[0][c] + red[1][c] + red[2][c] + red[3][c]) / (float)max(m1 - m0, 1);
+    __syncthreads();
+    const float mean = smean[c];
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    m = m0 + rl;
+    for (; m + 12 < m1; m += 16) {
+        const float d0 = xp[(size_t)m * ldx] - mean, d1 = xp[(size_t)(m + 4) * ldx] - mean;
+        const float d2 = xp[(size_t)(m + 8) * ldx] - mean, d3 = xp[(size_t)(m + 12) * ldx] - mean;
+        q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
+    }
+    for (; m < m1; m += 4) { const float d = xp[(size_t)m * ldx] - mean; q0 = fmaf(d, d, q0); }
+    __syncthreads();
+    red[rl][c] = (q0 + q1) + (q2 + q3);
+    __syncthreads();
+    if (rl == 0 && ok) {
+        float* pp = part + ((size_t)blockIdx.z * max_chunks + blockIdx.y) * 2 * N;
+        pp[n] = mean;
+        pp[N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void bnb_stats_final_kernel(const BnBank a, const float* part, int max_chunks) {
+    constexpr int CL = 16, PER = 8;
+    __shared__ float red[CL][16];
+    __shared__ float smean[16];
+    const st_bn_bank_seg& sg = a.s[blockIdx.y];
+    const int N = a.N, M = a.Bn * sg.T;
+    const int chunks = st_colreduce_chunks(M), rpc = (M + chunks - 1) / chunks;
+    const int c = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + c;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sg.batches_tracked) sg.batches_tracked[0] += 1;
+    const bool ok = n < N;
+    const float* pm = part + (size_t)blockIdx.y * max_chunks * 2 * N + min(n, N - 1);
+    const size_t cs = (size_t)2 * N;
+    float mu[PER], m2[PER], cnt[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int ch = cl + j * CL;
+        const bool in = ch < chunks;
+        const int chc = in ? ch : 0;
+        mu[j] = pm[(size_t)chc * cs]; m2[j] = pm[(size_t)chc * cs + N] * (in ? 1.0f : 0.0f);
+        cnt[j] = in ? (float)max(min(M, (ch + 1) * rpc) - ch * rpc, 0) : 0.0f;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc = fmaf(cnt[j], mu[j], acc);
+    red[cl][c] = acc;
+    __syncthreads();
+    if (cl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CL; ++k) t += red[k][c];
+        smean[c] = t / (float)M;
+    }
+    __syncthreads();
+    const float mean = smean[c];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const float d = mu[j] - mean; q += m2[j] + cnt[j] * d * d; }
+    __syncthreads();
+    red[cl][c] = q;
+    __syncthreads();
+    if (cl != 0 || !ok) return;
+    float m2t = 0.f;
+#pragma unroll
+    for (int k = 0; k < CL; ++k) m2t += red[k][c];
+    const float var_b = m2t / (float)M;
+    sg.mean[n] = mean;
+    sg.var[n] = var_b;
+    if (sg.run_mean) {
+        const float var_u = M > 1 ? m2t / (float)(M - 1) : var_b;
+        sg.run_mean[n] = (1.0f - sg.momentum) * sg.run_mean[n] + sg.momentum * mean;
+        sg.run_var[n] = (1.0f - sg.momentum) * sg.run_var[n] + sg.momentum * var_u;
+    }
+}
+
+// Y[(b Tout + t)][k N + n] = BN_k(x_k[b T_k + t][n]), t < Tout
+__global__ __launch_bounds__(256) void bnb_norm_kernel(const BnBank a, float* __restrict__ Y, int ldy, int Tout) {
+    const int N = a.N, W = a.nseg * N;
+    const size_t total = (size_t)a.Bn * Tout * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / W;
+        const int col = (int)(i - r * W);
+        const int k = col / N, n = col - k * N;
+        const st_bn_bank_seg& sg = a.s[k];
+        const int b = (int)(r / Tout), t = (int)(r - (size_t)b * Tout);
+        float v = (sg.x[((size_t)b * sg.T + t) * sg.ldx + n] - sg.mean[n]) / sqrtf(sg.var[n] + sg.eps);
+        v = v * (sg.w ? sg.w[n] : 1.0f) + (sg.b ? sg.b[n] : 0.0f);
+        Y[r * ldy + col] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bnb_bwd_reduce_kernel(const BnBank a, const float* __restrict__ dY, int lddy, int Tout, float* part, int max_chunks) {
+    __shared__ float r1[4][64], r2[4][64];
+    const int k = blockIdx.z;
+    const st_bn_bank_seg& sg = a.s[k];
+    const int N = a.N, T = sg.T, M = a.Bn * T;
+    const int chunks = st_colreduce_chunks(M), rpc = (M + chunks - 1) / chunks;
+    if ((int)blockIdx.y >= chunks) return;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int nc = min(n, N - 1);
+    const int m0 = blockIdx.y * rpc, m1 = min(M, m0 + rpc);
+    const float mu = sg.mean[nc], inv = 1.0f / sqrtf(sg.var[nc] + sg.eps);
+    const float* __restrict__ dp = dY + (size_t)k * N + nc;
+    const float* __restrict__ xp = sg.x + nc;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    // rows whose frame lies past the bank (t >= Tout: the trimmed position of an even-k conv) have dy = 0 and add nothing
+    auto dyrow = [&](int m) -> float {
+        const int b = m / T, t = m - b * T;
+        const float v = dp[((size_t)b * Tout + min(t, Tout - 1)) * lddy];
+        return v * (t < Tout ? 1.0f : 0.0f);
+    };
+    int m = m0 + rl;
+    for (; m + 4 < m1; m += 8) {
+        const float g0 = dyrow(m), g1 = dyrow(m + 4);
+        const float x0 = xp[(size_t)m * sg.ldx], x1 = xp[(size_t)(m + 4) * sg.ldx];
+        a0 += g0; a1 += g1;
+        b0 = fmaf(g0, (x0 - mu) * inv, b0); b1 = fmaf(g1, (x1 - mu) * inv, b1);
+    }
+    for (; m < m1; m += 4) {
+        const float g = dyrow(m);
+        a0 += g;
+        b0 = fmaf(g, (xp[(size_t)m * sg.ldx] - mu) * inv, b0);
+    }
+    r1[rl][c] = a0 + a1; r2[rl][c] = b0 + b1;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        float* pp = part + ((size_t)k * max_chunks + blockIdx.y) * 2 * N;
+        pp[n] = r1[0][c] + r1[1][c] + r1[2][c] + r1[3][c];
+        pp[N + n] = r2[0][c] + r2[1][c] + r2[2][c] + r2[3][c];
+    }
+}
+
+// sums_k[q][n] = sum over the segment's chunks of part[k][chunk][q][n]   (chunk_final_kernel's merge order)
+__global__ __launch_bounds__(256) void bnb_bwd_final_kernel(const BnBank a, const float* part, int max_chunks) {
+    constexpr int CL = 16, PER = 8;
+    __shared__ float red[CL][16];
+    const st_bn_bank_seg& sg = a.s[blockIdx.y];
+    const int N = a.N, M = a.Bn * sg.T;
+    const int chunks = st_colreduce_chunks(M);
+    const int c = threadIdx.x & 15, cl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + c;
+    const bool ok = i < 2 * N;
+    const int ic = min(i, 2 * N - 1);
+    const float* p = part + (size_t)blockIdx.y * max_chunks * 2 * N + ic;
+    const size_t cs = (size_t)2 * N;
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const int ch = cl + j * CL; v[j] = p[(size_t)(ch < chunks ? ch : 0) * cs] * (ch < chunks ? 1.0f : 0.0f); }
+    float sacc = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) sacc += v[j];
+    red[cl][c] = sacc;
+    __syncthreads();
+    if (cl != 0 || !ok) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < CL; ++k) t += red[k][c];
+    sg.sums[ic] = t;
+}
+
+__global__ __launch_bounds__(256) void bnb_bwd_apply_kernel(const BnBank a, const float* __restrict__ dY, int lddy, int Tout, int relu_in) {
+    const int k = blockIdx.y;
+    const st_bn_bank_seg& sg = a.s[k];
+    const int N = a.N, T = sg.T, M = a.Bn * T;
+    const size_t total = (size_t)M * N;
+    const float invM = 1.0f / (float)M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+        const int b = m / T, t = m - b * T;
+        const float g = dY[((size_t)b * Tout + min(t, Tout - 1)) * lddy + (size_t)k * N + n] * (t < Tout ? 1.0f : 0.0f);
+        const float inv = 1.0f / sqrtf(sg.var[n] + sg.eps);
+        const float xv = sg.x[(size_t)m * sg.ldx + n];
+        const float xh = (xv - sg.mean[n]) * inv;
+        float d = (sg.w ? sg.w[n] : 1.0f) * inv * (g - sg.sums[n] * invM - xh * sg.sums[N + n] * invM);
+        if (relu_in) d *= act_grad(xv, ST_ACT_RELU);
+        sg.dx[(size_t)m * sg.lddx + n] = d;
+    }
+}
+
 // One Highway layer on the pre-activations of its two Linear layers side by side, ht (M, 2C) = [h | t]   (see st_highway_ht_fwd)
 __global__ __launch_bounds__(256) void highway_ht_fwd_kernel(const float* __restrict__ ht, const float* __restrict__ x, float* __restrict__ y,
                                                              int C, size_t total) {
@@ -955,6 +1162,57 @@ extern "C" int st_highway_bwd(const float* dy, const float* H, const float* x, c
     ST_CHECK_ARG(dy && H && x && Tgate && dH && dT && dx_direct && total > 0, "st_highway_bwd: bad arguments");
     hipLaunchKernelGGL(highway_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        dy, H, x, Tgate, dH, dT, dx_direct, total);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t st_bn_bank_workspace_floats(int nseg, int max_rows, int N) {
+    return (size_t)nseg * st_colreduce_chunks(max_rows) * 2 * N;
+}
+
+static int bnb_fill(BnBank& a, const st_bn_bank_seg* segs, int nseg, int Bn, int N, int& max_chunks, size_t& max_rows, const char* who) {
+    ST_CHECK_ARG(segs && nseg > 0 && nseg <= ST_BN_BANK_MAX && Bn > 0 && N > 0, "%s: bad arguments (at most %d segments)", who, ST_BN_BANK_MAX);
+    a.nseg = nseg; a.Bn = Bn; a.N = N;
+    max_chunks = 1; max_rows = 0;
+    for (int k = 0; k < nseg; ++k) {
+        ST_CHECK_ARG(segs[k].x && segs[k].T > 0 && segs[k].ldx >= N && segs[k].mean && segs[k].var, "%s: segment %d incomplete", who, k);
+        a.s[k] = segs[k];
+        const int M = Bn * segs[k].T;
+        max_chunks = max(max_chunks, st_colreduce_chunks(M));
+        max_rows = max(max_rows, (size_t)M);
+    }
+    return 0;
+}
+
+extern "C" int st_bn_bank_fwd(const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* Y, int ldy, int Tout, float* ws, void* stream) {
+    (void)hipGetLastError();
+    BnBank a; int mc; size_t mr;
+    { const int rc = bnb_fill(a, segs, nseg, Bn, N, mc, mr, "st_bn_bank_fwd"); if (rc) return rc; }
+    ST_CHECK_ARG(Y && ws && Tout > 0 && ldy >= nseg * N, "st_bn_bank_fwd: bad output / workspace");
+    for (int k = 0; k < nseg; ++k) ST_CHECK_ARG(segs[k].T >= Tout, "st_bn_bank_fwd: segment %d has %d frames, the bank %d", k, segs[k].T, Tout);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bnb_stats_chunk_kernel, dim3((N + 63) / 64, mc, nseg), dim3(256), 0, st, a, ws, mc);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnb_stats_final_kernel, dim3((N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnb_norm_kernel, dim3(blocks_for((size_t)Bn * Tout * nseg * N)), dim3(256), 0, st, a, Y, ldy, Tout);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_bank_bwd(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, int relu_in, float* ws,
+                              void* stream) {
+    (void)hipGetLastError();
+    BnBank a; int mc; size_t mr;
+    { const int rc = bnb_fill(a, segs, nseg, Bn, N, mc, mr, "st_bn_bank_bwd"); if (rc) return rc; }
+    ST_CHECK_ARG(dY && ws && Tout > 0 && lddy >= nseg * N, "st_bn_bank_bwd: bad gradient / workspace");
+    for (int k = 0; k < nseg; ++k) ST_CHECK_ARG(segs[k].dx && segs[k].sums && segs[k].lddx >= N && segs[k].T >= Tout, "st_bn_bank_bwd: segment %d incomplete", k);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bnb_bwd_reduce_kernel, dim3((N + 63) / 64, mc, nseg), dim3(256), 0, st, a, dY, lddy, Tout, ws, mc);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnb_bwd_final_kernel, dim3((2 * N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnb_bwd_apply_kernel, dim3(blocks_for(mr * N), nseg), dim3(256), 0, st, a, dY, lddy, Tout, relu_in);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -55,7 +55,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // even for 80-column tensors, chunks of >= 64 rows
 // row chunks of the column reductions (BatchNorm statistics / backward sums, bias gradients): ~32 rows per chunk, at most 128 chunks
 // (two column blocks x 128 chunks = one workgroup per compute unit for the 128-channel layers of the CBHG)
-static inline int st_colreduce_chunks(int M) { int c = M / 32; if (c < 1) c = 1; if (c > 128) c = 128; return c; }
+static inline __host__ __device__ int st_colreduce_chunks(int M) { int c = M / 32; if (c < 1) c = 1; if (c > 128) c = 128; return c; }
 
 #define ST_WAVE 64
 

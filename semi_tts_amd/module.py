@@ -742,9 +742,16 @@ def _cbhg_forward_train(self, x):
     # (... and the K convolutions through ONE autograd function: one forward launch, the input gradient accumulated by the products)
     acts = set(blk.activation is not None for blk in self.conv1d_banks)
     assert len(acts) == 1
+    relu = acts.pop()
+    from . import parallel
+    bank_launches = not parallel.sync_bn_active() and len(self.conv1d_banks) <= 16      # (SyncBN: the group function shares the collectives)
     pre = AG.conv_group(x, [blk.conv1d.weight for blk in self.conv1d_banks], [blk.padding for blk in self.conv1d_banks],
-                        [T + 1 if (i + 1) % 2 == 0 else T for i in range(len(self.conv1d_banks))], act='relu' if acts.pop() else None)
-    bank = torch.cat([y[:, :T] for y in AG.batch_norm_train_group(pre, [blk.bn for blk in self.conv1d_banks])], dim=-1)
+                        [T + 1 if (i + 1) % 2 == 0 else T for i in range(len(self.conv1d_banks))], act='relu' if relu else None,
+                        act_grad_done=bank_launches and relu)
+    if bank_launches:      # the K BatchNorms as three launches, straight into the concatenated bank
+        bank = AG.batch_norm_bank(pre, [blk.bn for blk in self.conv1d_banks], T, relu_in=relu)
+    else:
+        bank = torch.cat([y[:, :T] for y in AG.batch_norm_train_group(pre, [blk.bn for blk in self.conv1d_banks])], dim=-1)
     y = self.conv1d_projs[0](bank, pool_prev=True)
     for blk in self.conv1d_projs[1:]:
         y = blk(y)

@@ -892,6 +892,54 @@ def highway_bwd(dy, H, x, Tg):
     return dH, dT, dx
 
 
+def _bn_bank_segs(xs, bns, means, vars_, dxs=None, sums=None, update_running=True):
+    import ctypes as C
+    n = len(xs)
+    segs = (_lib.StBnBankSeg * n)()
+    for k, (x, bn) in enumerate(zip(xs, bns)):
+        sg = segs[k]
+        sg.x, sg.ldx, sg.T = _p(x), int(x.stride(-2)), int(x.shape[1])
+        sg.w, sg.b = _p(bn.weight), _p(bn.bias)
+        if update_running and bn.running_mean is not None:
+            sg.run_mean, sg.run_var = _p(bn.running_mean), _p(bn.running_var)
+            sg.batches_tracked = _p(bn.num_batches_tracked, torch.int64)
+        sg.momentum, sg.eps = float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps)
+        sg.mean, sg.var = _p(means[k]), _p(vars_[k])
+        if dxs is not None:
+            sg.dx, sg.lddx, sg.sums = _p(dxs[k]), int(dxs[k].stride(-2)), _p(sums[k])
+    return segs
+
+
+def bn_bank_fwd(xs, bns, Tout):
+    """K BatchNorm1d layers (batch statistics, running statistics updated) of K tensors (Bn, T_k, N) -> the bank (Bn, Tout, K N) and the
+    (K, 2, N) statistics: 3 launches (st_bn_bank_fwd)"""
+    lib = _lib.load()
+    n, (Bn, _, N) = len(xs), xs[0].shape
+    dev = xs[0].device
+    stats = torch.empty(n, 2, N, device=dev, dtype=torch.float32)
+    Y = torch.empty(Bn, Tout, n * N, device=dev, dtype=torch.float32)
+    ws = torch.empty(int(lib.st_bn_bank_workspace_floats(n, int(Bn * max(x.shape[1] for x in xs)), int(N))), device=dev, dtype=torch.float32)
+    segs = _bn_bank_segs(xs, bns, [stats[k, 0] for k in range(n)], [stats[k, 1] for k in range(n)])
+    check(lib.st_bn_bank_fwd(segs, n, int(Bn), int(N), _p(Y), n * int(N), int(Tout), _p(ws), stream_handle()), 'st_bn_bank_fwd')
+    return Y, stats
+
+
+def bn_bank_bwd(dY, xs, bns, stats, relu_in):
+    """backward of bn_bank_fwd: dx_k over every row of segment k (through the ReLU in front of the norm when relu_in) and the (K, 2, N)
+    sums (d bias, d weight): 3 launches"""
+    lib = _lib.load()
+    n, (Bn, _, N) = len(xs), xs[0].shape
+    dev = xs[0].device
+    dxs = [torch.empty_like(x) for x in xs]
+    sums = torch.empty(n, 2, N, device=dev, dtype=torch.float32)
+    ws = torch.empty(int(lib.st_bn_bank_workspace_floats(n, int(Bn * max(x.shape[1] for x in xs)), int(N))), device=dev, dtype=torch.float32)
+    segs = _bn_bank_segs(xs, bns, [stats[k, 0] for k in range(n)], [stats[k, 1] for k in range(n)], dxs, [sums[k] for k in range(n)],
+                         update_running=False)
+    check(lib.st_bn_bank_bwd(segs, n, int(Bn), int(N), _p(dY), int(dY.stride(-2)), int(dY.shape[1]), 1 if relu_in else 0, _p(ws),
+                             stream_handle()), 'st_bn_bank_bwd')
+    return dxs, sums
+
+
 def cat_params(ws, transposed=False):
     """parameters side by side as one GEMM operand (cached per weight version, refreshed with the other layouts in one launch)"""
     return _LAYOUTS.get_cat(list(ws), 1 if transposed else 0)

@@ -131,6 +131,77 @@ def test_batchnorm_train_backward(dev, act):
     assert int(bnd.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize('relu_in', [False, True])
+def test_batchnorm_bank_against_torch(dev, relu_in):
+    """K BatchNorm1d layers of a conv bank as three launches per phase: segments of T and T + 1 frames (the statistics see every row,
+    the bank keeps the first T), the ReLU in front of the norm folded into the backward, running statistics of every layer updated --
+    against float64 nn.BatchNorm1d + torch.cat.  ref: src/module.py:590-598"""
+    import copy
+    from semi_tts_amd import autograd as AG
+    B, T, N, K = 3, 37, 24, 5
+    Ts = [T + 1 if (k + 1) % 2 == 0 else T for k in range(K)]
+    pres = [rnd(B, Ts[k], N, seed=10 + k) * 1.5 + 0.2 for k in range(K)]
+    bns = [torch.nn.BatchNorm1d(N, momentum=0.99, eps=1e-3) for _ in range(K)]
+    with torch.no_grad():
+        for k, bn in enumerate(bns):
+            bn.weight.copy_(rnd(N, seed=30 + k) * 0.3 + 1)
+            bn.bias.copy_(rnd(N, seed=40 + k) * 0.3)
+    bnd = [copy.deepcopy(bn).to(dev) for bn in bns]
+    dy = rnd(B, T, K * N, seed=5)
+    pd = [p.to(dev).requires_grad_() for p in pres]
+    xs = [torch.relu(p) for p in pd] if relu_in else pd
+    if relu_in:
+        # the bank returns gradients at the PRE-activations: hand it the ReLU outputs as leaves and compare with the chain rule below
+        xs = [torch.relu(p.detach()).requires_grad_() for p in pd]
+    bank = AG.batch_norm_bank(xs, bnd, T, relu_in)
+    bank.backward(dy.to(dev))
+    pr = [p.double().requires_grad_() for p in pres]
+    bref = [bn.double() for bn in bns]
+    yr = torch.cat([bref[k]((torch.relu(pr[k]) if relu_in else pr[k]).transpose(1, 2)).transpose(1, 2)[:, :T] for k in range(K)], -1)
+    yr.backward(dy.double())
+    assert bank.shape == (B, T, K * N) and maxdiff(bank, yr) < 1e-5
+    for k in range(K):
+        assert relerr(xs[k].grad, pr[k].grad) < 2e-5, k          # (relu_in: the gradient at the conv's pre-activation)
+        assert relerr(bnd[k].weight.grad, bref[k].weight.grad) < 2e-5 and relerr(bnd[k].bias.grad, bref[k].bias.grad) < 2e-5
+        assert maxdiff(bnd[k].running_mean, bref[k].running_mean) < 1e-5 and maxdiff(bnd[k].running_var, bref[k].running_var) < 1e-5
+        assert int(bnd[k].num_batches_tracked) == 1
+
+
+def test_highway_layer_backward_against_torch(dev):
+    """one Highway layer with its two Linear layers as a single N = 2C product (training path) vs float64 torch"""
+    from semi_tts_amd.module import Highway
+    Cn = 48
+    hw = Highway(Cn, Cn)
+    with torch.no_grad():
+        for i, p_ in enumerate(hw.parameters()):
+            p_.copy_(rnd(*p_.shape, seed=60 + i) * 0.3)
+    x = rnd(4, 19, Cn, seed=7)
+    dy = rnd(4, 19, Cn, seed=8)
+    import copy
+    hd = copy.deepcopy(hw).to(dev).train()
+    xd = x.to(dev).requires_grad_()
+    y = hd(xd)
+    y.backward(dy.to(dev))
+    xr = x.double().requires_grad_()
+    hr = copy.deepcopy(hw).double()
+    Hh, Tt = torch.relu(hr.H(xr)), torch.sigmoid(hr.T(xr))
+    yr = Hh * Tt + xr * (1 - Tt)
+    yr.backward(dy.double())
+    assert maxdiff(y, yr) < 1e-5 and relerr(xd.grad, xr.grad) < 2e-5
+    for (n_, pd_), (_, pr_) in zip(hd.named_parameters(), hr.named_parameters()):
+        assert relerr(pd_.grad, pr_.grad) < 2e-5, n_
+    # the weights move: the side-by-side layout is refreshed with the other cached layouts
+    with torch.no_grad():
+        for p_ in hd.parameters():
+            p_.add_(0.05)
+        for p_ in hr.parameters():
+            p_.add_(0.05)
+    y2 = hd(x.to(dev))
+    xr2 = x.double()
+    Hh, Tt = torch.relu(hr.H(xr2)), torch.sigmoid(hr.T(xr2))
+    assert maxdiff(y2, Hh * Tt + xr2 * (1 - Tt)) < 1e-5
+
+
 def test_highway_and_gather_backward(dev):
     from semi_tts_amd import autograd as AG
     H, Tg, x, dy = (rnd(4, 30, 48, seed=s) for s in (1, 2, 3, 4))

@@ -210,6 +210,15 @@ typedef struct st_attn_pre_job {
     int L, A, F, K;
     int parts;      /* workgroups per utterance (ranges of positions): 1, 2 or 4 */
     float* cf_out;  /* optional (B, L, F): the location features of the step, kept for the backward pass */
+    /* optional (p2_packed_w != NULL): ONE MORE packed linear inside the same launch whose operand is the product's THIRD range
+     * (act2 / mask2 applied) -- prenet layer 2 of the next decoder input behind proj (+) gate (+) prenet layer 1 (src/module.py:192,
+     * :337-339).  The third range also leaves as 8-byte {value, tag = p2_epoch} granules, (B, p2_K) words in p2_gran (zeroed by the
+     * caller before the first use of an epoch sequence), and (p2_N / 16) x batch-tile workgroups behind the attention ones wait for
+     * them.  p2_K = N - n_split2, a multiple of 16, at most 512; every workgroup of the launch must be resident at once (checked
+     * against the device's compute units).  A wait that does not complete sets bit 0 of *p2_status and leaves NaN. */
+    const float* p2_packed_w; int p2_K, p2_N, p2_act; const float* p2_mask; int p2_ldmask;
+    st_t16_view p2_dst;
+    unsigned long long* p2_gran; unsigned p2_epoch; unsigned* p2_status;
 } st_attn_pre_job;
 int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,
                                         const float* bias, int act, const float* mask, int ldmask,
@@ -693,6 +702,10 @@ typedef struct st_decoder_io {
                                         * step t+1 share one launch (st_lstm_cell_packed_pair_fwd) -- neither needs the other's output */
     float* pre_nat_tape;               /* optional (steps, 2, B, P): with prenet_norm, the Linear outputs of both prenet layers of every
                                         * own-output feedback are kept here (instead of pre_nat) for the backward */
+    unsigned long long* pre1_granules; /* optional (B, P) 64-bit words: with fuse_pre0 and the split attention step, prenet layer 2 of the next
+                                        * input runs INSIDE the proj (+) gate (+) prenet-layer-1 launch (st_attn_pre_job.p2_*), its operand
+                                        * handed over as granules -- one launch less per free-running decode step.  Zeroed by the callee per
+                                        * forward; time-outs go to handoff_status */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);

@@ -77,7 +77,7 @@ class StDecoderIO(C.Structure):
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p),
                 ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p),
                 ('dec_in0', C.c_void_p), ('pre_nat', C.c_void_p), ('attn_xchg', C.c_void_p), ('handoff_status', C.c_void_p),
-                ('pair_cells', C.c_int), ('pre_nat_tape', C.c_void_p)]
+                ('pair_cells', C.c_int), ('pre_nat_tape', C.c_void_p), ('pre1_granules', C.c_void_p)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -131,7 +131,9 @@ class StAttnBwdJob(C.Structure):
 class StAttnPreJob(C.Structure):
     _fields_ = [('pm', C.c_void_p), ('w_prev', C.c_void_p), ('ld_wprev', C.c_int), ('w_cum_prev', C.c_void_p),
                 ('loc_conv_w', C.c_void_p), ('loc_lin_w', C.c_void_p), ('s_buf', C.c_void_p),
-                ('L', C.c_int), ('A', C.c_int), ('F', C.c_int), ('K', C.c_int), ('parts', C.c_int), ('cf_out', C.c_void_p)]
+                ('L', C.c_int), ('A', C.c_int), ('F', C.c_int), ('K', C.c_int), ('parts', C.c_int), ('cf_out', C.c_void_p),
+                ('p2_packed_w', C.c_void_p), ('p2_K', C.c_int), ('p2_N', C.c_int), ('p2_act', C.c_int), ('p2_mask', C.c_void_p),
+                ('p2_ldmask', C.c_int), ('p2_dst', StT16View), ('p2_gran', C.c_void_p), ('p2_epoch', C.c_uint), ('p2_status', C.c_void_p)]
 
 
 class StAttnFinJob(C.Structure):

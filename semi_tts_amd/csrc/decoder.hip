@@ -19,8 +19,8 @@
 
 namespace {
 
-// zero up to eight buffers in one launch (blockIdx.y = buffer): the tapes' initial slots and the hand-off words of a forward
-struct ZeroArgs { float* p[8]; size_t floats[8]; int n; };
+// zero up to twelve buffers in one launch (blockIdx.y = buffer): the tapes' initial slots and the hand-off words of a forward
+struct ZeroArgs { float* p[12]; size_t floats[12]; int n; };
 __global__ __launch_bounds__(256) void zero_regions_kernel(const ZeroArgs a) {
     float* __restrict__ p = a.p[blockIdx.y];
     const size_t n = a.floats[blockIdx.y];
@@ -250,6 +250,12 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     const bool fuse_pq_fin = !fin_split && split_attn && !pre_in_pq && io->pq_granules && A % 16 == 0 && A <= 256 && E % 4 == 0 &&
                              (A / 16) * ((B + 15) / 16) + B * fin_parts <= st_device_cus();
     if (fin_rng || fuse_pq_fin) zero(io->pq_granules, (size_t)B * A * sizeof(unsigned long long));
+    // prenet layer 2 of the next input inside the proj (+) gate (+) prenet-layer-1 launch (st_attn_pre_job.p2_*): free-running steps with
+    // the folded layer 1, the split attention step (that launch exists), every workgroup of the launch resident at once
+    const int pre_parts_eff = (io->attn_pre_parts >= 2 && io->attn_pre_parts <= 64 && (io->attn_pre_parts & (io->attn_pre_parts - 1)) == 0) ? io->attn_pre_parts : 1;
+    const bool fuse_p2 = d->fuse_pre0 && split_attn && !defer && io->pre1_granules && P % 16 == 0 && P <= 512 &&
+                         ((in_dim + 1 + P + 15) / 16) * ((B + 15) / 16) + B * pre_parts_eff + (P / 16) * ((B + 15) / 16) <= st_device_cus();
+    if (fuse_p2) zero(io->pre1_granules, (size_t)B * P * sizeof(unsigned long long));
     if (fin_rng) zero(io->attn_xchg, st_attn_rng_xchg_words(B, E, sp_parts) * sizeof(unsigned long long));
     {
         size_t most = 0;
@@ -398,6 +404,13 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                w->attn_loc_conv_w, w->attn_loc_lin_w,
                                split_attn ? io->attn_s_buf + (size_t)(t + 1) * io->attn_s_step_floats : nullptr, L, A, d->F, d->K,
                                io->attn_pre_parts, io->attn_loc_tape ? io->attn_loc_tape + (size_t)(t + 1) * BL * d->F : nullptr};
+        const bool p2_now = fuse_p2 && t + 1 < steps && !ST_SKIPPED(6) && !ST_SKIPPED(5);
+        if (p2_now) {
+            job.p2_packed_w = io->packed + pl.p1; job.p2_K = P; job.p2_N = P; job.p2_act = ST_ACT_RELU;
+            job.p2_mask = io->prenet_mask ? io->prenet_mask + ((size_t)t * 2 + 1) * B * P : nullptr; job.p2_ldmask = P;
+            job.p2_dst = st_t16_view{xq_next, sv.q_kbs, 0};
+            job.p2_gran = io->pre1_granules; job.p2_epoch = (unsigned)(t + 1); job.p2_status = io->handoff_status;
+        }
         if (!ST_SKIPPED(4)) rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, ST_SKIPPED(7) ? Ko / 4 : Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
                                                  io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
                                                  io->stop_out + (size_t)t * d->r, steps * d->r, d->r,
@@ -411,8 +424,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         if (t + 1 < steps) {
             const int src = io->step_src[t];
             st_t16_view next = {xq_next, sv.q_kbs, 0};
-            if ((src == -1 || io->Bt < B) && !ST_SKIPPED(5)) {   // rows without a teacher feed their own output back
-                rc = prenet_own(w, d, io, pl, sv, t, fuse, stream);
+            if ((src == -1 || io->Bt < B) && !ST_SKIPPED(5) && !p2_now) {   // rows without a teacher feed their own output back
+                rc = prenet_own(w, d, io, pl, sv, t, fuse, stream);             // (p2_now: layer 2 rode in the launch above)
                 if (rc) return rc;
             }
             if (pure_tf) rc = 0;             // tiled for all steps before the loop

@@ -168,6 +168,8 @@ struct PkArgs {
     int n_split2; int act2; const float* mask2; int ldmask2; PkOut y3_dst;
     // optional: the plain range leaves as 8-byte {value, tag = epoch} granules (B, N) for consumer workgroups of the SAME launch
     unsigned long long* gran; unsigned epoch;
+    // optional: the third range likewise, (B, N - n_split2) granules (the operand of pk_gran_linear_body workgroups of the same launch)
+    unsigned long long* gran3;
 };
 
 // MODE 2: a linear whose output columns [n0, n0 + H) are dh of an LSTM cell -- the pointwise half of the cell's backward step
@@ -468,6 +470,12 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
                 v = st_act(v, a.act2);
                 if (a.mask2) v *= l_m2[r];
                 pk_store(a.y3_dst, b, n - a.n_split2, v);
+                if (a.gran3) {
+                    typedef __attribute__((address_space(1))) unsigned long long gu64;
+                    __hip_atomic_store((gu64*)(a.gran3 + (size_t)b * (a.N - a.n_split2) + (n - a.n_split2)),
+                                       ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
             } else if (a.n_split > 0 && n >= a.n_split) {
                 float* p = a.y2 + (size_t)b * a.ldy2 + (size_t)(n - a.n_split) * a.rep;
                 for (int j = 0; j < a.rep; ++j) p[j] = v;
@@ -684,9 +692,140 @@ __global__ __launch_bounds__(KW * 64) void pk_pw_ab_kernel(const f32x4* w, const
     pk_body<2, NB, KW, TRIP>(a, j - by * tiles_a, by, red, &pw);
 }
 
+// A packed linear whose x operand is PRODUCED BY OTHER WORKGROUPS OF THE SAME LAUNCH and arrives as {value, tag} granules, (B, K) row-major
+// (PkArgs.gran3 of the producer): prenet layer 2 behind the proj (+) gate (+) prenet-layer-1 product of a free-running decode step.  One
+// batch tile and one row tile per workgroup, KW waves; wave w takes the k-blocks w, w + KW, ...: its weight fragments are requested
+// BEFORE the wait (they do not depend on the producer), then each lane polls the 4 granules of its (batch row, 4 k's) slot per k-block
+// until every tag of the wave is `epoch` (at most PK_GRAN_SPINS rounds: then NaN and bit 0 of *status, like at_wait_granules), MFMAs,
+// the waves' partial sums through LDS, and the plain-range epilogue of pk_body (bias, activation, mask -> y / T16 destination).
+// K <= 16 KW MAXG: the weight fragments of a wave stay in registers.
+constexpr int PK_GRAN_SPINS = 1 << 18;
+template <int KW, int MAXG>
+__device__ __forceinline__ void pk_gran_linear_body(const PkArgs& a, const unsigned long long* xg, const int ldg, const unsigned epoch,
+                                                    unsigned* status, const int tile, const int bt, f32x4* red) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KB = a.KB;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)tile * a.w_kbs * 64), 0, KB * 1024, 0x00020000);
+    const unsigned voff = (unsigned)lane * 16u;
+    f32x4 w[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) w[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, voff + (unsigned)(wave + g * KW) * 1024u, 0, 0));   // past KB: zeros
+    // epilogue operands (bias, mask) requested before the wait as well
+    const int eb = bt * 16 + (lane & 15);
+    const int ebc = min(eb, a.B - 1);
+    const int n0 = tile * 16 + 4 * (lane >> 4);
+    const float* dummy = reinterpret_cast<const float*>(a.w);
+    float l_bias[4], l_m1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = min(n0 + r, a.N - 1);
+        l_bias[r] = (a.bias ? a.bias + n : dummy)[0];
+        l_m1[r] = (a.lmask ? a.lmask + (size_t)ebc * a.ldmask + n : dummy)[0];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    bool dead = false;
+    {   // ONE lane per wave watches ONE granule of the wave's first slot until it is fresh (the producers finish within a fraction of a
+        // microsecond of each other): 512 lanes polling four words each for the whole product would take fabric bandwidth from it
+        gu64* cp = (gu64*)(xg + (size_t)min(bt * 16, a.B - 1) * ldg + min(wave * 16, ldg - 4));
+        for (int sp = 0; sp < PK_GRAN_SPINS; ++sp) {
+            const unsigned long long c0 = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(__builtin_amdgcn_readfirstlane((unsigned)(c0 >> 32))) == epoch) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int kb = wave + g * KW;
+        if (kb >= KB) break;                                  // (wave-uniform)
+        // the lane's slot: batch row ebc, k = 16 kb + 4 (lane >> 4) .. + 3 (clamped to the last whole slot: columns past K meet zero weights)
+        gu64* gp = (gu64*)(xg + (size_t)ebc * ldg + min(kb * 16 + 4 * (lane >> 4), ldg - 4));
+        unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+        bool ok = false;
+        const int spins = dead ? 1 : PK_GRAN_SPINS;
+        for (int sp = 0; sp < spins; ++sp) {
+            g0 = __hip_atomic_load(gp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g2 = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g3 = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool mine = (unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch && (unsigned)(g2 >> 32) == epoch &&
+                              (unsigned)(g3 >> 32) == epoch;
+            ok = __all(mine);
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) {
+            dead = true;
+            if (lane == 0 && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float nanv = __builtin_nanf("");
+        const f32x4 x = ok ? f32x4{__uint_as_float((unsigned)g0), __uint_as_float((unsigned)g1), __uint_as_float((unsigned)g2), __uint_as_float((unsigned)g3)}
+                           : f32x4{nanv, nanv, nanv, nanv};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][cc], x[cc], acc, 0, 0, 0);
+    }
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (tid >= 64) return;
+    f32x4 s = red[lane];
+#pragma unroll
+    for (int ww = 1; ww < KW; ++ww) { const f32x4 t = red[ww * 64 + lane]; s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3]; }
+    if (eb >= a.B) return;
+    if (n0 + 3 < a.N) {
+        f32x4 v4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = st_act(s[r] + (a.bias ? l_bias[r] : 0.0f), a.act);
+            v4[r] = a.lmask ? v * l_m1[r] : v;
+        }
+        if (a.y) { float* py = a.y + (size_t)eb * a.ldy + n0; py[0] = v4[0]; py[1] = v4[1]; py[2] = v4[2]; py[3] = v4[3]; }
+        if (a.y_dst.base) *reinterpret_cast<f32x4*>(a.y_dst.base + t16_off(eb, a.y_dst.kb0 * 16 + n0, a.y_dst.kb_stride)) = v4;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + r;
+        if (n >= a.N) continue;
+        float v = st_act(s[r] + (a.bias ? l_bias[r] : 0.0f), a.act);
+        if (a.lmask) v *= l_m1[r];
+        if (a.y) a.y[(size_t)eb * a.ldy + n] = v;
+        pk_store(a.y_dst, eb, n, v);
+    }
+}
+
 // The proj (+) gate launch of decode step t with, on the compute units it leaves idle, the part of the attention of step t+1
 // that only needs the attention weights of step t (location conv + W_l + processed memory -> S): one workgroup per
 // utterance after the linear's workgroups.  The attention launch of step t+1 then starts from S.
+constexpr int PK_P2_MAXG = 4;      // k-blocks per wave of the in-launch second linear: K <= 16 * 8 * 4 = 512
+
+// ... and, P2: behind those, the workgroups of ONE MORE packed linear that consumes the product's third range as granules
+// (pk_gran_linear_body: prenet layer 2 of the next decoder input; n_at = attention workgroups, p2_tiles row tiles per batch tile)
+template <int NB, int KW, int TRIP, bool VEC, bool P2>
+__global__ __launch_bounds__(KW * 64) void pk_attnpre_p2_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                                const int B, const int N, const int tiles_a, const int n_lin,
+                                                                const float* at_pm, const float* at_wprev, const int at_L,
+                                                                const PkArgs a_rest, const AtArgs t_rest, const int n_at, const int p2_tiles,
+                                                                const PkArgs p2, unsigned* p2_status) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * NB * 64];
+    static_assert(KW * 64 == AT_THREADS, "both parts use 512-thread workgroups");
+    const int i = blockIdx.x;
+    if (i < n_lin) {
+        PkArgs a = a_rest;
+        a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N;
+        const int by = n_lin <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
+        pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
+    } else if (i < n_lin + n_at) {
+        AtArgs t = t_rest;
+        t.pm = at_pm; t.w_prev = at_wprev; t.L = at_L;
+        at_body<VEC, 1>(t, i - n_lin, pk_dyn_lds);
+    } else if (P2) {
+        const int j = i - n_lin - n_at;
+        const int bt = j / p2_tiles;
+        pk_gran_linear_body<KW, PK_P2_MAXG>(p2, a_rest.gran3, p2.KB * 16, a_rest.epoch, p2_status, j - bt * p2_tiles, bt, red);
+    }
+}
+
 template <int NB, int KW, int TRIP, bool VEC>
 __global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
                                                              const int B, const int N, const int tiles_a, const int n_lin,
@@ -757,9 +896,26 @@ __global__ __launch_bounds__(KW * 64, 4) void pk_attnrng_kernel(const f32x4* w, 
 int pk_fill(PkArgs& a, const float* packed_w, const st_t16_view* x, int K, const char* who);
 
 template <int NB>
-int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st) {
+int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st, const PkArgs* p2 = nullptr, unsigned* p2_status = nullptr) {
     constexpr int KW = 8, TRIP = NB == 1 ? PK_TRIP_SMALL : 2;
     const int BT = (a.B + 15) >> 4, gy = (BT + NB - 1) / NB;
+    if (p2) {       // + the workgroups of the in-launch second linear (every workgroup of the launch resident at once: checked by the caller)
+        const bool vec = (t.A % 4 == 0) && (t.F % 4 == 0) && st_aligned16(t.pm) && st_aligned16(t.loc_lin_w) && st_aligned16(t.s_buf);
+        const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K, 1, at_pos_per(t.L, t.pre_parts > 1 ? t.pre_parts : 1), vec && t.F == 32 && t.A % 16 == 0);
+        const size_t lds = (size_t)o.total * sizeof(float);
+        ST_CHECK_ARG(lds + sizeof(f32x4) * KW * NB * 64 <= 160 * 1024, "linear + attention-pre launch: L=%d needs too much LDS (use more parts)", t.L);
+        auto kern = vec ? pk_attnpre_p2_kernel<NB, KW, TRIP, true, true> : pk_attnpre_p2_kernel<NB, KW, TRIP, false, true>;
+        static size_t configured[2] = {0, 0};
+        if (lds > 48 * 1024 && lds > configured[vec ? 1 : 0]) {
+            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured[vec ? 1 : 0] = lds;
+        }
+        const int n_at = t.B * (t.pre_parts > 1 ? t.pre_parts : 1), p2_tiles = (p2->N + 15) / 16;
+        hipLaunchKernelGGL(kern, dim3(tiles * gy + n_at + p2_tiles * BT), dim3(KW * 64), lds, st, a.w, a.x, a.w_kbs, a.x_kbs,
+                           a.KB, a.B, a.N, tiles, tiles * gy, t.pm, t.w_prev, t.L, a, t, n_at, p2_tiles, *p2, p2_status);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
     const bool vec = (t.A % 4 == 0) && (t.F % 4 == 0) && st_aligned16(t.pm) && st_aligned16(t.loc_lin_w) && st_aligned16(t.s_buf);
     const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K, 1, at_pos_per(t.L, t.pre_parts > 1 ? t.pre_parts : 1), vec && t.F == 32 && t.A % 16 == 0);
     const size_t lds = (size_t)o.total * sizeof(float);
@@ -1036,6 +1192,24 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
         t.B = B; t.L = pre->L; t.A = pre->A; t.E = 4; t.F = pre->F; t.K = pre->K;
         t.pre_parts = (pre->parts >= 2 && pre->parts <= 64 && (pre->parts & (pre->parts - 1)) == 0) ? pre->parts : 1;
         const int BT = (B + 15) >> 4;
+        if (pre->p2_packed_w) {
+            // prenet layer 2 (or any linear over the third range) inside this launch: its operand travels as granules
+            ST_CHECK_ARG(n_split2 > 0 && pre->p2_gran && pre->p2_epoch != 0 && pre->p2_K == N - n_split2 && pre->p2_K % 16 == 0 &&
+                         pre->p2_K <= 16 * 8 * PK_P2_MAXG && pre->p2_N > 0 && pre->p2_dst.base && (reinterpret_cast<uintptr_t>(pre->p2_gran) & 7) == 0,
+                         "st_skinny_linear_packed_attnpre_fwd: bad in-launch linear (K = third range, a multiple of 16, at most %d)", 16 * 8 * PK_P2_MAXG);
+            PkArgs p2;
+            memset(&p2, 0, sizeof(p2));
+            p2.w = reinterpret_cast<const f32x4*>(pre->p2_packed_w);
+            p2.KB = pre->p2_K / 16; p2.w_kbs = p2.KB;
+            p2.B = B; p2.N = pre->p2_N; p2.act = pre->p2_act; p2.lmask = pre->p2_mask; p2.ldmask = pre->p2_ldmask;
+            p2.y_dst = pk_out(&pre->p2_dst);
+            a.gran3 = pre->p2_gran; a.epoch = pre->p2_epoch;
+            const int gy1 = BT;       // (NB = 1 below)
+            const int n_at = B * t.pre_parts, n_p2 = ((pre->p2_N + 15) / 16) * BT;
+            ST_CHECK_ARG(tiles * gy1 + n_at + n_p2 <= st_device_cus(), "st_skinny_linear_packed_attnpre_fwd: %d + %d + %d workgroups do not fit the device at once",
+                         tiles * gy1, n_at, n_p2);
+            return pk_launch_attnpre<1>(a, tiles, t, (hipStream_t)stream, &p2, pre->p2_status);
+        }
         if (BT == 1 || tiles <= 128) return pk_launch_attnpre<1>(a, tiles, t, (hipStream_t)stream);
         if (BT == 2) return pk_launch_attnpre<2>(a, tiles, t, (hipStream_t)stream);
         if (BT == 3) return pk_launch_attnpre<3>(a, tiles, t, (hipStream_t)stream);

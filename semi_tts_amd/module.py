@@ -14,6 +14,7 @@ Activations are kept channels-last (B, T, C) end to end (the reference transpose
 import ctypes as C
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -352,6 +353,7 @@ class Decoder(nn.Module):
         # device -> host copy); under stream capture nobody can, so GraphedDecoder / bench.py / gen_specgram check it after replays
         self.check_handoff = True
         self.handoff_status = None
+        self.prenet2_in_proj = os.environ.get('ST_P2', '0') == '1'       # prenet layer 2 inside the proj launch of a free-running step: MEASURED SLOWER (+0.4 us per step), off unless ST_P2=1
         self.attn_split_min_len = 128     # texts at least this long: fin part over position ranges (~attn_split_positions each) + combine
         self.attn_split_positions = 43
         self.bwd_fuse_pointwise = True   # training (teacher forcing): the cells' pointwise backward in the epilogues of the loop's products
@@ -613,6 +615,11 @@ class Decoder(nn.Module):
                 if self.handoff_status is None or self.handoff_status.device != dev:
                     self.handoff_status = torch.zeros(1, device=dev, dtype=torch.int32)
                 io.handoff_status = ops._p(self.handoff_status, torch.int32)
+                if fuse_pre0 and self.prenet2_in_proj:
+                    # ... and prenet layer 2 of the next input inside the proj (+) gate (+) prenet-layer-1 launch (its operand as granules):
+                    # three launches per free-running decode step + the two cells, instead of four
+                    tapes['pre1_gran'] = torch.empty(B, 2 * P, **f32)       # (B, P) 64-bit words
+                    io.pre1_granules = ops._p(tapes['pre1_gran'])
         check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()),
               'st_decoder_forward')
         if io.handoff_status and self.check_handoff and not ops.capturing():
@@ -622,7 +629,7 @@ class Decoder(nn.Module):
                 # launch), same masks -- and keep that form for the rest of the process
                 ops.degrade('decode loop (query projection -> attention hand-off)', 'one launch each (attn_pq_in_fin = False)')
                 self.attn_pq_in_fin = False
-                io.pq_granules, io.handoff_status, io.attn_xchg = None, None, None
+                io.pq_granules, io.handoff_status, io.attn_xchg, io.pre1_granules = None, None, None, None
                 check(lib.st_decoder_forward(C.byref(w), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_forward')
         if not keep_tapes and self.check_handoff and not ops.capturing():
             ops.check_persist_status(dev)           # (the text encoder's one-launch BiLSTM ran before this loop: Tacotron2.forward falls back)

@@ -78,6 +78,31 @@ def test_decode_loop_hand_off_survives_saturated_compute_units():
     assert bad == 0 and bool(torch.isfinite(ref[0]).all())
 
 
+def test_prenet_layer_two_inside_the_proj_launch_equals_the_separate_launch():
+    """the rejected-but-kept form of the free-running step (Decoder.prenet2_in_proj, ST_P2=1: prenet layer 2 as consumer workgroups of
+    the proj (+) gate (+) prenet-layer-1 launch, its operand handed over as granules) gives the outputs of the default form (one
+    launch of its own) -- same k order per output element -- and leaves the status word clear"""
+    from helpers import full_tacotron
+    from semi_tts_amd import ops
+    from semi_tts_amd.synthetic import synthetic_batch
+    dev = torch.device('cuda:0')
+    B, L, T = 32, 43, 60
+    m = full_tacotron(dev, seed=12, prenet_dropout=0.5)
+    txt, spk, _ = synthetic_batch(B, L, T, seed=6)
+    txt, spk = torch.from_numpy(txt).to(dev), torch.from_numpy(spk).to(dev)
+    outs = []
+    with torch.no_grad():
+        mem = m.encoder(txt, None).contiguous()
+        for flag in (False, True):
+            m.decoder.prenet2_in_proj = flag
+            torch.manual_seed(3)                              # the same prenet dropout masks
+            outs.append([t.clone() for t in m.decoder(mem, None, T, spk)])
+    torch.cuda.synchronize()
+    assert not ops.handoff_starved(m.decoder.handoff_status)
+    for x, y in zip(*outs):
+        assert bool(torch.isfinite(x).all()) and float((x - y).abs().max()) < 1e-6
+
+
 def test_eager_forward_falls_back_to_two_launches_when_the_hand_off_was_starved():
     """Decoder.forward (eager inference) reads the hand-off status back: a word left set by a starved launch means the pass is NaN --
     the loop runs again as two launches per hand-off (bit-identical results), warns once, and keeps that form"""

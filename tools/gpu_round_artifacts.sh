@@ -5,6 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/art_$TAG
 mkdir -p $OUT
 cd $ROOT
+export ST_COMMIT=${ST_COMMIT:-$(cat .st_commit 2>/dev/null)}
 echo "== PMC passes (HBM traffic, MFMA): C2 LSTM cell, C5 LSTM cell, VQ search"
 bash tools/gpu_pmc.sh $TAG > $OUT/pmc.log 2>&1; tail -3 $OUT/pmc.log
 python tools/pmc_summary.py $TAG > $OUT/pmc_summary.log 2>&1

@@ -847,8 +847,9 @@ int st_skinny_linear_packed_lstm_bwd_pair_fwd(const float* const* packed_w2, con
 int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
                                               const st_lstm_pw_job* job, const st_attn_bwd_job* ab, void* stream);
 int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
-/* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp, r*n_mels+1); NULL = zeros */
-int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int B, int Bp, int steps, int r, int n_mels,
+/* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp) rows of r*n_mels+1 values, row stride ld floats
+ * (a stride rounded up to a multiple of 4, pad columns zero, puts the two products over dY on the 16-byte kernels); NULL = zeros */
+int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int ld, int B, int Bp, int steps, int r, int n_mels,
                          void* stream);
 /* AdaIN statistics gradients (ref: src/module.py:267-269): adapted_t = std * (h_q_t - mean)
  * dstd = sum_t dadapt_t * (h_q_t - mean), dmean = -std * sum_t dadapt_t; *_step_stride / *_ld in elements */

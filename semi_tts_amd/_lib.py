@@ -243,7 +243,7 @@ SIGNATURES = {
     'st_lstm_cell_pair_fwd': [P, C.POINTER(P), C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, C.POINTER(P), I, I, P],
     'st_attn_dmem': [P, P, P, I, I, I, I, P],
     'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],
-    'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, P],
+    'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, I, P],
     'st_adain_bwd': [P, C.c_long, I, P, C.c_long, I, P, P, P, P, I, I, I, P],
     'st_mt_blocks': [P, I],
     'st_mt_grad_norm': [P, P, I, P, P, P],

@@ -720,13 +720,22 @@ class _DecoderFn(Function):
         hq_all = XQ[1:steps + 1].reshape(-1, XQw)[:, P + E:]               # h_q_t (dropped-out), rows (t, b)
         pq_all = ops.gemm(hq_all, wq)                                       # (steps*Bp, A)
         # output gradients through proj (+) gate for all steps at once
-        dY = torch.zeros(steps, Bp, in_dim + 1, **f32)
+        # teacher forcing: the rows of dY are padded to a multiple of 4 floats (zero columns) -- 16-byte addressable rows put the two
+        # products over them (dxo = dY [W_proj ; W_gate], the weight gradient dY^T [h_d | ctx]) on the LDS-DMA kernels (in_dim + 1 = 241
+        # at r = 3: 59 + 50 us on the element-wise ones).  Own-output feedback keeps the exact width (the loop indexes dY itself).
+        YW = in_dim + 1
+        YWp = YW if own else (YW + 3) // 4 * 4
+        dY = torch.zeros(steps, Bp, YWp, **f32)
         _lib.check(lib.st_decoder_pack_dout(ops._p(dmel.contiguous()) if dmel is not None else None,
                                             ops._p(dstop.contiguous()) if dstop is not None else None,
-                                            ops._p(dY), B, Bp, steps, r, n_mels, ops.stream_handle()), 'st_decoder_pack_dout')
+                                            ops._p(dY), YWp, B, Bp, steps, r, n_mels, ops.stream_handle()), 'st_decoder_pack_dout')
         wpg = torch.cat([proj_w.detach(), gate_w.detach()], 0)             # (in_dim+1, D+E)   parameter layout only
-        dY2 = dY.view(-1, in_dim + 1)
-        wpg_t = wpg.t().contiguous()
+        dY2 = dY.view(-1, YWp)
+        if YWp != YW:
+            wpg_t = torch.zeros(wpg.shape[1], YWp, **f32)
+            wpg_t[:, :YW] = wpg.t()
+        else:
+            wpg_t = wpg.t().contiguous()
         # teacher forcing: no step's input depends on an earlier output, so all steps go through proj (+) gate at once;
         # with own-output feedback the loop forms dxo_t after adding the feedback gradient to dmel_t
         dxo = torch.zeros(steps * Bp, XOw, **f32) if own else ops.gemm(dY2, wpg_t)          # (steps*Bp, D+E)
@@ -860,7 +869,7 @@ class _DecoderFn(Function):
                  c(dwq_cat[:, :P + E]), c(dwq_cat[:, P + E:]), dbq, dbq.clone(),
                  dwq_attn, dv, dwc, dwl,
                  c(dwd_cat[:, :E + Q]), c(dwd_cat[:, E + Q:]), dbd, dbd.clone(),
-                 c(dwpg[:in_dim]), c(dbpg[:in_dim]), c(dwpg[in_dim:]), c(dbpg[in_dim:]))
+                 c(dwpg[:in_dim]), c(dbpg[:in_dim]), c(dwpg[in_dim:in_dim + 1]), c(dbpg[in_dim:in_dim + 1]))
         if pre_norm:
             grads += tuple(dnorm[i] for i in range(4)) if own else (None,) * 4
         ctx.tapes = None

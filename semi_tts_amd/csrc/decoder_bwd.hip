@@ -297,7 +297,7 @@ namespace {
 
 // dY[t][b][:] = [dmel[b][t*r .. t*r+r][:] | sum_j dstop[b][t*r + j]]     rows b >= B of a slot are left untouched (zero)
 __global__ __launch_bounds__(256) void pack_dout_kernel(const float* dmel, const float* dstop, float* dY,
-                                                        int B, int Bp, int steps, int r, int n_mels) {
+                                                        int B, int Bp, int steps, int r, int n_mels, int ld) {
     const int in_dim = r * n_mels, W = in_dim + 1;
     const size_t total = (size_t)steps * B * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void pack_dout_kernel(const float* dmel, const
             v = 0.0f;
             if (dstop) for (int j = 0; j < r; ++j) v += dstop[(size_t)b * steps * r + (size_t)t * r + j];
         }
-        dY[((size_t)t * Bp + b) * W + c] = v;
+        dY[((size_t)t * Bp + b) * ld + c] = v;
     }
 }
 
@@ -335,15 +335,15 @@ __global__ __launch_bounds__(256) void adain_bwd_kernel(const float* da, long da
 
 }  // namespace
 
-extern "C" int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int B, int Bp, int steps, int r,
+extern "C" int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int ld, int B, int Bp, int steps, int r,
                                     int n_mels, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(dY && B > 0 && Bp >= B && steps > 0 && r > 0 && n_mels > 0, "st_decoder_pack_dout: bad arguments");
+    ST_CHECK_ARG(dY && B > 0 && Bp >= B && steps > 0 && r > 0 && n_mels > 0 && ld >= r * n_mels + 1, "st_decoder_pack_dout: bad arguments");
     const size_t total = (size_t)steps * B * (r * n_mels + 1);
     size_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_dout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dmel, dstop, dY, B, Bp,
-                       steps, r, n_mels);
+                       steps, r, n_mels, ld);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -903,7 +903,8 @@ def _bn_bank_segs(xs, bns, means, vars_, dxs=None, sums=None, update_running=Tru
         if update_running and bn.running_mean is not None:
             sg.run_mean, sg.run_var = _p(bn.running_mean), _p(bn.running_var)
             sg.batches_tracked = _p(bn.num_batches_tracked, torch.int64)
-        sg.momentum, sg.eps = float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps)
+        assert bn.momentum is not None, 'BatchNorm1d(momentum=None) (cumulative average) is not what the reference builds'
+        sg.momentum, sg.eps = float(bn.momentum), float(bn.eps)
         sg.mean, sg.var = _p(means[k]), _p(vars_[k])
         if dxs is not None:
             sg.dx, sg.lddx, sg.sums = _p(dxs[k]), int(dxs[k].stride(-2)), _p(sums[k])

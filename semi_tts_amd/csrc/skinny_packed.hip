@@ -899,7 +899,7 @@ template <int NB>
 int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st, const PkArgs* p2 = nullptr, unsigned* p2_status = nullptr) {
     constexpr int KW = 8, TRIP = NB == 1 ? PK_TRIP_SMALL : 2;
     const int BT = (a.B + 15) >> 4, gy = (BT + NB - 1) / NB;
-    if (p2) {       // + the workgroups of the in-launch second linear (every workgroup of the launch resident at once: checked by the caller)
+    if constexpr (NB == 1) if (p2) {       // + the workgroups of the in-launch second linear (every workgroup of the launch resident at once: checked by the caller)
         const bool vec = (t.A % 4 == 0) && (t.F % 4 == 0) && st_aligned16(t.pm) && st_aligned16(t.loc_lin_w) && st_aligned16(t.s_buf);
         const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K, 1, at_pos_per(t.L, t.pre_parts > 1 ? t.pre_parts : 1), vec && t.F == 32 && t.A % 16 == 0);
         const size_t lds = (size_t)o.total * sizeof(float);

@@ -82,6 +82,27 @@ class _ConvFn(Function):
             ops.fill_(up, 0.0)
             ops.copy3d(up[:, 0:(To - 1) * stride + 1:stride], dpre.view(Bn, To, N), Bn, To, N)
             dpre, To = up, To1
+        if (KT == 1 and N % 4 != 0 and N >= 64 and Cin % 4 == 0 and not pool_prev and stride == 1 and w.is_contiguous()
+                and _rows(dpre).shape[0] >= 1024 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]):
+            # a Linear whose output width is not a multiple of 4 (Linear(160, 1025) of the postnet): rows of dy are not 16-byte addressable
+            # and both backward products fall to the element-wise kernels (68 + 74 us at C2).  One copy into rows padded to Np floats
+            # (pad columns zero) and the padded transposed weight put them on the LDS-DMA kernels (~20 + 25 us).
+            Np = (N + 3) // 4 * 4
+            d2 = _rows(dpre)
+            M_ = d2.shape[0]
+            dyp = torch.empty(M_, Np, device=d2.device, dtype=torch.float32)
+            ops.copy2d(dyp, d2, M_, N)
+            dyp[:, N:].zero_()
+            dx = ops.gemm(dyp, ops.cat_params([w.detach()], transposed=True, pad_to=Np)).view(x.shape)
+            x2 = _rows(xw)
+            if has_b and ctx.needs_input_grad[2]:
+                dwp, dbp = ops.gemm_wgrad(dyp, x2, with_db=True)
+                db = dbp[:N]
+            else:
+                dwp = ops.gemm_wgrad(dyp, x2)
+            dw = dwp[:N]
+            dres = dy if has_res and ctx.needs_input_grad[3] else None
+            return dx, dw, db, dres, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             wt, tap_major = ops.dx_weight(w.detach())        # (cached per weight version: all weights re-laid out by one launch per step)
             dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pad, w_tap_major=tap_major)

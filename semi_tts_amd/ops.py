@@ -273,11 +273,11 @@ class _ParamLayouts:
         self.refresh()
         return dst
 
-    def get_cat(self, ws, mode):
+    def get_cat(self, ws, mode, pad_to=0):
         """Several parameters of equal Cin laid out side by side as ONE operand: mode 0 -> (sum N, Cin), their rows one after the other
         (the weight of one forward product in place of len(ws); 1-D parameters: their concatenation); mode 1 -> (Cin, sum N), their
         transposes as column blocks (the weight of one input-gradient product).  Same caching and the same single refresh launch as get()."""
-        key = (tuple(w.data_ptr() for w in ws), tuple(tuple(w.shape) for w in ws), mode, 'cat')
+        key = (tuple(w.data_ptr() for w in ws), tuple(tuple(w.shape) for w in ws), mode, 'cat', int(pad_to))
         c = self.cats.get(key)
         if c is not None and all(k in self.entries for k in c[1]):
             stale = False
@@ -298,12 +298,18 @@ class _ParamLayouts:
         Cin = 1 if one_d else int(ws[0].shape[1])
         assert all(w.is_contiguous() and w.dtype == torch.float32 and w.dim() == ws[0].dim() and (one_d or int(w.shape[1]) == Cin) for w in ws)
         Nt = sum(Ns)
-        dst = torch.empty((Nt,) if one_d else ((Nt, Cin) if mode == 0 else (Cin, Nt)), device=ws[0].device, dtype=torch.float32)
+        if pad_to:      # mode 1 only: (Cin, pad_to) with ZERO columns past sum N (a reduction axis padded to whole 16-byte pieces)
+            assert mode == 1 and not one_d and pad_to >= Nt
+            Nt_alloc = int(pad_to)
+            dst = torch.zeros(Cin, Nt_alloc, device=ws[0].device, dtype=torch.float32)
+        else:
+            Nt_alloc = Nt
+            dst = torch.empty((Nt,) if one_d else ((Nt, Cin) if mode == 0 else (Cin, Nt)), device=ws[0].device, dtype=torch.float32)
         keys, off = [], 0
         for w, N in zip(ws, Ns):
             part = dst[off:off + N] if (mode == 0 or one_d) else dst[:, off:off + N]
             k = (w.data_ptr(), tuple(w.shape), mode, 'part', dst.data_ptr(), off)
-            self.entries[k] = [w.detach(), part, -1, (N, Cin, 1), self.epoch, capturing(), Nt if (mode == 1 and not one_d) else 0]
+            self.entries[k] = [w.detach(), part, -1, (N, Cin, 1), self.epoch, capturing(), Nt_alloc if (mode == 1 and not one_d) else 0]
             keys.append(k)
             off += N
         self.cats[key] = (dst, keys)
@@ -941,9 +947,9 @@ def bn_bank_bwd(dY, xs, bns, stats, relu_in):
     return dxs, sums
 
 
-def cat_params(ws, transposed=False):
+def cat_params(ws, transposed=False, pad_to=0):
     """parameters side by side as one GEMM operand (cached per weight version, refreshed with the other layouts in one launch)"""
-    return _LAYOUTS.get_cat(list(ws), 1 if transposed else 0)
+    return _LAYOUTS.get_cat(list(ws), 1 if transposed else 0, pad_to)
 
 
 def highway_ht_fwd(ht, x):

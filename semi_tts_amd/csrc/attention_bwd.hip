@@ -25,16 +25,30 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
 
 // dmem[b][l][e] = sum_t w_t[b][l] * dctx_t[b][e]      (the context is ctx_t = sum_l w_t[l] mem[l])
 __global__ __launch_bounds__(256) void attn_dmem_kernel(const float* align, const float* dctx, float* dmem, int B, int steps, int L, int E) {
-    const size_t total = (size_t)B * L * E;
+    // a thread takes FOUR positions of one context dim: each dctx value (the bulk of the reads: steps x B x E, re-read by every position)
+    // is loaded once per four outputs.  Per output the sum runs over t ascending, as before.
+    const int LG = (L + 3) >> 2;
+    const size_t total = (size_t)B * LG * E;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(i % E);
-        const size_t bl = i / E;
-        const int l = (int)(bl % L), b = (int)(bl / L);
-        const float* wp = align + (size_t)b * steps * L + l;
+        const size_t bg = i / E;
+        const int lg = (int)(bg % LG), b = (int)(bg / LG);
+        const int l0 = lg * 4;
+        const float* wp = align + (size_t)b * steps * L;
         const float* dp = dctx + (size_t)b * E + e;
-        float acc = 0.0f;
-        for (int t = 0; t < steps; ++t) acc = fmaf(wp[(size_t)t * L], dp[(size_t)t * B * E], acc);
-        dmem[i] = acc;
+        const int l1 = min(l0 + 1, L - 1), l2 = min(l0 + 2, L - 1), l3 = min(l0 + 3, L - 1);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll 8
+        for (int t = 0; t < steps; ++t) {      // (unrolled: eight steps' loads in flight -- as a rolled loop it is a chain of dependent round trips)
+            const float d = dp[(size_t)t * B * E];
+            const float* wr = wp + (size_t)t * L;
+            a0 = fmaf(wr[l0], d, a0); a1 = fmaf(wr[l1], d, a1); a2 = fmaf(wr[l2], d, a2); a3 = fmaf(wr[l3], d, a3);
+        }
+        float* o = dmem + ((size_t)b * L + l0) * E + e;
+        o[0] = a0;
+        if (l0 + 1 < L) o[(size_t)E] = a1;
+        if (l0 + 2 < L) o[(size_t)2 * E] = a2;
+        if (l0 + 3 < L) o[(size_t)3 * E] = a3;
     }
 }
 
@@ -43,7 +57,7 @@ __global__ __launch_bounds__(256) void attn_dmem_kernel(const float* align, cons
 extern "C" int st_attn_dmem(const float* align, const float* dctx_tape, float* dmem, int B, int steps, int L, int E, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(align && dctx_tape && dmem && B > 0 && steps > 0 && L > 0 && E > 0, "st_attn_dmem: bad arguments");
-    size_t blocks = ((size_t)B * L * E + 255) / 256;
+    size_t blocks = ((size_t)B * ((L + 3) / 4) * E + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(attn_dmem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, align, dctx_tape, dmem, B, steps, L, E);
     ST_LAUNCH_CHECK();

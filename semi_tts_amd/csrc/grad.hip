@@ -614,12 +614,16 @@ __global__ __launch_bounds__(256) void pool_prev_bwd_kernel(const float* dyp, co
         const int c = (int)(i % C);
         const size_t row = i / C;
         const int t = (int)(row % T);
-        const float xv = x[i];
+        // all five operands requested at once from clamped addresses; the conditions select afterwards (as `if (cond) g += dyp[..]` every
+        // load sat behind a branch and a full wait)
+        const bool has_prev = t > 0, has_next = t + 1 < T;
+        const float xv = x[i], xp = x[has_prev ? i - C : i], xn = x[has_next ? i + C : i];
+        const float g0 = dyp[i], g1 = dyp[has_next ? i + C : i];
         float g = 0.0f;
         // contribution of output t: x[t] is selected when t == 0 or x[t] > x[t-1]
-        if (t == 0 || xv > x[i - C]) g += dyp[i];
+        g += ((!has_prev || xv > xp) ? 1.0f : 0.0f) * g0;          // (a factor: a select on the loaded value would pull the load behind the compare)
         // contribution of output t+1: x[t] is selected when x[t] >= x[t+1]
-        if (t + 1 < T && xv >= x[i + C]) g += dyp[i + C];
+        g += ((has_next && xv >= xn) ? 1.0f : 0.0f) * g1;
         dx[i] = g;
         (void)c;
     }
@@ -652,9 +656,12 @@ __global__ __launch_bounds__(512) void scatter_add_rows_kernel(const float* dout
     const int d = blockIdx.y * 64 + c;
     const int per = (n + 7) / 8, r0 = q * per, r1 = min(n, r0 + per);
     float acc = 0.0f;
-    if (d < D)
-        for (int r = r0; r < r1; ++r)
-            if (idx[r] == (int64_t)v) acc += dout[(size_t)r * D + d];
+    if (d < D) {
+        // every row is loaded (a wave reads one 256-byte run) and kept or dropped by a 0 / 1 factor: `if (idx == v) acc += dout[..]` is a
+        // branch around the load with a full wait behind it, `per` dependent round trips (finite gradients assumed: 0 * x = 0)
+#pragma unroll 8
+        for (int r = r0; r < r1; ++r) acc = fmaf(idx[r] == (int64_t)v ? 1.0f : 0.0f, dout[(size_t)r * D + d], acc);
+    }
     red[q][c] = acc;
     __syncthreads();
     if (q != 0 || d >= D) return;

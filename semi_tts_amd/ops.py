@@ -1069,8 +1069,14 @@ def untile_tape(flat, slots, Bp, kb_stride, segs):
     Consecutive slots are consecutive batch tiles, so one launch per segment un-tiles every step."""
     width = sum(k for _, k in segs)
     out = torch.empty(slots, Bp, width, device=flat.device, dtype=torch.float32)
-    col = 0
+    merged = []          # segments that follow each other in whole k-blocks are one run in both layouts: one launch for the run
     for kb0, k in segs:
+        if merged and merged[-1][1] % 16 == 0 and merged[-1][0] + merged[-1][1] // 16 == kb0:
+            merged[-1] = (merged[-1][0], merged[-1][1] + k)
+        else:
+            merged.append((kb0, k))
+    col = 0
+    for kb0, k in merged:
         v = t16_view(flat, kb_stride, kb0)
         check(_lib.load().st_untile_rows(C.byref(v), _p(out) + 4 * col, width, slots * Bp, k, stream_handle()), 'st_untile_rows')
         col += k

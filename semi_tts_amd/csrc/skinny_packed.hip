@@ -56,10 +56,13 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const PackArgs a) {
         if (row < a.N) {
             const float* p = a.w[s] + (size_t)row * a.ldw[s] + k;
             const int rem = a.k[s] - k;
-            if (rem > 0) v[0] = p[0];
-            if (rem > 1) v[1] = p[1];
-            if (rem > 2) v[2] = p[2];
-            if (rem > 3) v[3] = p[3];
+            if (rem >= 4 && st_aligned16(p)) v = st_ld4(p);          // whole pieces: one 16-byte load (four conditional scalar loads were four round trips)
+            else {
+                if (rem > 0) v[0] = p[0];
+                if (rem > 1) v[1] = p[1];
+                if (rem > 2) v[2] = p[2];
+                if (rem > 3) v[3] = p[3];
+            }
         }
         reinterpret_cast<f32x4*>(a.out)[idx] = v;
     }
@@ -87,6 +90,11 @@ __global__ __launch_bounds__(256) void pack_weight_t_kernel(const PackTArgs a) {
             int s = 0;
             while (s + 1 < a.nseg && row >= a.r0[s + 1]) ++s;
             const bool whole = a.vec && row + 4 <= a.r0[s + 1];      // the four rows lie in one segment, 16-byte addressable
+            if (whole && k + 4 <= a.K) {      // the usual piece: four independent 16-byte loads (with the per-row tests below each load sat behind a branch)
+                const float* p0 = a.w[s] + (size_t)k * a.ldw[s] + (row - a.r0[s]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) in[j] = st_ld4(p0 + (size_t)j * a.ldw[s]);
+            } else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (k + j >= a.K) continue;

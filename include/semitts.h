@@ -913,7 +913,8 @@ typedef struct st_relayout_desc {
                      * transposes of several Linear weights side by side = the weight of ONE input-gradient product) */
 } st_relayout_desc;
 int st_relayout_blocks(int N, int Cin, int KT);
-int st_relayout_batch(const st_relayout_desc* table_dev, int n, int total_blocks, void* stream);
+/* blk_desc_dev: optional DEVICE array of total_blocks ints, the descriptor index of every workgroup (NULL: each workgroup searches the table) */
+int st_relayout_batch(const st_relayout_desc* table_dev, int n, int total_blocks, const int* blk_desc_dev, void* stream);
 int st_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream);
 /* dst(b, :) = mean over t of src(b, t, :)    ref: teacher.mean(dim=1) src/module.py:194 */
 int st_mean_rows(const float* src, float* dst, int B, int T, int D, void* stream);

@@ -795,19 +795,38 @@ __global__ __launch_bounds__(256) void bnb_stats_final_kernel(const BnBank a, co
     }
 }
 
-// Y[(b Tout + t)][k N + n] = BN_k(x_k[b T_k + t][n]), t < Tout
-__global__ __launch_bounds__(256) void bnb_norm_kernel(const BnBank a, float* __restrict__ Y, int ldy, int Tout) {
-    const int N = a.N, W = a.nseg * N;
-    const size_t total = (size_t)a.Bn * Tout * W;
+// Y[(b Tout + t)][k N + n] = BN_k(x_k[b T_k + t][n]), t < Tout.  blockIdx.y = segment (its fields stay in scalar registers); four
+// channels per thread when N % 4 == 0 and the rows are 16-byte addressable
+__global__ __launch_bounds__(256) void bnb_norm_kernel(const BnBank a, float* __restrict__ Y, int ldy, int Tout, int vec) {
+    const int k = blockIdx.y;
+    const st_bn_bank_seg& sg = a.s[k];
+    const int N = a.N, T = sg.T, ldx = sg.ldx;
+    const float* __restrict__ x = sg.x;
+    if (vec) {
+        const int N4 = N >> 2;
+        const size_t total = (size_t)a.Bn * Tout * N4;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const size_t r = i / N4;
+            const int n = (int)(i - r * N4) * 4;
+            const int b = (int)(r / Tout), t = (int)(r - (size_t)b * Tout);
+            const f32x4 xv = st_ld4(x + ((size_t)b * T + t) * ldx + n);
+            const f32x4 mu = st_ld4(sg.mean + n), va = st_ld4(sg.var + n);
+            const f32x4 w4 = sg.w ? st_ld4(sg.w + n) : f32x4{1.f, 1.f, 1.f, 1.f}, b4 = sg.b ? st_ld4(sg.b + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (xv[c] - mu[c]) / sqrtf(va[c] + sg.eps) * w4[c] + b4[c];
+            *reinterpret_cast<f32x4*>(Y + r * ldy + (size_t)k * N + n) = o;
+        }
+        return;
+    }
+    const size_t total = (size_t)a.Bn * Tout * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i / W;
-        const int col = (int)(i - r * W);
-        const int k = col / N, n = col - k * N;
-        const st_bn_bank_seg& sg = a.s[k];
+        const size_t r = i / N;
+        const int n = (int)(i - r * N);
         const int b = (int)(r / Tout), t = (int)(r - (size_t)b * Tout);
-        float v = (sg.x[((size_t)b * sg.T + t) * sg.ldx + n] - sg.mean[n]) / sqrtf(sg.var[n] + sg.eps);
+        float v = (x[((size_t)b * T + t) * ldx + n] - sg.mean[n]) / sqrtf(sg.var[n] + sg.eps);
         v = v * (sg.w ? sg.w[n] : 1.0f) + (sg.b ? sg.b[n] : 0.0f);
-        Y[r * ldy + col] = v;
+        Y[r * ldy + (size_t)k * N + n] = v;
     }
 }
 
@@ -881,12 +900,37 @@ __global__ __launch_bounds__(256) void bnb_bwd_final_kernel(const BnBank a, cons
     sg.sums[ic] = t;
 }
 
-__global__ __launch_bounds__(256) void bnb_bwd_apply_kernel(const BnBank a, const float* __restrict__ dY, int lddy, int Tout, int relu_in) {
+__global__ __launch_bounds__(256) void bnb_bwd_apply_kernel(const BnBank a, const float* __restrict__ dY, int lddy, int Tout, int relu_in, int vec) {
     const int k = blockIdx.y;
     const st_bn_bank_seg& sg = a.s[k];
     const int N = a.N, T = sg.T, M = a.Bn * T;
-    const size_t total = (size_t)M * N;
     const float invM = 1.0f / (float)M;
+    if (vec) {      // four channels per thread (N % 4 == 0, 16-byte addressable rows): one row / frame split per four elements
+        const int N4 = N >> 2;
+        const size_t total = (size_t)M * N4;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const int m = (int)(i / N4), n = (int)(i - (size_t)m * N4) * 4;
+            const int b = m / T, t = m - b * T;
+            const f32x4 g4 = st_ld4(dY + ((size_t)b * Tout + min(t, Tout - 1)) * lddy + (size_t)k * N + n);
+            const f32x4 xv = st_ld4(sg.x + (size_t)m * sg.ldx + n);
+            const f32x4 mu = st_ld4(sg.mean + n), va = st_ld4(sg.var + n), s1 = st_ld4(sg.sums + n), s2 = st_ld4(sg.sums + N + n);
+            const f32x4 w4 = sg.w ? st_ld4(sg.w + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+            const float on = t < Tout ? 1.0f : 0.0f;
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float g = g4[c] * on;
+                const float inv = 1.0f / sqrtf(va[c] + sg.eps);
+                const float xh = (xv[c] - mu[c]) * inv;
+                float d = w4[c] * inv * (g - s1[c] * invM - xh * s2[c] * invM);
+                if (relu_in) d *= act_grad(xv[c], ST_ACT_RELU);
+                o[c] = d;
+            }
+            *reinterpret_cast<f32x4*>(sg.dx + (size_t)m * sg.lddx + n) = o;
+        }
+        return;
+    }
+    const size_t total = (size_t)M * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
         const int b = m / T, t = m - b * T;
@@ -928,9 +972,10 @@ __global__ __launch_bounds__(256) void highway_ht_bwd_kernel(const float* __rest
 // writes four consecutive destination floats (one 16-byte store when aligned) gathered from the source.
 //   mode 0: (N, Cin, KT) -> (N, KT, Cin)                      tap-major conv weight (forward GEMM operand)
 //   mode 1: (N, Cin, KT) -> (Cin, KT, N), taps reversed        weight of the input-gradient conv, tap-major (KT = 1: plain transpose)
-__global__ __launch_bounds__(256) void relayout_batch_kernel(const st_relayout_desc* __restrict__ table, int n) {
+__global__ __launch_bounds__(256) void relayout_batch_kernel(const st_relayout_desc* __restrict__ table, int n, const int* __restrict__ blk_desc) {
     int lo = 0, hi = n - 1;
-    while (lo < hi) {                      // last descriptor whose first workgroup is <= blockIdx.x
+    if (blk_desc) lo = blk_desc[blockIdx.x];      // (one load; the search below is log2(n) DEPENDENT round trips in front of every workgroup)
+    else while (lo < hi) {                 // last descriptor whose first workgroup is <= blockIdx.x
         const int mid = (lo + hi + 1) >> 1;
         if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
@@ -941,9 +986,8 @@ __global__ __launch_bounds__(256) void relayout_batch_kernel(const st_relayout_d
     float v[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const size_t i = i0 + c;
-        v[c] = 0.0f;
-        if (i >= total) continue;
+        // (elements past the end re-read the last one and are never stored: four independent loads instead of four behind a test each)
+        const size_t i = i0 + c < total ? i0 + c : total - 1;
         if (d.mode == 0) {
             const int ci = (int)(i % d.Cin);
             const size_t r = i / d.Cin;
@@ -1202,7 +1246,11 @@ extern "C" int st_bn_bank_fwd(const st_bn_bank_seg* segs, int nseg, int Bn, int 
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(bnb_stats_final_kernel, dim3((N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bnb_norm_kernel, dim3(blocks_for((size_t)Bn * Tout * nseg * N)), dim3(256), 0, st, a, Y, ldy, Tout);
+    int vec = N % 4 == 0 && ldy % 4 == 0 && st_aligned16(Y);
+    for (int k = 0; k < nseg && vec; ++k)
+        vec = segs[k].ldx % 4 == 0 && st_aligned16(segs[k].x) && st_aligned16(segs[k].mean) && st_aligned16(segs[k].var) &&
+              (!segs[k].w || st_aligned16(segs[k].w)) && (!segs[k].b || st_aligned16(segs[k].b));
+    hipLaunchKernelGGL(bnb_norm_kernel, dim3(blocks_for((size_t)Bn * Tout * N / (vec ? 4 : 1), 1024), nseg), dim3(256), 0, st, a, Y, ldy, Tout, vec);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -1219,7 +1267,11 @@ extern "C" int st_bn_bank_bwd(const st_bn_bank_seg* segs, int nseg, int Bn, int 
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(bnb_bwd_final_kernel, dim3((2 * N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bnb_bwd_apply_kernel, dim3(blocks_for(mr * N), nseg), dim3(256), 0, st, a, dY, lddy, Tout, relu_in);
+    int vec = N % 4 == 0 && lddy % 4 == 0 && st_aligned16(dY);
+    for (int k = 0; k < nseg && vec; ++k)
+        vec = segs[k].ldx % 4 == 0 && segs[k].lddx % 4 == 0 && st_aligned16(segs[k].x) && st_aligned16(segs[k].dx) && st_aligned16(segs[k].mean) &&
+              st_aligned16(segs[k].var) && st_aligned16(segs[k].sums) && (!segs[k].w || st_aligned16(segs[k].w));
+    hipLaunchKernelGGL(bnb_bwd_apply_kernel, dim3(blocks_for(mr * N / (vec ? 4 : 1), 1024), nseg), dim3(256), 0, st, a, dY, lddy, Tout, relu_in, vec);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -1274,10 +1326,10 @@ extern "C" int st_copy3d(float* dst, long dst_sb, long dst_st, const float* src,
 
 extern "C" int st_relayout_blocks(int N, int Cin, int KT) { return (int)(((size_t)N * Cin * KT + 1023) / 1024); }
 
-extern "C" int st_relayout_batch(const st_relayout_desc* table_dev, int n, int total_blocks, void* stream) {
+extern "C" int st_relayout_batch(const st_relayout_desc* table_dev, int n, int total_blocks, const int* blk_desc_dev, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(table_dev && n > 0 && total_blocks > 0, "st_relayout_batch: bad arguments");
-    hipLaunchKernelGGL(relayout_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+    hipLaunchKernelGGL(relayout_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n, blk_desc_dev);
     ST_LAUNCH_CHECK();
     return 0;
 }

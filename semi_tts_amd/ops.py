@@ -243,6 +243,7 @@ class _ParamLayouts:
         self.entries = {}       # key -> [alias, dst, version, (N, Cin, KT), epoch of the last use, pinned(, row stride of dst)]
         self.cats = {}          # key -> (dst, keys of its parts in `entries`): see get_cat
         self.table = None       # device descriptor table of the entries
+        self.blk_desc = None    # descriptor index of every workgroup of the refresh launch
         self.count = 0
         self.total_blocks = 0
         self.dirty = True
@@ -332,15 +333,19 @@ class _ParamLayouts:
             dev = next(iter(self.entries.values()))[1].device
             assert all(e[1].device == dev for e in self.entries.values()), 'parameter layouts of several devices in one process'
             arr = (_lib.StRelayoutDesc * len(self.entries))()
-            blk = 0
-            for d, (key, e) in zip(arr, self.entries.items()):
+            blk, owner = 0, []
+            for j, (d, (key, e)) in enumerate(zip(arr, self.entries.items())):
                 N, Cin, KT = e[3]
                 d.src, d.dst, d.N, d.Cin, d.KT, d.mode, d.blk0 = e[0].data_ptr(), e[1].data_ptr(), N, Cin, KT, key[2], blk
                 d.ld_dst = e[6] if len(e) > 6 else 0
-                blk += int(lib.st_relayout_blocks(N, Cin, KT))
+                nb = int(lib.st_relayout_blocks(N, Cin, KT))
+                owner += [j] * nb
+                blk += nb
             self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.blk_desc = torch.tensor(owner, dtype=torch.int32).to(dev)        # the descriptor of every workgroup
             self.count, self.total_blocks, self.dirty = len(self.entries), blk, False
-        check(lib.st_relayout_batch(_p(self.table, torch.uint8), self.count, self.total_blocks, stream_handle()), 'st_relayout_batch')
+        check(lib.st_relayout_batch(_p(self.table, torch.uint8), self.count, self.total_blocks, _p(self.blk_desc, torch.int32), stream_handle()),
+              'st_relayout_batch')
         for e in self.entries.values():
             e[2] = e[0]._version
 

@@ -463,6 +463,17 @@ size_t st_bn_bank_workspace_floats(int nseg, int max_rows, int N);
 int st_bn_bank_fwd(const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* Y, int ldy, int Tout, float* ws, void* stream);
 int st_bn_bank_bwd(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, int relu_in, float* ws,
                    void* stream);
+/* The same in SyncBN stages (data parallel; the collectives between the stages are the caller's -- ONE all-gather of the records and ONE
+ * all-reduce of the sums for the whole bank): st_bn_bank_stats_record writes (mean, M2, row count) of this rank's rows of every segment
+ * to rec (nseg, 2N + 1) and counts the batch; st_bn_bank_sync_merge turns the gathered allrec (world, nseg, 2N + 1) into the global mean /
+ * var of every segment (running statistics updated) and inv_total (nseg) = 1 / global row count; st_bn_bank_norm normalises.  Backward:
+ * st_bn_bank_bwd_reduce leaves this rank's sums in segs[k].sums; st_bn_bank_bwd_apply takes the all-reduced sums there and inv_total. */
+int st_bn_bank_stats_record(const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* rec, float* ws, void* stream);
+int st_bn_bank_sync_merge(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* allrec, int world, float* inv_total, void* stream);
+int st_bn_bank_norm(const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* Y, int ldy, int Tout, void* stream);
+int st_bn_bank_bwd_reduce(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, float* ws, void* stream);
+int st_bn_bank_bwd_apply(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, int relu_in,
+                         const float* inv_total, void* stream);
 int st_highway_ht_fwd(const float* ht, const float* x, float* y, int M, int C, void* stream);
 int st_highway_ht_bwd(const float* dy, const float* ht, const float* x, float* dht, float* dx_direct, int M, int C, void* stream);
 int st_highway_bwd(const float* dy, const float* H, const float* x, const float* Tgate,

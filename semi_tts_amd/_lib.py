@@ -269,6 +269,11 @@ SIGNATURES = {
     'st_bn_bank_workspace_floats': [I, I, I],
     'st_bn_bank_fwd': [C.POINTER(StBnBankSeg), I, I, I, P, I, I, P, P],
     'st_bn_bank_bwd': [C.POINTER(StBnBankSeg), I, I, I, P, I, I, I, P, P],
+    'st_bn_bank_stats_record': [C.POINTER(StBnBankSeg), I, I, I, P, P, P],
+    'st_bn_bank_sync_merge': [C.POINTER(StBnBankSeg), I, I, I, P, I, P, P],
+    'st_bn_bank_norm': [C.POINTER(StBnBankSeg), I, I, I, P, I, I, P],
+    'st_bn_bank_bwd_reduce': [C.POINTER(StBnBankSeg), I, I, I, P, I, I, P, P],
+    'st_bn_bank_bwd_apply': [C.POINTER(StBnBankSeg), I, I, I, P, I, I, I, P, P],
     'st_highway_ht_fwd': [P, P, P, I, I, P],
     'st_highway_ht_bwd': [P, P, P, P, P, I, I, P],
     'st_highway_bwd': [P, P, P, P, P, P, P, Z, P],

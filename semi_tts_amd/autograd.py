@@ -317,26 +317,38 @@ class _BnTrainGroupFn(Function):
 
 
 class _BnBankFn(Function):
-    """The K BatchNorm1d layers of the CBHG conv bank (src/module.py:590-598) WITHOUT SyncBN, straight into the concatenated bank: 3
+    """The K BatchNorm1d layers of the CBHG conv bank (src/module.py:590-598), straight into the concatenated bank: 3
     launches forward (K x 3 + a torch.cat before), 3 backward (K x (reduce, merge, apply, ReLU backward) + the zero-padding of the four
     trimmed positions before).  relu_in: the inputs are relu(conv) and the ReLU's backward rides in the apply launch -- the gradients
     returned for xs are then the gradients at the convs' PRE-activations (conv_group(..., act_grad_done=True) takes them as such)."""
 
     @staticmethod
     def forward(ctx, holder, Tout, relu_in, *tens):
+        from . import parallel
         n = len(holder)
         xs = [t.contiguous() for t in tens[:n]]
-        Y, stats = ops.bn_bank_fwd(xs, holder, Tout)
+        ctx.sync = parallel.sync_bn_active()
+        if ctx.sync:       # SyncBN: the same launches in stages, ONE all-gather of the K records between them
+            parallel._COUNTS['syncbn_fwd'] += 1
+            Y, stats, inv_total = ops.bn_bank_fwd_sync(xs, holder, Tout)
+        else:
+            Y, stats = ops.bn_bank_fwd(xs, holder, Tout)
+            inv_total = stats.new_empty(0)
         ctx.holder, ctx.relu_in = holder, relu_in
-        ctx.save_for_backward(stats, *xs)
+        ctx.save_for_backward(stats, inv_total, *xs)
         return Y
 
     @staticmethod
     def backward(ctx, dY):
+        from . import parallel
         sv = ctx.saved_tensors
-        stats, xs = sv[0], list(sv[1:])
+        stats, inv_total, xs = sv[0], sv[1], list(sv[2:])
         n = len(xs)
-        dxs, sums = ops.bn_bank_bwd(dY.contiguous(), xs, ctx.holder, stats, ctx.relu_in)
+        if ctx.sync:
+            parallel._COUNTS['syncbn_bwd'] += 1
+            dxs, sums = ops.bn_bank_bwd_sync(dY.contiguous(), xs, ctx.holder, stats, inv_total, ctx.relu_in)
+        else:
+            dxs, sums = ops.bn_bank_bwd(dY.contiguous(), xs, ctx.holder, stats, ctx.relu_in)
         gw = [sums[k, 1] for k in range(n)]
         gb = [sums[k, 0] for k in range(n)]
         return (None, None, None) + tuple(dxs) + tuple(gw) + tuple(gb)

@@ -740,7 +740,8 @@ __global__ __launch_bounds__(256) void bnb_stats_chunk_kernel(const BnBank a, fl
     }
 }
 
-__global__ __launch_bounds__(256) void bnb_stats_final_kernel(const BnBank a, const float* part, int max_chunks) {
+// rec != NULL (SyncBN, local half): (mean, M2, row count) of segment k go to rec[k (2N + 1) ..]; nothing else is written but batches_tracked
+__global__ __launch_bounds__(256) void bnb_stats_final_kernel(const BnBank a, const float* part, int max_chunks, float* rec) {
     constexpr int CL = 16, PER = 8;
     __shared__ float red[CL][16];
     __shared__ float smean[16];
@@ -786,12 +787,44 @@ __global__ __launch_bounds__(256) void bnb_stats_final_kernel(const BnBank a, co
 #pragma unroll
     for (int k = 0; k < CL; ++k) m2t += red[k][c];
     const float var_b = m2t / (float)M;
+    if (rec) {
+        float* r = rec + (size_t)blockIdx.y * (2 * N + 1);
+        r[n] = mean; r[N + n] = m2t;
+        if (n == 0) r[2 * N] = (float)M;
+        return;
+    }
     sg.mean[n] = mean;
     sg.var[n] = var_b;
     if (sg.run_mean) {
         const float var_u = M > 1 ? m2t / (float)(M - 1) : var_b;
         sg.run_mean[n] = (1.0f - sg.momentum) * sg.run_mean[n] + sg.momentum * mean;
         sg.run_var[n] = (1.0f - sg.momentum) * sg.run_var[n] + sg.momentum * var_u;
+    }
+}
+
+// SyncBN, merged half for all segments: allrec (world, nseg, 2N + 1) gathered records -> mean / var of the global batch of every segment
+// (+ running statistics) and 1 / (global row count) per segment.  The per-layer bn_sync_merge_kernel with a segment index.
+__global__ __launch_bounds__(256) void bnb_sync_merge_kernel(const BnBank a, const float* allrec, int world, float* inv_total_out) {
+    const int k = blockIdx.y;
+    const st_bn_bank_seg& sg = a.s[k];
+    const int N = a.N;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t rs = (size_t)2 * N + 1, ws_ = rs * a.nseg;
+    const float* rec = allrec + (size_t)k * rs;
+    float total = 0.0f;
+    for (int r = 0; r < world; ++r) total += rec[r * ws_ + 2 * N];
+    if (n == 0) inv_total_out[k] = 1.0f / total;
+    if (n >= N) return;
+    float acc = 0.0f;
+    for (int r = 0; r < world; ++r) acc = fmaf(rec[r * ws_ + 2 * N], rec[r * ws_ + n], acc);
+    const float mean = acc / total;
+    float m2 = 0.0f;
+    for (int r = 0; r < world; ++r) { const float d = rec[r * ws_ + n] - mean; m2 += rec[r * ws_ + N + n] + rec[r * ws_ + 2 * N] * d * d; }
+    sg.mean[n] = mean;
+    sg.var[n] = m2 / total;
+    if (sg.run_mean) {
+        sg.run_mean[n] = (1.0f - sg.momentum) * sg.run_mean[n] + sg.momentum * mean;
+        sg.run_var[n] = (1.0f - sg.momentum) * sg.run_var[n] + sg.momentum * (m2 / fmaxf(total - 1.0f, 1.0f));
     }
 }
 
@@ -900,11 +933,13 @@ __global__ __launch_bounds__(256) void bnb_bwd_final_kernel(const BnBank a, cons
     sg.sums[ic] = t;
 }
 
-__global__ __launch_bounds__(256) void bnb_bwd_apply_kernel(const BnBank a, const float* __restrict__ dY, int lddy, int Tout, int relu_in, int vec) {
+__global__ __launch_bounds__(256) void bnb_bwd_apply_kernel(const BnBank a, const float* __restrict__ dY, int lddy, int Tout, int relu_in, int vec,
+                                                            const float* __restrict__ inv_total) {
     const int k = blockIdx.y;
     const st_bn_bank_seg& sg = a.s[k];
     const int N = a.N, T = sg.T, M = a.Bn * T;
-    const float invM = 1.0f / (float)M;
+    // SyncBN: the sums were taken over every rank's rows; 1 / (global row count) of the segment comes as a device scalar
+    const float invM = inv_total ? inv_total[k] : 1.0f / (float)M;
     if (vec) {      // four channels per thread (N % 4 == 0, 16-byte addressable rows): one row / frame split per four elements
         const int N4 = N >> 2;
         const size_t total = (size_t)M * N4;
@@ -1235,6 +1270,8 @@ static int bnb_fill(BnBank& a, const st_bn_bank_seg* segs, int nseg, int Bn, int
     return 0;
 }
 
+static int bnb_norm_launch(const BnBank& a, const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* Y, int ldy, int Tout, hipStream_t st);
+
 extern "C" int st_bn_bank_fwd(const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* Y, int ldy, int Tout, float* ws, void* stream) {
     (void)hipGetLastError();
     BnBank a; int mc; size_t mr;
@@ -1244,8 +1281,46 @@ extern "C" int st_bn_bank_fwd(const st_bn_bank_seg* segs, int nseg, int Bn, int 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bnb_stats_chunk_kernel, dim3((N + 63) / 64, mc, nseg), dim3(256), 0, st, a, ws, mc);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bnb_stats_final_kernel, dim3((N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc);
+    hipLaunchKernelGGL(bnb_stats_final_kernel, dim3((N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc, (float*)nullptr);
     ST_LAUNCH_CHECK();
+    return bnb_norm_launch(a, segs, nseg, Bn, N, Y, ldy, Tout, st);
+}
+
+// ---- the same in its SyncBN stages (the collectives between them are the caller's): records -> [all-gather] -> merge -> normalise
+extern "C" int st_bn_bank_stats_record(const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* rec, float* ws, void* stream) {
+    (void)hipGetLastError();
+    BnBank a; int mc; size_t mr;
+    { const int rc = bnb_fill(a, segs, nseg, Bn, N, mc, mr, "st_bn_bank_stats_record"); if (rc) return rc; }
+    ST_CHECK_ARG(rec && ws, "st_bn_bank_stats_record: null record / workspace");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bnb_stats_chunk_kernel, dim3((N + 63) / 64, mc, nseg), dim3(256), 0, st, a, ws, mc);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnb_stats_final_kernel, dim3((N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc, rec);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_bank_sync_merge(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* allrec, int world, float* inv_total,
+                                     void* stream) {
+    (void)hipGetLastError();
+    BnBank a; int mc; size_t mr;
+    { const int rc = bnb_fill(a, segs, nseg, Bn, N, mc, mr, "st_bn_bank_sync_merge"); if (rc) return rc; }
+    ST_CHECK_ARG(allrec && world > 0 && inv_total, "st_bn_bank_sync_merge: bad arguments");
+    hipLaunchKernelGGL(bnb_sync_merge_kernel, dim3((N + 255) / 256, nseg), dim3(256), 0, (hipStream_t)stream, a, allrec, world, inv_total);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_bank_norm(const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* Y, int ldy, int Tout, void* stream) {
+    (void)hipGetLastError();
+    BnBank a; int mc; size_t mr;
+    { const int rc = bnb_fill(a, segs, nseg, Bn, N, mc, mr, "st_bn_bank_norm"); if (rc) return rc; }
+    ST_CHECK_ARG(Y && Tout > 0 && ldy >= nseg * N, "st_bn_bank_norm: bad output");
+    for (int k = 0; k < nseg; ++k) ST_CHECK_ARG(segs[k].T >= Tout, "st_bn_bank_norm: segment %d has %d frames, the bank %d", k, segs[k].T, Tout);
+    return bnb_norm_launch(a, segs, nseg, Bn, N, Y, ldy, Tout, (hipStream_t)stream);
+}
+
+static int bnb_norm_launch(const BnBank& a, const st_bn_bank_seg* segs, int nseg, int Bn, int N, float* Y, int ldy, int Tout, hipStream_t st) {
     int vec = N % 4 == 0 && ldy % 4 == 0 && st_aligned16(Y);
     for (int k = 0; k < nseg && vec; ++k)
         vec = segs[k].ldx % 4 == 0 && st_aligned16(segs[k].x) && st_aligned16(segs[k].mean) && st_aligned16(segs[k].var) &&
@@ -1255,25 +1330,48 @@ extern "C" int st_bn_bank_fwd(const st_bn_bank_seg* segs, int nseg, int Bn, int 
     return 0;
 }
 
+static int bnb_bwd_common(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, int relu_in, float* ws,
+                          int stage, const float* inv_total, void* stream, const char* who) {
+    BnBank a; int mc; size_t mr;
+    { const int rc = bnb_fill(a, segs, nseg, Bn, N, mc, mr, who); if (rc) return rc; }
+    ST_CHECK_ARG(dY && Tout > 0 && lddy >= nseg * N && (stage == 2 || ws), "%s: bad gradient / workspace", who);
+    for (int k = 0; k < nseg; ++k)
+        ST_CHECK_ARG(segs[k].sums && (stage == 1 || (segs[k].dx && segs[k].lddx >= N)) && segs[k].T >= Tout, "%s: segment %d incomplete", who, k);
+    hipStream_t st = (hipStream_t)stream;
+    if (stage != 2) {        // sums of this rank's rows
+        hipLaunchKernelGGL(bnb_bwd_reduce_kernel, dim3((N + 63) / 64, mc, nseg), dim3(256), 0, st, a, dY, lddy, Tout, ws, mc);
+        ST_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bnb_bwd_final_kernel, dim3((2 * N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc);
+        ST_LAUNCH_CHECK();
+    }
+    if (stage != 1) {
+        int vec = N % 4 == 0 && lddy % 4 == 0 && st_aligned16(dY);
+        for (int k = 0; k < nseg && vec; ++k)
+            vec = segs[k].ldx % 4 == 0 && segs[k].lddx % 4 == 0 && st_aligned16(segs[k].x) && st_aligned16(segs[k].dx) && st_aligned16(segs[k].mean) &&
+                  st_aligned16(segs[k].var) && st_aligned16(segs[k].sums) && (!segs[k].w || st_aligned16(segs[k].w));
+        hipLaunchKernelGGL(bnb_bwd_apply_kernel, dim3(blocks_for(mr * N / (vec ? 4 : 1), 1024), nseg), dim3(256), 0, st, a, dY, lddy, Tout, relu_in, vec,
+                           inv_total);
+        ST_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" int st_bn_bank_bwd(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, int relu_in, float* ws,
                               void* stream) {
     (void)hipGetLastError();
-    BnBank a; int mc; size_t mr;
-    { const int rc = bnb_fill(a, segs, nseg, Bn, N, mc, mr, "st_bn_bank_bwd"); if (rc) return rc; }
-    ST_CHECK_ARG(dY && ws && Tout > 0 && lddy >= nseg * N, "st_bn_bank_bwd: bad gradient / workspace");
-    for (int k = 0; k < nseg; ++k) ST_CHECK_ARG(segs[k].dx && segs[k].sums && segs[k].lddx >= N && segs[k].T >= Tout, "st_bn_bank_bwd: segment %d incomplete", k);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bnb_bwd_reduce_kernel, dim3((N + 63) / 64, mc, nseg), dim3(256), 0, st, a, dY, lddy, Tout, ws, mc);
-    ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bnb_bwd_final_kernel, dim3((2 * N + 15) / 16, nseg), dim3(256), 0, st, a, ws, mc);
-    ST_LAUNCH_CHECK();
-    int vec = N % 4 == 0 && lddy % 4 == 0 && st_aligned16(dY);
-    for (int k = 0; k < nseg && vec; ++k)
-        vec = segs[k].ldx % 4 == 0 && segs[k].lddx % 4 == 0 && st_aligned16(segs[k].x) && st_aligned16(segs[k].dx) && st_aligned16(segs[k].mean) &&
-              st_aligned16(segs[k].var) && st_aligned16(segs[k].sums) && (!segs[k].w || st_aligned16(segs[k].w));
-    hipLaunchKernelGGL(bnb_bwd_apply_kernel, dim3(blocks_for(mr * N / (vec ? 4 : 1), 1024), nseg), dim3(256), 0, st, a, dY, lddy, Tout, relu_in, vec);
-    ST_LAUNCH_CHECK();
-    return 0;
+    return bnb_bwd_common(segs, nseg, Bn, N, dY, lddy, Tout, relu_in, ws, 0, nullptr, stream, "st_bn_bank_bwd");
+}
+
+// SyncBN stages: local sums -> [all-reduce by the caller] -> apply with the global sums and 1 / (global row count) per segment
+extern "C" int st_bn_bank_bwd_reduce(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, float* ws, void* stream) {
+    (void)hipGetLastError();
+    return bnb_bwd_common(segs, nseg, Bn, N, dY, lddy, Tout, 0, ws, 1, nullptr, stream, "st_bn_bank_bwd_reduce");
+}
+
+extern "C" int st_bn_bank_bwd_apply(const st_bn_bank_seg* segs, int nseg, int Bn, int N, const float* dY, int lddy, int Tout, int relu_in,
+                                    const float* inv_total, void* stream) {
+    (void)hipGetLastError();
+    return bnb_bwd_common(segs, nseg, Bn, N, dY, lddy, Tout, relu_in, nullptr, 2, inv_total, stream, "st_bn_bank_bwd_apply");
 }
 
 extern "C" int st_highway_ht_fwd(const float* ht, const float* x, float* y, int M, int C, void* stream) {

@@ -750,8 +750,7 @@ def _cbhg_forward_train(self, x):
     acts = set(blk.activation is not None for blk in self.conv1d_banks)
     assert len(acts) == 1
     relu = acts.pop()
-    from . import parallel
-    bank_launches = not parallel.sync_bn_active() and len(self.conv1d_banks) <= 16      # (SyncBN: the group function shares the collectives)
+    bank_launches = len(self.conv1d_banks) <= 16      # (also under SyncBN: one all-gather and one all-reduce for the whole bank)
     pre = AG.conv_group(x, [blk.conv1d.weight for blk in self.conv1d_banks], [blk.padding for blk in self.conv1d_banks],
                         [T + 1 if (i + 1) % 2 == 0 else T for i in range(len(self.conv1d_banks))], act='relu' if relu else None,
                         act_grad_done=bank_launches and relu)

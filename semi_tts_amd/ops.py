@@ -936,6 +936,49 @@ def bn_bank_fwd(xs, bns, Tout):
     return Y, stats
 
 
+def bn_bank_fwd_sync(xs, bns, Tout):
+    """bn_bank_fwd under SyncBN: this rank's records -> ONE all-gather -> merge -> normalise.  Returns the bank, the (K, 2, N) global
+    statistics and inv_total (K) = 1 / global row count per segment."""
+    from . import parallel
+    lib = _lib.load()
+    n, (Bn, _, N) = len(xs), xs[0].shape
+    dev = xs[0].device
+    stats = torch.empty(n, 2, N, device=dev, dtype=torch.float32)
+    Y = torch.empty(Bn, Tout, n * N, device=dev, dtype=torch.float32)
+    ws = torch.empty(int(lib.st_bn_bank_workspace_floats(n, int(Bn * max(x.shape[1] for x in xs)), int(N))), device=dev, dtype=torch.float32)
+    segs = _bn_bank_segs(xs, bns, [stats[k, 0] for k in range(n)], [stats[k, 1] for k in range(n)])
+    rec = torch.empty(n, 2 * N + 1, device=dev, dtype=torch.float32)
+    check(lib.st_bn_bank_stats_record(segs, n, int(Bn), int(N), _p(rec), _p(ws), stream_handle()), 'st_bn_bank_stats_record')
+    allrec = parallel.all_gather_(rec).contiguous()                       # (world, n, 2N + 1)
+    inv_total = torch.empty(n, device=dev, dtype=torch.float32)
+    check(lib.st_bn_bank_sync_merge(segs, n, int(Bn), int(N), _p(allrec), int(allrec.shape[0]), _p(inv_total), stream_handle()),
+          'st_bn_bank_sync_merge')
+    check(lib.st_bn_bank_norm(segs, n, int(Bn), int(N), _p(Y), n * int(N), int(Tout), stream_handle()), 'st_bn_bank_norm')
+    return Y, stats, inv_total
+
+
+def bn_bank_bwd_sync(dY, xs, bns, stats, inv_total, relu_in):
+    """backward of bn_bank_fwd_sync: local sums -> ONE all-reduce -> apply.  Returns (dxs, LOCAL sums (K, 2, N)): the parameter gradients
+    keep this rank's sums (the gradient reducer averages them over the ranks), dx uses the global ones."""
+    from . import parallel
+    lib = _lib.load()
+    n, (Bn, _, N) = len(xs), xs[0].shape
+    dev = xs[0].device
+    dxs = [torch.empty_like(x) for x in xs]
+    local = torch.empty(n, 2, N, device=dev, dtype=torch.float32)
+    ws = torch.empty(int(lib.st_bn_bank_workspace_floats(n, int(Bn * max(x.shape[1] for x in xs)), int(N))), device=dev, dtype=torch.float32)
+    means, vars_ = [stats[k, 0] for k in range(n)], [stats[k, 1] for k in range(n)]
+    segs = _bn_bank_segs(xs, bns, means, vars_, dxs, [local[k] for k in range(n)], update_running=False)
+    check(lib.st_bn_bank_bwd_reduce(segs, n, int(Bn), int(N), _p(dY), int(dY.stride(-2)), int(dY.shape[1]), _p(ws), stream_handle()),
+          'st_bn_bank_bwd_reduce')
+    glob = local.clone()
+    parallel.all_reduce_sum_(glob)
+    segs = _bn_bank_segs(xs, bns, means, vars_, dxs, [glob[k] for k in range(n)], update_running=False)
+    check(lib.st_bn_bank_bwd_apply(segs, n, int(Bn), int(N), _p(dY), int(dY.stride(-2)), int(dY.shape[1]), 1 if relu_in else 0, _p(inv_total),
+                                   stream_handle()), 'st_bn_bank_bwd_apply')
+    return dxs, local
+
+
 def bn_bank_bwd(dY, xs, bns, stats, relu_in):
     """backward of bn_bank_fwd: dx_k over every row of segment k (through the ReLU in front of the norm when relu_in) and the (K, 2, N)
     sums (d bias, d weight): 3 launches"""

@@ -89,7 +89,7 @@ def host_cores():
 
 def cpu_timed(short_fn, full_fn, units_per_pass, unit, kind, sample, max_passes=3, budget=(25.0, 45.0)):
     """CPU baseline protocol shared by every workload: B=32 GEMMs stop scaling long before a 128-core host is full (and
-    oversubscribed thread pools get pathologically slow), so `short_fn()` (a few per cent of a pass) is timed at 8 ... all cores
+    oversubscribed thread pools get pathologically slow), so `short_fn()` (a few per cent of a pass) is timed at 8 ... 64 threads
     first; `full_fn(i)` (one full pass of the workload) then runs 1 warm-up + up to `max_passes` timed passes at the two fastest
     settings, and the better median is the baseline.  Bounded: the probe stops after 20 s, the passes after `budget` seconds."""
     import numpy as np
@@ -98,7 +98,7 @@ def cpu_timed(short_fn, full_fn, units_per_pass, unit, kind, sample, max_passes=
     probe = []
     t_start = time.perf_counter()
     with torch.no_grad() if kind != 'nn_modules_autograd' else torch.enable_grad():
-        for threads in sorted({t for t in (8, 16, 32, 64, cores) if t <= cores}):
+        for threads in sorted({t for t in (8, 16, 32, 64, min(cores, 64)) if t <= cores}):   # > 64 threads never won (r04: 13.7 s at 256)
             torch.set_num_threads(threads)
             short_fn()                                             # warm-up of the thread pool at this size
             t0 = time.perf_counter()

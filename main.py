@@ -23,8 +23,16 @@ parser.add_argument('--load', default=None, type=str, help='Load pre-trained mod
 parser.add_argument('--seed', default=0, type=int, help='Random seed for reproducable results.')
 parser.add_argument('--njobs', default=5, type=int, help='(unused: no data loader workers)')
 parser.add_argument('--cpu', action='store_true', help='Not supported: the path is MI355X-only.')
+parser.add_argument('--debug', action='store_true', help='Debug use. (parsed and never read by the reference either)')
+parser.add_argument('--no-pin', action='store_true', help='Disable pin-memory for dataloader (no data loader here: ignored)')
+parser.add_argument('--asr-decode', action='store_true', help='ASR beam decode (the reference dispatches to bin/asr_decode.py, which its tree lacks)')
 parser.add_argument('--gen-specgram', action='store_true', help='Generating mel/linear spectrogram.')
+parser.add_argument('--gen-gt-specgram', action='store_true', help='(the reference dispatches to bin/gen_gt_specgram.py, which its tree lacks)')
 parser.add_argument('--no-msg', action='store_true', help='Hide all messages.')
+parser.add_argument('--actual-len', action='store_true', help='Using actual len for CTC loss. (synthetic inputs are full length: no effect)')
+parser.add_argument('--store-best-per', action='store_true', help='Only store the model with best PER. (no dev corpus: no effect)')
+parser.add_argument('--asr-only', action='store_true', help='(the reference dispatches to bin/train_asr.py, which its tree lacks)')
+parser.add_argument('--gen-wav', action='store_true', help='Generate waveform using Griffin-Lim. (audio back end out of scope: ignored)')
 # synthetic-data knobs (the reference reads these from the corpus)
 parser.add_argument('--frames', default=256, type=int, help='mel frames per synthetic utterance')
 parser.add_argument('--batch-size', default=None, type=int)
@@ -35,10 +43,34 @@ parser.add_argument('--async-stats', action='store_true', help='training: no hos
                     'a NaN gradient norm skips the update on the device)')
 
 
-def main():
-    paras = parser.parse_args()
+# Flags of the reference (main.py:23-33) with nothing to do on this path, and those whose solver files are
+# absent from the reference tree itself (main.py:49-60 import bin/asr_decode.py, bin/gen_gt_specgram.py,
+# bin/train_asr.py, none of which exist): accepted by the parser so that existing launch lines keep working.
+IGNORED_FLAGS = ('debug', 'no_pin', 'actual_len', 'store_best_per', 'gen_wav')
+MISSING_SOLVERS = {'asr_decode': 'bin/asr_decode.py', 'gen_gt_specgram': 'bin/gen_gt_specgram.py',
+                   'asr_only': 'bin/train_asr.py'}
+
+
+def parse_args(argv=None):
+    """The reference's command lines parse unchanged (ref: main.py:14-41); returns the same `paras`
+    attributes it sets (`gpu`, `pin_memory` -- inverted there as here, main.py:40 --, `verbose`)."""
+    paras = parser.parse_args(argv)
     setattr(paras, 'gpu', not paras.cpu)
+    setattr(paras, 'pin_memory', False if paras.cpu else paras.no_pin)
     setattr(paras, 'verbose', not paras.no_msg)
+    for flag, path in MISSING_SOLVERS.items():
+        if getattr(paras, flag):
+            parser.error('--%s: the reference dispatches this mode to %s, which is not part of the reference tree; '
+                         'only the default (training) and --gen-specgram modes exist' % (flag.replace('_', '-'), path))
+    if paras.verbose:
+        for flag in IGNORED_FLAGS:
+            if getattr(paras, flag):
+                print('[INFO] --%s accepted for compatibility; it has no effect on this path' % flag.replace('_', '-'))
+    return paras
+
+
+def main(argv=None):
+    paras = parse_args(argv)
     config = yaml.load(open(paras.config, 'r'), Loader=yaml.FullLoader)
     if paras.batch_size is None:
         paras.batch_size = config['data']['corpus'].get('batch_size', 8)

@@ -29,6 +29,9 @@ def test_library_exports_every_declared_symbol():
     assert not missing, 'declared in semitts.h but not exported: %s' % missing
     # and the ctypes table binds exactly the declared set
     assert sorted(_lib.SIGNATURES) == declared
+    # INTEGRATION.md quotes the count of entry points: keep it the header's
+    quoted = re.search(r'entry points \((\d+)\)', open(os.path.join(REPO, 'INTEGRATION.md')).read())
+    assert quoted and int(quoted.group(1)) == len(declared), (quoted and quoted.group(1), len(declared))
     lib2 = _lib.load()
     assert lib2.st_abi_version() == 1
     assert lib2.st_t16_floats(32, 240) == 2 * 15 * 256
@@ -330,3 +333,34 @@ def test_bench_ranks_fall_back_to_gloo_when_the_rccl_probe_fails(tmp_path, fake)
     assert res['backend'] == 'gloo' and res['rccl_ranks'] == 0 and res['t'] == 2.0
     assert res['collectives']['backend'] == 'gloo' and res['collectives']['rccl_probe'].startswith('failed: rank')
     assert ('faked' in res['collectives']['rccl_probe']) == fake
+
+
+# Command lines of the reference's README ("Running": train from scratch / continue / inference) and every flag its parser
+# defines (ref: main.py:14-33).  Data, not code: an existing launch script must keep parsing.
+_REFERENCE_COMMAND_LINES = [
+    '--config config/supervised.yaml --njobs 8',
+    '--config config/supervised.yaml --njobs 8 --load ckpt/x/step_10000.pth',
+    '--gen-specgram --config config/supervised.yaml --njobs 8 --load ckpt/x/tts_1.pth --logdir out/',
+    '--config config/semi-multi-spkr-paired-data.yaml --name exp --logdir log/ --ckpdir ckpt/ --seed 3 --njobs 5 --debug '
+    '--no-pin --no-msg --actual-len --store-best-per --gen-wav',
+    '--config config/supervised.yaml --cpu',
+]
+
+
+@pytest.mark.parametrize('line', _REFERENCE_COMMAND_LINES)
+def test_main_parses_the_reference_command_lines(line):
+    sys.path.insert(0, REPO)
+    import main as entry
+    paras = entry.parse_args(line.split())
+    assert paras.gpu == (not paras.cpu) and paras.verbose == (not paras.no_msg)
+    assert paras.pin_memory == (False if paras.cpu else paras.no_pin)     # inverted in the reference too (main.py:40)
+    assert paras.config.startswith('config/')
+
+
+@pytest.mark.parametrize('flag', ['--asr-decode', '--gen-gt-specgram', '--asr-only'])
+def test_main_names_the_solvers_the_reference_tree_lacks(flag, capsys):
+    sys.path.insert(0, REPO)
+    import main as entry
+    with pytest.raises(SystemExit):
+        entry.parse_args(['--config', 'config/supervised.yaml', flag])
+    assert 'not part of the reference tree' in capsys.readouterr().err

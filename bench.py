@@ -640,6 +640,9 @@ def bench_train(args, rk):
         parallel.set_gradient_allreduce(True)
         parallel.sync_batchnorm(False)
         variants['no_syncbn'] = rk.timed(step, args.steps, 1)
+        parallel.set_gradient_allreduce(False)                    # the reducer attached, no collective at all: its own bookkeeping
+        variants['reducer_only'] = rk.timed(step, args.steps, 1)
+        parallel.set_gradient_allreduce(True)
         parallel.sync_batchnorm(True)
     # a starved in-launch hand-off poisons the forward with NaN and the guarded Adam then skips every update on the device: a step
     # time measured over skipped steps is not a measurement
@@ -665,12 +668,24 @@ def bench_train(args, rk):
             'ms_syncbn': round(ms['full'] - ms['no_syncbn'], 3) if 'no_syncbn' in ms else 0.0,
             'ms_variants': {k: round(v, 3) for k, v in ms.items()},
             'collectives_per_step': counts,
+            **({'reducer': dict(tr.reducer.stats, buckets=len(tr.reducer.buckets), static_graph=tr.reducer._sparse)} if getattr(tr, 'reducer', None) is not None else {}),
             # whole-step roofline: forward 132 GFLOP per C2 batch, training ~3x that, against the fp32 matrix peak
-            'roofline': {'bound': 'mfma', 'kernel': 'whole training step (~940 launches; the largest shares are the per-step products of the two loops and the weight-gradient GEMM tn_dma_kernel)',
+            'roofline': {'bound': 'mfma', 'kernel': 'whole training step (%s; the largest shares are the per-step products of the two loops and the weight-gradient GEMM tn_dma_kernel)' % _train_launches(),
                          'achieved': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None},
             'last': {k: float(last['st'][k]) for k in ('loss', 'grad_norm')}, 'stats_read': 'per step' if args.sync_stats else 'after the timed steps', 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             **({'cpu_baseline': cpu} if cpu is not None else {})}
+
+
+def _train_launches():
+    """launches of one training step as counted by the committed rocprofv3 kernel trace of one step (tools/gpu_train_prof.sh)"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_train_one_step_kernel_stats.csv')))
+    if not files:
+        return 'launch count: no committed kernel trace'
+    n = sum(float(r['launches_per_step']) for r in csv.DictReader(open(files[-1])))
+    return '%d launches per step in profiles/%s' % (round(n), os.path.basename(files[-1]))
 
 
 def cpu_baseline_train(tr, batch, config):

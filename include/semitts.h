@@ -885,6 +885,14 @@ int st_ctc_loss(const float* prob, const int64_t* text, float eps, float* loss, 
 size_t st_freq_loss_workspace_floats(void);
 int st_freq_loss(const float* pred, const float* label, float* loss, float* dpred, float* ws,
                  int B, int T, int D, int n_low, float w_all, float w_low, float w_diff, int l1, void* stream);
+/* st_gemm_wgrad[_db] of a Linear over CONCATENATED inputs (KT = 1; M rows), the result cut at input column `split`:
+ * dW0 (N, split) and dW1 (N, Cin - split) are the gradients of the two weights whose columns the product saw side by side -- an
+ * nn.LSTMCell fed with [x | h] has gates = [W_ih | W_hh] [x | h]^T (ref: src/module.py:227-231,275-280), so the BPTT weight gradient
+ * over the step tapes lands in the two parameters' own gradient tensors (under data parallelism: in their all-reduce bucket slots)
+ * instead of one tensor that two copies then cut up.  db (may be NULL) = column sums of dC; db_dup (may be NULL) receives the same
+ * sums once more (b_ih and b_hh have equal gradients). */
+int st_gemm_wgrad_split(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW0, int split, float* dW1,
+                        float* db, float* db_dup, float* ws, int M, int Cin, int N, int accumulate, void* stream);
 /* y = x * (*scalar)   (scalar on the device: the incoming gradient of a scalar loss) */
 int st_scale_by(const float* x, const float* scalar, float* y, size_t n, void* stream);
 
@@ -897,6 +905,15 @@ size_t st_mt_blocks(const long* n, int nt);                   /* floats of `part
 int st_mt_grad_norm(float* const* g, const long* n, int nt, float* partials, float* norm_out, void* stream);
 /* g *= max_norm / (norm + 1e-6) when that is < 1 (torch.nn.utils.clip_grad_norm_); norm is a device scalar */
 int st_mt_clip_scale(float* const* g, const long* n, int nt, const float* norm, float max_norm, void* stream);
+/* The same pair for gradients that are still the SUM over `world` data-parallel ranks (pre_scale = 1 / world): *norm_out =
+ * pre_scale * sqrt(sum g^2) = the norm of the AVERAGED gradients, and the clip launch multiplies every gradient by
+ * pre_scale * min(1, max_norm / (norm + 1e-6)) -- the average of the all-reduce costs no launch of its own (ref: the reference
+ * clips the single-process gradient, src/solver.py:145; data parallelism is this path's extension). */
+int st_mt_grad_norm_scaled(float* const* g, const long* n, int nt, float* partials, float* norm_out, float pre_scale, void* stream);
+int st_mt_clip_scale_pre(float* const* g, const long* n, int nt, const float* norm, float max_norm, float pre_scale, void* stream);
+/* dst_t[i] = src_t[i] for nt tensors in a handful of launches (gradients that autograd allocated elsewhere are gathered into their
+ * all-reduce bucket by one call per bucket) */
+int st_mt_copy(float* const* dst, float* const* src, const long* n, int nt, void* stream);
 /* torch.optim.Adam (no weight decay, no amsgrad): m = m + (g-m)(1-b1); v = b2 v + (1-b2) g^2;
  * p -= step_size * m / (sqrt(v)/bias_correction2_sqrt + eps), step_size = lr / (1 - b1^t) */
 int st_mt_adam(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,

@@ -248,6 +248,9 @@ SIGNATURES = {
     'st_mt_blocks': [P, I],
     'st_mt_grad_norm': [P, P, I, P, P, P],
     'st_mt_clip_scale': [P, P, I, P, F, P],
+    'st_mt_grad_norm_scaled': [P, P, I, P, P, F, P],
+    'st_mt_clip_scale_pre': [P, P, I, P, F, F, P],
+    'st_mt_copy': [P, P, P, I, P],
     'st_mt_adam': [P, P, P, P, P, I, F, F, F, F, F, P],
     'st_mt_adam_guarded': [P, P, P, P, P, I, F, F, F, F, F, P, P],
     'st_freq_loss': [P, P, P, P, P, I, I, I, I, F, F, F, I, P],
@@ -257,6 +260,7 @@ SIGNATURES = {
     'st_gemm_wgrad_workspace_floats': [I, I, I, I, I],
     'st_gemm_wgrad': [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, I, P],
     'st_gemm_wgrad_db': [P, I, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    'st_gemm_wgrad_split': [P, I, I, P, I, P, I, P, P, P, P, I, I, I, I, P],
     'st_colsum': [P, I, I, P, I, I, I, I, P, I, P, P],
     'st_act_bwd': [P, I, P, I, I, P, I, P, I, I, I, P],
     'st_bn_bwd': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, I, I, P, P, I, P, P],

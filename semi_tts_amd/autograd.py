@@ -46,13 +46,13 @@ class _ConvFn(Function):
             y = ops.gemm(xp, w, pad=pad, stride=stride, Tout=Tout, bias=b, act_pre=act, res=res, mask=mask)
         else:
             y = ops.gemm(x, w, pad=pad, stride=stride, Tout=Tout, bias=b, act_pre=act, res=res, mask=mask, pool_prev=pool_prev)
-        ctx.save_for_backward(x, w, y if act is not None else None, mask, xp)
+        ctx.save_for_backward(x, w, y if act is not None else None, mask, xp, b)
         ctx.cfg = (pad, act, pool_prev, b is not None, res is not None, stride)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y, mask, xp = ctx.saved_tensors
+        x, w, y, mask, xp, b = ctx.saved_tensors
         pad, act, pool_prev, has_b, has_res, stride = ctx.cfg
         xw, pool_w = (xp, False) if xp is not None else (x, pool_prev)       # the weight gradient's activation operand
         dy = dy.contiguous()
@@ -73,7 +73,7 @@ class _ConvFn(Function):
         # (the bias gradient rides in the weight-gradient launches when both are wanted and the conv has stride 1)
         db_in_wgrad = has_b and ctx.needs_input_grad[2] and ctx.needs_input_grad[1] and stride == 1
         if has_b and ctx.needs_input_grad[2] and not db_in_wgrad:
-            db = ops.colsum(_rows(dpre))
+            db = ops.colsum(_rows(dpre), out=ops.grad_slot(b))
         if stride > 1:
             # a stride-s conv is the stride-1 conv sampled every s positions: its gradients are those of the stride-1 conv for
             # an output gradient with zeros in between (zero-stuffing; only the speech encoder's second layer takes this path)
@@ -82,7 +82,7 @@ class _ConvFn(Function):
             ops.fill_(up, 0.0)
             ops.copy3d(up[:, 0:(To - 1) * stride + 1:stride], dpre.view(Bn, To, N), Bn, To, N)
             dpre, To = up, To1
-        if (KT == 1 and N % 4 != 0 and N >= 64 and Cin % 4 == 0 and not pool_prev and stride == 1 and w.is_contiguous()
+        if (KT == 1 and w.dim() == 2 and pad == 0 and N % 4 != 0 and N >= 64 and Cin % 4 == 0 and not pool_prev and stride == 1 and w.is_contiguous()
                 and _rows(dpre).shape[0] >= 1024 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]):
             # a Linear whose output width is not a multiple of 4 (Linear(160, 1025) of the postnet): rows of dy are not 16-byte addressable
             # and both backward products fall to the element-wise kernels (68 + 74 us at C2).  One copy into rows padded to Np floats
@@ -108,11 +108,13 @@ class _ConvFn(Function):
             dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pad, w_tap_major=tap_major)
             if pool_prev:
                 dx = ops.pool_prev_bwd(dx, x)
+        # (the parameter gradients are written where ops.grad_slot says: under data parallelism, into their all-reduce bucket)
         if db_in_wgrad:
-            dw, db = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, with_db=True)
+            dw, db = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, with_db=True,
+                                    out=ops.grad_slot(w), db_out=ops.grad_slot(b))
             dw = dw.view(w.shape)
         elif ctx.needs_input_grad[1]:
-            dw = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w).view(w.shape)
+            dw = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, out=ops.grad_slot(w)).view(w.shape)
         dres = dy if has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None, None, None, None, None
 
@@ -135,7 +137,7 @@ class _ConvGroupFn(Function):
         ops.gemm_flush(jobs)
         if grad_done:
             act = None
-        ctx.save_for_backward(x, *ws, *(ys if act is not None else []))
+        ctx.save_for_backward(x, *ws, *bs, *(ys if act is not None else []))
         ctx.cfg = (n, act, [int(cfg[2 * k]) for k in range(n)], [b is not None for b in bs])
         ctx.extra = len(args) - 4 * n
         return tuple(ys)
@@ -144,7 +146,7 @@ class _ConvGroupFn(Function):
     def backward(ctx, *dys):
         n, act, pads, has_b = ctx.cfg
         sv = ctx.saved_tensors
-        x, ws, ys = sv[0], sv[1:1 + n], sv[1 + n:]
+        x, ws, bs, ys = sv[0], sv[1:1 + n], sv[1 + n:1 + 2 * n], sv[1 + 2 * n:]
         if x.dim() == 3:
             Bn, Tin, Cin = x.shape
         else:
@@ -165,12 +167,13 @@ class _ConvGroupFn(Function):
             dw = db = None
             want_w, want_b = ctx.needs_input_grad[3 + k], has_b[k] and ctx.needs_input_grad[3 + n + k]
             if want_w and want_b:
-                dw, db = ops.gemm_wgrad(dpre, x, KT, pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N, with_db=True)
+                dw, db = ops.gemm_wgrad(dpre, x, KT, pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N, with_db=True,
+                                        out=ops.grad_slot(w), db_out=ops.grad_slot(bs[k]))
                 dw = dw.view(w.shape)
             elif want_w:
-                dw = ops.gemm_wgrad(dpre, x, KT, pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N).view(w.shape)
+                dw = ops.gemm_wgrad(dpre, x, KT, pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N, out=ops.grad_slot(w)).view(w.shape)
             elif want_b:
-                db = ops.colsum(_rows(dpre))
+                db = ops.colsum(_rows(dpre), out=ops.grad_slot(bs[k]))
             dws.append(dw)
             dbs.append(db)
         if dx is not None:
@@ -594,12 +597,12 @@ class _BiLstmFn(Function):
         gs = [torch.empty(T, B, 4, H, device=dev, dtype=torch.float32) for _ in range(2)]
         cs = [torch.empty(T, B, H, device=dev, dtype=torch.float32) for _ in range(2)]
         ops.lstm_seq2(xp_f.contiguous(), xp_b.contiguous(), w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, gs, cs)
-        ctx.save_for_backward(out, w_hh_f, w_hh_b, gs[0], cs[0], gs[1], cs[1])
+        ctx.save_for_backward(out, w_hh_f, w_hh_b, gs[0], cs[0], gs[1], cs[1], b_hh_f, b_hh_b)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        out, w_hh_f, w_hh_b, g_f, c_f, g_b, c_b = ctx.saved_tensors
+        out, w_hh_f, w_hh_b, g_f, c_f, g_b, c_b, b_hh_f, b_hh_b = ctx.saved_tensors
         dout = dout.contiguous()
         H = w_hh_f.shape[1]
         res = []
@@ -610,8 +613,8 @@ class _BiLstmFn(Function):
         for d in range(2):
             dxp = dxps[d]
             # h_{t-1} of the forward direction is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1 / -1
-            dw = ops.gemm_wgrad(dxp, out[:, :, d * H:(d + 1) * H], 1, 1 if d == 0 else -1)
-            db = ops.colsum(_rows(dxp))
+            dw = ops.gemm_wgrad(dxp, out[:, :, d * H:(d + 1) * H], 1, 1 if d == 0 else -1, out=ops.grad_slot((w_hh_f, w_hh_b)[d]))
+            db = ops.colsum(_rows(dxp), out=ops.grad_slot((b_hh_f, b_hh_b)[d]))
             res.append((dxp, dw, db))
         return res[0][0], res[1][0], res[0][1], res[0][2], res[1][1], res[1][2]
 
@@ -633,15 +636,15 @@ class _LstmFn(Function):
         g = torch.empty(T, B, 4, H, device=dev, dtype=torch.float32)
         c = torch.empty(T, B, H, device=dev, dtype=torch.float32)
         ops.lstm_seq(xp.contiguous(), w_hh, b_hh, out, 0, False, gates_tape=g, c_tape=c)
-        ctx.save_for_backward(out, w_hh, g, c)
+        ctx.save_for_backward(out, w_hh, g, c, b_hh)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        out, w_hh, g, c = ctx.saved_tensors
+        out, w_hh, g, c, b_hh = ctx.saved_tensors
         dxp = ops.lstm_seq_bwd(dout.contiguous(), 0, g, c, ops.dx_weight(w_hh.detach())[0], False)
-        dw = ops.gemm_wgrad(dxp, out, 1, 1)              # h_{t-1} is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1
-        return dxp, dw, ops.colsum(_rows(dxp))
+        dw = ops.gemm_wgrad(dxp, out, 1, 1, out=ops.grad_slot(w_hh))      # h_{t-1} is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1
+        return dxp, dw, ops.colsum(_rows(dxp), out=ops.grad_slot(b_hh))
 
 
 def lstm(xp, w_hh, b_hh):
@@ -658,17 +661,18 @@ class _BiGruFn(Function):
         out = torch.empty(B, T, 2 * H, device=gi_f.device, dtype=torch.float32)
         tape = torch.empty(2, B, T, 4, H, device=gi_f.device, dtype=torch.float32)
         ops.gru_seq(gi_f.contiguous(), gi_b.contiguous(), w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, tape)
-        ctx.save_for_backward(out, tape, w_hh_f, w_hh_b)
+        ctx.save_for_backward(out, tape, w_hh_f, w_hh_b, b_hh_f, b_hh_b)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        out, tape, w_hh_f, w_hh_b = ctx.saved_tensors
+        out, tape, w_hh_f, w_hh_b, b_hh_f, b_hh_b = ctx.saved_tensors
         H = w_hh_f.shape[1]
         dgi_f, dgi_b, dgh_f, dgh_b = ops.gru_seq_bwd(dout.contiguous(), out, tape, w_hh_f, w_hh_b)
-        dw_f = ops.gemm_wgrad(dgh_f, out[:, :, :H], 1, 1)
-        dw_b = ops.gemm_wgrad(dgh_b, out[:, :, H:], 1, -1)
-        return dgi_f, dgi_b, dw_f, ops.colsum(_rows(dgh_f)), dw_b, ops.colsum(_rows(dgh_b))
+        dw_f = ops.gemm_wgrad(dgh_f, out[:, :, :H], 1, 1, out=ops.grad_slot(w_hh_f))
+        dw_b = ops.gemm_wgrad(dgh_b, out[:, :, H:], 1, -1, out=ops.grad_slot(w_hh_b))
+        return (dgi_f, dgi_b, dw_f, ops.colsum(_rows(dgh_f), out=ops.grad_slot(b_hh_f)), dw_b,
+                ops.colsum(_rows(dgh_b), out=ops.grad_slot(b_hh_b)))
 
 
 def bigru(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
@@ -854,10 +858,13 @@ class _DecoderFn(Function):
 
         # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)
         dgq2, dgd2 = dgq.view(-1, 4 * Q), dgd.view(-1, 4 * D)
-        dwq_cat, dbq = ops.gemm_wgrad(dgq2, XQ[:steps].reshape(-1, XQw), with_db=True)      # (bias gradients inside the same launches)
-        dwd_cat, dbd = ops.gemm_wgrad(dgd2, XD.view(-1, XDw), with_db=True)
+        # the gradients of [W_ih | W_hh] leave the product's slab sum as the two parameters' own tensors, the bias gradient twice (b_ih
+        # and b_hh receive the same sums): no slicing copies -- and under data parallelism all of them are written straight into
+        # their all-reduce bucket slots (ops.grad_slot)
+        dwq_ih, dwq_hh, dbq, dbq2 = ops.gemm_wgrad_split(dgq2, XQ[:steps].reshape(-1, XQw), P + E, q_w_ih, q_w_hh, q_b_ih, q_b_hh, with_db=True)
+        dwd_ih, dwd_hh, dbd, dbd2 = ops.gemm_wgrad_split(dgd2, XD.view(-1, XDw), E + Q, d_w_ih, d_w_hh, d_b_ih, d_b_hh, with_db=True)
         dwpg, dbpg = ops.gemm_wgrad(dY2, XO.view(-1, XOw), with_db=True)
-        dwq_attn = ops.gemm_wgrad(dpq.view(-1, A), hq_all)
+        dwq_attn = ops.gemm_wgrad(dpq.view(-1, A), hq_all, out=ops.grad_slot(wq))
         # attention parameters / inputs: sums over the steps of the per-step tape slices
         dv = ops.colsum(dv_tape.view(-1, A)).view(v.shape)
         dwl = ops.gemm_wgrad(ds_tape.view(-1, A), loc_tape.view(-1, F))                     # (A, F)
@@ -899,9 +906,9 @@ class _DecoderFn(Function):
         ddec_in0 = dxq[0, :B, :P].contiguous() if ctx.has_in0 else None     # gradient of dec_in_0 = prenet(go frame)
         grads = (None, None, dmem, dpm, dstd, dmean, dteacher, ddec_in0,
                  dpre_w0, dpre_w1,                                                # prenet weights: only via own-output feedback
-                 c(dwq_cat[:, :P + E]), c(dwq_cat[:, P + E:]), dbq, dbq.clone(),
+                 dwq_ih, dwq_hh, dbq, dbq2,
                  dwq_attn, dv, dwc, dwl,
-                 c(dwd_cat[:, :E + Q]), c(dwd_cat[:, E + Q:]), dbd, dbd.clone(),
+                 dwd_ih, dwd_hh, dbd, dbd2,
                  c(dwpg[:in_dim]), c(dbpg[:in_dim]), c(dwpg[in_dim:in_dim + 1]), c(dbpg[in_dim:in_dim + 1]))
         if pre_norm:
             grads += tuple(dnorm[i] for i in range(4)) if own else (None,) * 4

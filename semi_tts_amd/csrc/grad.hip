@@ -418,8 +418,13 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, fl
 }
 
 // the same for a product with its bias gradient: elements [0, n) go to out, [n, n + nb) to out_b (slabs part_b[z][nb]; never accumulated)
+// SPLIT: the (rows, cols) result leaves as two matrices, columns [0, split) to out (rows, split) and [split, cols) to out1
+// (rows, cols - split): the gradient of a product over concatenated inputs [W_ih | W_hh] goes straight to the two parameters'
+// own gradient tensors (st_gemm_wgrad_split) instead of one tensor that is then cut up by two copies.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void sum_partials2_kernel(const float* part, float* out, size_t n, int Z, int accumulate,
-                                                            const float* part_b, float* out_b, size_t nb) {
+                                                            const float* part_b, float* out_b, size_t nb,
+                                                            float* out1, int cols, int split, float* out_b_dup) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + nb; i += (size_t)gridDim.x * blockDim.x) {
         const bool isb = i >= n;
         const float* p = isb ? part_b + (i - n) : part + i;
@@ -431,8 +436,14 @@ __global__ __launch_bounds__(256) void sum_partials2_kernel(const float* part, f
         }
         for (; z < Z; ++z) s0 += p[(size_t)z * stride];
         const float s = (s0 + s1) + (s2 + s3);
-        if (isb) out_b[i - n] = s;
-        else out[i] = accumulate ? out[i] + s : s;
+        if (isb) { out_b[i - n] = s; if (SPLIT && out_b_dup) out_b_dup[i - n] = s; continue; }
+        float* o = out + i;
+        if (SPLIT) {
+            const size_t row = i / (size_t)cols;
+            const int col = (int)(i - row * (size_t)cols);
+            o = col < split ? out + row * (size_t)split + col : out1 + row * (size_t)(cols - split) + (col - split);
+        }
+        *o = accumulate ? *o + s : s;
     }
 }
 
@@ -1087,7 +1098,7 @@ extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int 
 
 static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* db, float* ws,
                    int Bn, int Tin, int Tout, int Cin, int N, int KT, int pad, int pool_prev, int accumulate,
-                   void* stream) {
+                   void* stream, float* dW1 = nullptr, int split = 0, float* db_dup = nullptr) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dC && A && dW && ws && Bn > 0 && Tin > 0 && Tout > 0 && Cin > 0 && N > 0 && KT > 0, "st_gemm_wgrad: bad arguments");
     TnArgs g;
@@ -1108,7 +1119,7 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     hipStream_t st = (hipStream_t)stream;
     // one slab and nothing to add to: the product goes straight to dW (the decoder LSTMs' weight gradients are 29 and 42 MB --
     // the "sum" of one slab was a 17 us copy)
-    const bool direct = Z == 1 && !accumulate;
+    const bool direct = Z == 1 && !accumulate && !dW1;      // (a split result always leaves through the slab sum)
     if (direct) g.part = dW;
     if (db) g.db_part = direct ? db : ws + (size_t)Z * per;
     // the LDS-DMA form where every piece is whole (or wholly outside) and 16-byte addressable, no fold, no fused max-pool
@@ -1127,7 +1138,10 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     else hipLaunchKernelGGL((tn_kernel<64>), grid, dim3(TN_THREADS), 0, st, g);
     ST_LAUNCH_CHECK();
     if (direct) return 0;
-    if (db) hipLaunchKernelGGL(sum_partials2_kernel, dim3(blocks_for(per + N)), dim3(256), 0, st, ws, dW, per, Z, accumulate, g.db_part, db, (size_t)N);
+    if (dW1) hipLaunchKernelGGL(sum_partials2_kernel<true>, dim3(blocks_for(per + (db ? N : 0))), dim3(256), 0, st, ws, dW, per, Z, accumulate,
+                                db ? g.db_part : nullptr, db, (size_t)(db ? N : 0), dW1, Cin, split, db ? db_dup : nullptr);
+    else if (db) hipLaunchKernelGGL(sum_partials2_kernel<false>, dim3(blocks_for(per + N)), dim3(256), 0, st, ws, dW, per, Z, accumulate, g.db_part, db, (size_t)N,
+                                    nullptr, 0, 0, nullptr);
     else hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(per)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
     ST_LAUNCH_CHECK();
     return 0;
@@ -1146,6 +1160,16 @@ extern "C" int st_gemm_wgrad_db(const float* dC, int lddc, int dcoff, const floa
                                 void* stream) {
     ST_CHECK_ARG(db, "st_gemm_wgrad_db: null db");
     return tn_impl(dC, lddc, dcoff, A, lda, dW, db, ws, Bn, Tin, Tout, Cin, N, KT, pad, pool_prev, accumulate, stream);
+}
+
+// st_gemm_wgrad[_db] of a Linear over concatenated inputs, the result cut at input column `split`: dW0 (N, split) and dW1 (N, Cin - split)
+// are the gradients of the two weights whose columns the product saw side by side ([W_ih | W_hh] of an LSTM cell fed with [x | h]);
+// db (optional) = the column sums of dC, db_dup (optional) a second copy of them (b_ih and b_hh receive the same gradient).
+extern "C" int st_gemm_wgrad_split(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW0, int split, float* dW1,
+                                   float* db, float* db_dup, float* ws, int M, int Cin, int N, int accumulate, void* stream) {
+    ST_CHECK_ARG(dW0 && dW1 && split > 0 && split < Cin, "st_gemm_wgrad_split: needs two outputs and 0 < split (%d) < Cin (%d)", split, Cin);
+    ST_CHECK_ARG(db || !db_dup, "st_gemm_wgrad_split: db_dup without db");
+    return tn_impl(dC, lddc, dcoff, A, lda, dW0, db, ws, 1, M, M, Cin, N, 1, 0, 0, accumulate, stream, dW1, split, db_dup);
 }
 
 extern "C" size_t st_colreduce_workspace_floats(int M, int N) { return (size_t)2 * st_colreduce_chunks(M) * N + 2 * (size_t)N; }

@@ -17,10 +17,11 @@ struct MtArgs {
     // op parameters
     float* partial; int partial_base;            // sumsq
     const float* norm; float max_norm;           // scale
+    float pre_scale;                             // scale: every gradient is first multiplied by this (1 / world: the ranks' SUM -> average)
     float b1, b2, eps, step_size, bc2_sqrt;      // adam
 };
 
-// OP 0: partial[block] = sum g^2;  OP 1: g *= min(1, max_norm / (norm + 1e-6));  OP 2: Adam update
+// OP 0: partial[block] = sum g^2;  OP 1: g *= pre_scale * min(1, max_norm / (norm + 1e-6));  OP 2: Adam update;  OP 3: p = g (copy)
 template <int OP>
 __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
     __shared__ float red[MT_THREADS / 64];
@@ -52,23 +53,39 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
             a.partial[a.partial_base + blockIdx.x] = s;
         }
     } else if (OP == 1) {
-        const float coef = a.max_norm / (*a.norm + 1e-6f);         // torch.nn.utils.clip_grad_norm_
-        if (coef < 1.0f) {
+        // torch.nn.utils.clip_grad_norm_ on gradients that are still the SUM over the ranks: *norm is the norm of the averaged
+        // gradients (st_mt_grad_norm_scaled), and the 1 / world of the average rides in this launch (pre_scale = 1: the plain clip)
+        float coef = a.max_norm / (*a.norm + 1e-6f);
+        coef = (coef < 1.0f ? coef : 1.0f) * a.pre_scale;
+        if (coef != 1.0f) {
             f32x4* g4 = reinterpret_cast<f32x4*>(g + beg);
             for (long i = threadIdx.x; i < nvec; i += MT_THREADS) { f32x4 x = g4[i]; x[0] *= coef; x[1] *= coef; x[2] *= coef; x[3] *= coef; g4[i] = x; }
             for (long j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) g[j] *= coef;
         }
+    } else if (OP == 3) {
+        float* __restrict__ p = a.p[t];
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(g + beg);
+        f32x4* p4 = reinterpret_cast<f32x4*>(p + beg);
+        for (long i = threadIdx.x; i < nvec; i += MT_THREADS) p4[i] = g4[i];
+        for (long j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) p[j] = g[j];
     } else {
         // guarded form (st_mt_adam_guarded): no update at all when the gradient norm of this step is NaN / inf -- the decision the
         // reference takes on the host (`if math.isnan(grad_norm)`: skip optimizer.step(), src/solver.py:147-150) without a host round trip
         if (a.norm && !(fabsf(*a.norm) <= 3.0e38f)) return;
         float* __restrict__ p = a.p[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
         const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
+        // no contraction left to the compiler (the fused multiply-adds are the explicit ones): the 16-byte loop and the scalar loop
+        // (unaligned tensors, tails) must round alike -- a gradient that lives in an all-reduce bucket slot and one in a tensor of
+        // its own then give the same weights bit for bit (r04: the two loops were contracted differently; invisible in a one-step test)
         auto upd = [&](float gr, float& pi, float& mi, float& vi) {
-            mi = mi + (gr - mi) * omb1;                           // exp_avg.lerp_(grad, 1 - beta1)
-            vi = vi * a.b2 + omb2 * gr * gr;                      // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-            const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-            pi = pi - a.step_size * (mi / denom);
+#pragma clang fp contract(off)
+            mi = __builtin_fmaf(gr - mi, omb1, mi);                               // exp_avg.lerp_(grad, 1 - beta1)
+            const float g2 = gr * gr, vb = vi * a.b2;
+            vi = __builtin_fmaf(omb2, g2, vb);                                    // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+            const float sq = sqrtf(vi) / a.bc2_sqrt;
+            const float denom = sq + a.eps;
+            const float q = mi / denom;
+            pi = __builtin_fmaf(-a.step_size, q, pi);                             // param.addcdiv_(exp_avg, denom, value=-step_size)
         };
         const f32x4* g4 = reinterpret_cast<const f32x4*>(g + beg);
         f32x4* p4 = reinterpret_cast<f32x4*>(p + beg); f32x4* m4 = reinterpret_cast<f32x4*>(m + beg); f32x4* v4 = reinterpret_cast<f32x4*>(v + beg);
@@ -83,13 +100,13 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
     }
 }
 
-__global__ __launch_bounds__(64) void mt_norm_final_kernel(const float* partial, int n, float* out) {
+__global__ __launch_bounds__(64) void mt_norm_final_kernel(const float* partial, int n, float* out, float pre_scale) {
     // fixed-order sum of the per-block partials (a few hundred) by one wave (lane j: partials j, j + 64, ...; then a fixed tree over
     // the lanes), then the square root.  (One thread walking them all took 29 us.)
     float s = 0.0f;
     for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
     s = st_wave_sum(s);
-    if (threadIdx.x == 0) *out = sqrtf(s);
+    if (threadIdx.x == 0) *out = pre_scale == 1.0f ? sqrtf(s) : sqrtf(s) * pre_scale;
 }
 
 template <int OP>
@@ -131,27 +148,43 @@ extern "C" size_t st_mt_blocks(const long* n, int nt) {
     return b;
 }
 
-extern "C" int st_mt_grad_norm(float* const* g, const long* n, int nt, float* partials, float* norm_out, void* stream) {
+extern "C" int st_mt_grad_norm_scaled(float* const* g, const long* n, int nt, float* partials, float* norm_out, float pre_scale, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(g && n && nt > 0 && partials && norm_out, "st_mt_grad_norm: bad arguments");
+    ST_CHECK_ARG(g && n && nt > 0 && partials && norm_out && pre_scale > 0.0f, "st_mt_grad_norm: bad arguments");
     MtArgs a;
     memset(&a, 0, sizeof(a));
     a.partial = partials;
     int total = 0;
     int rc = mt_run<0>(a, nullptr, g, nullptr, nullptr, n, nt, (hipStream_t)stream, &total);
     if (rc) return rc;
-    hipLaunchKernelGGL(mt_norm_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, total, norm_out);
+    hipLaunchKernelGGL(mt_norm_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, total, norm_out, pre_scale);
     ST_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int st_mt_clip_scale(float* const* g, const long* n, int nt, const float* norm, float max_norm, void* stream) {
+extern "C" int st_mt_grad_norm(float* const* g, const long* n, int nt, float* partials, float* norm_out, void* stream) {
+    return st_mt_grad_norm_scaled(g, n, nt, partials, norm_out, 1.0f, stream);
+}
+
+extern "C" int st_mt_clip_scale_pre(float* const* g, const long* n, int nt, const float* norm, float max_norm, float pre_scale, void* stream) {
     (void)hipGetLastError();
-    ST_CHECK_ARG(g && n && nt > 0 && norm && max_norm > 0.0f, "st_mt_clip_scale: bad arguments");
+    ST_CHECK_ARG(g && n && nt > 0 && norm && max_norm > 0.0f && pre_scale > 0.0f, "st_mt_clip_scale: bad arguments");
     MtArgs a;
     memset(&a, 0, sizeof(a));
-    a.norm = norm; a.max_norm = max_norm;
+    a.norm = norm; a.max_norm = max_norm; a.pre_scale = pre_scale;
     return mt_run<1>(a, nullptr, g, nullptr, nullptr, n, nt, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int st_mt_clip_scale(float* const* g, const long* n, int nt, const float* norm, float max_norm, void* stream) {
+    return st_mt_clip_scale_pre(g, n, nt, norm, max_norm, 1.0f, stream);
+}
+
+extern "C" int st_mt_copy(float* const* dst, float* const* src, const long* n, int nt, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dst && src && n && nt > 0, "st_mt_copy: bad arguments");
+    MtArgs a;
+    memset(&a, 0, sizeof(a));
+    return mt_run<3>(a, dst, src, nullptr, nullptr, n, nt, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int st_mt_adam_guarded(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,

@@ -800,10 +800,66 @@ def bn_norm(x2d, xoff, N, mean, var, w, b, eps, act=None, out=None, yoff=0):
     return out
 
 
+# ------------------------------------------------------------------------- where parameter gradients are written
+_GRAD_SINK = None
+
+
+def set_grad_sink(sink, only_if=None):
+    """`sink.claim(param)` -> tensor or None decides where the kernels that produce parameter gradients write them: under data
+    parallelism parallel.GradReducer hands out the parameter's slot in its all-reduce bucket, so the gradient is born in the
+    communication buffer (no accumulate launch, no copy).  only_if: clear only when that sink is the registered one."""
+    global _GRAD_SINK
+    if only_if is not None and _GRAD_SINK is not only_if:
+        return
+    _GRAD_SINK = sink
+
+
+def grad_slot(param):
+    """the tensor the gradient of `param` should be written to (same shape), or None: allocate as usual"""
+    s = _GRAD_SINK
+    if s is None or param is None:
+        return None
+    return s.claim(param)
+
+
+def mt_copy(dsts, srcs):
+    """dsts[i] <- srcs[i] (contiguous fp32 device tensors of equal sizes) in a handful of multi-tensor launches"""
+    import ctypes as C
+    n = len(dsts)
+    dp = (C.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    sp = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    sz = (C.c_long * n)(*[t.numel() for t in dsts])
+    check(_lib.load().st_mt_copy(dp, sp, sz, n, stream_handle()), 'st_mt_copy')
+
+
+def gemm_wgrad_split(dc, a, split, w0=None, w1=None, b0=None, b1=None, with_db=False):
+    """gemm_wgrad of a Linear over concatenated inputs, cut at input column `split`: (dW0 (N, split), dW1 (N, Cin - split)[, db, db'])
+    -- the gradients of [W_ih | W_hh] (and b_ih, b_hh: equal) of an LSTM cell leave the product's fixed-order slab sum as the
+    parameters' own gradient tensors (w0 / w1 / b0 / b1: the parameters, asked for their grad_slot)"""
+    lib = _lib.load()
+    M, Cin = a.shape
+    N = dc.shape[-1]
+    f32 = dict(device=a.device, dtype=torch.float32)
+    d0, d1 = grad_slot(w0), grad_slot(w1)
+    d0 = d0 if d0 is not None else torch.empty(N, split, **f32)
+    d1 = d1 if d1 is not None else torch.empty(N, Cin - split, **f32)
+    db = dbd = None
+    if with_db:
+        db, dbd = grad_slot(b0), grad_slot(b1)
+        db = db if db is not None else torch.empty(N, **f32)
+        dbd = dbd if dbd is not None else torch.empty(N, **f32)
+    nws = int(lib.st_gemm_wgrad_workspace_floats(1, int(M), int(Cin), int(N), 1))
+    ws = torch.empty(nws, **f32)
+    check(lib.st_gemm_wgrad_split(_p(dc), int(dc.stride(-2)), 0, _p(a), int(a.stride(-2)), _p(d0), int(split), _p(d1),
+                                  _p(db), _p(dbd), _p(ws), int(M), int(Cin), int(N), 0, stream_handle()), 'st_gemm_wgrad_split')
+    return (d0, d1, db, dbd) if with_db else (d0, d1)
+
+
 def gemm_wgrad(dc, a, KT=1, pad=0, *, Bn=None, Tin=None, Tout=None, dcoff=0, N=None, pool_prev=False, out=None,
-               accumulate=False, with_db=False):
+               accumulate=False, with_db=False, db_out=None):
     """dW (N, Cin[, KT]) of C = conv1d/linear(a, W): dc (Bn, Tout, >=dcoff+N) or (M, .), a (Bn, Tin, Cin) or (M, Cin).
-    with_db: returns (dW, db) with db = the column sums of dc (the bias gradient), formed inside the same launches."""
+    with_db: returns (dW, db) with db = the column sums of dc (the bias gradient), formed inside the same launches.
+    out / db_out: where to write them (grad_slot of the parameters), else fresh tensors."""
     lib = _lib.load()
     if a.dim() == 3:
         Bn_, Tin_, Cin = a.shape
@@ -819,7 +875,7 @@ def gemm_wgrad(dc, a, KT=1, pad=0, *, Bn=None, Tin=None, Tout=None, dcoff=0, N=N
     nws = int(lib.st_gemm_wgrad_workspace_floats(int(Bn), int(Tout), int(Cin), int(N), int(KT)))
     ws = torch.empty(nws, device=a.device, dtype=torch.float32)
     if with_db:
-        db = torch.empty(N, device=a.device, dtype=torch.float32)
+        db = db_out if db_out is not None else torch.empty(N, device=a.device, dtype=torch.float32)
         check(lib.st_gemm_wgrad_db(_p(dc), int(dc.stride(-2)), int(dcoff), _p(a), int(a.stride(-2)), _p(out), _p(db), _p(ws), int(Bn),
                                    int(Tin), int(Tout), int(Cin), int(N), int(KT), int(pad), 1 if pool_prev else 0,
                                    1 if accumulate else 0, stream_handle()), 'st_gemm_wgrad_db')

@@ -61,9 +61,11 @@ def _tables(tensors):
     return (C.c_void_p * n)(*[t.data_ptr() for t in tensors]), (C.c_long * n)(*[t.numel() for t in tensors])
 
 
-def clip_grad_norm_(parameters, max_norm):
+def clip_grad_norm_(parameters, max_norm, pre_scale=1.0):
     """torch.nn.utils.clip_grad_norm_ (L2) on the multi-tensor HIP kernels: returns the total norm as a 0-dim device
     tensor and scales every .grad in place by max_norm / (norm + 1e-6) when that is below 1.
+    pre_scale (1 / world under data parallelism, parallel.GradReducer(defer_average=True)): the gradients are still the SUM over
+    the ranks -- the norm returned is that of the averaged gradients and the average itself rides in the scale launch.
     ref: BaseSolver.backward src/solver.py:145"""
     from . import _lib, ops
     grads = [p.grad for p in parameters if p.grad is not None]
@@ -77,8 +79,10 @@ def clip_grad_norm_(parameters, max_norm):
     dev = grads[0].device
     partials = torch.empty(int(lib.st_mt_blocks(sizes, len(grads))), device=dev, dtype=torch.float32)
     norm = torch.empty((), device=dev, dtype=torch.float32)
-    _lib.check(lib.st_mt_grad_norm(ptrs, sizes, len(grads), ops._p(partials), ops._p(norm), ops.stream_handle()), 'st_mt_grad_norm')
-    _lib.check(lib.st_mt_clip_scale(ptrs, sizes, len(grads), ops._p(norm), float(max_norm), ops.stream_handle()), 'st_mt_clip_scale')
+    _lib.check(lib.st_mt_grad_norm_scaled(ptrs, sizes, len(grads), ops._p(partials), ops._p(norm), float(pre_scale), ops.stream_handle()),
+               'st_mt_grad_norm')
+    _lib.check(lib.st_mt_clip_scale_pre(ptrs, sizes, len(grads), ops._p(norm), float(max_norm), float(pre_scale), ops.stream_handle()),
+               'st_mt_clip_scale')
     return norm
 
 

@@ -120,43 +120,64 @@ def allreduce_gradients(params, bucket_bytes=32 << 20, average=True):
 
 
 class GradReducer:
-    """Gradient all-reduce overlapped with the backward pass, without copies.
+    """Gradient all-reduce overlapped with the backward pass; gradients are BORN in their communication buffer.
 
     The parameters (in REVERSE registration order, which is roughly the order their gradients become ready: postnet first,
-    then the decoder's BPTT, then the encoder) are laid out in persistent flat fp32 buckets and every `p.grad` is a VIEW into
-    its bucket, so autograd accumulates straight into the communication buffer.  A post-accumulate hook counts the gradients
-    of a bucket; when the last one has arrived the bucket is READY, and ready buckets are issued strictly in index order
-    (bucket i only after buckets 0..i-1, as DDP does): ranks whose autograd graphs differ (a data-dependent
-    `ignore_speech_cycle`, per-rank `skip_prob` draws) still issue the same collectives in the same order.  The all-reduce is
-    asynchronous (RCCL runs it on its own stream while the rest of the backward pass keeps the compute stream busy);
-    `finish()` issues what is left, waits, and averages.  ~32 MiB buckets: 4 collectives for the 125 MB model -- few, large
-    messages are what the per-link-bound xGMI ring wants (ref: the step this replaces is BaseSolver.backward,
+    then the decoder's BPTT, then the encoder) are laid out in persistent flat fp32 buckets.  Before a backward pass every
+    `p.grad` is None and NOTHING is zeroed.  The kernels that produce parameter gradients ask for the parameter's bucket slot
+    (`ops.grad_slot(param)` -> this object's `claim`) and write their result there; autograd's AccumulateGrad then ADOPTS that
+    view as `p.grad` (an undefined .grad takes the incoming tensor, no accumulate launch).  Gradients that were produced
+    elsewhere (small tensors whose producers do not ask; sums autograd formed itself) are copied into their slots by ONE
+    multi-tensor launch per bucket when the bucket goes out.  (Round 4 pointed every p.grad at a zeroed slot instead:
+    125 MB of fills and one elementwise add launch per parameter -- 144 -- per step.)
+
+    A post-accumulate hook counts the gradients of a bucket; when the last one has arrived the bucket is READY, and ready
+    buckets are issued strictly in index order (bucket i only after buckets 0..i-1, as DDP does): ranks whose autograd graphs
+    differ (a data-dependent `ignore_speech_cycle`, per-rank `skip_prob` draws) still issue the same collectives in the same
+    order.  The all-reduce is asynchronous (RCCL runs it on its own stream while the rest of the backward pass keeps the
+    compute stream busy); `finish()` issues what is left and waits.  ~32 MiB buckets: 4 collectives for the 125 MB model -- few,
+    large messages are what the per-link-bound xGMI ring wants (ref: the step this replaces is BaseSolver.backward,
     src/solver.py:138-151, which needs the GLOBAL norm).
 
+    average: `finish()` leaves the mean over the ranks in every `.grad` (one multiply launch per bucket); with
+    defer_average=True it leaves the SUM and `grad_scale` = 1 / world for the caller to fold into its clip launch
+    (optim.clip_grad_norm_(..., pre_scale=...)): no launch at all.
+
     Which parameters received a gradient on ANY rank travels with the last bucket (one flag per parameter behind its
-    gradients, no extra collective): a parameter keeps its averaged gradient on every rank when at least one rank produced
+    gradients, no extra collective): a parameter keeps its reduced gradient on every rank when at least one rank produced
     one, and gets `.grad = None` on every rank when none did -- the optimiser then skips it everywhere or nowhere, and the
     global clip norm is the same on all ranks."""
 
-    def __init__(self, params, bucket_bytes=32 << 20, average=True, static_graph=False):
+    def __init__(self, params, bucket_bytes=32 << 20, average=True, static_graph=False, defer_average=False):
         """static_graph=True (a promise, as DistributedDataParallel's): every backward pass produces gradients for the same parameters
         in the same order on every rank.  The first pass runs as usual (one hook per parameter, registration-order buckets) and
         records the order in which the gradients arrive; the buckets are then REBUILT in that order over the parameters that
         actually receive gradients -- a bucket becomes ready as early as its position in the backward pass allows (the decoder's
         weight gradients go out while the encoder's backward still runs; parameters the step never touches, e.g. the speech
         encoder in the paired TTS step, no longer hold the last bucket back until finish()) -- and only the hook of each bucket's
-        LAST parameter stays registered: one Python call per bucket and step instead of one per parameter (144 calls, ~0.4 ms of
-        host time per step for the paired TTS model).  Trainers whose graph depends on the data (the speech / text cycles:
-        `ignore_speech_cycle`, per-rank `skip_prob` draws) must leave it off."""
-        self.params = [p for p in list(params)[::-1] if p.requires_grad]
+        LAST parameter stays registered: one Python call per bucket and step instead of one per parameter.  The promise is CHECKED:
+        a bucket whose closing gradient arrives while another of its gradients is still missing, a gradient produced after its
+        bucket went out, or a gradient for a parameter the recorded pass never touched (a teacher-forcing schedule that starts
+        feeding outputs back, a parameter that gets unfrozen) is noticed in the same step -- that step's buckets then go out from
+        finish(), complete, and the reducer returns to the per-parameter form for good, with a warning.  Trainers whose graph
+        depends on the data on purpose (the speech / text cycles) leave it off."""
+        self.all_params = [p for p in list(params)[::-1] if p.requires_grad]
+        self.params = list(self.all_params)
+        self.dropped = []                              # static graph: parameters the recorded pass never touched
         self.average = average
+        self.defer_average = bool(defer_average)
+        self.grad_scale = 1.0                          # what the gradients must still be multiplied by (defer_average)
         self.bucket_bytes = int(bucket_bytes)
         self.static_graph = bool(static_graph)
         self._sparse = False                           # static_graph: True once the buckets follow the recorded order
         self._fire_order = []                          # the recorded pass: parameters in the order their gradients arrived
         self._hooks = {}
+        self._active = False
+        self.stats = {'born_in_slot': 0, 'gathered': 0, 'zeroed': 0}      # of the last step (tests, bench)
         self._layout()
         self._hooks = {p: p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params}
+        from . import ops
+        ops.set_grad_sink(self)
         self.prepare()
 
     def _layout(self):
@@ -172,8 +193,9 @@ class GradReducer:
         if cur:
             self.buckets.append(cur)
         self.index = {p: i for i, p in enumerate(self.params)}
-        for bi, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
+        pad4 = lambda n: (n + 3) // 4 * 4              # every slot starts on a 16-byte boundary: the producing kernels, the clip
+        for bi, bucket in enumerate(self.buckets):     # and Adam launches then take the same (16-byte) code paths as on tensors of their own
+            n = sum(pad4(p.numel()) for p in bucket)
             if bi == len(self.buckets) - 1:
                 n += len(self.params)                  # the "fired on some rank" flags ride behind the last bucket's gradients
             flat = torch.zeros(n, device=bucket[0].device, dtype=torch.float32)
@@ -181,46 +203,80 @@ class GradReducer:
             off = 0
             for p in bucket:
                 self.slot[p] = (bi, off)
-                off += p.numel()
+                off += pad4(p.numel())
         self.flags = self.flats[-1][self.flats[-1].numel() - len(self.params):] if self.flats else None
+        self.ptr = {p: self.flats[bi].data_ptr() + 4 * off for p, (bi, off) in self.slot.items()}      # address of every slot
+        self._by_ptr = {p.data_ptr(): p for p in self.params}                                        # parameter storage -> parameter
 
     def _rebuild_static(self):
-        """after the recorded pass (its gradients are reduced and averaged in the OLD buckets): new buckets in arrival order over
-        the parameters that fired, this step's gradients carried over, one hook per bucket"""
-        old_view = {p: self._view(p) for p in self._fire_order}
-        dropped = [p for p in self.params if p not in old_view]
+        """after the recorded pass (its gradients are reduced in the OLD buckets): new buckets in arrival order over the parameters
+        that fired, this step's gradients carried over, one hook per bucket"""
+        old_grad = {p: p.grad for p in self._fire_order}
+        self.dropped = [p for p in self.params if p not in old_grad]
         for h in self._hooks.values():
             h.remove()
         self.params = list(self._fire_order)
         self._layout()
         for p in self.params:
             v = self._view(p)
-            v.copy_(old_view[p])
+            v.copy_(old_grad[p])
             p.grad = v
-        for p in dropped:
+        for p in self.dropped:
             p.grad = None                              # never touched by this (static) step: the optimiser skips it on every rank
         closers = [bucket[-1] for bucket in self.buckets]
         self._hooks = {p: p.register_post_accumulate_grad_hook(self._on_grad) for p in closers}
         self._sparse = True
+
+    def _revert_dynamic(self, why):
+        """the static promise did not hold: back to one hook per parameter over ALL parameters (this step's gradients stay where
+        they are -- views of the old buckets -- until the optimiser has used them)"""
+        import warnings
+        warnings.warn('GradReducer: static_graph promise broken (%s); back to per-parameter hooks' % why, RuntimeWarning)
+        for h in self._hooks.values():
+            h.remove()
+        self.static_graph, self._sparse = False, False
+        self.params, self.dropped = list(self.all_params), []
+        self._layout()
+        self._hooks = {p: p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params}
 
     def _view(self, p):
         bi, off = self.slot[p]
         return self.flats[bi][off:off + p.numel()].view_as(p)
 
     def prepare(self):
-        """before every backward pass (after optimizer.zero_grad): zero the buckets and (re-)attach the gradient views"""
-        for flat in self.flats:
-            flat.zero_()
+        """before every backward pass: no gradient exists (nothing is zeroed, nothing is attached)"""
         for p in self.params:
-            p.grad = self._view(p)
+            if p.grad is not None:
+                p.grad = None
+        for p in self.dropped:
+            if p.grad is not None:
+                p.grad = None
         self.count = [0] * len(self.buckets)
         self.fired = set()
+        self.claimed = set()
         self._fire_order = []
+        self._violated = None
         self.works = [None] * len(self.buckets)
         self.ready = [False] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.next = 0                                  # the next bucket to issue (in-order launches)
         self.order = []                                # launch order of this step (tests)
+        self.stats = {'born_in_slot': 0, 'gathered': 0, 'zeroed': 0}
+        self._active = True
+
+    def claim(self, param):
+        """ops.grad_slot: the bucket slot of `param` for the kernel that is about to produce its gradient (first request of a step
+        only; a second producer of the same parameter, or one that comes after the bucket went out, gets None and allocates)"""
+        if not self._active:
+            return None
+        p = self._by_ptr.get(param.data_ptr())
+        if p is None or p in self.claimed or p.numel() != param.numel():
+            return None
+        if self.launched[self.slot[p][0]]:
+            self._violated = self._violated or 'a gradient was produced after its bucket had gone out'
+            return None
+        self.claimed.add(p)
+        return self._view(p)
 
     def _on_grad(self, p):
         if self._sparse:                               # static graph: p completes its bucket (recorded in the first pass)
@@ -231,9 +287,6 @@ class GradReducer:
             return
         if p not in self.slot or p in self.fired:
             return
-        if p.grad is None or p.grad.data_ptr() != self._view(p).data_ptr():      # somebody replaced the view: copy back in
-            self._view(p).copy_(p.grad)
-            p.grad = self._view(p)
         self.fired.add(p)
         if self.static_graph:
             self._fire_order.append(p)
@@ -245,52 +298,109 @@ class GradReducer:
 
     def _launch_ready(self, everything=False):
         while self.next < len(self.buckets) and (everything or self.ready[self.next]):
-            self._launch(self.next)
+            if not self._launch(self.next, final=everything):
+                break
             self.next += 1
 
-    def _launch(self, bi):
+    def _gather(self, bi, final):
+        """every gradient of bucket bi into its slot: most were born there; the others are copied in by ONE multi-tensor launch and
+        re-pointed at their slots; the slot of a parameter without a gradient is zeroed (only when `final`).  False: a gradient is
+        still missing and the bucket must wait (static graph: the promise is broken)"""
+        stray, missing = [], []
+        ptr = self.ptr
+        for p in self.buckets[bi]:
+            g = p.grad
+            if g is None:
+                missing.append(p)
+            elif g.data_ptr() != ptr[p]:
+                stray.append(p)
+        if missing and not final:
+            return False
+        self.stats['born_in_slot'] += len(self.buckets[bi]) - len(stray) - len(missing)
+        self.stats['gathered'] += len(stray)
+        self.stats['zeroed'] += len(missing)
+        if stray:
+            views = [self._view(p) for p in stray]
+            srcs = [p.grad for p in stray]
+            if views[0].is_cuda and all(g.is_contiguous() and g.dtype == torch.float32 and g.numel() == v.numel() for g, v in zip(srcs, views)):
+                from . import ops
+                ops.mt_copy(views, srcs)
+            else:
+                for v, g in zip(views, srcs):
+                    v.copy_(g)
+            for p, v in zip(stray, views):
+                p.grad = v
+        for p in missing:
+            self._view(p).zero_()
+        return True
+
+    def _launch(self, bi, final=False):
+        if not self._gather(bi, final):
+            self._violated = self._violated or 'a bucket closed while one of its gradients was missing'
+            self.ready[bi] = False
+            return False
         self.launched[bi] = True
         self.order.append(bi)
         if not dist_on() or not _GRAD_ALLREDUCE:
-            return
+            return True
         flat = self.flats[bi]
-        if bi == len(self.buckets) - 1 and not self._sparse:    # flags of this rank; final here: every earlier bucket is out already
-            if len(self.fired) == len(self.params):
+        if bi == len(self.buckets) - 1:                # flags of this rank; final here: every earlier bucket is out already
+            has = [p.grad is not None for p in self.params]
+            if all(has):
                 self.flags.fill_(1.0)
             else:
-                self.flags.copy_(torch.tensor([1.0 if p in self.fired else 0.0 for p in self.params]), non_blocking=True)
+                self.flags.copy_(torch.tensor([1.0 if h else 0.0 for h in has]), non_blocking=True)
         _COUNTS['grad_buckets'] += 1
-        if bi == len(self.buckets) - 1 and self._sparse:
-            self.flags.fill_(1.0)                      # (static graph: every parameter fires every step)
         if flat.is_cuda and dist.get_backend() == 'gloo':      # functional tests on a box with fewer GPUs than ranks
             all_reduce_sum_(flat)
         else:
             self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
             _HANDOFF['async_buckets'] += 1
+        return True
 
     def finish(self):
         """after backward: issue the buckets that never filled up (parameters without a gradient this step contribute zeros),
-        wait, average.  A parameter that received no gradient on ANY rank gets `.grad = None` back, as autograd would have
-        left it (the optimiser skips it like the reference's does); one that fired on some other rank keeps the averaged
-        gradient here too."""
+        wait, average (or leave the sums and set `grad_scale`, defer_average).  A parameter that received no gradient on ANY rank
+        keeps `.grad = None`, as autograd left it (the optimiser skips it like the reference's does); one that fired on some
+        other rank gets the reduced gradient here too."""
         self._launch_ready(everything=True)
+        self._active = False
         reduced = dist_on() and _GRAD_ALLREDUCE
         world = dist.get_world_size() if reduced else 1
         for w in self.works:
             if w is not None:
                 w.wait()
-        if not self._sparse and len(self.fired) < len(self.params):
+        silent = [p for p in self.params if p.grad is None]
+        if silent:
             # only now, and only in the irregular case, the flags are read back (one small device -> host copy)
             anywhere = self.flags.detach().cpu().tolist() if reduced else None
-            for i, p in enumerate(self.params):
-                if p not in self.fired and (anywhere is None or anywhere[i] == 0.0):
-                    p.grad = None
+            for p in silent:
+                if anywhere is not None and anywhere[self.index[p]] != 0.0:
+                    p.grad = self._view(p)
+        extra = [p for p in self.dropped if p.grad is not None]
+        if extra:        # static graph: a parameter outside the recorded set fired -- reduce it now, on its own, and drop the promise
+            self._violated = self._violated or 'a parameter outside the recorded set received a gradient'
+            if reduced:
+                flat = torch.cat([p.grad.reshape(-1) for p in extra])
+                all_reduce_sum_(flat)
+                off = 0
+                for p in extra:
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+        self.grad_scale = 1.0
         if world > 1 and self.average:
-            n_flags = len(self.params)
-            for bi, flat in enumerate(self.flats):
-                (flat[:flat.numel() - n_flags] if bi == len(self.flats) - 1 else flat).mul_(1.0 / world)
+            if self.defer_average:
+                self.grad_scale = 1.0 / world
+            else:
+                n_flags = len(self.params)
+                for bi, flat in enumerate(self.flats):
+                    (flat[:flat.numel() - n_flags] if bi == len(self.flats) - 1 else flat).mul_(1.0 / world)
+                for p in extra:
+                    p.grad.mul_(1.0 / world)
         issued = sum(1 for l in self.launched if l)
-        if self.static_graph and not self._sparse and self._fire_order:
+        if self._violated and (self._sparse or self.static_graph):
+            self._revert_dynamic(self._violated)
+        elif self.static_graph and not self._sparse and self._fire_order:
             self._rebuild_static()
         return issued
 
@@ -298,6 +408,9 @@ class GradReducer:
         for h in self._hooks.values():
             h.remove()
         self._hooks = {}
+        self._active = False
+        from . import ops
+        ops.set_grad_sink(None, only_if=self)
 
 
 def all_gather_(t):

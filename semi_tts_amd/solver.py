@@ -197,9 +197,16 @@ class TtsTrainer(BaseSolver):
     async_stats = False      # True: train_step never waits for the GPU -- LazyStats, NaN steps skipped on the device (optim.FusedAdam guard)
 
     @staticmethod
-    def clip_grad_norm_(params, max_norm):
+    def clip_grad_norm_(params, max_norm, pre_scale=1.0):
         from .optim import clip_grad_norm_
-        return clip_grad_norm_(list(params), max_norm)
+        return clip_grad_norm_(list(params), max_norm, pre_scale)
+
+    def _clip(self):
+        """clip_grad_norm_(GRAD_CLIP) over the model; under data parallelism the 1 / world of the gradient average rides in it"""
+        scale = getattr(self, '_grad_scale', 1.0)
+        if scale != 1.0:
+            return self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP, pre_scale=scale)
+        return self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
 
     def __init__(self, config, paras, mode='train'):
         super().__init__(config, paras, mode)
@@ -245,13 +252,20 @@ class TtsTrainer(BaseSolver):
         from . import parallel
         self.reducer = None
         if parallel.dist_on():               # more than one rank, or collectives forced in a world of one (bench.py --dist)
-            self.reducer = parallel.GradReducer(self.model.parameters(), static_graph=self.STATIC_GRAPH)
+            # the static-graph promise (one hook per bucket) only where the step's autograd graph cannot change: no teacher-forcing
+            # schedule (own-output feedback adds the prenet's gradients to the graph); the reducer checks the promise anyway
+            static = self.STATIC_GRAPH and not getattr(self.optimizer, 'tf_type', False)
+            self.reducer = parallel.GradReducer(self.model.parameters(), static_graph=static, defer_average=True)
         return self.reducer
 
     def _reduce_gradients(self):
+        """sum the gradients over the ranks; what they must still be multiplied by (1 / world) goes into the clip launch"""
         from . import parallel
+        self._grad_scale = 1.0
         if getattr(self, 'reducer', None) is not None:
-            return self.reducer.finish()
+            n = self.reducer.finish()
+            self._grad_scale = self.reducer.grad_scale
+            return n
         return parallel.allreduce_gradients(self.model.parameters())
 
     def freq_loss(self, pred, label):
@@ -273,7 +287,7 @@ class TtsTrainer(BaseSolver):
         total = self.tts_weight * (mel_loss + linear_loss)
         total.backward()
         self._reduce_gradients()
-        grad_norm = self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
+        grad_norm = self._clip()
         from .optim import FusedAdam
         if self.async_stats and torch.is_tensor(grad_norm) and grad_norm.is_cuda and isinstance(getattr(self.optimizer, 'opt', None), FusedAdam):
             # no host round trip inside the step: the NaN check of BaseSolver.backward (src/solver.py:147-150) runs on the device (a
@@ -392,7 +406,7 @@ class VqvaeTrainer(TtsTrainer):
     def _finish_step(self, total, stats, tf_rate):
         total.backward()
         self._reduce_gradients()
-        gn = float(self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP))
+        gn = float(self._clip())
         if gn == gn:
             self.optimizer.step()
         else:

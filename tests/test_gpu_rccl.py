@@ -35,6 +35,9 @@ def test_c4_step_through_rccl_world_size_one_equals_plain_step():
     assert ro['reducer_attached']
     assert ro['gradients_bitwise_equal'] and ro['updated_weights_bitwise_equal'], ro
     assert ro['loss'] == res['plain']['loss'] and ro['grad_norm'] == res['plain']['grad_norm']
+    # third step, static-graph form: the big gradients are born in their bucket slots, the small rest is gathered, nothing is zeroed
+    third = ro['third_step']['reducer']
+    assert ro['third_step_loss_equal'] and third['sparse'] and third['zeroed'] == 0 and third['born_in_slot'] >= 40, ro
     assert rs['collectives_per_step'] == {'grad_buckets': 4, 'syncbn_fwd': 6, 'syncbn_bwd': 6, 'async_grad_buckets': 4}, rs
     assert rs['loss_abs_diff'] <= 1e-6 * max(1.0, abs(res['plain']['loss'])), rs
     assert rs['running_stats_max_rel_diff'] <= 1e-6, rs          # SyncBN-merged statistics: one rounding

@@ -200,8 +200,67 @@ for it in range(3):
     n4 = red4.finish()
 err4 = max((a.grad - b.grad).abs().max().item() for a, b in zip(net4.parameters(), ref.parameters()))
 sparse = red4._sparse and len(red4._hooks) == len(red4.buckets) and n4 == len(red4.buckets)
+# gradients BORN in their bucket slot: a producer that asks ops.grad_slot(param) writes there, autograd adopts the view (no copy,
+# no accumulate); a producer that does not ask is gathered into its slot when the bucket goes out; nothing is zeroed
+from semi_tts_amd import ops
+class SlotLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w, b)
+        return x @ w.t() + b
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        dw, slot = dy.t() @ x, ops.grad_slot(w)
+        if slot is not None:
+            slot.copy_(dw)
+            dw = slot
+        return dy @ w, dw, dy.sum(0)                   # (the bias gradient does not ask: a stray tensor, gathered at launch)
+net5 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+net5.load_state_dict(net.state_dict())
+red5 = GradReducer(net5.parameters(), bucket_bytes=64, average=True, defer_average=True)
+for it in range(2):
+    red5.prepare()
+    for flat in red5.flats:
+        flat.fill_(float('nan'))                       # stale bucket contents must never show: every slot is written or zeroed
+    h = SlotLinear.apply(x[lo:hi], net5[0].weight, net5[0].bias)
+    (SlotLinear.apply(h, net5[1].weight, net5[1].bias).pow(2).sum() / 8.0).backward()
+    red5.finish()
+err5 = max((a.grad - b.grad).abs().max().item() for a, b in zip(net5.parameters(), ref.parameters()))   # SUMS over the ranks ...
+born = (red5.stats['born_in_slot'] == 2 and red5.stats['gathered'] == 2 and red5.stats['zeroed'] == 0
+        and red5.grad_scale == 1.0 / world                                                              # ... the 1 / world is the caller's
+        and all(p.grad.data_ptr() == red5.ptr[p] for p in net5.parameters()))
+red5.close()
+no_sink = ops.grad_slot(net5[0].weight) is None
+# the static-graph promise is CHECKED: when the graph changes after the recorded pass (a parameter that never fired starts to, and
+# one that did stops), the step still reduces every gradient and the reducer goes back to per-parameter hooks with a warning
+import warnings
+net6 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(5, 3))
+broadcast_parameters(net6)
+red6 = GradReducer(net6.parameters(), bucket_bytes=64, average=False, static_graph=True)
+def run6(use_third):
+    red6.prepare()
+    h = net6[0](x[lo:hi])
+    ((net6[2](h) if use_third else net6[1](h)).pow(2).sum() / 8.0).backward()
+    red6.finish()
+run6(False); run6(False)
+was_sparse = red6._sparse
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter('always')
+    run6(True)
+ref6 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(5, 3))
+ref6.load_state_dict(net6.state_dict())
+(ref6[2](ref6[0](x)).pow(2).sum() / 8.0).backward()
+err6 = max((a.grad - b.grad).abs().max().item() for a, b in zip(list(net6[0].parameters()) + list(net6[2].parameters()),
+                                                                list(ref6[0].parameters()) + list(ref6[2].parameters())))
+reverted = (was_sparse and not red6._sparse and not red6.static_graph and len(red6._hooks) == 6
+            and any('static_graph promise broken' in str(w.message) for w in caught)
+            and all(p.grad is None for p in net6[1].parameters()))
+run6(True)                                             # and the per-parameter form carries on
+err6 = max(err6, max((a.grad - b.grad).abs().max().item() for a, b in zip(net6[2].parameters(), ref6[2].parameters())))
 if rank == 0:
-    print('RESULT', err, n, t, err2, n2, int(unused_none), int(views), int(in_order), int(shared), err4, int(sparse))
+    print('RESULT', err, n, t, err2, n2, int(unused_none), int(views), int(in_order), int(shared), err4, int(sparse),
+          err5, int(born), int(no_sink), err6, int(reverted))
 dist.destroy_process_group()
 '''
 
@@ -225,6 +284,9 @@ def test_two_process_gradient_allreduce_matches_single_process(tmp_path):
     assert line[8] == '1'                                   # buckets issued in index order although the ranks' graphs differ
     assert line[9] == '1'                                   # a parameter that fired on one rank only: same gradient on both
     assert float(line[10]) < 1e-5 and line[11] == '1'       # static graph: one hook per bucket after the first pass, same gradients
+    assert float(line[12]) < 1e-5 and line[13] == '1'       # gradients born in their bucket slots / gathered; sums + deferred 1 / world
+    assert line[14] == '1'                                  # a closed reducer hands out no slots
+    assert float(line[15]) < 1e-5 and line[16] == '1'       # broken static-graph promise: noticed, reduced correctly, reverted
 
 
 def test_cycle_step_alternates_and_gates_like_the_reference_loop():

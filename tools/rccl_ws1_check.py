@@ -4,7 +4,8 @@
 config/semi-multi-spkr-paired-data.yaml -- through the hook-driven GradReducer (asynchronous all-reduce on RCCL's stream),
 SyncBN's all_gather_into_tensor / all-reduce and the timing helper.  Sums over one rank are the identity, so:
 
-  * reducer only (SyncBN off): loss, grad norm, every gradient and every updated weight are BITWISE those of the plain step;
+  * reducer only (SyncBN off): loss, grad norm, every gradient and every updated weight are BITWISE those of the plain trainer
+    after three steps (gradients are born in / gathered into their all-reduce buckets; nothing is zeroed or accumulated);
   * reducer + SyncBN: the merged statistics are (mean * M) / M etc., equal to one rounding (<= 1e-6), the loss to 1e-6.
 
 Run as its own process (tests/test_gpu_rccl.py starts it as a child so that an RCCL failure cannot take pytest down).
@@ -64,13 +65,23 @@ def main():
         torch.cuda.synchronize()
         counts = parallel.collective_counts()
         counts['async_grad_buckets'] = parallel.async_bucket_count()
+        first = dict(st)
+        stats1 = {k: v.detach().clone() for k, v in tr.model.state_dict().items() if 'running_' in k}
+        grads1 = {k: p.grad.detach().clone() for k, p in tr.model.named_parameters() if p.grad is not None}
+        # two more steps: the reducer's second form (static graph: buckets in gradient-arrival order, one hook per bucket) must
+        # reproduce the plain trainer's third step just as well
+        for _ in range(2):
+            st = tr.train_step(*batch)
+        torch.cuda.synchronize()
+        later = dict(counts=parallel.collective_counts(), reducer=dict(tr.reducer.stats, sparse=tr.reducer._sparse,
+                     buckets=len(tr.reducer.buckets), dropped=len(tr.reducer.dropped)) if tr.reducer is not None else None)
         grads = {k: p.grad.detach().clone() for k, p in tr.model.named_parameters() if p.grad is not None}
         weights = {k: p.detach().clone() for k, p in tr.model.named_parameters()}
         stats = {k: v.detach().clone() for k, v in tr.model.state_dict().items() if 'running_' in k}
         had_reducer = tr.reducer is not None
         if tr.reducer is not None:
             tr.reducer.close()
-        return dict(st=st, counts=counts, grads=grads, weights=weights, stats=stats, reducer=had_reducer)
+        return dict(st=first, st3=st, counts=counts, grads=grads, weights=weights, stats=stats, reducer=had_reducer, later=later, stats1=stats1, grads1=grads1)
 
     plain = run(False, False)
     red = run(True, False)
@@ -91,19 +102,21 @@ def main():
         'workload': 'TtsTrainer.train_step, B=%d, %d frames, 109 speakers (C4 per-rank workload)' % (a.batch_size, a.frames),
         'plain': {k: plain['st'][k] for k in ('loss', 'grad_norm')},
         'reducer_only': {'loss': red['st']['loss'], 'grad_norm': red['st']['grad_norm'], 'collectives_per_step': red['counts'],
-                         'reducer_attached': red['reducer'],
+                         'reducer_attached': red['reducer'], 'third_step': red['later'],
+                         'third_step_loss_equal': red['st3']['loss'] == plain['st3']['loss'] and red['st3']['grad_norm'] == plain['st3']['grad_norm'],
                          'gradients_bitwise_equal': bitwise(red['grads'], plain['grads']),
                          'updated_weights_bitwise_equal': bitwise(red['weights'], plain['weights'])},
         'reducer_syncbn': {'loss': full['st']['loss'], 'grad_norm': full['st']['grad_norm'], 'collectives_per_step': full['counts'],
                            'loss_abs_diff': abs(full['st']['loss'] - plain['st']['loss']),
                            'grad_norm_rel_diff': abs(full['st']['grad_norm'] - plain['st']['grad_norm']) / plain['st']['grad_norm'],
-                           'running_stats_max_rel_diff': worst(full['stats'], plain['stats']),
-                           'gradient_max_rel_diff': worst(full['grads'], plain['grads'])},
+                           'running_stats_max_rel_diff': worst(full['stats1'], plain['stats1']),
+                           'gradient_max_rel_diff': worst(full['grads1'], plain['grads1'])},
         'max_over_ranks': t_max,
     }
     ok = (res['reducer_only']['reducer_attached'] and res['reducer_only']['gradients_bitwise_equal']
           and res['reducer_only']['updated_weights_bitwise_equal']
           and red['st']['loss'] == plain['st']['loss'] and red['st']['grad_norm'] == plain['st']['grad_norm']
+          and res['reducer_only']['third_step_loss_equal'] and red['later']['reducer']['sparse'] and red['later']['reducer']['zeroed'] == 0
           and res['reducer_only']['collectives_per_step']['grad_buckets'] == 4
           and res['reducer_syncbn']['collectives_per_step'] == {'grad_buckets': 4, 'syncbn_fwd': 6, 'syncbn_bwd': 6,
                                                                 'async_grad_buckets': 4 if a.backend == 'nccl' else 0}

@@ -634,7 +634,7 @@ def bench_train(args, rk):
     variants['full'] = elapsed
     counts = parallel.collective_counts()
     counts['async_grad_buckets'] = parallel.async_bucket_count()
-    if rk.world > 1 or rk.forced:
+    if (rk.world > 1 or rk.forced) and not args.no_variants:
         parallel.set_gradient_allreduce(False)
         variants['no_allreduce'] = rk.timed(step, args.steps, 1)
         parallel.set_gradient_allreduce(True)
@@ -725,6 +725,7 @@ def main():
     ap.add_argument('--sync-stats', action='store_true', help='--workload train: read loss / grad norm on the host every step (as the reference does)')
     ap.add_argument('--pre-parts', type=int, default=0, help=argparse.SUPPRESS)      # experiment: workgroups per utterance of the attention pre part
     ap.add_argument('--vq-head-only', action='store_true', help='c3: only the headline case (32 x 129 vectors, V = 512): PMC passes')
+    ap.add_argument('--no-variants', action='store_true', help='--workload train: only the full step (no timed variants without the collectives): for kernel traces')
     ap.add_argument('--dist', action='store_true',
                     help='with --gpus 1: initialise a world-size-1 process group (RCCL) and issue every collective anyway')
     ap.add_argument('--no-finite-check', action='store_true', help=argparse.SUPPRESS)    # timing experiments (tools/gpu_ablate.sh)

@@ -21,7 +21,7 @@ struct MtArgs {
     float b1, b2, eps, step_size, bc2_sqrt;      // adam
 };
 
-// OP 0: partial[block] = sum g^2;  OP 1: g *= pre_scale * min(1, max_norm / (norm + 1e-6));  OP 2: Adam update;  OP 3: p = g (copy)
+// OP 0: partial[block] = sum g^2;  OP 1: g *= pre_scale * min(1, max_norm / (norm + 1e-6));  OP 2: Adam update
 template <int OP>
 __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
     __shared__ float red[MT_THREADS / 64];
@@ -62,12 +62,6 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
             for (long i = threadIdx.x; i < nvec; i += MT_THREADS) { f32x4 x = g4[i]; x[0] *= coef; x[1] *= coef; x[2] *= coef; x[3] *= coef; g4[i] = x; }
             for (long j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) g[j] *= coef;
         }
-    } else if (OP == 3) {
-        float* __restrict__ p = a.p[t];
-        const f32x4* g4 = reinterpret_cast<const f32x4*>(g + beg);
-        f32x4* p4 = reinterpret_cast<f32x4*>(p + beg);
-        for (long i = threadIdx.x; i < nvec; i += MT_THREADS) p4[i] = g4[i];
-        for (long j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) p[j] = g[j];
     } else {
         // guarded form (st_mt_adam_guarded): no update at all when the gradient norm of this step is NaN / inf -- the decision the
         // reference takes on the host (`if math.isnan(grad_norm)`: skip optimizer.step(), src/solver.py:147-150) without a host round trip
@@ -107,6 +101,29 @@ __global__ __launch_bounds__(64) void mt_norm_final_kernel(const float* partial,
     for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
     s = st_wave_sum(s);
     if (threadIdx.x == 0) *out = pre_scale == 1.0f ? sqrtf(s) : sqrtf(s) * pre_scale;
+}
+
+// Many SMALL tensors copied by one launch (the gradients autograd allocated outside their all-reduce bucket: BatchNorm / bias / highway
+// parameters, ~50 tensors of 80 ... 370k floats): up to MC_T tensors per launch, 4096 floats per workgroup (the optimiser's 32768-float
+// chunks make such a launch as long as its largest tensor on ONE compute unit: 11 us).
+constexpr int MC_T = 96, MC_NB = 512, MC_CHUNK = 4096;
+struct McArgs {
+    float* dst[MC_T]; const float* src[MC_T]; int n[MC_T];
+    unsigned char blk_tensor[MC_NB]; unsigned short blk_chunk[MC_NB];
+};
+
+__global__ __launch_bounds__(MT_THREADS) void mc_kernel(const McArgs a) {
+    const int t = a.blk_tensor[blockIdx.x];
+    const int beg = (int)a.blk_chunk[blockIdx.x] * MC_CHUNK;
+    const int end = min(beg + MC_CHUNK, a.n[t]);
+    const float* __restrict__ s = a.src[t];
+    float* __restrict__ d = a.dst[t];
+    const bool vec = (((uintptr_t)s | (uintptr_t)d) & 15u) == 0;
+    const int nvec = vec ? ((end - beg) >> 2) : 0;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(s + beg);
+    f32x4* d4 = reinterpret_cast<f32x4*>(d + beg);
+    for (int i = threadIdx.x; i < nvec; i += MT_THREADS) d4[i] = s4[i];
+    for (int j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) d[j] = s[j];
 }
 
 template <int OP>
@@ -182,11 +199,29 @@ extern "C" int st_mt_clip_scale(float* const* g, const long* n, int nt, const fl
 extern "C" int st_mt_copy(float* const* dst, float* const* src, const long* n, int nt, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dst && src && n && nt > 0, "st_mt_copy: bad arguments");
-    MtArgs a;
-    memset(&a, 0, sizeof(a));
-    return mt_run<3>(a, dst, src, nullptr, nullptr, n, nt, (hipStream_t)stream, nullptr);
+    McArgs a;
+    int ti = 0, bl = 0;
+    auto flush = [&]() -> int {
+        if (bl == 0) { ti = 0; return 0; }
+        hipLaunchKernelGGL(mc_kernel, dim3(bl), dim3(MT_THREADS), 0, (hipStream_t)stream, a);
+        ST_LAUNCH_CHECK();
+        ti = 0; bl = 0;
+        return 0;
+    };
+    for (int t = 0; t < nt; ++t) {
+        if (n[t] <= 0) continue;
+        ST_CHECK_ARG(n[t] < (long)65535 * MC_CHUNK, "st_mt_copy: tensor %d has %ld elements", t, n[t]);
+        const int chunks = (int)((n[t] + MC_CHUNK - 1) / MC_CHUNK);
+        int c = 0;
+        while (c < chunks) {
+            if (ti == MC_T || bl == MC_NB) { int rc = flush(); if (rc) return rc; }
+            a.dst[ti] = dst[t]; a.src[ti] = src[t]; a.n[ti] = (int)n[t];
+            while (c < chunks && bl < MC_NB) { a.blk_tensor[bl] = (unsigned char)ti; a.blk_chunk[bl] = (unsigned short)c; ++bl; ++c; }
+            ++ti;
+        }
+    }
+    return flush();
 }
-
 extern "C" int st_mt_adam_guarded(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt,
                                   float beta1, float beta2, float eps, float step_size, float bias_correction2_sqrt,
                                   const float* guard_norm, void* stream) {

@@ -595,6 +595,40 @@ def test_multi_tensor_clip_and_adam_against_torch(dev):
     assert o2.state[hip[0]]['_step'] == 3
 
 
+def test_clip_with_pre_scale_and_multi_tensor_copy(dev):
+    """the data-parallel forms of the optimiser helpers: clip_grad_norm_(pre_scale = 1 / world) on gradients that are still the SUM over
+    the ranks = the plain clip on the averaged gradients (norm and result); ops.mt_copy gathers stray gradients into bucket slots
+    (aligned and unaligned, one element up to several chunks, more tensors than one launch takes)"""
+    from semi_tts_amd import ops
+    from semi_tts_amd.optim import clip_grad_norm_
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 3, 80, 4097, 40000, 1025 * 160] + [17 + i for i in range(120)]
+    srcs = [torch.randn(n, generator=g).to(dev) for n in sizes]
+    flat = torch.full((sum(sizes) + 8,), float('nan'), device=dev)
+    dsts, off = [], 1                                            # (slots packed back to back from an odd offset: every alignment occurs)
+    for n in sizes:
+        dsts.append(flat[off:off + n])
+        off += n
+    ops.mt_copy(dsts, srcs)
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d, s_)
+    assert bool(torch.isnan(flat[0])) and bool(torch.isnan(flat[off:]).all())
+    for world, max_norm in ((4, 5.0), (4, 0.05), (3, 0.05)):
+        class P:                                                 # (clip_grad_norm_ only reads .grad)
+            pass
+        avg, summed = [], []
+        for s_ in srcs[:40]:
+            a, b = P(), P()
+            a.grad, b.grad = (s_ / world).clone(), s_.clone()
+            avg.append(a)
+            summed.append(b)
+        n_ref = clip_grad_norm_(avg, max_norm)
+        n_got = clip_grad_norm_(summed, max_norm, pre_scale=1.0 / world)
+        assert abs(float(n_got) - float(n_ref)) <= 2e-6 * float(n_ref)
+        for a, b in zip(avg, summed):
+            assert maxdiff(a.grad, b.grad) <= 2e-6 * max(1.0, float(a.grad.abs().max()))
+
+
 def test_checkpoint_round_trip_resumes_training(dev, tmp_path):
     """{"model", "optimizer", "global_step"} (the reference's checkpoint layout, src/solver.py:203-216): train 2 steps,
     save, reload into a fresh trainer, and the third step must be bit-identical to continuing in place."""

@@ -816,6 +816,12 @@ typedef struct st_decoder_bwd_io {
     const float* pre_norm_w[2]; const float* pre_norm_rm[2]; const float* pre_norm_rv[2];
     float pre_norm_eps;
     float* dpre_norm_w[2]; float* dpre_norm_b[2];
+    /* attn_parts = 2 or 4 (with overlap_attn; 0 / 1 = off): the hosted attention backward of a step runs as that many workgroups per
+     * utterance (st_attn_bwd_job.parts) and the step's W_q^T dpq launch hosts the st_attn_hist_job; dloc_part (attn_parts, B, L, F) scratch */
+    int attn_parts; float* dloc_part;
+    /* with attn_parts = 2 and 16 < B <= 32: (dxd_splits, B, E+Q+D) scratch -- the decoder cell's product of the hosted launch runs K-split
+     * (st_skinny_partial_attn_bwd) and is summed, with its pointwise epilogue, in the step's W_q^T dpq launch (st_partial_sum_job); NULL = off */
+    float* dxd_part; int dxd_splits;
 } st_decoder_bwd_io;
 /* st_attn_step_bwd with S = pm + W_l loc of the step given (s_in, (B,L,A)): loc_t is not written (may be NULL) */
 int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
@@ -850,13 +856,57 @@ typedef struct st_attn_bwd_job {
     float* dpq; st_t16_view dpq_t16; float* dhist; float* ds_t; float* loc_t; float* dloc_t; float* hist_t;
     float* dctx_t; float* dv_t; const float* s_in;
     int B, L, A, E, F, K;
+    /* parts > 1 (2 or 4; 0 / 1 = the whole step in one workgroup per utterance): `parts` workgroups per utterance, each taking A / parts
+     * attention dims of the energy gradient; ds_t / dpq / dv_t / dctx_t are complete afterwards, the location-feature gradient only as
+     * `parts` partial sums in dloc_part (parts, B, L, F).  dhist / dloc_t / hist_t are NOT written and dcum is read-only (it must hold
+     * the total gradient w.r.t. cum_t; dcum_add must be NULL): the caller runs st_attn_hist_job next, which forms them. */
+    int parts; float* dloc_part;
 } st_attn_bwd_job;
+/* What a split attention backward (st_attn_bwd_job.parts > 1) leaves behind, one workgroup per utterance: dloc = the partial sums added in
+ * part order -> dloc_t (B, L, F); hist_t (B, L, 2) = [w_{t-1}, cum_{t-1}]; dhist (B, 2, L) = the gradient w.r.t. that history through the
+ * location conv (the transposed convolution of dloc with loc_conv_w (F, 2, K)); dcum (B, L; may be NULL) += dhist(:, 1, :), the gradient
+ * carried along cum_t = cum_{t-1} + w_t.  Backward of src/module.py:235-237,384-385 (stack / conv1d / transpose). */
+typedef struct st_attn_hist_job {
+    const float* dloc_part; int parts;
+    const float* loc_conv_w;
+    const float* w_prev; int ld_wprev; const float* w_cum_prev;
+    float* dloc_t; float* hist_t; float* dhist; float* dcum;
+    int B, L, F, K;
+} st_attn_hist_job;
 /* job may be NULL (the plain product); ab->s_in must be given (the forward kept S) */
 /* two st_skinny_linear_packed_lstm_bwd_fwd of one shape in one launch (arrays of two; y2 or its entries may be NULL) */
 int st_skinny_linear_packed_lstm_bwd_pair_fwd(const float* const* packed_w2, const st_t16_view* x2, int K, float* const* y2, int ldy,
                                               int B, int N, const st_lstm_pw_job* job2, void* stream);
 int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
                                               const st_lstm_pw_job* job, const st_attn_bwd_job* ab, void* stream);
+/* 1 when the attention backward's 48-position block (+ a hosting product's 8 KB) fits the LDS for these dims: what parts > 1 needs */
+int st_attn_bwd_wide_fits(int L, int A, int E, int F, int K);
+/* st_skinny_linear_packed_lstm_bwd_fwd with an st_attn_hist_job beside it in the same launch (the BPTT step's W_q^T dpq product, which
+ * occupies half of the compute units, hosts the history part of the step's split attention backward) */
+int st_skinny_linear_packed_lstm_bwd_attn_hist(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                               const st_lstm_pw_job* job, const st_attn_hist_job* hist, void* stream);
+/* K-split partial product for 16 < B <= 32 rows: part(s, b, n) = sum over the s-th of S equal ranges of k of x(b, k) W(n, k) -- two row
+ * tiles and both batch tiles per workgroup (half the bytes per output of st_skinny_linear_packed_fwd, whose workgroups each re-read a
+ * whole batch tile of x), N / 32 * S workgroups; N % 32 == 0, (K / 16) % S == 0; part (S, B, N).  With `ab` (an st_attn_bwd_job with
+ * parts = 2) the split attention backward of a BPTT step runs beside it in the same launch, as in
+ * st_skinny_linear_packed_lstm_bwd_attn_bwd.  The slabs are added -- in split order -- by an st_partial_sum_job of the caller's next launch:
+ *   y(b, n) = sum_s part(s, b, n), and for the columns [pw->n0, pw->n0 + pw->H) the pointwise LSTM backward of st_lstm_pw_job on them
+ * (pw may be NULL).  Backward of nn.LSTMCell's product, ref: src/module.py:277 (dgates . [W_ih | W_hh]). */
+typedef struct st_partial_sum_job {
+    const float* part; int S; int N;
+    float* y; int ldy;
+    const st_lstm_pw_job* pw;
+} st_partial_sum_job;
+int st_skinny_partial_attn_bwd(const float* packed_w, const st_t16_view* x, int K, float* part, int S, int B, int N,
+                               const st_attn_bwd_job* ab, void* stream);
+/* st_skinny_linear_packed_lstm_bwd_attn_hist with an st_partial_sum_job as well (same launch); hist may be NULL */
+int st_skinny_linear_packed_lstm_bwd_attn_hist_sum(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                                   const st_lstm_pw_job* job, const st_attn_hist_job* hist,
+                                                   const st_partial_sum_job* sum, void* stream);
+/* y = x W^T (no epilogue) with an st_attn_hist_job beside it: the BPTT step's dgates_q . [W_ih | W_hh] launch leaves 32 compute units idle
+ * for 9 us -- the history part of the step's split attention backward hides there completely */
+int st_skinny_linear_packed_attn_hist(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                      const st_attn_hist_job* hist, void* stream);
 int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
 /* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp) rows of r*n_mels+1 values, row stride ld floats
  * (a stride rounded up to a multiple of 4, pad columns zero, puts the two products over dY on the 16-byte kernels); NULL = zeros */

@@ -98,7 +98,8 @@ class StDecoderBwdIO(C.Structure):
                 [('fuse_pw', C.c_int), ('dgd_t16_b', C.c_void_p), ('dpq_t16', C.c_void_p), ('need_dxq0', C.c_int), ('attn_s_tape', C.c_void_p),
                  ('overlap_attn', C.c_int), ('prenet_norm', C.c_int), ('pre_y_tape', C.c_void_p), ('pre_norm_w', C.c_void_p * 2),
                  ('pre_norm_rm', C.c_void_p * 2), ('pre_norm_rv', C.c_void_p * 2), ('pre_norm_eps', C.c_float),
-                 ('dpre_norm_w', C.c_void_p * 2), ('dpre_norm_b', C.c_void_p * 2)])
+                 ('dpre_norm_w', C.c_void_p * 2), ('dpre_norm_b', C.c_void_p * 2), ('attn_parts', C.c_int), ('dloc_part', C.c_void_p),
+                 ('dxd_part', C.c_void_p), ('dxd_splits', C.c_int)])
 
 
 
@@ -125,7 +126,19 @@ class StAttnBwdJob(C.Structure):
                 ('dcum', C.c_void_p), ('dcum_add', C.c_void_p), ('ld_dcum_add', C.c_int),
                 ('dpq', C.c_void_p), ('dpq_t16', StT16View), ('dhist', C.c_void_p), ('ds_t', C.c_void_p), ('loc_t', C.c_void_p),
                 ('dloc_t', C.c_void_p), ('hist_t', C.c_void_p), ('dctx_t', C.c_void_p), ('dv_t', C.c_void_p), ('s_in', C.c_void_p),
-                ('B', C.c_int), ('L', C.c_int), ('A', C.c_int), ('E', C.c_int), ('F', C.c_int), ('K', C.c_int)]
+                ('B', C.c_int), ('L', C.c_int), ('A', C.c_int), ('E', C.c_int), ('F', C.c_int), ('K', C.c_int),
+                ('parts', C.c_int), ('dloc_part', C.c_void_p)]
+
+
+class StAttnHistJob(C.Structure):
+    _fields_ = [('dloc_part', C.c_void_p), ('parts', C.c_int), ('loc_conv_w', C.c_void_p),
+                ('w_prev', C.c_void_p), ('ld_wprev', C.c_int), ('w_cum_prev', C.c_void_p),
+                ('dloc_t', C.c_void_p), ('hist_t', C.c_void_p), ('dhist', C.c_void_p), ('dcum', C.c_void_p),
+                ('B', C.c_int), ('L', C.c_int), ('F', C.c_int), ('K', C.c_int)]
+
+
+class StPartialSumJob(C.Structure):
+    _fields_ = [('part', C.c_void_p), ('S', C.c_int), ('N', C.c_int), ('y', C.c_void_p), ('ldy', C.c_int), ('pw', C.c_void_p)]
 
 
 class StAttnPreJob(C.Structure):
@@ -233,6 +246,12 @@ SIGNATURES = {
                              P, P, I, P, C.POINTER(StT16View), P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     'st_skinny_linear_packed_lstm_bwd_fwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), P],
     'st_skinny_linear_packed_lstm_bwd_attn_bwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), C.POINTER(StAttnBwdJob), P],
+    'st_attn_bwd_wide_fits': [I, I, I, I, I],
+    'st_skinny_linear_packed_attn_hist': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StAttnHistJob), P],
+    'st_skinny_partial_attn_bwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StAttnBwdJob), P],
+    'st_skinny_linear_packed_lstm_bwd_attn_hist_sum': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), C.POINTER(StAttnHistJob),
+                                                       C.POINTER(StPartialSumJob), P],
+    'st_skinny_linear_packed_lstm_bwd_attn_hist': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), C.POINTER(StAttnHistJob), P],
     'st_lstm_seq2_fwd': [C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, C.POINTER(I), P, C.POINTER(P), C.POINTER(P), I, I, I, P],
     'st_lstm_seq2_persist_supported': [I, I, I, I, I, I],
     'st_lstm_seq2_persist_fwd': [C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), I, I, I, P, P],

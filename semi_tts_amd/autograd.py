@@ -830,6 +830,14 @@ class _DecoderFn(Function):
             bw.attn_query_w_t_p16 = ops._p(wt['pq_p16'])
             io.fuse_pw, io.dgd_t16_b, io.dpq_t16 = 1, ops._p(zb['dgd_t16_b']), ops._p(zb['dpq_t16'])
             io.overlap_attn = 1 if dec.bwd_overlap_attn else 0
+            parts = int(getattr(dec, 'bwd_attn_parts', 2))
+            if io.overlap_attn and parts > 1:      # the hosted attention backward as `parts` workgroups per utterance (decoder_bwd.hip)
+                dloc_part = e_(parts, B, L, F)
+                io.attn_parts, io.dloc_part = parts, ops._p(dloc_part)
+                dsplits = int(getattr(dec, 'bwd_dxd_splits', 2))
+                if parts == 2 and dsplits > 0 and 16 < B <= 32 and Bp == B:      # the hosted launch's product K-split into slabs
+                    dxd_part = e_(dsplits, B, XDw)
+                    io.dxd_part, io.dxd_splits = ops._p(dxd_part), dsplits
         src_arr = (C.c_int * max(steps, 1))(*src)
         io.step_src, io.Bt = C.cast(src_arr, C.POINTER(C.c_int)), Bt
         io.need_dxq0 = 1 if ctx.has_in0 else 0

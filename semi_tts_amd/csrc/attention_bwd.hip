@@ -96,6 +96,12 @@ static int ab_step_impl(const st_t16_view* dpq_t16, const float* pq, const float
     return 0;
 }
 
+// does the wide (48-position) block of the attention backward fit the LDS next to a hosting product's 8 KB? (what the split form needs)
+extern "C" int st_attn_bwd_wide_fits(int L, int A, int E, int F, int K) {
+    if (L <= 0 || A <= 0 || E <= 0 || F <= 0 || K <= 0) return 0;
+    return (size_t)ab_layout(L, A, E, F, K, AB_LBLK_MAX, true).total * sizeof(float) + 8 * 64 * sizeof(f32x4) <= 160 * 1024 ? 1 : 0;
+}
+
 extern "C" int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
                                   const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
                                   const float* loc_conv_w, const float* loc_lin_w, const float* v,

@@ -42,6 +42,18 @@ struct AbArgs {
     float* dv_t;      // (B, A)     sum_l de[l] * tanh(s[l][a])      -> dv = sum over (t, b)
     const float* s_in; // optional (B, L, A): pm + W_l loc of this step from the forward (then loc is neither recomputed nor written)
     int B, L, A, E, F, K;
+    float* dloc_part;  // NS > 1 parts per utterance (ab_body<.., NS>): (NS, B, L, F) partial location-feature gradients, summed by ab_hist_body
+};
+
+// What is left of the step when NS workgroups share an utterance (each takes A / NS attention dims): the partial dloc of the parts summed
+// in part order -> dloc_t tape slice, the history tape slice, the gradient w.r.t. the history through the location conv (P5) and the
+// carried cum gradient dcum += dhist[1].  One workgroup per utterance, hosted by the NEXT launch of the BPTT step (the W_q^T dpq product).
+struct AbHistArgs {
+    const float* dloc_part; int parts;
+    const float* loc_conv_w;
+    const float* w_prev; int ld_wprev; const float* w_cum_prev;
+    float* dloc_t; float* hist_t; float* dhist; float* dcum;
+    int B, L, F, K;
 };
 
 // tanh from one v_exp_f32 and one fast reciprocal (same as the forward kernel): |error| <= ~2e-7 absolute
@@ -52,18 +64,20 @@ __device__ __forceinline__ float ab_tanh(float x) {
 
 struct AbLds { int hist, hl, wct, f4, wl, wlt, ld, loc, dloc, w, dw, dctx, dsb, part, red, total; };
 
-__host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K, int lblk, bool has_s) {
+// lean (a part of a split step, ab_body<.., NS > 1>): no history, W_c, loc or dloc images -- two such workgroups (or one beside a
+// product workgroup of the hosting launch) then fit one compute unit's LDS
+__host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K, int lblk, bool has_s, bool lean = false) {
     AbLds o;
     int p = 0;
     o.f4 = (F + 3) & ~3;                  // rows of loc / dloc / W_l / transposed W_c padded to float4
     o.hl = (L + K + 4 + 3) & ~3;          // zero-padded history per channel
-    o.hist = p; p += 2 * o.hl;
-    o.wct = p; p += 2 * K * o.f4;         // W_c transposed to [c][k][f]
+    o.hist = p; p += lean ? 0 : 2 * o.hl;
+    o.wct = p; p += lean ? 0 : 2 * K * o.f4;   // W_c transposed to [c][k][f]
     o.wl = p; p += has_s ? 0 : A * o.f4;  // W_l [a][f] (only to recompute S)
     o.ld = ((A + 63) & ~63) + 4;          // row stride of the two MFMA operands: a padded to 64, +4 floats against bank conflicts
     o.wlt = p; p += 32 * o.ld;            // W_l^T [f][a] (rows f >= F and columns a >= A are zero)
-    o.loc = p; p += L * AB_FMAX;          // rows padded to AB_FMAX zeros: the energy phase reads them unconditionally
-    o.dloc = p; p += L * o.f4;
+    o.loc = p; p += lean ? 0 : L * AB_FMAX;    // rows padded to AB_FMAX zeros: the energy phase reads them unconditionally
+    o.dloc = p; p += lean ? 0 : L * o.f4;
     o.w = p; p += (L + 3) & ~3;
     o.dw = p; p += (L + 3) & ~3;
     o.dctx = p; p += (E + 3) & ~3;
@@ -76,13 +90,22 @@ __host__ __device__ inline AbLds ab_layout(int L, int A, int E, int F, int K, in
 
 // HAS_S: S = pm + W_l loc of the step comes from the forward pass (training keeps it: 1.4 MB per step against 288 GB) -- no
 // location conv (P1) and no 32-filter product per (position, dim) in the energy gradient (P3)
-template <bool HAS_S, int LBLK>
-__device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __restrict__ lds) {
-    constexpr int AB_LBLK = LBLK, AB_LPT = LBLK / 2;   // positions per thread and block (at least two threads share an attention dim)
+// NS > 1 (the BPTT loop's hosted launch; needs S): NS workgroups per utterance, part `part` takes the attention dims [part A / NS,
+// (part + 1) A / NS) of the energy gradient (P3: its tanh phase and its ds . W_l product shrink by NS; ds_t / dpq / dv_t are written per
+// dim, so nothing needs a sum there), stages only its rows of W_l, writes its PARTIAL dloc to a.dloc_part and leaves everything behind
+// the sum of the partials (dloc_t, hist_t, the conv-transpose P5, the carried dcum) to ab_hist_body in the next launch.  The staging of
+// the addends, dw = dctx . mem (P2) and the softmax backward are replicated in every part.  a.dcum is then read-only (= the total
+// gradient w.r.t. cum_t, maintained by ab_hist_body) and a.dcum_add must be NULL.
+template <bool HAS_S, int LBLK, int NS = 1>
+__device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __restrict__ lds, const int prt = 0) {
+    static_assert(NS == 1 || HAS_S, "parts need the forward's S");
+    static_assert(NS == 1 || NS == 2 || NS == 4, "1, 2 or 4 parts");
+    constexpr int AB_LBLK = LBLK, AB_LPT = LBLK / (2 * NS);   // positions per thread and block (at least 2 NS threads share an attention dim)
     constexpr int MTL = LBLK / 16;                      // MFMA row tiles per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L, A = a.A, E = a.E, F = a.F, K = a.K;
-    const AbLds o = ab_layout(L, A, E, F, K, LBLK, HAS_S);
+    const int As = A / NS, a_lo = prt * As;            // this part's attention dims (NS == 1: all of them)
+    const AbLds o = ab_layout(L, As, E, F, K, LBLK, HAS_S, NS > 1);
     float* hist = lds + o.hist; float* WcT = lds + o.wct; float* Wl = lds + o.wl; float* WlT = lds + o.wlt; float* loc = lds + o.loc;
     float* dloc = lds + o.dloc; float* ws = lds + o.w; float* dws = lds + o.dw; float* dctx = lds + o.dctx;
     float* dsb = lds + o.dsb; float* part = lds + o.part; float* red = lds + o.red;
@@ -90,7 +113,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
 
     AB_PROF(0);
     // energy-gradient role of this thread: fixed attention dim a0, positions l0 + grp, l0 + grp + ngrp, ...
-    const int a0 = tid % A, grp = tid / A, ngrp = AB_THREADS / A;    // host: A <= 256 and 512 % A == 0, so ngrp >= 2
+    const int a_l = tid % As, a0 = a_lo + a_l, grp = tid / As, ngrp = AB_THREADS / As;    // host: A <= 256 and 512 % A == 0, so ngrp >= 2 NS
     const float* __restrict__ pmb = (HAS_S ? a.s_in : a.pm) + (size_t)b * L * A;
     // processed-memory values of the first block: issued before anything else, consumed in P3
     // (buffer loads: the descriptor ends at row L, rows past it and slots past the block read zeros without a branch)
@@ -130,26 +153,28 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     for (int j = 0; j < 3; ++j) pe_dl[j] = (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + pl_e : pe_dummy)[0];
     // ---- P0: stage operands.  The first round of the weight loads goes to registers before any LDS traffic so
     // that all global latencies of this phase overlap (each separate load -> store loop costs one round trip).
-    const int nWc = F * 2 * K, nWl = A * F;
+    const int nWc = NS == 1 ? F * 2 * K : 0, nWl = As * F;       // (parts: W_c is only needed behind the sum of the partials)
+    const float* __restrict__ wl_src = a.loc_lin_w + (size_t)a_lo * F;      // rows [a_lo, a_lo + As) of W_l (A, F)
+    constexpr int WLR = 4 / NS;                                  // 16-byte register rounds of the W_l rows (F == 32, A <= 256)
     float wc_v[4], wl_v[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int i = tid + j * AB_THREADS; wc_v[j] = i < nWc ? a.loc_conv_w[i] : 0.0f; }
     // the usual shape (32 filters, 16-byte aligned W_l): four 16-byte loads per thread and shift / mask indexing below instead of
     // sixteen scalar loads and a division by F per element (this prologue is instruction-issue bound)
-    const bool wl_fast = F == AB_FMAX && nWl <= 16 * AB_THREADS && st_aligned16(a.loc_lin_w);
+    const bool wl_fast = F == AB_FMAX && nWl <= 4 * WLR * AB_THREADS && st_aligned16(wl_src);
     if (wl_fast) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WLR; ++j) {
             const int i4 = tid + j * AB_THREADS;
-            const f32x4 t = st_ld4(a.loc_lin_w + (size_t)min(i4, (nWl >> 2) - 1) * 4);
+            const f32x4 t = st_ld4(wl_src + (size_t)min(i4, (nWl >> 2) - 1) * 4);
             wl_v[4 * j] = t[0]; wl_v[4 * j + 1] = t[1]; wl_v[4 * j + 2] = t[2]; wl_v[4 * j + 3] = t[3];
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { const int i = tid + j * AB_THREADS; wl_v[j] = i < nWl ? a.loc_lin_w[i] : 0.0f; }
+        for (int j = 0; j < 16; ++j) { const int i = tid + j * AB_THREADS; wl_v[j] = i < nWl ? wl_src[i] : 0.0f; }
     }
     AB_PROF(8);
-    for (int i = tid; i < 2 * HL; i += AB_THREADS) {
+    if (NS == 1) for (int i = tid; i < 2 * HL; i += AB_THREADS) {
         const int c = i / HL, j = i - c * HL, l = j - pad;
         float v = 0.0f;
         if (l >= 0 && l < L) {
@@ -164,16 +189,16 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     // when F is not the full 32 filters (then whole arrays are cleared before the scattering stores)
     const bool ragged = F != AB_FMAX;
     if (ragged) {
-        for (int i = tid; i < 2 * K * F4; i += AB_THREADS) WcT[i] = 0.0f;
+        if (NS == 1) for (int i = tid; i < 2 * K * F4; i += AB_THREADS) WcT[i] = 0.0f;
         if (!HAS_S) for (int i = tid; i < A * F4; i += AB_THREADS) Wl[i] = 0.0f;      // (with S given W_l [a][f] has no LDS copy)
         for (int i = tid; i < 32 * LD; i += AB_THREADS) WlT[i] = 0.0f;
         for (int i = tid; i < AB_LBLK * LD; i += AB_THREADS) dsb[i] = 0.0f;
-        for (int i = tid; i < L * AB_FMAX; i += AB_THREADS) loc[i] = 0.0f;
+        if (NS == 1) for (int i = tid; i < L * AB_FMAX; i += AB_THREADS) loc[i] = 0.0f;
         st_lds_barrier();
     } else {
-        const int padw = LD - A;
+        const int padw = LD - As;
         for (int i = tid; i < (32 + AB_LBLK) * padw; i += AB_THREADS) {
-            const int r = i / padw, c = A + (i - r * padw);
+            const int r = i / padw, c = As + (i - r * padw);
             if (r < 32) WlT[r * LD + c] = 0.0f; else dsb[(r - 32) * LD + c] = 0.0f;
         }
     }
@@ -185,7 +210,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     }
     if (wl_fast) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WLR; ++j) {
             const int i4 = tid + j * AB_THREADS;
             if (i4 < (nWl >> 2)) {
                 const int aa = i4 >> 3, f0 = (i4 & 7) * 4;         // F == 32: eight float4 per W_l row
@@ -207,7 +232,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     }
     for (int i = tid + 16 * AB_THREADS; i < nWl; i += AB_THREADS) {
         const int aa = i / F, f = i - aa * F;
-        const float wv = a.loc_lin_w[i];
+        const float wv = wl_src[i];
         if (!HAS_S) Wl[aa * F4 + f] = wv;
         WlT[f * LD + aa] = wv;
     }
@@ -229,7 +254,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
         for (int j = 0; j < 3; ++j) g += a.dw_direct[j] ? dl[j] : 0.0f;
         if (a.dcum) {   // cum_t = cum_{t-1} + w_t: the total gradient w.r.t. cum_t reaches w_t and is carried to cum_{t-1}
             const float gc = gc0 + (a.dcum_add ? gc1 : 0.0f);
-            a.dcum[(size_t)b * L + l] = gc;
+            if (NS == 1) a.dcum[(size_t)b * L + l] = gc;      // (parts: dcum already is the total, kept by ab_hist_body)
             g += gc;
         }
         dws[l] = g;
@@ -244,7 +269,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
 #pragma unroll
         for (int j = 0; j < 3; ++j) g += a.dctx[j] ? dl[j] : 0.0f;
         dctx[e] = g;
-        a.dctx_t[(size_t)b * E + e] = g;
+        if (NS == 1 || prt == 0) a.dctx_t[(size_t)b * E + e] = g;
     }
     st_lds_barrier();
     // W_l row of this thread in registers (for s = pq + pm + W_l loc)
@@ -407,7 +432,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
 #ifndef AB_ABLATE_DSG      // (tools/mb only: phase timing without the tape stores)
                 if (valid) dsg[(size_t)l * A + a0] = ds2[ii];
 #endif
-                if (in_blk) dsb[row * LD + a0] = ds2[ii];            // zero for rows past L
+                if (in_blk) dsb[row * LD + a_l] = ds2[ii];           // zero for rows past L
             }
         }
 #pragma unroll
@@ -449,7 +474,9 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
             const int ll = rr * 16 + (tid >> 5);          // 16 positions x 32 filter lanes = 512 threads per pass
             const float sum = part[(0 * AB_LBLK + ll) * 32 + fl] + part[(1 * AB_LBLK + ll) * 32 + fl] +
                               part[(2 * AB_LBLK + ll) * 32 + fl] + part[(3 * AB_LBLK + ll) * 32 + fl];
-            if (l0 + ll < L && fl < F4) {
+            if (NS > 1) {            // this part's share of dloc: summed with the others' in ab_hist_body
+                if (l0 + ll < L && fl < F) a.dloc_part[(((size_t)prt * a.B + b) * L + l0 + ll) * F + fl] = sum;
+            } else if (l0 + ll < L && fl < F4) {
                 dloc[(l0 + ll) * F4 + fl] = sum;
                 if (fl < F) dlocg[(size_t)(l0 + ll) * F + fl] = sum;
             }
@@ -463,7 +490,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     st_lds_barrier();
     if (grp == 0) {
         float sv = 0.0f, sp = 0.0f;
-        for (int gq = 0; gq < ngrp; ++gq) { sv += fold[gq * A + a0]; sp += fold[AB_THREADS + gq * A + a0]; }
+        for (int gq = 0; gq < ngrp; ++gq) { sv += fold[gq * As + a_l]; sp += fold[AB_THREADS + gq * As + a_l]; }
         a.dv_t[(size_t)b * A + a0] = sv;
         a.dpq[(size_t)b * A + a0] = sp;
         if (a.dpq_t16) {
@@ -474,6 +501,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     AB_PROF(6);
     // ---- P5: gradient w.r.t. the attention history through the location conv
     // dhist[c][j] = sum_{f,k} dloc[j - k + pad][f] * Wc[f][c][k]; 8 adjacent lanes split the filters in float4 groups
+    if (NS > 1) { AB_PROF(7); return; }
     float* dh = a.dhist + (size_t)b * 2 * L;
     for (int base = 0; base < 2 * L; base += AB_THREADS / 8) {
         const int cj = base + (tid >> 3), q = tid & 7;
@@ -498,6 +526,137 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     AB_PROF(7);
 }
 
+// LDS image of ab_hist_body: W_c as [c][k + 3][f] with three zero taps in front and behind, dloc as [l + AB_HZ][f] between zero rows
+// (AB_HZ in front, AB_HZ + 4 behind) -- the sliding window of the conv-transpose then runs without a single bounds test.  Rows of dloc are
+// F4 + 4 floats apart (consecutive rows on different bank groups).
+constexpr int AB_HZ = 24;      // >= (K - 1) / 2 + 1 + AB_HU zero rows in front of dloc (host: K <= 31)
+constexpr int AB_HU = 6;       // rows of the sliding window requested from LDS together
+__host__ __device__ inline int ab_hist_lds_floats(int L, int F, int K) {
+    const int F4 = (F + 3) & ~3;
+    return 2 * (K + 6 + AB_HU) * F4 + (L + 2 * AB_HZ + 4) * (F4 + 4);
+}
+
+// See AbHistArgs.  dloc = part 0 + part 1 (+ ...) in part order; dhist[c][j] = sum_{f,k} dloc[j - k + pad][f] * Wc[f][c][k] as a sliding
+// window in registers: a thread owns 4 filters and 4 consecutive positions j0 .. j0 + 3 of BOTH channels and walks the dloc rows
+// j0 + 3 + pad down to j0 + pad - (K - 1): per row ONE dloc fragment and one new weight fragment per channel for 32 multiply-adds (the
+// per-output form of ab_body reads two fragments per 4 multiply-adds: 680 KB through a 128 B/clk LDS, 6-9k cycles -- measured).  The 8
+// lanes of a position block (filter groups) are then summed by DPP.
+__device__ __forceinline__ void ab_hist_body(const AbHistArgs& h, const int b, float* __restrict__ lds) {
+    const int tid = threadIdx.x;
+    const int L = h.L, F = h.F, K = h.K, F4 = (F + 3) & ~3, pad = (K - 1) / 2;
+    const int DLD = F4 + 4, WK = K + 6 + AB_HU;
+    float* WcT = lds;                     // [c][k + 3][f]
+    float* dlz = lds + 2 * WK * F4;       // [l + AB_HZ][f]
+    float* dloc = dlz + AB_HZ * DLD;
+    const int nWc = F * 2 * K, nD = L * F;
+    AB_PROF(0);
+    // every global operand of the first rounds is requested before anything is consumed (clamped addresses, selects afterwards)
+    float wc_v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wc_v[j] = h.loc_conv_w[min(tid + j * AB_THREADS, nWc - 1)];
+    const size_t pstride = (size_t)h.B * L * F;
+    const float* p0 = h.dloc_part + (size_t)b * L * F;
+    constexpr int DR = 3;                 // rounds of the partial sums held in registers (L F <= 1536: the usual 43 x 32)
+    float pv[DR][4];
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pv[r][q] = p0[(size_t)(q < h.parts ? q : 0) * pstride + min(tid + r * AB_THREADS, nD - 1)];
+    const int l_h = min(tid, L - 1);
+    const float hw = (h.w_prev ? h.w_prev + (size_t)b * h.ld_wprev : h.w_cum_prev + (size_t)b * L)[l_h];
+    const float hc = h.w_cum_prev[(size_t)b * L + l_h];
+    // the carried cum gradient of this thread's output block (consumed at the very end)
+    const int fg = tid & 7, ch = (tid >> 3) & 1, jb = tid >> 4, j0 = jb * 4;      // 4 filters x 1 channel x 4 positions per thread
+    float dc_old[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dc_old[jj] = (h.dcum ? h.dcum : h.w_cum_prev)[(size_t)b * L + min(j0 + jj, L - 1)];
+    AB_PROF(1);
+    // zero frame: the six pad taps of W_c, the pad rows of dloc (and everything when F is ragged)
+    // (the whole image: a linear 16-byte clear costs less than picking the pad rows out with divisions)
+    for (int i = tid; i < ab_hist_lds_floats(L, F, K) / 4; i += AB_THREADS) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st_lds_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                               // [c][k + 3][f] <- [f][c][k]
+        const int i = tid + j * AB_THREADS;
+        if (i < nWc) { const int f = i / (2 * K), ck = i - f * 2 * K, c = ck / K, k = ck - c * K; WcT[(c * WK + k + 3) * F4 + f] = wc_v[j]; }
+    }
+    AB_PROF(2);
+    for (int i = tid + 4 * AB_THREADS; i < nWc; i += AB_THREADS) {
+        const int f = i / (2 * K), ck = i - f * 2 * K, c = ck / K, k = ck - c * K;
+        WcT[(c * WK + k + 3) * F4 + f] = h.loc_conv_w[i];
+    }
+    float* dlt = h.dloc_t + (size_t)b * L * F;
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+        const int i = tid + r * AB_THREADS;
+        float sum = pv[r][0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) sum += q < h.parts ? pv[r][q] : 0.0f;
+        if (i < nD) { const int l = i / F, f = i - l * F; dloc[l * DLD + f] = sum; dlt[i] = sum; }
+    }
+    for (int i = tid + DR * AB_THREADS; i < nD; i += AB_THREADS) {
+        float sum = p0[i];
+        for (int q = 1; q < h.parts; ++q) sum += p0[(size_t)q * pstride + i];
+        const int l = i / F, f = i - l * F;
+        dloc[l * DLD + f] = sum; dlt[i] = sum;
+    }
+    // the history tape slice [w_{t-1}, cum_{t-1}] channels-last
+    for (int l = tid; l < L; l += AB_THREADS) {
+        const bool first = l == tid;
+        const float v0 = h.w_prev ? (first ? hw : h.w_prev[(size_t)b * h.ld_wprev + l]) : 0.0f;
+        const float v1 = first ? hc : h.w_cum_prev[(size_t)b * L + l];
+        *reinterpret_cast<float2*>(h.hist_t + ((size_t)b * L + l) * 2) = float2{v0, v1};
+    }
+    AB_PROF(3);
+    st_lds_barrier();
+    AB_PROF(4);
+    float* dh = h.dhist + (size_t)b * 2 * L;
+    for (int base = 0; base < L; base += (AB_THREADS / 16) * 4) {       // 32 position blocks of 4 per pass: L <= 128 in one
+        const int jq = base + j0;
+        f32x4 acc[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (jq < L) {
+            for (int f = fg * 4; f < F4; f += 32) {
+                // row r = jq + 3 + pad - s (s = 0 .. K + 2) meets output jq + jj with tap k = jj + s - 3: the weight window w[jj] holds the taps
+                // s - 3 .. s (zero taps outside [0, K)), shifted by one per row
+                const float* dr = dloc + (jq + 3 + pad) * DLD + f;
+                const float* w0 = WcT + ch * WK * F4 + f;
+                f32x4 wa[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) wa[jj] = *reinterpret_cast<const f32x4*>(w0 + jj * F4);
+                // AB_HU rows per batch, all their fragments requested before the first multiply-add (one LDS round trip per batch instead of
+                // one per row: the three busy waves cannot hide it); the rows / taps a last batch reads past the window are zeros
+                for (int s0 = 0; s0 < K + 3; s0 += AB_HU) {
+                    f32x4 d4[AB_HU], na[AB_HU];
+#pragma unroll
+                    for (int u_ = 0; u_ < AB_HU; ++u_) {
+                        d4[u_] = *reinterpret_cast<const f32x4*>(dr - (s0 + u_) * DLD);
+                        na[u_] = *reinterpret_cast<const f32x4*>(w0 + (s0 + u_ + 4) * F4);
+                    }
+#pragma unroll
+                    for (int u_ = 0; u_ < AB_HU; ++u_) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[jj] += d4[u_] * wa[jj];
+                        wa[0] = wa[1]; wa[1] = wa[2]; wa[2] = wa[3]; wa[3] = na[u_];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            float v = (acc[jj][0] + acc[jj][1]) + (acc[jj][2] + acc[jj][3]);
+            v = st_oct_sum_dpp(v);      // (uniform: all lanes active; fixed order)
+            const int j = jq + jj;
+            if (fg == 0 && j < L) {
+                dh[ch * L + j] = v;
+                // cum_t = cum_{t-1} + w_t: the gradient w.r.t. cum carries on
+                if (ch == 1 && h.dcum) h.dcum[(size_t)b * L + j] = (base == 0 ? dc_old[jj] : h.dcum[(size_t)b * L + j]) + v;
+            }
+        }
+    }
+    AB_PROF(5);
+}
 
 // argument block of one step from the C-ABI arguments (shared by the plain and the hosted launch); returns 0 or -1 with the error set
 inline int ab_fill(AbArgs& a, const st_t16_view* dpq_t16, const float* pq, const float* pm, const float* memory,
@@ -533,8 +692,8 @@ inline int ab_fill(AbArgs& a, const st_t16_view* dpq_t16, const float* pq, const
 inline bool ab_wide(const AbArgs& a, size_t extra = 0) {
     return a.s_in && (size_t)ab_layout(a.L, a.A, a.E, a.F, a.K, AB_LBLK_MAX, true).total * sizeof(float) + extra <= 160 * 1024;
 }
-inline size_t ab_lds_bytes(const AbArgs& a, bool wide) {
-    return (size_t)ab_layout(a.L, a.A, a.E, a.F, a.K, wide ? AB_LBLK_MAX : 16, a.s_in != nullptr).total * sizeof(float);
+inline size_t ab_lds_bytes(const AbArgs& a, bool wide, int parts = 1) {
+    return (size_t)ab_layout(a.L, a.A / parts, a.E, a.F, a.K, wide ? AB_LBLK_MAX : 16, a.s_in != nullptr, parts > 1).total * sizeof(float);
 }
 
 }  // namespace

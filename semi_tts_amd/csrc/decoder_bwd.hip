@@ -44,6 +44,8 @@ extern "C" int st_attn_step_bwd_t16(const float* pq, const float* pm, const floa
                                     float* dctx_t, float* dv_t, const float* s_in,
                                     int B, int L, int A, int E, int F, int K, void* stream);
 
+extern "C" int st_attn_bwd_wide_fits(int L, int A, int E, int F, int K);
+
 extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io,
                                    void* stream) {
     (void)hipGetLastError();
@@ -100,6 +102,17 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
         }
         // launch "b" of step t: dxd_t = dgates_d_t [W_ih_d | W_hh_d] (+ the decoder cell's pointwise step of t-1 in its epilogue: columns
         // [E+Q, E+Q+D) + dxo_{t-1}[:, :D] = dh_d(t-1)), optionally with the attention backward `ab` of the step AFTER it beside it
+        // the decoder cell's pointwise step of t-1 that rides behind the product of step t (t > 0)
+        auto pw_d = [&](int t, st_lstm_pw_job& j) {
+            memset(&j, 0, sizeof(j));
+            j.n0 = E + Q; j.H = D;
+            j.dh1 = io->dxo + (size_t)(t - 1) * Bp * XO; j.ld1 = XO;
+            j.mask = io->d_mask ? io->d_mask + (size_t)(t - 1) * BD : nullptr;
+            j.gates = io->gates_d_tape + (size_t)(t - 1) * 4 * BD;
+            j.c = io->cd_tape + (size_t)t * BD; j.ldc = D; j.c_prev = io->cd_tape + (size_t)(t - 1) * BD; j.ldcp = D;
+            j.dc = io->dcd; j.dgates = io->dgd + (size_t)(t - 1) * Bp * 4 * D; j.ldg = 4 * D;
+            j.dgates_t16.base = dgd_buf[(t - 1) & 1]; j.dgates_t16.kb_stride = kbd; j.dgates_t16.kb0 = 0;
+        };
         auto product_d = [&](int t, const st_attn_bwd_job* ab) -> int {
             float* dxd = io->dxd + (size_t)t * Bp * XD;
             st_t16_view x_v = {dgd_buf[t & 1], kbd, 0};
@@ -122,6 +135,16 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
         // the decoder cell's recurrence (dgates_d(t-1) from dgates_d(t) . W_hh_d and the output gradients) does not touch the attention /
         // query chain of step t: with overlap_attn its product runs ONE STEP AHEAD, beside the attention backward of step t
         const bool overlap = io->overlap_attn && io->attn_s_tape;
+        // the hosted attention backward as `parts` workgroups per utterance over slices of the attention dims; what needs the sum of their
+        // partial location-feature gradients (dloc_t, hist_t, the conv-transpose to dhist, the carried dcum) rides in the step's W_q^T dpq
+        // launch (st_attn_hist_job).  A = 256, 32 filters, texts whose wide block fits the LDS -- else the whole step per workgroup
+        int parts = overlap && io->dloc_part && (io->attn_parts == 2 || io->attn_parts == 4) ? io->attn_parts : 1;
+        if (parts > 1 && !(A % (16 * parts) == 0 && 512 % (A / parts) == 0 && 512 / (A / parts) >= 2 * parts && d->F == 32 && d->K <= 31 &&
+                           st_attn_bwd_wide_fits(L, A, E, d->F, d->K))) parts = 1;
+        // ... and, in that form, the decoder cell's product of the hosted launch K-split into partial slabs (two row tiles and both batch tiles
+        // per workgroup: half the bytes through the compute units; 2 B + N / 32 * S workgroups: one round) that the step's W_q^T dpq launch sums
+        const int dsplits = io->dxd_splits > 0 ? io->dxd_splits : 2;
+        const bool partial = parts == 2 && io->dxd_part && B > 16 && B <= 32 && XD % 32 == 0 && ((4 * D) / 16) % dsplits == 0 && Bp == B;
         if (overlap) { rc = product_d(steps - 1, nullptr); if (rc) return rc; }
         for (int t = steps - 1; t >= 0; --t) {
             const float* dxo = io->dxo + (size_t)t * Bp * XO;
@@ -142,13 +165,19 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
             ab.dctx[0] = dxo + D; ab.dctx[1] = dxd; ab.dctx[2] = dxq_next + P; ab.ld_dctx[0] = XO; ab.ld_dctx[1] = XD; ab.ld_dctx[2] = XQ; ab.n_dctx = 3;
             ab.dw_direct[0] = dhist_next; ab.dw_direct[1] = io->dalign ? io->dalign + (size_t)t * L : nullptr; ab.ld_dw[0] = 2 * L; ab.ld_dw[1] = ldal;
             ab.n_dw = io->dalign ? 2 : 1;
-            ab.dcum = io->dcum; ab.dcum_add = dhist_next + L; ab.ld_dcum_add = 2 * L;
+            // (split form: the history job of step t+1 has already added dhist(t+1)[1] into dcum)
+            ab.dcum = io->dcum; ab.dcum_add = parts > 1 ? nullptr : dhist_next + L; ab.ld_dcum_add = 2 * L;
+            const bool split = parts > 1 && overlap && t > 0;
+            if (split) { ab.parts = parts; ab.dloc_part = io->dloc_part; }
             ab.dpq = dpq; ab.dpq_t16 = dpq_v; ab.dhist = dhist_cur; ab.ds_t = io->ds_tape + (size_t)t * BL * A;
             ab.loc_t = io->loc_tape + (size_t)t * BL * d->F; ab.dloc_t = io->dloc_tape + (size_t)t * BL * d->F;
             ab.hist_t = io->hist_tape + (size_t)t * BL * 2; ab.dctx_t = io->dctx_tape + (size_t)t * B * E; ab.dv_t = io->dv_tape + (size_t)t * B * A;
             ab.s_in = io->attn_s_tape ? (t == 0 ? io->pm : io->attn_s_tape + (size_t)t * BL * A) : nullptr;
             ab.B = B; ab.L = L; ab.A = A; ab.E = E; ab.F = d->F; ab.K = d->K;
-            if (overlap && t > 0) rc = product_d(t - 1, &ab);        // [attention backward of t | decoder cell product of t-1]: one launch
+            if (split && partial) {      // [attention backward of t, two parts | K-split partial product of the decoder cell, step t-1]
+                st_t16_view x_v = {dgd_buf[(t - 1) & 1], kbd, 0};
+                rc = st_skinny_partial_attn_bwd(w->d_w_cat_t_p16, &x_v, 4 * D, io->dxd_part, dsplits, B, XD, &ab, stream);
+            } else if (overlap && t > 0) rc = product_d(t - 1, &ab);        // [attention backward of t | decoder cell product of t-1]: one launch
             else rc = st_attn_step_bwd_t16(ab.pq, ab.pm, ab.memory, ab.w_prev, ab.ld_wprev, ab.w_cum_prev, ab.w, ab.ld_w, ab.loc_conv_w, ab.loc_lin_w,
                                            ab.v, ab.dctx, ab.ld_dctx, ab.n_dctx, ab.dw_direct, ab.ld_dw, ab.n_dw, ab.dcum, ab.dcum_add, ab.ld_dcum_add,
                                            ab.dpq, &ab.dpq_t16, ab.dhist, ab.ds_t, ab.loc_t, ab.dloc_t, ab.hist_t, ab.dctx_t, ab.dv_t, ab.s_in,
@@ -166,11 +195,30 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                 j.c = io->cq_tape + (size_t)(t + 1) * BQ; j.ldc = Q; j.c_prev = io->cq_tape + (size_t)t * BQ; j.ldcp = Q;
                 j.dc = io->dcq; j.dgates = io->dgq + (size_t)t * Bp * 4 * Q; j.ldg = 4 * Q;
                 j.dgates_t16 = dgq_v;
-                rc = st_skinny_linear_packed_lstm_bwd_fwd(w->attn_query_w_t_p16, &dpq_v, A, io->dhq_attn, Q, B, Q, &j, stream);
+                if (split && partial) {
+                    // ... with the slabs of launch 1's partial product beside it: dxd_{t-1} + the decoder cell's pointwise step of t-2
+                    st_lstm_pw_job jd;
+                    st_partial_sum_job sj;
+                    memset(&sj, 0, sizeof(sj));
+                    sj.part = io->dxd_part; sj.S = dsplits; sj.N = XD; sj.y = io->dxd + (size_t)(t - 1) * Bp * XD; sj.ldy = XD;
+                    if (t - 1 > 0) { pw_d(t - 1, jd); sj.pw = &jd; }
+                    rc = st_skinny_linear_packed_lstm_bwd_attn_hist_sum(w->attn_query_w_t_p16, &dpq_v, A, io->dhq_attn, Q, B, Q, &j, nullptr, &sj, stream);
+                } else rc = st_skinny_linear_packed_lstm_bwd_fwd(w->attn_query_w_t_p16, &dpq_v, A, io->dhq_attn, Q, B, Q, &j, stream);
                 if (rc) return rc;
             }
             // f. gradient w.r.t. [dec_in_t | ctx_{t-1} | h_q_{t-1}]
-            if (t > 0 || io->need_dxq0) {
+            if (split) {
+                // ... with what the split attention backward of this step left behind (the sum of its partial dloc, the history tape, the
+                // conv-transpose to dhist, the carried dcum) on the compute units this product leaves idle
+                st_attn_hist_job hj;
+                memset(&hj, 0, sizeof(hj));
+                hj.dloc_part = io->dloc_part; hj.parts = parts; hj.loc_conv_w = w->attn_loc_conv_w;
+                hj.w_prev = ab.w_prev; hj.ld_wprev = ab.ld_wprev; hj.w_cum_prev = ab.w_cum_prev;
+                hj.dloc_t = ab.dloc_t; hj.hist_t = ab.hist_t; hj.dhist = dhist_cur; hj.dcum = io->dcum;
+                hj.B = B; hj.L = L; hj.F = d->F; hj.K = d->K;
+                rc = st_skinny_linear_packed_attn_hist(w->q_w_cat_t_p16, &dgq_v, 4 * Q, dxq, XQ, B, XQ, &hj, stream);
+                if (rc) return rc;
+            } else if (t > 0 || io->need_dxq0) {
                 rc = st_skinny_linear_packed_fwd(w->q_w_cat_t_p16, &dgq_v, 4 * Q, nullptr, ST_ACT_NONE, nullptr, 0, dxq, XQ, nullptr,
                                                  0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, XQ, stream);
                 if (rc) return rc;

@@ -245,10 +245,11 @@ __device__ __forceinline__ void pk_mma(const PkRegs<NB, TRIP>& r, f32x4 (&acc)[N
 
 // MODE 0: LSTM cell, MODE 1: linear
 template <int MODE, int NB, int KW, int TRIP>
-__device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const int by, f32x4* red, const PkPw* pw = nullptr) {
+__device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const int by, f32x4* red, const PkPw* pw = nullptr, const int tid0 = 0) {
     // the wave index is wave-uniform: telling the compiler (readfirstlane) keeps every k-block address in scalar registers,
     // so a load is `global_load v, lane_offset, s[base]` instead of a 64-bit vector address computation per load
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (tid0: first thread of this body's KW waves when two bodies share a workgroup, pk_pw_ab_dual_kernel)
+    const int tid = (int)threadIdx.x - tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bt0 = by * NB;
     const int BT = (a.B + 15) >> 4;
 
@@ -684,20 +685,264 @@ __global__ __launch_bounds__(KW * 64) void pk_pw_pair_kernel(const int n0, const
 // The decoder cell's backward product of step t-1 (pk_body MODE 2) with the attention-step backward of step t BESIDE it: in the BPTT
 // loop dgates_d(t-1) only needs the decoder cell's own recurrence, so the two do not depend on each other.  The attention
 // workgroups come FIRST (dispatched first: each holds a compute unit for ~17 us), the product's workgroups after them.
-template <int NB, int KW, int TRIP, int LBLK>
-__global__ __launch_bounds__(KW * 64) void pk_pw_ab_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+// NS > 1: NS attention workgroups per utterance (ab_body<.., NS>: each takes A / NS attention dims; what needs the sum of their partial
+// results runs as ab_hist_body in the next launch, pk_pw_hist_kernel).  Part p of utterance b is workgroup p B + b: the parts of an
+// utterance are a multiple of 8 apart in launch order -- the same XCD, so the memory / S tiles they both read meet in one L2.
+// NS > 1 is built for TWO workgroups per compute unit (at most 128 VGPRs, a lean LDS image): the 2 B attention workgroups and the product's
+// 2 N / 16 all reside at once -- with one workgroup per unit the product alone needs two rounds.
+template <int NB, int KW, int TRIP, int LBLK, int NS>
+__global__ __launch_bounds__(KW * 64) __attribute__((amdgpu_waves_per_eu((NS > 1 && NB == 1) ? 4 : 1, (NS > 1 && NB == 1) ? 4 : 8))) void pk_pw_ab_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
                                                            const int B, const int N, const int tiles_a, const int n_ab,
                                                            const PkArgs rest, const PkPw pw, const AbArgs ab) {
     extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
     __shared__ f32x4 red[KW * NB * 64];
     static_assert(KW * 64 == AB_THREADS, "both parts use 512-thread workgroups");
     const int i = blockIdx.x;
-    if (i < n_ab) { ab_body<true, LBLK>(ab, i, pk_dyn_lds); return; }
+    if (i < n_ab) {
+        if (NS == 1) ab_body<true, LBLK, 1>(ab, i, pk_dyn_lds);
+        else { const int part = i / ab.B; ab_body<true, LBLK, NS>(ab, i - part * ab.B, pk_dyn_lds, part); }
+        return;
+    }
     PkArgs a = rest;
     a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N; a.H = 0;
     const int j = i - n_ab;
     const int by = j / tiles_a;
     pk_body<2, NB, KW, TRIP>(a, j - by * tiles_a, by, red, &pw);
+}
+
+// ---- K-split partial products ------------------------------------------------------------------------------------------------------
+// y = x W^T for B <= 32 rows (two batch tiles) with TWO row tiles and BOTH batch tiles per workgroup -- every weight fragment and every
+// activation fragment feeds two MFMAs, so a workgroup takes in half the bytes per output of pk_body<.., NB = 1> (whose 2 N / 16 workgroups
+// each re-read a whole batch tile of x: 168 MB through the compute units for the 42 MB decoder-cell product, 15 us) -- and the reduction
+// axis cut into S ranges over workgroups so that N / 32 * S of them still fill the chip.  Split s of a tile pair writes its partial tile to
+// part[s] (S, B, N); a pk_sum_body job of the NEXT launch adds the S slabs in split order (fixed: bitwise reproducible) and runs the
+// epilogue (the pointwise LSTM backward of the columns that are a cell's dh).
+struct PkPartArgs {
+    const f32x4* w; int w_kbs;      // packed weights [tile][w_kbs][64]
+    const f32x4* x; int x_kbs;      // T16 activations (two batch tiles)
+    int KB, S;                      // k-blocks in total, splits (KB % S == 0)
+    int B, N;                       // N % 32 == 0
+    float* part;                    // (S, B, N)
+};
+
+template <int KW, int TRIP>
+__device__ __forceinline__ void pk_part_body(const PkPartArgs& p, const int j, f32x4* red) {
+    constexpr int RT = 2, NB = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tp = p.N >> 5;
+    const int sp = j / n_tp, tp = j - sp * n_tp;           // the splits of a tile pair are n_tp workgroups apart
+    const int KBs = p.KB / p.S, kb_lo = sp * KBs;
+    __amdgpu_buffer_rsrc_t rw[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+        rw[rt] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + ((size_t)(tp * RT + rt) * p.w_kbs + kb_lo) * 64), 0, KBs * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)kb_lo * 64), 0, ((NB - 1) * p.x_kbs + KBs) * 1024, 0x00020000);
+    const unsigned voff = (unsigned)lane * 16u;
+    constexpr int STEP = KW * TRIP;
+    const int G = (KBs + STEP - 1) / STEP;
+    const int rot = (int)((((unsigned)tp & 255u) * (unsigned)G) >> 8);
+    auto kb_of = [&](int gq) { int q = gq + rot; if (q >= G) q -= G; return q * STEP + wave; };
+    struct Regs { f32x4 w[TRIP][RT]; f32x4 x[TRIP][NB]; };
+    auto load = [&](Regs& r, int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < TRIP; ++t) {
+            const unsigned vo = voff + (unsigned)(kb + t * KW) * 1024u;         // past the split's range: zeros from the range check
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) r.w[t][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw[rt], vo, 0, 0));
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) r.x[t][bt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, bt * p.x_kbs * 1024, 0));
+        }
+    };
+    f32x4 acc[RT][NB];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) acc[rt][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const Regs& r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < TRIP; ++t)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt)
+                        acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.w[t][rt][cc], r.x[t][bt][cc], acc[rt][bt], 0, 0, 0);
+    };
+    Regs ra, rb;
+    if (G > 0) load(ra, kb_of(0));
+    if (G > 1) load(rb, kb_of(1));
+    {
+        int g = 0;
+        while (g < G) {
+            mma(ra);
+            if (g + 2 < G) load(ra, kb_of(g + 2));
+            ++g;
+            if (g >= G) break;
+            mma(rb);
+            if (g + 2 < G) load(rb, kb_of(g + 2));
+            ++g;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) red[((wave * RT + rt) * NB + bt) * 64 + lane] = acc[rt][bt];
+    __syncthreads();
+    if (tid >= RT * NB * 64) return;
+    const int e_rt = (tid >> 6) / NB, e_bt = (tid >> 6) % NB;       // waves 0..3 add the eight waves' partial tiles (wave order: fixed)
+    f32x4 sm = red[(e_rt * NB + e_bt) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) {
+        const f32x4 t = red[((w * RT + e_rt) * NB + e_bt) * 64 + lane];
+        sm[0] += t[0]; sm[1] += t[1]; sm[2] += t[2]; sm[3] += t[3];
+    }
+    const int b = e_bt * 16 + (lane & 15);
+    const int n0 = (tp * RT + e_rt) * 16 + 4 * (lane >> 4);       // the lane's 4 consecutive outputs of batch row b
+    if (b < p.B) *reinterpret_cast<f32x4*>(p.part + ((size_t)sp * p.B + b) * p.N + n0) = sm;
+}
+
+// y(b, n0 .. n0+3) = part[0] + part[1] + ... (split order), then -- for the columns [pw.n0, pw.n0 + pw.H) -- the pointwise LSTM backward
+// of pk_body's MODE 2 epilogue on them.  One thread per (batch row, 4 columns); blocks of KW * 64 threads; job block jb.
+struct PkSumArgs {
+    const float* part; int S;
+    int B, N;
+    float* y; int ldy;
+    PkPw pw;                        // pw.H == 0: no cell
+};
+
+__device__ __forceinline__ void pk_sum_body(const PkSumArgs& a, const int jb, const int nthreads) {
+    const int idx = jb * nthreads + (int)threadIdx.x;
+    const int n4 = a.N >> 2;
+    if (idx >= a.B * n4) return;
+    const int b = idx / n4, n0 = (idx - b * n4) * 4;
+    const PkPw& q = a.pw;
+    const bool cell = q.H > 0 && n0 >= q.n0 && n0 + 3 < q.n0 + q.H;
+    // every operand is requested before the first one is used (clamped / dummy addresses, selects afterwards)
+    const float* pp = a.part + (size_t)b * a.N + n0;
+    const size_t sstride = (size_t)a.B * a.N;
+    f32x4 pv[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) pv[s_] = st_ld4(pp + (size_t)(s_ < a.S ? s_ : 0) * sstride);
+    const int H = cell ? q.H : 4, u = cell ? n0 - q.n0 : 0;
+    const size_t bu = cell ? (size_t)b * H + u : 0;
+    const float* dummy = a.part;
+    const float* gp = cell ? q.gates + (size_t)b * 4 * H + u : dummy;
+    const f32x4 gi = st_ld4(gp), gf = st_ld4(cell ? gp + H : dummy), gg = st_ld4(cell ? gp + 2 * H : dummy), go = st_ld4(cell ? gp + 3 * H : dummy);
+    const f32x4 cr = st_ld4(cell ? q.c + (size_t)b * q.ldc + u : dummy);
+    const f32x4 dci = st_ld4(cell ? q.dc + bu : dummy);
+    const f32x4 l1 = st_ld4(cell && q.dh1 ? q.dh1 + (size_t)b * q.ld1 + u : dummy);
+    const f32x4 l2 = st_ld4(cell && q.dh2 ? q.dh2 + (size_t)b * q.ld2 + u : dummy);
+    const f32x4 sc = st_ld4(cell && q.scale2 ? q.scale2 + bu : dummy);
+    const f32x4 mk = st_ld4(cell && q.mask ? q.mask + bu : dummy);
+    const f32x4 cp = st_ld4(cell && q.c_prev ? q.c_prev + (size_t)b * q.ldcp + u : dummy);
+    f32x4 v4 = pv[0];
+#pragma unroll
+    for (int s_ = 1; s_ < 4; ++s_)
+        if (s_ < a.S) { v4[0] += pv[s_][0]; v4[1] += pv[s_][1]; v4[2] += pv[s_][2]; v4[3] += pv[s_][3]; }
+    for (int s_ = 4; s_ < a.S; ++s_) { const f32x4 t = st_ld4(pp + (size_t)s_ * sstride); v4[0] += t[0]; v4[1] += t[1]; v4[2] += t[2]; v4[3] += t[3]; }
+    *reinterpret_cast<f32x4*>(a.y + (size_t)b * a.ldy + n0) = v4;
+    if (!cell) return;
+    f32x4 d0, d1, d2, d3, dco;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float dh = v4[r];
+        if (q.dh1) dh += l1[r];
+        if (q.dh2) dh += l2[r] * (q.scale2 ? sc[r] : 1.0f);
+        if (q.mask) dh *= mk[r];
+        const float tc = tanhf(cr[r]);
+        const float cpv = q.c_prev ? cp[r] : 0.0f;
+        const float dc = dci[r] + dh * go[r] * (1.0f - tc * tc);
+        d0[r] = dc * gg[r] * gi[r] * (1.0f - gi[r]); d1[r] = dc * cpv * gf[r] * (1.0f - gf[r]);
+        d2[r] = dc * gi[r] * (1.0f - gg[r] * gg[r]); d3[r] = dh * tc * go[r] * (1.0f - go[r]);
+        dco[r] = dc * gf[r];
+    }
+    float* dg = q.dgates + (size_t)b * q.ldg + u;
+    *reinterpret_cast<f32x4*>(dg) = d0; *reinterpret_cast<f32x4*>(dg + H) = d1;
+    *reinterpret_cast<f32x4*>(dg + 2 * H) = d2; *reinterpret_cast<f32x4*>(dg + 3 * H) = d3;
+    if (q.dg_t16.base) {
+        const int k0 = q.dg_t16.kb0 * 16 + u;
+        *reinterpret_cast<f32x4*>(q.dg_t16.base + t16_off(b, k0, q.dg_t16.kb_stride)) = d0;
+        *reinterpret_cast<f32x4*>(q.dg_t16.base + t16_off(b, k0 + H, q.dg_t16.kb_stride)) = d1;
+        *reinterpret_cast<f32x4*>(q.dg_t16.base + t16_off(b, k0 + 2 * H, q.dg_t16.kb_stride)) = d2;
+        *reinterpret_cast<f32x4*>(q.dg_t16.base + t16_off(b, k0 + 3 * H, q.dg_t16.kb_stride)) = d3;
+    }
+    *reinterpret_cast<f32x4*>(q.dc + bu) = dco;
+}
+
+// BPTT launch 1 in the partial form: the NS B workgroups of the split attention backward of step t, then the K-split partial product
+// dgates_d(t-1) . [W_ih | W_hh] -- N / 32 * S workgroups; with S = 2 that is 64 + 160 at C2: one round, a compute unit each
+template <int KW, int TRIP, int LBLK, int NS>
+__global__ __launch_bounds__(KW * 64) void pk_part_ab_kernel(const PkPartArgs p, const int n_ab, const AbArgs ab, const int exp_) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * 4 * 64];
+    static_assert(KW * 64 == AB_THREADS, "both parts use 512-thread workgroups");
+    const int i = blockIdx.x;
+    if (exp_ == 1 && i < n_ab) return;
+    if (exp_ == 2 && i >= n_ab) return;
+    if (i < n_ab) {
+        const int part = i / ab.B;
+        ab_body<true, LBLK, NS>(ab, i - part * ab.B, pk_dyn_lds, part);
+        return;
+    }
+    pk_part_body<KW, TRIP>(p, i - n_ab, red);
+}
+
+// the partial product on its own (no attention backward beside it)
+template <int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_part_kernel(const PkPartArgs p) {
+    __shared__ f32x4 red[KW * 4 * 64];
+    pk_part_body<KW, TRIP>(p, blockIdx.x, red);
+}
+
+// The same launch with the product's TWO batch tiles of a row tile as the two halves of ONE 16-wave workgroup (B <= 32): N / 16 product
+// workgroups + NS B attention workgroups (the upper half of those exits at once) <= 256 -- every workgroup has a compute unit of its own,
+// in one round.  (320 + 64 eight-wave workgroups put up to three on a unit: 17.1 us per launch against 12.7 for the product alone; the two
+// halves of a pair also stream the same weight tile at the same time.)
+template <int KW, int TRIP, int LBLK, int NS>
+__global__ __launch_bounds__(2 * KW * 64) void pk_pw_ab_dual_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                                    const int B, const int N, const int n_ab,
+                                                                    const PkArgs rest, const PkPw pw, const AbArgs ab, const int exp_) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[2 * KW * 64];
+    static_assert(KW * 64 == AB_THREADS, "both parts use 512-thread bodies");
+    const int i = blockIdx.x;
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (KW * 64));
+    if (exp_ == 1 && i < n_ab) return;
+    if (exp_ == 2 && i >= n_ab) return;
+    if (i < n_ab) {
+        if (half) return;
+        const int part = i / ab.B;
+        ab_body<true, LBLK, NS>(ab, i - part * ab.B, pk_dyn_lds, part);
+        return;
+    }
+    PkArgs a = rest;
+    a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N; a.H = 0;
+    pk_body<2, 1, KW, TRIP>(a, i - n_ab, half, red + half * KW * 64, &pw, half * KW * 64);
+}
+
+// The W_q^T dpq product (+ the query cell's pointwise backward in its epilogue) of BPTT step t with what the split attention backward of
+// the same step left behind (ab_hist_body: one workgroup per utterance, dispatched first) BESIDE it: the product occupies half of the
+// compute units (128 workgroups), the history part a few microseconds on 32 of the others.
+// n_sum > 0: n_sum more workgroups in front of the product add the slabs of the previous launch's K-split partial product (pk_sum_body)
+// MODE 1: the plain product (the BPTT step's dgates_q . W launch: 224 of 256 compute units busy for 9 us -- the history part hides there)
+template <int MODE, int NB, int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_pw_hist_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                             const int B, const int N, const int tiles_a, const int n_h, const int n_sum,
+                                                             const PkArgs rest, const PkPw pw, const AbHistArgs hist, const PkSumArgs sum, const int exp_) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * NB * 64];
+    const int i = blockIdx.x;
+    if (exp_ == 3 && i < n_h) return;
+    if (exp_ == 4 && i >= n_h && i < n_h + n_sum) return;
+    if (exp_ == 5 && i >= n_h + n_sum) return;
+    if (i < n_h) { ab_hist_body(hist, i, pk_dyn_lds); return; }
+    if (i < n_h + n_sum) { pk_sum_body(sum, i - n_h, KW * 64); return; }
+    PkArgs a = rest;
+    a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N; a.H = 0;
+    const int j = i - n_h - n_sum;
+    const int by = j / tiles_a;
+    pk_body<MODE, NB, KW, TRIP>(a, j - by * tiles_a, by, red, MODE == 2 ? &pw : nullptr);
 }
 
 // A packed linear whose x operand is PRODUCED BY OTHER WORKGROUPS OF THE SAME LAUNCH and arrives as {value, tag} granules, (B, K) row-major
@@ -1454,7 +1699,17 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, 
     ST_CHECK_ARG(t.s_in, "st_skinny_linear_packed_lstm_bwd_attn_bwd: the hosted attention backward starts from the forward's S (s_in)");
     const size_t red_bytes = (size_t)8 * 1 * 64 * sizeof(f32x4);          // the product's static LDS in the same workgroup
     const bool wide = ab_wide(t, red_bytes);
-    const size_t lds = ab_lds_bytes(t, wide);
+    // parts > 1: the split form (see pk_pw_ab_kernel); the caller then runs st_skinny_linear_packed_lstm_bwd_attn_hist next
+    const int parts = ab->parts > 1 ? ab->parts : 1;
+    const size_t lds = ab_lds_bytes(t, wide, parts);
+    if (parts > 1) {
+        ST_CHECK_ARG(parts == 2 || parts == 4, "st_skinny_linear_packed_lstm_bwd_attn_bwd: parts = %d (1, 2 or 4)", parts);
+        ST_CHECK_ARG(ab->dloc_part && !ab->dcum_add && wide && lds + red_bytes <= 160 * 1024 && t.A % parts == 0 && AB_THREADS % (t.A / parts) == 0 &&
+                     (t.A / parts) % 16 == 0 && AB_THREADS / (t.A / parts) >= 2 * parts && t.A / parts <= AB_THREADS / (2 * parts),
+                     "st_skinny_linear_packed_lstm_bwd_attn_bwd: parts = %d needs dloc_part, no dcum_add (the history job keeps dcum), the wide block "
+                     "and A = %d splitting into parts of a multiple of 16 dims that divide %d", parts, t.A, AB_THREADS);
+        t.dloc_part = ab->dloc_part;
+    }
     if (lds + red_bytes > 160 * 1024) {
         // a text so long that the attention backward needs (nearly) all the LDS of a compute unit for itself: the two launches one after
         // the other (they are independent: any order)
@@ -1468,14 +1723,174 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, 
                                     ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in, ab->B, ab->L, ab->A, ab->E, ab->F, ab->K, stream);
     }
     const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
-    auto kern = wide ? pk_pw_ab_kernel<1, 8, 2, AB_LBLK_MAX> : pk_pw_ab_kernel<1, 8, 2, 16>;
-    static size_t lds_set[2] = {0, 0};
-    if (lds > 48 * 1024 && lds > lds_set[wide ? 1 : 0]) {
-        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[wide ? 1 : 0] = lds;
+    if (parts == 2 && BT == 2 && tiles + 2 * t.B <= 256 && getenv("ST_AB_NB2")) {
+        // both batch tiles of a row tile in ONE eight-wave workgroup (pk_body NB = 2: every weight fragment feeds two MFMAs): N / 16 product
+        // workgroups + 2 B attention workgroups <= 256: one round, a compute unit each
+        auto k2 = pk_pw_ab_kernel<2, 8, 2, AB_LBLK_MAX, 2>;
+        static size_t lds_nb2 = 0;
+        if (lds > 32 * 1024 && lds > lds_nb2) {
+            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_nb2 = lds;
+        }
+        hipLaunchKernelGGL(k2, dim3(2 * t.B + tiles), dim3(8 * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, tiles,
+                           2 * t.B, a, q, t);
+        ST_LAUNCH_CHECK();
+        return 0;
     }
-    hipLaunchKernelGGL(kern, dim3(t.B + tiles * BT), dim3(8 * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, tiles,
-                       t.B, a, q, t);
+    if (parts == 2 && BT == 2 && tiles + 2 * t.B <= 256 && !getenv("ST_AB_NO_DUAL")) {
+        auto kd = pk_pw_ab_dual_kernel<8, 2, AB_LBLK_MAX, 2>;
+        static size_t lds_dual = 0;
+        if (lds > 32 * 1024 && lds > lds_dual) {
+            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_dual = lds;
+        }
+        hipLaunchKernelGGL(kd, dim3(2 * t.B + tiles), dim3(2 * 8 * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N,
+                           2 * t.B, a, q, t, getenv("ST_EXP") ? atoi(getenv("ST_EXP")) : 0);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
+    auto kern = parts == 4 ? pk_pw_ab_kernel<1, 8, 2, AB_LBLK_MAX, 4> : parts == 2 ? pk_pw_ab_kernel<1, 8, 2, AB_LBLK_MAX, 2>
+                : wide ? pk_pw_ab_kernel<1, 8, 2, AB_LBLK_MAX, 1> : pk_pw_ab_kernel<1, 8, 2, 16, 1>;
+    static size_t lds_set[4] = {0, 0, 0, 0};
+    const int ki = parts == 4 ? 3 : parts == 2 ? 2 : wide ? 1 : 0;
+    if (lds > 48 * 1024 && lds > lds_set[ki]) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[ki] = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(parts * t.B + tiles * BT), dim3(8 * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, tiles,
+                       parts * t.B, a, q, t);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// st_skinny_linear_packed_lstm_bwd_fwd with the history part of a split attention backward (st_attn_hist_job) in the same launch
+static int pk_hist_sum_impl(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                            const st_lstm_pw_job* job, const st_attn_hist_job* hj, const st_partial_sum_job* sj, void* stream);
+
+extern "C" int st_skinny_linear_packed_lstm_bwd_attn_hist(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                                          const st_lstm_pw_job* job, const st_attn_hist_job* hj, void* stream) {
+    ST_CHECK_ARG(job && hj, "st_skinny_linear_packed_lstm_bwd_attn_hist: null job");
+    return pk_hist_sum_impl(packed_w, x, K, y, ldy, B, N, job, hj, nullptr, stream);
+}
+
+// ... and with the sum of a K-split partial product (st_partial_sum_job: the slabs st_skinny_partial_attn_bwd wrote in the launch before);
+// hj may be NULL here (the history part can ride in another launch: st_skinny_linear_packed_attn_hist)
+extern "C" int st_skinny_linear_packed_lstm_bwd_attn_hist_sum(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                                              const st_lstm_pw_job* job, const st_attn_hist_job* hj,
+                                                              const st_partial_sum_job* sj, void* stream) {
+    ST_CHECK_ARG(job && sj, "st_skinny_linear_packed_lstm_bwd_attn_hist_sum: null job");
+    return pk_hist_sum_impl(packed_w, x, K, y, ldy, B, N, job, hj, sj, stream);
+}
+
+// the plain product y = x W^T (st_skinny_linear_packed_fwd without epilogue) with an st_attn_hist_job beside it
+extern "C" int st_skinny_linear_packed_attn_hist(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                                                 const st_attn_hist_job* hj, void* stream) {
+    ST_CHECK_ARG(hj, "st_skinny_linear_packed_attn_hist: null history job");
+    return pk_hist_sum_impl(packed_w, x, K, y, ldy, B, N, nullptr, hj, nullptr, stream);
+}
+
+static int pk_sum_fill(PkSumArgs& sa, const st_partial_sum_job* sj, int B, const char* who) {
+    memset(&sa, 0, sizeof(sa));
+    ST_CHECK_ARG(sj->part && sj->S >= 1 && sj->N > 0 && sj->N % 4 == 0 && sj->y && sj->ldy >= sj->N && sj->ldy % 4 == 0 && st_aligned16(sj->part) &&
+                 st_aligned16(sj->y), "%s: bad sum job (N and ldy multiples of 4, 16-byte aligned slabs and output)", who);
+    sa.part = sj->part; sa.S = sj->S; sa.B = B; sa.N = sj->N; sa.y = sj->y; sa.ldy = sj->ldy;
+    if (sj->pw) {
+        int rc = pk_pw_fill(sa.pw, sj->pw, sj->N, sj->ldy, sj->y, who);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int pk_hist_sum_impl(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
+                            const st_lstm_pw_job* job, const st_attn_hist_job* hj, const st_partial_sum_job* sj, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(y && (hj || sj) && B > 0 && N > 0 && ldy >= N, "st_skinny_linear_packed_*_attn_hist: bad arguments");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, x, K, "st_skinny_linear_packed_*_attn_hist");
+    if (rc) return rc;
+    a.B = B; a.N = N; a.H = 0; a.act = ST_ACT_NONE;
+    a.y = y; a.ldy = ldy;
+    PkPw q;
+    memset(&q, 0, sizeof(q));
+    if (job) {
+        rc = pk_pw_fill(q, job, N, ldy, y, "st_skinny_linear_packed_lstm_bwd_attn_hist");
+        if (rc) return rc;
+    }
+    AbHistArgs h;
+    memset(&h, 0, sizeof(h));
+    size_t lds = 0;
+    if (hj) {
+        ST_CHECK_ARG(hj->dloc_part && hj->parts >= 1 && hj->parts <= 4 && hj->loc_conv_w && hj->w_cum_prev && hj->dloc_t && hj->hist_t && hj->dhist &&
+                     hj->B > 0 && hj->L > 0 && hj->F > 0 && hj->K > 0 && (hj->K & 1) && hj->K <= 31,
+                     "st_skinny_linear_packed_*_attn_hist: bad history job (odd K <= 31)");
+        h.dloc_part = hj->dloc_part; h.parts = hj->parts; h.loc_conv_w = hj->loc_conv_w; h.w_prev = hj->w_prev; h.ld_wprev = hj->ld_wprev;
+        h.w_cum_prev = hj->w_cum_prev; h.dloc_t = hj->dloc_t; h.hist_t = hj->hist_t; h.dhist = hj->dhist; h.dcum = hj->dcum;
+        h.B = hj->B; h.L = hj->L; h.F = hj->F; h.K = hj->K;
+        lds = (size_t)ab_hist_lds_floats(h.L, h.F, h.K) * sizeof(float);
+    }
+    const size_t red_bytes = (size_t)8 * 1 * 64 * sizeof(f32x4);
+    ST_CHECK_ARG(lds + red_bytes <= 160 * 1024, "st_skinny_linear_packed_*_attn_hist: L=%d needs %zu bytes of LDS", h.L, lds);
+    auto kern = job ? pk_pw_hist_kernel<2, 1, 8, 2> : pk_pw_hist_kernel<1, 1, 8, 2>;
+    static size_t lds_sets[2] = {0, 0};
+    size_t& lds_set = lds_sets[job ? 1 : 0];
+    if (lds > 48 * 1024 && lds > lds_set) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    PkSumArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    int n_sum = 0;
+    if (sj) {
+        rc = pk_sum_fill(sa, sj, B, "st_skinny_linear_packed_lstm_bwd_attn_hist_sum");
+        if (rc) return rc;
+        n_sum = (B * (sa.N >> 2) + 8 * 64 - 1) / (8 * 64);
+    }
+    const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
+    const int n_h = hj ? h.B : 0;
+    hipLaunchKernelGGL(kern, dim3(n_h + n_sum + tiles * BT), dim3(8 * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, tiles,
+                       n_h, n_sum, a, q, h, sa, getenv("ST_EXP") ? atoi(getenv("ST_EXP")) : 0);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// K-split partial product part[s] (B, N) = x[:, K-range s] . W[:, K-range s]^T (see pk_part_body; B <= 32, N % 32 == 0, (K / 16) % S == 0) with the
+// split attention backward of a BPTT step (ab->parts = 2, as st_skinny_linear_packed_lstm_bwd_attn_bwd) beside it in ONE launch; ab NULL: the
+// partial product alone.  The caller adds the slabs with an st_partial_sum_job in its next launch.
+extern "C" int st_skinny_partial_attn_bwd(const float* packed_w, const st_t16_view* x, int K, float* part, int S, int B, int N,
+                                          const st_attn_bwd_job* ab, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(packed_w && x && x->base && part && K > 0 && K % 16 == 0 && S >= 1 && (K / 16) % S == 0 && B > 16 && B <= 32 && N > 0 && N % 32 == 0 &&
+                 st_aligned16(part), "st_skinny_partial_attn_bwd: needs 16 < B <= 32 (two batch tiles), N %% 32 == 0, K %% (16 S) == 0 (B=%d N=%d K=%d S=%d)", B, N, K, S);
+    PkPartArgs p;
+    p.w = reinterpret_cast<const f32x4*>(packed_w); p.w_kbs = K / 16;
+    p.x = reinterpret_cast<const f32x4*>(x->base) + (size_t)x->kb0 * 64; p.x_kbs = x->kb_stride;
+    p.KB = K / 16; p.S = S; p.B = B; p.N = N; p.part = part;
+    const int n_prod = (N / 32) * S;
+    if (!ab) {
+        hipLaunchKernelGGL((pk_part_kernel<8, 2>), dim3(n_prod), dim3(8 * 64), 0, (hipStream_t)stream, p);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
+    AbArgs t;
+    if (ab_fill(t, &ab->dpq_t16, ab->pq, ab->pm, ab->memory, ab->w_prev, ab->ld_wprev, ab->w_cum_prev, ab->w, ab->ld_w, ab->loc_conv_w,
+                ab->loc_lin_w, ab->v, ab->dctx, ab->ld_dctx, ab->n_dctx, ab->dw_direct, ab->ld_dw, ab->n_dw, ab->dcum, ab->dcum_add,
+                ab->ld_dcum_add, ab->dpq, ab->dhist, ab->ds_t, ab->loc_t, ab->dloc_t, ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in,
+                ab->B, ab->L, ab->A, ab->E, ab->F, ab->K)) return -1;
+    const size_t red_bytes = (size_t)8 * 4 * 64 * sizeof(f32x4);
+    ST_CHECK_ARG(ab->parts == 2 && ab->dloc_part && !ab->dcum_add && t.s_in && ab_wide(t, red_bytes) && t.A % 32 == 0 && AB_THREADS % (t.A / 2) == 0 &&
+                 AB_THREADS / (t.A / 2) >= 4, "st_skinny_partial_attn_bwd: the attention job must be the two-part form (parts = 2, dloc_part, S kept, "
+                 "no dcum_add) with A = %d splitting into halves that divide %d", t.A, AB_THREADS);
+    t.dloc_part = ab->dloc_part;
+    const size_t lds = ab_lds_bytes(t, true, 2);
+    auto kern = pk_part_ab_kernel<8, 2, AB_LBLK_MAX, 2>;      // (TRIP = 3 / 4, i.e. deeper groups in flight: 14.4 / 13.8 us against 12.8)
+    const int trip = 2;
+    static size_t lds_set[5] = {0, 0, 0, 0, 0};
+    if (lds > 32 * 1024 && lds > lds_set[trip]) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[trip] = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(2 * t.B + n_prod), dim3(8 * 64), lds, (hipStream_t)stream, p, 2 * t.B, t, getenv("ST_EXP") ? atoi(getenv("ST_EXP")) : 0);
     ST_LAUNCH_CHECK();
     return 0;
 }

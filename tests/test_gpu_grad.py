@@ -1052,7 +1052,8 @@ def test_bptt_loop_with_hosted_attention_backward_is_bitwise_the_plain_loop(dev)
     """The software-pipelined BPTT loop (decoder cell product of step t-1 in ONE launch with the attention backward of step t,
     st_skinny_linear_packed_lstm_bwd_attn_bwd) only re-schedules the same kernels' work: every gradient of the full-size decoder
     (B = 32, L = 43, 6 steps, dropout on) is bit-identical to the loop with separate launches, and to the six-launch form's within
-    round-off."""
+    round-off.  The split form (bwd_attn_parts = 2: two attention workgroups per utterance over halves of the attention dims, the rest of
+    the step's attention backward in the W_q^T dpq launch) agrees within round-off and reproduces itself bit for bit."""
     from helpers import full_tacotron
     m = full_tacotron(dev, seed=4321, prenet_dropout=0.5).train()
     dec = m.decoder
@@ -1062,10 +1063,11 @@ def test_bptt_loop_with_hosted_attention_backward_is_bitwise_the_plain_loop(dev)
     teacher = torch.rand(B, steps * r, n_mels, generator=torch.Generator().manual_seed(3)).to(dev)
     douts = None
     res = {}
-    for mode in ('overlap', 'plain', 'six'):
-        dec.bwd_overlap_attn = mode == 'overlap'
+    for mode in ('overlap', 'split', 'plain', 'six'):
+        dec.bwd_overlap_attn = mode in ('overlap', 'split')
+        dec.bwd_attn_parts = 2 if mode == 'split' else 1        # 'split': the hosted attention backward as two workgroups per utterance
         dec.bwd_fuse_pointwise = mode != 'six'
-        dec.fwd_pair_cells = mode == 'overlap'          # (the forward's paired LSTM cells too: same work, one launch for two cells)
+        dec.fwd_pair_cells = mode in ('overlap', 'split')  # (the forward's paired LSTM cells too: same work, one launch for two cells)
         for p in dec.parameters():
             p.grad = None
         torch.manual_seed(77)                                   # the same dropout masks in every pass
@@ -1077,10 +1079,24 @@ def test_bptt_loop_with_hosted_attention_backward_is_bitwise_the_plain_loop(dev)
         res[mode] = dict(mel=mel.detach().clone(), dmem=mem.grad.clone(), dspk=spk.grad.clone(),
                          **{k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
     dec.bwd_overlap_attn = dec.bwd_fuse_pointwise = dec.fwd_pair_cells = True
+    dec.bwd_attn_parts = 2
     assert len(res['overlap']) > 20
     for k, v in res['overlap'].items():
         assert torch.equal(v, res['plain'][k]), k
         assert relerr(v, res['six'][k]) < 1e-5, k
+        # the split form adds the two halves' location-feature gradients after the products instead of inside them: round-off only
+        assert relerr(res['split'][k], v) < 1e-5, k
+    # ... and it is what a second run reproduces bit for bit (fixed summation order, no atomics)
+    dec.bwd_attn_parts = 2
+    for p in dec.parameters():
+        p.grad = None
+    torch.manual_seed(77)
+    mem, spk = mem0.clone().requires_grad_(), spk0.clone().requires_grad_()
+    mel, align, stop = dec(mem, None, teacher, spk, tf_rate=1.0)
+    torch.autograd.backward([mel, align, stop], douts)
+    again = dict(dmem=mem.grad.clone(), **{k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+    for k, v in again.items():
+        assert torch.equal(v, res['split'][k]), k
 
 
 def test_async_training_step_equals_the_synchronous_one_and_skips_nan_steps_on_device(dev):

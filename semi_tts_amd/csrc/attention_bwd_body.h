@@ -129,9 +129,12 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     const float* __restrict__ memb = a.memory + (size_t)b * L * E;
     const bool mem_pf = E <= 512;
     const __amdgpu_buffer_rsrc_t mem_rs = __builtin_amdgcn_make_buffer_rsrc((void*)memb, 0, L * E * 4, 0x00020000);
-    f32x4 mpf[4][2];
+    // (the split form has registers to spare: six rounds = 48 positions, the whole usual utterance -- a position past the prefetch
+    // costs an exposed global round trip in P2)
+    constexpr int MPF = NS > 1 ? 6 : 4;
+    f32x4 mpf[MPF][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < MPF; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int l = wave + j * NW, e = lane * 4 + h * 256;
@@ -326,7 +329,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
 #pragma unroll
             for (int h = 0; h < 2; ++h) { const int e = lane * 4 + h * 256; d4[h] = e < E ? *reinterpret_cast<const f32x4*>(dctx + e) : f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < MPF; ++j) {
                 const int l = wave + j * NW;
                 float acc = 0.0f;
 #pragma unroll
@@ -337,7 +340,7 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
                 acc = st_wave_sum_dpp(acc);
                 if (lane == 0 && l < L) dws[l] += acc;
             }
-            lstart = wave + 4 * NW;
+            lstart = wave + MPF * NW;
         }
         for (int l = lstart; l < L; l += 2 * NW) {          // remaining positions: two rows' loads in flight per wave
             const int l2 = l + NW;

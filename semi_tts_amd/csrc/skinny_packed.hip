@@ -710,6 +710,9 @@ __global__ __launch_bounds__(KW * 64) __attribute__((amdgpu_waves_per_eu((NS > 1
     pk_body<2, NB, KW, TRIP>(a, j - by * tiles_a, by, red, &pw);
 }
 
+// (development switch ST_EXP: parts of the hosted BPTT launches return at once -- timing ablations only, results are then garbage)
+static int st_exp_flag() { static int v = -1; if (v < 0) { const char* e = getenv("ST_EXP"); v = e ? atoi(e) : 0; } return v; }
+
 // ---- K-split partial products ------------------------------------------------------------------------------------------------------
 // y = x W^T for B <= 32 rows (two batch tiles) with TWO row tiles and BOTH batch tiles per workgroup -- every weight fragment and every
 // activation fragment feeds two MFMAs, so a workgroup takes in half the bytes per output of pk_body<.., NB = 1> (whose 2 N / 16 workgroups
@@ -876,11 +879,12 @@ template <int KW, int TRIP, int LBLK, int NS>
 __global__ __launch_bounds__(KW * 64) void pk_part_ab_kernel(const PkPartArgs p, const int n_ab, const AbArgs ab, const int exp_) {
     extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
     __shared__ f32x4 red[KW * 4 * 64];
-    static_assert(KW * 64 == AB_THREADS, "both parts use 512-thread workgroups");
+    static_assert(KW * 64 >= AB_THREADS, "the attention part runs on the first 512 threads");
     const int i = blockIdx.x;
     if (exp_ == 1 && i < n_ab) return;
     if (exp_ == 2 && i >= n_ab) return;
     if (i < n_ab) {
+        if (KW * 64 > AB_THREADS && (int)threadIdx.x >= AB_THREADS) return;
         const int part = i / ab.B;
         ab_body<true, LBLK, NS>(ab, i - part * ab.B, pk_dyn_lds, part);
         return;
@@ -1745,7 +1749,7 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, 
             lds_dual = lds;
         }
         hipLaunchKernelGGL(kd, dim3(2 * t.B + tiles), dim3(2 * 8 * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N,
-                           2 * t.B, a, q, t, getenv("ST_EXP") ? atoi(getenv("ST_EXP")) : 0);
+                           2 * t.B, a, q, t, st_exp_flag());
         ST_LAUNCH_CHECK();
         return 0;
     }
@@ -1849,7 +1853,7 @@ static int pk_hist_sum_impl(const float* packed_w, const st_t16_view* x, int K, 
     const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
     const int n_h = hj ? h.B : 0;
     hipLaunchKernelGGL(kern, dim3(n_h + n_sum + tiles * BT), dim3(8 * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N, tiles,
-                       n_h, n_sum, a, q, h, sa, getenv("ST_EXP") ? atoi(getenv("ST_EXP")) : 0);
+                       n_h, n_sum, a, q, h, sa, st_exp_flag());
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -1883,14 +1887,15 @@ extern "C" int st_skinny_partial_attn_bwd(const float* packed_w, const st_t16_vi
                  "no dcum_add) with A = %d splitting into halves that divide %d", t.A, AB_THREADS);
     t.dloc_part = ab->dloc_part;
     const size_t lds = ab_lds_bytes(t, true, 2);
-    auto kern = pk_part_ab_kernel<8, 2, AB_LBLK_MAX, 2>;      // (TRIP = 3 / 4, i.e. deeper groups in flight: 14.4 / 13.8 us against 12.8)
-    const int trip = 2;
+    const int kw16 = getenv("ST_PART_KW16") ? 1 : 0;
+    auto kern = kw16 ? pk_part_ab_kernel<16, 2, AB_LBLK_MAX, 2> : pk_part_ab_kernel<8, 2, AB_LBLK_MAX, 2>;      // (TRIP = 3 / 4, i.e. deeper groups in flight: 14.4 / 13.8 us against 12.8)
+    const int trip = 2 + kw16;
     static size_t lds_set[5] = {0, 0, 0, 0, 0};
     if (lds > 32 * 1024 && lds > lds_set[trip]) {
         ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set[trip] = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(2 * t.B + n_prod), dim3(8 * 64), lds, (hipStream_t)stream, p, 2 * t.B, t, getenv("ST_EXP") ? atoi(getenv("ST_EXP")) : 0);
+    hipLaunchKernelGGL(kern, dim3(2 * t.B + n_prod), dim3((kw16 ? 16 : 8) * 64), lds, (hipStream_t)stream, p, 2 * t.B, t, st_exp_flag());
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -762,26 +762,28 @@ class _DecoderFn(Function):
         # at r = 3: 59 + 50 us on the element-wise ones).  Own-output feedback keeps the exact width (the loop indexes dY itself).
         YW = in_dim + 1
         YWp = YW if own else (YW + 3) // 4 * 4
-        dY = torch.zeros(steps, Bp, YWp, **f32)
+        # (the pack launch writes every element of the rows b < B, pad columns included; pad rows only exist when B is not a multiple of 16)
+        dY = torch.empty(steps, Bp, YWp, **f32) if Bp == B else torch.zeros(steps, Bp, YWp, **f32)
         _lib.check(lib.st_decoder_pack_dout(ops._p(dmel.contiguous()) if dmel is not None else None,
                                             ops._p(dstop.contiguous()) if dstop is not None else None,
                                             ops._p(dY), YWp, B, Bp, steps, r, n_mels, ops.stream_handle()), 'st_decoder_pack_dout')
-        wpg = torch.cat([proj_w.detach(), gate_w.detach()], 0)             # (in_dim+1, D+E)   parameter layout only
         dY2 = dY.view(-1, YWp)
-        if YWp != YW:
-            wpg_t = torch.zeros(wpg.shape[1], YWp, **f32)
-            wpg_t[:, :YW] = wpg.t()
-        else:
-            wpg_t = wpg.t().contiguous()
+        # [W_proj ; W_gate]^T (D+E, YWp), zero pad columns: a cached parameter layout, refreshed with all the others by one launch per step
+        wpg_t = ops.cat_params([proj_w.detach(), gate_w.detach()], transposed=True, pad_to=YWp if YWp != YW else 0)
         # teacher forcing: no step's input depends on an earlier output, so all steps go through proj (+) gate at once;
         # with own-output feedback the loop forms dxo_t after adding the feedback gradient to dmel_t
         dxo = torch.zeros(steps * Bp, XOw, **f32) if own else ops.gemm(dY2, wpg_t)          # (steps*Bp, D+E)
 
         # every zero-initialised buffer of this backward comes out of ONE allocation and ONE fill launch
         fuse_pw = (not own) and dec.bwd_fuse_pointwise
-        zshapes = dict(dgq=(steps, Bp, 4 * Q), dgd=(steps, Bp, 4 * D), dxq=(steps + 1, Bp, XQw), dxd=(steps + 1, Bp, XDw),
-                       dpq=(steps, Bp, A), dcq=(B, Q), dcd=(B, D), dh0=(B, 2, L), dh1=(B, 2, L), dcum=(B, L), dhq_attn=(B, Q),
+        big = dict(dgq=(steps, Bp, 4 * Q), dgd=(steps, Bp, 4 * D), dxq=(steps + 1, Bp, XQw), dxd=(steps + 1, Bp, XDw), dpq=(steps, Bp, A))
+        zshapes = dict(dcq=(B, Q), dcd=(B, D), dh0=(B, 2, L), dh1=(B, 2, L), dcum=(B, L), dhq_attn=(B, Q),
                        dgq_t16=(ops.t16_floats(B, 4 * Q),), dgd_t16=(ops.t16_floats(B, 4 * D),))
+        # the step tapes of the fused loop are written in full by its launches when there are no pad rows (the step after the last one is
+        # passed as absent, not as a zero slot): no 140 MB fill in front of the loop.  Every other form starts from zeros.
+        lazy_big = fuse_pw and Bp == B and bool(getattr(dec, 'bwd_overlap_attn', False))
+        if not lazy_big:
+            zshapes.update(big)
         if fuse_pw:
             zshapes.update(dgd_t16_b=(ops.t16_floats(B, 4 * D),), dpq_t16=(ops.t16_floats(B, A),))
         numel = lambda shp: int(torch.Size(shp).numel())
@@ -791,12 +793,14 @@ class _DecoderFn(Function):
             zb[k] = pool[off:off + numel(shp)].view(*shp)
             off += (numel(shp) + 3) // 4 * 4
         z = lambda *shape: torch.zeros(*shape, **f32)
-        dgq, dgd, dxq, dxd, dpq = zb['dgq'], zb['dgd'], zb['dxq'], zb['dxd'], zb['dpq']
         e_ = lambda *shape: torch.empty(*shape, **f32)
+        if lazy_big:
+            zb.update({k: e_(*shp) for k, shp in big.items()})
+        dgq, dgd, dxq, dxd, dpq = zb['dgq'], zb['dgd'], zb['dxq'], zb['dxd'], zb['dpq']
         ds_tape, loc_tape, dloc_tape = e_(steps, B, L, A), e_(steps, B, L, F), e_(steps, B, L, F)
         hist_tape, dctx_tape, dv_tape = e_(steps, B, L, 2), e_(steps, B, E), e_(steps, B, A)
         dcq, dcd, dh0, dh1, dcum, dhq_attn = (zb[k] for k in ('dcq', 'dcd', 'dh0', 'dh1', 'dcum', 'dhq_attn'))
-        wt = dict(pq=wq.detach().t().contiguous())                                         # (Q, A)
+        wt = dict(pq=ops.dx_weight(wq.detach())[0])                                         # W_q^T (Q, A): cached parameter layout
         bw = StDecoderBwdWeights()
         bw.attn_query_w_t = ops._p(wt['pq'])
         bw.attn_v, bw.attn_loc_conv_w, bw.attn_loc_lin_w = ops._p(v), ops._p(wc), ops._p(wl)

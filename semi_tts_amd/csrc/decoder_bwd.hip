@@ -150,7 +150,8 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
             const float* dxo = io->dxo + (size_t)t * Bp * XO;
             float* dxd = io->dxd + (size_t)t * Bp * XD;
             float* dxq = io->dxq + (size_t)t * Bp * XQ;
-            const float* dxq_next = io->dxq + (size_t)(t + 1) * Bp * XQ;
+            // (no step behind the last one: absent addends instead of a zero slot -- the tapes need not start from zeros)
+            const float* dxq_next = t + 1 < steps ? io->dxq + (size_t)(t + 1) * Bp * XQ : nullptr;
             float* dpq = io->dpq + (size_t)t * Bp * A;
             float* dhist_cur = io->dhist[t & 1];
             const float* dhist_next = io->dhist[(t + 1) & 1];
@@ -162,7 +163,7 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
             ab.w_prev = t > 0 ? io->align + (size_t)(t - 1) * L : nullptr; ab.ld_wprev = ldal; ab.w_cum_prev = io->wcum_tape + (size_t)t * BL;
             ab.w = io->align + (size_t)t * L; ab.ld_w = ldal;
             ab.loc_conv_w = w->attn_loc_conv_w; ab.loc_lin_w = w->attn_loc_lin_w; ab.v = w->attn_v;
-            ab.dctx[0] = dxo + D; ab.dctx[1] = dxd; ab.dctx[2] = dxq_next + P; ab.ld_dctx[0] = XO; ab.ld_dctx[1] = XD; ab.ld_dctx[2] = XQ; ab.n_dctx = 3;
+            ab.dctx[0] = dxo + D; ab.dctx[1] = dxd; ab.dctx[2] = dxq_next ? dxq_next + P : nullptr; ab.ld_dctx[0] = XO; ab.ld_dctx[1] = XD; ab.ld_dctx[2] = XQ; ab.n_dctx = 3;
             ab.dw_direct[0] = dhist_next; ab.dw_direct[1] = io->dalign ? io->dalign + (size_t)t * L : nullptr; ab.ld_dw[0] = 2 * L; ab.ld_dw[1] = ldal;
             ab.n_dw = io->dalign ? 2 : 1;
             // (split form: the history job of step t+1 has already added dhist(t+1)[1] into dcum)
@@ -188,7 +189,7 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                 st_lstm_pw_job j;
                 memset(&j, 0, sizeof(j));
                 j.n0 = 0; j.H = Q;
-                j.dh1 = dxq_next + P + E; j.ld1 = XQ;
+                j.dh1 = dxq_next ? dxq_next + P + E : nullptr; j.ld1 = XQ;
                 j.dh2 = dxd + E; j.ld2 = XD; j.scale2 = io->ada_std;
                 j.mask = io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr;
                 j.gates = io->gates_q_tape + (size_t)t * 4 * BQ;
@@ -346,7 +347,7 @@ namespace {
 // dY[t][b][:] = [dmel[b][t*r .. t*r+r][:] | sum_j dstop[b][t*r + j]]     rows b >= B of a slot are left untouched (zero)
 __global__ __launch_bounds__(256) void pack_dout_kernel(const float* dmel, const float* dstop, float* dY,
                                                         int B, int Bp, int steps, int r, int n_mels, int ld) {
-    const int in_dim = r * n_mels, W = in_dim + 1;
+    const int in_dim = r * n_mels, W = ld;          // (all ld columns of a row: the pad columns past in_dim + 1 are written as zeros)
     const size_t total = (size_t)steps * B * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % W);
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(256) void pack_dout_kernel(const float* dmel, const
         const int b = (int)(row % B), t = (int)(row / B);
         float v;
         if (c < in_dim) v = dmel ? dmel[((size_t)b * steps + t) * in_dim + c] : 0.0f;
+        else if (c > in_dim) v = 0.0f;
         else {
             v = 0.0f;
             if (dstop) for (int j = 0; j < r; ++j) v += dstop[(size_t)b * steps * r + (size_t)t * r + j];
@@ -388,7 +390,7 @@ extern "C" int st_decoder_pack_dout(const float* dmel, const float* dstop, float
                                     int n_mels, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dY && B > 0 && Bp >= B && steps > 0 && r > 0 && n_mels > 0 && ld >= r * n_mels + 1, "st_decoder_pack_dout: bad arguments");
-    const size_t total = (size_t)steps * B * (r * n_mels + 1);
+    const size_t total = (size_t)steps * B * ld;
     size_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_dout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dmel, dstop, dY, B, Bp,

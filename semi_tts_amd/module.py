@@ -29,6 +29,17 @@ def _scaled_mask(shape, p, device):
     return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
+def _scaled_masks(shapes, p, device):
+    """several dropout masks of one rate from ONE draw (two launches for all of them instead of two each)"""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    flat = _scaled_mask((sum((n + 3) // 4 * 4 for n in sizes),), p, device)         # (16-byte aligned pieces)
+    out, off = [], 0
+    for shp, n in zip(shapes, sizes):
+        out.append(flat[off:off + n].view(*shp))
+        off += (n + 3) // 4 * 4
+    return out
+
+
 # ----------------------------------------------------------------------------- thin parameter wrappers
 class Conv1d(nn.Module):
     """ref: src/module.py:480-497 (xavier-uniform init with `w_init_gain`)"""
@@ -200,14 +211,10 @@ class Prenet(nn.Module):
 
     def forward(self, x, masks=None):
         """masks: optional list of scaled masks, one per layer (drawn on device when None)"""
+        if masks is None and self.apply_dropout > 0:       # (all layers' masks from one draw)
+            masks = _scaled_masks([x.shape[:-1] + (layer.linear.out_features,) for layer in self.layers], self.apply_dropout, x.device)
         for i, layer in enumerate(self.layers):
-            if masks is not None:
-                m = masks[i]
-            elif self.apply_dropout > 0:
-                m = _scaled_mask(x.shape[:-1] + (layer.linear.out_features,), self.apply_dropout, x.device)
-            else:
-                m = None
-            x = layer(x, act='relu', mask=m)
+            x = layer(x, act='relu', mask=masks[i] if masks is not None else None)
         return x
 
 
@@ -477,6 +484,8 @@ class Decoder(nn.Module):
             own_mask = _scaled_mask((steps, 2, B, P), self.prenet_dropout, dev)
         q_mask, d_mask = _masks.get('q'), _masks.get('d')
         if self.training:
+            if q_mask is None and d_mask is None and self.query_dropout.p == self.dec_dropout.p and self.query_dropout.p > 0:
+                q_mask, d_mask = _scaled_masks([(steps, B, Q), (steps, B, D)], self.query_dropout.p, dev)      # (one draw for both cells)
             if q_mask is None and self.query_dropout.p > 0:
                 q_mask = _scaled_mask((steps, B, Q), self.query_dropout.p, dev)
             if d_mask is None and self.dec_dropout.p > 0:

@@ -935,6 +935,17 @@ int st_ctc_loss(const float* prob, const int64_t* text, float eps, float* loss, 
 size_t st_freq_loss_workspace_floats(void);
 int st_freq_loss(const float* pred, const float* label, float* loss, float* dpred, float* ws,
                  int B, int T, int D, int n_low, float w_all, float w_low, float w_diff, int l1, void* stream);
+/* Several st_gemm_wgrad / st_gemm_wgrad_db (db may be NULL per job; no pooling, no accumulation) as ONE product launch and ONE slab-sum launch
+ * when every job takes the LDS-DMA form (16-byte addressable rows, N and Cin multiples of 4, Cin >= 16) on 64-tiles; otherwise one after the
+ * other.  Each job keeps its own slab count and summation order: bit for bit the results of the separate calls.  For the K weight
+ * gradients of the CBHG conv bank (80 x 80 x k: eight launches that each leave most of the chip idle) and the two directions of a
+ * recurrent layer.  ws: st_gemm_wgrad_batch_workspace_floats(jobs, n) floats.  ref: backward of src/module.py:590-598. */
+typedef struct st_wgrad_job {
+    const float* dC; int lddc, dcoff; const float* A; int lda; float* dW; float* db;
+    int Bn, Tin, Tout, Cin, N, KT, pad;
+} st_wgrad_job;
+size_t st_gemm_wgrad_batch_workspace_floats(const st_wgrad_job* jobs, int n);
+int st_gemm_wgrad_batch(const st_wgrad_job* jobs, int n, float* ws, void* stream);
 /* st_gemm_wgrad[_db] of a Linear over CONCATENATED inputs (KT = 1; M rows), the result cut at input column `split`:
  * dW0 (N, split) and dW1 (N, Cin - split) are the gradients of the two weights whose columns the product saw side by side -- an
  * nn.LSTMCell fed with [x | h] has gates = [W_ih | W_hh] [x | h]^T (ref: src/module.py:227-231,275-280), so the BPTT weight gradient

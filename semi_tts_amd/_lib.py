@@ -137,6 +137,11 @@ class StAttnHistJob(C.Structure):
                 ('B', C.c_int), ('L', C.c_int), ('F', C.c_int), ('K', C.c_int)]
 
 
+class StWgradJob(C.Structure):
+    _fields_ = [('dC', C.c_void_p), ('lddc', C.c_int), ('dcoff', C.c_int), ('A', C.c_void_p), ('lda', C.c_int), ('dW', C.c_void_p), ('db', C.c_void_p),
+                ('Bn', C.c_int), ('Tin', C.c_int), ('Tout', C.c_int), ('Cin', C.c_int), ('N', C.c_int), ('KT', C.c_int), ('pad', C.c_int)]
+
+
 class StPartialSumJob(C.Structure):
     _fields_ = [('part', C.c_void_p), ('S', C.c_int), ('N', C.c_int), ('y', C.c_void_p), ('ldy', C.c_int), ('pw', C.c_void_p)]
 
@@ -279,6 +284,8 @@ SIGNATURES = {
     'st_gemm_wgrad_workspace_floats': [I, I, I, I, I],
     'st_gemm_wgrad': [P, I, I, P, I, P, P, I, I, I, I, I, I, I, I, I, P],
     'st_gemm_wgrad_db': [P, I, I, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    'st_gemm_wgrad_batch_workspace_floats': [C.POINTER(StWgradJob), I],
+    'st_gemm_wgrad_batch': [C.POINTER(StWgradJob), I, P, P],
     'st_gemm_wgrad_split': [P, I, I, P, I, P, I, P, P, P, P, I, I, I, I, P],
     'st_colsum': [P, I, I, P, I, I, I, I, P, I, P, P],
     'st_act_bwd': [P, I, P, I, I, P, I, P, I, I, I, P],
@@ -310,7 +317,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
              'st_decoder_packed_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_ctc_workspace_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
-             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_freq_loss_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_attn_rng_xchg_words': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t,
+             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_gemm_wgrad_batch_workspace_floats': C.c_size_t, 'st_freq_loss_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_attn_rng_xchg_words': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t,
              'st_bn_bank_workspace_floats': C.c_size_t}
 
 _lib = None

@@ -151,7 +151,8 @@ class _ConvGroupFn(Function):
             Bn, Tin, Cin = x.shape
         else:
             Bn, Tin, Cin = 1, x.shape[0], x.shape[1]
-        dx, dws, dbs = None, [], []
+        dx, dws, dbs = None, [None] * n, [None] * n
+        wjobs = []                                       # the n weight-gradient products go out together: one launch + one slab sum
         for k in range(n):
             w = ws[k]
             N, KT = w.shape[0], (w.shape[2] if w.dim() == 3 else 1)
@@ -164,18 +165,15 @@ class _ConvGroupFn(Function):
                     dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pads[k], w_tap_major=tap_major)
                 else:                                    # (in place: every element is read and written by the same thread)
                     ops.gemm(dpre, wt, dx, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pads[k], w_tap_major=tap_major, res=dx)
-            dw = db = None
             want_w, want_b = ctx.needs_input_grad[3 + k], has_b[k] and ctx.needs_input_grad[3 + n + k]
-            if want_w and want_b:
-                dw, db = ops.gemm_wgrad(dpre, x, KT, pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N, with_db=True,
-                                        out=ops.grad_slot(w), db_out=ops.grad_slot(bs[k]))
-                dw = dw.view(w.shape)
-            elif want_w:
-                dw = ops.gemm_wgrad(dpre, x, KT, pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N, out=ops.grad_slot(w)).view(w.shape)
+            if want_w:       # (the parameter gradients are written where ops.grad_slot says)
+                wjobs.append((k, dict(dc=dpre, a=x, KT=KT, pad=pads[k], Bn=Bn, Tin=Tin, Tout=To, N=N, out=ops.grad_slot(w),
+                                      with_db=bool(want_b), db_out=ops.grad_slot(bs[k]) if want_b else None)))
             elif want_b:
-                db = ops.colsum(_rows(dpre), out=ops.grad_slot(bs[k]))
-            dws.append(dw)
-            dbs.append(db)
+                dbs[k] = ops.colsum(_rows(dpre), out=ops.grad_slot(bs[k]))
+        if wjobs:
+            for (k, _), (dw, db) in zip(wjobs, ops.gemm_wgrad_batch([j for _, j in wjobs])):
+                dws[k], dbs[k] = dw.view(ws[k].shape), db
         if dx is not None:
             dx = dx.view(x.shape)
         return (None, None, dx) + tuple(dws) + tuple(dbs) + (None,) * (2 * n + ctx.extra)
@@ -875,11 +873,13 @@ class _DecoderFn(Function):
         # their all-reduce bucket slots (ops.grad_slot)
         dwq_ih, dwq_hh, dbq, dbq2 = ops.gemm_wgrad_split(dgq2, XQ[:steps].reshape(-1, XQw), P + E, q_w_ih, q_w_hh, q_b_ih, q_b_hh, with_db=True)
         dwd_ih, dwd_hh, dbd, dbd2 = ops.gemm_wgrad_split(dgd2, XD.view(-1, XDw), E + Q, d_w_ih, d_w_hh, d_b_ih, d_b_hh, with_db=True)
-        dwpg, dbpg = ops.gemm_wgrad(dY2, XO.view(-1, XOw), with_db=True)
-        dwq_attn = ops.gemm_wgrad(dpq.view(-1, A), hq_all, out=ops.grad_slot(wq))
-        # attention parameters / inputs: sums over the steps of the per-step tape slices
+        # three more products over the tapes in one launch (+ one slab sum): proj (+) gate, the query projection, W_l (sums over the steps of
+        # the per-step tape slices)
+        (dwpg, dbpg), (dwq_attn, _), (dwl, _) = ops.gemm_wgrad_batch([
+            dict(dc=dY2, a=XO.view(-1, XOw), with_db=True),
+            dict(dc=dpq.view(-1, A), a=hq_all, out=ops.grad_slot(wq)),
+            dict(dc=ds_tape.view(-1, A), a=loc_tape.view(-1, F))])                          # (A, F)
         dv = ops.colsum(dv_tape.view(-1, A)).view(v.shape)
-        dwl = ops.gemm_wgrad(ds_tape.view(-1, A), loc_tape.view(-1, F))                     # (A, F)
         dwc = ops.gemm_wgrad(dloc_tape.view(steps * B, L, F), hist_tape.view(steps * B, L, 2), K, (K - 1) // 2)   # (F, 2, K)
         dpm = ops.colsum(ds_tape.view(steps, -1)).view(B, L, A)
         dmem = torch.empty(B, L, E, **f32)

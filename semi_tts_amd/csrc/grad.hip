@@ -269,7 +269,7 @@ typedef const __attribute__((address_space(1))) void* tn_gptr_t;
 typedef __attribute__((address_space(3))) void* tn_lptr_t;
 
 template <int TM>
-__global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) {
+__device__ __forceinline__ void tn_dma_body(const TnArgs& g, const int bx, const int by, const int bz) {
     constexpr int FR = TM / 32;
     constexpr int RC = 32;                              // rows per chunk
     constexpr int PPR = TM / 4;                         // 16-byte pieces per row
@@ -280,11 +280,11 @@ __global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) {
     extern __shared__ __attribute__((aligned(16))) float tn_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * TM;
+    const int n0 = bx * TM;
     const int cblocks = (g.Cin + TM - 1) / TM;
-    const int tap = blockIdx.y / cblocks;
-    const int c0 = (blockIdx.y - tap * cblocks) * TM;
-    const int z = blockIdx.z;
+    const int tap = by / cblocks;
+    const int c0 = (by - tap * cblocks) * TM;
+    const int z = bz;
     const int mbeg = z * g.rows_per_z, mend = min(g.M, mbeg + g.rows_per_z);
     const int srow = tid / PPR, sc = (tid % PPR) * 4;   // staging role: piece sc of rows srow, srow + RPI, ...
     const float* zp = reinterpret_cast<const float*>(&tn_zero4);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) {
 #pragma unroll
         for (int j = 0; j < FR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
-    const bool do_db = g.db_part != nullptr && blockIdx.y == 0;
+    const bool do_db = g.db_part != nullptr && by == 0;
     f32x4 dbacc[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) dbacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -399,6 +399,51 @@ __global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) {
                 out[((size_t)n * g.Cin + ci) * g.KT + tap] = acc[mt][nt][e];
             }
         }
+}
+
+template <int TM>
+__global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) { tn_dma_body<TM>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// Several weight-gradient products in ONE launch (st_gemm_wgrad_batch): the K convolutions of the CBHG bank (80 x 80 x k matrices: 4 k
+// tiles each -- eight launches of 10 ... 36 us that each leave most of the chip idle) or the two directions of a recurrent layer.
+// blockIdx.x runs through the jobs' own (x, y, z) grids one after the other.
+constexpr int TN_MAXJ = 8;
+struct TnBatch { TnArgs g[TN_MAXJ]; int blk0[TN_MAXJ + 1]; int gx[TN_MAXJ], gy[TN_MAXJ]; int n; };
+
+template <int TM>
+__global__ __launch_bounds__(TN_THREADS) void tn_dma_batch_kernel(const TnBatch b) {
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;
+    const int r = (int)blockIdx.x - b.blk0[j];
+    const int gx = b.gx[j], gxy = gx * b.gy[j];
+    const int bz = r / gxy, rr = r - bz * gxy, by = rr / gx;
+    tn_dma_body<TM>(b.g[j], rr - by * gx, by, bz);
+}
+
+// the slab sums of such a batch in one launch (each job's elements in its own block range; same per-element order as sum_partials*)
+struct SumBatch { const float* part[TN_MAXJ]; float* out[TN_MAXJ]; const float* part_b[TN_MAXJ]; float* out_b[TN_MAXJ];
+                  unsigned per[TN_MAXJ]; int nb[TN_MAXJ], Z[TN_MAXJ], acc[TN_MAXJ]; int blk0[TN_MAXJ + 1]; int n; };
+
+__global__ __launch_bounds__(256) void sum_partials_batch_kernel(const SumBatch b) {
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;
+    const size_t n = b.per[j], nb = (size_t)b.nb[j];
+    const int Z = b.Z[j], nblk = b.blk0[j + 1] - b.blk0[j];
+    const float* part = b.part[j]; const float* part_b = b.part_b[j];
+    for (size_t i = (size_t)((int)blockIdx.x - b.blk0[j]) * blockDim.x + threadIdx.x; i < n + nb; i += (size_t)nblk * blockDim.x) {
+        const bool isb = i >= n;
+        const float* p = isb ? part_b + (i - n) : part + i;
+        const size_t stride = isb ? nb : n;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 4 <= Z; z += 4) {
+            s0 += p[(size_t)z * stride]; s1 += p[(size_t)(z + 1) * stride]; s2 += p[(size_t)(z + 2) * stride]; s3 += p[(size_t)(z + 3) * stride];
+        }
+        for (; z < Z; ++z) s0 += p[(size_t)z * stride];
+        const float sm = (s0 + s1) + (s2 + s3);
+        if (isb) b.out_b[j][i - n] = sm;
+        else b.out[j][i] = b.acc[j] ? b.out[j][i] + sm : sm;
+    }
 }
 
 // out[i] (+)= sum_z part[z][i]   (fixed order)
@@ -1144,6 +1189,81 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
                                     nullptr, 0, 0, nullptr);
     else hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(per)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
     ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// Several st_gemm_wgrad[_db] (no pooling, no accumulate) as ONE product launch + ONE slab-sum launch when every job takes the LDS-DMA form
+// with 64-tiles (the small matrices this is for); otherwise one after the other.  Every job keeps the slab count and the summation order it
+// has on its own: the results are bit for bit those of the separate calls.
+static size_t tn_ws4(const st_wgrad_job& j) { return (st_gemm_wgrad_workspace_floats(j.Bn, j.Tout, j.Cin, j.N, j.KT) + 3) / 4 * 4; }
+
+extern "C" size_t st_gemm_wgrad_batch_workspace_floats(const st_wgrad_job* jobs, int n) {
+    size_t t = 0;
+    for (int i = 0; i < n; ++i) t += tn_ws4(jobs[i]);
+    return t;
+}
+
+extern "C" int st_gemm_wgrad_batch(const st_wgrad_job* jobs, int n, float* ws, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(jobs && n > 0 && ws, "st_gemm_wgrad_batch: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    bool batch = n <= TN_MAXJ && n > 1;
+    TnBatch tb;
+    SumBatch sb;
+    memset(&tb, 0, sizeof(tb));
+    memset(&sb, 0, sizeof(sb));
+    size_t off = 0;
+    int blocks = 0, sblocks = 0, nsum = 0;
+    for (int i = 0; i < n && batch; ++i) {
+        const st_wgrad_job& j = jobs[i];
+        ST_CHECK_ARG(j.dC && j.A && j.dW && j.Bn > 0 && j.Tin > 0 && j.Tout > 0 && j.Cin > 0 && j.N > 0 && j.KT > 0, "st_gemm_wgrad_batch: bad job %d", i);
+        TnArgs& g = tb.g[i];
+        g.dC = j.dC; g.lddc = j.lddc; g.dcoff = j.dcoff; g.A = j.A; g.lda = j.lda;
+        g.Bn = j.Bn; g.Tin = j.Tin; g.Tout = j.Tout; g.Cin = j.Cin; g.N = j.N; g.KT = j.KT; g.pad = j.pad; g.pool_prev = 0;
+        g.M = j.Bn * j.Tout;
+        const size_t per = (size_t)j.N * j.Cin * j.KT;
+        const int Z = (int)(st_gemm_wgrad_workspace_floats(j.Bn, j.Tout, j.Cin, j.N, j.KT) / (per + j.N));
+        g.rows_per_z = (((g.M + Z - 1) / Z) + 31) / 32 * 32;
+        g.fold = tn_fold(j.Cin, j.KT, 0) ? 1 : 0;
+        g.lin = (j.KT == 1 && j.pad == 0 && j.Tin == j.Tout) ? 1 : 0;
+        g.vecx = st_aligned16(j.dC) && (j.lddc % 4 == 0) && (j.dcoff % 4 == 0);
+        g.vecy = st_aligned16(j.A) && (j.lda % 4 == 0);
+        const bool dma = !g.fold && g.vecx && g.vecy && j.N % 4 == 0 && j.Cin % 4 == 0 && g.rows_per_z % 32 == 0;
+        if (!dma || tn_tile(j.Cin, j.N, j.KT) != 64 || per >= (1ull << 32)) { batch = false; break; }
+        float* wsj = ws + off;
+        const bool direct = Z == 1;
+        g.part = direct ? j.dW : wsj;
+        if (j.db) g.db_part = direct ? j.db : wsj + (size_t)Z * per;
+        tb.gx[i] = (j.N + 63) / 64; tb.gy[i] = ((j.Cin + 63) / 64) * j.KT;
+        tb.blk0[i] = blocks;
+        blocks += tb.gx[i] * tb.gy[i] * Z;
+        if (!direct) {
+            sb.part[nsum] = wsj; sb.out[nsum] = j.dW; sb.part_b[nsum] = j.db ? wsj + (size_t)Z * per : wsj; sb.out_b[nsum] = j.db;
+            sb.per[nsum] = (unsigned)per; sb.nb[nsum] = j.db ? j.N : 0; sb.Z[nsum] = Z; sb.acc[nsum] = 0;
+            sb.blk0[nsum] = sblocks;
+            sblocks += blocks_for(per + (j.db ? j.N : 0));
+            ++nsum;
+        }
+        off += tn_ws4(j);
+    }
+    if (!batch) {
+        off = 0;
+        for (int i = 0; i < n; ++i) {
+            const st_wgrad_job& j = jobs[i];
+            int rc = tn_impl(j.dC, j.lddc, j.dcoff, j.A, j.lda, j.dW, j.db, ws + off, j.Bn, j.Tin, j.Tout, j.Cin, j.N, j.KT, j.pad, 0, 0, stream);
+            if (rc) return rc;
+            off += tn_ws4(j);
+        }
+        return 0;
+    }
+    tb.blk0[n] = blocks; tb.n = n;
+    hipLaunchKernelGGL((tn_dma_batch_kernel<64>), dim3(blocks), dim3(TN_THREADS), (size_t)3 * 2 * 32 * 64 * sizeof(float), st, tb);
+    ST_LAUNCH_CHECK();
+    if (nsum) {
+        sb.blk0[nsum] = sblocks; sb.n = nsum;
+        hipLaunchKernelGGL(sum_partials_batch_kernel, dim3(sblocks), dim3(256), 0, st, sb);
+        ST_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -855,6 +855,44 @@ def gemm_wgrad_split(dc, a, split, w0=None, w1=None, b0=None, b1=None, with_db=F
     return (d0, d1, db, dbd) if with_db else (d0, d1)
 
 
+def gemm_wgrad_batch(jobs):
+    """[gemm_wgrad(dc, a, KT, pad, Bn=, Tin=, Tout=, N=, out=, with_db=, db_out=) for each job dict] as ONE product launch and ONE slab-sum
+    launch where the kernels allow (st_gemm_wgrad_batch: bit for bit the separate calls); returns [(dW, db or None)]"""
+    from ._lib import StWgradJob
+    lib = _lib.load()
+    n = len(jobs)
+    arr = (StWgradJob * n)()
+    outs = []
+    for i, j in enumerate(jobs):
+        dc, a = j['dc'], j['a']
+        if a.dim() == 3:
+            Bn_, Tin_, Cin = a.shape
+        else:
+            Bn_, Tin_, Cin = 1, a.shape[0], a.shape[1]
+        KT = int(j.get('KT', 1))
+        Bn = j.get('Bn') or Bn_
+        Tin = j.get('Tin') or Tin_
+        Tout = j.get('Tout')
+        if Tout is None:
+            Tout = dc.shape[1] if dc.dim() == 3 else dc.shape[0] // Bn
+        N = j.get('N') if j.get('N') is not None else dc.shape[-1]
+        out = j.get('out')
+        if out is None:
+            out = torch.empty((N, Cin, KT) if KT > 1 else (N, Cin), device=a.device, dtype=torch.float32)
+        db = None
+        if j.get('with_db'):
+            db = j.get('db_out')
+            if db is None:
+                db = torch.empty(N, device=a.device, dtype=torch.float32)
+        q = arr[i]
+        q.dC, q.lddc, q.dcoff, q.A, q.lda, q.dW, q.db = _p(dc), int(dc.stride(-2)), 0, _p(a), int(a.stride(-2)), _p(out), _p(db)
+        q.Bn, q.Tin, q.Tout, q.Cin, q.N, q.KT, q.pad = int(Bn), int(Tin), int(Tout), int(Cin), int(N), KT, int(j.get('pad', 0))
+        outs.append((out, db))
+    ws = torch.empty(int(lib.st_gemm_wgrad_batch_workspace_floats(arr, n)), device=jobs[0]['a'].device, dtype=torch.float32)
+    check(lib.st_gemm_wgrad_batch(arr, n, _p(ws), stream_handle()), 'st_gemm_wgrad_batch')
+    return outs
+
+
 def gemm_wgrad(dc, a, KT=1, pad=0, *, Bn=None, Tin=None, Tout=None, dcoff=0, N=None, pool_prev=False, out=None,
                accumulate=False, with_db=False, db_out=None):
     """dW (N, Cin[, KT]) of C = conv1d/linear(a, W): dc (Bn, Tout, >=dcoff+N) or (M, .), a (Bn, Tin, Cin) or (M, Cin).

@@ -25,8 +25,8 @@ rm -rf $OUT/prof
 echo "== secondary benches (each with roofline + cpu_baseline)"
 timeout 600 python bench.py --workload c5 --steps 5 --warmup 2 > $OUT/bench_c5.json 2>/dev/null; cut -c1-200 $OUT/bench_c5.json
 timeout 300 python bench.py --workload c3 --steps 10 > $OUT/bench_c3.json 2>/dev/null; cut -c1-200 $OUT/bench_c3.json
-timeout 900 python bench.py --workload train --steps 5 --warmup 2 > $OUT/bench_train.json 2>/dev/null; cut -c1-300 $OUT/bench_train.json
-timeout 900 python bench.py --workload train --dist --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | tail -1 > $OUT/train_step_rccl_ws1.json; cut -c1-200 $OUT/train_step_rccl_ws1.json
+timeout 900 python bench.py --workload train --steps 20 --warmup 5 > $OUT/bench_train.json 2>/dev/null; cut -c1-300 $OUT/bench_train.json
+timeout 900 python bench.py --workload train --dist --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | tail -1 > $OUT/train_step_rccl_ws1.json; cut -c1-200 $OUT/train_step_rccl_ws1.json
 timeout 600 python tools/rccl_ws1_check.py 2>/dev/null | grep '^{' | tail -1 > $OUT/rccl_ws1_check.json; cut -c1-200 $OUT/rccl_ws1_check.json
 ST_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --workload train --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $OUT/train_step_2ranks_gloo_shared_gpu.json; cut -c1-200 $OUT/train_step_2ranks_gloo_shared_gpu.json
 timeout 600 python tools/bench_full_forward.py 2>/dev/null | tail -1 > $OUT/bench_full_forward.json; cut -c1-300 $OUT/bench_full_forward.json

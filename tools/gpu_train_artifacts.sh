@@ -6,8 +6,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/art_$TAG
 mkdir -p $OUT
 cd $ROOT
-timeout 900 python bench.py --workload train --steps 8 --warmup 3 > $OUT/bench_train.json 2>/dev/null; cut -c1-300 $OUT/bench_train.json
-timeout 900 python bench.py --workload train --dist --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | tail -1 > $OUT/train_step_rccl_ws1.json; cut -c1-200 $OUT/train_step_rccl_ws1.json
+timeout 900 python bench.py --workload train --steps 20 --warmup 5 > $OUT/bench_train.json 2>/dev/null; cut -c1-300 $OUT/bench_train.json
+timeout 900 python bench.py --workload train --dist --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | tail -1 > $OUT/train_step_rccl_ws1.json; cut -c1-200 $OUT/train_step_rccl_ws1.json
 timeout 600 python tools/rccl_ws1_check.py 2>/dev/null | grep '^{' | tail -1 > $OUT/rccl_ws1_check.json; cut -c1-200 $OUT/rccl_ws1_check.json
 (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_train -o bench -- python3 $ROOT/bench.py --workload train --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/prof_train.err)
 DB=$(find $OUT/prof_train -name "*.db" | head -1)

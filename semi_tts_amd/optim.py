@@ -117,12 +117,17 @@ class FusedAdam(torch.optim.Optimizer):
                 st['_step'] = int(float(st['step']))
         self._cache = {}
 
-    def rollback_step(self):
+    def rollback_step(self, which=None):
         """a guarded step turned out to have been skipped on the device (TtsTrainer._skipped_on_device): take it off the host-side
-        step counts, so that the bias corrections of later steps and the checkpointed `step` agree with torch's Adam again"""
-        for st in self.state.values():
+        step counts, so that the bias corrections of later steps and the checkpointed `step` agree with torch's Adam again.
+        which: the value of `guarded_steps` just before that step() call -- only the parameters that took part in it (had a gradient)
+        are rolled back; None (or a step too long ago to be remembered): every parameter that has ever stepped"""
+        plist = self.__dict__.get('_guarded_log', {}).pop(which, None) if which is not None else None
+        for st in ([self.state[p] for p in plist] if plist is not None else self.state.values()):
             if st.get('_step', 0) > 0:
                 st['_step'] -= 1
+
+    guarded_steps = 0        # step() calls with a guard so far (the key of rollback_step)
 
     @torch.no_grad()
     def step(self, closure=None, guard_norm=None):
@@ -170,4 +175,10 @@ class FusedAdam(torch.optim.Optimizer):
                 # them (tap-major / packed weight copies, autograd's saved-tensor checks) sees the in-place update
                 for p in plist:
                     torch.autograd.graph.increment_version(p)
+        if guard_norm is not None:       # which parameters this (possibly skipped) update advanced: what a rollback has to undo
+            log = self.__dict__.setdefault('_guarded_log', {})
+            log[self.guarded_steps] = [p for group in self.param_groups for p in group['params'] if p.grad is not None]
+            if len(log) > 256:
+                del log[min(log)]
+            self.guarded_steps += 1
         return None

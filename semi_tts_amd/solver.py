@@ -8,6 +8,7 @@ SpecgramGenerator mirrors bin/gen_specgram.py:89-129: batched free-running decod
 (fp32) and `-align.npy` trimmed to [int(len*6)//r, text_len].
 """
 import json
+import math
 import os
 import time
 
@@ -160,7 +161,7 @@ class LazyStats(dict):
         if torch.is_tensor(v):
             v = float(v)
             dict.__setitem__(self, k, v)
-            if k == 'grad_norm' and v != v and self.on_nonfinite is not None:
+            if k == 'grad_norm' and not math.isfinite(v) and self.on_nonfinite is not None:     # (NaN or inf: what the device guard skips)
                 cb, self.on_nonfinite = self.on_nonfinite, None
                 cb(self)
         return v
@@ -292,14 +293,18 @@ class TtsTrainer(BaseSolver):
         if self.async_stats and torch.is_tensor(grad_norm) and grad_norm.is_cuda and isinstance(getattr(self.optimizer, 'opt', None), FusedAdam):
             # no host round trip inside the step: the NaN check of BaseSolver.backward (src/solver.py:147-150) runs on the device (a
             # non-finite norm makes the Adam launch a no-op) and the statistics stay device scalars until somebody reads them
+            opt_step = getattr(getattr(self.optimizer, 'opt', None), 'guarded_steps', 0)      # (the key of this update in the optimiser's log)
             self.optimizer.step(guard_norm=grad_norm)
             self.step += 1
             st = LazyStats(loss=total.detach(), mel_loss=mel_loss.detach(), linear_loss=linear_loss.detach(), grad_norm=grad_norm,
-                           tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
+                           tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1), step=self.step - 1,
+                           opt_step=opt_step)
             st.on_nonfinite = self._skipped_on_device
             self._unread.append(st)
-            if len(self._unread) >= self.STATS_WINDOW:          # bounded: at most STATS_WINDOW steps of device scalars are alive, and a
-                self.drain_stats()                              # poisoned forward is noticed within that many steps
+            # bounded: at most STATS_WINDOW steps of device scalars are alive.  While the one-launch BiLSTM is in use the window is short:
+            # a starved layer poisons every forward until somebody looks, and every poisoned step is an update skipped on the device
+            if len(self._unread) >= (self.STATS_WINDOW_PERSIST if ops.LSTM_PERSIST else self.STATS_WINDOW):
+                self.drain_stats()
             return st
         gn = float(grad_norm)
         if gn != gn:
@@ -312,11 +317,13 @@ class TtsTrainer(BaseSolver):
                     tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
 
     STATS_WINDOW = 64        # async_stats: steps whose statistics may stay unread on the device
+    STATS_WINDOW_PERSIST = 8     # ... while ops.LSTM_PERSIST is on (see train_step)
 
     def check_device_status(self):
         """a kernel of the training step reported starvation since the last check (the one-launch BiLSTM's status word)?  Such a
-        forward is NaN and the guarded Adam skips its update: the layer runs as one launch per time step from now on -- one skipped
-        step, not a run of silently skipped ones.  Returns True if it fell back."""
+        forward is NaN and the guarded Adam skips its update: the layer runs as one launch per time step from now on.  The synchronous
+        trainer loses one step to it; the asynchronous one notices when its statistics window drains (at most STATS_WINDOW_PERSIST
+        steps, each skipped on the device and rolled back individually).  Returns True if it fell back."""
         if ops.persist_starved(self.device):
             ops.degrade('one-launch BiLSTM layer', 'one launch per time step (ops.LSTM_PERSIST = False)')
             ops.LSTM_PERSIST = False
@@ -328,8 +335,9 @@ class TtsTrainer(BaseSolver):
         self.check_device_status()
         opt = getattr(self.optimizer, 'opt', None)
         if hasattr(opt, 'rollback_step'):
-            opt.rollback_step()                          # the host-side Adam step counts ran one ahead since then (bias corrections)
-        self.verbose('Error : grad norm is NaN @ step %s (update skipped on the device)' % st.get('step', '?'))
+            # the host-side Adam step counts of the parameters of THAT update ran one ahead since then (bias corrections)
+            opt.rollback_step(dict.get(st, 'opt_step'))
+        self.verbose('Error : grad norm is not finite @ step %s (update skipped on the device)' % dict.get(st, 'step', '?'))
 
     def drain_stats(self):
         """read the statistics of every step issued so far (waits for the GPU once)"""

@@ -4,6 +4,8 @@ oracle / the torch ops the reference's modules are made of.  Needs a real MI355X
 Tolerances are written next to each check; gradients are sums of O(rows) fp32 products, compared
 with a float64 CPU evaluation and normalised by the gradient's own scale.
 """
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1147,6 +1149,12 @@ def test_async_training_step_equals_the_synchronous_one_and_skips_nan_steps_on_d
             assert torch.equal(p.detach(), w0[k]), k
     for st in tr_n.optimizer.opt.state.values():
         assert float(st['exp_avg'].abs().max()) == 0.0 and float(st['exp_avg_sq'].abs().max()) == 0.0
+    # reading the norms rolled the host-side Adam step counts of exactly the parameters of those updates back (bias corrections and the
+    # checkpointed `step` then agree with an optimiser that never saw the skipped steps); every unread step is read here
+    tr_n.drain_stats()
+    assert all(not math.isfinite(s['grad_norm']) for s in st_n)
+    assert all(st.get('_step', 0) == 0 for st in tr_n.optimizer.opt.state.values())
+    assert tr_n.optimizer.opt.guarded_steps == len(st_n) and not tr_n.optimizer.opt.__dict__.get('_guarded_log')
 
 
 @pytest.mark.parametrize('M,N,Cin,KT', [(2752, 4096, 160, 1), (300, 70, 33, 1), (8256, 128, 80, 3), (5000, 200, 8, 5), (64, 16, 16, 1)])

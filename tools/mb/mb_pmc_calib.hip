@@ -36,6 +36,16 @@ __global__ __launch_bounds__(512) void k_row4s(const float* p, int L, int A, flo
     for (int l = grp; l < L; l += ngrp) a += t[(size_t)l * A + col];
     if (a == 12345.678f) out[blockIdx.x] = 1.0f;
 }
+// two workgroups read the SAME (L x A) tile at the same time: `same` != 0 -> the partners are nb workgroups apart in launch order (nb a multiple
+// of 8: the same XCD under round-robin placement), else adjacent (different XCDs)
+__global__ __launch_bounds__(512) void k_pair(const float* p, int L, int A, int nb, int same, float* out) {
+    const int tile = same ? (int)blockIdx.x % nb : (int)blockIdx.x >> 1;
+    const float* t = p + (size_t)tile * L * A;
+    const int a0 = threadIdx.x % A, grp = threadIdx.x / A, ngrp = 512 / A;
+    float a = 0;
+    for (int l = grp; l < L; l += ngrp) a += t[(size_t)l * A + a0];
+    if (a == 12345.678f) out[blockIdx.x] = 1.0f;
+}
 __global__ __launch_bounds__(512) void k_row16(const float* p, int L, int E, float* out) {
     const float* t = p + (size_t)blockIdx.x * L * E;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -77,6 +87,8 @@ int main() {
         fl(); hipLaunchKernelGGL(k_row4, dim3(NB), dim3(512), 0, 0, pa, L, A, out);
         fl(); hipLaunchKernelGGL(k_row4s, dim3(2 * NB), dim3(512), 0, 0, pa, L, A, out);
         fl(); hipLaunchKernelGGL(k_row16, dim3(NB), dim3(512), 0, 0, pe, L, E, out);
+        fl(); hipLaunchKernelGGL(k_pair, dim3(256), dim3(512), 0, 0, pa, L, A, 128, 1, out);      // 128 tiles, partners on one XCD
+        fl(); hipLaunchKernelGGL(k_pair, dim3(256), dim3(512), 0, 0, pa + (size_t)256 * L * A, L, A, 128, 0, out);      // ... on two XCDs
         fl(); hipLaunchKernelGGL(k_poll, dim3(256), dim3(512), 0, 0, words, npoll, out);
         fl(); hipLaunchKernelGGL(k_write16, dim3(2048), dim3(256), 0, 0, reinterpret_cast<f32x4*>(pw), nW / 4);
         fl(); hipLaunchKernelGGL(k_write4, dim3(2048), dim3(256), 0, 0, pw, nW);

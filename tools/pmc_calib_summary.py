@@ -12,6 +12,11 @@ for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
     con = sqlite3.connect(dbs[0])
     rows = con.execute("select name, count(*), avg(v), min(v), max(v), avg(duration) from (select name, dispatch_id, duration, sum(counter_value) as v "
                        "from pmc_events where counter_name = ? group by name, dispatch_id) group by name", (ctr,)).fetchall()
+    pair = con.execute("select dispatch_id, sum(counter_value) from pmc_events where counter_name = ? and name like 'k_pair%' group by dispatch_id "
+                       "order by dispatch_id", (ctr,)).fetchall()
+    if pair:
+        print('   k_pair (two workgroups read one 44 KB tile at once; 128 tiles = %d KB unique): launches in order [same XCD, two XCDs, ...] reported KB: %s'
+              % (128 * 43 * 256 * 4 // 1024, ' '.join('%.0f' % v for _, v in pair)))
     print('== %s (reported in KB per launch; summed over the rows of a dispatch)' % ctr)
     for name, n, avg, lo, hi, dur in rows:
         short = name.split('(')[0]

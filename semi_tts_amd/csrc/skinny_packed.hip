@@ -1705,10 +1705,10 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, 
     const bool wide = ab_wide(t, red_bytes);
     // parts > 1: the split form (see pk_pw_ab_kernel); the caller then runs st_skinny_linear_packed_lstm_bwd_attn_hist next
     const int parts = ab->parts > 1 ? ab->parts : 1;
-    const size_t lds = ab_lds_bytes(t, wide, parts);
+    const size_t lds = ab_lds_bytes(t, wide || parts > 1, parts);      // (the split form always runs the 48-position block, on its lean image)
     if (parts > 1) {
         ST_CHECK_ARG(parts == 2 || parts == 4, "st_skinny_linear_packed_lstm_bwd_attn_bwd: parts = %d (1, 2 or 4)", parts);
-        ST_CHECK_ARG(ab->dloc_part && !ab->dcum_add && wide && lds + red_bytes <= 160 * 1024 && t.A % parts == 0 && AB_THREADS % (t.A / parts) == 0 &&
+        ST_CHECK_ARG(ab->dloc_part && !ab->dcum_add && t.s_in && lds + red_bytes <= 160 * 1024 && t.A % parts == 0 && AB_THREADS % (t.A / parts) == 0 &&
                      (t.A / parts) % 16 == 0 && AB_THREADS / (t.A / parts) >= 2 * parts && t.A / parts <= AB_THREADS / (2 * parts),
                      "st_skinny_linear_packed_lstm_bwd_attn_bwd: parts = %d needs dloc_part, no dcum_add (the history job keeps dcum), the wide block "
                      "and A = %d splitting into parts of a multiple of 16 dims that divide %d", parts, t.A, AB_THREADS);
@@ -1882,8 +1882,8 @@ extern "C" int st_skinny_partial_attn_bwd(const float* packed_w, const st_t16_vi
                 ab->ld_dcum_add, ab->dpq, ab->dhist, ab->ds_t, ab->loc_t, ab->dloc_t, ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in,
                 ab->B, ab->L, ab->A, ab->E, ab->F, ab->K)) return -1;
     const size_t red_bytes = (size_t)8 * 4 * 64 * sizeof(f32x4);
-    ST_CHECK_ARG(ab->parts == 2 && ab->dloc_part && !ab->dcum_add && t.s_in && ab_wide(t, red_bytes) && t.A % 32 == 0 && AB_THREADS % (t.A / 2) == 0 &&
-                 AB_THREADS / (t.A / 2) >= 4, "st_skinny_partial_attn_bwd: the attention job must be the two-part form (parts = 2, dloc_part, S kept, "
+    ST_CHECK_ARG(ab->parts == 2 && ab->dloc_part && !ab->dcum_add && t.s_in && ab_lds_bytes(t, true, 2) + red_bytes <= 160 * 1024 && t.A % 32 == 0 &&
+                 AB_THREADS % (t.A / 2) == 0 && AB_THREADS / (t.A / 2) >= 4, "st_skinny_partial_attn_bwd: the attention job must be the two-part form (parts = 2, dloc_part, S kept, "
                  "no dcum_add) with A = %d splitting into halves that divide %d", t.A, AB_THREADS);
     t.dloc_part = ab->dloc_part;
     const size_t lds = ab_lds_bytes(t, true, 2);

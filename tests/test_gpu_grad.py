@@ -1101,6 +1101,36 @@ def test_bptt_loop_with_hosted_attention_backward_is_bitwise_the_plain_loop(dev)
         assert torch.equal(v, res['split'][k]), k
 
 
+@pytest.mark.parametrize('B,L', [(20, 43), (32, 61), (16, 43), (33, 20), (24, 97)])
+def test_split_bptt_forms_agree_across_shapes(dev, B, L):
+    """The split forms of the BPTT loop (two attention workgroups per utterance; K-split partial product of the decoder cell when 16 < B <= 32
+    is a multiple of 16; history part in the dgates_q launch) against the whole-step-per-workgroup loop on shapes around their limits: pad
+    rows (B = 20, 24, 33: no partial product, zero-filled tapes), one batch tile (B = 16), longer texts (L = 61, 97: several position
+    blocks).  Same arithmetic up to the order in which the two halves' location-feature gradients meet."""
+    from helpers import full_tacotron
+    m = full_tacotron(dev, seed=777, prenet_dropout=0.5).train()
+    dec = m.decoder
+    steps = 4
+    r, n_mels = dec.n_frames_per_step, dec.n_mels
+    mem0, spk0 = rnd(B, L, 512, seed=1).to(dev), rnd(B, 128, seed=2).to(dev)
+    teacher = torch.rand(B, steps * r, n_mels, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = {}
+    for parts in (1, 2):
+        dec.bwd_attn_parts = parts
+        for p in dec.parameters():
+            p.grad = None
+        torch.manual_seed(11)
+        mem, spk = mem0.clone().requires_grad_(), spk0.clone().requires_grad_()
+        mel, align, stop = dec(mem, None, teacher, spk, tf_rate=1.0)
+        torch.autograd.backward([mel, align, stop], [torch.ones_like(mel), rnd(*align.shape, seed=6).to(dev), torch.ones_like(stop)])
+        res[parts] = dict(dmem=mem.grad.clone(), dspk=spk.grad.clone(), **{k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+    dec.bwd_attn_parts = 2
+    assert len(res[2]) > 20
+    for k, v in res[2].items():
+        assert torch.isfinite(v).all(), k
+        assert relerr(v, res[1][k]) < 1e-5, k
+
+
 def test_async_training_step_equals_the_synchronous_one_and_skips_nan_steps_on_device(dev):
     """TtsTrainer.async_stats: no host read inside the step (LazyStats; Adam guarded by the device-side gradient norm).  Two steps give
     bit-identical weights and statistics to the synchronous trainer; a step whose gradient norm is NaN leaves weights and Adam moments

@@ -37,6 +37,18 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
         float acc = 0.0f, acc2 = 0.0f;
         const f32x4* g4 = reinterpret_cast<const f32x4*>(g + beg);
         long i = threadIdx.x;
+        // (eight pieces in flight per thread; the two running sums keep the pairing of the two-piece form: pieces 0, 2, 4, 6 of a round
+        // go to acc, 1, 3, 5, 7 to acc2 -- the same additions in the same order as four two-piece rounds)
+        for (; i + 7 * MT_THREADS < nvec; i += 8 * MT_THREADS) {
+            f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = g4[i + u * MT_THREADS];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc = fmaf(x[u][0], x[u][0], acc); acc = fmaf(x[u][1], x[u][1], acc); acc = fmaf(x[u][2], x[u][2], acc); acc = fmaf(x[u][3], x[u][3], acc);
+                acc2 = fmaf(x[u + 1][0], x[u + 1][0], acc2); acc2 = fmaf(x[u + 1][1], x[u + 1][1], acc2); acc2 = fmaf(x[u + 1][2], x[u + 1][2], acc2); acc2 = fmaf(x[u + 1][3], x[u + 1][3], acc2);
+            }
+        }
         for (; i + MT_THREADS < nvec; i += 2 * MT_THREADS) {
             const f32x4 x = g4[i], y = g4[i + MT_THREADS];
             acc = fmaf(x[0], x[0], acc); acc = fmaf(x[1], x[1], acc); acc = fmaf(x[2], x[2], acc); acc = fmaf(x[3], x[3], acc);
@@ -83,7 +95,21 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
         };
         const f32x4* g4 = reinterpret_cast<const f32x4*>(g + beg);
         f32x4* p4 = reinterpret_cast<f32x4*>(p + beg); f32x4* m4 = reinterpret_cast<f32x4*>(m + beg); f32x4* v4 = reinterpret_cast<f32x4*>(v + beg);
-        for (long i = threadIdx.x; i < nvec; i += MT_THREADS) {
+        // four 16-byte pieces per thread and round: sixteen loads in flight before the first update (one piece per round left a
+        // compute unit with 4 x 256 x 16 B = 16 KB in flight: 3.0 TB/s over the 680 MB of an update)
+        long i = threadIdx.x;
+        for (; i + 3 * MT_THREADS < nvec; i += 4 * MT_THREADS) {
+            f32x4 gg[4], pp[4], mm[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { gg[u] = g4[i + u * MT_THREADS]; pp[u] = p4[i + u * MT_THREADS]; mm[u] = m4[i + u * MT_THREADS]; vv[u] = v4[i + u * MT_THREADS]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { float pi = pp[u][c], mi = mm[u][c], vi = vv[u][c]; upd(gg[u][c], pi, mi, vi); pp[u][c] = pi; mm[u][c] = mi; vv[u][c] = vi; }
+                p4[i + u * MT_THREADS] = pp[u]; m4[i + u * MT_THREADS] = mm[u]; v4[i + u * MT_THREADS] = vv[u];
+            }
+        }
+        for (; i < nvec; i += MT_THREADS) {
             const f32x4 gg = g4[i];
             f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
 #pragma unroll

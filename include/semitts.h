@@ -242,6 +242,8 @@ typedef struct st_lstm_pw_job {
     float* dc;                                        /* (B, H) in: dL/dc_t, out: dL/dc_{t-1} */
     float* dgates; int ldg;                           /* (B, 4H) out */
     st_t16_view dgates_t16;                           /* optional second copy in T16 (K = 4H) */
+    int dh1_slabs; long dh1_slab_stride;              /* > 1: dh1 is the first of that many slabs (dh1_slab_stride floats apart) of a K-split
+                                                       * product (st_skinny_partial_attn_*): the addend is their sum, in slab order */
 } st_lstm_pw_job;
 int st_skinny_linear_packed_lstm_bwd_fwd(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
                                          const st_lstm_pw_job* job, void* stream);
@@ -822,7 +824,13 @@ typedef struct st_decoder_bwd_io {
     /* with attn_parts = 2 and 16 < B <= 32: (dxd_splits, B, E+Q+D) scratch -- the decoder cell's product of the hosted launch runs K-split
      * (st_skinny_partial_attn_bwd) and is summed, with its pointwise epilogue, in the step's W_q^T dpq launch (st_partial_sum_job); NULL = off */
     float* dxd_part; int dxd_splits;
+    /* ... and (steps + 1, dxq_splits, B, P+E+Q) slabs: the query cell's product dgates_q . [W_ih | W_hh] K-split as well; dxq then only receives
+     * step 0 (need_dxq0) and the callers sum the slabs' first P columns for the teacher gradient.  NULL = off.  dxq_splits <= 4. */
+    float* dxq_part; int dxq_splits;
 } st_decoder_bwd_io;
+/* which forms st_decoder_backward will take for these dimensions and buffers: bit 0 split attention backward, bit 1 partial decoder-cell
+ * product, bit 2 partial query-cell product (dxq_part holds the gradient w.r.t. the query cell's inputs as slabs) */
+int st_decoder_bwd_forms(const st_decoder_dims* d, const st_decoder_bwd_io* io);
 /* st_attn_step_bwd with S = pm + W_l loc of the step given (s_in, (B,L,A)): loc_t is not written (may be NULL) */
 int st_attn_step_bwd_s(const float* pq, const float* pm, const float* memory,
                        const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
@@ -861,6 +869,9 @@ typedef struct st_attn_bwd_job {
      * `parts` partial sums in dloc_part (parts, B, L, F).  dhist / dloc_t / hist_t are NOT written and dcum is read-only (it must hold
      * the total gradient w.r.t. cum_t; dcum_add must be NULL): the caller runs st_attn_hist_job next, which forms them. */
     int parts; float* dloc_part;
+    /* up to three more addends of the context gradient, behind dctx[0 .. n_dctx): the slabs of a K-split product (the gradient w.r.t.
+     * ctx_{t} inside dxq_{t+1} when that launch ran in the partial form) */
+    const float* dctx_more[3]; int ld_dctx_more[3]; int n_dctx_more;
 } st_attn_bwd_job;
 /* What a split attention backward (st_attn_bwd_job.parts > 1) leaves behind, one workgroup per utterance: dloc = the partial sums added in
  * part order -> dloc_t (B, L, F); hist_t (B, L, 2) = [w_{t-1}, cum_{t-1}]; dhist (B, 2, L) = the gradient w.r.t. that history through the
@@ -899,6 +910,11 @@ typedef struct st_partial_sum_job {
 } st_partial_sum_job;
 int st_skinny_partial_attn_bwd(const float* packed_w, const st_t16_view* x, int K, float* part, int S, int B, int N,
                                const st_attn_bwd_job* ab, void* stream);
+/* the partial product with an st_attn_hist_job beside it (BPTT launch 3, dgates_q . [W_ih | W_hh], in the partial form: its consumers -- the
+ * next attention backward's context addend and the query cell's dh1 addend -- take the S slabs as they are, st_attn_bwd_job.dctx_more and
+ * st_lstm_pw_job.dh1_slabs) */
+int st_skinny_partial_attn_hist(const float* packed_w, const st_t16_view* x, int K, float* part, int S, int B, int N,
+                                const st_attn_hist_job* hist, void* stream);
 /* st_skinny_linear_packed_lstm_bwd_attn_hist with an st_partial_sum_job as well (same launch); hist may be NULL */
 int st_skinny_linear_packed_lstm_bwd_attn_hist_sum(const float* packed_w, const st_t16_view* x, int K, float* y, int ldy, int B, int N,
                                                    const st_lstm_pw_job* job, const st_attn_hist_job* hist,

@@ -99,7 +99,7 @@ class StDecoderBwdIO(C.Structure):
                  ('overlap_attn', C.c_int), ('prenet_norm', C.c_int), ('pre_y_tape', C.c_void_p), ('pre_norm_w', C.c_void_p * 2),
                  ('pre_norm_rm', C.c_void_p * 2), ('pre_norm_rv', C.c_void_p * 2), ('pre_norm_eps', C.c_float),
                  ('dpre_norm_w', C.c_void_p * 2), ('dpre_norm_b', C.c_void_p * 2), ('attn_parts', C.c_int), ('dloc_part', C.c_void_p),
-                 ('dxd_part', C.c_void_p), ('dxd_splits', C.c_int)])
+                 ('dxd_part', C.c_void_p), ('dxd_splits', C.c_int), ('dxq_part', C.c_void_p), ('dxq_splits', C.c_int)])
 
 
 
@@ -107,7 +107,7 @@ class StLstmPwJob(C.Structure):
     _fields_ = [('n0', C.c_int), ('H', C.c_int), ('dh1', C.c_void_p), ('ld1', C.c_int), ('dh2', C.c_void_p), ('ld2', C.c_int),
                 ('scale2', C.c_void_p), ('mask', C.c_void_p), ('gates', C.c_void_p), ('c', C.c_void_p), ('ldc', C.c_int),
                 ('c_prev', C.c_void_p), ('ldcp', C.c_int), ('dc', C.c_void_p), ('dgates', C.c_void_p), ('ldg', C.c_int),
-                ('dgates_t16', StT16View)]
+                ('dgates_t16', StT16View), ('dh1_slabs', C.c_int), ('dh1_slab_stride', C.c_long)]
 
 
 class StLstmCellPackedJob(C.Structure):
@@ -127,7 +127,8 @@ class StAttnBwdJob(C.Structure):
                 ('dpq', C.c_void_p), ('dpq_t16', StT16View), ('dhist', C.c_void_p), ('ds_t', C.c_void_p), ('loc_t', C.c_void_p),
                 ('dloc_t', C.c_void_p), ('hist_t', C.c_void_p), ('dctx_t', C.c_void_p), ('dv_t', C.c_void_p), ('s_in', C.c_void_p),
                 ('B', C.c_int), ('L', C.c_int), ('A', C.c_int), ('E', C.c_int), ('F', C.c_int), ('K', C.c_int),
-                ('parts', C.c_int), ('dloc_part', C.c_void_p)]
+                ('parts', C.c_int), ('dloc_part', C.c_void_p),
+                ('dctx_more', C.c_void_p * 3), ('ld_dctx_more', C.c_int * 3), ('n_dctx_more', C.c_int)]
 
 
 class StAttnHistJob(C.Structure):
@@ -253,6 +254,8 @@ SIGNATURES = {
     'st_skinny_linear_packed_lstm_bwd_attn_bwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), C.POINTER(StAttnBwdJob), P],
     'st_attn_bwd_wide_fits': [I, I, I, I, I],
     'st_skinny_linear_packed_attn_hist': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StAttnHistJob), P],
+    'st_skinny_partial_attn_hist': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StAttnHistJob), P],
+    'st_decoder_bwd_forms': [C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO)],
     'st_skinny_partial_attn_bwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StAttnBwdJob), P],
     'st_skinny_linear_packed_lstm_bwd_attn_hist_sum': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), C.POINTER(StAttnHistJob),
                                                        C.POINTER(StPartialSumJob), P],

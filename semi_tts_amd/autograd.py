@@ -840,6 +840,10 @@ class _DecoderFn(Function):
                 if parts == 2 and dsplits > 0 and 16 < B <= 32 and Bp == B:      # the hosted launch's product K-split into slabs
                     dxd_part = e_(dsplits, B, XDw)
                     io.dxd_part, io.dxd_splits = ops._p(dxd_part), dsplits
+                    qsplits = int(getattr(dec, 'bwd_dxq_splits', 4))
+                    if lazy_big and 0 < qsplits <= 4:                            # ... and the query cell's (its consumers add the slabs up)
+                        dxq_part = e_(steps + 1, qsplits, B, XQw)
+                        io.dxq_part, io.dxq_splits = ops._p(dxq_part), qsplits
         src_arr = (C.c_int * max(steps, 1))(*src)
         io.step_src, io.Bt = C.cast(src_arr, C.POINTER(C.c_int)), Bt
         io.need_dxq0 = 1 if ctx.has_in0 else 0
@@ -864,6 +868,8 @@ class _DecoderFn(Function):
                         io.pre_norm_rm[l], io.pre_norm_rv[l] = ops._p(nm.running_mean), ops._p(nm.running_var)
                     io.dpre_norm_w[l], io.dpre_norm_b[l] = ops._p(dnorm[2 * l]), ops._p(dnorm[2 * l + 1])
                 io.pre_norm_eps = float(dec.prenet.layers[0].norm.eps)
+        # (does the loop leave the gradient w.r.t. the query cell's inputs as K-split slabs?  The library decides by shape; ask it)
+        dxq_slabs = bool(int(lib.st_decoder_bwd_forms(C.byref(dims), C.byref(io))) & 4)
         _lib.check(lib.st_decoder_backward(C.byref(bw), C.byref(dims), C.byref(io), ops.stream_handle()), 'st_decoder_backward')
 
         # weight gradients: TN GEMMs over the tapes (rows = (step, utterance); pad rows are zero)
@@ -902,7 +908,14 @@ class _DecoderFn(Function):
             Tt = teacher_pre.shape[1]
             dteacher = z(Bt, Tt, P)
             if steps > 1:
-                if list(src[:steps - 1]) == list(range(steps - 1)):
+                identity = list(src[:steps - 1]) == list(range(steps - 1))
+                if dxq_slabs and not identity:     # (rare: teacher-mean steps) the general forms below read whole rows: add the slabs up once
+                    dxq[1:steps] = dxq_part[1:steps].sum(1)
+                if identity and dxq_slabs:
+                    for sl in range(qsplits):      # the slabs of dxq_t[:, :P], added in slab order
+                        ops.copy3d(dteacher.view(Bt, Tt, P)[:, :steps - 1], dxq_part[1:steps, sl].permute(1, 0, 2)[:Bt, :, :P], Bt, steps - 1, P,
+                                   accumulate=sl > 0)
+                elif identity:
                     ops.copy3d(dteacher.view(Bt, Tt, P)[:, :steps - 1], dxq[1:steps].permute(1, 0, 2)[:Bt, :, :P], Bt, steps - 1, P)
                 else:
                     for t in range(steps - 1):

@@ -20,6 +20,7 @@ constexpr int AB_THREADS = 512;
 // block fits the LDS, else 16
 constexpr int AB_LBLK_MAX = 48;
 constexpr int AB_FMAX = 32;     // location filters held in registers per thread
+constexpr int AB_NDCTX = 6;     // addends of the context gradient: three (dxo, dxd, dxq) or, with dxq as K-split slabs, two + four
 
 struct AbArgs {
     const float* pq; const float* pm; const float* memory;
@@ -27,7 +28,7 @@ struct AbArgs {
     const float* w_cum_prev;               // cum_{t-1} (B, L)
     const float* w; int ld_w;              // w_t
     const float* loc_conv_w; const float* loc_lin_w; const float* v;
-    const float* dctx[3]; int ld_dctx[3];  // gradient w.r.t. ctx_t = sum of up to three addends (NULL = absent)
+    const float* dctx[AB_NDCTX]; int ld_dctx[AB_NDCTX];  // gradient w.r.t. ctx_t = sum of up to six addends, added in index order (NULL = absent)
     const float* dw_direct[3]; int ld_dw[3];   // gradient w.r.t. w_t: up to three addends (B rows each)
     float* dcum; const float* dcum_add; int ld_dcum_add;   // dL/dcum_t = dcum (B,L, in/out) + dcum_add; also an addend of dw
     float* dpq;                            // (B, A) out
@@ -147,13 +148,13 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     const float* pe_dummy = a.memory + (size_t)b * L * E + pl_e;
     const float pl_w = pl_dummy[0];
     const float pq_a = a.pq[(size_t)b * A + a0], v_a = a.v[a0];      // (consumed in P3: requested here, not behind the softmax)
-    float pl_dl[3], pe_dl[3];
+    float pl_dl[3], pe_dl[AB_NDCTX];
 #pragma unroll
     for (int j = 0; j < 3; ++j) pl_dl[j] = (a.dw_direct[j] ? a.dw_direct[j] + (size_t)b * a.ld_dw[j] + pl_l : pl_dummy)[0];
     const float pl_gc0 = (a.dcum ? a.dcum + (size_t)b * L + pl_l : pl_dummy)[0];
     const float pl_gc1 = (a.dcum && a.dcum_add ? a.dcum_add + (size_t)b * a.ld_dcum_add + pl_l : pl_dummy)[0];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) pe_dl[j] = (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + pl_e : pe_dummy)[0];
+    for (int j = 0; j < AB_NDCTX; ++j) pe_dl[j] = (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + pl_e : pe_dummy)[0];
     // ---- P0: stage operands.  The first round of the weight loads goes to registers before any LDS traffic so
     // that all global latencies of this phase overlap (each separate load -> store loop costs one round trip).
     const int nWc = NS == 1 ? F * 2 * K : 0, nWl = As * F;       // (parts: W_c is only needed behind the sum of the partials)
@@ -265,12 +266,12 @@ __device__ __forceinline__ void ab_body(const AbArgs& a, const int b, float* __r
     for (int e = tid; e < E; e += AB_THREADS) {
         const bool first = e == tid;
         const float* dummy = a.memory + (size_t)b * L * E + e;
-        float dl[3];
+        float dl[AB_NDCTX];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dl[j] = first ? pe_dl[j] : (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + e : dummy)[0];
+        for (int j = 0; j < AB_NDCTX; ++j) dl[j] = first ? pe_dl[j] : (a.dctx[j] ? a.dctx[j] + (size_t)b * a.ld_dctx[j] + e : dummy)[0];
         float g = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) g += a.dctx[j] ? dl[j] : 0.0f;
+        for (int j = 0; j < AB_NDCTX; ++j) g += a.dctx[j] ? dl[j] : 0.0f;
         dctx[e] = g;
         if (NS == 1 || prt == 0) a.dctx_t[(size_t)b * E + e] = g;
     }
@@ -677,7 +678,7 @@ inline int ab_fill(AbArgs& a, const st_t16_view* dpq_t16, const float* pq, const
     ST_CHECK_ARG(A <= AB_THREADS / 2 && AB_THREADS % A == 0, "st_attn_step_bwd: attn_dim=%d must divide %d", A, AB_THREADS / 2);
     ST_CHECK_ARG((E & 3) == 0 && st_aligned16(memory), "st_attn_step_bwd: E=%d must be a multiple of 4 (16-byte aligned rows)", E);
     ST_CHECK_ARG(F <= AB_FMAX, "st_attn_step_bwd: n_location_filters=%d > %d", F, AB_FMAX);
-    ST_CHECK_ARG(n_dctx >= 0 && n_dctx <= 3 && n_dw >= 0 && n_dw <= 3, "st_attn_step_bwd: at most 3 addends");
+    ST_CHECK_ARG(n_dctx >= 0 && n_dctx <= AB_NDCTX && n_dw >= 0 && n_dw <= 3, "st_attn_step_bwd: at most %d context addends, 3 weight addends", AB_NDCTX);
     memset(&a, 0, sizeof(a));
     a.pq = pq; a.pm = pm; a.memory = memory; a.w_prev = w_prev; a.ld_wprev = ld_wprev; a.w_cum_prev = w_cum_prev;
     a.w = w; a.ld_w = ld_w; a.loc_conv_w = loc_conv_w; a.loc_lin_w = loc_lin_w; a.v = v;

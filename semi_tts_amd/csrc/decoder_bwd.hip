@@ -46,6 +46,37 @@ extern "C" int st_attn_step_bwd_t16(const float* pq, const float* pm, const floa
 
 extern "C" int st_attn_bwd_wide_fits(int L, int A, int E, int F, int K);
 
+namespace {
+// which forms the fused BPTT loop takes (see st_decoder_bwd_forms): parts of the hosted attention backward, the two partial products
+struct BwdForms { int parts; bool partial_d, partial_q; int dsplits, qsplits; };
+BwdForms bwd_forms(const st_decoder_dims* d, const st_decoder_bwd_io* io) {
+    BwdForms f = {1, false, false, 2, 4};
+    const int B = d->B, L = d->L, E = d->E, P = d->P, Q = d->Q, D = d->D, A = d->A;
+    const int XQ = P + E + Q, XD = E + Q + D;
+    const bool overlap = io->overlap_attn && io->attn_s_tape && io->fuse_pw;
+    // the hosted attention backward as `parts` workgroups per utterance over slices of the attention dims; what needs the sum of their
+    // partial location-feature gradients (dloc_t, hist_t, the conv-transpose to dhist, the carried dcum) rides in the step's dgates_q
+    // launch (st_attn_hist_job).  A = 256, 32 filters, texts whose wide block fits the LDS -- else the whole step per workgroup
+    f.parts = overlap && io->dloc_part && (io->attn_parts == 2 || io->attn_parts == 4) ? io->attn_parts : 1;
+    if (f.parts > 1 && !(A % (16 * f.parts) == 0 && 512 % (A / f.parts) == 0 && 512 / (A / f.parts) >= 2 * f.parts && d->F == 32 && d->K <= 31 &&
+                         st_attn_bwd_wide_fits(L, A, E, d->F, d->K))) f.parts = 1;
+    // ... and, in that form, the decoder cell's product of the hosted launch K-split into partial slabs (two row tiles and both batch tiles
+    // per workgroup: half the bytes through the compute units; 2 B + N / 32 * S workgroups: one round) that the step's W_q^T dpq launch sums
+    f.dsplits = io->dxd_splits > 0 ? io->dxd_splits : 2;
+    f.partial_d = f.parts == 2 && io->dxd_part && B > 16 && B <= 32 && XD % 32 == 0 && ((4 * D) / 16) % f.dsplits == 0 && io->Bp == B;
+    // ... and the query cell's product likewise (N / 32 * S + B history workgroups); its consumers take the slabs as addends
+    f.qsplits = io->dxq_splits > 0 ? io->dxq_splits : 4;
+    f.partial_q = f.partial_d && io->dxq_part && f.qsplits <= 4 && XQ % 32 == 0 && ((4 * Q) / 16) % f.qsplits == 0;
+    return f;
+}
+}  // namespace
+
+extern "C" int st_decoder_bwd_forms(const st_decoder_dims* d, const st_decoder_bwd_io* io) {
+    if (!d || !io) return 0;
+    const BwdForms f = bwd_forms(d, io);
+    return (f.parts > 1 ? 1 : 0) | (f.partial_d ? 2 : 0) | (f.partial_q ? 4 : 0);
+}
+
 extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io,
                                    void* stream) {
     (void)hipGetLastError();
@@ -135,23 +166,17 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
         // the decoder cell's recurrence (dgates_d(t-1) from dgates_d(t) . W_hh_d and the output gradients) does not touch the attention /
         // query chain of step t: with overlap_attn its product runs ONE STEP AHEAD, beside the attention backward of step t
         const bool overlap = io->overlap_attn && io->attn_s_tape;
-        // the hosted attention backward as `parts` workgroups per utterance over slices of the attention dims; what needs the sum of their
-        // partial location-feature gradients (dloc_t, hist_t, the conv-transpose to dhist, the carried dcum) rides in the step's W_q^T dpq
-        // launch (st_attn_hist_job).  A = 256, 32 filters, texts whose wide block fits the LDS -- else the whole step per workgroup
-        int parts = overlap && io->dloc_part && (io->attn_parts == 2 || io->attn_parts == 4) ? io->attn_parts : 1;
-        if (parts > 1 && !(A % (16 * parts) == 0 && 512 % (A / parts) == 0 && 512 / (A / parts) >= 2 * parts && d->F == 32 && d->K <= 31 &&
-                           st_attn_bwd_wide_fits(L, A, E, d->F, d->K))) parts = 1;
-        // ... and, in that form, the decoder cell's product of the hosted launch K-split into partial slabs (two row tiles and both batch tiles
-        // per workgroup: half the bytes through the compute units; 2 B + N / 32 * S workgroups: one round) that the step's W_q^T dpq launch sums
-        const int dsplits = io->dxd_splits > 0 ? io->dxd_splits : 2;
-        const bool partial = parts == 2 && io->dxd_part && B > 16 && B <= 32 && XD % 32 == 0 && ((4 * D) / 16) % dsplits == 0 && Bp == B;
+        const BwdForms forms = bwd_forms(d, io);
+        const int parts = forms.parts, dsplits = forms.dsplits, qsplits = forms.qsplits;
+        const bool partial = forms.partial_d, partial_q = forms.partial_q;
+        const size_t qslab = (size_t)B * XQ;                 // one slab of dxq_part; a step holds qsplits of them
         if (overlap) { rc = product_d(steps - 1, nullptr); if (rc) return rc; }
         for (int t = steps - 1; t >= 0; --t) {
             const float* dxo = io->dxo + (size_t)t * Bp * XO;
             float* dxd = io->dxd + (size_t)t * Bp * XD;
             float* dxq = io->dxq + (size_t)t * Bp * XQ;
             // (no step behind the last one: absent addends instead of a zero slot -- the tapes need not start from zeros)
-            const float* dxq_next = t + 1 < steps ? io->dxq + (size_t)(t + 1) * Bp * XQ : nullptr;
+            const float* dxq_next = t + 1 < steps ? (partial_q ? io->dxq_part + (size_t)(t + 1) * qsplits * qslab : io->dxq + (size_t)(t + 1) * Bp * XQ) : nullptr;
             float* dpq = io->dpq + (size_t)t * Bp * A;
             float* dhist_cur = io->dhist[t & 1];
             const float* dhist_next = io->dhist[(t + 1) & 1];
@@ -164,6 +189,10 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
             ab.w = io->align + (size_t)t * L; ab.ld_w = ldal;
             ab.loc_conv_w = w->attn_loc_conv_w; ab.loc_lin_w = w->attn_loc_lin_w; ab.v = w->attn_v;
             ab.dctx[0] = dxo + D; ab.dctx[1] = dxd; ab.dctx[2] = dxq_next ? dxq_next + P : nullptr; ab.ld_dctx[0] = XO; ab.ld_dctx[1] = XD; ab.ld_dctx[2] = XQ; ab.n_dctx = 3;
+            if (partial_q && dxq_next) {     // the other slabs of dxq_{t+1} (slab order = addend order: fixed)
+                for (int sl = 1; sl < qsplits; ++sl) { ab.dctx_more[sl - 1] = dxq_next + (size_t)sl * qslab + P; ab.ld_dctx_more[sl - 1] = XQ; }
+                ab.n_dctx_more = qsplits - 1;
+            }
             ab.dw_direct[0] = dhist_next; ab.dw_direct[1] = io->dalign ? io->dalign + (size_t)t * L : nullptr; ab.ld_dw[0] = 2 * L; ab.ld_dw[1] = ldal;
             ab.n_dw = io->dalign ? 2 : 1;
             // (split form: the history job of step t+1 has already added dhist(t+1)[1] into dcum)
@@ -179,10 +208,15 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                 st_t16_view x_v = {dgd_buf[(t - 1) & 1], kbd, 0};
                 rc = st_skinny_partial_attn_bwd(w->d_w_cat_t_p16, &x_v, 4 * D, io->dxd_part, dsplits, B, XD, &ab, stream);
             } else if (overlap && t > 0) rc = product_d(t - 1, &ab);        // [attention backward of t | decoder cell product of t-1]: one launch
-            else rc = st_attn_step_bwd_t16(ab.pq, ab.pm, ab.memory, ab.w_prev, ab.ld_wprev, ab.w_cum_prev, ab.w, ab.ld_w, ab.loc_conv_w, ab.loc_lin_w,
-                                           ab.v, ab.dctx, ab.ld_dctx, ab.n_dctx, ab.dw_direct, ab.ld_dw, ab.n_dw, ab.dcum, ab.dcum_add, ab.ld_dcum_add,
+            else {
+                const float* dcx[6]; int ldx[6]; int ncx = 0;       // (the standalone call takes the slabs of dxq_{t+1} in one addend list)
+                for (int q_ = 0; q_ < ab.n_dctx; ++q_) { dcx[ncx] = ab.dctx[q_]; ldx[ncx++] = ab.ld_dctx[q_]; }
+                for (int q_ = 0; q_ < ab.n_dctx_more; ++q_) { dcx[ncx] = ab.dctx_more[q_]; ldx[ncx++] = ab.ld_dctx_more[q_]; }
+                rc = st_attn_step_bwd_t16(ab.pq, ab.pm, ab.memory, ab.w_prev, ab.ld_wprev, ab.w_cum_prev, ab.w, ab.ld_w, ab.loc_conv_w, ab.loc_lin_w,
+                                           ab.v, dcx, ldx, ncx, ab.dw_direct, ab.ld_dw, ab.n_dw, ab.dcum, ab.dcum_add, ab.ld_dcum_add,
                                            ab.dpq, &ab.dpq_t16, ab.dhist, ab.ds_t, ab.loc_t, ab.dloc_t, ab.hist_t, ab.dctx_t, ab.dv_t, ab.s_in,
                                            B, L, A, E, d->F, d->K, stream);
+            }
             if (rc) return rc;
             // d + e. dh_q = W_q^T dpq + (W_hh_q^T dgates_q)_{t+1} + std * d(adapted h_q): the query cell's pointwise part in the epilogue
             {
@@ -190,6 +224,7 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                 memset(&j, 0, sizeof(j));
                 j.n0 = 0; j.H = Q;
                 j.dh1 = dxq_next ? dxq_next + P + E : nullptr; j.ld1 = XQ;
+                if (partial_q && dxq_next) { j.dh1_slabs = qsplits; j.dh1_slab_stride = (long)qslab; }
                 j.dh2 = dxd + E; j.ld2 = XD; j.scale2 = io->ada_std;
                 j.mask = io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr;
                 j.gates = io->gates_q_tape + (size_t)t * 4 * BQ;
@@ -217,7 +252,8 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                 hj.w_prev = ab.w_prev; hj.ld_wprev = ab.ld_wprev; hj.w_cum_prev = ab.w_cum_prev;
                 hj.dloc_t = ab.dloc_t; hj.hist_t = ab.hist_t; hj.dhist = dhist_cur; hj.dcum = io->dcum;
                 hj.B = B; hj.L = L; hj.F = d->F; hj.K = d->K;
-                rc = st_skinny_linear_packed_attn_hist(w->q_w_cat_t_p16, &dgq_v, 4 * Q, dxq, XQ, B, XQ, &hj, stream);
+                if (partial_q) rc = st_skinny_partial_attn_hist(w->q_w_cat_t_p16, &dgq_v, 4 * Q, io->dxq_part + (size_t)t * qsplits * qslab, qsplits, B, XQ, &hj, stream);
+                else rc = st_skinny_linear_packed_attn_hist(w->q_w_cat_t_p16, &dgq_v, 4 * Q, dxq, XQ, B, XQ, &hj, stream);
                 if (rc) return rc;
             } else if (t > 0 || io->need_dxq0) {
                 rc = st_skinny_linear_packed_fwd(w->q_w_cat_t_p16, &dgq_v, 4 * Q, nullptr, ST_ACT_NONE, nullptr, 0, dxq, XQ, nullptr,

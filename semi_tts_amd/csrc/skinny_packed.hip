@@ -186,6 +186,7 @@ struct PkArgs {
 struct PkPw {
     int n0, H;
     const float* dh1; int ld1;                       // addend, (B rows, stride ld1), column u
+    int dh1_slabs; long dh1_slab_stride;             // > 1: dh1 is the first of that many slabs (floats apart) of a K-split product, added in order
     const float* dh2; int ld2; const float* scale2;  // optional addend times scale2 (B, H)
     const float* mask;                               // optional (B, H)
     const float* gates;                              // (B, 4, H) activated gates of the step
@@ -435,6 +436,9 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
                 const f32x4 dci = st_ld4(q.dc + bu);
                 const float* dummy = q.gates;
                 const f32x4 l1 = st_ld4(q.dh1 ? q.dh1 + (size_t)b * q.ld1 + u : dummy);
+                f32x4 l1s[3];                          // further slabs of a K-split addend (absent: the dummy address, dropped below)
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) l1s[sl] = st_ld4(q.dh1 && sl + 1 < q.dh1_slabs ? q.dh1 + (size_t)(sl + 1) * q.dh1_slab_stride + (size_t)b * q.ld1 + u : dummy);
                 const f32x4 l2 = st_ld4(q.dh2 ? q.dh2 + (size_t)b * q.ld2 + u : dummy);
                 const f32x4 sc = st_ld4(q.scale2 ? q.scale2 + bu : dummy);
                 const f32x4 mk = st_ld4(q.mask ? q.mask + bu : dummy);
@@ -443,7 +447,12 @@ __device__ __forceinline__ void pk_body(const PkArgs& a, const int tile, const i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float dh = v4[r];
-                    if (q.dh1) dh += l1[r];
+                    if (q.dh1) {
+                        float a1 = l1[r];
+#pragma unroll
+                        for (int sl = 0; sl < 3; ++sl) a1 += sl + 1 < q.dh1_slabs ? l1s[sl][r] : 0.0f;       // (slab order: fixed)
+                        dh += a1;
+                    }
                     if (q.dh2) dh += l2[r] * (q.scale2 ? sc[r] : 1.0f);
                     if (q.mask) dh *= mk[r];
                     const float tc = tanhf(cr[r]);
@@ -710,6 +719,18 @@ __global__ __launch_bounds__(KW * 64) __attribute__((amdgpu_waves_per_eu((NS > 1
     pk_body<2, NB, KW, TRIP>(a, j - by * tiles_a, by, red, &pw);
 }
 
+// the argument block of an attention-backward job: its context addends dctx[0 .. n_dctx) followed by dctx_more[0 .. n_dctx_more)
+static int ab_fill_job(AbArgs& t, const st_attn_bwd_job* ab) {
+    const float* dctx[AB_NDCTX]; int ld[AB_NDCTX]; int n = 0;
+    ST_CHECK_ARG(ab->n_dctx >= 0 && ab->n_dctx <= 3 && ab->n_dctx_more >= 0 && ab->n_dctx_more <= 3, "attention backward job: at most 3 + 3 context addends");
+    for (int j = 0; j < ab->n_dctx; ++j) { dctx[n] = ab->dctx[j]; ld[n++] = ab->ld_dctx[j]; }
+    for (int j = 0; j < ab->n_dctx_more; ++j) { dctx[n] = ab->dctx_more[j]; ld[n++] = ab->ld_dctx_more[j]; }
+    return ab_fill(t, &ab->dpq_t16, ab->pq, ab->pm, ab->memory, ab->w_prev, ab->ld_wprev, ab->w_cum_prev, ab->w, ab->ld_w, ab->loc_conv_w,
+                   ab->loc_lin_w, ab->v, dctx, ld, n, ab->dw_direct, ab->ld_dw, ab->n_dw, ab->dcum, ab->dcum_add,
+                   ab->ld_dcum_add, ab->dpq, ab->dhist, ab->ds_t, ab->loc_t, ab->dloc_t, ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in,
+                   ab->B, ab->L, ab->A, ab->E, ab->F, ab->K);
+}
+
 // (development switch ST_EXP: parts of the hosted BPTT launches return at once -- timing ablations only, results are then garbage)
 static int st_exp_flag() { static int v = -1; if (v < 0) { const char* e = getenv("ST_EXP"); v = e ? atoi(e) : 0; } return v; }
 
@@ -835,6 +856,9 @@ __device__ __forceinline__ void pk_sum_body(const PkSumArgs& a, const int jb, co
     const f32x4 cr = st_ld4(cell ? q.c + (size_t)b * q.ldc + u : dummy);
     const f32x4 dci = st_ld4(cell ? q.dc + bu : dummy);
     const f32x4 l1 = st_ld4(cell && q.dh1 ? q.dh1 + (size_t)b * q.ld1 + u : dummy);
+    f32x4 l1s[3];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) l1s[sl] = st_ld4(cell && q.dh1 && sl + 1 < q.dh1_slabs ? q.dh1 + (size_t)(sl + 1) * q.dh1_slab_stride + (size_t)b * q.ld1 + u : dummy);
     const f32x4 l2 = st_ld4(cell && q.dh2 ? q.dh2 + (size_t)b * q.ld2 + u : dummy);
     const f32x4 sc = st_ld4(cell && q.scale2 ? q.scale2 + bu : dummy);
     const f32x4 mk = st_ld4(cell && q.mask ? q.mask + bu : dummy);
@@ -850,7 +874,12 @@ __device__ __forceinline__ void pk_sum_body(const PkSumArgs& a, const int jb, co
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float dh = v4[r];
-        if (q.dh1) dh += l1[r];
+        if (q.dh1) {
+            float a1 = l1[r];
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) a1 += sl + 1 < q.dh1_slabs ? l1s[sl][r] : 0.0f;
+            dh += a1;
+        }
         if (q.dh2) dh += l2[r] * (q.scale2 ? sc[r] : 1.0f);
         if (q.mask) dh *= mk[r];
         const float tc = tanhf(cr[r]);
@@ -890,6 +919,16 @@ __global__ __launch_bounds__(KW * 64) void pk_part_ab_kernel(const PkPartArgs p,
         return;
     }
     pk_part_body<KW, TRIP>(p, i - n_ab, red);
+}
+
+// the partial product with the history part of a split attention backward beside it (BPTT launch 3 in the partial form)
+template <int KW, int TRIP>
+__global__ __launch_bounds__(KW * 64) void pk_part_hist_kernel(const PkPartArgs p, const int n_h, const AbHistArgs hist) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * 4 * 64];
+    const int i = blockIdx.x;
+    if (i < n_h) { ab_hist_body(hist, i, pk_dyn_lds); return; }
+    pk_part_body<KW, TRIP>(p, i - n_h, red);
 }
 
 // the partial product on its own (no attention backward beside it)
@@ -1614,7 +1653,7 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_fwd(const float* packed_w, const
     a.y = y; a.ldy = ldy;
     PkPw q;
     memset(&q, 0, sizeof(q));
-    q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
+    q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh1_slabs = job->dh1_slabs; q.dh1_slab_stride = job->dh1_slab_stride; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
     q.gates = job->gates; q.c = job->c; q.ldc = job->ldc; q.c_prev = job->c_prev; q.ldcp = job->ldcp; q.dc = job->dc;
     q.dgates = job->dgates; q.ldg = job->ldg; q.dg_t16 = pk_out(&job->dgates_t16);
     const int tiles = (N + 15) / 16, BT = (B + 15) >> 4;
@@ -1637,7 +1676,7 @@ static int pk_pw_fill(PkPw& q, const st_lstm_pw_job* job, int N, int ldy, const 
                  (!job->c_prev || st_aligned16(job->c_prev)) && (!job->dh1 || st_aligned16(job->dh1)) && (!job->dh2 || st_aligned16(job->dh2)) &&
                  (!job->scale2 || st_aligned16(job->scale2)) && (!job->mask || st_aligned16(job->mask)) &&
                  (!job->dgates_t16.base || st_aligned16(job->dgates_t16.base)), "%s: operands must be 16-byte aligned", who);
-    q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
+    q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh1_slabs = job->dh1_slabs; q.dh1_slab_stride = job->dh1_slab_stride; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
     q.gates = job->gates; q.c = job->c; q.ldc = job->ldc; q.c_prev = job->c_prev; q.ldcp = job->ldcp; q.dc = job->dc;
     q.dgates = job->dgates; q.ldg = job->ldg; q.dg_t16 = pk_out(&job->dgates_t16);
     return 0;
@@ -1691,15 +1730,12 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, 
                      (!job->c_prev || st_aligned16(job->c_prev)) && (!job->dh1 || st_aligned16(job->dh1)) && (!job->dh2 || st_aligned16(job->dh2)) &&
                      (!job->scale2 || st_aligned16(job->scale2)) && (!job->mask || st_aligned16(job->mask)) &&
                      (!job->dgates_t16.base || st_aligned16(job->dgates_t16.base)), "st_skinny_linear_packed_lstm_bwd_attn_bwd: operands must be 16-byte aligned");
-        q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
+        q.n0 = job->n0; q.H = H; q.dh1 = job->dh1; q.ld1 = job->ld1; q.dh1_slabs = job->dh1_slabs; q.dh1_slab_stride = job->dh1_slab_stride; q.dh2 = job->dh2; q.ld2 = job->ld2; q.scale2 = job->scale2; q.mask = job->mask;
         q.gates = job->gates; q.c = job->c; q.ldc = job->ldc; q.c_prev = job->c_prev; q.ldcp = job->ldcp; q.dc = job->dc;
         q.dgates = job->dgates; q.ldg = job->ldg; q.dg_t16 = pk_out(&job->dgates_t16);
     }      // (no job: H = 0, no column belongs to a cell -- the plain product)
     AbArgs t;
-    if (ab_fill(t, &ab->dpq_t16, ab->pq, ab->pm, ab->memory, ab->w_prev, ab->ld_wprev, ab->w_cum_prev, ab->w, ab->ld_w, ab->loc_conv_w,
-                ab->loc_lin_w, ab->v, ab->dctx, ab->ld_dctx, ab->n_dctx, ab->dw_direct, ab->ld_dw, ab->n_dw, ab->dcum, ab->dcum_add,
-                ab->ld_dcum_add, ab->dpq, ab->dhist, ab->ds_t, ab->loc_t, ab->dloc_t, ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in,
-                ab->B, ab->L, ab->A, ab->E, ab->F, ab->K)) return -1;
+    if (ab_fill_job(t, ab)) return -1;
     ST_CHECK_ARG(t.s_in, "st_skinny_linear_packed_lstm_bwd_attn_bwd: the hosted attention backward starts from the forward's S (s_in)");
     const size_t red_bytes = (size_t)8 * 1 * 64 * sizeof(f32x4);          // the product's static LDS in the same workgroup
     const bool wide = ab_wide(t, red_bytes);
@@ -1722,7 +1758,7 @@ extern "C" int st_skinny_linear_packed_lstm_bwd_attn_bwd(const float* packed_w, 
                                               nullptr, B, N, stream);
         if (rc) return rc;
         return st_attn_step_bwd_t16(ab->pq, ab->pm, ab->memory, ab->w_prev, ab->ld_wprev, ab->w_cum_prev, ab->w, ab->ld_w, ab->loc_conv_w,
-                                    ab->loc_lin_w, ab->v, ab->dctx, ab->ld_dctx, ab->n_dctx, ab->dw_direct, ab->ld_dw, ab->n_dw, ab->dcum,
+                                    ab->loc_lin_w, ab->v, t.dctx, t.ld_dctx, AB_NDCTX, ab->dw_direct, ab->ld_dw, ab->n_dw, ab->dcum,
                                     ab->dcum_add, ab->ld_dcum_add, ab->dpq, &ab->dpq_t16, ab->dhist, ab->ds_t, ab->loc_t, ab->dloc_t,
                                     ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in, ab->B, ab->L, ab->A, ab->E, ab->F, ab->K, stream);
     }
@@ -1858,6 +1894,36 @@ static int pk_hist_sum_impl(const float* packed_w, const st_t16_view* x, int K, 
     return 0;
 }
 
+// st_skinny_partial_attn_bwd's product with an st_attn_hist_job beside it instead of the attention backward
+extern "C" int st_skinny_partial_attn_hist(const float* packed_w, const st_t16_view* x, int K, float* part, int S, int B, int N,
+                                           const st_attn_hist_job* hj, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(packed_w && x && x->base && part && hj && K > 0 && K % 16 == 0 && S >= 1 && (K / 16) % S == 0 && B > 16 && B <= 32 && N > 0 && N % 32 == 0 &&
+                 st_aligned16(part), "st_skinny_partial_attn_hist: needs 16 < B <= 32 (two batch tiles), N %% 32 == 0, K %% (16 S) == 0 (B=%d N=%d K=%d S=%d)", B, N, K, S);
+    ST_CHECK_ARG(hj->dloc_part && hj->parts >= 1 && hj->parts <= 4 && hj->loc_conv_w && hj->w_cum_prev && hj->dloc_t && hj->hist_t && hj->dhist &&
+                 hj->B > 0 && hj->L > 0 && hj->F > 0 && hj->K > 0 && (hj->K & 1) && hj->K <= 31, "st_skinny_partial_attn_hist: bad history job (odd K <= 31)");
+    PkPartArgs p;
+    p.w = reinterpret_cast<const f32x4*>(packed_w); p.w_kbs = K / 16;
+    p.x = reinterpret_cast<const f32x4*>(x->base) + (size_t)x->kb0 * 64; p.x_kbs = x->kb_stride;
+    p.KB = K / 16; p.S = S; p.B = B; p.N = N; p.part = part;
+    AbHistArgs h;
+    memset(&h, 0, sizeof(h));
+    h.dloc_part = hj->dloc_part; h.parts = hj->parts; h.loc_conv_w = hj->loc_conv_w; h.w_prev = hj->w_prev; h.ld_wprev = hj->ld_wprev;
+    h.w_cum_prev = hj->w_cum_prev; h.dloc_t = hj->dloc_t; h.hist_t = hj->hist_t; h.dhist = hj->dhist; h.dcum = hj->dcum;
+    h.B = hj->B; h.L = hj->L; h.F = hj->F; h.K = hj->K;
+    const size_t lds = (size_t)ab_hist_lds_floats(h.L, h.F, h.K) * sizeof(float);
+    ST_CHECK_ARG(lds + 8 * 4 * 64 * sizeof(f32x4) <= 160 * 1024, "st_skinny_partial_attn_hist: L=%d needs %zu bytes of LDS", h.L, lds);
+    auto kern = pk_part_hist_kernel<8, 2>;
+    static size_t lds_set = 0;
+    if (lds > 32 * 1024 && lds > lds_set) {
+        ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(h.B + (N / 32) * S), dim3(8 * 64), lds, (hipStream_t)stream, p, h.B, h);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
 // K-split partial product part[s] (B, N) = x[:, K-range s] . W[:, K-range s]^T (see pk_part_body; B <= 32, N % 32 == 0, (K / 16) % S == 0) with the
 // split attention backward of a BPTT step (ab->parts = 2, as st_skinny_linear_packed_lstm_bwd_attn_bwd) beside it in ONE launch; ab NULL: the
 // partial product alone.  The caller adds the slabs with an st_partial_sum_job in its next launch.
@@ -1877,10 +1943,7 @@ extern "C" int st_skinny_partial_attn_bwd(const float* packed_w, const st_t16_vi
         return 0;
     }
     AbArgs t;
-    if (ab_fill(t, &ab->dpq_t16, ab->pq, ab->pm, ab->memory, ab->w_prev, ab->ld_wprev, ab->w_cum_prev, ab->w, ab->ld_w, ab->loc_conv_w,
-                ab->loc_lin_w, ab->v, ab->dctx, ab->ld_dctx, ab->n_dctx, ab->dw_direct, ab->ld_dw, ab->n_dw, ab->dcum, ab->dcum_add,
-                ab->ld_dcum_add, ab->dpq, ab->dhist, ab->ds_t, ab->loc_t, ab->dloc_t, ab->hist_t, ab->dctx_t, ab->dv_t, ab->s_in,
-                ab->B, ab->L, ab->A, ab->E, ab->F, ab->K)) return -1;
+    if (ab_fill_job(t, ab)) return -1;
     const size_t red_bytes = (size_t)8 * 4 * 64 * sizeof(f32x4);
     ST_CHECK_ARG(ab->parts == 2 && ab->dloc_part && !ab->dcum_add && t.s_in && ab_lds_bytes(t, true, 2) + red_bytes <= 160 * 1024 && t.A % 32 == 0 &&
                  AB_THREADS % (t.A / 2) == 0 && AB_THREADS / (t.A / 2) >= 4, "st_skinny_partial_attn_bwd: the attention job must be the two-part form (parts = 2, dloc_part, S kept, "

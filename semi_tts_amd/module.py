@@ -365,6 +365,7 @@ class Decoder(nn.Module):
         self.attn_split_positions = 43
         self.bwd_fuse_pointwise = True   # training (teacher forcing): the cells' pointwise backward in the epilogues of the loop's products
         self.bwd_overlap_attn = True     # ... and the decoder cell's product of step t-1 beside the attention backward of step t (one launch)
+        self.bwd_dxq_splits = int(os.environ.get('ST_DXQ_SPLITS', '4'))   # ... and the query cell's product likewise (0 = whole)
         self.bwd_dxd_splits = int(os.environ.get('ST_DXD_SPLITS', '2'))   # ... with the decoder cell's product of that launch K-split into slabs (0 = whole)
         self.bwd_attn_parts = int(os.environ.get('ST_ATTN_PARTS', '2'))          # ... that attention backward as 2 workgroups per utterance over halves of the attention dims (1 = whole)
         self.fwd_pair_cells = True       # teacher-forced forward: the decoder cell of step t and the query cell of step t+1 in one launch

@@ -39,7 +39,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix peak (256 CUs x 256 F
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 # PMC pass of the dominant kernel (tools/gpu_pmc.sh -> tools/pmc_summary.py): HBM bytes per launch.  bench.py does not
 # measure this itself (PMC counters need their own rocprofv3 passes); the value is quoted WITH its source file.
-TRAFFIC_FILES = ('profiles/r04_pmc_hbm_traffic%s.json', 'profiles/r03_pmc_hbm_traffic%s.json', 'profiles/r02_pmc_hbm_traffic%s.json', 'profiles/r01_pmc_hbm_traffic%s.json')
+TRAFFIC_FILES = ('profiles/r05_pmc_hbm_traffic%s.json', 'profiles/r04_pmc_hbm_traffic%s.json', 'profiles/r03_pmc_hbm_traffic%s.json', 'profiles/r02_pmc_hbm_traffic%s.json', 'profiles/r01_pmc_hbm_traffic%s.json')
 
 
 def decode_step_algorithmic_bytes(Bsz, Lt, dec):

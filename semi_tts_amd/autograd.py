@@ -96,10 +96,10 @@ class _ConvFn(Function):
             dx = ops.gemm(dyp, ops.cat_params([w.detach()], transposed=True, pad_to=Np)).view(x.shape)
             x2 = _rows(xw)
             if has_b and ctx.needs_input_grad[2]:
-                dwp, dbp = ops.gemm_wgrad(dyp, x2, with_db=True)
+                dwp, dbp = ops.gemm_wgrad(dyp, x2, with_db=True, later=ops.grad_first(w, b), params=(w, b))
                 db = dbp[:N]
             else:
-                dwp = ops.gemm_wgrad(dyp, x2)
+                dwp = ops.gemm_wgrad(dyp, x2, later=ops.grad_first(w), params=(w,))
             dw = dwp[:N]
             dres = dy if has_res and ctx.needs_input_grad[3] else None
             return dx, dw, db, dres, None, None, None, None, None, None
@@ -111,10 +111,11 @@ class _ConvFn(Function):
         # (the parameter gradients are written where ops.grad_slot says: under data parallelism, into their all-reduce bucket)
         if db_in_wgrad:
             dw, db = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, with_db=True,
-                                    out=ops.grad_slot(w), db_out=ops.grad_slot(b))
+                                    out=ops.grad_slot(w), db_out=ops.grad_slot(b), later=ops.grad_first(w, b), params=(w, b))
             dw = dw.view(w.shape)
         elif ctx.needs_input_grad[1]:
-            dw = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, out=ops.grad_slot(w)).view(w.shape)
+            dw = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, out=ops.grad_slot(w), later=ops.grad_first(w),
+                                params=(w,)).view(w.shape)
         dres = dy if has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None, None, None, None, None
 
@@ -172,7 +173,8 @@ class _ConvGroupFn(Function):
             elif want_b:
                 dbs[k] = ops.colsum(_rows(dpre), out=ops.grad_slot(bs[k]))
         if wjobs:
-            for (k, _), (dw, db) in zip(wjobs, ops.gemm_wgrad_batch([j for _, j in wjobs])):
+            wpar = tuple(ws[k] for k, _ in wjobs) + tuple(bs[k] for k, j in wjobs if j['with_db'])
+            for (k, _), (dw, db) in zip(wjobs, ops.gemm_wgrad_batch([j for _, j in wjobs], later=ops.grad_first(*wpar), params=wpar)):
                 dws[k], dbs[k] = dw.view(ws[k].shape), db
         if dx is not None:
             dx = dx.view(x.shape)
@@ -446,6 +448,7 @@ class _HighwayLayerFn(Function):
         ht = ops.gemm(x2, ops.cat_params([Hw, Tw]), bias=ops.cat_params([Hb, Tb]))
         ctx.save_for_backward(x2, ht, Hw, Tw)
         ctx.lead = lead
+        ctx.hb = (Hb, Tb)                # (identity only: which parameters the bias gradients belong to)
         return ops.highway_ht_fwd(ht, x2).view(*lead, -1)
 
     @staticmethod
@@ -455,7 +458,7 @@ class _HighwayLayerFn(Function):
         dht, dxd = ops.highway_ht_bwd(dy.contiguous().view(-1, Cn), ht, x2)
         # dx = dht [W_H ; W_T] + dy (1 - T): the weight of that product is the (C, 2C) "Linear weight" [W_H^T | W_T^T]
         dx = ops.gemm(dht, ops.cat_params([Hw.detach(), Tw.detach()], transposed=True), res=dxd)
-        dw, db = ops.gemm_wgrad(dht, x2, with_db=True)
+        dw, db = ops.gemm_wgrad(dht, x2, with_db=True, later=ops.grad_first(Hw, Tw, *ctx.hb), params=(Hw, Tw) + ctx.hb)
         return dx.view(*ctx.lead, Cn), dw[:Cn], db[:Cn], dw[Cn:], db[Cn:]
 
 
@@ -608,11 +611,13 @@ class _BiLstmFn(Function):
             dxps = ops.lstm_seq2_bwd(dout, (g_f, g_b), (c_f, c_b), None, (w_hh_f, w_hh_b))
         else:
             dxps = ops.lstm_seq2_bwd(dout, (g_f, g_b), (c_f, c_b), (ops.dx_weight(w_hh_f.detach())[0], ops.dx_weight(w_hh_b.detach())[0]))
+        par = ((w_hh_f, b_hh_f), (w_hh_b, b_hh_b))
         for d in range(2):
             dxp = dxps[d]
             # h_{t-1} of the forward direction is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1 / -1
-            dw = ops.gemm_wgrad(dxp, out[:, :, d * H:(d + 1) * H], 1, 1 if d == 0 else -1, out=ops.grad_slot((w_hh_f, w_hh_b)[d]))
-            db = ops.colsum(_rows(dxp), out=ops.grad_slot((b_hh_f, b_hh_b)[d]))
+            # (the bias gradient = the column sums of dxp rides in the product's launches; the product itself may wait: ops.flush_wgrads)
+            dw, db = ops.gemm_wgrad(dxp, out[:, :, d * H:(d + 1) * H], 1, 1 if d == 0 else -1, out=ops.grad_slot((w_hh_f, w_hh_b)[d]),
+                                    with_db=True, db_out=ops.grad_slot((b_hh_f, b_hh_b)[d]), later=ops.grad_first(*par[d]), params=par[d])
             res.append((dxp, dw, db))
         return res[0][0], res[1][0], res[0][1], res[0][2], res[1][1], res[1][2]
 
@@ -641,8 +646,10 @@ class _LstmFn(Function):
     def backward(ctx, dout):
         out, w_hh, g, c, b_hh = ctx.saved_tensors
         dxp = ops.lstm_seq_bwd(dout.contiguous(), 0, g, c, ops.dx_weight(w_hh.detach())[0], False)
-        dw = ops.gemm_wgrad(dxp, out, 1, 1, out=ops.grad_slot(w_hh))      # h_{t-1} is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1
-        return dxp, dw, ops.colsum(_rows(dxp), out=ops.grad_slot(b_hh))
+        # h_{t-1} is out[t-1] (zero at t = 0): a 1-tap "conv" with pad +1
+        dw, db = ops.gemm_wgrad(dxp, out, 1, 1, out=ops.grad_slot(w_hh), with_db=True, db_out=ops.grad_slot(b_hh),
+                                later=ops.grad_first(w_hh, b_hh), params=(w_hh, b_hh))
+        return dxp, dw, db
 
 
 def lstm(xp, w_hh, b_hh):
@@ -667,10 +674,12 @@ class _BiGruFn(Function):
         out, tape, w_hh_f, w_hh_b, b_hh_f, b_hh_b = ctx.saved_tensors
         H = w_hh_f.shape[1]
         dgi_f, dgi_b, dgh_f, dgh_b = ops.gru_seq_bwd(dout.contiguous(), out, tape, w_hh_f, w_hh_b)
-        dw_f = ops.gemm_wgrad(dgh_f, out[:, :, :H], 1, 1, out=ops.grad_slot(w_hh_f))
-        dw_b = ops.gemm_wgrad(dgh_b, out[:, :, H:], 1, -1, out=ops.grad_slot(w_hh_b))
-        return (dgi_f, dgi_b, dw_f, ops.colsum(_rows(dgh_f), out=ops.grad_slot(b_hh_f)), dw_b,
-                ops.colsum(_rows(dgh_b), out=ops.grad_slot(b_hh_b)))
+        par = (w_hh_f, b_hh_f, w_hh_b, b_hh_b)
+        (dw_f, db_f), (dw_b, db_b) = ops.gemm_wgrad_batch([
+            dict(dc=dgh_f, a=out[:, :, :H], KT=1, pad=1, out=ops.grad_slot(w_hh_f), with_db=True, db_out=ops.grad_slot(b_hh_f)),
+            dict(dc=dgh_b, a=out[:, :, H:], KT=1, pad=-1, out=ops.grad_slot(w_hh_b), with_db=True, db_out=ops.grad_slot(b_hh_b))],
+            later=ops.grad_first(*par), params=par)
+        return dgi_f, dgi_b, dw_f, db_f, dw_b, db_b
 
 
 def bigru(gi_f, gi_b, w_hh_f, b_hh_f, w_hh_b, b_hh_b):
@@ -881,12 +890,15 @@ class _DecoderFn(Function):
         dwd_ih, dwd_hh, dbd, dbd2 = ops.gemm_wgrad_split(dgd2, XD.view(-1, XDw), E + Q, d_w_ih, d_w_hh, d_b_ih, d_b_hh, with_db=True)
         # three more products over the tapes in one launch (+ one slab sum): proj (+) gate, the query projection, W_l (sums over the steps of
         # the per-step tape slices)
+        tail_par = (proj_w, proj_b, gate_w, gate_b, wq, wl)
         (dwpg, dbpg), (dwq_attn, _), (dwl, _) = ops.gemm_wgrad_batch([
             dict(dc=dY2, a=XO.view(-1, XOw), with_db=True),
             dict(dc=dpq.view(-1, A), a=hq_all, out=ops.grad_slot(wq)),
-            dict(dc=ds_tape.view(-1, A), a=loc_tape.view(-1, F))])                          # (A, F)
+            dict(dc=ds_tape.view(-1, A), a=loc_tape.view(-1, F))],                              # (A, F)
+            later=ops.grad_first(*tail_par), params=tail_par)
         dv = ops.colsum(dv_tape.view(-1, A)).view(v.shape)
-        dwc = ops.gemm_wgrad(dloc_tape.view(steps * B, L, F), hist_tape.view(steps * B, L, 2), K, (K - 1) // 2)   # (F, 2, K)
+        dwc = ops.gemm_wgrad(dloc_tape.view(steps * B, L, F), hist_tape.view(steps * B, L, 2), K, (K - 1) // 2,
+                             later=ops.grad_first(wc), params=(wc,))   # (F, 2, K)
         dpm = ops.colsum(ds_tape.view(steps, -1)).view(B, L, A)
         dmem = torch.empty(B, L, E, **f32)
         _lib.check(lib.st_attn_dmem(ops._p(align), ops._p(dctx_tape), ops._p(dmem), B, steps, L, E, ops.stream_handle()),
@@ -898,6 +910,7 @@ class _DecoderFn(Function):
         # prenet weights on the own-output path: dW1 = d2^T pre1, dW0 = dp1^T mel over the steps / rows that fed back
         dpre_w0 = dpre_w1 = None
         if own:
+            ops.grad_first(pre_w0, pre_w1)     # (announced: the teacher path's products of the same weights must not be queued behind these)
             mel_tb = z(steps, Bp, in_dim)                       # mel_t in (step, utterance) row order
             ops.copy3d(mel_tb.permute(1, 0, 2)[:B], mel_fwd.view(B, steps, in_dim), B, steps, in_dim)
             dpre_w1 = ops.gemm_wgrad(d2_tape.view(-1, P), pre1_nat.view(-1, P))

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) { tn
 // Several weight-gradient products in ONE launch (st_gemm_wgrad_batch): the K convolutions of the CBHG bank (80 x 80 x k matrices: 4 k
 // tiles each -- eight launches of 10 ... 36 us that each leave most of the chip idle) or the two directions of a recurrent layer.
 // blockIdx.x runs through the jobs' own (x, y, z) grids one after the other.
-constexpr int TN_MAXJ = 8;
+constexpr int TN_MAXJ = 16;
 struct TnBatch { TnArgs g[TN_MAXJ]; int blk0[TN_MAXJ + 1]; int gx[TN_MAXJ], gy[TN_MAXJ]; int n; };
 
 template <int TM>
@@ -1192,9 +1192,9 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     return 0;
 }
 
-// Several st_gemm_wgrad[_db] (no pooling, no accumulate) as ONE product launch + ONE slab-sum launch when every job takes the LDS-DMA form
-// with 64-tiles (the small matrices this is for); otherwise one after the other.  Every job keeps the slab count and the summation order it
-// has on its own: the results are bit for bit those of the separate calls.
+// Several st_gemm_wgrad[_db] (no pooling, no accumulate): the jobs that take the LDS-DMA form with 64-tiles (the small matrices this is
+// for) leave as ONE product launch + ONE slab-sum launch per group of up to TN_MAXJ, the others one after the other.  Every job keeps the
+// slab count and the summation order it has on its own: the results are bit for bit those of the separate calls.
 static size_t tn_ws4(const st_wgrad_job& j) { return (st_gemm_wgrad_workspace_floats(j.Bn, j.Tout, j.Cin, j.N, j.KT) + 3) / 4 * 4; }
 
 extern "C" size_t st_gemm_wgrad_batch_workspace_floats(const st_wgrad_job* jobs, int n) {
@@ -1207,17 +1207,36 @@ extern "C" int st_gemm_wgrad_batch(const st_wgrad_job* jobs, int n, float* ws, v
     (void)hipGetLastError();
     ST_CHECK_ARG(jobs && n > 0 && ws, "st_gemm_wgrad_batch: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    bool batch = n <= TN_MAXJ && n > 1;
     TnBatch tb;
     SumBatch sb;
-    memset(&tb, 0, sizeof(tb));
-    memset(&sb, 0, sizeof(sb));
+    int m = 0, blocks = 0, sblocks = 0, nsum = 0, gi[TN_MAXJ];
+    size_t goff[TN_MAXJ];
+    auto reset = [&] { memset(&tb, 0, sizeof(tb)); memset(&sb, 0, sizeof(sb)); m = blocks = sblocks = nsum = 0; };
+    auto single = [&](int i, size_t off) {
+        const st_wgrad_job& j = jobs[i];
+        return tn_impl(j.dC, j.lddc, j.dcoff, j.A, j.lda, j.dW, j.db, ws + off, j.Bn, j.Tin, j.Tout, j.Cin, j.N, j.KT, j.pad, 0, 0, stream);
+    };
+    auto flush = [&]() -> int {
+        if (m == 1) { const int rc = single(gi[0], goff[0]); reset(); return rc; }
+        if (m == 0) return 0;
+        tb.blk0[m] = blocks; tb.n = m;
+        hipLaunchKernelGGL((tn_dma_batch_kernel<64>), dim3(blocks), dim3(TN_THREADS), (size_t)3 * 2 * 32 * 64 * sizeof(float), st, tb);
+        ST_LAUNCH_CHECK();
+        if (nsum) {
+            sb.blk0[nsum] = sblocks; sb.n = nsum;
+            hipLaunchKernelGGL(sum_partials_batch_kernel, dim3(sblocks), dim3(256), 0, st, sb);
+            ST_LAUNCH_CHECK();
+        }
+        reset();
+        return 0;
+    };
+    reset();
     size_t off = 0;
-    int blocks = 0, sblocks = 0, nsum = 0;
-    for (int i = 0; i < n && batch; ++i) {
+    for (int i = 0; i < n; ++i) {
         const st_wgrad_job& j = jobs[i];
         ST_CHECK_ARG(j.dC && j.A && j.dW && j.Bn > 0 && j.Tin > 0 && j.Tout > 0 && j.Cin > 0 && j.N > 0 && j.KT > 0, "st_gemm_wgrad_batch: bad job %d", i);
-        TnArgs& g = tb.g[i];
+        TnArgs g;
+        memset(&g, 0, sizeof(g));
         g.dC = j.dC; g.lddc = j.lddc; g.dcoff = j.dcoff; g.A = j.A; g.lda = j.lda;
         g.Bn = j.Bn; g.Tin = j.Tin; g.Tout = j.Tout; g.Cin = j.Cin; g.N = j.N; g.KT = j.KT; g.pad = j.pad; g.pool_prev = 0;
         g.M = j.Bn * j.Tout;
@@ -1229,42 +1248,31 @@ extern "C" int st_gemm_wgrad_batch(const st_wgrad_job* jobs, int n, float* ws, v
         g.vecx = st_aligned16(j.dC) && (j.lddc % 4 == 0) && (j.dcoff % 4 == 0);
         g.vecy = st_aligned16(j.A) && (j.lda % 4 == 0);
         const bool dma = !g.fold && g.vecx && g.vecy && j.N % 4 == 0 && j.Cin % 4 == 0 && g.rows_per_z % 32 == 0;
-        if (!dma || tn_tile(j.Cin, j.N, j.KT) != 64 || per >= (1ull << 32)) { batch = false; break; }
-        float* wsj = ws + off;
-        const bool direct = Z == 1;
-        g.part = direct ? j.dW : wsj;
-        if (j.db) g.db_part = direct ? j.db : wsj + (size_t)Z * per;
-        tb.gx[i] = (j.N + 63) / 64; tb.gy[i] = ((j.Cin + 63) / 64) * j.KT;
-        tb.blk0[i] = blocks;
-        blocks += tb.gx[i] * tb.gy[i] * Z;
-        if (!direct) {
-            sb.part[nsum] = wsj; sb.out[nsum] = j.dW; sb.part_b[nsum] = j.db ? wsj + (size_t)Z * per : wsj; sb.out_b[nsum] = j.db;
-            sb.per[nsum] = (unsigned)per; sb.nb[nsum] = j.db ? j.N : 0; sb.Z[nsum] = Z; sb.acc[nsum] = 0;
-            sb.blk0[nsum] = sblocks;
-            sblocks += blocks_for(per + (j.db ? j.N : 0));
-            ++nsum;
+        if (!dma || tn_tile(j.Cin, j.N, j.KT) != 64 || per >= (1ull << 32)) {
+            const int rc = single(i, off);
+            if (rc) return rc;
+        } else {
+            float* wsj = ws + off;
+            const bool direct = Z == 1;
+            g.part = direct ? j.dW : wsj;
+            if (j.db) g.db_part = direct ? j.db : wsj + (size_t)Z * per;
+            tb.g[m] = g;
+            tb.gx[m] = (j.N + 63) / 64; tb.gy[m] = ((j.Cin + 63) / 64) * j.KT;
+            tb.blk0[m] = blocks;
+            blocks += tb.gx[m] * tb.gy[m] * Z;
+            if (!direct) {
+                sb.part[nsum] = wsj; sb.out[nsum] = j.dW; sb.part_b[nsum] = j.db ? wsj + (size_t)Z * per : wsj; sb.out_b[nsum] = j.db;
+                sb.per[nsum] = (unsigned)per; sb.nb[nsum] = j.db ? j.N : 0; sb.Z[nsum] = Z; sb.acc[nsum] = 0;
+                sb.blk0[nsum] = sblocks;
+                sblocks += blocks_for(per + (j.db ? j.N : 0));
+                ++nsum;
+            }
+            gi[m] = i; goff[m] = off;
+            if (++m == TN_MAXJ) { const int rc = flush(); if (rc) return rc; }
         }
         off += tn_ws4(j);
     }
-    if (!batch) {
-        off = 0;
-        for (int i = 0; i < n; ++i) {
-            const st_wgrad_job& j = jobs[i];
-            int rc = tn_impl(j.dC, j.lddc, j.dcoff, j.A, j.lda, j.dW, j.db, ws + off, j.Bn, j.Tin, j.Tout, j.Cin, j.N, j.KT, j.pad, 0, 0, stream);
-            if (rc) return rc;
-            off += tn_ws4(j);
-        }
-        return 0;
-    }
-    tb.blk0[n] = blocks; tb.n = n;
-    hipLaunchKernelGGL((tn_dma_batch_kernel<64>), dim3(blocks), dim3(TN_THREADS), (size_t)3 * 2 * 32 * 64 * sizeof(float), st, tb);
-    ST_LAUNCH_CHECK();
-    if (nsum) {
-        sb.blk0[nsum] = sblocks; sb.n = nsum;
-        hipLaunchKernelGGL(sum_partials_batch_kernel, dim3(sblocks), dim3(256), 0, st, sb);
-        ST_LAUNCH_CHECK();
-    }
-    return 0;
+    return flush();
 }
 
 extern "C" int st_gemm_wgrad(const float* dC, int lddc, int dcoff, const float* A, int lda, float* dW, float* ws,

@@ -4,6 +4,7 @@ PyTorch is used only for device memory and stream handles: every function here t
 contiguous fp32 (or int64 index) CUDA/HIP tensors, passes raw device pointers to
 libsemitts_hip.so and returns.  There is no eager/CPU fallback -- a CPU tensor raises.
 """
+import os
 import ctypes as C
 from contextlib import contextmanager
 
@@ -855,10 +856,114 @@ def gemm_wgrad_split(dc, a, split, w0=None, w1=None, b0=None, b1=None, with_db=F
     return (d0, d1, db, dbd) if with_db else (d0, d1)
 
 
-def gemm_wgrad_batch(jobs):
+# Weight gradients are leaves of the backward pass: nothing later in it reads them.  Inside an autograd backward the products marked
+# `later=True` are therefore only QUEUED (their output tensors exist at once, and are what the Function returns); the queue leaves as
+# batched launches (st_gemm_wgrad_batch: one product launch + one slab-sum launch per 16 small products instead of two launches each,
+# and small products share the chip) when it is full, before a gradient bucket is handed to the all-reduce (parallel.GradReducer),
+# and from an engine callback at the end of the backward pass -- before `backward()` returns.  ST_WGRAD_DEFER=0: every product at once.
+# A queued product must be the ONLY thing that has touched its parameter's gradient when it finally runs (it overwrites): the sites ask
+# `grad_first(*params)` -- True when this is the first gradient contribution to each of them in this backward pass -- and queue only
+# then; a later contribution to a parameter whose first one is still queued (the prenet's weights under partial teacher forcing: the
+# decoder's own-output path and the teacher path) sends the queue out first and runs at once, so autograd's in-place accumulate finds
+# both written.
+_WQ = []
+_WQ_TASK = -1
+_WQ_PENDING = set()
+_G_TASK = -1
+_G_COUNT = {}
+WGRAD_DEFER = os.environ.get('ST_WGRAD_DEFER', '1') != '0'
+WGRAD_QMAX = 16
+
+
+def _graph_task():
+    f = getattr(torch._C, '_current_graph_task_id', None)
+    return f() if f is not None else -1
+
+
+def flush_wgrads():
+    """launch the queued weight-gradient products (a no-op when there are none)"""
+    global _WQ
+    if _WQ:
+        jobs, _WQ = _WQ, []
+        _WQ_PENDING.clear()
+        gemm_wgrad_batch(jobs)
+
+
+def grad_first(*params):
+    """announce a gradient contribution to each of `params` (None entries ignored) by the calling backward function; True when it is
+    the first one to every one of them in this backward pass and all of them are leaves (the returned gradient goes straight to
+    `.grad`, nothing reads it on the way) -- the condition for handing the product to the queue (`later=`).  Outside a backward
+    pass: False."""
+    global _G_TASK
+    tid = _graph_task() if WGRAD_DEFER else -1
+    if tid == -1:
+        return False
+    if tid != _G_TASK:
+        _G_TASK = tid
+        _G_COUNT.clear()
+    first = True
+    for q in params:
+        if q is None:
+            continue
+        k = q.data_ptr()
+        n = _G_COUNT.get(k, 0) + 1
+        _G_COUNT[k] = n
+        if n > 1:
+            first = False
+            if k in _WQ_PENDING:
+                flush_wgrads()
+        if not q.is_leaf:                 # (computed from parameters by torch ops: their backward reads the gradient at once)
+            first = False
+    return first
+
+
+def _queue_wgrads(jobs, params=()):
+    """jobs (dicts of gemm_wgrad_batch, outputs allocated) onto the queue; False outside a backward pass (the caller launches them)"""
+    global _WQ_TASK
+    tid = _graph_task() if WGRAD_DEFER else -1
+    if tid == -1:
+        return False
+    if _WQ and _WQ_TASK != tid:
+        _WQ.clear()                       # (left by a backward pass that raised: their tensors belong to a step that is gone)
+        _WQ_PENDING.clear()
+    if not _WQ:
+        _WQ_TASK = tid
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+    _WQ.extend(jobs)
+    _WQ_PENDING.update(q.data_ptr() for q in params if q is not None)
+    if len(_WQ) >= WGRAD_QMAX:
+        flush_wgrads()
+    return True
+
+
+def _alias(t):
+    """a second tensor object over the same memory: autograd adopts a returned gradient as `.grad` only when nobody else holds that
+    OBJECT (otherwise it clones it on the spot -- here before the queued product has written it)"""
+    return None if t is None else t.view(t.shape)
+
+
+def _wgrad_job_outputs(j):
+    """fill in `out` / `db_out` of a job dict (fresh tensors where the caller named none); returns (dW, db or None)"""
+    dc, a = j['dc'], j['a']
+    Cin = a.shape[-1]
+    KT = int(j.get('KT', 1))
+    N = j.get('N') if j.get('N') is not None else dc.shape[-1]
+    if j.get('out') is None:
+        j['out'] = torch.empty((N, Cin, KT) if KT > 1 else (N, Cin), device=a.device, dtype=torch.float32)
+    if j.get('with_db') and j.get('db_out') is None:
+        j['db_out'] = torch.empty(N, device=a.device, dtype=torch.float32)
+    return j['out'], (j['db_out'] if j.get('with_db') else None)
+
+
+def gemm_wgrad_batch(jobs, later=False, params=()):
     """[gemm_wgrad(dc, a, KT, pad, Bn=, Tin=, Tout=, N=, out=, with_db=, db_out=) for each job dict] as ONE product launch and ONE slab-sum
-    launch where the kernels allow (st_gemm_wgrad_batch: bit for bit the separate calls); returns [(dW, db or None)]"""
+    launch per 16 where the kernels allow (st_gemm_wgrad_batch: bit for bit the separate calls); returns [(dW, db or None)].
+    later: inside a backward pass the jobs only join the queue (see above); pass `later=grad_first(*params)` and the same `params`."""
     from ._lib import StWgradJob
+    if later:
+        outs = [_wgrad_job_outputs(j) for j in jobs]
+        if _queue_wgrads(jobs, params):
+            return [(_alias(dw), _alias(db)) for dw, db in outs]
     lib = _lib.load()
     n = len(jobs)
     arr = (StWgradJob * n)()
@@ -894,10 +999,18 @@ def gemm_wgrad_batch(jobs):
 
 
 def gemm_wgrad(dc, a, KT=1, pad=0, *, Bn=None, Tin=None, Tout=None, dcoff=0, N=None, pool_prev=False, out=None,
-               accumulate=False, with_db=False, db_out=None):
+               accumulate=False, with_db=False, db_out=None, later=False, params=()):
     """dW (N, Cin[, KT]) of C = conv1d/linear(a, W): dc (Bn, Tout, >=dcoff+N) or (M, .), a (Bn, Tin, Cin) or (M, Cin).
     with_db: returns (dW, db) with db = the column sums of dc (the bias gradient), formed inside the same launches.
-    out / db_out: where to write them (grad_slot of the parameters), else fresh tensors."""
+    out / db_out: where to write them (grad_slot of the parameters), else fresh tensors.
+    later (= grad_first(*params), with the same `params`: the parameters whose gradients this writes): inside a backward pass the
+    product may be queued and launched with others (flush_wgrads); the caller must not write to `dc` / `a` afterwards."""
+    if later and WGRAD_DEFER and not pool_prev and not accumulate and dcoff == 0 and _graph_task() != -1:
+        j = dict(dc=dc, a=a, KT=KT, pad=pad, Bn=Bn, Tin=Tin, Tout=Tout, N=N, out=out, with_db=with_db, db_out=db_out)
+        dw, db = _wgrad_job_outputs(j)
+        if _queue_wgrads([j], params):
+            return (_alias(dw), _alias(db)) if with_db else _alias(dw)
+        out, db_out = dw, db
     lib = _lib.load()
     if a.dim() == 3:
         Bn_, Tin_, Cin = a.shape

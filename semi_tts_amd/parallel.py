@@ -335,6 +335,8 @@ class GradReducer:
         return True
 
     def _launch(self, bi, final=False):
+        from . import ops
+        ops.flush_wgrads()          # (weight-gradient products still queued write into these slots: out before the bucket is read)
         if not self._gather(bi, final):
             self._violated = self._violated or 'a bucket closed while one of its gradients was missing'
             self.ready[bi] = False

@@ -52,6 +52,49 @@ def conv_cl_ref(x, w, b, pad, Tout, act, pool_prev=False, res=None, mask=None):
     return y
 
 
+def test_queued_weight_gradients(dev):
+    """Weight-gradient products are queued during a backward pass and leave together (ops.flush_wgrads).  A layer applied TWICE gives
+    its weight two contributions: the second must find the first one written (it flushes the queue and runs at once) -- and a chain
+    of different layers (each queued) must give the gradients of the unqueued run (ST_WGRAD_DEFER=0 semantics: later=False), bit for bit."""
+    from semi_tts_amd import autograd as AG, ops
+    M, C = 512, 64
+    x1, x2 = rnd(M, C, seed=1), rnd(M, C, seed=2)
+    ws = [rnd(C, C, scale=C ** -0.5, seed=10 + i) for i in range(5)]
+    bs = [rnd(C, seed=20 + i) for i in range(5)]
+    dy = rnd(M, C, seed=3)
+
+    def run(defer):
+        old = ops.WGRAD_DEFER
+        ops.WGRAD_DEFER = defer
+        try:
+            wd = [w.to(dev).requires_grad_() for w in ws]
+            bd = [b.to(dev).requires_grad_() for b in bs]
+            a, b2 = x1.to(dev), x2.to(dev)
+            for i in range(5):
+                a = AG.linear(a, wd[i], bd[i], act='relu')
+            b2 = AG.linear(b2, wd[0], bd[0], act='relu')          # layer 0 again, on another input
+            (a + AG.linear(b2, wd[4], bd[4])).backward(dy.to(dev))   # ... and layer 4
+            assert not ops._WQ, 'the queue must be empty when backward() returns'
+            return [t.grad.clone() for t in wd + bd]
+        finally:
+            ops.WGRAD_DEFER = old
+
+    g1, g0 = run(True), run(False)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+    # against float64
+    wr = [w.double().requires_grad_() for w in ws]
+    br = [b.double().requires_grad_() for b in bs]
+    a, b2 = x1.double(), x2.double()
+    for i in range(5):
+        a = torch.relu(a @ wr[i].t() + br[i])
+    b2 = torch.relu(b2 @ wr[0].t() + br[0])
+    (a + b2 @ wr[4].t() + br[4]).backward(dy.double())
+    worst = max(relerr(g, r.grad) for g, r in zip(g1, wr + br))
+    report('queued_weight_gradients', worst=worst)
+    assert worst < 2e-5
+
+
 @pytest.mark.parametrize('B,T,Cin,N,KT,pad,act,pool', [
     (3, 37, 24, 40, 5, 2, None, False),        # encoder conv
     (2, 50, 80, 80, 4, 2, 'relu', False),      # even-k bank conv (Tout = T+1 and T below)

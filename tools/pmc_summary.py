@@ -88,7 +88,7 @@ def main():
                 kname = name[:60]
     out = dict(kernel=kname, commit=os.environ.get('ST_COMMIT') or _git_head(), FETCH_SIZE_avg_KB=round(vals['FETCH_SIZE'], 1), WRITE_SIZE_avg_KB=round(vals['WRITE_SIZE'], 1),
                correction='MI355X_MICROARCH.md: FETCH_SIZE reads exactly 1/2 of wide coalesced reads on gfx950 -> x2; '
-                          'WRITE_SIZE uncalibrated, taken as is',
+                          'WRITE_SIZE exact; both checked against kernels of known traffic in profiles/r05_pmc_calibration.txt',
                hbm_bytes_per_launch=int(round((2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)),
                algorithmic_bytes_per_launch=ALGO_BYTES,
                source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 2 --warmup 1 '

@@ -532,6 +532,13 @@ int st_lstm_seq2_persist_fwd(const float* const* xproj2, const float* const* w_h
  * W_hh^T launch per time step for the two directions */
 int st_lstm_seq2_bwd(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,
                      const float* const* w_hh_t2, float* const* dxproj2, float* ws, int B, int T, int H, void* stream);
+/* The same loop as ONE launch for all T steps (H % 32 == 0, H <= 256, 2 * H/16 * ceil(B/16) workgroups resident at once): the
+ * 4H x 16 slices of W_hh (the plain (4H, H) parameters, no transposed copy) and the carried dL/dc stay in registers, the gate gradients
+ * of the step before are polled straight out of dxproj2[d] (B, T, 4H), which the entry first fills with a sentinel (every word is
+ * written exactly once).  *status: as st_lstm_seq2_persist_fwd.  ref: backward of nn.LSTM src/module.py:432-438,458-460 */
+int st_lstm_seq2_bwd_persist_supported(int B, int T, int H, int ldd, int dcol0, int dcol1);
+int st_lstm_seq2_bwd_persist(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,
+                             const float* const* w_hh2, float* const* dxproj2, int B, int T, int H, unsigned* status, void* stream);
 int st_skinny_linear_pair_fwd(const st_seg* segs2, float* const* y2, int ldy, int B, int N, void* stream);
 /* st_lstm_seq2_bwd on packed operands: ONE launch per time step for the two directions -- dgates(s) . W_hh with the pointwise backward of
  * step s-1 in its epilogue (st_skinny_linear_packed_lstm_bwd_pair_fwd).  w_hh_t_p16_2: st_pack_weight_t of each direction's W_hh (N = H,

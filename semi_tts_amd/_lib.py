@@ -263,6 +263,8 @@ SIGNATURES = {
     'st_lstm_seq2_fwd': [C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, C.POINTER(I), P, C.POINTER(P), C.POINTER(P), I, I, I, P],
     'st_lstm_seq2_persist_supported': [I, I, I, I, I, I],
     'st_lstm_seq2_persist_fwd': [C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), I, I, I, P, P],
+    'st_lstm_seq2_bwd_persist_supported': [I, I, I, I, I, I],
+    'st_lstm_seq2_bwd_persist': [P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), I, I, I, P, P],
     'st_lstm_seq2_bwd': [P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), P, I, I, I, P],
     'st_skinny_linear_pair_fwd': [P, C.POINTER(P), I, I, I, P],
     'st_lstm_seq2_bwd_packed': [P, I, C.POINTER(I), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), P, P, I, I, I, P],

@@ -892,6 +892,185 @@ extern "C" int st_lstm_seq2_persist_fwd(const float* const* xproj2, const float*
     return 0;
 }
 
+// ---- BPTT of both directions of a bidirectional LSTM layer, ALL time steps in ONE launch ----------------------------------------------------
+// The per-step form (st_lstm_seq2_bwd_packed) is one launch of ~7.4 us per step: dh_rec = dgates(t+1) . W_hh with the pointwise backward
+// of step t in its epilogue.  Here the loop is one launch of (H/16) x ceil(B/16) x 2 workgroups of eight waves, all resident at once.
+// Workgroup (tile, bg, d) owns 16 hidden units and 16 batch rows of direction d: the 4H x 16 slice of W_hh it multiplies by stays in
+// REGISTERS (wave w holds the k-blocks w NKB .. w NKB + NKB - 1 of K = 4H), the carried dL/dc of its 16 x 16 cells stays in
+// registers, and a step is
+//   1. poll the gate gradients of the step processed before (all 4H of them, for the workgroup's 16 batch rows) straight out of the
+//      dxproj tensor the layer returns: the launcher fills it with the sentinel bit pattern and every word is written exactly once with
+//      an agent-scope store -- the data is the flag, exactly as in lstm_seq2_persist_kernel (canary word per producer, then the block
+//      with plain loads, then agent-scope re-reads of what is still missing);
+//   2. NKB x 4 fp32 MFMAs per wave (D[unit][batch] += W_hh[k][unit] dgates[batch][k]), the eight waves' partial sums through LDS, one
+//      LDS-only barrier per step (two buffers);
+//   3. waves 0 .. 3: dh = dout_t + dh_rec, the pointwise backward of one cell per lane (operands requested before the wait), the four
+//      gate gradients to dxproj.
+// What a step exchanges is 4H floats per batch row (the forward exchanges H): 64 KB per workgroup and step at H = 256, spread over eight
+// waves that each issue the same eight 16-byte loads a wave of the forward kernel does.
+namespace {
+struct LbArgs {
+    const float* dout; int ldd; int dcol[2];
+    const float* gates_tape[2]; const float* c_tape[2]; const float* w_hh[2];
+    float* dxp[2];
+    int B, T, H; unsigned* status;
+};
+
+template <int NKB>
+__global__ __launch_bounds__(512) void lstm_seq2_bwd_persist_kernel(const LbArgs a) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    __shared__ f32x4 red[2][8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, bg = blockIdx.y, d = blockIdx.z;
+    const int H = a.H, T = a.T, B = a.B, H4 = 4 * a.H;
+    const int ar = lane & 15, q = lane >> 4;
+    // MFMA A operand: lane supplies row `ar` (unit tile*16 + ar) of the 16 x 4 block, k = 16 kb + 4 q + cc: W_hh[k][unit]
+    f32x4 wreg[NKB];
+#pragma unroll
+    for (int i = 0; i < NKB; ++i) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) wreg[i][cc] = a.w_hh[d][(size_t)(16 * (wave * NKB + i) + 4 * q + cc) * H + tile * 16 + ar];
+    }
+    // B operand: column `ar` = batch row bg*16 + ar (rows past B read row B - 1; their columns of D are dropped), the same k
+    const float* xp = a.dxp[d] + (size_t)min(bg * 16 + ar, B - 1) * T * H4 + 16 * (wave * NKB) + 4 * q;
+    // pointwise role (waves 0 .. 3): D[row = 4 (lane >> 4) + r][col = lane & 15]; wave w takes r = w: unit ju of batch row pb
+    const int pb = bg * 16 + ar, ju = tile * 16 + 4 * q + (wave & 3);
+    const bool pw = pb < B;
+    const int pbc = min(pb, B - 1);
+    const size_t bhs = (size_t)B * H;
+    const float* gp = a.gates_tape[d] + (size_t)pbc * 4 * H + ju;
+    const float* cp_ = a.c_tape[d] + (size_t)pbc * H + ju;
+    const float* dop = a.dout + (size_t)pbc * T * a.ldd + a.dcol[d] + ju;
+    float* dgp = a.dxp[d] + (size_t)pbc * T * H4 + ju;
+    float dcreg = 0.0f;
+    bool dead = false;
+    for (int s = T - 1; s >= 0; --s) {                        // s = processing index of the forward
+        const int t = d ? T - 1 - s : s, tp = d ? t + 1 : t - 1, tn = d ? t - 1 : t + 1;
+        // the tapes and dout of this step do not depend on the recurrence: in flight during the wait
+        float g4[4], c4, cp4, do4;
+        if (wave < 4) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) g4[g] = gp[(size_t)t * 4 * bhs + g * H];
+            c4 = cp_[(size_t)t * bhs];
+            cp4 = cp_[(size_t)(s > 0 ? tp : t) * bhs];
+            do4 = dop[(size_t)t * a.ldd];
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (s < T - 1) {
+            f32x4 x[NKB];
+            bool ok = false;
+            const int spins = dead ? 1 : LP_SPINS;
+            // (a) one canary word per producer workgroup of this wave's K range (batch row bg*16, first unit of the block)
+            for (int sp = 0; sp < spins; ++sp) {
+                const int c = min(lane, NKB - 1);
+                gu32* cw = (gu32*)(a.dxp[d] + ((size_t)(bg * 16) * T + tn) * H4 + 16 * (wave * NKB + c));
+                const bool mine = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != LP_SENTINEL;
+                if (__all(mine)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // (b) the block itself with plain loads; a word that still holds the sentinel sends the wave to (c)
+            {
+#pragma unroll
+                for (int i = 0; i < NKB; ++i) x[i] = st_ld4(xp + (size_t)tn * H4 + 16 * i);
+                unsigned bad = 0;
+#pragma unroll
+                for (int i = 0; i < NKB; ++i) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bad |= (unsigned)(__float_as_uint(x[i][c]) == LP_SENTINEL);
+                }
+                ok = __all(bad == 0);
+            }
+            // (c) agent-scope re-reads of the block until it is complete
+            for (int sp = 0; sp < spins && !ok; ++sp) {
+                unsigned bad = 0;
+#pragma unroll
+                for (int i = 0; i < NKB; ++i) {
+                    gu64* g64 = (gu64*)(xp + (size_t)tn * H4 + 16 * i);
+                    const unsigned long long lo = __hip_atomic_load(g64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long hi = __hip_atomic_load(g64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned u0 = (unsigned)lo, u1 = (unsigned)(lo >> 32), u2 = (unsigned)hi, u3 = (unsigned)(hi >> 32);
+                    bad |= (unsigned)(u0 == LP_SENTINEL) | (unsigned)(u1 == LP_SENTINEL) | (unsigned)(u2 == LP_SENTINEL) | (unsigned)(u3 == LP_SENTINEL);
+                    x[i] = f32x4{__uint_as_float(u0), __uint_as_float(u1), __uint_as_float(u2), __uint_as_float(u3)};
+                }
+                ok = __all(bad == 0);
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok && !dead) {
+                dead = true;       // (a word still holding the sentinel is a NaN: the rows of this workgroup are poisoned from here on)
+                if (lane == 0 && a.status) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < NKB; ++i) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i][cc], x[i][cc], acc, 0, 0, 0);
+            }
+        }
+        float* rb = reinterpret_cast<float*>(red[s & 1]);          // [wave][r][lane]: written and read without bank conflicts
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rb[(wave * 4 + r) * 64 + lane] = acc[r];
+        st_lds_barrier();
+        if (wave < 4) {
+            float dh = do4;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dh += rb[(w * 4 + wave) * 64 + lane];
+            const float gi = g4[0], gf = g4[1], gg = g4[2], go = g4[3];
+            const float tc = st_tanh_fast(c4);                          // (the function the forward applied to this c)
+            const float dc = dcreg + dh * go * (1.0f - tc * tc);
+            float dg[4];
+            dg[0] = dc * gg * gi * (1.0f - gi);
+            dg[1] = s > 0 ? dc * cp4 * gf * (1.0f - gf) : 0.0f;
+            dg[2] = dc * gi * (1.0f - gg * gg);
+            dg[3] = dh * tc * go * (1.0f - go);
+            dcreg = dc * gf;
+            if (pw) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v = dg[g];
+                    const unsigned u = v != v ? 0x7FC00000u : __float_as_uint(v);      // (a NaN must not look like the sentinel)
+                    __hip_atomic_store((gu32*)(dgp + (size_t)t * H4 + g * H), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int st_lstm_seq2_bwd_persist_supported(int B, int T, int H, int ldd, int dcol0, int dcol1) {
+    const int nkb = H / 32;
+    return B > 0 && T > 0 && H > 0 && H % 32 == 0 && (nkb == 1 || nkb == 2 || nkb == 4 || nkb == 8) && ldd % 4 == 0 && dcol0 % 4 == 0 &&
+           dcol1 % 4 == 0 && dcol0 >= 0 && dcol1 >= 0 && ldd >= dcol0 + H && ldd >= dcol1 + H && 2 * (H / 16) * ((B + 15) / 16) <= st_device_cus();
+}
+
+extern "C" int st_lstm_seq2_bwd_persist(const float* dout, int ldd, const int* dcol2, const float* const* gates_tape2, const float* const* c_tape2,
+                                        const float* const* w_hh2, float* const* dxproj2, int B, int T, int H, unsigned* status, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dout && dcol2 && gates_tape2 && c_tape2 && w_hh2 && dxproj2 && gates_tape2[0] && gates_tape2[1] && c_tape2[0] && c_tape2[1] &&
+                 w_hh2[0] && w_hh2[1] && dxproj2[0] && dxproj2[1], "st_lstm_seq2_bwd_persist: bad arguments");
+    ST_CHECK_ARG(st_lstm_seq2_bwd_persist_supported(B, T, H, ldd, dcol2[0], dcol2[1]),
+                 "st_lstm_seq2_bwd_persist: unsupported shape B=%d T=%d H=%d ldd=%d (see st_lstm_seq2_bwd_persist_supported)", B, T, H, ldd);
+    ST_CHECK_ARG(st_aligned16(dout) && st_aligned16(gates_tape2[0]) && st_aligned16(gates_tape2[1]) && st_aligned16(c_tape2[0]) &&
+                 st_aligned16(c_tape2[1]) && st_aligned16(dxproj2[0]) && st_aligned16(dxproj2[1]), "st_lstm_seq2_bwd_persist: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    LbArgs a;
+    for (int d = 0; d < 2; ++d) {
+        a.dcol[d] = dcol2[d]; a.gates_tape[d] = gates_tape2[d]; a.c_tape[d] = c_tape2[d]; a.w_hh[d] = w_hh2[d]; a.dxp[d] = dxproj2[d];
+        ST_HIP(hipMemsetAsync(dxproj2[d], 0xFF, (size_t)B * T * 4 * H * sizeof(float), st));       // (every word = LP_SENTINEL)
+    }
+    a.dout = dout; a.ldd = ldd; a.B = B; a.T = T; a.H = H; a.status = status;
+    const dim3 grid(H / 16, (B + 15) / 16, 2), block(512);
+    switch (H / 32) {
+        case 1: hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<2>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<4>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<8>), grid, block, 0, st, a); break;
+    }
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int st_lstm_cell_bwd_pointwise(const float* dh0, int ld0, const float* dh1, int ld1, const float* dh2, int ld2,
                                           const float* scale2, const float* mask, const float* gates, const float* c, int ldc,
                                           const float* c_prev, int ldcp, float* dc, float* dgates, int ldg,

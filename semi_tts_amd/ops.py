@@ -641,9 +641,17 @@ def lstm_seq2_bwd(dout, gates_tapes, c_tapes, w_hh_ts, w_hhs=None):
     H % 16 == 0 the loop runs on packed operands, one launch per step (product + pointwise backward of the previous step)."""
     T, B, _, H = gates_tapes[0].shape
     dx = [torch.empty(B, T, 4 * H, device=dout.device, dtype=torch.float32) for _ in range(2)]
+    lib = _lib.load()
+    P2 = C.c_void_p * 2
+    arr = lambda a, b_: P2(_p(a), _p(b_))
+    if LSTM_PERSIST and w_hhs is not None and dout.stride(2) == 1 and dout.stride(0) == T * dout.stride(1) and dout.data_ptr() % 16 == 0 and \
+            all(w.is_contiguous() for w in w_hhs) and lib.st_lstm_seq2_bwd_persist_supported(B, T, H, int(dout.stride(1)), 0, H):
+        # all T steps in one launch (slices of W_hh and the carried dL/dc in registers, the gate gradients handed over through dx itself)
+        check(lib.st_lstm_seq2_bwd_persist(_p(dout), int(dout.stride(1)), (C.c_int * 2)(0, H), arr(*gates_tapes), arr(*c_tapes),
+                                           arr(*[w.detach() for w in w_hhs]), arr(*dx), B, T, H,
+                                           _p(persist_status(dout.device), torch.int32), stream_handle()), 'st_lstm_seq2_bwd_persist')
+        return dx
     if w_hhs is not None and H % 16 == 0:
-        P2 = C.c_void_p * 2
-        arr = lambda a, b_: P2(_p(a), _p(b_))
         packed = [pack_weight_t([w.detach()]) for w in w_hhs]                 # W_hh^T in MFMA order: N = H, K = 4H
         ws = torch.empty(2 * B * H, device=dout.device, dtype=torch.float32)
         t16 = torch.empty(4 * t16_floats(B, 4 * H), device=dout.device, dtype=torch.float32)

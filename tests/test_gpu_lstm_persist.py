@@ -123,3 +123,62 @@ def test_one_launch_bilstm_against_oracle(B, T, H, In):
     from helpers import report
     report('bilstm_one_launch_vs_oracle', B=B, T=T, H=H, err=err)
     assert err < 2e-5, err
+
+
+# ------------------------------------------------------------------------------------------------ backward through time, one launch
+@pytest.mark.parametrize('B,T,H', [(32, 43, 256), (5, 7, 64), (33, 9, 128), (16, 129, 256), (3, 1, 32), (20, 6, 32)])
+def test_one_launch_bilstm_backward_against_float64_autograd(B, T, H):
+    """st_lstm_seq2_bwd_persist (BPTT of both directions in one launch, gate gradients handed over through the returned tensor) against
+    the one-launch-per-step form and against float64 autograd through torch.nn.LSTM given the same input projections (W_ih = I).
+    ref: backward of nn.LSTM(bidirectional=True) src/module.py:432-438,458-460"""
+    from semi_tts_amd import ops, _lib
+    from helpers import report
+    dev = torch.device('cuda:0')
+    assert _lib.load().st_lstm_seq2_bwd_persist_supported(B, T, H, 2 * H, 0, H)
+    xp, w, b = _layer(B, T, H, seed=7 + B + T + H)
+    g = torch.Generator().manual_seed(99)
+    dout = torch.randn(B, T, 2 * H, generator=g)
+    out, gs, cs = _run(xp, w, b, dev, False, True)
+    wd = [t.to(dev) for t in w]
+
+    def bwd(persist):
+        old = ops.LSTM_PERSIST
+        ops.LSTM_PERSIST = persist
+        try:
+            dx = ops.lstm_seq2_bwd(dout.to(dev), gs, cs, None, wd)
+        finally:
+            ops.LSTM_PERSIST = old
+        torch.cuda.synchronize()
+        ops.check_persist_status(dev)
+        return dx
+
+    dx_p, dx_p2, dx_s = bwd(True), bwd(True), bwd(False)
+    lstm = torch.nn.LSTM(4 * H, H, batch_first=True, bidirectional=True).double()
+    with torch.no_grad():
+        for d, sfx in enumerate(('', '_reverse')):
+            getattr(lstm, 'weight_ih_l0' + sfx).copy_(torch.eye(4 * H))
+            getattr(lstm, 'bias_ih_l0' + sfx).zero_()
+            getattr(lstm, 'weight_hh_l0' + sfx).copy_(w[d])
+            getattr(lstm, 'bias_hh_l0' + sfx).copy_(b[d])
+    worst = 0.0
+    for d in range(2):
+        x = xp[d].double().requires_grad_()
+        y = lstm(x)[0][:, :, d * H:(d + 1) * H]
+        y.backward(dout[:, :, d * H:(d + 1) * H].double())
+        scale = float(x.grad.abs().max())
+        assert torch.isfinite(dx_p[d]).all()
+        assert torch.equal(dx_p[d], dx_p2[d])                                    # run to run: bit for bit
+        e_ref = float((dx_p[d].cpu().double() - x.grad).abs().max()) / scale
+        e_step = float((dx_p[d] - dx_s[d]).abs().max()) / scale
+        worst = max(worst, e_ref)
+        assert e_ref < 2e-5 and e_step < 2e-5, (d, e_ref, e_step)
+    report('bilstm_backward_one_launch', B=B, T=T, H=H, err=worst)
+
+
+def test_bilstm_backward_shapes_outside_the_one_launch_form():
+    from semi_tts_amd import _lib
+    lib = _lib.load()
+    assert not lib.st_lstm_seq2_bwd_persist_supported(32, 43, 24, 48, 0, 24)         # H % 32
+    assert not lib.st_lstm_seq2_bwd_persist_supported(32, 43, 512, 1024, 0, 512)     # the 4H x 16 slice no longer fits the registers
+    assert not lib.st_lstm_seq2_bwd_persist_supported(32, 43, 256, 514, 0, 256)      # rows of dout not 16-byte addressable
+    assert not lib.st_lstm_seq2_bwd_persist_supported(2048, 43, 256, 512, 0, 256)    # more workgroups than can be resident at once

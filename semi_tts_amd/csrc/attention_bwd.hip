@@ -24,31 +24,62 @@ __global__ __launch_bounds__(AB_THREADS) void ab_kernel(const AbArgs a) {
 }
 
 // dmem[b][l][e] = sum_t w_t[b][l] * dctx_t[b][e]      (the context is ctx_t = sum_l w_t[l] mem[l])
+// A workgroup takes four positions l0 .. l0 + 3 of one utterance and 256 context dims: 64 lanes x 4 dims, the steps dealt round-robin to
+// the four waves (a wave's dctx reads are 16-byte loads, each feeding 16 multiply-adds; the four weights of a step are wave-uniform).  The
+// four waves' sums meet in LDS in wave order: per output, four interleaved sums over t ascending, combined ((0 + 1) + (2 + 3)).
 __global__ __launch_bounds__(256) void attn_dmem_kernel(const float* align, const float* dctx, float* dmem, int B, int steps, int L, int E) {
-    // a thread takes FOUR positions of one context dim: each dctx value (the bulk of the reads: steps x B x E, re-read by every position)
-    // is loaded once per four outputs.  Per output the sum runs over t ascending, as before.
-    const int LG = (L + 3) >> 2;
-    const size_t total = (size_t)B * LG * E;
+    __shared__ f32x4 part[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int LG = (L + 3) >> 2, EB = (E + 255) >> 8;
+    int i = blockIdx.x;
+    const int eb = i % EB; i /= EB;
+    const int lg = i % LG, b = i / LG;
+    const int l0 = lg * 4, e = eb * 256 + lane * 4;
+    const bool eok = e < E;                                   // (E % 4 == 0: whole pieces)
+    const int lc[4] = {l0, min(l0 + 1, L - 1), min(l0 + 2, L - 1), min(l0 + 3, L - 1)};
+    const float* wp = align + (size_t)b * steps * L;
+    const float* dp = dctx + (size_t)b * E + (eok ? e : 0);
+    f32x4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = wave; t < steps; t += 4) {
+        const f32x4 d = st_ld4(dp + (size_t)t * B * E);
+        const float* wr = wp + (size_t)t * L;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float w = wr[lc[j]];
+            a[j][0] = fmaf(w, d[0], a[j][0]); a[j][1] = fmaf(w, d[1], a[j][1]); a[j][2] = fmaf(w, d[2], a[j][2]); a[j][3] = fmaf(w, d[3], a[j][3]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[wave - 1][j][lane] = a[j];
+    }
+    __syncthreads();
+    if (wave == 0 && eok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (l0 + j >= L) break;
+            const f32x4 p1 = part[0][j][lane], p2 = part[1][j][lane], p3 = part[2][j][lane];
+            f32x4 r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = (a[j][c] + p1[c]) + (p2[c] + p3[c]);
+            *reinterpret_cast<f32x4*>(dmem + ((size_t)b * L + l0 + j) * E + e) = r;
+        }
+    }
+}
+
+// (context widths that are not whole 16-byte pieces: one thread per output)
+__global__ __launch_bounds__(256) void attn_dmem_scalar_kernel(const float* align, const float* dctx, float* dmem, int B, int steps, int L, int E) {
+    const size_t total = (size_t)B * L * E;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(i % E);
-        const size_t bg = i / E;
-        const int lg = (int)(bg % LG), b = (int)(bg / LG);
-        const int l0 = lg * 4;
-        const float* wp = align + (size_t)b * steps * L;
-        const float* dp = dctx + (size_t)b * E + e;
-        const int l1 = min(l0 + 1, L - 1), l2 = min(l0 + 2, L - 1), l3 = min(l0 + 3, L - 1);
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-#pragma unroll 8
-        for (int t = 0; t < steps; ++t) {      // (unrolled: eight steps' loads in flight -- as a rolled loop it is a chain of dependent round trips)
-            const float d = dp[(size_t)t * B * E];
-            const float* wr = wp + (size_t)t * L;
-            a0 = fmaf(wr[l0], d, a0); a1 = fmaf(wr[l1], d, a1); a2 = fmaf(wr[l2], d, a2); a3 = fmaf(wr[l3], d, a3);
-        }
-        float* o = dmem + ((size_t)b * L + l0) * E + e;
-        o[0] = a0;
-        if (l0 + 1 < L) o[(size_t)E] = a1;
-        if (l0 + 2 < L) o[(size_t)2 * E] = a2;
-        if (l0 + 3 < L) o[(size_t)3 * E] = a3;
+        const size_t bl = i / E;
+        const int l = (int)(bl % L), b = (int)(bl / L);
+        float acc = 0.0f;
+        for (int t = 0; t < steps; ++t) acc = fmaf(align[((size_t)b * steps + t) * L + l], dctx[((size_t)t * B + b) * E + e], acc);
+        dmem[i] = acc;
     }
 }
 
@@ -57,8 +88,13 @@ __global__ __launch_bounds__(256) void attn_dmem_kernel(const float* align, cons
 extern "C" int st_attn_dmem(const float* align, const float* dctx_tape, float* dmem, int B, int steps, int L, int E, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(align && dctx_tape && dmem && B > 0 && steps > 0 && L > 0 && E > 0, "st_attn_dmem: bad arguments");
-    size_t blocks = ((size_t)B * ((L + 3) / 4) * E + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    if (E % 4 != 0 || !st_aligned16(dctx_tape) || !st_aligned16(dmem)) {
+        size_t nb = ((size_t)B * L * E + 255) / 256;
+        hipLaunchKernelGGL(attn_dmem_scalar_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, align, dctx_tape, dmem, B, steps, L, E);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
+    const size_t blocks = (size_t)B * ((L + 3) / 4) * ((E + 255) / 256);
     hipLaunchKernelGGL(attn_dmem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, align, dctx_tape, dmem, B, steps, L, E);
     ST_LAUNCH_CHECK();
     return 0;

@@ -404,6 +404,79 @@ __device__ __forceinline__ void tn_dma_body(const TnArgs& g, const int bx, const
 template <int TM>
 __global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) { tn_dma_body<TM>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
 
+// ---- weight gradient of a convolution with very few input channels (the attention's location conv: 2 channels x 31 taps -> 32 filters,
+// over steps x B sequences of L positions) --------------------------------------------------------------------------------------------------
+// tn_kernel's folded form gathers its (channel, tap) columns one element at a time (an integer division and a dependent scalar load per
+// element and 16-row chunk: 55 us for 0.46 GFLOP).  Here a workgroup stages a sequence's dC rows (64 at a time) and its input rows with
+// their halo into LDS as they lie in memory and takes the im2col columns from LDS on the fly:
+//   D[f][col = (ci, k)] += sum_t dC[t][f] * A[t + k - pad][ci]       wave w: column tile w, all filter tiles; reduction over t by 4.
+// Workgroup z handles the (sequence, 64-row block) units z, z + Z, ... (two LDS buffers, one barrier per unit) and writes slab z; the
+// slabs are summed in slab order (sum_partials_tall_kernel).  Shapes: N <= 64 filters (multiple of 4), Cin * KT <= 64 columns.
+struct CsArgs { const float* dC; int lddc; const float* A; int lda; float* part; int Bn, Tin, Tout, Cin, N, KT, pad, Z; };
+constexpr int CS_TB = 64;
+
+__global__ __launch_bounds__(256) void convw_small_kernel(const CsArgs g) {
+    __shared__ __attribute__((aligned(16))) float dcs[2][CS_TB * 68];          // [t][f], row stride 68: rows 4 apart on different banks
+    __shared__ float as_[2][(CS_TB + 64) * 4];                                 // [t + halo][ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ar = lane & 15, q = lane >> 4;
+    const int ncols = g.Cin * g.KT, NT = (g.N + 15) >> 4;
+    const int col = wave * 16 + ar;
+    const bool colok = col < ncols;
+    const int ci = colok ? col / g.KT : 0, kk = colok ? col - ci * g.KT : 0;
+    const int tblocks = (g.Tout + CS_TB - 1) / CS_TB;
+    const int units = g.Bn * tblocks;
+    const int halo = CS_TB + g.KT - 1;                                          // input rows a block of output rows reads
+    const int pieces = g.N >> 2;                                               // 16-byte pieces per dC row
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int u, int buf) {
+        const int b = u / tblocks, t0 = (u - b * tblocks) * CS_TB;
+        for (int i = tid; i < CS_TB * pieces; i += 256) {
+            const int t = i / pieces, pc = i - t * pieces;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t0 + t < g.Tout) v = st_ld4(g.dC + ((size_t)b * g.Tout + t0 + t) * g.lddc + pc * 4);
+            *reinterpret_cast<f32x4*>(&dcs[buf][t * 68 + pc * 4]) = v;
+        }
+        for (int i = tid; i < halo * g.Cin; i += 256) {
+            const int r = i / g.Cin, c = i - r * g.Cin;
+            const int ti = t0 + r - g.pad;
+            as_[buf][r * 4 + c] = (ti >= 0 && ti < g.Tin) ? g.A[((size_t)b * g.Tin + ti) * g.lda + c] : 0.0f;
+        }
+    };
+    int u = blockIdx.x, buf = 0;
+    if (u < units) stage(u, 0);
+    for (; u < units; u += g.Z) {
+        __syncthreads();                                   // unit u is staged; everybody is past the MFMAs of the unit before
+        if (u + g.Z < units) stage(u + g.Z, buf ^ 1);
+        const float* dc = dcs[buf];
+        const float* ap = as_[buf];
+#pragma unroll 4
+        for (int s = 0; s < CS_TB / 4; ++s) {
+            const int t = 4 * s + q;
+            const float bv = colok ? ap[(t + kk) * 4 + ci] : 0.0f;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                if (ft < NT) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(dc[t * 68 + ft * 16 + ar], bv, acc[ft], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    // D[row = f = ft*16 + 4q + r][col]: slab z = blockIdx.x
+    if (colok) {
+        float* out = g.part + (size_t)blockIdx.x * g.N * ncols;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = ft * 16 + 4 * q + r;
+                if (ft < NT && f < g.N) out[(size_t)f * ncols + col] = acc[ft][r];
+            }
+        }
+    }
+}
+
 // Several weight-gradient products in ONE launch (st_gemm_wgrad_batch): the K convolutions of the CBHG bank (80 x 80 x k matrices: 4 k
 // tiles each -- eight launches of 10 ... 36 us that each leave most of the chip idle) or the two directions of a recurrent layer.
 // blockIdx.x runs through the jobs' own (x, y, z) grids one after the other.
@@ -458,6 +531,27 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, fl
         }
         for (; z < Z; ++z) s0 += part[(size_t)z * n + i];
         const float s = (s0 + s1) + (s2 + s3);
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// very many slabs of a small matrix (the location conv's gradient: 256 slabs of 2k elements): with one thread per element the sum is a
+// chain of Z dependent-latency loads on a handful of workgroups.  Here a workgroup takes 32 elements, its eight 32-lane groups every
+// eighth slab each (four interleaved sums), and the eight partial sums meet in LDS in group order.
+__global__ __launch_bounds__(256) void sum_partials_tall_kernel(const float* part, float* out, size_t n, int Z, int accumulate) {
+    __shared__ float red[8][32];
+    const int e = threadIdx.x & 31, zg = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + e;
+    const bool ok = i < n;
+    const float* p = part + (ok ? i : 0);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = zg;
+    for (; z + 24 < Z; z += 32) { s0 += p[(size_t)z * n]; s1 += p[(size_t)(z + 8) * n]; s2 += p[(size_t)(z + 16) * n]; s3 += p[(size_t)(z + 24) * n]; }
+    for (; z < Z; z += 8) s0 += p[(size_t)z * n];
+    red[zg][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zg == 0 && ok) {
+        const float s = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
         out[i] = accumulate ? out[i] + s : s;
     }
 }
@@ -521,6 +615,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* X, int ldx, in
     red[rl][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl == 0 && n < N) part[(size_t)blockIdx.y * N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// few rows, very many columns (the processed-memory gradient: 85 step tapes of B x L x A floats): one thread per four columns walks
+// all rows with 16-byte loads -- no partials, no second launch.  Per column: four interleaved sums over the rows ascending.
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* X, int ldx, int M, int N4, float* out, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N4) return;
+    const float* xp = X + (size_t)i * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int m = 0;
+    for (; m + 4 <= M; m += 4) {
+        s0 = s0 + st_ld4(xp + (size_t)m * ldx); s1 = s1 + st_ld4(xp + (size_t)(m + 1) * ldx);
+        s2 = s2 + st_ld4(xp + (size_t)(m + 2) * ldx); s3 = s3 + st_ld4(xp + (size_t)(m + 3) * ldx);
+    }
+    for (; m < M; ++m) s0 = s0 + st_ld4(xp + (size_t)m * ldx);
+    f32x4 r = (s0 + s1) + (s2 + s3);
+    f32x4* o = reinterpret_cast<f32x4*>(out) + i;
+    if (accumulate) r = r + *o;
+    *o = r;
 }
 
 __device__ __forceinline__ float act_grad(float out, int act) {
@@ -1162,6 +1275,17 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     const int TM = tn_tile(Cin, N, KT);
     dim3 grid((N + TM - 1) / TM, g.fold ? (Cin * KT + TM - 1) / TM : ((Cin + TM - 1) / TM) * KT, Z);
     hipStream_t st = (hipStream_t)stream;
+    if (g.fold && !db && !dW1 && N <= 64 && N % 4 == 0 && Cin <= 4 && Cin * KT <= 64 && g.vecx && Z > 1) {
+        // few input channels: the im2col columns come out of LDS (convw_small_kernel), Z workgroups = Z slabs
+        CsArgs c;
+        c.dC = dC + dcoff; c.lddc = lddc; c.A = A; c.lda = lda; c.part = ws; c.Bn = Bn; c.Tin = Tin; c.Tout = Tout; c.Cin = Cin; c.N = N;
+        c.KT = KT; c.pad = pad; c.Z = Z;
+        hipLaunchKernelGGL(convw_small_kernel, dim3(Z), dim3(256), 0, st, c);
+        ST_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sum_partials_tall_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
     // one slab and nothing to add to: the product goes straight to dW (the decoder LSTMs' weight gradients are 29 and 42 MB --
     // the "sum" of one slab was a 17 us copy)
     const bool direct = Z == 1 && !accumulate && !dW1;      // (a split result always leaves through the slab sum)
@@ -1187,6 +1311,7 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
                                 db ? g.db_part : nullptr, db, (size_t)(db ? N : 0), dW1, Cin, split, db ? db_dup : nullptr);
     else if (db) hipLaunchKernelGGL(sum_partials2_kernel<false>, dim3(blocks_for(per + N)), dim3(256), 0, st, ws, dW, per, Z, accumulate, g.db_part, db, (size_t)N,
                                     nullptr, 0, 0, nullptr);
+    else if (Z >= 64 && per <= 65536) hipLaunchKernelGGL(sum_partials_tall_kernel, dim3((unsigned)((per + 31) / 32)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
     else hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks_for(per)), dim3(256), 0, st, ws, dW, per, Z, accumulate);
     ST_LAUNCH_CHECK();
     return 0;
@@ -1309,6 +1434,11 @@ extern "C" int st_colsum(const float* X, int ldx, int xoff, const float* Y, int 
     const int chunks = st_colreduce_chunks(M);
     const int rpc = (M + chunks - 1) / chunks;
     hipStream_t st = (hipStream_t)stream;
+    if (!Y && M <= 256 && N >= 65536 && N % 4 == 0 && ldx % 4 == 0 && xoff % 4 == 0 && st_aligned16(X) && st_aligned16(out)) {
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3((N / 4 + 255) / 256), dim3(256), 0, st, X + xoff, ldx, M, N / 4, out, accumulate);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, X, ldx, xoff, Y, ldy, yoff, M, N, rpc, ws);
     ST_LAUNCH_CHECK();
     hipLaunchKernelGGL(chunk_final_kernel, dim3((N + 15) / 16), dim3(256), 0, st, ws, chunks, 1, N, out, out, accumulate);

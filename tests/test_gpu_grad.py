@@ -52,6 +52,49 @@ def conv_cl_ref(x, w, b, pad, Tout, act, pool_prev=False, res=None, mask=None):
     return y
 
 
+@pytest.mark.parametrize('Bn,T,Cin,N,KT,pad', [
+    (85 * 4, 43, 2, 32, 31, 15),      # the location conv over the step tapes (C2 shape, fewer sequences)
+    (40, 171, 2, 32, 31, 15),         # C5's text length: three 64-row blocks per sequence
+    (700, 9, 1, 8, 5, 2),             # one channel, short sequences: more workgroups than the slab count covers in one pass
+    (3, 20, 4, 64, 16, 8),            # even kernel: Tout = T + 1
+    (2, 130, 3, 12, 7, 0),            # no padding: Tout = T - 6
+])
+def test_small_channel_conv_weight_gradient(dev, Bn, T, Cin, N, KT, pad):
+    """dW of a convolution with very few input channels (convw_small_kernel: im2col columns out of LDS) + the many-slab sum
+    (sum_partials_tall_kernel) against float64 autograd.  ref: backward of the location conv, src/module.py:239,371-407"""
+    from semi_tts_amd import ops
+    Tout = T + 2 * pad - KT + 1
+    x, dy = rnd(Bn, T, Cin, seed=5), rnd(Bn, Tout, N, seed=6)
+    dw = ops.gemm_wgrad(dy.to(dev), x.to(dev), KT, pad, Tout=Tout)
+    dw2 = ops.gemm_wgrad(dy.to(dev), x.to(dev), KT, pad, Tout=Tout)
+    assert torch.equal(dw, dw2)
+    w = torch.zeros(N, Cin, KT, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv1d(x.double().transpose(1, 2), w, padding=pad).transpose(1, 2)
+    assert y.shape[1] == Tout
+    y.backward(dy.double())
+    e = relerr(dw, w.grad)
+    report('small_channel_conv_wgrad', Bn=Bn, T=T, Cin=Cin, N=N, KT=KT, err=e)
+    assert e < 2e-5
+
+
+def test_attention_memory_gradient_and_wide_column_sums(dev):
+    """st_attn_dmem (dmem = sum_t w_t (x) dctx_t, four positions x 256 dims per workgroup) and the few-rows / many-columns form of
+    st_colsum (the processed-memory gradient: a sum over the step tapes) against float64"""
+    from semi_tts_amd import ops, _lib
+    lib = _lib.load()
+    for B, steps, L, E in ((32, 85, 43, 512), (3, 7, 10, 12), (5, 4, 9, 260), (2, 3, 5, 6)):
+        align, dctx = rnd(B, steps, L, seed=1), rnd(steps, B, E, seed=2)
+        dmem = torch.empty(B, L, E, device=dev)
+        ad, dd = align.to(dev), dctx.to(dev)
+        _lib.check(lib.st_attn_dmem(ops._p(ad), ops._p(dd), ops._p(dmem), B, steps, L, E, ops.stream_handle()), 'st_attn_dmem')
+        ref = torch.einsum('btl,tbe->ble', align.double(), dctx.double())
+        assert relerr(dmem, ref) < 2e-6, (B, steps, L, E)
+    for M, N in ((85, 32 * 43 * 256), (3, 65536), (200, 70000)):
+        x = rnd(M, N, seed=3)
+        s = ops.colsum(x.to(dev))
+        assert relerr(s, x.double().sum(0)) < 2e-6, (M, N)
+
+
 def test_queued_weight_gradients(dev):
     """Weight-gradient products are queued during a backward pass and leave together (ops.flush_wgrads).  A layer applied TWICE gives
     its weight two contributions: the second must find the first one written (it flushes the queue and runs at once) -- and a chain

@@ -431,29 +431,46 @@ __global__ __launch_bounds__(256) void convw_small_kernel(const CsArgs g) {
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto stage = [&](int u, int buf) {
+    // staging roles, fixed for the whole loop: up to four 16-byte pieces of dC and two input elements per thread and unit.  The next
+    // unit's pieces are requested BEFORE the MFMAs of the current one and go to LDS after them (registers in between): a unit costs
+    // its MFMAs, not a memory round trip.
+    int pt[4], pp[4], hr[2], hc[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = tid + j * 256; pt[j] = i / pieces; pp[j] = (i - pt[j] * pieces) * 4; if (i >= CS_TB * pieces) pt[j] = -1; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int i = tid + j * 256; hr[j] = i / g.Cin; hc[j] = i - hr[j] * g.Cin; if (i >= halo * g.Cin) hr[j] = -1; }
+    f32x4 rd[4];
+    float ra[2];
+    auto request = [&](int u) {
         const int b = u / tblocks, t0 = (u - b * tblocks) * CS_TB;
-        for (int i = tid; i < CS_TB * pieces; i += 256) {
-            const int t = i / pieces, pc = i - t * pieces;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t0 + t < g.Tout) v = st_ld4(g.dC + ((size_t)b * g.Tout + t0 + t) * g.lddc + pc * 4);
-            *reinterpret_cast<f32x4*>(&dcs[buf][t * 68 + pc * 4]) = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pt[j] >= 0 && t0 + pt[j] < g.Tout) rd[j] = st_ld4(g.dC + ((size_t)b * g.Tout + t0 + pt[j]) * g.lddc + pp[j]);
         }
-        for (int i = tid; i < halo * g.Cin; i += 256) {
-            const int r = i / g.Cin, c = i - r * g.Cin;
-            const int ti = t0 + r - g.pad;
-            as_[buf][r * 4 + c] = (ti >= 0 && ti < g.Tin) ? g.A[((size_t)b * g.Tin + ti) * g.lda + c] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ti = t0 + hr[j] - g.pad;
+            ra[j] = (hr[j] >= 0 && ti >= 0 && ti < g.Tin) ? g.A[((size_t)b * g.Tin + ti) * g.lda + hc[j]] : 0.0f;
         }
     };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (pt[j] >= 0) *reinterpret_cast<f32x4*>(&dcs[buf][pt[j] * 68 + pp[j]]) = rd[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) if (hr[j] >= 0) as_[buf][hr[j] * 4 + hc[j]] = ra[j];
+    };
     int u = blockIdx.x, buf = 0;
-    if (u < units) stage(u, 0);
+    if (u < units) request(u);
     for (; u < units; u += g.Z) {
-        __syncthreads();                                   // unit u is staged; everybody is past the MFMAs of the unit before
-        if (u + g.Z < units) stage(u + g.Z, buf ^ 1);
+        deposit(buf);
+        __syncthreads();                                   // unit u is in LDS; everybody is past the MFMAs of the unit before the last
+        if (u + g.Z < units) request(u + g.Z);
         const float* dc = dcs[buf];
         const float* ap = as_[buf];
-#pragma unroll 4
-        for (int s = 0; s < CS_TB / 4; ++s) {
+        const int t0 = (u % tblocks) * CS_TB;
+        const int nsteps = (min(CS_TB, g.Tout - t0) + 3) >> 2;      // (rows past the sequence are zero: whole steps of them are skipped)
+        for (int s = 0; s < nsteps; ++s) {
             const int t = 4 * s + q;
             const float bv = colok ? ap[(t + kk) * 4 + ci] : 0.0f;
 #pragma unroll
@@ -1232,8 +1249,20 @@ static inline int tn_tile(int Cin, int N, int KT) {
     return tiles128 >= 256 ? 128 : TN_T;
 }
 
+// shapes convw_small_kernel takes (next to: no bias gradient wanted, 16-byte addressable dC rows)
+static inline bool cs_shape(int Cin, int N, int KT) { return Cin <= 4 && KT > 1 && N <= 64 && N % 4 == 0 && Cin * KT <= 64; }
+
 extern "C" size_t st_gemm_wgrad_workspace_floats(int Bn, int Tout, int Cin, int N, int KT) {
     const int M = Bn * Tout;
+    if (cs_shape(Cin, N, KT)) {
+        // one slab per workgroup, several workgroups per compute unit (a unit = 64 rows of one sequence is a memory round trip plus a
+        // few hundred cycles of MFMAs: occupancy hides the round trips); the many slabs are cheap to add (sum_partials_tall_kernel)
+        const long units = (long)Bn * ((Tout + 63) / 64);
+        long Z = units / 2;
+        if (Z > 1024) Z = 1024;
+        if (Z < 2) Z = 2;
+        return (size_t)Z * N * Cin * KT + (size_t)Z * N;
+    }
     const int TM = tn_tile(Cin, N, KT);
     const int colblocks = tn_fold(Cin, KT, 0) ? (Cin * KT + TM - 1) / TM : ((Cin + TM - 1) / TM) * KT;
     const int tiles = ((N + TM - 1) / TM) * colblocks;
@@ -1275,7 +1304,7 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     const int TM = tn_tile(Cin, N, KT);
     dim3 grid((N + TM - 1) / TM, g.fold ? (Cin * KT + TM - 1) / TM : ((Cin + TM - 1) / TM) * KT, Z);
     hipStream_t st = (hipStream_t)stream;
-    if (g.fold && !db && !dW1 && N <= 64 && N % 4 == 0 && Cin <= 4 && Cin * KT <= 64 && g.vecx && Z > 1) {
+    if (cs_shape(Cin, N, KT) && !db && !dW1 && !pool_prev && g.vecx) {
         // few input channels: the im2col columns come out of LDS (convw_small_kernel), Z workgroups = Z slabs
         CsArgs c;
         c.dC = dC + dcoff; c.lddc = lddc; c.A = A; c.lda = lda; c.part = ws; c.Bn = Bn; c.Tin = Tin; c.Tout = Tout; c.Cin = Cin; c.N = N;

@@ -731,8 +731,13 @@ static int ab_fill_job(AbArgs& t, const st_attn_bwd_job* ab) {
                    ab->B, ab->L, ab->A, ab->E, ab->F, ab->K);
 }
 
-// (development switch ST_EXP: parts of the hosted BPTT launches return at once -- timing ablations only, results are then garbage)
+// (timing ablations only, in the SEPARATE library tools/gpu_ablate.sh builds with -DST_ABLATE: ST_EXP makes parts of the hosted BPTT
+// launches return at once -- results are then garbage.  The product library has no such switch: the flag is the constant 0.)
+#ifdef ST_ABLATE
 static int st_exp_flag() { static int v = -1; if (v < 0) { const char* e = getenv("ST_EXP"); v = e ? atoi(e) : 0; } return v; }
+#else
+static inline int st_exp_flag() { return 0; }
+#endif
 
 // ---- K-split partial products ------------------------------------------------------------------------------------------------------
 // y = x W^T for B <= 32 rows (two batch tiles) with TWO row tiles and BOTH batch tiles per workgroup -- every weight fragment and every

@@ -139,6 +139,24 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float* src, int ld
     }
 }
 
+// the same by whole 16-byte pieces (rows of dst 16-byte addressable): a wave reads one tile as it lies (1 KB) and every lane stores its
+// four columns of its row -- the element-wise form below moved 95 MB of step tapes per training step at 2 TB/s
+__global__ __launch_bounds__(256) void untile_rows_vec_kernel(const float* src, int kbs, int kb0, float* dst, int ld, int B, int K) {
+    const int KB = pk_kb(K), BT = (B + 15) >> 4;
+    const size_t total = (size_t)BT * KB * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const size_t blk = idx >> 6;
+        const int kb = (int)(blk % KB), bt = (int)(blk / KB);
+        const int b = bt * 16 + (lane & 15), k = kb * 16 + (lane >> 4) * 4;
+        if (b >= B || k >= K) continue;
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[((size_t)bt * kbs + kb0 + kb) * 64 + lane];
+        float* o = dst + (size_t)b * ld + k;
+        if (k + 4 <= K) *reinterpret_cast<f32x4*>(o) = v;
+        else { o[0] = v[0]; if (k + 1 < K) o[1] = v[1]; if (k + 2 < K) o[2] = v[2]; }
+    }
+}
+
 __global__ __launch_bounds__(256) void untile_rows_kernel(const float* src, int kbs, int kb0, float* dst, int ld, int B, int K) {
     const size_t total = (size_t)B * K;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1396,6 +1414,14 @@ extern "C" int st_tile_rows(const float* src, int ld, const st_t16_view* dst, in
 extern "C" int st_untile_rows(const st_t16_view* src, float* dst, int ld, int B, int K, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(src && src->base && dst && B > 0 && K > 0 && ld >= K, "st_untile_rows: bad arguments");
+    if (ld % 4 == 0 && st_aligned16(dst) && st_aligned16(src->base)) {
+        const size_t pieces = (size_t)((B + 15) >> 4) * pk_kb(K) * 64;
+        const size_t nb = (pieces + 255) / 256;
+        hipLaunchKernelGGL(untile_rows_vec_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, (hipStream_t)stream, src->base,
+                           src->kb_stride, src->kb0, dst, ld, B, K);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t total = (size_t)B * K;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;

@@ -336,6 +336,7 @@ class Ranks:
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        self.issue_seconds = time.perf_counter() - t0      # (diagnostic: how long the host needed to ISSUE the K steps; ~ the total = host-bound)
         self.barrier()
         return self.max_seconds(time.perf_counter() - t0)
 
@@ -632,6 +633,7 @@ def bench_train(args, rk):
     variants = {}
     elapsed = rk.timed(step, args.steps, args.warmup)
     variants['full'] = elapsed
+    issue_ms = rk.issue_seconds / args.steps * 1e3
     counts = parallel.collective_counts()
     counts['async_grad_buckets'] = parallel.async_bucket_count()
     if (rk.world > 1 or rk.forced) and not args.no_variants:
@@ -673,6 +675,8 @@ def bench_train(args, rk):
             'roofline': {'bound': 'mfma', 'kernel': 'whole training step (%s; the largest shares are the per-step products of the two loops and the weight-gradient GEMM tn_dma_kernel)' % _train_launches(),
                          'achieved': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(3 * 132.4e9 / (ms['full'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None},
+            'ms_host_issue_per_step': round(issue_ms, 3),      # (the host's time to issue a step of the 'full' variant; close to ms_per_step = the step is bound by the host)
+            'mt_table_misses': int(__import__('semi_tts_amd._lib', fromlist=['load']).load().st_mt_table_misses()),      # (block maps of the multi-tensor launches built so far: once per set of tensor addresses)
             'last': {k: float(last['st'][k]) for k in ('loss', 'grad_norm')}, 'stats_read': 'per step' if args.sync_stats else 'after the timed steps', 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             **({'cpu_baseline': cpu} if cpu is not None else {})}
 

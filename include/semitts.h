@@ -984,6 +984,8 @@ int st_scale_by(const float* x, const float* scalar, float* y, size_t n, void* s
  * ref: BaseSolver.backward src/solver.py:138-151 (clip_grad_norm_ 5.0, optimizer.step()), torch.optim.Adam as built by
  * src/optim.py.  The pointer arrays are HOST arrays of device pointers (nt tensors, n[t] elements each); the
  * kernels take them through their arguments, a few launches for ~100 tensors. */
+long st_mt_table_misses(void);   /* diagnostics: block maps built and uploaded so far (once per set of tensor addresses; the multi-tensor
+                                    * launches below read their tensor list from a cached device-side table) */
 size_t st_mt_blocks(const long* n, int nt);                   /* floats of `partials` st_mt_grad_norm needs */
 /* *norm_out (device) = sqrt(sum_t sum_i g_t[i]^2), fixed summation order */
 int st_mt_grad_norm(float* const* g, const long* n, int nt, float* partials, float* norm_out, void* stream);

@@ -275,6 +275,7 @@ SIGNATURES = {
     'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, I, P],
     'st_adain_bwd': [P, C.c_long, I, P, C.c_long, I, P, P, P, P, I, I, I, P],
     'st_mt_blocks': [P, I],
+    'st_mt_table_misses': [],
     'st_mt_grad_norm': [P, P, I, P, P, P],
     'st_mt_clip_scale': [P, P, I, P, F, P],
     'st_mt_grad_norm_scaled': [P, P, I, P, P, F, P],
@@ -322,7 +323,7 @@ SIGNATURES = {
 }
 _RESTYPES = {'st_last_error': C.c_char_p, 'st_packed_weight_floats': C.c_size_t, 'st_t16_floats': C.c_size_t,
              'st_decoder_packed_floats': C.c_size_t, 'st_vq_l2_workspace_floats': C.c_size_t, 'st_ctc_workspace_floats': C.c_size_t, 'st_decoder_tape_floats': C.c_size_t,
-             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_gemm_wgrad_batch_workspace_floats': C.c_size_t, 'st_freq_loss_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_attn_rng_xchg_words': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t,
+             'st_gemm_wgrad_workspace_floats': C.c_size_t, 'st_gemm_wgrad_batch_workspace_floats': C.c_size_t, 'st_freq_loss_workspace_floats': C.c_size_t, 'st_attn_fin_split_workspace_floats': C.c_size_t, 'st_attn_rng_xchg_words': C.c_size_t, 'st_colreduce_workspace_floats': C.c_size_t, 'st_mt_blocks': C.c_size_t, 'st_mt_table_misses': C.c_long,
              'st_bn_bank_workspace_floats': C.c_size_t}
 
 _lib = None

@@ -1,37 +1,41 @@
 // optim.hip -- the optimiser half of the training step as multi-tensor kernels.
 // ref: BaseSolver.backward src/solver.py:138-151 (clip_grad_norm_(5.0) then optimizer.step()), src/optim.py
-// (torch.optim.Adam with its defaults).  ~100 parameter tensors are processed by a handful of launches: tensor
-// pointers and the block -> (tensor, chunk) map travel in the kernel arguments, up to MT_T tensors / MT_NB
-// blocks per launch (no device-side tables, nothing to upload).
+// (torch.optim.Adam with its defaults).  ~100 parameter tensors are processed by ONE launch per pass: the tensor
+// pointers and the block -> (tensor, chunk) map sit in a cached device-side table (mt_table; the addresses repeat from step
+// to step).  During a stream capture, or when the table cannot be made, they travel in the kernel arguments instead,
+// up to MT_T tensors / MT_NB blocks per launch.
 #include "st_common.h"
 
 namespace {
 
 constexpr int MT_T = 24, MT_NB = 640, MT_CHUNK = 32768, MT_THREADS = 256;
 
-struct MtArgs {
-    float* p[MT_T]; float* g[MT_T]; float* m[MT_T]; float* v[MT_T];
-    long n[MT_T];
-    unsigned char blk_tensor[MT_NB];
-    unsigned short blk_chunk[MT_NB];         // chunk index inside the tensor (tensors up to 2^31 elements)
-    // op parameters
+struct MtOp {
     float* partial; int partial_base;            // sumsq
     const float* norm; float max_norm;           // scale
     float pre_scale;                             // scale: every gradient is first multiplied by this (1 / world: the ranks' SUM -> average)
     float b1, b2, eps, step_size, bc2_sqrt;      // adam
 };
+struct MtArgs {
+    float* p[MT_T]; float* g[MT_T]; float* m[MT_T]; float* v[MT_T];
+    long n[MT_T];
+    unsigned char blk_tensor[MT_NB];
+    unsigned short blk_chunk[MT_NB];         // chunk index inside the tensor (tensors up to 2^31 elements)
+    MtOp op;
+};
+// The same map in DEVICE memory (st_mt_* keep a small cache of such tables keyed on the pointer lists: parameters, moments and -- in steady
+// state, from the caching allocator or the reducer's bucket slots -- gradients sit at the same addresses every step): any number of
+// tensors and blocks in ONE launch.  With the map in the kernel arguments an optimiser step over the model's ~110 tensors was five
+// launches per pass, three of them a few dozen blocks on a 256-unit chip.
+struct MtTab { float* const* p; float* const* g; float* const* m; float* const* v; const long* n; const unsigned* blk; };
 
 // OP 0: partial[block] = sum g^2;  OP 1: g *= pre_scale * min(1, max_norm / (norm + 1e-6));  OP 2: Adam update
 template <int OP>
-__global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
-    __shared__ float red[MT_THREADS / 64];
-    const int t = a.blk_tensor[blockIdx.x];
-    const long beg = (long)a.blk_chunk[blockIdx.x] * MT_CHUNK;
-    const long n = a.n[t];
+__device__ __forceinline__ void mt_body(float* __restrict__ tp, float* __restrict__ g, float* __restrict__ tm, float* __restrict__ tv,
+                                        const long n, const long beg, const MtOp& a, float* red) {
     const long end = beg + MT_CHUNK < n ? beg + MT_CHUNK : n;
-    float* __restrict__ g = a.g[t];
     // 16-byte accesses when the chunk is aligned (torch allocations are; chunk starts are multiples of 32768 floats)
-    const bool vec = (((uintptr_t)g | (uintptr_t)a.p[t] | (uintptr_t)a.m[t] | (uintptr_t)a.v[t]) & 15u) == 0;
+    const bool vec = (((uintptr_t)g | (uintptr_t)tp | (uintptr_t)tm | (uintptr_t)tv) & 15u) == 0;
     const long nvec = vec ? ((end - beg) >> 2) : 0;
     if (OP == 0) {
         float acc = 0.0f, acc2 = 0.0f;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
         // guarded form (st_mt_adam_guarded): no update at all when the gradient norm of this step is NaN / inf -- the decision the
         // reference takes on the host (`if math.isnan(grad_norm)`: skip optimizer.step(), src/solver.py:147-150) without a host round trip
         if (a.norm && !(fabsf(*a.norm) <= 3.0e38f)) return;
-        float* __restrict__ p = a.p[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
+        float* __restrict__ p = tp; float* __restrict__ m = tm; float* __restrict__ v = tv;
         const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
         // no contraction left to the compiler (the fused multiply-adds are the explicit ones): the 16-byte loop and the scalar loop
         // (unaligned tensors, tails) must round alike -- a gradient that lives in an all-reduce bucket slot and one in a tensor of
@@ -120,6 +124,21 @@ __global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
     }
 }
 
+template <int OP>
+__global__ __launch_bounds__(MT_THREADS) void mt_kernel(const MtArgs a) {
+    __shared__ float red[MT_THREADS / 64];
+    const int t = a.blk_tensor[blockIdx.x];
+    mt_body<OP>(a.p[t], a.g[t], a.m[t], a.v[t], a.n[t], (long)a.blk_chunk[blockIdx.x] * MT_CHUNK, a.op, red);
+}
+
+template <int OP>
+__global__ __launch_bounds__(MT_THREADS) void mt_tab_kernel(const MtTab tb, const MtOp op) {
+    __shared__ float red[MT_THREADS / 64];
+    const unsigned e = tb.blk[blockIdx.x];
+    const int t = (int)(e >> 16);
+    mt_body<OP>(tb.p ? tb.p[t] : nullptr, tb.g[t], tb.m ? tb.m[t] : nullptr, tb.v ? tb.v[t] : nullptr, tb.n[t], (long)(e & 0xFFFFu) * MT_CHUNK, op, red);
+}
+
 __global__ __launch_bounds__(64) void mt_norm_final_kernel(const float* partial, int n, float* out, float pre_scale) {
     // fixed-order sum of the per-block partials (a few hundred) by one wave (lane j: partials j, j + 64, ...; then a fixed tree over
     // the lanes), then the square root.  (One thread walking them all took 29 us.)
@@ -152,13 +171,125 @@ __global__ __launch_bounds__(MT_THREADS) void mc_kernel(const McArgs a) {
     for (int j = beg + nvec * 4 + threadIdx.x; j < end; j += MT_THREADS) d[j] = s[j];
 }
 
+// ---- the block map in device memory --------------------------------------------------------------------------------------------------
+struct MtTabEntry { unsigned long long key; int dev; void* buf; void* host; size_t cap; hipEvent_t ev; bool ev_set; int nt, blocks; unsigned long long age; };
+constexpr int MT_TABS = 16;
+static MtTabEntry mt_tabs[MT_TABS];
+static unsigned long long mt_age = 0;
+static long mt_misses = 0;
+
+static unsigned long long mt_hash(unsigned long long h, const void* data, size_t bytes) {
+    const unsigned char* c = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+// the device table of (p, g, m, v, n) (lists that are absent stay null): cached; else built in the entry's pinned staging buffer and
+// uploaded by an asynchronous copy ON THE LAUNCH STREAM (a few KB; the host does not wait for the device: gradients that autograd
+// allocates afresh change their addresses from step to step and miss every time).  An entry's buffers are reused in place -- the
+// copy is ordered behind the launches that read the old contents, and the staging buffer is only rewritten after the event behind its
+// last copy has passed.  All launches of a process that share tables must be on one stream (they are: torch's current stream).
+// nullptr: no table (a stream capture is in progress, or a HIP call failed): the caller uses the kernel-argument form.
+static const MtTabEntry* mt_table(float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt, hipStream_t st, MtTab& tb) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    unsigned long long key = 1469598103934665603ull;
+    const int present = (p ? 1 : 0) | (m ? 2 : 0) | (v ? 4 : 0);
+    key = mt_hash(key, &present, sizeof(present));
+    key = mt_hash(key, &nt, sizeof(nt));
+    if (p) key = mt_hash(key, p, sizeof(float*) * nt);
+    key = mt_hash(key, g, sizeof(float*) * nt);
+    if (m) key = mt_hash(key, m, sizeof(float*) * nt);
+    if (v) key = mt_hash(key, v, sizeof(float*) * nt);
+    key = mt_hash(key, n, sizeof(long) * nt);
+    MtTabEntry* hit = nullptr;
+    MtTabEntry* victim = &mt_tabs[0];
+    for (int i = 0; i < MT_TABS; ++i) {
+        MtTabEntry& e = mt_tabs[i];
+        if (e.buf && e.key == key && e.dev == dev && e.nt == nt) { hit = &e; break; }
+        if (e.age < victim->age) victim = &e;
+    }
+    const size_t off_g = (size_t)nt * 8, off_m = 2 * off_g, off_v = 3 * off_g, off_n = 4 * off_g, off_blk = 5 * off_g;
+    if (!hit) {
+        ++mt_misses;
+        size_t blocks = 0;
+        for (int t = 0; t < nt; ++t) if (n[t] > 0) {
+            const size_t ch = (size_t)((n[t] + MT_CHUNK - 1) / MT_CHUNK);
+            if (ch > 65535 || t > 65535) return nullptr;
+            blocks += ch;
+        }
+        if (blocks == 0 || blocks > (1u << 30)) return nullptr;
+        const size_t bytes = off_blk + blocks * sizeof(unsigned);
+        MtTabEntry& e = *victim;
+        if (e.ev_set && hipEventSynchronize(e.ev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (e.dev != dev || e.cap < bytes) {          // (first use of the entry, another device, or a longer list: new buffers)
+            if (e.buf) (void)hipFree(e.buf);
+            if (e.host) (void)hipHostFree(e.host);
+            if (e.ev_set) (void)hipEventDestroy(e.ev);
+            e.buf = e.host = nullptr; e.ev_set = false; e.cap = 0;
+            const size_t cap = (bytes + 65535) / 65536 * 65536;
+            if (hipMalloc(&e.buf, cap) != hipSuccess || hipHostMalloc(&e.host, cap, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                if (e.buf) (void)hipFree(e.buf);
+                if (e.host) (void)hipHostFree(e.host);
+                e.buf = e.host = nullptr;
+                return nullptr;
+            }
+            e.cap = cap; e.ev_set = true; e.dev = dev;
+        }
+        unsigned char* host = static_cast<unsigned char*>(e.host);
+        memset(host, 0, off_blk);
+        if (p) memcpy(host, p, off_g);
+        memcpy(host + off_g, g, off_g);
+        if (m) memcpy(host + off_m, m, off_g);
+        if (v) memcpy(host + off_v, v, off_g);
+        memcpy(host + off_n, n, off_g);
+        unsigned* blk = reinterpret_cast<unsigned*>(host + off_blk);
+        size_t bi = 0;
+        for (int t = 0; t < nt; ++t) if (n[t] > 0) {
+            const unsigned ch = (unsigned)((n[t] + MT_CHUNK - 1) / MT_CHUNK);
+            for (unsigned c = 0; c < ch; ++c) blk[bi++] = ((unsigned)t << 16) | c;
+        }
+        if (hipMemcpyAsync(e.buf, e.host, bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(e.ev, st) != hipSuccess) {
+            (void)hipGetLastError();
+            e.key = 0; e.nt = -1;
+            return nullptr;
+        }
+        e.key = key; e.nt = nt; e.blocks = (int)blocks;
+        hit = &e;
+    }
+    hit->age = ++mt_age;
+    unsigned char* b = static_cast<unsigned char*>(hit->buf);
+    tb.p = p ? reinterpret_cast<float* const*>(b) : nullptr;
+    tb.g = reinterpret_cast<float* const*>(b + off_g);
+    tb.m = m ? reinterpret_cast<float* const*>(b + off_m) : nullptr;
+    tb.v = v ? reinterpret_cast<float* const*>(b + off_v) : nullptr;
+    tb.n = reinterpret_cast<const long*>(b + off_n);
+    tb.blk = reinterpret_cast<const unsigned*>(b + off_blk);
+    return hit;
+}
+
 template <int OP>
 int mt_run(MtArgs& a, float* const* p, float* const* g, float* const* m, float* const* v, const long* n, int nt, hipStream_t st,
            int* blocks_total) {
+    {   // ONE launch over a device-side block map (same block order, hence the same partial-sum order, as the launches below)
+        MtTab tb;
+        const MtTabEntry* e = mt_table(p, g, m, v, n, nt, st, tb);
+        if (e) {
+            a.op.partial_base = 0;
+            hipLaunchKernelGGL((mt_tab_kernel<OP>), dim3(e->blocks), dim3(MT_THREADS), 0, st, tb, a.op);
+            ST_LAUNCH_CHECK();
+            if (blocks_total) *blocks_total = e->blocks;
+            return 0;
+        }
+    }
     int ti = 0, bl = 0, base = 0;
     auto flush = [&]() -> int {
         if (bl == 0) { ti = 0; return 0; }
-        a.partial_base = base;
+        a.op.partial_base = base;
         hipLaunchKernelGGL((mt_kernel<OP>), dim3(bl), dim3(MT_THREADS), 0, st, a);
         ST_LAUNCH_CHECK();
         base += bl; ti = 0; bl = 0;
@@ -185,6 +316,9 @@ int mt_run(MtArgs& a, float* const* p, float* const* g, float* const* m, float* 
 
 }  // namespace
 
+// (diagnostics: how often a block map had to be built and uploaded -- once per set of tensor addresses)
+extern "C" long st_mt_table_misses(void) { return mt_misses; }
+
 extern "C" size_t st_mt_blocks(const long* n, int nt) {
     size_t b = 0;
     for (int t = 0; t < nt; ++t) if (n[t] > 0) b += (size_t)((n[t] + MT_CHUNK - 1) / MT_CHUNK);
@@ -196,7 +330,7 @@ extern "C" int st_mt_grad_norm_scaled(float* const* g, const long* n, int nt, fl
     ST_CHECK_ARG(g && n && nt > 0 && partials && norm_out && pre_scale > 0.0f, "st_mt_grad_norm: bad arguments");
     MtArgs a;
     memset(&a, 0, sizeof(a));
-    a.partial = partials;
+    a.op.partial = partials;
     int total = 0;
     int rc = mt_run<0>(a, nullptr, g, nullptr, nullptr, n, nt, (hipStream_t)stream, &total);
     if (rc) return rc;
@@ -214,7 +348,7 @@ extern "C" int st_mt_clip_scale_pre(float* const* g, const long* n, int nt, cons
     ST_CHECK_ARG(g && n && nt > 0 && norm && max_norm > 0.0f && pre_scale > 0.0f, "st_mt_clip_scale: bad arguments");
     MtArgs a;
     memset(&a, 0, sizeof(a));
-    a.norm = norm; a.max_norm = max_norm; a.pre_scale = pre_scale;
+    a.op.norm = norm; a.op.max_norm = max_norm; a.op.pre_scale = pre_scale;
     return mt_run<1>(a, nullptr, g, nullptr, nullptr, n, nt, (hipStream_t)stream, nullptr);
 }
 
@@ -255,8 +389,8 @@ extern "C" int st_mt_adam_guarded(float* const* p, float* const* g, float* const
     ST_CHECK_ARG(p && g && m && v && n && nt > 0 && bias_correction2_sqrt > 0.0f, "st_mt_adam: bad arguments");
     MtArgs a;
     memset(&a, 0, sizeof(a));
-    a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.step_size = step_size; a.bc2_sqrt = bias_correction2_sqrt;
-    a.norm = guard_norm;
+    a.op.b1 = beta1; a.op.b2 = beta2; a.op.eps = eps; a.op.step_size = step_size; a.op.bc2_sqrt = bias_correction2_sqrt;
+    a.op.norm = guard_norm;
     return mt_run<2>(a, p, g, m, v, n, nt, (hipStream_t)stream, nullptr);
 }
 

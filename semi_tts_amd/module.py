@@ -552,7 +552,7 @@ class Decoder(nn.Module):
         cache = self.__dict__.setdefault('_packed_cache', {}) if (self.cache_packed and not self.training) else None
         # keyed by the in-place version counters of the decoder's parameters: load_state_dict / an optimiser step bump them,
         # so a stale packing is never reused by an eager forward (a captured graph still needs refresh_weights())
-        ckey = (bool(fuse_pre0), str(dev), tuple(p._version for p in self.parameters()))
+        ckey = (bool(fuse_pre0), str(dev), tuple(p._version for p in self.parameters())) if cache is not None else None
         if cache is not None and ckey not in cache:
             cache.clear()
         if cache is not None and ckey in cache:

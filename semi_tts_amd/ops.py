@@ -22,7 +22,16 @@ def stream_handle():
     """hipStream_t (as int) all st_* calls are issued on: torch's current stream unless overridden."""
     if _stream_override is not None:
         return _stream_override
-    return torch.cuda.current_stream().cuda_stream
+    # (the raw handle straight from the C side: torch.cuda.current_stream() builds a Stream object through four Python layers -- 10 us a
+    # call, ~60 calls per training step and thread, once the host's time per step mattered: DESIGN 3.4)
+    return _raw_stream(_cur_device())
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+if _raw_stream is None or _cur_device is None:                 # (an older torch: the public way)
+    _raw_stream = lambda _dev: torch.cuda.current_stream().cuda_stream
+    _cur_device = lambda: 0
 
 
 def capturing():

@@ -166,6 +166,13 @@ class LazyStats(dict):
                 cb(self)
         return v
 
+    def put(self, k, v):
+        """the value of device scalar k, read by somebody else (drain_stats reads many in one copy); same side effects as reading it here"""
+        dict.__setitem__(self, k, v)
+        if k == 'grad_norm' and not math.isfinite(v) and self.on_nonfinite is not None:
+            cb, self.on_nonfinite = self.on_nonfinite, None
+            cb(self)
+
     def materialise(self):
         """read every device scalar (one wait for the GPU): the entry no longer holds device memory"""
         for k in dict.keys(self):
@@ -205,9 +212,12 @@ class TtsTrainer(BaseSolver):
     def _clip(self):
         """clip_grad_norm_(GRAD_CLIP) over the model; under data parallelism the 1 / world of the gradient average rides in it"""
         scale = getattr(self, '_grad_scale', 1.0)
+        params = self.__dict__.get('_clip_params')
+        if params is None:       # (nn.Module.parameters() walks the module tree through three generators: 0.25 ms per call for ~110 parameters)
+            params = self._clip_params = list(self.model.parameters())
         if scale != 1.0:
-            return self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP, pre_scale=scale)
-        return self.clip_grad_norm_(self.model.parameters(), self.GRAD_CLIP)
+            return self.clip_grad_norm_(params, self.GRAD_CLIP, pre_scale=scale)
+        return self.clip_grad_norm_(params, self.GRAD_CLIP)
 
     def __init__(self, config, paras, mode='train'):
         super().__init__(config, paras, mode)
@@ -237,6 +247,7 @@ class TtsTrainer(BaseSolver):
         from .optim import Optimizer
         from .synthetic import load_synthetic
         self.model = self._build_model().train()
+        self._clip_params = None
         hp = self.hp
         self.optimizer = Optimizer(self.model.parameters(), hp['optimizer'], hp['lr'], hp['lr_scheduler'],
                                    **{k: hp[k] for k in ('tf_start', 'tf_end', 'tf_step') if k in hp})
@@ -303,8 +314,11 @@ class TtsTrainer(BaseSolver):
             self._unread.append(st)
             # bounded: at most STATS_WINDOW steps of device scalars are alive.  While the one-launch BiLSTM is in use the window is short:
             # a starved layer poisons every forward until somebody looks, and every poisoned step is an update skipped on the device
-            if len(self._unread) >= (self.STATS_WINDOW_PERSIST if ops.LSTM_PERSIST else self.STATS_WINDOW):
-                self.drain_stats()
+            # (only the older half is read: the wait is for a step that finished a while ago, the GPU keeps the newer half queued and the
+            # host its lead -- a full drain every eighth step cost the data-parallel step 0.6 ms once the host was no longer far ahead)
+            window = self.STATS_WINDOW_PERSIST if ops.LSTM_PERSIST else self.STATS_WINDOW
+            if len(self._unread) >= window:
+                self.drain_stats(keep=window // 2)
             return st
         gn = float(grad_norm)
         if gn != gn:
@@ -317,7 +331,7 @@ class TtsTrainer(BaseSolver):
                     tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
 
     STATS_WINDOW = 64        # async_stats: steps whose statistics may stay unread on the device
-    STATS_WINDOW_PERSIST = 8     # ... while ops.LSTM_PERSIST is on (see train_step)
+    STATS_WINDOW_PERSIST = int(os.environ.get('ST_STATS_WINDOW_PERSIST', '8'))     # ... while ops.LSTM_PERSIST is on (see train_step)
 
     def check_device_status(self):
         """a kernel of the training step reported starvation since the last check (the one-launch BiLSTM's status word)?  Such a
@@ -339,9 +353,18 @@ class TtsTrainer(BaseSolver):
             opt.rollback_step(dict.get(st, 'opt_step'))
         self.verbose('Error : grad norm is not finite @ step %s (update skipped on the device)' % dict.get(st, 'step', '?'))
 
-    def drain_stats(self):
-        """read the statistics of every step issued so far (waits for the GPU once)"""
-        pending, self._unread = self._unread, []
+    def drain_stats(self, keep=0):
+        """read the statistics of the steps issued so far -- all but the `keep` newest (waits for the GPU once: for the newest step that
+        is read).  The device scalars of all those steps come back in ONE copy (one small gather launch) instead of one per scalar."""
+        n = len(self._unread) - keep
+        if n <= 0:
+            return
+        pending, self._unread = self._unread[:n], self._unread[n:]
+        slots = [(st, k) for st in pending for k in dict.keys(st) if torch.is_tensor(dict.__getitem__(st, k))]
+        if len(slots) > 1:
+            vals = torch.stack([dict.__getitem__(st, k).detach().reshape(()).float() for st, k in slots]).tolist()
+            for (st, k), v in zip(slots, vals):
+                st.put(k, v)
         for st in pending:
             st.materialise()
 

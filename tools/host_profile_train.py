@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Host-side profile of the training step (cProfile over N steps after warm-up, statistics unread: the host never waits for the GPU).
+usage: python tools/host_profile_train.py [--dist] [--steps N] > gpurun_out/host_profile.txt
+Where the host's time per step goes once the GPU side is short enough for the host to be the bound (round 5)."""
+import cProfile
+import io
+import os
+import pstats
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.environ.setdefault('ST_STATS_WINDOW_PERSIST', '1000')
+
+
+def main():
+    import argparse
+    import torch
+    import yaml
+    from argparse import Namespace
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dist', action='store_true')
+    ap.add_argument('--steps', type=int, default=30)
+    args = ap.parse_args()
+    import bench
+    if args.dist:
+        os.environ['ST_BENCH_FORCE_DIST'] = '1'
+    rk = bench.Ranks(Namespace(gpus=1, dist=args.dist))
+    from semi_tts_amd.solver import TtsTrainer
+    config = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-multi-spkr-paired-data.yaml')))
+    paras = Namespace(batch_size=bench.B, frames=bench.T_RAW, n_batches=1, seed=0, verbose=False, max_step=10 ** 9, load=None, n_spkr=109)
+    tr = TtsTrainer(config, paras, 'train').load_data().set_model()
+    batch = [t.to(rk.dev) for t in tr.batches[0]]
+    tr.async_stats = True
+    for _ in range(8):
+        tr.train_step(*batch)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable()
+    for _ in range(args.steps):
+        tr.train_step(*batch)
+    pr.disable()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print('host issue %.3f ms per step (under cProfile), GPU finished %.3f ms after the last issue' % ((t1 - t0) / args.steps * 1e3, (t2 - t1) * 1e3))
+    for key in ('tottime', 'cumtime'):
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
+        print(s.getvalue())
+    rk.close()
+
+
+if __name__ == '__main__':
+    main()

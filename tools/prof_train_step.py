@@ -10,7 +10,7 @@ import sys
 def main():
     con = sqlite3.connect(sys.argv[1])
     rows = con.execute("select name, start, end from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if 'mt_kernel<2>' in r[0]]       # the fused Adam update (optim.hip)
+    marks = [i for i, r in enumerate(rows) if 'mt_kernel<2>' in r[0] or 'mt_tab_kernel<2>' in r[0]]       # the fused Adam update (optim.hip)
     if len(marks) < 2:
         sys.exit('fewer than two optimiser launches in the trace')
     # the optimiser may be several launches per step (chunks): group marks closer than 200 us

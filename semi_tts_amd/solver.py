@@ -307,16 +307,34 @@ class TtsTrainer(BaseSolver):
             opt_step = getattr(getattr(self.optimizer, 'opt', None), 'guarded_steps', 0)      # (the key of this update in the optimiser's log)
             self.optimizer.step(guard_norm=grad_norm)
             self.step += 1
-            st = LazyStats(loss=total.detach(), mel_loss=mel_loss.detach(), linear_loss=linear_loss.detach(), grad_norm=grad_norm,
+            # the four device scalars of the step go into a row of a persistent ring: LazyStats then holds VIEWS, no allocation outlives
+            # the step, and the caching allocator hands every tensor of the next step the address it had in this one -- which is what
+            # lets the optimiser's device-side tables (optim.hip) and the hipGraphs of the two decoder loops (replay.h) be reused
+            # (scalars kept alive for 4 ... 8 steps made the addresses wander with a period of ~13 steps)
+            ring = self.__dict__.get('_stats_ring')
+            if ring is None or ring.device != grad_norm.device:
+                ring = self._stats_ring = torch.zeros(self.STATS_RING, 4, device=grad_norm.device)
+                self._stats_slot = 0
+                self._stats_host = torch.zeros(self.STATS_RING, 4).pin_memory()
+                self._stats_events = [torch.cuda.Event() for _ in range(self.STATS_RING)]
+                self._stats_stream = torch.cuda.Stream(device=grad_norm.device)
+            slot = self._stats_slot
+            row = ring[slot]
+            self._stats_slot = (slot + 1) % self.STATS_RING
+            torch.stack([total.detach().reshape(()), mel_loss.detach().reshape(()), linear_loss.detach().reshape(()),
+                         grad_norm.detach().reshape(())], out=row)
+            self._stats_events[slot].record()                 # (drain_stats waits for THIS step only, on a stream of its own)
+            st = LazyStats(loss=row[0], mel_loss=row[1], linear_loss=row[2], grad_norm=row[3],
                            tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1), step=self.step - 1,
                            opt_step=opt_step)
+            st.ring_slot = slot
             st.on_nonfinite = self._skipped_on_device
             self._unread.append(st)
             # bounded: at most STATS_WINDOW steps of device scalars are alive.  While the one-launch BiLSTM is in use the window is short:
             # a starved layer poisons every forward until somebody looks, and every poisoned step is an update skipped on the device
             # (only the older half is read: the wait is for a step that finished a while ago, the GPU keeps the newer half queued and the
             # host its lead -- a full drain every eighth step cost the data-parallel step 0.6 ms once the host was no longer far ahead)
-            window = self.STATS_WINDOW_PERSIST if ops.LSTM_PERSIST else self.STATS_WINDOW
+            window = min(self.STATS_WINDOW_PERSIST if ops.LSTM_PERSIST else self.STATS_WINDOW, self.STATS_RING - 1)
             if len(self._unread) >= window:
                 self.drain_stats(keep=window // 2)
             return st
@@ -331,6 +349,7 @@ class TtsTrainer(BaseSolver):
                     tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
 
     STATS_WINDOW = 64        # async_stats: steps whose statistics may stay unread on the device
+    STATS_RING = 256         # rows of the ring the unread statistics live in (> any window)
     STATS_WINDOW_PERSIST = int(os.environ.get('ST_STATS_WINDOW_PERSIST', '8'))     # ... while ops.LSTM_PERSIST is on (see train_step)
 
     def check_device_status(self):
@@ -360,11 +379,22 @@ class TtsTrainer(BaseSolver):
         if n <= 0:
             return
         pending, self._unread = self._unread[:n], self._unread[n:]
-        slots = [(st, k) for st in pending for k in dict.keys(st) if torch.is_tensor(dict.__getitem__(st, k))]
-        if len(slots) > 1:
-            vals = torch.stack([dict.__getitem__(st, k).detach().reshape(()).float() for st, k in slots]).tolist()
-            for (st, k), v in zip(slots, vals):
-                st.put(k, v)
+        ringed = [st for st in pending if getattr(st, 'ring_slot', None) is not None]
+        if ringed and self.__dict__.get('_stats_ring') is not None:
+            # the ring comes to the host on a stream of its own, behind the event of the NEWEST step that is read: the host waits for that
+            # step (finished a while ago when `keep` > 0), not for what has been issued since -- a read on the compute stream would be
+            # ordered behind everything queued on it.  No device allocation either (see train_step).
+            side = self._stats_stream
+            side.wait_event(self._stats_events[ringed[-1].ring_slot])
+            with torch.cuda.stream(side):
+                self._stats_host.copy_(self._stats_ring, non_blocking=True)
+            side.synchronize()
+            host = self._stats_host.tolist()
+            for st in ringed:
+                r = host[st.ring_slot]
+                for k, v in zip(('loss', 'mel_loss', 'linear_loss', 'grad_norm'), r):
+                    if torch.is_tensor(dict.__getitem__(st, k)):
+                        st.put(k, v)
         for st in pending:
             st.materialise()
 

@@ -37,11 +37,22 @@ def main():
         tr.train_step(*batch)
     torch.cuda.synchronize()
     pr = cProfile.Profile()
+    pr_bwd = cProfile.Profile()        # the backward functions run on the autograd engine's device thread: a profile of its own, switched on
+    orig_backward = torch.Tensor.backward      # by a hook on the loss and off by an engine callback
+
+    def backward(self, *a, **k):
+        def on(_g):
+            pr_bwd.enable()
+            torch.autograd.Variable._execution_engine.queue_callback(pr_bwd.disable)
+        self.register_hook(on)
+        return orig_backward(self, *a, **k)
+    torch.Tensor.backward = backward
     t0 = time.perf_counter()
     pr.enable()
     for _ in range(args.steps):
         tr.train_step(*batch)
     pr.disable()
+    torch.Tensor.backward = orig_backward
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -50,6 +61,13 @@ def main():
         s = io.StringIO()
         pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
         print(s.getvalue())
+    print('==== the autograd thread (backward functions)')
+    s = io.StringIO()
+    pstats.Stats(pr_bwd, stream=s).sort_stats('tottime').print_stats(40)
+    print(s.getvalue())
+    s = io.StringIO()
+    pstats.Stats(pr_bwd, stream=s).sort_stats('cumtime').print_stats(40)
+    print(s.getvalue())
     rk.close()
 
 

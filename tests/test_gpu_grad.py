@@ -683,6 +683,57 @@ def test_multi_tensor_clip_and_adam_against_torch(dev):
     assert o2.state[hip[0]]['_step'] == 3
 
 
+def test_optimiser_passes_table_form_equals_kernel_argument_form(dev):
+    """The gradient norm / clip / Adam launches read their tensor list from a cached device-side table (one launch per pass); during a
+    stream capture no table can be made and the list travels in the kernel arguments (several launches): same blocks in the same order,
+    so the two forms must agree bit for bit -- here the second form is run by capturing the calls into a hipGraph and replaying it."""
+    from semi_tts_amd import ops, _lib
+    from semi_tts_amd.optim import FusedAdam, clip_grad_norm_
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7,), (33, 5), (1, 1), (128, 257)] * 9 + [(3 * 1024 * 1024 + 5,)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [torch.randn(*s, generator=g) * 3.0 for s in shapes]
+
+    def fresh():
+        ps = [b.clone().to(dev).requires_grad_() for b in base]
+        for p, gr in zip(ps, grads):
+            p.grad = gr.clone().to(dev)
+        return ps, FusedAdam(ps, lr=1e-3)
+
+    lib = _lib.load()
+    pa, oa = fresh()
+    misses = lib.st_mt_table_misses()
+    na = clip_grad_norm_(pa, 5.0)
+    oa.step()
+    assert lib.st_mt_table_misses() > misses               # (the table form ran: new addresses, new tables)
+    torch.cuda.synchronize()
+    pb, ob = fresh()
+    gr = ops.Graph()
+    with gr.memory():
+        ob.step()                                          # (moments and workspaces exist before the capture; undone below)
+        clip_grad_norm_(pb, 5.0)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for p, b, g0 in zip(pb, base, grads):
+            p.copy_(b.to(dev)); p.grad.copy_(g0.to(dev))
+        for st in ob.state.values():
+            for k in ('exp_avg', 'exp_avg_sq'):
+                st[k].zero_()
+            st['_step'] = 0
+    held = {}
+    misses = lib.st_mt_table_misses()
+    with gr.capture():
+        with gr.memory():
+            held['n'] = clip_grad_norm_(pb, 5.0)
+            ob.step()
+    assert lib.st_mt_table_misses() == misses              # (no table during the capture)
+    gr.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(held['n'], na)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b) and torch.equal(a.grad, b.grad)
+
+
 def test_clip_with_pre_scale_and_multi_tensor_copy(dev):
     """the data-parallel forms of the optimiser helpers: clip_grad_norm_(pre_scale = 1 / world) on gradients that are still the SUM over
     the ranks = the plain clip on the averaged gradients (norm and result); ops.mt_copy gathers stray gradients into bucket slots

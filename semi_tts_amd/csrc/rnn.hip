@@ -581,7 +581,7 @@ struct LpArgs {
     const float* xproj[2]; const float* w_hh[2]; const float* b_hh[2];
     float* out; int ldo; int ocol[2];
     float* gates_tape[2]; float* c_tape[2];
-    int B, T, H; unsigned* status;
+    int B, T, H; unsigned* status; int xcd_map;
 };
 
 __global__ __launch_bounds__(256) void lp_fill_kernel(float* out, int ldo, int ocol0, int ocol1, int H, int rows) {
@@ -602,7 +602,14 @@ __global__ __launch_bounds__(256) void lstm_seq2_persist_kernel(const LpArgs a) 
     typedef __attribute__((address_space(1))) unsigned gu32;
     __shared__ f32x4 red[2][4 * RT * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x, d = blockIdx.y;
+    int tile = blockIdx.x, d = blockIdx.y;
+    if (a.xcd_map) {      // the workgroups of a direction on one half of the XCDs (workgroups go to the XCDs round-robin in launch order): the
+        // h blocks a workgroup polls then come from four L2s' worth of producers instead of eight -- 3.62 -> 3.51 us per step; a quarter
+        // or one XCD per direction loses (164 / 289 us per layer: two workgroups per unit, all hand-offs through one or two L2s).  Only
+        // speed depends on the placement: the hand-off itself is agent-scope stores and loads.
+        const int i = blockIdx.x + gridDim.x * blockIdx.y, xcd = i & 7, slot = i >> 3;
+        d = xcd >> 2; tile = slot * 4 + (xcd & 3);
+    }
     const int H = a.H, T = a.T, B = a.B;
     const int ar = lane & 15, q = lane >> 4;
     // MFMA A operand: lane supplies row `ar` of the 16 x 4 block = (unit tile*4 + ar/4, gate ar%4), k = 16 kb + 4 q + cc for the cc-th of
@@ -882,6 +889,7 @@ extern "C" int st_lstm_seq2_persist_fwd(const float* const* xproj2, const float*
         a.gates_tape[d] = gates_tape2 ? gates_tape2[d] : nullptr; a.c_tape[d] = c_tape2 ? c_tape2[d] : nullptr;
     }
     a.out = out; a.ldo = ldo; a.B = B; a.T = T; a.H = H; a.status = status;
+    a.xcd_map = (H / 4) % 4 == 0 ? 1 : 0;
     const size_t pieces = (size_t)B * T * (H / 2);
     hipLaunchKernelGGL(lp_fill_kernel, dim3((unsigned)((pieces + 255) / 256 < 1024 ? (pieces + 255) / 256 : 1024)), dim3(256), 0, st,
                        out, ldo, ocol2[0], ocol2[1], H, B * T);
@@ -894,8 +902,8 @@ extern "C" int st_lstm_seq2_persist_fwd(const float* const* xproj2, const float*
 
 // ---- BPTT of both directions of a bidirectional LSTM layer, ALL time steps in ONE launch ----------------------------------------------------
 // The per-step form (st_lstm_seq2_bwd_packed) is one launch of ~7.4 us per step: dh_rec = dgates(t+1) . W_hh with the pointwise backward
-// of step t in its epilogue.  Here the loop is one launch of (H/16) x ceil(B/16) x 2 workgroups of eight waves, all resident at once.
-// Workgroup (tile, bg, d) owns 16 hidden units and 16 batch rows of direction d: the 4H x 16 slice of W_hh it multiplies by stays in
+// of step t in its epilogue.  Here the loop is one launch of (H/16) x ceil(B/RG) x 2 workgroups of eight waves, all resident at once.
+// Workgroup (tile, bg, d) owns 16 hidden units and RG = 8 or 16 batch rows of direction d: the 4H x 16 slice of W_hh it multiplies by stays in
 // REGISTERS (wave w holds the k-blocks w NKB .. w NKB + NKB - 1 of K = 4H), the carried dL/dc of its 16 x 16 cells stays in
 // registers, and a step is
 //   1. poll the gate gradients of the step processed before (all 4H of them, for the workgroup's 16 batch rows) straight out of the
@@ -916,7 +924,7 @@ struct LbArgs {
     int B, T, H; unsigned* status;
 };
 
-template <int NKB>
+template <int NKB, int RG>
 __global__ __launch_bounds__(512) void lstm_seq2_bwd_persist_kernel(const LbArgs a) {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     typedef __attribute__((address_space(1))) unsigned gu32;
@@ -933,10 +941,13 @@ __global__ __launch_bounds__(512) void lstm_seq2_bwd_persist_kernel(const LbArgs
         for (int cc = 0; cc < 4; ++cc) wreg[i][cc] = a.w_hh[d][(size_t)(16 * (wave * NKB + i) + 4 * q + cc) * H + tile * 16 + ar];
     }
     // B operand: column `ar` = batch row bg*16 + ar (rows past B read row B - 1; their columns of D are dropped), the same k
-    const float* xp = a.dxp[d] + (size_t)min(bg * 16 + ar, B - 1) * T * H4 + 16 * (wave * NKB) + 4 * q;
+    // (RG = 8: eight batch rows per workgroup -- columns 8 .. 15 of the MFMA repeat rows 0 .. 7 (the same addresses: no extra traffic) and
+    // are dropped; twice the workgroups, half the gate gradients taken in per workgroup and step)
+    const int rr = ar & (RG - 1);
+    const float* xp = a.dxp[d] + (size_t)min(bg * RG + rr, B - 1) * T * H4 + 16 * (wave * NKB) + 4 * q;
     // pointwise role (waves 0 .. 3): D[row = 4 (lane >> 4) + r][col = lane & 15]; wave w takes r = w: unit ju of batch row pb
-    const int pb = bg * 16 + ar, ju = tile * 16 + 4 * q + (wave & 3);
-    const bool pw = pb < B;
+    const int pb = bg * RG + rr, ju = tile * 16 + 4 * q + (wave & 3);
+    const bool pw = pb < B && ar < RG;
     const int pbc = min(pb, B - 1);
     const size_t bhs = (size_t)B * H;
     const float* gp = a.gates_tape[d] + (size_t)pbc * 4 * H + ju;
@@ -964,7 +975,7 @@ __global__ __launch_bounds__(512) void lstm_seq2_bwd_persist_kernel(const LbArgs
             // (a) one canary word per producer workgroup of this wave's K range (batch row bg*16, first unit of the block)
             for (int sp = 0; sp < spins; ++sp) {
                 const int c = min(lane, NKB - 1);
-                gu32* cw = (gu32*)(a.dxp[d] + ((size_t)(bg * 16) * T + tn) * H4 + 16 * (wave * NKB + c));
+                gu32* cw = (gu32*)(a.dxp[d] + ((size_t)(bg * RG) * T + tn) * H4 + 16 * (wave * NKB + c));
                 const bool mine = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != LP_SENTINEL;
                 if (__all(mine)) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -1060,13 +1071,20 @@ extern "C" int st_lstm_seq2_bwd_persist(const float* dout, int ldd, const int* d
         ST_HIP(hipMemsetAsync(dxproj2[d], 0xFF, (size_t)B * T * 4 * H * sizeof(float), st));       // (every word = LP_SENTINEL)
     }
     a.dout = dout; a.ldd = ldd; a.B = B; a.T = T; a.H = H; a.status = status;
-    const dim3 grid(H / 16, (B + 15) / 16, 2), block(512);
+    // eight batch rows per workgroup while the workgroups fill at most half the device (the hand-off is bound by what a workgroup takes in
+    // per step: 220 -> 192 us per C2 layer; four rows -- every compute unit of the device -- gave 188 and leaves no room to be resident)
+    const int rg = 2 * (H / 16) * ((B + 7) / 8) <= st_device_cus() / 2 ? 8 : 16;
+    const dim3 grid(H / 16, (B + rg - 1) / rg, 2), block(512);
+#define LB_LAUNCH(NKB_) do { \
+        if (rg == 8) hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<NKB_, 8>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<NKB_, 16>), grid, block, 0, st, a); } while (0)
     switch (H / 32) {
-        case 1: hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<1>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<2>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<4>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((lstm_seq2_bwd_persist_kernel<8>), grid, block, 0, st, a); break;
+        case 1: LB_LAUNCH(1); break;
+        case 2: LB_LAUNCH(2); break;
+        case 4: LB_LAUNCH(4); break;
+        default: LB_LAUNCH(8); break;
     }
+#undef LB_LAUNCH
     ST_LAUNCH_CHECK();
     return 0;
 }

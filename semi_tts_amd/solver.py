@@ -309,8 +309,8 @@ class TtsTrainer(BaseSolver):
             self.step += 1
             # the four device scalars of the step go into a row of a persistent ring: LazyStats then holds VIEWS, no allocation outlives
             # the step, and the caching allocator hands every tensor of the next step the address it had in this one -- which is what
-            # lets the optimiser's device-side tables (optim.hip) and the hipGraphs of the two decoder loops (replay.h) be reused
-            # (scalars kept alive for 4 ... 8 steps made the addresses wander with a period of ~13 steps)
+            # lets the optimiser's device-side tables (optim.hip: mt_table) be reused instead of rebuilt (scalars kept alive for 4 ... 8 steps
+            # made the addresses wander with a period of ~13 steps)
             ring = self.__dict__.get('_stats_ring')
             if ring is None or ring.device != grad_norm.device:
                 ring = self._stats_ring = torch.zeros(self.STATS_RING, 4, device=grad_norm.device)

@@ -935,6 +935,12 @@ int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* 
  * (a stride rounded up to a multiple of 4, pad columns zero, puts the two products over dY on the 16-byte kernels); NULL = zeros */
 int st_decoder_pack_dout(const float* dmel, const float* dstop, float* dY, int ld, int B, int Bp, int steps, int r, int n_mels,
                          void* stream);
+/* the forward twin (teacher forcing with the deferred projection): Y (steps, Bp) rows [mel_t | stop_t] of stride ld -> mel (B, steps*r, n_mels)
+ * and stop (B, steps*r), a step's stop value repeated r times.  ref: src/module.py:283-287 */
+int st_decoder_unpack_out(const float* Y, float* mel, float* stop, int B, int Bp, int steps, int r, int n_mels, int ld, void* stream);
+/* gradient of prenet(teacher) under plain teacher forcing (step t + 1 reads frame t, src/module.py:190-206): dteacher (Bt, Tt, P) = the dec_in
+ * columns of dxq_{t+1}, summed over the S slabs of dxq_part (steps + 1, S, Bp, XQw) in slab order; frames t >= steps - 1: zeros */
+int st_decoder_dteacher_sum(const float* dxq_part, float* dteacher, int S, int Bp, int XQw, int Bt, int Tt, int P, int steps, void* stream);
 /* AdaIN statistics gradients (ref: src/module.py:267-269): adapted_t = std * (h_q_t - mean)
  * dstd = sum_t dadapt_t * (h_q_t - mean), dmean = -std * sum_t dadapt_t; *_step_stride / *_ld in elements */
 int st_adain_bwd(const float* dadapt, long da_step_stride, int da_ld, const float* hq, long hq_step_stride, int hq_ld,

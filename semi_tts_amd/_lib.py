@@ -273,6 +273,8 @@ SIGNATURES = {
     'st_attn_dmem': [P, P, P, I, I, I, I, P],
     'st_decoder_backward': [C.POINTER(StDecoderBwdWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO), P],
     'st_decoder_pack_dout': [P, P, P, I, I, I, I, I, I, P],
+    'st_decoder_unpack_out': [P, P, P, I, I, I, I, I, I, P],
+    'st_decoder_dteacher_sum': [P, P, I, I, I, I, I, I, I, P],
     'st_adain_bwd': [P, C.c_long, I, P, C.c_long, I, P, P, P, P, I, I, I, P],
     'st_mt_blocks': [P, I],
     'st_mt_table_misses': [],

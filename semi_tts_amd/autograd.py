@@ -919,9 +919,17 @@ class _DecoderFn(Function):
         dteacher = None
         if teacher_pre is not None:
             Tt = teacher_pre.shape[1]
-            dteacher = z(Bt, Tt, P)
-            if steps > 1:
-                identity = list(src[:steps - 1]) == list(range(steps - 1))
+            identity = list(src[:steps - 1]) == list(range(steps - 1))
+            if steps > 1 and identity and dxq_slabs and dxq_part.is_contiguous():
+                # (plain teacher forcing: the slabs of dxq_t[:, :P] added in slab order, frames no step read zeroed -- one launch)
+                dteacher = torch.empty(Bt, Tt, P, **f32)
+                _lib.check(lib.st_decoder_dteacher_sum(ops._p(dxq_part), ops._p(dteacher), int(dxq_part.shape[1]), int(dxq_part.shape[2]),
+                                                       int(dxq_part.shape[3]), Bt, Tt, P, steps, ops.stream_handle()), 'st_decoder_dteacher_sum')
+                steps_done = True
+            else:
+                dteacher = z(Bt, Tt, P)
+                steps_done = False
+            if steps > 1 and not steps_done:
                 if dxq_slabs and not identity:     # (rare: teacher-mean steps) the general forms below read whole rows: add the slabs up once
                     dxq[1:steps] = dxq_part[1:steps].sum(1)
                 if identity and dxq_slabs:

@@ -400,6 +400,39 @@ __global__ __launch_bounds__(256) void pack_dout_kernel(const float* dmel, const
     }
 }
 
+// the forward twin: Y[t][b][:] = [mel_t | stop_t] rows of the deferred proj (+) gate product -> mel[b][t*r .. ][:], stop[b][t*r + j] (the
+// stop value of a step repeated r times, src/module.py:287): one launch instead of 1 + r strided copies
+__global__ __launch_bounds__(256) void unpack_out_kernel(const float* Y, float* mel, float* stop, int B, int Bp, int steps, int r, int n_mels, int ld) {
+    const int in_dim = r * n_mels, W = in_dim + r;
+    const size_t total = (size_t)steps * B * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % W);
+        const size_t row = i / W;
+        const int t = (int)(row % steps), b = (int)(row / steps);
+        const float* y = Y + ((size_t)t * Bp + b) * ld;
+        if (c < in_dim) mel[((size_t)b * steps + t) * in_dim + c] = y[c];
+        else stop[(size_t)b * steps * r + (size_t)t * r + (c - in_dim)] = y[in_dim];
+    }
+}
+
+// gradient of prenet(teacher) under plain teacher forcing (step t + 1 read teacher frame t): dteacher[b][t][:] = the dec_in columns of
+// dxq_{t+1}, the S slabs of the K-split product added in slab order; frames no step read (t >= steps - 1) get zeros.  One launch instead
+// of a fill and one strided copy per slab.
+__global__ __launch_bounds__(256) void dteacher_sum_kernel(const float* dxq_part, float* dteacher, int S, int Bp, int XQw, int Bt, int Tt, int P, int steps) {
+    const size_t total = (size_t)Bt * Tt * P;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const size_t bt = i / P;
+        const int t = (int)(bt % Tt), b = (int)(bt / Tt);
+        float v = 0.0f;
+        if (t < steps - 1) {
+            const float* src = dxq_part + (((size_t)(t + 1) * S) * Bp + b) * XQw + p;
+            for (int sl = 0; sl < S; ++sl) v += src[(size_t)sl * Bp * XQw];
+        }
+        dteacher[i] = v;
+    }
+}
+
 // AdaIN parameter gradients: adapted_t = std * (h_q_t - mean)
 //   dstd[b][q] = sum_t da[t][b][q] * (h_q_t[b][q] - mean[b][q]);   dmean[b][q] = -std[b][q] * sum_t da[t][b][q]
 __global__ __launch_bounds__(256) void adain_bwd_kernel(const float* da, long da_st, int da_ld, const float* hq, long hq_st, int hq_ld,
@@ -431,6 +464,28 @@ extern "C" int st_decoder_pack_dout(const float* dmel, const float* dstop, float
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_dout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dmel, dstop, dY, B, Bp,
                        steps, r, n_mels, ld);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_decoder_unpack_out(const float* Y, float* mel, float* stop, int B, int Bp, int steps, int r, int n_mels, int ld, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(Y && mel && stop && B > 0 && Bp >= B && steps > 0 && r > 0 && n_mels > 0 && ld >= r * n_mels + 1, "st_decoder_unpack_out: bad arguments");
+    const size_t total = (size_t)steps * B * (r * n_mels + r);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(unpack_out_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Y, mel, stop, B, Bp, steps, r, n_mels, ld);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_decoder_dteacher_sum(const float* dxq_part, float* dteacher, int S, int Bp, int XQw, int Bt, int Tt, int P, int steps, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dxq_part && dteacher && S > 0 && Bp >= Bt && Bt > 0 && Tt > 0 && P > 0 && XQw >= P && steps > 0, "st_decoder_dteacher_sum: bad arguments");
+    const size_t total = (size_t)Bt * Tt * P;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dteacher_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dxq_part, dteacher, S, Bp, XQw, Bt, Tt, P, steps);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -379,12 +379,18 @@ class Decoder(nn.Module):
         pw, gw = self.proj.linear.weight, self.gate_layer.linear.weight
         in_dim, KO = pw.shape
         n_rows = in_dim + 1 + (self.prenet_dim if fuse_pre0 else 0)
-        pg_w = torch.empty(n_rows, KO, device=pw.device, dtype=torch.float32)
-        pg_b = torch.empty(n_rows, device=pw.device, dtype=torch.float32)
-        ops.copy2d(pg_w, pw, in_dim, KO)
-        ops.copy2d(pg_w[in_dim:], gw, 1, KO)
-        ops.copy2d(pg_b.view(1, -1), self.proj.linear.bias.view(1, -1), 1, in_dim)
-        ops.copy2d(pg_b.view(1, -1)[:, in_dim:], self.gate_layer.linear.bias.view(1, -1), 1, 1)
+        if not fuse_pre0 and not ops.capturing():
+            # (training / eager teacher forcing: the two concatenations are cached parameter layouts, refreshed with every other layout
+            # of the model by the one relayout launch of the step -- four copy launches less per forward)
+            pg_w = ops.cat_params([pw.detach(), gw.detach()])
+            pg_b = ops.cat_params([self.proj.linear.bias.detach(), self.gate_layer.linear.bias.detach()])
+        else:
+            pg_w = torch.empty(n_rows, KO, device=pw.device, dtype=torch.float32)
+            pg_b = torch.empty(n_rows, device=pw.device, dtype=torch.float32)
+            ops.copy2d(pg_w, pw, in_dim, KO)
+            ops.copy2d(pg_w[in_dim:], gw, 1, KO)
+            ops.copy2d(pg_b.view(1, -1), self.proj.linear.bias.view(1, -1), 1, in_dim)
+            ops.copy2d(pg_b.view(1, -1)[:, in_dim:], self.gate_layer.linear.bias.view(1, -1), 1, 1)
         if fuse_pre0:
             # prenet layer 1 of the own output, folded into the projection: relu(W0 (Wp y + bp)) =
             # relu((W0 Wp) y + W0 bp); the two products are formed once per forward on device
@@ -650,10 +656,9 @@ class Decoder(nn.Module):
             Bp = ((B + 15) // 16) * 16
             xo_nat = ops.untile_tape(tapes['xo'], steps, Bp, kb(D) + kb(E), [(0, D), (kb(D), E)])       # [h_d_t | ctx_t]
             y = ops.gemm(xo_nat.view(-1, D + E), keep[-2], bias=keep[-1]).view(steps, Bp, in_dim + 1)   # proj (+) gate rows
-            yb = y.permute(1, 0, 2)[:B]
-            ops.copy3d(mel.view(B, steps, in_dim), yb[:, :, :in_dim], B, steps, in_dim)
-            for j in range(r):                                                                       # stop.repeat(1, r) :287
-                ops.copy3d(stop.view(B, steps, r)[:, :, j:j + 1], yb[:, :, in_dim:], B, steps, 1)
+            # rows (t, b) of [mel_t | stop_t] -> mel (B, steps*r, n_mels), stop.repeat(1, r) (:287): one launch
+            check(lib.st_decoder_unpack_out(ops._p(y), ops._p(mel), ops._p(stop), B, Bp, steps, r, n_mels, in_dim + 1, ops.stream_handle()),
+                  'st_decoder_unpack_out')
             tapes['xo_nat'] = xo_nat
         tapes['packed'] = packed
         tapes.update(pm=pm, ada_std=ada_std, ada_mean=ada_mean, teacher_pre=teacher_pre, masks=(own_mask, q_mask, d_mask),

@@ -702,7 +702,7 @@ typedef struct st_decoder_io {
     int pre1_step_floats;     /* > 0: pre1_t16 is a tape of `steps` slots of that many floats (training keeps the prenet
                                * layer-1 output of every own-output feedback for the backward); 0: one scratch slot */
     int attn_s_step_floats;   /* > 0: attn_s_buf is a tape, slot t = S of step t (B*L*A floats apart), kept for the backward */
-    float* attn_loc_tape;     /* optional (steps, B, L, F): location features of every step (slot 0 is never written: zero it) */
+    float* attn_loc_tape;     /* optional (steps, B, L, F): location features of every step (slot 0, which no step writes, is zeroed by the callee) */
     float* attn_split_ws;     /* optional, st_attn_fin_split_workspace_floats(B, E, attn_split_parts) floats: long texts run the fin part
                                * split over attn_split_parts position ranges + a combine launch (st_attn_fin_split_fwd) */
     int attn_split_parts;

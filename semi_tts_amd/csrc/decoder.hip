@@ -216,6 +216,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     zero(io->zero_row, BL * sizeof(float));
     zero(io->xq_tape, sv.q_floats * sizeof(float));
     zero(io->xd_tape, sv.d_floats * sizeof(float));
+    if (io->attn_loc_tape) zero(io->attn_loc_tape, BL * d->F * sizeof(float));      // (slot 0: no step writes it -- there is no history yet)
 
     const size_t ldmel = (size_t)steps * in_dim;
     const int ldal = steps * L;

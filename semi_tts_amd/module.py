@@ -604,7 +604,7 @@ class Decoder(nn.Module):
         if self.attn_split and (not self.training or defer):
             if keep_tapes:      # training: S and the location features of every step stay for the backward pass
                 tapes['attn_s'] = torch.empty(steps, B, L, A, **f32)
-                tapes['attn_loc'] = torch.zeros(steps, B, L, self.n_location_filters, **f32)     # slot 0: no history yet
+                tapes['attn_loc'] = torch.empty(steps, B, L, self.n_location_filters, **f32)     # (slot 0 -- no history yet -- is zeroed by the loop's first launch)
                 io.attn_s_step_floats = B * L * A
                 io.attn_loc_tape = ops._p(tapes['attn_loc'])
             else:

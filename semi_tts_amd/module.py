@@ -24,9 +24,20 @@ from . import autograd as AG
 from ._lib import StDecoderWeights, StDecoderDims, StDecoderIO, check
 
 
+_ONES = {}
+
+
 def _scaled_mask(shape, p, device):
-    """bernoulli(1-p)/(1-p) dropout mask (device RNG; the values the reference's F.dropout multiplies by)"""
-    return torch.empty(shape, device=device, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p)
+    """bernoulli(1-p)/(1-p) dropout mask (device RNG; the values the reference's F.dropout multiplies by): F.dropout of a cached tensor of
+    ones -- ONE launch (bernoulli_ + div_ were two)"""
+    n = int(torch.Size(shape).numel())
+    key = (str(device), n)
+    ones = _ONES.get(key)
+    if ones is None:
+        if len(_ONES) > 64:
+            _ONES.clear()
+        ones = _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
+    return torch.nn.functional.dropout(ones, p, training=True).view(shape)
 
 
 def _scaled_masks(shapes, p, device):

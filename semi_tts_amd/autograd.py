@@ -800,7 +800,7 @@ class _DecoderFn(Function):
             zb[k] = pool[off:off + numel(shp)].view(*shp)
             off += (numel(shp) + 3) // 4 * 4
         z = lambda *shape: torch.zeros(*shape, **f32)
-        e_ = lambda *shape: torch.empty(*shape, **f32)
+        e_ = lambda *shape: ops.uninit(*shape, **f32)
         if lazy_big:
             zb.update({k: e_(*shp) for k, shp in big.items()})
         dgq, dgd, dxq, dxd, dpq = zb['dgq'], zb['dgd'], zb['dxq'], zb['dxd'], zb['dpq']

@@ -1068,7 +1068,13 @@ extern "C" int st_lstm_seq2_bwd_persist(const float* dout, int ldd, const int* d
     LbArgs a;
     for (int d = 0; d < 2; ++d) {
         a.dcol[d] = dcol2[d]; a.gates_tape[d] = gates_tape2[d]; a.c_tape[d] = c_tape2[d]; a.w_hh[d] = w_hh2[d]; a.dxp[d] = dxproj2[d];
-        ST_HIP(hipMemsetAsync(dxproj2[d], 0xFF, (size_t)B * T * 4 * H * sizeof(float), st));       // (every word = LP_SENTINEL)
+    }
+    // every word = LP_SENTINEL (one fill when the two tensors lie back to back: ops.lstm_seq2_bwd allocates them so)
+    const size_t words = (size_t)B * T * 4 * H;
+    if (dxproj2[1] == dxproj2[0] + words) ST_HIP(hipMemsetAsync(dxproj2[0], 0xFF, 2 * words * sizeof(float), st));
+    else {
+        ST_HIP(hipMemsetAsync(dxproj2[0], 0xFF, words * sizeof(float), st));
+        ST_HIP(hipMemsetAsync(dxproj2[1], 0xFF, words * sizeof(float), st));
     }
     a.dout = dout; a.ldd = ldd; a.B = B; a.T = T; a.H = H; a.status = status;
     // eight batch rows per workgroup while the workgroups fill at most half the device (the hand-off is bound by what a workgroup takes in

@@ -15,6 +15,18 @@ from ._lib import StSeg, StGemmEpilogue, check
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 
+# Debug aid (tests): buffers that are handed to the kernels UNINITIALISED because every element is written before it is read (step tapes
+# of the training loops, slab workspaces) are filled with NaN first -- a read of something nobody wrote then shows up in the result.
+POISON_UNINIT = False
+
+
+def uninit(*shape, device, dtype=torch.float32):
+    """torch.empty for a buffer whose every element the kernels write before reading it (NaN-filled under POISON_UNINIT)"""
+    t = torch.empty(*shape, device=device, dtype=dtype)
+    if POISON_UNINIT:
+        t.fill_(float('nan'))
+    return t
+
 _stream_override = None
 
 
@@ -649,7 +661,7 @@ def lstm_seq2_bwd(dout, gates_tapes, c_tapes, w_hh_ts, w_hhs=None):
     """both directions at once: dout (B,T,2H) -> (dxproj_f, dxproj_b), each (B,T,4H).  w_hhs = the two W_hh parameters (4H, H): with
     H % 16 == 0 the loop runs on packed operands, one launch per step (product + pointwise backward of the previous step)."""
     T, B, _, H = gates_tapes[0].shape
-    dx = [torch.empty(B, T, 4 * H, device=dout.device, dtype=torch.float32) for _ in range(2)]
+    dx = list(torch.empty(2, B, T, 4 * H, device=dout.device, dtype=torch.float32).unbind(0))      # (back to back: one sentinel fill)
     lib = _lib.load()
     P2 = C.c_void_p * 2
     arr = lambda a, b_: P2(_p(a), _p(b_))

@@ -280,3 +280,40 @@ def test_postnet_class_training_mode_against_reference_golden(dev):
     # without explicit masks the module draws its own (device RNG): finite, and about half of the last block's outputs dropped
     y2 = m(A['x'].to(dev))
     assert bool(torch.isfinite(y2).all()) and 0.3 < float((y2 == 0).float().mean()) < 0.7
+
+
+def test_c2_training_step_with_poisoned_uninitialised_buffers(dev):
+    """The training loops hand their step tapes and slab workspaces to the kernels UNINITIALISED where every element is written before
+    it is read (no padding at C2 sizes: B and every width a multiple of 16).  With those buffers filled with NaN first
+    (ops.POISON_UNINIT) the step must give the same gradients bit for bit: nothing reads what nobody wrote."""
+    import yaml
+    from semi_tts_amd import autograd as AG, ops
+    from semi_tts_amd.synthetic import load_synthetic, synthetic_train_batch
+    from semi_tts_amd.vqvae import VQVAE
+    cfg = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-single-spkr-paired-data.yaml')))
+    mcfg = cfg['model']
+    mcfg['codebook'].update(phn_attr_pth='', proj_attr=None)
+    sr, n_mels = cfg['data']['audio']['sample_rate'], cfg['data']['audio']['num_mels']
+    text, sid, mel, linear = (t.to(dev) for t in synthetic_train_batch(32, 256, 3, seed=17))
+
+    def run(poison):
+        m = VQVAE(80, 1025, 43, 109, **mcfg)
+        load_synthetic(m, 321)
+        m = m.to(dev).train()
+        old = ops.POISON_UNINIT
+        ops.POISON_UNINIT = poison
+        try:
+            torch.manual_seed(5)
+            mel_p, lin_p, *_ = m.text_to_speech(text, sid, None, None, None, None, mel, None, 1.0)
+            f = lambda p, l: AG.freq_loss(p, l, sr, n_mels, 'mse', True, True)
+            (f(mel_p, mel) + f(lin_p, linear)).backward()
+        finally:
+            ops.POISON_UNINIT = old
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    g0, g1 = run(False), run(True)
+    assert set(g0) == set(g1) and len(g0) > 100
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g0[k], g1[k]), k

@@ -268,10 +268,9 @@ __device__ const f32x4 tn_zero4 = {0.f, 0.f, 0.f, 0.f};
 typedef const __attribute__((address_space(1))) void* tn_gptr_t;
 typedef __attribute__((address_space(3))) void* tn_lptr_t;
 
-template <int TM>
+template <int TM, int RC = 32>
 __device__ __forceinline__ void tn_dma_body(const TnArgs& g, const int bx, const int by, const int bz) {
     constexpr int FR = TM / 32;
-    constexpr int RC = 32;                              // rows per chunk
     constexpr int PPR = TM / 4;                         // 16-byte pieces per row
     constexpr int RPI = TN_THREADS / PPR;               // rows one DMA pass of the workgroup covers (16 at TM = 64, 8 at 128)
     constexpr int NI = RC / RPI;                        // DMA instructions per thread, operand and chunk
@@ -403,6 +402,11 @@ __device__ __forceinline__ void tn_dma_body(const TnArgs& g, const int bx, const
 
 template <int TM>
 __global__ __launch_bounds__(TN_THREADS) void tn_dma_kernel(const TnArgs g) { tn_dma_body<TM>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+// 16-row chunks: three buffers of 2 x 16 x TM floats (48 KB at TM = 128, 24 KB at 64) -- three workgroups of the 128-tile form share a
+// compute unit instead of one (96 KB), and the waves of one cover the barrier and the DMA waits of another: the decoder LSTMs' weight
+// gradients 932 -> 840 us.  Same k order per output element (rows ascending): bit-identical results.
+template <int TM>
+__global__ __launch_bounds__(TN_THREADS) void tn_dma_rc16_kernel(const TnArgs g) { tn_dma_body<TM, 16>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // ---- weight gradient of a convolution with very few input channels (the attention's location conv: 2 channels x 31 taps -> 32 filters,
 // over steps x B sequences of L positions) --------------------------------------------------------------------------------------------------
@@ -1241,7 +1245,8 @@ inline int blocks_for(size_t n, int cap = 4096) {
 static inline bool tn_fold(int Cin, int KT, int pool_prev) { return Cin < 16 && KT > 1 && !pool_prev; }
 
 // 128 x 128 tiles only where they still give every compute unit a workgroup (>= 256 tiles: the two decoder-LSTM gradients, 4096 x 2560
-// and 4096 x 1792); below that the 64 x 64 form wins through occupancy.  Measured per training step (all weight-gradient products):
+// and 4096 x 1792); below that the 64 x 64 form wins through occupancy (re-measured with the 16-row-chunk 128 form, three workgroups per
+// unit: the encoder conv's gradient 81.8 vs 59.3 us, the final Linear's 68.4 vs 52.5; training step 8.87 / 9.02+ vs 8.80 ms at thresholds 64 / 16).  Measured per training step (all weight-gradient products):
 // 128-tiles wherever both dimensions reach 128: 2270 us; from 64 tiles on 2153; from 256 on 2112; from 512 on 2148
 static inline int tn_tile(int Cin, int N, int KT) {
     if (!(N >= 128 && Cin >= 128) || tn_fold(Cin, KT, 0)) return TN_T;
@@ -1325,12 +1330,8 @@ static int tn_impl(const float* dC, int lddc, int dcoff, const float* A, int lda
     const bool dma = !g.fold && !pool_prev && g.vecx && g.vecy && whole && g.rows_per_z % 32 == 0;
     if (dma) {
         const size_t lds = (size_t)3 * 2 * 32 * TM * sizeof(float);       // 48 KB at TM = 64, 96 KB at 128
-        static bool set128 = false;
-        if (TM == 128 && !set128) {
-            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tn_dma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            set128 = true;
-        }
-        if (TM == 128) hipLaunchKernelGGL((tn_dma_kernel<128>), grid, dim3(TN_THREADS), lds, st, g);
+        // (128 tiles: 16-row chunks, 48 KB -- three workgroups per compute unit; 64 tiles: 32-row chunks, 48 KB: 16-row chunks change nothing)
+        if (TM == 128) hipLaunchKernelGGL((tn_dma_rc16_kernel<128>), grid, dim3(TN_THREADS), lds / 2, st, g);
         else hipLaunchKernelGGL((tn_dma_kernel<64>), grid, dim3(TN_THREADS), lds, st, g);
     } else if (TM == 128) hipLaunchKernelGGL((tn_kernel<128>), grid, dim3(TN_THREADS), 0, st, g);
     else hipLaunchKernelGGL((tn_kernel<64>), grid, dim3(TN_THREADS), 0, st, g);

@@ -19,6 +19,8 @@ Secondary workloads (not the headline):
   c3     the VQ nearest-code search (L2Embedding.forward) at 32x129 / 256x129 vectors, V=43 / 512
   train  BASELINE config 4: the paired TTS training step, B=32 per GPU, 109 speakers, SyncBN over the
          global batch, RCCL all-reduce of the gradients (ms_allreduce / ms_syncbn reported)
+  cycle  BASELINE config 3 as the reference trains it: VqvaeTrainer.exec's alternating speech-first / text-first
+         cycles (CTC speech encoder + VQ search + run-length merge + TTS branch), paired + unpaired batch
 """
 import argparse
 import json
@@ -681,6 +683,145 @@ def bench_train(args, rk):
             **({'cpu_baseline': cpu} if cpu is not None else {})}
 
 
+# ===================================================================================== the two cycles (C3 as the reference trains it)
+def cycle_flops(Bp, Bu, T, L, Ta, Tau, dec, enc_asr, n_mels=N_MELS):
+    """algorithmic FLOPs of one cycle step's FORWARD: CTC speech encoder on the paired (+ unpaired) aug_mel, VQ search, the TTS branch
+    (SURVEY 8d per-unit figures: decoder step, text encoder per position, CBHG + Linear per frame) at the batch / text length it ran at"""
+    dim, k, st = enc_asr['dim'], enc_asr['kernel'], enc_asr['stride']
+    H = enc_asr['rnn_dim']
+    Tm = max(Ta, Tau) if Bu else Ta
+    cin, t, asr = n_mels, Tm, 0.0
+    for kk, ss in zip(k, st):
+        t = (t + 2 * (1 if kk != 1 else 0) - kk) // ss + 1
+        asr += 2.0 * cin * kk * dim * t
+        cin = dim
+    for layer in range(enc_asr['rnn_layers']):
+        asr += 2.0 * (cin + H) * 4 * H * 2 * t
+        cin = 2 * H
+    asr += 2.0 * cin * 64 * t + 2.0 * 64 * 43 * t
+    Bt = Bp + Bu
+    r = dec['n_frames_per_step']
+    steps = T // r
+    tts = Bt * (steps * 2.0 * (18847232 + 10944 * L) + 2.0 * (4358144 + 131072) * L + 1.655e6 * T)
+    return asr * Bt + tts
+
+
+def bench_cycle(args, rk):
+    """BASELINE config 3 as the reference trains it (main.py:61-63 -> bin/train_vqvae.py:111-270): VqvaeTrainer.exec's alternation of the
+    speech -> text -> speech cycle (even steps; with the unpaired batch: speech encoder + VQ search + run-length merge on paired ||
+    unpaired aug_mel, then the TTS branch on paired text || merged unpaired latents, unpair_speech_weight 10) and the
+    text -> speech -> text cycle (odd steps; unpair_text_weight 0: the paired batch alone through the TTS branch, then the speech encoder).
+    Timed: K steps of the alternating loop, then K steps of each kind on its own (kinds.*)."""
+    import torch
+    import yaml
+    from argparse import Namespace
+    from semi_tts_amd import parallel
+    from semi_tts_amd.solver import VqvaeTrainer
+    config = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-single-spkr-paired-data.yaml')))
+    Bc = args.batch_size or B
+    paras = Namespace(batch_size=Bc, unpair_batch_size=args.unpair_batch_size or Bc, frames=T_RAW, n_batches=1, seed=0, verbose=False,
+                      max_step=10 ** 9, load=None, n_spkr=109)
+    tr = VqvaeTrainer(config, paras, 'train').load_data().set_model()
+    tr.async_stats = not args.sync_stats
+    pair, unpair = tr.fetch_data('pair_iter'), tr.fetch_data('unpair_iter')
+    last = {}
+
+    def loop_step():
+        kind, use = tr.cycle_kind(tr.step)
+        last[kind] = tr.cycle_step(pair, unpair if use else None)
+
+    def only(kind):
+        def f():
+            tr.step += (tr.step % 2) != (0 if kind == 'speech_first' else 1)      # (the step counter picks the cycle; the lr schedule moves by one step)
+            last[kind] = tr.cycle_step(pair, unpair if tr.cycle_kind(tr.step)[1] else None)
+        return f
+
+    tr.step = 2                                   # past unpair_speech_start_step (0): the unpaired batch joins from the first timed step on
+    loop_step(); loop_step()
+    steps = args.steps + (args.steps % 2)         # whole pairs of cycles
+    elapsed = rk.timed(loop_step, steps, args.warmup + (args.warmup % 2))
+    issue_ms = rk.issue_seconds / steps * 1e3
+    kinds = {}
+    for kind in ('speech_first', 'text_first'):
+        e = rk.timed(only(kind), args.steps, 2)
+        kinds[kind] = {'ms_per_step': round(e / args.steps * 1e3, 3), 'ms_host_issue_per_step': round(rk.issue_seconds / args.steps * 1e3, 3)}
+    tr.drain_stats()
+    tr.check_device_status()
+    for kind in kinds:
+        assert float(last[kind]['grad_norm']) == float(last[kind]['grad_norm']), 'non-finite gradient norm in the timed steps (%s)' % kind
+    if rk.rank != 0:
+        return None
+    mel, aug, _, text, _ = pair
+    umel, uaug = unpair[0], unpair[1]
+    Bp, Tp, Lp = mel.shape[0], mel.shape[1], text.shape[1]
+    Bu = umel.shape[0]
+    Lu = int(last['speech_first'].get('unpair_text_len', 0))
+    dec = config['model']['decoder']['decoder']
+    enc = config['model']['encoder']
+    fl = {'speech_first': 3 * cycle_flops(Bp, Bu if Lu else 0, max(Tp, umel.shape[1]), max(Lp, Lu), aug.shape[1], uaug.shape[1], dec, enc),
+          'text_first': 3 * cycle_flops(Bp, 0, Tp, Lp, aug.shape[1], 0, dec, enc)}
+    frames = {'speech_first': Bp * Tp + (Bu * umel.shape[1] if Lu else 0), 'text_first': Bp * Tp}
+    for kind, d in kinds.items():
+        tf = fl[kind] / (d['ms_per_step'] * 1e-3) / 1e12
+        d.update(mel_frames_per_s=round(frames[kind] / (d['ms_per_step'] * 1e-3), 1), gflop_per_step=round(fl[kind] / 1e9, 1),
+                 roofline={'bound': 'mfma', 'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None},
+                 last={k: float(last[kind][k]) for k in ('loss', 'grad_norm', 'asr_loss', 'tts_loss') if k in last[kind]})
+    kinds['speech_first']['unpair_text_len'] = Lu
+    total_frames = rk.world * (frames['speech_first'] + frames['text_first']) * (steps // 2)
+    total_fl = (fl['speech_first'] + fl['text_first']) * (steps // 2)
+    tf = total_fl / elapsed / 1e12
+    cpu = None
+    if not args.no_cpu_baseline and rk.world == 1:
+        cpu = cpu_baseline_cycle(tr, pair, unpair, config)
+    n_par = sum(p.numel() for p in tr.model.parameters() if p.requires_grad)
+    return {'metric': 'training mel-frames/sec (VqvaeTrainer cycles: speech_to_text + VQ + mean_forward + text_to_speech, CTC + freq losses, bwd, clip, Adam)',
+            'value': round(total_frames / elapsed, 1), 'unit': 'mel-frames/s', 'n_gpus': rk.world, 'steps': steps,
+            'warmup': args.warmup + (args.warmup % 2), 'ms_per_step': round(elapsed / steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C3 cycles: VqvaeTrainer.exec alternation (even steps speech-first with the unpaired batch, odd steps text-first), '
+                                   'paired B=%d + unpaired B=%d per GPU, %d->%d frames, aug_mel %d frames, paired L=%d, merged unpaired L=%d, '
+                                   'L2 codebook V=%d, config/semi-single-spkr-paired-data.yaml'
+                                   % (Bp, Bu, T_RAW, Tp, aug.shape[1], Lp, Lu, tr.vocab_size),
+                       'parallelism': 'dp%d (utterance-sharded, SyncBN, gradient all-reduce of %.1f MB)' % (rk.world, n_par * 4 / 1e6)},
+            **rk.collectives_flat(),
+            'roofline': {'bound': 'mfma', 'kernel': 'whole alternating step (3 x forward FLOPs of the speech encoder, VQ search and TTS branch at the shapes they ran at)',
+                         'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None},
+            'kinds': kinds, 'ms_host_issue_per_step': round(issue_ms, 3),
+            'stats_read': 'per step' if args.sync_stats else 'after the timed steps (the merged lengths of mean_forward are the one host read of a speech-first step)',
+            'collectives_per_step': parallel.collective_counts(), 'ctc_nan': int(getattr(tr, 'ctc_nan', 0)),
+            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            **({'cpu_baseline': cpu} if cpu is not None else {})}
+
+
+def cpu_baseline_cycle(tr, pair, unpair, config):
+    """both cycles on the host through the torch.nn assembly of the whole VQVAE (oracle/nn_baseline.py: NNVqvae) under torch autograd:
+    one speech-first step with the unpaired batch + one text-first step = one unit of the alternating loop"""
+    import torch
+    from oracle import nn_baseline as NB
+    from oracle import tts_oracle as O
+    W = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+    net = NB.NNVqvae(W, config['model'], tr.n_mels).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    sr = config['data']['audio']['sample_rate']
+    fl = lambda p, l: O.freq_loss(p, l, sr, tr.n_mels)
+    pc, uc = tuple(t.cpu() for t in pair), tuple(t.cpu() for t in unpair)
+    cut = lambda b, n, f: (b[0][:n, :f], b[1][:n, :f], b[2][:n, :f], b[3][:n], b[4][:n])
+    hp = config['hparas']
+
+    def both(p, u):
+        NB.cycle_step(net, opt, 'speech_first', p, u, fl, hp)
+        NB.cycle_step(net, opt, 'text_first', p, None, fl, hp)
+    short = lambda: both(cut(pc, 2, 24), cut(uc, 2, 24))
+    full = lambda i: both(pc, uc)
+    frames = pc[0].shape[0] * pc[0].shape[1] * 2 + uc[0].shape[0] * uc[0].shape[1]
+    return cpu_timed(short, full, frames, 'mel-frames/s', 'nn_modules_autograd',
+                     'one speech-first step (paired B=%d || unpaired B=%d) + one text-first step (paired) of the torch.nn assembly of the whole VQVAE '
+                     '(oracle/nn_baseline.py: NNCtc + L2 codebook + host mean_forward + NNTacotron2, CTC + freq losses, backward, clip 5.0, Adam) '
+                     'under torch autograd; probe = the same at B=2+2, 24 frames' % (pc[0].shape[0], uc[0].shape[0]),
+                     max_passes=2, budget=(30.0, 50.0))
+
+
 def _train_launches():
     """launches of one training step as counted by the committed rocprofv3 kernel trace of one step (tools/gpu_train_prof.sh)"""
     import csv
@@ -734,7 +875,9 @@ def main():
                     help='with --gpus 1: initialise a world-size-1 process group (RCCL) and issue every collective anyway')
     ap.add_argument('--no-finite-check', action='store_true', help=argparse.SUPPRESS)    # timing experiments (tools/gpu_ablate.sh)
     ap.add_argument('--traffic-json', default=None, help='PMC summary (tools/pmc_summary.py) to quote as roofline.traffic')
-    ap.add_argument('--workload', choices=['c2', 'c5', 'c3', 'train'], default='c2',
+    ap.add_argument('--batch-size', type=int, default=None, help='--workload cycle: paired utterances per GPU (default 32; the config file says 8)')
+    ap.add_argument('--unpair-batch-size', type=int, default=None, help='--workload cycle: unpaired utterances per GPU (default: --batch-size)')
+    ap.add_argument('--workload', choices=['c2', 'c5', 'c3', 'train', 'cycle'], default='c2',
                     help="c2 = the headline configuration; c5 / c3 / train = secondary lines (see the module docstring)")
     ap.add_argument('--rccl-probe', action='store_true', help=argparse.SUPPRESS)        # child of a rank: see Ranks._probe_rccl
     args = ap.parse_args()
@@ -749,7 +892,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     rk = Ranks(args)
-    fn = {'c2': bench_decode, 'c5': bench_decode, 'c3': bench_vq, 'train': bench_train}[args.workload]
+    fn = {'c2': bench_decode, 'c5': bench_decode, 'c3': bench_vq, 'train': bench_train, 'cycle': bench_cycle}[args.workload]
     res = fn(args, rk)
     if rk.rank == 0:
         os.write(real_stdout, (json.dumps(res) + '\n').encode())

@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """Entry point with the reference's flags (ref: main.py:14-68): YAML config + Solver dispatch.
-Only the solvers on the TTS path exist here: `--gen-specgram` runs batched free-running
-synthesis, the default mode runs the paired TTS training step (forward, loss, backward on the HIP
-kernels; clip + Adam from torch), both on synthetic inputs (the corpus is not available).
+The dispatch is the reference's (main.py:49-63): `--gen-specgram` runs batched free-running synthesis
+(bin/gen_specgram.py), the default mode runs `VqvaeTrainer` -- the alternating speech -> text -> speech /
+text -> speech -> text cycles of bin/train_vqvae.py:111-270 (CTC speech encoder, codebook, run-length merge,
+TTS branch, CTC + freq losses, backward, clip + Adam, all on the HIP kernels) -- on synthetic paired and
+unpaired batches (the corpus is not available).  `--tts-only` keeps the paired TTS step alone (TtsTrainer).
 
+    python main.py --config config/semi-single-spkr-paired-data.yaml --max-step 20 [--frames 256 --batch-size 8]
     python main.py --config config/supervised.yaml --gen-specgram [--load ckpt.pth] [--frames 256 --batch-size 32]
-    python main.py --config config/supervised.yaml --max-step 20 [--frames 256 --batch-size 32]
+    python main.py --config config/supervised.yaml --tts-only --max-step 20 [--frames 256 --batch-size 32]
 """
 import argparse
 import random
@@ -37,6 +40,10 @@ parser.add_argument('--gen-wav', action='store_true', help='Generate waveform us
 parser.add_argument('--frames', default=256, type=int, help='mel frames per synthetic utterance')
 parser.add_argument('--batch-size', default=None, type=int)
 parser.add_argument('--n-batches', default=1, type=int)
+parser.add_argument('--unpair-batch-size', default=None, type=int, help='utterances per synthetic unpaired batch (default: --batch-size)')
+parser.add_argument('--unpair-frames', default=None, type=int, help='mel frames per synthetic unpaired utterance (default: --frames)')
+parser.add_argument('--stretch', action='store_true', help='aug_mel lengths drawn from data.audio.time_stretch_range (default: unstretched)')
+parser.add_argument('--tts-only', action='store_true', help='train the paired TTS branch alone (TtsTrainer) instead of the two cycles')
 parser.add_argument('--max-step', default=None, type=int, help='training steps (default: hparas.max_step)')
 parser.add_argument('--save', action='store_true', help='write ckpt/<name>/latest.pth ({model, optimizer, global_step}) after training')
 parser.add_argument('--async-stats', action='store_true', help='training: no host read of loss / gradient norm inside a step (read when logged; '
@@ -88,8 +95,11 @@ def main(argv=None):
     if paras.gen_specgram:
         from semi_tts_amd.solver import SpecgramGenerator as Solver
         mode = 'test'
-    else:
+    elif paras.tts_only:
         from semi_tts_amd.solver import TtsTrainer as Solver
+        mode = 'train'
+    else:                                                    # ref: main.py:61-63
+        from semi_tts_amd.solver import VqvaeTrainer as Solver
         mode = 'train'
     solver = Solver(config, paras, mode)
     solver.load_data()

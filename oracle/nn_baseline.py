@@ -235,3 +235,127 @@ def train_step(model: 'NNTacotron2', opt: torch.optim.Optimizer, txt_embed: Tens
     gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
     opt.step()
     return float(loss.detach()), float(gn)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The speech <-> text cycles of VqvaeTrainer.exec from stock torch.nn modules (round 6: CPU baseline of `bench.py --workload cycle`).
+class NNCtc(nn.Module):
+    """CTC speech encoder (src/asr.py:5-64) with ConvLayer (src/module.py:627-648) as nn.Conv1d / nn.BatchNorm1d / nn.LSTM / nn.Linear"""
+
+    def __init__(self, W: Dict[str, Tensor], cfg: dict, prefix: str = 'asr.'):
+        super().__init__()
+        self.cfg = cfg
+        self.convs, self.bns = nn.ModuleList(), nn.ModuleList()
+        for l, (k, s) in enumerate(zip(cfg['kernel'], cfg['stride'])):
+            w = W[prefix + 'layer%d.conv.weight' % l]
+            self.convs.append(_copy(nn.Conv1d(w.shape[1], w.shape[0], k, s, padding=1 if k != 1 else 0), W, prefix + 'layer%d.conv.' % l))
+            self.bns.append(_copy(nn.BatchNorm1d(w.shape[0]), W, prefix + 'layer%d.bn.' % l) if cfg['batch_norm'] else None)
+        self.act = getattr(torch, cfg['activation'].lower())
+        self.drop = nn.Dropout(cfg['dropout'])
+        w_ih = W[prefix + 'rnn.weight_ih_l0']
+        self.rnn = _copy(nn.LSTM(w_ih.shape[1], cfg['rnn_dim'], cfg['rnn_layers'], dropout=cfg['dropout'], batch_first=True,
+                                 bidirectional=bool(cfg['rnn_bid'])), W, prefix + 'rnn.')
+        self.norm = _copy(nn.LayerNorm(W[prefix + 'postnet.weight'].shape[1]), W, prefix + 'norm_layer.') if cfg['layer_norm'] else None
+        self.postnet = _linear(W[prefix + 'postnet.weight'], W[prefix + 'postnet.bias'])
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = x.transpose(1, 2)                                                   # src/asr.py:49
+        for conv, bn, res in zip(self.convs, self.bns, self.cfg['residual']):   # ConvLayer.forward, src/module.py:638-648
+            y = conv(x)
+            if bn is not None:
+                y = bn(y)
+            y = self.act(y)
+            if res:
+                y = y + x
+            x = self.drop(y)
+        y, _ = self.rnn(x.transpose(1, 2))                                      # :56
+        if self.norm is not None:
+            y = self.norm(y)
+        return self.postnet(self.drop(y))                                       # :62-63
+
+
+class NNVqvae(nn.Module):
+    """VQVAE with the L2 codebook (src/vqvae.py, src/embed.py:57-147; stop_grad = True, skip_prob = 0, no attribute table: the
+    synthetic-weight configuration bench.py runs)"""
+
+    def __init__(self, W: Dict[str, Tensor], model_cfg: dict, n_mels: int):
+        super().__init__()
+        hp = dict(model_cfg['decoder']['decoder'], n_mels=n_mels)
+        self.asr = NNCtc(W, model_cfg['encoder'])
+        self.table = nn.Parameter(W['codebook.learnable_table'].clone())
+        self.register_buffer('temp', W['codebook.temp'].clone())
+        self.spkr = nn.Embedding.from_pretrained(W['spkr_embed.weight'].clone(), freeze=False)
+        self.tts = NNTacotron2({k[4:]: v for k, v in W.items() if k.startswith('tts.')}, hp)
+        self.max_frames_per_phn = model_cfg['max_frames_per_phn']
+
+    def codebook(self, x: Tensor):
+        """L2Embedding.forward, src/embed.py:105-147"""
+        flat = x.reshape(-1, x.shape[-1])
+        sim = -((flat.pow(2).sum(-1, keepdim=True) + self.table.pow(2).sum(-1)) - 2 * flat.matmul(self.table.t()))
+        p = (torch.relu(self.temp) * sim).view(x.shape[0], x.shape[1], -1).softmax(dim=-1)
+        code = F.embedding(p.argmax(dim=-1), self.table)
+        return p, x + code - x.detach()
+
+    def mean_forward(self, p_code: Tensor, latent: Tensor):
+        """src/vqvae.py:218-257 as the reference runs it: one host list per utterance"""
+        T = latent.shape[1]
+        out, lens = [], []
+        for b, idx_seq in enumerate(p_code.argmax(dim=-1)):
+            idx_seq = idx_seq.tolist()
+            last_idx, last_pos, cur = idx_seq[0], 0, []
+            for t, idx in enumerate(idx_seq):
+                if last_idx != idx or (t - last_pos) > self.max_frames_per_phn:
+                    if last_idx != 0:
+                        cur.append(latent[b, last_pos:t].mean(dim=0))
+                    last_idx, last_pos = idx, t
+            if last_idx != 0:
+                cur.append(latent[b, last_pos:].mean(dim=0) if last_pos != T - 1 else latent[b, t])
+            if not cur:
+                return None
+            lens.append(len(cur))
+            out.append(torch.stack(cur, dim=0))
+        return nn.utils.rnn.pad_sequence(out, batch_first=True), torch.LongTensor(lens)
+
+
+def _pad_cat(a: Tensor, b: Tensor) -> Tensor:
+    T = max(a.shape[1], b.shape[1])
+    return torch.cat([F.pad(a, (0, 0, 0, T - a.shape[1])), F.pad(b, (0, 0, 0, T - b.shape[1]))], dim=0)
+
+
+def cycle_step(model: 'NNVqvae', opt: torch.optim.Optimizer, kind: str, pair, unpair, freq_loss, hparas: dict, clip: float = 5.0):
+    """one iteration of VqvaeTrainer.exec (bin/train_vqvae.py:124-270) with unpair_text_weight = 0 (the shipped configurations):
+    `speech_first` = speech_to_text(paired || unpaired aug_mel) -> mean_forward -> text_to_speech(paired text || merged latents),
+    `text_first` = text_to_speech(paired) -> speech_to_text(paired); CTC + freq losses, backward, clip, optimiser step"""
+    mel, aug, linear, text, sid = pair
+    opt.zero_grad()
+    Bp = mel.shape[0]
+    lat_p = F.embedding(text, model.table)
+    use_un = kind == 'speech_first' and unpair is not None
+    if kind == 'speech_first':
+        x = _pad_cat(aug, unpair[1]) if use_un else aug
+        p, q = model.codebook(model.asr(x))
+        merged = model.mean_forward(p[Bp:], q[Bp:]) if use_un else None
+        use_un = merged is not None
+    if use_un:
+        lat = _pad_cat(lat_p, merged[0])
+        teacher = _pad_cat(mel, unpair[0])
+        spk = torch.cat([model.spkr(sid), model.spkr(unpair[4])], dim=0)
+    else:
+        lat, teacher, spk = lat_p, mel, model.spkr(sid)
+    mel_p, _, _, _ = model.tts.forward_teacher(lat, teacher, spk)
+    lin_p = model.tts.postnet(mel_p.detach())                                   # separate_postnet: true (src/tts.py:47-50)
+    if kind != 'speech_first':
+        p, _ = model.codebook(model.asr(aug))
+    pp = p[:Bp]
+    tgt_len = (text != 0).sum(dim=-1)
+    ctc = F.ctc_loss((pp + 1e-10).transpose(0, 1).log(), text[text != 0], torch.full((Bp,), pp.shape[1], dtype=torch.long), tgt_len)
+    Tp = mel.shape[1]
+    loss = float(hparas.get('asr_weight', 1.0)) * ctc + float(hparas.get('tts_weight', 1.0)) * (
+        freq_loss(mel_p[:Bp, :Tp], mel) + freq_loss(lin_p[:Bp, :Tp], linear))
+    if use_un:
+        Tu = unpair[0].shape[1]
+        loss = loss + float(hparas.get('unpair_speech_weight', 10.0)) * (freq_loss(mel_p[Bp:, :Tu], unpair[0]) + freq_loss(lin_p[Bp:, :Tu], unpair[2]))
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+    opt.step()
+    return float(loss.detach()), float(gn)

@@ -86,11 +86,13 @@ class CTC(nn.Module):
         self.drop = nn.Dropout(dropout)
         self.postnet = nn.Linear(cur, out_dim)
 
-    def forward(self, x):
-        """x (B,T,n_mels) -> (B, T / time_reduce_factor, out_dim)                            ref: src/asr.py:46-64"""
+    def forward(self, x, _masks=None):
+        """x (B,T,n_mels) -> (B, T / time_reduce_factor, out_dim)                            ref: src/asr.py:46-64
+        `_masks` (tests only): explicit scaled dropout masks, one per conv layer then one per LSTM layer (None = draw)"""
         x = x.contiguous()
+        mk = (lambda i: _masks[i]) if _masks is not None else (lambda i: None)
         for l in range(self.layers):
-            x = getattr(self, 'layer' + str(l))(x)
+            x = getattr(self, 'layer' + str(l))(x, mk(l))
         B, T, _ = x.shape
         H = self.rnn_dim
         p = self.dropout if self.training else 0.0
@@ -107,7 +109,8 @@ class CTC(nn.Module):
                 if last and self.layer_norm:
                     x = AG.layer_norm(x, self.norm_layer)                                    # :57-58 (before self.drop)
                 if p > 0:   # inter-layer dropout of nn.LSTM, and (after the last layer) the dropout in front of the projection
-                    x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)
+                    m = mk(self.layers + layer)
+                    x = x * (m if m is not None else torch.empty_like(x).bernoulli_(1 - p).div_(1 - p))
             return AG.conv(x, self.postnet.weight, self.postnet.bias)
         Do = (2 if self.rnn_bid else 1) * H
         for layer in range(self.rnn_layers):
@@ -124,7 +127,8 @@ class CTC(nn.Module):
                 ln = self.norm_layer
                 x = ops.layer_norm(x.view(-1, Do), ln.weight, ln.bias, ln.eps).view(B, T, Do)
             if p > 0:   # inter-layer dropout of nn.LSTM and the dropout in front of the projection (:62)
-                x = x * torch.empty_like(x).bernoulli_(1 - p).div_(1 - p)
+                m = mk(self.layers + layer)
+                x = x * (m if m is not None else torch.empty_like(x).bernoulli_(1 - p).div_(1 - p))
         return ops.gemm(x, self.postnet.weight, bias=self.postnet.bias)
 
 

@@ -307,36 +307,8 @@ class TtsTrainer(BaseSolver):
             opt_step = getattr(getattr(self.optimizer, 'opt', None), 'guarded_steps', 0)      # (the key of this update in the optimiser's log)
             self.optimizer.step(guard_norm=grad_norm)
             self.step += 1
-            # the four device scalars of the step go into a row of a persistent ring: LazyStats then holds VIEWS, no allocation outlives
-            # the step, and the caching allocator hands every tensor of the next step the address it had in this one -- which is what
-            # lets the optimiser's device-side tables (optim.hip: mt_table) be reused instead of rebuilt (scalars kept alive for 4 ... 8 steps
-            # made the addresses wander with a period of ~13 steps)
-            ring = self.__dict__.get('_stats_ring')
-            if ring is None or ring.device != grad_norm.device:
-                ring = self._stats_ring = torch.zeros(self.STATS_RING, 4, device=grad_norm.device)
-                self._stats_slot = 0
-                self._stats_host = torch.zeros(self.STATS_RING, 4).pin_memory()
-                self._stats_events = [torch.cuda.Event() for _ in range(self.STATS_RING)]
-                self._stats_stream = torch.cuda.Stream(device=grad_norm.device)
-            slot = self._stats_slot
-            row = ring[slot]
-            self._stats_slot = (slot + 1) % self.STATS_RING
-            torch.stack([total.detach().reshape(()), mel_loss.detach().reshape(()), linear_loss.detach().reshape(()),
-                         grad_norm.detach().reshape(())], out=row)
-            self._stats_events[slot].record()                 # (drain_stats waits for THIS step only, on a stream of its own)
-            st = LazyStats(loss=row[0], mel_loss=row[1], linear_loss=row[2], grad_norm=row[3],
-                           tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1), step=self.step - 1,
-                           opt_step=opt_step)
-            st.ring_slot = slot
-            st.on_nonfinite = self._skipped_on_device
-            self._unread.append(st)
-            # bounded: at most STATS_WINDOW steps of device scalars are alive.  While the one-launch BiLSTM is in use the window is short:
-            # a starved layer poisons every forward until somebody looks, and every poisoned step is an update skipped on the device
-            # (only the older half is read: the wait is for a step that finished a while ago, the GPU keeps the newer half queued and the
-            # host its lead -- a full drain every eighth step cost the data-parallel step 0.6 ms once the host was no longer far ahead)
-            window = min(self.STATS_WINDOW_PERSIST if ops.LSTM_PERSIST else self.STATS_WINDOW, self.STATS_RING - 1)
-            if len(self._unread) >= window:
-                self.drain_stats(keep=window // 2)
+            st = self._ring_stats(dict(loss=total, mel_loss=mel_loss, linear_loss=linear_loss, grad_norm=grad_norm),
+                                  tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1), step=self.step - 1, opt_step=opt_step)
             return st
         gn = float(grad_norm)
         if gn != gn:
@@ -347,6 +319,41 @@ class TtsTrainer(BaseSolver):
         self.step += 1
         return dict(loss=float(total.detach()), mel_loss=float(mel_loss.detach()), linear_loss=float(linear_loss.detach()), grad_norm=gn,
                     tf_rate=tf_rate, lr=self.optimizer.lr_at(self.step - 1))
+
+    STATS_COLS = 8           # device scalars per row of the statistics ring
+
+    def _ring_stats(self, scalars, **extras):
+        """async_stats: the step's device scalars go into a row of a persistent ring: LazyStats then holds VIEWS, no allocation outlives
+        the step, and the caching allocator hands every tensor of the next step the address it had in this one -- which is what
+        lets the optimiser's device-side tables (optim.hip: mt_table) be reused instead of rebuilt (scalars kept alive for 4 ... 8 steps
+        made the addresses wander with a period of ~13 steps).  An event behind the row lets drain_stats wait for THIS step only."""
+        keys = tuple(scalars)
+        vals = [scalars[k] for k in keys]
+        dev = vals[-1].device
+        ring = self.__dict__.get('_stats_ring')
+        if ring is None or ring.device != dev:
+            ring = self._stats_ring = torch.zeros(self.STATS_RING, self.STATS_COLS, device=dev)
+            self._stats_slot = 0
+            self._stats_host = torch.zeros(self.STATS_RING, self.STATS_COLS).pin_memory()
+            self._stats_events = [torch.cuda.Event() for _ in range(self.STATS_RING)]
+            self._stats_stream = torch.cuda.Stream(device=dev)
+        slot = self._stats_slot
+        row = ring[slot]
+        self._stats_slot = (slot + 1) % self.STATS_RING
+        torch.stack([v.detach().reshape(()) for v in vals], out=row[:len(keys)])
+        self._stats_events[slot].record()                 # (drain_stats waits for THIS step only, on a stream of its own)
+        st = LazyStats({k: row[i] for i, k in enumerate(keys)}, **extras)
+        st.ring_slot, st.ring_keys = slot, keys
+        st.on_nonfinite = self._skipped_on_device
+        self._unread.append(st)
+        # bounded: at most STATS_WINDOW steps of device scalars are alive.  While the one-launch BiLSTM is in use the window is short:
+        # a starved layer poisons every forward until somebody looks, and every poisoned step is an update skipped on the device
+        # (only the older half is read: the wait is for a step that finished a while ago, the GPU keeps the newer half queued and the
+        # host its lead -- a full drain every eighth step cost the data-parallel step 0.6 ms once the host was no longer far ahead)
+        window = min(self.STATS_WINDOW_PERSIST if ops.LSTM_PERSIST else self.STATS_WINDOW, self.STATS_RING - 1)
+        if len(self._unread) >= window:
+            self.drain_stats(keep=window // 2)
+        return st
 
     STATS_WINDOW = 64        # async_stats: steps whose statistics may stay unread on the device
     STATS_RING = 256         # rows of the ring the unread statistics live in (> any window)
@@ -392,11 +399,15 @@ class TtsTrainer(BaseSolver):
             host = self._stats_host.tolist()
             for st in ringed:
                 r = host[st.ring_slot]
-                for k, v in zip(('loss', 'mel_loss', 'linear_loss', 'grad_norm'), r):
+                for k, v in zip(st.ring_keys, r):
                     if torch.is_tensor(dict.__getitem__(st, k)):
                         st.put(k, v)
         for st in pending:
             st.materialise()
+            self._stats_read(st)
+
+    def _stats_read(self, st):
+        """hook: the scalars of a step have just been read on the host"""
 
     def exec(self):
         t0 = time.perf_counter()
@@ -443,9 +454,14 @@ class VqvaeTrainer(TtsTrainer):
         from . import autograd as AG
         return AG.ctc_loss(prob, text, EPS)
 
+    def _async(self):
+        from .optim import FusedAdam
+        return self.async_stats and isinstance(getattr(self.optimizer, 'opt', None), FusedAdam)
+
     def _paired_losses(self, pair_prob, pair_post_prob, pm, pl, mel, linear, text, stats):
         """the terms both cycles share (bin/train_vqvae.py:208-224): CTC on the paired posteriors (+ the ASRPostnet term) and
-        freq_loss on the paired reconstruction; returns the weighted sum"""
+        freq_loss on the paired reconstruction; returns the weighted sum.  `stats` collects the step's scalars as DEVICE tensors:
+        whether and when they are read is _finish_step's business."""
         hp = self.hp
         asr_loss = self.ctc_loss(pair_prob, text)                                                 # :209
         asr_w = float(hp.get('asr_weight', 1.0))
@@ -454,41 +470,68 @@ class VqvaeTrainer(TtsTrainer):
             pw = float(self.model.asr_postnet_weight)
             asr_post_loss = AG.ctc_loss(pair_post_prob, text, EPS, apply_log=False)               # compute_ctcloss(..., apply_log=False)
             total = asr_w * (1.0 - pw) * asr_loss + asr_w * pw * asr_post_loss
-            stats['asr_post_loss'] = float(asr_post_loss.detach())
+            stats['asr_post_loss'] = asr_post_loss.detach()
         else:
             total = asr_w * asr_loss                                                              # :215
-        al = float(asr_loss.detach())
-        if al != al or al in (float('inf'), float('-inf')):                                       # :216-218: counted, and (as in the
-            self.ctc_nan = getattr(self, 'ctc_nan', 0) + 1                                        # reference) already inside total
+        # (:216-218: a NaN / inf CTC value is counted when the statistics are read -- as in the reference it is already inside total,
+        # the gradient norm is then NaN and the update is skipped)
         tts_loss = self.freq_loss(pm, mel) + self.freq_loss(pl, linear)                           # :221-224
-        stats.update(asr_loss=al, tts_loss=float(tts_loss.detach()))
+        stats.update(asr_loss=asr_loss.detach(), tts_loss=tts_loss.detach())
         return total + self.tts_weight * tts_loss
 
-    def _finish_step(self, total, stats, tf_rate):
+    def _count_ctc_nan(self, st):
+        for k in ('asr_loss', 'unpair_text_loss'):
+            if k in st and not math.isfinite(st[k]):
+                self.ctc_nan = getattr(self, 'ctc_nan', 0) + 1
+
+    def _finish_step(self, total, stats, tf_rate, kind):
+        """BaseSolver.backward (src/solver.py:138-151) + the step counter.  Synchronous form: the scalars are read here, a NaN gradient
+        norm skips the update (as the reference does).  async_stats: nothing is read -- the scalars go into the statistics ring, the
+        guarded Adam skips a non-finite step on the device (TtsTrainer.train_step)."""
         total.backward()
         self._reduce_gradients()
-        gn = float(self._clip())
+        grad_norm = self._clip()
+        lr = self.optimizer.lr_at(self.step)
+        if self._async() and torch.is_tensor(grad_norm) and grad_norm.is_cuda:
+            opt_step = getattr(self.optimizer.opt, 'guarded_steps', 0)
+            self.optimizer.step(guard_norm=grad_norm)
+            self.step += 1
+            scalars = dict(stats, loss=total, grad_norm=grad_norm)
+            return self._ring_stats(scalars, tf_rate=tf_rate, lr=lr, step=self.step - 1, opt_step=opt_step, kind=kind,
+                                    **{k: v for k, v in self._step_info.items()})
+        gn = float(grad_norm)
         if gn == gn:
             self.optimizer.step()
         else:
             self.check_device_status()                   # (a starved one-launch LSTM layer: per-step form from the next step on)
             self.verbose('Error : grad norm is NaN @ step ' + str(self.step))
         self.step += 1
-        stats.update(loss=float(total.detach()), grad_norm=gn, tf_rate=tf_rate)
-        return stats
+        out = {k: float(v) for k, v in stats.items()}
+        out.update(loss=float(total.detach()), grad_norm=gn, tf_rate=tf_rate, lr=lr, kind=kind, **self._step_info)
+        self._count_ctc_nan(out)
+        return out
 
-    def speech_first_step(self, mel, aug_mel, linear, text, sid, unpair_mel=None, unpair_aug_mel=None, unpair_linear=None,
-                          unpair_sid=None, _masks=None):
-        """The speech -> text -> speech cycle of VqvaeTrainer.exec (bin/train_vqvae.py:159-176,208-233)."""
+    def _begin_step(self):
         from . import parallel
-        hp = self.hp
         parallel.collective_counts(reset=True)
+        self._step_info = {}
         tf_rate = self.optimizer.pre_step(self.step)
         if getattr(self, 'reducer', None) is not None:
             self.reducer.prepare()
+        return tf_rate
+
+    def speech_first_step(self, mel, aug_mel, linear, text, sid, unpair_mel=None, unpair_aug_mel=None, unpair_linear=None,
+                          unpair_sid=None, _masks=None, _asr_masks=None):
+        """The speech -> text -> speech cycle of VqvaeTrainer.exec (bin/train_vqvae.py:159-176,208-233).  The only host read of the
+        forward pass is the merged lengths of the unpaired latents (autograd.mean_forward): they fix the text length the TTS branch
+        runs at (the reference reads every index, src/vqvae.py:225)."""
+        hp = self.hp
+        tf_rate = self._begin_step()
         pair_prob, _, unpair_prob, unpair_latent, unpair_latent_len, pair_post_prob, _ = self.model.speech_to_text(
-            paired_mel=aug_mel, unpaired_mel=unpair_aug_mel)
+            paired_mel=aug_mel, unpaired_mel=unpair_aug_mel, **({'_masks': _asr_masks} if _asr_masks is not None else {}))
         ignore_speech_cycle = unpair_latent is None                                               # :163-172
+        if unpair_aug_mel is not None:
+            self._step_info.update(unpair_text_len=0 if ignore_speech_cycle else int(unpair_latent.shape[1]))
         out = self.model.text_to_speech(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
                                         unpair_latent_len, mel, None if ignore_speech_cycle else unpair_mel, tf_rate, _masks=_masks)
         pm, pl, _, _, upm, upl, _, _ = out
@@ -498,21 +541,17 @@ class VqvaeTrainer(TtsTrainer):
             un = self.freq_loss(upm, unpair_mel) + self.freq_loss(upl, unpair_linear)
             if self.step > int(hp.get('unpair_speech_start_step', 0)):                            # :232: only after the warm-up steps
                 total = total + float(hp.get('unpair_speech_weight', 10.0)) * un
-            stats['unpair_speech_loss'] = float(un.detach())
-        return self._finish_step(total, stats, tf_rate)
+            stats['unpair_speech_loss'] = un.detach()
+        return self._finish_step(total, stats, tf_rate, 'speech_first')
 
-    def text_first_step(self, mel, aug_mel, linear, text, sid, unpair_text=None, unpair_sid=None, _masks=None):
+    def text_first_step(self, mel, aug_mel, linear, text, sid, unpair_text=None, unpair_sid=None, _masks=None, _asr_masks=None):
         """The text -> speech -> text cycle of VqvaeTrainer.exec (bin/train_vqvae.py:186-205,208-224,234-250): text_to_speech on the
         paired text (teacher forced) and, when given, the unpaired text (rows without a teacher feed their own output back); the
         unpaired prediction is DETACHED and goes through speech_to_text next to the paired mel with `using_fake_mel` (the codebook
         table is detached for the fake part); losses: the paired terms, plus CTC of the unpaired posteriors against the unpaired text
         (paras.actual_len = False: every frame counts).  A NaN / inf unpaired term is counted and dropped, as the reference does."""
-        from . import parallel
         hp = self.hp
-        parallel.collective_counts(reset=True)
-        tf_rate = self.optimizer.pre_step(self.step)
-        if getattr(self, 'reducer', None) is not None:
-            self.reducer.prepare()
+        tf_rate = self._begin_step()
         use_unpair_text = unpair_text is not None                                                 # the caller gates it (:128,:149-152)
         out = self.model.text_to_speech(text, sid, unpair_sid if use_unpair_text else None, None, unpair_text, None, mel, None,
                                         tf_rate, _masks=_masks)                                   # :190-199
@@ -520,34 +559,111 @@ class VqvaeTrainer(TtsTrainer):
         if use_unpair_text:
             upm = upm.detach()                                                                    # :201-202
         pair_prob, _, unpair_prob, _, _, pair_post_prob, _ = self.model.speech_to_text(
-            paired_mel=aug_mel, unpaired_mel=upm if use_unpair_text else None, using_fake_mel=use_unpair_text)   # :203-205
+            paired_mel=aug_mel, unpaired_mel=upm if use_unpair_text else None, using_fake_mel=use_unpair_text,
+            **({'_masks': _asr_masks} if _asr_masks is not None else {}))                        # :203-205
         stats = {}
         total = self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, stats)
         if use_unpair_text:                                                                       # :234-250
             ut = self.ctc_loss(unpair_prob, unpair_text)
+            stats['unpair_text_loss'] = ut.detach()
+            # :246-248: a non-finite unpaired term is dropped (and counted).  That decides what backward() sees, so it is the one scalar
+            # this cycle reads inside the step (only configurations with unpair_text_weight > 0 get here; none of the shipped ones)
             v = float(ut.detach())
-            if v != v or v in (float('inf'), float('-inf')):                                      # :246-248
-                self.ctc_nan = getattr(self, 'ctc_nan', 0) + 1
-            else:
+            if math.isfinite(v):
                 total = total + float(hp.get('unpair_text_weight', 0.0)) * ut
-            stats['unpair_text_loss'] = v
-        return self._finish_step(total, stats, tf_rate)
+        return self._finish_step(total, stats, tf_rate, 'text_first')
 
-    def cycle_step(self, pair, unpair=None, _masks=None):
+    def cycle_step(self, pair, unpair=None, _masks=None, _asr_masks=None):
         """One iteration of VqvaeTrainer.exec's loop body (bin/train_vqvae.py:124-150): even steps run the speech-first cycle, odd
         steps the text-first cycle; the unpaired batch joins only when its weight is positive and the step is past its start step.
         `pair` = (mel, aug_mel, linear, text, sid); `unpair` = the same five for the unpaired batch, or None."""
-        hp = self.hp
         mel, aug_mel, linear, text, sid = pair
-        use_text = float(hp.get('unpair_text_weight', 0.0)) > 0 and self.step > int(hp.get('unpair_text_start_step', 0))      # :128
-        use_speech = float(hp.get('unpair_speech_weight', 10.0)) > 0 and self.step > int(hp.get('unpair_speech_start_step', 0))  # :129
-        if self.step % 2 == 0:                                                                    # :137
-            if use_speech and unpair is not None:
+        kw = dict(_masks=_masks, _asr_masks=_asr_masks)
+        kind, use_unpair = self.cycle_kind(self.step)
+        if kind == 'speech_first':                                                                # :137
+            if use_unpair and unpair is not None:
                 umel, uaug, ulin, _, usid = unpair
                 return self.speech_first_step(mel, aug_mel, linear, text, sid, unpair_mel=umel, unpair_aug_mel=uaug,
-                                              unpair_linear=ulin, unpair_sid=usid, _masks=_masks)
-            return self.speech_first_step(mel, aug_mel, linear, text, sid, _masks=_masks)
-        if use_text and unpair is not None:
+                                              unpair_linear=ulin, unpair_sid=usid, **kw)
+            return self.speech_first_step(mel, aug_mel, linear, text, sid, **kw)
+        if use_unpair and unpair is not None:
             _, _, _, utext, usid = unpair
-            return self.text_first_step(mel, aug_mel, linear, text, sid, unpair_text=utext, unpair_sid=usid, _masks=_masks)
-        return self.text_first_step(mel, aug_mel, linear, text, sid, _masks=_masks)
+            return self.text_first_step(mel, aug_mel, linear, text, sid, unpair_text=utext, unpair_sid=usid, **kw)
+        return self.text_first_step(mel, aug_mel, linear, text, sid, **kw)
+
+    def cycle_kind(self, step):
+        """(which cycle step `step` runs, whether it takes an unpaired batch)        ref: bin/train_vqvae.py:128-129,137-150"""
+        hp = self.hp
+        if step % 2 == 0:
+            return 'speech_first', float(hp.get('unpair_speech_weight', 10.0)) > 0 and step > int(hp.get('unpair_speech_start_step', 0))
+        return 'text_first', float(hp.get('unpair_text_weight', 0.0)) > 0 and step > int(hp.get('unpair_text_start_step', 0))
+
+    def _stats_read(self, st):
+        self._count_ctc_nan(st)
+
+    # -- the solver protocol of main.py:65-68 on synthetic batches
+    def load_data(self):
+        """Synthetic counterparts of the reference's pair_set / unpair_set loaders (bin/train_vqvae.py:55-69; src/data.py is
+        outside the path): `n_batches` seeded batches each, a different seed per rank (utterance-level data parallelism), mel / linear
+        zero-padded to a multiple of r and aug_mel unpadded exactly as fetch_data delivers them (:33-53).  The unpaired set has its
+        own batch size and length (--unpair-batch-size / --unpair-frames; default: the paired ones)."""
+        from .synthetic import synthetic_cycle_batch
+        pa = self.paras
+        B = int(getattr(pa, 'batch_size', None) or self.config['data']['corpus'].get('batch_size', 8))
+        Bu = int(getattr(pa, 'unpair_batch_size', None) or B)
+        frames = int(getattr(pa, 'frames', 256))
+        uframes = int(getattr(pa, 'unpair_frames', None) or frames)
+        n = int(getattr(pa, 'n_batches', 1))
+        self.r = self.config['model']['decoder']['decoder']['n_frames_per_step']
+        rank = int(os.environ.get('RANK', 0))
+        seed = getattr(pa, 'seed', 0)
+        lo, hi = self.config['data']['audio'].get('time_stretch_range', [1.0, 1.0]) if getattr(pa, 'stretch', False) else (1.0, 1.0)
+        rs = np.random.RandomState(seed + 77 + rank)
+        mk = lambda b, f, sd: synthetic_cycle_batch(b, f, self.r, self.vocab_size, self.n_spkr, self.n_mels, self.linear_dim, seed=sd,
+                                                    stretch=float(rs.uniform(lo, hi)))
+        self.pair_set = [mk(B, frames, 1000 * rank + i + seed) for i in range(n)]
+        self.unpair_set = [mk(Bu, uframes, 500000 + 1000 * rank + i + seed) for i in range(n)]
+        self.pair_iter, self.unpair_iter = 0, 0
+        # (mel, aug_mel, linear, text, sid) -> the paired TTS step's (text, sid, mel, linear): TtsTrainer.exec on the same data
+        self.batches = [(b[3], b[4], b[0], b[2]) for b in self.pair_set]
+        return self
+
+    def fetch_data(self, iter_name):
+        """the next batch of `pair_iter` / `unpair_iter` on the device, the set restarting when it is exhausted (:33-41)"""
+        data = getattr(self, iter_name.replace('iter', 'set'))
+        i = getattr(self, iter_name)
+        setattr(self, iter_name, i + 1)
+        cache = self.__dict__.setdefault('_dev_batches', {})
+        key = (iter_name, i % len(data))
+        if key not in cache:                     # (the synthetic sets are small and fixed: on the device once)
+            cache[key] = tuple(t.to(self.device) for t in data[i % len(data)])
+        return cache[key]
+
+    def exec(self):
+        """VqvaeTrainer.exec's loop (bin/train_vqvae.py:111-150,270-300) without the corpus-side logging: paired batch every step,
+        the unpaired batch fetched only when the step's cycle uses it, cycles alternating"""
+        t0 = time.perf_counter()
+        frames = 0
+        cnt = {'unp_sph': 0, 'unp_txt': 0}
+        self.ctc_nan = 0
+        while self.step < self.max_step:
+            pair = self.fetch_data('pair_iter')
+            kind, use_unpair = self.cycle_kind(self.step)
+            unpair = self.fetch_data('unpair_iter') if use_unpair else None                       # :139-150
+            st = self.cycle_step(pair, unpair)
+            frames += pair[0].shape[0] * pair[0].shape[1] + (unpair[0].shape[0] * unpair[0].shape[1] if unpair is not None else 0)
+            if unpair is not None:
+                cnt['unp_sph' if kind == 'speech_first' else 'unp_txt'] += 1
+            self.log.append(st)
+            if self.step == 1 or self.step % 10 == 0:
+                self.verbose('Tr stat | step %d (%s) | Loss - %.4f (CTC-nan/unp-sph/unp-txt=%d/%d/%d) | Grad. Norm - %.3f | lr %.2e' %
+                             (self.step, kind, st['loss'], self.ctc_nan, cnt['unp_sph'], cnt['unp_txt'], st['grad_norm'], st['lr']))
+        torch.cuda.synchronize()
+        self.drain_stats()
+        self.check_device_status()
+        dt = time.perf_counter() - t0
+        if getattr(self.paras, 'save', False):
+            self.save_checkpoint('latest.pth', self.log[-1]['loss'] if self.log else 0.0)
+        self.verbose('%d steps, %d frames in %.2f s (%.0f frames/s incl. first-step set-up)' %
+                     (len(self.log), frames, dt, frames / max(dt, 1e-9)))
+        return self.log

@@ -71,3 +71,25 @@ def synthetic_train_batch(B, frames, r, vocab_size=43, n_spkr=109, n_mels=80, li
     mel = rs.uniform(0, 1, (B, T, n_mels)).astype(np.float32)
     linear = rs.uniform(0, 1, (B, T, linear_dim)).astype(np.float32)
     return torch.from_numpy(text), torch.from_numpy(sid), torch.from_numpy(mel), torch.from_numpy(linear)
+
+
+def synthetic_cycle_batch(B, frames, r, vocab_size=43, n_spkr=109, n_mels=80, linear_dim=1025, seed=5, stretch=1.0):
+    """one batch as VqvaeTrainer.fetch_data hands it to the cycles (bin/train_vqvae.py:33-53): (mel, aug_mel, linear, text, sid).
+    mel / linear in [0,1) over `frames` frames, then zero-padded (SPEC_PAD_VALUE = 0) to the next multiple of r -- at least one
+    frame, :43-45; aug_mel is the augmented copy the speech encoder sees: NOT padded (:47), additive noise of the configured SNR
+    range and, with `stretch` != 1, a different length (time_stretch_range of config data.audio; nearest-frame resampling)."""
+    import torch
+    rs = np.random.RandomState(seed)
+    T = frames + (r - frames % r)
+    L = int(np.ceil(frames / 6.0))
+    text = rs.randint(3, vocab_size, (B, L)).astype(np.int64)
+    text[:, -1] = 0
+    sid = rs.randint(0, n_spkr, (B,)).astype(np.int64)
+    mel = np.zeros((B, T, n_mels), np.float32)
+    mel[:, :frames] = rs.uniform(0, 1, (B, frames, n_mels))
+    linear = np.zeros((B, T, linear_dim), np.float32)
+    linear[:, :frames] = rs.uniform(0, 1, (B, frames, linear_dim))
+    Ta = max(4, int(round(frames * stretch)))
+    src = np.minimum((np.arange(Ta) / stretch).astype(np.int64), frames - 1)
+    aug = np.clip(mel[:, src] + rs.standard_normal((B, Ta, n_mels)).astype(np.float32) * 0.05, 0.0, 1.0).astype(np.float32)
+    return (torch.from_numpy(mel), torch.from_numpy(aug), torch.from_numpy(linear), torch.from_numpy(text), torch.from_numpy(sid))

@@ -105,14 +105,14 @@ class VQVAE(nn.Module):
         """run-length merge + blank filter of the quantised latents on device.      ref: :218-257"""
         return AG.mean_forward(p_code, latent, self.max_frames_per_phn)
 
-    def speech_to_text(self, paired_mel, unpaired_mel, using_fake_mel=False):
-        """same contract and return tuple as the reference (:106-141)"""
+    def speech_to_text(self, paired_mel, unpaired_mel, using_fake_mel=False, _masks=None):
+        """same contract and return tuple as the reference (:106-141); `_masks` (tests only) = explicit dropout masks of the encoder"""
         use_unpaired = unpaired_mel is not None
         if use_unpaired:
             paired_mel_bs, all_mel = self.padded_concat(paired_mel, unpaired_mel)
         else:
             all_mel, paired_mel_bs = paired_mel, len(paired_mel)
-        enc_latent = self.asr(all_mel)                                                          # :116
+        enc_latent = self.asr(all_mel, _masks) if _masks is not None else self.asr(all_mel)    # :116
         paired_post_prob = self.asr_postnet(enc_latent[:paired_mel_bs]) if self.use_asr_postnet else None   # :117
         first_n_real_mel = len(paired_mel) if using_fake_mel else 0
         p_code, quantized_latent, _, rest = self.codebook(enc_latent, first_n_real_mel)         # :119

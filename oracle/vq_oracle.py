@@ -137,3 +137,25 @@ def mean_forward(idx: np.ndarray, latent: np.ndarray, max_frames_per_phn: int
     for b, s in enumerate(seqs):
         out[b, :s.shape[0]] = s
     return out, np.array([s.shape[0] for s in seqs], np.int64)
+
+
+def mean_forward_torch(idx: Tensor, latent: Tensor, max_frames_per_phn: int) -> Optional[Tuple[Tensor, Tensor]]:
+    """`mean_forward` above on torch tensors, differentiable with respect to `latent` (what autograd sees in the reference: slices,
+    `.mean(dim=0)`, `torch.stack`, `pad_sequence`).  ref: src/vqvae.py:218-257.  idx (B,T) int64, latent (B,T,D)."""
+    B, T, D = latent.shape
+    seqs, lens = [], []
+    for b in range(B):
+        row = idx[b].tolist()
+        last_idx, last_pos, cur, t = row[0], 0, [], 0
+        for t, i in enumerate(row):
+            if last_idx != i or (t - last_pos) > max_frames_per_phn:                  # :231
+                if last_idx != 0:
+                    cur.append(latent[b, last_pos:t].mean(dim=0))                     # :234
+                last_idx, last_pos = i, t
+        if last_idx != 0:                                                             # :239-245
+            cur.append(latent[b, last_pos:].mean(dim=0) if last_pos != T - 1 else latent[b, t])
+        if not cur:
+            return None                                                               # :248-249
+        lens.append(len(cur))
+        seqs.append(torch.stack(cur, dim=0))
+    return torch.nn.utils.rnn.pad_sequence(seqs, batch_first=True), torch.tensor(lens, dtype=torch.int64)

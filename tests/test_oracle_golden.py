@@ -114,6 +114,11 @@ def test_vq_mean_forward():
         lat, ln = out
         assert np.array_equal(ln, A['len%d' % ci].numpy())
         assert np.abs(lat - A['out%d' % ci].numpy()).max() < 1e-6
+        # the differentiable torch form (used by the config-size cycle tests as the autograd reference)
+        lat_t, ln_t = VQ.mean_forward_torch(A['idx%d' % ci], A['lat%d' % ci], meta['max_frames_per_phn'])
+        assert torch.equal(ln_t, A['len%d' % ci].long())
+        assert (lat_t - A['out%d' % ci]).abs().max() < 1e-6
+    assert VQ.mean_forward_torch(torch.zeros(2, 5, dtype=torch.int64), torch.ones(2, 5, 3), 3) is None
 
 
 @pytest.mark.parametrize('name', ['asr_tiny_eval', 'asr_tiny_train', 'asr_tiny_ln_eval', 'asr_tiny_ln_train', 'asr_tiny_uni_eval',

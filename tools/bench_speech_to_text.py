@@ -51,7 +51,7 @@ def main():
         out['ms_eval_eager'] = timed(lambda: m.speech_to_text(pair[1], un[1]), a.steps)
     gs = GraphedSpeechToText(m, a.batch_size, a.frames, dev, B_unpair=a.unpair_batch_size).capture()
     gs.mel[:a.batch_size].copy_(pair[1]); gs.mel[a.batch_size:].copy_(un[1])
-    out['ms_eval_graph_replay'] = timed(lambda: gs.graph.replay(), a.steps)
+    out['ms_eval_graph_replay'] = timed(lambda: gs.graph.launch(), a.steps)
     m.train()
     with torch.no_grad():
         out['ms_train_mode_no_grad'] = timed(lambda: m.speech_to_text(pair[1], un[1]), a.steps)

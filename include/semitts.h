@@ -425,6 +425,22 @@ int st_bn_bwd_reduce(const float* dy, int ldd, int doff, const float* y, int ldy
 int st_bn_bwd_apply(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
                     const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
                     int M, int N, const float* s, int Mstat, float* dx, int lddx, int dxoff, void* stream);
+/* ConvLayer's tail in training (ref: src/module.py:641-646: BatchNorm -> activation -> (+ x) -> dropout) as ONE launch behind the conv:
+ * Tact (M, N) = act(BatchNorm(X)) with the given batch statistics, kept for the backward (NULL: not written), Y (M, N) = (Tact + res) * mask
+ * (res, mask: NULL = absent).  Contiguous rows of N floats, N % 4 == 0, 16-byte aligned.  Replaces nn.BatchNorm1d + torch.tanh + `+` +
+ * nn.Dropout of the reference (one launch instead of BatchNorm apply, add, bernoulli_, div_, mul). */
+int st_bn_norm_res_mask_fwd(const float* X, float* Tact, float* Y, int M, int N, const float* mean, const float* var,
+                            const float* w, const float* b, float eps, int act, const float* res, const float* mask, void* stream);
+/* The backward of that tail in the two halves of st_bn_bwd_reduce / st_bn_bwd_apply: dy is multiplied by `mask` on the way in, `y` is the
+ * kept Tact; the apply half also writes dres (M, N) = dy * mask, the gradient of the residual input (NULL: none); inv_total: NULL, or the
+ * device scalar of st_bn_sync_merge (s then holds the sums over all ranks). */
+int st_bn_bwd_reduce_masked(const float* dy, int ldd, const float* mask, int ldm, const float* y, int ldy, int act,
+                            const float* x, int ldx, const float* mean, const float* var, float eps,
+                            int M, int N, float* s, float* ws, void* stream);
+int st_bn_bwd_apply_masked(const float* dy, int ldd, const float* mask, int ldm, const float* y, int ldy, int act,
+                           const float* x, int ldx, const float* mean, const float* var, const float* w, float eps,
+                           int M, int N, const float* s, int Mstat, const float* inv_total, float* dx, int lddx,
+                           float* dres, int lddr, void* stream);
 /* SyncBN (the data-parallel form of the BatchNorm1d layers above; the reference trains on one device, ref: src/module.py:434-455,
  * so this is the path's own multi-GPU extension) with the row counts kept on the device:
  *   st_bn_stats_record   rec (2N + 1) = (mean[N], M2[N], row count) of this rank's rows -- what the ranks all-gather;

@@ -299,6 +299,9 @@ SIGNATURES = {
     'st_act_bwd': [P, I, P, I, I, P, I, P, I, I, I, P],
     'st_bn_bwd': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, I, I, P, P, I, P, P],
     'st_bn_bwd_reduce': [P, I, I, P, I, I, I, P, I, I, P, P, F, I, I, P, P, P],
+    'st_bn_norm_res_mask_fwd': [P, P, P, I, I, P, P, P, P, F, I, P, P, P],
+    'st_bn_bwd_reduce_masked': [P, I, P, I, P, I, I, P, I, P, P, F, I, I, P, P, P],
+    'st_bn_bwd_apply_masked': [P, I, P, I, P, I, I, P, I, P, P, P, F, I, I, P, I, P, P, I, P, I, P],
     'st_bn_bwd_apply': [P, I, I, P, I, I, I, P, I, I, P, P, P, F, I, I, P, I, P, I, I, P],
     'st_bn_stats_record': [P, I, I, I, I, P, P, P, P],
     'st_bn_sync_merge': [P, I, I, P, P, P, P, F, P, P],

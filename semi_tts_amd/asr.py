@@ -28,26 +28,39 @@ class ConvLayer(nn.Module):
             self.bn = nn.BatchNorm1d(out_dim)
         self.drop = nn.Dropout(dropout)
 
+    def out_len(self, T):
+        return (T + 2 * self.padding - self.conv.kernel_size[0]) // self.stride + 1
+
     def forward(self, x, mask=None):
-        """x (B,T,C) channels-last (the reference keeps (B,C,T))"""
+        """x (B,T,C) channels-last (the reference keeps (B,C,T)); `mask`: the scaled dropout mask of the output (None: drawn here)"""
         w, b = self.conv.weight, self.conv.bias
-        p = self.drop.p
+        p = self.drop.p if self.training else 0.0
+        if p > 0 and mask is None:
+            from .module import _scaled_mask
+            mask = _scaled_mask((x.shape[0], self.out_len(x.shape[1]), w.shape[0]), p, x.device)
+        res = x if self.residual else None
+        if self.training and self.batch_norm and w.shape[0] % 4 == 0:
+            if torch.is_grad_enabled():
+                # ONE autograd node: conv (+ bias) -> BatchNorm over the batch -> activation -> + x -> dropout      (src/module.py:638-648)
+                return AG.conv_layer(x, self.conv, self.bn, mask, self.padding, self.stride, self.activation, self.residual)
+            # no gradients: the same launches without the kept tensors (batch statistics of the biased conv output, then the fused tail)
+            bn = self.bn
+            y = ops.gemm(x.contiguous(), w, pad=self.padding, stride=self.stride, bias=b)
+            y2 = y.view(-1, y.shape[-1])
+            mean, var = ops.bn_stats(y2, 0, y.shape[-1], bn.running_mean, bn.running_var, bn.momentum, bn.num_batches_tracked)
+            _, out = ops.bn_norm_res_mask(y2, mean, var, bn.weight, bn.bias, bn.eps, self.activation,
+                                          res.contiguous().view(-1, y.shape[-1]) if res is not None else None,
+                                          mask.view(-1, y.shape[-1]) if mask is not None else None, want_t=False)
+            return out.view(y.shape)
         if self.training and torch.is_grad_enabled():
-            # differentiable: conv (+ bias) -> BatchNorm over the batch -> activation -> + x -> dropout     (src/module.py:638-648)
+            # (layers the fused node does not take: no BatchNorm, or a channel count that is not a multiple of 4)
             if self.batch_norm:
                 y = AG.batch_norm_train(AG.conv(x, w, b, pad=self.padding, stride=self.stride), self.bn, self.activation)
             else:
                 y = AG.conv(x, w, b, pad=self.padding, stride=self.stride, act=self.activation)
             if self.residual:
                 y = y + x
-            if p > 0:
-                y = y * (mask if mask is not None else torch.empty_like(y).bernoulli_(1 - p).div_(1 - p))
-            return y
-        if self.training and p > 0 and mask is None:
-            B, T, _ = x.shape
-            To = (T + 2 * self.padding - w.shape[2]) // self.stride + 1
-            mask = torch.empty(B, To, w.shape[0], device=x.device, dtype=torch.float32).bernoulli_(1 - p).div_(1 - p)
-        res = x if self.residual else None
+            return AG.mask_mul(y, mask) if mask is not None else y
         if not self.batch_norm:
             return ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b, act_post=self.activation, res=res, mask=mask)
         bn = self.bn
@@ -55,7 +68,7 @@ class ConvLayer(nn.Module):
             return ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b,
                             bn=(bn.running_mean, bn.running_var, bn.weight, bn.bias), bn_eps=bn.eps,
                             act_post=self.activation, res=res, mask=mask)
-        # training: batch statistics of the biased conv output first, then the same fused pass with them
+        # training without gradients, odd channel count: batch statistics of the biased conv output, then the fused pass with them
         y = ops.gemm(x, w, pad=self.padding, stride=self.stride, bias=b)
         mean, var = ops.bn_stats(y.view(-1, y.shape[-1]), 0, y.shape[-1], bn.running_mean, bn.running_var, bn.momentum,
                                  bn.num_batches_tracked)
@@ -90,12 +103,21 @@ class CTC(nn.Module):
         """x (B,T,n_mels) -> (B, T / time_reduce_factor, out_dim)                            ref: src/asr.py:46-64
         `_masks` (tests only): explicit scaled dropout masks, one per conv layer then one per LSTM layer (None = draw)"""
         x = x.contiguous()
+        p = self.dropout if self.training else 0.0
+        if _masks is None and p > 0:
+            # every dropout mask of the encoder (one per conv layer, one per LSTM layer: the same rate) from ONE draw
+            from .module import _scaled_masks
+            Bn, t, shapes = x.shape[0], x.shape[1], []
+            for l in range(self.layers):
+                t = getattr(self, 'layer' + str(l)).out_len(t)
+                shapes.append((Bn, t, self.dim[l + 1]))
+            shapes += [(Bn, t, (2 if self.rnn_bid else 1) * self.rnn_dim)] * self.rnn_layers
+            _masks = _scaled_masks(shapes, p, x.device)
         mk = (lambda i: _masks[i]) if _masks is not None else (lambda i: None)
         for l in range(self.layers):
             x = getattr(self, 'layer' + str(l))(x, mk(l))
         B, T, _ = x.shape
         H = self.rnn_dim
-        p = self.dropout if self.training else 0.0
         if self.training and torch.is_grad_enabled():
             for layer in range(self.rnn_layers):
                 g = lambda n, rev: getattr(self.rnn, '%s_l%d%s' % (n, layer, '_reverse' if rev else ''))
@@ -109,8 +131,7 @@ class CTC(nn.Module):
                 if last and self.layer_norm:
                     x = AG.layer_norm(x, self.norm_layer)                                    # :57-58 (before self.drop)
                 if p > 0:   # inter-layer dropout of nn.LSTM, and (after the last layer) the dropout in front of the projection
-                    m = mk(self.layers + layer)
-                    x = x * (m if m is not None else torch.empty_like(x).bernoulli_(1 - p).div_(1 - p))
+                    x = AG.mask_mul(x, mk(self.layers + layer))
             return AG.conv(x, self.postnet.weight, self.postnet.bias)
         Do = (2 if self.rnn_bid else 1) * H
         for layer in range(self.rnn_layers):
@@ -127,8 +148,7 @@ class CTC(nn.Module):
                 ln = self.norm_layer
                 x = ops.layer_norm(x.view(-1, Do), ln.weight, ln.bias, ln.eps).view(B, T, Do)
             if p > 0:   # inter-layer dropout of nn.LSTM and the dropout in front of the projection (:62)
-                m = mk(self.layers + layer)
-                x = x * (m if m is not None else torch.empty_like(x).bernoulli_(1 - p).div_(1 - p))
+                x = ops.act_bwd(x.view(-1, Do), None, None, mk(self.layers + layer).view(-1, Do)).view(B, T, Do)
         return ops.gemm(x, self.postnet.weight, bias=self.postnet.bias)
 
 
@@ -161,7 +181,12 @@ class ASRPostnet(nn.Module):
                 ops.lstm_seq2(xp[0], xp[1], g('weight_hh', False), g('weight_hh', True), g('bias_hh', False), g('bias_hh', True), out)
                 x = out
             if p > 0 or _masks is not None:   # nn.LSTM's inter-layer dropout after layer 0, self.dropout after layer 1
-                x = x * (_masks[layer] if _masks is not None else torch.empty_like(x).bernoulli_(1 - p).div_(1 - p))
+                if _masks is not None:
+                    m = _masks[layer]
+                else:
+                    from .module import _scaled_mask
+                    m = _scaled_mask(tuple(x.shape), p, x.device)
+                x = AG.mask_mul(x, m) if grad else ops.act_bwd(x.reshape(-1, 2 * H), None, None, m.reshape(-1, 2 * H)).view(B, T, 2 * H)
         if grad:
             return AG.log_softmax(AG.conv(x, self.linear.weight, self.linear.bias))
         return ops.log_softmax(ops.gemm(x, self.linear.weight, bias=self.linear.bias))

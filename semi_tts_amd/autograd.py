@@ -29,6 +29,36 @@ def _rows_strided(t):
     return t.contiguous().view(-1, t.shape[-1])
 
 
+def _conv_grads(x, xw, w, b, dpre, pad, KT, N, Bn, Tin, To, pool_prev, pool_w, need_dx, need_dw, db_in_wgrad, dx_res=None):
+    """input / weight (/ bias) gradients of a stride-1 channels-last conv from the gradient dpre (Bn, To, N) at its output; `dx_res`: a tensor
+    added to dx in the product's epilogue (the gradient of a residual path around the layer).  The weight-gradient products are queued."""
+    dx = dw = db = None
+    if need_dx:
+        wt, tap_major = ops.dx_weight(w.detach())        # (cached per weight version: all weights re-laid out by one launch per step)
+        dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pad, w_tap_major=tap_major, res=dx_res)
+        if pool_prev:
+            dx = ops.pool_prev_bwd(dx, x)
+    # (the parameter gradients are written where ops.grad_slot says: under data parallelism, into their all-reduce bucket)
+    if db_in_wgrad:
+        dw, db = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, with_db=True,
+                                out=ops.grad_slot(w), db_out=ops.grad_slot(b), later=ops.grad_first(w, b), params=(w, b))
+        dw = dw.view(w.shape)
+    elif need_dw:
+        dw = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, out=ops.grad_slot(w), later=ops.grad_first(w),
+                            params=(w,)).view(w.shape)
+    return dx, dw, db
+
+
+def _zero_stuff(dpre, Bn, To, N, Tin, pad, KT, stride):
+    """a stride-s conv is the stride-1 conv sampled every s positions: its gradients are those of the stride-1 conv for an output gradient
+    with zeros in between (only the speech encoder's second layer takes this path); returns (the stuffed gradient, its length)"""
+    To1 = Tin + 2 * pad - KT + 1
+    up = torch.empty(Bn, To1, N, device=dpre.device, dtype=torch.float32)
+    ops.fill_(up, 0.0)
+    ops.copy3d(up[:, 0:(To - 1) * stride + 1:stride], dpre.view(Bn, To, N), Bn, To, N)
+    return up, To1
+
+
 class _ConvFn(Function):
     """y = [act(conv1d/linear(pool?(x)) + b) (+ res)] (* mask), channels-last"""
 
@@ -75,13 +105,7 @@ class _ConvFn(Function):
         if has_b and ctx.needs_input_grad[2] and not db_in_wgrad:
             db = ops.colsum(_rows(dpre), out=ops.grad_slot(b))
         if stride > 1:
-            # a stride-s conv is the stride-1 conv sampled every s positions: its gradients are those of the stride-1 conv for
-            # an output gradient with zeros in between (zero-stuffing; only the speech encoder's second layer takes this path)
-            To1 = Tin + 2 * pad - KT + 1
-            up = torch.empty(Bn, To1, N, device=dpre.device, dtype=torch.float32)
-            ops.fill_(up, 0.0)
-            ops.copy3d(up[:, 0:(To - 1) * stride + 1:stride], dpre.view(Bn, To, N), Bn, To, N)
-            dpre, To = up, To1
+            dpre, To = _zero_stuff(dpre, Bn, To, N, Tin, pad, KT, stride)
         if (KT == 1 and w.dim() == 2 and pad == 0 and N % 4 != 0 and N >= 64 and Cin % 4 == 0 and not pool_prev and stride == 1 and w.is_contiguous()
                 and _rows(dpre).shape[0] >= 1024 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]):
             # a Linear whose output width is not a multiple of 4 (Linear(160, 1025) of the postnet): rows of dy are not 16-byte addressable
@@ -103,21 +127,101 @@ class _ConvFn(Function):
             dw = dwp[:N]
             dres = dy if has_res and ctx.needs_input_grad[3] else None
             return dx, dw, db, dres, None, None, None, None, None, None
-        if ctx.needs_input_grad[0]:
-            wt, tap_major = ops.dx_weight(w.detach())        # (cached per weight version: all weights re-laid out by one launch per step)
-            dx = ops.gemm(dpre, wt, Bn=Bn, Tin=To, Tout=Tin, pad=KT - 1 - pad, w_tap_major=tap_major)
-            if pool_prev:
-                dx = ops.pool_prev_bwd(dx, x)
-        # (the parameter gradients are written where ops.grad_slot says: under data parallelism, into their all-reduce bucket)
+        dx, dw, db2 = _conv_grads(x, xw, w, b, dpre, pad, KT, N, Bn, Tin, To, pool_prev, pool_w, ctx.needs_input_grad[0],
+                                  ctx.needs_input_grad[1], db_in_wgrad)
         if db_in_wgrad:
-            dw, db = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, with_db=True,
-                                    out=ops.grad_slot(w), db_out=ops.grad_slot(b), later=ops.grad_first(w, b), params=(w, b))
-            dw = dw.view(w.shape)
-        elif ctx.needs_input_grad[1]:
-            dw = ops.gemm_wgrad(dpre, xw, KT, pad, Bn=Bn, Tin=Tin, Tout=To, N=N, pool_prev=pool_w, out=ops.grad_slot(w), later=ops.grad_first(w),
-                                params=(w,)).view(w.shape)
+            db = db2
         dres = dy if has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None, None, None, None, None
+
+
+class _ConvLayerFn(Function):
+    """ConvLayer.forward in training (src/module.py:638-648) as ONE autograd node: Conv1d (+ bias) -> BatchNorm1d over the batch ->
+    activation -> (+ x) -> dropout mask.  Forward: the conv product, the statistics (two launches), ONE launch for normalisation +
+    activation + residual + mask (the reference: BatchNorm apply, tanh, add, bernoulli_, div_, mul).  Backward: the two halves of the
+    BatchNorm backward take the mask on the way in and hand out the residual's gradient, which the input-gradient product adds in its
+    epilogue (no mask / add / accumulate launches).  Under parallel.sync_batchnorm the statistics are the global batch's (_BnTrainFn)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, bn_w, bn_b, run_mean, run_var, tracked, mask, pad, stride, act, residual, eps, momentum):
+        from . import parallel
+        x = x.contiguous()
+        y = ops.gemm(x, w, pad=pad, stride=stride, bias=b)
+        N = y.shape[-1]
+        y2 = _rows(y)
+        M = y2.shape[0]
+        sync = parallel.sync_bn_active()
+        inv_total = None
+        if sync:
+            parallel._COUNTS['syncbn_fwd'] += 1
+            rec = parallel.all_gather_(ops.bn_stats_record(y2, 0, N, tracked))
+            mean, var, inv_total = ops.bn_sync_merge(rec, N, run_mean, run_var, momentum)
+        else:
+            mean, var = ops.bn_stats(y2, 0, N, run_mean, run_var, momentum, tracked)
+        t, out = ops.bn_norm_res_mask(y2, mean, var, bn_w, bn_b, eps, act, _rows(x) if residual else None,
+                                      _rows(mask) if mask is not None else None, want_t=act is not None)
+        ctx.save_for_backward(x, w, b, y, t, mean, var, bn_w, mask, inv_total)
+        ctx.cfg = (pad, stride, act, residual, eps, M, sync)
+        return out.view(y.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import parallel
+        x, w, b, y, t, mean, var, bn_w, mask, inv_total = ctx.saved_tensors
+        pad, stride, act, residual, eps, M, sync = ctx.cfg
+        d2, y2 = _rows_strided(dout), _rows(y)
+        N = y2.shape[1]
+        m2 = _rows(mask) if mask is not None else None
+        s = ops.bn_bwd_reduce(d2, t, act, y2, mean, var, eps, mask2d=m2)
+        dbn_b, dbn_w = s[:N], s[N:]
+        if sync:
+            dbn_b, dbn_w = dbn_b.clone(), dbn_w.clone()
+            parallel._COUNTS['syncbn_bwd'] += 1
+            parallel.all_reduce_sum_(s)
+        dpre, dres = ops.bn_bwd_apply(d2, t, act, y2, mean, var, bn_w, eps, s, M, inv_total, mask2d=m2, want_dres=residual)
+        Bn, Tin, Cin = x.shape
+        To = y.shape[1]
+        KT = w.shape[2]
+        dpre = dpre.view(Bn, To, N)
+        db = None
+        has_b = b is not None
+        db_in_wgrad = has_b and ctx.needs_input_grad[2] and ctx.needs_input_grad[1] and stride == 1
+        if has_b and ctx.needs_input_grad[2] and not db_in_wgrad:
+            db = ops.colsum(_rows(dpre), out=ops.grad_slot(b))
+        if stride > 1:
+            dpre, To = _zero_stuff(dpre, Bn, To, N, Tin, pad, KT, stride)
+        dx, dw, db2 = _conv_grads(x, x, w, b, dpre, pad, KT, N, Bn, Tin, To, False, False, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                  db_in_wgrad, dx_res=dres.view(x.shape) if dres is not None else None)
+        if db_in_wgrad:
+            db = db2
+        if dx is None and dres is not None:
+            dx = dres.view(x.shape)
+        return dx, dw, db, dbn_w, dbn_b, None, None, None, None, None, None, None, None, None, None
+
+
+def conv_layer(x, conv, bn, mask, pad, stride, act, residual):
+    """differentiable ConvLayer (speech encoder): see _ConvLayerFn"""
+    return _ConvLayerFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, mask,
+                              pad, stride, act, residual, bn.eps, bn.momentum)
+
+
+class _MaskMulFn(Function):
+    """y = x * mask (a scaled dropout mask drawn elsewhere); backward dy * mask -- the library's strided multiply, no ATen launch"""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        x = x.contiguous()
+        return ops.act_bwd(_rows(x), None, None, _rows(mask)).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        mask, = ctx.saved_tensors
+        return ops.act_bwd(_rows_strided(dy), None, None, _rows(mask)).view(dy.shape), None
+
+
+def mask_mul(x, mask):
+    return _MaskMulFn.apply(x, mask)
 
 
 class _ConvGroupFn(Function):

@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* dout, int ldd
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff,
                                                             int act, const float* x, int ldx, int xoff, const float* mean,
                                                             const float* var, float eps, int M, int N, int rows_per_chunk,
-                                                            float* part) {   // part[chunk][2][N]
+                                                            float* part, const float* mask = nullptr, int ldm = 0) {   // part[chunk][2][N]
     __shared__ float r1[4][64], r2[4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
@@ -696,18 +696,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, int
     const float* __restrict__ dp = dy + doff + nc;
     const float* __restrict__ xp = x + xoff + nc;
     const float* __restrict__ yp = act != ST_ACT_NONE ? y + yoff + nc : nullptr;
+    const float* __restrict__ kp = mask ? mask + nc : nullptr;        // dropout mask behind the activation: dyb = dy * mask * act'(y)
     // two rows per pass with independent sums: (up to) six loads in flight per thread instead of a chain of dependent round trips
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
     int m = m0 + rl;
     for (; m + 4 < m1; m += 8) {
         float g0 = dp[(size_t)m * ldd], g1 = dp[(size_t)(m + 4) * ldd];
         const float x0 = xp[(size_t)m * ldx], x1 = xp[(size_t)(m + 4) * ldx];
+        if (kp) { g0 *= kp[(size_t)m * ldm]; g1 *= kp[(size_t)(m + 4) * ldm]; }
         if (yp) { g0 *= act_grad(yp[(size_t)m * ldy], act); g1 *= act_grad(yp[(size_t)(m + 4) * ldy], act); }
         a0 += g0; a1 += g1;
         b0 = fmaf(g0, (x0 - mu) * inv, b0); b1 = fmaf(g1, (x1 - mu) * inv, b1);
     }
     for (; m < m1; m += 4) {
         float g = dp[(size_t)m * ldd];
+        if (kp) g *= kp[(size_t)m * ldm];
         if (yp) g *= act_grad(yp[(size_t)m * ldy], act);
         a0 += g;
         b0 = fmaf(g, (xp[(size_t)m * ldx] - mu) * inv, b0);
@@ -753,7 +756,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
                                                            int act, const float* x, int ldx, int xoff, const float* mean,
                                                            const float* var, const float* w, float eps, int M, int N,
                                                            const float* s1, const float* s2, float* dx, int lddx, int dxoff,
-                                                           int Mstat, const float* inv_total) {
+                                                           int Mstat, const float* inv_total, const float* mask = nullptr, int ldm = 0,
+                                                           float* dres = nullptr, int lddr = 0) {
     const size_t total = (size_t)M * N;
     // rows the statistics (and s1, s2) were taken over: > M under SyncBN, where 1 / (global row count) comes as a device scalar
     const float invM = inv_total ? inv_total[0] : 1.0f / (float)Mstat;
@@ -761,6 +765,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
         const size_t m = i / N;
         const int n = (int)(i - m * N);
         float g = dy[m * ldd + doff + n];
+        if (mask) g *= mask[m * ldm + n];
+        if (dres) dres[m * lddr + n] = g;          // the gradient of a residual input added behind the activation, in front of the mask
         if (act != ST_ACT_NONE) g *= act_grad(y[m * ldy + yoff + n], act);
         const float inv = 1.0f / sqrtf(var[n] + eps);
         const float xh = (x[m * ldx + xoff + n] - mean[n]) * inv;
@@ -872,6 +878,34 @@ __global__ __launch_bounds__(256) void bn_norm_fwd_kernel(const float* X, int ld
         float v = (X[m * ldx + xoff + n] - mean[n]) / sqrtf(var[n] + eps);
         v = v * (w ? w[n] : 1.0f) + (b ? b[n] : 0.0f);
         Y[m * ldy + yoff + n] = st_act(v, act);
+    }
+}
+
+// ConvLayer's tail in training (src/module.py:641-646): T = act(BatchNorm(X)) kept for the backward, Y = (T + res) * mask the layer's output
+// (res, mask optional); 16-byte pieces (N % 4 == 0, all rows 16-byte aligned)
+__global__ __launch_bounds__(256) void bn_norm_res_mask_fwd_kernel(const float* __restrict__ X, float* __restrict__ Tact, float* __restrict__ Y,
+                                                                   int N4, size_t total4, const float* __restrict__ mean,
+                                                                   const float* __restrict__ var, const float* __restrict__ w,
+                                                                   const float* __restrict__ b, float eps, int act,
+                                                                   const float* __restrict__ res, const float* __restrict__ mask) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = 4 * (int)(i % N4);
+        const f32x4 x = st_ld4(X + 4 * i), mu = st_ld4(mean + n), vr = st_ld4(var + n);
+        f32x4 g = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f}, k = {1.f, 1.f, 1.f, 1.f};
+        if (w) g = st_ld4(w + n);
+        if (b) be = st_ld4(b + n);
+        if (res) r = st_ld4(res + 4 * i);
+        if (mask) k = st_ld4(mask + 4 * i);
+        f32x4 t, y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = (x[j] - mu[j]) / sqrtf(vr[j] + eps);           // (bn_norm_fwd_kernel's expression, element for element)
+            v = v * g[j] + be[j];
+            t[j] = st_act(v, act);
+            y[j] = (t[j] + r[j]) * k[j];
+        }
+        if (Tact) *reinterpret_cast<f32x4*>(Tact + 4 * i) = t;
+        *reinterpret_cast<f32x4*>(Y + 4 * i) = y;
     }
 }
 
@@ -1508,13 +1542,43 @@ extern "C" int st_bn_bwd_reduce(const float* dy, int ldd, int doff, const float*
 
 static int bn_bwd_apply_impl(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
                              const float* x, int ldx, int xoff, const float* mean, const float* var, const float* w, float eps,
-                             int M, int N, const float* s, int Mstat, const float* inv_total, float* dx, int lddx, int dxoff, void* stream) {
+                             int M, int N, const float* s, int Mstat, const float* inv_total, float* dx, int lddx, int dxoff, void* stream,
+                             const float* mask = nullptr, int ldm = 0, float* dres = nullptr, int lddr = 0) {
     (void)hipGetLastError();
     ST_CHECK_ARG(dy && x && mean && var && s && dx && M > 0 && N > 0 && Mstat >= M && (act == ST_ACT_NONE || y), "st_bn_bwd_apply: bad arguments");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, (hipStream_t)stream, dy, ldd, doff, y, ldy, yoff,
-                       act, x, ldx, xoff, mean, var, w, eps, M, N, s, s + N, dx, lddx, dxoff, Mstat, inv_total);
+                       act, x, ldx, xoff, mean, var, w, eps, M, N, s, s + N, dx, lddx, dxoff, Mstat, inv_total, mask, ldm, dres, lddr);
     ST_LAUNCH_CHECK();
     return 0;
+}
+
+// The two halves of the BatchNorm backward for a layer whose forward was Y = (act(BN(x)) + res) * mask (st_bn_norm_res_mask_fwd; ConvLayer,
+// src/module.py:641-646): the incoming gradient is multiplied by the mask on the way in (no launch of its own), `y` is the kept act(BN(x)),
+// and the apply half also hands out dres = dy * mask, the gradient of the residual input (NULL: no residual).  inv_total as in
+// st_bn_bwd_apply_sync (NULL: the sums are divided by Mstat).
+extern "C" int st_bn_bwd_reduce_masked(const float* dy, int ldd, const float* mask, int ldm, const float* y, int ldy, int act,
+                                       const float* x, int ldx, const float* mean, const float* var, float eps,
+                                       int M, int N, float* s, float* ws, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dy && x && mean && var && s && ws && M > 0 && N > 0 && (act == ST_ACT_NONE || y), "st_bn_bwd_reduce_masked: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = ws + 2 * (size_t)N;
+    const int chunks = st_colreduce_chunks(M);
+    const int rpc = (M + chunks - 1) / chunks;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, dy, ldd, 0, y, ldy, 0, act,
+                       x, ldx, 0, mean, var, eps, M, N, rpc, part, mask, ldm);
+    ST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_final_kernel, dim3((2 * N + 15) / 16), dim3(256), 0, st, part, chunks, 2, N, s, s + N, 0);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_bn_bwd_apply_masked(const float* dy, int ldd, const float* mask, int ldm, const float* y, int ldy, int act,
+                                      const float* x, int ldx, const float* mean, const float* var, const float* w, float eps,
+                                      int M, int N, const float* s, int Mstat, const float* inv_total, float* dx, int lddx,
+                                      float* dres, int lddr, void* stream) {
+    return bn_bwd_apply_impl(dy, ldd, 0, y, ldy, 0, act, x, ldx, 0, mean, var, w, eps, M, N, s, inv_total ? M : Mstat, inv_total, dx, lddx, 0, stream,
+                             mask, ldm, dres, lddr);
 }
 
 extern "C" int st_bn_bwd_apply(const float* dy, int ldd, int doff, const float* y, int ldy, int yoff, int act,
@@ -1760,6 +1824,22 @@ extern "C" int st_bn_norm_fwd(const float* X, int ldx, int xoff, float* Y, int l
     ST_CHECK_ARG(X && Y && mean && var && M > 0 && N > 0, "st_bn_norm_fwd: bad arguments");
     hipLaunchKernelGGL(bn_norm_fwd_kernel, dim3(blocks_for((size_t)M * N)), dim3(256), 0, (hipStream_t)stream,
                        X, ldx, xoff, Y, ldy, yoff, M, N, mean, var, w, b, eps, act);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tact (M, N) = act(BatchNorm(X)) (may be NULL when nobody needs it), Y (M, N) = (Tact + res) * mask; X, res, mask, Tact, Y contiguous rows
+// of N floats, N % 4 == 0, 16-byte aligned.  ref: ConvLayer.forward, src/module.py:641-646
+extern "C" int st_bn_norm_res_mask_fwd(const float* X, float* Tact, float* Y, int M, int N, const float* mean, const float* var,
+                                       const float* w, const float* b, float eps, int act, const float* res, const float* mask,
+                                       void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(X && Y && mean && var && M > 0 && N > 0 && N % 4 == 0, "st_bn_norm_res_mask_fwd: bad arguments (N %% 4 == 0)");
+    ST_CHECK_ARG(st_aligned16(X) && st_aligned16(Y) && st_aligned16(Tact) && st_aligned16(res) && st_aligned16(mask) && st_aligned16(mean) && st_aligned16(var) && st_aligned16(w) && st_aligned16(b),
+                 "st_bn_norm_res_mask_fwd: 16-byte aligned operands");
+    const size_t total4 = (size_t)M * (N / 4);
+    hipLaunchKernelGGL(bn_norm_res_mask_fwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                       X, Tact, Y, N / 4, total4, mean, var, w, b, eps, act, res, mask);
     ST_LAUNCH_CHECK();
     return 0;
 }

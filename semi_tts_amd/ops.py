@@ -830,6 +830,17 @@ def bn_norm(x2d, xoff, N, mean, var, w, b, eps, act=None, out=None, yoff=0):
     return out
 
 
+def bn_norm_res_mask(x2d, mean, var, w, b, eps, act=None, res2d=None, mask2d=None, want_t=True):
+    """-> (t, y): t = act(BatchNorm(x)) kept for the backward (None unless want_t), y = (t + res) * mask -- one launch (ConvLayer's tail,
+    src/module.py:641-646).  Contiguous (M, N) operands."""
+    M, N = x2d.shape
+    y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    t = torch.empty(M, N, device=x2d.device, dtype=torch.float32) if want_t and (res2d is not None or mask2d is not None) else None
+    check(_lib.load().st_bn_norm_res_mask_fwd(_p(x2d), _p(t), _p(y), M, N, _p(mean), _p(var), _p(w), _p(b), float(eps), ACT[act],
+                                              _p(res2d), _p(mask2d), stream_handle()), 'st_bn_norm_res_mask_fwd')
+    return (t if t is not None else (y if want_t else None)), y
+
+
 # ------------------------------------------------------------------------- where parameter gradients are written
 _GRAD_SINK = None
 
@@ -1100,21 +1111,34 @@ def bn_bwd(dy2d, y2d, act, x2d, mean, var, w, eps, need_wb=True):
     return dx, dw, db
 
 
-def bn_bwd_reduce(dy2d, y2d, act, x2d, mean, var, eps):
-    """-> s (2N): [sum dyb, sum dyb * xhat] over the local rows"""
+def bn_bwd_reduce(dy2d, y2d, act, x2d, mean, var, eps, mask2d=None):
+    """-> s (2N): [sum dyb, sum dyb * xhat] over the local rows; mask2d: dy is multiplied by it on the way in (st_bn_norm_res_mask_fwd's backward)"""
     M, N = x2d.shape
     s = torch.empty(2 * N, device=x2d.device, dtype=torch.float32)
     ws = _colreduce_ws(M, N, x2d.device)
+    if mask2d is not None:
+        check(_lib.load().st_bn_bwd_reduce_masked(_p(dy2d), int(dy2d.stride(0)), _p(mask2d), int(mask2d.stride(0)), _p(y2d),
+                                                  int(y2d.stride(0)) if y2d is not None else 0, ACT[act], _p(x2d), int(x2d.stride(0)),
+                                                  _p(mean), _p(var), float(eps), M, N, _p(s), _p(ws), stream_handle()), 'st_bn_bwd_reduce_masked')
+        return s
     check(_lib.load().st_bn_bwd_reduce(_p(dy2d), int(dy2d.stride(0)), 0, _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, 0,
                                        ACT[act], _p(x2d), int(x2d.stride(0)), 0, _p(mean), _p(var), float(eps), M, N, _p(s), _p(ws),
                                        stream_handle()), 'st_bn_bwd_reduce')
     return s
 
 
-def bn_bwd_apply(dy2d, y2d, act, x2d, mean, var, w, eps, s, Mstat, inv_total=None):
-    """inv_total (device scalar, bn_sync_merge): s holds sums over all ranks' rows, divide them by the global count"""
+def bn_bwd_apply(dy2d, y2d, act, x2d, mean, var, w, eps, s, Mstat, inv_total=None, mask2d=None, want_dres=None):
+    """inv_total (device scalar, bn_sync_merge): s holds sums over all ranks' rows, divide them by the global count.
+    want_dres is not None: the masked form -> (dx, dres or None) with dres = dy * mask (the gradient of a residual input)"""
     M, N = x2d.shape
     dx = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    if want_dres is not None:
+        dres = torch.empty(M, N, device=x2d.device, dtype=torch.float32) if want_dres else None
+        check(_lib.load().st_bn_bwd_apply_masked(_p(dy2d), int(dy2d.stride(0)), _p(mask2d), int(mask2d.stride(0)) if mask2d is not None else 0,
+                                                 _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, ACT[act], _p(x2d), int(x2d.stride(0)),
+                                                 _p(mean), _p(var), _p(w), float(eps), M, N, _p(s), int(Mstat), _p(inv_total), _p(dx), N,
+                                                 _p(dres), N, stream_handle()), 'st_bn_bwd_apply_masked')
+        return dx, dres
     if inv_total is not None:
         check(_lib.load().st_bn_bwd_apply_sync(_p(dy2d), int(dy2d.stride(0)), 0, _p(y2d), int(y2d.stride(0)) if y2d is not None else 0, 0,
                                                ACT[act], _p(x2d), int(x2d.stride(0)), 0, _p(mean), _p(var), _p(w), float(eps), M, N,

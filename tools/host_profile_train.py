@@ -22,17 +22,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--dist', action='store_true')
     ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--cycle', action='store_true', help='the VqvaeTrainer cycles (config 3) instead of the paired TTS step')
+    ap.add_argument('--batch-size', type=int, default=None)
     args = ap.parse_args()
     import bench
     if args.dist:
         os.environ['ST_BENCH_FORCE_DIST'] = '1'
     rk = bench.Ranks(Namespace(gpus=1, dist=args.dist))
-    from semi_tts_amd.solver import TtsTrainer
-    config = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-multi-spkr-paired-data.yaml')))
-    paras = Namespace(batch_size=bench.B, frames=bench.T_RAW, n_batches=1, seed=0, verbose=False, max_step=10 ** 9, load=None, n_spkr=109)
-    tr = TtsTrainer(config, paras, 'train').load_data().set_model()
-    batch = [t.to(rk.dev) for t in tr.batches[0]]
+    from semi_tts_amd.solver import TtsTrainer, VqvaeTrainer
+    config = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-single-spkr-paired-data.yaml' if args.cycle else 'semi-multi-spkr-paired-data.yaml')))
+    paras = Namespace(batch_size=args.batch_size or bench.B, frames=bench.T_RAW, n_batches=1, seed=0, verbose=False, max_step=10 ** 9, load=None, n_spkr=109)
+    tr = (VqvaeTrainer if args.cycle else TtsTrainer)(config, paras, 'train').load_data().set_model()
     tr.async_stats = True
+    if args.cycle:
+        pair, unpair = tr.fetch_data('pair_iter'), tr.fetch_data('unpair_iter')
+        tr.step = 2
+
+        def one():
+            tr.cycle_step(pair, unpair if tr.cycle_kind(tr.step)[1] else None)
+        tr.train_step = lambda *a: one()
+        batch = ()
+    else:
+        batch = [t.to(rk.dev) for t in tr.batches[0]]
     for _ in range(8):
         tr.train_step(*batch)
     torch.cuda.synchronize()

@@ -973,6 +973,15 @@ int st_adain_bwd(const float* dadapt, long da_step_stride, int da_ld, const floa
 size_t st_ctc_workspace_floats(int B, int T);
 int st_ctc_loss(const float* prob, const int64_t* text, float eps, float* loss, float* dprob, float* ws,
                 int B, int T, int V, int L, int log_input, void* stream);
+
+/* The trainer's scalar arithmetic on loss values as one launch (ref: bin/train_vqvae.py:208-233: total_loss = asr_weight * asr_loss +
+ * tts_weight * (mel_loss + linear_loss) + unpair_speech_weight * ... -- a chain of one-element torch kernels there):
+ * *outs[j] = sum_i W[j * n + i] * *xs[i] for j < m (m <= 4 outputs, n <= ST_SCALAR_MAX terms, W on the host; in rows j > 0 a zero weight means the term is not a member of that sum).
+ * st_scalar_fanout is the backward of output 0: out[i] = w[i] * *dout. */
+#define ST_SCALAR_MAX 8
+int st_scalar_combine(const float* const* xs, int n, const float* W, int m, float* const* outs, void* stream);
+int st_scalar_fanout(const float* dout, const float* w, int n, float* out, void* stream);
+
 /* ------------------------------------------------------------------ trainer loss
  * loss = w_all*crit(pred,label) + w_low*crit(low n_low bins) + w_diff*crit(first differences along T), crit = MSE or
  * (l1 != 0) mean absolute error; writes the scalar to *loss and d loss / d pred to dpred (B,T,D).  ws: st_freq_loss_workspace_floats() floats (one partial sum per workgroup).

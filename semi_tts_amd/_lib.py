@@ -204,6 +204,8 @@ SIGNATURES = {
     'st_vq_l2_workspace_floats': [I, I],
     'st_ctc_workspace_floats': [I, I],
     'st_ctc_loss': [P, P, C.c_float, P, P, P, I, I, I, I, I, P],
+    'st_scalar_combine': [P, I, P, I, P, P],
+    'st_scalar_fanout': [P, P, I, P, P],
     'st_softmax_bwd': [P, P, P, C.c_float, P, P, I, I, P],
     'st_rowscale_combine': [P, C.c_float, P, P, C.c_float, P, P, I, I, P],
     'st_vq_mean_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],

@@ -224,6 +224,111 @@ def mask_mul(x, mask):
     return _MaskMulFn.apply(x, mask)
 
 
+def _contig3(x):
+    """x (B, T, D) as a contiguous tensor: itself, or one strided copy by the library (no ATen launch)"""
+    if x.is_contiguous():
+        return x
+    if x.dim() == 3 and x.stride(-1) == 1:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        return ops.copy3d(out, x, x.shape[0], x.shape[1], x.shape[2])
+    return x.contiguous()
+
+
+class _PaddedConcatFn(Function):
+    """VQVAE.padded_concat (src/vqvae.py:259-271): two (B, T, D) batches stacked on the batch axis, the shorter one zero-padded in time.
+    One fill (only when something is padded) + two strided copies of the library; backward hands out the two blocks of the gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        Ba, Ta, D = a.shape
+        Bb, Tb, _ = b.shape
+        T = max(Ta, Tb)
+        out = torch.empty(Ba + Bb, T, D, device=a.device, dtype=torch.float32)
+        if Ta != Tb:
+            ops.fill_(out, 0.0)
+        ops.copy3d(out[:Ba], a if a.stride(-1) == 1 else a.contiguous(), Ba, Ta, D)
+        ops.copy3d(out[Ba:], b if b.stride(-1) == 1 else b.contiguous(), Bb, Tb, D)
+        ctx.dims = (Ba, Ta, Bb, Tb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Ba, Ta, Bb, Tb = ctx.dims
+        da = _contig3(dout[:Ba, :Ta]) if ctx.needs_input_grad[0] else None
+        db = _contig3(dout[Ba:, :Tb]) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+def padded_concat(a, b):
+    return _PaddedConcatFn.apply(a, b)
+
+
+class _SplitPairFn(Function):
+    """(x[:Bp, :Tp], x[Bp:, :Tu]) of a (B, T, D) tensor -- the unpacking of VQVAE.text_to_speech (src/vqvae.py:187-195) -- with a backward
+    that writes the two incoming gradients into ONE tensor (two strided copies of the library; a fill only when a block is shorter than T).
+    Plain slicing costs autograd two full-size zero fills, two copies and an add (68 MB each for the linear spectrogram at B = 64)."""
+
+    @staticmethod
+    def forward(ctx, x, Bp, Tp, Tu):
+        ctx.dims = (tuple(x.shape), Bp, Tp, Tu)
+        return x[:Bp, :Tp], x[Bp:, :Tu]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        shape, Bp, Tp, Tu = ctx.dims
+        B, T, D = shape
+        dev = (da if da is not None else db).device
+        dx = torch.empty(shape, device=dev, dtype=torch.float32)
+        if Tp != T or Tu != T or da is None or db is None:
+            ops.fill_(dx, 0.0)
+        if da is not None:
+            ops.copy3d(dx[:Bp], da if da.stride(-1) == 1 else da.contiguous(), Bp, Tp, D)
+        if db is not None:
+            ops.copy3d(dx[Bp:], db if db.stride(-1) == 1 else db.contiguous(), B - Bp, Tu, D)
+        return dx, None, None, None
+
+
+def split_pair(x, Bp, Tp, Tu):
+    T = x.shape[1]
+    return _SplitPairFn.apply(x, int(Bp), min(int(Tp), T), min(int(Tu), T))
+
+
+class _ScalarCombineFn(Function):
+    """total = sum_i w_i x_i over one-element tensors (+ up to three more weighted sums for the log) in ONE launch; backward: one launch
+    for all the w_i * dtotal.  The reference's `total_loss = total_loss + w * loss` chain (bin/train_vqvae.py:208-233) is a one-element torch
+    kernel per operator, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, W, *xs):
+        from . import _lib
+        import ctypes as C
+        n, m = len(xs), len(W)
+        dev = xs[0].device
+        outs = [torch.empty((), device=dev, dtype=torch.float32) for _ in range(m)]
+        xa = (C.c_void_p * n)(*[ops._p(x) for x in xs])
+        oa = (C.c_void_p * m)(*[ops._p(o) for o in outs])
+        wa = (C.c_float * (n * m))(*[float(v) for row in W for v in row])
+        _lib.check(_lib.load().st_scalar_combine(xa, n, wa, m, oa, ops.stream_handle()), 'st_scalar_combine')
+        ctx.w = [float(v) for v in W[0]]
+        ctx.mark_non_differentiable(*outs[1:])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dtotal, *_):
+        from . import _lib
+        import ctypes as C
+        n = len(ctx.w)
+        out = torch.empty(n, device=dtotal.device, dtype=torch.float32)
+        wa = (C.c_float * n)(*ctx.w)
+        _lib.check(_lib.load().st_scalar_fanout(ops._p(dtotal.contiguous()), wa, n, ops._p(out), ops.stream_handle()), 'st_scalar_fanout')
+        return (None,) + tuple(out[i] if ctx.needs_input_grad[i + 1] else None for i in range(n))
+
+
+def scalar_combine(W, xs):
+    """W: rows of weights (row 0 = the differentiable total); xs: one-element tensors.  -> tuple of len(W) 0-d tensors"""
+    return _ScalarCombineFn.apply([list(r) for r in W], *xs)
+
+
 class _ConvGroupFn(Function):
     """n convolutions / linear maps of the SAME input (the K convs of the CBHG bank, src/module.py:590-598; the two directions' input
     projections of a bidirectional GRU / LSTM): y_k = act(conv1d_k(x) + b_k).  Forward: the n products go out as ONE launch where the
@@ -1083,7 +1188,7 @@ class _FreqLossFn(Function):
     @staticmethod
     def forward(ctx, pred, label, n_low, w_all, w_low, w_diff, l1):
         from . import _lib
-        pred, label = pred.contiguous(), label.contiguous()
+        pred, label = _contig3(pred), _contig3(label)
         B, T, D = pred.shape
         loss = torch.empty((), device=pred.device, dtype=torch.float32)
         dpred = torch.empty_like(pred)

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float* x, const flo
 // ---- CTC loss (ref: torch.nn.CTCLoss() as called by compute_ctcloss, bin/train_vqvae.py:430-444) ----------------------------
 //   lp(t, c) = log(prob(b, t, c) + eps);  targets = the non-zero tokens of text(b, :) in order;  every frame counts;  blank = 0
 //   loss = mean_b [ nll_b / max(S_b, 1) ],  nll_b = -log sum over alignments  (the alpha recursion in log space)
-// One workgroup per utterance walks alpha forward over the T frames (stored to a workspace), then beta backward, and emits
+// Per utterance one workgroup walks alpha forward over the T frames and another walks beta backward (both stored to a workspace); a third launch emits
 // d loss / d prob with the formula ATen's CPU kernel uses (grad wrt lp = exp(lp) - exp(log sum_{s in c}(alpha beta) + nll - lp),
 // chained through the log): one thread per state of the blank-extended target (2 S + 1 <= 256), lp values gathered per chunk of
 // CTC_TC frames into LDS, ONE LDS barrier per frame (double-buffered state), every reduction in a fixed order.
@@ -82,29 +82,19 @@ __device__ __forceinline__ float ctc_lse3(float a, float b, float c) {
     return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
 }
 
-// log_input != 0: `prob` already holds log-probabilities (ASRPostnet's log_softmax, compute_ctcloss(apply_log=False)); the gradient is
-// then taken with respect to them.  A token outside [0, V) poisons the utterance's loss and gradient with NaN (torch raises).
-__global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, const int64_t* text, float eps, float* nll_out,
-                                                          float* dprob, float* log_alpha, int B, int T, int V, int L, int log_input) {
-    extern __shared__ int ctc_dyn[];                 // cls_first[V]
-    __shared__ int lab[CTC_NT], nxt[CTC_NT];
-    __shared__ float st_a[2][CTC_NT], gam[2][CTC_NT];
-    __shared__ float lpS[CTC_TC][CTC_NT];
-    __shared__ int S_s, bad_s;
-    __shared__ float nll_s;
-    int* cls_first = ctc_dyn;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const float* pb = prob + (size_t)b * T * V;
+// blank-extended target of utterance b and, per label, the chain of the states that carry it (thread 0; the others wait at the barrier)
+__device__ __forceinline__ void ctc_setup(const int64_t* text, int b, int L, int V, int* lab, int* nxt, int* cls_first, int* S_out, int* bad_out) {
+    const int tid = threadIdx.x;
     for (int c = tid; c < V; c += CTC_NT) cls_first[c] = -1;
     __syncthreads();
-    if (tid == 0) {                                   // blank-extended target and, per label, the chain of the states that carry it
+    if (tid == 0) {
         int S = 0, bad = 0;
         for (int i = 0; i < L; ++i) {
             int64_t tk = text[(size_t)b * L + i];
             if (tk < 0 || tk >= V) { bad = 1; tk = 0; }            // never index cls_first / prob out of range
             if (tk != 0) { lab[2 * S + 1] = (int)tk; ++S; }
         }
-        bad_s = bad;
+        *bad_out = bad;
         for (int s2 = 0; s2 <= 2 * S; s2 += 2) lab[s2] = 0;
         for (int s2 = 0; s2 <= 2 * S; ++s2) nxt[s2] = -1;
         for (int s2 = 2 * S - 1; s2 >= 1; s2 -= 2) {   // odd states, descending: cls_first ends up as the FIRST occurrence
@@ -112,60 +102,75 @@ __global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, con
             nxt[s2] = cls_first[c];
             cls_first[c] = s2;
         }
-        S_s = S;
+        *S_out = S;
     }
     __syncthreads();
+}
+
+// log_input != 0: `prob` already holds log-probabilities (ASRPostnet's log_softmax, compute_ctcloss(apply_log=False)); the gradient is
+// then taken with respect to them.  A token outside [0, V) poisons the utterance's loss and gradient with NaN (torch raises).
+// grid (B, 2): workgroup (b, 0) walks alpha forward (-> log_alpha, nll), workgroup (b, 1) walks beta backward (-> log_beta) AT THE SAME TIME
+// on another compute unit -- the two recursions only meet in the gradient (ctc_grad_kernel); one workgroup doing both in turn took
+// 295 us at T = 128.  grid (B, 1) when no gradient is wanted.
+__global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, const int64_t* text, float eps, float* nll_out,
+                                                          float* log_alpha, float* log_beta, int B, int T, int V, int L, int log_input) {
+    extern __shared__ int ctc_dyn[];                 // cls_first[V]
+    __shared__ int lab[CTC_NT], nxt[CTC_NT];
+    __shared__ float st_a[2][CTC_NT];
+    __shared__ float lpS[CTC_TC][CTC_NT];
+    __shared__ int S_s, bad_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* pb = prob + (size_t)b * T * V;
+    ctc_setup(text, b, L, V, lab, nxt, ctc_dyn, &S_s, &bad_s);
     const int S = S_s, SP = 2 * S + 1;
     const bool on = tid < SP;
     const int my = on ? lab[tid] : 0;
     const bool skip_f = on && tid >= 2 && my != 0 && my != lab[tid - 2];            // alpha may come from s - 2
     const bool skip_b = on && tid + 2 < SP && lab[tid + 2] != 0 && lab[tid + 2] != my;   // beta may come from s + 2
-    float* la = log_alpha + (size_t)b * T * CTC_NT;
     auto gather = [&](int t0, int nt, int dir) {      // lpS[i][s] = lp(t0 + dir * i, lab[s]) for i < nt
         for (int i = 0; i < nt; ++i) {
             const float pv = on ? pb[(size_t)(t0 + dir * i) * V + my] : 0.0f;
             lpS[i][tid] = on ? (log_input ? pv : logf(pv + eps)) : -INFINITY;
         }
     };
-    // ---- alpha
     int cur = 0;
-    for (int t0 = 0; t0 < T; t0 += CTC_TC) {
-        const int nt = min(CTC_TC, T - t0);
-        __syncthreads();
-        gather(t0, nt, 1);
-        __syncthreads();
-        for (int i = 0; i < nt; ++i) {
-            const int t = t0 + i;
-            float a;
-            if (t == 0) a = (tid < 2 && on) ? lpS[0][tid] : -INFINITY;
-            else {
-                const float* pa = st_a[cur ^ 1];
-                const float a0 = on ? pa[tid] : -INFINITY, a1 = (on && tid >= 1) ? pa[tid - 1] : -INFINITY;
-                const float a2 = skip_f ? pa[tid - 2] : -INFINITY;
-                a = ctc_lse3(a0, a1, a2) + lpS[i][tid];
-                if (!on) a = -INFINITY;
+    if (blockIdx.y == 0) {
+        // ---- alpha
+        float* la = log_alpha + (size_t)b * T * CTC_NT;
+        for (int t0 = 0; t0 < T; t0 += CTC_TC) {
+            const int nt = min(CTC_TC, T - t0);
+            __syncthreads();
+            gather(t0, nt, 1);
+            __syncthreads();
+            for (int i = 0; i < nt; ++i) {
+                const int t = t0 + i;
+                float a;
+                if (t == 0) a = (tid < 2 && on) ? lpS[0][tid] : -INFINITY;
+                else {
+                    const float* pa = st_a[cur ^ 1];
+                    const float a0 = on ? pa[tid] : -INFINITY, a1 = (on && tid >= 1) ? pa[tid - 1] : -INFINITY;
+                    const float a2 = skip_f ? pa[tid - 2] : -INFINITY;
+                    a = ctc_lse3(a0, a1, a2) + lpS[i][tid];
+                    if (!on) a = -INFINITY;
+                }
+                st_a[cur][tid] = a;
+                la[(size_t)t * CTC_NT + tid] = a;
+                st_lds_barrier();
+                cur ^= 1;
             }
-            st_a[cur][tid] = a;
-            la[(size_t)t * CTC_NT + tid] = a;
-            st_lds_barrier();
-            cur ^= 1;
         }
+        if (tid == 0) {
+            const float* pa = st_a[cur ^ 1];
+            const float l1 = pa[SP - 1], l2 = SP >= 2 ? pa[SP - 2] : -INFINITY;
+            const float m = fmaxf(l1, l2);
+            float v = m == -INFINITY ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
+            if (bad_s) v = __builtin_nanf("");
+            nll_out[b] = v;
+        }
+        return;
     }
-    if (tid == 0) {
-        const float* pa = st_a[cur ^ 1];
-        const float l1 = pa[SP - 1], l2 = SP >= 2 ? pa[SP - 2] : -INFINITY;
-        const float m = fmaxf(l1, l2);
-        float v = m == -INFINITY ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
-        if (bad_s) v = __builtin_nanf("");
-        nll_s = v;
-        nll_out[b] = v;
-    }
-    __syncthreads();
-    const float nll = nll_s;
-    if (!dprob) return;
-    const float gr = bad_s ? __builtin_nanf("") : 1.0f / ((float)max(S, 1) * (float)B);
-    // ---- beta, occupancies and the gradient
-    cur = 0;
+    // ---- beta
+    float* lb = log_beta + (size_t)b * T * CTC_NT;
     for (int t1 = T - 1; t1 >= 0; t1 -= CTC_TC) {
         const int nt = min(CTC_TC, t1 + 1);
         __syncthreads();
@@ -184,42 +189,124 @@ __global__ __launch_bounds__(CTC_NT) void ctc_loss_kernel(const float* prob, con
                 if (!on) bt = -INFINITY;
             }
             st_a[cur][tid] = bt;
-            const float ab = on ? la[(size_t)t * CTC_NT + tid] + bt : -INFINITY;
-            gam[cur][tid] = ab == -INFINITY ? 0.0f : expf(ab - lps + nll);     // posterior occupancy of state s at frame t
+            lb[(size_t)t * CTC_NT + tid] = bt;
             st_lds_barrier();
-            const float* gq = gam[cur];
-            float blank = 0.0f;
-            if (tid < 64) {                          // blank = the even states: fixed-order wave reduction
-                for (int s2 = 2 * lane; s2 < SP; s2 += 128) blank += gq[s2];
-                blank = st_wave_sum_dpp(blank);
-            }
-            for (int c = tid; c < V; c += CTC_NT) {
-                float occ = 0.0f;
-                if (c == 0) occ = blank;
-                else for (int s2 = cls_first[c]; s2 >= 0; s2 = nxt[s2]) occ += gq[s2];
-                // d loss / d lp = gr * (exp(lp) - occ);  lp = log(p + eps)  ->  d / d prob = that / (p + eps)
-                const float pin = pb[(size_t)t * V + c];
-                const float p = log_input ? expf(pin) : pin + eps;
-                dprob[((size_t)b * T + t) * V + c] = log_input ? gr * (p - occ) : gr * (p - occ) / p;
-            }
             cur ^= 1;
         }
     }
 }
 
-__global__ void ctc_loss_final_kernel(const float* nll, const int64_t* text, int B, int L, float* loss) {
-    float s = 0.0f;
-    for (int b = 0; b < B; ++b) {
-        int S = 0;
-        for (int i = 0; i < L; ++i) S += text[(size_t)b * L + i] != 0;
-        s += nll[b] / (float)max(S, 1);
+// occupancies and the gradient: grid (B, ceil(T / CTC_TC)), a workgroup takes CTC_TC frames of one utterance -- every frame is independent
+// once alpha and beta are known.  Same expressions and summation orders as when this was the tail of the beta walk.
+__global__ __launch_bounds__(CTC_NT) void ctc_grad_kernel(const float* prob, const int64_t* text, float eps, const float* nll_in,
+                                                          float* dprob, const float* log_alpha, const float* log_beta,
+                                                          int B, int T, int V, int L, int log_input) {
+    extern __shared__ int ctc_dyn[];                 // cls_first[V]
+    __shared__ int lab[CTC_NT], nxt[CTC_NT];
+    __shared__ float gam[2][CTC_NT];
+    __shared__ int S_s, bad_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* pb = prob + (size_t)b * T * V;
+    int* cls_first = ctc_dyn;
+    ctc_setup(text, b, L, V, lab, nxt, cls_first, &S_s, &bad_s);
+    const int S = S_s, SP = 2 * S + 1;
+    const bool on = tid < SP;
+    const int my = on ? lab[tid] : 0;
+    const float nll = nll_in[b];
+    const float gr = bad_s ? __builtin_nanf("") : 1.0f / ((float)max(S, 1) * (float)B);
+    const float* la = log_alpha + (size_t)b * T * CTC_NT;
+    const float* lb = log_beta + (size_t)b * T * CTC_NT;
+    const int t0 = blockIdx.y * CTC_TC, t1 = min(T, t0 + CTC_TC);
+    int cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        const float pv = on ? pb[(size_t)t * V + my] : 0.0f;
+        const float lps = on ? (log_input ? pv : logf(pv + eps)) : -INFINITY;
+        const float ab = on ? la[(size_t)t * CTC_NT + tid] + lb[(size_t)t * CTC_NT + tid] : -INFINITY;
+        gam[cur][tid] = ab == -INFINITY ? 0.0f : expf(ab - lps + nll);     // posterior occupancy of state s at frame t
+        st_lds_barrier();
+        const float* gq = gam[cur];
+        float blank = 0.0f;
+        if (tid < 64) {                          // blank = the even states: fixed-order wave reduction
+            for (int s2 = 2 * lane; s2 < SP; s2 += 128) blank += gq[s2];
+            blank = st_wave_sum_dpp(blank);
+        }
+        for (int c = tid; c < V; c += CTC_NT) {
+            float occ = 0.0f;
+            if (c == 0) occ = blank;
+            else for (int s2 = cls_first[c]; s2 >= 0; s2 = nxt[s2]) occ += gq[s2];
+            // d loss / d lp = gr * (exp(lp) - occ);  lp = log(p + eps)  ->  d / d prob = that / (p + eps)
+            const float pin = pb[(size_t)t * V + c];
+            const float p = log_input ? expf(pin) : pin + eps;
+            dprob[((size_t)b * T + t) * V + c] = log_input ? gr * (p - occ) : gr * (p - occ) / p;
+        }
+        cur ^= 1;
     }
-    *loss = s / (float)B;
+}
+
+// loss = mean_b nll_b / max(S_b, 1): one wave, lane b counts its utterance's tokens (the lanes' loads run side by side; one thread walking
+// all B x L tokens took 88 us at B = 32, L = 43), the sum over b in ascending order as before (bit-identical)
+__global__ __launch_bounds__(64) void ctc_loss_final_kernel(const float* nll, const int64_t* text, int B, int L, float* loss) {
+    __shared__ float term[64];
+    float s = 0.0f;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + threadIdx.x;
+        int S = 0;
+        if (b < B) for (int i = 0; i < L; ++i) S += text[(size_t)b * L + i] != 0;
+        term[threadIdx.x] = b < B ? nll[b] / (float)max(S, 1) : 0.0f;
+        __syncthreads();
+        if (threadIdx.x == 0) for (int k = 0; k < min(64, B - b0); ++k) s += term[k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = s / (float)B;
+}
+
+// the trainer's scalar arithmetic on loss values (total = sum_i w_i loss_i, plus the sums the log prints) as ONE launch:
+// out[j] = sum_i W[j][i] * x_i, i in ascending order
+struct ScArgs { const float* x[ST_SCALAR_MAX]; float w[4][ST_SCALAR_MAX]; float* out[4]; int n, m; };
+__global__ void scalar_combine_kernel(ScArgs a) {
+    const int j = threadIdx.x;
+    if (j >= a.m) return;
+    float s = 0.0f;
+    for (int i = 0; i < a.n; ++i) if (j == 0 || a.w[j][i] != 0.0f) s += a.w[j][i] * a.x[i][0];      // (rows > 0 are sums over SUBSETS: a zero weight there means "not a member")
+    a.out[j][0] = s;
+}
+// its backward: out[i] = w_i * dout
+struct SfArgs { float w[ST_SCALAR_MAX]; int n; };
+__global__ void scalar_fanout_kernel(const float* dout, SfArgs a, float* out) {
+    const int i = threadIdx.x;
+    if (i < a.n) out[i] = a.w[i] * dout[0];
 }
 
 }  // namespace
 
-extern "C" size_t st_ctc_workspace_floats(int B, int T) { return (size_t)B * T * CTC_NT + (size_t)B; }
+extern "C" int st_scalar_combine(const float* const* xs, int n, const float* W, int m, float* const* outs, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(xs && W && outs && n > 0 && n <= ST_SCALAR_MAX && m > 0 && m <= 4, "st_scalar_combine: 1..%d terms, 1..4 outputs", ST_SCALAR_MAX);
+    ScArgs a{};
+    a.n = n; a.m = m;
+    for (int i = 0; i < n; ++i) { ST_CHECK_ARG(xs[i], "st_scalar_combine: null term"); a.x[i] = xs[i]; }
+    for (int j = 0; j < m; ++j) {
+        ST_CHECK_ARG(outs[j], "st_scalar_combine: null output");
+        a.out[j] = outs[j];
+        for (int i = 0; i < n; ++i) a.w[j][i] = W[j * n + i];
+    }
+    hipLaunchKernelGGL(scalar_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_scalar_fanout(const float* dout, const float* w, int n, float* out, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(dout && w && out && n > 0 && n <= ST_SCALAR_MAX, "st_scalar_fanout: 1..%d terms", ST_SCALAR_MAX);
+    SfArgs a{};
+    a.n = n;
+    for (int i = 0; i < n; ++i) a.w[i] = w[i];
+    hipLaunchKernelGGL(scalar_fanout_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dout, a, out);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t st_ctc_workspace_floats(int B, int T) { return 2 * (size_t)B * T * CTC_NT + (size_t)B; }
 
 extern "C" int st_ctc_loss(const float* prob, const int64_t* text, float eps, float* loss, float* dprob, float* ws,
                            int B, int T, int V, int L, int log_input, void* stream) {
@@ -230,10 +317,16 @@ extern "C" int st_ctc_loss(const float* prob, const int64_t* text, float eps, fl
     // hipFuncAttributeMaxDynamicSharedMemorySize: the argument check, not the launch, is what fails for a huge codebook
     ST_CHECK_ARG((size_t)V * sizeof(int) <= 40 * 1024, "st_ctc_loss: V=%d too large (at most %d classes)", V, 40 * 1024 / 4);
     hipStream_t st = (hipStream_t)stream;
-    float* nll = ws + (size_t)B * T * CTC_NT;
-    hipLaunchKernelGGL(ctc_loss_kernel, dim3(B), dim3(CTC_NT), (size_t)V * sizeof(int), st, prob, text, eps, nll, dprob, ws, B, T, V, L, log_input);
+    float* lbeta = ws + (size_t)B * T * CTC_NT;
+    float* nll = ws + 2 * (size_t)B * T * CTC_NT;
+    hipLaunchKernelGGL(ctc_loss_kernel, dim3(B, dprob ? 2 : 1), dim3(CTC_NT), (size_t)V * sizeof(int), st, prob, text, eps, nll, ws, lbeta, B, T, V, L, log_input);
     ST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ctc_loss_final_kernel, dim3(1), dim3(1), 0, st, nll, text, B, L, loss);
+    if (dprob) {
+        hipLaunchKernelGGL(ctc_grad_kernel, dim3(B, (T + CTC_TC - 1) / CTC_TC), dim3(CTC_NT), (size_t)V * sizeof(int), st, prob, text, eps, nll, dprob, ws, lbeta,
+                           B, T, V, L, log_input);
+        ST_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(ctc_loss_final_kernel, dim3(1), dim3(64), 0, st, nll, text, B, L, loss);
     ST_LAUNCH_CHECK();
     return 0;
 }

@@ -296,7 +296,8 @@ class TtsTrainer(BaseSolver):
             text, sid, None, None, None, None, mel, None, tf_rate, _masks=_masks)
         mel_loss = self.freq_loss(mel_pred, mel)
         linear_loss = self.freq_loss(linear_pred, linear)
-        total = self.tts_weight * (mel_loss + linear_loss)
+        from . import autograd as AG
+        total, = AG.scalar_combine([[self.tts_weight, self.tts_weight]], [mel_loss, linear_loss])     # (one launch; `w * (a + b)` is two, and three backward)
         total.backward()
         self._reduce_gradients()
         grad_norm = self._clip()
@@ -458,10 +459,10 @@ class VqvaeTrainer(TtsTrainer):
         from .optim import FusedAdam
         return self.async_stats and isinstance(getattr(self.optimizer, 'opt', None), FusedAdam)
 
-    def _paired_losses(self, pair_prob, pair_post_prob, pm, pl, mel, linear, text, stats):
+    def _paired_losses(self, pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats):
         """the terms both cycles share (bin/train_vqvae.py:208-224): CTC on the paired posteriors (+ the ASRPostnet term) and
-        freq_loss on the paired reconstruction; returns the weighted sum.  `stats` collects the step's scalars as DEVICE tensors:
-        whether and when they are read is _finish_step's business."""
+        freq_loss on the paired reconstruction.  Appends (weight, loss, statistics name) to `terms`: the weighted sum itself -- and the
+        partial sums the log prints -- are ONE launch in _finish_step (the reference's chain of one-element kernels)."""
         hp = self.hp
         asr_loss = self.ctc_loss(pair_prob, text)                                                 # :209
         asr_w = float(hp.get('asr_weight', 1.0))
@@ -469,15 +470,27 @@ class VqvaeTrainer(TtsTrainer):
             from . import autograd as AG
             pw = float(self.model.asr_postnet_weight)
             asr_post_loss = AG.ctc_loss(pair_post_prob, text, EPS, apply_log=False)               # compute_ctcloss(..., apply_log=False)
-            total = asr_w * (1.0 - pw) * asr_loss + asr_w * pw * asr_post_loss
+            terms += [(asr_w * (1.0 - pw), asr_loss, None), (asr_w * pw, asr_post_loss, None)]
             stats['asr_post_loss'] = asr_post_loss.detach()
         else:
-            total = asr_w * asr_loss                                                              # :215
+            terms.append((asr_w, asr_loss, None))                                                 # :215
         # (:216-218: a NaN / inf CTC value is counted when the statistics are read -- as in the reference it is already inside total,
         # the gradient norm is then NaN and the update is skipped)
-        tts_loss = self.freq_loss(pm, mel) + self.freq_loss(pl, linear)                           # :221-224
-        stats.update(asr_loss=asr_loss.detach(), tts_loss=tts_loss.detach())
-        return total + self.tts_weight * tts_loss
+        stats['asr_loss'] = asr_loss.detach()
+        terms += [(self.tts_weight, self.freq_loss(pm, mel), 'tts_loss'), (self.tts_weight, self.freq_loss(pl, linear), 'tts_loss')]   # :221-224
+
+    def _total(self, terms, stats):
+        """total = sum of weight * loss over `terms`; the named partial sums (unweighted, as the reference logs them) land in `stats`"""
+        from . import autograd as AG
+        names = []
+        for _, _, nm in terms:
+            if nm is not None and nm not in names:
+                names.append(nm)
+        W = [[w for w, _, _ in terms]] + [[1.0 if nm == k else 0.0 for _, _, nm in terms] for k in names]
+        outs = AG.scalar_combine(W, [x for _, x, _ in terms])
+        for k, v in zip(names, outs[1:]):
+            stats[k] = v
+        return outs[0]
 
     def _count_ctc_nan(self, st):
         for k in ('asr_loss', 'unpair_text_loss'):
@@ -535,14 +548,13 @@ class VqvaeTrainer(TtsTrainer):
         out = self.model.text_to_speech(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
                                         unpair_latent_len, mel, None if ignore_speech_cycle else unpair_mel, tf_rate, _masks=_masks)
         pm, pl, _, _, upm, upl, _, _ = out
-        stats = {}
-        total = self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, stats)
+        stats, terms = {}, []
+        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats)
         if not ignore_speech_cycle:                                                               # :227-233
-            un = self.freq_loss(upm, unpair_mel) + self.freq_loss(upl, unpair_linear)
-            if self.step > int(hp.get('unpair_speech_start_step', 0)):                            # :232: only after the warm-up steps
-                total = total + float(hp.get('unpair_speech_weight', 10.0)) * un
-            stats['unpair_speech_loss'] = un.detach()
-        return self._finish_step(total, stats, tf_rate, 'speech_first')
+            # :232: the unpaired term only counts after the warm-up steps (weight 0 before: computed and logged, as in the reference)
+            w = float(hp.get('unpair_speech_weight', 10.0)) if self.step > int(hp.get('unpair_speech_start_step', 0)) else 0.0
+            terms += [(w, self.freq_loss(upm, unpair_mel), 'unpair_speech_loss'), (w, self.freq_loss(upl, unpair_linear), 'unpair_speech_loss')]
+        return self._finish_step(self._total(terms, stats), stats, tf_rate, 'speech_first')
 
     def text_first_step(self, mel, aug_mel, linear, text, sid, unpair_text=None, unpair_sid=None, _masks=None, _asr_masks=None):
         """The text -> speech -> text cycle of VqvaeTrainer.exec (bin/train_vqvae.py:186-205,208-224,234-250): text_to_speech on the
@@ -561,8 +573,8 @@ class VqvaeTrainer(TtsTrainer):
         pair_prob, _, unpair_prob, _, _, pair_post_prob, _ = self.model.speech_to_text(
             paired_mel=aug_mel, unpaired_mel=upm if use_unpair_text else None, using_fake_mel=use_unpair_text,
             **({'_masks': _asr_masks} if _asr_masks is not None else {}))                        # :203-205
-        stats = {}
-        total = self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, stats)
+        stats, terms = {}, []
+        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats)
         if use_unpair_text:                                                                       # :234-250
             ut = self.ctc_loss(unpair_prob, unpair_text)
             stats['unpair_text_loss'] = ut.detach()
@@ -570,8 +582,8 @@ class VqvaeTrainer(TtsTrainer):
             # this cycle reads inside the step (only configurations with unpair_text_weight > 0 get here; none of the shipped ones)
             v = float(ut.detach())
             if math.isfinite(v):
-                total = total + float(hp.get('unpair_text_weight', 0.0)) * ut
-        return self._finish_step(total, stats, tf_rate, 'text_first')
+                terms.append((float(hp.get('unpair_text_weight', 0.0)), ut, None))
+        return self._finish_step(self._total(terms, stats), stats, tf_rate, 'text_first')
 
     def cycle_step(self, pair, unpair=None, _masks=None, _asr_masks=None):
         """One iteration of VqvaeTrainer.exec's loop body (bin/train_vqvae.py:124-150): even steps run the speech-first cycle, odd

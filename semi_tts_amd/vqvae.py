@@ -84,12 +84,7 @@ class VQVAE(nn.Module):
 
     def padded_concat(self, pair, unpair):
         """zero-pad the shorter of two (B, T, D) batches in time and stack them on the batch axis.  ref: :259-271"""
-        pair_bs, pair_ts, unpair_ts = pair.shape[0], pair.shape[1], unpair.shape[1]
-        T = max(pair_ts, unpair_ts)
-        out = torch.zeros(pair_bs + unpair.shape[0], T, pair.shape[2], device=pair.device, dtype=pair.dtype)
-        out[:pair_bs, :pair_ts] = pair
-        out[pair_bs:, :unpair_ts] = unpair
-        return pair_bs, out
+        return pair.shape[0], AG.padded_concat(pair, unpair)
 
     def embed_speakers(self, sid):
         if self.training and torch.is_grad_enabled():
@@ -141,13 +136,13 @@ class VQVAE(nn.Module):
             unpaired_ts += unpaired_ts % self.n_frames_per_step
             unpair_max_frame = unpaired_ts
             all_teacher = paired_teacher
-            all_spkr = torch.cat([self.embed_speakers(paired_sid), self.embed_speakers(unpaired_sid)], dim=0)
+            all_spkr = self.embed_speakers(torch.cat([paired_sid, unpaired_sid]))
         elif unpaired_latent is not None:                   # speech-to-speech cycle          :164-173
             use_unpaired = True
             paired_latent_bs, all_latent = self.padded_concat(paired_latent, unpaired_latent)
             paired_ts, unpaired_ts = paired_teacher.shape[1], unpaired_teacher.shape[1]
             _, all_teacher = self.padded_concat(paired_teacher, unpaired_teacher)
-            all_spkr = torch.cat([self.embed_speakers(paired_sid), self.embed_speakers(unpaired_sid)], dim=0)
+            all_spkr = self.embed_speakers(torch.cat([paired_sid, unpaired_sid]))       # (one lookup of both id lists = the cat of two lookups)
         else:                                                                                   # :174-180
             use_unpaired = False
             all_latent, all_teacher = paired_latent, paired_teacher
@@ -156,6 +151,11 @@ class VQVAE(nn.Module):
                                             unpair_max_frame=unpair_max_frame, _masks=_masks)   # :183-184
         if use_unpaired:                                                                        # :187-195
             b = paired_latent_bs
-            return (mel[:b, :paired_ts], linear[:b, :paired_ts], align[:b, :paired_ts], stop[:b],
-                    mel[b:, :unpaired_ts], linear[b:, :unpaired_ts], align[b:, :unpaired_ts], stop[b:])
+            if mel.requires_grad or linear.requires_grad:
+                # (the same slices; their backward writes both gradients into one tensor instead of zero-fill + copy + add per slice)
+                pm, um = AG.split_pair(mel, b, paired_ts, unpaired_ts)
+                pl, ul = AG.split_pair(linear, b, paired_ts, unpaired_ts)
+            else:
+                pm, um, pl, ul = mel[:b, :paired_ts], mel[b:, :unpaired_ts], linear[:b, :paired_ts], linear[b:, :unpaired_ts]
+            return (pm, pl, align[:b, :paired_ts], stop[:b], um, ul, align[b:, :unpaired_ts], stop[b:])
         return mel, linear, align, stop, None, None, None, None

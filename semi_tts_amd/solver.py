@@ -590,7 +590,7 @@ class VqvaeTrainer(TtsTrainer):
         steps the text-first cycle; the unpaired batch joins only when its weight is positive and the step is past its start step.
         `pair` = (mel, aug_mel, linear, text, sid); `unpair` = the same five for the unpaired batch, or None."""
         mel, aug_mel, linear, text, sid = pair
-        kw = dict(_masks=_masks, _asr_masks=_asr_masks)
+        kw = dict(_masks=_masks, **({'_asr_masks': _asr_masks} if _asr_masks is not None else {}))
         kind, use_unpair = self.cycle_kind(self.step)
         if kind == 'speech_first':                                                                # :137
             if use_unpair and unpair is not None:

@@ -851,6 +851,11 @@ typedef struct st_decoder_bwd_io {
      * step 0 (need_dxq0) and the callers sum the slabs' first P columns for the teacher gradient.  NULL = off.  dxq_splits <= 4. */
     float* dxq_part; int dxq_splits;
 } st_decoder_bwd_io;
+/* 1 when the dimensions allow the fused BPTT loop (st_decoder_bwd_io.fuse_pw: the pointwise halves of the two LSTM cells' backward steps,
+ * ref: src/module.py:227-231,275-280, in the epilogues of the loop's products): Q, D, E + Q multiples of 16, A and the input widths of the
+ * three products multiples of 4.  A caller asks BEFORE it decides to hand its step tapes over uninitialised; st_decoder_backward then
+ * fails (instead of falling back to the six-launch loop, which reads a zero slot) when fuse_pw is set and cannot be honoured. */
+int st_decoder_bwd_fuse_dims(const st_decoder_dims* d);
 /* which forms st_decoder_backward will take for these dimensions and buffers: bit 0 split attention backward, bit 1 partial decoder-cell
  * product, bit 2 partial query-cell product (dxq_part holds the gradient w.r.t. the query cell's inputs as slabs) */
 int st_decoder_bwd_forms(const st_decoder_dims* d, const st_decoder_bwd_io* io);

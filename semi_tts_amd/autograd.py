@@ -991,7 +991,10 @@ class _DecoderFn(Function):
         dxo = torch.zeros(steps * Bp, XOw, **f32) if own else ops.gemm(dY2, wpg_t)          # (steps*Bp, D+E)
 
         # every zero-initialised buffer of this backward comes out of ONE allocation and ONE fill launch
-        fuse_pw = (not own) and dec.bwd_fuse_pointwise
+        # (the fused loop only where the library takes the dimensions: asked beforehand, because the step tapes below are handed over
+        # uninitialised in that form -- st_decoder_backward refuses fuse_pw where it cannot honour it instead of falling back)
+        dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A, F=F, K=K, fuse_pre0=0)
+        fuse_pw = (not own) and dec.bwd_fuse_pointwise and bool(lib.st_decoder_bwd_fuse_dims(C.byref(dims)))
         big = dict(dgq=(steps, Bp, 4 * Q), dgd=(steps, Bp, 4 * D), dxq=(steps + 1, Bp, XQw), dxd=(steps + 1, Bp, XDw), dpq=(steps, Bp, A))
         zshapes = dict(dcq=(B, Q), dcd=(B, D), dh0=(B, 2, L), dh1=(B, 2, L), dcum=(B, L), dhq_attn=(B, Q),
                        dgq_t16=(ops.t16_floats(B, 4 * Q),), dgd_t16=(ops.t16_floats(B, 4 * D),))
@@ -1026,7 +1029,6 @@ class _DecoderFn(Function):
         wt['d_p16'] = ops.pack_weight_t([d_w_ih.detach(), d_w_hh.detach()])                 # N = E+Q+D, K = 4D
         bw.q_w_cat_t_p16, bw.d_w_cat_t_p16 = ops._p(wt['q_p16']), ops._p(wt['d_p16'])
         dgq_t16, dgd_t16 = zb['dgq_t16'], zb['dgd_t16']
-        dims = StDecoderDims(B=B, L=L, E=E, n_mels=n_mels, r=r, P=P, Q=Q, D=D, A=A, F=F, K=K, fuse_pre0=0)
         io = StDecoderBwdIO()
         io.memory, io.pm, io.ada_std, io.align = ops._p(memory), ops._p(pm), ops._p(ada_std), ops._p(align)
         io.wcum_tape, io.cq_tape, io.cd_tape = ops._p(tapes['wcum']), ops._p(tapes['cq']), ops._p(tapes['cd'])

@@ -71,6 +71,15 @@ BwdForms bwd_forms(const st_decoder_dims* d, const st_decoder_bwd_io* io) {
 }
 }  // namespace
 
+// the dimensions the fused BPTT loop (io.fuse_pw: pointwise halves in the products' epilogues) takes; anything else runs the six-launch loop
+static bool bwd_fuse_dims_ok(const st_decoder_dims* d) {
+    const int E = d->E, P = d->P, Q = d->Q, D = d->D, A = d->A;
+    const int XQ = P + E + Q, XD = E + Q + D, XO = D + E;
+    return Q % 16 == 0 && D % 16 == 0 && (E + Q) % 16 == 0 && A % 4 == 0 && XD % 4 == 0 && XQ % 4 == 0 && XO % 4 == 0;
+}
+
+extern "C" int st_decoder_bwd_fuse_dims(const st_decoder_dims* d) { return d && bwd_fuse_dims_ok(d) ? 1 : 0; }
+
 extern "C" int st_decoder_bwd_forms(const st_decoder_dims* d, const st_decoder_bwd_io* io) {
     if (!d || !io) return 0;
     const BwdForms f = bwd_forms(d, io);
@@ -109,9 +118,13 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
     const size_t BQ = (size_t)B * Q, BD = (size_t)B * D, BL = (size_t)B * L;
     const int ldal = steps * L;
     int rc;
-    const bool fuse_pw = io->fuse_pw && !own && packed && w->attn_query_w_t_p16 && io->dgd_t16_b && io->dpq_t16 && Q % 16 == 0 && D % 16 == 0 &&
-                         (E + Q) % 16 == 0 && A % 4 == 0 && XD % 4 == 0 && XQ % 4 == 0 && XO % 4 == 0 &&
+    const bool fuse_pw = io->fuse_pw && !own && packed && w->attn_query_w_t_p16 && io->dgd_t16_b && io->dpq_t16 && bwd_fuse_dims_ok(d) &&
                          (io->q_mask == nullptr || st_aligned16(io->q_mask)) && st_aligned16(io->dxo) && st_aligned16(io->dxd) && st_aligned16(io->dxq);
+    // A caller that asks for the fused loop may hand its step tapes over UNINITIALISED (the fused launches write every element; the
+    // six-launch loop reads the slot behind the last step as zeros): asking for it where it cannot run is an error, not a silent fall-back
+    // (st_decoder_bwd_fuse_dims answers the question about the dimensions beforehand)
+    ST_CHECK_ARG(!io->fuse_pw || fuse_pw, "st_decoder_backward: io.fuse_pw requested but the fused loop cannot run (own-output feedback, missing packed "
+                 "operands, dimensions st_decoder_bwd_fuse_dims rejects, or a step tape that is not 16-byte aligned)");
     ST_CHECK_ARG(packed || (w->q_w_cat_t && w->d_w_cat_t), "st_decoder_backward: neither packed nor natural [W_ih | W_hh]^T");
     ST_CHECK_ARG(fuse_pw || w->attn_query_w_t, "st_decoder_backward: natural W_q^T missing (needed without fuse_pw)");
     if (fuse_pw) {

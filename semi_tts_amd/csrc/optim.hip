@@ -4,6 +4,7 @@
 // pointers and the block -> (tensor, chunk) map sit in a cached device-side table (mt_table; the addresses repeat from step
 // to step).  During a stream capture, or when the table cannot be made, they travel in the kernel arguments instead,
 // up to MT_T tensors / MT_NB blocks per launch.
+#include <mutex>
 #include "st_common.h"
 
 namespace {
@@ -172,11 +173,12 @@ __global__ __launch_bounds__(MT_THREADS) void mc_kernel(const McArgs a) {
 }
 
 // ---- the block map in device memory --------------------------------------------------------------------------------------------------
-struct MtTabEntry { unsigned long long key; int dev; void* buf; void* host; size_t cap; hipEvent_t ev; bool ev_set; int nt, blocks; unsigned long long age; };
+struct MtTabEntry { unsigned long long key; int dev; void* buf; void* host; size_t cap; hipEvent_t ev; bool ev_set; int nt, blocks; unsigned long long age; hipStream_t stream; int present; };
 constexpr int MT_TABS = 16;
 static MtTabEntry mt_tabs[MT_TABS];
 static unsigned long long mt_age = 0;
 static long mt_misses = 0;
+static std::mutex mt_mutex;       // the table is process-wide state: two host threads (two streams) must not rebuild entries at once
 
 static unsigned long long mt_hash(unsigned long long h, const void* data, size_t bytes) {
     const unsigned char* c = static_cast<const unsigned char*>(data);
@@ -204,14 +206,23 @@ static const MtTabEntry* mt_table(float* const* p, float* const* g, float* const
     if (m) key = mt_hash(key, m, sizeof(float*) * nt);
     if (v) key = mt_hash(key, v, sizeof(float*) * nt);
     key = mt_hash(key, n, sizeof(long) * nt);
+    std::lock_guard<std::mutex> lock(mt_mutex);
     MtTabEntry* hit = nullptr;
     MtTabEntry* victim = &mt_tabs[0];
+    const size_t off_g = (size_t)nt * 8, off_m = 2 * off_g, off_v = 3 * off_g, off_n = 4 * off_g, off_blk = 5 * off_g;
     for (int i = 0; i < MT_TABS; ++i) {
         MtTabEntry& e = mt_tabs[i];
-        if (e.buf && e.key == key && e.dev == dev && e.nt == nt) { hit = &e; break; }
+        // A hit is the same LISTS, not just the same hash: the entry's host staging copy holds exactly what was uploaded (advisor, round 5:
+        // a 64-bit collision would let Adam write through stale pointers) -- and the same stream: the upload is ordered on the stream of
+        // the miss only, a launch on another stream could run before it.
+        if (e.buf && e.key == key && e.dev == dev && e.nt == nt && e.stream == st && e.present == present) {
+            const unsigned char* h = static_cast<const unsigned char*>(e.host);
+            const bool same = (!p || memcmp(h, p, off_g) == 0) && memcmp(h + off_g, g, off_g) == 0 && (!m || memcmp(h + off_m, m, off_g) == 0) &&
+                              (!v || memcmp(h + off_v, v, off_g) == 0) && memcmp(h + off_n, n, off_g) == 0;
+            if (same) { hit = &e; break; }
+        }
         if (e.age < victim->age) victim = &e;
     }
-    const size_t off_g = (size_t)nt * 8, off_m = 2 * off_g, off_v = 3 * off_g, off_n = 4 * off_g, off_blk = 5 * off_g;
     if (!hit) {
         ++mt_misses;
         size_t blocks = 0;
@@ -258,7 +269,7 @@ static const MtTabEntry* mt_table(float* const* p, float* const* g, float* const
             e.key = 0; e.nt = -1;
             return nullptr;
         }
-        e.key = key; e.nt = nt; e.blocks = (int)blocks;
+        e.key = key; e.nt = nt; e.blocks = (int)blocks; e.stream = st; e.present = present;
         hit = &e;
     }
     hit->age = ++mt_age;

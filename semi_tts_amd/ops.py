@@ -657,6 +657,32 @@ def lstm_seq_bwd(dout, dcol, gates_tape, c_tape, w_hh_t, reverse):
     return dxproj
 
 
+PERSIST_CU_RESERVE = int(os.environ.get('ST_PERSIST_CU_RESERVE', '32'))      # compute units left to RCCL's channels beside the one-launch BiLSTM backward
+_N_CU = {}
+
+
+def _persist_bwd_headroom(B, H):
+    """The one-launch BiLSTM backward needs all of its workgroups co-resident.  Under data parallelism the decoder's gradient buckets are
+    all-reduced by RCCL kernels on another stream exactly while the encoder's BiLSTM backward runs (advisor, round 5): with more than one
+    rank and asynchronous buckets in flight the launch must leave PERSIST_CU_RESERVE compute units free, or the per-step form runs instead
+    (a starved launch costs a skipped step and switches LSTM_PERSIST off for good)."""
+    sink = _GRAD_SINK
+    if sink is None or not getattr(sink, '_active', False):
+        return True
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return True
+    except Exception:
+        return True
+    if not any(w is not None for w in getattr(sink, 'works', ())):
+        return True
+    dev = torch.cuda.current_device()
+    if dev not in _N_CU:
+        _N_CU[dev] = device_info()['n_cu']
+    return 2 * (H // 16) * ((B + 15) // 16) <= _N_CU[dev] - PERSIST_CU_RESERVE
+
+
 def lstm_seq2_bwd(dout, gates_tapes, c_tapes, w_hh_ts, w_hhs=None):
     """both directions at once: dout (B,T,2H) -> (dxproj_f, dxproj_b), each (B,T,4H).  w_hhs = the two W_hh parameters (4H, H): with
     H % 16 == 0 the loop runs on packed operands, one launch per step (product + pointwise backward of the previous step)."""
@@ -666,7 +692,8 @@ def lstm_seq2_bwd(dout, gates_tapes, c_tapes, w_hh_ts, w_hhs=None):
     P2 = C.c_void_p * 2
     arr = lambda a, b_: P2(_p(a), _p(b_))
     if LSTM_PERSIST and w_hhs is not None and dout.stride(2) == 1 and dout.stride(0) == T * dout.stride(1) and dout.data_ptr() % 16 == 0 and \
-            all(w.is_contiguous() for w in w_hhs) and lib.st_lstm_seq2_bwd_persist_supported(B, T, H, int(dout.stride(1)), 0, H):
+            all(w.is_contiguous() for w in w_hhs) and lib.st_lstm_seq2_bwd_persist_supported(B, T, H, int(dout.stride(1)), 0, H) and \
+            _persist_bwd_headroom(B, H):
         # all T steps in one launch (slices of W_hh and the carried dL/dc in registers, the gate gradients handed over through dx itself)
         check(lib.st_lstm_seq2_bwd_persist(_p(dout), int(dout.stride(1)), (C.c_int * 2)(0, H), arr(*gates_tapes), arr(*c_tapes),
                                            arr(*[w.detach() for w in w_hhs]), arr(*dx), B, T, H,
@@ -953,6 +980,11 @@ def grad_first(*params):
             if k in _WQ_PENDING:
                 flush_wgrads()
         if not q.is_leaf:                 # (computed from parameters by torch ops: their backward reads the gradient at once)
+            first = False
+        # a parameter that already HAS a gradient (a second backward() without zero_grad -- gradient accumulation --, or
+        # zero_grad(set_to_none=False)) makes AccumulateGrad run `grad += new` the moment the function returns, and a tensor hook reads
+        # the gradient there as well: both before a queued product would have written it.  Such a product is launched at once.
+        elif q.grad is not None or q._backward_hooks:
             first = False
     return first
 

@@ -173,6 +173,9 @@ class GradReducer:
         self._fire_order = []                          # the recorded pass: parameters in the order their gradients arrived
         self._hooks = {}
         self._active = False
+        self._ctl = None                               # static graph under torch.distributed: the ranks' agreement about a step (finish / _settle)
+        self._ctl_pending = None
+        self._recorded_order = None
         self.stats = {'born_in_slot': 0, 'gathered': 0, 'zeroed': 0}      # of the last step (tests, bench)
         self._layout()
         self._hooks = {p: p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params}
@@ -211,16 +214,18 @@ class GradReducer:
     def _rebuild_static(self):
         """after the recorded pass (its gradients are reduced in the OLD buckets): new buckets in arrival order over the parameters
         that fired, this step's gradients carried over, one hook per bucket"""
-        old_grad = {p: p.grad for p in self._fire_order}
+        order = self._recorded_order if self._recorded_order is not None else self._fire_order
+        old_grad = {p: p.grad for p in order}
         self.dropped = [p for p in self.params if p not in old_grad]
         for h in self._hooks.values():
             h.remove()
-        self.params = list(self._fire_order)
+        self.params = list(order)
         self._layout()
         for p in self.params:
-            v = self._view(p)
-            v.copy_(old_grad[p])
-            p.grad = v
+            if old_grad[p] is not None:                # (decided at the next step's prepare(): the gradients are used up and gone by then)
+                v = self._view(p)
+                v.copy_(old_grad[p])
+                p.grad = v
         for p in self.dropped:
             p.grad = None                              # never touched by this (static) step: the optimiser skips it on every rank
         closers = [bucket[-1] for bucket in self.buckets]
@@ -245,6 +250,7 @@ class GradReducer:
 
     def prepare(self):
         """before every backward pass: no gradient exists (nothing is zeroed, nothing is attached)"""
+        self._settle()                                 # (what the ranks agreed on about the step before: same layout change on every rank)
         for p in self.params:
             if p.grad is not None:
                 p.grad = None
@@ -380,15 +386,32 @@ class GradReducer:
                 if anywhere is not None and anywhere[self.index[p]] != 0.0:
                     p.grad = self._view(p)
         extra = [p for p in self.dropped if p.grad is not None]
-        if extra:        # static graph: a parameter outside the recorded set fired -- reduce it now, on its own, and drop the promise
+        if extra:        # static graph: a parameter outside the recorded set fired -- the promise is gone
             self._violated = self._violated or 'a parameter outside the recorded set received a gradient'
-            if reduced:
-                flat = torch.cat([p.grad.reshape(-1) for p in extra])
-                all_reduce_sum_(flat)
-                off = 0
-                for p in extra:
-                    p.grad = flat[off:off + p.numel()].view_as(p)
-                    off += p.numel()
+        # The promise is per rank, the bucket layout is not: every rank must change it in the same step or the next all-reduces differ in
+        # size and order (advisor, round 5).  With a static graph every rank adds (violated, h, h^2) -- h a hash of the order its gradients
+        # arrived in during the recorded pass -- to a three-double all-reduce behind the buckets; the result comes to the host on its own
+        # (pinned copy + event) and is looked at when the next step begins (_settle): nobody waits for the GPU in a regular step.
+        # A rank that saw a violation itself reads the sum now: only if EVERY rank saw one (a change of the graph that comes with the step
+        # count, e.g. a teacher-forcing schedule) are this step's stray gradients reduced on their own -- a collective the other ranks
+        # would not join otherwise.
+        together = True
+        recording = self.static_graph and not self._sparse and bool(self._fire_order)
+        if reduced and (self.static_graph or self._sparse):
+            h = float(self._order_hash()) if recording else 0.0
+            total = self._exchange_control(1.0 if self._violated else 0.0, h, world, wait=bool(self._violated))
+            if self._violated:
+                together = total is not None and total[0] >= world
+        if extra and reduced and together:
+            flat = torch.cat([p.grad.reshape(-1) for p in extra])
+            all_reduce_sum_(flat)
+            off = 0
+            for p in extra:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        elif extra and reduced:
+            import warnings
+            warnings.warn('GradReducer: a gradient outside the recorded set on THIS rank only; it stays unreduced for this step', RuntimeWarning)
         self.grad_scale = 1.0
         if world > 1 and self.average:
             if self.defer_average:
@@ -400,11 +423,66 @@ class GradReducer:
                 for p in extra:
                     p.grad.mul_(1.0 / world)
         issued = sum(1 for l in self.launched if l)
-        if self._violated and (self._sparse or self.static_graph):
-            self._revert_dynamic(self._violated)
-        elif self.static_graph and not self._sparse and self._fire_order:
-            self._rebuild_static()
+        self._recorded_order = list(self._fire_order) if recording else None
+        if self._ctl_pending is None:                  # no exchange (one process, or collectives off): decide here and now
+            self._decide(bool(self._violated), True, self._violated)
         return issued
+
+    def _order_hash(self):
+        """the recorded arrival order as a number < 2^20 (its square is exact in a double)"""
+        h = 0
+        for p in self._fire_order:
+            h = (h * 1000003 + self.index[p] + 1) % 1048573
+        return h
+
+    def _exchange_control(self, violated, h, world, wait):
+        """all-reduce (violated, h, h^2) over the ranks; the sum goes to a pinned host buffer behind an event (read by _settle, or here
+        when `wait`).  Returns the summed triple when it was read."""
+        dev = self.flats[0].device
+        if self._ctl is None or self._ctl.device != dev:
+            self._ctl = torch.zeros(3, device=dev, dtype=torch.float64)
+            self._ctl_host = torch.zeros(3, dtype=torch.float64).pin_memory() if dev.type == 'cuda' else None
+            self._ctl_event = torch.cuda.Event() if dev.type == 'cuda' else None
+        ctl = self._ctl
+        ctl.zero_()
+        if violated:
+            ctl[0] = violated
+        if h:
+            ctl[1], ctl[2] = h, h * h
+        all_reduce_sum_(ctl)
+        self.stats['control'] = self.stats.get('control', 0) + 1
+        if self._ctl_host is None:                     # CPU tensors (gloo tests): the collective was synchronous
+            self._ctl_pending = ('value', ctl.tolist(), world)
+            return self._ctl_pending[1]
+        self._ctl_host.copy_(ctl, non_blocking=True)
+        self._ctl_event.record()
+        self._ctl_pending = ('event', None, world)
+        if wait:
+            self._ctl_event.synchronize()
+            return self._ctl_host.tolist()
+        return None
+
+    def _settle(self):
+        """at the beginning of a step: act on what the ranks exchanged at the end of the step before -- every rank reads the same sums and
+        changes (or keeps) its bucket layout in the same step"""
+        pend, self._ctl_pending = self._ctl_pending, None
+        if pend is None:
+            return
+        kind, val, world = pend
+        if kind == 'event':
+            self._ctl_event.synchronize()              # (finished long ago: a whole optimiser step has been issued since)
+            val = self._ctl_host.tolist()
+        viol, h, h2 = val
+        same_order = world * h2 == h * h               # (sum h)^2 == world * sum h^2  <=>  every rank recorded the same order; exact in doubles
+        why = 'reported by %d of %d ranks' % (int(viol), world) if viol > 0 else 'the ranks recorded different gradient orders'
+        self._decide(viol > 0, same_order, why)
+
+    def _decide(self, violated, same_order, why):
+        if (violated or not same_order) and (self._sparse or self.static_graph):
+            self._revert_dynamic(why)
+        elif self.static_graph and not self._sparse and self._recorded_order:
+            self._rebuild_static()
+        self._recorded_order = None
 
     def close(self):
         for h in self._hooks.values():

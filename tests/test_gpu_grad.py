@@ -138,6 +138,48 @@ def test_queued_weight_gradients(dev):
     assert worst < 2e-5
 
 
+def test_queued_weight_gradients_with_accumulation_and_hooks(dev):
+    """A parameter that already holds a gradient (two backward() calls without zero_grad, or zero_grad(set_to_none=False)) makes
+    AccumulateGrad add the new gradient the moment the backward function returns, and a tensor hook reads it there as well -- both before
+    a queued product would have written it.  Such products must run at once (ops.grad_first): same gradients as ST_WGRAD_DEFER=0, bit for bit."""
+    from semi_tts_amd import autograd as AG, ops
+    M, C = 256, 32
+    x1, x2 = rnd(M, C, seed=1), rnd(M, C, seed=2)
+    ws = [rnd(C, C, scale=C ** -0.5, seed=30 + i) for i in range(3)]
+    bs = [rnd(C, seed=40 + i) for i in range(3)]
+    dy = rnd(M, C, seed=3)
+
+    def run(defer):
+        old = ops.WGRAD_DEFER
+        ops.WGRAD_DEFER = defer
+        seen = []
+        try:
+            wd = [w.to(dev).requires_grad_() for w in ws]
+            bd = [b.to(dev).requires_grad_() for b in bs]
+            wd[1].register_hook(lambda g: seen.append(g.detach().clone()))        # a hook reads the gradient as it is handed over
+            for x in (x1, x2):                                                    # second pass: every .grad exists already
+                a = x.to(dev)
+                for i in range(3):
+                    a = AG.linear(a, wd[i], bd[i], act='relu')
+                a.backward(dy.to(dev))
+                assert not ops._WQ
+            torch.cuda.synchronize()
+            wd[0].grad.zero_(); bd[0].grad.zero_()                               # zero_grad(set_to_none=False) on one layer, then a third pass
+            a = x1.to(dev)
+            for i in range(3):
+                a = AG.linear(a, wd[i], bd[i], act='relu')
+            a.backward(dy.to(dev))
+            return [t.grad.clone() for t in wd + bd] + seen
+        finally:
+            ops.WGRAD_DEFER = old
+
+    g1, g0 = run(True), run(False)
+    assert len(g1) == len(g0) == 6 + 3
+    for a, b in zip(g1, g0):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('B,T,Cin,N,KT,pad,act,pool', [
     (3, 37, 24, 40, 5, 2, None, False),        # encoder conv
     (2, 50, 80, 80, 4, 2, 'relu', False),      # even-k bank conv (Tout = T+1 and T below)

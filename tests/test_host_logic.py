@@ -243,24 +243,51 @@ def run6(use_third):
     h = net6[0](x[lo:hi])
     ((net6[2](h) if use_third else net6[1](h)).pow(2).sum() / 8.0).backward()
     red6.finish()
-run6(False); run6(False)
-was_sparse = red6._sparse
-with warnings.catch_warnings(record=True) as caught:
-    warnings.simplefilter('always')
-    run6(True)
+run6(False); run6(False); run6(False)
+was_sparse = red6._sparse                              # (the ranks agree on the recorded order when the step after it begins)
+run6(True)                                             # every rank sees the violation: this step's stray gradients are reduced at once
 ref6 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(5, 3))
 ref6.load_state_dict(net6.state_dict())
 (ref6[2](ref6[0](x)).pow(2).sum() / 8.0).backward()
 err6 = max((a.grad - b.grad).abs().max().item() for a, b in zip(list(net6[0].parameters()) + list(net6[2].parameters()),
                                                                 list(ref6[0].parameters()) + list(ref6[2].parameters())))
-reverted = (was_sparse and not red6._sparse and not red6.static_graph and len(red6._hooks) == 6
-            and any('static_graph promise broken' in str(w.message) for w in caught)
-            and all(p.grad is None for p in net6[1].parameters()))
-run6(True)                                             # and the per-parameter form carries on
+still_sparse = red6._sparse                            # ... and the layout changes when the NEXT step begins, on every rank alike
+none1 = all(p.grad is None for p in net6[1].parameters())
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter('always')
+    run6(True)                                         # the per-parameter form carries on
+reverted = (was_sparse and still_sparse and not red6._sparse and not red6.static_graph and len(red6._hooks) == 6
+            and any('static_graph promise broken' in str(w.message) for w in caught) and none1)
 err6 = max(err6, max((a.grad - b.grad).abs().max().item() for a, b in zip(net6[2].parameters(), ref6[2].parameters())))
+# a violation on ONE rank only (advisor, round 5): the other rank must leave the static layout in the same step, or the next all-reduces
+# differ in size and order (a hang).  Rank 1 alone starts using the third layer; both ranks revert when the next step begins.
+net7 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(5, 3))
+broadcast_parameters(net7)
+red7 = GradReducer(net7.parameters(), bucket_bytes=64, average=False, static_graph=True)
+def run7(use_third):
+    red7.prepare()
+    h = net7[0](x[lo:hi])
+    ((net7[2](h) if use_third else net7[1](h)).pow(2).sum() / 8.0).backward()
+    red7.finish()
+run7(False); run7(False); run7(False)
+sparse7 = red7._sparse
+with warnings.catch_warnings(record=True):
+    warnings.simplefilter('always')
+    run7(rank == 1)
+    run7(False)                                        # (would hang or mix gradients if the two ranks' layouts differed)
+    run7(False)
+g7 = torch.cat([p.grad.reshape(-1) for p in list(net7[0].parameters()) + list(net7[1].parameters())])
+both7 = [torch.empty_like(g7) for _ in range(world)]
+dist.all_gather(both7, g7)
+ref7 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3), torch.nn.Linear(5, 3))
+ref7.load_state_dict(net7.state_dict())
+(ref7[1](ref7[0](x)).pow(2).sum() / 8.0).backward()
+r7 = torch.cat([p.grad.reshape(-1) for p in list(ref7[0].parameters()) + list(ref7[1].parameters())])
+local7 = int(sparse7 and not red7._sparse and not red7.static_graph and bool(torch.equal(both7[0], both7[1]))
+             and float((g7 - r7).abs().max()) < 1e-5)
 if rank == 0:
     print('RESULT', err, n, t, err2, n2, int(unused_none), int(views), int(in_order), int(shared), err4, int(sparse),
-          err5, int(born), int(no_sink), err6, int(reverted))
+          err5, int(born), int(no_sink), err6, int(reverted), local7)
 dist.destroy_process_group()
 '''
 
@@ -287,6 +314,7 @@ def test_two_process_gradient_allreduce_matches_single_process(tmp_path):
     assert float(line[12]) < 1e-5 and line[13] == '1'       # gradients born in their bucket slots / gathered; sums + deferred 1 / world
     assert line[14] == '1'                                  # a closed reducer hands out no slots
     assert float(line[15]) < 1e-5 and line[16] == '1'       # broken static-graph promise: noticed, reduced correctly, reverted
+    assert line[17] == '1'                                  # a violation on one rank only: both ranks leave the static layout in the same step
 
 
 def test_cycle_step_alternates_and_gates_like_the_reference_loop():

@@ -171,6 +171,11 @@ extern "C" size_t st_decoder_tape_floats(const st_decoder_dims* d, int which) {
     return which == 0 ? sv.q_floats : (which == 1 ? sv.d_floats : sv.o_floats);
 }
 
+// round-6 experiment (ST_SPLIT): plumbing of skinny_packed.hip, not part of the C ABI
+extern "C" int stx_host_partial(const float* packed_w, int w_kbs, int kb0, int KB, const st_t16_view* x, int S, int B, int N, float* part);
+extern "C" int stx_cell_partial(const float* part, int S, int w_kbs);
+extern "C" void stx_clear(void);
+
 extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io,
                                   void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
@@ -281,6 +286,32 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     }
     // teacher-forced training (deferred projection): [decoder cell of t | query cell of t+1] as one launch
     const bool pair_cells = defer && pure_tf && io->pair_cells;
+    // ST_SPLIT (experiment, round 6): the gate products over operands that are known one or two launches before their cell runs leave the
+    // cell launches -- bit 0: W_hh_d h_d(t-1) + W_ih_d[:, E:] AdaIN(h_q(t)) beside the pq / fin launch of step t, the decoder cell then reduces
+    // the context columns and adds the slab; bit 1: W_hh_q h_q(t) + W_ih_q[:, P:P+E] ctx_t beside the proj / attention-pre launch of step t,
+    // the query cell of step t+1 then reduces the prenet columns and adds the slab.
+    static float* split_ws = nullptr;
+    static size_t split_ws_floats = 0;
+    int split = getenv("ST_SPLIT") ? atoi(getenv("ST_SPLIT")) : 0;
+    const int split_S = getenv("ST_SPLIT_S") ? atoi(getenv("ST_SPLIT_S")) : 1;
+    if (split && !(fuse_pq_fin && !defer && !pair_cells && split_attn && !fuse_p2 && B > 16 && B <= 32 && Q % 16 == 0 && D % 16 == 0 && E % 16 == 0 && P % 16 == 0 &&
+                   (Q / 4) % 2 == 0 && (D / 4) % 2 == 0 && (split_S == 1 || split_S == 2))) split = 0;
+    if (split) {
+        const size_t need = (size_t)2 * B * 4 * (size_t)(Q > D ? Q : D) * 2;
+        if (split_ws_floats < need) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); split = 0; }
+            else {
+                if (split_ws) (void)hipFree(split_ws);
+                split_ws = nullptr; split_ws_floats = 0;
+                if (hipMalloc(&split_ws, need * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); split = 0; }
+                else split_ws_floats = need;
+            }
+        }
+    }
+    float* dpart = split_ws;
+    float* qpart = split_ws ? split_ws + (size_t)2 * B * 4 * (size_t)(Q > D ? Q : D) : nullptr;
+    stx_clear();
     for (int t = 0; t < steps; ++t) {
         float* xq = io->xq_tape + (size_t)t * sv.q_floats;
         float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
@@ -295,8 +326,10 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view hq_dst = {xq_next, sv.q_kbs, sv.q_h};
         st_t16_view ha_dst = {xd, sv.d_kbs, sv.d_ha};
         // (pair_cells: the query cell of step t > 0 ran beside the decoder cell of step t-1, see step 4)
+        const bool q_split = (split & 2) && t > 0;
+        if (q_split) stx_cell_partial(qpart, split_S, sv.q_kbs);
         if (!ST_SKIPPED(0) && !(pair_cells && t > 0))
-                            rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, Kq, w->q_b_ih, w->q_b_hh,
+                            rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, q_split ? 16 * sv.q_ctx : Kq, w->q_b_ih, w->q_b_hh,
                                      io->cq_tape + (size_t)t * BQ, Q, io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
                                      &hq_dst, nullptr, io->cq_tape + (size_t)(t + 1) * BQ, Q,
                                      io->gates_q_tape ? io->gates_q_tape + (size_t)t * 4 * BQ : nullptr,
@@ -350,6 +383,11 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             for (int c = 0; c < 3; ++c) fj.ctx_dst[c] = ctx_dst[c];
             fj.status = io->handoff_status;
             fj.n_ctx_dst = 3; fj.parts = fin_parts; fj.L = L; fj.A = A; fj.E = E; fj.F = d->F; fj.K = d->K;
+            if (split & 1) {
+                st_t16_view xd_known = {xd, sv.d_kbs, sv.d_ha};
+                rc = stx_host_partial(io->packed + pl.d, sv.d_kbs, sv.d_ha, sv.d_kbs - sv.d_ha, &xd_known, split_S, B, 4 * D, dpart);
+                if (rc) return rc;
+            }
             rc = st_query_attn_fin_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, stream);
         }
         else if (ST_SKIPPED(2)) rc = 0;
@@ -388,7 +426,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             jq.B = B; jq.H = Q;
             rc = st_lstm_cell_packed_pair_fwd(&jd, &jq, stream);
         } else
-        if (!ST_SKIPPED(3)) rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, Kd, w->d_b_ih, w->d_b_hh,
+        if (split & 1) stx_cell_partial(dpart, split_S, sv.d_kbs);
+        if (!ST_SKIPPED(3)) rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, (split & 1) ? 16 * sv.d_ha : Kd, w->d_b_ih, w->d_b_hh,
                                      io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                      &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                      io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
@@ -411,6 +450,11 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             job.p2_mask = io->prenet_mask ? io->prenet_mask + ((size_t)t * 2 + 1) * B * P : nullptr; job.p2_ldmask = P;
             job.p2_dst = st_t16_view{xq_next, sv.q_kbs, 0};
             job.p2_gran = io->pre1_granules; job.p2_epoch = (unsigned)(t + 1); job.p2_status = io->handoff_status;
+        }
+        if ((split & 2) && t + 1 < steps && split_attn) {
+            st_t16_view xq_known = {xq_next, sv.q_kbs, sv.q_ctx};
+            rc = stx_host_partial(io->packed + pl.q, sv.q_kbs, sv.q_ctx, sv.q_kbs - sv.q_ctx, &xq_known, split_S, B, 4 * Q, qpart);
+            if (rc) return rc;
         }
         if (!ST_SKIPPED(4)) rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, ST_SKIPPED(7) ? Ko / 4 : Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
                                                  io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
@@ -440,5 +484,6 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             if (rc) return rc;
         }
     }
+    stx_clear();
     return 0;
 }

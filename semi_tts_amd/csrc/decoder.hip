@@ -387,6 +387,10 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                 st_t16_view xd_known = {xd, sv.d_kbs, sv.d_ha};
                 rc = stx_host_partial(io->packed + pl.d, sv.d_kbs, sv.d_ha, sv.d_kbs - sv.d_ha, &xd_known, split_S, B, 4 * D, dpart);
                 if (rc) return rc;
+            } else if (split & 4) {      // two sites: the adapted-query columns here (slab B), the recurrent columns beside the proj launch of step t-1 (slab A)
+                st_t16_view xd_ha = {xd, sv.d_kbs, sv.d_ha};
+                rc = stx_host_partial(io->packed + pl.d, sv.d_kbs, sv.d_ha, sv.d_h - sv.d_ha, &xd_ha, 1, B, 4 * D, dpart + (size_t)B * 4 * D);
+                if (rc) return rc;
             }
             rc = st_query_attn_fin_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, stream);
         }
@@ -427,7 +431,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             rc = st_lstm_cell_packed_pair_fwd(&jd, &jq, stream);
         } else
         if (split & 1) stx_cell_partial(dpart, split_S, sv.d_kbs);
-        if (!ST_SKIPPED(3)) rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, (split & 1) ? 16 * sv.d_ha : Kd, w->d_b_ih, w->d_b_hh,
+        else if (split & 4) stx_cell_partial(t == 0 ? dpart + (size_t)B * 4 * D : dpart, t == 0 ? 1 : 2, sv.d_kbs);      // (h_d(-1) = 0: no slab A at step 0)
+        if (!ST_SKIPPED(3)) rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, (split & 5) ? 16 * sv.d_ha : Kd, w->d_b_ih, w->d_b_hh,
                                      io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                      &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                      io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
@@ -451,7 +456,12 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             job.p2_dst = st_t16_view{xq_next, sv.q_kbs, 0};
             job.p2_gran = io->pre1_granules; job.p2_epoch = (unsigned)(t + 1); job.p2_status = io->handoff_status;
         }
-        if ((split & 2) && t + 1 < steps && split_attn) {
+        if ((split & 4) && t + 1 < steps && split_attn) {      // slab A of step t+1: W_hh_d h_d(t), known since the decoder cell above
+            st_t16_view xd_h = {xd_next, sv.d_kbs, sv.d_h};
+            rc = stx_host_partial(io->packed + pl.d, sv.d_kbs, sv.d_h, sv.d_kbs - sv.d_h, &xd_h, 1, B, 4 * D, dpart);
+            if (rc) return rc;
+        }
+        else if ((split & 2) && t + 1 < steps && split_attn) {
             st_t16_view xq_known = {xq_next, sv.q_kbs, sv.q_ctx};
             rc = stx_host_partial(io->packed + pl.q, sv.q_kbs, sv.q_ctx, sv.q_kbs - sv.q_ctx, &xq_known, split_S, B, 4 * Q, qpart);
             if (rc) return rc;

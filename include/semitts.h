@@ -138,6 +138,14 @@ int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
                             float* c_out, int ldc, float* gates_out,
                             const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
                             int B, int H, void* stream);
+/* st_lstm_cell_packed_fwd (without AdaIN) over the LEADING K columns of a cell whose packed matrix has w_kbs k-blocks per row tile; the gate
+ * products over the remaining columns come as `part` (B, 4H), written by an st_partial_product_job of an earlier launch, and are added to
+ * the reduced gates.  16 < B <= 32, H / 4 even.  ref: nn.LSTMCell, src/module.py:275-280 */
+int st_lstm_cell_packed_part_fwd(const float* packed_w, int w_kbs, const st_t16_view* x, int K, const float* part,
+                                 const float* b_ih, const float* b_hh,
+                                 const float* c_prev, int ldc_prev, const float* mask,
+                                 const st_t16_view* h_dst0, const st_t16_view* h_dst1,
+                                 float* c_out, int ldc, float* gates_out, int B, int H, void* stream);
 /* The arguments of st_lstm_cell_packed_fwd as a struct, and two independent cells in ONE launch: under teacher forcing the decoder
  * cell of step t and the query cell of step t+1 both only wait for the attention of step t (src/module.py:216-288 with a teacher
  * frame as the next input).  Falls back to one launch per cell for shapes the 2-D tiled kernel does not take. */
@@ -276,6 +284,23 @@ typedef struct st_attn_fin_job {
 } st_attn_fin_job;
 int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
                           const st_attn_fin_job* job, int B, void* stream);
+/* A partial product part (B, N) = x[:, kb0 .. kb0 + KB) W[:, kb0 .. kb0 + KB)^T over a k-block range of a P16 matrix (w_kbs k-blocks per row
+ * tile; LSTM row order when the matrix is a cell's) and of a T16 activation buffer (x.kb0 = the range's first k-block in it): two row tiles
+ * and both batch tiles per workgroup (16 < B <= 32, N % 32 == 0), N / 32 workgroups. */
+typedef struct st_partial_product_job {
+    const float* packed_w; int w_kbs; int kb0; int KB;
+    st_t16_view x;
+    int N;
+    float* part;
+} st_partial_product_job;
+/* st_query_attn_fin_fwd with such a job beside it in the same launch (every workgroup on a compute unit of its own: (A / 16) ceil(B / 16) +
+ * B * parts + N / 32 <= compute units).  The decode step's use: the part of nn.LSTMCell's gate product (ref: src/module.py:275-280) whose
+ * operands do not depend on the attention of the step runs WHILE the attention runs. */
+int st_query_attn_fin_part_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
+                               const st_attn_fin_job* job, int B, const st_partial_product_job* part, void* stream);
+/* ... and the job as a launch of its own: what the decode loop issues in its two-launch pq / fin form (a starved hand-off degrades to it),
+ * so that both forms compute the same arithmetic bit for bit */
+int st_partial_product_fwd(const st_partial_product_job* job, int B, void* stream);
 /* Long texts (the fin part is bound by what ONE compute unit pulls in: S and the memory rows of an utterance): the same launch with the
  * fin part over `job->parts` (2..8) POSITION ranges per utterance -- local softmax statistics and an un-normalised partial context per
  * range, as st_attn_fin_split_fwd -- and the combine INSIDE the launch: the ranges of an utterance exchange (max, sum, partial context)
@@ -742,6 +767,11 @@ typedef struct st_decoder_io {
                                         * input runs INSIDE the proj (+) gate (+) prenet-layer-1 launch (st_attn_pre_job.p2_*), its operand
                                         * handed over as granules -- one launch less per free-running decode step.  Zeroed by the callee per
                                         * forward; time-outs go to handoff_status */
+    float* gate_part;                  /* optional (B, 4 D) scratch: in the one-launch pq + fin form (pq_granules) with 16 < B <= 32 the decoder
+                                        * cell's gate products over the operands that are known BEFORE the attention runs -- W_hh_d h_d(t-1) and
+                                        * W_ih_d[:, E:] AdaIN(h_q(t)), 2048 of the cell's 2560 reduction columns at C2 -- ride beside the pq / fin
+                                        * launch on compute units it leaves idle (st_query_attn_fin_part_fwd); the cell launch then reduces the
+                                        * context columns and adds this slab (st_lstm_cell_packed_part_fwd).  fp32 re-association only.  NULL = off */
 } st_decoder_io;
 
 size_t st_decoder_packed_floats(const st_decoder_dims* d);

@@ -77,7 +77,7 @@ class StDecoderIO(C.Structure):
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p),
                 ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p),
                 ('dec_in0', C.c_void_p), ('pre_nat', C.c_void_p), ('attn_xchg', C.c_void_p), ('handoff_status', C.c_void_p),
-                ('pair_cells', C.c_int), ('pre_nat_tape', C.c_void_p), ('pre1_granules', C.c_void_p)]
+                ('pair_cells', C.c_int), ('pre_nat_tape', C.c_void_p), ('pre1_granules', C.c_void_p), ('gate_part', C.c_void_p)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -221,6 +221,8 @@ SIGNATURES = {
     'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
     'st_lstm_cell_packed_fwd': [P, C.POINTER(StT16View), I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
                                 P, I, P, P, P, C.POINTER(StT16View), I, I, P],
+    'st_lstm_cell_packed_part_fwd': [P, I, C.POINTER(StT16View), I, P, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
+                                     P, I, P, I, I, P],
     'st_lstm_cell_packed_pair_fwd': [C.POINTER(StLstmCellPackedJob), C.POINTER(StLstmCellPackedJob), P],
     'st_skinny_linear_packed_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,
                                     I, I, P, I, C.POINTER(StT16View), I, I, P],
@@ -232,6 +234,8 @@ SIGNATURES = {
     'st_attn_fin_split_workspace_floats': [I, I, I],
     'st_attn_fin_split_fwd': [P, P, P, P, P, I, P, P, C.POINTER(StT16View), I, P, I, P, I, I, I, I, I, P],
     'st_query_attn_fin_fwd': [P, C.POINTER(StT16View), I, P, C.c_uint, C.POINTER(StAttnFinJob), I, P],
+    'st_query_attn_fin_part_fwd': [P, C.POINTER(StT16View), I, P, C.c_uint, C.POINTER(StAttnFinJob), I, P, P],
+    'st_partial_product_fwd': [P, I, P],
     'st_layer_norm_fwd': [P, I, P, P, F, P, I, P, P, I, I, P],
     'st_layer_norm_bwd': [P, I, P, I, P, P, P, P, I, P, I, I, P],
     'st_log_softmax_fwd': [P, P, I, I, P],

@@ -171,11 +171,6 @@ extern "C" size_t st_decoder_tape_floats(const st_decoder_dims* d, int which) {
     return which == 0 ? sv.q_floats : (which == 1 ? sv.d_floats : sv.o_floats);
 }
 
-// round-6 experiment (ST_SPLIT): plumbing of skinny_packed.hip, not part of the C ABI
-extern "C" int stx_host_partial(const float* packed_w, int w_kbs, int kb0, int KB, const st_t16_view* x, int S, int B, int N, float* part);
-extern "C" int stx_cell_partial(const float* part, int S, int w_kbs);
-extern "C" void stx_clear(void);
-
 extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io,
                                   void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
@@ -286,32 +281,18 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     }
     // teacher-forced training (deferred projection): [decoder cell of t | query cell of t+1] as one launch
     const bool pair_cells = defer && pure_tf && io->pair_cells;
-    // ST_SPLIT (experiment, round 6): the gate products over operands that are known one or two launches before their cell runs leave the
-    // cell launches -- bit 0: W_hh_d h_d(t-1) + W_ih_d[:, E:] AdaIN(h_q(t)) beside the pq / fin launch of step t, the decoder cell then reduces
-    // the context columns and adds the slab; bit 1: W_hh_q h_q(t) + W_ih_q[:, P:P+E] ctx_t beside the proj / attention-pre launch of step t,
-    // the query cell of step t+1 then reduces the prenet columns and adds the slab.
-    static float* split_ws = nullptr;
-    static size_t split_ws_floats = 0;
-    int split = getenv("ST_SPLIT") ? atoi(getenv("ST_SPLIT")) : 0;
-    const int split_S = getenv("ST_SPLIT_S") ? atoi(getenv("ST_SPLIT_S")) : 1;
-    if (split && !(fuse_pq_fin && !defer && !pair_cells && split_attn && !fuse_p2 && B > 16 && B <= 32 && Q % 16 == 0 && D % 16 == 0 && E % 16 == 0 && P % 16 == 0 &&
-                   (Q / 4) % 2 == 0 && (D / 4) % 2 == 0 && (split_S == 1 || split_S == 2))) split = 0;
-    if (split) {
-        const size_t need = (size_t)2 * B * 4 * (size_t)(Q > D ? Q : D) * 2;
-        if (split_ws_floats < need) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); split = 0; }
-            else {
-                if (split_ws) (void)hipFree(split_ws);
-                split_ws = nullptr; split_ws_floats = 0;
-                if (hipMalloc(&split_ws, need * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); split = 0; }
-                else split_ws_floats = need;
-            }
-        }
-    }
-    float* dpart = split_ws;
-    float* qpart = split_ws ? split_ws + (size_t)2 * B * 4 * (size_t)(Q > D ? Q : D) : nullptr;
-    stx_clear();
+    // io->gate_part: the decoder cell's gate products over [AdaIN(h_q(t)) | h_d(t-1)] -- known before the attention of step t runs -- ride
+    // beside the pq / fin launch; the cell launch reduces the context columns and adds the slab.  Measured (round 6, two boxes, A/B in
+    // one process): 2.71 -> 2.79 and 2.78 -> 2.84 M mel-frames/s.  The same for the query cell, or the two halves at two sites, LOSE
+    // (DESIGN.md section 3.5): a hosted product costs ~7 us + 3 us per 1024 columns whatever its host's length.
+    // (the other forms of the attention step issue the partial product as a launch of its own: same arithmetic bit for bit, so a starved
+    // hand-off that degrades to the two-launch form changes nothing but the speed)
+    const bool split_d = io->gate_part && !defer && !pair_cells && B > 16 && B <= 32 && D % 16 == 0 && (D / 4) % 2 == 0 &&
+                         E % 16 == 0 && Q % 16 == 0 && st_aligned16(io->gate_part);
+    const bool split_hosted = split_d && fuse_pq_fin && (A / 16) * ((B + 15) / 16) + B * fin_parts + (4 * D) / 32 <= st_device_cus();
+    st_partial_product_job pj_d;
+    memset(&pj_d, 0, sizeof(pj_d));
+    pj_d.packed_w = io->packed + pl.d; pj_d.w_kbs = sv.d_kbs; pj_d.kb0 = sv.d_ha; pj_d.KB = sv.d_kbs - sv.d_ha; pj_d.N = 4 * D; pj_d.part = io->gate_part;
     for (int t = 0; t < steps; ++t) {
         float* xq = io->xq_tape + (size_t)t * sv.q_floats;
         float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
@@ -326,10 +307,8 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         st_t16_view hq_dst = {xq_next, sv.q_kbs, sv.q_h};
         st_t16_view ha_dst = {xd, sv.d_kbs, sv.d_ha};
         // (pair_cells: the query cell of step t > 0 ran beside the decoder cell of step t-1, see step 4)
-        const bool q_split = (split & 2) && t > 0;
-        if (q_split) stx_cell_partial(qpart, split_S, sv.q_kbs);
         if (!ST_SKIPPED(0) && !(pair_cells && t > 0))
-                            rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, q_split ? 16 * sv.q_ctx : Kq, w->q_b_ih, w->q_b_hh,
+                            rc = st_lstm_cell_packed_fwd(io->packed + pl.q, &xq_v, Kq, w->q_b_ih, w->q_b_hh,
                                      io->cq_tape + (size_t)t * BQ, Q, io->q_mask ? io->q_mask + (size_t)t * BQ : nullptr,
                                      &hq_dst, nullptr, io->cq_tape + (size_t)(t + 1) * BQ, Q,
                                      io->gates_q_tape ? io->gates_q_tape + (size_t)t * 4 * BQ : nullptr,
@@ -383,15 +362,10 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             for (int c = 0; c < 3; ++c) fj.ctx_dst[c] = ctx_dst[c];
             fj.status = io->handoff_status;
             fj.n_ctx_dst = 3; fj.parts = fin_parts; fj.L = L; fj.A = A; fj.E = E; fj.F = d->F; fj.K = d->K;
-            if (split & 1) {
-                st_t16_view xd_known = {xd, sv.d_kbs, sv.d_ha};
-                rc = stx_host_partial(io->packed + pl.d, sv.d_kbs, sv.d_ha, sv.d_kbs - sv.d_ha, &xd_known, split_S, B, 4 * D, dpart);
-                if (rc) return rc;
-            } else if (split & 4) {      // two sites: the adapted-query columns here (slab B), the recurrent columns beside the proj launch of step t-1 (slab A)
-                st_t16_view xd_ha = {xd, sv.d_kbs, sv.d_ha};
-                rc = stx_host_partial(io->packed + pl.d, sv.d_kbs, sv.d_ha, sv.d_h - sv.d_ha, &xd_ha, 1, B, 4 * D, dpart + (size_t)B * 4 * D);
-                if (rc) return rc;
-            }
+            if (split_hosted && !ST_SKIPPED(3)) {
+                pj_d.x = st_t16_view{xd, sv.d_kbs, sv.d_ha};
+                rc = st_query_attn_fin_part_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, &pj_d, stream);
+            } else
             rc = st_query_attn_fin_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, stream);
         }
         else if (ST_SKIPPED(2)) rc = 0;
@@ -430,9 +404,18 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             jq.B = B; jq.H = Q;
             rc = st_lstm_cell_packed_pair_fwd(&jd, &jq, stream);
         } else
-        if (split & 1) stx_cell_partial(dpart, split_S, sv.d_kbs);
-        else if (split & 4) stx_cell_partial(t == 0 ? dpart + (size_t)B * 4 * D : dpart, t == 0 ? 1 : 2, sv.d_kbs);      // (h_d(-1) = 0: no slab A at step 0)
-        if (!ST_SKIPPED(3)) rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, (split & 5) ? 16 * sv.d_ha : Kd, w->d_b_ih, w->d_b_hh,
+        if (split_d && !split_hosted && !ST_SKIPPED(3)) {
+            pj_d.x = st_t16_view{xd, sv.d_kbs, sv.d_ha};
+            rc = st_partial_product_fwd(&pj_d, B, stream);
+            if (rc) return rc;
+        }
+        if (split_d && !ST_SKIPPED(3) && !(split_hosted && (ST_SKIPPED(1) || ST_SKIPPED(2))))
+            rc = st_lstm_cell_packed_part_fwd(io->packed + pl.d, sv.d_kbs, &xd_v, 16 * sv.d_ha, io->gate_part, w->d_b_ih, w->d_b_hh,
+                                              io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
+                                              &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
+                                              io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr, B, D, stream);
+        else
+        if (!ST_SKIPPED(3)) rc = st_lstm_cell_packed_fwd(io->packed + pl.d, &xd_v, Kd, w->d_b_ih, w->d_b_hh,
                                      io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                      &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                      io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
@@ -455,16 +438,6 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             job.p2_mask = io->prenet_mask ? io->prenet_mask + ((size_t)t * 2 + 1) * B * P : nullptr; job.p2_ldmask = P;
             job.p2_dst = st_t16_view{xq_next, sv.q_kbs, 0};
             job.p2_gran = io->pre1_granules; job.p2_epoch = (unsigned)(t + 1); job.p2_status = io->handoff_status;
-        }
-        if ((split & 4) && t + 1 < steps && split_attn) {      // slab A of step t+1: W_hh_d h_d(t), known since the decoder cell above
-            st_t16_view xd_h = {xd_next, sv.d_kbs, sv.d_h};
-            rc = stx_host_partial(io->packed + pl.d, sv.d_kbs, sv.d_h, sv.d_kbs - sv.d_h, &xd_h, 1, B, 4 * D, dpart);
-            if (rc) return rc;
-        }
-        else if ((split & 2) && t + 1 < steps && split_attn) {
-            st_t16_view xq_known = {xq_next, sv.q_kbs, sv.q_ctx};
-            rc = stx_host_partial(io->packed + pl.q, sv.q_kbs, sv.q_ctx, sv.q_kbs - sv.q_ctx, &xq_known, split_S, B, 4 * Q, qpart);
-            if (rc) return rc;
         }
         if (!ST_SKIPPED(4)) rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pg, &xo_v, ST_SKIPPED(7) ? Ko / 4 : Ko, w->projgate_b, ST_ACT_NONE, nullptr, 0,
                                                  io->mel_out + (size_t)t * in_dim, (int)ldmel, fuse ? nullptr : &mel_dst, in_dim,
@@ -494,6 +467,5 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             if (rc) return rc;
         }
     }
-    stx_clear();
     return 0;
 }

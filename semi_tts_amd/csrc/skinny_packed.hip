@@ -196,9 +196,9 @@ struct PkArgs {
     unsigned long long* gran; unsigned epoch;
     // optional: the third range likewise, (B, N - n_split2) granules (the operand of pk_gran_linear_body workgroups of the same launch)
     unsigned long long* gran3;
-    // optional (LSTM cell, 2-D tiled form): part_S slabs (part_S, B, N) of a K-split partial product of the SAME weight rows over the
-    // k-blocks this launch does not reduce (pk_part_body of an earlier launch), added to the gates in slab order
-    const float* part; int part_S;
+    // optional (LSTM cell, 2-D tiled form): a slab (B, N) of a partial product of the SAME weight rows over the k-blocks this launch does
+    // not reduce (pk_part_body of an earlier launch, st_query_attn_fin_part_fwd), added to the gates
+    const float* part;
 };
 
 // MODE 2: a linear whose output columns [n0, n0 + H) are dh of an LSTM cell -- the pointwise half of the cell's backward step
@@ -590,15 +590,12 @@ __device__ __forceinline__ void pk_lstm_rt2_body(const f32x4* wp, const f32x4* x
     const bool e_on = tid < RT * NB * 64 && eb < B;
     float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f};
     float e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
-    f32x4 e_p0 = {0.f, 0.f, 0.f, 0.f}, e_p1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 e_p = {0.f, 0.f, 0.f, 0.f};
     const float* dummy = reinterpret_cast<const float*>(wp);
     auto epi_prefetch = [&]() __attribute__((always_inline)) {
         if (e_on) {
-            if (a.part) {       // the partial gates of the k-blocks an earlier launch reduced: (slab, batch row, 4 gate rows of hidden unit u)
-                const float* pp = a.part + (size_t)eb * (4 * H) + (size_t)(tile0 + e_rt) * 16 + 4 * (lane >> 4);
-                e_p0 = st_ld4(pp);
-                e_p1 = st_ld4(pp + (a.part_S > 1 ? (size_t)B * 4 * H : 0));
-            }
+            // the partial gates of the k-blocks an earlier launch reduced: (batch row, the 4 gate rows of hidden unit u) -- pk_part_body's layout
+            if (a.part) e_p = st_ld4(a.part + (size_t)eb * (4 * H) + (size_t)(tile0 + e_rt) * 16 + 4 * (lane >> 4));
             const float* pbi = a.b_ih ? a.b_ih + u : dummy;
             const float* pbh = a.b_hh ? a.b_hh + u : dummy;
 #pragma unroll
@@ -641,10 +638,7 @@ __device__ __forceinline__ void pk_lstm_rt2_body(const f32x4* wp, const f32x4* x
         s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
     }
     if (eb >= B) return;
-    if (a.part) {
-        s[0] += e_p0[0]; s[1] += e_p0[1]; s[2] += e_p0[2]; s[3] += e_p0[3];
-        if (a.part_S > 1) { s[0] += e_p1[0]; s[1] += e_p1[1]; s[2] += e_p1[2]; s[3] += e_p1[3]; }
-    }
+    if (a.part) { s[0] += e_p[0]; s[1] += e_p[1]; s[2] += e_p[2]; s[3] += e_p[3]; }
     float e_b[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) e_b[r] = (a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f);
@@ -1203,10 +1197,10 @@ __global__ __launch_bounds__(KW * 64) void pk_attnfin_kernel(const f32x4* w, con
     else at_body<true, 2, AT_THREADS, true>(t, i - n_lin, pk_dyn_lds);
 }
 
-// ... and, beside them, a K-split partial product of the DECODER cell's gates over the operands that are known before the attention runs
-// (W_hh_d h_d(t-1) and W_ih_d[:, E:] AdaIN(h_q(t)): 2048 of the cell's 2560 reduction columns) on compute units the pq / fin launch
-// leaves idle; the cell launch that follows reduces the context columns only and adds the slab (PkArgs.part).  Experiment of round 6
-// (DESIGN.md section 3.5): the part workgroups use the dynamic LDS region as their reduction buffer.
+// ... and, beside them, a partial product of the DECODER cell's gates over the operands that are known before the attention runs
+// (W_hh_d h_d(t-1) and W_ih_d[:, E:] AdaIN(h_q(t)): 2048 of the cell's 2560 reduction columns at C2) on the compute units the pq / fin
+// launch leaves idle (32 + 64 of 256 workgroups at C2); the cell launch that follows reduces the context columns only and adds the slab
+// (PkArgs.part).  The part workgroups use the dynamic LDS region as their reduction buffer.  Round 6, DESIGN.md section 3.1.
 template <int NB, int KW, int TRIP>
 __global__ __launch_bounds__(KW * 64) void pk_attnfin_part_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
                                                                   const int B, const int N, const int tiles_a, const int n_lin,
@@ -1223,28 +1217,6 @@ __global__ __launch_bounds__(KW * 64) void pk_attnfin_part_kernel(const f32x4* w
     }
     else if (i < n_att) at_body<true, 2, AT_THREADS, true>(t, i - n_lin, pk_dyn_lds);
     else pk_part_body<KW, 2>(p, i - n_att, reinterpret_cast<f32x4*>(pk_dyn_lds));
-}
-
-// the proj (+) gate (+) prenet-1 linear and the attention pre part of the next step with a K-split partial product of the next QUERY
-// cell's gates beside them (W_hh_q h_q(t) and W_ih_q[:, P:P+E] ctx_t: 1536 of its 1792 reduction columns)
-template <int NB, int KW, int TRIP, bool VEC>
-__global__ __launch_bounds__(KW * 64) void pk_attnpre_part_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
-                                                                  const int B, const int N, const int tiles_a, const int n_lin,
-                                                                  const float* at_pm, const float* at_wprev, const int at_L,
-                                                                  const PkArgs a_rest, const AtArgs t_rest, const int n_att, const PkPartArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
-    __shared__ f32x4 red[KW * NB * 64];
-    const int i = blockIdx.x;
-    if (i >= n_att) { pk_part_body<KW, 2>(p, i - n_att, reinterpret_cast<f32x4*>(pk_dyn_lds)); return; }
-    PkArgs a = a_rest;
-    a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N;
-    AtArgs t = t_rest;
-    t.pm = at_pm; t.w_prev = at_wprev; t.L = at_L;
-    if (i < n_lin) {
-        const int by = n_lin <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
-        pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
-    }
-    else at_body<VEC, 1>(t, i - n_lin, pk_dyn_lds);
 }
 
 // Long texts: the query projection and the fin part over POSITION ranges (at_range_body) with the combine inside the launch: the
@@ -1271,11 +1243,6 @@ __global__ __launch_bounds__(KW * 64, 4) void pk_attnrng_kernel(const f32x4* w, 
 #endif
 int pk_fill(PkArgs& a, const float* packed_w, const st_t16_view* x, int K, const char* who);
 
-// round-6 experiment (dependency split of the decode step): a K-split partial product that the NEXT pq / fin launch or the next
-// proj / attention-pre launch of this thread hosts, and the slab the NEXT LSTM cell launch adds (set by decoder.hip through stx_*)
-thread_local PkPartArgs g_host_part; thread_local bool g_host_part_set = false;
-thread_local const float* g_cell_part = nullptr; thread_local int g_cell_part_S = 0, g_cell_w_kbs = 0;
-
 template <int NB>
 int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st, const PkArgs* p2 = nullptr, unsigned* p2_status = nullptr) {
     constexpr int KW = 8, TRIP = NB == 1 ? PK_TRIP_SMALL : 2;
@@ -1299,24 +1266,8 @@ int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t s
     }
     const bool vec = (t.A % 4 == 0) && (t.F % 4 == 0) && st_aligned16(t.pm) && st_aligned16(t.loc_lin_w) && st_aligned16(t.s_buf);
     const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K, 1, at_pos_per(t.L, t.pre_parts > 1 ? t.pre_parts : 1), vec && t.F == 32 && t.A % 16 == 0);
-    size_t lds = (size_t)o.total * sizeof(float);
+    const size_t lds = (size_t)o.total * sizeof(float);
     ST_CHECK_ARG(lds + sizeof(f32x4) * KW * NB * 64 <= 160 * 1024, "linear + attention-pre launch: L=%d needs too much LDS (use more parts)", t.L);
-    if constexpr (NB == 1) if (g_host_part_set) {        // + the workgroups of a hosted K-split partial product (their reduction buffer: the dynamic LDS)
-        g_host_part_set = false;
-        const PkPartArgs pp = g_host_part;
-        if (lds < sizeof(f32x4) * KW * 4 * 64) lds = sizeof(f32x4) * KW * 4 * 64;
-        auto kern = vec ? pk_attnpre_part_kernel<NB, KW, TRIP, true> : pk_attnpre_part_kernel<NB, KW, TRIP, false>;
-        static size_t configured[2] = {0, 0};
-        if (lds > 48 * 1024 && lds > configured[vec ? 1 : 0]) {
-            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured[vec ? 1 : 0] = lds;
-        }
-        const int n_att = tiles * gy + t.B * (t.pre_parts > 1 ? t.pre_parts : 1);
-        hipLaunchKernelGGL(kern, dim3(n_att + (pp.N >> 5) * pp.S), dim3(KW * 64), lds, st, a.w, a.x, a.w_kbs, a.x_kbs,
-                           a.KB, a.B, a.N, tiles, tiles * gy, t.pm, t.w_prev, t.L, a, t, n_att, pp);
-        ST_LAUNCH_CHECK();
-        return 0;
-    }
     auto kern = vec ? pk_attnpre_kernel<NB, KW, TRIP, true> : pk_attnpre_kernel<NB, KW, TRIP, false>;
     static size_t configured[2] = {0, 0};
     if (lds > 48 * 1024 && lds > configured[vec ? 1 : 0]) {
@@ -1509,6 +1460,33 @@ extern "C" int st_untile_rows(const st_t16_view* src, float* dst, int ld, int B,
     return 0;
 }
 
+static int lstm_cell_packed_impl(const float* packed_w, const st_t16_view* x, int K,
+                                 const float* b_ih, const float* b_hh,
+                                 const float* c_prev, int ldc_prev, const float* mask,
+                                 const st_t16_view* h_dst0, const st_t16_view* h_dst1,
+                                 float* c_out, int ldc, float* gates_out,
+                                 const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
+                                 int B, int H, int w_kbs, const float* part, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && c_out && h_dst0 && h_dst0->base, "st_lstm_cell_packed_fwd: bad arguments");
+    PkArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = pk_fill(a, packed_w, x, K, "st_lstm_cell_packed_fwd");
+    if (rc) return rc;
+    if (part) {      // K covers the leading k-blocks only; the products over the others arrive as a slab (2-D tiled form, B = 17..32)
+        ST_CHECK_ARG(pk_rt2_shape(B, H / 4) && ((B + 15) >> 4) == 2 && w_kbs >= a.KB && st_aligned16(part),
+                     "st_lstm_cell_packed_part_fwd: needs B = 17..32, an even number of row tiles, w_kbs >= K / 16 and a 16-byte aligned slab");
+        a.part = part; a.w_kbs = w_kbs;
+    }
+    a.B = B; a.N = 4 * H; a.H = H;
+    a.b_ih = b_ih; a.b_hh = b_hh;
+    a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
+    a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
+    a.h_dst[0] = pk_out(h_dst0); a.h_dst[1] = pk_out(h_dst1);
+    a.ada_std = ada_std; a.ada_mean = ada_mean; a.ha_dst = pk_out(hadapt_dst);
+    return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
+}
+
 extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
                                        const float* b_ih, const float* b_hh,
                                        const float* c_prev, int ldc_prev, const float* mask,
@@ -1516,24 +1494,18 @@ extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view*
                                        float* c_out, int ldc, float* gates_out,
                                        const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
                                        int B, int H, void* stream) {
-    (void)hipGetLastError();
-    ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && c_out && h_dst0 && h_dst0->base, "st_lstm_cell_packed_fwd: bad arguments");
-    PkArgs a;
-    memset(&a, 0, sizeof(a));
-    int rc = pk_fill(a, packed_w, x, K, "st_lstm_cell_packed_fwd");
-    if (rc) return rc;
-    a.B = B; a.N = 4 * H; a.H = H;
-    a.b_ih = b_ih; a.b_hh = b_hh;
-    a.c_prev = c_prev; a.ldc_prev = ldc_prev; a.mask = mask;
-    a.c_out = c_out; a.ldc = ldc; a.gates_out = gates_out;
-    a.h_dst[0] = pk_out(h_dst0); a.h_dst[1] = pk_out(h_dst1);
-    a.ada_std = ada_std; a.ada_mean = ada_mean; a.ha_dst = pk_out(hadapt_dst);
-    if (g_cell_part) {           // K covers the remaining k-blocks only; the rest arrives as slabs (2-D tiled form only: checked by the caller)
-        ST_CHECK_ARG(pk_rt2_shape(B, H / 4) && ((B + 15) >> 4) == 2, "st_lstm_cell_packed_fwd: a partial addend needs the 2-D tiled cell (B = 17..32)");
-        a.part = g_cell_part; a.part_S = g_cell_part_S; a.w_kbs = g_cell_w_kbs;
-        g_cell_part = nullptr;
-    }
-    return pk_dispatch<0>(a, H / 4, (hipStream_t)stream);
+    return lstm_cell_packed_impl(packed_w, x, K, b_ih, b_hh, c_prev, ldc_prev, mask, h_dst0, h_dst1, c_out, ldc, gates_out, ada_std, ada_mean,
+                                 hadapt_dst, B, H, 0, nullptr, stream);
+}
+
+extern "C" int st_lstm_cell_packed_part_fwd(const float* packed_w, int w_kbs, const st_t16_view* x, int K, const float* part,
+                                            const float* b_ih, const float* b_hh,
+                                            const float* c_prev, int ldc_prev, const float* mask,
+                                            const st_t16_view* h_dst0, const st_t16_view* h_dst1,
+                                            float* c_out, int ldc, float* gates_out, int B, int H, void* stream) {
+    ST_CHECK_ARG(part, "st_lstm_cell_packed_part_fwd: null slab");
+    return lstm_cell_packed_impl(packed_w, x, K, b_ih, b_hh, c_prev, ldc_prev, mask, h_dst0, h_dst1, c_out, ldc, gates_out, nullptr, nullptr,
+                                 nullptr, B, H, w_kbs, part, stream);
 }
 
 static int pk_lstm_fill(PkArgs& a, const st_lstm_cell_packed_job* j, const char* who) {
@@ -1628,8 +1600,8 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
     return pk_dispatch<1>(a, tiles, (hipStream_t)stream);
 }
 
-extern "C" int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
-                                     const st_attn_fin_job* job, int B, void* stream) {
+static int query_attn_fin_impl(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
+                               const st_attn_fin_job* job, int B, const st_partial_product_job* pj, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(packed_wq && h_q && h_q->base && granules && epoch != 0 && job && B > 0, "st_query_attn_fin_fwd: bad arguments");
     const int L = job->L, A = job->A, E = job->E, parts = job->parts;
@@ -1662,17 +1634,26 @@ extern "C" int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* 
     size_t lds = (size_t)o.total * sizeof(float);
     constexpr int KW = 8;
     ST_CHECK_ARG(lds + sizeof(f32x4) * KW * 64 <= 160 * 1024, "st_query_attn_fin_fwd: L=%d needs too much LDS", L);
-    if (g_host_part_set) {       // + the workgroups of a hosted K-split partial product
-        g_host_part_set = false;
-        const PkPartArgs pp = g_host_part;
-        if (lds < sizeof(f32x4) * KW * 4 * 64) lds = sizeof(f32x4) * KW * 4 * 64;
+    if (pj) {       // + the workgroups of the hosted partial product, one compute unit each like everything else in this launch
+        ST_CHECK_ARG(pj->packed_w && pj->x.base && pj->part && pj->KB > 0 && pj->kb0 >= 0 && pj->kb0 + pj->KB <= pj->w_kbs &&
+                     pj->x.kb0 + pj->KB <= pj->x.kb_stride && B > 16 && B <= 32 && pj->N > 0 && pj->N % 32 == 0 && st_aligned16(pj->packed_w) &&
+                     st_aligned16(pj->x.base) && st_aligned16(pj->part), "st_query_attn_fin_part_fwd: bad partial product (B = 17..32, N %% 32 == 0)");
+        const int n_part = pj->N >> 5;
+        ST_CHECK_ARG(n_lin + n_fin + n_part <= st_device_cus(), "st_query_attn_fin_part_fwd: %d + %d + %d workgroups do not fit the device at once",
+                     n_lin, n_fin, n_part);
+        PkPartArgs pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.w = reinterpret_cast<const f32x4*>(pj->packed_w) + (size_t)pj->kb0 * 64; pp.w_kbs = pj->w_kbs;
+        pp.x = reinterpret_cast<const f32x4*>(pj->x.base) + (size_t)pj->x.kb0 * 64; pp.x_kbs = pj->x.kb_stride;
+        pp.KB = pj->KB; pp.S = 1; pp.B = B; pp.N = pj->N; pp.part = pj->part;
+        if (lds < sizeof(f32x4) * KW * 4 * 64) lds = sizeof(f32x4) * KW * 4 * 64;        // (the part workgroups' reduction buffer lives in the dynamic region)
         auto kernp = pk_attnfin_part_kernel<1, KW, PK_TRIP_SMALL>;
         static size_t configured_p = 0;
         if (lds > 48 * 1024 && lds > configured_p) {
             ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             configured_p = lds;
         }
-        hipLaunchKernelGGL(kernp, dim3(n_lin + n_fin + (pp.N >> 5) * pp.S), dim3(KW * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N,
+        hipLaunchKernelGGL(kernp, dim3(n_lin + n_fin + n_part), dim3(KW * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N,
                            tiles, n_lin, a, t, n_lin + n_fin, pp);
         ST_LAUNCH_CHECK();
         return 0;
@@ -1685,6 +1666,33 @@ extern "C" int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* 
     }
     hipLaunchKernelGGL(kern, dim3(n_lin + n_fin), dim3(KW * 64), lds, (hipStream_t)stream, a.w, a.x, a.w_kbs, a.x_kbs, a.KB, a.B, a.N,
                        tiles, n_lin, a, t);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_query_attn_fin_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
+                                     const st_attn_fin_job* job, int B, void* stream) {
+    return query_attn_fin_impl(packed_wq, h_q, Q, granules, epoch, job, B, nullptr, stream);
+}
+
+extern "C" int st_query_attn_fin_part_fwd(const float* packed_wq, const st_t16_view* h_q, int Q, unsigned long long* granules, unsigned epoch,
+                                          const st_attn_fin_job* job, int B, const st_partial_product_job* part, void* stream) {
+    ST_CHECK_ARG(part, "st_query_attn_fin_part_fwd: null partial product job");
+    return query_attn_fin_impl(packed_wq, h_q, Q, granules, epoch, job, B, part, stream);
+}
+
+// the partial product as a launch of its own (the decode loop's two-launch pq / fin form: same arithmetic, one launch more)
+extern "C" int st_partial_product_fwd(const st_partial_product_job* pj, int B, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(pj && pj->packed_w && pj->x.base && pj->part && pj->KB > 0 && pj->kb0 >= 0 && pj->kb0 + pj->KB <= pj->w_kbs &&
+                 pj->x.kb0 + pj->KB <= pj->x.kb_stride && B > 16 && B <= 32 && pj->N > 0 && pj->N % 32 == 0 && st_aligned16(pj->packed_w) &&
+                 st_aligned16(pj->x.base) && st_aligned16(pj->part), "st_partial_product_fwd: bad job (B = 17..32, N %% 32 == 0)");
+    PkPartArgs pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.w = reinterpret_cast<const f32x4*>(pj->packed_w) + (size_t)pj->kb0 * 64; pp.w_kbs = pj->w_kbs;
+    pp.x = reinterpret_cast<const f32x4*>(pj->x.base) + (size_t)pj->x.kb0 * 64; pp.x_kbs = pj->x.kb_stride;
+    pp.KB = pj->KB; pp.S = 1; pp.B = B; pp.N = pj->N; pp.part = pj->part;
+    hipLaunchKernelGGL((pk_part_kernel<8, 2>), dim3(pj->N >> 5), dim3(8 * 64), 0, (hipStream_t)stream, pp);
     ST_LAUNCH_CHECK();
     return 0;
 }
@@ -2103,24 +2111,3 @@ extern "C" int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const 
     return pk_linear_impl(packed_w, x, K, bias, act, mask, ldmask, y, ldy, y_dst, n_split, y2, ldy2, rep,
                           n_split2, act2, mask2, ldmask2, y3_dst, B, N, pre, stream);
 }
-
-// ---- round-6 experiment plumbing (not part of the C ABI; called by decoder.hip) ------------------------------------------------------
-// the next pq / fin launch (st_query_attn_fin_fwd) or proj / attention-pre launch (st_skinny_linear_packed_attnpre_fwd) of this thread hosts
-// part (S, B, N) = x[:, kb0 .. kb0 + KB) W[:, kb0 .. kb0 + KB)^T: packed_w = the P16 matrix (w_kbs k-blocks per row tile), x = the T16 buffer
-extern "C" int stx_host_partial(const float* packed_w, int w_kbs, int kb0, int KB, const st_t16_view* x, int S, int B, int N, float* part) {
-    ST_CHECK_ARG(packed_w && x && x->base && part && KB > 0 && S >= 1 && S <= 2 && KB % S == 0 && B > 16 && B <= 32 && N % 32 == 0 && kb0 >= 0 &&
-                 kb0 + KB <= w_kbs && x->kb0 + KB <= x->kb_stride, "stx_host_partial: bad arguments");
-    PkPartArgs p;
-    memset(&p, 0, sizeof(p));
-    p.w = reinterpret_cast<const f32x4*>(packed_w) + (size_t)kb0 * 64; p.w_kbs = w_kbs;
-    p.x = reinterpret_cast<const f32x4*>(x->base) + (size_t)x->kb0 * 64; p.x_kbs = x->kb_stride;
-    p.KB = KB; p.S = S; p.B = B; p.N = N; p.part = part;
-    g_host_part = p; g_host_part_set = true;
-    return 0;
-}
-// the next st_lstm_cell_packed_fwd of this thread adds `part` (S, B, 4H) to its gates; its packed matrix has w_kbs k-blocks per row tile
-extern "C" int stx_cell_partial(const float* part, int S, int w_kbs) {
-    g_cell_part = part; g_cell_part_S = S; g_cell_w_kbs = w_kbs;
-    return 0;
-}
-extern "C" void stx_clear(void) { g_host_part_set = false; g_cell_part = nullptr; }

@@ -367,6 +367,9 @@ class Decoder(nn.Module):
         self.attn_pre_parts = 4      # workgroups per utterance of the pre part (measured at L = 43: 1 / 2 / 4 parts 37.1 / 35.9 / 35.4 us per step)
         self.attn_fin_parts = 2      # workgroups per utterance of the fin part (slices of the context dims)
         self.attn_pq_in_fin = True   # inference: query projection and fin part share one launch (in-launch hand-off of pq)
+        # ... and the part of the decoder cell's gate product that does not wait for the attention rides in that launch (round 6: +2-3 %
+        # mel-frames/s at C2; fp32 re-association only; ST_SPLIT_GATES=0 restores the whole product in the cell launch)
+        self.split_gates = os.environ.get('ST_SPLIT_GATES', '1') != '0'
         # the hand-off's failure word (st_decoder_io.handoff_status): an eager forward reads it back right away (one small
         # device -> host copy); under stream capture nobody can, so GraphedDecoder / bench.py / gen_specgram check it after replays
         self.check_handoff = True
@@ -641,6 +644,11 @@ class Decoder(nn.Module):
                     # decides: st_query_attn_rng_fits; the three-launch form stays the fall-back)
                     tapes['attn_xchg'] = torch.empty(2 * int(lib.st_attn_rng_xchg_words(B, E, sp)), **f32)
                     io.attn_xchg = ops._p(tapes['attn_xchg'])
+            if self.split_gates and not keep_tapes and 16 < B <= 32 and L < self.attn_split_min_len:
+                # the decoder cell's gate products over [AdaIN(h_q(t)) | h_d(t-1)] beside the pq / fin launch (st_decoder_io.gate_part; in the
+                # other forms of the attention step a launch of its own: the same arithmetic whatever the form)
+                tapes['gate_part'] = torch.empty(B, 4 * D, **f32)
+                io.gate_part = ops._p(tapes['gate_part'])
             if self.attn_pq_in_fin and not keep_tapes:
                 # query projection + attention fin part as ONE launch per step (st_query_attn_fin_fwd): pq is handed over inside
                 # the launch as 8-byte {value, tag} words; the library falls back to two launches when the shapes do not fit

@@ -103,6 +103,32 @@ def use_stream(handle):
         _stream_override = prev
 
 
+_SIDE_STREAMS = {}
+_SIDE_PENDING = []
+
+
+def side_stream(device):
+    """a second HIP stream per device for work that is independent of the main chain (the detached postnet branch of a training step)"""
+    key = str(device)
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+def side_pending(event=None):
+    """announce (event) / clear (None) side-stream work in flight: kernels that need every compute unit to themselves -- the one-launch
+    BiLSTM layers, whose workgroups wait for each other inside the launch -- make their stream wait for it first (join_side)"""
+    del _SIDE_PENDING[:]
+    if event is not None:
+        _SIDE_PENDING.append(event)
+
+
+def join_side():
+    for ev in _SIDE_PENDING:
+        torch.cuda.current_stream().wait_event(ev)
+
+
 def _p(t, dtype=torch.float32):
     """device pointer of a tensor (None -> NULL) after checking it is usable by the kernels"""
     if t is None:
@@ -637,6 +663,7 @@ def lstm_seq2(xproj_f, xproj_b, w_hh_f, w_hh_b, b_hh_f, b_hh_b, out, gates_tapes
     if LSTM_PERSIST and out.stride(2) == 1 and out.stride(0) == T * out.stride(1) and \
             all(t.data_ptr() % 16 == 0 for t in (out, w_hh_f, w_hh_b)) and w_hh_f.is_contiguous() and w_hh_b.is_contiguous() and \
             lib.st_lstm_seq2_persist_supported(B, T, H, int(out.stride(1)), 0, H):
+        join_side()               # (its workgroups wait for each other inside the launch: nothing else may hold compute units meanwhile)
         # all T steps in one launch (recurrent weights in registers, h handed over through `out` itself)
         check(lib.st_lstm_seq2_persist_fwd(arr(xproj_f, xproj_b), arr(w_hh_f, w_hh_b), arr(b_hh_f, b_hh_b), _p(out), int(out.stride(1)),
                                            (C.c_int * 2)(0, H), g2, c2, B, T, H, _p(persist_status(out.device), torch.int32), stream_handle()),
@@ -695,6 +722,7 @@ def lstm_seq2_bwd(dout, gates_tapes, c_tapes, w_hh_ts, w_hhs=None):
             all(w.is_contiguous() for w in w_hhs) and lib.st_lstm_seq2_bwd_persist_supported(B, T, H, int(dout.stride(1)), 0, H) and \
             _persist_bwd_headroom(B, H):
         # all T steps in one launch (slices of W_hh and the carried dL/dc in registers, the gate gradients handed over through dx itself)
+        join_side()
         check(lib.st_lstm_seq2_bwd_persist(_p(dout), int(dout.stride(1)), (C.c_int * 2)(0, H), arr(*gates_tapes), arr(*c_tapes),
                                            arr(*[w.detach() for w in w_hhs]), arr(*dx), B, T, H,
                                            _p(persist_status(dout.device), torch.int32), stream_handle()), 'st_lstm_seq2_bwd_persist')
@@ -953,7 +981,18 @@ def flush_wgrads():
     if _WQ:
         jobs, _WQ = _WQ, []
         _WQ_PENDING.clear()
-        gemm_wgrad_batch(jobs)
+        cur = stream_handle()
+        streams = []
+        for j in jobs:
+            if j.get('_stream', cur) not in streams:
+                streams.append(j.get('_stream', cur))
+        for h in streams:
+            group = [j for j in jobs if j.get('_stream', cur) == h]
+            if h == cur:
+                gemm_wgrad_batch(group)
+            else:
+                with use_stream(h):
+                    gemm_wgrad_batch(group)
 
 
 def grad_first(*params):
@@ -1001,6 +1040,9 @@ def _queue_wgrads(jobs, params=()):
     if not _WQ:
         _WQ_TASK = tid
         torch.autograd.Variable._execution_engine.queue_callback(flush_wgrads)
+    h = stream_handle()
+    for j in jobs:
+        j['_stream'] = h                  # (launched later, perhaps by another thread: on the stream its operands were produced on)
     _WQ.extend(jobs)
     _WQ_PENDING.update(q.data_ptr() for q in params if q is not None)
     if len(_WQ) >= WGRAD_QMAX:

@@ -257,6 +257,10 @@ class TtsTrainer(BaseSolver):
         parallel.sync_batchnorm(True)        # no-op for a single process; global-batch statistics under torch.distributed
         parallel.broadcast_parameters(self.model)
         self._attach_reducer()
+        # the detached postnet branch on a second stream (Tacotron2.postnet_side) -- without data parallelism only: a gradient bucket
+        # that goes out while the backward still runs must not mix gradients of two streams
+        self.model.tts.postnet_side = (self.reducer is None and type(self) is TtsTrainer and bool(getattr(self.model.tts, 'separate_postnet', False))
+                                       and os.environ.get('ST_POSTNET_SIDE', '1') != '0')
         return self
 
     def _attach_reducer(self):
@@ -294,11 +298,33 @@ class TtsTrainer(BaseSolver):
             self.reducer.prepare()
         mel_pred, linear_pred, align, _, _, _, _, _ = self.model.text_to_speech(
             text, sid, None, None, None, None, mel, None, tf_rate, _masks=_masks)
-        mel_loss = self.freq_loss(mel_pred, mel)
-        linear_loss = self.freq_loss(linear_pred, linear)
         from . import autograd as AG
-        total, = AG.scalar_combine([[self.tts_weight, self.tts_weight]], [mel_loss, linear_loss])     # (one launch; `w * (a + b)` is two, and three backward)
-        total.backward()
+        side = getattr(self.model.tts, 'postnet_stream', None)
+        w = self.tts_weight
+        if side is not None:
+            # separate_postnet (src/tts.py:47-50): the postnet saw mel_pred.detach(), on a second stream.  Its loss and its whole backward
+            # (CBHG incl. both GRU passes: ~1 ms that neither feeds nor waits for the decoder's backward through time) stay on that
+            # stream, beside the main chain; the streams join before the gradients are used.  d total / d linear_loss = tts_weight.
+            with torch.cuda.stream(side):
+                linear_loss = self.freq_loss(linear_pred, linear)
+                lin_total, = AG.scalar_combine([[w]], [linear_loss])
+                lin_total.backward()
+                ops.flush_wgrads()
+                ev = self.__dict__.setdefault('_side_event', torch.cuda.Event())
+                ev.record(side)
+            ops.side_pending(ev)                      # (the one-launch BiLSTM backward of the text encoder waits for it: it needs every compute unit)
+            mel_loss = self.freq_loss(mel_pred, mel)
+            mel_total, = AG.scalar_combine([[w]], [mel_loss])
+            mel_total.backward()
+            torch.cuda.current_stream().wait_event(ev)
+            ops.side_pending(None)
+            with torch.no_grad():
+                total, = AG.scalar_combine([[1.0, 1.0]], [mel_total.detach(), lin_total.detach()])
+        else:
+            mel_loss = self.freq_loss(mel_pred, mel)
+            linear_loss = self.freq_loss(linear_pred, linear)
+            total, = AG.scalar_combine([[w, w]], [mel_loss, linear_loss])     # (one launch; `w * (a + b)` is two, and three backward)
+            total.backward()
         self._reduce_gradients()
         grad_norm = self._clip()
         from .optim import FusedAdam

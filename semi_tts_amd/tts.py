@@ -33,6 +33,8 @@ class Tacotron2(nn.Module):
         self.use_summed_weights = self.decoder.use_summed_weights
         self.n_frames_per_step = self.decoder.n_frames_per_step
         self.postnet = None
+        self.postnet_side = False        # training: the detached postnet branch on a second stream (the caller continues it there; TtsTrainer)
+        self.postnet_stream = None
         if linear_dim is not None:
             # CBHG output size is 2 * input size                                    ref: src/tts.py:29-34
             self.postnet = nn.Sequential(CBHG(n_mels, K=8), _PostLinear(n_mels * 2, linear_dim))
@@ -55,9 +57,21 @@ class Tacotron2(nn.Module):
                 ops.degrade('one-launch BiLSTM layer', 'one launch per time step (ops.LSTM_PERSIST = False)')
                 ops.LSTM_PERSIST = False
         linear_pred = None
+        self.postnet_stream = None
         if self.postnet is not None:
             # separate_postnet only cuts the gradient (mel_pred.detach()); forward values are identical
-            linear_pred = self.postnet(mel_pred.detach() if self.separate_postnet else mel_pred)
+            if (self.postnet_side and self.separate_postnet and self.training and torch.is_grad_enabled() and mel_pred.is_cuda
+                    and not ops.capturing()):
+                # ... and makes the branch independent of everything behind mel_pred: CBHG forward, the linear loss and the whole CBHG
+                # backward neither feed nor wait for the decoder's backward through time.  A trainer that opted in (postnet_side) gets
+                # linear_pred computed on a second stream, continues the branch there (loss, backward) and joins before the optimiser.
+                side = ops.side_stream(mel_pred.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    linear_pred = self.postnet(mel_pred.detach())
+                self.postnet_stream = side
+            else:
+                linear_pred = self.postnet(mel_pred.detach() if self.separate_postnet else mel_pred)
         return mel_pred, linear_pred, alignment, stop
 
     def create_msg(self):

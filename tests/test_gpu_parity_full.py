@@ -317,3 +317,32 @@ def test_c2_training_step_with_poisoned_uninitialised_buffers(dev):
     for k in g0:
         assert torch.isfinite(g1[k]).all(), k
         assert torch.equal(g0[k], g1[k]), k
+
+
+def test_postnet_branch_on_a_second_stream_gives_bitwise_the_serial_step(dev):
+    """separate_postnet (src/tts.py:47-50): the postnet sees mel_pred.detach(), so CBHG forward + linear freq_loss + CBHG backward neither
+    feed nor wait for the decoder's backward through time.  TtsTrainer runs that branch on a second HIP stream beside the main chain
+    (Tacotron2.postnet_side) and joins before the clip: losses, gradient norm and EVERY weight after two steps must equal the serial
+    order bit for bit (no kernel's result depends on what runs beside it; the queued weight-gradient products leave on the stream their
+    operands were produced on) -- config-3 model at B = 8, 66 frames."""
+    import yaml
+    from argparse import Namespace
+    from semi_tts_amd.solver import TtsTrainer
+    cfg = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-single-spkr-paired-data.yaml')))
+    outs = []
+    for side in (False, True):
+        paras = Namespace(batch_size=8, frames=64, n_batches=1, seed=3, verbose=False, max_step=2, load=None)
+        tr = TtsTrainer(cfg, paras, 'train').load_data().set_model()
+        tr.model.tts.postnet_side = side
+        torch.manual_seed(7)
+        batch = [t.to(dev) for t in tr.batches[0]]
+        sts = [tr.train_step(*batch) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert (tr.model.tts.postnet_stream is not None) == side
+        outs.append(([(float(s['loss']), float(s['mel_loss']), float(s['linear_loss']), float(s['grad_norm'])) for s in sts],
+                     {k: v.detach().clone() for k, v in tr.model.state_dict().items()}))
+    (s0, w0), (s1, w1) = outs
+    assert s0 == s1, (s0, s1)
+    assert all(x == x for t in s1 for x in t)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k

@@ -257,10 +257,12 @@ class TtsTrainer(BaseSolver):
         parallel.sync_batchnorm(True)        # no-op for a single process; global-batch statistics under torch.distributed
         parallel.broadcast_parameters(self.model)
         self._attach_reducer()
-        # the detached postnet branch on a second stream (Tacotron2.postnet_side) -- without data parallelism only: a gradient bucket
-        # that goes out while the backward still runs must not mix gradients of two streams
+        # the detached postnet branch on a second stream (Tacotron2.postnet_side; ST_POSTNET_SIDE=1) -- without data parallelism only: a
+        # gradient bucket that goes out while the backward still runs must not mix gradients of two streams.  Bitwise the serial step
+        # (test_postnet_branch_on_a_second_stream_gives_bitwise_the_serial_step); OFF by default: measured round 6, the step is bound by the
+        # host's issue rate (9.1 of 9.7 ms), so the ~1 ms of GPU time it hides does not show (9.62 / 9.82 vs 9.73 / 9.83 ms)
         self.model.tts.postnet_side = (self.reducer is None and type(self) is TtsTrainer and bool(getattr(self.model.tts, 'separate_postnet', False))
-                                       and os.environ.get('ST_POSTNET_SIDE', '1') != '0')
+                                       and os.environ.get('ST_POSTNET_SIDE', '0') == '1')
         return self
 
     def _attach_reducer(self):

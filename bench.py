@@ -195,9 +195,13 @@ def rccl_probe_main():
     """`bench.py --rccl-probe` (a CHILD of every rank, started before the rank touches the GPU): initialise RCCL with the rank's
     coordinates on a port of its own, run one all-reduce over a device tensor and check the sum.  Exit code 0 = RCCL works on
     this node; anything else (exception, crash, the parent's time-out on a hang) = it does not, and the ranks go on with gloo."""
-    if os.environ.get('ST_BENCH_FAKE_RCCL_FAIL') == '1':        # tests: what a failing peer-memory set-up looks like from outside
+    fake = os.environ.get('ST_BENCH_FAKE_RCCL_FAIL')            # tests: what a failing peer-memory set-up looks like from outside
+    if fake == '1' or fake == 'rank:' + os.environ.get('RANK', ''):      # ('rank:3': on that rank only)
         sys.stderr.write('rccl probe: failure faked by ST_BENCH_FAKE_RCCL_FAIL\n')
         sys.exit(3)
+    if os.environ.get('ST_BENCH_FAKE_RCCL_OK') == '1':          # tests on a box without GPUs: every other rank's probe "passes"
+        print('RCCL_PROBE_OK')
+        return
     import datetime
     import torch
     import torch.distributed as dist

@@ -91,6 +91,86 @@ def test_two_rank_sync_bn_training_equals_single_process(tmp_path, cut):
     print('worst relative gradient difference DP vs single process: %.2e' % worst)
 
 
+def _batch12(A):
+    """12 utterances of the tiny model's shapes (the golden holds 4): seeded, the same in every process"""
+    g = torch.Generator().manual_seed(12)
+    txt = torch.randn(12, *A['txt_embed'].shape[1:], generator=g) * 0.5
+    spk = torch.randn(12, *A['spkr_embed'].shape[1:], generator=g) * 0.5
+    teacher = torch.rand(12, *A['teacher'].shape[1:], generator=g)
+    lin_t = torch.rand(12, A['teacher'].shape[1], 20, generator=g)
+    return txt, spk, teacher, lin_t
+
+
+def _step12(m, batch, rows, dev, weight=1.0):
+    from semi_tts_amd import autograd as AG
+    txt, spk, teacher, lin_t = (t[rows].to(dev) for t in batch)
+    mel, lin, _, _ = m(txt, None, teacher, spk, tf_rate=1.0)
+    loss = (AG.freq_loss(mel, teacher, 22050, 8) + AG.freq_loss(lin, lin_t, 22050, 8)) * weight
+    loss.backward()
+    return float(loss.detach())
+
+
+_SIZES8 = [3, 2, 2, 1, 1, 1, 1, 1]
+
+
+def _worker8(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from semi_tts_amd import parallel
+    dev = torch.device('cuda:0')
+    m, A, _ = _build(dev)
+    batch = _batch12(A)
+    parallel.sync_batchnorm(True)
+    parallel.broadcast_parameters(m)
+    lo = sum(_SIZES8[:rank])
+    n_r = _SIZES8[rank]
+    red = parallel.GradReducer(m.parameters(), bucket_bytes=64 << 10, average=True, defer_average=True)
+    loss = _step12(m, batch, slice(lo, lo + n_r), dev, weight=n_r * world / 12.0)
+    n_coll = red.finish()
+    assert n_coll > 1 and red.grad_scale == 1.0 / world
+    c = parallel.collective_counts()
+    assert c['syncbn_fwd'] == 6 and c['syncbn_bwd'] == 6
+    if rank == 0:
+        torch.save({'grads': {k: (p.grad * red.grad_scale).cpu() for k, p in m.named_parameters() if p.grad is not None},
+                    'stats': {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}}, out_path)
+    dist.destroy_process_group()
+
+
+def test_eight_rank_sync_bn_training_with_unequal_shards_equals_single_process(tmp_path):
+    """Eight ranks before an 8-GPU box sees them (here: eight processes sharing the test GPU, gloo for the collectives): shards of 3 / 2 / 2 /
+    1 / 1 / 1 / 1 / 1 utterances of a batch of 12, SyncBN statistics merged over the ranks' true row counts, gradients born in their buckets,
+    the sums all-reduced and 1 / world applied afterwards: averaged gradients and running statistics = the single-process full batch."""
+    import time
+    import torch.multiprocessing as mp
+    dev = torch.device('cuda:0')
+    m, A, _ = _build(dev)
+    _step12(m, _batch12(A), slice(0, 12), dev)
+    ref = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
+    ref_stats = {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}
+    out = str(tmp_path / 'dp8.pt')
+    ctx = mp.start_processes(_worker8, args=(8, 29317 + os.getpid() % 500, out), nprocs=8, join=False, start_method='spawn')
+    deadline = time.time() + 240
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail('eight data-parallel workers did not finish within 240 s')
+    got = torch.load(out)
+    worst = 0.0
+    for k, g in ref.items():
+        scale = float(g.abs().max())
+        if scale < 1e-6:
+            assert maxdiff(got['grads'][k], g) < 1e-6, k
+            continue
+        e = maxdiff(got['grads'][k], g) / scale
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)
+    for k, v in ref_stats.items():
+        assert maxdiff(got['stats'][k], v) < 1e-5, k
+    print('worst relative gradient difference, 8 ranks vs single process: %.2e' % worst)
+
+
 @pytest.mark.parametrize('N', [80, 128, 7])
 def test_sync_bn_record_merge_kernels_equal_the_statistics_of_the_concatenated_batch(N):
     """the two launches of the SyncBN forward (local record; merge of the gathered records) on three ragged shards = batch

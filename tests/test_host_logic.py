@@ -425,6 +425,110 @@ def test_bench_ranks_fall_back_to_gloo_when_the_rccl_probe_fails(tmp_path, fake)
     assert ('faked' in res['collectives']['rccl_probe']) == fake
 
 
+def test_eight_rank_bring_up_agrees_on_gloo_when_one_rank_probe_fails(tmp_path):
+    """The first 8-GPU run happens on a driver box with no chance to debug: eight ranks under torch.distributed.run, the RCCL probe
+    passing on seven of them (faked: no GPU here) and failing on rank 3 only.  EVERY rank must come up on gloo (a group half on RCCL
+    would hang), the barrier / max contract must work across all eight, and the line must name the rank whose probe failed."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_RANKS_WORKER.replace('gpus=2', 'gpus=8'))
+    env = dict(os.environ, ST_BENCH_ALLOW_CPU='1', ST_BENCH_PROBE_TIMEOUT='120', ST_BENCH_FAKE_RCCL_OK='1', ST_BENCH_FAKE_RCCL_FAIL='rank:3')
+    env.pop('ST_BENCH_BACKEND', None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                        '--master-port', '29547', str(script), REPO], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=400)
+    assert r.returncode == 0, r.stdout
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('RESULT ')][0][7:])
+    assert res['backend'] == 'gloo' and res['rccl_ranks'] == 0 and res['t'] == 8.0          # max over ranks of 1 + rank
+    assert res['collectives']['rccl_probe'].startswith('failed: rank 3') and 'faked' in res['collectives']['rccl_probe']
+
+
+_WORKER8 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from semi_tts_amd import ops
+from semi_tts_amd.parallel import GradReducer, broadcast_parameters, shard_range
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+sizes = [5, 4, 4, 4, 4, 4, 4, 3]                  # unequal shards of a global batch of 32 utterances
+N = sum(sizes)
+lo = sum(sizes[:rank]); hi = lo + sizes[rank]
+spans = [shard_range(N, world, r) for r in range(world)]
+cover = int(spans[0][0] == 0 and spans[-1][1] == N and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1)))
+g = torch.Generator().manual_seed(0)
+x = torch.randn(N, 6, generator=g)
+class SlotLinear(torch.autograd.Function):        # a producer that writes its weight gradient where ops.grad_slot says (born in the bucket)
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w, b)
+        return x @ w.t() + b
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        dw, slot = dy.t() @ x, ops.grad_slot(w)
+        if slot is not None:
+            slot.copy_(dw); dw = slot
+        return dy @ w, dw, dy.sum(0)
+def build():
+    torch.manual_seed(1234 + rank)              # replicas start different and are made identical
+    net = torch.nn.Sequential(torch.nn.Linear(6, 7), torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    broadcast_parameters(net)
+    return net
+def fwd(net, rows):
+    h = SlotLinear.apply(rows, net[0].weight, net[0].bias)
+    h = torch.tanh(SlotLinear.apply(h, net[1].weight, net[1].bias))
+    return net[2](h)
+def ref_grads(net):
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 7), torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    ref.load_state_dict(net.state_dict())
+    (fwd(ref, x).pow(2).sum() / N).backward()      # the single-process mean loss over the whole batch
+    return [p.grad for p in ref.parameters()]
+out = []
+for static in (False, True):
+    net = build()
+    ref = ref_grads(net)
+    red = GradReducer(net.parameters(), bucket_bytes=96, average=True, defer_average=True, static_graph=static)
+    for it in range(4):
+        red.prepare()
+        # each rank's MEAN loss weighted by its share of the global batch (n_r * world / N): the average over ranks is the global mean
+        (fwd(net, x[lo:hi]).pow(2).sum() / sizes[rank] * (sizes[rank] * world / N)).backward()
+        nb = red.finish()
+    scale = red.grad_scale                          # 1 / world: rides in the clip launch (optim.clip_grad_norm_(pre_scale=))
+    err = max(float((p.grad * scale - r).abs().max()) for p, r in zip(net.parameters(), ref))
+    norm = float(torch.sqrt(sum(((p.grad * scale).double() ** 2).sum() for p in net.parameters())))
+    norm_ref = float(torch.sqrt(sum((r.double() ** 2).sum() for r in ref)))
+    born = red.stats['born_in_slot']
+    same = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(same, torch.tensor([float(sum(float(p.grad.sum()) for p in net.parameters()))]))
+    agree = int(all(float(s) == float(same[0]) for s in same))
+    out += [err, abs(norm - norm_ref) / norm_ref, int(scale == 1.0 / world), int(born >= 2), int(nb == len(red.buckets) and nb > 1), agree,
+            int(red._sparse == static)]
+    red.close()
+if rank == 0:
+    print('RESULT', cover, *out)
+dist.destroy_process_group()
+"""
+
+
+def test_eight_process_reducer_with_unequal_shards_matches_single_process(tmp_path):
+    """world_size 8 over gloo before any 8-GPU box sees the reducer: unequal utterance shards (5/4/4/4/4/4/4/3 of 32), gradients born
+    in their bucket slots, the per-parameter (dynamic) and the one-hook-per-bucket (static, agreed across ranks) forms over four steps,
+    the sums in the buckets with 1 / world left to the clip (grad_scale): averaged gradients and their norm = the single-process
+    gradient of the whole batch; every rank ends with the same gradients bit for bit."""
+    script = tmp_path / 'worker8.py'
+    script.write_text(_WORKER8)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29551', WORLD_SIZE='8', OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), REPO], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0].splitlines() if l.startswith('RESULT')][0].split()
+    assert line[1] == '1'                                    # shard_range covers the batch once
+    for form in range(2):                                    # dynamic, static
+        err, nerr, scale_ok, born, buckets, agree, sparse = line[2 + 7 * form: 9 + 7 * form]
+        assert float(err) < 1e-5 and float(nerr) < 1e-5, (form, err, nerr)
+        assert scale_ok == '1' and born == '1' and buckets == '1' and agree == '1' and sparse == '1', (form, line)
+
+
 # Command lines of the reference's README ("Running": train from scratch / continue / inference) and every flag its parser
 # defines (ref: main.py:14-33).  Data, not code: an existing launch script must keep parsing.
 _REFERENCE_COMMAND_LINES = [

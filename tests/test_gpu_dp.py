@@ -149,7 +149,11 @@ def test_eight_rank_sync_bn_training_with_unequal_shards_equals_single_process(t
     ref = {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}
     ref_stats = {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}
     out = str(tmp_path / 'dp8.pt')
-    ctx = mp.start_processes(_worker8, args=(8, 29317 + os.getpid() % 500, out), nprocs=8, join=False, start_method='spawn')
+    import socket
+    with socket.socket() as sk:                 # a port nobody holds (fixed offsets collided once with a lingering listener)
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.start_processes(_worker8, args=(8, port, out), nprocs=8, join=False, start_method='spawn')
     deadline = time.time() + 240
     while not ctx.join(timeout=5):
         if time.time() > deadline:

@@ -403,7 +403,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             jq.ada_std = io->ada_std; jq.ada_mean = io->ada_mean; jq.hadapt_dst = st_t16_view{xd_next, sv.d_kbs, sv.d_ha};
             jq.B = B; jq.H = Q;
             rc = st_lstm_cell_packed_pair_fwd(&jd, &jq, stream);
-        } else
+        } else {
         if (split_d && !split_hosted && !ST_SKIPPED(3)) {
             pj_d.x = st_t16_view{xd, sv.d_kbs, sv.d_ha};
             rc = st_partial_product_fwd(&pj_d, B, stream);
@@ -420,6 +420,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
                                      &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                      io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr,
                                      nullptr, nullptr, nullptr, B, D, stream);
+        }
         if (rc) return rc;
 
         // 5. mel frames + stop logit (+ prenet layer 1 of the next input when fused)   ref: :282-287

@@ -121,6 +121,9 @@ size_t st_t16_floats(int B, int K);                                        /* si
  * 4t..4t+3 (so the cell update is workgroup-local). */
 int st_pack_weight(const float* const* w, const int* ldw, const int* k, int nseg, int N, int lstm_H,
                    float* packed, void* stream);
+/* ... for up to eight matrices in ONE launch (the six matrices of st_decoder_pack were six launches of ~10 us per forward / weight update) */
+typedef struct st_pack_job { const float* w[3]; int ldw[3]; int k[3]; int nseg; int N; int lstm_H; float* packed; } st_pack_job;
+int st_pack_weight_batch(const st_pack_job* jobs, int n, void* stream);
 /* P16 image of the TRANSPOSE of the column concatenation [w[0] | w[1] | ...] (each (K, cols[s]), row stride ldw[s]): N = sum cols,
  * one segment of K columns -- what st_pack_weight would make of torch.cat(w, 1).t().contiguous(), without those two copies
  * (the BPTT loop's W^T operands: backward of nn.LSTMCell / Linear, src/module.py:247-283). */

@@ -217,6 +217,7 @@ SIGNATURES = {
     'st_pack_weight_t': [C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, P, P],
     'st_relayout_blocks': [I, I, I],
     'st_relayout_batch': [P, I, I, P, P],
+    'st_pack_weight_batch': [P, I, P],
     'st_tile_rows': [P, I, C.POINTER(StT16View), I, I, P],
     'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
     'st_lstm_cell_packed_fwd': [P, C.POINTER(StT16View), I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),

@@ -1006,12 +1006,12 @@ class _DecoderFn(Function):
         if fuse_pw:
             zshapes.update(dgd_t16_b=(ops.t16_floats(B, 4 * D),), dpq_t16=(ops.t16_floats(B, A),))
         numel = lambda shp: int(torch.Size(shp).numel())
-        pool = torch.zeros(sum((numel(s) + 3) // 4 * 4 for s in zshapes.values()), **f32)      # (16-byte aligned pieces)
+        pool = ops.zeros(sum((numel(s) + 3) // 4 * 4 for s in zshapes.values()), **f32)      # (16-byte aligned pieces)
         zb, off = {}, 0
         for k, shp in zshapes.items():
             zb[k] = pool[off:off + numel(shp)].view(*shp)
             off += (numel(shp) + 3) // 4 * 4
-        z = lambda *shape: torch.zeros(*shape, **f32)
+        z = lambda *shape: ops.zeros(*shape, **f32)
         e_ = lambda *shape: ops.uninit(*shape, **f32)
         if lazy_big:
             zb.update({k: e_(*shp) for k, shp in big.items()})

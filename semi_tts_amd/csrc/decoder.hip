@@ -140,29 +140,22 @@ extern "C" int st_decoder_pack(const st_decoder_weights* w, const st_decoder_dim
     ST_CHECK_ARG(w && d && packed, "st_decoder_pack: null pointer");
     const PackedLayout pl = packed_layout(d);
     const int in_dim = d->r * d->n_mels;
-    int rc;
-    {   // query LSTM: K = [dec_in (P) | ctx (E) | h_q (Q)]                  ref: src/module.py:227-228
-        const float* ws[3] = {w->q_w_ih, w->q_w_ih + d->P, w->q_w_hh};
-        int ld[3] = {d->P + d->E, d->P + d->E, d->Q}, k[3] = {d->P, d->E, d->Q};
-        if ((rc = st_pack_weight(ws, ld, k, 3, 4 * d->Q, d->Q, packed + pl.q, stream))) return rc;
-    }
-    {   const float* ws[1] = {w->attn_query_w}; int ld[1] = {d->Q}, k[1] = {d->Q};
-        if ((rc = st_pack_weight(ws, ld, k, 1, d->A, 0, packed + pl.pq, stream))) return rc; }
-    {   // decoder LSTM: K = [ctx (E) | adapted h_q (Q) | h_d (D)]            ref: src/module.py:275-277
-        const float* ws[3] = {w->d_w_ih, w->d_w_ih + d->E, w->d_w_hh};
-        int ld[3] = {d->E + d->Q, d->E + d->Q, d->D}, k[3] = {d->E, d->Q, d->D};
-        if ((rc = st_pack_weight(ws, ld, k, 3, 4 * d->D, d->D, packed + pl.d, stream))) return rc;
-    }
-    {   // proj (+) gate: K = [h_d (D) | ctx (E)]                             ref: src/module.py:282-287
-        const float* ws[2] = {w->projgate_w, w->projgate_w + d->D};
-        int ld[2] = {d->D + d->E, d->D + d->E}, k[2] = {d->D, d->E};
-        if ((rc = st_pack_weight(ws, ld, k, 2, in_dim + 1 + (d->fuse_pre0 ? d->P : 0), 0, packed + pl.pg, stream))) return rc;
-    }
-    {   const float* ws[1] = {w->prenet_w0}; int ld[1] = {in_dim}, k[1] = {in_dim};
-        if ((rc = st_pack_weight(ws, ld, k, 1, d->P, 0, packed + pl.p0, stream))) return rc; }
-    {   const float* ws[1] = {w->prenet_w1}; int ld[1] = {d->P}, k[1] = {d->P};
-        if ((rc = st_pack_weight(ws, ld, k, 1, d->P, 0, packed + pl.p1, stream))) return rc; }
-    return 0;
+    st_pack_job j[6];
+    memset(j, 0, sizeof(j));
+    auto seg = [&](st_pack_job& q, int s, const float* wp, int ld, int k) { q.w[s] = wp; q.ldw[s] = ld; q.k[s] = k; q.nseg = s + 1; };
+    // query LSTM: K = [dec_in (P) | ctx (E) | h_q (Q)]                       ref: src/module.py:227-228
+    seg(j[0], 0, w->q_w_ih, d->P + d->E, d->P); seg(j[0], 1, w->q_w_ih + d->P, d->P + d->E, d->E); seg(j[0], 2, w->q_w_hh, d->Q, d->Q);
+    j[0].N = 4 * d->Q; j[0].lstm_H = d->Q; j[0].packed = packed + pl.q;
+    seg(j[1], 0, w->attn_query_w, d->Q, d->Q); j[1].N = d->A; j[1].packed = packed + pl.pq;
+    // decoder LSTM: K = [ctx (E) | adapted h_q (Q) | h_d (D)]                 ref: src/module.py:275-277
+    seg(j[2], 0, w->d_w_ih, d->E + d->Q, d->E); seg(j[2], 1, w->d_w_ih + d->E, d->E + d->Q, d->Q); seg(j[2], 2, w->d_w_hh, d->D, d->D);
+    j[2].N = 4 * d->D; j[2].lstm_H = d->D; j[2].packed = packed + pl.d;
+    // proj (+) gate: K = [h_d (D) | ctx (E)]                                  ref: src/module.py:282-287
+    seg(j[3], 0, w->projgate_w, d->D + d->E, d->D); seg(j[3], 1, w->projgate_w + d->D, d->D + d->E, d->E);
+    j[3].N = in_dim + 1 + (d->fuse_pre0 ? d->P : 0); j[3].packed = packed + pl.pg;
+    seg(j[4], 0, w->prenet_w0, in_dim, in_dim); j[4].N = d->P; j[4].packed = packed + pl.p0;
+    seg(j[5], 0, w->prenet_w1, d->P, d->P); j[5].N = d->P; j[5].packed = packed + pl.p1;
+    return st_pack_weight_batch(j, 6, stream);       // one launch for the six (they were ~10 us each)
 }
 
 extern "C" size_t st_decoder_tape_floats(const st_decoder_dims* d, int which) {

@@ -39,7 +39,15 @@ struct PackArgs {
 };
 
 // one thread per (tile, kb, lane): gathers 4 floats of one weight row
-__global__ __launch_bounds__(256) void pack_weight_kernel(const PackArgs a) {
+__device__ __forceinline__ void pack_weight_body(const PackArgs& a);
+__global__ __launch_bounds__(256) void pack_weight_kernel(const PackArgs a) { pack_weight_body(a); }
+
+// several matrices in one launch (blockIdx.y = matrix): the six P16 images of a decoder forward were six launches of ~10 us
+constexpr int PACK_BATCH_MAX = 8;
+struct PackBatch { PackArgs j[PACK_BATCH_MAX]; };
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackBatch b) { pack_weight_body(b.j[blockIdx.y]); }
+
+__device__ __forceinline__ void pack_weight_body(const PackArgs& a) {
     const size_t total = (size_t)a.tiles * a.KB * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -1381,12 +1389,9 @@ extern "C" size_t st_packed_weight_floats(const int* k, int nseg, int N, int lst
 
 extern "C" size_t st_t16_floats(int B, int K) { return (size_t)((B + 15) >> 4) * pk_kb(K) * 256; }
 
-extern "C" int st_pack_weight(const float* const* w, const int* ldw, const int* k, int nseg, int N, int lstm_H,
-                              float* packed, void* stream) {
-    (void)hipGetLastError();
+static int pack_fill(PackArgs& a, const float* const* w, const int* ldw, const int* k, int nseg, int N, int lstm_H, float* packed) {
     ST_CHECK_ARG(w && ldw && k && packed && nseg >= 1 && nseg <= PK_MAXSEG && N > 0, "st_pack_weight: bad arguments");
     ST_CHECK_ARG(lstm_H == 0 || (lstm_H % 4 == 0 && N == 4 * lstm_H), "st_pack_weight: lstm_H=%d N=%d", lstm_H, N);
-    PackArgs a;
     memset(&a, 0, sizeof(a));
     int kb = 0;
     for (int s = 0; s < nseg; ++s) {
@@ -1397,6 +1402,34 @@ extern "C" int st_pack_weight(const float* const* w, const int* ldw, const int* 
     a.nseg = nseg; a.N = N; a.H = lstm_H; a.KB = kb;
     a.tiles = lstm_H > 0 ? lstm_H / 4 : (N + 15) / 16;
     a.out = packed;
+    return 0;
+}
+
+// st_pack_weight for up to eight matrices in ONE launch (st_decoder_pack: the six matrices the decode loop streams)
+extern "C" int st_pack_weight_batch(const st_pack_job* jobs, int n, void* stream) {
+    (void)hipGetLastError();
+    ST_CHECK_ARG(jobs && n >= 1 && n <= PACK_BATCH_MAX, "st_pack_weight_batch: 1..%d jobs", PACK_BATCH_MAX);
+    PackBatch b;
+    size_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        int rc = pack_fill(b.j[i], jobs[i].w, jobs[i].ldw, jobs[i].k, jobs[i].nseg, jobs[i].N, jobs[i].lstm_H, jobs[i].packed);
+        if (rc) return rc;
+        const size_t total = (size_t)b.j[i].tiles * b.j[i].KB * 64;
+        most = total > most ? total : most;
+    }
+    int blocks = (int)((most + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, b);
+    ST_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int st_pack_weight(const float* const* w, const int* ldw, const int* k, int nseg, int N, int lstm_H,
+                              float* packed, void* stream) {
+    (void)hipGetLastError();
+    PackArgs a;
+    int rc = pack_fill(a, w, ldw, k, nseg, N, lstm_H, packed);
+    if (rc) return rc;
     const size_t total = (size_t)a.tiles * a.KB * 64;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;

@@ -559,7 +559,7 @@ class Decoder(nn.Module):
         # the own-output scratch is never touched) -- the C2 training step saves an 11 us fill of 90 MB
         no_pads = B % 16 == 0 and all(k % 16 == 0 for k in (P, E, Q, D, in_dim))
         tf_all = teacher_pre is not None and Bt == B and all(step_src[t] == min(t, Tt - 1) for t in range(steps - 1))
-        tiled = (ops.uninit if (keep_tapes and no_pads and tf_all and self.prenet_norm_type is None) else torch.zeros)(sum(sizes.values()), **f32)
+        tiled = (ops.uninit if (keep_tapes and no_pads and tf_all and self.prenet_norm_type is None) else ops.zeros)(sum(sizes.values()), **f32)
         tapes, off = {}, 0
         for k, n in sizes.items():
             tapes[k] = tiled[off:off + n]

@@ -30,6 +30,14 @@ def uninit(*shape, device, dtype=torch.float32):
 _stream_override = None
 
 
+def zeros(*shape, device, dtype=torch.float32):
+    """torch.zeros through the library's fill launch (a kernel trace of a step then shows no ATen fill; same launch count)"""
+    t = torch.empty(*shape, device=device, dtype=dtype)
+    if dtype == torch.float32 and t.numel() > 0:
+        return fill_(t, 0.0)
+    return t.zero_()
+
+
 def stream_handle():
     """hipStream_t (as int) all st_* calls are issued on: torch's current stream unless overridden."""
     if _stream_override is not None:

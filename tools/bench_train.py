@@ -49,7 +49,8 @@ def main():
         sync(); t0 = time.perf_counter()
         tf_rate = tr.optimizer.pre_step(tr.step)
         mp, lp, *_ = tr.model.text_to_speech(text, sid, None, None, None, None, mel, None, tf_rate)
-        total = tr.tts_weight * (tr.freq_loss(mp, mel) + tr.freq_loss(lp, linear))
+        from semi_tts_amd import autograd as AG
+        total, = AG.scalar_combine([[tr.tts_weight, tr.tts_weight]], [tr.freq_loss(mp, mel), tr.freq_loss(lp, linear)])     # (as TtsTrainer.train_step)
         sync(); t1 = time.perf_counter()
         total.backward()
         sync(); t2 = time.perf_counter()

@@ -142,9 +142,9 @@ int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view* x, int K,
                             const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
                             int B, int H, void* stream);
 /* st_lstm_cell_packed_fwd (without AdaIN) over the LEADING K columns of a cell whose packed matrix has w_kbs k-blocks per row tile; the gate
- * products over the remaining columns come as `part` (S, B, 4H), written by an st_partial_product_job of an earlier launch (its S), and are
- * added to the reduced gates in slab order.  16 < B <= 32, H / 4 even.  ref: nn.LSTMCell, src/module.py:275-280 */
-int st_lstm_cell_packed_part_fwd(const float* packed_w, int w_kbs, const st_t16_view* x, int K, const float* part, int S,
+ * products over the remaining columns come as `part` (B, 4H), written by an st_partial_product_job of an earlier launch, and are added to
+ * the reduced gates.  16 < B <= 32, H / 4 even.  ref: nn.LSTMCell, src/module.py:275-280 */
+int st_lstm_cell_packed_part_fwd(const float* packed_w, int w_kbs, const st_t16_view* x, int K, const float* part,
                                  const float* b_ih, const float* b_hh,
                                  const float* c_prev, int ldc_prev, const float* mask,
                                  const st_t16_view* h_dst0, const st_t16_view* h_dst1,
@@ -294,9 +294,6 @@ typedef struct st_partial_product_job {
     const float* packed_w; int w_kbs; int kb0; int KB;
     st_t16_view x;
     int N;
-    int S;          /* 1: one workgroup per tile pair, part (B, N).  2: FIVE workgroups per FOUR tile pairs (N % 128 == 0; N / 32 * 5 / 4
-                     * workgroups, e.g. 160 for a 4096-row cell: the compute units a pq / fin launch leaves idle), every tile pair's reduction
-                     * cut once -- part (2, B, N), the consumer adds slab 0 + slab 1 */
     float* part;
 } st_partial_product_job;
 /* st_query_attn_fin_fwd with such a job beside it in the same launch (every workgroup on a compute unit of its own: (A / 16) ceil(B / 16) +
@@ -773,7 +770,7 @@ typedef struct st_decoder_io {
                                         * input runs INSIDE the proj (+) gate (+) prenet-layer-1 launch (st_attn_pre_job.p2_*), its operand
                                         * handed over as granules -- one launch less per free-running decode step.  Zeroed by the callee per
                                         * forward; time-outs go to handoff_status */
-    float* gate_part;                  /* optional (2, B, 4 D) scratch: in the one-launch pq + fin form (pq_granules) with 16 < B <= 32 the decoder
+    float* gate_part;                  /* optional (B, 4 D) scratch: in the one-launch pq + fin form (pq_granules) with 16 < B <= 32 the decoder
                                         * cell's gate products over the operands that are known BEFORE the attention runs -- W_hh_d h_d(t-1) and
                                         * W_ih_d[:, E:] AdaIN(h_q(t)), 2048 of the cell's 2560 reduction columns at C2 -- ride beside the pq / fin
                                         * launch on compute units it leaves idle (st_query_attn_fin_part_fwd); the cell launch then reduces the

@@ -222,7 +222,7 @@ SIGNATURES = {
     'st_untile_rows': [C.POINTER(StT16View), P, I, I, I, P],
     'st_lstm_cell_packed_fwd': [P, C.POINTER(StT16View), I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
                                 P, I, P, P, P, C.POINTER(StT16View), I, I, P],
-    'st_lstm_cell_packed_part_fwd': [P, I, C.POINTER(StT16View), I, P, I, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
+    'st_lstm_cell_packed_part_fwd': [P, I, C.POINTER(StT16View), I, P, P, P, P, I, P, C.POINTER(StT16View), C.POINTER(StT16View),
                                      P, I, P, I, I, P],
     'st_lstm_cell_packed_pair_fwd': [C.POINTER(StLstmCellPackedJob), C.POINTER(StLstmCellPackedJob), P],
     'st_skinny_linear_packed_fwd': [P, C.POINTER(StT16View), I, P, I, P, I, P, I, C.POINTER(StT16View), I, P, I, I,

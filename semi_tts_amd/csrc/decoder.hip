@@ -286,9 +286,6 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     st_partial_product_job pj_d;
     memset(&pj_d, 0, sizeof(pj_d));
     pj_d.packed_w = io->packed + pl.d; pj_d.w_kbs = sv.d_kbs; pj_d.kb0 = sv.d_ha; pj_d.KB = sv.d_kbs - sv.d_ha; pj_d.N = 4 * D; pj_d.part = io->gate_part;
-    // five workgroups per four tile pairs where that fills exactly what the pq / fin launch leaves idle (160 of 256 units at C2), else one per pair
-    pj_d.S = ((4 * D / 32) % 4 == 0 && (A / 16) * ((B + 15) / 16) + B * fin_parts + (4 * D / 32) / 4 * 5 <= st_device_cus() &&
-              !(getenv("ST_SPLIT_FORM") && atoi(getenv("ST_SPLIT_FORM")) == 1)) ? 2 : 1;
     for (int t = 0; t < steps; ++t) {
         float* xq = io->xq_tape + (size_t)t * sv.q_floats;
         float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
@@ -406,7 +403,7 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
             if (rc) return rc;
         }
         if (split_d && !ST_SKIPPED(3) && !(split_hosted && (ST_SKIPPED(1) || ST_SKIPPED(2))))
-            rc = st_lstm_cell_packed_part_fwd(io->packed + pl.d, sv.d_kbs, &xd_v, 16 * sv.d_ha, io->gate_part, pj_d.S, w->d_b_ih, w->d_b_hh,
+            rc = st_lstm_cell_packed_part_fwd(io->packed + pl.d, sv.d_kbs, &xd_v, 16 * sv.d_ha, io->gate_part, w->d_b_ih, w->d_b_hh,
                                               io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                               &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                               io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr, B, D, stream);

@@ -206,7 +206,7 @@ struct PkArgs {
     unsigned long long* gran3;
     // optional (LSTM cell, 2-D tiled form): a slab (B, N) of a partial product of the SAME weight rows over the k-blocks this launch does
     // not reduce (pk_part_body of an earlier launch, st_query_attn_fin_part_fwd), added to the gates
-    const float* part; int part_S;
+    const float* part;
 };
 
 // MODE 2: a linear whose output columns [n0, n0 + H) are dh of an LSTM cell -- the pointwise half of the cell's backward step
@@ -598,16 +598,12 @@ __device__ __forceinline__ void pk_lstm_rt2_body(const f32x4* wp, const f32x4* x
     const bool e_on = tid < RT * NB * 64 && eb < B;
     float e_bi[4] = {0.f, 0.f, 0.f, 0.f}, e_bh[4] = {0.f, 0.f, 0.f, 0.f};
     float e_c = 0.f, e_m = 1.f, e_s = 0.f, e_mu = 0.f;
-    f32x4 e_p = {0.f, 0.f, 0.f, 0.f}, e_p1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 e_p = {0.f, 0.f, 0.f, 0.f};
     const float* dummy = reinterpret_cast<const float*>(wp);
     auto epi_prefetch = [&]() __attribute__((always_inline)) {
         if (e_on) {
             // the partial gates of the k-blocks an earlier launch reduced: (batch row, the 4 gate rows of hidden unit u) -- pk_part_body's layout
-            if (a.part) {
-                const float* pp = a.part + (size_t)eb * (4 * H) + (size_t)(tile0 + e_rt) * 16 + 4 * (lane >> 4);
-                e_p = st_ld4(pp);
-                e_p1 = st_ld4(pp + (a.part_S > 1 ? (size_t)B * 4 * H : 0));
-            }
+            if (a.part) e_p = st_ld4(a.part + (size_t)eb * (4 * H) + (size_t)(tile0 + e_rt) * 16 + 4 * (lane >> 4));
             const float* pbi = a.b_ih ? a.b_ih + u : dummy;
             const float* pbh = a.b_hh ? a.b_hh + u : dummy;
 #pragma unroll
@@ -650,10 +646,7 @@ __device__ __forceinline__ void pk_lstm_rt2_body(const f32x4* wp, const f32x4* x
         s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
     }
     if (eb >= B) return;
-    if (a.part) {
-        s[0] += e_p[0]; s[1] += e_p[1]; s[2] += e_p[2]; s[3] += e_p[3];
-        if (a.part_S > 1) { s[0] += e_p1[0]; s[1] += e_p1[1]; s[2] += e_p1[2]; s[3] += e_p1[3]; }
-    }
+    if (a.part) { s[0] += e_p[0]; s[1] += e_p[1]; s[2] += e_p[2]; s[3] += e_p[3]; }
     float e_b[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) e_b[r] = (a.b_ih ? e_bi[r] : 0.0f) + (a.b_hh ? e_bh[r] : 0.0f);
@@ -794,11 +787,13 @@ struct PkPartArgs {
     float* part;                    // (S, B, N)
 };
 
-// one segment: tile pair tp, k-blocks [kb_lo, kb_lo + KBs), written to slab sp
 template <int KW, int TRIP>
-__device__ __forceinline__ void pk_part_seg(const PkPartArgs& p, const int tp, const int kb_lo, const int KBs, const int sp, f32x4* red) {
+__device__ __forceinline__ void pk_part_body(const PkPartArgs& p, const int j, f32x4* red) {
     constexpr int RT = 2, NB = 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tp = p.N >> 5;
+    const int sp = j / n_tp, tp = j - sp * n_tp;           // the splits of a tile pair are n_tp workgroups apart
+    const int KBs = p.KB / p.S, kb_lo = sp * KBs;
     __amdgpu_buffer_rsrc_t rw[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -867,32 +862,6 @@ __device__ __forceinline__ void pk_part_seg(const PkPartArgs& p, const int tp, c
     const int b = e_bt * 16 + (lane & 15);
     const int n0 = (tp * RT + e_rt) * 16 + 4 * (lane >> 4);       // the lane's 4 consecutive outputs of batch row b
     if (b < p.B) *reinterpret_cast<f32x4*>(p.part + ((size_t)sp * p.B + b) * p.N + n0) = sm;
-}
-
-template <int KW, int TRIP>
-__device__ __forceinline__ void pk_part_body(const PkPartArgs& p, const int j, f32x4* red) {
-    const int n_tp = p.N >> 5;
-    const int sp = j / n_tp, tp = j - sp * n_tp;           // the splits of a tile pair are n_tp workgroups apart
-    const int KBs = p.KB / p.S;
-    pk_part_seg<KW, TRIP>(p, tp, sp * KBs, KBs, sp, red);
-}
-
-// FIVE workgroups per FOUR tile pairs (N / 32 * 5 / 4 workgroups: 160 for a 4096-row cell -- what the pq / fin launch leaves idle of 256
-// compute units): the 4 KB (tile pair, k-block) units of a group are dealt out in five contiguous runs, so a workgroup works on the end of
-// one tile pair's reduction and the beginning of the next one's.  Every tile pair is covered by exactly two runs: the one that starts at
-// k-block 0 writes slab 0, the one that ends at KB slab 1 -- the consumer adds slab 0 + slab 1 (fixed order).
-template <int KW, int TRIP>
-__device__ __forceinline__ void pk_part5_body(const PkPartArgs& p, const int j, f32x4* red) {
-    const int g = j / 5, w = j - g * 5;
-    const int U = 4 * p.KB;
-    const int start = (w * U) / 5, end = ((w + 1) * U) / 5;
-    const int tpa = start / p.KB, kba = start - tpa * p.KB;
-    const int enda = min(end, (tpa + 1) * p.KB);
-    pk_part_seg<KW, TRIP>(p, g * 4 + tpa, kba, enda - start, kba == 0 ? 0 : 1, red);
-    if (enda < end) {
-        __syncthreads();                                   // (the reduction buffer is reused)
-        pk_part_seg<KW, TRIP>(p, g * 4 + tpa + 1, 0, end - enda, 0, red);
-    }
 }
 
 // y(b, n0 .. n0+3) = part[0] + part[1] + ... (split order), then -- for the columns [pw.n0, pw.n0 + pw.H) -- the pointwise LSTM backward
@@ -998,13 +967,6 @@ __global__ __launch_bounds__(KW * 64) void pk_part_hist_kernel(const PkPartArgs 
     const int i = blockIdx.x;
     if (i < n_h) { ab_hist_body(hist, i, pk_dyn_lds); return; }
     pk_part_body<KW, TRIP>(p, i - n_h, red);
-}
-
-// the five-per-four form on its own (the decode loop's two-launch pq / fin form)
-template <int KW, int TRIP>
-__global__ __launch_bounds__(KW * 64) void pk_part5_kernel(const PkPartArgs p) {
-    __shared__ f32x4 red[KW * 4 * 64];
-    pk_part5_body<KW, TRIP>(p, blockIdx.x, red);
 }
 
 // the partial product on its own (no attention backward beside it)
@@ -1262,7 +1224,6 @@ __global__ __launch_bounds__(KW * 64) void pk_attnfin_part_kernel(const f32x4* w
         pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
     }
     else if (i < n_att) at_body<true, 2, AT_THREADS, true>(t, i - n_lin, pk_dyn_lds);
-    else if (p.S == 2) pk_part5_body<KW, 2>(p, i - n_att, reinterpret_cast<f32x4*>(pk_dyn_lds));
     else pk_part_body<KW, 2>(p, i - n_att, reinterpret_cast<f32x4*>(pk_dyn_lds));
 }
 
@@ -1538,7 +1499,7 @@ static int lstm_cell_packed_impl(const float* packed_w, const st_t16_view* x, in
                                  const st_t16_view* h_dst0, const st_t16_view* h_dst1,
                                  float* c_out, int ldc, float* gates_out,
                                  const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
-                                 int B, int H, int w_kbs, const float* part, int part_S, void* stream) {
+                                 int B, int H, int w_kbs, const float* part, void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(B > 0 && H > 0 && H % 4 == 0 && c_out && h_dst0 && h_dst0->base, "st_lstm_cell_packed_fwd: bad arguments");
     PkArgs a;
@@ -1548,7 +1509,7 @@ static int lstm_cell_packed_impl(const float* packed_w, const st_t16_view* x, in
     if (part) {      // K covers the leading k-blocks only; the products over the others arrive as a slab (2-D tiled form, B = 17..32)
         ST_CHECK_ARG(pk_rt2_shape(B, H / 4) && ((B + 15) >> 4) == 2 && w_kbs >= a.KB && st_aligned16(part),
                      "st_lstm_cell_packed_part_fwd: needs B = 17..32, an even number of row tiles, w_kbs >= K / 16 and a 16-byte aligned slab");
-        a.part = part; a.part_S = part_S; a.w_kbs = w_kbs;
+        a.part = part; a.w_kbs = w_kbs;
     }
     a.B = B; a.N = 4 * H; a.H = H;
     a.b_ih = b_ih; a.b_hh = b_hh;
@@ -1567,17 +1528,17 @@ extern "C" int st_lstm_cell_packed_fwd(const float* packed_w, const st_t16_view*
                                        const float* ada_std, const float* ada_mean, const st_t16_view* hadapt_dst,
                                        int B, int H, void* stream) {
     return lstm_cell_packed_impl(packed_w, x, K, b_ih, b_hh, c_prev, ldc_prev, mask, h_dst0, h_dst1, c_out, ldc, gates_out, ada_std, ada_mean,
-                                 hadapt_dst, B, H, 0, nullptr, 0, stream);
+                                 hadapt_dst, B, H, 0, nullptr, stream);
 }
 
-extern "C" int st_lstm_cell_packed_part_fwd(const float* packed_w, int w_kbs, const st_t16_view* x, int K, const float* part, int S,
+extern "C" int st_lstm_cell_packed_part_fwd(const float* packed_w, int w_kbs, const st_t16_view* x, int K, const float* part,
                                             const float* b_ih, const float* b_hh,
                                             const float* c_prev, int ldc_prev, const float* mask,
                                             const st_t16_view* h_dst0, const st_t16_view* h_dst1,
                                             float* c_out, int ldc, float* gates_out, int B, int H, void* stream) {
-    ST_CHECK_ARG(part && (S == 1 || S == 2), "st_lstm_cell_packed_part_fwd: null slab, or S not 1 / 2");
+    ST_CHECK_ARG(part, "st_lstm_cell_packed_part_fwd: null slab");
     return lstm_cell_packed_impl(packed_w, x, K, b_ih, b_hh, c_prev, ldc_prev, mask, h_dst0, h_dst1, c_out, ldc, gates_out, nullptr, nullptr,
-                                 nullptr, B, H, w_kbs, part, S, stream);
+                                 nullptr, B, H, w_kbs, part, stream);
 }
 
 static int pk_lstm_fill(PkArgs& a, const st_lstm_cell_packed_job* j, const char* who) {
@@ -1710,15 +1671,14 @@ static int query_attn_fin_impl(const float* packed_wq, const st_t16_view* h_q, i
         ST_CHECK_ARG(pj->packed_w && pj->x.base && pj->part && pj->KB > 0 && pj->kb0 >= 0 && pj->kb0 + pj->KB <= pj->w_kbs &&
                      pj->x.kb0 + pj->KB <= pj->x.kb_stride && B > 16 && B <= 32 && pj->N > 0 && pj->N % 32 == 0 && st_aligned16(pj->packed_w) &&
                      st_aligned16(pj->x.base) && st_aligned16(pj->part), "st_query_attn_fin_part_fwd: bad partial product (B = 17..32, N %% 32 == 0)");
-        ST_CHECK_ARG(pj->S == 1 || (pj->S == 2 && (pj->N >> 5) % 4 == 0), "st_query_attn_fin_part_fwd: S = 1, or 2 with N %% 128 == 0");
-        const int n_part = pj->S == 2 ? (pj->N >> 5) / 4 * 5 : pj->N >> 5;
+        const int n_part = pj->N >> 5;
         ST_CHECK_ARG(n_lin + n_fin + n_part <= st_device_cus(), "st_query_attn_fin_part_fwd: %d + %d + %d workgroups do not fit the device at once",
                      n_lin, n_fin, n_part);
         PkPartArgs pp;
         memset(&pp, 0, sizeof(pp));
         pp.w = reinterpret_cast<const f32x4*>(pj->packed_w) + (size_t)pj->kb0 * 64; pp.w_kbs = pj->w_kbs;
         pp.x = reinterpret_cast<const f32x4*>(pj->x.base) + (size_t)pj->x.kb0 * 64; pp.x_kbs = pj->x.kb_stride;
-        pp.KB = pj->KB; pp.S = pj->S; pp.B = B; pp.N = pj->N; pp.part = pj->part;
+        pp.KB = pj->KB; pp.S = 1; pp.B = B; pp.N = pj->N; pp.part = pj->part;
         if (lds < sizeof(f32x4) * KW * 4 * 64) lds = sizeof(f32x4) * KW * 4 * 64;        // (the part workgroups' reduction buffer lives in the dynamic region)
         auto kernp = pk_attnfin_part_kernel<1, KW, PK_TRIP_SMALL>;
         static size_t configured_p = 0;
@@ -1764,10 +1724,7 @@ extern "C" int st_partial_product_fwd(const st_partial_product_job* pj, int B, v
     memset(&pp, 0, sizeof(pp));
     pp.w = reinterpret_cast<const f32x4*>(pj->packed_w) + (size_t)pj->kb0 * 64; pp.w_kbs = pj->w_kbs;
     pp.x = reinterpret_cast<const f32x4*>(pj->x.base) + (size_t)pj->x.kb0 * 64; pp.x_kbs = pj->x.kb_stride;
-    ST_CHECK_ARG(pj->S == 1 || (pj->S == 2 && (pj->N >> 5) % 4 == 0), "st_partial_product_fwd: S = 1, or 2 with N %% 128 == 0");
-    pp.KB = pj->KB; pp.S = pj->S; pp.B = B; pp.N = pj->N; pp.part = pj->part;
-    if (pj->S == 2) hipLaunchKernelGGL((pk_part5_kernel<8, 2>), dim3((pj->N >> 5) / 4 * 5), dim3(8 * 64), 0, (hipStream_t)stream, pp);
-    else
+    pp.KB = pj->KB; pp.S = 1; pp.B = B; pp.N = pj->N; pp.part = pj->part;
     hipLaunchKernelGGL((pk_part_kernel<8, 2>), dim3(pj->N >> 5), dim3(8 * 64), 0, (hipStream_t)stream, pp);
     ST_LAUNCH_CHECK();
     return 0;

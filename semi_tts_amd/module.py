@@ -647,7 +647,7 @@ class Decoder(nn.Module):
             if self.split_gates and not keep_tapes and 16 < B <= 32 and L < self.attn_split_min_len:
                 # the decoder cell's gate products over [AdaIN(h_q(t)) | h_d(t-1)] beside the pq / fin launch (st_decoder_io.gate_part; in the
                 # other forms of the attention step a launch of its own: the same arithmetic whatever the form)
-                tapes['gate_part'] = torch.empty(2, B, 4 * D, **f32)
+                tapes['gate_part'] = torch.empty(B, 4 * D, **f32)
                 io.gate_part = ops._p(tapes['gate_part'])
             if self.attn_pq_in_fin and not keep_tapes:
                 # query projection + attention fin part as ONE launch per step (st_query_attn_fin_fwd): pq is handed over inside

@@ -199,7 +199,9 @@ class TtsTrainer(BaseSolver):
         loss.backward(); [all-reduce over ranks]; clip_grad_norm_(5.0); optimizer.step()
 
     Forward, loss, backward, gradient clipping and Adam all run on the HIP kernels (semi_tts_amd/autograd.py,
-    semi_tts_amd/optim.py).  The ASR/CTC half of the reference's step is outside the hot path."""
+    semi_tts_amd/optim.py).  The paired TTS branch alone (`main.py --tts-only`, `bench.py --workload train`); the whole loop of
+    the reference -- the alternating speech <-> text cycles with the CTC speech encoder, codebook and run-length merge -- is
+    VqvaeTrainer below, main.py's default mode."""
     GRAD_CLIP = 5.0
     STATIC_GRAPH = True      # the paired TTS step produces the same gradients in the same order every step (GradReducer: one hook per bucket)
     async_stats = False      # True: train_step never waits for the GPU -- LazyStats, NaN steps skipped on the device (optim.FusedAdam guard)

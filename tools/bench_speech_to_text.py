@@ -56,6 +56,18 @@ def main():
     with torch.no_grad():
         out['ms_train_mode_no_grad'] = timed(lambda: m.speech_to_text(pair[1], un[1]), a.steps)
     out['ms_train_mode_autograd_fwd'] = timed(lambda: m.speech_to_text(pair[1], un[1]), a.steps)
+    # forward + backward of the half on its own: random gradients into everything the cycle reads (posteriors of both parts, paired latents,
+    # merged unpaired latents); parameter gradients are dropped after each pass
+    g = torch.Generator(device=dev).manual_seed(3)
+    r = lambda t: torch.rand(t.shape, device=dev, generator=g)
+
+    def fwd_bwd():
+        pp, pl, up, ul, _, _, _ = m.speech_to_text(pair[1], un[1])
+        outs = [t for t in (pp, pl, up, ul) if t is not None and t.requires_grad]
+        torch.autograd.backward(outs, [r(t) for t in outs])
+        for p_ in m.parameters():
+            p_.grad = None
+    out['ms_train_fwd_bwd'] = timed(fwd_bwd, a.steps)
     Bt, Ta = a.batch_size + a.unpair_batch_size, a.frames
     sys.path.insert(0, ROOT)
     from bench import cycle_flops, MFMA_F32_PEAK_TFLOPS

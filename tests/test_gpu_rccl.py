@@ -44,3 +44,14 @@ def test_c4_step_through_rccl_world_size_one_equals_plain_step():
     assert rs['grad_norm_rel_diff'] <= 1e-5, rs
     assert res['max_over_ranks'] == 1.25
     assert rc == 0 and res['ok'], (res, err[-2000:])
+
+
+def test_cycle_steps_through_rccl_world_size_one_equal_the_plain_trainer():
+    """config 4 as the reference trains it (VqvaeTrainer on the multi-speaker configuration): four alternating cycle steps through the
+    dynamic GradReducer with RCCL all-reduces at world size 1 reproduce the plain trainer bit for bit; with SyncBN (12 BatchNorm gathers in
+    a text-first step: speech encoder 6, text encoder 3, CBHG bank 1, projections 2) to one rounding."""
+    rc, res, err = _run(['--cycle', '--batch-size', '8', '--frames', '64'])
+    assert res['backend'] == 'nccl' and res['reducer_attached']
+    assert res['statistics_equal'] and res['gradients_bitwise_equal'] and res['updated_weights_bitwise_equal'], res
+    assert res['syncbn_collectives_last_step']['syncbn_fwd'] == 12 and res['syncbn_loss_max_rel_diff'] <= 1e-5, res
+    assert rc == 0 and res['ok'], (res, err[-2000:])

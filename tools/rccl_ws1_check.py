@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--batch-size', type=int, default=32)
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--backend', default='nccl')
+    ap.add_argument('--cycle', action='store_true', help='the VqvaeTrainer cycles (config 3 / 4 as the reference trains them) instead of the paired TTS step')
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -52,6 +53,8 @@ def main():
     dist.init_process_group(a.backend, rank=0, world_size=1, **kw)
     t_init = time.perf_counter() - t0
     config = yaml.safe_load(open(os.path.join(ROOT, 'config', 'semi-multi-spkr-paired-data.yaml')))
+    if a.cycle:
+        return cycle_main(a, config, dev)
 
     def run(force, syncbn):
         parallel.force_collectives(force)
@@ -124,6 +127,57 @@ def main():
           and res['reducer_syncbn']['running_stats_max_rel_diff'] <= 1e-6
           and res['reducer_syncbn']['grad_norm_rel_diff'] <= 1e-5
           and t_max == 1.25)
+    res['ok'] = bool(ok)
+    print(json.dumps(res))
+    sys.stdout.flush()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def cycle_main(a, config, dev):
+    """config 4 as the reference trains it (main.py:61-63: VqvaeTrainer on the multi-speaker configuration): four alternating cycle steps --
+    speech-first with the unpaired batch, text-first -- through the dynamic GradReducer (the cycles' graphs depend on the data) with the
+    all-reduces on RCCL at world size 1: losses, gradient norms, every gradient and every weight bitwise those of the plain trainer; with
+    SyncBN on top (speech encoder's six BatchNorms included) to one rounding."""
+    import torch
+    import torch.distributed as dist
+    from semi_tts_amd import parallel
+    from semi_tts_amd.solver import VqvaeTrainer
+
+    def run(force, syncbn):
+        parallel.force_collectives(force)
+        paras = Namespace(batch_size=a.batch_size, frames=a.frames, n_batches=1, seed=0, verbose=False, max_step=10 ** 9, load=None, n_spkr=109)
+        tr = VqvaeTrainer(config, paras, 'train').load_data().set_model()
+        parallel.sync_batchnorm(syncbn)
+        pair, unpair = tr.fetch_data('pair_iter'), tr.fetch_data('unpair_iter')
+        torch.manual_seed(77)
+        tr.step = 2
+        sts = []
+        for _ in range(4):
+            st = tr.cycle_step(pair, unpair if tr.cycle_kind(tr.step)[1] else None)
+            sts.append({k: float(st[k]) for k in ('loss', 'grad_norm', 'asr_loss', 'tts_loss')})
+        torch.cuda.synchronize()
+        counts = parallel.collective_counts()
+        out = dict(sts=sts, counts=counts, reducer=tr.reducer is not None,
+                   grads={k: p.grad.detach().clone() for k, p in tr.model.named_parameters() if p.grad is not None},
+                   weights={k: p.detach().clone() for k, p in tr.model.named_parameters()})
+        if tr.reducer is not None:
+            out['stats'] = dict(tr.reducer.stats)
+            tr.reducer.close()
+        return out
+
+    plain, red, full = run(False, False), run(True, False), run(True, True)
+    bitwise = lambda x, y: set(x) == set(y) and all(torch.equal(x[k], y[k]) for k in x)
+    rel = max(abs(f['loss'] - p['loss']) / max(1.0, abs(p['loss'])) for f, p in zip(full['sts'], plain['sts']))
+    res = {'rccl_ranks': 1 if a.backend == 'nccl' else 0, 'backend': dist.get_backend(),
+           'workload': 'VqvaeTrainer.cycle_step x 4 (speech-first with the unpaired batch / text-first), B=%d + %d, %d frames, 109 speakers' % (a.batch_size, a.batch_size, a.frames),
+           'plain': plain['sts'], 'reducer_attached': red['reducer'], 'reducer_stats_last_step': red.get('stats'),
+           'statistics_equal': red['sts'] == plain['sts'],
+           'gradients_bitwise_equal': bitwise(red['grads'], plain['grads']), 'updated_weights_bitwise_equal': bitwise(red['weights'], plain['weights']),
+           'collectives_last_step': red['counts'], 'syncbn_collectives_last_step': full['counts'], 'syncbn_loss_max_rel_diff': rel}
+    # (text-first, the last step: 6 speech-encoder + 3 text-encoder + 1 bank + 2 projection BatchNorm gathers)
+    ok = (res['reducer_attached'] and res['statistics_equal'] and res['gradients_bitwise_equal'] and res['updated_weights_bitwise_equal']
+          and full['counts']['syncbn_fwd'] == 12 and full['counts']['syncbn_bwd'] == 12 and rel <= 1e-5)
     res['ok'] = bool(ok)
     print(json.dumps(res))
     sys.stdout.flush()

@@ -377,9 +377,10 @@ def event_timer(lib):
 # ===================================================================================== decode (c2 / c5)
 def lstm_probe(dec, dev, Bsz):
     """Roofline probe of the dominant kernel (the weight-streaming LSTM cell), measured with HIP events on the stream the
-    kernel runs on: the two launches of a decode step (query LSTM K=1792, decoder LSTM K=2560) alternate exactly as in the
-    loop, so the 75.5 MB of weights cycle through the caches as they do there.  Replayed from a hipGraph (as in the decode
-    loop) so the measurement sees device time, not the Python/ctypes issue rate."""
+    kernel runs on: the two launches of a decode step alternate exactly as in the loop -- query LSTM K=1792; decoder LSTM
+    K=2560, or (round 6, 16 < B <= 32: Decoder.split_gates) its 512 context columns + the slab of the 2048 columns that rode
+    beside the pq / fin launch -- so the weights cycle through the caches as they do there.  Replayed from a hipGraph (as in
+    the decode loop) so the measurement sees device time, not the Python/ctypes issue rate."""
     import torch
     from semi_tts_amd import _lib, ops
     lib = _lib.load()
@@ -395,9 +396,15 @@ def lstm_probe(dec, dev, Bsz):
     ho, co = torch.zeros(ops.t16_floats(Bsz, Q), **f32), torch.empty(Bsz, Q, **f32)
     xq_v, xd_v, ho_v = ops.t16_view(xq, K=Kq), ops.t16_view(xd, K=Kd), ops.t16_view(ho, K=Q)
 
+    split = bool(getattr(dec, 'split_gates', False)) and 16 < Bsz <= 32 and Q % 16 == 0 and D % 16 == 0 and E % 16 == 0
+    slab = torch.randn(Bsz, 4 * D, **f32) if split else None
+
     def pair():
         ops.lstm_cell_packed(pk_q, xq_v, Kq, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh, c_q, ho_v, co, Bsz, Q)
-        ops.lstm_cell_packed(pk_d, xd_v, Kd, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
+        if split:
+            ops.lstm_cell_packed_part(pk_d, Kd // 16, xd_v, E, slab, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
+        else:
+            ops.lstm_cell_packed(pk_d, xd_v, Kd, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
 
     inner, outer = 50, 10
     g2 = ops.Graph()
@@ -412,8 +419,9 @@ def lstm_probe(dec, dev, Bsz):
         for _ in range(outer):
             g2.launch()
     avg_us = tm.ms * 1e3 / (2 * inner * outer)
-    alg = 0.5 * (lstm_algorithmic_bytes(Bsz, Q, Kq) + lstm_algorithmic_bytes(Bsz, D, Kd))
-    flops = 0.5 * (2.0 * Bsz * 4 * Q * Kq + 2.0 * Bsz * 4 * D * Kd)
+    Kd_cell = E if split else Kd                        # (what the decoder CELL launch reduces; + the slab it reads)
+    alg = 0.5 * (lstm_algorithmic_bytes(Bsz, Q, Kq) + lstm_algorithmic_bytes(Bsz, D, Kd_cell) + (4.0 * Bsz * 4 * D if split else 0.0))
+    flops = 0.5 * (2.0 * Bsz * 4 * Q * Kq + 2.0 * Bsz * 4 * D * Kd_cell)
     return avg_us, alg, flops
 
 
@@ -489,7 +497,10 @@ def bench_decode(args, rk):
             except (OSError, KeyError, ValueError):
                 continue
     step_bytes = decode_step_algorithmic_bytes(B, L, dec)
-    roof = {'bound': 'hbm', 'kernel': kernel_name_of_lstm(B),
+    split_on = bool(getattr(dec, 'split_gates', False)) and 16 < B <= 32
+    roof = {'bound': 'hbm', 'kernel': kernel_name_of_lstm(B) + ('; two launches per step: the query cell (K = 1792) and the decoder cell over its 512 context '
+                                                                 'columns + the slab of the 2048 columns that ride beside the pq / fin launch (pk_attnfin_part_kernel, '
+                                                                 '33.5 MB of weights on 128 compute units: the largest single launch of the step)' if split_on else ''),
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
             'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(avg_us, 3),

@@ -1486,6 +1486,14 @@ def lstm_cell_packed(packed_w, x_view, Kpad, b_ih, b_hh, c_prev, h_dst0, c_out, 
                                               stream_handle()), 'st_lstm_cell_packed_fwd')
 
 
+def lstm_cell_packed_part(packed_w, w_kbs, x_view, Kpad, part, b_ih, b_hh, c_prev, h_dst0, c_out, B, H, h_dst1=None, mask=None, gates_out=None):
+    """the cell over its LEADING Kpad columns + the slab `part` (B, 4H) of the products over the others (st_lstm_cell_packed_part_fwd);
+    w_kbs = k-blocks per row tile of the whole packed matrix"""
+    check(_lib.load().st_lstm_cell_packed_part_fwd(_p(packed_w), int(w_kbs), C.byref(x_view), int(Kpad), _p(part), _p(b_ih), _p(b_hh),
+                                                   _p(c_prev), H, _p(mask), C.byref(h_dst0), _vp(h_dst1), _p(c_out), H, _p(gates_out),
+                                                   int(B), int(H), stream_handle()), 'st_lstm_cell_packed_part_fwd')
+
+
 def skinny_linear_packed(packed_w, x_view, Kpad, B, N, y=None, y_dst=None, bias=None, act=None, mask=None,
                          n_split=0, y2=None, rep=0, n_split2=0, act2=None, mask2=None, y3_dst=None):
     check(_lib.load().st_skinny_linear_packed_fwd(

@@ -41,7 +41,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix peak (256 CUs x 256 F
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 # PMC pass of the dominant kernel (tools/gpu_pmc.sh -> tools/pmc_summary.py): HBM bytes per launch.  bench.py does not
 # measure this itself (PMC counters need their own rocprofv3 passes); the value is quoted WITH its source file.
-TRAFFIC_FILES = ('profiles/r05_pmc_hbm_traffic%s.json', 'profiles/r04_pmc_hbm_traffic%s.json', 'profiles/r03_pmc_hbm_traffic%s.json', 'profiles/r02_pmc_hbm_traffic%s.json', 'profiles/r01_pmc_hbm_traffic%s.json')
+TRAFFIC_FILES = ('profiles/r06_pmc_hbm_traffic%s.json', 'profiles/r05_pmc_hbm_traffic%s.json', 'profiles/r04_pmc_hbm_traffic%s.json', 'profiles/r03_pmc_hbm_traffic%s.json', 'profiles/r02_pmc_hbm_traffic%s.json', 'profiles/r01_pmc_hbm_traffic%s.json')
 
 
 def decode_step_algorithmic_bytes(Bsz, Lt, dec):
@@ -407,18 +407,40 @@ def lstm_probe(dec, dev, Bsz):
             ops.lstm_cell_packed(pk_d, xd_v, Kd, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
 
     inner, outer = 50, 10
-    g2 = ops.Graph()
-    pair()
-    with g2.capture():
-        for _ in range(inner):
-            pair()
-    for _ in range(3):
-        g2.launch()
-    torch.cuda.synchronize()
-    with event_timer(lib)() as tm:
-        for _ in range(outer):
+
+    def timed_graph(body):
+        g2 = ops.Graph()
+        body()
+        with g2.capture():
+            for _ in range(inner):
+                body()
+        for _ in range(3):
             g2.launch()
-    avg_us = tm.ms * 1e3 / (2 * inner * outer)
+        torch.cuda.synchronize()
+        with event_timer(lib)() as tm:
+            for _ in range(outer):
+                g2.launch()
+        return tm.ms * 1e3 / (inner * outer)
+
+    if split:
+        # Since the split the two cell launches of a step move 38 MB of weights -- alone they would cycle inside the 32 MB of L2, which they do
+        # not in the loop (33.5 MB of decoder weights stream through the pq / fin launch in between, and 4 MB of memory tiles).  The probe
+        # therefore streams a 48 MB fill between the cells (the weights then come from the Infinity Cache, as in situ) and takes the fills'
+        # own time, measured the same way, off again.
+        wash = torch.empty(12 << 20, **f32)
+
+        def pair_washed():
+            ops.lstm_cell_packed(pk_q, xq_v, Kq, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh, c_q, ho_v, co, Bsz, Q)
+            ops.fill_(wash, 0.0)
+            ops.lstm_cell_packed_part(pk_d, Kd // 16, xd_v, E, slab, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
+            ops.fill_(wash, 0.0)
+
+        def wash_only():
+            ops.fill_(wash, 0.0)
+            ops.fill_(wash, 0.0)
+        avg_us = (timed_graph(pair_washed) - timed_graph(wash_only)) / 2
+    else:
+        avg_us = timed_graph(pair) / 2
     Kd_cell = E if split else Kd                        # (what the decoder CELL launch reduces; + the slab it reads)
     alg = 0.5 * (lstm_algorithmic_bytes(Bsz, Q, Kq) + lstm_algorithmic_bytes(Bsz, D, Kd_cell) + (4.0 * Bsz * 4 * D if split else 0.0))
     flops = 0.5 * (2.0 * Bsz * 4 * Q * Kq + 2.0 * Bsz * 4 * D * Kd_cell)

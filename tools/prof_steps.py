@@ -12,11 +12,13 @@ def code(n):
     if 'pk_kernel<1' in n: return 'l'
     if 'pk_attnpre_kernel' in n: return 'P'
     if 'pk_attnfin_kernel' in n: return 'F'
+    if 'pk_attnfin_part_kernel' in n: return 'G'      # pq + fin with the decoder cell's hosted gate product (round 6)
     if 'at_kernel' in n: return 'A'
     return 'x'
 seq = [(code(n), s, e) for n, s, e in rows]
 text = ''.join(c for c, _, _ in seq)
-for pat, names in (('LFLPl', ['LSTM_q', 'pq + attn fin part (one launch)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
+for pat, names in (('LGLPl', ['LSTM_q', 'pq + attn fin part + hosted decoder-gate product (one launch)', 'LSTM_d (context columns + slab)', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
+                   ('LFLPl', ['LSTM_q', 'pq + attn fin part (one launch)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
                    ('LlALPl', ['LSTM_q', 'pq', 'attn (fin part)', 'LSTM_d', 'proj+pre0 (+ attn pre part of t+1)', 'pre1']),
                    ('LlALll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj+pre0', 'pre1']),
                    ('LlALlll', ['LSTM_q', 'pq', 'attn', 'LSTM_d', 'proj', 'pre0', 'pre1'])):

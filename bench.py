@@ -422,35 +422,10 @@ def lstm_probe(dec, dev, Bsz):
                 g2.launch()
         return tm.ms * 1e3 / (inner * outer)
 
-    if split:
-        # Since the split the two cell launches of a step move 38 MB of weights -- alone they would cycle inside the 32 MB of L2, which they do
-        # not in the loop (33.5 MB of decoder weights stream through the pq / fin launch in between, and 4 MB of memory tiles).  The probe
-        # therefore streams a 48 MB fill between the cells (the weights then come from the Infinity Cache, as in situ) and takes the fills'
-        # own time, measured the same way, off again.
-        wash = torch.empty(12 << 20, **f32)
-        xq_nat, xd_nat, slab2 = torch.randn(Bsz, Kq, **f32), torch.randn(Bsz, Kd, **f32), torch.randn(Bsz, 4 * D, **f32)
-
-        def produce():      # the cells' operands are written by the launch before them, on other compute units (in the loop: prenet-2 / attention)
-            ops.tile_rows(xq_nat, out=xq)
-            ops.fill_(wash, 0.0)
-
-        def produce_d():
-            ops.tile_rows(xd_nat, out=xd)
-            ops.copy2d(slab, slab2, Bsz, 4 * D)
-            ops.fill_(wash, 0.0)
-
-        def pair_washed():
-            produce()
-            ops.lstm_cell_packed(pk_q, xq_v, Kq, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh, c_q, ho_v, co, Bsz, Q)
-            produce_d()
-            ops.lstm_cell_packed_part(pk_d, Kd // 16, xd_v, E, slab, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
-
-        def wash_only():
-            produce()
-            produce_d()
-        avg_us = (timed_graph(pair_washed) - timed_graph(wash_only)) / 2
-    else:
-        avg_us = timed_graph(pair) / 2
+    # (washing the caches between the cells, or having their operands written by a launch just before them, does not change the probe:
+    # 5.75-5.79 us either way; in situ the two launches take 7.4 + 5.2 us (kernel trace medians): the first loads of a launch that follows
+    # another one's stores cost more than back-to-back launches of the same kernel show)
+    avg_us = timed_graph(pair) / 2
     Kd_cell = E if split else Kd                        # (what the decoder CELL launch reduces; + the slab it reads)
     alg = 0.5 * (lstm_algorithmic_bytes(Bsz, Q, Kq) + lstm_algorithmic_bytes(Bsz, D, Kd_cell) + (4.0 * Bsz * 4 * D if split else 0.0))
     flops = 0.5 * (2.0 * Bsz * 4 * Q * Kq + 2.0 * Bsz * 4 * D * Kd_cell)

@@ -174,7 +174,8 @@ class GradReducer:
         self._hooks = {}
         self._active = False
         self._ctl = None                               # static graph under torch.distributed: the ranks' agreement about a step (finish / _settle)
-        self._ctl_pending = None
+        self._ctl_pending = []                         # agreements not yet acted on: (kind, value or ring slot, world, recorded order, steps waited)
+        self._ctl_used = False
         self._recorded_order = None
         self.stats = {'born_in_slot': 0, 'gathered': 0, 'zeroed': 0}      # of the last step (tests, bench)
         self._layout()
@@ -391,7 +392,8 @@ class GradReducer:
         # The promise is per rank, the bucket layout is not: every rank must change it in the same step or the next all-reduces differ in
         # size and order (advisor, round 5).  With a static graph every rank adds (violated, h, h^2) -- h a hash of the order its gradients
         # arrived in during the recorded pass -- to a three-double all-reduce behind the buckets; the result comes to the host on its own
-        # (pinned copy + event) and is looked at when the next step begins (_settle): nobody waits for the GPU in a regular step.
+        # (pinned copy + event) and is looked at when the SECOND step after it begins (_settle, CTL_DELAY): nobody waits for the GPU in a
+        # regular step.
         # A rank that saw a violation itself reads the sum now: only if EVERY rank saw one (a change of the graph that comes with the step
         # count, e.g. a teacher-forcing schedule) are this step's stray gradients reduced on their own -- a collective the other ranks
         # would not join otherwise.
@@ -423,8 +425,11 @@ class GradReducer:
                 for p in extra:
                     p.grad.mul_(1.0 / world)
         issued = sum(1 for l in self.launched if l)
-        self._recorded_order = list(self._fire_order) if recording else None
-        if self._ctl_pending is None:                  # no exchange (one process, or collectives off): decide here and now
+        if self._ctl_used:
+            self._ctl_used = False
+            self._ctl_pending[-1][3] = list(self._fire_order) if recording else None
+        else:                                          # no exchange (one process, or collectives off): decide here and now
+            self._recorded_order = list(self._fire_order) if recording else None
             self._decide(bool(self._violated), True, self._violated)
         return issued
 
@@ -439,10 +444,12 @@ class GradReducer:
         """all-reduce (violated, h, h^2) over the ranks; the sum goes to a pinned host buffer behind an event (read by _settle, or here
         when `wait`).  Returns the summed triple when it was read."""
         dev = self.flats[0].device
+        RING = 4
         if self._ctl is None or self._ctl.device != dev:
             self._ctl = torch.zeros(3, device=dev, dtype=torch.float64)
-            self._ctl_host = torch.zeros(3, dtype=torch.float64).pin_memory() if dev.type == 'cuda' else None
-            self._ctl_event = torch.cuda.Event() if dev.type == 'cuda' else None
+            self._ctl_host = torch.zeros(RING, 3, dtype=torch.float64).pin_memory() if dev.type == 'cuda' else None
+            self._ctl_events = [torch.cuda.Event() for _ in range(RING)] if dev.type == 'cuda' else None
+            self._ctl_slot = 0
         ctl = self._ctl
         ctl.zero_()
         if violated:
@@ -451,36 +458,48 @@ class GradReducer:
             ctl[1], ctl[2] = h, h * h
         all_reduce_sum_(ctl)
         self.stats['control'] = self.stats.get('control', 0) + 1
+        self._ctl_used = True
         if self._ctl_host is None:                     # CPU tensors (gloo tests): the collective was synchronous
-            self._ctl_pending = ('value', ctl.tolist(), world)
-            return self._ctl_pending[1]
-        self._ctl_host.copy_(ctl, non_blocking=True)
-        self._ctl_event.record()
-        self._ctl_pending = ('event', None, world)
+            val = ctl.tolist()
+            self._ctl_pending.append(['value', val, world, None, 0])
+            return val
+        slot = self._ctl_slot
+        self._ctl_slot = (slot + 1) % RING
+        self._ctl_host[slot].copy_(ctl, non_blocking=True)
+        self._ctl_events[slot].record()
+        self._ctl_pending.append(['event', slot, world, None, 0])
         if wait:
-            self._ctl_event.synchronize()
-            return self._ctl_host.tolist()
+            self._ctl_events[slot].synchronize()
+            return self._ctl_host[slot].tolist()
         return None
 
+    CTL_DELAY = 2        # device tensors: an agreement is acted on when the SECOND step after it begins -- its copy has long landed by then,
+                         # so the host, which runs about a step ahead of the GPU, never waits for it (acting one step later cost 0.5 ms per step)
+
     def _settle(self):
-        """at the beginning of a step: act on what the ranks exchanged at the end of the step before -- every rank reads the same sums and
+        """at the beginning of a step: act on what the ranks exchanged at the end of an earlier step -- every rank reads the same sums and
         changes (or keeps) its bucket layout in the same step"""
-        pend, self._ctl_pending = self._ctl_pending, None
-        if pend is None:
-            return
-        kind, val, world = pend
-        if kind == 'event':
-            self._ctl_event.synchronize()              # (finished long ago: a whole optimiser step has been issued since)
-            val = self._ctl_host.tolist()
-        viol, h, h2 = val
-        same_order = world * h2 == h * h               # (sum h)^2 == world * sum h^2  <=>  every rank recorded the same order; exact in doubles
-        why = 'reported by %d of %d ranks' % (int(viol), world) if viol > 0 else 'the ranks recorded different gradient orders'
-        self._decide(viol > 0, same_order, why)
+        keep = []
+        for ent in self._ctl_pending:
+            kind, val, world, order, age = ent
+            ent[4] = age = age + 1
+            if kind == 'event' and age < self.CTL_DELAY:
+                keep.append(ent)
+                continue
+            if kind == 'event':
+                self._ctl_events[val].synchronize()
+                val = self._ctl_host[val].tolist()
+            viol, h, h2 = val
+            same_order = world * h2 == h * h           # (sum h)^2 == world * sum h^2  <=>  every rank recorded the same order; exact in doubles
+            why = 'reported by %d of %d ranks' % (int(viol), world) if viol > 0 else 'the ranks recorded different gradient orders'
+            self._recorded_order = order
+            self._decide(viol > 0, same_order, why)
+        self._ctl_pending = keep
 
     def _decide(self, violated, same_order, why):
         if (violated or not same_order) and (self._sparse or self.static_graph):
             self._revert_dynamic(why)
-        elif self.static_graph and not self._sparse and self._recorded_order:
+        elif self.static_graph and not self._sparse and self._recorded_order and all(p in self.slot for p in self._recorded_order):
             self._rebuild_static()
         self._recorded_order = None
 

@@ -150,16 +150,27 @@ def test_eight_rank_sync_bn_training_with_unequal_shards_equals_single_process(t
     ref_stats = {k: v.cpu() for k, v in m.state_dict().items() if 'running_' in k}
     out = str(tmp_path / 'dp8.pt')
     import socket
-    with socket.socket() as sk:                 # a port nobody holds (fixed offsets collided once with a lingering listener)
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    ctx = mp.start_processes(_worker8, args=(8, port, out), nprocs=8, join=False, start_method='spawn')
-    deadline = time.time() + 240
-    while not ctx.join(timeout=5):
-        if time.time() > deadline:
-            for p in ctx.processes:
-                p.kill()
-            pytest.fail('eight data-parallel workers did not finish within 240 s')
+    from torch.multiprocessing.spawn import ProcessExitedException
+    for attempt in range(3):
+        with socket.socket() as sk:                 # a port nobody holds (fixed offsets collided once with a lingering listener)
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        ctx = mp.start_processes(_worker8, args=(8, port, out), nprocs=8, join=False, start_method='spawn')
+        deadline = time.time() + 240
+        try:
+            while not ctx.join(timeout=5):
+                if time.time() > deadline:
+                    for p in ctx.processes:
+                        p.kill()
+                    pytest.fail('eight data-parallel workers did not finish within 240 s')
+            break
+        except ProcessExitedException as e:
+            # Eight processes time-sharing ONE device is outside what this test is about (and what the runtime is tuned for): about one run
+            # in four a worker is killed by the driver (HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION while its code objects load).  A worker that
+            # dies by a SIGNAL is retried; a failed assertion inside a worker arrives as ProcessRaisedException and fails the test at once.
+            if attempt == 2:
+                raise
+            print('retrying after a worker was killed by a signal: %s' % e)
     got = torch.load(out)
     worst = 0.0
     for k, g in ref.items():

@@ -271,12 +271,15 @@ class _SplitPairFn(Function):
     @staticmethod
     def forward(ctx, x, Bp, Tp, Tu):
         ctx.dims = (tuple(x.shape), Bp, Tp, Tu)
+        ctx.set_materialize_grads(False)
         return x[:Bp, :Tp], x[Bp:, :Tu]
 
     @staticmethod
     def backward(ctx, da, db):
         shape, Bp, Tp, Tu = ctx.dims
         B, T, D = shape
+        if da is None and db is None:
+            return None, None, None, None
         dev = (da if da is not None else db).device
         dx = torch.empty(shape, device=dev, dtype=torch.float32)
         if Tp != T or Tu != T or da is None or db is None:
@@ -733,18 +736,22 @@ class _VqL2Fn(Function):
         ctx.save_for_backward(x, table, temp, p, idx)
         ctx.n_real, ctx.st_onehot = n_real, bool(st_onehot)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)          # (the text-first cycle without unpaired text never uses the quantised latents: no zero gradient for them)
         return p, out, idx
 
     @staticmethod
     def backward(ctx, dp, dlat, _didx):
         x, table, temp, p, idx = ctx.saved_tensors
         V, D = table.shape
-        x2, dl2 = _rows(x), _rows(dlat.contiguous())
+        if dp is None and dlat is None:
+            return None, None, None, None, None
+        x2 = _rows(x)
+        dl2 = _rows(dlat.contiguous()) if dlat is not None else None
         n = x2.shape[0]
         n_real = n if ctx.n_real is None else ctx.n_real
         tab = table.detach().contiguous()
-        dp2 = _rows(dp.contiguous())
-        if ctx.st_onehot:
+        dp2 = _rows(dp.contiguous()) if dp is not None else ops.zeros(n, V, device=x.device)
+        if ctx.st_onehot and dl2 is not None:
             dp2 = dp2 + ops.gemm(dl2, tab)                                           # d p_hard = dnew_latent E^T   (n, V)
         g, rs = ops.softmax_bwd(_rows(p), dp2, 1.0, temp, want_rowsum=True)
         dx = dtab = dtemp = None
@@ -752,7 +759,7 @@ class _VqL2Fn(Function):
             ge = ops.gemm(g, tab.t().contiguous())                                   # (n, D) = g E
             dx = ops.rowscale_combine(ge, 2.0, x2, rs.reshape(-1), -2.0, dl2).view(x.shape)
         if ctx.needs_input_grad[1]:
-            dtab = ops.scatter_add_rows(dl2, idx.reshape(-1), V)
+            dtab = ops.scatter_add_rows(dl2, idx.reshape(-1), V) if dl2 is not None else None
             if n_real > 0:
                 gx = ops.gemm_wgrad(g[:n_real], x2[:n_real])                       # (V, D) = g^T x over the real rows
                 cs = ops.colsum(g[:n_real])
@@ -935,6 +942,7 @@ class _DecoderFn(Function):
     def forward(ctx, dec, plan, memory, pm, ada_std, ada_mean, teacher_pre, dec_in0, *params):
         mel, align, stop, tapes = dec._run_loop(plan, memory, pm, ada_std, ada_mean, teacher_pre, keep_tapes=True)
         ctx.dec, ctx.plan, ctx.tapes = dec, plan, tapes
+        ctx.set_materialize_grads(False)          # (no zero tensors for outputs nobody differentiates: alignment and stop logits in training)
         ctx.has_in0 = dec_in0 is not None
         ctx.save_for_backward(memory, pm, ada_std, ada_mean, teacher_pre, align, mel, *params)
         return mel, align, stop

@@ -9,8 +9,8 @@ echo "== main.py default mode (VqvaeTrainer) on config 3, 20 steps"
 timeout 600 python main.py --config config/semi-single-spkr-paired-data.yaml --max-step 20 > $OUT/main_cycle_20_steps.log 2>&1; echo "exit $?"; tail -4 $OUT/main_cycle_20_steps.log
 echo "== bench.py --workload cycle (B = 32 + 32, then the configuration file's 8 + 8)"
 if [ "$2" == "quick" ]; then NOCPU=--no-cpu-baseline; fi
-timeout 900 python bench.py --workload cycle --steps 10 --warmup 2 $NOCPU > $OUT/bench_cycle.json 2> $OUT/bench_cycle.err; echo "exit $?"; cut -c1-400 $OUT/bench_cycle.json
-timeout 900 python bench.py --workload cycle --batch-size 8 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_cycle_b8.json 2> $OUT/bench_cycle_b8.err; echo "exit $?"; cut -c1-400 $OUT/bench_cycle_b8.json
+timeout 900 python bench.py --workload cycle --steps 20 --warmup 6 $NOCPU > $OUT/bench_cycle.json 2> $OUT/bench_cycle.err; echo "exit $?"; cut -c1-400 $OUT/bench_cycle.json
+timeout 900 python bench.py --workload cycle --batch-size 8 --steps 20 --warmup 6 --no-cpu-baseline > $OUT/bench_cycle_b8.json 2> $OUT/bench_cycle_b8.err; echo "exit $?"; cut -c1-400 $OUT/bench_cycle_b8.json
 echo "== kernel trace: one steady-state step of each cycle kind"
 (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace -d $OUT/prof -o cycle -- python3 $ROOT/bench.py --workload cycle --steps 2 --warmup 2 --no-cpu-baseline > $OUT/bench_cycle_under_rocprof.json 2> $OUT/prof.err)
 DB=$(find $OUT/prof -name "*.db" | head -1)

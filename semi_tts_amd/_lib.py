@@ -264,6 +264,8 @@ SIGNATURES = {
     'st_skinny_partial_attn_hist': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StAttnHistJob), P],
     'st_decoder_bwd_forms': [C.POINTER(StDecoderDims), C.POINTER(StDecoderBwdIO)],
     'st_decoder_bwd_fuse_dims': [C.POINTER(StDecoderDims)],
+    'st_loop_graph_stats': [P, P],
+    'st_loop_graphs_enable': [I],
     'st_skinny_partial_attn_bwd': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StAttnBwdJob), P],
     'st_skinny_linear_packed_lstm_bwd_attn_hist_sum': [P, C.POINTER(StT16View), I, P, I, I, I, C.POINTER(StLstmPwJob), C.POINTER(StAttnHistJob),
                                                        C.POINTER(StPartialSumJob), P],

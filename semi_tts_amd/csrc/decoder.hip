@@ -15,6 +15,7 @@
 // State lives in caller-owned tapes indexed by step; nothing is overwritten, so the same
 // buffers are the saved tensors of the backward pass.
 #include "st_common.h"
+#include "loop_graph.h"
 #include <cstdlib>
 
 namespace {
@@ -164,9 +165,42 @@ extern "C" size_t st_decoder_tape_floats(const st_decoder_dims* d, int which) {
     return which == 0 ? sv.q_floats : (which == 1 ? sv.d_floats : sv.o_floats);
 }
 
+static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io, void* stream);
+
+static stlg::Cache g_fwd_graphs;
+extern "C" void st_loop_graph_stats(long* fwd3, long* bwd3);      // (defined in decoder_bwd.hip: {replays, captures, eager} of both loops)
+extern "C" void stx_fwd_loop_graph_stats(long* out3) {
+    std::lock_guard<std::mutex> lock(g_fwd_graphs.mu);
+    out3[0] = g_fwd_graphs.replays; out3[1] = g_fwd_graphs.captures; out3[2] = g_fwd_graphs.eager;
+}
+
 extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io,
                                   void* stream) {
     (void)hipGetLastError();  // drop stale errors left by other HIP users of this thread
+    ST_CHECK_ARG(w && d && io, "st_decoder_forward: null struct pointer");
+    // the teacher-forced loop of a training step (tapes kept, projection deferred) comes back with bit-identical arguments step after step:
+    // captured at the second sighting, replayed with one launch afterwards (loop_graph.h)
+    if (io->defer_proj && io->steps > 0 && io->step_src && stlg::enabled()) {
+        st_decoder_io key_io = *io;
+        key_io.step_src = nullptr;                       // (a host array: its CONTENTS are part of the key, not its address)
+        uint64_t key = stlg::fnv(stlg::FNV0, w, sizeof(*w));
+        key = stlg::fnv(key, d, sizeof(*d));
+        key = stlg::fnv(key, &key_io, sizeof(key_io));
+        key = stlg::fnv(key, io->step_src, sizeof(int) * (size_t)io->steps);
+        stlg::Entry* e = nullptr;
+        const int mode = stlg::begin(g_fwd_graphs, key, (hipStream_t)stream, &e);
+        if (mode == 1) return 0;
+        int rc = decoder_forward_issue(w, d, io, stream);
+        if (mode == 2) {
+            rc = stlg::end(g_fwd_graphs, e, (hipStream_t)stream, rc);
+            if (rc == -5) st_set_error("st_decoder_forward: capturing the loop into a hipGraph failed");
+        }
+        return rc;
+    }
+    return decoder_forward_issue(w, d, io, stream);
+}
+
+static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_dims* d, const st_decoder_io* io, void* stream) {
     ST_CHECK_ARG(w && d && io, "st_decoder_forward: null struct pointer");
     const int B = d->B, L = d->L, E = d->E, P = d->P, Q = d->Q, D = d->D, A = d->A;
     const int steps = io->steps;

@@ -14,6 +14,7 @@
 //   f. dxq_t = dgates_q_t [W_ih_q | W_hh_q]     -> d(dec_in_t), dctx_{t-1}, dh_q carried to t-1
 // Weight gradients are the caller's TN GEMMs over the tapes written here (dgates_q/d, dpq) afterwards.
 #include "st_common.h"
+#include "loop_graph.h"
 
 extern "C" int st_attn_step_bwd(const float* pq, const float* pm, const float* memory,
                                 const float* w_prev, int ld_wprev, const float* w_cum_prev, const float* w, int ld_w,
@@ -86,9 +87,45 @@ extern "C" int st_decoder_bwd_forms(const st_decoder_dims* d, const st_decoder_b
     return (f.parts > 1 ? 1 : 0) | (f.partial_d ? 2 : 0) | (f.partial_q ? 4 : 0);
 }
 
+static int decoder_backward_issue(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream);
+
+static stlg::Cache g_bwd_graphs;
+namespace stlg { int& enabled_flag() { static int v = -1; return v; } }
+extern "C" int st_loop_graphs_enable(int on) { int& v = stlg::enabled_flag(); const int old = v; v = on ? 1 : 0; return old; }
+extern "C" void stx_fwd_loop_graph_stats(long* out3);
+extern "C" void st_loop_graph_stats(long* fwd3, long* bwd3) {
+    if (fwd3) stx_fwd_loop_graph_stats(fwd3);
+    if (bwd3) {
+        std::lock_guard<std::mutex> lock(g_bwd_graphs.mu);
+        bwd3[0] = g_bwd_graphs.replays; bwd3[1] = g_bwd_graphs.captures; bwd3[2] = g_bwd_graphs.eager;
+    }
+}
+
 extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io,
                                    void* stream) {
     (void)hipGetLastError();
+    ST_CHECK_ARG(w && d && io, "st_decoder_backward: null struct pointer");
+    if (io->steps > 0 && stlg::enabled()) {              // (see st_decoder_forward: the loop of a training step repeats its arguments)
+        st_decoder_bwd_io key_io = *io;
+        key_io.step_src = nullptr;
+        uint64_t key = stlg::fnv(stlg::FNV0, w, sizeof(*w));
+        key = stlg::fnv(key, d, sizeof(*d));
+        key = stlg::fnv(key, &key_io, sizeof(key_io));
+        if (io->step_src) key = stlg::fnv(key, io->step_src, sizeof(int) * (size_t)io->steps);
+        stlg::Entry* e = nullptr;
+        const int mode = stlg::begin(g_bwd_graphs, key, (hipStream_t)stream, &e);
+        if (mode == 1) return 0;
+        int rc = decoder_backward_issue(w, d, io, stream);
+        if (mode == 2) {
+            rc = stlg::end(g_bwd_graphs, e, (hipStream_t)stream, rc);
+            if (rc == -5) st_set_error("st_decoder_backward: capturing the loop into a hipGraph failed");
+        }
+        return rc;
+    }
+    return decoder_backward_issue(w, d, io, stream);
+}
+
+static int decoder_backward_issue(const st_decoder_bwd_weights* w, const st_decoder_dims* d, const st_decoder_bwd_io* io, void* stream) {
     ST_CHECK_ARG(w && d && io, "st_decoder_backward: null struct pointer");
     const int B = d->B, L = d->L, E = d->E, P = d->P, Q = d->Q, D = d->D, A = d->A;
     const int steps = io->steps, Bp = io->Bp;

@@ -390,3 +390,43 @@ def test_training_step_with_poisoned_uninitialised_buffers_at_other_dimensions(d
     for k in g0:
         assert torch.isfinite(g1[k]).all(), k
         assert torch.equal(g0[k], g1[k]), k
+
+
+def test_decoder_loops_replayed_from_graphs_give_bitwise_the_eager_steps(dev):
+    """The two C++ loops of a training step come back with bit-identical arguments step after step (the allocator repeats its addresses);
+    the library captures them into hipGraphs at the second sighting and replays them (loop_graph.h).  Six steps with the replay on must
+    equal six steps with it off bit for bit -- losses, gradient norms, every weight -- and the counters must show replays of both loops."""
+    import ctypes as C
+    import yaml
+    from argparse import Namespace
+    from semi_tts_amd import _lib
+    from semi_tts_amd.solver import TtsTrainer
+    lib = _lib.load()
+    cfg = yaml.safe_load(open(os.path.join(REPO, 'config', 'semi-single-spkr-paired-data.yaml')))
+    outs = []
+    prev = lib.st_loop_graphs_enable(1)
+    try:
+        for on in (0, 1):
+            lib.st_loop_graphs_enable(on)
+            f0, b0 = (C.c_long * 3)(), (C.c_long * 3)()
+            lib.st_loop_graph_stats(f0, b0)
+            paras = Namespace(batch_size=32, frames=64, n_batches=1, seed=3, verbose=False, max_step=6, load=None)
+            tr = TtsTrainer(cfg, paras, 'train').load_data().set_model()
+            tr.async_stats = True
+            torch.manual_seed(7)
+            batch = [t.to(dev) for t in tr.batches[0]]
+            sts = [tr.train_step(*batch) for _ in range(6)]
+            tr.drain_stats()
+            torch.cuda.synchronize()
+            f1, b1 = (C.c_long * 3)(), (C.c_long * 3)()
+            lib.st_loop_graph_stats(f1, b1)
+            outs.append(([(float(s['loss']), float(s['grad_norm'])) for s in sts], {k: v.detach().clone() for k, v in tr.model.state_dict().items()},
+                         (f1[0] - f0[0], b1[0] - b0[0], f1[1] - f0[1], b1[1] - b0[1])))
+    finally:
+        lib.st_loop_graphs_enable(prev if prev >= 0 else 1)
+    (s0, w0, c0), (s1, w1, c1) = outs
+    assert c0 == (0, 0, 0, 0), c0                      # off: nothing captured, nothing replayed
+    assert c1[0] >= 2 and c1[1] >= 2 and c1[2] >= 1 and c1[3] >= 1, c1      # on: both loops captured and replayed
+    assert s0 == s1, (s0, s1)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k

@@ -187,10 +187,18 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
         key = stlg::fnv(key, d, sizeof(*d));
         key = stlg::fnv(key, &key_io, sizeof(key_io));
         key = stlg::fnv(key, io->step_src, sizeof(int) * (size_t)io->steps);
+        if (getenv("ST_LOOP_GRAPHS_DEBUG")) {
+            fprintf(stderr, "fwd key %016llx w %016llx d %016llx io %016llx:", (unsigned long long)key, (unsigned long long)stlg::fnv(stlg::FNV0, w, sizeof(*w)),
+                    (unsigned long long)stlg::fnv(stlg::FNV0, d, sizeof(*d)), (unsigned long long)stlg::fnv(stlg::FNV0, &key_io, sizeof(key_io)));
+            const void* const* pp = reinterpret_cast<const void* const*>(&key_io);
+            for (size_t i = 0; i < sizeof(key_io) / sizeof(void*); ++i) fprintf(stderr, " %p", pp[i]);
+            fprintf(stderr, "\n");
+        }
         stlg::Entry* e = nullptr;
-        const int mode = stlg::begin(g_fwd_graphs, key, (hipStream_t)stream, &e);
+        hipStream_t issue_on = (hipStream_t)stream;
+        const int mode = stlg::begin(g_fwd_graphs, key, (hipStream_t)stream, &e, &issue_on);
         if (mode == 1) return 0;
-        int rc = decoder_forward_issue(w, d, io, stream);
+        int rc = decoder_forward_issue(w, d, io, (void*)issue_on);
         if (mode == 2) {
             rc = stlg::end(g_fwd_graphs, e, (hipStream_t)stream, rc);
             if (rc == -5) st_set_error("st_decoder_forward: capturing the loop into a hipGraph failed");

@@ -113,9 +113,10 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
         key = stlg::fnv(key, &key_io, sizeof(key_io));
         if (io->step_src) key = stlg::fnv(key, io->step_src, sizeof(int) * (size_t)io->steps);
         stlg::Entry* e = nullptr;
-        const int mode = stlg::begin(g_bwd_graphs, key, (hipStream_t)stream, &e);
+        hipStream_t issue_on = (hipStream_t)stream;
+        const int mode = stlg::begin(g_bwd_graphs, key, (hipStream_t)stream, &e, &issue_on);
         if (mode == 1) return 0;
-        int rc = decoder_backward_issue(w, d, io, stream);
+        int rc = decoder_backward_issue(w, d, io, (void*)issue_on);
         if (mode == 2) {
             rc = stlg::end(g_bwd_graphs, e, (hipStream_t)stream, rc);
             if (rc == -5) st_set_error("st_decoder_backward: capturing the loop into a hipGraph failed");

@@ -21,6 +21,7 @@ struct Cache {
     Entry e[SLOTS] = {};
     unsigned long long age = 0;
     long replays = 0, captures = 0, eager = 0;
+    hipStream_t cap = nullptr;          // the capture runs on a stream of the cache's own: torch's default stream is the legacy stream, which cannot capture
     std::mutex mu;
 };
 
@@ -38,10 +39,11 @@ inline bool enabled() {
     return v != 0;
 }
 
-// 1: replayed, nothing left to do.  2: a capture has begun on `st` -- the caller issues its launches and calls end().  0: the caller issues
-// its launches as usual (first sighting, an outer capture in progress, a HIP error, the cache switched off).
-inline int begin(Cache& c, uint64_t key, hipStream_t st, Entry** out) {
+// 1: replayed, nothing left to do.  2: a capture has begun on *issue_on -- the caller issues its launches THERE and calls end().  0: the caller
+// issues its launches on `st` as usual (first sighting, an outer capture in progress, a HIP error, the cache switched off).
+inline int begin(Cache& c, uint64_t key, hipStream_t st, Entry** out, hipStream_t* issue_on) {
     *out = nullptr;
+    *issue_on = st;
     if (!enabled()) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
@@ -66,8 +68,10 @@ inline int begin(Cache& c, uint64_t key, hipStream_t st, Entry** out) {
     }
     if (hit && hit->seen > 0) {                        // second sighting: capture
         hit->age = ++c.age;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); hit->seen = -1; ++c.eager; return 0; }
+        if (!c.cap && hipStreamCreateWithFlags(&c.cap, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c.cap = nullptr; }
+        if (!c.cap || hipStreamBeginCapture(c.cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); hit->seen = -1; ++c.eager; return 0; }
         *out = hit;
+        *issue_on = c.cap;
         return 2;
     }
     if (!hit) {
@@ -81,7 +85,7 @@ inline int begin(Cache& c, uint64_t key, hipStream_t st, Entry** out) {
 // ends the capture begun by begin() == 2 and launches the graph; rc_issue = what the issuing code returned
 inline int end(Cache& c, Entry* e, hipStream_t st, int rc_issue) {
     hipGraph_t g = nullptr;
-    const hipError_t ce = hipStreamEndCapture(st, &g);
+    const hipError_t ce = hipStreamEndCapture(c.cap, &g);
     std::lock_guard<std::mutex> lock(c.mu);
     if (rc_issue != 0 || ce != hipSuccess || !g) {
         (void)hipGetLastError();

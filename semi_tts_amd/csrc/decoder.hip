@@ -180,20 +180,13 @@ extern "C" int st_decoder_forward(const st_decoder_weights* w, const st_decoder_
     ST_CHECK_ARG(w && d && io, "st_decoder_forward: null struct pointer");
     // the teacher-forced loop of a training step (tapes kept, projection deferred) comes back with bit-identical arguments step after step:
     // captured at the second sighting, replayed with one launch afterwards (loop_graph.h)
-    if (io->defer_proj && io->steps > 0 && io->step_src && stlg::enabled()) {
+    if (io->defer_proj && io->steps > 0 && io->step_src && stlg::enabled(d->B)) {
         st_decoder_io key_io = *io;
         key_io.step_src = nullptr;                       // (a host array: its CONTENTS are part of the key, not its address)
         uint64_t key = stlg::fnv(stlg::FNV0, w, sizeof(*w));
         key = stlg::fnv(key, d, sizeof(*d));
         key = stlg::fnv(key, &key_io, sizeof(key_io));
         key = stlg::fnv(key, io->step_src, sizeof(int) * (size_t)io->steps);
-        if (getenv("ST_LOOP_GRAPHS_DEBUG")) {
-            fprintf(stderr, "fwd key %016llx w %016llx d %016llx io %016llx:", (unsigned long long)key, (unsigned long long)stlg::fnv(stlg::FNV0, w, sizeof(*w)),
-                    (unsigned long long)stlg::fnv(stlg::FNV0, d, sizeof(*d)), (unsigned long long)stlg::fnv(stlg::FNV0, &key_io, sizeof(key_io)));
-            const void* const* pp = reinterpret_cast<const void* const*>(&key_io);
-            for (size_t i = 0; i < sizeof(key_io) / sizeof(void*); ++i) fprintf(stderr, " %p", pp[i]);
-            fprintf(stderr, "\n");
-        }
         stlg::Entry* e = nullptr;
         hipStream_t issue_on = (hipStream_t)stream;
         const int mode = stlg::begin(g_fwd_graphs, key, (hipStream_t)stream, &e, &issue_on);

@@ -91,7 +91,7 @@ static int decoder_backward_issue(const st_decoder_bwd_weights* w, const st_deco
 
 static stlg::Cache g_bwd_graphs;
 namespace stlg { int& enabled_flag() { static int v = -1; return v; } }
-extern "C" int st_loop_graphs_enable(int on) { int& v = stlg::enabled_flag(); const int old = v; v = on ? 1 : 0; return old; }
+extern "C" int st_loop_graphs_enable(int on) { int& v = stlg::enabled_flag(); const int old = v; v = on < 0 ? -1 : (on == 2 ? 2 : (on ? 1 : 0)); return old; }
 extern "C" void stx_fwd_loop_graph_stats(long* out3);
 extern "C" void st_loop_graph_stats(long* fwd3, long* bwd3) {
     if (fwd3) stx_fwd_loop_graph_stats(fwd3);
@@ -105,7 +105,7 @@ extern "C" int st_decoder_backward(const st_decoder_bwd_weights* w, const st_dec
                                    void* stream) {
     (void)hipGetLastError();
     ST_CHECK_ARG(w && d && io, "st_decoder_backward: null struct pointer");
-    if (io->steps > 0 && stlg::enabled()) {              // (see st_decoder_forward: the loop of a training step repeats its arguments)
+    if (io->steps > 0 && stlg::enabled(d->B)) {              // (see st_decoder_forward: the loop of a training step repeats its arguments)
         st_decoder_bwd_io key_io = *io;
         key_io.step_src = nullptr;
         uint64_t key = stlg::fnv(stlg::FNV0, w, sizeof(*w));

@@ -423,7 +423,7 @@ def test_decoder_loops_replayed_from_graphs_give_bitwise_the_eager_steps(dev):
             outs.append(([(float(s['loss']), float(s['grad_norm'])) for s in sts], {k: v.detach().clone() for k, v in tr.model.state_dict().items()},
                          (f1[0] - f0[0], b1[0] - b0[0], f1[1] - f0[1], b1[1] - b0[1])))
     finally:
-        lib.st_loop_graphs_enable(prev if prev >= 0 else 1)
+        lib.st_loop_graphs_enable(prev)
     (s0, w0, c0), (s1, w1, c1) = outs
     assert c0 == (0, 0, 0, 0), c0                      # off: nothing captured, nothing replayed
     assert c1[0] >= 2 and c1[1] >= 2 and c1[2] >= 1 and c1[3] >= 1, c1      # on: both loops captured and replayed

@@ -988,9 +988,9 @@ int st_decoder_backward(const st_decoder_bwd_weights* w, const st_decoder_dims* 
 /* The two loops of a training step (st_decoder_forward with defer_proj, st_decoder_backward) are called with bit-identical arguments step after
  * step once the caller's allocator repeats its addresses: at the second sighting of an argument set the loop's launches are captured into a
  * hipGraph (thread-local capture on the calling stream) and replayed with one launch whenever the set comes back; other sets run eagerly.
- * By default only for B <= 16, where the host's issue rate bounds the step (ST_LOOP_GRAPHS=1 / 0 forces it on / off).  st_loop_graph_stats: {replays, captures, eager calls} of the forward / backward loop (either may be NULL). */
+ * OFF unless asked for (ST_LOOP_GRAPHS=1, st_loop_graphs_enable): it saves host time (0.8 ms of a C2 step), which the measured steps are not bound by.  st_loop_graph_stats: {replays, captures, eager calls} of the forward / backward loop (either may be NULL). */
 void st_loop_graph_stats(long* fwd3, long* bwd3);
-/* the replay at run time: 1 on, 0 off, 2 the default policy (B <= 16), -1 re-read ST_LOOP_GRAPHS; returns the previous setting */
+/* the replay at run time: 1 on, 0 off, -1 re-read ST_LOOP_GRAPHS; returns the previous setting */
 int st_loop_graphs_enable(int on);
 /* dY(t, b, :) = [dmel(b, t*r .. t*r+r-1, :) | sum_j dstop(b, t*r+j)]   (steps, Bp) rows of r*n_mels+1 values, row stride ld floats
  * (a stride rounded up to a multiple of 4, pad columns zero, puts the two products over dY on the 16-byte kernels); NULL = zeros */

@@ -91,7 +91,7 @@ static int decoder_backward_issue(const st_decoder_bwd_weights* w, const st_deco
 
 static stlg::Cache g_bwd_graphs;
 namespace stlg { int& enabled_flag() { static int v = -1; return v; } }
-extern "C" int st_loop_graphs_enable(int on) { int& v = stlg::enabled_flag(); const int old = v; v = on < 0 ? -1 : (on == 2 ? 2 : (on ? 1 : 0)); return old; }
+extern "C" int st_loop_graphs_enable(int on) { int& v = stlg::enabled_flag(); const int old = v; v = on < 0 ? -1 : (on ? 1 : 0); return old; }
 extern "C" void stx_fwd_loop_graph_stats(long* out3);
 extern "C" void st_loop_graph_stats(long* fwd3, long* bwd3) {
     if (fwd3) stx_fwd_loop_graph_stats(fwd3);

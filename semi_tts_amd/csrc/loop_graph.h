@@ -5,8 +5,8 @@
 // called with bit-identical arguments step after step: the launches of such a call are captured into a hipGraph at the second sighting
 // of an argument set (on the calling stream, thread-local capture) and replayed with ONE launch whenever the same arguments come back.
 // Any other argument set -- another shape, another address -- runs eagerly as before.  Round 5 measured this with the step bound by
-// the GPU (no gain: a replay's kernels start ~0.2 us later each); round 6 keeps it for small batches, where the host is the bound
-// (ST_LOOP_GRAPHS=1 / 0 forces it on / off).
+// the GPU (no gain: a replay's kernels start ~0.2 us later each); round 6 measured it again at small batches (the GPU bounds those steps too)
+// and keeps it as an option: ST_LOOP_GRAPHS=1.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,14 +33,15 @@ inline uint64_t fnv(uint64_t h, const void* p, size_t n) {
 constexpr uint64_t FNV0 = 1469598103934665603ull;
 
 int& enabled_flag();                                   // (one flag for the library: defined in decoder_bwd.hip)
-// 1 / 0: forced on / off (ST_LOOP_GRAPHS, st_loop_graphs_enable); 2 = the default policy: on for B <= 16.  Measured (round 6, DESIGN.md section
-// 3.5): the replay takes 0.8 ms of host time off a C2 training step (8.1 -> 7.3 ms) -- and nothing off the step at B = 32, which the GPU bounds
-// (8.78 -> 8.90 ms: a replay's kernels start a little later each); at the cycles' configuration batch (8 + 8) the host is the bound and the
-// text-first step gets 0.8 ms shorter.
+// 1 / 0: on / off (ST_LOOP_GRAPHS, st_loop_graphs_enable); OFF unless asked for.  Measured (round 6): the replay takes
+// 0.8 ms of HOST time off a C2 training step (8.1 -> 7.3 ms) and 1.2 ms off a text-first cycle step at B = 8 (10.0 -> 8.8 ms) -- and nothing off
+// either step: both are bound by the GPU's chains of dependent launches (8.78 -> 8.90 ms; 10.0 -> 10.1 ms), and a replay's kernels start a
+// little later each.  Kept for hosts slower than the measured ones.
 inline bool enabled(int B = 0) {
+    (void)B;
     int& v = enabled_flag();
-    if (v < 0) { const char* e = getenv("ST_LOOP_GRAPHS"); v = e ? (atoi(e) ? 1 : 0) : 2; }
-    return v == 1 || (v == 2 && B > 0 && B <= 16);
+    if (v < 0) { const char* e = getenv("ST_LOOP_GRAPHS"); v = e && atoi(e) ? 1 : 0; }
+    return v == 1;
 }
 
 // 1: replayed, nothing left to do.  2: a capture has begun on *issue_on -- the caller issues its launches THERE and calls end().  0: the caller

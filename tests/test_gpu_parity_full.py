@@ -394,8 +394,8 @@ def test_training_step_with_poisoned_uninitialised_buffers_at_other_dimensions(d
 
 def test_decoder_loops_replayed_from_graphs_give_bitwise_the_eager_steps(dev):
     """The two C++ loops of a training step come back with bit-identical arguments step after step (the allocator repeats its addresses);
-    the library captures them into hipGraphs at the second sighting and replays them (loop_graph.h).  Six steps with the replay on must
-    equal six steps with it off bit for bit -- losses, gradient norms, every weight -- and the counters must show replays of both loops."""
+    the library captures them into hipGraphs at the second sighting and replays them (loop_graph.h).  Twelve steps with the replay on must
+    equal twelve steps with it off bit for bit -- losses, gradient norms, every weight -- and the counters must show replays of both loops."""
     import ctypes as C
     import yaml
     from argparse import Namespace
@@ -408,14 +408,16 @@ def test_decoder_loops_replayed_from_graphs_give_bitwise_the_eager_steps(dev):
     try:
         for on in (0, 1):
             lib.st_loop_graphs_enable(on)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()           # (the allocator repeats its addresses once it has settled: start both runs from the same empty state)
             f0, b0 = (C.c_long * 3)(), (C.c_long * 3)()
             lib.st_loop_graph_stats(f0, b0)
-            paras = Namespace(batch_size=32, frames=64, n_batches=1, seed=3, verbose=False, max_step=6, load=None)
+            paras = Namespace(batch_size=32, frames=64, n_batches=1, seed=3, verbose=False, max_step=12, load=None)
             tr = TtsTrainer(cfg, paras, 'train').load_data().set_model()
             tr.async_stats = True
             torch.manual_seed(7)
             batch = [t.to(dev) for t in tr.batches[0]]
-            sts = [tr.train_step(*batch) for _ in range(6)]
+            sts = [tr.train_step(*batch) for _ in range(12)]
             tr.drain_stats()
             torch.cuda.synchronize()
             f1, b1 = (C.c_long * 3)(), (C.c_long * 3)()
@@ -426,7 +428,7 @@ def test_decoder_loops_replayed_from_graphs_give_bitwise_the_eager_steps(dev):
         lib.st_loop_graphs_enable(prev)
     (s0, w0, c0), (s1, w1, c1) = outs
     assert c0 == (0, 0, 0, 0), c0                      # off: nothing captured, nothing replayed
-    assert c1[0] >= 2 and c1[1] >= 2 and c1[2] >= 1 and c1[3] >= 1, c1      # on: both loops captured and replayed
+    assert c1[0] >= 1 and c1[1] >= 1 and c1[2] >= 1 and c1[3] >= 1, c1      # on: both loops captured and replayed
     assert s0 == s1, (s0, s1)
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k

@@ -378,8 +378,8 @@ def event_timer(lib):
 def lstm_probe(dec, dev, Bsz):
     """Roofline probe of the dominant kernel (the weight-streaming LSTM cell), measured with HIP events on the stream the
     kernel runs on: the two launches of a decode step alternate exactly as in the loop -- query LSTM K=1792; decoder LSTM
-    K=2560, or (round 6, 16 < B <= 32: Decoder.split_gates) its 512 context columns + the slab of the 2048 columns that rode
-    beside the pq / fin launch -- so the weights cycle through the caches as they do there.  Replayed from a hipGraph (as in
+    K=2560, or (round 6, 16 < B <= 32: Decoder.split_gates) the first half of its reduction (Decoder.gate_split_k: 1280 columns) + the slab
+    of the other half that rode beside the pq / fin launch -- so the weights cycle through the caches as they do there.  Replayed from a hipGraph (as in
     the decode loop) so the measurement sees device time, not the Python/ctypes issue rate."""
     import torch
     from semi_tts_amd import _lib, ops
@@ -398,11 +398,12 @@ def lstm_probe(dec, dev, Bsz):
 
     split = bool(getattr(dec, 'split_gates', False)) and 16 < Bsz <= 32 and Q % 16 == 0 and D % 16 == 0 and E % 16 == 0
     slab = torch.randn(Bsz, 4 * D, **f32) if split else None
+    Kc = dec.gate_split_k() if split else Kd
 
     def pair():
         ops.lstm_cell_packed(pk_q, xq_v, Kq, dec.query_rnn.bias_ih, dec.query_rnn.bias_hh, c_q, ho_v, co, Bsz, Q)
         if split:
-            ops.lstm_cell_packed_part(pk_d, Kd // 16, xd_v, E, slab, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
+            ops.lstm_cell_packed_part(pk_d, Kd // 16, xd_v, Kc, slab, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
         else:
             ops.lstm_cell_packed(pk_d, xd_v, Kd, dec.dec_rnn.bias_ih, dec.dec_rnn.bias_hh, c_d, ho_v, co, Bsz, D)
 
@@ -426,7 +427,7 @@ def lstm_probe(dec, dev, Bsz):
     # 5.75-5.79 us either way; in situ the two launches take 7.4 + 5.2 us (kernel trace medians): the first loads of a launch that follows
     # another one's stores cost more than back-to-back launches of the same kernel show)
     avg_us = timed_graph(pair) / 2
-    Kd_cell = E if split else Kd                        # (what the decoder CELL launch reduces; + the slab it reads)
+    Kd_cell = Kc                                        # (what the decoder CELL launch reduces; + the slab it reads)
     alg = 0.5 * (lstm_algorithmic_bytes(Bsz, Q, Kq) + lstm_algorithmic_bytes(Bsz, D, Kd_cell) + (4.0 * Bsz * 4 * D if split else 0.0))
     flops = 0.5 * (2.0 * Bsz * 4 * Q * Kq + 2.0 * Bsz * 4 * D * Kd_cell)
     return avg_us, alg, flops
@@ -505,9 +506,12 @@ def bench_decode(args, rk):
                 continue
     step_bytes = decode_step_algorithmic_bytes(B, L, dec)
     split_on = bool(getattr(dec, 'split_gates', False)) and 16 < B <= 32
-    roof = {'bound': 'hbm', 'kernel': kernel_name_of_lstm(B) + ('; two launches per step: the query cell (K = 1792) and the decoder cell over its 512 context '
-                                                                 'columns + the slab of the 2048 columns that ride beside the pq / fin launch (pk_attnfin_part_kernel, '
-                                                                 '33.5 MB of weights on 128 compute units: the largest single launch of the step)' if split_on else ''),
+    kc = dec.gate_split_k() if split_on else 0
+    kd_all = dec.enc_embed_dim + dec.query_rnn_dim + dec.dec_rnn_dim
+    roof = {'bound': 'hbm', 'kernel': kernel_name_of_lstm(B) + (('; two launches per step: the query cell (K = 1792) and the decoder cell over the first %d columns of its '
+                                                                  'reduction + the slab of the other %d that ride beside the pq / fin launch (pk_attnfin_part_kernel, '
+                                                                  '%.1f MB of weights on 128 compute units)') % (kc, kd_all - kc, 16.0 * dec.dec_rnn_dim * (kd_all - kc) / 1e6)
+                                                                 if split_on else ''),
             'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
             'algorithmic_bytes_per_launch': alg, 'avg_launch_us': round(avg_us, 3),

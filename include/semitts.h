@@ -771,12 +771,18 @@ typedef struct st_decoder_io {
                                         * handed over as granules -- one launch less per free-running decode step.  Zeroed by the callee per
                                         * forward; time-outs go to handoff_status */
     float* gate_part;                  /* optional (B, 4 D) scratch: in the one-launch pq + fin form (pq_granules) with 16 < B <= 32 the decoder
-                                        * cell's gate products over the operands that are known BEFORE the attention runs -- W_hh_d h_d(t-1) and
-                                        * W_ih_d[:, E:] AdaIN(h_q(t)), 2048 of the cell's 2560 reduction columns at C2 -- ride beside the pq / fin
-                                        * launch on compute units it leaves idle (st_query_attn_fin_part_fwd); the cell launch then reduces the
-                                        * context columns and adds this slab (st_lstm_cell_packed_part_fwd).  fp32 re-association only.  NULL = off */
+                                        * cell's gate products over operands that are known BEFORE the attention runs -- the tail of the cell's
+                                        * reduction [ctx | AdaIN(h_q(t)) | h_d(t-1)] from column gate_part_k on -- ride beside the pq / fin launch
+                                        * on compute units it leaves idle (st_query_attn_fin_part_fwd); the cell launch then reduces the first
+                                        * gate_part_k columns and adds this slab (st_lstm_cell_packed_part_fwd).  fp32 re-association only.
+                                        * NULL = off */
+    int gate_part_k;                   /* the cell's own share of the reduction: a multiple of 16 in [kb16(E) * 16, K_d); 0 = the callee's rule
+                                        * (st_decoder_gate_split_k: half of the reduction in whole rounds of 16 k-blocks -- C2: 1280 of 2560,
+                                        * measured best of 512 ... 2048) */
 } st_decoder_io;
 
+/* the default of st_decoder_io.gate_part_k for these dimensions */
+int st_decoder_gate_split_k(const st_decoder_dims* d);
 size_t st_decoder_packed_floats(const st_decoder_dims* d);
 /* floats of ONE slot of xq_tape (which = 0), xd_tape (1), xo_tape (2) */
 size_t st_decoder_tape_floats(const st_decoder_dims* d, int which);

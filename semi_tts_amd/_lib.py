@@ -77,7 +77,7 @@ class StDecoderIO(C.Structure):
                 ('pre1_step_floats', C.c_int), ('attn_s_step_floats', C.c_int), ('attn_loc_tape', C.c_void_p),
                 ('attn_split_ws', C.c_void_p), ('attn_split_parts', C.c_int), ('pq_granules', C.c_void_p),
                 ('dec_in0', C.c_void_p), ('pre_nat', C.c_void_p), ('attn_xchg', C.c_void_p), ('handoff_status', C.c_void_p),
-                ('pair_cells', C.c_int), ('pre_nat_tape', C.c_void_p), ('pre1_granules', C.c_void_p), ('gate_part', C.c_void_p)]
+                ('pair_cells', C.c_int), ('pre_nat_tape', C.c_void_p), ('pre1_granules', C.c_void_p), ('gate_part', C.c_void_p), ('gate_part_k', C.c_int)]
 
 
 class StDecoderBwdWeights(C.Structure):
@@ -248,6 +248,7 @@ SIGNATURES = {
     'st_attn_rng_xchg_words': [I, I, I],
     'st_query_attn_rng_fwd': [P, C.POINTER(StT16View), I, P, P, C.c_uint, C.POINTER(StAttnFinJob), I, P],
     'st_decoder_packed_floats': [C.POINTER(StDecoderDims)],
+    'st_decoder_gate_split_k': [C.POINTER(StDecoderDims)],
     'st_decoder_tape_floats': [C.POINTER(StDecoderDims), I],
     'st_decoder_pack': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), P, P],
     'st_decoder_forward': [C.POINTER(StDecoderWeights), C.POINTER(StDecoderDims), C.POINTER(StDecoderIO), P],

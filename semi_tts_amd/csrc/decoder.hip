@@ -134,6 +134,14 @@ int prenet_own(const st_decoder_weights* w, const st_decoder_dims* d, const st_d
 
 }  // namespace
 
+extern "C" int st_decoder_gate_split_k(const st_decoder_dims* d) {
+    if (!d) return 0;
+    const StepViews sv = step_views(d);
+    int hosted = (sv.d_kbs / 2) / 16 * 16;                 // k-blocks that ride beside pq / fin: half the reduction, whole rounds of 16
+    if (hosted < 16 || hosted > sv.d_kbs - sv.d_ha) hosted = sv.d_kbs - sv.d_ha;
+    return 16 * (sv.d_kbs - hosted);
+}
+
 extern "C" size_t st_decoder_packed_floats(const st_decoder_dims* d) { return d ? packed_layout(d).total : 0; }
 
 extern "C" int st_decoder_pack(const st_decoder_weights* w, const st_decoder_dims* d, float* packed, void* stream) {
@@ -320,7 +328,12 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
     const bool split_hosted = split_d && fuse_pq_fin && (A / 16) * ((B + 15) / 16) + B * fin_parts + (4 * D) / 32 <= st_device_cus();
     st_partial_product_job pj_d;
     memset(&pj_d, 0, sizeof(pj_d));
-    pj_d.packed_w = io->packed + pl.d; pj_d.w_kbs = sv.d_kbs; pj_d.kb0 = sv.d_ha; pj_d.KB = sv.d_kbs - sv.d_ha; pj_d.N = 4 * D; pj_d.part = io->gate_part;
+    // ... how much of it: measured at C2 (hosted 512 / 768 / 1024 / 1280 / 1536 / 2048 columns: 2.78 / 2.83 / 2.88 / 2.89 / 2.86 / 2.81 M
+    // mel-frames/s, whole rounds of 16 k-blocks for the 8 waves x 2 only -- 1088 ... 1408 in steps of 64 all lose to 1280): the cell keeps half.
+    ST_CHECK_ARG(io->gate_part_k == 0 || !io->gate_part || (io->gate_part_k % 16 == 0 && io->gate_part_k >= 16 * sv.d_ha && io->gate_part_k < 16 * sv.d_kbs),
+                 "st_decoder_forward: gate_part_k = %d must be a multiple of 16 in [%d, %d)", io->gate_part_k, 16 * sv.d_ha, 16 * sv.d_kbs);
+    const int d_k0 = (io->gate_part_k ? io->gate_part_k : st_decoder_gate_split_k(d)) / 16;
+    pj_d.packed_w = io->packed + pl.d; pj_d.w_kbs = sv.d_kbs; pj_d.kb0 = d_k0; pj_d.KB = sv.d_kbs - d_k0; pj_d.N = 4 * D; pj_d.part = io->gate_part;
     for (int t = 0; t < steps; ++t) {
         float* xq = io->xq_tape + (size_t)t * sv.q_floats;
         float* xq_next = io->xq_tape + (size_t)(t + 1) * sv.q_floats;
@@ -391,7 +404,7 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
             fj.status = io->handoff_status;
             fj.n_ctx_dst = 3; fj.parts = fin_parts; fj.L = L; fj.A = A; fj.E = E; fj.F = d->F; fj.K = d->K;
             if (split_hosted && !ST_SKIPPED(3)) {
-                pj_d.x = st_t16_view{xd, sv.d_kbs, sv.d_ha};
+                pj_d.x = st_t16_view{xd, sv.d_kbs, d_k0};
                 rc = st_query_attn_fin_part_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, &pj_d, stream);
             } else
             rc = st_query_attn_fin_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, stream);
@@ -433,12 +446,12 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
             rc = st_lstm_cell_packed_pair_fwd(&jd, &jq, stream);
         } else {
         if (split_d && !split_hosted && !ST_SKIPPED(3)) {
-            pj_d.x = st_t16_view{xd, sv.d_kbs, sv.d_ha};
+            pj_d.x = st_t16_view{xd, sv.d_kbs, d_k0};
             rc = st_partial_product_fwd(&pj_d, B, stream);
             if (rc) return rc;
         }
         if (split_d && !ST_SKIPPED(3) && !(split_hosted && (ST_SKIPPED(1) || ST_SKIPPED(2))))
-            rc = st_lstm_cell_packed_part_fwd(io->packed + pl.d, sv.d_kbs, &xd_v, 16 * sv.d_ha, io->gate_part, w->d_b_ih, w->d_b_hh,
+            rc = st_lstm_cell_packed_part_fwd(io->packed + pl.d, sv.d_kbs, &xd_v, 16 * d_k0, io->gate_part, w->d_b_ih, w->d_b_hh,
                                               io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,
                                               &hd_dst0, &hd_dst1, io->cd_tape + (size_t)(t + 1) * BD, D,
                                               io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr, B, D, stream);

@@ -370,6 +370,7 @@ class Decoder(nn.Module):
         # ... and the part of the decoder cell's gate product that does not wait for the attention rides in that launch (round 6: +2-3 %
         # mel-frames/s at C2; fp32 re-association only; ST_SPLIT_GATES=0 restores the whole product in the cell launch)
         self.split_gates = os.environ.get('ST_SPLIT_GATES', '1') != '0'
+        self.split_cell_k = int(os.environ.get('ST_SPLIT_CELL_K', '0'))       # reduction columns the decoder cell keeps (0 = st_decoder_gate_split_k)
         # the hand-off's failure word (st_decoder_io.handoff_status): an eager forward reads it back right away (one small
         # device -> host copy); under stream capture nobody can, so GraphedDecoder / bench.py / gen_specgram check it after replays
         self.check_handoff = True
@@ -386,6 +387,17 @@ class Decoder(nn.Module):
         self.attn_rng_one_launch = True   # long texts: query projection + fin part over position ranges + combine in one launch
 
     # -- helpers ---------------------------------------------------------------------------------
+    def gate_split_k(self):
+        """reduction columns of the decoder cell's gate product that stay in the cell launch when the rest rides beside pq / fin (split_gates):
+        the library's rule for these dimensions unless ST_SPLIT_CELL_K overrides it"""
+        if self.split_cell_k:
+            return int(self.split_cell_k)
+        import ctypes as C
+        from . import _lib
+        d = StDecoderDims(B=32, L=1, E=self.enc_embed_dim, n_mels=self.n_mels, r=self.n_frames_per_step, P=self.prenet_dim,
+                          Q=self.query_rnn_dim, D=self.dec_rnn_dim, A=1)
+        return int(_lib.load().st_decoder_gate_split_k(C.byref(d)))
+
     def _weights_struct(self, keep, fuse_pre0=False):
         w = StDecoderWeights()
         # [proj ; gate (; W_pre0 . W_proj)] assembled with library kernels only, so that a hipGraph capture
@@ -645,10 +657,12 @@ class Decoder(nn.Module):
                     tapes['attn_xchg'] = torch.empty(2 * int(lib.st_attn_rng_xchg_words(B, E, sp)), **f32)
                     io.attn_xchg = ops._p(tapes['attn_xchg'])
             if self.split_gates and not keep_tapes and 16 < B <= 32 and L < self.attn_split_min_len:
-                # the decoder cell's gate products over [AdaIN(h_q(t)) | h_d(t-1)] beside the pq / fin launch (st_decoder_io.gate_part; in the
-                # other forms of the attention step a launch of its own: the same arithmetic whatever the form)
+                # the tail of the decoder cell's gate products -- columns of [ctx | AdaIN(h_q(t)) | h_d(t-1)] known before the attention runs --
+                # beside the pq / fin launch (st_decoder_io.gate_part; in the other forms of the attention step a launch of its own: the same
+                # arithmetic whatever the form).  gate_part_k = 0: the library's split (half of the reduction); ST_SPLIT_CELL_K for ablations
                 tapes['gate_part'] = torch.empty(B, 4 * D, **f32)
                 io.gate_part = ops._p(tapes['gate_part'])
+                io.gate_part_k = int(self.split_cell_k)
             if self.attn_pq_in_fin and not keep_tapes:
                 # query projection + attention fin part as ONE launch per step (st_query_attn_fin_fwd): pq is handed over inside
                 # the launch as 8-byte {value, tag} words; the library falls back to two launches when the shapes do not fit

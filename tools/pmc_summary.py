@@ -9,8 +9,8 @@ import sqlite3
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALGO_BYTES = 19709952          # mean algorithmic bytes of one LSTM-cell launch at C2 since round 6 (bench.py: lstm_probe -- query cell K = 1792,
-                               # decoder cell K = 512 + its 512 KB slab; 36356096 with ST_SPLIT_GATES=0: both cells at full K)
+ALGO_BYTES = 26050560          # mean algorithmic bytes of one LSTM-cell launch at C2 since round 6 (bench.py: lstm_probe -- query cell K = 1792,
+                               # decoder cell K = 1280 + its 512 KB slab; 36356096 with ST_SPLIT_GATES=0: both cells at full K)
 
 
 SFX = ''

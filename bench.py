@@ -123,7 +123,7 @@ def cpu_timed(short_fn, full_fn, units_per_pass, unit, kind, sample, max_passes=
         best = min(full, key=lambda th: float(np.median(full[th][1:])))
         times = full[best]
     t = float(np.median(times[1:]))
-    return {'value': units_per_pass / t, 'unit': unit, 'cores': best, 'kind': kind.replace('_autograd', ''), 'host_cores': cores,
+    return {'value': units_per_pass / t, 'unit': unit, 'cores': best, 'kind': 'port', 'assembly': kind.replace('_autograd', ''), 'host_cores': cores,
             'seconds_per_pass': t, 'thread_probe': probe,
             'full_pass_seconds': {str(k): [round(x, 4) for x in v] for k, v in full.items()},
             'sample': sample + '; %d timed pass(es) after 1 warm-up, median; torch CPU fp32, %d threads = the better of the two fastest '

@@ -367,7 +367,7 @@ class Decoder(nn.Module):
         self.attn_pre_parts = 4      # workgroups per utterance of the pre part (measured at L = 43: 1 / 2 / 4 parts 37.1 / 35.9 / 35.4 us per step)
         self.attn_fin_parts = 2      # workgroups per utterance of the fin part (slices of the context dims)
         self.attn_pq_in_fin = True   # inference: query projection and fin part share one launch (in-launch hand-off of pq)
-        # ... and the part of the decoder cell's gate product that does not wait for the attention rides in that launch (round 6: +2-3 %
+        # ... and the part of the decoder cell's gate product that does not wait for the attention rides in that launch (round 6: +4 %
         # mel-frames/s at C2; fp32 re-association only; ST_SPLIT_GATES=0 restores the whole product in the cell launch)
         self.split_gates = os.environ.get('ST_SPLIT_GATES', '1') != '0'
         self.split_cell_k = int(os.environ.get('ST_SPLIT_CELL_K', '0'))       # reduction columns the decoder cell keeps (0 = st_decoder_gate_split_k)

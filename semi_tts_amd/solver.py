@@ -259,12 +259,14 @@ class TtsTrainer(BaseSolver):
         parallel.sync_batchnorm(True)        # no-op for a single process; global-batch statistics under torch.distributed
         parallel.broadcast_parameters(self.model)
         self._attach_reducer()
-        # the detached postnet branch on a second stream (Tacotron2.postnet_side; ST_POSTNET_SIDE=1) -- without data parallelism only: a
-        # gradient bucket that goes out while the backward still runs must not mix gradients of two streams.  Bitwise the serial step
-        # (test_postnet_branch_on_a_second_stream_gives_bitwise_the_serial_step); OFF by default: measured round 6, the step is bound by the
-        # host's issue rate (9.1 of 9.7 ms), so the ~1 ms of GPU time it hides does not show (9.62 / 9.82 vs 9.73 / 9.83 ms)
+        # the detached postnet branch on a second stream (Tacotron2.postnet_side; ST_POSTNET_SIDE=0 turns it off) -- without data parallelism
+        # only: a gradient bucket that goes out while the backward still runs must not mix gradients of two streams.  Bitwise the serial step
+        # (test_postnet_branch_on_a_second_stream_gives_bitwise_the_serial_step).  Measured (round 6, A/B pairs in one process on the box of
+        # the final artifacts): 8.83 -> 8.62 ms per C2 training step, with or without the loop graphs (earlier boxes of the round: -0.07 ...
+        # -0.18 ms): the ~1 ms of CBHG forward / backward mostly hides behind the decoder's backward through time, the host's issue time
+        # (7.9 ms) is the next floor.
         self.model.tts.postnet_side = (self.reducer is None and type(self) is TtsTrainer and bool(getattr(self.model.tts, 'separate_postnet', False))
-                                       and os.environ.get('ST_POSTNET_SIDE', '0') == '1')
+                                       and os.environ.get('ST_POSTNET_SIDE', '1') != '0')
         return self
 
     def _attach_reducer(self):

@@ -265,7 +265,7 @@ class TtsTrainer(BaseSolver):
         # the final artifacts): 8.83 -> 8.62 ms per C2 training step, with or without the loop graphs (earlier boxes of the round: -0.07 ...
         # -0.18 ms): the ~1 ms of CBHG forward / backward mostly hides behind the decoder's backward through time, the host's issue time
         # (7.9 ms) is the next floor.
-        self.model.tts.postnet_side = (self.reducer is None and type(self) is TtsTrainer and bool(getattr(self.model.tts, 'separate_postnet', False))
+        self.model.tts.postnet_side = (self.reducer is None and bool(getattr(self.model.tts, 'separate_postnet', False))
                                        and os.environ.get('ST_POSTNET_SIDE', '1') != '0')
         return self
 
@@ -491,7 +491,7 @@ class VqvaeTrainer(TtsTrainer):
         from .optim import FusedAdam
         return self.async_stats and isinstance(getattr(self.optimizer, 'opt', None), FusedAdam)
 
-    def _paired_losses(self, pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats):
+    def _paired_losses(self, pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_done=False):
         """the terms both cycles share (bin/train_vqvae.py:208-224): CTC on the paired posteriors (+ the ASRPostnet term) and
         freq_loss on the paired reconstruction.  Appends (weight, loss, statistics name) to `terms`: the weighted sum itself -- and the
         partial sums the log prints -- are ONE launch in _finish_step (the reference's chain of one-element kernels)."""
@@ -509,7 +509,9 @@ class VqvaeTrainer(TtsTrainer):
         # (:216-218: a NaN / inf CTC value is counted when the statistics are read -- as in the reference it is already inside total,
         # the gradient norm is then NaN and the update is skipped)
         stats['asr_loss'] = asr_loss.detach()
-        terms += [(self.tts_weight, self.freq_loss(pm, mel), 'tts_loss'), (self.tts_weight, self.freq_loss(pl, linear), 'tts_loss')]   # :221-224
+        terms.append((self.tts_weight, self.freq_loss(pm, mel), 'tts_loss'))                                                  # :221-224
+        if not linear_done:                                  # (else: _side_branch has it, on the postnet's stream)
+            terms.append((self.tts_weight, self.freq_loss(pl, linear), 'tts_loss'))
 
     def _total(self, terms, stats):
         """total = sum of weight * loss over `terms`; the named partial sums (unweighted, as the reference logs them) land in `stats`"""
@@ -529,11 +531,52 @@ class VqvaeTrainer(TtsTrainer):
             if k in st and not math.isfinite(st[k]):
                 self.ctc_nan = getattr(self, 'ctc_nan', 0) + 1
 
-    def _finish_step(self, total, stats, tf_rate, kind):
+    def _side_branch(self, side_terms):
+        """separate_postnet (src/tts.py:47-50) cuts the gradient between the decoder and the postnet: when Tacotron2 ran the postnet on the
+        second stream (`postnet_stream`, TtsTrainer.set_model), the branch's losses (freq_loss of the linear spectrograms: `side_terms`) and its
+        whole backward (CBHG incl. both GRU passes) are issued there NOW, beside whatever the main stream does next; _finish_step joins the
+        streams after the main backward.  d total / d loss_i = w_i whatever the rest of the sum, so the two backward passes give the gradients
+        of the one pass bit for bit (the branch's parameters get no other contribution).  Returns None when the postnet ran on the main stream."""
+        side = getattr(self.model.tts, 'postnet_stream', None)
+        if side is None:
+            return None
+        with torch.cuda.stream(side):
+            stats = {}
+            total = self._total([(w, f(), nm) for w, f, nm in side_terms], stats)
+            total.backward()
+            ops.flush_wgrads()
+            ev = self.__dict__.setdefault('_side_event', torch.cuda.Event())
+            ev.record(side)
+        ops.side_pending(ev)                      # (one-launch BiLSTM layers of the main stream wait for it: they need every compute unit)
+        return total.detach(), stats, ev
+
+    def _finish_step(self, terms, stats, tf_rate, kind, side=None):
         """BaseSolver.backward (src/solver.py:138-151) + the step counter.  Synchronous form: the scalars are read here, a NaN gradient
         norm skips the update (as the reference does).  async_stats: nothing is read -- the scalars go into the statistics ring, the
-        guarded Adam skips a non-finite step on the device (TtsTrainer.train_step)."""
+        guarded Adam skips a non-finite step on the device (TtsTrainer.train_step).  `side`: what _side_branch returned."""
+        total = self._total(terms, stats)
         total.backward()
+        if side is not None:
+            from . import autograd as AG
+            side_total, side_stats, ev = side
+            torch.cuda.current_stream().wait_event(ev)
+            ops.side_pending(None)
+            # the two halves of the sum, and of each named partial sum, in one launch
+            names = [k for k in side_stats]
+            xs = [total.detach(), side_total] + [stats[k] for k in names if k in stats] + [side_stats[k] for k in names]
+            W = [[1.0, 1.0] + [0.0] * (len(xs) - 2)]
+            n_main = sum(1 for k in names if k in stats)
+            for i, k in enumerate(names):
+                row = [0.0] * len(xs)
+                row[2 + n_main + i] = 1.0
+                if k in stats:
+                    row[2 + [q for q in names if q in stats].index(k)] = 1.0
+                W.append(row)
+            with torch.no_grad():
+                outs = AG.scalar_combine(W, xs)
+            total = outs[0]
+            for k, v in zip(names, outs[1:]):
+                stats[k] = v
         self._reduce_gradients()
         grad_norm = self._clip()
         lr = self.optimizer.lr_at(self.step)
@@ -580,13 +623,17 @@ class VqvaeTrainer(TtsTrainer):
         out = self.model.text_to_speech(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
                                         unpair_latent_len, mel, None if ignore_speech_cycle else unpair_mel, tf_rate, _masks=_masks)
         pm, pl, _, _, upm, upl, _, _ = out
+        # :232: the unpaired term only counts after the warm-up steps (weight 0 before: computed and logged, as in the reference)
+        w = float(hp.get('unpair_speech_weight', 10.0)) if self.step > int(hp.get('unpair_speech_start_step', 0)) else 0.0
+        side = self._side_branch([(self.tts_weight, lambda: self.freq_loss(pl, linear), 'tts_loss')] +
+                                 ([] if ignore_speech_cycle else [(w, lambda: self.freq_loss(upl, unpair_linear), 'unpair_speech_loss')]))
         stats, terms = {}, []
-        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats)
+        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_done=side is not None)
         if not ignore_speech_cycle:                                                               # :227-233
-            # :232: the unpaired term only counts after the warm-up steps (weight 0 before: computed and logged, as in the reference)
-            w = float(hp.get('unpair_speech_weight', 10.0)) if self.step > int(hp.get('unpair_speech_start_step', 0)) else 0.0
-            terms += [(w, self.freq_loss(upm, unpair_mel), 'unpair_speech_loss'), (w, self.freq_loss(upl, unpair_linear), 'unpair_speech_loss')]
-        return self._finish_step(self._total(terms, stats), stats, tf_rate, 'speech_first')
+            terms.append((w, self.freq_loss(upm, unpair_mel), 'unpair_speech_loss'))
+            if side is None:
+                terms.append((w, self.freq_loss(upl, unpair_linear), 'unpair_speech_loss'))
+        return self._finish_step(terms, stats, tf_rate, 'speech_first', side)
 
     def text_first_step(self, mel, aug_mel, linear, text, sid, unpair_text=None, unpair_sid=None, _masks=None, _asr_masks=None):
         """The text -> speech -> text cycle of VqvaeTrainer.exec (bin/train_vqvae.py:186-205,208-224,234-250): text_to_speech on the
@@ -597,16 +644,23 @@ class VqvaeTrainer(TtsTrainer):
         hp = self.hp
         tf_rate = self._begin_step()
         use_unpair_text = unpair_text is not None                                                 # the caller gates it (:128,:149-152)
+        asr = None
+        if not use_unpair_text:
+            # Without unpaired text the two halves of this cycle do not feed each other: the speech encoder goes FIRST (the reference runs it
+            # second, :203-205), so that everything behind text_to_speech is backward work the postnet branch can run beside (_side_branch)
+            asr = self.model.speech_to_text(paired_mel=aug_mel, unpaired_mel=None, using_fake_mel=False,
+                                            **({'_masks': _asr_masks} if _asr_masks is not None else {}))
         out = self.model.text_to_speech(text, sid, unpair_sid if use_unpair_text else None, None, unpair_text, None, mel, None,
                                         tf_rate, _masks=_masks)                                   # :190-199
         pm, pl, _, _, upm, _, _, _ = out
+        side = self._side_branch([(self.tts_weight, lambda: self.freq_loss(pl, linear), 'tts_loss')])
         if use_unpair_text:
             upm = upm.detach()                                                                    # :201-202
-        pair_prob, _, unpair_prob, _, _, pair_post_prob, _ = self.model.speech_to_text(
-            paired_mel=aug_mel, unpaired_mel=upm if use_unpair_text else None, using_fake_mel=use_unpair_text,
-            **({'_masks': _asr_masks} if _asr_masks is not None else {}))                        # :203-205
+            asr = self.model.speech_to_text(paired_mel=aug_mel, unpaired_mel=upm, using_fake_mel=True,
+                                            **({'_masks': _asr_masks} if _asr_masks is not None else {}))   # :203-205
+        pair_prob, _, unpair_prob, _, _, pair_post_prob, _ = asr
         stats, terms = {}, []
-        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats)
+        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_done=side is not None)
         if use_unpair_text:                                                                       # :234-250
             ut = self.ctc_loss(unpair_prob, unpair_text)
             stats['unpair_text_loss'] = ut.detach()
@@ -615,7 +669,7 @@ class VqvaeTrainer(TtsTrainer):
             v = float(ut.detach())
             if math.isfinite(v):
                 terms.append((float(hp.get('unpair_text_weight', 0.0)), ut, None))
-        return self._finish_step(self._total(terms, stats), stats, tf_rate, 'text_first')
+        return self._finish_step(terms, stats, tf_rate, 'text_first', side)
 
     def cycle_step(self, pair, unpair=None, _masks=None, _asr_masks=None):
         """One iteration of VqvaeTrainer.exec's loop body (bin/train_vqvae.py:124-150): even steps run the speech-first cycle, odd

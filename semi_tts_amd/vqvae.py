@@ -154,7 +154,12 @@ class VQVAE(nn.Module):
             if mel.requires_grad or linear.requires_grad:
                 # (the same slices; their backward writes both gradients into one tensor instead of zero-fill + copy + add per slice)
                 pm, um = AG.split_pair(mel, b, paired_ts, unpaired_ts)
-                pl, ul = AG.split_pair(linear, b, paired_ts, unpaired_ts)
+                side = getattr(self.tts, 'postnet_stream', None)
+                if side is not None:                 # (the postnet ran on the second stream: the backward of its split belongs there too)
+                    with torch.cuda.stream(side):
+                        pl, ul = AG.split_pair(linear, b, paired_ts, unpaired_ts)
+                else:
+                    pl, ul = AG.split_pair(linear, b, paired_ts, unpaired_ts)
             else:
                 pm, um, pl, ul = mel[:b, :paired_ts], mel[b:, :unpaired_ts], linear[:b, :paired_ts], linear[b:, :unpaired_ts]
             return (pm, pl, align[:b, :paired_ts], stop[:b], um, ul, align[b:, :unpaired_ts], stop[b:])

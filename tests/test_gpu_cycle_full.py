@@ -285,3 +285,34 @@ def test_cycle_steps_asynchronous_statistics_equal_the_synchronous_ones(dev):
     assert s0 == s1, (s0, s1)
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k
+
+
+def test_cycle_steps_with_the_postnet_branch_on_a_second_stream_equal_the_one_stream_steps(dev):
+    """separate_postnet: the linear-spectrogram losses and the CBHG backward of both cycle kinds on the second stream (Tacotron2.postnet_side,
+    VqvaeTrainer._side_branch) beside the main backward -- four alternating steps at B = 4 + 4: same statistics, same weights bit for bit as
+    the steps on one stream."""
+    cfg = _config()
+    assert cfg['model']['decoder'].get('separate_postnet', False)
+    from semi_tts_amd.synthetic import synthetic_cycle_batch
+    pair = [t.to(dev) for t in synthetic_cycle_batch(4, 64, 3, seed=5)]
+    unpair = [t.to(dev) for t in synthetic_cycle_batch(4, 64, 3, seed=6)]
+    outs = []
+    for side in (False, True):
+        model = _model(cfg, dev, seed=77)
+        model.tts.postnet_side = side
+        tr, _ = _trainer(cfg, model)
+        tr.clip_grad_norm_ = type(tr).clip_grad_norm_
+        tr.async_stats = True
+        torch.manual_seed(11)
+        tr.step = 2
+        log = [tr.cycle_step(pair, unpair if tr.cycle_kind(tr.step)[1] else None) for _ in range(4)]
+        assert (model.tts.postnet_stream is not None) == side
+        tr.drain_stats()
+        torch.cuda.synchronize()
+        outs.append(([{k: float(st[k]) for k in ('loss', 'asr_loss', 'tts_loss', 'grad_norm')} for st in log],
+                     [float(st.get('unpair_speech_loss', 0.0)) for st in log], {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (s0, u0, w0), (s1, u1, w1) = outs
+    assert s0 == s1, (s0, s1)
+    assert u0 == u1 and any(u0), (u0, u1)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k

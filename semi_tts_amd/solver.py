@@ -491,7 +491,7 @@ class VqvaeTrainer(TtsTrainer):
         from .optim import FusedAdam
         return self.async_stats and isinstance(getattr(self.optimizer, 'opt', None), FusedAdam)
 
-    def _paired_losses(self, pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_done=False):
+    def _paired_losses(self, pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_loss=None):
         """the terms both cycles share (bin/train_vqvae.py:208-224): CTC on the paired posteriors (+ the ASRPostnet term) and
         freq_loss on the paired reconstruction.  Appends (weight, loss, statistics name) to `terms`: the weighted sum itself -- and the
         partial sums the log prints -- are ONE launch in _finish_step (the reference's chain of one-element kernels)."""
@@ -509,9 +509,9 @@ class VqvaeTrainer(TtsTrainer):
         # (:216-218: a NaN / inf CTC value is counted when the statistics are read -- as in the reference it is already inside total,
         # the gradient norm is then NaN and the update is skipped)
         stats['asr_loss'] = asr_loss.detach()
-        terms.append((self.tts_weight, self.freq_loss(pm, mel), 'tts_loss'))                                                  # :221-224
-        if not linear_done:                                  # (else: _side_branch has it, on the postnet's stream)
-            terms.append((self.tts_weight, self.freq_loss(pl, linear), 'tts_loss'))
+        # (linear_loss: the value _side_branch computed -- and sent backward -- on the postnet's stream)                           :221-224
+        terms += [(self.tts_weight, self.freq_loss(pm, mel), 'tts_loss'),
+                  (self.tts_weight, linear_loss if linear_loss is not None else self.freq_loss(pl, linear), 'tts_loss')]
 
     def _total(self, terms, stats):
         """total = sum of weight * loss over `terms`; the named partial sums (unweighted, as the reference logs them) land in `stats`"""
@@ -536,47 +536,36 @@ class VqvaeTrainer(TtsTrainer):
         second stream (`postnet_stream`, TtsTrainer.set_model), the branch's losses (freq_loss of the linear spectrograms: `side_terms`) and its
         whole backward (CBHG incl. both GRU passes) are issued there NOW, beside whatever the main stream does next; _finish_step joins the
         streams after the main backward.  d total / d loss_i = w_i whatever the rest of the sum, so the two backward passes give the gradients
-        of the one pass bit for bit (the branch's parameters get no other contribution).  Returns None when the postnet ran on the main stream."""
+        of the one pass bit for bit (the branch's parameters get no other contribution).  Returns None when the postnet ran on the main stream,
+        else (event, the loss values in the order of `side_terms`): the caller puts them where the one-stream step has these terms."""
         side = getattr(self.model.tts, 'postnet_stream', None)
         if side is None:
             return None
         with torch.cuda.stream(side):
-            stats = {}
-            total = self._total([(w, f(), nm) for w, f, nm in side_terms], stats)
+            vals = [f() for _, f, _ in side_terms]
+            total = self._total([(w, x, nm) for (w, _, nm), x in zip(side_terms, vals)], {})
             total.backward()
             ops.flush_wgrads()
             ev = self.__dict__.setdefault('_side_event', torch.cuda.Event())
             ev.record(side)
         ops.side_pending(ev)                      # (one-launch BiLSTM layers of the main stream wait for it: they need every compute unit)
-        return total.detach(), stats, ev
+        return ev, [x.detach() for x in vals]
 
     def _finish_step(self, terms, stats, tf_rate, kind, side=None):
         """BaseSolver.backward (src/solver.py:138-151) + the step counter.  Synchronous form: the scalars are read here, a NaN gradient
         norm skips the update (as the reference does).  async_stats: nothing is read -- the scalars go into the statistics ring, the
         guarded Adam skips a non-finite step on the device (TtsTrainer.train_step).  `side`: what _side_branch returned."""
-        total = self._total(terms, stats)
-        total.backward()
-        if side is not None:
-            from . import autograd as AG
-            side_total, side_stats, ev = side
-            torch.cuda.current_stream().wait_event(ev)
+        if side is None:
+            total = self._total(terms, stats)
+            total.backward()
+        else:
+            # the terms the second stream has already sent backward (no graph: detached values) stay out of this backward pass ...
+            self._total([t for t in terms if t[1].requires_grad], {}).backward()
+            torch.cuda.current_stream().wait_event(side[0])
             ops.side_pending(None)
-            # the two halves of the sum, and of each named partial sum, in one launch
-            names = [k for k in side_stats]
-            xs = [total.detach(), side_total] + [stats[k] for k in names if k in stats] + [side_stats[k] for k in names]
-            W = [[1.0, 1.0] + [0.0] * (len(xs) - 2)]
-            n_main = sum(1 for k in names if k in stats)
-            for i, k in enumerate(names):
-                row = [0.0] * len(xs)
-                row[2 + n_main + i] = 1.0
-                if k in stats:
-                    row[2 + [q for q in names if q in stats].index(k)] = 1.0
-                W.append(row)
+            # ... and the reported sums are ONE launch over all terms in the order of the one-stream step: the same arithmetic, bit for bit
             with torch.no_grad():
-                outs = AG.scalar_combine(W, xs)
-            total = outs[0]
-            for k, v in zip(names, outs[1:]):
-                stats[k] = v
+                total = self._total([(w, x.detach(), nm) for w, x, nm in terms], stats)
         self._reduce_gradients()
         grad_norm = self._clip()
         lr = self.optimizer.lr_at(self.step)
@@ -627,12 +616,12 @@ class VqvaeTrainer(TtsTrainer):
         w = float(hp.get('unpair_speech_weight', 10.0)) if self.step > int(hp.get('unpair_speech_start_step', 0)) else 0.0
         side = self._side_branch([(self.tts_weight, lambda: self.freq_loss(pl, linear), 'tts_loss')] +
                                  ([] if ignore_speech_cycle else [(w, lambda: self.freq_loss(upl, unpair_linear), 'unpair_speech_loss')]))
+        lin = side[1] if side is not None else [None, None]
         stats, terms = {}, []
-        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_done=side is not None)
+        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_loss=lin[0])
         if not ignore_speech_cycle:                                                               # :227-233
-            terms.append((w, self.freq_loss(upm, unpair_mel), 'unpair_speech_loss'))
-            if side is None:
-                terms.append((w, self.freq_loss(upl, unpair_linear), 'unpair_speech_loss'))
+            terms += [(w, self.freq_loss(upm, unpair_mel), 'unpair_speech_loss'),
+                      (w, lin[1] if side is not None else self.freq_loss(upl, unpair_linear), 'unpair_speech_loss')]
         return self._finish_step(terms, stats, tf_rate, 'speech_first', side)
 
     def text_first_step(self, mel, aug_mel, linear, text, sid, unpair_text=None, unpair_sid=None, _masks=None, _asr_masks=None):
@@ -660,7 +649,7 @@ class VqvaeTrainer(TtsTrainer):
                                             **({'_masks': _asr_masks} if _asr_masks is not None else {}))   # :203-205
         pair_prob, _, unpair_prob, _, _, pair_post_prob, _ = asr
         stats, terms = {}, []
-        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_done=side is not None)
+        self._paired_losses(pair_prob, pair_post_prob, pm, pl, mel, linear, text, terms, stats, linear_loss=side[1][0] if side is not None else None)
         if use_unpair_text:                                                                       # :234-250
             ut = self.ctc_loss(unpair_prob, unpair_text)
             stats['unpair_text_loss'] = ut.detach()

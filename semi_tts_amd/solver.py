@@ -265,9 +265,21 @@ class TtsTrainer(BaseSolver):
         # the final artifacts): 8.83 -> 8.62 ms per C2 training step, with or without the loop graphs (earlier boxes of the round: -0.07 ...
         # -0.18 ms): the ~1 ms of CBHG forward / backward mostly hides behind the decoder's backward through time, the host's issue time
         # (7.9 ms) is the next floor.
-        self.model.tts.postnet_side = (self.reducer is None and bool(getattr(self.model.tts, 'separate_postnet', False))
-                                       and os.environ.get('ST_POSTNET_SIDE', '1') != '0')
+        self.postnet_side = (self.reducer is None and bool(getattr(self.model.tts, 'separate_postnet', False))
+                             and os.environ.get('ST_POSTNET_SIDE', '1') != '0')
+        # (Tacotron2.postnet_side itself is raised only around the trainer's own text_to_speech calls, _tts: anybody else who calls the model
+        # gets every output on the stream it called on)
         return self
+
+    def _tts(self, *args, **kw):
+        """VQVAE.text_to_speech for a step of THIS trainer: with `postnet_side` the postnet output comes back on the second stream
+        (Tacotron2.postnet_stream) and the caller continues the branch there (train_step, VqvaeTrainer._side_branch)"""
+        tts = self.model.tts
+        tts.postnet_side = bool(getattr(self, 'postnet_side', False))
+        try:
+            return self.model.text_to_speech(*args, **kw)
+        finally:
+            tts.postnet_side = False
 
     def _attach_reducer(self):
         """under torch.distributed: gradients live in flat buckets that are all-reduced while the backward pass still runs"""
@@ -302,7 +314,7 @@ class TtsTrainer(BaseSolver):
         tf_rate = self.optimizer.pre_step(self.step)
         if getattr(self, 'reducer', None) is not None:
             self.reducer.prepare()
-        mel_pred, linear_pred, align, _, _, _, _, _ = self.model.text_to_speech(
+        mel_pred, linear_pred, align, _, _, _, _, _ = self._tts(
             text, sid, None, None, None, None, mel, None, tf_rate, _masks=_masks)
         from . import autograd as AG
         side = getattr(self.model.tts, 'postnet_stream', None)
@@ -609,7 +621,7 @@ class VqvaeTrainer(TtsTrainer):
         ignore_speech_cycle = unpair_latent is None                                               # :163-172
         if unpair_aug_mel is not None:
             self._step_info.update(unpair_text_len=0 if ignore_speech_cycle else int(unpair_latent.shape[1]))
-        out = self.model.text_to_speech(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
+        out = self._tts(text, sid, None if ignore_speech_cycle else unpair_sid, unpair_latent, None,
                                         unpair_latent_len, mel, None if ignore_speech_cycle else unpair_mel, tf_rate, _masks=_masks)
         pm, pl, _, _, upm, upl, _, _ = out
         # :232: the unpaired term only counts after the warm-up steps (weight 0 before: computed and logged, as in the reference)
@@ -639,7 +651,7 @@ class VqvaeTrainer(TtsTrainer):
             # second, :203-205), so that everything behind text_to_speech is backward work the postnet branch can run beside (_side_branch)
             asr = self.model.speech_to_text(paired_mel=aug_mel, unpaired_mel=None, using_fake_mel=False,
                                             **({'_masks': _asr_masks} if _asr_masks is not None else {}))
-        out = self.model.text_to_speech(text, sid, unpair_sid if use_unpair_text else None, None, unpair_text, None, mel, None,
+        out = self._tts(text, sid, unpair_sid if use_unpair_text else None, None, unpair_text, None, mel, None,
                                         tf_rate, _masks=_masks)                                   # :190-199
         pm, pl, _, _, upm, _, _, _ = out
         side = self._side_branch([(self.tts_weight, lambda: self.freq_loss(pl, linear), 'tts_loss')])

@@ -299,8 +299,8 @@ def test_cycle_steps_with_the_postnet_branch_on_a_second_stream_equal_the_one_st
     outs = []
     for side in (False, True):
         model = _model(cfg, dev, seed=77)
-        model.tts.postnet_side = side
         tr, _ = _trainer(cfg, model)
+        tr.postnet_side = side
         tr.clip_grad_norm_ = type(tr).clip_grad_norm_
         tr.async_stats = True
         torch.manual_seed(11)

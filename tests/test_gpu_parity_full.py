@@ -333,7 +333,7 @@ def test_postnet_branch_on_a_second_stream_gives_bitwise_the_serial_step(dev):
     for side in (False, True):
         paras = Namespace(batch_size=8, frames=64, n_batches=1, seed=3, verbose=False, max_step=2, load=None)
         tr = TtsTrainer(cfg, paras, 'train').load_data().set_model()
-        tr.model.tts.postnet_side = side
+        tr.postnet_side = side
         torch.manual_seed(7)
         batch = [t.to(dev) for t in tr.batches[0]]
         sts = [tr.train_step(*batch) for _ in range(2)]

@@ -160,6 +160,8 @@ typedef struct st_lstm_cell_packed_job {
     float* c_out; int ldc; float* gates_out;
     const float* ada_std; const float* ada_mean; st_t16_view hadapt_dst;   /* hadapt_dst.base may be NULL */
     int B, H;
+    const float* part; int w_kbs;   /* optional (as st_lstm_cell_packed_part_fwd): K covers the LEADING k-blocks of a matrix packed with w_kbs
+                                     * k-blocks per tile; the gate products over the others arrive as the (B, 4 H) slab `part` */
 } st_lstm_cell_packed_job;
 int st_lstm_cell_packed_pair_fwd(const st_lstm_cell_packed_job* j0, const st_lstm_cell_packed_job* j1, void* stream);
 /* st_skinny_linear_fwd on packed operands; output natural (y) and/or T16 (y_dst).
@@ -215,6 +217,7 @@ int st_attn_fin_t16_fwd(const float* pq, const float* s_buf, const float* memory
 /* st_skinny_linear_packed_fwd plus, as extra workgroups of the same launch (one per utterance), st_attn_pre_fwd for the NEXT
  * decode step: the proj (+) gate launch of step t leaves most compute units idle and the attention weights of step t are
  * already known, so S of step t+1 is ready when its attention launch starts. */
+struct st_partial_product_job;
 typedef struct st_attn_pre_job {
     const float* pm; const float* w_prev; int ld_wprev; const float* w_cum_prev;
     const float* loc_conv_w; const float* loc_lin_w; float* s_buf;
@@ -230,6 +233,10 @@ typedef struct st_attn_pre_job {
     const float* p2_packed_w; int p2_K, p2_N, p2_act; const float* p2_mask; int p2_ldmask;
     st_t16_view p2_dst;
     unsigned long long* p2_gran; unsigned p2_epoch; unsigned* p2_status;
+    /* optional: a K-split partial product (st_partial_product_job, below) on the compute units the launch leaves idle -- teacher-forced
+     * training hosts the tail of the decoder cell's gate reduction beside the query projection + attention pre part (B = 17..32; the
+     * launch then has N / 16 x 2 + B x parts + job->N / 32 workgroups).  Not together with p2 */
+    const struct st_partial_product_job* part;
 } st_attn_pre_job;
 int st_skinny_linear_packed_attnpre_fwd(const float* packed_w, const st_t16_view* x, int K,
                                         const float* bias, int act, const float* mask, int ldmask,

@@ -114,7 +114,7 @@ class StLstmCellPackedJob(C.Structure):
     _fields_ = [('packed_w', C.c_void_p), ('x', StT16View), ('K', C.c_int), ('b_ih', C.c_void_p), ('b_hh', C.c_void_p),
                 ('c_prev', C.c_void_p), ('ldc_prev', C.c_int), ('mask', C.c_void_p), ('h_dst0', StT16View), ('h_dst1', StT16View),
                 ('c_out', C.c_void_p), ('ldc', C.c_int), ('gates_out', C.c_void_p), ('ada_std', C.c_void_p), ('ada_mean', C.c_void_p),
-                ('hadapt_dst', StT16View), ('B', C.c_int), ('H', C.c_int)]
+                ('hadapt_dst', StT16View), ('B', C.c_int), ('H', C.c_int), ('part', C.c_void_p), ('w_kbs', C.c_int)]
 
 
 class StAttnBwdJob(C.Structure):
@@ -152,7 +152,8 @@ class StAttnPreJob(C.Structure):
                 ('loc_conv_w', C.c_void_p), ('loc_lin_w', C.c_void_p), ('s_buf', C.c_void_p),
                 ('L', C.c_int), ('A', C.c_int), ('F', C.c_int), ('K', C.c_int), ('parts', C.c_int), ('cf_out', C.c_void_p),
                 ('p2_packed_w', C.c_void_p), ('p2_K', C.c_int), ('p2_N', C.c_int), ('p2_act', C.c_int), ('p2_mask', C.c_void_p),
-                ('p2_ldmask', C.c_int), ('p2_dst', StT16View), ('p2_gran', C.c_void_p), ('p2_epoch', C.c_uint), ('p2_status', C.c_void_p)]
+                ('p2_ldmask', C.c_int), ('p2_dst', StT16View), ('p2_gran', C.c_void_p), ('p2_epoch', C.c_uint), ('p2_status', C.c_void_p),
+                ('part', C.c_void_p)]
 
 
 class StAttnFinJob(C.Structure):

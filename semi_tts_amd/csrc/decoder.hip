@@ -323,9 +323,15 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
     // (DESIGN.md section 3.5): a hosted product costs ~7 us + 3 us per 1024 columns whatever its host's length.
     // (the other forms of the attention step issue the partial product as a launch of its own: same arithmetic bit for bit, so a starved
     // hand-off that degrades to the two-launch form changes nothing but the speed)
-    const bool split_d = io->gate_part && !defer && !pair_cells && B > 16 && B <= 32 && D % 16 == 0 && (D / 4) % 2 == 0 &&
+    // Teacher-forced training (deferred projection) has the same split: there the product rides beside the query projection + attention pre
+    // part of the step (pre_in_pq; its operands come from the paired cell launch of the step before), the paired launch adds the slab.
+    const bool split_d = io->gate_part && (!defer || pre_in_pq) && B > 16 && B <= 32 && D % 16 == 0 && (D / 4) % 2 == 0 &&
                          E % 16 == 0 && Q % 16 == 0 && st_aligned16(io->gate_part);
     const bool split_hosted = split_d && fuse_pq_fin && (A / 16) * ((B + 15) / 16) + B * fin_parts + (4 * D) / 32 <= st_device_cus();
+    // (two attention-pre workgroups per utterance then: with four, 16 + 128 + 128 workgroups would not fit the device in one round)
+    const int pre_parts_split = io->attn_pre_parts > 2 ? 2 : io->attn_pre_parts;
+    const bool split_pre = split_d && pre_in_pq && A <= 16 * 128 &&
+                           ((A + 15) / 16) * ((B + 15) / 16) + B * (pre_parts_split > 1 ? pre_parts_split : 1) + (4 * D) / 32 <= st_device_cus();
     st_partial_product_job pj_d;
     memset(&pj_d, 0, sizeof(pj_d));
     // ... how much of it: measured at C2 (hosted 512 / 768 / 1024 / 1280 / 1536 / 2048 columns: 2.78 / 2.83 / 2.88 / 2.89 / 2.86 / 2.81 M
@@ -340,6 +346,7 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
         float* xd = io->xd_tape + (size_t)t * sv.d_floats;
         float* xd_next = io->xd_tape + (size_t)(t + 1) * sv.d_floats;
         float* xo = io->xo_tape + (size_t)t * sv.o_floats;
+        bool prod_done = false;          // the hosted part of the decoder cell's gate product of this step has been issued
 
         // 1. query LSTM (+ AdaIN of the new hidden state)                ref: :227-231, :267-269
         //    h_q_t -> xq_{t+1}[h part] (next step's recurrent input, also the query projection's input)
@@ -361,8 +368,13 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
         else if (pre_in_pq && t > 0) {   // attention pre part of THIS step rides along (needs only the weights of step t-1)
             st_attn_pre_job job = {io->pm, io->align_out + (size_t)(t - 1) * L, ldal, io->wcum_tape + (size_t)t * BL,
                                    w->attn_loc_conv_w, w->attn_loc_lin_w, io->attn_s_buf + (size_t)t * io->attn_s_step_floats, L, A, d->F,
-                                   d->K, io->attn_pre_parts,
+                                   d->K, split_pre ? pre_parts_split : io->attn_pre_parts,
                                    io->attn_loc_tape ? io->attn_loc_tape + (size_t)t * BL * d->F : nullptr};
+            if (split_pre) {             // ... and the tail of the decoder cell's gate product of this step
+                pj_d.x = st_t16_view{xd, sv.d_kbs, d_k0};
+                job.part = &pj_d;
+                prod_done = true;
+            }
             rc = st_skinny_linear_packed_attnpre_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), nullptr, ST_ACT_NONE, nullptr, 0,
                                                      io->pq_buf, A, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, B, A,
                                                      &job, stream);
@@ -405,6 +417,7 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
             fj.n_ctx_dst = 3; fj.parts = fin_parts; fj.L = L; fj.A = A; fj.E = E; fj.F = d->F; fj.K = d->K;
             if (split_hosted && !ST_SKIPPED(3)) {
                 pj_d.x = st_t16_view{xd, sv.d_kbs, d_k0};
+                prod_done = true;
                 rc = st_query_attn_fin_part_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, &pj_d, stream);
             } else
             rc = st_query_attn_fin_fwd(io->packed + pl.pq, &hq_dst, 16 * kb16(Q), io->pq_granules, (unsigned)(t + 1), &fj, B, stream);
@@ -427,11 +440,17 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
         st_t16_view xd_v = {xd, sv.d_kbs, 0};
         st_t16_view hd_dst0 = {xd_next, sv.d_kbs, sv.d_h};
         st_t16_view hd_dst1 = {xo, sv.o_kbs, 0};
+        if (split_d && !prod_done && !ST_SKIPPED(3) && !(split_hosted && (ST_SKIPPED(1) || ST_SKIPPED(2)))) {       // (no launch of this step could host the product: one of its own, same arithmetic)
+            pj_d.x = st_t16_view{xd, sv.d_kbs, d_k0};
+            rc = st_partial_product_fwd(&pj_d, B, stream);
+            if (rc) return rc;
+        }
         if (pair_cells && t + 1 < steps) {
             // teacher forcing: the query cell of step t+1 needs ctx_t, h_q_t and a teacher frame -- not h_d_t.  Both cells in one launch.
             st_lstm_cell_packed_job jd, jq;
             memset(&jd, 0, sizeof(jd)); memset(&jq, 0, sizeof(jq));
             jd.packed_w = io->packed + pl.d; jd.x = xd_v; jd.K = Kd; jd.b_ih = w->d_b_ih; jd.b_hh = w->d_b_hh;
+            if (split_d) { jd.K = 16 * d_k0; jd.part = io->gate_part; jd.w_kbs = sv.d_kbs; }
             jd.c_prev = io->cd_tape + (size_t)t * BD; jd.ldc_prev = D; jd.mask = io->d_mask ? io->d_mask + (size_t)t * BD : nullptr;
             jd.h_dst0 = hd_dst0; jd.h_dst1 = hd_dst1; jd.c_out = io->cd_tape + (size_t)(t + 1) * BD; jd.ldc = D;
             jd.gates_out = io->gates_d_tape ? io->gates_d_tape + (size_t)t * 4 * BD : nullptr;
@@ -445,11 +464,6 @@ static int decoder_forward_issue(const st_decoder_weights* w, const st_decoder_d
             jq.B = B; jq.H = Q;
             rc = st_lstm_cell_packed_pair_fwd(&jd, &jq, stream);
         } else {
-        if (split_d && !split_hosted && !ST_SKIPPED(3)) {
-            pj_d.x = st_t16_view{xd, sv.d_kbs, d_k0};
-            rc = st_partial_product_fwd(&pj_d, B, stream);
-            if (rc) return rc;
-        }
         if (split_d && !ST_SKIPPED(3) && !(split_hosted && (ST_SKIPPED(1) || ST_SKIPPED(2))))
             rc = st_lstm_cell_packed_part_fwd(io->packed + pl.d, sv.d_kbs, &xd_v, 16 * d_k0, io->gate_part, w->d_b_ih, w->d_b_hh,
                                               io->cd_tape + (size_t)t * BD, D, io->d_mask ? io->d_mask + (size_t)t * BD : nullptr,

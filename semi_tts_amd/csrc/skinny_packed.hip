@@ -1182,6 +1182,29 @@ __global__ __launch_bounds__(KW * 64) void pk_attnpre_kernel(const f32x4* w, con
     else at_body<VEC, 1>(t, i - n_lin, pk_dyn_lds);
 }
 
+// ... or, behind the attention-pre workgroups, the workgroups of a K-split partial product (pk_part_body): teacher-forced training hosts the
+// tail of the decoder cell's gate reduction here (its operands come from the launch before), the paired cell launch adds the slab.
+template <int NB, int KW, int TRIP, bool VEC>
+__global__ __launch_bounds__(KW * 64) void pk_attnpre_part_kernel(const f32x4* w, const f32x4* x, const int w_kbs, const int x_kbs, const int KB,
+                                                                  const int B, const int N, const int tiles_a, const int n_lin,
+                                                                  const float* at_pm, const float* at_wprev, const int at_L,
+                                                                  const PkArgs a_rest, const AtArgs t_rest, const int n_at, const PkPartArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float pk_dyn_lds[];
+    __shared__ f32x4 red[KW * NB * 64];
+    static_assert(KW * 64 == AT_THREADS, "both parts use 512-thread workgroups");
+    const int i = blockIdx.x;
+    if (i < n_lin) {
+        PkArgs a = a_rest;
+        a.w = w; a.x = x; a.w_kbs = w_kbs; a.x_kbs = x_kbs; a.KB = KB; a.B = B; a.N = N;
+        const int by = n_lin <= 2 * tiles_a ? (i >= tiles_a ? 1 : 0) : i / tiles_a;
+        pk_body<1, NB, KW, TRIP>(a, i - by * tiles_a, by, red);
+    } else if (i < n_lin + n_at) {
+        AtArgs t = t_rest;
+        t.pm = at_pm; t.w_prev = at_wprev; t.L = at_L;
+        at_body<VEC, 1>(t, i - n_lin, pk_dyn_lds);
+    } else pk_part_body<KW, 2>(p, i - n_lin - n_at, reinterpret_cast<f32x4*>(pk_dyn_lds));
+}
+
 // A small linear whose CONSUMER rides in the same launch: the query projection pq = W_q h_q (first n_lin workgroups) and the fin
 // part of the attention step (energies, softmax, context; the workgroups after them).  The fin workgroups request everything
 // that does not depend on pq at once and then wait for pq as {value, tag} granules (at_body<.., GRAN = true>): one kernel
@@ -1252,9 +1275,28 @@ __global__ __launch_bounds__(KW * 64, 4) void pk_attnrng_kernel(const f32x4* w, 
 int pk_fill(PkArgs& a, const float* packed_w, const st_t16_view* x, int K, const char* who);
 
 template <int NB>
-int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st, const PkArgs* p2 = nullptr, unsigned* p2_status = nullptr) {
+int pk_launch_attnpre(const PkArgs& a, int tiles, const AtArgs& t, hipStream_t st, const PkArgs* p2 = nullptr, unsigned* p2_status = nullptr,
+                      const PkPartArgs* pp = nullptr) {
     constexpr int KW = 8, TRIP = NB == 1 ? PK_TRIP_SMALL : 2;
     const int BT = (a.B + 15) >> 4, gy = (BT + NB - 1) / NB;
+    if constexpr (NB == 1) if (pp) {       // + the workgroups of a hosted partial product (their reduction buffer lives in the dynamic LDS region)
+        const bool vec = (t.A % 4 == 0) && (t.F % 4 == 0) && st_aligned16(t.pm) && st_aligned16(t.loc_lin_w) && st_aligned16(t.s_buf);
+        const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K, 1, at_pos_per(t.L, t.pre_parts > 1 ? t.pre_parts : 1), vec && t.F == 32 && t.A % 16 == 0);
+        size_t lds = (size_t)o.total * sizeof(float);
+        if (lds < sizeof(f32x4) * KW * 4 * 64) lds = sizeof(f32x4) * KW * 4 * 64;
+        ST_CHECK_ARG(lds + sizeof(f32x4) * KW * NB * 64 <= 160 * 1024, "linear + attention-pre launch: L=%d needs too much LDS (use more parts)", t.L);
+        auto kern = vec ? pk_attnpre_part_kernel<NB, KW, TRIP, true> : pk_attnpre_part_kernel<NB, KW, TRIP, false>;
+        static size_t configured[2] = {0, 0};
+        if (lds > 32 * 1024 && lds > configured[vec ? 1 : 0]) {
+            ST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured[vec ? 1 : 0] = lds;
+        }
+        const int n_at = t.B * (t.pre_parts > 1 ? t.pre_parts : 1);
+        hipLaunchKernelGGL(kern, dim3(tiles * gy + n_at + (pp->N >> 5)), dim3(KW * 64), lds, st, a.w, a.x, a.w_kbs, a.x_kbs,
+                           a.KB, a.B, a.N, tiles, tiles * gy, t.pm, t.w_prev, t.L, a, t, n_at, *pp);
+        ST_LAUNCH_CHECK();
+        return 0;
+    }
     if constexpr (NB == 1) if (p2) {       // + the workgroups of the in-launch second linear (every workgroup of the launch resident at once: checked by the caller)
         const bool vec = (t.A % 4 == 0) && (t.F % 4 == 0) && st_aligned16(t.pm) && st_aligned16(t.loc_lin_w) && st_aligned16(t.s_buf);
         const AtLds o = at_layout(t.L, t.A, t.E, t.F, t.K, 1, at_pos_per(t.L, t.pre_parts > 1 ? t.pre_parts : 1), vec && t.F == 32 && t.A % 16 == 0);
@@ -1552,6 +1594,11 @@ static int pk_lstm_fill(PkArgs& a, const st_lstm_cell_packed_job* j, const char*
     a.c_out = j->c_out; a.ldc = j->ldc; a.gates_out = j->gates_out;
     a.h_dst[0] = pk_out(&j->h_dst0); a.h_dst[1] = pk_out(&j->h_dst1);
     a.ada_std = j->ada_std; a.ada_mean = j->ada_mean; a.ha_dst = pk_out(&j->hadapt_dst);
+    if (j->part) {       // (as lstm_cell_packed_impl: K covers the leading k-blocks, the others arrive as a slab)
+        ST_CHECK_ARG(pk_rt2_shape(j->B, j->H / 4) && ((j->B + 15) >> 4) == 2 && j->w_kbs >= a.KB && st_aligned16(j->part),
+                     "%s: a slab needs B = 17..32, an even number of row tiles, w_kbs >= K / 16 and 16-byte alignment", who);
+        a.part = j->part; a.w_kbs = j->w_kbs;
+    }
     return 0;
 }
 
@@ -1609,6 +1656,7 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
         const int BT = (B + 15) >> 4;
         if (pre->p2_packed_w) {
             // prenet layer 2 (or any linear over the third range) inside this launch: its operand travels as granules
+            ST_CHECK_ARG(!pre->part, "st_skinny_linear_packed_attnpre_fwd: p2 and a hosted partial product exclude each other");
             ST_CHECK_ARG(n_split2 > 0 && pre->p2_gran && pre->p2_epoch != 0 && pre->p2_K == N - n_split2 && pre->p2_K % 16 == 0 &&
                          pre->p2_K <= 16 * 8 * PK_P2_MAXG && pre->p2_N > 0 && pre->p2_dst.base && (reinterpret_cast<uintptr_t>(pre->p2_gran) & 7) == 0,
                          "st_skinny_linear_packed_attnpre_fwd: bad in-launch linear (K = third range, a multiple of 16, at most %d)", 16 * 8 * PK_P2_MAXG);
@@ -1624,6 +1672,19 @@ static int pk_linear_impl(const float* packed_w, const st_t16_view* x, int K,
             ST_CHECK_ARG(tiles * gy1 + n_at + n_p2 <= st_device_cus(), "st_skinny_linear_packed_attnpre_fwd: %d + %d + %d workgroups do not fit the device at once",
                          tiles * gy1, n_at, n_p2);
             return pk_launch_attnpre<1>(a, tiles, t, (hipStream_t)stream, &p2, pre->p2_status);
+        }
+        if (pre->part) {
+            const st_partial_product_job* pj = pre->part;
+            ST_CHECK_ARG(pj->packed_w && pj->x.base && pj->part && pj->KB > 0 && pj->kb0 >= 0 && pj->kb0 + pj->KB <= pj->w_kbs &&
+                         pj->x.kb0 + pj->KB <= pj->x.kb_stride && B > 16 && B <= 32 && pj->N > 0 && pj->N % 32 == 0 && st_aligned16(pj->packed_w) &&
+                         st_aligned16(pj->x.base) && st_aligned16(pj->part) && tiles <= 128,
+                         "st_skinny_linear_packed_attnpre_fwd: bad partial product (B = 17..32, N %% 32 == 0, a linear of at most 128 row tiles)");
+            PkPartArgs pp;
+            memset(&pp, 0, sizeof(pp));
+            pp.w = reinterpret_cast<const f32x4*>(pj->packed_w) + (size_t)pj->kb0 * 64; pp.w_kbs = pj->w_kbs;
+            pp.x = reinterpret_cast<const f32x4*>(pj->x.base) + (size_t)pj->x.kb0 * 64; pp.x_kbs = pj->x.kb_stride;
+            pp.KB = pj->KB; pp.S = 1; pp.B = B; pp.N = pj->N; pp.part = pj->part;
+            return pk_launch_attnpre<1>(a, tiles, t, (hipStream_t)stream, nullptr, nullptr, &pp);
         }
         if (BT == 1 || tiles <= 128) return pk_launch_attnpre<1>(a, tiles, t, (hipStream_t)stream);
         if (BT == 2) return pk_launch_attnpre<2>(a, tiles, t, (hipStream_t)stream);

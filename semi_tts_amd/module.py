@@ -371,6 +371,7 @@ class Decoder(nn.Module):
         # mel-frames/s at C2; fp32 re-association only; ST_SPLIT_GATES=0 restores the whole product in the cell launch)
         self.split_gates = os.environ.get('ST_SPLIT_GATES', '1') != '0'
         self.split_cell_k = int(os.environ.get('ST_SPLIT_CELL_K', '0'))       # reduction columns the decoder cell keeps (0 = st_decoder_gate_split_k)
+        self.split_gates_train = os.environ.get('ST_SPLIT_GATES_TRAIN', '1') != '0'      # ... the same split in the teacher-forced training loop
         # the hand-off's failure word (st_decoder_io.handoff_status): an eager forward reads it back right away (one small
         # device -> host copy); under stream capture nobody can, so GraphedDecoder / bench.py / gen_specgram check it after replays
         self.check_handoff = True
@@ -656,10 +657,11 @@ class Decoder(nn.Module):
                     # decides: st_query_attn_rng_fits; the three-launch form stays the fall-back)
                     tapes['attn_xchg'] = torch.empty(2 * int(lib.st_attn_rng_xchg_words(B, E, sp)), **f32)
                     io.attn_xchg = ops._p(tapes['attn_xchg'])
-            if self.split_gates and not keep_tapes and 16 < B <= 32 and L < self.attn_split_min_len:
+            if self.split_gates and 16 < B <= 32 and ((not keep_tapes and L < self.attn_split_min_len) or (defer and self.split_gates_train)):
                 # the tail of the decoder cell's gate products -- columns of [ctx | AdaIN(h_q(t)) | h_d(t-1)] known before the attention runs --
                 # beside the pq / fin launch (st_decoder_io.gate_part; in the other forms of the attention step a launch of its own: the same
-                # arithmetic whatever the form).  gate_part_k = 0: the library's split (half of the reduction); ST_SPLIT_CELL_K for ablations
+                # arithmetic whatever the form).  gate_part_k = 0: the library's split (half of the reduction); ST_SPLIT_CELL_K for ablations.
+                # Teacher-forced training (defer): the product rides beside the query projection + attention pre part, the paired cell launch adds it
                 tapes['gate_part'] = torch.empty(B, 4 * D, **f32)
                 io.gate_part = ops._p(tapes['gate_part'])
                 io.gate_part_k = int(self.split_cell_k)

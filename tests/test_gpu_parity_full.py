@@ -432,3 +432,92 @@ def test_decoder_loops_replayed_from_graphs_give_bitwise_the_eager_steps(dev):
     assert s0 == s1, (s0, s1)
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k
+
+
+# ------------------------------------------------------------------------------------ the decoder cell's dependency split (round 6)
+def test_decoder_gate_split_at_every_cut_agrees_with_the_whole_cell_and_the_oracle(dev):
+    """Decoder.split_gates: a suffix of the decoder cell's gate reduction [ctx | AdaIN(h_q(t)) | h_d(t-1)] rides beside the pq / fin launch, the
+    cell launch reduces the columns in front of the cut (st_decoder_io.gate_part / gate_part_k).  C2 shape, 20 free-running steps, prenet
+    dropout 0: every cut -- the library's rule (half, 1280) and 512 / 1024 / 1536 / 2048 -- agrees with the unsplit step to fp32 re-association
+    and with the oracle to the north-star tolerance; the two-launch form of the attention step issues the same product as a launch of its own
+    and is bit-identical to the hosted form; a cut that is not a multiple of 16 or inside the context columns is refused."""
+    import ctypes as C
+    from semi_tts_amd import _lib
+    from semi_tts_amd._lib import StDecoderDims
+    from semi_tts_amd.synthetic import synthetic_batch
+    m = full_tacotron(dev, seed=31)
+    dec = m.decoder
+    B, L, T = 32, 43, 60
+    txt, spk, _ = synthetic_batch(B, L, 3, seed=12)
+    txt, spk = torch.from_numpy(txt), torch.from_numpy(spk)
+    with torch.no_grad():
+        mem = m.encoder(txt.to(dev), None)
+    d = StDecoderDims(B=B, L=L, E=512, n_mels=80, r=3, P=256, Q=1024, D=1024, A=128)
+    assert _lib.load().st_decoder_gate_split_k(C.byref(d)) == 1280 == dec.gate_split_k()
+
+    def run(split, k=0, pq_in_fin=True):
+        dec.split_gates, dec.split_cell_k, dec.attn_pq_in_fin = split, k, pq_in_fin
+        with torch.no_grad():
+            return [t.clone() for t in dec(mem, None, T, spk.to(dev), tf_rate=0.0)]
+    try:
+        whole = run(False)
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        with torch.no_grad():
+            mel_r, al_r, st_r = O.decoder_forward(_weights(m), mem.cpu(), T, spk, full_hp(0.0))
+        worst = 0.0
+        for k in (0, 512, 1024, 1536, 2048):
+            got = run(True, k)
+            e = max(maxdiff(a, b) for a, b in zip(got, whole))
+            worst = max(worst, e)
+            assert e < 2e-5, (k, e)
+            assert maxdiff(got[0], mel_r) < 5e-5 and maxdiff(got[1], al_r) < 1e-4 and maxdiff(got[2], st_r) < 1e-3, k
+            again = run(True, k)
+            assert all(torch.equal(a, b) for a, b in zip(got, again)), k
+            if k in (0, 1024):
+                two = run(True, k, pq_in_fin=False)          # the product as a launch of its own
+                assert all(torch.equal(a, b) for a, b in zip(got, two)), k
+        report('decoder_gate_split_cuts', worst_vs_whole_cell=worst)
+        for bad in (1000, 256, 2560):
+            with pytest.raises(RuntimeError):
+                run(True, bad)
+    finally:
+        dec.split_gates, dec.split_cell_k, dec.attn_pq_in_fin = True, 0, True
+
+
+def test_training_loop_with_the_gate_split_agrees_with_the_unsplit_loop(dev):
+    """The same split in the teacher-forced loop (Decoder.split_gates_train: the product rides beside the query projection + attention pre
+    part, the paired cell launch adds the slab): outputs and every gradient of the full-size decoder agree with the unsplit loop to fp32
+    re-association, and the split loop reproduces itself bit for bit."""
+    m = full_tacotron(dev, seed=4321, prenet_dropout=0.5).train()
+    dec = m.decoder
+    B, L, steps = 32, 43, 6
+    r, n_mels = dec.n_frames_per_step, dec.n_mels
+    g = torch.Generator().manual_seed(1)
+    mem0, spk0 = torch.randn(B, L, 512, generator=g).to(dev), torch.randn(B, 128, generator=g).to(dev)
+    teacher = torch.rand(B, steps * r, n_mels, generator=g).to(dev)
+    douts = None
+    res = []
+    try:
+        for split in (False, True, True):
+            dec.split_gates_train = split
+            for p in dec.parameters():
+                p.grad = None
+            torch.manual_seed(77)
+            mem, spk = mem0.clone().requires_grad_(), spk0.clone().requires_grad_()
+            mel, align, stop = dec(mem, None, teacher, spk, tf_rate=1.0)
+            if douts is None:
+                douts = [torch.randn(t.shape, generator=g).to(dev) for t in (mel, align, stop)]
+            torch.autograd.backward([mel, align, stop], douts)
+            res.append(dict(mel=mel.detach().clone(), align=align.detach().clone(), dmem=mem.grad.clone(), dspk=spk.grad.clone(),
+                            **{k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None}))
+    finally:
+        dec.split_gates_train = True
+    whole, split, again = res
+    assert len(whole) > 20
+    worst = 0.0
+    for k, v in whole.items():
+        e = float((split[k] - v).abs().max() / v.abs().max().clamp_min(1e-12))
+        worst = max(worst, e)
+        assert e < 2e-5, (k, e)
+        assert torch.equal(split[k], again[k]), k
+    report('training_gate_split', worst_rel=worst, n=len(whole))

@@ -37,6 +37,16 @@ def test_library_exports_every_declared_symbol():
     assert lib2.st_t16_floats(32, 240) == 2 * 15 * 256
     k = (ctypes.c_int * 3)(256, 512, 1024)
     assert lib2.st_packed_weight_floats(k, 3, 4096, 1024) == 256 * 112 * 256
+    # where the library cuts the decoder cell's gate reduction (host arithmetic): half of [ctx | AdaIN(h_q) | h_d] in whole rounds of 16
+    # k-blocks, never inside the context columns
+    from semi_tts_amd._lib import StDecoderDims
+    for (E, Q, D), want in (((512, 1024, 1024), 1280), ((512, 520, 520), None), ((64, 64, 64), None), ((512, 256, 256), None)):
+        d = StDecoderDims(B=32, L=43, E=E, n_mels=80, r=3, P=256, Q=Q, D=D, A=128)
+        cut = lib2.st_decoder_gate_split_k(ctypes.byref(d))
+        kb = lambda n: (n + 15) // 16
+        total = 16 * (kb(E) + kb(Q) + kb(D))
+        assert cut % 16 == 0 and 16 * kb(E) <= cut < total, (E, Q, D, cut)
+        assert want is None or cut == want
 
 
 def test_product_path_refuses_cpu_tensors():
